@@ -1,0 +1,297 @@
+"""ctypes binding of the CPU ORACLE (test infrastructure, NOT product code).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  See oracle/upsp_oracle.h for the reference file:line each function
+restates and for the parity status (pinned / unpinned) of each group.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libupsp_oracle.so")
+
+
+def build(force=False):
+    """Compile oracle/*.c with gcc (recipe: oracle/Makefile)."""
+    srcs = [f for f in os.listdir(_HERE) if f.endswith("_oracle.c") or f.endswith(".h")]
+    stale = (not os.path.exists(_LIB_PATH)) or any(
+        os.path.getmtime(os.path.join(_HERE, s)) > os.path.getmtime(_LIB_PATH) for s in srcs
+    )
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+class Ray(C.Structure):
+    _fields_ = [("o", C.c_float * 3), ("d", C.c_float * 3), ("inv", C.c_float * 3),
+                ("kx", C.c_int), ("ky", C.c_int), ("kz", C.c_int),
+                ("Sx", C.c_float), ("Sy", C.c_float), ("Sz", C.c_float)]
+
+
+class Hit(C.Structure):
+    _fields_ = [("pos", C.c_float * 3), ("nrm", C.c_float * 3),
+                ("t", C.c_float), ("u", C.c_float), ("v", C.c_float), ("w", C.c_float),
+                ("geomID", C.c_int32), ("primID", C.c_int32)]
+
+
+class Node(C.Structure):
+    _fields_ = [("bmin", C.c_float * 3), ("bmax", C.c_float * 3), ("offset", C.c_int32),
+                ("nprims", C.c_uint16), ("axis", C.c_uint8), ("pad", C.c_uint8)]
+
+
+class BvhStruct(C.Structure):
+    _fields_ = [("ntris", C.c_size_t), ("verts", C.POINTER(C.c_float)),
+                ("prim_ids", C.POINTER(C.c_int32)), ("nodes", C.POINTER(Node)),
+                ("nnodes", C.c_int32), ("depth", C.c_int32)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("K", C.c_double * 9), ("dist", C.c_double * 5), ("R", C.c_double * 9),
+                ("t", C.c_double * 3), ("width", C.c_int32), ("height", C.c_int32)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.orc_bvh_create.restype = C.POINTER(BvhStruct)
+        L.orc_bvh_create.argtypes = [C.c_void_p, C.c_size_t]
+        L.orc_bvh_destroy.argtypes = [C.POINTER(BvhStruct)]
+        L.orc_bvh_intersect.restype = C.c_int
+        L.orc_bvh_intersect.argtypes = [C.POINTER(BvhStruct), C.POINTER(Ray), C.POINTER(Hit),
+                                        C.c_void_p, C.c_void_p]
+        L.orc_bvh_intersect_batch.argtypes = [C.POINTER(BvhStruct), C.c_void_p, C.c_void_p,
+                                              C.c_size_t, C.c_int] + [C.c_void_p] * 6 + \
+                                             [C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_ray_init.argtypes = [C.POINTER(Ray), C.c_void_p, C.c_void_p]
+        L.orc_hit_init.argtypes = [C.POINTER(Hit)]
+        L.orc_project_point.argtypes = [C.POINTER(Camera), C.c_void_p, C.c_void_p]
+        L.orc_cam_center.argtypes = [C.POINTER(Camera), C.c_void_p]
+        L.orc_create_projection.restype = C.c_int64
+        L.orc_create_projection.argtypes = [C.POINTER(BvhStruct), C.POINTER(Camera)] + \
+            [C.c_void_p] * 4 + [C.c_size_t, C.c_float] + [C.c_void_p] * 4 + [C.c_int]
+        L.orc_adjust_weights.argtypes = [C.c_int, C.c_size_t] + [C.c_void_p] * 5 + [C.c_int]
+        L.orc_skipped_nodes.restype = C.c_size_t
+        L.orc_skipped_nodes.argtypes = [C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.orc_fix_hot_pixels.restype = C.c_int
+        L.orc_fix_hot_pixels.argtypes = [C.c_void_p] + [C.c_int] * 5
+        L.orc_project_frame_f32.argtypes = [C.c_void_p] * 3 + [C.c_size_t, C.c_void_p]
+        L.orc_project_frame_u16.argtypes = [C.c_void_p] * 3 + [C.c_size_t, C.c_void_p]
+        L.orc_accumulate.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.orc_finals.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64,
+                                 C.c_void_p, C.c_void_p]
+        L.orc_apportion.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_transpose.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        for name, args, res in _OPTIONAL:
+            if hasattr(L, name):
+                getattr(L, name).argtypes = args
+                getattr(L, name).restype = res
+        _lib = L
+    return _lib
+
+
+_OPTIONAL = [
+    ("orc_gaussian_kernel", [C.c_int, C.c_void_p], C.c_int),
+    ("orc_blur_f32", [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int], None),
+    ("orc_warp_affine_u16", [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int], None),
+    ("orc_warp_affine_f32", [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int], None),
+    ("orc_find_transform_ecc", [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                C.c_double, C.c_void_p], C.c_int),
+    ("orc_register_pixel_u16", [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                C.c_double, C.c_int, C.c_void_p], C.c_int),
+    ("orc_polyfit2d", [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p], C.c_int),
+    ("orc_polyval2d", [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p], None),
+    ("orc_patch_clusters", [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6, None),
+]
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def make_camera(K, dist, R, t, width, height):
+    cam = Camera()
+    cam.K[:] = np.asarray(K, dtype=np.float64).ravel().tolist()
+    d = np.zeros(5)
+    dd = np.asarray(dist, dtype=np.float64).ravel()
+    d[: min(5, dd.size)] = dd[:5]
+    cam.dist[:] = d.tolist()
+    cam.R[:] = np.asarray(R, dtype=np.float64).ravel().tolist()
+    cam.t[:] = np.asarray(t, dtype=np.float64).ravel().tolist()
+    cam.width, cam.height = int(width), int(height)
+    return cam
+
+
+class OracleBVH:
+    """rt::BVH restated on the CPU (reference: cpp/raycast/pspRT.cpp)."""
+
+    def __init__(self, tris9):
+        tris9 = _f32(tris9).reshape(-1)
+        assert tris9.size % 9 == 0
+        self.ntris = tris9.size // 9
+        self._h = lib().orc_bvh_create(_p(tris9), self.ntris)
+        if not self._h:
+            raise ValueError("BVH::BVH() : no primitives!")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_bvh_destroy(self._h)
+            self._h = None
+
+    @property
+    def nnodes(self):
+        return self._h.contents.nnodes
+
+    @property
+    def depth(self):
+        return self._h.contents.depth
+
+    def nodes(self):
+        n = self.nnodes
+        buf = C.string_at(self._h.contents.nodes, n * C.sizeof(Node))
+        dt = np.dtype([("bmin", "<f4", 3), ("bmax", "<f4", 3), ("offset", "<i4"),
+                       ("nprims", "<u2"), ("axis", "u1"), ("pad", "u1")])
+        return np.frombuffer(buf, dtype=dt).copy()
+
+    def prim_ids(self):
+        return np.ctypeslib.as_array(self._h.contents.prim_ids, shape=(self.ntris,)).copy()
+
+    def intersect_one(self, o, d):
+        r, h = Ray(), Hit()
+        lib().orc_ray_init(C.byref(r), _p(_f32(o)), _p(_f32(d)))
+        lib().orc_hit_init(C.byref(h))
+        any_hit = lib().orc_bvh_intersect(self._h, C.byref(r), C.byref(h), None, None)
+        return bool(any_hit), h
+
+    def intersect(self, org, dirs, threads=0, stats=False):
+        """Batch closest hit.  org: (3,) shared or (N,3); dirs: (N,3)."""
+        dirs = _f32(dirs).reshape(-1, 3)
+        org = _f32(org)
+        n = dirs.shape[0]
+        stride = 0 if org.size == 3 else 3
+        if stride:
+            assert org.reshape(-1, 3).shape[0] == n
+        hit = np.zeros(n, np.uint8)
+        t = np.zeros(n, np.float32)
+        prim = np.zeros(n, np.int32)
+        uvw = np.zeros((n, 3), np.float32)
+        pos = np.zeros((n, 3), np.float32)
+        nrm = np.zeros((n, 3), np.float32)
+        nv, nt = C.c_uint64(0), C.c_uint64(0)
+        lib().orc_bvh_intersect_batch(self._h, _p(org), _p(dirs), n, stride, _p(hit), _p(t),
+                                      _p(prim), _p(uvw), _p(pos), _p(nrm), int(threads),
+                                      C.addressof(nv), C.addressof(nt))
+        out = dict(hit=hit.astype(bool), t=t, prim=prim, uvw=uvw, pos=pos, nrm=nrm)
+        if stats:
+            out["nodes_visited"] = nv.value
+            out["tris_tested"] = nt.value
+        return out
+
+
+def project_points(cam, xyz):
+    xyz = _f32(xyz).reshape(-1, 3)
+    out = np.zeros((xyz.shape[0], 2), np.float32)
+    for i in range(xyz.shape[0]):
+        lib().orc_project_point(C.byref(cam), _p(xyz[i]), _p(out[i]))
+    return out
+
+
+def cam_center(cam):
+    c = np.zeros(3, np.float64)
+    lib().orc_cam_center(C.byref(cam), _p(c))
+    return c
+
+
+def create_projection(bvh, cam, nodes, normals, tri_nodes, oblique_thresh, datanode=None,
+                      threads=0):
+    nodes = _f32(nodes).reshape(-1, 3)
+    normals = _f32(normals).reshape(-1, 3)
+    tri_nodes = np.ascontiguousarray(tri_nodes, dtype=np.int32).reshape(-1)
+    n = nodes.shape[0]
+    pix = np.zeros(n, np.int32)
+    uv = np.zeros(2 * n, np.float32)
+    cnt = np.zeros(cam.width * cam.height, np.uint8)
+    nrays = C.c_uint64(0)
+    dn = None if datanode is None else np.ascontiguousarray(datanode, dtype=np.uint8)
+    acc = lib().orc_create_projection(bvh._h, C.byref(cam), _p(nodes), _p(normals), _p(dn),
+                                      _p(tri_nodes), n, np.float32(oblique_thresh), _p(pix),
+                                      _p(uv), _p(cnt), C.addressof(nrays), int(threads))
+    return dict(pix=pix, uv=uv, nodecount=cnt.reshape(cam.height, cam.width),
+                accepted=int(acc), nrays=int(nrays.value))
+
+
+def adjust_weights(pix, weight, nodes, normals, centers, mode):
+    pix = np.ascontiguousarray(pix, dtype=np.int32)
+    ncams, n = pix.shape
+    weight = np.ascontiguousarray(weight, dtype=np.float32).copy()
+    centers = np.ascontiguousarray(centers, dtype=np.float64)
+    lib().orc_adjust_weights(ncams, n, _p(pix), _p(weight), _p(_f32(nodes)), _p(_f32(normals)),
+                             _p(centers), int(mode))
+    return weight
+
+
+def skipped_nodes(pix):
+    pix = np.ascontiguousarray(pix, dtype=np.int32)
+    if pix.ndim == 1:
+        pix = pix[None]
+    ncams, n = pix.shape
+    sk = np.zeros(n, np.uint8)
+    lib().orc_skipped_nodes(ncams, n, _p(pix), _p(sk))
+    return sk.astype(bool)
+
+
+def fix_hot_pixels(img, thresh=4064, min_change=512, max_hot=5):
+    """Returns (fixed copy, status) ; status -1 = too many hot pixels (frame untouched)."""
+    img = np.ascontiguousarray(img, dtype=np.uint16).copy()
+    st = lib().orc_fix_hot_pixels(_p(img), img.shape[0], img.shape[1], thresh, min_change, max_hot)
+    return img, st
+
+
+def project_frame(img, pix, weight=None):
+    pix = np.ascontiguousarray(pix, dtype=np.int32)
+    out = np.zeros(pix.size, np.float32)
+    w = None if weight is None else _f32(weight)
+    img = np.ascontiguousarray(img)
+    if img.dtype == np.uint16:
+        lib().orc_project_frame_u16(_p(img), _p(pix), _p(w), pix.size, _p(out))
+    else:
+        img = _f32(img)
+        lib().orc_project_frame_f32(_p(img), _p(pix), _p(w), pix.size, _p(out))
+    return out
+
+
+def accumulate(sol, s, ss):
+    lib().orc_accumulate(_p(_f32(sol)), sol.size, _p(s), _p(ss))
+
+
+def finals(s, ss, nframes):
+    avg = np.zeros(s.size, np.float32)
+    rms = np.zeros(s.size, np.float32)
+    lib().orc_finals(_p(s), _p(ss), s.size, int(nframes), _p(avg), _p(rms))
+    return avg, rms
+
+
+def apportion(value, nbins):
+    st = np.zeros(nbins, np.int32)
+    ex = np.zeros(nbins, np.int32)
+    lib().orc_apportion(int(value), int(nbins), _p(st), _p(ex))
+    return st, ex
+
+
+def transpose(src):
+    src = _f32(src)
+    y, x = src.shape
+    dst = np.zeros((x, y), np.float32)
+    lib().orc_transpose(_p(src), x, y, _p(dst))
+    return dst

@@ -1,0 +1,104 @@
+"""Helpers that restate the *input preparation* the reference's Python tests perform
+before they reach the ray caster (test/python/test_visibility.py setUpClass):
+
+* read_p3d_grid            python/upsp/processing/p3d_utilities.py:87-139
+* p3d_to_triangles         python/upsp/processing/p3d_conversions.py:201-222
+* package_primitives       python/upsp/cam_cal_utils/visibility.py:167-212
+* tvecs_and_norms          python/upsp/cam_cal_utils/visibility.py:591-657
+* read_camera_tunnel_cal   python/upsp/cam_cal_utils/parsers.py:353-397
+
+tests/golden/make_golden.py checks these against the reference's own modules
+(in the build container, where /root/reference exists).  The data files under
+tests/golden/ (fml_tc3_volume.grid, camera01_35_6.json) are fixtures held by the
+reference's test suite (test/data/).
+"""
+import json
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def read_p3d_grid(filename):
+    with open(filename, "rb") as f:
+        np.fromfile(f, dtype=np.int32, count=1)
+        n_zones = int(np.fromfile(f, dtype=np.int32, count=1)[0])
+        np.fromfile(f, dtype=np.int32, count=1)
+        np.fromfile(f, dtype=np.int32, count=1)
+        zone_sz = np.fromfile(f, dtype=np.int32, count=n_zones * 3).reshape(n_zones, 3)
+        np.fromfile(f, dtype=np.int32, count=1)
+        xs, ys, zs = [], [], []
+        for i in range(n_zones):
+            zs_ = int(np.prod(zone_sz[i]))
+            np.fromfile(f, dtype=np.int32, count=1)
+            xyz = np.fromfile(f, dtype=np.float32, count=3 * zs_)
+            np.fromfile(f, dtype=np.int32, count=1)
+            xs.append(xyz[:zs_].astype(np.float64))
+            ys.append(xyz[zs_:2 * zs_].astype(np.float64))
+            zs.append(xyz[2 * zs_:].astype(np.float64))
+    return zone_sz, np.concatenate(xs), np.concatenate(ys), np.concatenate(zs)
+
+
+def p3d_to_triangles(zone_sz, x, y, z):
+    """Returns (vertices [V,3] f64, indices [F,3] int) like p3d_to_gltf_triangles."""
+    verts, inds = [], []
+    idx0 = 0   # offset into the grid arrays
+    for imax, jmax, kmax in zone_sz:
+        imax, jmax = int(imax), int(jmax)
+        n = imax * jmax
+        verts.append(np.stack([x[idx0:idx0 + n], y[idx0:idx0 + n], z[idx0:idx0 + n]], axis=1))
+        ii, jj = np.meshgrid(np.arange(imax - 1), np.arange(jmax - 1), indexing="ij")
+        ii, jj = ii.ravel(), jj.ravel()
+        p0 = idx0 + jj * imax + ii
+        p1 = p0 + 1
+        p2 = idx0 + (jj + 1) * imax + ii + 1
+        p3 = idx0 + (jj + 1) * imax + ii
+        quad = np.stack([p0, p1, p2, p0, p2, p3], axis=1).reshape(-1, 3)
+        inds.append(quad)
+        idx0 += n
+    return np.concatenate(verts), np.concatenate(inds)
+
+
+def _nondegenerate(faces):
+    a, b, c = faces[:, 0], faces[:, 1], faces[:, 2]
+    deg = (a == b).all(1) | (a == c).all(1) | (b == c).all(1)
+    return ~deg
+
+
+def package_primitives(verts, inds):
+    """[T*9] float64 triangle soup, degenerate faces dropped."""
+    faces = verts[inds]
+    return faces[_nondegenerate(faces)].reshape(-1)
+
+
+def tvecs_and_norms(verts, inds):
+    """Unique nodes in first-appearance order and the normal of the first face
+    that contains each of them."""
+    faces = verts[inds]
+    faces = faces[_nondegenerate(faces)]
+    A = faces[:, 1] - faces[:, 0]
+    B = faces[:, 2] - faces[:, 1]
+    fn = np.cross(A, B)
+    flat = faces.reshape(-1, 3) + 0.0          # -0.0 -> +0.0 so that equal tuples compare equal
+    _, first = np.unique(flat, axis=0, return_index=True)
+    first.sort()
+    return flat[first], fn[first // 3], faces, fn
+
+
+def read_camera_tunnel_cal(path, dims):
+    """dims = (image height, image width).  Returns rmat, tvec(3,1), cameraMatrix, distCoeffs."""
+    with open(path) as f:
+        cal = json.load(f)
+    upsp_cm = np.array(cal["uPSP_cameraMatrix"], dtype=np.float64)
+    cm = upsp_cm.copy()
+    # convert_uPSP_cm_to_cv2_cm (parsers.py): principal point is stored relative to image centre
+    cm[0, 2] = upsp_cm[0, 2] + dims[1] / 2
+    cm[1, 2] = upsp_cm[1, 2] + dims[0] / 2
+    return (np.array(cal["rmat"]), np.array(cal["tvec"]).reshape(3, 1), cm,
+            np.array(cal["distCoeffs"]))
+
+
+def fml_grid():
+    zs, x, y, z = read_p3d_grid(os.path.join(GOLDEN, "fml_tc3_volume.grid"))
+    return p3d_to_triangles(zs, x, y, z)
