@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric on MI355X.
+
+One STEP = one pass of the hot path over one batch of synthetic input
+(BASELINE.json configs[1]: 1 000 frames, 1024x1024, ~1 M-triangle wind-tunnel model,
+ray cast + projection only):
+
+    projection build  (create_projection_mat: ~0.5 M node rays + jitter retries)
+  + frame loop        (hot-pixel repair -> nearest-pixel projection -> double
+                       accumulators -> node-major time series) over every frame
+  + finals            (avg / rms)
+  + for N > 1: the end-of-run exchanges (all_reduce of the accumulators and the
+    all_to_all time-series exchange over RCCL/xGMI)
+
+with mesh, BVH, camera and all frames already resident in HBM.  Frames shard over
+ranks (weak scaling: every GPU processes --frames frames).
+
+Prints ONE JSON line on rank 0.  `value` = frames/s over the whole job;
+`mrays_per_s` = node rays/s of the projection-build kernel alone.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=1000, help="frames per GPU per step")
+    ap.add_argument("--size", type=int, default=1024, help="frame is size x size")
+    ap.add_argument("--small", action="store_true", help="reduced mesh/frames (plumbing check)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(verts, tris, cam_dict, size, nframes_step, pix_full, sample_frames=24):
+    """Oracle (CPU restatement, kind 'port') on a bounded sample of the same workload."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as orc
+    from upsp_processing_amd import synthetic as syn, engine
+    cores = os.cpu_count() or 1
+    s9, tn = syn.soup(verts, tris)
+    nrm = syn.node_normals(verts, tris)
+    t0 = time.perf_counter()
+    obv = orc.OracleBVH(s9)
+    t_build = time.perf_counter() - t0
+    cam = orc.make_camera(cam_dict["K"], cam_dict["dist"], cam_dict["R"], cam_dict["t"], size, size)
+    # projection build on a node sample (every k-th node), all cores (OpenMP)
+    k = max(1, verts.shape[0] // 60000)
+    dn = np.zeros(verts.shape[0], np.uint8)
+    dn[::k] = 1
+    t0 = time.perf_counter()
+    r = orc.create_projection(obv, cam, verts, nrm, tn, engine.oblique_threshold(70.0), datanode=dn,
+                              threads=cores)
+    t_proj = time.perf_counter() - t0
+    mrays = r["nrays"] / t_proj / 1e6
+    # the frame sample gathers through the complete projection (the index array the
+    # GPU step produced -- input data for the timed CPU loop, parity-checked in tests/)
+    pix = np.ascontiguousarray(pix_full, dtype=np.int32)
+    frames = syn.synth_frames_numpy(sample_frames, size, size, seed=99)
+    sk = orc.skipped_nodes(pix)
+
+    def one(f):
+        img, _ = orc.fix_hot_pixels(frames[f])
+        sol = orc.project_frame(img, pix, None)
+        sol[sk] = np.nan
+        return sol
+
+    s, ss = np.zeros(pix.size), np.zeros(pix.size)
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        for sol in ex.map(one, range(sample_frames)):
+            orc.accumulate(sol, s, ss)
+    t_frames = time.perf_counter() - t0
+    per_frame = t_frames / sample_frames
+    t_proj_full = t_proj * k
+    fps = nframes_step / (t_proj_full + per_frame * nframes_step)
+    return {"value": fps, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "oracle/: projection build on every %d-th node (%d rays, %.2f s, OpenMP) "
+                      "+ %d frames of the frame loop (%.3f s); extrapolated to the %d-frame step"
+                      % (k, r["nrays"], t_proj, sample_frames, t_frames, nframes_step),
+            "mrays_per_s": mrays, "frame_loop_frames_per_s": 1.0 / per_frame,
+            "bvh_build_s": t_build}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    from upsp_processing_amd import _capi, engine, synthetic as syn, distributed as D
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local))
+    _capi.lib()
+
+    size = a.size
+    F = a.frames
+    if a.small:
+        verts, tris = syn.tunnel_model(100, 240, 40, 80)
+        F = min(F, 64)
+    else:
+        verts, tris = syn.tunnel_model()          # 1 001 520 triangles, 500 766 nodes
+    s9, tn = syn.soup(verts, tris)
+    nrm = syn.node_normals(verts, tris)
+    N = verts.shape[0]
+    cd = syn.pinhole_camera(size, size, center=(0, 0, 20), half_extent=6.0)
+    cam = _capi.make_camera(cd["K"], cd["dist"], cd["R"], cd["t"], size, size)
+
+    bvh = engine.BVH(s9)
+    d_nodes = torch.as_tensor(verts).cuda()
+    d_nrm = torch.as_tensor(nrm).cuda()
+    d_tn = torch.as_tensor(tn).cuda()
+    # this rank's frames (global frame index = rank*F + f), resident in HBM
+    frames = torch.empty((F, size, size), dtype=torch.uint16, device="cuda")
+    chunk = 50
+    for f0 in range(0, F, chunk):
+        syn.synth_frames_torch(min(chunk, F - f0), size, size, first=rank * F + f0, out=frames[f0:f0 + chunk])
+    shard = D.Shard(F * world, N, rank, world)
+    pipe = engine.FramePipeline(1, size, size, N)
+    rows_t = torch.empty((N, F), dtype=torch.float32, device="cuda")
+    series = torch.empty((shard.node_count[rank], F * world), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    t_ray, t_frames, t_xchg = [], [], []
+    nrays_last = [0]
+
+    def step(record):
+        e = [ev() for _ in range(4)]
+        e[0].record()
+        proj = engine.build_projection(bvh, cam, d_nodes, d_nrm, d_tn, 70.0)
+        e[1].record()
+        pipe.reset()
+        pipe.set_projection(0, proj["pix"])
+        pipe.process(frames, first_frame=rank * F, rows_t=rows_t, want_rows=False)
+        e[2].record()
+        s, ss = pipe.accumulators()
+        D.allreduce_sums(s, ss)
+        D.exchange_time_series(rows_t, shard, out=series)
+        avg, rms = pipe.finalize(F * world)
+        e[3].record()
+        if record:
+            torch.cuda.synchronize()
+            t_ray.append(e[0].elapsed_time(e[1]))
+            t_frames.append(e[1].elapsed_time(e[2]))
+            t_xchg.append(e[2].elapsed_time(e[3]))
+            nrays_last[0] = proj["nrays"]
+            nrays_last[1:] = [proj["pix"]]
+        return avg
+
+    for _ in range(a.warmup):
+        step(False)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step(True)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    ms_step = dt / a.steps * 1e3
+    total_frames = F * world
+    fps = total_frames * a.steps / dt
+    ray_ms = float(np.mean(t_ray))
+    frm_ms = float(np.mean(t_frames))
+    mrays = nrays_last[0] / (ray_ms * 1e-3) / 1e6
+
+    # roofline of the dominant kernel (HIP-event timed on the launch stream)
+    tri_bytes = bvh.info["device_bytes"]
+    if ray_ms >= frm_ms:
+        algo = nrays_last[0] * 40 + tri_bytes          # 40 B/ray + scene once
+        ach = algo / (ray_ms * 1e-3) / 1e9
+        roof = {"kernel": "projection_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": algo, "launch_ms": ray_ms}
+    else:
+        algo = F * (2 * size * size + 12 * N)          # 2 MiB + 12 B x N per frame
+        ach = algo / (frm_ms * 1e-3) / 1e9
+        roof = {"kernel": "frame loop (hot_scan+hot_fix+gather+transpose)", "bound": "hbm",
+                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": None, "algorithmic_bytes_per_launch": algo, "launch_ms": frm_ms}
+
+    out = {
+        "metric": "frames/s", "value": fps, "unit": "frames/s", "n_gpus": world,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32 (u16 frames, f64 accumulators)",
+        "data": "synthetic",
+        "config": {"workload": "configs[1]: %d frames/GPU x %dx%d u16, %d-tri tunnel model (%d nodes), "
+                               "raycast+projection" % (F, size, size, tris.shape[0], N),
+                   "frames_per_gpu": F, "nodes": N, "triangles": int(tris.shape[0]),
+                   "parallelism": "frames sharded x%d" % world},
+        "mrays_per_s": mrays, "rays_per_step": nrays_last[0],
+        "breakdown_ms": {"projection_build": ray_ms, "frame_loop": frm_ms,
+                         "exchange_finals": float(np.mean(t_xchg))},
+        "frame_loop_frames_per_s": F / (frm_ms * 1e-3),
+        "roofline": roof,
+    }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(verts, tris, cd, size, F, nrays_last[1].cpu().numpy())
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

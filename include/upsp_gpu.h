@@ -1,0 +1,259 @@
+/*
+ * upsp_gpu.h -- C ABI of libupsp_gpu.so, the MI355X (gfx950) engine for the
+ * ray-cast + per-frame projection hot path of nasa/upsp-processing.
+ *
+ * This is the drop-in boundary: every entry point names the reference interface
+ * (file:line under the upstream repository) it replaces.  Plain pointers and
+ * sizes only; no torch / OpenCV / Eigen / Imath types.  Pointers named d_* are
+ * DEVICE pointers (HBM of the current HIP device), h_* are host pointers.
+ * `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *
+ * All functions return UPSP_OK (0) or a negative upsp_status; none of them
+ * exits the process (the reference's DIE()/ASSERT() macros call exit(),
+ * cpp/include/utils/pspError.h:47-98).  upsp_last_error() returns a message
+ * for the calling thread.
+ */
+#ifndef UPSP_GPU_H
+#define UPSP_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum upsp_status {
+    UPSP_OK = 0,
+    UPSP_ERR_INVALID = -1,   /* bad argument (null pointer, size mismatch ...) */
+    UPSP_ERR_EMPTY = -2,     /* BVH without primitives (pspRT.cpp:320-323, 362-365) */
+    UPSP_ERR_DEPTH = -3,     /* BVH deeper than the 64-entry traversal stack (pspRT.cpp:374) */
+    UPSP_ERR_HIP = -4,       /* HIP runtime error, see upsp_last_error() */
+    UPSP_ERR_NO_DEVICE = -5, /* no gfx950 device visible */
+    UPSP_ERR_DIVERGED = -6   /* ECC registration failed (cv::findTransformECC would throw) */
+} upsp_status;
+
+const char *upsp_last_error(void);
+/* Library / device identification: writes e.g. "gfx950" into arch (>= 32 bytes). */
+int upsp_device_info(int *n_devices, char *arch, int *n_cus);
+int upsp_version(void);
+
+/* ======================================================================== *
+ *  1.  BVH ray-triangle intersector   (reference: cpp/raycast/pspRT.cpp)
+ * ======================================================================== */
+
+typedef struct upsp_bvh upsp_bvh;
+
+/* Replaces rt::CreateBVH(raw, stride) (cpp/include/utils/pspRT.h:131-135),
+ * rt::CreateTriangleMesh + rt::BVH::BVH (cpp/raycast/pspRT.cpp:206-222,313-344)
+ * and createBVH() of psp_process (cpp/exec/psp_process.cpp:44-53).
+ * h_tris9: triangle soup, 9 floats per triangle (x,y,z of the 3 vertices).
+ * The SAH tree has the reference's topology and leaf order; it is laid out for
+ * the GPU (two child boxes per 64-byte node, 48-byte triangle records) and
+ * uploaded to the current device. */
+int upsp_bvh_create(const float *h_tris9, size_t ntris, upsp_bvh **out);
+void upsp_bvh_destroy(upsp_bvh *bvh);
+
+typedef struct upsp_bvh_info {
+    uint64_t ntris;
+    uint32_t n_ref_nodes;   /* LinearNode count of the reference layout (leaves + interior) */
+    uint32_t n_gpu_nodes;   /* 64-byte interior nodes on the device */
+    uint32_t depth;         /* tree height = worst-case traversal stack depth */
+    uint32_t max_leaf;      /* largest leaf (triangles) */
+    float bounds_min[3];    /* rt::BVH::bounds() (pspRT.cpp:353-357) */
+    float bounds_max[3];
+    uint64_t device_bytes;  /* HBM footprint of nodes + triangles */
+    double build_seconds;
+} upsp_bvh_info;
+int upsp_bvh_get_info(const upsp_bvh *bvh, upsp_bvh_info *info);
+
+/* Per-ray outputs, structure of arrays; any pointer may be NULL (not written). */
+typedef struct upsp_hits {
+    uint8_t *hit;   /* [n]   return value of rt::BVH::intersect: any triangle hit with t>=0 */
+    float *t;       /* [n]   Hit.t   (FLT_MAX when no hit, pspRT.cpp:21) */
+    int32_t *prim;  /* [n]   Hit.primID = index into the input soup (-1 when no hit) */
+    float *uvw;     /* [n*3] Hit.u, v, w */
+    float *pos;     /* [n*3] Hit.pos = o + t*d (pspRT.cpp:179) */
+    float *nrm;     /* [n*3] Hit.nrm (un-normalised, pspRT.cpp:182-190) */
+} upsp_hits;
+
+/* Replaces n calls of  rt::Ray(o,d) + rt::Hit() + rt::BVH::intersect(ray,&hit)
+ * (cpp/raycast/pspRT.cpp:45-69, 359-431; pybind: cpp/pybind11/raycast.cpp:16-35).
+ * Closest hit (min t, first found in the reference's traversal order on ties).
+ * org_stride = 3: one origin per ray; org_stride = 0: a single shared origin. */
+int upsp_bvh_intersect(const upsp_bvh *bvh, const float *d_org, int org_stride,
+                       const float *d_dir, size_t n, const upsp_hits *d_out, void *stream);
+/* Same with host buffers (staged through HBM); convenience for the bindings. */
+int upsp_bvh_intersect_host(const upsp_bvh *bvh, const float *h_org, int org_stride,
+                            const float *h_dir, size_t n, const upsp_hits *h_out);
+
+/* Occlusion query: only the boolean return value of rt::BVH::intersect, i.e.
+ * what VisibilityChecker.does_intersect consumes
+ * (python/upsp/cam_cal_utils/visibility.py:392-420).  Stops at the first hit. */
+int upsp_bvh_occluded(const upsp_bvh *bvh, const float *d_org, int org_stride,
+                      const float *d_dir, size_t n, uint8_t *d_hit, void *stream);
+int upsp_bvh_occluded_host(const upsp_bvh *bvh, const float *h_org, int org_stride,
+                           const float *h_dir, size_t n, uint8_t *h_hit);
+
+/* Traversal statistics of the last intersect/occluded/projection launch on this
+ * BVH (summed over rays): interior nodes fetched, triangles tested, rays cast.
+ * Collected only after upsp_bvh_enable_stats(bvh, 1). */
+int upsp_bvh_enable_stats(upsp_bvh *bvh, int on);
+int upsp_bvh_last_stats(const upsp_bvh *bvh, uint64_t *nodes, uint64_t *tris, uint64_t *rays);
+
+/* ======================================================================== *
+ *  2.  Projection build   (reference: create_projection_mat,
+ *                           cpp/exec/psp_process.cpp:167-355)
+ * ======================================================================== */
+
+/* Inputs of cv::projectPoints as used by CameraCal::map_point_to_image
+ * (cpp/lib/CameraCal.ipp:218-231); get_cam_center (cpp/lib/CameraCal.cpp:192-203)
+ * is derived from R, t. */
+typedef struct upsp_camera {
+    double K[9];    /* cameraMatrix, row-major */
+    double dist[5]; /* k1,k2,p1,p2,k3 */
+    double R[9];    /* model->camera rotation, row-major */
+    double t[3];
+    int32_t width, height;
+} upsp_camera;
+
+/* One camera.  For every node: project to the image, in-frame test, primary ray
+ * camera->node, visibility by the hit triangle's node ids, <=6 jittered retries,
+ * oblique-angle test; result is the <=1-nnz-per-row projection matrix as two
+ * dense arrays:
+ *   d_pix[n]    = round(v)*W + round(u) of the nearest pixel, -1 when the node
+ *                 has no entry in the reference's sparse matrix
+ *   d_uv[2n..]  = (u/W, v/H) (camNN-uv file, psp_process.cpp:1615-1620), 0 otherwise
+ *   d_nodecount = [H*W] u8 saturating nodes-per-pixel image (may be NULL)
+ * d_datanode (may be NULL) = Model::is_datanode mask; d_tri_nodes = extract_tris()
+ * triNodes [3*ntris] (cpp/lib/TriModel.ipp:261-299).
+ * oblique_thresh = deg2rad(180 - oblique_angle) as float (psp_process.cpp:1602). */
+int upsp_projection_build(upsp_bvh *bvh, const upsp_camera *cam, const float *d_nodes,
+                          const float *d_normals, const uint8_t *d_datanode,
+                          const int32_t *d_tri_nodes, size_t nnodes, float oblique_thresh,
+                          int32_t *d_pix, float *d_uv, uint8_t *d_nodecount,
+                          uint64_t *h_nrays, void *stream);
+
+/* adjust_projection_for_weights with BestView (mode 0) / AverageViews (mode 1)
+ * (cpp/lib/projection.ipp:911-1078, 227-268).  d_pix, d_weight: [ncams*nnodes];
+ * d_weight is scaled in place (caller initialises it to 1).  h_centers: ncams*3
+ * doubles (CameraCal::get_cam_center). */
+int upsp_projection_weights(int ncams, size_t nnodes, const int32_t *d_pix, float *d_weight,
+                            const float *d_nodes, const float *d_normals,
+                            const double *h_centers, int mode, void *stream);
+
+/* identify_skipped_nodes (cpp/lib/projection.ipp:857-880): d_skipped[n] = 1 iff
+ * no camera has an entry for node n.  *h_count (may be NULL) = number skipped. */
+int upsp_projection_skipped(int ncams, size_t nnodes, const int32_t *d_pix,
+                            uint8_t *d_skipped, uint64_t *h_count, void *stream);
+
+/* camera centre C = -R^T t  (cpp/lib/CameraCal.cpp:192-203) */
+int upsp_camera_center(const upsp_camera *cam, double h_center[3]);
+/* cv::projectPoints on n points (host convenience, same arithmetic as the kernel) */
+int upsp_project_points_host(const upsp_camera *cam, const float *h_xyz, size_t n, float *h_uv);
+
+/* ======================================================================== *
+ *  3.  Per-frame pipeline   (reference: frame loop of psp_process phase 1,
+ *                            cpp/exec/psp_process.cpp:1743-1851)
+ * ======================================================================== */
+
+typedef struct upsp_pipeline upsp_pipeline;
+
+typedef struct upsp_pipeline_opts {
+    /* fix_hot_pixels defaults, cpp/include/utils/cv_extras.h:154-155 */
+    int32_t hot_enable, hot_thresh, hot_min_change, hot_max;
+    /* registration: 0 none, 1 pixel (ECC affine) ; upsp_inputs.h:22-38 */
+    int32_t registration;
+    int32_t ecc_max_iters;  /* 50   (psp_process.cpp:1781) */
+    double ecc_eps;         /* 1e-3 (psp_process.cpp:1782) */
+    int32_t interp;         /* 1 linear, 0 nearest (PixelInterpolationType) */
+    /* filter: 0 none, 1 gaussian, 2 box ; filter_size odd (psp_process.cpp:1296) */
+    int32_t filter, filter_size;
+    /* polynomial target patcher on/off (TargetPatchType) */
+    int32_t patch;
+    int32_t reserved[5];
+} upsp_pipeline_opts;
+
+void upsp_pipeline_default_opts(upsp_pipeline_opts *o);
+
+int upsp_pipeline_create(int ncams, int width, int height, size_t nnodes,
+                         const upsp_pipeline_opts *opts, upsp_pipeline **out);
+void upsp_pipeline_destroy(upsp_pipeline *p);
+
+/* Projection of camera `cam` (copied): d_pix [nnodes] int32, d_weight [nnodes] f32
+ * (NULL = all ones).  Equivalent of elems.projs[c] (psp_process.cpp:1591-1640). */
+int upsp_pipeline_set_projection(upsp_pipeline *p, int cam, const int32_t *d_pix,
+                                 const float *d_weight);
+/* Nodes set to NaN in every row (psp_process.cpp:1822-1825); NULL = derive from
+ * the projections with identify_skipped_nodes. */
+int upsp_pipeline_set_skipped(upsp_pipeline *p, const uint8_t *d_skipped);
+/* ECC template of camera `cam` = first frame as f32 (elems.first_frames[c],
+ * psp_process.cpp:2057-2058). */
+int upsp_pipeline_set_reference(upsp_pipeline *p, int cam, const float *d_ref32f);
+/* Patch tables of camera `cam` (PatchClusters members bounds_x/y, internal_x/y,
+ * cpp/include/patches.h:76-110): CSR-style offsets [nclusters+1] into the
+ * boundary / interior pixel lists (host pointers, copied). */
+int upsp_pipeline_set_patches(upsp_pipeline *p, int cam, int nclusters,
+                              const int32_t *h_b_off, const int32_t *h_bx, const int32_t *h_by,
+                              const int32_t *h_i_off, const int32_t *h_ix, const int32_t *h_iy);
+
+/* Process `nframes` consecutive frames of every camera.
+ *   d_frames[c]      u16 frames of camera c, [nframes][H][W] contiguous.  Hot-pixel
+ *                    correction is applied IN PLACE like the reference (:1772).
+ *   first_frame      global index f of the first frame (frame 0 is never
+ *                    registered in the loop, psp_process.cpp:1777)
+ *   d_rows           [nframes][nnodes] f32 = intensity_buf rows (may be NULL)
+ *   d_rows_t, ld_t   optional transposed output: d_rows_t[n*ld_t + col0 + f]
+ *                    (= intensity_transpose layout, psp_process.cpp:2027-2032)
+ *   d_warps          optional [nframes][ncams][6] f32 ECC warp matrices
+ * The double accumulators sum / sumsq (psp_process.cpp:1827-1831) held by the
+ * pipeline are updated. */
+int upsp_pipeline_process(upsp_pipeline *p, const uint16_t *const *d_frames, int nframes,
+                          int64_t first_frame, float *d_rows, float *d_rows_t, int64_t ld_t,
+                          int64_t col0, float *d_warps, void *stream);
+
+/* Accumulator access (device pointers to nnodes doubles each), used for the
+ * cross-GPU sum that replaces MPI_Reduce (psp_process.cpp:1866-1872). */
+int upsp_pipeline_accumulators(upsp_pipeline *p, double **d_sum, double **d_sumsq);
+int upsp_pipeline_reset(upsp_pipeline *p);
+/* avg = sum/N, rms = sqrt(sumsq/N) narrowed to f32 (psp_process.cpp:1933-1936) */
+int upsp_pipeline_finalize(upsp_pipeline *p, uint64_t nframes_total, float *d_avg,
+                           float *d_rms, void *stream);
+
+/* ---- stand-alone per-frame operators (same kernels the pipeline uses) ------ */
+
+/* upsp::fix_hot_pixels (cpp/utils/cv_extras.cpp:230-275) on nframes frames in place;
+ * d_status[f] (may be NULL) = pixels replaced, -1 if more than max_hot looked hot. */
+int upsp_fix_hot_pixels(uint16_t *d_frames, int nframes, int rows, int cols, int thresh,
+                        int min_change, int max_hot, int32_t *d_status, void *stream);
+/* upsp::project_frame (cpp/lib/projection.ipp:883-908) for one u16 / f32 image */
+int upsp_project_frame_u16(const uint16_t *d_img, const int32_t *d_pix, const float *d_weight,
+                           size_t nnodes, float *d_out, void *stream);
+int upsp_project_frame_f32(const float *d_img, const int32_t *d_pix, const float *d_weight,
+                           size_t nnodes, float *d_out, void *stream);
+/* local_transpose (cpp/exec/psp_process.cpp:647-689): dst[x][y] = src[y][x];
+ * src is [y_extent][x_extent], dst rows have leading dimension ld_dst >= y_extent. */
+int upsp_transpose_f32(const float *d_src, int64_t x_extent, int64_t y_extent, float *d_dst,
+                       int64_t ld_dst, void *stream);
+/* apportion (cpp/exec/psp_process.cpp:611-624) */
+int upsp_apportion(int value, int nbins, int *h_start, int *h_extent);
+
+/* upsp::register_pixel (cpp/lib/registration.cpp:32-81) on one frame:
+ * ECC affine (cv::findTransformECC semantics) then inverse-map warp of the u16 frame.
+ * h_warp6: resulting 2x3 matrix; returns iterations (>=1) or a negative status. */
+int upsp_register_pixel_u16(const float *d_ref32f, const uint16_t *d_inp, int rows, int cols,
+                            int max_iters, double eps, int interp, uint16_t *d_out,
+                            float *h_warp6, void *stream);
+/* cv::GaussianBlur(img,img,Size(k,k),0) / cv::blur(img,img,Size(k,k)) as used at
+ * psp_process.cpp:1802-1807 ; box = 0 gaussian, 1 box */
+int upsp_blur_f32(const float *d_src, float *d_dst, int rows, int cols, int k, int box,
+                  void *stream);
+/* PatchClusters<float>::operator() (cpp/lib/patches.ipp:98-165) on one f32 image */
+int upsp_patch_f32(float *d_img, int rows, int cols, int nclusters, const int32_t *h_b_off,
+                   const int32_t *h_bx, const int32_t *h_by, const int32_t *h_i_off,
+                   const int32_t *h_ix, const int32_t *h_iy, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UPSP_GPU_H */

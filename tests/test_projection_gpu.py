@@ -1,0 +1,88 @@
+"""GPU parity: projection build (create_projection_mat), camera weights and skipped
+nodes vs the CPU oracle.  Bar: identical pixel index per node, bit-identical uv."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def setup_case(oracle, mesh, cam_kw, size):
+    from upsp_processing_amd import _capi, synthetic as syn
+    v, t = mesh
+    s9, tn = syn.soup(v, t)
+    nrm = syn.node_normals(v, t)
+    c = syn.pinhole_camera(size[0], size[1], **cam_kw)
+    cam_g = _capi.make_camera(c["K"], c["dist"], c["R"], c["t"], *size)
+    cam_o = oracle.make_camera(c["K"], c["dist"], c["R"], c["t"], *size)
+    return v, t, s9, tn, nrm, cam_g, cam_o
+
+
+@pytest.mark.parametrize("case", ["sphere10k", "tunnel", "tunnel_k1"])
+def test_projection_matches_oracle(gpu_lib, oracle, case):
+    from upsp_processing_amd import engine, synthetic as syn
+    if case == "sphere10k":      # BASELINE config 1: 512x512 frame, 10k-tri sphere
+        mesh, kw, size = syn.uv_sphere(50, 100), dict(), (512, 512)
+    elif case == "tunnel":
+        mesh, kw, size = syn.tunnel_model(100, 240, 40, 80), dict(center=(0, 0, 20), half_extent=6.0), (1024, 512)
+    else:
+        mesh, kw, size = syn.tunnel_model(60, 120, 24, 48), dict(center=(0, 0, 20), half_extent=5.0, k1=-0.09, azimuth_deg=35), (640, 480)
+    v, t, s9, tn, nrm, cam_g, cam_o = setup_case(oracle, mesh, kw, size)
+    bvh = engine.BVH(s9)
+    obv = oracle.OracleBVH(s9)
+    dn = (np.arange(v.shape[0]) % 11 != 0).astype(np.uint8) if case == "tunnel" else None
+    g = engine.build_projection(bvh, cam_g, v, nrm, tn, 70.0, datanode=dn, nodecount=True)
+    o = oracle.create_projection(obv, cam_o, v, nrm, tn, engine.oblique_threshold(70.0), datanode=dn)
+    pix = g["pix"].cpu().numpy()
+    assert (pix >= 0).sum() > 100
+    assert np.array_equal(pix, o["pix"])
+    assert np.array_equal(g["uv"].cpu().numpy().view(np.int32), o["uv"].view(np.int32))
+    assert g["nrays"] == o["nrays"]
+    assert np.array_equal(g["nodecount"].cpu().numpy(), o["nodecount"])
+    sk, cnt = engine.skipped_nodes(g["pix"])
+    assert np.array_equal(sk.cpu().numpy(), oracle.skipped_nodes(o["pix"])) and cnt == (pix < 0).sum()
+
+
+def test_multi_camera_weights(gpu_lib, oracle):
+    from upsp_processing_amd import engine, _capi, synthetic as syn
+    v, t = syn.tunnel_model(60, 120, 24, 48)
+    s9, tn = syn.soup(v, t)
+    nrm = syn.node_normals(v, t)
+    bvh, obv = engine.BVH(s9), oracle.OracleBVH(s9)
+    pix_g, pix_o, centers = [], [], []
+    for az in (0, 60, 120, 200):
+        c = syn.pinhole_camera(512, 512, center=(0, 0, 20), half_extent=6.0, azimuth_deg=az)
+        cg = _capi.make_camera(c["K"], c["dist"], c["R"], c["t"], 512, 512)
+        co = oracle.make_camera(c["K"], c["dist"], c["R"], c["t"], 512, 512)
+        pix_g.append(engine.build_projection(bvh, cg, v, nrm, tn, 70.0)["pix"])
+        pix_o.append(oracle.create_projection(obv, co, v, nrm, tn, engine.oblique_threshold(70.0))["pix"])
+        centers.append(engine.camera_center(cg))
+    import torch
+    pg = torch.stack(pix_g)
+    po = np.stack(pix_o)
+    assert np.array_equal(pg.cpu().numpy(), po)
+    assert ((po >= 0).sum(0) >= 2).sum() > 50      # overlap exists
+    for mode, m in (("best_view", 0), ("average_view", 1)):
+        wg = engine.projection_weights(pg, v, nrm, np.array(centers), mode).cpu().numpy()
+        wo = oracle.adjust_weights(po, np.ones_like(po, dtype=np.float32), v, nrm, np.array(centers), m)
+        # f64 acos -> f32: 1 ulp tolerance
+        assert np.allclose(wg, wo, rtol=2e-7, atol=0)
+        seen = po >= 0
+        s = (wg * seen).sum(0)
+        assert np.allclose(s[seen.any(0)], 1.0, atol=1e-6)
+
+
+def test_empty_and_ragged(gpu_lib):
+    from upsp_processing_amd import engine, _capi, synthetic as syn
+    v, t = syn.uv_sphere(8, 16)
+    s9, tn = syn.soup(v, t)
+    bvh = engine.BVH(s9)
+    c = syn.pinhole_camera(64, 48)
+    cam = _capi.make_camera(c["K"], c["dist"], c["R"], c["t"], 64, 48)
+    # camera looking away: nothing projects into the frame
+    c2 = syn.pinhole_camera(64, 48, center=(0, 0, 4))
+    c2["R"] = -c2["R"]; c2["R"][0] *= -1
+    cam2 = _capi.make_camera(c2["K"], c2["dist"], c2["R"], -c2["R"] @ np.array([0, 0, 4.0]), 64, 48)
+    g = engine.build_projection(bvh, cam2, v, syn.node_normals(v, t), tn, 70.0)
+    assert (g["pix"].cpu().numpy() == -1).all()
+    with pytest.raises(ValueError):
+        engine.build_projection(bvh, cam, v, v, tn[:-3], 70.0)

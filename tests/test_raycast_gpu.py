@@ -1,0 +1,167 @@
+"""GPU parity: HIP ray caster (through the C ABI and the pybind11 `raycast` module)
+vs the CPU oracle on identical inputs.  Bar: bit-exact hit flag, t, primID, u/v/w,
+pos, nrm (integer / IEEE +-*/ work; see DESIGN.md 'parity')."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def rand_rays(n, seed, spread=3.0, jitter=0.6):
+    rng = np.random.default_rng(seed)
+    org = (rng.normal(size=(n, 3)) * spread).astype(np.float32)
+    dirs = (-org + rng.normal(size=(n, 3)) * jitter).astype(np.float32)
+    return org, dirs
+
+
+def assert_hits_equal(g, o):
+    hit_g = g["hit"].cpu().numpy() if hasattr(g["hit"], "cpu") else g["hit"]
+    assert np.array_equal(hit_g, o["hit"])
+    for k in ("t", "prim", "uvw", "pos", "nrm"):
+        a = g[k].cpu().numpy() if hasattr(g[k], "cpu") else g[k]
+        b = o[k]
+        same = (a.view(np.int32) == b.view(np.int32)) if a.dtype == np.float32 else (a == b)
+        assert same.all(), (k, np.argwhere(~same)[:5], a[~same][:5], b[~same][:5])
+
+
+@pytest.mark.parametrize("nlat,nlon", [(2, 3), (12, 24), (50, 100)])
+def test_closest_hit_sphere_bitwise(gpu_lib, oracle, nlat, nlon):
+    from upsp_processing_amd import engine, synthetic as syn
+    v, t = syn.uv_sphere(nlat, nlon)
+    s9, _ = syn.soup(v, t)
+    bvh = engine.BVH(s9)
+    obv = oracle.OracleBVH(s9)
+    assert bvh.info["n_ref_nodes"] == obv.nnodes and bvh.info["depth"] == obv.depth
+    org, dirs = rand_rays(20000, nlat)
+    assert_hits_equal(bvh.intersect(org, dirs), obv.intersect(org, dirs))
+    # shared origin (camera rays), un-normalised directions
+    o1 = np.array([0.1, -0.2, 4.0], np.float32)
+    d2 = (np.random.default_rng(1).normal(size=(5000, 3)) * [0.3, 0.3, 0.05] + [0, 0, -1]).astype(np.float32) * 7.5
+    assert_hits_equal(bvh.intersect(o1, d2), obv.intersect(o1, d2))
+    occ = bvh.occluded(org, dirs).cpu().numpy()
+    assert np.array_equal(occ, obv.intersect(org, dirs)["hit"])
+
+
+def test_tunnel_model_and_vertex_rays_bitwise(gpu_lib, oracle):
+    """Rays aimed exactly at mesh vertices (the create_projection_mat pattern: grazing
+    box corners, exact-zero edge functions -> double fallback, equal-t ties)."""
+    from upsp_processing_amd import engine, synthetic as syn
+    v, t = syn.tunnel_model(60, 120, 24, 48)
+    s9, _ = syn.soup(v, t)
+    bvh = engine.BVH(s9)
+    obv = oracle.OracleBVH(s9)
+    cam = np.array([0.5, 3.0, 20.0], np.float32)
+    d = (v - cam).astype(np.float32)
+    assert_hits_equal(bvh.intersect(cam, d), obv.intersect(cam, d))
+    dn = d / np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    assert_hits_equal(bvh.intersect(cam, dn), obv.intersect(cam, dn))
+    # axis-aligned rays: zero direction components, origins inside / on boxes
+    org = np.repeat(v[::7], 3, axis=0).astype(np.float32)
+    dirs = np.tile(np.eye(3, dtype=np.float32), (org.shape[0] // 3, 1))
+    assert_hits_equal(bvh.intersect(org, dirs), obv.intersect(org, dirs))
+    assert_hits_equal(bvh.intersect(org, -dirs), obv.intersect(org, -dirs))
+
+
+def test_degenerate_scenes(gpu_lib, oracle):
+    from upsp_processing_amd import engine, _capi
+    # single triangle (root is a leaf), coplanar axis-aligned quad pair (flat boxes)
+    tri = np.array([0, 0, 1, 0, 1, 0, 1, 0, 0], np.float32)
+    quad = np.array([0, 0, 2, 1, 0, 2, 1, 1, 2, 0, 0, 2, 1, 1, 2, 0, 1, 2], np.float32)
+    # 200 identical triangles: zero centroid extent -> one oversized leaf (pspRT.cpp:485-494)
+    many = np.tile(tri, 200)
+    for s9 in (tri, quad, many, np.concatenate([tri, quad, many])):
+        bvh, obv = engine.BVH(s9), oracle.OracleBVH(s9)
+        org, dirs = rand_rays(4000, 9, spread=2.0, jitter=1.0)
+        assert_hits_equal(bvh.intersect(org, dirs), obv.intersect(org, dirs))
+    with pytest.raises(_capi.UpspError):
+        engine.BVH(np.zeros(0, np.float32))        # reference: "no primitives!" then DIE
+    bvh = engine.BVH(tri)
+    out = bvh.intersect(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))
+    assert out["t"].numel() == 0
+
+
+def test_reference_toy_kats_through_pybind(gpu_lib):
+    """test/python/test_visibility.py toy scenes through the drop-in `raycast` module."""
+    from upsp_processing_amd import raycast
+    from upsp_processing_amd.visibility import VisibilityChecker
+    t0 = [0., 0., 1., 0., 1., 0., 1., 0., 0.]
+    t1 = [0., 0., 1., 0., 1., 0., 0., 1., 1.]
+    scene = raycast.CreateBVH(t0 + t1, 3)
+    assert type(scene).__name__ == "BVH"       # external_calibrate.py:1453
+    vc = VisibilityChecker(scene, oblique_angle=70, epsilon=1e-4)
+    A = np.array
+    cam = A([1., 1., 1.]).reshape(3, 1)
+    assert vc.is_visible(cam, A([[2., 2, 2], [3, 3, 3]]), A([[1., 1, 1], [1, 1, 1]])).tolist() == []
+    assert vc.is_visible(cam, A([[0., 0, 0], [-1, -1, -1]]), A([[.9, .9, .9], [1.1, 1.1, 1.1]])).tolist() == []
+    assert vc.is_visible(A([-8., -8, 0]), A([[-5., -5, 0], [-5, -1, 0]]), A([[-.9, 0, 0], [0, -1.2, 0]])).tolist() == [0, 1]
+    assert vc.is_visible(A([-2., -2, -2]).reshape(3, 1), A([[-1., -1, -1], [0, 0, 0]]), -np.ones((2, 3))).tolist() == [0, 1]
+    nodes = A([[2., 2, 2], [3, 3, 3], [.9, .9, .9], [.5, .5, .5], [0, 0, 0], [-1, -1, -1]])
+    assert vc.is_visible(cam, nodes, np.ones((6, 3))).tolist() == [2, 3]
+    # single-ray API exactly as visibility.py:410-412 uses it
+    r = raycast.Ray(0.25, 0.25, 5.0, 0.0, 0.0, -1.0)
+    h = raycast.Hit()
+    assert scene.intersect(r, h) is True
+    assert np.allclose(h.pos, [0.25, 0.25, 0.5])
+    h2 = raycast.Hit()
+    assert scene.intersect(raycast.Ray(5, 5, 5, 0, 0, 1), h2) is False
+    assert h2.pos == [0.0, 0.0, 0.0]
+
+
+def test_camera01_regression_gpu(gpu_lib, fml):
+    """test_camera01 (test/python/test_visibility.py:243-254): 148 608 visible nodes on the
+    reference's 609 120-triangle grid, and the same index set as the oracle."""
+    import refdata
+    from upsp_processing_amd import raycast
+    from upsp_processing_amd.visibility import VisibilityChecker
+    scene = raycast.CreateBVH(fml["prims"], 3)
+    vc = VisibilityChecker(scene, oblique_angle=70, epsilon=1e-4)
+    vis = vc.is_visible(fml["cam_t"], fml["nodes"], fml["norms"])
+    assert len(vis) == 148608
+    golden = np.load(os.path.join(refdata.GOLDEN, "camera01_visible.npz"))["visible"]
+    assert np.array_equal(vis, golden)
+
+
+def test_photogrammetry_hit_position(gpu_lib, fml, oracle):
+    """Closest-hit positions on the reference grid: GPU == oracle bit for bit on 50k rays
+    from camera01 towards grid nodes (the does_intersect(return_pos=True) path,
+    target_bumping.py:54)."""
+    from upsp_processing_amd import engine
+    bvh = engine.BVH(fml["prims"])
+    obv = oracle.OracleBVH(fml["prims"])
+    cam = fml["cam_t"].reshape(3).astype(np.float32)
+    d = (fml["nodes"][::6] - cam).astype(np.float32)
+    assert_hits_equal(bvh.intersect(cam, d), obv.intersect(cam, d))
+
+
+def test_full_size_properties(gpu_lib):
+    """BASELINE config size (1 M-tri model, 1 Mi rays): size-independent properties.
+    * scale invariance of the hit set: d and 2d hit the same triangle with t/2;
+    * every reported hit re-verifies: pos = o + t d lies in the triangle's plane;
+    * occluded() == intersect().hit."""
+    import torch
+    from upsp_processing_amd import engine, synthetic as syn
+    v, t = syn.tunnel_model()
+    s9, _ = syn.soup(v, t)
+    bvh = engine.BVH(s9)
+    assert bvh.info["ntris"] == 1001520
+    n = 1 << 20
+    g = torch.Generator(device="cuda"); g.manual_seed(7)
+    cam = torch.tensor([0.0, 0.0, 20.0], device="cuda")
+    tgt = (torch.rand((n, 3), generator=g, device="cuda") - 0.5) * torch.tensor([14.0, 4.0, 2.0], device="cuda")
+    d = tgt - cam
+    a = bvh.intersect(cam, d)
+    b = bvh.intersect(cam, 2.0 * d)
+    assert torch.equal(a["hit"], b["hit"]) and torch.equal(a["prim"], b["prim"])
+    h = a["hit"]
+    assert 0.2 < h.float().mean().item() < 0.9
+    assert torch.allclose(a["t"][h], 2.0 * b["t"][h], rtol=1e-6)
+    assert torch.equal(bvh.occluded(cam, d), h)
+    tri = torch.as_tensor(s9, device="cuda").reshape(-1, 3, 3)[a["prim"][h].long()]
+    nrm = torch.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0], dim=1)
+    nrm = nrm / nrm.norm(dim=1, keepdim=True)
+    dist = ((a["pos"][h] - tri[:, 0]) * nrm).sum(1).abs()
+    assert dist.max().item() < 1e-4
+    uvw = a["uvw"][h]
+    assert (uvw.sum(1) - 1).abs().max().item() < 1e-5 and uvw.min().item() >= 0

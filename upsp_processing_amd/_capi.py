@@ -1,0 +1,137 @@
+"""ctypes view of libupsp_gpu.so -- the C ABI declared in include/upsp_gpu.h.
+
+There is deliberately NO fallback: if the HIP library is missing or fails to load,
+importing the compute path raises.  (The CPU oracle under oracle/ is test
+infrastructure and is never imported from here.)
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libupsp_gpu.so")
+
+UPSP_OK = 0
+STATUS = {0: "UPSP_OK", -1: "UPSP_ERR_INVALID", -2: "UPSP_ERR_EMPTY", -3: "UPSP_ERR_DEPTH",
+          -4: "UPSP_ERR_HIP", -5: "UPSP_ERR_NO_DEVICE", -6: "UPSP_ERR_DIVERGED"}
+
+
+class UpspError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("%s: %s" % (STATUS.get(status, status), msg))
+        self.status = status
+
+
+class BvhInfo(C.Structure):
+    _fields_ = [("ntris", C.c_uint64), ("n_ref_nodes", C.c_uint32), ("n_gpu_nodes", C.c_uint32),
+                ("depth", C.c_uint32), ("max_leaf", C.c_uint32),
+                ("bounds_min", C.c_float * 3), ("bounds_max", C.c_float * 3),
+                ("device_bytes", C.c_uint64), ("build_seconds", C.c_double)]
+
+
+class Hits(C.Structure):
+    _fields_ = [("hit", C.c_void_p), ("t", C.c_void_p), ("prim", C.c_void_p),
+                ("uvw", C.c_void_p), ("pos", C.c_void_p), ("nrm", C.c_void_p)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("K", C.c_double * 9), ("dist", C.c_double * 5), ("R", C.c_double * 9),
+                ("t", C.c_double * 3), ("width", C.c_int32), ("height", C.c_int32)]
+
+
+class PipelineOpts(C.Structure):
+    _fields_ = [("hot_enable", C.c_int32), ("hot_thresh", C.c_int32),
+                ("hot_min_change", C.c_int32), ("hot_max", C.c_int32),
+                ("registration", C.c_int32), ("ecc_max_iters", C.c_int32),
+                ("ecc_eps", C.c_double), ("interp", C.c_int32),
+                ("filter", C.c_int32), ("filter_size", C.c_int32), ("patch", C.c_int32),
+                ("reserved", C.c_int32 * 5)]
+
+
+_vp, _sz, _i, _i64, _u64p = C.c_void_p, C.c_size_t, C.c_int, C.c_int64, C.POINTER(C.c_uint64)
+
+# name -> (restype, argtypes); every function include/upsp_gpu.h declares
+SIGNATURES = {
+    "upsp_last_error": (C.c_char_p, []),
+    "upsp_device_info": (_i, [C.POINTER(_i), C.c_char_p, C.POINTER(_i)]),
+    "upsp_version": (_i, []),
+    "upsp_bvh_create": (_i, [_vp, _sz, C.POINTER(_vp)]),
+    "upsp_bvh_destroy": (None, [_vp]),
+    "upsp_bvh_get_info": (_i, [_vp, C.POINTER(BvhInfo)]),
+    "upsp_bvh_intersect": (_i, [_vp, _vp, _i, _vp, _sz, C.POINTER(Hits), _vp]),
+    "upsp_bvh_intersect_host": (_i, [_vp, _vp, _i, _vp, _sz, C.POINTER(Hits)]),
+    "upsp_bvh_occluded": (_i, [_vp, _vp, _i, _vp, _sz, _vp, _vp]),
+    "upsp_bvh_occluded_host": (_i, [_vp, _vp, _i, _vp, _sz, _vp]),
+    "upsp_bvh_enable_stats": (_i, [_vp, _i]),
+    "upsp_bvh_last_stats": (_i, [_vp, _u64p, _u64p, _u64p]),
+    "upsp_projection_build": (_i, [_vp, C.POINTER(Camera), _vp, _vp, _vp, _vp, _sz, C.c_float,
+                                   _vp, _vp, _vp, _u64p, _vp]),
+    "upsp_projection_weights": (_i, [_i, _sz, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "upsp_projection_skipped": (_i, [_i, _sz, _vp, _vp, _u64p, _vp]),
+    "upsp_camera_center": (_i, [C.POINTER(Camera), _vp]),
+    "upsp_project_points_host": (_i, [C.POINTER(Camera), _vp, _sz, _vp]),
+    "upsp_pipeline_default_opts": (None, [C.POINTER(PipelineOpts)]),
+    "upsp_pipeline_create": (_i, [_i, _i, _i, _sz, C.POINTER(PipelineOpts), C.POINTER(_vp)]),
+    "upsp_pipeline_destroy": (None, [_vp]),
+    "upsp_pipeline_set_projection": (_i, [_vp, _i, _vp, _vp]),
+    "upsp_pipeline_set_skipped": (_i, [_vp, _vp]),
+    "upsp_pipeline_set_reference": (_i, [_vp, _i, _vp]),
+    "upsp_pipeline_set_patches": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "upsp_pipeline_process": (_i, [_vp, C.POINTER(_vp), _i, _i64, _vp, _vp, _i64, _i64, _vp, _vp]),
+    "upsp_pipeline_accumulators": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
+    "upsp_pipeline_reset": (_i, [_vp]),
+    "upsp_pipeline_finalize": (_i, [_vp, C.c_uint64, _vp, _vp, _vp]),
+    "upsp_fix_hot_pixels": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "upsp_project_frame_u16": (_i, [_vp, _vp, _vp, _sz, _vp, _vp]),
+    "upsp_project_frame_f32": (_i, [_vp, _vp, _vp, _sz, _vp, _vp]),
+    "upsp_transpose_f32": (_i, [_vp, _i64, _i64, _vp, _i64, _vp]),
+    "upsp_apportion": (_i, [_i, _i, _vp, _vp]),
+    "upsp_register_pixel_u16": (_i, [_vp, _vp, _i, _i, _i, C.c_double, _i, _vp, _vp, _vp]),
+    "upsp_blur_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "upsp_patch_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libupsp_gpu.so; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "libupsp_gpu.so not found at %s -- build it with "
+                "`python -m upsp_processing_amd.build` (there is no CPU fallback)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the ABI lost a symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != UPSP_OK:
+        raise UpspError(rc, (lib().upsp_last_error() or b"").decode())
+    return rc
+
+
+def make_camera(K, dist, R, t, width, height):
+    import numpy as np
+    cam = Camera()
+    cam.K[:] = np.asarray(K, dtype=np.float64).ravel().tolist()
+    d = np.zeros(5)
+    dd = np.asarray(dist, dtype=np.float64).ravel()
+    d[:min(5, dd.size)] = dd[:5]
+    cam.dist[:] = d.tolist()
+    cam.R[:] = np.asarray(R, dtype=np.float64).ravel().tolist()
+    cam.t[:] = np.asarray(t, dtype=np.float64).ravel().tolist()
+    cam.width, cam.height = int(width), int(height)
+    return cam
+
+
+def device_info():
+    n, cus = C.c_int(0), C.c_int(0)
+    arch = C.create_string_buffer(64)
+    check(lib().upsp_device_info(C.byref(n), arch, C.byref(cus)))
+    return dict(n_devices=n.value, arch=arch.value.decode(), n_cus=cus.value)

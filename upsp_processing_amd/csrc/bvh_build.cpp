@@ -1,0 +1,226 @@
+// Host-side BVH construction for the MI355X ray caster.
+//
+// The tree is the reference's tree: top-down SAH with 12 centroid buckets on the
+// widest centroid axis, leaves of <= 4 triangles (or any size when the centroid
+// extent is zero) -- rt::BVH::recursiveBuild, cpp/raycast/pspRT.cpp:456-572 --
+// because closest-hit ties are broken by traversal order (strict `<`,
+// pspRT.cpp:395) and the engine must return the same primID as the reference.
+// Only the memory layout is new: interior nodes become 64-byte records holding
+// both child boxes (upsp_internal.h), triangles become 48-byte records stored in
+// leaf order, so that one wave-wide fetch serves both box tests of a step.
+//
+// Works on structure-of-arrays primitive data and an index permutation; the
+// permutation is split in place with the same element order libstdc++'s
+// std::partition produces (pspRT.cpp:545-553), which fixes the order of the
+// triangles inside a leaf.
+#include <algorithm>
+#include <cfloat>
+#include <cstring>
+
+#include "upsp_internal.h"
+
+namespace upsp {
+namespace {
+
+struct Box {
+    float lo[3], hi[3];
+    void clear()
+    {
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = FLT_MAX;
+            hi[a] = -FLT_MAX;
+        }
+    }
+    void grow(const float *p)
+    {
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::min(lo[a], p[a]);
+            hi[a] = std::max(hi[a], p[a]);
+        }
+    }
+    void grow(const Box &b)
+    {
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::min(lo[a], b.lo[a]);
+            hi[a] = std::max(hi[a], b.hi[a]);
+        }
+    }
+    bool empty() const { return hi[0] < lo[0] || hi[1] < lo[1] || hi[2] < lo[2]; }
+    // Imath::Box::size(): zero vector for an empty box
+    float extent(int a) const { return empty() ? 0.0f : hi[a] - lo[a]; }
+    int widest() const
+    {
+        int m = 0;
+        for (int a = 1; a < 3; ++a)
+            if (extent(a) > extent(m)) m = a;
+        return m;
+    }
+    // rt::SurfaceArea (pspRT.cpp:266-270)
+    float area() const
+    {
+        float dx = extent(0), dy = extent(1), dz = extent(2);
+        return 2 * (dx * dy + dx * dz + dy * dz);
+    }
+};
+
+struct Builder {
+    const float *soup;
+    std::vector<Box> pbox;       // per input triangle
+    std::vector<float> cen;      // 3 per input triangle
+    std::vector<uint32_t> perm;  // working permutation of triangle ids
+    HostBvh &out;
+    static constexpr int kBuckets = 12;
+    static constexpr int kLeafPrims = 4;
+
+    Builder(const float *s, size_t n, HostBvh &o) : soup(s), pbox(n), cen(3 * n), perm(n), out(o)
+    {
+        for (size_t i = 0; i < n; ++i) {
+            Box &b = pbox[i];
+            b.clear();
+            b.grow(s + 9 * i);
+            b.grow(s + 9 * i + 3);
+            b.grow(s + 9 * i + 6);
+            for (int a = 0; a < 3; ++a) cen[3 * i + a] = .5f * b.lo[a] + .5f * b.hi[a];
+            perm[i] = (uint32_t)i;
+        }
+    }
+
+    int bucket(const Box &cb, uint32_t id, int dim) const
+    {
+        // rt::Offset(centroidBounds, centroid)[dim] (pspRT.cpp:257-264)
+        float o = cen[3 * (size_t)id + dim] - cb.lo[dim];
+        if (cb.hi[dim] > cb.lo[dim]) o /= cb.hi[dim] - cb.lo[dim];
+        int b = (int)(kBuckets * o);
+        return b == kBuckets ? kBuckets - 1 : b;
+    }
+
+    // Emits triangles [lo,hi) of perm as one or more device leaves; returns child ref.
+    int32_t emit_leaf(uint32_t lo, uint32_t hi, const Box &box, uint32_t depth)
+    {
+        uint32_t n = hi - lo;
+        out.max_leaf = std::max(out.max_leaf, n);
+        out.depth = std::max(out.depth, depth);
+        if (n <= (uint32_t)kMaxLeaf) {
+            uint32_t first = (uint32_t)out.tris.size();
+            for (uint32_t i = lo; i < hi; ++i) {
+                uint32_t id = perm[i];
+                GpuTri t;
+                std::memset(&t, 0, sizeof(t));
+                std::memcpy(t.a, soup + 9 * (size_t)id, 12);
+                std::memcpy(t.b, soup + 9 * (size_t)id + 3, 12);
+                std::memcpy(t.c, soup + 9 * (size_t)id + 6, 12);
+                t.prim = (int32_t)id;
+                out.tris.push_back(t);
+            }
+            return ~(int32_t)((first << kLeafBits) | (n - 1));
+        }
+        // oversized leaf (zero centroid extent, pspRT.cpp:485-494): ordered chain of
+        // pseudo-nodes whose child boxes are the leaf box, preserving the order.
+        uint32_t me = (uint32_t)out.nodes.size();
+        out.nodes.emplace_back();
+        int32_t l = emit_leaf(lo, lo + kMaxLeaf, box, depth + 1);
+        int32_t r = emit_leaf(lo + kMaxLeaf, hi, box, depth + 1);
+        write_node(me, box, box, l, r, kMetaOrdered);
+        return (int32_t)me;
+    }
+
+    void write_node(uint32_t idx, const Box &L, const Box &R, int32_t l, int32_t r, uint32_t meta)
+    {
+        float *q = out.nodes[idx].q;
+        q[0] = L.lo[0]; q[1] = L.lo[1]; q[2] = L.lo[2]; q[3] = L.hi[0];
+        q[4] = L.hi[1]; q[5] = L.hi[2]; q[6] = R.lo[0]; q[7] = R.lo[1];
+        q[8] = R.lo[2]; q[9] = R.hi[0]; q[10] = R.hi[1]; q[11] = R.hi[2];
+        std::memcpy(&q[12], &l, 4);
+        std::memcpy(&q[13], &r, 4);
+        std::memcpy(&q[14], &meta, 4);
+        q[15] = 0.0f;
+    }
+
+    // Returns the child ref of the subtree over perm[lo,hi) and its bounds.
+    int32_t build(uint32_t lo, uint32_t hi, uint32_t depth, Box &bounds)
+    {
+        out.n_ref_nodes++;
+        bounds.clear();
+        for (uint32_t i = lo; i < hi; ++i) bounds.grow(pbox[perm[i]]);
+        uint32_t n = hi - lo;
+        if (n <= (uint32_t)kLeafPrims) return emit_leaf(lo, hi, bounds, depth);
+
+        Box cb;
+        cb.clear();
+        for (uint32_t i = lo; i < hi; ++i) cb.grow(&cen[3 * (size_t)perm[i]]);
+        int dim = cb.widest();
+        if (cb.hi[dim] == cb.lo[dim]) return emit_leaf(lo, hi, bounds, depth);
+
+        int cnt[kBuckets] = {0};
+        Box bb[kBuckets];
+        for (auto &b : bb) b.clear();
+        for (uint32_t i = lo; i < hi; ++i) {
+            int b = bucket(cb, perm[i], dim);
+            cnt[b]++;
+            bb[b].grow(pbox[perm[i]]);
+        }
+        // SAH cost of splitting after each bucket (pspRT.cpp:513-536)
+        float best_cost = 0.0f;
+        int best = 0;
+        const float parent_area = bounds.area();
+        for (int s = 0; s < kBuckets - 1; ++s) {
+            Box b0, b1;
+            b0.clear();
+            b1.clear();
+            int c0 = 0, c1 = 0;
+            for (int j = 0; j <= s; ++j) {
+                b0.grow(bb[j]);
+                c0 += cnt[j];
+            }
+            for (int j = s + 1; j < kBuckets; ++j) {
+                b1.grow(bb[j]);
+                c1 += cnt[j];
+            }
+            float cost = 1.f + ((float)c0 * b0.area() + (float)c1 * b1.area()) / parent_area;
+            if (s == 0 || cost < best_cost) {
+                best_cost = cost;
+                best = s;
+            }
+        }
+
+        // in-place split, element order of libstdc++ std::partition (bidirectional)
+        uint32_t f = lo, l = hi;
+        while (true) {
+            while (f != l && bucket(cb, perm[f], dim) <= best) ++f;
+            if (f == l) break;
+            --l;
+            while (f != l && !(bucket(cb, perm[l], dim) <= best)) --l;
+            if (f == l) break;
+            std::swap(perm[f], perm[l]);
+            ++f;
+        }
+        uint32_t mid = f;
+        if (mid == lo || mid == hi) return emit_leaf(lo, hi, bounds, depth);  // non-finite input
+
+        uint32_t me = (uint32_t)out.nodes.size();
+        out.nodes.emplace_back();
+        Box L, R;
+        int32_t lref = build(lo, mid, depth + 1, L);
+        int32_t rref = build(mid, hi, depth + 1, R);
+        write_node(me, L, R, lref, rref, (uint32_t)dim);
+        return (int32_t)me;
+    }
+};
+
+}  // namespace
+
+void build_bvh(const float *tris9, size_t ntris, HostBvh &out)
+{
+    out = HostBvh();
+    out.nodes.reserve(ntris / 2 + 16);
+    out.tris.reserve(ntris);
+    Builder b(tris9, ntris, out);
+    Box root;
+    out.root_ref = b.build(0, (uint32_t)ntris, 0, root);
+    for (int a = 0; a < 3; ++a) {
+        out.root_min[a] = root.lo[a];
+        out.root_max[a] = root.hi[a];
+    }
+}
+
+}  // namespace upsp

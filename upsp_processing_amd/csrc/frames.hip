@@ -1,0 +1,470 @@
+// Per-frame kernels of the psp_process phase-1 loop on MI355X (gfx950):
+// hot-pixel repair, nearest-pixel projection (gather) with the double
+// accumulators, finals, tiled transpose, multi-camera weights.
+//
+// All of this is HBM-bound byte/gather work (no MFMA): the kernels are laid out
+// for coalesced 16-byte-per-lane streaming of the u16 frames, one surface node
+// per lane for the gather (node-contiguous row stores), register-resident
+// accumulators across a batch of frames, and an LDS tile for the transpose.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "pipeline.h"
+#include "upsp_internal.h"
+
+namespace upsp {
+namespace {
+
+constexpr int kHotCap = 64;  // recorded hot-pixel positions per frame
+
+// ---------------------------------------------------------------- hot pixels --
+// Pass 1 of upsp::fix_hot_pixels (cpp/utils/cv_extras.cpp:237-247): find pixels
+// >= thresh.  16 bytes (8 pixels) per lane per step; the frame is otherwise only
+// streamed through (this is the one compulsory full read of a frame).
+__global__ void __launch_bounds__(256)
+    hot_scan_kernel(const uint16_t *__restrict__ frames, size_t npix, int thresh,
+                    unsigned *__restrict__ count, unsigned *__restrict__ pos)
+{
+    const size_t f = blockIdx.y;
+    const uint4 *src = reinterpret_cast<const uint4 *>(frames + f * npix);
+    const size_t nvec = npix / 8;
+    const unsigned th = (unsigned)thresh;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const uint4 v = src[i];
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+        // quick reject: any half-word >= thresh ?
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) any |= ((w[k] & 0xFFFFu) >= th) || ((w[k] >> 16) >= th);
+        if (any) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const unsigned px = (w[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
+                if (px >= th) {
+                    const unsigned slot = atomicAdd(&count[f], 1u);
+                    if (slot < (unsigned)kHotCap) pos[f * kHotCap + slot] = (unsigned)(i * 8 + k);
+                }
+            }
+        }
+    }
+    // tail pixels when npix is not a multiple of 8
+    if (blockIdx.x == 0 && threadIdx.x < (npix & 7)) {
+        const size_t p = nvec * 8 + threadIdx.x;
+        if (frames[f * npix + p] >= th) {
+            const unsigned slot = atomicAdd(&count[f], 1u);
+            if (slot < (unsigned)kHotCap) pos[f * kHotCap + slot] = (unsigned)p;
+        }
+    }
+}
+
+// Pass 2 (cv_extras.cpp:249-274): sequential repair in scan order, one lane per frame.
+__global__ void hot_fix_kernel(uint16_t *__restrict__ frames, int nframes, int rows, int cols,
+                               int min_change, int max_hot, const unsigned *__restrict__ count,
+                               unsigned *__restrict__ pos, int32_t *__restrict__ status)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nframes) return;
+    const unsigned n = count[f];
+    if (n > (unsigned)max_hot) {  // "too many pixels look hot": frame untouched
+        if (status) status[f] = -1;
+        return;
+    }
+    unsigned *p = pos + (size_t)f * kHotCap;
+    for (unsigned i = 1; i < n; ++i) {  // scan order
+        const unsigned v = p[i];
+        unsigned j = i;
+        while (j > 0 && p[j - 1] > v) {
+            p[j] = p[j - 1];
+            --j;
+        }
+        p[j] = v;
+    }
+    uint16_t *img = frames + (size_t)f * rows * cols;
+    int replaced = 0;
+    for (unsigned h = 0; h < n; ++h) {
+        const int row = (int)(p[h] / (unsigned)cols), col = (int)(p[h] % (unsigned)cols);
+        uint16_t vals[4];
+        unsigned nv = 0;
+        if (row > 0) vals[nv++] = img[(size_t)(row - 1) * cols + col];
+        if (col > 0) vals[nv++] = img[(size_t)row * cols + col - 1];
+        if (row < rows - 1) vals[nv++] = img[(size_t)(row + 1) * cols + col];
+        if (col < cols - 1) vals[nv++] = img[(size_t)row * cols + col + 1];
+        for (unsigned i = 1; i < nv; ++i) {
+            const uint16_t v = vals[i];
+            unsigned j = i;
+            while (j > 0 && vals[j - 1] > v) {
+                vals[j] = vals[j - 1];
+                --j;
+            }
+            vals[j] = v;
+        }
+        const uint16_t old_val = img[(size_t)row * cols + col];
+        const uint16_t new_val = vals[nv / 2];
+        if ((int)old_val - (int)new_val > min_change) {
+            img[(size_t)row * cols + col] = new_val;
+            ++replaced;
+        }
+    }
+    if (status) status[f] = replaced;
+}
+
+// ------------------------------------------------------------------- gather --
+// upsp::project_frame with <= 1 entry per row (cpp/lib/projection.ipp:883-908)
+// followed by the frame-loop tail (cpp/exec/psp_process.cpp:1813-1843):
+//   sol[n] = sum_c w_c[n] * f32(img_c[pix_c[n]])   (float, camera order)
+//   sol[n] = NaN for skipped nodes
+//   sumsq[n] += (double)(sol*sol) ; sum[n] += sol          (double)
+// One node per lane; pix / weight stay in registers for the whole batch of
+// frames, the accumulators too (one 16-byte read-modify-write per node and batch).
+struct GatherArgs {
+    const void *img[kMaxCams];      // frame 0 of the batch, camera c
+    const int32_t *pix[kMaxCams];
+    const float *weight[kMaxCams];  // may be null (= 1)
+    int is_f32[kMaxCams];
+    int ncams;
+    size_t npix;
+};
+
+template <int NCAMS>
+__global__ void __launch_bounds__(256)
+    gather_kernel(GatherArgs a, const uint8_t *__restrict__ skipped, unsigned nnodes, int nframes,
+                  float *__restrict__ rows, double *__restrict__ sum, double *__restrict__ sumsq)
+{
+    const unsigned n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= nnodes) return;
+    const int nc = NCAMS > 0 ? NCAMS : a.ncams;
+    int32_t px[NCAMS > 0 ? NCAMS : kMaxCams];
+    float w[NCAMS > 0 ? NCAMS : kMaxCams];
+#pragma unroll
+    for (int c = 0; c < nc; ++c) {
+        px[c] = a.pix[c][n];
+        w[c] = a.weight[c] ? a.weight[c][n] : 1.0f;
+    }
+    const bool skip = skipped && skipped[n];
+    double s = 0.0, ss = 0.0;
+    const float qnan = __builtin_nanf("");
+#pragma unroll 4
+    for (int f = 0; f < nframes; ++f) {
+        float sol = 0.0f;
+#pragma unroll
+        for (int c = 0; c < nc; ++c) {
+            float v = 0.0f;
+            if (px[c] >= 0) {
+                const size_t off = (size_t)f * a.npix + (size_t)px[c];
+                const float pxv = a.is_f32[c] ? reinterpret_cast<const float *>(a.img[c])[off]
+                                              : (float)reinterpret_cast<const uint16_t *>(a.img[c])[off];
+                v = 0.0f + w[c] * pxv;
+            }
+            sol = (c == 0) ? v : sol + v;
+        }
+        if (skip) sol = qnan;
+        s += (double)sol;
+        ss += (double)(sol * sol);
+        if (rows) rows[(size_t)f * nnodes + n] = sol;
+    }
+    sum[n] += s;
+    sumsq[n] += ss;
+}
+
+__global__ void finals_kernel(const double *__restrict__ sum, const double *__restrict__ sumsq,
+                              unsigned nnodes, double nframes, float *__restrict__ avg,
+                              float *__restrict__ rms)
+{
+    const unsigned n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= nnodes) return;
+    if (avg) avg[n] = (float)(sum[n] / nframes);           // psp_process.cpp:1934
+    if (rms) rms[n] = (float)sqrt(sumsq[n] / nframes);     // psp_process.cpp:1935
+}
+
+// ---------------------------------------------------------------- transpose --
+// local_transpose (psp_process.cpp:647-689): dst[x][y] = src[y][x].  64x64 f32
+// tile through LDS (row stride 65 words: conflict-free column reads), 256-byte
+// coalesced rows on both sides.
+__global__ void __launch_bounds__(256)
+    transpose_kernel(const float *__restrict__ src, long long x_extent, long long y_extent,
+                     float *__restrict__ dst, long long ld_dst)
+{
+    __shared__ float tile[64][65];
+    const long long x0 = (long long)blockIdx.x * 64, y0 = (long long)blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+#pragma unroll
+    for (int j = 0; j < 64; j += 4) {
+        const long long y = y0 + ty + j, x = x0 + tx;
+        if (y < y_extent && x < x_extent) tile[ty + j][tx] = src[y * x_extent + x];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 64; j += 4) {
+        const long long x = x0 + ty + j, y = y0 + tx;
+        if (x < x_extent && y < y_extent) dst[x * ld_dst + y] = tile[tx][ty + j];
+    }
+}
+
+// ------------------------------------------------------------------ weights --
+struct Centers {
+    float c[kMaxCams][3];
+};
+
+// adjust_projection_for_weights + BestView / AverageViews
+// (cpp/lib/projection.ipp:911-1078, 227-268; angle_between cv_extras.ipp:69-73)
+__global__ void weights_kernel(int ncams, unsigned nnodes, const int32_t *__restrict__ pix,
+                               float *__restrict__ weight, const float *__restrict__ nodes,
+                               const float *__restrict__ normals, Centers ctr, int mode)
+{
+    const unsigned n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= nnodes) return;
+    float ang[kMaxCams];
+    int cnt = 0;
+    const float px = nodes[3 * (size_t)n], py = nodes[3 * (size_t)n + 1], pz = nodes[3 * (size_t)n + 2];
+    const float nx = normals[3 * (size_t)n], ny = normals[3 * (size_t)n + 1], nz = normals[3 * (size_t)n + 2];
+    for (int c = 0; c < ncams; ++c) {
+        ang[c] = 0.0f;
+        if (pix[(size_t)c * nnodes + n] < 0) continue;
+        const float dx = px - ctr.c[c][0], dy = py - ctr.c[c][1], dz = pz - ctr.c[c][2];
+        const float dot = dx * nx + dy * ny + dz * nz;
+        const double n1 = sqrt((double)dx * dx + (double)dy * dy + (double)dz * dz);
+        const double n2 = sqrt((double)nx * nx + (double)ny * ny + (double)nz * nz);
+        ang[c] = (float)acos(dot / n1 / n2);
+        ++cnt;
+    }
+    if (cnt < 2) return;
+    if (mode == 0) {
+        int best = -1;
+        for (int c = 0; c < ncams; ++c) {
+            if (pix[(size_t)c * nnodes + n] < 0) continue;
+            if (best < 0 || ang[c] > ang[best]) best = c;
+        }
+        for (int c = 0; c < ncams; ++c)
+            if (pix[(size_t)c * nnodes + n] >= 0) weight[(size_t)c * nnodes + n] *= (c == best) ? 1.0f : 0.0f;
+    } else {
+        float s = 0.0f;
+        for (int c = 0; c < ncams; ++c)
+            if (pix[(size_t)c * nnodes + n] >= 0) s += ang[c];
+        for (int c = 0; c < ncams; ++c)
+            if (pix[(size_t)c * nnodes + n] >= 0) weight[(size_t)c * nnodes + n] *= ang[c] / s;
+    }
+}
+
+__global__ void skipped_kernel(int ncams, unsigned nnodes, const int32_t *__restrict__ pix,
+                               uint8_t *__restrict__ skipped, unsigned long long *count)
+{
+    const unsigned n = blockIdx.x * blockDim.x + threadIdx.x;
+    bool sk = false;
+    if (n < nnodes) {
+        bool found = false;
+        for (int c = 0; c < ncams; ++c) found |= pix[(size_t)c * nnodes + n] >= 0;
+        sk = !found;
+        skipped[n] = sk ? 1 : 0;
+    }
+    const unsigned long long m = __ballot(sk);
+    if ((threadIdx.x & 63) == 0 && m && count) atomicAdd(count, (unsigned long long)__popcll(m));
+}
+
+__global__ void project_one_kernel(const void *img, int is_f32, const int32_t *__restrict__ pix,
+                                   const float *__restrict__ weight, unsigned nnodes,
+                                   float *__restrict__ out)
+{
+    const unsigned n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= nnodes) return;
+    const int32_t p = pix[n];
+    float v = 0.0f;
+    if (p >= 0) {
+        const float pv = is_f32 ? reinterpret_cast<const float *>(img)[p]
+                                : (float)reinterpret_cast<const uint16_t *>(img)[p];
+        v = 0.0f + (weight ? weight[n] : 1.0f) * pv;
+    }
+    out[n] = v;
+}
+
+}  // namespace
+
+// ---- launchers used by pipeline.cpp -----------------------------------------
+int launch_hot_fix(uint16_t *d_frames, int nframes, int rows, int cols, int thresh,
+                   int min_change, int max_hot, unsigned *d_count, unsigned *d_pos,
+                   int32_t *d_status, hipStream_t st)
+{
+    if (nframes <= 0) return UPSP_OK;
+    if (max_hot < 0 || max_hot >= kHotCap) return fail(UPSP_ERR_INVALID, "max_hot must be in [0,63]");
+    const size_t npix = (size_t)rows * cols;
+    UPSP_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(unsigned) * (size_t)nframes, st));
+    size_t bx = (npix / 8 + 255) / 256;
+    if (bx > 128) bx = 128;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(hot_scan_kernel, dim3((unsigned)bx, (unsigned)nframes), dim3(256), 0, st,
+                       d_frames, npix, thresh, d_count, d_pos);
+    hipLaunchKernelGGL(hot_fix_kernel, dim3((nframes + 63) / 64), dim3(64), 0, st, d_frames,
+                       nframes, rows, cols, min_change, max_hot, d_count, d_pos, d_status);
+    UPSP_HIP_CHECK(hipGetLastError());
+    return UPSP_OK;
+}
+
+int launch_gather(const PipelineGather &g, hipStream_t st)
+{
+    if (g.nnodes == 0 || g.nframes <= 0) return UPSP_OK;
+    GatherArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.ncams = g.ncams;
+    a.npix = g.npix;
+    for (int c = 0; c < g.ncams; ++c) {
+        a.img[c] = g.img[c];
+        a.pix[c] = g.pix[c];
+        a.weight[c] = g.weight[c];
+        a.is_f32[c] = g.is_f32[c];
+    }
+    const dim3 grid((unsigned)((g.nnodes + 255) / 256)), block(256);
+    if (g.ncams == 1)
+        hipLaunchKernelGGL((gather_kernel<1>), grid, block, 0, st, a, g.skipped, (unsigned)g.nnodes,
+                           g.nframes, g.rows, g.sum, g.sumsq);
+    else
+        hipLaunchKernelGGL((gather_kernel<0>), grid, block, 0, st, a, g.skipped, (unsigned)g.nnodes,
+                           g.nframes, g.rows, g.sum, g.sumsq);
+    UPSP_HIP_CHECK(hipGetLastError());
+    return UPSP_OK;
+}
+
+int launch_finals(const double *sum, const double *sumsq, size_t nnodes, uint64_t nframes,
+                  float *avg, float *rms, hipStream_t st)
+{
+    if (nnodes == 0) return UPSP_OK;
+    hipLaunchKernelGGL(finals_kernel, dim3((unsigned)((nnodes + 255) / 256)), dim3(256), 0, st, sum,
+                       sumsq, (unsigned)nnodes, (double)nframes, avg, rms);
+    UPSP_HIP_CHECK(hipGetLastError());
+    return UPSP_OK;
+}
+
+}  // namespace upsp
+
+using namespace upsp;
+
+extern "C" {
+
+int upsp_fix_hot_pixels(uint16_t *d_frames, int nframes, int rows, int cols, int thresh,
+                        int min_change, int max_hot, int32_t *d_status, void *stream)
+{
+    if (nframes == 0) return UPSP_OK;
+    if (!d_frames || nframes < 0 || rows <= 0 || cols <= 0)
+        return fail(UPSP_ERR_INVALID, "bad frame buffer / size");
+    hipStream_t st = (hipStream_t)stream;
+    unsigned *cnt = nullptr, *pos = nullptr;
+    UPSP_HIP_CHECK(hipMalloc(&cnt, sizeof(unsigned) * (size_t)nframes));
+    hipError_t e = hipMalloc(&pos, sizeof(unsigned) * (size_t)nframes * kHotCap);
+    int rc = UPSP_OK;
+    if (e != hipSuccess) {
+        rc = fail(UPSP_ERR_HIP, hipGetErrorString(e));
+    } else {
+        rc = launch_hot_fix(d_frames, nframes, rows, cols, thresh, min_change, max_hot, cnt, pos,
+                            d_status, st);
+        if (rc == UPSP_OK && hipStreamSynchronize(st) != hipSuccess)
+            rc = fail(UPSP_ERR_HIP, "hot-pixel kernels failed");
+    }
+    (void)hipFree(cnt);
+    if (pos) (void)hipFree(pos);
+    return rc;
+}
+
+static int project_one(const void *img, int is_f32, const int32_t *d_pix, const float *d_weight,
+                       size_t nnodes, float *d_out, void *stream)
+{
+    if (nnodes == 0) return UPSP_OK;
+    if (!img || !d_pix || !d_out) return fail(UPSP_ERR_INVALID, "null device buffer");
+    hipLaunchKernelGGL(project_one_kernel, dim3((unsigned)((nnodes + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, img, is_f32, d_pix, d_weight, (unsigned)nnodes, d_out);
+    UPSP_HIP_CHECK(hipGetLastError());
+    return UPSP_OK;
+}
+
+int upsp_project_frame_u16(const uint16_t *d_img, const int32_t *d_pix, const float *d_weight,
+                           size_t nnodes, float *d_out, void *stream)
+{
+    return project_one(d_img, 0, d_pix, d_weight, nnodes, d_out, stream);
+}
+
+int upsp_project_frame_f32(const float *d_img, const int32_t *d_pix, const float *d_weight,
+                           size_t nnodes, float *d_out, void *stream)
+{
+    return project_one(d_img, 1, d_pix, d_weight, nnodes, d_out, stream);
+}
+
+int upsp_transpose_f32(const float *d_src, int64_t x_extent, int64_t y_extent, float *d_dst,
+                       int64_t ld_dst, void *stream)
+{
+    if (x_extent == 0 || y_extent == 0) return UPSP_OK;
+    if (!d_src || !d_dst || x_extent < 0 || y_extent < 0 || ld_dst < y_extent)
+        return fail(UPSP_ERR_INVALID, "bad transpose arguments");
+    const long long gx = (x_extent + 63) / 64, gy = (y_extent + 63) / 64;
+    if (gy > 65535) return fail(UPSP_ERR_INVALID, "y_extent too large for one launch");
+    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0,
+                       (hipStream_t)stream, d_src, (long long)x_extent, (long long)y_extent, d_dst,
+                       (long long)ld_dst);
+    UPSP_HIP_CHECK(hipGetLastError());
+    return UPSP_OK;
+}
+
+/* apportion, cpp/exec/psp_process.cpp:611-624 */
+int upsp_apportion(int value, int nbins, int *h_start, int *h_extent)
+{
+    if (value < 0 || nbins <= 0 || !h_start || !h_extent)
+        return fail(UPSP_ERR_INVALID, "bad apportion arguments");
+    const unsigned long block = (unsigned long)(value / nbins);
+    const unsigned long rem = (unsigned long)value - block * (unsigned long)nbins;
+    unsigned long next = 0;
+    for (unsigned long b = 0; b < (unsigned long)nbins; ++b) {
+        h_start[b] = (int)next;
+        h_extent[b] = (int)(block + (b < rem ? 1 : 0));
+        next += (unsigned long)h_extent[b];
+    }
+    return UPSP_OK;
+}
+
+int upsp_projection_weights(int ncams, size_t nnodes, const int32_t *d_pix, float *d_weight,
+                            const float *d_nodes, const float *d_normals,
+                            const double *h_centers, int mode, void *stream)
+{
+    if (ncams <= 0 || ncams > kMaxCams) return fail(UPSP_ERR_INVALID, "ncams out of range");
+    if (nnodes == 0) return UPSP_OK;
+    if (!d_pix || !d_weight || !d_nodes || !d_normals || !h_centers)
+        return fail(UPSP_ERR_INVALID, "null argument");
+    if (mode != 0 && mode != 1) return fail(UPSP_ERR_INVALID, "mode must be 0 or 1");
+    Centers ctr;
+    std::memset(&ctr, 0, sizeof(ctr));
+    for (int c = 0; c < ncams; ++c)
+        for (int a = 0; a < 3; ++a) ctr.c[c][a] = (float)h_centers[3 * c + a];
+    hipLaunchKernelGGL(weights_kernel, dim3((unsigned)((nnodes + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, ncams, (unsigned)nnodes, d_pix, d_weight, d_nodes,
+                       d_normals, ctr, mode);
+    UPSP_HIP_CHECK(hipGetLastError());
+    return UPSP_OK;
+}
+
+int upsp_projection_skipped(int ncams, size_t nnodes, const int32_t *d_pix, uint8_t *d_skipped,
+                            uint64_t *h_count, void *stream)
+{
+    if (ncams <= 0) return fail(UPSP_ERR_INVALID, "ncams out of range");
+    if (h_count) *h_count = 0;
+    if (nnodes == 0) return UPSP_OK;
+    if (!d_pix || !d_skipped) return fail(UPSP_ERR_INVALID, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long *cnt = nullptr;
+    if (h_count) {
+        UPSP_HIP_CHECK(hipMalloc(&cnt, sizeof(*cnt)));
+        UPSP_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(*cnt), st));
+    }
+    hipLaunchKernelGGL(skipped_kernel, dim3((unsigned)((nnodes + 255) / 256)), dim3(256), 0, st,
+                       ncams, (unsigned)nnodes, d_pix, d_skipped, cnt);
+    hipError_t e = hipGetLastError();
+    if (h_count && e == hipSuccess) {
+        unsigned long long h = 0;
+        e = hipMemcpyAsync(&h, cnt, sizeof(h), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        *h_count = h;
+    }
+    if (cnt) (void)hipFree(cnt);
+    if (e != hipSuccess) return fail(UPSP_ERR_HIP, hipGetErrorString(e));
+    return UPSP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,59 @@
+// Shared declarations of the per-frame pipeline (frames.hip, registration.hip,
+// imageops.hip, pipeline.hip).
+#ifndef UPSP_PIPELINE_H
+#define UPSP_PIPELINE_H
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+namespace upsp {
+
+constexpr int kMaxCams = 16;
+
+struct PipelineGather {
+    int ncams = 0;
+    size_t npix = 0;      // pixels per frame
+    size_t nnodes = 0;
+    int nframes = 0;
+    const void *img[kMaxCams] = {nullptr};  // first frame of the batch (u16 or f32)
+    int is_f32[kMaxCams] = {0};
+    const int32_t *pix[kMaxCams] = {nullptr};
+    const float *weight[kMaxCams] = {nullptr};
+    const uint8_t *skipped = nullptr;
+    float *rows = nullptr;  // [nframes][nnodes], may be null
+    double *sum = nullptr, *sumsq = nullptr;
+};
+
+int launch_hot_fix(uint16_t *d_frames, int nframes, int rows, int cols, int thresh,
+                   int min_change, int max_hot, unsigned *d_count, unsigned *d_pos,
+                   int32_t *d_status, hipStream_t st);
+int launch_gather(const PipelineGather &g, hipStream_t st);
+int launch_finals(const double *sum, const double *sumsq, size_t nnodes, uint64_t nframes,
+                  float *avg, float *rms, hipStream_t st);
+
+// ---- image stages (imageops.hip / registration.hip) --------------------------
+struct PatchTables;   // device copies of PatchClusters' boundary / interior lists
+struct FrameScratch;  // per-sub-batch working images (warped u16, f32)
+
+int patch_tables_create(int rows, int cols, int nclusters, const int32_t *h_b_off,
+                        const int32_t *h_bx, const int32_t *h_by, const int32_t *h_i_off,
+                        const int32_t *h_ix, const int32_t *h_iy, PatchTables **out);
+void patch_tables_free(PatchTables *t);
+int frame_scratch_ensure(FrameScratch **s, int ncams, int batch, int rows, int cols,
+                         bool need_warp, bool need_f32);
+void frame_scratch_free(FrameScratch *s);
+
+}  // namespace upsp
+
+struct upsp_pipeline_opts;
+namespace upsp {
+// register -> patch -> filter for `nb` frames of camera `cam` (psp_process.cpp:1776-1807).
+// *img_out / *is_f32_out: image the gather reads.  d_warps: [nb][ncams][6] or null.
+int run_frame_stages(FrameScratch *s, int cam, const uint16_t *d_frames, int nb,
+                     int64_t first_frame, int rows, int cols, const upsp_pipeline_opts &opts,
+                     const float *d_ref, const PatchTables *patches, float *d_warps, int ncams,
+                     const void **img_out, int *is_f32_out, hipStream_t st);
+}  // namespace upsp
+#endif

@@ -1,0 +1,309 @@
+// Host orchestration of the per-frame pipeline: the body of the psp_process
+// phase-1 frame loop (cpp/exec/psp_process.cpp:1743-1851) as a sequence of batched
+// kernel launches on one HIP stream.
+//
+// Frames are processed in sub-batches sized so that a sub-batch of u16 frames
+// (and its f32 working copies when patching / filtering is on) stays inside the
+// 256 MiB Infinity Cache between the streaming hot-pixel scan and the gather:
+// HBM then sees each frame byte once.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "pipeline.h"
+#include "upsp_internal.h"
+
+using namespace upsp;
+
+struct upsp_pipeline {
+    int ncams = 0, width = 0, height = 0;
+    size_t nnodes = 0;
+    upsp_pipeline_opts opts;
+    int32_t *d_pix[kMaxCams] = {nullptr};
+    float *d_weight[kMaxCams] = {nullptr};
+    bool has_proj[kMaxCams] = {false};
+    uint8_t *d_skipped = nullptr;
+    bool skipped_user = false, skipped_valid = false;
+    double *d_sum = nullptr, *d_sumsq = nullptr;
+    // hot-pixel scratch (per frame of a sub-batch)
+    unsigned *d_hot_count = nullptr, *d_hot_pos = nullptr;
+    int hot_capacity = 0;
+    // registration / patch / filter state
+    float *d_ref[kMaxCams] = {nullptr};
+    upsp::PatchTables *patches[kMaxCams] = {nullptr};
+    upsp::FrameScratch *scratch = nullptr;
+    int batch = 32;
+};
+
+namespace {
+
+void free_dev(void *p)
+{
+    if (p) (void)hipFree(p);
+}
+
+int ensure_hot(upsp_pipeline *p, int nframes)
+{
+    if (nframes <= p->hot_capacity) return UPSP_OK;
+    free_dev(p->d_hot_count);
+    free_dev(p->d_hot_pos);
+    p->d_hot_count = p->d_hot_pos = nullptr;
+    p->hot_capacity = 0;
+    UPSP_HIP_CHECK(hipMalloc(&p->d_hot_count, sizeof(unsigned) * (size_t)nframes));
+    UPSP_HIP_CHECK(hipMalloc(&p->d_hot_pos, sizeof(unsigned) * (size_t)nframes * 64));
+    p->hot_capacity = nframes;
+    return UPSP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void upsp_pipeline_default_opts(upsp_pipeline_opts *o)
+{
+    if (!o) return;
+    std::memset(o, 0, sizeof(*o));
+    o->hot_enable = 1;
+    o->hot_thresh = 4064;     // cpp/include/utils/cv_extras.h:154-155
+    o->hot_min_change = 512;
+    o->hot_max = 5;
+    o->registration = 0;      // RegistrationType::None (cpp/lib/upsp_inputs.cpp:29-33)
+    o->ecc_max_iters = 50;
+    o->ecc_eps = 1e-3;
+    o->interp = 1;
+    o->filter = 0;
+    o->filter_size = 1;
+    o->patch = 0;
+}
+
+int upsp_pipeline_create(int ncams, int width, int height, size_t nnodes,
+                         const upsp_pipeline_opts *opts, upsp_pipeline **out)
+{
+    if (!out) return fail(UPSP_ERR_INVALID, "out is null");
+    *out = nullptr;
+    if (ncams <= 0 || ncams > kMaxCams) return fail(UPSP_ERR_INVALID, "ncams out of range");
+    if (width <= 0 || height <= 0) return fail(UPSP_ERR_INVALID, "bad image size");
+    if (nnodes == 0 || nnodes > 0xF0000000ull) return fail(UPSP_ERR_INVALID, "bad node count");
+    upsp_pipeline *p = new upsp_pipeline();
+    p->ncams = ncams;
+    p->width = width;
+    p->height = height;
+    p->nnodes = nnodes;
+    if (opts)
+        p->opts = *opts;
+    else
+        upsp_pipeline_default_opts(&p->opts);
+    if (p->opts.filter != 0 && (p->opts.filter_size < 1 || (p->opts.filter_size % 2) == 0)) {
+        delete p;
+        return fail(UPSP_ERR_INVALID, "filter_size must be odd");  // psp_process.cpp:1296
+    }
+    hipError_t e = hipMalloc(&p->d_sum, sizeof(double) * nnodes);
+    if (e == hipSuccess) e = hipMalloc(&p->d_sumsq, sizeof(double) * nnodes);
+    if (e == hipSuccess) e = hipMalloc(&p->d_skipped, nnodes);
+    if (e == hipSuccess) e = hipMemset(p->d_sum, 0, sizeof(double) * nnodes);
+    if (e == hipSuccess) e = hipMemset(p->d_sumsq, 0, sizeof(double) * nnodes);
+    if (e == hipSuccess) e = hipMemset(p->d_skipped, 0, nnodes);
+    if (e != hipSuccess) {
+        upsp_pipeline_destroy(p);
+        return fail(UPSP_ERR_HIP, std::string("pipeline alloc: ") + hipGetErrorString(e));
+    }
+    // sub-batch: keep u16 frames (+ f32 copies) of all cameras within ~128 MiB
+    const size_t per_frame = (size_t)width * height * (size_t)ncams *
+                             (2 + ((p->opts.patch || p->opts.filter) ? 4 : 0) +
+                              (p->opts.registration ? 2 : 0));
+    size_t b = (128u << 20) / std::max<size_t>(per_frame, 1);
+    p->batch = (int)std::min<size_t>(std::max<size_t>(b, 1), 256);
+    *out = p;
+    return UPSP_OK;
+}
+
+void upsp_pipeline_destroy(upsp_pipeline *p)
+{
+    if (!p) return;
+    for (int c = 0; c < kMaxCams; ++c) {
+        free_dev(p->d_pix[c]);
+        free_dev(p->d_weight[c]);
+        free_dev(p->d_ref[c]);
+        upsp::patch_tables_free(p->patches[c]);
+    }
+    upsp::frame_scratch_free(p->scratch);
+    free_dev(p->d_skipped);
+    free_dev(p->d_sum);
+    free_dev(p->d_sumsq);
+    free_dev(p->d_hot_count);
+    free_dev(p->d_hot_pos);
+    delete p;
+}
+
+int upsp_pipeline_set_projection(upsp_pipeline *p, int cam, const int32_t *d_pix,
+                                 const float *d_weight)
+{
+    if (!p || cam < 0 || cam >= p->ncams || !d_pix) return fail(UPSP_ERR_INVALID, "bad argument");
+    if (!p->d_pix[cam]) UPSP_HIP_CHECK(hipMalloc(&p->d_pix[cam], sizeof(int32_t) * p->nnodes));
+    UPSP_HIP_CHECK(hipMemcpy(p->d_pix[cam], d_pix, sizeof(int32_t) * p->nnodes,
+                             hipMemcpyDeviceToDevice));
+    if (d_weight) {
+        if (!p->d_weight[cam]) UPSP_HIP_CHECK(hipMalloc(&p->d_weight[cam], sizeof(float) * p->nnodes));
+        UPSP_HIP_CHECK(hipMemcpy(p->d_weight[cam], d_weight, sizeof(float) * p->nnodes,
+                                 hipMemcpyDeviceToDevice));
+    } else {
+        free_dev(p->d_weight[cam]);
+        p->d_weight[cam] = nullptr;
+    }
+    p->has_proj[cam] = true;
+    if (!p->skipped_user) p->skipped_valid = false;
+    return UPSP_OK;
+}
+
+int upsp_pipeline_set_skipped(upsp_pipeline *p, const uint8_t *d_skipped)
+{
+    if (!p) return fail(UPSP_ERR_INVALID, "null pipeline");
+    if (d_skipped) {
+        UPSP_HIP_CHECK(hipMemcpy(p->d_skipped, d_skipped, p->nnodes, hipMemcpyDeviceToDevice));
+        p->skipped_user = true;
+        p->skipped_valid = true;
+    } else {
+        p->skipped_user = false;
+        p->skipped_valid = false;
+    }
+    return UPSP_OK;
+}
+
+int upsp_pipeline_set_reference(upsp_pipeline *p, int cam, const float *d_ref32f)
+{
+    if (!p || cam < 0 || cam >= p->ncams || !d_ref32f) return fail(UPSP_ERR_INVALID, "bad argument");
+    const size_t bytes = sizeof(float) * (size_t)p->width * p->height;
+    if (!p->d_ref[cam]) UPSP_HIP_CHECK(hipMalloc(&p->d_ref[cam], bytes));
+    UPSP_HIP_CHECK(hipMemcpy(p->d_ref[cam], d_ref32f, bytes, hipMemcpyDeviceToDevice));
+    return UPSP_OK;
+}
+
+int upsp_pipeline_set_patches(upsp_pipeline *p, int cam, int nclusters, const int32_t *h_b_off,
+                              const int32_t *h_bx, const int32_t *h_by, const int32_t *h_i_off,
+                              const int32_t *h_ix, const int32_t *h_iy)
+{
+    if (!p || cam < 0 || cam >= p->ncams) return fail(UPSP_ERR_INVALID, "bad argument");
+    upsp::patch_tables_free(p->patches[cam]);
+    p->patches[cam] = nullptr;
+    if (nclusters == 0) return UPSP_OK;
+    return upsp::patch_tables_create(p->height, p->width, nclusters, h_b_off, h_bx, h_by, h_i_off,
+                                     h_ix, h_iy, &p->patches[cam]);
+}
+
+int upsp_pipeline_accumulators(upsp_pipeline *p, double **d_sum, double **d_sumsq)
+{
+    if (!p) return fail(UPSP_ERR_INVALID, "null pipeline");
+    if (d_sum) *d_sum = p->d_sum;
+    if (d_sumsq) *d_sumsq = p->d_sumsq;
+    return UPSP_OK;
+}
+
+int upsp_pipeline_reset(upsp_pipeline *p)
+{
+    if (!p) return fail(UPSP_ERR_INVALID, "null pipeline");
+    UPSP_HIP_CHECK(hipMemset(p->d_sum, 0, sizeof(double) * p->nnodes));
+    UPSP_HIP_CHECK(hipMemset(p->d_sumsq, 0, sizeof(double) * p->nnodes));
+    return UPSP_OK;
+}
+
+int upsp_pipeline_finalize(upsp_pipeline *p, uint64_t nframes_total, float *d_avg, float *d_rms,
+                           void *stream)
+{
+    if (!p || nframes_total == 0) return fail(UPSP_ERR_INVALID, "bad argument");
+    return launch_finals(p->d_sum, p->d_sumsq, p->nnodes, nframes_total, d_avg, d_rms,
+                         (hipStream_t)stream);
+}
+
+int upsp_pipeline_process(upsp_pipeline *p, const uint16_t *const *d_frames, int nframes,
+                          int64_t first_frame, float *d_rows, float *d_rows_t, int64_t ld_t,
+                          int64_t col0, float *d_warps, void *stream)
+{
+    if (!p || !d_frames || nframes < 0) return fail(UPSP_ERR_INVALID, "bad argument");
+    if (nframes == 0) return UPSP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    for (int c = 0; c < p->ncams; ++c) {
+        if (!d_frames[c]) return fail(UPSP_ERR_INVALID, "null frame pointer");
+        if (!p->has_proj[c]) return fail(UPSP_ERR_INVALID, "projection not set for a camera");
+        if (p->opts.registration && !p->d_ref[c])
+            return fail(UPSP_ERR_INVALID, "registration enabled but no reference frame set");
+    }
+    if (d_rows_t && ld_t < col0 + nframes) return fail(UPSP_ERR_INVALID, "ld_t too small");
+    if (!p->skipped_valid) {
+        // identify_skipped_nodes over all cameras (projection.ipp:857-880)
+        std::vector<int32_t *> tmp(p->ncams);
+        int32_t *d_all = nullptr;
+        UPSP_HIP_CHECK(hipMalloc(&d_all, sizeof(int32_t) * p->nnodes * (size_t)p->ncams));
+        for (int c = 0; c < p->ncams; ++c)
+            (void)hipMemcpyAsync(d_all + (size_t)c * p->nnodes, p->d_pix[c],
+                                 sizeof(int32_t) * p->nnodes, hipMemcpyDeviceToDevice, st);
+        int rc = upsp_projection_skipped(p->ncams, p->nnodes, d_all, p->d_skipped, nullptr, st);
+        (void)hipStreamSynchronize(st);
+        (void)hipFree(d_all);
+        if (rc != UPSP_OK) return rc;
+        p->skipped_valid = true;
+    }
+    const bool need_f32 = p->opts.patch || p->opts.filter;
+    const bool need_stage = need_f32 || p->opts.registration;
+    const size_t npix = (size_t)p->width * p->height;
+    const int B = p->batch;
+    if (need_stage) {
+        int rc = upsp::frame_scratch_ensure(&p->scratch, p->ncams, B, p->height, p->width,
+                                            p->opts.registration != 0, need_f32);
+        if (rc != UPSP_OK) return rc;
+    }
+    // scratch rows for the transposed output when the caller does not want rows
+    float *rows_tmp = nullptr;
+    if (d_rows_t && !d_rows) {
+        UPSP_HIP_CHECK(hipMalloc(&rows_tmp, sizeof(float) * p->nnodes * (size_t)std::min(B, nframes)));
+    }
+    int rc = UPSP_OK;
+    for (int f0 = 0; f0 < nframes && rc == UPSP_OK; f0 += B) {
+        const int nb = std::min(B, nframes - f0);
+        PipelineGather g;
+        g.ncams = p->ncams;
+        g.npix = npix;
+        g.nnodes = p->nnodes;
+        g.nframes = nb;
+        g.skipped = p->d_skipped;
+        g.sum = p->d_sum;
+        g.sumsq = p->d_sumsq;
+        g.rows = d_rows ? d_rows + (size_t)f0 * p->nnodes : rows_tmp;
+        for (int c = 0; c < p->ncams && rc == UPSP_OK; ++c) {
+            uint16_t *frames = const_cast<uint16_t *>(d_frames[c]) + (size_t)f0 * npix;
+            if (p->opts.hot_enable) {  // psp_process.cpp:1772
+                rc = ensure_hot(p, nb);
+                if (rc == UPSP_OK)
+                    rc = launch_hot_fix(frames, nb, p->height, p->width, p->opts.hot_thresh,
+                                        p->opts.hot_min_change, p->opts.hot_max, p->d_hot_count,
+                                        p->d_hot_pos, nullptr, st);
+                if (rc != UPSP_OK) break;
+            }
+            const void *img = frames;
+            int is_f32 = 0;
+            if (need_stage) {
+                rc = upsp::run_frame_stages(p->scratch, c, frames, nb, first_frame + f0,
+                                            p->height, p->width, p->opts, p->d_ref[c],
+                                            p->patches[c],
+                                            d_warps ? d_warps + ((size_t)f0 * p->ncams) * 6 : nullptr,
+                                            p->ncams, &img, &is_f32, st);
+                if (rc != UPSP_OK) break;
+            }
+            g.img[c] = img;
+            g.is_f32[c] = is_f32;
+            g.pix[c] = p->d_pix[c];
+            g.weight[c] = p->d_weight[c];
+        }
+        if (rc == UPSP_OK) rc = launch_gather(g, st);
+        if (rc == UPSP_OK && d_rows_t)
+            rc = upsp_transpose_f32(g.rows, (int64_t)p->nnodes, nb, d_rows_t + col0 + f0, ld_t, st);
+    }
+    if (rows_tmp) {
+        (void)hipStreamSynchronize(st);
+        (void)hipFree(rows_tmp);
+    }
+    return rc;
+}
+
+}  // extern "C"

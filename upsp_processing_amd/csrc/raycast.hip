@@ -1,0 +1,1038 @@
+// MI355X (gfx950) BVH ray caster: closest-hit / any-hit batch queries and the
+// projection-build kernel (create_projection_mat of psp_process).
+//
+// Execution model
+//   * one ray per lane, 64-lane wavefronts, 256-thread workgroups;
+//   * persistent waves: a wave pulls blocks of work items from a global queue and
+//     re-fills lanes whose ray has finished as soon as fewer than kRefill lanes
+//     are still traversing (ballot + prefix popcount assigns queue slots to idle
+//     lanes), so divergence in ray length does not leave the SIMD half empty;
+//   * the traversal stack lives in LDS, laid out [entry][thread] so that every
+//     push/pop of a wave is one conflict-free ds_read/ds_write_b32;
+//   * interior nodes are 64-byte records with BOTH child boxes (4 x dwordx4 per
+//     lane), triangles are 48-byte records (3 x dwordx4) in leaf order.
+//
+// Numerical contract (see DESIGN.md "parity"): compiled with -ffp-contract=off.
+//   * ray set-up, the watertight triangle test with its double fallback and the
+//     hit record follow cpp/raycast/pspRT.cpp:45-69 and :109-193 operation by
+//     operation (IEEE + - * / only);
+//   * a box is entered iff Imath::intersects(Box3f, Line3f(o,o+d)) accepts it
+//     (call site pspRT.cpp:382-385).  The decision is made with reciprocal
+//     multiplies and an error bound; only when the margin is inside the bound is
+//     the exact division form evaluated, so the accepted set is identical;
+//   * on top of that a subtree is skipped when its near plane along the ray's
+//     major axis lies beyond the current closest hit.  Every t the triangle test
+//     can produce for a triangle inside the box is >= that plane distance (up to
+//     7 ulp, a 4e-6 guard is used), so skipping never changes t, primID or the
+//     tie-break (strict `<`, near-child-first order, pspRT.cpp:395,410-419).
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+
+#include "upsp_internal.h"
+
+namespace upsp {
+
+thread_local std::string g_error;
+void set_error(const std::string &msg) { g_error = msg; }
+int fail(int status, const std::string &msg)
+{
+    g_error = msg;
+    return status;
+}
+
+namespace {
+
+constexpr int kBlock = 256;       // threads per workgroup (4 waves)
+constexpr int kChunk = 256;       // work items taken from the global queue at once
+constexpr int kRefill = 40;       // leave the traversal loop to re-fill below this many live lanes
+constexpr int kDone = INT32_MIN;  // "no current node"
+
+struct Ray {
+    float ox, oy, oz;     // rt::Ray::o
+    float dx, dy, dz;     // rt::Ray::d
+    float lx, ly, lz;     // Imath::Line3f(o, o+d).dir
+    float ilx, ily, ilz;  // ~1/l (filter only)
+    float Sx, Sy, Sz;     // watertight shear (pspRT.cpp:63-65)
+    int kx, ky, kz;
+    unsigned neg;         // bit a = ray.i[a] < 0 (dirIsNeg, pspRT.cpp:369)
+    bool exact_only;      // some |l| is tiny: skip the reciprocal filter
+};
+
+__device__ __forceinline__ float pick(float x, float y, float z, int k)
+{
+    return k == 0 ? x : (k == 1 ? y : z);
+}
+
+// Imath::Vec3<float>::length(): sqrt(dot), scaled form below 2*FLT_MIN
+__device__ __forceinline__ float imath_length(float x, float y, float z)
+{
+    float l2 = x * x + y * y + z * z;
+    if (l2 < 2.0f * FLT_MIN) {
+        float ax = fabsf(x), ay = fabsf(y), az = fabsf(z);
+        float m = ax;
+        if (m < ay) m = ay;
+        if (m < az) m = az;
+        if (m == 0.0f) return 0.0f;
+        ax /= m;
+        ay /= m;
+        az /= m;
+        return m * sqrtf(ax * ax + ay * ay + az * az);
+    }
+    return sqrtf(l2);
+}
+
+// rt::Ray::Ray(o, d), pspRT.cpp:45-69, plus the per-ray constants of the box test.
+__device__ __forceinline__ void ray_setup(Ray &r, float ox, float oy, float oz, float dx,
+                                          float dy, float dz)
+{
+    r.ox = ox; r.oy = oy; r.oz = oz;
+    r.dx = dx; r.dy = dy; r.dz = dz;
+    float ax = fabsf(dx), ay = fabsf(dy), az = fabsf(dz);
+    int kz = (ax > ay) ? (ax > az ? 0 : 2) : (ay > az ? 1 : 2);  // MAX_DIM, pspRT.cpp:41
+    int kx = kz + 1; if (kx == 3) kx = 0;
+    int ky = kx + 1; if (ky == 3) ky = 0;
+    float dkz = pick(dx, dy, dz, kz);
+    if (dkz < 0.0f) { int t = kx; kx = ky; ky = t; }
+    r.kx = kx; r.ky = ky; r.kz = kz;
+    r.Sx = pick(dx, dy, dz, kx) / dkz;
+    r.Sy = pick(dx, dy, dz, ky) / dkz;
+    r.Sz = 1.0f / dkz;
+    r.neg = ((1.0f / dx) < 0.0f ? 1u : 0u) | ((1.0f / dy) < 0.0f ? 2u : 0u) |
+            ((1.0f / dz) < 0.0f ? 4u : 0u);
+    // Imath::Line3f(o, o + d): dir = ((o+d) - o).normalize()
+    float lx = (ox + dx) - ox, ly = (oy + dy) - oy, lz = (oz + dz) - oz;
+    float len = imath_length(lx, ly, lz);
+    if (len != 0.0f) { lx /= len; ly /= len; lz /= len; }
+    r.lx = lx; r.ly = ly; r.lz = lz;
+    r.ilx = __builtin_amdgcn_rcpf(lx);
+    r.ily = __builtin_amdgcn_rcpf(ly);
+    r.ilz = __builtin_amdgcn_rcpf(lz);
+    const float tiny = 1e-18f;
+    r.exact_only = (lx != 0.0f && fabsf(lx) < tiny) || (ly != 0.0f && fabsf(ly) < tiny) ||
+                   (lz != 0.0f && fabsf(lz) < tiny) || !(len == len) || len == 0.0f;
+}
+
+// One axis of Imath::intersects(Box3f, Line3f, V3f&) (ImathBoxAlgo.h).  EXACT uses
+// the library's division, otherwise a reciprocal multiply (error <= 2 ulp).
+template <bool EXACT>
+__device__ __forceinline__ bool box_axis(float lo, float hi, float o, float l, float il,
+                                         float &tFront, float &tBack)
+{
+    const float TMAX = FLT_MAX;
+    if (l == 0.0f) return !(o < lo || o > hi);
+    const bool neg = l < 0.0f;
+    const float far = neg ? lo : hi;
+    const float near = neg ? hi : lo;
+    if (neg ? (o < far) : (o > far)) return false;
+    const float lim = TMAX * l;
+    const float dB = far - o;
+    const bool okB = neg ? (l < -1.0f || dB > lim) : (l > 1.0f || dB < lim);
+    const float tB = EXACT ? dB / l : dB * il;
+    if (okB && tBack > tB) tBack = tB;
+    const bool front = neg ? (o >= near) : (o <= near);
+    const float dF = near - o;
+    const bool okF = neg ? (l < -1.0f || dF > lim) : (l > 1.0f || dF < lim);
+    const float tF = okF ? (EXACT ? dF / l : dF * il) : TMAX;
+    if (front && tFront < tF) tFront = tF;
+    return true;
+}
+
+template <bool EXACT>
+__device__ __forceinline__ int box_eval(const Ray &r, float lox, float loy, float loz, float hix,
+                                        float hiy, float hiz)
+{
+    // returns 1 accept, 0 reject, -1 undecided (filter only)
+    float tFront = -1.0f, tBack = FLT_MAX;
+    if (!box_axis<EXACT>(lox, hix, r.ox, r.lx, r.ilx, tFront, tBack)) return 0;
+    if (!box_axis<EXACT>(loy, hiy, r.oy, r.ly, r.ily, tFront, tBack)) return 0;
+    if (!box_axis<EXACT>(loz, hiz, r.oz, r.lz, r.ilz, tFront, tBack)) return 0;
+    if (EXACT) return tFront <= tBack ? 1 : 0;
+    const float e = 6e-7f;  // > 2 * (rcp 1 ulp + mul 0.5 ulp)
+    if (tFront + fabsf(tFront) * e <= tBack - tBack * e) return 1;
+    if (tFront - fabsf(tFront) * e > tBack + tBack * e) return 0;
+    return -1;
+}
+
+// Imath::intersects(box, Line3f(o,o+d), ip): same accept/reject as the library.
+__device__ __forceinline__ bool box_hit(const Ray &r, float lox, float loy, float loz, float hix,
+                                        float hiy, float hiz)
+{
+    if (hix < lox || hiy < loy || hiz < loz) return false;  // isEmpty()
+    if (r.ox >= lox && r.ox <= hix && r.oy >= loy && r.oy <= hiy && r.oz >= loz && r.oz <= hiz)
+        return true;  // origin inside (inclusive)
+    int v = r.exact_only ? -1 : box_eval<false>(r, lox, loy, loz, hix, hiy, hiz);
+    if (v < 0) v = box_eval<true>(r, lox, loy, loz, hix, hiy, hiz);
+    return v != 0;
+}
+
+// Distance (ray parameter) of the box's near plane along the ray's major axis.
+__device__ __forceinline__ float near_depth(const Ray &r, float lox, float loy, float loz,
+                                            float hix, float hiy, float hiz)
+{
+    const float lo = pick(lox, loy, loz, r.kz), hi = pick(hix, hiy, hiz, r.kz);
+    const float o = pick(r.ox, r.oy, r.oz, r.kz);
+    const float pl = r.Sz < 0.0f ? hi : lo;
+    return (pl - o) * r.Sz;
+}
+
+struct TriHit {
+    float t, u, v, w;
+};
+
+// rt::Triangle::intersect, pspRT.cpp:109-173 (hit distance and barycentrics).
+__device__ __forceinline__ bool tri_test(const Ray &r, float ax, float ay, float az, float bx,
+                                         float by, float bz, float cx, float cy, float cz,
+                                         TriHit &h)
+{
+    const float Ax_ = ax - r.ox, Ay_ = ay - r.oy, Az_ = az - r.oz;
+    const float Bx_ = bx - r.ox, By_ = by - r.oy, Bz_ = bz - r.oz;
+    const float Cx_ = cx - r.ox, Cy_ = cy - r.oy, Cz_ = cz - r.oz;
+    const float Akx = pick(Ax_, Ay_, Az_, r.kx), Aky = pick(Ax_, Ay_, Az_, r.ky),
+                Akz = pick(Ax_, Ay_, Az_, r.kz);
+    const float Bkx = pick(Bx_, By_, Bz_, r.kx), Bky = pick(Bx_, By_, Bz_, r.ky),
+                Bkz = pick(Bx_, By_, Bz_, r.kz);
+    const float Ckx = pick(Cx_, Cy_, Cz_, r.kx), Cky = pick(Cx_, Cy_, Cz_, r.ky),
+                Ckz = pick(Cx_, Cy_, Cz_, r.kz);
+    const float Ax = Akx - r.Sx * Akz;
+    const float Ay = Aky - r.Sy * Akz;
+    const float Bx = Bkx - r.Sx * Bkz;
+    const float By = Bky - r.Sy * Bkz;
+    const float Cx = Ckx - r.Sx * Ckz;
+    const float Cy = Cky - r.Sy * Ckz;
+
+    float U = Cx * By - Cy * Bx;
+    float V = Ax * Cy - Ay * Cx;
+    float W = Bx * Ay - By * Ax;
+    if (U == 0.0f || V == 0.0f || W == 0.0f) {
+        double CxBy = (double)Cx * (double)By;
+        double CyBx = (double)Cy * (double)Bx;
+        U = (float)(CxBy - CyBx);
+        double AxCy = (double)Ax * (double)Cy;
+        double AyCx = (double)Ay * (double)Cx;
+        V = (float)(AxCy - AyCx);
+        double BxAy = (double)Bx * (double)Ay;
+        double ByAx = (double)By * (double)Ax;
+        W = (float)(BxAy - ByAx);
+    }
+    if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return false;
+    const float det = U + V + W;
+    if (det == 0.0f) return false;
+    const float Az = r.Sz * Akz;
+    const float Bz = r.Sz * Bkz;
+    const float Cz = r.Sz * Ckz;
+    const float T = U * Az + V * Bz + W * Cz;
+    float xorf_T = fabsf(T);
+    if (signbit(T) != signbit(det)) xorf_T = -xorf_T;
+    const float abs_det = fabsf(det);
+    const float inf = __builtin_inff();
+    if (xorf_T < 0.0f * abs_det || inf * abs_det < xorf_T) return false;
+    const float rcpDet = 1.0f / det;
+    h.u = U * rcpDet;
+    h.v = V * rcpDet;
+    h.w = W * rcpDet;
+    h.t = T * rcpDet;
+    return true;
+}
+
+struct Scene {
+    const float4 *nodes;  // 4 per interior node
+    const float4 *tris;   // 3 per triangle slot
+    int root_ref;
+    float rlo[3], rhi[3];
+};
+
+struct Trav {
+    int cur;        // current ref, kDone when finished
+    int sp;         // stack entries
+    float best_t;   // closest t so far (FLT_MAX = none)
+    float limit;    // best_t with the pruning guard applied
+    int best_slot;  // triangle slot of the closest hit
+    bool any;       // rt::BVH::intersect return value
+    unsigned n_nodes, n_tris;
+};
+
+__device__ __forceinline__ void trav_begin(Trav &s, const Ray &r, const Scene &sc)
+{
+    s.sp = 0;
+    s.best_t = FLT_MAX;
+    s.limit = __builtin_inff();
+    s.best_slot = -1;
+    s.any = false;
+    s.cur = box_hit(r, sc.rlo[0], sc.rlo[1], sc.rlo[2], sc.rhi[0], sc.rhi[1], sc.rhi[2])
+                ? sc.root_ref
+                : kDone;
+}
+
+__device__ __forceinline__ void trav_pop(Trav &s, const int *stack)
+{
+    if (s.sp == 0) {
+        s.cur = kDone;
+    } else {
+        --s.sp;
+        s.cur = stack[s.sp * kBlock];
+    }
+}
+
+// Runs the lane's traversal until it finishes (returns) -- or, when `more` work is
+// queued, until fewer than kRefill lanes of the wave are still busy.
+template <bool ANYHIT, bool STATS>
+__device__ __forceinline__ void trav_run(Trav &s, const Ray &r, const Scene &sc, int *stack,
+                                         bool more)
+{
+    while (s.cur != kDone) {
+        // ---- interior nodes: descend until a leaf (or nothing) is current ----
+        while (s.cur >= 0) {
+            const float4 *np = sc.nodes + 4 * (size_t)s.cur;
+            const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+            if (STATS) ++s.n_nodes;
+            const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
+            const unsigned meta = __float_as_uint(q3.z);
+            bool hL = box_hit(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
+            bool hR = box_hit(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w);
+            if (!ANYHIT) {
+                hL = hL && !(near_depth(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y) > s.limit);
+                hR = hR && !(near_depth(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w) > s.limit);
+            }
+            // near child first: dirIsNeg[node->axis] (pspRT.cpp:410-419)
+            const bool swap = !(meta & kMetaOrdered) && ((r.neg >> (meta & 3u)) & 1u);
+            const int first = swap ? right : left, second = swap ? left : right;
+            const bool hF = swap ? hR : hL, hS = swap ? hL : hR;
+            if (hF) {
+                s.cur = first;
+                if (hS) {
+                    stack[s.sp * kBlock] = second;
+                    ++s.sp;
+                }
+            } else if (hS) {
+                s.cur = second;
+            } else {
+                trav_pop(s, stack);
+            }
+        }
+        // ---- leaf ----
+        if (s.cur != kDone) {
+            const unsigned code = (unsigned)(~s.cur);
+            const unsigned first = code >> kLeafBits, count = (code & (kMaxLeaf - 1)) + 1;
+            bool stop = false;
+            for (unsigned i = 0; i < count; ++i) {
+                const float4 *tp = sc.tris + 3 * (size_t)(first + i);
+                const float4 a = tp[0], b = tp[1], c = tp[2];
+                if (STATS) ++s.n_tris;
+                TriHit h;
+                if (tri_test(r, a.x, a.y, a.z, b.x, b.y, b.z, c.x, c.y, c.z, h)) {
+                    s.any = true;
+                    if (ANYHIT) {
+                        stop = true;
+                        break;
+                    }
+                    if (h.t < s.best_t) {  // strict <, pspRT.cpp:395
+                        s.best_t = h.t;
+                        s.best_slot = (int)(first + i);
+                        s.limit = h.t + fabsf(h.t) * 4e-6f;
+                    }
+                }
+            }
+            if (stop) {
+                s.cur = kDone;
+                s.sp = 0;
+            } else {
+                trav_pop(s, stack);
+            }
+        }
+        if (more && __popcll(__ballot(s.cur != kDone)) < kRefill) break;
+    }
+}
+
+__device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63u; }
+
+// Wave-level work distribution.  `cur`/`end` are wave-uniform.
+struct WaveQueue {
+    unsigned *head;
+    unsigned total;
+    unsigned cur, end;
+    bool exhausted;
+};
+
+__device__ __forceinline__ void queue_init(WaveQueue &q, unsigned *head, unsigned total)
+{
+    q.head = head;
+    q.total = total;
+    q.cur = q.end = 0;
+    q.exhausted = false;
+}
+
+// Gives idle lanes (want == true) a work item; returns true and the index for lanes
+// that received one.  Must be called by all lanes of the wave.
+__device__ __forceinline__ bool queue_take(WaveQueue &q, bool want, unsigned &item)
+{
+    const unsigned long long idle = __ballot(want);
+    if (idle == 0ull) return false;
+    if (q.cur >= q.end) {
+        if (q.exhausted) return false;
+        unsigned c = 0;
+        if (lane_id() == 0) c = atomicAdd(q.head, (unsigned)kChunk);
+        c = __builtin_amdgcn_readfirstlane(c);
+        if (c >= q.total) {
+            q.exhausted = true;
+            return false;
+        }
+        q.cur = c;
+        q.end = min(c + (unsigned)kChunk, q.total);
+    }
+    const unsigned n_idle = __popcll(idle);
+    const unsigned take = min(n_idle, q.end - q.cur);
+    const unsigned rank = __popcll(idle & ((1ull << lane_id()) - 1ull));
+    const bool got = want && rank < take;
+    item = q.cur + rank;
+    q.cur += take;
+    return got;
+}
+
+__device__ __forceinline__ bool queue_has_more(const WaveQueue &q)
+{
+    return q.cur < q.end || !q.exhausted;
+}
+
+// Hit record of the winning triangle: Hit.{u,v,w,t,pos,nrm,primID} (pspRT.cpp:173-190).
+__device__ __forceinline__ void write_hit(const Ray &r, const Scene &sc, const Trav &s,
+                                          size_t i, const upsp_hits &out)
+{
+    float t = FLT_MAX, u = 0.f, v = 0.f, w = 0.f;
+    float px = 0.f, py = 0.f, pz = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;
+    int prim = -1;
+    if (s.best_slot >= 0) {
+        const float4 *tp = sc.tris + 3 * (size_t)s.best_slot;
+        const float4 a = tp[0], b = tp[1], c = tp[2];
+        TriHit h;
+        tri_test(r, a.x, a.y, a.z, b.x, b.y, b.z, c.x, c.y, c.z, h);
+        t = h.t; u = h.u; v = h.v; w = h.w;
+        prim = __float_as_int(a.w);
+        px = r.ox + t * r.dx;
+        py = r.oy + t * r.dy;
+        pz = r.oz + t * r.dz;
+        const float e1x = b.x - a.x, e1y = b.y - a.y, e1z = b.z - a.z;
+        const float e2x = c.x - a.x, e2y = c.y - a.y, e2z = c.z - a.z;
+        const float EPS = 1e-3f;
+        if (!(imath_length(e1x, e1y, e1z) < EPS || imath_length(e2x, e2y, e2z) < EPS)) {
+            nx = e1y * e2z - e1z * e2y;
+            ny = e1z * e2x - e1x * e2z;
+            nz = e1x * e2y - e1y * e2x;
+            if (nx * r.dx + ny * r.dy + nz * r.dz > 0.0f) { nx = -nx; ny = -ny; nz = -nz; }
+        }
+    }
+    if (out.hit) out.hit[i] = s.any ? 1 : 0;
+    if (out.t) out.t[i] = t;
+    if (out.prim) out.prim[i] = prim;
+    if (out.uvw) { out.uvw[3 * i] = u; out.uvw[3 * i + 1] = v; out.uvw[3 * i + 2] = w; }
+    if (out.pos) { out.pos[3 * i] = px; out.pos[3 * i + 1] = py; out.pos[3 * i + 2] = pz; }
+    if (out.nrm) { out.nrm[3 * i] = nx; out.nrm[3 * i + 1] = ny; out.nrm[3 * i + 2] = nz; }
+}
+
+__device__ __forceinline__ void flush_stats(unsigned *work, unsigned n_nodes, unsigned n_tris,
+                                            unsigned n_rays)
+{
+    unsigned long long *st = reinterpret_cast<unsigned long long *>(work + 2);
+    // wave-level reduction first, one atomic per wave and counter
+    for (int off = 32; off > 0; off >>= 1) {
+        n_nodes += __shfl_down(n_nodes, off);
+        n_tris += __shfl_down(n_tris, off);
+        n_rays += __shfl_down(n_rays, off);
+    }
+    if (lane_id() == 0) {
+        atomicAdd(&st[0], (unsigned long long)n_nodes);
+        atomicAdd(&st[1], (unsigned long long)n_tris);
+        atomicAdd(&st[2], (unsigned long long)n_rays);
+    }
+}
+
+// ------------------------------------------------------------------------
+//  Batch query kernel: n independent rays (closest hit or occlusion).
+// ------------------------------------------------------------------------
+template <bool ANYHIT, bool STATS>
+__global__ void __launch_bounds__(kBlock)
+    cast_kernel(Scene sc, const float *__restrict__ org, int org_stride,
+                const float *__restrict__ dir, unsigned n, upsp_hits out, unsigned *work)
+{
+    extern __shared__ int lds_stack[];
+    int *stack = lds_stack + threadIdx.x;
+    WaveQueue q;
+    queue_init(q, work, n);
+    Ray r;
+    Trav s;
+    s.cur = kDone;
+    s.n_nodes = s.n_tris = 0;
+    unsigned item = 0, my_rays = 0;
+    bool busy = false;
+
+    for (;;) {
+        // ---- re-fill idle lanes ----
+        for (;;) {
+            unsigned it;
+            const bool got = queue_take(q, !busy, it);
+            if (got) {
+                item = it;
+                const float *o = org + (size_t)org_stride * it;
+                const float *d = dir + 3 * (size_t)it;
+                ray_setup(r, o[0], o[1], o[2], d[0], d[1], d[2]);
+                trav_begin(s, r, sc);
+                busy = true;
+                ++my_rays;
+            }
+            if (__ballot(!busy) == 0ull || !queue_has_more(q)) break;
+        }
+        if (__ballot(busy) == 0ull) break;
+        // ---- traverse ----
+        if (busy) {
+            trav_run<ANYHIT, STATS>(s, r, sc, stack, queue_has_more(q));
+            if (s.cur == kDone) {
+                if (ANYHIT) {
+                    if (out.hit) out.hit[item] = s.any ? 1 : 0;
+                } else {
+                    write_hit(r, sc, s, item, out);
+                }
+                busy = false;
+            }
+        }
+    }
+    if (STATS) flush_stats(work, s.n_nodes, s.n_tris, my_rays);
+}
+
+// ------------------------------------------------------------------------
+//  Projection build: create_projection_mat (psp_process.cpp:167-355)
+// ------------------------------------------------------------------------
+struct Cam {
+    double K[9], dist[5], R[9], t[3];
+    float ox, oy, oz;  // camera centre narrowed to f32 (psp_process.cpp:193-194)
+    int W, H;
+};
+
+// cv::projectPoints for one point (double arithmetic), result as Point2f.
+__host__ __device__ inline void project_point(const double *K, const double *k, const double *R,
+                                              const double *t, float X_, float Y_, float Z_,
+                                              float &u, float &v)
+{
+    const double X = X_, Y = Y_, Z = Z_;
+    double x = R[0] * X + R[1] * Y + R[2] * Z + t[0];
+    double y = R[3] * X + R[4] * Y + R[5] * Z + t[1];
+    double z = R[6] * X + R[7] * Y + R[8] * Z + t[2];
+    z = z ? 1. / z : 1;
+    x *= z;
+    y *= z;
+    const double r2 = x * x + y * y;
+    const double r4 = r2 * r2;
+    const double r6 = r4 * r2;
+    const double a1 = 2 * x * y;
+    const double a2 = r2 + 2 * x * x;
+    const double a3 = r2 + 2 * y * y;
+    const double cdist = 1 + k[0] * r2 + k[1] * r4 + k[4] * r6;
+    const double xd = x * cdist + k[2] * a1 + k[3] * a2;
+    const double yd = y * cdist + k[2] * a3 + k[3] * a1;
+    u = (float)(xd * K[0] + K[2]);
+    v = (float)(yd * K[4] + K[5]);
+}
+
+struct NodeJob {
+    unsigned node;
+    int attempt;       // 0 primary ray, 1..6 jittered retries
+    float u, v;        // image point (Point2f)
+    float px, py, pz;  // node position
+};
+
+__device__ __forceinline__ bool tri_has_node(const int32_t *tri_nodes, int prim, int nidx)
+{
+    const int32_t *t = tri_nodes + 3 * (size_t)prim;
+    return t[0] == nidx || t[1] == nidx || t[2] == nidx;
+}
+
+template <bool STATS>
+__global__ void __launch_bounds__(kBlock)
+    projection_kernel(Scene sc, Cam cam, const float *__restrict__ nodes,
+                      const float *__restrict__ normals, const uint8_t *__restrict__ datanode,
+                      const int32_t *__restrict__ tri_nodes, unsigned nnodes,
+                      float oblique_thresh, int32_t *__restrict__ pix, float *__restrict__ uv,
+                      unsigned *work)
+{
+    extern __shared__ int lds_stack[];
+    int *stack = lds_stack + threadIdx.x;
+    WaveQueue q;
+    queue_init(q, work, nnodes);
+    Ray r;
+    Trav s;
+    s.cur = kDone;
+    s.n_nodes = s.n_tris = 0;
+    NodeJob job;
+    job.node = 0; job.attempt = 0; job.u = job.v = 0.f; job.px = job.py = job.pz = 0.f;
+    unsigned my_rays = 0;
+    bool busy = false;
+
+    for (;;) {
+        for (;;) {
+            unsigned it;
+            const bool got = queue_take(q, !busy, it);
+            if (got) {
+                // default: no entry in the sparse matrix, uv = (0,0) (psp_process.cpp:179-182)
+                pix[it] = -1;
+                uv[2 * (size_t)it] = 0.f;
+                uv[2 * (size_t)it + 1] = 0.f;
+                if (!datanode || datanode[it]) {  // :241
+                    const float X = nodes[3 * (size_t)it], Y = nodes[3 * (size_t)it + 1],
+                                Z = nodes[3 * (size_t)it + 2];
+                    float u, v;
+                    project_point(cam.K, cam.dist, cam.R, cam.t, X, Y, Z, u, v);  // :248
+                    // upsp::contains(Size, Point2i(pt)) :252 ; Point2f->Point2i = cvRound
+                    const int rx = (int)rintf(u), ry = (int)rintf(v);
+                    if (rx >= 0 && ry >= 0 && rx < cam.W && ry < cam.H) {
+                        float dx = X - cam.ox, dy = Y - cam.oy, dz = Z - cam.oz;
+                        const float len = imath_length(dx, dy, dz);  // .normalize() :256
+                        if (len != 0.0f) { dx /= len; dy /= len; dz /= len; }
+                        ray_setup(r, cam.ox, cam.oy, cam.oz, dx, dy, dz);
+                        trav_begin(s, r, sc);
+                        job.node = it; job.attempt = 0; job.u = u; job.v = v;
+                        job.px = X; job.py = Y; job.pz = Z;
+                        busy = true;
+                        ++my_rays;
+                    }
+                }
+            }
+            if (__ballot(!busy) == 0ull || !queue_has_more(q)) break;
+        }
+        if (__ballot(busy) == 0ull) break;
+
+        if (busy) {
+            trav_run<false, STATS>(s, r, sc, stack, queue_has_more(q));
+            if (s.cur == kDone) {
+                bool visible = false;
+                if (s.any && s.best_slot >= 0) {
+                    const int prim = __float_as_int(sc.tris[3 * (size_t)s.best_slot].w);
+                    visible = tri_has_node(tri_nodes, prim, (int)job.node);  // :263-267
+                }
+                const bool primary_missed = (job.attempt == 0) && !s.any;  // :261
+                if (visible) {
+                    // oblique test with the PRIMARY direction (:298-306)
+                    float dx = job.px - cam.ox, dy = job.py - cam.oy, dz = job.pz - cam.oz;
+                    const float len = imath_length(dx, dy, dz);
+                    if (len != 0.0f) { dx /= len; dy /= len; dz /= len; }
+                    const float *nn = normals + 3 * (size_t)job.node;
+                    const float cos_theta = nn[0] * dx + nn[1] * dy + nn[2] * dz;
+                    const float theta = (float)acos((double)cos_theta);
+                    if (theta > oblique_thresh) {
+                        const int px_ = (int)roundf(job.u), py_ = (int)roundf(job.v);  // :319
+                        const long long idx = (long long)py_ * cam.W + px_;
+                        if (idx >= 0 && idx < (long long)cam.W * cam.H) {
+                            uv[2 * (size_t)job.node] = job.u / (float)cam.W;  // :311-314
+                            uv[2 * (size_t)job.node + 1] = job.v / (float)cam.H;
+                            pix[job.node] = (int32_t)idx;
+                        }
+                    }
+                    busy = false;
+                } else if (primary_missed || job.attempt >= 6) {
+                    busy = false;
+                } else {
+                    // next jittered retry, un-normalised direction (:270-295)
+                    const int k = job.attempt;  // 0..5
+                    ++job.attempt;
+                    const float L = 1e-4f;
+                    const float sgn = (k & 1) ? L : -L;
+                    const float sx = (k >> 1) == 0 ? sgn : 0.0f;
+                    const float sy = (k >> 1) == 1 ? sgn : 0.0f;
+                    const float sz = (k >> 1) == 2 ? sgn : 0.0f;
+                    const float qx = job.px + sx, qy = job.py + sy, qz = job.pz + sz;
+                    ray_setup(r, cam.ox, cam.oy, cam.oz, qx - cam.ox, qy - cam.oy, qz - cam.oz);
+                    trav_begin(s, r, sc);
+                    ++my_rays;
+                }
+            }
+        }
+    }
+    flush_stats(work, STATS ? s.n_nodes : 0u, STATS ? s.n_tris : 0u, my_rays);
+}
+
+__global__ void nodecount_kernel(const int32_t *__restrict__ pix, unsigned nnodes,
+                                 unsigned *__restrict__ counts)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nnodes && pix[i] >= 0) atomicAdd(&counts[pix[i]], 1u);
+}
+__global__ void saturate_kernel(const unsigned *__restrict__ counts, unsigned n,
+                                uint8_t *__restrict__ out)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (uint8_t)min(counts[i], 255u);  // psp_process.cpp:335-347
+}
+
+// ------------------------------------------------------------------------
+//  host side
+// ------------------------------------------------------------------------
+int stack_entries(const upsp_bvh *b)
+{
+    // LDS stack depth per thread: tree height rounded up to a multiple of 8, >= 8
+    int d = (int)b->info.depth;
+    d = ((d + 7) / 8) * 8;
+    return d < 8 ? 8 : d;
+}
+
+Scene make_scene(const upsp_bvh *b)
+{
+    Scene sc;
+    sc.nodes = reinterpret_cast<const float4 *>(b->d_nodes);
+    sc.tris = reinterpret_cast<const float4 *>(b->d_tris);
+    sc.root_ref = b->root_ref;
+    for (int a = 0; a < 3; ++a) {
+        sc.rlo[a] = b->root_min[a];
+        sc.rhi[a] = b->root_max[a];
+    }
+    return sc;
+}
+
+struct DeviceProps {
+    int cus = 0;
+    bool ok = false;
+};
+DeviceProps &props()
+{
+    static DeviceProps p;
+    if (!p.ok) {
+        hipDeviceProp_t dp;
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&dp, dev) == hipSuccess) {
+            p.cus = dp.multiProcessorCount;
+            p.ok = true;
+        }
+    }
+    return p;
+}
+
+// persistent grid: enough workgroups to fill the chip at the LDS-limited occupancy
+int grid_for(size_t items, size_t lds_bytes)
+{
+    const int cus = props().cus > 0 ? props().cus : 256;
+    int per_cu = (int)((160u * 1024u) / (lds_bytes ? lds_bytes : 1));
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    size_t want = (items + kBlock - 1) / kBlock;
+    size_t cap = (size_t)cus * (size_t)per_cu;
+    size_t g = want < cap ? want : cap;
+    return (int)(g ? g : 1);
+}
+
+int read_stats(upsp_bvh *b, hipStream_t st)
+{
+    unsigned long long h[3];
+    UPSP_HIP_CHECK(hipMemcpyAsync(h, b->d_work + 2, sizeof(h), hipMemcpyDeviceToHost, st));
+    UPSP_HIP_CHECK(hipStreamSynchronize(st));
+    b->last_stats[0] = h[0];
+    b->last_stats[1] = h[1];
+    b->last_stats[2] = h[2];
+    return UPSP_OK;
+}
+
+template <bool ANYHIT>
+int launch_cast(const upsp_bvh *cb, const float *d_org, int org_stride, const float *d_dir,
+                size_t n, const upsp_hits &out, hipStream_t st)
+{
+    upsp_bvh *b = const_cast<upsp_bvh *>(cb);
+    if (!b) return fail(UPSP_ERR_INVALID, "null BVH");
+    if (n == 0) return UPSP_OK;
+    if (!d_org || !d_dir) return fail(UPSP_ERR_INVALID, "null ray buffers");
+    if (org_stride != 0 && org_stride != 3) return fail(UPSP_ERR_INVALID, "org_stride must be 0 or 3");
+    if (n > 0xFFFFFF00ull - kChunk) return fail(UPSP_ERR_INVALID, "too many rays in one call");
+    const int entries = stack_entries(b);
+    if (entries > 64) return fail(UPSP_ERR_DEPTH, "BVH deeper than 64 levels");
+    const size_t lds = (size_t)entries * kBlock * sizeof(int);
+    UPSP_HIP_CHECK(hipMemsetAsync(b->d_work, 0, 8 * sizeof(unsigned), st));
+    const int grid = grid_for(n, lds);
+    const Scene sc = make_scene(b);
+    if (b->stats_on)
+        hipLaunchKernelGGL((cast_kernel<ANYHIT, true>), dim3(grid), dim3(kBlock), lds, st, sc,
+                           d_org, org_stride, d_dir, (unsigned)n, out, b->d_work);
+    else
+        hipLaunchKernelGGL((cast_kernel<ANYHIT, false>), dim3(grid), dim3(kBlock), lds, st, sc,
+                           d_org, org_stride, d_dir, (unsigned)n, out, b->d_work);
+    UPSP_HIP_CHECK(hipGetLastError());
+    if (b->stats_on) return read_stats(b, st);
+    return UPSP_OK;
+}
+
+}  // namespace
+}  // namespace upsp
+
+namespace upsp {
+namespace {
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf()
+    {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+};
+
+template <bool ANYHIT>
+int cast_host(const upsp_bvh *bvh, const float *h_org, int org_stride, const float *h_dir,
+              size_t n, const upsp_hits &h_out)
+{
+    if (!bvh) return fail(UPSP_ERR_INVALID, "null BVH");
+    if (n == 0) return UPSP_OK;
+    if (!h_org || !h_dir) return fail(UPSP_ERR_INVALID, "null ray buffers");
+    if (org_stride != 0 && org_stride != 3) return fail(UPSP_ERR_INVALID, "org_stride must be 0 or 3");
+    DevBuf org, dir, hit, t, prim, uvw, pos, nrm;
+    const size_t no = org_stride ? 3 * n : 3;
+    UPSP_HIP_CHECK(org.alloc(no * 4));
+    UPSP_HIP_CHECK(dir.alloc(3 * n * 4));
+    UPSP_HIP_CHECK(hipMemcpy(org.p, h_org, no * 4, hipMemcpyHostToDevice));
+    UPSP_HIP_CHECK(hipMemcpy(dir.p, h_dir, 3 * n * 4, hipMemcpyHostToDevice));
+    upsp_hits d;
+    std::memset(&d, 0, sizeof(d));
+    if (h_out.hit) { UPSP_HIP_CHECK(hit.alloc(n)); d.hit = (uint8_t *)hit.p; }
+    if (!ANYHIT) {
+        if (h_out.t) { UPSP_HIP_CHECK(t.alloc(n * 4)); d.t = (float *)t.p; }
+        if (h_out.prim) { UPSP_HIP_CHECK(prim.alloc(n * 4)); d.prim = (int32_t *)prim.p; }
+        if (h_out.uvw) { UPSP_HIP_CHECK(uvw.alloc(n * 12)); d.uvw = (float *)uvw.p; }
+        if (h_out.pos) { UPSP_HIP_CHECK(pos.alloc(n * 12)); d.pos = (float *)pos.p; }
+        if (h_out.nrm) { UPSP_HIP_CHECK(nrm.alloc(n * 12)); d.nrm = (float *)nrm.p; }
+    }
+    int rc = launch_cast<ANYHIT>(bvh, (const float *)org.p, org_stride, (const float *)dir.p, n,
+                                 d, nullptr);
+    if (rc != UPSP_OK) return rc;
+    UPSP_HIP_CHECK(hipDeviceSynchronize());
+    if (d.hit) UPSP_HIP_CHECK(hipMemcpy(h_out.hit, d.hit, n, hipMemcpyDeviceToHost));
+    if (d.t) UPSP_HIP_CHECK(hipMemcpy(h_out.t, d.t, n * 4, hipMemcpyDeviceToHost));
+    if (d.prim) UPSP_HIP_CHECK(hipMemcpy(h_out.prim, d.prim, n * 4, hipMemcpyDeviceToHost));
+    if (d.uvw) UPSP_HIP_CHECK(hipMemcpy(h_out.uvw, d.uvw, n * 12, hipMemcpyDeviceToHost));
+    if (d.pos) UPSP_HIP_CHECK(hipMemcpy(h_out.pos, d.pos, n * 12, hipMemcpyDeviceToHost));
+    if (d.nrm) UPSP_HIP_CHECK(hipMemcpy(h_out.nrm, d.nrm, n * 12, hipMemcpyDeviceToHost));
+    return UPSP_OK;
+}
+}  // namespace
+}  // namespace upsp
+
+using namespace upsp;
+
+extern "C" {
+
+const char *upsp_last_error(void) { return g_error.c_str(); }
+
+int upsp_version(void) { return 100; }
+
+int upsp_device_info(int *n_devices, char *arch, int *n_cus)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    if (n_devices) *n_devices = n;
+    if (arch) arch[0] = 0;
+    if (n_cus) *n_cus = 0;
+    if (n == 0) return fail(UPSP_ERR_NO_DEVICE, "no HIP device visible");
+    hipDeviceProp_t dp;
+    int dev = 0;
+    UPSP_HIP_CHECK(hipGetDevice(&dev));
+    UPSP_HIP_CHECK(hipGetDeviceProperties(&dp, dev));
+    if (arch) {
+        std::strncpy(arch, dp.gcnArchName, 31);
+        arch[31] = 0;
+    }
+    if (n_cus) *n_cus = dp.multiProcessorCount;
+    return UPSP_OK;
+}
+
+int upsp_bvh_create(const float *h_tris9, size_t ntris, upsp_bvh **out)
+{
+    if (!out) return fail(UPSP_ERR_INVALID, "out is null");
+    *out = nullptr;
+    if (ntris == 0 || !h_tris9) return fail(UPSP_ERR_EMPTY, "BVH::BVH() : no primitives!");
+    if (ntris >= (1u << 25)) return fail(UPSP_ERR_INVALID, "more than 2^25 triangles");
+    auto t0 = std::chrono::steady_clock::now();
+    HostBvh hb;
+    build_bvh(h_tris9, ntris, hb);
+    if (hb.depth > 64) return fail(UPSP_ERR_DEPTH, "BVH deeper than 64 levels");
+
+    upsp_bvh *b = new upsp_bvh();
+    UPSP_HIP_CHECK(hipGetDevice(&b->device));
+    const size_t nb = std::max<size_t>(hb.nodes.size(), 1) * sizeof(GpuNode);
+    const size_t tb = hb.tris.size() * sizeof(GpuTri);
+    hipError_t e = hipMalloc(&b->d_nodes, nb);
+    if (e == hipSuccess) e = hipMalloc(&b->d_tris, tb);
+    if (e == hipSuccess) e = hipMalloc(&b->d_work, 8 * sizeof(unsigned));
+    if (e == hipSuccess && !hb.nodes.empty())
+        e = hipMemcpy(b->d_nodes, hb.nodes.data(), hb.nodes.size() * sizeof(GpuNode),
+                      hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(b->d_tris, hb.tris.data(), tb, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(b->d_work, 0, 8 * sizeof(unsigned));
+    if (e != hipSuccess) {
+        upsp_bvh_destroy(b);
+        return fail(UPSP_ERR_HIP, std::string("BVH upload: ") + hipGetErrorString(e));
+    }
+    b->root_ref = hb.root_ref;
+    std::memset(&b->info, 0, sizeof(b->info));
+    for (int a = 0; a < 3; ++a) {
+        b->root_min[a] = b->info.bounds_min[a] = hb.root_min[a];
+        b->root_max[a] = b->info.bounds_max[a] = hb.root_max[a];
+    }
+    b->info.ntris = ntris;
+    b->info.n_ref_nodes = hb.n_ref_nodes;
+    b->info.n_gpu_nodes = (uint32_t)hb.nodes.size();
+    b->info.depth = hb.depth;
+    b->info.max_leaf = hb.max_leaf;
+    b->info.device_bytes = nb + tb;
+    b->info.build_seconds =
+        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    *out = b;
+    return UPSP_OK;
+}
+
+void upsp_bvh_destroy(upsp_bvh *b)
+{
+    if (!b) return;
+    if (b->d_nodes) (void)hipFree(b->d_nodes);
+    if (b->d_tris) (void)hipFree(b->d_tris);
+    if (b->d_work) (void)hipFree(b->d_work);
+    delete b;
+}
+
+int upsp_bvh_get_info(const upsp_bvh *b, upsp_bvh_info *info)
+{
+    if (!b || !info) return fail(UPSP_ERR_INVALID, "null argument");
+    *info = b->info;
+    return UPSP_OK;
+}
+
+int upsp_bvh_enable_stats(upsp_bvh *b, int on)
+{
+    if (!b) return fail(UPSP_ERR_INVALID, "null BVH");
+    b->stats_on = on ? 1 : 0;
+    return UPSP_OK;
+}
+
+int upsp_bvh_last_stats(const upsp_bvh *b, uint64_t *nodes, uint64_t *tris, uint64_t *rays)
+{
+    if (!b) return fail(UPSP_ERR_INVALID, "null BVH");
+    if (nodes) *nodes = b->last_stats[0];
+    if (tris) *tris = b->last_stats[1];
+    if (rays) *rays = b->last_stats[2];
+    return UPSP_OK;
+}
+
+int upsp_bvh_intersect(const upsp_bvh *bvh, const float *d_org, int org_stride,
+                       const float *d_dir, size_t n, const upsp_hits *d_out, void *stream)
+{
+    if (!d_out) return fail(UPSP_ERR_INVALID, "null output");
+    return launch_cast<false>(bvh, d_org, org_stride, d_dir, n, *d_out, (hipStream_t)stream);
+}
+
+int upsp_bvh_occluded(const upsp_bvh *bvh, const float *d_org, int org_stride,
+                      const float *d_dir, size_t n, uint8_t *d_hit, void *stream)
+{
+    if (!d_hit) return fail(UPSP_ERR_INVALID, "null output");
+    upsp_hits out;
+    std::memset(&out, 0, sizeof(out));
+    out.hit = d_hit;
+    return launch_cast<true>(bvh, d_org, org_stride, d_dir, n, out, (hipStream_t)stream);
+}
+
+int upsp_bvh_intersect_host(const upsp_bvh *bvh, const float *h_org, int org_stride,
+                            const float *h_dir, size_t n, const upsp_hits *h_out)
+{
+    if (!h_out) return fail(UPSP_ERR_INVALID, "null output");
+    return cast_host<false>(bvh, h_org, org_stride, h_dir, n, *h_out);
+}
+
+int upsp_bvh_occluded_host(const upsp_bvh *bvh, const float *h_org, int org_stride,
+                           const float *h_dir, size_t n, uint8_t *h_hit)
+{
+    if (!h_hit) return fail(UPSP_ERR_INVALID, "null output");
+    upsp_hits out;
+    std::memset(&out, 0, sizeof(out));
+    out.hit = h_hit;
+    return cast_host<true>(bvh, h_org, org_stride, h_dir, n, out);
+}
+
+int upsp_camera_center(const upsp_camera *cam, double c[3])
+{
+    if (!cam || !c) return fail(UPSP_ERR_INVALID, "null argument");
+    const double *R = cam->R, *t = cam->t;
+    for (int i = 0; i < 3; ++i) c[i] = -(R[0 + i] * t[0] + R[3 + i] * t[1] + R[6 + i] * t[2]);
+    return UPSP_OK;
+}
+
+int upsp_project_points_host(const upsp_camera *cam, const float *h_xyz, size_t n, float *h_uv)
+{
+    if (!cam || (!h_xyz && n) || (!h_uv && n)) return fail(UPSP_ERR_INVALID, "null argument");
+    for (size_t i = 0; i < n; ++i)
+        project_point(cam->K, cam->dist, cam->R, cam->t, h_xyz[3 * i], h_xyz[3 * i + 1],
+                      h_xyz[3 * i + 2], h_uv[2 * i], h_uv[2 * i + 1]);
+    return UPSP_OK;
+}
+
+int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_nodes,
+                          const float *d_normals, const uint8_t *d_datanode,
+                          const int32_t *d_tri_nodes, size_t nnodes, float oblique_thresh,
+                          int32_t *d_pix, float *d_uv, uint8_t *d_nodecount, uint64_t *h_nrays,
+                          void *stream)
+{
+    if (!b || !cam) return fail(UPSP_ERR_INVALID, "null BVH / camera");
+    if (nnodes == 0) {
+        if (h_nrays) *h_nrays = 0;
+        return UPSP_OK;
+    }
+    if (!d_nodes || !d_normals || !d_tri_nodes || !d_pix || !d_uv)
+        return fail(UPSP_ERR_INVALID, "null device buffer");
+    if (cam->width <= 0 || cam->height <= 0) return fail(UPSP_ERR_INVALID, "bad image size");
+    if (nnodes > 0xFFFFFF00ull - kChunk) return fail(UPSP_ERR_INVALID, "too many nodes");
+    hipStream_t st = (hipStream_t)stream;
+    const int entries = stack_entries(b);
+    if (entries > 64) return fail(UPSP_ERR_DEPTH, "BVH deeper than 64 levels");
+    const size_t lds = (size_t)entries * kBlock * sizeof(int);
+
+    Cam c;
+    std::memcpy(c.K, cam->K, sizeof(c.K));
+    std::memcpy(c.dist, cam->dist, sizeof(c.dist));
+    std::memcpy(c.R, cam->R, sizeof(c.R));
+    std::memcpy(c.t, cam->t, sizeof(c.t));
+    double cc[3];
+    upsp_camera_center(cam, cc);
+    c.ox = (float)cc[0];
+    c.oy = (float)cc[1];
+    c.oz = (float)cc[2];
+    c.W = cam->width;
+    c.H = cam->height;
+
+    UPSP_HIP_CHECK(hipMemsetAsync(b->d_work, 0, 8 * sizeof(unsigned), st));
+    const int grid = grid_for(nnodes, lds);
+    const Scene sc = make_scene(b);
+    if (b->stats_on)
+        hipLaunchKernelGGL((projection_kernel<true>), dim3(grid), dim3(kBlock), lds, st, sc, c,
+                           d_nodes, d_normals, d_datanode, d_tri_nodes, (unsigned)nnodes,
+                           oblique_thresh, d_pix, d_uv, b->d_work);
+    else
+        hipLaunchKernelGGL((projection_kernel<false>), dim3(grid), dim3(kBlock), lds, st, sc, c,
+                           d_nodes, d_normals, d_datanode, d_tri_nodes, (unsigned)nnodes,
+                           oblique_thresh, d_pix, d_uv, b->d_work);
+    UPSP_HIP_CHECK(hipGetLastError());
+
+    if (d_nodecount) {
+        const unsigned npix = (unsigned)c.W * (unsigned)c.H;
+        unsigned *counts = nullptr;
+        UPSP_HIP_CHECK(hipMalloc(&counts, (size_t)npix * 4));
+        hipError_t e = hipMemsetAsync(counts, 0, (size_t)npix * 4, st);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(nodecount_kernel, dim3(((unsigned)nnodes + 255) / 256), dim3(256),
+                               0, st, d_pix, (unsigned)nnodes, counts);
+            hipLaunchKernelGGL(saturate_kernel, dim3((npix + 255) / 256), dim3(256), 0, st, counts,
+                               npix, d_nodecount);
+            e = hipStreamSynchronize(st);
+        }
+        (void)hipFree(counts);
+        if (e != hipSuccess) return fail(UPSP_ERR_HIP, hipGetErrorString(e));
+    }
+    if (h_nrays || b->stats_on) {
+        int rc = read_stats(b, st);
+        if (rc != UPSP_OK) return rc;
+        if (h_nrays) *h_nrays = b->last_stats[2];
+    }
+    return UPSP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,80 @@
+// Internal declarations shared by the host/HIP translation units of libupsp_gpu.so.
+#ifndef UPSP_INTERNAL_H
+#define UPSP_INTERNAL_H
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "upsp_gpu.h"
+
+namespace upsp {
+
+// ---- error plumbing --------------------------------------------------------
+void set_error(const std::string &msg);
+int fail(int status, const std::string &msg);
+
+#define UPSP_HIP_CHECK(expr)                                                              \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess)                                                             \
+            return ::upsp::fail(UPSP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+// ---- device BVH layout -----------------------------------------------------
+// One 64-byte record per INTERIOR node of the reference's binary SAH tree; it
+// carries the boxes of both children so one fetch decides both descents.
+//   q0 = (lmin.x lmin.y lmin.z lmax.x)   q1 = (lmax.y lmax.z rmin.x rmin.y)
+//   q2 = (rmin.z rmax.x rmax.y rmax.z)   q3 = (left, right, meta, 0) as int bits
+// child ref >= 0 : interior node index; < 0 : leaf, ~ref = (first_slot << 6) | (count-1)
+// meta bits 0-1 : split axis (LinearNode::axis, pspRT.h:79); bit 2 : ordered
+// (always visit left first; used when an oversized leaf is split into a chain).
+struct alignas(64) GpuNode {
+    float q[16];
+};
+static_assert(sizeof(GpuNode) == 64, "GpuNode must be 64 bytes");
+
+// 48-byte triangle record in leaf order: (A, primID) (B, -) (C, -)
+struct alignas(16) GpuTri {
+    float a[3];
+    int32_t prim;
+    float b[3];
+    int32_t pad0;
+    float c[3];
+    int32_t pad1;
+};
+static_assert(sizeof(GpuTri) == 48, "GpuTri must be 48 bytes");
+
+constexpr int kLeafBits = 6;
+constexpr int kMaxLeaf = 1 << kLeafBits;  // triangles addressable by one leaf ref
+constexpr uint32_t kMetaOrdered = 4u;
+
+struct HostBvh {
+    std::vector<GpuNode> nodes;
+    std::vector<GpuTri> tris;
+    int32_t root_ref = 0;
+    float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
+    uint32_t n_ref_nodes = 0;
+    uint32_t depth = 0;
+    uint32_t max_leaf = 0;
+};
+
+// SAH build with the reference's topology and leaf order (pspRT.cpp:456-572).
+void build_bvh(const float *tris9, size_t ntris, HostBvh &out);
+
+}  // namespace upsp
+
+struct upsp_bvh {
+    upsp::GpuNode *d_nodes = nullptr;
+    upsp::GpuTri *d_tris = nullptr;
+    uint32_t *d_work = nullptr;   // [0] work-queue head, [2..7] 64-bit stats
+    int32_t root_ref = 0;
+    float root_min[3], root_max[3];
+    upsp_bvh_info info;
+    int device = 0;
+    int stats_on = 0;
+    uint64_t last_stats[3] = {0, 0, 0};
+};
+
+#endif

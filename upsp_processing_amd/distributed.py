@@ -1,0 +1,103 @@
+"""Frame sharding across GPUs and the end-of-run exchanges of psp_process phase 1.
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm,
+"gloo" on CPU for tests).  Frames shard trivially -- the reference does the same
+across MPI ranks (cpp/exec/psp_process.cpp:1519-1529) -- so the data path has no
+collective until the end of the run, where three exchanges happen:
+
+* sum of the per-rank double accumulators: MPI_Reduce + MPI_Bcast in the reference
+  (psp_process.cpp:1866-1872, 2019-2023) -> one all_reduce(SUM) of 2 x N doubles;
+* the time-series exchange: every rank holds full rows [frames_r x N] and must end
+  with full time series [nodes_r x F] -- global_transpose (psp_process.cpp:707-771:
+  local transpose, one block per rank pair, strided placement).  On xGMI every GPU
+  pair has its own link, so the exchange is ONE all_to_all_single in which all 7
+  links of every GPU carry exactly one block at the same time;
+* optional gather of everything to rank 0 (BASELINE north-star wording).
+"""
+import torch
+import torch.distributed as dist
+
+
+def apportion(value, nbins):
+    """apportion (psp_process.cpp:611-624): contiguous near-equal ranges."""
+    block, rem = divmod(int(value), int(nbins))
+    start, extent, nxt = [], [], 0
+    for b in range(nbins):
+        start.append(nxt)
+        extent.append(block + (1 if b < rem else 0))
+        nxt += extent[-1]
+    return start, extent
+
+
+class Shard:
+    """Frame / node ownership of this rank (rank_start_frame, rank_num_frames,
+    rank_start_node, rank_num_nodes of psp_process.cpp:1519-1529)."""
+
+    def __init__(self, nframes, nnodes, rank=None, world=None):
+        if rank is None:
+            rank = dist.get_rank() if dist.is_initialized() else 0
+        if world is None:
+            world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank, self.world = rank, world
+        self.nframes, self.nnodes = nframes, nnodes
+        self.frame_start, self.frame_count = apportion(nframes, world)
+        self.node_start, self.node_count = apportion(nnodes, world)
+
+    @property
+    def my_frames(self):
+        return self.frame_start[self.rank], self.frame_count[self.rank]
+
+    @property
+    def my_nodes(self):
+        return self.node_start[self.rank], self.node_count[self.rank]
+
+
+def allreduce_sums(total, sumsq, group=None):
+    """Sum the double accumulators over ranks (in place)."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        both = torch.stack([total, sumsq])
+        dist.all_reduce(both, op=dist.ReduceOp.SUM, group=group)
+        total.copy_(both[0])
+        sumsq.copy_(both[1])
+    return total, sumsq
+
+
+def exchange_time_series(rows_t, shard, group=None, out=None):
+    """global_transpose (psp_process.cpp:707-771).
+
+    rows_t : [N, frames_r] f32 -- this rank's frames, already node-major (the local
+             transpose is done by the frame pipeline / upsp_transpose_f32).
+    returns [nodes_r, F] f32 -- complete time series of this rank's node slice."""
+    r, w = shard.rank, shard.world
+    n0, nn = shard.my_nodes
+    f_r = shard.frame_count[r]
+    assert rows_t.shape == (shard.nnodes, f_r) and rows_t.is_contiguous()
+    if out is None:
+        out = torch.empty((nn, shard.nframes), dtype=rows_t.dtype, device=rows_t.device)
+    if w == 1 or not dist.is_initialized():
+        out.copy_(rows_t)
+        return out
+    in_split = [shard.node_count[d] * f_r for d in range(w)]       # block for rank d
+    out_split = [nn * shard.frame_count[s] for s in range(w)]      # block from rank s
+    recv = torch.empty(sum(out_split), dtype=rows_t.dtype, device=rows_t.device)
+    dist.all_to_all_single(recv, rows_t.reshape(-1), out_split, in_split, group=group)
+    off = 0
+    for s in range(w):
+        fs = shard.frame_count[s]
+        if fs and nn:
+            out[:, shard.frame_start[s]:shard.frame_start[s] + fs] = recv[off:off + nn * fs].view(nn, fs)
+        off += nn * fs
+    return out
+
+
+def gather_time_series_to_root(series, shard, group=None):
+    """Single gather of the node-major slices to rank 0: [N, F] on rank 0, None elsewhere."""
+    if shard.world == 1 or not dist.is_initialized():
+        return series
+    if shard.rank == 0:
+        parts = [torch.empty((shard.node_count[s], shard.nframes), dtype=series.dtype,
+                             device=series.device) for s in range(shard.world)]
+        dist.gather(series, parts, dst=0, group=group)
+        return torch.cat(parts, dim=0)
+    dist.gather(series, None, dst=0, group=group)
+    return None

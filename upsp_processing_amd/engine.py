@@ -1,0 +1,325 @@
+"""Device-resident wrappers over the C ABI (include/upsp_gpu.h).
+
+torch is plumbing here: it owns the HBM buffers (tensors) and the HIP stream; every
+computation happens inside libupsp_gpu.so.  All functions take / return CUDA(HIP)
+tensors and launch on torch's current stream.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _capi
+from ._capi import check, lib
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _dev(x, dtype):
+    """numpy / tensor -> contiguous device tensor of dtype."""
+    if isinstance(x, torch.Tensor):
+        return x.to(device="cuda", dtype=dtype).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(x), dtype=dtype).to("cuda").contiguous()
+
+
+class BVH:
+    """rt::BVH on the GPU (reference: cpp/raycast/pspRT.cpp:313-431).
+
+    Parameters: triangle soup, 9 floats per triangle (rt::CreateBVH(raw, 3))."""
+
+    def __init__(self, tris9):
+        tris9 = np.ascontiguousarray(tris9, dtype=np.float32).reshape(-1)
+        if tris9.size % 9:
+            raise ValueError("triangle soup must hold 9 floats per triangle")
+        h = C.c_void_p()
+        check(lib().upsp_bvh_create(tris9.ctypes.data_as(C.c_void_p), tris9.size // 9, C.byref(h)))
+        self._h = h
+        self.ntris = tris9.size // 9
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().upsp_bvh_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def info(self):
+        i = _capi.BvhInfo()
+        check(lib().upsp_bvh_get_info(self._h, C.byref(i)))
+        return dict(ntris=i.ntris, n_ref_nodes=i.n_ref_nodes, n_gpu_nodes=i.n_gpu_nodes,
+                    depth=i.depth, max_leaf=i.max_leaf, device_bytes=i.device_bytes,
+                    build_seconds=i.build_seconds, bounds_min=list(i.bounds_min),
+                    bounds_max=list(i.bounds_max))
+
+    def enable_stats(self, on=True):
+        check(lib().upsp_bvh_enable_stats(self._h, int(bool(on))))
+
+    def last_stats(self):
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        check(lib().upsp_bvh_last_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(nodes=a.value, tris=b.value, rays=c.value)
+
+    @staticmethod
+    def _rays(org, dirs):
+        dirs = _dev(dirs, torch.float32).reshape(-1, 3)
+        org = _dev(org, torch.float32)
+        n = dirs.shape[0]
+        if org.numel() == 3:
+            stride = 0
+        else:
+            org = org.reshape(-1, 3)
+            if org.shape[0] != n:
+                raise ValueError("origins must be (3,) or (N,3)")
+            stride = 3
+        return org, stride, dirs, n
+
+    def intersect(self, org, dirs, want=("hit", "t", "prim", "uvw", "pos", "nrm")):
+        """Closest hit of N rays (rt::BVH::intersect semantics). Returns dict of tensors."""
+        org, stride, dirs, n = self._rays(org, dirs)
+        out = {}
+        h = _capi.Hits()
+        shapes = dict(hit=((n,), torch.uint8), t=((n,), torch.float32), prim=((n,), torch.int32),
+                      uvw=((n, 3), torch.float32), pos=((n, 3), torch.float32),
+                      nrm=((n, 3), torch.float32))
+        for k in want:
+            shp, dt = shapes[k]
+            out[k] = torch.empty(shp, dtype=dt, device="cuda")
+            setattr(h, k, out[k].data_ptr())
+        check(lib().upsp_bvh_intersect(self._h, _ptr(org), stride, _ptr(dirs), n, C.byref(h),
+                                       _stream()))
+        if "hit" in out:
+            out["hit"] = out["hit"].bool()
+        return out
+
+    def occluded(self, org, dirs):
+        """Boolean return value of rt::BVH::intersect for N rays (any hit)."""
+        org, stride, dirs, n = self._rays(org, dirs)
+        hit = torch.empty(n, dtype=torch.uint8, device="cuda")
+        check(lib().upsp_bvh_occluded(self._h, _ptr(org), stride, _ptr(dirs), n, _ptr(hit),
+                                      _stream()))
+        return hit.bool()
+
+
+def oblique_threshold(oblique_angle_deg):
+    """deg2_rad(180. - oblique_angle) narrowed to float (psp_process.cpp:1602)."""
+    return float(np.float32((180.0 - float(np.float32(oblique_angle_deg))) * 3.141592653589793 / 180.0))
+
+
+def camera_center(cam):
+    c = (C.c_double * 3)()
+    check(lib().upsp_camera_center(C.byref(cam), c))
+    return np.array(list(c))
+
+
+def project_points(cam, xyz):
+    xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+    uv = np.zeros((xyz.shape[0], 2), np.float32)
+    check(lib().upsp_project_points_host(C.byref(cam), xyz.ctypes.data_as(C.c_void_p),
+                                         xyz.shape[0], uv.ctypes.data_as(C.c_void_p)))
+    return uv
+
+
+def build_projection(bvh, cam, nodes, normals, tri_nodes, oblique_angle=70.0, datanode=None,
+                     nodecount=False):
+    """create_projection_mat (psp_process.cpp:167-355) for one camera.
+
+    Returns dict(pix int32[N] (-1 = no entry), uv f32[2N], nrays, nodecount u8[H,W] | None)."""
+    nodes = _dev(nodes, torch.float32).reshape(-1, 3)
+    normals = _dev(normals, torch.float32).reshape(-1, 3)
+    tri_nodes = _dev(tri_nodes, torch.int32).reshape(-1)
+    if tri_nodes.numel() != 3 * bvh.ntris:
+        raise ValueError("tri_nodes must hold 3 node ids per triangle of the BVH")
+    n = nodes.shape[0]
+    dn = None if datanode is None else _dev(datanode, torch.uint8).reshape(-1)
+    pix = torch.empty(n, dtype=torch.int32, device="cuda")
+    uv = torch.empty(2 * n, dtype=torch.float32, device="cuda")
+    cnt = torch.empty((cam.height, cam.width), dtype=torch.uint8, device="cuda") if nodecount else None
+    nrays = C.c_uint64(0)
+    check(lib().upsp_projection_build(bvh.handle, C.byref(cam), _ptr(nodes), _ptr(normals),
+                                      _ptr(dn), _ptr(tri_nodes), n,
+                                      C.c_float(oblique_threshold(oblique_angle)), _ptr(pix),
+                                      _ptr(uv), _ptr(cnt), C.byref(nrays), _stream()))
+    return dict(pix=pix, uv=uv, nrays=int(nrays.value), nodecount=cnt)
+
+
+def projection_weights(pix, nodes, normals, centers, mode="average_view"):
+    """adjust_projection_for_weights (projection.ipp:911-1078).  pix: [ncams, N] int32.
+    Returns weight [ncams, N] f32 (1 where a single camera sees the node)."""
+    pix = _dev(pix, torch.int32)
+    ncams, n = pix.shape
+    w = torch.ones((ncams, n), dtype=torch.float32, device="cuda")
+    centers = np.ascontiguousarray(centers, dtype=np.float64).reshape(ncams, 3)
+    m = {"best_view": 0, "average_view": 1}[mode]
+    check(lib().upsp_projection_weights(ncams, n, _ptr(pix), _ptr(w),
+                                        _ptr(_dev(nodes, torch.float32)),
+                                        _ptr(_dev(normals, torch.float32)),
+                                        centers.ctypes.data_as(C.c_void_p), m, _stream()))
+    return w
+
+
+def skipped_nodes(pix):
+    """identify_skipped_nodes (projection.ipp:857-880).  pix: [ncams, N] or [N]."""
+    pix = _dev(pix, torch.int32)
+    if pix.dim() == 1:
+        pix = pix[None]
+    ncams, n = pix.shape
+    sk = torch.empty(n, dtype=torch.uint8, device="cuda")
+    cnt = C.c_uint64(0)
+    check(lib().upsp_projection_skipped(ncams, n, _ptr(pix), _ptr(sk), C.byref(cnt), _stream()))
+    return sk.bool(), int(cnt.value)
+
+
+def fix_hot_pixels(frames, thresh=4064, min_change=512, max_hot=5):
+    """upsp::fix_hot_pixels in place on u16 frames [F,H,W]; returns status int32[F]."""
+    assert frames.is_cuda and frames.dtype == torch.uint16 and frames.is_contiguous()
+    if frames.dim() == 2:
+        frames = frames[None]
+    f, h, w = frames.shape
+    st = torch.empty(f, dtype=torch.int32, device="cuda")
+    check(lib().upsp_fix_hot_pixels(_ptr(frames), f, h, w, thresh, min_change, max_hot, _ptr(st),
+                                    _stream()))
+    return st
+
+
+def project_frame(img, pix, weight=None):
+    """upsp::project_frame (projection.ipp:883-908) for one u16 / f32 image."""
+    assert img.is_cuda and img.is_contiguous()
+    n = pix.numel()
+    out = torch.empty(n, dtype=torch.float32, device="cuda")
+    fn = lib().upsp_project_frame_u16 if img.dtype == torch.uint16 else lib().upsp_project_frame_f32
+    if img.dtype not in (torch.uint16, torch.float32):
+        raise TypeError("image must be uint16 or float32")
+    check(fn(_ptr(img), _ptr(pix), _ptr(weight), n, _ptr(out), _stream()))
+    return out
+
+
+def transpose(src, out=None, ld=None, col0=0):
+    """local_transpose (psp_process.cpp:647-689): [Y,X] f32 -> [X,Y]."""
+    assert src.is_cuda and src.dtype == torch.float32 and src.is_contiguous()
+    y, x = src.shape
+    if out is None:
+        out = torch.empty((x, y), dtype=torch.float32, device="cuda")
+        ld = y
+    check(lib().upsp_transpose_f32(_ptr(src), x, y, C.c_void_p(out.data_ptr() + 4 * col0), ld,
+                                   _stream()))
+    return out
+
+
+def apportion(value, nbins):
+    """apportion (psp_process.cpp:611-624) -> (start[], extent[])."""
+    st = (C.c_int * nbins)()
+    ex = (C.c_int * nbins)()
+    check(lib().upsp_apportion(int(value), int(nbins), st, ex))
+    return list(st), list(ex)
+
+
+class FramePipeline:
+    """Body of the psp_process phase-1 frame loop (psp_process.cpp:1743-1851)."""
+
+    def __init__(self, ncams, width, height, nnodes, **opts):
+        o = _capi.PipelineOpts()
+        lib().upsp_pipeline_default_opts(C.byref(o))
+        for k, v in opts.items():
+            if not hasattr(o, k):
+                raise TypeError("unknown pipeline option %r" % k)
+            setattr(o, k, v)
+        h = C.c_void_p()
+        check(lib().upsp_pipeline_create(ncams, width, height, nnodes, C.byref(o), C.byref(h)))
+        self._h, self.ncams, self.width, self.height, self.nnodes = h, ncams, width, height, nnodes
+        self.opts = o
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().upsp_pipeline_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def set_projection(self, cam, pix, weight=None):
+        pix = _dev(pix, torch.int32)
+        w = None if weight is None else _dev(weight, torch.float32)
+        assert pix.numel() == self.nnodes
+        check(lib().upsp_pipeline_set_projection(self._h, cam, _ptr(pix), _ptr(w)))
+        torch.cuda.synchronize()
+
+    def set_skipped(self, skipped):
+        sk = None if skipped is None else _dev(skipped, torch.uint8)
+        check(lib().upsp_pipeline_set_skipped(self._h, _ptr(sk)))
+
+    def set_reference(self, cam, ref32f):
+        ref = _dev(ref32f, torch.float32)
+        assert ref.numel() == self.width * self.height
+        check(lib().upsp_pipeline_set_reference(self._h, cam, _ptr(ref)))
+
+    def set_patches(self, cam, clusters):
+        """clusters: list of dict(bx,by,ix,iy) integer pixel lists (PatchClusters members)."""
+        b_off, i_off = [0], [0]
+        bx, by, ix, iy = [], [], [], []
+        for cl in clusters:
+            bx += list(cl["bx"]); by += list(cl["by"]); ix += list(cl["ix"]); iy += list(cl["iy"])
+            b_off.append(len(bx)); i_off.append(len(ix))
+        arr = [np.asarray(a, dtype=np.int32) for a in (b_off, bx, by, i_off, ix, iy)]
+        p = [a.ctypes.data_as(C.c_void_p) for a in arr]
+        check(lib().upsp_pipeline_set_patches(self._h, cam, len(clusters), *p))
+
+    def process(self, frames, first_frame=0, rows=None, rows_t=None, col0=0, want_rows=True,
+                warps=None):
+        """frames: list (one per camera) of u16 tensors [F,H,W] (modified in place by the
+        hot-pixel fix, like the reference).  Returns rows [F,N] f32 (or None)."""
+        if isinstance(frames, torch.Tensor):
+            frames = [frames]
+        assert len(frames) == self.ncams
+        f = frames[0].shape[0]
+        for fr in frames:
+            assert fr.is_cuda and fr.dtype == torch.uint16 and fr.is_contiguous()
+            assert tuple(fr.shape) == (f, self.height, self.width)
+        if rows is None and want_rows:
+            rows = torch.empty((f, self.nnodes), dtype=torch.float32, device="cuda")
+        ptrs = (C.c_void_p * self.ncams)(*[fr.data_ptr() for fr in frames])
+        ld = 0 if rows_t is None else rows_t.stride(0)
+        check(lib().upsp_pipeline_process(self._h, ptrs, f, int(first_frame), _ptr(rows),
+                                          _ptr(rows_t), ld, col0, _ptr(warps), _stream()))
+        return rows
+
+    def accumulators(self):
+        """(sum, sumsq) as float64 tensors aliasing the pipeline's device buffers."""
+        a, b = C.c_void_p(), C.c_void_p()
+        check(lib().upsp_pipeline_accumulators(self._h, C.byref(a), C.byref(b)))
+        return _alias_f64(a.value, self.nnodes, self), _alias_f64(b.value, self.nnodes, self)
+
+    def reset(self):
+        check(lib().upsp_pipeline_reset(self._h))
+
+    def finalize(self, nframes_total):
+        avg = torch.empty(self.nnodes, dtype=torch.float32, device="cuda")
+        rms = torch.empty(self.nnodes, dtype=torch.float32, device="cuda")
+        check(lib().upsp_pipeline_finalize(self._h, int(nframes_total), _ptr(avg), _ptr(rms),
+                                           _stream()))
+        return avg, rms
+
+
+class _DevArray:
+    """__cuda_array_interface__ view of a raw device pointer (keeps `owner` alive)."""
+
+    def __init__(self, ptr, n, typestr, owner):
+        self.__cuda_array_interface__ = dict(shape=(n,), typestr=typestr, data=(ptr, False),
+                                             version=2)
+        self._owner = owner
+
+
+def _alias_f64(ptr, n, owner):
+    t = torch.as_tensor(_DevArray(ptr, n, "<f8", owner), device="cuda")
+    t._upsp_owner = owner
+    return t
