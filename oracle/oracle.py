@@ -295,3 +295,65 @@ def transpose(src):
     dst = np.zeros((x, y), np.float32)
     lib().orc_transpose(_p(src), x, y, _p(dst))
     return dst
+
+
+# ---- image operators (PARITY UNPINNED: OpenCV / Eigen restatements) --------------
+
+def blur(img, k, box=False):
+    img = _f32(img)
+    out = np.zeros_like(img)
+    lib().orc_blur_f32(_p(img), _p(out), img.shape[0], img.shape[1], int(k), int(bool(box)))
+    return out
+
+
+def warp_affine(img, M, interp=1):
+    M = _f32(M).reshape(6)
+    img = np.ascontiguousarray(img)
+    out = np.zeros_like(img)
+    if img.dtype == np.uint16:
+        lib().orc_warp_affine_u16(_p(img), _p(out), img.shape[0], img.shape[1], _p(M), int(interp))
+    else:
+        img = _f32(img)
+        out = np.zeros_like(img)
+        lib().orc_warp_affine_f32(_p(img), _p(out), img.shape[0], img.shape[1], _p(M), int(interp))
+    return out
+
+
+def find_transform_ecc(ref, inp, M=None, max_iters=50, eps=1e-3):
+    ref, inp = _f32(ref), _f32(inp)
+    M = np.array([1, 0, 0, 0, 1, 0], np.float32) if M is None else _f32(M).reshape(6).copy()
+    rho = C.c_double(0)
+    it = lib().orc_find_transform_ecc(_p(ref), _p(inp), ref.shape[0], ref.shape[1], _p(M),
+                                      int(max_iters), float(eps), C.addressof(rho))
+    return M.reshape(2, 3), it, rho.value
+
+
+def register_pixel(ref, frame_u16, max_iters=50, eps=1e-3, interp=1):
+    ref = _f32(ref)
+    fr = np.ascontiguousarray(frame_u16, dtype=np.uint16)
+    M = np.zeros(6, np.float32)
+    out = np.zeros_like(fr)
+    it = lib().orc_register_pixel_u16(_p(ref), _p(fr), fr.shape[0], fr.shape[1], _p(M),
+                                      int(max_iters), float(eps), int(interp), _p(out))
+    return out, M.reshape(2, 3), it
+
+
+def polyfit2d(x, y, z):
+    x = np.ascontiguousarray(x, dtype=np.int32)
+    y = np.ascontiguousarray(y, dtype=np.int32)
+    z = _f32(z)
+    poly = np.zeros(10, np.float32)
+    rank = lib().orc_polyfit2d(_p(x), _p(y), _p(z), x.size, _p(poly))
+    return poly, rank
+
+
+def patch_clusters(img, clusters):
+    img = _f32(img).copy()
+    b_off, i_off = [0], [0]
+    bx, by, ix, iy = [], [], [], []
+    for cl in clusters:
+        bx += list(cl["bx"]); by += list(cl["by"]); ix += list(cl["ix"]); iy += list(cl["iy"])
+        b_off.append(len(bx)); i_off.append(len(ix))
+    arr = [np.asarray(a, dtype=np.int32) for a in (b_off, bx, by, i_off, ix, iy)]
+    lib().orc_patch_clusters(_p(img), img.shape[1], len(clusters), *[_p(a) for a in arr])
+    return img

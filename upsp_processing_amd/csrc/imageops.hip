@@ -1,54 +1,948 @@
-// Image stages of the frame loop (register -> patch -> filter).  First cut: the
-// stage plumbing only; kernels follow.
+// Image stages of the psp_process frame loop on MI355X (gfx950):
+//   register (ECC affine + inverse-map warp)   cpp/lib/registration.cpp:32-81
+//   patch    (cubic 2-D polynomial over fiducials) cpp/lib/patches.ipp:98-236
+//   filter   (GaussianBlur / blur)               cpp/exec/psp_process.cpp:1802-1807
+//
+// The arithmetic of these stages lives in OpenCV 4.5.2 / Eigen 3.3.9 in the
+// reference (un-vendored, no reference test): the kernels follow the published
+// algorithms as restated in oracle/image_oracle.c.
+//
+// ECC on the GPU.  All frames of a sub-batch iterate in lock step.  One iteration
+// is ONE pass over the template-sized pixel grid per frame: the warped image, the
+// two warped gradients (central differences recomputed from the blurred frame on
+// the fly, never stored) and the nearest-neighbour mask are evaluated per pixel and
+// folded into 45 double sums; everything OpenCV derives from zero-mean images
+// (correlation, Hessian, projections, lambda, the parameter step) follows from
+// those sums algebraically, so no second pass and no Jacobian planes exist.  The
+// sums are reduced deterministically (fixed block partials, fixed order) and a
+// one-lane-per-frame kernel does the 6x6 float LU solve exactly like cv::Mat::inv.
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <vector>
 
 #include "pipeline.h"
 #include "upsp_internal.h"
 
 namespace upsp {
+namespace {
 
+constexpr int kEccBlocks = 64;   // partial-sum blocks per frame
+constexpr int kEccSums = 45;
+constexpr int kMaxKernel = 63;   // largest odd filter size
+
+// ------------------------------------------------------------------ utils --
+__host__ __device__ inline int reflect101(int i, int n)
+{
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) {
+        if (i < 0) i = -i;
+        if (i >= n) i = 2 * n - 2 - i;
+    }
+    return i;
+}
+
+__global__ void u16_to_f32_kernel(const uint16_t *__restrict__ src, float *__restrict__ dst, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = (float)src[i];
+}
+
+// ---------------------------------------------------------------- filters --
+struct FilterCoef {
+    float k[kMaxKernel];
+    int size;
+};
+
+// cv::getGaussianKernel(k, sigma <= 0, CV_32F)
+int gaussian_coef(int k, FilterCoef &fc)
+{
+    if (k < 1 || (k & 1) == 0 || k > kMaxKernel) return -1;
+    fc.size = k;
+    static const float t1[] = {1.f};
+    static const float t3[] = {0.25f, 0.5f, 0.25f};
+    static const float t5[] = {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f};
+    static const float t7[] = {0.03125f, 0.109375f, 0.21875f, 0.28125f, 0.21875f, 0.109375f, 0.03125f};
+    const float *fixed = k == 1 ? t1 : k == 3 ? t3 : k == 5 ? t5 : k == 7 ? t7 : nullptr;
+    if (fixed) {
+        std::memcpy(fc.k, fixed, sizeof(float) * (size_t)k);
+        return 0;
+    }
+    const double sigma = ((k - 1) * 0.5 - 1) * 0.3 + 0.8;
+    const double scale2 = -0.5 / (sigma * sigma);
+    double sum = 0;
+    for (int i = 0; i < k; ++i) {
+        const double x = i - (k - 1) * 0.5;
+        fc.k[i] = (float)std::exp(scale2 * x * x);
+        sum += fc.k[i];
+    }
+    sum = 1. / sum;
+    for (int i = 0; i < k; ++i) fc.k[i] = (float)(fc.k[i] * sum);
+    return 0;
+}
+
+// Symmetric separable filter, one pass (HORIZ: along x, else along y), float
+// accumulation in the order  k[r]*c + sum_j k[r+j]*(a[-j] + a[+j]).
+template <typename SRC, bool HORIZ>
+__global__ void __launch_bounds__(256)
+    gauss_pass_kernel(const SRC *__restrict__ src, float *__restrict__ dst, int rows, int cols,
+                      FilterCoef fc)
+{
+    const size_t npix = (size_t)rows * cols;
+    const SRC *s = src + (size_t)blockIdx.y * npix;
+    float *d = dst + (size_t)blockIdx.y * npix;
+    const int r = fc.size / 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int y = (int)(i / (size_t)cols), x = (int)(i % (size_t)cols);
+        float acc = fc.k[r] * (float)s[i];
+        for (int j = 1; j <= r; ++j) {
+            float a, b;
+            if (HORIZ) {
+                a = (float)s[(size_t)y * cols + reflect101(x - j, cols)];
+                b = (float)s[(size_t)y * cols + reflect101(x + j, cols)];
+            } else {
+                a = (float)s[(size_t)reflect101(y - j, rows) * cols + x];
+                b = (float)s[(size_t)reflect101(y + j, rows) * cols + x];
+            }
+            acc += fc.k[r + j] * (a + b);
+        }
+        d[i] = acc;
+    }
+}
+
+// cv::blur: double sums, scale 1/(k*k) (box filter with CV_64F sums for CV_32F input)
+template <bool HORIZ>
+__global__ void __launch_bounds__(256)
+    box_pass_kernel(const void *__restrict__ src_, void *__restrict__ dst_, int rows, int cols, int k)
+{
+    const size_t npix = (size_t)rows * cols;
+    const int r = k / 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int y = (int)(i / (size_t)cols), x = (int)(i % (size_t)cols);
+        double s = 0;
+        if (HORIZ) {
+            const float *src = reinterpret_cast<const float *>(src_) + (size_t)blockIdx.y * npix;
+            for (int j = -r; j <= r; ++j) s += src[(size_t)y * cols + reflect101(x + j, cols)];
+            (reinterpret_cast<double *>(dst_) + (size_t)blockIdx.y * npix)[i] = s;
+        } else {
+            const double *src = reinterpret_cast<const double *>(src_) + (size_t)blockIdx.y * npix;
+            for (int j = -r; j <= r; ++j) s += src[(size_t)reflect101(y + j, rows) * cols + x];
+            (reinterpret_cast<float *>(dst_) + (size_t)blockIdx.y * npix)[i] =
+                (float)(s * (1.0 / ((double)k * k)));
+        }
+    }
+}
+
+unsigned grid_for_pixels(size_t npix)
+{
+    size_t g = (npix + 255) / 256;
+    return (unsigned)std::min<size_t>(g, 1024);
+}
+
+// GaussianBlur(src,dst,Size(k,k),0) for nimg images; tmp: nimg*npix floats
+template <typename SRC>
+int launch_gauss(const SRC *src, float *dst, float *tmp, int nimg, int rows, int cols, int k,
+                 hipStream_t st)
+{
+    FilterCoef fc;
+    if (gaussian_coef(k, fc) != 0) return fail(UPSP_ERR_INVALID, "filter size must be odd and <= 63");
+    const dim3 grid(grid_for_pixels((size_t)rows * cols), (unsigned)nimg), block(256);
+    hipLaunchKernelGGL((gauss_pass_kernel<SRC, true>), grid, block, 0, st, src, tmp, rows, cols, fc);
+    hipLaunchKernelGGL((gauss_pass_kernel<float, false>), grid, block, 0, st, (const float *)tmp, dst,
+                       rows, cols, fc);
+    UPSP_HIP_CHECK(hipGetLastError());
+    return UPSP_OK;
+}
+
+// -------------------------------------------------------------- warpAffine --
+struct WarpCoord {
+    int sx, sy, ax, ay;
+};
+
+// WarpAffineInvoker (OpenCV imgwarp.cpp): AB_BITS 10, INTER_BITS 5, cvRound of doubles
+__device__ __forceinline__ WarpCoord warp_coord(const double *M, int x, int y, int interp)
+{
+    const int AB_SCALE = 1024;
+    const int round_delta = interp ? 16 : 512;
+    const int adelta = __double2int_rn(M[0] * x * AB_SCALE);
+    const int bdelta = __double2int_rn(M[3] * x * AB_SCALE);
+    const int X0 = __double2int_rn((M[1] * y + M[2]) * AB_SCALE) + round_delta;
+    const int Y0 = __double2int_rn((M[4] * y + M[5]) * AB_SCALE) + round_delta;
+    WarpCoord c;
+    if (interp) {
+        const int X = (X0 + adelta) >> 5, Y = (Y0 + bdelta) >> 5;
+        c.sx = X >> 5; c.sy = Y >> 5; c.ax = X & 31; c.ay = Y & 31;
+    } else {
+        c.sx = (X0 + adelta) >> 10; c.sy = (Y0 + bdelta) >> 10; c.ax = c.ay = 0;
+    }
+    c.sx = max(-32768, min(32767, c.sx));  // saturate_cast<short>
+    c.sy = max(-32768, min(32767, c.sy));
+    return c;
+}
+
+// remapBilinear<Cast<float,T>,...>, BORDER_CONSTANT 0.  F(y,x) fetches a source pixel.
+template <typename F>
+__device__ __forceinline__ float bilinear(F fetch, int rows, int cols, WarpCoord c)
+{
+    const float fx = c.ax * (1.f / 32), fy = c.ay * (1.f / 32);
+    const float w0 = (1.f - fy) * (1.f - fx), w1 = (1.f - fy) * fx, w2 = fy * (1.f - fx), w3 = fy * fx;
+    const int sx = c.sx, sy = c.sy;
+    if ((unsigned)sx < (unsigned)(cols - 1) && (unsigned)sy < (unsigned)(rows - 1))
+        return fetch(sy, sx) * w0 + fetch(sy, sx + 1) * w1 + fetch(sy + 1, sx) * w2 + fetch(sy + 1, sx + 1) * w3;
+    if (sx >= cols || sx + 1 < 0 || sy >= rows || sy + 1 < 0) return 0.f;
+    const bool x0 = sx >= 0 && sx < cols, x1 = sx + 1 >= 0 && sx + 1 < cols;
+    const bool y0 = sy >= 0 && sy < rows, y1 = sy + 1 >= 0 && sy + 1 < rows;
+    const float v0 = (x0 && y0) ? fetch(sy, sx) : 0.f;
+    const float v1 = (x1 && y0) ? fetch(sy, sx + 1) : 0.f;
+    const float v2 = (x0 && y1) ? fetch(sy + 1, sx) : 0.f;
+    const float v3 = (x1 && y1) ? fetch(sy + 1, sx + 1) : 0.f;
+    return v0 * w0 + v1 * w1 + v2 * w2 + v3 * w3;
+}
+
+// per-frame ECC state
+struct EccState {
+    float M[6];
+    double rho, last_rho;
+    int iters;
+    int done;     // 1 converged / iteration cap, 2 identity (frame 0), <0 error
+};
+
+// cv::warpAffine(u16, M, INTER_LINEAR|NEAREST + WARP_INVERSE_MAP) for every frame
+__global__ void __launch_bounds__(256)
+    warp_u16_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, int rows, int cols,
+                    const EccState *__restrict__ state, int interp)
+{
+    const size_t npix = (size_t)rows * cols;
+    const uint16_t *s = src + (size_t)blockIdx.y * npix;
+    uint16_t *d = dst + (size_t)blockIdx.y * npix;
+    const EccState &es = state[blockIdx.y];
+    double M[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) M[i] = es.M[i];
+    const bool identity = es.done == 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix;
+         i += (size_t)gridDim.x * blockDim.x) {
+        if (identity) {
+            d[i] = s[i];
+            continue;
+        }
+        const int y = (int)(i / (size_t)cols), x = (int)(i % (size_t)cols);
+        const WarpCoord c = warp_coord(M, x, y, interp);
+        uint16_t o;
+        if (interp) {
+            const float v = bilinear([&](int yy, int xx) { return (float)s[(size_t)yy * cols + xx]; },
+                                     rows, cols, c);
+            const int iv = (int)rintf(v);  // saturate_cast<ushort>(float)
+            o = (uint16_t)max(0, min(65535, iv));
+        } else {
+            o = ((unsigned)c.sx < (unsigned)cols && (unsigned)c.sy < (unsigned)rows)
+                    ? s[(size_t)c.sy * cols + c.sx]
+                    : (uint16_t)0;
+        }
+        d[i] = o;
+    }
+}
+
+// --------------------------------------------------------------------- ECC --
+// Sum slots:
+//  0 n   1 Sw   2 Sww   3 St   4 Stt   5 Stw          (masked)
+//  6..11  S_all  J_k * w        12..17 S_mask J_k      18..23 S_mask J_k * t
+//  24..44 S_all  J_a * J_b  (a <= b, row-major upper triangle)
+__global__ void __launch_bounds__(256)
+    ecc_sums_kernel(const float *__restrict__ img, const float *__restrict__ tmpl, int rows,
+                    int cols, const EccState *__restrict__ state, double *__restrict__ partial)
+{
+    const int f = blockIdx.y;
+    const EccState &es = state[f];
+    if (es.done) return;
+    const size_t npix = (size_t)rows * cols;
+    const float *I = img + (size_t)f * npix;
+    double M[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) M[i] = es.M[i];
+    double acc[kEccSums];
+#pragma unroll
+    for (int k = 0; k < kEccSums; ++k) acc[k] = 0.0;
+
+    auto pix = [&](int yy, int xx) { return I[(size_t)yy * cols + xx]; };
+    // filter2D [-0.5 0 0.5] (BORDER_REFLECT_101) of the blurred frame, on the fly
+    auto gxf = [&](int yy, int xx) {
+        return -0.5f * pix(yy, reflect101(xx - 1, cols)) + 0.5f * pix(yy, reflect101(xx + 1, cols));
+    };
+    auto gyf = [&](int yy, int xx) {
+        return -0.5f * pix(reflect101(yy - 1, rows), xx) + 0.5f * pix(reflect101(yy + 1, rows), xx);
+    };
+
+    const size_t per_block = (npix + gridDim.x - 1) / gridDim.x;
+    const size_t lo = (size_t)blockIdx.x * per_block;
+    const size_t hi = min(npix, lo + per_block);
+    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const int y = (int)(i / (size_t)cols), x = (int)(i % (size_t)cols);
+        const WarpCoord c = warp_coord(M, x, y, 1);
+        const WarpCoord cn = warp_coord(M, x, y, 0);
+        const bool m = (unsigned)cn.sx < (unsigned)cols && (unsigned)cn.sy < (unsigned)rows;
+        const float w = bilinear(pix, rows, cols, c);
+        const float gx = bilinear(gxf, rows, cols, c);
+        const float gy = bilinear(gyf, rows, cols, c);
+        const float X = (float)x, Y = (float)y;
+        const float J[6] = {gx * X, gy * X, gx * Y, gy * Y, gx, gy};
+        const float t = tmpl[i];
+        if (m) {
+            acc[0] += 1.0;
+            acc[1] += (double)w;
+            acc[2] += (double)w * w;
+            acc[3] += (double)t;
+            acc[4] += (double)t * t;
+            acc[5] += (double)t * w;
+        }
+        int h = 24;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            acc[6 + a] += (double)J[a] * w;
+            if (m) {
+                acc[12 + a] += (double)J[a];
+                acc[18 + a] += (double)J[a] * t;
+            }
+#pragma unroll
+            for (int b = a; b < 6; ++b) acc[h++] += (double)J[a] * J[b];
+        }
+    }
+    // deterministic block reduction: wave shuffle tree, then 4 waves through LDS
+    __shared__ double red[4][kEccSums];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < kEccSums; ++k) {
+        double v = acc[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kEccSums) {
+        const double v = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+        partial[((size_t)f * gridDim.x + blockIdx.x) * kEccSums + threadIdx.x] = v;
+    }
+}
+
+// hal::LU32f-based inverse (cv::Mat::inv, DECOMP_LU) of a 6x6 float matrix
+__device__ bool inv6(const float *Ain, float *inv)
+{
+    float A[6][6], b[6][6];
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) {
+            A[i][j] = Ain[i * 6 + j];
+            b[i][j] = i == j ? 1.f : 0.f;
+        }
+    const float eps = FLT_EPSILON * 10;
+    for (int i = 0; i < 6; ++i) {
+        int k = i;
+        for (int j = i + 1; j < 6; ++j)
+            if (fabsf(A[j][i]) > fabsf(A[k][i])) k = j;
+        if (fabsf(A[k][i]) < eps) return false;
+        if (k != i) {
+            for (int j = i; j < 6; ++j) { const float t = A[i][j]; A[i][j] = A[k][j]; A[k][j] = t; }
+            for (int j = 0; j < 6; ++j) { const float t = b[i][j]; b[i][j] = b[k][j]; b[k][j] = t; }
+        }
+        const float d = -1 / A[i][i];
+        for (int j = i + 1; j < 6; ++j) {
+            const float alpha = A[j][i] * d;
+            for (int kk = i + 1; kk < 6; ++kk) A[j][kk] += alpha * A[i][kk];
+            for (int kk = 0; kk < 6; ++kk) b[j][kk] += alpha * b[i][kk];
+        }
+    }
+    for (int i = 5; i >= 0; --i)
+        for (int j = 0; j < 6; ++j) {
+            float s = b[i][j];
+            for (int k = i + 1; k < 6; ++k) s -= A[i][k] * b[k][j];
+            b[i][j] = s / A[i][i];
+        }
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) inv[i * 6 + j] = b[i][j];
+    return true;
+}
+
+// One lane per frame: the body of the cv::findTransformECC iteration after the
+// image passes (ecc.cpp): meanStdDev, rho, hessian inverse, lambda, deltaP, update.
+__global__ void ecc_solve_kernel(EccState *__restrict__ state, const double *__restrict__ partial,
+                                 int nframes, int nblocks, int max_iters, double eps)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nframes) return;
+    EccState &es = state[f];
+    if (es.done) return;
+    double S[kEccSums];
+    for (int k = 0; k < kEccSums; ++k) S[k] = 0.0;
+    for (int b = 0; b < nblocks; ++b)
+        for (int k = 0; k < kEccSums; ++k) S[k] += partial[((size_t)f * nblocks + b) * kEccSums + k];
+    const double n = S[0];
+    const double mw = n ? S[1] / n : 0, mt = n ? S[3] / n : 0;
+    const double vw = n ? S[2] / n - mw * mw : 0, vt = n ? S[4] / n - mt * mt : 0;
+    const double sdw = sqrt(vw > 0 ? vw : 0), sdt = sqrt(vt > 0 ? vt : 0);
+    const double tmpNorm = sqrt(n * sdt * sdt), imgNorm = sqrt(n * sdw * sdw);
+    const double corr = S[5] - n * mt * mw;
+    float Hf[36], Hinv[36], ipf[6], tpf[6];
+    int h = 24;
+    for (int a = 0; a < 6; ++a) {
+        ipf[a] = (float)(S[6 + a] - mw * S[12 + a]);
+        tpf[a] = (float)(S[18 + a] - mt * S[12 + a]);
+        for (int b = a; b < 6; ++b) {
+            Hf[a * 6 + b] = Hf[b * 6 + a] = (float)S[h];
+            ++h;
+        }
+    }
+    if (!inv6(Hf, Hinv))
+        for (int i = 0; i < 36; ++i) Hinv[i] = 0.f;
+    es.last_rho = es.rho;
+    es.rho = corr / (imgNorm * tmpNorm);
+    es.iters += 1;
+    if (es.rho != es.rho) {  // "NaN encountered."
+        es.done = -1;
+        return;
+    }
+    float iph[6];
+    for (int i = 0; i < 6; ++i) {
+        double s = 0;
+        for (int j = 0; j < 6; ++j) s += (double)Hinv[i * 6 + j] * ipf[j];
+        iph[i] = (float)s;
+    }
+    double d_ip = 0, d_tp = 0;
+    for (int i = 0; i < 6; ++i) {
+        d_ip += (double)ipf[i] * iph[i];
+        d_tp += (double)tpf[i] * iph[i];
+    }
+    const double lambda_n = imgNorm * imgNorm - d_ip;
+    const double lambda_d = corr - d_tp;
+    if (lambda_d <= 0.0) {  // "The algorithm stopped before its convergence..."
+        es.rho = -1;
+        es.done = -2;
+        return;
+    }
+    const float lambda = (float)(lambda_n / lambda_d);
+    // errorProjection = J^T (lambda*tz - wz) = lambda*tp - ip
+    float epf[6], dp[6];
+    for (int i = 0; i < 6; ++i) epf[i] = (float)((double)lambda * tpf[i] - (double)ipf[i]);
+    for (int i = 0; i < 6; ++i) {
+        double s = 0;
+        for (int j = 0; j < 6; ++j) s += (double)Hinv[i * 6 + j] * epf[j];
+        dp[i] = (float)s;
+    }
+    es.M[0] += dp[0]; es.M[3] += dp[1]; es.M[1] += dp[2];
+    es.M[4] += dp[3]; es.M[2] += dp[4]; es.M[5] += dp[5];
+    // for (i = 1; i <= N && fabs(rho - last_rho) >= eps; i++)
+    if (es.iters >= max_iters || !(fabs(es.rho - es.last_rho) >= eps)) es.done = 1;
+}
+
+__global__ void ecc_init_kernel(EccState *state, int nframes, long long first_frame)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nframes) return;
+    EccState &es = state[f];
+    es.M[0] = 1; es.M[1] = 0; es.M[2] = 0; es.M[3] = 0; es.M[4] = 1; es.M[5] = 0;  // eye(2,3)
+    es.rho = -1;
+    es.last_rho = 0;  // set by the host wrapper to -eps
+    es.iters = 0;
+    es.done = (first_frame + f == 0) ? 2 : 0;  // frame 0 is not registered (psp_process.cpp:1777)
+}
+
+__global__ void ecc_set_last_rho(EccState *state, int nframes, double eps)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < nframes) state[f].last_rho = -eps;
+}
+
+__global__ void ecc_count_active(const EccState *state, int nframes, int *out)
+{
+    int active = 0, err = 0;
+    for (int f = threadIdx.x; f < nframes; f += blockDim.x) {
+        active += state[f].done == 0;
+        err += state[f].done < 0;
+    }
+    atomicAdd(&out[0], active);
+    atomicAdd(&out[1], err);
+}
+
+__global__ void ecc_export_warps(const EccState *state, int nframes, float *warps, int stride)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nframes) return;
+    for (int i = 0; i < 6; ++i) warps[(size_t)f * stride + i] = state[f].M[i];
+}
+
+// ----------------------------------------------------------------- patches --
+// Per cluster: coef = P z (P = pseudo-inverse of the cubic design matrix in centred,
+// scaled coordinates, built once on the host in double), then evaluate at the
+// interior pixels.  One workgroup per (cluster, frame).
+struct ClusterDesc {
+    int b_off, nb, i_off, ni;
+    float cx, cy, sx, sy;  // x' = (x - cx) * sx
+};
+
+__device__ __forceinline__ void monomials(float x, float y, float *m)
+{
+    // order of polyfit2D: y^i x^j, i outer, j inner, i + j <= 3 (patches.ipp:185-193)
+    const float x2 = x * x, y2 = y * y;
+    m[0] = 1.f; m[1] = x; m[2] = x2; m[3] = x2 * x;
+    m[4] = y; m[5] = y * x; m[6] = y * x2;
+    m[7] = y2; m[8] = y2 * x;
+    m[9] = y2 * y;
+}
+
+__global__ void __launch_bounds__(256)
+    patch_kernel(float *__restrict__ imgs, size_t npix, int cols, const ClusterDesc *__restrict__ cl,
+                 int cluster0, const int32_t *__restrict__ b_idx, const float *__restrict__ P,
+                 const int32_t *__restrict__ i_idx)
+{
+    const ClusterDesc d = cl[cluster0 + blockIdx.x];
+    float *img = imgs + (size_t)blockIdx.y * npix;
+    if (d.nb < 10) return;  // too few boundary points (patches.ipp:103)
+    __shared__ double red[4][10];
+    __shared__ float coef[10];
+    double acc[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) acc[k] = 0.0;
+    for (int j = threadIdx.x; j < d.nb; j += blockDim.x) {
+        const float z = img[b_idx[d.b_off + j]];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) acc[k] += (double)P[(size_t)10 * (d.b_off + j) + k] * z;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        double v = acc[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 10)
+        coef[threadIdx.x] = (float)(((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) +
+                                    red[3][threadIdx.x]);
+    __syncthreads();
+    for (int j = threadIdx.x; j < d.ni; j += blockDim.x) {
+        const int idx = i_idx[d.i_off + j];
+        const float x = ((float)(idx % cols) - d.cx) * d.sx, y = ((float)(idx / cols) - d.cy) * d.sy;
+        float m[10];
+        monomials(x, y, m);
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) v += coef[k] * m[k];
+        img[idx] = v;
+    }
+}
+
+// Host: pseudo-inverse of the m x 10 design matrix by column-pivoted Householder QR
+// in double (rank-truncated).  P is returned as [m][10] (row = boundary point).
+void pinv_design(const std::vector<double> &A, int m, std::vector<float> &P)
+{
+    const int nc = 10;
+    std::vector<double> Q(A);  // column-major m x nc
+    std::vector<double> Rinv;  // unused
+    std::vector<int> perm(nc);
+    std::vector<double> tau(nc, 0.0);
+    for (int k = 0; k < nc; ++k) perm[k] = k;
+    auto col = [&](int j) { return &Q[(size_t)j * m]; };
+    double maxnorm = 0;
+    int rank = nc;
+    for (int k = 0; k < nc; ++k) {
+        int big = k;
+        double bign = -1;
+        for (int j = k; j < nc; ++j) {
+            double s = 0;
+            for (int r = k; r < m; ++r) s += col(j)[r] * col(j)[r];
+            if (s > bign) { bign = s; big = j; }
+        }
+        if (k == 0) maxnorm = std::sqrt(bign);
+        if (std::sqrt(bign) <= 1e-10 * maxnorm) { rank = k; break; }
+        if (big != k) {
+            for (int r = 0; r < m; ++r) std::swap(col(k)[r], col(big)[r]);
+            std::swap(perm[k], perm[big]);
+        }
+        double *c = col(k);
+        double tail = 0;
+        for (int r = k + 1; r < m; ++r) tail += c[r] * c[r];
+        const double c0 = c[k];
+        double beta = std::sqrt(c0 * c0 + tail);
+        if (c0 >= 0) beta = -beta;
+        if (tail == 0) { tau[k] = 0; continue; }
+        for (int r = k + 1; r < m; ++r) c[r] /= (c0 - beta);
+        tau[k] = (beta - c0) / beta;
+        c[k] = beta;
+        for (int j = k + 1; j < nc; ++j) {
+            double *cj = col(j);
+            double t = cj[k];
+            for (int r = k + 1; r < m; ++r) t += c[r] * cj[r];
+            cj[k] -= tau[k] * t;
+            for (int r = k + 1; r < m; ++r) cj[r] -= tau[k] * c[r] * t;
+        }
+    }
+    // P = Pi * [R11^-1 0] * Q^T : apply to each unit vector e_r of R^m
+    P.assign((size_t)m * nc, 0.f);
+    std::vector<double> v(m);
+    for (int r0 = 0; r0 < m; ++r0) {
+        std::fill(v.begin(), v.end(), 0.0);
+        v[r0] = 1.0;
+        for (int k = 0; k < rank; ++k) {
+            if (tau[k] == 0) continue;
+            const double *c = col(k);
+            double t = v[k];
+            for (int r = k + 1; r < m; ++r) t += c[r] * v[r];
+            v[k] -= tau[k] * t;
+            for (int r = k + 1; r < m; ++r) v[r] -= tau[k] * c[r] * t;
+        }
+        double sol[10] = {0};
+        for (int i = rank - 1; i >= 0; --i) {
+            double s = v[i];
+            for (int j = i + 1; j < rank; ++j) s -= col(j)[i] * sol[j];
+            sol[i] = s / col(i)[i];
+        }
+        for (int k = 0; k < rank; ++k) P[(size_t)r0 * nc + perm[k]] = (float)sol[k];
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------ PatchTables --
 struct PatchTables {
     int nclusters = 0;
-};
-struct FrameScratch {
-    int dummy = 0;
+    bool sequential = false;  // a boundary of one cluster overlaps another's interior
+    ClusterDesc *d_desc = nullptr;
+    int32_t *d_bidx = nullptr, *d_iidx = nullptr;
+    float *d_P = nullptr;
 };
 
-int patch_tables_create(int, int, int, const int32_t *, const int32_t *, const int32_t *,
-                        const int32_t *, const int32_t *, const int32_t *, PatchTables **out)
+void patch_tables_free(PatchTables *t)
 {
-    if (out) *out = nullptr;
-    return fail(UPSP_ERR_INVALID, "patching kernels not built yet");
+    if (!t) return;
+    if (t->d_desc) (void)hipFree(t->d_desc);
+    if (t->d_bidx) (void)hipFree(t->d_bidx);
+    if (t->d_iidx) (void)hipFree(t->d_iidx);
+    if (t->d_P) (void)hipFree(t->d_P);
+    delete t;
 }
-void patch_tables_free(PatchTables *t) { delete t; }
-int frame_scratch_ensure(FrameScratch **, int, int, int, int, bool, bool)
+
+int patch_tables_create(int rows, int cols, int nclusters, const int32_t *b_off, const int32_t *bx,
+                        const int32_t *by, const int32_t *i_off, const int32_t *ix,
+                        const int32_t *iy, PatchTables **out)
 {
-    return fail(UPSP_ERR_INVALID, "registration / patch / filter kernels not built yet");
+    if (!out) return fail(UPSP_ERR_INVALID, "out is null");
+    *out = nullptr;
+    if (nclusters < 0 || !b_off || !i_off) return fail(UPSP_ERR_INVALID, "bad patch tables");
+    const int nbt = b_off[nclusters], nit = i_off[nclusters];
+    if ((nbt && (!bx || !by)) || (nit && (!ix || !iy))) return fail(UPSP_ERR_INVALID, "bad patch tables");
+    std::vector<ClusterDesc> desc(nclusters);
+    std::vector<int32_t> bidx(std::max(nbt, 1)), iidx(std::max(nit, 1));
+    std::vector<float> Pall((size_t)std::max(nbt, 1) * 10, 0.f);
+    std::vector<int> owner((size_t)rows * cols, -1);
+    bool sequential = false;
+    for (int c = 0; c < nclusters; ++c) {
+        ClusterDesc &d = desc[c];
+        d.b_off = b_off[c]; d.nb = b_off[c + 1] - b_off[c];
+        d.i_off = i_off[c]; d.ni = i_off[c + 1] - i_off[c];
+        if (d.nb < 0 || d.ni < 0) return fail(UPSP_ERR_INVALID, "patch offsets not monotone");
+        double mx = 0, my = 0, lox = 1e30, hix = -1e30, loy = 1e30, hiy = -1e30;
+        for (int j = 0; j < d.nb; ++j) {
+            const int x = bx[d.b_off + j], y = by[d.b_off + j];
+            if (x < 0 || y < 0 || x >= cols || y >= rows) return fail(UPSP_ERR_INVALID, "patch pixel outside the frame");
+            bidx[d.b_off + j] = y * cols + x;
+            mx += x; my += y;
+            lox = std::min<double>(lox, x); hix = std::max<double>(hix, x);
+            loy = std::min<double>(loy, y); hiy = std::max<double>(hiy, y);
+        }
+        for (int j = 0; j < d.ni; ++j) {
+            const int x = ix[d.i_off + j], y = iy[d.i_off + j];
+            if (x < 0 || y < 0 || x >= cols || y >= rows) return fail(UPSP_ERR_INVALID, "patch pixel outside the frame");
+            iidx[d.i_off + j] = y * cols + x;
+        }
+        if (d.nb >= 10) {
+            mx /= d.nb; my /= d.nb;
+            const double hx = std::max(0.5 * (hix - lox), 1.0), hy = std::max(0.5 * (hiy - loy), 1.0);
+            d.cx = (float)mx; d.cy = (float)my;
+            d.sx = (float)(1.0 / hx); d.sy = (float)(1.0 / hy);
+            std::vector<double> A((size_t)d.nb * 10);
+            for (int j = 0; j < d.nb; ++j) {
+                // same float coordinate transform the kernel applies to interior pixels
+                const float x = ((float)bx[d.b_off + j] - d.cx) * d.sx, y = ((float)by[d.b_off + j] - d.cy) * d.sy;
+                const double xd = x, yd = y;
+                const double mono[10] = {1, xd, xd * xd, xd * xd * xd, yd, yd * xd, yd * xd * xd,
+                                         yd * yd, yd * yd * xd, yd * yd * yd};
+                for (int k = 0; k < 10; ++k) A[(size_t)k * d.nb + j] = mono[k];
+            }
+            std::vector<float> P;
+            pinv_design(A, d.nb, P);
+            std::memcpy(&Pall[(size_t)d.b_off * 10], P.data(), sizeof(float) * P.size());
+        } else {
+            d.cx = d.cy = 0; d.sx = d.sy = 1;
+        }
+    }
+    // dependency check: does any cluster read a pixel another cluster writes?
+    for (int c = 0; c < nclusters; ++c)
+        if (desc[c].nb >= 10)
+            for (int j = 0; j < desc[c].ni; ++j) owner[iidx[desc[c].i_off + j]] = c;
+    for (int c = 0; c < nclusters && !sequential; ++c)
+        for (int j = 0; j < desc[c].nb; ++j) {
+            const int o = owner[bidx[desc[c].b_off + j]];
+            if (o >= 0 && o != c) { sequential = true; break; }
+        }
+    PatchTables *t = new PatchTables();
+    t->nclusters = nclusters;
+    t->sequential = sequential;
+    hipError_t e = hipMalloc(&t->d_desc, sizeof(ClusterDesc) * std::max(nclusters, 1));
+    if (e == hipSuccess) e = hipMalloc(&t->d_bidx, sizeof(int32_t) * bidx.size());
+    if (e == hipSuccess) e = hipMalloc(&t->d_iidx, sizeof(int32_t) * iidx.size());
+    if (e == hipSuccess) e = hipMalloc(&t->d_P, sizeof(float) * Pall.size());
+    if (e == hipSuccess && nclusters)
+        e = hipMemcpy(t->d_desc, desc.data(), sizeof(ClusterDesc) * nclusters, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(t->d_bidx, bidx.data(), sizeof(int32_t) * bidx.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(t->d_iidx, iidx.data(), sizeof(int32_t) * iidx.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(t->d_P, Pall.data(), sizeof(float) * Pall.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        patch_tables_free(t);
+        return fail(UPSP_ERR_HIP, std::string("patch tables: ") + hipGetErrorString(e));
+    }
+    *out = t;
+    return UPSP_OK;
 }
-void frame_scratch_free(FrameScratch *s) { delete s; }
-int run_frame_stages(FrameScratch *, int, const uint16_t *, int, int64_t, int, int,
-                     const upsp_pipeline_opts &, const float *, const PatchTables *, float *, int,
-                     const void **, int *, hipStream_t)
+
+static int launch_patch(const PatchTables *t, float *imgs, int nimg, int rows, int cols, hipStream_t st)
 {
-    return fail(UPSP_ERR_INVALID, "registration / patch / filter kernels not built yet");
+    if (!t || t->nclusters == 0 || nimg == 0) return UPSP_OK;
+    const size_t npix = (size_t)rows * cols;
+    if (!t->sequential) {
+        hipLaunchKernelGGL(patch_kernel, dim3(t->nclusters, nimg), dim3(256), 0, st, imgs, npix, cols,
+                           t->d_desc, 0, t->d_bidx, t->d_P, t->d_iidx);
+    } else {
+        for (int c = 0; c < t->nclusters; ++c)  // cluster order of the reference (patches.ipp:101)
+            hipLaunchKernelGGL(patch_kernel, dim3(1, nimg), dim3(256), 0, st, imgs, npix, cols,
+                               t->d_desc, c, t->d_bidx, t->d_P, t->d_iidx);
+    }
+    UPSP_HIP_CHECK(hipGetLastError());
+    return UPSP_OK;
+}
+
+// ----------------------------------------------------------- FrameScratch --
+struct FrameScratch {
+    int ncams = 0, batch = 0, rows = 0, cols = 0;
+    uint16_t *warp[kMaxCams] = {nullptr};   // registered u16 frames
+    float *f32[kMaxCams] = {nullptr};       // patched / filtered frames
+    float *ecc_img = nullptr;               // blurred input frames
+    float *tmp = nullptr;                   // filter intermediate (float), also box sums (double)
+    float *tmpl[kMaxCams] = {nullptr};      // blurred ECC templates
+    const float *tmpl_src[kMaxCams] = {nullptr};
+    double *partial = nullptr;
+    EccState *state = nullptr;
+    int *counter = nullptr;
+};
+
+void frame_scratch_free(FrameScratch *s)
+{
+    if (!s) return;
+    for (int c = 0; c < kMaxCams; ++c) {
+        if (s->warp[c]) (void)hipFree(s->warp[c]);
+        if (s->f32[c]) (void)hipFree(s->f32[c]);
+        if (s->tmpl[c]) (void)hipFree(s->tmpl[c]);
+    }
+    if (s->ecc_img) (void)hipFree(s->ecc_img);
+    if (s->tmp) (void)hipFree(s->tmp);
+    if (s->partial) (void)hipFree(s->partial);
+    if (s->state) (void)hipFree(s->state);
+    if (s->counter) (void)hipFree(s->counter);
+    delete s;
+}
+
+void frame_scratch_new_reference(FrameScratch *s, int cam)
+{
+    if (s && cam >= 0 && cam < kMaxCams) s->tmpl_src[cam] = nullptr;
+}
+
+int frame_scratch_ensure(FrameScratch **ps, int ncams, int batch, int rows, int cols, bool need_warp,
+                         bool need_f32)
+{
+    FrameScratch *s = *ps;
+    if (s && (s->ncams != ncams || s->batch < batch || s->rows != rows || s->cols != cols)) {
+        frame_scratch_free(s);
+        s = nullptr;
+    }
+    if (!s) {
+        s = new FrameScratch();
+        s->ncams = ncams; s->batch = batch; s->rows = rows; s->cols = cols;
+        *ps = s;
+    }
+    const size_t n = (size_t)batch * rows * cols;
+    for (int c = 0; c < ncams; ++c) {
+        if (need_warp && !s->warp[c]) UPSP_HIP_CHECK(hipMalloc(&s->warp[c], n * sizeof(uint16_t)));
+        if (need_f32 && !s->f32[c]) UPSP_HIP_CHECK(hipMalloc(&s->f32[c], n * sizeof(float)));
+        if (need_warp && !s->tmpl[c]) UPSP_HIP_CHECK(hipMalloc(&s->tmpl[c], (size_t)rows * cols * sizeof(float)));
+    }
+    if (need_warp && !s->ecc_img) UPSP_HIP_CHECK(hipMalloc(&s->ecc_img, n * sizeof(float)));
+    if (!s->tmp) UPSP_HIP_CHECK(hipMalloc(&s->tmp, n * sizeof(double)));
+    if (need_warp && !s->partial)
+        UPSP_HIP_CHECK(hipMalloc(&s->partial, sizeof(double) * (size_t)batch * kEccBlocks * kEccSums));
+    if (!s->state) UPSP_HIP_CHECK(hipMalloc(&s->state, sizeof(EccState) * (size_t)batch));
+    if (!s->counter) UPSP_HIP_CHECK(hipMalloc(&s->counter, 2 * sizeof(int)));
+    return UPSP_OK;
+}
+
+// ECC registration of nb frames against the blurred template; leaves the warp in state[].
+static int run_ecc(FrameScratch *s, const float *tmpl_blur, const uint16_t *frames, int nb,
+                   int64_t first_frame, int rows, int cols, int max_iters, double eps, hipStream_t st)
+{
+    int rc = launch_gauss<uint16_t>(frames, s->ecc_img, s->tmp, nb, rows, cols, 5, st);
+    if (rc != UPSP_OK) return rc;
+    const dim3 g1((nb + 63) / 64), b1(64);
+    hipLaunchKernelGGL(ecc_init_kernel, g1, b1, 0, st, s->state, nb, (long long)first_frame);
+    hipLaunchKernelGGL(ecc_set_last_rho, g1, b1, 0, st, s->state, nb, eps);
+    int it = 0;
+    while (it < max_iters) {
+        // a few iterations between host checks of the active-frame count
+        const int burst = it == 0 ? 3 : 2;
+        for (int k = 0; k < burst && it < max_iters; ++k, ++it) {
+            hipLaunchKernelGGL(ecc_sums_kernel, dim3(kEccBlocks, nb), dim3(256), 0, st,
+                               (const float *)s->ecc_img, tmpl_blur, rows, cols,
+                               (const EccState *)s->state, s->partial);
+            hipLaunchKernelGGL(ecc_solve_kernel, g1, b1, 0, st, s->state, (const double *)s->partial,
+                               nb, kEccBlocks, max_iters, eps);
+        }
+        int h[2] = {0, 0};
+        UPSP_HIP_CHECK(hipMemsetAsync(s->counter, 0, 2 * sizeof(int), st));
+        hipLaunchKernelGGL(ecc_count_active, dim3(1), dim3(64), 0, st, (const EccState *)s->state, nb,
+                           s->counter);
+        UPSP_HIP_CHECK(hipMemcpyAsync(h, s->counter, sizeof(h), hipMemcpyDeviceToHost, st));
+        UPSP_HIP_CHECK(hipStreamSynchronize(st));
+        if (h[1] > 0)
+            return fail(UPSP_ERR_DIVERGED,
+                        "ECC registration did not converge (cv::findTransformECC would throw)");
+        if (h[0] == 0) break;
+    }
+    UPSP_HIP_CHECK(hipGetLastError());
+    return UPSP_OK;
+}
+
+int run_frame_stages(FrameScratch *s, int cam, const uint16_t *d_frames, int nb, int64_t first_frame,
+                     int rows, int cols, const upsp_pipeline_opts &opts, const float *d_ref,
+                     const PatchTables *patches, float *d_warps, int ncams, const void **img_out,
+                     int *is_f32_out, hipStream_t st)
+{
+    const size_t npix = (size_t)rows * cols;
+    const uint16_t *cur = d_frames;
+    const dim3 pgrid(grid_for_pixels(npix), (unsigned)nb), block(256);
+    if (opts.registration) {
+        if (s->tmpl_src[cam] != d_ref) {  // blurred template, once per reference image
+            int rc = launch_gauss<float>(d_ref, s->tmpl[cam], s->tmp, 1, rows, cols, 5, st);
+            if (rc != UPSP_OK) return rc;
+            s->tmpl_src[cam] = d_ref;
+        }
+        int rc = run_ecc(s, s->tmpl[cam], d_frames, nb, first_frame, rows, cols, opts.ecc_max_iters,
+                         opts.ecc_eps, st);
+        if (rc != UPSP_OK) return rc;
+        hipLaunchKernelGGL(warp_u16_kernel, pgrid, block, 0, st, d_frames, s->warp[cam], rows, cols,
+                           (const EccState *)s->state, opts.interp);
+        if (d_warps)
+            hipLaunchKernelGGL(ecc_export_warps, dim3((nb + 63) / 64), dim3(64), 0, st,
+                               (const EccState *)s->state, nb, d_warps + (size_t)cam * 6, ncams * 6);
+        cur = s->warp[cam];
+    }
+    if (opts.patch || opts.filter) {
+        float *f = s->f32[cam];
+        hipLaunchKernelGGL(u16_to_f32_kernel, dim3(2048), dim3(256), 0, st, cur, f, npix * (size_t)nb);
+        if (opts.patch) {
+            int rc = launch_patch(patches, f, nb, rows, cols, st);
+            if (rc != UPSP_OK) return rc;
+        }
+        if (opts.filter == 1) {
+            int rc = launch_gauss<float>(f, f, s->tmp, nb, rows, cols, opts.filter_size, st);
+            if (rc != UPSP_OK) return rc;
+        } else if (opts.filter == 2) {
+            hipLaunchKernelGGL((box_pass_kernel<true>), pgrid, block, 0, st, (const void *)f,
+                               (void *)s->tmp, rows, cols, opts.filter_size);
+            hipLaunchKernelGGL((box_pass_kernel<false>), pgrid, block, 0, st, (const void *)s->tmp,
+                               (void *)f, rows, cols, opts.filter_size);
+        }
+        *img_out = f;
+        *is_f32_out = 1;
+    } else {
+        *img_out = cur;
+        *is_f32_out = 0;
+    }
+    UPSP_HIP_CHECK(hipGetLastError());
+    return UPSP_OK;
 }
 
 }  // namespace upsp
 
 using namespace upsp;
+
 extern "C" {
-int upsp_register_pixel_u16(const float *, const uint16_t *, int, int, int, double, int,
-                            uint16_t *, float *, void *)
+
+int upsp_register_pixel_u16(const float *d_ref32f, const uint16_t *d_inp, int rows, int cols,
+                            int max_iters, double eps, int interp, uint16_t *d_out, float *h_warp6,
+                            void *stream)
 {
-    return fail(UPSP_ERR_INVALID, "registration kernels not built yet");
+    if (!d_ref32f || !d_inp || !d_out || rows <= 0 || cols <= 0 || max_iters < 1)
+        return fail(UPSP_ERR_INVALID, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    FrameScratch *s = nullptr;
+    int rc = frame_scratch_ensure(&s, 1, 1, rows, cols, true, false);
+    int iters = 0;
+    if (rc == UPSP_OK) rc = launch_gauss<float>(d_ref32f, s->tmpl[0], s->tmp, 1, rows, cols, 5, st);
+    // first_frame = 1: a stand-alone call always registers (psp_process.cpp:1662-1679)
+    if (rc == UPSP_OK) rc = run_ecc(s, s->tmpl[0], d_inp, 1, 1, rows, cols, max_iters, eps, st);
+    if (rc == UPSP_OK) {
+        hipLaunchKernelGGL(warp_u16_kernel, dim3(grid_for_pixels((size_t)rows * cols), 1), dim3(256), 0,
+                           st, d_inp, d_out, rows, cols, (const EccState *)s->state, interp);
+        EccState h;
+        hipError_t e = hipMemcpyAsync(&h, s->state, sizeof(h), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) {
+            rc = fail(UPSP_ERR_HIP, hipGetErrorString(e));
+        } else {
+            if (h_warp6) std::memcpy(h_warp6, h.M, sizeof(h.M));
+            iters = h.iters;
+        }
+    }
+    frame_scratch_free(s);
+    return rc == UPSP_OK ? iters : rc;
 }
-int upsp_blur_f32(const float *, float *, int, int, int, int, void *)
+
+int upsp_blur_f32(const float *d_src, float *d_dst, int rows, int cols, int k, int box, void *stream)
 {
-    return fail(UPSP_ERR_INVALID, "filter kernels not built yet");
+    if (!d_src || !d_dst || rows <= 0 || cols <= 0) return fail(UPSP_ERR_INVALID, "bad argument");
+    if (k < 1 || (k & 1) == 0 || k > kMaxKernel) return fail(UPSP_ERR_INVALID, "filter size must be odd and <= 63");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t npix = (size_t)rows * cols;
+    void *tmp = nullptr;
+    UPSP_HIP_CHECK(hipMalloc(&tmp, npix * sizeof(double)));
+    int rc = UPSP_OK;
+    if (!box) {
+        rc = launch_gauss<float>(d_src, d_dst, (float *)tmp, 1, rows, cols, k, st);
+    } else {
+        const dim3 grid(grid_for_pixels(npix), 1), block(256);
+        hipLaunchKernelGGL((box_pass_kernel<true>), grid, block, 0, st, (const void *)d_src, tmp, rows, cols, k);
+        hipLaunchKernelGGL((box_pass_kernel<false>), grid, block, 0, st, (const void *)tmp, (void *)d_dst, rows, cols, k);
+    }
+    hipError_t e = hipStreamSynchronize(st);
+    (void)hipFree(tmp);
+    if (rc == UPSP_OK && e != hipSuccess) rc = fail(UPSP_ERR_HIP, hipGetErrorString(e));
+    return rc;
 }
-int upsp_patch_f32(float *, int, int, int, const int32_t *, const int32_t *, const int32_t *,
-                   const int32_t *, const int32_t *, const int32_t *, void *)
+
+int upsp_patch_f32(float *d_img, int rows, int cols, int nclusters, const int32_t *h_b_off,
+                   const int32_t *h_bx, const int32_t *h_by, const int32_t *h_i_off,
+                   const int32_t *h_ix, const int32_t *h_iy, void *stream)
 {
-    return fail(UPSP_ERR_INVALID, "patch kernels not built yet");
+    if (!d_img || rows <= 0 || cols <= 0) return fail(UPSP_ERR_INVALID, "bad argument");
+    if (nclusters == 0) return UPSP_OK;
+    PatchTables *t = nullptr;
+    int rc = patch_tables_create(rows, cols, nclusters, h_b_off, h_bx, h_by, h_i_off, h_ix, h_iy, &t);
+    if (rc != UPSP_OK) return rc;
+    rc = launch_patch(t, d_img, 1, rows, cols, (hipStream_t)stream);
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    patch_tables_free(t);
+    if (rc == UPSP_OK && e != hipSuccess) rc = fail(UPSP_ERR_HIP, hipGetErrorString(e));
+    return rc;
 }
-}
+
+}  // extern "C"

@@ -44,6 +44,7 @@ void patch_tables_free(PatchTables *t);
 int frame_scratch_ensure(FrameScratch **s, int ncams, int batch, int rows, int cols,
                          bool need_warp, bool need_f32);
 void frame_scratch_free(FrameScratch *s);
+void frame_scratch_new_reference(FrameScratch *s, int cam);  // ECC template changed
 
 }  // namespace upsp
 

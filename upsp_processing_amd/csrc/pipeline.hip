@@ -177,6 +177,7 @@ int upsp_pipeline_set_reference(upsp_pipeline *p, int cam, const float *d_ref32f
     const size_t bytes = sizeof(float) * (size_t)p->width * p->height;
     if (!p->d_ref[cam]) UPSP_HIP_CHECK(hipMalloc(&p->d_ref[cam], bytes));
     UPSP_HIP_CHECK(hipMemcpy(p->d_ref[cam], d_ref32f, bytes, hipMemcpyDeviceToDevice));
+    upsp::frame_scratch_new_reference(p->scratch, cam);
     return UPSP_OK;
 }
 

@@ -323,3 +323,46 @@ def _alias_f64(ptr, n, owner):
     t = torch.as_tensor(_DevArray(ptr, n, "<f8", owner), device="cuda")
     t._upsp_owner = owner
     return t
+
+
+def register_pixel(ref32f, frame_u16, max_iters=50, eps=1e-3, interp=1):
+    """upsp::register_pixel (cpp/lib/registration.cpp:32-81) for one frame.
+    Returns (registered u16 frame, warp 2x3 float32 numpy, iterations)."""
+    assert ref32f.is_cuda and ref32f.dtype == torch.float32 and ref32f.is_contiguous()
+    assert frame_u16.is_cuda and frame_u16.dtype == torch.uint16 and frame_u16.is_contiguous()
+    h, w = frame_u16.shape
+    out = torch.empty_like(frame_u16)
+    warp = (C.c_float * 6)()
+    rc = lib().upsp_register_pixel_u16(_ptr(ref32f), _ptr(frame_u16), h, w, int(max_iters),
+                                       float(eps), int(interp), _ptr(out), warp, _stream())
+    if rc < 0:
+        check(rc)
+    return out, np.array(list(warp), dtype=np.float32).reshape(2, 3), rc
+
+
+def blur(img32f, k, box=False):
+    """cv::GaussianBlur(img,img,Size(k,k),0) / cv::blur(img,img,Size(k,k)) (psp_process.cpp:1802-1807)."""
+    assert img32f.is_cuda and img32f.dtype == torch.float32 and img32f.is_contiguous()
+    h, w = img32f.shape
+    out = torch.empty_like(img32f)
+    check(lib().upsp_blur_f32(_ptr(img32f), _ptr(out), h, w, int(k), int(bool(box)), _stream()))
+    return out
+
+
+def _cluster_arrays(clusters):
+    b_off, i_off = [0], [0]
+    bx, by, ix, iy = [], [], [], []
+    for cl in clusters:
+        bx += list(cl["bx"]); by += list(cl["by"]); ix += list(cl["ix"]); iy += list(cl["iy"])
+        b_off.append(len(bx)); i_off.append(len(ix))
+    return [np.asarray(a, dtype=np.int32) for a in (b_off, bx, by, i_off, ix, iy)]
+
+
+def patch(img32f, clusters):
+    """PatchClusters<float>::operator() (cpp/lib/patches.ipp:98-165), in place on a f32 image."""
+    assert img32f.is_cuda and img32f.dtype == torch.float32 and img32f.is_contiguous()
+    h, w = img32f.shape
+    arr = _cluster_arrays(clusters)
+    check(lib().upsp_patch_f32(_ptr(img32f), h, w, len(clusters),
+                               *[a.ctypes.data_as(C.c_void_p) for a in arr], _stream()))
+    return img32f
