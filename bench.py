@@ -41,10 +41,13 @@ def parse():
     ap.add_argument("--size", type=int, default=1024, help="frame is size x size")
     ap.add_argument("--small", action="store_true", help="reduced mesh/frames (plumbing check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--model", default="quad", choices=["quad", "uv"],
+                    help="quad: cube-sphere tunnel model (valence <= 6); uv: UV-sphere model with "
+                         "1000-valent polar fans (worst case for per-ray traversal length)")
     return ap.parse_args()
 
 
-def cpu_baseline(verts, tris, cam_dict, size, nframes_step, pix_full, sample_frames=24):
+def cpu_baseline(verts, tris, cam_dict, size, nframes_step, pix_full, sample_frames=256):
     """Oracle (CPU restatement, kind 'port') on a bounded sample of the same workload."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as orc
@@ -57,7 +60,7 @@ def cpu_baseline(verts, tris, cam_dict, size, nframes_step, pix_full, sample_fra
     t_build = time.perf_counter() - t0
     cam = orc.make_camera(cam_dict["K"], cam_dict["dist"], cam_dict["R"], cam_dict["t"], size, size)
     # projection build on a node sample (every k-th node), all cores (OpenMP)
-    k = max(1, verts.shape[0] // 60000)
+    k = 1
     dn = np.zeros(verts.shape[0], np.uint8)
     dn[::k] = 1
     t0 = time.perf_counter()
@@ -114,10 +117,12 @@ def main():
     size = a.size
     F = a.frames
     if a.small:
-        verts, tris = syn.tunnel_model(100, 240, 40, 80)
+        verts, tris = syn.tunnel_model_quad(64, 24)
         F = min(F, 64)
+    elif a.model == "uv":
+        verts, tris = syn.tunnel_model()          # 1 001 520 triangles, 500 766 nodes, polar fans
     else:
-        verts, tris = syn.tunnel_model()          # 1 001 520 triangles, 500 766 nodes
+        verts, tris = syn.tunnel_model_quad()     # 1 001 904 triangles, 500 958 nodes, valence <= 6
     s9, tn = syn.soup(verts, tris)
     nrm = syn.node_normals(verts, tris)
     N = verts.shape[0]

@@ -27,9 +27,11 @@
 //     tie-break (strict `<`, near-child-first order, pspRT.cpp:395,410-419).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cfloat>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "upsp_internal.h"
@@ -47,19 +49,30 @@ int fail(int status, const std::string &msg)
 namespace {
 
 constexpr int kBlock = 256;       // threads per workgroup (4 waves)
-constexpr int kChunk = 256;       // work items taken from the global queue at once
-constexpr int kRefill = 40;       // leave the traversal loop to re-fill below this many live lanes
+constexpr int kChunkMax = 1024;    // largest block of work items taken from the global queue at once
+constexpr int kRefillDefault = 40;  // leave the traversal loop to re-fill below this many live lanes
 constexpr int kDone = INT32_MIN;  // "no current node"
 
 struct Ray {
     float ox, oy, oz;     // rt::Ray::o
     float dx, dy, dz;     // rt::Ray::d
-    float lx, ly, lz;     // Imath::Line3f(o, o+d).dir
-    float ilx, ily, ilz;  // ~1/l (filter only)
     float Sx, Sy, Sz;     // watertight shear (pspRT.cpp:63-65)
     int kx, ky, kz;
     unsigned neg;         // bit a = ray.i[a] < 0 (dirIsNeg, pspRT.cpp:369)
-    bool exact_only;      // some |l| is tiny: skip the reciprocal filter
+    // Box test (Imath::intersects(Box3f, Line3f(o,o+d), ip)) in per-axis MIRRORED form:
+    // an axis whose line direction l is negative is reflected (o -> -o, [lo,hi] ->
+    // [-hi,-lo], l -> -l), which maps the library's `dir < 0` branch onto its `dir > 0`
+    // branch with bit-identical differences, quotients and comparisons.
+    float mox, moy, moz;  // mirrored origin
+    float mlx, mly, mlz;  // |l| (0 for an axis the line does not move along)
+    float ilx, ily, ilz;  // ~1/|l| (filter only)
+    float limx, limy, limz;  // FLT_MAX * |l| (the library's overflow guard)
+    unsigned flip;        // bit a: axis mirrored (l < 0)
+    unsigned zero;        // bit a: l == 0
+    unsigned big;         // bit a: |l| > 1
+    float absSz;          // |Sz|
+    bool prune_ok;        // major axis of d and of l agree in sign -> depth pruning valid
+    bool exact_only;      // some |l| is tiny / not finite: skip the reciprocal filter
 };
 
 __device__ __forceinline__ float pick(float x, float y, float z, int k)
@@ -101,82 +114,120 @@ __device__ __forceinline__ void ray_setup(Ray &r, float ox, float oy, float oz, 
     r.Sx = pick(dx, dy, dz, kx) / dkz;
     r.Sy = pick(dx, dy, dz, ky) / dkz;
     r.Sz = 1.0f / dkz;
+    r.absSz = fabsf(r.Sz);
     r.neg = ((1.0f / dx) < 0.0f ? 1u : 0u) | ((1.0f / dy) < 0.0f ? 2u : 0u) |
             ((1.0f / dz) < 0.0f ? 4u : 0u);
     // Imath::Line3f(o, o + d): dir = ((o+d) - o).normalize()
     float lx = (ox + dx) - ox, ly = (oy + dy) - oy, lz = (oz + dz) - oz;
     float len = imath_length(lx, ly, lz);
     if (len != 0.0f) { lx /= len; ly /= len; lz /= len; }
-    r.lx = lx; r.ly = ly; r.lz = lz;
-    r.ilx = __builtin_amdgcn_rcpf(lx);
-    r.ily = __builtin_amdgcn_rcpf(ly);
-    r.ilz = __builtin_amdgcn_rcpf(lz);
+    r.flip = (lx < 0.0f ? 1u : 0u) | (ly < 0.0f ? 2u : 0u) | (lz < 0.0f ? 4u : 0u);
+    r.zero = (lx == 0.0f ? 1u : 0u) | (ly == 0.0f ? 2u : 0u) | (lz == 0.0f ? 4u : 0u);
+    r.mox = lx < 0.0f ? -ox : ox;
+    r.moy = ly < 0.0f ? -oy : oy;
+    r.moz = lz < 0.0f ? -oz : oz;
+    r.mlx = fabsf(lx); r.mly = fabsf(ly); r.mlz = fabsf(lz);
+    r.big = (r.mlx > 1.0f ? 1u : 0u) | (r.mly > 1.0f ? 2u : 0u) | (r.mlz > 1.0f ? 4u : 0u);
+    r.ilx = __builtin_amdgcn_rcpf(r.mlx);
+    r.ily = __builtin_amdgcn_rcpf(r.mly);
+    r.ilz = __builtin_amdgcn_rcpf(r.mlz);
+    r.limx = FLT_MAX * r.mlx; r.limy = FLT_MAX * r.mly; r.limz = FLT_MAX * r.mlz;
     const float tiny = 1e-18f;
-    r.exact_only = (lx != 0.0f && fabsf(lx) < tiny) || (ly != 0.0f && fabsf(ly) < tiny) ||
-                   (lz != 0.0f && fabsf(lz) < tiny) || !(len == len) || len == 0.0f;
+    r.exact_only = (lx != 0.0f && r.mlx < tiny) || (ly != 0.0f && r.mly < tiny) ||
+                   (lz != 0.0f && r.mlz < tiny) || !(len == len) || len == 0.0f;
+    const float lkz = pick(lx, ly, lz, kz);
+    r.prune_ok = lkz != 0.0f && ((lkz < 0.0f) == (dkz < 0.0f));
 }
 
-// One axis of Imath::intersects(Box3f, Line3f, V3f&) (ImathBoxAlgo.h).  EXACT uses
-// the library's division, otherwise a reciprocal multiply (error <= 2 ulp).
-template <bool EXACT>
-__device__ __forceinline__ bool box_axis(float lo, float hi, float o, float l, float il,
-                                         float &tFront, float &tBack)
+// One axis of the library test in mirrored form (line direction >= 0).  All
+// predicates are computed unconditionally (no early return): the kernel's hot loop
+// stays branch-free.  d?: differences to the far / near plane.
+struct AxisEval {
+    float dB, dF;
+    bool out, inside, okB, okF, front;
+};
+
+__device__ __forceinline__ AxisEval axis_eval(float lo, float hi, float mo, float lim, bool flip,
+                                              bool zero, bool big)
 {
-    const float TMAX = FLT_MAX;
-    if (l == 0.0f) return !(o < lo || o > hi);
-    const bool neg = l < 0.0f;
-    const float far = neg ? lo : hi;
-    const float near = neg ? hi : lo;
-    if (neg ? (o < far) : (o > far)) return false;
-    const float lim = TMAX * l;
-    const float dB = far - o;
-    const bool okB = neg ? (l < -1.0f || dB > lim) : (l > 1.0f || dB < lim);
-    const float tB = EXACT ? dB / l : dB * il;
-    if (okB && tBack > tB) tBack = tB;
-    const bool front = neg ? (o >= near) : (o <= near);
-    const float dF = near - o;
-    const bool okF = neg ? (l < -1.0f || dF > lim) : (l > 1.0f || dF < lim);
-    const float tF = okF ? (EXACT ? dF / l : dF * il) : TMAX;
-    if (front && tFront < tF) tFront = tF;
-    return true;
+    const float mlo = flip ? -hi : lo, mhi = flip ? -lo : hi;
+    AxisEval e;
+    e.dB = mhi - mo;            // >= 0 unless the origin is beyond the far plane
+    e.dF = mlo - mo;            // >= 0 iff the origin is at / before the near plane
+    // bitwise (not short-circuit) logic: keeps the evaluation free of branches
+    const bool beyond = e.dB < 0.0f, before = e.dF > 0.0f;
+    e.out = beyond | (zero & before);
+    e.inside = !(beyond | before);
+    e.okB = !zero & (big | (e.dB < lim));
+    e.okF = big | (e.dF < lim);
+    e.front = !zero & (e.dF >= 0.0f);
+    return e;
 }
 
-template <bool EXACT>
-__device__ __forceinline__ int box_eval(const Ray &r, float lox, float loy, float loz, float hix,
-                                        float hiy, float hiz)
+struct BoxEval {
+    bool accept;     // decided: entered
+    bool undecided;  // filter margin too small -> needs the exact divisions
+};
+
+// Filtered decision with reciprocal multiplies (relative error <= 2 ulp per quotient).
+__device__ __forceinline__ BoxEval box_filter(const Ray &r, float lox, float loy, float loz,
+                                              float hix, float hiy, float hiz, float &dFk)
 {
-    // returns 1 accept, 0 reject, -1 undecided (filter only)
-    float tFront = -1.0f, tBack = FLT_MAX;
-    if (!box_axis<EXACT>(lox, hix, r.ox, r.lx, r.ilx, tFront, tBack)) return 0;
-    if (!box_axis<EXACT>(loy, hiy, r.oy, r.ly, r.ily, tFront, tBack)) return 0;
-    if (!box_axis<EXACT>(loz, hiz, r.oz, r.lz, r.ilz, tFront, tBack)) return 0;
-    if (EXACT) return tFront <= tBack ? 1 : 0;
+    const AxisEval ex = axis_eval(lox, hix, r.mox, r.limx, r.flip & 1u, r.zero & 1u, r.big & 1u);
+    const AxisEval ey = axis_eval(loy, hiy, r.moy, r.limy, r.flip & 2u, r.zero & 2u, r.big & 2u);
+    const AxisEval ez = axis_eval(loz, hiz, r.moz, r.limz, r.flip & 4u, r.zero & 4u, r.big & 4u);
+    dFk = pick(ex.dF, ey.dF, ez.dF, r.kz);
+    const bool inside = ex.inside & ey.inside & ez.inside;
+    const bool out = ex.out | ey.out | ez.out;
+    float tBack = FLT_MAX, tFront = -1.0f;
+    const float bx = ex.dB * r.ilx, by = ey.dB * r.ily, bz = ez.dB * r.ilz;
+    tBack = (ex.okB & (tBack > bx)) ? bx : tBack;
+    tBack = (ey.okB & (tBack > by)) ? by : tBack;
+    tBack = (ez.okB & (tBack > bz)) ? bz : tBack;
+    const float fx = ex.okF ? ex.dF * r.ilx : FLT_MAX;
+    const float fy = ey.okF ? ey.dF * r.ily : FLT_MAX;
+    const float fz = ez.okF ? ez.dF * r.ilz : FLT_MAX;
+    tFront = (ex.front & (tFront < fx)) ? fx : tFront;
+    tFront = (ey.front & (tFront < fy)) ? fy : tFront;
+    tFront = (ez.front & (tFront < fz)) ? fz : tFront;
     const float e = 6e-7f;  // > 2 * (rcp 1 ulp + mul 0.5 ulp)
-    if (tFront + fabsf(tFront) * e <= tBack - tBack * e) return 1;
-    if (tFront - fabsf(tFront) * e > tBack + tBack * e) return 0;
-    return -1;
+    const bool sure_acc = tFront + fabsf(tFront) * e <= tBack - tBack * e;
+    const bool sure_rej = tFront - fabsf(tFront) * e > tBack + tBack * e;
+    BoxEval b;
+    b.accept = inside | (!out & sure_acc);
+    b.undecided = !inside & !out & ((!sure_acc & !sure_rej) | r.exact_only);
+    return b;
+}
+
+// The library's arithmetic (true divisions); only evaluated for undecided boxes.
+__device__ __forceinline__ bool box_exact(const Ray &r, float lox, float loy, float loz, float hix,
+                                       float hiy, float hiz)
+{
+    const AxisEval ex = axis_eval(lox, hix, r.mox, r.limx, r.flip & 1u, r.zero & 1u, r.big & 1u);
+    const AxisEval ey = axis_eval(loy, hiy, r.moy, r.limy, r.flip & 2u, r.zero & 2u, r.big & 2u);
+    const AxisEval ez = axis_eval(loz, hiz, r.moz, r.limz, r.flip & 4u, r.zero & 4u, r.big & 4u);
+    if (ex.inside && ey.inside && ez.inside) return true;
+    if (ex.out || ey.out || ez.out) return false;
+    float tBack = FLT_MAX, tFront = -1.0f;
+    if (ex.okB) { const float t = ex.dB / r.mlx; if (tBack > t) tBack = t; }
+    if (ey.okB) { const float t = ey.dB / r.mly; if (tBack > t) tBack = t; }
+    if (ez.okB) { const float t = ez.dB / r.mlz; if (tBack > t) tBack = t; }
+    if (ex.front) { const float t = ex.okF ? ex.dF / r.mlx : FLT_MAX; if (tFront < t) tFront = t; }
+    if (ey.front) { const float t = ey.okF ? ey.dF / r.mly : FLT_MAX; if (tFront < t) tFront = t; }
+    if (ez.front) { const float t = ez.okF ? ez.dF / r.mlz : FLT_MAX; if (tFront < t) tFront = t; }
+    return tFront <= tBack;
 }
 
 // Imath::intersects(box, Line3f(o,o+d), ip): same accept/reject as the library.
+// (Boxes of the tree are never empty, so isEmpty() is not re-tested per visit.)
 __device__ __forceinline__ bool box_hit(const Ray &r, float lox, float loy, float loz, float hix,
                                         float hiy, float hiz)
 {
-    if (hix < lox || hiy < loy || hiz < loz) return false;  // isEmpty()
-    if (r.ox >= lox && r.ox <= hix && r.oy >= loy && r.oy <= hiy && r.oz >= loz && r.oz <= hiz)
-        return true;  // origin inside (inclusive)
-    int v = r.exact_only ? -1 : box_eval<false>(r, lox, loy, loz, hix, hiy, hiz);
-    if (v < 0) v = box_eval<true>(r, lox, loy, loz, hix, hiy, hiz);
-    return v != 0;
-}
-
-// Distance (ray parameter) of the box's near plane along the ray's major axis.
-__device__ __forceinline__ float near_depth(const Ray &r, float lox, float loy, float loz,
-                                            float hix, float hiy, float hiz)
-{
-    const float lo = pick(lox, loy, loz, r.kz), hi = pick(hix, hiy, hiz, r.kz);
-    const float o = pick(r.ox, r.oy, r.oz, r.kz);
-    const float pl = r.Sz < 0.0f ? hi : lo;
-    return (pl - o) * r.Sz;
+    float dFk;
+    const BoxEval b = box_filter(r, lox, loy, loz, hix, hiy, hiz, dFk);
+    bool acc = b.accept;
+    if (b.undecided) acc = box_exact(r, lox, loy, loz, hix, hiy, hiz);
+    return acc;
 }
 
 struct TriHit {
@@ -242,6 +293,8 @@ struct Scene {
     const float4 *nodes;  // 4 per interior node
     const float4 *tris;   // 3 per triangle slot
     int root_ref;
+    int refill;           // re-fill threshold (live lanes)
+    unsigned chunk;       // work items per queue grab (multiple of 64)
     float rlo[3], rhi[3];
 };
 
@@ -253,11 +306,13 @@ struct Trav {
     int best_slot;  // triangle slot of the closest hit
     bool any;       // rt::BVH::intersect return value
     unsigned n_nodes, n_tris;
+    unsigned ray_nodes, ray_tris;  // STATS: steps of the current ray
 };
 
 __device__ __forceinline__ void trav_begin(Trav &s, const Ray &r, const Scene &sc)
 {
     s.sp = 0;
+    s.ray_nodes = s.ray_tris = 0;
     s.best_t = FLT_MAX;
     s.limit = __builtin_inff();
     s.best_slot = -1;
@@ -281,21 +336,28 @@ __device__ __forceinline__ void trav_pop(Trav &s, const int *stack)
 // queued, until fewer than kRefill lanes of the wave are still busy.
 template <bool ANYHIT, bool STATS>
 __device__ __forceinline__ void trav_run(Trav &s, const Ray &r, const Scene &sc, int *stack,
-                                         bool more)
+                                         bool more, int refill)
 {
     while (s.cur != kDone) {
         // ---- interior nodes: descend until a leaf (or nothing) is current ----
         while (s.cur >= 0) {
             const float4 *np = sc.nodes + 4 * (size_t)s.cur;
             const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
-            if (STATS) ++s.n_nodes;
+            if (STATS) { ++s.n_nodes; ++s.ray_nodes; }
             const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
             const unsigned meta = __float_as_uint(q3.z);
-            bool hL = box_hit(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
-            bool hR = box_hit(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w);
+            float dFl, dFr;
+            const BoxEval bl = box_filter(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, dFl);
+            const BoxEval br = box_filter(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, dFr);
+            bool hL = bl.accept, hR = br.accept;
+            if (__ballot(bl.undecided | br.undecided) != 0ull) {  // rare: grazing contact
+                if (bl.undecided) hL = box_exact(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
+                if (br.undecided) hR = box_exact(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w);
+            }
             if (!ANYHIT) {
-                hL = hL && !(near_depth(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y) > s.limit);
-                hR = hR && !(near_depth(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w) > s.limit);
+                // near plane of the child box along the ray's major axis, as a ray parameter
+                hL = hL & !(r.prune_ok & (dFl * r.absSz > s.limit));
+                hR = hR & !(r.prune_ok & (dFr * r.absSz > s.limit));
             }
             // near child first: dirIsNeg[node->axis] (pspRT.cpp:410-419)
             const bool swap = !(meta & kMetaOrdered) && ((r.neg >> (meta & 3u)) & 1u);
@@ -321,7 +383,7 @@ __device__ __forceinline__ void trav_run(Trav &s, const Ray &r, const Scene &sc,
             for (unsigned i = 0; i < count; ++i) {
                 const float4 *tp = sc.tris + 3 * (size_t)(first + i);
                 const float4 a = tp[0], b = tp[1], c = tp[2];
-                if (STATS) ++s.n_tris;
+                if (STATS) { ++s.n_tris; ++s.ray_tris; }
                 TriHit h;
                 if (tri_test(r, a.x, a.y, a.z, b.x, b.y, b.z, c.x, c.y, c.z, h)) {
                     s.any = true;
@@ -343,7 +405,7 @@ __device__ __forceinline__ void trav_run(Trav &s, const Ray &r, const Scene &sc,
                 trav_pop(s, stack);
             }
         }
-        if (more && __popcll(__ballot(s.cur != kDone)) < kRefill) break;
+        if (more && __popcll(__ballot(s.cur != kDone)) < refill) break;
     }
 }
 
@@ -354,14 +416,24 @@ struct WaveQueue {
     unsigned *head;
     unsigned total;
     unsigned cur, end;
+    unsigned chunk, base;
     bool exhausted;
 };
 
-__device__ __forceinline__ void queue_init(WaveQueue &q, unsigned *head, unsigned total)
+// Every wave owns chunk #wave statically (no atomic storm at launch); further chunks
+// come from the shared counter, offset by the statically assigned range.
+__device__ __forceinline__ void queue_init(WaveQueue &q, unsigned *head, unsigned total,
+                                           unsigned chunk)
 {
     q.head = head;
     q.total = total;
-    q.cur = q.end = 0;
+    q.chunk = chunk;
+    const unsigned waves_per_block = blockDim.x >> 6;
+    const unsigned wave = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
+    q.base = gridDim.x * waves_per_block * chunk;
+    const unsigned long long first = (unsigned long long)wave * chunk;
+    q.cur = first < total ? (unsigned)first : total;
+    q.end = min(q.cur + chunk, total);
     q.exhausted = false;
 }
 
@@ -374,14 +446,15 @@ __device__ __forceinline__ bool queue_take(WaveQueue &q, bool want, unsigned &it
     if (q.cur >= q.end) {
         if (q.exhausted) return false;
         unsigned c = 0;
-        if (lane_id() == 0) c = atomicAdd(q.head, (unsigned)kChunk);
+        if (lane_id() == 0) c = atomicAdd(q.head, q.chunk);
         c = __builtin_amdgcn_readfirstlane(c);
-        if (c >= q.total) {
+        if (c >= q.total - min(q.total, q.base)) {
             q.exhausted = true;
             return false;
         }
+        c += q.base;
         q.cur = c;
-        q.end = min(c + (unsigned)kChunk, q.total);
+        q.end = min(c + q.chunk, q.total);
     }
     const unsigned n_idle = __popcll(idle);
     const unsigned take = min(n_idle, q.end - q.cur);
@@ -460,7 +533,7 @@ __global__ void __launch_bounds__(kBlock)
     extern __shared__ int lds_stack[];
     int *stack = lds_stack + threadIdx.x;
     WaveQueue q;
-    queue_init(q, work, n);
+    queue_init(q, work, n, sc.chunk);
     Ray r;
     Trav s;
     s.cur = kDone;
@@ -487,8 +560,12 @@ __global__ void __launch_bounds__(kBlock)
         if (__ballot(busy) == 0ull) break;
         // ---- traverse ----
         if (busy) {
-            trav_run<ANYHIT, STATS>(s, r, sc, stack, queue_has_more(q));
+            trav_run<ANYHIT, STATS>(s, r, sc, stack, queue_has_more(q), sc.refill);
             if (s.cur == kDone) {
+                if (STATS) {
+                    atomicMax(&work[8], s.ray_nodes);
+                    atomicMax(&work[9], s.ray_tris);
+                }
                 if (ANYHIT) {
                     if (out.hit) out.hit[item] = s.any ? 1 : 0;
                 } else {
@@ -535,45 +612,75 @@ __host__ __device__ inline void project_point(const double *K, const double *k, 
     v = (float)(yd * K[4] + K[5]);
 }
 
-struct NodeJob {
-    unsigned node;
-    int attempt;       // 0 primary ray, 1..6 jittered retries
-    float u, v;        // image point (Point2f)
-    float px, py, pz;  // node position
-};
-
 __device__ __forceinline__ bool tri_has_node(const int32_t *tri_nodes, int prim, int nidx)
 {
     const int32_t *t = tri_nodes + 3 * (size_t)prim;
-    return t[0] == nidx || t[1] == nidx || t[2] == nidx;
+    return (t[0] == nidx) | (t[1] == nidx) | (t[2] == nidx);
 }
 
-template <bool STATS>
+// A visible node: oblique test with the PRIMARY direction, then the matrix entry
+// (psp_process.cpp:298-322).  u, v = image point (Point2f).
+__device__ __forceinline__ void accept_node(const Cam &cam, const float *__restrict__ nodes,
+                                            const float *__restrict__ normals, unsigned node,
+                                            float u, float v, float oblique_thresh,
+                                            int32_t *__restrict__ pix, float *__restrict__ uv)
+{
+    float dx = nodes[3 * (size_t)node] - cam.ox, dy = nodes[3 * (size_t)node + 1] - cam.oy,
+          dz = nodes[3 * (size_t)node + 2] - cam.oz;
+    const float len = imath_length(dx, dy, dz);
+    if (len != 0.0f) { dx /= len; dy /= len; dz /= len; }
+    const float *nn = normals + 3 * (size_t)node;
+    const float cos_theta = nn[0] * dx + nn[1] * dy + nn[2] * dz;
+    const float theta = (float)acos((double)cos_theta);
+    if (theta > oblique_thresh) {
+        const int px_ = (int)roundf(u), py_ = (int)roundf(v);  // :319 std::round
+        const long long idx = (long long)py_ * cam.W + px_;
+        if (idx >= 0 && idx < (long long)cam.W * cam.H) {
+            uv[2 * (size_t)node] = u / (float)cam.W;  // :311-314
+            uv[2 * (size_t)node + 1] = v / (float)cam.H;
+            pix[node] = (int32_t)idx;
+        }
+    }
+}
+
+// Work words of the projection build (upsp_bvh::d_work):
+//   [0] queue head   [2..7] three 64-bit statistics   [8],[9] longest ray (stats)
+//   [10] number of nodes whose primary ray hit a triangle that does not contain them
+constexpr int kWorkRetryCount = 10;
+
+// Phase 0 -- one PRIMARY ray per node (psp_process.cpp:236-267).  Nodes that are hit
+// on a foreign triangle go to the retry list; their image point is parked in uv[].
+// Phase 1 -- the <= 6 jittered retries (psp_process.cpp:269-296) of every listed node
+// as INDEPENDENT rays, six adjacent work items per node.  The reference stops at the
+// first retry that sees the node; the outcome ("any retry sees it") is the same, so
+// all six are cast and the reference's ray count is reconstructed from the bit mask.
+template <bool STATS, int PHASE>
 __global__ void __launch_bounds__(kBlock)
     projection_kernel(Scene sc, Cam cam, const float *__restrict__ nodes,
                       const float *__restrict__ normals, const uint8_t *__restrict__ datanode,
                       const int32_t *__restrict__ tri_nodes, unsigned nnodes,
                       float oblique_thresh, int32_t *__restrict__ pix, float *__restrict__ uv,
+                      unsigned *__restrict__ retry_nodes, unsigned *__restrict__ retry_mask,
                       unsigned *work)
 {
     extern __shared__ int lds_stack[];
     int *stack = lds_stack + threadIdx.x;
+    const unsigned total = PHASE == 0 ? nnodes : work[kWorkRetryCount] * 6u;
     WaveQueue q;
-    queue_init(q, work, nnodes);
+    queue_init(q, work, total, sc.chunk);
     Ray r;
     Trav s;
     s.cur = kDone;
     s.n_nodes = s.n_tris = 0;
-    NodeJob job;
-    job.node = 0; job.attempt = 0; job.u = job.v = 0.f; job.px = job.py = job.pz = 0.f;
-    unsigned my_rays = 0;
+    unsigned item = 0, my_rays = 0;
+    float ju = 0.f, jv = 0.f;
     bool busy = false;
 
     for (;;) {
         for (;;) {
             unsigned it;
             const bool got = queue_take(q, !busy, it);
-            if (got) {
+            if (got && PHASE == 0) {
                 // default: no entry in the sparse matrix, uv = (0,0) (psp_process.cpp:179-182)
                 pix[it] = -1;
                 uv[2 * (size_t)it] = 0.f;
@@ -585,70 +692,85 @@ __global__ void __launch_bounds__(kBlock)
                     project_point(cam.K, cam.dist, cam.R, cam.t, X, Y, Z, u, v);  // :248
                     // upsp::contains(Size, Point2i(pt)) :252 ; Point2f->Point2i = cvRound
                     const int rx = (int)rintf(u), ry = (int)rintf(v);
-                    if (rx >= 0 && ry >= 0 && rx < cam.W && ry < cam.H) {
+                    if ((u == u) & (v == v) & (rx >= 0) & (ry >= 0) & (rx < cam.W) & (ry < cam.H)) {
                         float dx = X - cam.ox, dy = Y - cam.oy, dz = Z - cam.oz;
                         const float len = imath_length(dx, dy, dz);  // .normalize() :256
                         if (len != 0.0f) { dx /= len; dy /= len; dz /= len; }
                         ray_setup(r, cam.ox, cam.oy, cam.oz, dx, dy, dz);
                         trav_begin(s, r, sc);
-                        job.node = it; job.attempt = 0; job.u = u; job.v = v;
-                        job.px = X; job.py = Y; job.pz = Z;
+                        item = it; ju = u; jv = v;
                         busy = true;
                         ++my_rays;
                     }
                 }
+            }
+            if (got && PHASE == 1) {
+                // retry k of listed node: pos +- 1e-4 on one axis, UN-normalised direction
+                const unsigned node = retry_nodes[it / 6u];
+                const int k = (int)(it % 6u);
+                const float L = 1e-4f;
+                const float sgn = (k & 1) ? L : -L;
+                const float qx = nodes[3 * (size_t)node] + ((k >> 1) == 0 ? sgn : 0.0f);
+                const float qy = nodes[3 * (size_t)node + 1] + ((k >> 1) == 1 ? sgn : 0.0f);
+                const float qz = nodes[3 * (size_t)node + 2] + ((k >> 1) == 2 ? sgn : 0.0f);
+                ray_setup(r, cam.ox, cam.oy, cam.oz, qx - cam.ox, qy - cam.oy, qz - cam.oz);
+                trav_begin(s, r, sc);
+                item = it;
+                busy = true;
+                ++my_rays;
             }
             if (__ballot(!busy) == 0ull || !queue_has_more(q)) break;
         }
         if (__ballot(busy) == 0ull) break;
 
         if (busy) {
-            trav_run<false, STATS>(s, r, sc, stack, queue_has_more(q));
+            trav_run<false, STATS>(s, r, sc, stack, queue_has_more(q), sc.refill);
             if (s.cur == kDone) {
+                busy = false;
+                const unsigned node = PHASE == 0 ? item : retry_nodes[item / 6u];
                 bool visible = false;
                 if (s.any && s.best_slot >= 0) {
                     const int prim = __float_as_int(sc.tris[3 * (size_t)s.best_slot].w);
-                    visible = tri_has_node(tri_nodes, prim, (int)job.node);  // :263-267
+                    visible = tri_has_node(tri_nodes, prim, (int)node);  // :263-267 / :289-294
                 }
-                const bool primary_missed = (job.attempt == 0) && !s.any;  // :261
-                if (visible) {
-                    // oblique test with the PRIMARY direction (:298-306)
-                    float dx = job.px - cam.ox, dy = job.py - cam.oy, dz = job.pz - cam.oz;
-                    const float len = imath_length(dx, dy, dz);
-                    if (len != 0.0f) { dx /= len; dy /= len; dz /= len; }
-                    const float *nn = normals + 3 * (size_t)job.node;
-                    const float cos_theta = nn[0] * dx + nn[1] * dy + nn[2] * dz;
-                    const float theta = (float)acos((double)cos_theta);
-                    if (theta > oblique_thresh) {
-                        const int px_ = (int)roundf(job.u), py_ = (int)roundf(job.v);  // :319
-                        const long long idx = (long long)py_ * cam.W + px_;
-                        if (idx >= 0 && idx < (long long)cam.W * cam.H) {
-                            uv[2 * (size_t)job.node] = job.u / (float)cam.W;  // :311-314
-                            uv[2 * (size_t)job.node + 1] = job.v / (float)cam.H;
-                            pix[job.node] = (int32_t)idx;
-                        }
+                if (PHASE == 0) {
+                    if (visible) {
+                        accept_node(cam, nodes, normals, node, ju, jv, oblique_thresh, pix, uv);
+                    } else if (s.any) {  // hit something else: jittered retries (a miss: :261)
+                        const unsigned slot = atomicAdd(&work[kWorkRetryCount], 1u);
+                        retry_nodes[slot] = node;
+                        retry_mask[slot] = 0u;
+                        uv[2 * (size_t)node] = ju;  // parked for phase 2
+                        uv[2 * (size_t)node + 1] = jv;
                     }
-                    busy = false;
-                } else if (primary_missed || job.attempt >= 6) {
-                    busy = false;
-                } else {
-                    // next jittered retry, un-normalised direction (:270-295)
-                    const int k = job.attempt;  // 0..5
-                    ++job.attempt;
-                    const float L = 1e-4f;
-                    const float sgn = (k & 1) ? L : -L;
-                    const float sx = (k >> 1) == 0 ? sgn : 0.0f;
-                    const float sy = (k >> 1) == 1 ? sgn : 0.0f;
-                    const float sz = (k >> 1) == 2 ? sgn : 0.0f;
-                    const float qx = job.px + sx, qy = job.py + sy, qz = job.pz + sz;
-                    ray_setup(r, cam.ox, cam.oy, cam.oz, qx - cam.ox, qy - cam.oy, qz - cam.oz);
-                    trav_begin(s, r, sc);
-                    ++my_rays;
+                } else if (visible) {
+                    atomicOr(&retry_mask[item / 6u], 1u << (item % 6u));
                 }
             }
         }
     }
-    flush_stats(work, STATS ? s.n_nodes : 0u, STATS ? s.n_tris : 0u, my_rays);
+    flush_stats(work, STATS ? s.n_nodes : 0u, STATS ? s.n_tris : 0u, PHASE == 0 ? my_rays : 0u);
+}
+
+// Phase 2: retry outcome per listed node + the reference's ray count
+// (1 + index of the first successful retry, or 6).
+__global__ void projection_finish_kernel(Cam cam, const float *__restrict__ nodes,
+                                         const float *__restrict__ normals, float oblique_thresh,
+                                         int32_t *__restrict__ pix, float *__restrict__ uv,
+                                         const unsigned *__restrict__ retry_nodes,
+                                         const unsigned *__restrict__ retry_mask, unsigned *work)
+{
+    const unsigned count = work[kWorkRetryCount];
+    unsigned rays = 0;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        const unsigned node = retry_nodes[i], mask = retry_mask[i];
+        const float u = uv[2 * (size_t)node], v = uv[2 * (size_t)node + 1];
+        uv[2 * (size_t)node] = 0.f;
+        uv[2 * (size_t)node + 1] = 0.f;
+        rays += mask ? (unsigned)__ffs((int)mask) : 6u;
+        if (mask) accept_node(cam, nodes, normals, node, u, v, oblique_thresh, pix, uv);
+    }
+    flush_stats(work, 0u, 0u, rays);
 }
 
 __global__ void nodecount_kernel(const int32_t *__restrict__ pix, unsigned nnodes,
@@ -667,6 +789,12 @@ __global__ void saturate_kernel(const unsigned *__restrict__ counts, unsigned n,
 // ------------------------------------------------------------------------
 //  host side
 // ------------------------------------------------------------------------
+int env_int(const char *name, int dflt)
+{
+    const char *v = std::getenv(name);
+    return v ? std::atoi(v) : dflt;
+}
+
 int stack_entries(const upsp_bvh *b)
 {
     // LDS stack depth per thread: tree height rounded up to a multiple of 8, >= 8
@@ -675,12 +803,18 @@ int stack_entries(const upsp_bvh *b)
     return d < 8 ? 8 : d;
 }
 
-Scene make_scene(const upsp_bvh *b)
+Scene make_scene(const upsp_bvh *b, size_t items, int grid)
 {
     Scene sc;
+    // chunk: ~1/2 of a wave's fair share, multiple of 64, in [64, kChunkMax]
+    size_t share = items / ((size_t)grid * (kBlock / 64) * 2 + 1);
+    share = (share / 64) * 64;
+    sc.chunk = (unsigned)std::min<size_t>(std::max<size_t>(share, 64), kChunkMax);
     sc.nodes = reinterpret_cast<const float4 *>(b->d_nodes);
     sc.tris = reinterpret_cast<const float4 *>(b->d_tris);
     sc.root_ref = b->root_ref;
+    static const int refill = env_int("UPSP_REFILL", kRefillDefault);
+    sc.refill = refill;
     for (int a = 0; a < 3; ++a) {
         sc.rlo[a] = b->root_min[a];
         sc.rhi[a] = b->root_max[a];
@@ -711,7 +845,8 @@ int grid_for(size_t items, size_t lds_bytes)
 {
     const int cus = props().cus > 0 ? props().cus : 256;
     int per_cu = (int)((160u * 1024u) / (lds_bytes ? lds_bytes : 1));
-    if (per_cu > 8) per_cu = 8;
+    static const int cap_per_cu = env_int("UPSP_BLOCKS_PER_CU", 8);
+    if (per_cu > cap_per_cu) per_cu = cap_per_cu;
     if (per_cu < 1) per_cu = 1;
     size_t want = (items + kBlock - 1) / kBlock;
     size_t cap = (size_t)cus * (size_t)per_cu;
@@ -722,8 +857,12 @@ int grid_for(size_t items, size_t lds_bytes)
 int read_stats(upsp_bvh *b, hipStream_t st)
 {
     unsigned long long h[3];
+    unsigned mx[2];
     UPSP_HIP_CHECK(hipMemcpyAsync(h, b->d_work + 2, sizeof(h), hipMemcpyDeviceToHost, st));
+    UPSP_HIP_CHECK(hipMemcpyAsync(mx, b->d_work + 8, sizeof(mx), hipMemcpyDeviceToHost, st));
     UPSP_HIP_CHECK(hipStreamSynchronize(st));
+    if (std::getenv("UPSP_TRACE_STATS"))
+        std::fprintf(stderr, "[upsp] longest ray: %u node steps, %u triangle tests\n", mx[0], mx[1]);
     b->last_stats[0] = h[0];
     b->last_stats[1] = h[1];
     b->last_stats[2] = h[2];
@@ -739,13 +878,13 @@ int launch_cast(const upsp_bvh *cb, const float *d_org, int org_stride, const fl
     if (n == 0) return UPSP_OK;
     if (!d_org || !d_dir) return fail(UPSP_ERR_INVALID, "null ray buffers");
     if (org_stride != 0 && org_stride != 3) return fail(UPSP_ERR_INVALID, "org_stride must be 0 or 3");
-    if (n > 0xFFFFFF00ull - kChunk) return fail(UPSP_ERR_INVALID, "too many rays in one call");
+    if (n > 0xF0000000ull) return fail(UPSP_ERR_INVALID, "too many rays in one call");
     const int entries = stack_entries(b);
     if (entries > 64) return fail(UPSP_ERR_DEPTH, "BVH deeper than 64 levels");
     const size_t lds = (size_t)entries * kBlock * sizeof(int);
-    UPSP_HIP_CHECK(hipMemsetAsync(b->d_work, 0, 8 * sizeof(unsigned), st));
+    UPSP_HIP_CHECK(hipMemsetAsync(b->d_work, 0, 16 * sizeof(unsigned), st));
     const int grid = grid_for(n, lds);
-    const Scene sc = make_scene(b);
+    const Scene sc = make_scene(b, n, grid);
     if (b->stats_on)
         hipLaunchKernelGGL((cast_kernel<ANYHIT, true>), dim3(grid), dim3(kBlock), lds, st, sc,
                            d_org, org_stride, d_dir, (unsigned)n, out, b->d_work);
@@ -855,12 +994,12 @@ int upsp_bvh_create(const float *h_tris9, size_t ntris, upsp_bvh **out)
     const size_t tb = hb.tris.size() * sizeof(GpuTri);
     hipError_t e = hipMalloc(&b->d_nodes, nb);
     if (e == hipSuccess) e = hipMalloc(&b->d_tris, tb);
-    if (e == hipSuccess) e = hipMalloc(&b->d_work, 8 * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc(&b->d_work, 16 * sizeof(unsigned));
     if (e == hipSuccess && !hb.nodes.empty())
         e = hipMemcpy(b->d_nodes, hb.nodes.data(), hb.nodes.size() * sizeof(GpuNode),
                       hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(b->d_tris, hb.tris.data(), tb, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemset(b->d_work, 0, 8 * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemset(b->d_work, 0, 16 * sizeof(unsigned));
     if (e != hipSuccess) {
         upsp_bvh_destroy(b);
         return fail(UPSP_ERR_HIP, std::string("BVH upload: ") + hipGetErrorString(e));
@@ -889,6 +1028,8 @@ void upsp_bvh_destroy(upsp_bvh *b)
     if (b->d_nodes) (void)hipFree(b->d_nodes);
     if (b->d_tris) (void)hipFree(b->d_tris);
     if (b->d_work) (void)hipFree(b->d_work);
+    if (b->d_retry_nodes) (void)hipFree(b->d_retry_nodes);
+    if (b->d_retry_mask) (void)hipFree(b->d_retry_mask);
     delete b;
 }
 
@@ -980,7 +1121,7 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
     if (!d_nodes || !d_normals || !d_tri_nodes || !d_pix || !d_uv)
         return fail(UPSP_ERR_INVALID, "null device buffer");
     if (cam->width <= 0 || cam->height <= 0) return fail(UPSP_ERR_INVALID, "bad image size");
-    if (nnodes > 0xFFFFFF00ull - kChunk) return fail(UPSP_ERR_INVALID, "too many nodes");
+    if (nnodes > 0xF0000000ull) return fail(UPSP_ERR_INVALID, "too many nodes");
     hipStream_t st = (hipStream_t)stream;
     const int entries = stack_entries(b);
     if (entries > 64) return fail(UPSP_ERR_DEPTH, "BVH deeper than 64 levels");
@@ -999,17 +1140,34 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
     c.W = cam->width;
     c.H = cam->height;
 
-    UPSP_HIP_CHECK(hipMemsetAsync(b->d_work, 0, 8 * sizeof(unsigned), st));
+    // retry list: worst case every node
+    if (b->retry_capacity < nnodes) {
+        if (b->d_retry_nodes) (void)hipFree(b->d_retry_nodes);
+        if (b->d_retry_mask) (void)hipFree(b->d_retry_mask);
+        b->d_retry_nodes = b->d_retry_mask = nullptr;
+        b->retry_capacity = 0;
+        UPSP_HIP_CHECK(hipMalloc(&b->d_retry_nodes, sizeof(unsigned) * nnodes));
+        UPSP_HIP_CHECK(hipMalloc(&b->d_retry_mask, sizeof(unsigned) * nnodes));
+        b->retry_capacity = nnodes;
+    }
+    UPSP_HIP_CHECK(hipMemsetAsync(b->d_work, 0, 16 * sizeof(unsigned), st));
     const int grid = grid_for(nnodes, lds);
-    const Scene sc = make_scene(b);
-    if (b->stats_on)
-        hipLaunchKernelGGL((projection_kernel<true>), dim3(grid), dim3(kBlock), lds, st, sc, c,
-                           d_nodes, d_normals, d_datanode, d_tri_nodes, (unsigned)nnodes,
-                           oblique_thresh, d_pix, d_uv, b->d_work);
-    else
-        hipLaunchKernelGGL((projection_kernel<false>), dim3(grid), dim3(kBlock), lds, st, sc, c,
-                           d_nodes, d_normals, d_datanode, d_tri_nodes, (unsigned)nnodes,
-                           oblique_thresh, d_pix, d_uv, b->d_work);
+    const Scene sc = make_scene(b, nnodes, grid);
+    // phase 1 runs over 6 x (listed nodes), a count only the device knows: full
+    // persistent grid, chunk sized for the typical case (half of the nodes listed)
+    const int grid1 = grid_for(6 * nnodes, lds);
+    Scene sc1 = make_scene(b, 3 * nnodes, grid1);
+#define UPSP_LAUNCH_PROJ(STATS, PHASE, G, SC)                                                    \
+    hipLaunchKernelGGL((projection_kernel<STATS, PHASE>), dim3(G), dim3(kBlock), lds, st, SC, c, \
+                       d_nodes, d_normals, d_datanode, d_tri_nodes, (unsigned)nnodes,           \
+                       oblique_thresh, d_pix, d_uv, b->d_retry_nodes, b->d_retry_mask, b->d_work)
+    if (b->stats_on) UPSP_LAUNCH_PROJ(true, 0, grid, sc); else UPSP_LAUNCH_PROJ(false, 0, grid, sc);
+    UPSP_HIP_CHECK(hipMemsetAsync(b->d_work, 0, sizeof(unsigned), st));  // queue head
+    if (b->stats_on) UPSP_LAUNCH_PROJ(true, 1, grid1, sc1); else UPSP_LAUNCH_PROJ(false, 1, grid1, sc1);
+#undef UPSP_LAUNCH_PROJ
+    hipLaunchKernelGGL(projection_finish_kernel, dim3(256), dim3(256), 0, st, c, d_nodes, d_normals,
+                       oblique_thresh, d_pix, d_uv, (const unsigned *)b->d_retry_nodes,
+                       (const unsigned *)b->d_retry_mask, b->d_work);
     UPSP_HIP_CHECK(hipGetLastError());
 
     if (d_nodecount) {

@@ -68,7 +68,9 @@ void build_bvh(const float *tris9, size_t ntris, HostBvh &out);
 struct upsp_bvh {
     upsp::GpuNode *d_nodes = nullptr;
     upsp::GpuTri *d_tris = nullptr;
-    uint32_t *d_work = nullptr;   // [0] work-queue head, [2..7] 64-bit stats
+    uint32_t *d_work = nullptr;   // [0] work-queue head, [2..7] 64-bit stats, [8..10] see raycast.hip
+    uint32_t *d_retry_nodes = nullptr, *d_retry_mask = nullptr;  // projection-build retry list
+    size_t retry_capacity = 0;
     int32_t root_ref = 0;
     float root_min[3], root_max[3];
     upsp_bvh_info info;

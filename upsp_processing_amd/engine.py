@@ -162,9 +162,9 @@ def projection_weights(pix, nodes, normals, centers, mode="average_view"):
     w = torch.ones((ncams, n), dtype=torch.float32, device="cuda")
     centers = np.ascontiguousarray(centers, dtype=np.float64).reshape(ncams, 3)
     m = {"best_view": 0, "average_view": 1}[mode]
-    check(lib().upsp_projection_weights(ncams, n, _ptr(pix), _ptr(w),
-                                        _ptr(_dev(nodes, torch.float32)),
-                                        _ptr(_dev(normals, torch.float32)),
+    d_nodes = _dev(nodes, torch.float32)      # keep both alive until the launch is queued
+    d_normals = _dev(normals, torch.float32)
+    check(lib().upsp_projection_weights(ncams, n, _ptr(pix), _ptr(w), _ptr(d_nodes), _ptr(d_normals),
                                         centers.ctypes.data_as(C.c_void_p), m, _stream()))
     return w
 

@@ -32,6 +32,37 @@ def uv_sphere(nlat, nlon, radius=1.0, scale=(1.0, 1.0, 1.0), offset=(0.0, 0.0, 0
     return verts.astype(np.float32), np.concatenate(tris).astype(np.int32)
 
 
+def cube_sphere(m, radius=1.0, scale=(1.0, 1.0, 1.0), offset=(0.0, 0.0, 0.0)):
+    """Sphere from a subdivided cube (m x m quads per face, 12 m^2 triangles, 6 m^2 + 2
+    vertices, valence <= 6 everywhere), counter-clockwise seen from outside."""
+    g = np.arange(m + 1)
+    a, b = np.meshgrid(g, g, indexing="ij")
+    a, b = a.ravel(), b.ravel()
+    zero, full = np.zeros_like(a), np.full_like(a, m)
+    # (lattice point, (du, dv)) with du x dv pointing outward
+    faces = [(np.stack([full, a, b], 1)), (np.stack([zero, b, a], 1)),
+             (np.stack([b, full, a], 1)), (np.stack([a, zero, b], 1)),
+             (np.stack([a, b, full], 1)), (np.stack([b, a, zero], 1))]
+    pts = np.concatenate(faces)
+    key = (pts[:, 0] * (m + 1) + pts[:, 1]) * (m + 1) + pts[:, 2]
+    uniq, first, inv = np.unique(key, return_index=True, return_inverse=True)
+    lattice = pts[first].astype(np.float64) / m * 2.0 - 1.0
+    verts = lattice / np.linalg.norm(lattice, axis=1, keepdims=True)
+    verts = verts * radius * np.asarray(scale)[None] + np.asarray(offset)[None]
+    i, j = np.meshgrid(np.arange(m), np.arange(m), indexing="ij")
+    i, j = i.ravel(), j.ravel()
+    tris = []
+    for f in range(6):
+        base = f * (m + 1) ** 2
+        p00 = inv[base + i * (m + 1) + j]
+        p10 = inv[base + (i + 1) * (m + 1) + j]
+        p11 = inv[base + (i + 1) * (m + 1) + j + 1]
+        p01 = inv[base + i * (m + 1) + j + 1]
+        tris.append(np.stack([p00, p10, p11], 1))
+        tris.append(np.stack([p00, p11, p01], 1))
+    return verts.astype(np.float32), np.concatenate(tris).astype(np.int32)
+
+
 def merge_meshes(parts):
     verts, tris, base = [], [], 0
     for v, t in parts:
@@ -42,12 +73,22 @@ def merge_meshes(parts):
 
 
 def tunnel_model(nlat=400, nlon=1000, blat=160, blon=320):
-    """'Wind-tunnel model': sphere stretched x6 along x plus two offset booster
-    ellipsoids that occlude part of the body.  Defaults: 1 001 520 triangles,
-    500 766 nodes."""
+    """'Wind-tunnel model' from UV spheres (polar fans: two vertices of valence nlon):
+    sphere stretched x6 along x plus two offset booster ellipsoids that occlude part of
+    the body.  Defaults: 1 001 520 triangles, 500 766 nodes."""
     body = uv_sphere(nlat, nlon, 1.0, scale=(6.0, 1.0, 1.0))
     b1 = uv_sphere(blat, blon, 0.45, scale=(5.0, 1.0, 1.0), offset=(-1.0, 1.25, 0.35))
     b2 = uv_sphere(blat, blon, 0.45, scale=(5.0, 1.0, 1.0), offset=(-1.0, -1.25, 0.35))
+    return merge_meshes([body, b1, b2])
+
+
+def tunnel_model_quad(m=258, mb=92):
+    """'Wind-tunnel model' from cube spheres (structured-grid-like, valence <= 6): the
+    same body + two boosters layout.  Defaults: 12*(258^2 + 2*92^2) = 1 001 904 triangles,
+    500 958 nodes."""
+    body = cube_sphere(m, 1.0, scale=(6.0, 1.0, 1.0))
+    b1 = cube_sphere(mb, 0.45, scale=(5.0, 1.0, 1.0), offset=(-1.0, 1.25, 0.35))
+    b2 = cube_sphere(mb, 0.45, scale=(5.0, 1.0, 1.0), offset=(-1.0, -1.25, 0.35))
     return merge_meshes([body, b1, b2])
 
 
