@@ -141,7 +141,8 @@ def main():
     shard = D.Shard(F * world, N, rank, world)
     pipe = engine.FramePipeline(1, size, size, N)
     rows_t = torch.empty((N, F), dtype=torch.float32, device="cuda")
-    series = torch.empty((shard.node_count[rank], F * world), dtype=torch.float32, device="cuda")
+    series = (torch.empty((shard.node_count[rank], F * world), dtype=torch.float32, device="cuda")
+              if world > 1 else None)
     torch.cuda.synchronize()
 
     ev = lambda: torch.cuda.Event(enable_timing=True)

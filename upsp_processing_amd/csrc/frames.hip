@@ -170,6 +170,73 @@ __global__ void __launch_bounds__(256)
     sumsq[n] += ss;
 }
 
+// Fused gather + accumulate + transpose for a sub-batch of <= 64 frames.
+// A workgroup owns 64 consecutive nodes.  Phase 1: lane = node, wave g gathers frames
+// g, g+4, ... into an LDS tile and keeps its part of the double sums.  Phase 2: the
+// tile is written node-major (256-byte rows of the [N x F] time series =
+// intensity_transpose layout, psp_process.cpp:2027-2032) and, if requested,
+// frame-major (intensity_buf rows) -- both fully coalesced, no second pass over HBM.
+template <int NCAMS>
+__global__ void __launch_bounds__(256)
+    gather_tile_kernel(GatherArgs a, const uint8_t *__restrict__ skipped, unsigned nnodes,
+                       int nframes, float *__restrict__ rows, float *__restrict__ rows_t,
+                       long long ld_t, double *__restrict__ sum, double *__restrict__ sumsq)
+{
+    __shared__ float tile[64][65];        // [frame][node]
+    __shared__ double part[2][4][64];     // [sum|sumsq][wave][node]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned n0 = blockIdx.x * 64u, n = n0 + lane;
+    const int nc = NCAMS > 0 ? NCAMS : a.ncams;
+    const bool live = n < nnodes;
+    int32_t px[NCAMS > 0 ? NCAMS : kMaxCams];
+    float w[NCAMS > 0 ? NCAMS : kMaxCams];
+#pragma unroll
+    for (int c = 0; c < nc; ++c) {
+        px[c] = live ? a.pix[c][n] : -1;
+        w[c] = (live && a.weight[c]) ? a.weight[c][n] : 1.0f;
+    }
+    const bool skip = live && skipped && skipped[n];
+    const float qnan = __builtin_nanf("");
+    double s = 0.0, ss = 0.0;
+#pragma unroll 4
+    for (int f = wave; f < nframes; f += 4) {
+        float sol = 0.0f;
+#pragma unroll
+        for (int c = 0; c < nc; ++c) {
+            float v = 0.0f;
+            if (px[c] >= 0) {
+                const size_t off = (size_t)f * a.npix + (size_t)px[c];
+                const float pxv = a.is_f32[c] ? reinterpret_cast<const float *>(a.img[c])[off]
+                                              : (float)reinterpret_cast<const uint16_t *>(a.img[c])[off];
+                v = 0.0f + w[c] * pxv;
+            }
+            sol = (c == 0) ? v : sol + v;
+        }
+        if (skip) sol = qnan;
+        s += (double)sol;
+        ss += (double)(sol * sol);
+        tile[f][lane] = sol;
+    }
+    part[0][wave][lane] = s;
+    part[1][wave][lane] = ss;
+    __syncthreads();
+    if (wave == 0 && live) {
+        // fixed order -> bit-reproducible accumulators
+        sum[n] += ((part[0][0][lane] + part[0][1][lane]) + part[0][2][lane]) + part[0][3][lane];
+        sumsq[n] += ((part[1][0][lane] + part[1][1][lane]) + part[1][2][lane]) + part[1][3][lane];
+    }
+    if (rows_t) {  // lane = frame, wave g writes nodes g, g+4, ...: 256-byte row segments
+        for (int j = wave; j < 64; j += 4) {
+            const unsigned nn = n0 + (unsigned)j;
+            if (nn < nnodes && lane < nframes) rows_t[(long long)nn * ld_t + lane] = tile[lane][j];
+        }
+    }
+    if (rows) {    // lane = node, wave g writes frames g, g+4, ...
+        for (int f = wave; f < nframes; f += 4)
+            if (live) rows[(size_t)f * nnodes + n] = tile[f][lane];
+    }
+}
+
 __global__ void finals_kernel(const double *__restrict__ sum, const double *__restrict__ sumsq,
                               unsigned nnodes, double nframes, float *__restrict__ avg,
                               float *__restrict__ rms)
@@ -315,6 +382,20 @@ int launch_gather(const PipelineGather &g, hipStream_t st)
         a.weight[c] = g.weight[c];
         a.is_f32[c] = g.is_f32[c];
     }
+    if (g.nframes <= 64) {
+        const dim3 tgrid((unsigned)((g.nnodes + 63) / 64)), tblock(256);
+        if (g.ncams == 1)
+            hipLaunchKernelGGL((gather_tile_kernel<1>), tgrid, tblock, 0, st, a, g.skipped,
+                               (unsigned)g.nnodes, g.nframes, g.rows, g.rows_t, (long long)g.ld_t,
+                               g.sum, g.sumsq);
+        else
+            hipLaunchKernelGGL((gather_tile_kernel<0>), tgrid, tblock, 0, st, a, g.skipped,
+                               (unsigned)g.nnodes, g.nframes, g.rows, g.rows_t, (long long)g.ld_t,
+                               g.sum, g.sumsq);
+        UPSP_HIP_CHECK(hipGetLastError());
+        return UPSP_OK;
+    }
+    if (g.rows_t) return fail(UPSP_ERR_INVALID, "transposed output needs sub-batches of <= 64 frames");
     const dim3 grid((unsigned)((g.nnodes + 255) / 256)), block(256);
     if (g.ncams == 1)
         hipLaunchKernelGGL((gather_kernel<1>), grid, block, 0, st, a, g.skipped, (unsigned)g.nnodes,

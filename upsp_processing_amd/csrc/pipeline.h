@@ -23,6 +23,8 @@ struct PipelineGather {
     const float *weight[kMaxCams] = {nullptr};
     const uint8_t *skipped = nullptr;
     float *rows = nullptr;  // [nframes][nnodes], may be null
+    float *rows_t = nullptr;  // node-major: rows_t[n*ld_t + f], may be null
+    int64_t ld_t = 0;
     double *sum = nullptr, *sumsq = nullptr;
 };
 

@@ -114,7 +114,7 @@ int upsp_pipeline_create(int ncams, int width, int height, size_t nnodes,
                              (2 + ((p->opts.patch || p->opts.filter) ? 4 : 0) +
                               (p->opts.registration ? 2 : 0));
     size_t b = (128u << 20) / std::max<size_t>(per_frame, 1);
-    p->batch = (int)std::min<size_t>(std::max<size_t>(b, 1), 256);
+    p->batch = (int)std::min<size_t>(std::max<size_t>(b, 1), 64);  // one gather tile = 64 frames
     *out = p;
     return UPSP_OK;
 }
@@ -254,11 +254,6 @@ int upsp_pipeline_process(upsp_pipeline *p, const uint16_t *const *d_frames, int
                                             p->opts.registration != 0, need_f32);
         if (rc != UPSP_OK) return rc;
     }
-    // scratch rows for the transposed output when the caller does not want rows
-    float *rows_tmp = nullptr;
-    if (d_rows_t && !d_rows) {
-        UPSP_HIP_CHECK(hipMalloc(&rows_tmp, sizeof(float) * p->nnodes * (size_t)std::min(B, nframes)));
-    }
     int rc = UPSP_OK;
     for (int f0 = 0; f0 < nframes && rc == UPSP_OK; f0 += B) {
         const int nb = std::min(B, nframes - f0);
@@ -270,7 +265,9 @@ int upsp_pipeline_process(upsp_pipeline *p, const uint16_t *const *d_frames, int
         g.skipped = p->d_skipped;
         g.sum = p->d_sum;
         g.sumsq = p->d_sumsq;
-        g.rows = d_rows ? d_rows + (size_t)f0 * p->nnodes : rows_tmp;
+        g.rows = d_rows ? d_rows + (size_t)f0 * p->nnodes : nullptr;
+        g.rows_t = d_rows_t ? d_rows_t + col0 + f0 : nullptr;
+        g.ld_t = ld_t;
         for (int c = 0; c < p->ncams && rc == UPSP_OK; ++c) {
             uint16_t *frames = const_cast<uint16_t *>(d_frames[c]) + (size_t)f0 * npix;
             if (p->opts.hot_enable) {  // psp_process.cpp:1772
@@ -297,12 +294,6 @@ int upsp_pipeline_process(upsp_pipeline *p, const uint16_t *const *d_frames, int
             g.weight[c] = p->d_weight[c];
         }
         if (rc == UPSP_OK) rc = launch_gather(g, st);
-        if (rc == UPSP_OK && d_rows_t)
-            rc = upsp_transpose_f32(g.rows, (int64_t)p->nnodes, nb, d_rows_t + col0 + f0, ld_t, st);
-    }
-    if (rows_tmp) {
-        (void)hipStreamSynchronize(st);
-        (void)hipFree(rows_tmp);
     }
     return rc;
 }

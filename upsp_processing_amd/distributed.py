@@ -72,11 +72,13 @@ def exchange_time_series(rows_t, shard, group=None, out=None):
     n0, nn = shard.my_nodes
     f_r = shard.frame_count[r]
     assert rows_t.shape == (shard.nnodes, f_r) and rows_t.is_contiguous()
-    if out is None:
-        out = torch.empty((nn, shard.nframes), dtype=rows_t.dtype, device=rows_t.device)
     if w == 1 or not dist.is_initialized():
+        if out is None:
+            return rows_t                      # single rank: already the complete series
         out.copy_(rows_t)
         return out
+    if out is None:
+        out = torch.empty((nn, shard.nframes), dtype=rows_t.dtype, device=rows_t.device)
     in_split = [shard.node_count[d] * f_r for d in range(w)]       # block for rank d
     out_split = [nn * shard.frame_count[s] for s in range(w)]      # block from rank s
     recv = torch.empty(sum(out_split), dtype=rows_t.dtype, device=rows_t.device)
