@@ -148,6 +148,7 @@ def main():
     ev = lambda: torch.cuda.Event(enable_timing=True)
     t_ray, t_frames, t_xchg = [], [], []
     nrays_last = [0]
+    primary_rays_last, retry_nodes_last = [0], [0]
 
     def step(record):
         e = [ev() for _ in range(4)]
@@ -170,6 +171,8 @@ def main():
             t_xchg.append(e[2].elapsed_time(e[3]))
             nrays_last[0] = proj["nrays"]
             nrays_last[1:] = [proj["pix"]]
+            primary_rays_last[0] = proj["primary_rays"]
+            retry_nodes_last[0] = proj["retry_nodes"]
         return avg
 
     for _ in range(a.warmup):
@@ -181,6 +184,7 @@ def main():
         torch.cuda.synchronize()
 
     barrier()
+    _capi.timing_enable(True)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step(True)
@@ -198,20 +202,37 @@ def main():
     frm_ms = float(np.mean(t_frames))
     mrays = nrays_last[0] / (ray_ms * 1e-3) / 1e6
 
-    # roofline of the dominant kernel (HIP-event timed on the launch stream)
-    tri_bytes = bvh.info["device_bytes"]
-    if ray_ms >= frm_ms:
-        algo = nrays_last[0] * 40 + tri_bytes          # 40 B/ray + scene once
-        ach = algo / (ray_ms * 1e-3) / 1e9
-        roof = {"kernel": "projection_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                "algorithmic_bytes_per_launch": algo, "launch_ms": ray_ms}
-    else:
-        algo = F * (2 * size * size + 12 * N)          # 2 MiB + 12 B x N per frame
-        ach = algo / (frm_ms * 1e-3) / 1e9
-        roof = {"kernel": "frame loop (hot_scan+hot_fix+gather+transpose)", "bound": "hbm",
-                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                "traffic": None, "algorithmic_bytes_per_launch": algo, "launch_ms": frm_ms}
+    # per-kernel durations: HIP events recorded by the library on the launch stream
+    # during the timed steps (upsp_timing_enable / upsp_timing_report)
+    timing = _capi.timing_report()
+    kernels = {}
+    n_retry_rays = 6 * retry_nodes_last[0]
+    scene_bytes = bvh.info["device_bytes"]
+    per_step_bytes = {
+        # 40 B per ray (24 B ray + 16 B hit record) + the scene once per launch
+        "projection_kernel<primary>": primary_rays_last[0] * 40 + scene_bytes,
+        "projection_kernel<retry>": n_retry_rays * 40 + scene_bytes,
+        # frame unit = 2 MiB frame + 12 B x N (pix, weight, out)
+        "gather_tile_kernel": F * (2 * size * size + 12 * N),
+        # the compulsory full read of every frame
+        "hot_scan_kernel": F * 2 * size * size,
+    }
+    for name, (calls, total_ms) in timing.items():
+        ms_step_k = total_ms / a.steps
+        k = {"calls_per_step": calls / a.steps, "ms_per_step": ms_step_k,
+             "avg_launch_ms": total_ms / max(calls, 1)}
+        if name in per_step_bytes:
+            k["algorithmic_bytes_per_step"] = per_step_bytes[name]
+            k["achieved_GBps"] = per_step_bytes[name] / (ms_step_k * 1e-3) / 1e9 if ms_step_k else None
+        kernels[name] = k
+    dom = max((n for n in kernels if n in per_step_bytes), key=lambda n: kernels[n]["ms_per_step"])
+    dk = kernels[dom]
+    calls = max(dk["calls_per_step"], 1)
+    roof = {"kernel": dom, "bound": "hbm",
+            "achieved": dk["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": dk["achieved_GBps"] / HBM_PEAK_GBS, "traffic": None,
+            "algorithmic_bytes_per_launch": per_step_bytes[dom] / calls,
+            "avg_launch_ms": dk["avg_launch_ms"], "launches_per_step": calls}
 
     out = {
         "metric": "frames/s", "value": fps, "unit": "frames/s", "n_gpus": world,
@@ -223,10 +244,12 @@ def main():
                    "frames_per_gpu": F, "nodes": N, "triangles": int(tris.shape[0]),
                    "parallelism": "frames sharded x%d" % world},
         "mrays_per_s": mrays, "rays_per_step": nrays_last[0],
+        "rays_cast_per_step": primary_rays_last[0] + 6 * retry_nodes_last[0],
         "breakdown_ms": {"projection_build": ray_ms, "frame_loop": frm_ms,
                          "exchange_finals": float(np.mean(t_xchg))},
         "frame_loop_frames_per_s": F / (frm_ms * 1e-3),
         "roofline": roof,
+        "kernels": kernels,
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(verts, tris, cd, size, F, nrays_last[1].cpu().numpy())

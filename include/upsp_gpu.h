@@ -134,6 +134,13 @@ int upsp_projection_build(upsp_bvh *bvh, const upsp_camera *cam, const float *d_
                           int32_t *d_pix, float *d_uv, uint8_t *d_nodecount,
                           uint64_t *h_nrays, void *stream);
 
+/* Work actually done by the last upsp_projection_build on this BVH: primary rays cast
+ * and nodes that went through the jittered retries (all six retry rays of such a node
+ * are cast as independent rays; *h_nrays above reports the REFERENCE's sequential
+ * count, 1 + index of the first successful retry). */
+int upsp_projection_last_counts(const upsp_bvh *bvh, uint64_t *primary_rays,
+                                uint64_t *retry_nodes);
+
 /* adjust_projection_for_weights with BestView (mode 0) / AverageViews (mode 1)
  * (cpp/lib/projection.ipp:911-1078, 227-268).  d_pix, d_weight: [ncams*nnodes];
  * d_weight is scaled in place (caller initialises it to 1).  h_centers: ncams*3
@@ -252,6 +259,17 @@ int upsp_blur_f32(const float *d_src, float *d_dst, int rows, int cols, int k, i
 int upsp_patch_f32(float *d_img, int rows, int cols, int nclusters, const int32_t *h_b_off,
                    const int32_t *h_bx, const int32_t *h_by, const int32_t *h_i_off,
                    const int32_t *h_ix, const int32_t *h_iy, void *stream);
+
+/* ======================================================================== *
+ *  4.  Measurement support (no reference counterpart; the reference only has
+ *      psp::BlockTimer / timedBarrierPoint wall-clock prints, pspTimer.h:10-41)
+ * ======================================================================== */
+
+/* Per-kernel timing with HIP events recorded on the launch stream.  enable(1) clears
+ * earlier records.  report(): one line per kernel "name calls total_ms"; the caller
+ * must have synchronised the stream(s). */
+int upsp_timing_enable(int on);
+int upsp_timing_report(char *buf, size_t cap);
 
 #ifdef __cplusplus
 }

@@ -74,3 +74,13 @@ if a.frames:
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         print("frame loop: %.3f ms for %d frames, %.0f frames/s" % (dt * 1e3, F, F / dt))
+# per-kernel timing of one more projection build + closest-hit with normalised directions
+_capi.timing_enable(True)
+p = engine.build_projection(bvh, cam, d_nodes, d_nrm, d_tn, 70.0)
+dn = d / d.norm(dim=1, keepdim=True)
+h = bvh.intersect(cam_c, dn, want=("hit", "t", "prim"))
+h = bvh.intersect(cam_c, d, want=("hit", "t", "prim"))
+torch.cuda.synchronize()
+for k, v in _capi.timing_report().items():
+    print("timing", k, v)
+print("hit fraction", h["hit"].float().mean().item())

@@ -65,6 +65,7 @@ SIGNATURES = {
     "upsp_bvh_last_stats": (_i, [_vp, _u64p, _u64p, _u64p]),
     "upsp_projection_build": (_i, [_vp, C.POINTER(Camera), _vp, _vp, _vp, _vp, _sz, C.c_float,
                                    _vp, _vp, _vp, _u64p, _vp]),
+    "upsp_projection_last_counts": (_i, [_vp, _u64p, _u64p]),
     "upsp_projection_weights": (_i, [_i, _sz, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "upsp_projection_skipped": (_i, [_i, _sz, _vp, _vp, _u64p, _vp]),
     "upsp_camera_center": (_i, [C.POINTER(Camera), _vp]),
@@ -88,6 +89,8 @@ SIGNATURES = {
     "upsp_register_pixel_u16": (_i, [_vp, _vp, _i, _i, _i, C.c_double, _i, _vp, _vp, _vp]),
     "upsp_blur_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "upsp_patch_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "upsp_timing_enable": (_i, [_i]),
+    "upsp_timing_report": (_i, [C.c_char_p, _sz]),
 }
 
 _lib = None
@@ -135,3 +138,18 @@ def device_info():
     arch = C.create_string_buffer(64)
     check(lib().upsp_device_info(C.byref(n), arch, C.byref(cus)))
     return dict(n_devices=n.value, arch=arch.value.decode(), n_cus=cus.value)
+
+
+def timing_enable(on=True):
+    check(lib().upsp_timing_enable(int(bool(on))))
+
+
+def timing_report():
+    """dict name -> (calls, total_ms) of the kernels timed since timing_enable(True)."""
+    buf = C.create_string_buffer(1 << 16)
+    check(lib().upsp_timing_report(buf, len(buf)))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, n, ms = line.rsplit(" ", 2)
+        out[name] = (int(n), float(ms))
+    return out

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <vector>
 
+#include "ktimer.h"
 #include "pipeline.h"
 #include "upsp_internal.h"
 
@@ -361,8 +362,12 @@ int launch_hot_fix(uint16_t *d_frames, int nframes, int rows, int cols, int thre
     size_t bx = (npix / 8 + 255) / 256;
     if (bx > 128) bx = 128;
     if (bx < 1) bx = 1;
+    {
+    KTimed kt("hot_scan_kernel", st);
     hipLaunchKernelGGL(hot_scan_kernel, dim3((unsigned)bx, (unsigned)nframes), dim3(256), 0, st,
                        d_frames, npix, thresh, d_count, d_pos);
+    }
+    KTimed kt2("hot_fix_kernel", st);
     hipLaunchKernelGGL(hot_fix_kernel, dim3((nframes + 63) / 64), dim3(64), 0, st, d_frames,
                        nframes, rows, cols, min_change, max_hot, d_count, d_pos, d_status);
     UPSP_HIP_CHECK(hipGetLastError());
@@ -383,6 +388,7 @@ int launch_gather(const PipelineGather &g, hipStream_t st)
         a.is_f32[c] = g.is_f32[c];
     }
     if (g.nframes <= 64) {
+        KTimed kt("gather_tile_kernel", st);
         const dim3 tgrid((unsigned)((g.nnodes + 63) / 64)), tblock(256);
         if (g.ncams == 1)
             hipLaunchKernelGGL((gather_tile_kernel<1>), tgrid, tblock, 0, st, a, g.skipped,

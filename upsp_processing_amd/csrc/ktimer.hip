@@ -1,0 +1,94 @@
+// Per-kernel timing registry: hipEvent pairs recorded on the stream the kernel is
+// launched on; resolved at report time (after the caller has synchronised).
+#include "ktimer.h"
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "upsp_internal.h"
+
+namespace upsp {
+namespace {
+struct Span {
+    hipEvent_t a, b;
+};
+struct Entry {
+    std::vector<Span> spans;
+};
+std::mutex g_mu;
+bool g_on = false;
+std::map<std::string, Entry> g_entries;
+std::vector<std::string> g_order;
+std::string g_current;
+hipEvent_t g_start;
+}  // namespace
+
+bool ktimer_on() { return g_on; }
+
+void ktimer_begin(const char *name, hipStream_t st)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_current = name;
+    if (hipEventCreate(&g_start) != hipSuccess) return;
+    (void)hipEventRecord(g_start, st);
+}
+
+void ktimer_end(hipStream_t st)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    (void)hipEventRecord(e, st);
+    if (!g_entries.count(g_current)) g_order.push_back(g_current);
+    g_entries[g_current].spans.push_back({g_start, e});
+}
+}  // namespace upsp
+
+using namespace upsp;
+
+extern "C" {
+
+int upsp_timing_enable(int on)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_on = on != 0;
+    if (!g_on) return UPSP_OK;
+    for (auto &kv : g_entries)
+        for (auto &s : kv.second.spans) {
+            (void)hipEventDestroy(s.a);
+            (void)hipEventDestroy(s.b);
+        }
+    g_entries.clear();
+    g_order.clear();
+    return UPSP_OK;
+}
+
+int upsp_timing_report(char *buf, size_t cap)
+{
+    if (!buf || cap == 0) return fail(UPSP_ERR_INVALID, "null buffer");
+    std::lock_guard<std::mutex> lk(g_mu);
+    std::string out;
+    for (const auto &name : g_order) {
+        const Entry &e = g_entries[name];
+        double total = 0;
+        int n = 0;
+        for (const auto &s : e.spans) {
+            float ms = 0;
+            if (hipEventSynchronize(s.b) == hipSuccess && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+                total += ms;
+                ++n;
+            }
+        }
+        char line[256];
+        std::snprintf(line, sizeof(line), "%s %d %.6f\n", name.c_str(), n, total);
+        out += line;
+    }
+    if (out.size() + 1 > cap) return fail(UPSP_ERR_INVALID, "timing report buffer too small");
+    std::memcpy(buf, out.c_str(), out.size() + 1);
+    return UPSP_OK;
+}
+}

@@ -77,6 +77,7 @@ struct upsp_bvh {
     int device = 0;
     int stats_on = 0;
     uint64_t last_stats[3] = {0, 0, 0};
+    uint64_t last_primary = 0, last_retry_nodes = 0;
 };
 
 #endif

@@ -151,7 +151,10 @@ def build_projection(bvh, cam, nodes, normals, tri_nodes, oblique_angle=70.0, da
                                       _ptr(dn), _ptr(tri_nodes), n,
                                       C.c_float(oblique_threshold(oblique_angle)), _ptr(pix),
                                       _ptr(uv), _ptr(cnt), C.byref(nrays), _stream()))
-    return dict(pix=pix, uv=uv, nrays=int(nrays.value), nodecount=cnt)
+    pr, rn = C.c_uint64(0), C.c_uint64(0)
+    check(lib().upsp_projection_last_counts(bvh.handle, C.byref(pr), C.byref(rn)))
+    return dict(pix=pix, uv=uv, nrays=int(nrays.value), nodecount=cnt,
+                primary_rays=int(pr.value), retry_nodes=int(rn.value))
 
 
 def projection_weights(pix, nodes, normals, centers, mode="average_view"):
