@@ -1,0 +1,92 @@
+"""CPU, 2 processes over gloo: the N>1 path of the frame loop -- frame sharding
+(apportion), the sum of the double accumulators (MPI_Reduce + MPI_Bcast in the reference,
+psp_process.cpp:1866-1872, 2019-2023), the time-series exchange (global_transpose,
+psp_process.cpp:707-771) and the gather-to-root option.  Per-rank rows are produced by the
+oracle (test infrastructure) so the collectives are checked against a single-process run
+of the same frames."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, F, N, seed, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from upsp_processing_amd import distributed as D
+    shard = D.Shard(F, N)
+    assert shard.rank == rank and shard.world == world
+    rng = np.random.default_rng(seed)
+    rows_all = rng.normal(size=(F, N)).astype(np.float32)       # what one process would produce
+    rows_all[:, ::7] = np.nan                                   # skipped nodes
+    f0, nf = shard.my_frames
+    mine = rows_all[f0:f0 + nf]
+    s = torch.as_tensor(np.nansum(mine.astype(np.float64), axis=0))
+    ss = torch.as_tensor(np.nansum(mine.astype(np.float64) ** 2, axis=0))
+    D.allreduce_sums(s, ss)
+    rows_t = torch.as_tensor(np.ascontiguousarray(mine.T))
+    series = D.exchange_time_series(rows_t, shard)
+    n0, nn = shard.my_nodes
+    full = D.gather_time_series_to_root(series, shard)
+    q.put((rank, s.numpy(), ss.numpy(), series.numpy(), n0, nn,
+           None if full is None else full.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("F,N", [(11, 37), (4, 5), (1, 3)])
+def test_two_rank_exchange(F, N):
+    world, seed = 2, 123
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, F, N, seed, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(seed)
+    rows_all = rng.normal(size=(F, N)).astype(np.float32)
+    rows_all[:, ::7] = np.nan
+    ref_t = rows_all.T
+    tot = np.nansum(rows_all.astype(np.float64), axis=0)
+    tot2 = np.nansum(rows_all.astype(np.float64) ** 2, axis=0)
+    for rank, s, ss, series, n0, nn, full in res:
+        assert np.allclose(s, tot, rtol=1e-13) and np.allclose(ss, tot2, rtol=1e-13)
+        assert series.shape == (nn, F)
+        assert np.array_equal(series.view(np.int32), np.ascontiguousarray(ref_t[n0:n0 + nn]).view(np.int32))
+        if rank == 0:
+            assert np.array_equal(full.view(np.int32), np.ascontiguousarray(ref_t).view(np.int32))
+        else:
+            assert full is None
+
+
+def test_shard_matches_reference_apportion(oracle):
+    from upsp_processing_amd import distributed as D, engine
+    for value, bins in [(100000, 8), (10, 4), (3, 5), (0, 2), (12345, 7)]:
+        st, ex = D.apportion(value, bins)
+        so, eo = oracle.apportion(value, bins)
+        assert st == so.tolist() and ex == eo.tolist()
+        st2, ex2 = engine.apportion(value, bins)
+        assert st2 == st and ex2 == ex
+    sh = D.Shard(100000, 500958, rank=3, world=8)
+    assert sh.my_frames == (37500, 12500) and sum(sh.node_count) == 500958

@@ -1,0 +1,35 @@
+#!/bin/bash
+# rocprofv3 passes for bench.py on the GPU box: kernel-trace stats + HBM traffic counters
+# (FETCH_SIZE and WRITE_SIZE in separate --pmc passes, MI355X_MICROARCH.md "rocprofv3 PMC slots").
+# usage: tools/profile_bench.sh <tag> [bench args...]
+tag=$1; shift
+out=gpurun_out/prof_$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --no-cpu-baseline "$@" > $out/trace.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/$c -- python3 bench.py --no-cpu-baseline "$@" > $out/$c.log 2>&1
+done
+python3 - $out <<'PY'
+import csv, glob, sys, collections, json
+out = sys.argv[1]
+res = collections.OrderedDict()
+f = glob.glob(out + "/trace/*/*kernel_stats.csv")
+if f:
+    for r in csv.DictReader(open(f[0])):
+        if "upsp" in r["Name"]:
+            name = r["Name"].split("(anonymous namespace)::")[-1].split("(")[0]
+            res[name] = dict(calls=int(r["Calls"]), avg_ns=float(r["AverageNs"]), total_ns=int(r["TotalDurationNs"]))
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = glob.glob(out + "/%s/*/*counter_collection.csv" % c)
+    if not f: continue
+    acc = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(f[0])):
+        if "upsp" in r["Kernel_Name"] and r["Counter_Name"] == c:
+            name = r["Kernel_Name"].split("(anonymous namespace)::")[-1].split("(")[0]
+            acc[name][0] += 1; acc[name][1] += float(r["Counter_Value"])
+    for name, (n, v) in acc.items():
+        res.setdefault(name, {})[c + "_KB_per_launch"] = v / n
+json.dump(res, open(out + "/summary.json", "w"), indent=1)
+for k, v in res.items(): print(k, v)
+PY

@@ -33,14 +33,12 @@ __global__ void __launch_bounds__(256)
     const uint4 *src = reinterpret_cast<const uint4 *>(frames + f * npix);
     const size_t nvec = npix / 8;
     const unsigned th = (unsigned)thresh;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
-         i += (size_t)gridDim.x * blockDim.x) {
-        const uint4 v = src[i];
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    auto check = [&](const uint4 v, size_t i) {
         const unsigned w[4] = {v.x, v.y, v.z, v.w};
-        // quick reject: any half-word >= thresh ?
-        bool any = false;
+        bool any = false;  // quick reject: any half-word >= thresh ?
 #pragma unroll
-        for (int k = 0; k < 4; ++k) any |= ((w[k] & 0xFFFFu) >= th) || ((w[k] >> 16) >= th);
+        for (int k = 0; k < 4; ++k) any |= ((w[k] & 0xFFFFu) >= th) | ((w[k] >> 16) >= th);
         if (any) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -51,7 +49,17 @@ __global__ void __launch_bounds__(256)
                 }
             }
         }
+    };
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // four independent 16-byte loads in flight per lane
+    for (; i + 3 * stride < nvec; i += 4 * stride) {
+        const uint4 v0 = src[i], v1 = src[i + stride], v2 = src[i + 2 * stride], v3 = src[i + 3 * stride];
+        check(v0, i);
+        check(v1, i + stride);
+        check(v2, i + 2 * stride);
+        check(v3, i + 3 * stride);
     }
+    for (; i < nvec; i += stride) check(src[i], i);
     // tail pixels when npix is not a multiple of 8
     if (blockIdx.x == 0 && threadIdx.x < (npix & 7)) {
         const size_t p = nvec * 8 + threadIdx.x;
@@ -199,24 +207,35 @@ __global__ void __launch_bounds__(256)
     const bool skip = live && skipped && skipped[n];
     const float qnan = __builtin_nanf("");
     double s = 0.0, ss = 0.0;
-#pragma unroll 4
-    for (int f = wave; f < nframes; f += 4) {
-        float sol = 0.0f;
+    // 16 frames per lane (f = wave, wave+4, ...): issue every gather before using any
+    float sol[16];
 #pragma unroll
-        for (int c = 0; c < nc; ++c) {
-            float v = 0.0f;
-            if (px[c] >= 0) {
-                const size_t off = (size_t)f * a.npix + (size_t)px[c];
-                const float pxv = a.is_f32[c] ? reinterpret_cast<const float *>(a.img[c])[off]
-                                              : (float)reinterpret_cast<const uint16_t *>(a.img[c])[off];
-                v = 0.0f + w[c] * pxv;
+    for (int i = 0; i < 16; ++i) {
+        const int f = wave + 4 * i;
+        float acc = 0.0f;
+        if (f < nframes) {
+#pragma unroll
+            for (int c = 0; c < nc; ++c) {
+                float v = 0.0f;
+                if (px[c] >= 0) {
+                    const size_t off = (size_t)f * a.npix + (size_t)px[c];
+                    const float pxv = a.is_f32[c] ? reinterpret_cast<const float *>(a.img[c])[off]
+                                                  : (float)reinterpret_cast<const uint16_t *>(a.img[c])[off];
+                    v = 0.0f + w[c] * pxv;
+                }
+                acc = (c == 0) ? v : acc + v;
             }
-            sol = (c == 0) ? v : sol + v;
         }
-        if (skip) sol = qnan;
-        s += (double)sol;
-        ss += (double)(sol * sol);
-        tile[f][lane] = sol;
+        sol[i] = skip ? qnan : acc;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int f = wave + 4 * i;
+        if (f < nframes) {
+            s += (double)sol[i];
+            ss += (double)(sol[i] * sol[i]);
+            tile[f][lane] = sol[i];
+        }
     }
     part[0][wave][lane] = s;
     part[1][wave][lane] = ss;

@@ -93,13 +93,22 @@ def exchange_time_series(rows_t, shard, group=None, out=None):
 
 
 def gather_time_series_to_root(series, shard, group=None):
-    """Single gather of the node-major slices to rank 0: [N, F] on rank 0, None elsewhere."""
+    """Single gather of the node-major slices to rank 0: [N, F] on rank 0, None elsewhere.
+    Slices are ragged (apportion), so this is one point-to-point transfer per rank
+    (grouped isend / irecv -- on RCCL one ncclGroup, every sender on its own xGMI link
+    into the root)."""
     if shard.world == 1 or not dist.is_initialized():
         return series
     if shard.rank == 0:
-        parts = [torch.empty((shard.node_count[s], shard.nframes), dtype=series.dtype,
-                             device=series.device) for s in range(shard.world)]
-        dist.gather(series, parts, dst=0, group=group)
-        return torch.cat(parts, dim=0)
-    dist.gather(series, None, dst=0, group=group)
+        full = torch.empty((shard.nnodes, shard.nframes), dtype=series.dtype, device=series.device)
+        n0, nn = shard.my_nodes
+        full[n0:n0 + nn] = series
+        ops = [dist.P2POp(dist.irecv, full[shard.node_start[s]:shard.node_start[s] + shard.node_count[s]],
+                          s, group) for s in range(1, shard.world) if shard.node_count[s]]
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+        return full
+    if shard.node_count[shard.rank]:
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, series.contiguous(), 0, group)]):
+            w.wait()
     return None
