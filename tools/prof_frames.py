@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Frame-loop profiling driver: python tools/prof_frames.py --frames F [--ld LD]"""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from upsp_processing_amd import _capi, engine, synthetic as syn
+ap = argparse.ArgumentParser()
+ap.add_argument("--frames", type=int, default=1000)
+ap.add_argument("--ld", type=int, default=0)
+ap.add_argument("--nodes", type=int, default=500958)
+ap.add_argument("--vis", type=float, default=0.38)
+ap.add_argument("--reps", type=int, default=3)
+a = ap.parse_args()
+size, N, F = 1024, a.nodes, a.frames
+g = torch.Generator(device="cuda"); g.manual_seed(1)
+# spatially coherent projection: node i -> pixel along a space-filling-ish sweep
+pix = (torch.arange(N, device="cuda", dtype=torch.int64) * (size * size) // N).to(torch.int32)
+pix[torch.rand(N, generator=g, device="cuda") > a.vis] = -1
+frames = torch.empty((F, size, size), dtype=torch.uint16, device="cuda")
+for f0 in range(0, F, 50):
+    syn.synth_frames_torch(min(50, F - f0), size, size, first=f0, out=frames[f0:f0 + 50])
+pipe = engine.FramePipeline(1, size, size, N)
+pipe.set_projection(0, pix)
+ld = a.ld or F
+buf = torch.empty((N, ld), dtype=torch.float32, device="cuda")
+rows_t = buf[:, :F] if ld != F else buf
+for r in range(a.reps):
+    _capi.timing_enable(True)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    pipe.process(frames, 0, rows_t=rows_t, want_rows=False)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    rep = _capi.timing_report()
+    print("F=%d ld=%d: %.3f ms  %.0f frames/s | " % (F, ld, dt * 1e3, F / dt) +
+          " ".join("%s=%.3f" % (k.split("_kernel")[0], v[1]) for k, v in rep.items()))

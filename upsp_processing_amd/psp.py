@@ -1,0 +1,190 @@
+"""Phase 1 of psp_process on the GPU engine (cpp/exec/psp_process.cpp:1438-2040).
+
+`Phase1` mirrors the reference's control flow for the hot path and nothing else:
+
+    createBVH -> per camera create_projection_mat -> adjust_projection_for_weights ->
+    identify_skipped_nodes -> first-frame solution sol1 -> frame loop -> reductions ->
+    finals (avg, rms, intensity_ratio_0, coverage) -> node-major time series
+
+Inputs are flat arrays (what the reference's model / calibration / video readers produce);
+outputs are tensors plus, optionally, the reference's flat files (raw little-endian f32,
+no header; cpp/exec/psp_process.cpp:524-540, docs/sphinx/file-formats.rst:821-894).
+
+Multi-GPU: construct under torch.distributed (one process per GPU).  Frames are sharded
+with apportion(); all cameras of a frame stay on one GPU so the per-node fusion is local.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _capi, distributed as D, engine
+
+
+class Phase1:
+    def __init__(self, tris9, tri_nodes, nodes, normals, cameras, image_size, oblique_angle=70.0,
+                 overlap="average_view", datanode=None, registration=False, interp=1,
+                 filter=None, filter_size=1, patches=None, nframes_total=None):
+        """cameras: list of dict(K, dist, R, t); image_size = (width, height)."""
+        self.width, self.height = image_size
+        self.ncams = len(cameras)
+        self.nnodes = int(np.asarray(nodes).reshape(-1, 3).shape[0])
+        self.bvh = engine.BVH(tris9)                                  # createBVH :44-53
+        self.d_nodes = torch.as_tensor(np.ascontiguousarray(nodes, np.float32)).cuda()
+        self.d_normals = torch.as_tensor(np.ascontiguousarray(normals, np.float32)).cuda()
+        self.d_tri_nodes = torch.as_tensor(np.ascontiguousarray(tri_nodes, np.int32)).cuda()
+        self.cams = [_capi.make_camera(c["K"], c["dist"], c["R"], c["t"], self.width, self.height)
+                     for c in cameras]
+        self.centers = np.array([engine.camera_center(c) for c in self.cams])
+        self.nrays = 0
+        pix, self.uv = [], []
+        for cam in self.cams:                                          # :1597-1622
+            p = engine.build_projection(self.bvh, cam, self.d_nodes, self.d_normals,
+                                        self.d_tri_nodes, oblique_angle, datanode=datanode)
+            pix.append(p["pix"])
+            self.uv.append(p["uv"])
+            self.nrays += p["nrays"]
+        self.pix = torch.stack(pix)
+        # :1632-1640 ; a single camera needs no weights
+        self.weight = (engine.projection_weights(self.pix, self.d_nodes, self.d_normals,
+                                                 self.centers, overlap)
+                       if self.ncams > 1 else None)
+        self.skipped, self.nskipped = engine.skipped_nodes(self.pix)   # :1644
+        opts = dict(registration=int(bool(registration)), interp=int(interp),
+                    patch=int(patches is not None))
+        if filter:
+            opts.update(filter={"gaussian": 1, "box": 2}[filter], filter_size=int(filter_size))
+        self.pipe = engine.FramePipeline(self.ncams, self.width, self.height, self.nnodes, **opts)
+        for c in range(self.ncams):
+            self.pipe.set_projection(c, self.pix[c], None if self.weight is None else self.weight[c])
+            if patches is not None:
+                self.pipe.set_patches(c, patches[c])
+        self.pipe.set_skipped(self.skipped)
+        self.registration = bool(registration)
+        self._patches = patches
+        self.sol1 = None
+        self.frames_done = 0
+
+    # -- first frame (psp_process.cpp:1655-1713) ------------------------------------
+    def set_first_frames(self, first_frames):
+        """first_frames: list of RAW u16 [H,W] tensors (frame 1 of every camera).
+
+        * ECC template of the frame loop = raw first frame as f32, without hot-pixel
+          repair (elems.first_frames, psp_process.cpp:2057-2058);
+        * sol1 = the hot-pixel-repaired first frame (first_frames_raw, :880-884) registered
+          against its own f32 copy (first_frames_32f, :1676), patched, filtered, projected."""
+        raws = [f.to(device="cuda").reshape(self.height, self.width).contiguous() for f in first_frames]
+        for c, r in enumerate(raws):
+            self.pipe.set_reference(c, r.to(torch.float32))
+        fixed = [r.clone().reshape(1, self.height, self.width) for r in raws]
+        for f in fixed:
+            engine.fix_hot_pixels(f)
+        o = self.pipe.opts
+        tmp = engine.FramePipeline(self.ncams, self.width, self.height, self.nnodes,
+                                   hot_enable=0, registration=o.registration, interp=o.interp,
+                                   filter=o.filter, filter_size=o.filter_size, patch=o.patch)
+        for c in range(self.ncams):
+            tmp.set_projection(c, self.pix[c], None if self.weight is None else self.weight[c])
+            tmp.set_reference(c, fixed[c][0].to(torch.float32))
+            if self._patches is not None:
+                tmp.set_patches(c, self._patches[c])
+        tmp.set_skipped(self.skipped)
+        frames = fixed
+        self.sol1 = tmp.process(frames, first_frame=1)[0].clone()
+        tmp.close()
+        return self.sol1
+
+    # -- frame loop (psp_process.cpp:1743-1851) --------------------------------------
+    def process(self, frames, first_frame, rows_t=None, col0=0, want_rows=False):
+        """frames: list (per camera) of u16 [F,H,W] tensors, global index of frame 0 =
+        first_frame.  rows_t: optional [N, >=col0+F] node-major output."""
+        rows = self.pipe.process(frames, first_frame=first_frame, rows_t=rows_t, col0=col0,
+                                 want_rows=want_rows)
+        self.frames_done += frames[0].shape[0]
+        return rows
+
+    # -- reductions + finals (psp_process.cpp:1866-1979) -----------------------------
+    def finalize(self, nframes_total):
+        s, ss = self.pipe.accumulators()
+        D.allreduce_sums(s, ss)                                        # MPI_Reduce + MPI_Bcast
+        avg, rms = self.pipe.finalize(nframes_total)
+        out = dict(avg=avg, rms=rms)
+        if self.sol1 is not None:
+            out["ratio_0"] = avg / self.sol1 - 1.0                     # :1948-1950
+        # coverage = sum_c project(ones) (:1955-1975)
+        ones = torch.ones((self.height, self.width), dtype=torch.float32, device="cuda")
+        cov = None
+        for c in range(self.ncams):
+            w = None if self.weight is None else self.weight[c].contiguous()
+            ind = engine.project_frame(ones, self.pix[c].contiguous(), w)
+            cov = ind if cov is None else cov + ind
+        out["coverage"] = cov
+        return out
+
+    @staticmethod
+    def dump_vv(path, v, maxels=1000):
+        """Regression slices vv-*.dat (psp_process.cpp:1984-2016)."""
+        v = np.asarray(v, dtype=np.float32)
+        step = 1 if v.size < maxels else v.size // maxels
+        np.ascontiguousarray(v[::step][:maxels]).tofile(path)
+
+    def write_outputs(self, out_dir, finals, series=None, node_start=0):
+        """Flat files of phase 1.  `series`: this rank's [nodes_r, F] slice, written at its
+        byte offset into the shared intensity_transpose file like the reference's pwrite
+        (:958-963)."""
+        os.makedirs(out_dir, exist_ok=True)
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        if rank == 0:
+            for name, key in (("intensity_avg", "avg"), ("intensity_rms", "rms"),
+                              ("intensity_ratio_0", "ratio_0"), ("coverage", "coverage")):
+                if key in finals:
+                    finals[key].cpu().numpy().astype("<f4").tofile(os.path.join(out_dir, name))
+            for c in range(self.ncams):
+                self.uv[c].cpu().numpy().astype("<f4").tofile(
+                    os.path.join(out_dir, "cam%02d-uv" % (c + 1)))
+            self.dump_vv(os.path.join(out_dir, "vv-int-rms.dat"), finals["rms"].cpu().numpy())
+            self.dump_vv(os.path.join(out_dir, "vv-int-avg.dat"), finals["avg"].cpu().numpy())
+            self.dump_vv(os.path.join(out_dir, "vv-int-coverage.dat"), finals["coverage"].cpu().numpy())
+            if self.sol1 is not None:
+                self.dump_vv(os.path.join(out_dir, "vv-int-sample1.dat"), finals["ratio_0"].cpu().numpy())
+        if series is not None:
+            path = os.path.join(out_dir, "intensity_transpose")
+            nf = series.shape[1]
+            data = series.cpu().numpy().astype("<f4")
+            fd = os.open(path, os.O_RDWR | os.O_CREAT, 0o644)
+            try:
+                os.pwrite(fd, data.tobytes(), nf * node_start * 4)
+            finally:
+                os.close(fd)
+
+    def close(self):
+        self.pipe.close()
+        self.bvh.close()
+
+
+def run_phase1(job, frames_per_cam, nframes_total=None, out_dir=None, chunk=256):
+    """Drive a whole phase 1 on this rank's share of the frames.
+
+    frames_per_cam: list (per camera) of u16 [F_total, H, W] arrays / tensors holding ALL
+    frames (every rank slices its own share with apportion()).  Returns (finals, series)."""
+    F = int(frames_per_cam[0].shape[0]) if nframes_total is None else int(nframes_total)
+    shard = D.Shard(F, job.nnodes)
+    f0, nf = shard.my_frames
+    job.set_first_frames([torch.as_tensor(np.asarray(fr[0])) if not isinstance(fr, torch.Tensor) else fr[0]
+                          for fr in frames_per_cam])
+    rows_t = torch.empty((job.nnodes, max(nf, 1)), dtype=torch.float32, device="cuda")
+    for c0 in range(0, nf, chunk):
+        n = min(chunk, nf - c0)
+        batch = []
+        for fr in frames_per_cam:
+            b = fr[f0 + c0:f0 + c0 + n]
+            if not isinstance(b, torch.Tensor):
+                b = torch.as_tensor(np.ascontiguousarray(b))
+            batch.append(b.to("cuda").contiguous())
+        job.process(batch, first_frame=f0 + c0, rows_t=rows_t, col0=c0)
+    finals = job.finalize(F)
+    series = D.exchange_time_series(rows_t[:, :nf].contiguous() if rows_t.shape[1] != nf else rows_t, shard)
+    if out_dir:
+        job.write_outputs(out_dir, finals, series, node_start=shard.my_nodes[0])
+    return finals, series
