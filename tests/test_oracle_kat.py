@@ -182,3 +182,17 @@ def test_projection_oracle_sphere(oracle):
     assert r["nodecount"].sum() == vis.sum()
     sk = oracle.skipped_nodes(r["pix"])
     assert np.array_equal(sk, ~vis)
+
+
+def test_fixture_manifest(fml):
+    """Inputs prepared by tests/refdata.py hash to what tests/golden/make_golden.py recorded
+    when it ran the reference's own Python input preparation on the same files."""
+    import hashlib, json, os
+    import refdata
+    man = json.load(open(os.path.join(refdata.GOLDEN, "golden_manifest.json")))
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    assert sha(fml["prims"]) == man["primitives_sha256"]
+    assert sha(fml["nodes"]) == man["nodes_sha256"]
+    assert sha(fml["norms"]) == man["normals_sha256"]
+    vis = np.load(os.path.join(refdata.GOLDEN, "camera01_visible.npz"))["visible"]
+    assert len(vis) == man["visible_count"] == 148608 and sha(vis) == man["visible_sha256"]
