@@ -12,21 +12,25 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python3 - $out <<'PY'
 import csv, glob, sys, collections, json
+import re
 out = sys.argv[1]
 res = collections.OrderedDict()
+def kname(full):
+    m = re.search(r"\(anonymous namespace\)::(\w+)(<[^>]*>)?\(", full)
+    return (m.group(1) + (m.group(2) or "")) if m else full[:60]
 f = glob.glob(out + "/trace/*/*kernel_stats.csv")
 if f:
     for r in csv.DictReader(open(f[0])):
         if "upsp" in r["Name"]:
-            name = r["Name"].split("(anonymous namespace)::")[-1].split("(")[0]
-            res[name] = dict(calls=int(r["Calls"]), avg_ns=float(r["AverageNs"]), total_ns=int(r["TotalDurationNs"]))
+            name = kname(r["Name"])
+            res.setdefault(name, {}).update(calls=int(r["Calls"]), avg_ns=float(r["AverageNs"]), total_ns=int(r["TotalDurationNs"]))
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(out + "/%s/*/*counter_collection.csv" % c)
     if not f: continue
     acc = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(f[0])):
         if "upsp" in r["Kernel_Name"] and r["Counter_Name"] == c:
-            name = r["Kernel_Name"].split("(anonymous namespace)::")[-1].split("(")[0]
+            name = kname(r["Kernel_Name"])
             acc[name][0] += 1; acc[name][1] += float(r["Counter_Value"])
     for name, (n, v) in acc.items():
         res.setdefault(name, {})[c + "_KB_per_launch"] = v / n

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -245,10 +246,36 @@ __global__ void __launch_bounds__(256)
         sum[n] += ((part[0][0][lane] + part[0][1][lane]) + part[0][2][lane]) + part[0][3][lane];
         sumsq[n] += ((part[1][0][lane] + part[1][1][lane]) + part[1][2][lane]) + part[1][3][lane];
     }
-    if (rows_t) {  // lane = frame, wave g writes nodes g, g+4, ...: 256-byte row segments
-        for (int j = wave; j < 64; j += 4) {
-            const unsigned nn = n0 + (unsigned)j;
-            if (nn < nnodes && lane < nframes) rows_t[(long long)nn * ld_t + lane] = tile[lane][j];
+    if (rows_t) {
+        const bool vec_ok = ((ld_t & 3) == 0) && ((reinterpret_cast<size_t>(rows_t) & 15) == 0);
+        if (vec_ok) {
+            // 16 lanes x 16 B = one 256-byte row segment, 4 rows per wave instruction
+            const int c4 = (lane & 15) * 4, rsub = lane >> 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int j = wave * 16 + i * 4 + rsub;  // node within the tile
+                const unsigned nn = n0 + (unsigned)j;
+                if (nn < nnodes && c4 < nframes) {
+                    float4 v;
+                    v.x = tile[c4][j];
+                    v.y = tile[c4 + 1][j];
+                    v.z = tile[c4 + 2][j];
+                    v.w = tile[c4 + 3][j];
+                    float *dst = rows_t + (long long)nn * ld_t + c4;
+                    if (c4 + 3 < nframes) {
+                        *reinterpret_cast<float4 *>(dst) = v;
+                    } else {
+                        dst[0] = v.x;
+                        if (c4 + 1 < nframes) dst[1] = v.y;
+                        if (c4 + 2 < nframes) dst[2] = v.z;
+                    }
+                }
+            }
+        } else {  // lane = frame, wave g writes nodes g, g+4, ...: 256-byte row segments
+            for (int j = wave; j < 64; j += 4) {
+                const unsigned nn = n0 + (unsigned)j;
+                if (nn < nnodes && lane < nframes) rows_t[(long long)nn * ld_t + lane] = tile[lane][j];
+            }
         }
     }
     if (rows) {    // lane = node, wave g writes frames g, g+4, ...
@@ -379,7 +406,8 @@ int launch_hot_fix(uint16_t *d_frames, int nframes, int rows, int cols, int thre
     const size_t npix = (size_t)rows * cols;
     UPSP_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(unsigned) * (size_t)nframes, st));
     size_t bx = (npix / 8 + 255) / 256;
-    if (bx > 128) bx = 128;
+    static const size_t bx_cap = std::getenv("UPSP_SCAN_BX") ? (size_t)std::atoi(std::getenv("UPSP_SCAN_BX")) : 128;
+    if (bx > bx_cap) bx = bx_cap;
     if (bx < 1) bx = 1;
     {
     KTimed kt("hot_scan_kernel", st);

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -35,6 +36,9 @@ struct upsp_pipeline {
     upsp::PatchTables *patches[kMaxCams] = {nullptr};
     upsp::FrameScratch *scratch = nullptr;
     int batch = 32;
+    // second stream: the gather of sub-batch k overlaps the hot-pixel scan of k+1
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_in = nullptr, ev_fix[2] = {nullptr, nullptr}, ev_out = nullptr;
 };
 
 namespace {
@@ -129,6 +133,9 @@ void upsp_pipeline_destroy(upsp_pipeline *p)
         upsp::patch_tables_free(p->patches[c]);
     }
     upsp::frame_scratch_free(p->scratch);
+    if (p->aux) (void)hipStreamDestroy(p->aux);
+    for (hipEvent_t e : {p->ev_in, p->ev_fix[0], p->ev_fix[1], p->ev_out})
+        if (e) (void)hipEventDestroy(e);
     free_dev(p->d_skipped);
     free_dev(p->d_sum);
     free_dev(p->d_sumsq);
@@ -255,7 +262,24 @@ int upsp_pipeline_process(upsp_pipeline *p, const uint16_t *const *d_frames, int
         if (rc != UPSP_OK) return rc;
     }
     int rc = UPSP_OK;
-    for (int f0 = 0; f0 < nframes && rc == UPSP_OK; f0 += B) {
+    // Two-stream schedule (plain projection path only): scan+repair on the caller's
+    // stream, gathers on an internal stream, ordered by events.  Reads of sub-batch k+1
+    // then overlap the time-series writes of sub-batch k.
+    static const bool overlap_env = std::getenv("UPSP_NO_OVERLAP") == nullptr;
+    const bool overlap = overlap_env && !need_stage && p->opts.hot_enable && nframes > B;
+    if (overlap && !p->aux) {
+        UPSP_HIP_CHECK(hipStreamCreateWithFlags(&p->aux, hipStreamNonBlocking));
+        UPSP_HIP_CHECK(hipEventCreateWithFlags(&p->ev_in, hipEventDisableTiming));
+        UPSP_HIP_CHECK(hipEventCreateWithFlags(&p->ev_fix[0], hipEventDisableTiming));
+        UPSP_HIP_CHECK(hipEventCreateWithFlags(&p->ev_fix[1], hipEventDisableTiming));
+        UPSP_HIP_CHECK(hipEventCreateWithFlags(&p->ev_out, hipEventDisableTiming));
+    }
+    if (overlap) {  // the gather stream starts after everything already queued on `st`
+        UPSP_HIP_CHECK(hipEventRecord(p->ev_in, st));
+        UPSP_HIP_CHECK(hipStreamWaitEvent(p->aux, p->ev_in, 0));
+    }
+    int kbatch = 0;
+    for (int f0 = 0; f0 < nframes && rc == UPSP_OK; f0 += B, ++kbatch) {
         const int nb = std::min(B, nframes - f0);
         PipelineGather g;
         g.ncams = p->ncams;
@@ -293,7 +317,18 @@ int upsp_pipeline_process(upsp_pipeline *p, const uint16_t *const *d_frames, int
             g.pix[c] = p->d_pix[c];
             g.weight[c] = p->d_weight[c];
         }
-        if (rc == UPSP_OK) rc = launch_gather(g, st);
+        if (rc == UPSP_OK && overlap) {
+            hipEvent_t e = p->ev_fix[kbatch & 1];
+            UPSP_HIP_CHECK(hipEventRecord(e, st));
+            UPSP_HIP_CHECK(hipStreamWaitEvent(p->aux, e, 0));
+            rc = launch_gather(g, p->aux);
+        } else if (rc == UPSP_OK) {
+            rc = launch_gather(g, st);
+        }
+    }
+    if (overlap) {  // join: later work on `st` sees the gathers
+        UPSP_HIP_CHECK(hipEventRecord(p->ev_out, p->aux));
+        UPSP_HIP_CHECK(hipStreamWaitEvent(st, p->ev_out, 0));
     }
     return rc;
 }
