@@ -10,6 +10,9 @@ ap.add_argument("--ld", type=int, default=0)
 ap.add_argument("--nodes", type=int, default=500958)
 ap.add_argument("--vis", type=float, default=0.38)
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--reg", action="store_true")
+ap.add_argument("--filter", type=int, default=0)
+ap.add_argument("--patch", type=int, default=0, help="number of fiducial clusters")
 a = ap.parse_args()
 size, N, F = 1024, a.nodes, a.frames
 g = torch.Generator(device="cuda"); g.manual_seed(1)
@@ -19,8 +22,23 @@ pix[torch.rand(N, generator=g, device="cuda") > a.vis] = -1
 frames = torch.empty((F, size, size), dtype=torch.uint16, device="cuda")
 for f0 in range(0, F, 50):
     syn.synth_frames_torch(min(50, F - f0), size, size, first=f0, out=frames[f0:f0 + 50])
-pipe = engine.FramePipeline(1, size, size, N)
+opts = {}
+if a.reg: opts["registration"] = 1
+if a.filter: opts.update(filter=1, filter_size=a.filter)
+if a.patch: opts["patch"] = 1
+pipe = engine.FramePipeline(1, size, size, N, **opts)
 pipe.set_projection(0, pix)
+pipe.set_reference(0, frames[0].to(torch.float32))
+if a.patch:
+    rng = np.random.default_rng(0)
+    cl = []
+    for k in range(a.patch):
+        cx, cy = int(rng.integers(20, size - 20)), int(rng.integers(20, size - 20))
+        xs, ys = np.meshgrid(np.arange(cx - 10, cx + 11), np.arange(cy - 10, cy + 11))
+        r = np.hypot(xs - cx, ys - cy)
+        b, i = (r > 5) & (r <= 8), r <= 5
+        cl.append(dict(bx=xs[b], by=ys[b], ix=xs[i], iy=ys[i]))
+    pipe.set_patches(0, cl)
 ld = a.ld or F
 buf = torch.empty((N, ld), dtype=torch.float32, device="cuda")
 rows_t = buf[:, :F] if ld != F else buf
