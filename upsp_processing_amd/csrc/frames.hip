@@ -437,14 +437,18 @@ int launch_gather(const PipelineGather &g, hipStream_t st)
     if (g.nframes <= 64) {
         KTimed kt("gather_tile_kernel", st);
         const dim3 tgrid((unsigned)((g.nnodes + 63) / 64)), tblock(256);
-        if (g.ncams == 1)
-            hipLaunchKernelGGL((gather_tile_kernel<1>), tgrid, tblock, 0, st, a, g.skipped,
-                               (unsigned)g.nnodes, g.nframes, g.rows, g.rows_t, (long long)g.ld_t,
-                               g.sum, g.sumsq);
-        else
-            hipLaunchKernelGGL((gather_tile_kernel<0>), tgrid, tblock, 0, st, a, g.skipped,
-                               (unsigned)g.nnodes, g.nframes, g.rows, g.rows_t, (long long)g.ld_t,
-                               g.sum, g.sumsq);
+#define UPSP_TILE(NC)                                                                          \
+    hipLaunchKernelGGL((gather_tile_kernel<NC>), tgrid, tblock, 0, st, a, g.skipped,          \
+                       (unsigned)g.nnodes, g.nframes, g.rows, g.rows_t, (long long)g.ld_t,    \
+                       g.sum, g.sumsq)
+        switch (g.ncams) {  // per-camera pix / weight stay in registers for 1..4 cameras
+            case 1: UPSP_TILE(1); break;
+            case 2: UPSP_TILE(2); break;
+            case 3: UPSP_TILE(3); break;
+            case 4: UPSP_TILE(4); break;
+            default: UPSP_TILE(0); break;
+        }
+#undef UPSP_TILE
         UPSP_HIP_CHECK(hipGetLastError());
         return UPSP_OK;
     }

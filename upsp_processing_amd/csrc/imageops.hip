@@ -24,6 +24,7 @@
 #include <cstring>
 #include <vector>
 
+#include "ktimer.h"
 #include "pipeline.h"
 #include "upsp_internal.h"
 
@@ -153,6 +154,7 @@ int launch_gauss(const SRC *src, float *dst, float *tmp, int nimg, int rows, int
     FilterCoef fc;
     if (gaussian_coef(k, fc) != 0) return fail(UPSP_ERR_INVALID, "filter size must be odd and <= 63");
     const dim3 grid(grid_for_pixels((size_t)rows * cols), (unsigned)nimg), block(256);
+    KTimed kt("gauss_pass_kernels", st);
     hipLaunchKernelGGL((gauss_pass_kernel<SRC, true>), grid, block, 0, st, src, tmp, rows, cols, fc);
     hipLaunchKernelGGL((gauss_pass_kernel<float, false>), grid, block, 0, st, (const float *)tmp, dst,
                        rows, cols, fc);
@@ -284,33 +286,48 @@ __global__ void __launch_bounds__(256)
     const size_t hi = min(npix, lo + per_block);
     for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         const int y = (int)(i / (size_t)cols), x = (int)(i % (size_t)cols);
-        const WarpCoord c = warp_coord(M, x, y, 1);
-        const WarpCoord cn = warp_coord(M, x, y, 0);
-        const bool m = (unsigned)cn.sx < (unsigned)cols && (unsigned)cn.sy < (unsigned)rows;
+        // fixed-point source coordinate once; the INTER_LINEAR and INTER_NEAREST (mask)
+        // variants differ only in the rounding offset (16 vs 512) and the shift
+        const int Xr = __double2int_rn((M[1] * y + M[2]) * 1024) + __double2int_rn(M[0] * x * 1024);
+        const int Yr = __double2int_rn((M[4] * y + M[5]) * 1024) + __double2int_rn(M[3] * x * 1024);
+        WarpCoord c;
+        {
+            const int X = (Xr + 16) >> 5, Y = (Yr + 16) >> 5;
+            c.sx = max(-32768, min(32767, X >> 5));
+            c.sy = max(-32768, min(32767, Y >> 5));
+            c.ax = X & 31;
+            c.ay = Y & 31;
+        }
+        const int nx = max(-32768, min(32767, (Xr + 512) >> 10)), ny = max(-32768, min(32767, (Yr + 512) >> 10));
+        const bool m = (unsigned)nx < (unsigned)cols && (unsigned)ny < (unsigned)rows;
         const float w = bilinear(pix, rows, cols, c);
         const float gx = bilinear(gxf, rows, cols, c);
         const float gy = bilinear(gyf, rows, cols, c);
         const float X = (float)x, Y = (float)y;
         const float J[6] = {gx * X, gy * X, gx * Y, gy * Y, gx, gy};
         const float t = tmpl[i];
-        if (m) {
-            acc[0] += 1.0;
-            acc[1] += (double)w;
-            acc[2] += (double)w * w;
-            acc[3] += (double)t;
-            acc[4] += (double)t * t;
-            acc[5] += (double)t * w;
-        }
+        // masked terms enter with weight mm = 1 / 0 (branch-free); fma = one rounding
+        const double mm = m ? 1.0 : 0.0, wd = w, td = t, tm = m ? td : 0.0, wm = m ? wd : 0.0;
+        acc[0] += mm;
+        acc[1] += wm;
+        acc[2] = fma(wm, wd, acc[2]);
+        acc[3] += tm;
+        acc[4] = fma(tm, td, acc[4]);
+        acc[5] = fma(tm, wd, acc[5]);
+        double Jd[6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) Jd[a] = (double)J[a];
         int h = 24;
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
-            acc[6 + a] += (double)J[a] * w;
-            if (m) {
-                acc[12 + a] += (double)J[a];
-                acc[18 + a] += (double)J[a] * t;
-            }
+            acc[6 + a] = fma(Jd[a], wd, acc[6 + a]);
+            acc[12 + a] = fma(Jd[a], mm, acc[12 + a]);
+            acc[18 + a] = fma(Jd[a], tm, acc[18 + a]);
 #pragma unroll
-            for (int b = a; b < 6; ++b) acc[h++] += (double)J[a] * J[b];
+            for (int b = a; b < 6; ++b) {
+                acc[h] = fma(Jd[a], Jd[b], acc[h]);
+                ++h;
+            }
         }
     }
     // deterministic block reduction: wave shuffle tree, then 4 waves through LDS
@@ -368,17 +385,26 @@ __device__ bool inv6(const float *Ain, float *inv)
 
 // One lane per frame: the body of the cv::findTransformECC iteration after the
 // image passes (ecc.cpp): meanStdDev, rho, hessian inverse, lambda, deltaP, update.
-__global__ void ecc_solve_kernel(EccState *__restrict__ state, const double *__restrict__ partial,
-                                 int nframes, int nblocks, int max_iters, double eps)
+__global__ void __launch_bounds__(64)
+    ecc_solve_kernel(EccState *__restrict__ state, const double *__restrict__ partial,
+                     int nframes, int nblocks, int max_iters, double eps)
 {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    // one wave per frame: lanes 0..44 reduce one sum each over the block partials (fixed
+    // order), lane 0 then runs the scalar part
+    const int f = blockIdx.x;
     if (f >= nframes) return;
     EccState &es = state[f];
     if (es.done) return;
+    __shared__ double Ssh[kEccSums];
+    if (threadIdx.x < kEccSums) {
+        double v = 0.0;
+        for (int b = 0; b < nblocks; ++b) v += partial[((size_t)f * nblocks + b) * kEccSums + threadIdx.x];
+        Ssh[threadIdx.x] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
     double S[kEccSums];
-    for (int k = 0; k < kEccSums; ++k) S[k] = 0.0;
-    for (int b = 0; b < nblocks; ++b)
-        for (int k = 0; k < kEccSums; ++k) S[k] += partial[((size_t)f * nblocks + b) * kEccSums + k];
+    for (int k = 0; k < kEccSums; ++k) S[k] = Ssh[k];
     const double n = S[0];
     const double mw = n ? S[1] / n : 0, mt = n ? S[3] / n : 0;
     const double vw = n ? S[2] / n - mw * mw : 0, vt = n ? S[4] / n - mt * mt : 0;
@@ -800,11 +826,15 @@ static int run_ecc(FrameScratch *s, const float *tmpl_blur, const uint16_t *fram
         // a few iterations between host checks of the active-frame count
         const int burst = it == 0 ? 3 : 2;
         for (int k = 0; k < burst && it < max_iters; ++k, ++it) {
-            hipLaunchKernelGGL(ecc_sums_kernel, dim3(kEccBlocks, nb), dim3(256), 0, st,
-                               (const float *)s->ecc_img, tmpl_blur, rows, cols,
-                               (const EccState *)s->state, s->partial);
-            hipLaunchKernelGGL(ecc_solve_kernel, g1, b1, 0, st, s->state, (const double *)s->partial,
-                               nb, kEccBlocks, max_iters, eps);
+            {
+                KTimed kt("ecc_sums_kernel", st);
+                hipLaunchKernelGGL(ecc_sums_kernel, dim3(kEccBlocks, nb), dim3(256), 0, st,
+                                   (const float *)s->ecc_img, tmpl_blur, rows, cols,
+                                   (const EccState *)s->state, s->partial);
+            }
+            KTimed kt2("ecc_solve_kernel", st);
+            hipLaunchKernelGGL(ecc_solve_kernel, dim3(nb), dim3(64), 0, st, s->state,
+                               (const double *)s->partial, nb, kEccBlocks, max_iters, eps);
         }
         int h[2] = {0, 0};
         UPSP_HIP_CHECK(hipMemsetAsync(s->counter, 0, 2 * sizeof(int), st));
@@ -838,8 +868,11 @@ int run_frame_stages(FrameScratch *s, int cam, const uint16_t *d_frames, int nb,
         int rc = run_ecc(s, s->tmpl[cam], d_frames, nb, first_frame, rows, cols, opts.ecc_max_iters,
                          opts.ecc_eps, st);
         if (rc != UPSP_OK) return rc;
-        hipLaunchKernelGGL(warp_u16_kernel, pgrid, block, 0, st, d_frames, s->warp[cam], rows, cols,
-                           (const EccState *)s->state, opts.interp);
+        {
+            KTimed kt("warp_u16_kernel", st);
+            hipLaunchKernelGGL(warp_u16_kernel, pgrid, block, 0, st, d_frames, s->warp[cam], rows, cols,
+                               (const EccState *)s->state, opts.interp);
+        }
         if (d_warps)
             hipLaunchKernelGGL(ecc_export_warps, dim3((nb + 63) / 64), dim3(64), 0, st,
                                (const EccState *)s->state, nb, d_warps + (size_t)cam * 6, ncams * 6);

@@ -1010,6 +1010,61 @@ struct DevBuf {
     hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
 };
 
+// Small host batches (the per-ray calls of the pybind `BVH.intersect`): one pinned
+// host block + one device block cached in the BVH, one H2D copy, one launch, one D2H
+// copy on a private stream -- no allocation, no device-wide synchronisation.
+constexpr size_t kStageRays = 4096;
+constexpr size_t kStageBytesPerRay = 24 + 1 + 4 + 4 + 12 + 12 + 12 + 3;  // in + outputs (+pad)
+
+template <bool ANYHIT>
+int cast_host_small(upsp_bvh *b, const float *h_org, int org_stride, const float *h_dir, size_t n,
+                    const upsp_hits &h_out)
+{
+    const size_t cap = kStageRays * 72;
+    if (!b->d_stage) {
+        UPSP_HIP_CHECK(hipMalloc(&b->d_stage, cap));
+        UPSP_HIP_CHECK(hipHostMalloc(&b->h_stage, cap, hipHostMallocDefault));
+        UPSP_HIP_CHECK(hipStreamCreateWithFlags(&b->stage_stream, hipStreamNonBlocking));
+    }
+    hipStream_t st = b->stage_stream;
+    // layout (both sides): org[3n] dir[3n] | t[n] prim[n] uvw[3n] pos[3n] nrm[3n] hit[n]
+    char *h = static_cast<char *>(b->h_stage), *d = static_cast<char *>(b->d_stage);
+    const size_t in_bytes = 24 * n, o_t = in_bytes, o_prim = o_t + 4 * n, o_uvw = o_prim + 4 * n,
+                 o_pos = o_uvw + 12 * n, o_nrm = o_pos + 12 * n, o_hit = o_nrm + 12 * n,
+                 total = o_hit + n;
+    float *ho = reinterpret_cast<float *>(h);
+    for (size_t i = 0; i < n; ++i) {
+        const float *o = h_org + (org_stride ? 3 * i : 0);
+        ho[3 * i] = o[0]; ho[3 * i + 1] = o[1]; ho[3 * i + 2] = o[2];
+    }
+    std::memcpy(h + 12 * n, h_dir, 12 * n);
+    UPSP_HIP_CHECK(hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, st));
+    upsp_hits dv;
+    std::memset(&dv, 0, sizeof(dv));
+    dv.hit = reinterpret_cast<uint8_t *>(d + o_hit);
+    if (!ANYHIT) {
+        dv.t = reinterpret_cast<float *>(d + o_t);
+        dv.prim = reinterpret_cast<int32_t *>(d + o_prim);
+        dv.uvw = reinterpret_cast<float *>(d + o_uvw);
+        dv.pos = reinterpret_cast<float *>(d + o_pos);
+        dv.nrm = reinterpret_cast<float *>(d + o_nrm);
+    }
+    int rc = launch_cast<ANYHIT>(b, reinterpret_cast<const float *>(d), 3,
+                                 reinterpret_cast<const float *>(d + 12 * n), n, dv, st);
+    if (rc != UPSP_OK) return rc;
+    UPSP_HIP_CHECK(hipMemcpyAsync(h + in_bytes, d + in_bytes, total - in_bytes, hipMemcpyDeviceToHost, st));
+    UPSP_HIP_CHECK(hipStreamSynchronize(st));
+    if (h_out.hit) std::memcpy(h_out.hit, h + o_hit, n);
+    if (!ANYHIT) {
+        if (h_out.t) std::memcpy(h_out.t, h + o_t, 4 * n);
+        if (h_out.prim) std::memcpy(h_out.prim, h + o_prim, 4 * n);
+        if (h_out.uvw) std::memcpy(h_out.uvw, h + o_uvw, 12 * n);
+        if (h_out.pos) std::memcpy(h_out.pos, h + o_pos, 12 * n);
+        if (h_out.nrm) std::memcpy(h_out.nrm, h + o_nrm, 12 * n);
+    }
+    return UPSP_OK;
+}
+
 template <bool ANYHIT>
 int cast_host(const upsp_bvh *bvh, const float *h_org, int org_stride, const float *h_dir,
               size_t n, const upsp_hits &h_out)
@@ -1018,6 +1073,8 @@ int cast_host(const upsp_bvh *bvh, const float *h_org, int org_stride, const flo
     if (n == 0) return UPSP_OK;
     if (!h_org || !h_dir) return fail(UPSP_ERR_INVALID, "null ray buffers");
     if (org_stride != 0 && org_stride != 3) return fail(UPSP_ERR_INVALID, "org_stride must be 0 or 3");
+    if (n <= kStageRays && !bvh->stats_on)
+        return cast_host_small<ANYHIT>(const_cast<upsp_bvh *>(bvh), h_org, org_stride, h_dir, n, h_out);
     DevBuf org, dir, hit, t, prim, uvw, pos, nrm;
     const size_t no = org_stride ? 3 * n : 3;
     UPSP_HIP_CHECK(org.alloc(no * 4));
@@ -1037,7 +1094,7 @@ int cast_host(const upsp_bvh *bvh, const float *h_org, int org_stride, const flo
     int rc = launch_cast<ANYHIT>(bvh, (const float *)org.p, org_stride, (const float *)dir.p, n,
                                  d, nullptr);
     if (rc != UPSP_OK) return rc;
-    UPSP_HIP_CHECK(hipDeviceSynchronize());
+    UPSP_HIP_CHECK(hipStreamSynchronize(nullptr));
     if (d.hit) UPSP_HIP_CHECK(hipMemcpy(h_out.hit, d.hit, n, hipMemcpyDeviceToHost));
     if (d.t) UPSP_HIP_CHECK(hipMemcpy(h_out.t, d.t, n * 4, hipMemcpyDeviceToHost));
     if (d.prim) UPSP_HIP_CHECK(hipMemcpy(h_out.prim, d.prim, n * 4, hipMemcpyDeviceToHost));
@@ -1130,6 +1187,9 @@ void upsp_bvh_destroy(upsp_bvh *b)
     if (b->d_work) (void)hipFree(b->d_work);
     if (b->d_retry_nodes) (void)hipFree(b->d_retry_nodes);
     if (b->d_retry_mask) (void)hipFree(b->d_retry_mask);
+    if (b->d_stage) (void)hipFree(b->d_stage);
+    if (b->h_stage) (void)hipHostFree(b->h_stage);
+    if (b->stage_stream) (void)hipStreamDestroy(b->stage_stream);
     delete b;
 }
 

@@ -71,6 +71,8 @@ struct upsp_bvh {
     uint32_t *d_work = nullptr;   // [0] work-queue head, [2..7] 64-bit stats, [8..10] see raycast.hip
     uint32_t *d_retry_nodes = nullptr, *d_retry_mask = nullptr;  // projection-build retry list
     size_t retry_capacity = 0;
+    void *d_stage = nullptr, *h_stage = nullptr;  // small host batches (pybind per-ray calls)
+    struct ihipStream_t *stage_stream = nullptr;
     int32_t root_ref = 0;
     float root_min[3], root_max[3];
     upsp_bvh_info info;
