@@ -165,3 +165,36 @@ def test_full_size_properties(gpu_lib):
     assert dist.max().item() < 1e-4
     uvw = a["uvw"][h]
     assert (uvw.sum(1) - 1).abs().max().item() < 1e-5 and uvw.min().item() >= 0
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_random_soups_bitwise(gpu_lib, oracle, seed):
+    """Unstructured triangle soups (overlapping, sliver, zero-area, duplicated, axis-aligned
+    triangles; coordinates on a coarse lattice so that exact ties and exact-zero edge functions
+    are common) x rays with zero / negative-zero / huge / tiny components."""
+    from upsp_processing_amd import engine
+    rng = np.random.default_rng(seed)
+    ntri = [7, 300, 5000, 20000][seed]
+    lattice = rng.integers(-8, 9, size=(ntri, 3, 3)).astype(np.float32) * 0.25
+    smooth = rng.normal(size=(ntri, 3, 3)).astype(np.float32)
+    tris = np.where(rng.random((ntri, 1, 1)) < 0.5, lattice, smooth * 2)
+    tris[::11, 2] = tris[::11, 1]                       # zero-area (two equal vertices)
+    tris[::13] = tris[1::13][: len(tris[::13])] if len(tris[1::13]) >= len(tris[::13]) else tris[::13]  # duplicates
+    tris[::17, :, 2] = 0.5                              # axis-aligned (flat boxes)
+    s9 = np.ascontiguousarray(tris.reshape(-1), np.float32)
+    bvh, obv = engine.BVH(s9), oracle.OracleBVH(s9)
+    assert bvh.info["n_ref_nodes"] == obv.nnodes
+    n = 30000
+    org = (rng.integers(-12, 13, size=(n, 3)) * 0.25).astype(np.float32)
+    dirs = rng.normal(size=(n, 3)).astype(np.float32)
+    dirs[::5] = rng.integers(-2, 3, size=(len(dirs[::5]), 3)).astype(np.float32)   # lattice directions, zeros
+    dirs[1::7, 0] = -0.0
+    dirs[2::9] *= 1e6
+    dirs[3::9] *= 1e-6
+    dirs[(dirs == 0).all(1)] = [0, 0, 1]
+    # rays aimed exactly at vertices
+    tgt = tris.reshape(-1, 3)[rng.integers(0, ntri * 3, size=n // 3)]
+    dirs[: n // 3] = tgt - org[: n // 3]
+    dirs[(dirs == 0).all(1)] = [1, 0, 0]
+    assert_hits_equal(bvh.intersect(org, dirs), obv.intersect(org, dirs))
+    assert np.array_equal(bvh.occluded(org, dirs).cpu().numpy(), obv.intersect(org, dirs)["hit"])
