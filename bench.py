@@ -140,15 +140,20 @@ def main():
         syn.synth_frames_torch(min(chunk, F - f0), size, size, first=rank * F + f0, out=frames[f0:f0 + chunk])
     shard = D.Shard(F * world, N, rank, world)
     pipe = engine.FramePipeline(1, size, size, N)
-    rows_t = torch.empty((N, F), dtype=torch.float32, device="cuda")
-    series = (torch.empty((shard.node_count[rank], F * world), dtype=torch.float32, device="cuda")
-              if world > 1 else None)
+    rows_t = torch.empty((N, F), dtype=torch.float32, device="cuda") if world == 1 else None
     torch.cuda.synchronize()
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
     t_ray, t_frames, t_xchg = [], [], []
     nrays_last = [0]
     primary_rays_last, retry_nodes_last = [0], [0]
+
+    # N > 1: the frame loop runs in K chunks and the all-to-all of chunk k is issued
+    # asynchronously while chunk k+1 is being processed (distributed.TimeSeriesExchange)
+    K = 4 if world > 1 else 1
+    exch = D.TimeSeriesExchange(shard, K) if world > 1 else None
+    chunk_bufs = ([torch.empty((N, exch.my_chunk(k)[1]), dtype=torch.float32, device="cuda")
+                   for k in range(K)] if world > 1 else None)
 
     def step(record):
         e = [ev() for _ in range(4)]
@@ -157,11 +162,20 @@ def main():
         e[1].record()
         pipe.reset()
         pipe.set_projection(0, proj["pix"])
-        pipe.process(frames, first_frame=rank * F, rows_t=rows_t, want_rows=False)
+        if world == 1:
+            pipe.process(frames, first_frame=rank * F, rows_t=rows_t, want_rows=False)
+        else:
+            exch.k = 0
+            for k in range(K):
+                c0, fc = exch.my_chunk(k)
+                pipe.process(frames[c0:c0 + fc], first_frame=rank * F + c0, rows_t=chunk_bufs[k],
+                             want_rows=False)
+                exch.submit(chunk_bufs[k])
         e[2].record()
         s, ss = pipe.accumulators()
         D.allreduce_sums(s, ss)
-        D.exchange_time_series(rows_t, shard, out=series)
+        if world > 1:
+            exch.finish()
         avg, rms = pipe.finalize(F * world)
         e[3].record()
         if record:

@@ -43,6 +43,12 @@ def _worker(rank, world, port, F, N, seed, q):
     D.allreduce_sums(s, ss)
     rows_t = torch.as_tensor(np.ascontiguousarray(mine.T))
     series = D.exchange_time_series(rows_t, shard)
+    # the same exchange pipelined in 3 chunks must give the same slice
+    ex = D.TimeSeriesExchange(shard, 3, device="cpu")
+    for k in range(3):
+        c0, fc = ex.my_chunk(k)
+        ex.submit(rows_t[:, c0:c0 + fc].contiguous())
+    assert torch.equal(ex.finish().view(torch.int32), series.view(torch.int32))
     n0, nn = shard.my_nodes
     full = D.gather_time_series_to_root(series, shard)
     q.put((rank, s.numpy(), ss.numpy(), series.numpy(), n0, nn,

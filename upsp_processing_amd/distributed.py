@@ -92,6 +92,61 @@ def exchange_time_series(rows_t, shard, group=None, out=None):
     return out
 
 
+class TimeSeriesExchange:
+    """global_transpose pipelined with the frame loop: the rank's frames are produced in K
+    chunks; the all-to-all of chunk k is issued asynchronously as soon as its node-major
+    block exists, so the xGMI transfers overlap the gathers of chunk k+1.  Every rank uses the
+    same K; rank s cuts its own frame range with apportion(frame_count[s], K), so all ranks
+    know every block shape without communication."""
+
+    def __init__(self, shard, nchunks, dtype=torch.float32, device="cuda", group=None):
+        self.shard, self.K, self.group = shard, max(1, int(nchunks)), group
+        n0, nn = shard.my_nodes
+        self.out = torch.empty((nn, shard.nframes), dtype=dtype, device=device)
+        self.chunks = [apportion(shard.frame_count[s], self.K) for s in range(shard.world)]
+        self.pending = []
+        self.k = 0
+
+    def my_chunk(self, k):
+        """(local frame offset, frame count) of this rank's chunk k."""
+        st, ex = self.chunks[self.shard.rank]
+        return st[k], ex[k]
+
+    def submit(self, rows_t_chunk):
+        """rows_t_chunk: [N, fc] contiguous, this rank's chunk number len(submitted)."""
+        sh, k = self.shard, self.k
+        c0, fc = self.my_chunk(k)
+        assert rows_t_chunk.shape == (sh.nnodes, fc) and rows_t_chunk.is_contiguous()
+        n0, nn = sh.my_nodes
+        if sh.world == 1 or not dist.is_initialized():
+            if fc:
+                self.out[:, c0:c0 + fc] = rows_t_chunk
+            self.k += 1
+            return
+        in_split = [sh.node_count[d] * fc for d in range(sh.world)]
+        out_split = [nn * self.chunks[s][1][k] for s in range(sh.world)]
+        recv = torch.empty(sum(out_split), dtype=rows_t_chunk.dtype, device=rows_t_chunk.device)
+        work = dist.all_to_all_single(recv, rows_t_chunk.reshape(-1), out_split, in_split,
+                                      group=self.group, async_op=True)
+        self.pending.append((work, recv, k, rows_t_chunk))   # keep the send buffer alive
+        self.k += 1
+
+    def finish(self):
+        sh = self.shard
+        n0, nn = sh.my_nodes
+        for work, recv, k, _ in self.pending:
+            work.wait()
+            off = 0
+            for s in range(sh.world):
+                fs = self.chunks[s][1][k]
+                if fs and nn:
+                    col = sh.frame_start[s] + self.chunks[s][0][k]
+                    self.out[:, col:col + fs] = recv[off:off + nn * fs].view(nn, fs)
+                off += nn * fs
+        self.pending = []
+        return self.out
+
+
 def gather_time_series_to_root(series, shard, group=None):
     """Single gather of the node-major slices to rank 0: [N, F] on rank 0, None elsewhere.
     Slices are ragged (apportion), so this is one point-to-point transfer per rank
