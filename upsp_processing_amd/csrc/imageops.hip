@@ -300,9 +300,28 @@ __global__ void __launch_bounds__(256)
         }
         const int nx = max(-32768, min(32767, (Xr + 512) >> 10)), ny = max(-32768, min(32767, (Yr + 512) >> 10));
         const bool m = (unsigned)nx < (unsigned)cols && (unsigned)ny < (unsigned)rows;
-        const float w = bilinear(pix, rows, cols, c);
-        const float gx = bilinear(gxf, rows, cols, c);
-        const float gy = bilinear(gyf, rows, cols, c);
+        float w, gx, gy;
+        if (c.sx >= 1 && c.sx + 2 < cols && c.sy >= 1 && c.sy + 2 < rows) {
+            // fully interior footprint: 12 pixels, no border handling; same arithmetic as
+            // the generic path (bilinear of I, of [-0.5 0 0.5] along x and along y)
+            const float *r0 = I + (size_t)(c.sy - 1) * cols + c.sx;
+            const float *r1 = r0 + cols, *r2 = r1 + cols, *r3 = r2 + cols;
+            const float a0 = r0[0], a1 = r0[1];
+            const float b_1 = r1[-1], b0 = r1[0], b1 = r1[1], b2 = r1[2];
+            const float c_1 = r2[-1], c0 = r2[0], c1 = r2[1], c2 = r2[2];
+            const float d0 = r3[0], d1 = r3[1];
+            const float fx = c.ax * (1.f / 32), fy = c.ay * (1.f / 32);
+            const float w0 = (1.f - fy) * (1.f - fx), w1 = (1.f - fy) * fx, w2 = fy * (1.f - fx), w3 = fy * fx;
+            w = b0 * w0 + b1 * w1 + c0 * w2 + c1 * w3;
+            gx = (-0.5f * b_1 + 0.5f * b1) * w0 + (-0.5f * b0 + 0.5f * b2) * w1 +
+                 (-0.5f * c_1 + 0.5f * c1) * w2 + (-0.5f * c0 + 0.5f * c2) * w3;
+            gy = (-0.5f * a0 + 0.5f * c0) * w0 + (-0.5f * a1 + 0.5f * c1) * w1 +
+                 (-0.5f * b0 + 0.5f * d0) * w2 + (-0.5f * b1 + 0.5f * d1) * w3;
+        } else {
+            w = bilinear(pix, rows, cols, c);
+            gx = bilinear(gxf, rows, cols, c);
+            gy = bilinear(gyf, rows, cols, c);
+        }
         const float X = (float)x, Y = (float)y;
         const float J[6] = {gx * X, gy * X, gx * Y, gy * Y, gx, gy};
         const float t = tmpl[i];
