@@ -1,0 +1,39 @@
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from upsp_processing_amd import _capi, engine, synthetic as syn
+t0 = time.time()
+v, t = syn.tunnel_model_quad(576, 205)       # ~5.0 M triangles
+s9, tn = syn.soup(v, t); nrm = syn.node_normals(v, t)
+print("mesh", v.shape, t.shape, "%.1fs" % (time.time() - t0))
+bvh = engine.BVH(s9); print(bvh.info)
+size = 1024
+dn, dm, dt = [torch.as_tensor(x).cuda() for x in (v, nrm, tn)]
+pix = []
+for az in (0, 90, 180, 270):
+    cd = syn.pinhole_camera(size, size, center=(0, 0, 20), half_extent=6.0, azimuth_deg=az)
+    cam = _capi.make_camera(cd["K"], cd["dist"], cd["R"], cd["t"], size, size)
+    for r in range(2):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        p = engine.build_projection(bvh, cam, dn, dm, dt, 70.0)
+        torch.cuda.synchronize(); dt_ = time.perf_counter() - t0
+    print("cam az=%d: %.2f ms, %d rays (%.0f Mrays/s), visible %d" % (az, dt_ * 1e3, p["nrays"], p["nrays"] / dt_ / 1e6, int((p["pix"] >= 0).sum())))
+    pix.append(p["pix"])
+pix = torch.stack(pix)
+centers = np.array([engine.camera_center(_capi.make_camera(*(lambda c: (c["K"], c["dist"], c["R"], c["t"]))(syn.pinhole_camera(size, size, center=(0, 0, 20), half_extent=6.0, azimuth_deg=az)), size, size)) for az in (0, 90, 180, 270)])
+w = engine.projection_weights(pix, dn, dm, centers, "average_view")
+sk, ns = engine.skipped_nodes(pix)
+print("skipped", ns, "of", v.shape[0])
+F = 64
+frames = [syn.synth_frames_torch(F, size, size, first=100 * c) for c in range(4)]
+pipe = engine.FramePipeline(4, size, size, v.shape[0])
+for c in range(4):
+    pipe.set_projection(c, pix[c], w[c])
+rows_t = torch.empty((v.shape[0], F), dtype=torch.float32, device="cuda")
+for r in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    pipe.process(frames, 0, rows_t=rows_t, want_rows=False)
+    torch.cuda.synchronize(); d = time.perf_counter() - t0
+print("4-camera frame loop: %.2f ms for %d frame sets (%.0f camera-frames/s)" % (d * 1e3, F, 4 * F / d))
+ok = ~sk
+print("finite", torch.isfinite(rows_t[ok]).all().item(), "nan skipped", torch.isnan(rows_t[sk]).all().item())

@@ -209,6 +209,56 @@ struct Builder {
 
 }  // namespace
 
+// The first `top` interior nodes are renumbered in breadth-first order (the rest keep
+// their depth-first order behind them), so the upper levels of the tree -- the nodes every
+// ray visits -- form one contiguous block that the traversal kernels stage in LDS.
+// Only indices change; topology, child order and leaf order are untouched.
+static void relabel_top_breadth_first(HostBvh &out, uint32_t top)
+{
+    const uint32_t n = (uint32_t)out.nodes.size();
+    if (n == 0 || out.root_ref < 0) return;
+    top = std::min(top, n);
+    std::vector<uint32_t> order;   // new index -> old index
+    std::vector<int32_t> newid(n, -1);
+    order.reserve(n);
+    auto child = [&](uint32_t node, int k) {
+        int32_t r;
+        std::memcpy(&r, &out.nodes[node].q[12 + k], 4);
+        return r;
+    };
+    order.push_back((uint32_t)out.root_ref);
+    newid[out.root_ref] = 0;
+    for (size_t head = 0; head < order.size() && order.size() < top; ++head)
+        for (int k = 0; k < 2; ++k) {
+            const int32_t c = child(order[head], k);
+            if (c >= 0 && newid[c] < 0 && order.size() < top) {
+                newid[c] = (int32_t)order.size();
+                order.push_back((uint32_t)c);
+            }
+        }
+    out.top_nodes = (uint32_t)order.size();
+    for (uint32_t i = 0; i < n; ++i)
+        if (newid[i] < 0) {
+            newid[i] = (int32_t)order.size();
+            order.push_back(i);
+        }
+    std::vector<GpuNode> renum(n);
+    for (uint32_t ni = 0; ni < n; ++ni) {
+        GpuNode g = out.nodes[order[ni]];
+        for (int k = 0; k < 2; ++k) {
+            int32_t r;
+            std::memcpy(&r, &g.q[12 + k], 4);
+            if (r >= 0) {
+                r = newid[r];
+                std::memcpy(&g.q[12 + k], &r, 4);
+            }
+        }
+        renum[ni] = g;
+    }
+    out.nodes.swap(renum);
+    out.root_ref = newid[out.root_ref];
+}
+
 void build_bvh(const float *tris9, size_t ntris, HostBvh &out)
 {
     out = HostBvh();
@@ -221,6 +271,7 @@ void build_bvh(const float *tris9, size_t ntris, HostBvh &out)
         out.root_min[a] = root.lo[a];
         out.root_max[a] = root.hi[a];
     }
+    relabel_top_breadth_first(out, kTopNodesMax);
 }
 
 }  // namespace upsp

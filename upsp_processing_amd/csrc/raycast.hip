@@ -296,6 +296,8 @@ struct Scene {
     int root_ref;
     int refill;           // re-fill threshold (live lanes)
     unsigned chunk;       // work items per queue grab (multiple of 64)
+    int top;              // nodes [0, top) are staged in LDS (breadth-first upper tree)
+    int stack_ints;       // LDS ints taken by the traversal stacks (top nodes follow)
     float rlo[3], rhi[3];
 };
 
@@ -337,13 +339,19 @@ __device__ __forceinline__ void trav_pop(Trav &s, const int *stack)
 // queued, until fewer than kRefill lanes of the wave are still busy.
 template <bool ANYHIT, bool STATS>
 __device__ __forceinline__ void trav_run(Trav &s, const Ray &r, const Scene &sc, int *stack,
-                                         bool more, int refill)
+                                         const float4 *top_lds, bool more, int refill)
 {
     while (s.cur != kDone) {
         // ---- interior nodes: descend until a leaf (or nothing) is current ----
         while (s.cur >= 0) {
-            const float4 *np = sc.nodes + 4 * (size_t)s.cur;
-            const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+            float4 q0, q1, q2, q3;
+            if (s.cur < sc.top) {  // upper tree: staged in LDS by stage_top()
+                const float4 *lp = top_lds + 4 * s.cur;
+                q0 = lp[0]; q1 = lp[1]; q2 = lp[2]; q3 = lp[3];
+            } else {
+                const float4 *np = sc.nodes + 4 * (size_t)s.cur;
+                q0 = np[0]; q1 = np[1]; q2 = np[2]; q3 = np[3];
+            }
             if (STATS) { ++s.n_nodes; ++s.ray_nodes; }
             const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
             const unsigned meta = __float_as_uint(q3.z);
@@ -411,6 +419,16 @@ __device__ __forceinline__ void trav_run(Trav &s, const Ray &r, const Scene &sc,
 }
 
 __device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63u; }
+
+// Copies the breadth-first upper tree (sc.top nodes x 64 B) behind the traversal stacks
+// in LDS; returns its base.  Called by every thread of the workgroup at kernel start.
+__device__ __forceinline__ const float4 *stage_top(const Scene &sc, int *lds)
+{
+    float4 *dst = reinterpret_cast<float4 *>(lds + sc.stack_ints);
+    for (int i = threadIdx.x; i < sc.top * 4; i += blockDim.x) dst[i] = sc.nodes[i];
+    __syncthreads();
+    return dst;
+}
 
 // Wave-level work distribution.  `cur`/`end` are wave-uniform.
 struct WaveQueue {
@@ -551,6 +569,7 @@ __global__ void __launch_bounds__(kBlock)
 {
     extern __shared__ int lds_stack[];
     int *stack = lds_stack + threadIdx.x;
+    const float4 *top_lds = stage_top(sc, lds_stack);
     WaveQueue q;
     queue_init(q, work, n, sc.chunk);
     Ray r;
@@ -579,7 +598,7 @@ __global__ void __launch_bounds__(kBlock)
         if (__ballot(busy) == 0ull) break;
         // ---- traverse ----
         if (busy) {
-            trav_run<ANYHIT, STATS>(s, r, sc, stack, queue_has_more(q), sc.refill);
+            trav_run<ANYHIT, STATS>(s, r, sc, stack, top_lds, queue_has_more(q), sc.refill);
             if (s.cur == kDone) {
                 if (STATS) {
                     atomicMax(&work[8], s.ray_nodes);
@@ -688,6 +707,7 @@ __global__ void __launch_bounds__(kBlock)
 {
     extern __shared__ int lds_stack[];
     int *stack = lds_stack + threadIdx.x;
+    const float4 *top_lds = stage_top(sc, lds_stack);
     const unsigned total = PHASE == 0 ? nnodes : work[kWorkRetryCount] * 6u;
     WaveQueue q;
     queue_init(q, work, total, sc.chunk);
@@ -735,7 +755,7 @@ __global__ void __launch_bounds__(kBlock)
         if (__ballot(busy) == 0ull) break;
 
         if (busy) {
-            trav_run<false, STATS>(s, r, sc, stack, queue_has_more(q), sc.refill);
+            trav_run<false, STATS>(s, r, sc, stack, top_lds, queue_has_more(q), sc.refill);
             if (s.cur == kDone) {
                 busy = false;
                 const unsigned node = PHASE == 0 ? item : retry_nodes[item / 6u];
@@ -892,6 +912,17 @@ int stack_entries(const upsp_bvh *b)
     return d < 8 ? 8 : d;
 }
 
+int top_count(const upsp_bvh *b)
+{
+    static const int top_cap = env_int("UPSP_TOP_NODES", 0);  // measured slower: off
+    return (int)std::min<uint32_t>(b->top_nodes, (uint32_t)std::max(top_cap, 0));
+}
+
+size_t lds_bytes(const upsp_bvh *b)
+{
+    return (size_t)stack_entries(b) * kBlock * sizeof(int) + (size_t)top_count(b) * sizeof(GpuNode);
+}
+
 Scene make_scene(const upsp_bvh *b, size_t items, int grid)
 {
     Scene sc;
@@ -902,6 +933,8 @@ Scene make_scene(const upsp_bvh *b, size_t items, int grid)
     sc.nodes = reinterpret_cast<const float4 *>(b->d_nodes);
     sc.tris = reinterpret_cast<const float4 *>(b->d_tris);
     sc.root_ref = b->root_ref;
+    sc.top = top_count(b);
+    sc.stack_ints = stack_entries(b) * kBlock;
     static const int refill = env_int("UPSP_REFILL", kRefillDefault);
     sc.refill = refill;
     for (int a = 0; a < 3; ++a) {
@@ -979,7 +1012,7 @@ int launch_cast(const upsp_bvh *cb, const float *d_org, int org_stride, const fl
     if (n > 0xF0000000ull) return fail(UPSP_ERR_INVALID, "too many rays in one call");
     const int entries = stack_entries(b);
     if (entries > 64) return fail(UPSP_ERR_DEPTH, "BVH deeper than 64 levels");
-    const size_t lds = (size_t)entries * kBlock * sizeof(int);
+    const size_t lds = lds_bytes(b);
     UPSP_HIP_CHECK(hipMemsetAsync(b->d_work, 0, 16 * sizeof(unsigned), st));
     const int grid = grid_for(n, lds);
     const Scene sc = make_scene(b, n, grid);
@@ -1162,6 +1195,7 @@ int upsp_bvh_create(const float *h_tris9, size_t ntris, upsp_bvh **out)
         return fail(UPSP_ERR_HIP, std::string("BVH upload: ") + hipGetErrorString(e));
     }
     b->root_ref = hb.root_ref;
+    b->top_nodes = hb.top_nodes;
     std::memset(&b->info, 0, sizeof(b->info));
     for (int a = 0; a < 3; ++a) {
         b->root_min[a] = b->info.bounds_min[a] = hb.root_min[a];
@@ -1293,7 +1327,7 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
     hipStream_t st = (hipStream_t)stream;
     const int entries = stack_entries(b);
     if (entries > 64) return fail(UPSP_ERR_DEPTH, "BVH deeper than 64 levels");
-    const size_t lds = (size_t)entries * kBlock * sizeof(int);
+    const size_t lds = lds_bytes(b);
 
     Cam c;
     std::memcpy(c.K, cam->K, sizeof(c.K));

@@ -49,6 +49,7 @@ static_assert(sizeof(GpuTri) == 48, "GpuTri must be 48 bytes");
 constexpr int kLeafBits = 6;
 constexpr int kMaxLeaf = 1 << kLeafBits;  // triangles addressable by one leaf ref
 constexpr uint32_t kMetaOrdered = 4u;
+constexpr uint32_t kTopNodesMax = 255;  // upper-tree nodes renumbered breadth-first (LDS staging)
 
 struct HostBvh {
     std::vector<GpuNode> nodes;
@@ -58,6 +59,7 @@ struct HostBvh {
     uint32_t n_ref_nodes = 0;
     uint32_t depth = 0;
     uint32_t max_leaf = 0;
+    uint32_t top_nodes = 0;  // nodes [0, top_nodes) are the breadth-first upper tree
 };
 
 // SAH build with the reference's topology and leaf order (pspRT.cpp:456-572).
@@ -74,6 +76,7 @@ struct upsp_bvh {
     void *d_stage = nullptr, *h_stage = nullptr;  // small host batches (pybind per-ray calls)
     struct ihipStream_t *stage_stream = nullptr;
     int32_t root_ref = 0;
+    uint32_t top_nodes = 0;
     float root_min[3], root_max[3];
     upsp_bvh_info info;
     int device = 0;
