@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--size", type=int, default=1024, help="frame is size x size")
     ap.add_argument("--small", action="store_true", help="reduced mesh/frames (plumbing check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-chunked", action="store_true",
+                    help="run the chunked / pipelined-exchange frame loop of the N>1 path on one GPU")
     ap.add_argument("--model", default="quad", choices=["quad", "uv"],
                     help="quad: cube-sphere tunnel model (valence <= 6); uv: UV-sphere model with "
                          "1000-valent polar fans (worst case for per-ray traversal length)")
@@ -140,7 +142,8 @@ def main():
         syn.synth_frames_torch(min(chunk, F - f0), size, size, first=rank * F + f0, out=frames[f0:f0 + chunk])
     shard = D.Shard(F * world, N, rank, world)
     pipe = engine.FramePipeline(1, size, size, N)
-    rows_t = torch.empty((N, F), dtype=torch.float32, device="cuda") if world == 1 else None
+    rows_t = (torch.empty((N, F), dtype=torch.float32, device="cuda")
+              if not (world > 1 or a.force_chunked) else None)
     torch.cuda.synchronize()
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
@@ -150,10 +153,11 @@ def main():
 
     # N > 1: the frame loop runs in K chunks and the all-to-all of chunk k is issued
     # asynchronously while chunk k+1 is being processed (distributed.TimeSeriesExchange)
-    K = 4 if world > 1 else 1
-    exch = D.TimeSeriesExchange(shard, K) if world > 1 else None
+    chunked = world > 1 or a.force_chunked          # --force-chunked: exercise the N>1 loop on one GPU
+    K = 4 if chunked else 1
+    exch = D.TimeSeriesExchange(shard, K) if chunked else None
     chunk_bufs = ([torch.empty((N, exch.my_chunk(k)[1]), dtype=torch.float32, device="cuda")
-                   for k in range(K)] if world > 1 else None)
+                   for k in range(K)] if chunked else None)
 
     def step(record):
         e = [ev() for _ in range(4)]
@@ -162,7 +166,7 @@ def main():
         e[1].record()
         pipe.reset()
         pipe.set_projection(0, proj["pix"])
-        if world == 1:
+        if not chunked:
             pipe.process(frames, first_frame=rank * F, rows_t=rows_t, want_rows=False)
         else:
             exch.k = 0
@@ -174,8 +178,8 @@ def main():
         e[2].record()
         s, ss = pipe.accumulators()
         D.allreduce_sums(s, ss)
-        if world > 1:
-            exch.finish()
+        if chunked:
+            series = exch.finish()
         avg, rms = pipe.finalize(F * world)
         e[3].record()
         if record:

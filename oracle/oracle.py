@@ -141,12 +141,13 @@ class OracleBVH:
         assert tris9.size % 9 == 0
         self.ntris = tris9.size // 9
         self._h = lib().orc_bvh_create(_p(tris9), self.ntris)
+        self._destroy = lib().orc_bvh_destroy
         if not self._h:
             raise ValueError("BVH::BVH() : no primitives!")
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().orc_bvh_destroy(self._h)
+            self._destroy(self._h)
             self._h = None
 
     @property

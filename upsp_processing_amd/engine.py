@@ -41,11 +41,12 @@ class BVH:
         h = C.c_void_p()
         check(lib().upsp_bvh_create(tris9.ctypes.data_as(C.c_void_p), tris9.size // 9, C.byref(h)))
         self._h = h
+        self._destroy = lib().upsp_bvh_destroy      # bound now: module globals vanish at exit
         self.ntris = tris9.size // 9
 
     def close(self):
         if getattr(self, "_h", None):
-            lib().upsp_bvh_destroy(self._h)
+            self._destroy(self._h)
             self._h = None
 
     __del__ = close
@@ -241,11 +242,12 @@ class FramePipeline:
         h = C.c_void_p()
         check(lib().upsp_pipeline_create(ncams, width, height, nnodes, C.byref(o), C.byref(h)))
         self._h, self.ncams, self.width, self.height, self.nnodes = h, ncams, width, height, nnodes
+        self._destroy = lib().upsp_pipeline_destroy
         self.opts = o
 
     def close(self):
         if getattr(self, "_h", None):
-            lib().upsp_pipeline_destroy(self._h)
+            self._destroy(self._h)
             self._h = None
 
     __del__ = close
