@@ -261,6 +261,20 @@ int upsp_patch_f32(float *d_img, int rows, int cols, int nclusters, const int32_
                    const int32_t *h_ix, const int32_t *h_iy, void *stream);
 
 /* ======================================================================== *
+ *  3b. Video decode -> device   (reference:
+ *      upsp::unpack_12bit cpp/lib/PSPVideo.cpp:134-149, MrawReader::read_frame
+ *      cpp/lib/MrawReader.cpp:113-146, 12-bit CineReader path cpp/lib/CineReader.cpp:428)
+ * ======================================================================== */
+
+/* Unpacks nframes frames of 12-bit packed pixels (3 bytes -> 2 pixels, MSBs first,
+ * npix*3/2 bytes per frame, npix even) into u16 [nframes][npix] on the device.  Uploading the
+ * packed bytes and unpacking in HBM moves 1.5 instead of 2 bytes per pixel over PCIe.
+ * If d_hot_count != NULL (nframes counters, zeroed by the caller) the kernel also counts
+ * the pixels >= hot_thresh per frame while they are in registers (pass 1 of fix_hot_pixels). */
+int upsp_unpack_12bit(const uint8_t *d_packed, int nframes, size_t npix, uint16_t *d_frames,
+                      int hot_thresh, uint32_t *d_hot_count, void *stream);
+
+/* ======================================================================== *
  *  4.  Measurement support (no reference counterpart; the reference only has
  *      psp::BlockTimer / timedBarrierPoint wall-clock prints, pspTimer.h:10-41)
  * ======================================================================== */

@@ -98,6 +98,7 @@ def lib():
 
 
 _OPTIONAL = [
+    ("orc_unpack_12bit", [C.c_void_p, C.c_size_t, C.c_void_p], None),
     ("orc_gaussian_kernel", [C.c_int, C.c_void_p], C.c_int),
     ("orc_blur_f32", [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int], None),
     ("orc_warp_affine_u16", [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int], None),
@@ -358,3 +359,10 @@ def patch_clusters(img, clusters):
     arr = [np.asarray(a, dtype=np.int32) for a in (b_off, bx, by, i_off, ix, iy)]
     lib().orc_patch_clusters(_p(img), img.shape[1], len(clusters), *[_p(a) for a in arr])
     return img
+
+
+def unpack_12bit(packed):
+    packed = np.ascontiguousarray(packed, dtype=np.uint8).reshape(-1)
+    out = np.zeros(packed.size * 2 // 3, np.uint16)
+    lib().orc_unpack_12bit(_p(packed), packed.size, _p(out))
+    return out

@@ -202,6 +202,11 @@ void orc_patch_clusters(float *img, int cols, int nclusters, const int32_t *b_of
                         const int32_t *bx, const int32_t *by, const int32_t *i_off,
                         const int32_t *ix, const int32_t *iy);
 
+/* ------------------------------------------------------------- video ---- */
+
+/* upsp::unpack_12bit, cpp/lib/PSPVideo.cpp:134-149 (MRAW / 12-bit CINE frames) */
+void orc_unpack_12bit(const uint8_t *packed, size_t nbytes, uint16_t *out);
+
 #ifdef __cplusplus
 }
 #endif
