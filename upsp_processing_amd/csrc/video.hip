@@ -70,9 +70,15 @@ __global__ void __launch_bounds__(256)
             if (hot_count) hot += (dst[i] >= hot_thresh) + (dst[i + 1] >= hot_thresh);
         }
     }
-    if (hot_count) {
+    if (hot_count) {  // wave shuffle, then one atomic per workgroup (and only if non-zero)
+        __shared__ unsigned wsum[4];
         for (int off = 32; off > 0; off >>= 1) hot += __shfl_down(hot, off);
-        if ((threadIdx.x & 63) == 0 && hot) atomicAdd(&hot_count[f], hot);
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = hot;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+            if (tot) atomicAdd(&hot_count[f], tot);
+        }
     }
 }
 
