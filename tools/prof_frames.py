@@ -49,4 +49,4 @@ for r in range(a.reps):
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     rep = _capi.timing_report()
     print("F=%d ld=%d: %.3f ms  %.0f frames/s | " % (F, ld, dt * 1e3, F / dt) +
-          " ".join("%s=%.3f" % (k.split("_kernel")[0], v[1]) for k, v in rep.items()))
+          " ".join("%s=%.3f(%d)" % (k.split("_kernel")[0], v[1], v[0]) for k, v in rep.items()))

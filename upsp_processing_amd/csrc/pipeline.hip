@@ -113,12 +113,17 @@ int upsp_pipeline_create(int ncams, int width, int height, size_t nnodes,
         upsp_pipeline_destroy(p);
         return fail(UPSP_ERR_HIP, std::string("pipeline alloc: ") + hipGetErrorString(e));
     }
-    // sub-batch: keep u16 frames (+ f32 copies) of all cameras within ~128 MiB
+    // sub-batch: one gather tile = 64 frames; without image stages that is also what keeps
+    // the u16 frames of a sub-batch (128 MiB at 1 Mpix) inside the Infinity Cache between
+    // the hot-pixel scan and the gather.  With registration the ECC iterations run in lock
+    // step over the sub-batch and late iterations have few active frames: 64 frames per
+    // launch keep the chip busy.  Patch / filter only: bounded by the f32 working copies.
     const size_t per_frame = (size_t)width * height * (size_t)ncams *
-                             (2 + ((p->opts.patch || p->opts.filter) ? 4 : 0) +
-                              (p->opts.registration ? 2 : 0));
-    size_t b = (128u << 20) / std::max<size_t>(per_frame, 1);
-    p->batch = (int)std::min<size_t>(std::max<size_t>(b, 1), 64);  // one gather tile = 64 frames
+                             (2 + ((p->opts.patch || p->opts.filter) ? 4 : 0));
+    size_t b = (p->opts.registration ? (512u << 20) : (128u << 20)) / std::max<size_t>(per_frame, 1);
+    static const int batch_env = std::getenv("UPSP_BATCH") ? std::atoi(std::getenv("UPSP_BATCH")) : 0;
+    if (batch_env > 0) b = (size_t)batch_env;
+    p->batch = (int)std::min<size_t>(std::max<size_t>(b, 1), 64);
     *out = p;
     return UPSP_OK;
 }

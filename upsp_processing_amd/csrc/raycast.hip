@@ -337,77 +337,90 @@ __device__ __forceinline__ void trav_pop(Trav &s, const int *stack)
 
 // Runs the lane's traversal until it finishes (returns) -- or, when `more` work is
 // queued, until fewer than kRefill lanes of the wave are still busy.
+// One interior-node step: fetch the 64-byte record, test both child boxes, descend to
+// the near child (push the far one) or pop.
+template <bool ANYHIT, bool STATS>
+__device__ __forceinline__ void node_step(Trav &s, const Ray &r, const Scene &sc, int *stack,
+                                          const float4 *top_lds)
+{
+    float4 q0, q1, q2, q3;
+    if (s.cur < sc.top) {  // upper tree: staged in LDS by stage_top()
+        const float4 *lp = top_lds + 4 * s.cur;
+        q0 = lp[0]; q1 = lp[1]; q2 = lp[2]; q3 = lp[3];
+    } else {
+        const float4 *np = sc.nodes + 4 * (size_t)s.cur;
+        q0 = np[0]; q1 = np[1]; q2 = np[2]; q3 = np[3];
+    }
+    if (STATS) { ++s.n_nodes; ++s.ray_nodes; }
+    const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
+    const unsigned meta = __float_as_uint(q3.z);
+    float dFl, dFr;
+    const BoxEval bl = box_filter(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, dFl);
+    const BoxEval br = box_filter(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, dFr);
+    bool hL = bl.accept, hR = br.accept;
+    if (__ballot(bl.undecided | br.undecided) != 0ull) {  // rare: grazing contact
+        if (bl.undecided) hL = box_exact(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
+        if (br.undecided) hR = box_exact(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w);
+    }
+    if (!ANYHIT) {
+        // near plane of the child box along the ray's major axis, as a ray parameter
+        hL = hL & !(r.prune_ok & (dFl * r.absSz > s.limit));
+        hR = hR & !(r.prune_ok & (dFr * r.absSz > s.limit));
+    }
+    // near child first: dirIsNeg[node->axis] (pspRT.cpp:410-419)
+    const bool swap = !(meta & kMetaOrdered) && ((r.neg >> (meta & 3u)) & 1u);
+    const int first = swap ? right : left, second = swap ? left : right;
+    const bool hF = swap ? hR : hL, hS = swap ? hL : hR;
+    if (hF) {
+        s.cur = first;
+        if (hS) {
+            stack[s.sp * kBlock] = second;
+            ++s.sp;
+        }
+    } else if (hS) {
+        s.cur = second;
+    } else {
+        trav_pop(s, stack);
+    }
+}
+
+// Tests the triangles of one leaf in leaf order; returns true when an any-hit query is done.
+template <bool ANYHIT, bool STATS>
+__device__ __forceinline__ bool leaf_step(Trav &s, const Ray &r, const Scene &sc, int leaf)
+{
+    const unsigned code = (unsigned)(~leaf);
+    const unsigned first = code >> kLeafBits, count = (code & (kMaxLeaf - 1)) + 1;
+    for (unsigned i = 0; i < count; ++i) {
+        const float4 *tp = sc.tris + 3 * (size_t)(first + i);
+        const float4 a = tp[0], b = tp[1], c = tp[2];
+        if (STATS) { ++s.n_tris; ++s.ray_tris; }
+        TriHit h;
+        if (tri_test(r, a.x, a.y, a.z, b.x, b.y, b.z, c.x, c.y, c.z, h)) {
+            s.any = true;
+            if (ANYHIT) return true;
+            if (h.t < s.best_t) {  // strict <, pspRT.cpp:395
+                s.best_t = h.t;
+                s.best_slot = (int)(first + i);
+                s.limit = h.t + fabsf(h.t) * 4e-6f;
+            }
+        }
+    }
+    return false;
+}
+
+// Runs the lane's traversal until it finishes (returns) -- or, when `more` work is
+// queued, until fewer than `refill` lanes of the wave are still busy.  Classic while-while:
+// descend interior nodes until every live lane holds a leaf, then test the leaves.
+// (A speculative variant that parks one leaf and keeps descending was measured 15 % slower:
+// the delayed pruning limit costs more node visits than the better lane occupancy saves.)
 template <bool ANYHIT, bool STATS>
 __device__ __forceinline__ void trav_run(Trav &s, const Ray &r, const Scene &sc, int *stack,
                                          const float4 *top_lds, bool more, int refill)
 {
     while (s.cur != kDone) {
-        // ---- interior nodes: descend until a leaf (or nothing) is current ----
-        while (s.cur >= 0) {
-            float4 q0, q1, q2, q3;
-            if (s.cur < sc.top) {  // upper tree: staged in LDS by stage_top()
-                const float4 *lp = top_lds + 4 * s.cur;
-                q0 = lp[0]; q1 = lp[1]; q2 = lp[2]; q3 = lp[3];
-            } else {
-                const float4 *np = sc.nodes + 4 * (size_t)s.cur;
-                q0 = np[0]; q1 = np[1]; q2 = np[2]; q3 = np[3];
-            }
-            if (STATS) { ++s.n_nodes; ++s.ray_nodes; }
-            const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
-            const unsigned meta = __float_as_uint(q3.z);
-            float dFl, dFr;
-            const BoxEval bl = box_filter(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, dFl);
-            const BoxEval br = box_filter(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, dFr);
-            bool hL = bl.accept, hR = br.accept;
-            if (__ballot(bl.undecided | br.undecided) != 0ull) {  // rare: grazing contact
-                if (bl.undecided) hL = box_exact(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
-                if (br.undecided) hR = box_exact(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w);
-            }
-            if (!ANYHIT) {
-                // near plane of the child box along the ray's major axis, as a ray parameter
-                hL = hL & !(r.prune_ok & (dFl * r.absSz > s.limit));
-                hR = hR & !(r.prune_ok & (dFr * r.absSz > s.limit));
-            }
-            // near child first: dirIsNeg[node->axis] (pspRT.cpp:410-419)
-            const bool swap = !(meta & kMetaOrdered) && ((r.neg >> (meta & 3u)) & 1u);
-            const int first = swap ? right : left, second = swap ? left : right;
-            const bool hF = swap ? hR : hL, hS = swap ? hL : hR;
-            if (hF) {
-                s.cur = first;
-                if (hS) {
-                    stack[s.sp * kBlock] = second;
-                    ++s.sp;
-                }
-            } else if (hS) {
-                s.cur = second;
-            } else {
-                trav_pop(s, stack);
-            }
-        }
-        // ---- leaf ----
+        while (s.cur >= 0) node_step<ANYHIT, STATS>(s, r, sc, stack, top_lds);
         if (s.cur != kDone) {
-            const unsigned code = (unsigned)(~s.cur);
-            const unsigned first = code >> kLeafBits, count = (code & (kMaxLeaf - 1)) + 1;
-            bool stop = false;
-            for (unsigned i = 0; i < count; ++i) {
-                const float4 *tp = sc.tris + 3 * (size_t)(first + i);
-                const float4 a = tp[0], b = tp[1], c = tp[2];
-                if (STATS) { ++s.n_tris; ++s.ray_tris; }
-                TriHit h;
-                if (tri_test(r, a.x, a.y, a.z, b.x, b.y, b.z, c.x, c.y, c.z, h)) {
-                    s.any = true;
-                    if (ANYHIT) {
-                        stop = true;
-                        break;
-                    }
-                    if (h.t < s.best_t) {  // strict <, pspRT.cpp:395
-                        s.best_t = h.t;
-                        s.best_slot = (int)(first + i);
-                        s.limit = h.t + fabsf(h.t) * 4e-6f;
-                    }
-                }
-            }
-            if (stop) {
+            if (leaf_step<ANYHIT, STATS>(s, r, sc, s.cur)) {
                 s.cur = kDone;
                 s.sp = 0;
             } else {
