@@ -378,6 +378,21 @@ __global__ void skipped_kernel(int ncams, unsigned nnodes, const int32_t *__rest
     if ((threadIdx.x & 63) == 0 && m && count) atomicAdd(count, (unsigned long long)__popcll(m));
 }
 
+struct PixPtrs {
+    const int32_t *p[kMaxCams];
+};
+
+// identify_skipped_nodes over per-camera arrays (no staging copy, no host sync)
+__global__ void skipped_ptrs_kernel(int ncams, unsigned nnodes, PixPtrs pp,
+                                    uint8_t *__restrict__ skipped)
+{
+    const unsigned n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= nnodes) return;
+    bool found = false;
+    for (int c = 0; c < ncams; ++c) found |= pp.p[c][n] >= 0;
+    skipped[n] = found ? 0 : 1;
+}
+
 __global__ void project_one_kernel(const void *img, int is_f32, const int32_t *__restrict__ pix,
                                    const float *__restrict__ weight, unsigned nnodes,
                                    float *__restrict__ out)
@@ -460,6 +475,17 @@ int launch_gather(const PipelineGather &g, hipStream_t st)
     else
         hipLaunchKernelGGL((gather_kernel<0>), grid, block, 0, st, a, g.skipped, (unsigned)g.nnodes,
                            g.nframes, g.rows, g.sum, g.sumsq);
+    UPSP_HIP_CHECK(hipGetLastError());
+    return UPSP_OK;
+}
+
+int launch_skipped(int ncams, size_t nnodes, const int32_t *const *d_pix, uint8_t *d_skipped,
+                   hipStream_t st)
+{
+    PixPtrs pp;
+    for (int c = 0; c < kMaxCams; ++c) pp.p[c] = c < ncams ? d_pix[c] : nullptr;
+    hipLaunchKernelGGL(skipped_ptrs_kernel, dim3((unsigned)((nnodes + 255) / 256)), dim3(256), 0, st,
+                       ncams, (unsigned)nnodes, pp, d_skipped);
     UPSP_HIP_CHECK(hipGetLastError());
     return UPSP_OK;
 }

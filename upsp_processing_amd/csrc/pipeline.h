@@ -32,6 +32,8 @@ int launch_hot_fix(uint16_t *d_frames, int nframes, int rows, int cols, int thre
                    int min_change, int max_hot, unsigned *d_count, unsigned *d_pos,
                    int32_t *d_status, hipStream_t st);
 int launch_gather(const PipelineGather &g, hipStream_t st);
+int launch_skipped(int ncams, size_t nnodes, const int32_t *const *d_pix, uint8_t *d_skipped,
+                   hipStream_t st);
 int launch_finals(const double *sum, const double *sumsq, size_t nnodes, uint64_t nframes,
                   float *avg, float *rms, hipStream_t st);
 

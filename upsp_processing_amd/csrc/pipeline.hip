@@ -244,16 +244,8 @@ int upsp_pipeline_process(upsp_pipeline *p, const uint16_t *const *d_frames, int
     }
     if (d_rows_t && ld_t < col0 + nframes) return fail(UPSP_ERR_INVALID, "ld_t too small");
     if (!p->skipped_valid) {
-        // identify_skipped_nodes over all cameras (projection.ipp:857-880)
-        std::vector<int32_t *> tmp(p->ncams);
-        int32_t *d_all = nullptr;
-        UPSP_HIP_CHECK(hipMalloc(&d_all, sizeof(int32_t) * p->nnodes * (size_t)p->ncams));
-        for (int c = 0; c < p->ncams; ++c)
-            (void)hipMemcpyAsync(d_all + (size_t)c * p->nnodes, p->d_pix[c],
-                                 sizeof(int32_t) * p->nnodes, hipMemcpyDeviceToDevice, st);
-        int rc = upsp_projection_skipped(p->ncams, p->nnodes, d_all, p->d_skipped, nullptr, st);
-        (void)hipStreamSynchronize(st);
-        (void)hipFree(d_all);
+        // identify_skipped_nodes over all cameras (projection.ipp:857-880), stream-ordered
+        int rc = upsp::launch_skipped(p->ncams, p->nnodes, p->d_pix, p->d_skipped, st);
         if (rc != UPSP_OK) return rc;
         p->skipped_valid = true;
     }
