@@ -1,0 +1,93 @@
+"""psp_process command-line surface: flag / input-deck parsing and the .tri reader on CPU;
+end-to-end run (deck -> .tri grid + camera JSON + 12-bit .mraw -> flat files) on the GPU,
+checked against the phase-1 driver called directly."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+
+def write_case(tmp, nframes=12, size=(192, 160), registration="none", filt="none"):
+    from upsp_processing_amd import psp_process as cli, synthetic as syn
+    W, H = size
+    v, t = syn.tunnel_model_quad(16, 6)
+    cli.write_tri_grid(os.path.join(tmp, "model.tri"), v, t, comps=np.ones(len(t), np.int32))
+    cams = []
+    for c, az in enumerate((0, 70)):
+        cd = syn.pinhole_camera(W, H, center=(0.2, 0.1, 20), half_extent=6.5, azimuth_deg=az)
+        json.dump({"cameraMatrix": cd["K"].tolist(), "distCoeffs": [0.0, 0.0, 0.0, 0.0],
+                   "rmat": cd["R"].tolist(), "tvec": cd["t"].tolist(), "imageSize": [W, H]},
+                  open(os.path.join(tmp, "cam%02d.json" % (c + 1)), "w"))
+        fr = syn.synth_frames_numpy(nframes, H, W, seed=40 + c, noise=2.0, hot=True)
+        pix = fr.reshape(nframes, -1)
+        buf = np.zeros((nframes, pix.shape[1] * 3 // 2), np.uint8)      # pack_12bpp layout
+        buf[:, 0::3] = pix[:, 0::2] >> 4
+        buf[:, 1::3] = ((pix[:, 0::2] & 0x0F) << 4) | (pix[:, 1::2] >> 8)
+        buf[:, 2::3] = pix[:, 1::2] & 0xFF
+        buf.tofile(os.path.join(tmp, "cam%02d.mraw" % (c + 1)))
+        with open(os.path.join(tmp, "cam%02d.cih" % (c + 1)), "w") as f:
+            f.write("#Camera Information Header\r\nRecord Rate(fps) : 1000\r\nTotal Frame : %d\r\n"
+                    "Image Width : %d\r\nImage Height : %d\r\nColor Bit : 12\r\n" % (nframes, W, H))
+        cams.append((cd, fr))
+    with open(os.path.join(tmp, "run.inp"), "w") as f:
+        f.write("@general\n  test = t1\n  run = 1\n  sequence = 2\n  tunnel = ames_unitary\n"
+                "@vars\n  dir = %s\n@all\n  grid = $dir/model.tri\n" % tmp)
+        for c in (1, 2):
+            f.write("@camera\n  number = %d\n  filename = $dir/cam%02d.mraw\n"
+                    "  calibration = $dir/cam%02d.json\n  aedc = false\n" % (c, c, c))
+        f.write("@options\n  registration = %s\n  filter = %s\n  filter_size = 3\n"
+                "  overlap = best_view\n  oblique_angle = 70\n  number_frames = %d\n"
+                "@output\n  dir = $dir/out\n" % (registration, filt, nframes))
+    return v, t, cams
+
+
+def test_deck_flags_and_tri_reader(tmp_path):
+    from upsp_processing_amd import psp_process as cli
+    v, t, cams = write_case(str(tmp_path))
+    flags = cli.parse_flags(["-input_file=%s/run.inp" % tmp_path, "-h5_out=x.h5", "-frames=5", "--checkout"])
+    assert flags["frames"] == "5" and flags["checkout"] == "true"
+    with pytest.raises(cli.DeckError):
+        cli.parse_flags(["-h5_out=x.h5"])
+    deck = cli.parse_input_deck(flags["input_file"])
+    assert deck["all"]["grid"] == "%s/model.tri" % tmp_path and len(deck["camera"]) == 2
+    assert deck["options"]["overlap"] == "best_view" and deck["options"]["target_patcher"] == "none"
+    xyz, tris, comps = cli.read_tri_grid(deck["all"]["grid"])
+    assert np.array_equal(xyz, v) and np.array_equal(tris, t) and comps.size == len(t)
+    cal = cli.read_camera_json(deck["camera"][1]["calibration"])
+    assert cal["size"] == (192, 160) and np.allclose(cal["K"], cams[1][0]["K"])
+    bad = str(tmp_path / "bad.inp")
+    open(bad, "w").write(open(flags["input_file"]).read().replace("filter_size = 3", "filter_size = 4")
+                         .replace("filter = none", "filter = gaussian"))
+    with pytest.raises(cli.DeckError):
+        cli.parse_input_deck(bad)
+    open(bad, "w").write(open(flags["input_file"]).read() + "@options\n  target_patcher = polynomial\n")
+    with pytest.raises(cli.DeckError):
+        cli.parse_input_deck(bad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("filt", ["none", "gaussian"])
+def test_cli_end_to_end(gpu_lib, tmp_path, filt):
+    import torch
+    from upsp_processing_amd import psp, psp_process as cli, synthetic as syn
+    tmp = str(tmp_path)
+    v, t, cams = write_case(tmp, filt=filt)
+    assert cli.main(["-input_file=%s/run.inp" % tmp, "-h5_out=%s/o.h5" % tmp, "-paint_cal=none"]) == 0
+    out = os.path.join(tmp, "out")
+    n, F = v.shape[0], 12
+    series = np.fromfile(os.path.join(out, "intensity_transpose"), "<f4").reshape(n, F)
+    # the same phase 1 through the driver, frames handed over unpacked
+    s9, tn = syn.soup(v, t)
+    job = psp.Phase1(s9, tn, v, syn.node_normals(v, t),
+                     [dict(K=c["K"], dist=c["dist"], R=c["R"], t=c["t"]) for c, _ in cams], (192, 160),
+                     overlap="best_view", filter=None if filt == "none" else filt, filter_size=3)
+    finals, ser2 = psp.run_phase1(job, [fr.copy() for _, fr in cams])
+    assert np.array_equal(series.view(np.int32), ser2.cpu().numpy().view(np.int32))
+    for name, key in (("intensity_avg", "avg"), ("intensity_rms", "rms"), ("coverage", "coverage"),
+                      ("intensity_ratio_0", "ratio_0")):
+        a = np.fromfile(os.path.join(out, name), "<f4")
+        assert np.array_equal(a.view(np.int32), finals[key].cpu().numpy().view(np.int32)), name
+    assert np.array_equal(np.fromfile(os.path.join(out, "X"), "<f4"), v[:, 0])
+    assert os.path.getsize(os.path.join(out, "cam01-uv")) == 8 * n
+    job.close()

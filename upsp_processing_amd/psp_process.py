@@ -1,0 +1,217 @@
+"""`psp_process` command-line surface for phase 1 on the GPU engine.
+
+    python -m upsp_processing_amd.psp_process -input_file=run.inp -h5_out=out.h5 -paint_cal=paint.json \\
+           [-frames=N] [-add_out_dir=DIR] [-cutoff_x_max=X]
+
+Accepts the reference's flags (cv::CommandLineParser style `-name=value`,
+cpp/exec/psp_process.cpp:1193-1218) and its input deck (`@general / @vars / @all / @camera /
+@options / @output` with `$var` substitution, docs/sphinx/file-formats.rst:239-470,
+cpp/lib/upsp_inputs.cpp) for the part of the pipeline this repository implements:
+
+* grid: Cart3D `.tri` (cpp/lib/TriModel.ipp:117-257)        [PLOT3D grids: not built]
+* camera calibration JSON (cpp/lib/CameraCal.cpp:19-54)
+* video: 12-bit Photron `.mraw` (cpp/lib/MrawReader.cpp)      [`.cine`: not built]
+* options: registration = none|pixel, filter = none|gaussian|box (+ filter_size),
+  overlap = best_view|average_view, oblique_angle, number_frames
+  [target_patcher = polynomial needs the phase-0 patch set-up, SURVEY.md 8f N2: rejected]
+
+and writes the phase-1 flat files (intensity_transpose, intensity_avg, intensity_rms,
+intensity_ratio_0, coverage, camNN-uv, vv-int-*.dat; cpp/exec/psp_process.cpp:524-540).
+Phase 2 (pressure) and the HDF5 container are out of scope; `-h5_out` / `-paint_cal` are
+accepted and ignored.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+
+class DeckError(ValueError):
+    pass
+
+
+def parse_flags(argv):
+    """cv::CommandLineParser syntax: -name=value or --name=value; bare -name = true."""
+    flags = {}
+    for a in argv:
+        if not a.startswith("-"):
+            raise DeckError("unexpected argument %r" % a)
+        a = a.lstrip("-")
+        k, _, v = a.partition("=")
+        flags[k] = v if v != "" else "true"
+    for req in ("input_file",):
+        if req not in flags:
+            raise DeckError("missing required flag -%s" % req)
+    return flags
+
+
+def parse_input_deck(path):
+    """FileInputs::Load (cpp/lib/upsp_inputs.cpp): sections with key = value lines."""
+    deck = {"general": {}, "vars": {}, "all": {}, "camera": [], "options": {}, "output": {}}
+    section = None
+    with open(path) as f:
+        for raw in f:
+            line = raw.split("#", 1)[0].strip()
+            if not line:
+                continue
+            if line.startswith("@"):
+                section = line[1:].strip().lower()
+                if section not in deck:
+                    raise DeckError("unknown section @%s" % section)
+                if section == "camera":
+                    deck["camera"].append({})
+                continue
+            if section is None or "=" not in line:
+                raise DeckError("malformed line %r" % raw.rstrip())
+            k, v = [t.strip() for t in line.split("=", 1)]
+            for name, val in deck["vars"].items():       # $var substitution
+                v = v.replace("$" + name, val)
+            (deck["camera"][-1] if section == "camera" else deck[section])[k] = v
+    opts = deck["options"]
+    # defaults: cpp/lib/upsp_inputs.cpp:29-33
+    opts.setdefault("target_patcher", "none")
+    opts.setdefault("registration", "none")
+    opts.setdefault("filter", "none")
+    opts.setdefault("filter_size", "1")
+    opts.setdefault("overlap", "average_view")
+    opts.setdefault("oblique_angle", "70")
+    # validation: cpp/exec/psp_process.cpp:1284-1319
+    if deck["general"].get("tunnel", "ames_unitary") != "ames_unitary":
+        raise DeckError("only tunnel = ames_unitary is supported")
+    if opts["registration"] not in ("none", "pixel"):
+        raise DeckError("registration must be none or pixel")
+    if opts["filter"] not in ("none", "gaussian", "box"):
+        raise DeckError("filter must be none, gaussian or box")
+    if opts["filter"] != "none" and int(opts["filter_size"]) % 2 == 0:
+        raise DeckError("filter_size must be odd")
+    if opts["overlap"] not in ("best_view", "average_view"):
+        raise DeckError("overlap must be best_view or average_view")
+    if opts["target_patcher"] != "none":
+        raise DeckError("target_patcher = %s needs the phase-0 patch set-up, which this engine "
+                        "does not build" % opts["target_patcher"])
+    if not deck["camera"]:
+        raise DeckError("no @camera section")
+    return deck
+
+
+def read_tri_grid(path):
+    """Cart3D unformatted `.tri` (cpp/lib/TriModel.ipp:117-257): Fortran records
+    {n_node, n_tri} / n_node x (x,y,z) f32 / n_tri x (n1,n2,n3) int32 1-based / [components]."""
+    with open(path, "rb") as f:
+        buf = f.read()
+    off = 0
+
+    def record():
+        nonlocal off
+        n = int(np.frombuffer(buf, "<i4", 1, off)[0])
+        body = buf[off + 4:off + 4 + n]
+        tail = int(np.frombuffer(buf, "<i4", 1, off + 4 + n)[0])
+        if tail != n:
+            raise DeckError("corrupt Fortran record in %s" % path)
+        off += 8 + n
+        return body
+
+    n_node, n_tri = np.frombuffer(record(), "<i4", 2)
+    xyz = np.frombuffer(record(), "<f4").reshape(n_node, 3).copy()
+    tris = np.frombuffer(record(), "<i4").reshape(n_tri, 3).astype(np.int32) - 1
+    comps = None
+    if off < len(buf):
+        comps = np.frombuffer(record(), "<i4").copy()
+    return xyz, tris, comps
+
+
+def write_tri_grid(path, xyz, tris, comps=None):
+    """Inverse of read_tri_grid (used by tests and synthetic data writers)."""
+    def rec(a):
+        b = np.ascontiguousarray(a).tobytes()
+        n = np.array([len(b)], "<i4").tobytes()
+        return n + b + n
+    with open(path, "wb") as f:
+        f.write(rec(np.array([xyz.shape[0], tris.shape[0]], "<i4")))
+        f.write(rec(xyz.astype("<f4")))
+        f.write(rec((tris + 1).astype("<i4")))
+        if comps is not None:
+            f.write(rec(np.asarray(comps, "<i4")))
+
+
+def read_camera_json(path):
+    """read_json_camera_calibration (cpp/lib/CameraCal.cpp:19-54): only the first four
+    distortion coefficients are read."""
+    j = json.load(open(path))
+    dist = np.zeros(5)
+    dc = np.asarray(j["distCoeffs"], dtype=np.float64).ravel()
+    dist[:min(4, dc.size)] = dc[:4]
+    return dict(K=np.asarray(j["cameraMatrix"], dtype=np.float64),
+                dist=dist, R=np.asarray(j["rmat"], dtype=np.float64),
+                t=np.asarray(j["tvec"], dtype=np.float64).ravel(),
+                size=(int(j["imageSize"][0]), int(j["imageSize"][1])))
+
+
+def main(argv=None):
+    import torch
+    from . import psp, synthetic, video, distributed as D
+    flags = parse_flags(sys.argv[1:] if argv is None else argv)
+    deck = parse_input_deck(flags["input_file"])
+    opts = deck["options"]
+    grid = deck["all"].get("grid")
+    if not grid or not grid.endswith(".tri"):
+        raise DeckError("only Cart3D .tri grids are supported (got %r)" % grid)
+    xyz, tris, _ = read_tri_grid(grid)
+    datanode = None
+    if "cutoff_x_max" in flags:                       # psp_process.cpp:1448-1487
+        datanode = (xyz[:, 0] <= float(flags["cutoff_x_max"])).astype(np.uint8)
+    normals = synthetic.node_normals(xyz, tris)       # TriModel_::calcNormals
+    s9, tri_nodes = synthetic.soup(xyz, tris)         # TriModel_::extract_tris
+    cams, readers = [], []
+    for c in deck["camera"]:
+        cal = read_camera_json(c["calibration"])
+        cams.append(cal)
+        fn = c.get("filename") or c.get("cine")
+        if not fn or not fn.endswith(".mraw"):
+            raise DeckError("only .mraw video is supported (got %r)" % fn)
+        readers.append(video.MrawReader(fn))
+    size = cams[0]["size"]
+    for cal, r in zip(cams, readers):
+        if cal["size"] != size or (r.width, r.height) != size:
+            raise DeckError("camera calibration / video sizes disagree")
+    nframes = min(r.num_frames for r in readers)
+    if "number_frames" in opts and int(opts["number_frames"]) > 0:
+        nframes = min(nframes, int(opts["number_frames"]))
+    if "frames" in flags and int(flags["frames"]) > 0:
+        nframes = min(nframes, int(flags["frames"]))
+
+    job = psp.Phase1(s9, tri_nodes, xyz, normals, cams, size,
+                     oblique_angle=float(opts["oblique_angle"]), overlap=opts["overlap"],
+                     datanode=datanode, registration=opts["registration"] == "pixel",
+                     filter=None if opts["filter"] == "none" else opts["filter"],
+                     filter_size=int(opts["filter_size"]))
+    shard = D.Shard(nframes, job.nnodes)
+    f0, nf = shard.my_frames
+    job.set_first_frames([r.read_frames_device(1, 1)[0] for r in readers])
+    rows_t = torch.empty((job.nnodes, max(nf, 1)), dtype=torch.float32, device="cuda")
+    chunk = 256
+    for c0 in range(0, nf, chunk):
+        n = min(chunk, nf - c0)
+        batch = [r.read_frames_device(f0 + c0 + 1, n) for r in readers]     # 1-based frames
+        job.process(batch, first_frame=f0 + c0, rows_t=rows_t, col0=c0)
+        if shard.rank == 0 and c0 % (chunk * 4) == 0:
+            print("  Rank 0:: processing frame %d" % (f0 + c0))
+    finals = job.finalize(nframes)
+    series = D.exchange_time_series(rows_t[:, :nf].contiguous() if rows_t.shape[1] != nf else rows_t, shard)
+    out_dir = flags.get("add_out_dir") or deck["output"].get("dir") or "."
+    job.write_outputs(out_dir, finals, series, node_start=shard.my_nodes[0])
+    if shard.rank == 0:
+        for name, col in (("X", 0), ("Y", 1), ("Z", 2)):                    # :524-540
+            xyz[:, col].astype("<f4").tofile(os.path.join(out_dir, name))
+        print("phase 1 complete: %d frames, %d nodes, %d rays" % (nframes, job.nnodes, job.nrays))
+    job.close()
+    return 0
+
+
+if __name__ == "__main__":
+    try:
+        sys.exit(main())
+    except DeckError as e:
+        print("psp_process: %s" % e, file=sys.stderr)
+        sys.exit(1)
