@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--size", type=int, default=1024, help="frame is size x size")
     ap.add_argument("--small", action="store_true", help="reduced mesh/frames (plumbing check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--registration", action="store_true",
+                    help="configs[2] shape: per-frame ECC registration before the projection")
     ap.add_argument("--force-chunked", action="store_true",
                     help="run the chunked / pipelined-exchange frame loop of the N>1 path on one GPU")
     ap.add_argument("--model", default="quad", choices=["quad", "uv"],
@@ -141,7 +143,9 @@ def main():
     for f0 in range(0, F, chunk):
         syn.synth_frames_torch(min(chunk, F - f0), size, size, first=rank * F + f0, out=frames[f0:f0 + chunk])
     shard = D.Shard(F * world, N, rank, world)
-    pipe = engine.FramePipeline(1, size, size, N)
+    pipe = engine.FramePipeline(1, size, size, N, registration=int(a.registration))
+    if a.registration:
+        pipe.set_reference(0, frames[0].to(torch.float32))   # raw first frame as ECC template
     rows_t = (torch.empty((N, F), dtype=torch.float32, device="cuda")
               if not (world > 1 or a.force_chunked) else None)
     torch.cuda.synchronize()
@@ -274,8 +278,10 @@ def main():
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "configs[1]: %d frames/GPU x %dx%d u16, %d-tri tunnel model (%d nodes), "
-                               "raycast+projection" % (F, size, size, tris.shape[0], N),
+        "config": {"workload": "configs[%d]: %d frames/GPU x %dx%d u16, %d-tri tunnel model (%d nodes), "
+                               "raycast+%sprojection" % (2 if a.registration else 1, F, size, size,
+                                                         tris.shape[0], N,
+                                                         "registration+" if a.registration else ""),
                    "frames_per_gpu": F, "nodes": N, "triangles": int(tris.shape[0]),
                    "parallelism": "frames sharded x%d" % world},
         "mrays_per_s": mrays, "rays_per_step": nrays_last[0],

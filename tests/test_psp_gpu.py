@@ -72,3 +72,49 @@ def test_phase1_two_cameras(gpu_lib, oracle, tmp_path):
     assert np.fromfile(os.path.join(tmp_path, "cam02-uv"), dtype="<f4").size == 2 * n
     assert np.fromfile(os.path.join(tmp_path, "vv-int-avg.dat"), dtype="<f4").size == min(n, 1000)
     job.close()
+
+
+def test_phase1_registration_filter_two_cameras(gpu_lib, oracle):
+    """Two cameras with pixel registration + Gaussian filter through the phase-1 driver vs the
+    oracle pieces in reference order (template = RAW first frame for the loop, repaired first
+    frame for sol1; frame 0 is not registered in the loop, psp_process.cpp:1662-1679, 1777)."""
+    import torch
+    from upsp_processing_amd import engine, psp, synthetic as syn
+    W, H, F = 224, 160, 7
+    v, t = syn.tunnel_model_quad(16, 6)
+    s9, tn = syn.soup(v, t)
+    nrm = syn.node_normals(v, t)
+    cams = [syn.pinhole_camera(W, H, center=(0.3, 0.1, 20), half_extent=6.5, azimuth_deg=az) for az in (0, 55)]
+    frames = [syn.synth_frames_numpy(F, H, W, seed=31 + c, noise=2.0, hot=True) for c in range(2)]
+    job = psp.Phase1(s9, tn, v, nrm, cams, (W, H), overlap="average_view", registration=True,
+                     filter="gaussian", filter_size=3)
+    finals, series = psp.run_phase1(job, [f.copy() for f in frames], chunk=4)
+
+    obv = oracle.OracleBVH(s9)
+    thr = engine.oblique_threshold(70.0)
+    ocams = [oracle.make_camera(c["K"], c["dist"], c["R"], c["t"], W, H) for c in cams]
+    pix = np.stack([oracle.create_projection(obv, oc, v, nrm, tn, thr)["pix"] for oc in ocams])
+    centers = np.array([oracle.cam_center(oc) for oc in ocams])
+    wgt = oracle.adjust_weights(pix, np.ones_like(pix, dtype=np.float32), v, nrm, centers, 1)
+    sk = oracle.skipped_nodes(pix)
+    n = v.shape[0]
+    rows = np.zeros((F, n), np.float32)
+    for f in range(F):
+        sol = None
+        for c in range(2):
+            img, _ = oracle.fix_hot_pixels(frames[c][f])
+            if f > 0:
+                img, M, it = oracle.register_pixel(frames[c][0].astype(np.float32), img)
+                assert it > 0
+            img = oracle.blur(img.astype(np.float32), 3)
+            cs = oracle.project_frame(img, pix[c], wgt[c])
+            sol = cs if sol is None else (sol + cs).astype(np.float32)
+        rows[f] = sol
+    ok = ~sk
+    got = series.cpu().numpy()
+    assert np.isnan(got[sk]).all()
+    # frame 0: no registration -> only the 1-ulp camera weights differ
+    assert np.allclose(got[ok, 0], rows[0, ok], rtol=3e-7)
+    d = np.abs(got[ok, 1:] - rows[1:, ok].T)
+    assert d.max() <= 12.0 and d.mean() <= 0.5        # same bar as tests/test_imageops_gpu.py
+    job.close()
