@@ -21,6 +21,8 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -31,7 +33,8 @@
 namespace upsp {
 namespace {
 
-constexpr int kEccBlocks = 64;   // partial-sum blocks per frame
+constexpr int kEccBlocks = 64;   // partial-sum blocks per frame (full sub-batch)
+constexpr int kEccBlocksMax = 512;  // ... when only a few frames are still iterating
 constexpr int kEccSums = 45;
 constexpr int kMaxKernel = 63;   // largest odd filter size
 
@@ -404,21 +407,24 @@ __device__ bool inv6(const float *Ain, float *inv)
 
 // One lane per frame: the body of the cv::findTransformECC iteration after the
 // image passes (ecc.cpp): meanStdDev, rho, hessian inverse, lambda, deltaP, update.
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
     ecc_solve_kernel(EccState *__restrict__ state, const double *__restrict__ partial,
                      int nframes, int nblocks, int max_iters, double eps)
 {
-    // one wave per frame: lanes 0..44 reduce one sum each over the block partials (fixed
-    // order), lane 0 then runs the scalar part
+    // one workgroup per frame: wave w reduces sums k = w, w+4, ... over the block partials
+    // (lane l takes blocks l, l+64, ...; fixed shuffle tree -> deterministic), lane 0 of the
+    // workgroup then runs the scalar part
     const int f = blockIdx.x;
     if (f >= nframes) return;
     EccState &es = state[f];
     if (es.done) return;
     __shared__ double Ssh[kEccSums];
-    if (threadIdx.x < kEccSums) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = wave; k < kEccSums; k += 4) {
         double v = 0.0;
-        for (int b = 0; b < nblocks; ++b) v += partial[((size_t)f * nblocks + b) * kEccSums + threadIdx.x];
-        Ssh[threadIdx.x] = v;
+        for (int b = lane; b < nblocks; b += 64) v += partial[((size_t)f * nblocks + b) * kEccSums + k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if (lane == 0) Ssh[k] = v;
     }
     __syncthreads();
     if (threadIdx.x != 0) return;
@@ -825,7 +831,7 @@ int frame_scratch_ensure(FrameScratch **ps, int ncams, int batch, int rows, int 
     if (need_warp && !s->ecc_img) UPSP_HIP_CHECK(hipMalloc(&s->ecc_img, n * sizeof(float)));
     if (!s->tmp) UPSP_HIP_CHECK(hipMalloc(&s->tmp, n * sizeof(double)));
     if (need_warp && !s->partial)
-        UPSP_HIP_CHECK(hipMalloc(&s->partial, sizeof(double) * (size_t)batch * kEccBlocks * kEccSums));
+        UPSP_HIP_CHECK(hipMalloc(&s->partial, sizeof(double) * (size_t)batch * kEccBlocksMax * kEccSums));
     if (!s->state) UPSP_HIP_CHECK(hipMalloc(&s->state, sizeof(EccState) * (size_t)batch));
     if (!s->counter) UPSP_HIP_CHECK(hipMalloc(&s->counter, 2 * sizeof(int)));
     return UPSP_OK;
@@ -841,19 +847,23 @@ static int run_ecc(FrameScratch *s, const float *tmpl_blur, const uint16_t *fram
     hipLaunchKernelGGL(ecc_init_kernel, g1, b1, 0, st, s->state, nb, (long long)first_frame);
     hipLaunchKernelGGL(ecc_set_last_rho, g1, b1, 0, st, s->state, nb, eps);
     int it = 0;
+    int active = nb;  // frames still iterating (known to the host after every burst)
     while (it < max_iters) {
-        // a few iterations between host checks of the active-frame count
+        // a few iterations between host checks of the active-frame count; frames that have
+        // converged exit at once, so late bursts spread the remaining frames over more blocks
         const int burst = it == 0 ? 3 : 2;
+        int blocks = kEccBlocks;
+        while (blocks < kEccBlocksMax && (long long)blocks * active < 2048) blocks *= 2;
         for (int k = 0; k < burst && it < max_iters; ++k, ++it) {
             {
                 KTimed kt("ecc_sums_kernel", st);
-                hipLaunchKernelGGL(ecc_sums_kernel, dim3(kEccBlocks, nb), dim3(256), 0, st,
+                hipLaunchKernelGGL(ecc_sums_kernel, dim3(blocks, nb), dim3(256), 0, st,
                                    (const float *)s->ecc_img, tmpl_blur, rows, cols,
                                    (const EccState *)s->state, s->partial);
             }
             KTimed kt2("ecc_solve_kernel", st);
-            hipLaunchKernelGGL(ecc_solve_kernel, dim3(nb), dim3(64), 0, st, s->state,
-                               (const double *)s->partial, nb, kEccBlocks, max_iters, eps);
+            hipLaunchKernelGGL(ecc_solve_kernel, dim3(nb), dim3(256), 0, st, s->state,
+                               (const double *)s->partial, nb, blocks, max_iters, eps);
         }
         int h[2] = {0, 0};
         UPSP_HIP_CHECK(hipMemsetAsync(s->counter, 0, 2 * sizeof(int), st));
@@ -865,8 +875,23 @@ static int run_ecc(FrameScratch *s, const float *tmpl_blur, const uint16_t *fram
             return fail(UPSP_ERR_DIVERGED,
                         "ECC registration did not converge (cv::findTransformECC would throw)");
         if (h[0] == 0) break;
+        active = h[0];
     }
     UPSP_HIP_CHECK(hipGetLastError());
+    if (std::getenv("UPSP_TRACE_ECC")) {
+        std::vector<EccState> h(nb);
+        UPSP_HIP_CHECK(hipMemcpy(h.data(), s->state, sizeof(EccState) * nb, hipMemcpyDeviceToHost));
+        int tot = 0, mx = 0;
+        for (int i = 0; i < nb; ++i) {
+            const auto &e = h[i];
+            tot += e.iters; mx = std::max(mx, e.iters);
+            if (e.iters > 8)
+                std::fprintf(stderr, "[upsp]   frame %lld: %d iters rho=%.9f last=%.9f M=[%g %g %g; %g %g %g]\n",
+                             (long long)first_frame + i, e.iters, e.rho, e.last_rho, e.M[0], e.M[1], e.M[2], e.M[3], e.M[4], e.M[5]);
+        }
+        std::fprintf(stderr, "[upsp] ECC sub-batch of %d frames: %d frame-iterations, max %d, %d launches\n",
+                     nb, tot, mx, it);
+    }
     return UPSP_OK;
 }
 
