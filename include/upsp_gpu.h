@@ -275,6 +275,36 @@ int upsp_unpack_12bit(const uint8_t *d_packed, int nframes, size_t npix, uint16_
                       int hot_thresh, uint32_t *d_hot_count, void *stream);
 
 /* ======================================================================== *
+ *  3c. Phase 2: node-major time series -> delta-Cp   (reference:
+ *      phase-2 node loop cpp/exec/psp_process.cpp:2452-2507, finals :2537-2545,
+ *      upsp::TransPolyFitter<float> cpp/lib/filtering.ipp:12-79 / cpp/include/filtering.h:24-87,
+ *      upsp::PaintCalibration::get_gain cpp/lib/non_cv_upsp.cpp:66-68)
+ * ======================================================================== */
+
+/* TransPolyFitter::eval_fit for npts rows: d_data_t [npts][ld_in >= nframes] (node-major, the
+ * layout the reference maps as column-major Eigen data) -> d_fit_t [npts][ld_out] = value of
+ * the degree-`degree` least-squares polynomial through each row over x = (float)f/nframes.
+ * degree 0..7.  d_poly (optional) [npts][degree+1] = monomial coefficients (poly_ of the
+ * reference, filtering.ipp:65-66).  May run in place (d_fit_t == d_data_t). */
+int upsp_transpoly_fit(const float *d_data_t, long long ld_in, size_t npts, int nframes, int degree,
+                       float *d_fit_t, long long ld_out, float *d_poly, void *stream);
+
+/* Phase-2 node loop over this rank's node slice.  d_intensity_t [nnodes][ld_in] f32 (the
+ * intensity_transpose block); per-node inputs d_iref (sol_avg_final), d_coverage, d_steady
+ * (NULL = wind-off: zeros, :2354-2356), d_model_temp (NULL = the scalar `model_temp`, :2319)
+ * indexed like the slice; paint_cal = a,b,c,d,e,f (host array).  Writes d_pressure_t
+ * [nnodes][ld_out] (delta-Cp; NaN rows where coverage == 0 -- the reference leaves those rows
+ * of its malloc'ed buffer unwritten), and, each optional: d_sum / d_sumsq (double partials,
+ * local_avg / local_rms), d_avg = sum/F, d_rms = sqrt(sumsq/F), d_gain (NaN where coverage==0).
+ * May run in place (d_pressure_t == d_intensity_t). */
+int upsp_phase2_pressure(const float *d_intensity_t, long long ld_in, size_t nnodes, int nframes,
+                         const float *d_iref, const float *d_coverage, const float *d_steady,
+                         const float *d_model_temp, float model_temp, const float paint_cal[6],
+                         float qbar, float ps, int degree, float *d_pressure_t, long long ld_out,
+                         double *d_sum, double *d_sumsq, float *d_avg, float *d_rms, float *d_gain,
+                         void *stream);
+
+/* ======================================================================== *
  *  4.  Measurement support (no reference counterpart; the reference only has
  *      psp::BlockTimer / timedBarrierPoint wall-clock prints, pspTimer.h:10-41)
  * ======================================================================== */

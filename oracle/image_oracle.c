@@ -21,6 +21,7 @@
  * Reduction orders inside the libraries' SIMD loops are not reproducible.
  */
 #include "upsp_oracle.h"
+#include "qr_f32.h"
 
 #include <float.h>
 #include <math.h>
@@ -444,108 +445,7 @@ int orc_polyfit2d(const int32_t *x, const int32_t *y, const float *z, int m, flo
                     A[(size_t)cnt++ * m + r] = (float)pow((double)y[r], i) * (float)pow((double)x[r], j);
         c[r] = z[r];
     }
-    float hcoef[nc], normU[nc], normD[nc];
-    int trans[nc];
-    float maxnorm = 0;
-    for (int k = 0; k < nc; ++k) {
-        float s = 0;
-        for (int r = 0; r < m; ++r) s += A[(size_t)k * m + r] * A[(size_t)k * m + r];
-        normD[k] = normU[k] = sqrtf(s);
-        if (normU[k] > maxnorm) maxnorm = normU[k];
-    }
-    float th = maxnorm * FLT_EPSILON / (float)m;
-    const float threshold_helper = th * th;
-    const float downdate = sqrtf(FLT_EPSILON);
-    int nonzero = nc;
-    for (int k = 0; k < nc; ++k) {
-        int big = k;
-        for (int j = k + 1; j < nc; ++j)
-            if (normU[j] > normU[big]) big = j;
-        float bigsq = normU[big] * normU[big];
-        if (nonzero == nc && bigsq < threshold_helper * (float)(m - k)) nonzero = k;
-        trans[k] = big;
-        if (big != k) {
-            for (int r = 0; r < m; ++r) {
-                float t = A[(size_t)k * m + r];
-                A[(size_t)k * m + r] = A[(size_t)big * m + r];
-                A[(size_t)big * m + r] = t;
-            }
-            float t = normU[k]; normU[k] = normU[big]; normU[big] = t;
-            t = normD[k]; normD[k] = normD[big]; normD[big] = t;
-        }
-        /* makeHouseholderInPlace on A(k:m, k) */
-        float *col = &A[(size_t)k * m];
-        float tail = 0;
-        for (int r = k + 1; r < m; ++r) tail += col[r] * col[r];
-        float c0 = col[k], beta, tau;
-        if (tail <= FLT_MIN) {
-            tau = 0;
-            beta = c0;
-            for (int r = k + 1; r < m; ++r) col[r] = 0;
-        } else {
-            beta = sqrtf(c0 * c0 + tail);
-            if (c0 >= 0) beta = -beta;
-            for (int r = k + 1; r < m; ++r) col[r] = col[r] / (c0 - beta);
-            tau = (beta - c0) / beta;
-        }
-        hcoef[k] = tau;
-        col[k] = beta;
-        /* applyHouseholderOnTheLeft to the remaining columns */
-        if (tau != 0)
-            for (int j = k + 1; j < nc; ++j) {
-                float *cj = &A[(size_t)j * m];
-                float tmp = 0;
-                for (int r = k + 1; r < m; ++r) tmp += col[r] * cj[r];
-                tmp += cj[k];
-                cj[k] -= tau * tmp;
-                for (int r = k + 1; r < m; ++r) cj[r] -= tau * col[r] * tmp;
-            }
-        for (int j = k + 1; j < nc; ++j) {
-            if (normU[j] != 0) {
-                float temp = fabsf(A[(size_t)j * m + k]) / normU[j];
-                temp = (1 + temp) * (1 - temp);
-                temp = temp < 0 ? 0 : temp;
-                float r2 = normU[j] / normD[j];
-                float temp2 = temp * r2 * r2;
-                if (temp2 <= downdate) {
-                    float s = 0;
-                    for (int r = k + 1; r < m; ++r) s += A[(size_t)j * m + r] * A[(size_t)j * m + r];
-                    normD[j] = sqrtf(s);
-                    normU[j] = normD[j];
-                } else {
-                    normU[j] *= sqrtf(temp);
-                }
-            }
-        }
-    }
-    /* c = Q^T z */
-    for (int k = 0; k < nonzero; ++k) {
-        float *col = &A[(size_t)k * m];
-        float tau = hcoef[k];
-        if (tau == 0) continue;
-        float tmp = 0;
-        for (int r = k + 1; r < m; ++r) tmp += col[r] * c[r];
-        tmp += c[k];
-        c[k] -= tau * tmp;
-        for (int r = k + 1; r < m; ++r) c[r] -= tau * col[r] * tmp;
-    }
-    /* back substitution on R(0:nonzero, 0:nonzero) */
-    float sol[nc] = {0};
-    for (int i = nonzero - 1; i >= 0; --i) {
-        float s = c[i];
-        for (int j = i + 1; j < nonzero; ++j) s -= A[(size_t)j * m + i] * sol[j];
-        sol[i] = s / A[(size_t)i * m + i];
-    }
-    /* undo the column permutation (sequence of transpositions) */
-    int perm[nc];
-    for (int k = 0; k < nc; ++k) perm[k] = k;
-    for (int k = 0; k < nc; ++k) {
-        int t = perm[k];
-        perm[k] = perm[trans[k]];
-        perm[trans[k]] = t;
-    }
-    for (int k = 0; k < nc; ++k) poly[k] = 0;
-    for (int k = 0; k < nonzero; ++k) poly[perm[k]] = sol[k];
+    const int nonzero = orc_colpiv_qr_solve_f32(A, c, m, nc, poly);
     free(A);
     free(c);
     return nonzero;

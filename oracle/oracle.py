@@ -110,6 +110,11 @@ _OPTIONAL = [
     ("orc_polyfit2d", [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p], C.c_int),
     ("orc_polyval2d", [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p], None),
     ("orc_patch_clusters", [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6, None),
+    ("orc_transpoly_design", [C.c_int, C.c_int, C.c_void_p], None),
+    ("orc_transpoly_fit", [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
+    ("orc_paint_gain", [C.c_void_p, C.c_float, C.c_float], C.c_float),
+    ("orc_phase2", [C.c_void_p, C.c_size_t, C.c_int] + [C.c_void_p] * 5 + [C.c_float, C.c_float, C.c_int]
+     + [C.c_void_p] * 4 + [C.c_int], None),
 ]
 
 
@@ -366,3 +371,42 @@ def unpack_12bit(packed):
     out = np.zeros(packed.size * 2 // 3, np.uint16)
     lib().orc_unpack_12bit(_p(packed), packed.size, _p(out))
     return out
+
+
+def transpoly_design(nframes, degree):
+    """TransPolyFitter design matrix, returned [nframes, degree+1] (A_(f,c))."""
+    A = np.zeros((degree + 1, nframes), np.float32)
+    lib().orc_transpoly_design(nframes, degree, _p(A))
+    return A.T.copy()
+
+
+def transpoly_fit(y, degree, nframes=None):
+    """TransPolyFitter::eval_fit for one point: returns (poly[degree+1], fit[nframes])."""
+    y = _f32(y).reshape(-1)
+    n = y.size if nframes is None else nframes
+    A = np.zeros((degree + 1, n), np.float32)
+    lib().orc_transpoly_design(n, degree, _p(A))
+    poly = np.zeros(degree + 1, np.float32)
+    fit = np.zeros(n, np.float32)
+    lib().orc_transpoly_fit(_p(A), n, degree + 1, _p(y), _p(poly), _p(fit))
+    return poly, fit
+
+
+def paint_gain(cal, T, Pss):
+    cal = _f32(cal).reshape(6)
+    return float(lib().orc_paint_gain(_p(cal), float(T), float(Pss)))
+
+
+def phase2(intensity_t, iref, coverage, steady, model_temp, cal, qbar, ps, degree=6, threads=0):
+    """psp_process phase-2 node loop.  Returns dict(pressure_t, sum, sumsq, gain)."""
+    I = _f32(intensity_t)
+    n, F = I.shape
+    out = np.full((n, F), np.nan, np.float32)
+    s = np.zeros(n, np.float64)
+    ss = np.zeros(n, np.float64)
+    g = np.zeros(n, np.float64)
+    cal = _f32(cal).reshape(6)
+    iref, coverage, steady, model_temp = (_f32(a).reshape(n) for a in (iref, coverage, steady, model_temp))
+    lib().orc_phase2(_p(I), n, F, _p(iref), _p(coverage), _p(steady), _p(model_temp), _p(cal),
+                     float(qbar), float(ps), int(degree), _p(out), _p(s), _p(ss), _p(g), int(threads))
+    return dict(pressure_t=out, sum=s, sumsq=ss, gain=g)

@@ -28,6 +28,9 @@
  *                        the reference tree and covered by no reference test.
  *   patch_*              PARITY UNPINNED: Eigen 3.3.9 colPivHouseholderQr
  *                        (un-vendored), no reference test for PatchClusters.
+ *   transpoly / phase2   pinned: cpp/test/test_filtering.cpp:19-113 (TransPolyfitter
+ *                        known-answer test); the QR itself is Eigen (un-vendored),
+ *                        restated in qr_f32.h.
  */
 #ifndef UPSP_ORACLE_H
 #define UPSP_ORACLE_H
@@ -201,6 +204,22 @@ void orc_polyval2d(const int32_t *x, const int32_t *y, int n, const float poly[1
 void orc_patch_clusters(float *img, int cols, int nclusters, const int32_t *b_off,
                         const int32_t *bx, const int32_t *by, const int32_t *i_off,
                         const int32_t *ix, const int32_t *iy);
+
+/* ------------------------------------------------------------ phase 2 --- */
+
+/* upsp::TransPolyFitter<float> (cpp/lib/filtering.ipp:12-79): design matrix
+ * A[c*nframes+f] = pow((float)f/nframes, c) and the per-point fit + evaluation.
+ * Eigen colPivHouseholderQr -> qr_f32.h; pinned by cpp/test/test_filtering.cpp:19-113. */
+void orc_transpoly_design(int nframes, int degree, float *A);
+int orc_transpoly_fit(const float *A, int nframes, int ncoef, const float *y, float *poly,
+                      float *fit);
+/* PaintCalibration::get_gain, cpp/lib/non_cv_upsp.cpp:66-68 ; cal = a,b,c,d,e,f */
+float orc_paint_gain(const float cal[6], float T, float Pss);
+/* phase-2 node loop, cpp/exec/psp_process.cpp:2452-2507 */
+void orc_phase2(const float *intensity_t, size_t nnodes, int nframes, const float *iref,
+                const float *coverage, const float *steady, const float *model_temp,
+                const float cal[6], float qbar, float ps, int degree, float *pressure_t,
+                double *sum, double *sumsq, double *gain_out, int threads);
 
 /* ------------------------------------------------------------- video ---- */
 

@@ -91,3 +91,39 @@ def test_cli_end_to_end(gpu_lib, tmp_path, filt):
     assert np.array_equal(np.fromfile(os.path.join(out, "X"), "<f4"), v[:, 0])
     assert os.path.getsize(os.path.join(out, "cam01-uv")) == 8 * n
     job.close()
+
+
+@pytest.mark.gpu
+def test_cli_phase2(gpu_lib, oracle, tmp_path):
+    """Phase 1 + phase 2 through the CLI; delta-Cp rows against the oracle run on the
+    intensity_transpose / intensity_avg / coverage files the same run wrote."""
+    from upsp_processing_amd import psp_process as cli, phase2
+    tmp = str(tmp_path)
+    v, t, cams = write_case(tmp, nframes=40)
+    deck = open(os.path.join(tmp, "run.inp")).read().replace("@all\n", "@all\n  sds = %s/run.wtd\n" % tmp)
+    open(os.path.join(tmp, "run.inp"), "w").write(deck)
+    open(os.path.join(tmp, "run.wtd"), "w").write(
+        "RUN 1 2\n#  MACH ALPHA BETA PHI PTOT TTF PS Q TCAVG\n0.85 1.0 0.0 0.0 2100.0 95.0 1300.0 620.0 68.0\n")
+    open(os.path.join(tmp, "paint.cal"), "w").write("a = 0.9\nb = -0.002\nc = 0\nd = 0.0008\ne = 0\nf = 0\n")
+    assert cli.main(["-input_file=%s/run.inp" % tmp, "-h5_out=%s/o.h5" % tmp,
+                     "-paint_cal=%s/paint.cal" % tmp]) == 0
+    out = os.path.join(tmp, "out")
+    n, F = v.shape[0], 40
+    I = np.fromfile(os.path.join(out, "intensity_transpose"), "<f4").reshape(n, F)
+    P = np.fromfile(os.path.join(out, "pressure_transpose"), "<f4").reshape(n, F)
+    avg = np.fromfile(os.path.join(out, "intensity_avg"), "<f4")
+    cov = np.fromfile(os.path.join(out, "coverage"), "<f4")
+    cal = phase2.read_paint_calibration(os.path.join(tmp, "paint.cal"))
+    I_safe = np.where(np.isnan(I), 1.0, I).astype(np.float32)
+    want = oracle.phase2(I_safe, np.nan_to_num(avg, nan=1.0), cov, np.zeros(n, np.float32),
+                         np.full(n, 68.0, np.float32), cal, 620.0, 1300.0, 6)
+    live = cov != 0
+    assert live.sum() > 100 and np.isnan(P[~live]).all()
+    scale = np.abs(want["gain"][live]).max() * 144.0 / 620.0
+    assert np.max(np.abs(P[live] - want["pressure_t"][live])) < 2e-5 * scale
+    gain = np.fromfile(os.path.join(out, "gain"), "<f4")
+    assert np.array_equal(gain[live], want["gain"][live].astype(np.float32))
+    rms = np.fromfile(os.path.join(out, "rms"), "<f4")
+    assert np.allclose(rms[live], np.sqrt((P[live].astype(np.float64) ** 2).mean(1)), rtol=1e-6)
+    assert np.all(np.fromfile(os.path.join(out, "model_temp"), "<f4") == 68.0)
+    assert os.path.getsize(os.path.join(out, "steady_state")) == 4 * n

@@ -50,6 +50,9 @@ def _worker(rank, world, port, F, N, seed, q):
         ex.submit(rows_t[:, c0:c0 + fc].contiguous())
     assert torch.equal(ex.finish().view(torch.int32), series.view(torch.int32))
     n0, nn = shard.my_nodes
+    # phase-2 per-node vectors: each rank owns its node slice, every rank gets the whole vector
+    whole = D.gather_node_vector(torch.arange(n0, n0 + nn, dtype=torch.float32) * 2.0, shard)
+    assert torch.equal(whole, torch.arange(N, dtype=torch.float32) * 2.0)
     full = D.gather_time_series_to_root(series, shard)
     q.put((rank, s.numpy(), ss.numpy(), series.numpy(), n0, nn,
            None if full is None else full.numpy()))

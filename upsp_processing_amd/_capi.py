@@ -90,6 +90,9 @@ SIGNATURES = {
     "upsp_blur_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "upsp_patch_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "upsp_unpack_12bit": (_i, [_vp, _i, _sz, _vp, _i, _vp, _vp]),
+    "upsp_transpoly_fit": (_i, [_vp, C.c_longlong, _sz, _i, _i, _vp, C.c_longlong, _vp, _vp]),
+    "upsp_phase2_pressure": (_i, [_vp, C.c_longlong, _sz, _i, _vp, _vp, _vp, _vp, C.c_float, _vp,
+                                  C.c_float, C.c_float, _i, _vp, C.c_longlong, _vp, _vp, _vp, _vp, _vp, _vp]),
     "upsp_timing_enable": (_i, [_i]),
     "upsp_timing_report": (_i, [C.c_char_p, _sz]),
 }

@@ -167,3 +167,18 @@ def gather_time_series_to_root(series, shard, group=None):
         for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, series.contiguous(), 0, group)]):
             w.wait()
     return None
+
+
+def gather_node_vector(v, shard, group=None):
+    """Concatenates the per-rank node slices of a per-node vector on every rank (phase 2's
+    rms / avg / gain: the reference MPI_Reduce-sums vectors that are zero outside the owner's
+    slice, psp_process.cpp:2521-2527).  Slices differ by at most one node (apportion), so the
+    vector is padded to the longest slice for one all_gather."""
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        return v
+    longest = max(shard.node_count)
+    pad = torch.zeros(longest, dtype=v.dtype, device=v.device)
+    pad[:v.numel()] = v
+    parts = [torch.empty_like(pad) for _ in range(shard.world)]
+    dist.all_gather(parts, pad, group=group)
+    return torch.cat([p[:n] for p, n in zip(parts, shard.node_count)])

@@ -371,3 +371,70 @@ def patch(img32f, clusters):
     check(lib().upsp_patch_f32(_ptr(img32f), h, w, len(clusters),
                                *[a.ctypes.data_as(C.c_void_p) for a in arr], _stream()))
     return img32f
+
+
+# ----------------------------------------------------------------------------- phase 2 --
+class TransPolyFitter:
+    """upsp::TransPolyFitter<float> on the GPU (cpp/include/filtering.h:24-87,
+    cpp/lib/filtering.ipp:12-79): least-squares polynomial of `degree` over x = f/n_frames
+    through every row of node-major data."""
+
+    def __init__(self, n_frames, degree, n_pts):
+        if not 0 <= int(degree) <= 7:
+            raise ValueError("polynomial degree must be 0..7")
+        self.n_frames, self.degree, self.n_pts = int(n_frames), int(degree), int(n_pts)
+        self.poly = torch.zeros((self.n_pts, self.degree + 1), dtype=torch.float32, device="cuda")
+
+    def eval_fit(self, data, n_pts=None, curr_pt=0):
+        """data: [n_pts, n_frames] f32 (node-major chunk).  Returns the fit values
+        [n_pts, n_frames] and stores the coefficients of points curr_pt.. (filtering.ipp:48-79)."""
+        data = _dev(data, torch.float32).reshape(-1, self.n_frames)
+        n = data.shape[0] if n_pts is None else int(n_pts)
+        out = torch.empty((n, self.n_frames), dtype=torch.float32, device="cuda")
+        poly = torch.empty((n, self.degree + 1), dtype=torch.float32, device="cuda")
+        check(lib().upsp_transpoly_fit(_ptr(data), self.n_frames, n, self.n_frames, self.degree,
+                                       _ptr(out), self.n_frames, _ptr(poly), _stream()))
+        self.poly[curr_pt:curr_pt + n] = poly
+        return out
+
+    def skip_fit(self, curr_pt):
+        self.poly[curr_pt] = 0.0
+
+
+def phase2_pressure(intensity_t, iref, coverage, paint_cal, qbar, ps, steady=None, model_temp=70.0,
+                    degree=6, out=None, want=("avg", "rms", "gain")):
+    """Phase-2 node loop (cpp/exec/psp_process.cpp:2452-2507) over a node-major slice.
+
+    intensity_t [n, F] (may be a column slice of a wider buffer: stride(0) is honoured);
+    iref/coverage/steady [n]; model_temp: scalar or [n].  out: destination (defaults to a new
+    tensor; pass intensity_t itself to run in place).  Returns dict(pressure_t, sum, sumsq, ...)."""
+    if intensity_t.dim() != 2 or intensity_t.stride(1) != 1 or intensity_t.dtype != torch.float32:
+        raise ValueError("intensity_t must be a 2-D f32 tensor with unit column stride")
+    n, F = intensity_t.shape
+    if out is None:
+        out = torch.empty((n, F), dtype=torch.float32, device="cuda")
+    if out.shape != (n, F) or out.stride(1) != 1 or out.dtype != torch.float32:
+        raise ValueError("bad output tensor")
+    iref = _dev(iref, torch.float32)
+    coverage = _dev(coverage, torch.float32)
+    steady_t = None if steady is None else _dev(steady, torch.float32)
+    temp_t, temp_s = None, 0.0
+    if isinstance(model_temp, (int, float)):
+        temp_s = float(model_temp)
+    else:
+        temp_t = _dev(model_temp, torch.float32)
+    for t in (iref, coverage, steady_t, temp_t):
+        if t is not None and t.numel() != n:
+            raise ValueError("per-node input has the wrong length")
+    cal = (C.c_float * 6)(*[float(v) for v in paint_cal])
+    res = dict(pressure_t=out,
+               sum=torch.empty(n, dtype=torch.float64, device="cuda"),
+               sumsq=torch.empty(n, dtype=torch.float64, device="cuda"))
+    for k in want:
+        res[k] = torch.empty(n, dtype=torch.float32, device="cuda")
+    check(lib().upsp_phase2_pressure(
+        _ptr(intensity_t), intensity_t.stride(0), n, F, _ptr(iref), _ptr(coverage), _ptr(steady_t),
+        _ptr(temp_t), temp_s, cal, float(qbar), float(ps), int(degree), _ptr(out), out.stride(0),
+        _ptr(res["sum"]), _ptr(res["sumsq"]), _ptr(res.get("avg")), _ptr(res.get("rms")),
+        _ptr(res.get("gain")), _stream()))
+    return res

@@ -17,7 +17,12 @@ cpp/lib/upsp_inputs.cpp) for the part of the pipeline this repository implements
 
 and writes the phase-1 flat files (intensity_transpose, intensity_avg, intensity_rms,
 intensity_ratio_0, coverage, camNN-uv, vv-int-*.dat; cpp/exec/psp_process.cpp:524-540).
-Phase 2 (pressure) and the HDF5 container are out of scope; `-h5_out` / `-paint_cal` are
+
+Phase 2 (cpp/exec/psp_process.cpp:2260-2625) runs when `-paint_cal` names a readable file and
+the deck's @all section has `sds` (tunnel conditions): delta-Cp per node and frame ->
+pressure_transpose, rms, avg, gain, steady_state, model_temp, vv-cp-*.dat.  Wind-off only
+(no `-steady_p3d`): interpolating a structured steady-state solution onto an unstructured grid
+(upsp::interpolate, kd-tree) is not built.  The HDF5 container is out of scope; `-h5_out` is
 accepted and ignored.
 """
 import json
@@ -205,6 +210,21 @@ def main(argv=None):
         for name, col in (("X", 0), ("Y", 1), ("Z", 2)):                    # :524-540
             xyz[:, col].astype("<f4").tofile(os.path.join(out_dir, name))
         print("phase 1 complete: %d frames, %d nodes, %d rays" % (nframes, job.nnodes, job.nrays))
+
+    # ---- phase 2 (psp_process.cpp:2260-2625) ----
+    paint_cal, sds = flags.get("paint_cal"), deck["all"].get("sds")
+    if paint_cal and os.path.isfile(paint_cal) and sds:
+        from . import phase2
+        if flags.get("steady_p3d"):
+            raise DeckError("-steady_p3d: interpolation of a steady-state solution onto a .tri grid "
+                            "is not built (wind-off processing only)")
+        p2 = phase2.Phase2(phase2.read_paint_calibration(paint_cal), phase2.read_tunnel_conditions(sds))
+        n0, nn = shard.my_nodes
+        res = p2.process(series, finals["avg"][n0:n0 + nn].contiguous(),
+                         finals["coverage"][n0:n0 + nn].contiguous(), in_place=True)
+        p2.write_outputs(out_dir, res, p2.gather_finals(res, shard), None, job.nnodes, node_start=n0)
+        if shard.rank == 0:
+            print("phase 2 complete: model temperature %.1f F, qbar %.2f" % (p2.model_temp, p2.tcond["qbar"]))
     job.close()
     return 0
 
