@@ -305,6 +305,19 @@ int upsp_phase2_pressure(const float *d_intensity_t, long long ld_in, size_t nno
                          void *stream);
 
 /* ======================================================================== *
+ *  3d. Nearest model node   (reference: kd_nearest
+ *      cpp/raycast/pspKdtree.c:284-372 over TriModel_::generate_kd_tree
+ *      cpp/lib/TriModel.ipp:915-937; callers cpp/exec/psp_process.cpp:95-100,136-141)
+ * ======================================================================== */
+
+/* For each query point (double xyz, like the kd-tree's pos argument) the index of the nearest
+ * node of d_nodes3 [nnodes][3] f32 and, optionally, the squared distance (double, accumulated
+ * x,y,z like kd_nearest_i).  Exhaustive scan: same minimum distance as the kd-tree; the same
+ * index unless two nodes are exactly equidistant (then the lowest index).  nqueries <= 65535. */
+int upsp_nearest_nodes(const float *d_nodes3, size_t nnodes, const double *d_query3, size_t nqueries,
+                       int32_t *d_index, double *d_dist2, void *stream);
+
+/* ======================================================================== *
  *  4.  Measurement support (no reference counterpart; the reference only has
  *      psp::BlockTimer / timedBarrierPoint wall-clock prints, pspTimer.h:10-41)
  * ======================================================================== */

@@ -110,6 +110,9 @@ _OPTIONAL = [
     ("orc_polyfit2d", [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p], C.c_int),
     ("orc_polyval2d", [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p], None),
     ("orc_patch_clusters", [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6, None),
+    ("orc_kd_build", [C.c_void_p, C.c_size_t], C.c_void_p),
+    ("orc_kd_free", [C.c_void_p], None),
+    ("orc_kd_nearest_batch", [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p], None),
     ("orc_transpoly_design", [C.c_int, C.c_int, C.c_void_p], None),
     ("orc_transpoly_fit", [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
     ("orc_paint_gain", [C.c_void_p, C.c_float, C.c_float], C.c_float),
@@ -410,3 +413,75 @@ def phase2(intensity_t, iref, coverage, steady, model_temp, cal, qbar, ps, degre
     lib().orc_phase2(_p(I), n, F, _p(iref), _p(coverage), _p(steady), _p(model_temp), _p(cal),
                      float(qbar), float(ps), int(degree), _p(out), _p(s), _p(ss), _p(g), int(threads))
     return dict(pressure_t=out, sum=s, sumsq=ss, gain=g)
+
+
+class KdTree:
+    """kd-tree over the model nodes, restated (oracle/kd_oracle.c)."""
+
+    def __init__(self, nodes):
+        nodes = _f32(nodes).reshape(-1, 3)
+        self._free = lib().orc_kd_free
+        self._h = lib().orc_kd_build(_p(nodes), nodes.shape[0])
+
+    def nearest(self, queries):
+        q = np.ascontiguousarray(queries, dtype=np.float64).reshape(-1, 3)
+        idx = np.zeros(q.shape[0], np.int32)
+        d2 = np.zeros(q.shape[0], np.float64)
+        lib().orc_kd_nearest_batch(self._h, _p(q), q.shape[0], _p(idx), _p(d2))
+        return idx, d2
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._free(self._h)
+            self._h = None
+
+
+_REF_KD = os.path.join(_HERE, "_ref", "libpspkdtree.so")
+
+
+def build_ref():
+    """Compile the buildable part of the reference (the vendored kd-tree) into oracle/_ref/
+    when /root/reference is present; returns True if the library exists afterwards."""
+    if os.path.isdir("/root/reference/cpp/raycast"):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "ref"])
+    return os.path.exists(_REF_KD)
+
+
+class RefKdTree:
+    """The reference's own kd-tree (cpp/raycast/pspKdtree.c compiled into oracle/_ref/),
+    driven like TriModel_::generate_kd_tree (cpp/lib/TriModel.ipp:915-937) and getTargets
+    (cpp/exec/psp_process.cpp:95-100)."""
+
+    def __init__(self, nodes):
+        if not os.path.exists(_REF_KD):
+            raise FileNotFoundError(_REF_KD)
+        L = C.CDLL(_REF_KD)
+        L.kd_create.restype = C.c_void_p
+        L.kd_create.argtypes = [C.c_int]
+        L.kd_insert3.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p]
+        L.kd_nearest.restype = C.c_void_p
+        L.kd_nearest.argtypes = [C.c_void_p, C.c_void_p]
+        L.kd_res_item_data.restype = C.c_void_p
+        L.kd_res_item_data.argtypes = [C.c_void_p]
+        L.kd_res_free.argtypes = [C.c_void_p]
+        L.kd_free.argtypes = [C.c_void_p]
+        self.L = L
+        self.t = L.kd_create(3)
+        nodes = _f32(nodes).reshape(-1, 3)
+        for i in range(nodes.shape[0]):
+            # user data = node index + 1 (a NULL pointer cannot be told from index 0 via ctypes)
+            L.kd_insert3(self.t, float(nodes[i, 0]), float(nodes[i, 1]), float(nodes[i, 2]), C.c_void_p(i + 1))
+
+    def nearest(self, queries):
+        q = np.ascontiguousarray(queries, dtype=np.float64).reshape(-1, 3)
+        out = np.zeros(q.shape[0], np.int32)
+        for k in range(q.shape[0]):
+            res = self.L.kd_nearest(self.t, q[k].ctypes.data_as(C.c_void_p))
+            out[k] = int(self.L.kd_res_item_data(res)) - 1
+            self.L.kd_res_free(res)
+        return out
+
+    def __del__(self):
+        if getattr(self, "t", None):
+            self.L.kd_free(self.t)
+            self.t = None

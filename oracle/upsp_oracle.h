@@ -28,6 +28,8 @@
  *                        the reference tree and covered by no reference test.
  *   patch_*              PARITY UNPINNED: Eigen 3.3.9 colPivHouseholderQr
  *                        (un-vendored), no reference test for PatchClusters.
+ *   kd_*                 pinned: the vendored kd-tree itself (cpp/raycast/pspKdtree.c) is
+ *                        compiled into oracle/_ref/ and compared node-for-node.
  *   transpoly / phase2   pinned: cpp/test/test_filtering.cpp:19-113 (TransPolyfitter
  *                        known-answer test); the QR itself is Eigen (un-vendored),
  *                        restated in qr_f32.h.
@@ -204,6 +206,17 @@ void orc_polyval2d(const int32_t *x, const int32_t *y, int n, const float poly[1
 void orc_patch_clusters(float *img, int cols, int nclusters, const int32_t *b_off,
                         const int32_t *bx, const int32_t *by, const int32_t *i_off,
                         const int32_t *ix, const int32_t *iy);
+
+/* ------------------------------------------------------------ kd-tree --- */
+
+/* kd_nearest over all model nodes, cpp/raycast/pspKdtree.c:131-171,260-372 (vendored in the
+ * reference; oracle/_ref/libpspkdtree.so is the real thing where /root/reference exists). */
+typedef struct orc_kdtree orc_kdtree;
+orc_kdtree *orc_kd_build(const float *nodes3, size_t n);
+void orc_kd_free(orc_kdtree *t);
+int32_t orc_kd_nearest(const orc_kdtree *t, const double pos[3], double *dist2_out);
+void orc_kd_nearest_batch(const orc_kdtree *t, const double *query3, size_t nq, int32_t *index,
+                          double *dist2);
 
 /* ------------------------------------------------------------ phase 2 --- */
 

@@ -438,3 +438,17 @@ def phase2_pressure(intensity_t, iref, coverage, paint_cal, qbar, ps, steady=Non
         _ptr(res["sum"]), _ptr(res["sumsq"]), _ptr(res.get("avg")), _ptr(res.get("rms")),
         _ptr(res.get("gain")), _stream()))
     return res
+
+
+# ------------------------------------------------------------------------ nearest node --
+def nearest_nodes(nodes, queries, want_dist=False):
+    """kd_nearest over all model nodes (cpp/raycast/pspKdtree.c:284-372) as an exhaustive
+    GPU scan.  nodes: [N,3] f32 device tensor (or array); queries: [Q,3] (double).
+    Returns int32 [Q] (and the squared distances, double [Q], if want_dist)."""
+    nodes = _dev(nodes, torch.float32).reshape(-1, 3)
+    q = _dev(queries, torch.float64).reshape(-1, 3)
+    idx = torch.empty(q.shape[0], dtype=torch.int32, device="cuda")
+    d2 = torch.empty(q.shape[0], dtype=torch.float64, device="cuda") if want_dist else None
+    check(lib().upsp_nearest_nodes(_ptr(nodes), nodes.shape[0], _ptr(q), q.shape[0], _ptr(idx),
+                                   _ptr(d2), _stream()))
+    return (idx, d2) if want_dist else idx
