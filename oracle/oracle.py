@@ -113,6 +113,16 @@ _OPTIONAL = [
     ("orc_kd_build", [C.c_void_p, C.c_size_t], C.c_void_p),
     ("orc_kd_free", [C.c_void_p], None),
     ("orc_kd_nearest_batch", [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p], None),
+    ("orc_get_targets", [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float,
+                         C.c_void_p], None),
+    ("orc_target_diameters", [C.c_void_p] * 6 + [C.c_size_t, C.c_void_p], None),
+    ("orc_cluster_points", [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p], C.c_int),
+    ("orc_intensity_histc", [C.c_void_p, C.c_size_t, C.c_uint, C.c_int, C.c_void_p, C.c_void_p], None),
+    ("orc_find_peaks", [C.c_void_p, C.c_int, C.c_uint, C.c_void_p], C.c_int),
+    ("orc_first_min_threshold", [C.c_void_p, C.c_int, C.c_uint], C.c_uint),
+    ("orc_patch_tables", [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_int, C.c_uint, C.c_uint, C.c_void_p,
+                          C.c_uint, C.c_uint] + [C.c_void_p] * 6, None),
+    ("orc_free", [C.c_void_p], None),
     ("orc_transpoly_design", [C.c_int, C.c_int, C.c_void_p], None),
     ("orc_transpoly_fit", [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
     ("orc_paint_gain", [C.c_void_p, C.c_float, C.c_float], C.c_float),
@@ -485,3 +495,77 @@ class RefKdTree:
         if getattr(self, "t", None):
             self.L.kd_free(self.t)
             self.t = None
+
+
+# ------------------------------------------------------------- phase-0 patch set-up --
+def get_targets(bvh, kd, cam, normals, xyz, oblique_thresh):
+    xyz = _f32(xyz).reshape(-1, 3)
+    normals = _f32(normals).reshape(-1, 3)
+    keep = np.zeros(xyz.shape[0], np.uint8)
+    lib().orc_get_targets(bvh._h, kd._h, C.byref(cam), _p(normals), _p(xyz), xyz.shape[0],
+                          float(oblique_thresh), _p(keep))
+    return keep.astype(bool)
+
+
+def target_diameters(kd, cam, normals, xyz, uv, diam):
+    xyz, uv, diam = _f32(xyz).reshape(-1, 3), _f32(uv).reshape(-1, 2), _f32(diam).reshape(-1)
+    normals = _f32(normals).reshape(-1, 3)
+    out = np.zeros(diam.size, np.float32)
+    lib().orc_target_diameters(kd._h, C.byref(cam), _p(normals), _p(xyz), _p(uv), _p(diam), diam.size, _p(out))
+    return out
+
+
+def cluster_points(uv, diam, bound_pts):
+    uv, diam = _f32(uv).reshape(-1, 2), _f32(diam).reshape(-1)
+    n = diam.size
+    order = np.zeros(max(n, 1), np.int32)
+    off = np.zeros(n + 1, np.int32)
+    ncl = lib().orc_cluster_points(_p(uv), _p(diam), n, int(bound_pts), _p(order), _p(off))
+    return order[:n], off[:ncl + 1]
+
+
+def intensity_histc(img, depth=12, bins=-1):
+    img = np.ascontiguousarray(img, dtype=np.uint16)
+    nb = (1 << min(depth, 16)) if bins == -1 else bins
+    edges = np.zeros(nb + 1, np.int32)
+    counts = np.zeros(nb, np.int32)
+    lib().orc_intensity_histc(_p(img), img.size, depth, bins, _p(edges), _p(counts))
+    return edges, counts
+
+
+def find_peaks(data, separation=0):
+    d = np.ascontiguousarray(data, dtype=np.float64)
+    peaks = np.zeros(max(d.size, 1), np.uint32)
+    n = lib().orc_find_peaks(_p(d), d.size, separation, _p(peaks))
+    return peaks[:n].tolist()
+
+
+def first_min_threshold(counts, separation=1):
+    c = np.ascontiguousarray(counts, dtype=np.int32)
+    return int(lib().orc_first_min_threshold(_p(c), c.size, separation))
+
+
+def patch_tables(uv, diam, order, cl_off, size, bound_pts=2, buffer=1, ref=None, thresh=0, offset=2):
+    """PatchClusters ctor (+ threshold_bounds when ref is given) -> list of dict(bx,by,ix,iy)."""
+    uv, diam = _f32(uv).reshape(-1, 2), _f32(diam).reshape(-1)
+    order = np.ascontiguousarray(order, dtype=np.int32)
+    cl_off = np.ascontiguousarray(cl_off, dtype=np.int32)
+    ncl = cl_off.size - 1
+    refa = None if ref is None else np.ascontiguousarray(ref, dtype=np.uint16)
+    ptrs = [C.c_void_p() for _ in range(6)]
+    lib().orc_patch_tables(_p(uv), _p(diam), _p(order), _p(cl_off), ncl, size[0], size[1], bound_pts,
+                           buffer, _p(refa), int(thresh), int(offset), *[C.byref(p) for p in ptrs])
+
+    def take(ptr, n):
+        if n == 0 or not ptr.value:
+            return np.zeros(0, np.int32)
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int32)), shape=(n,)).copy()
+    b_off = take(ptrs[0], ncl + 1)
+    i_off = take(ptrs[3], ncl + 1)
+    bx, by = take(ptrs[1], int(b_off[-1])), take(ptrs[2], int(b_off[-1]))
+    ix, iy = take(ptrs[4], int(i_off[-1])), take(ptrs[5], int(i_off[-1]))
+    for p in ptrs:
+        if p.value:
+            lib().orc_free(p)
+    return [dict(bx=bx[b_off[c]:b_off[c + 1]], by=by[b_off[c]:b_off[c + 1]],
+                 ix=ix[i_off[c]:i_off[c + 1]], iy=iy[i_off[c]:i_off[c + 1]]) for c in range(ncl)]

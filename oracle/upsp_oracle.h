@@ -28,6 +28,8 @@
  *                        the reference tree and covered by no reference test.
  *   patch_*              PARITY UNPINNED: Eigen 3.3.9 colPivHouseholderQr
  *                        (un-vendored), no reference test for PatchClusters.
+ *   patch set-up         PARITY UNPINNED (no reference test): getTargets, diameters,
+ *                        clustering, pixel lists, histogram threshold (patchsetup_oracle.c).
  *   kd_*                 pinned: the vendored kd-tree itself (cpp/raycast/pspKdtree.c) is
  *                        compiled into oracle/_ref/ and compared node-for-node.
  *   transpoly / phase2   pinned: cpp/test/test_filtering.cpp:19-113 (TransPolyfitter
@@ -217,6 +219,33 @@ void orc_kd_free(orc_kdtree *t);
 int32_t orc_kd_nearest(const orc_kdtree *t, const double pos[3], double *dist2_out);
 void orc_kd_nearest_batch(const orc_kdtree *t, const double *query3, size_t nq, int32_t *index,
                           double *dist2);
+
+/* ------------------------------------------------- phase-0 patch set-up --- */
+
+/* getTargets, cpp/exec/psp_process.cpp:55-112 */
+void orc_get_targets(const orc_bvh *bvh, const orc_kdtree *kd, const orc_camera *cam,
+                     const float *normals3, const float *xyz3, size_t n, float oblique_thresh,
+                     uint8_t *keep);
+/* get_target_diameters, psp_process.cpp:114-165 */
+void orc_target_diameters(const orc_kdtree *kd, const orc_camera *cam, const float *normals3,
+                          const float *xyz3, const float *uv2, const float *diam_in, size_t n,
+                          float *diam_out);
+/* cluster_points, cpp/lib/patches.ipp:239-276 */
+int orc_cluster_points(const float *uv2, const float *diam, int n, int bound_pts, int32_t *order,
+                       int32_t *cl_off);
+/* intensity_histc cpp/lib/image_processing.ipp:10-50; find_peaks / first_min_threshold
+ * cpp/utils/clustering.ipp:9-96 */
+void orc_intensity_histc(const uint16_t *img, size_t npix, unsigned depth, int bins, int32_t *edges,
+                         int32_t *counts);
+int orc_find_peaks(const double *data, int n, unsigned separation, uint32_t *peaks);
+unsigned orc_first_min_threshold(const int32_t *counts, int n, unsigned separation);
+/* PatchClusters ctor + threshold_bounds, patches.ipp:14-94,279-485 */
+void orc_patch_tables(const float *uv2, const float *diam, const int32_t *order,
+                      const int32_t *cl_off, int ncl, int cols, int rows, unsigned bound_pts,
+                      unsigned buffer, const uint16_t *ref, unsigned thresh, unsigned offset,
+                      int32_t **b_off, int32_t **bx, int32_t **by, int32_t **i_off, int32_t **ix,
+                      int32_t **iy);
+void orc_free(void *p);
 
 /* ------------------------------------------------------------ phase 2 --- */
 

@@ -127,3 +127,51 @@ def test_cli_phase2(gpu_lib, oracle, tmp_path):
     assert np.allclose(rms[live], np.sqrt((P[live].astype(np.float64) ** 2).mean(1)), rtol=1e-6)
     assert np.all(np.fromfile(os.path.join(out, "model_temp"), "<f4") == 68.0)
     assert os.path.getsize(os.path.join(out, "steady_state")) == 4 * n
+
+
+@pytest.mark.gpu
+def test_cli_target_patcher(gpu_lib, tmp_path):
+    """target_patcher = polynomial: phase-0 set-up from a targets file, then the patched frame loop.
+    Only nodes that look at patch-interior pixels may change w.r.t. the unpatched run."""
+    import torch
+    from upsp_processing_amd import _capi, engine, patch_setup as ps, psp_process as cli, synthetic as syn
+    tmp = str(tmp_path)
+    v, t, cams = write_case(tmp, nframes=6)
+    assert cli.main(["-input_file=%s/run.inp" % tmp, "-h5_out=x"]) == 0
+    n, F = v.shape[0], 6
+    base = np.fromfile(os.path.join(tmp, "out", "intensity_transpose"), "<f4").reshape(n, F).copy()
+    rng = np.random.default_rng(4)
+    pick = rng.choice(n, 40, replace=False)
+    with open(os.path.join(tmp, "model.tgts"), "w") as f:
+        f.write("*Targets\n")
+        for i, k in enumerate(pick):
+            p = v[k] * 1.0005
+            f.write("%d %.5f %.5f %.5f 0 0 1 0.25 1 1 1 st%02d\n" % (i + 1, p[0], p[1], p[2], i + 1))
+    deck = open(os.path.join(tmp, "run.inp")).read()
+    deck = deck.replace("@all\n", "@all\n  targets = %s/model.tgts\n" % tmp)
+    deck = deck.replace("@options\n", "@options\n  target_patcher = polynomial\n")
+    open(os.path.join(tmp, "run.inp"), "w").write(deck)
+    assert cli.main(["-input_file=%s/run.inp" % tmp, "-h5_out=x", "-bound_pts=2", "-buffer_pts=1"]) == 0
+    got = np.fromfile(os.path.join(tmp, "out", "intensity_transpose"), "<f4").reshape(n, F)
+    # which nodes may change: those whose pixel (either camera) is interior to a patch
+    s9, tn = syn.soup(v, t)
+    nrm = syn.node_normals(v, t)
+    bvh = engine.BVH(s9)
+    d_nodes, d_nrm, d_tn = (torch.as_tensor(a).cuda() for a in (v, nrm, tn))
+    may = np.zeros(n, bool)
+    nvis = 0
+    for c, (cd, fr) in enumerate(cams):
+        cam = _capi.make_camera(cd["K"], cd["dist"][:4], cd["R"], cd["t"], 192, 160)
+        tabs, vis, _ = ps.initialize_image_patches(bvh, cam, (192, 160), os.path.join(tmp, "model.tgts"),
+                                                   fr[0], d_nodes, nrm)
+        nvis += len(vis)
+        inner = set()
+        for tab in tabs:
+            if tab["bx"].size >= 10:
+                inner.update((tab["iy"].astype(np.int64) * 192 + tab["ix"]).tolist())
+        pix = engine.build_projection(bvh, cam, d_nodes, d_nrm, d_tn, 70.0)["pix"].cpu().numpy()
+        may |= np.isin(pix, np.fromiter(inner, np.int64, len(inner)))
+    assert nvis > 5
+    same = (got.view(np.int32) == base.view(np.int32)).all(1)
+    assert same[~may].all() and (~same[may]).any()
+    bvh.close()

@@ -25,8 +25,13 @@ from . import _capi, distributed as D, engine
 class Phase1:
     def __init__(self, tris9, tri_nodes, nodes, normals, cameras, image_size, oblique_angle=70.0,
                  overlap="average_view", datanode=None, registration=False, interp=1,
-                 filter=None, filter_size=1, patches=None, nframes_total=None):
-        """cameras: list of dict(K, dist, R, t); image_size = (width, height)."""
+                 filter=None, filter_size=1, patches=None, nframes_total=None, targets=None,
+                 first_frames=None, bit_depth=12, bound_pts=2, buffer_pts=1, target_diam_sf=1.2):
+        """cameras: list of dict(K, dist, R, t); image_size = (width, height).
+
+        patches: per camera list of dict(bx, by, ix, iy) (PatchClusters tables), or give
+        `targets` (one target file per camera) + `first_frames` (raw u16 [H,W] frame 1 per
+        camera) to run the phase-0 set-up here (InitializeImagePatches, :2088-2182)."""
         self.width, self.height = image_size
         self.ncams = len(cameras)
         self.nnodes = int(np.asarray(nodes).reshape(-1, 3).shape[0])
@@ -51,6 +56,19 @@ class Phase1:
                                                  self.centers, overlap)
                        if self.ncams > 1 else None)
         self.skipped, self.nskipped = engine.skipped_nodes(self.pix)   # :1644
+        self.visible_targets = None
+        if patches is None and targets is not None:
+            from . import patch_setup
+            patches, self.visible_targets = [], []
+            for c, cam in enumerate(self.cams):
+                fr = first_frames[c]
+                fr = fr.cpu().numpy() if isinstance(fr, torch.Tensor) else np.asarray(fr)
+                tab, vis, _ = patch_setup.initialize_image_patches(
+                    self.bvh, cam, image_size, targets[c], fr.reshape(self.height, self.width),
+                    self.d_nodes, normals, oblique_angle=oblique_angle, bit_depth=bit_depth,
+                    bound_pts=bound_pts, buffer_pts=buffer_pts, target_diam_sf=target_diam_sf)
+                patches.append(tab)
+                self.visible_targets.append(vis)
         opts = dict(registration=int(bool(registration)), interp=int(interp),
                     patch=int(patches is not None))
         if filter:

@@ -13,7 +13,8 @@ cpp/lib/upsp_inputs.cpp) for the part of the pipeline this repository implements
 * video: 12-bit Photron `.mraw` (cpp/lib/MrawReader.cpp)      [`.cine`: not built]
 * options: registration = none|pixel, filter = none|gaussian|box (+ filter_size),
   overlap = best_view|average_view, oblique_angle, number_frames
-  [target_patcher = polynomial needs the phase-0 patch set-up, SURVEY.md 8f N2: rejected]
+  target_patcher = none|polynomial (targets file in @all or @camera; flags -bound_pts,
+  -buffer_pts, -target_diam_sf, cpp/exec/psp_process.cpp:1207-1210)
 
 and writes the phase-1 flat files (intensity_transpose, intensity_avg, intensity_rms,
 intensity_ratio_0, coverage, camNN-uv, vv-int-*.dat; cpp/exec/psp_process.cpp:524-540).
@@ -92,9 +93,13 @@ def parse_input_deck(path):
         raise DeckError("filter_size must be odd")
     if opts["overlap"] not in ("best_view", "average_view"):
         raise DeckError("overlap must be best_view or average_view")
-    if opts["target_patcher"] != "none":
-        raise DeckError("target_patcher = %s needs the phase-0 patch set-up, which this engine "
-                        "does not build" % opts["target_patcher"])
+    if opts["target_patcher"] not in ("none", "polynomial"):
+        raise DeckError("target_patcher must be none or polynomial")
+    if opts["target_patcher"] == "polynomial":
+        for c in deck["camera"]:
+            c.setdefault("targets", deck["all"].get("targets", ""))   # upsp_inputs.cpp:160-166
+            if not c["targets"] or not os.path.isfile(c["targets"]):
+                raise DeckError("Targets file %r: not found" % c["targets"])
     if not deck["camera"]:
         raise DeckError("no @camera section")
     return deck
@@ -186,14 +191,24 @@ def main(argv=None):
     if "frames" in flags and int(flags["frames"]) > 0:
         nframes = min(nframes, int(flags["frames"]))
 
+    first = [r.read_frames_device(1, 1)[0] for r in readers]
+    patch_kw = {}
+    if opts["target_patcher"] == "polynomial":                      # phase 0, :2088-2182
+        patch_kw = dict(targets=[c["targets"] for c in deck["camera"]], first_frames=first,
+                        bit_depth=12, bound_pts=int(flags.get("bound_pts", 2)),
+                        buffer_pts=int(flags.get("buffer_pts", 1)),
+                        target_diam_sf=float(flags.get("target_diam_sf", 1.2)))
     job = psp.Phase1(s9, tri_nodes, xyz, normals, cams, size,
                      oblique_angle=float(opts["oblique_angle"]), overlap=opts["overlap"],
                      datanode=datanode, registration=opts["registration"] == "pixel",
                      filter=None if opts["filter"] == "none" else opts["filter"],
-                     filter_size=int(opts["filter_size"]))
+                     filter_size=int(opts["filter_size"]), **patch_kw)
+    if job.visible_targets is not None and (not D.dist.is_initialized() or D.dist.get_rank() == 0):
+        for c, vis in enumerate(job.visible_targets):
+            print("camera %d: %d visible targets patched" % (c + 1, len(vis)))
     shard = D.Shard(nframes, job.nnodes)
     f0, nf = shard.my_frames
-    job.set_first_frames([r.read_frames_device(1, 1)[0] for r in readers])
+    job.set_first_frames(first)
     rows_t = torch.empty((job.nnodes, max(nf, 1)), dtype=torch.float32, device="cuda")
     chunk = 256
     for c0 in range(0, nf, chunk):
