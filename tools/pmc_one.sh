@@ -3,7 +3,7 @@
 # usage: tools/pmc_one.sh <outdir> "<counter list>" <script.py> [args...]
 out=$1; grp=$2; shift; shift
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-timeout 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out -- python3 "$@" > $out.log 2>&1
+timeout ${PMC_TIMEOUT:-150} rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out -- python3 "$@" > $out.log 2>&1
 f=$(find $out -name "*counter_collection.csv" | head -1)
 [ -n "$f" ] && python3 - "$f" <<'PY'
 import csv, sys, collections

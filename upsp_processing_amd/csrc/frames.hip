@@ -21,20 +21,27 @@ namespace upsp {
 namespace {
 
 constexpr int kHotCap = 64;  // recorded hot-pixel positions per frame
+// ticket counters sit 128 B apart: same-line atomics serialise (~88 per us per line)
+constexpr int kTicketStride = 32;
 
 // ---------------------------------------------------------------- hot pixels --
+__device__ void fix_frame(uint16_t *__restrict__ img, int rows, int cols, int min_change, int max_hot,
+                          unsigned n, unsigned *p, int32_t *status_f);
+
 // Pass 1 of upsp::fix_hot_pixels (cpp/utils/cv_extras.cpp:237-247): find pixels
 // >= thresh.  16 bytes (8 pixels) per lane per step; the frame is otherwise only
 // streamed through (this is the one compulsory full read of a frame).
 __global__ void __launch_bounds__(256)
-    hot_scan_kernel(const uint16_t *__restrict__ frames, size_t npix, int thresh,
-                    unsigned *__restrict__ count, unsigned *__restrict__ pos)
+    hot_scan_kernel(uint16_t *frames, size_t npix, int thresh, unsigned *__restrict__ count,
+                    unsigned *__restrict__ pos, unsigned *__restrict__ done, int rows, int cols,
+                    int min_change, int max_hot, int32_t *__restrict__ status)
 {
     const size_t f = blockIdx.y;
-    const uint4 *src = reinterpret_cast<const uint4 *>(frames + f * npix);
+    const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(frames + f * npix);
     const size_t nvec = npix / 8;
     const unsigned th = (unsigned)thresh;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
+    int wrote = 0;
     auto check = [&](const uint4 v, size_t i) {
         const unsigned w[4] = {v.x, v.y, v.z, v.w};
         bool any = false;  // quick reject: any half-word >= thresh ?
@@ -46,7 +53,8 @@ __global__ void __launch_bounds__(256)
                 const unsigned px = (w[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
                 if (px >= th) {
                     const unsigned slot = atomicAdd(&count[f], 1u);
-                    if (slot < (unsigned)kHotCap) pos[f * kHotCap + slot] = (unsigned)(i * 8 + k);
+                    if (slot < (unsigned)kHotCap)
+                        wrote |= (int)atomicExch(&pos[f * kHotCap + slot], (unsigned)(i * 8 + k)) | 1;
                 }
             }
         }
@@ -66,24 +74,37 @@ __global__ void __launch_bounds__(256)
         const size_t p = nvec * 8 + threadIdx.x;
         if (frames[f * npix + p] >= th) {
             const unsigned slot = atomicAdd(&count[f], 1u);
-            if (slot < (unsigned)kHotCap) pos[f * kHotCap + slot] = (unsigned)p;
+            if (slot < (unsigned)kHotCap) wrote |= (int)atomicExch(&pos[f * kHotCap + slot], (unsigned)p) | 1;
+        }
+    }
+    // Pass 2 in the same launch: the workgroup that finishes a frame last repairs it (lane 0).
+    // Counters and positions only ever move through device-scope atomics (performed at the
+    // memory side, coherent across the 8 XCDs) -- an agent-scope fence would cost an L2
+    // write-back per workgroup on this part.  `wrote` carries the atomics' return values, so
+    // they have completed before the barrier; the ticket follows the barrier.  The last
+    // workgroup also zeroes the counters for the next launch (no memset between sub-batches).
+    const int any_wrote = __syncthreads_or(wrote);
+    if (threadIdx.x == 0) {
+        const unsigned ticket = atomicAdd(&done[f * kTicketStride], (unsigned)(any_wrote >= 0));   // always 1
+        if (ticket == gridDim.x - 1) {
+            const unsigned n = atomicExch(&count[f], 0u);
+            atomicExch(&done[f * kTicketStride], 0u);
+            unsigned p[kHotCap];
+            const unsigned m = n < (unsigned)kHotCap ? n : (unsigned)kHotCap;
+            for (unsigned i = 0; i < m; ++i) p[i] = atomicAdd(&pos[f * kHotCap + i], 0u);
+            fix_frame(frames + f * npix, rows, cols, min_change, max_hot, n, p, status ? status + f : nullptr);
         }
     }
 }
 
 // Pass 2 (cv_extras.cpp:249-274): sequential repair in scan order, one lane per frame.
-__global__ void hot_fix_kernel(uint16_t *__restrict__ frames, int nframes, int rows, int cols,
-                               int min_change, int max_hot, const unsigned *__restrict__ count,
-                               unsigned *__restrict__ pos, int32_t *__restrict__ status)
+__device__ void fix_frame(uint16_t *__restrict__ img, int rows, int cols, int min_change, int max_hot,
+                          unsigned n, unsigned *p, int32_t *status_f)
 {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= nframes) return;
-    const unsigned n = count[f];
     if (n > (unsigned)max_hot) {  // "too many pixels look hot": frame untouched
-        if (status) status[f] = -1;
+        if (status_f) *status_f = -1;
         return;
     }
-    unsigned *p = pos + (size_t)f * kHotCap;
     for (unsigned i = 1; i < n; ++i) {  // scan order
         const unsigned v = p[i];
         unsigned j = i;
@@ -93,10 +114,10 @@ __global__ void hot_fix_kernel(uint16_t *__restrict__ frames, int nframes, int r
         }
         p[j] = v;
     }
-    uint16_t *img = frames + (size_t)f * rows * cols;
     int replaced = 0;
     for (unsigned h = 0; h < n; ++h) {
-        const int row = (int)(p[h] / (unsigned)cols), col = (int)(p[h] % (unsigned)cols);
+        const unsigned ph = p[h];
+        const int row = (int)(ph / (unsigned)cols), col = (int)(ph % (unsigned)cols);
         uint16_t vals[4];
         unsigned nv = 0;
         if (row > 0) vals[nv++] = img[(size_t)(row - 1) * cols + col];
@@ -119,7 +140,7 @@ __global__ void hot_fix_kernel(uint16_t *__restrict__ frames, int nframes, int r
             ++replaced;
         }
     }
-    if (status) status[f] = replaced;
+    if (status_f) *status_f = replaced;
 }
 
 // ------------------------------------------------------------------- gather --
@@ -186,7 +207,7 @@ __global__ void __launch_bounds__(256)
 // tile is written node-major (256-byte rows of the [N x F] time series =
 // intensity_transpose layout, psp_process.cpp:2027-2032) and, if requested,
 // frame-major (intensity_buf rows) -- both fully coalesced, no second pass over HBM.
-template <int NCAMS>
+template <int NCAMS, bool kStreamStores>
 __global__ void __launch_bounds__(256)
     gather_tile_kernel(GatherArgs a, const uint8_t *__restrict__ skipped, unsigned nnodes,
                        int nframes, float *__restrict__ rows, float *__restrict__ rows_t,
@@ -263,7 +284,14 @@ __global__ void __launch_bounds__(256)
                     v.w = tile[c4 + 3][j];
                     float *dst = rows_t + (long long)nn * ld_t + c4;
                     if (c4 + 3 < nframes) {
-                        *reinterpret_cast<float4 *>(dst) = v;
+                        // streaming store: the series is not read again by the frame loop, keep
+                        // L2 / Infinity Cache for the frames the gathers are reading
+                        typedef float v4f __attribute__((ext_vector_type(4)));
+                        v4f nv = {v.x, v.y, v.z, v.w};
+                        if (kStreamStores)
+                            __builtin_nontemporal_store(nv, reinterpret_cast<v4f *>(dst));
+                        else
+                            *reinterpret_cast<v4f *>(dst) = nv;
                     } else {
                         dst[0] = v.x;
                         if (c4 + 1 < nframes) dst[1] = v.y;
@@ -412,6 +440,8 @@ __global__ void project_one_kernel(const void *img, int is_f32, const int32_t *_
 }  // namespace
 
 // ---- launchers used by pipeline.cpp -----------------------------------------
+size_t hot_counter_words(int nframes) { return (size_t)nframes * (1 + kTicketStride); }
+
 int launch_hot_fix(uint16_t *d_frames, int nframes, int rows, int cols, int thresh,
                    int min_change, int max_hot, unsigned *d_count, unsigned *d_pos,
                    int32_t *d_status, hipStream_t st)
@@ -419,19 +449,16 @@ int launch_hot_fix(uint16_t *d_frames, int nframes, int rows, int cols, int thre
     if (nframes <= 0) return UPSP_OK;
     if (max_hot < 0 || max_hot >= kHotCap) return fail(UPSP_ERR_INVALID, "max_hot must be in [0,63]");
     const size_t npix = (size_t)rows * cols;
-    UPSP_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(unsigned) * (size_t)nframes, st));
+    // d_count holds hot_counter_words(nframes) counters (hot pixels per frame, then one padded
+    // ticket counter per frame); zero when allocated, the kernel leaves them zero
     size_t bx = (npix / 8 + 255) / 256;
     static const size_t bx_cap = std::getenv("UPSP_SCAN_BX") ? (size_t)std::atoi(std::getenv("UPSP_SCAN_BX")) : 128;
     if (bx > bx_cap) bx = bx_cap;
     if (bx < 1) bx = 1;
-    {
     KTimed kt("hot_scan_kernel", st);
     hipLaunchKernelGGL(hot_scan_kernel, dim3((unsigned)bx, (unsigned)nframes), dim3(256), 0, st,
-                       d_frames, npix, thresh, d_count, d_pos);
-    }
-    KTimed kt2("hot_fix_kernel", st);
-    hipLaunchKernelGGL(hot_fix_kernel, dim3((nframes + 63) / 64), dim3(64), 0, st, d_frames,
-                       nframes, rows, cols, min_change, max_hot, d_count, d_pos, d_status);
+                       d_frames, npix, thresh, d_count, d_pos, d_count + nframes, rows, cols,
+                       min_change, max_hot, d_status);
     UPSP_HIP_CHECK(hipGetLastError());
     return UPSP_OK;
 }
@@ -453,9 +480,17 @@ int launch_gather(const PipelineGather &g, hipStream_t st)
         KTimed kt("gather_tile_kernel", st);
         const dim3 tgrid((unsigned)((g.nnodes + 63) / 64)), tblock(256);
 #define UPSP_TILE(NC)                                                                          \
-    hipLaunchKernelGGL((gather_tile_kernel<NC>), tgrid, tblock, 0, st, a, g.skipped,          \
-                       (unsigned)g.nnodes, g.nframes, g.rows, g.rows_t, (long long)g.ld_t,    \
-                       g.sum, g.sumsq)
+    do {                                                                                       \
+        if (stream_stores)                                                                     \
+            hipLaunchKernelGGL((gather_tile_kernel<NC, true>), tgrid, tblock, 0, st, a,        \
+                               g.skipped, (unsigned)g.nnodes, g.nframes, g.rows, g.rows_t,     \
+                               (long long)g.ld_t, g.sum, g.sumsq);                             \
+        else                                                                                   \
+            hipLaunchKernelGGL((gather_tile_kernel<NC, false>), tgrid, tblock, 0, st, a,       \
+                               g.skipped, (unsigned)g.nnodes, g.nframes, g.rows, g.rows_t,     \
+                               (long long)g.ld_t, g.sum, g.sumsq);                             \
+    } while (0)
+        static const bool stream_stores = std::getenv("UPSP_NO_STREAM_STORES") == nullptr;
         switch (g.ncams) {  // per-camera pix / weight stay in registers for 1..4 cameras
             case 1: UPSP_TILE(1); break;
             case 2: UPSP_TILE(2); break;
@@ -514,7 +549,8 @@ int upsp_fix_hot_pixels(uint16_t *d_frames, int nframes, int rows, int cols, int
         return fail(UPSP_ERR_INVALID, "bad frame buffer / size");
     hipStream_t st = (hipStream_t)stream;
     unsigned *cnt = nullptr, *pos = nullptr;
-    UPSP_HIP_CHECK(hipMalloc(&cnt, sizeof(unsigned) * (size_t)nframes));
+    UPSP_HIP_CHECK(hipMalloc(&cnt, sizeof(unsigned) * hot_counter_words(nframes)));
+    UPSP_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * hot_counter_words(nframes), st));
     hipError_t e = hipMalloc(&pos, sizeof(unsigned) * (size_t)nframes * kHotCap);
     int rc = UPSP_OK;
     if (e != hipSuccess) {

@@ -28,6 +28,7 @@ struct PipelineGather {
     double *sum = nullptr, *sumsq = nullptr;
 };
 
+size_t hot_counter_words(int nframes);   // size of the counter buffer launch_hot_fix needs (zeroed)
 int launch_hot_fix(uint16_t *d_frames, int nframes, int rows, int cols, int thresh,
                    int min_change, int max_hot, unsigned *d_count, unsigned *d_pos,
                    int32_t *d_status, hipStream_t st);
