@@ -146,7 +146,9 @@ def main():
     pipe = engine.FramePipeline(1, size, size, N, registration=int(a.registration))
     if a.registration:
         pipe.set_reference(0, frames[0].to(torch.float32))   # raw first frame as ECC template
-    rows_t = (torch.empty((N, F), dtype=torch.float32, device="cuda")
+    # node-major time series [N, F] with the padded row pitch engine.series_ld() recommends
+    ld = engine.series_ld(F)
+    rows_t = (torch.empty((N, ld), dtype=torch.float32, device="cuda")[:, :F]
               if not (world > 1 or a.force_chunked) else None)
     torch.cuda.synchronize()
 
@@ -176,8 +178,9 @@ def main():
             exch.k = 0
             for k in range(K):
                 c0, fc = exch.my_chunk(k)
-                pipe.process(frames[c0:c0 + fc], first_frame=rank * F + c0, rows_t=chunk_bufs[k],
-                             want_rows=False)
+                if fc:
+                    pipe.process(frames[c0:c0 + fc], first_frame=rank * F + c0, rows_t=chunk_bufs[k],
+                                 want_rows=False)
                 exch.submit(chunk_bufs[k])
         e[2].record()
         s, ss = pipe.accumulators()

@@ -158,6 +158,7 @@ struct GatherArgs {
     int is_f32[kMaxCams];
     int ncams;
     size_t npix;
+    int dbg;
 };
 
 template <int NCAMS>
@@ -223,7 +224,7 @@ __global__ void __launch_bounds__(256)
     float w[NCAMS > 0 ? NCAMS : kMaxCams];
 #pragma unroll
     for (int c = 0; c < nc; ++c) {
-        px[c] = live ? a.pix[c][n] : -1;
+        px[c] = (live && !(a.dbg & 2)) ? a.pix[c][n] : -1;
         w[c] = (live && a.weight[c]) ? a.weight[c][n] : 1.0f;
     }
     const bool skip = live && skipped && skipped[n];
@@ -267,7 +268,7 @@ __global__ void __launch_bounds__(256)
         sum[n] += ((part[0][0][lane] + part[0][1][lane]) + part[0][2][lane]) + part[0][3][lane];
         sumsq[n] += ((part[1][0][lane] + part[1][1][lane]) + part[1][2][lane]) + part[1][3][lane];
     }
-    if (rows_t) {
+    if (rows_t && !(a.dbg & 1)) {
         const bool vec_ok = ((ld_t & 3) == 0) && ((reinterpret_cast<size_t>(rows_t) & 15) == 0);
         if (vec_ok) {
             // 16 lanes x 16 B = one 256-byte row segment, 4 rows per wave instruction
@@ -470,6 +471,8 @@ int launch_gather(const PipelineGather &g, hipStream_t st)
     std::memset(&a, 0, sizeof(a));
     a.ncams = g.ncams;
     a.npix = g.npix;
+    static const int dbg = std::getenv("UPSP_GATHER_DBG") ? std::atoi(std::getenv("UPSP_GATHER_DBG")) : 0;
+    a.dbg = dbg;
     for (int c = 0; c < g.ncams; ++c) {
         a.img[c] = g.img[c];
         a.pix[c] = g.pix[c];

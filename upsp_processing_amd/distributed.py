@@ -71,7 +71,7 @@ def exchange_time_series(rows_t, shard, group=None, out=None):
     r, w = shard.rank, shard.world
     n0, nn = shard.my_nodes
     f_r = shard.frame_count[r]
-    assert rows_t.shape == (shard.nnodes, f_r) and rows_t.is_contiguous()
+    assert rows_t.shape == (shard.nnodes, f_r) and (rows_t.numel() == 0 or rows_t.stride(1) == 1)
     if w == 1 or not dist.is_initialized():
         if out is None:
             return rows_t                      # single rank: already the complete series
@@ -79,6 +79,7 @@ def exchange_time_series(rows_t, shard, group=None, out=None):
         return out
     if out is None:
         out = torch.empty((nn, shard.nframes), dtype=rows_t.dtype, device=rows_t.device)
+    rows_t = rows_t.contiguous()               # padded row pitch (engine.series_ld) -> packed blocks
     in_split = [shard.node_count[d] * f_r for d in range(w)]       # block for rank d
     out_split = [nn * shard.frame_count[s] for s in range(w)]      # block from rank s
     recv = torch.empty(sum(out_split), dtype=rows_t.dtype, device=rows_t.device)
@@ -92,6 +93,17 @@ def exchange_time_series(rows_t, shard, group=None, out=None):
     return out
 
 
+def aligned_chunks(nframes, nchunks, align=64):
+    """Cuts nframes into nchunks contiguous pieces whose boundaries are multiples of `align`
+    (as evenly as that allows; trailing pieces may be empty).  Returns (starts, extents) like
+    apportion()."""
+    bounds = [min(nframes, int(round(k * nframes / nchunks / align)) * align) for k in range(nchunks)]
+    bounds.append(nframes)
+    for k in range(1, nchunks + 1):
+        bounds[k] = max(bounds[k], bounds[k - 1])
+    return bounds[:-1], [bounds[k + 1] - bounds[k] for k in range(nchunks)]
+
+
 class TimeSeriesExchange:
     """global_transpose pipelined with the frame loop: the rank's frames are produced in K
     chunks; the all-to-all of chunk k is issued asynchronously as soon as its node-major
@@ -103,7 +115,9 @@ class TimeSeriesExchange:
         self.shard, self.K, self.group = shard, max(1, int(nchunks)), group
         n0, nn = shard.my_nodes
         self.out = torch.empty((nn, shard.nframes), dtype=dtype, device=device)
-        self.chunks = [apportion(shard.frame_count[s], self.K) for s in range(shard.world)]
+        # chunk boundaries on multiples of 64 frames (the last chunk takes the remainder): every
+        # chunk buffer then has 256-byte-aligned rows, which the gather writes as whole 128-B lines
+        self.chunks = [aligned_chunks(shard.frame_count[s], self.K) for s in range(shard.world)]
         self.pending = []
         self.k = 0
 

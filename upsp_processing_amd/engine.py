@@ -229,6 +229,16 @@ def apportion(value, nbins):
     return list(st), list(ex)
 
 
+def series_ld(nframes):
+    """Row pitch (in floats) for a node-major time-series buffer [N, nframes]: rows start on
+    256-byte boundaries, so every 64-frame row segment the gather writes is two whole 128-B
+    lines, and the pitch is an odd multiple of 256 B, so consecutive rows do not map to the same
+    HBM channels (a 4-KiB pitch measured 8 % slower than 4352 B on MI355X).  Pass
+    `torch.empty((N, ld))[:, :nframes]` as rows_t."""
+    ld = (int(nframes) + 63) // 64 * 64
+    return ld + 64 if (ld // 64) % 2 == 0 else ld
+
+
 class FramePipeline:
     """Body of the psp_process phase-1 frame loop (psp_process.cpp:1743-1851)."""
 

@@ -191,7 +191,8 @@ def run_phase1(job, frames_per_cam, nframes_total=None, out_dir=None, chunk=256)
     f0, nf = shard.my_frames
     job.set_first_frames([torch.as_tensor(np.asarray(fr[0])) if not isinstance(fr, torch.Tensor) else fr[0]
                           for fr in frames_per_cam])
-    rows_t = torch.empty((job.nnodes, max(nf, 1)), dtype=torch.float32, device="cuda")
+    rows_t = torch.empty((job.nnodes, engine.series_ld(max(nf, 1))), dtype=torch.float32,
+                         device="cuda")[:, :max(nf, 1)]
     for c0 in range(0, nf, chunk):
         n = min(chunk, nf - c0)
         batch = []
@@ -202,7 +203,7 @@ def run_phase1(job, frames_per_cam, nframes_total=None, out_dir=None, chunk=256)
             batch.append(b.to("cuda").contiguous())
         job.process(batch, first_frame=f0 + c0, rows_t=rows_t, col0=c0)
     finals = job.finalize(F)
-    series = D.exchange_time_series(rows_t[:, :nf].contiguous() if rows_t.shape[1] != nf else rows_t, shard)
+    series = D.exchange_time_series(rows_t[:, :nf], shard)
     if out_dir:
         job.write_outputs(out_dir, finals, series, node_start=shard.my_nodes[0])
     return finals, series

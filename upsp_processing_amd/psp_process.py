@@ -160,7 +160,7 @@ def read_camera_json(path):
 
 def main(argv=None):
     import torch
-    from . import psp, synthetic, video, distributed as D
+    from . import engine, psp, synthetic, video, distributed as D
     flags = parse_flags(sys.argv[1:] if argv is None else argv)
     deck = parse_input_deck(flags["input_file"])
     opts = deck["options"]
@@ -209,7 +209,8 @@ def main(argv=None):
     shard = D.Shard(nframes, job.nnodes)
     f0, nf = shard.my_frames
     job.set_first_frames(first)
-    rows_t = torch.empty((job.nnodes, max(nf, 1)), dtype=torch.float32, device="cuda")
+    rows_t = torch.empty((job.nnodes, engine.series_ld(max(nf, 1))), dtype=torch.float32,
+                         device="cuda")[:, :max(nf, 1)]
     chunk = 256
     for c0 in range(0, nf, chunk):
         n = min(chunk, nf - c0)
@@ -218,7 +219,7 @@ def main(argv=None):
         if shard.rank == 0 and c0 % (chunk * 4) == 0:
             print("  Rank 0:: processing frame %d" % (f0 + c0))
     finals = job.finalize(nframes)
-    series = D.exchange_time_series(rows_t[:, :nf].contiguous() if rows_t.shape[1] != nf else rows_t, shard)
+    series = D.exchange_time_series(rows_t[:, :nf], shard)
     out_dir = flags.get("add_out_dir") or deck["output"].get("dir") or "."
     job.write_outputs(out_dir, finals, series, node_start=shard.my_nodes[0])
     if shard.rank == 0:
