@@ -71,7 +71,7 @@ def exchange_time_series(rows_t, shard, group=None, out=None):
     r, w = shard.rank, shard.world
     n0, nn = shard.my_nodes
     f_r = shard.frame_count[r]
-    assert rows_t.shape == (shard.nnodes, f_r) and (rows_t.numel() == 0 or rows_t.stride(1) == 1)
+    assert rows_t.shape == (shard.nnodes, f_r) and (rows_t.shape[1] <= 1 or rows_t.stride(1) == 1)
     if w == 1 or not dist.is_initialized():
         if out is None:
             return rows_t                      # single rank: already the complete series
