@@ -137,6 +137,7 @@ def main():
     d_nodes = torch.as_tensor(verts).cuda()
     d_nrm = torch.as_tensor(nrm).cuda()
     d_tn = torch.as_tensor(tn).cuda()
+    bvh.set_tri_nodes(d_tn, N)      # createBVH(model, triNodes): once per model, like the BVH itself
     # this rank's frames (global frame index = rank*F + f), resident in HBM
     frames = torch.empty((F, size, size), dtype=torch.uint16, device="cuda")
     chunk = 50
@@ -238,13 +239,17 @@ def main():
     kernels = {}
     n_retry_rays = 6 * retry_nodes_last[0]
     scene_bytes = bvh.info["device_bytes"]
+    gather_launches = -(-F // 64) if not chunked else sum(-(-exch.my_chunk(k)[1] // 64) for k in range(K))
     per_step_bytes = {
         # 40 B per ray (24 B ray + 16 B hit record) + the scene once per launch
         "projection_kernel<primary>": primary_rays_last[0] * 40 + scene_bytes,
         "projection_kernel<retry>": n_retry_rays * 40 + scene_bytes,
-        # frame unit = 2 MiB frame + 12 B x N (pix, weight, out), split as
-        # 12 B x N for the gather and the 2 MiB compulsory full read for the hot-pixel scan
-        "gather_tile_kernel": F * 12 * N,
+        # frame unit = 2 MiB frame + 12 B x N (pix 4, weight 4, out 4).  The 2 MiB
+        # compulsory full read of the frame belongs to the hot-pixel scan (the gather's pixel reads
+        # hit the Infinity Cache); the gather keeps pix / weight in registers across its 64-frame
+        # tile, so per launch it needs 4 B x N x frames written + 8 B x N read once -- counting
+        # 12 B x N per FRAME would credit bytes the kernel never has to move.
+        "gather_tile_kernel": F * 4 * N + gather_launches * 8 * N,
         "hot_scan_kernel": F * 2 * size * size,
     }
     for name, (calls, total_ms) in timing.items():
@@ -292,6 +297,8 @@ def main():
         "breakdown_ms": {"projection_build": ray_ms, "frame_loop": frm_ms,
                          "exchange_finals": float(np.mean(t_xchg))},
         "frame_loop_frames_per_s": F / (frm_ms * 1e-3),
+        # whole frame loop against HBM: (2 MiB + 4 B x N) per frame + 8 B x N per 64-frame tile
+        "frame_loop_GBps": (F * (2 * size * size + 4 * N) + gather_launches * 8 * N) / (frm_ms * 1e-3) / 1e9,
         "roofline": roof,
         "kernels": kernels,
     }

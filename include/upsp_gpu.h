@@ -67,6 +67,14 @@ typedef struct upsp_bvh_info {
 } upsp_bvh_info;
 int upsp_bvh_get_info(const upsp_bvh *bvh, upsp_bvh_info *info);
 
+/* createBVH(model, triNodes) also returns the triangle -> node ids (cpp/exec/psp_process.cpp:44-53,
+ * TriModel_::extract_tris cpp/lib/TriModel.ipp:261-299).  Handing them to the BVH (device array,
+ * 3 ints per input triangle, node ids in [0, nnodes)) lets upsp_projection_build bound every
+ * camera -> node ray by the node's own triangles: same visibility verdicts, far fewer node
+ * visits.  Optional; used only by projection builds that pass the same d_tri_nodes pointer and
+ * nnodes.  Call again when the array's contents change; (NULL, 0) clears. */
+int upsp_bvh_set_tri_nodes(upsp_bvh *bvh, const int32_t *d_tri_nodes, size_t nnodes, void *stream);
+
 /* Per-ray outputs, structure of arrays; any pointer may be NULL (not written). */
 typedef struct upsp_hits {
     uint8_t *hit;   /* [n]   return value of rt::BVH::intersect: any triangle hit with t>=0 */

@@ -40,6 +40,21 @@ def test_projection_matches_oracle(gpu_lib, oracle, case):
     assert np.array_equal(g["nodecount"].cpu().numpy(), o["nodecount"])
     sk, cnt = engine.skipped_nodes(g["pix"])
     assert np.array_equal(sk.cpu().numpy(), oracle.skipped_nodes(o["pix"])) and cnt == (pix < 0).sum()
+    # same build with the node -> triangle adjacency handed to the BVH (bounded visibility
+    # rays, upsp_bvh_set_tri_nodes): identical verdicts, identical reference ray count
+    import torch
+    d_tn = torch.as_tensor(tn).cuda()
+    bvh.set_tri_nodes(d_tn, v.shape[0])
+    bvh.enable_stats(True)
+    g2 = engine.build_projection(bvh, cam_g, v, nrm, d_tn, 70.0, datanode=dn, nodecount=True)
+    st_bounded = bvh.last_stats()
+    assert np.array_equal(g2["pix"].cpu().numpy(), o["pix"])
+    assert np.array_equal(g2["uv"].cpu().numpy().view(np.int32), o["uv"].view(np.int32))
+    assert g2["nrays"] == o["nrays"]
+    g3 = engine.build_projection(bvh, cam_g, v, nrm, tn, 70.0, datanode=dn)   # other buffer: classic path
+    st_classic = bvh.last_stats()
+    assert np.array_equal(g3["pix"].cpu().numpy(), o["pix"])
+    assert st_bounded["nodes"] <= st_classic["nodes"]                         # the bound only ever prunes
 
 
 def test_multi_camera_weights(gpu_lib, oracle):

@@ -299,6 +299,7 @@ struct Scene {
     int top;              // nodes [0, top) are staged in LDS (breadth-first upper tree)
     int stack_ints;       // LDS ints taken by the traversal stacks (top nodes follow)
     float rlo[3], rhi[3];
+    const unsigned *adj_off, *adj_slot;   // node -> adjacent triangle slots (may be null)
 };
 
 struct Trav {
@@ -308,6 +309,7 @@ struct Trav {
     float limit;    // best_t with the pruning guard applied
     int best_slot;  // triangle slot of the closest hit
     bool any;       // rt::BVH::intersect return value
+    float own_min;  // visibility rays: stop as soon as the closest hit is nearer than this
     unsigned n_nodes, n_tris;
     unsigned ray_nodes, ray_tris;  // STATS: steps of the current ray
 };
@@ -320,6 +322,7 @@ __device__ __forceinline__ void trav_begin(Trav &s, const Ray &r, const Scene &s
     s.limit = __builtin_inff();
     s.best_slot = -1;
     s.any = false;
+    s.own_min = -__builtin_inff();
     s.cur = box_hit(r, sc.rlo[0], sc.rlo[1], sc.rlo[2], sc.rhi[0], sc.rhi[1], sc.rhi[2])
                 ? sc.root_ref
                 : kDone;
@@ -402,6 +405,9 @@ __device__ __forceinline__ bool leaf_step(Trav &s, const Ray &r, const Scene &sc
                 s.best_t = h.t;
                 s.best_slot = (int)(first + i);
                 s.limit = h.t + fabsf(h.t) * 4e-6f;
+                // visibility ray: every triangle of the target node is farther than this hit,
+                // so the closest hit cannot be one of them any more -- outcome decided
+                if (h.t < s.own_min) return true;
             }
         }
     }
@@ -711,6 +717,57 @@ __global__ void __launch_bounds__(256)
 // as INDEPENDENT rays, six adjacent work items per node.  The reference stops at the
 // first retry that sees the node; the outcome ("any retry sees it") is the same, so
 // all six are cast and the reference's ray count is reconstructed from the bit mask.
+// Visibility rays (camera -> a model node) only ask whether the CLOSEST hit lies on a triangle
+// of that node (psp_process.cpp:263-267, 289-294).  With the node -> triangle adjacency the ray
+// is first tested against the node's own triangles (same tri_test arithmetic as the traversal):
+//   * their largest t bounds the search: a triangle farther than that is never the answer, so
+//     the traversal starts with that pruning limit instead of +inf (nothing behind the node is
+//     visited);
+//   * their smallest t is an exit: once the running closest hit is nearer than every own
+//     triangle the outcome is "foreign triangle" whatever else is found.
+// The traversal itself is unchanged (same boxes accepted, same order, strict <), so the verdict
+// is the reference's: an own triangle the reference cannot reach through its box tests is not
+// reached here either, it only tightens nothing.  kMaxOwn caps the direct tests (polar fans).
+constexpr unsigned kMaxOwn = 16;
+struct OwnBound {
+    float tmin, tmax;
+    bool known, hit;   // known: adjacency available and small enough; hit: some own triangle is hit
+};
+__device__ __forceinline__ OwnBound own_bound(const Ray &r, const Scene &sc, unsigned node)
+{
+    OwnBound o;
+    o.tmin = __builtin_inff();
+    o.tmax = -__builtin_inff();
+    o.known = o.hit = false;
+    if (!sc.adj_off) return o;
+    const unsigned b = sc.adj_off[node], e = sc.adj_off[node + 1];
+    if (e - b > kMaxOwn) return o;
+    o.known = true;
+    for (unsigned k = b; k < e; ++k) {
+        const float4 *tp = sc.tris + 3 * (size_t)sc.adj_slot[k];
+        const float4 a = tp[0], bb = tp[1], c = tp[2];
+        TriHit h;
+        if (tri_test(r, a.x, a.y, a.z, bb.x, bb.y, bb.z, c.x, c.y, c.z, h)) {
+            o.hit = true;
+            o.tmin = fminf(o.tmin, h.t);
+            o.tmax = fmaxf(o.tmax, h.t);
+        }
+    }
+    return o;
+}
+
+// Applies the bound to a freshly started traversal.  Returns false when the ray needs no
+// traversal at all (retry rays that miss every own triangle cannot see the node).
+template <int PHASE>
+__device__ __forceinline__ bool apply_own_bound(Trav &s, const OwnBound &o)
+{
+    if (!o.known) return true;
+    if (!o.hit) return PHASE == 0;   // primary: still has to learn whether anything is hit (:261)
+    s.limit = o.tmax + fabsf(o.tmax) * 4e-6f;
+    s.own_min = o.tmin;
+    return true;
+}
+
 template <bool STATS, int PHASE>
 __global__ void __launch_bounds__(kBlock)
     projection_kernel(Scene sc, Cam cam, const float *__restrict__ nodes,
@@ -729,7 +786,7 @@ __global__ void __launch_bounds__(kBlock)
     s.cur = kDone;
     s.n_nodes = s.n_tris = 0;
     unsigned item = 0, my_rays = 0;
-    bool busy = false;
+    bool busy = false, bounded = false;
 
     for (;;) {
         for (;;) {
@@ -743,6 +800,9 @@ __global__ void __launch_bounds__(kBlock)
                     if (len != 0.0f) { dx /= len; dy /= len; dz /= len; }
                     ray_setup(r, cam.ox, cam.oy, cam.oz, dx, dy, dz);
                     trav_begin(s, r, sc);
+                    const OwnBound ob = own_bound(r, sc, it);
+                    apply_own_bound<0>(s, ob);
+                    bounded = ob.known & ob.hit;
                     item = it;
                     busy = true;
                     ++my_rays;
@@ -760,8 +820,8 @@ __global__ void __launch_bounds__(kBlock)
                 ray_setup(r, cam.ox, cam.oy, cam.oz, qx - cam.ox, qy - cam.oy, qz - cam.oz);
                 trav_begin(s, r, sc);
                 item = it;
-                busy = true;
                 ++my_rays;
+                busy = apply_own_bound<1>(s, own_bound(r, sc, node));   // false: cannot see it
             }
             if (__ballot(!busy) == 0ull || !queue_has_more(q)) break;
         }
@@ -769,6 +829,13 @@ __global__ void __launch_bounds__(kBlock)
 
         if (busy) {
             trav_run<false, STATS>(s, r, sc, stack, top_lds, queue_has_more(q), sc.refill);
+            if (PHASE == 0 && s.cur == kDone && bounded && !s.any) {
+                // An own triangle is hit when tested directly but was not reached through the
+                // boxes, and nothing nearer exists: whether the ray hits ANYTHING (retries or
+                // no entry, :261) is decided beyond the bound -> classic unbounded traversal.
+                bounded = false;
+                trav_begin(s, r, sc);
+            }
             if (s.cur == kDone) {
                 busy = false;
                 const unsigned node = PHASE == 0 ? item : retry_nodes[item / 6u];
@@ -950,6 +1017,7 @@ Scene make_scene(const upsp_bvh *b, size_t items, int grid)
     sc.stack_ints = stack_entries(b) * kBlock;
     static const int refill = env_int("UPSP_REFILL", kRefillDefault);
     sc.refill = refill;
+    sc.adj_off = sc.adj_slot = nullptr;
     for (int a = 0; a < 3; ++a) {
         sc.rlo[a] = b->root_min[a];
         sc.rhi[a] = b->root_max[a];
@@ -1209,6 +1277,8 @@ int upsp_bvh_create(const float *h_tris9, size_t ntris, upsp_bvh **out)
     }
     b->root_ref = hb.root_ref;
     b->top_nodes = hb.top_nodes;
+    b->prim_slot.assign(ntris, 0u);
+    for (size_t sl = 0; sl < hb.tris.size(); ++sl) b->prim_slot[(size_t)hb.tris[sl].prim] = (uint32_t)sl;
     std::memset(&b->info, 0, sizeof(b->info));
     for (int a = 0; a < 3; ++a) {
         b->root_min[a] = b->info.bounds_min[a] = hb.root_min[a];
@@ -1234,6 +1304,8 @@ void upsp_bvh_destroy(upsp_bvh *b)
     if (b->d_work) (void)hipFree(b->d_work);
     if (b->d_retry_nodes) (void)hipFree(b->d_retry_nodes);
     if (b->d_retry_mask) (void)hipFree(b->d_retry_mask);
+    if (b->d_adj_off) (void)hipFree(b->d_adj_off);
+    if (b->d_adj_slot) (void)hipFree(b->d_adj_slot);
     if (b->d_stage) (void)hipFree(b->d_stage);
     if (b->h_stage) (void)hipHostFree(b->h_stage);
     if (b->stage_stream) (void)hipStreamDestroy(b->stage_stream);
@@ -1244,6 +1316,43 @@ int upsp_bvh_get_info(const upsp_bvh *b, upsp_bvh_info *info)
 {
     if (!b || !info) return fail(UPSP_ERR_INVALID, "null argument");
     *info = b->info;
+    return UPSP_OK;
+}
+
+int upsp_bvh_set_tri_nodes(upsp_bvh *b, const int32_t *d_tri_nodes, size_t nnodes, void *stream)
+{
+    if (!b) return fail(UPSP_ERR_INVALID, "null BVH");
+    if (b->d_adj_off) (void)hipFree(b->d_adj_off);
+    if (b->d_adj_slot) (void)hipFree(b->d_adj_slot);
+    b->d_adj_off = b->d_adj_slot = nullptr;
+    b->adj_src = nullptr;
+    b->adj_nnodes = 0;
+    if (!d_tri_nodes || nnodes == 0) return UPSP_OK;          // cleared
+    const size_t ntris = b->info.ntris;
+    if (nnodes >= 0xFFFFFFF0ull) return fail(UPSP_ERR_INVALID, "too many nodes");
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<int32_t> tn(3 * ntris);
+    UPSP_HIP_CHECK(hipMemcpyAsync(tn.data(), d_tri_nodes, tn.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    UPSP_HIP_CHECK(hipStreamSynchronize(st));
+    std::vector<uint32_t> off(nnodes + 1, 0u), slot(3 * ntris);
+    for (size_t i = 0; i < tn.size(); ++i) {
+        if (tn[i] < 0 || (size_t)tn[i] >= nnodes) return fail(UPSP_ERR_INVALID, "triangle node index out of range");
+        ++off[(size_t)tn[i] + 1];
+    }
+    for (size_t n = 0; n < nnodes; ++n) off[n + 1] += off[n];
+    std::vector<uint32_t> fill(off.begin(), off.end() - 1);
+    for (size_t t = 0; t < ntris; ++t)
+        for (int k = 0; k < 3; ++k) {
+            const size_t n = (size_t)tn[3 * t + k];
+            // a degenerate triangle listing the node twice is entered twice: harmless (min / max)
+            slot[fill[n]++] = b->prim_slot[t];
+        }
+    UPSP_HIP_CHECK(hipMalloc(&b->d_adj_off, off.size() * sizeof(uint32_t)));
+    UPSP_HIP_CHECK(hipMalloc(&b->d_adj_slot, std::max<size_t>(slot.size(), 1) * sizeof(uint32_t)));
+    UPSP_HIP_CHECK(hipMemcpy(b->d_adj_off, off.data(), off.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    UPSP_HIP_CHECK(hipMemcpy(b->d_adj_slot, slot.data(), slot.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    b->adj_src = d_tri_nodes;
+    b->adj_nnodes = nnodes;
     return UPSP_OK;
 }
 
@@ -1367,11 +1476,25 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
     }
     UPSP_HIP_CHECK(hipMemsetAsync(b->d_work, 0, 16 * sizeof(unsigned), st));
     const int grid = grid_for(nnodes, lds);
-    const Scene sc = make_scene(b, nnodes, grid);
+    Scene sc = make_scene(b, nnodes, grid);
     // step 3 runs over 6 x (listed nodes), a count only the device knows: full
     // persistent grid, chunk sized for the typical case (half of the nodes listed)
     const int grid1 = grid_for(6 * nnodes, lds);
-    const Scene sc1 = make_scene(b, 3 * nnodes, grid1);
+    Scene sc1 = make_scene(b, 3 * nnodes, grid1);
+    static const bool own_bound_on = std::getenv("UPSP_NO_OWN_BOUND") == nullptr;
+    if (own_bound_on && b->d_adj_off && b->adj_src == (const void *)d_tri_nodes && b->adj_nnodes == nnodes) {
+        // bounded visibility rays (own_bound) for the retry pass only: measured on MI355X the
+        // primary rays gain nothing (the near-first traversal finds the front surface at once
+        // and prunes behind it; 0.44 -> 0.47 ms with the extra own-triangle tests), the retries
+        // lose the rays that miss every own triangle and exit early: 0.70 -> 0.59 ms
+        static const bool bound_primary = std::getenv("UPSP_OWN_BOUND_PRIMARY") != nullptr;
+        sc1.adj_off = b->d_adj_off;
+        sc1.adj_slot = b->d_adj_slot;
+        if (bound_primary) {
+            sc.adj_off = b->d_adj_off;
+            sc.adj_slot = b->d_adj_slot;
+        }
+    }
     const dim3 egrid((unsigned)((nnodes + 255) / 256)), eblock(256);
     if (nnodes >= 65536) prefetch_bvh(b, st);
     {

@@ -72,6 +72,11 @@ struct upsp_bvh {
     upsp::GpuTri *d_tris = nullptr;
     uint32_t *d_work = nullptr;   // [0] work-queue head, [2..7] 64-bit stats, [8..10] see raycast.hip
     uint32_t *d_retry_nodes = nullptr, *d_retry_mask = nullptr;  // projection-build retry list
+    std::vector<uint32_t> prim_slot;   // host: triangle slot (leaf order) of every input triangle
+    // node -> adjacent triangle slots (CSR), set by upsp_bvh_set_tri_nodes (bounded visibility rays)
+    uint32_t *d_adj_off = nullptr, *d_adj_slot = nullptr;
+    const void *adj_src = nullptr;     // the d_tri_nodes buffer the adjacency was built from
+    size_t adj_nnodes = 0;
     size_t retry_capacity = 0;
     void *d_stage = nullptr, *h_stage = nullptr;  // small host batches (pybind per-ray calls)
     struct ihipStream_t *stage_stream = nullptr;

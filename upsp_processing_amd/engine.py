@@ -64,6 +64,13 @@ class BVH:
                     build_seconds=i.build_seconds, bounds_min=list(i.bounds_min),
                     bounds_max=list(i.bounds_max))
 
+    def set_tri_nodes(self, tri_nodes, nnodes):
+        """Triangle -> node ids of createBVH(model, triNodes) (psp_process.cpp:44-53): device int32
+        tensor [3T].  Speeds up build_projection calls that pass the SAME tensor."""
+        assert tri_nodes.is_cuda and tri_nodes.dtype == torch.int32 and tri_nodes.is_contiguous()
+        check(lib().upsp_bvh_set_tri_nodes(self._h, _ptr(tri_nodes), int(nnodes), _stream()))
+        self._tri_nodes = tri_nodes       # keep the buffer (and its address) alive
+
     def enable_stats(self, on=True):
         check(lib().upsp_bvh_enable_stats(self._h, int(bool(on))))
 

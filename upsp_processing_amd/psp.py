@@ -39,6 +39,7 @@ class Phase1:
         self.d_nodes = torch.as_tensor(np.ascontiguousarray(nodes, np.float32)).cuda()
         self.d_normals = torch.as_tensor(np.ascontiguousarray(normals, np.float32)).cuda()
         self.d_tri_nodes = torch.as_tensor(np.ascontiguousarray(tri_nodes, np.int32)).cuda()
+        self.bvh.set_tri_nodes(self.d_tri_nodes, self.nnodes)        # createBVH(model, triNodes)
         self.cams = [_capi.make_camera(c["K"], c["dist"], c["R"], c["t"], self.width, self.height)
                      for c in cameras]
         self.centers = np.array([engine.camera_center(c) for c in self.cams])
