@@ -74,6 +74,7 @@ struct Ray {
     float absSz;          // |Sz|
     bool prune_ok;        // major axis of d and of l agree in sign -> depth pruning valid
     bool exact_only;      // some |l| is tiny / not finite: skip the reciprocal filter
+    bool simple;          // no special case of the box test can occur inside this scene (ray_classify)
 };
 
 __device__ __forceinline__ float pick(float x, float y, float z, int k)
@@ -138,6 +139,7 @@ __device__ __forceinline__ void ray_setup(Ray &r, float ox, float oy, float oz, 
                    (lz != 0.0f && r.mlz < tiny) || !(len == len) || len == 0.0f;
     const float lkz = pick(lx, ly, lz, kz);
     r.prune_ok = lkz != 0.0f && ((lkz < 0.0f) == (dkz < 0.0f));
+    r.simple = false;
 }
 
 // One axis of the library test in mirrored form (line direction >= 0).  All
@@ -197,6 +199,34 @@ __device__ __forceinline__ BoxEval box_filter(const Ray &r, float lox, float loy
     BoxEval b;
     b.accept = inside | (!out & sure_acc);
     b.undecided = !inside & !out & ((!sure_acc & !sure_rej) | r.exact_only);
+    return b;
+}
+
+// The same filtered decision for rays of the "simple" class (ray_classify): the line moves
+// along all three axes and the library's overflow guards (d < FLT_MAX * |l|) hold for every
+// box inside the scene bounds, so okB = okF = true, front = (dF >= 0), out = (some dB < 0),
+// and the sequential min / max updates collapse into min3 / max3.  Same values, fewer VALU ops.
+__device__ __forceinline__ BoxEval box_filter_simple(const Ray &r, float lox, float loy, float loz,
+                                                     float hix, float hiy, float hiz, float &dFk)
+{
+    const bool fx_ = r.flip & 1u, fy_ = r.flip & 2u, fz_ = r.flip & 4u;
+    const float dBx = (fx_ ? -lox : hix) - r.mox, dFx = (fx_ ? -hix : lox) - r.mox;
+    const float dBy = (fy_ ? -loy : hiy) - r.moy, dFy = (fy_ ? -hiy : loy) - r.moy;
+    const float dBz = (fz_ ? -loz : hiz) - r.moz, dFz = (fz_ ? -hiz : loz) - r.moz;
+    dFk = pick(dFx, dFy, dFz, r.kz);
+    const bool out = fminf(fminf(dBx, dBy), dBz) < 0.0f;
+    const bool inside = !out & !(fmaxf(fmaxf(dFx, dFy), dFz) > 0.0f);
+    const float tBack = fminf(FLT_MAX, fminf(fminf(dBx * r.ilx, dBy * r.ily), dBz * r.ilz));
+    const float fx = dFx >= 0.0f ? dFx * r.ilx : -1.0f;
+    const float fy = dFy >= 0.0f ? dFy * r.ily : -1.0f;
+    const float fz = dFz >= 0.0f ? dFz * r.ilz : -1.0f;
+    const float tFront = fmaxf(fmaxf(fx, fy), fmaxf(fz, -1.0f));
+    const float e = 6e-7f;
+    const bool sure_acc = tFront + fabsf(tFront) * e <= tBack - tBack * e;
+    const bool sure_rej = tFront - fabsf(tFront) * e > tBack + tBack * e;
+    BoxEval b;
+    b.accept = inside | (!out & sure_acc);
+    b.undecided = !inside & !out & !sure_acc & !sure_rej;
     return b;
 }
 
@@ -328,6 +358,19 @@ __device__ __forceinline__ void trav_begin(Trav &s, const Ray &r, const Scene &s
                 : kDone;
 }
 
+// Marks the ray "simple" when no special case of the library's box test can occur for any box
+// inside the scene bounds: all three line components non-zero, reciprocal filter usable, and
+// every overflow guard `d < FLT_MAX * |l|` satisfied because |d| <= D = the largest distance
+// along an axis between the origin and the scene bounds.
+__device__ __forceinline__ void ray_classify(Ray &r, const Scene &sc)
+{
+    const float D = fmaxf(fmaxf(fmaxf(fabsf(sc.rlo[0] - r.ox), fabsf(sc.rhi[0] - r.ox)),
+                                fmaxf(fabsf(sc.rlo[1] - r.oy), fabsf(sc.rhi[1] - r.oy))),
+                          fmaxf(fabsf(sc.rlo[2] - r.oz), fabsf(sc.rhi[2] - r.oz)));
+    const float lim = fminf(fminf(r.limx, r.limy), r.limz);
+    r.simple = (r.zero == 0u) & !r.exact_only & (D < lim) & (D == D) & (D < 1e30f);
+}
+
 __device__ __forceinline__ void trav_pop(Trav &s, const int *stack)
 {
     if (s.sp == 0) {
@@ -358,8 +401,14 @@ __device__ __forceinline__ void node_step(Trav &s, const Ray &r, const Scene &sc
     const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
     const unsigned meta = __float_as_uint(q3.z);
     float dFl, dFr;
-    const BoxEval bl = box_filter(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, dFl);
-    const BoxEval br = box_filter(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, dFr);
+    BoxEval bl, br;
+    if (__ballot(!r.simple) == 0ull) {   // wave-uniform: every lane holds a simple-class ray
+        bl = box_filter_simple(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, dFl);
+        br = box_filter_simple(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, dFr);
+    } else {
+        bl = box_filter(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, dFl);
+        br = box_filter(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, dFr);
+    }
     bool hL = bl.accept, hR = br.accept;
     if (__ballot(bl.undecided | br.undecided) != 0ull) {  // rare: grazing contact
         if (bl.undecided) hL = box_exact(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
@@ -592,6 +641,7 @@ __global__ void __launch_bounds__(kBlock)
     WaveQueue q;
     queue_init(q, work, n, sc.chunk);
     Ray r;
+    r.simple = true;   // idle lanes must not veto the wave-uniform fast path
     Trav s;
     s.cur = kDone;
     s.n_nodes = s.n_tris = 0;
@@ -608,6 +658,7 @@ __global__ void __launch_bounds__(kBlock)
                 const float *o = org + (size_t)org_stride * it;
                 const float *d = dir + 3 * (size_t)it;
                 ray_setup(r, o[0], o[1], o[2], d[0], d[1], d[2]);
+                ray_classify(r, sc);
                 trav_begin(s, r, sc);
                 busy = true;
                 ++my_rays;
@@ -782,6 +833,7 @@ __global__ void __launch_bounds__(kBlock)
     WaveQueue q;
     queue_init(q, work, total, sc.chunk);
     Ray r;
+    r.simple = true;   // idle lanes must not veto the wave-uniform fast path
     Trav s;
     s.cur = kDone;
     s.n_nodes = s.n_tris = 0;
@@ -799,6 +851,7 @@ __global__ void __launch_bounds__(kBlock)
                     const float len = imath_length(dx, dy, dz);  // .normalize() :256
                     if (len != 0.0f) { dx /= len; dy /= len; dz /= len; }
                     ray_setup(r, cam.ox, cam.oy, cam.oz, dx, dy, dz);
+                    ray_classify(r, sc);
                     trav_begin(s, r, sc);
                     const OwnBound ob = own_bound(r, sc, it);
                     apply_own_bound<0>(s, ob);
@@ -818,6 +871,7 @@ __global__ void __launch_bounds__(kBlock)
                 const float qy = nodes[3 * (size_t)node + 1] + ((k >> 1) == 1 ? sgn : 0.0f);
                 const float qz = nodes[3 * (size_t)node + 2] + ((k >> 1) == 2 ? sgn : 0.0f);
                 ray_setup(r, cam.ox, cam.oy, cam.oz, qx - cam.ox, qy - cam.oy, qz - cam.oz);
+                ray_classify(r, sc);
                 trav_begin(s, r, sc);
                 item = it;
                 ++my_rays;
