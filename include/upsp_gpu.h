@@ -202,6 +202,12 @@ int upsp_pipeline_set_projection(upsp_pipeline *p, int cam, const int32_t *d_pix
 /* Nodes set to NaN in every row (psp_process.cpp:1822-1825); NULL = derive from
  * the projections with identify_skipped_nodes. */
 int upsp_pipeline_set_skipped(upsp_pipeline *p, const uint8_t *d_skipped);
+
+/* P3D zone overlaps: model.adjust_solution(sol) (cpp/lib/P3DModel.ipp:143-157) runs on every frame
+ * AFTER the accumulators took the node's own value and BEFORE the row is stored
+ * (cpp/exec/psp_process.cpp:1827-1839).  d_src [nnodes] int32: src[n] = node whose value node n
+ * holds after the copy loop (n itself for ordinary nodes).  NULL switches it off. */
+int upsp_pipeline_set_overlap_source(upsp_pipeline *pipe, const int32_t *d_src);
 /* ECC template of camera `cam` = first frame as f32 (elems.first_frames[c],
  * psp_process.cpp:2057-2058). */
 int upsp_pipeline_set_reference(upsp_pipeline *p, int cam, const float *d_ref32f);

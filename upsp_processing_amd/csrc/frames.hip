@@ -159,6 +159,7 @@ struct GatherArgs {
     int ncams;
     size_t npix;
     int dbg;
+    const int32_t *src;            // overlap source map or null
 };
 
 template <int NCAMS>
@@ -200,6 +201,25 @@ __global__ void __launch_bounds__(256)
     }
     sum[n] += s;
     sumsq[n] += ss;
+    if (a.src && rows && (unsigned)a.src[n] != n) {   // adjust_solution: stored value = source node's
+        const unsigned ns = (unsigned)a.src[n];
+        const bool skip2 = skipped && skipped[ns];
+        for (int f = 0; f < nframes; ++f) {
+            float sol = 0.0f;
+            for (int c = 0; c < nc; ++c) {
+                const int32_t p2 = a.pix[c][ns];
+                float v = 0.0f;
+                if (p2 >= 0) {
+                    const size_t off = (size_t)f * a.npix + (size_t)p2;
+                    const float pxv = a.is_f32[c] ? reinterpret_cast<const float *>(a.img[c])[off]
+                                                  : (float)reinterpret_cast<const uint16_t *>(a.img[c])[off];
+                    v = 0.0f + (a.weight[c] ? a.weight[c][ns] : 1.0f) * pxv;
+                }
+                sol = (c == 0) ? v : sol + v;
+            }
+            rows[(size_t)f * nnodes + n] = skip2 ? qnan : sol;
+        }
+    }
 }
 
 // Fused gather + accumulate + transpose for a sub-batch of <= 64 frames.
@@ -208,7 +228,7 @@ __global__ void __launch_bounds__(256)
 // tile is written node-major (256-byte rows of the [N x F] time series =
 // intensity_transpose layout, psp_process.cpp:2027-2032) and, if requested,
 // frame-major (intensity_buf rows) -- both fully coalesced, no second pass over HBM.
-template <int NCAMS, bool kStreamStores>
+template <int NCAMS, bool kStreamStores, bool kHasSrc>
 __global__ void __launch_bounds__(256)
     gather_tile_kernel(GatherArgs a, const uint8_t *__restrict__ skipped, unsigned nnodes,
                        int nframes, float *__restrict__ rows, float *__restrict__ rows_t,
@@ -230,6 +250,10 @@ __global__ void __launch_bounds__(256)
     const bool skip = live && skipped && skipped[n];
     const float qnan = __builtin_nanf("");
     double s = 0.0, ss = 0.0;
+    // P3D zone overlaps (adjust_solution, psp_process.cpp:1833-1835): the accumulators take the
+    // node's own value, the stored series the value of its source node.  Rare (zone edges).
+    const unsigned ns = (kHasSrc && live) ? (unsigned)a.src[n] : n;
+    const bool alt = kHasSrc && ns != n;
     // 16 frames per lane (f = wave, wave+4, ...): issue every gather before using any
     float sol[16];
 #pragma unroll
@@ -258,6 +282,26 @@ __global__ void __launch_bounds__(256)
             s += (double)sol[i];
             ss += (double)(sol[i] * sol[i]);
             tile[f][lane] = sol[i];
+        }
+    }
+    if (alt) {   // overwrite the tile column with the source node's solution
+        const bool skip2 = skipped && skipped[ns];
+        for (int i = 0; i < 16; ++i) {
+            const int f = wave + 4 * i;
+            if (f >= nframes) break;
+            float acc = 0.0f;
+            for (int c = 0; c < nc; ++c) {
+                const int32_t p2 = a.pix[c][ns];
+                float v = 0.0f;
+                if (p2 >= 0) {
+                    const size_t off = (size_t)f * a.npix + (size_t)p2;
+                    const float pxv = a.is_f32[c] ? reinterpret_cast<const float *>(a.img[c])[off]
+                                                  : (float)reinterpret_cast<const uint16_t *>(a.img[c])[off];
+                    v = 0.0f + (a.weight[c] ? a.weight[c][ns] : 1.0f) * pxv;
+                }
+                acc = (c == 0) ? v : acc + v;
+            }
+            tile[f][lane] = skip2 ? qnan : acc;
         }
     }
     part[0][wave][lane] = s;
@@ -471,6 +515,7 @@ int launch_gather(const PipelineGather &g, hipStream_t st)
     std::memset(&a, 0, sizeof(a));
     a.ncams = g.ncams;
     a.npix = g.npix;
+    a.src = g.src;
     static const int dbg = std::getenv("UPSP_GATHER_DBG") ? std::atoi(std::getenv("UPSP_GATHER_DBG")) : 0;
     a.dbg = dbg;
     for (int c = 0; c < g.ncams; ++c) {
@@ -482,16 +527,14 @@ int launch_gather(const PipelineGather &g, hipStream_t st)
     if (g.nframes <= 64) {
         KTimed kt("gather_tile_kernel", st);
         const dim3 tgrid((unsigned)((g.nnodes + 63) / 64)), tblock(256);
+#define UPSP_TILE2(NC, SS, HS)                                                                 \
+    hipLaunchKernelGGL((gather_tile_kernel<NC, SS, HS>), tgrid, tblock, 0, st, a, g.skipped,   \
+                       (unsigned)g.nnodes, g.nframes, g.rows, g.rows_t, (long long)g.ld_t,     \
+                       g.sum, g.sumsq)
 #define UPSP_TILE(NC)                                                                          \
     do {                                                                                       \
-        if (stream_stores)                                                                     \
-            hipLaunchKernelGGL((gather_tile_kernel<NC, true>), tgrid, tblock, 0, st, a,        \
-                               g.skipped, (unsigned)g.nnodes, g.nframes, g.rows, g.rows_t,     \
-                               (long long)g.ld_t, g.sum, g.sumsq);                             \
-        else                                                                                   \
-            hipLaunchKernelGGL((gather_tile_kernel<NC, false>), tgrid, tblock, 0, st, a,       \
-                               g.skipped, (unsigned)g.nnodes, g.nframes, g.rows, g.rows_t,     \
-                               (long long)g.ld_t, g.sum, g.sumsq);                             \
+        if (g.src) { if (stream_stores) UPSP_TILE2(NC, true, true); else UPSP_TILE2(NC, false, true); } \
+        else { if (stream_stores) UPSP_TILE2(NC, true, false); else UPSP_TILE2(NC, false, false); }     \
     } while (0)
         static const bool stream_stores = std::getenv("UPSP_NO_STREAM_STORES") == nullptr;
         switch (g.ncams) {  // per-camera pix / weight stay in registers for 1..4 cameras
@@ -502,6 +545,7 @@ int launch_gather(const PipelineGather &g, hipStream_t st)
             default: UPSP_TILE(0); break;
         }
 #undef UPSP_TILE
+#undef UPSP_TILE2
         UPSP_HIP_CHECK(hipGetLastError());
         return UPSP_OK;
     }

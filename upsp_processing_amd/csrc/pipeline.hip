@@ -26,6 +26,7 @@ struct upsp_pipeline {
     float *d_weight[kMaxCams] = {nullptr};
     bool has_proj[kMaxCams] = {false};
     uint8_t *d_skipped = nullptr;
+    int32_t *d_src = nullptr;        // overlap source map (P3D adjust_solution), optional
     bool skipped_user = false, skipped_valid = false;
     double *d_sum = nullptr, *d_sumsq = nullptr;
     // hot-pixel scratch (per frame of a sub-batch)
@@ -144,6 +145,7 @@ void upsp_pipeline_destroy(upsp_pipeline *p)
     for (hipEvent_t e : {p->ev_in, p->ev_fix[0], p->ev_fix[1], p->ev_out})
         if (e) (void)hipEventDestroy(e);
     free_dev(p->d_skipped);
+    free_dev(p->d_src);
     free_dev(p->d_sum);
     free_dev(p->d_sumsq);
     free_dev(p->d_hot_count);
@@ -182,6 +184,19 @@ int upsp_pipeline_set_skipped(upsp_pipeline *p, const uint8_t *d_skipped)
         p->skipped_user = false;
         p->skipped_valid = false;
     }
+    return UPSP_OK;
+}
+
+int upsp_pipeline_set_overlap_source(upsp_pipeline *p, const int32_t *d_src)
+{
+    if (!p) return fail(UPSP_ERR_INVALID, "null pipeline");
+    if (!d_src) {
+        if (p->d_src) (void)hipFree(p->d_src);
+        p->d_src = nullptr;
+        return UPSP_OK;
+    }
+    if (!p->d_src) UPSP_HIP_CHECK(hipMalloc(&p->d_src, sizeof(int32_t) * std::max<size_t>(p->nnodes, 1)));
+    UPSP_HIP_CHECK(hipMemcpy(p->d_src, d_src, sizeof(int32_t) * p->nnodes, hipMemcpyDeviceToDevice));
     return UPSP_OK;
 }
 
@@ -289,6 +304,7 @@ int upsp_pipeline_process(upsp_pipeline *p, const uint16_t *const *d_frames, int
         g.nnodes = p->nnodes;
         g.nframes = nb;
         g.skipped = p->d_skipped;
+        g.src = p->d_src;
         g.sum = p->d_sum;
         g.sumsq = p->d_sumsq;
         g.rows = d_rows ? d_rows + (size_t)f0 * p->nnodes : nullptr;

@@ -280,6 +280,11 @@ class FramePipeline:
         sk = None if skipped is None else _dev(skipped, torch.uint8)
         check(lib().upsp_pipeline_set_skipped(self._h, _ptr(sk)))
 
+    def set_overlap_source(self, src):
+        """P3D adjust_solution: src int32 [N] (grids.P3DModel.overlap_source()); None = off."""
+        self._src = None if src is None else _dev(src, torch.int32)
+        check(lib().upsp_pipeline_set_overlap_source(self._h, _ptr(self._src)))
+
     def set_reference(self, cam, ref32f):
         ref = _dev(ref32f, torch.float32)
         assert ref.numel() == self.width * self.height

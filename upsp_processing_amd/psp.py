@@ -26,12 +26,15 @@ class Phase1:
     def __init__(self, tris9, tri_nodes, nodes, normals, cameras, image_size, oblique_angle=70.0,
                  overlap="average_view", datanode=None, registration=False, interp=1,
                  filter=None, filter_size=1, patches=None, nframes_total=None, targets=None,
-                 first_frames=None, bit_depth=12, bound_pts=2, buffer_pts=1, target_diam_sf=1.2):
+                 first_frames=None, bit_depth=12, bound_pts=2, buffer_pts=1, target_diam_sf=1.2,
+                 overlap_src=None):
         """cameras: list of dict(K, dist, R, t); image_size = (width, height).
 
         patches: per camera list of dict(bx, by, ix, iy) (PatchClusters tables), or give
         `targets` (one target file per camera) + `first_frames` (raw u16 [H,W] frame 1 per
-        camera) to run the phase-0 set-up here (InitializeImagePatches, :2088-2182)."""
+        camera) to run the phase-0 set-up here (InitializeImagePatches, :2088-2182).
+        overlap_src: int32 [N] source map of a structured (PLOT3D) model's zone overlaps
+        (grids.P3DModel.overlap_source(); model.adjust_solution, :1833-1835, :1938-1940, :1975-1977)."""
         self.width, self.height = image_size
         self.ncams = len(cameras)
         self.nnodes = int(np.asarray(nodes).reshape(-1, 3).shape[0])
@@ -80,6 +83,10 @@ class Phase1:
             if patches is not None:
                 self.pipe.set_patches(c, patches[c])
         self.pipe.set_skipped(self.skipped)
+        self.overlap_src = None
+        if overlap_src is not None:
+            self.overlap_src = torch.as_tensor(np.ascontiguousarray(overlap_src, np.int32)).cuda()
+            self.pipe.set_overlap_source(self.overlap_src)
         self.registration = bool(registration)
         self._patches = patches
         self.sol1 = None
@@ -109,6 +116,8 @@ class Phase1:
             if self._patches is not None:
                 tmp.set_patches(c, self._patches[c])
         tmp.set_skipped(self.skipped)
+        if self.overlap_src is not None:
+            tmp.set_overlap_source(self.overlap_src)                  # model.adjust_solution(sol1), :1713
         frames = fixed
         self.sol1 = tmp.process(frames, first_frame=1)[0].clone()
         tmp.close()
@@ -128,6 +137,9 @@ class Phase1:
         s, ss = self.pipe.accumulators()
         D.allreduce_sums(s, ss)                                        # MPI_Reduce + MPI_Bcast
         avg, rms = self.pipe.finalize(nframes_total)
+        if self.overlap_src is not None:                               # :1937-1940
+            idx = self.overlap_src.long()
+            avg, rms = avg[idx], rms[idx]
         out = dict(avg=avg, rms=rms)
         if self.sol1 is not None:
             out["ratio_0"] = avg / self.sol1 - 1.0                     # :1948-1950
@@ -138,6 +150,8 @@ class Phase1:
             w = None if self.weight is None else self.weight[c].contiguous()
             ind = engine.project_frame(ones, self.pix[c].contiguous(), w)
             cov = ind if cov is None else cov + ind
+        if self.overlap_src is not None:                               # :1975-1977
+            cov = cov[self.overlap_src.long()]
         out["coverage"] = cov
         return out
 

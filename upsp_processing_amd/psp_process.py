@@ -8,7 +8,8 @@ cpp/exec/psp_process.cpp:1193-1218) and its input deck (`@general / @vars / @all
 @options / @output` with `$var` substitution, docs/sphinx/file-formats.rst:239-470,
 cpp/lib/upsp_inputs.cpp) for the part of the pipeline this repository implements:
 
-* grid: Cart3D `.tri` (cpp/lib/TriModel.ipp:117-257)        [PLOT3D grids: not built]
+* grid: Cart3D `.tri` (cpp/lib/TriModel.ipp:117-257) or PLOT3D surface grid `.p3d/.g/.x/.grid/.grd`
+  (cpp/lib/plot3d.cpp, cpp/lib/P3DModel.ipp; zone overlaps within 1e-3, psp_process.cpp:1378)
 * camera calibration JSON (cpp/lib/CameraCal.cpp:19-54)
 * video: 12-bit Photron `.mraw` (cpp/lib/MrawReader.cpp)      [`.cine`: not built]
 * options: registration = none|pixel, filter = none|gaussian|box (+ filter_size),
@@ -165,14 +166,23 @@ def main(argv=None):
     deck = parse_input_deck(flags["input_file"])
     opts = deck["options"]
     grid = deck["all"].get("grid")
-    if not grid or not grid.endswith(".tri"):
-        raise DeckError("only Cart3D .tri grids are supported (got %r)" % grid)
-    xyz, tris, _ = read_tri_grid(grid)
+    ext = (grid or "").rsplit(".", 1)[-1]
+    overlap_src = None
+    if ext == "tri":                                   # GridType::Tri (upsp_inputs.cpp:438-444)
+        xyz, tris, _ = read_tri_grid(grid)
+        normals = synthetic.node_normals(xyz, tris)    # TriModel_::calcNormals
+        s9, tri_nodes = synthetic.soup(xyz, tris)      # TriModel_::extract_tris
+    elif ext in ("p3d", "g", "x", "grid", "grd"):      # GridType::P3D
+        from . import grids
+        model = grids.P3DModel.from_file(grid, 1e-3)   # psp_process.cpp:1378
+        xyz, normals = model.nodes(), model.normals
+        s9, tri_nodes = model.extract_tris()
+        overlap_src = model.overlap_source()
+    else:
+        raise DeckError("grid must be a Cart3D .tri or a PLOT3D .p3d/.g/.x/.grid/.grd file (got %r)" % grid)
     datanode = None
     if "cutoff_x_max" in flags:                       # psp_process.cpp:1448-1487
         datanode = (xyz[:, 0] <= float(flags["cutoff_x_max"])).astype(np.uint8)
-    normals = synthetic.node_normals(xyz, tris)       # TriModel_::calcNormals
-    s9, tri_nodes = synthetic.soup(xyz, tris)         # TriModel_::extract_tris
     cams, readers = [], []
     for c in deck["camera"]:
         cal = read_camera_json(c["calibration"])
@@ -202,7 +212,7 @@ def main(argv=None):
                      oblique_angle=float(opts["oblique_angle"]), overlap=opts["overlap"],
                      datanode=datanode, registration=opts["registration"] == "pixel",
                      filter=None if opts["filter"] == "none" else opts["filter"],
-                     filter_size=int(opts["filter_size"]), **patch_kw)
+                     filter_size=int(opts["filter_size"]), overlap_src=overlap_src, **patch_kw)
     if job.visible_targets is not None and (not D.dist.is_initialized() or D.dist.get_rank() == 0):
         for c, vis in enumerate(job.visible_targets):
             print("camera %d: %d visible targets patched" % (c + 1, len(vis)))
