@@ -86,3 +86,41 @@ def test_cli_plot3d_grid(gpu_lib, tmp_path):
     avg = np.fromfile(os.path.join(tmp, "out", "intensity_avg"), "<f4")
     assert np.array_equal(avg[moved].view(np.int32), avg[src[moved]].view(np.int32))
     assert np.isfinite(series).any()
+
+
+def test_cli_plot3d_wind_on(gpu_lib, oracle, tmp_path):
+    """PLOT3D model + steady-state function file (wind-on): gain per node from
+    Pss = qbar * steady + ps (psp_process.cpp:2475-2476), float formula bit-exact."""
+    import struct
+    from upsp_processing_amd import grids, psp_process as cli
+    from test_cli import write_case
+    tmp = str(tmp_path)
+    write_case(tmp, nframes=16)
+    J, K = 20, 12
+    u, v = np.meshgrid(np.linspace(-4, 4, J), np.linspace(-2, 2, K))
+    g = dict(zones=[(J, K, 1)], x=u.ravel().astype(np.float32), y=v.ravel().astype(np.float32),
+             z=(0.2 * np.cos(0.5 * u)).ravel().astype(np.float32))
+    grids.write_plot3d_grid(os.path.join(tmp, "model.x"), g)
+    n = J * K
+    steady = (0.5 * np.sin(np.arange(n))).astype(np.float32)
+    with open(os.path.join(tmp, "steady.f"), "wb") as f:          # no record separators
+        f.write(struct.pack("<i", 1) + struct.pack("<iiii", J, K, 1, 1) + steady.tobytes())
+    deck = open(os.path.join(tmp, "run.inp")).read().replace("model.tri", "model.x")
+    deck = deck.replace("@all\n", "@all\n  sds = %s/run.wtd\n" % tmp)
+    open(os.path.join(tmp, "run.inp"), "w").write(deck)
+    open(os.path.join(tmp, "run.wtd"), "w").write("#  MACH TTF PS Q TCAVG\n0.85 95.0 1300.0 620.0 68.0\n")
+    open(os.path.join(tmp, "paint.cal"), "w").write("a = 0.9\nb = -0.002\nd = 0.0008\n")
+    assert cli.main(["-input_file=%s/run.inp" % tmp, "-h5_out=x", "-paint_cal=%s/paint.cal" % tmp,
+                     "-steady_p3d=%s/steady.f" % tmp]) == 0
+    out = os.path.join(tmp, "out")
+    cov = np.fromfile(os.path.join(out, "coverage"), "<f4")
+    gain = np.fromfile(os.path.join(out, "gain"), "<f4")
+    live = cov != 0
+    assert live.sum() > 20
+    want = np.array([oracle.paint_gain([0.9, -0.002, 0, 0.0008, 0, 0], 68.0, np.float32(np.float32(620.0) * s + np.float32(1300.0)))
+                     for s in steady], np.float32)
+    assert np.array_equal(gain[live], want[live])
+    assert np.array_equal(np.fromfile(os.path.join(out, "steady_state"), "<f4"), steady)
+    with pytest.raises(cli.DeckError):
+        cli.main(["-input_file=%s/run.inp" % tmp, "-h5_out=x", "-paint_cal=%s/paint.cal" % tmp,
+                  "-steady_p3d=%s/paint.cal" % tmp])

@@ -93,7 +93,7 @@ class Phase2:
         from . import distributed as D
         return {k: D.gather_node_vector(res[k], shard) for k in ("avg", "rms", "gain")}
 
-    def write_outputs(self, out_dir, res, finals, steady, nnodes, node_start=0):
+    def write_outputs(self, out_dir, res, finals, steady, nnodes, node_start=0, model_temp=None):
         """Flat files of phase 2 (:2548-2612): pressure_transpose (each rank at its byte offset),
         rms, avg, gain, steady_state (Cp > 3 -> NaN), model_temp, vv-cp-rms/avg.dat."""
         from .psp import Phase1
@@ -111,6 +111,7 @@ class Phase2:
             st = np.zeros(nnodes, np.float32) if steady is None else np.array(steady, np.float32)
             st[st > 3.0] = np.nan                                       # :2567-2571
             st.astype("<f4").tofile(os.path.join(out_dir, "steady_state"))
-            np.full(nnodes, self.model_temp, "<f4").tofile(os.path.join(out_dir, "model_temp"))
+            (np.full(nnodes, self.model_temp, "<f4") if model_temp is None
+             else np.asarray(model_temp, "<f4")).tofile(os.path.join(out_dir, "model_temp"))
             Phase1.dump_vv(os.path.join(out_dir, "vv-cp-rms.dat"), finals["rms"].cpu().numpy())
             Phase1.dump_vv(os.path.join(out_dir, "vv-cp-avg.dat"), finals["avg"].cpu().numpy())

@@ -22,9 +22,9 @@ intensity_ratio_0, coverage, camNN-uv, vv-int-*.dat; cpp/exec/psp_process.cpp:52
 
 Phase 2 (cpp/exec/psp_process.cpp:2260-2625) runs when `-paint_cal` names a readable file and
 the deck's @all section has `sds` (tunnel conditions): delta-Cp per node and frame ->
-pressure_transpose, rms, avg, gain, steady_state, model_temp, vv-cp-*.dat.  Wind-off only
-(no `-steady_p3d`): interpolating a structured steady-state solution onto an unstructured grid
-(upsp::interpolate, kd-tree) is not built.  The HDF5 container is out of scope; `-h5_out` is
+pressure_transpose, rms, avg, gain, steady_state, model_temp, vv-cp-*.dat.  `-steady_p3d` /
+`-model_temp_p3d` (PLOT3D function files) are read for PLOT3D model grids; interpolating a
+structured steady-state solution onto an unstructured grid (upsp::interpolate) is not built.  The HDF5 container is out of scope; `-h5_out` is
 accepted and ignored.
 """
 import json
@@ -241,14 +241,35 @@ def main(argv=None):
     paint_cal, sds = flags.get("paint_cal"), deck["all"].get("sds")
     if paint_cal and os.path.isfile(paint_cal) and sds:
         from . import phase2
-        if flags.get("steady_p3d"):
-            raise DeckError("-steady_p3d: interpolation of a steady-state solution onto a .tri grid "
-                            "is not built (wind-off processing only)")
+        steady = temp = None
+        if flags.get("steady_p3d") or flags.get("model_temp_p3d"):
+            # structured models read one scalar per grid point (psp_process.cpp:2327-2335, 2360-2368);
+            # unstructured ones would need upsp::interpolate from the steady grid: not built
+            if overlap_src is None:
+                raise DeckError("-steady_p3d / -model_temp_p3d need a PLOT3D model grid (interpolation onto "
+                                ".tri grids is not built)")
+            from . import grids
+            for key in ("steady_p3d", "model_temp_p3d"):
+                if flags.get(key):
+                    try:
+                        vals = grids.read_plot3d_scalar_function_file(flags[key])
+                    except (OSError, ValueError) as e:
+                        raise DeckError(str(e))
+                    if vals.size != job.nnodes:
+                        raise DeckError("%s inconsistent with grid (expect %d values, got %d)"
+                                        % (key, job.nnodes, vals.size))
+                    if key == "steady_p3d":
+                        steady = vals
+                    else:
+                        temp = vals
         p2 = phase2.Phase2(phase2.read_paint_calibration(paint_cal), phase2.read_tunnel_conditions(sds))
         n0, nn = shard.my_nodes
         res = p2.process(series, finals["avg"][n0:n0 + nn].contiguous(),
-                         finals["coverage"][n0:n0 + nn].contiguous(), in_place=True)
-        p2.write_outputs(out_dir, res, p2.gather_finals(res, shard), None, job.nnodes, node_start=n0)
+                         finals["coverage"][n0:n0 + nn].contiguous(),
+                         steady=None if steady is None else steady[n0:n0 + nn],
+                         model_temp=None if temp is None else temp[n0:n0 + nn], in_place=True)
+        p2.write_outputs(out_dir, res, p2.gather_finals(res, shard), steady, job.nnodes, node_start=n0,
+                         model_temp=temp)
         if shard.rank == 0:
             print("phase 2 complete: model temperature %.1f F, qbar %.2f" % (p2.model_temp, p2.tcond["qbar"]))
     job.close()
