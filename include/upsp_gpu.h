@@ -149,6 +149,12 @@ int upsp_projection_build(upsp_bvh *bvh, const upsp_camera *cam, const float *d_
 int upsp_projection_last_counts(const upsp_bvh *bvh, uint64_t *primary_rays,
                                 uint64_t *retry_nodes);
 
+/* upsp_projection_build with h_nrays == NULL does not wait for the device.  The counters of the
+ * most recent build stay in the BVH's work buffer; this call waits for `stream` and reads them
+ * (reference ray count, primary rays, nodes that went through the retries). */
+int upsp_projection_fetch_counts(upsp_bvh *bvh, uint64_t *nrays, uint64_t *primary_rays,
+                                 uint64_t *retry_nodes, void *stream);
+
 /* adjust_projection_for_weights with BestView (mode 0) / AverageViews (mode 1)
  * (cpp/lib/projection.ipp:911-1078, 227-268).  d_pix, d_weight: [ncams*nnodes];
  * d_weight is scaled in place (caller initialises it to 1).  h_centers: ncams*3

@@ -65,6 +65,7 @@ SIGNATURES = {
     "upsp_bvh_last_stats": (_i, [_vp, _u64p, _u64p, _u64p]),
     "upsp_projection_build": (_i, [_vp, C.POINTER(Camera), _vp, _vp, _vp, _vp, _sz, C.c_float,
                                    _vp, _vp, _vp, _u64p, _vp]),
+    "upsp_projection_fetch_counts": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "upsp_projection_last_counts": (_i, [_vp, _u64p, _u64p]),
     "upsp_projection_weights": (_i, [_i, _sz, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "upsp_projection_skipped": (_i, [_i, _sz, _vp, _vp, _u64p, _vp]),

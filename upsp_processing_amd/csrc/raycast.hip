@@ -1460,6 +1460,23 @@ int upsp_bvh_occluded_host(const upsp_bvh *bvh, const float *h_org, int org_stri
     return cast_host<true>(bvh, h_org, org_stride, h_dir, n, out);
 }
 
+int upsp_projection_fetch_counts(upsp_bvh *b, uint64_t *nrays, uint64_t *primary_rays,
+                                 uint64_t *retry_nodes, void *stream)
+{
+    if (!b) return fail(UPSP_ERR_INVALID, "null BVH");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = read_stats(b, st);
+    if (rc != UPSP_OK) return rc;
+    unsigned cnt[2] = {0, 0};
+    UPSP_HIP_CHECK(hipMemcpy(cnt, b->d_work + kWorkRetryCount, sizeof(cnt), hipMemcpyDeviceToHost));
+    b->last_retry_nodes = cnt[0];
+    b->last_primary = cnt[1];
+    if (nrays) *nrays = b->last_stats[2];
+    if (primary_rays) *primary_rays = b->last_primary;
+    if (retry_nodes) *retry_nodes = b->last_retry_nodes;
+    return UPSP_OK;
+}
+
 int upsp_projection_last_counts(const upsp_bvh *b, uint64_t *primary_rays, uint64_t *retry_nodes)
 {
     if (!b) return fail(UPSP_ERR_INVALID, "null BVH");

@@ -139,11 +139,21 @@ def project_points(cam, xyz):
     return uv
 
 
+def projection_counts(bvh):
+    """Counters of the most recent build_projection on this BVH (waits for the stream):
+    dict(nrays = the reference's ray count, primary_rays, retry_nodes)."""
+    a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+    check(lib().upsp_projection_fetch_counts(bvh.handle, C.byref(a), C.byref(b), C.byref(c), _stream()))
+    return dict(nrays=int(a.value), primary_rays=int(b.value), retry_nodes=int(c.value))
+
+
 def build_projection(bvh, cam, nodes, normals, tri_nodes, oblique_angle=70.0, datanode=None,
-                     nodecount=False):
+                     nodecount=False, counts=True):
     """create_projection_mat (psp_process.cpp:167-355) for one camera.
 
-    Returns dict(pix int32[N] (-1 = no entry), uv f32[2N], nrays, nodecount u8[H,W] | None)."""
+    Returns dict(pix int32[N] (-1 = no entry), uv f32[2N], nrays, nodecount u8[H,W] | None).
+    counts=False: no host synchronisation (the ray counters stay on the device; see
+    projection_counts)."""
     nodes = _dev(nodes, torch.float32).reshape(-1, 3)
     normals = _dev(normals, torch.float32).reshape(-1, 3)
     tri_nodes = _dev(tri_nodes, torch.int32).reshape(-1)
@@ -158,7 +168,9 @@ def build_projection(bvh, cam, nodes, normals, tri_nodes, oblique_angle=70.0, da
     check(lib().upsp_projection_build(bvh.handle, C.byref(cam), _ptr(nodes), _ptr(normals),
                                       _ptr(dn), _ptr(tri_nodes), n,
                                       C.c_float(oblique_threshold(oblique_angle)), _ptr(pix),
-                                      _ptr(uv), _ptr(cnt), C.byref(nrays), _stream()))
+                                      _ptr(uv), _ptr(cnt), C.byref(nrays) if counts else None, _stream()))
+    if not counts:
+        return dict(pix=pix, uv=uv, nodecount=cnt)
     pr, rn = C.c_uint64(0), C.c_uint64(0)
     check(lib().upsp_projection_last_counts(bvh.handle, C.byref(pr), C.byref(rn)))
     return dict(pix=pix, uv=uv, nrays=int(nrays.value), nodecount=cnt,
