@@ -179,12 +179,17 @@ def main():
             pipe.process(frames, first_frame=rank * F, rows_t=rows_t, want_rows=False)
         else:
             exch.k = 0
+            # rows of nodes no camera sees are NaN on every rank: they do not travel, and the gather
+            # writes the travelling rows packed (row map) straight into the send buffers
+            exch.set_skipped(engine.skipped_nodes(proj["pix"], want_count=False)[0])
+            pipe.set_row_map(exch.row_map())
+            nrows = exch.packed_rows()
             for k in range(K):
                 c0, fc = exch.my_chunk(k)
+                buf = chunk_bufs[k][:nrows]
                 if fc:
-                    pipe.process(frames[c0:c0 + fc], first_frame=rank * F + c0, rows_t=chunk_bufs[k],
-                                 want_rows=False)
-                exch.submit(chunk_bufs[k])
+                    pipe.process(frames[c0:c0 + fc], first_frame=rank * F + c0, rows_t=buf, want_rows=False)
+                exch.submit(buf, packed=True)
         e[2].record()
         s, ss = pipe.accumulators()
         D.allreduce_sums(s, ss)

@@ -214,6 +214,12 @@ int upsp_pipeline_set_skipped(upsp_pipeline *p, const uint8_t *d_skipped);
  * (cpp/exec/psp_process.cpp:1827-1839).  d_src [nnodes] int32: src[n] = node whose value node n
  * holds after the copy loop (n itself for ordinary nodes).  NULL switches it off. */
 int upsp_pipeline_set_overlap_source(upsp_pipeline *pipe, const int32_t *d_src);
+
+/* Packed time series: d_rowmap [nnodes] int32 gives the row of d_rows_t a node's series goes to;
+ * < 0 = the row is not stored (used by the multi-GPU exchange, which does not send the all-NaN
+ * rows of nodes no camera sees; the reference's global_transpose, cpp/exec/psp_process.cpp:707-771,
+ * moves them).  Accumulators and frame-major rows are unaffected.  NULL = identity. */
+int upsp_pipeline_set_row_map(upsp_pipeline *pipe, const int32_t *d_rowmap);
 /* ECC template of camera `cam` = first frame as f32 (elems.first_frames[c],
  * psp_process.cpp:2057-2058). */
 int upsp_pipeline_set_reference(upsp_pipeline *p, int cam, const float *d_ref32f);

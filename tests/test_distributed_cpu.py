@@ -49,6 +49,24 @@ def _worker(rank, world, port, F, N, seed, q):
         c0, fc = ex.my_chunk(k)
         ex.submit(rows_t[:, c0:c0 + fc].contiguous())
     assert torch.equal(ex.finish().view(torch.int32), series.view(torch.int32))
+    # ... and once more sending only the rows of nodes some camera sees (the others are NaN rows
+    # every rank can fill in by itself)
+    ex2 = D.TimeSeriesExchange(shard, 3, device="cpu")
+    ex2.set_skipped(torch.as_tensor(np.isnan(rows_all[0])))
+    for k in range(3):
+        c0, fc = ex2.my_chunk(k)
+        ex2.submit(rows_t[:, c0:c0 + fc])
+    assert torch.equal(ex2.finish().view(torch.int32), series.view(torch.int32))
+    assert sum(ex2.vis_count) == int((~np.isnan(rows_all[0])).sum())
+    # ... and with the rows packed by the producer (what the gather does with a row map)
+    ex3 = D.TimeSeriesExchange(shard, 3, device="cpu")
+    ex3.set_skipped(torch.as_tensor(np.isnan(rows_all[0])))
+    rm = ex3.row_map()
+    assert int((rm >= 0).sum()) == ex3.packed_rows() and torch.equal(rm[ex3.vis], torch.arange(ex3.packed_rows(), dtype=torch.int32))
+    for k in range(3):
+        c0, fc = ex3.my_chunk(k)
+        ex3.submit(rows_t[:, c0:c0 + fc].index_select(0, ex3.vis), packed=True)
+    assert torch.equal(ex3.finish().view(torch.int32), series.view(torch.int32))
     n0, nn = shard.my_nodes
     # phase-2 per-node vectors: each rank owns its node slice, every rank gets the whole vector
     whole = D.gather_node_vector(torch.arange(n0, n0 + nn, dtype=torch.float32) * 2.0, shard)

@@ -160,6 +160,7 @@ struct GatherArgs {
     size_t npix;
     int dbg;
     const int32_t *src;            // overlap source map or null
+    const int32_t *rowmap;         // packed rows of rows_t or null
 };
 
 template <int NCAMS>
@@ -321,13 +322,15 @@ __global__ void __launch_bounds__(256)
             for (int i = 0; i < 4; ++i) {
                 const int j = wave * 16 + i * 4 + rsub;  // node within the tile
                 const unsigned nn = n0 + (unsigned)j;
-                if (nn < nnodes && c4 < nframes) {
+                // packed series (multi-GPU exchange sends only rows some camera sees)
+                const long long row = (nn < nnodes) ? (a.rowmap ? (long long)a.rowmap[nn] : (long long)nn) : -1;
+                if (row >= 0 && c4 < nframes) {
                     float4 v;
                     v.x = tile[c4][j];
                     v.y = tile[c4 + 1][j];
                     v.z = tile[c4 + 2][j];
                     v.w = tile[c4 + 3][j];
-                    float *dst = rows_t + (long long)nn * ld_t + c4;
+                    float *dst = rows_t + row * ld_t + c4;
                     if (c4 + 3 < nframes) {
                         // streaming store: the series is not read again by the frame loop, keep
                         // L2 / Infinity Cache for the frames the gathers are reading
@@ -347,7 +350,8 @@ __global__ void __launch_bounds__(256)
         } else {  // lane = frame, wave g writes nodes g, g+4, ...: 256-byte row segments
             for (int j = wave; j < 64; j += 4) {
                 const unsigned nn = n0 + (unsigned)j;
-                if (nn < nnodes && lane < nframes) rows_t[(long long)nn * ld_t + lane] = tile[lane][j];
+                const long long row = (nn < nnodes) ? (a.rowmap ? (long long)a.rowmap[nn] : (long long)nn) : -1;
+                if (row >= 0 && lane < nframes) rows_t[row * ld_t + lane] = tile[lane][j];
             }
         }
     }
@@ -516,6 +520,7 @@ int launch_gather(const PipelineGather &g, hipStream_t st)
     a.ncams = g.ncams;
     a.npix = g.npix;
     a.src = g.src;
+    a.rowmap = g.rowmap;
     static const int dbg = std::getenv("UPSP_GATHER_DBG") ? std::atoi(std::getenv("UPSP_GATHER_DBG")) : 0;
     a.dbg = dbg;
     for (int c = 0; c < g.ncams; ++c) {

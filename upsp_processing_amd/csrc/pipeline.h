@@ -22,6 +22,7 @@ struct PipelineGather {
     const int32_t *pix[kMaxCams] = {nullptr};
     const float *weight[kMaxCams] = {nullptr};
     const uint8_t *skipped = nullptr;
+    const int32_t *rowmap = nullptr;  // node -> row of rows_t (packed series), < 0 = row not stored
     const int32_t *src = nullptr;  // overlap source map (adjust_solution): stored value of node n = sol[src[n]]
     float *rows = nullptr;  // [nframes][nnodes], may be null
     float *rows_t = nullptr;  // node-major: rows_t[n*ld_t + f], may be null

@@ -27,6 +27,7 @@ struct upsp_pipeline {
     bool has_proj[kMaxCams] = {false};
     uint8_t *d_skipped = nullptr;
     int32_t *d_src = nullptr;        // overlap source map (P3D adjust_solution), optional
+    int32_t *d_rowmap = nullptr;     // packed time-series rows (node -> row, < 0 = not stored), optional
     bool skipped_user = false, skipped_valid = false;
     double *d_sum = nullptr, *d_sumsq = nullptr;
     // hot-pixel scratch (per frame of a sub-batch)
@@ -146,6 +147,7 @@ void upsp_pipeline_destroy(upsp_pipeline *p)
         if (e) (void)hipEventDestroy(e);
     free_dev(p->d_skipped);
     free_dev(p->d_src);
+    free_dev(p->d_rowmap);
     free_dev(p->d_sum);
     free_dev(p->d_sumsq);
     free_dev(p->d_hot_count);
@@ -197,6 +199,19 @@ int upsp_pipeline_set_overlap_source(upsp_pipeline *p, const int32_t *d_src)
     }
     if (!p->d_src) UPSP_HIP_CHECK(hipMalloc(&p->d_src, sizeof(int32_t) * std::max<size_t>(p->nnodes, 1)));
     UPSP_HIP_CHECK(hipMemcpy(p->d_src, d_src, sizeof(int32_t) * p->nnodes, hipMemcpyDeviceToDevice));
+    return UPSP_OK;
+}
+
+int upsp_pipeline_set_row_map(upsp_pipeline *p, const int32_t *d_rowmap)
+{
+    if (!p) return fail(UPSP_ERR_INVALID, "null pipeline");
+    if (!d_rowmap) {
+        if (p->d_rowmap) (void)hipFree(p->d_rowmap);
+        p->d_rowmap = nullptr;
+        return UPSP_OK;
+    }
+    if (!p->d_rowmap) UPSP_HIP_CHECK(hipMalloc(&p->d_rowmap, sizeof(int32_t) * std::max<size_t>(p->nnodes, 1)));
+    UPSP_HIP_CHECK(hipMemcpy(p->d_rowmap, d_rowmap, sizeof(int32_t) * p->nnodes, hipMemcpyDeviceToDevice));
     return UPSP_OK;
 }
 
@@ -305,6 +320,7 @@ int upsp_pipeline_process(upsp_pipeline *p, const uint16_t *const *d_frames, int
         g.nframes = nb;
         g.skipped = p->d_skipped;
         g.src = p->d_src;
+        g.rowmap = p->d_rowmap;
         g.sum = p->d_sum;
         g.sumsq = p->d_sumsq;
         g.rows = d_rows ? d_rows + (size_t)f0 * p->nnodes : nullptr;

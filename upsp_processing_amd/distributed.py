@@ -108,8 +108,13 @@ class TimeSeriesExchange:
     """global_transpose pipelined with the frame loop: the rank's frames are produced in K
     chunks; the all-to-all of chunk k is issued asynchronously as soon as its node-major
     block exists, so the xGMI transfers overlap the gathers of chunk k+1.  Every rank uses the
-    same K; rank s cuts its own frame range with apportion(frame_count[s], K), so all ranks
-    know every block shape without communication."""
+    same K; rank s cuts its own frame range with aligned_chunks(frame_count[s], K), so all ranks
+    know every block shape without communication.
+
+    set_skipped(): nodes no camera sees hold NaN in every frame (psp_process.cpp:1821-1825) and
+    the skipped set is the same on every rank (the projection is replicated), so only the rows
+    of the other nodes travel -- on a closed model more than half of the nodes face away from a
+    camera, i.e. more than half of the all-to-all bytes are NaNs every rank already knows."""
 
     def __init__(self, shard, nchunks, dtype=torch.float32, device="cuda", group=None):
         self.shard, self.K, self.group = shard, max(1, int(nchunks)), group
@@ -120,43 +125,96 @@ class TimeSeriesExchange:
         self.chunks = [aligned_chunks(shard.frame_count[s], self.K) for s in range(shard.world)]
         self.pending = []
         self.k = 0
+        self.vis = None          # indices of the rows that travel (all ranks' slices, ascending)
+        self.vis_count = None    # rows that travel per destination rank
+        self.vis_mine = None     # their positions inside this rank's slice
+        self._row_map = None
+
+    def set_skipped(self, skipped):
+        """skipped: bool / uint8 [N] on the exchange's device, identical on every rank; None
+        switches back to sending every row.  Costs one device->host read of W counters."""
+        sh = self.shard
+        if skipped is None:
+            self.vis = self.vis_count = self.vis_mine = self._row_map = None
+            return
+        keep = (skipped == 0) if skipped.dtype != torch.bool else ~skipped
+        vis = torch.nonzero(keep, as_tuple=False).reshape(-1)
+        if self.vis is not None and self.vis.shape == vis.shape and bool(torch.equal(self.vis, vis)):
+            return                                      # same set as before: out's NaN rows are in place
+        self.vis = vis
+        self._row_map = None
+        bounds = torch.tensor([sh.node_start[d] for d in range(sh.world)] + [sh.nnodes], device=self.vis.device)
+        cuts = torch.searchsorted(self.vis, bounds).cpu().tolist()
+        self.vis_count = [cuts[d + 1] - cuts[d] for d in range(sh.world)]
+        n0, nn = sh.my_nodes
+        r = sh.rank
+        self.vis_mine = self.vis[cuts[r]:cuts[r + 1]] - n0
+        self.out.fill_(float("nan"))                    # rows that do not travel
 
     def my_chunk(self, k):
         """(local frame offset, frame count) of this rank's chunk k."""
         st, ex = self.chunks[self.shard.rank]
         return st[k], ex[k]
 
-    def submit(self, rows_t_chunk):
-        """rows_t_chunk: [N, fc] contiguous, this rank's chunk number len(submitted)."""
+    def row_map(self):
+        """int32 [N]: row of the packed chunk buffer for every node that travels, -1 for the rest
+        (FramePipeline.set_row_map): the gather then writes the packed rows itself."""
+        sh = self.shard
+        if self._row_map is None:
+            m = torch.full((sh.nnodes,), -1, dtype=torch.int32, device=self.vis.device)
+            m[self.vis] = torch.arange(self.vis.numel(), dtype=torch.int32, device=self.vis.device)
+            self._row_map = m
+        return self._row_map
+
+    def packed_rows(self):
+        return sum(self.vis_count) if self.vis is not None else self.shard.nnodes
+
+    def submit(self, rows_t_chunk, packed=False):
+        """rows_t_chunk: [N, fc] (unit column stride), this rank's chunk number len(submitted);
+        packed=True: [packed_rows(), fc], already reduced to the travelling rows (row_map())."""
         sh, k = self.shard, self.k
         c0, fc = self.my_chunk(k)
-        assert rows_t_chunk.shape == (sh.nnodes, fc) and rows_t_chunk.is_contiguous()
+        assert rows_t_chunk.shape == ((self.packed_rows() if packed else sh.nnodes), fc)
+        assert not packed or self.vis is not None
         n0, nn = sh.my_nodes
+        self.k += 1
         if sh.world == 1 or not dist.is_initialized():
             if fc:
-                self.out[:, c0:c0 + fc] = rows_t_chunk
-            self.k += 1
+                if self.vis is None:
+                    self.out[:, c0:c0 + fc] = rows_t_chunk
+                else:
+                    self.out[self.vis_mine, c0:c0 + fc] = (rows_t_chunk if packed
+                                                           else rows_t_chunk.index_select(0, self.vis))
             return
-        in_split = [sh.node_count[d] * fc for d in range(sh.world)]
-        out_split = [nn * self.chunks[s][1][k] for s in range(sh.world)]
-        recv = torch.empty(sum(out_split), dtype=rows_t_chunk.dtype, device=rows_t_chunk.device)
-        work = dist.all_to_all_single(recv, rows_t_chunk.reshape(-1), out_split, in_split,
+        if self.vis is None:
+            send = rows_t_chunk.contiguous()
+            count_out, count_in = sh.node_count, nn
+        else:
+            # packed rows, ordered by destination
+            send = rows_t_chunk.contiguous() if packed else rows_t_chunk.index_select(0, self.vis)
+            count_out, count_in = self.vis_count, self.vis_count[sh.rank]
+        in_split = [count_out[d] * fc for d in range(sh.world)]
+        out_split = [count_in * self.chunks[s][1][k] for s in range(sh.world)]
+        recv = torch.empty(sum(out_split), dtype=send.dtype, device=send.device)
+        work = dist.all_to_all_single(recv, send.reshape(-1), out_split, in_split,
                                       group=self.group, async_op=True)
-        self.pending.append((work, recv, k, rows_t_chunk))   # keep the send buffer alive
-        self.k += 1
+        self.pending.append((work, recv, k, send, count_in))    # keep the send buffer alive
 
     def finish(self):
         sh = self.shard
-        n0, nn = sh.my_nodes
-        for work, recv, k, _ in self.pending:
+        for work, recv, k, _, rows_in in self.pending:
             work.wait()
             off = 0
             for s in range(sh.world):
                 fs = self.chunks[s][1][k]
-                if fs and nn:
+                if fs and rows_in:
                     col = sh.frame_start[s] + self.chunks[s][0][k]
-                    self.out[:, col:col + fs] = recv[off:off + nn * fs].view(nn, fs)
-                off += nn * fs
+                    blk = recv[off:off + rows_in * fs].view(rows_in, fs)
+                    if self.vis is None:
+                        self.out[:, col:col + fs] = blk
+                    else:
+                        self.out[self.vis_mine, col:col + fs] = blk
+                off += rows_in * fs
         self.pending = []
         return self.out
 

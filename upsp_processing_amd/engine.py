@@ -192,16 +192,18 @@ def projection_weights(pix, nodes, normals, centers, mode="average_view"):
     return w
 
 
-def skipped_nodes(pix):
-    """identify_skipped_nodes (projection.ipp:857-880).  pix: [ncams, N] or [N]."""
+def skipped_nodes(pix, want_count=True):
+    """identify_skipped_nodes (projection.ipp:857-880).  pix: [ncams, N] or [N].
+    want_count=False skips the host read-back of the count (returns None for it)."""
     pix = _dev(pix, torch.int32)
     if pix.dim() == 1:
         pix = pix[None]
     ncams, n = pix.shape
     sk = torch.empty(n, dtype=torch.uint8, device="cuda")
     cnt = C.c_uint64(0)
-    check(lib().upsp_projection_skipped(ncams, n, _ptr(pix), _ptr(sk), C.byref(cnt), _stream()))
-    return sk.bool(), int(cnt.value)
+    check(lib().upsp_projection_skipped(ncams, n, _ptr(pix), _ptr(sk), C.byref(cnt) if want_count else None,
+                                        _stream()))
+    return sk.bool(), (int(cnt.value) if want_count else None)
 
 
 def fix_hot_pixels(frames, thresh=4064, min_change=512, max_hot=5):
@@ -291,6 +293,11 @@ class FramePipeline:
     def set_skipped(self, skipped):
         sk = None if skipped is None else _dev(skipped, torch.uint8)
         check(lib().upsp_pipeline_set_skipped(self._h, _ptr(sk)))
+
+    def set_row_map(self, rowmap):
+        """Packed time series: rowmap int32 [N] = row of rows_t per node, < 0 = not stored."""
+        self._rowmap = None if rowmap is None else _dev(rowmap, torch.int32)
+        check(lib().upsp_pipeline_set_row_map(self._h, _ptr(self._rowmap)))
 
     def set_overlap_source(self, src):
         """P3D adjust_solution: src int32 [N] (grids.P3DModel.overlap_source()); None = off."""
