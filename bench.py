@@ -309,6 +309,22 @@ def main():
         "roofline": roof,
         "kernels": kernels,
     }
+    if world == 1:
+        # SURVEY.md 8(d) stress mode "frame with re-raycast": one projection build (N_nodes visibility
+        # rays + retries) per frame instead of per run (docs/sphinx/known-issues.rst:18-30: model motion)
+        nrr = 20
+        one = torch.empty((N, engine.series_ld(1)), dtype=torch.float32, device="cuda")[:, :1]
+        pipe.reset()
+        torch.cuda.synchronize()
+        r0, r1 = ev(), ev()
+        r0.record()
+        for i in range(nrr):
+            pr = engine.build_projection(bvh, cam, d_nodes, d_nrm, d_tn, 70.0, counts=False)
+            pipe.set_projection(0, pr["pix"])
+            pipe.process(frames[i:i + 1], first_frame=i, rows_t=one, want_rows=False)
+        r1.record()
+        torch.cuda.synchronize()
+        out["reraycast_frames_per_s"] = nrr / (r0.elapsed_time(r1) * 1e-3)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(verts, tris, cd, size, F, nrays_last[1].cpu().numpy())
     elif rank == 0:
