@@ -237,7 +237,9 @@ __global__ void __launch_bounds__(256)
 {
     __shared__ float tile[64][65];        // [frame][node]
     __shared__ double part[2][4][64];     // [sum|sumsq][wave][node]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the wave index as a scalar: everything that depends only on it (frame < nframes) becomes a
+    // uniform branch instead of an exec-mask sequence
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned n0 = blockIdx.x * 64u, n = n0 + lane;
     const int nc = NCAMS > 0 ? NCAMS : a.ncams;
     const bool live = n < nnodes;
