@@ -300,6 +300,14 @@ int upsp_patch_f32(float *d_img, int rows, int cols, int nclusters, const int32_
 int upsp_unpack_12bit(const uint8_t *d_packed, int nframes, size_t npix, uint16_t *d_frames,
                       int hot_thresh, uint32_t *d_hot_count, void *stream);
 
+/* 10-bit packed Phantom CINE frames (5 bytes -> 4 pixels, MSBs first; upsp::unpack_10bit,
+ * cpp/lib/PSPVideo.cpp:111-132; npix divisible by 4, npix*5/4 bytes per frame) -> u16, passed
+ * through the 1024-entry 10 -> 12 bit look-up table d_lut when it is not NULL
+ * (CineReader::read_packed, cpp/lib/CineReader.cpp:409-423; the table is camera data published
+ * with the Cine file format and is supplied by the caller). */
+int upsp_unpack_10bit(const uint8_t *d_packed, int nframes, size_t npix, const uint16_t *d_lut,
+                      uint16_t *d_frames, void *stream);
+
 /* ======================================================================== *
  *  3c. Phase 2: node-major time series -> delta-Cp   (reference:
  *      phase-2 node loop cpp/exec/psp_process.cpp:2452-2507, finals :2537-2545,

@@ -99,6 +99,7 @@ def lib():
 
 _OPTIONAL = [
     ("orc_unpack_12bit", [C.c_void_p, C.c_size_t, C.c_void_p], None),
+    ("orc_unpack_10bit", [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p], None),
     ("orc_gaussian_kernel", [C.c_int, C.c_void_p], C.c_int),
     ("orc_blur_f32", [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int], None),
     ("orc_warp_affine_u16", [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int], None),
@@ -383,6 +384,14 @@ def unpack_12bit(packed):
     packed = np.ascontiguousarray(packed, dtype=np.uint8).reshape(-1)
     out = np.zeros(packed.size * 2 // 3, np.uint16)
     lib().orc_unpack_12bit(_p(packed), packed.size, _p(out))
+    return out
+
+
+def unpack_10bit(packed, lut=None):
+    packed = np.ascontiguousarray(packed, dtype=np.uint8).reshape(-1)
+    out = np.zeros(packed.size * 4 // 5, np.uint16)
+    lut = None if lut is None else np.ascontiguousarray(lut, dtype=np.uint16)
+    lib().orc_unpack_10bit(_p(packed), packed.size, _p(lut), _p(out))
     return out
 
 

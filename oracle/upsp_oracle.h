@@ -267,6 +267,8 @@ void orc_phase2(const float *intensity_t, size_t nnodes, int nframes, const floa
 
 /* upsp::unpack_12bit, cpp/lib/PSPVideo.cpp:134-149 (MRAW / 12-bit CINE frames) */
 void orc_unpack_12bit(const uint8_t *packed, size_t nbytes, uint16_t *out);
+/* upsp::unpack_10bit, cpp/lib/PSPVideo.cpp:111-132, + optional 10->12 bit LUT (CineReader.cpp:409-423) */
+void orc_unpack_10bit(const uint8_t *packed, size_t nbytes, const uint16_t *lut, uint16_t *out);
 
 #ifdef __cplusplus
 }

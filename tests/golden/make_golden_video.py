@@ -35,6 +35,13 @@ def main():
            "sample_stride": 65521,
            "sample": pix[::65521].astype(int).tolist(),
            "max": int(pix.max()), "sum": int(pix.astype(np.int64).sum())}
+    # 10-bit packing: the reference's unpack_10bpp (util.py:6-22) on a seeded byte string
+    rng = np.random.default_rng(20240607)
+    b10 = rng.integers(0, 256, 5 * 4096, dtype=np.uint8).tobytes()
+    p10 = util.unpack_10bpp(b10)
+    man["unpack10"] = {"seed": 20240607, "nbytes": len(b10),
+                       "sha256": hashlib.sha256(p10.astype("<u2").tobytes()).hexdigest(),
+                       "head": p10[:16].astype(int).tolist(), "sum": int(p10.astype(np.int64).sum())}
     json.dump(man, open(os.path.join(HERE, "mraw_golden.json"), "w"), indent=1)
     print(man["sha256"], man["max"], man["sum"], man["sample"][:8])
 

@@ -11,6 +11,9 @@ import pytest
 import refdata
 
 
+GOLD = refdata.GOLDEN
+
+
 def golden():
     return json.load(open(os.path.join(refdata.GOLDEN, "mraw_golden.json")))
 
@@ -73,3 +76,111 @@ def test_unpack_gpu_bitwise(gpu_lib, oracle):
         sol = oracle.project_frame(img, pix.cpu().numpy(), None)
         sol[pix.cpu().numpy() < 0] = np.nan
         assert np.array_equal(rows[fidx].view(np.int32), sol.view(np.int32))
+
+
+# ------------------------------------------------------------------ 10-bit / CINE --------
+def _bytes10():
+    man = json.load(open(os.path.join(GOLD, "mraw_golden.json")))["unpack10"]
+    rng = np.random.default_rng(man["seed"])
+    return man, rng.integers(0, 256, man["nbytes"], dtype=np.uint8)
+
+
+def test_oracle_unpack10_matches_reference_unpacker(oracle):
+    """oracle vs the golden produced by python/upsp/video/util.py:unpack_10bpp."""
+    import hashlib
+    man, b = _bytes10()
+    pix = oracle.unpack_10bit(b)
+    assert hashlib.sha256(pix.astype("<u2").tobytes()).hexdigest() == man["sha256"]
+    assert pix[:16].tolist() == man["head"] and int(pix.astype(np.int64).sum()) == man["sum"]
+    lut = (np.arange(1024, dtype=np.uint16)[::-1] * 4).astype(np.uint16)
+    assert np.array_equal(oracle.unpack_10bit(b, lut), lut[pix])
+
+
+def _write_cine(path, frames_bytes, width, height, bpp):
+    """Minimal Cine container: CINEFILEHEADER (44 B), BITMAPINFOHEADER (40 B), SETUP (RealBPP @896,
+    FrameRate @768), image offsets, then per image {annotation size = 8, image size, pixels}."""
+    import struct
+    n = len(frames_bytes)
+    off_setup = 84
+    setup = bytearray(7240)
+    setup[140:142] = b"ST"
+    struct.pack_into("<H", setup, 142, 7240)
+    struct.pack_into("<I", setup, 768, 5000)
+    struct.pack_into("<I", setup, 896, bpp)
+    off_offsets = off_setup + len(setup)
+    first_img = off_offsets + 8 * n
+    offs, pos = [], first_img
+    for fb in frames_bytes:
+        offs.append(pos)
+        pos += 8 + len(fb)
+    head = bytearray(84)
+    head[0:2] = b"CI"
+    struct.pack_into("<HHH", head, 2, 44, 0, 1)
+    struct.pack_into("<iIiIIII", head, 8, 0, n, 0, n, 44, off_setup, off_offsets)
+    struct.pack_into("<IiiHHII", head, 44, 40, width, height, 1, 16, 256, len(frames_bytes[0]))
+    with open(path, "wb") as f:
+        f.write(head)
+        f.write(setup)
+        f.write(np.array(offs, "<i8").tobytes())
+        for fb in frames_bytes:
+            f.write(struct.pack("<II", 8, len(fb)))
+            f.write(fb)
+
+
+def test_cine_reader_header(tmp_path):
+    from upsp_processing_amd import video
+    W, H = 64, 48
+    fb = [bytes(W * H * 12 // 8)] * 3
+    p = str(tmp_path / "a.cine")
+    _write_cine(p, fb, W, H, 12)
+    r = video.CineReader(p)
+    assert (r.width, r.height, r.num_frames, r.bit_depth, r.frame_rate) == (W, H, 3, 12, 5000)
+    assert r.read_packed(2, 2).shape == (2, W * H * 3 // 2)
+    with pytest.raises(IndexError):
+        r.read_packed(3, 2)
+    _write_cine(p, [bytes(W * H * 10 // 8)], W, H, 10)
+    assert video.CineReader(p).bit_depth == 12 and video.CineReader(p).raw_bit_depth == 10
+
+
+@pytest.mark.gpu
+def test_unpack10_gpu_vs_oracle(gpu_lib, oracle):
+    import torch
+    from upsp_processing_amd import video
+    rng = np.random.default_rng(9)
+    for (H, W, F) in ((32, 64, 3), (6, 10, 2), (128, 256, 2)):
+        b = rng.integers(0, 256, (F, H * W * 5 // 4), dtype=np.uint8)
+        lut = rng.integers(0, 4096, 1024).astype(np.uint16)
+        for l in (None, lut):
+            got = video.unpack_10bit(torch.as_tensor(b).cuda(), H, W, l).cpu().numpy()
+            want = np.stack([oracle.unpack_10bit(b[f], l) for f in range(F)]).reshape(F, H, W)
+            assert np.array_equal(got, want)
+    man, bb = _bytes10()
+    got = video.unpack_10bit(torch.as_tensor(bb[None]).cuda(), 64, 256).cpu().numpy().reshape(-1)
+    assert got[:16].tolist() == man["head"] and int(got.astype(np.int64).sum()) == man["sum"]
+
+
+@pytest.mark.gpu
+def test_cine_reader_frames(gpu_lib, oracle, tmp_path):
+    from upsp_processing_amd import video
+    rng = np.random.default_rng(3)
+    W, H = 64, 32
+    p = str(tmp_path / "a.cine")
+    pix = rng.integers(0, 4096, (3, H * W)).astype(np.uint16)
+    pk = np.zeros((3, H * W * 3 // 2), np.uint8)
+    pk[:, 0::3] = pix[:, 0::2] >> 4
+    pk[:, 1::3] = ((pix[:, 0::2] & 0x0F) << 4) | (pix[:, 1::2] >> 8)
+    pk[:, 2::3] = pix[:, 1::2] & 0xFF
+    _write_cine(p, [pk[i].tobytes() for i in range(3)], W, H, 12)
+    fr = video.CineReader(p).read_frames_device(2, 2).cpu().numpy()
+    assert np.array_equal(fr.reshape(2, -1), pix[1:])
+    b10 = rng.integers(0, 256, (2, H * W * 5 // 4), dtype=np.uint8)
+    _write_cine(p, [b10[i].tobytes() for i in range(2)], W, H, 10)
+    lut = (np.arange(1024) * 4).astype(np.uint16)
+    with pytest.raises(ValueError):
+        video.CineReader(p).read_frames_device(1, 1)
+    fr = video.CineReader(p, lut=lut).read_frames_device(1, 2).cpu().numpy()
+    assert np.array_equal(fr.reshape(2, -1), np.stack([oracle.unpack_10bit(b10[i], lut) for i in range(2)]))
+    words = rng.integers(0, 4096, (1, H, W)).astype("<u2")
+    _write_cine(p, [words[0].tobytes()], W, H, 8)
+    fr = video.CineReader(p).read_frames_device(1, 1).cpu().numpy()
+    assert np.array_equal(fr[0], words[0][::-1])

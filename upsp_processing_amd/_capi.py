@@ -92,6 +92,7 @@ SIGNATURES = {
     "upsp_register_pixel_u16": (_i, [_vp, _vp, _i, _i, _i, C.c_double, _i, _vp, _vp, _vp]),
     "upsp_blur_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "upsp_patch_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "upsp_unpack_10bit": (_i, [_vp, _i, _sz, _vp, _vp, _vp]),
     "upsp_unpack_12bit": (_i, [_vp, _i, _sz, _vp, _i, _vp, _vp]),
     "upsp_transpoly_fit": (_i, [_vp, C.c_longlong, _sz, _i, _i, _vp, C.c_longlong, _vp, _vp]),
     "upsp_phase2_pressure": (_i, [_vp, C.c_longlong, _sz, _i, _vp, _vp, _vp, _vp, C.c_float, _vp,

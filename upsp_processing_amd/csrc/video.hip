@@ -82,10 +82,91 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+// 10-bit packed Phantom CINE frames: 5 bytes -> 4 pixels, MSBs first (upsp::unpack_10bit,
+// cpp/lib/PSPVideo.cpp:111-132), then the camera's 10 -> 12 bit look-up table
+// (CineReader::read_packed, cpp/lib/CineReader.cpp:409-423).  20 bytes in, 16 pixels out per lane.
+__global__ void __launch_bounds__(256)
+    unpack10_kernel(const uint8_t *__restrict__ packed, size_t npix, const uint16_t *__restrict__ lut,
+                    uint16_t *__restrict__ out)
+{
+    const size_t f = blockIdx.y;
+    const uint8_t *src = packed + f * (npix / 4 * 5);
+    uint16_t *dst = out + f * npix;
+    const size_t ngroups = npix / 16;   // 20 bytes -> 16 pixels
+    const bool aligned = ((reinterpret_cast<size_t>(src) & 3) == 0) && ((reinterpret_cast<size_t>(dst) & 15) == 0);
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups;
+         g += (size_t)gridDim.x * blockDim.x) {
+        unsigned w[5];
+        if (aligned) {
+            const unsigned *s32 = reinterpret_cast<const unsigned *>(src) + 5 * g;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) w[k] = s32[k];
+        } else {
+            for (int k = 0; k < 5; ++k)
+                w[k] = src[20 * g + 4 * k] | (src[20 * g + 4 * k + 1] << 8) |
+                       (src[20 * g + 4 * k + 2] << 16) | ((unsigned)src[20 * g + 4 * k + 3] << 24);
+        }
+        auto byte = [&](int i) { return (w[i >> 2] >> ((i & 3) * 8)) & 0xFFu; };
+        unsigned px[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned p = byte(5 * q), qq = byte(5 * q + 1), r = byte(5 * q + 2), s_ = byte(5 * q + 3),
+                           t = byte(5 * q + 4);
+            px[4 * q] = (p << 2) | (qq >> 6);
+            px[4 * q + 1] = ((qq & 0x3Fu) << 4) | (r >> 4);
+            px[4 * q + 2] = ((r & 0x0Fu) << 6) | (s_ >> 2);
+            px[4 * q + 3] = ((s_ & 0x03u) << 8) | t;
+        }
+        if (lut) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) px[k] = lut[px[k]];
+        }
+        if (aligned) {
+            uint4 o0, o1;
+            o0.x = px[0] | (px[1] << 16); o0.y = px[2] | (px[3] << 16);
+            o0.z = px[4] | (px[5] << 16); o0.w = px[6] | (px[7] << 16);
+            o1.x = px[8] | (px[9] << 16); o1.y = px[10] | (px[11] << 16);
+            o1.z = px[12] | (px[13] << 16); o1.w = px[14] | (px[15] << 16);
+            reinterpret_cast<uint4 *>(dst)[2 * g] = o0;
+            reinterpret_cast<uint4 *>(dst)[2 * g + 1] = o1;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) dst[16 * g + k] = (uint16_t)px[k];
+        }
+    }
+    // tail: remaining groups of 4 pixels (npix a multiple of 4, not of 16)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        for (size_t i = ngroups * 16; i + 3 < npix; i += 4) {
+            const size_t b = i / 4 * 5;
+            const unsigned p = src[b], q = src[b + 1], r = src[b + 2], s_ = src[b + 3], t = src[b + 4];
+            unsigned v[4] = {(p << 2) | (q >> 6), ((q & 0x3Fu) << 4) | (r >> 4), ((r & 0x0Fu) << 6) | (s_ >> 2),
+                             ((s_ & 0x03u) << 8) | t};
+            for (int k = 0; k < 4; ++k) dst[i + k] = (uint16_t)(lut ? lut[v[k]] : v[k]);
+        }
+    }
+}
+
 }  // namespace
 }  // namespace upsp
 
 using namespace upsp;
+
+extern "C" int upsp_unpack_10bit(const uint8_t *d_packed, int nframes, size_t npix,
+                                 const uint16_t *d_lut, uint16_t *d_frames, void *stream)
+{
+    if (nframes == 0 || npix == 0) return UPSP_OK;
+    if (!d_packed || !d_frames || nframes < 0) return fail(UPSP_ERR_INVALID, "bad argument");
+    if (npix & 3) return fail(UPSP_ERR_INVALID, "10-bit packing needs a pixel count divisible by 4");
+    hipStream_t st = (hipStream_t)stream;
+    size_t bx = (npix / 16 + 255) / 256;
+    if (bx > 256) bx = 256;
+    if (bx < 1) bx = 1;
+    KTimed kt("unpack10_kernel", st);
+    hipLaunchKernelGGL(unpack10_kernel, dim3((unsigned)bx, (unsigned)nframes), dim3(256), 0, st,
+                       d_packed, npix, d_lut, d_frames);
+    UPSP_HIP_CHECK(hipGetLastError());
+    return UPSP_OK;
+}
 
 extern "C" int upsp_unpack_12bit(const uint8_t *d_packed, int nframes, size_t npix,
                                  uint16_t *d_frames, int hot_thresh, uint32_t *d_hot_count,

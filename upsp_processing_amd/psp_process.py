@@ -11,7 +11,8 @@ cpp/lib/upsp_inputs.cpp) for the part of the pipeline this repository implements
 * grid: Cart3D `.tri` (cpp/lib/TriModel.ipp:117-257) or PLOT3D surface grid `.p3d/.g/.x/.grid/.grd`
   (cpp/lib/plot3d.cpp, cpp/lib/P3DModel.ipp; zone overlaps within 1e-3, psp_process.cpp:1378)
 * camera calibration JSON (cpp/lib/CameraCal.cpp:19-54)
-* video: 12-bit Photron `.mraw` (cpp/lib/MrawReader.cpp)      [`.cine`: not built]
+* video: 12-bit Photron `.mraw` (cpp/lib/MrawReader.cpp) or Phantom `.cine` (cpp/lib/CineReader.cpp:
+  12-bit packed, 10-bit packed with the look-up table given in UPSP_CINE_LUT, 8-bit mode)
 * options: registration = none|pixel, filter = none|gaussian|box (+ filter_size),
   overlap = best_view|average_view, oblique_angle, number_frames
   target_patcher = none|polynomial (targets file in @all or @camera; flags -bound_pts,
@@ -188,9 +189,15 @@ def main(argv=None):
         cal = read_camera_json(c["calibration"])
         cams.append(cal)
         fn = c.get("filename") or c.get("cine")
-        if not fn or not fn.endswith(".mraw"):
-            raise DeckError("only .mraw video is supported (got %r)" % fn)
-        readers.append(video.MrawReader(fn))
+        if fn and fn.endswith(".mraw"):
+            readers.append(video.MrawReader(fn))
+        elif fn and fn.endswith(".cine"):
+            try:
+                readers.append(video.CineReader(fn))              # 10-bit files: UPSP_CINE_LUT
+            except (ValueError, NotImplementedError) as e:
+                raise DeckError(str(e))
+        else:
+            raise DeckError("video must be a .mraw or .cine file (got %r)" % fn)
     size = cams[0]["size"]
     for cal, r in zip(cams, readers):
         if cal["size"] != size or (r.width, r.height) != size:

@@ -65,3 +65,92 @@ def unpack_12bit(packed, height, width, hot_thresh=None):
     _capi.check(_capi.lib().upsp_unpack_12bit(_ptr(packed), f, npix, _ptr(out),
                                               int(hot_thresh or 0), _ptr(cnt), _stream()))
     return out if hot_thresh is None else (out, cnt)
+
+
+def unpack_10bit(packed, height, width, lut=None):
+    """packed: u8 CUDA tensor [F, H*W*5/4].  lut: 1024-entry 10 -> 12 bit table or None.
+    Returns u16 [F,H,W]."""
+    import torch
+    from . import _capi
+    from .engine import _dev, _ptr, _stream
+    assert packed.is_cuda and packed.dtype == torch.uint8 and packed.is_contiguous()
+    f = packed.shape[0] if packed.dim() == 2 else 1
+    npix = height * width
+    assert packed.numel() == f * npix * 5 // 4
+    d_lut = None
+    if lut is not None:
+        d_lut = _dev(np.asarray(lut).astype(np.uint16), torch.uint16)
+        assert d_lut.numel() == 1024
+    out = torch.empty((f, height, width), dtype=torch.uint16, device="cuda")
+    _capi.check(_capi.lib().upsp_unpack_10bit(_ptr(packed), f, npix, _ptr(d_lut), _ptr(out), _stream()))
+    return out
+
+
+class CineReader:
+    """Mirror of upsp::CineReader (cpp/include/CineReader.h, cpp/lib/CineReader.cpp) for what
+    psp_process needs: properties from CINEFILEHEADER / BITMAPINFOHEADER / SETUP (field offsets of
+    the published Vision Research Cine format: SETUP.FrameRate @768, SETUP.RealBPP @896), the
+    image-offset table, and frames -- 12-bit packed and 10-bit packed (+ LUT) unpacked on the GPU,
+    8-bit-mode files as 16-bit words flipped vertically (read_linear, CineReader.cpp:435-451).
+
+    The 10 -> 12 bit look-up table is camera data published with the format; pass it as `lut`
+    (array or path of a raw little-endian u16[1024] file) or through the UPSP_CINE_LUT variable."""
+
+    def __init__(self, cine_file, lut=None):
+        import struct
+        if not os.path.isfile(cine_file):
+            raise ValueError("Video File is invalid")
+        self.cine_file = cine_file
+        with open(cine_file, "rb") as f:
+            head = f.read(44 + 40)
+            if len(head) < 84 or head[:2] != b"CI":
+                raise ValueError("not a Cine file: %s" % cine_file)
+            (self.first_image_no, self.num_frames, off_image_header, off_setup,
+             off_image_offsets) = struct.unpack_from("<iIIII", head, 16)
+            self.width, self.height = struct.unpack_from("<ii", head, 44 + 4)
+            f.seek(off_setup)
+            setup = f.read(900)
+            self.frame_rate = struct.unpack_from("<I", setup, 768)[0]
+            self.raw_bit_depth = struct.unpack_from("<I", setup, 896)[0]     # bits_per_pixel_ (:143)
+            f.seek(off_image_offsets)
+            self.image_offsets = np.frombuffer(f.read(8 * self.num_frames), "<i8").copy()
+        self.bit_depth = 12 if self.raw_bit_depth == 10 else self.raw_bit_depth   # :175
+        if self.raw_bit_depth not in (8, 10, 12):
+            raise NotImplementedError("Cine bit depth %d not supported" % self.raw_bit_depth)
+        self.frame_bytes = (self.width * self.height * 2 if self.raw_bit_depth == 8
+                            else self.width * self.height * self.raw_bit_depth // 8)
+        if lut is None and os.environ.get("UPSP_CINE_LUT"):
+            lut = os.environ["UPSP_CINE_LUT"]
+        if isinstance(lut, str):
+            lut = np.fromfile(lut, "<u2")
+        self.lut = None if lut is None else np.asarray(lut).astype(np.uint16)
+        if self.lut is not None and self.lut.size != 1024:
+            raise ValueError("the Cine look-up table needs 1024 entries")
+
+    def read_packed(self, first, count):
+        """Raw bytes of frames first..first+count-1 (1-based); pixel data start 8 bytes after the
+        image offset (annotation size + image size words, CineReader.cpp:456)."""
+        if first < 1 or first + count - 1 > self.num_frames:
+            raise IndexError("frame out of range")
+        out = np.empty((count, self.frame_bytes), np.uint8)
+        with open(self.cine_file, "rb") as f:
+            for i in range(count):
+                f.seek(int(self.image_offsets[first - 1 + i]) + 8)
+                out[i] = np.fromfile(f, dtype=np.uint8, count=self.frame_bytes)
+        return out
+
+    def read_frames_device(self, first, count, hot_thresh=None):
+        import torch
+        raw = self.read_packed(first, count)
+        if self.raw_bit_depth == 12:
+            return unpack_12bit(torch.as_tensor(raw).cuda(), self.height, self.width, hot_thresh)
+        if self.raw_bit_depth == 10:
+            if self.lut is None:
+                raise ValueError("10-bit Cine files need the 10 -> 12 bit look-up table (lut= / UPSP_CINE_LUT)")
+            fr = unpack_10bit(torch.as_tensor(raw).cuda(), self.height, self.width, self.lut)
+        else:
+            words = raw.view("<u2").reshape(count, self.height, self.width)[:, ::-1, :]   # flip(A, B, 0)
+            fr = torch.as_tensor(np.ascontiguousarray(words)).cuda()
+        if hot_thresh is None:
+            return fr
+        return fr, (fr.reshape(count, -1) >= hot_thresh).sum(1).to(torch.int32)
