@@ -309,7 +309,7 @@ def main():
         "roofline": roof,
         "kernels": kernels,
     }
-    if world == 1:
+    if world == 1 and not a.registration:
         # SURVEY.md 8(d) stress mode "frame with re-raycast": one projection build (N_nodes visibility
         # rays + retries) per frame instead of per run (docs/sphinx/known-issues.rst:18-30: model motion)
         nrr = 20

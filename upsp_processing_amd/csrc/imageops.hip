@@ -851,7 +851,9 @@ static int run_ecc(FrameScratch *s, const float *tmpl_blur, const uint16_t *fram
     while (it < max_iters) {
         // a few iterations between host checks of the active-frame count; frames that have
         // converged exit at once, so late bursts spread the remaining frames over more blocks
-        const int burst = it == 0 ? 3 : 2;
+        // (a host check costs a stream round trip of ~40 us; most frames converge within 3-5
+        // iterations, the rare oscillating ones run to max_iters, so the bursts grow)
+        const int burst = it == 0 ? 3 : (it < 7 ? 2 : (it < 15 ? 8 : 16));
         int blocks = kEccBlocks;
         while (blocks < kEccBlocksMax && (long long)blocks * active < 2048) blocks *= 2;
         for (int k = 0; k < burst && it < max_iters; ++k, ++it) {
