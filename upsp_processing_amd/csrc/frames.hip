@@ -158,7 +158,6 @@ struct GatherArgs {
     int is_f32[kMaxCams];
     int ncams;
     size_t npix;
-    int dbg;
     const int32_t *src;            // overlap source map or null
     const int32_t *rowmap;         // packed rows of rows_t or null
 };
@@ -247,7 +246,7 @@ __global__ void __launch_bounds__(256)
     float w[NCAMS > 0 ? NCAMS : kMaxCams];
 #pragma unroll
     for (int c = 0; c < nc; ++c) {
-        px[c] = (live && !(a.dbg & 2)) ? a.pix[c][n] : -1;
+        px[c] = live ? a.pix[c][n] : -1;
         w[c] = (live && a.weight[c]) ? a.weight[c][n] : 1.0f;
     }
     const bool skip = live && skipped && skipped[n];
@@ -315,7 +314,7 @@ __global__ void __launch_bounds__(256)
         sum[n] += ((part[0][0][lane] + part[0][1][lane]) + part[0][2][lane]) + part[0][3][lane];
         sumsq[n] += ((part[1][0][lane] + part[1][1][lane]) + part[1][2][lane]) + part[1][3][lane];
     }
-    if (rows_t && !(a.dbg & 1)) {
+    if (rows_t) {
         const bool vec_ok = ((ld_t & 3) == 0) && ((reinterpret_cast<size_t>(rows_t) & 15) == 0);
         if (vec_ok) {
             // 16 lanes x 16 B = one 256-byte row segment, 4 rows per wave instruction
@@ -523,8 +522,6 @@ int launch_gather(const PipelineGather &g, hipStream_t st)
     a.npix = g.npix;
     a.src = g.src;
     a.rowmap = g.rowmap;
-    static const int dbg = std::getenv("UPSP_GATHER_DBG") ? std::atoi(std::getenv("UPSP_GATHER_DBG")) : 0;
-    a.dbg = dbg;
     for (int c = 0; c < g.ncams; ++c) {
         a.img[c] = g.img[c];
         a.pix[c] = g.pix[c];
