@@ -259,6 +259,11 @@ __global__ void __launch_bounds__(256)
 //  0 n   1 Sw   2 Sww   3 St   4 Stt   5 Stw          (masked)
 //  6..11  S_all  J_k * w        12..17 S_mask J_k      18..23 S_mask J_k * t
 //  24..44 S_all  J_a * J_b  (a <= b, row-major upper triangle)
+// IDENT: every active frame still holds the identity warp (first iteration of register_pixel,
+// cpp/lib/registration.cpp:52-53): source pixel = target pixel, zero fractions, so the bilinear
+// weights are (1,0,0,0) and the general arithmetic reduces EXACTLY to the centre taps
+// (x*1 + y*0 + .. = x in float) -- 5 loads and no interpolation instead of 12 loads.
+template <bool IDENT>
 __global__ void __launch_bounds__(256)
     ecc_sums_kernel(const float *__restrict__ img, const float *__restrict__ tmpl, int rows,
                     int cols, const EccState *__restrict__ state, double *__restrict__ partial)
@@ -304,7 +309,12 @@ __global__ void __launch_bounds__(256)
         const int nx = max(-32768, min(32767, (Xr + 512) >> 10)), ny = max(-32768, min(32767, (Yr + 512) >> 10));
         const bool m = (unsigned)nx < (unsigned)cols && (unsigned)ny < (unsigned)rows;
         float w, gx, gy;
-        if (c.sx >= 1 && c.sx + 2 < cols && c.sy >= 1 && c.sy + 2 < rows) {
+        if (IDENT && x >= 1 && x + 2 < cols && y >= 1 && y + 2 < rows) {
+            const float *r1 = I + (size_t)y * cols + x;
+            w = r1[0];
+            gx = -0.5f * r1[-1] + 0.5f * r1[1];
+            gy = -0.5f * r1[-cols] + 0.5f * r1[cols];
+        } else if (c.sx >= 1 && c.sx + 2 < cols && c.sy >= 1 && c.sy + 2 < rows) {
             // fully interior footprint: 12 pixels, no border handling; same arithmetic as
             // the generic path (bilinear of I, of [-0.5 0 0.5] along x and along y)
             const float *r0 = I + (size_t)(c.sy - 1) * cols + c.sx;
@@ -859,9 +869,14 @@ static int run_ecc(FrameScratch *s, const float *tmpl_blur, const uint16_t *fram
         for (int k = 0; k < burst && it < max_iters; ++k, ++it) {
             {
                 KTimed kt("ecc_sums_kernel", st);
-                hipLaunchKernelGGL(ecc_sums_kernel, dim3(blocks, nb), dim3(256), 0, st,
-                                   (const float *)s->ecc_img, tmpl_blur, rows, cols,
-                                   (const EccState *)s->state, s->partial);
+                if (it == 0)
+                    hipLaunchKernelGGL(ecc_sums_kernel<true>, dim3(blocks, nb), dim3(256), 0, st,
+                                       (const float *)s->ecc_img, tmpl_blur, rows, cols,
+                                       (const EccState *)s->state, s->partial);
+                else
+                    hipLaunchKernelGGL(ecc_sums_kernel<false>, dim3(blocks, nb), dim3(256), 0, st,
+                                       (const float *)s->ecc_img, tmpl_blur, rows, cols,
+                                       (const EccState *)s->state, s->partial);
             }
             KTimed kt2("ecc_solve_kernel", st);
             hipLaunchKernelGGL(ecc_solve_kernel, dim3(nb), dim3(256), 0, st, s->state,

@@ -820,7 +820,7 @@ __device__ __forceinline__ bool apply_own_bound(Trav &s, const OwnBound &o)
 }
 
 template <bool STATS, int PHASE>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 8)))
     projection_kernel(Scene sc, Cam cam, const float *__restrict__ nodes,
                       const int32_t *__restrict__ tri_nodes, unsigned nnodes,
                       int32_t *__restrict__ pix, unsigned *__restrict__ retry_nodes,
