@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--size", type=int, default=1024, help="frame is size x size")
     ap.add_argument("--small", action="store_true", help="reduced mesh/frames (plumbing check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-reraycast", action="store_true", help="skip the re-raycast stress figure (profiling runs)")
     ap.add_argument("--registration", action="store_true",
                     help="configs[2] shape: per-frame ECC registration before the projection")
     ap.add_argument("--force-chunked", action="store_true",
@@ -275,7 +276,7 @@ def main():
     # MI355X_MICROARCH.md "HBM"; counter unit = KB) -- per launch, same launch shape
     traffic = None
     prof = os.path.join(ROOT, "profiles", "r01_bench_summary.json")
-    pkey = {"gather_tile_kernel": "gather_tile_kernel<1, true>", "hot_scan_kernel": "hot_scan_kernel",
+    pkey = {"gather_tile_kernel": "gather_tile_kernel<1, true, false>", "hot_scan_kernel": "hot_scan_kernel",
             "projection_kernel<primary>": "projection_kernel<false, 0>",
             "projection_kernel<retry>": "projection_kernel<false, 1>"}.get(dom)
     if os.path.exists(prof) and pkey:
@@ -309,7 +310,7 @@ def main():
         "roofline": roof,
         "kernels": kernels,
     }
-    if world == 1 and not a.registration:
+    if world == 1 and not a.registration and not a.no_reraycast:
         # SURVEY.md 8(d) stress mode "frame with re-raycast": one projection build (N_nodes visibility
         # rays + retries) per frame instead of per run (docs/sphinx/known-issues.rst:18-30: model motion)
         nrr = 20

@@ -6,9 +6,9 @@ tag=$1; shift
 out=gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --no-cpu-baseline "$@" > $out/trace.log 2>&1
+timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --no-cpu-baseline --no-reraycast "$@" > $out/trace.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 240 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/$c -- python3 bench.py --no-cpu-baseline "$@" > $out/$c.log 2>&1
+  timeout 240 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/$c -- python3 bench.py --no-cpu-baseline --no-reraycast "$@" > $out/$c.log 2>&1
 done
 python3 - $out <<'PY'
 import csv, glob, sys, collections, json
