@@ -9,6 +9,7 @@ print("mesh", v.shape, t.shape, "%.1fs" % (time.time() - t0))
 bvh = engine.BVH(s9); print(bvh.info)
 size = 1024
 dn, dm, dt = [torch.as_tensor(x).cuda() for x in (v, nrm, tn)]
+bvh.set_tri_nodes(dt, v.shape[0])
 pix = []
 for az in (0, 90, 180, 270):
     cd = syn.pinhole_camera(size, size, center=(0, 0, 20), half_extent=6.0, azimuth_deg=az)
@@ -29,7 +30,7 @@ frames = [syn.synth_frames_torch(F, size, size, first=100 * c) for c in range(4)
 pipe = engine.FramePipeline(4, size, size, v.shape[0])
 for c in range(4):
     pipe.set_projection(c, pix[c], w[c])
-rows_t = torch.empty((v.shape[0], F), dtype=torch.float32, device="cuda")
+rows_t = torch.empty((v.shape[0], engine.series_ld(F)), dtype=torch.float32, device="cuda")[:, :F]
 for r in range(3):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     pipe.process(frames, 0, rows_t=rows_t, want_rows=False)
