@@ -378,41 +378,38 @@ __global__ void __launch_bounds__(256)
     }
 }
 
-// hal::LU32f-based inverse (cv::Mat::inv, DECOMP_LU) of a 6x6 float matrix
-__device__ bool inv6(const float *Ain, float *inv)
+// hal::LU32f-based inverse (cv::Mat::inv, DECOMP_LU) of a 6x6 float matrix.  A (in place) and b
+// are work arrays of 36 floats each in LDS: the pivoting indexes them dynamically, and private
+// arrays with dynamic indices live in scratch (global memory) -- the one lane that runs this
+// was spending most of the solve kernel's 31 us there.
+__device__ bool inv6(float *A, float *b)
 {
-    float A[6][6], b[6][6];
     for (int i = 0; i < 6; ++i)
-        for (int j = 0; j < 6; ++j) {
-            A[i][j] = Ain[i * 6 + j];
-            b[i][j] = i == j ? 1.f : 0.f;
-        }
+        for (int j = 0; j < 6; ++j) b[i * 6 + j] = i == j ? 1.f : 0.f;
     const float eps = FLT_EPSILON * 10;
     for (int i = 0; i < 6; ++i) {
         int k = i;
         for (int j = i + 1; j < 6; ++j)
-            if (fabsf(A[j][i]) > fabsf(A[k][i])) k = j;
-        if (fabsf(A[k][i]) < eps) return false;
+            if (fabsf(A[j * 6 + i]) > fabsf(A[k * 6 + i])) k = j;
+        if (fabsf(A[k * 6 + i]) < eps) return false;
         if (k != i) {
-            for (int j = i; j < 6; ++j) { const float t = A[i][j]; A[i][j] = A[k][j]; A[k][j] = t; }
-            for (int j = 0; j < 6; ++j) { const float t = b[i][j]; b[i][j] = b[k][j]; b[k][j] = t; }
+            for (int j = i; j < 6; ++j) { const float t = A[i * 6 + j]; A[i * 6 + j] = A[k * 6 + j]; A[k * 6 + j] = t; }
+            for (int j = 0; j < 6; ++j) { const float t = b[i * 6 + j]; b[i * 6 + j] = b[k * 6 + j]; b[k * 6 + j] = t; }
         }
-        const float d = -1 / A[i][i];
+        const float d = -1 / A[i * 6 + i];
         for (int j = i + 1; j < 6; ++j) {
-            const float alpha = A[j][i] * d;
-            for (int kk = i + 1; kk < 6; ++kk) A[j][kk] += alpha * A[i][kk];
-            for (int kk = 0; kk < 6; ++kk) b[j][kk] += alpha * b[i][kk];
+            const float alpha = A[j * 6 + i] * d;
+            for (int kk = i + 1; kk < 6; ++kk) A[j * 6 + kk] += alpha * A[i * 6 + kk];
+            for (int kk = 0; kk < 6; ++kk) b[j * 6 + kk] += alpha * b[i * 6 + kk];
         }
     }
     for (int i = 5; i >= 0; --i)
         for (int j = 0; j < 6; ++j) {
-            float s = b[i][j];
-            for (int k = i + 1; k < 6; ++k) s -= A[i][k] * b[k][j];
-            b[i][j] = s / A[i][i];
+            float s = b[i * 6 + j];
+            for (int k = i + 1; k < 6; ++k) s -= A[i * 6 + k] * b[k * 6 + j];
+            b[i * 6 + j] = s / A[i * 6 + i];
         }
-    for (int i = 0; i < 6; ++i)
-        for (int j = 0; j < 6; ++j) inv[i * 6 + j] = b[i][j];
-    return true;
+    return true;   // b holds the inverse
 }
 
 // One lane per frame: the body of the cv::findTransformECC iteration after the
@@ -446,7 +443,8 @@ __global__ void __launch_bounds__(256)
     const double sdw = sqrt(vw > 0 ? vw : 0), sdt = sqrt(vt > 0 ? vt : 0);
     const double tmpNorm = sqrt(n * sdt * sdt), imgNorm = sqrt(n * sdw * sdw);
     const double corr = S[5] - n * mt * mw;
-    float Hf[36], Hinv[36], ipf[6], tpf[6];
+    __shared__ float Hf[36], Hinv[36];
+    float ipf[6], tpf[6];
     int h = 24;
     for (int a = 0; a < 6; ++a) {
         ipf[a] = (float)(S[6 + a] - mw * S[12 + a]);
