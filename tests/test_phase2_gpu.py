@@ -126,3 +126,34 @@ def test_phase2_errors(gpu_lib):
         engine.phase2_pressure(I, np.ones(4), np.ones(4), [1, 0, 0, 0, 0, 0], 1.0, 1.0, degree=9)
     with pytest.raises(ValueError):
         engine.phase2_pressure(I, np.ones(3), np.ones(4), [1, 0, 0, 0, 0, 0], 1.0, 1.0)
+
+
+def test_phase2_full_size_properties(gpu_lib):
+    """BASELINE size (500 958 nodes x 1000 frames): size-independent properties.
+    * a series that IS a polynomial of degree <= 6 in f/F is removed completely (delta-Cp ~ 0);
+    * delta-Cp is linear in the gain and invariant under scaling I and Iref together;
+    * rms^2 == mean(cp^2) of the stored rows."""
+    import torch
+    from upsp_processing_amd import engine
+    n, F = 500958, 1000
+    g = torch.Generator(device="cuda").manual_seed(7)
+    t = torch.arange(F, device="cuda", dtype=torch.float64) / F
+    c = torch.rand((n, 4), device="cuda", generator=g, dtype=torch.float64)
+    poly = 1.0 + 0.05 * c[:, :1] * t[None] - 0.04 * c[:, 1:2] * t[None] ** 3 + 0.02 * c[:, 2:3] * t[None] ** 6
+    I = (1500.0 / poly).to(torch.float32)                     # Iref / I = poly (up to float rounding)
+    iref = torch.full((n,), 1500.0, device="cuda")
+    cov = torch.ones(n, device="cuda")
+    cal = [1.0, 0, 0, 0, 0, 0]
+    r = engine.phase2_pressure(I, iref, cov, cal, 144.0, 1000.0)          # gain 1, 144/q = 1
+    assert float(r["pressure_t"].abs().max()) < 5e-6                       # float rounding of y only
+    # linear in the gain, invariant under a common scale of I and Iref
+    noise = 1.0 + 0.01 * torch.randn((n, F), device="cuda", generator=g)
+    I2 = (I * noise).contiguous()
+    a = engine.phase2_pressure(I2, iref, cov, cal, 144.0, 1000.0)
+    b = engine.phase2_pressure(I2, iref, cov, [2.0, 0, 0, 0, 0, 0], 144.0, 1000.0)
+    assert torch.equal(b["pressure_t"], 2.0 * a["pressure_t"])             # power of two: exact
+    s = engine.phase2_pressure((I2 * 2.0).contiguous(), iref * 2.0, cov, cal, 144.0, 1000.0)
+    assert torch.equal(s["pressure_t"], a["pressure_t"])
+    ms = (a["pressure_t"].double() ** 2).mean(1)
+    assert torch.allclose(a["rms"].double() ** 2, ms, rtol=1e-5, atol=1e-12)
+    assert float(a["rms"].mean()) > 1e-3
