@@ -125,3 +125,24 @@ def test_full_size_frame_loop_properties(gpu_lib):
     ok = pix >= 0
     assert torch.allclose(avg[ok], ref[:, ok].double().mean(0).float(), rtol=1e-6)
     assert torch.allclose(rms[ok], ref[:, ok].double().pow(2).mean(0).sqrt().float(), rtol=1e-6)
+
+
+def test_hot_pixels_saturated_frames(gpu_lib, oracle):
+    """Frames with very many pixels >= thresh (saturation) stay untouched (count > max_hot) and do
+    not stall the scan; mixed with repairable frames in the same batch."""
+    import torch
+    from upsp_processing_amd import engine
+    rng = np.random.default_rng(77)
+    fr = rng.integers(100, 3000, (6, 256, 320)).astype(np.uint16)
+    fr[1, 40:200, 10:300] = 4095                      # ~46k saturated pixels
+    fr[3][rng.random((256, 320)) < 0.2] = 4090        # scattered
+    fr[2, 17, 23] = 4095                              # repairable
+    fr[4, 0, 0] = 4095
+    fr[4, 255, 319] = 4080
+    res = [oracle.fix_hot_pixels(fr[i]) for i in range(6)]
+    want = np.stack([r[0] for r in res])
+    wst = [int(r[1]) for r in res]
+    d = torch.as_tensor(fr).cuda()
+    st = engine.fix_hot_pixels(d).cpu().numpy()
+    assert np.array_equal(d.cpu().numpy(), want)
+    assert st.tolist() == wst and st[1] == -1 and st[3] == -1 and st[2] == 1

@@ -48,6 +48,10 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
         for (int k = 0; k < 4; ++k) any |= ((w[k] & 0xFFFFu) >= th) | ((w[k] >> 16) >= th);
         if (any) {
+            // a saturated frame holds thousands of such pixels; once the (monotonic) counter is
+            // past max_hot the verdict "too many, leave the frame alone" is settled and further
+            // same-address atomics would only serialise (~88 per us)
+            if (__hip_atomic_load(&count[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (unsigned)max_hot) return;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const unsigned px = (w[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
