@@ -125,6 +125,10 @@ int upsp_pipeline_create(int ncams, int width, int height, size_t nnodes,
     const size_t per_frame = (size_t)width * height * (size_t)ncams *
                              (2 + ((p->opts.patch || p->opts.filter) ? 4 : 0));
     size_t b = (p->opts.registration ? (512u << 20) : (128u << 20)) / std::max<size_t>(per_frame, 1);
+    // plain projection path: always a full 64-frame tile.  With several cameras the frames of a
+    // sub-batch no longer fit the Infinity Cache, but short tiles cost more than the misses
+    // (4 cameras, 5 M triangles: 0.84 / 0.65 / 0.57 ms per 64 frame sets at 16 / 32 / 64 frames)
+    if (!(p->opts.registration || p->opts.patch || p->opts.filter)) b = 64;
     static const int batch_env = std::getenv("UPSP_BATCH") ? std::atoi(std::getenv("UPSP_BATCH")) : 0;
     if (batch_env > 0) b = (size_t)batch_env;
     p->batch = (int)std::min<size_t>(std::max<size_t>(b, 1), 64);
