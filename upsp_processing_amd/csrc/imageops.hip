@@ -430,42 +430,74 @@ __global__ void __launch_bounds__(256)
     __syncthreads();
     if (threadIdx.x < kEccSums) {
         const double v = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
-        partial[((size_t)f * gridDim.x + blockIdx.x) * kEccSums + threadIdx.x] = v;
+        // [frame][sum][block]: the solve kernel reads one sum over all blocks with coalesced loads
+        partial[((size_t)f * kEccSums + threadIdx.x) * kEccBlocksMax + blockIdx.x] = v;
     }
 }
 
-// hal::LU32f-based inverse (cv::Mat::inv, DECOMP_LU) of a 6x6 float matrix.  A (in place) and b
-// are work arrays of 36 floats each in LDS: the pivoting indexes them dynamically, and private
-// arrays with dynamic indices live in scratch (global memory) -- the one lane that runs this
-// was spending most of the solve kernel's 31 us there.
-__device__ bool inv6(float *A, float *b)
+// hal::LU32f-based inverse (cv::Mat::inv, DECOMP_LU) of a 6x6 float matrix, same operations in
+// the same order.  Everything is unrolled with compile-time indices (the row exchange of the
+// partial pivoting is a select over the candidate rows), so both matrices live in registers: the
+// one lane that runs this was spending ~25 us per call on dependent scratch / LDS round trips.
+__device__ bool inv6(const float *Ain, float *inv)
 {
+    float A[6][6], b[6][6];
+#pragma unroll
     for (int i = 0; i < 6; ++i)
-        for (int j = 0; j < 6; ++j) b[i * 6 + j] = i == j ? 1.f : 0.f;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            A[i][j] = Ain[i * 6 + j];
+            b[i][j] = i == j ? 1.f : 0.f;
+        }
     const float eps = FLT_EPSILON * 10;
+    bool ok = true;
+#pragma unroll
     for (int i = 0; i < 6; ++i) {
         int k = i;
-        for (int j = i + 1; j < 6; ++j)
-            if (fabsf(A[j * 6 + i]) > fabsf(A[k * 6 + i])) k = j;
-        if (fabsf(A[k * 6 + i]) < eps) return false;
-        if (k != i) {
-            for (int j = i; j < 6; ++j) { const float t = A[i * 6 + j]; A[i * 6 + j] = A[k * 6 + j]; A[k * 6 + j] = t; }
-            for (int j = 0; j < 6; ++j) { const float t = b[i * 6 + j]; b[i * 6 + j] = b[k * 6 + j]; b[k * 6 + j] = t; }
-        }
-        const float d = -1 / A[i * 6 + i];
+        float best = fabsf(A[i][i]);
+#pragma unroll
         for (int j = i + 1; j < 6; ++j) {
-            const float alpha = A[j * 6 + i] * d;
-            for (int kk = i + 1; kk < 6; ++kk) A[j * 6 + kk] += alpha * A[i * 6 + kk];
-            for (int kk = 0; kk < 6; ++kk) b[j * 6 + kk] += alpha * b[i * 6 + kk];
+            const float v = fabsf(A[j][i]);
+            if (v > best) { best = v; k = j; }
+        }
+        if (best < eps) ok = false;
+#pragma unroll
+        for (int r = i + 1; r < 6; ++r) {           // rows i <-> k, k known only at run time
+            const bool sw = k == r;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const float ta = A[i][c], tb = b[i][c];
+                A[i][c] = sw ? A[r][c] : ta;
+                A[r][c] = sw ? ta : A[r][c];
+                b[i][c] = sw ? b[r][c] : tb;
+                b[r][c] = sw ? tb : b[r][c];
+            }
+        }
+        const float d = -1 / A[i][i];
+#pragma unroll
+        for (int j = i + 1; j < 6; ++j) {
+            const float alpha = A[j][i] * d;
+#pragma unroll
+            for (int kk = i + 1; kk < 6; ++kk) A[j][kk] += alpha * A[i][kk];
+#pragma unroll
+            for (int kk = 0; kk < 6; ++kk) b[j][kk] += alpha * b[i][kk];
         }
     }
+    if (!ok) return false;
+#pragma unroll
     for (int i = 5; i >= 0; --i)
+#pragma unroll
         for (int j = 0; j < 6; ++j) {
-            float s = b[i * 6 + j];
-            for (int k = i + 1; k < 6; ++k) s -= A[i * 6 + k] * b[k * 6 + j];
-            b[i * 6 + j] = s / A[i * 6 + i];
+            float sacc = b[i][j];
+#pragma unroll
+            for (int k = i + 1; k < 6; ++k) sacc -= A[i][k] * b[k][j];
+            b[i][j] = sacc / A[i][i];
         }
-    return true;   // b holds the inverse
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) inv[i * 6 + j] = b[i][j];
+    return true;
 }
 
 // One lane per frame: the body of the cv::findTransformECC iteration after the
@@ -485,7 +517,8 @@ __global__ void __launch_bounds__(256)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int k = wave; k < kEccSums; k += 4) {
         double v = 0.0;
-        for (int b = lane; b < nblocks; b += 64) v += partial[((size_t)f * nblocks + b) * kEccSums + k];
+        const double *pk = partial + ((size_t)f * kEccSums + k) * kEccBlocksMax;
+        for (int b = lane; b < nblocks; b += 64) v += pk[b];
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
         if (lane == 0) Ssh[k] = v;
     }
@@ -499,8 +532,7 @@ __global__ void __launch_bounds__(256)
     const double sdw = sqrt(vw > 0 ? vw : 0), sdt = sqrt(vt > 0 ? vt : 0);
     const double tmpNorm = sqrt(n * sdt * sdt), imgNorm = sqrt(n * sdw * sdw);
     const double corr = S[5] - n * mt * mw;
-    __shared__ float Hf[36], Hinv[36];
-    float ipf[6], tpf[6];
+    float Hf[36], Hinv[36], ipf[6], tpf[6];
     int h = 24;
     for (int a = 0; a < 6; ++a) {
         ipf[a] = (float)(S[6 + a] - mw * S[12 + a]);
