@@ -38,7 +38,7 @@ struct upsp_pipeline {
     upsp::PatchTables *patches[kMaxCams] = {nullptr};
     upsp::FrameScratch *scratch = nullptr;
     int batch = 32;
-    // second stream: the gather of sub-batch k overlaps the hot-pixel scan of k+1
+    // optional second stream (UPSP_OVERLAP=1): the gather of sub-batch k overlaps the scan of k+1
     hipStream_t aux = nullptr;
     hipEvent_t ev_in = nullptr, ev_fix[2] = {nullptr, nullptr}, ev_out = nullptr;
 };
