@@ -351,6 +351,17 @@ int upsp_phase2_pressure(const float *d_intensity_t, long long ld_in, size_t nno
 int upsp_nearest_nodes(const float *d_nodes3, size_t nnodes, const double *d_query3, size_t nqueries,
                        int32_t *d_index, double *d_dist2, void *stream);
 
+/* upsp::interpolate (cpp/lib/interpolation.ipp:16-70): inverse-distance weighting over the k
+ * nearest source nodes (ascending distance, float accumulation, exact hit -> that value), used to
+ * carry a structured steady-state solution onto an unstructured model grid
+ * (cpp/exec/psp_process.cpp:2341-2344, 2374-2377: k = 10, p = 2).  Source nodes / data are HOST
+ * arrays (binned into a uniform grid here, once), queries and result live on the device.
+ * d_neighbors (optional) [nquery][k] receives the neighbour ids (-1 padded).  k <= 16.
+ * Waits for `stream` before returning. */
+int upsp_interpolate_idw(const float *h_src_nodes3, const float *h_src_data, size_t nsrc,
+                         const float *d_query_nodes3, size_t nquery, int k, float p, float *d_out,
+                         int32_t *d_neighbors, void *stream);
+
 /* ======================================================================== *
  *  4.  Measurement support (no reference counterpart; the reference only has
  *      psp::BlockTimer / timedBarrierPoint wall-clock prints, pspTimer.h:10-41)

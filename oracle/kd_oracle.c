@@ -155,3 +155,38 @@ void orc_kd_nearest_batch(const orc_kdtree *t, const double *query3, size_t nq, 
 {
     for (size_t q = 0; q < nq; ++q) index[q] = orc_kd_nearest(t, &query3[3 * q], dist2 ? &dist2[q] : NULL);
 }
+
+/* upsp::interpolate, cpp/lib/interpolation.ipp:16-70 (+ nearest_k_neighbors, cpp/lib/models.ipp:503-571),
+ * exhaustive: k nearest by (distance, index) ascending, inverse-distance weights, float sums.
+ * PARITY UNPINNED: the reference's test for it is disabled (cpp/test/run_tests.cpp:15). */
+void orc_interpolate_idw(const float *src3, const float *data, size_t nsrc, const float *q3, size_t nq,
+                         int k, float p, float *out, int32_t *nbr)
+{
+    double *bd = (double *)malloc(sizeof(double) * (size_t)k);
+    int32_t *bi = (int32_t *)malloc(sizeof(int32_t) * (size_t)k);
+    for (size_t q = 0; q < nq; ++q) {
+        int have = 0;
+        for (size_t n = 0; n < nsrc; ++n) {
+            const float dx = q3[3 * q] - src3[3 * n], dy = q3[3 * q + 1] - src3[3 * n + 1], dz = q3[3 * q + 2] - src3[3 * n + 2];
+            const double d = sqrt((double)dx * dx + (double)dy * dy + (double)dz * dz);
+            if (have < k || d < bd[have - 1]) {
+                int j = have < k ? have : k - 1;
+                while (j > 0 && bd[j - 1] > d) { bd[j] = bd[j - 1]; bi[j] = bi[j - 1]; --j; }
+                bd[j] = d; bi[j] = (int32_t)n;
+                if (have < k) ++have;
+            }
+        }
+        float acc = 0.0f, total = 0.0f;
+        for (int j = 0; j < have; ++j) {
+            const float dist = (float)bd[j];
+            if (dist == 0.0f) { total = 1.0f; acc = data[bi[j]]; break; }
+            const float pw = p == 2.0f ? dist * dist : powf(dist, p);   /* = correctly rounded pow(dist, 2) */
+            const float w = (float)(1.0 / (double)pw);
+            acc += data[bi[j]] * w;
+            total += w;
+        }
+        out[q] = acc / total;
+        if (nbr) for (int j = 0; j < k; ++j) nbr[q * (size_t)k + j] = j < have ? bi[j] : -1;
+    }
+    free(bd); free(bi);
+}

@@ -111,6 +111,8 @@ _OPTIONAL = [
     ("orc_polyfit2d", [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p], C.c_int),
     ("orc_polyval2d", [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p], None),
     ("orc_patch_clusters", [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6, None),
+    ("orc_interpolate_idw", [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_float,
+                             C.c_void_p, C.c_void_p], None),
     ("orc_kd_build", [C.c_void_p, C.c_size_t], C.c_void_p),
     ("orc_kd_free", [C.c_void_p], None),
     ("orc_kd_nearest_batch", [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p], None),
@@ -578,3 +580,14 @@ def patch_tables(uv, diam, order, cl_off, size, bound_pts=2, buffer=1, ref=None,
             lib().orc_free(p)
     return [dict(bx=bx[b_off[c]:b_off[c + 1]], by=by[b_off[c]:b_off[c + 1]],
                  ix=ix[i_off[c]:i_off[c + 1]], iy=iy[i_off[c]:i_off[c + 1]]) for c in range(ncl)]
+
+
+def interpolate_idw(src_nodes, src_data, query_nodes, k=10, p=2.0):
+    """upsp::interpolate restated exhaustively: returns (values f32 [Q], neighbours int32 [Q,k])."""
+    src = _f32(src_nodes).reshape(-1, 3)
+    data = _f32(src_data).reshape(-1)
+    q = _f32(query_nodes).reshape(-1, 3)
+    out = np.zeros(q.shape[0], np.float32)
+    nbr = np.zeros((q.shape[0], k), np.int32)
+    lib().orc_interpolate_idw(_p(src), _p(data), src.shape[0], _p(q), q.shape[0], int(k), float(p), _p(out), _p(nbr))
+    return out, nbr

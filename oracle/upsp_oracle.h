@@ -217,6 +217,9 @@ typedef struct orc_kdtree orc_kdtree;
 orc_kdtree *orc_kd_build(const float *nodes3, size_t n);
 void orc_kd_free(orc_kdtree *t);
 int32_t orc_kd_nearest(const orc_kdtree *t, const double pos[3], double *dist2_out);
+/* upsp::interpolate, cpp/lib/interpolation.ipp:16-70 (exhaustive k-nearest + IDW). PARITY UNPINNED. */
+void orc_interpolate_idw(const float *src3, const float *data, size_t nsrc, const float *q3, size_t nq,
+                         int k, float p, float *out, int32_t *nbr);
 void orc_kd_nearest_batch(const orc_kdtree *t, const double *query3, size_t nq, int32_t *index,
                           double *dist2);
 

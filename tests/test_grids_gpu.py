@@ -124,3 +124,33 @@ def test_cli_plot3d_wind_on(gpu_lib, oracle, tmp_path):
     with pytest.raises(cli.DeckError):
         cli.main(["-input_file=%s/run.inp" % tmp, "-h5_out=x", "-paint_cal=%s/paint.cal" % tmp,
                   "-steady_p3d=%s/paint.cal" % tmp])
+
+
+def test_cli_tri_model_wind_on_interpolated(gpu_lib, oracle, tmp_path):
+    """.tri model + structured steady grid: steady-state Cp interpolated onto the model nodes
+    (upsp::interpolate, k = 10, p = 2) and written to steady_state."""
+    import struct
+    from upsp_processing_amd import grids, psp_process as cli
+    from test_cli import write_case
+    tmp = str(tmp_path)
+    v, t, cams = write_case(tmp, nframes=8)
+    J, K = 60, 30
+    th, ph = np.meshgrid(np.linspace(0, 2 * np.pi, J), np.linspace(0.05, np.pi - 0.05, K))
+    sg = dict(zones=[(J, K, 1)], x=(6 * np.cos(ph)).ravel().astype(np.float32),
+              y=(np.sin(ph) * np.cos(th)).ravel().astype(np.float32), z=(np.sin(ph) * np.sin(th)).ravel().astype(np.float32))
+    grids.write_plot3d_grid(os.path.join(tmp, "steady.x"), sg)
+    cp = (0.5 * np.cos(ph) ** 2 - 0.2).ravel().astype(np.float32)
+    with open(os.path.join(tmp, "steady.f"), "wb") as f:
+        f.write(struct.pack("<i", 1) + struct.pack("<iiii", J, K, 1, 1) + cp.tobytes())
+    deck = open(os.path.join(tmp, "run.inp")).read().replace("@all\n", "@all\n  sds = %s/run.wtd\n" % tmp)
+    open(os.path.join(tmp, "run.inp"), "w").write(deck)
+    open(os.path.join(tmp, "run.wtd"), "w").write("#  MACH TTF PS Q TCAVG\n0.85 95.0 1300.0 620.0 68.0\n")
+    open(os.path.join(tmp, "paint.cal"), "w").write("a = 0.9\nb = -0.002\nd = 0.0008\n")
+    args = ["-input_file=%s/run.inp" % tmp, "-h5_out=x", "-paint_cal=%s/paint.cal" % tmp, "-steady_p3d=%s/steady.f" % tmp]
+    with pytest.raises(cli.DeckError):
+        cli.main(args)                                              # .tri model: needs -steady_grid
+    assert cli.main(args + ["-steady_grid=%s/steady.x" % tmp]) == 0
+    nodes = np.stack([sg["x"], sg["y"], sg["z"]], axis=1)
+    want, _ = oracle.interpolate_idw(nodes, cp, v, 10, 2.0)
+    got = np.fromfile(os.path.join(tmp, "out", "steady_state"), "<f4")
+    assert np.array_equal(got.view(np.int32), want.view(np.int32))

@@ -98,6 +98,7 @@ SIGNATURES = {
     "upsp_phase2_pressure": (_i, [_vp, C.c_longlong, _sz, _i, _vp, _vp, _vp, _vp, C.c_float, _vp,
                                   C.c_float, C.c_float, _i, _vp, C.c_longlong, _vp, _vp, _vp, _vp, _vp, _vp]),
     "upsp_bvh_set_tri_nodes": (_i, [_vp, _vp, _sz, _vp]),
+    "upsp_interpolate_idw": (_i, [_vp, _vp, _sz, _vp, _sz, _i, C.c_float, _vp, _vp, _vp]),
     "upsp_nearest_nodes": (_i, [_vp, _sz, _vp, _sz, _vp, _vp, _vp]),
     "upsp_timing_enable": (_i, [_i]),
     "upsp_timing_report": (_i, [C.c_char_p, _sz]),

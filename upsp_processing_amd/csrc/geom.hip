@@ -16,6 +16,10 @@
 // kd-tree returns whichever its traversal meets first and this scan returns the lowest index.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
 #include "ktimer.h"
 #include "upsp_internal.h"
 
@@ -121,6 +125,191 @@ extern "C" int upsp_nearest_nodes(const float *d_nodes3, size_t nnodes, const do
     }
     hipError_t e = hipGetLastError();
     (void)hipFreeAsync(partial, st);
+    if (e != hipSuccess) return fail(UPSP_ERR_HIP, hipGetErrorString(e));
+    return UPSP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// upsp::interpolate (cpp/lib/interpolation.ipp:16-70): values on the nodes of one grid carried to
+// the nodes of another by inverse-distance weighting over the k nearest source nodes
+// (nearest_k_neighbors, cpp/lib/models.ipp:503-571: best-first octree search, neighbours come out
+// in ascending distance).  psp_process uses it to put a structured steady-state Cp / temperature
+// solution onto an unstructured model grid (k = 10, p = 2; psp_process.cpp:2341-2344, 2374-2377).
+//
+// Source nodes are binned into a uniform grid on the host (counting sort, once); one query per
+// lane walks cubic shells of cells outwards and keeps the k best candidates sorted in registers;
+// it stops when the k-th distance cannot be beaten by any unvisited shell.
+namespace upsp {
+namespace {
+
+constexpr int kMaxK = 16;
+
+struct CellGrid {
+    float lo[3], inv_cell;
+    int dim[3];
+    const unsigned *cell_start;   // [ncells + 1]
+    const unsigned *cell_pts;     // source node ids, grouped by cell
+};
+
+__global__ void __launch_bounds__(256)
+    idw_kernel(CellGrid g, const float *__restrict__ src_nodes, const float *__restrict__ src_data,
+               const float *__restrict__ q_nodes, unsigned nq, int k, float p, float *__restrict__ out,
+               int32_t *__restrict__ nbr_out)
+{
+    const unsigned q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const float px = q_nodes[3 * (size_t)q], py = q_nodes[3 * (size_t)q + 1], pz = q_nodes[3 * (size_t)q + 2];
+    double bd[kMaxK];
+    int bi[kMaxK];
+    int have = 0;
+    const float cell = 1.0f / g.inv_cell;
+    int c[3];
+    c[0] = min(max((int)floorf((px - g.lo[0]) * g.inv_cell), 0), g.dim[0] - 1);
+    c[1] = min(max((int)floorf((py - g.lo[1]) * g.inv_cell), 0), g.dim[1] - 1);
+    c[2] = min(max((int)floorf((pz - g.lo[2]) * g.inv_cell), 0), g.dim[2] - 1);
+    // distance from the query to the border of its (clamped) cell block of radius r is at least
+    // r * cell - (offset inside / outside the home cell); use the conservative bound below
+    const float off = fmaxf(fmaxf(fabsf(px - (g.lo[0] + (c[0] + 0.5f) * cell)), fabsf(py - (g.lo[1] + (c[1] + 0.5f) * cell))),
+                            fabsf(pz - (g.lo[2] + (c[2] + 0.5f) * cell)));
+    const int rmax = max(max(g.dim[0], g.dim[1]), g.dim[2]);
+    for (int r = 0; r <= rmax; ++r) {
+        for (int dz = -r; dz <= r; ++dz) {
+            const int z = c[2] + dz;
+            if (z < 0 || z >= g.dim[2]) continue;
+            for (int dy = -r; dy <= r; ++dy) {
+                const int y = c[1] + dy;
+                if (y < 0 || y >= g.dim[1]) continue;
+                const bool face = (abs(dz) == r) || (abs(dy) == r);
+                for (int dx = -r; dx <= r; dx += (face ? 1 : 2 * r > 0 ? 2 * r : 1)) {   // shell cells only
+                    const int x = c[0] + dx;
+                    if (x < 0 || x >= g.dim[0]) continue;
+                    const size_t ci = ((size_t)z * g.dim[1] + y) * g.dim[0] + x;
+                    for (unsigned e = g.cell_start[ci]; e < g.cell_start[ci + 1]; ++e) {
+                        const int n = (int)g.cell_pts[e];
+                        // cv::norm(pos - node): double sqrt of the float differences' squares
+                        const float ddx = px - src_nodes[3 * (size_t)n], ddy = py - src_nodes[3 * (size_t)n + 1],
+                                    ddz = pz - src_nodes[3 * (size_t)n + 2];
+                        const double d = sqrt((double)ddx * ddx + (double)ddy * ddy + (double)ddz * ddz);
+                        if (have < k || d < bd[have - 1] || (d == bd[have - 1] && n < bi[have - 1])) {
+                            int j = have < k ? have : k - 1;      // insertion, ascending (distance, index)
+                            while (j > 0 && (bd[j - 1] > d || (bd[j - 1] == d && bi[j - 1] > n))) {
+                                bd[j] = bd[j - 1];
+                                bi[j] = bi[j - 1];
+                                --j;
+                            }
+                            bd[j] = d;
+                            bi[j] = n;
+                            if (have < k) ++have;
+                        }
+                    }
+                }
+            }
+        }
+        // every unvisited point is farther than this from the query
+        const float reach = (r + 0.5f) * cell - off;
+        if (have == k && bd[k - 1] <= (double)reach) break;
+    }
+    // inverse-distance weighting in float, neighbours in ascending distance (interpolation.ipp:46-64)
+    float acc = 0.0f, total = 0.0f;
+    for (int j = 0; j < have; ++j) {
+        const float dist = (float)bd[j];
+        if (dist == 0.0f) {
+            total = 1.0f;
+            acc = src_data[bi[j]];
+            break;
+        }
+        // pow(dist, 2) is dist * dist rounded once -- what a correctly rounded pow returns
+        const float pw = p == 2.0f ? dist * dist : powf(dist, p);
+        const float weight = (float)(1.0 / (double)pw);
+        acc += src_data[bi[j]] * weight;
+        total += weight;
+    }
+    out[q] = acc / total;
+    if (nbr_out)
+        for (int j = 0; j < k; ++j) nbr_out[(size_t)q * k + j] = j < have ? bi[j] : -1;
+}
+
+}  // namespace
+}  // namespace upsp
+
+extern "C" int upsp_interpolate_idw(const float *h_src_nodes3, const float *h_src_data, size_t nsrc,
+                                    const float *d_query_nodes3, size_t nquery, int k, float p,
+                                    float *d_out, int32_t *d_neighbors, void *stream)
+{
+    if (nquery == 0) return UPSP_OK;
+    if (!h_src_nodes3 || !h_src_data || !d_query_nodes3 || !d_out) return fail(UPSP_ERR_INVALID, "null buffer");
+    if (nsrc == 0) return fail(UPSP_ERR_INVALID, "no source nodes");
+    if (k < 1 || k > kMaxK) return fail(UPSP_ERR_INVALID, "k must be in [1,16]");
+    if (nsrc > 0x7ffffff0ull || nquery > 0xfffffff0ull) return fail(UPSP_ERR_INVALID, "too many nodes");
+    hipStream_t st = (hipStream_t)stream;
+    // uniform grid with ~4 source nodes per cell on average (cubic cells)
+    float lo[3] = {h_src_nodes3[0], h_src_nodes3[1], h_src_nodes3[2]}, hi[3] = {lo[0], lo[1], lo[2]};
+    for (size_t i = 0; i < nsrc; ++i)
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::min(lo[a], h_src_nodes3[3 * i + a]);
+            hi[a] = std::max(hi[a], h_src_nodes3[3 * i + a]);
+        }
+    double ext[3];
+    for (int a = 0; a < 3; ++a) ext[a] = std::max((double)hi[a] - lo[a], 1e-6);
+    // surface grids are ~2-D: size the cells from the two largest extents
+    double e_sorted[3] = {ext[0], ext[1], ext[2]};
+    std::sort(e_sorted, e_sorted + 3);
+    const double area = e_sorted[2] * e_sorted[1];
+    float cell = (float)std::sqrt(area * 4.0 / (double)nsrc);
+    if (!(cell > 0)) cell = 1.0f;
+    CellGrid g;
+    size_t ncells = 1;
+    for (;;) {
+        ncells = 1;
+        for (int a = 0; a < 3; ++a) {
+            g.dim[a] = std::max(1, (int)std::floor(ext[a] / cell) + 1);
+            ncells *= (size_t)g.dim[a];
+        }
+        if (ncells <= (size_t)64 * 1024 * 1024) break;
+        cell *= 1.26f;
+    }
+    for (int a = 0; a < 3; ++a) g.lo[a] = lo[a];
+    g.inv_cell = 1.0f / cell;
+    std::vector<unsigned> start(ncells + 1, 0u), pts(nsrc), cell_of(nsrc);
+    for (size_t i = 0; i < nsrc; ++i) {
+        size_t ci = 0, mul = 1;
+        for (int a = 0; a < 3; ++a) {
+            const int c = std::min(std::max((int)std::floor((h_src_nodes3[3 * i + a] - lo[a]) * g.inv_cell), 0), g.dim[a] - 1);
+            ci += (size_t)c * mul;
+            mul *= (size_t)g.dim[a];
+        }
+        cell_of[i] = (unsigned)ci;
+        ++start[ci + 1];
+    }
+    for (size_t c = 0; c < ncells; ++c) start[c + 1] += start[c];
+    {
+        std::vector<unsigned> fill(start.begin(), start.end() - 1);
+        for (size_t i = 0; i < nsrc; ++i) pts[fill[cell_of[i]]++] = (unsigned)i;   // ascending ids inside a cell
+    }
+    unsigned *d_start = nullptr, *d_pts = nullptr;
+    float *d_src = nullptr, *d_data = nullptr;
+    hipError_t e = hipMalloc(&d_start, start.size() * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc(&d_pts, pts.size() * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc(&d_src, nsrc * 3 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&d_data, nsrc * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_start, start.data(), start.size() * sizeof(unsigned), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_pts, pts.data(), pts.size() * sizeof(unsigned), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_src, h_src_nodes3, nsrc * 3 * sizeof(float), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_data, h_src_data, nsrc * sizeof(float), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        g.cell_start = d_start;
+        g.cell_pts = d_pts;
+        KTimed kt("idw_kernel", st);
+        hipLaunchKernelGGL(idw_kernel, dim3((unsigned)((nquery + 255) / 256)), dim3(256), 0, st, g,
+                           (const float *)d_src, (const float *)d_data, d_query_nodes3, (unsigned)nquery, k, p,
+                           d_out, d_neighbors);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);    // host vectors and temporaries go away
+    if (d_start) (void)hipFree(d_start);
+    if (d_pts) (void)hipFree(d_pts);
+    if (d_src) (void)hipFree(d_src);
+    if (d_data) (void)hipFree(d_data);
     if (e != hipSuccess) return fail(UPSP_ERR_HIP, hipGetErrorString(e));
     return UPSP_OK;
 }

@@ -493,3 +493,20 @@ def nearest_nodes(nodes, queries, want_dist=False):
     check(lib().upsp_nearest_nodes(_ptr(nodes), nodes.shape[0], _ptr(q), q.shape[0], _ptr(idx),
                                    _ptr(d2), _stream()))
     return (idx, d2) if want_dist else idx
+
+
+def interpolate_idw(src_nodes, src_data, query_nodes, k=10, p=2.0, want_neighbors=False):
+    """upsp::interpolate (cpp/lib/interpolation.ipp:16-70): k-nearest inverse-distance weighting.
+    src_nodes [M,3] / src_data [M]: host arrays; query_nodes [Q,3]: array or device tensor.
+    Returns f32 [Q] on the device (and the neighbour ids int32 [Q,k] if requested)."""
+    src_nodes = np.ascontiguousarray(src_nodes, dtype=np.float32).reshape(-1, 3)
+    src_data = np.ascontiguousarray(src_data, dtype=np.float32).reshape(-1)
+    if src_data.size != src_nodes.shape[0]:
+        raise ValueError("one value per source node")
+    q = _dev(query_nodes, torch.float32).reshape(-1, 3)
+    out = torch.empty(q.shape[0], dtype=torch.float32, device="cuda")
+    nb = torch.empty((q.shape[0], int(k)), dtype=torch.int32, device="cuda") if want_neighbors else None
+    check(lib().upsp_interpolate_idw(src_nodes.ctypes.data_as(C.c_void_p), src_data.ctypes.data_as(C.c_void_p),
+                                     src_nodes.shape[0], _ptr(q), q.shape[0], int(k), C.c_float(p), _ptr(out),
+                                     _ptr(nb), _stream()))
+    return (out, nb) if want_neighbors else out

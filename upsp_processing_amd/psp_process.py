@@ -24,8 +24,8 @@ intensity_ratio_0, coverage, camNN-uv, vv-int-*.dat; cpp/exec/psp_process.cpp:52
 Phase 2 (cpp/exec/psp_process.cpp:2260-2625) runs when `-paint_cal` names a readable file and
 the deck's @all section has `sds` (tunnel conditions): delta-Cp per node and frame ->
 pressure_transpose, rms, avg, gain, steady_state, model_temp, vv-cp-*.dat.  `-steady_p3d` /
-`-model_temp_p3d` (PLOT3D function files) are read for PLOT3D model grids; interpolating a
-structured steady-state solution onto an unstructured grid (upsp::interpolate) is not built.  The HDF5 container is out of scope; `-h5_out` is
+`-model_temp_p3d` (PLOT3D function files) are read directly for PLOT3D model grids and interpolated
+from `-steady_grid` (upsp::interpolate: 10 nearest nodes, inverse-distance weights) for `.tri` models.  The HDF5 container is out of scope; `-h5_out` is
 accepted and ignored.
 """
 import json
@@ -251,17 +251,28 @@ def main(argv=None):
         steady = temp = None
         if flags.get("steady_p3d") or flags.get("model_temp_p3d"):
             # structured models read one scalar per grid point (psp_process.cpp:2327-2335, 2360-2368);
-            # unstructured ones would need upsp::interpolate from the steady grid: not built
-            if overlap_src is None:
-                raise DeckError("-steady_p3d / -model_temp_p3d need a PLOT3D model grid (interpolation onto "
-                                ".tri grids is not built)")
+            # unstructured ones interpolate it from the structured steady grid (-steady_grid) with
+            # upsp::interpolate, k = 10, p = 2 (:2336-2344, 2369-2377)
             from . import grids
+            sgrid = None
+            if overlap_src is None:
+                if not flags.get("steady_grid"):
+                    raise DeckError("-steady_p3d / -model_temp_p3d on a .tri model need -steady_grid")
+                try:
+                    sgrid = grids.P3DModel.from_file(flags["steady_grid"], 1e-3)
+                except (OSError, ValueError) as e:
+                    raise DeckError(str(e))
             for key in ("steady_p3d", "model_temp_p3d"):
                 if flags.get(key):
                     try:
                         vals = grids.read_plot3d_scalar_function_file(flags[key])
                     except (OSError, ValueError) as e:
                         raise DeckError(str(e))
+                    if sgrid is not None:
+                        if vals.size != sgrid.size():
+                            raise DeckError("%s inconsistent with the steady grid (expect %d values, got %d)"
+                                            % (key, sgrid.size(), vals.size))
+                        vals = engine.interpolate_idw(sgrid.nodes(), vals, xyz, 10, 2.0).cpu().numpy()
                     if vals.size != job.nnodes:
                         raise DeckError("%s inconsistent with grid (expect %d values, got %d)"
                                         % (key, job.nnodes, vals.size))
