@@ -129,6 +129,24 @@ class TimeSeriesExchange:
         self.vis_count = None    # rows that travel per destination rank
         self.vis_mine = None     # their positions inside this rank's slice
         self._row_map = None
+        if str(device).startswith("cuda"):
+            self._prewarm(device)
+
+    @staticmethod
+    def _prewarm(device):
+        """Runs every torch operator the exchange uses once on tiny tensors, so that their device
+        code is loaded before the first measured step (lazy module loading costs tens of ms)."""
+        a = torch.zeros(8, dtype=torch.bool, device=device)
+        a[::2] = True
+        v = torch.nonzero(~a, as_tuple=False).reshape(-1)
+        torch.equal(v, v.clone())
+        torch.searchsorted(v, torch.tensor([0, 3, 8], device=device)).cpu()
+        m = torch.full((8,), -1, dtype=torch.int32, device=device)
+        m[v] = torch.arange(v.numel(), dtype=torch.int32, device=device)
+        o = torch.empty((8, 4), dtype=torch.float32, device=device)
+        o.fill_(float("nan"))
+        o[v - 1, 1:3] = torch.ones((v.numel(), 2), device=device)
+        o.index_select(0, v)
 
     def set_skipped(self, skipped):
         """skipped: bool / uint8 [N] on the exchange's device, identical on every rank; None
