@@ -220,6 +220,11 @@ int upsp_pipeline_set_overlap_source(upsp_pipeline *pipe, const int32_t *d_src);
  * rows of nodes no camera sees; the reference's global_transpose, cpp/exec/psp_process.cpp:707-771,
  * moves them).  Accumulators and frame-major rows are unaffected.  NULL = identity. */
 int upsp_pipeline_set_row_map(upsp_pipeline *pipe, const int32_t *d_rowmap);
+
+/* Receiving side of the packed exchange: block d_src [nrows][ncols] f32 (contiguous) is copied
+ * to rows d_rowidx[r] (int64) of d_dst (row pitch ld floats; add the column offset to d_dst). */
+int upsp_scatter_rows_f32(const float *d_src, size_t nrows, int ncols, const int64_t *d_rowidx,
+                          float *d_dst, long long ld, void *stream);
 /* ECC template of camera `cam` = first frame as f32 (elems.first_frames[c],
  * psp_process.cpp:2057-2058). */
 int upsp_pipeline_set_reference(upsp_pipeline *p, int cam, const float *d_ref32f);

@@ -376,6 +376,27 @@ __global__ void finals_kernel(const double *__restrict__ sum, const double *__re
     if (rms) rms[n] = (float)sqrt(sumsq[n] / nframes);     // psp_process.cpp:1935
 }
 
+// Row scatter for the time-series exchange: packed block src [nrows][ncols] -> rows rowidx[r] of
+// dst (row pitch ld, column offset already applied).  One wave per row segment, 16 B per lane.
+__global__ void __launch_bounds__(256)
+    scatter_rows_kernel(const float *__restrict__ src, long long nrows, int ncols,
+                        const long long *__restrict__ rowidx, float *__restrict__ dst, long long ld)
+{
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= nrows) return;
+    const int lane = threadIdx.x & 63;
+    const float *s = src + r * ncols;
+    float *d = dst + rowidx[r] * ld;
+    const bool vec = ((ncols & 3) == 0) && ((ld & 3) == 0) && ((reinterpret_cast<size_t>(src) & 15) == 0) &&
+                     ((reinterpret_cast<size_t>(dst) & 15) == 0);
+    if (vec) {
+        for (int c = lane * 4; c < ncols; c += 256)
+            *reinterpret_cast<float4 *>(d + c) = *reinterpret_cast<const float4 *>(s + c);
+    } else {
+        for (int c = lane; c < ncols; c += 64) d[c] = s[c];
+    }
+}
+
 // ---------------------------------------------------------------- transpose --
 // local_transpose (psp_process.cpp:647-689): dst[x][y] = src[y][x].  64x64 f32
 // tile through LDS (row stride 65 words: conflict-free column reads), 256-byte
@@ -595,6 +616,17 @@ int launch_finals(const double *sum, const double *sumsq, size_t nnodes, uint64_
 using namespace upsp;
 
 extern "C" {
+
+int upsp_scatter_rows_f32(const float *d_src, size_t nrows, int ncols, const int64_t *d_rowidx,
+                          float *d_dst, long long ld, void *stream)
+{
+    if (nrows == 0 || ncols == 0) return UPSP_OK;
+    if (!d_src || !d_rowidx || !d_dst || ncols < 0 || ld < ncols) return fail(UPSP_ERR_INVALID, "bad argument");
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       d_src, (long long)nrows, ncols, reinterpret_cast<const long long *>(d_rowidx), d_dst, ld);
+    UPSP_HIP_CHECK(hipGetLastError());
+    return UPSP_OK;
+}
 
 int upsp_fix_hot_pixels(uint16_t *d_frames, int nframes, int rows, int cols, int thresh,
                         int min_change, int max_hot, int32_t *d_status, void *stream)

@@ -93,6 +93,20 @@ def exchange_time_series(rows_t, shard, group=None, out=None):
     return out
 
 
+def _scatter_rows(out, rows, col, blk):
+    """out[rows, col:col+blk.shape[1]] = blk ; library kernel on the GPU, torch indexing on the CPU."""
+    if out.is_cuda:
+        import ctypes as C
+        from . import _capi
+        blk = blk.contiguous()
+        dst = out[:, col:]
+        _capi.check(_capi.lib().upsp_scatter_rows_f32(
+            C.c_void_p(blk.data_ptr()), blk.shape[0], blk.shape[1], C.c_void_p(rows.data_ptr()),
+            C.c_void_p(dst.data_ptr()), out.stride(0), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    else:
+        out[rows, col:col + blk.shape[1]] = blk
+
+
 def aligned_chunks(nframes, nchunks, align=64):
     """Cuts nframes into nchunks contiguous pieces whose boundaries are multiples of `align`
     (as evenly as that allows; trailing pieces may be empty).  Returns (starts, extents) like
@@ -201,8 +215,8 @@ class TimeSeriesExchange:
                 if self.vis is None:
                     self.out[:, c0:c0 + fc] = rows_t_chunk
                 else:
-                    self.out[self.vis_mine, c0:c0 + fc] = (rows_t_chunk if packed
-                                                           else rows_t_chunk.index_select(0, self.vis))
+                    _scatter_rows(self.out, self.vis_mine, c0,
+                                  rows_t_chunk if packed else rows_t_chunk.index_select(0, self.vis))
             return
         if self.vis is None:
             send = rows_t_chunk.contiguous()
@@ -231,7 +245,7 @@ class TimeSeriesExchange:
                     if self.vis is None:
                         self.out[:, col:col + fs] = blk
                     else:
-                        self.out[self.vis_mine, col:col + fs] = blk
+                        _scatter_rows(self.out, self.vis_mine, col, blk)
                 off += rows_in * fs
         self.pending = []
         return self.out
