@@ -143,6 +143,7 @@ class TimeSeriesExchange:
         self.vis_count = None    # rows that travel per destination rank
         self.vis_mine = None     # their positions inside this rank's slice
         self._row_map = None
+        self._keep = None
         if str(device).startswith("cuda"):
             self._prewarm(device)
 
@@ -167,13 +168,13 @@ class TimeSeriesExchange:
         switches back to sending every row.  Costs one device->host read of W counters."""
         sh = self.shard
         if skipped is None:
-            self.vis = self.vis_count = self.vis_mine = self._row_map = None
+            self.vis = self.vis_count = self.vis_mine = self._row_map = self._keep = None
             return
         keep = (skipped == 0) if skipped.dtype != torch.bool else ~skipped
-        vis = torch.nonzero(keep, as_tuple=False).reshape(-1)
-        if self.vis is not None and self.vis.shape == vis.shape and bool(torch.equal(self.vis, vis)):
+        if self._keep is not None and self._keep.shape == keep.shape and bool(torch.equal(self._keep, keep)):
             return                                      # same set as before: out's NaN rows are in place
-        self.vis = vis
+        self._keep = keep.clone()
+        self.vis = torch.nonzero(keep, as_tuple=False).reshape(-1)
         self._row_map = None
         bounds = torch.tensor([sh.node_start[d] for d in range(sh.world)] + [sh.nnodes], device=self.vis.device)
         cuts = torch.searchsorted(self.vis, bounds).cpu().tolist()
