@@ -14,8 +14,11 @@
 // std::partition produces (pspRT.cpp:545-553), which fixes the order of the
 // triangles inside a leaf.
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
+#include <cstdlib>
 #include <cstring>
+#include <thread>
 
 #include "upsp_internal.h"
 
@@ -63,16 +66,15 @@ struct Box {
     }
 };
 
-struct Builder {
+// Per-triangle data shared by every builder (read-only) + the permutation they split in place
+// (each builder works on its own disjoint range of it).
+struct Prims {
     const float *soup;
     std::vector<Box> pbox;       // per input triangle
     std::vector<float> cen;      // 3 per input triangle
     std::vector<uint32_t> perm;  // working permutation of triangle ids
-    HostBvh &out;
-    static constexpr int kBuckets = 12;
-    static constexpr int kLeafPrims = 4;
 
-    Builder(const float *s, size_t n, HostBvh &o) : soup(s), pbox(n), cen(3 * n), perm(n), out(o)
+    Prims(const float *s, size_t n) : soup(s), pbox(n), cen(3 * n), perm(n)
     {
         for (size_t i = 0; i < n; ++i) {
             Box &b = pbox[i];
@@ -84,6 +86,28 @@ struct Builder {
             perm[i] = (uint32_t)i;
         }
     }
+};
+
+// A subtree whose construction is deferred to a worker thread: the skeleton builder only needs
+// its bounds (for the parent's record) and leaves a placeholder child reference behind.
+struct Job {
+    uint32_t lo, hi, depth;
+    uint32_t parent;   // node of the skeleton holding the placeholder
+    int slot;          // 0 = left, 1 = right, -1 = the whole tree is this one job
+};
+
+struct Builder {
+    const float *soup;
+    const std::vector<Box> &pbox;
+    const std::vector<float> &cen;
+    std::vector<uint32_t> &perm;
+    HostBvh &out;
+    std::vector<Job> *jobs = nullptr;   // non-null: defer subtrees of <= defer_below triangles
+    uint32_t defer_below = 0;
+    static constexpr int kBuckets = 12;
+    static constexpr int kLeafPrims = 4;
+
+    Builder(Prims &p, HostBvh &o) : soup(p.soup), pbox(p.pbox), cen(p.cen), perm(p.perm), out(o) {}
 
     int bucket(const Box &cb, uint32_t id, int dim) const
     {
@@ -137,12 +161,19 @@ struct Builder {
     }
 
     // Returns the child ref of the subtree over perm[lo,hi) and its bounds.
+    // child reference that stands for deferred job j until the subtrees are stitched in
+    static int32_t placeholder(size_t j) { return (int32_t)(0x40000000u | (uint32_t)j); }
+
     int32_t build(uint32_t lo, uint32_t hi, uint32_t depth, Box &bounds)
     {
-        out.n_ref_nodes++;
         bounds.clear();
         for (uint32_t i = lo; i < hi; ++i) bounds.grow(pbox[perm[i]]);
         uint32_t n = hi - lo;
+        if (jobs && n <= defer_below && n > (uint32_t)kLeafPrims) {
+            jobs->push_back(Job{lo, hi, depth, 0u, 0});
+            return placeholder(jobs->size() - 1);
+        }
+        out.n_ref_nodes++;
         if (n <= (uint32_t)kLeafPrims) return emit_leaf(lo, hi, bounds, depth);
 
         Box cb;
@@ -200,8 +231,14 @@ struct Builder {
         uint32_t me = (uint32_t)out.nodes.size();
         out.nodes.emplace_back();
         Box L, R;
+        const size_t j0 = jobs ? jobs->size() : 0;
         int32_t lref = build(lo, mid, depth + 1, L);
+        const size_t j1 = jobs ? jobs->size() : 0;
         int32_t rref = build(mid, hi, depth + 1, R);
+        if (jobs) {   // remember where the placeholders of directly deferred children live
+            if (j1 == j0 + 1 && lref == placeholder(j0)) { (*jobs)[j0].parent = me; (*jobs)[j0].slot = 0; }
+            if (jobs->size() == j1 + 1 && rref == placeholder(j1)) { (*jobs)[j1].parent = me; (*jobs)[j1].slot = 1; }
+        }
         write_node(me, L, R, lref, rref, (uint32_t)dim);
         return (int32_t)me;
     }
@@ -259,14 +296,73 @@ static void relabel_top_breadth_first(HostBvh &out, uint32_t top)
     out.root_ref = newid[out.root_ref];
 }
 
+// The tree is the one the sequential recursion produces (same splits, same leaf order); only the
+// numbering of nodes / triangle slots differs: the skeleton (upper levels, built first) comes
+// first, the deferred subtrees follow in discovery order.  Nothing depends on the numbering.
 void build_bvh(const float *tris9, size_t ntris, HostBvh &out)
 {
     out = HostBvh();
     out.nodes.reserve(ntris / 2 + 16);
     out.tris.reserve(ntris);
-    Builder b(tris9, ntris, out);
+    Prims prims(tris9, ntris);
+    unsigned nthreads = std::thread::hardware_concurrency();
+    if (const char *e = std::getenv("UPSP_BUILD_THREADS")) nthreads = (unsigned)std::max(1, std::atoi(e));
+    nthreads = std::min(std::max(nthreads, 1u), 32u);
     Box root;
-    out.root_ref = b.build(0, (uint32_t)ntris, 0, root);
+    if (nthreads <= 1 || ntris < 65536) {
+        Builder b(prims, out);
+        out.root_ref = b.build(0, (uint32_t)ntris, 0, root);
+    } else {
+        // skeleton: upper levels here, subtrees of <= ntris / (8 * threads) triangles deferred
+        std::vector<Job> jobs;
+        Builder top(prims, out);
+        top.jobs = &jobs;
+        top.defer_below = (uint32_t)std::max<size_t>(ntris / (8 * (size_t)nthreads), 1024);
+        out.root_ref = top.build(0, (uint32_t)ntris, 0, root);
+        std::vector<HostBvh> sub(jobs.size());
+        std::vector<int32_t> sub_ref(jobs.size());
+        std::atomic<size_t> next{0};
+        auto worker = [&]() {
+            for (size_t j = next++; j < jobs.size(); j = next++) {
+                Builder b(prims, sub[j]);
+                Box bb;
+                sub_ref[j] = b.build(jobs[j].lo, jobs[j].hi, jobs[j].depth, bb);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < nthreads; ++t) pool.emplace_back(worker);
+        worker();
+        for (auto &t : pool) t.join();
+        // stitch: append every subtree, relocating its interior indices and leaf slots
+        for (size_t j = 0; j < jobs.size(); ++j) {
+            const uint32_t node_off = (uint32_t)out.nodes.size(), tri_off = (uint32_t)out.tris.size();
+            auto reloc = [&](int32_t r) -> int32_t {
+                if (r >= 0) return r + (int32_t)node_off;
+                const uint32_t code = (uint32_t)(~r);
+                return ~(int32_t)((((code >> kLeafBits) + tri_off) << kLeafBits) | (code & (kMaxLeaf - 1)));
+            };
+            for (GpuNode g : sub[j].nodes) {
+                for (int k = 0; k < 2; ++k) {
+                    int32_t r;
+                    std::memcpy(&r, &g.q[12 + k], 4);
+                    r = reloc(r);
+                    std::memcpy(&g.q[12 + k], &r, 4);
+                }
+                out.nodes.push_back(g);
+            }
+            out.tris.insert(out.tris.end(), sub[j].tris.begin(), sub[j].tris.end());
+            const int32_t ref = reloc(sub_ref[j]);
+            if (jobs[j].slot < 0 || out.root_ref == Builder::placeholder(j)) {
+                out.root_ref = ref;
+            } else {
+                std::memcpy(&out.nodes[jobs[j].parent].q[12 + jobs[j].slot], &ref, 4);
+            }
+            out.n_ref_nodes += sub[j].n_ref_nodes;
+            out.depth = std::max(out.depth, sub[j].depth);
+            out.max_leaf = std::max(out.max_leaf, sub[j].max_leaf);
+            sub[j] = HostBvh();
+        }
+    }
     for (int a = 0; a < 3; ++a) {
         out.root_min[a] = root.lo[a];
         out.root_max[a] = root.hi[a];
