@@ -248,7 +248,7 @@ struct Builder {
 
 // The first `top` interior nodes are renumbered in breadth-first order (the rest keep
 // their depth-first order behind them), so the upper levels of the tree -- the nodes every
-// ray visits -- form one contiguous block that the traversal kernels stage in LDS.
+// ray visits -- form one contiguous block of cache lines.
 // Only indices change; topology, child order and leaf order are untouched.
 static void relabel_top_breadth_first(HostBvh &out, uint32_t top)
 {

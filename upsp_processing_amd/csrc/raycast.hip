@@ -326,8 +326,6 @@ struct Scene {
     int root_ref;
     int refill;           // re-fill threshold (live lanes)
     unsigned chunk;       // work items per queue grab (multiple of 64)
-    int top;              // nodes [0, top) are staged in LDS (breadth-first upper tree)
-    int stack_ints;       // LDS ints taken by the traversal stacks (top nodes follow)
     float rlo[3], rhi[3];
     const unsigned *adj_off, *adj_slot;   // node -> adjacent triangle slots (may be null)
 };
@@ -386,17 +384,10 @@ __device__ __forceinline__ void trav_pop(Trav &s, const int *stack)
 // One interior-node step: fetch the 64-byte record, test both child boxes, descend to
 // the near child (push the far one) or pop.
 template <bool ANYHIT, bool STATS>
-__device__ __forceinline__ void node_step(Trav &s, const Ray &r, const Scene &sc, int *stack,
-                                          const float4 *top_lds)
+__device__ __forceinline__ void node_step(Trav &s, const Ray &r, const Scene &sc, int *stack)
 {
-    float4 q0, q1, q2, q3;
-    if (s.cur < sc.top) {  // upper tree: staged in LDS by stage_top()
-        const float4 *lp = top_lds + 4 * s.cur;
-        q0 = lp[0]; q1 = lp[1]; q2 = lp[2]; q3 = lp[3];
-    } else {
-        const float4 *np = sc.nodes + 4 * (size_t)s.cur;
-        q0 = np[0]; q1 = np[1]; q2 = np[2]; q3 = np[3];
-    }
+    const float4 *np = sc.nodes + 4 * (size_t)s.cur;
+    const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
     if (STATS) { ++s.n_nodes; ++s.ray_nodes; }
     const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
     const unsigned meta = __float_as_uint(q3.z);
@@ -470,10 +461,10 @@ __device__ __forceinline__ bool leaf_step(Trav &s, const Ray &r, const Scene &sc
 // the delayed pruning limit costs more node visits than the better lane occupancy saves.)
 template <bool ANYHIT, bool STATS>
 __device__ __forceinline__ void trav_run(Trav &s, const Ray &r, const Scene &sc, int *stack,
-                                         const float4 *top_lds, bool more, int refill)
+                                         bool more, int refill)
 {
     while (s.cur != kDone) {
-        while (s.cur >= 0) node_step<ANYHIT, STATS>(s, r, sc, stack, top_lds);
+        while (s.cur >= 0) node_step<ANYHIT, STATS>(s, r, sc, stack);
         if (s.cur != kDone) {
             if (leaf_step<ANYHIT, STATS>(s, r, sc, s.cur)) {
                 s.cur = kDone;
@@ -487,16 +478,6 @@ __device__ __forceinline__ void trav_run(Trav &s, const Ray &r, const Scene &sc,
 }
 
 __device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63u; }
-
-// Copies the breadth-first upper tree (sc.top nodes x 64 B) behind the traversal stacks
-// in LDS; returns its base.  Called by every thread of the workgroup at kernel start.
-__device__ __forceinline__ const float4 *stage_top(const Scene &sc, int *lds)
-{
-    float4 *dst = reinterpret_cast<float4 *>(lds + sc.stack_ints);
-    for (int i = threadIdx.x; i < sc.top * 4; i += blockDim.x) dst[i] = sc.nodes[i];
-    __syncthreads();
-    return dst;
-}
 
 // Wave-level work distribution.  `cur`/`end` are wave-uniform.
 struct WaveQueue {
@@ -637,7 +618,6 @@ __global__ void __launch_bounds__(kBlock)
 {
     extern __shared__ int lds_stack[];
     int *stack = lds_stack + threadIdx.x;
-    const float4 *top_lds = stage_top(sc, lds_stack);
     WaveQueue q;
     queue_init(q, work, n, sc.chunk);
     Ray r;
@@ -668,7 +648,7 @@ __global__ void __launch_bounds__(kBlock)
         if (__ballot(busy) == 0ull) break;
         // ---- traverse ----
         if (busy) {
-            trav_run<ANYHIT, STATS>(s, r, sc, stack, top_lds, queue_has_more(q), sc.refill);
+            trav_run<ANYHIT, STATS>(s, r, sc, stack, queue_has_more(q), sc.refill);
             if (s.cur == kDone) {
                 if (STATS) {
                     atomicMax(&work[8], s.ray_nodes);
@@ -828,7 +808,6 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 
 {
     extern __shared__ int lds_stack[];
     int *stack = lds_stack + threadIdx.x;
-    const float4 *top_lds = stage_top(sc, lds_stack);
     const unsigned total = PHASE == 0 ? nnodes : work[kWorkRetryCount] * 6u;
     WaveQueue q;
     queue_init(q, work, total, sc.chunk);
@@ -882,7 +861,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 
         if (__ballot(busy) == 0ull) break;
 
         if (busy) {
-            trav_run<false, STATS>(s, r, sc, stack, top_lds, queue_has_more(q), sc.refill);
+            trav_run<false, STATS>(s, r, sc, stack, queue_has_more(q), sc.refill);
             if (PHASE == 0 && s.cur == kDone && bounded && !s.any) {
                 // An own triangle is hit when tested directly but was not reached through the
                 // boxes, and nothing nearer exists: whether the ray hits ANYTHING (retries or
@@ -1046,15 +1025,9 @@ int stack_entries(const upsp_bvh *b)
     return d < 8 ? 8 : d;
 }
 
-int top_count(const upsp_bvh *b)
-{
-    static const int top_cap = env_int("UPSP_TOP_NODES", 0);  // measured slower: off
-    return (int)std::min<uint32_t>(b->top_nodes, (uint32_t)std::max(top_cap, 0));
-}
-
 size_t lds_bytes(const upsp_bvh *b)
 {
-    return (size_t)stack_entries(b) * kBlock * sizeof(int) + (size_t)top_count(b) * sizeof(GpuNode);
+    return (size_t)stack_entries(b) * kBlock * sizeof(int);
 }
 
 Scene make_scene(const upsp_bvh *b, size_t items, int grid)
@@ -1067,8 +1040,6 @@ Scene make_scene(const upsp_bvh *b, size_t items, int grid)
     sc.nodes = reinterpret_cast<const float4 *>(b->d_nodes);
     sc.tris = reinterpret_cast<const float4 *>(b->d_tris);
     sc.root_ref = b->root_ref;
-    sc.top = top_count(b);
-    sc.stack_ints = stack_entries(b) * kBlock;
     static const int refill = env_int("UPSP_REFILL", kRefillDefault);
     sc.refill = refill;
     sc.adj_off = sc.adj_slot = nullptr;

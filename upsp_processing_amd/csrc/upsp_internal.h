@@ -49,7 +49,7 @@ static_assert(sizeof(GpuTri) == 48, "GpuTri must be 48 bytes");
 constexpr int kLeafBits = 6;
 constexpr int kMaxLeaf = 1 << kLeafBits;  // triangles addressable by one leaf ref
 constexpr uint32_t kMetaOrdered = 4u;
-constexpr uint32_t kTopNodesMax = 255;  // upper-tree nodes renumbered breadth-first (LDS staging)
+constexpr uint32_t kTopNodesMax = 255;  // upper-tree nodes renumbered breadth-first (contiguous in memory)
 
 struct HostBvh {
     std::vector<GpuNode> nodes;
