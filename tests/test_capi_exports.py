@@ -61,3 +61,25 @@ def test_project_points_matches_oracle(oracle):
     b = oracle.project_points(cam_o, pts)
     assert np.array_equal(a, b)
     assert np.allclose(engine.camera_center(cam_g), oracle.cam_center(cam_o), rtol=0, atol=0)
+
+
+def test_header_is_plain_c(tmp_path):
+    """The boundary is a C ABI: include/upsp_gpu.h must compile as C99 on its own (what a cgo /
+    ctypes / JNI binding sees), and a C translation unit must link against the library."""
+    import subprocess
+    from upsp_processing_amd import _capi
+    hdr = os.path.join(ROOT, "include", "upsp_gpu.h")
+    subprocess.run(["gcc", "-x", "c", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror",
+                    "-fsyntax-only", hdr], check=True)
+    src = tmp_path / "probe.c"
+    src.write_text('#include "upsp_gpu.h"\n#include <stdio.h>\n'
+                   "int main(void){int s[4],e[4];"
+                   "if(upsp_apportion(10,4,s,e)!=UPSP_OK) return 1;"
+                   'printf("%d %d %d %d\\n",e[0],e[1],e[2],e[3]);return 0;}\n')
+    exe = tmp_path / "probe"
+    libdir = os.path.dirname(_capi.LIB_PATH)
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                    "-L", libdir, "-l:" + os.path.basename(_capi.LIB_PATH),
+                    "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    assert out.split() == ["3", "3", "2", "2"]
