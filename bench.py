@@ -46,6 +46,8 @@ def parse():
                     help="configs[2] shape: per-frame ECC registration before the projection")
     ap.add_argument("--force-chunked", action="store_true",
                     help="run the chunked / pipelined-exchange frame loop of the N>1 path on one GPU")
+    ap.add_argument("--f32-wire", action="store_true",
+                    help="N>1 / --force-chunked: exchange the series as f32 instead of u16")
     ap.add_argument("--model", default="quad", choices=["quad", "uv"],
                     help="quad: cube-sphere tunnel model (valence <= 6); uv: UV-sphere model with "
                          "1000-valent polar fans (worst case for per-ray traversal length)")
@@ -166,9 +168,13 @@ def main():
     exch = D.TimeSeriesExchange(shard, K) if chunked else None
     chunk_bufs = ([torch.empty((N, exch.my_chunk(k)[1]), dtype=torch.float32, device="cuda")
                    for k in range(K)] if chunked else None)
+    # one camera, no weights, no filter: the series values are exact 16-bit integers, so the
+    # travelling rows are produced and sent as u16 (half the bytes) and widened by the receiver
+    chunk_bufs16 = ([torch.empty((N, exch.my_chunk(k)[1]), dtype=torch.uint16, device="cuda")
+                     for k in range(K)] if chunked else None)
 
     ev_log = []
-    mode = {"packed": True}
+    mode = {"packed": True, "u16": not a.f32_wire}
 
     def step(record):
         e = [ev() for _ in range(4)]
@@ -196,9 +202,18 @@ def main():
             nrows = exch.packed_rows() if packed else N
             for k in range(K):
                 c0, fc = exch.my_chunk(k)
-                buf = chunk_bufs[k][:nrows]
+                u16 = packed and mode["u16"]
+                buf = (chunk_bufs16 if u16 else chunk_bufs)[k][:nrows]
                 if fc:
-                    pipe.process(frames[c0:c0 + fc], first_frame=rank * F + c0, rows_t=buf, want_rows=False)
+                    try:
+                        pipe.process(frames[c0:c0 + fc], first_frame=rank * F + c0, rows_t=buf, want_rows=False)
+                    except _capi.UpspError as ex:
+                        if not u16:
+                            raise
+                        print("bench: u16 series refused (%r), sending f32" % (ex,), file=sys.stderr)
+                        mode["u16"] = False
+                        buf = chunk_bufs[k][:nrows]
+                        pipe.process(frames[c0:c0 + fc], first_frame=rank * F + c0, rows_t=buf, want_rows=False)
                 exch.submit(buf, packed=packed)
         e[2].record()
         s, ss = pipe.accumulators()
@@ -257,6 +272,8 @@ def main():
     n_retry_rays = 6 * retry_nodes_last[0]
     scene_bytes = bvh.info["device_bytes"]
     gather_launches = -(-F // 64) if not chunked else sum(-(-exch.my_chunk(k)[1] // 64) for k in range(K))
+    series_rows = exch.packed_rows() if (chunked and mode["packed"]) else N
+    series_esz = 2 if (chunked and mode["packed"] and mode["u16"]) else 4
     per_step_bytes = {
         # 40 B per ray (24 B ray + 16 B hit record) + the scene once per launch
         "projection_kernel<primary>": primary_rays_last[0] * 40 + scene_bytes,
@@ -266,7 +283,8 @@ def main():
         # hit the Infinity Cache); the gather keeps pix / weight in registers across its 64-frame
         # tile, so per launch it needs 4 B x N x frames written + 8 B x N read once -- counting
         # 12 B x N per FRAME would credit bytes the kernel never has to move.
-        "gather_tile_kernel": F * 4 * N + gather_launches * 8 * N,
+        # (N > 1: only the rows that travel are stored, as u16 when the values are 16-bit integers)
+        "gather_tile_kernel": F * series_esz * series_rows + gather_launches * 8 * N,
         "hot_scan_kernel": F * 2 * size * size,
     }
     for name, (calls, total_ms) in timing.items():
@@ -308,14 +326,17 @@ def main():
                                                          tris.shape[0], N,
                                                          "registration+" if a.registration else ""),
                    "frames_per_gpu": F, "nodes": N, "triangles": int(tris.shape[0]),
-                   "parallelism": "frames sharded x%d" % world},
+                   "parallelism": "frames sharded x%d" % world,
+                   **({"exchange": "%d chunks, %s rows as %s" % (K, "visible" if mode["packed"] else "all",
+                                                                 "u16" if series_esz == 2 else "f32")}
+                      if chunked else {})},
         "mrays_per_s": mrays, "rays_per_step": nrays_last[0],
         "rays_cast_per_step": primary_rays_last[0] + 6 * retry_nodes_last[0],
         "breakdown_ms": {"projection_build": ray_ms, "frame_loop": frm_ms,
                          "exchange_finals": float(np.mean(t_xchg))},
         "frame_loop_frames_per_s": F / (frm_ms * 1e-3),
         # whole frame loop against HBM: (2 MiB + 4 B x N) per frame + 8 B x N per 64-frame tile
-        "frame_loop_GBps": (F * (2 * size * size + 4 * N) + gather_launches * 8 * N) / (frm_ms * 1e-3) / 1e9,
+        "frame_loop_GBps": (F * (2 * size * size + series_esz * series_rows) + gather_launches * 8 * N) / (frm_ms * 1e-3) / 1e9,
         "roofline": roof,
         "kernels": kernels,
     }

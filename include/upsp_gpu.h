@@ -225,6 +225,9 @@ int upsp_pipeline_set_row_map(upsp_pipeline *pipe, const int32_t *d_rowmap);
  * to rows d_rowidx[r] (int64) of d_dst (row pitch ld floats; add the column offset to d_dst). */
 int upsp_scatter_rows_f32(const float *d_src, size_t nrows, int ncols, const int64_t *d_rowidx,
                           float *d_dst, long long ld, void *stream);
+/* The same for a block that travelled as u16 (upsp_pipeline_process_u16): values are widened to f32. */
+int upsp_scatter_rows_u16(const uint16_t *d_src, size_t nrows, int ncols, const int64_t *d_rowidx,
+                          float *d_dst, long long ld, void *stream);
 /* ECC template of camera `cam` = first frame as f32 (elems.first_frames[c],
  * psp_process.cpp:2057-2058). */
 int upsp_pipeline_set_reference(upsp_pipeline *p, int cam, const float *d_ref32f);
@@ -249,6 +252,17 @@ int upsp_pipeline_set_patches(upsp_pipeline *p, int cam, int nclusters,
 int upsp_pipeline_process(upsp_pipeline *p, const uint16_t *const *d_frames, int nframes,
                           int64_t first_frame, float *d_rows, float *d_rows_t, int64_t ld_t,
                           int64_t col0, float *d_warps, void *stream);
+
+/* upsp_pipeline_process with the node-major time series stored as u16 (d_series_u16[n*ld_t + col0
+ * + f], pitch in elements) and no other output: the wire format of the multi-GPU time-series
+ * exchange (global_transpose, cpp/exec/psp_process.cpp:707-771), half the bytes of f32.  Lossless
+ * and accepted only when every stored value is an exact 16-bit integer: one camera, no weight
+ * vector, no patch / filter stage (raw or registered u16 frames) -- UPSP_ERR_INVALID otherwise.
+ * NaN has no u16 encoding: rows of nodes no camera sees are written as 0, so use a row map that
+ * leaves them out (upsp_pipeline_set_row_map); upsp_scatter_rows_u16 widens the received blocks. */
+int upsp_pipeline_process_u16(upsp_pipeline *p, const uint16_t *const *d_frames, int nframes,
+                              int64_t first_frame, uint16_t *d_series_u16, int64_t ld_t,
+                              int64_t col0, float *d_warps, void *stream);
 
 /* Accumulator access (device pointers to nnodes doubles each), used for the
  * cross-GPU sum that replaces MPI_Reduce (psp_process.cpp:1866-1872). */

@@ -107,6 +107,52 @@ def test_two_rank_exchange(F, N):
             assert full is None
 
 
+def _worker_u16(rank, world, port, F, N, seed, q):
+    """The exchange with u16 chunks (integer-valued series: one camera, no weights) must deliver
+    the same f32 series as the f32 exchange."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from upsp_processing_amd import distributed as D
+    shard = D.Shard(F, N)
+    rng = np.random.default_rng(seed)
+    rows_all = rng.integers(0, 65536, size=(F, N)).astype(np.float32)
+    rows_all[0, 1], rows_all[0, 2] = 65535.0, 32768.0          # sign bit of the int16 view
+    rows_all[:, ::5] = np.nan
+    f0, nf = shard.my_frames
+    rows_t = torch.as_tensor(np.ascontiguousarray(rows_all[f0:f0 + nf].T))
+    series = D.exchange_time_series(rows_t, shard)
+    ex = D.TimeSeriesExchange(shard, 3, device="cpu")
+    ex.set_skipped(torch.as_tensor(np.isnan(rows_all[0])))
+    vis = ex.vis.numpy()
+    for k in range(3):
+        c0, fc = ex.my_chunk(k)
+        blk = rows_t.numpy()[vis, c0:c0 + fc].astype(np.uint16)
+        ex.submit(torch.from_numpy(np.ascontiguousarray(blk)), packed=True)
+    got = ex.finish()
+    assert got.dtype == torch.float32
+    assert torch.equal(got.view(torch.int32), series.view(torch.int32))
+    q.put(rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("F,N", [(200, 41), (3, 6)])
+def test_two_rank_exchange_u16_wire(F, N):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_u16, args=(r, world, port, F, N, 7, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    assert sorted(q.get(timeout=120) for _ in range(world)) == [0, 1]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+
+
 def test_shard_matches_reference_apportion(oracle):
     from upsp_processing_amd import distributed as D, engine
     for value, bins in [(100000, 8), (10, 4), (3, 5), (0, 2), (12345, 7)]:

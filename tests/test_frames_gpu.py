@@ -146,3 +146,72 @@ def test_hot_pixels_saturated_frames(gpu_lib, oracle):
     st = engine.fix_hot_pixels(d).cpu().numpy()
     assert np.array_equal(d.cpu().numpy(), want)
     assert st.tolist() == wst and st[1] == -1 and st[3] == -1 and st[2] == 1
+
+
+@pytest.mark.parametrize("F,ld_extra", [(41, 0), (64, 4), (130, 3)])
+def test_packed_and_u16_series(gpu_lib, oracle, F, ld_extra):
+    """Row map (packed series: only the rows of visible nodes are stored) and the u16 wire format
+    of the time-series exchange, against the plain f32 node-major series -- bit for bit."""
+    import torch
+    from upsp_processing_amd import engine, synthetic as syn, _capi
+    H, W, n = 96, 128, 3001
+    rng = np.random.default_rng(F)
+    frames = syn.synth_frames_numpy(F, H, W, seed=11, hot=True)
+    frames[0].flat[:3] = (65535, 32768, 0)
+    pix = rng.integers(0, H * W, size=n).astype(np.int32)
+    pix[:3] = (0, 1, 2)
+    pix[rng.random(n) < 0.4] = -1
+    pix[:3] = (0, 1, 2)
+    d_pix = torch.as_tensor(pix).cuda()
+    pipe = engine.FramePipeline(1, W, H, n, hot_enable=0)
+    pipe.set_projection(0, d_pix)
+    d_frames = torch.as_tensor(frames).cuda()
+    full = torch.empty((n, F), dtype=torch.float32, device="cuda")
+    pipe.process(d_frames, 0, rows_t=full, want_rows=False)
+    s0 = [a.clone() for a in pipe.accumulators()]
+    # oracle: gather rows
+    for f in (0, F - 1):
+        sol = oracle.project_frame(frames[f], pix, None)
+        sol[pix < 0] = np.nan
+        assert np.array_equal(full[:, f].cpu().numpy().view(np.int32), sol.view(np.int32))
+    vis = torch.nonzero(d_pix >= 0).reshape(-1)
+    rowmap = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    rowmap[vis] = torch.arange(vis.numel(), dtype=torch.int32, device="cuda")
+    pipe.set_row_map(rowmap)
+    ld = F + ld_extra
+    for dtype in (torch.float32, torch.uint16):
+        pipe.reset()
+        if dtype == torch.float32:
+            buf = torch.full((vis.numel(), ld), -7.0, dtype=dtype, device="cuda")
+        else:
+            buf = torch.full((vis.numel(), ld), 7, dtype=torch.int32, device="cuda").to(torch.uint16)
+        half = 17
+        pipe.process(d_frames[:half].contiguous(), 0, rows_t=buf[:, :F], want_rows=False)
+        pipe.process(d_frames[half:].contiguous(), half, rows_t=buf[:, :F], col0=half, want_rows=False)
+        got = buf.cpu().numpy()
+        want = full.index_select(0, vis).cpu().numpy()
+        assert np.array_equal(got[:, :F].astype(np.float32), want)
+        assert (got[:, F:] == (7 if dtype == torch.uint16 else -7.0)).all()   # nothing past the frames
+        s1 = pipe.accumulators()
+        assert torch.equal(s0[0].view(torch.int64), s1[0].view(torch.int64))
+        assert torch.equal(s0[1].view(torch.int64), s1[1].view(torch.int64))
+        # receiving side: scatter the packed block back into a NaN-filled full series
+        out = torch.full((n, F + 5), float("nan"), dtype=torch.float32, device="cuda")
+        from upsp_processing_amd.distributed import _scatter_rows
+        _scatter_rows(out, vis, 2, buf[:, :F].contiguous())
+        assert torch.equal(out[:, 2:F + 2].contiguous().view(torch.int32), full.view(torch.int32))
+        assert torch.isnan(out[:, :2]).all() and torch.isnan(out[:, F + 2:]).all()
+    pipe.set_row_map(None)
+    # u16 is refused wherever the stored values need not be 16-bit integers
+    b16 = torch.zeros((n, F), dtype=torch.int32, device="cuda").to(torch.uint16)
+    pipe.set_projection(0, d_pix, torch.ones(n))
+    with pytest.raises(_capi.UpspError):
+        pipe.process(d_frames, 0, rows_t=b16, want_rows=False)
+    p2 = engine.FramePipeline(1, W, H, n, filter=1, filter_size=3)
+    p2.set_projection(0, d_pix)
+    with pytest.raises(_capi.UpspError):
+        p2.process(d_frames, 0, rows_t=b16, want_rows=False)
+    p3 = engine.FramePipeline(2, W, H, n)
+    p3.set_projection(0, d_pix); p3.set_projection(1, d_pix)
+    with pytest.raises(_capi.UpspError):
+        p3.process([d_frames, d_frames.clone()], 0, rows_t=b16, want_rows=False)

@@ -50,5 +50,16 @@ for k in range(4):
         pipe.process(frames[c0:c0 + fc], first_frame=c0, rows_t=buf, want_rows=False)
     ex3.submit(buf, packed=True)
 assert torch.equal(ex3.finish().view(torch.int32), ref.view(torch.int32))
+# ... and the same rows produced and exchanged as u16 (integer-valued series)
+pipe.reset()
+ex4 = D.TimeSeriesExchange(shard, 4)
+ex4.set_skipped(engine.skipped_nodes(pix, want_count=False)[0])
+for k in range(4):
+    c0, fc = ex4.my_chunk(k)
+    buf = torch.full((ex4.packed_rows(), fc), 9, dtype=torch.int32, device="cuda").to(torch.uint16)
+    if fc:
+        pipe.process(frames[c0:c0 + fc], first_frame=c0, rows_t=buf, want_rows=False)
+    ex4.submit(buf, packed=True)
+assert torch.equal(ex4.finish().view(torch.int32), ref.view(torch.int32))
 pipe.set_row_map(None)
 print("chunked == single-call: ok")

@@ -76,12 +76,14 @@ SIGNATURES = {
     "upsp_pipeline_destroy": (None, [_vp]),
     "upsp_pipeline_set_projection": (_i, [_vp, _i, _vp, _vp]),
     "upsp_scatter_rows_f32": (_i, [_vp, _sz, _i, _vp, _vp, C.c_longlong, _vp]),
+    "upsp_scatter_rows_u16": (_i, [_vp, _sz, _i, _vp, _vp, C.c_longlong, _vp]),
     "upsp_pipeline_set_row_map": (_i, [_vp, _vp]),
     "upsp_pipeline_set_overlap_source": (_i, [_vp, _vp]),
     "upsp_pipeline_set_skipped": (_i, [_vp, _vp]),
     "upsp_pipeline_set_reference": (_i, [_vp, _i, _vp]),
     "upsp_pipeline_set_patches": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "upsp_pipeline_process": (_i, [_vp, C.POINTER(_vp), _i, _i64, _vp, _vp, _i64, _i64, _vp, _vp]),
+    "upsp_pipeline_process_u16": (_i, [_vp, C.POINTER(_vp), _i, _i64, _vp, _i64, _i64, _vp, _vp]),
     "upsp_pipeline_accumulators": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
     "upsp_pipeline_reset": (_i, [_vp]),
     "upsp_pipeline_finalize": (_i, [_vp, C.c_uint64, _vp, _vp, _vp]),

@@ -164,6 +164,7 @@ struct GatherArgs {
     size_t npix;
     const int32_t *src;            // overlap source map or null
     const int32_t *rowmap;         // packed rows of rows_t or null
+    uint16_t *rows_t16;            // node-major series as u16 (instead of rows_t) or null
 };
 
 template <int NCAMS>
@@ -360,9 +361,201 @@ __global__ void __launch_bounds__(256)
             }
         }
     }
+    if (a.rows_t16) {
+        // the same row segments as u16 (time-series exchange of integer-valued series: half the
+        // bytes); NaN (node no camera sees) has no u16 encoding and is stored as 0
+        uint16_t *rt = a.rows_t16;
+        if (((ld_t & 3) == 0) && ((reinterpret_cast<size_t>(rt) & 7) == 0)) {
+            const int c4 = (lane & 15) * 4, rsub = lane >> 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int j = wave * 16 + i * 4 + rsub;
+                const unsigned nn = n0 + (unsigned)j;
+                const long long row = (nn < nnodes) ? (a.rowmap ? (long long)a.rowmap[nn] : (long long)nn) : -1;
+                if (row >= 0 && c4 < nframes) {
+                    const unsigned v0 = (unsigned)fmaxf(tile[c4][j], 0.0f), v1 = (unsigned)fmaxf(tile[c4 + 1][j], 0.0f),
+                                   v2 = (unsigned)fmaxf(tile[c4 + 2][j], 0.0f), v3 = (unsigned)fmaxf(tile[c4 + 3][j], 0.0f);
+                    uint16_t *dst = rt + row * ld_t + c4;
+                    if (c4 + 3 < nframes) {
+                        typedef unsigned v2u __attribute__((ext_vector_type(2)));
+                        const v2u nv = {v0 | (v1 << 16), v2 | (v3 << 16)};
+                        if (kStreamStores)
+                            __builtin_nontemporal_store(nv, reinterpret_cast<v2u *>(dst));
+                        else
+                            *reinterpret_cast<v2u *>(dst) = nv;
+                    } else {
+                        dst[0] = (uint16_t)v0;
+                        if (c4 + 1 < nframes) dst[1] = (uint16_t)v1;
+                        if (c4 + 2 < nframes) dst[2] = (uint16_t)v2;
+                    }
+                }
+            }
+        } else {
+            for (int j = wave; j < 64; j += 4) {
+                const unsigned nn = n0 + (unsigned)j;
+                const long long row = (nn < nnodes) ? (a.rowmap ? (long long)a.rowmap[nn] : (long long)nn) : -1;
+                if (row >= 0 && lane < nframes) rt[row * ld_t + lane] = (uint16_t)(unsigned)fmaxf(tile[lane][j], 0.0f);
+            }
+        }
+    }
     if (rows) {    // lane = node, wave g writes frames g, g+4, ...
         for (int f = wave; f < nframes; f += 4)
             if (live) rows[(size_t)f * nnodes + n] = tile[f][lane];
+    }
+}
+
+// The same tile for the common case -- one camera, no weight vector, u16 frames (raw or registered):
+// every value is an exact 16-bit integer, so the LDS tile holds u16 pairs (8.4 KB instead of
+// 16.6 KB) and a workgroup is WAVES x 64 lanes with 64 / WAVES gathers in flight per lane.  The
+// gather is bound by the latency of its dependent chain (pix -> pixel -> LDS -> store) times the
+// workgroups a CU can hold, not by bytes (storing a fifth of the bytes did not change its time):
+// the small tile lets a CU hold 8 workgroups instead of 7 and halves the LDS traffic; 64-frame
+// launch 46 -> 38 us on MI355X.  Sums of 16-bit integers (and of their float squares) are exact in double, so
+// sum / sumsq are bit-identical to gather_tile_kernel's whatever the order.
+template <int WAVES, bool kStreamStores, bool kHasSrc>
+__global__ void __launch_bounds__(WAVES * 64)
+    gather_tile16_kernel(GatherArgs a, const uint8_t *__restrict__ skipped, unsigned nnodes,
+                         int nframes, float *__restrict__ rows, float *__restrict__ rows_t,
+                         long long ld_t, double *__restrict__ sum, double *__restrict__ sumsq)
+{
+    constexpr int kPitch = 66;            // 2 rows apart = 4 banks apart: conflict-free both ways
+    constexpr int NP = 32 / WAVES;        // frame pairs per lane
+    constexpr int RPW = 64 / WAVES;       // rows (nodes) each wave writes
+    __shared__ unsigned tile[32][kPitch]; // [frame pair p][node]: frame 2p | frame 2p+1 << 16
+    __shared__ double part[2][WAVES][64];
+    __shared__ unsigned char skipf[64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned n0 = blockIdx.x * 64u, n = n0 + lane;
+    const bool live = n < nnodes;
+    const int32_t px = live ? a.pix[0][n] : -1;
+    const bool skip = live && skipped && skipped[n];
+    const unsigned ns = (kHasSrc && live) ? (unsigned)a.src[n] : n;
+    const bool alt = kHasSrc && ns != n;
+    const uint16_t *__restrict__ img = reinterpret_cast<const uint16_t *>(a.img[0]);
+    const float qnan = __builtin_nanf("");
+    unsigned pk[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {        // every gather is issued before any is used
+        const int f0 = 2 * (wave + WAVES * i);
+        unsigned lo = 0, hi = 0;
+        if (px >= 0) {
+            if (f0 < nframes) lo = img[(size_t)f0 * a.npix + (size_t)px];
+            if (f0 + 1 < nframes) hi = img[(size_t)(f0 + 1) * a.npix + (size_t)px];
+        }
+        pk[i] = lo | (hi << 16);
+    }
+    double s = 0.0, ss = 0.0;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int p = wave + WAVES * i;
+        if (2 * p < nframes) {
+            const float v = skip ? qnan : (float)(pk[i] & 0xFFFFu);
+            s += (double)v;
+            ss += (double)(v * v);
+        }
+        if (2 * p + 1 < nframes) {
+            const float v = skip ? qnan : (float)(pk[i] >> 16);
+            s += (double)v;
+            ss += (double)(v * v);
+        }
+        tile[p][lane] = pk[i];
+    }
+    bool skip_out = skip;
+    if (alt) {   // adjust_solution: the stored series is the source node's
+        const int32_t p2 = a.pix[0][ns];
+        skip_out = skipped && skipped[ns];
+        for (int i = 0; i < NP; ++i) {
+            const int f0 = 2 * (wave + WAVES * i);
+            if (f0 >= nframes) break;
+            unsigned lo = 0, hi = 0;
+            if (p2 >= 0) {
+                lo = img[(size_t)f0 * a.npix + (size_t)p2];
+                if (f0 + 1 < nframes) hi = img[(size_t)(f0 + 1) * a.npix + (size_t)p2];
+            }
+            tile[f0 >> 1][lane] = lo | (hi << 16);
+        }
+    }
+    if (wave == 0) skipf[lane] = skip_out ? 1 : 0;
+    part[0][wave][lane] = s;
+    part[1][wave][lane] = ss;
+    __syncthreads();
+    if (wave == 0 && live) {
+        double t0 = part[0][0][lane], t1 = part[1][0][lane];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) {
+            t0 += part[0][w][lane];
+            t1 += part[1][w][lane];
+        }
+        sum[n] += t0;
+        sumsq[n] += t1;
+    }
+    uint16_t *__restrict__ rt16 = a.rows_t16;
+    if (rows_t || rt16) {
+        const bool vec_ok = rows_t ? (((ld_t & 3) == 0) && ((reinterpret_cast<size_t>(rows_t) & 15) == 0))
+                                   : (((ld_t & 3) == 0) && ((reinterpret_cast<size_t>(rt16) & 7) == 0));
+        if (vec_ok) {
+            // 16 lanes x 4 frames = one row segment, 4 rows per wave instruction
+            const int c4 = (lane & 15) * 4, rsub = lane >> 4;
+#pragma unroll
+            for (int i = 0; i < RPW / 4; ++i) {
+                const int j = wave * RPW + i * 4 + rsub;
+                const unsigned nn = n0 + (unsigned)j;
+                const long long row = (nn < nnodes) ? (a.rowmap ? (long long)a.rowmap[nn] : (long long)nn) : -1;
+                if (row >= 0 && c4 < nframes) {
+                    const unsigned d0 = tile[c4 >> 1][j], d1 = tile[(c4 >> 1) + 1][j];
+                    const bool sk = skipf[j] != 0;
+                    if (rows_t) {
+                        typedef float v4f __attribute__((ext_vector_type(4)));
+                        v4f nv;
+                        nv.x = sk ? qnan : (float)(d0 & 0xFFFFu);
+                        nv.y = sk ? qnan : (float)(d0 >> 16);
+                        nv.z = sk ? qnan : (float)(d1 & 0xFFFFu);
+                        nv.w = sk ? qnan : (float)(d1 >> 16);
+                        float *dst = rows_t + row * ld_t + c4;
+                        if (c4 + 3 < nframes) {
+                            if (kStreamStores)
+                                __builtin_nontemporal_store(nv, reinterpret_cast<v4f *>(dst));
+                            else
+                                *reinterpret_cast<v4f *>(dst) = nv;
+                        } else {
+                            dst[0] = nv.x;
+                            if (c4 + 1 < nframes) dst[1] = nv.y;
+                            if (c4 + 2 < nframes) dst[2] = nv.z;
+                        }
+                    } else {   // u16 series (exchange wire format): NaN rows are stored as 0
+                        typedef unsigned v2u __attribute__((ext_vector_type(2)));
+                        const v2u nv = {sk ? 0u : d0, sk ? 0u : d1};
+                        uint16_t *dst = rt16 + row * ld_t + c4;
+                        if (c4 + 3 < nframes) {
+                            if (kStreamStores)
+                                __builtin_nontemporal_store(nv, reinterpret_cast<v2u *>(dst));
+                            else
+                                *reinterpret_cast<v2u *>(dst) = nv;
+                        } else {
+                            dst[0] = (uint16_t)(nv.x & 0xFFFFu);
+                            if (c4 + 1 < nframes) dst[1] = (uint16_t)(nv.x >> 16);
+                            if (c4 + 2 < nframes) dst[2] = (uint16_t)(nv.y & 0xFFFFu);
+                        }
+                    }
+                }
+            }
+        } else {  // lane = frame: 256-byte (128-byte) row segments, any alignment
+            for (int j = wave; j < 64; j += WAVES) {
+                const unsigned nn = n0 + (unsigned)j;
+                const long long row = (nn < nnodes) ? (a.rowmap ? (long long)a.rowmap[nn] : (long long)nn) : -1;
+                if (row >= 0 && lane < nframes) {
+                    const unsigned v = (tile[lane >> 1][j] >> (16 * (lane & 1))) & 0xFFFFu;
+                    const bool sk = skipf[j] != 0;
+                    if (rows_t) rows_t[row * ld_t + lane] = sk ? qnan : (float)v;
+                    else rt16[row * ld_t + lane] = sk ? (uint16_t)0 : (uint16_t)v;
+                }
+            }
+        }
+    }
+    if (rows) {    // lane = node, wave g writes frames g, g+WAVES, ...
+        const bool sk = skipf[lane] != 0;
+        for (int f = wave; f < nframes; f += WAVES)
+            if (live) rows[(size_t)f * nnodes + n] = sk ? qnan : (float)((tile[f >> 1][lane] >> (16 * (f & 1))) & 0xFFFFu);
     }
 }
 
@@ -394,6 +587,33 @@ __global__ void __launch_bounds__(256)
             *reinterpret_cast<float4 *>(d + c) = *reinterpret_cast<const float4 *>(s + c);
     } else {
         for (int c = lane; c < ncols; c += 64) d[c] = s[c];
+    }
+}
+
+// The same for a u16 block (integer-valued series that travelled as u16): 8 B per lane in, 16 B out.
+__global__ void __launch_bounds__(256)
+    scatter_rows_u16_kernel(const uint16_t *__restrict__ src, long long nrows, int ncols,
+                            const long long *__restrict__ rowidx, float *__restrict__ dst, long long ld)
+{
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= nrows) return;
+    const int lane = threadIdx.x & 63;
+    const uint16_t *s = src + r * ncols;
+    float *d = dst + rowidx[r] * ld;
+    const bool vec = ((ncols & 3) == 0) && ((ld & 3) == 0) && ((reinterpret_cast<size_t>(src) & 7) == 0) &&
+                     ((reinterpret_cast<size_t>(dst) & 15) == 0);
+    if (vec) {
+        for (int c = lane * 4; c < ncols; c += 256) {
+            const uint2 v = *reinterpret_cast<const uint2 *>(s + c);
+            float4 o;
+            o.x = (float)(v.x & 0xFFFFu);
+            o.y = (float)(v.x >> 16);
+            o.z = (float)(v.y & 0xFFFFu);
+            o.w = (float)(v.y >> 16);
+            *reinterpret_cast<float4 *>(d + c) = o;
+        }
+    } else {
+        for (int c = lane; c < ncols; c += 64) d[c] = (float)s[c];
     }
 }
 
@@ -547,6 +767,7 @@ int launch_gather(const PipelineGather &g, hipStream_t st)
     a.npix = g.npix;
     a.src = g.src;
     a.rowmap = g.rowmap;
+    a.rows_t16 = g.rows_t16;
     for (int c = 0; c < g.ncams; ++c) {
         a.img[c] = g.img[c];
         a.pix[c] = g.pix[c];
@@ -556,6 +777,25 @@ int launch_gather(const PipelineGather &g, hipStream_t st)
     if (g.nframes <= 64) {
         KTimed kt("gather_tile_kernel", st);
         const dim3 tgrid((unsigned)((g.nnodes + 63) / 64)), tblock(256);
+        static const bool stream_stores = std::getenv("UPSP_NO_STREAM_STORES") == nullptr;
+        static const int tile16_waves = std::getenv("UPSP_GATHER_WAVES") ? std::atoi(std::getenv("UPSP_GATHER_WAVES")) : 4;
+        if (g.ncams == 1 && !g.weight[0] && !g.is_f32[0] && tile16_waves > 0) {
+            // exact 16-bit values: u16 LDS tile, more gathers in flight per CU
+#define UPSP_T16(W, SS, HS)                                                                    \
+    hipLaunchKernelGGL((gather_tile16_kernel<W, SS, HS>), tgrid, dim3(W * 64), 0, st, a,       \
+                       g.skipped, (unsigned)g.nnodes, g.nframes, g.rows, g.rows_t,             \
+                       (long long)g.ld_t, g.sum, g.sumsq)
+#define UPSP_T16W(W)                                                                           \
+    do {                                                                                       \
+        if (g.src) { if (stream_stores) UPSP_T16(W, true, true); else UPSP_T16(W, false, true); }      \
+        else { if (stream_stores) UPSP_T16(W, true, false); else UPSP_T16(W, false, false); }          \
+    } while (0)
+            if (tile16_waves == 2) UPSP_T16W(2); else UPSP_T16W(4);   // measured: 4 waves 38 us, 2 waves 42, 8 waves 41
+#undef UPSP_T16W
+#undef UPSP_T16
+            UPSP_HIP_CHECK(hipGetLastError());
+            return UPSP_OK;
+        }
 #define UPSP_TILE2(NC, SS, HS)                                                                 \
     hipLaunchKernelGGL((gather_tile_kernel<NC, SS, HS>), tgrid, tblock, 0, st, a, g.skipped,   \
                        (unsigned)g.nnodes, g.nframes, g.rows, g.rows_t, (long long)g.ld_t,     \
@@ -565,7 +805,6 @@ int launch_gather(const PipelineGather &g, hipStream_t st)
         if (g.src) { if (stream_stores) UPSP_TILE2(NC, true, true); else UPSP_TILE2(NC, false, true); } \
         else { if (stream_stores) UPSP_TILE2(NC, true, false); else UPSP_TILE2(NC, false, false); }     \
     } while (0)
-        static const bool stream_stores = std::getenv("UPSP_NO_STREAM_STORES") == nullptr;
         switch (g.ncams) {  // per-camera pix / weight stay in registers for 1..4 cameras
             case 1: UPSP_TILE(1); break;
             case 2: UPSP_TILE(2); break;
@@ -578,7 +817,7 @@ int launch_gather(const PipelineGather &g, hipStream_t st)
         UPSP_HIP_CHECK(hipGetLastError());
         return UPSP_OK;
     }
-    if (g.rows_t) return fail(UPSP_ERR_INVALID, "transposed output needs sub-batches of <= 64 frames");
+    if (g.rows_t || g.rows_t16) return fail(UPSP_ERR_INVALID, "transposed output needs sub-batches of <= 64 frames");
     const dim3 grid((unsigned)((g.nnodes + 255) / 256)), block(256);
     if (g.ncams == 1)
         hipLaunchKernelGGL((gather_kernel<1>), grid, block, 0, st, a, g.skipped, (unsigned)g.nnodes,
@@ -623,6 +862,17 @@ int upsp_scatter_rows_f32(const float *d_src, size_t nrows, int ncols, const int
     if (nrows == 0 || ncols == 0) return UPSP_OK;
     if (!d_src || !d_rowidx || !d_dst || ncols < 0 || ld < ncols) return fail(UPSP_ERR_INVALID, "bad argument");
     hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       d_src, (long long)nrows, ncols, reinterpret_cast<const long long *>(d_rowidx), d_dst, ld);
+    UPSP_HIP_CHECK(hipGetLastError());
+    return UPSP_OK;
+}
+
+int upsp_scatter_rows_u16(const uint16_t *d_src, size_t nrows, int ncols, const int64_t *d_rowidx,
+                          float *d_dst, long long ld, void *stream)
+{
+    if (nrows == 0 || ncols == 0) return UPSP_OK;
+    if (!d_src || !d_rowidx || !d_dst || ncols < 0 || ld < ncols) return fail(UPSP_ERR_INVALID, "bad argument");
+    hipLaunchKernelGGL(scatter_rows_u16_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        d_src, (long long)nrows, ncols, reinterpret_cast<const long long *>(d_rowidx), d_dst, ld);
     UPSP_HIP_CHECK(hipGetLastError());
     return UPSP_OK;

@@ -26,6 +26,7 @@ struct PipelineGather {
     const int32_t *src = nullptr;  // overlap source map (adjust_solution): stored value of node n = sol[src[n]]
     float *rows = nullptr;  // [nframes][nnodes], may be null
     float *rows_t = nullptr;  // node-major: rows_t[n*ld_t + f], may be null
+    uint16_t *rows_t16 = nullptr;  // the node-major series as u16 instead (pitch ld_t elements), may be null
     int64_t ld_t = 0;
     double *sum = nullptr, *sumsq = nullptr;
 };

@@ -268,12 +268,19 @@ int upsp_pipeline_finalize(upsp_pipeline *p, uint64_t nframes_total, float *d_av
                          (hipStream_t)stream);
 }
 
-int upsp_pipeline_process(upsp_pipeline *p, const uint16_t *const *d_frames, int nframes,
-                          int64_t first_frame, float *d_rows, float *d_rows_t, int64_t ld_t,
-                          int64_t col0, float *d_warps, void *stream)
+static int process_impl(upsp_pipeline *p, const uint16_t *const *d_frames, int nframes,
+                        int64_t first_frame, float *d_rows, float *d_rows_t, uint16_t *d_rows_t16,
+                        int64_t ld_t, int64_t col0, float *d_warps, void *stream)
 {
     if (!p || !d_frames || nframes < 0) return fail(UPSP_ERR_INVALID, "bad argument");
     if (nframes == 0) return UPSP_OK;
+    if (d_rows_t16) {
+        // the stored values must be exact 16-bit integers: one camera, weight 1, the gather reading
+        // u16 pixels (raw or warped frames; the patch and filter stages produce floats)
+        if (p->ncams != 1 || p->d_weight[0] || p->opts.patch || p->opts.filter)
+            return fail(UPSP_ERR_INVALID, "u16 series needs one camera, no weights, no patch / filter stage");
+        if (ld_t < col0 + nframes) return fail(UPSP_ERR_INVALID, "ld_t too small");
+    }
     hipStream_t st = (hipStream_t)stream;
     for (int c = 0; c < p->ncams; ++c) {
         if (!d_frames[c]) return fail(UPSP_ERR_INVALID, "null frame pointer");
@@ -332,6 +339,7 @@ int upsp_pipeline_process(upsp_pipeline *p, const uint16_t *const *d_frames, int
         g.sumsq = p->d_sumsq;
         g.rows = d_rows ? d_rows + (size_t)f0 * p->nnodes : nullptr;
         g.rows_t = d_rows_t ? d_rows_t + col0 + f0 : nullptr;
+        g.rows_t16 = d_rows_t16 ? d_rows_t16 + col0 + f0 : nullptr;
         g.ld_t = ld_t;
         for (int c = 0; c < p->ncams && rc == UPSP_OK; ++c) {
             uint16_t *frames = const_cast<uint16_t *>(d_frames[c]) + (size_t)f0 * npix;
@@ -372,6 +380,23 @@ int upsp_pipeline_process(upsp_pipeline *p, const uint16_t *const *d_frames, int
         UPSP_HIP_CHECK(hipStreamWaitEvent(st, p->ev_out, 0));
     }
     return rc;
+}
+
+int upsp_pipeline_process(upsp_pipeline *p, const uint16_t *const *d_frames, int nframes,
+                          int64_t first_frame, float *d_rows, float *d_rows_t, int64_t ld_t,
+                          int64_t col0, float *d_warps, void *stream)
+{
+    return process_impl(p, d_frames, nframes, first_frame, d_rows, d_rows_t, nullptr, ld_t, col0,
+                        d_warps, stream);
+}
+
+int upsp_pipeline_process_u16(upsp_pipeline *p, const uint16_t *const *d_frames, int nframes,
+                              int64_t first_frame, uint16_t *d_series_u16, int64_t ld_t,
+                              int64_t col0, float *d_warps, void *stream)
+{
+    if (!d_series_u16) return fail(UPSP_ERR_INVALID, "null series buffer");
+    return process_impl(p, d_frames, nframes, first_frame, nullptr, nullptr, d_series_u16, ld_t,
+                        col0, d_warps, stream);
 }
 
 }  // extern "C"

@@ -93,18 +93,25 @@ def exchange_time_series(rows_t, shard, group=None, out=None):
     return out
 
 
+def _widen_u16(blk):
+    """u16 -> f32 with operators every backend has (uint16 tensors support little else)."""
+    return blk.view(torch.int16).to(torch.int32).bitwise_and_(0xFFFF).to(torch.float32)
+
+
 def _scatter_rows(out, rows, col, blk):
-    """out[rows, col:col+blk.shape[1]] = blk ; library kernel on the GPU, torch indexing on the CPU."""
+    """out[rows, col:col+blk.shape[1]] = blk ; library kernel on the GPU, torch indexing on the CPU.
+    blk is f32, or u16 (the exchange's wire format for integer-valued series), widened here."""
     if out.is_cuda:
         import ctypes as C
         from . import _capi
         blk = blk.contiguous()
         dst = out[:, col:]
-        _capi.check(_capi.lib().upsp_scatter_rows_f32(
+        fn = _capi.lib().upsp_scatter_rows_u16 if blk.dtype == torch.uint16 else _capi.lib().upsp_scatter_rows_f32
+        _capi.check(fn(
             C.c_void_p(blk.data_ptr()), blk.shape[0], blk.shape[1], C.c_void_p(rows.data_ptr()),
             C.c_void_p(dst.data_ptr()), out.stride(0), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     else:
-        out[rows, col:col + blk.shape[1]] = blk
+        out[rows, col:col + blk.shape[1]] = _widen_u16(blk) if blk.dtype == torch.uint16 else blk
 
 
 def aligned_chunks(nframes, nchunks, align=64):
@@ -209,6 +216,10 @@ class TimeSeriesExchange:
         c0, fc = self.my_chunk(k)
         assert rows_t_chunk.shape == ((self.packed_rows() if packed else sh.nnodes), fc)
         assert not packed or self.vis is not None
+        # u16 chunks (FramePipeline.process with a uint16 rows_t: integer-valued series, half the
+        # bytes on the links) exist only packed -- u16 cannot hold the NaN rows
+        wire16 = rows_t_chunk.dtype == torch.uint16
+        assert not wire16 or packed
         n0, nn = sh.my_nodes
         self.k += 1
         if sh.world == 1 or not dist.is_initialized():
@@ -226,17 +237,20 @@ class TimeSeriesExchange:
             # packed rows, ordered by destination
             send = rows_t_chunk.contiguous() if packed else rows_t_chunk.index_select(0, self.vis)
             count_out, count_in = self.vis_count, self.vis_count[sh.rank]
-        in_split = [count_out[d] * fc for d in range(sh.world)]
-        out_split = [count_in * self.chunks[s][1][k] for s in range(sh.world)]
-        recv = torch.empty(sum(out_split), dtype=send.dtype, device=send.device)
-        work = dist.all_to_all_single(recv, send.reshape(-1), out_split, in_split,
-                                      group=self.group, async_op=True)
-        self.pending.append((work, recv, k, send, count_in))    # keep the send buffer alive
+        esz = 2 if wire16 else 1                        # u16 travels as bytes (every backend has uint8)
+        in_split = [count_out[d] * fc * esz for d in range(sh.world)]
+        out_split = [count_in * self.chunks[s][1][k] * esz for s in range(sh.world)]
+        flat = send.reshape(-1).view(torch.uint8) if wire16 else send.reshape(-1)
+        recv = torch.empty(sum(out_split), dtype=flat.dtype, device=send.device)
+        work = dist.all_to_all_single(recv, flat, out_split, in_split, group=self.group, async_op=True)
+        self.pending.append((work, recv, k, send, count_in, wire16))    # keep the send buffer alive
 
     def finish(self):
         sh = self.shard
-        for work, recv, k, _, rows_in in self.pending:
+        for work, recv, k, _, rows_in, wire16 in self.pending:
             work.wait()
+            if wire16:
+                recv = recv.view(torch.uint16)
             off = 0
             for s in range(sh.world):
                 fs = self.chunks[s][1][k]

@@ -331,9 +331,16 @@ class FramePipeline:
         for fr in frames:
             assert fr.is_cuda and fr.dtype == torch.uint16 and fr.is_contiguous()
             assert tuple(fr.shape) == (f, self.height, self.width)
+        ptrs = (C.c_void_p * self.ncams)(*[fr.data_ptr() for fr in frames])
+        if rows_t is not None and rows_t.dtype == torch.uint16:
+            # wire format of the time-series exchange (upsp_pipeline_process_u16): the library
+            # refuses it unless every stored value is an exact 16-bit integer
+            assert rows_t.is_cuda and (rows_t.shape[1] <= 1 or rows_t.stride(1) == 1)
+            check(lib().upsp_pipeline_process_u16(self._h, ptrs, f, int(first_frame), _ptr(rows_t),
+                                                  rows_t.stride(0), col0, _ptr(warps), _stream()))
+            return None
         if rows is None and want_rows:
             rows = torch.empty((f, self.nnodes), dtype=torch.float32, device="cuda")
-        ptrs = (C.c_void_p * self.ncams)(*[fr.data_ptr() for fr in frames])
         ld = 0 if rows_t is None else rows_t.stride(0)
         check(lib().upsp_pipeline_process(self._h, ptrs, f, int(first_frame), _ptr(rows),
                                           _ptr(rows_t), ld, col0, _ptr(warps), _stream()))
