@@ -569,51 +569,62 @@ __global__ void finals_kernel(const double *__restrict__ sum, const double *__re
     if (rms) rms[n] = (float)sqrt(sumsq[n] / nframes);     // psp_process.cpp:1935
 }
 
-// Row scatter for the time-series exchange: packed block src [nrows][ncols] -> rows rowidx[r] of
-// dst (row pitch ld, column offset already applied).  One wave per row segment, 16 B per lane.
-__global__ void __launch_bounds__(256)
-    scatter_rows_kernel(const float *__restrict__ src, long long nrows, int ncols,
-                        const long long *__restrict__ rowidx, float *__restrict__ dst, long long ld)
+// Row scatter for the time-series exchange: packed block src [nrows][ncols] (f32, or u16 for
+// integer-valued series that travelled as u16) -> rows rowidx[r] of dst (f32, row pitch ld, column
+// offset already applied).  A wave moves 4 rows, 16 B of output per lane and row.  Bound by the
+// strided row-segment writes (190 k x 1 KB segments: 62 us = 3.5 TB/s, one or four rows per wave alike).
+template <typename T>
+__device__ __forceinline__ void load4(const T *p, float (&o)[4]);
+template <>
+__device__ __forceinline__ void load4<float>(const float *p, float (&o)[4])
 {
-    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= nrows) return;
-    const int lane = threadIdx.x & 63;
-    const float *s = src + r * ncols;
-    float *d = dst + rowidx[r] * ld;
-    const bool vec = ((ncols & 3) == 0) && ((ld & 3) == 0) && ((reinterpret_cast<size_t>(src) & 15) == 0) &&
-                     ((reinterpret_cast<size_t>(dst) & 15) == 0);
-    if (vec) {
-        for (int c = lane * 4; c < ncols; c += 256)
-            *reinterpret_cast<float4 *>(d + c) = *reinterpret_cast<const float4 *>(s + c);
-    } else {
-        for (int c = lane; c < ncols; c += 64) d[c] = s[c];
-    }
+    const float4 v = *reinterpret_cast<const float4 *>(p);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+template <>
+__device__ __forceinline__ void load4<uint16_t>(const uint16_t *p, float (&o)[4])
+{
+    const uint2 v = *reinterpret_cast<const uint2 *>(p);
+    o[0] = (float)(v.x & 0xFFFFu); o[1] = (float)(v.x >> 16);
+    o[2] = (float)(v.y & 0xFFFFu); o[3] = (float)(v.y >> 16);
 }
 
-// The same for a u16 block (integer-valued series that travelled as u16): 8 B per lane in, 16 B out.
+template <typename T>
 __global__ void __launch_bounds__(256)
-    scatter_rows_u16_kernel(const uint16_t *__restrict__ src, long long nrows, int ncols,
-                            const long long *__restrict__ rowidx, float *__restrict__ dst, long long ld)
+    scatter_rows_kernel(const T *__restrict__ src, long long nrows, int ncols,
+                        const long long *__restrict__ rowidx, float *__restrict__ dst, long long ld)
 {
-    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= nrows) return;
+    const long long r0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+    if (r0 >= nrows) return;
     const int lane = threadIdx.x & 63;
-    const uint16_t *s = src + r * ncols;
-    float *d = dst + rowidx[r] * ld;
-    const bool vec = ((ncols & 3) == 0) && ((ld & 3) == 0) && ((reinterpret_cast<size_t>(src) & 7) == 0) &&
+    const int nr = (int)((nrows - r0) < 4 ? (nrows - r0) : 4);
+    const bool vec = ((ncols & 3) == 0) && ((ld & 3) == 0) &&
+                     ((reinterpret_cast<size_t>(src) & (4 * sizeof(T) - 1)) == 0) &&
                      ((reinterpret_cast<size_t>(dst) & 15) == 0);
     if (vec) {
+        typedef float v4f __attribute__((ext_vector_type(4)));   // streamed: the series is not re-read here
         for (int c = lane * 4; c < ncols; c += 256) {
-            const uint2 v = *reinterpret_cast<const uint2 *>(s + c);
-            float4 o;
-            o.x = (float)(v.x & 0xFFFFu);
-            o.y = (float)(v.x >> 16);
-            o.z = (float)(v.y & 0xFFFFu);
-            o.w = (float)(v.y >> 16);
-            *reinterpret_cast<float4 *>(d + c) = o;
+            float v[4][4];
+            long long row[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < nr) {
+                    row[k] = rowidx[r0 + k];
+                    load4<T>(src + (r0 + k) * ncols + c, v[k]);
+                }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < nr) {
+                    const v4f o = {v[k][0], v[k][1], v[k][2], v[k][3]};
+                    __builtin_nontemporal_store(o, reinterpret_cast<v4f *>(dst + row[k] * ld + c));
+                }
         }
     } else {
-        for (int c = lane; c < ncols; c += 64) d[c] = (float)s[c];
+        for (int k = 0; k < nr; ++k) {
+            const T *s = src + (r0 + k) * ncols;
+            float *d = dst + rowidx[r0 + k] * ld;
+            for (int c = lane; c < ncols; c += 64) d[c] = (float)s[c];
+        }
     }
 }
 
@@ -861,7 +872,7 @@ int upsp_scatter_rows_f32(const float *d_src, size_t nrows, int ncols, const int
 {
     if (nrows == 0 || ncols == 0) return UPSP_OK;
     if (!d_src || !d_rowidx || !d_dst || ncols < 0 || ld < ncols) return fail(UPSP_ERR_INVALID, "bad argument");
-    hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(scatter_rows_kernel<float>, dim3((unsigned)((nrows + 15) / 16)), dim3(256), 0, (hipStream_t)stream,
                        d_src, (long long)nrows, ncols, reinterpret_cast<const long long *>(d_rowidx), d_dst, ld);
     UPSP_HIP_CHECK(hipGetLastError());
     return UPSP_OK;
@@ -872,7 +883,7 @@ int upsp_scatter_rows_u16(const uint16_t *d_src, size_t nrows, int ncols, const 
 {
     if (nrows == 0 || ncols == 0) return UPSP_OK;
     if (!d_src || !d_rowidx || !d_dst || ncols < 0 || ld < ncols) return fail(UPSP_ERR_INVALID, "bad argument");
-    hipLaunchKernelGGL(scatter_rows_u16_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(scatter_rows_kernel<uint16_t>, dim3((unsigned)((nrows + 15) / 16)), dim3(256), 0, (hipStream_t)stream,
                        d_src, (long long)nrows, ncols, reinterpret_cast<const long long *>(d_rowidx), d_dst, ld);
     UPSP_HIP_CHECK(hipGetLastError());
     return UPSP_OK;
