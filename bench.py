@@ -303,7 +303,7 @@ def main():
     # MI355X_MICROARCH.md "HBM"; counter unit = KB) -- per launch, same launch shape
     traffic = None
     prof = os.path.join(ROOT, "profiles", "r01_bench_summary.json")
-    pkey = {"gather_tile_kernel": "gather_tile_kernel<1, true, false>", "hot_scan_kernel": "hot_scan_kernel",
+    pkey = {"gather_tile_kernel": "gather_tile16_kernel<4, true, false>", "hot_scan_kernel": "hot_scan_kernel",
             "projection_kernel<primary>": "projection_kernel<false, 0>",
             "projection_kernel<retry>": "projection_kernel<false, 1>"}.get(dom)
     if os.path.exists(prof) and pkey:

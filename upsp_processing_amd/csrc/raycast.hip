@@ -891,32 +891,46 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 
                 PHASE == 0 ? my_rays : 0u, PHASE == 0 ? my_rays : 0u);
 }
 
-// Step 2b (elementwise): compact the nodes that need retries into a list; one queue
-// atomic per workgroup (the traversal kernel itself issues none).
+// Step 2b (elementwise): compact the nodes that need retries into a list.  One queue atomic per
+// workgroup of kRetryListItems x 256 nodes: atomics on one address retire at ~88 per us on this
+// part, so one per 256 nodes (1957 of them) made this a 24-us kernel.
+constexpr int kRetryListItems = 8;
 __global__ void __launch_bounds__(256)
     retry_list_kernel(const int32_t *__restrict__ pix, unsigned nnodes,
                       unsigned *__restrict__ retry_nodes, unsigned *__restrict__ retry_mask,
                       unsigned *work)
 {
-    __shared__ unsigned wave_cnt[4], block_base;
-    const unsigned n = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool need = n < nnodes && pix[n] == kPixRetry;
-    const unsigned long long m = __ballot(need);
+    __shared__ unsigned wave_cnt[kRetryListItems][4], block_base;
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) wave_cnt[wave] = (unsigned)__popcll(m);
+    const unsigned base = blockIdx.x * (256u * kRetryListItems) + threadIdx.x;
+    unsigned long long m[kRetryListItems];
+    bool need[kRetryListItems];
+#pragma unroll
+    for (int k = 0; k < kRetryListItems; ++k) {
+        const unsigned n = base + 256u * k;
+        need[k] = n < nnodes && pix[n] == kPixRetry;
+        m[k] = __ballot(need[k]);
+        if (lane == 0) wave_cnt[k][wave] = (unsigned)__popcll(m[k]);
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned tot = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        unsigned tot = 0;
+        for (int k = 0; k < kRetryListItems; ++k)
+            for (int w = 0; w < 4; ++w) {   // exclusive prefix in place
+                const unsigned c = wave_cnt[k][w];
+                wave_cnt[k][w] = tot;
+                tot += c;
+            }
         block_base = tot ? atomicAdd(&work[kWorkRetryCount], tot) : 0u;
     }
     __syncthreads();
-    if (need) {
-        unsigned off = block_base;
-        for (unsigned w = 0; w < wave; ++w) off += wave_cnt[w];
-        const unsigned slot = off + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-        retry_nodes[slot] = n;
-        retry_mask[slot] = 0u;
-    }
+#pragma unroll
+    for (int k = 0; k < kRetryListItems; ++k)
+        if (need[k]) {
+            const unsigned slot = block_base + wave_cnt[k][wave] + (unsigned)__popcll(m[k] & ((1ull << lane) - 1ull));
+            retry_nodes[slot] = base + 256u * k;
+            retry_mask[slot] = 0u;
+        }
 }
 
 // Step 4: retry outcome per listed node + the reference's ray count
@@ -1555,7 +1569,8 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
     UPSP_HIP_CHECK(hipMemsetAsync(b->d_work, 0, sizeof(unsigned), st));  // queue head
     {
         KTimed kt("retry_list_kernel", st);
-        hipLaunchKernelGGL(retry_list_kernel, egrid, eblock, 0, st, (const int32_t *)d_pix,
+        const dim3 lgrid((unsigned)((nnodes + 256 * kRetryListItems - 1) / (256 * kRetryListItems)));
+        hipLaunchKernelGGL(retry_list_kernel, lgrid, eblock, 0, st, (const int32_t *)d_pix,
                            (unsigned)nnodes, b->d_retry_nodes, b->d_retry_mask, b->d_work);
     }
     {
