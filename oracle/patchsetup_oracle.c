@@ -23,7 +23,12 @@
 
 #define ORC_PI 3.141592653589793 /* cpp/include/utils/general_utils.h:17-18 */
 
-static int cv_round_f(float v) { return (int)lrint((double)v); }
+/* cvRound(float) = cvtss2si: NaN / beyond the int range -> 0x80000000 (out of frame), no wrap-around */
+static int cv_round_f(float v)
+{
+    if (!(v >= -2147483648.0f && v < 2147483648.0f)) return (int)0x80000000u;
+    return (int)lrint((double)v);
+}
 
 static int in_frame_i(int w, int h, float u, float v)
 { /* upsp::contains(cv::Size, cv::Point2i(Point2f)) cpp/lib/projection.cpp:10-13 */

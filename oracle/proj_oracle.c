@@ -10,6 +10,7 @@
  */
 #include "upsp_oracle.h"
 
+#include <limits.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -77,8 +78,15 @@ static void norm3(float v[3])
     }
 }
 
-/* cv::Point2f -> cv::Point2i conversion = cvRound (round half to even) */
-static int cv_round(float v) { return (int)lrintf(v); }
+/* cv::Point2f -> cv::Point2i conversion = saturate_cast<int>(float) = cvRound(float): round half to
+ * even through cvtss2si, which answers 0x80000000 ("integer indefinite") for NaN and for values
+ * outside the int range -- a strongly distorted far-off node (|pt| ~ 1e10) is out of frame, it must
+ * not wrap around into it. */
+static int cv_round(float v)
+{
+    if (!(v >= -2147483648.0f && v < 2147483648.0f)) return INT_MIN;
+    return (int)lrintf(v);
+}
 
 static int tri_has_node(const int32_t *tri_nodes3, int32_t prim, int32_t nidx)
 {

@@ -72,8 +72,14 @@ while time.time() < t_end:
             if adj:
                 bvh.set_tri_nodes(d_tn, v.shape[0])
             g = engine.build_projection(bvh, cg, v, nrm, d_tn, 70.0)
-            ok = ok and np.array_equal(g["pix"].cpu().numpy(), want["pix"]) and g["nrays"] == want["nrays"] \
+            okp = np.array_equal(g["pix"].cpu().numpy(), want["pix"]) and g["nrays"] == want["nrays"] \
                 and same(g["uv"], want["uv"])
+            if not okp:
+                gp = g["pix"].cpu().numpy()
+                bad = np.nonzero(gp != want["pix"])[0]
+                print("  projection mismatch (adjacency %s): %d nodes differ, first %s gpu %s oracle %s; nrays %d vs %d"
+                      % (adj, bad.size, bad[:5], gp[bad[:5]], want["pix"][bad[:5]], g["nrays"], want["nrays"]), flush=True)
+            ok = ok and okp
     nscenes += 1
     print("seed %d kind %d tris %d: %s" % (seed, kind, s9.size // 9, "ok" if ok else "MISMATCH"), flush=True)
     bvh.close()

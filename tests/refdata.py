@@ -102,3 +102,31 @@ def read_camera_tunnel_cal(path, dims):
 def fml_grid():
     zs, x, y, z = read_p3d_grid(os.path.join(GOLDEN, "fml_tc3_volume.grid"))
     return p3d_to_triangles(zs, x, y, z)
+
+
+def distorted_plates_scene():
+    """Two axis-aligned plates seen by a camera with k1 = -0.05 whose far-off nodes project to
+    |pt| ~ 1e10 .. 1e16 pixels (scene 6438 of tests/debug/soak_raycast.py, which exposed an int
+    wrap-around in the oracle's cvRound).  Returns (verts, tris, camera dict, (W, H))."""
+    import numpy as np
+    from upsp_processing_amd import synthetic as syn
+    rng = np.random.default_rng(6438)
+    g = int(rng.integers(2, 30))
+    x, y = np.meshgrid(np.arange(g + 1, dtype=np.float32), np.arange(g + 1, dtype=np.float32))
+    v = np.stack([x.ravel(), y.ravel(), np.zeros(x.size, np.float32)], 1)
+    q = np.arange(g * g)
+    i0 = q // g * (g + 1) + q % g
+    t = np.concatenate([np.stack([i0, i0 + 1, i0 + g + 2], 1),
+                        np.stack([i0 + g + 2, i0 + g + 1, i0], 1)]).astype(np.int32)
+    v2 = v.copy()
+    v2[:, 2] = rng.choice([0.5, 1.0, 3.0])
+    v = np.ascontiguousarray(np.concatenate([v, v2]), np.float32)
+    t = np.concatenate([t, t + x.size])
+    m = 4000                      # the soak draws its test rays here: keep the generator in step
+    rng.normal(size=(m, 3)); rng.normal(size=(m, 3)); rng.integers(0, v.shape[0], m); rng.normal(size=(1, 3))
+    rng.integers(0, 3, m); rng.choice([-1.0, 1.0, 2.5], m); rng.choice([0.0, 0.0, 0.1], (m, 3))
+    W, H = int(rng.choice([64, 200, 512])), int(rng.choice([48, 160, 512]))
+    cam = syn.pinhole_camera(W, H, center=tuple(rng.normal(size=3) * 3 + np.array([0, 0, 12])),
+                             half_extent=float(rng.uniform(2, 7)), k1=float(rng.choice([0.0, -0.05])),
+                             azimuth_deg=float(rng.uniform(0, 360)))
+    return v, t, cam, (W, H)

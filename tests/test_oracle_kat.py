@@ -196,3 +196,24 @@ def test_fixture_manifest(fml):
     assert sha(fml["norms"]) == man["normals_sha256"]
     vis = np.load(os.path.join(refdata.GOLDEN, "camera01_visible.npz"))["visible"]
     assert len(vis) == man["visible_count"] == 148608 and sha(vis) == man["visible_sha256"]
+
+
+def test_far_off_distorted_nodes_are_out_of_frame(oracle):
+    """cv::Point2f -> Point2i is cvRound = cvtss2si: a node whose distorted projection lies beyond
+    the int range (|pt| ~ 1e10 px) gives 0x80000000 -- out of frame -- and must not wrap around
+    into the frame (psp_process.cpp:252, upsp::contains(Size, Point2i(pt)))."""
+    import refdata
+    from upsp_processing_amd import synthetic as syn
+    v, t, c, (W, H) = refdata.distorted_plates_scene()
+    s9, tn = syn.soup(v, t)
+    nrm = syn.node_normals(v, t)
+    cam = oracle.make_camera(c["K"], c["dist"], c["R"], c["t"], W, H)
+    pt = oracle.project_points(cam, v)
+    assert (np.abs(pt) >= 2.0 ** 31).any()                       # the case is present
+    ok = (np.abs(pt) < 2.0 ** 31).all(1)
+    r = np.where(ok[:, None], np.rint(np.where(ok[:, None], pt, 0)), -1).astype(np.int64)
+    in_frame = ok & (r[:, 0] >= 0) & (r[:, 1] >= 0) & (r[:, 0] < W) & (r[:, 1] < H)
+    res = oracle.create_projection(oracle.OracleBVH(s9), cam, v, nrm, tn,
+                                   np.float32((180.0 - 70.0) * 3.141592653589793 / 180.0))
+    # every in-frame node costs one primary ray; none of them needs a retry in this scene
+    assert res["nrays"] == int(in_frame.sum()) == 35

@@ -111,3 +111,25 @@ def test_empty_and_ragged(gpu_lib):
     assert (g["pix"].cpu().numpy() == -1).all()
     with pytest.raises(ValueError):
         engine.build_projection(bvh, cam, v, v, tn[:-3], 70.0)
+
+
+def test_far_off_distorted_nodes(gpu_lib, oracle):
+    """Nodes whose distorted projection is beyond the int range are out of frame on both sides
+    (cvRound saturation), with and without the adjacency / occluder-witness path."""
+    import torch
+    import refdata
+    from upsp_processing_amd import _capi, engine, synthetic as syn
+    v, t, c, (W, H) = refdata.distorted_plates_scene()
+    s9, tn = syn.soup(v, t)
+    nrm = syn.node_normals(v, t)
+    cam_g = _capi.make_camera(c["K"], c["dist"], c["R"], c["t"], W, H)
+    cam_o = oracle.make_camera(c["K"], c["dist"], c["R"], c["t"], W, H)
+    o = oracle.create_projection(oracle.OracleBVH(s9), cam_o, v, nrm, tn, engine.oblique_threshold(70.0))
+    bvh = engine.BVH(s9)
+    d_tn = torch.as_tensor(tn).cuda()
+    for adj in (False, True):
+        if adj:
+            bvh.set_tri_nodes(d_tn, v.shape[0])
+        g = engine.build_projection(bvh, cam_g, v, nrm, d_tn, 70.0)
+        assert np.array_equal(g["pix"].cpu().numpy(), o["pix"])
+        assert g["nrays"] == o["nrays"] == 35

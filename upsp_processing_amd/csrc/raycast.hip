@@ -328,6 +328,9 @@ struct Scene {
     unsigned chunk;       // work items per queue grab (multiple of 64)
     float rlo[3], rhi[3];
     const unsigned *adj_off, *adj_slot;   // node -> adjacent triangle slots (may be null)
+    const uint2 *slot_path;               // triangle slot -> (offset, length) of its box chain (may be null)
+    const unsigned *path_ref;             // chain entries: (interior node << 1) | side
+    int *witness;                         // per node: slot hit by the primary ray (retry nodes)
 };
 
 struct Trav {
@@ -717,6 +720,7 @@ constexpr int32_t kPixRetry = -4;     // primary ray hit a foreign triangle: ret
 //   [10] nodes whose primary ray hit a triangle that does not contain them
 //   [11] primary rays cast
 constexpr int kWorkRetryCount = 10;
+constexpr int kWorkTodoCount = 12;   // rays witness_kernel could not decide
 
 // Step 1 (elementwise, fp64): cal.map_point_to_image + in-frame test
 // (psp_process.cpp:241-252).  The image point is parked in uv[].
@@ -732,9 +736,11 @@ __global__ void __launch_bounds__(256)
     if (!datanode || datanode[n]) {  // :241
         project_point(cam.K, cam.dist, cam.R, cam.t, nodes[3 * (size_t)n], nodes[3 * (size_t)n + 1],
                       nodes[3 * (size_t)n + 2], u, v);  // :248
-        // upsp::contains(Size, Point2i(pt)) :252 ; Point2f->Point2i = cvRound
-        const int rx = (int)rintf(u), ry = (int)rintf(v);
-        if ((u == u) & (v == v) & (rx >= 0) & (ry >= 0) & (rx < cam.W) & (ry < cam.H))
+        // upsp::contains(Size, Point2i(pt)) :252 ; Point2f->Point2i = cvRound (cvtss2si: NaN and
+        // values beyond the int range give INT_MIN, i.e. out of frame)
+        const bool finite_int = (fabsf(u) < 2147483648.0f) & (fabsf(v) < 2147483648.0f);   // false for NaN
+        const int rx = finite_int ? (int)rintf(u) : -1, ry = finite_int ? (int)rintf(v) : -1;
+        if ((rx >= 0) & (ry >= 0) & (rx < cam.W) & (ry < cam.H))
             state = kPixInFrame;
     }
     pix[n] = state;
@@ -799,16 +805,187 @@ __device__ __forceinline__ bool apply_own_bound(Trav &s, const OwnBound &o)
     return true;
 }
 
+// Occluder witness.  A node is listed for retries because its primary ray hit a foreign triangle W
+// first.  The six retry rays differ from the primary ray by 1e-4 model units at the node, so they
+// almost always hit W as well.  A retry ray is decided "not visible" without any traversal when
+//   * W is hit at t_w < own_min (nearer than every triangle of the node, tested directly), and
+//   * the reference's traversal reaches W: the root box (trav_begin) and every child box on the
+//     chain root -> leaf(W) accept the ray (the reference descends on the box test alone, no
+//     pruning by distance -- cpp/raycast/pspRT.cpp:380-423), evaluated with the traversal's own box test.
+// Then the closest hit the reference finds is at t <= t_w < own_min, i.e. on a foreign triangle.
+// Anything else (W missed, not nearer, a box on the chain rejected) falls back to the traversal.
+__device__ __forceinline__ bool box_accepts(const Ray &r, bool all_simple, const float2 a, const float2 b,
+                                            const float2 c)
+{
+    float dF;
+    const BoxEval e = all_simple ? box_filter_simple(r, a.x, a.y, b.x, b.y, c.x, c.y, dF)
+                                 : box_filter(r, a.x, a.y, b.x, b.y, c.x, c.y, dF);
+    return e.undecided ? box_exact(r, a.x, a.y, b.x, b.y, c.x, c.y) : e.accept;
+}
+
+// Retry k of a listed node (psp_process.cpp:269-281): target = node position +- 1e-4 on one axis,
+// UN-normalised direction.
+__device__ __forceinline__ void retry_ray(Ray &r, const Cam &cam, const float *__restrict__ nodes,
+                                          unsigned node, int k)
+{
+    const float L = 1e-4f;
+    const float sgn = (k & 1) ? L : -L;
+    const float qx = nodes[3 * (size_t)node] + ((k >> 1) == 0 ? sgn : 0.0f);
+    const float qy = nodes[3 * (size_t)node + 1] + ((k >> 1) == 1 ? sgn : 0.0f);
+    const float qz = nodes[3 * (size_t)node + 2] + ((k >> 1) == 2 ? sgn : 0.0f);
+    ray_setup(r, cam.ox, cam.oy, cam.oz, qx - cam.ox, qy - cam.oy, qz - cam.oz);
+}
+
+// Step 3a: decides the retry rays that need no traversal.  One wave = kWitNodes listed nodes x 6
+// rays (lane = 6 * node + retry).  Per ray: root box, the node's own triangles (own_bound), the
+// witness triangle; then the box chains of the wave's witness leaves are staged through LDS by
+// all lanes at once (every load independent: the per-ray walk inside the traversal kernel was a
+// chain of ~25 dependent loads and cost more than the traversals it saved) and each ray tests
+// its chain from LDS.  Output: todo_mask[listed node] = retries that still need the traversal.
+constexpr int kWitNodes = 10;
+constexpr int kWitSeg = 16;   // chain boxes staged per node and pass
+__global__ void __launch_bounds__(64)
+    witness_kernel(Scene sc, Cam cam, const float *__restrict__ nodes,
+                   const unsigned *__restrict__ retry_nodes, unsigned *__restrict__ todo_mask,
+                   const unsigned *__restrict__ work)
+{
+    __shared__ float boxes[kWitNodes][kWitSeg][6];
+    __shared__ unsigned chain_off[kWitNodes], chain_len[kWitNodes];
+    const unsigned count = work[kWorkRetryCount];
+    const unsigned lane = threadIdx.x;
+    const unsigned j = lane / 6u, k = lane % 6u;
+    const unsigned li = blockIdx.x * kWitNodes + j;
+    if (blockIdx.x * kWitNodes >= count) return;          // whole wave past the list (uniform)
+    const bool active = lane < 6u * kWitNodes && li < count;
+    if (lane < kWitNodes) chain_len[lane] = 0u;
+    __syncthreads();
+    Ray r;
+    r.simple = true;
+    bool undecided = false, chain = false;
+    unsigned len = 0;
+    if (active) {
+        const unsigned node = retry_nodes[li];
+        retry_ray(r, cam, nodes, node, (int)k);
+        ray_classify(r, sc);
+        if (box_hit(r, sc.rlo[0], sc.rlo[1], sc.rlo[2], sc.rhi[0], sc.rhi[1], sc.rhi[2])) {   // trav_begin
+            const OwnBound ob = own_bound(r, sc, node);
+            if (!ob.known) {
+                undecided = true;
+            } else if (ob.hit) {              // (no own triangle hit: cannot see the node, decided)
+                const int slot = sc.witness[node];
+                bool near_hit = false;
+                if (slot >= 0) {
+                    const float4 *tp = sc.tris + 3 * (size_t)slot;
+                    const float4 a = tp[0], b = tp[1], c = tp[2];
+                    TriHit h;
+                    near_hit = tri_test(r, a.x, a.y, a.z, b.x, b.y, b.z, c.x, c.y, c.z, h) && h.t < ob.tmin;
+                }
+                if (near_hit) {
+                    const uint2 pl = sc.slot_path[slot];
+                    chain = true;
+                    len = pl.y;
+                    chain_off[j] = pl.x;      // the six rays of a node write the same values
+                    chain_len[j] = pl.y;
+                } else {
+                    undecided = true;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (__ballot(chain) != 0ull) {
+        unsigned maxlen = 0;
+        for (int n = 0; n < kWitNodes; ++n) maxlen = max(maxlen, chain_len[n]);
+        const bool all_simple = __ballot(!r.simple) == 0ull;
+        const float2 *nodes2 = reinterpret_cast<const float2 *>(sc.nodes);
+        bool ok = true;
+        for (unsigned base = 0; base < maxlen; base += kWitSeg) {
+            // stage kWitNodes x kWitSeg boxes: record = 16 floats, left box = floats 0..5, right 6..11
+            for (unsigned b = lane; b < kWitNodes * kWitSeg; b += 64u) {
+                const unsigned jj = b / kWitSeg, e = base + b % kWitSeg;
+                if (e < chain_len[jj]) {
+                    const unsigned ref = sc.path_ref[chain_off[jj] + e];
+                    const float2 *p = nodes2 + 8 * (size_t)(ref >> 1) + 3 * (ref & 1u);
+                    const float2 a = p[0], bb = p[1], c = p[2];
+                    float *d = boxes[jj][b % kWitSeg];
+                    d[0] = a.x; d[1] = a.y; d[2] = bb.x; d[3] = bb.y; d[4] = c.x; d[5] = c.y;
+                }
+            }
+            __syncthreads();
+            const unsigned n = (chain && len > base) ? min((unsigned)kWitSeg, len - base) : 0u;
+            for (unsigned e = 0; e < (unsigned)kWitSeg; ++e) {
+                if (__ballot(e < n && ok) == 0ull) break;
+                if (e < n && ok) {
+                    const float *d = boxes[j][e];
+                    ok = box_accepts(r, all_simple, make_float2(d[0], d[1]), make_float2(d[2], d[3]),
+                                     make_float2(d[4], d[5]));
+                }
+            }
+            __syncthreads();
+        }
+        if (chain && !ok) undecided = true;   // a box on the chain rejects the ray: ask the traversal
+    }
+    const unsigned long long m = __ballot(undecided);
+    if (active && k == 0u) todo_mask[li] = (unsigned)((m >> (6u * j)) & 63ull);
+}
+
+// Step 3b: compact the undecided retries into a ray list (item = 6 * listed node + retry); one
+// queue atomic per workgroup of 1024 listed nodes.
+__global__ void __launch_bounds__(256)
+    todo_list_kernel(const unsigned *__restrict__ todo_mask, unsigned *__restrict__ todo_rays,
+                     unsigned *work)
+{
+    constexpr int kItems = 4;
+    __shared__ unsigned wave_cnt[kItems][4], block_base;
+    const unsigned count = work[kWorkRetryCount];
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned base = blockIdx.x * (256u * kItems) + threadIdx.x;
+    if (blockIdx.x * (256u * kItems) >= count) return;
+    unsigned mask[kItems], pre[kItems];
+#pragma unroll
+    for (int i = 0; i < kItems; ++i) {
+        const unsigned li = base + 256u * i;
+        mask[i] = li < count ? todo_mask[li] : 0u;
+        unsigned c = (unsigned)__popc(mask[i]), incl = c;   // inclusive wave scan of the counts
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned v = __shfl_up(incl, off);
+            if ((int)lane >= off) incl += v;
+        }
+        pre[i] = incl - c;
+        if (lane == 63) wave_cnt[i][wave] = incl;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned tot = 0;
+        for (int i = 0; i < kItems; ++i)
+            for (int w = 0; w < 4; ++w) {
+                const unsigned c = wave_cnt[i][w];
+                wave_cnt[i][w] = tot;
+                tot += c;
+            }
+        block_base = tot ? atomicAdd(&work[kWorkTodoCount], tot) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kItems; ++i) {
+        unsigned slot = block_base + wave_cnt[i][wave] + pre[i];
+        const unsigned li = base + 256u * i;
+        for (unsigned mm = mask[i]; mm; mm &= mm - 1u)
+            todo_rays[slot++] = 6u * li + (unsigned)(__ffs((int)mm) - 1);
+    }
+}
+
 template <bool STATS, int PHASE>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 8)))
     projection_kernel(Scene sc, Cam cam, const float *__restrict__ nodes,
                       const int32_t *__restrict__ tri_nodes, unsigned nnodes,
                       int32_t *__restrict__ pix, unsigned *__restrict__ retry_nodes,
-                      unsigned *__restrict__ retry_mask, unsigned *work)
+                      unsigned *__restrict__ retry_mask, const unsigned *__restrict__ todo_rays,
+                      unsigned *work)
 {
     extern __shared__ int lds_stack[];
     int *stack = lds_stack + threadIdx.x;
-    const unsigned total = PHASE == 0 ? nnodes : work[kWorkRetryCount] * 6u;
+    const unsigned total = PHASE == 0 ? nnodes : PHASE == 1 ? work[kWorkRetryCount] * 6u : work[kWorkTodoCount];
     WaveQueue q;
     queue_init(q, work, total, sc.chunk);
     Ray r;
@@ -840,19 +1017,14 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 
                     ++my_rays;
                 }
             }
-            if (got && PHASE == 1) {
-                // retry k of listed node: pos +- 1e-4 on one axis, UN-normalised direction
-                const unsigned node = retry_nodes[it / 6u];
-                const int k = (int)(it % 6u);
-                const float L = 1e-4f;
-                const float sgn = (k & 1) ? L : -L;
-                const float qx = nodes[3 * (size_t)node] + ((k >> 1) == 0 ? sgn : 0.0f);
-                const float qy = nodes[3 * (size_t)node + 1] + ((k >> 1) == 1 ? sgn : 0.0f);
-                const float qz = nodes[3 * (size_t)node + 2] + ((k >> 1) == 2 ? sgn : 0.0f);
-                ray_setup(r, cam.ox, cam.oy, cam.oz, qx - cam.ox, qy - cam.oy, qz - cam.oz);
+            if (got && PHASE >= 1) {
+                // PHASE 1: every retry of every listed node; PHASE 2: the rays witness_kernel left
+                const unsigned ray = PHASE == 2 ? todo_rays[it] : it;
+                const unsigned node = retry_nodes[ray / 6u];
+                retry_ray(r, cam, nodes, node, (int)(ray % 6u));
                 ray_classify(r, sc);
                 trav_begin(s, r, sc);
-                item = it;
+                item = ray;
                 ++my_rays;
                 busy = apply_own_bound<1>(s, own_bound(r, sc, node));   // false: cannot see it
             }
@@ -881,6 +1053,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 
                     // primary ray missed everything -> no entry (:261); hit on a foreign
                     // triangle -> jittered retries (listed by retry_list_kernel)
                     pix[node] = visible ? kPixVisible : (s.any ? kPixRetry : kPixNone);
+                    if (sc.witness && !visible && s.any) sc.witness[node] = s.best_slot;
                 } else if (visible) {
                     atomicOr(&retry_mask[item / 6u], 1u << (item % 6u));
                 }
@@ -1057,6 +1230,9 @@ Scene make_scene(const upsp_bvh *b, size_t items, int grid)
     static const int refill = env_int("UPSP_REFILL", kRefillDefault);
     sc.refill = refill;
     sc.adj_off = sc.adj_slot = nullptr;
+    sc.slot_path = nullptr;
+    sc.path_ref = nullptr;
+    sc.witness = nullptr;
     for (int a = 0; a < 3; ++a) {
         sc.rlo[a] = b->root_min[a];
         sc.rhi[a] = b->root_max[a];
@@ -1314,6 +1490,45 @@ int upsp_bvh_create(const float *h_tris9, size_t ntris, upsp_bvh **out)
         upsp_bvh_destroy(b);
         return fail(UPSP_ERR_HIP, std::string("BVH upload: ") + hipGetErrorString(e));
     }
+    {
+        // box chain of every leaf: the child boxes a ray must pass, root downwards, to reach it
+        // (depth-first with an explicit stack; `cur` is the chain of the frame being expanded)
+        std::vector<uint32_t> slot_path(2 * hb.tris.size(), 0u), path_ref;
+        struct Frame { int32_t ref; uint32_t entry; uint32_t depth; };
+        std::vector<Frame> st2;
+        std::vector<uint32_t> cur(65, 0u);
+        st2.push_back({hb.root_ref, 0u, 0u});
+        while (!st2.empty()) {
+            const Frame f = st2.back();
+            st2.pop_back();
+            if (f.depth > 0) cur[f.depth - 1] = f.entry;
+            if (f.ref < 0) {
+                const uint32_t code = (uint32_t)(~f.ref);
+                const uint32_t first = code >> kLeafBits, count = (code & (kMaxLeaf - 1)) + 1;
+                const uint32_t off = (uint32_t)path_ref.size();
+                path_ref.insert(path_ref.end(), cur.begin(), cur.begin() + f.depth);
+                for (uint32_t k = 0; k < count; ++k) {
+                    slot_path[2 * (size_t)(first + k)] = off;
+                    slot_path[2 * (size_t)(first + k) + 1] = f.depth;
+                }
+                continue;
+            }
+            int32_t left, right;
+            std::memcpy(&left, &hb.nodes[(size_t)f.ref].q[12], 4);
+            std::memcpy(&right, &hb.nodes[(size_t)f.ref].q[13], 4);
+            st2.push_back({right, ((uint32_t)f.ref << 1) | 1u, f.depth + 1});
+            st2.push_back({left, ((uint32_t)f.ref << 1) | 0u, f.depth + 1});
+        }
+        for (int k = 0; k < 4; ++k) path_ref.push_back(path_ref.empty() ? 0u : path_ref.back());  // read-ahead pad
+        e = hipMalloc(&b->d_slot_path, slot_path.size() * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc(&b->d_path_ref, path_ref.size() * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemcpy(b->d_slot_path, slot_path.data(), slot_path.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(b->d_path_ref, path_ref.data(), path_ref.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            upsp_bvh_destroy(b);
+            return fail(UPSP_ERR_HIP, std::string("BVH upload: ") + hipGetErrorString(e));
+        }
+    }
     b->root_ref = hb.root_ref;
     b->top_nodes = hb.top_nodes;
     b->prim_slot.assign(ntris, 0u);
@@ -1345,6 +1560,11 @@ void upsp_bvh_destroy(upsp_bvh *b)
     if (b->d_retry_mask) (void)hipFree(b->d_retry_mask);
     if (b->d_adj_off) (void)hipFree(b->d_adj_off);
     if (b->d_adj_slot) (void)hipFree(b->d_adj_slot);
+    if (b->d_slot_path) (void)hipFree(b->d_slot_path);
+    if (b->d_path_ref) (void)hipFree(b->d_path_ref);
+    if (b->d_witness) (void)hipFree(b->d_witness);
+    if (b->d_todo_mask) (void)hipFree(b->d_todo_mask);
+    if (b->d_todo_rays) (void)hipFree(b->d_todo_rays);
     if (b->d_stage) (void)hipFree(b->d_stage);
     if (b->h_stage) (void)hipHostFree(b->h_stage);
     if (b->stage_stream) (void)hipStreamDestroy(b->stage_stream);
@@ -1524,10 +1744,17 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
     if (b->retry_capacity < nnodes) {
         if (b->d_retry_nodes) (void)hipFree(b->d_retry_nodes);
         if (b->d_retry_mask) (void)hipFree(b->d_retry_mask);
-        b->d_retry_nodes = b->d_retry_mask = nullptr;
+        if (b->d_witness) (void)hipFree(b->d_witness);
+        if (b->d_todo_mask) (void)hipFree(b->d_todo_mask);
+        if (b->d_todo_rays) (void)hipFree(b->d_todo_rays);
+        b->d_retry_nodes = b->d_retry_mask = b->d_todo_mask = b->d_todo_rays = nullptr;
+        b->d_witness = nullptr;
         b->retry_capacity = 0;
         UPSP_HIP_CHECK(hipMalloc(&b->d_retry_nodes, sizeof(unsigned) * nnodes));
         UPSP_HIP_CHECK(hipMalloc(&b->d_retry_mask, sizeof(unsigned) * nnodes));
+        UPSP_HIP_CHECK(hipMalloc(&b->d_witness, sizeof(int32_t) * nnodes));
+        UPSP_HIP_CHECK(hipMalloc(&b->d_todo_mask, sizeof(unsigned) * nnodes));
+        UPSP_HIP_CHECK(hipMalloc(&b->d_todo_rays, sizeof(unsigned) * 6 * nnodes));
         b->retry_capacity = nnodes;
     }
     UPSP_HIP_CHECK(hipMemsetAsync(b->d_work, 0, 16 * sizeof(unsigned), st));
@@ -1538,6 +1765,7 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
     const int grid1 = grid_for(6 * nnodes, lds);
     Scene sc1 = make_scene(b, 3 * nnodes, grid1);
     static const bool own_bound_on = std::getenv("UPSP_NO_OWN_BOUND") == nullptr;
+    bool use_witness = false;
     if (own_bound_on && b->d_adj_off && b->adj_src == (const void *)d_tri_nodes && b->adj_nnodes == nnodes) {
         // bounded visibility rays (own_bound) for the retry pass only: measured on MI355X the
         // primary rays gain nothing (the near-first traversal finds the front surface at once
@@ -1546,6 +1774,16 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
         static const bool bound_primary = std::getenv("UPSP_OWN_BOUND_PRIMARY") != nullptr;
         sc1.adj_off = b->d_adj_off;
         sc1.adj_slot = b->d_adj_slot;
+        // occluder witness (witness_kernel): the primary pass records the triangle it hit, the
+        // retries test that triangle and its box chain first and only the rest is traversed
+        static const bool witness_on = std::getenv("UPSP_NO_WITNESS") == nullptr;
+        if (witness_on && b->d_slot_path && b->d_path_ref && b->d_witness && b->d_todo_mask && b->d_todo_rays) {
+            use_witness = true;
+            sc.witness = b->d_witness;
+            sc1.witness = b->d_witness;
+            sc1.slot_path = reinterpret_cast<const uint2 *>(b->d_slot_path);
+            sc1.path_ref = b->d_path_ref;
+        }
         if (bound_primary) {
             sc.adj_off = b->d_adj_off;
             sc.adj_slot = b->d_adj_slot;
@@ -1561,7 +1799,7 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
 #define UPSP_LAUNCH_PROJ(STATS, PHASE, G, SC)                                                    \
     hipLaunchKernelGGL((projection_kernel<STATS, PHASE>), dim3(G), dim3(kBlock), lds, st, SC, c, \
                        d_nodes, d_tri_nodes, (unsigned)nnodes, d_pix, b->d_retry_nodes,          \
-                       b->d_retry_mask, b->d_work)
+                       b->d_retry_mask, (const unsigned *)b->d_todo_rays, b->d_work)
     {
         KTimed kt("projection_kernel<primary>", st);
         if (b->stats_on) UPSP_LAUNCH_PROJ(true, 0, grid, sc); else UPSP_LAUNCH_PROJ(false, 0, grid, sc);
@@ -1573,7 +1811,20 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
         hipLaunchKernelGGL(retry_list_kernel, lgrid, eblock, 0, st, (const int32_t *)d_pix,
                            (unsigned)nnodes, b->d_retry_nodes, b->d_retry_mask, b->d_work);
     }
-    {
+    if (use_witness) {
+        {
+            KTimed kt("witness_kernels", st);
+            hipLaunchKernelGGL(witness_kernel, dim3((unsigned)((nnodes + kWitNodes - 1) / kWitNodes)), dim3(64), 0,
+                               st, sc1, c, d_nodes, (const unsigned *)b->d_retry_nodes, b->d_todo_mask,
+                               (const unsigned *)b->d_work);
+            hipLaunchKernelGGL(todo_list_kernel, dim3((unsigned)((nnodes + 1023) / 1024)), dim3(256), 0, st,
+                               (const unsigned *)b->d_todo_mask, b->d_todo_rays, b->d_work);
+        }
+        KTimed kt("projection_kernel<retry>", st);
+        Scene sc2 = sc1;
+        sc2.chunk = 64;   // few rays are left (~3.5 %; 16 lanes per wave and 16-ray chunks: 0.37 instead of 0.21 ms)
+        if (b->stats_on) UPSP_LAUNCH_PROJ(true, 2, grid1, sc2); else UPSP_LAUNCH_PROJ(false, 2, grid1, sc2);
+    } else {
         KTimed kt("projection_kernel<retry>", st);
         if (b->stats_on) UPSP_LAUNCH_PROJ(true, 1, grid1, sc1); else UPSP_LAUNCH_PROJ(false, 1, grid1, sc1);
     }
@@ -1611,6 +1862,12 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
         UPSP_HIP_CHECK(hipMemcpy(cnt, b->d_work + kWorkRetryCount, sizeof(cnt), hipMemcpyDeviceToHost));
         b->last_retry_nodes = cnt[0];
         b->last_primary = cnt[1];
+        if (std::getenv("UPSP_DEBUG_COUNTS")) {
+            unsigned w[16];
+            UPSP_HIP_CHECK(hipMemcpy(w, b->d_work, sizeof(w), hipMemcpyDeviceToHost));
+            std::fprintf(stderr, "upsp work: retry_nodes %u  todo_rays %u  max_nodes/ray %u  max_tris/ray %u\n",
+                         w[kWorkRetryCount], w[kWorkTodoCount], w[8], w[9]);
+        }
     }
     return UPSP_OK;
 }

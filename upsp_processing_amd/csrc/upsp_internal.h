@@ -75,6 +75,11 @@ struct upsp_bvh {
     std::vector<uint32_t> prim_slot;   // host: triangle slot (leaf order) of every input triangle
     // node -> adjacent triangle slots (CSR), set by upsp_bvh_set_tri_nodes (bounded visibility rays)
     uint32_t *d_adj_off = nullptr, *d_adj_slot = nullptr;
+    // root-to-leaf box chain of every triangle slot (occluder witness test of the retry rays):
+    // d_slot_path[slot] = (offset, length) into d_path_ref, entries (interior node << 1) | side
+    uint32_t *d_slot_path = nullptr, *d_path_ref = nullptr;
+    int32_t *d_witness = nullptr;      // per node: triangle slot the primary ray hit (retry nodes)
+    uint32_t *d_todo_mask = nullptr, *d_todo_rays = nullptr;   // retries the witness test left undecided
     const void *adj_src = nullptr;     // the d_tri_nodes buffer the adjacency was built from
     size_t adj_nnodes = 0;
     size_t retry_capacity = 0;

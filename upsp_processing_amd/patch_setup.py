@@ -80,7 +80,10 @@ def read_psp_target_file(path, label="*Targets", planar=False):
 
 
 def cv_round(v):
-    """cvRound: round half to even."""
+    """cvRound: round half to even; NaN and values beyond the int range give INT_MIN like cvtss2si."""
+    v = float(v)
+    if not (-2147483648.0 <= v < 2147483648.0):
+        return -2147483648
     return int(np.rint(v))
 
 
