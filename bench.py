@@ -277,7 +277,10 @@ def main():
     per_step_bytes = {
         # 40 B per ray (24 B ray + 16 B hit record) + the scene once per launch
         "projection_kernel<primary>": primary_rays_last[0] * 40 + scene_bytes,
-        "projection_kernel<retry>": n_retry_rays * 40 + scene_bytes,
+        # the occluder-witness pass sees every retry ray (ray + verdict); the traversal that follows
+        # only the few it leaves undecided (count known to the device only) plus the scene
+        "witness_kernels": n_retry_rays * 40,
+        "projection_kernel<retry>": scene_bytes,
         # frame unit = 2 MiB frame + 12 B x N (pix 4, weight 4, out 4).  The 2 MiB
         # compulsory full read of the frame belongs to the hot-pixel scan (the gather's pixel reads
         # hit the Infinity Cache); the gather keeps pix / weight in registers across its 64-frame
