@@ -12,10 +12,12 @@ agg = collections.OrderedDict()
 for r in rows:
     k = r["Kernel_Name"]
     if "upsp" not in k: continue
-    short = k.split("(anonymous namespace)::")[-1].split("(")[0]
+    import re
+    m = re.search(r"\(anonymous namespace\)::(\w+)(<[^>]*>)?\(", k)
+    short = (m.group(1) + (m.group(2) or "")) if m else k[:40]
     key = (short, r["Counter_Name"])
     a = agg.setdefault(key, [0, 0.0, 0.0])
     a[0] += 1; a[1] += float(r["Counter_Value"]); a[2] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 for (k, c), (n, v, t) in agg.items():
-    print("%-28s %-36s calls=%d avg=%.6g avg_ns=%.0f" % (k[:28], c, n, v / n, t / n))
+    print("%-38s %-32s calls=%d avg=%.6g avg_ns=%.0f" % (k[:38], c, n, v / n, t / n))
 PY
