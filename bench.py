@@ -48,6 +48,9 @@ def parse():
                     help="run the chunked / pipelined-exchange frame loop of the N>1 path on one GPU")
     ap.add_argument("--f32-wire", action="store_true",
                     help="N>1 / --force-chunked: exchange the series as f32 instead of u16")
+    ap.add_argument("--overlap", action="store_true",
+                    help="hot-pixel scan of all frames on a side stream, concurrent with the projection "
+                         "build (measured slower on MI355X: the gathers then miss the Infinity Cache)")
     ap.add_argument("--model", default="quad", choices=["quad", "uv"],
                     help="quad: cube-sphere tunnel model (valence <= 6); uv: UV-sphere model with "
                          "1000-valent polar fans (worst case for per-ray traversal length)")
@@ -115,10 +118,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    # rehearsal of the N > 1 code path on a one-GPU box: UPSP_BENCH_BACKEND=gloo with every rank on
+    # cuda:0 (UPSP_BENCH_ONE_GPU=1).  The driver's runs use RCCL, one rank per GPU.
+    backend = os.environ.get("UPSP_BENCH_BACKEND", "nccl")
+    if os.environ.get("UPSP_BENCH_ONE_GPU"):
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     _capi.lib()
 
     size = a.size
@@ -175,16 +186,31 @@ def main():
 
     ev_log = []
     mode = {"packed": True, "u16": not a.f32_wire}
+    # fix_hot_pixels does not depend on the projection: with --overlap its streaming scan of every
+    # frame runs on a side stream while the (latency-bound) projection build occupies the main
+    # stream and the gathers wait for both.  Same results (tests/test_frames_gpu.py).  Measured on
+    # MI355X it LOSES (step 1.68 -> 1.86 ms): the gathers then read frames from HBM instead of the
+    # Infinity Cache (39 -> 59 us per launch) and the traversal kernels slow down by a third under
+    # the scan's traffic -- so it is off by default.
+    overlap = a.overlap and not a.registration
+    side = torch.cuda.Stream() if overlap else None
 
     def step(record):
         e = [ev() for _ in range(4)]
         e[0].record()
+        main = torch.cuda.current_stream()
+        if overlap:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                pipe.fix_hot_pixels(frames)
         proj = engine.build_projection(bvh, cam, d_nodes, d_nrm, d_tn, 70.0, counts=False)   # no host sync
         e[1].record()
         pipe.reset()
         pipe.set_projection(0, proj["pix"])
+        if overlap:
+            main.wait_stream(side)
         if not chunked:
-            pipe.process(frames, first_frame=rank * F, rows_t=rows_t, want_rows=False)
+            pipe.process(frames, first_frame=rank * F, rows_t=rows_t, want_rows=False, hot_fixed=overlap)
         else:
             exch.k = 0
             packed = mode["packed"]
@@ -206,14 +232,16 @@ def main():
                 buf = (chunk_bufs16 if u16 else chunk_bufs)[k][:nrows]
                 if fc:
                     try:
-                        pipe.process(frames[c0:c0 + fc], first_frame=rank * F + c0, rows_t=buf, want_rows=False)
+                        pipe.process(frames[c0:c0 + fc], first_frame=rank * F + c0, rows_t=buf, want_rows=False,
+                                     hot_fixed=overlap)
                     except _capi.UpspError as ex:
                         if not u16:
                             raise
                         print("bench: u16 series refused (%r), sending f32" % (ex,), file=sys.stderr)
                         mode["u16"] = False
                         buf = chunk_bufs[k][:nrows]
-                        pipe.process(frames[c0:c0 + fc], first_frame=rank * F + c0, rows_t=buf, want_rows=False)
+                        pipe.process(frames[c0:c0 + fc], first_frame=rank * F + c0, rows_t=buf, want_rows=False,
+                                     hot_fixed=overlap)
                 exch.submit(buf, packed=packed)
         e[2].record()
         s, ss = pipe.accumulators()
@@ -323,13 +351,15 @@ def main():
         "metric": "frames/s", "value": fps, "unit": "frames/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-        "data": "synthetic",
+        "data": "synthetic", **({"backend": backend} if world > 1 and backend != "nccl" else {}),
         "config": {"workload": "configs[%d]: %d frames/GPU x %dx%d u16, %d-tri tunnel model (%d nodes), "
                                "raycast+%sprojection" % (2 if a.registration else 1, F, size, size,
                                                          tris.shape[0], N,
                                                          "registration+" if a.registration else ""),
                    "frames_per_gpu": F, "nodes": N, "triangles": int(tris.shape[0]),
                    "parallelism": "frames sharded x%d" % world,
+                   "schedule": ("hot-pixel scan of all frames on a side stream, concurrent with the projection build"
+                                if overlap else "projection build, then scan + gather per 64-frame sub-batch"),
                    **({"exchange": "%d chunks, %s rows as %s" % (K, "visible" if mode["packed"] else "all",
                                                                  "u16" if series_esz == 2 else "f32")}
                       if chunked else {})},

@@ -205,6 +205,18 @@ void upsp_pipeline_destroy(upsp_pipeline *p);
  * (NULL = all ones).  Equivalent of elems.projs[c] (psp_process.cpp:1591-1640). */
 int upsp_pipeline_set_projection(upsp_pipeline *p, int cam, const int32_t *d_pix,
                                  const float *d_weight);
+/* The same with the copies ordered on `stream` instead of blocking the host: the projection build
+ * (upsp_projection_build) and the frame loop can then be queued back to back. */
+int upsp_pipeline_set_projection_async(upsp_pipeline *p, int cam, const int32_t *d_pix,
+                                       const float *d_weight, void *stream);
+/* fix_hot_pixels (cpp/utils/cv_extras.cpp:230-275, called at cpp/exec/psp_process.cpp:1772) does not
+ * depend on the projection: upsp_pipeline_fix_hot_pixels queues the scan + repair of `nframes`
+ * resident frames (in place, pipeline's thresholds) on `stream` -- e.g. a second stream while the
+ * projection is still being built -- and upsp_pipeline_set_hot_enable(p, 0) makes the following
+ * upsp_pipeline_process calls skip their own scan of those frames (1 switches it back on).  The
+ * caller orders the streams (event between the scan and the first process call). */
+int upsp_pipeline_fix_hot_pixels(upsp_pipeline *p, uint16_t *d_frames, int nframes, void *stream);
+int upsp_pipeline_set_hot_enable(upsp_pipeline *p, int enable);
 /* Nodes set to NaN in every row (psp_process.cpp:1822-1825); NULL = derive from
  * the projections with identify_skipped_nodes. */
 int upsp_pipeline_set_skipped(upsp_pipeline *p, const uint8_t *d_skipped);

@@ -215,3 +215,46 @@ def test_packed_and_u16_series(gpu_lib, oracle, F, ld_extra):
     p3.set_projection(0, d_pix); p3.set_projection(1, d_pix)
     with pytest.raises(_capi.UpspError):
         p3.process([d_frames, d_frames.clone()], 0, rows_t=b16, want_rows=False)
+
+
+@pytest.mark.parametrize("F", [41, 150])
+def test_hot_pixel_prescan_on_side_stream(gpu_lib, oracle, F):
+    """fix_hot_pixels queued ahead of the frame loop on a second stream (the schedule bench.py
+    uses: the scan runs while the projection is built) + process(hot_fixed=True): rows,
+    transposed rows, repaired frames and accumulators identical to the in-loop scan / the oracle."""
+    import torch
+    from upsp_processing_amd import engine, synthetic as syn
+    H, W, n = 96, 128, 3000
+    rng = np.random.default_rng(11)
+    frames = [syn.synth_frames_numpy(F, H, W, seed=21, hot=True)]
+    frames[0][3, 5, 7] = 4095
+    frames[0][F - 1, H - 1, W - 1] = 4095
+    frames[0][7][rng.random((H, W)) < 0.1] = 4090          # saturated frame: left alone
+    pix = rng.integers(-1, H * W, size=(1, n)).astype(np.int32)
+    pix[0, :200] = 5 * W + 7                                # many nodes on a repaired pixel
+    weight = np.ones((1, n), np.float32)
+    rows_o, s_o, ss_o = run_loop_oracle(oracle, frames, pix, weight)
+    want_frames = np.stack([oracle.fix_hot_pixels(frames[0][f])[0] for f in range(F)])
+
+    pipe = engine.FramePipeline(1, W, H, n)
+    d = torch.as_tensor(frames[0].copy()).cuda()
+    side, main = torch.cuda.Stream(), torch.cuda.current_stream()
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        pipe.fix_hot_pixels(d)
+    pipe.set_projection(0, pix[0])
+    main.wait_stream(side)
+    rows_t = torch.zeros((n, engine.series_ld(F)), dtype=torch.float32, device="cuda")
+    rows = pipe.process(d, 0, rows_t=rows_t, hot_fixed=True)
+    assert pipe.opts.hot_enable == 1
+    assert np.array_equal(d.cpu().numpy(), want_frames)
+    assert np.array_equal(rows.cpu().numpy().view(np.int32), rows_o.view(np.int32))
+    assert np.array_equal(rows_t[:, :F].cpu().numpy().view(np.int32), rows_o.T.view(np.int32))
+    s_g, ss_g = [a.cpu().numpy() for a in pipe.accumulators()]
+    ok = ~np.isnan(s_o)
+    assert np.array_equal(np.isnan(s_g), np.isnan(s_o))
+    assert np.allclose(s_g[ok], s_o[ok], rtol=1e-12) and np.allclose(ss_g[ok], ss_o[ok], rtol=1e-12)
+    # the in-loop scan on already repaired frames changes nothing (idempotent)
+    pipe.reset()
+    rows2 = pipe.process(d, 0)
+    assert torch.equal(rows2.view(torch.int32), rows.view(torch.int32))

@@ -33,6 +33,9 @@ struct upsp_pipeline {
     // hot-pixel scratch (per frame of a sub-batch)
     unsigned *d_hot_count = nullptr, *d_hot_pos = nullptr;
     int hot_capacity = 0;
+    // the same scratch for upsp_pipeline_fix_hot_pixels (may run on another stream than process)
+    unsigned *d_pre_count = nullptr, *d_pre_pos = nullptr;
+    int pre_capacity = 0;
     // registration / patch / filter state
     float *d_ref[kMaxCams] = {nullptr};
     upsp::PatchTables *patches[kMaxCams] = {nullptr};
@@ -50,19 +53,24 @@ void free_dev(void *p)
     if (p) (void)hipFree(p);
 }
 
+int ensure_hot_scratch(unsigned *&count, unsigned *&pos, int &capacity, int nframes)
+{
+    if (nframes <= capacity) return UPSP_OK;
+    free_dev(count);
+    free_dev(pos);
+    count = pos = nullptr;
+    capacity = 0;
+    UPSP_HIP_CHECK(hipMalloc(&count, sizeof(unsigned) * upsp::hot_counter_words(nframes)));   // counts + tickets
+    UPSP_HIP_CHECK(hipMemset(count, 0, sizeof(unsigned) * upsp::hot_counter_words(nframes)));
+    UPSP_HIP_CHECK(hipDeviceSynchronize());   // rare (allocation): zeroed before any stream uses it
+    UPSP_HIP_CHECK(hipMalloc(&pos, sizeof(unsigned) * (size_t)nframes * 64));
+    capacity = nframes;
+    return UPSP_OK;
+}
+
 int ensure_hot(upsp_pipeline *p, int nframes)
 {
-    if (nframes <= p->hot_capacity) return UPSP_OK;
-    free_dev(p->d_hot_count);
-    free_dev(p->d_hot_pos);
-    p->d_hot_count = p->d_hot_pos = nullptr;
-    p->hot_capacity = 0;
-    UPSP_HIP_CHECK(hipMalloc(&p->d_hot_count, sizeof(unsigned) * upsp::hot_counter_words(nframes)));   // counts + tickets
-    UPSP_HIP_CHECK(hipMemset(p->d_hot_count, 0, sizeof(unsigned) * upsp::hot_counter_words(nframes)));
-    UPSP_HIP_CHECK(hipDeviceSynchronize());   // rare (allocation): zeroed before any stream uses it
-    UPSP_HIP_CHECK(hipMalloc(&p->d_hot_pos, sizeof(unsigned) * (size_t)nframes * 64));
-    p->hot_capacity = nframes;
-    return UPSP_OK;
+    return ensure_hot_scratch(p->d_hot_count, p->d_hot_pos, p->hot_capacity, nframes);
 }
 
 }  // namespace
@@ -159,6 +167,8 @@ void upsp_pipeline_destroy(upsp_pipeline *p)
     free_dev(p->d_sumsq);
     free_dev(p->d_hot_count);
     free_dev(p->d_hot_pos);
+    free_dev(p->d_pre_count);
+    free_dev(p->d_pre_pos);
     delete p;
 }
 
@@ -180,6 +190,51 @@ int upsp_pipeline_set_projection(upsp_pipeline *p, int cam, const int32_t *d_pix
     p->has_proj[cam] = true;
     if (!p->skipped_user) p->skipped_valid = false;
     return UPSP_OK;
+}
+
+int upsp_pipeline_set_projection_async(upsp_pipeline *p, int cam, const int32_t *d_pix,
+                                       const float *d_weight, void *stream)
+{
+    if (!p || cam < 0 || cam >= p->ncams || !d_pix) return fail(UPSP_ERR_INVALID, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (!p->d_pix[cam]) UPSP_HIP_CHECK(hipMalloc(&p->d_pix[cam], sizeof(int32_t) * p->nnodes));
+    UPSP_HIP_CHECK(hipMemcpyAsync(p->d_pix[cam], d_pix, sizeof(int32_t) * p->nnodes,
+                                  hipMemcpyDeviceToDevice, st));
+    if (d_weight) {
+        if (!p->d_weight[cam]) UPSP_HIP_CHECK(hipMalloc(&p->d_weight[cam], sizeof(float) * p->nnodes));
+        UPSP_HIP_CHECK(hipMemcpyAsync(p->d_weight[cam], d_weight, sizeof(float) * p->nnodes,
+                                      hipMemcpyDeviceToDevice, st));
+    } else if (p->d_weight[cam]) {
+        // a weight vector may still be read by launches queued earlier: release it stream-ordered
+        UPSP_HIP_CHECK(hipStreamSynchronize(st));
+        free_dev(p->d_weight[cam]);
+        p->d_weight[cam] = nullptr;
+    }
+    p->has_proj[cam] = true;
+    if (!p->skipped_user) p->skipped_valid = false;
+    return UPSP_OK;
+}
+
+int upsp_pipeline_set_hot_enable(upsp_pipeline *p, int enable)
+{
+    if (!p) return fail(UPSP_ERR_INVALID, "null pipeline");
+    p->opts.hot_enable = enable ? 1 : 0;
+    return UPSP_OK;
+}
+
+int upsp_pipeline_fix_hot_pixels(upsp_pipeline *p, uint16_t *d_frames, int nframes, void *stream)
+{
+    if (!p || nframes < 0 || (nframes > 0 && !d_frames)) return fail(UPSP_ERR_INVALID, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t npix = (size_t)p->width * p->height;
+    // same 64-frame launches as the frame loop (the counters clean themselves between launches)
+    const int B = 64;
+    int rc = ensure_hot_scratch(p->d_pre_count, p->d_pre_pos, p->pre_capacity, std::min(B, std::max(nframes, 1)));
+    for (int f0 = 0; f0 < nframes && rc == UPSP_OK; f0 += B)
+        rc = launch_hot_fix(d_frames + (size_t)f0 * npix, std::min(B, nframes - f0), p->height, p->width,
+                            p->opts.hot_thresh, p->opts.hot_min_change, p->opts.hot_max,
+                            p->d_pre_count, p->d_pre_pos, nullptr, st);
+    return rc;
 }
 
 int upsp_pipeline_set_skipped(upsp_pipeline *p, const uint8_t *d_skipped)

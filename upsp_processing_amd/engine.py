@@ -287,8 +287,17 @@ class FramePipeline:
         pix = _dev(pix, torch.int32)
         w = None if weight is None else _dev(weight, torch.float32)
         assert pix.numel() == self.nnodes
-        check(lib().upsp_pipeline_set_projection(self._h, cam, _ptr(pix), _ptr(w)))
-        torch.cuda.synchronize()
+        # copies ordered on the current stream (no host synchronisation: the projection build and
+        # the frame loop are queued back to back)
+        check(lib().upsp_pipeline_set_projection_async(self._h, cam, _ptr(pix), _ptr(w), _stream()))
+
+    def fix_hot_pixels(self, frames):
+        """Queue the hot-pixel scan + repair of resident u16 frames [F,H,W] (one camera) on the
+        current stream, ahead of process(..., hot_fixed=True).  It does not depend on the
+        projection, so it can run on a side stream while the projection is being built."""
+        assert frames.is_cuda and frames.dtype == torch.uint16 and frames.is_contiguous()
+        assert tuple(frames.shape[1:]) == (self.height, self.width)
+        check(lib().upsp_pipeline_fix_hot_pixels(self._h, _ptr(frames), frames.shape[0], _stream()))
 
     def set_skipped(self, skipped):
         sk = None if skipped is None else _dev(skipped, torch.uint8)
@@ -321,9 +330,16 @@ class FramePipeline:
         check(lib().upsp_pipeline_set_patches(self._h, cam, len(clusters), *p))
 
     def process(self, frames, first_frame=0, rows=None, rows_t=None, col0=0, want_rows=True,
-                warps=None):
+                warps=None, hot_fixed=False):
         """frames: list (one per camera) of u16 tensors [F,H,W] (modified in place by the
-        hot-pixel fix, like the reference).  Returns rows [F,N] f32 (or None)."""
+        hot-pixel fix, like the reference).  Returns rows [F,N] f32 (or None).
+        hot_fixed: the frames already went through fix_hot_pixels() -- skip the scan."""
+        if hot_fixed and self.opts.hot_enable:
+            check(lib().upsp_pipeline_set_hot_enable(self._h, 0))
+            try:
+                return self.process(frames, first_frame, rows, rows_t, col0, want_rows, warps)
+            finally:
+                check(lib().upsp_pipeline_set_hot_enable(self._h, 1))
         if isinstance(frames, torch.Tensor):
             frames = [frames]
         assert len(frames) == self.ncams
