@@ -331,6 +331,7 @@ struct Scene {
     const uint2 *slot_path;               // triangle slot -> (offset, length) of its box chain (may be null)
     const unsigned *path_ref;             // chain entries: (interior node << 1) | side
     int *witness;                         // per node: slot hit by the primary ray (retry nodes)
+    unsigned *hist;                       // debug (UPSP_DEBUG_HIST with statistics on): [0..47] steps per residual ray, [48..55] witness verdicts
 };
 
 struct Trav {
@@ -505,7 +506,10 @@ __device__ __forceinline__ void queue_init(WaveQueue &q, unsigned *head, unsigne
     const unsigned long long first = (unsigned long long)wave * chunk;
     q.cur = first < total ? (unsigned)first : total;
     q.end = min(q.cur + chunk, total);
-    q.exhausted = false;
+    // the statically assigned chunks already cover every item: nobody has to ask the shared counter
+    // (one same-address atomic per wave, 6144 of them, just to learn that it is empty: ~25 us of the
+    // residual retry traversal)
+    q.exhausted = (unsigned long long)q.base >= total;
 }
 
 // Gives idle lanes (want == true) a work item; returns true and the index for lanes
@@ -867,18 +871,24 @@ __global__ void __launch_bounds__(64)
         const unsigned node = retry_nodes[li];
         retry_ray(r, cam, nodes, node, (int)k);
         ray_classify(r, sc);
+        int why = 48;   // debug verdict code (sc.hist)
         if (box_hit(r, sc.rlo[0], sc.rlo[1], sc.rlo[2], sc.rhi[0], sc.rhi[1], sc.rhi[2])) {   // trav_begin
             const OwnBound ob = own_bound(r, sc, node);
+            why = 50;
             if (!ob.known) {
                 undecided = true;
+                why = 49;
             } else if (ob.hit) {              // (no own triangle hit: cannot see the node, decided)
                 const int slot = sc.witness[node];
                 bool near_hit = false;
+                why = 51;
                 if (slot >= 0) {
                     const float4 *tp = sc.tris + 3 * (size_t)slot;
                     const float4 a = tp[0], b = tp[1], c = tp[2];
                     TriHit h;
-                    near_hit = tri_test(r, a.x, a.y, a.z, b.x, b.y, b.z, c.x, c.y, c.z, h) && h.t < ob.tmin;
+                    const bool wh = tri_test(r, a.x, a.y, a.z, b.x, b.y, b.z, c.x, c.y, c.z, h);
+                    near_hit = wh && h.t < ob.tmin;
+                    why = !wh ? 52 : near_hit ? 55 : 53;
                 }
                 if (near_hit) {
                     const uint2 pl = sc.slot_path[slot];
@@ -891,6 +901,7 @@ __global__ void __launch_bounds__(64)
                 }
             }
         }
+        if (sc.hist) atomicAdd(&sc.hist[why], 1u);
     }
     __syncthreads();
     if (__ballot(chain) != 0ull) {
@@ -923,7 +934,10 @@ __global__ void __launch_bounds__(64)
             }
             __syncthreads();
         }
-        if (chain && !ok) undecided = true;   // a box on the chain rejects the ray: ask the traversal
+        if (chain && !ok) {   // a box on the chain rejects the ray: ask the traversal
+            undecided = true;
+            if (sc.hist) atomicAdd(&sc.hist[54], 1u);
+        }
     }
     const unsigned long long m = __ballot(undecided);
     if (active && k == 0u) todo_mask[li] = (unsigned)((m >> (6u * j)) & 63ull);
@@ -1043,6 +1057,8 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 
             }
             if (s.cur == kDone) {
                 busy = false;
+                if (STATS && PHASE == 2 && sc.hist)
+                    atomicAdd(&sc.hist[min(47u, (s.ray_nodes + s.ray_tris) >> 4)], 1u);
                 const unsigned node = PHASE == 0 ? item : retry_nodes[item / 6u];
                 bool visible = false;
                 if (s.any && s.best_slot >= 0) {
@@ -1233,6 +1249,7 @@ Scene make_scene(const upsp_bvh *b, size_t items, int grid)
     sc.slot_path = nullptr;
     sc.path_ref = nullptr;
     sc.witness = nullptr;
+    sc.hist = nullptr;
     for (int a = 0; a < 3; ++a) {
         sc.rlo[a] = b->root_min[a];
         sc.rhi[a] = b->root_max[a];
@@ -1811,6 +1828,12 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
         hipLaunchKernelGGL(retry_list_kernel, lgrid, eblock, 0, st, (const int32_t *)d_pix,
                            (unsigned)nnodes, b->d_retry_nodes, b->d_retry_mask, b->d_work);
     }
+    unsigned *d_hist = nullptr;
+    if (use_witness && b->stats_on && std::getenv("UPSP_DEBUG_HIST")) {
+        UPSP_HIP_CHECK(hipMalloc(&d_hist, 64 * sizeof(unsigned)));
+        UPSP_HIP_CHECK(hipMemsetAsync(d_hist, 0, 64 * sizeof(unsigned), st));
+        sc1.hist = d_hist;
+    }
     if (use_witness) {
         {
             KTimed kt("witness_kernels", st);
@@ -1824,6 +1847,16 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
         Scene sc2 = sc1;
         sc2.chunk = 64;   // few rays are left (~3.5 %; 16 lanes per wave and 16-ray chunks: 0.37 instead of 0.21 ms)
         if (b->stats_on) UPSP_LAUNCH_PROJ(true, 2, grid1, sc2); else UPSP_LAUNCH_PROJ(false, 2, grid1, sc2);
+        if (d_hist) {   // debug: (node visits + triangle tests) per residual ray, 16 per bin; witness verdicts per retry ray
+            unsigned h[64];
+            UPSP_HIP_CHECK(hipMemcpy(h, d_hist, sizeof(h), hipMemcpyDeviceToHost));
+            (void)hipFree(d_hist);
+            std::fprintf(stderr, "upsp residual-ray steps histogram (bin = 16 steps):");
+            for (int i = 0; i < 48; ++i) std::fprintf(stderr, " %u", h[i]);
+            std::fprintf(stderr, "\nupsp witness verdicts: root box missed %u, adjacency unknown %u, no own triangle hit %u, "
+                         "no witness slot %u, witness missed %u, witness behind the node %u, chain rejected %u, decided %u\n",
+                         h[48], h[49], h[50], h[51], h[52], h[53], h[54], h[55]);
+        }
     } else {
         KTimed kt("projection_kernel<retry>", st);
         if (b->stats_on) UPSP_LAUNCH_PROJ(true, 1, grid1, sc1); else UPSP_LAUNCH_PROJ(false, 1, grid1, sc1);
