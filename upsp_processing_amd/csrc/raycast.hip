@@ -325,6 +325,7 @@ struct Scene {
     const float4 *tris;   // 3 per triangle slot
     int root_ref;
     int refill;           // re-fill threshold (live lanes)
+    int desc_cap;         // interior-node steps before the lanes that already hold a leaf get to test it (0 = no cap)
     unsigned chunk;       // work items per queue grab (multiple of 64)
     float rlo[3], rhi[3];
     const unsigned *adj_off, *adj_slot;   // node -> adjacent triangle slots (may be null)
@@ -459,17 +460,29 @@ __device__ __forceinline__ bool leaf_step(Trav &s, const Ray &r, const Scene &sc
 }
 
 // Runs the lane's traversal until it finishes (returns) -- or, when `more` work is
-// queued, until fewer than `refill` lanes of the wave are still busy.  Classic while-while:
-// descend interior nodes until every live lane holds a leaf, then test the leaves.
+// queued, until fewer than `refill` lanes of the wave are still busy.  While-while with a CAPPED
+// descent: at most `desc_cap` interior-node rounds, then the lanes that hold a leaf test it while the
+// others wait (they continue their descent in the next round).  The uncapped form -- every live lane
+// descends until ALL of them hold a leaf -- leaves the early lanes idle for as long as the deepest
+// descent of the wave; with the cap both kernels gain (primary 0.288 -> 0.265 ms at 6 rounds,
+// residual retries 0.179 -> 0.145 ms at 4; 1 round: 0.354 / 0.190, 2: 0.295 / 0.157, 8: 0.269 / 0.150).
+// The sequence of operations of each LANE is unchanged (node steps down to a leaf, the leaf, pop), only
+// the interleaving of the lanes differs, so results are bit-identical.
 // (A speculative variant that parks one leaf and keeps descending was measured 15 % slower:
 // the delayed pruning limit costs more node visits than the better lane occupancy saves.)
 template <bool ANYHIT, bool STATS>
 __device__ __forceinline__ void trav_run(Trav &s, const Ray &r, const Scene &sc, int *stack,
                                          bool more, int refill)
 {
+    const int cap = sc.desc_cap;
     while (s.cur != kDone) {
-        while (s.cur >= 0) node_step<ANYHIT, STATS>(s, r, sc, stack);
-        if (s.cur != kDone) {
+        if (cap == 0) {
+            while (s.cur >= 0) node_step<ANYHIT, STATS>(s, r, sc, stack);
+        } else {
+            for (int d = 0; d < cap && __ballot(s.cur >= 0) != 0ull; ++d)
+                if (s.cur >= 0) node_step<ANYHIT, STATS>(s, r, sc, stack);
+        }
+        if (s.cur != kDone && s.cur < 0) {
             if (leaf_step<ANYHIT, STATS>(s, r, sc, s.cur)) {
                 s.cur = kDone;
                 s.sp = 0;
@@ -1245,6 +1258,8 @@ Scene make_scene(const upsp_bvh *b, size_t items, int grid)
     sc.root_ref = b->root_ref;
     static const int refill = env_int("UPSP_REFILL", kRefillDefault);
     sc.refill = refill;
+    static const int desc_cap = env_int("UPSP_DESC_CAP", 6);
+    sc.desc_cap = desc_cap;
     sc.adj_off = sc.adj_slot = nullptr;
     sc.slot_path = nullptr;
     sc.path_ref = nullptr;
@@ -1845,6 +1860,8 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
         }
         KTimed kt("projection_kernel<retry>", st);
         Scene sc2 = sc1;
+        static const int desc_cap2 = env_int("UPSP_DESC_CAP_RESIDUAL", 4);
+        sc2.desc_cap = desc_cap2;
         sc2.chunk = 64;   // few rays are left (~3.5 %; 16 lanes per wave and 16-ray chunks: 0.37 instead of 0.21 ms)
         if (b->stats_on) UPSP_LAUNCH_PROJ(true, 2, grid1, sc2); else UPSP_LAUNCH_PROJ(false, 2, grid1, sc2);
         if (d_hist) {   // debug: (node visits + triangle tests) per residual ray, 16 per bin; witness verdicts per retry ray
