@@ -258,3 +258,62 @@ def test_hot_pixel_prescan_on_side_stream(gpu_lib, oracle, F):
     pipe.reset()
     rows2 = pipe.process(d, 0)
     assert torch.equal(rows2.view(torch.int32), rows.view(torch.int32))
+
+
+@pytest.mark.parametrize("F", [70, 64])
+def test_large_model_series_variants(gpu_lib, F):
+    """70 001 nodes, full u16 range: the node-major series written with and without the frame-major
+    rows, in ragged calls, after a change of projection, packed as u16 through a row map and with an
+    overlap source map -- all bit-identical to a torch gather; accumulators identical between the
+    variants.  (Written for a pixel-sorted node order of the gather, which was measured and dropped:
+    DESIGN.md section 4; kept as a consistency test of the gather's output paths.)"""
+    import torch
+    from upsp_processing_amd import engine
+    H, W, n = 200, 300, 70001
+    g = torch.Generator(device="cuda"); g.manual_seed(F)
+    pix = torch.randint(0, H * W, (n,), generator=g, device="cuda", dtype=torch.int32)
+    pix[torch.rand(n, generator=g, device="cuda") < 0.45] = -1
+    pix[:5] = torch.tensor([H * W - 1, 0, -1, 0, H * W - 1], dtype=torch.int32, device="cuda")   # ties, extremes
+    frames = torch.randint(0, 65536, (F, H, W), generator=g, device="cuda", dtype=torch.int32).to(torch.uint16)
+    ref = frames.reshape(F, -1).to(torch.int32)[:, pix.clamp(min=0).long()].float()
+    ref[:, pix < 0] = float("nan")
+    pipe = engine.FramePipeline(1, W, H, n, hot_enable=0)
+    pipe.set_projection(0, pix)
+    # with frame-major rows
+    rt0 = torch.zeros((n, engine.series_ld(F)), dtype=torch.float32, device="cuda")
+    rows = pipe.process(frames, 0, rows_t=rt0)
+    assert torch.equal(rows.view(torch.int32), ref.view(torch.int32))
+    s0 = [a.clone() for a in pipe.accumulators()]
+    # node-major series only, two ragged calls
+    pipe.reset()
+    rt1 = torch.zeros_like(rt0)
+    pipe.process(frames[:33].contiguous(), 0, rows_t=rt1, want_rows=False)
+    pipe.process(frames[33:].contiguous(), 33, rows_t=rt1, col0=33, want_rows=False)
+    assert torch.equal(rt1[:, :F].view(torch.int32), ref.t().contiguous().view(torch.int32))
+    assert torch.equal(rt0.view(torch.int32), rt1.view(torch.int32))
+    s1 = pipe.accumulators()
+    assert torch.equal(s0[0].view(torch.int64), s1[0].view(torch.int64))
+    assert torch.equal(s0[1].view(torch.int64), s1[1].view(torch.int64))
+    # a new projection
+    pix2 = pix.flip(0).contiguous()
+    pipe.set_projection(0, pix2)
+    pipe.reset()
+    rt2 = torch.zeros_like(rt0)
+    pipe.process(frames, 0, rows_t=rt2, want_rows=False)
+    assert torch.equal(rt2[:, :F].view(torch.int32), ref.flip(1).t().contiguous().view(torch.int32))
+    # packed u16 series through a row map + overlap source map
+    vis = torch.nonzero(pix2 >= 0).reshape(-1)
+    rowmap = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    rowmap[vis] = torch.arange(vis.numel(), dtype=torch.int32, device="cuda")
+    src = torch.arange(n, dtype=torch.int32, device="cuda")
+    src[vis[:100]] = vis[100:200].to(torch.int32)          # the stored series of these nodes is another node's
+    pipe.set_row_map(rowmap)
+    pipe.set_overlap_source(src)
+    pipe.reset()
+    buf = torch.zeros((vis.numel(), engine.series_ld(F)), dtype=torch.int32, device="cuda").to(torch.uint16)
+    pipe.process(frames, 0, rows_t=buf[:, :F], want_rows=False)
+    want = rt2[:, :F].index_select(0, src.long()).index_select(0, vis)
+    assert torch.equal(buf[:, :F].to(torch.int32).float(), want)
+    s2 = pipe.accumulators()          # accumulators take the node's own value
+    ok = pix2 >= 0
+    assert torch.equal(s2[0][ok], rt2[:, :F].double().sum(1)[ok])

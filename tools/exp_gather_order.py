@@ -26,7 +26,8 @@ tv = torch.nn.functional.pad(vis, (0, (-N) % 64)).view(-1, 64).sum(1)
 print("tiles: all-invisible %d, full %d, partial %d" % (int((tv == 0).sum()), int((tv == 64).sum()), int(((tv > 0) & (tv < 64)).sum())))
 order_sorted = torch.argsort(torch.where(vis, pix, torch.full_like(pix, 1 << 30)), stable=True)
 g = torch.Generator(device="cuda"); g.manual_seed(0)
-variants = {"mesh order": pix, "sorted by pixel": pix[order_sorted],
+order_vis = torch.argsort((~vis).to(torch.int8), stable=True)          # visible nodes first, mesh order kept
+variants = {"mesh order": pix, "visible first": pix[order_vis], "sorted by pixel": pix[order_sorted],
             "random order": pix[torch.randperm(N, device="cuda", generator=g)]}
 for name, p in variants.items():
     pipe = engine.FramePipeline(1, size, size, N)
