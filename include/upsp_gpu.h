@@ -192,7 +192,11 @@ typedef struct upsp_pipeline_opts {
     int32_t filter, filter_size;
     /* polynomial target patcher on/off (TargetPatchType) */
     int32_t patch;
-    int32_t reserved[5];
+    /* frame-loop schedule of the plain path (one camera, no weights, no image stage, node-major series):
+     * 0 = choose (fused scan + projection pass when a 64-frame sub-batch does not fit the 256 MiB Infinity
+     * Cache, else scan kernel + gather kernel), 1 = always the fused pass, 2 = never.  Same results. */
+    int32_t fused_scan;
+    int32_t reserved[4];
 } upsp_pipeline_opts;
 
 void upsp_pipeline_default_opts(upsp_pipeline_opts *o);

@@ -148,8 +148,9 @@ def test_hot_pixels_saturated_frames(gpu_lib, oracle):
     assert st.tolist() == wst and st[1] == -1 and st[3] == -1 and st[2] == 1
 
 
+@pytest.mark.parametrize("fused", [1, 2])
 @pytest.mark.parametrize("F,ld_extra", [(41, 0), (64, 4), (130, 3)])
-def test_packed_and_u16_series(gpu_lib, oracle, F, ld_extra):
+def test_packed_and_u16_series(gpu_lib, oracle, F, ld_extra, fused):
     """Row map (packed series: only the rows of visible nodes are stored) and the u16 wire format
     of the time-series exchange, against the plain f32 node-major series -- bit for bit."""
     import torch
@@ -163,7 +164,7 @@ def test_packed_and_u16_series(gpu_lib, oracle, F, ld_extra):
     pix[rng.random(n) < 0.4] = -1
     pix[:3] = (0, 1, 2)
     d_pix = torch.as_tensor(pix).cuda()
-    pipe = engine.FramePipeline(1, W, H, n, hot_enable=0)
+    pipe = engine.FramePipeline(1, W, H, n, hot_enable=0, fused_scan=fused)   # 1: fused pass, 2: scan + gather kernels
     pipe.set_projection(0, d_pix)
     d_frames = torch.as_tensor(frames).cuda()
     full = torch.empty((n, F), dtype=torch.float32, device="cuda")
@@ -217,8 +218,9 @@ def test_packed_and_u16_series(gpu_lib, oracle, F, ld_extra):
         p3.process([d_frames, d_frames.clone()], 0, rows_t=b16, want_rows=False)
 
 
+@pytest.mark.parametrize("fused", [1, 2])
 @pytest.mark.parametrize("F", [41, 150])
-def test_hot_pixel_prescan_on_side_stream(gpu_lib, oracle, F):
+def test_hot_pixel_prescan_on_side_stream(gpu_lib, oracle, F, fused):
     """fix_hot_pixels queued ahead of the frame loop on a second stream (the schedule bench.py
     uses: the scan runs while the projection is built) + process(hot_fixed=True): rows,
     transposed rows, repaired frames and accumulators identical to the in-loop scan / the oracle."""
@@ -236,7 +238,7 @@ def test_hot_pixel_prescan_on_side_stream(gpu_lib, oracle, F):
     rows_o, s_o, ss_o = run_loop_oracle(oracle, frames, pix, weight)
     want_frames = np.stack([oracle.fix_hot_pixels(frames[0][f])[0] for f in range(F)])
 
-    pipe = engine.FramePipeline(1, W, H, n)
+    pipe = engine.FramePipeline(1, W, H, n, fused_scan=fused)
     d = torch.as_tensor(frames[0].copy()).cuda()
     side, main = torch.cuda.Stream(), torch.cuda.current_stream()
     side.wait_stream(main)
@@ -260,8 +262,9 @@ def test_hot_pixel_prescan_on_side_stream(gpu_lib, oracle, F):
     assert torch.equal(rows2.view(torch.int32), rows.view(torch.int32))
 
 
+@pytest.mark.parametrize("fused", [1, 2])
 @pytest.mark.parametrize("F", [70, 64])
-def test_large_model_series_variants(gpu_lib, F):
+def test_large_model_series_variants(gpu_lib, F, fused):
     """70 001 nodes, full u16 range: the node-major series written with and without the frame-major
     rows, in ragged calls, after a change of projection, packed as u16 through a row map and with an
     overlap source map -- all bit-identical to a torch gather; accumulators identical between the
@@ -277,7 +280,7 @@ def test_large_model_series_variants(gpu_lib, F):
     frames = torch.randint(0, 65536, (F, H, W), generator=g, device="cuda", dtype=torch.int32).to(torch.uint16)
     ref = frames.reshape(F, -1).to(torch.int32)[:, pix.clamp(min=0).long()].float()
     ref[:, pix < 0] = float("nan")
-    pipe = engine.FramePipeline(1, W, H, n, hot_enable=0)
+    pipe = engine.FramePipeline(1, W, H, n, hot_enable=0, fused_scan=fused)
     pipe.set_projection(0, pix)
     # with frame-major rows
     rt0 = torch.zeros((n, engine.series_ld(F)), dtype=torch.float32, device="cuda")
@@ -317,3 +320,62 @@ def test_large_model_series_variants(gpu_lib, F):
     s2 = pipe.accumulators()          # accumulators take the node's own value
     ok = pix2 >= 0
     assert torch.equal(s2[0][ok], rt2[:, :F].double().sum(1)[ok])
+
+
+@pytest.mark.parametrize("F", [5, 64, 200])
+def test_fused_pass_hot_pixels_vs_oracle(gpu_lib, oracle, F):
+    """The fused scan + projection pass (fused_scan=1) against the oracle frame loop with hot pixels
+    of every kind: repairable ones on pixels several nodes read, on pixels nobody reads, at the image
+    corners and next to each other (the second repair sees the first), a frame with exactly max_hot,
+    one with max_hot + 1 (left alone) and a saturated frame; node-major series, repaired frames and
+    accumulators bit-identical, also for a user skip list and packed u16 rows."""
+    import torch
+    from upsp_processing_amd import engine, synthetic as syn
+    H, W, n = 64, 130, 2500          # 8320 pixels: 65 tiles of 128
+    rng = np.random.default_rng(100 + F)
+    fr = syn.synth_frames_numpy(F, H, W, seed=33, hot=False)
+    fr = np.minimum(fr, 3000).astype(np.uint16)
+    pix = rng.integers(-1, H * W, size=(1, n)).astype(np.int32)
+    pix[0, :40] = 7 * W + 9                       # many nodes on one pixel
+    pix[0, 40:60] = 0                             # corner pixels
+    pix[0, 60:80] = H * W - 1
+    pix[0, 80] = 7 * W + 10
+    f0 = 0
+    fr[f0, 7, 9] = 4095; fr[f0, 7, 10] = 4090     # neighbours: the second repair reads the first
+    fr[f0, 0, 0] = 4095; fr[f0, H - 1, W - 1] = 4070
+    if F > 2:
+        fr[2].flat[rng.choice(H * W, 5, replace=False)] = 4095         # exactly max_hot
+        fr[1].flat[rng.choice(H * W, 6, replace=False)] = 4095         # one too many: untouched
+    if F > 4:
+        fr[4][rng.random((H, W)) < 0.3] = 4080                         # saturated
+        fr[3, 20, 20] = 4064                                           # == thresh, small change vs neighbours
+        fr[3, 19, 20] = fr[3, 21, 20] = fr[3, 20, 19] = fr[3, 20, 21] = 3900   # old - new = 164 <= 512: kept
+    fr[F - 1, 30, 64] = 4095
+    weight = np.ones((1, n), np.float32)
+    rows_o, s_o, ss_o = run_loop_oracle(oracle, [fr], pix, weight)
+    want_frames = np.stack([oracle.fix_hot_pixels(fr[f])[0] for f in range(F)])
+    pipe = engine.FramePipeline(1, W, H, n, fused_scan=1)
+    pipe.set_projection(0, pix[0])
+    d = torch.as_tensor(fr.copy()).cuda()
+    rt = torch.full((n, engine.series_ld(F)), -3.0, dtype=torch.float32, device="cuda")
+    pipe.process(d, 0, rows_t=rt[:, :F], want_rows=False)
+    assert np.array_equal(d.cpu().numpy(), want_frames)
+    assert np.array_equal(rt[:, :F].cpu().numpy().view(np.int32), rows_o.T.view(np.int32))
+    assert (rt[:, F:] == -3.0).all()
+    s_g, ss_g = [a.cpu().numpy() for a in pipe.accumulators()]
+    assert np.array_equal(s_g.view(np.int64), s_o.view(np.int64)) or (
+        np.array_equal(np.isnan(s_g), np.isnan(s_o)) and np.array_equal(s_g[~np.isnan(s_o)], s_o[~np.isnan(s_o)]))
+    ok = ~np.isnan(s_o)
+    assert np.array_equal(ss_g[ok], ss_o[ok])
+    # user skip list (some visible nodes skipped) + packed u16 rows
+    sk = np.zeros(n, np.uint8); sk[pix[0] < 0] = 1; sk[5] = 1; sk[100] = 1
+    pipe.set_skipped(torch.as_tensor(sk).cuda())
+    rowmap = np.full(n, -1, np.int32); keep = np.nonzero(sk == 0)[0]; rowmap[keep] = np.arange(keep.size)
+    pipe.set_row_map(torch.as_tensor(rowmap).cuda())
+    pipe.reset()
+    d2 = torch.as_tensor(fr.copy()).cuda()
+    buf = torch.zeros((keep.size, engine.series_ld(F)), dtype=torch.int32, device="cuda").to(torch.uint16)
+    pipe.process(d2, 0, rows_t=buf[:, :F], want_rows=False)
+    assert np.array_equal(buf[:, :F].cpu().numpy().astype(np.float32), rows_o.T[keep])
+    s2 = pipe.accumulators()[0].cpu().numpy()
+    assert np.isnan(s2[5]) and np.isnan(s2[100]) and np.array_equal(s2[keep], s_o[keep])

@@ -10,11 +10,12 @@ ap.add_argument("--ld", type=int, default=0)
 ap.add_argument("--nodes", type=int, default=500958)
 ap.add_argument("--vis", type=float, default=0.38)
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--size", type=int, default=1024)
 ap.add_argument("--reg", action="store_true")
 ap.add_argument("--filter", type=int, default=0)
 ap.add_argument("--patch", type=int, default=0, help="number of fiducial clusters")
 a = ap.parse_args()
-size, N, F = 1024, a.nodes, a.frames
+size, N, F = a.size, a.nodes, a.frames
 g = torch.Generator(device="cuda"); g.manual_seed(1)
 # spatially coherent projection: node i -> pixel along a space-filling-ish sweep
 pix = (torch.arange(N, device="cuda", dtype=torch.int64) * (size * size) // N).to(torch.int32)

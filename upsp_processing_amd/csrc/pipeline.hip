@@ -33,6 +33,10 @@ struct upsp_pipeline {
     // hot-pixel scratch (per frame of a sub-batch)
     unsigned *d_hot_count = nullptr, *d_hot_pos = nullptr;
     int hot_capacity = 0;
+    // fused scan + gather: pixel tile -> nodes (built on first use after a projection change)
+    unsigned *d_tile_off = nullptr, *d_tile_cur = nullptr;
+    void *d_tile_entries = nullptr;
+    bool tilemap_valid = false;
     // the same scratch for upsp_pipeline_fix_hot_pixels (may run on another stream than process)
     unsigned *d_pre_count = nullptr, *d_pre_pos = nullptr;
     int pre_capacity = 0;
@@ -92,6 +96,7 @@ void upsp_pipeline_default_opts(upsp_pipeline_opts *o)
     o->filter = 0;
     o->filter_size = 1;
     o->patch = 0;
+    o->fused_scan = 0;
 }
 
 int upsp_pipeline_create(int ncams, int width, int height, size_t nnodes,
@@ -169,6 +174,9 @@ void upsp_pipeline_destroy(upsp_pipeline *p)
     free_dev(p->d_hot_pos);
     free_dev(p->d_pre_count);
     free_dev(p->d_pre_pos);
+    free_dev(p->d_tile_off);
+    free_dev(p->d_tile_cur);
+    free_dev(p->d_tile_entries);
     delete p;
 }
 
@@ -188,6 +196,7 @@ int upsp_pipeline_set_projection(upsp_pipeline *p, int cam, const int32_t *d_pix
         p->d_weight[cam] = nullptr;
     }
     p->has_proj[cam] = true;
+    p->tilemap_valid = false;
     if (!p->skipped_user) p->skipped_valid = false;
     return UPSP_OK;
 }
@@ -211,6 +220,7 @@ int upsp_pipeline_set_projection_async(upsp_pipeline *p, int cam, const int32_t 
         p->d_weight[cam] = nullptr;
     }
     p->has_proj[cam] = true;
+    p->tilemap_valid = false;
     if (!p->skipped_user) p->skipped_valid = false;
     return UPSP_OK;
 }
@@ -240,6 +250,7 @@ int upsp_pipeline_fix_hot_pixels(upsp_pipeline *p, uint16_t *d_frames, int nfram
 int upsp_pipeline_set_skipped(upsp_pipeline *p, const uint8_t *d_skipped)
 {
     if (!p) return fail(UPSP_ERR_INVALID, "null pipeline");
+    p->tilemap_valid = false;   // the pixel-tile map carries the flag
     if (d_skipped) {
         UPSP_HIP_CHECK(hipMemcpy(p->d_skipped, d_skipped, p->nnodes, hipMemcpyDeviceToDevice));
         p->skipped_user = true;
@@ -378,6 +389,60 @@ static int process_impl(upsp_pipeline *p, const uint16_t *const *d_frames, int n
     if (overlap) {  // the gather stream starts after everything already queued on `st`
         UPSP_HIP_CHECK(hipEventRecord(p->ev_in, st));
         UPSP_HIP_CHECK(hipStreamWaitEvent(p->aux, p->ev_in, 0));
+    }
+    // Fused scan + projection pass (frames.hip: fused_scan_gather_kernel): one camera, no weights, u16
+    // frames straight from the caller, node-major series only.  Measured on MI355X: at 1 Mpix, where
+    // the 64-frame sub-batch (128 MiB) stays in the Infinity Cache between the scan and the gather,
+    // the two kernels (25 + 39 us per sub-batch) and the fused pass (65 us) are level, and the fused
+    // pass needs the pixel-tile map once per projection; at 4 Mpix (512 MiB per sub-batch) the gather
+    // reads from HBM and the fused pass is 1.6x faster (134 vs 221 us).  Hence the default below.
+    static const char *fused_env = std::getenv("UPSP_FUSED");   // "1" / "0" override the option
+    int fused_mode = p->opts.fused_scan;
+    if (fused_env) fused_mode = std::atoi(fused_env) ? 1 : 2;
+    const bool fused_ok = p->ncams == 1 && !p->d_weight[0] && !need_stage && !d_rows &&
+                          (d_rows_t || d_rows_t16) && !p->d_src && (npix % 2) == 0 && B == 64 && !overlap &&
+                          p->nnodes <= 64 * tilemap_tiles(npix);   // constant rows: <= 64 nodes per workgroup
+    const bool fused = fused_ok && (fused_mode == 1 || (fused_mode == 0 && npix * 2 * 64 > ((size_t)160 << 20)));
+    if (fused) {
+        if (!p->tilemap_valid) {
+            const size_t ntiles = tilemap_tiles(npix);
+            if (!p->d_tile_off) UPSP_HIP_CHECK(hipMalloc(&p->d_tile_off, sizeof(unsigned) * (ntiles + 1)));
+            if (!p->d_tile_cur) UPSP_HIP_CHECK(hipMalloc(&p->d_tile_cur, sizeof(unsigned) * ntiles));
+            if (!p->d_tile_entries) UPSP_HIP_CHECK(hipMalloc(&p->d_tile_entries, 8 * p->nnodes));
+            rc = launch_tilemap_build(p->d_pix[0], p->d_skipped, p->nnodes, npix, p->d_tile_off, p->d_tile_cur,
+                                      p->d_tile_entries, st);
+            if (rc != UPSP_OK) return rc;
+            p->tilemap_valid = true;
+        }
+        PipelineGather g;
+        g.ncams = 1;
+        g.npix = npix;
+        g.nnodes = p->nnodes;
+        g.skipped = p->d_skipped;
+        g.rowmap = p->d_rowmap;
+        g.sum = p->d_sum;
+        g.sumsq = p->d_sumsq;
+        g.pix[0] = p->d_pix[0];
+        g.ld_t = ld_t;
+        g.rows_t = d_rows_t ? d_rows_t + col0 : nullptr;
+        g.rows_t16 = d_rows_t16 ? d_rows_t16 + col0 : nullptr;
+        const bool hot = p->opts.hot_enable != 0;
+        if (rc == UPSP_OK && hot) rc = ensure_hot(p, nframes);   // one counter per frame of the CALL
+        uint16_t *fr = const_cast<uint16_t *>(d_frames[0]);
+        for (int f0 = 0; f0 < nframes && rc == UPSP_OK; f0 += B) {
+            g.nframes = std::min(B, nframes - f0);
+            g.rows_t = d_rows_t ? d_rows_t + col0 + f0 : nullptr;
+            g.rows_t16 = d_rows_t16 ? d_rows_t16 + col0 + f0 : nullptr;
+            rc = launch_fused(g, fr + (size_t)f0 * npix, hot, p->opts.hot_thresh, p->opts.hot_max, p->d_tile_off,
+                              p->d_tile_entries, p->d_hot_count + f0, p->d_hot_pos + (size_t)f0 * 64, st);
+        }
+        if (rc == UPSP_OK && hot) {   // repair + re-projection of the few frames that hold hot pixels
+            g.rows_t = d_rows_t ? d_rows_t + col0 : nullptr;
+            g.rows_t16 = d_rows_t16 ? d_rows_t16 + col0 : nullptr;
+            rc = launch_hot_fixup(g, fr, nframes, p->height, p->width, p->opts.hot_min_change, p->opts.hot_max,
+                                  p->d_tile_off, p->d_tile_entries, p->d_hot_count, p->d_hot_pos, st);
+        }
+        return rc;
     }
     int kbatch = 0;
     for (int f0 = 0; f0 < nframes && rc == UPSP_OK; f0 += B, ++kbatch) {
