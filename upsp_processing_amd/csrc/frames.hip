@@ -559,64 +559,71 @@ __global__ void __launch_bounds__(WAVES * 64)
     }
 }
 
-// ------------------------------------------------------ fused scan + gather --
-// One camera, no weights, u16 frames, no image stage: the hot-pixel scan and the projection are ONE
-// pass over the frames.  The gather above reads every pixel some node sees a second time, lane by
-// lane (2-byte loads, one address per lane: ~1 TA cycle per lane, and only fast while the sub-batch
-// still sits in the Infinity Cache).  Here the roles are turned round: a workgroup owns a TILE of
-// 128 consecutive pixels, streams that tile of all (<= 64) frames of the sub-batch through LDS with
-// fully coalesced 256-byte loads -- counting the hot pixels on the way, that is the scan -- and then
-// pushes the pixels some node sees out to those nodes' rows: per node one 256-byte row segment
-// (16 lanes x 16 B), read column-wise from the LDS tile.  The pixel -> node map (nodes bucketed by
-// tile, built once per projection by three small kernels) replaces the node -> pixel gather.  HBM
-// sees every frame byte once and every series byte once; nothing depends on cache residency.
-//   * rows of nodes without a pixel are constant (NaN / 0): every workgroup writes a share of them
-//     while its frames stream in;
-//   * hot pixels: the pass cannot know a frame's count before it has seen the whole frame, so it
-//     projects the pixels as they are; hot_fixup_kernel then repairs the (rare) frames with
-//     1..max_hot hot pixels in place exactly like fix_frame and patches the few series entries and
-//     accumulators that saw a replaced pixel.  All values are integers < 2^16 (squares rounded to
-//     float like the gather's), their double sums are exact, so "add new - old" gives the same bits
-//     as summing the repaired values.
+// --------------------------------------------- streamed scan + projection (2 passes) --
+// One camera, no weights, u16 frames, no image stage, node-major series.  The gather above reads
+// every pixel some node sees a second time, lane by lane (2-byte loads, one address per lane, ~1 TA
+// cycle per lane, and only fast while the 64-frame sub-batch still sits in the Infinity Cache).
+// Here the frame data is turned round on its single way through the chip:
+//
+//   pass A (scan_compact_kernel): a workgroup owns a TILE of 128 consecutive pixels and streams
+//     that tile of all (<= 64) frames of the sub-batch through LDS with coalesced 256-byte loads,
+//     counting the hot pixels on the way (that is the scan).  The few pixels of the tile that some
+//     node reads ("active" pixels: 66 k of 1 M on the bench model) leave the tile TRANSPOSED: 64
+//     consecutive u16 -- the pixel's time series over the sub-batch -- per active pixel, into a
+//     compact buffer (8 MB per sub-batch, L2 / Infinity-Cache resident whatever the frame size).
+//     The work per tile is bounded by its 128 pixels, however many nodes read them.
+//   pass B (node_stream_kernel): 16 lanes per node read the node's pixel series (128 contiguous
+//     bytes), widen it, add it to the accumulators and write the 256-byte row segment; nodes without
+//     a pixel get their constant row (NaN when no camera sees them, psp_process.cpp:1821-1825).
+//     Nodes in mesh order, rows in row order: a pure streaming write.
+//
+// HBM sees every frame byte once (pass A, reads only) and every series byte once (pass B, writes only);
+// nothing depends on the frames staying in a cache between the passes.  (A single fused pass that
+// pushes the pixels straight to the nodes' rows was built first: its node work piles up on the 10 % of
+// the tiles that cover the model, and reads and writes interleave in HBM -- level with scan + gather at
+// 1 Mpix.  DESIGN.md section 4.)
+//   * hot pixels: pass A cannot know a frame's count before the whole frame has gone by, so the passes
+//     project the pixels as they are; hot_repair_kernel then repairs the (rare) frames with
+//     1..max_hot hot pixels in place exactly like fix_frame and lists the replaced pixels, and
+//     hot_patch_kernel re-projects them: series entry and accumulators of every node on such a pixel.
+//     All values are integers < 2^16 (squares rounded to float like the gather's), their double sums
+//     are exact, so "add new - old" gives the same bits as summing the repaired values.
 constexpr int kFusedPix = 128;     // pixels per tile
 constexpr int kFusedPitch = 65;    // dwords per LDS row: 64 (128 px) + 1 pad
 
-// Nodes next to each other in the mesh mostly fall into the same pixel tile: one atomic per (wave, tile)
-// instead of one per node (190 k atomics on ~2000 hot counters took 63 us per kernel).
-// Returns the lane's slot in its tile for FILL (base from the leader's atomic + rank in the wave).
-template <bool FILL>
-__device__ __forceinline__ unsigned tile_slot(unsigned *__restrict__ counter, bool has, unsigned t)
-{
-    unsigned slot = 0;
-    unsigned long long todo = __ballot(has);
-    const unsigned long long lt = (1ull << (threadIdx.x & 63)) - 1ull;
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const unsigned t0 = __shfl(t, leader);
-        const unsigned long long m = __ballot(has && t == t0) & todo;
-        if (has && t == t0) {
-            unsigned base = 0;
-            if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(&counter[t0], (unsigned)__popcll(m));
-            if (FILL) slot = __shfl(base, leader) + (unsigned)__popcll(m & lt);
-        } else if (FILL) {
-            (void)__shfl(0u, leader);
-        }
-        todo &= ~m;
-    }
-    return slot;
-}
-
+// active-pixel map, step 1: flag[pixel] = 1 for pixels some node reads (flag zeroed by the caller)
 __global__ void __launch_bounds__(256)
-    tilemap_count_kernel(const int32_t *__restrict__ pix, unsigned nnodes, unsigned *__restrict__ cnt)
+    amap_mark_kernel(const int32_t *__restrict__ pix, unsigned nnodes, uint8_t *__restrict__ flag)
 {
     const unsigned n = blockIdx.x * blockDim.x + threadIdx.x;
-    const int32_t p = n < nnodes ? pix[n] : -1;
-    (void)tile_slot<false>(cnt, p >= 0, (unsigned)p / kFusedPix);
+    if (n >= nnodes) return;
+    const int32_t p = pix[n];
+    if (p >= 0) flag[p] = 1;
 }
 
-// exclusive scan of the tile counts (one workgroup); cnt becomes the fill cursor (= offset)
+// step 2: rank of every active pixel inside its 128-pixel tile (flag becomes 0x80 | rank) and the
+// number of active pixels per tile.  One wave per 64 pixels, two waves per tile.
+__global__ void __launch_bounds__(256)
+    amap_rank_kernel(uint8_t *__restrict__ flag, size_t npix, unsigned *__restrict__ tile_cnt)
+{
+    __shared__ unsigned wave_cnt[4];
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool act = p < npix && flag[p] != 0;
+    const unsigned long long m = __ballot(act);
+    if (lane == 0) wave_cnt[wave] = (unsigned)__popcll(m);
+    __syncthreads();
+    const unsigned before = (wave & 1) ? wave_cnt[wave - 1] : 0u;   // first half of the same tile
+    if (act) flag[p] = (uint8_t)(0x80u | (before + (unsigned)__popcll(m & ((1ull << lane) - 1ull))));
+    if (lane == 0 && !(wave & 1)) {
+        const size_t tile = (size_t)blockIdx.x * 2 + (wave >> 1);
+        if (tile * kFusedPix < npix) tile_cnt[tile] = wave_cnt[wave] + wave_cnt[wave + 1];
+    }
+}
+
+// exclusive scan of the tile counts (one workgroup): off[0..ntiles], off[ntiles] = total
 __global__ void __launch_bounds__(1024)
-    tilemap_scan_kernel(unsigned *__restrict__ cnt, unsigned *__restrict__ off, unsigned ntiles)
+    tilemap_scan_kernel(const unsigned *__restrict__ cnt, unsigned *__restrict__ off, unsigned ntiles)
 {
     __shared__ unsigned part[1024];
     __shared__ unsigned carry;
@@ -643,7 +650,6 @@ __global__ void __launch_bounds__(1024)
         for (int k = 0; k < 8; ++k)
             if (i0 + k < ntiles) {
                 off[i0 + k] = run;
-                cnt[i0 + k] = run;
                 run += v[k];
             }
         __syncthreads();
@@ -653,20 +659,20 @@ __global__ void __launch_bounds__(1024)
     if (threadIdx.x == 0) off[ntiles] = carry;
 }
 
+// step 3: node -> index of its pixel's series in the compact buffer (-1: no pixel)
 __global__ void __launch_bounds__(256)
-    tilemap_fill_kernel(const int32_t *__restrict__ pix, const uint8_t *__restrict__ skipped, unsigned nnodes,
-                        unsigned *__restrict__ cursor, uint2 *__restrict__ entries)
+    amap_nodes_kernel(const int32_t *__restrict__ pix, unsigned nnodes, const uint8_t *__restrict__ flag,
+                      const unsigned *__restrict__ tile_off, int32_t *__restrict__ node_k)
 {
     const unsigned n = blockIdx.x * blockDim.x + threadIdx.x;
-    const int32_t p = n < nnodes ? pix[n] : -1;
-    const unsigned slot = tile_slot<true>(cursor, p >= 0, (unsigned)p / kFusedPix);
-    // y = pixel within the tile | "no camera sees this node" << 8; order inside a tile does not matter
-    if (p >= 0) entries[slot] = make_uint2(n, ((unsigned)p % kFusedPix) | ((skipped && skipped[n]) ? 0x100u : 0u));
+    if (n >= nnodes) return;
+    const int32_t p = pix[n];
+    node_k[n] = p >= 0 ? (int32_t)(tile_off[(unsigned)p / kFusedPix] + (flag[p] & 0x7Fu)) : -1;
 }
 
 // Sum over the 16 lanes of a DPP row (all lanes get the total): four VALU adds fed by DPP moves
-// (quad swaps, half-row mirror, row mirror) instead of ds_bpermute round trips -- the shuffle form
-// was a chain of 16 LDS-crossbar operations per node.  Exact for the integer-valued sums used here.
+// (quad swaps, half-row mirror, row mirror) instead of ds_bpermute round trips.  Exact for the
+// integer-valued sums used here.
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov_f64(double x)
 {
@@ -684,38 +690,18 @@ __device__ __forceinline__ double group16_sum(double v)
     return v;
 }
 
+// Pass A.  compact: [active pixel][cpitch] u16; this launch fills 64 columns from `compact` on
+// (frames past nframes hold 0).
 template <bool HOT>
 __global__ void __launch_bounds__(256)
-    fused_scan_gather_kernel(const uint16_t *__restrict__ frames, size_t npix, int nframes,
-                             const unsigned *__restrict__ tile_off, const uint2 *__restrict__ entries,
-                             const uint8_t *__restrict__ skipped, const int32_t *__restrict__ rowmap,
-                             float *__restrict__ rows_t, uint16_t *__restrict__ rows_t16, long long ld_t,
-                             double *__restrict__ sum, double *__restrict__ sumsq, unsigned thresh,
-                             unsigned max_hot, unsigned *__restrict__ count, unsigned *__restrict__ pos,
-                             const int32_t *__restrict__ pix, unsigned nnodes, unsigned npw)
+    scan_compact_kernel(const uint16_t *__restrict__ frames, size_t npix, int nframes,
+                        const uint8_t *__restrict__ flag, const unsigned *__restrict__ tile_off,
+                        uint16_t *__restrict__ compact, unsigned cpitch, unsigned thresh, unsigned max_hot,
+                        unsigned *__restrict__ count, unsigned *__restrict__ pos)
 {
     __shared__ unsigned tile[64][kFusedPitch];   // [frame][pixel pair]
+    __shared__ int act_k[kFusedPix];             // compact index of the tile's pixels, -1 = nobody reads it
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int grp = lane >> 4, gl = lane & 15, c4 = 4 * gl;   // 16 lanes x 4 frames = one 64-frame row segment
-    const float qnan = __builtin_nanf("");
-    const bool vec_ok = rows_t ? (((ld_t & 3) == 0) && ((reinterpret_cast<size_t>(rows_t) & 15) == 0))
-                               : (((ld_t & 3) == 0) && ((reinterpret_cast<size_t>(rows_t16) & 7) == 0));
-    // Rows of nodes WITHOUT a pixel are constant -- NaN when no camera sees the node
-    // (psp_process.cpp:1821-1825), 0 for an empty row of the projection matrix.  Every workgroup
-    // writes the segments of its share of the node range (npw nodes, <= 4 per 16-lane group): the
-    // loads of pix / skipped go out first, the stores as soon as they are back, and neither has
-    // anything to do with the frames streaming in meanwhile.
-    constexpr int kShare = 4;
-    int32_t spx[kShare];
-    unsigned char ssk[kShare];
-#pragma unroll
-    for (int k = 0; k < kShare; ++k) {
-        const unsigned r = (unsigned)(wave * 4 + grp) + 16u * k;
-        const unsigned n = blockIdx.x * npw + r;
-        const bool ok = r < npw && n < nnodes;
-        spx[k] = ok ? pix[n] : 0;
-        ssk[k] = (ok && skipped) ? skipped[n] : (unsigned char)0;
-    }
     const size_t p0 = (size_t)blockIdx.x * kFusedPix + 2u * (unsigned)lane;   // this lane's pixel pair
     const bool in = p0 + 1 < npix;                                            // npix is even
     // wave w streams frames w, w+4, ..: one 256-byte segment per wave load, all 16 issued up front
@@ -725,42 +711,10 @@ __global__ void __launch_bounds__(256)
         const int f = wave + 4 * i;
         v[i] = (in && f < nframes) ? *reinterpret_cast<const unsigned *>(frames + (size_t)f * npix + p0) : 0u;
     }
-    // the tile's node list goes through LDS as well: the first 512 entries are fetched right behind
-    // the frames (coalesced, two per thread) and parked next to the tile before the barrier, so the
-    // projection loop below has no dependent global load per node.  (Dense parts of the image hold
-    // 200-300 nodes per 128-pixel tile: a serial chain of list loads made those workgroups the tail.)
-    constexpr unsigned kEnt = 512;
-    __shared__ uint2 ent[kEnt];
-    const unsigned e0 = tile_off[blockIdx.x], e1 = tile_off[blockIdx.x + 1];
-    uint2 pre0 = make_uint2(0u, 0u), pre1 = make_uint2(0u, 0u);
-    if (e0 + threadIdx.x < e1) pre0 = entries[e0 + threadIdx.x];
-    if (e0 + 256u + threadIdx.x < e1) pre1 = entries[e0 + 256u + threadIdx.x];
-#pragma unroll
-    for (int k = 0; k < kShare; ++k) {
-        const unsigned r = (unsigned)(wave * 4 + grp) + 16u * k;
-        const unsigned n = blockIdx.x * npw + r;
-        if (!(r < npw && n < nnodes) || spx[k] >= 0) continue;
-        const bool sk = ssk[k] != 0;
-        if (gl == 0 && sk) {
-            sum[n] = (double)qnan;       // x + NaN = NaN
-            sumsq[n] = (double)qnan;
-        }
-        const long long row = rowmap ? (long long)rowmap[n] : (long long)n;
-        if (row < 0 || c4 >= nframes) continue;
-        const float val = sk ? qnan : 0.0f;
-        if (rows_t) {
-            float *dst = rows_t + row * ld_t + c4;
-            typedef float v4f __attribute__((ext_vector_type(4)));
-            const v4f nv = {val, val, val, val};
-            if (vec_ok && c4 + 3 < nframes) {
-                __builtin_nontemporal_store(nv, reinterpret_cast<v4f *>(dst));
-            } else {
-                for (int j = 0; j < 4 && c4 + j < nframes; ++j) dst[j] = val;
-            }
-        } else {   // u16 series: NaN has no encoding, such rows are stored as 0 (and normally left out by the row map)
-            uint16_t *dst = rows_t16 + row * ld_t + c4;
-            for (int j = 0; j < 4 && c4 + j < nframes; ++j) dst[j] = (uint16_t)0;
-        }
+    if (threadIdx.x < kFusedPix) {
+        const size_t p = (size_t)blockIdx.x * kFusedPix + threadIdx.x;
+        const unsigned fl = p < npix ? flag[p] : 0u;
+        act_k[threadIdx.x] = fl ? (int)(tile_off[blockIdx.x] + (fl & 0x7Fu)) : -1;
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -778,136 +732,175 @@ __global__ void __launch_bounds__(256)
             }
         }
     }
-    ent[threadIdx.x] = pre0;
-    ent[256u + threadIdx.x] = pre1;
     __syncthreads();
-    // one node: its 64-frame row segment (16 lanes x 4 frames) + its accumulators
-    auto emit = [&](const uint2 en) {
-        const unsigned n = en.x, col = (en.y & 0x7Fu) >> 1, sh = 16u * (en.y & 1u);
-        const bool sk = (en.y & 0x100u) != 0u;
-        unsigned d[4];
+    // 8 lanes per active pixel: lane j packs frames 8j .. 8j+7 of the pixel's column into 16 bytes
+    const int grp = threadIdx.x >> 3, j8 = threadIdx.x & 7;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) d[k] = (tile[c4 + k][col] >> sh) & 0xFFFFu;
-        double s = 0.0, ss = 0.0;
+    for (int r = 0; r < kFusedPix / 32; ++r) {
+        const int o = grp + 32 * r;
+        const int k = act_k[o];
+        if (k < 0) continue;
+        const unsigned col = (unsigned)o >> 1, sh = 16u * ((unsigned)o & 1u);
+        unsigned w[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (c4 + k < nframes) {
-                const float x = (float)d[k];
-                s += (double)x;
-                ss += (double)(x * x);
-            }
-        s = group16_sum(s);
-        ss = group16_sum(ss);
-        if (gl == 0) {
-            // fire-and-forget adds (exact: integer-valued doubles): a read-modify-write would put a
-            // global load on the critical path of every node
-            (void)__hip_atomic_fetch_add(&sum[n], sk ? (double)qnan : s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            (void)__hip_atomic_fetch_add(&sumsq[n], sk ? (double)qnan : ss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int q = 0; q < 4; ++q) {
+            const unsigned a = (tile[8 * j8 + 2 * q][col] >> sh) & 0xFFFFu;
+            const unsigned b = (tile[8 * j8 + 2 * q + 1][col] >> sh) & 0xFFFFu;
+            w[q] = a | (b << 16);
         }
-        const long long row = rowmap ? (long long)rowmap[n] : (long long)n;
-        if (row < 0 || c4 >= nframes) return;
-        if (rows_t) {
-            float *dst = rows_t + row * ld_t + c4;
-            typedef float v4f __attribute__((ext_vector_type(4)));
-            const v4f nv = {sk ? qnan : (float)d[0], sk ? qnan : (float)d[1], sk ? qnan : (float)d[2],
-                            sk ? qnan : (float)d[3]};
-            if (vec_ok && c4 + 3 < nframes) {
-                __builtin_nontemporal_store(nv, reinterpret_cast<v4f *>(dst));
-            } else {
-                dst[0] = nv.x;
-                if (c4 + 1 < nframes) dst[1] = nv.y;
-                if (c4 + 2 < nframes) dst[2] = nv.z;
-                if (c4 + 3 < nframes) dst[3] = nv.w;
-            }
-        } else {   // u16 series (exchange wire format): NaN rows are stored as 0
-            uint16_t *dst = rows_t16 + row * ld_t + c4;
-            typedef unsigned v2u __attribute__((ext_vector_type(2)));
-            const v2u nv = {sk ? 0u : (d[0] | (d[1] << 16)), sk ? 0u : (d[2] | (d[3] << 16))};
-            if (vec_ok && c4 + 3 < nframes) {
-                __builtin_nontemporal_store(nv, reinterpret_cast<v2u *>(dst));
-            } else {
-                dst[0] = (uint16_t)(nv.x & 0xFFFFu);
-                if (c4 + 1 < nframes) dst[1] = (uint16_t)(nv.x >> 16);
-                if (c4 + 2 < nframes) dst[2] = (uint16_t)(nv.y & 0xFFFFu);
-                if (c4 + 3 < nframes) dst[3] = (uint16_t)(nv.y >> 16);
-            }
-        }
-    };
-    const unsigned total = e1 - e0;
-    for (unsigned base = 0; base < total; base += kEnt) {       // (uniform) one round unless the tile holds > 512 nodes
-        if (base) {
-            __syncthreads();
-            if (base + threadIdx.x < total) ent[threadIdx.x] = entries[e0 + base + threadIdx.x];
-            if (base + 256u + threadIdx.x < total) ent[256u + threadIdx.x] = entries[e0 + base + 256u + threadIdx.x];
-            __syncthreads();
-        }
-        const unsigned cnt = min(kEnt, total - base);
-        for (unsigned i = (unsigned)(wave * 4 + grp); i < cnt; i += 16u) emit(ent[i]);
+        *reinterpret_cast<uint4 *>(compact + (size_t)k * cpitch + 8 * j8) = make_uint4(w[0], w[1], w[2], w[3]);
     }
 }
 
-// Frames with 1..max_hot hot pixels: repair in place (same code as the scan kernel's pass 2), then
-// re-project the replaced pixels: series entry and accumulators of every node on such a pixel.
-__global__ void __launch_bounds__(64)
-    hot_fixup_kernel(uint16_t *frames, size_t npix, int rows, int cols, int min_change, int max_hot,
-                     unsigned *__restrict__ count, const unsigned *__restrict__ pos,
-                     const unsigned *__restrict__ tile_off, const uint2 *__restrict__ entries,
-                     const uint8_t *__restrict__ skipped, const int32_t *__restrict__ rowmap,
-                     float *__restrict__ rows_t, uint16_t *__restrict__ rows_t16, long long ld_t,
-                     double *__restrict__ sum, double *__restrict__ sumsq)
+// Pass B.  16 lanes per node; the node's series over the (<= kStreamFrames) frames that pass A has
+// parked in the compact buffer goes out as one contiguous piece of its row: lane l handles frames
+// 64 c + 4 l .. + 3 of every 64-frame chunk c.  Measured: 256-byte pieces (one 64-frame sub-batch per
+// pass) 32.9 us per 64 frames = 3.9 TB/s of row writes; 1-KB pieces (four sub-batches per pass) 34.6 us --
+// the strided row pieces are what HBM charges for, not their number, so the sub-batch stays at 64.
+constexpr int kStreamFrames = 64;
+__global__ void __launch_bounds__(256)
+    node_stream_kernel(const uint16_t *__restrict__ compact, unsigned cpitch, const int32_t *__restrict__ node_k,
+                       const uint8_t *__restrict__ skipped, const int32_t *__restrict__ rowmap,
+                       unsigned nnodes, int nframes, float *__restrict__ rows_t,
+                       uint16_t *__restrict__ rows_t16, long long ld_t, double *__restrict__ sum,
+                       double *__restrict__ sumsq)
 {
-    __shared__ unsigned chg_pos[kHotCap], chg_old[kHotCap], chg_new[kHotCap];
-    __shared__ unsigned nchg;
-    const size_t f = blockIdx.x;
-    const unsigned n = count[f];
-    if (n == 0u) return;                       // (uniform) nearly every frame
-    if (threadIdx.x == 0) {
-        count[f] = 0u;                         // clean for the next launch
-        nchg = 0u;
-        if (n <= (unsigned)max_hot) {
-            unsigned p[kHotCap];
-            for (unsigned i = 0; i < n; ++i) p[i] = pos[f * kHotCap + i];
-            uint16_t *img = frames + f * npix;
-            uint16_t before[kHotCap];
-            for (unsigned i = 0; i < n; ++i) before[i] = img[p[i]];
-            fix_frame(img, rows, cols, min_change, max_hot, n, p, nullptr);   // sorts p
-            // `before` was taken in recording order, p is sorted now: compare through the image
-            unsigned m = 0;
-            for (unsigned i = 0; i < n; ++i) {
-                // value the projection saw = the hot value (>= thresh); after the repair the pixel
-                // either still holds it or holds the replacement
-                unsigned oldv = 0;
-                for (unsigned j = 0; j < n; ++j)
-                    if (pos[f * kHotCap + j] == p[i]) oldv = before[j];
-                const unsigned newv = img[p[i]];
-                if (newv != oldv) {
-                    chg_pos[m] = p[i];
-                    chg_old[m] = oldv;
-                    chg_new[m] = newv;
-                    ++m;
+    constexpr int kChunks = kStreamFrames / 64;
+    const unsigned n = blockIdx.x * 16u + (threadIdx.x >> 4);
+    const int gl = threadIdx.x & 15, c4 = 4 * gl;
+    if (n >= nnodes) return;
+    const int k = node_k[n];
+    const bool sk = skipped && skipped[n];
+    const long long row = rowmap ? (long long)rowmap[n] : (long long)n;
+    const float qnan = __builtin_nanf("");
+    uint2 w[kChunks];
+#pragma unroll
+    for (int c = 0; c < kChunks; ++c)
+        w[c] = (k >= 0 && 64 * c < nframes) ? *reinterpret_cast<const uint2 *>(compact + (size_t)k * cpitch + 64 * c + c4)
+                                            : make_uint2(0u, 0u);
+    if (k >= 0) {
+        double s = 0.0, ss = 0.0;
+#pragma unroll
+        for (int c = 0; c < kChunks; ++c) {
+            const unsigned d[4] = {w[c].x & 0xFFFFu, w[c].x >> 16, w[c].y & 0xFFFFu, w[c].y >> 16};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (64 * c + c4 + q < nframes) {
+                    const float x = (float)d[q];
+                    s += (double)x;
+                    ss += (double)(x * x);
                 }
-            }
-            nchg = m;
         }
+        s = group16_sum(s);
+        ss = group16_sum(ss);
+        if (gl == 0) {
+            sum[n] += sk ? (double)qnan : s;        // one group owns the node
+            sumsq[n] += sk ? (double)qnan : ss;
+        }
+    } else if (gl == 0 && sk) {
+        sum[n] = (double)qnan;       // x + NaN = NaN
+        sumsq[n] = (double)qnan;
     }
-    __syncthreads();
-    for (unsigned c = 0; c < nchg; ++c) {
-        const unsigned t = chg_pos[c] / kFusedPix, po = chg_pos[c] % kFusedPix;
-        const float xo = (float)chg_old[c], xn = (float)chg_new[c];
-        for (unsigned e = tile_off[t] + threadIdx.x; e < tile_off[t + 1]; e += 64u) {
-            const uint2 en = entries[e];
-            if ((en.y & 0x7Fu) != po) continue;
-            const unsigned node = en.x;
-            if (en.y & 0x100u) continue;                     // no camera sees it: stays NaN
-            atomicAdd(&sum[node], (double)xn - (double)xo);
-            atomicAdd(&sumsq[node], (double)(xn * xn) - (double)(xo * xo));
-            const long long row = rowmap ? (long long)rowmap[node] : (long long)node;
-            if (row < 0) continue;
-            if (rows_t) rows_t[row * ld_t + (long long)f] = xn;
-            else rows_t16[row * ld_t + (long long)f] = (uint16_t)chg_new[c];
+    if (row < 0) return;
+    const bool vec_ok = rows_t ? (((ld_t & 3) == 0) && ((reinterpret_cast<size_t>(rows_t) & 15) == 0))
+                               : (((ld_t & 3) == 0) && ((reinterpret_cast<size_t>(rows_t16) & 7) == 0));
+#pragma unroll
+    for (int c = 0; c < kChunks; ++c) {
+        const int f0 = 64 * c + c4;
+        if (f0 >= nframes) continue;
+        const unsigned d[4] = {w[c].x & 0xFFFFu, w[c].x >> 16, w[c].y & 0xFFFFu, w[c].y >> 16};
+        if (rows_t) {
+            float *dst = rows_t + row * ld_t + f0;
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            // a node without a pixel: 0 (empty row of the projection matrix); no camera sees it: NaN
+            const v4f nv = {sk ? qnan : (float)d[0], sk ? qnan : (float)d[1], sk ? qnan : (float)d[2],
+                            sk ? qnan : (float)d[3]};
+            if (vec_ok && f0 + 3 < nframes) {
+                __builtin_nontemporal_store(nv, reinterpret_cast<v4f *>(dst));
+            } else {
+                dst[0] = nv.x;
+                if (f0 + 1 < nframes) dst[1] = nv.y;
+                if (f0 + 2 < nframes) dst[2] = nv.z;
+                if (f0 + 3 < nframes) dst[3] = nv.w;
+            }
+        } else {   // u16 series (exchange wire format): NaN rows are stored as 0
+            uint16_t *dst = rows_t16 + row * ld_t + f0;
+            typedef unsigned v2u __attribute__((ext_vector_type(2)));
+            const v2u nv = {sk ? 0u : (d[0] | (d[1] << 16)), sk ? 0u : (d[2] | (d[3] << 16))};
+            if (vec_ok && f0 + 3 < nframes) {
+                __builtin_nontemporal_store(nv, reinterpret_cast<v2u *>(dst));
+            } else {
+                dst[0] = (uint16_t)(nv.x & 0xFFFFu);
+                if (f0 + 1 < nframes) dst[1] = (uint16_t)(nv.x >> 16);
+                if (f0 + 2 < nframes) dst[2] = (uint16_t)(nv.y & 0xFFFFu);
+                if (f0 + 3 < nframes) dst[3] = (uint16_t)(nv.y >> 16);
+            }
         }
     }
 }
+
+// Frames with 1..max_hot hot pixels: repair in place (same code as the scan kernel's pass 2) and
+// list the replaced pixels as (frame, position, old, new) for hot_patch_kernel.  One lane per frame.
+__global__ void __launch_bounds__(64)
+    hot_repair_kernel(uint16_t *frames, size_t npix, int nframes, int rows, int cols, int min_change,
+                      int max_hot, unsigned *__restrict__ count, const unsigned *__restrict__ pos,
+                      unsigned *__restrict__ nchanges, uint4 *__restrict__ changes, unsigned cap)
+{
+    const size_t f = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= (size_t)nframes) return;
+    const unsigned n = count[f];
+    if (n == 0u) return;
+    count[f] = 0u;                             // clean for the next launch
+    if (n > (unsigned)max_hot) return;         // "too many pixels look hot": frame untouched
+    unsigned p[kHotCap];
+    uint16_t before[kHotCap];
+    uint16_t *img = frames + f * npix;
+    for (unsigned i = 0; i < n; ++i) {
+        p[i] = pos[f * kHotCap + i];
+        before[i] = img[p[i]];
+    }
+    fix_frame(img, rows, cols, min_change, max_hot, n, p, nullptr);   // sorts p
+    for (unsigned i = 0; i < n; ++i) {
+        unsigned oldv = 0;
+        for (unsigned j = 0; j < n; ++j)
+            if (pos[f * kHotCap + j] == p[i]) oldv = before[j];
+        const unsigned newv = img[p[i]];
+        if (newv != oldv) {
+            const unsigned slot = atomicAdd(nchanges, 1u);
+            if (slot < cap) changes[slot] = make_uint4((unsigned)f, p[i], oldv, newv);
+        }
+    }
+}
+
+// Re-projection of the replaced pixels: every node reading one gets its series entry and its
+// accumulators corrected.  One lane per node against the (short) change list.
+__global__ void __launch_bounds__(256)
+    hot_patch_kernel(const int32_t *__restrict__ pix, const uint8_t *__restrict__ skipped,
+                     const int32_t *__restrict__ rowmap, unsigned nnodes, unsigned *__restrict__ nchanges,
+                     const uint4 *__restrict__ changes, unsigned cap, float *__restrict__ rows_t,
+                     uint16_t *__restrict__ rows_t16, long long ld_t, double *__restrict__ sum,
+                     double *__restrict__ sumsq)
+{
+    const unsigned m = min(*nchanges, cap);
+    if (m == 0u) return;                       // (uniform) nearly every call
+    const unsigned n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= nnodes) return;
+    const int32_t p = pix[n];
+    if (p < 0 || (skipped && skipped[n])) return;             // no pixel / stays NaN
+    const long long row = rowmap ? (long long)rowmap[n] : (long long)n;
+    for (unsigned c = 0; c < m; ++c) {
+        const uint4 ch = changes[c];
+        if (ch.y != (unsigned)p) continue;
+        const float xo = (float)ch.z, xn = (float)ch.w;
+        sum[n] += (double)xn - (double)xo;                    // one lane owns the node
+        sumsq[n] += (double)(xn * xn) - (double)(xo * xo);
+        if (row < 0) continue;
+        if (rows_t) rows_t[row * ld_t + (long long)ch.x] = xn;
+        else rows_t16[row * ld_t + (long long)ch.x] = (uint16_t)ch.w;
+    }
+}
+
+__global__ void hot_patch_reset_kernel(unsigned *nchanges) { *nchanges = 0u; }
 
 __global__ void finals_kernel(const double *__restrict__ sum, const double *__restrict__ sumsq,
                               unsigned nnodes, double nframes, float *__restrict__ avg,
@@ -1119,66 +1112,80 @@ int launch_hot_fix(uint16_t *d_frames, int nframes, int rows, int cols, int thre
     return UPSP_OK;
 }
 
-// ---- fused scan + gather (see fused_scan_gather_kernel) -----------------------
+// ---- streamed scan + projection (scan_compact_kernel / node_stream_kernel) ----
 size_t tilemap_tiles(size_t npix) { return (npix + kFusedPix - 1) / kFusedPix; }
 
-// pixel tile -> nodes: d_off [ntiles + 1], d_cursor [ntiles] (scratch), d_entries [nnodes] (uint2)
-int launch_tilemap_build(const int32_t *d_pix, const uint8_t *d_skipped, size_t nnodes, size_t npix,
-                         unsigned *d_off, unsigned *d_cursor, void *d_entries, hipStream_t st)
+// Active-pixel map of a projection: d_flag [npix] bytes (0 or 0x80 | rank in its tile), d_off
+// [ntiles + 1] (compact index of a tile's first active pixel; d_off[ntiles] = number of active
+// pixels), d_node_k [nnodes].  d_cnt [ntiles] is scratch.
+int launch_amap_build(const int32_t *d_pix, size_t nnodes, size_t npix, uint8_t *d_flag, unsigned *d_cnt,
+                      unsigned *d_off, int32_t *d_node_k, hipStream_t st)
 {
     const unsigned ntiles = (unsigned)tilemap_tiles(npix);
-    KTimed kt("tilemap_build", st);
-    UPSP_HIP_CHECK(hipMemsetAsync(d_cursor, 0, sizeof(unsigned) * ntiles, st));
+    KTimed kt("amap_build", st);
+    UPSP_HIP_CHECK(hipMemsetAsync(d_flag, 0, npix, st));
     const dim3 g((unsigned)((nnodes + 255) / 256)), b(256);
-    hipLaunchKernelGGL(tilemap_count_kernel, g, b, 0, st, d_pix, (unsigned)nnodes, d_cursor);
-    hipLaunchKernelGGL(tilemap_scan_kernel, dim3(1), dim3(1024), 0, st, d_cursor, d_off, ntiles);
-    hipLaunchKernelGGL(tilemap_fill_kernel, g, b, 0, st, d_pix, d_skipped, (unsigned)nnodes, d_cursor,
-                       reinterpret_cast<uint2 *>(d_entries));
+    hipLaunchKernelGGL(amap_mark_kernel, g, b, 0, st, d_pix, (unsigned)nnodes, d_flag);
+    hipLaunchKernelGGL(amap_rank_kernel, dim3((unsigned)((npix + 255) / 256)), b, 0, st, d_flag, npix, d_cnt);
+    hipLaunchKernelGGL(tilemap_scan_kernel, dim3(1), dim3(1024), 0, st, (const unsigned *)d_cnt, d_off, ntiles);
+    hipLaunchKernelGGL(amap_nodes_kernel, g, b, 0, st, d_pix, (unsigned)nnodes, (const uint8_t *)d_flag,
+                       (const unsigned *)d_off, d_node_k);
     UPSP_HIP_CHECK(hipGetLastError());
     return UPSP_OK;
 }
 
-// One sub-batch (<= 64 frames): scan + projection in one pass.  d_count: one counter per frame of
-// the sub-batch (zero on entry; launch_hot_fixup leaves them zero), d_pos: 64 positions per frame.
-int launch_fused(const PipelineGather &g, uint16_t *d_frames, bool hot, int thresh, int max_hot,
-                 const unsigned *d_off, const void *d_entries, unsigned *d_count, unsigned *d_pos,
-                 hipStream_t st)
+int stream_frames_max() { return kStreamFrames; }
+
+// Pass A for one sub-batch (<= 64 frames) into columns [col, col + 64) of the compact buffer.
+// d_count: one counter per frame of the sub-batch (zero on entry; launch_hot_fixup leaves them zero),
+// d_pos: 64 positions per frame.
+int launch_scan_compact(uint16_t *d_frames, size_t npix, int nframes, bool hot, int thresh, int max_hot,
+                        const uint8_t *d_flag, const unsigned *d_off, uint16_t *d_compact, int col,
+                        unsigned *d_count, unsigned *d_pos, hipStream_t st)
 {
-    if (g.nframes <= 0 || g.nframes > 64) return fail(UPSP_ERR_INVALID, "fused pass takes 1..64 frames");
+    if (nframes <= 0 || nframes > 64) return fail(UPSP_ERR_INVALID, "scan pass takes 1..64 frames");
     if (max_hot < 0 || max_hot >= kHotCap) return fail(UPSP_ERR_INVALID, "max_hot must be in [0,63]");
-    const unsigned ntiles = (unsigned)tilemap_tiles(g.npix);
-    const uint2 *ent = reinterpret_cast<const uint2 *>(d_entries);
-    // constant rows (nodes without a pixel): every workgroup takes npw nodes, <= 64 (4 per 16-lane group);
-    // models with more nodes per pixel tile than that keep the separate fill pass
-    const unsigned npw = (unsigned)((g.nnodes + ntiles - 1) / ntiles);
-    if (npw > 64u) return fail(UPSP_ERR_INVALID, "fused pass: more than 64 nodes per pixel tile");
-    {
-        KTimed kt("fused_scan_gather_kernel", st);
-        if (hot)
-            hipLaunchKernelGGL(fused_scan_gather_kernel<true>, dim3(ntiles), dim3(256), 0, st, d_frames, g.npix,
-                               g.nframes, d_off, ent, g.skipped, g.rowmap, g.rows_t, g.rows_t16, (long long)g.ld_t,
-                               g.sum, g.sumsq, (unsigned)thresh, (unsigned)max_hot, d_count, d_pos, g.pix[0],
-                               (unsigned)g.nnodes, npw);
-        else
-            hipLaunchKernelGGL(fused_scan_gather_kernel<false>, dim3(ntiles), dim3(256), 0, st, d_frames, g.npix,
-                               g.nframes, d_off, ent, g.skipped, g.rowmap, g.rows_t, g.rows_t16, (long long)g.ld_t,
-                               g.sum, g.sumsq, 0u, 0u, d_count, d_pos, g.pix[0], (unsigned)g.nnodes, npw);
-    }
+    const unsigned ntiles = (unsigned)tilemap_tiles(npix);
+    KTimed kt("scan_compact_kernel", st);
+    if (hot)
+        hipLaunchKernelGGL(scan_compact_kernel<true>, dim3(ntiles), dim3(256), 0, st, d_frames, npix, nframes, d_flag,
+                           d_off, d_compact + col, (unsigned)kStreamFrames, (unsigned)thresh, (unsigned)max_hot,
+                           d_count, d_pos);
+    else
+        hipLaunchKernelGGL(scan_compact_kernel<false>, dim3(ntiles), dim3(256), 0, st, d_frames, npix, nframes, d_flag,
+                           d_off, d_compact + col, (unsigned)kStreamFrames, 0u, 0u, d_count, d_pos);
+    UPSP_HIP_CHECK(hipGetLastError());
+    return UPSP_OK;
+}
+
+// Pass B for the g.nframes (<= stream_frames_max()) frames parked in the compact buffer.
+int launch_node_stream(const PipelineGather &g, const int32_t *d_node_k, const uint16_t *d_compact, hipStream_t st)
+{
+    if (g.nframes <= 0 || g.nframes > kStreamFrames) return fail(UPSP_ERR_INVALID, "stream pass: too many frames");
+    KTimed kt("node_stream_kernel", st);
+    hipLaunchKernelGGL(node_stream_kernel, dim3((unsigned)((g.nnodes + 15) / 16)), dim3(256), 0, st, d_compact,
+                       (unsigned)kStreamFrames, d_node_k, g.skipped, g.rowmap, (unsigned)g.nnodes, g.nframes, g.rows_t,
+                       g.rows_t16, (long long)g.ld_t, g.sum, g.sumsq);
     UPSP_HIP_CHECK(hipGetLastError());
     return UPSP_OK;
 }
 
 // Hot-pixel fix-up of all `nframes` frames of a call (any number; g.rows_t / g.rows_t16 point at the
-// column of the first frame; d_count / d_pos hold one counter / 64 positions per frame).
+// column of the first frame; d_count / d_pos hold one counter / 64 positions per frame; d_changes:
+// 1 + 4 * cap words, word 0 = number of changes).
 int launch_hot_fixup(const PipelineGather &g, uint16_t *d_frames, int nframes, int rows, int cols,
-                     int min_change, int max_hot, const unsigned *d_off, const void *d_entries,
-                     unsigned *d_count, const unsigned *d_pos, hipStream_t st)
+                     int min_change, int max_hot, unsigned *d_count, const unsigned *d_pos,
+                     unsigned *d_changes, unsigned cap, hipStream_t st)
 {
     if (nframes <= 0) return UPSP_OK;
-    KTimed kt("hot_fixup_kernel", st);
-    hipLaunchKernelGGL(hot_fixup_kernel, dim3((unsigned)nframes), dim3(64), 0, st, d_frames, g.npix, rows, cols,
-                       min_change, max_hot, d_count, d_pos, d_off, reinterpret_cast<const uint2 *>(d_entries),
-                       g.skipped, g.rowmap, g.rows_t, g.rows_t16, (long long)g.ld_t, g.sum, g.sumsq);
+    KTimed kt("hot_fixup_kernels", st);
+    uint4 *list = reinterpret_cast<uint4 *>(d_changes + 4);
+    hipLaunchKernelGGL(hot_patch_reset_kernel, dim3(1), dim3(1), 0, st, d_changes);
+    hipLaunchKernelGGL(hot_repair_kernel, dim3((unsigned)((nframes + 63) / 64)), dim3(64), 0, st, d_frames, g.npix,
+                       nframes, rows, cols, min_change, max_hot, d_count, d_pos, d_changes, list, cap);
+    hipLaunchKernelGGL(hot_patch_kernel, dim3((unsigned)((g.nnodes + 255) / 256)), dim3(256), 0, st, g.pix[0],
+                       g.skipped, g.rowmap, (unsigned)g.nnodes, d_changes, (const uint4 *)list, cap, g.rows_t,
+                       g.rows_t16, (long long)g.ld_t, g.sum, g.sumsq);
     UPSP_HIP_CHECK(hipGetLastError());
     return UPSP_OK;
 }

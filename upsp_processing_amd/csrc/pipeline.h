@@ -36,16 +36,18 @@ int launch_hot_fix(uint16_t *d_frames, int nframes, int rows, int cols, int thre
                    int min_change, int max_hot, unsigned *d_count, unsigned *d_pos,
                    int32_t *d_status, hipStream_t st);
 int launch_gather(const PipelineGather &g, hipStream_t st);
-// fused scan + gather (one camera, no weights, u16 frames, no image stage): frames.hip
+// streamed scan + projection (one camera, no weights, u16 frames, no image stage): frames.hip
 size_t tilemap_tiles(size_t npix);
-int launch_tilemap_build(const int32_t *d_pix, const uint8_t *d_skipped, size_t nnodes, size_t npix,
-                         unsigned *d_off, unsigned *d_cursor, void *d_entries, hipStream_t st);
-int launch_fused(const PipelineGather &g, uint16_t *d_frames, bool hot, int thresh, int max_hot,
-                 const unsigned *d_off, const void *d_entries, unsigned *d_count, unsigned *d_pos,
-                 hipStream_t st);
+int launch_amap_build(const int32_t *d_pix, size_t nnodes, size_t npix, uint8_t *d_flag, unsigned *d_cnt,
+                      unsigned *d_off, int32_t *d_node_k, hipStream_t st);
+int stream_frames_max();
+int launch_scan_compact(uint16_t *d_frames, size_t npix, int nframes, bool hot, int thresh, int max_hot,
+                        const uint8_t *d_flag, const unsigned *d_off, uint16_t *d_compact, int col,
+                        unsigned *d_count, unsigned *d_pos, hipStream_t st);
+int launch_node_stream(const PipelineGather &g, const int32_t *d_node_k, const uint16_t *d_compact, hipStream_t st);
 int launch_hot_fixup(const PipelineGather &g, uint16_t *d_frames, int nframes, int rows, int cols,
-                     int min_change, int max_hot, const unsigned *d_off, const void *d_entries,
-                     unsigned *d_count, const unsigned *d_pos, hipStream_t st);
+                     int min_change, int max_hot, unsigned *d_count, const unsigned *d_pos,
+                     unsigned *d_changes, unsigned cap, hipStream_t st);
 int launch_skipped(int ncams, size_t nnodes, const int32_t *const *d_pix, uint8_t *d_skipped,
                    hipStream_t st);
 int launch_finals(const double *sum, const double *sumsq, size_t nnodes, uint64_t nframes,

@@ -33,9 +33,13 @@ struct upsp_pipeline {
     // hot-pixel scratch (per frame of a sub-batch)
     unsigned *d_hot_count = nullptr, *d_hot_pos = nullptr;
     int hot_capacity = 0;
-    // fused scan + gather: pixel tile -> nodes (built on first use after a projection change)
-    unsigned *d_tile_off = nullptr, *d_tile_cur = nullptr;
-    void *d_tile_entries = nullptr;
+    // streamed scan + projection: active-pixel map (built on first use after a projection change),
+    // compact pixel-series buffer of a sub-batch, change list of the hot-pixel fix-up
+    uint8_t *d_aflag = nullptr;
+    unsigned *d_tile_off = nullptr, *d_tile_cnt = nullptr;
+    int32_t *d_node_k = nullptr;
+    uint16_t *d_compact = nullptr;
+    unsigned *d_changes = nullptr;
     bool tilemap_valid = false;
     // the same scratch for upsp_pipeline_fix_hot_pixels (may run on another stream than process)
     unsigned *d_pre_count = nullptr, *d_pre_pos = nullptr;
@@ -174,9 +178,12 @@ void upsp_pipeline_destroy(upsp_pipeline *p)
     free_dev(p->d_hot_pos);
     free_dev(p->d_pre_count);
     free_dev(p->d_pre_pos);
+    free_dev(p->d_aflag);
     free_dev(p->d_tile_off);
-    free_dev(p->d_tile_cur);
-    free_dev(p->d_tile_entries);
+    free_dev(p->d_tile_cnt);
+    free_dev(p->d_node_k);
+    free_dev(p->d_compact);
+    free_dev(p->d_changes);
     delete p;
 }
 
@@ -250,7 +257,7 @@ int upsp_pipeline_fix_hot_pixels(upsp_pipeline *p, uint16_t *d_frames, int nfram
 int upsp_pipeline_set_skipped(upsp_pipeline *p, const uint8_t *d_skipped)
 {
     if (!p) return fail(UPSP_ERR_INVALID, "null pipeline");
-    p->tilemap_valid = false;   // the pixel-tile map carries the flag
+
     if (d_skipped) {
         UPSP_HIP_CHECK(hipMemcpy(p->d_skipped, d_skipped, p->nnodes, hipMemcpyDeviceToDevice));
         p->skipped_user = true;
@@ -278,6 +285,7 @@ int upsp_pipeline_set_overlap_source(upsp_pipeline *p, const int32_t *d_src)
 int upsp_pipeline_set_row_map(upsp_pipeline *p, const int32_t *d_rowmap)
 {
     if (!p) return fail(UPSP_ERR_INVALID, "null pipeline");
+
     if (!d_rowmap) {
         if (p->d_rowmap) (void)hipFree(p->d_rowmap);
         p->d_rowmap = nullptr;
@@ -400,17 +408,22 @@ static int process_impl(upsp_pipeline *p, const uint16_t *const *d_frames, int n
     int fused_mode = p->opts.fused_scan;
     if (fused_env) fused_mode = std::atoi(fused_env) ? 1 : 2;
     const bool fused_ok = p->ncams == 1 && !p->d_weight[0] && !need_stage && !d_rows &&
-                          (d_rows_t || d_rows_t16) && !p->d_src && (npix % 2) == 0 && B == 64 && !overlap &&
-                          p->nnodes <= 64 * tilemap_tiles(npix);   // constant rows: <= 64 nodes per workgroup
+                          (d_rows_t || d_rows_t16) && !p->d_src && (npix % 2) == 0 && B == 64 && !overlap;
     const bool fused = fused_ok && (fused_mode == 1 || (fused_mode == 0 && npix * 2 * 64 > ((size_t)160 << 20)));
     if (fused) {
+        constexpr unsigned kChangeCap = 4096;
         if (!p->tilemap_valid) {
             const size_t ntiles = tilemap_tiles(npix);
+            if (!p->d_aflag) UPSP_HIP_CHECK(hipMalloc(&p->d_aflag, npix));
             if (!p->d_tile_off) UPSP_HIP_CHECK(hipMalloc(&p->d_tile_off, sizeof(unsigned) * (ntiles + 1)));
-            if (!p->d_tile_cur) UPSP_HIP_CHECK(hipMalloc(&p->d_tile_cur, sizeof(unsigned) * ntiles));
-            if (!p->d_tile_entries) UPSP_HIP_CHECK(hipMalloc(&p->d_tile_entries, 8 * p->nnodes));
-            rc = launch_tilemap_build(p->d_pix[0], p->d_skipped, p->nnodes, npix, p->d_tile_off, p->d_tile_cur,
-                                      p->d_tile_entries, st);
+            if (!p->d_tile_cnt) UPSP_HIP_CHECK(hipMalloc(&p->d_tile_cnt, sizeof(unsigned) * ntiles));
+            if (!p->d_node_k) UPSP_HIP_CHECK(hipMalloc(&p->d_node_k, sizeof(int32_t) * p->nnodes));
+            // one series of stream_frames_max() u16 per active pixel; there are at most min(nodes, pixels) of them
+            if (!p->d_compact)
+                UPSP_HIP_CHECK(hipMalloc(&p->d_compact, (size_t)2 * stream_frames_max() * std::min(p->nnodes, npix)));
+            if (!p->d_changes) UPSP_HIP_CHECK(hipMalloc(&p->d_changes, sizeof(unsigned) * (4 + 4 * kChangeCap)));
+            rc = launch_amap_build(p->d_pix[0], p->nnodes, npix, p->d_aflag, p->d_tile_cnt, p->d_tile_off,
+                                   p->d_node_k, st);
             if (rc != UPSP_OK) return rc;
             p->tilemap_valid = true;
         }
@@ -424,23 +437,27 @@ static int process_impl(upsp_pipeline *p, const uint16_t *const *d_frames, int n
         g.sumsq = p->d_sumsq;
         g.pix[0] = p->d_pix[0];
         g.ld_t = ld_t;
-        g.rows_t = d_rows_t ? d_rows_t + col0 : nullptr;
-        g.rows_t16 = d_rows_t16 ? d_rows_t16 + col0 : nullptr;
         const bool hot = p->opts.hot_enable != 0;
-        if (rc == UPSP_OK && hot) rc = ensure_hot(p, nframes);   // one counter per frame of the CALL
+        if (hot) rc = ensure_hot(p, nframes);   // one counter per frame of the CALL
         uint16_t *fr = const_cast<uint16_t *>(d_frames[0]);
-        for (int f0 = 0; f0 < nframes && rc == UPSP_OK; f0 += B) {
-            g.nframes = std::min(B, nframes - f0);
-            g.rows_t = d_rows_t ? d_rows_t + col0 + f0 : nullptr;
-            g.rows_t16 = d_rows_t16 ? d_rows_t16 + col0 + f0 : nullptr;
-            rc = launch_fused(g, fr + (size_t)f0 * npix, hot, p->opts.hot_thresh, p->opts.hot_max, p->d_tile_off,
-                              p->d_tile_entries, p->d_hot_count + f0, p->d_hot_pos + (size_t)f0 * 64, st);
+        // pass A per 64-frame sub-batch, pass B once per group of stream_frames_max() frames
+        const int S = stream_frames_max();
+        for (int s0 = 0; s0 < nframes && rc == UPSP_OK; s0 += S) {
+            const int ns = std::min(S, nframes - s0);
+            for (int f0 = s0; f0 < s0 + ns && rc == UPSP_OK; f0 += B)
+                rc = launch_scan_compact(fr + (size_t)f0 * npix, npix, std::min(B, s0 + ns - f0), hot, p->opts.hot_thresh,
+                                         p->opts.hot_max, p->d_aflag, p->d_tile_off, p->d_compact, f0 - s0,
+                                         hot ? p->d_hot_count + f0 : nullptr, hot ? p->d_hot_pos + (size_t)f0 * 64 : nullptr, st);
+            g.nframes = ns;
+            g.rows_t = d_rows_t ? d_rows_t + col0 + s0 : nullptr;
+            g.rows_t16 = d_rows_t16 ? d_rows_t16 + col0 + s0 : nullptr;
+            if (rc == UPSP_OK) rc = launch_node_stream(g, p->d_node_k, p->d_compact, st);
         }
         if (rc == UPSP_OK && hot) {   // repair + re-projection of the few frames that hold hot pixels
             g.rows_t = d_rows_t ? d_rows_t + col0 : nullptr;
             g.rows_t16 = d_rows_t16 ? d_rows_t16 + col0 : nullptr;
             rc = launch_hot_fixup(g, fr, nframes, p->height, p->width, p->opts.hot_min_change, p->opts.hot_max,
-                                  p->d_tile_off, p->d_tile_entries, p->d_hot_count, p->d_hot_pos, st);
+                                  p->d_hot_count, p->d_hot_pos, p->d_changes, kChangeCap, st);
         }
         return rc;
     }
