@@ -515,12 +515,32 @@ __global__ void __launch_bounds__(256)
     if (es.done) return;
     __shared__ double Ssh[kEccSums];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int k = wave; k < kEccSums; k += 4) {
-        double v = 0.0;
-        const double *pk = partial + ((size_t)f * kEccSums + k) * kEccBlocksMax;
-        for (int b = lane; b < nblocks; b += 64) v += pk[b];
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-        if (lane == 0) Ssh[k] = v;
+    // every load of the wave's <= 12 sums is issued before the first reduction (one sum after the
+    // other made this a chain of 12 global-load latencies: 33 us per launch, 15 % of the ECC path)
+    constexpr int kPerWave = (kEccSums + 3) / 4;
+    double v[kPerWave];
+#pragma unroll
+    for (int i = 0; i < kPerWave; ++i) {
+        const int k = wave + 4 * i;
+        // first block of 64 partials: one independent load per sum
+        v[i] = (k < kEccSums && lane < nblocks) ? partial[((size_t)f * kEccSums + k) * kEccBlocksMax + lane] : 0.0;
+    }
+    if (nblocks > 64) {   // few active frames -> more, smaller blocks per frame (same order per lane as one loop)
+#pragma unroll
+        for (int i = 0; i < kPerWave; ++i) {
+            const int k = wave + 4 * i;
+            if (k < kEccSums) {
+                const double *pk = partial + ((size_t)f * kEccSums + k) * kEccBlocksMax;
+                for (int b = lane + 64; b < nblocks; b += 64) v[i] += pk[b];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < kPerWave; ++i) {
+        double x = v[i];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);   // fixed tree -> deterministic
+        const int k = wave + 4 * i;
+        if (lane == 0 && k < kEccSums) Ssh[k] = x;
     }
     __syncthreads();
     if (threadIdx.x != 0) return;
