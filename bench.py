@@ -341,7 +341,7 @@ def main():
     # WRITE_SIZE collected separately; FETCH_SIZE doubled per the gfx950 correction of
     # MI355X_MICROARCH.md "HBM"; counter unit = KB) -- per launch, same launch shape
     traffic = None
-    prof = os.path.join(ROOT, "profiles", "r01_bench_summary.json")
+    prof = os.path.join(ROOT, "profiles", "r01_streamed_summary.json" if a.streamed else "r01_bench_summary.json")
     pkey = {"gather_tile_kernel": "gather_tile16_kernel<4, true, false>", "hot_scan_kernel": "hot_scan_kernel",
             "scan_compact_kernel": "scan_compact_kernel<true>", "node_stream_kernel": "node_stream_kernel",
             "projection_kernel<primary>": "projection_kernel<false, 0>",

@@ -1822,7 +1822,8 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
         }
     }
     const dim3 egrid((unsigned)((nnodes + 255) / 256)), eblock(256);
-    if (nnodes >= 65536) prefetch_bvh(b, st);
+    static const bool prefetch_on = std::getenv("UPSP_NO_PREFETCH") == nullptr;
+    if (prefetch_on && nnodes >= 65536) prefetch_bvh(b, st);
     {
         KTimed kt("project_nodes_kernel", st);
         hipLaunchKernelGGL(project_nodes_kernel, egrid, eblock, 0, st, c, d_nodes, d_datanode,
