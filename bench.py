@@ -51,10 +51,9 @@ def parse():
     ap.add_argument("--overlap", action="store_true",
                     help="hot-pixel scan of all frames on a side stream, concurrent with the projection "
                          "build (measured slower on MI355X: the gathers then miss the Infinity Cache)")
-    ap.add_argument("--streamed", action="store_true",
-                    help="frame loop as the streamed two-pass schedule (scan + compact pixel series, then one pass "
-                         "over the nodes) instead of scan kernel + gather kernel; the library picks it by itself "
-                         "for sub-batches that do not fit the Infinity Cache (level at 1 Mpix)")
+    ap.add_argument("--two-kernel", action="store_true",
+                    help="frame loop as scan kernel + gather kernel instead of the (default) streamed two-pass "
+                         "schedule (scan + compact pixel series, then one pass over the nodes)")
     ap.add_argument("--model", default="quad", choices=["quad", "uv"],
                     help="quad: cube-sphere tunnel model (valence <= 6); uv: UV-sphere model with "
                          "1000-valent polar fans (worst case for per-ray traversal length)")
@@ -163,7 +162,7 @@ def main():
         syn.synth_frames_torch(min(chunk, F - f0), size, size, first=rank * F + f0, out=frames[f0:f0 + chunk])
     shard = D.Shard(F * world, N, rank, world)
     pipe = engine.FramePipeline(1, size, size, N, registration=int(a.registration),
-                                fused_scan=1 if a.streamed else 0)
+                                fused_scan=2 if a.two_kernel else 0)
     if a.registration:
         pipe.set_reference(0, frames[0].to(torch.float32))   # raw first frame as ECC template
     # node-major time series [N, F] with the padded row pitch engine.series_ld() recommends
@@ -341,7 +340,7 @@ def main():
     # WRITE_SIZE collected separately; FETCH_SIZE doubled per the gfx950 correction of
     # MI355X_MICROARCH.md "HBM"; counter unit = KB) -- per launch, same launch shape
     traffic = None
-    prof = os.path.join(ROOT, "profiles", "r01_streamed_summary.json" if a.streamed else "r01_bench_summary.json")
+    prof = os.path.join(ROOT, "profiles", "r01_bench_summary.json")
     pkey = {"gather_tile_kernel": "gather_tile16_kernel<4, true, false>", "hot_scan_kernel": "hot_scan_kernel",
             "scan_compact_kernel": "scan_compact_kernel<true>", "node_stream_kernel": "node_stream_kernel",
             "projection_kernel<primary>": "projection_kernel<false, 0>",
@@ -368,8 +367,9 @@ def main():
                    "frames_per_gpu": F, "nodes": N, "triangles": int(tris.shape[0]),
                    "parallelism": "frames sharded x%d" % world,
                    "schedule": ("hot-pixel scan of all frames on a side stream, concurrent with the projection build"
-                                if overlap else "projection build, then scan + compact / node stream per 64-frame sub-batch"
-                                if a.streamed else "projection build, then scan + gather per 64-frame sub-batch"),
+                                if overlap else "projection build, then scan + gather kernels per 64-frame sub-batch"
+                                if (a.two_kernel or a.registration) else
+                                "projection build, then scan + compact / node stream passes per 64-frame sub-batch"),
                    **({"exchange": "%d chunks, %s rows as %s" % (K, "visible" if mode["packed"] else "all",
                                                                  "u16" if series_esz == 2 else "f32")}
                       if chunked else {})},

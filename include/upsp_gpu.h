@@ -193,8 +193,8 @@ typedef struct upsp_pipeline_opts {
     /* polynomial target patcher on/off (TargetPatchType) */
     int32_t patch;
     /* frame-loop schedule of the plain path (one camera, no weights, no image stage, node-major series):
-     * 0 = choose (fused scan + projection pass when a 64-frame sub-batch does not fit the 256 MiB Infinity
-     * Cache, else scan kernel + gather kernel), 1 = always the fused pass, 2 = never.  Same results. */
+     * 0 / 1 = streamed two-pass schedule (scan + compact pixel series, then one pass over the nodes),
+     * 2 = scan kernel + gather kernel (relies on the sub-batch staying in the Infinity Cache).  Same results. */
     int32_t fused_scan;
     int32_t reserved[4];
 } upsp_pipeline_opts;

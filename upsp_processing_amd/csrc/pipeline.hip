@@ -398,18 +398,19 @@ static int process_impl(upsp_pipeline *p, const uint16_t *const *d_frames, int n
         UPSP_HIP_CHECK(hipEventRecord(p->ev_in, st));
         UPSP_HIP_CHECK(hipStreamWaitEvent(p->aux, p->ev_in, 0));
     }
-    // Fused scan + projection pass (frames.hip: fused_scan_gather_kernel): one camera, no weights, u16
-    // frames straight from the caller, node-major series only.  Measured on MI355X: at 1 Mpix, where
-    // the 64-frame sub-batch (128 MiB) stays in the Infinity Cache between the scan and the gather,
-    // the two kernels (25 + 39 us per sub-batch) and the fused pass (65 us) are level, and the fused
-    // pass needs the pixel-tile map once per projection; at 4 Mpix (512 MiB per sub-batch) the gather
-    // reads from HBM and the fused pass is 1.6x faster (134 vs 221 us).  Hence the default below.
+    // Streamed two-pass schedule (frames.hip: scan_compact_kernel + node_stream_kernel) for the plain
+    // path: one camera, no weights, u16 frames straight from the caller, node-major series only.
+    // Measured on MI355X per 64-frame sub-batch of 1-Mpix frames: 25.8 + 32.4 us against 25.4 + 38.7 us
+    // for scan kernel + gather kernel (f32 rows of all nodes), 25.5 + 21.6 against 25.4 + 32.2 us with
+    // packed u16 rows (multi-GPU exchange); 4-Mpix frames (sub-batch larger than the Infinity Cache):
+    // 1.3x.  It needs the active-pixel map once per projection (25 us).  Default when eligible.
     static const char *fused_env = std::getenv("UPSP_FUSED");   // "1" / "0" override the option
     int fused_mode = p->opts.fused_scan;
     if (fused_env) fused_mode = std::atoi(fused_env) ? 1 : 2;
     const bool fused_ok = p->ncams == 1 && !p->d_weight[0] && !need_stage && !d_rows &&
-                          (d_rows_t || d_rows_t16) && !p->d_src && (npix % 2) == 0 && B == 64 && !overlap;
-    const bool fused = fused_ok && (fused_mode == 1 || (fused_mode == 0 && npix * 2 * 64 > ((size_t)160 << 20)));
+                          (d_rows_t || d_rows_t16) && !p->d_src && (npix % 2) == 0 && B == 64 && !overlap &&
+                          p->nnodes < ((size_t)1 << 31);
+    const bool fused = fused_ok && fused_mode != 2;
     if (fused) {
         constexpr unsigned kChangeCap = 4096;
         if (!p->tilemap_valid) {
