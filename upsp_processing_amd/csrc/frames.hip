@@ -755,10 +755,10 @@ __global__ void __launch_bounds__(256)
 
 // Pass B.  16 lanes per node; the node's series over the (<= kStreamFrames) frames that pass A has
 // parked in the compact buffer goes out as one contiguous piece of its row: lane l handles frames
-// 64 c + 4 l .. + 3 of every 64-frame chunk c.  Measured: 256-byte pieces (one 64-frame sub-batch per
-// pass) 32.9 us per 64 frames = 3.9 TB/s of row writes; 1-KB pieces (four sub-batches per pass) 34.6 us --
-// the strided row pieces are what HBM charges for, not their number, so the sub-batch stays at 64.
-constexpr int kStreamFrames = 64;
+// 64 c + 4 l .. + 3 of every 64-frame chunk c.  Four sub-batches per pass (1-KB row pieces, a quarter
+// of the per-node bookkeeping): 28.7 us per 64 frames of f32 rows against 32.4 with one sub-batch per
+// pass (256-byte pieces), 11.9 against 21.6 us for packed u16 rows.
+constexpr int kStreamFrames = 256;
 constexpr int kNodesPerGroup = 4;     // a wave (4 groups of 16 lanes) takes 16 consecutive nodes
 __global__ void __launch_bounds__(256)
     node_stream_kernel(const uint16_t *__restrict__ compact, unsigned cpitch, const int32_t *__restrict__ node_k,
@@ -795,24 +795,32 @@ __global__ void __launch_bounds__(256)
         sk[i] = __shfl(m_sk, j) != 0;
         row[i] = __shfl(m_row, j);
     }
-    uint2 w[kNodesPerGroup];
+    constexpr int kChunks = kStreamFrames / 64;     // 64-frame sub-batches parked in the compact buffer
+    uint2 w[kNodesPerGroup][kChunks];
 #pragma unroll
     for (int i = 0; i < kNodesPerGroup; ++i)
-        // (ordinary loads: the compact buffer was written a moment ago and sits in L2 / Infinity Cache;
-        // streaming loads here cost 20 us per launch)
-        w[i] = k[i] >= 0 ? *reinterpret_cast<const uint2 *>(compact + (size_t)k[i] * cpitch + c4) : make_uint2(0u, 0u);
+#pragma unroll
+        for (int c = 0; c < kChunks; ++c)
+            // (ordinary loads: the compact buffer was written a moment ago and sits in L2 / Infinity Cache;
+            // streaming loads here cost 20 us per launch)
+            w[i][c] = (k[i] >= 0 && 64 * c < nframes)
+                          ? *reinterpret_cast<const uint2 *>(compact + (size_t)k[i] * cpitch + 64 * c + c4)
+                          : make_uint2(0u, 0u);
     double add_s = 0.0, add_ss = 0.0;     // lanes 0..15: what their node's accumulators gain
 #pragma unroll
     for (int i = 0; i < kNodesPerGroup; ++i) {
-        const unsigned d[4] = {w[i].x & 0xFFFFu, w[i].x >> 16, w[i].y & 0xFFFFu, w[i].y >> 16};
         double s = 0.0, ss = 0.0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (c4 + q < nframes) {
-                const float x = (float)d[q];
-                s += (double)x;
-                ss += (double)(x * x);
-            }
+        for (int c = 0; c < kChunks; ++c) {
+            const unsigned d[4] = {w[i][c].x & 0xFFFFu, w[i][c].x >> 16, w[i][c].y & 0xFFFFu, w[i][c].y >> 16};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (64 * c + c4 + q < nframes) {
+                    const float x = (float)d[q];
+                    s += (double)x;
+                    ss += (double)(x * x);
+                }
+        }
         s = group16_sum(s);               // every lane of the group holds the node's total
         ss = group16_sum(ss);
         // node j = 4 i + g belongs to lane j of the wave: it reads the total from lane 16 g (any lane of group g)
@@ -823,32 +831,38 @@ __global__ void __launch_bounds__(256)
             add_ss = tss;
         }
         const unsigned n = wbase + (unsigned)(4 * i + grp);
-        if (n >= nnodes || row[i] < 0 || c4 >= nframes) continue;
-        if (rows_t) {
-            float *dst = rows_t + (long long)row[i] * ld_t + c4;
-            typedef float v4f __attribute__((ext_vector_type(4)));
-            // a node without a pixel: 0 (empty row of the projection matrix); no camera sees it: NaN
-            const v4f nv = {sk[i] ? qnan : (float)d[0], sk[i] ? qnan : (float)d[1], sk[i] ? qnan : (float)d[2],
-                            sk[i] ? qnan : (float)d[3]};
-            if (vec_ok && c4 + 3 < nframes) {
-                __builtin_nontemporal_store(nv, reinterpret_cast<v4f *>(dst));
-            } else {
-                dst[0] = nv.x;
-                if (c4 + 1 < nframes) dst[1] = nv.y;
-                if (c4 + 2 < nframes) dst[2] = nv.z;
-                if (c4 + 3 < nframes) dst[3] = nv.w;
-            }
-        } else {   // u16 series (exchange wire format): NaN rows are stored as 0
-            uint16_t *dst = rows_t16 + (long long)row[i] * ld_t + c4;
-            typedef unsigned v2u __attribute__((ext_vector_type(2)));
-            const v2u nv = {sk[i] ? 0u : (d[0] | (d[1] << 16)), sk[i] ? 0u : (d[2] | (d[3] << 16))};
-            if (vec_ok && c4 + 3 < nframes) {
-                __builtin_nontemporal_store(nv, reinterpret_cast<v2u *>(dst));
-            } else {
-                dst[0] = (uint16_t)(nv.x & 0xFFFFu);
-                if (c4 + 1 < nframes) dst[1] = (uint16_t)(nv.x >> 16);
-                if (c4 + 2 < nframes) dst[2] = (uint16_t)(nv.y & 0xFFFFu);
-                if (c4 + 3 < nframes) dst[3] = (uint16_t)(nv.y >> 16);
+        if (n >= nnodes || row[i] < 0) continue;
+#pragma unroll
+        for (int c = 0; c < kChunks; ++c) {
+            const int f0 = 64 * c + c4;
+            if (f0 >= nframes) continue;
+            const unsigned d[4] = {w[i][c].x & 0xFFFFu, w[i][c].x >> 16, w[i][c].y & 0xFFFFu, w[i][c].y >> 16};
+            if (rows_t) {
+                float *dst = rows_t + (long long)row[i] * ld_t + f0;
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                // a node without a pixel: 0 (empty row of the projection matrix); no camera sees it: NaN
+                const v4f nv = {sk[i] ? qnan : (float)d[0], sk[i] ? qnan : (float)d[1], sk[i] ? qnan : (float)d[2],
+                                sk[i] ? qnan : (float)d[3]};
+                if (vec_ok && f0 + 3 < nframes) {
+                    __builtin_nontemporal_store(nv, reinterpret_cast<v4f *>(dst));
+                } else {
+                    dst[0] = nv.x;
+                    if (f0 + 1 < nframes) dst[1] = nv.y;
+                    if (f0 + 2 < nframes) dst[2] = nv.z;
+                    if (f0 + 3 < nframes) dst[3] = nv.w;
+                }
+            } else {   // u16 series (exchange wire format): NaN rows are stored as 0
+                uint16_t *dst = rows_t16 + (long long)row[i] * ld_t + f0;
+                typedef unsigned v2u __attribute__((ext_vector_type(2)));
+                const v2u nv = {sk[i] ? 0u : (d[0] | (d[1] << 16)), sk[i] ? 0u : (d[2] | (d[3] << 16))};
+                if (vec_ok && f0 + 3 < nframes) {
+                    __builtin_nontemporal_store(nv, reinterpret_cast<v2u *>(dst));
+                } else {
+                    dst[0] = (uint16_t)(nv.x & 0xFFFFu);
+                    if (f0 + 1 < nframes) dst[1] = (uint16_t)(nv.x >> 16);
+                    if (f0 + 2 < nframes) dst[2] = (uint16_t)(nv.y & 0xFFFFu);
+                    if (f0 + 3 < nframes) dst[3] = (uint16_t)(nv.y >> 16);
+                }
             }
         }
     }
