@@ -304,6 +304,7 @@ def main():
     n_retry_rays = 6 * retry_nodes_last[0]
     scene_bytes = bvh.info["device_bytes"]
     gather_launches = -(-F // 64) if not chunked else sum(-(-exch.my_chunk(k)[1] // 64) for k in range(K))
+    stream_launches = -(-F // 256) if not chunked else sum(-(-exch.my_chunk(k)[1] // 256) for k in range(K))
     series_rows = exch.packed_rows() if (chunked and mode["packed"]) else N
     series_esz = 2 if (chunked and mode["packed"] and mode["u16"]) else 4
     per_step_bytes = {
@@ -323,7 +324,8 @@ def main():
         "hot_scan_kernel": F * 2 * size * size,
         # --streamed: pass A reads the frames (its compact buffer stays in cache), pass B writes the series
         "scan_compact_kernel": F * 2 * size * size,
-        "node_stream_kernel": F * series_esz * series_rows + gather_launches * 8 * N,
+        # (one pass B per 256 frames: index 4 B + flags + accumulators per node and launch)
+        "node_stream_kernel": F * series_esz * series_rows + stream_launches * 8 * N,
     }
     for name, (calls, total_ms) in timing.items():
         ms_step_k = total_ms / a.steps
