@@ -379,3 +379,42 @@ def test_fused_pass_hot_pixels_vs_oracle(gpu_lib, oracle, F):
     assert np.array_equal(buf[:, :F].cpu().numpy().astype(np.float32), rows_o.T[keep])
     s2 = pipe.accumulators()[0].cpu().numpy()
     assert np.isnan(s2[5]) and np.isnan(s2[100]) and np.array_equal(s2[keep], s_o[keep])
+
+
+@pytest.mark.parametrize("F", [41, 300])
+def test_multi_camera_streamed_schedule(gpu_lib, oracle, F):
+    """Three cameras with weights, node-major series only: the streamed schedule (fused_scan=1: one
+    compact buffer per camera, pass B sums the cameras in order) against scan + gather (fused_scan=2)
+    -- rows bit-identical, accumulators to 1e-12 (summation order) -- and against the oracle loop."""
+    import torch
+    from upsp_processing_amd import engine, synthetic as syn
+    H, W, n, ncams = 96, 128, 3000, 3
+    rng = np.random.default_rng(7 + F)
+    frames = [syn.synth_frames_numpy(F, H, W, seed=50 + c, hot=True) for c in range(ncams)]
+    pix = rng.integers(-1, H * W, size=(ncams, n)).astype(np.int32)
+    pix[:, ::17] = -1                                        # skipped in every camera
+    pix[1, ::5] = -1
+    weight = rng.random((ncams, n)).astype(np.float32)
+    rows_o, s_o, ss_o = run_loop_oracle(oracle, frames, pix, weight)
+    res = {}
+    for mode in (1, 2):
+        pipe = engine.FramePipeline(ncams, W, H, n, fused_scan=mode)
+        for c in range(ncams):
+            pipe.set_projection(c, pix[c], weight[c])
+        d_frames = [torch.as_tensor(f.copy()).cuda() for f in frames]
+        rt = torch.full((n, engine.series_ld(F)), -5.0, dtype=torch.float32, device="cuda")
+        half = 17
+        pipe.process([f[:half].contiguous() for f in d_frames], 0, rows_t=rt[:, :F], want_rows=False)
+        pipe.process([f[half:].contiguous() for f in d_frames], half, rows_t=rt[:, :F], col0=half, want_rows=False)
+        s, ss = [a.cpu().numpy() for a in pipe.accumulators()]
+        res[mode] = (rt.cpu().numpy(), s, ss, [f.cpu().numpy() for f in d_frames])
+    r1, r2 = res[1], res[2]
+    assert np.array_equal(r1[0].view(np.int32), r2[0].view(np.int32))
+    assert np.array_equal(r1[0][:, :F].view(np.int32), rows_o.T.view(np.int32))
+    assert (r1[0][:, F:] == -5.0).all()
+    for c in range(ncams):
+        assert np.array_equal(r1[3][c], r2[3][c])            # frames repaired the same way
+    ok = ~np.isnan(s_o)
+    assert np.array_equal(np.isnan(r1[1]), np.isnan(s_o))
+    assert np.allclose(r1[1][ok], s_o[ok], rtol=1e-12) and np.allclose(r1[2][ok], ss_o[ok], rtol=1e-12)
+    assert np.allclose(r1[1][ok], r2[1][ok], rtol=1e-12) and np.allclose(r1[2][ok], r2[2][ok], rtol=1e-12)

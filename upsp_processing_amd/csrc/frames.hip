@@ -877,6 +877,84 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+// Pass B for several cameras (and weights): sol = sum over the cameras, in camera order, of
+// w_c * f32(pixel_c) exactly as gather_tile_kernel forms it (psp_process.cpp:1813-1819), from one
+// compact buffer per camera.  One node per 16-lane group; f32 rows only.  The accumulators add the
+// frames of a lane first and the lanes of the group after (DPP), a different order from the gather's:
+// same values to ~1e-16 relative (the parity bar for the accumulators is 1e-12).
+struct StreamMultiArgs {
+    int ncams;
+    const uint16_t *compact[kMaxCams];
+    const int32_t *node_k[kMaxCams];
+    const float *weight[kMaxCams];
+};
+__global__ void __launch_bounds__(256)
+    node_stream_multi_kernel(StreamMultiArgs a, unsigned cpitch, const uint8_t *__restrict__ skipped,
+                             const int32_t *__restrict__ rowmap, unsigned nnodes, int nframes,
+                             float *__restrict__ rows_t, long long ld_t, double *__restrict__ sum,
+                             double *__restrict__ sumsq)
+{
+    constexpr int kChunks = kStreamFrames / 64;
+    const unsigned n = blockIdx.x * 16u + (threadIdx.x >> 4);
+    const int gl = threadIdx.x & 15, c4 = 4 * gl;
+    if (n >= nnodes) return;
+    const bool sk = skipped && skipped[n];
+    const long long row = rowmap ? (long long)rowmap[n] : (long long)n;
+    const float qnan = __builtin_nanf("");
+    float acc[kChunks][4];
+    for (int c = 0; c < a.ncams; ++c) {
+        const int k = a.node_k[c][n];
+        const float w = a.weight[c] ? a.weight[c][n] : 1.0f;
+#pragma unroll
+        for (int ch = 0; ch < kChunks; ++ch) {
+            float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (k >= 0 && 64 * ch < nframes) {
+                const uint2 t = *reinterpret_cast<const uint2 *>(a.compact[c] + (size_t)k * cpitch + 64 * ch + c4);
+                v[0] = 0.0f + w * (float)(t.x & 0xFFFFu);
+                v[1] = 0.0f + w * (float)(t.x >> 16);
+                v[2] = 0.0f + w * (float)(t.y & 0xFFFFu);
+                v[3] = 0.0f + w * (float)(t.y >> 16);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[ch][q] = (c == 0) ? v[q] : acc[ch][q] + v[q];
+        }
+    }
+    double s = 0.0, ss = 0.0;
+#pragma unroll
+    for (int ch = 0; ch < kChunks; ++ch)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (64 * ch + c4 + q < nframes) {
+                const float sol = sk ? qnan : acc[ch][q];
+                s += (double)sol;
+                ss += (double)(sol * sol);
+            }
+    s = group16_sum(s);
+    ss = group16_sum(ss);
+    if (gl == 0) {
+        sum[n] += s;
+        sumsq[n] += ss;
+    }
+    if (row < 0) return;
+    const bool vec_ok = ((ld_t & 3) == 0) && ((reinterpret_cast<size_t>(rows_t) & 15) == 0);
+#pragma unroll
+    for (int ch = 0; ch < kChunks; ++ch) {
+        const int f0 = 64 * ch + c4;
+        if (f0 >= nframes) continue;
+        float *dst = rows_t + row * ld_t + f0;
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f nv = {sk ? qnan : acc[ch][0], sk ? qnan : acc[ch][1], sk ? qnan : acc[ch][2], sk ? qnan : acc[ch][3]};
+        if (vec_ok && f0 + 3 < nframes) {
+            __builtin_nontemporal_store(nv, reinterpret_cast<v4f *>(dst));
+        } else {
+            dst[0] = nv.x;
+            if (f0 + 1 < nframes) dst[1] = nv.y;
+            if (f0 + 2 < nframes) dst[2] = nv.z;
+            if (f0 + 3 < nframes) dst[3] = nv.w;
+        }
+    }
+}
+
 // Frames with 1..max_hot hot pixels: repair in place (same code as the scan kernel's pass 2) and
 // list the replaced pixels as (frame, position, old, new) for hot_patch_kernel.  One lane per frame.
 __global__ void __launch_bounds__(64)
@@ -1204,6 +1282,28 @@ int launch_node_stream(const PipelineGather &g, const int32_t *d_node_k, const u
     hipLaunchKernelGGL(node_stream_kernel, dim3((unsigned)((g.nnodes + 63) / 64)), dim3(256), 0, st, d_compact,
                        (unsigned)kStreamFrames, d_node_k, g.skipped, g.rowmap, (unsigned)g.nnodes, g.nframes, g.rows_t,
                        g.rows_t16, (long long)g.ld_t, g.sum, g.sumsq);
+    UPSP_HIP_CHECK(hipGetLastError());
+    return UPSP_OK;
+}
+
+// Pass B for g.ncams cameras: node_k[c] / compact[c] per camera, weights from g.weight.
+int launch_node_stream_multi(const PipelineGather &g, const int32_t *const *d_node_k,
+                             const uint16_t *const *d_compact, hipStream_t st)
+{
+    if (g.nframes <= 0 || g.nframes > kStreamFrames) return fail(UPSP_ERR_INVALID, "stream pass: too many frames");
+    if (g.ncams < 1 || g.ncams > kMaxCams || !g.rows_t) return fail(UPSP_ERR_INVALID, "stream pass: bad camera count / no f32 rows");
+    StreamMultiArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.ncams = g.ncams;
+    for (int c = 0; c < g.ncams; ++c) {
+        a.compact[c] = d_compact[c];
+        a.node_k[c] = d_node_k[c];
+        a.weight[c] = g.weight[c];
+    }
+    KTimed kt("node_stream_multi_kernel", st);
+    hipLaunchKernelGGL(node_stream_multi_kernel, dim3((unsigned)((g.nnodes + 15) / 16)), dim3(256), 0, st, a,
+                       (unsigned)kStreamFrames, g.skipped, g.rowmap, (unsigned)g.nnodes, g.nframes, g.rows_t,
+                       (long long)g.ld_t, g.sum, g.sumsq);
     UPSP_HIP_CHECK(hipGetLastError());
     return UPSP_OK;
 }

@@ -45,6 +45,8 @@ int launch_scan_compact(uint16_t *d_frames, size_t npix, int nframes, bool hot, 
                         const uint8_t *d_flag, const unsigned *d_off, uint16_t *d_compact, int col,
                         unsigned *d_count, unsigned *d_pos, hipStream_t st);
 int launch_node_stream(const PipelineGather &g, const int32_t *d_node_k, const uint16_t *d_compact, hipStream_t st);
+int launch_node_stream_multi(const PipelineGather &g, const int32_t *const *d_node_k,
+                             const uint16_t *const *d_compact, hipStream_t st);
 int launch_hot_fixup(const PipelineGather &g, uint16_t *d_frames, int nframes, int rows, int cols,
                      int min_change, int max_hot, unsigned *d_count, const unsigned *d_pos,
                      unsigned *d_changes, unsigned cap, hipStream_t st);
