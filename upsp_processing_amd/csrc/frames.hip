@@ -894,64 +894,85 @@ __global__ void __launch_bounds__(256)
                              float *__restrict__ rows_t, long long ld_t, double *__restrict__ sum,
                              double *__restrict__ sumsq)
 {
+    // like node_stream_kernel: a wave takes 16 consecutive nodes, lanes 0..15 fetch their scalars
+    // (per camera: compact index and weight) coalesced and hand them to the 16-lane groups by shuffles
     constexpr int kChunks = kStreamFrames / 64;
-    const unsigned n = blockIdx.x * 16u + (threadIdx.x >> 4);
-    const int gl = threadIdx.x & 15, c4 = 4 * gl;
-    if (n >= nnodes) return;
-    const bool sk = skipped && skipped[n];
-    const long long row = rowmap ? (long long)rowmap[n] : (long long)n;
+    const int lane = threadIdx.x & 63, grp = lane >> 4, gl = lane & 15, c4 = 4 * gl;
+    const unsigned wbase = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 16u;
+    if (wbase >= nnodes) return;                                              // (uniform per wave)
     const float qnan = __builtin_nanf("");
-    float acc[kChunks][4];
-    for (int c = 0; c < a.ncams; ++c) {
-        const int k = a.node_k[c][n];
-        const float w = a.weight[c] ? a.weight[c][n] : 1.0f;
+    const bool vec_ok = ((ld_t & 3) == 0) && ((reinterpret_cast<size_t>(rows_t) & 15) == 0);
+    const unsigned mn = wbase + (unsigned)gl;
+    const bool mok = lane < 16 && mn < nnodes;
+    const int m_sk = (mok && skipped) ? (int)skipped[mn] : 0;
+    const int m_row = mok ? (rowmap ? rowmap[mn] : (int)mn) : -1;
+    const double m_s = mok ? sum[mn] : 0.0, m_ss = mok ? sumsq[mn] : 0.0;
+    double add_s = 0.0, add_ss = 0.0;
+#pragma unroll 1
+    for (int i = 0; i < 4; ++i) {                 // group g, round i -> node j = 4 i + g of the wave
+        const int j = 4 * i + grp;
+        const bool sk = __shfl(m_sk, j) != 0;
+        const int row = __shfl(m_row, j);
+        float acc[kChunks][4];
+        for (int c = 0; c < a.ncams; ++c) {
+            const int mk = mok ? a.node_k[c][mn] : -1;                       // lanes 0..15, coalesced
+            const float mw = (mok && a.weight[c]) ? a.weight[c][mn] : 1.0f;  // (re-read per round: L1 hits)
+            const int k = __shfl(mk, j);
+            const float w = __shfl(mw, j);
+#pragma unroll
+            for (int ch = 0; ch < kChunks; ++ch) {
+                float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (k >= 0 && 64 * ch < nframes) {
+                    const uint2 t = *reinterpret_cast<const uint2 *>(a.compact[c] + (size_t)k * cpitch + 64 * ch + c4);
+                    v[0] = 0.0f + w * (float)(t.x & 0xFFFFu);
+                    v[1] = 0.0f + w * (float)(t.x >> 16);
+                    v[2] = 0.0f + w * (float)(t.y & 0xFFFFu);
+                    v[3] = 0.0f + w * (float)(t.y >> 16);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[ch][q] = (c == 0) ? v[q] : acc[ch][q] + v[q];
+            }
+        }
+        double s = 0.0, ss = 0.0;
+#pragma unroll
+        for (int ch = 0; ch < kChunks; ++ch)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (64 * ch + c4 + q < nframes) {
+                    const float sol = sk ? qnan : acc[ch][q];
+                    s += (double)sol;
+                    ss += (double)(sol * sol);
+                }
+        s = group16_sum(s);
+        ss = group16_sum(ss);
+        const int src = 16 * (gl & 3);
+        const double ts = __shfl(s, src), tss = __shfl(ss, src);
+        if (lane < 16 && (gl >> 2) == i) {
+            add_s = ts;
+            add_ss = tss;
+        }
+        const unsigned n = wbase + (unsigned)j;
+        if (n >= nnodes || row < 0) continue;
 #pragma unroll
         for (int ch = 0; ch < kChunks; ++ch) {
-            float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (k >= 0 && 64 * ch < nframes) {
-                const uint2 t = *reinterpret_cast<const uint2 *>(a.compact[c] + (size_t)k * cpitch + 64 * ch + c4);
-                v[0] = 0.0f + w * (float)(t.x & 0xFFFFu);
-                v[1] = 0.0f + w * (float)(t.x >> 16);
-                v[2] = 0.0f + w * (float)(t.y & 0xFFFFu);
-                v[3] = 0.0f + w * (float)(t.y >> 16);
+            const int f0 = 64 * ch + c4;
+            if (f0 >= nframes) continue;
+            float *dst = rows_t + (long long)row * ld_t + f0;
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            const v4f nv = {sk ? qnan : acc[ch][0], sk ? qnan : acc[ch][1], sk ? qnan : acc[ch][2], sk ? qnan : acc[ch][3]};
+            if (vec_ok && f0 + 3 < nframes) {
+                __builtin_nontemporal_store(nv, reinterpret_cast<v4f *>(dst));
+            } else {
+                dst[0] = nv.x;
+                if (f0 + 1 < nframes) dst[1] = nv.y;
+                if (f0 + 2 < nframes) dst[2] = nv.z;
+                if (f0 + 3 < nframes) dst[3] = nv.w;
             }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[ch][q] = (c == 0) ? v[q] : acc[ch][q] + v[q];
         }
     }
-    double s = 0.0, ss = 0.0;
-#pragma unroll
-    for (int ch = 0; ch < kChunks; ++ch)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (64 * ch + c4 + q < nframes) {
-                const float sol = sk ? qnan : acc[ch][q];
-                s += (double)sol;
-                ss += (double)(sol * sol);
-            }
-    s = group16_sum(s);
-    ss = group16_sum(ss);
-    if (gl == 0) {
-        sum[n] += s;
-        sumsq[n] += ss;
-    }
-    if (row < 0) return;
-    const bool vec_ok = ((ld_t & 3) == 0) && ((reinterpret_cast<size_t>(rows_t) & 15) == 0);
-#pragma unroll
-    for (int ch = 0; ch < kChunks; ++ch) {
-        const int f0 = 64 * ch + c4;
-        if (f0 >= nframes) continue;
-        float *dst = rows_t + row * ld_t + f0;
-        typedef float v4f __attribute__((ext_vector_type(4)));
-        const v4f nv = {sk ? qnan : acc[ch][0], sk ? qnan : acc[ch][1], sk ? qnan : acc[ch][2], sk ? qnan : acc[ch][3]};
-        if (vec_ok && f0 + 3 < nframes) {
-            __builtin_nontemporal_store(nv, reinterpret_cast<v4f *>(dst));
-        } else {
-            dst[0] = nv.x;
-            if (f0 + 1 < nframes) dst[1] = nv.y;
-            if (f0 + 2 < nframes) dst[2] = nv.z;
-            if (f0 + 3 < nframes) dst[3] = nv.w;
-        }
+    if (mok) {
+        sum[mn] = m_s + add_s;
+        sumsq[mn] = m_ss + add_ss;
     }
 }
 
@@ -1301,7 +1322,7 @@ int launch_node_stream_multi(const PipelineGather &g, const int32_t *const *d_no
         a.weight[c] = g.weight[c];
     }
     KTimed kt("node_stream_multi_kernel", st);
-    hipLaunchKernelGGL(node_stream_multi_kernel, dim3((unsigned)((g.nnodes + 15) / 16)), dim3(256), 0, st, a,
+    hipLaunchKernelGGL(node_stream_multi_kernel, dim3((unsigned)((g.nnodes + 63) / 64)), dim3(256), 0, st, a,
                        (unsigned)kStreamFrames, g.skipped, g.rowmap, (unsigned)g.nnodes, g.nframes, g.rows_t,
                        (long long)g.ld_t, g.sum, g.sumsq);
     UPSP_HIP_CHECK(hipGetLastError());

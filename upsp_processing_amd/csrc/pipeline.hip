@@ -480,9 +480,8 @@ static int process_impl(upsp_pipeline *p, const uint16_t *const *d_frames, int n
     // buffer per camera; the hot-pixel scan + repair stays the stand-alone kernel (a replaced pixel would
     // have to be re-projected through every camera's weights), pass A runs without the count.  Opt-in
     // (`fused_scan = 1`): measured on the 5 M-triangle / 4-camera shape it is still behind scan + gather
-    // (0.63 vs 0.56 ms per 64 frame sets) -- its pass B fetches two scalars per camera and node with one
-    // transaction each and the scan is a pass of its own; it needs the coalesced-scalar treatment of the
-    // one-camera pass B before it can become the default.
+    // (0.63-0.66 vs 0.56 ms per 64 frame sets): the scan is a pass of its own there and pass B is bound by
+    // the number of memory transactions per node (four series reads + one row piece), DESIGN.md section 7.
     const bool multi_ok = p->ncams > 1 && !need_stage && !d_rows && d_rows_t && !d_rows_t16 && !p->d_src &&
                           (npix % 2) == 0 && B == 64 && !overlap && p->nnodes < ((size_t)1 << 31);
     if (multi_ok && fused_mode == 1) {
