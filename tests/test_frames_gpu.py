@@ -322,7 +322,7 @@ def test_large_model_series_variants(gpu_lib, F, fused):
     assert torch.equal(s2[0][ok], rt2[:, :F].double().sum(1)[ok])
 
 
-@pytest.mark.parametrize("F", [5, 64, 200])
+@pytest.mark.parametrize("F", [1, 5, 64, 200, 257, 300])
 def test_fused_pass_hot_pixels_vs_oracle(gpu_lib, oracle, F):
     """The fused scan + projection pass (fused_scan=1) against the oracle frame loop with hot pixels
     of every kind: repairable ones on pixels several nodes read, on pixels nobody reads, at the image
@@ -418,3 +418,37 @@ def test_multi_camera_streamed_schedule(gpu_lib, oracle, F):
     assert np.array_equal(np.isnan(r1[1]), np.isnan(s_o))
     assert np.allclose(r1[1][ok], s_o[ok], rtol=1e-12) and np.allclose(r1[2][ok], ss_o[ok], rtol=1e-12)
     assert np.allclose(r1[1][ok], r2[1][ok], rtol=1e-12) and np.allclose(r1[2][ok], r2[2][ok], rtol=1e-12)
+
+
+def test_full_size_streamed_frame_loop_properties(gpu_lib):
+    """BASELINE frame size (1024x1024, 0.5 M nodes) through the default streamed schedule, 300 frames
+    (two passes B: 256 + 44): series == frame[pix] exactly, NaN rows for nodes without a pixel,
+    accumulators == exact integer sums, identical to the scan + gather schedule."""
+    import torch
+    from upsp_processing_amd import engine
+    H = W = 1024
+    n, F = 500766, 300
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    pix = torch.randint(0, H * W, (n,), generator=g, device="cuda", dtype=torch.int32)
+    pix[::5] = -1
+    pix[1:2000] = 77 * W + 99                       # many nodes on one pixel
+    frames = torch.randint(0, 4000, (F, H, W), generator=g, device="cuda", dtype=torch.int32).to(torch.uint16)
+    ld = engine.series_ld(F)
+    out = {}
+    for mode in (0, 2):
+        pipe = engine.FramePipeline(1, W, H, n, fused_scan=mode)
+        pipe.set_projection(0, pix)
+        rt = torch.empty((n, ld), dtype=torch.float32, device="cuda")[:, :F]
+        pipe.process(frames, 0, rows_t=rt, want_rows=False)
+        out[mode] = (rt, [a.clone() for a in pipe.accumulators()])
+    rt = out[0][0]
+    vis = pix >= 0
+    for f in (0, 63, 64, 255, 256, F - 1):
+        ref = frames[f].reshape(-1).to(torch.int32)[pix.clamp(min=0).long()].float()
+        assert torch.equal(rt[vis, f], ref[vis])
+    assert torch.isnan(rt[~vis]).all()
+    assert torch.equal(rt.contiguous().view(torch.int32), out[2][0].contiguous().view(torch.int32))
+    s0, ss0 = out[0][1]
+    assert torch.equal(s0[vis], rt[vis].double().sum(1)) and torch.equal(ss0[vis], (rt[vis] * rt[vis]).double().sum(1))
+    assert torch.equal(s0.view(torch.int64), out[2][1][0].view(torch.int64))
+    assert torch.equal(ss0.view(torch.int64), out[2][1][1].view(torch.int64))
