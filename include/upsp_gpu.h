@@ -236,6 +236,8 @@ int upsp_pipeline_set_overlap_source(upsp_pipeline *pipe, const int32_t *d_src);
  * rows of nodes no camera sees; the reference's global_transpose, cpp/exec/psp_process.cpp:707-771,
  * moves them).  Accumulators and frame-major rows are unaffected.  NULL = identity. */
 int upsp_pipeline_set_row_map(upsp_pipeline *pipe, const int32_t *d_rowmap);
+/* The same with the copy ordered on `stream` (no host block between the projection build and the frame loop). */
+int upsp_pipeline_set_row_map_async(upsp_pipeline *pipe, const int32_t *d_rowmap, void *stream);
 
 /* Receiving side of the packed exchange: block d_src [nrows][ncols] f32 (contiguous) is copied
  * to rows d_rowidx[r] (int64) of d_dst (row pitch ld floats; add the column offset to d_dst). */

@@ -81,6 +81,7 @@ SIGNATURES = {
     "upsp_scatter_rows_f32": (_i, [_vp, _sz, _i, _vp, _vp, C.c_longlong, _vp]),
     "upsp_scatter_rows_u16": (_i, [_vp, _sz, _i, _vp, _vp, C.c_longlong, _vp]),
     "upsp_pipeline_set_row_map": (_i, [_vp, _vp]),
+    "upsp_pipeline_set_row_map_async": (_i, [_vp, _vp, _vp]),
     "upsp_pipeline_set_overlap_source": (_i, [_vp, _vp]),
     "upsp_pipeline_set_skipped": (_i, [_vp, _vp]),
     "upsp_pipeline_set_reference": (_i, [_vp, _i, _vp]),

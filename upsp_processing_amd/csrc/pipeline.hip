@@ -296,18 +296,33 @@ int upsp_pipeline_set_overlap_source(upsp_pipeline *p, const int32_t *d_src)
     return UPSP_OK;
 }
 
-int upsp_pipeline_set_row_map(upsp_pipeline *p, const int32_t *d_rowmap)
+static int set_row_map_impl(upsp_pipeline *p, const int32_t *d_rowmap, bool async, hipStream_t st)
 {
     if (!p) return fail(UPSP_ERR_INVALID, "null pipeline");
-
     if (!d_rowmap) {
-        if (p->d_rowmap) (void)hipFree(p->d_rowmap);
+        if (p->d_rowmap) {
+            if (async) UPSP_HIP_CHECK(hipStreamSynchronize(st));   // launches queued earlier may still read it
+            (void)hipFree(p->d_rowmap);
+        }
         p->d_rowmap = nullptr;
         return UPSP_OK;
     }
     if (!p->d_rowmap) UPSP_HIP_CHECK(hipMalloc(&p->d_rowmap, sizeof(int32_t) * std::max<size_t>(p->nnodes, 1)));
-    UPSP_HIP_CHECK(hipMemcpy(p->d_rowmap, d_rowmap, sizeof(int32_t) * p->nnodes, hipMemcpyDeviceToDevice));
+    if (async)
+        UPSP_HIP_CHECK(hipMemcpyAsync(p->d_rowmap, d_rowmap, sizeof(int32_t) * p->nnodes, hipMemcpyDeviceToDevice, st));
+    else
+        UPSP_HIP_CHECK(hipMemcpy(p->d_rowmap, d_rowmap, sizeof(int32_t) * p->nnodes, hipMemcpyDeviceToDevice));
     return UPSP_OK;
+}
+
+int upsp_pipeline_set_row_map(upsp_pipeline *p, const int32_t *d_rowmap)
+{
+    return set_row_map_impl(p, d_rowmap, false, nullptr);
+}
+
+int upsp_pipeline_set_row_map_async(upsp_pipeline *p, const int32_t *d_rowmap, void *stream)
+{
+    return set_row_map_impl(p, d_rowmap, true, (hipStream_t)stream);
 }
 
 int upsp_pipeline_set_reference(upsp_pipeline *p, int cam, const float *d_ref32f)

@@ -306,7 +306,7 @@ class FramePipeline:
     def set_row_map(self, rowmap):
         """Packed time series: rowmap int32 [N] = row of rows_t per node, < 0 = not stored."""
         self._rowmap = None if rowmap is None else _dev(rowmap, torch.int32)
-        check(lib().upsp_pipeline_set_row_map(self._h, _ptr(self._rowmap)))
+        check(lib().upsp_pipeline_set_row_map_async(self._h, _ptr(self._rowmap), _stream()))
 
     def set_overlap_source(self, src):
         """P3D adjust_solution: src int32 [N] (grids.P3DModel.overlap_source()); None = off."""
