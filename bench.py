@@ -166,7 +166,7 @@ def main():
     if a.registration:
         pipe.set_reference(0, frames[0].to(torch.float32))   # raw first frame as ECC template
     # node-major time series [N, F] with the padded row pitch engine.series_ld() recommends
-    ld = engine.series_ld(F)
+    ld = int(os.environ.get("UPSP_BENCH_LD", "0")) or engine.series_ld(F, whole_rows=True)
     rows_t = (torch.empty((N, ld), dtype=torch.float32, device="cuda")[:, :F]
               if not (world > 1 or a.force_chunked) else None)
     torch.cuda.synchronize()
@@ -305,6 +305,7 @@ def main():
     scene_bytes = bvh.info["device_bytes"]
     gather_launches = -(-F // 64) if not chunked else sum(-(-exch.my_chunk(k)[1] // 64) for k in range(K))
     stream_launches = -(-F // 256) if not chunked else sum(-(-exch.my_chunk(k)[1] // 256) for k in range(K))
+    row_launches = -(-F // 1024) if not chunked else sum(-(-exch.my_chunk(k)[1] // 1024) for k in range(K))
     series_rows = exch.packed_rows() if (chunked and mode["packed"]) else N
     series_esz = 2 if (chunked and mode["packed"] and mode["u16"]) else 4
     per_step_bytes = {
@@ -326,6 +327,8 @@ def main():
         "scan_compact_kernel": F * 2 * size * size,
         # (one pass B per 256 frames: index 4 B + flags + accumulators per node and launch)
         "node_stream_kernel": F * series_esz * series_rows + stream_launches * 8 * N,
+        # (whole-row pass B: one launch per <= 1024 frames)
+        "node_rows_kernel": F * series_esz * series_rows + row_launches * 8 * N,
     }
     for name, (calls, total_ms) in timing.items():
         ms_step_k = total_ms / a.steps

@@ -193,10 +193,14 @@ typedef struct upsp_pipeline_opts {
     /* polynomial target patcher on/off (TargetPatchType) */
     int32_t patch;
     /* frame-loop schedule of the plain path (one camera, no weights, no image stage, node-major series):
-     * 0 / 1 = streamed two-pass schedule (scan + compact pixel series, then one pass over the nodes),
-     * 2 = scan kernel + gather kernel (relies on the sub-batch staying in the Infinity Cache).  Same results. */
+     * 0 / 1 = streamed two-pass schedule (pass A: scan + compact pixel series of up to 1024 frames per
+     * launch, pass B: every node's row piece written once, whole), 2 = scan kernel + gather kernel per
+     * 64 frames (relies on the sub-batch staying in the Infinity Cache).  Same results. */
     int32_t fused_scan;
-    int32_t reserved[4];
+    /* streamed schedule: budget in MiB for the compact pixel-series buffer (2 B x active pixels x frames
+     * of a group); 0 = default (2048).  It bounds the frames per pass A / pass B pair (64 .. 1024). */
+    int32_t compact_mb;
+    int32_t reserved[3];
 } upsp_pipeline_opts;
 
 void upsp_pipeline_default_opts(upsp_pipeline_opts *o);
@@ -267,7 +271,7 @@ int upsp_pipeline_set_patches(upsp_pipeline *p, int cam, int nclusters,
  *   d_warps          optional [nframes][ncams][6] f32 ECC warp matrices
  * The double accumulators sum / sumsq (psp_process.cpp:1827-1831) held by the
  * pipeline are updated. */
-int upsp_pipeline_process(upsp_pipeline *p, const uint16_t *const *d_frames, int nframes,
+int upsp_pipeline_process(upsp_pipeline *p, uint16_t *const *d_frames, int nframes,
                           int64_t first_frame, float *d_rows, float *d_rows_t, int64_t ld_t,
                           int64_t col0, float *d_warps, void *stream);
 
@@ -276,9 +280,11 @@ int upsp_pipeline_process(upsp_pipeline *p, const uint16_t *const *d_frames, int
  * exchange (global_transpose, cpp/exec/psp_process.cpp:707-771), half the bytes of f32.  Lossless
  * and accepted only when every stored value is an exact 16-bit integer: one camera, no weight
  * vector, no patch / filter stage (raw or registered u16 frames) -- UPSP_ERR_INVALID otherwise.
- * NaN has no u16 encoding: rows of nodes no camera sees are written as 0, so use a row map that
- * leaves them out (upsp_pipeline_set_row_map); upsp_scatter_rows_u16 widens the received blocks. */
-int upsp_pipeline_process_u16(upsp_pipeline *p, const uint16_t *const *d_frames, int nframes,
+ * NaN has no u16 encoding, so a row map that leaves out the nodes no camera sees is REQUIRED
+ * (upsp_pipeline_set_row_map; UPSP_ERR_INVALID without one -- a row of a skipped node that the map
+ * does store is written as 0); upsp_scatter_rows_u16 widens the received blocks.  The frames are
+ * repaired in place like in upsp_pipeline_process. */
+int upsp_pipeline_process_u16(upsp_pipeline *p, uint16_t *const *d_frames, int nframes,
                               int64_t first_frame, uint16_t *d_series_u16, int64_t ld_t,
                               int64_t col0, float *d_warps, void *stream);
 

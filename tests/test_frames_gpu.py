@@ -322,7 +322,7 @@ def test_large_model_series_variants(gpu_lib, F, fused):
     assert torch.equal(s2[0][ok], rt2[:, :F].double().sum(1)[ok])
 
 
-@pytest.mark.parametrize("F", [1, 5, 64, 200, 257, 300])
+@pytest.mark.parametrize("F", [1, 5, 64, 200, 257, 300, 513, 1030])
 def test_fused_pass_hot_pixels_vs_oracle(gpu_lib, oracle, F):
     """The fused scan + projection pass (fused_scan=1) against the oracle frame loop with hot pixels
     of every kind: repairable ones on pixels several nodes read, on pixels nobody reads, at the image
@@ -381,6 +381,74 @@ def test_fused_pass_hot_pixels_vs_oracle(gpu_lib, oracle, F):
     assert np.isnan(s2[5]) and np.isnan(s2[100]) and np.array_equal(s2[keep], s_o[keep])
 
 
+@pytest.mark.parametrize("compact_mb", [0, 1])
+def test_stuck_hot_pixels_whole_call(gpu_lib, oracle, compact_mb):
+    """The case fix_hot_pixels exists for (cpp/utils/cv_extras.cpp:230-275): a camera with 5 stuck
+    pixels, hot in every one of the 1000 frames of ONE process() call = 5 000 replaced pixels (round 1
+    silently dropped everything past 4 096).  Two of the stuck pixels are read by many nodes, one by
+    nobody, two sit next to each other (the second repair sees the first).  Node-major series,
+    repaired frames and accumulators bit-identical to the oracle loop -- also with a compact-buffer
+    budget that cuts the call into several frame groups, and packed u16 rows."""
+    import torch
+    from upsp_processing_amd import engine, synthetic as syn
+    H, W, n, F = 48, 130, 2000, 1000
+    rng = np.random.default_rng(4242)
+    fr = syn.synth_frames_numpy(F, H, W, seed=77, hot=False)
+    fr = np.minimum(fr, 3000).astype(np.uint16)
+    stuck = [(7, 9), (7, 10), (30, 64), (0, 0), (H - 1, W - 1)]
+    for (r, c) in stuck:
+        fr[:, r, c] = 4095
+    fr[:, 7, 10] = rng.integers(4064, 4096, F).astype(np.uint16)      # flickers between hot values
+    fr[17, 20, 20] = 4095                                             # frame 17: six hot pixels -> left alone
+    fr[500, 30, 64] = 2000                                            # frame 500: four hot pixels
+    pix = rng.integers(-1, H * W, size=(1, n)).astype(np.int32)
+    pix[0][pix[0] == 30 * W + 64] = -1
+    pix[0, :300] = 7 * W + 9                       # many nodes on a stuck pixel
+    pix[0, 300:450] = H * W - 1                    # ... and on another one
+    pix[0, 450] = 7 * W + 10
+    pix[0, 451] = 0
+    weight = np.ones((1, n), np.float32)
+    rows_o, s_o, ss_o = run_loop_oracle(oracle, [fr], pix, weight)
+    want_frames = np.stack([oracle.fix_hot_pixels(fr[f])[0] for f in range(F)])
+    assert (want_frames != fr).sum() > 4096        # more changes than round 1's list could hold
+    pipe = engine.FramePipeline(1, W, H, n, fused_scan=1, compact_mb=compact_mb)
+    pipe.set_projection(0, pix[0])
+    d = torch.as_tensor(fr.copy()).cuda()
+    rt = torch.full((n, engine.series_ld(F, whole_rows=True)), -3.0, dtype=torch.float32, device="cuda")
+    pipe.process(d, 0, rows_t=rt[:, :F], want_rows=False)
+    assert np.array_equal(d.cpu().numpy(), want_frames)
+    assert np.array_equal(rt[:, :F].cpu().numpy().view(np.int32), rows_o.T.view(np.int32))
+    assert (rt[:, F:] == -3.0).all()
+    s_g, ss_g = [a.cpu().numpy() for a in pipe.accumulators()]
+    ok = ~np.isnan(s_o)
+    assert np.array_equal(np.isnan(s_g), np.isnan(s_o))
+    assert np.array_equal(s_g[ok], s_o[ok]) and np.array_equal(ss_g[ok], ss_o[ok])
+    # the same through the scan + gather schedule
+    p2 = engine.FramePipeline(1, W, H, n, fused_scan=2)
+    p2.set_projection(0, pix[0])
+    d2 = torch.as_tensor(fr.copy()).cuda()
+    rt2 = torch.full((n, engine.series_ld(F)), -3.0, dtype=torch.float32, device="cuda")
+    p2.process(d2, 0, rows_t=rt2[:, :F], want_rows=False)
+    assert torch.equal(rt2[:, :F].contiguous().view(torch.int32), rt[:, :F].contiguous().view(torch.int32))
+    # packed u16 rows in two calls (second call starts at a column that is not a multiple of 64)
+    keep = np.nonzero(pix[0] >= 0)[0]
+    rowmap = np.full(n, -1, np.int32); rowmap[keep] = np.arange(keep.size)
+    pipe.set_row_map(torch.as_tensor(rowmap).cuda())
+    pipe.reset()
+    d3 = torch.as_tensor(fr.copy()).cuda()
+    buf = torch.zeros((keep.size, F + 8), dtype=torch.int32, device="cuda").to(torch.uint16)
+    pipe.process(d3[:333].contiguous(), 0, rows_t=buf[:, :F], want_rows=False)
+    pipe.process(d3[333:].contiguous(), 333, rows_t=buf[:, :F], col0=333, want_rows=False)
+    assert np.array_equal(buf[:, :F].cpu().numpy().astype(np.float32), rows_o.T[keep])
+    s3, ss3 = [a.cpu().numpy() for a in pipe.accumulators()]
+    assert np.array_equal(s3[ok], s_o[ok]) and np.array_equal(ss3[ok], ss_o[ok])
+    # u16 rows need a row map (NaN has no u16 encoding)
+    pipe.set_row_map(None)
+    from upsp_processing_amd import _capi
+    with pytest.raises(_capi.UpspError):
+        pipe.process(d3, 0, rows_t=torch.zeros((n, F), dtype=torch.int32, device="cuda").to(torch.uint16), want_rows=False)
+
+
 @pytest.mark.parametrize("F", [41, 300])
 def test_multi_camera_streamed_schedule(gpu_lib, oracle, F):
     """Three cameras with weights, node-major series only: the streamed schedule (fused_scan=1: one
@@ -422,8 +490,8 @@ def test_multi_camera_streamed_schedule(gpu_lib, oracle, F):
 
 def test_full_size_streamed_frame_loop_properties(gpu_lib):
     """BASELINE frame size (1024x1024, 0.5 M nodes) through the default streamed schedule, 300 frames
-    (two passes B: 256 + 44): series == frame[pix] exactly, NaN rows for nodes without a pixel,
-    accumulators == exact integer sums, identical to the scan + gather schedule."""
+    (one pass A + one whole-row pass B): series == frame[pix] exactly, NaN rows for nodes without a
+    pixel, accumulators == exact integer sums, identical to the scan + gather schedule."""
     import torch
     from upsp_processing_amd import engine
     H = W = 1024

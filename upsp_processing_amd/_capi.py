@@ -44,7 +44,7 @@ class PipelineOpts(C.Structure):
                 ("registration", C.c_int32), ("ecc_max_iters", C.c_int32),
                 ("ecc_eps", C.c_double), ("interp", C.c_int32),
                 ("filter", C.c_int32), ("filter_size", C.c_int32), ("patch", C.c_int32),
-                ("fused_scan", C.c_int32), ("reserved", C.c_int32 * 4)]
+                ("fused_scan", C.c_int32), ("compact_mb", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 _vp, _sz, _i, _i64, _u64p = C.c_void_p, C.c_size_t, C.c_int, C.c_int64, C.POINTER(C.c_uint64)

@@ -8,6 +8,7 @@
 // accumulators across a batch of frames, and an LDS tile for the transpose.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -621,42 +622,76 @@ __global__ void __launch_bounds__(256)
     }
 }
 
-// exclusive scan of the tile counts (one workgroup): off[0..ntiles], off[ntiles] = total
+// exclusive scan of the tile counts (one workgroup): off[0..ntiles], off[ntiles] = total; and of the
+// "tile has an active pixel" flags: arank[0..ntiles], arank[ntiles] = number of active tiles
 __global__ void __launch_bounds__(1024)
-    tilemap_scan_kernel(const unsigned *__restrict__ cnt, unsigned *__restrict__ off, unsigned ntiles)
+    tilemap_scan_kernel(const unsigned *__restrict__ cnt, unsigned *__restrict__ off, unsigned *__restrict__ arank,
+                        unsigned ntiles)
 {
-    __shared__ unsigned part[1024];
-    __shared__ unsigned carry;
-    if (threadIdx.x == 0) carry = 0u;
+    __shared__ unsigned long long part[1024];   // low word: pixels, high word: active tiles
+    __shared__ unsigned long long carry;
+    if (threadIdx.x == 0) carry = 0ull;
     __syncthreads();
     for (unsigned base = 0; base < ntiles; base += 1024u * 8u) {
         const unsigned i0 = base + threadIdx.x * 8u;
-        unsigned v[8], tot = 0;
+        unsigned v[8];
+        unsigned long long tot = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             v[k] = i0 + k < ntiles ? cnt[i0 + k] : 0u;
-            tot += v[k];
+            tot += (unsigned long long)v[k] + ((unsigned long long)(v[k] != 0u) << 32);
         }
         part[threadIdx.x] = tot;
         __syncthreads();
         for (unsigned d = 1; d < 1024u; d <<= 1) {   // Hillis-Steele inclusive scan
-            const unsigned a = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+            const unsigned long long a = threadIdx.x >= d ? part[threadIdx.x - d] : 0ull;
             __syncthreads();
             part[threadIdx.x] += a;
             __syncthreads();
         }
-        unsigned run = carry + part[threadIdx.x] - tot;
+        unsigned long long run = carry + part[threadIdx.x] - tot;
 #pragma unroll
         for (int k = 0; k < 8; ++k)
             if (i0 + k < ntiles) {
-                off[i0 + k] = run;
-                run += v[k];
+                off[i0 + k] = (unsigned)(run & 0xFFFFFFFFull);
+                if (arank) arank[i0 + k] = (unsigned)(run >> 32);
+                run += (unsigned long long)v[k] + ((unsigned long long)(v[k] != 0u) << 32);
             }
         __syncthreads();
         if (threadIdx.x == 1023) carry += part[1023];
         __syncthreads();
     }
-    if (threadIdx.x == 0) off[ntiles] = carry;
+    if (threadIdx.x == 0) {
+        off[ntiles] = (unsigned)(carry & 0xFFFFFFFFull);
+        if (arank) arank[ntiles] = (unsigned)(carry >> 32);
+    }
+}
+
+// Visiting order of the tiles in pass A.  The tiles with active pixels are the only ones that write
+// (their compact series), and on a real model they are neighbours (the model covers a band of the
+// frame): visited in natural order their stores arrive in bursts inside the read stream, which costs
+// pass A 0.39 instead of 0.35 ms per 1024 frames (tools/probe/passA_stages.hip).  order[] spreads the
+// A active tiles evenly over the n slots (active tile j -> slot floor(j n / A)) and fills the other
+// slots with the inactive tiles, both kinds in their natural order (reads of neighbouring workgroups
+// stay neighbours, the compact rows of successive active tiles too).
+__global__ void __launch_bounds__(256)
+    amap_lists_kernel(const unsigned *__restrict__ cnt, const unsigned *__restrict__ arank, unsigned ntiles,
+                      unsigned *__restrict__ act, unsigned *__restrict__ inact)
+{
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntiles) return;
+    if (cnt[t]) act[arank[t]] = t;
+    else inact[t - arank[t]] = t;
+}
+__global__ void __launch_bounds__(256)
+    amap_order_kernel(const unsigned *__restrict__ arank, unsigned ntiles, const unsigned *__restrict__ act,
+                      const unsigned *__restrict__ inact, unsigned *__restrict__ order)
+{
+    const unsigned p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= ntiles) return;
+    const unsigned long long A = arank[ntiles], n = ntiles;
+    const unsigned long long j = ((unsigned long long)p * A + n - 1) / n;    // active slots before slot p
+    order[p] = (j < A && (j * n) / A == p) ? act[j] : inact[p - j];
 }
 
 // step 3: node -> index of its pixel's series in the compact buffer (-1: no pixel)
@@ -690,20 +725,33 @@ __device__ __forceinline__ double group16_sum(double v)
     return v;
 }
 
-// Pass A.  compact: [active pixel][cpitch] u16; this launch fills 64 columns from `compact` on
-// (frames past nframes hold 0).
+// Pass A.  compact: [active pixel][cpitch] u16; blockIdx.y = 64-frame group g of the call: it fills
+// columns 64 g .. 64 g + 63 (frames past nframes hold 0).  count / pos: one counter / kHotCap positions
+// per frame of the call.  A tile nobody reads (most of them: the model covers part of the frame) is only
+// streamed through for the hot-pixel count.
 template <bool HOT>
 __global__ void __launch_bounds__(256)
-    scan_compact_kernel(const uint16_t *__restrict__ frames, size_t npix, int nframes,
+    scan_compact_kernel(const uint16_t *__restrict__ frames, size_t npix, int nframes_call,
                         const uint8_t *__restrict__ flag, const unsigned *__restrict__ tile_off,
                         uint16_t *__restrict__ compact, unsigned cpitch, unsigned thresh, unsigned max_hot,
-                        unsigned *__restrict__ count, unsigned *__restrict__ pos)
+                        unsigned *__restrict__ count, unsigned *__restrict__ pos, const unsigned *__restrict__ order)
 {
     __shared__ unsigned tile[64][kFusedPitch];   // [frame][pixel pair]
     __shared__ int act_k[kFusedPix];             // compact index of the tile's pixels, -1 = nobody reads it
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const size_t p0 = (size_t)blockIdx.x * kFusedPix + 2u * (unsigned)lane;   // this lane's pixel pair
+    const int g = blockIdx.y;
+    const unsigned tl = order ? order[blockIdx.x] : blockIdx.x;   // this workgroup's tile
+    const int nframes = min(64, nframes_call - 64 * g);
+    frames += (size_t)g * 64 * npix;
+    compact += 64 * g;
+    if (HOT) {
+        count += 64 * g;
+        pos += (size_t)64 * g * kHotCap;
+    }
+    const size_t p0 = (size_t)tl * kFusedPix + 2u * (unsigned)lane;   // this lane's pixel pair
     const bool in = p0 + 1 < npix;                                            // npix is even
+    const unsigned k0 = tile_off[tl];
+    const bool any_active = tile_off[tl + 1] != k0;                   // (uniform)
     // wave w streams frames w, w+4, ..: one 256-byte segment per wave load, all 16 issued up front
     unsigned v[16];
 #pragma unroll
@@ -712,15 +760,15 @@ __global__ void __launch_bounds__(256)
         // streamed: the frames are not read again by this schedule
         v[i] = (in && f < nframes) ? __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(frames + (size_t)f * npix + p0)) : 0u;
     }
-    if (threadIdx.x < kFusedPix) {
-        const size_t p = (size_t)blockIdx.x * kFusedPix + threadIdx.x;
+    if (any_active && threadIdx.x < kFusedPix) {
+        const size_t p = (size_t)tl * kFusedPix + threadIdx.x;
         const unsigned fl = p < npix ? flag[p] : 0u;
-        act_k[threadIdx.x] = fl ? (int)(tile_off[blockIdx.x] + (fl & 0x7Fu)) : -1;
+        act_k[threadIdx.x] = fl ? (int)(k0 + (fl & 0x7Fu)) : -1;
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int f = wave + 4 * i;
-        tile[f][lane] = v[i];
+        if (any_active) tile[f][lane] = v[i];
         if (HOT && (((v[i] & 0xFFFFu) >= thresh) | ((v[i] >> 16) >= thresh))) {
             // pass 1 of fix_hot_pixels; once the counter is past max_hot the verdict is settled
             if (__hip_atomic_load(&count[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= max_hot) {
@@ -733,6 +781,7 @@ __global__ void __launch_bounds__(256)
             }
         }
     }
+    if (!any_active) return;
     __syncthreads();
     // 8 lanes per active pixel: lane j packs frames 8j .. 8j+7 of the pixel's column into 16 bytes
     const int grp = threadIdx.x >> 3, j8 = threadIdx.x & 7;
@@ -750,6 +799,137 @@ __global__ void __launch_bounds__(256)
             w[q] = a | (b << 16);
         }
         *reinterpret_cast<uint4 *>(compact + (size_t)k * cpitch + 8 * j8) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+// Pass B, whole rows.  The series of a node over all (<= kGroupFramesMax) frames of a call sits in
+// the compact buffer, so its row piece is written once, contiguously: LPR lanes per row (lane l:
+// frames 4 l .. 4 l + 3), 256 / LPR rows per sweep, ROWS sweeps per workgroup.  Rows of nodes without a
+// pixel are a constant fill with no load at all.  Measured on MI355X (tools/probe/store_shapes.hip,
+// 500 958 rows x 4000 B): a workgroup sweeping one whole 4-KB row per store instruction 5.7-5.9 TB/s
+// at a 4096-B pitch against 4.3 TB/s for the 1-KB pieces of node_stream_kernel.
+// Accumulators: per-lane integer sums (values < 2^16, exact) and double sums of the float squares
+// (integers < 2^32, exact in any order), reduced per wave by DPP, per row through LDS.
+constexpr int kGroupFramesMax = 1024;
+__device__ __forceinline__ unsigned group16_sum_u32(unsigned v)
+{
+    v += (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);
+    v += (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);
+    v += (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true);
+    v += (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xF, 0xF, true);
+    return v;
+}
+template <int L>
+__device__ __forceinline__ double readlane_f64(double x)
+{
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFll), L);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), L);
+    return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
+template <int LPR, int ROWS, bool U16>
+__global__ void __launch_bounds__(256)
+    node_rows_kernel(const uint16_t *__restrict__ compact, unsigned cpitch, const int32_t *__restrict__ node_k,
+                     const uint8_t *__restrict__ skipped, const int32_t *__restrict__ rowmap, unsigned nnodes,
+                     int nframes, float *__restrict__ rows_t, uint16_t *__restrict__ rows_t16, long long ld_t,
+                     double *__restrict__ sum, double *__restrict__ sumsq)
+{
+    constexpr int RPS = 256 / LPR;          // rows per sweep
+    constexpr int WPR = LPR / 64;           // waves per row
+    constexpr int NR = RPS * ROWS;          // rows (consecutive nodes) per workgroup
+    __shared__ int s_k[NR], s_row[NR], s_sk[NR];
+    __shared__ unsigned p_s[NR][WPR];
+    __shared__ double p_ss[NR][WPR];
+    const unsigned n0 = blockIdx.x * (unsigned)NR;
+    const int t = threadIdx.x;
+    if (t < NR) {
+        const unsigned n = n0 + (unsigned)t;
+        const bool ok = n < nnodes;
+        s_k[t] = ok ? node_k[n] : -1;
+        s_sk[t] = (ok && skipped) ? (int)skipped[n] : 0;
+        s_row[t] = ok ? (rowmap ? rowmap[n] : (int)n) : -1;     // rows are < 2^31 (node count check at create)
+    }
+    __syncthreads();
+    const int sub = t / LPR, l = t % LPR, wr = l >> 6, lane = t & 63;
+    const int f0 = 4 * l;
+    const float qnan = __builtin_nanf("");
+    const bool vec_ok = U16 ? (((ld_t & 3) == 0) && ((reinterpret_cast<size_t>(rows_t16) & 7) == 0))
+                            : (((ld_t & 3) == 0) && ((reinterpret_cast<size_t>(rows_t) & 15) == 0));
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) {
+        const int r = j * RPS + sub;                            // (uniform per wave)
+        const int k = s_k[r], row = s_row[r];
+        const bool sk = s_sk[r] != 0;
+        uint2 w = make_uint2(0u, 0u);
+        // (ordinary loads: the compact buffer was written a moment ago and sits in L2 / Infinity Cache)
+        if (k >= 0 && !sk && f0 < nframes) w = *reinterpret_cast<const uint2 *>(compact + (size_t)k * cpitch + f0);
+        const unsigned d[4] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16};
+        unsigned s = 0u;
+        double ss = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (f0 + q < nframes) {
+                const float x = (float)d[q];
+                s += d[q];
+                ss += (double)(x * x);
+            }
+        s = group16_sum_u32(s);
+        ss = group16_sum(ss);
+        // the wave's total from its four DPP rows
+        const unsigned ws = (unsigned)__builtin_amdgcn_readlane((int)s, 0) + (unsigned)__builtin_amdgcn_readlane((int)s, 16) +
+                            (unsigned)__builtin_amdgcn_readlane((int)s, 32) + (unsigned)__builtin_amdgcn_readlane((int)s, 48);
+        const double wss = (readlane_f64<0>(ss) + readlane_f64<16>(ss)) + (readlane_f64<32>(ss) + readlane_f64<48>(ss));
+        if (lane == 0) {
+            p_s[r][wr] = ws;
+            p_ss[r][wr] = wss;
+        }
+        if (row < 0 || f0 >= nframes) continue;                 // row not stored (packed series) / past the end
+        if (!U16) {
+            float *dst = rows_t + (long long)row * ld_t + f0;
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            // a node without a pixel: 0 (empty row of the projection matrix); no camera sees it: NaN
+            const v4f nv = {sk ? qnan : (float)d[0], sk ? qnan : (float)d[1], sk ? qnan : (float)d[2], sk ? qnan : (float)d[3]};
+            if (vec_ok && f0 + 3 < nframes) {
+                __builtin_nontemporal_store(nv, reinterpret_cast<v4f *>(dst));
+            } else {
+                dst[0] = nv.x;
+                if (f0 + 1 < nframes) dst[1] = nv.y;
+                if (f0 + 2 < nframes) dst[2] = nv.z;
+                if (f0 + 3 < nframes) dst[3] = nv.w;
+            }
+        } else {   // u16 series (exchange wire format; callers store visible rows only)
+            uint16_t *dst = rows_t16 + (long long)row * ld_t + f0;
+            typedef unsigned v2u __attribute__((ext_vector_type(2)));
+            const v2u nv = {sk ? 0u : w.x, sk ? 0u : w.y};
+            if (vec_ok && f0 + 3 < nframes) {
+                __builtin_nontemporal_store(nv, reinterpret_cast<v2u *>(dst));
+            } else {
+                dst[0] = (uint16_t)(nv.x & 0xFFFFu);
+                if (f0 + 1 < nframes) dst[1] = (uint16_t)(nv.x >> 16);
+                if (f0 + 2 < nframes) dst[2] = (uint16_t)(nv.y & 0xFFFFu);
+                if (f0 + 3 < nframes) dst[3] = (uint16_t)(nv.y >> 16);
+            }
+        }
+    }
+    __syncthreads();
+    // accumulators: a node with a pixel gains its sums (NaN when no camera sees it); without a pixel it
+    // gains 0, or turns NaN when no camera sees it
+    if (t < NR) {
+        const unsigned n = n0 + (unsigned)t;
+        if (n < nnodes) {
+            const bool msk = s_sk[t] != 0;
+            if (s_k[t] >= 0 || msk) {
+                unsigned as = 0u;
+                double ass = 0.0;
+#pragma unroll
+                for (int q = 0; q < WPR; ++q) {
+                    as += p_s[t][q];
+                    ass += p_ss[t][q];
+                }
+                sum[n] = msk ? (double)qnan : sum[n] + (double)as;
+                sumsq[n] = msk ? (double)qnan : sumsq[n] + ass;
+            }
+        }
     }
 }
 
@@ -977,15 +1157,20 @@ __global__ void __launch_bounds__(256)
 }
 
 // Frames with 1..max_hot hot pixels: repair in place (same code as the scan kernel's pass 2) and
-// list the replaced pixels as (frame, position, old, new) for hot_patch_kernel.  One lane per frame.
+// list the replaced pixels as (frame, position, old, new) for hot_patch_kernel.  One lane per frame;
+// frame f owns slots [f * max_hot, (f + 1) * max_hot) of the list (a frame replaces at most max_hot
+// pixels), nch[f] = how many it filled -- no cap, no order that depends on the atomics.
+// *ntotal (zero on entry) counts the changes of the call: the list kernels below return at once when
+// it stays zero (nearly every call).
 __global__ void __launch_bounds__(64)
     hot_repair_kernel(uint16_t *frames, size_t npix, int nframes, int rows, int cols, int min_change,
                       int max_hot, unsigned *__restrict__ count, const unsigned *__restrict__ pos,
-                      unsigned *__restrict__ nchanges, uint4 *__restrict__ changes, unsigned cap)
+                      unsigned *__restrict__ ntotal, unsigned *__restrict__ nch, uint4 *__restrict__ changes)
 {
     const size_t f = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= (size_t)nframes) return;
     const unsigned n = count[f];
+    nch[f] = 0u;
     if (n == 0u) return;
     count[f] = 0u;                             // clean for the next launch
     if (n > (unsigned)max_hot) return;         // "too many pixels look hot": frame untouched
@@ -997,47 +1182,71 @@ __global__ void __launch_bounds__(64)
         before[i] = img[p[i]];
     }
     fix_frame(img, rows, cols, min_change, max_hot, n, p, nullptr);   // sorts p
+    unsigned m = 0;
     for (unsigned i = 0; i < n; ++i) {
         unsigned oldv = 0;
         for (unsigned j = 0; j < n; ++j)
             if (pos[f * kHotCap + j] == p[i]) oldv = before[j];
         const unsigned newv = img[p[i]];
-        if (newv != oldv) {
-            const unsigned slot = atomicAdd(nchanges, 1u);
-            if (slot < cap) changes[slot] = make_uint4((unsigned)f, p[i], oldv, newv);
-        }
+        if (newv != oldv) changes[f * (size_t)max_hot + m++] = make_uint4((unsigned)f, p[i], oldv, newv);
     }
+    nch[f] = m;
+    if (m) atomicAdd(ntotal, m);
 }
 
-// Re-projection of the replaced pixels: every node reading one gets its series entry and its
-// accumulators corrected.  One lane per node against the (short) change list.
+// Pixel -> nodes lists for the re-projection (built only in calls that replaced a pixel): head[p] =
+// a node reading pixel p (-1: none), next[n] = the next node on the same pixel.  The order inside a
+// list depends on the atomics; the patches of different nodes are independent of each other.
 __global__ void __launch_bounds__(256)
-    hot_patch_kernel(const int32_t *__restrict__ pix, const uint8_t *__restrict__ skipped,
-                     const int32_t *__restrict__ rowmap, unsigned nnodes, unsigned *__restrict__ nchanges,
-                     const uint4 *__restrict__ changes, unsigned cap, float *__restrict__ rows_t,
-                     uint16_t *__restrict__ rows_t16, long long ld_t, double *__restrict__ sum,
-                     double *__restrict__ sumsq)
+    hot_lists_init_kernel(const unsigned *__restrict__ ntotal, int32_t *__restrict__ head, size_t npix)
 {
-    const unsigned m = min(*nchanges, cap);
-    if (m == 0u) return;                       // (uniform) nearly every call
+    if (*ntotal == 0u) return;                 // (uniform)
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < npix) head[p] = -1;
+}
+__global__ void __launch_bounds__(256)
+    hot_lists_build_kernel(const unsigned *__restrict__ ntotal, const int32_t *__restrict__ pix, unsigned nnodes,
+                           int32_t *__restrict__ head, int32_t *__restrict__ next)
+{
+    if (*ntotal == 0u) return;                 // (uniform)
     const unsigned n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= nnodes) return;
     const int32_t p = pix[n];
-    if (p < 0 || (skipped && skipped[n])) return;             // no pixel / stays NaN
-    const long long row = rowmap ? (long long)rowmap[n] : (long long)n;
-    for (unsigned c = 0; c < m; ++c) {
-        const uint4 ch = changes[c];
-        if (ch.y != (unsigned)p) continue;
-        const float xo = (float)ch.z, xn = (float)ch.w;
-        sum[n] += (double)xn - (double)xo;                    // one lane owns the node
-        sumsq[n] += (double)(xn * xn) - (double)(xo * xo);
+    if (p >= 0) next[n] = atomicExch(&head[p], (int32_t)n);
+}
+
+// Re-projection of the replaced pixels: every node reading one gets its series entry and its
+// accumulators corrected.  One lane per change slot.  A pixel that is hot in many frames of the
+// call (a stuck pixel) has many lanes on the same node: the accumulators move by atomics -- every
+// term is an integer-valued double far below 2^53, so the result does not depend on their order.
+__global__ void __launch_bounds__(256)
+    hot_patch_kernel(const unsigned *__restrict__ ntotal, const unsigned *__restrict__ nch,
+                     const uint4 *__restrict__ changes, int nframes, int max_hot,
+                     const int32_t *__restrict__ head, const int32_t *__restrict__ next,
+                     const uint8_t *__restrict__ skipped, const int32_t *__restrict__ rowmap,
+                     float *__restrict__ rows_t, uint16_t *__restrict__ rows_t16, long long ld_t,
+                     double *__restrict__ sum, double *__restrict__ sumsq)
+{
+    if (*ntotal == 0u) return;                 // (uniform) nearly every call
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (unsigned)nframes * (unsigned)max_hot) return;
+    const unsigned f = i / (unsigned)max_hot;
+    if (i - f * (unsigned)max_hot >= nch[f]) return;
+    const uint4 ch = changes[i];
+    const float xo = (float)ch.z, xn = (float)ch.w;
+    const double ds = (double)xn - (double)xo, dss = (double)(xn * xn) - (double)(xo * xo);
+    for (int32_t n = head[ch.y]; n >= 0; n = next[n]) {
+        if (skipped && skipped[n]) continue;                  // stays NaN
+        unsafeAtomicAdd(&sum[n], ds);
+        unsafeAtomicAdd(&sumsq[n], dss);
+        const long long row = rowmap ? (long long)rowmap[n] : (long long)n;
         if (row < 0) continue;
         if (rows_t) rows_t[row * ld_t + (long long)ch.x] = xn;
         else rows_t16[row * ld_t + (long long)ch.x] = (uint16_t)ch.w;
     }
 }
 
-__global__ void hot_patch_reset_kernel(unsigned *nchanges) { *nchanges = 0u; }
+__global__ void hot_patch_reset_kernel(unsigned *ntotal) { *ntotal = 0u; }
 
 __global__ void finals_kernel(const double *__restrict__ sum, const double *__restrict__ sumsq,
                               unsigned nnodes, double nframes, float *__restrict__ avg,
@@ -1256,7 +1465,7 @@ size_t tilemap_tiles(size_t npix) { return (npix + kFusedPix - 1) / kFusedPix; }
 // [ntiles + 1] (compact index of a tile's first active pixel; d_off[ntiles] = number of active
 // pixels), d_node_k [nnodes].  d_cnt [ntiles] is scratch.
 int launch_amap_build(const int32_t *d_pix, size_t nnodes, size_t npix, uint8_t *d_flag, unsigned *d_cnt,
-                      unsigned *d_off, int32_t *d_node_k, hipStream_t st)
+                      unsigned *d_off, int32_t *d_node_k, unsigned *d_order, hipStream_t st)
 {
     const unsigned ntiles = (unsigned)tilemap_tiles(npix);
     KTimed kt("amap_build", st);
@@ -1264,33 +1473,46 @@ int launch_amap_build(const int32_t *d_pix, size_t nnodes, size_t npix, uint8_t 
     const dim3 g((unsigned)((nnodes + 255) / 256)), b(256);
     hipLaunchKernelGGL(amap_mark_kernel, g, b, 0, st, d_pix, (unsigned)nnodes, d_flag);
     hipLaunchKernelGGL(amap_rank_kernel, dim3((unsigned)((npix + 255) / 256)), b, 0, st, d_flag, npix, d_cnt);
-    hipLaunchKernelGGL(tilemap_scan_kernel, dim3(1), dim3(1024), 0, st, (const unsigned *)d_cnt, d_off, ntiles);
+    // d_order (optional): 4 * (ntiles + 1) words = visiting order [ntiles], active-tile ranks [ntiles + 1], the
+    // two tile lists [ntiles] each
+    unsigned *arank = d_order ? d_order + ntiles : nullptr;
+    hipLaunchKernelGGL(tilemap_scan_kernel, dim3(1), dim3(1024), 0, st, (const unsigned *)d_cnt, d_off, arank, ntiles);
     hipLaunchKernelGGL(amap_nodes_kernel, g, b, 0, st, d_pix, (unsigned)nnodes, (const uint8_t *)d_flag,
                        (const unsigned *)d_off, d_node_k);
+    if (d_order) {
+        unsigned *act = d_order + 2 * (size_t)ntiles + 1, *inact = act + ntiles;
+        const dim3 gt((ntiles + 255) / 256);
+        hipLaunchKernelGGL(amap_lists_kernel, gt, b, 0, st, (const unsigned *)d_cnt, (const unsigned *)arank, ntiles, act, inact);
+        hipLaunchKernelGGL(amap_order_kernel, gt, b, 0, st, (const unsigned *)arank, ntiles, (const unsigned *)act,
+                           (const unsigned *)inact, d_order);
+    }
     UPSP_HIP_CHECK(hipGetLastError());
     return UPSP_OK;
 }
 
 int stream_frames_max() { return kStreamFrames; }
+int group_frames_max() { return kGroupFramesMax; }
 
-// Pass A for one sub-batch (<= 64 frames) into columns [col, col + 64) of the compact buffer.
-// d_count: one counter per frame of the sub-batch (zero on entry; launch_hot_fixup leaves them zero),
-// d_pos: 64 positions per frame.
+// Pass A for `nframes` frames (any number: one workgroup row per 64-frame group) into columns
+// [col, col + nframes) of the compact buffer (row pitch cpitch u16 >= col + nframes rounded up to 64).
+// d_count: one counter per frame (zero on entry; launch_hot_fixup leaves them zero), d_pos: 64
+// positions per frame.
 int launch_scan_compact(uint16_t *d_frames, size_t npix, int nframes, bool hot, int thresh, int max_hot,
-                        const uint8_t *d_flag, const unsigned *d_off, uint16_t *d_compact, int col,
-                        unsigned *d_count, unsigned *d_pos, hipStream_t st)
+                        const uint8_t *d_flag, const unsigned *d_off, const unsigned *d_order, uint16_t *d_compact,
+                        unsigned cpitch, int col, unsigned *d_count, unsigned *d_pos, hipStream_t st)
 {
-    if (nframes <= 0 || nframes > 64) return fail(UPSP_ERR_INVALID, "scan pass takes 1..64 frames");
+    if (nframes <= 0) return UPSP_OK;
     if (max_hot < 0 || max_hot >= kHotCap) return fail(UPSP_ERR_INVALID, "max_hot must be in [0,63]");
+    const int ngroups = (nframes + 63) / 64;
+    if ((col & 63) || (unsigned)(col + 64 * ngroups) > cpitch) return fail(UPSP_ERR_INVALID, "scan pass: compact buffer too narrow");
     const unsigned ntiles = (unsigned)tilemap_tiles(npix);
     KTimed kt("scan_compact_kernel", st);
     if (hot)
-        hipLaunchKernelGGL(scan_compact_kernel<true>, dim3(ntiles), dim3(256), 0, st, d_frames, npix, nframes, d_flag,
-                           d_off, d_compact + col, (unsigned)kStreamFrames, (unsigned)thresh, (unsigned)max_hot,
-                           d_count, d_pos);
+        hipLaunchKernelGGL(scan_compact_kernel<true>, dim3(ntiles, (unsigned)ngroups), dim3(256), 0, st, d_frames, npix, nframes,
+                           d_flag, d_off, d_compact + col, cpitch, (unsigned)thresh, (unsigned)max_hot, d_count, d_pos, d_order);
     else
-        hipLaunchKernelGGL(scan_compact_kernel<false>, dim3(ntiles), dim3(256), 0, st, d_frames, npix, nframes, d_flag,
-                           d_off, d_compact + col, (unsigned)kStreamFrames, 0u, 0u, d_count, d_pos);
+        hipLaunchKernelGGL(scan_compact_kernel<false>, dim3(ntiles, (unsigned)ngroups), dim3(256), 0, st, d_frames, npix, nframes,
+                           d_flag, d_off, d_compact + col, cpitch, 0u, 0u, d_count, d_pos, d_order);
     UPSP_HIP_CHECK(hipGetLastError());
     return UPSP_OK;
 }
@@ -1303,6 +1525,36 @@ int launch_node_stream(const PipelineGather &g, const int32_t *d_node_k, const u
     hipLaunchKernelGGL(node_stream_kernel, dim3((unsigned)((g.nnodes + 63) / 64)), dim3(256), 0, st, d_compact,
                        (unsigned)kStreamFrames, d_node_k, g.skipped, g.rowmap, (unsigned)g.nnodes, g.nframes, g.rows_t,
                        g.rows_t16, (long long)g.ld_t, g.sum, g.sumsq);
+    UPSP_HIP_CHECK(hipGetLastError());
+    return UPSP_OK;
+}
+
+// Pass B, whole rows, for the g.nframes (<= group_frames_max()) frames parked in the compact buffer.
+int launch_node_rows(const PipelineGather &g, const int32_t *d_node_k, const uint16_t *d_compact, unsigned cpitch,
+                     hipStream_t st)
+{
+    if (g.nframes <= 0 || g.nframes > kGroupFramesMax || (unsigned)g.nframes > cpitch)
+        return fail(UPSP_ERR_INVALID, "row pass: too many frames");
+    static const int rows_env = std::getenv("UPSP_ROWS_PER_WG") ? std::atoi(std::getenv("UPSP_ROWS_PER_WG")) : 4;
+    const unsigned nn = (unsigned)g.nnodes;
+    KTimed kt("node_rows_kernel", st);
+#define UPSP_NR(LPR, ROWS, U16)                                                                              \
+    hipLaunchKernelGGL((node_rows_kernel<LPR, ROWS, U16>), dim3((nn + (256 / LPR) * ROWS - 1) / ((256 / LPR) * ROWS)), \
+                       dim3(256), 0, st, d_compact, cpitch, d_node_k, g.skipped, g.rowmap, nn, g.nframes, g.rows_t,  \
+                       g.rows_t16, (long long)g.ld_t, g.sum, g.sumsq)
+#define UPSP_NR_R(LPR, U16)                                                                                  \
+    do {                                                                                                     \
+        if (rows_env >= 8) UPSP_NR(LPR, 8, U16); else if (rows_env >= 4) UPSP_NR(LPR, 4, U16);              \
+        else if (rows_env >= 2) UPSP_NR(LPR, 2, U16); else UPSP_NR(LPR, 1, U16);                            \
+    } while (0)
+#define UPSP_NR_L(U16)                                                                                       \
+    do {                                                                                                     \
+        if (g.nframes > 512) UPSP_NR_R(256, U16); else if (g.nframes > 256) UPSP_NR_R(128, U16); else UPSP_NR_R(64, U16); \
+    } while (0)
+    if (g.rows_t16) UPSP_NR_L(true); else UPSP_NR_L(false);
+#undef UPSP_NR_L
+#undef UPSP_NR_R
+#undef UPSP_NR
     UPSP_HIP_CHECK(hipGetLastError());
     return UPSP_OK;
 }
@@ -1330,21 +1582,34 @@ int launch_node_stream_multi(const PipelineGather &g, const int32_t *const *d_no
 }
 
 // Hot-pixel fix-up of all `nframes` frames of a call (any number; g.rows_t / g.rows_t16 point at the
-// column of the first frame; d_count / d_pos hold one counter / 64 positions per frame; d_changes:
-// 1 + 4 * cap words, word 0 = number of changes).
+// column of the first frame; d_count / d_pos hold one counter / 64 positions per frame).  Scratch:
+// d_changes 4 words (word 0 = number of changes of the call) + nframes words (changes per frame) rounded
+// up to a multiple of 4 + 4 * nframes * max_hot words (hot_changes_words()); d_head [npix], d_next [nnodes].
+size_t hot_changes_words(int nframes, int max_hot)
+{
+    return 4 + (((size_t)nframes + 3) & ~(size_t)3) + 4 * (size_t)nframes * (size_t)std::max(max_hot, 1);
+}
 int launch_hot_fixup(const PipelineGather &g, uint16_t *d_frames, int nframes, int rows, int cols,
                      int min_change, int max_hot, unsigned *d_count, const unsigned *d_pos,
-                     unsigned *d_changes, unsigned cap, hipStream_t st)
+                     unsigned *d_changes, int32_t *d_head, int32_t *d_next, hipStream_t st)
 {
     if (nframes <= 0) return UPSP_OK;
     KTimed kt("hot_fixup_kernels", st);
-    uint4 *list = reinterpret_cast<uint4 *>(d_changes + 4);
+    unsigned *nch = d_changes + 4;
+    uint4 *list = reinterpret_cast<uint4 *>(d_changes + 4 + (((size_t)nframes + 3) & ~(size_t)3));
     hipLaunchKernelGGL(hot_patch_reset_kernel, dim3(1), dim3(1), 0, st, d_changes);
     hipLaunchKernelGGL(hot_repair_kernel, dim3((unsigned)((nframes + 63) / 64)), dim3(64), 0, st, d_frames, g.npix,
-                       nframes, rows, cols, min_change, max_hot, d_count, d_pos, d_changes, list, cap);
-    hipLaunchKernelGGL(hot_patch_kernel, dim3((unsigned)((g.nnodes + 255) / 256)), dim3(256), 0, st, g.pix[0],
-                       g.skipped, g.rowmap, (unsigned)g.nnodes, d_changes, (const uint4 *)list, cap, g.rows_t,
-                       g.rows_t16, (long long)g.ld_t, g.sum, g.sumsq);
+                       nframes, rows, cols, min_change, max_hot, d_count, d_pos, d_changes, nch, list);
+    if (max_hot > 0) {
+        hipLaunchKernelGGL(hot_lists_init_kernel, dim3((unsigned)((g.npix + 255) / 256)), dim3(256), 0, st,
+                           (const unsigned *)d_changes, d_head, g.npix);
+        hipLaunchKernelGGL(hot_lists_build_kernel, dim3((unsigned)((g.nnodes + 255) / 256)), dim3(256), 0, st,
+                           (const unsigned *)d_changes, g.pix[0], (unsigned)g.nnodes, d_head, d_next);
+        hipLaunchKernelGGL(hot_patch_kernel, dim3((unsigned)(((size_t)nframes * max_hot + 255) / 256)), dim3(256), 0, st,
+                           (const unsigned *)d_changes, (const unsigned *)nch, (const uint4 *)list, nframes, max_hot,
+                           (const int32_t *)d_head, (const int32_t *)d_next, g.skipped, g.rowmap, g.rows_t, g.rows_t16,
+                           (long long)g.ld_t, g.sum, g.sumsq);
+    }
     UPSP_HIP_CHECK(hipGetLastError());
     return UPSP_OK;
 }

@@ -38,18 +38,23 @@ int launch_hot_fix(uint16_t *d_frames, int nframes, int rows, int cols, int thre
 int launch_gather(const PipelineGather &g, hipStream_t st);
 // streamed scan + projection (one camera, no weights, u16 frames, no image stage): frames.hip
 size_t tilemap_tiles(size_t npix);
+// d_order: optional, 4 * (tiles + 1) words; its first `tiles` words = the order pass A visits the tiles in
 int launch_amap_build(const int32_t *d_pix, size_t nnodes, size_t npix, uint8_t *d_flag, unsigned *d_cnt,
-                      unsigned *d_off, int32_t *d_node_k, hipStream_t st);
-int stream_frames_max();
+                      unsigned *d_off, int32_t *d_node_k, unsigned *d_order, hipStream_t st);
+int stream_frames_max();   // frames per pass B of the multi-camera streamed schedule (compact row pitch there)
+int group_frames_max();    // frames per pass B (whole rows) of the one-camera streamed schedule
 int launch_scan_compact(uint16_t *d_frames, size_t npix, int nframes, bool hot, int thresh, int max_hot,
-                        const uint8_t *d_flag, const unsigned *d_off, uint16_t *d_compact, int col,
-                        unsigned *d_count, unsigned *d_pos, hipStream_t st);
+                        const uint8_t *d_flag, const unsigned *d_off, const unsigned *d_order, uint16_t *d_compact,
+                        unsigned cpitch, int col, unsigned *d_count, unsigned *d_pos, hipStream_t st);
 int launch_node_stream(const PipelineGather &g, const int32_t *d_node_k, const uint16_t *d_compact, hipStream_t st);
+int launch_node_rows(const PipelineGather &g, const int32_t *d_node_k, const uint16_t *d_compact, unsigned cpitch,
+                     hipStream_t st);
 int launch_node_stream_multi(const PipelineGather &g, const int32_t *const *d_node_k,
                              const uint16_t *const *d_compact, hipStream_t st);
+size_t hot_changes_words(int nframes, int max_hot);   // size of d_changes for launch_hot_fixup
 int launch_hot_fixup(const PipelineGather &g, uint16_t *d_frames, int nframes, int rows, int cols,
                      int min_change, int max_hot, unsigned *d_count, const unsigned *d_pos,
-                     unsigned *d_changes, unsigned cap, hipStream_t st);
+                     unsigned *d_changes, int32_t *d_head, int32_t *d_next, hipStream_t st);
 int launch_skipped(int ncams, size_t nnodes, const int32_t *const *d_pix, uint8_t *d_skipped,
                    hipStream_t st);
 int launch_finals(const double *sum, const double *sumsq, size_t nnodes, uint64_t nframes,

@@ -36,10 +36,15 @@ struct upsp_pipeline {
     // streamed scan + projection: active-pixel map (built on first use after a projection change),
     // compact pixel-series buffer of a sub-batch, change list of the hot-pixel fix-up
     uint8_t *d_aflag = nullptr;
-    unsigned *d_tile_off = nullptr, *d_tile_cnt = nullptr;
+    unsigned *d_tile_off = nullptr, *d_tile_cnt = nullptr, *d_tile_order = nullptr;
     int32_t *d_node_k = nullptr;
     uint16_t *d_compact = nullptr;
-    unsigned *d_changes = nullptr;
+    size_t compact_bytes = 0;        // allocated size of d_compact
+    unsigned n_active = 0;           // active pixels of the current map (read back once per map build)
+    unsigned *h_active = nullptr;    // pinned word for that read-back
+    unsigned *d_changes = nullptr;   // hot-pixel change list of a call (frames.hip: hot_changes_words)
+    size_t changes_words = 0;
+    int32_t *d_head = nullptr, *d_next = nullptr;   // pixel -> nodes lists of the hot-pixel re-projection
     bool tilemap_valid = false;
     // the same per camera for the multi-camera streamed schedule
     uint8_t *m_aflag[kMaxCams] = {nullptr};
@@ -187,9 +192,13 @@ void upsp_pipeline_destroy(upsp_pipeline *p)
     free_dev(p->d_aflag);
     free_dev(p->d_tile_off);
     free_dev(p->d_tile_cnt);
+    free_dev(p->d_tile_order);
     free_dev(p->d_node_k);
     free_dev(p->d_compact);
     free_dev(p->d_changes);
+    free_dev(p->d_head);
+    free_dev(p->d_next);
+    if (p->h_active) (void)hipHostFree(p->h_active);
     for (int c = 0; c < kMaxCams; ++c) {
         free_dev(p->m_aflag[c]);
         free_dev(p->m_tile_off[c]);
@@ -371,7 +380,7 @@ int upsp_pipeline_finalize(upsp_pipeline *p, uint64_t nframes_total, float *d_av
                          (hipStream_t)stream);
 }
 
-static int process_impl(upsp_pipeline *p, const uint16_t *const *d_frames, int nframes,
+static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes,
                         int64_t first_frame, float *d_rows, float *d_rows_t, uint16_t *d_rows_t16,
                         int64_t ld_t, int64_t col0, float *d_warps, void *stream)
 {
@@ -382,6 +391,9 @@ static int process_impl(upsp_pipeline *p, const uint16_t *const *d_frames, int n
         // u16 pixels (raw or warped frames; the patch and filter stages produce floats)
         if (p->ncams != 1 || p->d_weight[0] || p->opts.patch || p->opts.filter)
             return fail(UPSP_ERR_INVALID, "u16 series needs one camera, no weights, no patch / filter stage");
+        // NaN has no u16 encoding: rows of nodes no camera sees must not be stored (the caller keeps them
+        // out with a row map; rows of skipped nodes that the map does store are written as 0)
+        if (!p->d_rowmap) return fail(UPSP_ERR_INVALID, "u16 series needs a row map (upsp_pipeline_set_row_map) that leaves out the skipped nodes");
         if (ld_t < col0 + nframes) return fail(UPSP_ERR_INVALID, "ld_t too small");
     }
     hipStream_t st = (hipStream_t)stream;
@@ -441,21 +453,39 @@ static int process_impl(upsp_pipeline *p, const uint16_t *const *d_frames, int n
                           p->nnodes < ((size_t)1 << 31);
     const bool fused = fused_ok && fused_mode != 2;
     if (fused) {
-        constexpr unsigned kChangeCap = 4096;
         if (!p->tilemap_valid) {
             const size_t ntiles = tilemap_tiles(npix);
             if (!p->d_aflag) UPSP_HIP_CHECK(hipMalloc(&p->d_aflag, npix));
             if (!p->d_tile_off) UPSP_HIP_CHECK(hipMalloc(&p->d_tile_off, sizeof(unsigned) * (ntiles + 1)));
             if (!p->d_tile_cnt) UPSP_HIP_CHECK(hipMalloc(&p->d_tile_cnt, sizeof(unsigned) * ntiles));
             if (!p->d_node_k) UPSP_HIP_CHECK(hipMalloc(&p->d_node_k, sizeof(int32_t) * p->nnodes));
-            // one series of stream_frames_max() u16 per active pixel; there are at most min(nodes, pixels) of them
-            if (!p->d_compact)
-                UPSP_HIP_CHECK(hipMalloc(&p->d_compact, (size_t)2 * stream_frames_max() * std::min(p->nnodes, npix)));
-            if (!p->d_changes) UPSP_HIP_CHECK(hipMalloc(&p->d_changes, sizeof(unsigned) * (4 + 4 * kChangeCap)));
+            if (!p->d_tile_order) UPSP_HIP_CHECK(hipMalloc(&p->d_tile_order, sizeof(unsigned) * 4 * (ntiles + 1)));
+            if (!p->h_active) UPSP_HIP_CHECK(hipHostMalloc(&p->h_active, sizeof(unsigned), hipHostMallocDefault));
             rc = launch_amap_build(p->d_pix[0], p->nnodes, npix, p->d_aflag, p->d_tile_cnt, p->d_tile_off,
-                                   p->d_node_k, st);
+                                   p->d_node_k, p->d_tile_order, st);
             if (rc != UPSP_OK) return rc;
+            // the compact buffer is sized from the number of active pixels: one read-back per projection
+            UPSP_HIP_CHECK(hipMemcpyAsync(p->h_active, p->d_tile_off + ntiles, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+            UPSP_HIP_CHECK(hipStreamSynchronize(st));
+            p->n_active = *p->h_active;
             p->tilemap_valid = true;
+        }
+        // Frames per group (one pass A launch + one pass B launch): as many as the compact buffer may hold,
+        // at most group_frames_max().  One series of `cp` u16 per active pixel.
+        const size_t budget = (size_t)(p->opts.compact_mb > 0 ? p->opts.compact_mb : 2048) << 20;
+        const size_t nact = std::max<size_t>(p->n_active, 1);
+        int S = (int)std::min<size_t>((size_t)group_frames_max(), (budget / (2 * nact)) / 64 * 64);
+        S = std::max(S, 64);
+        const unsigned cp = (unsigned)((std::min(nframes, S) + 63) / 64 * 64);
+        if (nact * cp * 2 > p->compact_bytes) {
+            if (p->d_compact) {
+                UPSP_HIP_CHECK(hipStreamSynchronize(st));    // launches queued earlier may still use it
+                free_dev(p->d_compact);
+                p->d_compact = nullptr;
+                p->compact_bytes = 0;
+            }
+            UPSP_HIP_CHECK(hipMalloc(&p->d_compact, nact * cp * 2));
+            p->compact_bytes = nact * cp * 2;
         }
         PipelineGather g;
         g.ncams = 1;
@@ -468,26 +498,37 @@ static int process_impl(upsp_pipeline *p, const uint16_t *const *d_frames, int n
         g.pix[0] = p->d_pix[0];
         g.ld_t = ld_t;
         const bool hot = p->opts.hot_enable != 0;
-        if (hot) rc = ensure_hot(p, nframes);   // one counter per frame of the CALL
-        uint16_t *fr = const_cast<uint16_t *>(d_frames[0]);
-        // pass A per 64-frame sub-batch, pass B once per group of stream_frames_max() frames
-        const int S = stream_frames_max();
+        if (hot) {
+            rc = ensure_hot(p, nframes);   // one counter per frame of the CALL
+            if (rc != UPSP_OK) return rc;
+            const size_t words = hot_changes_words(nframes, p->opts.hot_max);
+            if (words > p->changes_words) {
+                if (p->d_changes) UPSP_HIP_CHECK(hipStreamSynchronize(st));
+                free_dev(p->d_changes);
+                p->d_changes = nullptr;
+                p->changes_words = 0;
+                UPSP_HIP_CHECK(hipMalloc(&p->d_changes, sizeof(unsigned) * words));
+                p->changes_words = words;
+            }
+            if (!p->d_head) UPSP_HIP_CHECK(hipMalloc(&p->d_head, sizeof(int32_t) * npix));
+            if (!p->d_next) UPSP_HIP_CHECK(hipMalloc(&p->d_next, sizeof(int32_t) * p->nnodes));
+        }
+        uint16_t *fr = d_frames[0];
         for (int s0 = 0; s0 < nframes && rc == UPSP_OK; s0 += S) {
             const int ns = std::min(S, nframes - s0);
-            for (int f0 = s0; f0 < s0 + ns && rc == UPSP_OK; f0 += B)
-                rc = launch_scan_compact(fr + (size_t)f0 * npix, npix, std::min(B, s0 + ns - f0), hot, p->opts.hot_thresh,
-                                         p->opts.hot_max, p->d_aflag, p->d_tile_off, p->d_compact, f0 - s0,
-                                         hot ? p->d_hot_count + f0 : nullptr, hot ? p->d_hot_pos + (size_t)f0 * 64 : nullptr, st);
+            rc = launch_scan_compact(fr + (size_t)s0 * npix, npix, ns, hot, p->opts.hot_thresh, p->opts.hot_max, p->d_aflag,
+                                     p->d_tile_off, p->d_tile_order, p->d_compact, cp, 0, hot ? p->d_hot_count + s0 : nullptr,
+                                     hot ? p->d_hot_pos + (size_t)s0 * 64 : nullptr, st);
             g.nframes = ns;
             g.rows_t = d_rows_t ? d_rows_t + col0 + s0 : nullptr;
             g.rows_t16 = d_rows_t16 ? d_rows_t16 + col0 + s0 : nullptr;
-            if (rc == UPSP_OK) rc = launch_node_stream(g, p->d_node_k, p->d_compact, st);
+            if (rc == UPSP_OK) rc = launch_node_rows(g, p->d_node_k, p->d_compact, cp, st);
         }
         if (rc == UPSP_OK && hot) {   // repair + re-projection of the few frames that hold hot pixels
             g.rows_t = d_rows_t ? d_rows_t + col0 : nullptr;
             g.rows_t16 = d_rows_t16 ? d_rows_t16 + col0 : nullptr;
             rc = launch_hot_fixup(g, fr, nframes, p->height, p->width, p->opts.hot_min_change, p->opts.hot_max,
-                                  p->d_hot_count, p->d_hot_pos, p->d_changes, kChangeCap, st);
+                                  p->d_hot_count, p->d_hot_pos, p->d_changes, p->d_head, p->d_next, st);
         }
         return rc;
     }
@@ -510,7 +551,7 @@ static int process_impl(upsp_pipeline *p, const uint16_t *const *d_frames, int n
             if (!p->m_compact[c])
                 UPSP_HIP_CHECK(hipMalloc(&p->m_compact[c], (size_t)2 * stream_frames_max() * std::min(p->nnodes, npix)));
             rc = launch_amap_build(p->d_pix[c], p->nnodes, npix, p->m_aflag[c], p->d_tile_cnt, p->m_tile_off[c],
-                                   p->m_node_k[c], st);
+                                   p->m_node_k[c], nullptr, st);
             if (rc != UPSP_OK) return rc;
             p->m_valid[c] = true;
         }
@@ -528,7 +569,7 @@ static int process_impl(upsp_pipeline *p, const uint16_t *const *d_frames, int n
         for (int s0 = 0; s0 < nframes && rc == UPSP_OK; s0 += S) {
             const int ns = std::min(S, nframes - s0);
             for (int c = 0; c < p->ncams && rc == UPSP_OK; ++c) {
-                uint16_t *fr = const_cast<uint16_t *>(d_frames[c]);
+                uint16_t *fr = d_frames[c];
                 for (int f0 = s0; f0 < s0 + ns && rc == UPSP_OK; f0 += B) {
                     const int nb = std::min(B, s0 + ns - f0);
                     if (p->opts.hot_enable) {
@@ -540,7 +581,8 @@ static int process_impl(upsp_pipeline *p, const uint16_t *const *d_frames, int n
                     }
                     if (rc == UPSP_OK)
                         rc = launch_scan_compact(fr + (size_t)f0 * npix, npix, nb, false, 0, 0, p->m_aflag[c],
-                                                 p->m_tile_off[c], p->m_compact[c], f0 - s0, nullptr, nullptr, st);
+                                                 p->m_tile_off[c], nullptr, p->m_compact[c], (unsigned)stream_frames_max(), f0 - s0,
+                                                 nullptr, nullptr, st);
                 }
             }
             g.nframes = ns;
@@ -567,7 +609,7 @@ static int process_impl(upsp_pipeline *p, const uint16_t *const *d_frames, int n
         g.rows_t16 = d_rows_t16 ? d_rows_t16 + col0 + f0 : nullptr;
         g.ld_t = ld_t;
         for (int c = 0; c < p->ncams && rc == UPSP_OK; ++c) {
-            uint16_t *frames = const_cast<uint16_t *>(d_frames[c]) + (size_t)f0 * npix;
+            uint16_t *frames = d_frames[c] + (size_t)f0 * npix;
             if (p->opts.hot_enable) {  // psp_process.cpp:1772
                 rc = ensure_hot(p, nb);
                 if (rc == UPSP_OK)
@@ -607,7 +649,7 @@ static int process_impl(upsp_pipeline *p, const uint16_t *const *d_frames, int n
     return rc;
 }
 
-int upsp_pipeline_process(upsp_pipeline *p, const uint16_t *const *d_frames, int nframes,
+int upsp_pipeline_process(upsp_pipeline *p, uint16_t *const *d_frames, int nframes,
                           int64_t first_frame, float *d_rows, float *d_rows_t, int64_t ld_t,
                           int64_t col0, float *d_warps, void *stream)
 {
@@ -615,7 +657,7 @@ int upsp_pipeline_process(upsp_pipeline *p, const uint16_t *const *d_frames, int
                         d_warps, stream);
 }
 
-int upsp_pipeline_process_u16(upsp_pipeline *p, const uint16_t *const *d_frames, int nframes,
+int upsp_pipeline_process_u16(upsp_pipeline *p, uint16_t *const *d_frames, int nframes,
                               int64_t first_frame, uint16_t *d_series_u16, int64_t ld_t,
                               int64_t col0, float *d_warps, void *stream)
 {

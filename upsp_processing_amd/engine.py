@@ -250,13 +250,18 @@ def apportion(value, nbins):
     return list(st), list(ex)
 
 
-def series_ld(nframes):
+def series_ld(nframes, whole_rows=False):
     """Row pitch (in floats) for a node-major time-series buffer [N, nframes]: rows start on
-    256-byte boundaries, so every 64-frame row segment the gather writes is two whole 128-B
-    lines, and the pitch is an odd multiple of 256 B, so consecutive rows do not map to the same
-    HBM channels (a 4-KiB pitch measured 8 % slower than 4352 B on MI355X).  Pass
-    `torch.empty((N, ld))[:, :nframes]` as rows_t."""
+    256-byte boundaries.  Callers that fill the rows in column chunks (process(..., col0=...) per
+    64..256 frames, or any schedule other than the streamed one) get an odd multiple of 256 B, so
+    that the same piece of consecutive rows does not map to the same HBM channels (a 4-KiB pitch
+    measured 8 % slower than 4352 B for 256-B pieces on MI355X).  whole_rows=True: one process()
+    call writes every row piece whole (streamed schedule, <= 1024 frames per call): the plain
+    multiple of 256 B is best there (tools/probe/store_shapes.hip: 5.7-5.9 TB/s at 4096 B against
+    5.0-5.2 at 4352 B).  Pass `torch.empty((N, ld))[:, :nframes]` as rows_t."""
     ld = (int(nframes) + 63) // 64 * 64
+    if whole_rows:
+        return ld
     return ld + 64 if (ld // 64) % 2 == 0 else ld
 
 
