@@ -15,12 +15,18 @@ ray cast + projection only):
 with mesh, BVH, camera and all frames already resident in HBM.  Frames shard over
 ranks (weak scaling: every GPU processes --frames frames).
 
-Prints ONE JSON line on rank 0.  `value` = frames/s over the whole job;
-`mrays_per_s` = node rays/s of the projection-build kernel alone.
+`python bench.py --gpus N` with N > 1 and no rank environment starts N rank processes itself
+(torch.distributed.run, one per GPU, RCCL) before anything touches the GPU; under an external
+launcher (RANK / WORLD_SIZE set) it is one of the ranks.  Rank 0 prints ONE JSON line.
+`value` = frames/s over the whole job; `mrays_per_s` = reference-equivalent node rays/s of the
+projection build (rays the reference would cast / build time; most retry rays are decided here by
+the occluder witness instead of a traversal -- `rays_cast_per_step` counts what is really cast).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -48,21 +54,36 @@ def parse():
                     help="run the chunked / pipelined-exchange frame loop of the N>1 path on one GPU")
     ap.add_argument("--f32-wire", action="store_true",
                     help="N>1 / --force-chunked: exchange the series as f32 instead of u16")
-    ap.add_argument("--overlap", action="store_true",
-                    help="hot-pixel scan of all frames on a side stream, concurrent with the projection "
-                         "build (measured slower on MI355X: the gathers then miss the Infinity Cache)")
     ap.add_argument("--two-kernel", action="store_true",
-                    help="frame loop as scan kernel + gather kernel instead of the (default) streamed two-pass "
-                         "schedule (scan + compact pixel series, then one pass over the nodes)")
+                    help="frame loop as scan kernel + gather kernel per 64 frames instead of the (default) "
+                         "streamed two-pass schedule (pass A: scan + compact pixel series, pass B: whole rows)")
     ap.add_argument("--model", default="quad", choices=["quad", "uv"],
                     help="quad: cube-sphere tunnel model (valence <= 6); uv: UV-sphere model with "
                          "1000-valent polar fans (worst case for per-ray traversal length)")
+    ap.add_argument("--fill-frame", action="store_true",
+                    help="1 M-triangle sphere filling the frame instead of the tunnel model: ~0.2 M visible nodes on "
+                         "as many active pixels, so the compact pixel series (2 KB per active pixel and 1000 frames) "
+                         "no longer fit the Infinity Cache")
+    ap.add_argument("--plain-frames", action="store_true",
+                    help="round-1 frame content (no background, fiducial discs or hot pixels)")
     return ap.parse_args()
 
 
-def cpu_baseline(verts, tris, cam_dict, size, nframes_step, pix_full, sample_frames=256):
-    """Oracle (CPU restatement, kind 'port') on a bounded sample of the same workload."""
-    from concurrent.futures import ThreadPoolExecutor
+def spawn_ranks(n):
+    """`--gpus N` without a rank environment: start the N ranks as fresh child processes (nothing in
+    this process has touched the GPU) and pass rank 0's line through."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def cpu_baseline(verts, tris, cam_dict, size, nframes_step, sample):
+    """Oracle (CPU restatement, kind 'port') on a bounded sample of the same workload: the projection
+    build on the full model (OpenMP over node blocks like psp_process.cpp:218-260) and the frame loop
+    (OpenMP over frames like psp_process.cpp:1742-1851) on the first `len(sample)` frames of the step."""
     from oracle import oracle as orc
     from upsp_processing_amd import synthetic as syn, engine
     cores = os.cpu_count() or 1
@@ -72,46 +93,42 @@ def cpu_baseline(verts, tris, cam_dict, size, nframes_step, pix_full, sample_fra
     obv = orc.OracleBVH(s9)
     t_build = time.perf_counter() - t0
     cam = orc.make_camera(cam_dict["K"], cam_dict["dist"], cam_dict["R"], cam_dict["t"], size, size)
-    # projection build on a node sample (every k-th node), all cores (OpenMP)
-    k = 1
-    dn = np.zeros(verts.shape[0], np.uint8)
-    dn[::k] = 1
     t0 = time.perf_counter()
-    r = orc.create_projection(obv, cam, verts, nrm, tn, engine.oblique_threshold(70.0), datanode=dn,
-                              threads=cores)
+    r = orc.create_projection(obv, cam, verts, nrm, tn, engine.oblique_threshold(70.0), threads=cores)
     t_proj = time.perf_counter() - t0
     mrays = r["nrays"] / t_proj / 1e6
-    # the frame sample gathers through the complete projection (the index array the
-    # GPU step produced -- input data for the timed CPU loop, parity-checked in tests/)
-    pix = np.ascontiguousarray(pix_full, dtype=np.int32)
-    frames = syn.synth_frames_numpy(sample_frames, size, size, seed=99)
-    sk = orc.skipped_nodes(pix)
-
-    def one(f):
-        img, _ = orc.fix_hot_pixels(frames[f])
-        sol = orc.project_frame(img, pix, None)
-        sol[sk] = np.nan
-        return sol
-
-    s, ss = np.zeros(pix.size), np.zeros(pix.size)
+    pix = np.ascontiguousarray(r["pix"], dtype=np.int32)
+    frames = sample.copy()
     t0 = time.perf_counter()
-    with ThreadPoolExecutor(cores) as ex:
-        for sol in ex.map(one, range(sample_frames)):
-            orc.accumulate(sol, s, ss)
+    _, s, ss = orc.frame_loop(frames, pix, want_rows=False, threads=cores)
     t_frames = time.perf_counter() - t0
-    per_frame = t_frames / sample_frames
-    t_proj_full = t_proj * k
-    fps = nframes_step / (t_proj_full + per_frame * nframes_step)
-    return {"value": fps, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "oracle/: projection build on every %d-th node (%d rays, %.2f s, OpenMP) "
-                      "+ %d frames of the frame loop (%.3f s); extrapolated to the %d-frame step"
-                      % (k, r["nrays"], t_proj, sample_frames, t_frames, nframes_step),
-            "mrays_per_s": mrays, "frame_loop_frames_per_s": 1.0 / per_frame,
-            "bvh_build_s": t_build}
+    # the loop has a fixed cost per run (every thread allocates and merges its own 2 x N doubles,
+    # psp_process.cpp:1744-1745, 1845-1850): a second, shorter run separates it from the per-frame cost
+    n_short = max(1, frames.shape[0] // 4)
+    short = sample[:n_short].copy()
+    t0 = time.perf_counter()
+    orc.frame_loop(short, pix, want_rows=False, threads=cores)
+    t_short = time.perf_counter() - t0
+    per_frame = max(t_frames - t_short, 1e-9) / max(frames.shape[0] - n_short, 1)
+    t_fixed = max(t_frames - per_frame * frames.shape[0], 0.0)
+    # a few rows for the parity check of the series (single thread, rows kept)
+    few = sample[:8].copy()
+    rows8, _, _ = orc.frame_loop(few, pix, want_rows=True, threads=1)
+    fps = nframes_step / (t_proj + t_fixed + per_frame * nframes_step)
+    out = {"value": fps, "unit": "frames/s", "cores": cores, "kind": "port",
+           "sample": "oracle/ (C, OpenMP, %d threads): projection build on the full model (%d rays, %.2f s) "
+                     "+ %d and %d frames of the frame loop (%.3f s, %.3f s -> %.2f ms per frame + %.2f s per run); "
+                     "extrapolated to the %d-frame step"
+                     % (cores, r["nrays"], t_proj, frames.shape[0], n_short, t_frames, t_short, per_frame * 1e3, t_fixed,
+                        nframes_step),
+           "mrays_per_s": mrays, "frame_loop_frames_per_s": 1.0 / per_frame, "bvh_build_s": t_build}
+    return out, dict(pix=pix, nrays=int(r["nrays"]), sum=s, sumsq=ss, rows8=rows8, frames_fixed=frames)
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a.gpus))
     import torch
     import torch.distributed as dist
     from upsp_processing_amd import _capi, engine, synthetic as syn, distributed as D
@@ -119,6 +136,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d" % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     # rehearsal of the N > 1 code path on a one-GPU box: UPSP_BENCH_BACKEND=gloo with every rank on
@@ -140,6 +159,8 @@ def main():
     if a.small:
         verts, tris = syn.tunnel_model_quad(64, 24)
         F = min(F, 64)
+    elif a.fill_frame:
+        verts, tris = syn.cube_sphere(289, 6.0)   # 1 002 252 triangles, 501 128 nodes: a sphere that fills the frame
     elif a.model == "uv":
         verts, tris = syn.tunnel_model()          # 1 001 520 triangles, 500 766 nodes, polar fans
     else:
@@ -147,7 +168,7 @@ def main():
     s9, tn = syn.soup(verts, tris)
     nrm = syn.node_normals(verts, tris)
     N = verts.shape[0]
-    cd = syn.pinhole_camera(size, size, center=(0, 0, 20), half_extent=6.0)
+    cd = syn.pinhole_camera(size, size, center=(0, 0, 20), half_extent=6.0, fill=0.95 if a.fill_frame else 0.7)
     cam = _capi.make_camera(cd["K"], cd["dist"], cd["R"], cd["t"], size, size)
 
     bvh = engine.BVH(s9)
@@ -155,108 +176,83 @@ def main():
     d_nrm = torch.as_tensor(nrm).cuda()
     d_tn = torch.as_tensor(tn).cuda()
     bvh.set_tri_nodes(d_tn, N)      # createBVH(model, triNodes): once per model, like the BVH itself
+    # static content of the frames: model silhouette / background, fiducial discs
+    proj0 = engine.build_projection(bvh, cam, d_nodes, d_nrm, d_tn, 70.0, counts=False)
+    pix0 = proj0["pix"].cpu().numpy()
+    layout = None if a.plain_frames else syn.scene_layout(pix0, size, size)
+    n_active = int(np.unique(pix0[pix0 >= 0]).size)
     # this rank's frames (global frame index = rank*F + f), resident in HBM
     frames = torch.empty((F, size, size), dtype=torch.uint16, device="cuda")
     chunk = 50
     for f0 in range(0, F, chunk):
-        syn.synth_frames_torch(min(chunk, F - f0), size, size, first=rank * F + f0, out=frames[f0:f0 + chunk])
+        syn.synth_frames_torch(min(chunk, F - f0), size, size, first=rank * F + f0, out=frames[f0:f0 + chunk],
+                               layout=layout, hot=not a.plain_frames)
+    n_sample = min(F, 256)
+    sample = (frames[:n_sample].cpu().view(torch.int16).numpy().view(np.uint16).copy()
+              if (rank == 0 and world == 1 and not a.no_cpu_baseline) else None)   # before any in-place repair
     shard = D.Shard(F * world, N, rank, world)
     pipe = engine.FramePipeline(1, size, size, N, registration=int(a.registration),
                                 fused_scan=2 if a.two_kernel else 0)
     if a.registration:
         pipe.set_reference(0, frames[0].to(torch.float32))   # raw first frame as ECC template
-    # node-major time series [N, F] with the padded row pitch engine.series_ld() recommends
-    ld = int(os.environ.get("UPSP_BENCH_LD", "0")) or engine.series_ld(F, whole_rows=True)
-    rows_t = (torch.empty((N, ld), dtype=torch.float32, device="cuda")[:, :F]
-              if not (world > 1 or a.force_chunked) else None)
+    # node-major time series [N, F]; one process() call writes every row piece whole
+    streamed = not (a.two_kernel or a.registration)
+    ld = int(os.environ.get("UPSP_BENCH_LD", "0")) or engine.series_ld(F, whole_rows=streamed)
+    chunked = world > 1 or a.force_chunked          # --force-chunked: exercise the N>1 loop on one GPU
+    rows_t = torch.empty((N, ld), dtype=torch.float32, device="cuda")[:, :F] if not chunked else None
     torch.cuda.synchronize()
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
     t_ray, t_frames, t_xchg = [], [], []
-    nrays_last = [0]
-    primary_rays_last, retry_nodes_last = [0], [0]
+    last_pix = [None]
 
     # N > 1: the frame loop runs in K chunks and the all-to-all of chunk k is issued
     # asynchronously while chunk k+1 is being processed (distributed.TimeSeriesExchange)
-    chunked = world > 1 or a.force_chunked          # --force-chunked: exercise the N>1 loop on one GPU
     K = 4 if chunked else 1
     exch = D.TimeSeriesExchange(shard, K) if chunked else None
-    chunk_bufs = ([torch.empty((N, exch.my_chunk(k)[1]), dtype=torch.float32, device="cuda")
-                   for k in range(K)] if chunked else None)
     # one camera, no weights, no filter: the series values are exact 16-bit integers, so the
     # travelling rows are produced and sent as u16 (half the bytes) and widened by the receiver
-    chunk_bufs16 = ([torch.empty((N, exch.my_chunk(k)[1]), dtype=torch.uint16, device="cuda")
-                     for k in range(K)] if chunked else None)
-
+    u16_wire = chunked and not a.f32_wire
+    chunk_bufs = ([torch.empty((N, exch.my_chunk(k)[1]), dtype=torch.uint16 if u16_wire else torch.float32,
+                               device="cuda") for k in range(K)] if chunked else None)
     ev_log = []
-    mode = {"packed": True, "u16": not a.f32_wire}
-    # fix_hot_pixels does not depend on the projection: with --overlap its streaming scan of every
-    # frame runs on a side stream while the (latency-bound) projection build occupies the main
-    # stream and the gathers wait for both.  Same results (tests/test_frames_gpu.py).  Measured on
-    # MI355X it LOSES (step 1.68 -> 1.86 ms): the gathers then read frames from HBM instead of the
-    # Infinity Cache (39 -> 59 us per launch) and the traversal kernels slow down by a third under
-    # the scan's traffic -- so it is off by default.
-    overlap = a.overlap and not a.registration
-    side = torch.cuda.Stream() if overlap else None
+    first_step = [True]
 
     def step(record):
         e = [ev() for _ in range(4)]
         e[0].record()
-        main = torch.cuda.current_stream()
-        if overlap:
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                pipe.fix_hot_pixels(frames)
         proj = engine.build_projection(bvh, cam, d_nodes, d_nrm, d_tn, 70.0, counts=False)   # no host sync
         e[1].record()
         pipe.reset()
         pipe.set_projection(0, proj["pix"])
-        if overlap:
-            main.wait_stream(side)
         if not chunked:
-            pipe.process(frames, first_frame=rank * F, rows_t=rows_t, want_rows=False, hot_fixed=overlap)
+            pipe.process(frames, first_frame=rank * F, rows_t=rows_t, want_rows=False)
         else:
             exch.k = 0
-            packed = mode["packed"]
-            if packed:
-                # rows of nodes no camera sees are NaN on every rank: they do not travel, and the
-                # gather writes the travelling rows packed (row map) straight into the send buffers
-                try:
-                    exch.set_skipped(engine.skipped_nodes(proj["pix"], want_count=False)[0])
-                    pipe.set_row_map(exch.row_map())
-                except Exception as ex:      # never exercised on >1 GPU before the scaling run: keep it alive
-                    print("bench: packed exchange unavailable (%r), sending every row" % (ex,), file=sys.stderr)
-                    mode["packed"] = packed = False
-                    exch.set_skipped(None)
-                    pipe.set_row_map(None)
-            nrows = exch.packed_rows() if packed else N
+            # rows of nodes no camera sees are NaN on every rank: they do not travel, and pass B writes
+            # the travelling rows packed (row map) straight into the send buffers.  The projection is
+            # rebuilt every step and is the same every step: the travelling set is derived (one host
+            # read of W counters) in the first step and only verified on the device afterwards.
+            exch.set_skipped(engine.skipped_nodes(proj["pix"], want_count=False)[0], assume_same=not first_step[0])
+            first_step[0] = False
+            pipe.set_row_map(exch.row_map())
+            nrows = exch.packed_rows()
             for k in range(K):
                 c0, fc = exch.my_chunk(k)
-                u16 = packed and mode["u16"]
-                buf = (chunk_bufs16 if u16 else chunk_bufs)[k][:nrows]
+                buf = chunk_bufs[k][:nrows]
                 if fc:
-                    try:
-                        pipe.process(frames[c0:c0 + fc], first_frame=rank * F + c0, rows_t=buf, want_rows=False,
-                                     hot_fixed=overlap)
-                    except _capi.UpspError as ex:
-                        if not u16:
-                            raise
-                        print("bench: u16 series refused (%r), sending f32" % (ex,), file=sys.stderr)
-                        mode["u16"] = False
-                        buf = chunk_bufs[k][:nrows]
-                        pipe.process(frames[c0:c0 + fc], first_frame=rank * F + c0, rows_t=buf, want_rows=False,
-                                     hot_fixed=overlap)
-                exch.submit(buf, packed=packed)
+                    pipe.process(frames[c0:c0 + fc], first_frame=rank * F + c0, rows_t=buf, want_rows=False)
+                exch.submit(buf, packed=True)
         e[2].record()
         s, ss = pipe.accumulators()
         D.allreduce_sums(s, ss)
         if chunked:
-            series = exch.finish()
+            exch.finish()
         avg, rms = pipe.finalize(F * world)
         e[3].record()
         if record:                      # events are read after the timed loop: no host sync inside it
             ev_log.append(e)
-            nrays_last[1:] = [proj["pix"]]
+            last_pix[0] = proj["pix"]
         return avg
 
     for _ in range(a.warmup):
@@ -273,18 +269,21 @@ def main():
         step(True)
     barrier()
     dt = time.perf_counter() - t0
+    if chunked:
+        exch.verify()                   # the travelling set did not change between the steps
     for e in ev_log:
         t_ray.append(e[0].elapsed_time(e[1]))
         t_frames.append(e[1].elapsed_time(e[2]))
         t_xchg.append(e[2].elapsed_time(e[3]))
     pc = engine.projection_counts(bvh)
-    nrays_last[0], primary_rays_last[0], retry_nodes_last[0] = pc["nrays"], pc["primary_rays"], pc["retry_nodes"]
+    nrays, primary_rays, retry_nodes = pc["nrays"], pc["primary_rays"], pc["retry_nodes"]
     # the same K steps once more with the library's per-kernel HIP-event timers on
     # (two extra events per launch on the launch stream; kept out of the headline time)
     _capi.timing_enable(True)
     for _ in range(a.steps):
         step(False)
     barrier()
+    _capi.timing_enable(False)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -295,41 +294,46 @@ def main():
     fps = total_frames * a.steps / dt
     ray_ms = float(np.mean(t_ray))
     frm_ms = float(np.mean(t_frames))
-    mrays = nrays_last[0] / (ray_ms * 1e-3) / 1e6
+    mrays = nrays / (ray_ms * 1e-3) / 1e6
 
     # per-kernel durations: HIP events recorded by the library on the launch stream
     # during the timed steps (upsp_timing_enable / upsp_timing_report)
     timing = _capi.timing_report()
     kernels = {}
-    n_retry_rays = 6 * retry_nodes_last[0]
+    n_retry_rays = 6 * retry_nodes
     scene_bytes = bvh.info["device_bytes"]
-    gather_launches = -(-F // 64) if not chunked else sum(-(-exch.my_chunk(k)[1] // 64) for k in range(K))
-    stream_launches = -(-F // 256) if not chunked else sum(-(-exch.my_chunk(k)[1] // 256) for k in range(K))
-    row_launches = -(-F // 1024) if not chunked else sum(-(-exch.my_chunk(k)[1] // 1024) for k in range(K))
-    series_rows = exch.packed_rows() if (chunked and mode["packed"]) else N
-    series_esz = 2 if (chunked and mode["packed"] and mode["u16"]) else 4
+    my_chunks = [exch.my_chunk(k)[1] for k in range(K)] if chunked else [F]
+    gather_launches = sum(-(-c // 64) for c in my_chunks)
+    row_launches = sum(-(-c // 1024) for c in my_chunks)
+    series_rows = exch.packed_rows() if chunked else N
+    series_esz = 2 if u16_wire else 4
+    npx = size * size
     per_step_bytes = {
         # 40 B per ray (24 B ray + 16 B hit record) + the scene once per launch
-        "projection_kernel<primary>": primary_rays_last[0] * 40 + scene_bytes,
+        "projection_kernel<primary>": primary_rays * 40 + scene_bytes,
         # the occluder-witness pass sees every retry ray (ray + verdict); the traversal that follows
         # only the few it leaves undecided (count known to the device only) plus the scene
         "witness_kernels": n_retry_rays * 40,
         "projection_kernel<retry>": scene_bytes,
         # frame unit = 2 MiB frame + 12 B x N (pix 4, weight 4, out 4).  The 2 MiB
-        # compulsory full read of the frame belongs to the hot-pixel scan (the gather's pixel reads
-        # hit the Infinity Cache); the gather keeps pix / weight in registers across its 64-frame
-        # tile, so per launch it needs 4 B x N x frames written + 8 B x N read once -- counting
-        # 12 B x N per FRAME would credit bytes the kernel never has to move.
+        # compulsory full read of the frame belongs to the scan (pass A / hot_scan_kernel); the series
+        # writers keep the per-node index in registers across a launch, so per LAUNCH they need
+        # 4 B x N x frames written + 8 B x N read once -- counting 12 B x N per FRAME would credit
+        # bytes the kernel never has to move.
         # (N > 1: only the rows that travel are stored, as u16 when the values are 16-bit integers)
         "gather_tile_kernel": F * series_esz * series_rows + gather_launches * 8 * N,
-        "hot_scan_kernel": F * 2 * size * size,
-        # --streamed: pass A reads the frames (its compact buffer stays in cache), pass B writes the series
-        "scan_compact_kernel": F * 2 * size * size,
-        # (one pass B per 256 frames: index 4 B + flags + accumulators per node and launch)
-        "node_stream_kernel": F * series_esz * series_rows + stream_launches * 8 * N,
-        # (whole-row pass B: one launch per <= 1024 frames)
+        "hot_scan_kernel": F * 2 * npx,
+        "scan_compact_kernel": F * 2 * npx,
         "node_rows_kernel": F * series_esz * series_rows + row_launches * 8 * N,
+        # SURVEY.md 8(d) with registration: 8 B per pixel and ECC iteration (blurred frame + template,
+        # gradients recomputed on the fly), warp 2 B in + 2 B out per pixel, pre-blur 2 B in + 4 B out
+        "warp_u16_kernel": F * 4 * npx,
+        "gauss_pass_kernels": F * 6 * npx,
     }
+    if a.registration:
+        st = pipe.ecc_stats()            # average ECC iterations per frame over every step run so far
+        per_step_bytes["ecc_sums_kernel"] = st["frame_iterations"] / max(st["frames"], 1) * F * 8 * npx
+        ecc_iters_per_frame = st["frame_iterations"] / max(st["frames"], 1)
     for name, (calls, total_ms) in timing.items():
         ms_step_k = total_ms / a.steps
         k = {"calls_per_step": calls / a.steps, "ms_per_step": ms_step_k,
@@ -341,25 +345,25 @@ def main():
     dom = max((n for n in kernels if n in per_step_bytes), key=lambda n: kernels[n]["ms_per_step"])
     dk = kernels[dom]
     calls = max(dk["calls_per_step"], 1)
-    # HBM traffic of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
-    # WRITE_SIZE collected separately; FETCH_SIZE doubled per the gfx950 correction of
-    # MI355X_MICROARCH.md "HBM"; counter unit = KB) -- per launch, same launch shape
-    traffic = None
-    prof = os.path.join(ROOT, "profiles", "r01_bench_summary.json")
-    pkey = {"gather_tile_kernel": "gather_tile16_kernel<4, true, false>", "hot_scan_kernel": "hot_scan_kernel",
-            "scan_compact_kernel": "scan_compact_kernel<true>", "node_stream_kernel": "node_stream_kernel",
-            "projection_kernel<primary>": "projection_kernel<false, 0>",
-            "projection_kernel<retry>": "projection_kernel<false, 1>"}.get(dom)
-    if os.path.exists(prof) and pkey:
-        pj = json.load(open(prof)).get(pkey, {})
-        if "FETCH_SIZE_KB_per_launch" in pj and "WRITE_SIZE_KB_per_launch" in pj:
-            traffic = (2 * pj["FETCH_SIZE_KB_per_launch"] + pj["WRITE_SIZE_KB_per_launch"]) * 1024
+    # HBM traffic of that kernel: only from a rocprofv3 PMC summary of THIS configuration, handed over
+    # explicitly (tools/profile_bench.sh writes it: FETCH_SIZE and WRITE_SIZE in separate passes, the
+    # gfx950 FETCH correction applied for the streaming kernels); otherwise null
+    traffic, traffic_src = None, None
+    prof = os.environ.get("UPSP_BENCH_TRAFFIC_JSON")
+    if prof and os.path.exists(prof):
+        pj = json.load(open(prof))
+        same = pj.get("bench_args", "").split() == [x for x in sys.argv[1:] if x not in ("--no-cpu-baseline", "--no-reraycast")]
+        if same and dom in pj.get("traffic_bytes_per_launch", {}):
+            traffic, traffic_src = pj["traffic_bytes_per_launch"][dom], os.path.relpath(os.path.abspath(prof), ROOT)
     roof = {"kernel": dom, "bound": "hbm",
             "achieved": dk["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": dk["achieved_GBps"] / HBM_PEAK_GBS, "traffic": traffic,
+            "frac": dk["achieved_GBps"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": per_step_bytes[dom] / calls,
             "avg_launch_ms": dk["avg_launch_ms"], "launches_per_step": calls}
 
+    sched = ("projection build, then hot-pixel scan + gather kernels per 64-frame sub-batch"
+             if (a.two_kernel or a.registration) else
+             "projection build, then pass A (scan + compact pixel series) and pass B (whole rows) per <= 1024 frames")
     out = {
         "metric": "frames/s", "value": fps, "unit": "frames/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True,
@@ -370,24 +374,26 @@ def main():
                                                          tris.shape[0], N,
                                                          "registration+" if a.registration else ""),
                    "frames_per_gpu": F, "nodes": N, "triangles": int(tris.shape[0]),
-                   "parallelism": "frames sharded x%d" % world,
-                   "schedule": ("hot-pixel scan of all frames on a side stream, concurrent with the projection build"
-                                if overlap else "projection build, then scan + gather kernels per 64-frame sub-batch"
-                                if (a.two_kernel or a.registration) else
-                                "projection build, then scan + compact / node stream passes per 64-frame sub-batch"),
-                   **({"exchange": "%d chunks, %s rows as %s" % (K, "visible" if mode["packed"] else "all",
-                                                                 "u16" if series_esz == 2 else "f32")}
+                   "active_pixels": n_active, "series_row_pitch": ld if not chunked else None,
+                   "frame_content": ("model intensity + noise" if a.plain_frames else
+                                     "SURVEY 8(d): model intensity x 24 fiducial discs, background 60, noise 8, "
+                                     "<= 3 hot pixels in 1 % of the frames"),
+                   "parallelism": "frames sharded x%d" % world, "schedule": sched,
+                   **({"exchange": "%d chunks, visible rows as %s" % (K, "u16" if u16_wire else "f32")}
                       if chunked else {})},
-        "mrays_per_s": mrays, "rays_per_step": nrays_last[0],
-        "rays_cast_per_step": primary_rays_last[0] + 6 * retry_nodes_last[0],
+        "mrays_per_s": mrays, "mrays_per_s_kind": "reference-equivalent (rays the reference casts / build time)",
+        "rays_per_step": nrays, "rays_cast_per_step": primary_rays + n_retry_rays,
         "breakdown_ms": {"projection_build": ray_ms, "frame_loop": frm_ms,
                          "exchange_finals": float(np.mean(t_xchg))},
         "frame_loop_frames_per_s": F / (frm_ms * 1e-3),
-        # whole frame loop against HBM: (2 MiB + 4 B x N) per frame + 8 B x N per 64-frame tile
-        "frame_loop_GBps": (F * (2 * size * size + series_esz * series_rows) + gather_launches * 8 * N) / (frm_ms * 1e-3) / 1e9,
+        # whole frame loop against HBM: (2 MiB + 4 B x N) per frame + 8 B x N per series launch
+        "frame_loop_GBps": (F * (2 * npx + series_esz * series_rows) +
+                            (row_launches if streamed else gather_launches) * 8 * N) / (frm_ms * 1e-3) / 1e9,
         "roofline": roof,
         "kernels": kernels,
     }
+    if a.registration:
+        out["ecc_iterations_per_frame"] = ecc_iters_per_frame
     if world == 1 and not a.registration and not a.no_reraycast:
         # SURVEY.md 8(d) stress mode "frame with re-raycast": one projection build (N_nodes visibility
         # rays + retries) per frame instead of per run (docs/sphinx/known-issues.rst:18-30: model motion)
@@ -405,7 +411,31 @@ def main():
         torch.cuda.synchronize()
         out["reraycast_frames_per_s"] = nrr / (r0.elapsed_time(r1) * 1e-3)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(verts, tris, cd, size, F, nrays_last[1].cpu().numpy())
+        out["cpu_baseline"], ref = cpu_baseline(verts, tris, cd, size, F, sample)
+        if not a.registration:
+            # parity of THIS run against the oracle: the projection of the full 1 M-triangle model, and the
+            # frame loop on the sample the CPU just processed (same bits in: the frames as generated)
+            gpix = last_pix[0].cpu().numpy()
+            d_sample = torch.as_tensor(sample.view(np.int16)).view(torch.uint16).cuda()
+            p2 = engine.FramePipeline(1, size, size, N, fused_scan=2 if a.two_kernel else 0)
+            p2.set_projection(0, last_pix[0])
+            rt = torch.empty((N, engine.series_ld(n_sample, whole_rows=True)), dtype=torch.float32, device="cuda")[:, :n_sample]
+            p2.process(d_sample, first_frame=0, rows_t=rt, want_rows=False)
+            gs, gss = [x.cpu().numpy() for x in p2.accumulators()]
+            ok = ~np.isnan(ref["sum"])
+            checks = {
+                "projection_pix_full_model": bool(np.array_equal(gpix, ref["pix"])),
+                "reference_ray_count": bool(nrays == ref["nrays"]),
+                "series_rows_8_frames": bool(np.array_equal(rt[:, :8].cpu().numpy().T.view(np.int32), ref["rows8"].view(np.int32))),
+                "repaired_frames": bool(np.array_equal(d_sample.cpu().view(torch.int16).numpy().view(np.uint16), ref["frames_fixed"])),
+                "accumulators_%d_frames" % n_sample: bool(np.array_equal(np.isnan(gs), ~ok) and np.array_equal(gs[ok], ref["sum"][ok])
+                                                       and np.array_equal(gss[ok], ref["sumsq"][ok])),
+            }
+            out["parity_checked"] = all(checks.values())
+            out["parity"] = checks
+            if not out["parity_checked"]:
+                print(json.dumps(out), flush=True)
+                raise SystemExit("bench.py: GPU results differ from the oracle: %r" % (checks,))
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

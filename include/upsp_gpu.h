@@ -197,8 +197,9 @@ typedef struct upsp_pipeline_opts {
      * launch, pass B: every node's row piece written once, whole), 2 = scan kernel + gather kernel per
      * 64 frames (relies on the sub-batch staying in the Infinity Cache).  Same results. */
     int32_t fused_scan;
-    /* streamed schedule: budget in MiB for the compact pixel-series buffer (2 B x active pixels x frames
-     * of a group); 0 = default (2048).  It bounds the frames per pass A / pass B pair (64 .. 1024). */
+    /* streamed schedule: budget in MiB for the compact pixel-series buffer (2 B x min(nodes, pixels) x
+     * frames of a group, allocated on first use); 0 = default (2048).  It bounds the frames per pass A /
+     * pass B pair (64 .. 1024). */
     int32_t compact_mb;
     int32_t reserved[3];
 } upsp_pipeline_opts;
@@ -287,6 +288,11 @@ int upsp_pipeline_process(upsp_pipeline *p, uint16_t *const *d_frames, int nfram
 int upsp_pipeline_process_u16(upsp_pipeline *p, uint16_t *const *d_frames, int nframes,
                               int64_t first_frame, uint16_t *d_series_u16, int64_t ld_t,
                               int64_t col0, float *d_warps, void *stream);
+
+/* Statistics of the registration stage since the pipeline was created: ECC iterations summed over
+ * the registered frames (cv::findTransformECC's loop count, cpp/lib/registration.cpp:64) and the
+ * number of frames that went through it. */
+int upsp_pipeline_ecc_stats(upsp_pipeline *p, uint64_t *frame_iterations, uint64_t *frames);
 
 /* Accumulator access (device pointers to nnodes doubles each), used for the
  * cross-GPU sum that replaces MPI_Reduce (psp_process.cpp:1866-1872). */

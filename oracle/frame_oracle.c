@@ -88,6 +88,47 @@ void orc_accumulate(const float *sol, size_t nnodes, double *sum, double *sumsq)
     }
 }
 
+/* The plain frame loop (one camera, no registration / patch / filter) the way the reference runs it,
+ * psp_process.cpp:1742-1851: `#pragma omp parallel` with thread-private double accumulators,
+ * `omp for schedule(dynamic, 1)` over the frames, partials merged under `omp critical`.  Per frame:
+ * fix_hot_pixels in place (:1772), project_frame (:1810), NaN for the skipped nodes (:1822-1825),
+ * accumulators (:1828-1831), row stored (:1837-1839; rows may be NULL -- the timed baseline keeps
+ * only the accumulators).  The summation order over frames depends on the thread schedule, exactly
+ * as in the reference (parity bar for avg / rms is relative). */
+void orc_frame_loop_u16(uint16_t *frames, int nframes, int rows, int cols, const int32_t *pix,
+                        const float *weight, const int32_t *skipped, size_t nskipped, size_t nnodes,
+                        int thresh, int min_change, int max_hot, float *out_rows, double *sum,
+                        double *sumsq, int threads)
+{
+    const size_t npix = (size_t)rows * (size_t)cols;
+#pragma omp parallel num_threads(threads > 0 ? threads : 1)
+    {
+        double *l_rms = (double *)calloc(nnodes, sizeof(double));
+        double *l_avg = (double *)calloc(nnodes, sizeof(double));
+        float *sol_own = out_rows ? NULL : (float *)malloc(sizeof(float) * nnodes);
+#pragma omp for schedule(dynamic, 1) nowait
+        for (int f = 0; f < nframes; ++f) {
+            uint16_t *img = frames + (size_t)f * npix;
+            float *sol = out_rows ? out_rows + (size_t)f * nnodes : sol_own;
+            orc_fix_hot_pixels(img, rows, cols, thresh, min_change, max_hot);
+            orc_project_frame_u16(img, pix, weight, nnodes, sol);
+            for (size_t i = 0; i < nskipped; ++i) sol[skipped[i]] = NAN;
+            for (size_t i = 0; i < nnodes; ++i) {
+                l_rms[i] += (sol[i] * sol[i]);
+                l_avg[i] += sol[i];
+            }
+        }
+#pragma omp critical
+        for (size_t i = 0; i < nnodes; ++i) {
+            sumsq[i] += l_rms[i];
+            sum[i] += l_avg[i];
+        }
+        free(l_rms);
+        free(l_avg);
+        free(sol_own);
+    }
+}
+
 /* psp_process.cpp:1933-1936 */
 void orc_finals(const double *sum, const double *sumsq, size_t nnodes, uint64_t nframes,
                 float *avg, float *rms)

@@ -85,6 +85,10 @@ def lib():
         L.orc_project_frame_f32.argtypes = [C.c_void_p] * 3 + [C.c_size_t, C.c_void_p]
         L.orc_project_frame_u16.argtypes = [C.c_void_p] * 3 + [C.c_size_t, C.c_void_p]
         L.orc_accumulate.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.orc_frame_loop_u16.argtypes = ([C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_int])
+        L.orc_frame_loop_u16.restype = None
         L.orc_finals.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64,
                                  C.c_void_p, C.c_void_p]
         L.orc_apportion.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
@@ -296,6 +300,22 @@ def project_frame(img, pix, weight=None):
 
 def accumulate(sol, s, ss):
     lib().orc_accumulate(_p(_f32(sol)), sol.size, _p(s), _p(ss))
+
+
+def frame_loop(frames, pix, weight=None, skipped=None, thresh=4064, min_change=512, max_hot=5,
+               want_rows=True, threads=1):
+    """The plain frame loop of psp_process.cpp:1742-1851 (OpenMP over frames, thread-private double
+    accumulators).  frames: u16 [F,H,W], repaired IN PLACE.  Returns (rows [F,N] or None, sum, sumsq)."""
+    assert frames.dtype == np.uint16 and frames.flags.c_contiguous and frames.ndim == 3
+    pix = np.ascontiguousarray(pix, dtype=np.int32)
+    w = None if weight is None else _f32(weight)
+    sk = np.nonzero(skipped_nodes(pix) if skipped is None else np.asarray(skipped))[0].astype(np.int32)
+    F, H, W = frames.shape
+    rows = np.empty((F, pix.size), np.float32) if want_rows else None
+    s, ss = np.zeros(pix.size), np.zeros(pix.size)
+    lib().orc_frame_loop_u16(_p(frames), F, H, W, _p(pix), _p(w), _p(sk), sk.size, pix.size, thresh, min_change,
+                             max_hot, _p(rows), _p(s), _p(ss), int(threads))
+    return rows, s, ss
 
 
 def finals(s, ss, nframes):

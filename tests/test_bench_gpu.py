@@ -1,0 +1,56 @@
+"""GPU: bench.py contract -- the JSON line, the in-run parity check against the oracle, and the
+N > 1 launch path (`--gpus N` starts its own ranks).  Sub-processes: the test process keeps its own
+GPU context, every bench run is a fresh child."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(args, env=None, timeout=600):
+    e = dict(os.environ)
+    e.pop("RANK", None); e.pop("WORLD_SIZE", None); e.pop("LOCAL_RANK", None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=e,
+                       capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_small_line_and_parity(gpu_lib):
+    d = run_bench(["--small", "--steps", "2", "--warmup", "1"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+              "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["metric"] == "frames/s"
+    assert d["parity_checked"] is True and all(d["parity"].values()), d["parity"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["traffic"] is None                        # no PMC summary was handed over
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+
+
+def test_bench_two_ranks_on_one_gpu_gloo(gpu_lib):
+    """`--gpus 2` launches its own two ranks; on a one-GPU box both sit on cuda:0 and talk through gloo
+    (the RCCL run needs two GPUs: next test).  The exchange runs packed u16 rows in 4 chunks."""
+    d = run_bench(["--gpus", "2", "--small", "--steps", "2", "--warmup", "1"],
+                  env={"UPSP_BENCH_BACKEND": "gloo", "UPSP_BENCH_ONE_GPU": "1"})
+    assert d["n_gpus"] == 2 and d["backend"] == "gloo"
+    assert d["config"]["exchange"] == "4 chunks, visible rows as u16"
+    assert d["config"]["parallelism"] == "frames sharded x2"
+
+
+def test_bench_two_ranks_rccl(gpu_lib):
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL over xGMI)")
+    d = run_bench(["--gpus", "2", "--small", "--steps", "2", "--warmup", "1"])
+    assert d["n_gpus"] == 2 and "backend" not in d
+    assert d["config"]["exchange"] == "4 chunks, visible rows as u16"

@@ -175,3 +175,37 @@ def test_cli_target_patcher(gpu_lib, tmp_path):
     same = (got.view(np.int32) == base.view(np.int32)).all(1)
     assert same[~may].all() and (~same[may]).any()
     bvh.close()
+
+
+@pytest.mark.gpu
+def test_cli_two_ranks(gpu_lib, tmp_path):
+    """`bin/psp_process -ranks=2`: the executable starts its own two ranks (one GPU here: both on
+    cuda:0 over gloo; RCCL when two GPUs are visible), frames shard, rank 0 creates the shared flat
+    files and every rank writes its node slice at its byte offset -- byte-identical to the
+    single-rank run (the double accumulators are exact integer sums on this path)."""
+    import subprocess
+    import sys
+    import torch
+    tmp1, tmp2 = str(tmp_path / "one"), str(tmp_path / "two")
+    os.makedirs(tmp1); os.makedirs(tmp2)
+    write_case(tmp1, nframes=13)
+    write_case(tmp2, nframes=13)
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bin", "psp_process")
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r1 = subprocess.run([sys.executable, exe, "-input_file=%s/run.inp" % tmp1, "-h5_out=x"], env=env,
+                        capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    if torch.cuda.device_count() < 2:
+        env.update(UPSP_BACKEND="gloo", UPSP_ONE_GPU="1")
+    # a stale, longer output file must not survive
+    os.makedirs(os.path.join(tmp2, "out"))
+    open(os.path.join(tmp2, "out", "intensity_transpose"), "wb").write(b"\xff" * 10_000_000)
+    r2 = subprocess.run([sys.executable, exe, "-input_file=%s/run.inp" % tmp2, "-h5_out=x", "-ranks=2"], env=env,
+                        capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    for name in ("intensity_transpose", "intensity_avg", "intensity_rms", "coverage", "intensity_ratio_0", "cam02-uv"):
+        a = open(os.path.join(tmp1, "out", name), "rb").read()
+        b = open(os.path.join(tmp2, "out", name), "rb").read()
+        assert a == b, name

@@ -624,13 +624,15 @@ __global__ void ecc_set_last_rho(EccState *state, int nframes, double eps)
 
 __global__ void ecc_count_active(const EccState *state, int nframes, int *out)
 {
-    int active = 0, err = 0;
+    int active = 0, err = 0, iters = 0;
     for (int f = threadIdx.x; f < nframes; f += blockDim.x) {
         active += state[f].done == 0;
         err += state[f].done < 0;
+        iters += state[f].iters;
     }
     atomicAdd(&out[0], active);
     atomicAdd(&out[1], err);
+    atomicAdd(&out[2], iters);       // frame-iterations so far (statistics)
 }
 
 __global__ void ecc_export_warps(const EccState *state, int nframes, float *warps, int stride)
@@ -903,7 +905,14 @@ struct FrameScratch {
     double *partial = nullptr;
     EccState *state = nullptr;
     int *counter = nullptr;
+    unsigned long long ecc_frame_iters = 0, ecc_frames = 0;   // statistics: ECC iterations summed over frames, frames
 };
+
+void frame_scratch_ecc_stats(const FrameScratch *s, unsigned long long *frame_iters, unsigned long long *frames)
+{
+    *frame_iters = s ? s->ecc_frame_iters : 0;
+    *frames = s ? s->ecc_frames : 0;
+}
 
 void frame_scratch_free(FrameScratch *s)
 {
@@ -951,7 +960,7 @@ int frame_scratch_ensure(FrameScratch **ps, int ncams, int batch, int rows, int 
     if (need_warp && !s->partial)
         UPSP_HIP_CHECK(hipMalloc(&s->partial, sizeof(double) * (size_t)batch * kEccBlocksMax * kEccSums));
     if (!s->state) UPSP_HIP_CHECK(hipMalloc(&s->state, sizeof(EccState) * (size_t)batch));
-    if (!s->counter) UPSP_HIP_CHECK(hipMalloc(&s->counter, 2 * sizeof(int)));
+    if (!s->counter) UPSP_HIP_CHECK(hipMalloc(&s->counter, 4 * sizeof(int)));
     return UPSP_OK;
 }
 
@@ -966,6 +975,7 @@ static int run_ecc(FrameScratch *s, const float *tmpl_blur, const uint16_t *fram
     hipLaunchKernelGGL(ecc_set_last_rho, g1, b1, 0, st, s->state, nb, eps);
     int it = 0;
     int active = nb;  // frames still iterating (known to the host after every burst)
+    int iters_done = 0;
     while (it < max_iters) {
         // a few iterations between host checks of the active-frame count; frames that have
         // converged exit at once, so late bursts spread the remaining frames over more blocks
@@ -990,8 +1000,8 @@ static int run_ecc(FrameScratch *s, const float *tmpl_blur, const uint16_t *fram
             hipLaunchKernelGGL(ecc_solve_kernel, dim3(nb), dim3(256), 0, st, s->state,
                                (const double *)s->partial, nb, blocks, max_iters, eps);
         }
-        int h[2] = {0, 0};
-        UPSP_HIP_CHECK(hipMemsetAsync(s->counter, 0, 2 * sizeof(int), st));
+        int h[3] = {0, 0, 0};
+        UPSP_HIP_CHECK(hipMemsetAsync(s->counter, 0, 3 * sizeof(int), st));
         hipLaunchKernelGGL(ecc_count_active, dim3(1), dim3(64), 0, st, (const EccState *)s->state, nb,
                            s->counter);
         UPSP_HIP_CHECK(hipMemcpyAsync(h, s->counter, sizeof(h), hipMemcpyDeviceToHost, st));
@@ -999,9 +1009,12 @@ static int run_ecc(FrameScratch *s, const float *tmpl_blur, const uint16_t *fram
         if (h[1] > 0)
             return fail(UPSP_ERR_DIVERGED,
                         "ECC registration did not converge (cv::findTransformECC would throw)");
+        iters_done = h[2];
         if (h[0] == 0) break;
         active = h[0];
     }
+    s->ecc_frame_iters += (unsigned long long)iters_done;
+    s->ecc_frames += (unsigned long long)nb;
     UPSP_HIP_CHECK(hipGetLastError());
     if (std::getenv("UPSP_TRACE_ECC")) {
         std::vector<EccState> h(nb);

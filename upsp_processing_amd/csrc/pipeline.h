@@ -72,6 +72,7 @@ int frame_scratch_ensure(FrameScratch **s, int ncams, int batch, int rows, int c
                          bool need_warp, bool need_f32);
 void frame_scratch_free(FrameScratch *s);
 void frame_scratch_new_reference(FrameScratch *s, int cam);  // ECC template changed
+void frame_scratch_ecc_stats(const FrameScratch *s, unsigned long long *frame_iters, unsigned long long *frames);
 
 }  // namespace upsp
 

@@ -18,6 +18,46 @@ import torch
 import torch.distributed as dist
 
 
+def init_from_env(backend=None):
+    """One process per GPU: reads RANK / LOCAL_RANK / WORLD_SIZE (torchrun, or psp_process -ranks=N),
+    selects this rank's device BEFORE any other GPU call and joins the process group ("nccl" = RCCL
+    over xGMI; UPSP_BACKEND=gloo with UPSP_ONE_GPU=1 rehearses several ranks on one GPU).  The
+    equivalent of MPI_Init + MPI_Comm_rank/size in the reference (cpp/exec/psp_process.cpp:1322-1330).
+    Returns (rank, world).  Without the environment: (0, 1), nothing initialised."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = 0 if os.environ.get("UPSP_ONE_GPU") else int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    if world > 1 and not dist.is_initialized():
+        backend = backend or os.environ.get("UPSP_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world
+
+
+def shutdown():
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def create_shared_file(path, nbytes, group=None):
+    """Rank 0 creates / truncates a flat output file every rank then pwrite()s its slice into
+    (the reference opens intensity_transpose once and writes at byte offsets, psp_process.cpp:958-963);
+    the barrier keeps the other ranks from writing into a file that is about to be truncated."""
+    import os
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if rank == 0:
+        with open(path, "wb") as f:
+            f.truncate(int(nbytes))
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.barrier(group)
+    return os.open(path, os.O_RDWR)
+
+
 def apportion(value, nbins):
     """apportion (psp_process.cpp:611-624): contiguous near-equal ranges."""
     block, rem = divmod(int(value), int(nbins))
@@ -151,6 +191,7 @@ class TimeSeriesExchange:
         self.vis_mine = None     # their positions inside this rank's slice
         self._row_map = None
         self._keep = None
+        self._mismatch = None    # device flag: an assume_same set_skipped() saw a different set
         if str(device).startswith("cuda"):
             self._prewarm(device)
 
@@ -169,17 +210,27 @@ class TimeSeriesExchange:
         o.fill_(float("nan"))
         o[v - 1, 1:3] = torch.ones((v.numel(), 2), device=device)
         o.index_select(0, v)
+        bad = (a != a.clone()).any()
+        bad = bad | (a != a).any()          # set_skipped(assume_same=True)
+        bool(bad)
 
-    def set_skipped(self, skipped):
+    def set_skipped(self, skipped, assume_same=False):
         """skipped: bool / uint8 [N] on the exchange's device, identical on every rank; None
-        switches back to sending every row.  Costs one device->host read of W counters."""
+        switches back to sending every row.  Deriving the travelling set costs one device->host
+        read of W counters (the all-to-all split sizes live on the host).
+
+        assume_same=True: the caller states that the set is the one of the previous call (the
+        projection did not change).  Nothing is read back; the claim is checked on the device and
+        verify() raises if it was ever wrong."""
         sh = self.shard
         if skipped is None:
             self.vis = self.vis_count = self.vis_mine = self._row_map = self._keep = None
             return
         keep = (skipped == 0) if skipped.dtype != torch.bool else ~skipped
-        if self._keep is not None and self._keep.shape == keep.shape and bool(torch.equal(self._keep, keep)):
-            return                                      # same set as before: out's NaN rows are in place
+        if assume_same and self._keep is not None and self._keep.shape == keep.shape:
+            bad = (self._keep != keep).any()
+            self._mismatch = bad if self._mismatch is None else (self._mismatch | bad)
+            return
         self._keep = keep.clone()
         self.vis = torch.nonzero(keep, as_tuple=False).reshape(-1)
         self._row_map = None
@@ -190,6 +241,12 @@ class TimeSeriesExchange:
         r = sh.rank
         self.vis_mine = self.vis[cuts[r]:cuts[r + 1]] - n0
         self.out.fill_(float("nan"))                    # rows that do not travel
+
+    def verify(self):
+        """Raises if a set_skipped(..., assume_same=True) call was handed a different set (one host read)."""
+        if self._mismatch is not None and bool(self._mismatch):
+            raise RuntimeError("TimeSeriesExchange: the skipped-node set changed although assume_same was given")
+        self._mismatch = None
 
     def my_chunk(self, k):
         """(local frame offset, frame count) of this rank's chunk k."""
@@ -213,6 +270,8 @@ class TimeSeriesExchange:
         """rows_t_chunk: [N, fc] (unit column stride), this rank's chunk number len(submitted);
         packed=True: [packed_rows(), fc], already reduced to the travelling rows (row_map())."""
         sh, k = self.shard, self.k
+        if k >= self.K:
+            raise RuntimeError("TimeSeriesExchange.submit: all %d chunks were already submitted (finish() first)" % self.K)
         c0, fc = self.my_chunk(k)
         assert rows_t_chunk.shape == ((self.packed_rows() if packed else sh.nnodes), fc)
         assert not packed or self.vis is not None
@@ -263,6 +322,7 @@ class TimeSeriesExchange:
                         _scatter_rows(self.out, self.vis_mine, col, blk)
                 off += rows_in * fs
         self.pending = []
+        self.k = 0                      # ready for the next pass over the chunks
         return self.out
 
 

@@ -367,6 +367,12 @@ class FramePipeline:
                                           _ptr(rows_t), ld, col0, _ptr(warps), _stream()))
         return rows
 
+    def ecc_stats(self):
+        """Registration statistics since creation: dict(frame_iterations, frames)."""
+        a, b = C.c_uint64(), C.c_uint64()
+        check(lib().upsp_pipeline_ecc_stats(self._h, C.byref(a), C.byref(b)))
+        return dict(frame_iterations=a.value, frames=b.value)
+
     def accumulators(self):
         """(sum, sumsq) as float64 tensors aliasing the pipeline's device buffers."""
         a, b = C.c_void_p(), C.c_void_p()

@@ -100,7 +100,8 @@ class Phase2:
         os.makedirs(out_dir, exist_ok=True)
         rank = dist.get_rank() if dist.is_initialized() else 0
         P = res["pressure_t"]
-        fd = os.open(os.path.join(out_dir, "pressure_transpose"), os.O_RDWR | os.O_CREAT, 0o644)
+        from . import distributed as D
+        fd = D.create_shared_file(os.path.join(out_dir, "pressure_transpose"), nnodes * P.shape[1] * 4)
         try:
             os.pwrite(fd, P.cpu().numpy().astype("<f4").tobytes(), P.shape[1] * node_start * 4)
         finally:

@@ -185,7 +185,7 @@ class Phase1:
             path = os.path.join(out_dir, "intensity_transpose")
             nf = series.shape[1]
             data = series.cpu().numpy().astype("<f4")
-            fd = os.open(path, os.O_RDWR | os.O_CREAT, 0o644)
+            fd = D.create_shared_file(path, self.nnodes * nf * 4)
             try:
                 os.pwrite(fd, data.tobytes(), nf * node_start * 4)
             finally:

@@ -160,10 +160,37 @@ def read_camera_json(path):
                 size=(int(j["imageSize"][0]), int(j["imageSize"][1])))
 
 
+def spawn_ranks(n, argv):
+    """`-ranks=N` (the `mpiexec -n N psp_process ...` of the reference's batch templates): start N rank
+    processes, one per GPU, before this process has touched a GPU; exit code = theirs."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", "upsp_processing_amd.psp_process"]
+    return subprocess.call(cmd + [a for a in argv if not a.lstrip("-").startswith("ranks=")])
+
+
 def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    flags = parse_flags(argv)
+    nranks = int(flags.get("ranks", "1"))
+    if nranks > 1 and "RANK" not in os.environ:
+        return spawn_ranks(nranks, argv)
     import torch
     from . import engine, psp, synthetic, video, distributed as D
-    flags = parse_flags(sys.argv[1:] if argv is None else argv)
+    D.init_from_env()               # device of this rank + process group (MPI_Init of the reference)
+    try:
+        return run(flags)
+    finally:
+        D.shutdown()
+
+
+def run(flags):
+    import torch
+    from . import engine, psp, synthetic, video, distributed as D
     deck = parse_input_deck(flags["input_file"])
     opts = deck["options"]
     grid = deck["all"].get("grid")

@@ -167,10 +167,54 @@ def synth_frames_numpy(nframes, height, width, first=0, seed=20240607, noise=8.0
     return out
 
 
+def hot_pixel_positions(frame, height, width, seed=20240607, active=None):
+    """<= 3 injected hot pixels (value 4095) in 1 % of the frames.  Deterministic in
+    (seed, global frame index).  Returns a list of flat pixel positions (empty for 99 % of the frames);
+    with `active` (flat indices of pixels some node reads) the first one lands on such a pixel, so that
+    the repair reaches the time series."""
+    if frame % 100 != 17:
+        return []
+    rng = np.random.default_rng(seed + 7919 * (frame + 1))
+    n = int(rng.integers(1, 4))
+    pos = [int(rng.integers(0, height * width)) for _ in range(n)]
+    if active is not None and len(active):
+        pos[0] = int(active[int(rng.integers(0, len(active)))])
+    return pos
+
+
+def scene_layout(pix, height, width, ndiscs=24):
+    """Static content of the synthetic frames derived from a projection: the model
+    silhouette (pixels some node reads, dilated by 2 px; everything else is background = 60) and 24
+    fiducial discs (radius 3-5 px, intensity x 0.3) centred on evenly spaced visible nodes.
+    pix: int32 [N] (numpy or tensor).  Returns dict(mask bool [H,W], scale f32 [H,W], active int64 [A])
+    as numpy arrays."""
+    pix = np.asarray(pix.cpu() if hasattr(pix, "cpu") else pix).reshape(-1)
+    act = np.unique(pix[pix >= 0]).astype(np.int64)
+    m = np.zeros((height, width), bool)
+    m.flat[act] = True
+    d = m.copy()
+    for dy in range(-2, 3):                     # 5 x 5 dilation
+        for dx in range(-2, 3):
+            sh = np.zeros_like(m)
+            ys, yd = (slice(max(dy, 0), height + min(dy, 0)), slice(max(-dy, 0), height + min(-dy, 0)))
+            xs, xd = (slice(max(dx, 0), width + min(dx, 0)), slice(max(-dx, 0), width + min(-dx, 0)))
+            sh[yd, xd] = m[ys, xs]
+            d |= sh
+    scale = np.ones((height, width), np.float32)
+    if act.size and ndiscs > 0:
+        yy, xx = np.mgrid[0:height, 0:width]
+        for i in range(ndiscs):
+            c = int(act[(i * act.size) // ndiscs + act.size // (2 * ndiscs)])
+            cy, cx, r = c // width, c % width, 3 + i % 3
+            scale[(yy - cy) ** 2 + (xx - cx) ** 2 <= r * r] = 0.3
+    return dict(mask=d, scale=scale, active=act)
+
+
 def synth_frames_torch(nframes, height, width, first=0, seed=20240607, noise=8.0, device="cuda",
-                       out=None):
+                       out=None, layout=None, hot=False):
     """Same image model synthesised on the device (bench input; noise from torch's
-    generator, so values differ from synth_frames_numpy)."""
+    generator, so values differ from synth_frames_numpy).  layout = scene_layout(...): background 60
+    outside the model, fiducial discs x 0.3; hot=True: hot_pixel_positions() (1 % of the frames)."""
     import torch
     A = torch.as_tensor(frame_params(first + nframes, seed)[first:], dtype=torch.float32, device=device)
     g = torch.Generator(device=device)
@@ -179,11 +223,23 @@ def synth_frames_torch(nframes, height, width, first=0, seed=20240607, noise=8.0
     x = torch.arange(width, device=device, dtype=torch.float32)[None, :]
     if out is None:
         out = torch.empty((nframes, height, width), dtype=torch.uint16, device=device)
+    mask = scale = active = None
+    if layout is not None:
+        mask = torch.as_tensor(layout["mask"], device=device)
+        scale = torch.as_tensor(layout["scale"], device=device)
+        active = layout["active"]
     for i in range(nframes):
         xp = A[i, 0, 0] * x + A[i, 0, 1] * y + A[i, 0, 2]
         yp = A[i, 1, 0] * x + A[i, 1, 1] * y + A[i, 1, 2]
         img = (1800 + 900 * torch.sin(2 * math.pi * 3 * xp / width) * torch.cos(2 * math.pi * 2 * yp / height)
                + 50 * math.sin(2 * math.pi * (first + i) / 64))
+        if layout is not None:
+            img = torch.where(mask, img * scale, torch.full_like(img, 60.0))
         img = img + noise * torch.randn(img.shape, generator=g, device=device)
         out[i] = img.round().clamp_(0, 4095).to(torch.int32).to(torch.uint16)
+        if hot:
+            pos = hot_pixel_positions(first + i, height, width, seed, active)
+            if pos:
+                flat = out[i].view(torch.int16).reshape(-1)
+                flat[torch.as_tensor(pos, device=device)] = 4095
     return out
