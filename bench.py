@@ -99,28 +99,23 @@ def cpu_baseline(verts, tris, cam_dict, size, nframes_step, sample):
     mrays = r["nrays"] / t_proj / 1e6
     pix = np.ascontiguousarray(r["pix"], dtype=np.int32)
     frames = sample.copy()
+    tm = {}
     t0 = time.perf_counter()
-    _, s, ss = orc.frame_loop(frames, pix, want_rows=False, threads=cores)
+    _, s, ss = orc.frame_loop(frames, pix, want_rows=False, threads=cores, timing=tm)
     t_frames = time.perf_counter() - t0
-    # the loop has a fixed cost per run (every thread allocates and merges its own 2 x N doubles,
-    # psp_process.cpp:1744-1745, 1845-1850): a second, shorter run separates it from the per-frame cost
-    n_short = max(1, frames.shape[0] // 4)
-    short = sample[:n_short].copy()
-    t0 = time.perf_counter()
-    orc.frame_loop(short, pix, want_rows=False, threads=cores)
-    t_short = time.perf_counter() - t0
-    per_frame = max(t_frames - t_short, 1e-9) / max(frames.shape[0] - n_short, 1)
-    t_fixed = max(t_frames - per_frame * frames.shape[0], 0.0)
+    # per frame: the loop proper; per run: every thread allocates / first-touches and later merges its
+    # own 2 x N doubles (psp_process.cpp:1744-1745, 1845-1850), amortised over a whole run
+    per_frame = tm["loop"] / frames.shape[0]
+    t_fixed = tm["setup"] + tm["merge"]
     # a few rows for the parity check of the series (single thread, rows kept)
     few = sample[:8].copy()
     rows8, _, _ = orc.frame_loop(few, pix, want_rows=True, threads=1)
     fps = nframes_step / (t_proj + t_fixed + per_frame * nframes_step)
     out = {"value": fps, "unit": "frames/s", "cores": cores, "kind": "port",
            "sample": "oracle/ (C, OpenMP, %d threads): projection build on the full model (%d rays, %.2f s) "
-                     "+ %d and %d frames of the frame loop (%.3f s, %.3f s -> %.2f ms per frame + %.2f s per run); "
-                     "extrapolated to the %d-frame step"
-                     % (cores, r["nrays"], t_proj, frames.shape[0], n_short, t_frames, t_short, per_frame * 1e3, t_fixed,
-                        nframes_step),
+                     "+ %d frames of the frame loop (%.3f s: %.3f ms per frame + %.2f s per run for the "
+                     "thread-private accumulators); extrapolated to the %d-frame step"
+                     % (cores, r["nrays"], t_proj, frames.shape[0], t_frames, per_frame * 1e3, t_fixed, nframes_step),
            "mrays_per_s": mrays, "frame_loop_frames_per_s": 1.0 / per_frame, "bvh_build_s": t_build}
     return out, dict(pix=pix, nrays=int(r["nrays"]), sum=s, sumsq=ss, rows8=rows8, frames_fixed=frames)
 

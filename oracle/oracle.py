@@ -87,7 +87,7 @@ def lib():
         L.orc_accumulate.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.orc_frame_loop_u16.argtypes = ([C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
-                                          C.c_void_p, C.c_int])
+                                          C.c_void_p, C.c_int, C.c_void_p])
         L.orc_frame_loop_u16.restype = None
         L.orc_finals.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64,
                                  C.c_void_p, C.c_void_p]
@@ -303,9 +303,10 @@ def accumulate(sol, s, ss):
 
 
 def frame_loop(frames, pix, weight=None, skipped=None, thresh=4064, min_change=512, max_hot=5,
-               want_rows=True, threads=1):
+               want_rows=True, threads=1, timing=None):
     """The plain frame loop of psp_process.cpp:1742-1851 (OpenMP over frames, thread-private double
-    accumulators).  frames: u16 [F,H,W], repaired IN PLACE.  Returns (rows [F,N] or None, sum, sumsq)."""
+    accumulators).  frames: u16 [F,H,W], repaired IN PLACE.  Returns (rows [F,N] or None, sum, sumsq).
+    timing: dict that receives the seconds spent in set-up / frame loop / merge."""
     assert frames.dtype == np.uint16 and frames.flags.c_contiguous and frames.ndim == 3
     pix = np.ascontiguousarray(pix, dtype=np.int32)
     w = None if weight is None else _f32(weight)
@@ -313,8 +314,11 @@ def frame_loop(frames, pix, weight=None, skipped=None, thresh=4064, min_change=5
     F, H, W = frames.shape
     rows = np.empty((F, pix.size), np.float32) if want_rows else None
     s, ss = np.zeros(pix.size), np.zeros(pix.size)
+    sec = None if timing is None else np.zeros(3)
     lib().orc_frame_loop_u16(_p(frames), F, H, W, _p(pix), _p(w), _p(sk), sk.size, pix.size, thresh, min_change,
-                             max_hot, _p(rows), _p(s), _p(ss), int(threads))
+                             max_hot, _p(rows), _p(s), _p(ss), int(threads), _p(sec))
+    if timing is not None:
+        timing.update(setup=float(sec[0]), loop=float(sec[1]), merge=float(sec[2]))
     return rows, s, ss
 
 

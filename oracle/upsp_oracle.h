@@ -166,7 +166,7 @@ void orc_project_frame_u16(const uint16_t *img, const int32_t *pix, const float 
 void orc_frame_loop_u16(uint16_t *frames, int nframes, int rows, int cols, const int32_t *pix,
                         const float *weight, const int32_t *skipped, size_t nskipped, size_t nnodes,
                         int thresh, int min_change, int max_hot, float *out_rows, double *sum,
-                        double *sumsq, int threads);
+                        double *sumsq, int threads, double *seconds);
 void orc_accumulate(const float *sol, size_t nnodes, double *sum, double *sumsq);
 /* finals, psp_process.cpp:1930-1979 */
 void orc_finals(const double *sum, const double *sumsq, size_t nnodes, uint64_t nframes,

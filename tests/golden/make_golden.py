@@ -78,6 +78,15 @@ def main():
     rm, tv, cm, dc = refdata.read_camera_tunnel_cal(cal, (512, 1024))
     assert all(np.array_equal(a, b) for a, b in ((rm, rm_ref), (tv, tv_ref), (cm, cm_ref), (dc, dc_ref)))
 
+    # targets file reader (parsers.read_tgts) -- fixture test/data/fml_tc3_volume.tgts
+    tg_ref = parsers.read_tgts(os.path.join(REF, "test/data/fml_tc3_volume.tgts"))
+    tg = refdata.read_tgts(os.path.join(HERE, "fml_tc3_volume.tgts"))
+    assert len(tg) == len(tg_ref) == 24
+    for a, b in zip(tg, tg_ref):
+        assert a.keys() == b.keys()
+        for k in a:
+            assert np.array_equal(a[k], b[k]) if isinstance(a[k], np.ndarray) else a[k] == b[k], k
+
     from oracle import oracle as orc
     from test_oracle_kat import OracleScene
     from upsp_processing_amd.visibility import VisibilityChecker

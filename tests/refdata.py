@@ -99,6 +99,39 @@ def read_camera_tunnel_cal(path, dims):
             np.array(cal["distCoeffs"]))
 
 
+def read_tgts(path, output_target_types=None):
+    """parsers.read_tgts (python/upsp/cam_cal_utils/parsers.py:13-97): the *Targets section."""
+    targets, section = [], None
+    for raw in open(path):
+        line = [x for x in raw.rstrip("\n").split(" ") if x != ""]
+        if len(line) <= 1:                 # a one-item line names the section, an empty line ends it
+            section = line[0] if len(line) == 1 else None
+            continue
+        if section != "*Targets":
+            continue
+        last = line[-1]
+        ttype = "dot" if "st" in last else "kulite" if "mK" in last else "painted_kulite" if "pK" in last else last
+        if output_target_types is None or ttype in output_target_types:
+            targets.append({"target_type": ttype,
+                            "tvec": np.expand_dims([float(x) for x in line[1:4]], 1),
+                            "norm": np.expand_dims([float(x) for x in line[4:7]], 1),
+                            "size": float(line[7]), "name": last, "idx": int(line[0]),
+                            "zones": (int(line[8]), int(line[9]), int(line[10]))})
+    return targets
+
+
+# inputs of test/python/test_photogrammetry.py setUpClass (:24-34) -- reference-held test data
+PHOTOGRAMMETRY_CAL = dict(
+    rmat=np.array([[-0.999726480569, -0.0129787134506, 0.0194555145360],
+                   [-0.013183724300, 0.9998585205361, -0.0104464503478],
+                   [-0.019317180494, -0.0107000891804, -0.9997561475826]]),
+    tvec=np.array([[-5.093035986816], [-0.07716666965650], [11.556054197934]]),
+    cameraMatrix=np.array([[1380.2632820187425, 0.0, 533.908701486902032],
+                           [0.0, 1380.2632820187425, 256.778541140320840],
+                           [0.0, 0.0, 1.0]]),
+    distCoeffs=np.array([[-0.09098491035825468, 0.0, 0.0, 0.0, 0.0]]))
+
+
 def fml_grid():
     zs, x, y, z = read_p3d_grid(os.path.join(GOLDEN, "fml_tc3_volume.grid"))
     return p3d_to_triangles(zs, x, y, z)

@@ -133,3 +133,31 @@ def test_far_off_distorted_nodes(gpu_lib, oracle):
         g = engine.build_projection(bvh, cam_g, v, nrm, d_tn, 70.0)
         assert np.array_equal(g["pix"].cpu().numpy(), o["pix"])
         assert g["nrays"] == o["nrays"] == 35
+
+
+@pytest.mark.parametrize("model", ["quad", "uv"])
+def test_projection_full_size_vs_oracle(gpu_lib, oracle, model):
+    """BASELINE configs[1] at its own size: the projection of the bench's 1 001 904-triangle tunnel
+    model (and of the UV-sphere variant with 1000-valent polar fans) onto the 1024 x 1024 frame,
+    `pix`, `uv`, node count image and the reference ray count against the oracle (OpenMP; 0.3 s on
+    the GPU box's host cores), with and without the node -> triangle adjacency."""
+    import os
+    import torch
+    from upsp_processing_amd import engine, synthetic as syn
+    mesh = syn.tunnel_model_quad() if model == "quad" else syn.tunnel_model()
+    v, t, s9, tn, nrm, cam_g, cam_o = setup_case(oracle, mesh, dict(center=(0, 0, 20), half_extent=6.0), (1024, 1024))
+    assert t.shape[0] > 1_000_000
+    bvh = engine.BVH(s9)
+    obv = oracle.OracleBVH(s9)
+    o = oracle.create_projection(obv, cam_o, v, nrm, tn, engine.oblique_threshold(70.0), threads=os.cpu_count() or 1)
+    d_tn = torch.as_tensor(tn).cuda()
+    g0 = engine.build_projection(bvh, cam_g, v, nrm, tn, 70.0, nodecount=True)      # classic retries
+    bvh.set_tri_nodes(d_tn, v.shape[0])
+    g1 = engine.build_projection(bvh, cam_g, v, nrm, d_tn, 70.0, nodecount=True)    # own-triangle bound + witness
+    assert (o["pix"] >= 0).sum() > 100_000
+    for g in (g0, g1):
+        assert np.array_equal(g["pix"].cpu().numpy(), o["pix"])
+        assert np.array_equal(g["uv"].cpu().numpy().view(np.int32), o["uv"].view(np.int32))
+        assert g["nrays"] == o["nrays"]
+        assert np.array_equal(g["nodecount"].cpu().numpy(), o["nodecount"])
+    bvh.close()
