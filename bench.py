@@ -80,13 +80,38 @@ def spawn_ranks(n):
     return subprocess.call(cmd)
 
 
+def usable_cpus():
+    """Host cores this process may really use: the affinity mask and the cgroup CPU quota (a one-GPU box
+    of the pool exposes all of the host's logical CPUs but grants a share of them)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(round(int(txt[0]) / int(txt[1])))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(round(q / per))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(verts, tris, cam_dict, size, nframes_step, sample):
     """Oracle (CPU restatement, kind 'port') on a bounded sample of the same workload: the projection
     build on the full model (OpenMP over node blocks like psp_process.cpp:218-260) and the frame loop
     (OpenMP over frames like psp_process.cpp:1742-1851) on the first `len(sample)` frames of the step."""
     from oracle import oracle as orc
     from upsp_processing_amd import synthetic as syn, engine
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()
     s9, tn = syn.soup(verts, tris)
     nrm = syn.node_normals(verts, tris)
     t0 = time.perf_counter()

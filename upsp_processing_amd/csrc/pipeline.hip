@@ -522,8 +522,9 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
         uint16_t *fr = d_frames[0];
         for (int s0 = 0; s0 < nframes && rc == UPSP_OK; s0 += S) {
             const int ns = std::min(S, nframes - s0);
+            static const bool dbg_noorder = std::getenv("UPSP_NO_TILE_ORDER") != nullptr;   // (measurement switch)
             rc = launch_scan_compact(fr + (size_t)s0 * npix, npix, ns, hot, p->opts.hot_thresh, p->opts.hot_max, p->d_aflag,
-                                     p->d_tile_off, p->d_tile_order, p->d_compact, cp, 0, hot ? p->d_hot_count + s0 : nullptr,
+                                     p->d_tile_off, dbg_noorder ? nullptr : p->d_tile_order, p->d_compact, cp, 0, hot ? p->d_hot_count + s0 : nullptr,
                                      hot ? p->d_hot_pos + (size_t)s0 * 64 : nullptr, st);
             g.nframes = ns;
             g.rows_t = d_rows_t ? d_rows_t + col0 + s0 : nullptr;
