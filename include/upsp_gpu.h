@@ -302,6 +302,26 @@ int upsp_pipeline_reset(upsp_pipeline *p);
 int upsp_pipeline_finalize(upsp_pipeline *p, uint64_t nframes_total, float *d_avg,
                            float *d_rms, void *stream);
 
+/* ---- frame feed from host memory ------------------------------------------------------------
+ * Replaces the reference's read-ahead thread + per-frame wait (cpp/exec/psp_process.cpp:867-1007,
+ * 1756-1764): a ring of `nslots` pinned host buffers of `slot_bytes`, each with a device twin, and a
+ * copy stream of its own.  Per chunk of frames:
+ *   upsp_feed_acquire  -> next slot and its pinned host pointer (blocks only while that slot's
+ *                         previous upload / consumer are still in flight); fill it (read the file
+ *                         straight into it)
+ *   upsp_feed_commit   -> hipMemcpyAsync host -> device twin on the copy stream; `consumer_stream`
+ *                         is made to wait for it; returns the device pointer
+ *   ... launches on consumer_stream that read the device pointer (upsp_unpack_12bit, upsp_pipeline_process)
+ *   upsp_feed_release  -> marks the point on consumer_stream after which the device twin may be
+ *                         overwritten
+ * Slots are used round-robin and must be released in the order they were committed. */
+typedef struct upsp_feed upsp_feed;
+int upsp_feed_create(size_t slot_bytes, int nslots, upsp_feed **out);
+void upsp_feed_destroy(upsp_feed *f);
+int upsp_feed_acquire(upsp_feed *f, int *slot, void **h_ptr);
+int upsp_feed_commit(upsp_feed *f, int slot, size_t nbytes, void *consumer_stream, void **d_ptr);
+int upsp_feed_release(upsp_feed *f, int slot, void *consumer_stream);
+
 /* ---- stand-alone per-frame operators (same kernels the pipeline uses) ------ */
 
 /* upsp::fix_hot_pixels (cpp/utils/cv_extras.cpp:230-275) on nframes frames in place;

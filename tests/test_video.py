@@ -184,3 +184,37 @@ def test_cine_reader_frames(gpu_lib, oracle, tmp_path):
     _write_cine(p, [words[0].tobytes()], W, H, 8)
     fr = video.CineReader(p).read_frames_device(1, 1).cpu().numpy()
     assert np.array_equal(fr[0], words[0][::-1])
+
+
+@pytest.mark.gpu
+def test_frame_feed_ring(gpu_lib):
+    """Pinned staging ring: 7 chunks through 3 slots, uploads on the copy stream, the 12-bit unpack on
+    the consumer stream -- every chunk arrives intact although the slots are reused while earlier
+    chunks are still being consumed; misuse is refused."""
+    import torch
+    from upsp_processing_amd import _capi, video
+    H, W, n = 64, 96, 5
+    fb = H * W * 3 // 2
+    feed = video.FrameFeed(n * fb, 3)
+    rng = np.random.default_rng(3)
+    outs, want = [], []
+    for k in range(7):
+        raw = rng.integers(0, 256, (n, fb), dtype=np.uint8)
+
+        def fill(dst, raw=raw):
+            dst[:raw.size] = raw.reshape(-1)
+            return raw.size
+        d = feed.upload(fill)
+        outs.append(video.unpack_12bit(d.view(n, fb), H, W))
+        feed.release()
+        b = raw.astype(np.uint16)
+        px = np.empty((n, H * W), np.uint16)
+        px[:, 0::2] = (b[:, 0::3] << 4) | (b[:, 1::3] >> 4)
+        px[:, 1::2] = ((b[:, 1::3] & 0x0F) << 8) | b[:, 2::3]
+        want.append(px.reshape(n, H, W))
+    torch.cuda.synchronize()
+    for o, w in zip(outs, want):
+        assert np.array_equal(o.cpu().view(torch.int16).numpy().view(np.uint16), w)
+    with pytest.raises(_capi.UpspError):
+        feed.upload(lambda dst: feed.slot_bytes + 1)        # more bytes than the slot holds
+    feed.close()

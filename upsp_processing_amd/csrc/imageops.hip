@@ -345,11 +345,16 @@ __global__ void __launch_bounds__(256)
         return -0.5f * pix(reflect101(yy - 1, rows), xx) + 0.5f * pix(reflect101(yy + 1, rows), xx);
     };
 
-    const size_t per_block = (npix + gridDim.x - 1) / gridDim.x;
-    const size_t lo = (size_t)blockIdx.x * per_block;
-    const size_t hi = min(npix, lo + per_block);
-    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        const int y = (int)(i / (size_t)cols), x = (int)(i % (size_t)cols);
+    // pixels lo + tid, + 256, ... of this block's range, with (x, y) carried along instead of a
+    // 64-bit division per pixel and 32-bit offsets (the launcher refuses images of 2^31 pixels):
+    // the division and the 64-bit address arithmetic were a third of the loop's ~330 instructions
+    const unsigned npx = (unsigned)npix;
+    const unsigned per_block = (npx + gridDim.x - 1) / gridDim.x;
+    const unsigned lo = blockIdx.x * per_block;
+    const unsigned hi = min(npx, lo + per_block);
+    unsigned i = lo + threadIdx.x;
+    int y = (int)(i / (unsigned)cols), x = (int)(i % (unsigned)cols);
+    for (; i < hi; i += 256u) {
         // fixed-point source coordinate once; the INTER_LINEAR and INTER_NEAREST (mask)
         // variants differ only in the rounding offset (16 vs 512) and the shift
         const int Xr = __double2int_rn((M[1] * y + M[2]) * 1024) + __double2int_rn(M[0] * x * 1024);
@@ -366,14 +371,14 @@ __global__ void __launch_bounds__(256)
         const bool m = (unsigned)nx < (unsigned)cols && (unsigned)ny < (unsigned)rows;
         float w, gx, gy;
         if (IDENT && x >= 1 && x + 2 < cols && y >= 1 && y + 2 < rows) {
-            const float *r1 = I + (size_t)y * cols + x;
+            const float *r1 = I + i;
             w = r1[0];
             gx = -0.5f * r1[-1] + 0.5f * r1[1];
             gy = -0.5f * r1[-cols] + 0.5f * r1[cols];
         } else if (c.sx >= 1 && c.sx + 2 < cols && c.sy >= 1 && c.sy + 2 < rows) {
             // fully interior footprint: 12 pixels, no border handling; same arithmetic as
             // the generic path (bilinear of I, of [-0.5 0 0.5] along x and along y)
-            const float *r0 = I + (size_t)(c.sy - 1) * cols + c.sx;
+            const float *r0 = I + (unsigned)((c.sy - 1) * cols + c.sx);
             const float *r1 = r0 + cols, *r2 = r1 + cols, *r3 = r2 + cols;
             const float a0 = r0[0], a1 = r0[1];
             const float b_1 = r1[-1], b0 = r1[0], b1 = r1[1], b2 = r1[2];
@@ -416,6 +421,11 @@ __global__ void __launch_bounds__(256)
                 acc[h] = fma(Jd[a], Jd[b], acc[h]);
                 ++h;
             }
+        }
+        x += 256;
+        while (x >= cols) {
+            x -= cols;
+            ++y;
         }
     }
     // deterministic block reduction: wave shuffle tree, then 4 waves through LDS
@@ -968,6 +978,7 @@ int frame_scratch_ensure(FrameScratch **ps, int ncams, int batch, int rows, int 
 static int run_ecc(FrameScratch *s, const float *tmpl_blur, const uint16_t *frames, int nb,
                    int64_t first_frame, int rows, int cols, int max_iters, double eps, hipStream_t st)
 {
+    if ((long long)rows * cols >= (1ll << 31)) return fail(UPSP_ERR_INVALID, "registration: image too large");
     int rc = launch_gauss<uint16_t>(frames, s->ecc_img, s->tmp, nb, rows, cols, 5, st);
     if (rc != UPSP_OK) return rc;
     const dim3 g1((nb + 63) / 64), b1(64);

@@ -256,9 +256,13 @@ def run(flags):
     rows_t = torch.empty((job.nnodes, engine.series_ld(max(nf, 1))), dtype=torch.float32,
                          device="cuda")[:, :max(nf, 1)]
     chunk = 256
+    # frames go disk -> pinned ring -> device on a copy stream of their own (the reference's read-ahead
+    # thread, psp_process.cpp:867-1007): the upload of chunk k + 1 overlaps the processing of chunk k
+    feeds = [video.FrameFeed(min(chunk, max(nf, 1)) * r.frame_bytes, 3) if getattr(r, "raw_bit_depth", 12) == 12
+             else None for r in readers]
     for c0 in range(0, nf, chunk):
         n = min(chunk, nf - c0)
-        batch = [r.read_frames_device(f0 + c0 + 1, n) for r in readers]     # 1-based frames
+        batch = [r.read_frames_device(f0 + c0 + 1, n, feed=fd) for r, fd in zip(readers, feeds)]     # 1-based frames
         job.process(batch, first_frame=f0 + c0, rows_t=rows_t, col0=c0)
         if shard.rank == 0 and c0 % (chunk * 4) == 0:
             print("  Rank 0:: processing frame %d" % (f0 + c0))

@@ -44,11 +44,78 @@ class MrawReader:
             buf = np.fromfile(f, dtype=np.uint8, count=count * self.frame_bytes)
         return buf.reshape(count, self.frame_bytes)
 
-    def read_frames_device(self, first, count, hot_thresh=None):
-        """u16 tensor [count, H, W] on the GPU (+ per-frame hot-pixel counts if requested)."""
+    def read_packed_into(self, dst, first, count):
+        """The same bytes read straight into `dst` (u8 array, e.g. a pinned FrameFeed slot)."""
+        if first < 1 or first + count - 1 > self.num_frames:
+            raise IndexError("frame out of range")
+        n = count * self.frame_bytes
+        with open(self.mraw_file, "rb", buffering=0) as f:
+            f.seek((first - 1) * self.frame_bytes)
+            got = f.readinto(memoryview(dst.reshape(-1)[:n]))
+        if got != n:
+            raise IOError("short read from %s" % self.mraw_file)
+        return n
+
+    def read_frames_device(self, first, count, hot_thresh=None, feed=None):
+        """u16 tensor [count, H, W] on the GPU (+ per-frame hot-pixel counts if requested).
+        feed: a FrameFeed -- the bytes go disk -> pinned slot -> device on the feed's copy stream,
+        without blocking the host on the transfer."""
         import torch
+        if feed is not None:
+            packed = feed.upload(lambda dst: self.read_packed_into(dst, first, count))
+            out = unpack_12bit(packed.view(count, self.frame_bytes), self.height, self.width, hot_thresh)
+            feed.release()
+            return out
         packed = torch.as_tensor(self.read_packed(first, count)).cuda()
         return unpack_12bit(packed, self.height, self.width, hot_thresh)
+
+
+class FrameFeed:
+    """Pinned staging ring + copy stream (include/upsp_gpu.h: upsp_feed_*; the reference's read-ahead
+    thread, cpp/exec/psp_process.cpp:867-1007).  One upload() / release() pair per chunk of frames:
+
+        packed = feed.upload(fill)       # fill(dst_u8_array) -> number of bytes it wrote
+        frames = unpack_12bit(packed.view(n, frame_bytes), H, W)   # current stream waits for the copy only
+        feed.release()                   # the slot may be overwritten once the stream gets here
+
+    The host blocks only when all `nslots` slots are in flight."""
+
+    def __init__(self, slot_bytes, nslots=3):
+        from . import _capi
+        h = C.c_void_p()
+        _capi.check(_capi.lib().upsp_feed_create(int(slot_bytes), int(nslots), C.byref(h)))
+        self._h, self.slot_bytes, self.nslots = h, int(slot_bytes), int(nslots)
+        self._destroy = _capi.lib().upsp_feed_destroy
+        self._pending = []
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def upload(self, fill):
+        """Acquire the next slot, let fill(dst) write into its pinned buffer (dst: numpy u8 view of
+        the whole slot; returns the byte count), start the upload.  Returns a u8 device tensor view."""
+        import torch
+        from . import _capi
+        from .engine import _stream
+        slot, hp = C.c_int(), C.c_void_p()
+        _capi.check(_capi.lib().upsp_feed_acquire(self._h, C.byref(slot), C.byref(hp)))
+        dst = np.ctypeslib.as_array(C.cast(hp, C.POINTER(C.c_uint8)), shape=(self.slot_bytes,))
+        n = int(fill(dst))
+        dp = C.c_void_p()
+        _capi.check(_capi.lib().upsp_feed_commit(self._h, slot.value, n, _stream(), C.byref(dp)))
+        self._pending.append(slot.value)
+        from .engine import _DevArray
+        t = torch.as_tensor(_DevArray(dp.value, max(n, 1), "|u1", self), device="cuda")[:n]
+        return t
+
+    def release(self):
+        from . import _capi
+        from .engine import _stream
+        _capi.check(_capi.lib().upsp_feed_release(self._h, self._pending.pop(0), _stream()))
 
 
 def unpack_12bit(packed, height, width, hot_thresh=None):
@@ -139,8 +206,16 @@ class CineReader:
                 out[i] = np.fromfile(f, dtype=np.uint8, count=self.frame_bytes)
         return out
 
-    def read_frames_device(self, first, count, hot_thresh=None):
+    def read_frames_device(self, first, count, hot_thresh=None, feed=None):
         import torch
+        if feed is not None and self.raw_bit_depth == 12:
+            def fill(dst):
+                dst[:count * self.frame_bytes].reshape(count, self.frame_bytes)[:] = self.read_packed(first, count)
+                return count * self.frame_bytes
+            packed = feed.upload(fill)
+            out = unpack_12bit(packed.view(count, self.frame_bytes), self.height, self.width, hot_thresh)
+            feed.release()
+            return out
         raw = self.read_packed(first, count)
         if self.raw_bit_depth == 12:
             return unpack_12bit(torch.as_tensor(raw).cuda(), self.height, self.width, hot_thresh)
