@@ -345,61 +345,22 @@ __global__ void __launch_bounds__(256)
         return -0.5f * pix(reflect101(yy - 1, rows), xx) + 0.5f * pix(reflect101(yy + 1, rows), xx);
     };
 
-    // pixels lo + tid, + 256, ... of this block's range, with (x, y) carried along instead of a
-    // 64-bit division per pixel and 32-bit offsets (the launcher refuses images of 2^31 pixels):
-    // the division and the 64-bit address arithmetic were a third of the loop's ~330 instructions
-    const unsigned npx = (unsigned)npix;
-    const unsigned per_block = (npx + gridDim.x - 1) / gridDim.x;
-    const unsigned lo = blockIdx.x * per_block;
-    const unsigned hi = min(npx, lo + per_block);
-    unsigned i = lo + threadIdx.x;
-    int y = (int)(i / (unsigned)cols), x = (int)(i % (unsigned)cols);
-    for (; i < hi; i += 256u) {
-        // fixed-point source coordinate once; the INTER_LINEAR and INTER_NEAREST (mask)
-        // variants differ only in the rounding offset (16 vs 512) and the shift
+    // fixed-point source coordinate of pixel (x, y) (WarpAffineInvoker) and the nearest-neighbour mask
+    auto coords = [&](int x, int y, WarpCoord &c) {
         const int Xr = __double2int_rn((M[1] * y + M[2]) * 1024) + __double2int_rn(M[0] * x * 1024);
         const int Yr = __double2int_rn((M[4] * y + M[5]) * 1024) + __double2int_rn(M[3] * x * 1024);
-        WarpCoord c;
-        {
-            const int X = (Xr + 16) >> 5, Y = (Yr + 16) >> 5;
-            c.sx = max(-32768, min(32767, X >> 5));
-            c.sy = max(-32768, min(32767, Y >> 5));
-            c.ax = X & 31;
-            c.ay = Y & 31;
-        }
+        const int X = (Xr + 16) >> 5, Y = (Yr + 16) >> 5;
+        c.sx = max(-32768, min(32767, X >> 5));
+        c.sy = max(-32768, min(32767, Y >> 5));
+        c.ax = X & 31;
+        c.ay = Y & 31;
         const int nx = max(-32768, min(32767, (Xr + 512) >> 10)), ny = max(-32768, min(32767, (Yr + 512) >> 10));
-        const bool m = (unsigned)nx < (unsigned)cols && (unsigned)ny < (unsigned)rows;
-        float w, gx, gy;
-        if (IDENT && x >= 1 && x + 2 < cols && y >= 1 && y + 2 < rows) {
-            const float *r1 = I + i;
-            w = r1[0];
-            gx = -0.5f * r1[-1] + 0.5f * r1[1];
-            gy = -0.5f * r1[-cols] + 0.5f * r1[cols];
-        } else if (c.sx >= 1 && c.sx + 2 < cols && c.sy >= 1 && c.sy + 2 < rows) {
-            // fully interior footprint: 12 pixels, no border handling; same arithmetic as
-            // the generic path (bilinear of I, of [-0.5 0 0.5] along x and along y)
-            const float *r0 = I + (unsigned)((c.sy - 1) * cols + c.sx);
-            const float *r1 = r0 + cols, *r2 = r1 + cols, *r3 = r2 + cols;
-            const float a0 = r0[0], a1 = r0[1];
-            const float b_1 = r1[-1], b0 = r1[0], b1 = r1[1], b2 = r1[2];
-            const float c_1 = r2[-1], c0 = r2[0], c1 = r2[1], c2 = r2[2];
-            const float d0 = r3[0], d1 = r3[1];
-            const float fx = c.ax * (1.f / 32), fy = c.ay * (1.f / 32);
-            const float w0 = (1.f - fy) * (1.f - fx), w1 = (1.f - fy) * fx, w2 = fy * (1.f - fx), w3 = fy * fx;
-            w = b0 * w0 + b1 * w1 + c0 * w2 + c1 * w3;
-            gx = (-0.5f * b_1 + 0.5f * b1) * w0 + (-0.5f * b0 + 0.5f * b2) * w1 +
-                 (-0.5f * c_1 + 0.5f * c1) * w2 + (-0.5f * c0 + 0.5f * c2) * w3;
-            gy = (-0.5f * a0 + 0.5f * c0) * w0 + (-0.5f * a1 + 0.5f * c1) * w1 +
-                 (-0.5f * b0 + 0.5f * d0) * w2 + (-0.5f * b1 + 0.5f * d1) * w3;
-        } else {
-            w = bilinear(pix, rows, cols, c);
-            gx = bilinear(gxf, rows, cols, c);
-            gy = bilinear(gyf, rows, cols, c);
-        }
+        return (unsigned)nx < (unsigned)cols && (unsigned)ny < (unsigned)rows;
+    };
+    // the 45 sums of one pixel; masked terms enter with weight mm = 1 / 0 (branch-free); fma = one rounding
+    auto accumulate = [&](float w, float gx, float gy, float t, bool m, int x, int y) {
         const float X = (float)x, Y = (float)y;
         const float J[6] = {gx * X, gy * X, gx * Y, gy * Y, gx, gy};
-        const float t = tmpl[i];
-        // masked terms enter with weight mm = 1 / 0 (branch-free); fma = one rounding
         const double mm = m ? 1.0 : 0.0, wd = w, td = t, tm = m ? td : 0.0, wm = m ? wd : 0.0;
         acc[0] += mm;
         acc[1] += wm;
@@ -422,15 +383,101 @@ __global__ void __launch_bounds__(256)
                 ++h;
             }
         }
+    };
+    // fully interior footprint: 12 pixels, no border handling; same arithmetic as the generic path
+    // (bilinear of I, of [-0.5 0 0.5] along x and along y)
+    auto interior = [&](const WarpCoord &c, float &w, float &gx, float &gy) {
+        const float *r0 = I + (unsigned)((c.sy - 1) * cols + c.sx);
+        const float *r1 = r0 + cols, *r2 = r1 + cols, *r3 = r2 + cols;
+        const float a0 = r0[0], a1 = r0[1];
+        const float b_1 = r1[-1], b0 = r1[0], b1 = r1[1], b2 = r1[2];
+        const float c_1 = r2[-1], c0 = r2[0], c1 = r2[1], c2 = r2[2];
+        const float d0 = r3[0], d1 = r3[1];
+        const float fx = c.ax * (1.f / 32), fy = c.ay * (1.f / 32);
+        const float w0 = (1.f - fy) * (1.f - fx), w1 = (1.f - fy) * fx, w2 = fy * (1.f - fx), w3 = fy * fx;
+        w = b0 * w0 + b1 * w1 + c0 * w2 + c1 * w3;
+        gx = (-0.5f * b_1 + 0.5f * b1) * w0 + (-0.5f * b0 + 0.5f * b2) * w1 +
+             (-0.5f * c_1 + 0.5f * c1) * w2 + (-0.5f * c0 + 0.5f * c2) * w3;
+        gy = (-0.5f * a0 + 0.5f * c0) * w0 + (-0.5f * a1 + 0.5f * c1) * w1 +
+             (-0.5f * b0 + 0.5f * d0) * w2 + (-0.5f * b1 + 0.5f * d1) * w3;
+    };
+
+    // Pixels lo + tid, + 256, ... of this block's range, (x, y) carried along (no division per pixel,
+    // 32-bit offsets: the launcher refuses images of 2^31 pixels).
+    //
+    // Pixels whose footprint touches the image border need the generic bilinear (reflect-101 gradients,
+    // constant-0 border): ~300 instructions against ~130.  A 256-pixel strip of a 1024-wide image holds
+    // such a pixel in two of its four waves, so taking that path inside the sweep made HALF of all
+    // wave-iterations pay for it (measured: 482 us per 64-frame launch against 324 us with the border
+    // path switched off).  The sweep therefore only LISTS those pixels -- per wave, in LDS, slots by
+    // ballot + prefix count, so the order is fixed -- and the wave works its list off afterwards, 64 border
+    // pixels per trip.  A list that runs full falls back to the path in place.
+    constexpr unsigned kListCap = 1024;   // per wave
+    __shared__ unsigned blist[4][kListCap];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned nlist = 0;                    // (wave-uniform)
+    const unsigned npx = (unsigned)npix;
+    const unsigned per_block = (npx + gridDim.x - 1) / gridDim.x;
+    const unsigned lo = blockIdx.x * per_block;
+    const unsigned hi = min(npx, lo + per_block);
+    unsigned i = lo + threadIdx.x;
+    int y = (int)(i / (unsigned)cols), x = (int)(i % (unsigned)cols);
+    for (; i < hi; i += 256u) {
+        WarpCoord c;
+        const bool m = coords(x, y, c);
+        float w = 0.f, gx = 0.f, gy = 0.f;
+        bool fast;
+        if (IDENT) {
+            fast = x >= 1 && x + 2 < cols && y >= 1 && y + 2 < rows;
+            if (fast) {
+                const float *r1 = I + i;
+                w = r1[0];
+                gx = -0.5f * r1[-1] + 0.5f * r1[1];
+                gy = -0.5f * r1[-cols] + 0.5f * r1[cols];
+            }
+        } else {
+            fast = c.sx >= 1 && c.sx + 2 < cols && c.sy >= 1 && c.sy + 2 < rows;
+            if (fast) interior(c, w, gx, gy);
+        }
+        bool now = fast;
+        const unsigned long long slow = __ballot(!fast);
+        if (slow != 0ull) {                                  // (rare for a wave)
+            const unsigned n = (unsigned)__popcll(slow);
+            if (nlist + n <= kListCap) {
+                if (!fast) blist[wave][nlist + (unsigned)__popcll(slow & ((1ull << lane) - 1ull))] = i;
+                nlist += n;
+            } else if (!fast) {                              // list full: generic path in place
+                w = bilinear(pix, rows, cols, c);
+                gx = bilinear(gxf, rows, cols, c);
+                gy = bilinear(gyf, rows, cols, c);
+                now = true;
+            }
+        }
+        if (now) accumulate(w, gx, gy, tmpl[i], m, x, y);
         x += 256;
         while (x >= cols) {
             x -= cols;
             ++y;
         }
     }
+    // the listed pixels (a wave reads what it wrote itself: LDS operations of a wave complete in order)
+    for (unsigned k = (unsigned)lane; k < nlist; k += 64u) {
+        const unsigned ib = blist[wave][k];
+        const int yb = (int)(ib / (unsigned)cols), xb = (int)(ib % (unsigned)cols);
+        WarpCoord c;
+        const bool m = coords(xb, yb, c);
+        float w, gx, gy;
+        if (!IDENT && c.sx >= 1 && c.sx + 2 < cols && c.sy >= 1 && c.sy + 2 < rows) {
+            interior(c, w, gx, gy);                          // (not reached: such pixels are never listed)
+        } else {
+            w = bilinear(pix, rows, cols, c);
+            gx = bilinear(gxf, rows, cols, c);
+            gy = bilinear(gyf, rows, cols, c);
+        }
+        accumulate(w, gx, gy, tmpl[ib], m, xb, yb);
+    }
     // deterministic block reduction: wave shuffle tree, then 4 waves through LDS
     __shared__ double red[4][kEccSums];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < kEccSums; ++k) {
         double v = acc[k];
