@@ -195,7 +195,9 @@ typedef struct upsp_pipeline_opts {
     /* frame-loop schedule of the plain path (one camera, no weights, no image stage, node-major series):
      * 0 / 1 = streamed two-pass schedule (pass A: scan + compact pixel series of up to 1024 frames per
      * launch, pass B: every node's row piece written once, whole), 2 = scan kernel + gather kernel per
-     * 64 frames (relies on the sub-batch staying in the Infinity Cache).  Same results. */
+     * 64 frames (relies on the sub-batch staying in the Infinity Cache).  Same results.  Several cameras
+     * (weights allowed): 1 = streamed (one compact buffer per camera, pass B sums the cameras in order),
+     * 2 = scan + gather, 0 = streamed for calls of >= 192 frames (rows bit-identical, accumulators to 1e-12). */
     int32_t fused_scan;
     /* streamed schedule: budget in MiB for the compact pixel-series buffer (2 B x min(nodes, pixels) x
      * frames of a group, allocated on first use); 0 = default (2048).  It bounds the frames per pass A /

@@ -462,6 +462,14 @@ def test_multi_camera_streamed_schedule(gpu_lib, oracle, F):
     pix = rng.integers(-1, H * W, size=(ncams, n)).astype(np.int32)
     pix[:, ::17] = -1                                        # skipped in every camera
     pix[1, ::5] = -1
+    # stuck hot pixels in two cameras, both read by the same nodes (two replaced pixels on one (node, frame));
+    # a third one next to the first (its repair sees the repaired neighbour)
+    frames[0][:, 5, 7] = 4095
+    frames[0][::2, 5, 8] = 4090
+    frames[2][:, 9, 3] = 4095
+    pix[0, 1:60] = 5 * W + 7
+    pix[2, 1:60] = 9 * W + 3
+    pix[0, 60:70] = 5 * W + 8
     weight = rng.random((ncams, n)).astype(np.float32)
     rows_o, s_o, ss_o = run_loop_oracle(oracle, frames, pix, weight)
     res = {}

@@ -25,16 +25,26 @@ centers = np.array([engine.camera_center(_capi.make_camera(*(lambda c: (c["K"], 
 w = engine.projection_weights(pix, dn, dm, centers, "average_view")
 sk, ns = engine.skipped_nodes(pix)
 print("skipped", ns, "of", v.shape[0])
-F = 64
-frames = [syn.synth_frames_torch(F, size, size, first=100 * c) for c in range(4)]
-pipe = engine.FramePipeline(4, size, size, v.shape[0])
-for c in range(4):
-    pipe.set_projection(c, pix[c], w[c])
-rows_t = torch.empty((v.shape[0], engine.series_ld(F)), dtype=torch.float32, device="cuda")[:, :F]
-for r in range(3):
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    pipe.process(frames, 0, rows_t=rows_t, want_rows=False)
-    torch.cuda.synchronize(); d = time.perf_counter() - t0
-print("4-camera frame loop: %.2f ms for %d frame sets (%.0f camera-frames/s)" % (d * 1e3, F, 4 * F / d))
-ok = ~sk
-print("finite", torch.isfinite(rows_t[ok]).all().item(), "nan skipped", torch.isnan(rows_t[sk]).all().item())
+for F in (1000,):
+    frames = [syn.synth_frames_torch(F, size, size, first=100 * c) for c in range(4)]
+    for mode, name in ((2, "scan + gather"), (1, "streamed (pass A per camera, whole-row pass B)")):
+        pipe = engine.FramePipeline(4, size, size, v.shape[0], fused_scan=mode)
+        for c in range(4):
+            pipe.set_projection(c, pix[c], w[c])
+        rows_t = torch.empty((v.shape[0], engine.series_ld(F, whole_rows=(mode == 1))), dtype=torch.float32, device="cuda")[:, :F]
+        for r in range(4):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            pipe.process(frames, 0, rows_t=rows_t, want_rows=False)
+            torch.cuda.synchronize(); d = time.perf_counter() - t0
+        if F == 1000:
+            _capi.timing_enable(True)
+            pipe.process(frames, 0, rows_t=rows_t, want_rows=False)
+            torch.cuda.synchronize()
+            _capi.timing_enable(False)
+            print("   kernels:", {k: (c, round(ms, 3)) for k, (c, ms) in _capi.timing_report().items()})
+        print("4-camera frame loop, %-48s F=%3d: %.2f ms (%.0f camera-frames/s, %.2f TB/s of frames + series)"
+              % (name, F, d * 1e3, 4 * F / d, F * (4 * 2 * size * size + 4 * v.shape[0]) / d / 1e12))
+        ok = ~sk
+        assert torch.isfinite(rows_t[ok]).all().item() and torch.isnan(rows_t[sk]).all().item()
+        pipe.close()
+    del frames

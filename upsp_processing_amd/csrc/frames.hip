@@ -1156,6 +1156,108 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+// Pass B, whole rows, for several cameras (and weights): sol = sum over the cameras, in camera order, of
+// w_c * f32(pixel_c) exactly as gather_tile_kernel forms it (psp_process.cpp:1813-1819), from one compact
+// buffer per camera; row layout and lane mapping of node_rows_kernel.  The accumulators add the frames of
+// a lane first and the lanes after: a different order from the gather's, same values to ~1e-16 relative
+// (the parity bar for the accumulators is 1e-12).
+template <int LPR, int ROWS>
+__global__ void __launch_bounds__(256)
+    node_rows_multi_kernel(StreamMultiArgs a, unsigned cpitch, const uint8_t *__restrict__ skipped,
+                           const int32_t *__restrict__ rowmap, unsigned nnodes, int nframes,
+                           float *__restrict__ rows_t, long long ld_t, double *__restrict__ sum,
+                           double *__restrict__ sumsq)
+{
+    constexpr int RPS = 256 / LPR, WPR = LPR / 64, NR = RPS * ROWS;
+    __shared__ int s_k[NR][kMaxCams];
+    __shared__ float s_w[NR][kMaxCams];
+    __shared__ int s_row[NR], s_sk[NR];
+    __shared__ double p_s[NR][WPR], p_ss[NR][WPR];
+    const unsigned n0 = blockIdx.x * (unsigned)NR;
+    const int t = threadIdx.x;
+    for (int e = t; e < NR * a.ncams; e += 256) {
+        const int r = e / a.ncams, c = e % a.ncams;
+        const unsigned n = n0 + (unsigned)r;
+        const bool ok = n < nnodes;
+        s_k[r][c] = ok ? a.node_k[c][n] : -1;
+        s_w[r][c] = (ok && a.weight[c]) ? a.weight[c][n] : 1.0f;
+    }
+    if (t < NR) {
+        const unsigned n = n0 + (unsigned)t;
+        const bool ok = n < nnodes;
+        s_sk[t] = (ok && skipped) ? (int)skipped[n] : 0;
+        s_row[t] = ok ? (rowmap ? rowmap[n] : (int)n) : -1;
+    }
+    __syncthreads();
+    const int sub = t / LPR, l = t % LPR, wr = l >> 6, lane = t & 63;
+    const int f0 = 4 * l;
+    const float qnan = __builtin_nanf("");
+    const bool vec_ok = ((ld_t & 3) == 0) && ((reinterpret_cast<size_t>(rows_t) & 15) == 0);
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) {
+        const int r = j * RPS + sub;                            // (uniform per wave)
+        const int row = s_row[r];
+        const bool sk = s_sk[r] != 0;
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int c = 0; c < a.ncams; ++c) {
+            const int k = s_k[r][c];
+            const float w = s_w[r][c];
+            float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (k >= 0 && f0 < nframes) {
+                const uint2 tt = *reinterpret_cast<const uint2 *>(a.compact[c] + (size_t)k * cpitch + f0);
+                v[0] = 0.0f + w * (float)(tt.x & 0xFFFFu);
+                v[1] = 0.0f + w * (float)(tt.x >> 16);
+                v[2] = 0.0f + w * (float)(tt.y & 0xFFFFu);
+                v[3] = 0.0f + w * (float)(tt.y >> 16);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = (c == 0) ? v[q] : acc[q] + v[q];
+        }
+        double s = 0.0, ss = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (f0 + q < nframes) {
+                const float sol = sk ? qnan : acc[q];
+                s += (double)sol;
+                ss += (double)(sol * sol);
+            }
+        s = group16_sum(s);
+        ss = group16_sum(ss);
+        const double ws = (readlane_f64<0>(s) + readlane_f64<16>(s)) + (readlane_f64<32>(s) + readlane_f64<48>(s));
+        const double wss = (readlane_f64<0>(ss) + readlane_f64<16>(ss)) + (readlane_f64<32>(ss) + readlane_f64<48>(ss));
+        if (lane == 0) {
+            p_s[r][wr] = ws;
+            p_ss[r][wr] = wss;
+        }
+        if (row < 0 || f0 >= nframes || n0 + (unsigned)r >= nnodes) continue;
+        float *dst = rows_t + (long long)row * ld_t + f0;
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f nv = {sk ? qnan : acc[0], sk ? qnan : acc[1], sk ? qnan : acc[2], sk ? qnan : acc[3]};
+        if (vec_ok && f0 + 3 < nframes) {
+            __builtin_nontemporal_store(nv, reinterpret_cast<v4f *>(dst));
+        } else {
+            dst[0] = nv.x;
+            if (f0 + 1 < nframes) dst[1] = nv.y;
+            if (f0 + 2 < nframes) dst[2] = nv.z;
+            if (f0 + 3 < nframes) dst[3] = nv.w;
+        }
+    }
+    __syncthreads();
+    if (t < NR) {
+        const unsigned n = n0 + (unsigned)t;
+        if (n < nnodes) {
+            double as = 0.0, ass = 0.0;
+#pragma unroll
+            for (int q = 0; q < WPR; ++q) {
+                as += p_s[t][q];
+                ass += p_ss[t][q];
+            }
+            sum[n] += as;
+            sumsq[n] += ass;
+        }
+    }
+}
+
 // Frames with 1..max_hot hot pixels: repair in place (same code as the scan kernel's pass 2) and
 // list the replaced pixels as (frame, position, old, new) for hot_patch_kernel.  One lane per frame;
 // frame f owns slots [f * max_hot, (f + 1) * max_hot) of the list (a frame replaces at most max_hot
@@ -1243,6 +1345,51 @@ __global__ void __launch_bounds__(256)
         if (row < 0) continue;
         if (rows_t) rows_t[row * ld_t + (long long)ch.x] = xn;
         else rows_t16[row * ld_t + (long long)ch.x] = (uint16_t)ch.w;
+    }
+}
+
+// The same for several cameras.  The value of node n in frame f is sol = sum over the cameras, in order, of
+// w_c * f32(frame_c[pix_c[n]]) in float (psp_process.cpp:1813-1819): a replaced pixel of one camera changes it
+// non-linearly (float rounding), so the entry is RECOMPUTED from the repaired frames of all cameras --
+// the gather's own arithmetic -- and swapped into the row; the accumulators move by (new - old) with old = the
+// value the swap returned, which makes a second change on the same (node, frame) a no-op (several cameras,
+// or several hot pixels of one camera, can land on one node).  Runs after the frames of ALL cameras are
+// repaired.  Accumulators: sums of doubles in another order than the gather's (parity bar 1e-12).
+struct HotMultiArgs {
+    int ncams;
+    const uint16_t *frames[kMaxCams];
+    const int32_t *pix[kMaxCams];
+    const float *weight[kMaxCams];
+};
+__global__ void __launch_bounds__(256)
+    hot_patch_multi_kernel(HotMultiArgs a, size_t npix, const unsigned *__restrict__ ntotal,
+                           const unsigned *__restrict__ nch, const uint4 *__restrict__ changes, int nframes,
+                           int max_hot, const int32_t *__restrict__ head, const int32_t *__restrict__ next,
+                           const uint8_t *__restrict__ skipped, float *__restrict__ rows_t, long long ld_t,
+                           double *__restrict__ sum, double *__restrict__ sumsq)
+{
+    if (*ntotal == 0u) return;                 // (uniform) nearly every call
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (unsigned)nframes * (unsigned)max_hot) return;
+    const unsigned f = i / (unsigned)max_hot;
+    if (i - f * (unsigned)max_hot >= nch[f]) return;
+    const uint4 ch = changes[i];
+    for (int32_t n = head[ch.y]; n >= 0; n = next[n]) {
+        if (skipped && skipped[n]) continue;                  // stays NaN
+        float sol = 0.0f;
+        for (int c = 0; c < a.ncams; ++c) {
+            const int32_t p = a.pix[c][n];
+            const float w = a.weight[c] ? a.weight[c][n] : 1.0f;
+            const float v = p >= 0 ? 0.0f + w * (float)a.frames[c][(size_t)ch.x * npix + (size_t)p] : 0.0f;
+            sol = c == 0 ? v : sol + v;
+        }
+        const unsigned oldb = atomicExch(reinterpret_cast<unsigned *>(rows_t + (long long)n * ld_t + (long long)ch.x),
+                                         __float_as_uint(sol));
+        const float old = __uint_as_float(oldb);
+        if (old != sol) {
+            unsafeAtomicAdd(&sum[n], (double)sol - (double)old);
+            unsafeAtomicAdd(&sumsq[n], (double)(sol * sol) - (double)(old * old));
+        }
     }
 }
 
@@ -1581,6 +1728,34 @@ int launch_node_stream_multi(const PipelineGather &g, const int32_t *const *d_no
     return UPSP_OK;
 }
 
+// Pass B, whole rows, for g.ncams cameras and the g.nframes (<= group_frames_max()) frames parked in the
+// per-camera compact buffers (row pitch cpitch).
+int launch_node_rows_multi(const PipelineGather &g, const int32_t *const *d_node_k, const uint16_t *const *d_compact,
+                           unsigned cpitch, hipStream_t st)
+{
+    if (g.nframes <= 0 || g.nframes > kGroupFramesMax || (unsigned)g.nframes > cpitch)
+        return fail(UPSP_ERR_INVALID, "row pass: too many frames");
+    if (g.ncams < 1 || g.ncams > kMaxCams || !g.rows_t) return fail(UPSP_ERR_INVALID, "row pass: bad camera count / no f32 rows");
+    StreamMultiArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.ncams = g.ncams;
+    for (int c = 0; c < g.ncams; ++c) {
+        a.compact[c] = d_compact[c];
+        a.node_k[c] = d_node_k[c];
+        a.weight[c] = g.weight[c];
+    }
+    const unsigned nn = (unsigned)g.nnodes;
+    KTimed kt("node_rows_multi_kernel", st);
+#define UPSP_NRM(LPR, ROWS)                                                                                   \
+    hipLaunchKernelGGL((node_rows_multi_kernel<LPR, ROWS>), dim3((nn + (256 / LPR) * ROWS - 1) / ((256 / LPR) * ROWS)), \
+                       dim3(256), 0, st, a, cpitch, g.skipped, g.rowmap, nn, g.nframes, g.rows_t, (long long)g.ld_t, \
+                       g.sum, g.sumsq)
+    if (g.nframes > 512) UPSP_NRM(256, 4); else if (g.nframes > 256) UPSP_NRM(128, 4); else UPSP_NRM(64, 4);
+#undef UPSP_NRM
+    UPSP_HIP_CHECK(hipGetLastError());
+    return UPSP_OK;
+}
+
 // Hot-pixel fix-up of all `nframes` frames of a call (any number; g.rows_t / g.rows_t16 point at the
 // column of the first frame; d_count / d_pos hold one counter / 64 positions per frame).  Scratch:
 // d_changes 4 words (word 0 = number of changes of the call) + nframes words (changes per frame) rounded
@@ -1610,6 +1785,53 @@ int launch_hot_fixup(const PipelineGather &g, uint16_t *d_frames, int nframes, i
                            (const int32_t *)d_head, (const int32_t *)d_next, g.skipped, g.rowmap, g.rows_t, g.rows_t16,
                            (long long)g.ld_t, g.sum, g.sumsq);
     }
+    UPSP_HIP_CHECK(hipGetLastError());
+    return UPSP_OK;
+}
+
+// Hot-pixel fix-up for several cameras after a streamed pass over UNREPAIRED frames (pass A counted the hot
+// pixels per camera and frame): repair the frames of every camera, then re-project the replaced pixels.
+// d_count / d_pos: per camera c at c * nframes (counters) and c * nframes * 64 (positions); d_changes: per camera
+// hot_changes_words(nframes, max_hot) words; d_head: ncams * npix, d_next: ncams * nnodes.  g.rows_t points at
+// the column of the first frame; identity row map only.
+int launch_hot_fixup_multi(const PipelineGather &g, uint16_t *const *d_frames, int nframes, int rows, int cols,
+                           int min_change, int max_hot, unsigned *d_count, const unsigned *d_pos,
+                           unsigned *d_changes, int32_t *d_head, int32_t *d_next, hipStream_t st)
+{
+    if (nframes <= 0) return UPSP_OK;
+    if (g.rowmap || !g.rows_t) return fail(UPSP_ERR_INVALID, "multi-camera hot-pixel fix-up needs f32 rows without a row map");
+    KTimed kt("hot_fixup_kernels", st);
+    const size_t words = hot_changes_words(nframes, max_hot);
+    HotMultiArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.ncams = g.ncams;
+    for (int c = 0; c < g.ncams; ++c) {
+        a.frames[c] = d_frames[c];
+        a.pix[c] = g.pix[c];
+        a.weight[c] = g.weight[c];
+    }
+    for (int c = 0; c < g.ncams; ++c) {       // every camera's frames are repaired before anything is re-projected
+        unsigned *chg = d_changes + (size_t)c * words;
+        uint4 *list = reinterpret_cast<uint4 *>(chg + 4 + (((size_t)nframes + 3) & ~(size_t)3));
+        hipLaunchKernelGGL(hot_patch_reset_kernel, dim3(1), dim3(1), 0, st, chg);
+        hipLaunchKernelGGL(hot_repair_kernel, dim3((unsigned)((nframes + 63) / 64)), dim3(64), 0, st, d_frames[c], g.npix,
+                           nframes, rows, cols, min_change, max_hot, d_count + (size_t)c * nframes,
+                           d_pos + (size_t)c * nframes * kHotCap, chg, chg + 4, list);
+    }
+    if (max_hot > 0)
+        for (int c = 0; c < g.ncams; ++c) {
+            unsigned *chg = d_changes + (size_t)c * words;
+            uint4 *list = reinterpret_cast<uint4 *>(chg + 4 + (((size_t)nframes + 3) & ~(size_t)3));
+            int32_t *head = d_head + (size_t)c * g.npix, *next = d_next + (size_t)c * g.nnodes;
+            hipLaunchKernelGGL(hot_lists_init_kernel, dim3((unsigned)((g.npix + 255) / 256)), dim3(256), 0, st,
+                               (const unsigned *)chg, head, g.npix);
+            hipLaunchKernelGGL(hot_lists_build_kernel, dim3((unsigned)((g.nnodes + 255) / 256)), dim3(256), 0, st,
+                               (const unsigned *)chg, g.pix[c], (unsigned)g.nnodes, head, next);
+            hipLaunchKernelGGL(hot_patch_multi_kernel, dim3((unsigned)(((size_t)nframes * max_hot + 255) / 256)), dim3(256),
+                               0, st, a, g.npix, (const unsigned *)chg, (const unsigned *)(chg + 4), (const uint4 *)list,
+                               nframes, max_hot, (const int32_t *)head, (const int32_t *)next, g.skipped, g.rows_t,
+                               (long long)g.ld_t, g.sum, g.sumsq);
+        }
     UPSP_HIP_CHECK(hipGetLastError());
     return UPSP_OK;
 }

@@ -51,10 +51,15 @@ int launch_node_rows(const PipelineGather &g, const int32_t *d_node_k, const uin
                      hipStream_t st);
 int launch_node_stream_multi(const PipelineGather &g, const int32_t *const *d_node_k,
                              const uint16_t *const *d_compact, hipStream_t st);
+int launch_node_rows_multi(const PipelineGather &g, const int32_t *const *d_node_k, const uint16_t *const *d_compact,
+                           unsigned cpitch, hipStream_t st);
 size_t hot_changes_words(int nframes, int max_hot);   // size of d_changes for launch_hot_fixup
 int launch_hot_fixup(const PipelineGather &g, uint16_t *d_frames, int nframes, int rows, int cols,
                      int min_change, int max_hot, unsigned *d_count, const unsigned *d_pos,
                      unsigned *d_changes, int32_t *d_head, int32_t *d_next, hipStream_t st);
+int launch_hot_fixup_multi(const PipelineGather &g, uint16_t *const *d_frames, int nframes, int rows, int cols,
+                           int min_change, int max_hot, unsigned *d_count, const unsigned *d_pos,
+                           unsigned *d_changes, int32_t *d_head, int32_t *d_next, hipStream_t st);
 int launch_skipped(int ncams, size_t nnodes, const int32_t *const *d_pix, uint8_t *d_skipped,
                    hipStream_t st);
 int launch_finals(const double *sum, const double *sumsq, size_t nnodes, uint64_t nframes,

@@ -43,12 +43,14 @@ struct upsp_pipeline {
     unsigned *d_changes = nullptr;   // hot-pixel change list of a call (frames.hip: hot_changes_words)
     size_t changes_words = 0;
     int32_t *d_head = nullptr, *d_next = nullptr;   // pixel -> nodes lists of the hot-pixel re-projection
+    size_t head_elems = 0, next_elems = 0;
     bool tilemap_valid = false;
     // the same per camera for the multi-camera streamed schedule
     uint8_t *m_aflag[kMaxCams] = {nullptr};
     unsigned *m_tile_off[kMaxCams] = {nullptr};
     int32_t *m_node_k[kMaxCams] = {nullptr};
     uint16_t *m_compact[kMaxCams] = {nullptr};
+    size_t m_compact_bytes[kMaxCams] = {0};
     bool m_valid[kMaxCams] = {false};
     // the same scratch for upsp_pipeline_fix_hot_pixels (may run on another stream than process)
     unsigned *d_pre_count = nullptr, *d_pre_pos = nullptr;
@@ -516,8 +518,18 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
                 UPSP_HIP_CHECK(hipMalloc(&p->d_changes, sizeof(unsigned) * words));
                 p->changes_words = words;
             }
-            if (!p->d_head) UPSP_HIP_CHECK(hipMalloc(&p->d_head, sizeof(int32_t) * npix));
-            if (!p->d_next) UPSP_HIP_CHECK(hipMalloc(&p->d_next, sizeof(int32_t) * p->nnodes));
+            if (p->head_elems < npix) {
+                free_dev(p->d_head);
+                p->d_head = nullptr;
+                UPSP_HIP_CHECK(hipMalloc(&p->d_head, sizeof(int32_t) * npix));
+                p->head_elems = npix;
+            }
+            if (p->next_elems < p->nnodes) {
+                free_dev(p->d_next);
+                p->d_next = nullptr;
+                UPSP_HIP_CHECK(hipMalloc(&p->d_next, sizeof(int32_t) * p->nnodes));
+                p->next_elems = p->nnodes;
+            }
         }
         uint16_t *fr = d_frames[0];
         for (int s0 = 0; s0 < nframes && rc == UPSP_OK; s0 += S) {
@@ -547,16 +559,34 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
     // the number of memory transactions per node (four series reads + one row piece), DESIGN.md section 7.
     const bool multi_ok = p->ncams > 1 && !need_stage && !d_rows && d_rows_t && !d_rows_t16 && !p->d_src &&
                           (npix % 2) == 0 && B == 64 && !overlap && p->nnodes < ((size_t)1 << 31);
-    if (multi_ok && fused_mode == 1) {
+    // default (fused_scan = 0): streamed from 192 frames per call on -- measured on the 5 M-triangle / 4-camera
+    // shape (tools/scale_5m.py): 256 frame sets 1.68 ms against 2.20 ms for scan + gather, 64 frame sets 0.84
+    // against 0.57 ms (short calls write 256-B row pieces either way and pay pass A on top)
+    if (multi_ok && (fused_mode == 1 || (fused_mode == 0 && nframes >= 192))) {
         const size_t ntiles = tilemap_tiles(npix);
+        // frames per group (pass A per camera, then ONE whole-row pass B): the per-camera compact buffers
+        // (2 B x min(nodes, pixels) x frames) share the budget opts.compact_mb (default 2048 MiB per camera)
+        const size_t budget = (size_t)(p->opts.compact_mb > 0 ? p->opts.compact_mb : 2048 * p->ncams) << 20;
+        const size_t nact = std::max<size_t>(std::min(p->nnodes, npix), 1);
+        int S = (int)std::min<size_t>((size_t)group_frames_max(), (budget / ((size_t)p->ncams * 2 * nact)) / 64 * 64);
+        S = std::max(S, 64);
+        const unsigned cp = (unsigned)((std::min(nframes, S) + 63) / 64 * 64);
         for (int c = 0; c < p->ncams; ++c) {
+            if (nact * cp * 2 > p->m_compact_bytes[c]) {
+                if (p->m_compact[c]) {
+                    UPSP_HIP_CHECK(hipStreamSynchronize(st));
+                    free_dev(p->m_compact[c]);
+                    p->m_compact[c] = nullptr;
+                    p->m_compact_bytes[c] = 0;
+                }
+                UPSP_HIP_CHECK(hipMalloc(&p->m_compact[c], nact * cp * 2));
+                p->m_compact_bytes[c] = nact * cp * 2;
+            }
             if (p->m_valid[c]) continue;
             if (!p->m_aflag[c]) UPSP_HIP_CHECK(hipMalloc(&p->m_aflag[c], npix));
             if (!p->m_tile_off[c]) UPSP_HIP_CHECK(hipMalloc(&p->m_tile_off[c], sizeof(unsigned) * (ntiles + 1)));
             if (!p->d_tile_cnt) UPSP_HIP_CHECK(hipMalloc(&p->d_tile_cnt, sizeof(unsigned) * ntiles));
             if (!p->m_node_k[c]) UPSP_HIP_CHECK(hipMalloc(&p->m_node_k[c], sizeof(int32_t) * p->nnodes));
-            if (!p->m_compact[c])
-                UPSP_HIP_CHECK(hipMalloc(&p->m_compact[c], (size_t)2 * stream_frames_max() * std::min(p->nnodes, npix)));
             rc = launch_amap_build(p->d_pix[c], p->nnodes, npix, p->m_aflag[c], p->d_tile_cnt, p->m_tile_off[c],
                                    p->m_node_k[c], nullptr, st);
             if (rc != UPSP_OK) return rc;
@@ -571,15 +601,56 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
         g.sum = p->d_sum;
         g.sumsq = p->d_sumsq;
         g.ld_t = ld_t;
-        for (int c = 0; c < p->ncams; ++c) g.weight[c] = p->d_weight[c];
-        const int S = stream_frames_max();
+        for (int c = 0; c < p->ncams; ++c) {
+            g.weight[c] = p->d_weight[c];
+            g.pix[c] = p->d_pix[c];
+        }
+        // Hot pixels.  Without a row map the count rides on pass A (one read of every frame instead of two) and the
+        // rare replaced pixels are re-projected through all cameras afterwards (launch_hot_fixup_multi); with a row
+        // map the scan + repair stays a pass of its own per 64 frames, pass A following while they are in cache.
+        const bool hot = p->opts.hot_enable != 0;
+        const bool hot_fused = hot && !p->d_rowmap;
+        if (hot_fused) {
+            rc = ensure_hot(p, nframes * p->ncams);
+            if (rc != UPSP_OK) return rc;
+            const size_t words = hot_changes_words(nframes, p->opts.hot_max) * (size_t)p->ncams;
+            if (words > p->changes_words) {
+                if (p->d_changes) UPSP_HIP_CHECK(hipStreamSynchronize(st));
+                free_dev(p->d_changes);
+                p->d_changes = nullptr;
+                p->changes_words = 0;
+                UPSP_HIP_CHECK(hipMalloc(&p->d_changes, sizeof(unsigned) * words));
+                p->changes_words = words;
+            }
+            if (p->head_elems < npix * p->ncams) {
+                if (p->d_head) UPSP_HIP_CHECK(hipStreamSynchronize(st));
+                free_dev(p->d_head);
+                p->d_head = nullptr;
+                UPSP_HIP_CHECK(hipMalloc(&p->d_head, sizeof(int32_t) * npix * p->ncams));
+                p->head_elems = npix * p->ncams;
+            }
+            if (p->next_elems < p->nnodes * p->ncams) {
+                if (p->d_next) UPSP_HIP_CHECK(hipStreamSynchronize(st));
+                free_dev(p->d_next);
+                p->d_next = nullptr;
+                UPSP_HIP_CHECK(hipMalloc(&p->d_next, sizeof(int32_t) * p->nnodes * p->ncams));
+                p->next_elems = p->nnodes * p->ncams;
+            }
+        }
         for (int s0 = 0; s0 < nframes && rc == UPSP_OK; s0 += S) {
             const int ns = std::min(S, nframes - s0);
             for (int c = 0; c < p->ncams && rc == UPSP_OK; ++c) {
                 uint16_t *fr = d_frames[c];
+                if (hot_fused) {
+                    rc = launch_scan_compact(fr + (size_t)s0 * npix, npix, ns, true, p->opts.hot_thresh, p->opts.hot_max,
+                                             p->m_aflag[c], p->m_tile_off[c], nullptr, p->m_compact[c], cp, 0,
+                                             p->d_hot_count + (size_t)c * nframes + s0,
+                                             p->d_hot_pos + ((size_t)c * nframes + s0) * 64, st);
+                    continue;
+                }
                 for (int f0 = s0; f0 < s0 + ns && rc == UPSP_OK; f0 += B) {
                     const int nb = std::min(B, s0 + ns - f0);
-                    if (p->opts.hot_enable) {
+                    if (hot) {
                         rc = ensure_hot(p, nb);
                         if (rc == UPSP_OK)
                             rc = launch_hot_fix(fr + (size_t)f0 * npix, nb, p->height, p->width, p->opts.hot_thresh,
@@ -588,13 +659,18 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
                     }
                     if (rc == UPSP_OK)
                         rc = launch_scan_compact(fr + (size_t)f0 * npix, npix, nb, false, 0, 0, p->m_aflag[c],
-                                                 p->m_tile_off[c], nullptr, p->m_compact[c], (unsigned)stream_frames_max(), f0 - s0,
+                                                 p->m_tile_off[c], nullptr, p->m_compact[c], cp, f0 - s0,
                                                  nullptr, nullptr, st);
                 }
             }
             g.nframes = ns;
             g.rows_t = d_rows_t + col0 + s0;
-            if (rc == UPSP_OK) rc = launch_node_stream_multi(g, p->m_node_k, p->m_compact, st);
+            if (rc == UPSP_OK) rc = launch_node_rows_multi(g, p->m_node_k, p->m_compact, cp, st);
+        }
+        if (rc == UPSP_OK && hot_fused) {
+            g.rows_t = d_rows_t + col0;
+            rc = launch_hot_fixup_multi(g, d_frames, nframes, p->height, p->width, p->opts.hot_min_change, p->opts.hot_max,
+                                        p->d_hot_count, p->d_hot_pos, p->d_changes, p->d_head, p->d_next, st);
         }
         return rc;
     }
