@@ -105,7 +105,7 @@ def usable_cpus():
     return n
 
 
-def cpu_baseline(verts, tris, cam_dict, size, nframes_step, sample):
+def cpu_baseline(verts, tris, cam_dict, size, nframes_step, sample, registration=False):
     """Oracle (CPU restatement, kind 'port') on a bounded sample of the same workload: the projection
     build on the full model (OpenMP over node blocks like psp_process.cpp:218-260) and the frame loop
     (OpenMP over frames like psp_process.cpp:1742-1851) on the first `len(sample)` frames of the step."""
@@ -132,6 +132,19 @@ def cpu_baseline(verts, tris, cam_dict, size, nframes_step, sample):
     # own 2 x N doubles (psp_process.cpp:1744-1745, 1845-1850), amortised over a whole run
     per_frame = tm["loop"] / frames.shape[0]
     t_fixed = tm["setup"] + tm["merge"]
+    reg_note = ""
+    if registration:
+        # configs[2]: register_pixel (ECC + warp, cpp/lib/registration.cpp:32-81) per frame before the projection;
+        # one frame per thread like the reference's OpenMP loop (psp_process.cpp:1776-1795), bounded sample
+        from concurrent.futures import ThreadPoolExecutor
+        nreg = min(sample.shape[0] - 1, 2 * cores)
+        ref32 = sample[0].astype(np.float32)
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:
+            its = list(ex.map(lambda f: orc.register_pixel(ref32, sample[f])[2], range(1, nreg + 1)))
+        t_reg = time.perf_counter() - t0
+        per_frame += t_reg / nreg
+        reg_note = " + register_pixel on %d frames (%.2f s, %.1f ECC iterations per frame)" % (nreg, t_reg, float(np.mean(its)))
     # a few rows for the parity check of the series (single thread, rows kept)
     few = sample[:8].copy()
     rows8, _, _ = orc.frame_loop(few, pix, want_rows=True, threads=1)
@@ -139,8 +152,9 @@ def cpu_baseline(verts, tris, cam_dict, size, nframes_step, sample):
     out = {"value": fps, "unit": "frames/s", "cores": cores, "kind": "port",
            "sample": "oracle/ (C, OpenMP, %d threads): projection build on the full model (%d rays, %.2f s) "
                      "+ %d frames of the frame loop (%.3f s: %.3f ms per frame + %.2f s per run for the "
-                     "thread-private accumulators); extrapolated to the %d-frame step"
-                     % (cores, r["nrays"], t_proj, frames.shape[0], t_frames, per_frame * 1e3, t_fixed, nframes_step),
+                     "thread-private accumulators)%s; extrapolated to the %d-frame step"
+                     % (cores, r["nrays"], t_proj, frames.shape[0], t_frames, tm["loop"] / frames.shape[0] * 1e3, t_fixed,
+                        reg_note, nframes_step),
            "mrays_per_s": mrays, "frame_loop_frames_per_s": 1.0 / per_frame, "bvh_build_s": t_build}
     return out, dict(pix=pix, nrays=int(r["nrays"]), sum=s, sumsq=ss, rows8=rows8, frames_fixed=frames)
 
@@ -477,7 +491,7 @@ def main():
     if world == 1 and not a.registration and not a.no_reraycast:
         out["host_feed"] = host_feed_rate(pipe, frames, N, size, last_pix[0])
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"], ref = cpu_baseline(verts, tris, cd, size, F, sample)
+        out["cpu_baseline"], ref = cpu_baseline(verts, tris, cd, size, F, sample, registration=a.registration)
         if not a.registration:
             # parity of THIS run against the oracle: the projection of the full 1 M-triangle model, and the
             # frame loop on the sample the CPU just processed (same bits in: the frames as generated)
