@@ -90,6 +90,15 @@ def test_cli_end_to_end(gpu_lib, tmp_path, filt):
         assert np.array_equal(a.view(np.int32), finals[key].cpu().numpy().view(np.int32)), name
     assert np.array_equal(np.fromfile(os.path.join(out, "X"), "<f4"), v[:, 0])
     assert os.path.getsize(os.path.join(out, "cam01-uv")) == 8 * n
+    png = open(os.path.join(out, "cam02-nodecount.png"), "rb").read()
+    assert png[:8] == b"\x89PNG\r\n\x1a\n" and png[12:16] == b"IHDR"
+    import struct, zlib
+    w_, h_ = struct.unpack(">II", png[16:24])
+    assert (w_, h_) == (192, 160)
+    idat = png[png.index(b"IDAT") + 4:png.index(b"IEND") - 8]
+    rows_ = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h_, 1 + 3 * w_)[:, 1:].reshape(h_, w_, 3)
+    cnt = job.nodecount[1].cpu().numpy()
+    assert ((rows_.sum(2) == 0) == (cnt == 0)).all() and (cnt > 0).any()
     job.close()
 
 

@@ -47,12 +47,13 @@ class Phase1:
                      for c in cameras]
         self.centers = np.array([engine.camera_center(c) for c in self.cams])
         self.nrays = 0
-        pix, self.uv = [], []
+        pix, self.uv, self.nodecount = [], [], []
         for cam in self.cams:                                          # :1597-1622
             p = engine.build_projection(self.bvh, cam, self.d_nodes, self.d_normals,
-                                        self.d_tri_nodes, oblique_angle, datanode=datanode)
+                                        self.d_tri_nodes, oblique_angle, datanode=datanode, nodecount=True)
             pix.append(p["pix"])
             self.uv.append(p["uv"])
+            self.nodecount.append(p["nodecount"])      # u8 [H, W], saturating (psp_process.cpp:335-347)
             self.nrays += p["nrays"]
         self.pix = torch.stack(pix)
         # :1632-1640 ; a single camera needs no weights
@@ -176,6 +177,8 @@ class Phase1:
             for c in range(self.ncams):
                 self.uv[c].cpu().numpy().astype("<f4").tofile(
                     os.path.join(out_dir, "cam%02d-uv" % (c + 1)))
+                write_nodecount_png(os.path.join(out_dir, "cam%02d-nodecount.png" % (c + 1)),
+                                    self.nodecount[c].cpu().numpy())
             self.dump_vv(os.path.join(out_dir, "vv-int-rms.dat"), finals["rms"].cpu().numpy())
             self.dump_vv(os.path.join(out_dir, "vv-int-avg.dat"), finals["avg"].cpu().numpy())
             self.dump_vv(os.path.join(out_dir, "vv-int-coverage.dat"), finals["coverage"].cpu().numpy())
@@ -194,6 +197,26 @@ class Phase1:
     def close(self):
         self.pipe.close()
         self.bvh.close()
+
+
+def write_nodecount_png(path, counts):
+    """camNN-nodecount.png (psp_process.cpp:1608-1614): the nodes-per-pixel image through the colour map
+    of upsp::nodes_per_pixel_colormap (cpp/utils/cv_extras.cpp:277-290: 0 black, 1 green, 2 yellow, 3 orange,
+    4 light orange, >= 5 white).  The reference adds a colour bar with text labels to the right of the image
+    (cv::putText); this writer stores the colour-mapped image alone (8-bit RGB PNG, zlib only)."""
+    import struct
+    import zlib
+    lut = np.full((256, 3), 255, np.uint8)
+    lut[:5] = [(0, 0, 0), (0, 255, 0), (255, 255, 0), (255, 153, 51), (255, 204, 153)]     # RGB of the BGR table
+    img = lut[np.asarray(counts, dtype=np.uint8)]
+    h, w = img.shape[:2]
+    raw = np.concatenate([np.zeros((h, 1), np.uint8), img.reshape(h, w * 3)], axis=1).tobytes()   # filter 0 per row
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0))
+                + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
 
 
 def run_phase1(job, frames_per_cam, nframes_total=None, out_dir=None, chunk=256):
