@@ -347,6 +347,7 @@ struct Trav {
     unsigned n_nodes, n_tris;
     unsigned ray_nodes, ray_tris;  // STATS: steps of the current ray
     unsigned touched;              // xor of the words read ahead (keeps those loads alive, never used)
+    unsigned w_node_rounds, w_tri_rounds;   // STATS: rounds of the WAVE (counted by its first executing lane)
 };
 
 __device__ __forceinline__ void trav_begin(Trav &s, const Ray &r, const Scene &sc)
@@ -456,6 +457,7 @@ __device__ __forceinline__ bool leaf_step(Trav &s, const Ray &r, const Scene &sc
         const float4 *tp = sc.tris + 3 * (size_t)(first + i);
         const float4 a = tp[0], b = tp[1], c = tp[2];
         if (STATS) { ++s.n_tris; ++s.ray_tris; }
+        if (STATS && (threadIdx.x & 63u) == (unsigned)__ffsll((long long)__ballot(true)) - 1u) ++s.w_tri_rounds;
         TriHit h;
         if (tri_test(r, a.x, a.y, a.z, b.x, b.y, b.z, c.x, c.y, c.z, h)) {
             s.any = true;
@@ -493,8 +495,10 @@ __device__ __forceinline__ void trav_run(Trav &s, const Ray &r, const Scene &sc,
         if (cap == 0) {
             while (s.cur >= 0) node_step<ANYHIT, STATS>(s, r, sc, stack);
         } else {
-            for (int d = 0; d < cap && __ballot(s.cur >= 0) != 0ull; ++d)
+            for (int d = 0; d < cap && __ballot(s.cur >= 0) != 0ull; ++d) {
+                if (STATS && (threadIdx.x & 63u) == (unsigned)__ffsll((long long)__ballot(true)) - 1u) ++s.w_node_rounds;
                 if (s.cur >= 0) node_step<ANYHIT, STATS>(s, r, sc, stack);
+            }
         }
         if (s.cur != kDone && s.cur < 0) {
             if (leaf_step<ANYHIT, STATS>(s, r, sc, s.cur)) {
@@ -660,6 +664,7 @@ __global__ void __launch_bounds__(kBlock)
     s.cur = kDone;
     s.n_nodes = s.n_tris = 0;
     s.touched = 0;
+    s.w_node_rounds = s.w_tri_rounds = 0;
     unsigned item = 0, my_rays = 0;
     bool busy = false;
 
@@ -699,6 +704,10 @@ __global__ void __launch_bounds__(kBlock)
         }
     }
     if (sc.touch > 1 && s.touched == 0xFFFFFFFFu) atomicAdd(&work[13], 1u);   // (never: keeps the read-ahead loads)
+    if (STATS) {
+        if (s.w_node_rounds) atomicAdd(&work[14], s.w_node_rounds);
+        if (s.w_tri_rounds) atomicAdd(&work[15], s.w_tri_rounds);
+    }
     if (STATS) flush_stats(work, lds_stack, s.n_nodes, s.n_tris, my_rays);
 }
 
@@ -1073,6 +1082,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 
     s.cur = kDone;
     s.n_nodes = s.n_tris = 0;
     s.touched = 0;
+    s.w_node_rounds = s.w_tri_rounds = 0;
     unsigned item = 0, my_rays = 0;
     bool busy = false, bounded = false;
 
@@ -1143,6 +1153,10 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 
         }
     }
     if (sc.touch > 1 && s.touched == 0xFFFFFFFFu) atomicAdd(&work[13], 1u);   // (never: keeps the read-ahead loads)
+    if (STATS) {
+        if (s.w_node_rounds) atomicAdd(&work[14], s.w_node_rounds);
+        if (s.w_tri_rounds) atomicAdd(&work[15], s.w_tri_rounds);
+    }
     flush_stats(work, lds_stack, STATS ? s.n_nodes : 0u, STATS ? s.n_tris : 0u,
                 PHASE == 0 ? my_rays : 0u, PHASE == 0 ? my_rays : 0u);
 }
@@ -1379,8 +1393,13 @@ int read_stats(upsp_bvh *b, hipStream_t st)
     UPSP_HIP_CHECK(hipMemcpyAsync(h, b->d_work + 2, sizeof(h), hipMemcpyDeviceToHost, st));
     UPSP_HIP_CHECK(hipMemcpyAsync(mx, b->d_work + 8, sizeof(mx), hipMemcpyDeviceToHost, st));
     UPSP_HIP_CHECK(hipStreamSynchronize(st));
-    if (std::getenv("UPSP_TRACE_STATS"))
-        std::fprintf(stderr, "[upsp] longest ray: %u node steps, %u triangle tests\n", mx[0], mx[1]);
+    if (std::getenv("UPSP_TRACE_STATS")) {
+        unsigned wr[2] = {0, 0};
+        UPSP_HIP_CHECK(hipMemcpy(wr, b->d_work + 14, sizeof(wr), hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "[upsp] longest ray: %u node steps, %u triangle tests; lanes active per wave round: node steps "
+                     "%.1f of 64 (%llu lane steps / %u rounds), triangle tests %.1f of 64 (%llu / %u)\n", mx[0], mx[1],
+                     wr[0] ? (double)h[0] / wr[0] : 0.0, h[0], wr[0], wr[1] ? (double)h[1] / wr[1] : 0.0, h[1], wr[1]);
+    }
     b->last_stats[0] = h[0];
     b->last_stats[1] = h[1];
     b->last_stats[2] = h[2];
