@@ -64,6 +64,9 @@ def parse():
                     help="1 M-triangle sphere filling the frame instead of the tunnel model: ~0.2 M visible nodes on "
                          "as many active pixels, so the compact pixel series (2 KB per active pixel and 1000 frames) "
                          "no longer fit the Infinity Cache")
+    ap.add_argument("--overlap", action="store_true",
+                    help="pass A of the frame loop (hot-pixel count + compact pixel series, from the candidate pixels of "
+                         "the in-frame nodes) on a second stream while the rays of the projection build are cast")
     ap.add_argument("--plain-frames", action="store_true",
                     help="round-1 frame content (no background, fiducial discs or hot pixels)")
     return ap.parse_args()
@@ -296,13 +299,26 @@ def main():
     ev_log = []
     first_step = [True]
 
+    overlap = a.overlap and streamed and not chunked and F <= 1024
+    side = torch.cuda.Stream() if overlap else None
+
     def step(record):
         e = [ev() for _ in range(4)]
         e[0].record()
+        main = torch.cuda.current_stream()
+        if overlap:
+            # which pixels the frame loop will read is known once the nodes are projected into the image
+            # (step 1 of create_projection_mat); pass A does not need the visibility verdicts
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                pipe.set_active_hint(engine.candidate_pixels(cam, d_nodes))
+                pipe.prescan(frames)
         proj = engine.build_projection(bvh, cam, d_nodes, d_nrm, d_tn, 70.0, counts=False)   # no host sync
         e[1].record()
         pipe.reset()
         pipe.set_projection(0, proj["pix"])
+        if overlap:
+            main.wait_stream(side)
         if not chunked:
             pipe.process(frames, first_frame=rank * F, rows_t=rows_t, want_rows=False)
         else:
@@ -441,6 +457,8 @@ def main():
 
     sched = ("projection build, then hot-pixel scan + gather kernels per 64-frame sub-batch"
              if (a.two_kernel or a.registration) else
+             "pass A (scan + compact pixel series of the candidate pixels) on a second stream beside the ray casting of the "
+             "projection build, then pass B (whole rows)" if overlap else
              "projection build, then pass A (scan + compact pixel series) and pass B (whole rows) per <= 1024 frames")
     out = {
         "metric": "frames/s", "value": fps, "unit": "frames/s", "n_gpus": world,

@@ -155,6 +155,13 @@ int upsp_projection_last_counts(const upsp_bvh *bvh, uint64_t *primary_rays,
 int upsp_projection_fetch_counts(upsp_bvh *bvh, uint64_t *nrays, uint64_t *primary_rays,
                                  uint64_t *retry_nodes, void *stream);
 
+/* Step 1 of create_projection_mat alone (psp_process.cpp:241-252 + :319): d_pix[n] = the pixel node n is stored
+ * at IF a ray sees it (same arithmetic as upsp_projection_build: cv::projectPoints in double, in-frame test on the
+ * cvRound-ed point, std::round for the stored pixel), -1 for nodes outside the frame / the data-node mask.  Every
+ * projection of this camera is a subset: input of upsp_pipeline_set_active_hint. */
+int upsp_projection_candidate_pixels(const upsp_camera *cam, const float *d_nodes, const uint8_t *d_datanode,
+                                     size_t nnodes, int32_t *d_pix, void *stream);
+
 /* adjust_projection_for_weights with BestView (mode 0) / AverageViews (mode 1)
  * (cpp/lib/projection.ipp:911-1078, 227-268).  d_pix, d_weight: [ncams*nnodes];
  * d_weight is scaled in place (caller initialises it to 1).  h_centers: ncams*3
@@ -228,6 +235,20 @@ int upsp_pipeline_set_projection_async(upsp_pipeline *p, int cam, const int32_t 
  * caller orders the streams (event between the scan and the first process call). */
 int upsp_pipeline_fix_hot_pixels(upsp_pipeline *p, uint16_t *d_frames, int nframes, void *stream);
 int upsp_pipeline_set_hot_enable(upsp_pipeline *p, int enable);
+/* Pass A of the streamed schedule (hot-pixel count + transposed series of the pixels nodes read) depends on
+ * the frames and on WHICH pixels are read, not on the visibility verdicts: with a candidate set -- the pixel every
+ * in-frame node would be stored at, upsp_projection_candidate_pixels, a superset of any projection of that camera --
+ * it can run while create_projection_mat is still casting rays (fix_hot_pixels, psp_process.cpp:1772, and the ray
+ * cast, :167-355, are independent in the reference too):
+ *   upsp_pipeline_set_active_hint(p, d_candidates, s2)   map of the candidate pixels (kept across projection changes
+ *                                                         until cleared with NULL)
+ *   upsp_pipeline_prescan(p, d_frames, n, s2)             pass A of n <= 1024 frames on stream s2
+ *   upsp_pipeline_set_projection_async(...) ; upsp_pipeline_process(p, &d_frames, n, ...)   -- after s2's work
+ *                                                         (caller's event): pass B + hot-pixel fix-up only
+ * A node whose final pixel is missing from the candidate set is served from the frames directly (correct, slow).
+ * One camera, plain path. */
+int upsp_pipeline_set_active_hint(upsp_pipeline *p, const int32_t *d_pix_candidates, void *stream);
+int upsp_pipeline_prescan(upsp_pipeline *p, uint16_t *d_frames, int nframes, void *stream);
 /* Nodes set to NaN in every row (psp_process.cpp:1822-1825); NULL = derive from
  * the projections with identify_skipped_nodes. */
 int upsp_pipeline_set_skipped(upsp_pipeline *p, const uint8_t *d_skipped);

@@ -528,3 +528,81 @@ def test_full_size_streamed_frame_loop_properties(gpu_lib):
     assert torch.equal(s0[vis], rt[vis].double().sum(1)) and torch.equal(ss0[vis], (rt[vis] * rt[vis]).double().sum(1))
     assert torch.equal(s0.view(torch.int64), out[2][1][0].view(torch.int64))
     assert torch.equal(ss0.view(torch.int64), out[2][1][1].view(torch.int64))
+
+
+@pytest.mark.parametrize("F", [70, 300])
+def test_prescan_with_candidate_map(gpu_lib, oracle, F):
+    """Pass A ahead of the projection (upsp_pipeline_set_active_hint + upsp_pipeline_prescan on a second
+    stream), the projection set afterwards, process() = pass B + fix-up only: series, repaired frames and
+    accumulators bit-identical to the oracle loop -- with hot pixels, with a projection that is a strict
+    subset of the candidates, with nodes whose pixel is NOT among the candidates (served from the frames),
+    and again after a projection change that reuses the candidate map."""
+    import torch
+    from upsp_processing_amd import engine, synthetic as syn
+    H, W, n = 64, 130, 2500
+    rng = np.random.default_rng(7 * F)
+    fr = np.minimum(syn.synth_frames_numpy(F, H, W, seed=81, hot=False), 3000).astype(np.uint16)
+    fr[:, 7, 9] = 4095                                   # stuck pixel, read by many nodes
+    fr[3, 20, 21] = 4095
+    cand = rng.integers(-1, H * W, size=n).astype(np.int32)
+    cand[:40] = 7 * W + 9
+    weight = np.ones((1, n), np.float32)
+    pipe = engine.FramePipeline(1, W, H, n)
+    side, main = torch.cuda.Stream(), torch.cuda.current_stream()
+    for trial in range(2):
+        pix = cand.copy()
+        pix[rng.random(n) < 0.5] = -1                    # the rays saw only half of the candidates
+        pix[:40] = 7 * W + 9
+        extra = rng.choice(n, 25, replace=False)         # pixels outside the candidate set
+        pix[extra] = rng.integers(0, H * W, 25)
+        rows_o, s_o, ss_o = run_loop_oracle(oracle, [fr], pix[None], weight)
+        want_frames = np.stack([oracle.fix_hot_pixels(fr[f])[0] for f in range(F)])
+        d = torch.as_tensor(fr.copy()).cuda()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            if trial == 0:
+                pipe.set_active_hint(torch.as_tensor(cand).cuda())
+            pipe.prescan(d)
+        pipe.reset()
+        pipe.set_projection(0, pix)
+        main.wait_stream(side)
+        rt = torch.full((n, engine.series_ld(F, whole_rows=True)), -3.0, dtype=torch.float32, device="cuda")
+        pipe.process(d, 0, rows_t=rt[:, :F], want_rows=False)
+        assert np.array_equal(d.cpu().numpy(), want_frames)
+        assert np.array_equal(rt[:, :F].cpu().numpy().view(np.int32), rows_o.T.view(np.int32))
+        assert (rt[:, F:] == -3.0).all()
+        s_g, ss_g = [a.cpu().numpy() for a in pipe.accumulators()]
+        ok = ~np.isnan(s_o)
+        assert np.array_equal(np.isnan(s_g), ~ok)
+        assert np.array_equal(s_g[ok], s_o[ok]) and np.array_equal(ss_g[ok], ss_o[ok])
+    # without a prescan the same pipeline still runs its own pass A (candidate map in place)
+    pipe.reset()
+    d = torch.as_tensor(fr.copy()).cuda()
+    rt2 = torch.empty((n, F), dtype=torch.float32, device="cuda")
+    pipe.process(d, 0, rows_t=rt2, want_rows=False)
+    assert torch.equal(rt2.view(torch.int32), rt[:, :F].contiguous().view(torch.int32))
+    pipe.set_active_hint(None)
+    pipe.reset()
+    d = torch.as_tensor(fr.copy()).cuda()
+    rt3 = torch.empty((n, F), dtype=torch.float32, device="cuda")
+    pipe.process(d, 0, rows_t=rt3, want_rows=False)
+    assert torch.equal(rt3.view(torch.int32), rt2.view(torch.int32))
+
+
+def test_candidate_pixels_superset(gpu_lib):
+    """upsp_projection_candidate_pixels: every pixel of the projection equals the node's candidate pixel."""
+    import torch
+    from upsp_processing_amd import _capi, engine, synthetic as syn
+    v, t = syn.tunnel_model_quad(40, 14)
+    s9, tn = syn.soup(v, t)
+    nrm = syn.node_normals(v, t)
+    for k1, az in ((0.0, 0), (-0.09, 40)):
+        c = syn.pinhole_camera(512, 384, center=(0.1, 0.2, 20), half_extent=5.0, k1=k1, azimuth_deg=az)
+        cam = _capi.make_camera(c["K"], c["dist"], c["R"], c["t"], 512, 384)
+        bvh = engine.BVH(s9)
+        pix = engine.build_projection(bvh, cam, v, nrm, tn, 70.0)["pix"]
+        cand = engine.candidate_pixels(cam, v)
+        seen = pix >= 0
+        assert int(seen.sum()) > 100 and torch.equal(pix[seen], cand[seen])
+        assert int((cand >= 0).sum()) > int(seen.sum())
+        bvh.close()

@@ -702,7 +702,11 @@ __global__ void __launch_bounds__(256)
     const unsigned n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= nnodes) return;
     const int32_t p = pix[n];
-    node_k[n] = p >= 0 ? (int32_t)(tile_off[(unsigned)p / kFusedPix] + (flag[p] & 0x7Fu)) : -1;
+    // -2: the node reads a pixel the map does not hold (only with a map built from a candidate set,
+    // upsp_pipeline_set_active_hint): pass B then fetches that node's values from the frames themselves
+    int32_t k = -1;
+    if (p >= 0) k = flag[p] ? (int32_t)(tile_off[(unsigned)p / kFusedPix] + (flag[p] & 0x7Fu)) : -2;
+    node_k[n] = k;
 }
 
 // Sum over the 16 lanes of a DPP row (all lanes get the total): four VALU adds fed by DPP moves
@@ -832,7 +836,8 @@ __global__ void __launch_bounds__(256)
     node_rows_kernel(const uint16_t *__restrict__ compact, unsigned cpitch, const int32_t *__restrict__ node_k,
                      const uint8_t *__restrict__ skipped, const int32_t *__restrict__ rowmap, unsigned nnodes,
                      int nframes, float *__restrict__ rows_t, uint16_t *__restrict__ rows_t16, long long ld_t,
-                     double *__restrict__ sum, double *__restrict__ sumsq)
+                     double *__restrict__ sum, double *__restrict__ sumsq, const uint16_t *__restrict__ frames,
+                     size_t npix, const int32_t *__restrict__ pix)
 {
     constexpr int RPS = 256 / LPR;          // rows per sweep
     constexpr int WPR = LPR / 64;           // waves per row
@@ -863,6 +868,13 @@ __global__ void __launch_bounds__(256)
         uint2 w = make_uint2(0u, 0u);
         // (ordinary loads: the compact buffer was written a moment ago and sits in L2 / Infinity Cache)
         if (k >= 0 && !sk && f0 < nframes) w = *reinterpret_cast<const uint2 *>(compact + (size_t)k * cpitch + f0);
+        if (k == -2 && !sk && f0 < nframes) {                   // (rare) pixel outside the candidate map: from the frames
+            const size_t pp = (size_t)pix[n0 + (unsigned)r];
+            unsigned v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = f0 + q < nframes ? (unsigned)frames[(size_t)(f0 + q) * npix + pp] : 0u;
+            w = make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
+        }
         const unsigned d[4] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16};
         unsigned s = 0u;
         double ss = 0.0;
@@ -918,7 +930,7 @@ __global__ void __launch_bounds__(256)
         const unsigned n = n0 + (unsigned)t;
         if (n < nnodes) {
             const bool msk = s_sk[t] != 0;
-            if (s_k[t] >= 0 || msk) {
+            if (s_k[t] != -1 || msk) {
                 unsigned as = 0u;
                 double ass = 0.0;
 #pragma unroll
@@ -1677,6 +1689,16 @@ int launch_node_stream(const PipelineGather &g, const int32_t *d_node_k, const u
 }
 
 // Pass B, whole rows, for the g.nframes (<= group_frames_max()) frames parked in the compact buffer.
+int launch_amap_nodes(const int32_t *d_pix, size_t nnodes, const uint8_t *d_flag, const unsigned *d_off,
+                      int32_t *d_node_k, hipStream_t st)
+{
+    hipLaunchKernelGGL(amap_nodes_kernel, dim3((unsigned)((nnodes + 255) / 256)), dim3(256), 0, st, d_pix, (unsigned)nnodes,
+                       d_flag, d_off, d_node_k);
+    UPSP_HIP_CHECK(hipGetLastError());
+    return UPSP_OK;
+}
+
+// g.img[0]: the group's first frame (u16) -- only read for nodes whose pixel is missing from the map (node_k == -2)
 int launch_node_rows(const PipelineGather &g, const int32_t *d_node_k, const uint16_t *d_compact, unsigned cpitch,
                      hipStream_t st)
 {
@@ -1688,7 +1710,7 @@ int launch_node_rows(const PipelineGather &g, const int32_t *d_node_k, const uin
 #define UPSP_NR(LPR, ROWS, U16)                                                                              \
     hipLaunchKernelGGL((node_rows_kernel<LPR, ROWS, U16>), dim3((nn + (256 / LPR) * ROWS - 1) / ((256 / LPR) * ROWS)), \
                        dim3(256), 0, st, d_compact, cpitch, d_node_k, g.skipped, g.rowmap, nn, g.nframes, g.rows_t,  \
-                       g.rows_t16, (long long)g.ld_t, g.sum, g.sumsq)
+                       g.rows_t16, (long long)g.ld_t, g.sum, g.sumsq, (const uint16_t *)g.img[0], g.npix, g.pix[0])
 #define UPSP_NR_R(LPR, U16)                                                                                  \
     do {                                                                                                     \
         if (rows_env >= 8) UPSP_NR(LPR, 8, U16); else if (rows_env >= 4) UPSP_NR(LPR, 4, U16);              \

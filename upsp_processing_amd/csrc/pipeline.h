@@ -41,6 +41,8 @@ size_t tilemap_tiles(size_t npix);
 // d_order: optional, 4 * (tiles + 1) words; its first `tiles` words = the order pass A visits the tiles in
 int launch_amap_build(const int32_t *d_pix, size_t nnodes, size_t npix, uint8_t *d_flag, unsigned *d_cnt,
                       unsigned *d_off, int32_t *d_node_k, unsigned *d_order, hipStream_t st);
+int launch_amap_nodes(const int32_t *d_pix, size_t nnodes, const uint8_t *d_flag, const unsigned *d_off,
+                      int32_t *d_node_k, hipStream_t st);
 int stream_frames_max();   // frames per pass B of the multi-camera streamed schedule (compact row pitch there)
 int group_frames_max();    // frames per pass B (whole rows) of the one-camera streamed schedule
 int launch_scan_compact(uint16_t *d_frames, size_t npix, int nframes, bool hot, int thresh, int max_hot,

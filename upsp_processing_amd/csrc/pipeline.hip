@@ -45,6 +45,11 @@ struct upsp_pipeline {
     int32_t *d_head = nullptr, *d_next = nullptr;   // pixel -> nodes lists of the hot-pixel re-projection
     size_t head_elems = 0, next_elems = 0;
     bool tilemap_valid = false;
+    // candidate map (upsp_pipeline_set_active_hint): the map outlives projection changes, only node_k is redone
+    bool hint_active = false, node_k_valid = false;
+    // pass A already run by upsp_pipeline_prescan for these frames (consumed by the next matching process call)
+    const uint16_t *prescan_frames = nullptr;
+    int prescan_n = 0;
     // the same per camera for the multi-camera streamed schedule
     uint8_t *m_aflag[kMaxCams] = {nullptr};
     unsigned *m_tile_off[kMaxCams] = {nullptr};
@@ -224,7 +229,8 @@ int upsp_pipeline_set_projection(upsp_pipeline *p, int cam, const int32_t *d_pix
     }
     p->has_proj[cam] = true;
     p->m_valid[cam] = false;
-    p->tilemap_valid = false;
+    if (!p->hint_active) p->tilemap_valid = false;
+    p->node_k_valid = false;
     if (!p->skipped_user) p->skipped_valid = false;
     return UPSP_OK;
 }
@@ -249,7 +255,8 @@ int upsp_pipeline_set_projection_async(upsp_pipeline *p, int cam, const int32_t 
     }
     p->has_proj[cam] = true;
     p->m_valid[cam] = false;
-    p->tilemap_valid = false;
+    if (!p->hint_active) p->tilemap_valid = false;
+    p->node_k_valid = false;
     if (!p->skipped_user) p->skipped_valid = false;
     return UPSP_OK;
 }
@@ -389,6 +396,134 @@ int upsp_pipeline_finalize(upsp_pipeline *p, uint64_t nframes_total, float *d_av
                          (hipStream_t)stream);
 }
 
+// ---- streamed schedule, one camera: shared by upsp_pipeline_prescan and the frame loop ----
+// Builds the active-pixel map from `d_pix_src` (the projection, or a candidate set) if there is none.
+static int streamed_map(upsp_pipeline *p, const int32_t *d_pix_src, size_t npix, hipStream_t st)
+{
+    if (p->tilemap_valid) return UPSP_OK;
+    const size_t ntiles = tilemap_tiles(npix);
+    if (!p->d_aflag) UPSP_HIP_CHECK(hipMalloc(&p->d_aflag, npix));
+    if (!p->d_tile_off) UPSP_HIP_CHECK(hipMalloc(&p->d_tile_off, sizeof(unsigned) * (ntiles + 1)));
+    if (!p->d_tile_cnt) UPSP_HIP_CHECK(hipMalloc(&p->d_tile_cnt, sizeof(unsigned) * ntiles));
+    if (!p->d_node_k) UPSP_HIP_CHECK(hipMalloc(&p->d_node_k, sizeof(int32_t) * p->nnodes));
+    if (!p->d_tile_order) UPSP_HIP_CHECK(hipMalloc(&p->d_tile_order, sizeof(unsigned) * 4 * (ntiles + 1)));
+    int rc = launch_amap_build(d_pix_src, p->nnodes, npix, p->d_aflag, p->d_tile_cnt, p->d_tile_off, p->d_node_k,
+                               p->d_tile_order, st);
+    if (rc != UPSP_OK) return rc;
+    p->tilemap_valid = true;
+    return UPSP_OK;
+}
+
+// Frames per group (one pass A launch + one pass B launch): as many as the compact buffer may hold, at most
+// group_frames_max().  One series of `cp` u16 per active pixel.  The number of active pixels is known on the
+// device only; reading it back costs a stream round trip per projection, after which the host has to issue the
+// whole frame loop with the GPU idle (measured with the projection rebuilt every step: chunked N > 1 loop
+// 0.98 -> 3.0 ms per 1000 frames).  So the buffer is sized for the bound min(nodes, pixels), within the budget
+// opts.compact_mb.  Also sizes the hot-pixel scratch of the call.
+static int streamed_buffers(upsp_pipeline *p, size_t npix, int nframes, hipStream_t st, int *S_out, unsigned *cp_out)
+{
+    const size_t budget = (size_t)(p->opts.compact_mb > 0 ? p->opts.compact_mb : 2048) << 20;
+    const size_t nact = std::max<size_t>(std::min(p->nnodes, npix), 1);
+    int S = (int)std::min<size_t>((size_t)group_frames_max(), (budget / (2 * nact)) / 64 * 64);
+    S = std::max(S, 64);
+    const unsigned cp = (unsigned)((std::min(nframes, S) + 63) / 64 * 64);
+    if (nact * cp * 2 > p->compact_bytes) {
+        if (p->d_compact) {
+            UPSP_HIP_CHECK(hipStreamSynchronize(st));    // launches queued earlier may still use it
+            free_dev(p->d_compact);
+            p->d_compact = nullptr;
+            p->compact_bytes = 0;
+        }
+        UPSP_HIP_CHECK(hipMalloc(&p->d_compact, nact * cp * 2));
+        p->compact_bytes = nact * cp * 2;
+    }
+    if (p->opts.hot_enable) {
+        int rc = ensure_hot(p, nframes);   // one counter per frame of the CALL
+        if (rc != UPSP_OK) return rc;
+        const size_t words = hot_changes_words(nframes, p->opts.hot_max);
+        if (words > p->changes_words) {
+            if (p->d_changes) UPSP_HIP_CHECK(hipStreamSynchronize(st));
+            free_dev(p->d_changes);
+            p->d_changes = nullptr;
+            p->changes_words = 0;
+            UPSP_HIP_CHECK(hipMalloc(&p->d_changes, sizeof(unsigned) * words));
+            p->changes_words = words;
+        }
+        if (p->head_elems < npix) {
+            if (p->d_head) UPSP_HIP_CHECK(hipStreamSynchronize(st));
+            free_dev(p->d_head);
+            p->d_head = nullptr;
+            UPSP_HIP_CHECK(hipMalloc(&p->d_head, sizeof(int32_t) * npix));
+            p->head_elems = npix;
+        }
+        if (p->next_elems < p->nnodes) {
+            if (p->d_next) UPSP_HIP_CHECK(hipStreamSynchronize(st));
+            free_dev(p->d_next);
+            p->d_next = nullptr;
+            UPSP_HIP_CHECK(hipMalloc(&p->d_next, sizeof(int32_t) * p->nnodes));
+            p->next_elems = p->nnodes;
+        }
+    }
+    *S_out = S;
+    *cp_out = cp;
+    return UPSP_OK;
+}
+
+static int streamed_pass_a(upsp_pipeline *p, uint16_t *fr, size_t npix, int s0, int ns, unsigned cp, hipStream_t st)
+{
+    const bool hot = p->opts.hot_enable != 0;
+    static const bool dbg_noorder = std::getenv("UPSP_NO_TILE_ORDER") != nullptr;   // (measurement switch)
+    return launch_scan_compact(fr + (size_t)s0 * npix, npix, ns, hot, p->opts.hot_thresh, p->opts.hot_max, p->d_aflag,
+                               p->d_tile_off, dbg_noorder ? nullptr : p->d_tile_order, p->d_compact, cp, 0,
+                               hot ? p->d_hot_count + s0 : nullptr, hot ? p->d_hot_pos + (size_t)s0 * 64 : nullptr, st);
+}
+
+int upsp_pipeline_set_active_hint(upsp_pipeline *p, const int32_t *d_pix_candidates, void *stream)
+{
+    if (!p) return fail(UPSP_ERR_INVALID, "null pipeline");
+    if (!d_pix_candidates) {
+        p->hint_active = false;
+        p->tilemap_valid = false;
+        p->node_k_valid = false;
+        return UPSP_OK;
+    }
+    const size_t npix = (size_t)p->width * p->height;
+    if (p->ncams != 1 || (npix % 2) != 0 || p->nnodes >= ((size_t)1 << 31))
+        return fail(UPSP_ERR_INVALID, "active hint: one camera, even pixel count");
+    p->tilemap_valid = false;
+    int rc = streamed_map(p, d_pix_candidates, npix, (hipStream_t)stream);
+    if (rc != UPSP_OK) return rc;
+    p->hint_active = true;
+    p->node_k_valid = false;
+    p->prescan_frames = nullptr;
+    return UPSP_OK;
+}
+
+int upsp_pipeline_prescan(upsp_pipeline *p, uint16_t *d_frames, int nframes, void *stream)
+{
+    if (!p || !d_frames || nframes <= 0) return fail(UPSP_ERR_INVALID, "bad argument");
+    const size_t npix = (size_t)p->width * p->height;
+    if (p->ncams != 1 || p->d_weight[0] || p->opts.registration || p->opts.patch || p->opts.filter || p->d_src ||
+        (npix % 2) != 0 || p->batch != 64 || p->opts.fused_scan == 2)
+        return fail(UPSP_ERR_INVALID, "prescan: plain one-camera path with the streamed schedule only");
+    if (!p->tilemap_valid) {
+        if (!p->has_proj[0]) return fail(UPSP_ERR_INVALID, "prescan: neither an active hint nor a projection is set");
+        int rc = streamed_map(p, p->d_pix[0], npix, (hipStream_t)stream);
+        if (rc != UPSP_OK) return rc;
+        p->node_k_valid = true;
+    }
+    int S = 0;
+    unsigned cp = 0;
+    int rc = streamed_buffers(p, npix, nframes, (hipStream_t)stream, &S, &cp);
+    if (rc != UPSP_OK) return rc;
+    if (nframes > S) return fail(UPSP_ERR_INVALID, "prescan: more frames than one pass A / pass B group holds");
+    rc = streamed_pass_a(p, d_frames, npix, 0, nframes, cp, (hipStream_t)stream);
+    if (rc != UPSP_OK) return rc;
+    p->prescan_frames = d_frames;
+    p->prescan_n = nframes;
+    return UPSP_OK;
+}
+
 static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes,
                         int64_t first_frame, float *d_rows, float *d_rows_t, uint16_t *d_rows_t16,
                         int64_t ld_t, int64_t col0, float *d_warps, void *stream)
@@ -463,38 +598,20 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
     const bool fused = fused_ok && fused_mode != 2;
     if (fused) {
         if (!p->tilemap_valid) {
-            const size_t ntiles = tilemap_tiles(npix);
-            if (!p->d_aflag) UPSP_HIP_CHECK(hipMalloc(&p->d_aflag, npix));
-            if (!p->d_tile_off) UPSP_HIP_CHECK(hipMalloc(&p->d_tile_off, sizeof(unsigned) * (ntiles + 1)));
-            if (!p->d_tile_cnt) UPSP_HIP_CHECK(hipMalloc(&p->d_tile_cnt, sizeof(unsigned) * ntiles));
-            if (!p->d_node_k) UPSP_HIP_CHECK(hipMalloc(&p->d_node_k, sizeof(int32_t) * p->nnodes));
-            if (!p->d_tile_order) UPSP_HIP_CHECK(hipMalloc(&p->d_tile_order, sizeof(unsigned) * 4 * (ntiles + 1)));
-            rc = launch_amap_build(p->d_pix[0], p->nnodes, npix, p->d_aflag, p->d_tile_cnt, p->d_tile_off,
-                                   p->d_node_k, p->d_tile_order, st);
+            rc = streamed_map(p, p->d_pix[0], npix, st);
             if (rc != UPSP_OK) return rc;
-            p->tilemap_valid = true;
+            p->node_k_valid = true;
+            p->hint_active = false;
         }
-        // Frames per group (one pass A launch + one pass B launch): as many as the compact buffer may hold,
-        // at most group_frames_max().  One series of `cp` u16 per active pixel.  The number of active
-        // pixels is known on the device only; reading it back costs a stream round trip per projection,
-        // after which the host has to issue the whole frame loop with the GPU idle (measured with the
-        // projection rebuilt every step: chunked N > 1 loop 0.98 -> 3.0 ms per 1000 frames).  So the
-        // buffer is sized for the bound min(nodes, pixels), within the budget opts.compact_mb.
-        const size_t budget = (size_t)(p->opts.compact_mb > 0 ? p->opts.compact_mb : 2048) << 20;
-        const size_t nact = std::max<size_t>(std::min(p->nnodes, npix), 1);
-        int S = (int)std::min<size_t>((size_t)group_frames_max(), (budget / (2 * nact)) / 64 * 64);
-        S = std::max(S, 64);
-        const unsigned cp = (unsigned)((std::min(nframes, S) + 63) / 64 * 64);
-        if (nact * cp * 2 > p->compact_bytes) {
-            if (p->d_compact) {
-                UPSP_HIP_CHECK(hipStreamSynchronize(st));    // launches queued earlier may still use it
-                free_dev(p->d_compact);
-                p->d_compact = nullptr;
-                p->compact_bytes = 0;
-            }
-            UPSP_HIP_CHECK(hipMalloc(&p->d_compact, nact * cp * 2));
-            p->compact_bytes = nact * cp * 2;
+        if (!p->node_k_valid) {     // candidate map kept across a projection change: only node -> series index is redone
+            rc = launch_amap_nodes(p->d_pix[0], p->nnodes, p->d_aflag, p->d_tile_off, p->d_node_k, st);
+            if (rc != UPSP_OK) return rc;
+            p->node_k_valid = true;
         }
+        int S = 0;
+        unsigned cp = 0;
+        rc = streamed_buffers(p, npix, nframes, st, &S, &cp);
+        if (rc != UPSP_OK) return rc;
         PipelineGather g;
         g.ncams = 1;
         g.npix = npix;
@@ -506,39 +623,16 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
         g.pix[0] = p->d_pix[0];
         g.ld_t = ld_t;
         const bool hot = p->opts.hot_enable != 0;
-        if (hot) {
-            rc = ensure_hot(p, nframes);   // one counter per frame of the CALL
-            if (rc != UPSP_OK) return rc;
-            const size_t words = hot_changes_words(nframes, p->opts.hot_max);
-            if (words > p->changes_words) {
-                if (p->d_changes) UPSP_HIP_CHECK(hipStreamSynchronize(st));
-                free_dev(p->d_changes);
-                p->d_changes = nullptr;
-                p->changes_words = 0;
-                UPSP_HIP_CHECK(hipMalloc(&p->d_changes, sizeof(unsigned) * words));
-                p->changes_words = words;
-            }
-            if (p->head_elems < npix) {
-                free_dev(p->d_head);
-                p->d_head = nullptr;
-                UPSP_HIP_CHECK(hipMalloc(&p->d_head, sizeof(int32_t) * npix));
-                p->head_elems = npix;
-            }
-            if (p->next_elems < p->nnodes) {
-                free_dev(p->d_next);
-                p->d_next = nullptr;
-                UPSP_HIP_CHECK(hipMalloc(&p->d_next, sizeof(int32_t) * p->nnodes));
-                p->next_elems = p->nnodes;
-            }
-        }
         uint16_t *fr = d_frames[0];
+        // pass A of exactly these frames may already have run (upsp_pipeline_prescan, e.g. on another stream
+        // while the projection was being built; the caller orders the streams)
+        const bool prescanned = p->prescan_frames == fr && p->prescan_n == nframes && nframes <= S;
+        p->prescan_frames = nullptr;
         for (int s0 = 0; s0 < nframes && rc == UPSP_OK; s0 += S) {
             const int ns = std::min(S, nframes - s0);
-            static const bool dbg_noorder = std::getenv("UPSP_NO_TILE_ORDER") != nullptr;   // (measurement switch)
-            rc = launch_scan_compact(fr + (size_t)s0 * npix, npix, ns, hot, p->opts.hot_thresh, p->opts.hot_max, p->d_aflag,
-                                     p->d_tile_off, dbg_noorder ? nullptr : p->d_tile_order, p->d_compact, cp, 0, hot ? p->d_hot_count + s0 : nullptr,
-                                     hot ? p->d_hot_pos + (size_t)s0 * 64 : nullptr, st);
+            if (!prescanned) rc = streamed_pass_a(p, fr, npix, s0, ns, cp, st);
             g.nframes = ns;
+            g.img[0] = fr + (size_t)s0 * npix;
             g.rows_t = d_rows_t ? d_rows_t + col0 + s0 : nullptr;
             g.rows_t16 = d_rows_t16 ? d_rows_t16 + col0 + s0 : nullptr;
             if (rc == UPSP_OK) rc = launch_node_rows(g, p->d_node_k, p->d_compact, cp, st);

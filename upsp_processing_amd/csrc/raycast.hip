@@ -327,6 +327,7 @@ struct Scene {
     int refill;           // re-fill threshold (live lanes)
     int desc_cap;         // interior-node steps before the lanes that already hold a leaf get to test it (0 = no cap)
     int touch;            // 1: node_step touches the records of both children before it tests their boxes
+    int xcd;              // 1: XCD-aware static assignment of the work items (queue_init)
     unsigned chunk;       // work items per queue grab (multiple of 64)
     float rlo[3], rhi[3];
     const unsigned *adj_off, *adj_slot;   // node -> adjacent triangle slots (may be null)
@@ -526,13 +527,19 @@ struct WaveQueue {
 // Every wave owns chunk #wave statically (no atomic storm at launch); further chunks
 // come from the shared counter, offset by the statically assigned range.
 __device__ __forceinline__ void queue_init(WaveQueue &q, unsigned *head, unsigned total,
-                                           unsigned chunk)
+                                           unsigned chunk, bool xcd_aware = true)
 {
     q.head = head;
     q.total = total;
     q.chunk = chunk;
     const unsigned waves_per_block = blockDim.x >> 6;
-    const unsigned wave = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
+    // XCD-aware static assignment: workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one), each
+    // with its own 4-MiB L2.  Work items are in mesh order, i.e. spatially coherent, so the workgroups of one XCD take
+    // one contiguous eighth of the item range and that XCD's L2 holds one region's subtrees instead of all of them.
+    // (Placement is not guaranteed by HIP: this is for speed only, any mapping is a bijection.)
+    const unsigned nb = gridDim.x, xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const unsigned vb = xcd_aware ? xcd * (nb >> 3) + min(xcd, nb & 7u) + slot : blockIdx.x;
+    const unsigned wave = vb * waves_per_block + (threadIdx.x >> 6);
     q.base = gridDim.x * waves_per_block * chunk;
     const unsigned long long first = (unsigned long long)wave * chunk;
     q.cur = first < total ? (unsigned)first : total;
@@ -657,7 +664,7 @@ __global__ void __launch_bounds__(kBlock)
     extern __shared__ int lds_stack[];
     int *stack = lds_stack + threadIdx.x;
     WaveQueue q;
-    queue_init(q, work, n, sc.chunk);
+    queue_init(q, work, n, sc.chunk, sc.xcd != 0);
     Ray r;
     r.simple = true;   // idle lanes must not veto the wave-uniform fast path
     Trav s;
@@ -788,6 +795,29 @@ __global__ void __launch_bounds__(256)
     pix[n] = state;
     uv[2 * (size_t)n] = state == kPixInFrame ? u : 0.f;      // default uv = (0,0) (:179-182)
     uv[2 * (size_t)n + 1] = state == kPixInFrame ? v : 0.f;
+}
+
+// Step 1 + the pixel of :319 for every in-frame node, whatever the rays will say (upsp_projection_candidate_pixels)
+__global__ void __launch_bounds__(256)
+    candidate_pixels_kernel(Cam cam, const float *__restrict__ nodes, const uint8_t *__restrict__ datanode,
+                            unsigned nnodes, int32_t *__restrict__ pix)
+{
+    const unsigned n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= nnodes) return;
+    int32_t out = -1;
+    if (!datanode || datanode[n]) {
+        float u, v;
+        project_point(cam.K, cam.dist, cam.R, cam.t, nodes[3 * (size_t)n], nodes[3 * (size_t)n + 1],
+                      nodes[3 * (size_t)n + 2], u, v);
+        const bool finite_int = (fabsf(u) < 2147483648.0f) & (fabsf(v) < 2147483648.0f);
+        const int rx = finite_int ? (int)rintf(u) : -1, ry = finite_int ? (int)rintf(v) : -1;
+        if ((rx >= 0) & (ry >= 0) & (rx < cam.W) & (ry < cam.H)) {
+            const int px_ = (int)roundf(u), py_ = (int)roundf(v);
+            const long long idx = (long long)py_ * cam.W + px_;
+            if (idx >= 0 && idx < (long long)cam.W * cam.H) out = (int32_t)idx;
+        }
+    }
+    pix[n] = out;
 }
 
 // Step 2 -- one PRIMARY ray per in-frame node (psp_process.cpp:254-267).  Nodes hit on
@@ -1075,7 +1105,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 
     int *stack = lds_stack + threadIdx.x;
     const unsigned total = PHASE == 0 ? nnodes : PHASE == 1 ? work[kWorkRetryCount] * 6u : work[kWorkTodoCount];
     WaveQueue q;
-    queue_init(q, work, total, sc.chunk);
+    queue_init(q, work, total, sc.chunk, sc.xcd != 0 && PHASE == 0);   // (retry lists are not in mesh order)
     Ray r;
     r.simple = true;   // idle lanes must not veto the wave-uniform fast path
     Trav s;
@@ -1333,6 +1363,10 @@ Scene make_scene(const upsp_bvh *b, size_t items, int grid)
     //  visit cost more issue slots than the warm line saves.  Kept as a switch for other models.)
     static const int touch = env_int("UPSP_TOUCH", 0) ? 1 : 0;
     sc.touch = touch;
+    // (measured: primary traversal 267-271 -> 263 us, batch queries alike; residual retries +2 %: their list is not
+    //  in mesh order, so they keep the plain mapping)
+    static const int xcd = env_int("UPSP_XCD_AWARE", 1) ? 1 : 0;
+    sc.xcd = xcd;
     sc.adj_off = sc.adj_slot = nullptr;
     sc.slot_path = nullptr;
     sc.path_ref = nullptr;
@@ -2000,6 +2034,27 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
                          w[kWorkRetryCount], w[kWorkTodoCount], w[8], w[9]);
         }
     }
+    return UPSP_OK;
+}
+
+int upsp_projection_candidate_pixels(const upsp_camera *cam, const float *d_nodes, const uint8_t *d_datanode,
+                                     size_t nnodes, int32_t *d_pix, void *stream)
+{
+    if (!cam || !d_nodes || !d_pix) return fail(UPSP_ERR_INVALID, "null argument");
+    if (cam->width <= 0 || cam->height <= 0) return fail(UPSP_ERR_INVALID, "bad image size");
+    if (nnodes == 0) return UPSP_OK;
+    if (nnodes > 0xF0000000ull) return fail(UPSP_ERR_INVALID, "too many nodes");
+    Cam c;
+    std::memcpy(c.K, cam->K, sizeof(c.K));
+    std::memcpy(c.dist, cam->dist, sizeof(c.dist));
+    std::memcpy(c.R, cam->R, sizeof(c.R));
+    std::memcpy(c.t, cam->t, sizeof(c.t));
+    c.ox = c.oy = c.oz = 0.0f;
+    c.W = cam->width;
+    c.H = cam->height;
+    hipLaunchKernelGGL(candidate_pixels_kernel, dim3((unsigned)((nnodes + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       c, d_nodes, d_datanode, (unsigned)nnodes, d_pix);
+    UPSP_HIP_CHECK(hipGetLastError());
     return UPSP_OK;
 }
 

@@ -177,6 +177,16 @@ def build_projection(bvh, cam, nodes, normals, tri_nodes, oblique_angle=70.0, da
                 primary_rays=int(pr.value), retry_nodes=int(rn.value))
 
 
+def candidate_pixels(cam, nodes, datanode=None):
+    """Step 1 of create_projection_mat alone: int32 [N], the pixel every in-frame node would be stored at
+    (-1 otherwise) -- a superset of any projection of this camera (FramePipeline.set_active_hint)."""
+    nodes = _dev(nodes, torch.float32).reshape(-1, 3)
+    dn = None if datanode is None else _dev(datanode, torch.uint8).reshape(-1)
+    pix = torch.empty(nodes.shape[0], dtype=torch.int32, device="cuda")
+    check(lib().upsp_projection_candidate_pixels(C.byref(cam), _ptr(nodes), _ptr(dn), nodes.shape[0], _ptr(pix), _stream()))
+    return pix
+
+
 def projection_weights(pix, nodes, normals, centers, mode="average_view"):
     """adjust_projection_for_weights (projection.ipp:911-1078).  pix: [ncams, N] int32.
     Returns weight [ncams, N] f32 (1 where a single camera sees the node)."""
@@ -303,6 +313,19 @@ class FramePipeline:
         assert frames.is_cuda and frames.dtype == torch.uint16 and frames.is_contiguous()
         assert tuple(frames.shape[1:]) == (self.height, self.width)
         check(lib().upsp_pipeline_fix_hot_pixels(self._h, _ptr(frames), frames.shape[0], _stream()))
+
+    def set_active_hint(self, pix_candidates):
+        """Active-pixel map from a candidate set (engine.candidate_pixels) instead of a projection: pass A
+        (prescan) can then run before / while the projection is built.  None clears it."""
+        self._hint = None if pix_candidates is None else _dev(pix_candidates, torch.int32)
+        check(lib().upsp_pipeline_set_active_hint(self._h, _ptr(self._hint), _stream()))
+
+    def prescan(self, frames):
+        """Pass A (hot-pixel count + compact pixel series) of u16 frames [F <= 1024, H, W] on the current
+        stream; the next process() call on the same tensor runs pass B + the hot-pixel fix-up only."""
+        assert frames.is_cuda and frames.dtype == torch.uint16 and frames.is_contiguous()
+        assert tuple(frames.shape[1:]) == (self.height, self.width)
+        check(lib().upsp_pipeline_prescan(self._h, _ptr(frames), frames.shape[0], _stream()))
 
     def set_skipped(self, skipped):
         sk = None if skipped is None else _dev(skipped, torch.uint8)
