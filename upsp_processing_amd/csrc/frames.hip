@@ -566,27 +566,29 @@ __global__ void __launch_bounds__(WAVES * 64)
 // cycle per lane, and only fast while the 64-frame sub-batch still sits in the Infinity Cache).
 // Here the frame data is turned round on its single way through the chip:
 //
-//   pass A (scan_compact_kernel): a workgroup owns a TILE of 128 consecutive pixels and streams
-//     that tile of all (<= 64) frames of the sub-batch through LDS with coalesced 256-byte loads,
-//     counting the hot pixels on the way (that is the scan).  The few pixels of the tile that some
-//     node reads ("active" pixels: 66 k of 1 M on the bench model) leave the tile TRANSPOSED: 64
-//     consecutive u16 -- the pixel's time series over the sub-batch -- per active pixel, into a
-//     compact buffer (8 MB per sub-batch, L2 / Infinity-Cache resident whatever the frame size).
-//     The work per tile is bounded by its 128 pixels, however many nodes read them.
-//   pass B (node_stream_kernel): 16 lanes per node read the node's pixel series (128 contiguous
-//     bytes), widen it, add it to the accumulators and write the 256-byte row segment; nodes without
-//     a pixel get their constant row (NaN when no camera sees them, psp_process.cpp:1821-1825).
-//     Nodes in mesh order, rows in row order: a pure streaming write.
+//   pass A (scan_compact_kernel, one launch per <= 1024 frames): a workgroup owns a TILE of 128
+//     consecutive pixels of one 64-frame group and streams it through registers with coalesced 256-byte
+//     loads, counting the hot pixels on the way (that is the scan).  The few pixels of the tile that some
+//     node reads ("active" pixels: 66 k of 1 M on the bench model) leave the tile TRANSPOSED through LDS:
+//     64 consecutive u16 per active pixel and group into the pixel's series in the compact buffer, which
+//     holds all frames of the call.  The work per tile is bounded by its 128 pixels, however many nodes
+//     read them.
+//   pass B (node_rows_kernel, one launch per <= 1024 frames): a workgroup sweeps whole row pieces --
+//     256 / 128 / 64 lanes per row, a lane converts 4 frames (8-byte load from the pixel's series, 16-byte
+//     store) -- adds the accumulators and fills the constant rows of nodes without a pixel (NaN when no
+//     camera sees them, psp_process.cpp:1821-1825).  Nodes in mesh order, rows in row order: a pure
+//     streaming write.  (node_stream_kernel is round 1's form of this pass: 16 lanes per node, 1-KB pieces.)
 //
-// HBM sees every frame byte once (pass A, reads only) and every series byte once (pass B, writes only);
-// nothing depends on the frames staying in a cache between the passes.  (A single fused pass that
-// pushes the pixels straight to the nodes' rows was built first: its node work piles up on the 10 % of
-// the tiles that cover the model, and reads and writes interleave in HBM -- level with scan + gather at
-// 1 Mpix.  DESIGN.md section 4.)
+// HBM sees every frame byte once (pass A, reads + 6 % compact stores) and every series byte once (pass B,
+// writes + the compact series); nothing depends on the frames staying in a cache between the passes.  (A
+// single fused pass that pushes the pixels straight to the nodes' rows was built first: its node work piles
+// up on the 10 % of the tiles that cover the model, and reads and writes interleave in HBM -- level with
+// scan + gather at 1 Mpix.  DESIGN.md section 4.)
 //   * hot pixels: pass A cannot know a frame's count before the whole frame has gone by, so the passes
 //     project the pixels as they are; hot_repair_kernel then repairs the (rare) frames with
 //     1..max_hot hot pixels in place exactly like fix_frame and lists the replaced pixels, and
-//     hot_patch_kernel re-projects them: series entry and accumulators of every node on such a pixel.
+//     hot_patch_kernel re-projects them (through pixel -> node lists built only when a call replaced
+//     something): series entry and accumulators of every node on such a pixel.
 //     All values are integers < 2^16 (squares rounded to float like the gather's), their double sums
 //     are exact, so "add new - old" gives the same bits as summing the repaired values.
 constexpr int kFusedPix = 128;     // pixels per tile

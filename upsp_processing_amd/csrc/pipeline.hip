@@ -645,12 +645,8 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
         }
         return rc;
     }
-    // Several cameras (weights allowed): the same two passes with one active-pixel map and one compact
-    // buffer per camera; the hot-pixel scan + repair stays the stand-alone kernel (a replaced pixel would
-    // have to be re-projected through every camera's weights), pass A runs without the count.  Opt-in
-    // (`fused_scan = 1`): measured on the 5 M-triangle / 4-camera shape it is still behind scan + gather
-    // (0.63-0.66 vs 0.56 ms per 64 frame sets): the scan is a pass of its own there and pass B is bound by
-    // the number of memory transactions per node (four series reads + one row piece), DESIGN.md section 7.
+    // Several cameras (weights allowed): the same two passes with one active-pixel map and one whole-call compact
+    // buffer per camera; pass B (node_rows_multi_kernel) sums the cameras in order with their weights.
     const bool multi_ok = p->ncams > 1 && !need_stage && !d_rows && d_rows_t && !d_rows_t16 && !p->d_src &&
                           (npix % 2) == 0 && B == 64 && !overlap && p->nnodes < ((size_t)1 << 31);
     // default (fused_scan = 0): streamed from 192 frames per call on -- measured on the 5 M-triangle / 4-camera
