@@ -227,7 +227,13 @@ def main():
     if os.environ.get("UPSP_BENCH_ONE_GPU"):
         local = 0
     torch.cuda.set_device(local)
-    if world > 1:
+    force_coll = world == 1 and bool(os.environ.get("UPSP_FORCE_COLLECTIVES"))   # one-rank group: RCCL calls on one GPU
+    if force_coll:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        with socket.socket() as sck:
+            sck.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(sck.getsockname()[1]))
+    if world > 1 or force_coll:
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local))
@@ -353,7 +359,7 @@ def main():
         step(False)
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_coll:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -465,6 +471,7 @@ def main():
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic", **({"backend": backend} if world > 1 and backend != "nccl" else {}),
+        **({"collectives": "issued through %s in a one-rank group" % ("RCCL" if backend == "nccl" else backend)} if force_coll else {}),
         "config": {"workload": "configs[%d]: %d frames/GPU x %dx%d u16, %d-tri tunnel model (%d nodes), "
                                "raycast+%sprojection" % (2 if a.registration else 1, F, size, size,
                                                          tris.shape[0], N,
@@ -529,6 +536,9 @@ def main():
                 "accumulators_%d_frames" % n_sample: bool(np.array_equal(np.isnan(gs), ~ok) and np.array_equal(gs[ok], ref["sum"][ok])
                                                        and np.array_equal(gss[ok], ref["sumsq"][ok])),
             }
+            if chunked:   # the series as it came out of the (chunked, packed, u16) exchange
+                checks["exchange_series_8_frames"] = bool(np.array_equal(
+                    exch.out[:, :8].cpu().numpy().T.view(np.int32), ref["rows8"].view(np.int32)))
             out["parity_checked"] = all(checks.values())
             out["parity"] = checks
             if not out["parity_checked"]:
@@ -538,7 +548,7 @@ def main():
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_coll:
         dist.destroy_process_group()
 
 

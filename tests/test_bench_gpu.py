@@ -47,6 +47,16 @@ def test_bench_two_ranks_on_one_gpu_gloo(gpu_lib):
     assert d["config"]["parallelism"] == "frames sharded x2"
 
 
+def test_bench_rccl_one_rank_group(gpu_lib):
+    """RCCL refuses two ranks on one GPU, so on a one-GPU box the N > 1 loop runs in a ONE-rank nccl group with the
+    collectives forced (all_reduce of the accumulators, async all_to_all_single of the packed u16 chunks as bytes,
+    barrier): the calls, dtypes and split sizes go through RCCL itself."""
+    d = run_bench(["--force-chunked", "--small", "--steps", "2", "--warmup", "1"], env={"UPSP_FORCE_COLLECTIVES": "1"})
+    assert d["n_gpus"] == 1 and d["collectives"].startswith("issued through RCCL")
+    assert d["config"]["exchange"] == "4 chunks, visible rows as u16"
+    assert d["parity_checked"] is True
+
+
 def test_bench_two_ranks_rccl(gpu_lib):
     import torch
     if torch.cuda.device_count() < 2:

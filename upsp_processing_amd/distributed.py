@@ -14,8 +14,14 @@ collective until the end of the run, where three exchanges happen:
   links of every GPU carry exactly one block at the same time;
 * optional gather of everything to rank 0 (BASELINE north-star wording).
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+# UPSP_FORCE_COLLECTIVES=1: issue the collectives even in a one-rank group (a one-GPU box can then run
+# the all_reduce / all_to_all_single calls through RCCL itself -- two ranks on one GPU are refused by RCCL)
+FORCE_COLLECTIVES = bool(os.environ.get("UPSP_FORCE_COLLECTIVES"))
 
 
 def init_from_env(backend=None):
@@ -94,7 +100,7 @@ class Shard:
 
 def allreduce_sums(total, sumsq, group=None):
     """Sum the double accumulators over ranks (in place)."""
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_initialized() and (dist.get_world_size(group) > 1 or FORCE_COLLECTIVES):
         both = torch.stack([total, sumsq])
         dist.all_reduce(both, op=dist.ReduceOp.SUM, group=group)
         total.copy_(both[0])
@@ -281,7 +287,7 @@ class TimeSeriesExchange:
         assert not wire16 or packed
         n0, nn = sh.my_nodes
         self.k += 1
-        if sh.world == 1 or not dist.is_initialized():
+        if (sh.world == 1 and not FORCE_COLLECTIVES) or not dist.is_initialized():
             if fc:
                 if self.vis is None:
                     self.out[:, c0:c0 + fc] = rows_t_chunk
