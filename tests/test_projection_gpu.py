@@ -57,6 +57,46 @@ def test_projection_matches_oracle(gpu_lib, oracle, case):
     assert st_bounded["nodes"] <= st_classic["nodes"]                         # the bound only ever prunes
 
 
+@pytest.mark.parametrize("steps,stack", [(8, 4096), (8, 128), (40, 4096), (1, 130)])
+def test_heavy_ray_handoff(gpu_lib, oracle, monkeypatch, steps, stack):
+    """Rays that need more than UPSP_HEAVY_STEPS node visits + triangle tests leave the one-lane traversal and are
+    walked by a whole wave (heavy_kernel; default 256 steps: only the rays through high-valence vertices).  With a
+    threshold of a few steps most rays of the build take that road, primary and retries; with a 128-entry stack
+    most of those overflow it and take the one-lane fallback inside heavy_kernel.  Same verdicts either way."""
+    import torch
+    from upsp_processing_amd import engine, synthetic as syn
+    mesh, kw, size = syn.tunnel_model(100, 240, 40, 80), dict(center=(0, 0, 20), half_extent=6.0), (1024, 512)
+    v, t, s9, tn, nrm, cam_g, cam_o = setup_case(oracle, mesh, kw, size)
+    bvh = engine.BVH(s9)
+    obv = oracle.OracleBVH(s9)
+    o = oracle.create_projection(obv, cam_o, v, nrm, tn, engine.oblique_threshold(70.0))
+    monkeypatch.setenv("UPSP_HEAVY_STEPS", str(steps))
+    monkeypatch.setenv("UPSP_HEAVY_STACK", str(stack))
+    d_tn = torch.as_tensor(tn).cuda()
+    for adjacency in (False, True):
+        if adjacency:
+            bvh.set_tri_nodes(d_tn, v.shape[0])
+        g = engine.build_projection(bvh, cam_g, v, nrm, d_tn if adjacency else tn, 70.0)
+        assert np.array_equal(g["pix"].cpu().numpy(), o["pix"])
+        assert np.array_equal(g["uv"].cpu().numpy().view(np.int32), o["uv"].view(np.int32))
+        assert g["nrays"] == o["nrays"]
+    # a pole of the UV sphere seen head-on: the ray to the pole vertex meets every triangle of its fan
+    mesh = syn.uv_sphere(60, 900)
+    from upsp_processing_amd import _capi
+    v, t = mesh
+    s9, tn = syn.soup(v, t)
+    nrm = syn.node_normals(v, t)
+    bvh, obv = engine.BVH(s9), oracle.OracleBVH(s9)
+    for az in (0.0, 90.0, 37.0):
+        c = syn.pinhole_camera(256, 256, center=(0, 0, 20), half_extent=1.5, azimuth_deg=az)
+        cg = _capi.make_camera(c["K"], c["dist"], c["R"], c["t"], 256, 256)
+        co = oracle.make_camera(c["K"], c["dist"], c["R"], c["t"], 256, 256)
+        g = engine.build_projection(bvh, cg, v, nrm, tn, 70.0)
+        o = oracle.create_projection(obv, co, v, nrm, tn, engine.oblique_threshold(70.0))
+        assert np.array_equal(g["pix"].cpu().numpy(), o["pix"])
+        assert g["nrays"] == o["nrays"]
+
+
 def test_multi_camera_weights(gpu_lib, oracle):
     from upsp_processing_amd import engine, _capi, synthetic as syn
     v, t = syn.tunnel_model(60, 120, 24, 48)

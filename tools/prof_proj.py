@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from upsp_processing_amd import _capi, engine, synthetic as syn
 size = 1024
-verts, tris = syn.tunnel_model_quad()
+verts, tris = syn.tunnel_model() if 'uv' in sys.argv[1:] else syn.tunnel_model_quad()
 s9, tn = syn.soup(verts, tris); nrm = syn.node_normals(verts, tris)
 cd = syn.pinhole_camera(size, size, center=(0, 0, 20), half_extent=6.0)
 cam = _capi.make_camera(cd["K"], cd["dist"], cd["R"], cd["t"], size, size)

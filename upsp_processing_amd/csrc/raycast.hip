@@ -328,6 +328,9 @@ struct Scene {
     int desc_cap;         // interior-node steps before the lanes that already hold a leaf get to test it (0 = no cap)
     int touch;            // 1: node_step touches the records of both children before it tests their boxes
     int xcd;              // 1: XCD-aware static assignment of the work items (queue_init)
+    unsigned heavy_steps; // a ray that needs more node visits + triangle tests than this is handed to heavy_kernel (0 = never)
+    unsigned *heavy_items;   // list of the work items handed over (kHeavyCap entries), count in work[kWorkHeavyCount]
+    unsigned heavy_stack;    // entries of heavy_kernel's stack that may be used (<= kHeavyStack; tests shrink it)
     unsigned chunk;       // work items per queue grab (multiple of 64)
     float rlo[3], rhi[3];
     const unsigned *adj_off, *adj_slot;   // node -> adjacent triangle slots (may be null)
@@ -349,12 +352,14 @@ struct Trav {
     unsigned ray_nodes, ray_tris;  // STATS: steps of the current ray
     unsigned touched;              // xor of the words read ahead (keeps those loads alive, never used)
     unsigned w_node_rounds, w_tri_rounds;   // STATS: rounds of the WAVE (counted by its first executing lane)
+    unsigned steps;                // node visits + triangle tests of the current ray
 };
 
 __device__ __forceinline__ void trav_begin(Trav &s, const Ray &r, const Scene &sc)
 {
     s.sp = 0;
     s.ray_nodes = s.ray_tris = 0;
+    s.steps = 0;
     s.best_t = FLT_MAX;
     s.limit = __builtin_inff();
     s.best_slot = -1;
@@ -397,6 +402,7 @@ __device__ __forceinline__ void node_step(Trav &s, const Ray &r, const Scene &sc
 {
     const float4 *np = sc.nodes + 4 * (size_t)s.cur;
     const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+    ++s.steps;
     if (STATS) { ++s.n_nodes; ++s.ray_nodes; }
     const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
     const unsigned meta = __float_as_uint(q3.z);
@@ -457,6 +463,7 @@ __device__ __forceinline__ bool leaf_step(Trav &s, const Ray &r, const Scene &sc
     for (unsigned i = 0; i < count; ++i) {
         const float4 *tp = sc.tris + 3 * (size_t)(first + i);
         const float4 a = tp[0], b = tp[1], c = tp[2];
+        ++s.steps;
         if (STATS) { ++s.n_tris; ++s.ray_tris; }
         if (STATS && (threadIdx.x & 63u) == (unsigned)__ffsll((long long)__ballot(true)) - 1u) ++s.w_tri_rounds;
         TriHit h;
@@ -510,6 +517,7 @@ __device__ __forceinline__ void trav_run(Trav &s, const Ray &r, const Scene &sc,
             }
         }
         if (more && __popcll(__ballot(s.cur != kDone)) < refill) break;
+        if (!ANYHIT && sc.heavy_steps && __ballot(s.cur != kDone && s.steps > sc.heavy_steps) != 0ull) break;
     }
 }
 
@@ -770,6 +778,9 @@ constexpr int32_t kPixRetry = -4;     // primary ray hit a foreign triangle: ret
 //   [11] primary rays cast
 constexpr int kWorkRetryCount = 10;
 constexpr int kWorkTodoCount = 12;   // rays witness_kernel could not decide
+constexpr int kWorkHeavyCount = 16;  // work items handed to heavy_kernel: [16] by the primary pass, [17] by the retry pass
+constexpr int kWorkWords = 32;
+constexpr unsigned kHeavyCap = 65536;
 
 // Step 1 (elementwise, fp64): cal.map_point_to_image + in-frame test
 // (psp_process.cpp:241-252).  The image point is parked in uv[].
@@ -1154,14 +1165,28 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 
 
         if (busy) {
             trav_run<false, STATS>(s, r, sc, stack, queue_has_more(q), sc.refill);
-            if (PHASE == 0 && s.cur == kDone && bounded && !s.any) {
+            if (sc.heavy_steps && s.cur != kDone && s.steps > sc.heavy_steps) {
+                // a ray that keeps going (e.g. through a vertex shared by ~1000 triangles: every box of the fan is
+                // pierced, every triangle hit) would hold its wave for as long as ONE lane needs for thousands of
+                // dependent steps: hand it to heavy_kernel, where a whole wave walks it
+                const unsigned slot = atomicAdd(&work[kWorkHeavyCount + (PHASE ? 1 : 0)], 1u);
+                if (slot < kHeavyCap) {
+                    sc.heavy_items[slot] = item;
+                    s.cur = kDone;
+                    s.sp = 0;
+                    busy = false;
+                } else {
+                    s.steps = 0;     // list full: carry on here (and do not ask again at once)
+                }
+            }
+            if (busy && PHASE == 0 && s.cur == kDone && bounded && !s.any) {
                 // An own triangle is hit when tested directly but was not reached through the
                 // boxes, and nothing nearer exists: whether the ray hits ANYTHING (retries or
                 // no entry, :261) is decided beyond the bound -> classic unbounded traversal.
                 bounded = false;
                 trav_begin(s, r, sc);
             }
-            if (s.cur == kDone) {
+            if (busy && s.cur == kDone) {
                 busy = false;
                 if (STATS && PHASE == 2 && sc.hist)
                     atomicAdd(&sc.hist[min(47u, (s.ray_nodes + s.ray_tris) >> 4)], 1u);
@@ -1189,6 +1214,213 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 
     }
     flush_stats(work, lds_stack, STATS ? s.n_nodes : 0u, STATS ? s.n_tris : 0u,
                 PHASE == 0 ? my_rays : 0u, PHASE == 0 ? my_rays : 0u);
+}
+
+// One ray per WAVE.  The work items projection_kernel handed over are walked with a wave-wide stack in LDS:
+// every lane pops one entry -- an interior node (both child boxes tested with the traversal's own filtered /
+// exact box test, accepted children pushed) or a leaf (its triangles tested) -- so a ray that pierces thousands
+// of boxes advances 64 of them per step instead of one.  No pruning: exactly the boxes the reference enters
+// (pspRT.cpp:380-423).  The reference keeps the FIRST minimum in its near-child-first depth-first order
+// (strict <, :395); here every entry carries its position in that order as a key -- one bit per level (0 =
+// the child visited first), the triangle's position in its leaf in the low bits -- and the winner is the
+// smallest t, then the smallest key.  Same closest hit, same verdict as the one-lane traversal.
+constexpr unsigned kHeavyStack = 4096;
+struct HeavyBest {
+    float t;
+    unsigned long long key;
+    int slot;
+};
+template <int PHASE>
+__global__ void __launch_bounds__(64)
+    heavy_kernel(Scene sc, Cam cam, const float *__restrict__ nodes, const int32_t *__restrict__ tri_nodes,
+                 int32_t *__restrict__ pix, const unsigned *__restrict__ retry_nodes,
+                 unsigned *__restrict__ retry_mask, const unsigned *__restrict__ work)
+{
+    __shared__ int q_ref[kHeavyStack];
+    __shared__ unsigned long long q_key[kHeavyStack];
+    __shared__ unsigned char q_depth[kHeavyStack];
+    const unsigned lane = threadIdx.x;
+    const unsigned count = min(work[kWorkHeavyCount + (PHASE ? 1 : 0)], kHeavyCap);
+    for (unsigned h = blockIdx.x; h < count; h += gridDim.x) {
+        const unsigned item = sc.heavy_items[h];
+        const unsigned node = PHASE == 0 ? item : retry_nodes[item / 6u];
+        Ray r;
+        if (PHASE == 0) {
+            float dx = nodes[3 * (size_t)item] - cam.ox, dy = nodes[3 * (size_t)item + 1] - cam.oy,
+                  dz = nodes[3 * (size_t)item + 2] - cam.oz;
+            const float len = imath_length(dx, dy, dz);
+            if (len != 0.0f) { dx /= len; dy /= len; dz /= len; }
+            ray_setup(r, cam.ox, cam.oy, cam.oz, dx, dy, dz);
+        } else {
+            retry_ray(r, cam, nodes, node, (int)(item % 6u));
+        }
+        ray_classify(r, sc);
+        unsigned top = 0;                         // (wave-uniform) entries on the stack
+        if (box_hit(r, sc.rlo[0], sc.rlo[1], sc.rlo[2], sc.rhi[0], sc.rhi[1], sc.rhi[2])) {   // trav_begin
+            if (lane == 0) {
+                q_ref[0] = sc.root_ref;
+                q_key[0] = 0ull;
+                q_depth[0] = 0;
+            }
+            top = 1;
+        }
+        __syncthreads();
+        HeavyBest best;
+        best.t = FLT_MAX;
+        best.key = ~0ull;
+        best.slot = -1;
+        bool any = false, overflow = false;
+        while (top > 0) {
+            const unsigned n = min(top, 64u);
+            const bool have = lane < n;
+            int ref = 0;
+            unsigned long long key = 0ull;
+            unsigned depth = 0;
+            if (have) {
+                ref = q_ref[top - n + lane];
+                key = q_key[top - n + lane];
+                depth = q_depth[top - n + lane];
+            }
+            top -= n;
+            __syncthreads();
+            bool pF = false, pS = false;
+            int first = 0, second = 0;
+            if (have && ref >= 0) {
+                const float4 *np = sc.nodes + 4 * (size_t)ref;
+                const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+                const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
+                const unsigned meta = __float_as_uint(q3.z);
+                const bool hL = box_hit(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
+                const bool hR = box_hit(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w);
+                const bool swap = !(meta & kMetaOrdered) && ((r.neg >> (meta & 3u)) & 1u);
+                first = swap ? right : left;
+                second = swap ? left : right;
+                pF = swap ? hR : hL;
+                pS = swap ? hL : hR;
+            } else if (have) {
+                const unsigned code = (unsigned)(~ref);
+                const unsigned f0 = code >> kLeafBits, cnt = (code & (kMaxLeaf - 1)) + 1;
+                for (unsigned i = 0; i < cnt; ++i) {
+                    const float4 *tp = sc.tris + 3 * (size_t)(f0 + i);
+                    const float4 a = tp[0], b = tp[1], c = tp[2];
+                    TriHit th;
+                    if (tri_test(r, a.x, a.y, a.z, b.x, b.y, b.z, c.x, c.y, c.z, th)) {
+                        any = true;
+                        const unsigned long long k = key | (unsigned long long)i;
+                        if (th.t < best.t || (th.t == best.t && k < best.key)) {
+                            best.t = th.t;
+                            best.key = k;
+                            best.slot = (int)(f0 + i);
+                        }
+                    }
+                }
+            }
+            // push the accepted children (wave-wide prefix counts); the level's bit sits below the bits of the levels above
+            const unsigned long long mF = __ballot(pF), mS = __ballot(pS);
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            const unsigned add = (unsigned)__popcll(mF) + (unsigned)__popcll(mS);
+            if (top + add > sc.heavy_stack || __ballot(have && ref >= 0 && depth >= 56u) != 0ull) {
+                overflow = true;   // more open boxes than the stack holds (or deeper than the keys): lane 0 walks it alone
+                break;
+            }
+            const unsigned pos = top + (unsigned)__popcll(mF & lt) + (unsigned)__popcll(mS & lt);
+            const unsigned long long bit = 1ull << (62u - depth);
+            // the child visited FIRST must be popped... in any order: the keys decide, not the order of the stack
+            if (pF) {
+                q_ref[pos] = first;
+                q_key[pos] = key;
+                q_depth[pos] = (unsigned char)(depth + 1u);
+            }
+            if (pS) {
+                const unsigned p2 = pos + (pF ? 1u : 0u);
+                q_ref[p2] = second;
+                q_key[p2] = key | bit;
+                q_depth[p2] = (unsigned char)(depth + 1u);
+            }
+            top += add;
+            __syncthreads();
+        }
+        __syncthreads();
+        if (overflow) {
+            // the reference's loop as it stands (pspRT.cpp:380-423), one lane, its stack in q_ref
+            best.t = FLT_MAX;
+            best.key = ~0ull;
+            best.slot = -1;
+            any = false;
+            if (lane == 0) {
+                int sp = 0;
+                int cur = sc.root_ref;
+                for (;;) {
+                    if (cur >= 0) {
+                        const float4 *np = sc.nodes + 4 * (size_t)cur;
+                        const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+                        const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
+                        const unsigned meta = __float_as_uint(q3.z);
+                        const bool hL = box_hit(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
+                        const bool hR = box_hit(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w);
+                        const bool swap = !(meta & kMetaOrdered) && ((r.neg >> (meta & 3u)) & 1u);
+                        const int first = swap ? right : left, second = swap ? left : right;
+                        const bool hF = swap ? hR : hL, hS = swap ? hL : hR;
+                        if (hF) {
+                            cur = first;
+                            if (hS) q_ref[sp++] = second;
+                            continue;
+                        }
+                        if (hS) {
+                            cur = second;
+                            continue;
+                        }
+                    } else {
+                        const unsigned code = (unsigned)(~cur);
+                        const unsigned f0 = code >> kLeafBits, cnt = (code & (kMaxLeaf - 1)) + 1;
+                        for (unsigned i = 0; i < cnt; ++i) {
+                            const float4 *tp = sc.tris + 3 * (size_t)(f0 + i);
+                            const float4 a = tp[0], b = tp[1], c = tp[2];
+                            TriHit th;
+                            if (tri_test(r, a.x, a.y, a.z, b.x, b.y, b.z, c.x, c.y, c.z, th)) {
+                                any = true;
+                                if (th.t < best.t) {
+                                    best.t = th.t;
+                                    best.key = 0ull;
+                                    best.slot = (int)(f0 + i);
+                                }
+                            }
+                        }
+                    }
+                    if (sp == 0) break;
+                    cur = q_ref[--sp];
+                }
+            }
+        }
+        // wave-wide winner: smallest t, then smallest key
+        float bt = best.t;
+        for (int off = 32; off > 0; off >>= 1) bt = fminf(bt, __shfl_xor(bt, off));
+        unsigned long long bk = best.t == bt ? best.key : ~0ull;
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_xor(bk, off);
+            bk = o < bk ? o : bk;
+        }
+        const bool any_w = __ballot(any) != 0ull;
+        const unsigned long long win = __ballot(any && best.t == bt && best.key == bk);
+        const int wl = win ? __ffsll((long long)win) - 1 : 0;
+        const int best_slot = __shfl(best.slot, wl);
+        if (lane == 0) {
+            {
+                bool visible = false;
+                if (any_w && best_slot >= 0) {
+                    const int prim = __float_as_int(sc.tris[3 * (size_t)best_slot].w);
+                    visible = tri_has_node(tri_nodes, prim, (int)node);
+                }
+                if (PHASE == 0) {
+                    pix[node] = visible ? kPixVisible : (any_w ? kPixRetry : kPixNone);
+                    if (sc.witness && !visible && any_w) sc.witness[node] = best_slot;
+                } else if (visible) {
+                    atomicOr(&retry_mask[item / 6u], 1u << (item % 6u));
+                }
+            }
+        }
+        __syncthreads();
+    }
 }
 
 // Step 2b (elementwise): compact the nodes that need retries into a list.  One queue atomic per
@@ -1367,6 +1599,9 @@ Scene make_scene(const upsp_bvh *b, size_t items, int grid)
     //  in mesh order, so they keep the plain mapping)
     static const int xcd = env_int("UPSP_XCD_AWARE", 1) ? 1 : 0;
     sc.xcd = xcd;
+    sc.heavy_steps = 0;
+    sc.heavy_items = nullptr;
+    sc.heavy_stack = 0;
     sc.adj_off = sc.adj_slot = nullptr;
     sc.slot_path = nullptr;
     sc.path_ref = nullptr;
@@ -1453,7 +1688,7 @@ int launch_cast(const upsp_bvh *cb, const float *d_org, int org_stride, const fl
     const int entries = stack_entries(b);
     if (entries > 64) return fail(UPSP_ERR_DEPTH, "BVH deeper than 64 levels");
     const size_t lds = lds_bytes(b);
-    UPSP_HIP_CHECK(hipMemsetAsync(b->d_work, 0, 16 * sizeof(unsigned), st));
+    UPSP_HIP_CHECK(hipMemsetAsync(b->d_work, 0, kWorkWords * sizeof(unsigned), st));
     const int grid = grid_for(n, lds);
     const Scene sc = make_scene(b, n, grid);
     if (n >= 65536) prefetch_bvh(b, st);
@@ -1624,12 +1859,12 @@ int upsp_bvh_create(const float *h_tris9, size_t ntris, upsp_bvh **out)
     const size_t tb = hb.tris.size() * sizeof(GpuTri);
     hipError_t e = hipMalloc(&b->d_nodes, nb);
     if (e == hipSuccess) e = hipMalloc(&b->d_tris, tb);
-    if (e == hipSuccess) e = hipMalloc(&b->d_work, 16 * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc(&b->d_work, kWorkWords * sizeof(unsigned));
     if (e == hipSuccess && !hb.nodes.empty())
         e = hipMemcpy(b->d_nodes, hb.nodes.data(), hb.nodes.size() * sizeof(GpuNode),
                       hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(b->d_tris, hb.tris.data(), tb, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemset(b->d_work, 0, 16 * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemset(b->d_work, 0, kWorkWords * sizeof(unsigned));
     if (e != hipSuccess) {
         upsp_bvh_destroy(b);
         return fail(UPSP_ERR_HIP, std::string("BVH upload: ") + hipGetErrorString(e));
@@ -1709,6 +1944,7 @@ void upsp_bvh_destroy(upsp_bvh *b)
     if (b->d_witness) (void)hipFree(b->d_witness);
     if (b->d_todo_mask) (void)hipFree(b->d_todo_mask);
     if (b->d_todo_rays) (void)hipFree(b->d_todo_rays);
+    if (b->d_heavy) (void)hipFree(b->d_heavy);
     if (b->d_stage) (void)hipFree(b->d_stage);
     if (b->h_stage) (void)hipHostFree(b->h_stage);
     if (b->stage_stream) (void)hipStreamDestroy(b->stage_stream);
@@ -1901,13 +2137,36 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
         UPSP_HIP_CHECK(hipMalloc(&b->d_todo_rays, sizeof(unsigned) * 6 * nnodes));
         b->retry_capacity = nnodes;
     }
-    UPSP_HIP_CHECK(hipMemsetAsync(b->d_work, 0, 16 * sizeof(unsigned), st));
+    if (!b->d_heavy) UPSP_HIP_CHECK(hipMalloc(&b->d_heavy, sizeof(unsigned) * kHeavyCap));
+    UPSP_HIP_CHECK(hipMemsetAsync(b->d_work, 0, kWorkWords * sizeof(unsigned), st));
     const int grid = grid_for(nnodes, lds);
     Scene sc = make_scene(b, nnodes, grid);
     // step 3 runs over 6 x (listed nodes), a count only the device knows: full
     // persistent grid, chunk sized for the typical case (half of the nodes listed)
     const int grid1 = grid_for(6 * nnodes, lds);
     Scene sc1 = make_scene(b, 3 * nnodes, grid1);
+    // rays that need more than this many node visits + triangle tests leave the one-lane traversal (heavy_kernel);
+    // the keys of heavy_kernel hold 56 levels.  Measured on MI355X (1M-triangle models, 1024^2 camera), build time:
+    //   UV-sphere model (1000-triangle polar fans): off 2.89 ms, 320: 1.26, 256: 1.14, 160: 1.05, 128: 1.02, 96: 1.10, 64: 1.74
+    //   cube-sphere model (valence <= 6):           off 0.59 ms, 256: 0.59, 160: 0.59, 128: 0.63 (ONE ray), 96: 0.66, 64: 1.25
+    // a ray costs heavy_kernel 40-100 us however few steps it had left (one round per tree level, ~1.3 us each), so the
+    // threshold sits above the longest ordinary ray of the well-shaped model
+    // (read per build, not once: the tests move both to drive many rays through heavy_kernel and its fallback)
+    const int heavy_steps = env_int("UPSP_HEAVY_STEPS", 160);
+    const int heavy_stack = env_int("UPSP_HEAVY_STACK", (int)kHeavyStack);
+    const bool heavy_on = heavy_steps > 0 && b->info.depth <= 56 && b->d_heavy;
+    if (heavy_on) {
+        sc.heavy_steps = sc1.heavy_steps = (unsigned)heavy_steps;
+        sc.heavy_items = sc1.heavy_items = b->d_heavy;
+        sc.heavy_stack = sc1.heavy_stack = (unsigned)std::min<int>(std::max(heavy_stack, 128), (int)kHeavyStack);
+    }
+    static const int heavy_grid = env_int("UPSP_HEAVY_GRID", 512);
+#define UPSP_LAUNCH_HEAVY(PHASE, SC)                                                                             \
+    if (heavy_on) {                                                                                              \
+        KTimed kth("heavy_kernel", st);                                                                          \
+        hipLaunchKernelGGL((heavy_kernel<PHASE>), dim3(heavy_grid), dim3(64), 0, st, SC, c, d_nodes, d_tri_nodes, \
+                           d_pix, (const unsigned *)b->d_retry_nodes, b->d_retry_mask, (const unsigned *)b->d_work); \
+    }
     static const bool own_bound_on = std::getenv("UPSP_NO_OWN_BOUND") == nullptr;
     bool use_witness = false;
     if (own_bound_on && b->d_adj_off && b->adj_src == (const void *)d_tri_nodes && b->adj_nnodes == nnodes) {
@@ -1951,6 +2210,7 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
         KTimed kt("projection_kernel<primary>", st);
         if (b->stats_on) UPSP_LAUNCH_PROJ(true, 0, grid, sc); else UPSP_LAUNCH_PROJ(false, 0, grid, sc);
     }
+    UPSP_LAUNCH_HEAVY(0, sc)
     UPSP_HIP_CHECK(hipMemsetAsync(b->d_work, 0, sizeof(unsigned), st));  // queue head
     {
         KTimed kt("retry_list_kernel", st);
@@ -1973,12 +2233,15 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
             hipLaunchKernelGGL(todo_list_kernel, dim3((unsigned)((nnodes + 1023) / 1024)), dim3(256), 0, st,
                                (const unsigned *)b->d_todo_mask, b->d_todo_rays, b->d_work);
         }
-        KTimed kt("projection_kernel<retry>", st);
         Scene sc2 = sc1;
         static const int desc_cap2 = env_int("UPSP_DESC_CAP_RESIDUAL", 4);
         sc2.desc_cap = desc_cap2;
         sc2.chunk = 64;   // few rays are left (~3.5 %; 16 lanes per wave and 16-ray chunks: 0.37 instead of 0.21 ms)
-        if (b->stats_on) UPSP_LAUNCH_PROJ(true, 2, grid1, sc2); else UPSP_LAUNCH_PROJ(false, 2, grid1, sc2);
+        {
+            KTimed kt("projection_kernel<retry>", st);
+            if (b->stats_on) UPSP_LAUNCH_PROJ(true, 2, grid1, sc2); else UPSP_LAUNCH_PROJ(false, 2, grid1, sc2);
+        }
+        UPSP_LAUNCH_HEAVY(2, sc2)
         if (d_hist) {   // debug: (node visits + triangle tests) per residual ray, 16 per bin; witness verdicts per retry ray
             unsigned h[64];
             UPSP_HIP_CHECK(hipMemcpy(h, d_hist, sizeof(h), hipMemcpyDeviceToHost));
@@ -1990,10 +2253,14 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
                          h[48], h[49], h[50], h[51], h[52], h[53], h[54], h[55]);
         }
     } else {
-        KTimed kt("projection_kernel<retry>", st);
-        if (b->stats_on) UPSP_LAUNCH_PROJ(true, 1, grid1, sc1); else UPSP_LAUNCH_PROJ(false, 1, grid1, sc1);
+        {
+            KTimed kt("projection_kernel<retry>", st);
+            if (b->stats_on) UPSP_LAUNCH_PROJ(true, 1, grid1, sc1); else UPSP_LAUNCH_PROJ(false, 1, grid1, sc1);
+        }
+        UPSP_LAUNCH_HEAVY(1, sc1)
     }
 #undef UPSP_LAUNCH_PROJ
+#undef UPSP_LAUNCH_HEAVY
     {
         KTimed ktf("projection_finish_kernels", st);
         hipLaunchKernelGGL(projection_retry_outcome_kernel, dim3(256), dim3(256), 0, st, d_pix,
@@ -2030,8 +2297,10 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
         if (std::getenv("UPSP_DEBUG_COUNTS")) {
             unsigned w[16];
             UPSP_HIP_CHECK(hipMemcpy(w, b->d_work, sizeof(w), hipMemcpyDeviceToHost));
-            std::fprintf(stderr, "upsp work: retry_nodes %u  todo_rays %u  max_nodes/ray %u  max_tris/ray %u\n",
-                         w[kWorkRetryCount], w[kWorkTodoCount], w[8], w[9]);
+            unsigned hv[2] = {0, 0};
+            UPSP_HIP_CHECK(hipMemcpy(hv, b->d_work + kWorkHeavyCount, sizeof(hv), hipMemcpyDeviceToHost));
+            std::fprintf(stderr, "upsp work: retry_nodes %u  todo_rays %u  max_nodes/ray %u  max_tris/ray %u  heavy rays: primary %u, retries %u\n",
+                         w[kWorkRetryCount], w[kWorkTodoCount], w[8], w[9], hv[0], hv[1]);
         }
     }
     return UPSP_OK;

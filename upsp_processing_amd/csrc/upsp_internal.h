@@ -80,6 +80,7 @@ struct upsp_bvh {
     uint32_t *d_slot_path = nullptr, *d_path_ref = nullptr;
     int32_t *d_witness = nullptr;      // per node: triangle slot the primary ray hit (retry nodes)
     uint32_t *d_todo_mask = nullptr, *d_todo_rays = nullptr;   // retries the witness test left undecided
+    uint32_t *d_heavy = nullptr;                               // work items handed to heavy_kernel
     const void *adj_src = nullptr;     // the d_tri_nodes buffer the adjacency was built from
     size_t adj_nnodes = 0;
     size_t retry_capacity = 0;
