@@ -19,8 +19,10 @@ ranks (weak scaling: every GPU processes --frames frames).
 (torch.distributed.run, one per GPU, RCCL) before anything touches the GPU; under an external
 launcher (RANK / WORLD_SIZE set) it is one of the ranks.  Rank 0 prints ONE JSON line.
 `value` = frames/s over the whole job; `mrays_per_s` = reference-equivalent node rays/s of the
-projection build (rays the reference would cast / build time; most retry rays are decided here by
-the occluder witness instead of a traversal -- `rays_cast_per_step` counts what is really cast).
+projection build (rays the reference would cast / build time).  The build applies the oblique test before the
+rays (nodes it rejects have no entry whatever their rays say and cast none) and decides most retry rays by
+the occluder witness instead of a traversal -- `rays_cast_per_step` counts what is really cast, and
+`mrays_cast_per_s` is that count over the build time.
 """
 import argparse
 import json
@@ -376,7 +378,12 @@ def main():
         t_frames.append(e[1].elapsed_time(e[2]))
         t_xchg.append(e[2].elapsed_time(e[3]))
     pc = engine.projection_counts(bvh)
-    nrays, primary_rays, retry_nodes = pc["nrays"], pc["primary_rays"], pc["retry_nodes"]
+    primary_rays, retry_nodes = pc["primary_rays"], pc["retry_nodes"]
+    # the rays the REFERENCE casts for this camera: one build (not timed) that casts them all, in the reference's
+    # order (oblique test last); its entries must be the ones of the timed builds
+    pr_ref = engine.build_projection(bvh, cam, d_nodes, d_nrm, d_tn, 70.0, counts=True)
+    nrays = pr_ref["nrays"]
+    same_entries = bool(torch.equal(pr_ref["pix"], last_pix[0]))
     # the same K steps once more with the library's per-kernel HIP-event timers on
     # (two extra events per launch on the launch stream; kept out of the headline time)
     _capi.timing_enable(True)
@@ -486,6 +493,9 @@ def main():
                       if chunked else {})},
         "mrays_per_s": mrays, "mrays_per_s_kind": "reference-equivalent (rays the reference casts / build time)",
         "rays_per_step": nrays, "rays_cast_per_step": primary_rays + n_retry_rays,
+        "mrays_cast_per_s": (primary_rays + n_retry_rays) / (ray_ms * 1e-3) / 1e6,
+        "rays_note": "nodes the oblique test rejects cast no ray in the timed builds (they have no entry whatever "
+                     "their rays say); a build in the reference's order gives the same entries: %s" % same_entries,
         "breakdown_ms": {"projection_build": ray_ms, "frame_loop": frm_ms,
                          "exchange_finals": float(np.mean(t_xchg))},
         "frame_loop_frames_per_s": F / (frm_ms * 1e-3),
@@ -531,6 +541,7 @@ def main():
             checks = {
                 "projection_pix_full_model": bool(np.array_equal(gpix, ref["pix"])),
                 "reference_ray_count": bool(nrays == ref["nrays"]),
+                "oblique_test_first_same_entries": same_entries,
                 "series_rows_8_frames": bool(np.array_equal(rt[:, :8].cpu().numpy().T.view(np.int32), ref["rows8"].view(np.int32))),
                 "repaired_frames": bool(np.array_equal(d_sample.cpu().view(torch.int16).numpy().view(np.uint16), ref["frames_fixed"])),
                 "accumulators_%d_frames" % n_sample: bool(np.array_equal(np.isnan(gs), ~ok) and np.array_equal(gs[ok], ref["sum"][ok])

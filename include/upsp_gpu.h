@@ -135,7 +135,16 @@ typedef struct upsp_camera {
  *   d_nodecount = [H*W] u8 saturating nodes-per-pixel image (may be NULL)
  * d_datanode (may be NULL) = Model::is_datanode mask; d_tri_nodes = extract_tris()
  * triNodes [3*ntris] (cpp/lib/TriModel.ipp:261-299).
- * oblique_thresh = deg2rad(180 - oblique_angle) as float (psp_process.cpp:1602). */
+ * oblique_thresh = deg2rad(180 - oblique_angle) as float (psp_process.cpp:1602).
+ * h_nrays (may be NULL): the number of rays the reference casts for this camera (1 primary ray per in-frame node
+ * + its sequential retries); the call then waits for the device.
+ * Order of the tests: the reference applies the oblique test last (psp_process.cpp:298-306), to the nodes its rays
+ * have seen; it depends on the node normal and the primary direction only, and a node that fails it has no entry
+ * whatever the rays said.  With h_nrays == NULL the test is applied BEFORE any ray is cast and the nodes that fail
+ * cast none (identical d_pix / d_uv / d_nodecount; on a closed body two thirds of the in-frame nodes drop out,
+ * the back-facing ones that would go through all six retries first).  With h_nrays != NULL (or statistics
+ * enabled) the rays are cast as the reference casts them, because counting them means casting them.
+ * UPSP_OBLIQUE_CULL=0 in the environment keeps the reference's order in every call. */
 int upsp_projection_build(upsp_bvh *bvh, const upsp_camera *cam, const float *d_nodes,
                           const float *d_normals, const uint8_t *d_datanode,
                           const int32_t *d_tri_nodes, size_t nnodes, float oblique_thresh,
@@ -151,7 +160,8 @@ int upsp_projection_last_counts(const upsp_bvh *bvh, uint64_t *primary_rays,
 
 /* upsp_projection_build with h_nrays == NULL does not wait for the device.  The counters of the
  * most recent build stay in the BVH's work buffer; this call waits for `stream` and reads them
- * (reference ray count, primary rays, nodes that went through the retries). */
+ * (ray count, primary rays, nodes that went through the retries -- of the nodes that passed the oblique test,
+ * see upsp_projection_build: NOT the reference's count). */
 int upsp_projection_fetch_counts(upsp_bvh *bvh, uint64_t *nrays, uint64_t *primary_rays,
                                  uint64_t *retry_nodes, void *stream);
 

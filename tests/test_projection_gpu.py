@@ -55,6 +55,16 @@ def test_projection_matches_oracle(gpu_lib, oracle, case):
     st_classic = bvh.last_stats()
     assert np.array_equal(g3["pix"].cpu().numpy(), o["pix"])
     assert st_bounded["nodes"] <= st_classic["nodes"]                         # the bound only ever prunes
+    # counts=False (what the frame loops use): the oblique test runs before the rays and the nodes it rejects cast
+    # none -- same entries, uv and node-count image; fewer rays than the reference casts
+    bvh.enable_stats(False)
+    for tnn in (d_tn, tn):
+        g4 = engine.build_projection(bvh, cam_g, v, nrm, tnn, 70.0, datanode=dn, nodecount=True, counts=False)
+        assert np.array_equal(g4["pix"].cpu().numpy(), o["pix"])
+        assert np.array_equal(g4["uv"].cpu().numpy().view(np.int32), o["uv"].view(np.int32))
+        assert np.array_equal(g4["nodecount"].cpu().numpy(), o["nodecount"])
+        pc = engine.projection_counts(bvh)
+        assert (pix >= 0).sum() <= pc["primary_rays"] < g["primary_rays"] and pc["nrays"] < o["nrays"]
 
 
 @pytest.mark.parametrize("steps,stack", [(8, 4096), (8, 128), (40, 4096), (1, 130)])
@@ -80,6 +90,8 @@ def test_heavy_ray_handoff(gpu_lib, oracle, monkeypatch, steps, stack):
         assert np.array_equal(g["pix"].cpu().numpy(), o["pix"])
         assert np.array_equal(g["uv"].cpu().numpy().view(np.int32), o["uv"].view(np.int32))
         assert g["nrays"] == o["nrays"]
+        g = engine.build_projection(bvh, cam_g, v, nrm, d_tn if adjacency else tn, 70.0, counts=False)
+        assert np.array_equal(g["pix"].cpu().numpy(), o["pix"])
     # a pole of the UV sphere seen head-on: the ray to the pole vertex meets every triangle of its fan
     mesh = syn.uv_sphere(60, 900)
     from upsp_processing_amd import _capi

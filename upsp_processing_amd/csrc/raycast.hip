@@ -331,6 +331,7 @@ struct Scene {
     unsigned heavy_steps; // a ray that needs more node visits + triangle tests than this is handed to heavy_kernel (0 = never)
     unsigned *heavy_items;   // list of the work items handed over (kHeavyCap entries), count in work[kWorkHeavyCount]
     unsigned heavy_stack;    // entries of heavy_kernel's stack that may be used (<= kHeavyStack; tests shrink it)
+    unsigned pack;           // primary rays per wave when the resident waves can take the whole list at once (0: queue)
     unsigned chunk;       // work items per queue grab (multiple of 64)
     float rlo[3], rhi[3];
     const unsigned *adj_off, *adj_slot;   // node -> adjacent triangle slots (may be null)
@@ -779,14 +780,37 @@ constexpr int32_t kPixRetry = -4;     // primary ray hit a foreign triangle: ret
 constexpr int kWorkRetryCount = 10;
 constexpr int kWorkTodoCount = 12;   // rays witness_kernel could not decide
 constexpr int kWorkHeavyCount = 16;  // work items handed to heavy_kernel: [16] by the primary pass, [17] by the retry pass
+constexpr int kWorkPrimaryCount = 18; // nodes that cast a primary ray (retry_list_kernel<kPixInFrame>)
 constexpr int kWorkWords = 32;
 constexpr unsigned kHeavyCap = 65536;
 
 // Step 1 (elementwise, fp64): cal.map_point_to_image + in-frame test
 // (psp_process.cpp:241-252).  The image point is parked in uv[].
+// The oblique test of psp_process.cpp:298-306: angle between the node's normal and the PRIMARY ray direction
+// (normalised camera -> node vector, Imath arithmetic), acos in double, compared as float.
+__device__ __forceinline__ bool oblique_forward(const Cam &cam, const float *__restrict__ nodes,
+                                                const float *__restrict__ normals, unsigned n, float oblique_thresh)
+{
+    float dx = nodes[3 * (size_t)n] - cam.ox, dy = nodes[3 * (size_t)n + 1] - cam.oy,
+          dz = nodes[3 * (size_t)n + 2] - cam.oz;
+    const float len = imath_length(dx, dy, dz);
+    if (len != 0.0f) { dx /= len; dy /= len; dz /= len; }
+    const float *nn = normals + 3 * (size_t)n;
+    const float cos_theta = nn[0] * dx + nn[1] * dy + nn[2] * dz;
+    const float theta = (float)acos((double)cos_theta);
+    return theta > oblique_thresh;
+}
+
+// cull: the reference casts the rays of a node first and applies the oblique test to the nodes they see
+// (psp_process.cpp:254-306); the test itself uses nothing the rays produce (node normal, primary direction), and a
+// node that fails it gets no entry whatever the rays said.  With `cull` it is therefore applied HERE and the nodes
+// that fail never cast a ray: same matrix entries, uv and node-count image -- on a closed body two thirds of the
+// in-frame nodes (every back-facing one, which are also the ones that go through the six retries) drop out.
+// Without it the rays are cast as the reference casts them (needed for its ray count, upsp_projection_build h_nrays).
 __global__ void __launch_bounds__(256)
     project_nodes_kernel(Cam cam, const float *__restrict__ nodes,
                          const uint8_t *__restrict__ datanode, unsigned nnodes,
+                         const float *__restrict__ normals, float oblique_thresh, int cull,
                          int32_t *__restrict__ pix, float *__restrict__ uv)
 {
     const unsigned n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -802,6 +826,8 @@ __global__ void __launch_bounds__(256)
         const int rx = finite_int ? (int)rintf(u) : -1, ry = finite_int ? (int)rintf(v) : -1;
         if ((rx >= 0) & (ry >= 0) & (rx < cam.W) & (ry < cam.H))
             state = kPixInFrame;
+        if (cull && state == kPixInFrame && !oblique_forward(cam, nodes, normals, n, oblique_thresh))
+            state = kPixNone;
     }
     pix[n] = state;
     uv[2 * (size_t)n] = state == kPixInFrame ? u : 0.f;      // default uv = (0,0) (:179-182)
@@ -1114,9 +1140,34 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 
 {
     extern __shared__ int lds_stack[];
     int *stack = lds_stack + threadIdx.x;
-    const unsigned total = PHASE == 0 ? nnodes : PHASE == 1 ? work[kWorkRetryCount] * 6u : work[kWorkTodoCount];
+    const unsigned total = PHASE == 0 ? work[kWorkPrimaryCount] : PHASE == 1 ? work[kWorkRetryCount] * 6u : work[kWorkTodoCount];
+    // PHASE 0 works off the dense list of nodes that cast a ray (retry_list_kernel<kPixInFrame>; `todo_rays` holds it
+    // during this pass).  When the resident waves can take the whole list at once the assignment is static and nobody
+    // touches the shared counter: after the early oblique test a camera has ~200 k rays for ~6000 resident waves, and
+    // draining a sparse item range through the queue (thousands of same-address atomics, chunks without a single ray)
+    // cost more than the traversals -- the pass took 160 us with 1400 rays and 250 us with 193 k.
     WaveQueue q;
-    queue_init(q, work, total, sc.chunk, sc.xcd != 0 && PHASE == 0);   // (retry lists are not in mesh order)
+    bool packed = false;
+    if (PHASE == 0 && sc.pack) {
+        // `pack` rays per wave; the waves that get any are spread evenly over the XCDs (workgroup b runs on XCD b & 7),
+        // one contiguous eighth of the (mesh-ordered) list per XCD
+        const unsigned wpb = blockDim.x >> 6;
+        const unsigned nchunks = (total + sc.pack - 1u) / sc.pack;
+        const unsigned per_xcd = ((nchunks + wpb - 1u) / wpb + 7u) >> 3;
+        if (per_xcd * 8u <= gridDim.x) {
+            packed = true;
+            const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+            const unsigned long long first = ((unsigned long long)(xcd * per_xcd + slot) * wpb + (threadIdx.x >> 6)) * sc.pack;
+            q.head = work;
+            q.total = total;
+            q.chunk = sc.pack;
+            q.base = 0;
+            q.cur = (slot < per_xcd && first < total) ? (unsigned)first : total;
+            q.end = min(q.cur + sc.pack, total);
+            q.exhausted = true;
+        }
+    }
+    if (!packed) queue_init(q, work, total, sc.chunk, sc.xcd != 0 && PHASE == 0);   // (retry lists are not in mesh order)
     Ray r;
     r.simple = true;   // idle lanes must not veto the wave-uniform fast path
     Trav s;
@@ -1132,7 +1183,8 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 
             unsigned it;
             const bool got = queue_take(q, !busy, it);
             if (got && PHASE == 0) {
-                if (pix[it] == kPixInFrame) {
+                it = todo_rays[it];
+                {
                     float dx = nodes[3 * (size_t)it] - cam.ox, dy = nodes[3 * (size_t)it + 1] - cam.oy,
                           dz = nodes[3 * (size_t)it + 2] - cam.oz;
                     const float len = imath_length(dx, dy, dz);  // .normalize() :256
@@ -1427,6 +1479,9 @@ __global__ void __launch_bounds__(64)
 // workgroup of kRetryListItems x 256 nodes: atomics on one address retire at ~88 per us on this
 // part, so one per 256 nodes (1957 of them) made this a 24-us kernel.
 constexpr int kRetryListItems = 8;
+// (STATE = kPixRetry: the retry list + its cleared bit masks, count in work[kWorkRetryCount];
+//  STATE = kPixInFrame: the nodes that cast a primary ray, count in work[kWorkPrimaryCount], no masks)
+template <int32_t STATE>
 __global__ void __launch_bounds__(256)
     retry_list_kernel(const int32_t *__restrict__ pix, unsigned nnodes,
                       unsigned *__restrict__ retry_nodes, unsigned *__restrict__ retry_mask,
@@ -1440,7 +1495,7 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int k = 0; k < kRetryListItems; ++k) {
         const unsigned n = base + 256u * k;
-        need[k] = n < nnodes && pix[n] == kPixRetry;
+        need[k] = n < nnodes && pix[n] == STATE;
         m[k] = __ballot(need[k]);
         if (lane == 0) wave_cnt[k][wave] = (unsigned)__popcll(m[k]);
     }
@@ -1453,7 +1508,7 @@ __global__ void __launch_bounds__(256)
                 wave_cnt[k][w] = tot;
                 tot += c;
             }
-        block_base = tot ? atomicAdd(&work[kWorkRetryCount], tot) : 0u;
+        block_base = tot ? atomicAdd(&work[STATE == kPixRetry ? kWorkRetryCount : kWorkPrimaryCount], tot) : 0u;
     }
     __syncthreads();
 #pragma unroll
@@ -1461,7 +1516,7 @@ __global__ void __launch_bounds__(256)
         if (need[k]) {
             const unsigned slot = block_base + wave_cnt[k][wave] + (unsigned)__popcll(m[k] & ((1ull << lane) - 1ull));
             retry_nodes[slot] = base + 256u * k;
-            retry_mask[slot] = 0u;
+            if (STATE == kPixRetry) retry_mask[slot] = 0u;
         }
 }
 
@@ -1498,14 +1553,7 @@ __global__ void __launch_bounds__(256)
     float ou = 0.f, ov = 0.f;
     if (state == kPixVisible) {
         const float u = uv[2 * (size_t)n], v = uv[2 * (size_t)n + 1];
-        float dx = nodes[3 * (size_t)n] - cam.ox, dy = nodes[3 * (size_t)n + 1] - cam.oy,
-              dz = nodes[3 * (size_t)n + 2] - cam.oz;
-        const float len = imath_length(dx, dy, dz);
-        if (len != 0.0f) { dx /= len; dy /= len; dz /= len; }
-        const float *nn = normals + 3 * (size_t)n;
-        const float cos_theta = nn[0] * dx + nn[1] * dy + nn[2] * dz;
-        const float theta = (float)acos((double)cos_theta);
-        if (theta > oblique_thresh) {
+        if (oblique_forward(cam, nodes, normals, n, oblique_thresh)) {
             const int px_ = (int)roundf(u), py_ = (int)roundf(v);  // :319 std::round
             const long long idx = (long long)py_ * cam.W + px_;
             if (idx >= 0 && idx < (long long)cam.W * cam.H) {
@@ -1599,6 +1647,7 @@ Scene make_scene(const upsp_bvh *b, size_t items, int grid)
     //  in mesh order, so they keep the plain mapping)
     static const int xcd = env_int("UPSP_XCD_AWARE", 1) ? 1 : 0;
     sc.xcd = xcd;
+    sc.pack = 0;
     sc.heavy_steps = 0;
     sc.heavy_items = nullptr;
     sc.heavy_stack = 0;
@@ -2160,6 +2209,8 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
         sc.heavy_items = sc1.heavy_items = b->d_heavy;
         sc.heavy_stack = sc1.heavy_stack = (unsigned)std::min<int>(std::max(heavy_stack, 128), (int)kHeavyStack);
     }
+    static const int pack = env_int("UPSP_PRIMARY_PACK", 64);
+    sc.pack = (unsigned)std::min(std::max(pack, 0), 64);
     static const int heavy_grid = env_int("UPSP_HEAVY_GRID", 512);
 #define UPSP_LAUNCH_HEAVY(PHASE, SC)                                                                             \
     if (heavy_on) {                                                                                              \
@@ -2199,8 +2250,17 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
     if (prefetch_on && nnodes >= 65536) prefetch_bvh(b, st);
     {
         KTimed kt("project_nodes_kernel", st);
+        // (UPSP_OBLIQUE_CULL=0: always cast the reference's rays; 2: never, even when they are counted -- for profiling)
+        static const int cull_env = env_int("UPSP_OBLIQUE_CULL", 1);
+        const int cull = (cull_env == 2 || (cull_env == 1 && !h_nrays && !b->stats_on)) ? 1 : 0;
         hipLaunchKernelGGL(project_nodes_kernel, egrid, eblock, 0, st, c, d_nodes, d_datanode,
-                           (unsigned)nnodes, d_pix, d_uv);
+                           (unsigned)nnodes, d_normals, oblique_thresh, cull, d_pix, d_uv);
+    }
+    {
+        KTimed kt("primary_list_kernel", st);
+        const dim3 lgrid((unsigned)((nnodes + 256 * kRetryListItems - 1) / (256 * kRetryListItems)));
+        hipLaunchKernelGGL(retry_list_kernel<kPixInFrame>, lgrid, eblock, 0, st, (const int32_t *)d_pix,
+                           (unsigned)nnodes, b->d_todo_rays, (unsigned *)nullptr, b->d_work);
     }
 #define UPSP_LAUNCH_PROJ(STATS, PHASE, G, SC)                                                    \
     hipLaunchKernelGGL((projection_kernel<STATS, PHASE>), dim3(G), dim3(kBlock), lds, st, SC, c, \
@@ -2215,7 +2275,7 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
     {
         KTimed kt("retry_list_kernel", st);
         const dim3 lgrid((unsigned)((nnodes + 256 * kRetryListItems - 1) / (256 * kRetryListItems)));
-        hipLaunchKernelGGL(retry_list_kernel, lgrid, eblock, 0, st, (const int32_t *)d_pix,
+        hipLaunchKernelGGL(retry_list_kernel<kPixRetry>, lgrid, eblock, 0, st, (const int32_t *)d_pix,
                            (unsigned)nnodes, b->d_retry_nodes, b->d_retry_mask, b->d_work);
     }
     unsigned *d_hist = nullptr;

@@ -141,7 +141,8 @@ def project_points(cam, xyz):
 
 def projection_counts(bvh):
     """Counters of the most recent build_projection on this BVH (waits for the stream):
-    dict(nrays = the reference's ray count, primary_rays, retry_nodes)."""
+    dict(nrays = rays by the reference's sequential count, primary_rays, retry_nodes) -- of the nodes that
+    were not dropped by the early oblique test when the build ran with counts=False."""
     a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
     check(lib().upsp_projection_fetch_counts(bvh.handle, C.byref(a), C.byref(b), C.byref(c), _stream()))
     return dict(nrays=int(a.value), primary_rays=int(b.value), retry_nodes=int(c.value))
@@ -152,8 +153,11 @@ def build_projection(bvh, cam, nodes, normals, tri_nodes, oblique_angle=70.0, da
     """create_projection_mat (psp_process.cpp:167-355) for one camera.
 
     Returns dict(pix int32[N] (-1 = no entry), uv f32[2N], nrays, nodecount u8[H,W] | None).
-    counts=False: no host synchronisation (the ray counters stay on the device; see
-    projection_counts)."""
+    counts=True: nrays = the number of rays the reference casts; they are all cast (the call waits for the device).
+    counts=False: no host synchronisation, and the oblique test runs BEFORE the rays: nodes it rejects (no entry
+    whatever their rays say) cast none -- same pix / uv / nodecount, about a third of the rays on a closed body
+    (include/upsp_gpu.h, upsp_projection_build).  The counters of that build stay on the device
+    (projection_counts)."""
     nodes = _dev(nodes, torch.float32).reshape(-1, 3)
     normals = _dev(normals, torch.float32).reshape(-1, 3)
     tri_nodes = _dev(tri_nodes, torch.int32).reshape(-1)

@@ -27,7 +27,7 @@ class Phase1:
                  overlap="average_view", datanode=None, registration=False, interp=1,
                  filter=None, filter_size=1, patches=None, nframes_total=None, targets=None,
                  first_frames=None, bit_depth=12, bound_pts=2, buffer_pts=1, target_diam_sf=1.2,
-                 overlap_src=None):
+                 overlap_src=None, count_rays=False):
         """cameras: list of dict(K, dist, R, t); image_size = (width, height).
 
         patches: per camera list of dict(bx, by, ix, iy) (PatchClusters tables), or give
@@ -49,12 +49,15 @@ class Phase1:
         self.nrays = 0
         pix, self.uv, self.nodecount = [], [], []
         for cam in self.cams:                                          # :1597-1622
+            # (count_rays: also report the number of rays the reference would cast -- which means casting them all;
+            #  otherwise nodes the oblique test rejects cast none, engine.build_projection)
             p = engine.build_projection(self.bvh, cam, self.d_nodes, self.d_normals,
-                                        self.d_tri_nodes, oblique_angle, datanode=datanode, nodecount=True)
+                                        self.d_tri_nodes, oblique_angle, datanode=datanode, nodecount=True,
+                                        counts=count_rays)
             pix.append(p["pix"])
             self.uv.append(p["uv"])
             self.nodecount.append(p["nodecount"])      # u8 [H, W], saturating (psp_process.cpp:335-347)
-            self.nrays += p["nrays"]
+            self.nrays += p["nrays"] if count_rays else engine.projection_counts(self.bvh)["nrays"]
         self.pix = torch.stack(pix)
         # :1632-1640 ; a single camera needs no weights
         self.weight = (engine.projection_weights(self.pix, self.d_nodes, self.d_normals,
