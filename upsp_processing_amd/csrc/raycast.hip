@@ -331,7 +331,7 @@ struct Scene {
     unsigned heavy_steps; // a ray that needs more node visits + triangle tests than this is handed to heavy_kernel (0 = never)
     unsigned *heavy_items;   // list of the work items handed over (kHeavyCap entries), count in work[kWorkHeavyCount]
     unsigned heavy_stack;    // entries of heavy_kernel's stack that may be used (<= kHeavyStack; tests shrink it)
-    unsigned pack;           // primary rays per wave when the resident waves can take the whole list at once (0: queue)
+    unsigned pack_waves;     // projection passes: waves a ray list is spread over when the grid can take it at once (0: queue)
     unsigned chunk;       // work items per queue grab (multiple of 64)
     float rlo[3], rhi[3];
     const unsigned *adj_off, *adj_slot;   // node -> adjacent triangle slots (may be null)
@@ -1146,24 +1146,29 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 
     // touches the shared counter: after the early oblique test a camera has ~200 k rays for ~6000 resident waves, and
     // draining a sparse item range through the queue (thousands of same-address atomics, chunks without a single ray)
     // cost more than the traversals -- the pass took 160 us with 1400 rays and 250 us with 193 k.
+    // Rays per wave: the list spread over `pack_waves` waves (3 per SIMD: enough to overlap the node fetches of one
+    // wave with the box tests of another; measured with 193 k primary rays: 64 per wave 149 us, 48: 156, 32: 180,
+    // 16: 194), at least 1 (a few thousand residual retries run one or two to a wave, each for as long as its own
+    // chain of steps and no longer), at most 64.
     WaveQueue q;
     bool packed = false;
-    if (PHASE == 0 && sc.pack) {
-        // `pack` rays per wave; the waves that get any are spread evenly over the XCDs (workgroup b runs on XCD b & 7),
-        // one contiguous eighth of the (mesh-ordered) list per XCD
+    if (sc.pack_waves) {
+        const unsigned pack = min(max((total + sc.pack_waves - 1u) / sc.pack_waves, 1u), 64u);
+        // the waves that get any are spread evenly over the XCDs (workgroup b runs on XCD b & 7), one contiguous
+        // eighth of the list per XCD (the primary list is in mesh order)
         const unsigned wpb = blockDim.x >> 6;
-        const unsigned nchunks = (total + sc.pack - 1u) / sc.pack;
+        const unsigned nchunks = (total + pack - 1u) / pack;
         const unsigned per_xcd = ((nchunks + wpb - 1u) / wpb + 7u) >> 3;
         if (per_xcd * 8u <= gridDim.x) {
             packed = true;
             const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-            const unsigned long long first = ((unsigned long long)(xcd * per_xcd + slot) * wpb + (threadIdx.x >> 6)) * sc.pack;
+            const unsigned long long first = ((unsigned long long)(xcd * per_xcd + slot) * wpb + (threadIdx.x >> 6)) * pack;
             q.head = work;
             q.total = total;
-            q.chunk = sc.pack;
+            q.chunk = pack;
             q.base = 0;
             q.cur = (slot < per_xcd && first < total) ? (unsigned)first : total;
-            q.end = min(q.cur + sc.pack, total);
+            q.end = min(q.cur + pack, total);
             q.exhausted = true;
         }
     }
@@ -1647,7 +1652,7 @@ Scene make_scene(const upsp_bvh *b, size_t items, int grid)
     //  in mesh order, so they keep the plain mapping)
     static const int xcd = env_int("UPSP_XCD_AWARE", 1) ? 1 : 0;
     sc.xcd = xcd;
-    sc.pack = 0;
+    sc.pack_waves = 0;
     sc.heavy_steps = 0;
     sc.heavy_items = nullptr;
     sc.heavy_stack = 0;
@@ -2209,8 +2214,8 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
         sc.heavy_items = sc1.heavy_items = b->d_heavy;
         sc.heavy_stack = sc1.heavy_stack = (unsigned)std::min<int>(std::max(heavy_stack, 128), (int)kHeavyStack);
     }
-    static const int pack = env_int("UPSP_PRIMARY_PACK", 64);
-    sc.pack = (unsigned)std::min(std::max(pack, 0), 64);
+    static const int waves_per_simd = env_int("UPSP_WAVES_PER_SIMD", 3);
+    sc.pack_waves = sc1.pack_waves = (unsigned)std::max(waves_per_simd, 0) * 4u * (unsigned)(props().cus > 0 ? props().cus : 256);
     static const int heavy_grid = env_int("UPSP_HEAVY_GRID", 512);
 #define UPSP_LAUNCH_HEAVY(PHASE, SC)                                                                             \
     if (heavy_on) {                                                                                              \
