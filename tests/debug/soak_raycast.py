@@ -80,6 +80,12 @@ while time.time() < t_end:
                 print("  projection mismatch (adjacency %s): %d nodes differ, first %s gpu %s oracle %s; nrays %d vs %d"
                       % (adj, bad.size, bad[:5], gp[bad[:5]], want["pix"][bad[:5]], g["nrays"], want["nrays"]), flush=True)
             ok = ok and okp
+            # the order the frame loops use: oblique test first, no rays for the nodes it rejects
+            g = engine.build_projection(bvh, cg, v, nrm, d_tn, 70.0, counts=False)
+            okc = np.array_equal(g["pix"].cpu().numpy(), want["pix"]) and same(g["uv"], want["uv"])
+            if not okc:
+                print("  projection mismatch with the oblique test first (adjacency %s)" % adj, flush=True)
+            ok = ok and okc
     nscenes += 1
     print("seed %d kind %d tris %d: %s" % (seed, kind, s9.size // 9, "ok" if ok else "MISMATCH"), flush=True)
     bvh.close()
