@@ -25,6 +25,9 @@ struct upsp_pipeline {
     int32_t *d_pix[kMaxCams] = {nullptr};
     float *d_weight[kMaxCams] = {nullptr};
     bool has_proj[kMaxCams] = {false};
+    unsigned *d_read_list[kMaxCams] = {nullptr};  // count + pixels with a node (registration as the last image stage)
+    uint8_t *d_read_mask = nullptr;               // scratch of the list build
+    bool read_list_valid[kMaxCams] = {false};
     uint8_t *d_skipped = nullptr;
     int32_t *d_src = nullptr;        // overlap source map (P3D adjust_solution), optional
     int32_t *d_rowmap = nullptr;     // packed time-series rows (node -> row, < 0 = not stored), optional
@@ -178,6 +181,7 @@ void upsp_pipeline_destroy(upsp_pipeline *p)
     for (int c = 0; c < kMaxCams; ++c) {
         free_dev(p->d_pix[c]);
         free_dev(p->d_weight[c]);
+        free_dev(p->d_read_list[c]);
         free_dev(p->d_ref[c]);
         upsp::patch_tables_free(p->patches[c]);
     }
@@ -185,6 +189,7 @@ void upsp_pipeline_destroy(upsp_pipeline *p)
     if (p->aux) (void)hipStreamDestroy(p->aux);
     for (hipEvent_t e : {p->ev_in, p->ev_fix[0], p->ev_fix[1], p->ev_out})
         if (e) (void)hipEventDestroy(e);
+    free_dev(p->d_read_mask);
     free_dev(p->d_skipped);
     free_dev(p->d_src);
     free_dev(p->d_rowmap);
@@ -228,6 +233,7 @@ int upsp_pipeline_set_projection(upsp_pipeline *p, int cam, const int32_t *d_pix
         p->d_weight[cam] = nullptr;
     }
     p->has_proj[cam] = true;
+    p->read_list_valid[cam] = false;
     p->m_valid[cam] = false;
     if (!p->hint_active) p->tilemap_valid = false;
     p->node_k_valid = false;
@@ -254,6 +260,7 @@ int upsp_pipeline_set_projection_async(upsp_pipeline *p, int cam, const int32_t 
         p->d_weight[cam] = nullptr;
     }
     p->has_proj[cam] = true;
+    p->read_list_valid[cam] = false;
     p->m_valid[cam] = false;
     if (!p->hint_active) p->tilemap_valid = false;
     p->node_k_valid = false;
@@ -794,11 +801,22 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
             const void *img = frames;
             int is_f32 = 0;
             if (need_stage) {
+                const unsigned *read_list = nullptr;
+                if (p->opts.registration && !p->opts.patch && !p->opts.filter && npix < 0xFFFFFFFFull) {
+                    if (!p->d_read_list[c]) UPSP_HIP_CHECK(hipMalloc(&p->d_read_list[c], sizeof(unsigned) * (npix + 1)));
+                    if (!p->d_read_mask) UPSP_HIP_CHECK(hipMalloc(&p->d_read_mask, npix));
+                    if (!p->read_list_valid[c]) {
+                        rc = upsp::launch_pixel_list(p->d_pix[c], p->nnodes, p->d_read_mask, p->d_read_list[c], npix, st);
+                        if (rc != UPSP_OK) break;
+                        p->read_list_valid[c] = true;
+                    }
+                    read_list = p->d_read_list[c];
+                }
                 rc = upsp::run_frame_stages(p->scratch, c, frames, nb, first_frame + f0,
                                             p->height, p->width, p->opts, p->d_ref[c],
                                             p->patches[c],
                                             d_warps ? d_warps + ((size_t)f0 * p->ncams) * 6 : nullptr,
-                                            p->ncams, &img, &is_f32, st);
+                                            p->ncams, read_list, &img, &is_f32, st);
                 if (rc != UPSP_OK) break;
             }
             g.img[c] = img;
