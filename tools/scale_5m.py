@@ -18,7 +18,14 @@ for az in (0, 90, 180, 270):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         p = engine.build_projection(bvh, cam, dn, dm, dt, 70.0)
         torch.cuda.synchronize(); dt_ = time.perf_counter() - t0
-    print("cam az=%d: %.2f ms, %d rays (%.0f Mrays/s), visible %d" % (az, dt_ * 1e3, p["nrays"], p["nrays"] / dt_ / 1e6, int((p["pix"] >= 0).sum())))
+    for r in range(2):     # the order the frame loops use: oblique test first, no rays for the nodes it rejects
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        p2 = engine.build_projection(bvh, cam, dn, dm, dt, 70.0, counts=False)
+        torch.cuda.synchronize(); dt2 = time.perf_counter() - t0
+    pc = engine.projection_counts(bvh)
+    print("cam az=%d: reference order %.2f ms, %d rays (%.0f Mrays/s); oblique test first %.2f ms, %d primary rays + %d retry nodes, "
+          "same entries %s; visible %d" % (az, dt_ * 1e3, p["nrays"], p["nrays"] / dt_ / 1e6, dt2 * 1e3, pc["primary_rays"],
+                                          pc["retry_nodes"], bool(torch.equal(p["pix"], p2["pix"])), int((p["pix"] >= 0).sum())))
     pix.append(p["pix"])
 pix = torch.stack(pix)
 centers = np.array([engine.camera_center(_capi.make_camera(*(lambda c: (c["K"], c["dist"], c["R"], c["t"]))(syn.pinhole_camera(size, size, center=(0, 0, 20), half_extent=6.0, azimuth_deg=az)), size, size)) for az in (0, 90, 180, 270)])
