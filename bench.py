@@ -22,7 +22,8 @@ launcher (RANK / WORLD_SIZE set) it is one of the ranks.  Rank 0 prints ONE JSON
 projection build (rays the reference would cast / build time).  The build applies the oblique test before the
 rays (nodes it rejects have no entry whatever their rays say and cast none) and decides most retry rays by
 the occluder witness instead of a traversal -- `rays_cast_per_step` counts what is really cast, and
-`mrays_cast_per_s` is that count over the build time.
+`mrays_cast_per_s` is that count over the build time.  `pixel_rays` is the plain ray caster: closest hit of one ray per
+pixel of the frame (1 Mpix onto the 1 M-triangle model), every ray traversed, a sample checked against the oracle.
 """
 import argparse
 import json
@@ -110,6 +111,52 @@ def usable_cpus():
     return n
 
 
+def pixel_rays(cam_dict, size):
+    """One ray per pixel of the size x size frame: camera centre -> through the pixel (pinhole part of the
+    calibration; the bench camera has no distortion).  Returns (origin f32[3], dirs f32[size*size, 3])."""
+    K, R, t = [np.asarray(cam_dict[k], np.float64) for k in ("K", "R", "t")]
+    c = -R.T @ t
+    v, u = np.meshgrid(np.arange(size, dtype=np.float64), np.arange(size, dtype=np.float64), indexing="ij")
+    pc = np.stack([(u - K[0, 2]) / K[0, 0], (v - K[1, 2]) / K[1, 1], np.ones_like(u)], -1).reshape(-1, 3)
+    d = pc @ R                                  # R^T applied to every row
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return c.astype(np.float32), d.astype(np.float32)
+
+
+def pixel_ray_rate(bvh, cam_dict, size, check_with=None):
+    """The other half of BASELINE's metric taken literally: closest hit of ONE RAY PER PIXEL of the 1 Mpix frame
+    against the 1 M-triangle model through upsp_bvh_intersect (rt::BVH::intersect semantics: t, primID) -- every ray
+    is traversed, nothing is culled or witnessed.  check_with: oracle BVH -> a strided sample is compared bit for bit."""
+    import torch
+    org, dirs = pixel_rays(cam_dict, size)
+    d_org, d_dirs = torch.as_tensor(org).cuda(), torch.as_tensor(dirs).cuda()
+    for _ in range(2):
+        h = bvh.intersect(d_org, d_dirs, want=("hit", "t", "prim"))
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 5
+    e0.record()
+    for _ in range(reps):
+        h = bvh.intersect(d_org, d_dirs, want=("hit", "t", "prim"))
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    out = {"rays": int(dirs.shape[0]), "ms": ms, "mrays_per_s": dirs.shape[0] / (ms * 1e-3) / 1e6,
+           "hit_fraction": float(h["hit"].float().mean().item()),
+           "what": "closest hit (t, primID) of one ray per pixel of the %d x %d frame, upsp_bvh_intersect; all rays traversed" % (size, size)}
+    if check_with is not None:
+        idx = np.arange(0, dirs.shape[0], 37)
+        t0 = time.perf_counter()
+        o = check_with.intersect(org, dirs[idx], threads=usable_cpus())
+        dt = time.perf_counter() - t0
+        g_hit, g_t, g_prim = [h[k].cpu().numpy()[idx] for k in ("hit", "t", "prim")]
+        out["parity_sample"] = int(idx.size)
+        out["parity"] = bool(np.array_equal(g_hit, o["hit"]) and np.array_equal(g_prim, o["prim"])
+                             and np.array_equal(g_t.view(np.int32), o["t"].view(np.int32)))
+        out["cpu_mrays_per_s"] = idx.size / dt / 1e6
+    return out
+
+
 def cpu_baseline(verts, tris, cam_dict, size, nframes_step, sample, registration=False):
     """Oracle (CPU restatement, kind 'port') on a bounded sample of the same workload: the projection
     build on the full model (OpenMP over node blocks like psp_process.cpp:218-260) and the frame loop
@@ -161,7 +208,7 @@ def cpu_baseline(verts, tris, cam_dict, size, nframes_step, sample, registration
                      % (cores, r["nrays"], t_proj, frames.shape[0], t_frames, tm["loop"] / frames.shape[0] * 1e3, t_fixed,
                         reg_note, nframes_step),
            "mrays_per_s": mrays, "frame_loop_frames_per_s": 1.0 / per_frame, "bvh_build_s": t_build}
-    return out, dict(pix=pix, nrays=int(r["nrays"]), sum=s, sumsq=ss, rows8=rows8, frames_fixed=frames)
+    return out, dict(pix=pix, nrays=int(r["nrays"]), sum=s, sumsq=ss, rows8=rows8, frames_fixed=frames, obv=obv)
 
 
 def host_feed_rate(pipe, frames, N, size, pix, chunk=64, nchunks=16):
@@ -525,6 +572,8 @@ def main():
         out["reraycast_frames_per_s"] = nrr / (r0.elapsed_time(r1) * 1e-3)
     if world == 1 and not a.registration and not a.no_reraycast:
         out["host_feed"] = host_feed_rate(pipe, frames, N, size, last_pix[0])
+        if a.no_cpu_baseline:
+            out["pixel_rays"] = pixel_ray_rate(bvh, cd, size)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"], ref = cpu_baseline(verts, tris, cd, size, F, sample, registration=a.registration)
         if not a.registration:
@@ -550,6 +599,9 @@ def main():
             if chunked:   # the series as it came out of the (chunked, packed, u16) exchange
                 checks["exchange_series_8_frames"] = bool(np.array_equal(
                     exch.out[:, :8].cpu().numpy().T.view(np.int32), ref["rows8"].view(np.int32)))
+            if not a.no_reraycast:
+                out["pixel_rays"] = pixel_ray_rate(bvh, cd, size, check_with=ref["obv"])
+                checks["pixel_rays_closest_hit_sample"] = out["pixel_rays"]["parity"]
             out["parity_checked"] = all(checks.values())
             out["parity"] = checks
             if not out["parity_checked"]:
