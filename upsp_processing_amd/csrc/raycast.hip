@@ -665,15 +665,103 @@ __device__ __forceinline__ void flush_stats(unsigned *work, int *lds, unsigned n
 // ------------------------------------------------------------------------
 //  Batch query kernel: n independent rays (closest hit or occlusion).
 // ------------------------------------------------------------------------
-template <bool ANYHIT, bool STATS>
+constexpr int kWorkPrimaryCount = 18; // length of the dense ray list of the pass that runs (cast_entry_kernel /
+                                      // retry_list_kernel<kPixInFrame>)
+
+// A ray list spread over `pack_waves` waves (3 per SIMD: enough to overlap the node fetches of one wave with the box
+// tests of another; measured with 193 k primary rays of a projection build: 64 per wave 149 us, 48: 156, 32: 180,
+// 16: 194), at least 1 ray per wave (a few thousand rays run one or two to a wave, each for as long as its own chain
+// of steps and no longer), at most 64.  Static assignment, nobody touches the shared counter; the waves that get any
+// are spread evenly over the XCDs (workgroup b runs on XCD b & 7), one contiguous eighth of the list per XCD.
+// Returns false when the grid cannot take the list at once (the caller falls back to the queue).
+__device__ __forceinline__ bool queue_init_spread(WaveQueue &q, unsigned *work, unsigned total, unsigned pack_waves)
+{
+    if (!pack_waves) return false;
+    const unsigned pack = min(max((total + pack_waves - 1u) / pack_waves, 1u), 64u);
+    const unsigned wpb = blockDim.x >> 6;
+    const unsigned nchunks = (total + pack - 1u) / pack;
+    const unsigned per_xcd = ((nchunks + wpb - 1u) / wpb + 7u) >> 3;
+    if (per_xcd * 8u > gridDim.x) return false;
+    const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const unsigned long long first = ((unsigned long long)(xcd * per_xcd + slot) * wpb + (threadIdx.x >> 6)) * pack;
+    q.head = work;
+    q.total = total;
+    q.chunk = pack;
+    q.base = 0;
+    q.cur = (slot < per_xcd && first < total) ? (unsigned)first : total;
+    q.end = min(q.cur + pack, total);
+    q.exhausted = true;
+    return true;
+}
+
+// First pass of a large batch: the rays that miss the root box (trav_begin's test; on the bench's pixel rays 4 of 5)
+// get their "no hit" record here, the others go on a dense list (one atomic per 2048 rays) that cast_kernel<LISTED>
+// works off with queue_init_spread.  Same records as the one-pass form.
+constexpr int kEntryItems = 8;
+template <bool ANYHIT>
+__global__ void __launch_bounds__(256)
+    cast_entry_kernel(Scene sc, const float *__restrict__ org, int org_stride, const float *__restrict__ dir,
+                      unsigned n, upsp_hits out, unsigned *__restrict__ list, unsigned *work)
+{
+    __shared__ unsigned wave_cnt[kEntryItems][4], block_base;
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned base = blockIdx.x * (256u * kEntryItems) + threadIdx.x;
+    unsigned long long m[kEntryItems];
+    bool need[kEntryItems];
+#pragma unroll
+    for (int k = 0; k < kEntryItems; ++k) {
+        const unsigned i = base + 256u * k;
+        need[k] = false;
+        if (i < n) {
+            const float *o = org + (size_t)org_stride * i;
+            const float *d = dir + 3 * (size_t)i;
+            Ray r;
+            ray_setup(r, o[0], o[1], o[2], d[0], d[1], d[2]);
+            ray_classify(r, sc);
+            need[k] = box_hit(r, sc.rlo[0], sc.rlo[1], sc.rlo[2], sc.rhi[0], sc.rhi[1], sc.rhi[2]);
+            if (!need[k]) {
+                if (ANYHIT) {
+                    if (out.hit) out.hit[i] = 0;
+                } else {
+                    Trav s;
+                    s.any = false;
+                    s.best_slot = -1;
+                    write_hit(r, sc, s, i, out);
+                }
+            }
+        }
+        m[k] = __ballot(need[k]);
+        if (lane == 0) wave_cnt[k][wave] = (unsigned)__popcll(m[k]);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned tot = 0;
+        for (int k = 0; k < kEntryItems; ++k)
+            for (int w = 0; w < 4; ++w) {   // exclusive prefix in place
+                const unsigned c = wave_cnt[k][w];
+                wave_cnt[k][w] = tot;
+                tot += c;
+            }
+        block_base = tot ? atomicAdd(&work[kWorkPrimaryCount], tot) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kEntryItems; ++k)
+        if (need[k])
+            list[block_base + wave_cnt[k][wave] + (unsigned)__popcll(m[k] & ((1ull << lane) - 1ull))] = base + 256u * k;
+}
+
+template <bool ANYHIT, bool STATS, bool LISTED = false>
 __global__ void __launch_bounds__(kBlock)
     cast_kernel(Scene sc, const float *__restrict__ org, int org_stride,
-                const float *__restrict__ dir, unsigned n, upsp_hits out, unsigned *work)
+                const float *__restrict__ dir, unsigned n, upsp_hits out, unsigned *work,
+                const unsigned *__restrict__ list = nullptr)
 {
     extern __shared__ int lds_stack[];
     int *stack = lds_stack + threadIdx.x;
     WaveQueue q;
-    queue_init(q, work, n, sc.chunk, sc.xcd != 0);
+    const unsigned total = LISTED ? work[kWorkPrimaryCount] : n;
+    if (!(LISTED && queue_init_spread(q, work, total, sc.pack_waves))) queue_init(q, work, total, sc.chunk, sc.xcd != 0);
     Ray r;
     r.simple = true;   // idle lanes must not veto the wave-uniform fast path
     Trav s;
@@ -690,6 +778,7 @@ __global__ void __launch_bounds__(kBlock)
             unsigned it;
             const bool got = queue_take(q, !busy, it);
             if (got) {
+                if (LISTED) it = list[it];
                 item = it;
                 const float *o = org + (size_t)org_stride * it;
                 const float *d = dir + 3 * (size_t)it;
@@ -780,7 +869,6 @@ constexpr int32_t kPixRetry = -4;     // primary ray hit a foreign triangle: ret
 constexpr int kWorkRetryCount = 10;
 constexpr int kWorkTodoCount = 12;   // rays witness_kernel could not decide
 constexpr int kWorkHeavyCount = 16;  // work items handed to heavy_kernel: [16] by the primary pass, [17] by the retry pass
-constexpr int kWorkPrimaryCount = 18; // nodes that cast a primary ray (retry_list_kernel<kPixInFrame>)
 constexpr int kWorkWords = 32;
 constexpr unsigned kHeavyCap = 65536;
 
@@ -1146,32 +1234,8 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 
     // touches the shared counter: after the early oblique test a camera has ~200 k rays for ~6000 resident waves, and
     // draining a sparse item range through the queue (thousands of same-address atomics, chunks without a single ray)
     // cost more than the traversals -- the pass took 160 us with 1400 rays and 250 us with 193 k.
-    // Rays per wave: the list spread over `pack_waves` waves (3 per SIMD: enough to overlap the node fetches of one
-    // wave with the box tests of another; measured with 193 k primary rays: 64 per wave 149 us, 48: 156, 32: 180,
-    // 16: 194), at least 1 (a few thousand residual retries run one or two to a wave, each for as long as its own
-    // chain of steps and no longer), at most 64.
     WaveQueue q;
-    bool packed = false;
-    if (sc.pack_waves) {
-        const unsigned pack = min(max((total + sc.pack_waves - 1u) / sc.pack_waves, 1u), 64u);
-        // the waves that get any are spread evenly over the XCDs (workgroup b runs on XCD b & 7), one contiguous
-        // eighth of the list per XCD (the primary list is in mesh order)
-        const unsigned wpb = blockDim.x >> 6;
-        const unsigned nchunks = (total + pack - 1u) / pack;
-        const unsigned per_xcd = ((nchunks + wpb - 1u) / wpb + 7u) >> 3;
-        if (per_xcd * 8u <= gridDim.x) {
-            packed = true;
-            const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-            const unsigned long long first = ((unsigned long long)(xcd * per_xcd + slot) * wpb + (threadIdx.x >> 6)) * pack;
-            q.head = work;
-            q.total = total;
-            q.chunk = pack;
-            q.base = 0;
-            q.cur = (slot < per_xcd && first < total) ? (unsigned)first : total;
-            q.end = min(q.cur + pack, total);
-            q.exhausted = true;
-        }
-    }
+    const bool packed = queue_init_spread(q, work, total, sc.pack_waves);
     if (!packed) queue_init(q, work, total, sc.chunk, sc.xcd != 0 && PHASE == 0);   // (retry lists are not in mesh order)
     Ray r;
     r.simple = true;   // idle lanes must not veto the wave-uniform fast path
@@ -1744,8 +1808,31 @@ int launch_cast(const upsp_bvh *cb, const float *d_org, int org_stride, const fl
     const size_t lds = lds_bytes(b);
     UPSP_HIP_CHECK(hipMemsetAsync(b->d_work, 0, kWorkWords * sizeof(unsigned), st));
     const int grid = grid_for(n, lds);
-    const Scene sc = make_scene(b, n, grid);
+    Scene sc = make_scene(b, n, grid);
     if (n >= 65536) prefetch_bvh(b, st);
+    static const bool two_pass = env_int("UPSP_CAST_TWO_PASS", 1) != 0;
+    if (two_pass && n >= 65536 && !b->stats_on) {
+        if (b->cast_list_capacity < n) {
+            if (b->d_cast_list) (void)hipFree(b->d_cast_list);
+            b->d_cast_list = nullptr;
+            b->cast_list_capacity = 0;
+            UPSP_HIP_CHECK(hipMalloc(&b->d_cast_list, sizeof(unsigned) * n));
+            b->cast_list_capacity = n;
+        }
+        static const int waves_per_simd = env_int("UPSP_WAVES_PER_SIMD", 3);
+        sc.pack_waves = (unsigned)std::max(waves_per_simd, 0) * 4u * (unsigned)(props().cus > 0 ? props().cus : 256);
+        {
+            KTimed kte("cast_entry_kernel", st);
+            const dim3 egrid((unsigned)((n + 256 * kEntryItems - 1) / (256 * kEntryItems)));
+            hipLaunchKernelGGL((cast_entry_kernel<ANYHIT>), egrid, dim3(256), 0, st, sc, d_org, org_stride, d_dir,
+                               (unsigned)n, out, b->d_cast_list, b->d_work);
+        }
+        KTimed kt(ANYHIT ? "cast_kernel<anyhit>" : "cast_kernel<closest>", st);
+        hipLaunchKernelGGL((cast_kernel<ANYHIT, false, true>), dim3(grid), dim3(kBlock), lds, st, sc,
+                           d_org, org_stride, d_dir, (unsigned)n, out, b->d_work, (const unsigned *)b->d_cast_list);
+        UPSP_HIP_CHECK(hipGetLastError());
+        return UPSP_OK;
+    }
     KTimed kt(ANYHIT ? "cast_kernel<anyhit>" : "cast_kernel<closest>", st);
     if (b->stats_on)
         hipLaunchKernelGGL((cast_kernel<ANYHIT, true>), dim3(grid), dim3(kBlock), lds, st, sc,
@@ -1999,6 +2086,7 @@ void upsp_bvh_destroy(upsp_bvh *b)
     if (b->d_todo_mask) (void)hipFree(b->d_todo_mask);
     if (b->d_todo_rays) (void)hipFree(b->d_todo_rays);
     if (b->d_heavy) (void)hipFree(b->d_heavy);
+    if (b->d_cast_list) (void)hipFree(b->d_cast_list);
     if (b->d_stage) (void)hipFree(b->d_stage);
     if (b->h_stage) (void)hipHostFree(b->h_stage);
     if (b->stage_stream) (void)hipStreamDestroy(b->stage_stream);

@@ -81,6 +81,8 @@ struct upsp_bvh {
     int32_t *d_witness = nullptr;      // per node: triangle slot the primary ray hit (retry nodes)
     uint32_t *d_todo_mask = nullptr, *d_todo_rays = nullptr;   // retries the witness test left undecided
     uint32_t *d_heavy = nullptr;                               // work items handed to heavy_kernel
+    uint32_t *d_cast_list = nullptr;                           // batch queries: rays that enter the root box
+    size_t cast_list_capacity = 0;
     const void *adj_src = nullptr;     // the d_tri_nodes buffer the adjacency was built from
     size_t adj_nnodes = 0;
     size_t retry_capacity = 0;
