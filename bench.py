@@ -141,8 +141,10 @@ def pixel_ray_rate(bvh, cam_dict, size, check_with=None):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
+    alg = dirs.shape[0] * 40 + bvh.info["device_bytes"]      # 40 B per ray + the scene once per batch
     out = {"rays": int(dirs.shape[0]), "ms": ms, "mrays_per_s": dirs.shape[0] / (ms * 1e-3) / 1e6,
            "hit_fraction": float(h["hit"].float().mean().item()),
+           "algorithmic_bytes": int(alg), "achieved_GBps": alg / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": alg / (ms * 1e-3) / 8e12,
            "what": "closest hit (t, primID) of one ray per pixel of the %d x %d frame, upsp_bvh_intersect; all rays traversed" % (size, size)}
     if check_with is not None:
         idx = np.arange(0, dirs.shape[0], 37)
