@@ -426,11 +426,44 @@ __global__ void __launch_bounds__(256)
     const unsigned per_block = (npx + gridDim.x - 1) / gridDim.x;
     const unsigned lo = blockIdx.x * per_block;
     const unsigned hi = min(npx, lo + per_block);
+    // The fixed-point coordinate is a sum of a term per row and a term per column, each rounded on its own
+    // (WarpAffineInvoker: X0 + adelta[x]): 20 double-precision instructions per pixel when evaluated in place -- and the
+    // kernel is bound by its VALU instruction count (~206 per pixel, tools/probe/dfma_rate.hip: every f64 instruction
+    // issues at the 4-cycle rate of the f32 ones).  The block tabulates both once (its rows: <= 64, the columns:
+    // <= 2048) and a pixel reads two LDS entries.  Same integers.
+    constexpr unsigned kTabCols = 2048, kTabRows = 64;
+    __shared__ int2 ctab[IDENT ? 1 : kTabCols], rtab[IDENT ? 1 : kTabRows];
+    const unsigned y_lo = lo / (unsigned)cols;
+    const bool tab = !IDENT && lo < hi && (unsigned)cols <= kTabCols && (hi - 1u) / (unsigned)cols - y_lo < kTabRows;
+    if (tab) {
+        for (unsigned cx = threadIdx.x; cx < (unsigned)cols; cx += 256u)
+            ctab[cx] = make_int2(__double2int_rn(M[0] * (int)cx * 1024), __double2int_rn(M[3] * (int)cx * 1024));
+        const unsigned nr = (hi - 1u) / (unsigned)cols - y_lo + 1u;
+        if (threadIdx.x < nr) {
+            const int yy = (int)(y_lo + threadIdx.x);
+            rtab[threadIdx.x] = make_int2(__double2int_rn((M[1] * yy + M[2]) * 1024), __double2int_rn((M[4] * yy + M[5]) * 1024));
+        }
+        __syncthreads();
+    }
+    auto coords_tab = [&](int x, int y, WarpCoord &c) {
+        const int2 rt = rtab[(unsigned)y - y_lo], ct = ctab[x];
+        const int Xr = rt.x + ct.x, Yr = rt.y + ct.y;
+        const int X = (Xr + 16) >> 5, Y = (Yr + 16) >> 5;
+        c.sx = max(-32768, min(32767, X >> 5));
+        c.sy = max(-32768, min(32767, Y >> 5));
+        c.ax = X & 31;
+        c.ay = Y & 31;
+        const int nx = max(-32768, min(32767, (Xr + 512) >> 10)), ny = max(-32768, min(32767, (Yr + 512) >> 10));
+        return (unsigned)nx < (unsigned)cols && (unsigned)ny < (unsigned)rows;
+    };
     unsigned i = lo + threadIdx.x;
     int y = (int)(i / (unsigned)cols), x = (int)(i % (unsigned)cols);
     for (; i < hi; i += 256u) {
         WarpCoord c;
-        const bool m = coords(x, y, c);
+        // IDENT: the warp is the identity in every active frame: source pixel = target pixel, zero fractions, and the
+        // nearest-neighbour mask pixel is the pixel itself (Xr = 1024 x exactly) -- nothing to compute
+        bool m = true;
+        if (!IDENT) m = tab ? coords_tab(x, y, c) : coords(x, y, c);
         float w = 0.f, gx = 0.f, gy = 0.f;
         bool fast;
         if (IDENT) {
@@ -453,6 +486,7 @@ __global__ void __launch_bounds__(256)
                 if (!fast) blist[wave][nlist + (unsigned)__popcll(slow & ((1ull << lane) - 1ull))] = i;
                 nlist += n;
             } else if (!fast) {                              // list full: generic path in place
+                if (IDENT) coords(x, y, c);
                 w = bilinear(pix, rows, cols, c);
                 gx = bilinear(gxf, rows, cols, c);
                 gy = bilinear(gyf, rows, cols, c);
