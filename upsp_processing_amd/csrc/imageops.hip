@@ -35,6 +35,8 @@ namespace {
 
 constexpr int kEccBlocks = 64;   // partial-sum blocks per frame (full sub-batch)
 constexpr int kEccBlocksMax = 512;  // ... when only a few frames are still iterating
+constexpr int kEccBorderBlocks = 16; // partial-sum blocks of ecc_border_kernel (after the interior kernel's)
+constexpr int kEccStride = kEccBlocksMax + kEccBorderBlocks;   // partial sums per (frame, sum)
 constexpr int kEccSums = 45;
 constexpr int kMaxKernel = 63;   // largest odd filter size
 
@@ -189,6 +191,12 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+int env_int_io(const char *name, int dflt)
+{
+    const char *v = std::getenv(name);
+    return v ? std::atoi(v) : dflt;
+}
+
 unsigned grid_for_pixels(size_t npix)
 {
     size_t g = (npix + 255) / 256;
@@ -272,7 +280,25 @@ struct EccState {
     double rho, last_rho;
     int iters;
     int done;     // 1 converged / iteration cap, 2 identity (frame 0), <0 error
+    int band;     // pixels farther than this from every image edge have their whole bilinear footprint (and its
+                  // gradient taps) inside the image under M (ecc_band): ecc_interior_kernel takes them, ecc_border_kernel the rest
 };
+
+// Width of the border band for the warp M: an affine displacement |M p - p| is largest at a corner of the image; the
+// fixed-point source pixel is within 1.02 of M p, the footprint reaches 1 pixel before and 2 behind it.
+__device__ __forceinline__ int ecc_band(const float *Mf, int rows, int cols)
+{
+    double D = 0.0;
+    for (int cy = 0; cy < 2; ++cy)
+        for (int cx = 0; cx < 2; ++cx) {
+            const double x = cx ? cols - 1 : 0, y = cy ? rows - 1 : 0;
+            const double dx = fabs((double)Mf[0] * x + (double)Mf[1] * y + (double)Mf[2] - x);
+            const double dy = fabs((double)Mf[3] * x + (double)Mf[4] * y + (double)Mf[5] - y);
+            D = fmax(D, fmax(dx, dy));
+        }
+    if (!(D < 1.0e6)) return 1 << 24;      // (also NaN: everything is border)
+    return (int)ceil(D) + 3;
+}
 
 // cv::warpAffine(u16, M, INTER_LINEAR|NEAREST + WARP_INVERSE_MAP) for every frame.
 // list (may be null; [0] = count, then pixel indices): only the listed pixels are produced -- the warped frame of the
@@ -325,199 +351,54 @@ __global__ void __launch_bounds__(256)
 // cpp/lib/registration.cpp:52-53): source pixel = target pixel, zero fractions, so the bilinear
 // weights are (1,0,0,0) and the general arithmetic reduces EXACTLY to the centre taps
 // (x*1 + y*0 + .. = x in float) -- 5 loads and no interpolation instead of 12 loads.
-template <bool IDENT>
-__global__ void __launch_bounds__(256)
-    ecc_sums_kernel(const float *__restrict__ img, const float *__restrict__ tmpl, int rows,
-                    int cols, const EccState *__restrict__ state, double *__restrict__ partial)
+//
+// One launch per iteration (ecc_sums2_kernel), the pixels split by WHERE they are:
+//   * interior blocks: pixels farther than EccState::band from every edge -- the whole 12-pixel footprint is inside
+//     the image and the nearest-neighbour mask is 1 by construction (ecc_band), so there is no test, no list and no
+//     fallback in the loop.  The inner rectangle is one index range split evenly over the blocks; a trip loads for
+//     several pixels per thread (identity iteration: 2 x 4 consecutive pixels from 16-B loads; general: 4 pixels)
+//     before it accumulates any, and lanes past the end of the range add zeros instead of branching;
+//   * band blocks: 2 x band rows + 2 x band columns (~1.5 % of a 1024^2 frame), generic bilinear with border
+//     handling; first in dispatch order so that their few long trips run beside the interior blocks.
+// Same per-pixel arithmetic everywhere, fixed order of the block partials (band slots, then interior slots).
+// (Round 2's first form was ONE sweep with a per-wave list of border pixels and an in-place fallback: 146 VGPRs, 3
+// waves per SIMD, every trip waiting a memory latency for its own loads -- 460 / 500 us per 64-frame launch for the
+// identity / a general iteration where the VALU work is 180 / 350 us; every attempt to put more loads in flight
+// INSIDE that loop made the compiler spend 220-256 registers.  Now 215 / 385 us.)
+__device__ __forceinline__ void ecc_accumulate(double (&acc)[kEccSums], float w, float gx, float gy, float t, bool m,
+                                               int x, int y)
 {
-    const int f = blockIdx.y;
-    const EccState &es = state[f];
-    if (es.done) return;
-    const size_t npix = (size_t)rows * cols;
-    const float *I = img + (size_t)f * npix;
-    double M[6];
+    const float X = (float)x, Y = (float)y;
+    const float J[6] = {gx * X, gy * X, gx * Y, gy * Y, gx, gy};
+    const double mm = m ? 1.0 : 0.0, wd = w, td = t, tm = m ? td : 0.0, wm = m ? wd : 0.0;
+    acc[0] += mm;
+    acc[1] += wm;
+    acc[2] = fma(wm, wd, acc[2]);
+    acc[3] += tm;
+    acc[4] = fma(tm, td, acc[4]);
+    acc[5] = fma(tm, wd, acc[5]);
+    double Jd[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) M[i] = es.M[i];
-    double acc[kEccSums];
+    for (int a = 0; a < 6; ++a) Jd[a] = (double)J[a];
+    int h = 24;
 #pragma unroll
-    for (int k = 0; k < kEccSums; ++k) acc[k] = 0.0;
-
-    auto pix = [&](int yy, int xx) { return I[(size_t)yy * cols + xx]; };
-    // filter2D [-0.5 0 0.5] (BORDER_REFLECT_101) of the blurred frame, on the fly
-    auto gxf = [&](int yy, int xx) {
-        return -0.5f * pix(yy, reflect101(xx - 1, cols)) + 0.5f * pix(yy, reflect101(xx + 1, cols));
-    };
-    auto gyf = [&](int yy, int xx) {
-        return -0.5f * pix(reflect101(yy - 1, rows), xx) + 0.5f * pix(reflect101(yy + 1, rows), xx);
-    };
-
-    // fixed-point source coordinate of pixel (x, y) (WarpAffineInvoker) and the nearest-neighbour mask
-    auto coords = [&](int x, int y, WarpCoord &c) {
-        const int Xr = __double2int_rn((M[1] * y + M[2]) * 1024) + __double2int_rn(M[0] * x * 1024);
-        const int Yr = __double2int_rn((M[4] * y + M[5]) * 1024) + __double2int_rn(M[3] * x * 1024);
-        const int X = (Xr + 16) >> 5, Y = (Yr + 16) >> 5;
-        c.sx = max(-32768, min(32767, X >> 5));
-        c.sy = max(-32768, min(32767, Y >> 5));
-        c.ax = X & 31;
-        c.ay = Y & 31;
-        const int nx = max(-32768, min(32767, (Xr + 512) >> 10)), ny = max(-32768, min(32767, (Yr + 512) >> 10));
-        return (unsigned)nx < (unsigned)cols && (unsigned)ny < (unsigned)rows;
-    };
-    // the 45 sums of one pixel; masked terms enter with weight mm = 1 / 0 (branch-free); fma = one rounding
-    auto accumulate = [&](float w, float gx, float gy, float t, bool m, int x, int y) {
-        const float X = (float)x, Y = (float)y;
-        const float J[6] = {gx * X, gy * X, gx * Y, gy * Y, gx, gy};
-        const double mm = m ? 1.0 : 0.0, wd = w, td = t, tm = m ? td : 0.0, wm = m ? wd : 0.0;
-        acc[0] += mm;
-        acc[1] += wm;
-        acc[2] = fma(wm, wd, acc[2]);
-        acc[3] += tm;
-        acc[4] = fma(tm, td, acc[4]);
-        acc[5] = fma(tm, wd, acc[5]);
-        double Jd[6];
+    for (int a = 0; a < 6; ++a) {
+        acc[6 + a] = fma(Jd[a], wd, acc[6 + a]);
+        acc[12 + a] = fma(Jd[a], mm, acc[12 + a]);
+        acc[18 + a] = fma(Jd[a], tm, acc[18 + a]);
 #pragma unroll
-        for (int a = 0; a < 6; ++a) Jd[a] = (double)J[a];
-        int h = 24;
-#pragma unroll
-        for (int a = 0; a < 6; ++a) {
-            acc[6 + a] = fma(Jd[a], wd, acc[6 + a]);
-            acc[12 + a] = fma(Jd[a], mm, acc[12 + a]);
-            acc[18 + a] = fma(Jd[a], tm, acc[18 + a]);
-#pragma unroll
-            for (int b = a; b < 6; ++b) {
-                acc[h] = fma(Jd[a], Jd[b], acc[h]);
-                ++h;
-            }
-        }
-    };
-    // fully interior footprint: 12 pixels, no border handling; same arithmetic as the generic path
-    // (bilinear of I, of [-0.5 0 0.5] along x and along y)
-    auto interior = [&](const WarpCoord &c, float &w, float &gx, float &gy) {
-        const float *r0 = I + (unsigned)((c.sy - 1) * cols + c.sx);
-        const float *r1 = r0 + cols, *r2 = r1 + cols, *r3 = r2 + cols;
-        const float a0 = r0[0], a1 = r0[1];
-        const float b_1 = r1[-1], b0 = r1[0], b1 = r1[1], b2 = r1[2];
-        const float c_1 = r2[-1], c0 = r2[0], c1 = r2[1], c2 = r2[2];
-        const float d0 = r3[0], d1 = r3[1];
-        const float fx = c.ax * (1.f / 32), fy = c.ay * (1.f / 32);
-        const float w0 = (1.f - fy) * (1.f - fx), w1 = (1.f - fy) * fx, w2 = fy * (1.f - fx), w3 = fy * fx;
-        w = b0 * w0 + b1 * w1 + c0 * w2 + c1 * w3;
-        gx = (-0.5f * b_1 + 0.5f * b1) * w0 + (-0.5f * b0 + 0.5f * b2) * w1 +
-             (-0.5f * c_1 + 0.5f * c1) * w2 + (-0.5f * c0 + 0.5f * c2) * w3;
-        gy = (-0.5f * a0 + 0.5f * c0) * w0 + (-0.5f * a1 + 0.5f * c1) * w1 +
-             (-0.5f * b0 + 0.5f * d0) * w2 + (-0.5f * b1 + 0.5f * d1) * w3;
-    };
-
-    // Pixels lo + tid, + 256, ... of this block's range, (x, y) carried along (no division per pixel,
-    // 32-bit offsets: the launcher refuses images of 2^31 pixels).
-    //
-    // Pixels whose footprint touches the image border need the generic bilinear (reflect-101 gradients,
-    // constant-0 border): ~300 instructions against ~130.  A 256-pixel strip of a 1024-wide image holds
-    // such a pixel in two of its four waves, so taking that path inside the sweep made HALF of all
-    // wave-iterations pay for it (measured: 482 us per 64-frame launch against 324 us with the border
-    // path switched off).  The sweep therefore only LISTS those pixels -- per wave, in LDS, slots by
-    // ballot + prefix count, so the order is fixed -- and the wave works its list off afterwards, 64 border
-    // pixels per trip.  A list that runs full falls back to the path in place.
-    constexpr unsigned kListCap = 1024;   // per wave
-    __shared__ unsigned blist[4][kListCap];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned nlist = 0;                    // (wave-uniform)
-    const unsigned npx = (unsigned)npix;
-    const unsigned per_block = (npx + gridDim.x - 1) / gridDim.x;
-    const unsigned lo = blockIdx.x * per_block;
-    const unsigned hi = min(npx, lo + per_block);
-    // The fixed-point coordinate is a sum of a term per row and a term per column, each rounded on its own
-    // (WarpAffineInvoker: X0 + adelta[x]): 20 double-precision instructions per pixel when evaluated in place -- and the
-    // kernel is bound by its VALU instruction count (~206 per pixel, tools/probe/dfma_rate.hip: every f64 instruction
-    // issues at the 4-cycle rate of the f32 ones).  The block tabulates both once (its rows: <= 64, the columns:
-    // <= 2048) and a pixel reads two LDS entries.  Same integers.
-    constexpr unsigned kTabCols = 2048, kTabRows = 64;
-    __shared__ int2 ctab[IDENT ? 1 : kTabCols], rtab[IDENT ? 1 : kTabRows];
-    const unsigned y_lo = lo / (unsigned)cols;
-    const bool tab = !IDENT && lo < hi && (unsigned)cols <= kTabCols && (hi - 1u) / (unsigned)cols - y_lo < kTabRows;
-    if (tab) {
-        for (unsigned cx = threadIdx.x; cx < (unsigned)cols; cx += 256u)
-            ctab[cx] = make_int2(__double2int_rn(M[0] * (int)cx * 1024), __double2int_rn(M[3] * (int)cx * 1024));
-        const unsigned nr = (hi - 1u) / (unsigned)cols - y_lo + 1u;
-        if (threadIdx.x < nr) {
-            const int yy = (int)(y_lo + threadIdx.x);
-            rtab[threadIdx.x] = make_int2(__double2int_rn((M[1] * yy + M[2]) * 1024), __double2int_rn((M[4] * yy + M[5]) * 1024));
-        }
-        __syncthreads();
-    }
-    auto coords_tab = [&](int x, int y, WarpCoord &c) {
-        const int2 rt = rtab[(unsigned)y - y_lo], ct = ctab[x];
-        const int Xr = rt.x + ct.x, Yr = rt.y + ct.y;
-        const int X = (Xr + 16) >> 5, Y = (Yr + 16) >> 5;
-        c.sx = max(-32768, min(32767, X >> 5));
-        c.sy = max(-32768, min(32767, Y >> 5));
-        c.ax = X & 31;
-        c.ay = Y & 31;
-        const int nx = max(-32768, min(32767, (Xr + 512) >> 10)), ny = max(-32768, min(32767, (Yr + 512) >> 10));
-        return (unsigned)nx < (unsigned)cols && (unsigned)ny < (unsigned)rows;
-    };
-    unsigned i = lo + threadIdx.x;
-    int y = (int)(i / (unsigned)cols), x = (int)(i % (unsigned)cols);
-    for (; i < hi; i += 256u) {
-        WarpCoord c;
-        // IDENT: the warp is the identity in every active frame: source pixel = target pixel, zero fractions, and the
-        // nearest-neighbour mask pixel is the pixel itself (Xr = 1024 x exactly) -- nothing to compute
-        bool m = true;
-        if (!IDENT) m = tab ? coords_tab(x, y, c) : coords(x, y, c);
-        float w = 0.f, gx = 0.f, gy = 0.f;
-        bool fast;
-        if (IDENT) {
-            fast = x >= 1 && x + 2 < cols && y >= 1 && y + 2 < rows;
-            if (fast) {
-                const float *r1 = I + i;
-                w = r1[0];
-                gx = -0.5f * r1[-1] + 0.5f * r1[1];
-                gy = -0.5f * r1[-cols] + 0.5f * r1[cols];
-            }
-        } else {
-            fast = c.sx >= 1 && c.sx + 2 < cols && c.sy >= 1 && c.sy + 2 < rows;
-            if (fast) interior(c, w, gx, gy);
-        }
-        bool now = fast;
-        const unsigned long long slow = __ballot(!fast);
-        if (slow != 0ull) {                                  // (rare for a wave)
-            const unsigned n = (unsigned)__popcll(slow);
-            if (nlist + n <= kListCap) {
-                if (!fast) blist[wave][nlist + (unsigned)__popcll(slow & ((1ull << lane) - 1ull))] = i;
-                nlist += n;
-            } else if (!fast) {                              // list full: generic path in place
-                if (IDENT) coords(x, y, c);
-                w = bilinear(pix, rows, cols, c);
-                gx = bilinear(gxf, rows, cols, c);
-                gy = bilinear(gyf, rows, cols, c);
-                now = true;
-            }
-        }
-        if (now) accumulate(w, gx, gy, tmpl[i], m, x, y);
-        x += 256;
-        while (x >= cols) {
-            x -= cols;
-            ++y;
+        for (int b = a; b < 6; ++b) {
+            acc[h] = fma(Jd[a], Jd[b], acc[h]);
+            ++h;
         }
     }
-    // the listed pixels (a wave reads what it wrote itself: LDS operations of a wave complete in order)
-    for (unsigned k = (unsigned)lane; k < nlist; k += 64u) {
-        const unsigned ib = blist[wave][k];
-        const int yb = (int)(ib / (unsigned)cols), xb = (int)(ib % (unsigned)cols);
-        WarpCoord c;
-        const bool m = coords(xb, yb, c);
-        float w, gx, gy;
-        if (!IDENT && c.sx >= 1 && c.sx + 2 < cols && c.sy >= 1 && c.sy + 2 < rows) {
-            interior(c, w, gx, gy);                          // (not reached: such pixels are never listed)
-        } else {
-            w = bilinear(pix, rows, cols, c);
-            gx = bilinear(gxf, rows, cols, c);
-            gy = bilinear(gyf, rows, cols, c);
-        }
-        accumulate(w, gx, gy, tmpl[ib], m, xb, yb);
-    }
-    // deterministic block reduction: wave shuffle tree, then 4 waves through LDS
+}
+
+// deterministic block reduction of the 45 sums: wave shuffle tree, then 4 waves through LDS
+__device__ __forceinline__ void ecc_block_store(const double (&acc)[kEccSums], double *__restrict__ partial, int f, int slot)
+{
     __shared__ double red[4][kEccSums];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < kEccSums; ++k) {
         double v = acc[k];
@@ -527,9 +408,270 @@ __global__ void __launch_bounds__(256)
     __syncthreads();
     if (threadIdx.x < kEccSums) {
         const double v = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
-        // [frame][sum][block]: the solve kernel reads one sum over all blocks with coalesced loads
-        partial[((size_t)f * kEccSums + threadIdx.x) * kEccBlocksMax + blockIdx.x] = v;
+        partial[((size_t)f * kEccSums + threadIdx.x) * kEccStride + slot] = v;
     }
+}
+
+struct EccMargins { int top, bottom, left, right; };
+__device__ __forceinline__ EccMargins ecc_margins(int band, int rows, int cols)
+{
+    EccMargins g;
+    g.top = min(band, rows / 2);
+    g.bottom = min(band, rows - g.top);
+    g.left = min(band, cols / 2);
+    g.right = min(band, cols - g.left);
+    return g;
+}
+
+template <bool IDENT, int KP>
+__device__ __forceinline__ void ecc_interior_body(const float *__restrict__ img, const float *__restrict__ tmpl, int rows,
+                                                  int cols, const EccState *__restrict__ state,
+                                                  double *__restrict__ partial, int f, unsigned blk, unsigned nblk)
+{
+    const EccState &es = state[f];
+    const float *I = img + (size_t)f * rows * cols;
+    double acc[kEccSums];
+#pragma unroll
+    for (int k = 0; k < kEccSums; ++k) acc[k] = 0.0;
+    const EccMargins g = ecc_margins(IDENT ? 3 : es.band, rows, cols);
+    const int x_lo = g.left, x_hi = cols - g.right, y_lo = g.top, y_hi = rows - g.bottom;   // [lo, hi)
+    const int W = max(x_hi - x_lo, 0), H = max(y_hi - y_lo, 0);
+    // The inner rectangle as ONE index range split evenly over the blocks (whatever the image width: a trip always has
+    // all 256 lanes at work except at the end of the block's range); (column, row) carried along, no division per trip.
+    if (IDENT) {
+        // items = groups of four consecutive pixels of a row (the last group of a row may be short);
+        // source pixel = target pixel, zero fractions: w = I, gx / gy = central differences; mask 1
+        const unsigned G = ((unsigned)W + 3u) / 4u, total = G * (unsigned)H;
+        const unsigned per_block = (total + nblk - 1) / nblk;
+        const unsigned j_lo = min(total, blk * per_block), j_hi = min(total, j_lo + per_block);
+        unsigned j = j_lo + threadIdx.x;
+        unsigned gy = G ? j / G : 0u, gx = G ? j % G : 0u;
+        for (unsigned jb = j_lo; jb < j_hi; jb += 256u * KP) {     // (uniform trip count; lanes past the end add zeros)
+            float4 c[KP], u[KP], d[KP], t[KP];
+            float l[KP], r[KP];
+            int xs[KP], ys[KP];
+            bool in[KP];
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                in[k] = j < j_hi;
+                xs[k] = in[k] ? x_lo + 4 * (int)gx : x_lo;         // (lanes past the end: any address inside the image)
+                ys[k] = in[k] ? y_lo + (int)gy : y_lo;
+                const float *r1 = I + (size_t)ys[k] * cols + xs[k];
+                c[k] = *reinterpret_cast<const float4 *>(r1);      // (4-B aligned 16-B loads)
+                u[k] = *reinterpret_cast<const float4 *>(r1 - cols);
+                d[k] = *reinterpret_cast<const float4 *>(r1 + cols);
+                t[k] = *reinterpret_cast<const float4 *>(tmpl + (size_t)ys[k] * cols + xs[k]);
+                l[k] = r1[-1];
+                r[k] = r1[4];
+                j += 256u;
+                gx += 256u;
+                while (gx >= G && G) {
+                    gx -= G;
+                    ++gy;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                const int x = xs[k], y = ys[k];
+                const bool m0 = in[k], m1 = in[k] && x + 1 < x_hi, m2 = in[k] && x + 2 < x_hi, m3 = in[k] && x + 3 < x_hi;
+                __builtin_amdgcn_sched_barrier(0);
+                ecc_accumulate(acc, m0 ? c[k].x : 0.f, m0 ? -0.5f * l[k] + 0.5f * c[k].y : 0.f,
+                               m0 ? -0.5f * u[k].x + 0.5f * d[k].x : 0.f, m0 ? t[k].x : 0.f, m0, x, y);
+                __builtin_amdgcn_sched_barrier(0);
+                ecc_accumulate(acc, m1 ? c[k].y : 0.f, m1 ? -0.5f * c[k].x + 0.5f * c[k].z : 0.f,
+                               m1 ? -0.5f * u[k].y + 0.5f * d[k].y : 0.f, m1 ? t[k].y : 0.f, m1, x + 1, y);
+                __builtin_amdgcn_sched_barrier(0);
+                ecc_accumulate(acc, m2 ? c[k].z : 0.f, m2 ? -0.5f * c[k].y + 0.5f * c[k].w : 0.f,
+                               m2 ? -0.5f * u[k].z + 0.5f * d[k].z : 0.f, m2 ? t[k].z : 0.f, m2, x + 2, y);
+                __builtin_amdgcn_sched_barrier(0);
+                ecc_accumulate(acc, m3 ? c[k].w : 0.f, m3 ? -0.5f * c[k].z + 0.5f * r[k] : 0.f,
+                               m3 ? -0.5f * u[k].w + 0.5f * d[k].w : 0.f, m3 ? t[k].w : 0.f, m3, x + 3, y);
+            }
+        }
+    } else {
+        double M[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) M[i] = es.M[i];
+        const unsigned total = (unsigned)W * (unsigned)H;
+        const unsigned per_block = (total + nblk - 1) / nblk;
+        const unsigned q_lo = min(total, blk * per_block), q_hi = min(total, q_lo + per_block);
+        // the two terms of the fixed-point coordinate (WarpAffineInvoker's X0 / Y0 per row, adelta / bdelta per column),
+        // each rounded on its own, tabulated once per block: same integers as evaluating them per pixel
+        constexpr int kTabCols = 2048, kTabRows = 64;
+        __shared__ int2 ctab[kTabCols], rtab[kTabRows];
+        const unsigned ry_lo = W ? q_lo / (unsigned)W : 0u;
+        const unsigned nrows_blk = (q_hi > q_lo && W) ? (q_hi - 1u) / (unsigned)W - ry_lo + 1u : 0u;
+        const bool tab = cols <= kTabCols && nrows_blk <= (unsigned)kTabRows;
+        if (tab) {
+            for (int cx = threadIdx.x; cx < cols; cx += 256)
+                ctab[cx] = make_int2(__double2int_rn(M[0] * cx * 1024), __double2int_rn(M[3] * cx * 1024));
+            if (threadIdx.x < nrows_blk) {
+                const int yy = y_lo + (int)(ry_lo + threadIdx.x);
+                rtab[threadIdx.x] = make_int2(__double2int_rn((M[1] * yy + M[2]) * 1024), __double2int_rn((M[4] * yy + M[5]) * 1024));
+            }
+            __syncthreads();
+        }
+        unsigned q = q_lo + threadIdx.x;
+        unsigned py = W ? q / (unsigned)W : 0u, px = W ? q % (unsigned)W : 0u;     // (inside the inner rectangle)
+        for (unsigned qb = q_lo; qb < q_hi; qb += 256u * KP) {    // (uniform trip count; lanes past the end add zeros)
+            // KP pixels per thread and trip (q, q + 256, ..): KP x 13 loads in flight
+            float v[KP][12], t[KP], fx[KP], fy[KP];
+            int xs[KP], ys[KP];
+            bool on[KP];
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                on[k] = q < q_hi;
+                const unsigned ry = on[k] ? py : ry_lo;
+                xs[k] = on[k] ? x_lo + (int)px : x_lo;
+                ys[k] = y_lo + (int)ry;
+                int2 rt, ct;
+                if (tab) {
+                    rt = rtab[ry - ry_lo];
+                    ct = ctab[xs[k]];
+                } else {
+                    rt = make_int2(__double2int_rn((M[1] * ys[k] + M[2]) * 1024), __double2int_rn((M[4] * ys[k] + M[5]) * 1024));
+                    ct = make_int2(__double2int_rn(M[0] * xs[k] * 1024), __double2int_rn(M[3] * xs[k] * 1024));
+                }
+                const int Xr = rt.x + ct.x, Yr = rt.y + ct.y;
+                const int Xq = (Xr + 16) >> 5, Yq = (Yr + 16) >> 5;
+                const int sx = Xq >> 5, sy = Yq >> 5;     // (inside the image by construction: no saturation, no test)
+                fx[k] = (Xq & 31) * (1.f / 32);
+                fy[k] = (Yq & 31) * (1.f / 32);
+                const float *r0 = I + (unsigned)((sy - 1) * cols + sx);
+                const float *r1 = r0 + cols, *r2 = r1 + cols, *r3 = r2 + cols;
+                v[k][0] = r0[0]; v[k][1] = r0[1];
+                v[k][2] = r1[-1]; v[k][3] = r1[0]; v[k][4] = r1[1]; v[k][5] = r1[2];
+                v[k][6] = r2[-1]; v[k][7] = r2[0]; v[k][8] = r2[1]; v[k][9] = r2[2];
+                v[k][10] = r3[0]; v[k][11] = r3[1];
+                t[k] = tmpl[(size_t)ys[k] * cols + xs[k]];
+                q += 256u;
+                px += 256u;
+                while (px >= (unsigned)W && W) {
+                    px -= (unsigned)W;
+                    ++py;
+                }
+            }
+            float w[KP], gx[KP], gy[KP];
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                // bilinear of I, of [-0.5 0 0.5] along x and along y over the 12-pixel footprint
+                const float a0 = v[k][0], a1 = v[k][1];
+                const float b_1 = v[k][2], b0 = v[k][3], b1 = v[k][4], b2 = v[k][5];
+                const float c_1 = v[k][6], c0 = v[k][7], c1 = v[k][8], c2 = v[k][9];
+                const float d0 = v[k][10], d1 = v[k][11];
+                const float w0 = (1.f - fy[k]) * (1.f - fx[k]), w1 = (1.f - fy[k]) * fx[k], w2 = fy[k] * (1.f - fx[k]),
+                            w3 = fy[k] * fx[k];
+                w[k] = b0 * w0 + b1 * w1 + c0 * w2 + c1 * w3;
+                gx[k] = (-0.5f * b_1 + 0.5f * b1) * w0 + (-0.5f * b0 + 0.5f * b2) * w1 +
+                        (-0.5f * c_1 + 0.5f * c1) * w2 + (-0.5f * c0 + 0.5f * c2) * w3;
+                gy[k] = (-0.5f * a0 + 0.5f * c0) * w0 + (-0.5f * a1 + 0.5f * c1) * w1 +
+                        (-0.5f * b0 + 0.5f * d0) * w2 + (-0.5f * b1 + 0.5f * d1) * w3;
+            }
+#pragma unroll
+            for (int k = 0; k < KP; ++k)
+                ecc_accumulate(acc, on[k] ? w[k] : 0.f, on[k] ? gx[k] : 0.f, on[k] ? gy[k] : 0.f, on[k] ? t[k] : 0.f, on[k],
+                               xs[k], ys[k]);
+        }
+    }
+    ecc_block_store(acc, partial, f, (int)(kEccBorderBlocks + blk));
+}
+
+// The band: top and bottom strips over the full width, left and right strips between them; generic bilinear
+// (border value 0, reflect-101 gradient taps), nearest-neighbour mask evaluated.  Workgroups first_slot .. first_slot +
+// kEccBorderBlocks - 1 of the same launch as the interior ones (as a launch of its own the band cost 55 us per 64 frames
+// behind 190 / 350 us of interior: a few trips of long dependent chains that nothing overlapped).
+__device__ __forceinline__ void ecc_border_body(const float *__restrict__ img, const float *__restrict__ tmpl, int rows,
+                                                int cols, const EccState *__restrict__ state, double *__restrict__ partial,
+                                                int f, unsigned bidx, int ident)
+{
+    const EccState &es = state[f];
+    const float *I = img + (size_t)f * rows * cols;
+    double M[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) M[i] = es.M[i];
+    double acc[kEccSums];
+#pragma unroll
+    for (int k = 0; k < kEccSums; ++k) acc[k] = 0.0;
+    auto pix = [&](int yy, int xx) { return I[(size_t)yy * cols + xx]; };
+    auto gxf = [&](int yy, int xx) {
+        return -0.5f * pix(yy, reflect101(xx - 1, cols)) + 0.5f * pix(yy, reflect101(xx + 1, cols));
+    };
+    auto gyf = [&](int yy, int xx) {
+        return -0.5f * pix(reflect101(yy - 1, rows), xx) + 0.5f * pix(reflect101(yy + 1, rows), xx);
+    };
+    const EccMargins g = ecc_margins(ident ? 3 : es.band, rows, cols);
+    const int H = rows - g.top - g.bottom, side = g.left + g.right;
+    // (32-bit indices: run_ecc refuses images of 2^31 pixels)
+    const unsigned n_top = (unsigned)g.top * (unsigned)cols, n_bot = (unsigned)g.bottom * (unsigned)cols,
+                   n_side = (unsigned)H * (unsigned)side;
+    const unsigned total = n_top + n_bot + n_side;
+    for (unsigned j = bidx * 256u + threadIdx.x; j < total; j += (unsigned)kEccBorderBlocks * 256u) {
+        int x, y;
+        if (j < n_top) {
+            y = (int)(j / (unsigned)cols);
+            x = (int)(j % (unsigned)cols);
+        } else if (j < n_top + n_bot) {
+            const unsigned q = j - n_top;
+            y = rows - g.bottom + (int)(q / (unsigned)cols);
+            x = (int)(q % (unsigned)cols);
+        } else {
+            const unsigned q = j - n_top - n_bot;
+            y = g.top + (int)(q / (unsigned)side);
+            const int k = (int)(q % (unsigned)side);
+            x = k < g.left ? k : cols - side + k;
+        }
+        const int Xr = __double2int_rn((M[1] * y + M[2]) * 1024) + __double2int_rn(M[0] * x * 1024);
+        const int Yr = __double2int_rn((M[4] * y + M[5]) * 1024) + __double2int_rn(M[3] * x * 1024);
+        const int Xq = (Xr + 16) >> 5, Yq = (Yr + 16) >> 5;
+        WarpCoord c;
+        c.sx = max(-32768, min(32767, Xq >> 5));
+        c.sy = max(-32768, min(32767, Yq >> 5));
+        c.ax = Xq & 31;
+        c.ay = Yq & 31;
+        const int nx = max(-32768, min(32767, (Xr + 512) >> 10)), ny = max(-32768, min(32767, (Yr + 512) >> 10));
+        const bool m = (unsigned)nx < (unsigned)cols && (unsigned)ny < (unsigned)rows;
+        float w, gx, gy;
+        if (c.sx >= 1 && c.sx + 2 < cols && c.sy >= 1 && c.sy + 2 < rows) {
+            // footprint and gradient taps inside the image (all of the band but its outermost ring or two): the 12 pixels
+            // directly -- the generic path below evaluates to the same operations on the same values
+            const float *r0 = I + (unsigned)((c.sy - 1) * cols + c.sx);
+            const float *r1 = r0 + cols, *r2 = r1 + cols, *r3 = r2 + cols;
+            const float a0 = r0[0], a1 = r0[1];
+            const float b_1 = r1[-1], b0 = r1[0], b1 = r1[1], b2 = r1[2];
+            const float c_1 = r2[-1], c0 = r2[0], c1 = r2[1], c2 = r2[2];
+            const float d0 = r3[0], d1 = r3[1];
+            const float fx = c.ax * (1.f / 32), fy = c.ay * (1.f / 32);
+            const float w0 = (1.f - fy) * (1.f - fx), w1 = (1.f - fy) * fx, w2 = fy * (1.f - fx), w3 = fy * fx;
+            w = b0 * w0 + b1 * w1 + c0 * w2 + c1 * w3;
+            gx = (-0.5f * b_1 + 0.5f * b1) * w0 + (-0.5f * b0 + 0.5f * b2) * w1 +
+                 (-0.5f * c_1 + 0.5f * c1) * w2 + (-0.5f * c0 + 0.5f * c2) * w3;
+            gy = (-0.5f * a0 + 0.5f * c0) * w0 + (-0.5f * a1 + 0.5f * c1) * w1 +
+                 (-0.5f * b0 + 0.5f * d0) * w2 + (-0.5f * b1 + 0.5f * d1) * w3;
+        } else {
+            w = bilinear(pix, rows, cols, c);
+            gx = bilinear(gxf, rows, cols, c);
+            gy = bilinear(gyf, rows, cols, c);
+        }
+        ecc_accumulate(acc, w, gx, gy, tmpl[(size_t)y * cols + x], m, x, y);
+    }
+    ecc_block_store(acc, partial, f, (int)bidx);
+}
+
+// grid (frames, kEccBorderBlocks + interior blocks): the frame is the FAST index, so the band blocks of all frames
+// (slots 0 .. kEccBorderBlocks-1: few trips of long dependent chains) are dispatched first and run beside the interior
+// blocks instead of after them (as the last blocks of the launch they were a 50-us tail)
+template <bool IDENT, int KP, int WAVES>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
+    ecc_sums2_kernel(const float *__restrict__ img, const float *__restrict__ tmpl, int rows, int cols,
+                     const EccState *__restrict__ state, double *__restrict__ partial)
+{
+    const int f = blockIdx.x;
+    if (state[f].done) return;
+    const unsigned nint = gridDim.y - (unsigned)kEccBorderBlocks;
+    if (blockIdx.y >= (unsigned)kEccBorderBlocks)
+        ecc_interior_body<IDENT, KP>(img, tmpl, rows, cols, state, partial, f, blockIdx.y - (unsigned)kEccBorderBlocks, nint);
+    else
+        ecc_border_body(img, tmpl, rows, cols, state, partial, f, blockIdx.y, IDENT ? 1 : 0);
 }
 
 // hal::LU32f-based inverse (cv::Mat::inv, DECOMP_LU) of a 6x6 float matrix, same operations in
@@ -601,7 +743,7 @@ __device__ bool inv6(const float *Ain, float *inv)
 // image passes (ecc.cpp): meanStdDev, rho, hessian inverse, lambda, deltaP, update.
 __global__ void __launch_bounds__(256)
     ecc_solve_kernel(EccState *__restrict__ state, const double *__restrict__ partial,
-                     int nframes, int nblocks, int max_iters, double eps)
+                     int nframes, int nblocks, int max_iters, double eps, int rows, int cols)
 {
     // one workgroup per frame: wave w reduces sums k = w, w+4, ... over the block partials
     // (lane l takes blocks l, l+64, ...; fixed shuffle tree -> deterministic), lane 0 of the
@@ -620,14 +762,14 @@ __global__ void __launch_bounds__(256)
     for (int i = 0; i < kPerWave; ++i) {
         const int k = wave + 4 * i;
         // first block of 64 partials: one independent load per sum
-        v[i] = (k < kEccSums && lane < nblocks) ? partial[((size_t)f * kEccSums + k) * kEccBlocksMax + lane] : 0.0;
+        v[i] = (k < kEccSums && lane < nblocks) ? partial[((size_t)f * kEccSums + k) * kEccStride + lane] : 0.0;
     }
     if (nblocks > 64) {   // few active frames -> more, smaller blocks per frame (same order per lane as one loop)
 #pragma unroll
         for (int i = 0; i < kPerWave; ++i) {
             const int k = wave + 4 * i;
             if (k < kEccSums) {
-                const double *pk = partial + ((size_t)f * kEccSums + k) * kEccBlocksMax;
+                const double *pk = partial + ((size_t)f * kEccSums + k) * kEccStride;
                 for (int b = lane + 64; b < nblocks; b += 64) v[i] += pk[b];
             }
         }
@@ -697,6 +839,7 @@ __global__ void __launch_bounds__(256)
     }
     es.M[0] += dp[0]; es.M[3] += dp[1]; es.M[1] += dp[2];
     es.M[4] += dp[3]; es.M[2] += dp[4]; es.M[5] += dp[5];
+    es.band = ecc_band(es.M, rows, cols);
     // for (i = 1; i <= N && fabs(rho - last_rho) >= eps; i++)
     if (es.iters >= max_iters || !(fabs(es.rho - es.last_rho) >= eps)) es.done = 1;
 }
@@ -711,6 +854,7 @@ __global__ void ecc_init_kernel(EccState *state, int nframes, long long first_fr
     es.last_rho = 0;  // set by the host wrapper to -eps
     es.iters = 0;
     es.done = (first_frame + f == 0) ? 2 : 0;  // frame 0 is not registered (psp_process.cpp:1777)
+    es.band = 3;                               // identity
 }
 
 __global__ void ecc_set_last_rho(EccState *state, int nframes, double eps)
@@ -1055,7 +1199,7 @@ int frame_scratch_ensure(FrameScratch **ps, int ncams, int batch, int rows, int 
     if (need_warp && !s->ecc_img) UPSP_HIP_CHECK(hipMalloc(&s->ecc_img, n * sizeof(float)));
     if (!s->tmp) UPSP_HIP_CHECK(hipMalloc(&s->tmp, n * sizeof(double)));
     if (need_warp && !s->partial)
-        UPSP_HIP_CHECK(hipMalloc(&s->partial, sizeof(double) * (size_t)batch * kEccBlocksMax * kEccSums));
+        UPSP_HIP_CHECK(hipMalloc(&s->partial, sizeof(double) * (size_t)batch * kEccStride * kEccSums));
     if (!s->state) UPSP_HIP_CHECK(hipMalloc(&s->state, sizeof(EccState) * (size_t)batch));
     if (!s->counter) UPSP_HIP_CHECK(hipMalloc(&s->counter, 4 * sizeof(int)));
     return UPSP_OK;
@@ -1082,21 +1226,33 @@ static int run_ecc(FrameScratch *s, const float *tmpl_blur, const uint16_t *fram
         const int burst = it == 0 ? 3 : (it < 7 ? 2 : (it < 15 ? 8 : 16));
         int blocks = kEccBlocks;
         while (blocks < kEccBlocksMax && (long long)blocks * active < 2048) blocks *= 2;
+        const int nblocks_total = blocks + kEccBorderBlocks;
         for (int k = 0; k < burst && it < max_iters; ++k, ++it) {
             {
                 KTimed kt("ecc_sums_kernel", st);
-                if (it == 0)
-                    hipLaunchKernelGGL(ecc_sums_kernel<true>, dim3(blocks, nb), dim3(256), 0, st,
-                                       (const float *)s->ecc_img, tmpl_blur, rows, cols,
-                                       (const EccState *)s->state, s->partial);
-                else
-                    hipLaunchKernelGGL(ecc_sums_kernel<false>, dim3(blocks, nb), dim3(256), 0, st,
-                                       (const float *)s->ecc_img, tmpl_blur, rows, cols,
-                                       (const EccState *)s->state, s->partial);
+#define UPSP_ECC_LAUNCH(ID, KPX, WV)                                                                          \
+    hipLaunchKernelGGL((ecc_sums2_kernel<ID, KPX, WV>), dim3(nb, blocks + kEccBorderBlocks), dim3(256), 0, st,    \
+                       (const float *)s->ecc_img, tmpl_blur, rows, cols, (const EccState *)s->state, s->partial)
+                // pixels per thread and trip / waves per SIMD, measured on 1000 frames of 1024^2 (tools/exp_ecc.sh; ms of the
+                // sums per step): general iteration 1 px 2 waves 12.2, 2 px 10.8, 3 px 10.5, 4 px 10.3; held to 3 waves
+                // (46-54 spilled registers) 13.6-14.8; identity iteration 4 px 3 waves 10.8 (with 2 px general), 8 px 10.6,
+                // 8 px 2 waves 11.1.  UPSP_ECC_VARIANT / UPSP_ECC_IVARIANT select the others.
+                static const int variant = env_int_io("UPSP_ECC_VARIANT", 2);
+                static const int ivariant = env_int_io("UPSP_ECC_IVARIANT", 1);
+                if (it == 0) {
+                    if (ivariant == 1) UPSP_ECC_LAUNCH(true, 2, 3);
+                    else if (ivariant == 2) UPSP_ECC_LAUNCH(true, 2, 2);
+                    else UPSP_ECC_LAUNCH(true, 1, 3);
+                }
+                else if (variant == 1) UPSP_ECC_LAUNCH(false, 3, 2);
+                else if (variant == 2) UPSP_ECC_LAUNCH(false, 4, 2);
+                else if (variant == 3) UPSP_ECC_LAUNCH(false, 1, 2);
+                else UPSP_ECC_LAUNCH(false, 2, 2);
+#undef UPSP_ECC_LAUNCH
             }
             KTimed kt2("ecc_solve_kernel", st);
             hipLaunchKernelGGL(ecc_solve_kernel, dim3(nb), dim3(256), 0, st, s->state,
-                               (const double *)s->partial, nb, blocks, max_iters, eps);
+                               (const double *)s->partial, nb, nblocks_total, max_iters, eps, rows, cols);
         }
         int h[3] = {0, 0, 0};
         UPSP_HIP_CHECK(hipMemsetAsync(s->counter, 0, 3 * sizeof(int), st));
