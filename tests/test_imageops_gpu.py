@@ -56,6 +56,33 @@ def test_register_pixel(gpu_lib, oracle, interp):
         assert np.array_equal(out_g.cpu().numpy(), oracle.warp_affine(fr[f], M_g, interp))
 
 
+@pytest.mark.parametrize("H,W,shift", [(96, 131, (7.3, -4.6)), (48, 64, (1.4, 0.7)), (200, 300, (-15.2, 11.8)), (33, 47, (0.3, -0.2))])
+def test_register_pixel_band(gpu_lib, oracle, H, W, shift):
+    """The ECC sums are taken by interior blocks (pixels farther than a band from every edge, no border handling) and
+    band blocks (generic bilinear); the band follows the warp.  Odd image sizes, shifts of many pixels (wide bands, a band
+    that swallows most of a small image), shear: same iteration count and warp as the oracle."""
+    import torch
+    from upsp_processing_amd import engine
+    rng = np.random.default_rng(H * W)
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    def scene(y, x):
+        return (1800 + 700 * np.sin(2 * np.pi * 3 * x / W) * np.cos(2 * np.pi * 2 * y / H)
+                + 400 * np.exp(-((x - 0.6 * W) ** 2 + (y - 0.4 * H) ** 2) / (0.02 * W * H)))
+    ref16 = np.clip(scene(yy, xx) + rng.normal(0, 2, (H, W)), 0, 4095).astype(np.uint16)
+    A = np.array([[1.0 + 2e-3, 1.5e-3, shift[0]], [-1e-3, 1.0 - 1e-3, shift[1]]])
+    xs = A[0, 0] * xx + A[0, 1] * yy + A[0, 2]
+    ys = A[1, 0] * xx + A[1, 1] * yy + A[1, 2]
+    inp16 = np.clip(scene(ys, xs) + rng.normal(0, 2, (H, W)), 0, 4095).astype(np.uint16)
+    ref = ref16.astype(np.float32)
+    out_g, M_g, it_g = engine.register_pixel(torch.as_tensor(ref).cuda(), torch.as_tensor(inp16.copy()).cuda(), interp=1)
+    out_o, M_o, it_o = oracle.register_pixel(ref, inp16, interp=1)
+    assert it_g == it_o, (it_g, it_o)
+    assert it_o >= 2
+    assert np.abs(M_g[:, :2] - M_o[:, :2]).max() <= 1e-4
+    assert np.abs(M_g[:, 2] - M_o[:, 2]).max() <= 2e-3
+    assert np.array_equal(out_g.cpu().numpy(), oracle.warp_affine(inp16, M_g, 1))
+
+
 def test_patch(gpu_lib, oracle):
     import torch
     from upsp_processing_amd import engine
