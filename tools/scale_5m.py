@@ -32,6 +32,15 @@ centers = np.array([engine.camera_center(_capi.make_camera(*(lambda c: (c["K"], 
 w = engine.projection_weights(pix, dn, dm, centers, "average_view")
 sk, ns = engine.skipped_nodes(pix)
 print("skipped", ns, "of", v.shape[0])
+if os.environ.get("UPSP_EXP_PIXEL_ORDER"):
+    # experiment: the model's nodes renumbered by the pixel of the first camera that sees them, so that nodes reading
+    # the same pixel series are neighbours in pass B
+    key = torch.full((v.shape[0],), 1 << 30, dtype=torch.int64, device="cuda")
+    for c in range(3, -1, -1):
+        key = torch.where(pix[c] >= 0, pix[c].long() + (c << 24), key)
+    perm = torch.argsort(key, stable=True)
+    pix = pix[:, perm].contiguous(); w = w[:, perm].contiguous(); sk = sk[perm].contiguous()
+    print("nodes renumbered in pixel order")
 for F in (1000,):
     frames = [syn.synth_frames_torch(F, size, size, first=100 * c) for c in range(4)]
     for mode, name in ((2, "scan + gather"), (1, "streamed (pass A per camera, whole-row pass B)")):
