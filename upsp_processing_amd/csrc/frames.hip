@@ -867,10 +867,45 @@ __global__ void __launch_bounds__(256)
         const int r = j * RPS + sub;                            // (uniform per wave)
         const int k = s_k[r], row = s_row[r];
         const bool sk = s_sk[r] != 0;
+        if (sk || k == -1) {
+            // (uniform per wave) a row without data -- no camera sees the node: NaN; no pixel: 0 -- is a constant fill:
+            // no load, no sums, no reductions (its partials are not read below).  These are 60 % of the rows of the bench
+            // model, and the kernel was bound by its VALU instructions (PMC: 194 M wave-instructions per launch = 0.32 of
+            // its 0.40 ms at one per 4 cycles), most of them the per-row reductions.
+            if (row >= 0 && f0 < nframes) {
+                if (!U16) {
+                    float *dst = rows_t + (long long)row * ld_t + f0;
+                    typedef float v4f __attribute__((ext_vector_type(4)));
+                    const float c = sk ? qnan : 0.0f;
+                    const v4f nv = {c, c, c, c};
+                    if (vec_ok && f0 + 3 < nframes) {
+                        __builtin_nontemporal_store(nv, reinterpret_cast<v4f *>(dst));
+                    } else {
+                        dst[0] = c;
+                        if (f0 + 1 < nframes) dst[1] = c;
+                        if (f0 + 2 < nframes) dst[2] = c;
+                        if (f0 + 3 < nframes) dst[3] = c;
+                    }
+                } else {
+                    uint16_t *dst = rows_t16 + (long long)row * ld_t + f0;
+                    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+                    const v2u nv = {0u, 0u};
+                    if (vec_ok && f0 + 3 < nframes) {
+                        __builtin_nontemporal_store(nv, reinterpret_cast<v2u *>(dst));
+                    } else {
+                        dst[0] = 0;
+                        if (f0 + 1 < nframes) dst[1] = 0;
+                        if (f0 + 2 < nframes) dst[2] = 0;
+                        if (f0 + 3 < nframes) dst[3] = 0;
+                    }
+                }
+            }
+            continue;
+        }
         uint2 w = make_uint2(0u, 0u);
         // (ordinary loads: the compact buffer was written a moment ago and sits in L2 / Infinity Cache)
-        if (k >= 0 && !sk && f0 < nframes) w = *reinterpret_cast<const uint2 *>(compact + (size_t)k * cpitch + f0);
-        if (k == -2 && !sk && f0 < nframes) {                   // (rare) pixel outside the candidate map: from the frames
+        if (k >= 0 && f0 < nframes) w = *reinterpret_cast<const uint2 *>(compact + (size_t)k * cpitch + f0);
+        if (k == -2 && f0 < nframes) {                          // (rare) pixel outside the candidate map: from the frames
             const size_t pp = (size_t)pix[n0 + (unsigned)r];
             unsigned v[4];
 #pragma unroll
