@@ -1261,10 +1261,11 @@ static int run_ecc(FrameScratch *s, const float *tmpl_blur, const uint16_t *fram
     hipLaunchKernelGGL((ecc_sums2_kernel<ID, KPX, WV>), dim3(nb, blocks + kEccBorderBlocks), dim3(256), 0, st,    \
                        (const float *)s->ecc_img, tmpl_blur, rows, cols, (const EccState *)s->state, s->partial)
                 // pixels per thread and trip / waves per SIMD, measured on 1000 frames of 1024^2 (tools/exp_ecc.sh; ms of the
-                // sums per step): general iteration 1 px 2 waves 12.2, 2 px 10.8, 3 px 10.5, 4 px 10.3; held to 3 waves
-                // (46-54 spilled registers) 13.6-14.8; identity iteration 4 px 3 waves 10.8 (with 2 px general), 8 px 10.6,
-                // 8 px 2 waves 11.1.  UPSP_ECC_VARIANT / UPSP_ECC_IVARIANT select the others.
-                static const int variant = env_int_io("UPSP_ECC_VARIANT", 2);
+                // sums per step): general iteration 2 px at 3 waves per SIMD (162 VGPRs) 8.7; at 2 waves: 1 px 12.2, 2 px 10.1,
+                // 3 px 10.5, 4 px 9.6; 1 px at 3 waves 9.9, 3 px at 3 waves (10 spilled registers) 10.0; identity iteration
+                // 4 px at 3 waves 9.9 (with the default general form), 8 px 9.6, 8 px at 2 waves 10.4.
+                // UPSP_ECC_VARIANT / UPSP_ECC_IVARIANT select the others.
+                static const int variant = env_int_io("UPSP_ECC_VARIANT", 4);
                 static const int ivariant = env_int_io("UPSP_ECC_IVARIANT", 1);
                 if (it == 0) {
                     if (ivariant == 1) UPSP_ECC_LAUNCH(true, 2, 3);
@@ -1274,6 +1275,9 @@ static int run_ecc(FrameScratch *s, const float *tmpl_blur, const uint16_t *fram
                 else if (variant == 1) UPSP_ECC_LAUNCH(false, 3, 2);
                 else if (variant == 2) UPSP_ECC_LAUNCH(false, 4, 2);
                 else if (variant == 3) UPSP_ECC_LAUNCH(false, 1, 2);
+                else if (variant == 4) UPSP_ECC_LAUNCH(false, 2, 3);
+                else if (variant == 5) UPSP_ECC_LAUNCH(false, 1, 3);
+                else if (variant == 6) UPSP_ECC_LAUNCH(false, 3, 3);
                 else UPSP_ECC_LAUNCH(false, 2, 2);
 #undef UPSP_ECC_LAUNCH
             }
