@@ -12,6 +12,7 @@ bvh = engine.BVH(s9)
 d_nodes, d_nrm, d_tn = [torch.as_tensor(x).cuda() for x in (verts, nrm, tn)]
 bvh.set_tri_nodes(d_tn, verts.shape[0])
 for r in range(3):
-    p = engine.build_projection(bvh, cam, d_nodes, d_nrm, d_tn, 70.0)
+    p = engine.build_projection(bvh, cam, d_nodes, d_nrm, d_tn, 70.0, counts="ref" in sys.argv[1:])
+    if "nrays" not in p: p.update(engine.projection_counts(bvh))
 torch.cuda.synchronize()
 print(p["nrays"], p["primary_rays"], p["retry_nodes"])
