@@ -6,7 +6,8 @@ import bench
 from upsp_processing_amd import _capi, engine, synthetic as syn
 size = 1024
 fill = "fill" in sys.argv[1:]
-verts, tris = syn.cube_sphere(289, 6.0) if fill else syn.tunnel_model_quad()
+uv = "uv" in sys.argv[1:]
+verts, tris = syn.cube_sphere(289, 6.0) if fill else syn.tunnel_model() if uv else syn.tunnel_model_quad()
 s9, tn = syn.soup(verts, tris)
 cd = syn.pinhole_camera(size, size, center=(0, 0, 20), half_extent=6.0)
 bvh = engine.BVH(s9)
@@ -25,7 +26,7 @@ for want in (("hit", "t", "prim"), ("hit", "t", "prim", "uvw", "pos", "nrm")):
     torch.cuda.synchronize()
     _capi.timing_enable(False)
     rep = _capi.timing_report()
-    print("%s model, outputs %s: %.1f us per call; hit %.3f; " % ("fill" if fill else "tunnel", "+".join(want), e0.elapsed_time(e1) / 5 * 1e3, h["hit"].float().mean().item()) +
+    print("%s model, outputs %s: %.1f us per call; hit %.3f; " % ("fill" if fill else "uv" if uv else "tunnel", "+".join(want), e0.elapsed_time(e1) / 5 * 1e3, h["hit"].float().mean().item()) +
           "  ".join("%s %.1f us" % (k, v[1] / v[0] * 1e3) for k, v in rep.items() if v[0]), flush=True)
 occ = bvh.occluded(d_org, d_dirs)
 torch.cuda.synchronize()

@@ -518,7 +518,7 @@ __device__ __forceinline__ void trav_run(Trav &s, const Ray &r, const Scene &sc,
             }
         }
         if (more && __popcll(__ballot(s.cur != kDone)) < refill) break;
-        if (!ANYHIT && sc.heavy_steps && __ballot(s.cur != kDone && s.steps > sc.heavy_steps) != 0ull) break;
+        if (sc.heavy_steps && __ballot(s.cur != kDone && s.steps > sc.heavy_steps) != 0ull) break;
     }
 }
 
@@ -665,6 +665,8 @@ __device__ __forceinline__ void flush_stats(unsigned *work, int *lds, unsigned n
 // ------------------------------------------------------------------------
 //  Batch query kernel: n independent rays (closest hit or occlusion).
 // ------------------------------------------------------------------------
+constexpr int kWorkHeavyCast = 16;    // rays cast_kernel handed to heavy_cast_kernel (the projection's [16], [17] alike)
+constexpr unsigned kHeavyCapCast = 65536;
 constexpr int kWorkPrimaryCount = 18; // length of the dense ray list of the pass that runs (cast_entry_kernel /
                                       // retry_list_kernel<kPixInFrame>)
 
@@ -794,7 +796,20 @@ __global__ void __launch_bounds__(kBlock)
         // ---- traverse ----
         if (busy) {
             trav_run<ANYHIT, STATS>(s, r, sc, stack, queue_has_more(q), sc.refill);
-            if (s.cur == kDone) {
+            if (!STATS && sc.heavy_steps && s.cur != kDone && s.steps > sc.heavy_steps) {
+                // a ray that keeps going (through a vertex shared by ~1000 triangles, along a stack of slivers): handed
+                // to heavy_cast_kernel, where a whole wave walks it (see heavy_kernel)
+                const unsigned slot = atomicAdd(&work[kWorkHeavyCast], 1u);
+                if (slot < kHeavyCapCast) {
+                    sc.heavy_items[slot] = item;
+                    s.cur = kDone;
+                    s.sp = 0;
+                    busy = false;
+                } else {
+                    s.steps = 0;     // list full: carry on here
+                }
+            }
+            if (busy && s.cur == kDone) {
                 if (STATS) {
                     atomicMax(&work[8], s.ray_nodes);
                     atomicMax(&work[9], s.ray_tris);
@@ -1351,6 +1366,166 @@ struct HeavyBest {
     unsigned long long key;
     int slot;
 };
+// The wave-wide walk of one ray (see heavy_kernel): all 64 lanes of a one-wave workgroup call it with the same ray;
+// q_* are the workgroup's LDS stack arrays (kHeavyStack entries).  Out: whether any triangle is hit and the slot of the
+// reference's closest hit.  STOP_AT_ANY (occlusion queries): the walk ends with the first round that finds a hit.
+template <bool STOP_AT_ANY>
+__device__ __forceinline__ void heavy_walk(const Ray &r, const Scene &sc, int *q_ref, unsigned long long *q_key,
+                                           unsigned char *q_depth, bool &any_w, int &best_slot)
+{
+    const unsigned lane = threadIdx.x;
+    unsigned top = 0;                         // (wave-uniform) entries on the stack
+    if (box_hit(r, sc.rlo[0], sc.rlo[1], sc.rlo[2], sc.rhi[0], sc.rhi[1], sc.rhi[2])) {   // trav_begin
+        if (lane == 0) {
+            q_ref[0] = sc.root_ref;
+            q_key[0] = 0ull;
+            q_depth[0] = 0;
+        }
+        top = 1;
+    }
+    __syncthreads();
+    HeavyBest best;
+    best.t = FLT_MAX;
+    best.key = ~0ull;
+    best.slot = -1;
+    bool any = false, overflow = false;
+    while (top > 0) {
+        if (STOP_AT_ANY && __ballot(any) != 0ull) break;
+        const unsigned n = min(top, 64u);
+        const bool have = lane < n;
+        int ref = 0;
+        unsigned long long key = 0ull;
+        unsigned depth = 0;
+        if (have) {
+            ref = q_ref[top - n + lane];
+            key = q_key[top - n + lane];
+            depth = q_depth[top - n + lane];
+        }
+        top -= n;
+        __syncthreads();
+        bool pF = false, pS = false;
+        int first = 0, second = 0;
+        if (have && ref >= 0) {
+            const float4 *np = sc.nodes + 4 * (size_t)ref;
+            const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+            const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
+            const unsigned meta = __float_as_uint(q3.z);
+            const bool hL = box_hit(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
+            const bool hR = box_hit(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w);
+            const bool swap = !(meta & kMetaOrdered) && ((r.neg >> (meta & 3u)) & 1u);
+            first = swap ? right : left;
+            second = swap ? left : right;
+            pF = swap ? hR : hL;
+            pS = swap ? hL : hR;
+        } else if (have) {
+            const unsigned code = (unsigned)(~ref);
+            const unsigned f0 = code >> kLeafBits, cnt = (code & (kMaxLeaf - 1)) + 1;
+            for (unsigned i = 0; i < cnt; ++i) {
+                const float4 *tp = sc.tris + 3 * (size_t)(f0 + i);
+                const float4 a = tp[0], b = tp[1], c = tp[2];
+                TriHit th;
+                if (tri_test(r, a.x, a.y, a.z, b.x, b.y, b.z, c.x, c.y, c.z, th)) {
+                    any = true;
+                    const unsigned long long k = key | (unsigned long long)i;
+                    if (th.t < best.t || (th.t == best.t && k < best.key)) {
+                        best.t = th.t;
+                        best.key = k;
+                        best.slot = (int)(f0 + i);
+                    }
+                }
+            }
+        }
+        // push the accepted children (wave-wide prefix counts); the level's bit sits below the bits of the levels above
+        const unsigned long long mF = __ballot(pF), mS = __ballot(pS);
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        const unsigned add = (unsigned)__popcll(mF) + (unsigned)__popcll(mS);
+        if (top + add > sc.heavy_stack || __ballot(have && ref >= 0 && depth >= 56u) != 0ull) {
+            overflow = true;   // more open boxes than the stack holds (or deeper than the keys): lane 0 walks it alone
+            break;
+        }
+        const unsigned pos = top + (unsigned)__popcll(mF & lt) + (unsigned)__popcll(mS & lt);
+        const unsigned long long bit = 1ull << (62u - depth);
+        // the child visited FIRST must be popped... in any order: the keys decide, not the order of the stack
+        if (pF) {
+            q_ref[pos] = first;
+            q_key[pos] = key;
+            q_depth[pos] = (unsigned char)(depth + 1u);
+        }
+        if (pS) {
+            const unsigned p2 = pos + (pF ? 1u : 0u);
+            q_ref[p2] = second;
+            q_key[p2] = key | bit;
+            q_depth[p2] = (unsigned char)(depth + 1u);
+        }
+        top += add;
+        __syncthreads();
+    }
+    __syncthreads();
+    if (overflow) {
+        // the reference's loop as it stands (pspRT.cpp:380-423), one lane, its stack in q_ref
+        best.t = FLT_MAX;
+        best.key = ~0ull;
+        best.slot = -1;
+        any = false;
+        if (lane == 0) {
+            int sp = 0;
+            int cur = sc.root_ref;
+            for (;;) {
+                if (cur >= 0) {
+                    const float4 *np = sc.nodes + 4 * (size_t)cur;
+                    const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+                    const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
+                    const unsigned meta = __float_as_uint(q3.z);
+                    const bool hL = box_hit(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
+                    const bool hR = box_hit(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w);
+                    const bool swap = !(meta & kMetaOrdered) && ((r.neg >> (meta & 3u)) & 1u);
+                    const int first = swap ? right : left, second = swap ? left : right;
+                    const bool hF = swap ? hR : hL, hS = swap ? hL : hR;
+                    if (hF) {
+                        cur = first;
+                        if (hS) q_ref[sp++] = second;
+                        continue;
+                    }
+                    if (hS) {
+                        cur = second;
+                        continue;
+                    }
+                } else {
+                    const unsigned code = (unsigned)(~cur);
+                    const unsigned f0 = code >> kLeafBits, cnt = (code & (kMaxLeaf - 1)) + 1;
+                    for (unsigned i = 0; i < cnt; ++i) {
+                        const float4 *tp = sc.tris + 3 * (size_t)(f0 + i);
+                        const float4 a = tp[0], b = tp[1], c = tp[2];
+                        TriHit th;
+                        if (tri_test(r, a.x, a.y, a.z, b.x, b.y, b.z, c.x, c.y, c.z, th)) {
+                            any = true;
+                            if (th.t < best.t) {
+                                best.t = th.t;
+                                best.key = 0ull;
+                                best.slot = (int)(f0 + i);
+                            }
+                        }
+                    }
+                }
+                if (sp == 0) break;
+                cur = q_ref[--sp];
+            }
+        }
+    }
+    // wave-wide winner: smallest t, then smallest key
+    float bt = best.t;
+    for (int off = 32; off > 0; off >>= 1) bt = fminf(bt, __shfl_xor(bt, off));
+    unsigned long long bk = best.t == bt ? best.key : ~0ull;
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(bk, off);
+        bk = o < bk ? o : bk;
+    }
+    any_w = __ballot(any) != 0ull;
+    const unsigned long long win = __ballot(any && best.t == bt && best.key == bk);
+    const int wl = win ? __ffsll((long long)win) - 1 : 0;
+    best_slot = __shfl(best.slot, wl);
+}
+
 template <int PHASE>
 __global__ void __launch_bounds__(64)
     heavy_kernel(Scene sc, Cam cam, const float *__restrict__ nodes, const int32_t *__restrict__ tri_nodes,
@@ -1376,155 +1551,9 @@ __global__ void __launch_bounds__(64)
             retry_ray(r, cam, nodes, node, (int)(item % 6u));
         }
         ray_classify(r, sc);
-        unsigned top = 0;                         // (wave-uniform) entries on the stack
-        if (box_hit(r, sc.rlo[0], sc.rlo[1], sc.rlo[2], sc.rhi[0], sc.rhi[1], sc.rhi[2])) {   // trav_begin
-            if (lane == 0) {
-                q_ref[0] = sc.root_ref;
-                q_key[0] = 0ull;
-                q_depth[0] = 0;
-            }
-            top = 1;
-        }
-        __syncthreads();
-        HeavyBest best;
-        best.t = FLT_MAX;
-        best.key = ~0ull;
-        best.slot = -1;
-        bool any = false, overflow = false;
-        while (top > 0) {
-            const unsigned n = min(top, 64u);
-            const bool have = lane < n;
-            int ref = 0;
-            unsigned long long key = 0ull;
-            unsigned depth = 0;
-            if (have) {
-                ref = q_ref[top - n + lane];
-                key = q_key[top - n + lane];
-                depth = q_depth[top - n + lane];
-            }
-            top -= n;
-            __syncthreads();
-            bool pF = false, pS = false;
-            int first = 0, second = 0;
-            if (have && ref >= 0) {
-                const float4 *np = sc.nodes + 4 * (size_t)ref;
-                const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
-                const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
-                const unsigned meta = __float_as_uint(q3.z);
-                const bool hL = box_hit(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
-                const bool hR = box_hit(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w);
-                const bool swap = !(meta & kMetaOrdered) && ((r.neg >> (meta & 3u)) & 1u);
-                first = swap ? right : left;
-                second = swap ? left : right;
-                pF = swap ? hR : hL;
-                pS = swap ? hL : hR;
-            } else if (have) {
-                const unsigned code = (unsigned)(~ref);
-                const unsigned f0 = code >> kLeafBits, cnt = (code & (kMaxLeaf - 1)) + 1;
-                for (unsigned i = 0; i < cnt; ++i) {
-                    const float4 *tp = sc.tris + 3 * (size_t)(f0 + i);
-                    const float4 a = tp[0], b = tp[1], c = tp[2];
-                    TriHit th;
-                    if (tri_test(r, a.x, a.y, a.z, b.x, b.y, b.z, c.x, c.y, c.z, th)) {
-                        any = true;
-                        const unsigned long long k = key | (unsigned long long)i;
-                        if (th.t < best.t || (th.t == best.t && k < best.key)) {
-                            best.t = th.t;
-                            best.key = k;
-                            best.slot = (int)(f0 + i);
-                        }
-                    }
-                }
-            }
-            // push the accepted children (wave-wide prefix counts); the level's bit sits below the bits of the levels above
-            const unsigned long long mF = __ballot(pF), mS = __ballot(pS);
-            const unsigned long long lt = (1ull << lane) - 1ull;
-            const unsigned add = (unsigned)__popcll(mF) + (unsigned)__popcll(mS);
-            if (top + add > sc.heavy_stack || __ballot(have && ref >= 0 && depth >= 56u) != 0ull) {
-                overflow = true;   // more open boxes than the stack holds (or deeper than the keys): lane 0 walks it alone
-                break;
-            }
-            const unsigned pos = top + (unsigned)__popcll(mF & lt) + (unsigned)__popcll(mS & lt);
-            const unsigned long long bit = 1ull << (62u - depth);
-            // the child visited FIRST must be popped... in any order: the keys decide, not the order of the stack
-            if (pF) {
-                q_ref[pos] = first;
-                q_key[pos] = key;
-                q_depth[pos] = (unsigned char)(depth + 1u);
-            }
-            if (pS) {
-                const unsigned p2 = pos + (pF ? 1u : 0u);
-                q_ref[p2] = second;
-                q_key[p2] = key | bit;
-                q_depth[p2] = (unsigned char)(depth + 1u);
-            }
-            top += add;
-            __syncthreads();
-        }
-        __syncthreads();
-        if (overflow) {
-            // the reference's loop as it stands (pspRT.cpp:380-423), one lane, its stack in q_ref
-            best.t = FLT_MAX;
-            best.key = ~0ull;
-            best.slot = -1;
-            any = false;
-            if (lane == 0) {
-                int sp = 0;
-                int cur = sc.root_ref;
-                for (;;) {
-                    if (cur >= 0) {
-                        const float4 *np = sc.nodes + 4 * (size_t)cur;
-                        const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
-                        const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
-                        const unsigned meta = __float_as_uint(q3.z);
-                        const bool hL = box_hit(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
-                        const bool hR = box_hit(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w);
-                        const bool swap = !(meta & kMetaOrdered) && ((r.neg >> (meta & 3u)) & 1u);
-                        const int first = swap ? right : left, second = swap ? left : right;
-                        const bool hF = swap ? hR : hL, hS = swap ? hL : hR;
-                        if (hF) {
-                            cur = first;
-                            if (hS) q_ref[sp++] = second;
-                            continue;
-                        }
-                        if (hS) {
-                            cur = second;
-                            continue;
-                        }
-                    } else {
-                        const unsigned code = (unsigned)(~cur);
-                        const unsigned f0 = code >> kLeafBits, cnt = (code & (kMaxLeaf - 1)) + 1;
-                        for (unsigned i = 0; i < cnt; ++i) {
-                            const float4 *tp = sc.tris + 3 * (size_t)(f0 + i);
-                            const float4 a = tp[0], b = tp[1], c = tp[2];
-                            TriHit th;
-                            if (tri_test(r, a.x, a.y, a.z, b.x, b.y, b.z, c.x, c.y, c.z, th)) {
-                                any = true;
-                                if (th.t < best.t) {
-                                    best.t = th.t;
-                                    best.key = 0ull;
-                                    best.slot = (int)(f0 + i);
-                                }
-                            }
-                        }
-                    }
-                    if (sp == 0) break;
-                    cur = q_ref[--sp];
-                }
-            }
-        }
-        // wave-wide winner: smallest t, then smallest key
-        float bt = best.t;
-        for (int off = 32; off > 0; off >>= 1) bt = fminf(bt, __shfl_xor(bt, off));
-        unsigned long long bk = best.t == bt ? best.key : ~0ull;
-        for (int off = 32; off > 0; off >>= 1) {
-            const unsigned long long o = __shfl_xor(bk, off);
-            bk = o < bk ? o : bk;
-        }
-        const bool any_w = __ballot(any) != 0ull;
-        const unsigned long long win = __ballot(any && best.t == bt && best.key == bk);
-        const int wl = win ? __ffsll((long long)win) - 1 : 0;
-        const int best_slot = __shfl(best.slot, wl);
+        bool any_w;
+        int best_slot;
+        heavy_walk<false>(r, sc, q_ref, q_key, q_depth, any_w, best_slot);
         if (lane == 0) {
             {
                 bool visible = false;
@@ -1538,6 +1567,40 @@ __global__ void __launch_bounds__(64)
                 } else if (visible) {
                     atomicOr(&retry_mask[item / 6u], 1u << (item % 6u));
                 }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// The same walk for the rays a batch query gave up (cast_kernel): full hit record, or the occlusion flag.
+template <bool ANYHIT>
+__global__ void __launch_bounds__(64)
+    heavy_cast_kernel(Scene sc, const float *__restrict__ org, int org_stride, const float *__restrict__ dir,
+                      upsp_hits out, const unsigned *__restrict__ work)
+{
+    __shared__ int q_ref[kHeavyStack];
+    __shared__ unsigned long long q_key[kHeavyStack];
+    __shared__ unsigned char q_depth[kHeavyStack];
+    const unsigned count = min(work[kWorkHeavyCast], kHeavyCap);
+    for (unsigned h = blockIdx.x; h < count; h += gridDim.x) {
+        const unsigned item = sc.heavy_items[h];
+        const float *o = org + (size_t)org_stride * item;
+        const float *d = dir + 3 * (size_t)item;
+        Ray r;
+        ray_setup(r, o[0], o[1], o[2], d[0], d[1], d[2]);
+        ray_classify(r, sc);
+        bool any_w;
+        int best_slot;
+        heavy_walk<ANYHIT>(r, sc, q_ref, q_key, q_depth, any_w, best_slot);
+        if (threadIdx.x == 0) {
+            if (ANYHIT) {
+                if (out.hit) out.hit[item] = any_w ? 1 : 0;
+            } else {
+                Trav s;
+                s.any = any_w;
+                s.best_slot = any_w ? best_slot : -1;
+                write_hit(r, sc, s, item, out);
             }
         }
         __syncthreads();
@@ -1809,6 +1872,26 @@ int launch_cast(const upsp_bvh *cb, const float *d_org, int org_stride, const fl
     UPSP_HIP_CHECK(hipMemsetAsync(b->d_work, 0, kWorkWords * sizeof(unsigned), st));
     const int grid = grid_for(n, lds);
     Scene sc = make_scene(b, n, grid);
+    // rays that need more than this many node visits + triangle tests leave the one-lane traversal (heavy_cast_kernel).
+    // Measured on the bench's 1 Mi pixel rays (tools/exp_heavy_cast.sh; us per call):
+    //   UV-sphere tunnel model (1000-triangle polar fans, slivers): off 1307, 640: 940, 384: 703, 256: 519, 160: 397, 128: 352
+    //   frame-filling cube sphere (42 % hits, many long grazing rays): off 564, 384: 582, 256: 583, 160: 662, 128: 679
+    //   cube-sphere tunnel model: off 166, any threshold 174-180 (the empty launch)
+    // -- above the projection's 160: a batch may hold any ray, and thousands that are merely long are cheaper where they are
+    static const int heavy_steps = env_int("UPSP_HEAVY_STEPS_CAST", 256);
+    const bool heavy_on = heavy_steps > 0 && !b->stats_on && b->info.depth <= 56;
+    if (heavy_on) {
+        if (!b->d_heavy) UPSP_HIP_CHECK(hipMalloc(&b->d_heavy, sizeof(unsigned) * kHeavyCap));
+        sc.heavy_steps = (unsigned)heavy_steps;
+        sc.heavy_items = b->d_heavy;
+        sc.heavy_stack = kHeavyStack;
+    }
+    auto launch_heavy = [&]() {
+        if (!heavy_on) return;
+        KTimed kth("heavy_cast_kernel", st);
+        hipLaunchKernelGGL((heavy_cast_kernel<ANYHIT>), dim3(512), dim3(64), 0, st, sc, d_org, org_stride, d_dir, out,
+                           (const unsigned *)b->d_work);
+    };
     if (n >= 65536) prefetch_bvh(b, st);
     static const bool two_pass = env_int("UPSP_CAST_TWO_PASS", 1) != 0;
     if (two_pass && n >= 65536 && !b->stats_on) {
@@ -1827,19 +1910,25 @@ int launch_cast(const upsp_bvh *cb, const float *d_org, int org_stride, const fl
             hipLaunchKernelGGL((cast_entry_kernel<ANYHIT>), egrid, dim3(256), 0, st, sc, d_org, org_stride, d_dir,
                                (unsigned)n, out, b->d_cast_list, b->d_work);
         }
-        KTimed kt(ANYHIT ? "cast_kernel<anyhit>" : "cast_kernel<closest>", st);
-        hipLaunchKernelGGL((cast_kernel<ANYHIT, false, true>), dim3(grid), dim3(kBlock), lds, st, sc,
-                           d_org, org_stride, d_dir, (unsigned)n, out, b->d_work, (const unsigned *)b->d_cast_list);
+        {
+            KTimed kt(ANYHIT ? "cast_kernel<anyhit>" : "cast_kernel<closest>", st);
+            hipLaunchKernelGGL((cast_kernel<ANYHIT, false, true>), dim3(grid), dim3(kBlock), lds, st, sc,
+                               d_org, org_stride, d_dir, (unsigned)n, out, b->d_work, (const unsigned *)b->d_cast_list);
+        }
+        launch_heavy();
         UPSP_HIP_CHECK(hipGetLastError());
         return UPSP_OK;
     }
-    KTimed kt(ANYHIT ? "cast_kernel<anyhit>" : "cast_kernel<closest>", st);
-    if (b->stats_on)
-        hipLaunchKernelGGL((cast_kernel<ANYHIT, true>), dim3(grid), dim3(kBlock), lds, st, sc,
-                           d_org, org_stride, d_dir, (unsigned)n, out, b->d_work);
-    else
-        hipLaunchKernelGGL((cast_kernel<ANYHIT, false>), dim3(grid), dim3(kBlock), lds, st, sc,
-                           d_org, org_stride, d_dir, (unsigned)n, out, b->d_work);
+    {
+        KTimed kt(ANYHIT ? "cast_kernel<anyhit>" : "cast_kernel<closest>", st);
+        if (b->stats_on)
+            hipLaunchKernelGGL((cast_kernel<ANYHIT, true>), dim3(grid), dim3(kBlock), lds, st, sc,
+                               d_org, org_stride, d_dir, (unsigned)n, out, b->d_work);
+        else
+            hipLaunchKernelGGL((cast_kernel<ANYHIT, false>), dim3(grid), dim3(kBlock), lds, st, sc,
+                               d_org, org_stride, d_dir, (unsigned)n, out, b->d_work);
+    }
+    launch_heavy();
     UPSP_HIP_CHECK(hipGetLastError());
     if (b->stats_on) return read_stats(b, st);
     return UPSP_OK;
