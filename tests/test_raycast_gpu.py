@@ -163,6 +163,30 @@ def test_large_batch_two_pass_bitwise(gpu_lib, oracle):
     assert np.array_equal(bvh.occluded(org, d2).cpu().numpy(), o["hit"])
 
 
+@pytest.mark.parametrize("steps", [3, 40])
+def test_heavy_rays_of_a_batch(gpu_lib, oracle, monkeypatch, steps):
+    """Batch queries hand rays that exceed UPSP_HEAVY_STEPS_CAST node visits + triangle tests (default 256: rays through
+    the 1000-triangle polar fans of a UV sphere) to a kernel in which a whole wave walks one ray.  With a threshold of a
+    few steps most rays take that road: full hit records and occlusion flags against the oracle, small and large batches
+    (the latter through the two-pass form), rays aimed at the poles."""
+    import os
+    from upsp_processing_amd import engine, synthetic as syn
+    monkeypatch.setenv("UPSP_HEAVY_STEPS_CAST", str(steps))
+    v, t = syn.tunnel_model(60, 300, 24, 48)
+    s9, _ = syn.soup(v, t)
+    bvh, obv = engine.BVH(s9), oracle.OracleBVH(s9)
+    thr = os.cpu_count() or 1
+    rng = np.random.default_rng(11)
+    cam = np.array([0.2, 0.1, 20.0], np.float32)
+    for n in (6000, 90_000):
+        tgt = v[rng.integers(0, v.shape[0], n)] + rng.normal(size=(n, 3)).astype(np.float32) * rng.choice([0.0, 1e-3, 0.4], (n, 1))
+        tgt[::7] = v[np.argmax(np.abs(v[:, 0]))]            # a pole of the stretched sphere
+        d = (tgt - cam).astype(np.float32)
+        g, o = bvh.intersect(cam, d), obv.intersect(cam, d, threads=thr)
+        assert_hits_equal(g, o)
+        assert np.array_equal(bvh.occluded(cam, d).cpu().numpy(), o["hit"])
+
+
 def test_full_size_properties(gpu_lib):
     """BASELINE config size (1 M-tri model, 1 Mi rays): size-independent properties.
     * scale invariance of the hit set: d and 2d hit the same triangle with t/2;

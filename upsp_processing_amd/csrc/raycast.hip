@@ -1878,7 +1878,7 @@ int launch_cast(const upsp_bvh *cb, const float *d_org, int org_stride, const fl
     //   frame-filling cube sphere (42 % hits, many long grazing rays): off 564, 384: 582, 256: 583, 160: 662, 128: 679
     //   cube-sphere tunnel model: off 166, any threshold 174-180 (the empty launch)
     // -- above the projection's 160: a batch may hold any ray, and thousands that are merely long are cheaper where they are
-    static const int heavy_steps = env_int("UPSP_HEAVY_STEPS_CAST", 256);
+    const int heavy_steps = env_int("UPSP_HEAVY_STEPS_CAST", 256);   // (read per call: the tests move it)
     const bool heavy_on = heavy_steps > 0 && !b->stats_on && b->info.depth <= 56;
     if (heavy_on) {
         if (!b->d_heavy) UPSP_HIP_CHECK(hipMalloc(&b->d_heavy, sizeof(unsigned) * kHeavyCap));
