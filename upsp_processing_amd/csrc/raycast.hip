@@ -1366,23 +1366,32 @@ struct HeavyBest {
     unsigned long long key;
     int slot;
 };
-// The wave-wide walk of one ray (see heavy_kernel): all 64 lanes of a one-wave workgroup call it with the same ray;
-// q_* are the workgroup's LDS stack arrays (kHeavyStack entries).  Out: whether any triangle is hit and the slot of the
+// The workgroup-wide walk of one ray (see heavy_kernel): all kHeavyThreads threads call it with the same ray; q_* are
+// the workgroup's LDS stack arrays (kHeavyStack entries).  Out: whether any triangle is hit and the slot of the
 // reference's closest hit.  STOP_AT_ANY (occlusion queries): the walk ends with the first round that finds a hit.
+// (Four waves: with one, the ray through a 1000-triangle fan -- a frontier of ~1000 open boxes -- took 16 rounds per
+// level of the fan where it now takes 4: heavy_kernel 100 -> see DESIGN.md.)
+constexpr unsigned kHeavyThreads = 256;
 template <bool STOP_AT_ANY>
 __device__ __forceinline__ void heavy_walk(const Ray &r, const Scene &sc, int *q_ref, unsigned long long *q_key,
                                            unsigned char *q_depth, bool &any_w, int &best_slot)
 {
-    const unsigned lane = threadIdx.x;
-    unsigned top = 0;                         // (wave-uniform) entries on the stack
+    constexpr unsigned NW = kHeavyThreads / 64;
+    __shared__ unsigned s_cnt[NW], s_flag[2];            // per-wave push counts; [0] overflow, [1] any hit
+    __shared__ float s_bt[NW];
+    __shared__ unsigned long long s_bk[NW];
+    __shared__ int s_bs[NW], s_any[NW];
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    unsigned top = 0;                         // (uniform) entries on the stack
     if (box_hit(r, sc.rlo[0], sc.rlo[1], sc.rlo[2], sc.rhi[0], sc.rhi[1], sc.rhi[2])) {   // trav_begin
-        if (lane == 0) {
+        if (tid == 0) {
             q_ref[0] = sc.root_ref;
             q_key[0] = 0ull;
             q_depth[0] = 0;
         }
         top = 1;
     }
+    if (tid < 2) s_flag[tid] = 0u;
     __syncthreads();
     HeavyBest best;
     best.t = FLT_MAX;
@@ -1390,19 +1399,17 @@ __device__ __forceinline__ void heavy_walk(const Ray &r, const Scene &sc, int *q
     best.slot = -1;
     bool any = false, overflow = false;
     while (top > 0) {
-        if (STOP_AT_ANY && __ballot(any) != 0ull) break;
-        const unsigned n = min(top, 64u);
-        const bool have = lane < n;
+        const unsigned n = min(top, kHeavyThreads);
+        const bool have = tid < n;
         int ref = 0;
         unsigned long long key = 0ull;
         unsigned depth = 0;
         if (have) {
-            ref = q_ref[top - n + lane];
-            key = q_key[top - n + lane];
-            depth = q_depth[top - n + lane];
+            ref = q_ref[top - n + tid];
+            key = q_key[top - n + tid];
+            depth = q_depth[top - n + tid];
         }
         top -= n;
-        __syncthreads();
         bool pF = false, pS = false;
         int first = 0, second = 0;
         if (have && ref >= 0) {
@@ -1435,17 +1442,28 @@ __device__ __forceinline__ void heavy_walk(const Ray &r, const Scene &sc, int *q
                 }
             }
         }
-        // push the accepted children (wave-wide prefix counts); the level's bit sits below the bits of the levels above
+        // push the accepted children (prefix counts per wave, then over the waves); the level's bit sits below the bits of
+        // the levels above.  The stack is popped in any order: the keys decide, not the order of the stack.
         const unsigned long long mF = __ballot(pF), mS = __ballot(pS);
         const unsigned long long lt = (1ull << lane) - 1ull;
-        const unsigned add = (unsigned)__popcll(mF) + (unsigned)__popcll(mS);
-        if (top + add > sc.heavy_stack || __ballot(have && ref >= 0 && depth >= 56u) != 0ull) {
-            overflow = true;   // more open boxes than the stack holds (or deeper than the keys): lane 0 walks it alone
+        if (lane == 0) s_cnt[wave] = (unsigned)__popcll(mF) + (unsigned)__popcll(mS);
+        if (have && ref >= 0 && depth >= 56u) s_flag[0] = 1u;      // deeper than the keys hold
+        if (STOP_AT_ANY && any) s_flag[1] = 1u;
+        __syncthreads();                                            // (also: every read of this round's entries is done)
+        unsigned base = top, add = 0;
+#pragma unroll
+        for (unsigned w = 0; w < NW; ++w) {
+            const unsigned c = s_cnt[w];
+            if (w < wave) base += c;
+            add += c;
+        }
+        if (top + add > sc.heavy_stack || s_flag[0]) {
+            overflow = true;   // more open boxes than the stack holds (or deeper than the keys): one thread walks it alone
             break;
         }
-        const unsigned pos = top + (unsigned)__popcll(mF & lt) + (unsigned)__popcll(mS & lt);
+        if (STOP_AT_ANY && s_flag[1]) break;
+        const unsigned pos = base + (unsigned)__popcll(mF & lt) + (unsigned)__popcll(mS & lt);
         const unsigned long long bit = 1ull << (62u - depth);
-        // the child visited FIRST must be popped... in any order: the keys decide, not the order of the stack
         if (pF) {
             q_ref[pos] = first;
             q_key[pos] = key;
@@ -1462,12 +1480,12 @@ __device__ __forceinline__ void heavy_walk(const Ray &r, const Scene &sc, int *q
     }
     __syncthreads();
     if (overflow) {
-        // the reference's loop as it stands (pspRT.cpp:380-423), one lane, its stack in q_ref
+        // the reference's loop as it stands (pspRT.cpp:380-423), one thread, its stack in q_ref
         best.t = FLT_MAX;
         best.key = ~0ull;
         best.slot = -1;
         any = false;
-        if (lane == 0) {
+        if (tid == 0) {
             int sp = 0;
             int cur = sc.root_ref;
             for (;;) {
@@ -1512,7 +1530,7 @@ __device__ __forceinline__ void heavy_walk(const Ray &r, const Scene &sc, int *q
             }
         }
     }
-    // wave-wide winner: smallest t, then smallest key
+    // winner of each wave -- smallest t, then smallest key -- then of the workgroup
     float bt = best.t;
     for (int off = 32; off > 0; off >>= 1) bt = fminf(bt, __shfl_xor(bt, off));
     unsigned long long bk = best.t == bt ? best.key : ~0ull;
@@ -1520,14 +1538,36 @@ __device__ __forceinline__ void heavy_walk(const Ray &r, const Scene &sc, int *q
         const unsigned long long o = __shfl_xor(bk, off);
         bk = o < bk ? o : bk;
     }
-    any_w = __ballot(any) != 0ull;
+    const bool any_wave = __ballot(any) != 0ull;
     const unsigned long long win = __ballot(any && best.t == bt && best.key == bk);
     const int wl = win ? __ffsll((long long)win) - 1 : 0;
-    best_slot = __shfl(best.slot, wl);
+    const int slot_wave = __shfl(best.slot, wl);
+    if (lane == 0) {
+        s_bt[wave] = any_wave ? bt : FLT_MAX;
+        s_bk[wave] = any_wave ? bk : ~0ull;
+        s_bs[wave] = any_wave ? slot_wave : -1;
+        s_any[wave] = any_wave ? 1 : 0;
+    }
+    __syncthreads();
+    any_w = false;
+    best_slot = -1;
+    float wt = FLT_MAX;
+    unsigned long long wk = ~0ull;
+#pragma unroll
+    for (unsigned w = 0; w < NW; ++w) {
+        if (!s_any[w]) continue;
+        if (!any_w || s_bt[w] < wt || (s_bt[w] == wt && s_bk[w] < wk)) {
+            wt = s_bt[w];
+            wk = s_bk[w];
+            best_slot = s_bs[w];
+        }
+        any_w = true;
+    }
+    __syncthreads();       // (the per-wave slots are free for the next ray)
 }
 
 template <int PHASE>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(kHeavyThreads)
     heavy_kernel(Scene sc, Cam cam, const float *__restrict__ nodes, const int32_t *__restrict__ tri_nodes,
                  int32_t *__restrict__ pix, const unsigned *__restrict__ retry_nodes,
                  unsigned *__restrict__ retry_mask, const unsigned *__restrict__ work)
@@ -1575,7 +1615,7 @@ __global__ void __launch_bounds__(64)
 
 // The same walk for the rays a batch query gave up (cast_kernel): full hit record, or the occlusion flag.
 template <bool ANYHIT>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(kHeavyThreads)
     heavy_cast_kernel(Scene sc, const float *__restrict__ org, int org_stride, const float *__restrict__ dir,
                       upsp_hits out, const unsigned *__restrict__ work)
 {
@@ -1889,7 +1929,7 @@ int launch_cast(const upsp_bvh *cb, const float *d_org, int org_stride, const fl
     auto launch_heavy = [&]() {
         if (!heavy_on) return;
         KTimed kth("heavy_cast_kernel", st);
-        hipLaunchKernelGGL((heavy_cast_kernel<ANYHIT>), dim3(512), dim3(64), 0, st, sc, d_org, org_stride, d_dir, out,
+        hipLaunchKernelGGL((heavy_cast_kernel<ANYHIT>), dim3(512), dim3(kHeavyThreads), 0, st, sc, d_org, org_stride, d_dir, out,
                            (const unsigned *)b->d_work);
     };
     if (n >= 65536) prefetch_bvh(b, st);
@@ -2397,7 +2437,7 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
 #define UPSP_LAUNCH_HEAVY(PHASE, SC)                                                                             \
     if (heavy_on) {                                                                                              \
         KTimed kth("heavy_kernel", st);                                                                          \
-        hipLaunchKernelGGL((heavy_kernel<PHASE>), dim3(heavy_grid), dim3(64), 0, st, SC, c, d_nodes, d_tri_nodes, \
+        hipLaunchKernelGGL((heavy_kernel<PHASE>), dim3(heavy_grid), dim3(kHeavyThreads), 0, st, SC, c, d_nodes, d_tri_nodes, \
                            d_pix, (const unsigned *)b->d_retry_nodes, b->d_retry_mask, (const unsigned *)b->d_work); \
     }
     static const bool own_bound_on = std::getenv("UPSP_NO_OWN_BOUND") == nullptr;
