@@ -18,3 +18,14 @@ run UPSP_DESC_CAP=12
 run UPSP_XCD_AWARE=0
 run UPSP_NO_WITNESS=1
 run UPSP_OBLIQUE_CULL=0
+# blocks per CU / refill thresholds (all rays resident at once wins)
+for b in 1 2 3 4 6 8; do run UPSP_BLOCKS_PER_CU=$b; done
+for b in 1 2 4; do run UPSP_BLOCKS_PER_CU=$b UPSP_REFILL=56; done
+for b in 1 2 4; do run UPSP_BLOCKS_PER_CU=$b UPSP_REFILL=24; done
+# own-triangle bound for the primary rays, residual descent cap
+run A=0
+run UPSP_OWN_BOUND_PRIMARY=1
+run UPSP_OWN_BOUND_PRIMARY=1 UPSP_HEAVY_STEPS=64
+run UPSP_NO_OWN_BOUND=1
+run UPSP_DESC_CAP_RESIDUAL=2
+run UPSP_DESC_CAP_RESIDUAL=8
