@@ -284,6 +284,10 @@ int upsp_scatter_rows_f32(const float *d_src, size_t nrows, int ncols, const int
 /* The same for a block that travelled as u16 (upsp_pipeline_process_u16): values are widened to f32. */
 int upsp_scatter_rows_u16(const uint16_t *d_src, size_t nrows, int ncols, const int64_t *d_rowidx,
                           float *d_dst, long long ld, void *stream);
+/* The rows that do NOT travel (nodes no camera sees, psp_process.cpp:1821-1825: NaN in every frame): columns [0, ncols) of
+ * rows d_rowidx[r] of d_dst <- value.  Part of every exchange, like the scatter of the rows that do travel. */
+int upsp_fill_rows_f32(float value, size_t nrows, int ncols, const int64_t *d_rowidx, float *d_dst, long long ld,
+                       void *stream);
 /* ECC template of camera `cam` = first frame as f32 (elems.first_frames[c],
  * psp_process.cpp:2057-2058). */
 int upsp_pipeline_set_reference(upsp_pipeline *p, int cam, const float *d_ref32f);

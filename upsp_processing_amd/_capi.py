@@ -78,6 +78,7 @@ SIGNATURES = {
     "upsp_pipeline_set_projection_async": (_i, [_vp, _i, _vp, _vp, _vp]),
     "upsp_pipeline_fix_hot_pixels": (_i, [_vp, _vp, _i, _vp]),
     "upsp_pipeline_set_hot_enable": (_i, [_vp, _i]),
+    "upsp_fill_rows_f32": (_i, [C.c_float, _sz, _i, _vp, _vp, C.c_longlong, _vp]),
     "upsp_scatter_rows_f32": (_i, [_vp, _sz, _i, _vp, _vp, C.c_longlong, _vp]),
     "upsp_scatter_rows_u16": (_i, [_vp, _sz, _i, _vp, _vp, C.c_longlong, _vp]),
     "upsp_pipeline_set_row_map": (_i, [_vp, _vp]),

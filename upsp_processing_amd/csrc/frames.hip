@@ -1991,7 +1991,44 @@ int launch_finals(const double *sum, const double *sumsq, size_t nnodes, uint64_
 
 using namespace upsp;
 
+// rows rowidx[r] of dst (pitch ld) <- value, columns [0, ncols): the workgroup sweeps one row per store instruction
+// (4 KB for a 1000-frame row, like pass B), 8 rows per workgroup, 16-B streaming stores
+constexpr int kFillRows = 8;
+__global__ void __launch_bounds__(256)
+    fill_rows_kernel(long long nrows, int ncols, const long long *__restrict__ rowidx, float *__restrict__ dst,
+                     long long ld, float value)
+{
+    const long long r0 = (long long)blockIdx.x * kFillRows;
+    const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<size_t>(dst) & 15) == 0);
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f o = {value, value, value, value};
+#pragma unroll
+    for (int k = 0; k < kFillRows; ++k) {
+        const long long r = r0 + k;
+        if (r >= nrows) break;
+        float *d = dst + rowidx[r] * ld;
+        if (vec) {
+            int c = (int)threadIdx.x * 4;
+            for (; c + 3 < ncols; c += 1024) __builtin_nontemporal_store(o, reinterpret_cast<v4f *>(d + c));
+            for (; c < ncols; ++c) d[c] = value;     // (the thread that holds the ragged end)
+        } else {
+            for (int c = threadIdx.x; c < ncols; c += 256) d[c] = value;
+        }
+    }
+}
+
 extern "C" {
+
+int upsp_fill_rows_f32(float value, size_t nrows, int ncols, const int64_t *d_rowidx, float *d_dst, long long ld,
+                       void *stream)
+{
+    if (nrows == 0 || ncols == 0) return UPSP_OK;
+    if (!d_rowidx || !d_dst || ncols < 0 || ld < ncols) return fail(UPSP_ERR_INVALID, "bad argument");
+    hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)((nrows + kFillRows - 1) / kFillRows)), dim3(256), 0, (hipStream_t)stream,
+                       (long long)nrows, ncols, reinterpret_cast<const long long *>(d_rowidx), d_dst, ld, value);
+    UPSP_HIP_CHECK(hipGetLastError());
+    return UPSP_OK;
+}
 
 int upsp_scatter_rows_f32(const float *d_src, size_t nrows, int ncols, const int64_t *d_rowidx,
                           float *d_dst, long long ld, void *stream)

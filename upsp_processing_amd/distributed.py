@@ -144,6 +144,20 @@ def _widen_u16(blk):
     return blk.view(torch.int16).to(torch.int32).bitwise_and_(0xFFFF).to(torch.float32)
 
 
+def _fill_rows(out, rows, value):
+    """out[rows, :] = value ; library kernel on the GPU, torch indexing on the CPU."""
+    if rows.numel() == 0:
+        return
+    if out.is_cuda:
+        import ctypes as C
+        from . import _capi
+        _capi.check(_capi.lib().upsp_fill_rows_f32(
+            C.c_float(value), rows.numel(), out.shape[1], C.c_void_p(rows.data_ptr()), C.c_void_p(out.data_ptr()),
+            out.stride(0), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    else:
+        out[rows] = value
+
+
 def _scatter_rows(out, rows, col, blk):
     """out[rows, col:col+blk.shape[1]] = blk ; library kernel on the GPU, torch indexing on the CPU.
     blk is f32, or u16 (the exchange's wire format for integer-valued series), widened here."""
@@ -213,6 +227,9 @@ class TimeSeriesExchange:
         m = torch.full((8,), -1, dtype=torch.int32, device=device)
         m[v] = torch.arange(v.numel(), dtype=torch.int32, device=device)
         o = torch.empty((8, 4), dtype=torch.float32, device=device)
+        mm = torch.ones(8, dtype=torch.bool, device=device)
+        mm[v] = False
+        torch.nonzero(mm, as_tuple=False)
         o.fill_(float("nan"))
         o[v - 1, 1:3] = torch.ones((v.numel(), 2), device=device)
         o.index_select(0, v)
@@ -246,7 +263,10 @@ class TimeSeriesExchange:
         n0, nn = sh.my_nodes
         r = sh.rank
         self.vis_mine = self.vis[cuts[r]:cuts[r + 1]] - n0
-        self.out.fill_(float("nan"))                    # rows that do not travel
+        # the rows of this rank's slice that do NOT travel: NaN in every frame, written by every exchange (finish())
+        mine = torch.ones(nn, dtype=torch.bool, device=self.vis.device)
+        mine[self.vis_mine] = False
+        self.nan_mine = torch.nonzero(mine, as_tuple=False).reshape(-1)
 
     def verify(self):
         """Raises if a set_skipped(..., assume_same=True) call was handed a different set (one host read)."""
@@ -329,6 +349,8 @@ class TimeSeriesExchange:
                 off += rows_in * fs
         self.pending = []
         self.k = 0                      # ready for the next pass over the chunks
+        if self.vis is not None:
+            _fill_rows(self.out, self.nan_mine, float("nan"))      # rows that do not travel (psp_process.cpp:1821-1825)
         return self.out
 
 
