@@ -67,6 +67,13 @@ def _worker(rank, world, port, F, N, seed, q):
         c0, fc = ex3.my_chunk(k)
         ex3.submit(rows_t[:, c0:c0 + fc].index_select(0, ex3.vis), packed=True)
     assert torch.equal(ex3.finish().view(torch.int32), series.view(torch.int32))
+    # a second pass through the same exchange delivers a complete slice again: the rows that do not travel are written
+    # by every finish(), not once
+    ex3.out.zero_()
+    for k in range(3):
+        c0, fc = ex3.my_chunk(k)
+        ex3.submit(rows_t[:, c0:c0 + fc].index_select(0, ex3.vis), packed=True)
+    assert torch.equal(ex3.finish().view(torch.int32), series.view(torch.int32))
     n0, nn = shard.my_nodes
     # phase-2 per-node vectors: each rank owns its node slice, every rank gets the whole vector
     whole = D.gather_node_vector(torch.arange(n0, n0 + nn, dtype=torch.float32) * 2.0, shard)
