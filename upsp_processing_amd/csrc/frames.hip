@@ -1993,7 +1993,7 @@ using namespace upsp;
 
 // rows rowidx[r] of dst (pitch ld) <- value, columns [0, ncols): the workgroup sweeps one row per store instruction
 // (4 KB for a 1000-frame row, like pass B), 8 rows per workgroup, 16-B streaming stores
-constexpr int kFillRows = 8;
+constexpr int kFillRows = 16;
 __global__ void __launch_bounds__(256)
     fill_rows_kernel(long long nrows, int ncols, const long long *__restrict__ rowidx, float *__restrict__ dst,
                      long long ld, float value)
@@ -2002,11 +2002,13 @@ __global__ void __launch_bounds__(256)
     const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<size_t>(dst) & 15) == 0);
     typedef float v4f __attribute__((ext_vector_type(4)));
     const v4f o = {value, value, value, value};
+    long long rows[kFillRows];       // every index first: the stores below do not wait for one load each
+#pragma unroll
+    for (int k = 0; k < kFillRows; ++k) rows[k] = r0 + k < nrows ? rowidx[r0 + k] : -1;
 #pragma unroll
     for (int k = 0; k < kFillRows; ++k) {
-        const long long r = r0 + k;
-        if (r >= nrows) break;
-        float *d = dst + rowidx[r] * ld;
+        if (rows[k] < 0) break;
+        float *d = dst + rows[k] * ld;
         if (vec) {
             int c = (int)threadIdx.x * 4;
             for (; c + 3 < ncols; c += 1024) __builtin_nontemporal_store(o, reinterpret_cast<v4f *>(d + c));
