@@ -64,7 +64,9 @@ def test_projection_matches_oracle(gpu_lib, oracle, case):
         assert np.array_equal(g4["uv"].cpu().numpy().view(np.int32), o["uv"].view(np.int32))
         assert np.array_equal(g4["nodecount"].cpu().numpy(), o["nodecount"])
         pc = engine.projection_counts(bvh)
-        assert (pix >= 0).sum() <= pc["primary_rays"] < g["primary_rays"] and pc["nrays"] < o["nrays"]
+        import os
+        if os.environ.get("UPSP_OBLIQUE_CULL", "1") == "1":
+            assert (pix >= 0).sum() <= pc["primary_rays"] < g["primary_rays"] and pc["nrays"] < o["nrays"]
 
 
 @pytest.mark.parametrize("steps,stack", [(8, 4096), (8, 128), (40, 4096), (1, 130)])
