@@ -892,15 +892,17 @@ __global__ void ecc_set_last_rho(EccState *state, int nframes, double eps)
 
 __global__ void ecc_count_active(const EccState *state, int nframes, int *out)
 {
-    int active = 0, err = 0, iters = 0;
+    int active = 0, err = 0, iters = 0, most = 0;
     for (int f = threadIdx.x; f < nframes; f += blockDim.x) {
         active += state[f].done == 0;
         err += state[f].done < 0;
         iters += state[f].iters;
+        most = max(most, state[f].iters);
     }
     atomicAdd(&out[0], active);
     atomicAdd(&out[1], err);
     atomicAdd(&out[2], iters);       // frame-iterations so far (statistics)
+    atomicMax(&out[3], most);        // iterations of the frame that needed most (sizes the next sub-batch's first burst)
 }
 
 __global__ void ecc_export_warps(const EccState *state, int nframes, float *warps, int stride)
@@ -1174,6 +1176,7 @@ struct FrameScratch {
     EccState *state = nullptr;
     int *counter = nullptr;
     unsigned long long ecc_frame_iters = 0, ecc_frames = 0;   // statistics: ECC iterations summed over frames, frames
+    int ecc_first_burst = 3;                                  // iterations issued before the first host check
 };
 
 void frame_scratch_ecc_stats(const FrameScratch *s, unsigned long long *frame_iters, unsigned long long *frames)
@@ -1244,13 +1247,15 @@ static int run_ecc(FrameScratch *s, const float *tmpl_blur, const uint16_t *fram
     hipLaunchKernelGGL(ecc_set_last_rho, g1, b1, 0, st, s->state, nb, eps);
     int it = 0;
     int active = nb;  // frames still iterating (known to the host after every burst)
-    int iters_done = 0;
+    int iters_done = 0, most_iters = 0;
     while (it < max_iters) {
         // a few iterations between host checks of the active-frame count; frames that have
         // converged exit at once, so late bursts spread the remaining frames over more blocks
         // (a host check costs a stream round trip of ~40 us; most frames converge within 3-5
         // iterations, the rare oscillating ones run to max_iters, so the bursts grow)
-        const int burst = it == 0 ? 3 : (it < 7 ? 2 : (it < 15 ? 8 : 16));
+        // (first burst: as many iterations as the previous sub-batch's slowest frame took -- on steady footage every
+        //  frame converges with its second iteration, and a third launch pair that finds nothing to do costs 10 us)
+        const int burst = it == 0 ? s->ecc_first_burst : (it < 7 ? 2 : (it < 15 ? 8 : 16));
         int blocks = kEccBlocks;
         while (blocks < kEccBlocksMax && (long long)blocks * active < 2048) blocks *= 2;
         const int nblocks_total = blocks + kEccBorderBlocks;
@@ -1285,8 +1290,8 @@ static int run_ecc(FrameScratch *s, const float *tmpl_blur, const uint16_t *fram
             hipLaunchKernelGGL(ecc_solve_kernel, dim3(nb), dim3(256), 0, st, s->state,
                                (const double *)s->partial, nb, nblocks_total, max_iters, eps, rows, cols);
         }
-        int h[3] = {0, 0, 0};
-        UPSP_HIP_CHECK(hipMemsetAsync(s->counter, 0, 3 * sizeof(int), st));
+        int h[4] = {0, 0, 0, 0};
+        UPSP_HIP_CHECK(hipMemsetAsync(s->counter, 0, 4 * sizeof(int), st));
         hipLaunchKernelGGL(ecc_count_active, dim3(1), dim3(64), 0, st, (const EccState *)s->state, nb,
                            s->counter);
         UPSP_HIP_CHECK(hipMemcpyAsync(h, s->counter, sizeof(h), hipMemcpyDeviceToHost, st));
@@ -1295,9 +1300,11 @@ static int run_ecc(FrameScratch *s, const float *tmpl_blur, const uint16_t *fram
             return fail(UPSP_ERR_DIVERGED,
                         "ECC registration did not converge (cv::findTransformECC would throw)");
         iters_done = h[2];
+        most_iters = h[3];
         if (h[0] == 0) break;
         active = h[0];
     }
+    s->ecc_first_burst = std::min(std::max(most_iters, 2), 4);
     s->ecc_frame_iters += (unsigned long long)iters_done;
     s->ecc_frames += (unsigned long long)nb;
     UPSP_HIP_CHECK(hipGetLastError());
