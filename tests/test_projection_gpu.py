@@ -111,6 +111,43 @@ def test_heavy_ray_handoff(gpu_lib, oracle, monkeypatch, steps, stack):
         assert g["nrays"] == o["nrays"]
 
 
+def test_dense_soup_every_ray_heavy(gpu_lib, oracle):
+    """A soup of large overlapping triangles (the kind-0 scenes of tests/debug/soak_raycast.py with spread 2): every
+    camera -> node ray needs ~1000 node visits and ~800 triangle tests, so every primary ray and every retry of the build
+    is handed to heavy_kernel (tens of thousands of work items), and the batch queries to heavy_cast_kernel."""
+    import os
+    import torch
+    from upsp_processing_amd import _capi, engine, synthetic as syn
+    rng = np.random.default_rng(21150)
+    n = 1400
+    c = rng.normal(size=(n, 1, 3)) * 3
+    s9 = (c + rng.normal(size=(n, 3, 3)) * 2.0).astype(np.float32).reshape(-1)
+    v = np.ascontiguousarray(s9.reshape(-1, 3), np.float32)
+    tn = np.arange(v.shape[0], dtype=np.int32)
+    nrm = np.tile(np.float32([0, 0, 1]), (v.shape[0], 1))
+    nrm[::2] = np.float32([0, 0, -1])            # half of the nodes pass the oblique test for a camera on +z
+    bvh, obv = engine.BVH(s9), oracle.OracleBVH(s9)
+    cd = syn.pinhole_camera(256, 256, center=(1.0, -2.0, 40.0), half_extent=12.0)
+    cg = _capi.make_camera(cd["K"], cd["dist"], cd["R"], cd["t"], 256, 256)
+    co = oracle.make_camera(cd["K"], cd["dist"], cd["R"], cd["t"], 256, 256)
+    want = oracle.create_projection(obv, co, v, nrm, tn, engine.oblique_threshold(70.0), threads=os.cpu_count() or 1)
+    assert want["nrays"] > 3 * v.shape[0]        # most nodes go through the retries
+    d_tn = torch.as_tensor(tn).cuda()
+    for adjacency in (False, True):
+        if adjacency:
+            bvh.set_tri_nodes(d_tn, v.shape[0])
+        g = engine.build_projection(bvh, cg, v, nrm, d_tn, 70.0)
+        assert np.array_equal(g["pix"].cpu().numpy(), want["pix"]) and g["nrays"] == want["nrays"]
+        g = engine.build_projection(bvh, cg, v, nrm, d_tn, 70.0, counts=False)
+        assert np.array_equal(g["pix"].cpu().numpy(), want["pix"])
+    cam = oracle.cam_center(co).astype(np.float32)
+    d = (v - cam).astype(np.float32)
+    gh, oh = bvh.intersect(cam, d, want=("hit", "t", "prim")), obv.intersect(cam, d, threads=os.cpu_count() or 1)
+    assert np.array_equal(gh["prim"].cpu().numpy(), oh["prim"])
+    assert np.array_equal(gh["t"].cpu().numpy().view(np.int32), oh["t"].view(np.int32))
+    assert np.array_equal(bvh.occluded(cam, d).cpu().numpy(), oh["hit"])
+
+
 def test_multi_camera_weights(gpu_lib, oracle):
     from upsp_processing_amd import engine, _capi, synthetic as syn
     v, t = syn.tunnel_model(60, 120, 24, 48)
