@@ -23,7 +23,14 @@ projection build (rays the reference would cast / build time).  The build applie
 rays (nodes it rejects have no entry whatever their rays say and cast none) and decides most retry rays by
 the occluder witness instead of a traversal -- `rays_cast_per_step` counts what is really cast, and
 `mrays_cast_per_s` is that count over the build time.  `pixel_rays` is the plain ray caster: closest hit of one ray per
-pixel of the frame (1 Mpix onto the 1 M-triangle model), every ray traversed, a sample checked against the oracle.
+pixel of the frame (1 Mpix onto the 1 M-triangle model), every ray traversed, a sample checked against the oracle;
+`pixel_rays_fill` is the same on a 1 M-triangle sphere that fills the frame (every ray enters the tree), both with the
+rays that ENTER the root box counted apart and the traversal bytes per ray (nodes visited x 64 B + triangles tested x
+48 B) from the statistics counters.
+
+`configs2` (default run) / `--registration`: BASELINE configs[2], per-frame ECC registration in front of the projection,
+with its own roofline (ecc_sums_kernel), iterations per frame, CPU baseline (`register_pixel` included) and parity block
+(warps, iteration counts, warped rows against the oracle on the frames the CPU baseline registered).
 """
 import argparse
 import json
@@ -123,10 +130,29 @@ def pixel_rays(cam_dict, size):
     return c.astype(np.float32), d.astype(np.float32)
 
 
+def orc_bvh(tris9):
+    from oracle import oracle as orc
+    return orc.OracleBVH(tris9)
+
+
+def rays_entering(org, dirs, lo, hi):
+    """Rays whose LINE pierces the box [lo, hi] (slab test in double on the host; the count reported beside the
+    traversal rate -- the traversal itself uses the library's own box test)."""
+    o = np.asarray(org, np.float64).reshape(1, 3)
+    d = np.asarray(dirs, np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t0, t1 = (np.asarray(lo, np.float64) - o) / d, (np.asarray(hi, np.float64) - o) / d
+    tn, tf = np.fmin(t0, t1).max(1), np.fmax(t0, t1).min(1)
+    return int((tn <= tf).sum())
+
+
 def pixel_ray_rate(bvh, cam_dict, size, check_with=None):
     """The other half of BASELINE's metric taken literally: closest hit of ONE RAY PER PIXEL of the 1 Mpix frame
     against the 1 M-triangle model through upsp_bvh_intersect (rt::BVH::intersect semantics: t, primID) -- every ray
-    is traversed, nothing is culled or witnessed.  check_with: oracle BVH -> a strided sample is compared bit for bit."""
+    is traversed, nothing is culled or witnessed.  check_with: oracle BVH -> a strided sample is compared bit for bit.
+    Reported: all rays / s, the rays that enter the root box / s (the others end at the first box test), the hit
+    fraction, and SURVEY.md 8(d)'s traversal bytes per ray from the statistics counters of one extra, untimed call
+    (interior nodes visited x 64 B + triangles tested x 48 B; what rt::BVH::intersect touches, pspRT.cpp:376-429)."""
     import torch
     org, dirs = pixel_rays(cam_dict, size)
     d_org, d_dirs = torch.as_tensor(org).cuda(), torch.as_tensor(dirs).cuda()
@@ -140,12 +166,31 @@ def pixel_ray_rate(bvh, cam_dict, size, check_with=None):
         h = bvh.intersect(d_org, d_dirs, want=("hit", "t", "prim"))
     e1.record()
     torch.cuda.synchronize()
+    bvh.check()
     ms = e0.elapsed_time(e1) / reps
-    alg = dirs.shape[0] * 40 + bvh.info["device_bytes"]      # 40 B per ray + the scene once per batch
-    out = {"rays": int(dirs.shape[0]), "ms": ms, "mrays_per_s": dirs.shape[0] / (ms * 1e-3) / 1e6,
+    n = dirs.shape[0]
+    info = bvh.info
+    entered = rays_entering(org, dirs, info["bounds_min"], info["bounds_max"])
+    bvh.enable_stats(True)                      # one-lane traversal of every ray with the counters on (not timed)
+    bvh.intersect(d_org, d_dirs, want=("hit",))
+    st = bvh.last_stats()
+    bvh.enable_stats(False)
+    trav_bytes = st["nodes"] * 64 + st["tris"] * 48
+    alg = n * 40                                 # 24 B ray + 16 B hit record
+    out = {"rays": int(n), "ms": ms, "mrays_per_s": n / (ms * 1e-3) / 1e6,
+           "rays_entered": entered, "mrays_entered_per_s": entered / (ms * 1e-3) / 1e6,
            "hit_fraction": float(h["hit"].float().mean().item()),
+           "nodes_visited_per_entered_ray": st["nodes"] / max(entered, 1),
+           "tris_tested_per_entered_ray": st["tris"] / max(entered, 1),
+           "traversal_bytes_per_ray": trav_bytes / max(n, 1),
+           "traversal_bytes_per_entered_ray": trav_bytes / max(entered, 1),
+           "traversal_GBps": trav_bytes / (ms * 1e-3) / 1e9,
            "algorithmic_bytes": int(alg), "achieved_GBps": alg / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": alg / (ms * 1e-3) / 8e12,
-           "what": "closest hit (t, primID) of one ray per pixel of the %d x %d frame, upsp_bvh_intersect; all rays traversed" % (size, size)}
+           "scene_bytes": int(info["device_bytes"]),
+           "what": "closest hit (t, primID) of one ray per pixel of the %d x %d frame, upsp_bvh_intersect; all rays traversed; "
+                   "algorithmic bytes = 40 B per ray (the scene, %d MB, is cache-resident across the batch and not credited); "
+                   "traversal bytes = nodes visited x 64 B + triangles tested x 48 B from the statistics counters"
+                   % (size, size, info["device_bytes"] // 1000000)}
     if check_with is not None:
         idx = np.arange(0, dirs.shape[0], 37)
         t0 = time.perf_counter()
@@ -186,19 +231,28 @@ def cpu_baseline(verts, tris, cam_dict, size, nframes_step, sample, registration
     # own 2 x N doubles (psp_process.cpp:1744-1745, 1845-1850), amortised over a whole run
     per_frame = tm["loop"] / frames.shape[0]
     t_fixed = tm["setup"] + tm["merge"]
-    reg_note = ""
+    reg_note, reg = "", None
     if registration:
-        # configs[2]: register_pixel (ECC + warp, cpp/lib/registration.cpp:32-81) per frame before the projection;
-        # one frame per thread like the reference's OpenMP loop (psp_process.cpp:1776-1795), bounded sample
+        # configs[2]: register_pixel (ECC + warp, cpp/lib/registration.cpp:32-81) per frame before the projection,
+        # after fix_hot_pixels like the loop (psp_process.cpp:1771-1795); one frame per thread like the reference's
+        # OpenMP loop, bounded sample.  The template is the RAW first frame (psp_process.cpp:2057-2058).
         from concurrent.futures import ThreadPoolExecutor
         nreg = min(sample.shape[0] - 1, 2 * cores)
         ref32 = sample[0].astype(np.float32)
+
+        def one(f):
+            img, _ = orc.fix_hot_pixels(sample[f])
+            out, M, it = orc.register_pixel(ref32, img)
+            return img, M, it, orc.project_frame(out, pix, None)
         t0 = time.perf_counter()
         with ThreadPoolExecutor(cores) as ex:
-            its = list(ex.map(lambda f: orc.register_pixel(ref32, sample[f])[2], range(1, nreg + 1)))
+            res = list(ex.map(one, range(1, nreg + 1)))
         t_reg = time.perf_counter() - t0
         per_frame += t_reg / nreg
-        reg_note = " + register_pixel on %d frames (%.2f s, %.1f ECC iterations per frame)" % (nreg, t_reg, float(np.mean(its)))
+        reg = dict(first=1, fixed=[r[0] for r in res], M=np.stack([r[1] for r in res]), its=np.array([r[2] for r in res]),
+                   rows=[r[3] for r in res], seconds_per_frame=t_reg / nreg * cores)
+        reg_note = " + fix_hot_pixels, register_pixel, project_frame on %d frames (%.2f s, %.1f ECC iterations per frame)" % (
+            nreg, t_reg, float(np.mean(reg["its"])))
     # a few rows for the parity check of the series (single thread, rows kept)
     few = sample[:8].copy()
     rows8, _, _ = orc.frame_loop(few, pix, want_rows=True, threads=1)
@@ -210,7 +264,116 @@ def cpu_baseline(verts, tris, cam_dict, size, nframes_step, sample, registration
                      % (cores, r["nrays"], t_proj, frames.shape[0], t_frames, tm["loop"] / frames.shape[0] * 1e3, t_fixed,
                         reg_note, nframes_step),
            "mrays_per_s": mrays, "frame_loop_frames_per_s": 1.0 / per_frame, "bvh_build_s": t_build}
-    return out, dict(pix=pix, nrays=int(r["nrays"]), sum=s, sumsq=ss, rows8=rows8, frames_fixed=frames, obv=obv)
+    return out, dict(pix=pix, nrays=int(r["nrays"]), sum=s, sumsq=ss, rows8=rows8, frames_fixed=frames, obv=obv, reg=reg,
+                     t_proj=t_proj, t_fixed=t_fixed, loop_per_frame=tm["loop"] / frames.shape[0], cores=cores)
+
+
+def registration_parity(ref, sample, gpix_dev, N, size):
+    """configs[2] parity of THIS run: the frames the CPU baseline registered (oracle: fix_hot_pixels -> register_pixel
+    -> project_frame) through a fresh registration pipeline on the GPU.  Bars (tests/test_imageops_gpu.py): warp
+    matrix max|dM| <= 1e-4 (linear part) / 2e-3 px (translation), identical iteration counts, series rows bit-exact
+    against project_frame(warpAffine(frame, M_gpu)) (exact integer arithmetic), and within 8 counts of the oracle's
+    own chain."""
+    import torch
+    from oracle import oracle as orc
+    from upsp_processing_amd import engine
+    reg = ref["reg"]
+    nreg = len(reg["fixed"])
+    d = torch.as_tensor(sample[:nreg + 1].view(np.int16)).view(torch.uint16).cuda()
+    p = engine.FramePipeline(1, size, size, N, registration=1)
+    p.set_projection(0, gpix_dev)
+    p.set_reference(0, d[0].to(torch.float32))
+    warps = torch.zeros((nreg + 1, 1, 6), dtype=torch.float32, device="cuda")
+    iters = torch.zeros((nreg + 1, 1), dtype=torch.int32, device="cuda")
+    rows = p.process(d, 0, warps=warps, ecc_iters=iters).cpu().numpy()
+    w = warps.cpu().numpy()[1:, 0].reshape(nreg, 2, 3)
+    it = iters.cpu().numpy()[1:, 0]
+    pix = ref["pix"]
+    ok = pix >= 0
+    d_lin = float(np.abs(w[:, :, :2] - reg["M"][:, :, :2]).max())
+    d_tr = float(np.abs(w[:, :, 2] - reg["M"][:, :, 2]).max())
+    exact, worst = True, 0.0
+    for i in range(nreg):
+        want = orc.project_frame(orc.warp_affine(reg["fixed"][i], w[i], 1), pix, None)
+        exact = exact and bool(np.array_equal(rows[i + 1, ok].view(np.int32), want[ok].view(np.int32)))
+        worst = max(worst, float(np.abs(rows[i + 1, ok] - reg["rows"][i][ok]).max()))
+    checks = {
+        "ecc_warp_linear_1e-4": d_lin <= 1e-4, "ecc_warp_translation_2e-3_px": d_tr <= 2e-3,
+        "ecc_iteration_counts": bool(np.array_equal(it, reg["its"])),
+        "rows_bitexact_for_gpu_warp": exact, "rows_vs_oracle_chain_8_counts": worst <= 8.0,
+    }
+    return checks, {"frames": nreg, "max_dM_linear": d_lin, "max_dM_translation_px": d_tr, "max_dI_vs_oracle_chain": worst,
+                    "iterations": [int(x) for x in it]}
+
+
+def registration_block(bvh, cam, d_nodes, d_nrm, d_tn, frames, restore, N, size, n_active, steps, warmup):
+    """BASELINE configs[2] on the resident frames: projection build + (fix_hot_pixels -> ECC registration -> warp of the
+    pixels nodes read -> projection) over every frame + finals.  Returns the sub-block of the JSON line."""
+    import torch
+    from upsp_processing_amd import _capi, engine
+    F = frames.shape[0]
+    npx = size * size
+    pipe = engine.FramePipeline(1, size, size, N, registration=1)
+    restore()
+    pipe.set_reference(0, frames[0].to(torch.float32))      # raw first frame as ECC template (psp_process.cpp:2057)
+    rows_t = torch.empty((N, engine.series_ld(F)), dtype=torch.float32, device="cuda")[:, :F]
+
+    def step():
+        restore()
+        proj = engine.build_projection(bvh, cam, d_nodes, d_nrm, d_tn, 70.0, counts=False)
+        pipe.reset()
+        pipe.set_projection(0, proj["pix"])
+        pipe.process(frames, first_frame=0, rows_t=rows_t, want_rows=False)
+        return pipe.finalize(F)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    st0 = pipe.ecc_stats()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st1 = pipe.ecc_stats()
+    iters = (st1["frame_iterations"] - st0["frame_iterations"]) / max(st1["frames"] - st0["frames"], 1)
+    _capi.timing_enable(True)
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    _capi.timing_enable(False)
+    rep = _capi.timing_report(spread=True)
+    ms_step = dt / steps * 1e3
+    bytes_step = {
+        # SURVEY.md 8(d) with registration: 8 B per pixel and ECC iteration (blurred frame + template, gradients
+        # recomputed on the fly); pre-blur 2 B in + 4 B out per pixel; the warp produces only the pixels a node reads:
+        # per listed pixel 4 B list entry + 4 x 2 B source pixels + 2 B out
+        "ecc_sums_kernel": iters * F * 8 * npx,
+        "gauss_pass_kernels": F * 6 * npx,
+        "warp_u16_kernel": F * n_active * 14,
+        "hot_scan_kernel": F * 2 * npx,
+        "gather_tile_kernel": F * 4 * N + (-(-F // 64)) * 8 * N,
+        "node_rows_kernel": F * 4 * N + (-(-F // 1024)) * 8 * N,
+    }
+    kernels = {}
+    for name, (calls, total, lo, med, hi) in rep.items():
+        k = {"calls_per_step": calls / steps, "ms_per_step": total / steps, "avg_launch_ms": total / max(calls, 1)}
+        if name in bytes_step and total:
+            k["algorithmic_bytes_per_step"] = bytes_step[name]
+            k["achieved_GBps"] = bytes_step[name] / (total / steps * 1e-3) / 1e9
+        kernels[name] = k
+    dom = max((n for n in kernels if "achieved_GBps" in kernels[n]), key=lambda n: kernels[n]["ms_per_step"])
+    dk = kernels[dom]
+    return {
+        "workload": "configs[2]: %d frames x %dx%d u16, per-frame ECC registration + projection, projection build per step" % (F, size, size),
+        "value": F * steps / dt, "unit": "frames/s", "steps": steps, "warmup": warmup, "ms_per_step": ms_step,
+        "ecc_iterations_per_frame": iters,
+        "roofline": {"kernel": dom, "bound": "hbm", "achieved": dk["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": dk["achieved_GBps"] / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": dk["algorithmic_bytes_per_step"] / max(dk["calls_per_step"], 1),
+                     "avg_launch_ms": dk["avg_launch_ms"], "launches_per_step": dk["calls_per_step"]},
+        "kernels": kernels,
+    }
 
 
 def host_feed_rate(pipe, frames, N, size, pix, chunk=64, nchunks=16):
@@ -328,6 +491,17 @@ def main():
     n_sample = min(F, 256)
     sample = (frames[:n_sample].cpu().view(torch.int16).numpy().view(np.uint16).copy()
               if (rank == 0 and world == 1 and not a.no_cpu_baseline) else None)   # before any in-place repair
+    # The frame loop repairs hot pixels IN PLACE (like the reference): after the first step no frame would hold one
+    # and the repair / re-projection branch would never run inside the timed region.  Pristine copies of the few
+    # frames that carry hot pixels (1 % of them) are therefore put back before every step -- a stand-in for new
+    # frames arriving (<= 10 x 2 MiB device copy per 1000 frames, inside the timed region).
+    f16 = frames.view(torch.int16)
+    hot_idx = torch.nonzero((f16.reshape(F, -1) >= 4064).any(1), as_tuple=False).reshape(-1)
+    pristine = f16[hot_idx].clone()
+
+    def restore_hot():
+        if hot_idx.numel():
+            f16[hot_idx] = pristine
     shard = D.Shard(F * world, N, rank, world)
     pipe = engine.FramePipeline(1, size, size, N, registration=int(a.registration),
                                 fused_scan=2 if a.two_kernel else 0)
@@ -361,6 +535,7 @@ def main():
 
     def step(record):
         e = [ev() for _ in range(4)]
+        restore_hot()
         e[0].record()
         main = torch.cuda.current_stream()
         if overlap:
@@ -422,6 +597,7 @@ def main():
     dt = time.perf_counter() - t0
     if chunked:
         exch.verify()                   # the travelling set did not change between the steps
+    bvh.check()                         # no walk ran past its round cap (UPSP_ERR_INTERNAL otherwise)
     for e in ev_log:
         t_ray.append(e[0].elapsed_time(e[1]))
         t_frames.append(e[1].elapsed_time(e[2]))
@@ -454,7 +630,8 @@ def main():
 
     # per-kernel durations: HIP events recorded by the library on the launch stream
     # during the timed steps (upsp_timing_enable / upsp_timing_report)
-    timing = _capi.timing_report()
+    timing_full = _capi.timing_report(spread=True)
+    timing = {k: v[:2] for k, v in timing_full.items()}
     kernels = {}
     n_retry_rays = 6 * retry_nodes
     scene_bytes = bvh.info["device_bytes"]
@@ -483,9 +660,14 @@ def main():
         "node_rows_kernel": F * series_esz * series_rows + row_launches * 8 * N,
         # SURVEY.md 8(d) with registration: 8 B per pixel and ECC iteration (blurred frame + template,
         # gradients recomputed on the fly), warp 2 B in + 2 B out per pixel, pre-blur 2 B in + 4 B out
-        "warp_u16_kernel": F * 4 * npx,
+        # the warp produces only the pixels a node reads (list): 4 B list entry + 4 x 2 B source + 2 B out each
+        "warp_u16_kernel": F * n_active * 14,
         "gauss_pass_kernels": F * 6 * npx,
     }
+    # traversal passes: SURVEY.md 8(d)'s 40 B per ray; the scene is NOT credited per launch (a pass of a few thousand
+    # rays touches a fraction of it, and it stays cache-resident between the passes)
+    per_step_bytes["projection_kernel<primary>"] = primary_rays * 40
+    del per_step_bytes["projection_kernel<retry>"]
     if a.registration:
         st = pipe.ecc_stats()            # average ECC iterations per frame over every step run so far
         per_step_bytes["ecc_sums_kernel"] = st["frame_iterations"] / max(st["frames"], 1) * F * 8 * npx
@@ -497,6 +679,9 @@ def main():
         if name in per_step_bytes:
             k["algorithmic_bytes_per_step"] = per_step_bytes[name]
             k["achieved_GBps"] = per_step_bytes[name] / (ms_step_k * 1e-3) / 1e9 if ms_step_k else None
+        if name in ("scan_compact_kernel", "node_rows_kernel", "ecc_sums_kernel"):
+            lo, med, hi = timing_full[name][2:]
+            k["launch_ms_min_median_max"] = [lo, med, hi]      # spread over the timed launches (device state)
         kernels[name] = k
     dom = max((n for n in kernels if n in per_step_bytes), key=lambda n: kernels[n]["ms_per_step"])
     dk = kernels[dom]
@@ -506,9 +691,23 @@ def main():
     # gfx950 FETCH correction applied for the streaming kernels); otherwise null
     traffic, traffic_src = None, None
     prof = os.environ.get("UPSP_BENCH_TRAFFIC_JSON")
+    if not prof:
+        # default: the newest tracked summary (tools/profile_bench.sh writes profiles/rNN_bench_summary.json from the
+        # same command); it is only used when its bench_args are this run's arguments
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_summary.json")))
+        prof = cands[-1] if cands else None
     if prof and os.path.exists(prof):
         pj = json.load(open(prof))
-        same = pj.get("bench_args", "").split() == [x for x in sys.argv[1:] if x not in ("--no-cpu-baseline", "--no-reraycast")]
+        mine, skip = [], False
+        for x in sys.argv[1:]:       # arguments that do not change the launches: baseline / stress switches, the step counts
+            if skip:
+                skip = False
+            elif x in ("--steps", "--warmup", "--gpus"):
+                skip = True
+            elif not (x in ("--no-cpu-baseline", "--no-reraycast") or x.startswith(("--steps=", "--warmup=", "--gpus="))):
+                mine.append(x)
+        same = pj.get("bench_args", "").split() == mine and world == 1
         if same and dom in pj.get("traffic_bytes_per_launch", {}):
             traffic, traffic_src = pj["traffic_bytes_per_launch"][dom], os.path.relpath(os.path.abspath(prof), ROOT)
     roof = {"kernel": dom, "bound": "hbm",
@@ -576,12 +775,23 @@ def main():
         out["host_feed"] = host_feed_rate(pipe, frames, N, size, last_pix[0])
         if a.no_cpu_baseline:
             out["pixel_rays"] = pixel_ray_rate(bvh, cd, size)
+    plain_default = world == 1 and not a.registration and not a.no_reraycast and not chunked and not a.small
+    if plain_default:
+        # BASELINE configs[2] beside the headline: the same resident frames with per-frame ECC registration
+        out["configs2"] = registration_block(bvh, cam, d_nodes, d_nrm, d_tn, frames, restore_hot, N, size, n_active,
+                                             steps=2, warmup=1)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"], ref = cpu_baseline(verts, tris, cd, size, F, sample, registration=a.registration)
+        with_reg = a.registration or plain_default
+        out["cpu_baseline"], ref = cpu_baseline(verts, tris, cd, size, F, sample, registration=with_reg)
+        gpix = last_pix[0].cpu().numpy()
+        checks = {
+            "projection_pix_full_model": bool(np.array_equal(gpix, ref["pix"])),
+            "reference_ray_count": bool(nrays == ref["nrays"]),
+            "oblique_test_first_same_entries": same_entries,
+        }
         if not a.registration:
             # parity of THIS run against the oracle: the projection of the full 1 M-triangle model, and the
             # frame loop on the sample the CPU just processed (same bits in: the frames as generated)
-            gpix = last_pix[0].cpu().numpy()
             d_sample = torch.as_tensor(sample.view(np.int16)).view(torch.uint16).cuda()
             p2 = engine.FramePipeline(1, size, size, N, fused_scan=2 if a.two_kernel else 0)
             p2.set_projection(0, last_pix[0])
@@ -589,26 +799,53 @@ def main():
             p2.process(d_sample, first_frame=0, rows_t=rt, want_rows=False)
             gs, gss = [x.cpu().numpy() for x in p2.accumulators()]
             ok = ~np.isnan(ref["sum"])
-            checks = {
-                "projection_pix_full_model": bool(np.array_equal(gpix, ref["pix"])),
-                "reference_ray_count": bool(nrays == ref["nrays"]),
-                "oblique_test_first_same_entries": same_entries,
+            checks.update({
                 "series_rows_8_frames": bool(np.array_equal(rt[:, :8].cpu().numpy().T.view(np.int32), ref["rows8"].view(np.int32))),
                 "repaired_frames": bool(np.array_equal(d_sample.cpu().view(torch.int16).numpy().view(np.uint16), ref["frames_fixed"])),
                 "accumulators_%d_frames" % n_sample: bool(np.array_equal(np.isnan(gs), ~ok) and np.array_equal(gs[ok], ref["sum"][ok])
                                                        and np.array_equal(gss[ok], ref["sumsq"][ok])),
-            }
+            })
             if chunked:   # the series as it came out of the (chunked, packed, u16) exchange
                 checks["exchange_series_8_frames"] = bool(np.array_equal(
                     exch.out[:, :8].cpu().numpy().T.view(np.int32), ref["rows8"].view(np.int32)))
             if not a.no_reraycast:
                 out["pixel_rays"] = pixel_ray_rate(bvh, cd, size, check_with=ref["obv"])
                 checks["pixel_rays_closest_hit_sample"] = out["pixel_rays"]["parity"]
-            out["parity_checked"] = all(checks.values())
-            out["parity"] = checks
-            if not out["parity_checked"]:
-                print(json.dumps(out), flush=True)
-                raise SystemExit("bench.py: GPU results differ from the oracle: %r" % (checks,))
+        if with_reg:
+            # configs[2]: warps, iteration counts and registered rows of the frames the CPU baseline registered
+            rchecks, rinfo = registration_parity(ref, sample, last_pix[0], N, size)
+            checks.update({"registration_" + k: v for k, v in rchecks.items()})
+            tgt = out if a.registration else out["configs2"]
+            tgt["registration_parity"] = rinfo
+            if not a.registration:
+                # CPU baseline of configs[2]: the same oracle loop with register_pixel per frame
+                pf = ref["loop_per_frame"] + ref["reg"]["seconds_per_frame"] / ref["cores"]
+                out["configs2"]["cpu_baseline"] = {
+                    "value": F / (ref["t_proj"] + ref["t_fixed"] + pf * F), "unit": "frames/s", "cores": ref["cores"], "kind": "port",
+                    "sample": "oracle/ (C, %d threads, one frame per thread): fix_hot_pixels + register_pixel + project_frame on %d frames "
+                              "(%.2f s per frame and thread) + the plain loop's per-frame cost; extrapolated to %d frames"
+                              % (ref["cores"], len(ref["reg"]["fixed"]), ref["reg"]["seconds_per_frame"], F)}
+                # the headline's CPU baseline is the PLAIN loop (configs[1]): take the registration cost out again
+                cb = out["cpu_baseline"]
+                cb["value"] = F / (ref["t_proj"] + ref["t_fixed"] + ref["loop_per_frame"] * F)
+                cb["frame_loop_frames_per_s"] = 1.0 / ref["loop_per_frame"]
+                cb["sample"] = cb["sample"].split(" + fix_hot_pixels, register_pixel")[0] + "; extrapolated to the %d-frame step" % F
+        if plain_default:
+            # the plain ray caster once more on a scene where every pixel's ray enters the tree: a 1 M-triangle sphere
+            # that fills the frame (the tunnel model covers 8 % of the pixels)
+            fv, ft = syn.cube_sphere(289, 6.0)
+            fs9, _ = syn.soup(fv, ft)
+            fcd = syn.pinhole_camera(size, size, center=(0, 0, 20), half_extent=6.0, fill=0.95)
+            fbvh = engine.BVH(fs9)
+            out["pixel_rays_fill"] = pixel_ray_rate(fbvh, fcd, size, check_with=orc_bvh(fs9))
+            out["pixel_rays_fill"]["scene"] = "cube sphere, %d triangles, filling the frame" % ft.shape[0]
+            checks["pixel_rays_fill_closest_hit_sample"] = out["pixel_rays_fill"]["parity"]
+            fbvh.close()
+        out["parity_checked"] = all(checks.values())
+        out["parity"] = checks
+        if not out["parity_checked"]:
+            print(json.dumps(out), flush=True)
+            raise SystemExit("bench.py: GPU results differ from the oracle: %r" % (checks,))
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

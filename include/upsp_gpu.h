@@ -30,7 +30,9 @@ typedef enum upsp_status {
     UPSP_ERR_DEPTH = -3,     /* BVH deeper than the 64-entry traversal stack (pspRT.cpp:374) */
     UPSP_ERR_HIP = -4,       /* HIP runtime error, see upsp_last_error() */
     UPSP_ERR_NO_DEVICE = -5, /* no gfx950 device visible */
-    UPSP_ERR_DIVERGED = -6   /* ECC registration failed (cv::findTransformECC would throw) */
+    UPSP_ERR_DIVERGED = -6,  /* ECC registration failed (cv::findTransformECC would throw) */
+    UPSP_ERR_INTERNAL = -7   /* a BVH walk ran past its round cap (2 x nodes: broken tree); the reference DIEs on a
+                                broken BVH (pspRT.cpp:362-365) -- here an error code, never a wedged device */
 } upsp_status;
 
 const char *upsp_last_error(void);
@@ -107,6 +109,14 @@ int upsp_bvh_occluded_host(const upsp_bvh *bvh, const float *h_org, int org_stri
  * BVH (summed over rays): interior nodes fetched, triangles tested, rays cast.
  * Collected only after upsp_bvh_enable_stats(bvh, 1). */
 int upsp_bvh_enable_stats(upsp_bvh *bvh, int on);
+
+/* Waits for `stream` and reports whether any walk launched on this BVH since the last check ran past its
+ * round cap (UPSP_ERR_INTERNAL; a ray visits every node of a well-formed tree at most once, so a walk that needs
+ * more than 2 x nodes rounds is running on a broken tree and ends with an error flag instead of looping:
+ * the reference DIEs on a broken BVH, cpp/raycast/pspRT.cpp:362-365).  The host-buffer queries, the statistics and
+ * upsp_projection_fetch_counts / upsp_projection_build(h_nrays != NULL) check by themselves; callers that queue
+ * device-side launches without synchronising call this at their own synchronisation point. */
+int upsp_bvh_check(upsp_bvh *bvh, void *stream);
 int upsp_bvh_last_stats(const upsp_bvh *bvh, uint64_t *nodes, uint64_t *tris, uint64_t *rays);
 
 /* ======================================================================== *
@@ -330,6 +340,10 @@ int upsp_pipeline_process_u16(upsp_pipeline *p, uint16_t *const *d_frames, int n
  * the registered frames (cv::findTransformECC's loop count, cpp/lib/registration.cpp:64) and the
  * number of frames that went through it. */
 int upsp_pipeline_ecc_stats(upsp_pipeline *p, uint64_t *frame_iterations, uint64_t *frames);
+/* Per-frame iteration counts of the registration stage (the value cv::findTransformECC's loop ends with,
+ * cpp/lib/registration.cpp:64): d_iters int32 [nframes][ncams] of every following upsp_pipeline_process
+ * call is filled stream-ordered (frame 0 of a run, never registered: 0); NULL switches it off. */
+int upsp_pipeline_set_ecc_iterations_out(upsp_pipeline *p, int32_t *d_iters);
 
 /* Accumulator access (device pointers to nnodes doubles each), used for the
  * cross-GPU sum that replaces MPI_Reduce (psp_process.cpp:1866-1872). */
@@ -357,6 +371,9 @@ int upsp_feed_create(size_t slot_bytes, int nslots, upsp_feed **out);
 void upsp_feed_destroy(upsp_feed *f);
 int upsp_feed_acquire(upsp_feed *f, int *slot, void **h_ptr);
 int upsp_feed_commit(upsp_feed *f, int slot, size_t nbytes, void *consumer_stream, void **d_ptr);
+/* gives an acquired slot back unfilled (the reader failed: short read, frame out of range); it is the
+ * next slot upsp_feed_acquire hands out */
+int upsp_feed_abort(upsp_feed *f, int slot);
 int upsp_feed_release(upsp_feed *f, int slot, void *consumer_stream);
 
 /* ---- stand-alone per-frame operators (same kernels the pipeline uses) ------ */
@@ -474,8 +491,8 @@ int upsp_interpolate_idw(const float *h_src_nodes3, const float *h_src_data, siz
  * ======================================================================== */
 
 /* Per-kernel timing with HIP events recorded on the launch stream.  enable(1) clears
- * earlier records.  report(): one line per kernel "name calls total_ms"; the caller
- * must have synchronised the stream(s). */
+ * earlier records.  report(): one line per kernel "name calls total_ms min_ms median_ms max_ms" (the last
+ * three: spread of the single timed spans); the caller must have synchronised the stream(s). */
 int upsp_timing_enable(int on);
 int upsp_timing_report(char *buf, size_t cap);
 

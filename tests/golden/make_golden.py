@@ -3,8 +3,11 @@
 
 Runs ONLY in the build container (needs /root/reference).  It
 
-1. copies the reference's own test data files used by the ray-cast KATs
-   (test/data/fml_tc3_volume.grid, test/data/camera-tunnel-calibration/camera01_35_6.json);
+1. copies EVERY reference-held data file the tests use (FIXTURES below: the fml grid, camera calibration,
+   target list, tunnel-conditions sample, the PLOT3D / TriModel sample files; the MRAW pair is handled by
+   make_golden_video.py), checks that the committed copies are byte-identical to the reference's, and records
+   each one's origin in the manifest (`reference_files`, `reference_data_fixtures`) -- regeneration cannot
+   silently drop provenance;
 2. imports the reference's *Python* input-preparation code unmodified
    (upsp.processing.p3d_utilities / p3d_conversions, upsp.cam_cal_utils.parsers,
    VisibilityChecker.package_primitives / get_tvecs_and_norms) and checks that
@@ -33,17 +36,61 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+# committed fixture (relative to tests/golden/) -> (path under /root/reference, what it is / which reference test holds its expectations)
+FIXTURES = {
+    "fml_tc3_volume.grid": ("test/data/fml_tc3_volume.grid",
+                            "PLOT3D surface grid of the reference's regression model (test/python/test_visibility.py)"),
+    "camera01_35_6.json": ("test/data/camera-tunnel-calibration/camera01_35_6.json",
+                           "camera-to-tunnel calibration of camera 1"),
+    "wtd_test.wtd": ("test/data/wtd_test.wtd", "tunnel-conditions sample read by read_tunnel_conditions"),
+    "fml_tc3_volume.tgts": ("test/data/fml_tc3_volume.tgts", "target / fiducial list of the fml grid"),
+}
+for _n in ("sphere_unf_single_integration_sp.x", "sphere_unf_single_integration_dp.x",
+           "sphere_unf_single_integration_sp_bigend.x", "sphere_unf_single_integration_dp_bigend.x",
+           "sphere_unf_multi_integration_sp.x", "sphere_unf_multi_integration_dp.x",
+           "sphere_unf_multi_integration_sp_bigend.x", "sphere_unf_multi_integration_dp_bigend.x",
+           "sphere_unf_multi_integration_sp_iblank.x", "sphere_unf_multi_integration_dp_iblank.x",
+           "sphere_unf_single.tri", "sphere_unf_multi.tri", "sphere_unf_multi.i.tri"):
+    FIXTURES["p3d/" + _n] = ("cpp/test/inputs/" + _n,
+                             "PLOT3D / TriModel sample (expectations: cpp/test/test_plot3d.cpp:5-128, cpp/test/test_trimodel.cpp:63-141)")
+for _n in ("26-scalars-with-seps.f", "26-scalars-without-seps.f"):
+    FIXTURES["p3d/" + _n] = ("cpp/test/sample_data/" + _n, "PLOT3D function-file sample (cpp/test/test_plot3d.cpp)")
+
+
+def file_sha(path):
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()
+
+
+def sync_fixtures():
+    """Copy missing fixtures from the reference, verify the committed ones byte for byte; returns the provenance block."""
+    prov = {}
+    for name, (src, what) in sorted(FIXTURES.items()):
+        dst, ref = os.path.join(HERE, name), os.path.join(REF, src)
+        assert os.path.exists(ref), "reference fixture missing: " + src
+        if not os.path.exists(dst):
+            os.makedirs(os.path.dirname(dst), exist_ok=True)
+            shutil.copyfile(ref, dst)
+            os.chmod(dst, 0o644)
+        assert file_sha(dst) == file_sha(ref), "committed fixture %s differs from %s" % (name, src)
+        prov[name] = {"from": src, "what": what + "; data file, copied verbatim", "sha256": file_sha(dst)}
+    return prov
+
+
 def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
 def main():
     assert os.path.isdir(REF), "reference tree not mounted"
-    for src in ("test/data/fml_tc3_volume.grid", "test/data/camera-tunnel-calibration/camera01_35_6.json"):
-        dst = os.path.join(HERE, os.path.basename(src))
-        if not os.path.exists(dst):
-            shutil.copyfile(os.path.join(REF, src), dst)
-            os.chmod(dst, 0o644)
+    prov = sync_fixtures()
+    if "--fixtures-only" in sys.argv:             # provenance block only (no reference Python imported)
+        mpath = os.path.join(HERE, "golden_manifest.json")
+        manifest = json.load(open(mpath))
+        manifest["reference_files"] = sorted(v["from"] for v in prov.values())
+        manifest["reference_data_fixtures"] = prov
+        json.dump(manifest, open(mpath, "w"), indent=1)
+        print("provenance of %d fixtures written" % len(prov))
+        return
     if not hasattr(np, "product"):
         np.product = np.prod                      # removed in NumPy 2, used by p3d_utilities.py:114
     for name in ("cv2", "upsp.raycast"):          # import-only placeholders, never called
@@ -95,8 +142,8 @@ def main():
     assert len(vis) == 148608, len(vis)
     np.savez_compressed(os.path.join(HERE, "camera01_visible.npz"), visible=vis.astype(np.int32))
     manifest = {
-        "reference_files": ["test/data/fml_tc3_volume.grid",
-                            "test/data/camera-tunnel-calibration/camera01_35_6.json"],
+        "reference_files": sorted(v["from"] for v in prov.values()),
+        "reference_data_fixtures": prov,
         "primitives_sha256": sha(prims.astype(np.float32)),
         "nodes_sha256": sha(nodes), "normals_sha256": sha(norms),
         "visible_count": int(len(vis)), "visible_sha256": sha(vis.astype(np.int32)),

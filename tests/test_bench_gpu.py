@@ -37,6 +37,19 @@ def test_bench_small_line_and_parity(gpu_lib):
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
 
 
+def test_bench_small_registration_parity(gpu_lib):
+    """`--registration` (configs[2] shape) checks itself too: warps, ECC iteration counts and registered rows of the
+    frames the CPU baseline registered, against the oracle, at the bench's own 1024 x 1024 image size."""
+    d = run_bench(["--small", "--registration", "--steps", "1", "--warmup", "1"])
+    assert d["config"]["workload"].startswith("configs[2]")
+    assert d["parity_checked"] is True and all(d["parity"].values()), d["parity"]
+    for k in ("registration_ecc_warp_linear_1e-4", "registration_ecc_warp_translation_2e-3_px",
+              "registration_ecc_iteration_counts", "registration_rows_bitexact_for_gpu_warp"):
+        assert d["parity"][k] is True, k
+    assert d["registration_parity"]["frames"] >= 2 and d["ecc_iterations_per_frame"] >= 1.0
+    assert d["roofline"]["kernel"] in d["kernels"]
+
+
 def test_bench_two_ranks_on_one_gpu_gloo(gpu_lib):
     """`--gpus 2` launches its own two ranks; on a one-GPU box both sit on cuda:0 and talk through gloo
     (the RCCL run needs two GPUs: next test).  The exchange runs packed u16 rows in 4 chunks."""

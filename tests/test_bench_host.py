@@ -25,3 +25,14 @@ def test_usable_cpus_is_positive():
     import bench
     n = bench.usable_cpus()
     assert isinstance(n, int) and n >= 1
+
+
+def test_rays_entering_counts_the_lines_through_the_box():
+    """bench.rays_entering (the `rays_entered` figure of the pixel-ray legs): slab test of the ray's LINE, axis-parallel
+    rays included."""
+    import bench
+    org = np.array([0.0, 0.0, 10.0])
+    d = np.array([[0, 0, -1.0], [0, 0, 1.0], [1, 0, 0.0], [0.05, 0, -1.0], [0.5, 0, -1.0], [0, 0.0999, -1.0]])
+    # box [-1, 1]^3: straight down enters; straight up is the same LINE (the reference's box test is a line test);
+    # parallel to x at z = 10 misses; slightly tilted enters (x = 0.45..0.55 inside the slab), strongly tilted misses
+    assert bench.rays_entering(org, d, [-1, -1, -1], [1, 1, 1]) == 4

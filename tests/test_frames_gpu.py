@@ -589,6 +589,58 @@ def test_prescan_with_candidate_map(gpu_lib, oracle, F):
     assert torch.equal(rt3.view(torch.int32), rt2.view(torch.int32))
 
 
+def test_stale_prescan_is_dropped(gpu_lib):
+    """prescan(frames) -> set_projection(another projection, no active hint) -> process(frames): the compact
+    series pass A wrote were laid out with the OLD active-pixel map and must not be consumed (ADVICE r2);
+    the result equals a process call without any prescan.  Likewise after set_active_hint(None), and a
+    prescan is dropped by an intervening process call of other frames."""
+    import torch
+    from upsp_processing_amd import engine, synthetic as syn
+    H, W, n, F = 64, 130, 2500, 70
+    rng = np.random.default_rng(5)
+    fr = np.minimum(syn.synth_frames_numpy(F, H, W, seed=82, hot=False), 3000).astype(np.uint16)
+    pix_a = rng.integers(-1, H * W, size=n).astype(np.int32)
+    pix_b = rng.integers(-1, H * W, size=n).astype(np.int32)
+
+    def plain(pix, frames):
+        q = engine.FramePipeline(1, W, H, n)
+        q.set_projection(0, pix)
+        rt = torch.empty((n, F), dtype=torch.float32, device="cuda")
+        q.process(torch.as_tensor(frames.copy()).cuda(), 0, rows_t=rt, want_rows=False)
+        return rt.view(torch.int32).clone(), [a.clone() for a in q.accumulators()]
+
+    want, acc = plain(pix_b, fr)
+    d = torch.as_tensor(fr.copy()).cuda()
+    for how in ("projection", "hint_cleared"):
+        pipe = engine.FramePipeline(1, W, H, n)
+        if how == "projection":
+            pipe.set_projection(0, pix_a)
+            pipe.prescan(d)
+            pipe.set_projection(0, pix_b)
+        else:
+            pipe.set_active_hint(torch.as_tensor(pix_a).cuda())
+            pipe.prescan(d)
+            pipe.set_active_hint(None)
+            pipe.set_projection(0, pix_b)
+        rt = torch.empty((n, F), dtype=torch.float32, device="cuda")
+        pipe.process(d, 0, rows_t=rt, want_rows=False)
+        assert torch.equal(rt.view(torch.int32), want), how
+        for g, w in zip(pipe.accumulators(), acc):
+            assert torch.equal(g.view(torch.int64), w.view(torch.int64)), how
+    # a prescan is consumed or dropped by the NEXT process call: other frames in between, then the first batch
+    fr2 = np.minimum(syn.synth_frames_numpy(F, H, W, seed=83, hot=False), 3000).astype(np.uint16)
+    pipe = engine.FramePipeline(1, W, H, n)
+    pipe.set_projection(0, pix_b)
+    pipe.prescan(d)
+    d2 = torch.as_tensor(fr2.copy()).cuda()
+    rt = torch.empty((n, F), dtype=torch.float32, device="cuda")
+    pipe.process(d2, 0, rows_t=rt, want_rows=False)
+    assert torch.equal(rt.view(torch.int32), plain(pix_b, fr2)[0])
+    pipe.reset()
+    pipe.process(d, 0, rows_t=rt, want_rows=False)
+    assert torch.equal(rt.view(torch.int32), want)
+
+
 def test_candidate_pixels_superset(gpu_lib):
     """upsp_projection_candidate_pixels: every pixel of the projection equals the node's candidate pixel."""
     import torch

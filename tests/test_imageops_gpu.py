@@ -169,3 +169,73 @@ def test_pipeline_with_stages(gpu_lib, oracle, cfg):
         assert np.array_equal(w[0], [1, 0, 0, 0, 1, 0])     # frame 0 is never registered
         d = np.abs(rows_g[:, ok] - rows_o[:, ok])
         assert d.max() <= 12.0 and d.mean() <= 0.5
+
+
+def test_registration_full_size_1024(gpu_lib, oracle):
+    """configs[2] at its own image size: 1024 x 1024 frames through FramePipeline(registration=1) against
+    oracle.register_pixel + project_frame (cpp/lib/registration.cpp:32-81, cpp/exec/psp_process.cpp:1776-1795).
+
+    9 frames of the bench's image model (sub-pixel jitter, hot pixels) + one frame moved by ~9 px with shear
+    (wide border band of the ECC sums: the interior / band split of ecc_sums2_kernel takes its ranges from the
+    image size and the warp) + one moved by 2.4 px.  Bars:
+      ECC warp matrix        max|dM| <= 1e-4 (linear part), <= 2e-3 px (translation), per frame
+      ECC iteration count    identical, per frame
+      warped u16 frame       bit-exact for the GPU's own matrix (exact integer arithmetic)
+      series rows            bit-exact vs project_frame(warpAffine(frame, M_gpu)); vs the oracle's own chain
+                             (its M) within |dI| <= 8 counts, mean <= 0.25 (|grad I| ~ 17 counts/px x <= 2e-3 px
+                             + the 1/32-px requantisation of the warp coordinates, at most one step = 0.5 counts;
+                             noise 8 counts rms carried by both)"""
+    import torch
+    from upsp_processing_amd import engine, synthetic as syn
+    H = W = 1024
+    F, n = 11, 60000
+    frames = syn.synth_frames_numpy(F - 2, H, W, seed=11, hot=True)
+    ref = frames[0].astype(np.float32)
+    # two frames with real model motion: frame 0's scene resampled through a known affine map (border pixels
+    # come in as 0 -> the mask and the band paths are exercised), fresh noise on top
+    rng = np.random.default_rng(12)
+    moved = []
+    for A in (np.array([[1.0 + 2.5e-3, 2e-3, 8.7], [-1.5e-3, 1.0 - 2e-3, -9.4]], np.float32),
+              np.array([[1.0, -4e-4, -2.4], [6e-4, 1.0, 1.3]], np.float32)):
+        m = oracle.warp_affine(frames[0], A, 1).astype(np.float64) + rng.normal(0, 4, (H, W))
+        moved.append(np.clip(np.rint(m), 0, 4095).astype(np.uint16))
+    frames = np.concatenate([frames[:5], moved[0][None], frames[5:], moved[1][None]])
+    assert frames.shape[0] == F
+    inner = rng.integers(16, H - 16, n) * W + rng.integers(16, W - 16, n)
+    pix = inner.astype(np.int32)
+    pix[::17] = -1
+    pipe = engine.FramePipeline(1, W, H, n, registration=1)
+    pipe.set_projection(0, pix)
+    pipe.set_reference(0, ref)
+    warps = torch.zeros((F, 1, 6), dtype=torch.float32, device="cuda")
+    iters = torch.full((F, 1), -1, dtype=torch.int32, device="cuda")
+    d = torch.as_tensor(frames.copy()).cuda()
+    rows_g = pipe.process(d, 0, warps=warps, ecc_iters=iters).cpu().numpy()
+    w = warps.cpu().numpy()[:, 0].reshape(F, 2, 3)
+    it_g = iters.cpu().numpy()[:, 0]
+    ok = pix >= 0
+    assert np.isnan(rows_g[:, ~ok]).all()
+    assert np.array_equal(w[0].reshape(-1), [1, 0, 0, 0, 1, 0]) and it_g[0] == 0      # frame 0 is never registered
+    st = pipe.ecc_stats()
+    assert st["frames"] == F and st["frame_iterations"] == int(it_g.sum())
+    worst = [0.0, 0.0, 0.0]
+    for f in range(F):
+        img, _ = oracle.fix_hot_pixels(frames[f])
+        assert np.array_equal(d[f].cpu().numpy(), img), f                              # repaired in place, like the reference
+        if f == 0:
+            assert np.array_equal(rows_g[0, ok].view(np.int32), oracle.project_frame(img, pix, None)[ok].view(np.int32))
+            continue
+        out_o, M_o, it_o = oracle.register_pixel(ref, img)
+        assert it_g[f] == it_o, (f, it_g[f], it_o)
+        dl, dt = np.abs(w[f][:, :2] - M_o[:, :2]).max(), np.abs(w[f][:, 2] - M_o[:, 2]).max()
+        assert dl <= 1e-4 and dt <= 2e-3, (f, dl, dt)
+        # same matrix -> same u16 frame -> same rows, bit for bit
+        warped = oracle.warp_affine(img, w[f], 1)
+        want = oracle.project_frame(warped, pix, None)
+        assert np.array_equal(rows_g[f, ok].view(np.int32), want[ok].view(np.int32)), f
+        # the whole oracle chain with its own matrix
+        dd = np.abs(rows_g[f, ok] - oracle.project_frame(out_o, pix, None)[ok])
+        assert dd.max() <= 8.0 and dd.mean() <= 0.25, (f, dd.max(), dd.mean())
+        worst = [max(worst[0], dl), max(worst[1], dt), max(worst[2], float(dd.max()))]
+    assert it_g[5] >= 3                                                                 # the 9-px frame really iterates
+    print("1024^2 registration: iterations %s, worst |dM| %.2e, |dt| %.2e px, |dI| %.2f" % (it_g.tolist(), *worst))

@@ -187,6 +187,60 @@ def test_heavy_rays_of_a_batch(gpu_lib, oracle, monkeypatch, steps):
         assert np.array_equal(bvh.occluded(cam, d).cpu().numpy(), o["hit"])
 
 
+def test_walks_end_with_an_error_not_a_hang(gpu_lib, oracle, monkeypatch):
+    """Every walk carries a round cap (2 x nodes on a well-formed tree, which no ray can reach); a walk that runs past
+    it sets an error flag and ENDS, and the next synchronising entry point returns UPSP_ERR_INTERNAL -- the reference
+    DIEs on a broken BVH (pspRT.cpp:362-365), the device is never wedged.  Forced here with UPSP_ROUND_CAP = 2 rounds:
+    the one-lane traversal (batch query, projection build), the cooperative walk (every ray handed over) and the
+    explicit check; afterwards, with the cap back at its real value, the same calls are bit-exact again."""
+    import torch
+    from upsp_processing_amd import _capi, engine, synthetic as syn
+    v, t = syn.uv_sphere(40, 80)
+    s9, tn = syn.soup(v, t)
+    nrm = syn.node_normals(v, t)
+    bvh, obv = engine.BVH(s9), oracle.OracleBVH(s9)
+    cam = np.array([0.1, 0.2, 20.0], np.float32)
+    d = (v[::3] - cam).astype(np.float32)
+    c = syn.pinhole_camera(256, 256)
+    cam_g = _capi.make_camera(c["K"], c["dist"], c["R"], c["t"], 256, 256)
+    d_nodes, d_nrm, d_tn = [torch.as_tensor(a).cuda() for a in (v, nrm, tn)]
+
+    def expect_internal(fn):
+        with pytest.raises(_capi.UpspError) as e:
+            fn()
+        assert e.value.status == -7, e.value
+
+    monkeypatch.setenv("UPSP_ROUND_CAP", "2")
+    bvh.intersect(torch.as_tensor(cam).cuda(), torch.as_tensor(d).cuda())      # device buffers: no sync, no error yet ...
+    expect_internal(bvh.check)                                                  # ... reported at the caller's sync point
+    bvh.check()                                                                 # (reported once)
+
+    def host_query():                                                           # host buffers: the call synchronises itself
+        import ctypes as C
+        n = d.shape[0]
+        tt = np.zeros(n, np.float32)
+        h = _capi.Hits()
+        h.t = tt.ctypes.data
+        _capi.check(gpu_lib.upsp_bvh_intersect_host(bvh.handle, cam.ctypes.data_as(C.c_void_p), 0,
+                                                    d.ctypes.data_as(C.c_void_p), n, C.byref(h)))
+    expect_internal(host_query)
+    expect_internal(lambda: engine.build_projection(bvh, cam_g, d_nodes, d_nrm, d_tn, 70.0, counts=True))
+    monkeypatch.setenv("UPSP_HEAVY_STEPS_CAST", "1")                           # every ray to the cooperative walk
+    bvh.intersect(torch.as_tensor(cam).cuda(), torch.as_tensor(d).cuda())
+    expect_internal(bvh.check)
+    monkeypatch.delenv("UPSP_ROUND_CAP")
+    g, o = bvh.intersect(cam, d), obv.intersect(cam, d)
+    assert_hits_equal(g, o)
+    bvh.check()
+    monkeypatch.delenv("UPSP_HEAVY_STEPS_CAST")
+    assert_hits_equal(bvh.intersect(cam, d), o)
+    p = engine.build_projection(bvh, cam_g, d_nodes, d_nrm, d_tn, 70.0, counts=True)
+    cam_o = oracle.make_camera(c["K"], c["dist"], c["R"], c["t"], 256, 256)
+    po = oracle.create_projection(obv, cam_o, v, nrm, tn, engine.oblique_threshold(70.0))
+    assert np.array_equal(p["pix"].cpu().numpy(), po["pix"]) and p["nrays"] == po["nrays"]
+    bvh.check()
+
+
 def test_full_size_properties(gpu_lib):
     """BASELINE config size (1 M-tri model, 1 Mi rays): size-independent properties.
     * scale invariance of the hit set: d and 2d hit the same triangle with t/2;

@@ -217,4 +217,19 @@ def test_frame_feed_ring(gpu_lib):
         assert np.array_equal(o.cpu().view(torch.int16).numpy().view(np.uint16), w)
     with pytest.raises(_capi.UpspError):
         feed.upload(lambda dst: feed.slot_bytes + 1)        # more bytes than the slot holds
+
+    def bad_reader(dst):
+        raise IndexError("frame out of range")
+    with pytest.raises(IndexError):
+        feed.upload(bad_reader)                             # the reader fails: the slot goes back (upsp_feed_abort)
+    for k in range(4):                                      # ... and the feed is still usable, all the way round the ring
+        raw = rng.integers(0, 256, (n, fb), dtype=np.uint8)
+
+        def fill2(dst, raw=raw):
+            dst[:raw.size] = raw.reshape(-1)
+            return raw.size
+        d = feed.upload(fill2)
+        got = d.cpu().numpy().copy()
+        feed.release()
+        assert np.array_equal(got, raw.reshape(-1))
     feed.close()

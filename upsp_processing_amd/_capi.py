@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libupsp_gpu.so")
 
 UPSP_OK = 0
 STATUS = {0: "UPSP_OK", -1: "UPSP_ERR_INVALID", -2: "UPSP_ERR_EMPTY", -3: "UPSP_ERR_DEPTH",
-          -4: "UPSP_ERR_HIP", -5: "UPSP_ERR_NO_DEVICE", -6: "UPSP_ERR_DIVERGED"}
+          -4: "UPSP_ERR_HIP", -5: "UPSP_ERR_NO_DEVICE", -6: "UPSP_ERR_DIVERGED", -7: "UPSP_ERR_INTERNAL"}
 
 
 class UpspError(RuntimeError):
@@ -62,6 +62,7 @@ SIGNATURES = {
     "upsp_bvh_occluded": (_i, [_vp, _vp, _i, _vp, _sz, _vp, _vp]),
     "upsp_bvh_occluded_host": (_i, [_vp, _vp, _i, _vp, _sz, _vp]),
     "upsp_bvh_enable_stats": (_i, [_vp, _i]),
+    "upsp_bvh_check": (_i, [_vp, _vp]),
     "upsp_bvh_last_stats": (_i, [_vp, _u64p, _u64p, _u64p]),
     "upsp_projection_build": (_i, [_vp, C.POINTER(Camera), _vp, _vp, _vp, _vp, _sz, C.c_float,
                                    _vp, _vp, _vp, _u64p, _vp]),
@@ -89,6 +90,7 @@ SIGNATURES = {
     "upsp_pipeline_set_patches": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "upsp_pipeline_process": (_i, [_vp, C.POINTER(_vp), _i, _i64, _vp, _vp, _i64, _i64, _vp, _vp]),
     "upsp_pipeline_ecc_stats": (_i, [_vp, _vp, _vp]),
+    "upsp_pipeline_set_ecc_iterations_out": (_i, [_vp, _vp]),
     "upsp_pipeline_set_active_hint": (_i, [_vp, _vp, _vp]),
     "upsp_pipeline_prescan": (_i, [_vp, _vp, _i, _vp]),
     "upsp_projection_candidate_pixels": (_i, [C.POINTER(Camera), _vp, _vp, _sz, _vp, _vp]),
@@ -96,6 +98,7 @@ SIGNATURES = {
     "upsp_feed_destroy": (None, [_vp]),
     "upsp_feed_acquire": (_i, [_vp, C.POINTER(_i), C.POINTER(_vp)]),
     "upsp_feed_commit": (_i, [_vp, _i, _sz, _vp, C.POINTER(_vp)]),
+    "upsp_feed_abort": (_i, [_vp, _i]),
     "upsp_feed_release": (_i, [_vp, _i, _vp]),
     "upsp_pipeline_process_u16": (_i, [_vp, C.POINTER(_vp), _i, _i64, _vp, _i64, _i64, _vp, _vp]),
     "upsp_pipeline_accumulators": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
@@ -172,12 +175,13 @@ def timing_enable(on=True):
     check(lib().upsp_timing_enable(int(bool(on))))
 
 
-def timing_report():
-    """dict name -> (calls, total_ms) of the kernels timed since timing_enable(True)."""
+def timing_report(spread=False):
+    """dict name -> (calls, total_ms) of the kernels timed since timing_enable(True);
+    spread=True: (calls, total_ms, min_ms, median_ms, max_ms) -- the spread of the single timed spans."""
     buf = C.create_string_buffer(1 << 16)
     check(lib().upsp_timing_report(buf, len(buf)))
     out = {}
     for line in buf.value.decode().splitlines():
-        name, n, ms = line.rsplit(" ", 2)
-        out[name] = (int(n), float(ms))
+        name, n, ms, lo, med, hi = line.rsplit(" ", 5)
+        out[name] = (int(n), float(ms), float(lo), float(med), float(hi)) if spread else (int(n), float(ms))
     return out

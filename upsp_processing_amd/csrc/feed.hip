@@ -105,6 +105,16 @@ int upsp_feed_commit(upsp_feed *f, int slot, size_t nbytes, void *consumer_strea
     return UPSP_OK;
 }
 
+int upsp_feed_abort(upsp_feed *f, int slot)
+{
+    if (!f || slot < 0 || slot >= f->nslots) return fail(UPSP_ERR_INVALID, "bad argument");
+    if (f->state[slot] != 1) return fail(UPSP_ERR_INVALID, "feed: slot was not acquired");
+    // nothing was uploaded and nobody waits on it: the slot is simply free again and is the next one handed out
+    f->state[slot] = 0;
+    f->next = slot;
+    return UPSP_OK;
+}
+
 int upsp_feed_release(upsp_feed *f, int slot, void *consumer_stream)
 {
     if (!f || slot < 0 || slot >= f->nslots) return fail(UPSP_ERR_INVALID, "bad argument");

@@ -905,11 +905,13 @@ __global__ void ecc_count_active(const EccState *state, int nframes, int *out)
     atomicMax(&out[3], most);        // iterations of the frame that needed most (sizes the next sub-batch's first burst)
 }
 
-__global__ void ecc_export_warps(const EccState *state, int nframes, float *warps, int stride)
+__global__ void ecc_export_warps(const EccState *state, int nframes, float *warps, int stride, int32_t *iters, int istride)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= nframes) return;
-    for (int i = 0; i < 6; ++i) warps[(size_t)f * stride + i] = state[f].M[i];
+    if (warps)
+        for (int i = 0; i < 6; ++i) warps[(size_t)f * stride + i] = state[f].M[i];
+    if (iters) iters[(size_t)f * istride] = state[f].iters;
 }
 
 // ----------------------------------------------------------------- patches --
@@ -1383,8 +1385,8 @@ int launch_pixel_list(const int32_t *d_pix, size_t nnodes, uint8_t *d_mask, unsi
 
 int run_frame_stages(FrameScratch *s, int cam, const uint16_t *d_frames, int nb, int64_t first_frame,
                      int rows, int cols, const upsp_pipeline_opts &opts, const float *d_ref,
-                     const PatchTables *patches, float *d_warps, int ncams, const unsigned *d_read_list,
-                     const void **img_out, int *is_f32_out, hipStream_t st)
+                     const PatchTables *patches, float *d_warps, int32_t *d_iters, int ncams,
+                     const unsigned *d_read_list, const void **img_out, int *is_f32_out, hipStream_t st)
 {
     const size_t npix = (size_t)rows * cols;
     const uint16_t *cur = d_frames;
@@ -1406,9 +1408,10 @@ int run_frame_stages(FrameScratch *s, int cam, const uint16_t *d_frames, int nb,
             hipLaunchKernelGGL(warp_u16_kernel, wgrid, block, 0, st, d_frames, s->warp[cam], rows, cols,
                                (const EccState *)s->state, opts.interp, listed ? d_read_list : (const unsigned *)nullptr);
         }
-        if (d_warps)
+        if (d_warps || d_iters)
             hipLaunchKernelGGL(ecc_export_warps, dim3((nb + 63) / 64), dim3(64), 0, st,
-                               (const EccState *)s->state, nb, d_warps + (size_t)cam * 6, ncams * 6);
+                               (const EccState *)s->state, nb, d_warps ? d_warps + (size_t)cam * 6 : (float *)nullptr,
+                               ncams * 6, d_iters ? d_iters + cam : (int32_t *)nullptr, ncams);
         cur = s->warp[cam];
     }
     if (opts.filter == 1 && !opts.patch) {

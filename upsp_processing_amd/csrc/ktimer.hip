@@ -2,6 +2,7 @@
 // launched on; resolved at report time (after the caller has synchronised).
 #include "ktimer.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -76,15 +77,20 @@ int upsp_timing_report(char *buf, size_t cap)
         const Entry &e = g_entries[name];
         double total = 0;
         int n = 0;
+        std::vector<float> each;
         for (const auto &s : e.spans) {
             float ms = 0;
             if (hipEventSynchronize(s.b) == hipSuccess && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
                 total += ms;
+                each.push_back(ms);
                 ++n;
             }
         }
-        char line[256];
-        std::snprintf(line, sizeof(line), "%s %d %.6f\n", name.c_str(), n, total);
+        std::sort(each.begin(), each.end());
+        // name, spans, total ms, then the spread of the spans: min, median, max
+        char line[320];
+        std::snprintf(line, sizeof(line), "%s %d %.6f %.6f %.6f %.6f\n", name.c_str(), n, total,
+                      n ? each.front() : 0.f, n ? each[n / 2] : 0.f, n ? each.back() : 0.f);
         out += line;
     }
     if (out.size() + 1 > cap) return fail(UPSP_ERR_INVALID, "timing report buffer too small");

@@ -53,6 +53,9 @@ struct upsp_pipeline {
     // pass A already run by upsp_pipeline_prescan for these frames (consumed by the next matching process call)
     const uint16_t *prescan_frames = nullptr;
     int prescan_n = 0;
+    // generation of the active-pixel map (bumped by every rebuild / invalidation): a prescan is only consumed by a
+    // process call that still sees the map its compact buffer was laid out with
+    uint64_t map_gen = 0, prescan_gen = 0;
     // the same per camera for the multi-camera streamed schedule
     uint8_t *m_aflag[kMaxCams] = {nullptr};
     unsigned *m_tile_off[kMaxCams] = {nullptr};
@@ -65,6 +68,7 @@ struct upsp_pipeline {
     int pre_capacity = 0;
     // registration / patch / filter state
     float *d_ref[kMaxCams] = {nullptr};
+    int32_t *d_ecc_iters = nullptr;   // caller's buffer (upsp_pipeline_set_ecc_iterations_out), optional
     upsp::PatchTables *patches[kMaxCams] = {nullptr};
     upsp::FrameScratch *scratch = nullptr;
     int batch = 32;
@@ -93,6 +97,15 @@ int ensure_hot_scratch(unsigned *&count, unsigned *&pos, int &capacity, int nfra
     UPSP_HIP_CHECK(hipMalloc(&pos, sizeof(unsigned) * (size_t)nframes * 64));
     capacity = nframes;
     return UPSP_OK;
+}
+
+// The active-pixel map no longer describes what the next frame loop reads: a pass A that already ran
+// (upsp_pipeline_prescan) laid its compact buffer out with the old map and must not be consumed.
+void invalidate_map(upsp_pipeline *p)
+{
+    p->tilemap_valid = false;
+    p->prescan_frames = nullptr;
+    ++p->map_gen;
 }
 
 int ensure_hot(upsp_pipeline *p, int nframes)
@@ -235,7 +248,7 @@ int upsp_pipeline_set_projection(upsp_pipeline *p, int cam, const int32_t *d_pix
     p->has_proj[cam] = true;
     p->read_list_valid[cam] = false;
     p->m_valid[cam] = false;
-    if (!p->hint_active) p->tilemap_valid = false;
+    if (!p->hint_active) invalidate_map(p);
     p->node_k_valid = false;
     if (!p->skipped_user) p->skipped_valid = false;
     return UPSP_OK;
@@ -262,7 +275,7 @@ int upsp_pipeline_set_projection_async(upsp_pipeline *p, int cam, const int32_t 
     p->has_proj[cam] = true;
     p->read_list_valid[cam] = false;
     p->m_valid[cam] = false;
-    if (!p->hint_active) p->tilemap_valid = false;
+    if (!p->hint_active) invalidate_map(p);
     p->node_k_valid = false;
     if (!p->skipped_user) p->skipped_valid = false;
     return UPSP_OK;
@@ -387,6 +400,13 @@ int upsp_pipeline_ecc_stats(upsp_pipeline *p, uint64_t *frame_iterations, uint64
     return UPSP_OK;
 }
 
+int upsp_pipeline_set_ecc_iterations_out(upsp_pipeline *p, int32_t *d_iters)
+{
+    if (!p) return fail(UPSP_ERR_INVALID, "null pipeline");
+    p->d_ecc_iters = d_iters;
+    return UPSP_OK;
+}
+
 int upsp_pipeline_reset(upsp_pipeline *p)
 {
     if (!p) return fail(UPSP_ERR_INVALID, "null pipeline");
@@ -418,6 +438,8 @@ static int streamed_map(upsp_pipeline *p, const int32_t *d_pix_src, size_t npix,
                                p->d_tile_order, st);
     if (rc != UPSP_OK) return rc;
     p->tilemap_valid = true;
+    p->prescan_frames = nullptr;     // a rebuilt map: whatever pass A wrote before belongs to the old one
+    ++p->map_gen;
     return UPSP_OK;
 }
 
@@ -490,14 +512,14 @@ int upsp_pipeline_set_active_hint(upsp_pipeline *p, const int32_t *d_pix_candida
     if (!p) return fail(UPSP_ERR_INVALID, "null pipeline");
     if (!d_pix_candidates) {
         p->hint_active = false;
-        p->tilemap_valid = false;
+        invalidate_map(p);
         p->node_k_valid = false;
         return UPSP_OK;
     }
     const size_t npix = (size_t)p->width * p->height;
     if (p->ncams != 1 || (npix % 2) != 0 || p->nnodes >= ((size_t)1 << 31))
         return fail(UPSP_ERR_INVALID, "active hint: one camera, even pixel count");
-    p->tilemap_valid = false;
+    invalidate_map(p);
     int rc = streamed_map(p, d_pix_candidates, npix, (hipStream_t)stream);
     if (rc != UPSP_OK) return rc;
     p->hint_active = true;
@@ -528,6 +550,7 @@ int upsp_pipeline_prescan(upsp_pipeline *p, uint16_t *d_frames, int nframes, voi
     if (rc != UPSP_OK) return rc;
     p->prescan_frames = d_frames;
     p->prescan_n = nframes;
+    p->prescan_gen = p->map_gen;
     return UPSP_OK;
 }
 
@@ -548,6 +571,9 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
         if (ld_t < col0 + nframes) return fail(UPSP_ERR_INVALID, "ld_t too small");
     }
     hipStream_t st = (hipStream_t)stream;
+    // a prescan is consumed -- or dropped -- by the very next process call, whichever path that call takes
+    const uint16_t *prescan_frames = p->prescan_frames;
+    p->prescan_frames = nullptr;
     for (int c = 0; c < p->ncams; ++c) {
         if (!d_frames[c]) return fail(UPSP_ERR_INVALID, "null frame pointer");
         if (!p->has_proj[c]) return fail(UPSP_ERR_INVALID, "projection not set for a camera");
@@ -633,8 +659,8 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
         uint16_t *fr = d_frames[0];
         // pass A of exactly these frames may already have run (upsp_pipeline_prescan, e.g. on another stream
         // while the projection was being built; the caller orders the streams)
-        const bool prescanned = p->prescan_frames == fr && p->prescan_n == nframes && nframes <= S;
-        p->prescan_frames = nullptr;
+        const bool prescanned = prescan_frames == fr && p->prescan_n == nframes && nframes <= S &&
+                                p->prescan_gen == p->map_gen;
         for (int s0 = 0; s0 < nframes && rc == UPSP_OK; s0 += S) {
             const int ns = std::min(S, nframes - s0);
             if (!prescanned) rc = streamed_pass_a(p, fr, npix, s0, ns, cp, st);
@@ -816,6 +842,7 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
                                             p->height, p->width, p->opts, p->d_ref[c],
                                             p->patches[c],
                                             d_warps ? d_warps + ((size_t)f0 * p->ncams) * 6 : nullptr,
+                                            p->d_ecc_iters ? p->d_ecc_iters + (size_t)f0 * p->ncams : nullptr,
                                             p->ncams, read_list, &img, &is_f32, st);
                 if (rc != UPSP_OK) break;
             }

@@ -339,6 +339,13 @@ struct Scene {
     const unsigned *path_ref;             // chain entries: (interior node << 1) | side
     int *witness;                         // per node: slot hit by the primary ray (retry nodes)
     unsigned *hist;                       // debug (UPSP_DEBUG_HIST with statistics on): [0..47] steps per residual ray, [48..55] witness verdicts
+    // No walk may outlive the tree: a ray visits every interior node and every leaf at most once, so a traversal call
+    // (or a cooperative walk) that needs more rounds than `round_cap` = 2 x nodes + slack is running on a broken tree
+    // (cyclic child references, overwritten records).  It sets a bit of *err and ends; the entry points return
+    // UPSP_ERR_INTERNAL at their next synchronisation (the reference DIEs on a broken BVH, pspRT.cpp:362-365 -- an
+    // error, never a wedged device).
+    unsigned round_cap;
+    unsigned *err;                        // bit 0 one-lane traversal, bit 1 cooperative walk, bit 2 its one-thread fallback
 };
 
 struct Trav {
@@ -500,9 +507,17 @@ __device__ __forceinline__ void trav_run(Trav &s, const Ray &r, const Scene &sc,
                                          bool more, int refill)
 {
     const int cap = sc.desc_cap;
+    unsigned rounds = 0;       // (the same in every lane that is still in the loop)
     while (s.cur != kDone) {
+        if (++rounds > sc.round_cap) {      // never on a well-formed tree (Scene::round_cap)
+            atomicOr(sc.err, 1u);
+            s.cur = kDone;
+            s.sp = 0;
+            break;
+        }
         if (cap == 0) {
-            while (s.cur >= 0) node_step<ANYHIT, STATS>(s, r, sc, stack);
+            unsigned inner = 0;
+            while (s.cur >= 0 && ++inner <= sc.round_cap) node_step<ANYHIT, STATS>(s, r, sc, stack);
         } else {
             for (int d = 0; d < cap && __ballot(s.cur >= 0) != 0ull; ++d) {
                 if (STATS && (threadIdx.x & 63u) == (unsigned)__ffsll((long long)__ballot(true)) - 1u) ++s.w_node_rounds;
@@ -1398,7 +1413,12 @@ __device__ __forceinline__ void heavy_walk(const Ray &r, const Scene &sc, int *q
     best.key = ~0ull;
     best.slot = -1;
     bool any = false, overflow = false;
+    unsigned rounds = 0;
     while (top > 0) {
+        if (++rounds > sc.round_cap) {       // (uniform) every round pops at least one entry, a tree has < round_cap of them
+            if (tid == 0) atomicOr(sc.err, 2u);
+            break;
+        }
         const unsigned n = min(top, kHeavyThreads);
         const bool have = tid < n;
         int ref = 0;
@@ -1488,7 +1508,11 @@ __device__ __forceinline__ void heavy_walk(const Ray &r, const Scene &sc, int *q
         if (tid == 0) {
             int sp = 0;
             int cur = sc.root_ref;
-            for (;;) {
+            for (unsigned visits = 0;; ++visits) {
+                if (visits > sc.round_cap) {
+                    atomicOr(sc.err, 4u);
+                    break;
+                }
                 if (cur >= 0) {
                     const float4 *np = sc.nodes + 4 * (size_t)cur;
                     const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
@@ -1501,7 +1525,7 @@ __device__ __forceinline__ void heavy_walk(const Ray &r, const Scene &sc, int *q
                     const bool hF = swap ? hR : hL, hS = swap ? hL : hR;
                     if (hF) {
                         cur = first;
-                        if (hS) q_ref[sp++] = second;
+                        if (hS && sp < (int)kHeavyStack) q_ref[sp++] = second;
                         continue;
                     }
                     if (hS) {
@@ -1828,6 +1852,10 @@ Scene make_scene(const upsp_bvh *b, size_t items, int grid)
     sc.path_ref = nullptr;
     sc.witness = nullptr;
     sc.hist = nullptr;
+    // (UPSP_ROUND_CAP: the tests set it low to see the error come back)
+    const int cap_env = env_int("UPSP_ROUND_CAP", 0);
+    sc.round_cap = cap_env > 0 ? (unsigned)cap_env : 2u * (unsigned)b->info.n_gpu_nodes + 130u;
+    sc.err = b->d_err;
     for (int a = 0; a < 3; ++a) {
         sc.rlo[a] = b->root_min[a];
         sc.rhi[a] = b->root_max[a];
@@ -1876,13 +1904,30 @@ void prefetch_bvh(upsp_bvh *b, hipStream_t st)
                        reinterpret_cast<const uint4 *>(b->d_tris), nb, b->d_work);
 }
 
+// The walks' error word (Scene::err), read at a point where the host synchronises with `st` anyway.
+int check_walk_error(upsp_bvh *b, hipStream_t st)
+{
+    unsigned e = 0;
+    UPSP_HIP_CHECK(hipMemcpyAsync(&e, b->d_err, sizeof(e), hipMemcpyDeviceToHost, st));
+    UPSP_HIP_CHECK(hipStreamSynchronize(st));
+    if (!e) return UPSP_OK;
+    UPSP_HIP_CHECK(hipMemsetAsync(b->d_err, 0, sizeof(unsigned), st));
+    char msg[160];
+    std::snprintf(msg, sizeof(msg), "BVH walk exceeded its round cap (flags 0x%x: 1 traversal, 2 cooperative walk, 4 its "
+                  "fallback): broken tree -- results of that call are invalid", e);
+    return fail(UPSP_ERR_INTERNAL, msg);
+}
+
 int read_stats(upsp_bvh *b, hipStream_t st)
 {
     unsigned long long h[3];
     unsigned mx[2];
     UPSP_HIP_CHECK(hipMemcpyAsync(h, b->d_work + 2, sizeof(h), hipMemcpyDeviceToHost, st));
     UPSP_HIP_CHECK(hipMemcpyAsync(mx, b->d_work + 8, sizeof(mx), hipMemcpyDeviceToHost, st));
-    UPSP_HIP_CHECK(hipStreamSynchronize(st));
+    {
+        const int rc = check_walk_error(b, st);     // (synchronises st)
+        if (rc != UPSP_OK) return rc;
+    }
     if (std::getenv("UPSP_TRACE_STATS")) {
         unsigned wr[2] = {0, 0};
         UPSP_HIP_CHECK(hipMemcpy(wr, b->d_work + 14, sizeof(wr), hipMemcpyDeviceToHost));
@@ -2031,7 +2076,8 @@ int cast_host_small(upsp_bvh *b, const float *h_org, int org_stride, const float
                                  reinterpret_cast<const float *>(d + 12 * n), n, dv, st);
     if (rc != UPSP_OK) return rc;
     UPSP_HIP_CHECK(hipMemcpyAsync(h + in_bytes, d + in_bytes, total - in_bytes, hipMemcpyDeviceToHost, st));
-    UPSP_HIP_CHECK(hipStreamSynchronize(st));
+    rc = check_walk_error(b, st);                   // (synchronises st)
+    if (rc != UPSP_OK) return rc;
     if (h_out.hit) std::memcpy(h_out.hit, h + o_hit, n);
     if (!ANYHIT) {
         if (h_out.t) std::memcpy(h_out.t, h + o_t, 4 * n);
@@ -2072,7 +2118,8 @@ int cast_host(const upsp_bvh *bvh, const float *h_org, int org_stride, const flo
     int rc = launch_cast<ANYHIT>(bvh, (const float *)org.p, org_stride, (const float *)dir.p, n,
                                  d, nullptr);
     if (rc != UPSP_OK) return rc;
-    UPSP_HIP_CHECK(hipStreamSynchronize(nullptr));
+    rc = check_walk_error(const_cast<upsp_bvh *>(bvh), nullptr);   // (synchronises the stream)
+    if (rc != UPSP_OK) return rc;
     if (d.hit) UPSP_HIP_CHECK(hipMemcpy(h_out.hit, d.hit, n, hipMemcpyDeviceToHost));
     if (d.t) UPSP_HIP_CHECK(hipMemcpy(h_out.t, d.t, n * 4, hipMemcpyDeviceToHost));
     if (d.prim) UPSP_HIP_CHECK(hipMemcpy(h_out.prim, d.prim, n * 4, hipMemcpyDeviceToHost));
@@ -2129,12 +2176,13 @@ int upsp_bvh_create(const float *h_tris9, size_t ntris, upsp_bvh **out)
     const size_t tb = hb.tris.size() * sizeof(GpuTri);
     hipError_t e = hipMalloc(&b->d_nodes, nb);
     if (e == hipSuccess) e = hipMalloc(&b->d_tris, tb);
-    if (e == hipSuccess) e = hipMalloc(&b->d_work, kWorkWords * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc(&b->d_work, (kWorkWords + 4) * sizeof(unsigned));   // + the walks' error word
     if (e == hipSuccess && !hb.nodes.empty())
         e = hipMemcpy(b->d_nodes, hb.nodes.data(), hb.nodes.size() * sizeof(GpuNode),
                       hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(b->d_tris, hb.tris.data(), tb, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemset(b->d_work, 0, kWorkWords * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemset(b->d_work, 0, (kWorkWords + 4) * sizeof(unsigned));
+    b->d_err = b->d_work + kWorkWords;      // (outlives the per-call clearing of the work words)
     if (e != hipSuccess) {
         upsp_bvh_destroy(b);
         return fail(UPSP_ERR_HIP, std::string("BVH upload: ") + hipGetErrorString(e));
@@ -2264,6 +2312,12 @@ int upsp_bvh_set_tri_nodes(upsp_bvh *b, const int32_t *d_tri_nodes, size_t nnode
     b->adj_src = d_tri_nodes;
     b->adj_nnodes = nnodes;
     return UPSP_OK;
+}
+
+int upsp_bvh_check(upsp_bvh *b, void *stream)
+{
+    if (!b) return fail(UPSP_ERR_INVALID, "null BVH");
+    return check_walk_error(b, (hipStream_t)stream);
 }
 
 int upsp_bvh_enable_stats(upsp_bvh *b, int on)

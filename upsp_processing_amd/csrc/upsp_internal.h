@@ -71,6 +71,7 @@ struct upsp_bvh {
     upsp::GpuNode *d_nodes = nullptr;
     upsp::GpuTri *d_tris = nullptr;
     uint32_t *d_work = nullptr;   // [0] work-queue head, [2..7] 64-bit stats, [8..10] see raycast.hip
+    uint32_t *d_err = nullptr;    // error word of the walks (round cap exceeded), behind the work words
     uint32_t *d_retry_nodes = nullptr, *d_retry_mask = nullptr;  // projection-build retry list
     std::vector<uint32_t> prim_slot;   // host: triangle slot (leaf order) of every input triangle
     // node -> adjacent triangle slots (CSR), set by upsp_bvh_set_tri_nodes (bounded visibility rays)

@@ -74,6 +74,11 @@ class BVH:
     def enable_stats(self, on=True):
         check(lib().upsp_bvh_enable_stats(self._h, int(bool(on))))
 
+    def check(self):
+        """Waits for the current stream; raises (UPSP_ERR_INTERNAL) if a walk queued on this BVH since the last
+        check ran past its round cap -- a broken tree is an error, never a wedged device (upsp_bvh_check)."""
+        check(lib().upsp_bvh_check(self._h, _stream()))
+
     def last_stats(self):
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
         check(lib().upsp_bvh_last_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
@@ -362,16 +367,25 @@ class FramePipeline:
         check(lib().upsp_pipeline_set_patches(self._h, cam, len(clusters), *p))
 
     def process(self, frames, first_frame=0, rows=None, rows_t=None, col0=0, want_rows=True,
-                warps=None, hot_fixed=False):
+                warps=None, hot_fixed=False, ecc_iters=None):
         """frames: list (one per camera) of u16 tensors [F,H,W] (modified in place by the
         hot-pixel fix, like the reference).  Returns rows [F,N] f32 (or None).
-        hot_fixed: the frames already went through fix_hot_pixels() -- skip the scan."""
+        hot_fixed: the frames already went through fix_hot_pixels() -- skip the scan.
+        warps / ecc_iters: optional outputs of the registration stage, f32 [F, ncams, 6] and int32 [F, ncams]
+        (warp matrix and iteration count of cv::findTransformECC per frame)."""
         if hot_fixed and self.opts.hot_enable:
             check(lib().upsp_pipeline_set_hot_enable(self._h, 0))
             try:
-                return self.process(frames, first_frame, rows, rows_t, col0, want_rows, warps)
+                return self.process(frames, first_frame, rows, rows_t, col0, want_rows, warps, ecc_iters=ecc_iters)
             finally:
                 check(lib().upsp_pipeline_set_hot_enable(self._h, 1))
+        if ecc_iters is not None:
+            assert ecc_iters.is_cuda and ecc_iters.dtype == torch.int32 and ecc_iters.is_contiguous()
+            check(lib().upsp_pipeline_set_ecc_iterations_out(self._h, _ptr(ecc_iters)))
+            try:
+                return self.process(frames, first_frame, rows, rows_t, col0, want_rows, warps)
+            finally:
+                check(lib().upsp_pipeline_set_ecc_iterations_out(self._h, None))
         if isinstance(frames, torch.Tensor):
             frames = [frames]
         assert len(frames) == self.ncams

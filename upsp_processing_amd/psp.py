@@ -34,7 +34,11 @@ class Phase1:
         `targets` (one target file per camera) + `first_frames` (raw u16 [H,W] frame 1 per
         camera) to run the phase-0 set-up here (InitializeImagePatches, :2088-2182).
         overlap_src: int32 [N] source map of a structured (PLOT3D) model's zone overlaps
-        (grids.P3DModel.overlap_source(); model.adjust_solution, :1833-1835, :1938-1940, :1975-1977)."""
+        (grids.P3DModel.overlap_source(); model.adjust_solution, :1833-1835, :1938-1940, :1975-1977).
+        count_rays: `self.nrays` is the number of rays the REFERENCE casts for these cameras (every in-frame node's
+        primary ray + its retries: the build then casts them all, in the reference's order); by default it is the
+        number of rays this build really cast (nodes the oblique test rejects cast none, most retries are decided
+        by the occluder witness) -- `self.nrays_kind` says which."""
         self.width, self.height = image_size
         self.ncams = len(cameras)
         self.nnodes = int(np.asarray(nodes).reshape(-1, 3).shape[0])
@@ -47,6 +51,7 @@ class Phase1:
                      for c in cameras]
         self.centers = np.array([engine.camera_center(c) for c in self.cams])
         self.nrays = 0
+        self.nrays_kind = "rays the reference casts" if count_rays else "rays cast"
         pix, self.uv, self.nodecount = [], [], []
         for cam in self.cams:                                          # :1597-1622
             # (count_rays: also report the number of rays the reference would cast -- which means casting them all;

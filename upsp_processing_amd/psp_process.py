@@ -27,6 +27,9 @@ pressure_transpose, rms, avg, gain, steady_state, model_temp, vv-cp-*.dat.  `-st
 `-model_temp_p3d` (PLOT3D function files) are read directly for PLOT3D model grids and interpolated
 from `-steady_grid` (upsp::interpolate: 10 nearest nodes, inverse-distance weights) for `.tri` models.  The HDF5 container is out of scope; `-h5_out` is
 accepted and ignored.
+
+`-count_rays` (not a reference flag): phase 1 reports the number of rays the REFERENCE casts for the cameras
+(every in-frame node's ray + retries, which means casting them all) instead of the rays this build really cast.
 """
 import json
 import os
@@ -246,7 +249,8 @@ def run(flags):
                      oblique_angle=float(opts["oblique_angle"]), overlap=opts["overlap"],
                      datanode=datanode, registration=opts["registration"] == "pixel",
                      filter=None if opts["filter"] == "none" else opts["filter"],
-                     filter_size=int(opts["filter_size"]), overlap_src=overlap_src, **patch_kw)
+                     filter_size=int(opts["filter_size"]), overlap_src=overlap_src,
+                     count_rays="count_rays" in flags, **patch_kw)
     if job.visible_targets is not None and (not D.dist.is_initialized() or D.dist.get_rank() == 0):
         for c, vis in enumerate(job.visible_targets):
             print("camera %d: %d visible targets patched" % (c + 1, len(vis)))
@@ -260,12 +264,19 @@ def run(flags):
     # thread, psp_process.cpp:867-1007): the upload of chunk k + 1 overlaps the processing of chunk k
     feeds = [video.FrameFeed(min(chunk, max(nf, 1)) * r.frame_bytes, 3) if getattr(r, "raw_bit_depth", 12) == 12
              else None for r in readers]
-    for c0 in range(0, nf, chunk):
-        n = min(chunk, nf - c0)
-        batch = [r.read_frames_device(f0 + c0 + 1, n, feed=fd) for r, fd in zip(readers, feeds)]     # 1-based frames
-        job.process(batch, first_frame=f0 + c0, rows_t=rows_t, col0=c0)
-        if shard.rank == 0 and c0 % (chunk * 4) == 0:
-            print("  Rank 0:: processing frame %d" % (f0 + c0))
+    try:
+        for c0 in range(0, nf, chunk):
+            n = min(chunk, nf - c0)
+            batch = [r.read_frames_device(f0 + c0 + 1, n, feed=fd) for r, fd in zip(readers, feeds)]     # 1-based frames
+            job.process(batch, first_frame=f0 + c0, rows_t=rows_t, col0=c0)
+            if shard.rank == 0 and c0 % (chunk * 4) == 0:
+                print("  Rank 0:: processing frame %d" % (f0 + c0))
+    finally:
+        # pinned slots + device twins (3 x 256 frames per camera) are not left to the garbage collector
+        torch.cuda.synchronize()
+        for fd in feeds:
+            if fd is not None:
+                fd.close()
     finals = job.finalize(nframes)
     series = D.exchange_time_series(rows_t[:, :nf], shard)
     out_dir = flags.get("add_out_dir") or deck["output"].get("dir") or "."
@@ -273,7 +284,7 @@ def run(flags):
     if shard.rank == 0:
         for name, col in (("X", 0), ("Y", 1), ("Z", 2)):                    # :524-540
             xyz[:, col].astype("<f4").tofile(os.path.join(out_dir, name))
-        print("phase 1 complete: %d frames, %d nodes, %d rays" % (nframes, job.nnodes, job.nrays))
+        print("phase 1 complete: %d frames, %d nodes, %d %s" % (nframes, job.nnodes, job.nrays, job.nrays_kind))
 
     # ---- phase 2 (psp_process.cpp:2260-2625) ----
     paint_cal, sds = flags.get("paint_cal"), deck["all"].get("sds")

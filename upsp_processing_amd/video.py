@@ -104,9 +104,15 @@ class FrameFeed:
         slot, hp = C.c_int(), C.c_void_p()
         _capi.check(_capi.lib().upsp_feed_acquire(self._h, C.byref(slot), C.byref(hp)))
         dst = np.ctypeslib.as_array(C.cast(hp, C.POINTER(C.c_uint8)), shape=(self.slot_bytes,))
-        n = int(fill(dst))
         dp = C.c_void_p()
-        _capi.check(_capi.lib().upsp_feed_commit(self._h, slot.value, n, _stream(), C.byref(dp)))
+        try:
+            n = int(fill(dst))
+            _capi.check(_capi.lib().upsp_feed_commit(self._h, slot.value, n, _stream(), C.byref(dp)))
+        except BaseException:
+            # the reader failed (frame out of range, short read) or the commit was refused: give the slot
+            # back unfilled, the feed stays usable (upsp_feed_abort)
+            _capi.lib().upsp_feed_abort(self._h, slot.value)
+            raise
         self._pending.append(slot.value)
         from .engine import _DevArray
         t = torch.as_tensor(_DevArray(dp.value, max(n, 1), "|u1", self), device="cuda")[:n]
