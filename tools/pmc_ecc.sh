@@ -14,12 +14,14 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.OrderedDict()
 for r in rows:
     k = r["Kernel_Name"]
-    if "ecc_sums" not in k and "warp_u16" not in k: continue
-    short = k.split("(anonymous namespace)::")[-1].split("(")[0]
+    if "ecc_sums" not in k and "ecc_cols" not in k and "warp_u16" not in k and "gauss_fused" not in k: continue
+    import re
+    mm = re.search(r"\(anonymous namespace\)::(\w+)(<[^>]*>)?\(", k)
+    short = ((mm.group(1) + (mm.group(2) or "")) if mm else k[:40]).replace("unsigned short", "u16")
     a = agg.setdefault((short, r["Counter_Name"]), [0, 0.0])
     a[0] += 1; a[1] += float(r["Counter_Value"])
 for (k, c), (n, v) in agg.items():
-    print("%-28s %-36s calls=%d avg=%.5g" % (k[:28], c, n, v / n))
+    print("%-34s %-36s calls=%d avg=%.5g" % (k[:34], c, n, v / n))
 PY
   rm -rf $out/p$i
 done <<'GROUPS'

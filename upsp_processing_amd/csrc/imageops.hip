@@ -35,7 +35,7 @@ namespace {
 
 constexpr int kEccBlocks = 64;   // partial-sum blocks per frame (full sub-batch)
 constexpr int kEccBlocksMax = 512;  // ... when only a few frames are still iterating
-constexpr int kEccBorderBlocks = 16; // partial-sum blocks of ecc_border_kernel (after the interior kernel's)
+constexpr int kEccBorderBlocks = 48; // partial-sum blocks of the band (slots before the interior blocks'); ecc_band_cols_body needs >= 3 x ceil(cols / 256)
 constexpr int kEccStride = kEccBlocksMax + kEccBorderBlocks;   // partial sums per (frame, sum)
 constexpr int kEccSums = 45;
 constexpr int kMaxKernel = 63;   // largest odd filter size
@@ -684,6 +684,458 @@ __device__ __forceinline__ void ecc_border_body(const float *__restrict__ img, c
     ecc_block_store(acc, partial, f, (int)bidx);
 }
 
+// ---- interior of the frame, round 3: one COLUMN per thread ------------------------------------------------------
+// The 45 sums are products of three things: the warped gradients {gx, gy}, the pixel coordinates {X, Y, 1} and
+// {w, 1, t} (or a second gradient).  A thread that owns ONE column x and walks down its rows has a constant X, so X
+// comes out of every sum and is multiplied in once, at the end; Y is the row offset r inside a segment of kEccFlush
+// rows (a small exact integer), shifted to the true row when the segment's partial sums are folded into the thread's
+// double totals.  What is left per pixel are 21 sums
+//     {gx, gy} x {1, w, t} x {1, r}        12        {gx^2, gy^2, gx gy} x {1, r, r^2}     9
+// accumulated as packed float pairs (v_pk_fma_f32) over at most kEccFlush rows, + the five scalar sums of w and t
+// in double (they decide rho, i.e. the iteration count): ~22 VALU instructions per pixel where the 45 double sums of
+// round 2 took ~75, and the fixed-point source coordinate splits into a per-thread column term and a per-row term
+// from a small LDS table (~10 instead of ~45).  Float partials: a segment sum of <= 32 terms carries a relative
+// error of <~1e-7, random over the 30 000 segments of a frame -- the same order as the float rounding of every
+// Jacobian element in cv::findTransformECC itself, and five orders below the 1e-4 parity bar (tests: same iteration
+// counts, |dM| ~ 1e-7).  The identity iteration (5 loads, no interpolation) becomes memory-bound.
+typedef float v2f __attribute__((ext_vector_type(2)));
+constexpr int kEccFlush = 32;        // rows per float segment
+constexpr int kEccRowTab = 2048;     // rows of one block whose per-row coordinate terms are tabulated in LDS
+
+struct EccPart {        // float partial sums of one segment
+    v2f G0, G1, Gw0, Gw1, Gt0, Gt1, Q0, Q1, Q2, C01;
+    float C2;
+};
+struct EccTot {         // double totals of the thread's column piece (Y = true row)
+    double G0[2], G1[2], Gw0[2], Gw1[2], Gt0[2], Gt1[2], Q0[2], Q1[2], Q2[2], C0, C1, C2;
+    double Sw, Sww, St, Stt, Stw, n;
+};
+
+__device__ __forceinline__ void ecc_part_zero(EccPart &p)
+{
+    const v2f z = {0.f, 0.f};
+    p.G0 = p.G1 = p.Gw0 = p.Gw1 = p.Gt0 = p.Gt1 = p.Q0 = p.Q1 = p.Q2 = p.C01 = z;
+    p.C2 = 0.f;
+}
+
+// one pixel: warped value w, warped gradients gx / gy, template t, row offset rf (= r as a float) in its segment.
+// MASKED (band pixels): m = the nearest-neighbour mask of cv::findTransformECC; masked sums as in ecc_accumulate
+// (n, the scalar sums, sum_mask J, sum_mask J t), the others over all pixels.
+template <bool MASKED>
+__device__ __forceinline__ void ecc_part_add(EccPart &p, EccTot &T, float w, float gx, float gy, float t, float rf, bool m = true)
+{
+    const v2f G = {gx, gy}, R = {rf, rf}, W = {w, w}, Tt = {t, t};
+    const v2f Z = {0.f, 0.f};
+    const v2f Gm = (MASKED && !m) ? Z : G;
+    const float rf2 = rf * rf;
+    const v2f R2 = {rf2, rf2};
+    p.G0 += Gm;
+    p.G1 = __builtin_elementwise_fma(Gm, R, p.G1);
+    const v2f Gw = G * W, Gt = Gm * Tt, Q = G * G;
+    p.Gw0 += Gw;
+    p.Gw1 = __builtin_elementwise_fma(Gw, R, p.Gw1);
+    p.Gt0 += Gt;
+    p.Gt1 = __builtin_elementwise_fma(Gt, R, p.Gt1);
+    p.Q0 += Q;
+    p.Q1 = __builtin_elementwise_fma(Q, R, p.Q1);
+    p.Q2 = __builtin_elementwise_fma(Q, R2, p.Q2);
+    const float c = gx * gy;
+    const v2f Cc = {c, c}, R01 = {1.f, rf};
+    p.C01 = __builtin_elementwise_fma(Cc, R01, p.C01);
+    p.C2 = __builtin_fmaf(c, rf2, p.C2);
+    const double wd = w, td = t;
+    const double wm = (MASKED && !m) ? 0.0 : wd, tm = (MASKED && !m) ? 0.0 : td;
+    if (MASKED) T.n += m ? 1.0 : 0.0;
+    T.Sw += wm;
+    T.Sww = fma(wm, wd, T.Sww);
+    T.St += tm;
+    T.Stt = fma(tm, td, T.Stt);
+    T.Stw = fma(tm, wd, T.Stw);
+}
+
+// segment -> totals: rows of the segment are yb + r
+__device__ __forceinline__ void ecc_part_flush(const EccPart &p, EccTot &T, int yb)
+{
+    const double Y = (double)yb, Y2 = Y * Y, Yd = 2.0 * Y;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const double g0 = p.G0[k], g1 = p.G1[k], gw0 = p.Gw0[k], gw1 = p.Gw1[k], gt0 = p.Gt0[k], gt1 = p.Gt1[k];
+        const double q0 = p.Q0[k], q1 = p.Q1[k], q2 = p.Q2[k];
+        T.G0[k] += g0;
+        T.G1[k] += fma(Y, g0, g1);
+        T.Gw0[k] += gw0;
+        T.Gw1[k] += fma(Y, gw0, gw1);
+        T.Gt0[k] += gt0;
+        T.Gt1[k] += fma(Y, gt0, gt1);
+        T.Q0[k] += q0;
+        T.Q1[k] += fma(Y, q0, q1);
+        T.Q2[k] += fma(Y2, q0, fma(Yd, q1, q2));
+    }
+    const double c0 = p.C01[0], c1 = p.C01[1], c2 = p.C2;
+    T.C0 += c0;
+    T.C1 += fma(Y, c0, c1);
+    T.C2 += fma(Y2, c0, fma(Yd, c1, c2));
+}
+
+// the k-th of the 45 sums (layout of ecc_accumulate) from a thread's totals and its column X
+template <int K>
+__device__ __forceinline__ double ecc_tot_value(const EccTot &T, double X)
+{
+    const double X2 = X * X;
+    switch (K) {
+    case 0: return T.n;
+    case 1: return T.Sw;
+    case 2: return T.Sww;
+    case 3: return T.St;
+    case 4: return T.Stt;
+    case 5: return T.Stw;
+    case 6: return X * T.Gw0[0];
+    case 7: return X * T.Gw0[1];
+    case 8: return T.Gw1[0];
+    case 9: return T.Gw1[1];
+    case 10: return T.Gw0[0];
+    case 11: return T.Gw0[1];
+    case 12: return X * T.G0[0];
+    case 13: return X * T.G0[1];
+    case 14: return T.G1[0];
+    case 15: return T.G1[1];
+    case 16: return T.G0[0];
+    case 17: return T.G0[1];
+    case 18: return X * T.Gt0[0];
+    case 19: return X * T.Gt0[1];
+    case 20: return T.Gt1[0];
+    case 21: return T.Gt1[1];
+    case 22: return T.Gt0[0];
+    case 23: return T.Gt0[1];
+    // J J^T, upper triangle row-major, J = [gx X, gy X, gx Y, gy Y, gx, gy]
+    case 24: return X2 * T.Q0[0];     // (0,0) gx^2 X^2
+    case 25: return X2 * T.C0;        // (0,1) gx gy X^2
+    case 26: return X * T.Q1[0];      // (0,2) gx^2 X Y
+    case 27: return X * T.C1;         // (0,3) gx gy X Y
+    case 28: return X * T.Q0[0];      // (0,4) gx^2 X
+    case 29: return X * T.C0;         // (0,5) gx gy X
+    case 30: return X2 * T.Q0[1];     // (1,1) gy^2 X^2
+    case 31: return X * T.C1;         // (1,2) gy gx X Y
+    case 32: return X * T.Q1[1];      // (1,3) gy^2 X Y
+    case 33: return X * T.C0;         // (1,4) gy gx X
+    case 34: return X * T.Q0[1];      // (1,5) gy^2 X
+    case 35: return T.Q2[0];          // (2,2) gx^2 Y^2
+    case 36: return T.C2;             // (2,3) gx gy Y^2
+    case 37: return T.Q1[0];          // (2,4) gx^2 Y
+    case 38: return T.C1;             // (2,5) gx gy Y
+    case 39: return T.Q2[1];          // (3,3) gy^2 Y^2
+    case 40: return T.C1;             // (3,4) gy gx Y
+    case 41: return T.Q1[1];          // (3,5) gy^2 Y
+    case 42: return T.Q0[0];          // (4,4) gx^2
+    case 43: return T.C0;             // (4,5) gx gy
+    default: return T.Q0[1];          // (5,5) gy^2
+    }
+}
+
+// Wave-wide sum of a double with DPP moves only (no ds_bpermute round trips: 45 sums x 6 dependent shuffle steps were a
+// ~25 000-cycle latency chain at the end of every block): quad swaps, half-row mirror, row mirror -> every lane holds its
+// row's sum; row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3 -> lane 63 holds the wave's.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add_f64(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xFFFFFFFFll), CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xF, false);
+    return v + __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);   // (rows outside the mask add 0.0)
+}
+__device__ __forceinline__ double wave_sum_to_lane63(double v)
+{
+    v = dpp_add_f64<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+    v = dpp_add_f64<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
+    v = dpp_add_f64<0x141, 0xF>(v);   // row_half_mirror
+    v = dpp_add_f64<0x140, 0xF>(v);   // row_mirror
+    v = dpp_add_f64<0x142, 0xA>(v);   // row_bcast15 -> rows 1, 3
+    v = dpp_add_f64<0x143, 0xC>(v);   // row_bcast31 -> rows 2, 3
+    return v;
+}
+
+// block reduction of the 45 sums straight from the totals (one value at a time: the 45 doubles never exist at once);
+// fixed order everywhere -- deterministic
+template <int K>
+__device__ __forceinline__ void ecc_tot_reduce(const EccTot &T, double X, bool on, double (*red)[kEccSums])
+{
+    const double v = wave_sum_to_lane63(on ? ecc_tot_value<K>(T, X) : 0.0);
+    if ((threadIdx.x & 63) == 63) red[threadIdx.x >> 6][K] = v;
+    if constexpr (K + 1 < kEccSums) ecc_tot_reduce<K + 1>(T, X, on, red);
+}
+
+// a block without any pixel: its partial sums are zero
+__device__ __forceinline__ void ecc_store_zeros(double *__restrict__ partial, int f, unsigned slot)
+{
+    if (threadIdx.x < kEccSums) partial[((size_t)f * kEccSums + threadIdx.x) * kEccStride + slot] = 0.0;
+}
+
+template <bool IDENT, int UR>
+__device__ __forceinline__ void ecc_cols_trip(const float *__restrict__ I, const float *__restrict__ tmpl, int cols, int x,
+                                              int y, int r, int ax, int bx, const int2 *rtab, int rt0, const double *M,
+                                              EccPart &P, EccTot &T)
+{
+    if (IDENT) {
+        // source pixel = target pixel: w = I, gradients = central differences of I (zero fractions make the bilinear
+        // weights (1,0,0,0), so the general arithmetic reduces exactly to these taps)
+        const float *pc = I + (size_t)y * cols + x;
+        float cc[UR + 2], ll[UR], rr[UR], tt[UR];
+#pragma unroll
+        for (int k = 0; k < UR + 2; ++k) cc[k] = pc[(k - 1) * cols];
+#pragma unroll
+        for (int k = 0; k < UR; ++k) {
+            ll[k] = pc[k * cols - 1];
+            rr[k] = pc[k * cols + 1];
+            tt[k] = tmpl[(size_t)(y + k) * cols + x];
+        }
+#pragma unroll
+        for (int k = 0; k < UR; ++k)
+            ecc_part_add<false>(P, T, cc[k + 1], -0.5f * ll[k] + 0.5f * rr[k], -0.5f * cc[k] + 0.5f * cc[k + 2], tt[k], (float)(r + k));
+    } else {
+        float v[UR][12], tt[UR], fx[UR], fy[UR];
+#pragma unroll
+        for (int k = 0; k < UR; ++k) {
+            int2 rt;
+            if (rtab) {
+                rt = rtab[y + k - rt0];
+            } else {
+                const int yy = y + k;
+                rt = make_int2(__double2int_rn((M[1] * yy + M[2]) * 1024), __double2int_rn((M[4] * yy + M[5]) * 1024));
+            }
+            // WarpAffineInvoker's fixed-point coordinate: per-row term + per-column term, each rounded on its own
+            const int Xr = rt.x + ax, Yr = rt.y + bx;
+            const int Xq = (Xr + 16) >> 5, Yq = (Yr + 16) >> 5;
+            const int sx = Xq >> 5, sy = Yq >> 5;        // (footprint inside the image by construction: ecc_band)
+            fx[k] = (Xq & 31) * (1.f / 32);
+            fy[k] = (Yq & 31) * (1.f / 32);
+            const float *r0 = I + (unsigned)((sy - 1) * cols + sx);
+            const float *r1 = r0 + cols, *r2 = r1 + cols, *r3 = r2 + cols;
+            v[k][0] = r0[0]; v[k][1] = r0[1];
+            v[k][2] = r1[-1]; v[k][3] = r1[0]; v[k][4] = r1[1]; v[k][5] = r1[2];
+            v[k][6] = r2[-1]; v[k][7] = r2[0]; v[k][8] = r2[1]; v[k][9] = r2[2];
+            v[k][10] = r3[0]; v[k][11] = r3[1];
+            tt[k] = tmpl[(size_t)(y + k) * cols + x];
+        }
+#pragma unroll
+        for (int k = 0; k < UR; ++k) {
+            // bilinear of I, of [-0.5 0 0.5] along x and along y over the 12-pixel footprint (same operations as round 2)
+            const float a0 = v[k][0], a1 = v[k][1];
+            const float b_1 = v[k][2], b0 = v[k][3], b1 = v[k][4], b2 = v[k][5];
+            const float c_1 = v[k][6], c0 = v[k][7], c1 = v[k][8], c2 = v[k][9];
+            const float d0 = v[k][10], d1 = v[k][11];
+            const float w0 = (1.f - fy[k]) * (1.f - fx[k]), w1 = (1.f - fy[k]) * fx[k], w2 = fy[k] * (1.f - fx[k]),
+                        w3 = fy[k] * fx[k];
+            const float w = b0 * w0 + b1 * w1 + c0 * w2 + c1 * w3;
+            const float gx = (-0.5f * b_1 + 0.5f * b1) * w0 + (-0.5f * b0 + 0.5f * b2) * w1 +
+                             (-0.5f * c_1 + 0.5f * c1) * w2 + (-0.5f * c0 + 0.5f * c2) * w3;
+            const float gy = (-0.5f * a0 + 0.5f * c0) * w0 + (-0.5f * a1 + 0.5f * c1) * w1 +
+                             (-0.5f * b0 + 0.5f * d0) * w2 + (-0.5f * b1 + 0.5f * d1) * w3;
+            ecc_part_add<false>(P, T, w, gx, gy, tt[k], (float)(r + k));
+        }
+    }
+}
+
+// Interior block `blk` of `nblk`: the inner rectangle (farther than the band from every edge) is cut into column tiles
+// of 256 and, per tile, into nblk / tiles row pieces; blocks beyond that store zeros.  Needs nblk >= tiles (the host
+// checks: cols <= 256 x interior blocks, else the round-2 kernel runs).
+template <bool IDENT, int UR>
+__device__ __forceinline__ void ecc_cols_body(const float *__restrict__ img, const float *__restrict__ tmpl, int rows,
+                                              int cols, const EccState *__restrict__ state,
+                                              double *__restrict__ partial, int f, unsigned blk, unsigned nblk)
+{
+    __shared__ double red[4][kEccSums];
+    __shared__ int2 rtab_s[kEccRowTab];
+    const EccState &es = state[f];
+    const float *I = img + (size_t)f * rows * cols;
+    const EccMargins g = ecc_margins(IDENT ? 3 : es.band, rows, cols);
+    const int x_lo = g.left, x_hi = cols - g.right, y_lo = g.top, y_hi = rows - g.bottom;   // [lo, hi)
+    const int W = max(x_hi - x_lo, 0), H = max(y_hi - y_lo, 0);
+    const unsigned tiles = ((unsigned)W + 255u) / 256u;
+    const unsigned pieces = tiles ? nblk / tiles : 0u;                       // row pieces per column tile (>= 1)
+    const bool work = tiles && blk < tiles * pieces && H > 0;
+    const unsigned ct = work ? blk % tiles : 0u, piece = work ? blk / tiles : 0u;
+    const int rpp = pieces ? (int)(((unsigned)H + pieces - 1u) / pieces) : 0;  // rows per piece
+    const int y0 = work ? min(y_hi, y_lo + (int)piece * rpp) : 0, y1 = work ? min(y_hi, y0 + rpp) : 0;
+    const int x = x_lo + (int)ct * 256 + (int)threadIdx.x;
+    const bool on = work && x < x_hi && y1 > y0;
+    if (!work || y1 <= y0) {            // (uniform) more blocks than pieces: nothing to add
+        ecc_store_zeros(partial, f, kEccBorderBlocks + blk);
+        return;
+    }
+    double M[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) M[i] = es.M[i];
+    const bool tab = !IDENT && (y1 - y0) <= kEccRowTab;
+    if (!IDENT && tab) {
+        for (int i = threadIdx.x; i < y1 - y0; i += 256) {
+            const int yy = y0 + i;
+            rtab_s[i] = make_int2(__double2int_rn((M[1] * yy + M[2]) * 1024), __double2int_rn((M[4] * yy + M[5]) * 1024));
+        }
+        __syncthreads();
+    }
+    EccTot T;
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+        T.G0[k] = T.G1[k] = T.Gw0[k] = T.Gw1[k] = T.Gt0[k] = T.Gt1[k] = T.Q0[k] = T.Q1[k] = T.Q2[k] = 0.0;
+    T.C0 = T.C1 = T.C2 = T.Sw = T.Sww = T.St = T.Stt = T.Stw = 0.0;
+    T.n = on ? (double)(y1 - y0) : 0.0;          // mask = 1 on every interior pixel
+    if (on) {
+        const int ax = IDENT ? 0 : __double2int_rn(M[0] * x * 1024), bx = IDENT ? 0 : __double2int_rn(M[3] * x * 1024);
+        const int2 *rt = (!IDENT && tab) ? rtab_s : nullptr;
+        for (int yb = y0; yb < y1; yb += kEccFlush) {
+            const int ne = min(kEccFlush, y1 - yb);
+            EccPart P;
+            ecc_part_zero(P);
+            int r = 0;
+            for (; r + UR <= ne; r += UR) ecc_cols_trip<IDENT, UR>(I, tmpl, cols, x, yb + r, r, ax, bx, rt, y0, M, P, T);
+            for (; r < ne; ++r) ecc_cols_trip<IDENT, 1>(I, tmpl, cols, x, yb + r, r, ax, bx, rt, y0, M, P, T);
+            ecc_part_flush(P, T, yb);
+        }
+    }
+    ecc_tot_reduce<0>(T, (double)x, on, red);
+    __syncthreads();
+    if (threadIdx.x < kEccSums) {
+        const double v = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+        partial[((size_t)f * kEccSums + threadIdx.x) * kEccStride + (kEccBorderBlocks + blk)] = v;
+    }
+}
+
+// The band of the same launch, also one column per thread (no 45 double accumulators anywhere in this kernel: with
+// round 2's band body inside, the kernel needed 146+ VGPRs whatever the interior loop used).  Band blocks:
+//   [0, tiles)            top strip    rows [0, top),            one column tile of 256 each
+//   [tiles, 2 tiles)      bottom strip rows [rows - bottom, rows)
+//   the rest              the left + right strips between them: `side` = left + right columns; a block's 256 threads
+//                         are (column, row piece) pairs, so a 6-column band still has 42 threads per block at work
+// Generic bilinear (constant-0 border, reflect-101 gradient taps) and the nearest-neighbour mask, as in round 2.
+__device__ __forceinline__ void ecc_band_cols_body(const float *__restrict__ img, const float *__restrict__ tmpl, int rows,
+                                                   int cols, const EccState *__restrict__ state,
+                                                   double *__restrict__ partial, int f, unsigned bidx, bool ident)
+{
+    __shared__ double red[4][kEccSums];
+    const EccState &es = state[f];
+    const float *I = img + (size_t)f * rows * cols;
+    double M[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) M[i] = es.M[i];
+    const EccMargins g = ecc_margins(ident ? 3 : es.band, rows, cols);
+    const int tiles = (cols + 255) / 256;
+    const int tid = (int)threadIdx.x;
+    int x = -1, ya = 0, yb = 0;
+    if ((int)bidx < tiles) {
+        x = (int)bidx * 256 + tid;
+        ya = 0;
+        yb = g.top;
+    } else if ((int)bidx < 2 * tiles) {
+        x = ((int)bidx - tiles) * 256 + tid;
+        ya = rows - g.bottom;
+        yb = rows;
+    } else {
+        const int side = g.left + g.right, H = rows - g.top - g.bottom;
+        const int sb = (int)bidx - 2 * tiles, nsb = kEccBorderBlocks - 2 * tiles;
+        const int tiles_s = (side + 255) / 256;
+        int pb = tiles_s ? nsb / tiles_s : 0;                    // blocks per column tile of the strips ...
+        if (side > 0 && H > 0 && pb >= 1) {
+            // ... of which only as many are used as give every thread ~8 rows (the others store zeros at once)
+            const int sp_min = 256 / min(256, side);
+            pb = min(pb, max(1, (H + 8 * sp_min - 1) / (8 * sp_min)));
+        }
+        if (side > 0 && H > 0 && pb >= 1 && sb < tiles_s * pb) {
+            const int ts = sb % tiles_s, pblk = sb / tiles_s;
+            const int cs = min(256, side - ts * 256), sp = 256 / cs;
+            const int c = tid % cs, q = tid / cs;
+            if (q < sp) {
+                const int pieces = pb * sp, rpp = (H + pieces - 1) / pieces, piece = pblk * sp + q;
+                ya = min(rows - g.bottom, g.top + piece * rpp);
+                yb = min(rows - g.bottom, ya + rpp);
+                const int k = ts * 256 + c;
+                x = k < g.left ? k : cols - side + k;
+            }
+        }
+    }
+    const bool on = x >= 0 && x < cols && yb > ya;
+    if (!__syncthreads_or(on ? 1 : 0)) {     // no thread of the block has a pixel (spare band block, empty strip)
+        ecc_store_zeros(partial, f, bidx);
+        return;
+    }
+    EccTot T;
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+        T.G0[k] = T.G1[k] = T.Gw0[k] = T.Gw1[k] = T.Gt0[k] = T.Gt1[k] = T.Q0[k] = T.Q1[k] = T.Q2[k] = 0.0;
+    T.C0 = T.C1 = T.C2 = T.Sw = T.Sww = T.St = T.Stt = T.Stw = T.n = 0.0;
+    if (on) {
+        auto pix = [&](int yy, int xx) { return I[(size_t)yy * cols + xx]; };
+        auto gxf = [&](int yy, int xx) {
+            return -0.5f * pix(yy, reflect101(xx - 1, cols)) + 0.5f * pix(yy, reflect101(xx + 1, cols));
+        };
+        auto gyf = [&](int yy, int xx) {
+            return -0.5f * pix(reflect101(yy - 1, rows), xx) + 0.5f * pix(reflect101(yy + 1, rows), xx);
+        };
+        const int ax = __double2int_rn(M[0] * x * 1024), bx = __double2int_rn(M[3] * x * 1024);
+        for (int y0 = ya; y0 < yb; y0 += kEccFlush) {
+            const int ne = min(kEccFlush, yb - y0);
+            EccPart P;
+            ecc_part_zero(P);
+            for (int r = 0; r < ne; ++r) {
+                const int y = y0 + r;
+                const int Xr = __double2int_rn((M[1] * y + M[2]) * 1024) + ax;
+                const int Yr = __double2int_rn((M[4] * y + M[5]) * 1024) + bx;
+                const int Xq = (Xr + 16) >> 5, Yq = (Yr + 16) >> 5;
+                WarpCoord c;
+                c.sx = max(-32768, min(32767, Xq >> 5));
+                c.sy = max(-32768, min(32767, Yq >> 5));
+                c.ax = Xq & 31;
+                c.ay = Yq & 31;
+                const int nx = max(-32768, min(32767, (Xr + 512) >> 10)), ny = max(-32768, min(32767, (Yr + 512) >> 10));
+                const bool m = (unsigned)nx < (unsigned)cols && (unsigned)ny < (unsigned)rows;
+                float w, gx, gy;
+                if (c.sx >= 1 && c.sx + 2 < cols && c.sy >= 1 && c.sy + 2 < rows) {
+                    // footprint and gradient taps inside the image (all of the band but its outermost ring or two): the 12
+                    // pixels directly -- the generic path below evaluates to the same operations on the same values
+                    const float *r0 = I + (unsigned)((c.sy - 1) * cols + c.sx);
+                    const float *r1 = r0 + cols, *r2 = r1 + cols, *r3 = r2 + cols;
+                    const float a0 = r0[0], a1 = r0[1];
+                    const float b_1 = r1[-1], b0 = r1[0], b1 = r1[1], b2 = r1[2];
+                    const float c_1 = r2[-1], c0 = r2[0], c1 = r2[1], c2 = r2[2];
+                    const float d0 = r3[0], d1 = r3[1];
+                    const float fx = c.ax * (1.f / 32), fy = c.ay * (1.f / 32);
+                    const float w0 = (1.f - fy) * (1.f - fx), w1 = (1.f - fy) * fx, w2 = fy * (1.f - fx), w3 = fy * fx;
+                    w = b0 * w0 + b1 * w1 + c0 * w2 + c1 * w3;
+                    gx = (-0.5f * b_1 + 0.5f * b1) * w0 + (-0.5f * b0 + 0.5f * b2) * w1 +
+                         (-0.5f * c_1 + 0.5f * c1) * w2 + (-0.5f * c0 + 0.5f * c2) * w3;
+                    gy = (-0.5f * a0 + 0.5f * c0) * w0 + (-0.5f * a1 + 0.5f * c1) * w1 +
+                         (-0.5f * b0 + 0.5f * d0) * w2 + (-0.5f * b1 + 0.5f * d1) * w3;
+                } else {
+                    w = bilinear(pix, rows, cols, c);
+                    gx = bilinear(gxf, rows, cols, c);
+                    gy = bilinear(gyf, rows, cols, c);
+                }
+                ecc_part_add<true>(P, T, w, gx, gy, tmpl[(size_t)y * cols + x], (float)r, m);
+            }
+            ecc_part_flush(P, T, y0);
+        }
+    }
+    ecc_tot_reduce<0>(T, (double)x, on, red);
+    __syncthreads();
+    if (threadIdx.x < kEccSums) {
+        const double v = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+        partial[((size_t)f * kEccSums + threadIdx.x) * kEccStride + bidx] = v;
+    }
+}
+
+template <bool IDENT, int UR, int WAVES>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
+    ecc_cols_kernel(const float *__restrict__ img, const float *__restrict__ tmpl, int rows, int cols,
+                    const EccState *__restrict__ state, double *__restrict__ partial)
+{
+    const int f = blockIdx.x;
+    if (state[f].done) return;
+    const unsigned nint = gridDim.y - (unsigned)kEccBorderBlocks;
+    if (blockIdx.y >= (unsigned)kEccBorderBlocks)
+        ecc_cols_body<IDENT, UR>(img, tmpl, rows, cols, state, partial, f, blockIdx.y - (unsigned)kEccBorderBlocks, nint);
+    else
+        ecc_band_cols_body(img, tmpl, rows, cols, state, partial, f, blockIdx.y, IDENT);
+}
+
 // grid (frames, kEccBorderBlocks + interior blocks): the frame is the FAST index, so the band blocks of all frames
 // (slots 0 .. kEccBorderBlocks-1: few trips of long dependent chains) are dispatched first and run beside the interior
 // blocks instead of after them (as the last blocks of the launch they were a 50-us tail)
@@ -1267,14 +1719,35 @@ static int run_ecc(FrameScratch *s, const float *tmpl_blur, const uint16_t *fram
 #define UPSP_ECC_LAUNCH(ID, KPX, WV)                                                                          \
     hipLaunchKernelGGL((ecc_sums2_kernel<ID, KPX, WV>), dim3(nb, blocks + kEccBorderBlocks), dim3(256), 0, st,    \
                        (const float *)s->ecc_img, tmpl_blur, rows, cols, (const EccState *)s->state, s->partial)
-                // pixels per thread and trip / waves per SIMD, measured on 1000 frames of 1024^2 (tools/exp_ecc.sh; ms of the
-                // sums per step): general iteration 2 px at 3 waves per SIMD (162 VGPRs) 8.7; at 2 waves: 1 px 12.2, 2 px 10.1,
-                // 3 px 10.5, 4 px 9.6; 1 px at 3 waves 9.9, 3 px at 3 waves (10 spilled registers) 10.0; identity iteration
-                // 4 px at 3 waves 9.9 (with the default general form), 8 px 9.6, 8 px at 2 waves 10.4.
+#define UPSP_ECC_COLS(ID, URX, WV)                                                                            \
+    hipLaunchKernelGGL((ecc_cols_kernel<ID, URX, WV>), dim3(nb, blocks + kEccBorderBlocks), dim3(256), 0, st,     \
+                       (const float *)s->ecc_img, tmpl_blur, rows, cols, (const EccState *)s->state, s->partial)
+                // Round 3: one column per thread, factored packed-float sums (ecc_cols_kernel); needs one column tile of 256 per
+                // interior block at least.  UPSP_ECC_KERNEL=2 selects round 2's kernel (A/B, and images wider than that).
+                static const int kernel_sel = env_int_io("UPSP_ECC_KERNEL", 3);
+                static const int cvariant = env_int_io("UPSP_ECC_CVARIANT", 0);
+                const bool use_cols = kernel_sel == 3 && (long long)cols <= 256ll * blocks && 3 * ((cols + 255) / 256) <= kEccBorderBlocks;
+                // pixels per thread and trip / waves per SIMD of round 2's kernel, measured on 1000 frames of 1024^2
+                // (tools/exp_ecc.sh; ms of the sums per step): general iteration 2 px at 3 waves per SIMD (162 VGPRs) 8.7; at 2
+                // waves: 1 px 12.2, 2 px 10.1, 3 px 10.5, 4 px 9.6; 1 px at 3 waves 9.9, 3 px at 3 waves (10 spilled registers)
+                // 10.0; identity iteration 4 px at 3 waves 9.9 (with the default general form), 8 px 9.6, 8 px at 2 waves 10.4.
                 // UPSP_ECC_VARIANT / UPSP_ECC_IVARIANT select the others.
                 static const int variant = env_int_io("UPSP_ECC_VARIANT", 4);
                 static const int ivariant = env_int_io("UPSP_ECC_IVARIANT", 1);
-                if (it == 0) {
+                if (use_cols) {
+                    if (it == 0) {
+                        if (cvariant == 1) UPSP_ECC_COLS(true, 8, 4);
+                        else if (cvariant == 2) UPSP_ECC_COLS(true, 4, 3);
+                        else if (cvariant == 3) UPSP_ECC_COLS(true, 2, 4);
+                        else UPSP_ECC_COLS(true, 4, 4);
+                    } else {
+                        if (cvariant == 1) UPSP_ECC_COLS(false, 4, 3);
+                        else if (cvariant == 2) UPSP_ECC_COLS(false, 2, 3);
+                        else if (cvariant == 3) UPSP_ECC_COLS(false, 1, 4);
+                        else UPSP_ECC_COLS(false, 2, 4);
+                    }
+                }
+                else if (it == 0) {
                     if (ivariant == 1) UPSP_ECC_LAUNCH(true, 2, 3);
                     else if (ivariant == 2) UPSP_ECC_LAUNCH(true, 2, 2);
                     else UPSP_ECC_LAUNCH(true, 1, 3);
@@ -1286,6 +1759,7 @@ static int run_ecc(FrameScratch *s, const float *tmpl_blur, const uint16_t *fram
                 else if (variant == 5) UPSP_ECC_LAUNCH(false, 1, 3);
                 else if (variant == 6) UPSP_ECC_LAUNCH(false, 3, 3);
                 else UPSP_ECC_LAUNCH(false, 2, 2);
+#undef UPSP_ECC_COLS
 #undef UPSP_ECC_LAUNCH
             }
             KTimed kt2("ecc_solve_kernel", st);
