@@ -700,7 +700,7 @@ __device__ __forceinline__ void ecc_border_body(const float *__restrict__ img, c
 // counts, |dM| ~ 1e-7).  The identity iteration (5 loads, no interpolation) becomes memory-bound.
 typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr int kEccFlush = 32;        // rows per float segment
-constexpr int kEccRowTab = 2048;     // rows of one block whose per-row coordinate terms are tabulated in LDS
+constexpr int kEccRowTab = 3840;     // rows of one block's piece at most: their per-row coordinate terms are tabulated in LDS
 
 struct EccPart {        // float partial sums of one segment
     v2f G0, G1, Gw0, Gw1, Gt0, Gt1, Q0, Q1, Q2, C01;
@@ -832,9 +832,8 @@ __device__ __forceinline__ double ecc_tot_value(const EccTot &T, double X)
     }
 }
 
-// Wave-wide sum of a double with DPP moves only (no ds_bpermute round trips: 45 sums x 6 dependent shuffle steps were a
-// ~25 000-cycle latency chain at the end of every block): quad swaps, half-row mirror, row mirror -> every lane holds its
-// row's sum; row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3 -> lane 63 holds the wave's.
+// One step of a sum over the lanes of a DPP row with moves only (no ds_bpermute round trips: 45 sums x 6 dependent
+// shuffle steps were a ~25 000-cycle latency chain at the end of every block).
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_add_f64(double v)
 {
@@ -843,25 +842,39 @@ __device__ __forceinline__ double dpp_add_f64(double v)
     const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xF, false);
     return v + __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);   // (rows outside the mask add 0.0)
 }
-__device__ __forceinline__ double wave_sum_to_lane63(double v)
-{
-    v = dpp_add_f64<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
-    v = dpp_add_f64<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
-    v = dpp_add_f64<0x141, 0xF>(v);   // row_half_mirror
-    v = dpp_add_f64<0x140, 0xF>(v);   // row_mirror
-    v = dpp_add_f64<0x142, 0xA>(v);   // row_bcast15 -> rows 1, 3
-    v = dpp_add_f64<0x143, 0xC>(v);   // row_bcast31 -> rows 2, 3
-    return v;
-}
 
-// block reduction of the 45 sums straight from the totals (one value at a time: the 45 doubles never exist at once);
-// fixed order everywhere -- deterministic
-template <int K>
-__device__ __forceinline__ void ecc_tot_reduce(const EccTot &T, double X, bool on, double (*red)[kEccSums])
+// Block reduction of the 45 sums straight from the totals, through LDS in three chunks of 15 (the 45 doubles of a
+// thread never exist at once): every thread writes its 15 values, thread (v, p) = (t / 16, t % 16) adds 16 of the 256
+// entries of value v (stride 16: conflict-free), the 16 partials of a value sit in one DPP row and are added there.
+// ~80 instructions per chunk and thread where the wave-wide DPP reduction of every value took ~30 per VALUE -- 1400
+// per thread, a third of the identity kernel's VALU instructions (PMC, profiles/r03_ecc_pmc.txt).  Fixed order: deterministic.
+constexpr int kEccChunk = 15;
+static_assert(kEccSums == 3 * kEccChunk, "three chunks");
+template <int C, int J>
+__device__ __forceinline__ void ecc_tot_put(const EccTot &T, double X, bool on, double (*lds)[256])
 {
-    const double v = wave_sum_to_lane63(on ? ecc_tot_value<K>(T, X) : 0.0);
-    if ((threadIdx.x & 63) == 63) red[threadIdx.x >> 6][K] = v;
-    if constexpr (K + 1 < kEccSums) ecc_tot_reduce<K + 1>(T, X, on, red);
+    lds[J][threadIdx.x] = on ? ecc_tot_value<C * kEccChunk + J>(T, X) : 0.0;
+    if constexpr (J + 1 < kEccChunk) ecc_tot_put<C, J + 1>(T, X, on, lds);
+}
+template <int C>
+__device__ __forceinline__ void ecc_tot_store(const EccTot &T, double X, bool on, double (*lds)[256],
+                                              double *__restrict__ partial, int f, unsigned slot)
+{
+    ecc_tot_put<C, 0>(T, X, on, lds);
+    __syncthreads();
+    const int v = (int)threadIdx.x >> 4, p = (int)threadIdx.x & 15;
+    if (v < kEccChunk) {                       // (waves 0 .. 3, whole DPP rows)
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s += lds[v][j * 16 + p];
+        s = dpp_add_f64<0xB1, 0xF>(s);
+        s = dpp_add_f64<0x4E, 0xF>(s);
+        s = dpp_add_f64<0x141, 0xF>(s);
+        s = dpp_add_f64<0x140, 0xF>(s);        // every lane of the row holds the block's sum of value v
+        if (p == 0) partial[((size_t)f * kEccSums + (C * kEccChunk + v)) * kEccStride + slot] = s;
+    }
+    __syncthreads();
+    if constexpr (C + 1 < 3) ecc_tot_store<C + 1>(T, X, on, lds, partial, f, slot);
 }
 
 // a block without any pixel: its partial sums are zero
@@ -870,66 +883,126 @@ __device__ __forceinline__ void ecc_store_zeros(double *__restrict__ partial, in
     if (threadIdx.x < kEccSums) partial[((size_t)f * kEccSums + threadIdx.x) * kEccStride + slot] = 0.0;
 }
 
-template <bool IDENT, int UR>
+// Identity iteration with NEIGHBOUR = 1: the left / right taps come from the neighbouring lanes' centre values by DPP
+// wave shifts (lane 0 and lane 63 load theirs: one load instruction per row under a two-lane exec mask), so a trip is
+// UR + 2 column loads + UR template loads -- registers and load slots that go into more rows in flight: the kernel is
+// bound by the bytes it keeps in flight (measured: 8 rows per trip against 4 ...).  Every lane of the wave must run
+// the trip (lanes past the rectangle read valid columns and are left out of the reduction).
+// uniform base + 32-bit BYTE offset of the lane (+ a constant): the form the compiler turns into
+// `global_load_dword v, v_off, s[base] offset:imm` -- one 32-bit add per ROW of a trip instead of a 64-bit shift-and-add
+// per LOAD (26 of the 239 VALU instructions of a general two-row trip, 32 of 166 in the identity trip)
+template <int IMM = 0>
+__device__ __forceinline__ float ld_f32(const float *base, unsigned byte_off)
+{
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off + IMM);
+}
+
+template <int IMM = 0>
+__device__ __forceinline__ v2f ld_v2f(const float *base, unsigned byte_off)      // two consecutive pixels, one 8-byte load
+{
+    return *reinterpret_cast<const v2f *>(reinterpret_cast<const char *>(base) + byte_off + IMM);
+}
+
+template <bool IDENT, int UR, int NEIGHBOUR = 0>
 __device__ __forceinline__ void ecc_cols_trip(const float *__restrict__ I, const float *__restrict__ tmpl, int cols, int x,
                                               int y, int r, int ax, int bx, const int2 *rtab, int rt0, const double *M,
                                               EccPart &P, EccTot &T)
 {
-    if (IDENT) {
-        // source pixel = target pixel: w = I, gradients = central differences of I (zero fractions make the bilinear
-        // weights (1,0,0,0), so the general arithmetic reduces exactly to these taps)
-        const float *pc = I + (size_t)y * cols + x;
-        float cc[UR + 2], ll[UR], rr[UR], tt[UR];
+    if (IDENT && NEIGHBOUR) {
+        // (uniform base + 32-bit lane offsets: one address register per load instead of a 64-bit pair)
+        const unsigned pitch = 4u * (unsigned)cols, o0 = 4u * (unsigned)(y * cols + x);
+        const int lane = threadIdx.x & 63;
+        float cc[UR + 2], tt[UR], hh[UR];
+        unsigned ob[UR + 2];
 #pragma unroll
-        for (int k = 0; k < UR + 2; ++k) cc[k] = pc[(k - 1) * cols];
+        for (int k = 0; k < UR + 2; ++k) ob[k] = o0 + (unsigned)(k - 1) * pitch;
+#pragma unroll
+        for (int k = 0; k < UR + 2; ++k) cc[k] = ld_f32(I, ob[k]);
+#pragma unroll
+        for (int k = 0; k < UR; ++k) tt[k] = ld_f32(tmpl, ob[k + 1]);
+#pragma unroll
+        for (int k = 0; k < UR; ++k) hh[k] = 0.f;
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < UR; ++k) hh[k] = ld_f32<-4>(I, ob[k + 1]);
+        } else if (lane == 63) {
+#pragma unroll
+            for (int k = 0; k < UR; ++k) hh[k] = ld_f32<4>(I, ob[k + 1]);
+        }
 #pragma unroll
         for (int k = 0; k < UR; ++k) {
-            ll[k] = pc[k * cols - 1];
-            rr[k] = pc[k * cols + 1];
-            tt[k] = tmpl[(size_t)(y + k) * cols + x];
+            // wave_shr:1 -> lane i reads lane i - 1 (lane 0 keeps `old` = its loaded halo); wave_shl:1 -> lane i + 1
+            const float l = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(hh[k]), __float_as_int(cc[k + 1]), 0x138, 0xF, 0xF, false));
+            const float rr = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(hh[k]), __float_as_int(cc[k + 1]), 0x130, 0xF, 0xF, false));
+            __builtin_amdgcn_sched_barrier(0);      // one row after the other: the rows' temporaries must not all be live at once
+            ecc_part_add<false>(P, T, cc[k + 1], 0.5f * (rr - l), 0.5f * (cc[k + 2] - cc[k]), tt[k], (float)(r + k));   // (= -a/2 + b/2 exactly)
+        }
+    } else if (IDENT) {
+        // source pixel = target pixel: w = I, gradients = central differences of I (zero fractions make the bilinear
+        // weights (1,0,0,0), so the general arithmetic reduces exactly to these taps)
+        const unsigned pitch = 4u * (unsigned)cols, o0 = 4u * (unsigned)(y * cols + x);
+        float cc[UR + 2], ll[UR], rr[UR], tt[UR];
+        unsigned ob[UR + 2];
+#pragma unroll
+        for (int k = 0; k < UR + 2; ++k) ob[k] = o0 + (unsigned)(k - 1) * pitch;
+#pragma unroll
+        for (int k = 0; k < UR + 2; ++k) cc[k] = ld_f32(I, ob[k]);
+#pragma unroll
+        for (int k = 0; k < UR; ++k) {
+            ll[k] = ld_f32<-4>(I, ob[k + 1]);
+            rr[k] = ld_f32<4>(I, ob[k + 1]);
+            tt[k] = ld_f32(tmpl, ob[k + 1]);
         }
 #pragma unroll
         for (int k = 0; k < UR; ++k)
-            ecc_part_add<false>(P, T, cc[k + 1], -0.5f * ll[k] + 0.5f * rr[k], -0.5f * cc[k] + 0.5f * cc[k + 2], tt[k], (float)(r + k));
+            ecc_part_add<false>(P, T, cc[k + 1], 0.5f * (rr[k] - ll[k]), 0.5f * (cc[k + 2] - cc[k]), tt[k], (float)(r + k));
     } else {
-        float v[UR][12], tt[UR], fx[UR], fy[UR];
+        // footprint of a pixel (rows sy-1 .. sy+2 = a, b, c, d; columns sx-1 .. sx+2 = _1, 0, 1, 2), loaded so that the
+        // pairs the arithmetic works on are the pairs the loads deliver: {a0,a1} {b0,b1} {c0,c1} {d0,d1} from 8-byte loads,
+        // {b_1,b2} {c_1,c2} from two 4-byte loads each
+        v2f A[UR], Bm[UR], Cm[UR], D[UR], Be[UR], Ce[UR];
+        float tt[UR], fx[UR], fy[UR];
+        const unsigned pitch = 4u * (unsigned)cols, ot = 4u * (unsigned)(y * cols + x);
 #pragma unroll
         for (int k = 0; k < UR; ++k) {
-            int2 rt;
-            if (rtab) {
-                rt = rtab[y + k - rt0];
-            } else {
-                const int yy = y + k;
-                rt = make_int2(__double2int_rn((M[1] * yy + M[2]) * 1024), __double2int_rn((M[4] * yy + M[5]) * 1024));
-            }
-            // WarpAffineInvoker's fixed-point coordinate: per-row term + per-column term, each rounded on its own
+            // WarpAffineInvoker's fixed-point coordinate: per-row term (LDS table of the block's rows) + per-column term,
+            // each rounded on its own
+            const int2 rt = rtab[y + k - rt0];
             const int Xr = rt.x + ax, Yr = rt.y + bx;
             const int Xq = (Xr + 16) >> 5, Yq = (Yr + 16) >> 5;
             const int sx = Xq >> 5, sy = Yq >> 5;        // (footprint inside the image by construction: ecc_band)
             fx[k] = (Xq & 31) * (1.f / 32);
             fy[k] = (Yq & 31) * (1.f / 32);
-            const float *r0 = I + (unsigned)((sy - 1) * cols + sx);
-            const float *r1 = r0 + cols, *r2 = r1 + cols, *r3 = r2 + cols;
-            v[k][0] = r0[0]; v[k][1] = r0[1];
-            v[k][2] = r1[-1]; v[k][3] = r1[0]; v[k][4] = r1[1]; v[k][5] = r1[2];
-            v[k][6] = r2[-1]; v[k][7] = r2[0]; v[k][8] = r2[1]; v[k][9] = r2[2];
-            v[k][10] = r3[0]; v[k][11] = r3[1];
-            tt[k] = tmpl[(size_t)(y + k) * cols + x];
+            // (rows and columns < 2^15 here: 24-bit multiply, full rate)
+            const unsigned q0 = 4u * (unsigned)(__mul24(sy - 1, cols) + sx), q1 = q0 + pitch, q2 = q1 + pitch, q3 = q2 + pitch;
+            A[k] = ld_v2f(I, q0);
+            Be[k][0] = ld_f32<-4>(I, q1);
+            Bm[k] = ld_v2f(I, q1);
+            Be[k][1] = ld_f32<8>(I, q1);
+            Ce[k][0] = ld_f32<-4>(I, q2);
+            Cm[k] = ld_v2f(I, q2);
+            Ce[k][1] = ld_f32<8>(I, q2);
+            D[k] = ld_v2f(I, q3);
+            tt[k] = ld_f32(tmpl, ot + (unsigned)k * pitch);
         }
 #pragma unroll
         for (int k = 0; k < UR; ++k) {
-            // bilinear of I, of [-0.5 0 0.5] along x and along y over the 12-pixel footprint (same operations as round 2)
-            const float a0 = v[k][0], a1 = v[k][1];
-            const float b_1 = v[k][2], b0 = v[k][3], b1 = v[k][4], b2 = v[k][5];
-            const float c_1 = v[k][6], c0 = v[k][7], c1 = v[k][8], c2 = v[k][9];
-            const float d0 = v[k][10], d1 = v[k][11];
-            const float w0 = (1.f - fy[k]) * (1.f - fx[k]), w1 = (1.f - fy[k]) * fx[k], w2 = fy[k] * (1.f - fx[k]),
-                        w3 = fy[k] * fx[k];
-            const float w = b0 * w0 + b1 * w1 + c0 * w2 + c1 * w3;
-            const float gx = (-0.5f * b_1 + 0.5f * b1) * w0 + (-0.5f * b0 + 0.5f * b2) * w1 +
-                             (-0.5f * c_1 + 0.5f * c1) * w2 + (-0.5f * c0 + 0.5f * c2) * w3;
-            const float gy = (-0.5f * a0 + 0.5f * c0) * w0 + (-0.5f * a1 + 0.5f * c1) * w1 +
-                             (-0.5f * b0 + 0.5f * d0) * w2 + (-0.5f * b1 + 0.5f * d1) * w3;
+            // Bilinear interpolation of I and of its central differences along x and y (cv::findTransformECC warps the two
+            // gradient IMAGES).  All three are linear in the pixels, so with V_j = the vertical interpolation at column j
+            //     w  = V_0 + fx (V_1 - V_0)
+            //     gx = 1/2 [ (V_1 - V_-1) + fx ((V_2 - V_0) - (V_1 - V_-1)) ]
+            //     gy = 1/2 [ p_0 + fx (p_1 - p_0) ],   p = (c - a) + fy ((d - b) - (c - a))  at columns 0, 1
+            // -- 19 instructions where the four-weight form of round 2 took ~50.  With zero fractions (identity) these
+            // are exactly the taps of the identity iteration: V_j = b_j, w = b_0, gx = (b_1 - b_-1) / 2, gy = (c_0 - a_0) / 2.
+            const v2f FY = {fy[k], fy[k]};
+            const v2f Vm = __builtin_elementwise_fma(FY, Cm[k] - Bm[k], Bm[k]);     // {V_0, V_1}
+            const v2f Ve = __builtin_elementwise_fma(FY, Ce[k] - Be[k], Be[k]);     // {V_-1, V_2}
+            const float w = __builtin_fmaf(fx[k], Vm[1] - Vm[0], Vm[0]);
+            const float dx0 = Vm[1] - Ve[0], dx1 = Ve[1] - Vm[0];
+            const float gx = 0.5f * __builtin_fmaf(fx[k], dx1 - dx0, dx0);
+            const v2f E = Cm[k] - A[k], F = D[k] - Bm[k];
+            const v2f Pp = __builtin_elementwise_fma(FY, F - E, E);
+            const float gy = 0.5f * __builtin_fmaf(fx[k], Pp[1] - Pp[0], Pp[0]);
             ecc_part_add<false>(P, T, w, gx, gy, tt[k], (float)(r + k));
         }
     }
@@ -938,13 +1011,15 @@ __device__ __forceinline__ void ecc_cols_trip(const float *__restrict__ I, const
 // Interior block `blk` of `nblk`: the inner rectangle (farther than the band from every edge) is cut into column tiles
 // of 256 and, per tile, into nblk / tiles row pieces; blocks beyond that store zeros.  Needs nblk >= tiles (the host
 // checks: cols <= 256 x interior blocks, else the round-2 kernel runs).
-template <bool IDENT, int UR>
+template <bool IDENT, int UR, int NEIGHBOUR>
 __device__ __forceinline__ void ecc_cols_body(const float *__restrict__ img, const float *__restrict__ tmpl, int rows,
                                               int cols, const EccState *__restrict__ state,
-                                              double *__restrict__ partial, int f, unsigned blk, unsigned nblk)
+                                              double *__restrict__ partial, int f, unsigned blk, unsigned nblk,
+                                              double (*lds_red)[256])
 {
-    __shared__ double red[4][kEccSums];
-    __shared__ int2 rtab_s[kEccRowTab];
+    // one LDS area: the per-row coordinate table while the rows are walked, the reduction chunks afterwards
+    static_assert(sizeof(int2) * kEccRowTab <= sizeof(double) * kEccChunk * 256, "row table fits the reduction area");
+    int2 *rtab_s = reinterpret_cast<int2 *>(&lds_red[0][0]);
     const EccState &es = state[f];
     const float *I = img + (size_t)f * rows * cols;
     const EccMargins g = ecc_margins(IDENT ? 3 : es.band, rows, cols);
@@ -956,8 +1031,11 @@ __device__ __forceinline__ void ecc_cols_body(const float *__restrict__ img, con
     const unsigned ct = work ? blk % tiles : 0u, piece = work ? blk / tiles : 0u;
     const int rpp = pieces ? (int)(((unsigned)H + pieces - 1u) / pieces) : 0;  // rows per piece
     const int y0 = work ? min(y_hi, y_lo + (int)piece * rpp) : 0, y1 = work ? min(y_hi, y0 + rpp) : 0;
-    const int x = x_lo + (int)ct * 256 + (int)threadIdx.x;
-    const bool on = work && x < x_hi && y1 > y0;
+    const int x_own = x_lo + (int)ct * 256 + (int)threadIdx.x;
+    const bool on = work && x_own < x_hi && y1 > y0;
+    // NEIGHBOUR: lanes past the rectangle run along on a valid column (the lane after the last one must hold column
+    // x_hi, which exists: the band is >= 3 wide) and are left out of the reduction
+    const int x = NEIGHBOUR ? min(x_own, cols - 1) : x_own;
     if (!work || y1 <= y0) {            // (uniform) more blocks than pieces: nothing to add
         ecc_store_zeros(partial, f, kEccBorderBlocks + blk);
         return;
@@ -965,8 +1043,7 @@ __device__ __forceinline__ void ecc_cols_body(const float *__restrict__ img, con
     double M[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) M[i] = es.M[i];
-    const bool tab = !IDENT && (y1 - y0) <= kEccRowTab;
-    if (!IDENT && tab) {
+    if (!IDENT) {      // (the host sizes the grid so that a piece has at most kEccRowTab rows)
         for (int i = threadIdx.x; i < y1 - y0; i += 256) {
             const int yy = y0 + i;
             rtab_s[i] = make_int2(__double2int_rn((M[1] * yy + M[2]) * 1024), __double2int_rn((M[4] * yy + M[5]) * 1024));
@@ -979,25 +1056,21 @@ __device__ __forceinline__ void ecc_cols_body(const float *__restrict__ img, con
         T.G0[k] = T.G1[k] = T.Gw0[k] = T.Gw1[k] = T.Gt0[k] = T.Gt1[k] = T.Q0[k] = T.Q1[k] = T.Q2[k] = 0.0;
     T.C0 = T.C1 = T.C2 = T.Sw = T.Sww = T.St = T.Stt = T.Stw = 0.0;
     T.n = on ? (double)(y1 - y0) : 0.0;          // mask = 1 on every interior pixel
-    if (on) {
+    if (on || NEIGHBOUR) {
         const int ax = IDENT ? 0 : __double2int_rn(M[0] * x * 1024), bx = IDENT ? 0 : __double2int_rn(M[3] * x * 1024);
-        const int2 *rt = (!IDENT && tab) ? rtab_s : nullptr;
+        const int2 *rt = rtab_s;
         for (int yb = y0; yb < y1; yb += kEccFlush) {
             const int ne = min(kEccFlush, y1 - yb);
             EccPart P;
             ecc_part_zero(P);
             int r = 0;
-            for (; r + UR <= ne; r += UR) ecc_cols_trip<IDENT, UR>(I, tmpl, cols, x, yb + r, r, ax, bx, rt, y0, M, P, T);
-            for (; r < ne; ++r) ecc_cols_trip<IDENT, 1>(I, tmpl, cols, x, yb + r, r, ax, bx, rt, y0, M, P, T);
+            for (; r + UR <= ne; r += UR) ecc_cols_trip<IDENT, UR, NEIGHBOUR>(I, tmpl, cols, x, yb + r, r, ax, bx, rt, y0, M, P, T);
+            for (; r < ne; ++r) ecc_cols_trip<IDENT, 1, NEIGHBOUR>(I, tmpl, cols, x, yb + r, r, ax, bx, rt, y0, M, P, T);
             ecc_part_flush(P, T, yb);
         }
     }
-    ecc_tot_reduce<0>(T, (double)x, on, red);
-    __syncthreads();
-    if (threadIdx.x < kEccSums) {
-        const double v = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
-        partial[((size_t)f * kEccSums + threadIdx.x) * kEccStride + (kEccBorderBlocks + blk)] = v;
-    }
+    __syncthreads();                              // (every read of the row table is done)
+    ecc_tot_store<0>(T, (double)x, on, lds_red, partial, f, kEccBorderBlocks + blk);
 }
 
 // The band of the same launch, also one column per thread (no 45 double accumulators anywhere in this kernel: with
@@ -1009,9 +1082,9 @@ __device__ __forceinline__ void ecc_cols_body(const float *__restrict__ img, con
 // Generic bilinear (constant-0 border, reflect-101 gradient taps) and the nearest-neighbour mask, as in round 2.
 __device__ __forceinline__ void ecc_band_cols_body(const float *__restrict__ img, const float *__restrict__ tmpl, int rows,
                                                    int cols, const EccState *__restrict__ state,
-                                                   double *__restrict__ partial, int f, unsigned bidx, bool ident)
+                                                   double *__restrict__ partial, int f, unsigned bidx, bool ident,
+                                                   double (*lds_red)[256])
 {
-    __shared__ double red[4][kEccSums];
     const EccState &es = state[f];
     const float *I = img + (size_t)f * rows * cols;
     double M[6];
@@ -1114,26 +1187,22 @@ __device__ __forceinline__ void ecc_band_cols_body(const float *__restrict__ img
             ecc_part_flush(P, T, y0);
         }
     }
-    ecc_tot_reduce<0>(T, (double)x, on, red);
-    __syncthreads();
-    if (threadIdx.x < kEccSums) {
-        const double v = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
-        partial[((size_t)f * kEccSums + threadIdx.x) * kEccStride + bidx] = v;
-    }
+    ecc_tot_store<0>(T, (double)x, on, lds_red, partial, f, bidx);
 }
 
-template <bool IDENT, int UR, int WAVES>
+template <bool IDENT, int UR, int WAVES, int NEIGHBOUR = 0>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
     ecc_cols_kernel(const float *__restrict__ img, const float *__restrict__ tmpl, int rows, int cols,
                     const EccState *__restrict__ state, double *__restrict__ partial)
 {
+    __shared__ double lds_red[kEccChunk][256];     // row table / reduction chunks of whichever body runs
     const int f = blockIdx.x;
     if (state[f].done) return;
     const unsigned nint = gridDim.y - (unsigned)kEccBorderBlocks;
     if (blockIdx.y >= (unsigned)kEccBorderBlocks)
-        ecc_cols_body<IDENT, UR>(img, tmpl, rows, cols, state, partial, f, blockIdx.y - (unsigned)kEccBorderBlocks, nint);
+        ecc_cols_body<IDENT, UR, NEIGHBOUR>(img, tmpl, rows, cols, state, partial, f, blockIdx.y - (unsigned)kEccBorderBlocks, nint, lds_red);
     else
-        ecc_band_cols_body(img, tmpl, rows, cols, state, partial, f, blockIdx.y, IDENT);
+        ecc_band_cols_body(img, tmpl, rows, cols, state, partial, f, blockIdx.y, IDENT, lds_red);
 }
 
 // grid (frames, kEccBorderBlocks + interior blocks): the frame is the FAST index, so the band blocks of all frames
@@ -1710,8 +1779,18 @@ static int run_ecc(FrameScratch *s, const float *tmpl_blur, const uint16_t *fram
         // (first burst: as many iterations as the previous sub-batch's slowest frame took -- on steady footage every
         //  frame converges with its second iteration, and a third launch pair that finds nothing to do costs 10 us)
         const int burst = it == 0 ? s->ecc_first_burst : (it < 7 ? 2 : (it < 15 ? 8 : 16));
-        int blocks = kEccBlocks;
-        while (blocks < kEccBlocksMax && (long long)blocks * active < 2048) blocks *= 2;
+        // Interior blocks per frame.  Round 3's kernel: every block ends with a reduction of the 45 sums that costs as
+        // much as ~10 rows of its 256 columns, so a block should walk a few hundred rows -- 16 blocks per frame (4 column
+        // tiles x 4 row pieces of 256 at 1024^2: 1024 blocks for a full sub-batch = one resident set at 4 per CU), more
+        // when few frames are still iterating; at least one per column tile of 256.
+        static const int kernel_sel = env_int_io("UPSP_ECC_KERNEL", 3);
+        const int tiles = (cols + 255) / 256;
+        const bool cols_ok = kernel_sel == 3 && 3 * tiles <= kEccBorderBlocks && tiles <= kEccBlocksMax;
+        static const int blocks0 = env_int_io("UPSP_ECC_BLOCKS", 64);     // (measured 16 / 32 / 64: 6.74 / 6.25 / 6.03 ms of sums per 1000 frames)
+        int blocks = cols_ok ? blocks0 : kEccBlocks;
+        while (blocks < kEccBlocksMax && ((long long)blocks * active < (cols_ok ? 1024 : 2048) ||
+                                          (cols_ok && (blocks < tiles || rows > (long long)kEccRowTab * (blocks / tiles)))))
+            blocks *= 2;
         const int nblocks_total = blocks + kEccBorderBlocks;
         for (int k = 0; k < burst && it < max_iters; ++k, ++it) {
             {
@@ -1719,14 +1798,14 @@ static int run_ecc(FrameScratch *s, const float *tmpl_blur, const uint16_t *fram
 #define UPSP_ECC_LAUNCH(ID, KPX, WV)                                                                          \
     hipLaunchKernelGGL((ecc_sums2_kernel<ID, KPX, WV>), dim3(nb, blocks + kEccBorderBlocks), dim3(256), 0, st,    \
                        (const float *)s->ecc_img, tmpl_blur, rows, cols, (const EccState *)s->state, s->partial)
-#define UPSP_ECC_COLS(ID, URX, WV)                                                                            \
-    hipLaunchKernelGGL((ecc_cols_kernel<ID, URX, WV>), dim3(nb, blocks + kEccBorderBlocks), dim3(256), 0, st,     \
+#define UPSP_ECC_COLS(ID, URX, WV, ...)                                                                       \
+    hipLaunchKernelGGL((ecc_cols_kernel<ID, URX, WV, ##__VA_ARGS__>), dim3(nb, blocks + kEccBorderBlocks), dim3(256), 0, st, \
                        (const float *)s->ecc_img, tmpl_blur, rows, cols, (const EccState *)s->state, s->partial)
                 // Round 3: one column per thread, factored packed-float sums (ecc_cols_kernel); needs one column tile of 256 per
                 // interior block at least.  UPSP_ECC_KERNEL=2 selects round 2's kernel (A/B, and images wider than that).
-                static const int kernel_sel = env_int_io("UPSP_ECC_KERNEL", 3);
                 static const int cvariant = env_int_io("UPSP_ECC_CVARIANT", 0);
-                const bool use_cols = kernel_sel == 3 && (long long)cols <= 256ll * blocks && 3 * ((cols + 255) / 256) <= kEccBorderBlocks;
+                const bool use_cols = cols_ok && blocks >= tiles && rows <= (long long)kEccRowTab * (blocks / tiles) &&
+                                      rows < 32768 && cols < 32768;
                 // pixels per thread and trip / waves per SIMD of round 2's kernel, measured on 1000 frames of 1024^2
                 // (tools/exp_ecc.sh; ms of the sums per step): general iteration 2 px at 3 waves per SIMD (162 VGPRs) 8.7; at 2
                 // waves: 1 px 12.2, 2 px 10.1, 3 px 10.5, 4 px 9.6; 1 px at 3 waves 9.9, 3 px at 3 waves (10 spilled registers)
@@ -1735,15 +1814,21 @@ static int run_ecc(FrameScratch *s, const float *tmpl_blur, const uint16_t *fram
                 static const int variant = env_int_io("UPSP_ECC_VARIANT", 4);
                 static const int ivariant = env_int_io("UPSP_ECC_IVARIANT", 1);
                 if (use_cols) {
+                    // UPSP_ECC_CVARIANT = 10 x identity variant + general variant (measurement switch)
+                    const int iv = cvariant / 10, gv = cvariant % 10;
                     if (it == 0) {
-                        if (cvariant == 1) UPSP_ECC_COLS(true, 8, 4);
-                        else if (cvariant == 2) UPSP_ECC_COLS(true, 4, 3);
-                        else if (cvariant == 3) UPSP_ECC_COLS(true, 2, 4);
-                        else UPSP_ECC_COLS(true, 4, 4);
+                        // (measured, us per 64-frame launch on one box: plain 4 rows per trip 172, DPP taps 4 rows 163, 8 rows at
+                        //  3 waves per SIMD 191, 8 rows at 4 waves -- 82 spilled registers -- 390)
+                        if (iv == 1) UPSP_ECC_COLS(true, 8, 4, 1);
+                        else if (iv == 2) UPSP_ECC_COLS(true, 4, 4);
+                        else if (iv == 3) UPSP_ECC_COLS(true, 8, 3, 1);
+                        else UPSP_ECC_COLS(true, 4, 4, 1);
                     } else {
-                        if (cvariant == 1) UPSP_ECC_COLS(false, 4, 3);
-                        else if (cvariant == 2) UPSP_ECC_COLS(false, 2, 3);
-                        else if (cvariant == 3) UPSP_ECC_COLS(false, 1, 4);
+                        // (general iteration, same box: 2 rows per trip at 4 waves per SIMD 316, 4 rows at 3 waves 306, 3 at 3: 313,
+                        //  2 at 3: 330 -- flat: neither rows in flight nor occupancy is what bounds it)
+                        if (gv == 1) UPSP_ECC_COLS(false, 4, 3);
+                        else if (gv == 3) UPSP_ECC_COLS(false, 3, 3);
+                        else if (gv == 4) UPSP_ECC_COLS(false, 2, 3);
                         else UPSP_ECC_COLS(false, 2, 4);
                     }
                 }
