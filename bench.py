@@ -64,12 +64,18 @@ def parse():
                     help="run the chunked / pipelined-exchange frame loop of the N>1 path on one GPU")
     ap.add_argument("--f32-wire", action="store_true",
                     help="N>1 / --force-chunked: exchange the series as f32 instead of u16")
+    ap.add_argument("--wire12", action="store_true",
+                    help="N>1 (RCCL): the u16 series packed to 12 bits for the wire (3 bytes per 2 frames; 12-bit cameras)")
     ap.add_argument("--two-kernel", action="store_true",
                     help="frame loop as scan kernel + gather kernel per 64 frames instead of the (default) "
                          "streamed two-pass schedule (pass A: scan + compact pixel series, pass B: whole rows)")
-    ap.add_argument("--model", default="quad", choices=["quad", "uv"],
+    ap.add_argument("--model", default="quad", choices=["quad", "uv", "5m"],
                     help="quad: cube-sphere tunnel model (valence <= 6); uv: UV-sphere model with "
-                         "1000-valent polar fans (worst case for per-ray traversal length)")
+                         "1000-valent polar fans (worst case for per-ray traversal length); 5m: the 5 M-triangle "
+                         "tunnel model of configs[4] (use with --cameras)")
+    ap.add_argument("--cameras", type=int, default=1,
+                    help="configs[4] shape: N cameras around the model (azimuth 0, 90, 180, 270 ...), AverageViews weights, "
+                         "one frame SET (a frame of every camera) per step unit; on one GPU")
     ap.add_argument("--fill-frame", action="store_true",
                     help="1 M-triangle sphere filling the frame instead of the tunnel model: ~0.2 M visible nodes on "
                          "as many active pixels, so the compact pixel series (2 KB per active pixel and 1000 frames) "
@@ -426,8 +432,205 @@ def host_feed_rate(pipe, frames, N, size, pix, chunk=64, nchunks=16):
                    "stream -> unpack in HBM -> frame loop; uploads overlap the processing" % chunk}
 
 
+def multi_camera_main(a):
+    """configs[4] shape on ONE GPU (BASELINE: 4-camera multi-view, 5 M-triangle mesh; all cameras of a frame are kept
+    on one GPU): step = a projection build per camera + AverageViews weights + skipped nodes + the weighted frame loop
+    over F frame sets (pass A per camera, one whole-row pass B: sol = sum_c w_c * frame_c[pix_c], camera order,
+    psp_process.cpp:1771-1843) + finals."""
+    import torch
+    from upsp_processing_amd import _capi, engine, synthetic as syn
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(0)
+    _capi.lib()
+    C, size, F = a.cameras, a.size, a.frames
+    if a.small:
+        verts, tris = syn.tunnel_model_quad(64, 24)
+        F = min(F, 256)
+    elif a.model == "5m":
+        verts, tris = syn.tunnel_model_quad(576, 205)      # 4 990 104 triangles, 2 495 058 nodes
+    else:
+        verts, tris = syn.tunnel_model_quad()
+    s9, tn = syn.soup(verts, tris)
+    nrm = syn.node_normals(verts, tris)
+    N = verts.shape[0]
+    npx = size * size
+    cds = [syn.pinhole_camera(size, size, center=(0, 0, 20), half_extent=6.0, azimuth_deg=360.0 * c / C) for c in range(C)]
+    cams = [_capi.make_camera(cd["K"], cd["dist"], cd["R"], cd["t"], size, size) for cd in cds]
+    centers = np.array([engine.camera_center(c) for c in cams])
+    bvh = engine.BVH(s9)
+    d_nodes, d_nrm, d_tn = [torch.as_tensor(x).cuda() for x in (verts, nrm, tn)]
+    bvh.set_tri_nodes(d_tn, N)
+    frames = [syn.synth_frames_torch(F, size, size, first=100 * c, hot=True) for c in range(C)]
+    n_sample = min(F, 32)
+    sample = [fr[:n_sample].cpu().view(torch.int16).numpy().view(np.uint16).copy() for fr in frames] if not a.no_cpu_baseline else None
+    hot_idx = [torch.nonzero((fr.view(torch.int16).reshape(F, -1) >= 4064).any(1), as_tuple=False).reshape(-1) for fr in frames]
+    pristine = [fr.view(torch.int16)[h].clone() for fr, h in zip(frames, hot_idx)]
+    pipe = engine.FramePipeline(C, size, size, N)
+    rows_t = torch.empty((N, engine.series_ld(F, whole_rows=True)), dtype=torch.float32, device="cuda")[:, :F]
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    ev_log, last = [], {}
+
+    def step(record):
+        for fr, h, p in zip(frames, hot_idx, pristine):       # new frames arrive: the repaired ones are put back
+            if h.numel():
+                fr.view(torch.int16)[h] = p
+        e = [ev() for _ in range(3)]
+        e[0].record()
+        pix = torch.stack([engine.build_projection(bvh, cam, d_nodes, d_nrm, d_tn, 70.0, counts=False)["pix"] for cam in cams])
+        w = engine.projection_weights(pix, d_nodes, d_nrm, centers, "average_view")      # adjust_projection_for_weights
+        e[1].record()
+        pipe.reset()
+        for c in range(C):
+            pipe.set_projection(c, pix[c], w[c])
+        pipe.process(frames, first_frame=0, rows_t=rows_t, want_rows=False)
+        avg, rms = pipe.finalize(F)
+        e[2].record()
+        if record:
+            ev_log.append(e)
+            last.update(pix=pix, w=w)
+        return avg
+
+    for _ in range(a.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step(True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    bvh.check()
+    _capi.timing_enable(True)
+    for _ in range(a.steps):
+        step(False)
+    torch.cuda.synchronize()
+    _capi.timing_enable(False)
+    rep = _capi.timing_report(spread=True)
+    pix, w = last["pix"], last["w"]
+    active = [int(torch.unique(pix[c][pix[c] >= 0]).numel()) for c in range(C)]
+    seen = int(((pix >= 0).sum(0) > 0).sum().item())
+    seen_by = float((pix >= 0).sum().item()) / max(seen, 1)
+    # algorithmic bytes of the pass-B launch: every row written once (4 B x N x F), the per-node scalars of every camera
+    # once (index + weight), every active pixel's series read once (2 B x F each)
+    row_bytes = 4 * N * F
+    alg_b = row_bytes + 8 * N * C + 2 * F * sum(active)
+    per_step = {"node_rows_multi_kernel": alg_b, "scan_compact_kernel": C * F * 2 * npx}
+    kernels = {}
+    for name, (calls, total, lo, med, hi) in rep.items():
+        k = {"calls_per_step": calls / a.steps, "ms_per_step": total / a.steps, "avg_launch_ms": total / max(calls, 1)}
+        if name in per_step and total:
+            k["algorithmic_bytes_per_step"] = per_step[name]
+            k["achieved_GBps"] = per_step[name] / (total / a.steps * 1e-3) / 1e9
+            k["launch_ms_min_median_max"] = [lo, med, hi]
+        kernels[name] = k
+    dom = max((n for n in kernels if "achieved_GBps" in kernels[n]), key=lambda n: kernels[n]["ms_per_step"])
+    dk = kernels[dom]
+    traffic, traffic_src = None, None
+    prof = os.environ.get("UPSP_BENCH_TRAFFIC_JSON")
+    if prof and os.path.exists(prof):
+        pj = json.load(open(prof))
+        if dom in pj.get("traffic_bytes_per_launch", {}):
+            traffic, traffic_src = pj["traffic_bytes_per_launch"][dom], os.path.relpath(os.path.abspath(prof), ROOT)
+    ms_step = dt / a.steps * 1e3
+    out = {
+        "metric": "frames/s", "value": F * a.steps / dt, "unit": "frames/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "camera_frames_per_s": C * F * a.steps / dt,
+        "config": {"workload": "configs[4] shape on one GPU: %d cameras x %d frames x %dx%d u16, %d-tri tunnel model (%d nodes), "
+                               "raycast+weighted projection; a frame = one frame of every camera" % (C, F, size, size, tris.shape[0], N),
+                   "cameras": C, "frames_per_camera": F, "nodes": N, "triangles": int(tris.shape[0]),
+                   "nodes_seen": seen, "cameras_per_seen_node": seen_by, "active_pixels_per_camera": active,
+                   "parallelism": "one GPU", "schedule": "per camera: projection build; pass A per camera; one whole-row pass B over all cameras"},
+        "breakdown_ms": {"projection_builds_and_weights": float(np.mean([e[0].elapsed_time(e[1]) for e in ev_log])),
+                         "frame_loop_and_finals": float(np.mean([e[1].elapsed_time(e[2]) for e in ev_log]))},
+        "roofline": {"kernel": dom, "bound": "hbm", "achieved": dk["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": dk["achieved_GBps"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "algorithmic_bytes_per_launch": dk["algorithmic_bytes_per_step"] / max(dk["calls_per_step"], 1),
+                     "avg_launch_ms": dk["avg_launch_ms"], "launches_per_step": dk["calls_per_step"]},
+        "pass_b_row_GBps": row_bytes / (kernels["node_rows_multi_kernel"]["ms_per_step"] * 1e-3) / 1e9 if "node_rows_multi_kernel" in kernels else None,
+        "kernels": kernels,
+    }
+    if not a.no_cpu_baseline:
+        # oracle (CPU port): projection of every camera on the full model, weights, and the weighted loop on a bounded
+        # sample of frame sets (one frame set per thread, like the reference's OpenMP loop)
+        from concurrent.futures import ThreadPoolExecutor
+        from oracle import oracle as orc
+        cores = usable_cpus()
+        obv = orc.OracleBVH(s9)
+        t0 = time.perf_counter()
+        opix = np.stack([orc.create_projection(obv, orc.make_camera(cd["K"], cd["dist"], cd["R"], cd["t"], size, size), verts, nrm, tn,
+                                               engine.oblique_threshold(70.0), threads=cores)["pix"] for cd in cds]).astype(np.int32)
+        t_proj = time.perf_counter() - t0
+        ow = orc.adjust_weights(opix, np.ones((C, N), np.float32), verts, nrm, centers, 1)      # 1 = AverageViews
+        osk = orc.skipped_nodes(opix)
+
+        def one(f):
+            sol = None
+            for c in range(C):
+                img, _ = orc.fix_hot_pixels(sample[c][f])
+                cs = orc.project_frame(img, opix[c], ow[c])
+                sol = cs if sol is None else (sol + cs).astype(np.float32)
+            sol[osk] = np.nan
+            return sol
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:
+            rows_o = list(ex.map(one, range(n_sample)))
+        t_loop = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": F / (t_proj + t_loop / n_sample * F), "unit": "frames/s", "cores": cores, "kind": "port",
+                               "sample": "oracle/ (C, %d threads): projection of the %d cameras on the full model (%.1f s) + the weighted loop on %d "
+                                         "frame sets (%.2f s); extrapolated to %d frame sets" % (cores, C, t_proj, n_sample, t_loop, F)}
+        gw = w.cpu().numpy()
+        p2 = engine.FramePipeline(C, size, size, N, fused_scan=1)
+        for c in range(C):
+            p2.set_projection(c, pix[c], w[c])
+        rt = torch.empty((N, engine.series_ld(n_sample, whole_rows=True)), dtype=torch.float32, device="cuda")[:, :n_sample]
+        p2.process([torch.as_tensor(sm.view(np.int16)).view(torch.uint16).cuda() for sm in sample], 0, rows_t=rt, want_rows=False)
+        gr = rt.cpu().numpy()
+        gs, gss = [x.cpu().numpy() for x in p2.accumulators()]
+        ro = np.stack(rows_o)
+        ok = ~np.isnan(ro[0])
+        so, sso = ro[:, ok].astype(np.float64).sum(0), (ro[:, ok] * ro[:, ok]).astype(np.float64).sum(0)
+        seen2 = (opix >= 0).sum(0) >= 2
+        checks = {
+            "projection_pix_all_cameras": bool(np.array_equal(pix.cpu().numpy(), opix)),
+            # AverageViews weights: f64 acos -> f32, a few 1e-7 relative (tests/test_projection_gpu.py)
+            "weights_rel_4e-7": bool(np.abs(gw - ow).max() <= 4e-7),
+            "series_rows_%d_frame_sets_for_gpu_weights" % n_sample: None,
+            "nan_rows": bool(np.array_equal(np.isnan(gr[:, 0]), ~ok)),
+            "accumulators_rel_1e-12": bool(np.allclose(gs[ok], so, rtol=1e-9) and np.allclose(gss[ok], sso, rtol=1e-9)),
+        }
+        # the series against the oracle's weighted sum evaluated with the GPU's weights (the weights themselves are compared
+        # above, to 1 ulp): bit for bit
+        def one_g(f):
+            sol = None
+            for c in range(C):
+                img, _ = orc.fix_hot_pixels(sample[c][f])
+                cs = orc.project_frame(img, opix[c], gw[c])
+                sol = cs if sol is None else (sol + cs).astype(np.float32)
+            return sol
+        with ThreadPoolExecutor(cores) as ex:
+            rg = np.stack(list(ex.map(one_g, range(n_sample))))
+        checks["series_rows_%d_frame_sets_for_gpu_weights" % n_sample] = bool(np.array_equal(gr[ok].T.view(np.int32), rg[:, ok].view(np.int32)))
+        acc_ok = np.allclose(gs[ok], rg[:, ok].astype(np.float64).sum(0), rtol=1e-12) and np.allclose(
+            gss[ok], (rg[:, ok] * rg[:, ok]).astype(np.float64).sum(0), rtol=1e-12)
+        checks["accumulators_rel_1e-12"] = bool(acc_ok)
+        out["parity_checked"] = all(checks.values())
+        out["parity"] = checks
+        out["config"]["nodes_seen_by_two_or_more"] = int(seen2.sum())
+        if not out["parity_checked"]:
+            print(json.dumps(out), flush=True)
+            raise SystemExit("bench.py: GPU results differ from the oracle: %r" % (checks,))
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out), flush=True)
+
+
 def main():
     a = parse()
+    if a.cameras > 1:
+        if a.gpus != 1:
+            raise SystemExit("bench.py --cameras: one GPU (all cameras of a frame are kept on one GPU)")
+        return multi_camera_main(a)
     if a.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(a.gpus))
     import torch
@@ -527,7 +730,7 @@ def main():
     # N > 1: the frame loop runs in K chunks and the all-to-all of chunk k is issued
     # asynchronously while chunk k+1 is being processed (distributed.TimeSeriesExchange)
     K = 4 if chunked else 1
-    exch = D.TimeSeriesExchange(shard, K) if chunked else None
+    exch = D.TimeSeriesExchange(shard, K, wire12=a.wire12) if chunked else None
     # one camera, no weights, no filter: the series values are exact 16-bit integers, so the
     # travelling rows are produced and sent as u16 (half the bytes) and widened by the receiver
     u16_wire = chunked and not a.f32_wire
@@ -743,7 +946,7 @@ def main():
                                      "SURVEY 8(d): model intensity x 24 fiducial discs, background 60, noise 8, "
                                      "<= 3 hot pixels in 1 % of the frames"),
                    "parallelism": "frames sharded x%d" % world, "schedule": sched,
-                   **({"exchange": "%d chunks, visible rows as %s" % (K, "u16" if u16_wire else "f32")}
+                   **({"exchange": "%d chunks, visible rows as %s" % (K, ("u16 packed to 12 bit" if a.wire12 else "u16") if u16_wire else "f32")}
                       if chunked else {})},
         "mrays_per_s": mrays, "mrays_per_s_kind": "reference-equivalent (rays the reference casts / build time)",
         "rays_per_step": nrays, "rays_cast_per_step": primary_rays + n_retry_rays,
@@ -759,6 +962,17 @@ def main():
         "roofline": roof,
         "kernels": kernels,
     }
+    if chunked:
+        # what a rank hands to the exchange per step, and how much of it crossed a link in THIS run (nothing in a one-rank
+        # group; (N - 1) / N of it at N ranks, one block per xGMI link and chunk)
+        wire_bytes = 1.5 if (u16_wire and a.wire12) else series_esz
+        xb = exch.exchange_bytes()
+        out["exchange_bytes_per_step"] = {
+            "travelling_rows": int(series_rows), "frames_per_rank": F, "wire_bytes_per_value": wire_bytes,
+            "packed_series_bytes_per_rank": int(series_rows * F * wire_bytes),
+            "leaves_the_gpu_at_8_ranks": int(series_rows * F * wire_bytes * 7 / 8),
+            "sent_to_other_ranks_this_run": None if xb is None else xb[0],
+            "transport": "C ABI upsp_exchange_* over RCCL" if xb is not None else ("torch.distributed (%s)" % backend if world > 1 else "local scatter (one rank)")}
     if a.registration:
         out["ecc_iterations_per_frame"] = ecc_iters_per_frame
     if world == 1 and not a.registration and not a.no_reraycast:
@@ -856,8 +1070,10 @@ def main():
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if exch is not None:
+        exch.close()
     if world > 1 or force_coll:
-        dist.destroy_process_group()
+        D.shutdown()
 
 
 if __name__ == "__main__":

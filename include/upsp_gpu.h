@@ -486,6 +486,66 @@ int upsp_interpolate_idw(const float *h_src_nodes3, const float *h_src_data, siz
                          int32_t *d_neighbors, void *stream);
 
 /* ======================================================================== *
+ *  3b.  Between the ranks of a job: one process per GPU, RCCL over xGMI
+ *       (reference: MPI in psp_process -- apportion cpp/exec/psp_process.cpp:611-624,
+ *        MPI_Reduce + MPI_Bcast of the accumulators :1866-1872, 2019-2023,
+ *        global_transpose of the time series :707-771)
+ * ======================================================================== */
+
+/* A communicator of `world` ranks.  librccl is looked up in the running process first (PyTorch
+ * brings its own copy) and in librccl.so.1 otherwise; it is not a link-time dependency.
+ *   upsp_comm_unique_id   rank 0 makes the id (ncclGetUniqueId) and hands the 128 bytes to the others
+ *                         (MPI_Bcast in a C++ host, any byte broadcast otherwise)
+ *   upsp_comm_create      ncclCommInitRank on the CURRENT device (select it first)
+ *   upsp_comm_from_nccl   wraps an ncclComm_t the host program already owns (not destroyed here)
+ *   upsp_comm_create_local  `world` ranks in THIS process on the current device, device-to-device copies in
+ *                         place of the links (tests: RCCL refuses two ranks on one GPU); the ranks are driven one
+ *                         after the other from one thread: every rank submits before any rank finishes, and the
+ *                         all-reduce completes with the call of the last rank */
+typedef struct upsp_comm upsp_comm;
+int upsp_comm_unique_id(uint8_t id[128]);
+int upsp_comm_create(const uint8_t id[128], int rank, int world, upsp_comm **out);
+int upsp_comm_from_nccl(void *nccl_comm, upsp_comm **out);
+int upsp_comm_create_local(int world, upsp_comm **out_ranks);
+void upsp_comm_destroy(upsp_comm *c);
+int upsp_comm_rank(const upsp_comm *c, int *rank, int *world);
+
+/* Sum of the double accumulators over the ranks, in place, on `stream` (MPI_Reduce + MPI_Bcast,
+ * cpp/exec/psp_process.cpp:1866-1872, 2019-2023): one grouped pair of all-reduces of n doubles. */
+int upsp_allreduce_sums(upsp_comm *c, double *d_sum, double *d_sumsq, size_t n, void *stream);
+
+/* Time-series exchange (global_transpose, cpp/exec/psp_process.cpp:707-771): every rank holds the series of ALL
+ * nodes over ITS frames and ends with the series of ITS nodes over ALL frames.  Frames and nodes are apportioned
+ * like cpp/exec/psp_process.cpp:611-624, 1519-1529 (upsp_exchange_layout).  The rank's frames are produced in
+ * `nchunks` chunks on 64-frame boundaries (upsp_exchange_chunk); chunk k is sent -- one grouped send / receive per
+ * peer on the exchange's own stream, every xGMI link carrying one block -- while chunk k + 1 is processed.
+ *   upsp_exchange_set_skipped  which rows travel: nodes no camera sees (d_skipped, identical on every rank; NULL:
+ *                         none) are NaN in every frame everywhere and are filled by the receiver.  One host read;
+ *                         assume_same != 0: the caller states the set did not change since the last call -- checked
+ *                         on the device, reported by upsp_exchange_verify.
+ *   upsp_exchange_rows    the row map for upsp_pipeline_set_row_map (packed row of every travelling node, ordered
+ *                         by destination) and the number of packed rows: the frame loop writes chunk buffers
+ *                         [packed_rows][chunk frames] (f32, or u16 with upsp_pipeline_process_u16) itself
+ *   upsp_exchange_submit  chunk k (k = 0, 1, ... in order) as produced on `stream`; wire = 4 (f32 buffer), 2 (u16
+ *                         buffer) or 12 (u16 buffer, packed to 12 bits for the wire: 12-bit cameras; a value above
+ *                         4095 is an error at verify).  The buffer must stay untouched until finish.
+ *   upsp_exchange_finish  waits for the transfers on `stream`, places every received block into d_series
+ *                         [nodes of this rank][ld >= F] (f32; u16 / 12-bit blocks are widened) and writes the NaN rows
+ *   upsp_exchange_bytes   bytes this rank sent to / received from OTHER ranks in the last finished pass */
+typedef struct upsp_exchange upsp_exchange;
+int upsp_exchange_create(upsp_comm *c, int64_t nframes_total, int64_t nnodes, int nchunks, upsp_exchange **out);
+void upsp_exchange_destroy(upsp_exchange *x);
+int upsp_exchange_layout(const upsp_exchange *x, int64_t *frame_start, int64_t *frame_count, int64_t *node_start,
+                         int64_t *node_count);
+int upsp_exchange_chunk(const upsp_exchange *x, int k, int64_t *first_frame, int64_t *nframes);
+int upsp_exchange_set_skipped(upsp_exchange *x, const uint8_t *d_skipped, int assume_same, void *stream);
+int upsp_exchange_rows(const upsp_exchange *x, const int32_t **d_rowmap, int64_t *packed_rows);
+int upsp_exchange_submit(upsp_exchange *x, const void *d_chunk, int wire, void *stream);
+int upsp_exchange_finish(upsp_exchange *x, float *d_series, int64_t ld, void *stream);
+int upsp_exchange_verify(upsp_exchange *x, void *stream);
+int upsp_exchange_bytes(const upsp_exchange *x, uint64_t *sent, uint64_t *received);
+
+/* ======================================================================== *
  *  4.  Measurement support (no reference counterpart; the reference only has
  *      psp::BlockTimer / timedBarrierPoint wall-clock prints, pspTimer.h:10-41)
  * ======================================================================== */

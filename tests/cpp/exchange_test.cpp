@@ -1,0 +1,213 @@
+// The C-ABI exchange (include/upsp_gpu.h section 3b) driven the way a C++ psp_process would drive it
+// (cpp/exec/psp_process.cpp:707-771, 1866-1872): communicator -> exchange -> set_skipped -> chunks -> finish,
+// plus the all-reduce of the accumulators.
+//   exchange_test local W         W ranks in this process on one GPU (device-to-device copies in place of the links)
+//   exchange_test rccl1           a one-rank RCCL communicator (RCCL refuses two ranks on one GPU)
+//   exchange_test rccl RANK WORLD IDFILE   one rank of a real multi-GPU job (rank 0 writes the id file)
+// Truth: series(n, f) = (31 n + 7 f) mod 4096 for the nodes that travel, NaN for every 5th node (no camera sees it).
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "upsp_gpu.h"
+
+#define CHECK(call)                                                                                  \
+    do {                                                                                             \
+        const int rc_ = (call);                                                                      \
+        if (rc_ != 0) {                                                                              \
+            std::fprintf(stderr, "%s:%d: %s -> %d (%s)\n", __FILE__, __LINE__, #call, rc_, upsp_last_error()); \
+            std::exit(1);                                                                            \
+        }                                                                                            \
+    } while (0)
+#define HIPCHECK(call)                                                                   \
+    do {                                                                                 \
+        const hipError_t e_ = (call);                                                    \
+        if (e_ != hipSuccess) {                                                          \
+            std::fprintf(stderr, "%s:%d: %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); \
+            std::exit(1);                                                                \
+        }                                                                                \
+    } while (0)
+
+static const int64_t N = 1003, F = 517;     // ragged on purpose: neither divides by 2, 3 or 64
+static const int K = 3;
+
+static bool skipped(int64_t n) { return n % 5 == 2; }
+static unsigned truth(int64_t n, int64_t f) { return (unsigned)((31 * n + 7 * f) % 4096); }
+
+struct RankState {
+    upsp_comm *comm = nullptr;
+    upsp_exchange *x = nullptr;
+    std::vector<void *> chunks;
+    double *d_sum = nullptr, *d_sumsq = nullptr;
+    float *d_series = nullptr;
+    int64_t f0 = 0, nf = 0, n0 = 0, nn = 0;
+};
+
+static void submit_all(RankState &r, const uint8_t *d_skipped, int wire)
+{
+    CHECK(upsp_exchange_set_skipped(r.x, d_skipped, 0, nullptr));
+    const int32_t *d_rowmap = nullptr;
+    int64_t packed = 0;
+    CHECK(upsp_exchange_rows(r.x, &d_rowmap, &packed));
+    std::vector<int32_t> rowmap(N);
+    HIPCHECK(hipMemcpy(rowmap.data(), d_rowmap, sizeof(int32_t) * N, hipMemcpyDeviceToHost));
+    for (int k = 0; k < K; ++k) {
+        int64_t c0 = 0, fc = 0;
+        CHECK(upsp_exchange_chunk(r.x, k, &c0, &fc));
+        const size_t esz = wire == 4 ? 4 : 2;
+        std::vector<uint8_t> h((size_t)packed * fc * esz + 1);
+        for (int64_t n = 0; n < N; ++n) {
+            if (rowmap[n] < 0) continue;
+            for (int64_t f = 0; f < fc; ++f) {
+                const unsigned v = truth(n, r.f0 + c0 + f);
+                if (wire == 4) reinterpret_cast<float *>(h.data())[(size_t)rowmap[n] * fc + f] = (float)v;
+                else reinterpret_cast<uint16_t *>(h.data())[(size_t)rowmap[n] * fc + f] = (uint16_t)v;
+            }
+        }
+        void *d = nullptr;
+        HIPCHECK(hipMalloc(&d, h.size()));
+        HIPCHECK(hipMemcpy(d, h.data(), h.size(), hipMemcpyHostToDevice));
+        r.chunks.push_back(d);
+        CHECK(upsp_exchange_submit(r.x, d, wire, nullptr));
+    }
+}
+
+static int check_rank(RankState &r, int world)
+{
+    std::vector<float> got((size_t)r.nn * F);
+    HIPCHECK(hipMemcpy(got.data(), r.d_series, sizeof(float) * got.size(), hipMemcpyDeviceToHost));
+    int bad = 0;
+    for (int64_t i = 0; i < r.nn; ++i)
+        for (int64_t f = 0; f < F; ++f) {
+            const float g = got[(size_t)i * F + f];
+            const int64_t n = r.n0 + i;
+            const bool ok = skipped(n) ? std::isnan(g) : g == (float)truth(n, f);
+            if (!ok && bad++ < 5) std::fprintf(stderr, "node %lld frame %lld: got %g\n", (long long)n, (long long)f, g);
+        }
+    std::vector<double> s(N), ss(N);
+    HIPCHECK(hipMemcpy(s.data(), r.d_sum, sizeof(double) * N, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(ss.data(), r.d_sumsq, sizeof(double) * N, hipMemcpyDeviceToHost));
+    for (int64_t n = 0; n < N; ++n) {
+        const double want = (double)world * (world - 1) / 2.0 + (double)world * n, want2 = 2.0 * world * n;
+        if (s[n] != want || ss[n] != want2) {
+            if (bad++ < 5) std::fprintf(stderr, "all-reduce node %lld: %g %g (want %g %g)\n", (long long)n, s[n], ss[n], want, want2);
+        }
+    }
+    return bad;
+}
+
+static void prepare(RankState &r, int rank)
+{
+    CHECK(upsp_exchange_create(r.comm, F, N, K, &r.x));
+    CHECK(upsp_exchange_layout(r.x, &r.f0, &r.nf, &r.n0, &r.nn));
+    std::vector<double> s(N), ss(N);
+    for (int64_t n = 0; n < N; ++n) {
+        s[n] = rank + (double)n;          // sum over ranks: W (W - 1) / 2 + W n
+        ss[n] = 2.0 * n;
+    }
+    HIPCHECK(hipMalloc(&r.d_sum, sizeof(double) * N));
+    HIPCHECK(hipMalloc(&r.d_sumsq, sizeof(double) * N));
+    HIPCHECK(hipMemcpy(r.d_sum, s.data(), sizeof(double) * N, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(r.d_sumsq, ss.data(), sizeof(double) * N, hipMemcpyHostToDevice));
+    HIPCHECK(hipMalloc(&r.d_series, sizeof(float) * (size_t)(r.nn > 0 ? r.nn : 1) * F));
+    HIPCHECK(hipMemset(r.d_series, 0x7b, sizeof(float) * (size_t)(r.nn > 0 ? r.nn : 1) * F));
+}
+
+int main(int argc, char **argv)
+{
+    const std::string mode = argc > 1 ? argv[1] : "local";
+    std::vector<uint8_t> sk(N);
+    for (int64_t n = 0; n < N; ++n) sk[n] = skipped(n) ? 1 : 0;
+    uint8_t *d_sk = nullptr;
+    if (mode == "rccl") {       // select the device before anything else
+        HIPCHECK(hipSetDevice(std::atoi(argv[2])));
+    }
+    HIPCHECK(hipMalloc(&d_sk, N));
+    HIPCHECK(hipMemcpy(d_sk, sk.data(), N, hipMemcpyHostToDevice));
+    int bad = 0;
+    if (mode == "local") {
+        const int W = argc > 2 ? std::atoi(argv[2]) : 2;
+        for (int wire : {4, 2, 12}) {
+            std::vector<upsp_comm *> comms(W);
+            CHECK(upsp_comm_create_local(W, comms.data()));
+            std::vector<RankState> ranks(W);
+            for (int r = 0; r < W; ++r) {
+                ranks[r].comm = comms[r];
+                prepare(ranks[r], r);
+            }
+            for (int r = 0; r < W; ++r) submit_all(ranks[r], d_sk, wire);                     // every rank submits ...
+            for (int r = 0; r < W; ++r) CHECK(upsp_allreduce_sums(comms[r], ranks[r].d_sum, ranks[r].d_sumsq, N, nullptr));
+            for (int r = 0; r < W; ++r) CHECK(upsp_exchange_finish(ranks[r].x, ranks[r].d_series, F, nullptr));   // ... then every rank finishes
+            HIPCHECK(hipDeviceSynchronize());
+            uint64_t sent = 0, recv = 0, tot_s = 0, tot_r = 0;
+            for (int r = 0; r < W; ++r) {
+                CHECK(upsp_exchange_verify(ranks[r].x, nullptr));
+                bad += check_rank(ranks[r], W);
+                CHECK(upsp_exchange_bytes(ranks[r].x, &sent, &recv));
+                tot_s += sent;
+                tot_r += recv;
+            }
+            if (tot_s != tot_r) {
+                std::fprintf(stderr, "bytes sent %llu != received %llu\n", (unsigned long long)tot_s, (unsigned long long)tot_r);
+                ++bad;
+            }
+            std::printf("local W=%d wire=%d: %s, %llu bytes between ranks\n", W, wire, bad ? "FAILED" : "ok", (unsigned long long)tot_s);
+            for (int r = 0; r < W; ++r) {
+                upsp_exchange_destroy(ranks[r].x);
+                upsp_comm_destroy(comms[r]);
+            }
+        }
+    } else {
+        int rank = 0, world = 1;
+        uint8_t id[128];
+        if (mode == "rccl") {
+            rank = std::atoi(argv[2]);
+            world = std::atoi(argv[3]);
+            const char *path = argv[4];
+            if (rank == 0) {
+                CHECK(upsp_comm_unique_id(id));
+                std::string tmp = std::string(path) + ".tmp";
+                FILE *f = std::fopen(tmp.c_str(), "wb");
+                std::fwrite(id, 1, 128, f);
+                std::fclose(f);
+                std::rename(tmp.c_str(), path);
+            } else {
+                FILE *f = nullptr;
+                for (int i = 0; i < 600 && !(f = std::fopen(path, "rb")); ++i) {
+                    struct timespec ts = {0, 100000000};
+                    nanosleep(&ts, nullptr);
+                }
+                if (!f || std::fread(id, 1, 128, f) != 128) { std::fprintf(stderr, "no id file\n"); return 1; }
+                std::fclose(f);
+            }
+        } else {
+            CHECK(upsp_comm_unique_id(id));
+        }
+        for (int wire : {4, 2, 12}) {
+            RankState r;
+            if (mode != "rccl" && wire != 4) CHECK(upsp_comm_unique_id(id));      // (an id makes one communicator)
+            CHECK(upsp_comm_create(id, rank, world, &r.comm));
+            prepare(r, rank);
+            submit_all(r, d_sk, wire);
+            CHECK(upsp_allreduce_sums(r.comm, r.d_sum, r.d_sumsq, N, nullptr));
+            CHECK(upsp_exchange_finish(r.x, r.d_series, F, nullptr));
+            HIPCHECK(hipDeviceSynchronize());
+            CHECK(upsp_exchange_verify(r.x, nullptr));
+            bad += check_rank(r, world);
+            uint64_t sent = 0, recv = 0;
+            CHECK(upsp_exchange_bytes(r.x, &sent, &recv));
+            std::printf("rccl rank %d of %d wire=%d: %s, %llu bytes to other ranks\n", rank, world, wire, bad ? "FAILED" : "ok",
+                        (unsigned long long)sent);
+            upsp_exchange_destroy(r.x);
+            upsp_comm_destroy(r.comm);
+            if (mode == "rccl") break;      // (one communicator per id)
+        }
+    }
+    return bad ? 1 : 0;
+}

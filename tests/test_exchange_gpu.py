@@ -1,0 +1,56 @@
+"""GPU: the rank-to-rank exchanges behind the C ABI (include/upsp_gpu.h section 3b), driven by a C++ program the way
+a C++ psp_process would (cpp/exec/psp_process.cpp:707-771, 1866-1872).
+
+* `local W`: W ranks in one process on one GPU -- device-to-device copies stand in for the links, everything else
+  (apportion, chunk boundaries, ragged blocks, packed rows, the f32 / u16 / 12-bit wire formats, NaN rows, byte
+  counts) is the code a multi-GPU run executes; W = 1, 2, 3, 5 with node and frame counts that divide by none of them;
+* `rccl1`: the same through RCCL itself in a one-rank communicator (grouped ncclSend / ncclRecv to self, ncclAllReduce);
+* two real RCCL ranks where two GPUs are visible (skipped on a one-GPU box: RCCL refuses two ranks on one device)."""
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def exe(tmp_path_factory, gpu_lib):
+    out = str(tmp_path_factory.mktemp("xchg") / "exchange_test")
+    libdir = os.path.join(ROOT, "upsp_processing_amd", "lib")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "exchange_test.cpp"), "-o", out,
+                           "-L" + libdir, "-lupsp_gpu", "-Wl,-rpath," + libdir])
+    return out
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 5])
+def test_exchange_local_ranks(exe, world):
+    r = subprocess.run([exe, "local", str(world)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 3 and all(" ok," in l for l in lines), r.stdout
+    sent = [int(l.split(", ")[1].split()[0]) for l in lines]
+    if world == 1:
+        assert sent == [0, 0, 0]
+    else:
+        assert sent[0] == 2 * sent[1] and sent[2] < sent[1]        # f32 : u16 : 12 bit
+
+
+def test_exchange_rccl_one_rank(exe):
+    r = subprocess.run([exe, "rccl1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count(" ok,") == 3, r.stdout
+
+
+def test_exchange_rccl_two_ranks(exe, tmp_path):
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL over xGMI)")
+    idf = str(tmp_path / "nccl_id")
+    ps = [subprocess.Popen([exe, "rccl", str(r), "2", idf], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+          for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in ps]
+    assert all(p.returncode == 0 for p in ps), outs
+    assert all(" ok," in o for o in outs), outs

@@ -120,6 +120,23 @@ SIGNATURES = {
     "upsp_bvh_set_tri_nodes": (_i, [_vp, _vp, _sz, _vp]),
     "upsp_interpolate_idw": (_i, [_vp, _vp, _sz, _vp, _sz, _i, C.c_float, _vp, _vp, _vp]),
     "upsp_nearest_nodes": (_i, [_vp, _sz, _vp, _sz, _vp, _vp, _vp]),
+    "upsp_comm_unique_id": (_i, [_vp]),
+    "upsp_comm_create": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
+    "upsp_comm_from_nccl": (_i, [_vp, C.POINTER(_vp)]),
+    "upsp_comm_create_local": (_i, [_i, C.POINTER(_vp)]),
+    "upsp_comm_destroy": (None, [_vp]),
+    "upsp_comm_rank": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    "upsp_allreduce_sums": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "upsp_exchange_create": (_i, [_vp, C.c_int64, C.c_int64, _i, C.POINTER(_vp)]),
+    "upsp_exchange_destroy": (None, [_vp]),
+    "upsp_exchange_layout": (_i, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "upsp_exchange_chunk": (_i, [_vp, _i, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "upsp_exchange_set_skipped": (_i, [_vp, _vp, _i, _vp]),
+    "upsp_exchange_rows": (_i, [_vp, C.POINTER(_vp), C.POINTER(C.c_int64)]),
+    "upsp_exchange_submit": (_i, [_vp, _vp, _i, _vp]),
+    "upsp_exchange_finish": (_i, [_vp, _vp, C.c_int64, _vp]),
+    "upsp_exchange_verify": (_i, [_vp, _vp]),
+    "upsp_exchange_bytes": (_i, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "upsp_timing_enable": (_i, [_i]),
     "upsp_timing_report": (_i, [C.c_char_p, _sz]),
 }

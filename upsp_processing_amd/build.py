@@ -19,7 +19,8 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libupsp_gpu.so")
 ARCH = "gfx950"
 
-HIP_SOURCES = ["raycast.hip", "frames.hip", "imageops.hip", "pipeline.hip", "ktimer.hip", "video.hip", "phase2.hip", "geom.hip", "feed.hip"]
+HIP_SOURCES = ["raycast.hip", "frames.hip", "imageops.hip", "pipeline.hip", "ktimer.hip", "video.hip", "phase2.hip", "geom.hip", "feed.hip",
+               "exchange.hip"]
 CXX_SOURCES = ["bvh_build.cpp"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
@@ -55,7 +56,7 @@ def build_lib(force=False):
                 cmd.insert(2, "hip")
             _run(cmd)
     if force or _stale(LIB, objs):
-        _run([HIPCC, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs)
+        _run([HIPCC, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs + ["-ldl"])   # (RCCL: dlopen, see exchange.hip)
     return LIB
 
 

@@ -1,0 +1,692 @@
+// End-of-run exchanges of psp_process phase 1 between the ranks of one job, behind the C ABI:
+//
+//   * sum of the per-rank double accumulators      MPI_Reduce + MPI_Bcast, cpp/exec/psp_process.cpp:1866-1872, 2019-2023
+//   * time-series exchange [frames_r x N] -> [nodes_r x F]   global_transpose, cpp/exec/psp_process.cpp:707-771
+//     with apportion() (:611-624) deciding who owns which frames and nodes
+//
+// One process per GPU.  The transport is RCCL (the ROCm NCCL) over xGMI: every GPU pair has its own link, so the
+// exchange of a chunk is ONE group of point-to-point sends / receives in which all links of a GPU carry exactly one
+// block at the same time -- no ring, no staging through a root.  The rank's frames are produced in K chunks and the
+// exchange of chunk k is in flight (on the exchange's own stream) while chunk k + 1 is processed.  Rows of nodes no
+// camera sees are NaN in every frame on every rank (psp_process.cpp:1821-1825): they do not travel; the receiver
+// fills them.  With one camera, no weights and no float image stage the travelling rows are exact 16-bit integers
+// and go as u16 -- or, for 12-bit cameras, packed to 12 bits (3 bytes per 2 frames).
+//
+// librccl is NOT a link-time dependency: its entry points are looked up in the running process first (PyTorch brings
+// its own copy, and two RCCLs in one process are one too many) and in librccl.so.1 otherwise.
+//
+// A second transport, "local", runs all ranks of a group inside ONE process on one GPU (device-to-device copies in
+// place of the links): the pool this was built on has one GPU per box and RCCL refuses two ranks on one device, so
+// this is how the bookkeeping of W > 1 ranks -- block offsets, ragged slices, chunk placement -- is executed on real
+// device buffers by the tests (tests/cpp/exchange_test.cpp).
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "ktimer.h"
+#include "upsp_gpu.h"
+#include "upsp_internal.h"
+
+using namespace upsp;
+
+namespace {
+
+// ---- RCCL entry points, resolved at first use ---------------------------------------------------------------
+struct Rccl {
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+    std::string why;
+};
+
+Rccl &rccl()
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void *h = nullptr;
+        auto sym = [&](const char *name) -> void * {
+            void *p = dlsym(RTLD_DEFAULT, name);          // already in the process (PyTorch's copy)?
+            if (!p) {
+                if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+                if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+                if (h) p = dlsym(h, name);
+            }
+            if (!p && r.why.empty()) r.why = std::string("RCCL symbol not found: ") + name;
+            return p;
+        };
+#define UPSP_SYM(field, name) r.field = reinterpret_cast<decltype(r.field)>(sym(name))
+        UPSP_SYM(GetUniqueId, "ncclGetUniqueId");
+        UPSP_SYM(CommInitRank, "ncclCommInitRank");
+        UPSP_SYM(CommDestroy, "ncclCommDestroy");
+        UPSP_SYM(CommCount, "ncclCommCount");
+        UPSP_SYM(CommUserRank, "ncclCommUserRank");
+        UPSP_SYM(GroupStart, "ncclGroupStart");
+        UPSP_SYM(GroupEnd, "ncclGroupEnd");
+        UPSP_SYM(Send, "ncclSend");
+        UPSP_SYM(Recv, "ncclRecv");
+        UPSP_SYM(AllReduce, "ncclAllReduce");
+        UPSP_SYM(GetErrorString, "ncclGetErrorString");
+#undef UPSP_SYM
+        r.ok = r.why.empty();
+    });
+    return r;
+}
+
+int nccl_fail(ncclResult_t e, const char *what)
+{
+    Rccl &r = rccl();
+    return fail(UPSP_ERR_HIP, std::string(what) + ": " + (r.GetErrorString ? r.GetErrorString(e) : "RCCL error"));
+}
+#define UPSP_NCCL_CHECK(call, what)                              \
+    do {                                                         \
+        const ncclResult_t e_ = (call);                          \
+        if (e_ != ncclSuccess) return nccl_fail(e_, what);       \
+    } while (0)
+
+// ---- the local transport: every rank of the group lives in this process ------------------------------------------
+struct LocalPost {
+    const void *ptr;
+    size_t bytes;
+    hipEvent_t ready;
+};
+struct LocalGroup {
+    int world = 0;
+    std::mutex mu;
+    std::map<std::tuple<int, int, int>, LocalPost> sends;          // (src, dst, tag) -> posted block
+    std::vector<std::pair<double *, double *>> reduce_posts;         // accumulators posted for the current all-reduce
+    size_t reduce_n = 0;
+};
+
+}  // namespace
+
+struct upsp_comm {
+    int kind = 0;                 // 0 RCCL, 1 local
+    int rank = 0, world = 1;
+    ncclComm_t nccl = nullptr;
+    bool own = false;             // the communicator was created here (upsp_comm_create) and is destroyed here
+    std::shared_ptr<LocalGroup> local;
+};
+
+namespace {
+
+// apportion (psp_process.cpp:611-624): contiguous near-equal ranges
+void apportion(int64_t value, int nbins, std::vector<int64_t> &start, std::vector<int64_t> &extent)
+{
+    const int64_t block = value / nbins, rem = value % nbins;
+    start.assign(nbins, 0);
+    extent.assign(nbins, 0);
+    int64_t next = 0;
+    for (int b = 0; b < nbins; ++b) {
+        start[b] = next;
+        extent[b] = block + (b < rem ? 1 : 0);
+        next += extent[b];
+    }
+}
+
+// nframes cut into nchunks contiguous pieces whose boundaries are multiples of `align` (as evenly as that allows;
+// trailing pieces may be empty) -- every rank cuts every rank's frame range the same way, so all block shapes are
+// known everywhere without communication
+void aligned_chunks(int64_t nframes, int nchunks, int64_t align, std::vector<int64_t> &start, std::vector<int64_t> &extent)
+{
+    std::vector<int64_t> b(nchunks + 1);
+    for (int k = 0; k < nchunks; ++k) {
+        // (round half to even like Python's round(): the Python host code and this must agree on every boundary)
+        const double q = (double)k * (double)nframes / (double)nchunks / (double)align;
+        b[k] = std::min<int64_t>(nframes, (int64_t)std::nearbyint(q) * align);
+    }
+    b[nchunks] = nframes;
+    for (int k = 1; k <= nchunks; ++k) b[k] = std::max(b[k], b[k - 1]);
+    start.assign(b.begin(), b.end() - 1);
+    extent.resize(nchunks);
+    for (int k = 0; k < nchunks; ++k) extent[k] = b[k + 1] - b[k];
+}
+
+// ---- 12-bit wire format -----------------------------------------------------------------------------------------------
+// rows [R][fc] u16 (pitch fc) -> [R][3 * ceil(fc / 2)] bytes: two values in three bytes (v0 >> 4, (v0 & 15) << 4 | v1 >> 8, v1 & 255);
+// a value above 4095 sets *err
+__global__ void __launch_bounds__(256)
+    pack12_rows_kernel(const uint16_t *__restrict__ src, long long nrows, int fc, uint8_t *__restrict__ dst, unsigned *err)
+{
+    const int pairs = (fc + 1) / 2;
+    const long long total = nrows * pairs;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / pairs;
+        const int p = (int)(i % pairs);
+        const unsigned v0 = src[r * fc + 2 * p], v1 = (2 * p + 1 < fc) ? src[r * fc + 2 * p + 1] : 0u;
+        if ((v0 | v1) > 4095u) atomicOr(err, 1u);
+        uint8_t *d = dst + (r * pairs + p) * 3;
+        d[0] = (uint8_t)(v0 >> 4);
+        d[1] = (uint8_t)(((v0 & 15u) << 4) | (v1 >> 8));
+        d[2] = (uint8_t)(v1 & 255u);
+    }
+}
+
+// 12-bit block [nrows][3 * ceil(fc / 2) bytes] from the wire -> rows rowidx[r] of dst (f32, pitch ld), columns [0, fc): a wave
+// per row, a lane widens four values (6 bytes) per trip and stores them as one 16-byte piece when the row allows it
+__global__ void __launch_bounds__(256)
+    place12_rows_kernel(const uint8_t *__restrict__ src, long long nrows, int fc, const long long *__restrict__ rowidx,
+                        float *__restrict__ dst, long long ld)
+{
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= nrows) return;
+    const int lane = threadIdx.x & 63;
+    const int pairs = (fc + 1) / 2;
+    const uint8_t *s = src + r * pairs * 3;
+    float *d = dst + rowidx[r] * ld;
+    const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<size_t>(dst) & 15) == 0);
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    for (int c = 4 * lane; c < fc; c += 256) {           // values c .. c + 3 = pairs c / 2, c / 2 + 1
+        const uint8_t *q = s + (c / 2) * 3;
+        const unsigned b0 = q[0], b1 = q[1], b2 = q[2];
+        const bool two = c + 2 < fc;
+        const unsigned b3 = two ? q[3] : 0u, b4 = two ? q[4] : 0u, b5 = two ? q[5] : 0u;
+        const v4f o = {(float)((b0 << 4) | (b1 >> 4)), (float)(((b1 & 15u) << 8) | b2),
+                       (float)((b3 << 4) | (b4 >> 4)), (float)(((b4 & 15u) << 8) | b5)};
+        if (vec && c + 3 < fc) {
+            __builtin_nontemporal_store(o, reinterpret_cast<v4f *>(d + c));
+        } else {
+            d[c] = o.x;
+            if (c + 1 < fc) d[c + 1] = o.y;
+            if (c + 2 < fc) d[c + 2] = o.z;
+            if (c + 3 < fc) d[c + 3] = o.w;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+    keep_differs_kernel(const uint8_t *__restrict__ skipped, const uint8_t *__restrict__ keep, size_t n, unsigned *flag)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && ((skipped[i] == 0) != (keep[i] != 0))) atomicOr(flag, 1u);
+}
+
+__global__ void sum_posts_kernel(double *const *bufs, int nb, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int b = 0; b < nb; ++b) s += bufs[b][i];       // rank order: the same sum on every rank
+    for (int b = 0; b < nb; ++b) bufs[b][i] = s;
+}
+
+}  // namespace
+
+struct upsp_exchange {
+    upsp_comm *c = nullptr;
+    int K = 1;
+    int64_t F = 0, N = 0;
+    std::vector<int64_t> frame_start, frame_count, node_start, node_count;
+    std::vector<std::vector<int64_t>> chunk_start, chunk_count;       // [rank][chunk]
+    // travelling rows (all nodes when no skip list was given)
+    bool have_rows = false;
+    int64_t nvis = 0;
+    std::vector<int64_t> cut;                  // cut[d] .. cut[d + 1]: packed rows that go to rank d
+    int32_t *d_rowmap = nullptr;
+    int64_t *d_vis_mine = nullptr, *d_nan_mine = nullptr;
+    int64_t n_vis_mine = 0, n_nan_mine = 0;
+    uint8_t *d_keep = nullptr;
+    unsigned *d_flags = nullptr;               // [0] travelling set changed under assume_same, [1] 12-bit overflow
+    // chunks in flight
+    int k = 0;
+    int wire = 0;                              // bytes per element of the chunks submitted so far: 4, 2; 12 = packed 12 bit
+    std::vector<std::vector<void *>> stage;    // [chunk][source rank] received block
+    std::vector<std::vector<size_t>> stage_bytes;
+    std::vector<void *> packed;                // [chunk] 12-bit send buffer
+    std::vector<size_t> packed_bytes;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+    uint64_t bytes_sent = 0, bytes_received = 0;   // of the pass in flight (to other ranks: what crosses a link)
+    uint64_t last_sent = 0, last_received = 0;     // of the last finished pass
+};
+
+namespace {
+
+size_t wire_row_bytes(int wire, int64_t fc)
+{
+    return wire == 12 ? (size_t)((fc + 1) / 2) * 3 : (size_t)fc * (size_t)wire;
+}
+
+void free_rows(upsp_exchange *x)
+{
+    for (void *p : {(void *)x->d_rowmap, (void *)x->d_vis_mine, (void *)x->d_nan_mine, (void *)x->d_keep})
+        if (p) (void)hipFree(p);
+    x->d_rowmap = nullptr;
+    x->d_vis_mine = x->d_nan_mine = nullptr;
+    x->d_keep = nullptr;
+    x->have_rows = false;
+}
+
+int ensure_buffer(void *&p, size_t &have, size_t want)
+{
+    if (want <= have) return UPSP_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    have = 0;
+    UPSP_HIP_CHECK(hipMalloc(&p, std::max<size_t>(want, 1)));
+    have = want;
+    return UPSP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int upsp_comm_unique_id(uint8_t id[128])
+{
+    if (!id) return fail(UPSP_ERR_INVALID, "null id");
+    Rccl &r = rccl();
+    if (!r.ok) return fail(UPSP_ERR_HIP, "RCCL is not available: " + r.why);
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    ncclUniqueId u;
+    UPSP_NCCL_CHECK(r.GetUniqueId(&u), "ncclGetUniqueId");
+    std::memcpy(id, &u, 128);
+    return UPSP_OK;
+}
+
+int upsp_comm_create(const uint8_t id[128], int rank, int world, upsp_comm **out)
+{
+    if (!out) return fail(UPSP_ERR_INVALID, "out is null");
+    *out = nullptr;
+    if (!id || world < 1 || rank < 0 || rank >= world) return fail(UPSP_ERR_INVALID, "bad rank / world");
+    Rccl &r = rccl();
+    if (!r.ok) return fail(UPSP_ERR_HIP, "RCCL is not available: " + r.why);
+    ncclUniqueId u;
+    std::memcpy(&u, id, 128);
+    ncclComm_t comm = nullptr;
+    UPSP_NCCL_CHECK(r.CommInitRank(&comm, world, u, rank), "ncclCommInitRank");
+    upsp_comm *c = new upsp_comm();
+    c->kind = 0;
+    c->rank = rank;
+    c->world = world;
+    c->nccl = comm;
+    c->own = true;
+    *out = c;
+    return UPSP_OK;
+}
+
+int upsp_comm_from_nccl(void *nccl_comm, upsp_comm **out)
+{
+    if (!out) return fail(UPSP_ERR_INVALID, "out is null");
+    *out = nullptr;
+    if (!nccl_comm) return fail(UPSP_ERR_INVALID, "null communicator");
+    Rccl &r = rccl();
+    if (!r.ok) return fail(UPSP_ERR_HIP, "RCCL is not available: " + r.why);
+    int rank = 0, world = 0;
+    UPSP_NCCL_CHECK(r.CommCount((ncclComm_t)nccl_comm, &world), "ncclCommCount");
+    UPSP_NCCL_CHECK(r.CommUserRank((ncclComm_t)nccl_comm, &rank), "ncclCommUserRank");
+    upsp_comm *c = new upsp_comm();
+    c->kind = 0;
+    c->rank = rank;
+    c->world = world;
+    c->nccl = (ncclComm_t)nccl_comm;
+    c->own = false;
+    *out = c;
+    return UPSP_OK;
+}
+
+int upsp_comm_create_local(int world, upsp_comm **out_ranks)
+{
+    if (!out_ranks || world < 1 || world > 64) return fail(UPSP_ERR_INVALID, "bad argument");
+    auto g = std::make_shared<LocalGroup>();
+    g->world = world;
+    for (int r = 0; r < world; ++r) {
+        upsp_comm *c = new upsp_comm();
+        c->kind = 1;
+        c->rank = r;
+        c->world = world;
+        c->local = g;
+        out_ranks[r] = c;
+    }
+    return UPSP_OK;
+}
+
+void upsp_comm_destroy(upsp_comm *c)
+{
+    if (!c) return;
+    if (c->kind == 0 && c->own && c->nccl && rccl().CommDestroy) (void)rccl().CommDestroy(c->nccl);
+    delete c;
+}
+
+int upsp_comm_rank(const upsp_comm *c, int *rank, int *world)
+{
+    if (!c) return fail(UPSP_ERR_INVALID, "null communicator");
+    if (rank) *rank = c->rank;
+    if (world) *world = c->world;
+    return UPSP_OK;
+}
+
+int upsp_allreduce_sums(upsp_comm *c, double *d_sum, double *d_sumsq, size_t n, void *stream)
+{
+    if (!c || !d_sum || !d_sumsq) return fail(UPSP_ERR_INVALID, "bad argument");
+    if (n == 0) return UPSP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (c->kind == 0) {
+        Rccl &r = rccl();
+        KTimed kt("allreduce_sums", st);
+        UPSP_NCCL_CHECK(r.GroupStart(), "ncclGroupStart");
+        UPSP_NCCL_CHECK(r.AllReduce(d_sum, d_sum, n, ncclDouble, ncclSum, c->nccl, st), "ncclAllReduce");
+        UPSP_NCCL_CHECK(r.AllReduce(d_sumsq, d_sumsq, n, ncclDouble, ncclSum, c->nccl, st), "ncclAllReduce");
+        UPSP_NCCL_CHECK(r.GroupEnd(), "ncclGroupEnd");
+        return UPSP_OK;
+    }
+    // local transport: the call of the LAST rank of the group does the sums for everybody (the ranks are driven one
+    // after the other from one thread; every buffer must be complete on its stream by then: synchronised here)
+    LocalGroup &g = *c->local;
+    std::lock_guard<std::mutex> lk(g.mu);
+    UPSP_HIP_CHECK(hipStreamSynchronize(st));
+    if (g.reduce_posts.empty()) g.reduce_n = n;
+    if (g.reduce_n != n) return fail(UPSP_ERR_INVALID, "local all-reduce: sizes differ between the ranks");
+    g.reduce_posts.emplace_back(d_sum, d_sumsq);
+    if ((int)g.reduce_posts.size() < g.world) return UPSP_OK;
+    for (int which = 0; which < 2; ++which) {
+        std::vector<double *> h(g.world);
+        for (int b = 0; b < g.world; ++b) h[b] = which ? g.reduce_posts[b].second : g.reduce_posts[b].first;
+        double **d = nullptr;
+        UPSP_HIP_CHECK(hipMalloc(&d, sizeof(double *) * g.world));
+        UPSP_HIP_CHECK(hipMemcpy(d, h.data(), sizeof(double *) * g.world, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(sum_posts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (double *const *)d, g.world, n);
+        UPSP_HIP_CHECK(hipStreamSynchronize(st));
+        (void)hipFree(d);
+    }
+    g.reduce_posts.clear();
+    return UPSP_OK;
+}
+
+int upsp_exchange_create(upsp_comm *c, int64_t nframes_total, int64_t nnodes, int nchunks, upsp_exchange **out)
+{
+    if (!out) return fail(UPSP_ERR_INVALID, "out is null");
+    *out = nullptr;
+    if (!c || nframes_total < 0 || nnodes <= 0 || nchunks < 1 || nchunks > 1024) return fail(UPSP_ERR_INVALID, "bad argument");
+    upsp_exchange *x = new upsp_exchange();
+    x->c = c;
+    x->K = nchunks;
+    x->F = nframes_total;
+    x->N = nnodes;
+    apportion(nframes_total, c->world, x->frame_start, x->frame_count);
+    apportion(nnodes, c->world, x->node_start, x->node_count);
+    x->chunk_start.resize(c->world);
+    x->chunk_count.resize(c->world);
+    for (int s = 0; s < c->world; ++s) aligned_chunks(x->frame_count[s], nchunks, 64, x->chunk_start[s], x->chunk_count[s]);
+    x->stage.assign(nchunks, std::vector<void *>(c->world, nullptr));
+    x->stage_bytes.assign(nchunks, std::vector<size_t>(c->world, 0));
+    x->packed.assign(nchunks, nullptr);
+    x->packed_bytes.assign(nchunks, 0);
+    hipError_t e = hipStreamCreateWithFlags(&x->comm_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&x->ev_ready, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&x->ev_done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMalloc(&x->d_flags, 2 * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemset(x->d_flags, 0, 2 * sizeof(unsigned));
+    if (e != hipSuccess) {
+        upsp_exchange_destroy(x);
+        return fail(UPSP_ERR_HIP, std::string("exchange: ") + hipGetErrorString(e));
+    }
+    *out = x;
+    return UPSP_OK;
+}
+
+void upsp_exchange_destroy(upsp_exchange *x)
+{
+    if (!x) return;
+    if (x->comm_stream) (void)hipStreamSynchronize(x->comm_stream);
+    free_rows(x);
+    for (auto &v : x->stage)
+        for (void *p : v)
+            if (p) (void)hipFree(p);
+    for (void *p : x->packed)
+        if (p) (void)hipFree(p);
+    if (x->d_flags) (void)hipFree(x->d_flags);
+    if (x->ev_ready) (void)hipEventDestroy(x->ev_ready);
+    if (x->ev_done) (void)hipEventDestroy(x->ev_done);
+    if (x->comm_stream) (void)hipStreamDestroy(x->comm_stream);
+    delete x;
+}
+
+int upsp_exchange_layout(const upsp_exchange *x, int64_t *frame_start, int64_t *frame_count, int64_t *node_start,
+                         int64_t *node_count)
+{
+    if (!x) return fail(UPSP_ERR_INVALID, "null exchange");
+    const int r = x->c->rank;
+    if (frame_start) *frame_start = x->frame_start[r];
+    if (frame_count) *frame_count = x->frame_count[r];
+    if (node_start) *node_start = x->node_start[r];
+    if (node_count) *node_count = x->node_count[r];
+    return UPSP_OK;
+}
+
+int upsp_exchange_chunk(const upsp_exchange *x, int k, int64_t *first_frame, int64_t *nframes)
+{
+    if (!x || k < 0 || k >= x->K) return fail(UPSP_ERR_INVALID, "bad chunk");
+    const int r = x->c->rank;
+    if (first_frame) *first_frame = x->chunk_start[r][k];
+    if (nframes) *nframes = x->chunk_count[r][k];
+    return UPSP_OK;
+}
+
+int upsp_exchange_set_skipped(upsp_exchange *x, const uint8_t *d_skipped, int assume_same, void *stream)
+{
+    if (!x) return fail(UPSP_ERR_INVALID, "null exchange");
+    hipStream_t st = (hipStream_t)stream;
+    const int W = x->c->world, me = x->c->rank;
+    const size_t N = (size_t)x->N;
+    if (assume_same && x->have_rows && d_skipped && x->d_keep) {
+        // the caller states that the set is the one of the previous call (the projection did not change): nothing is
+        // read back, the claim is checked on the device and upsp_exchange_finish reports a broken one
+        hipLaunchKernelGGL(keep_differs_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, d_skipped,
+                           (const uint8_t *)x->d_keep, N, x->d_flags);
+        UPSP_HIP_CHECK(hipGetLastError());
+        return UPSP_OK;
+    }
+    // the travelling set: one device -> host read of the flags (once per projection), lists built on the host
+    std::vector<uint8_t> sk(N, 0);
+    if (d_skipped) {
+        UPSP_HIP_CHECK(hipMemcpyAsync(sk.data(), d_skipped, N, hipMemcpyDeviceToHost, st));
+        UPSP_HIP_CHECK(hipStreamSynchronize(st));
+    }
+    std::vector<int32_t> rowmap(N, -1);
+    std::vector<uint8_t> keep(N);
+    std::vector<int64_t> vis_mine, nan_mine;
+    x->cut.assign(W + 1, 0);
+    int64_t row = 0;
+    for (int d = 0; d < W; ++d) {
+        x->cut[d] = row;
+        for (int64_t n = x->node_start[d]; n < x->node_start[d] + x->node_count[d]; ++n) {
+            keep[n] = sk[n] == 0;
+            if (keep[n]) {
+                rowmap[n] = (int32_t)row++;
+                if (d == me) vis_mine.push_back(n - x->node_start[me]);
+            } else if (d == me) {
+                nan_mine.push_back(n - x->node_start[me]);
+            }
+        }
+    }
+    x->cut[W] = row;
+    x->nvis = row;
+    UPSP_HIP_CHECK(hipStreamSynchronize(st));        // launches queued earlier may still read the old lists
+    free_rows(x);
+    x->n_vis_mine = (int64_t)vis_mine.size();
+    x->n_nan_mine = (int64_t)nan_mine.size();
+    UPSP_HIP_CHECK(hipMalloc(&x->d_rowmap, sizeof(int32_t) * N));
+    UPSP_HIP_CHECK(hipMalloc(&x->d_keep, N));
+    UPSP_HIP_CHECK(hipMalloc(&x->d_vis_mine, sizeof(int64_t) * std::max<size_t>(vis_mine.size(), 1)));
+    UPSP_HIP_CHECK(hipMalloc(&x->d_nan_mine, sizeof(int64_t) * std::max<size_t>(nan_mine.size(), 1)));
+    UPSP_HIP_CHECK(hipMemcpy(x->d_rowmap, rowmap.data(), sizeof(int32_t) * N, hipMemcpyHostToDevice));
+    UPSP_HIP_CHECK(hipMemcpy(x->d_keep, keep.data(), N, hipMemcpyHostToDevice));
+    if (!vis_mine.empty())
+        UPSP_HIP_CHECK(hipMemcpy(x->d_vis_mine, vis_mine.data(), sizeof(int64_t) * vis_mine.size(), hipMemcpyHostToDevice));
+    if (!nan_mine.empty())
+        UPSP_HIP_CHECK(hipMemcpy(x->d_nan_mine, nan_mine.data(), sizeof(int64_t) * nan_mine.size(), hipMemcpyHostToDevice));
+    x->have_rows = true;
+    return UPSP_OK;
+}
+
+int upsp_exchange_rows(const upsp_exchange *x, const int32_t **d_rowmap, int64_t *packed_rows)
+{
+    if (!x || !x->have_rows) return fail(UPSP_ERR_INVALID, "exchange: upsp_exchange_set_skipped first");
+    if (d_rowmap) *d_rowmap = x->d_rowmap;
+    if (packed_rows) *packed_rows = x->nvis;
+    return UPSP_OK;
+}
+
+int upsp_exchange_submit(upsp_exchange *x, const void *d_chunk, int wire, void *stream)
+{
+    if (!x || !x->have_rows) return fail(UPSP_ERR_INVALID, "exchange: upsp_exchange_set_skipped first");
+    if (wire != 4 && wire != 2 && wire != 12) return fail(UPSP_ERR_INVALID, "exchange: wire format is 4 (f32), 2 (u16) or 12 (u16 packed to 12 bit)");
+    if (x->k >= x->K) return fail(UPSP_ERR_INVALID, "exchange: every chunk was already submitted (finish first)");
+    if (x->k > 0 && wire != x->wire) return fail(UPSP_ERR_INVALID, "exchange: the chunks of one pass share a wire format");
+    const int W = x->c->world, me = x->c->rank, k = x->k;
+    const int64_t fc = x->chunk_count[me][k];
+    if (fc > 0 && x->nvis > 0 && !d_chunk) return fail(UPSP_ERR_INVALID, "exchange: null chunk");
+    hipStream_t st = (hipStream_t)stream;
+    x->wire = wire;
+    if (k == 0) x->bytes_sent = x->bytes_received = 0;
+    const size_t rb = wire_row_bytes(wire, fc);
+    const uint8_t *send = static_cast<const uint8_t *>(d_chunk);
+    if (wire == 12 && fc > 0 && x->nvis > 0) {
+        int rc = ensure_buffer(x->packed[k], x->packed_bytes[k], rb * (size_t)x->nvis);
+        if (rc != UPSP_OK) return rc;
+        KTimed kt("pack12_rows_kernel", st);
+        hipLaunchKernelGGL(pack12_rows_kernel, dim3(2048), dim3(256), 0, st, static_cast<const uint16_t *>(d_chunk),
+                           (long long)x->nvis, (int)fc, static_cast<uint8_t *>(x->packed[k]), x->d_flags + 1);
+        send = static_cast<const uint8_t *>(x->packed[k]);
+    }
+    // staging for what arrives: from rank s, my rows x its chunk k
+    const int64_t rows_in = x->cut[me + 1] - x->cut[me];
+    for (int s = 0; s < W; ++s) {
+        const size_t want = wire_row_bytes(wire, x->chunk_count[s][k]) * (size_t)rows_in;
+        int rc = ensure_buffer(x->stage[k][s], x->stage_bytes[k][s], want);
+        if (rc != UPSP_OK) return rc;
+    }
+    x->k += 1;
+    UPSP_HIP_CHECK(hipEventRecord(x->ev_ready, st));
+    if (x->c->kind == 0) {
+        Rccl &r = rccl();
+        UPSP_HIP_CHECK(hipStreamWaitEvent(x->comm_stream, x->ev_ready, 0));
+        UPSP_NCCL_CHECK(r.GroupStart(), "ncclGroupStart");
+        for (int p = 0; p < W; ++p) {
+            const size_t out_b = rb * (size_t)(x->cut[p + 1] - x->cut[p]);
+            const size_t in_b = wire_row_bytes(wire, x->chunk_count[p][k]) * (size_t)rows_in;
+            if (out_b) {
+                UPSP_NCCL_CHECK(r.Send(send + rb * (size_t)x->cut[p], out_b, ncclUint8, p, x->c->nccl, x->comm_stream), "ncclSend");
+                if (p != me) x->bytes_sent += out_b;
+            }
+            if (in_b) {
+                UPSP_NCCL_CHECK(r.Recv(x->stage[k][p], in_b, ncclUint8, p, x->c->nccl, x->comm_stream), "ncclRecv");
+                if (p != me) x->bytes_received += in_b;
+            }
+        }
+        UPSP_NCCL_CHECK(r.GroupEnd(), "ncclGroupEnd");
+        return UPSP_OK;
+    }
+    // local transport: post my blocks; the receivers copy them when they finish
+    LocalGroup &g = *x->c->local;
+    std::lock_guard<std::mutex> lk(g.mu);
+    for (int p = 0; p < W; ++p) {
+        const size_t out_b = rb * (size_t)(x->cut[p + 1] - x->cut[p]);
+        hipEvent_t ev = nullptr;
+        UPSP_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        UPSP_HIP_CHECK(hipEventRecord(ev, st));
+        g.sends[std::make_tuple(me, p, k)] = LocalPost{send + rb * (size_t)x->cut[p], out_b, ev};
+        if (p != me) x->bytes_sent += out_b;
+    }
+    return UPSP_OK;
+}
+
+int upsp_exchange_finish(upsp_exchange *x, float *d_series, int64_t ld, void *stream)
+{
+    if (!x || !x->have_rows || !d_series) return fail(UPSP_ERR_INVALID, "bad argument");
+    if (x->k != x->K) return fail(UPSP_ERR_INVALID, "exchange: finish before every chunk was submitted");
+    if (ld < x->F) return fail(UPSP_ERR_INVALID, "exchange: ld smaller than the frame count");
+    hipStream_t st = (hipStream_t)stream;
+    const int W = x->c->world, me = x->c->rank;
+    const int64_t rows_in = x->cut[me + 1] - x->cut[me];
+    if (x->c->kind == 0) {
+        UPSP_HIP_CHECK(hipEventRecord(x->ev_done, x->comm_stream));
+        UPSP_HIP_CHECK(hipStreamWaitEvent(st, x->ev_done, 0));
+    } else {
+        LocalGroup &g = *x->c->local;
+        std::lock_guard<std::mutex> lk(g.mu);
+        for (int k = 0; k < x->K; ++k)
+            for (int s = 0; s < W; ++s) {
+                const size_t in_b = wire_row_bytes(x->wire, x->chunk_count[s][k]) * (size_t)rows_in;
+                auto it = g.sends.find(std::make_tuple(s, me, k));
+                if (it == g.sends.end()) return fail(UPSP_ERR_INVALID, "local exchange: a rank has not submitted yet");
+                if (it->second.bytes != in_b) return fail(UPSP_ERR_INVALID, "local exchange: block sizes disagree between the ranks");
+                UPSP_HIP_CHECK(hipStreamWaitEvent(st, it->second.ready, 0));
+                if (in_b) UPSP_HIP_CHECK(hipMemcpyAsync(x->stage[k][s], it->second.ptr, in_b, hipMemcpyDeviceToDevice, st));
+                if (s != me) x->bytes_received += in_b;
+                (void)hipEventDestroy(it->second.ready);
+                g.sends.erase(it);
+            }
+    }
+    {
+        KTimed kt("exchange_place_kernels", st);
+        for (int k = 0; k < x->K; ++k)
+            for (int s = 0; s < W; ++s) {
+                const int64_t fs = x->chunk_count[s][k];
+                if (!fs || !rows_in) continue;
+                float *dst = d_series + x->frame_start[s] + x->chunk_start[s][k];
+                int rc = UPSP_OK;
+                if (x->wire == 4)
+                    rc = upsp_scatter_rows_f32(static_cast<const float *>(x->stage[k][s]), (size_t)rows_in, (int)fs, x->d_vis_mine, dst, ld, stream);
+                else if (x->wire == 2)
+                    rc = upsp_scatter_rows_u16(static_cast<const uint16_t *>(x->stage[k][s]), (size_t)rows_in, (int)fs, x->d_vis_mine, dst, ld, stream);
+                else
+                    hipLaunchKernelGGL(place12_rows_kernel, dim3((unsigned)((rows_in + 3) / 4)), dim3(256), 0, st,
+                                       static_cast<const uint8_t *>(x->stage[k][s]), (long long)rows_in, (int)fs,
+                                       (const long long *)x->d_vis_mine, dst, (long long)ld);
+                if (rc != UPSP_OK) return rc;
+            }
+        UPSP_HIP_CHECK(hipGetLastError());
+    }
+    // the rows that do not travel: NaN in every frame (psp_process.cpp:1821-1825), written by every exchange
+    if (x->n_nan_mine) {
+        int rc = upsp_fill_rows_f32(__builtin_nanf(""), (size_t)x->n_nan_mine, (int)x->F, x->d_nan_mine, d_series, ld, stream);
+        if (rc != UPSP_OK) return rc;
+    }
+    x->k = 0;
+    x->last_sent = x->bytes_sent;
+    x->last_received = x->bytes_received;
+    return UPSP_OK;
+}
+
+int upsp_exchange_verify(upsp_exchange *x, void *stream)
+{
+    if (!x) return fail(UPSP_ERR_INVALID, "null exchange");
+    unsigned h[2] = {0, 0};
+    UPSP_HIP_CHECK(hipMemcpyAsync(h, x->d_flags, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    UPSP_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    if (h[0] || h[1]) UPSP_HIP_CHECK(hipMemset(x->d_flags, 0, sizeof(h)));
+    if (h[0]) return fail(UPSP_ERR_INVALID, "exchange: the skipped-node set changed although assume_same was given");
+    if (h[1]) return fail(UPSP_ERR_INVALID, "exchange: a series value above 4095 was sent in the 12-bit wire format");
+    return UPSP_OK;
+}
+
+int upsp_exchange_bytes(const upsp_exchange *x, uint64_t *sent, uint64_t *received)
+{
+    if (!x) return fail(UPSP_ERR_INVALID, "null exchange");
+    if (sent) *sent = x->last_sent;
+    if (received) *received = x->last_received;
+    return UPSP_OK;
+}
+
+}  // extern "C"

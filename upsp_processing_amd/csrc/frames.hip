@@ -1210,7 +1210,11 @@ __global__ void __launch_bounds__(256)
 // buffer per camera; row layout and lane mapping of node_rows_kernel.  The accumulators add the frames of
 // a lane first and the lanes after: a different order from the gather's, same values to ~1e-16 relative
 // (the parity bar for the accumulators is 1e-12).
-template <int LPR, int ROWS>
+// Round 3: (1) the compact series of EVERY camera and EVERY sweep of the workgroup are requested before any of them
+// is used (round 2 walked sweep by sweep, camera by camera: ROWS x cameras dependent load -> convert -> add chains per
+// lane); (2) a row no camera sees (NaN in every frame) or that reads no pixel (0) is a constant fill -- no loads, no
+// sums, no reductions, like in node_rows_kernel; (3) NC = the camera count at compile time (2 .. 4; 0 = any).
+template <int LPR, int ROWS, int NC>
 __global__ void __launch_bounds__(256)
     node_rows_multi_kernel(StreamMultiArgs a, unsigned cpitch, const uint8_t *__restrict__ skipped,
                            const int32_t *__restrict__ rowmap, unsigned nnodes, int nframes,
@@ -1218,14 +1222,16 @@ __global__ void __launch_bounds__(256)
                            double *__restrict__ sumsq)
 {
     constexpr int RPS = 256 / LPR, WPR = LPR / 64, NR = RPS * ROWS;
-    __shared__ int s_k[NR][kMaxCams];
-    __shared__ float s_w[NR][kMaxCams];
-    __shared__ int s_row[NR], s_sk[NR];
+    constexpr int MC = NC ? NC : kMaxCams;
+    __shared__ int s_k[NR][MC];
+    __shared__ float s_w[NR][MC];
+    __shared__ int s_row[NR], s_kind[NR];       // kind: 0 data, 1 no camera sees the node (NaN), 2 reads no pixel (0)
     __shared__ double p_s[NR][WPR], p_ss[NR][WPR];
+    const int ncams = NC ? NC : a.ncams;
     const unsigned n0 = blockIdx.x * (unsigned)NR;
     const int t = threadIdx.x;
-    for (int e = t; e < NR * a.ncams; e += 256) {
-        const int r = e / a.ncams, c = e % a.ncams;
+    for (int e = t; e < NR * ncams; e += 256) {
+        const int r = e / ncams, c = e % ncams;
         const unsigned n = n0 + (unsigned)r;
         const bool ok = n < nnodes;
         s_k[r][c] = ok ? a.node_k[c][n] : -1;
@@ -1234,7 +1240,9 @@ __global__ void __launch_bounds__(256)
     if (t < NR) {
         const unsigned n = n0 + (unsigned)t;
         const bool ok = n < nnodes;
-        s_sk[t] = (ok && skipped) ? (int)skipped[n] : 0;
+        bool any = false;
+        for (int c = 0; c < ncams; ++c) any = any || (ok && a.node_k[c][n] >= 0);
+        s_kind[t] = (ok && skipped && skipped[n]) ? 1 : (any ? 0 : 2);
         s_row[t] = ok ? (rowmap ? rowmap[n] : (int)n) : -1;
     }
     __syncthreads();
@@ -1242,33 +1250,64 @@ __global__ void __launch_bounds__(256)
     const int f0 = 4 * l;
     const float qnan = __builtin_nanf("");
     const bool vec_ok = ((ld_t & 3) == 0) && ((reinterpret_cast<size_t>(rows_t) & 15) == 0);
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    // every load of the workgroup's rows first ...
+    uint2 tt[ROWS][MC];
 #pragma unroll
     for (int j = 0; j < ROWS; ++j) {
         const int r = j * RPS + sub;                            // (uniform per wave)
-        const int row = s_row[r];
-        const bool sk = s_sk[r] != 0;
-        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        for (int c = 0; c < a.ncams; ++c) {
-            const int k = s_k[r][c];
-            const float w = s_w[r][c];
-            float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (k >= 0 && f0 < nframes) {
-                const uint2 tt = *reinterpret_cast<const uint2 *>(a.compact[c] + (size_t)k * cpitch + f0);
-                v[0] = 0.0f + w * (float)(tt.x & 0xFFFFu);
-                v[1] = 0.0f + w * (float)(tt.x >> 16);
-                v[2] = 0.0f + w * (float)(tt.y & 0xFFFFu);
-                v[3] = 0.0f + w * (float)(tt.y >> 16);
-            }
+        const bool data = s_kind[r] == 0 && f0 < nframes;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] = (c == 0) ? v[q] : acc[q] + v[q];
+        for (int c = 0; c < MC; ++c) {
+            tt[j][c] = make_uint2(0u, 0u);
+            if (c < ncams) {
+                const int k = s_k[r][c];
+                if (data && k >= 0) tt[j][c] = *reinterpret_cast<const uint2 *>(a.compact[c] + (size_t)k * cpitch + f0);
+            }
+        }
+    }
+    // ... then the rows
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) {
+        const int r = j * RPS + sub;
+        const int row = s_row[r], kind = s_kind[r];
+        const bool stored = row >= 0 && f0 < nframes && n0 + (unsigned)r < nnodes;
+        if (kind != 0) {                                        // (uniform per wave) constant fill
+            if (stored) {
+                float *dst = rows_t + (long long)row * ld_t + f0;
+                const float cv = kind == 1 ? qnan : 0.0f;
+                const v4f nv = {cv, cv, cv, cv};
+                if (vec_ok && f0 + 3 < nframes) {
+                    __builtin_nontemporal_store(nv, reinterpret_cast<v4f *>(dst));
+                } else {
+                    dst[0] = cv;
+                    if (f0 + 1 < nframes) dst[1] = cv;
+                    if (f0 + 2 < nframes) dst[2] = cv;
+                    if (f0 + 3 < nframes) dst[3] = cv;
+                }
+            }
+            continue;
+        }
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int c = 0; c < MC; ++c) {
+            // (uniform per wave) a camera that does not see the node contributes 0.0f + w * 0 = +0 in the gather; every
+            // term here is >= +0, so leaving it out changes no bit -- and a node is seen by 1.x cameras on average
+            if (c < ncams && s_k[r][c] >= 0) {
+                const float w = s_w[r][c];
+                const uint2 q = tt[j][c];
+                const float v[4] = {0.0f + w * (float)(q.x & 0xFFFFu), 0.0f + w * (float)(q.x >> 16),
+                                    0.0f + w * (float)(q.y & 0xFFFFu), 0.0f + w * (float)(q.y >> 16)};
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) acc[qq] = acc[qq] + v[qq];
+            }
         }
         double s = 0.0, ss = 0.0;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             if (f0 + q < nframes) {
-                const float sol = sk ? qnan : acc[q];
-                s += (double)sol;
-                ss += (double)(sol * sol);
+                s += (double)acc[q];
+                ss += (double)(acc[q] * acc[q]);
             }
         s = group16_sum(s);
         ss = group16_sum(ss);
@@ -1278,10 +1317,9 @@ __global__ void __launch_bounds__(256)
             p_s[r][wr] = ws;
             p_ss[r][wr] = wss;
         }
-        if (row < 0 || f0 >= nframes || n0 + (unsigned)r >= nnodes) continue;
+        if (!stored) continue;
         float *dst = rows_t + (long long)row * ld_t + f0;
-        typedef float v4f __attribute__((ext_vector_type(4)));
-        const v4f nv = {sk ? qnan : acc[0], sk ? qnan : acc[1], sk ? qnan : acc[2], sk ? qnan : acc[3]};
+        const v4f nv = {acc[0], acc[1], acc[2], acc[3]};
         if (vec_ok && f0 + 3 < nframes) {
             __builtin_nontemporal_store(nv, reinterpret_cast<v4f *>(dst));
         } else {
@@ -1295,14 +1333,20 @@ __global__ void __launch_bounds__(256)
     if (t < NR) {
         const unsigned n = n0 + (unsigned)t;
         if (n < nnodes) {
-            double as = 0.0, ass = 0.0;
+            const int kind = s_kind[t];
+            if (kind == 1) {
+                sum[n] = (double)qnan;
+                sumsq[n] = (double)qnan;
+            } else if (kind == 0) {
+                double as = 0.0, ass = 0.0;
 #pragma unroll
-            for (int q = 0; q < WPR; ++q) {
-                as += p_s[t][q];
-                ass += p_ss[t][q];
+                for (int q = 0; q < WPR; ++q) {
+                    as += p_s[t][q];
+                    ass += p_ss[t][q];
+                }
+                sum[n] += as;
+                sumsq[n] += ass;
             }
-            sum[n] += as;
-            sumsq[n] += ass;
         }
     }
 }
@@ -1805,11 +1849,24 @@ int launch_node_rows_multi(const PipelineGather &g, const int32_t *const *d_node
     }
     const unsigned nn = (unsigned)g.nnodes;
     KTimed kt("node_rows_multi_kernel", st);
-#define UPSP_NRM(LPR, ROWS)                                                                                   \
-    hipLaunchKernelGGL((node_rows_multi_kernel<LPR, ROWS>), dim3((nn + (256 / LPR) * ROWS - 1) / ((256 / LPR) * ROWS)), \
+#define UPSP_NRM(LPR, ROWS, NC)                                                                               \
+    hipLaunchKernelGGL((node_rows_multi_kernel<LPR, ROWS, NC>), dim3((nn + (256 / LPR) * ROWS - 1) / ((256 / LPR) * ROWS)), \
                        dim3(256), 0, st, a, cpitch, g.skipped, g.rowmap, nn, g.nframes, g.rows_t, (long long)g.ld_t, \
                        g.sum, g.sumsq)
-    if (g.nframes > 512) UPSP_NRM(256, 4); else if (g.nframes > 256) UPSP_NRM(128, 4); else UPSP_NRM(64, 4);
+#define UPSP_NRM_NC(LPR, ROWS)                                                                                \
+    do {                                                                                                      \
+        if (g.ncams == 2) UPSP_NRM(LPR, ROWS, 2);                                                             \
+        else if (g.ncams == 3) UPSP_NRM(LPR, ROWS, 3);                                                        \
+        else if (g.ncams == 4) UPSP_NRM(LPR, ROWS, 4);                                                        \
+        else UPSP_NRM(LPR, 2, 0);                                                                             \
+    } while (0)
+    // sweeps per workgroup (UPSP_MULTI_ROWS, measurement switch; 4 cameras, 2.5 M nodes, 1000 frame sets: 2 sweeps 4.28 ms,
+    // 4: 3.35, 8: 3.16 -- consecutive nodes share pixels, and the per-workgroup staging is paid once per 8 rows)
+    static const int rows_env = std::getenv("UPSP_MULTI_ROWS") ? std::atoi(std::getenv("UPSP_MULTI_ROWS")) : 8;
+    if (g.nframes > 512) { if (rows_env == 8) UPSP_NRM_NC(256, 8); else if (rows_env == 2) UPSP_NRM_NC(256, 2); else UPSP_NRM_NC(256, 4); }
+    else if (g.nframes > 256) UPSP_NRM_NC(128, 4);
+    else UPSP_NRM_NC(64, 4);
+#undef UPSP_NRM_NC
 #undef UPSP_NRM
     UPSP_HIP_CHECK(hipGetLastError());
     return UPSP_OK;

@@ -1,9 +1,13 @@
 """Frame sharding across GPUs and the end-of-run exchanges of psp_process phase 1.
 
-One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm,
-"gloo" on CPU for tests).  Frames shard trivially -- the reference does the same
-across MPI ranks (cpp/exec/psp_process.cpp:1519-1529) -- so the data path has no
-collective until the end of the run, where three exchanges happen:
+One process per GPU.  torch.distributed starts the job and carries the rendezvous; the DATA of the
+end-of-run exchanges moves through the library's own C-ABI exchange (include/upsp_gpu.h section 3b:
+upsp_comm_* / upsp_allreduce_sums / upsp_exchange_*, RCCL over xGMI) whenever the ranks sit on GPUs
+with the "nccl" backend -- the same entry points a C++ psp_process binds.  With the "gloo" backend
+(CPU tests, several ranks rehearsed on one GPU) the same bookkeeping runs here on torch.distributed
+calls.  Frames shard trivially -- the reference does the same across MPI ranks
+(cpp/exec/psp_process.cpp:1519-1529) -- so the data path has no collective until the end of the run,
+where three exchanges happen:
 
 * sum of the per-rank double accumulators: MPI_Reduce + MPI_Bcast in the reference
   (psp_process.cpp:1866-1872, 2019-2023) -> one all_reduce(SUM) of 2 x N doubles;
@@ -22,6 +26,35 @@ import torch.distributed as dist
 # UPSP_FORCE_COLLECTIVES=1: issue the collectives even in a one-rank group (a one-GPU box can then run
 # the all_reduce / all_to_all_single calls through RCCL itself -- two ranks on one GPU are refused by RCCL)
 FORCE_COLLECTIVES = bool(os.environ.get("UPSP_FORCE_COLLECTIVES"))
+
+
+_LIB_COMM = {}
+
+
+def lib_comm(group=None):
+    """The library's RCCL communicator of the process group (created on first use: rank 0 makes the
+    ncclUniqueId, torch.distributed broadcasts its 128 bytes, every rank calls upsp_comm_create on its
+    current device).  None when the group does not run on RCCL (gloo) or there is no group."""
+    if not dist.is_initialized() or not torch.cuda.is_available():
+        return None
+    if dist.get_backend(group) != "nccl":
+        return None
+    key = id(group)
+    if key not in _LIB_COMM:
+        import ctypes as C
+        from . import _capi
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        buf = (C.c_uint8 * 128)()
+        if rank == 0:
+            _capi.check(_capi.lib().upsp_comm_unique_id(buf))
+        t = torch.tensor(list(buf), dtype=torch.uint8, device="cuda")
+        if world > 1:
+            dist.broadcast(t, src=0, group=group)
+        ident = (C.c_uint8 * 128)(*t.cpu().tolist())
+        h = C.c_void_p()
+        _capi.check(_capi.lib().upsp_comm_create(ident, rank, world, C.byref(h)))
+        _LIB_COMM[key] = h
+    return _LIB_COMM[key]
 
 
 def init_from_env(backend=None):
@@ -46,6 +79,12 @@ def init_from_env(backend=None):
 
 
 def shutdown():
+    if _LIB_COMM:
+        from . import _capi
+        torch.cuda.synchronize()
+        for h in _LIB_COMM.values():
+            _capi.lib().upsp_comm_destroy(h)
+        _LIB_COMM.clear()
     if dist.is_initialized():
         dist.destroy_process_group()
 
@@ -101,6 +140,14 @@ class Shard:
 def allreduce_sums(total, sumsq, group=None):
     """Sum the double accumulators over ranks (in place)."""
     if dist.is_initialized() and (dist.get_world_size(group) > 1 or FORCE_COLLECTIVES):
+        comm = lib_comm(group) if total.is_cuda else None
+        if comm is not None:       # RCCL through the C ABI (upsp_allreduce_sums)
+            import ctypes as C
+            from . import _capi
+            assert total.is_contiguous() and sumsq.is_contiguous() and total.dtype == torch.float64
+            _capi.check(_capi.lib().upsp_allreduce_sums(comm, C.c_void_p(total.data_ptr()), C.c_void_p(sumsq.data_ptr()),
+                                                        total.numel(), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            return total, sumsq
         both = torch.stack([total, sumsq])
         dist.all_reduce(both, op=dist.ReduceOp.SUM, group=group)
         total.copy_(both[0])
@@ -123,6 +170,18 @@ def exchange_time_series(rows_t, shard, group=None, out=None):
             return rows_t                      # single rank: already the complete series
         out.copy_(rows_t)
         return out
+    if rows_t.is_cuda and rows_t.dtype == torch.float32 and lib_comm(group) is not None:
+        # RCCL through the C ABI (upsp_exchange_*): one chunk, every row travels
+        x = TimeSeriesExchange(shard, 1, device=rows_t.device, group=group)
+        x.set_skipped(None)
+        x.submit(rows_t.contiguous(), packed=True)
+        res = x.finish()
+        if out is not None:
+            out.copy_(res)
+            res = out
+        torch.cuda.current_stream().synchronize()
+        x.close()
+        return res
     if out is None:
         out = torch.empty((nn, shard.nframes), dtype=rows_t.dtype, device=rows_t.device)
     rows_t = rows_t.contiguous()               # padded row pitch (engine.series_ld) -> packed blocks
@@ -197,10 +256,13 @@ class TimeSeriesExchange:
     of the other nodes travel -- on a closed model more than half of the nodes face away from a
     camera, i.e. more than half of the all-to-all bytes are NaNs every rank already knows."""
 
-    def __init__(self, shard, nchunks, dtype=torch.float32, device="cuda", group=None):
+    def __init__(self, shard, nchunks, dtype=torch.float32, device="cuda", group=None, wire12=False):
+        """wire12: u16 chunks are packed to 12 bits for the wire (12-bit cameras: 3 bytes per 2 frames; C-ABI
+        exchange only -- a value above 4095 is an error at verify())."""
         self.shard, self.K, self.group = shard, max(1, int(nchunks)), group
         n0, nn = shard.my_nodes
         self.out = torch.empty((nn, shard.nframes), dtype=dtype, device=device)
+        self.wire12 = bool(wire12)
         # chunk boundaries on multiples of 64 frames (the last chunk takes the remainder): every
         # chunk buffer then has 256-byte-aligned rows, which the gather writes as whole 128-B lines
         self.chunks = [aligned_chunks(shard.frame_count[s], self.K) for s in range(shard.world)]
@@ -212,8 +274,42 @@ class TimeSeriesExchange:
         self._row_map = None
         self._keep = None
         self._mismatch = None    # device flag: an assume_same set_skipped() saw a different set
+        self._unverified = False # an assume_same claim is pending: verify() has not been called since
+        self._x = None           # C-ABI exchange (upsp_exchange_*): RCCL ranks on GPUs
+        comm = lib_comm(group) if (str(device).startswith("cuda") and dtype == torch.float32
+                                   and (shard.world > 1 or FORCE_COLLECTIVES)) else None
+        if comm is not None:
+            import ctypes as C
+            from . import _capi
+            h = C.c_void_p()
+            _capi.check(_capi.lib().upsp_exchange_create(comm, shard.nframes, shard.nnodes, self.K, C.byref(h)))
+            self._x = h
+            self._destroy = _capi.lib().upsp_exchange_destroy
+            self._sends = []
+            for k in range(self.K):            # the library cuts the chunks itself: both sides must agree
+                a, b = C.c_int64(), C.c_int64()
+                _capi.check(_capi.lib().upsp_exchange_chunk(h, k, C.byref(a), C.byref(b)))
+                assert (a.value, b.value) == self.my_chunk(k), (k, a.value, b.value, self.my_chunk(k))
         if str(device).startswith("cuda"):
             self._prewarm(device)
+
+    def close(self):
+        if getattr(self, "_unverified", False):
+            import warnings
+            warnings.warn("TimeSeriesExchange: set_skipped(assume_same=True) was used and verify() was never called -- "
+                          "a changed travelling set would have gone unnoticed")
+            self._unverified = False
+        if getattr(self, "_x", None):
+            torch.cuda.synchronize()
+            self._destroy(self._x)
+            self._x = None
+
+    __del__ = close
+
+    @staticmethod
+    def _stream():
+        import ctypes as C
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     @staticmethod
     def _prewarm(device):
@@ -246,6 +342,16 @@ class TimeSeriesExchange:
         projection did not change).  Nothing is read back; the claim is checked on the device and
         verify() raises if it was ever wrong."""
         sh = self.shard
+        if self._x is not None:
+            import ctypes as C
+            from . import _capi
+            sk = None if skipped is None else skipped.to(torch.uint8).contiguous()
+            self._sk = sk                      # (alive until the stream has read it)
+            _capi.check(_capi.lib().upsp_exchange_set_skipped(self._x, C.c_void_p(sk.data_ptr() if sk is not None else 0),
+                                                              int(bool(assume_same)), self._stream()))
+            self._row_map = None
+            self.vis = True                    # (the lists live in the library)
+            return
         if skipped is None:
             self.vis = self.vis_count = self.vis_mine = self._row_map = self._keep = None
             return
@@ -253,6 +359,7 @@ class TimeSeriesExchange:
         if assume_same and self._keep is not None and self._keep.shape == keep.shape:
             bad = (self._keep != keep).any()
             self._mismatch = bad if self._mismatch is None else (self._mismatch | bad)
+            self._unverified = True            # verify() must be called before the results are trusted
             return
         self._keep = keep.clone()
         self.vis = torch.nonzero(keep, as_tuple=False).reshape(-1)
@@ -269,7 +376,15 @@ class TimeSeriesExchange:
         self.nan_mine = torch.nonzero(mine, as_tuple=False).reshape(-1)
 
     def verify(self):
-        """Raises if a set_skipped(..., assume_same=True) call was handed a different set (one host read)."""
+        """Raises if a set_skipped(..., assume_same=True) call was handed a different set (one host read) -- or, C-ABI
+        exchange, if a 12-bit chunk held a value above 4095.  finish() does not check (no host read in the loop): call
+        this once after the last pass of a run whenever assume_same was used."""
+        if self._x is not None:
+            from . import _capi
+            _capi.check(_capi.lib().upsp_exchange_verify(self._x, self._stream()))
+            self._unverified = False
+            return
+        self._unverified = False
         if self._mismatch is not None and bool(self._mismatch):
             raise RuntimeError("TimeSeriesExchange: the skipped-node set changed although assume_same was given")
         self._mismatch = None
@@ -283,6 +398,16 @@ class TimeSeriesExchange:
         """int32 [N]: row of the packed chunk buffer for every node that travels, -1 for the rest
         (FramePipeline.set_row_map): the gather then writes the packed rows itself."""
         sh = self.shard
+        if self._x is not None:
+            if self._row_map is None:
+                import ctypes as C
+                from . import _capi
+                from .engine import _DevArray
+                p, n = C.c_void_p(), C.c_int64()
+                _capi.check(_capi.lib().upsp_exchange_rows(self._x, C.byref(p), C.byref(n)))
+                self._row_map = torch.as_tensor(_DevArray(p.value, sh.nnodes, "<i4", self), device="cuda")
+                self._packed = int(n.value)
+            return self._row_map
         if self._row_map is None:
             m = torch.full((sh.nnodes,), -1, dtype=torch.int32, device=self.vis.device)
             m[self.vis] = torch.arange(self.vis.numel(), dtype=torch.int32, device=self.vis.device)
@@ -290,6 +415,9 @@ class TimeSeriesExchange:
         return self._row_map
 
     def packed_rows(self):
+        if self._x is not None:
+            self.row_map()
+            return self._packed
         return sum(self.vis_count) if self.vis is not None else self.shard.nnodes
 
     def submit(self, rows_t_chunk, packed=False):
@@ -298,6 +426,22 @@ class TimeSeriesExchange:
         sh, k = self.shard, self.k
         if k >= self.K:
             raise RuntimeError("TimeSeriesExchange.submit: all %d chunks were already submitted (finish() first)" % self.K)
+        if self._x is not None:
+            import ctypes as C
+            from . import _capi
+            if self.vis is None:
+                self.set_skipped(None)
+            c0, fc = self.my_chunk(k)
+            if not packed:                     # whole rows [N, fc]: reduce to the travelling ones
+                rows_t_chunk = rows_t_chunk.index_select(0, torch.nonzero(self.row_map() >= 0, as_tuple=False).reshape(-1))
+            send = rows_t_chunk.contiguous()
+            assert send.shape == (self.packed_rows(), fc), (tuple(send.shape), self.packed_rows(), fc)
+            wire = 4 if send.dtype == torch.float32 else (12 if self.wire12 else 2)
+            assert send.dtype in (torch.float32, torch.uint16)
+            self._sends.append(send)           # untouched until finish
+            _capi.check(_capi.lib().upsp_exchange_submit(self._x, C.c_void_p(send.data_ptr()), wire, self._stream()))
+            self.k += 1
+            return
         c0, fc = self.my_chunk(k)
         assert rows_t_chunk.shape == ((self.packed_rows() if packed else sh.nnodes), fc)
         assert not packed or self.vis is not None
@@ -332,6 +476,14 @@ class TimeSeriesExchange:
 
     def finish(self):
         sh = self.shard
+        if self._x is not None:
+            import ctypes as C
+            from . import _capi
+            _capi.check(_capi.lib().upsp_exchange_finish(self._x, C.c_void_p(self.out.data_ptr()), self.out.stride(0),
+                                                         self._stream()))
+            self._sends = []                   # (stream-ordered after the placement of everything received)
+            self.k = 0
+            return self.out
         for work, recv, k, _, rows_in, wire16 in self.pending:
             work.wait()
             if wire16:
@@ -352,6 +504,20 @@ class TimeSeriesExchange:
         if self.vis is not None:
             _fill_rows(self.out, self.nan_mine, float("nan"))      # rows that do not travel (psp_process.cpp:1821-1825)
         return self.out
+
+
+def _exchange_bytes(self):
+    """(sent, received) bytes that crossed a link in the last finished pass (C-ABI exchange), else None."""
+    if self._x is None:
+        return None
+    import ctypes as C
+    from . import _capi
+    a, b = C.c_uint64(), C.c_uint64()
+    _capi.check(_capi.lib().upsp_exchange_bytes(self._x, C.byref(a), C.byref(b)))
+    return int(a.value), int(b.value)
+
+
+TimeSeriesExchange.exchange_bytes = _exchange_bytes
 
 
 def gather_time_series_to_root(series, shard, group=None):
