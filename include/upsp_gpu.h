@@ -556,6 +556,14 @@ int upsp_exchange_bytes(const upsp_exchange *x, uint64_t *sent, uint64_t *receiv
 int upsp_timing_enable(int on);
 int upsp_timing_report(char *buf, size_t cap);
 
+/* Phase labels (reference: timedBarrierPoint / psp::BlockTimer, cpp/exec/psp_process.cpp:585-606): begin / end
+ * nest; every phase is a roctx range (rocprofv3 --marker-trace: libroctx64 is looked up at run time, not linked) and,
+ * with UPSP_PHASE_TIMES set, a "+++ label [total elapsed, this phase]" line on stderr like the reference's.  The
+ * caller synchronises its stream(s) before upsp_phase_end when the phase's GPU work is to be inside the wall-clock figure.
+ * UPSP_ROCTX=1 additionally wraps every timed kernel group of upsp_timing_* in a range of its own. */
+int upsp_phase_begin(const char *label);
+int upsp_phase_end(double *seconds);
+
 #ifdef __cplusplus
 }
 #endif

@@ -83,3 +83,28 @@ def test_header_is_plain_c(tmp_path):
                     "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
     assert out.split() == ["3", "3", "2", "2"]
+
+
+def test_phase_labels_and_exchange_layout_on_the_host():
+    """Host-only parts of the round-3 entry points: phase labels (roctx range + the reference's timedBarrierPoint line,
+    cpp/exec/psp_process.cpp:585-606) and the misuse paths of the communicator API that need no device."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from upsp_processing_amd import _capi\n"
+            "with _capi.phase('phase 1: frame loop', sync=False) as outer:\n"
+            "    with _capi.phase('inner', sync=False) as inner:\n"
+            "        pass\n"
+            "assert inner.seconds >= 0 and outer.seconds >= inner.seconds\n"
+            "import ctypes as C\n"
+            "s = C.c_double()\n"
+            "assert _capi.lib().upsp_phase_end(C.byref(s)) == -1          # end without begin\n"
+            "h = C.c_void_p()\n"
+            "assert _capi.lib().upsp_comm_create(None, 0, 1, C.byref(h)) == -1\n"
+            "assert _capi.lib().upsp_exchange_create(None, 10, 10, 1, C.byref(h)) == -1\n"
+            "print('ok')\n" % ROOT)
+    env = dict(os.environ, UPSP_PHASE_TIMES="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr
+    lines = [l for l in r.stderr.splitlines() if l.startswith("+++ ")]
+    assert len(lines) == 2 and lines[0].startswith("+++ inner") and lines[1].startswith("+++ phase 1: frame loop"), r.stderr

@@ -7,7 +7,11 @@ CPU oracle (GPU: tests/test_reference_pins_gpu.py):
   three visible targets in camera coordinates (3 decimals) -- visibility + lens-model step on targets;
 * test/python/test_photogrammetry.py:401-428  get_occlusions_targets: the ONLY reference vector on
   Hit.pos / the closest hit: [-10.70026875, -2.03368831, -7.0] (6 decimals);
-* test/python/test_visibility.py:149-171      is_visible_and_inside_incal -> 117 553 nodes.
+* test/python/test_visibility.py:149-171      is_visible_and_inside_incal -> 117 553 nodes;
+* test/python/test_target_bumping.py:60-160   does_intersect(target, normal, return_pos=True) of the 24 targets of
+  the fml grid, seven of them pushed 0.02 INTO the model along their normals: exactly those seven come back as real
+  occlusions (distance to the hit >= the tgts / grid tolerance), at a distance of 0.02 (2 decimals); pushed 0.02
+  OUTWARDS, none of the 24 is occluded beyond the tolerance (weak pins: 2 decimals).
 Inputs: the reference's fixtures under tests/golden/ and the calibration constants of its setUpClass
 (tests/refdata.py).  The expected numbers are the reference's."""
 import copy
@@ -67,6 +71,53 @@ def check_target_pins(chk):
     assert occ[-1][0]
     np.testing.assert_array_almost_equal(occ[-1][1], np.array([[-10.70026875], [-2.03368831], [-7.0]]))
     return len(vis)
+
+
+def check_bumping_pins(chk):
+    """target_bumping.get_bumping_occlusion / is_real_occlusion / tgts_get_internals (python/upsp/target_operations/
+    target_bumping.py:15-147) restated on the checker's does_intersect(return_pos=True), with the inputs and
+    expectations of test/python/test_target_bumping.py:60-160."""
+    tgts = refdata.read_tgts(TGTS)
+    internals = [1, 2, 3, 5, 8, 13, 21]
+
+    def occlusion(t):
+        tv = np.array(t["tvec"], dtype=np.float64)
+        nm = np.array(t["norm"], dtype=np.float64)
+        nm /= np.linalg.norm(nm)
+        eps, chk.epsilon = chk.epsilon, 0          # (the reference clears epsilon for this query: any occlusion counts)
+        try:
+            hit, pos = chk.does_intersect(tv, nm, return_pos=True)
+        finally:
+            chk.epsilon = eps
+        return (True, float(np.linalg.norm(tv - pos))) if hit else (False, -1.0)
+
+    tol = float(np.linalg.norm([np.sqrt(3) * 1e-4, np.sqrt(3) * 1e-3]))      # tgts_tol 1e-4, grid_tol 1e-3
+    # pushed inwards: tgts_get_internals returns exactly the seven, and the hit is 0.02 away
+    pushed = copy.deepcopy(tgts)
+    for i in internals:
+        pushed[i]["tvec"] = pushed[i]["tvec"] - 0.02 * pushed[i]["norm"]
+    real, dist = [], {}
+    for i, t in enumerate(pushed):
+        hit, d = occlusion(t)
+        if hit and d >= tol:
+            real.append(t["name"])
+        dist[i] = (hit, d)
+    assert real == [tgts[i]["name"] for i in internals], (real, dist)
+    for i in internals:
+        assert dist[i][0] and abs(dist[i][1] - 0.02) < 5e-3, (i, dist[i])        # assertAlmostEqual(.., 0.02, 2)
+    # untouched and pushed outwards: nothing beyond the tolerance
+    for sign in (0.0, 1.0):
+        moved = copy.deepcopy(tgts)
+        for i in internals:
+            moved[i]["tvec"] = moved[i]["tvec"] + sign * 0.02 * moved[i]["norm"]
+        for i, t in enumerate(moved):
+            hit, d = occlusion(t)
+            assert not (hit and d >= tol), (sign, i, d)
+    return len(real)
+
+
+def test_target_bumping_pins(checker):
+    assert check_bumping_pins(checker) == 7
 
 
 def test_project_3d_point_pins(oracle):

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import refdata
-from test_reference_pins import CAL, check_projection_pins, check_target_pins
+from test_reference_pins import CAL, check_bumping_pins, check_projection_pins, check_target_pins
 from upsp_processing_amd.visibility import VisibilityChecker
 
 pytestmark = pytest.mark.gpu
@@ -35,3 +35,8 @@ def test_is_visible_and_inside_incal_117553_gpu(checker, fml):
     got = checker.is_visible_and_inside_incal(CAL["rmat"], CAL["tvec"], CAL["cameraMatrix"], dc, fml["nodes"], fml["norms"],
                                               {"critical_pt": "first"})
     assert len(got) == 117553
+
+
+def test_target_bumping_pins_gpu(checker):
+    """test/python/test_target_bumping.py:60-160 through the GPU closest-hit query (does_intersect(return_pos=True))."""
+    assert check_bumping_pins(checker) == 7

@@ -137,6 +137,8 @@ SIGNATURES = {
     "upsp_exchange_finish": (_i, [_vp, _vp, C.c_int64, _vp]),
     "upsp_exchange_verify": (_i, [_vp, _vp]),
     "upsp_exchange_bytes": (_i, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "upsp_phase_begin": (_i, [C.c_char_p]),
+    "upsp_phase_end": (_i, [C.POINTER(C.c_double)]),
     "upsp_timing_enable": (_i, [_i]),
     "upsp_timing_report": (_i, [C.c_char_p, _sz]),
 }
@@ -186,6 +188,28 @@ def device_info():
     arch = C.create_string_buffer(64)
     check(lib().upsp_device_info(C.byref(n), arch, C.byref(cus)))
     return dict(n_devices=n.value, arch=arch.value.decode(), n_cus=cus.value)
+
+
+class phase:
+    """`with _capi.phase("phase 1: frame loop"):` -- a roctx range + (UPSP_PHASE_TIMES) the reference's timedBarrierPoint
+    line (cpp/exec/psp_process.cpp:585-606); the GPU is synchronised at the end so that the figure holds the phase's work."""
+
+    def __init__(self, label, sync=True):
+        self.label, self.sync, self.seconds = label, sync, None
+
+    def __enter__(self):
+        check(lib().upsp_phase_begin(self.label.encode()))
+        return self
+
+    def __exit__(self, *exc):
+        if self.sync:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+        s = C.c_double()
+        check(lib().upsp_phase_end(C.byref(s)))
+        self.seconds = s.value
+        return False
 
 
 def timing_enable(on=True):

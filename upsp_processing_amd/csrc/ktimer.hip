@@ -2,7 +2,11 @@
 // launched on; resolved at report time (after the caller has synchronised).
 #include "ktimer.h"
 
+#include <dlfcn.h>
+
 #include <algorithm>
+#include <chrono>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -28,11 +32,53 @@ std::string g_current;
 hipEvent_t g_start;
 }  // namespace
 
+// roctx ranges (rocprofv3 --marker-trace shows them as a time line of phases): libroctx64 is looked up at first use,
+// not linked; without it the labels are wall-clock lines only.
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+};
+Roctx &roctx()
+{
+    static Roctx r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void *p = dlsym(RTLD_DEFAULT, "roctxRangePushA");
+        void *h = nullptr;
+        if (!p) {
+            h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+            if (h) p = dlsym(h, "roctxRangePushA");
+        }
+        void *q = dlsym(RTLD_DEFAULT, "roctxRangePop");
+        if (!q && h) q = dlsym(h, "roctxRangePop");
+        if (p && q) {
+            r.push = reinterpret_cast<int (*)(const char *)>(p);
+            r.pop = reinterpret_cast<int (*)()>(q);
+        }
+    });
+    return r;
+}
+bool roctx_wanted()
+{
+    static const bool on = std::getenv("UPSP_ROCTX") != nullptr;
+    return on;
+}
+
+struct Phase {
+    std::string label;
+    std::chrono::steady_clock::time_point t0;
+};
+std::vector<Phase> g_phases;
+std::chrono::steady_clock::time_point g_base;
+bool g_have_base = false;
+
 bool ktimer_on() { return g_on; }
 
 void ktimer_begin(const char *name, hipStream_t st)
 {
     std::lock_guard<std::mutex> lk(g_mu);
+    if (roctx_wanted() && roctx().push) roctx().push(name);
     g_current = name;
     if (hipEventCreate(&g_start) != hipSuccess) return;
     (void)hipEventRecord(g_start, st);
@@ -46,6 +92,7 @@ void ktimer_end(hipStream_t st)
     (void)hipEventRecord(e, st);
     if (!g_entries.count(g_current)) g_order.push_back(g_current);
     g_entries[g_current].spans.push_back({g_start, e});
+    if (roctx_wanted() && roctx().pop) roctx().pop();
 }
 }  // namespace upsp
 
@@ -65,6 +112,38 @@ int upsp_timing_enable(int on)
         }
     g_entries.clear();
     g_order.clear();
+    return UPSP_OK;
+}
+
+int upsp_phase_begin(const char *label)
+{
+    if (!label) return fail(UPSP_ERR_INVALID, "null label");
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (roctx().push) roctx().push(label);
+    const auto now = std::chrono::steady_clock::now();
+    if (!g_have_base) {
+        g_base = now;
+        g_have_base = true;
+    }
+    g_phases.push_back({label, now});
+    return UPSP_OK;
+}
+
+int upsp_phase_end(double *seconds)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_phases.empty()) return fail(UPSP_ERR_INVALID, "upsp_phase_end without upsp_phase_begin");
+    if (roctx().pop) roctx().pop();
+    const auto now = std::chrono::steady_clock::now();
+    const Phase ph = g_phases.back();
+    g_phases.pop_back();
+    const double dt = std::chrono::duration<double>(now - ph.t0).count();
+    if (seconds) *seconds = dt;
+    // the reference's timedBarrierPoint line (cpp/exec/psp_process.cpp:585-606), without the barrier
+    static const bool print = std::getenv("UPSP_PHASE_TIMES") != nullptr;
+    if (print)
+        std::fprintf(stderr, "+++ %s   [total elapsed:%g,  this phase:%g]\n", ph.label.c_str(),
+                     std::chrono::duration<double>(now - g_base).count(), dt);
     return UPSP_OK;
 }
 

@@ -245,6 +245,19 @@ def run(flags):
                         bit_depth=12, bound_pts=int(flags.get("bound_pts", 2)),
                         buffer_pts=int(flags.get("buffer_pts", 1)),
                         target_diam_sf=float(flags.get("target_diam_sf", 1.2)))
+    # phase labels: roctx ranges + (UPSP_PHASE_TIMES=1) the reference's "+++ label [total elapsed ...]" lines
+    # (timedBarrierPoint, cpp/exec/psp_process.cpp:585-606)
+    from . import _capi
+    phases = []
+
+    def begin(label):
+        phases.append(_capi.phase(label))
+        phases[-1].__enter__()
+
+    def end():
+        phases.pop().__exit__(None, None, None)
+
+    begin("phase 1: BVH + projection matrices (createBVH, create_projection_mat)")
     job = psp.Phase1(s9, tri_nodes, xyz, normals, cams, size,
                      oblique_angle=float(opts["oblique_angle"]), overlap=opts["overlap"],
                      datanode=datanode, registration=opts["registration"] == "pixel",
@@ -254,6 +267,7 @@ def run(flags):
     if job.visible_targets is not None and (not D.dist.is_initialized() or D.dist.get_rank() == 0):
         for c, vis in enumerate(job.visible_targets):
             print("camera %d: %d visible targets patched" % (c + 1, len(vis)))
+    end()
     shard = D.Shard(nframes, job.nnodes)
     f0, nf = shard.my_frames
     job.set_first_frames(first)
@@ -264,6 +278,7 @@ def run(flags):
     # thread, psp_process.cpp:867-1007): the upload of chunk k + 1 overlaps the processing of chunk k
     feeds = [video.FrameFeed(min(chunk, max(nf, 1)) * r.frame_bytes, 3) if getattr(r, "raw_bit_depth", 12) == 12
              else None for r in readers]
+    begin("phase 1: frame loop (read, register, patch, project, accumulate)")
     try:
         for c0 in range(0, nf, chunk):
             n = min(chunk, nf - c0)
@@ -277,19 +292,25 @@ def run(flags):
         for fd in feeds:
             if fd is not None:
                 fd.close()
+    end()
+    begin("phase 1: reductions + time-series exchange (MPI_Reduce, global_transpose)")
     finals = job.finalize(nframes)
     series = D.exchange_time_series(rows_t[:, :nf], shard)
+    end()
+    begin("phase 1: output files")
     out_dir = flags.get("add_out_dir") or deck["output"].get("dir") or "."
     job.write_outputs(out_dir, finals, series, node_start=shard.my_nodes[0])
     if shard.rank == 0:
         for name, col in (("X", 0), ("Y", 1), ("Z", 2)):                    # :524-540
             xyz[:, col].astype("<f4").tofile(os.path.join(out_dir, name))
         print("phase 1 complete: %d frames, %d nodes, %d %s" % (nframes, job.nnodes, job.nrays, job.nrays_kind))
+    end()
 
     # ---- phase 2 (psp_process.cpp:2260-2625) ----
     paint_cal, sds = flags.get("paint_cal"), deck["all"].get("sds")
     if paint_cal and os.path.isfile(paint_cal) and sds:
         from . import phase2
+        begin("phase 2: intensity -> pressure")
         steady = temp = None
         if flags.get("steady_p3d") or flags.get("model_temp_p3d"):
             # structured models read one scalar per grid point (psp_process.cpp:2327-2335, 2360-2368);
@@ -332,6 +353,7 @@ def run(flags):
                          model_temp=temp)
         if shard.rank == 0:
             print("phase 2 complete: model temperature %.1f F, qbar %.2f" % (p2.model_temp, p2.tcond["qbar"]))
+        end()
     job.close()
     return 0
 
