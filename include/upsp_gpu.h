@@ -404,6 +404,10 @@ int upsp_register_pixel_u16(const float *d_ref32f, const uint16_t *d_inp, int ro
  * psp_process.cpp:1802-1807 ; box = 0 gaussian, 1 box */
 int upsp_blur_f32(const float *d_src, float *d_dst, int rows, int cols, int k, int box,
                   void *stream);
+/* convertTo(CV_32F) + cv::GaussianBlur(Size(k,k), 0) of nimg u16 frames [nimg][rows][cols] in one pass (the pre-blur of
+ * cv::findTransformECC, cpp/lib/registration.cpp:57-60, and the filter stage on raw frames, psp_process.cpp:1802-1804);
+ * sizes 3 / 5 / 7 in one fused tile kernel (2 B in, 4 B out per pixel). */
+int upsp_blur_u16(const uint16_t *d_src, float *d_dst, int nimg, int rows, int cols, int k, void *stream);
 /* PatchClusters<float>::operator() (cpp/lib/patches.ipp:98-165) on one f32 image */
 int upsp_patch_f32(float *d_img, int rows, int cols, int nclusters, const int32_t *h_b_off,
                    const int32_t *h_bx, const int32_t *h_by, const int32_t *h_i_off,

@@ -38,6 +38,31 @@ def test_blur_bitwise(gpu_lib, oracle):
                                   oracle.blur(img, k, box=True).view(np.int32)), (shape, k)
 
 
+@pytest.mark.parametrize("cols_kernel", [0, 1])
+def test_blur_u16_bitwise(gpu_lib, oracle, monkeypatch, cols_kernel):
+    """upsp_blur_u16 (convertTo + GaussianBlur of u16 frames in one pass, the registration's pre-blur) against the
+    oracle's GaussianBlur of the converted frame, bit for bit -- through the tile kernel and (UPSP_GAUSS5_COLS=1)
+    through the column-walking 5 x 5 kernel (one wave per 62 columns, rows rolling in registers, neighbours by DPP wave
+    shifts, reflect-101 by reflected loads): widths around the 62-column tiles and the 4-wave workgroups, heights
+    around the 64-row pieces, images smaller than the kernel's halo, several frames in one call; other kernel sizes."""
+    import torch
+    from upsp_processing_amd import engine
+    monkeypatch.setenv("UPSP_GAUSS5_COLS", str(cols_kernel))
+    rng = np.random.default_rng(9)
+    for shape in [(5, 5), (7, 61), (64, 62), (65, 63), (130, 124), (33, 125), (200, 249), (129, 300), (70, 1024 + 3)]:
+        fr = rng.integers(0, 4096, size=(3,) + shape, dtype=np.uint16)
+        fr[0, 0, :] = 4095
+        fr[1, :, -1] = 0
+        g = engine.blur_u16(torch.as_tensor(fr).cuda(), 5).cpu().numpy()
+        for f in range(3):
+            want = oracle.blur(fr[f].astype(np.float32), 5)
+            assert np.array_equal(g[f].view(np.int32), want.view(np.int32)), (shape, f, np.abs(g[f] - want).max())
+    fr = rng.integers(0, 4096, size=(40, 57), dtype=np.uint16)
+    for k in (3, 7, 9):
+        g = engine.blur_u16(torch.as_tensor(fr).cuda(), k).cpu().numpy()
+        assert np.array_equal(g.view(np.int32), oracle.blur(fr.astype(np.float32), k).view(np.int32)), k
+
+
 @pytest.mark.parametrize("interp", [1, 0])
 def test_register_pixel(gpu_lib, oracle, interp):
     import torch
@@ -56,13 +81,15 @@ def test_register_pixel(gpu_lib, oracle, interp):
         assert np.array_equal(out_g.cpu().numpy(), oracle.warp_affine(fr[f], M_g, interp))
 
 
+@pytest.mark.parametrize("fused", [0, 1])
 @pytest.mark.parametrize("H,W,shift", [(96, 131, (7.3, -4.6)), (48, 64, (1.4, 0.7)), (200, 300, (-15.2, 11.8)), (33, 47, (0.3, -0.2))])
-def test_register_pixel_band(gpu_lib, oracle, H, W, shift):
+def test_register_pixel_band(gpu_lib, oracle, monkeypatch, H, W, shift, fused):
     """The ECC sums are taken by interior blocks (pixels farther than a band from every edge, no border handling) and
     band blocks (generic bilinear); the band follows the warp.  Odd image sizes, shifts of many pixels (wide bands, a band
     that swallows most of a small image), shear: same iteration count and warp as the oracle."""
     import torch
     from upsp_processing_amd import engine
+    monkeypatch.setenv("UPSP_ECC_FUSED", str(fused))      # 1: blur + identity iteration in one column-walking kernel
     rng = np.random.default_rng(H * W)
     yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
     def scene(y, x):

@@ -16,7 +16,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 def short(k):
     mm = re.search(r"\(anonymous namespace\)::(\w+)(<[^>]*>)?\(", k)
     return ((mm.group(1) + (mm.group(2) or "")) if mm else k[:40]).replace("unsigned short", "u16")
-want = ("ecc_sums", "ecc_cols", "gauss_fused", "ecc_solve", "gauss5_ecc")
+want = ("ecc_sums", "ecc_cols", "gauss_fused", "ecc_solve", "gauss5_")
 dur = collections.defaultdict(float)
 for r in rows:
     k = short(r["Kernel_Name"])

@@ -111,6 +111,7 @@ SIGNATURES = {
     "upsp_apportion": (_i, [_i, _i, _vp, _vp]),
     "upsp_register_pixel_u16": (_i, [_vp, _vp, _i, _i, _i, C.c_double, _i, _vp, _vp, _vp]),
     "upsp_blur_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "upsp_blur_u16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "upsp_patch_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "upsp_unpack_10bit": (_i, [_vp, _i, _sz, _vp, _vp, _vp]),
     "upsp_unpack_12bit": (_i, [_vp, _i, _sz, _vp, _i, _vp, _vp]),

@@ -1205,6 +1205,149 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
         ecc_band_cols_body(img, tmpl, rows, cols, state, partial, f, blockIdx.y, IDENT, lds_red);
 }
 
+// ---- Gaussian 5 x 5 pre-blur and the identity iteration of the ECC in ONE pass ----------------------------------------
+// cv::findTransformECC blurs the input (GaussianBlur 5 x 5) and its first iteration runs with the identity warp: the
+// warped image IS the blurred image and the warped gradients are its central differences.  Round 2 wrote the blurred
+// frame (tile kernel, 6 B per pixel) and read it back for the identity sums (8 B per pixel); here one column-walking
+// kernel does both: 2 B (frame) + 4 B (template) in, 4 B (blurred frame, for the later iterations) out.
+//
+// A WAVE owns 62 columns (lanes 1 .. 62; lanes 0 and 63 carry the two neighbour columns the x-gradient needs) and
+// walks down the rows of its piece with everything rolling in registers: the horizontal pass takes the four neighbour
+// pixels from the neighbouring lanes by DPP wave shifts (lanes 0 / 63 load theirs), five rows of horizontal results
+// give a blurred row, three blurred rows give the gradients -- no LDS, no barrier in the loop, waves independent.
+// Same float operations in the same order as gauss_pass_kernel / gauss_fused_kernel (the blurred frame is bit-identical:
+// tests/test_imageops_gpu.py compares upsp_blur_u16 with the oracle), reflect-101 by loading reflected rows and
+// columns: a lane on a virtual column -1 computes exactly the blurred column 1, so the gradient taps at the image border
+// are cv::Sobel's reflected ones without a special case, and the whole frame is "interior" (mask = 1 everywhere under
+// the identity warp): no band blocks in this launch.
+constexpr int kGcOwn = 62;           // columns a wave owns
+
+__device__ __forceinline__ float dpp_shr1(float old, float v)      // lane i <- lane i - 1, lane 0 <- old
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), 0x138, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float dpp_shl1(float old, float v)      // lane i <- lane i + 1, lane 63 <- old
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), 0x130, 0xF, 0xF, false));
+}
+
+template <bool ECC, int U>
+__device__ __forceinline__ void gauss5_cols_body(const uint16_t *__restrict__ src, float *__restrict__ dst,
+                                                 const float *__restrict__ tmpl, int rows, int cols, int rpp, float k0,
+                                                 float k1, float k2, const EccState *__restrict__ state,
+                                                 double *__restrict__ partial, unsigned slot0, double (*lds_red)[256])
+{
+    const int f = blockIdx.x;
+    if (ECC && state[f].done) return;
+    const int lane = threadIdx.x & 63;
+    const int tile = (int)blockIdx.z * 4 + (int)(threadIdx.x >> 6);        // column tile of this wave
+    const int x = tile * kGcOwn - 1 + lane;                                // (virtual for x < 0 or x >= cols)
+    const int y0 = (int)blockIdx.y * rpp, y1 = min(rows, y0 + rpp);
+    const bool wave_on = tile * kGcOwn < cols && y1 > y0;                   // (uniform per wave)
+    const bool own = wave_on && lane >= 1 && lane <= kGcOwn && x >= 0 && x < cols;
+    const size_t npix = (size_t)rows * cols;
+    const uint16_t *S = src + (size_t)f * npix;
+    float *B = dst + (size_t)f * npix;
+    EccTot T;
+    if (ECC) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            T.G0[k] = T.G1[k] = T.Gw0[k] = T.Gw1[k] = T.Gt0[k] = T.Gt1[k] = T.Q0[k] = T.Q1[k] = T.Q2[k] = 0.0;
+        T.C0 = T.C1 = T.C2 = T.Sw = T.Sww = T.St = T.Stt = T.Stw = 0.0;
+        T.n = own ? (double)(y1 - y0) : 0.0;
+    }
+    if (wave_on) {
+        // column offsets of the lane's own pixel and of the two pixels only the edge lanes fetch (reflect-101)
+        const unsigned cx = 2u * (unsigned)reflect101(x, cols);
+        const unsigned ca = 2u * (unsigned)reflect101(lane == 0 ? x - 1 : x + 1, cols);
+        const unsigned cb = 2u * (unsigned)reflect101(lane == 0 ? x - 2 : x + 2, cols);
+        const bool edge = lane == 0 || lane == 63;
+        const unsigned pitch2 = 2u * (unsigned)cols;
+        const unsigned ox = 4u * (unsigned)max(0, min(x, cols - 1));        // f32 column offset (template, output)
+        float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f, h4 = 0.f;              // h(yi - 4 .. yi)
+        float b0 = 0.f, b1 = 0.f, b2 = 0.f;                                  // b(yb - 2 .. yb)
+        EccPart P;
+        if (ECC) ecc_part_zero(P);
+        int yseg = y0;                                                      // first row of the open float segment
+        const int niter = (y1 - y0) + 6;
+        for (int g = 0; g < niter; g += U) {
+            // the loads of U input rows first
+            float s[U], ha[U], hb[U], tt[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int yi = y0 - 3 + g + u;
+                const unsigned ro = (unsigned)reflect101(min(max(yi, -(rows - 1)), 2 * rows - 2), rows) * pitch2;
+                s[u] = (float)*reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(S) + (ro + cx));
+                ha[u] = hb[u] = 0.f;
+                if (edge) {
+                    ha[u] = (float)*reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(S) + (ro + ca));
+                    hb[u] = (float)*reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(S) + (ro + cb));
+                }
+                if (ECC) {
+                    const int ye = min(max(yi - 3, 0), rows - 1);
+                    tt[u] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(tmpl) + ((unsigned)ye * 2u * pitch2 + ox));
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = g + u;
+                if (k >= niter) break;                                     // (uniform)
+                const int yi = y0 - 3 + k;
+                // horizontal pass: neighbours by wave shifts; lanes 0 / 63 supply the pixels beyond the wave
+                const float m1 = dpp_shr1(ha[u], s[u]), p1 = dpp_shl1(ha[u], s[u]);
+                const float m2 = dpp_shr1(hb[u], m1), p2 = dpp_shl1(hb[u], p1);
+                float hn = k0 * s[u];
+                hn += k1 * (m1 + p1);
+                hn += k2 * (m2 + p2);
+                h0 = h1; h1 = h2; h2 = h3; h3 = h4; h4 = hn;
+                if (k < 4) continue;
+                // vertical pass: blurred row yb = yi - 2
+                float bn = k0 * h2;
+                bn += k1 * (h1 + h3);
+                bn += k2 * (h0 + h4);
+                const int yb = yi - 2;
+                if (own && yb >= y0 && yb < y1)
+                    __builtin_nontemporal_store(bn, reinterpret_cast<float *>(reinterpret_cast<char *>(B) + ((unsigned)yb * 2u * pitch2 + ox)));
+                b0 = b1; b1 = b2; b2 = bn;
+                if (!ECC || k < 6) continue;
+                // identity iteration at row ye = yi - 3: w = b, gradients = central differences of b
+                const int ye = yi - 3;
+                const float l = dpp_shr1(0.f, b1), r = dpp_shl1(0.f, b1);
+                if (ye - yseg == kEccFlush) {                               // (uniform)
+                    ecc_part_flush(P, T, yseg);
+                    ecc_part_zero(P);
+                    yseg = ye;
+                }
+                ecc_part_add<false>(P, T, b1, 0.5f * (r - l), 0.5f * (b2 - b0), tt[u], (float)(ye - yseg));
+            }
+        }
+        if (ECC) ecc_part_flush(P, T, yseg);
+    }
+    if (ECC) {
+        const unsigned slot = slot0 + blockIdx.y * gridDim.z + blockIdx.z;
+        ecc_tot_store<0>(T, (double)x, own, lds_red, partial, f, slot);
+    }
+}
+
+// blur + identity iteration: the ECC totals hold the kernel at 4 (3) waves per SIMD
+template <int U, int WAVES>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
+    gauss5_ecc0_kernel(const uint16_t *__restrict__ src, float *__restrict__ dst, const float *__restrict__ tmpl, int rows,
+                       int cols, int rpp, float k0, float k1, float k2, const EccState *__restrict__ state,
+                       double *__restrict__ partial, unsigned slot0)
+{
+    __shared__ double lds_red[kEccChunk][256];
+    gauss5_cols_body<true, U>(src, dst, tmpl, rows, cols, rpp, k0, k1, k2, state, partial, slot0, lds_red);
+}
+// blur alone: ~30 registers, as many waves as the CU takes
+template <int U>
+__global__ void __launch_bounds__(256)
+    gauss5_blur_kernel(const uint16_t *__restrict__ src, float *__restrict__ dst, int rows, int cols, int rpp, float k0, float k1,
+                       float k2)
+{
+    gauss5_cols_body<false, U>(src, dst, nullptr, rows, cols, rpp, k0, k1, k2, nullptr, nullptr, 0u, nullptr);
+}
+
 // grid (frames, kEccBorderBlocks + interior blocks): the frame is the FAST index, so the band blocks of all frames
 // (slots 0 .. kEccBorderBlocks-1: few trips of long dependent chains) are dispatched first and run beside the interior
 // blocks instead of after them (as the last blocks of the launch they were a 50-us tail)
@@ -1685,6 +1828,39 @@ static int launch_patch(const PatchTables *t, float *imgs, int nimg, int rows, i
     return UPSP_OK;
 }
 
+// GaussianBlur(u16 -> f32, 5 x 5) of nimg frames by the column-walking kernel; with `state` / `partial` / `tmpl` also the
+// identity iteration of the ECC (one partial-sum slot per workgroup: *nslots of them, slots 0 .. *nslots - 1).
+static int launch_gauss5_cols(const uint16_t *src, float *dst, int nimg, int rows, int cols, const float *tmpl,
+                              const EccState *state, double *partial, int *nslots, hipStream_t st)
+{
+    FilterCoef fc;
+    if (gaussian_coef(5, fc) != 0) return fail(UPSP_ERR_INVALID, "gaussian 5");
+    const int ntiles = (cols + kGcOwn - 1) / kGcOwn, zb = (ntiles + 3) / 4;
+    int rpp = 64;
+    while ((long long)((rows + rpp - 1) / rpp) * zb > kEccStride) rpp *= 2;     // (one slot per workgroup)
+    const int pieces = (rows + rpp - 1) / rpp;
+    if (nimg > 65535 || pieces > 65535 || zb > 65535) return fail(UPSP_ERR_INVALID, "gaussian: image too large");
+    const dim3 grid((unsigned)nimg, (unsigned)pieces, (unsigned)zb);
+    const int uvar = env_int_io("UPSP_GAUSS5_VARIANT", 0);       // (measurement switch)
+    if (state) {
+        KTimed kt("gauss5_ecc0_kernel", st);
+#define UPSP_G5E(UU, WV)                                                                                        \
+    hipLaunchKernelGGL((gauss5_ecc0_kernel<UU, WV>), grid, dim3(256), 0, st, src, dst, tmpl, rows, cols, rpp, fc.k[2], fc.k[3], \
+                       fc.k[4], state, partial, 0u)
+        if (uvar == 1) UPSP_G5E(8, 3); else if (uvar == 2) UPSP_G5E(8, 4); else if (uvar == 3) UPSP_G5E(2, 4); else UPSP_G5E(4, 4);
+#undef UPSP_G5E
+        if (nslots) *nslots = pieces * zb;
+    } else {
+        KTimed kt("gauss_pass_kernels", st);
+#define UPSP_G5B(UU)                                                                                            \
+    hipLaunchKernelGGL((gauss5_blur_kernel<UU>), grid, dim3(256), 0, st, src, dst, rows, cols, rpp, fc.k[2], fc.k[3], fc.k[4])
+        if (uvar == 1) UPSP_G5B(8); else if (uvar == 2) UPSP_G5B(16); else if (uvar == 3) UPSP_G5B(2); else UPSP_G5B(4);
+#undef UPSP_G5B
+    }
+    UPSP_HIP_CHECK(hipGetLastError());
+    return UPSP_OK;
+}
+
 // ----------------------------------------------------------- FrameScratch --
 struct FrameScratch {
     int ncams = 0, batch = 0, rows = 0, cols = 0;
@@ -1763,22 +1939,46 @@ static int run_ecc(FrameScratch *s, const float *tmpl_blur, const uint16_t *fram
                    int64_t first_frame, int rows, int cols, int max_iters, double eps, hipStream_t st)
 {
     if ((long long)rows * cols >= (1ll << 31)) return fail(UPSP_ERR_INVALID, "registration: image too large");
-    int rc = launch_gauss<uint16_t>(frames, s->ecc_img, s->tmp, nb, rows, cols, 5, st);
-    if (rc != UPSP_OK) return rc;
+    // Pre-blur (GaussianBlur 5 x 5) and the first iteration.  Every frame starts from the identity warp
+    // (cpp/lib/registration.cpp:52-53), so the first iteration needs no warp.  Default: the tile kernel blurs, the
+    // column kernel's identity variant takes the sums (134 + 130 us per 64 frames of 1024^2).  UPSP_ECC_FUSED=1: ONE
+    // column-walking kernel blurs and sums (gauss5_ecc0_kernel) -- built because it moves 10 instead of 14 bytes per
+    // pixel, measured at 280-290 us: a wave's 128-byte requests for its 62 u16 pixels of a row keep the L1 waiting on
+    // pending misses (PMC: 68 % of the time; 4 / 8 / 16 rows in flight, 3 / 4 / 8 waves per SIMD and streamed loads all
+    // within 280-365 us).  Kept as a switch, parity-tested; UPSP_ECC_FUSED=2: column-walking blur alone (184 us) + the
+    // identity variant.
+    const int fused_env = env_int_io("UPSP_ECC_FUSED", 0);
+    const bool fused = fused_env == 1 && rows >= 5 && cols >= 5;
     const dim3 g1((nb + 63) / 64), b1(64);
     hipLaunchKernelGGL(ecc_init_kernel, g1, b1, 0, st, s->state, nb, (long long)first_frame);
     hipLaunchKernelGGL(ecc_set_last_rho, g1, b1, 0, st, s->state, nb, eps);
     int it = 0;
+    if (fused) {
+        int nslots = 0;
+        int rc = launch_gauss5_cols(frames, s->ecc_img, nb, rows, cols, tmpl_blur, (const EccState *)s->state, s->partial, &nslots, st);
+        if (rc != UPSP_OK) return rc;
+        KTimed kt2("ecc_solve_kernel", st);
+        hipLaunchKernelGGL(ecc_solve_kernel, dim3(nb), dim3(256), 0, st, s->state, (const double *)s->partial, nb, nslots,
+                           max_iters, eps, rows, cols);
+        it = 1;
+    } else {
+        int rc = (fused_env == 2 && rows >= 5 && cols >= 5)
+                     ? launch_gauss5_cols(frames, s->ecc_img, nb, rows, cols, nullptr, nullptr, nullptr, nullptr, st)
+                     : launch_gauss<uint16_t>(frames, s->ecc_img, s->tmp, nb, rows, cols, 5, st);
+        if (rc != UPSP_OK) return rc;
+    }
+    bool first_burst = true;
     int active = nb;  // frames still iterating (known to the host after every burst)
     int iters_done = 0, most_iters = 0;
-    while (it < max_iters) {
+    for (;;) {
         // a few iterations between host checks of the active-frame count; frames that have
         // converged exit at once, so late bursts spread the remaining frames over more blocks
         // (a host check costs a stream round trip of ~40 us; most frames converge within 3-5
         // iterations, the rare oscillating ones run to max_iters, so the bursts grow)
         // (first burst: as many iterations as the previous sub-batch's slowest frame took -- on steady footage every
         //  frame converges with its second iteration, and a third launch pair that finds nothing to do costs 10 us)
-        const int burst = it == 0 ? s->ecc_first_burst : (it < 7 ? 2 : (it < 15 ? 8 : 16));
+        const int burst = first_burst ? std::max(1, s->ecc_first_burst - it) : (it < 7 ? 2 : (it < 15 ? 8 : 16));
+        first_burst = false;
         // Interior blocks per frame.  Round 3's kernel: every block ends with a reduction of the 45 sums that costs as
         // much as ~10 rows of its 256 columns, so a block should walk a few hundred rows -- 16 blocks per frame (4 column
         // tiles x 4 row pieces of 256 at 1024^2: 1024 blocks for a full sub-batch = one resident set at 4 per CU), more
@@ -1862,7 +2062,7 @@ static int run_ecc(FrameScratch *s, const float *tmpl_blur, const uint16_t *fram
                         "ECC registration did not converge (cv::findTransformECC would throw)");
         iters_done = h[2];
         most_iters = h[3];
-        if (h[0] == 0) break;
+        if (h[0] == 0 || it >= max_iters) break;
         active = h[0];
     }
     s->ecc_first_burst = std::min(std::max(most_iters, 2), 4);
@@ -2044,6 +2244,22 @@ int upsp_register_pixel_u16(const float *d_ref32f, const uint16_t *d_inp, int ro
     }
     frame_scratch_free(s);
     return rc == UPSP_OK ? iters : rc;
+}
+
+int upsp_blur_u16(const uint16_t *d_src, float *d_dst, int nimg, int rows, int cols, int k, void *stream)
+{
+    if (!d_src || !d_dst || nimg <= 0 || rows <= 0 || cols <= 0) return fail(UPSP_ERR_INVALID, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    // (UPSP_GAUSS5_COLS=1: the column-walking 5 x 5 kernel instead of the tile kernel -- measurement / test switch)
+    if (k == 5 && rows >= 5 && cols >= 5 && (long long)rows * cols < (1ll << 29) && env_int_io("UPSP_GAUSS5_COLS", 0))
+        return launch_gauss5_cols(d_src, d_dst, nimg, rows, cols, nullptr, nullptr, nullptr, nullptr, st);
+    float *tmp = nullptr;
+    UPSP_HIP_CHECK(hipMalloc(&tmp, sizeof(float) * (size_t)nimg * rows * cols));
+    int rc = launch_gauss<uint16_t>(d_src, d_dst, tmp, nimg, rows, cols, k, st);
+    hipError_t e = hipStreamSynchronize(st);
+    (void)hipFree(tmp);
+    if (rc == UPSP_OK && e != hipSuccess) rc = fail(UPSP_ERR_HIP, hipGetErrorString(e));
+    return rc;
 }
 
 int upsp_blur_f32(const float *d_src, float *d_dst, int rows, int cols, int k, int box, void *stream)

@@ -461,6 +461,17 @@ def register_pixel(ref32f, frame_u16, max_iters=50, eps=1e-3, interp=1):
     return out, np.array(list(warp), dtype=np.float32).reshape(2, 3), rc
 
 
+def blur_u16(frames_u16, k=5):
+    """convertTo(CV_32F) + cv::GaussianBlur(Size(k,k), 0) of u16 frames [F,H,W] (or [H,W]) in one pass: f32 tensor of
+    the same shape (upsp_blur_u16; k = 5 is the registration's pre-blur kernel, cpp/lib/registration.cpp:57-60)."""
+    assert frames_u16.is_cuda and frames_u16.dtype == torch.uint16 and frames_u16.is_contiguous()
+    fr = frames_u16 if frames_u16.dim() == 3 else frames_u16[None]
+    f, h, w = fr.shape
+    out = torch.empty((f, h, w), dtype=torch.float32, device="cuda")
+    check(lib().upsp_blur_u16(_ptr(fr), _ptr(out), f, h, w, int(k), _stream()))
+    return out if frames_u16.dim() == 3 else out[0]
+
+
 def blur(img32f, k, box=False):
     """cv::GaussianBlur(img,img,Size(k,k),0) / cv::blur(img,img,Size(k,k)) (psp_process.cpp:1802-1807)."""
     assert img32f.is_cuda and img32f.dtype == torch.float32 and img32f.is_contiguous()
