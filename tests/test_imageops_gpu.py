@@ -289,4 +289,38 @@ def test_registration_full_size_1024(gpu_lib, oracle):
         assert dd.max() <= 2.0 * step / 32.0 + 1.0 and dd.mean() <= 0.25, (f, dd.max(), step, dd.mean())
         worst = [max(worst[0], dl), max(worst[1], dt), max(worst[2], float(dd.max()))]
     assert it_g[5] >= 3                                                                 # the 9-px frame really iterates
+    # node-major series wanted: the warp writes the active pixels straight into the compact buffer and pass B writes whole
+    # rows (the bench's schedule) -- same bits as the frame-major rows above, same accumulators as the gather's
+    acc_a = [a.clone() for a in pipe.accumulators()]
+    for split in (F, 7):
+        pipe2 = engine.FramePipeline(1, W, H, n, registration=1)
+        pipe2.set_projection(0, pix)
+        pipe2.set_reference(0, ref)
+        rt = torch.full((n, engine.series_ld(F)), -7.0, dtype=torch.float32, device="cuda")
+        d2 = torch.as_tensor(frames.copy()).cuda()
+        w2 = torch.zeros((F, 1, 6), dtype=torch.float32, device="cuda")
+        for f0 in range(0, F, split):
+            f1 = min(F, f0 + split)
+            pipe2.process(d2[f0:f1], f0, rows_t=rt[:, :F], col0=f0, want_rows=False, warps=w2[f0:f1])
+        got = rt[:, :F].cpu().numpy().T
+        assert np.isnan(got[:, ~ok]).all() and (rt[:, F:] == -7.0).all() and torch.equal(d2, d)
+        if split == F:
+            # one call: the same sub-batch as above, so the same warps -> the same bits, the same accumulators
+            assert torch.equal(w2, warps)
+            assert np.array_equal(got[:, ok].view(np.int32), rows_g[:, ok].view(np.int32))
+            for a, b in zip(pipe2.accumulators(), acc_a):
+                aa, bb = a.cpu().numpy(), b.cpu().numpy()
+                assert np.array_equal(np.isnan(aa), np.isnan(bb)) and np.array_equal(aa[~np.isnan(aa)], bb[~np.isnan(bb)])
+        else:
+            # calls of 7 frames into column blocks of the same rows: other sub-batches -> the double sums of the ECC are
+            # reduced in another order (and the float segments of the column sums start at other rows) -> a warp differs by
+            # ~1e-5 px, far inside the 2e-3 px bar; every row is exact for the warp it reports
+            ww = w2.cpu().numpy()[:, 0].reshape(F, 2, 3)
+            assert np.abs(ww[:, :, :2] - w[:, :, :2]).max() <= 1e-6 and np.abs(ww[:, :, 2] - w[:, :, 2]).max() <= 1e-4
+            for f in range(1, F):
+                img, _ = oracle.fix_hot_pixels(frames[f])
+                want = oracle.project_frame(oracle.warp_affine(img, ww[f], 1), pix, None)
+                assert np.array_equal(got[f, ok].view(np.int32), want[ok].view(np.int32)), (split, f)
+            s2 = pipe2.accumulators()[0].cpu().numpy()
+            assert np.array_equal(s2[ok], got[:, ok].astype(np.float64).sum(0))
     print("1024^2 registration: iterations %s, worst |dM| %.2e, |dt| %.2e px, |dI| %.2f" % (it_g.tolist(), *worst))

@@ -1,6 +1,5 @@
 set -o pipefail
-for fv in "1 0 0" "2 0 0" "0 0 40" "0 0 0"; do
-  set -- $fv
-  echo "== UPSP_ECC_FUSED=$1 UPSP_GAUSS5_VARIANT=$2 CVARIANT=$3"
-  UPSP_ECC_FUSED=$1 UPSP_GAUSS5_VARIANT=$2 bash tools/gpu_ecc_variants.sh "$3" | grep "variant\|gauss\|true"
-done
+mkdir -p gpurun_out/r3h
+python -m pytest tests/test_imageops_gpu.py tests/test_psp_gpu.py -x -q -m gpu > gpurun_out/r3h/tests.log 2>&1; rc=$?; echo "tests rc=$rc"; tail -3 gpurun_out/r3h/tests.log
+[ $rc -eq 0 ] || exit 1
+bash tools/gpu_ecc_variants.sh "0" | grep "variant"

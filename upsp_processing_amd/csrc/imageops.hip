@@ -129,11 +129,11 @@ __global__ void __launch_bounds__(256)
 // in the intermediate image), so the result is bit-identical -- with 1/3 of the HBM traffic
 // (and none for a separate u16 -> f32 conversion).  Not usable in place.
 constexpr int kGaussTW = 64, kGaussTH = 32;
-template <typename SRC, int R>
+template <typename SRC, int R, int TW = kGaussTW, int TH = kGaussTH>
 __global__ void __launch_bounds__(256)
     gauss_fused_kernel(const SRC *__restrict__ src, float *__restrict__ dst, int rows, int cols, FilterCoef fc)
 {
-    constexpr int TW = kGaussTW, TH = kGaussTH, IW = TW + 2 * R, IH = TH + 2 * R;
+    constexpr int IW = TW + 2 * R, IH = TH + 2 * R;
     __shared__ float in[IH][IW + 1];
     __shared__ float hb[IH][TW + 1];
     const size_t npix = (size_t)rows * cols;
@@ -243,6 +243,16 @@ int launch_gauss(const SRC *src, float *dst, float *tmp, int nimg, int rows, int
     if (r >= 1 && r <= 3 && (const void *)src != (const void *)dst && rows > r && cols > r && nimg <= 65535) {
         const dim3 fgrid((unsigned)((cols + kGaussTW - 1) / kGaussTW), (unsigned)((rows + kGaussTH - 1) / kGaussTH),
                          (unsigned)nimg);
+        const int tv = env_int_io("UPSP_GAUSS_TILE", 0);      // (measurement switch: tile shape of the 5 x 5 kernel)
+        if (r == 2 && tv) {
+#define UPSP_GT(W_, H_)                                                                                       \
+    hipLaunchKernelGGL((gauss_fused_kernel<SRC, 2, W_, H_>), dim3((unsigned)((cols + W_ - 1) / W_), (unsigned)((rows + H_ - 1) / H_), \
+                                                                  (unsigned)nimg), block, 0, st, src, dst, rows, cols, fc)
+            if (tv == 1) UPSP_GT(128, 16); else if (tv == 2) UPSP_GT(128, 32); else if (tv == 3) UPSP_GT(256, 16); else UPSP_GT(256, 8);
+#undef UPSP_GT
+            UPSP_HIP_CHECK(hipGetLastError());
+            return UPSP_OK;
+        }
         if (r == 1) hipLaunchKernelGGL((gauss_fused_kernel<SRC, 1>), fgrid, block, 0, st, src, dst, rows, cols, fc);
         else if (r == 2) hipLaunchKernelGGL((gauss_fused_kernel<SRC, 2>), fgrid, block, 0, st, src, dst, rows, cols, fc);
         else hipLaunchKernelGGL((gauss_fused_kernel<SRC, 3>), fgrid, block, 0, st, src, dst, rows, cols, fc);
@@ -366,6 +376,76 @@ __global__ void __launch_bounds__(256)
                     : (uint16_t)0;
         }
         d[i] = o;
+    }
+}
+
+// Registration as the LAST image stage (no patch, no filter) with node-major series wanted: the warped frame is a
+// scratch image only the projection reads, and the projection reads the active pixels (~6 % of a frame).  The warp
+// then writes those pixels straight into the compact [active pixel][frame] buffer of the streamed schedule -- 64
+// pixels x the <= 64 frames of the sub-batch per workgroup, transposed through LDS so that an active pixel's 64 frames
+// leave as one 128-byte piece -- and pass B (node_rows_kernel, whole 4-KB rows, 0.63 of the HBM peak) writes the series
+// once per <= 1024 frames instead of gather_tile_kernel per 64 (0.29).  pix_of_k: pixel of every compact row.
+__global__ void __launch_bounds__(256)
+    amap_pixels_kernel(const uint8_t *__restrict__ flag, const unsigned *__restrict__ tile_off, size_t npix,
+                       unsigned *__restrict__ pix_of_k)
+{
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= npix) return;
+    const unsigned fl = flag[p];
+    if (fl) pix_of_k[tile_off[p / 128] + (fl & 0x7Fu)] = (unsigned)p;
+}
+
+__global__ void __launch_bounds__(256)
+    warp_compact_kernel(const uint16_t *__restrict__ src, int rows, int cols, const EccState *__restrict__ state,
+                        int nframes, int interp, const unsigned *__restrict__ pix_of_k, const unsigned *__restrict__ nact_ptr,
+                        uint16_t *__restrict__ compact, unsigned cpitch, unsigned col0)
+{
+    __shared__ uint16_t tile[64][66];            // [frame][pixel]
+    const unsigned nact = *nact_ptr;
+    const unsigned k0 = blockIdx.x * 64u;
+    if (k0 >= nact) return;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned k = k0 + (unsigned)lane;
+    const bool valid = k < nact;
+    const size_t npix = (size_t)rows * cols;
+    const unsigned p = valid ? pix_of_k[k] : 0u;
+    const int y = (int)(p / (unsigned)cols), x = (int)(p % (unsigned)cols);
+    for (int f = wave; f < nframes; f += 4) {                    // (uniform per wave)
+        const EccState &es = state[f];
+        const uint16_t *s = src + (size_t)f * npix;
+        uint16_t o;
+        if (es.done == 2) {
+            o = s[p];                                            // frame 0 of a run: never registered
+        } else {
+            double M[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) M[i] = es.M[i];
+            const WarpCoord c = warp_coord(M, x, y, interp);
+            if (interp) {
+                const float v = bilinear([&](int yy, int xx) { return (float)s[(size_t)yy * cols + xx]; }, rows, cols, c);
+                const int iv = (int)rintf(v);  // saturate_cast<ushort>(float)
+                o = (uint16_t)max(0, min(65535, iv));
+            } else {
+                o = ((unsigned)c.sx < (unsigned)cols && (unsigned)c.sy < (unsigned)rows) ? s[(size_t)c.sy * cols + c.sx]
+                                                                                          : (uint16_t)0;
+            }
+        }
+        tile[f][lane] = o;
+    }
+    __syncthreads();
+    // 4 threads per pixel, 16 frames (32 bytes) each: an active pixel's frames of this sub-batch are one 128-byte piece
+    const int q = threadIdx.x >> 2, j = threadIdx.x & 3;
+    if (k0 + (unsigned)q < nact) {
+        unsigned w[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int f = 16 * j + 2 * i;
+            const unsigned a = f < nframes ? tile[f][q] : 0u, b = f + 1 < nframes ? tile[f + 1][q] : 0u;
+            w[i] = a | (b << 16);
+        }
+        uint16_t *dst = compact + (size_t)(k0 + (unsigned)q) * cpitch + col0 + 16u * (unsigned)j;
+        if (16 * j < nframes) *reinterpret_cast<uint4 *>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
+        if (16 * j + 8 < nframes) *reinterpret_cast<uint4 *>(dst + 8) = make_uint4(w[4], w[5], w[6], w[7]);
     }
 }
 
@@ -1535,38 +1615,42 @@ __global__ void __launch_bounds__(256)
     if (es.iters >= max_iters || !(fabs(es.rho - es.last_rho) >= eps)) es.done = 1;
 }
 
-__global__ void ecc_init_kernel(EccState *state, int nframes, long long first_frame)
+__global__ void ecc_init_kernel(EccState *state, int nframes, long long first_frame, double eps)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= nframes) return;
     EccState &es = state[f];
     es.M[0] = 1; es.M[1] = 0; es.M[2] = 0; es.M[3] = 0; es.M[4] = 1; es.M[5] = 0;  // eye(2,3)
     es.rho = -1;
-    es.last_rho = 0;  // set by the host wrapper to -eps
+    es.last_rho = -eps;
     es.iters = 0;
     es.done = (first_frame + f == 0) ? 2 : 0;  // frame 0 is not registered (psp_process.cpp:1777)
     es.band = 3;                               // identity
 }
 
-__global__ void ecc_set_last_rho(EccState *state, int nframes, double eps)
-{
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f < nframes) state[f].last_rho = -eps;
-}
-
-__global__ void ecc_count_active(const EccState *state, int nframes, int *out)
+// one wave: out[0] frames still iterating, [1] frames in error, [2] frame-iterations so far (statistics), [3] iterations of
+// the frame that needed most (sizes the next sub-batch's first burst).  Writes all four: nothing to clear beforehand.
+__global__ void __launch_bounds__(64) ecc_count_active(const EccState *state, int nframes, int *out)
 {
     int active = 0, err = 0, iters = 0, most = 0;
-    for (int f = threadIdx.x; f < nframes; f += blockDim.x) {
+    for (int f = threadIdx.x; f < nframes; f += 64) {
         active += state[f].done == 0;
         err += state[f].done < 0;
         iters += state[f].iters;
         most = max(most, state[f].iters);
     }
-    atomicAdd(&out[0], active);
-    atomicAdd(&out[1], err);
-    atomicAdd(&out[2], iters);       // frame-iterations so far (statistics)
-    atomicMax(&out[3], most);        // iterations of the frame that needed most (sizes the next sub-batch's first burst)
+    for (int off = 32; off > 0; off >>= 1) {
+        active += __shfl_down(active, off);
+        err += __shfl_down(err, off);
+        iters += __shfl_down(iters, off);
+        most = max(most, __shfl_down(most, off));
+    }
+    if (threadIdx.x == 0) {
+        out[0] = active;
+        out[1] = err;
+        out[2] = iters;
+        out[3] = most;
+    }
 }
 
 __global__ void ecc_export_warps(const EccState *state, int nframes, float *warps, int stride, int32_t *iters, int istride)
@@ -1950,8 +2034,7 @@ static int run_ecc(FrameScratch *s, const float *tmpl_blur, const uint16_t *fram
     const int fused_env = env_int_io("UPSP_ECC_FUSED", 0);
     const bool fused = fused_env == 1 && rows >= 5 && cols >= 5;
     const dim3 g1((nb + 63) / 64), b1(64);
-    hipLaunchKernelGGL(ecc_init_kernel, g1, b1, 0, st, s->state, nb, (long long)first_frame);
-    hipLaunchKernelGGL(ecc_set_last_rho, g1, b1, 0, st, s->state, nb, eps);
+    hipLaunchKernelGGL(ecc_init_kernel, g1, b1, 0, st, s->state, nb, (long long)first_frame, eps);
     int it = 0;
     if (fused) {
         int nslots = 0;
@@ -2052,7 +2135,6 @@ static int run_ecc(FrameScratch *s, const float *tmpl_blur, const uint16_t *fram
                                (const double *)s->partial, nb, nblocks_total, max_iters, eps, rows, cols);
         }
         int h[4] = {0, 0, 0, 0};
-        UPSP_HIP_CHECK(hipMemsetAsync(s->counter, 0, 4 * sizeof(int), st));
         hipLaunchKernelGGL(ecc_count_active, dim3(1), dim3(64), 0, st, (const EccState *)s->state, nb,
                            s->counter);
         UPSP_HIP_CHECK(hipMemcpyAsync(h, s->counter, sizeof(h), hipMemcpyDeviceToHost, st));
@@ -2129,6 +2211,14 @@ __global__ void __launch_bounds__(256)
             list[1 + block_base + wave_cnt[k][wave] + (unsigned)__popcll(m[k] & ((1ull << lane) - 1ull))] = base + 256u * k;
 }
 
+int launch_amap_pixels(const uint8_t *d_flag, const unsigned *d_tile_off, size_t npix, unsigned *d_pix_of_k, hipStream_t st)
+{
+    hipLaunchKernelGGL(amap_pixels_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, d_flag, d_tile_off, npix,
+                       d_pix_of_k);
+    UPSP_HIP_CHECK(hipGetLastError());
+    return UPSP_OK;
+}
+
 int launch_pixel_list(const int32_t *d_pix, size_t nnodes, uint8_t *d_mask, unsigned *d_list, size_t npix, hipStream_t st)
 {
     UPSP_HIP_CHECK(hipMemsetAsync(d_mask, 0, npix, st));
@@ -2145,7 +2235,8 @@ int launch_pixel_list(const int32_t *d_pix, size_t nnodes, uint8_t *d_mask, unsi
 int run_frame_stages(FrameScratch *s, int cam, const uint16_t *d_frames, int nb, int64_t first_frame,
                      int rows, int cols, const upsp_pipeline_opts &opts, const float *d_ref,
                      const PatchTables *patches, float *d_warps, int32_t *d_iters, int ncams,
-                     const unsigned *d_read_list, const void **img_out, int *is_f32_out, hipStream_t st)
+                     const unsigned *d_read_list, const WarpCompact *wc, const void **img_out, int *is_f32_out,
+                     hipStream_t st)
 {
     const size_t npix = (size_t)rows * cols;
     const uint16_t *cur = d_frames;
@@ -2159,7 +2250,12 @@ int run_frame_stages(FrameScratch *s, int cam, const uint16_t *d_frames, int nb,
         int rc = run_ecc(s, s->tmpl[cam], d_frames, nb, first_frame, rows, cols, opts.ecc_max_iters,
                          opts.ecc_eps, st);
         if (rc != UPSP_OK) return rc;
-        {
+        if (wc) {      // registration is the last image stage and node-major series are wanted: straight into the compact buffer
+            KTimed kt("warp_u16_kernel", st);
+            hipLaunchKernelGGL(warp_compact_kernel, dim3((unsigned)((wc->max_active + 63) / 64)), block, 0, st, d_frames, rows,
+                               cols, (const EccState *)s->state, nb, opts.interp, wc->pix_of_k, wc->nact, wc->compact,
+                               wc->cpitch, wc->col0);
+        } else {
             KTimed kt("warp_u16_kernel", st);
             const bool listed = !opts.patch && !opts.filter && d_read_list;
             // (the list is short -- its length is only known on the device: 64 workgroups per frame stride over it)

@@ -85,6 +85,16 @@ void frame_scratch_ecc_stats(const FrameScratch *s, unsigned long long *frame_it
 
 struct upsp_pipeline_opts;
 namespace upsp {
+// target of the warp when registration is the last image stage of the streamed schedule: the compact
+// [active pixel][frame] buffer (column col0 on, pitch cpitch); pix_of_k = pixel of every compact row,
+// *nact = rows in use (device), max_active = bound of it (grid size)
+struct WarpCompact {
+    const unsigned *pix_of_k = nullptr, *nact = nullptr;
+    size_t max_active = 0;
+    uint16_t *compact = nullptr;
+    unsigned cpitch = 0, col0 = 0;
+};
+int launch_amap_pixels(const uint8_t *d_flag, const unsigned *d_tile_off, size_t npix, unsigned *d_pix_of_k, hipStream_t st);
 // register -> patch -> filter for `nb` frames of camera `cam` (psp_process.cpp:1776-1807).
 // *img_out / *is_f32_out: image the gather reads.  d_warps: [nb][ncams][6] or null; d_iters: [nb][ncams] or null.
 // d_read_list (may be null): [1 + rows*cols] words, count and then the pixels the gather will read.  When registration
@@ -92,7 +102,8 @@ namespace upsp {
 int run_frame_stages(FrameScratch *s, int cam, const uint16_t *d_frames, int nb,
                      int64_t first_frame, int rows, int cols, const upsp_pipeline_opts &opts,
                      const float *d_ref, const PatchTables *patches, float *d_warps, int32_t *d_iters, int ncams,
-                     const unsigned *d_read_list, const void **img_out, int *is_f32_out, hipStream_t st);
+                     const unsigned *d_read_list, const WarpCompact *wc, const void **img_out, int *is_f32_out,
+                     hipStream_t st);
 // d_list[0] = number of distinct pixels with a node, d_list[1..] = those pixels (any order); d_mask: npix bytes of scratch
 int launch_pixel_list(const int32_t *d_pix, size_t nnodes, uint8_t *d_mask, unsigned *d_list, size_t npix, hipStream_t st);
 }  // namespace upsp

@@ -56,6 +56,8 @@ struct upsp_pipeline {
     // generation of the active-pixel map (bumped by every rebuild / invalidation): a prescan is only consumed by a
     // process call that still sees the map its compact buffer was laid out with
     uint64_t map_gen = 0, prescan_gen = 0;
+    unsigned *d_pix_of_k = nullptr;     // pixel of every compact row (registration straight into the compact buffer)
+    uint64_t pixk_gen = ~0ull;
     // the same per camera for the multi-camera streamed schedule
     uint8_t *m_aflag[kMaxCams] = {nullptr};
     unsigned *m_tile_off[kMaxCams] = {nullptr};
@@ -218,6 +220,7 @@ void upsp_pipeline_destroy(upsp_pipeline *p)
     free_dev(p->d_tile_order);
     free_dev(p->d_node_k);
     free_dev(p->d_compact);
+    free_dev(p->d_pix_of_k);
     free_dev(p->d_changes);
     free_dev(p->d_head);
     free_dev(p->d_next);
@@ -678,6 +681,83 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
         }
         return rc;
     }
+    // Registration as the last image stage, one camera, node-major series: per 64-frame sub-batch hot-pixel repair ->
+    // ECC -> warp of the active pixels straight into the compact buffer; per <= 1024 frames ONE pass B (whole rows)
+    // instead of a gather per sub-batch.  (UPSP_REG_STREAMED=0: warp the pixel list into scratch frames + gather.)
+    static const bool reg_streamed_env = !std::getenv("UPSP_REG_STREAMED") || std::atoi(std::getenv("UPSP_REG_STREAMED")) != 0;
+    const bool reg_streamed = reg_streamed_env && p->ncams == 1 && !p->d_weight[0] && p->opts.registration && !need_f32 &&
+                              !d_rows && (d_rows_t || d_rows_t16) && !p->d_src && (npix % 2) == 0 && npix < 0xFFFFFFFFull &&
+                              !overlap && p->nnodes < ((size_t)1 << 31) && fused_mode != 2;
+    if (reg_streamed) {
+        if (!p->tilemap_valid) {
+            rc = streamed_map(p, p->d_pix[0], npix, st);
+            if (rc != UPSP_OK) return rc;
+            p->node_k_valid = true;
+            p->hint_active = false;
+        }
+        if (!p->node_k_valid) {
+            rc = launch_amap_nodes(p->d_pix[0], p->nnodes, p->d_aflag, p->d_tile_off, p->d_node_k, st);
+            if (rc != UPSP_OK) return rc;
+            p->node_k_valid = true;
+        }
+        const size_t nact_max = std::max<size_t>(std::min(p->nnodes, npix), 1);
+        if (!p->d_pix_of_k) UPSP_HIP_CHECK(hipMalloc(&p->d_pix_of_k, sizeof(unsigned) * nact_max));
+        if (p->pixk_gen != p->map_gen) {
+            rc = launch_amap_pixels(p->d_aflag, p->d_tile_off, npix, p->d_pix_of_k, st);
+            if (rc != UPSP_OK) return rc;
+            p->pixk_gen = p->map_gen;
+        }
+        int S = 0;
+        unsigned cp = 0;
+        rc = streamed_buffers(p, npix, nframes, st, &S, &cp);
+        if (rc != UPSP_OK) return rc;
+        rc = upsp::frame_scratch_ensure(&p->scratch, 1, B, p->height, p->width, true, false);
+        if (rc != UPSP_OK) return rc;
+        PipelineGather g;
+        g.ncams = 1;
+        g.npix = npix;
+        g.nnodes = p->nnodes;
+        g.skipped = p->d_skipped;
+        g.rowmap = p->d_rowmap;
+        g.sum = p->d_sum;
+        g.sumsq = p->d_sumsq;
+        g.pix[0] = p->d_pix[0];
+        g.ld_t = ld_t;
+        WarpCompact wc;
+        wc.pix_of_k = p->d_pix_of_k;
+        wc.nact = p->d_tile_off + tilemap_tiles(npix);
+        wc.max_active = nact_max;
+        wc.compact = p->d_compact;
+        wc.cpitch = cp;
+        uint16_t *fr = d_frames[0];
+        for (int s0 = 0; s0 < nframes && rc == UPSP_OK; s0 += S) {
+            const int ns = std::min(S, nframes - s0);
+            for (int f0 = s0; f0 < s0 + ns && rc == UPSP_OK; f0 += B) {
+                const int nb = std::min(B, s0 + ns - f0);
+                uint16_t *frames = fr + (size_t)f0 * npix;
+                if (p->opts.hot_enable) {  // psp_process.cpp:1772
+                    rc = ensure_hot(p, nb);
+                    if (rc == UPSP_OK)
+                        rc = launch_hot_fix(frames, nb, p->height, p->width, p->opts.hot_thresh, p->opts.hot_min_change,
+                                            p->opts.hot_max, p->d_hot_count, p->d_hot_pos, nullptr, st);
+                    if (rc != UPSP_OK) break;
+                }
+                wc.col0 = (unsigned)(f0 - s0);
+                const void *img = nullptr;
+                int is_f32 = 0;
+                rc = upsp::run_frame_stages(p->scratch, 0, frames, nb, first_frame + f0, p->height, p->width, p->opts, p->d_ref[0],
+                                            nullptr, d_warps ? d_warps + (size_t)f0 * 6 : nullptr,
+                                            p->d_ecc_iters ? p->d_ecc_iters + f0 : nullptr, 1, nullptr, &wc, &img, &is_f32, st);
+            }
+            if (rc != UPSP_OK) break;
+            g.nframes = ns;
+            g.img[0] = fr + (size_t)s0 * npix;
+            g.rows_t = d_rows_t ? d_rows_t + col0 + s0 : nullptr;
+            g.rows_t16 = d_rows_t16 ? d_rows_t16 + col0 + s0 : nullptr;
+            rc = launch_node_rows(g, p->d_node_k, p->d_compact, cp, st);
+        }
+        return rc;
+    }
     // Several cameras (weights allowed): the same two passes with one active-pixel map and one whole-call compact
     // buffer per camera; pass B (node_rows_multi_kernel) sums the cameras in order with their weights.
     const bool multi_ok = p->ncams > 1 && !need_stage && !d_rows && d_rows_t && !d_rows_t16 && !p->d_src &&
@@ -843,7 +923,7 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
                                             p->patches[c],
                                             d_warps ? d_warps + ((size_t)f0 * p->ncams) * 6 : nullptr,
                                             p->d_ecc_iters ? p->d_ecc_iters + (size_t)f0 * p->ncams : nullptr,
-                                            p->ncams, read_list, &img, &is_f32, st);
+                                            p->ncams, read_list, nullptr, &img, &is_f32, st);
                 if (rc != UPSP_OK) break;
             }
             g.img[c] = img;
