@@ -8,9 +8,9 @@ tag=$1; shift
 out=gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --no-cpu-baseline --no-reraycast "$@" > $out/trace.log 2>&1 || exit 1
+timeout -k 10 ${PROFILE_TIMEOUT:-300} rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --no-cpu-baseline --no-reraycast "$@" > $out/trace.log 2>&1 || exit 1
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/$c -- python3 bench.py --no-cpu-baseline --no-reraycast "$@" > $out/$c.log 2>&1 || exit 1
+  timeout -k 10 ${PROFILE_TIMEOUT:-300} rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/$c -- python3 bench.py --no-cpu-baseline --no-reraycast "$@" > $out/$c.log 2>&1 || exit 1
 done
 python3 - $out "$@" <<'PY'
 import csv, glob, sys, collections, json, re, shutil
@@ -46,6 +46,10 @@ traffic = {}
 for name, v in res.items():
     key, stream = bench_name.get(name, (None, False))
     if name.startswith("node_rows_kernel"): key, stream = "node_rows_kernel", True
+    if name.startswith("node_rows_multi_kernel"): key, stream = "node_rows_multi_kernel", True
+    if name.startswith("ecc_cols_kernel") or name.startswith("ecc_sums2_kernel"): key, stream = "ecc_sums_kernel", True
+    if name.startswith("gauss_fused_kernel<unsigned short"): key, stream = "gauss_pass_kernels", True
+    if name.startswith("warp_compact_kernel"): key, stream = "warp_u16_kernel", False
     if name.startswith("gather_tile"): key, stream = "gather_tile_kernel", True
     if key and "FETCH_SIZE_KB_per_launch" in v and "WRITE_SIZE_KB_per_launch" in v:
         traffic[key] = ((2 if stream else 1) * v["FETCH_SIZE_KB_per_launch"] + v["WRITE_SIZE_KB_per_launch"]) * 1024
@@ -57,9 +61,9 @@ for d in ("trace", "FETCH_SIZE", "WRITE_SIZE"):      # raw traces are large: kee
     shutil.rmtree(out + "/" + d, ignore_errors=True)
 for k, v in res.items(): print(k, v)
 PY
-UPSP_BENCH_TRAFFIC_JSON=$out/summary.json timeout -k 10 400 python3 bench.py "$@" > $out/bench_line.json 2> $out/bench_line.err || exit 1
+UPSP_BENCH_TRAFFIC_JSON=$out/summary.json timeout -k 10 ${BENCH_TIMEOUT:-500} python3 bench.py "$@" > $out/bench_line.json 2> $out/bench_line.err || exit 1
 python3 - $out <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1] + "/bench_line.json").read().strip().splitlines()[-1])
-print({k: d[k] for k in ("value", "ms_per_step", "mrays_per_s", "breakdown_ms")}); print(d["roofline"]); print(d.get("cpu_baseline")); print(d.get("parity"))
+print({k: d.get(k) for k in ("value", "ms_per_step", "mrays_per_s", "breakdown_ms")}); print(d["roofline"]); print(d.get("cpu_baseline")); print(d.get("parity"))
 PY

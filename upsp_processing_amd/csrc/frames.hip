@@ -1226,7 +1226,9 @@ __global__ void __launch_bounds__(256)
     __shared__ int s_k[NR][MC];
     __shared__ float s_w[NR][MC];
     __shared__ int s_row[NR], s_kind[NR];       // kind: 0 data, 1 no camera sees the node (NaN), 2 reads no pixel (0)
-    __shared__ double p_s[NR][WPR], p_ss[NR][WPR];
+    // per row and wave four partial sums (one per 16-lane DPP row): the last two reduction steps are done by the thread that
+    // owns the node's accumulators, from LDS, instead of 16 v_readlane per wave and row
+    __shared__ double p_s[NR][WPR * 4], p_ss[NR][WPR * 4];
     const int ncams = NC ? NC : a.ncams;
     const unsigned n0 = blockIdx.x * (unsigned)NR;
     const int t = threadIdx.x;
@@ -1296,8 +1298,9 @@ __global__ void __launch_bounds__(256)
             if (c < ncams && s_k[r][c] >= 0) {
                 const float w = s_w[r][c];
                 const uint2 q = tt[j][c];
-                const float v[4] = {0.0f + w * (float)(q.x & 0xFFFFu), 0.0f + w * (float)(q.x >> 16),
-                                    0.0f + w * (float)(q.y & 0xFFFFu), 0.0f + w * (float)(q.y >> 16)};
+                // (the gather forms 0.0f + w * pixel: with acc starting at +0 the extra +0 changes no bit of the sum)
+                const float v[4] = {w * (float)(q.x & 0xFFFFu), w * (float)(q.x >> 16),
+                                    w * (float)(q.y & 0xFFFFu), w * (float)(q.y >> 16)};
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq) acc[qq] = acc[qq] + v[qq];
             }
@@ -1311,11 +1314,9 @@ __global__ void __launch_bounds__(256)
             }
         s = group16_sum(s);
         ss = group16_sum(ss);
-        const double ws = (readlane_f64<0>(s) + readlane_f64<16>(s)) + (readlane_f64<32>(s) + readlane_f64<48>(s));
-        const double wss = (readlane_f64<0>(ss) + readlane_f64<16>(ss)) + (readlane_f64<32>(ss) + readlane_f64<48>(ss));
-        if (lane == 0) {
-            p_s[r][wr] = ws;
-            p_ss[r][wr] = wss;
+        if ((lane & 15) == 0) {
+            p_s[r][wr * 4 + (lane >> 4)] = s;
+            p_ss[r][wr * 4 + (lane >> 4)] = ss;
         }
         if (!stored) continue;
         float *dst = rows_t + (long long)row * ld_t + f0;
@@ -1340,9 +1341,9 @@ __global__ void __launch_bounds__(256)
             } else if (kind == 0) {
                 double as = 0.0, ass = 0.0;
 #pragma unroll
-                for (int q = 0; q < WPR; ++q) {
-                    as += p_s[t][q];
-                    ass += p_ss[t][q];
+                for (int q = 0; q < WPR; ++q) {        // (the order the readlane form used: rows of a wave, then the waves)
+                    as += (p_s[t][4 * q] + p_s[t][4 * q + 1]) + (p_s[t][4 * q + 2] + p_s[t][4 * q + 3]);
+                    ass += (p_ss[t][4 * q] + p_ss[t][4 * q + 1]) + (p_ss[t][4 * q + 2] + p_ss[t][4 * q + 3]);
                 }
                 sum[n] += as;
                 sumsq[n] += ass;
@@ -1861,7 +1862,9 @@ int launch_node_rows_multi(const PipelineGather &g, const int32_t *const *d_node
         else UPSP_NRM(LPR, 2, 0);                                                                             \
     } while (0)
     // sweeps per workgroup (UPSP_MULTI_ROWS, measurement switch; 4 cameras, 2.5 M nodes, 1000 frame sets: 2 sweeps 4.28 ms,
-    // 4: 3.35, 8: 3.16 -- consecutive nodes share pixels, and the per-workgroup staging is paid once per 8 rows)
+    // 4: 3.35, 8: 3.16 -- consecutive nodes share pixels, and the per-workgroup staging is paid once per 8 rows; with the
+    // leaner sums 2.97.  Tried and dropped: row / series indices through v_readfirstlane (scalar addresses, SGPR-base
+    // loads) -- the scalar branches around the loads serialise them: 3.51 ms)
     static const int rows_env = std::getenv("UPSP_MULTI_ROWS") ? std::atoi(std::getenv("UPSP_MULTI_ROWS")) : 8;
     if (g.nframes > 512) { if (rows_env == 8) UPSP_NRM_NC(256, 8); else if (rows_env == 2) UPSP_NRM_NC(256, 2); else UPSP_NRM_NC(256, 4); }
     else if (g.nframes > 256) UPSP_NRM_NC(128, 4);
