@@ -64,6 +64,10 @@ def parse():
                     help="run the chunked / pipelined-exchange frame loop of the N>1 path on one GPU")
     ap.add_argument("--f32-wire", action="store_true",
                     help="N>1 / --force-chunked: exchange the series as f32 instead of u16")
+    ap.add_argument("--row-wire", action="store_true",
+                    help="N>1 / --force-chunked: the node ROWS travel (packed u16 rows of the nodes some camera sees).  Default: the "
+                         "series of the ACTIVE PIXELS travel (a third of the bytes on the bench model: several nodes read one pixel) "
+                         "and the owner of a node runs pass B over all frames of the run")
     ap.add_argument("--wire12", action="store_true",
                     help="N>1 (RCCL): the u16 series packed to 12 bits for the wire (3 bytes per 2 frames; 12-bit cameras)")
     ap.add_argument("--two-kernel", action="store_true",
@@ -734,6 +738,7 @@ def main():
     # one camera, no weights, no filter: the series values are exact 16-bit integers, so the
     # travelling rows are produced and sent as u16 (half the bytes) and widened by the receiver
     u16_wire = chunked and not a.f32_wire
+    pixel_wire = chunked and not a.row_wire and not a.f32_wire
     chunk_bufs = ([torch.empty((N, exch.my_chunk(k)[1]), dtype=torch.uint16 if u16_wire else torch.float32,
                                device="cuda") for k in range(K)] if chunked else None)
     ev_log = []
@@ -762,6 +767,17 @@ def main():
             main.wait_stream(side)
         if not chunked:
             pipe.process(frames, first_frame=rank * F, rows_t=rows_t, want_rows=False)
+        elif pixel_wire:
+            # the sender runs pass A (+ hot-pixel repair) per chunk and ships the active pixels' series; the owner of a node
+            # runs pass B over all frames (exch.finish_pixels below)
+            exch.k = 0
+            tab = pipe.pixel_series(None)           # node -> compact row of this projection
+            exch.set_pixels(tab["node_k"], engine.skipped_nodes(proj["pix"], want_count=False)[0], assume_same=not first_step[0])
+            first_step[0] = False
+            for k in range(K):
+                c0, fc = exch.my_chunk(k)
+                ps = pipe.pixel_series(frames[c0:c0 + fc]) if fc else tab
+                exch.submit_pixels(ps)
         else:
             exch.k = 0
             # rows of nodes no camera sees are NaN on every rank: they do not travel, and pass B writes
@@ -780,8 +796,10 @@ def main():
                 exch.submit(buf, packed=True)
         e[2].record()
         s, ss = pipe.accumulators()
+        if pixel_wire:
+            exch.finish_pixels(s, ss)             # pass B of this rank's nodes over all frames: series + its slice of the sums
         D.allreduce_sums(s, ss)
-        if chunked:
+        if chunked and not pixel_wire:
             exch.finish()
         avg, rms = pipe.finalize(F * world)
         e[3].record()
@@ -847,7 +865,7 @@ def main():
     my_chunks = [exch.my_chunk(k)[1] for k in range(K)] if chunked else [F]
     gather_launches = sum(-(-c // 64) for c in my_chunks)
     row_launches = sum(-(-c // 1024) for c in my_chunks)
-    series_rows = exch.packed_rows() if chunked else N
+    series_rows = (exch.pixel_rows()[0] if pixel_wire else exch.packed_rows()) if chunked else N
     series_esz = 2 if u16_wire else 4
     npx = size * size
     per_step_bytes = {
@@ -877,6 +895,9 @@ def main():
     # rays touches a fraction of it, and it stays cache-resident between the passes)
     per_step_bytes["projection_kernel<primary>"] = primary_rays * 40
     del per_step_bytes["projection_kernel<retry>"]
+    if pixel_wire:       # pass B runs on the owner of the nodes, over all frames of the run, f32 rows
+        nn_me, f_all = shard.my_nodes[1], F * world
+        per_step_bytes["node_rows_kernel"] = f_all * 4 * nn_me + (-(-f_all // 1024)) * 8 * nn_me
     if a.registration:
         st = pipe.ecc_stats()            # average ECC iterations per frame over every step run so far
         per_step_bytes["ecc_sums_kernel"] = st["frame_iterations"] / max(st["frames"], 1) * F * 8 * npx
@@ -946,7 +967,8 @@ def main():
                                      "SURVEY 8(d): model intensity x 24 fiducial discs, background 60, noise 8, "
                                      "<= 3 hot pixels in 1 % of the frames"),
                    "parallelism": "frames sharded x%d" % world, "schedule": sched,
-                   **({"exchange": "%d chunks, visible rows as %s" % (K, ("u16 packed to 12 bit" if a.wire12 else "u16") if u16_wire else "f32")}
+                   **({"exchange": "%d chunks, %s as %s" % (K, "active-pixel series" if pixel_wire else "visible rows",
+                                                            ("u16 packed to 12 bit" if a.wire12 else "u16") if u16_wire else "f32")}
                       if chunked else {})},
         "mrays_per_s": mrays, "mrays_per_s_kind": "reference-equivalent (rays the reference casts / build time)",
         "rays_per_step": nrays, "rays_cast_per_step": primary_rays + n_retry_rays,
@@ -968,11 +990,13 @@ def main():
         wire_bytes = 1.5 if (u16_wire and a.wire12) else series_esz
         xb = exch.exchange_bytes()
         out["exchange_bytes_per_step"] = {
-            "travelling_rows": int(series_rows), "frames_per_rank": F, "wire_bytes_per_value": wire_bytes,
+            "travelling_rows": int(series_rows), "what_travels": "active-pixel series" if pixel_wire else "node rows",
+            "frames_per_rank": F, "wire_bytes_per_value": wire_bytes,
             "packed_series_bytes_per_rank": int(series_rows * F * wire_bytes),
             "leaves_the_gpu_at_8_ranks": int(series_rows * F * wire_bytes * 7 / 8),
             "sent_to_other_ranks_this_run": None if xb is None else xb[0],
-            "transport": "C ABI upsp_exchange_* over RCCL" if xb is not None else ("torch.distributed (%s)" % backend if world > 1 else "local scatter (one rank)")}
+            "transport": ("C ABI upsp_exchange_* over RCCL" if (world > 1 or force_coll) else "C ABI upsp_exchange_*, one rank in process (device copies)")
+                         if xb is not None else "torch.distributed (%s)" % backend}
     if a.registration:
         out["ecc_iterations_per_frame"] = ecc_iters_per_frame
     if world == 1 and not a.registration and not a.no_reraycast:
@@ -1071,6 +1095,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     if exch is not None:
+        exch.verify()                   # (the timer-on steps made assume_same claims too)
         exch.close()
     if world > 1 or force_coll:
         D.shutdown()

@@ -549,6 +549,32 @@ int upsp_exchange_finish(upsp_exchange *x, float *d_series, int64_t ld, void *st
 int upsp_exchange_verify(upsp_exchange *x, void *stream);
 int upsp_exchange_bytes(const upsp_exchange *x, uint64_t *sent, uint64_t *received);
 
+/* The same exchange with the series of the ACTIVE PIXELS on the wire instead of the node rows (plain one-camera path:
+ * a node's series is its pixel's, and a model finer than the pixel grid has several nodes per pixel -- the bench model
+ * 190 k travelling nodes on 66 k pixels).  Every destination receives the pixels its node slice reads, each once, and
+ * runs pass B (the series + accumulators of ITS nodes over ALL frames) itself:
+ *   upsp_pipeline_pixel_series  pass A alone: the REPAIRED series of every active pixel over `nframes` (<= 1024) frames
+ *                         in the pipeline's compact buffer [active pixel][*cpitch] u16 (frames repaired in place like
+ *                         fix_hot_pixels); *d_node_k [nnodes]: compact row of every node (< 0: none)
+ *   upsp_exchange_set_pixels    which pixel rows go where, from d_node_k (identical on every rank) and the skipped nodes
+ *                         (one host read per projection; assume_same as above)
+ *   upsp_exchange_submit_pixels chunk k out of the sender's compact buffer (wire 2: u16, 12: packed to 12 bits)
+ *   upsp_exchange_finish_pixels places what arrived and runs pass B: d_series [nodes of this rank][ld >= F] f32 with NaN
+ *                         rows for the skipped nodes; d_sum_mine / d_sumsq_mine [nodes of this rank] gain the sums over all
+ *                         frames (pass the slice of the full-length accumulators: the other ranks' slices stay zero, and
+ *                         upsp_allreduce_sums then delivers the complete vectors like in the row mode)
+ *   upsp_rows_from_pixel_series pass B alone (used by the above): series and accumulators of nnodes nodes from pixel series */
+int upsp_pipeline_pixel_series(upsp_pipeline *pipe, uint16_t *d_frames, int nframes, void *stream, const uint16_t **d_compact,
+                               uint32_t *cpitch, const int32_t **d_node_k, const uint32_t **d_nactive);
+int upsp_rows_from_pixel_series(const uint16_t *d_compact, uint32_t cpitch, const int32_t *d_node_k, const uint8_t *d_skipped,
+                                size_t nnodes, int64_t nframes, float *d_rows_t, int64_t ld, double *d_sum, double *d_sumsq,
+                                void *stream);
+int upsp_exchange_set_pixels(upsp_exchange *x, const int32_t *d_node_k, const uint8_t *d_skipped, int assume_same, void *stream);
+int upsp_exchange_pixel_rows(const upsp_exchange *x, int64_t *rows_out, int64_t *rows_in);
+int upsp_exchange_submit_pixels(upsp_exchange *x, const uint16_t *d_compact, uint32_t cpitch, int wire, void *stream);
+int upsp_exchange_finish_pixels(upsp_exchange *x, float *d_series, int64_t ld, double *d_sum_mine, double *d_sumsq_mine,
+                                void *stream);
+
 /* ======================================================================== *
  *  4.  Measurement support (no reference counterpart; the reference only has
  *      psp::BlockTimer / timedBarrierPoint wall-clock prints, pspTimer.h:10-41)

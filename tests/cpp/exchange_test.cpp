@@ -2,6 +2,7 @@
 // (cpp/exec/psp_process.cpp:707-771, 1866-1872): communicator -> exchange -> set_skipped -> chunks -> finish,
 // plus the all-reduce of the accumulators.
 //   exchange_test local W         W ranks in this process on one GPU (device-to-device copies in place of the links)
+//   exchange_test pixels W        the pixel-series mode (the owners of the nodes run pass B) with W local ranks
 //   exchange_test rccl1           a one-rank RCCL communicator (RCCL refuses two ranks on one GPU)
 //   exchange_test rccl RANK WORLD IDFILE   one rank of a real multi-GPU job (rank 0 writes the id file)
 // Truth: series(n, f) = (31 n + 7 f) mod 4096 for the nodes that travel, NaN for every 5th node (no camera sees it).
@@ -119,6 +120,106 @@ static void prepare(RankState &r, int rank)
     HIPCHECK(hipMemset(r.d_series, 0x7b, sizeof(float) * (size_t)(r.nn > 0 ? r.nn : 1) * F));
 }
 
+// ---- pixel-series mode: A active pixels, node n reads pixel (7 n) mod A (every 9th node: none), pixel series
+// px(k, f) = (13 k + 5 f) mod 4096
+static const int64_t A = 211;
+static int32_t node_pixel(int64_t n) { return n % 9 == 4 ? -1 : (int32_t)((7 * n) % A); }
+static unsigned px(int64_t k, int64_t f) { return (unsigned)((13 * k + 5 * f) % 4096); }
+
+static int run_pixels(int W)
+{
+    int bad = 0;
+    std::vector<uint8_t> sk(N);
+    std::vector<int32_t> nk(N);
+    for (int64_t n = 0; n < N; ++n) {
+        sk[n] = skipped(n) ? 1 : 0;
+        nk[n] = node_pixel(n);
+    }
+    uint8_t *d_sk = nullptr;
+    int32_t *d_nk = nullptr;
+    HIPCHECK(hipMalloc(&d_sk, N));
+    HIPCHECK(hipMalloc(&d_nk, sizeof(int32_t) * N));
+    HIPCHECK(hipMemcpy(d_sk, sk.data(), N, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(d_nk, nk.data(), sizeof(int32_t) * N, hipMemcpyHostToDevice));
+    for (int wire : {2, 12}) {
+        std::vector<upsp_comm *> comms(W);
+        CHECK(upsp_comm_create_local(W, comms.data()));
+        std::vector<RankState> ranks(W);
+        std::vector<std::vector<void *>> bufs(W);
+        for (int r = 0; r < W; ++r) {
+            ranks[r].comm = comms[r];
+            CHECK(upsp_exchange_create(comms[r], F, N, K, &ranks[r].x));
+            CHECK(upsp_exchange_layout(ranks[r].x, &ranks[r].f0, &ranks[r].nf, &ranks[r].n0, &ranks[r].nn));
+            HIPCHECK(hipMalloc(&ranks[r].d_sum, sizeof(double) * N));
+            HIPCHECK(hipMalloc(&ranks[r].d_sumsq, sizeof(double) * N));
+            HIPCHECK(hipMemset(ranks[r].d_sum, 0, sizeof(double) * N));
+            HIPCHECK(hipMemset(ranks[r].d_sumsq, 0, sizeof(double) * N));
+            HIPCHECK(hipMalloc(&ranks[r].d_series, sizeof(float) * (size_t)(ranks[r].nn > 0 ? ranks[r].nn : 1) * F));
+            CHECK(upsp_exchange_set_pixels(ranks[r].x, d_nk, d_sk, 0, nullptr));
+        }
+        for (int r = 0; r < W; ++r)                              // every rank submits its chunks: its own compact buffer per chunk
+            for (int k = 0; k < K; ++k) {
+                int64_t c0 = 0, fc = 0;
+                CHECK(upsp_exchange_chunk(ranks[r].x, k, &c0, &fc));
+                const unsigned cp = (unsigned)((fc + 63) / 64 * 64 + 64);
+                std::vector<uint16_t> h((size_t)A * cp, 0xFFFF);
+                for (int64_t a = 0; a < A; ++a)
+                    for (int64_t f = 0; f < fc; ++f) h[(size_t)a * cp + f] = (uint16_t)px(a, ranks[r].f0 + c0 + f);
+                void *d = nullptr;
+                HIPCHECK(hipMalloc(&d, h.size() * 2));
+                HIPCHECK(hipMemcpy(d, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+                bufs[r].push_back(d);
+                CHECK(upsp_exchange_submit_pixels(ranks[r].x, static_cast<const uint16_t *>(d), cp, wire, nullptr));
+            }
+        for (int r = 0; r < W; ++r)
+            CHECK(upsp_exchange_finish_pixels(ranks[r].x, ranks[r].d_series, F, ranks[r].d_sum + ranks[r].n0, ranks[r].d_sumsq + ranks[r].n0, nullptr));
+        for (int r = 0; r < W; ++r) CHECK(upsp_allreduce_sums(comms[r], ranks[r].d_sum, ranks[r].d_sumsq, N, nullptr));
+        HIPCHECK(hipDeviceSynchronize());
+        uint64_t tot_s = 0, tot_rows = 0;
+        for (int r = 0; r < W; ++r) {
+            CHECK(upsp_exchange_verify(ranks[r].x, nullptr));
+            std::vector<float> got((size_t)ranks[r].nn * F);
+            HIPCHECK(hipMemcpy(got.data(), ranks[r].d_series, sizeof(float) * got.size(), hipMemcpyDeviceToHost));
+            std::vector<double> s(N), ss(N);
+            HIPCHECK(hipMemcpy(s.data(), ranks[r].d_sum, sizeof(double) * N, hipMemcpyDeviceToHost));
+            HIPCHECK(hipMemcpy(ss.data(), ranks[r].d_sumsq, sizeof(double) * N, hipMemcpyDeviceToHost));
+            for (int64_t i = 0; i < ranks[r].nn; ++i) {
+                const int64_t n = ranks[r].n0 + i;
+                for (int64_t f = 0; f < F; ++f) {
+                    const float g = got[(size_t)i * F + f];
+                    const float want = nk[n] < 0 ? 0.f : (float)px(nk[n], f);
+                    if (skipped(n) ? !std::isnan(g) : g != want) {
+                        if (bad++ < 5) std::fprintf(stderr, "pixels: node %lld frame %lld: got %g want %g\n", (long long)n, (long long)f, g, want);
+                    }
+                }
+            }
+            for (int64_t n = 0; n < N; ++n) {                   // complete accumulators on every rank after the all-reduce
+                double ws = 0, wss = 0;
+                for (int64_t f = 0; f < F; ++f) {
+                    const double v = nk[n] < 0 ? 0.0 : (double)px(nk[n], f);
+                    ws += v;
+                    wss += v * v;
+                }
+                const bool ok = skipped(n) ? (std::isnan(s[n]) && std::isnan(ss[n])) : (s[n] == ws && ss[n] == wss);
+                if (!ok && bad++ < 5) std::fprintf(stderr, "pixels: accumulators of node %lld: %g %g (want %g %g)\n", (long long)n, s[n], ss[n], ws, wss);
+            }
+            uint64_t sent = 0, recv = 0;
+            int64_t rows_out = 0, rows_in = 0;
+            CHECK(upsp_exchange_bytes(ranks[r].x, &sent, &recv));
+            CHECK(upsp_exchange_pixel_rows(ranks[r].x, &rows_out, &rows_in));
+            tot_s += sent;
+            tot_rows += (uint64_t)rows_in;
+        }
+        std::printf("pixels W=%d wire=%d: %s, %llu bytes between ranks, %llu pixel rows for %lld travelling nodes\n", W, wire,
+                    bad ? "FAILED" : "ok", (unsigned long long)tot_s, (unsigned long long)tot_rows, (long long)(N - N / 5));
+        for (int r = 0; r < W; ++r) {
+            upsp_exchange_destroy(ranks[r].x);
+            upsp_comm_destroy(comms[r]);
+        }
+    }
+    return bad;
+}
+
 int main(int argc, char **argv)
 {
     const std::string mode = argc > 1 ? argv[1] : "local";
@@ -131,6 +232,7 @@ int main(int argc, char **argv)
     HIPCHECK(hipMalloc(&d_sk, N));
     HIPCHECK(hipMemcpy(d_sk, sk.data(), N, hipMemcpyHostToDevice));
     int bad = 0;
+    if (mode == "pixels") return run_pixels(argc > 2 ? std::atoi(argv[2]) : 2) ? 1 : 0;
     if (mode == "local") {
         const int W = argc > 2 ? std::atoi(argv[2]) : 2;
         for (int wire : {4, 2, 12}) {

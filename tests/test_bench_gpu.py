@@ -53,7 +53,7 @@ def test_bench_small_registration_parity(gpu_lib):
 def test_bench_two_ranks_on_one_gpu_gloo(gpu_lib):
     """`--gpus 2` launches its own two ranks; on a one-GPU box both sit on cuda:0 and talk through gloo
     (the RCCL run needs two GPUs: next test).  The exchange runs packed u16 rows in 4 chunks."""
-    d = run_bench(["--gpus", "2", "--small", "--steps", "2", "--warmup", "1"],
+    d = run_bench(["--gpus", "2", "--row-wire", "--small", "--steps", "2", "--warmup", "1"],
                   env={"UPSP_BENCH_BACKEND": "gloo", "UPSP_BENCH_ONE_GPU": "1"})
     assert d["n_gpus"] == 2 and d["backend"] == "gloo"
     assert d["config"]["exchange"] == "4 chunks, visible rows as u16"
@@ -64,10 +64,26 @@ def test_bench_rccl_one_rank_group(gpu_lib):
     """RCCL refuses two ranks on one GPU, so on a one-GPU box the N > 1 loop runs in a ONE-rank nccl group with the
     collectives forced (all_reduce of the accumulators, async all_to_all_single of the packed u16 chunks as bytes,
     barrier): the calls, dtypes and split sizes go through RCCL itself."""
-    d = run_bench(["--force-chunked", "--small", "--steps", "2", "--warmup", "1"], env={"UPSP_FORCE_COLLECTIVES": "1"})
+    d = run_bench(["--force-chunked", "--row-wire", "--small", "--steps", "2", "--warmup", "1"], env={"UPSP_FORCE_COLLECTIVES": "1"})
     assert d["n_gpus"] == 1 and d["collectives"].startswith("issued through RCCL")
     assert d["config"]["exchange"] == "4 chunks, visible rows as u16"
     assert d["parity_checked"] is True
+
+
+def test_bench_pixel_wire(gpu_lib):
+    """The default of the N > 1 loop: the active pixels' series travel and the owner of a node runs pass B over all frames -- through the
+    C-ABI exchange over RCCL (one-rank group) and over gloo with two ranks on this GPU; the series that come out are
+    compared with the oracle in the run (one rank) like the row exchange's."""
+    d = run_bench(["--force-chunked", "--small", "--steps", "2", "--warmup", "1"], env={"UPSP_FORCE_COLLECTIVES": "1"})
+    assert d["config"]["exchange"] == "4 chunks, active-pixel series as u16" and d["parity_checked"] is True
+    x = d["exchange_bytes_per_step"]
+    assert x["what_travels"] == "active-pixel series" and x["transport"].startswith("C ABI")
+    d2 = run_bench(["--force-chunked", "--row-wire", "--small", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-reraycast"],
+                   env={"UPSP_FORCE_COLLECTIVES": "1"})
+    assert x["travelling_rows"] < d2["exchange_bytes_per_step"]["travelling_rows"]          # fewer pixel rows than node rows
+    d = run_bench(["--gpus", "2", "--small", "--steps", "2", "--warmup", "1"],
+                  env={"UPSP_BENCH_BACKEND": "gloo", "UPSP_BENCH_ONE_GPU": "1"})
+    assert d["n_gpus"] == 2 and d["config"]["exchange"] == "4 chunks, active-pixel series as u16"
 
 
 def test_bench_two_ranks_rccl(gpu_lib):
@@ -76,4 +92,4 @@ def test_bench_two_ranks_rccl(gpu_lib):
         pytest.skip("needs two GPUs (RCCL over xGMI)")
     d = run_bench(["--gpus", "2", "--small", "--steps", "2", "--warmup", "1"])
     assert d["n_gpus"] == 2 and "backend" not in d
-    assert d["config"]["exchange"] == "4 chunks, visible rows as u16"
+    assert d["config"]["exchange"] == "4 chunks, active-pixel series as u16"

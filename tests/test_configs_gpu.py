@@ -111,6 +111,26 @@ def _rank_main(rank, world, port, tmp):
     series = exch.finish()
     avg, rms = pipe.finalize(F)
     n0, nn = shard.my_nodes
+    # the same run with the ACTIVE PIXELS' series on the wire: pass A per chunk on the sender, pass B over all frames on the
+    # owner of the nodes -- same series, same accumulators, bit for bit
+    pipe2 = engine.FramePipeline(1, W, H, N)
+    pipe2.set_projection(0, pix)
+    mine2 = torch.as_tensor(frames[f0:f0 + nf].copy()).cuda()
+    ex2 = D.TimeSeriesExchange(shard, K)
+    tab = pipe2.pixel_series(None)
+    ex2.set_pixels(tab["node_k"], engine.skipped_nodes(pix, want_count=False)[0])
+    for k in range(K):
+        c0, fc = ex2.my_chunk(k)
+        ex2.submit_pixels(pipe2.pixel_series(mine2[c0:c0 + fc].contiguous()) if fc else tab)
+    s2, ss2 = pipe2.accumulators()
+    series2 = ex2.finish_pixels(s2, ss2)
+    D.allreduce_sums(s2, ss2)
+    assert torch.equal(series2.view(torch.int32), series.view(torch.int32))
+    ok = ~torch.isnan(s)
+    assert torch.equal(torch.isnan(s2), ~ok) and torch.equal(s2[ok], s[ok]) and torch.equal(ss2[ok], ss[ok])
+    assert torch.equal(mine2, mine)                                   # frames repaired in place either way
+    rows_px, rows_in = ex2.pixel_rows()
+    assert rows_px <= 2 * int(tab["nactive"].item()) and rows_px < exch.packed_rows()
     np.savez(os.path.join(tmp, "rank%d.npz" % rank), series=series.cpu().numpy(), avg=avg.cpu().numpy(),
              rms=rms.cpu().numpy(), n0=n0, nn=nn)
     dist.destroy_process_group()

@@ -170,3 +170,67 @@ def test_shard_matches_reference_apportion(oracle):
         assert st2 == st and ex2 == ex
     sh = D.Shard(100000, 500958, rank=3, world=8)
     assert sh.my_frames == (37500, 12500) and sum(sh.node_count) == 500958
+
+
+def _worker_pixels(rank, world, port, F, N, A, seed, q):
+    """Pixel-series mode: the ranks exchange the series of the active pixels, each destination the pixels its node slice
+    reads, and the owner of a node forms its series and its accumulators over ALL frames."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from upsp_processing_amd import distributed as D
+    shard = D.Shard(F, N)
+    rng = np.random.default_rng(seed)
+    pixel_series = rng.integers(0, 65536, size=(A, F)).astype(np.int32)       # what pass A leaves: [active pixel][frame]
+    pixel_series[0, 0], pixel_series[A - 1, F - 1] = 65535, 32768             # sign bit of the int16 view
+    node_k = rng.integers(-1, A, size=N).astype(np.int32)                     # several nodes per pixel, some without
+    skipped = (np.arange(N) % 6 == 1)
+    f0, nf = shard.my_frames
+    ex = D.TimeSeriesExchange(shard, 3, device="cpu")
+    ex.set_pixels(torch.as_tensor(node_k), torch.as_tensor(skipped))
+    for k in range(3):
+        c0, fc = ex.my_chunk(k)
+        comp = np.zeros((A, fc + 5), np.uint16)                                # this rank's compact buffer of the chunk (padded pitch)
+        comp[:, :fc] = pixel_series[:, f0 + c0:f0 + c0 + fc].astype(np.uint16)
+        ex.submit_pixels(torch.from_numpy(comp))
+    s, ss = torch.zeros(N, dtype=torch.float64), torch.zeros(N, dtype=torch.float64)
+    series = ex.finish_pixels(s, ss).clone()
+    D.allreduce_sums(s, ss)
+    rows_out, rows_in = ex.pixel_rows()
+    # second pass with assume_same: verified on the "device"
+    ex.set_pixels(torch.as_tensor(node_k), torch.as_tensor(skipped), assume_same=True)
+    ex.verify()
+    n0, nn = shard.my_nodes
+    q.put((rank, series.numpy(), s.numpy(), ss.numpy(), n0, nn, rows_out, rows_in))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("F,N,A", [(23, 61, 17), (5, 9, 4), (2, 3, 1)])
+def test_two_rank_pixel_series_exchange(F, N, A):
+    world, seed = 2, 77
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_pixels, args=(r, world, port, F, N, A, seed, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(seed)
+    pixel_series = rng.integers(0, 65536, size=(A, F)).astype(np.int32)
+    pixel_series[0, 0], pixel_series[A - 1, F - 1] = 65535, 32768
+    node_k = rng.integers(-1, A, size=N).astype(np.int32)
+    skipped = (np.arange(N) % 6 == 1)
+    want = np.where((node_k >= 0)[:, None], pixel_series[np.clip(node_k, 0, None)], 0).astype(np.float32)
+    want[skipped] = np.nan
+    ws, wss = want.astype(np.float64).sum(1), (want * want).astype(np.float64).sum(1)
+    for rank, series, s, ss, n0, nn, rows_out, rows_in in res:
+        assert series.shape == (nn, F)
+        assert np.array_equal(series.view(np.int32), want[n0:n0 + nn].view(np.int32))
+        ok = ~skipped
+        assert np.array_equal(s[ok], ws[ok]) and np.array_equal(ss[ok], wss[ok]) and np.isnan(s[~ok]).all()
+        assert rows_in <= A and rows_out <= world * A

@@ -38,6 +38,20 @@ def test_exchange_local_ranks(exe, world):
         assert sent[0] == 2 * sent[1] and sent[2] < sent[1]        # f32 : u16 : 12 bit
 
 
+@pytest.mark.parametrize("world", [1, 2, 3, 5])
+def test_exchange_pixel_series_local_ranks(exe, world):
+    """The pixel-series mode (upsp_exchange_set_pixels / submit_pixels / finish_pixels): every destination receives the
+    active pixels its node slice reads, each once, and runs pass B itself -- series, NaN rows and COMPLETE accumulators
+    (after the all-reduce of slices that are zero elsewhere) against the closed form, u16 and 12-bit wire; fewer pixel
+    rows than travelling nodes cross the links."""
+    r = subprocess.run([exe, "pixels", str(world)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 2 and all(" ok," in l for l in lines), r.stdout
+    rows = int(lines[0].split(", ")[2].split()[0])
+    assert rows <= 211 * world and rows < 803            # <= A pixels per destination, fewer than the travelling nodes
+
+
 def test_exchange_rccl_one_rank(exe):
     r = subprocess.run([exe, "rccl1"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr

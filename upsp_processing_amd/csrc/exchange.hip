@@ -220,6 +220,57 @@ __global__ void __launch_bounds__(256)
     if (i < n && ((skipped[i] == 0) != (keep[i] != 0))) atomicOr(flag, 1u);
 }
 
+// send[i][0 .. fc) = compact[send_k[i]][0 .. fc): the pixel rows the destinations read, out of the sender's compact buffer
+// (a wave per row; 8 bytes per lane and trip)
+__global__ void __launch_bounds__(256)
+    gather_pixel_rows_kernel(const uint16_t *__restrict__ compact, unsigned cpitch, const uint32_t *__restrict__ send_k,
+                             long long nrows, int fc, uint16_t *__restrict__ send)
+{
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= nrows) return;
+    const int lane = threadIdx.x & 63;
+    const uint16_t *s = compact + (size_t)send_k[r] * cpitch;
+    uint16_t *d = send + r * fc;
+    if ((fc & 3) == 0 && (cpitch & 3u) == 0u) {
+        for (int c = 4 * lane; c < fc; c += 256) *reinterpret_cast<uint2 *>(d + c) = *reinterpret_cast<const uint2 *>(s + c);
+    } else {
+        for (int c = lane; c < fc; c += 64) d[c] = s[c];
+    }
+}
+
+// received block [nrows][fc] (u16, or packed 12 bit) -> columns [col, col + fc) of dst [nrows][pitch] u16
+template <int WIRE>
+__global__ void __launch_bounds__(256)
+    place_pixel_rows_kernel(const uint8_t *__restrict__ src, long long nrows, int fc, uint16_t *__restrict__ dst, long long pitch)
+{
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= nrows) return;
+    const int lane = threadIdx.x & 63;
+    uint16_t *d = dst + r * pitch;
+    if (WIRE == 2) {
+        const uint16_t *s = reinterpret_cast<const uint16_t *>(src) + r * fc;
+        for (int c = lane; c < fc; c += 64) d[c] = s[c];
+    } else {
+        const int pairs = (fc + 1) / 2;
+        const uint8_t *s = src + r * pairs * 3;
+        for (int p = lane; p < pairs; p += 64) {
+            const unsigned b0 = s[3 * p], b1 = s[3 * p + 1], b2 = s[3 * p + 2];
+            d[2 * p] = (uint16_t)((b0 << 4) | (b1 >> 4));
+            if (2 * p + 1 < fc) d[2 * p + 1] = (uint16_t)(((b1 & 15u) << 8) | b2);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+    nodek_differs_kernel(const int32_t *__restrict__ a, const int32_t *__restrict__ b, const uint8_t *__restrict__ sk,
+                         const uint8_t *__restrict__ keep, size_t n, unsigned *flag)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const bool k0 = sk ? sk[i] == 0 : true;
+    if (a[i] != b[i] || (k0 != (keep[i] != 0))) atomicOr(flag, 1u);
+}
+
 __global__ void sum_posts_kernel(double *const *bufs, int nb, size_t n)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -255,6 +306,18 @@ struct upsp_exchange {
     std::vector<size_t> packed_bytes;
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+    // pixel-series mode (upsp_exchange_set_pixels): what travels are the series of the ACTIVE PIXELS each destination's
+    // nodes read; `cut` / `nvis` then count pixel rows
+    int mode = 0;                               // 0 node rows, 1 pixel series
+    uint32_t *d_send_k = nullptr;               // compact row (sender side) of every travelling pixel row, by destination
+    int32_t *d_node_local = nullptr;            // my nodes -> row of d_compact_me (-1: no pixel)
+    uint8_t *d_skipped_me = nullptr;            // my nodes: no camera sees them
+    int32_t *d_nodek_prev = nullptr;            // node_k the lists were derived from (assume_same check)
+    uint16_t *d_compact_me = nullptr;           // [rows_in][fpad]: the pixel series my nodes read, all frames of the run
+    size_t compact_me_bytes = 0;
+    int64_t fpad = 0;
+    std::vector<void *> gathered;               // [chunk] send buffer: the rows of d_send_k out of the sender's compact buffer
+    std::vector<size_t> gathered_bytes;
     uint64_t bytes_sent = 0, bytes_received = 0;   // of the pass in flight (to other ranks: what crosses a link)
     uint64_t last_sent = 0, last_received = 0;     // of the last finished pass
 };
@@ -268,11 +331,16 @@ size_t wire_row_bytes(int wire, int64_t fc)
 
 void free_rows(upsp_exchange *x)
 {
-    for (void *p : {(void *)x->d_rowmap, (void *)x->d_vis_mine, (void *)x->d_nan_mine, (void *)x->d_keep})
+    for (void *p : {(void *)x->d_rowmap, (void *)x->d_vis_mine, (void *)x->d_nan_mine, (void *)x->d_keep, (void *)x->d_send_k,
+                    (void *)x->d_node_local, (void *)x->d_skipped_me, (void *)x->d_nodek_prev})
         if (p) (void)hipFree(p);
     x->d_rowmap = nullptr;
     x->d_vis_mine = x->d_nan_mine = nullptr;
     x->d_keep = nullptr;
+    x->d_send_k = nullptr;
+    x->d_node_local = nullptr;
+    x->d_skipped_me = nullptr;
+    x->d_nodek_prev = nullptr;
     x->have_rows = false;
 }
 
@@ -431,6 +499,8 @@ int upsp_exchange_create(upsp_comm *c, int64_t nframes_total, int64_t nnodes, in
     x->stage_bytes.assign(nchunks, std::vector<size_t>(c->world, 0));
     x->packed.assign(nchunks, nullptr);
     x->packed_bytes.assign(nchunks, 0);
+    x->gathered.assign(nchunks, nullptr);
+    x->gathered_bytes.assign(nchunks, 0);
     hipError_t e = hipStreamCreateWithFlags(&x->comm_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&x->ev_ready, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&x->ev_done, hipEventDisableTiming);
@@ -454,6 +524,9 @@ void upsp_exchange_destroy(upsp_exchange *x)
             if (p) (void)hipFree(p);
     for (void *p : x->packed)
         if (p) (void)hipFree(p);
+    for (void *p : x->gathered)
+        if (p) (void)hipFree(p);
+    if (x->d_compact_me) (void)hipFree(x->d_compact_me);
     if (x->d_flags) (void)hipFree(x->d_flags);
     if (x->ev_ready) (void)hipEventDestroy(x->ev_ready);
     if (x->ev_done) (void)hipEventDestroy(x->ev_done);
@@ -488,7 +561,7 @@ int upsp_exchange_set_skipped(upsp_exchange *x, const uint8_t *d_skipped, int as
     hipStream_t st = (hipStream_t)stream;
     const int W = x->c->world, me = x->c->rank;
     const size_t N = (size_t)x->N;
-    if (assume_same && x->have_rows && d_skipped && x->d_keep) {
+    if (assume_same && x->have_rows && x->mode == 0 && d_skipped && x->d_keep) {
         // the caller states that the set is the one of the previous call (the projection did not change): nothing is
         // read back, the claim is checked on the device and upsp_exchange_finish reports a broken one
         hipLaunchKernelGGL(keep_differs_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, d_skipped,
@@ -536,27 +609,27 @@ int upsp_exchange_set_skipped(upsp_exchange *x, const uint8_t *d_skipped, int as
     if (!nan_mine.empty())
         UPSP_HIP_CHECK(hipMemcpy(x->d_nan_mine, nan_mine.data(), sizeof(int64_t) * nan_mine.size(), hipMemcpyHostToDevice));
     x->have_rows = true;
+    x->mode = 0;
     return UPSP_OK;
 }
 
 int upsp_exchange_rows(const upsp_exchange *x, const int32_t **d_rowmap, int64_t *packed_rows)
 {
-    if (!x || !x->have_rows) return fail(UPSP_ERR_INVALID, "exchange: upsp_exchange_set_skipped first");
+    if (!x || !x->have_rows || x->mode != 0) return fail(UPSP_ERR_INVALID, "exchange: upsp_exchange_set_skipped first");
     if (d_rowmap) *d_rowmap = x->d_rowmap;
     if (packed_rows) *packed_rows = x->nvis;
     return UPSP_OK;
 }
 
-int upsp_exchange_submit(upsp_exchange *x, const void *d_chunk, int wire, void *stream)
+// chunk k of this rank on the wire: rows [cut[p], cut[p + 1]) x fc go to rank p, my rows x chunk k of rank p come back
+static int submit_core(upsp_exchange *x, const void *d_chunk, int wire, hipStream_t st)
 {
-    if (!x || !x->have_rows) return fail(UPSP_ERR_INVALID, "exchange: upsp_exchange_set_skipped first");
     if (wire != 4 && wire != 2 && wire != 12) return fail(UPSP_ERR_INVALID, "exchange: wire format is 4 (f32), 2 (u16) or 12 (u16 packed to 12 bit)");
     if (x->k >= x->K) return fail(UPSP_ERR_INVALID, "exchange: every chunk was already submitted (finish first)");
     if (x->k > 0 && wire != x->wire) return fail(UPSP_ERR_INVALID, "exchange: the chunks of one pass share a wire format");
     const int W = x->c->world, me = x->c->rank, k = x->k;
     const int64_t fc = x->chunk_count[me][k];
     if (fc > 0 && x->nvis > 0 && !d_chunk) return fail(UPSP_ERR_INVALID, "exchange: null chunk");
-    hipStream_t st = (hipStream_t)stream;
     x->wire = wire;
     if (k == 0) x->bytes_sent = x->bytes_received = 0;
     const size_t rb = wire_row_bytes(wire, fc);
@@ -611,33 +684,49 @@ int upsp_exchange_submit(upsp_exchange *x, const void *d_chunk, int wire, void *
     return UPSP_OK;
 }
 
-int upsp_exchange_finish(upsp_exchange *x, float *d_series, int64_t ld, void *stream)
+// every block of the pass is in its staging buffer once `st` gets there
+static int receive_core(upsp_exchange *x, hipStream_t st)
 {
-    if (!x || !x->have_rows || !d_series) return fail(UPSP_ERR_INVALID, "bad argument");
     if (x->k != x->K) return fail(UPSP_ERR_INVALID, "exchange: finish before every chunk was submitted");
-    if (ld < x->F) return fail(UPSP_ERR_INVALID, "exchange: ld smaller than the frame count");
-    hipStream_t st = (hipStream_t)stream;
     const int W = x->c->world, me = x->c->rank;
     const int64_t rows_in = x->cut[me + 1] - x->cut[me];
     if (x->c->kind == 0) {
         UPSP_HIP_CHECK(hipEventRecord(x->ev_done, x->comm_stream));
         UPSP_HIP_CHECK(hipStreamWaitEvent(st, x->ev_done, 0));
-    } else {
-        LocalGroup &g = *x->c->local;
-        std::lock_guard<std::mutex> lk(g.mu);
-        for (int k = 0; k < x->K; ++k)
-            for (int s = 0; s < W; ++s) {
-                const size_t in_b = wire_row_bytes(x->wire, x->chunk_count[s][k]) * (size_t)rows_in;
-                auto it = g.sends.find(std::make_tuple(s, me, k));
-                if (it == g.sends.end()) return fail(UPSP_ERR_INVALID, "local exchange: a rank has not submitted yet");
-                if (it->second.bytes != in_b) return fail(UPSP_ERR_INVALID, "local exchange: block sizes disagree between the ranks");
-                UPSP_HIP_CHECK(hipStreamWaitEvent(st, it->second.ready, 0));
-                if (in_b) UPSP_HIP_CHECK(hipMemcpyAsync(x->stage[k][s], it->second.ptr, in_b, hipMemcpyDeviceToDevice, st));
-                if (s != me) x->bytes_received += in_b;
-                (void)hipEventDestroy(it->second.ready);
-                g.sends.erase(it);
-            }
+        return UPSP_OK;
     }
+    LocalGroup &g = *x->c->local;
+    std::lock_guard<std::mutex> lk(g.mu);
+    for (int k = 0; k < x->K; ++k)
+        for (int s = 0; s < W; ++s) {
+            const size_t in_b = wire_row_bytes(x->wire, x->chunk_count[s][k]) * (size_t)rows_in;
+            auto it = g.sends.find(std::make_tuple(s, me, k));
+            if (it == g.sends.end()) return fail(UPSP_ERR_INVALID, "local exchange: a rank has not submitted yet");
+            if (it->second.bytes != in_b) return fail(UPSP_ERR_INVALID, "local exchange: block sizes disagree between the ranks");
+            UPSP_HIP_CHECK(hipStreamWaitEvent(st, it->second.ready, 0));
+            if (in_b) UPSP_HIP_CHECK(hipMemcpyAsync(x->stage[k][s], it->second.ptr, in_b, hipMemcpyDeviceToDevice, st));
+            if (s != me) x->bytes_received += in_b;
+            (void)hipEventDestroy(it->second.ready);
+            g.sends.erase(it);
+        }
+    return UPSP_OK;
+}
+
+int upsp_exchange_submit(upsp_exchange *x, const void *d_chunk, int wire, void *stream)
+{
+    if (!x || !x->have_rows || x->mode != 0) return fail(UPSP_ERR_INVALID, "exchange: upsp_exchange_set_skipped first");
+    return submit_core(x, d_chunk, wire, (hipStream_t)stream);
+}
+
+int upsp_exchange_finish(upsp_exchange *x, float *d_series, int64_t ld, void *stream)
+{
+    if (!x || !x->have_rows || x->mode != 0 || !d_series) return fail(UPSP_ERR_INVALID, "bad argument");
+    if (ld < x->F) return fail(UPSP_ERR_INVALID, "exchange: ld smaller than the frame count");
+    hipStream_t st = (hipStream_t)stream;
+    const int W = x->c->world, me = x->c->rank;
+    const int64_t rows_in = x->cut[me + 1] - x->cut[me];
+    int rc = receive_core(x, st);
+    if (rc != UPSP_OK) return rc;
     {
         KTimed kt("exchange_place_kernels", st);
         for (int k = 0; k < x->K; ++k)
@@ -645,7 +734,6 @@ int upsp_exchange_finish(upsp_exchange *x, float *d_series, int64_t ld, void *st
                 const int64_t fs = x->chunk_count[s][k];
                 if (!fs || !rows_in) continue;
                 float *dst = d_series + x->frame_start[s] + x->chunk_start[s][k];
-                int rc = UPSP_OK;
                 if (x->wire == 4)
                     rc = upsp_scatter_rows_f32(static_cast<const float *>(x->stage[k][s]), (size_t)rows_in, (int)fs, x->d_vis_mine, dst, ld, stream);
                 else if (x->wire == 2)
@@ -660,7 +748,145 @@ int upsp_exchange_finish(upsp_exchange *x, float *d_series, int64_t ld, void *st
     }
     // the rows that do not travel: NaN in every frame (psp_process.cpp:1821-1825), written by every exchange
     if (x->n_nan_mine) {
-        int rc = upsp_fill_rows_f32(__builtin_nanf(""), (size_t)x->n_nan_mine, (int)x->F, x->d_nan_mine, d_series, ld, stream);
+        rc = upsp_fill_rows_f32(__builtin_nanf(""), (size_t)x->n_nan_mine, (int)x->F, x->d_nan_mine, d_series, ld, stream);
+        if (rc != UPSP_OK) return rc;
+    }
+    x->k = 0;
+    x->last_sent = x->bytes_sent;
+    x->last_received = x->bytes_received;
+    return UPSP_OK;
+}
+
+// ---- pixel-series mode --------------------------------------------------------------------------------------------------
+// What a node's series is made of is the series of the PIXEL it reads, and on a model finer than the pixel grid several
+// nodes read the same pixel (the bench model: 190 k travelling nodes on 66 k active pixels).  Here the ranks exchange
+// the active pixels' u16 series -- every destination gets the pixels its node slice reads, each once -- and the OWNER of
+// a node runs pass B over all frames of the run: the series come out the same, the accumulators complete (no partial
+// sums to reduce: other ranks' slices stay zero, so upsp_allreduce_sums still delivers the full vectors), and a third of
+// the bytes cross the links.
+int upsp_exchange_set_pixels(upsp_exchange *x, const int32_t *d_node_k, const uint8_t *d_skipped, int assume_same, void *stream)
+{
+    if (!x || !d_node_k) return fail(UPSP_ERR_INVALID, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int W = x->c->world, me = x->c->rank;
+    const size_t N = (size_t)x->N;
+    if (assume_same && x->have_rows && x->mode == 1 && x->d_nodek_prev && x->d_keep) {
+        hipLaunchKernelGGL(nodek_differs_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, d_node_k,
+                           (const int32_t *)x->d_nodek_prev, d_skipped, (const uint8_t *)x->d_keep, N, x->d_flags);
+        UPSP_HIP_CHECK(hipGetLastError());
+        return UPSP_OK;
+    }
+    std::vector<int32_t> nk(N);
+    std::vector<uint8_t> sk(N, 0);
+    UPSP_HIP_CHECK(hipMemcpyAsync(nk.data(), d_node_k, sizeof(int32_t) * N, hipMemcpyDeviceToHost, st));
+    if (d_skipped) UPSP_HIP_CHECK(hipMemcpyAsync(sk.data(), d_skipped, N, hipMemcpyDeviceToHost, st));
+    UPSP_HIP_CHECK(hipStreamSynchronize(st));
+    std::vector<uint32_t> send_k;
+    std::vector<int32_t> local(std::max<int64_t>(x->node_count[me], 1), -1);
+    std::vector<uint8_t> keep(N), sk_me(std::max<int64_t>(x->node_count[me], 1), 0);
+    x->cut.assign(W + 1, 0);
+    for (int d = 0; d < W; ++d) {
+        x->cut[d] = (int64_t)send_k.size();
+        const int64_t n0 = x->node_start[d], n1 = n0 + x->node_count[d];
+        std::vector<uint32_t> ks;
+        for (int64_t n = n0; n < n1; ++n) {
+            keep[n] = sk[n] == 0;
+            if (keep[n] && nk[n] >= 0) ks.push_back((uint32_t)nk[n]);
+        }
+        std::sort(ks.begin(), ks.end());
+        ks.erase(std::unique(ks.begin(), ks.end()), ks.end());
+        if (d == me) {
+            for (int64_t n = n0; n < n1; ++n) {
+                sk_me[n - n0] = sk[n];
+                if (keep[n] && nk[n] >= 0)
+                    local[n - n0] = (int32_t)(std::lower_bound(ks.begin(), ks.end(), (uint32_t)nk[n]) - ks.begin());
+            }
+        }
+        send_k.insert(send_k.end(), ks.begin(), ks.end());
+    }
+    x->cut[W] = (int64_t)send_k.size();
+    free_rows(x);
+    x->nvis = (int64_t)send_k.size();
+    const size_t nn = (size_t)std::max<int64_t>(x->node_count[me], 1);
+    UPSP_HIP_CHECK(hipMalloc(&x->d_send_k, sizeof(uint32_t) * std::max<size_t>(send_k.size(), 1)));
+    UPSP_HIP_CHECK(hipMalloc(&x->d_node_local, sizeof(int32_t) * nn));
+    UPSP_HIP_CHECK(hipMalloc(&x->d_skipped_me, nn));
+    UPSP_HIP_CHECK(hipMalloc(&x->d_nodek_prev, sizeof(int32_t) * N));
+    UPSP_HIP_CHECK(hipMalloc(&x->d_keep, N));
+    if (!send_k.empty()) UPSP_HIP_CHECK(hipMemcpy(x->d_send_k, send_k.data(), sizeof(uint32_t) * send_k.size(), hipMemcpyHostToDevice));
+    UPSP_HIP_CHECK(hipMemcpy(x->d_node_local, local.data(), sizeof(int32_t) * nn, hipMemcpyHostToDevice));
+    UPSP_HIP_CHECK(hipMemcpy(x->d_skipped_me, sk_me.data(), nn, hipMemcpyHostToDevice));
+    UPSP_HIP_CHECK(hipMemcpy(x->d_nodek_prev, nk.data(), sizeof(int32_t) * N, hipMemcpyHostToDevice));
+    UPSP_HIP_CHECK(hipMemcpy(x->d_keep, keep.data(), N, hipMemcpyHostToDevice));
+    // the pixel series my nodes read, all frames of the run: [rows_in][fpad] u16
+    const int64_t rows_in = x->cut[me + 1] - x->cut[me];
+    x->fpad = (x->F + 63) / 64 * 64;
+    const size_t want = sizeof(uint16_t) * (size_t)std::max<int64_t>(rows_in, 1) * (size_t)std::max<int64_t>(x->fpad, 64);
+    int rc = ensure_buffer(reinterpret_cast<void *&>(x->d_compact_me), x->compact_me_bytes, want);
+    if (rc != UPSP_OK) return rc;
+    x->have_rows = true;
+    x->mode = 1;
+    return UPSP_OK;
+}
+
+int upsp_exchange_pixel_rows(const upsp_exchange *x, int64_t *rows_out, int64_t *rows_in)
+{
+    if (!x || !x->have_rows || x->mode != 1) return fail(UPSP_ERR_INVALID, "exchange: upsp_exchange_set_pixels first");
+    if (rows_out) *rows_out = x->nvis;
+    if (rows_in) *rows_in = x->cut[x->c->rank + 1] - x->cut[x->c->rank];
+    return UPSP_OK;
+}
+
+int upsp_exchange_submit_pixels(upsp_exchange *x, const uint16_t *d_compact, uint32_t cpitch, int wire, void *stream)
+{
+    if (!x || !x->have_rows || x->mode != 1) return fail(UPSP_ERR_INVALID, "exchange: upsp_exchange_set_pixels first");
+    if (wire != 2 && wire != 12) return fail(UPSP_ERR_INVALID, "exchange: pixel series travel as u16 (2) or packed to 12 bits (12)");
+    if (x->k >= x->K) return fail(UPSP_ERR_INVALID, "exchange: every chunk was already submitted (finish first)");
+    hipStream_t st = (hipStream_t)stream;
+    const int k = x->k;
+    const int64_t fc = x->chunk_count[x->c->rank][k];
+    if (fc > 0 && x->nvis > 0) {
+        if (!d_compact || (int64_t)cpitch < fc) return fail(UPSP_ERR_INVALID, "exchange: compact buffer too narrow for the chunk");
+        int rc = ensure_buffer(x->gathered[k], x->gathered_bytes[k], sizeof(uint16_t) * (size_t)x->nvis * (size_t)fc);
+        if (rc != UPSP_OK) return rc;
+        KTimed kt("gather_pixel_rows_kernel", st);
+        hipLaunchKernelGGL(gather_pixel_rows_kernel, dim3((unsigned)((x->nvis + 3) / 4)), dim3(256), 0, st, d_compact, cpitch,
+                           (const uint32_t *)x->d_send_k, (long long)x->nvis, (int)fc, static_cast<uint16_t *>(x->gathered[k]));
+        UPSP_HIP_CHECK(hipGetLastError());
+    }
+    return submit_core(x, x->gathered[k], wire, st);
+}
+
+int upsp_exchange_finish_pixels(upsp_exchange *x, float *d_series, int64_t ld, double *d_sum_mine, double *d_sumsq_mine, void *stream)
+{
+    if (!x || !x->have_rows || x->mode != 1 || !d_series || !d_sum_mine || !d_sumsq_mine) return fail(UPSP_ERR_INVALID, "bad argument");
+    if (ld < x->F) return fail(UPSP_ERR_INVALID, "exchange: ld smaller than the frame count");
+    hipStream_t st = (hipStream_t)stream;
+    const int W = x->c->world, me = x->c->rank;
+    const int64_t rows_in = x->cut[me + 1] - x->cut[me];
+    int rc = receive_core(x, st);
+    if (rc != UPSP_OK) return rc;
+    {
+        KTimed kt("exchange_place_kernels", st);
+        for (int k = 0; k < x->K; ++k)
+            for (int s = 0; s < W; ++s) {
+                const int64_t fs = x->chunk_count[s][k];
+                if (!fs || !rows_in) continue;
+                uint16_t *dst = x->d_compact_me + x->frame_start[s] + x->chunk_start[s][k];
+                const dim3 grid((unsigned)((rows_in + 3) / 4)), block(256);
+                if (x->wire == 2)
+                    hipLaunchKernelGGL(place_pixel_rows_kernel<2>, grid, block, 0, st, static_cast<const uint8_t *>(x->stage[k][s]),
+                                       (long long)rows_in, (int)fs, dst, (long long)x->fpad);
+                else
+                    hipLaunchKernelGGL(place_pixel_rows_kernel<12>, grid, block, 0, st, static_cast<const uint8_t *>(x->stage[k][s]),
+                                       (long long)rows_in, (int)fs, dst, (long long)x->fpad);
+            }
+        UPSP_HIP_CHECK(hipGetLastError());
+    }
+    // pass B by the owner of the nodes, over every frame of the run: series, NaN rows, complete accumulators
+    if (x->node_count[me] > 0 && x->F > 0) {
+        rc = upsp_rows_from_pixel_series(x->d_compact_me, (uint32_t)x->fpad, x->d_node_local, x->d_skipped_me,
+                                         (size_t)x->node_count[me], x->F, d_series, ld, d_sum_mine, d_sumsq_mine, stream);
         if (rc != UPSP_OK) return rc;
     }
     x->k = 0;

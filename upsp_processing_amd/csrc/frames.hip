@@ -1442,6 +1442,26 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+// The replaced pixels written into the compact [active pixel][frame] series (pass A stored them as they were): what
+// travels in the pixel-series exchange is the REPAIRED series.  One lane per change slot; col0 = column of frame 0.
+__global__ void __launch_bounds__(256)
+    hot_patch_compact_kernel(const unsigned *__restrict__ ntotal, const unsigned *__restrict__ nch,
+                             const uint4 *__restrict__ changes, int nframes, int max_hot,
+                             const uint8_t *__restrict__ flag, const unsigned *__restrict__ tile_off,
+                             uint16_t *__restrict__ compact, unsigned cpitch)
+{
+    if (*ntotal == 0u) return;                 // (uniform) nearly every call
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (unsigned)nframes * (unsigned)max_hot) return;
+    const unsigned f = i / (unsigned)max_hot;
+    if (i - f * (unsigned)max_hot >= nch[f]) return;
+    const uint4 ch = changes[i];
+    const unsigned fl = flag[ch.y];
+    if (!fl) return;                           // nobody reads the pixel
+    const unsigned k = tile_off[ch.y / kFusedPix] + (fl & 0x7Fu);
+    compact[(size_t)k * cpitch + ch.x] = (uint16_t)ch.w;
+}
+
 // The same for several cameras.  The value of node n in frame f is sol = sum over the cameras, in order, of
 // w_c * f32(frame_c[pix_c[n]]) in float (psp_process.cpp:1813-1819): a replaced pixel of one camera changes it
 // non-linearly (float rounding), so the entry is RECOMPUTED from the repaired frames of all cameras --
@@ -1913,6 +1933,27 @@ int launch_hot_fixup(const PipelineGather &g, uint16_t *d_frames, int nframes, i
 // d_count / d_pos: per camera c at c * nframes (counters) and c * nframes * 64 (positions); d_changes: per camera
 // hot_changes_words(nframes, max_hot) words; d_head: ncams * npix, d_next: ncams * nnodes.  g.rows_t points at
 // the column of the first frame; identity row map only.
+// Repairs the frames with 1 .. max_hot hot pixels (fix_hot_pixels) and writes the replaced pixels into the compact
+// series pass A stored (frames of one pass A group: compact column = frame index).
+int launch_hot_repair_compact(uint16_t *d_frames, size_t npix, int nframes, int rows, int cols, int min_change, int max_hot,
+                              unsigned *d_count, const unsigned *d_pos, unsigned *d_changes, const uint8_t *d_flag,
+                              const unsigned *d_tile_off, uint16_t *d_compact, unsigned cpitch, hipStream_t st)
+{
+    if (nframes <= 0) return UPSP_OK;
+    KTimed kt("hot_fixup_kernels", st);
+    unsigned *nch = d_changes + 4;
+    uint4 *list = reinterpret_cast<uint4 *>(d_changes + 4 + (((size_t)nframes + 3) & ~(size_t)3));
+    hipLaunchKernelGGL(hot_patch_reset_kernel, dim3(1), dim3(1), 0, st, d_changes);
+    hipLaunchKernelGGL(hot_repair_kernel, dim3((unsigned)((nframes + 63) / 64)), dim3(64), 0, st, d_frames, npix, nframes,
+                       rows, cols, min_change, max_hot, d_count, d_pos, d_changes, nch, list);
+    if (max_hot > 0)
+        hipLaunchKernelGGL(hot_patch_compact_kernel, dim3((unsigned)(((size_t)nframes * max_hot + 255) / 256)), dim3(256), 0, st,
+                           (const unsigned *)d_changes, (const unsigned *)nch, (const uint4 *)list, nframes, max_hot, d_flag,
+                           d_tile_off, d_compact, cpitch);
+    UPSP_HIP_CHECK(hipGetLastError());
+    return UPSP_OK;
+}
+
 int launch_hot_fixup_multi(const PipelineGather &g, uint16_t *const *d_frames, int nframes, int rows, int cols,
                            int min_change, int max_hot, unsigned *d_count, const unsigned *d_pos,
                            unsigned *d_changes, int32_t *d_head, int32_t *d_next, hipStream_t st)

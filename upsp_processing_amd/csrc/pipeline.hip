@@ -557,6 +557,76 @@ int upsp_pipeline_prescan(upsp_pipeline *p, uint16_t *d_frames, int nframes, voi
     return UPSP_OK;
 }
 
+// Pass A as an operator (pixel-series exchange: the sender runs pass A only, the owner of a node runs pass B over all
+// frames of the run).  Leaves the REPAIRED series of every active pixel over these frames in the pipeline's compact
+// buffer and repairs the frames in place.
+int upsp_pipeline_pixel_series(upsp_pipeline *p, uint16_t *d_frames, int nframes, void *stream, const uint16_t **d_compact,
+                               uint32_t *cpitch, const int32_t **d_node_k, const uint32_t **d_nactive)
+{
+    // (nframes == 0: only the active-pixel map and the node -> row table of the current projection are made ready)
+    if (!p || nframes < 0 || (nframes > 0 && !d_frames)) return fail(UPSP_ERR_INVALID, "bad argument");
+    const size_t npix = (size_t)p->width * p->height;
+    if (p->ncams != 1 || p->d_weight[0] || p->opts.registration || p->opts.patch || p->opts.filter || p->d_src ||
+        (npix % 2) != 0 || p->nnodes >= ((size_t)1 << 31))
+        return fail(UPSP_ERR_INVALID, "pixel series: plain one-camera path only (integer-valued series)");
+    if (!p->has_proj[0]) return fail(UPSP_ERR_INVALID, "pixel series: projection not set");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = UPSP_OK;
+    if (!p->tilemap_valid) {
+        rc = streamed_map(p, p->d_pix[0], npix, st);
+        if (rc != UPSP_OK) return rc;
+        p->node_k_valid = true;
+        p->hint_active = false;
+    }
+    if (!p->node_k_valid) {
+        rc = launch_amap_nodes(p->d_pix[0], p->nnodes, p->d_aflag, p->d_tile_off, p->d_node_k, st);
+        if (rc != UPSP_OK) return rc;
+        p->node_k_valid = true;
+    }
+    int S = 0;
+    unsigned cp = 0;
+    rc = streamed_buffers(p, npix, std::max(nframes, 1), st, &S, &cp);
+    if (rc != UPSP_OK) return rc;
+    if (nframes > S) return fail(UPSP_ERR_INVALID, "pixel series: more frames than one pass A group holds (<= 1024 per call)");
+    p->prescan_frames = nullptr;
+    if (nframes > 0) rc = streamed_pass_a(p, d_frames, npix, 0, nframes, cp, st);
+    if (rc != UPSP_OK) return rc;
+    if (p->opts.hot_enable && nframes > 0)
+        rc = launch_hot_repair_compact(d_frames, npix, nframes, p->height, p->width, p->opts.hot_min_change, p->opts.hot_max,
+                                       p->d_hot_count, p->d_hot_pos, p->d_changes, p->d_aflag, p->d_tile_off, p->d_compact, cp, st);
+    if (d_compact) *d_compact = p->d_compact;
+    if (cpitch) *cpitch = cp;
+    if (d_node_k) *d_node_k = p->d_node_k;
+    if (d_nactive) *d_nactive = p->d_tile_off + tilemap_tiles(npix);
+    return rc;
+}
+
+// Pass B as an operator: node-major series (and accumulators) of `nnodes` nodes over `nframes` frames from the pixel
+// series they read.  d_node_k [nnodes]: row of d_compact per node (< 0: no pixel -> 0); d_skipped: NaN rows.
+int upsp_rows_from_pixel_series(const uint16_t *d_compact, uint32_t cpitch, const int32_t *d_node_k, const uint8_t *d_skipped,
+                                size_t nnodes, int64_t nframes, float *d_rows_t, int64_t ld, double *d_sum, double *d_sumsq,
+                                void *stream)
+{
+    if (!d_compact || !d_node_k || !d_rows_t || !d_sum || !d_sumsq || nnodes == 0 || nnodes >= ((size_t)1 << 31))
+        return fail(UPSP_ERR_INVALID, "bad argument");
+    if (nframes < 0 || ld < nframes || (int64_t)cpitch < nframes) return fail(UPSP_ERR_INVALID, "rows from pixel series: pitch smaller than the frame count");
+    PipelineGather g;
+    g.ncams = 1;
+    g.nnodes = nnodes;
+    g.skipped = d_skipped;
+    g.sum = d_sum;
+    g.sumsq = d_sumsq;
+    g.ld_t = ld;
+    const int G = group_frames_max();
+    int rc = UPSP_OK;
+    for (int64_t f0 = 0; f0 < nframes && rc == UPSP_OK; f0 += G) {
+        g.nframes = (int)std::min<int64_t>(G, nframes - f0);
+        g.rows_t = d_rows_t + f0;
+        rc = launch_node_rows(g, d_node_k, d_compact + f0, cpitch, (hipStream_t)stream);
+    }
+    return rc;
+}
+
 static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes,
                         int64_t first_frame, float *d_rows, float *d_rows_t, uint16_t *d_rows_t16,
                         int64_t ld_t, int64_t col0, float *d_warps, void *stream)

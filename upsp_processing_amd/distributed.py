@@ -35,8 +35,19 @@ def lib_comm(group=None):
     """The library's RCCL communicator of the process group (created on first use: rank 0 makes the
     ncclUniqueId, torch.distributed broadcasts its 128 bytes, every rank calls upsp_comm_create on its
     current device).  None when the group does not run on RCCL (gloo) or there is no group."""
-    if not dist.is_initialized() or not torch.cuda.is_available():
+    if not torch.cuda.is_available():
         return None
+    if not dist.is_initialized():
+        # one rank, no process group: the same entry points through the library's in-process transport
+        # (upsp_comm_create_local with one rank: device-to-device copies), so that a single-GPU run of the chunked loop
+        # executes the code a multi-GPU run executes
+        if "local1" not in _LIB_COMM:
+            import ctypes as C
+            from . import _capi
+            arr = (C.c_void_p * 1)()
+            _capi.check(_capi.lib().upsp_comm_create_local(1, arr))
+            _LIB_COMM["local1"] = C.c_void_p(arr[0])
+        return _LIB_COMM["local1"]
     if dist.get_backend(group) != "nccl":
         return None
     key = id(group)
@@ -170,7 +181,7 @@ def exchange_time_series(rows_t, shard, group=None, out=None):
             return rows_t                      # single rank: already the complete series
         out.copy_(rows_t)
         return out
-    if rows_t.is_cuda and rows_t.dtype == torch.float32 and lib_comm(group) is not None:
+    if rows_t.is_cuda and rows_t.dtype == torch.float32 and dist.is_initialized() and lib_comm(group) is not None:
         # RCCL through the C ABI (upsp_exchange_*): one chunk, every row travels
         x = TimeSeriesExchange(shard, 1, device=rows_t.device, group=group)
         x.set_skipped(None)
@@ -277,7 +288,7 @@ class TimeSeriesExchange:
         self._unverified = False # an assume_same claim is pending: verify() has not been called since
         self._x = None           # C-ABI exchange (upsp_exchange_*): RCCL ranks on GPUs
         comm = lib_comm(group) if (str(device).startswith("cuda") and dtype == torch.float32
-                                   and (shard.world > 1 or FORCE_COLLECTIVES)) else None
+                                   and (shard.world > 1 or FORCE_COLLECTIVES or not dist.is_initialized())) else None
         if comm is not None:
             import ctypes as C
             from . import _capi
@@ -518,6 +529,148 @@ def _exchange_bytes(self):
 
 
 TimeSeriesExchange.exchange_bytes = _exchange_bytes
+
+
+# ---- pixel-series mode ---------------------------------------------------------------------------------------------------
+# A node's series is the series of the pixel it reads; on a model finer than the pixel grid several nodes share a pixel.
+# The ranks then exchange the u16 series of the ACTIVE PIXELS -- every destination gets the pixels its node slice reads,
+# each once -- and the owner of a node runs pass B over all frames of the run (upsp_exchange_set_pixels / submit_pixels /
+# finish_pixels; here the same bookkeeping on torch.distributed for gloo).  Sender side: FramePipeline.pixel_series
+# (pass A + hot-pixel repair) per chunk instead of process().
+
+def _set_pixels(self, node_k, skipped, assume_same=False):
+    """node_k int32 [N]: row of the sender's compact buffer per node (< 0: none), identical on every rank (the projection
+    is replicated); skipped uint8 / bool [N]."""
+    sh = self.shard
+    if self._x is not None:
+        import ctypes as C
+        from . import _capi
+        sk = None if skipped is None else skipped.to(torch.uint8).contiguous()
+        self._sk, self._nk = sk, node_k
+        _capi.check(_capi.lib().upsp_exchange_set_pixels(self._x, C.c_void_p(node_k.data_ptr()),
+                                                         C.c_void_p(sk.data_ptr() if sk is not None else 0),
+                                                         int(bool(assume_same)), self._stream()))
+        if assume_same:
+            self._unverified = True
+        self.vis = True
+        return
+    keep = torch.ones(sh.nnodes, dtype=torch.bool, device=node_k.device) if skipped is None else (skipped == 0)
+    if assume_same and getattr(self, "_px", None) is not None:
+        bad = (self._px["nk"] != node_k).any() | (self._px["keep"] != keep).any()
+        self._mismatch = bad if self._mismatch is None else (self._mismatch | bad)
+        self._unverified = True
+        return
+    lists, cut, local = [], [0], None
+    for d in range(sh.world):
+        n0, nn = sh.node_start[d], sh.node_count[d]
+        nk, kp = node_k[n0:n0 + nn].long(), keep[n0:n0 + nn]
+        ks = torch.unique(nk[kp & (nk >= 0)])                 # sorted
+        lists.append(ks)
+        cut.append(cut[-1] + ks.numel())
+        if d == sh.rank:
+            local = torch.where(kp & (nk >= 0), torch.searchsorted(ks, nk.clamp(min=0)), torch.full_like(nk, -1))
+            sk_me = ~kp
+    self._px = dict(nk=node_k.clone(), keep=keep.clone(), send_k=torch.cat(lists) if lists else None, cut=cut, local=local,
+                    skipped_me=sk_me, compact_me=torch.zeros((cut[sh.rank + 1] - cut[sh.rank], sh.nframes), dtype=torch.int32,
+                                                            device=node_k.device))
+    self.vis = True
+
+
+def _pixel_rows(self):
+    """(pixel rows this rank sends per chunk, pixel rows it receives)."""
+    if self._x is not None:
+        import ctypes as C
+        from . import _capi
+        a, b = C.c_int64(), C.c_int64()
+        _capi.check(_capi.lib().upsp_exchange_pixel_rows(self._x, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+    c = self._px["cut"]
+    return c[-1], c[self.shard.rank + 1] - c[self.shard.rank]
+
+
+def _submit_pixels(self, compact, cpitch=None):
+    """compact: the sender's [active pixel][>= chunk frames] u16 series of its chunk number len(submitted) -- the dict
+    FramePipeline.pixel_series returns (C-ABI exchange), or a tensor (torch.distributed path)."""
+    sh, k = self.shard, self.k
+    if k >= self.K:
+        raise RuntimeError("TimeSeriesExchange.submit_pixels: all %d chunks were already submitted (finish_pixels() first)" % self.K)
+    c0, fc = self.my_chunk(k)
+    if self._x is not None:
+        import ctypes as C
+        from . import _capi
+        ptr, cp = (compact["ptr"], compact["cpitch"]) if isinstance(compact, dict) else (compact.data_ptr(), compact.stride(0))
+        _capi.check(_capi.lib().upsp_exchange_submit_pixels(self._x, C.c_void_p(ptr), cp, 12 if self.wire12 else 2, self._stream()))
+        self.k += 1
+        return
+    px = self._px
+    if isinstance(compact, dict):          # the pipeline's buffer (FramePipeline.pixel_series): a view, no copy
+        from .engine import _DevArray
+        compact = torch.as_tensor(_DevArray(compact["ptr"], compact["rows"] * compact["cpitch"], "<i2", compact["owner"]),
+                                  device="cuda").view(compact["rows"], compact["cpitch"])
+    comp = compact.view(torch.int16) if compact.dtype == torch.uint16 else compact
+    send = comp.index_select(0, px["send_k"])[:, :fc].contiguous()                # [sum |L_d|][fc], by destination
+    self.k += 1
+    cut, r = px["cut"], sh.rank
+    rows_in = cut[r + 1] - cut[r]
+    if not (dist.is_initialized() and sh.world > 1):
+        self.pending.append((None, send, k, send, rows_in, False))
+        return
+    in_split = [(cut[d + 1] - cut[d]) * fc * 2 for d in range(sh.world)]
+    out_split = [rows_in * self.chunks[s][1][k] * 2 for s in range(sh.world)]
+    flat = send.reshape(-1).view(torch.uint8)
+    recv = torch.empty(sum(out_split), dtype=torch.uint8, device=send.device)
+    work = dist.all_to_all_single(recv, flat, out_split, in_split, group=self.group, async_op=True)
+    self.pending.append((work, recv, k, send, rows_in, True))
+
+
+def _finish_pixels(self, total, sumsq):
+    """Places what arrived and runs pass B for this rank's nodes over all frames: returns the series [nodes_r, F] (NaN rows
+    for the skipped nodes) and ADDS the sums over all frames into total / sumsq [N] at this rank's slice (float64; the other
+    ranks' slices are left alone: with zeroed accumulators allreduce_sums then delivers the complete vectors)."""
+    sh = self.shard
+    n0, nn = sh.my_nodes
+    if self._x is not None:
+        import ctypes as C
+        from . import _capi
+        assert total.is_contiguous() and sumsq.is_contiguous() and total.dtype == torch.float64
+        _capi.check(_capi.lib().upsp_exchange_finish_pixels(self._x, C.c_void_p(self.out.data_ptr()), self.out.stride(0),
+                                                            C.c_void_p(total.data_ptr() + 8 * n0), C.c_void_p(sumsq.data_ptr() + 8 * n0),
+                                                            self._stream()))
+        self.k = 0
+        return self.out
+    px = self._px
+    cm = px["compact_me"]
+    for work, recv, k, _, rows_in, wired in self.pending:
+        if work is not None:
+            work.wait()
+        off = 0
+        for s in range(sh.world):
+            fs = self.chunks[s][1][k]
+            if wired:
+                blk = recv[off * 1:off + rows_in * fs * 2].view(torch.int16).view(rows_in, fs) if fs and rows_in else None
+                off += rows_in * fs * 2
+            else:      # one rank: the send buffer is the block
+                blk = recv[:, :fs] if s == sh.rank else None
+            if blk is not None and fs and rows_in:
+                col = sh.frame_start[s] + self.chunks[s][0][k]
+                cm[:, col:col + fs] = blk.to(torch.int32) & 0xFFFF
+    self.pending = []
+    self.k = 0
+    loc = px["local"]
+    vals = torch.where((loc >= 0)[:, None], cm.index_select(0, loc.clamp(min=0)), torch.zeros((), dtype=torch.int32, device=cm.device))
+    series = vals.to(torch.float32)
+    series[px["skipped_me"]] = float("nan")
+    self.out.copy_(series)
+    d = series.double()
+    total[n0:n0 + nn] += d.sum(1)
+    sumsq[n0:n0 + nn] += (series * series).double().sum(1)
+    return self.out
+
+
+TimeSeriesExchange.set_pixels = _set_pixels
+TimeSeriesExchange.pixel_rows = _pixel_rows
+TimeSeriesExchange.submit_pixels = _submit_pixels
+TimeSeriesExchange.finish_pixels = _finish_pixels
 
 
 def gather_time_series_to_root(series, shard, group=None):

@@ -336,6 +336,23 @@ class FramePipeline:
         assert tuple(frames.shape[1:]) == (self.height, self.width)
         check(lib().upsp_pipeline_prescan(self._h, _ptr(frames), frames.shape[0], _stream()))
 
+    def pixel_series(self, frames):
+        """Pass A alone (upsp_pipeline_pixel_series): the REPAIRED u16 series of every active pixel over these (<= 1024)
+        frames, left in the pipeline's compact buffer; the frames are repaired in place.  Returns dict(ptr = device address
+        of the buffer [active pixel][cpitch], cpitch, node_k = int32 [N] tensor aliasing the pipeline's node -> row table,
+        nactive = uint32 [1] tensor (rows in use)).  Valid until the next call on this pipeline."""
+        comp, nk, na, cp = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint32()
+        if frames is None or frames.shape[0] == 0:      # only the node -> row table of the current projection
+            check(lib().upsp_pipeline_pixel_series(self._h, None, 0, _stream(), C.byref(comp), C.byref(cp), C.byref(nk), C.byref(na)))
+        else:
+            assert frames.is_cuda and frames.dtype == torch.uint16 and frames.is_contiguous()
+            assert tuple(frames.shape[1:]) == (self.height, self.width)
+            check(lib().upsp_pipeline_pixel_series(self._h, _ptr(frames), frames.shape[0], _stream(), C.byref(comp), C.byref(cp),
+                                                   C.byref(nk), C.byref(na)))
+        return dict(ptr=comp.value, cpitch=int(cp.value), rows=min(self.nnodes, self.width * self.height), owner=self,
+                    node_k=torch.as_tensor(_DevArray(nk.value, self.nnodes, "<i4", self), device="cuda"),
+                    nactive=torch.as_tensor(_DevArray(na.value, 1, "<u4", self), device="cuda"))
+
     def set_skipped(self, skipped):
         sk = None if skipped is None else _dev(skipped, torch.uint8)
         check(lib().upsp_pipeline_set_skipped(self._h, _ptr(sk)))
