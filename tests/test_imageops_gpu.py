@@ -312,11 +312,11 @@ def test_registration_full_size_1024(gpu_lib, oracle):
                 aa, bb = a.cpu().numpy(), b.cpu().numpy()
                 assert np.array_equal(np.isnan(aa), np.isnan(bb)) and np.array_equal(aa[~np.isnan(aa)], bb[~np.isnan(bb)])
         else:
-            # calls of 7 frames into column blocks of the same rows: other sub-batches -> the double sums of the ECC are
-            # reduced in another order (and the float segments of the column sums start at other rows) -> a warp differs by
-            # ~1e-5 px, far inside the 2e-3 px bar; every row is exact for the warp it reports
+            # calls of 7 frames into column blocks of the same rows: other sub-batches, the SAME warps bit for bit -- the
+            # blocks (and with them the float segments of the column sums) are cut by the image geometry alone, not by how
+            # many frames of the sub-batch are still iterating
             ww = w2.cpu().numpy()[:, 0].reshape(F, 2, 3)
-            assert np.abs(ww[:, :, :2] - w[:, :, :2]).max() <= 1e-6 and np.abs(ww[:, :, 2] - w[:, :, 2]).max() <= 1e-4
+            assert np.array_equal(ww.view(np.int32), w.view(np.int32))
             for f in range(1, F):
                 img, _ = oracle.fix_hot_pixels(frames[f])
                 want = oracle.project_frame(oracle.warp_affine(img, ww[f], 1), pix, None)

@@ -520,9 +520,11 @@ __device__ __forceinline__ void ecc_block_store(const double (&acc)[kEccSums], d
 }
 
 struct EccMargins { int top, bottom, left, right; };
+__device__ int g_ecc_band_extra = 0;     // debug (UPSP_ECC_BAND_EXTRA): widen the band, i.e. move pixels from the interior loops to the band's
 __device__ __forceinline__ EccMargins ecc_margins(int band, int rows, int cols)
 {
     EccMargins g;
+    band += g_ecc_band_extra;
     g.top = min(band, rows / 2);
     g.bottom = min(band, rows - g.top);
     g.left = min(band, cols / 2);
@@ -789,6 +791,7 @@ struct EccPart {        // float partial sums of one segment
 struct EccTot {         // double totals of the thread's column piece (Y = true row)
     double G0[2], G1[2], Gw0[2], Gw1[2], Gt0[2], Gt1[2], Q0[2], Q1[2], Q2[2], C0, C1, C2;
     double Sw, Sww, St, Stt, Stw, n;
+    float cf;           // centre: the float products are taken with (w - cf) and (t - cf), see ecc_part_add
 };
 
 __device__ __forceinline__ void ecc_part_zero(EccPart &p)
@@ -801,10 +804,20 @@ __device__ __forceinline__ void ecc_part_zero(EccPart &p)
 // one pixel: warped value w, warped gradients gx / gy, template t, row offset rf (= r as a float) in its segment.
 // MASKED (band pixels): m = the nearest-neighbour mask of cv::findTransformECC; masked sums as in ecc_accumulate
 // (n, the scalar sums, sum_mask J, sum_mask J t), the others over all pixels.
+// Interior pixels: the products with w and t are taken with (w - c), (t - c), c = T.cf = an INTEGER near the template's mean
+// (ecc_center_kernel), and c x (sum of the gradients) is added back in double at the end (ecc_tot_value).  The
+// subtraction is exact (12-bit images blurred to floats below 4096 minus an integer below 4096), the identity
+// sum g w = sum g (w - c) + c sum g too; what changes is the size of the numbers that get rounded: a product g w with
+// w ~ 1800 carries an absolute rounding error of |g| x 1e-4, the same product with |w - c| ~ 100 a tenth of that --
+// and what the solve uses is sum J w - mean(w) sum J, a difference that used to cancel the leading 1-2 digits of these
+// sums (measured on a 49 x 888 frame against sums taken in exact arithmetic: relative error of sum gy w 3.2e-8 ->
+// see DESIGN.md section 8; the reference rounds every one of these sums to FLOAT before its 6 x 6 solve, so a sum that
+// lands on another float moves the result by a float ulp amplified by the solve).
 template <bool MASKED>
 __device__ __forceinline__ void ecc_part_add(EccPart &p, EccTot &T, float w, float gx, float gy, float t, float rf, bool m = true)
 {
-    const v2f G = {gx, gy}, R = {rf, rf}, W = {w, w}, Tt = {t, t};
+    const float wc = MASKED ? w : w - T.cf, tc = MASKED ? t : t - T.cf;
+    const v2f G = {gx, gy}, R = {rf, rf}, W = {wc, wc}, Tt = {tc, tc};
     const v2f Z = {0.f, 0.f};
     const v2f Gm = (MASKED && !m) ? Z : G;
     const float rf2 = rf * rf;
@@ -861,7 +874,7 @@ __device__ __forceinline__ void ecc_part_flush(const EccPart &p, EccTot &T, int 
 template <int K>
 __device__ __forceinline__ double ecc_tot_value(const EccTot &T, double X)
 {
-    const double X2 = X * X;
+    const double X2 = X * X, c = (double)T.cf;      // (sum g w = sum g (w - c) + c sum g: exact, in double)
     switch (K) {
     case 0: return T.n;
     case 1: return T.Sw;
@@ -869,24 +882,24 @@ __device__ __forceinline__ double ecc_tot_value(const EccTot &T, double X)
     case 3: return T.St;
     case 4: return T.Stt;
     case 5: return T.Stw;
-    case 6: return X * T.Gw0[0];
-    case 7: return X * T.Gw0[1];
-    case 8: return T.Gw1[0];
-    case 9: return T.Gw1[1];
-    case 10: return T.Gw0[0];
-    case 11: return T.Gw0[1];
+    case 6: return X * (T.Gw0[0] + c * T.G0[0]);
+    case 7: return X * (T.Gw0[1] + c * T.G0[1]);
+    case 8: return T.Gw1[0] + c * T.G1[0];
+    case 9: return T.Gw1[1] + c * T.G1[1];
+    case 10: return T.Gw0[0] + c * T.G0[0];
+    case 11: return T.Gw0[1] + c * T.G0[1];
     case 12: return X * T.G0[0];
     case 13: return X * T.G0[1];
     case 14: return T.G1[0];
     case 15: return T.G1[1];
     case 16: return T.G0[0];
     case 17: return T.G0[1];
-    case 18: return X * T.Gt0[0];
-    case 19: return X * T.Gt0[1];
-    case 20: return T.Gt1[0];
-    case 21: return T.Gt1[1];
-    case 22: return T.Gt0[0];
-    case 23: return T.Gt0[1];
+    case 18: return X * (T.Gt0[0] + c * T.G0[0]);
+    case 19: return X * (T.Gt0[1] + c * T.G0[1]);
+    case 20: return T.Gt1[0] + c * T.G1[0];
+    case 21: return T.Gt1[1] + c * T.G1[1];
+    case 22: return T.Gt0[0] + c * T.G0[0];
+    case 23: return T.Gt0[1] + c * T.G0[1];
     // J J^T, upper triangle row-major, J = [gx X, gy X, gx Y, gy Y, gx, gy]
     case 24: return X2 * T.Q0[0];     // (0,0) gx^2 X^2
     case 25: return X2 * T.C0;        // (0,1) gx gy X^2
@@ -1070,16 +1083,21 @@ __device__ __forceinline__ void ecc_cols_trip(const float *__restrict__ I, const
             // Bilinear interpolation of I and of its central differences along x and y (cv::findTransformECC warps the two
             // gradient IMAGES).  All three are linear in the pixels, so with V_j = the vertical interpolation at column j
             //     w  = V_0 + fx (V_1 - V_0)
-            //     gx = 1/2 [ (V_1 - V_-1) + fx ((V_2 - V_0) - (V_1 - V_-1)) ]
+            //     gx = 1/2 [ q_0 + fx (q_1 - q_0) ],   q = (b_+ - b_-) + fy ((c_+ - c_-) - (b_+ - b_-))  at columns 0, 1
             //     gy = 1/2 [ p_0 + fx (p_1 - p_0) ],   p = (c - a) + fy ((d - b) - (c - a))  at columns 0, 1
             // -- 19 instructions where the four-weight form of round 2 took ~50.  With zero fractions (identity) these
             // are exactly the taps of the identity iteration: V_j = b_j, w = b_0, gx = (b_1 - b_-1) / 2, gy = (c_0 - a_0) / 2.
+            // (gx from the horizontal DIFFERENCES of the pixels, interpolated -- not from differences of the interpolated
+            //  V_j: those carry the rounding of values ~2000, 1e-4, into a gradient of a few counts, 1e-5 relative, where the
+            //  reference's warped gradient image is good to 1e-7; the ECC iteration amplifies that on small or weakly
+            //  textured images -- tests/debug/soak_ecc.py found it, 8e-3 px on a 97 x 258 frame.  Two instructions more.)
             const v2f FY = {fy[k], fy[k]};
             const v2f Vm = __builtin_elementwise_fma(FY, Cm[k] - Bm[k], Bm[k]);     // {V_0, V_1}
-            const v2f Ve = __builtin_elementwise_fma(FY, Ce[k] - Be[k], Be[k]);     // {V_-1, V_2}
             const float w = __builtin_fmaf(fx[k], Vm[1] - Vm[0], Vm[0]);
-            const float dx0 = Vm[1] - Ve[0], dx1 = Ve[1] - Vm[0];
-            const float gx = 0.5f * __builtin_fmaf(fx[k], dx1 - dx0, dx0);
+            const v2f Db = {Bm[k][1] - Be[k][0], Be[k][1] - Bm[k][0]};             // {b_1 - b_-1, b_2 - b_0}: exact-ish differences
+            const v2f Dc = {Cm[k][1] - Ce[k][0], Ce[k][1] - Cm[k][0]};
+            const v2f Qx = __builtin_elementwise_fma(FY, Dc - Db, Db);
+            const float gx = 0.5f * __builtin_fmaf(fx[k], Qx[1] - Qx[0], Qx[0]);
             const v2f E = Cm[k] - A[k], F = D[k] - Bm[k];
             const v2f Pp = __builtin_elementwise_fma(FY, F - E, E);
             const float gy = 0.5f * __builtin_fmaf(fx[k], Pp[1] - Pp[0], Pp[0]);
@@ -1095,7 +1113,7 @@ template <bool IDENT, int UR, int NEIGHBOUR>
 __device__ __forceinline__ void ecc_cols_body(const float *__restrict__ img, const float *__restrict__ tmpl, int rows,
                                               int cols, const EccState *__restrict__ state,
                                               double *__restrict__ partial, int f, unsigned blk, unsigned nblk,
-                                              double (*lds_red)[256])
+                                              double (*lds_red)[256], float center)
 {
     // one LDS area: the per-row coordinate table while the rows are walked, the reduction chunks afterwards
     static_assert(sizeof(int2) * kEccRowTab <= sizeof(double) * kEccChunk * 256, "row table fits the reduction area");
@@ -1136,6 +1154,7 @@ __device__ __forceinline__ void ecc_cols_body(const float *__restrict__ img, con
         T.G0[k] = T.G1[k] = T.Gw0[k] = T.Gw1[k] = T.Gt0[k] = T.Gt1[k] = T.Q0[k] = T.Q1[k] = T.Q2[k] = 0.0;
     T.C0 = T.C1 = T.C2 = T.Sw = T.Sww = T.St = T.Stt = T.Stw = 0.0;
     T.n = on ? (double)(y1 - y0) : 0.0;          // mask = 1 on every interior pixel
+    T.cf = center;
     if (on || NEIGHBOUR) {
         const int ax = IDENT ? 0 : __double2int_rn(M[0] * x * 1024), bx = IDENT ? 0 : __double2int_rn(M[3] * x * 1024);
         const int2 *rt = rtab_s;
@@ -1215,6 +1234,7 @@ __device__ __forceinline__ void ecc_band_cols_body(const float *__restrict__ img
     for (int k = 0; k < 2; ++k)
         T.G0[k] = T.G1[k] = T.Gw0[k] = T.Gw1[k] = T.Gt0[k] = T.Gt1[k] = T.Q0[k] = T.Q1[k] = T.Q2[k] = 0.0;
     T.C0 = T.C1 = T.C2 = T.Sw = T.Sww = T.St = T.Stt = T.Stw = T.n = 0.0;
+    T.cf = 0.f;
     if (on) {
         auto pix = [&](int yy, int xx) { return I[(size_t)yy * cols + xx]; };
         auto gxf = [&](int yy, int xx) {
@@ -1270,17 +1290,40 @@ __device__ __forceinline__ void ecc_band_cols_body(const float *__restrict__ img
     ecc_tot_store<0>(T, (double)x, on, lds_red, partial, f, bidx);
 }
 
+// centre of the float products (ecc_part_add): the mean of a 64 x 64 sample grid of the blurred template, rounded to an
+// integer and kept inside [0, 4095] (any integer there keeps w - c exact; the nearer to the image's mean, the smaller the
+// products).  Once per reference image; fixed order: deterministic.
+__global__ void __launch_bounds__(256) ecc_center_kernel(const float *__restrict__ tmpl, int rows, int cols, float *__restrict__ out)
+{
+    __shared__ double sh[256];
+    double a = 0.0;
+    for (int k = threadIdx.x; k < 4096; k += 256) {
+        const int y = (int)(((long long)(k >> 6) * rows) >> 6), x = (int)(((long long)(k & 63) * cols) >> 6);
+        a += (double)tmpl[(size_t)y * cols + x];
+    }
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double m = sh[0] / 4096.0;
+        out[0] = (m >= 0.0 && m <= 4095.0) ? (float)rint(m) : 0.f;      // (images outside the 12-bit range: no centring)
+    }
+}
+
 template <bool IDENT, int UR, int WAVES, int NEIGHBOUR = 0>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
     ecc_cols_kernel(const float *__restrict__ img, const float *__restrict__ tmpl, int rows, int cols,
-                    const EccState *__restrict__ state, double *__restrict__ partial)
+                    const EccState *__restrict__ state, double *__restrict__ partial, const float *__restrict__ center)
 {
     __shared__ double lds_red[kEccChunk][256];     // row table / reduction chunks of whichever body runs
     const int f = blockIdx.x;
     if (state[f].done) return;
     const unsigned nint = gridDim.y - (unsigned)kEccBorderBlocks;
     if (blockIdx.y >= (unsigned)kEccBorderBlocks)
-        ecc_cols_body<IDENT, UR, NEIGHBOUR>(img, tmpl, rows, cols, state, partial, f, blockIdx.y - (unsigned)kEccBorderBlocks, nint, lds_red);
+        ecc_cols_body<IDENT, UR, NEIGHBOUR>(img, tmpl, rows, cols, state, partial, f, blockIdx.y - (unsigned)kEccBorderBlocks, nint, lds_red, *center);
     else
         ecc_band_cols_body(img, tmpl, rows, cols, state, partial, f, blockIdx.y, IDENT, lds_red);
 }
@@ -1335,6 +1378,7 @@ __device__ __forceinline__ void gauss5_cols_body(const uint16_t *__restrict__ sr
             T.G0[k] = T.G1[k] = T.Gw0[k] = T.Gw1[k] = T.Gt0[k] = T.Gt1[k] = T.Q0[k] = T.Q1[k] = T.Q2[k] = 0.0;
         T.C0 = T.C1 = T.C2 = T.Sw = T.Sww = T.St = T.Stt = T.Stw = 0.0;
         T.n = own ? (double)(y1 - y0) : 0.0;
+        T.cf = 0.f;                               // (opt-in measurement kernel: products not centred)
     }
     if (wave_on) {
         // column offsets of the lane's own pixel and of the two pixels only the edge lanes fetch (reflect-101)
@@ -1955,6 +1999,7 @@ struct FrameScratch {
     float *tmp = nullptr;                   // filter intermediate (float), also box sums (double)
     float *tmpl[kMaxCams] = {nullptr};      // blurred ECC templates
     const float *tmpl_src[kMaxCams] = {nullptr};
+    float *center = nullptr;                // [kMaxCams] centre of the float products of the ECC sums (ecc_center_kernel)
     double *partial = nullptr;
     EccState *state = nullptr;
     int *counter = nullptr;
@@ -1978,6 +2023,7 @@ void frame_scratch_free(FrameScratch *s)
         if (s->tmpl[c]) (void)hipFree(s->tmpl[c]);
     }
     if (s->ecc_img) (void)hipFree(s->ecc_img);
+    if (s->center) (void)hipFree(s->center);
     if (s->tmp) (void)hipFree(s->tmp);
     if (s->partial) (void)hipFree(s->partial);
     if (s->state) (void)hipFree(s->state);
@@ -2010,6 +2056,10 @@ int frame_scratch_ensure(FrameScratch **ps, int ncams, int batch, int rows, int 
         if (need_warp && !s->tmpl[c]) UPSP_HIP_CHECK(hipMalloc(&s->tmpl[c], (size_t)rows * cols * sizeof(float)));
     }
     if (need_warp && !s->ecc_img) UPSP_HIP_CHECK(hipMalloc(&s->ecc_img, n * sizeof(float)));
+    if (need_warp && !s->center) {
+        UPSP_HIP_CHECK(hipMalloc(&s->center, kMaxCams * sizeof(float)));
+        UPSP_HIP_CHECK(hipMemset(s->center, 0, kMaxCams * sizeof(float)));
+    }
     if (!s->tmp) UPSP_HIP_CHECK(hipMalloc(&s->tmp, n * sizeof(double)));
     if (need_warp && !s->partial)
         UPSP_HIP_CHECK(hipMalloc(&s->partial, sizeof(double) * (size_t)batch * kEccStride * kEccSums));
@@ -2019,7 +2069,7 @@ int frame_scratch_ensure(FrameScratch **ps, int ncams, int batch, int rows, int 
 }
 
 // ECC registration of nb frames against the blurred template; leaves the warp in state[].
-static int run_ecc(FrameScratch *s, const float *tmpl_blur, const uint16_t *frames, int nb,
+static int run_ecc(FrameScratch *s, const float *tmpl_blur, const float *d_center, const uint16_t *frames, int nb,
                    int64_t first_frame, int rows, int cols, int max_iters, double eps, hipStream_t st)
 {
     if ((long long)rows * cols >= (1ll << 31)) return fail(UPSP_ERR_INVALID, "registration: image too large");
@@ -2050,6 +2100,12 @@ static int run_ecc(FrameScratch *s, const float *tmpl_blur, const uint16_t *fram
                      : launch_gauss<uint16_t>(frames, s->ecc_img, s->tmp, nb, rows, cols, 5, st);
         if (rc != UPSP_OK) return rc;
     }
+    static const int band_extra = [] {
+        const int e = env_int_io("UPSP_ECC_BAND_EXTRA", 0);
+        if (e > 0) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ecc_band_extra), &e, sizeof(e));
+        return e;
+    }();
+    (void)band_extra;
     bool first_burst = true;
     int active = nb;  // frames still iterating (known to the host after every burst)
     int iters_done = 0, most_iters = 0;
@@ -2069,9 +2125,17 @@ static int run_ecc(FrameScratch *s, const float *tmpl_blur, const uint16_t *fram
         static const int kernel_sel = env_int_io("UPSP_ECC_KERNEL", 3);
         const int tiles = (cols + 255) / 256;
         const bool cols_ok = kernel_sel == 3 && 3 * tiles <= kEccBorderBlocks && tiles <= kEccBlocksMax;
-        static const int blocks0 = env_int_io("UPSP_ECC_BLOCKS", 64);     // (measured 16 / 32 / 64: 6.74 / 6.25 / 6.03 ms of sums per 1000 frames)
+        static const int blocks0 = std::min(std::max(env_int_io("UPSP_ECC_BLOCKS", 64), 1), kEccBlocksMax);     // (measured 16 / 32 / 64: 6.74 / 6.25 / 6.03 ms of sums per 1000 frames)
         int blocks = cols_ok ? blocks0 : kEccBlocks;
-        while (blocks < kEccBlocksMax && ((long long)blocks * active < (cols_ok ? 1024 : 2048) ||
+        // The column kernel's float segments follow the row pieces, i.e. the block count: it must not depend on how many
+        // frames are still iterating, or the last bits of a frame's sums -- and through the reference's float 6 x 6 solve
+        // 1e-5 .. 1e-4 px of its warp -- would depend on which frames share its sub-batch (measured: 2.6e-4 px between a
+        // frame registered in a batch of 11 and in a batch of 7).  One count per image geometry: the warp of a frame is
+        // the same bits in any batch (tests/test_imageops_gpu.py).  UPSP_ECC_BLOCKS_GROW=1: round 2's policy for the
+        // column kernel too (more, smaller blocks when few frames are left: faster tails, batch-dependent bits).
+        static const int blocks_grow = env_int_io("UPSP_ECC_BLOCKS_GROW", 0);
+        const bool grow = !cols_ok || blocks_grow;
+        while (blocks < kEccBlocksMax && ((grow && (long long)blocks * active < (cols_ok ? 1024 : 2048)) ||
                                           (cols_ok && (blocks < tiles || rows > (long long)kEccRowTab * (blocks / tiles)))))
             blocks *= 2;
         const int nblocks_total = blocks + kEccBorderBlocks;
@@ -2083,7 +2147,7 @@ static int run_ecc(FrameScratch *s, const float *tmpl_blur, const uint16_t *fram
                        (const float *)s->ecc_img, tmpl_blur, rows, cols, (const EccState *)s->state, s->partial)
 #define UPSP_ECC_COLS(ID, URX, WV, ...)                                                                       \
     hipLaunchKernelGGL((ecc_cols_kernel<ID, URX, WV, ##__VA_ARGS__>), dim3(nb, blocks + kEccBorderBlocks), dim3(256), 0, st, \
-                       (const float *)s->ecc_img, tmpl_blur, rows, cols, (const EccState *)s->state, s->partial)
+                       (const float *)s->ecc_img, tmpl_blur, rows, cols, (const EccState *)s->state, s->partial, d_center)
                 // Round 3: one column per thread, factored packed-float sums (ecc_cols_kernel); needs one column tile of 256 per
                 // interior block at least.  UPSP_ECC_KERNEL=2 selects round 2's kernel (A/B, and images wider than that).
                 static const int cvariant = env_int_io("UPSP_ECC_CVARIANT", 0);
@@ -2129,6 +2193,17 @@ static int run_ecc(FrameScratch *s, const float *tmpl_blur, const uint16_t *fram
                 else UPSP_ECC_LAUNCH(false, 2, 2);
 #undef UPSP_ECC_COLS
 #undef UPSP_ECC_LAUNCH
+            }
+            static const int dump = env_int_io("UPSP_ECC_DUMP", -1);      // debug: the 45 sums of frame 0 at iteration `dump`
+            if (dump == it) {
+                std::vector<double> h((size_t)kEccSums * kEccStride);
+                UPSP_HIP_CHECK(hipStreamSynchronize(st));
+                UPSP_HIP_CHECK(hipMemcpy(h.data(), s->partial, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
+                for (int k = 0; k < kEccSums; ++k) {
+                    long double a = 0;
+                    for (int b = 0; b < nblocks_total; ++b) a += h[(size_t)k * kEccStride + b];
+                    std::fprintf(stderr, "[upsp] ecc sum %2d = %.17Lg\n", k, a);
+                }
             }
             KTimed kt2("ecc_solve_kernel", st);
             hipLaunchKernelGGL(ecc_solve_kernel, dim3(nb), dim3(256), 0, st, s->state,
@@ -2245,9 +2320,10 @@ int run_frame_stages(FrameScratch *s, int cam, const uint16_t *d_frames, int nb,
         if (s->tmpl_src[cam] != d_ref) {  // blurred template, once per reference image
             int rc = launch_gauss<float>(d_ref, s->tmpl[cam], s->tmp, 1, rows, cols, 5, st);
             if (rc != UPSP_OK) return rc;
+            hipLaunchKernelGGL(ecc_center_kernel, dim3(1), dim3(256), 0, st, (const float *)s->tmpl[cam], rows, cols, s->center + cam);
             s->tmpl_src[cam] = d_ref;
         }
-        int rc = run_ecc(s, s->tmpl[cam], d_frames, nb, first_frame, rows, cols, opts.ecc_max_iters,
+        int rc = run_ecc(s, s->tmpl[cam], s->center + cam, d_frames, nb, first_frame, rows, cols, opts.ecc_max_iters,
                          opts.ecc_eps, st);
         if (rc != UPSP_OK) return rc;
         if (wc) {      // registration is the last image stage and node-major series are wanted: straight into the compact buffer
@@ -2323,8 +2399,10 @@ int upsp_register_pixel_u16(const float *d_ref32f, const uint16_t *d_inp, int ro
     int rc = frame_scratch_ensure(&s, 1, 1, rows, cols, true, false);
     int iters = 0;
     if (rc == UPSP_OK) rc = launch_gauss<float>(d_ref32f, s->tmpl[0], s->tmp, 1, rows, cols, 5, st);
+    if (rc == UPSP_OK)
+        hipLaunchKernelGGL(ecc_center_kernel, dim3(1), dim3(256), 0, st, (const float *)s->tmpl[0], rows, cols, s->center);
     // first_frame = 1: a stand-alone call always registers (psp_process.cpp:1662-1679)
-    if (rc == UPSP_OK) rc = run_ecc(s, s->tmpl[0], d_inp, 1, 1, rows, cols, max_iters, eps, st);
+    if (rc == UPSP_OK) rc = run_ecc(s, s->tmpl[0], s->center, d_inp, 1, 1, rows, cols, max_iters, eps, st);
     if (rc == UPSP_OK) {
         hipLaunchKernelGGL(warp_u16_kernel, dim3(grid_for_pixels((size_t)rows * cols), 1), dim3(256), 0,
                            st, d_inp, d_out, rows, cols, (const EccState *)s->state, interp, (const unsigned *)nullptr);
