@@ -1,14 +1,13 @@
 #!/bin/bash
-# Per-launch durations of the ECC kernels of one registration step (rocprofv3 kernel trace); GPU box, repository root.
+# Per-kernel durations of one registration sub-batch (rocprofv3 kernel trace of tools/prof_ecc.py); GPU box, repository root.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/eccprof -- python3 bench.py --registration --no-cpu-baseline --no-reraycast --steps 1 --warmup 1 > gpurun_out/eccprof.log 2>&1
+rm -rf gpurun_out/eccprof
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/eccprof -- python3 tools/prof_ecc.py > gpurun_out/eccprof.log 2>&1
 python3 - <<PY
-import csv,glob,re
-f=glob.glob("gpurun_out/eccprof/*/*kernel_trace.csv")[0]
-rows=[r for r in csv.DictReader(open(f)) if "ecc_" in r["Kernel_Name"] and ("sums" in r["Kernel_Name"] or "interior" in r["Kernel_Name"] or "border" in r["Kernel_Name"])]
-rows.sort(key=lambda r:int(r["Start_Timestamp"]))
-def tag(n):
-    m=re.search(r"ecc_(\w+?)_kernel(<(\w+)>)?", n); return (m.group(1)[0].upper()+("t" if m.group(3)=="true" else "f" if m.group(3) else ""))
-print(" ".join("%s%.0f" % (tag(r["Kernel_Name"]), (int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3) for r in rows[-60:]))
+import csv,glob
+f=glob.glob("gpurun_out/eccprof/*/*kernel_stats.csv")[0]
+for r in csv.DictReader(open(f)):
+    if any(k in r["Name"] for k in ("ecc_", "gauss", "warp_", "node_rows", "hot_")):
+        print("%-60s calls %4s avg %8.1f us  min %8.1f max %8.1f" % (r["Name"][:60], r["Calls"], float(r["AverageNs"])/1e3, float(r["MinNs"])/1e3, float(r["MaxNs"])/1e3))
 PY
 rm -rf gpurun_out/eccprof

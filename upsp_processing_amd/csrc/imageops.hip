@@ -996,7 +996,7 @@ __device__ __forceinline__ v2f ld_v2f(const float *base, unsigned byte_off)     
     return *reinterpret_cast<const v2f *>(reinterpret_cast<const char *>(base) + byte_off + IMM);
 }
 
-template <bool IDENT, int UR, int NEIGHBOUR = 0>
+template <bool IDENT, int UR, int NEIGHBOUR = 0, int GXD = 1>
 __device__ __forceinline__ void ecc_cols_trip(const float *__restrict__ I, const float *__restrict__ tmpl, int cols, int x,
                                               int y, int r, int ax, int bx, const int2 *rtab, int rt0, const double *M,
                                               EccPart &P, EccTot &T)
@@ -1094,10 +1094,19 @@ __device__ __forceinline__ void ecc_cols_trip(const float *__restrict__ I, const
             const v2f FY = {fy[k], fy[k]};
             const v2f Vm = __builtin_elementwise_fma(FY, Cm[k] - Bm[k], Bm[k]);     // {V_0, V_1}
             const float w = __builtin_fmaf(fx[k], Vm[1] - Vm[0], Vm[0]);
-            const v2f Db = {Bm[k][1] - Be[k][0], Be[k][1] - Bm[k][0]};             // {b_1 - b_-1, b_2 - b_0}: exact-ish differences
-            const v2f Dc = {Cm[k][1] - Ce[k][0], Ce[k][1] - Cm[k][0]};
-            const v2f Qx = __builtin_elementwise_fma(FY, Dc - Db, Db);
-            const float gx = 0.5f * __builtin_fmaf(fx[k], Qx[1] - Qx[0], Qx[0]);
+            float gx;
+            if (GXD) {
+                // q_j = (b_+ - b_-) + fy ((c_+ - c_-) - (b_+ - b_-)), the bracket regrouped as (c_+ - b_+) - (c_- - b_-) so that the
+                // packed differences the loads deliver as pairs (Cm - Bm, Ce - Be) are used as they are
+                const v2f Dm = Cm[k] - Bm[k], De = Ce[k] - Be[k];                     // {c0-b0, c1-b1}, {c_1-b_1, c2-b2}
+                const float q0 = __builtin_fmaf(fy[k], Dm[1] - De[0], Bm[k][1] - Be[k][0]);
+                const float q1 = __builtin_fmaf(fy[k], De[1] - Dm[0], Be[k][1] - Bm[k][0]);
+                gx = 0.5f * __builtin_fmaf(fx[k], q1 - q0, q0);
+            } else {      // (measurement switch UPSP_ECC_GX=0: the first form, differences of the interpolated columns)
+                const v2f Ve = __builtin_elementwise_fma(FY, Ce[k] - Be[k], Be[k]);     // {V_-1, V_2}
+                const float dx0 = Vm[1] - Ve[0], dx1 = Ve[1] - Vm[0];
+                gx = 0.5f * __builtin_fmaf(fx[k], dx1 - dx0, dx0);
+            }
             const v2f E = Cm[k] - A[k], F = D[k] - Bm[k];
             const v2f Pp = __builtin_elementwise_fma(FY, F - E, E);
             const float gy = 0.5f * __builtin_fmaf(fx[k], Pp[1] - Pp[0], Pp[0]);
@@ -1109,7 +1118,7 @@ __device__ __forceinline__ void ecc_cols_trip(const float *__restrict__ I, const
 // Interior block `blk` of `nblk`: the inner rectangle (farther than the band from every edge) is cut into column tiles
 // of 256 and, per tile, into nblk / tiles row pieces; blocks beyond that store zeros.  Needs nblk >= tiles (the host
 // checks: cols <= 256 x interior blocks, else the round-2 kernel runs).
-template <bool IDENT, int UR, int NEIGHBOUR>
+template <bool IDENT, int UR, int NEIGHBOUR, int GXD>
 __device__ __forceinline__ void ecc_cols_body(const float *__restrict__ img, const float *__restrict__ tmpl, int rows,
                                               int cols, const EccState *__restrict__ state,
                                               double *__restrict__ partial, int f, unsigned blk, unsigned nblk,
@@ -1163,8 +1172,8 @@ __device__ __forceinline__ void ecc_cols_body(const float *__restrict__ img, con
             EccPart P;
             ecc_part_zero(P);
             int r = 0;
-            for (; r + UR <= ne; r += UR) ecc_cols_trip<IDENT, UR, NEIGHBOUR>(I, tmpl, cols, x, yb + r, r, ax, bx, rt, y0, M, P, T);
-            for (; r < ne; ++r) ecc_cols_trip<IDENT, 1, NEIGHBOUR>(I, tmpl, cols, x, yb + r, r, ax, bx, rt, y0, M, P, T);
+            for (; r + UR <= ne; r += UR) ecc_cols_trip<IDENT, UR, NEIGHBOUR, GXD>(I, tmpl, cols, x, yb + r, r, ax, bx, rt, y0, M, P, T);
+            for (; r < ne; ++r) ecc_cols_trip<IDENT, 1, NEIGHBOUR, GXD>(I, tmpl, cols, x, yb + r, r, ax, bx, rt, y0, M, P, T);
             ecc_part_flush(P, T, yb);
         }
     }
@@ -1313,7 +1322,7 @@ __global__ void __launch_bounds__(256) ecc_center_kernel(const float *__restrict
     }
 }
 
-template <bool IDENT, int UR, int WAVES, int NEIGHBOUR = 0>
+template <bool IDENT, int UR, int WAVES, int NEIGHBOUR = 0, int GXD = 1>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
     ecc_cols_kernel(const float *__restrict__ img, const float *__restrict__ tmpl, int rows, int cols,
                     const EccState *__restrict__ state, double *__restrict__ partial, const float *__restrict__ center)
@@ -1323,7 +1332,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
     if (state[f].done) return;
     const unsigned nint = gridDim.y - (unsigned)kEccBorderBlocks;
     if (blockIdx.y >= (unsigned)kEccBorderBlocks)
-        ecc_cols_body<IDENT, UR, NEIGHBOUR>(img, tmpl, rows, cols, state, partial, f, blockIdx.y - (unsigned)kEccBorderBlocks, nint, lds_red, *center);
+        ecc_cols_body<IDENT, UR, NEIGHBOUR, GXD>(img, tmpl, rows, cols, state, partial, f, blockIdx.y - (unsigned)kEccBorderBlocks, nint, lds_red, *center);
     else
         ecc_band_cols_body(img, tmpl, rows, cols, state, partial, f, blockIdx.y, IDENT, lds_red);
 }
@@ -2151,6 +2160,7 @@ static int run_ecc(FrameScratch *s, const float *tmpl_blur, const float *d_cente
                 // Round 3: one column per thread, factored packed-float sums (ecc_cols_kernel); needs one column tile of 256 per
                 // interior block at least.  UPSP_ECC_KERNEL=2 selects round 2's kernel (A/B, and images wider than that).
                 static const int cvariant = env_int_io("UPSP_ECC_CVARIANT", 0);
+                static const int gx_form = env_int_io("UPSP_ECC_GX", 1);
                 const bool use_cols = cols_ok && blocks >= tiles && rows <= (long long)kEccRowTab * (blocks / tiles) &&
                                       rows < 32768 && cols < 32768;
                 // pixels per thread and trip / waves per SIMD of round 2's kernel, measured on 1000 frames of 1024^2
@@ -2173,10 +2183,14 @@ static int run_ecc(FrameScratch *s, const float *tmpl_blur, const float *d_cente
                     } else {
                         // (general iteration, same box: 2 rows per trip at 4 waves per SIMD 316, 4 rows at 3 waves 306, 3 at 3: 313,
                         //  2 at 3: 330 -- flat: neither rows in flight nor occupancy is what bounds it)
+                        // with gx taken from pixel differences (GXD, the default since the ECC soak): 2 rows at 4 waves -- 4 spilled
+                        // registers -- 6.13 ms of sums per 1000 frames, at 3 waves (146 VGPRs) 5.34, 4 rows at 3 waves 6.38;
+                        // the first gx form (UPSP_ECC_GX=0) at 4 waves 5.29
                         if (gv == 1) UPSP_ECC_COLS(false, 4, 3);
                         else if (gv == 3) UPSP_ECC_COLS(false, 3, 3);
-                        else if (gv == 4) UPSP_ECC_COLS(false, 2, 3);
-                        else UPSP_ECC_COLS(false, 2, 4);
+                        else if (gv == 5) UPSP_ECC_COLS(false, 2, 4);
+                        else if (gx_form == 0) UPSP_ECC_COLS(false, 2, 4, 0, 0);
+                        else UPSP_ECC_COLS(false, 2, 3);
                     }
                 }
                 else if (it == 0) {
