@@ -324,3 +324,49 @@ def test_registration_full_size_1024(gpu_lib, oracle):
             s2 = pipe2.accumulators()[0].cpu().numpy()
             assert np.array_equal(s2[ok], got[:, ok].astype(np.float64).sum(0))
     print("1024^2 registration: iterations %s, worst |dM| %.2e, |dt| %.2e px, |dI| %.2f" % (it_g.tolist(), *worst))
+
+
+def test_registration_sub_batches_pipelined(gpu_lib, oracle, monkeypatch):
+    """More frames than one sub-batch through the streamed registration path: the hot-pixel repair and the pre-blur of
+    sub-batch k + 1 run on a side stream while sub-batch k iterates (two blurred-frame buffers).  Same bits as the
+    one-stream schedule (UPSP_REG_PIPELINE=0) -- series, warps, iteration counts, accumulators, repaired frames -- over
+    several calls (buffers and events re-used), with hot pixels in frames of every sub-batch; and 3 frames against the oracle."""
+    import torch
+    from upsp_processing_amd import engine, synthetic as syn
+    H, W, F, n = 96, 160, 200, 3000
+    frames = syn.synth_frames_numpy(F, H, W, seed=21, hot=True)
+    rng = np.random.default_rng(22)
+    for f in (3, 64, 65, 130, 199):                      # hot pixels in every sub-batch of 64
+        frames[f, rng.integers(2, H - 2), rng.integers(2, W - 2)] = 4090
+    ref = frames[0].astype(np.float32)
+    pix = (rng.integers(8, H - 8, n) * W + rng.integers(8, W - 8, n)).astype(np.int32)
+    pix[::13] = -1
+    ok = pix >= 0
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("UPSP_REG_PIPELINE", mode)
+        pipe = engine.FramePipeline(1, W, H, n, registration=1)
+        pipe.set_projection(0, pix)
+        pipe.set_reference(0, ref)
+        ld = engine.series_ld(F)
+        rt = torch.full((n, ld), -3.0, dtype=torch.float32, device="cuda")
+        d = torch.as_tensor(frames.copy()).cuda()
+        w = torch.zeros((F, 1, 6), dtype=torch.float32, device="cuda")
+        it = torch.full((F, 1), -1, dtype=torch.int32, device="cuda")
+        for f0, f1 in ((0, 150), (150, 200)):            # two calls: 3 sub-batches, then 1 (not pipelined)
+            pipe.process(d[f0:f1], f0, rows_t=rt[:, :F], col0=f0, want_rows=False, warps=w[f0:f1], ecc_iters=it[f0:f1])
+        torch.cuda.synchronize()
+        out[mode] = (rt.cpu().numpy(), w.cpu().numpy(), it.cpu().numpy(), [a.cpu().numpy() for a in pipe.accumulators()], d.cpu().numpy())
+    a, b = out["1"], out["0"]
+    assert np.array_equal(a[0].view(np.int32), b[0].view(np.int32)) and np.array_equal(a[1].view(np.int32), b[1].view(np.int32))
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[4], b[4])
+    for x, y in zip(a[3], b[3]):
+        assert np.array_equal(np.isnan(x), np.isnan(y)) and np.array_equal(x[~np.isnan(x)], y[~np.isnan(y)])
+    for f in (64, 65, 199):
+        img, _ = oracle.fix_hot_pixels(frames[f])
+        assert np.array_equal(a[4][f], img)
+        _, M_o, it_o = oracle.register_pixel(ref, img)
+        M_g = a[1][f, 0].reshape(2, 3)
+        assert a[2][f, 0] == it_o and np.abs(M_g[:, :2] - M_o[:, :2]).max() <= 1e-4 and np.abs(M_g[:, 2] - M_o[:, 2]).max() <= 2e-3
+        want = oracle.project_frame(oracle.warp_affine(img, M_g, 1), pix, None)
+        assert np.array_equal(a[0][ok, f].view(np.int32), want[ok].view(np.int32))

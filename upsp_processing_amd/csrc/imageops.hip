@@ -2005,6 +2005,7 @@ struct FrameScratch {
     float *f32[kMaxCams] = {nullptr};       // patched / filtered frames
     float *f32b[kMaxCams] = {nullptr};      // Gaussian-filtered frames when the filter input is f32[] itself
     float *ecc_img = nullptr;               // blurred input frames
+    float *ecc_img2 = nullptr;              // second buffer: the pre-blur of the NEXT sub-batch runs ahead on another stream (frame_scratch_preblur)
     float *tmp = nullptr;                   // filter intermediate (float), also box sums (double)
     float *tmpl[kMaxCams] = {nullptr};      // blurred ECC templates
     const float *tmpl_src[kMaxCams] = {nullptr};
@@ -2032,6 +2033,7 @@ void frame_scratch_free(FrameScratch *s)
         if (s->tmpl[c]) (void)hipFree(s->tmpl[c]);
     }
     if (s->ecc_img) (void)hipFree(s->ecc_img);
+    if (s->ecc_img2) (void)hipFree(s->ecc_img2);
     if (s->center) (void)hipFree(s->center);
     if (s->tmp) (void)hipFree(s->tmp);
     if (s->partial) (void)hipFree(s->partial);
@@ -2079,7 +2081,8 @@ int frame_scratch_ensure(FrameScratch **ps, int ncams, int batch, int rows, int 
 
 // ECC registration of nb frames against the blurred template; leaves the warp in state[].
 static int run_ecc(FrameScratch *s, const float *tmpl_blur, const float *d_center, const uint16_t *frames, int nb,
-                   int64_t first_frame, int rows, int cols, int max_iters, double eps, hipStream_t st)
+                   int64_t first_frame, int rows, int cols, int max_iters, double eps, hipStream_t st,
+                   const float *preblurred = nullptr)
 {
     if ((long long)rows * cols >= (1ll << 31)) return fail(UPSP_ERR_INVALID, "registration: image too large");
     // Pre-blur (GaussianBlur 5 x 5) and the first iteration.  Every frame starts from the identity warp
@@ -2090,8 +2093,9 @@ static int run_ecc(FrameScratch *s, const float *tmpl_blur, const float *d_cente
     // pending misses (PMC: 68 % of the time; 4 / 8 / 16 rows in flight, 3 / 4 / 8 waves per SIMD and streamed loads all
     // within 280-365 us).  Kept as a switch, parity-tested; UPSP_ECC_FUSED=2: column-walking blur alone (184 us) + the
     // identity variant.
-    const int fused_env = env_int_io("UPSP_ECC_FUSED", 0);
+    const int fused_env = preblurred ? 0 : env_int_io("UPSP_ECC_FUSED", 0);
     const bool fused = fused_env == 1 && rows >= 5 && cols >= 5;
+    const float *blurred = preblurred ? preblurred : s->ecc_img;      // (GaussianBlur 5 x 5 of the frames)
     const dim3 g1((nb + 63) / 64), b1(64);
     hipLaunchKernelGGL(ecc_init_kernel, g1, b1, 0, st, s->state, nb, (long long)first_frame, eps);
     int it = 0;
@@ -2103,7 +2107,7 @@ static int run_ecc(FrameScratch *s, const float *tmpl_blur, const float *d_cente
         hipLaunchKernelGGL(ecc_solve_kernel, dim3(nb), dim3(256), 0, st, s->state, (const double *)s->partial, nb, nslots,
                            max_iters, eps, rows, cols);
         it = 1;
-    } else {
+    } else if (!preblurred) {
         int rc = (fused_env == 2 && rows >= 5 && cols >= 5)
                      ? launch_gauss5_cols(frames, s->ecc_img, nb, rows, cols, nullptr, nullptr, nullptr, nullptr, st)
                      : launch_gauss<uint16_t>(frames, s->ecc_img, s->tmp, nb, rows, cols, 5, st);
@@ -2153,10 +2157,10 @@ static int run_ecc(FrameScratch *s, const float *tmpl_blur, const float *d_cente
                 KTimed kt("ecc_sums_kernel", st);
 #define UPSP_ECC_LAUNCH(ID, KPX, WV)                                                                          \
     hipLaunchKernelGGL((ecc_sums2_kernel<ID, KPX, WV>), dim3(nb, blocks + kEccBorderBlocks), dim3(256), 0, st,    \
-                       (const float *)s->ecc_img, tmpl_blur, rows, cols, (const EccState *)s->state, s->partial)
+                       blurred, tmpl_blur, rows, cols, (const EccState *)s->state, s->partial)
 #define UPSP_ECC_COLS(ID, URX, WV, ...)                                                                       \
     hipLaunchKernelGGL((ecc_cols_kernel<ID, URX, WV, ##__VA_ARGS__>), dim3(nb, blocks + kEccBorderBlocks), dim3(256), 0, st, \
-                       (const float *)s->ecc_img, tmpl_blur, rows, cols, (const EccState *)s->state, s->partial, d_center)
+                       blurred, tmpl_blur, rows, cols, (const EccState *)s->state, s->partial, d_center)
                 // Round 3: one column per thread, factored packed-float sums (ecc_cols_kernel); needs one column tile of 256 per
                 // interior block at least.  UPSP_ECC_KERNEL=2 selects round 2's kernel (A/B, and images wider than that).
                 static const int cvariant = env_int_io("UPSP_ECC_CVARIANT", 0);
@@ -2321,11 +2325,28 @@ int launch_pixel_list(const int32_t *d_pix, size_t nnodes, uint8_t *d_mask, unsi
     return UPSP_OK;
 }
 
+// GaussianBlur 5 x 5 of nb frames (the ECC's pre-blur, cpp/lib/registration.cpp:57-60) into one of the scratch's two blurred-frame
+// buffers, on any stream: the streamed registration loop runs it for sub-batch k + 1 while sub-batch k iterates -- a
+// memory-bound kernel beside the issue-bound ECC sums, and work for the GPU while the host reads "frames still
+// iterating" back.  *out = the buffer to hand to run_frame_stages.
+int frame_scratch_preblur(FrameScratch *s, int slot, const uint16_t *d_frames, int nb, int rows, int cols, hipStream_t st,
+                          const float **out)
+{
+    if (!s || !s->ecc_img || nb > s->batch) return fail(UPSP_ERR_INVALID, "pre-blur: scratch not set up");
+    if (slot && !s->ecc_img2) UPSP_HIP_CHECK(hipMalloc(&s->ecc_img2, (size_t)s->batch * rows * cols * sizeof(float)));
+    float *dst = slot ? s->ecc_img2 : s->ecc_img;
+    // (the 5 x 5 tile kernel: no intermediate image, nothing shared with the other stream)
+    if (rows <= 2 || cols <= 2) return fail(UPSP_ERR_INVALID, "pre-blur: image too small for the tile kernel");
+    int rc = launch_gauss<uint16_t>(d_frames, dst, nullptr, nb, rows, cols, 5, st);
+    if (rc == UPSP_OK) *out = dst;
+    return rc;
+}
+
 int run_frame_stages(FrameScratch *s, int cam, const uint16_t *d_frames, int nb, int64_t first_frame,
                      int rows, int cols, const upsp_pipeline_opts &opts, const float *d_ref,
                      const PatchTables *patches, float *d_warps, int32_t *d_iters, int ncams,
                      const unsigned *d_read_list, const WarpCompact *wc, const void **img_out, int *is_f32_out,
-                     hipStream_t st)
+                     hipStream_t st, const float *preblurred)
 {
     const size_t npix = (size_t)rows * cols;
     const uint16_t *cur = d_frames;
@@ -2338,7 +2359,7 @@ int run_frame_stages(FrameScratch *s, int cam, const uint16_t *d_frames, int nb,
             s->tmpl_src[cam] = d_ref;
         }
         int rc = run_ecc(s, s->tmpl[cam], s->center + cam, d_frames, nb, first_frame, rows, cols, opts.ecc_max_iters,
-                         opts.ecc_eps, st);
+                         opts.ecc_eps, st, preblurred);
         if (rc != UPSP_OK) return rc;
         if (wc) {      // registration is the last image stage and node-major series are wanted: straight into the compact buffer
             KTimed kt("warp_u16_kernel", st);

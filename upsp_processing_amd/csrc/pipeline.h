@@ -106,7 +106,10 @@ int run_frame_stages(FrameScratch *s, int cam, const uint16_t *d_frames, int nb,
                      int64_t first_frame, int rows, int cols, const upsp_pipeline_opts &opts,
                      const float *d_ref, const PatchTables *patches, float *d_warps, int32_t *d_iters, int ncams,
                      const unsigned *d_read_list, const WarpCompact *wc, const void **img_out, int *is_f32_out,
-                     hipStream_t st);
+                     hipStream_t st, const float *preblurred = nullptr);
+// the ECC's 5 x 5 pre-blur of nb frames into blurred-frame buffer `slot` (0 / 1) of the scratch, on any stream
+int frame_scratch_preblur(FrameScratch *s, int slot, const uint16_t *d_frames, int nb, int rows, int cols, hipStream_t st,
+                          const float **out);
 // d_list[0] = number of distinct pixels with a node, d_list[1..] = those pixels (any order); d_mask: npix bytes of scratch
 int launch_pixel_list(const int32_t *d_pix, size_t nnodes, uint8_t *d_mask, unsigned *d_list, size_t npix, hipStream_t st);
 }  // namespace upsp

@@ -77,6 +77,9 @@ struct upsp_pipeline {
     // optional second stream (UPSP_OVERLAP=1): the gather of sub-batch k overlaps the scan of k+1
     hipStream_t aux = nullptr;
     hipEvent_t ev_in = nullptr, ev_fix[2] = {nullptr, nullptr}, ev_out = nullptr;
+    // streamed registration: hot-pixel repair + pre-blur of sub-batch k + 1 run on `pre` while sub-batch k iterates
+    hipStream_t pre = nullptr;
+    hipEvent_t ev_pre_in = nullptr, ev_blur[2] = {nullptr, nullptr}, ev_used[2] = {nullptr, nullptr};
 };
 
 namespace {
@@ -202,7 +205,8 @@ void upsp_pipeline_destroy(upsp_pipeline *p)
     }
     upsp::frame_scratch_free(p->scratch);
     if (p->aux) (void)hipStreamDestroy(p->aux);
-    for (hipEvent_t e : {p->ev_in, p->ev_fix[0], p->ev_fix[1], p->ev_out})
+    if (p->pre) (void)hipStreamDestroy(p->pre);
+    for (hipEvent_t e : {p->ev_in, p->ev_fix[0], p->ev_fix[1], p->ev_out, p->ev_pre_in, p->ev_blur[0], p->ev_blur[1], p->ev_used[0], p->ev_used[1]})
         if (e) (void)hipEventDestroy(e);
     free_dev(p->d_read_mask);
     free_dev(p->d_skipped);
@@ -800,32 +804,75 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
         wc.compact = p->d_compact;
         wc.cpitch = cp;
         uint16_t *fr = d_frames[0];
-        for (int s0 = 0; s0 < nframes && rc == UPSP_OK; s0 += S) {
-            const int ns = std::min(S, nframes - s0);
-            for (int f0 = s0; f0 < s0 + ns && rc == UPSP_OK; f0 += B) {
-                const int nb = std::min(B, s0 + ns - f0);
-                uint16_t *frames = fr + (size_t)f0 * npix;
-                if (p->opts.hot_enable) {  // psp_process.cpp:1772
-                    rc = ensure_hot(p, nb);
-                    if (rc == UPSP_OK)
-                        rc = launch_hot_fix(frames, nb, p->height, p->width, p->opts.hot_thresh, p->opts.hot_min_change,
-                                            p->opts.hot_max, p->d_hot_count, p->d_hot_pos, nullptr, st);
-                    if (rc != UPSP_OK) break;
-                }
-                wc.col0 = (unsigned)(f0 - s0);
-                const void *img = nullptr;
-                int is_f32 = 0;
-                rc = upsp::run_frame_stages(p->scratch, 0, frames, nb, first_frame + f0, p->height, p->width, p->opts, p->d_ref[0],
-                                            nullptr, d_warps ? d_warps + (size_t)f0 * 6 : nullptr,
-                                            p->d_ecc_iters ? p->d_ecc_iters + f0 : nullptr, 1, nullptr, &wc, &img, &is_f32, st);
-            }
-            if (rc != UPSP_OK) break;
-            g.nframes = ns;
-            g.img[0] = fr + (size_t)s0 * npix;
-            g.rows_t = d_rows_t ? d_rows_t + col0 + s0 : nullptr;
-            g.rows_t16 = d_rows_t16 ? d_rows_t16 + col0 + s0 : nullptr;
-            rc = launch_node_rows(g, p->d_node_k, p->d_compact, cp, st);
+        // Sub-batch k + 1's hot-pixel repair and pre-blur run on a stream of their own while sub-batch k iterates (two blurred-
+        // frame buffers): the pre-blur is memory-bound, the ECC sums issue-bound, and the host's read-back of "frames still
+        // iterating" no longer leaves the GPU without work.  UPSP_REG_PIPELINE=0: one stream, stage after stage.
+        const bool pipe_env = !std::getenv("UPSP_REG_PIPELINE") || std::atoi(std::getenv("UPSP_REG_PIPELINE")) != 0;
+        const bool pipelined = pipe_env && nframes > B && p->height > 2 && p->width > 2 && !std::getenv("UPSP_ECC_FUSED");
+        if (pipelined && !p->pre) {
+            UPSP_HIP_CHECK(hipStreamCreateWithFlags(&p->pre, hipStreamNonBlocking));
+            for (hipEvent_t *e : {&p->ev_pre_in, &p->ev_blur[0], &p->ev_blur[1], &p->ev_used[0], &p->ev_used[1]})
+                UPSP_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
         }
+        auto repair = [&](uint16_t *frames, int nb, hipStream_t s_) -> int {
+            if (!p->opts.hot_enable) return UPSP_OK;  // psp_process.cpp:1772
+            int r = ensure_hot(p, nb);
+            if (r == UPSP_OK)
+                r = launch_hot_fix(frames, nb, p->height, p->width, p->opts.hot_thresh, p->opts.hot_min_change, p->opts.hot_max,
+                                   p->d_hot_count, p->d_hot_pos, nullptr, s_);
+            return r;
+        };
+        // sub-batches of the whole call, in order
+        struct Sub { int f0, nb, s0; };
+        std::vector<Sub> subs;
+        for (int s0 = 0; s0 < nframes; s0 += S)
+            for (int f0 = s0; f0 < std::min(s0 + S, nframes); f0 += B) subs.push_back({f0, std::min(B, std::min(s0 + S, nframes) - f0), s0});
+        const float *blurred[2] = {nullptr, nullptr};
+        auto ahead = [&](size_t i) -> int {        // repair + pre-blur of sub-batch i on the side stream
+            const int slot = (int)(i & 1);
+            uint16_t *frames = fr + (size_t)subs[i].f0 * npix;
+            if (i >= 2) UPSP_HIP_CHECK(hipStreamWaitEvent(p->pre, p->ev_used[slot], 0));     // sub-batch i - 2 has read the buffer
+            int r = repair(frames, subs[i].nb, p->pre);
+            if (r == UPSP_OK) r = upsp::frame_scratch_preblur(p->scratch, slot, frames, subs[i].nb, p->height, p->width, p->pre, &blurred[slot]);
+            if (r == UPSP_OK) UPSP_HIP_CHECK(hipEventRecord(p->ev_blur[slot], p->pre));
+            return r;
+        };
+        if (pipelined) {
+            UPSP_HIP_CHECK(hipEventRecord(p->ev_pre_in, st));      // the frames are ready where the caller's stream is now
+            UPSP_HIP_CHECK(hipStreamWaitEvent(p->pre, p->ev_pre_in, 0));
+            rc = ahead(0);
+        }
+        for (size_t i = 0; i < subs.size() && rc == UPSP_OK; ++i) {
+            const int f0 = subs[i].f0, nb = subs[i].nb, s0 = subs[i].s0;
+            uint16_t *frames = fr + (size_t)f0 * npix;
+            const float *pre = nullptr;
+            if (pipelined) {
+                if (i + 1 < subs.size()) rc = ahead(i + 1);
+                if (rc != UPSP_OK) break;
+                UPSP_HIP_CHECK(hipStreamWaitEvent(st, p->ev_blur[i & 1], 0));
+                pre = blurred[i & 1];
+            } else {
+                rc = repair(frames, nb, st);
+                if (rc != UPSP_OK) break;
+            }
+            wc.col0 = (unsigned)(f0 - s0);
+            const void *img = nullptr;
+            int is_f32 = 0;
+            rc = upsp::run_frame_stages(p->scratch, 0, frames, nb, first_frame + f0, p->height, p->width, p->opts, p->d_ref[0],
+                                        nullptr, d_warps ? d_warps + (size_t)f0 * 6 : nullptr,
+                                        p->d_ecc_iters ? p->d_ecc_iters + f0 : nullptr, 1, nullptr, &wc, &img, &is_f32, st, pre);
+            if (pipelined && rc == UPSP_OK) UPSP_HIP_CHECK(hipEventRecord(p->ev_used[i & 1], st));
+            const bool last_of_group = i + 1 == subs.size() || subs[i + 1].s0 != s0;
+            if (rc == UPSP_OK && last_of_group) {
+                const int ns = std::min(S, nframes - s0);
+                g.nframes = ns;
+                g.img[0] = fr + (size_t)s0 * npix;
+                g.rows_t = d_rows_t ? d_rows_t + col0 + s0 : nullptr;
+                g.rows_t16 = d_rows_t16 ? d_rows_t16 + col0 + s0 : nullptr;
+                rc = launch_node_rows(g, p->d_node_k, p->d_compact, cp, st);
+            }
+        }
+        if (pipelined && rc != UPSP_OK) (void)hipStreamSynchronize(p->pre);      // nothing of this call may outlive it
         return rc;
     }
     // Several cameras (weights allowed): the same two passes with one active-pixel map and one whole-call compact
