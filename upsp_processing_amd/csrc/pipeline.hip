@@ -804,10 +804,14 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
         wc.compact = p->d_compact;
         wc.cpitch = cp;
         uint16_t *fr = d_frames[0];
-        // Sub-batch k + 1's hot-pixel repair and pre-blur run on a stream of their own while sub-batch k iterates (two blurred-
-        // frame buffers): the pre-blur is memory-bound, the ECC sums issue-bound, and the host's read-back of "frames still
-        // iterating" no longer leaves the GPU without work.  UPSP_REG_PIPELINE=0: one stream, stage after stage.
-        const bool pipe_env = !std::getenv("UPSP_REG_PIPELINE") || std::atoi(std::getenv("UPSP_REG_PIPELINE")) != 0;
+        // UPSP_REG_PIPELINE=1 (opt-in, measured and NOT the default): sub-batch k + 1's hot-pixel repair and pre-blur run on a
+        // stream of their own while sub-batch k iterates (two blurred-frame buffers) -- a memory-bound kernel beside the
+        // issue-bound ECC sums, and work for the GPU while the host reads "frames still iterating" back.  Same bits
+        // (tests/test_imageops_gpu.py::test_registration_sub_batches_pipelined), but 10.3 instead of 9.87 ms per 1000 frames:
+        // beside each other the sums take 7.9 instead of 5.3 ms and the pre-blur 3.6 instead of 2.1 -- the second 256 MB of
+        // blurred frames pushes the first out of the Infinity Cache between the identity and the general iteration, the
+        // same outcome as every other overlap of two streaming phases tried on this part (DESIGN.md sections 7 and 8).
+        const bool pipe_env = std::getenv("UPSP_REG_PIPELINE") && std::atoi(std::getenv("UPSP_REG_PIPELINE")) != 0;
         const bool pipelined = pipe_env && nframes > B && p->height > 2 && p->width > 2 && !std::getenv("UPSP_ECC_FUSED");
         if (pipelined && !p->pre) {
             UPSP_HIP_CHECK(hipStreamCreateWithFlags(&p->pre, hipStreamNonBlocking));
