@@ -63,6 +63,29 @@ def test_blur_u16_bitwise(gpu_lib, oracle, monkeypatch, cols_kernel):
         assert np.array_equal(g.view(np.int32), oracle.blur(fr.astype(np.float32), k).view(np.int32)), k
 
 
+@pytest.mark.parametrize("quad", [1, 0])
+def test_blur_u16_quad_bitwise(gpu_lib, oracle, monkeypatch, quad):
+    """The 5 x 5 blur of u16 frames with four pixels per lane (gauss5_quad_kernel: widths that are multiples of 4 --
+    every camera format; UPSP_GAUSS5_QUAD=0 = the tile kernel on the same inputs), bit for bit against the oracle:
+    widths around the 256-column waves and the 1024-column workgroups (partly filled waves, halo loads of lanes 0 / 63,
+    reflected columns at both image edges), heights around the 64-row pieces and below the kernel's halo, extreme
+    values at the borders, several frames per call."""
+    import torch
+    from upsp_processing_amd import engine
+    monkeypatch.setenv("UPSP_GAUSS5_QUAD", str(quad))
+    rng = np.random.default_rng(19)
+    for shape in [(3, 8), (5, 12), (64, 256), (65, 260), (63, 252), (130, 1024), (37, 1028), (129, 1020), (70, 2052), (200, 516)]:
+        fr = rng.integers(0, 4096, size=(3,) + shape, dtype=np.uint16)
+        fr[0, 0, :] = 4095
+        fr[0, :, 0] = 0
+        fr[1, :, -1] = 4095
+        fr[2, -1, :] = 0
+        g = engine.blur_u16(torch.as_tensor(fr).cuda(), 5).cpu().numpy()
+        for f in range(3):
+            want = oracle.blur(fr[f].astype(np.float32), 5)
+            assert np.array_equal(g[f].view(np.int32), want.view(np.int32)), (shape, f, np.abs(g[f] - want).max())
+
+
 @pytest.mark.parametrize("interp", [1, 0])
 def test_register_pixel(gpu_lib, oracle, interp):
     import torch

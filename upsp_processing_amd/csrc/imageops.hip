@@ -231,6 +231,10 @@ unsigned grid_for_pixels(size_t npix)
 }
 
 // GaussianBlur(src,dst,Size(k,k),0) for nimg images; tmp: nimg*npix floats
+// the four-pixels-per-lane 5 x 5 kernel (defined with the ECC kernels below); false: not applicable, nothing launched
+bool launch_gauss5_quad(const uint16_t *src, float *dst, int nimg, int rows, int cols, const FilterCoef &fc, hipStream_t st);
+inline bool launch_gauss5_quad(const float *, float *, int, int, int, const FilterCoef &, hipStream_t) { return false; }
+
 template <typename SRC>
 int launch_gauss(const SRC *src, float *dst, float *tmp, int nimg, int rows, int cols, int k,
                  hipStream_t st)
@@ -254,6 +258,7 @@ int launch_gauss(const SRC *src, float *dst, float *tmp, int nimg, int rows, int
             return UPSP_OK;
         }
         if (r == 1) hipLaunchKernelGGL((gauss_fused_kernel<SRC, 1>), fgrid, block, 0, st, src, dst, rows, cols, fc);
+        else if (r == 2 && launch_gauss5_quad(src, dst, nimg, rows, cols, fc, st)) {}        // (u16 frames, cols % 4 == 0)
         else if (r == 2) hipLaunchKernelGGL((gauss_fused_kernel<SRC, 2>), fgrid, block, 0, st, src, dst, rows, cols, fc);
         else hipLaunchKernelGGL((gauss_fused_kernel<SRC, 3>), fgrid, block, 0, st, src, dst, rows, cols, fc);
         UPSP_HIP_CHECK(hipGetLastError());
@@ -1479,6 +1484,104 @@ __global__ void __launch_bounds__(256)
                        float k2)
 {
     gauss5_cols_body<false, U>(src, dst, nullptr, rows, cols, rpp, k0, k1, k2, nullptr, nullptr, 0u, nullptr);
+}
+
+// ---- Gaussian 5 x 5 of u16 frames, FOUR pixels per lane (round 3) -------------------------------------------------------
+// The tile kernel (gauss_fused_kernel) moves 6 B per pixel at 3.0 TB/s: its 2-byte loads and the LDS round trip keep
+// few bytes in flight.  Here a lane owns four consecutive pixels of a row -- one 8-byte load (a wave reads 512
+// contiguous bytes), one 16-byte store (a wave writes 1 KB) -- and walks down its rows with the five rows of horizontal
+// results rolling in registers; the two pixels it needs from either neighbour come by DPP wave shifts (lanes 0 / 63
+// load theirs, 4 bytes each), so the horizontal pass costs 4 shuffles per FOUR pixels.  No LDS, no barrier, waves
+// independent.  Same float operations in the same order as gauss_pass_kernel (bit-identical output:
+// tests/test_imageops_gpu.py::test_blur_u16_bitwise); reflect-101 by loading reflected rows, and at the left / right
+// image edge by taking the reflected columns from the lane's own four pixels.  Needs cols % 4 == 0 and cols >= 8.
+template <int U>
+__global__ void __launch_bounds__(256)
+    gauss5_quad_kernel(const uint16_t *__restrict__ src, float *__restrict__ dst, int rows, int cols, int rpp, float k0, float k1,
+                       float k2)
+{
+    const int f = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int xw = ((int)blockIdx.z * 4 + (int)(threadIdx.x >> 6)) * 256;    // first column of this wave
+    if (xw >= cols) return;                                                    // (uniform per wave)
+    const int x0 = xw + 4 * lane;
+    const bool valid = x0 < cols;                                              // all four pixels or none (cols % 4 == 0)
+    const int xl = valid ? x0 : cols - 4;                                      // (idle lanes re-read the last quad)
+    const int y0 = (int)blockIdx.y * rpp, y1 = min(rows, y0 + rpp);
+    if (y1 <= y0) return;
+    const size_t npix = (size_t)rows * cols;
+    const char *S = reinterpret_cast<const char *>(src + (size_t)f * npix);
+    char *B = reinterpret_cast<char *>(dst + (size_t)f * npix);
+    const unsigned pitch2 = 2u * (unsigned)cols, cx = 2u * (unsigned)xl;
+    const bool left_img = x0 == 0, right_img = x0 + 4 >= cols;                 // the image's own edges: reflected columns
+    const bool halo_l = lane == 0 && !left_img, halo_r = lane == 63 && !right_img && valid;
+    float h[5][4];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) h[i][j] = 0.f;
+    const int niter = (y1 - y0) + 4;                                           // input rows y0 - 2 .. y1 + 1
+    for (int g = 0; g < niter; g += U) {
+        uint2 q[U];
+        unsigned hl[U], hr[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int yi = y0 - 2 + g + u;
+            const unsigned ro = (unsigned)reflect101(min(max(yi, -(rows - 1)), 2 * rows - 2), rows) * pitch2;
+            q[u] = *reinterpret_cast<const uint2 *>(S + (ro + cx));
+            hl[u] = hr[u] = 0u;
+            if (halo_l) hl[u] = *reinterpret_cast<const unsigned *>(S + (ro + cx - 4u));     // columns x0 - 2, x0 - 1
+            if (halo_r) hr[u] = *reinterpret_cast<const unsigned *>(S + (ro + cx + 8u));     // columns x0 + 4, x0 + 5
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = g + u;
+            if (k >= niter) break;                                             // (uniform)
+            const float p0 = (float)(q[u].x & 0xFFFFu), p1 = (float)(q[u].x >> 16), p2 = (float)(q[u].y & 0xFFFFu), p3 = (float)(q[u].y >> 16);
+            // the neighbours' pixels: lane i - 1's p2, p3 and lane i + 1's p0, p1 (lanes 0 / 63: the loaded halo)
+            float a2 = dpp_shr1((float)(hl[u] & 0xFFFFu), p2), a3 = dpp_shr1((float)(hl[u] >> 16), p3);
+            float c0 = dpp_shl1((float)(hr[u] & 0xFFFFu), p0), c1 = dpp_shl1((float)(hr[u] >> 16), p1);
+            if (left_img) { a3 = p1; a2 = p2; }                                // columns -1, -2 -> 1, 2
+            if (right_img) { c0 = p2; c1 = p1; }                               // columns cols, cols + 1 -> cols - 2, cols - 3
+            float n0 = k0 * p0, n1 = k0 * p1, n2 = k0 * p2, n3 = k0 * p3;
+            n0 += k1 * (a3 + p1); n1 += k1 * (p0 + p2); n2 += k1 * (p1 + p3); n3 += k1 * (p2 + c0);
+            n0 += k2 * (a2 + p2); n1 += k2 * (a3 + p3); n2 += k2 * (p0 + c0); n3 += k2 * (p1 + c1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { h[0][j] = h[1][j]; h[1][j] = h[2][j]; h[2][j] = h[3][j]; h[3][j] = h[4][j]; }
+            h[4][0] = n0; h[4][1] = n1; h[4][2] = n2; h[4][3] = n3;
+            if (k < 4) continue;
+            const int yb = y0 - 2 + k - 2;                                     // blurred row: the middle of the five
+            float4 o;
+            float *ov = &o.x;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float bn = k0 * h[2][j];
+                bn += k1 * (h[1][j] + h[3][j]);
+                bn += k2 * (h[0][j] + h[4][j]);
+                ov[j] = bn;
+            }
+            if (valid) *reinterpret_cast<float4 *>(B + ((unsigned)yb * 2u * pitch2 + 4u * (unsigned)x0)) = o;
+        }
+    }
+}
+
+bool launch_gauss5_quad(const uint16_t *src, float *dst, int nimg, int rows, int cols, const FilterCoef &fc, hipStream_t st)
+{
+    // UPSP_GAUSS5_QUAD=0: the tile kernel (measurement / test switch)
+    if (!env_int_io("UPSP_GAUSS5_QUAD", 1) || (cols & 3) || cols < 8 || rows < 3 || (long long)rows * cols >= (1ll << 29) ||
+        (reinterpret_cast<uintptr_t>(src) & 7) || (reinterpret_cast<uintptr_t>(dst) & 15) || nimg > 65535)
+        return false;
+    const int rpp = std::max(8, env_int_io("UPSP_GAUSS5_QUAD_RPP", 64)), uvar = env_int_io("UPSP_GAUSS5_QUAD_U", 8);   // (measurement switches)
+    // (1000 frames of 1024^2, ms of pre-blur per step: 2 / 4 / 6 / 8 rows in flight 1.60 / 1.50 / 1.35 / 1.25-1.33 at 64 rows per
+    //  piece; 8 rows in flight at 16 / 32 / 48 / 128 rows per piece 1.32 / 1.36 / 1.39 / 1.52; the tile kernel 2.13)
+    const int pieces = (rows + rpp - 1) / rpp, zb = (cols + 1023) / 1024;
+    if (pieces > 65535 || zb > 65535) return false;
+#define UPSP_GQ(UU)                                                                                                 \
+    hipLaunchKernelGGL((gauss5_quad_kernel<UU>), dim3((unsigned)nimg, (unsigned)pieces, (unsigned)zb), dim3(256), 0, st, src, dst, rows, \
+                       cols, rpp, fc.k[2], fc.k[3], fc.k[4])
+    if (uvar == 2) UPSP_GQ(2); else if (uvar == 4) UPSP_GQ(4); else if (uvar == 6) UPSP_GQ(6); else UPSP_GQ(8);
+#undef UPSP_GQ
+    return true;
 }
 
 // grid (frames, kEccBorderBlocks + interior blocks): the frame is the FAST index, so the band blocks of all frames
