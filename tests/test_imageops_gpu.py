@@ -366,8 +366,11 @@ def test_registration_sub_batches_pipelined(gpu_lib, oracle, monkeypatch):
     pix[::13] = -1
     ok = pix >= 0
     out = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("UPSP_REG_PIPELINE", mode)
+    for mode in ("1", "0", "scan in the blur"):
+        # third schedule: fix_hot_pixels folded into the pre-blur (UPSP_HOT_IN_BLUR=1: the blur flags the frames that hold a hot
+        # pixel, only those are scanned, repaired and blurred again)
+        monkeypatch.setenv("UPSP_REG_PIPELINE", mode if mode in "01" else "0")
+        monkeypatch.setenv("UPSP_HOT_IN_BLUR", "0" if mode in "01" else "1")
         pipe = engine.FramePipeline(1, W, H, n, registration=1)
         pipe.set_projection(0, pix)
         pipe.set_reference(0, ref)
@@ -380,11 +383,14 @@ def test_registration_sub_batches_pipelined(gpu_lib, oracle, monkeypatch):
             pipe.process(d[f0:f1], f0, rows_t=rt[:, :F], col0=f0, want_rows=False, warps=w[f0:f1], ecc_iters=it[f0:f1])
         torch.cuda.synchronize()
         out[mode] = (rt.cpu().numpy(), w.cpu().numpy(), it.cpu().numpy(), [a.cpu().numpy() for a in pipe.accumulators()], d.cpu().numpy())
-    a, b = out["1"], out["0"]
-    assert np.array_equal(a[0].view(np.int32), b[0].view(np.int32)) and np.array_equal(a[1].view(np.int32), b[1].view(np.int32))
-    assert np.array_equal(a[2], b[2]) and np.array_equal(a[4], b[4])
-    for x, y in zip(a[3], b[3]):
-        assert np.array_equal(np.isnan(x), np.isnan(y)) and np.array_equal(x[~np.isnan(x)], y[~np.isnan(y)])
+    b = out["0"]
+    for other in ("1", "scan in the blur"):
+        a = out[other]
+        assert np.array_equal(a[0].view(np.int32), b[0].view(np.int32)) and np.array_equal(a[1].view(np.int32), b[1].view(np.int32)), other
+        assert np.array_equal(a[2], b[2]) and np.array_equal(a[4], b[4]), other
+        for x, y in zip(a[3], b[3]):
+            assert np.array_equal(np.isnan(x), np.isnan(y)) and np.array_equal(x[~np.isnan(x)], y[~np.isnan(y)]), other
+    a = out["1"]
     for f in (64, 65, 199):
         img, _ = oracle.fix_hot_pixels(frames[f])
         assert np.array_equal(a[4][f], img)

@@ -35,9 +35,12 @@ __device__ void fix_frame(uint16_t *__restrict__ img, int rows, int cols, int mi
 __global__ void __launch_bounds__(256)
     hot_scan_kernel(uint16_t *frames, size_t npix, int thresh, unsigned *__restrict__ count,
                     unsigned *__restrict__ pos, unsigned *__restrict__ done, int rows, int cols,
-                    int min_change, int max_hot, int32_t *__restrict__ status)
+                    int min_change, int max_hot, int32_t *__restrict__ status, const unsigned *__restrict__ only)
 {
     const size_t f = blockIdx.y;
+    // `only` (may be null): per-frame flags set by a kernel that has already seen every pixel (the registration's
+    // pre-blur): frames without a pixel >= thresh have nothing to scan for
+    if (only && !only[f]) return;
     const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(frames + f * npix);
     const size_t nvec = npix / 8;
     const unsigned th = (unsigned)thresh;
@@ -1700,7 +1703,7 @@ size_t hot_counter_words(int nframes) { return (size_t)nframes * (1 + kTicketStr
 
 int launch_hot_fix(uint16_t *d_frames, int nframes, int rows, int cols, int thresh,
                    int min_change, int max_hot, unsigned *d_count, unsigned *d_pos,
-                   int32_t *d_status, hipStream_t st)
+                   int32_t *d_status, hipStream_t st, const unsigned *d_only)
 {
     if (nframes <= 0) return UPSP_OK;
     if (max_hot < 0 || max_hot >= kHotCap) return fail(UPSP_ERR_INVALID, "max_hot must be in [0,63]");
@@ -1714,7 +1717,7 @@ int launch_hot_fix(uint16_t *d_frames, int nframes, int rows, int cols, int thre
     KTimed kt("hot_scan_kernel", st);
     hipLaunchKernelGGL(hot_scan_kernel, dim3((unsigned)bx, (unsigned)nframes), dim3(256), 0, st,
                        d_frames, npix, thresh, d_count, d_pos, d_count + nframes, rows, cols,
-                       min_change, max_hot, d_status);
+                       min_change, max_hot, d_status, d_only);
     UPSP_HIP_CHECK(hipGetLastError());
     return UPSP_OK;
 }

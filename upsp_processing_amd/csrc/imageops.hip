@@ -232,8 +232,10 @@ unsigned grid_for_pixels(size_t npix)
 
 // GaussianBlur(src,dst,Size(k,k),0) for nimg images; tmp: nimg*npix floats
 // the four-pixels-per-lane 5 x 5 kernel (defined with the ECC kernels below); false: not applicable, nothing launched
-bool launch_gauss5_quad(const uint16_t *src, float *dst, int nimg, int rows, int cols, const FilterCoef &fc, hipStream_t st);
+bool launch_gauss5_quad(const uint16_t *src, float *dst, int nimg, int rows, int cols, const FilterCoef &fc, hipStream_t st,
+                        unsigned thresh = 0, unsigned *flag = nullptr, int only_flagged = 0);
 inline bool launch_gauss5_quad(const float *, float *, int, int, int, const FilterCoef &, hipStream_t) { return false; }
+bool gauss5_quad_applies(const uint16_t *src, const float *dst, int nimg, int rows, int cols);
 
 template <typename SRC>
 int launch_gauss(const SRC *src, float *dst, float *tmp, int nimg, int rows, int cols, int k,
@@ -1498,9 +1500,15 @@ __global__ void __launch_bounds__(256)
 template <int U>
 __global__ void __launch_bounds__(256)
     gauss5_quad_kernel(const uint16_t *__restrict__ src, float *__restrict__ dst, int rows, int cols, int rpp, float k0, float k1,
-                       float k2)
+                       float k2, unsigned thresh, unsigned *__restrict__ flag, int only_flagged)
 {
+    // flag (may be null): per-frame words.  only_flagged = 0: set flag[f] when a pixel of the frame is >= thresh (the scan of
+    // fix_hot_pixels, cv_extras.cpp:237-247, done on the pixels the blur loads anyway); 1: blur only the frames whose
+    // flag is set (their second blur, after the repair)
     const int f = blockIdx.x;
+    if (only_flagged && !flag[f]) return;
+    const bool detect = flag && !only_flagged;
+    unsigned hot = 0u;
     const int lane = threadIdx.x & 63;
     const int xw = ((int)blockIdx.z * 4 + (int)(threadIdx.x >> 6)) * 256;    // first column of this wave
     if (xw >= cols) return;                                                    // (uniform per wave)
@@ -1537,6 +1545,9 @@ __global__ void __launch_bounds__(256)
         for (int u = 0; u < U; ++u) {
             const int k = g + u;
             if (k >= niter) break;                                             // (uniform)
+            if (detect)
+                hot |= (unsigned)((q[u].x & 0xFFFFu) >= thresh) | (unsigned)((q[u].x >> 16) >= thresh) |
+                       (unsigned)((q[u].y & 0xFFFFu) >= thresh) | (unsigned)((q[u].y >> 16) >= thresh);
             const float p0 = (float)(q[u].x & 0xFFFFu), p1 = (float)(q[u].x >> 16), p2 = (float)(q[u].y & 0xFFFFu), p3 = (float)(q[u].y >> 16);
             // the neighbours' pixels: lane i - 1's p2, p3 and lane i + 1's p0, p1 (lanes 0 / 63: the loaded halo)
             float a2 = dpp_shr1((float)(hl[u] & 0xFFFFu), p2), a3 = dpp_shr1((float)(hl[u] >> 16), p3);
@@ -1563,14 +1574,22 @@ __global__ void __launch_bounds__(256)
             if (valid) *reinterpret_cast<float4 *>(B + ((unsigned)yb * 2u * pitch2 + 4u * (unsigned)x0)) = o;
         }
     }
+    // (every pixel of the frame is loaded by some lane -- halo rows and re-read quads only repeat pixels of the same frame)
+    if (detect && __any(hot) && lane == 0) atomicOr(&flag[f], 1u);
 }
 
-bool launch_gauss5_quad(const uint16_t *src, float *dst, int nimg, int rows, int cols, const FilterCoef &fc, hipStream_t st)
+bool gauss5_quad_applies(const uint16_t *src, const float *dst, int nimg, int rows, int cols)
 {
     // UPSP_GAUSS5_QUAD=0: the tile kernel (measurement / test switch)
-    if (!env_int_io("UPSP_GAUSS5_QUAD", 1) || (cols & 3) || cols < 8 || rows < 3 || (long long)rows * cols >= (1ll << 29) ||
-        (reinterpret_cast<uintptr_t>(src) & 7) || (reinterpret_cast<uintptr_t>(dst) & 15) || nimg > 65535)
-        return false;
+    return env_int_io("UPSP_GAUSS5_QUAD", 1) && !(cols & 3) && cols >= 8 && rows >= 3 && (long long)rows * cols < (1ll << 29) &&
+           !(reinterpret_cast<uintptr_t>(src) & 7) && !(reinterpret_cast<uintptr_t>(dst) & 15) && nimg <= 65535 &&
+           !((size_t)rows * cols & 3);          // (every frame of the batch 8-byte aligned)
+}
+
+bool launch_gauss5_quad(const uint16_t *src, float *dst, int nimg, int rows, int cols, const FilterCoef &fc, hipStream_t st,
+                        unsigned thresh, unsigned *flag, int only_flagged)
+{
+    if (!gauss5_quad_applies(src, dst, nimg, rows, cols)) return false;
     const int rpp = std::max(8, env_int_io("UPSP_GAUSS5_QUAD_RPP", 64)), uvar = env_int_io("UPSP_GAUSS5_QUAD_U", 8);   // (measurement switches)
     // (1000 frames of 1024^2, ms of pre-blur per step: 2 / 4 / 6 / 8 rows in flight 1.60 / 1.50 / 1.35 / 1.25-1.33 at 64 rows per
     //  piece; 8 rows in flight at 16 / 32 / 48 / 128 rows per piece 1.32 / 1.36 / 1.39 / 1.52; the tile kernel 2.13)
@@ -1578,7 +1597,7 @@ bool launch_gauss5_quad(const uint16_t *src, float *dst, int nimg, int rows, int
     if (pieces > 65535 || zb > 65535) return false;
 #define UPSP_GQ(UU)                                                                                                 \
     hipLaunchKernelGGL((gauss5_quad_kernel<UU>), dim3((unsigned)nimg, (unsigned)pieces, (unsigned)zb), dim3(256), 0, st, src, dst, rows, \
-                       cols, rpp, fc.k[2], fc.k[3], fc.k[4])
+                       cols, rpp, fc.k[2], fc.k[3], fc.k[4], thresh, flag, only_flagged)
     if (uvar == 2) UPSP_GQ(2); else if (uvar == 4) UPSP_GQ(4); else if (uvar == 6) UPSP_GQ(6); else UPSP_GQ(8);
 #undef UPSP_GQ
     return true;
@@ -2113,6 +2132,7 @@ struct FrameScratch {
     float *tmpl[kMaxCams] = {nullptr};      // blurred ECC templates
     const float *tmpl_src[kMaxCams] = {nullptr};
     float *center = nullptr;                // [kMaxCams] centre of the float products of the ECC sums (ecc_center_kernel)
+    unsigned *hot_flag = nullptr;           // [batch] frames in which the pre-blur saw a pixel >= the hot threshold (HotFuse)
     double *partial = nullptr;
     EccState *state = nullptr;
     int *counter = nullptr;
@@ -2138,6 +2158,7 @@ void frame_scratch_free(FrameScratch *s)
     if (s->ecc_img) (void)hipFree(s->ecc_img);
     if (s->ecc_img2) (void)hipFree(s->ecc_img2);
     if (s->center) (void)hipFree(s->center);
+    if (s->hot_flag) (void)hipFree(s->hot_flag);
     if (s->tmp) (void)hipFree(s->tmp);
     if (s->partial) (void)hipFree(s->partial);
     if (s->state) (void)hipFree(s->state);
@@ -2170,6 +2191,7 @@ int frame_scratch_ensure(FrameScratch **ps, int ncams, int batch, int rows, int 
         if (need_warp && !s->tmpl[c]) UPSP_HIP_CHECK(hipMalloc(&s->tmpl[c], (size_t)rows * cols * sizeof(float)));
     }
     if (need_warp && !s->ecc_img) UPSP_HIP_CHECK(hipMalloc(&s->ecc_img, n * sizeof(float)));
+    if (need_warp && !s->hot_flag) UPSP_HIP_CHECK(hipMalloc(&s->hot_flag, sizeof(unsigned) * (size_t)batch));
     if (need_warp && !s->center) {
         UPSP_HIP_CHECK(hipMalloc(&s->center, kMaxCams * sizeof(float)));
         UPSP_HIP_CHECK(hipMemset(s->center, 0, kMaxCams * sizeof(float)));
@@ -2185,7 +2207,7 @@ int frame_scratch_ensure(FrameScratch **ps, int ncams, int batch, int rows, int 
 // ECC registration of nb frames against the blurred template; leaves the warp in state[].
 static int run_ecc(FrameScratch *s, const float *tmpl_blur, const float *d_center, const uint16_t *frames, int nb,
                    int64_t first_frame, int rows, int cols, int max_iters, double eps, hipStream_t st,
-                   const float *preblurred = nullptr)
+                   const float *preblurred = nullptr, const HotFuse *hot = nullptr, uint16_t *frames_rw = nullptr)
 {
     if ((long long)rows * cols >= (1ll << 31)) return fail(UPSP_ERR_INVALID, "registration: image too large");
     // Pre-blur (GaussianBlur 5 x 5) and the first iteration.  Every frame starts from the identity warp
@@ -2210,6 +2232,21 @@ static int run_ecc(FrameScratch *s, const float *tmpl_blur, const float *d_cente
         hipLaunchKernelGGL(ecc_solve_kernel, dim3(nb), dim3(256), 0, st, s->state, (const double *)s->partial, nb, nslots,
                            max_iters, eps, rows, cols);
         it = 1;
+    } else if (!preblurred && hot) {
+        // fix_hot_pixels inside the pre-blur: blur + flag, repair the flagged frames (normally none), blur those again
+        FilterCoef fc;
+        if (gaussian_coef(5, fc) != 0) return fail(UPSP_ERR_INVALID, "gaussian 5");
+        UPSP_HIP_CHECK(hipMemsetAsync(s->hot_flag, 0, sizeof(unsigned) * (size_t)nb, st));
+        {
+            KTimed kt("gauss_pass_kernels", st);
+            if (!launch_gauss5_quad(frames, s->ecc_img, nb, rows, cols, fc, st, (unsigned)hot->thresh, s->hot_flag, 0))
+                return fail(UPSP_ERR_INTERNAL, "pre-blur with the hot-pixel scan: geometry not supported (frame_stages_fuse_hot)");
+        }
+        int rc = launch_hot_fix(frames_rw, nb, rows, cols, hot->thresh, hot->min_change, hot->max_hot, hot->d_count, hot->d_pos, nullptr,
+                                st, s->hot_flag);
+        if (rc != UPSP_OK) return rc;
+        KTimed kt("gauss_pass_kernels", st);
+        (void)launch_gauss5_quad(frames, s->ecc_img, nb, rows, cols, fc, st, 0u, s->hot_flag, 1);
     } else if (!preblurred) {
         int rc = (fused_env == 2 && rows >= 5 && cols >= 5)
                      ? launch_gauss5_cols(frames, s->ecc_img, nb, rows, cols, nullptr, nullptr, nullptr, nullptr, st)
@@ -2432,6 +2469,16 @@ int launch_pixel_list(const int32_t *d_pix, size_t nnodes, uint8_t *d_mask, unsi
 // buffers, on any stream: the streamed registration loop runs it for sub-batch k + 1 while sub-batch k iterates -- a
 // memory-bound kernel beside the issue-bound ECC sums, and work for the GPU while the host reads "frames still
 // iterating" back.  *out = the buffer to hand to run_frame_stages.
+bool frame_stages_fuse_hot(const uint16_t *d_frames, int rows, int cols, const upsp_pipeline_opts &opts)
+{
+    // (the scratch's blurred-frame buffer comes from hipMalloc: 256-byte aligned)
+    // Opt-in (UPSP_HOT_IN_BLUR=1), measured and NOT the default: it saves the 27-us scan per sub-batch and pays it back with
+    // what replaces it -- a memset of the flags, a scan launch whose blocks all exit and a second blur launch whose blocks
+    // all exit: 9.5-9.6 against 9.38 ms per 1000 frames.
+    return opts.registration && !std::getenv("UPSP_ECC_FUSED") && env_int_io("UPSP_HOT_IN_BLUR", 0) &&
+           gauss5_quad_applies(d_frames, nullptr, 1, rows, cols);
+}
+
 int frame_scratch_preblur(FrameScratch *s, int slot, const uint16_t *d_frames, int nb, int rows, int cols, hipStream_t st,
                           const float **out)
 {
@@ -2449,7 +2496,7 @@ int run_frame_stages(FrameScratch *s, int cam, const uint16_t *d_frames, int nb,
                      int rows, int cols, const upsp_pipeline_opts &opts, const float *d_ref,
                      const PatchTables *patches, float *d_warps, int32_t *d_iters, int ncams,
                      const unsigned *d_read_list, const WarpCompact *wc, const void **img_out, int *is_f32_out,
-                     hipStream_t st, const float *preblurred)
+                     hipStream_t st, const float *preblurred, const HotFuse *hot)
 {
     const size_t npix = (size_t)rows * cols;
     const uint16_t *cur = d_frames;
@@ -2462,7 +2509,7 @@ int run_frame_stages(FrameScratch *s, int cam, const uint16_t *d_frames, int nb,
             s->tmpl_src[cam] = d_ref;
         }
         int rc = run_ecc(s, s->tmpl[cam], s->center + cam, d_frames, nb, first_frame, rows, cols, opts.ecc_max_iters,
-                         opts.ecc_eps, st, preblurred);
+                         opts.ecc_eps, st, preblurred, hot, const_cast<uint16_t *>(d_frames));
         if (rc != UPSP_OK) return rc;
         if (wc) {      // registration is the last image stage and node-major series are wanted: straight into the compact buffer
             KTimed kt("warp_u16_kernel", st);

@@ -34,7 +34,7 @@ struct PipelineGather {
 size_t hot_counter_words(int nframes);   // size of the counter buffer launch_hot_fix needs (zeroed)
 int launch_hot_fix(uint16_t *d_frames, int nframes, int rows, int cols, int thresh,
                    int min_change, int max_hot, unsigned *d_count, unsigned *d_pos,
-                   int32_t *d_status, hipStream_t st);
+                   int32_t *d_status, hipStream_t st, const unsigned *d_only = nullptr);
 int launch_gather(const PipelineGather &g, hipStream_t st);
 // streamed scan + projection (one camera, no weights, u16 frames, no image stage): frames.hip
 size_t tilemap_tiles(size_t npix);
@@ -91,6 +91,13 @@ namespace upsp {
 // target of the warp when registration is the last image stage of the streamed schedule: the compact
 // [active pixel][frame] buffer (column col0 on, pitch cpitch); pix_of_k = pixel of every compact row,
 // *nact = rows in use (device), max_active = bound of it (grid size)
+// fix_hot_pixels folded into the registration's pre-blur (the blur reads every pixel anyway): the blur flags the frames that
+// hold a pixel >= thresh, hot_scan_kernel runs for those only (normally none), and they are blurred again.  d_count /
+// d_pos: the scratch of launch_hot_fix.
+struct HotFuse {
+    int thresh = 0, min_change = 0, max_hot = 0;
+    unsigned *d_count = nullptr, *d_pos = nullptr;
+};
 struct WarpCompact {
     const unsigned *pix_of_k = nullptr, *nact = nullptr;
     size_t max_active = 0;
@@ -106,7 +113,9 @@ int run_frame_stages(FrameScratch *s, int cam, const uint16_t *d_frames, int nb,
                      int64_t first_frame, int rows, int cols, const upsp_pipeline_opts &opts,
                      const float *d_ref, const PatchTables *patches, float *d_warps, int32_t *d_iters, int ncams,
                      const unsigned *d_read_list, const WarpCompact *wc, const void **img_out, int *is_f32_out,
-                     hipStream_t st, const float *preblurred = nullptr);
+                     hipStream_t st, const float *preblurred = nullptr, const HotFuse *hot = nullptr);
+// true when run_frame_stages can take the hot-pixel repair into its pre-blur for frames of this geometry (HotFuse)
+bool frame_stages_fuse_hot(const uint16_t *d_frames, int rows, int cols, const upsp_pipeline_opts &opts);
 // the ECC's 5 x 5 pre-blur of nb frames into blurred-frame buffer `slot` (0 / 1) of the scratch, on any stream
 int frame_scratch_preblur(FrameScratch *s, int slot, const uint16_t *d_frames, int nb, int rows, int cols, hipStream_t st,
                           const float **out);

@@ -850,11 +850,23 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
             const int f0 = subs[i].f0, nb = subs[i].nb, s0 = subs[i].s0;
             uint16_t *frames = fr + (size_t)f0 * npix;
             const float *pre = nullptr;
+            upsp::HotFuse fuse;
+            const upsp::HotFuse *hotp = nullptr;
             if (pipelined) {
                 if (i + 1 < subs.size()) rc = ahead(i + 1);
                 if (rc != UPSP_OK) break;
                 UPSP_HIP_CHECK(hipStreamWaitEvent(st, p->ev_blur[i & 1], 0));
                 pre = blurred[i & 1];
+            } else if (p->opts.hot_enable && upsp::frame_stages_fuse_hot(frames, p->height, p->width, p->opts)) {
+                // the repair rides on the pre-blur (upsp::HotFuse): no scan launch of its own
+                rc = ensure_hot(p, nb);
+                if (rc != UPSP_OK) break;
+                fuse.thresh = p->opts.hot_thresh;
+                fuse.min_change = p->opts.hot_min_change;
+                fuse.max_hot = p->opts.hot_max;
+                fuse.d_count = p->d_hot_count;
+                fuse.d_pos = p->d_hot_pos;
+                hotp = &fuse;
             } else {
                 rc = repair(frames, nb, st);
                 if (rc != UPSP_OK) break;
@@ -864,7 +876,7 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
             int is_f32 = 0;
             rc = upsp::run_frame_stages(p->scratch, 0, frames, nb, first_frame + f0, p->height, p->width, p->opts, p->d_ref[0],
                                         nullptr, d_warps ? d_warps + (size_t)f0 * 6 : nullptr,
-                                        p->d_ecc_iters ? p->d_ecc_iters + f0 : nullptr, 1, nullptr, &wc, &img, &is_f32, st, pre);
+                                        p->d_ecc_iters ? p->d_ecc_iters + f0 : nullptr, 1, nullptr, &wc, &img, &is_f32, st, pre, hotp);
             if (pipelined && rc == UPSP_OK) UPSP_HIP_CHECK(hipEventRecord(p->ev_used[i & 1], st));
             const bool last_of_group = i + 1 == subs.size() || subs[i + 1].s0 != s0;
             if (rc == UPSP_OK && last_of_group) {
