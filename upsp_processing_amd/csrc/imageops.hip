@@ -417,27 +417,63 @@ __global__ void __launch_bounds__(256)
     const size_t npix = (size_t)rows * cols;
     const unsigned p = valid ? pix_of_k[k] : 0u;
     const int y = (int)(p / (unsigned)cols), x = (int)(p % (unsigned)cols);
-    for (int f = wave; f < nframes; f += 4) {                    // (uniform per wave)
-        const EccState &es = state[f];
-        const uint16_t *s = src + (size_t)f * npix;
-        uint16_t o;
-        if (es.done == 2) {
-            o = s[p];                                            // frame 0 of a run: never registered
-        } else {
+    // A wave takes the frames wave, wave + 4, ... -- four of them per step, their 16 source pixels loaded before any is
+    // used (one frame per step was a chain of 16 gather latencies per wave: 31 us per 64-frame sub-batch).  The loads are
+    // unconditional on clamped coordinates; a footprint that leaves the image (or nearest-neighbour mode) takes the generic path.
+    constexpr int UF = 4;
+    for (int fb = wave; fb < nframes; fb += 4 * UF) {            // (uniform per wave)
+        WarpCoord c[UF];
+        unsigned short t[UF][4];
+        bool live[UF], raw[UF], fast[UF];
+#pragma unroll
+        for (int u = 0; u < UF; ++u) {
+            const int f = fb + 4 * u;
+            live[u] = f < nframes;
+            const EccState &es = state[live[u] ? f : fb];
+            raw[u] = es.done == 2;                               // frame 0 of a run: never registered
             double M[6];
 #pragma unroll
             for (int i = 0; i < 6; ++i) M[i] = es.M[i];
-            const WarpCoord c = warp_coord(M, x, y, interp);
-            if (interp) {
-                const float v = bilinear([&](int yy, int xx) { return (float)s[(size_t)yy * cols + xx]; }, rows, cols, c);
+            c[u] = warp_coord(M, x, y, interp);
+            fast[u] = interp && (unsigned)c[u].sx < (unsigned)(cols - 1) && (unsigned)c[u].sy < (unsigned)(rows - 1);
+            const uint16_t *s = src + (size_t)(live[u] ? f : fb) * npix;
+            const int lx = max(0, min(cols - 2, c[u].sx)), ly = max(0, min(rows - 2, c[u].sy));
+            const uint16_t *q = s + (size_t)ly * cols + lx;
+            t[u][0] = t[u][1] = t[u][2] = t[u][3] = 0;
+            if (rows >= 2 && cols >= 2) {                        // (uniform)
+                t[u][0] = q[0];
+                t[u][1] = q[1];
+                t[u][2] = q[cols];
+                t[u][3] = q[cols + 1];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UF; ++u) {
+            if (!live[u]) break;                                 // (uniform)
+            const int f = fb + 4 * u;
+            uint16_t o;
+            if (raw[u]) {
+                o = src[(size_t)f * npix + p];
+            } else if (fast[u]) {
+                // remapBilinear's four-weight form (bilinear() above), same operations in the same order
+                const float fx = c[u].ax * (1.f / 32), fy = c[u].ay * (1.f / 32);
+                const float w0 = (1.f - fy) * (1.f - fx), w1 = (1.f - fy) * fx, w2 = fy * (1.f - fx), w3 = fy * fx;
+                const float v = (float)t[u][0] * w0 + (float)t[u][1] * w1 + (float)t[u][2] * w2 + (float)t[u][3] * w3;
                 const int iv = (int)rintf(v);  // saturate_cast<ushort>(float)
                 o = (uint16_t)max(0, min(65535, iv));
             } else {
-                o = ((unsigned)c.sx < (unsigned)cols && (unsigned)c.sy < (unsigned)rows) ? s[(size_t)c.sy * cols + c.sx]
-                                                                                          : (uint16_t)0;
+                const uint16_t *s = src + (size_t)f * npix;
+                if (interp) {
+                    const float v = bilinear([&](int yy, int xx) { return (float)s[(size_t)yy * cols + xx]; }, rows, cols, c[u]);
+                    const int iv = (int)rintf(v);
+                    o = (uint16_t)max(0, min(65535, iv));
+                } else {
+                    o = ((unsigned)c[u].sx < (unsigned)cols && (unsigned)c[u].sy < (unsigned)rows) ? s[(size_t)c[u].sy * cols + c[u].sx]
+                                                                                                    : (uint16_t)0;
+                }
             }
+            tile[f][lane] = o;
         }
-        tile[f][lane] = o;
     }
     __syncthreads();
     // 4 threads per pixel, 16 frames (32 bytes) each: an active pixel's frames of this sub-batch are one 128-byte piece
