@@ -9,7 +9,7 @@ if [ $part = a ]; then
   UPSP_FORCE_COLLECTIVES=1 timeout -k 10 400 python3 bench.py --force-chunked > gpurun_out/prof_r03/bench_line_chunked_rccl.json 2> gpurun_out/prof_r03/chunked.err; echo "chunked (pixel series, rccl) rc=$?"
   UPSP_FORCE_COLLECTIVES=1 timeout -k 10 300 python3 bench.py --force-chunked --wire12 --no-cpu-baseline --no-reraycast > gpurun_out/prof_r03/bench_line_chunked_rccl_12bit.json 2> gpurun_out/prof_r03/chunked12.err; echo "chunked 12 rc=$?"
   UPSP_FORCE_COLLECTIVES=1 timeout -k 10 300 python3 bench.py --force-chunked --row-wire --no-cpu-baseline --no-reraycast > gpurun_out/prof_r03/bench_line_chunked_rccl_rows.json 2> gpurun_out/prof_r03/chunkedrows.err; echo "chunked rows rc=$?"
-  bash tools/pmc_script.sh "ecc_cols|gauss_fused|ecc_solve|warp_compact|node_rows|hot_scan" tools/prof_ecc.py > gpurun_out/prof_r03/ecc_pmc.txt 2>&1; echo "ecc pmc rc=$?"
+  bash tools/pmc_script.sh "ecc_cols|gauss_fused|gauss5_quad|ecc_solve|warp_compact|node_rows|hot_scan" tools/prof_ecc.py > gpurun_out/prof_r03/ecc_pmc.txt 2>&1; echo "ecc pmc rc=$?"
 else
   PROFILE_TIMEOUT=500 BENCH_TIMEOUT=700 bash tools/profile_bench.sh r03_multi --cameras 4 --model 5m --steps 3 --warmup 1 2>&1 | tail -6
   PMC_TIMEOUT=400 bash tools/pmc_script.sh "node_rows_multi|scan_compact" tools/prof_multi.py > gpurun_out/prof_r03_multi/multi_pmc.txt 2>&1; echo "multi pmc rc=$?"
