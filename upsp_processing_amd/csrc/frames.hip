@@ -1217,7 +1217,7 @@ __global__ void __launch_bounds__(256)
 // is used (round 2 walked sweep by sweep, camera by camera: ROWS x cameras dependent load -> convert -> add chains per
 // lane); (2) a row no camera sees (NaN in every frame) or that reads no pixel (0) is a constant fill -- no loads, no
 // sums, no reductions, like in node_rows_kernel; (3) NC = the camera count at compile time (2 .. 4; 0 = any).
-template <int LPR, int ROWS, int NC>
+template <int LPR, int ROWS, int NC, int FPL = 4>
 __global__ void __launch_bounds__(256)
     node_rows_multi_kernel(StreamMultiArgs a, unsigned cpitch, const uint8_t *__restrict__ skipped,
                            const int32_t *__restrict__ rowmap, unsigned nnodes, int nframes,
@@ -1252,22 +1252,32 @@ __global__ void __launch_bounds__(256)
     }
     __syncthreads();
     const int sub = t / LPR, l = t % LPR, wr = l >> 6, lane = t & 63;
+    // FPL frames per lane: 4, or 8 = two groups of 4 that lie 4 * LPR frames apart (every load / store instruction of a wave
+    // still covers one contiguous piece of the row; 8 consecutive frames per lane made the stores half-empty: 4.1 ms against
+    // 2.99): half as many lanes per row, so the per-row reductions of the double sums are paid half as often
+    static_assert(FPL == 4 || FPL == 8, "frames per lane");
+    constexpr int GS = 4 * LPR;                                  // distance of a lane's two groups
     const int f0 = 4 * l;
     const float qnan = __builtin_nanf("");
     const bool vec_ok = ((ld_t & 3) == 0) && ((reinterpret_cast<size_t>(rows_t) & 15) == 0);
     typedef float v4f __attribute__((ext_vector_type(4)));
     // every load of the workgroup's rows first ...
-    uint2 tt[ROWS][MC];
+    uint2 tt[ROWS][MC][FPL / 4];
 #pragma unroll
     for (int j = 0; j < ROWS; ++j) {
         const int r = j * RPS + sub;                            // (uniform per wave)
         const bool data = s_kind[r] == 0 && f0 < nframes;
 #pragma unroll
         for (int c = 0; c < MC; ++c) {
-            tt[j][c] = make_uint2(0u, 0u);
+#pragma unroll
+            for (int h = 0; h < FPL / 4; ++h) tt[j][c][h] = make_uint2(0u, 0u);
             if (c < ncams) {
                 const int k = s_k[r][c];
-                if (data && k >= 0) tt[j][c] = *reinterpret_cast<const uint2 *>(a.compact[c] + (size_t)k * cpitch + f0);
+                if (data && k >= 0) {
+                    const uint16_t *src = a.compact[c] + (size_t)k * cpitch + f0;      // (rows padded to 64 frames: in bounds)
+                    tt[j][c][0] = *reinterpret_cast<const uint2 *>(src);
+                    if (FPL == 8 && f0 + GS < nframes) tt[j][c][FPL / 4 - 1] = *reinterpret_cast<const uint2 *>(src + GS);
+                }
             }
         }
     }
@@ -1282,36 +1292,45 @@ __global__ void __launch_bounds__(256)
                 float *dst = rows_t + (long long)row * ld_t + f0;
                 const float cv = kind == 1 ? qnan : 0.0f;
                 const v4f nv = {cv, cv, cv, cv};
-                if (vec_ok && f0 + 3 < nframes) {
-                    __builtin_nontemporal_store(nv, reinterpret_cast<v4f *>(dst));
-                } else {
-                    dst[0] = cv;
-                    if (f0 + 1 < nframes) dst[1] = cv;
-                    if (f0 + 2 < nframes) dst[2] = cv;
-                    if (f0 + 3 < nframes) dst[3] = cv;
+#pragma unroll
+                for (int h = 0; h < FPL / 4; ++h) {
+                    const int fh = f0 + GS * h;
+                    if (vec_ok && fh + 3 < nframes) {
+                        __builtin_nontemporal_store(nv, reinterpret_cast<v4f *>(dst + GS * h));
+                    } else {
+                        if (fh < nframes) dst[GS * h] = cv;
+                        if (fh + 1 < nframes) dst[GS * h + 1] = cv;
+                        if (fh + 2 < nframes) dst[GS * h + 2] = cv;
+                        if (fh + 3 < nframes) dst[GS * h + 3] = cv;
+                    }
                 }
             }
             continue;
         }
-        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        float acc[FPL];
+#pragma unroll
+        for (int q = 0; q < FPL; ++q) acc[q] = 0.0f;
 #pragma unroll
         for (int c = 0; c < MC; ++c) {
             // (uniform per wave) a camera that does not see the node contributes 0.0f + w * 0 = +0 in the gather; every
             // term here is >= +0, so leaving it out changes no bit -- and a node is seen by 1.x cameras on average
             if (c < ncams && s_k[r][c] >= 0) {
                 const float w = s_w[r][c];
-                const uint2 q = tt[j][c];
-                // (the gather forms 0.0f + w * pixel: with acc starting at +0 the extra +0 changes no bit of the sum)
-                const float v[4] = {w * (float)(q.x & 0xFFFFu), w * (float)(q.x >> 16),
-                                    w * (float)(q.y & 0xFFFFu), w * (float)(q.y >> 16)};
 #pragma unroll
-                for (int qq = 0; qq < 4; ++qq) acc[qq] = acc[qq] + v[qq];
+                for (int h = 0; h < FPL / 4; ++h) {
+                    const uint2 q = tt[j][c][h];
+                    // (the gather forms 0.0f + w * pixel: with acc starting at +0 the extra +0 changes no bit of the sum)
+                    const float v[4] = {w * (float)(q.x & 0xFFFFu), w * (float)(q.x >> 16),
+                                        w * (float)(q.y & 0xFFFFu), w * (float)(q.y >> 16)};
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) acc[4 * h + qq] = acc[4 * h + qq] + v[qq];
+                }
             }
         }
         double s = 0.0, ss = 0.0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (f0 + q < nframes) {
+        for (int q = 0; q < FPL; ++q)
+            if (f0 + (q >> 2) * GS + (q & 3) < nframes) {
                 s += (double)acc[q];
                 ss += (double)(acc[q] * acc[q]);
             }
@@ -1323,14 +1342,18 @@ __global__ void __launch_bounds__(256)
         }
         if (!stored) continue;
         float *dst = rows_t + (long long)row * ld_t + f0;
-        const v4f nv = {acc[0], acc[1], acc[2], acc[3]};
-        if (vec_ok && f0 + 3 < nframes) {
-            __builtin_nontemporal_store(nv, reinterpret_cast<v4f *>(dst));
-        } else {
-            dst[0] = nv.x;
-            if (f0 + 1 < nframes) dst[1] = nv.y;
-            if (f0 + 2 < nframes) dst[2] = nv.z;
-            if (f0 + 3 < nframes) dst[3] = nv.w;
+#pragma unroll
+        for (int h = 0; h < FPL / 4; ++h) {
+            const int fh = f0 + GS * h;
+            const v4f nv = {acc[4 * h], acc[4 * h + 1], acc[4 * h + 2], acc[4 * h + 3]};
+            if (vec_ok && fh + 3 < nframes) {
+                __builtin_nontemporal_store(nv, reinterpret_cast<v4f *>(dst + GS * h));
+            } else {
+                if (fh < nframes) dst[GS * h] = nv.x;
+                if (fh + 1 < nframes) dst[GS * h + 1] = nv.y;
+                if (fh + 2 < nframes) dst[GS * h + 2] = nv.z;
+                if (fh + 3 < nframes) dst[GS * h + 3] = nv.w;
+            }
         }
     }
     __syncthreads();
@@ -1873,10 +1896,16 @@ int launch_node_rows_multi(const PipelineGather &g, const int32_t *const *d_node
     }
     const unsigned nn = (unsigned)g.nnodes;
     KTimed kt("node_rows_multi_kernel", st);
-#define UPSP_NRM(LPR, ROWS, NC)                                                                               \
-    hipLaunchKernelGGL((node_rows_multi_kernel<LPR, ROWS, NC>), dim3((nn + (256 / LPR) * ROWS - 1) / ((256 / LPR) * ROWS)), \
+#define UPSP_NRM(LPR, ROWS, NC, ...)                                                                          \
+    hipLaunchKernelGGL((node_rows_multi_kernel<LPR, ROWS, NC, ##__VA_ARGS__>), dim3((nn + (256 / LPR) * ROWS - 1) / ((256 / LPR) * ROWS)), \
                        dim3(256), 0, st, a, cpitch, g.skipped, g.rowmap, nn, g.nframes, g.rows_t, (long long)g.ld_t, \
                        g.sum, g.sumsq)
+#define UPSP_NRM8_NC(LPR, ROWS)                                                                               \
+    do {                                                                                                      \
+        if (g.ncams == 2) UPSP_NRM(LPR, ROWS, 2, 8);                                                          \
+        else if (g.ncams == 3) UPSP_NRM(LPR, ROWS, 3, 8);                                                     \
+        else UPSP_NRM(LPR, ROWS, 4, 8);                                                                       \
+    } while (0)
 #define UPSP_NRM_NC(LPR, ROWS)                                                                                \
     do {                                                                                                      \
         if (g.ncams == 2) UPSP_NRM(LPR, ROWS, 2);                                                             \
@@ -1889,9 +1918,17 @@ int launch_node_rows_multi(const PipelineGather &g, const int32_t *const *d_node
     // leaner sums 2.97.  Tried and dropped: row / series indices through v_readfirstlane (scalar addresses, SGPR-base
     // loads) -- the scalar branches around the loads serialise them: 3.51 ms)
     static const int rows_env = std::getenv("UPSP_MULTI_ROWS") ? std::atoi(std::getenv("UPSP_MULTI_ROWS")) : 8;
-    if (g.nframes > 512) { if (rows_env == 8) UPSP_NRM_NC(256, 8); else if (rows_env == 2) UPSP_NRM_NC(256, 2); else UPSP_NRM_NC(256, 4); }
+    // eight frames per lane (two groups of four, 128 lanes per row of <= 1024 frames): 2.93-2.94 ms against 2.99-3.13 with four
+    // (4 cameras, 2.5 M nodes, 1000 frame sets; as 8 CONSECUTIVE frames per lane, i.e. half-empty store instructions, 4.1 ms).
+    // The kernel is not bound by its instructions (PMC: VALU busy 53 %): a workgroup lives ~12 us, most of it the two
+    // dependent memory latencies of its staging and its series loads.  UPSP_MULTI_FPL=4: the four-frame form.
+    static const int fpl_env = std::getenv("UPSP_MULTI_FPL") ? std::atoi(std::getenv("UPSP_MULTI_FPL")) : 8;
+    const bool fpl8 = fpl_env == 8 && g.ncams >= 2 && g.ncams <= 4;
+    if (g.nframes > 512 && fpl8) { if (rows_env == 2) UPSP_NRM8_NC(128, 1); else if (rows_env == 8) UPSP_NRM8_NC(128, 4); else UPSP_NRM8_NC(128, 2); }
+    else if (g.nframes > 512) { if (rows_env == 8) UPSP_NRM_NC(256, 8); else if (rows_env == 2) UPSP_NRM_NC(256, 2); else UPSP_NRM_NC(256, 4); }
     else if (g.nframes > 256) UPSP_NRM_NC(128, 4);
     else UPSP_NRM_NC(64, 4);
+#undef UPSP_NRM8_NC
 #undef UPSP_NRM_NC
 #undef UPSP_NRM
     UPSP_HIP_CHECK(hipGetLastError());
