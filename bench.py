@@ -394,8 +394,8 @@ def registration_block(bvh, cam, d_nodes, d_nrm, d_tn, frames, restore, N, size,
 
 
 # "ecc_sums_kernel" is the timer label of the ECC sums launch of every round; the symbols a rocprofv3 trace shows for it
-ECC_SYMBOLS = {"ecc_sums_kernel": {"kernel_symbols": ["ecc_cols_kernel<true,4,4,1,1> (iterations from the identity warp)",
-                                                      "ecc_cols_kernel<false,2,3,0,1> (general warp)"]}}
+ECC_SYMBOLS = {"ecc_sums_kernel": {"kernel_symbols": ["ecc_cols_kernel<true,4,4,1,1,0> (iterations from the identity warp)",
+                                                      "ecc_cols_kernel<false,2,3,0,1,0> (general warp)"]}}
 
 
 def host_feed_rate(pipe, frames, N, size, pix, chunk=64, nchunks=16):

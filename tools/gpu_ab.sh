@@ -4,6 +4,6 @@ for e in "$@"; do
   python3 - "$e" <<'PY'
 import json,sys
 d=json.loads(open("gpurun_out/ab.json").read().strip().splitlines()[-1]); k=d["kernels"]
-print("%-40s %7.0f frames/s  step %.2f ms  ecc %.2f  gauss %.2f  solve %.2f" % (sys.argv[1], d["value"], d["ms_per_step"], k["ecc_sums_kernel"]["ms_per_step"], k["gauss_pass_kernels"]["ms_per_step"], k["ecc_solve_kernel"]["ms_per_step"]))
+print("%-40s %7.0f frames/s  step %.2f ms  ecc %.2f  gauss %.2f  solve %.2f" % (sys.argv[1], d["value"], d["ms_per_step"], k["ecc_sums_kernel"]["ms_per_step"], k["gauss_pass_kernels"]["ms_per_step"], k.get("ecc_solve_kernel", {"ms_per_step": 0.0})["ms_per_step"]))
 PY
 done

@@ -986,6 +986,22 @@ __device__ __forceinline__ double dpp_add_f64(double v)
 // per thread, a third of the identity kernel's VALU instructions (PMC, profiles/r03_ecc_pmc.txt).  Fixed order: deterministic.
 constexpr int kEccChunk = 15;
 static_assert(kEccSums == 3 * kEccChunk, "three chunks");
+// A block's 45 partial sums leave either as plain stores (the solve is the next launch) or, when the LAST block of the frame
+// solves in the same launch (ecc_cols_kernel<..., FUSE>), as device-scope atomic exchanges: performed at the memory side,
+// coherent across the 8 XCDs without an L2 write-back (hot_scan_kernel's hand-off).  g_ecc_sink takes the exchanges'
+// return values so that they have completed before the block's barrier and ticket.
+struct EccOut {
+    double *partial;
+    bool atomic;
+    unsigned long long sink;
+};
+__device__ __forceinline__ void ecc_out_put(EccOut &o, size_t idx, double v)
+{
+    if (o.atomic)
+        o.sink |= atomicExch(reinterpret_cast<unsigned long long *>(o.partial + idx), (unsigned long long)__double_as_longlong(v));
+    else
+        o.partial[idx] = v;
+}
 template <int C, int J>
 __device__ __forceinline__ void ecc_tot_put(const EccTot &T, double X, bool on, double (*lds)[256])
 {
@@ -994,7 +1010,7 @@ __device__ __forceinline__ void ecc_tot_put(const EccTot &T, double X, bool on, 
 }
 template <int C>
 __device__ __forceinline__ void ecc_tot_store(const EccTot &T, double X, bool on, double (*lds)[256],
-                                              double *__restrict__ partial, int f, unsigned slot)
+                                              EccOut &out, int f, unsigned slot)
 {
     ecc_tot_put<C, 0>(T, X, on, lds);
     __syncthreads();
@@ -1007,16 +1023,16 @@ __device__ __forceinline__ void ecc_tot_store(const EccTot &T, double X, bool on
         s = dpp_add_f64<0x4E, 0xF>(s);
         s = dpp_add_f64<0x141, 0xF>(s);
         s = dpp_add_f64<0x140, 0xF>(s);        // every lane of the row holds the block's sum of value v
-        if (p == 0) partial[((size_t)f * kEccSums + (C * kEccChunk + v)) * kEccStride + slot] = s;
+        if (p == 0) ecc_out_put(out, ((size_t)f * kEccSums + (C * kEccChunk + v)) * kEccStride + slot, s);
     }
     __syncthreads();
-    if constexpr (C + 1 < 3) ecc_tot_store<C + 1>(T, X, on, lds, partial, f, slot);
+    if constexpr (C + 1 < 3) ecc_tot_store<C + 1>(T, X, on, lds, out, f, slot);
 }
 
 // a block without any pixel: its partial sums are zero
-__device__ __forceinline__ void ecc_store_zeros(double *__restrict__ partial, int f, unsigned slot)
+__device__ __forceinline__ void ecc_store_zeros(EccOut &out, int f, unsigned slot)
 {
-    if (threadIdx.x < kEccSums) partial[((size_t)f * kEccSums + threadIdx.x) * kEccStride + slot] = 0.0;
+    if (threadIdx.x < kEccSums) ecc_out_put(out, ((size_t)f * kEccSums + threadIdx.x) * kEccStride + slot, 0.0);
 }
 
 // Identity iteration with NEIGHBOUR = 1: the left / right taps come from the neighbouring lanes' centre values by DPP
@@ -1164,7 +1180,7 @@ __device__ __forceinline__ void ecc_cols_trip(const float *__restrict__ I, const
 template <bool IDENT, int UR, int NEIGHBOUR, int GXD>
 __device__ __forceinline__ void ecc_cols_body(const float *__restrict__ img, const float *__restrict__ tmpl, int rows,
                                               int cols, const EccState *__restrict__ state,
-                                              double *__restrict__ partial, int f, unsigned blk, unsigned nblk,
+                                              EccOut &out, int f, unsigned blk, unsigned nblk,
                                               double (*lds_red)[256], float center)
 {
     // one LDS area: the per-row coordinate table while the rows are walked, the reduction chunks afterwards
@@ -1187,7 +1203,7 @@ __device__ __forceinline__ void ecc_cols_body(const float *__restrict__ img, con
     // x_hi, which exists: the band is >= 3 wide) and are left out of the reduction
     const int x = NEIGHBOUR ? min(x_own, cols - 1) : x_own;
     if (!work || y1 <= y0) {            // (uniform) more blocks than pieces: nothing to add
-        ecc_store_zeros(partial, f, kEccBorderBlocks + blk);
+        ecc_store_zeros(out, f, kEccBorderBlocks + blk);
         return;
     }
     double M[6];
@@ -1221,7 +1237,7 @@ __device__ __forceinline__ void ecc_cols_body(const float *__restrict__ img, con
         }
     }
     __syncthreads();                              // (every read of the row table is done)
-    ecc_tot_store<0>(T, (double)x, on, lds_red, partial, f, kEccBorderBlocks + blk);
+    ecc_tot_store<0>(T, (double)x, on, lds_red, out, f, kEccBorderBlocks + blk);
 }
 
 // The band of the same launch, also one column per thread (no 45 double accumulators anywhere in this kernel: with
@@ -1233,7 +1249,7 @@ __device__ __forceinline__ void ecc_cols_body(const float *__restrict__ img, con
 // Generic bilinear (constant-0 border, reflect-101 gradient taps) and the nearest-neighbour mask, as in round 2.
 __device__ __forceinline__ void ecc_band_cols_body(const float *__restrict__ img, const float *__restrict__ tmpl, int rows,
                                                    int cols, const EccState *__restrict__ state,
-                                                   double *__restrict__ partial, int f, unsigned bidx, bool ident,
+                                                   EccOut &out, int f, unsigned bidx, bool ident,
                                                    double (*lds_red)[256])
 {
     const EccState &es = state[f];
@@ -1278,7 +1294,7 @@ __device__ __forceinline__ void ecc_band_cols_body(const float *__restrict__ img
     }
     const bool on = x >= 0 && x < cols && yb > ya;
     if (!__syncthreads_or(on ? 1 : 0)) {     // no thread of the block has a pixel (spare band block, empty strip)
-        ecc_store_zeros(partial, f, bidx);
+        ecc_store_zeros(out, f, bidx);
         return;
     }
     EccTot T;
@@ -1339,7 +1355,7 @@ __device__ __forceinline__ void ecc_band_cols_body(const float *__restrict__ img
             ecc_part_flush(P, T, y0);
         }
     }
-    ecc_tot_store<0>(T, (double)x, on, lds_red, partial, f, bidx);
+    ecc_tot_store<0>(T, (double)x, on, lds_red, out, f, bidx);
 }
 
 // centre of the float products (ecc_part_add): the mean of a 64 x 64 sample grid of the blurred template, rounded to an
@@ -1365,19 +1381,41 @@ __global__ void __launch_bounds__(256) ecc_center_kernel(const float *__restrict
     }
 }
 
-template <bool IDENT, int UR, int WAVES, int NEIGHBOUR = 0, int GXD = 1>
+template <bool ATOMIC>
+__device__ __forceinline__ void ecc_solve_body(EccState &es, const double *__restrict__ partial, int f, int nblocks, int max_iters, double eps,
+                               int rows, int cols, double *Ssh);
+constexpr int kEccTicketStride = 32;     // one ticket per frame on its own 128-byte line
+
+// FUSE: the block that finishes a frame LAST (a ticket per frame) reduces the frame's partial sums and solves the iteration in
+// the same launch -- no ecc_solve_kernel launch between two sums launches (16 us of a dependent chain + a launch gap, 32 times
+// per 1000 frames).  The partials and the ticket move through device-scope atomics only (EccOut).
+template <bool IDENT, int UR, int WAVES, int NEIGHBOUR = 0, int GXD = 1, int FUSE = 0>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
     ecc_cols_kernel(const float *__restrict__ img, const float *__restrict__ tmpl, int rows, int cols,
-                    const EccState *__restrict__ state, double *__restrict__ partial, const float *__restrict__ center)
+                    EccState *__restrict__ state, double *__restrict__ partial, const float *__restrict__ center,
+                    unsigned *__restrict__ tickets, int max_iters, double eps)
 {
     __shared__ double lds_red[kEccChunk][256];     // row table / reduction chunks of whichever body runs
     const int f = blockIdx.x;
     if (state[f].done) return;
     const unsigned nint = gridDim.y - (unsigned)kEccBorderBlocks;
+    EccOut out = {partial, FUSE != 0, 0ull};
     if (blockIdx.y >= (unsigned)kEccBorderBlocks)
-        ecc_cols_body<IDENT, UR, NEIGHBOUR, GXD>(img, tmpl, rows, cols, state, partial, f, blockIdx.y - (unsigned)kEccBorderBlocks, nint, lds_red, *center);
+        ecc_cols_body<IDENT, UR, NEIGHBOUR, GXD>(img, tmpl, rows, cols, state, out, f, blockIdx.y - (unsigned)kEccBorderBlocks, nint, lds_red, *center);
     else
-        ecc_band_cols_body(img, tmpl, rows, cols, state, partial, f, blockIdx.y, IDENT, lds_red);
+        ecc_band_cols_body(img, tmpl, rows, cols, state, out, f, blockIdx.y, IDENT, lds_red);
+    if (FUSE) {
+        // (the exchanges' return values are in out.sink: they have completed before the barrier; the ticket follows it)
+        __shared__ int s_last;
+        const int any = __syncthreads_or((int)(out.sink == 0x7FF8DEADBEEF0001ull));      // (never true: only the dependency matters)
+        if (threadIdx.x == 0) {
+            const unsigned ticket = atomicAdd(&tickets[(size_t)f * kEccTicketStride], 1u + (unsigned)any);
+            s_last = ticket == gridDim.y - 1u;
+            if (s_last) atomicExch(&tickets[(size_t)f * kEccTicketStride], 0u);          // clean for the next launch
+        }
+        __syncthreads();
+        if (s_last) ecc_solve_body<true>(state[f], partial, f, (int)gridDim.y, max_iters, eps, rows, cols, &lds_red[0][0]);
+    }
 }
 
 // ---- Gaussian 5 x 5 pre-blur and the identity iteration of the ECC in ONE pass ----------------------------------------
@@ -1501,7 +1539,8 @@ __device__ __forceinline__ void gauss5_cols_body(const uint16_t *__restrict__ sr
     }
     if (ECC) {
         const unsigned slot = slot0 + blockIdx.y * gridDim.z + blockIdx.z;
-        ecc_tot_store<0>(T, (double)x, own, lds_red, partial, f, slot);
+        EccOut out = {partial, false, 0ull};
+        ecc_tot_store<0>(T, (double)x, own, lds_red, out, f, slot);
     }
 }
 
@@ -1660,7 +1699,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
 // the same order.  Everything is unrolled with compile-time indices (the row exchange of the
 // partial pivoting is a select over the candidate rows), so both matrices live in registers: the
 // one lane that runs this was spending ~25 us per call on dependent scratch / LDS round trips.
-__device__ bool inv6(const float *Ain, float *inv)
+__device__ __forceinline__ bool inv6(const float *Ain, float *inv)
 {
     float A[6][6], b[6][6];
 #pragma unroll
@@ -1723,18 +1762,18 @@ __device__ bool inv6(const float *Ain, float *inv)
 
 // One lane per frame: the body of the cv::findTransformECC iteration after the
 // image passes (ecc.cpp): meanStdDev, rho, hessian inverse, lambda, deltaP, update.
-__global__ void __launch_bounds__(256)
-    ecc_solve_kernel(EccState *__restrict__ state, const double *__restrict__ partial,
-                     int nframes, int nblocks, int max_iters, double eps, int rows, int cols)
+// One iteration's solve for frame f: wave w reduces sums k = w, w+4, ... over the block partials (lane l takes blocks l, l+64,
+// ...; fixed shuffle tree -> deterministic), thread 0 then runs the scalar part.  All 256 threads of the workgroup call it.
+// ATOMIC: the partials were written with device-scope atomics by other workgroups of the SAME launch and are read the same way.
+template <bool ATOMIC>
+__device__ __forceinline__ void ecc_solve_body(EccState &es, const double *__restrict__ partial, int f, int nblocks, int max_iters, double eps,
+                               int rows, int cols, double *Ssh)
 {
-    // one workgroup per frame: wave w reduces sums k = w, w+4, ... over the block partials
-    // (lane l takes blocks l, l+64, ...; fixed shuffle tree -> deterministic), lane 0 of the
-    // workgroup then runs the scalar part
-    const int f = blockIdx.x;
-    if (f >= nframes) return;
-    EccState &es = state[f];
-    if (es.done) return;
-    __shared__ double Ssh[kEccSums];
+    auto ld = [&](const double *p) -> double {
+        if (ATOMIC)
+            return __longlong_as_double((long long)atomicAdd(reinterpret_cast<unsigned long long *>(const_cast<double *>(p)), 0ull));
+        return *p;
+    };
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // every load of the wave's <= 12 sums is issued before the first reduction (one sum after the
     // other made this a chain of 12 global-load latencies: 33 us per launch, 15 % of the ECC path)
@@ -1744,7 +1783,7 @@ __global__ void __launch_bounds__(256)
     for (int i = 0; i < kPerWave; ++i) {
         const int k = wave + 4 * i;
         // first block of 64 partials: one independent load per sum
-        v[i] = (k < kEccSums && lane < nblocks) ? partial[((size_t)f * kEccSums + k) * kEccStride + lane] : 0.0;
+        v[i] = (k < kEccSums && lane < nblocks) ? ld(&partial[((size_t)f * kEccSums + k) * kEccStride + lane]) : 0.0;
     }
     if (nblocks > 64) {   // few active frames -> more, smaller blocks per frame (same order per lane as one loop)
 #pragma unroll
@@ -1752,7 +1791,7 @@ __global__ void __launch_bounds__(256)
             const int k = wave + 4 * i;
             if (k < kEccSums) {
                 const double *pk = partial + ((size_t)f * kEccSums + k) * kEccStride;
-                for (int b = lane + 64; b < nblocks; b += 64) v[i] += pk[b];
+                for (int b = lane + 64; b < nblocks; b += 64) v[i] += ld(&pk[b]);
             }
         }
     }
@@ -1765,8 +1804,7 @@ __global__ void __launch_bounds__(256)
     }
     __syncthreads();
     if (threadIdx.x != 0) return;
-    double S[kEccSums];
-    for (int k = 0; k < kEccSums; ++k) S[k] = Ssh[k];
+    const double *S = Ssh;          // (read from LDS where needed: 90 registers less in the kernels that carry this body)
     const double n = S[0];
     const double mw = n ? S[1] / n : 0, mt = n ? S[3] / n : 0;
     const double vw = n ? S[2] / n - mw * mw : 0, vt = n ? S[4] / n - mt * mt : 0;
@@ -1824,6 +1862,19 @@ __global__ void __launch_bounds__(256)
     es.band = ecc_band(es.M, rows, cols);
     // for (i = 1; i <= N && fabs(rho - last_rho) >= eps; i++)
     if (es.iters >= max_iters || !(fabs(es.rho - es.last_rho) >= eps)) es.done = 1;
+}
+
+__global__ void __launch_bounds__(256)
+    ecc_solve_kernel(EccState *__restrict__ state, const double *__restrict__ partial,
+                     int nframes, int nblocks, int max_iters, double eps, int rows, int cols)
+{
+    // one workgroup per frame
+    const int f = blockIdx.x;
+    if (f >= nframes) return;
+    EccState &es = state[f];
+    if (es.done) return;
+    __shared__ double Ssh[kEccSums];
+    ecc_solve_body<false>(es, partial, f, nblocks, max_iters, eps, rows, cols, Ssh);
 }
 
 __global__ void ecc_init_kernel(EccState *state, int nframes, long long first_frame, double eps)
@@ -2169,6 +2220,7 @@ struct FrameScratch {
     const float *tmpl_src[kMaxCams] = {nullptr};
     float *center = nullptr;                // [kMaxCams] centre of the float products of the ECC sums (ecc_center_kernel)
     unsigned *hot_flag = nullptr;           // [batch] frames in which the pre-blur saw a pixel >= the hot threshold (HotFuse)
+    unsigned *tickets = nullptr;            // [batch][kEccTicketStride] blocks of a frame that have delivered their sums (fused solve); zero between launches
     double *partial = nullptr;
     EccState *state = nullptr;
     int *counter = nullptr;
@@ -2195,6 +2247,7 @@ void frame_scratch_free(FrameScratch *s)
     if (s->ecc_img2) (void)hipFree(s->ecc_img2);
     if (s->center) (void)hipFree(s->center);
     if (s->hot_flag) (void)hipFree(s->hot_flag);
+    if (s->tickets) (void)hipFree(s->tickets);
     if (s->tmp) (void)hipFree(s->tmp);
     if (s->partial) (void)hipFree(s->partial);
     if (s->state) (void)hipFree(s->state);
@@ -2228,6 +2281,10 @@ int frame_scratch_ensure(FrameScratch **ps, int ncams, int batch, int rows, int 
     }
     if (need_warp && !s->ecc_img) UPSP_HIP_CHECK(hipMalloc(&s->ecc_img, n * sizeof(float)));
     if (need_warp && !s->hot_flag) UPSP_HIP_CHECK(hipMalloc(&s->hot_flag, sizeof(unsigned) * (size_t)batch));
+    if (need_warp && !s->tickets) {
+        UPSP_HIP_CHECK(hipMalloc(&s->tickets, sizeof(unsigned) * (size_t)batch * kEccTicketStride));
+        UPSP_HIP_CHECK(hipMemset(s->tickets, 0, sizeof(unsigned) * (size_t)batch * kEccTicketStride));
+    }
     if (need_warp && !s->center) {
         UPSP_HIP_CHECK(hipMalloc(&s->center, kMaxCams * sizeof(float)));
         UPSP_HIP_CHECK(hipMemset(s->center, 0, kMaxCams * sizeof(float)));
@@ -2329,6 +2386,7 @@ static int run_ecc(FrameScratch *s, const float *tmpl_blur, const float *d_cente
             blocks *= 2;
         const int nblocks_total = blocks + kEccBorderBlocks;
         for (int k = 0; k < burst && it < max_iters; ++k, ++it) {
+            bool fused_solve = false;
             {
                 KTimed kt("ecc_sums_kernel", st);
 #define UPSP_ECC_LAUNCH(ID, KPX, WV)                                                                          \
@@ -2336,11 +2394,17 @@ static int run_ecc(FrameScratch *s, const float *tmpl_blur, const float *d_cente
                        blurred, tmpl_blur, rows, cols, (const EccState *)s->state, s->partial)
 #define UPSP_ECC_COLS(ID, URX, WV, ...)                                                                       \
     hipLaunchKernelGGL((ecc_cols_kernel<ID, URX, WV, ##__VA_ARGS__>), dim3(nb, blocks + kEccBorderBlocks), dim3(256), 0, st, \
-                       blurred, tmpl_blur, rows, cols, (const EccState *)s->state, s->partial, d_center)
+                       blurred, tmpl_blur, rows, cols, s->state, s->partial, d_center, s->tickets, max_iters, eps)
                 // Round 3: one column per thread, factored packed-float sums (ecc_cols_kernel); needs one column tile of 256 per
                 // interior block at least.  UPSP_ECC_KERNEL=2 selects round 2's kernel (A/B, and images wider than that).
                 static const int cvariant = env_int_io("UPSP_ECC_CVARIANT", 0);
                 static const int gx_form = env_int_io("UPSP_ECC_GX", 1);
+                // UPSP_ECC_FUSE_SOLVE=1 (opt-in, measured and NOT the default): the solve in the sums launch, by the block that
+                // finishes a frame last.  Same bits (tests/test_imageops_gpu.py), but the sums take 6.13 instead of 5.41 + 0.52 ms
+                // per 1000 frames: the 45 partial sums of every block leave as device-scope atomics, and the launch ends with the
+                // same one-thread chain the solve kernel is -- all 64 frames finish together, so nothing hides it.
+                const int fuse_solve = env_int_io("UPSP_ECC_FUSE_SOLVE", 0);
+                fused_solve = false;
                 const bool use_cols = cols_ok && blocks >= tiles && rows <= (long long)kEccRowTab * (blocks / tiles) &&
                                       rows < 32768 && cols < 32768;
                 // pixels per thread and trip / waves per SIMD of round 2's kernel, measured on 1000 frames of 1024^2
@@ -2359,6 +2423,7 @@ static int run_ecc(FrameScratch *s, const float *tmpl_blur, const float *d_cente
                         if (iv == 1) UPSP_ECC_COLS(true, 8, 4, 1);
                         else if (iv == 2) UPSP_ECC_COLS(true, 4, 4);
                         else if (iv == 3) UPSP_ECC_COLS(true, 8, 3, 1);
+                        else if (fuse_solve) { UPSP_ECC_COLS(true, 4, 4, 1, 1, 1); fused_solve = true; }
                         else UPSP_ECC_COLS(true, 4, 4, 1);
                     } else {
                         // (general iteration, same box: 2 rows per trip at 4 waves per SIMD 316, 4 rows at 3 waves 306, 3 at 3: 313,
@@ -2370,6 +2435,7 @@ static int run_ecc(FrameScratch *s, const float *tmpl_blur, const float *d_cente
                         else if (gv == 3) UPSP_ECC_COLS(false, 3, 3);
                         else if (gv == 5) UPSP_ECC_COLS(false, 2, 4);
                         else if (gx_form == 0) UPSP_ECC_COLS(false, 2, 4, 0, 0);
+                        else if (fuse_solve) { UPSP_ECC_COLS(false, 2, 3, 0, 1, 1); fused_solve = true; }
                         else UPSP_ECC_COLS(false, 2, 3);
                     }
                 }
@@ -2399,9 +2465,11 @@ static int run_ecc(FrameScratch *s, const float *tmpl_blur, const float *d_cente
                     std::fprintf(stderr, "[upsp] ecc sum %2d = %.17Lg\n", k, a);
                 }
             }
-            KTimed kt2("ecc_solve_kernel", st);
-            hipLaunchKernelGGL(ecc_solve_kernel, dim3(nb), dim3(256), 0, st, s->state,
-                               (const double *)s->partial, nb, nblocks_total, max_iters, eps, rows, cols);
+            if (!fused_solve) {
+                KTimed kt2("ecc_solve_kernel", st);
+                hipLaunchKernelGGL(ecc_solve_kernel, dim3(nb), dim3(256), 0, st, s->state,
+                                   (const double *)s->partial, nb, nblocks_total, max_iters, eps, rows, cols);
+            }
         }
         int h[4] = {0, 0, 0, 0};
         hipLaunchKernelGGL(ecc_count_active, dim3(1), dim3(64), 0, st, (const EccState *)s->state, nb,
