@@ -8,13 +8,13 @@ import numpy as np
 import pytest
 
 
-def write_case(tmp, nframes=12, size=(192, 160), registration="none", filt="none"):
+def write_case(tmp, nframes=12, size=(192, 160), registration="none", filt="none", ncams=2):
     from upsp_processing_amd import psp_process as cli, synthetic as syn
     W, H = size
     v, t = syn.tunnel_model_quad(16, 6)
     cli.write_tri_grid(os.path.join(tmp, "model.tri"), v, t, comps=np.ones(len(t), np.int32))
     cams = []
-    for c, az in enumerate((0, 70)):
+    for c, az in enumerate((0, 70)[:ncams]):
         cd = syn.pinhole_camera(W, H, center=(0.2, 0.1, 20), half_extent=6.5, azimuth_deg=az)
         json.dump({"cameraMatrix": cd["K"].tolist(), "distCoeffs": [0.0, 0.0, 0.0, 0.0],
                    "rmat": cd["R"].tolist(), "tvec": cd["t"].tolist(), "imageSize": [W, H]},
@@ -33,7 +33,7 @@ def write_case(tmp, nframes=12, size=(192, 160), registration="none", filt="none
     with open(os.path.join(tmp, "run.inp"), "w") as f:
         f.write("@general\n  test = t1\n  run = 1\n  sequence = 2\n  tunnel = ames_unitary\n"
                 "@vars\n  dir = %s\n@all\n  grid = $dir/model.tri\n" % tmp)
-        for c in (1, 2):
+        for c in (1, 2)[:ncams]:
             f.write("@camera\n  number = %d\n  filename = $dir/cam%02d.mraw\n"
                     "  calibration = $dir/cam%02d.json\n  aedc = false\n" % (c, c, c))
         f.write("@options\n  registration = %s\n  filter = %s\n  filter_size = 3\n"
@@ -218,3 +218,35 @@ def test_cli_two_ranks(gpu_lib, tmp_path):
         a = open(os.path.join(tmp1, "out", name), "rb").read()
         b = open(os.path.join(tmp2, "out", name), "rb").read()
         assert a == b, name
+
+
+@pytest.mark.gpu
+def test_cli_two_ranks_one_camera_pixel_wire(gpu_lib, tmp_path):
+    """One camera, no image stage, `-ranks=2`: the time-series exchange carries the active pixels' u16 series and the owner
+    of a node runs pass B (psp.Phase1.frame_loop_pixel_wire) -- every output file byte-identical to the single-rank run
+    and to a two-rank run with the node rows on the wire (UPSP_ROW_WIRE=1).  140 frames: two exchange chunks per rank of
+    unequal length, hot pixels in both."""
+    import subprocess
+    import sys
+    import torch
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bin", "psp_process")
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "UPSP_ROW_WIRE"):
+        env.pop(k, None)
+    outs = {}
+    for name, ranks, extra in (("one", 0, {}), ("pixels", 2, {}), ("rows", 2, {"UPSP_ROW_WIRE": "1"})):
+        tmp = str(tmp_path / name)
+        os.makedirs(tmp)
+        write_case(tmp, nframes=140, size=(96, 80), ncams=1)
+        e = dict(env, **extra)
+        if ranks and torch.cuda.device_count() < 2:
+            e.update(UPSP_BACKEND="gloo", UPSP_ONE_GPU="1")
+        cmd = [sys.executable, exe, "-input_file=%s/run.inp" % tmp, "-h5_out=x"] + (["-ranks=%d" % ranks] if ranks else [])
+        r = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[name] = {n: open(os.path.join(tmp, "out", n), "rb").read()
+                      for n in ("intensity_transpose", "intensity_avg", "intensity_rms", "coverage", "intensity_ratio_0", "cam01-uv")}
+    for n, a in outs["one"].items():
+        assert a == outs["pixels"][n], ("pixel wire", n)
+        assert a == outs["rows"][n], ("row wire", n)
+    assert len(outs["one"]["intensity_transpose"]) > 140 * 4 * 100

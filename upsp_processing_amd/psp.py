@@ -141,6 +141,43 @@ class Phase1:
         self.frames_done += frames[0].shape[0]
         return rows
 
+    # -- N > 1: which form of the series travels (psp_process.cpp:707-771) ----------------
+    def pixel_wire(self, shard):
+        """True when the time-series exchange can carry the ACTIVE PIXELS' u16 series instead of f32 node rows: one
+        camera, no weights, no float image stage, no overlap map -- every series value is then the integer value of a
+        pixel, a third (and less) of the bytes on the links, and the owner of a node runs pass B.
+        UPSP_ROW_WIRE=1 forces the node rows."""
+        return (shard.world > 1 and self.ncams == 1 and self.weight is None and not self.registration
+                and self._patches is None and not self.pipe.opts.filter and self.overlap_src is None
+                and not os.environ.get("UPSP_ROW_WIRE"))
+
+    def frame_loop_pixel_wire(self, shard, read_chunk, chunk=256, progress=None):
+        """This rank's frame loop with the pixel series on the wire: pass A per chunk (hot-pixel repair included), the
+        chunk's series sent while the next chunk is read and scanned, pass B over all frames on the owner of the nodes.
+        read_chunk(c0, n) -> list with the camera's u16 [n, H, W] device tensor of this rank's frames c0 .. c0 + n.
+        Returns this rank's [nodes_r, F] f32 slice; the accumulators hold this rank's share of the sums (finalize()
+        all-reduces them as always)."""
+        nf_max = max(shard.frame_count)
+        K = max(1, -(-nf_max // chunk))                                # the same on every rank
+        ex = D.TimeSeriesExchange(shard, K)
+        tab = self.pipe.pixel_series(None)                             # the active-pixel map alone
+        ex.set_pixels(tab["node_k"], self.skipped)
+        for k in range(K):
+            c0, fc = ex.my_chunk(k)
+            if fc:
+                batch = read_chunk(c0, fc)
+                ex.submit_pixels(self.pipe.pixel_series(batch[0].contiguous()))
+                self.frames_done += fc
+            else:
+                ex.submit_pixels(tab)                                  # (a rank with fewer chunks still takes part)
+            if progress:
+                progress(c0)
+        s, ss = self.pipe.accumulators()
+        series = ex.finish_pixels(s, ss)
+        torch.cuda.current_stream().synchronize()
+        ex.close()
+        return series
+
     # -- reductions + finals (psp_process.cpp:1866-1979) -----------------------------
     def finalize(self, nframes_total):
         s, ss = self.pipe.accumulators()
@@ -237,6 +274,20 @@ def run_phase1(job, frames_per_cam, nframes_total=None, out_dir=None, chunk=256)
     f0, nf = shard.my_frames
     job.set_first_frames([torch.as_tensor(np.asarray(fr[0])) if not isinstance(fr, torch.Tensor) else fr[0]
                           for fr in frames_per_cam])
+    def to_dev(c0, n):
+        batch = []
+        for fr in frames_per_cam:
+            b = fr[f0 + c0:f0 + c0 + n]
+            if not isinstance(b, torch.Tensor):
+                b = torch.as_tensor(np.ascontiguousarray(b))
+            batch.append(b.to("cuda").contiguous())
+        return batch
+    if job.pixel_wire(shard):
+        series = job.frame_loop_pixel_wire(shard, to_dev, chunk)
+        finals = job.finalize(F)
+        if out_dir:
+            job.write_outputs(out_dir, finals, series, node_start=shard.my_nodes[0])
+        return finals, series
     rows_t = torch.empty((job.nnodes, engine.series_ld(max(nf, 1))), dtype=torch.float32,
                          device="cuda")[:, :max(nf, 1)]
     for c0 in range(0, nf, chunk):

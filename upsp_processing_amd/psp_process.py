@@ -279,8 +279,15 @@ def run(flags):
     feeds = [video.FrameFeed(min(chunk, max(nf, 1)) * r.frame_bytes, 3) if getattr(r, "raw_bit_depth", 12) == 12
              else None for r in readers]
     begin("phase 1: frame loop (read, register, patch, project, accumulate)")
+    series = None
     try:
-        for c0 in range(0, nf, chunk):
+        if job.pixel_wire(shard):
+            # N > 1, one camera, no float stage: the active pixels' series travel chunk by chunk while the next chunk is
+            # read, the owner of a node writes its rows (psp.Phase1.frame_loop_pixel_wire)
+            series = job.frame_loop_pixel_wire(
+                shard, lambda c0, n: [r.read_frames_device(f0 + c0 + 1, n, feed=fd) for r, fd in zip(readers, feeds)], chunk,
+                progress=lambda c0: print("  Rank 0:: processing frame %d" % (f0 + c0)) if shard.rank == 0 and c0 % (chunk * 4) == 0 else None)
+        for c0 in range(0, nf if series is None else 0, chunk):
             n = min(chunk, nf - c0)
             batch = [r.read_frames_device(f0 + c0 + 1, n, feed=fd) for r, fd in zip(readers, feeds)]     # 1-based frames
             job.process(batch, first_frame=f0 + c0, rows_t=rows_t, col0=c0)
@@ -295,7 +302,8 @@ def run(flags):
     end()
     begin("phase 1: reductions + time-series exchange (MPI_Reduce, global_transpose)")
     finals = job.finalize(nframes)
-    series = D.exchange_time_series(rows_t[:, :nf], shard)
+    if series is None:
+        series = D.exchange_time_series(rows_t[:, :nf], shard)
     end()
     begin("phase 1: output files")
     out_dir = flags.get("add_out_dir") or deck["output"].get("dir") or "."
