@@ -85,8 +85,11 @@ def parse():
                          "as many active pixels, so the compact pixel series (2 KB per active pixel and 1000 frames) "
                          "no longer fit the Infinity Cache")
     ap.add_argument("--overlap", action="store_true",
-                    help="pass A of the frame loop (hot-pixel count + compact pixel series, from the candidate pixels of "
-                         "the in-frame nodes) on a second stream while the rays of the projection build are cast")
+                    help="(the default since round 3; accepted for old command lines) pass A of the frame loop (hot-pixel count "
+                         "+ compact pixel series, from the candidate pixels of the in-frame nodes) on a second stream while the "
+                         "rays of the projection build are cast")
+    ap.add_argument("--serial", action="store_true",
+                    help="one stream: projection build, then pass A, then pass B (round 2's default schedule)")
     ap.add_argument("--plain-frames", action="store_true",
                     help="round-1 frame content (no background, fiducial discs or hot pixels)")
     return ap.parse_args()
@@ -750,7 +753,10 @@ def main():
     ev_log = []
     first_step = [True]
 
-    overlap = a.overlap and streamed and not chunked and F <= 1024
+    # Pass A reads the frames and needs only the CANDIDATE pixels (known after step 1 of create_projection_mat), the ray casting
+    # is a latency-bound chain of dependent fetches: side by side they take 0.59-0.63 ms where one after the other they take
+    # 0.29 + 0.35-0.39 (tools/gpu_overlap_ab.sh, three alternations in one call: step 1.10-1.13 against 1.16-1.18 ms)
+    overlap = not a.serial and not a.registration and streamed and not chunked and F <= 1024
     side = torch.cuda.Stream() if overlap else None
 
     def step(record):
@@ -952,6 +958,10 @@ def main():
             "algorithmic_bytes_per_launch": per_step_bytes[dom] / calls,
             "avg_launch_ms": dk["avg_launch_ms"], "launches_per_step": calls}
     roof.update(ECC_SYMBOLS.get(dom, {}))
+    if overlap:
+        roof["note"] = ("default schedule: pass A (scan_compact_kernel) runs on a second stream beside the ray casting of the projection "
+                        "build and shares the memory system with it; alone (--serial) it takes 0.35-0.40 ms = 0.66 of peak, and the step "
+                        "4-5 % longer")
 
     sched = ("projection build, then hot-pixel scan + gather kernels per 64-frame sub-batch"
              if (a.two_kernel or a.registration) else
