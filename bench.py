@@ -757,21 +757,34 @@ def main():
     # is a latency-bound chain of dependent fetches: side by side they take 0.59-0.63 ms where one after the other they take
     # 0.29 + 0.35-0.39 (tools/gpu_overlap_ab.sh, three alternations in one call: step 1.10-1.13 against 1.16-1.18 ms)
     overlap = not a.serial and not a.registration and streamed and not chunked and F <= 1024
-    side = torch.cuda.Stream() if overlap else None
+    # The BUILD goes to the side stream, issued first and with high priority; pass A follows on the main stream: the traversal
+    # kernels are chains of dependent fetches that need few wave slots but need them early, pass A fills whatever is left
+    # (tools/gpu_prio_ab.sh, step in ms: pass A on the side stream 1.151 / 1.172, the build on the side stream 1.124, the build
+    # on a high-priority side stream 1.107 / 1.131, pass A on a high-priority side stream 1.208).  UPSP_BENCH_BUILD_ON_SIDE=0 /
+    # UPSP_BENCH_SIDE_PRIORITY=0: the other arrangements.
+    swap = overlap and os.environ.get("UPSP_BENCH_BUILD_ON_SIDE", "1") == "1"
+    side = torch.cuda.Stream(priority=int(os.environ.get("UPSP_BENCH_SIDE_PRIORITY", "-1" if swap else "0"))) if overlap else None
 
     def step(record):
         e = [ev() for _ in range(4)]
         restore_hot()
         e[0].record()
         main = torch.cuda.current_stream()
-        if overlap:
+        if swap:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                proj = engine.build_projection(bvh, cam, d_nodes, d_nrm, d_tn, 70.0, counts=False)
+            pipe.set_active_hint(engine.candidate_pixels(cam, d_nodes))
+            pipe.prescan(frames)
+        elif overlap:
             # which pixels the frame loop will read is known once the nodes are projected into the image
             # (step 1 of create_projection_mat); pass A does not need the visibility verdicts
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 pipe.set_active_hint(engine.candidate_pixels(cam, d_nodes))
                 pipe.prescan(frames)
-        proj = engine.build_projection(bvh, cam, d_nodes, d_nrm, d_tn, 70.0, counts=False)   # no host sync
+        if not swap:
+            proj = engine.build_projection(bvh, cam, d_nodes, d_nrm, d_tn, 70.0, counts=False)   # no host sync
         e[1].record()
         pipe.reset()
         pipe.set_projection(0, proj["pix"])
@@ -972,14 +985,14 @@ def main():
             "avg_launch_ms": dk["avg_launch_ms"], "launches_per_step": calls}
     roof.update(ECC_SYMBOLS.get(dom, {}))
     if overlap:
-        roof["note"] = ("default schedule: pass A (scan_compact_kernel) runs on a second stream beside the ray casting of the projection "
-                        "build and shares the memory system with it; alone (--serial) it takes 0.35-0.40 ms = 0.66 of peak, and the step "
-                        "4-5 % longer")
+        roof["note"] = ("default schedule: pass A (scan_compact_kernel) runs beside the ray casting of the projection build (which has a "
+                        "high-priority stream of its own) and shares the memory system with it; alone (--serial) it takes 0.35-0.40 ms = "
+                        "0.66 of peak, and the step 5-8 % longer")
 
     sched = ("projection build, then hot-pixel scan + gather kernels per 64-frame sub-batch"
              if (a.two_kernel or a.registration) else
-             "pass A (scan + compact pixel series of the candidate pixels) on a second stream beside the ray casting of the "
-             "projection build, then pass B (whole rows)" if overlap else
+             "the ray casting of the projection build on a high-priority stream of its own, pass A (scan + compact pixel series of the "
+             "candidate pixels) beside it, then pass B (whole rows)" if overlap else
              "projection build, then pass A (scan + compact pixel series) and pass B (whole rows) per <= 1024 frames")
     out = {
         "metric": "frames/s", "value": fps, "unit": "frames/s", "n_gpus": world,
