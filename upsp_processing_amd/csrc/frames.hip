@@ -1242,6 +1242,9 @@ __global__ void __launch_bounds__(256)
         s_k[r][c] = ok ? a.node_k[c][n] : -1;
         s_w[r][c] = (ok && a.weight[c]) ? a.weight[c][n] : 1.0f;
     }
+    // the node's accumulators are read HERE, with the staging loads, not after the rows: their read-modify-write was a third
+    // dependent memory latency at the end of every workgroup
+    double acc_s = 0.0, acc_ss = 0.0;
     if (t < NR) {
         const unsigned n = n0 + (unsigned)t;
         const bool ok = n < nnodes;
@@ -1249,6 +1252,10 @@ __global__ void __launch_bounds__(256)
         for (int c = 0; c < ncams; ++c) any = any || (ok && a.node_k[c][n] >= 0);
         s_kind[t] = (ok && skipped && skipped[n]) ? 1 : (any ? 0 : 2);
         s_row[t] = ok ? (rowmap ? rowmap[n] : (int)n) : -1;
+        if (ok) {
+            acc_s = sum[n];
+            acc_ss = sumsq[n];
+        }
     }
     __syncthreads();
     const int sub = t / LPR, l = t % LPR, wr = l >> 6, lane = t & 63;
@@ -1371,8 +1378,8 @@ __global__ void __launch_bounds__(256)
                     as += (p_s[t][4 * q] + p_s[t][4 * q + 1]) + (p_s[t][4 * q + 2] + p_s[t][4 * q + 3]);
                     ass += (p_ss[t][4 * q] + p_ss[t][4 * q + 1]) + (p_ss[t][4 * q + 2] + p_ss[t][4 * q + 3]);
                 }
-                sum[n] += as;
-                sumsq[n] += ass;
+                sum[n] = acc_s + as;
+                sumsq[n] = acc_ss + ass;
             }
         }
     }
