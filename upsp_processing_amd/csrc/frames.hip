@@ -1931,7 +1931,7 @@ int launch_node_rows_multi(const PipelineGather &g, const int32_t *const *d_node
     // dependent memory latencies of its staging and its series loads.  UPSP_MULTI_FPL=4: the four-frame form.
     static const int fpl_env = std::getenv("UPSP_MULTI_FPL") ? std::atoi(std::getenv("UPSP_MULTI_FPL")) : 8;
     const bool fpl8 = fpl_env == 8 && g.ncams >= 2 && g.ncams <= 4;
-    if (g.nframes > 512 && fpl8) { if (rows_env == 2) UPSP_NRM8_NC(128, 1); else if (rows_env == 8) UPSP_NRM8_NC(128, 4); else UPSP_NRM8_NC(128, 2); }
+    if (g.nframes > 512 && fpl8) { if (rows_env == 2) UPSP_NRM8_NC(128, 1); else if (rows_env == 8) UPSP_NRM8_NC(128, 4); else if (rows_env == 6) UPSP_NRM8_NC(128, 3); else if (rows_env == 10) UPSP_NRM8_NC(128, 5); else UPSP_NRM8_NC(128, 2); }
     else if (g.nframes > 512) { if (rows_env == 8) UPSP_NRM_NC(256, 8); else if (rows_env == 2) UPSP_NRM_NC(256, 2); else UPSP_NRM_NC(256, 4); }
     else if (g.nframes > 256) UPSP_NRM_NC(128, 4);
     else UPSP_NRM_NC(64, 4);
