@@ -563,11 +563,9 @@ __device__ __forceinline__ void ecc_block_store(const double (&acc)[kEccSums], d
 }
 
 struct EccMargins { int top, bottom, left, right; };
-__device__ int g_ecc_band_extra = 0;     // debug (UPSP_ECC_BAND_EXTRA): widen the band, i.e. move pixels from the interior loops to the band's
 __device__ __forceinline__ EccMargins ecc_margins(int band, int rows, int cols)
 {
     EccMargins g;
-    band += g_ecc_band_extra;
     g.top = min(band, rows / 2);
     g.bottom = min(band, rows - g.top);
     g.left = min(band, cols / 2);
@@ -2346,12 +2344,6 @@ static int run_ecc(FrameScratch *s, const float *tmpl_blur, const float *d_cente
                      : launch_gauss<uint16_t>(frames, s->ecc_img, s->tmp, nb, rows, cols, 5, st);
         if (rc != UPSP_OK) return rc;
     }
-    static const int band_extra = [] {
-        const int e = env_int_io("UPSP_ECC_BAND_EXTRA", 0);
-        if (e > 0) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ecc_band_extra), &e, sizeof(e));
-        return e;
-    }();
-    (void)band_extra;
     bool first_burst = true;
     int active = nb;  // frames still iterating (known to the host after every burst)
     int iters_done = 0, most_iters = 0;
