@@ -1573,17 +1573,19 @@ __global__ void __launch_bounds__(256)
 template <int U>
 __global__ void __launch_bounds__(256)
     gauss5_quad_kernel(const uint16_t *__restrict__ src, float *__restrict__ dst, int rows, int cols, int rpp, float k0, float k1,
-                       float k2, unsigned thresh, unsigned *__restrict__ flag, int only_flagged)
+                       float k2, unsigned thresh, unsigned *__restrict__ flag, int only_flagged, int frame_slowest)
 {
     // flag (may be null): per-frame words.  only_flagged = 0: set flag[f] when a pixel of the frame is >= thresh (the scan of
     // fix_hot_pixels, cv_extras.cpp:237-247, done on the pixels the blur loads anyway); 1: blur only the frames whose
     // flag is set (their second blur, after the repair)
-    const int f = blockIdx.x;
+    // (frame_slowest: grid (column groups, row pieces, frames) instead of (frames, row pieces, column groups) -- measurement switch)
+    const int f = frame_slowest ? blockIdx.z : blockIdx.x;
+    const int bz = frame_slowest ? blockIdx.x : blockIdx.z;
     if (only_flagged && !flag[f]) return;
     const bool detect = flag && !only_flagged;
     unsigned hot = 0u;
     const int lane = threadIdx.x & 63;
-    const int xw = ((int)blockIdx.z * 4 + (int)(threadIdx.x >> 6)) * 256;    // first column of this wave
+    const int xw = (bz * 4 + (int)(threadIdx.x >> 6)) * 256;    // first column of this wave
     if (xw >= cols) return;                                                    // (uniform per wave)
     const int x0 = xw + 4 * lane;
     const bool valid = x0 < cols;                                              // all four pixels or none (cols % 4 == 0)
@@ -1668,9 +1670,11 @@ bool launch_gauss5_quad(const uint16_t *src, float *dst, int nimg, int rows, int
     //  piece; 8 rows in flight at 16 / 32 / 48 / 128 rows per piece 1.32 / 1.36 / 1.39 / 1.52; the tile kernel 2.13)
     const int pieces = (rows + rpp - 1) / rpp, zb = (cols + 1023) / 1024;
     if (pieces > 65535 || zb > 65535) return false;
+    // frames slowest in the grid: 1.27 against 1.35 ms of pre-blur per 1000 frames, and the identity iteration behind it 1-2 % faster
+    const int fs = env_int_io("UPSP_GAUSS5_QUAD_ORDER", 1);
 #define UPSP_GQ(UU)                                                                                                 \
-    hipLaunchKernelGGL((gauss5_quad_kernel<UU>), dim3((unsigned)nimg, (unsigned)pieces, (unsigned)zb), dim3(256), 0, st, src, dst, rows, \
-                       cols, rpp, fc.k[2], fc.k[3], fc.k[4], thresh, flag, only_flagged)
+    hipLaunchKernelGGL((gauss5_quad_kernel<UU>), fs ? dim3((unsigned)zb, (unsigned)pieces, (unsigned)nimg) : dim3((unsigned)nimg, (unsigned)pieces, (unsigned)zb), dim3(256), 0, st, src, dst, rows, \
+                       cols, rpp, fc.k[2], fc.k[3], fc.k[4], thresh, flag, only_flagged, fs)
     if (uvar == 2) UPSP_GQ(2); else if (uvar == 4) UPSP_GQ(4); else if (uvar == 6) UPSP_GQ(6); else UPSP_GQ(8);
 #undef UPSP_GQ
     return true;
