@@ -136,7 +136,7 @@ def _rank_main(rank, world, port, tmp):
     dist.destroy_process_group()
 
 
-def test_config3_shape_sharded_frames_two_ranks(gpu_lib, tmp_path):
+def test_config3_shape_sharded_frames_two_ranks(gpu_lib, oracle, tmp_path):
     import socket
     import torch
     import torch.multiprocessing as mp
@@ -166,3 +166,21 @@ def test_config3_shape_sharded_frames_two_ranks(gpu_lib, tmp_path):
         assert np.array_equal(d["series"].view(np.int32), full[n0:n0 + nn].view(np.int32))
         assert np.array_equal(d["avg"].view(np.int32), avg.cpu().numpy().view(np.int32))
         assert np.array_equal(d["rms"].view(np.int32), rms.cpu().numpy().view(np.int32))
+    # ... and the ORACLE loop on the same frames (fix_hot_pixels -> project_frame -> NaN rows -> double accumulators,
+    # psp_process.cpp:1771-1843): what the two ranks deliver after the exchange is the reference's series, bit for bit
+    sk = oracle.skipped_nodes(pix[None])
+    want = np.empty((F, N), np.float32)
+    s_o, ss_o = np.zeros(N), np.zeros(N)
+    for f in range(F):
+        img, _ = oracle.fix_hot_pixels(frames[f])
+        sol = oracle.project_frame(img, pix, None)
+        sol[sk] = np.nan
+        oracle.accumulate(sol, s_o, ss_o)
+        want[f] = sol
+    got = np.concatenate([np.load(str(tmp_path / ("rank%d.npz" % r)))["series"] for r in range(2)])
+    assert np.array_equal(got.view(np.int32), want.T.view(np.int32))
+    a_o, r_o = (s_o / F).astype(np.float32), np.sqrt(ss_o / F).astype(np.float32)
+    ok = ~sk
+    assert np.isnan(avg.cpu().numpy()[sk]).all()
+    assert np.array_equal(avg.cpu().numpy()[ok].view(np.int32), a_o[ok].view(np.int32))
+    assert np.allclose(rms.cpu().numpy()[ok], r_o[ok], rtol=1e-6, atol=0)
