@@ -88,6 +88,8 @@ def parse():
                     help="(the default since round 3; accepted for old command lines) pass A of the frame loop (hot-pixel count "
                          "+ compact pixel series, from the candidate pixels of the in-frame nodes) on a second stream while the "
                          "rays of the projection build are cast")
+    ap.add_argument("--chunks", type=int, default=4,
+                    help="N > 1 loop: chunks the rank's frames are exchanged in (the exchange of chunk k runs while chunk k + 1 is scanned)")
     ap.add_argument("--serial", action="store_true",
                     help="one stream: projection build, then pass A, then pass B (round 2's default schedule)")
     ap.add_argument("--plain-frames", action="store_true",
@@ -742,7 +744,7 @@ def main():
 
     # N > 1: the frame loop runs in K chunks and the all-to-all of chunk k is issued
     # asynchronously while chunk k+1 is being processed (distributed.TimeSeriesExchange)
-    K = 4 if chunked else 1
+    K = max(1, a.chunks) if chunked else 1
     exch = D.TimeSeriesExchange(shard, K, wire12=a.wire12) if chunked else None
     # one camera, no weights, no filter: the series values are exact 16-bit integers, so the
     # travelling rows are produced and sent as u16 (half the bytes) and widened by the receiver
