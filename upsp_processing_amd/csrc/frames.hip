@@ -1217,7 +1217,12 @@ __global__ void __launch_bounds__(256)
 // is used (round 2 walked sweep by sweep, camera by camera: ROWS x cameras dependent load -> convert -> add chains per
 // lane); (2) a row no camera sees (NaN in every frame) or that reads no pixel (0) is a constant fill -- no loads, no
 // sums, no reductions, like in node_rows_kernel; (3) NC = the camera count at compile time (2 .. 4; 0 = any).
-template <int LPR, int ROWS, int NC, int FPL = 4>
+// PIPE: persistent workgroups -- a workgroup takes the node groups blockIdx.x, blockIdx.x + gridDim.x, ... and fetches the staging
+// data (series indices, weights, row, accumulators) of its NEXT group into registers before it starts on the rows of the current
+// one (two staging areas in LDS): of the two dependent memory latencies per group, staging and series loads, the first is hidden.
+// Measured and NOT the default (UPSP_MULTI_PIPE=n workgroups per CU): the loop-carried staging registers take the kernel from 96 to
+// 130 VGPRs (3 instead of 5 waves per SIMD): 3.14-3.23 ms against 2.68-2.74; held to 96 registers it spills 33 of them: 4.0 ms.
+template <int LPR, int ROWS, int NC, int FPL = 4, int PIPE = 0>
 __global__ void __launch_bounds__(256)
     node_rows_multi_kernel(StreamMultiArgs a, unsigned cpitch, const uint8_t *__restrict__ skipped,
                            const int32_t *__restrict__ rowmap, unsigned nnodes, int nframes,
@@ -1226,38 +1231,72 @@ __global__ void __launch_bounds__(256)
 {
     constexpr int RPS = 256 / LPR, WPR = LPR / 64, NR = RPS * ROWS;
     constexpr int MC = NC ? NC : kMaxCams;
-    __shared__ int s_k[NR][MC];
-    __shared__ float s_w[NR][MC];
-    __shared__ int s_row[NR], s_kind[NR];       // kind: 0 data, 1 no camera sees the node (NaN), 2 reads no pixel (0)
+    constexpr int NB = PIPE ? 2 : 1;
+    __shared__ int sb_k[NB][NR][MC];
+    __shared__ float sb_w[NB][NR][MC];
+    __shared__ int sb_row[NB][NR], sb_kind[NB][NR];       // kind: 0 data, 1 no camera sees the node (NaN), 2 reads no pixel (0)
     // per row and wave four partial sums (one per 16-lane DPP row): the last two reduction steps are done by the thread that
     // owns the node's accumulators, from LDS, instead of 16 v_readlane per wave and row
     __shared__ double p_s[NR][WPR * 4], p_ss[NR][WPR * 4];
     const int ncams = NC ? NC : a.ncams;
-    const unsigned n0 = blockIdx.x * (unsigned)NR;
     const int t = threadIdx.x;
-    for (int e = t; e < NR * ncams; e += 256) {
-        const int r = e / ncams, c = e % ncams;
-        const unsigned n = n0 + (unsigned)r;
-        const bool ok = n < nnodes;
-        s_k[r][c] = ok ? a.node_k[c][n] : -1;
-        s_w[r][c] = (ok && a.weight[c]) ? a.weight[c][n] : 1.0f;
-    }
-    // the node's accumulators are read HERE, with the staging loads, not after the rows: their read-modify-write was a third
-    // dependent memory latency at the end of every workgroup
-    double acc_s = 0.0, acc_ss = 0.0;
-    if (t < NR) {
-        const unsigned n = n0 + (unsigned)t;
-        const bool ok = n < nnodes;
-        bool any = false;
-        for (int c = 0; c < ncams; ++c) any = any || (ok && a.node_k[c][n] >= 0);
-        s_kind[t] = (ok && skipped && skipped[n]) ? 1 : (any ? 0 : 2);
-        s_row[t] = ok ? (rowmap ? rowmap[n] : (int)n) : -1;
-        if (ok) {
-            acc_s = sum[n];
-            acc_ss = sumsq[n];
+    static_assert(NR * MC <= 256, "one staging element per thread");
+    const unsigned ngroups = (nnodes + (unsigned)NR - 1u) / (unsigned)NR;
+    // staging of one node group: global loads into registers (stage_load), registers into LDS area b (stage_store)
+    struct Stage { int k; float w; int kind, row; double s, ss; };
+    auto stage_load = [&](unsigned g) {
+        Stage st;
+        st.k = -1; st.w = 1.0f; st.kind = 2; st.row = -1; st.s = 0.0; st.ss = 0.0;
+        const unsigned nb0 = g * (unsigned)NR;
+        if (t < NR * ncams) {
+            const int r = t / ncams, c = t % ncams;
+            const unsigned n = nb0 + (unsigned)r;
+            if (n < nnodes) {
+                st.k = a.node_k[c][n];
+                st.w = a.weight[c] ? a.weight[c][n] : 1.0f;
+            }
         }
-    }
+        if (t < NR) {
+            // the node's accumulators are read HERE, with the staging loads, not after the rows: their read-modify-write was a
+            // third dependent memory latency at the end of every group
+            const unsigned n = nb0 + (unsigned)t;
+            const bool ok = n < nnodes;
+            bool any = false;
+            for (int c = 0; c < ncams; ++c) any = any || (ok && a.node_k[c][n] >= 0);
+            st.kind = (ok && skipped && skipped[n]) ? 1 : (any ? 0 : 2);
+            st.row = ok ? (rowmap ? rowmap[n] : (int)n) : -1;
+            if (ok) {
+                st.s = sum[n];
+                st.ss = sumsq[n];
+            }
+        }
+        return st;
+    };
+    auto stage_store = [&](const Stage &st, int b) {
+        if (t < NR * ncams) {
+            sb_k[b][t / ncams][t % ncams] = st.k;
+            sb_w[b][t / ncams][t % ncams] = st.w;
+        }
+        if (t < NR) {
+            sb_kind[b][t] = st.kind;
+            sb_row[b][t] = st.row;
+        }
+    };
+    unsigned g = blockIdx.x;
+    if (g >= ngroups) return;
+    int buf = 0;
+    Stage cur = stage_load(g);
+    stage_store(cur, 0);
     __syncthreads();
+    for (;;) {
+    const unsigned gn = PIPE ? g + gridDim.x : ngroups;
+    Stage nxt = cur;
+    if (PIPE && gn < ngroups) nxt = stage_load(gn);             // in flight while the rows of group g are written
+    const unsigned n0 = g * (unsigned)NR;
+    const double acc_s = cur.s, acc_ss = cur.ss;
+    int (*s_k)[MC] = sb_k[buf];
+    float (*s_w)[MC] = sb_w[buf];
+    int *s_row = sb_row[buf], *s_kind = sb_kind[buf];
     const int sub = t / LPR, l = t % LPR, wr = l >> 6, lane = t & 63;
     // FPL frames per lane: 4, or 8 = two groups of 4 that lie 4 * LPR frames apart (every load / store instruction of a wave
     // still covers one contiguous piece of the row; 8 consecutive frames per lane made the stores half-empty: 4.1 ms against
@@ -1382,6 +1421,13 @@ __global__ void __launch_bounds__(256)
                 sumsq[n] = acc_ss + ass;
             }
         }
+    }
+    if (!PIPE || gn >= ngroups) break;
+    stage_store(nxt, buf ^ 1);        // (area buf ^ 1 was last read two barriers ago)
+    __syncthreads();                  // also: p_s / p_ss are free again
+    g = gn;
+    buf ^= 1;
+    cur = nxt;
     }
 }
 
@@ -1913,6 +1959,9 @@ int launch_node_rows_multi(const PipelineGather &g, const int32_t *const *d_node
         else if (g.ncams == 3) UPSP_NRM(LPR, ROWS, 3, 8);                                                     \
         else UPSP_NRM(LPR, ROWS, 4, 8);                                                                       \
     } while (0)
+#define UPSP_NRMP(NC)                                                                                         \
+    hipLaunchKernelGGL((node_rows_multi_kernel<128, 4, NC, 8, 1>), dim3(std::min((nn + 7u) / 8u, pipe_wgs)), dim3(256), 0, st, a, cpitch, \
+                       g.skipped, g.rowmap, nn, g.nframes, g.rows_t, (long long)g.ld_t, g.sum, g.sumsq)
 #define UPSP_NRM_NC(LPR, ROWS)                                                                                \
     do {                                                                                                      \
         if (g.ncams == 2) UPSP_NRM(LPR, ROWS, 2);                                                             \
@@ -1931,10 +1980,17 @@ int launch_node_rows_multi(const PipelineGather &g, const int32_t *const *d_node
     // dependent memory latencies of its staging and its series loads.  UPSP_MULTI_FPL=4: the four-frame form.
     static const int fpl_env = std::getenv("UPSP_MULTI_FPL") ? std::atoi(std::getenv("UPSP_MULTI_FPL")) : 8;
     const bool fpl8 = fpl_env == 8 && g.ncams >= 2 && g.ncams <= 4;
-    if (g.nframes > 512 && fpl8) { if (rows_env == 2) UPSP_NRM8_NC(128, 1); else if (rows_env == 8) UPSP_NRM8_NC(128, 4); else if (rows_env == 6) UPSP_NRM8_NC(128, 3); else if (rows_env == 10) UPSP_NRM8_NC(128, 5); else UPSP_NRM8_NC(128, 2); }
+    // UPSP_MULTI_PIPE=n: n persistent workgroups per CU with the next group's staging prefetched (0: one workgroup per group)
+    static const int pipe_env = std::getenv("UPSP_MULTI_PIPE") ? std::atoi(std::getenv("UPSP_MULTI_PIPE")) : 0;
+    const unsigned pipe_wgs = 256u * (unsigned)std::max(pipe_env, 1);
+    if (g.nframes > 512 && fpl8 && pipe_env > 0 && rows_env == 8) {
+        if (g.ncams == 2) UPSP_NRMP(2); else if (g.ncams == 3) UPSP_NRMP(3); else UPSP_NRMP(4);
+    }
+    else if (g.nframes > 512 && fpl8) { if (rows_env == 2) UPSP_NRM8_NC(128, 1); else if (rows_env == 8) UPSP_NRM8_NC(128, 4); else if (rows_env == 6) UPSP_NRM8_NC(128, 3); else if (rows_env == 10) UPSP_NRM8_NC(128, 5); else UPSP_NRM8_NC(128, 2); }
     else if (g.nframes > 512) { if (rows_env == 8) UPSP_NRM_NC(256, 8); else if (rows_env == 2) UPSP_NRM_NC(256, 2); else UPSP_NRM_NC(256, 4); }
     else if (g.nframes > 256) UPSP_NRM_NC(128, 4);
     else UPSP_NRM_NC(64, 4);
+#undef UPSP_NRMP
 #undef UPSP_NRM8_NC
 #undef UPSP_NRM_NC
 #undef UPSP_NRM
