@@ -1222,7 +1222,7 @@ __global__ void __launch_bounds__(256)
 // one (two staging areas in LDS): of the two dependent memory latencies per group, staging and series loads, the first is hidden.
 // Measured and NOT the default (UPSP_MULTI_PIPE=n workgroups per CU): the loop-carried staging registers take the kernel from 96 to
 // 130 VGPRs (3 instead of 5 waves per SIMD): 3.14-3.23 ms against 2.68-2.74; held to 96 registers it spills 33 of them: 4.0 ms.
-template <int LPR, int ROWS, int NC, int FPL = 4, int PIPE = 0>
+template <int LPR, int ROWS, int NC, int FPL = 4, int PIPE = 0, int AHEAD = ROWS>
 __global__ void __launch_bounds__(256)
     node_rows_multi_kernel(StreamMultiArgs a, unsigned cpitch, const uint8_t *__restrict__ skipped,
                            const int32_t *__restrict__ rowmap, unsigned nnodes, int nframes,
@@ -1307,10 +1307,9 @@ __global__ void __launch_bounds__(256)
     const float qnan = __builtin_nanf("");
     const bool vec_ok = ((ld_t & 3) == 0) && ((reinterpret_cast<size_t>(rows_t) & 15) == 0);
     typedef float v4f __attribute__((ext_vector_type(4)));
-    // every load of the workgroup's rows first ...
+    // the series loads run AHEAD sweeps in front of the rows that use them (AHEAD = ROWS: every load of the workgroup first)
     uint2 tt[ROWS][MC][FPL / 4];
-#pragma unroll
-    for (int j = 0; j < ROWS; ++j) {
+    auto series_load = [&](int j) {
         const int r = j * RPS + sub;                            // (uniform per wave)
         const bool data = s_kind[r] == 0 && f0 < nframes;
 #pragma unroll
@@ -1326,10 +1325,13 @@ __global__ void __launch_bounds__(256)
                 }
             }
         }
-    }
+    };
+#pragma unroll
+    for (int j = 0; j < AHEAD && j < ROWS; ++j) series_load(j);
     // ... then the rows
 #pragma unroll
     for (int j = 0; j < ROWS; ++j) {
+        if (j + AHEAD < ROWS) series_load(j + AHEAD);
         const int r = j * RPS + sub;
         const int row = s_row[r], kind = s_kind[r];
         const bool stored = row >= 0 && f0 < nframes && n0 + (unsigned)r < nnodes;
@@ -1955,10 +1957,13 @@ int launch_node_rows_multi(const PipelineGather &g, const int32_t *const *d_node
                        g.sum, g.sumsq)
 #define UPSP_NRM8_NC(LPR, ROWS)                                                                               \
     do {                                                                                                      \
-        if (g.ncams == 2) UPSP_NRM(LPR, ROWS, 2, 8);                                                          \
-        else if (g.ncams == 3) UPSP_NRM(LPR, ROWS, 3, 8);                                                     \
-        else UPSP_NRM(LPR, ROWS, 4, 8);                                                                       \
+        if (g.ncams == 2) UPSP_NRM(LPR, ROWS, 2, 8, 0, 1);                                                    \
+        else if (g.ncams == 3) UPSP_NRM(LPR, ROWS, 3, 8, 0, 1);                                               \
+        else UPSP_NRM(LPR, ROWS, 4, 8, 0, 1);                                                                 \
     } while (0)
+#define UPSP_NRMA(NC, AH)                                                                                     \
+    hipLaunchKernelGGL((node_rows_multi_kernel<128, 4, NC, 8, 0, AH>), dim3((nn + 7u) / 8u), dim3(256), 0, st, a, cpitch, \
+                       g.skipped, g.rowmap, nn, g.nframes, g.rows_t, (long long)g.ld_t, g.sum, g.sumsq)
 #define UPSP_NRMP(NC)                                                                                         \
     hipLaunchKernelGGL((node_rows_multi_kernel<128, 4, NC, 8, 1>), dim3(std::min((nn + 7u) / 8u, pipe_wgs)), dim3(256), 0, st, a, cpitch, \
                        g.skipped, g.rowmap, nn, g.nframes, g.rows_t, (long long)g.ld_t, g.sum, g.sumsq)
@@ -1983,13 +1988,20 @@ int launch_node_rows_multi(const PipelineGather &g, const int32_t *const *d_node
     // UPSP_MULTI_PIPE=n: n persistent workgroups per CU with the next group's staging prefetched (0: one workgroup per group)
     static const int pipe_env = std::getenv("UPSP_MULTI_PIPE") ? std::atoi(std::getenv("UPSP_MULTI_PIPE")) : 0;
     const unsigned pipe_wgs = 256u * (unsigned)std::max(pipe_env, 1);
-    if (g.nframes > 512 && fpl8 && pipe_env > 0 && rows_env == 8) {
+    // series loads ONE sweep in front of the rows that use them (72 VGPRs, 7 waves per SIMD) instead of all four sweeps first (96, 5
+    // waves): 2.71 against 2.86 ms on one box; two sweeps in front 2.97.  UPSP_MULTI_AHEAD=n (4 cameras): n = 2, 3, 4 for comparison
+    static const int ahead_env = std::getenv("UPSP_MULTI_AHEAD") ? std::atoi(std::getenv("UPSP_MULTI_AHEAD")) : 0;
+    if (g.nframes > 512 && fpl8 && ahead_env > 1 && rows_env == 8 && g.ncams == 4) {
+        if (ahead_env == 2) UPSP_NRMA(4, 2); else if (ahead_env == 3) UPSP_NRMA(4, 3); else UPSP_NRMA(4, 4);
+    }
+    else if (g.nframes > 512 && fpl8 && pipe_env > 0 && rows_env == 8) {
         if (g.ncams == 2) UPSP_NRMP(2); else if (g.ncams == 3) UPSP_NRMP(3); else UPSP_NRMP(4);
     }
     else if (g.nframes > 512 && fpl8) { if (rows_env == 2) UPSP_NRM8_NC(128, 1); else if (rows_env == 8) UPSP_NRM8_NC(128, 4); else if (rows_env == 6) UPSP_NRM8_NC(128, 3); else if (rows_env == 10) UPSP_NRM8_NC(128, 5); else UPSP_NRM8_NC(128, 2); }
     else if (g.nframes > 512) { if (rows_env == 8) UPSP_NRM_NC(256, 8); else if (rows_env == 2) UPSP_NRM_NC(256, 2); else UPSP_NRM_NC(256, 4); }
     else if (g.nframes > 256) UPSP_NRM_NC(128, 4);
     else UPSP_NRM_NC(64, 4);
+#undef UPSP_NRMA
 #undef UPSP_NRMP
 #undef UPSP_NRM8_NC
 #undef UPSP_NRM_NC
