@@ -2430,6 +2430,8 @@ static int run_ecc(FrameScratch *s, const float *tmpl_blur, const float *d_cente
                         if (gv == 1) UPSP_ECC_COLS(false, 4, 3);
                         else if (gv == 3) UPSP_ECC_COLS(false, 3, 3);
                         else if (gv == 5) UPSP_ECC_COLS(false, 2, 4);
+                        else if (gv == 6) UPSP_ECC_COLS(false, 1, 4);
+                        else if (gv == 7) UPSP_ECC_COLS(false, 1, 5);
                         else if (gx_form == 0) UPSP_ECC_COLS(false, 2, 4, 0, 0);
                         else if (fuse_solve) { UPSP_ECC_COLS(false, 2, 3, 0, 1, 1); fused_solve = true; }
                         else UPSP_ECC_COLS(false, 2, 3);
