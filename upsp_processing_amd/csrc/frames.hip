@@ -1997,7 +1997,7 @@ int launch_node_rows_multi(const PipelineGather &g, const int32_t *const *d_node
     else if (g.nframes > 512 && fpl8 && pipe_env > 0 && rows_env == 8) {
         if (g.ncams == 2) UPSP_NRMP(2); else if (g.ncams == 3) UPSP_NRMP(3); else UPSP_NRMP(4);
     }
-    else if (g.nframes > 512 && fpl8) { if (rows_env == 2) UPSP_NRM8_NC(128, 1); else if (rows_env == 8) UPSP_NRM8_NC(128, 4); else if (rows_env == 6) UPSP_NRM8_NC(128, 3); else if (rows_env == 10) UPSP_NRM8_NC(128, 5); else UPSP_NRM8_NC(128, 2); }
+    else if (g.nframes > 512 && fpl8) { if (rows_env == 2) UPSP_NRM8_NC(128, 1); else if (rows_env == 8) UPSP_NRM8_NC(128, 4); else if (rows_env == 6) UPSP_NRM8_NC(128, 3); else if (rows_env == 10) UPSP_NRM8_NC(128, 5); else if (rows_env == 16) UPSP_NRM8_NC(128, 8); else UPSP_NRM8_NC(128, 2); }
     else if (g.nframes > 512 && ahead_env == 1 && g.ncams == 4) UPSP_NRM(256, 8, 4, 4, 0, 1);      // (measurement: four frames per lane, one sweep ahead)
     else if (g.nframes > 512) { if (rows_env == 8) UPSP_NRM_NC(256, 8); else if (rows_env == 2) UPSP_NRM_NC(256, 2); else UPSP_NRM_NC(256, 4); }
     else if (g.nframes > 256) UPSP_NRM_NC(128, 4);
