@@ -366,13 +366,16 @@ def test_registration_sub_batches_pipelined(gpu_lib, oracle, monkeypatch):
     pix[::13] = -1
     ok = pix >= 0
     out = {}
-    for mode in ("1", "0", "scan in the blur", "solve in the sums launch"):
+    for mode in ("1", "0", "scan in the blur", "solve in the sums launch", "no look-ahead"):
         # third schedule: fix_hot_pixels folded into the pre-blur (UPSP_HOT_IN_BLUR=1: the blur flags the frames that hold a hot
         # pixel, only those are scanned, repaired and blurred again)
         monkeypatch.setenv("UPSP_REG_PIPELINE", mode if mode in "01" else "0")
         monkeypatch.setenv("UPSP_HOT_IN_BLUR", "1" if mode == "scan in the blur" else "0")
         # fourth: the iteration's solve done by the last block of the sums launch (UPSP_ECC_FUSE_SOLVE=1, device-scope atomics)
         monkeypatch.setenv("UPSP_ECC_FUSE_SOLVE", "1" if mode == "solve in the sums launch" else "0")
+        # "0" is the default schedule: one stream, the next sub-batch's repair + pre-blur enqueued while the host reads "frames
+        # still iterating" back (UPSP_REG_AHEAD=1); fifth: without that look-ahead
+        monkeypatch.setenv("UPSP_REG_AHEAD", "0" if mode == "no look-ahead" else "1")
         pipe = engine.FramePipeline(1, W, H, n, registration=1)
         pipe.set_projection(0, pix)
         pipe.set_reference(0, ref)
@@ -386,7 +389,7 @@ def test_registration_sub_batches_pipelined(gpu_lib, oracle, monkeypatch):
         torch.cuda.synchronize()
         out[mode] = (rt.cpu().numpy(), w.cpu().numpy(), it.cpu().numpy(), [a.cpu().numpy() for a in pipe.accumulators()], d.cpu().numpy())
     b = out["0"]
-    for other in ("1", "scan in the blur", "solve in the sums launch"):
+    for other in ("1", "scan in the blur", "solve in the sums launch", "no look-ahead"):
         a = out[other]
         assert np.array_equal(a[0].view(np.int32), b[0].view(np.int32)) and np.array_equal(a[1].view(np.int32), b[1].view(np.int32)), other
         assert np.array_equal(a[2], b[2]) and np.array_equal(a[4], b[4]), other

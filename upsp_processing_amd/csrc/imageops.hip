@@ -17,6 +17,7 @@
 // sums are reduced deterministically (fixed block partials, fixed order) and a
 // one-lane-per-frame kernel does the 6x6 float LU solve exactly like cv::Mat::inv.
 #include <hip/hip_runtime.h>
+#include <functional>
 
 #include <algorithm>
 #include <cfloat>
@@ -2222,6 +2223,8 @@ struct FrameScratch {
     const float *tmpl_src[kMaxCams] = {nullptr};
     float *center = nullptr;                // [kMaxCams] centre of the float products of the ECC sums (ecc_center_kernel)
     unsigned *hot_flag = nullptr;           // [batch] frames in which the pre-blur saw a pixel >= the hot threshold (HotFuse)
+    int *h_counter = nullptr;               // pinned: where "frames still iterating" is read back to
+    hipEvent_t ev_counter = nullptr;        // ... and the event behind that copy
     unsigned *tickets = nullptr;            // [batch][kEccTicketStride] blocks of a frame that have delivered their sums (fused solve); zero between launches
     double *partial = nullptr;
     EccState *state = nullptr;
@@ -2250,6 +2253,8 @@ void frame_scratch_free(FrameScratch *s)
     if (s->center) (void)hipFree(s->center);
     if (s->hot_flag) (void)hipFree(s->hot_flag);
     if (s->tickets) (void)hipFree(s->tickets);
+    if (s->h_counter) (void)hipHostFree(s->h_counter);
+    if (s->ev_counter) (void)hipEventDestroy(s->ev_counter);
     if (s->tmp) (void)hipFree(s->tmp);
     if (s->partial) (void)hipFree(s->partial);
     if (s->state) (void)hipFree(s->state);
@@ -2283,6 +2288,10 @@ int frame_scratch_ensure(FrameScratch **ps, int ncams, int batch, int rows, int 
     }
     if (need_warp && !s->ecc_img) UPSP_HIP_CHECK(hipMalloc(&s->ecc_img, n * sizeof(float)));
     if (need_warp && !s->hot_flag) UPSP_HIP_CHECK(hipMalloc(&s->hot_flag, sizeof(unsigned) * (size_t)batch));
+    if (need_warp && !s->h_counter) {
+        UPSP_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&s->h_counter), 4 * sizeof(int), hipHostMallocDefault));
+        UPSP_HIP_CHECK(hipEventCreateWithFlags(&s->ev_counter, hipEventDisableTiming));
+    }
     if (need_warp && !s->tickets) {
         UPSP_HIP_CHECK(hipMalloc(&s->tickets, sizeof(unsigned) * (size_t)batch * kEccTicketStride));
         UPSP_HIP_CHECK(hipMemset(s->tickets, 0, sizeof(unsigned) * (size_t)batch * kEccTicketStride));
@@ -2302,7 +2311,8 @@ int frame_scratch_ensure(FrameScratch **ps, int ncams, int batch, int rows, int 
 // ECC registration of nb frames against the blurred template; leaves the warp in state[].
 static int run_ecc(FrameScratch *s, const float *tmpl_blur, const float *d_center, const uint16_t *frames, int nb,
                    int64_t first_frame, int rows, int cols, int max_iters, double eps, hipStream_t st,
-                   const float *preblurred = nullptr, const HotFuse *hot = nullptr, uint16_t *frames_rw = nullptr)
+                   const float *preblurred = nullptr, const HotFuse *hot = nullptr, uint16_t *frames_rw = nullptr,
+                   const std::function<int()> *while_waiting = nullptr)
 {
     if ((long long)rows * cols >= (1ll << 31)) return fail(UPSP_ERR_INVALID, "registration: image too large");
     // Pre-blur (GaussianBlur 5 x 5) and the first iteration.  Every frame starts from the identity warp
@@ -2348,7 +2358,7 @@ static int run_ecc(FrameScratch *s, const float *tmpl_blur, const float *d_cente
                      : launch_gauss<uint16_t>(frames, s->ecc_img, s->tmp, nb, rows, cols, 5, st);
         if (rc != UPSP_OK) return rc;
     }
-    bool first_burst = true;
+    bool first_burst = true, waited = false;
     int active = nb;  // frames still iterating (known to the host after every burst)
     int iters_done = 0, most_iters = 0;
     for (;;) {
@@ -2472,8 +2482,17 @@ static int run_ecc(FrameScratch *s, const float *tmpl_blur, const float *d_cente
         int h[4] = {0, 0, 0, 0};
         hipLaunchKernelGGL(ecc_count_active, dim3(1), dim3(64), 0, st, (const EccState *)s->state, nb,
                            s->counter);
-        UPSP_HIP_CHECK(hipMemcpyAsync(h, s->counter, sizeof(h), hipMemcpyDeviceToHost, st));
-        UPSP_HIP_CHECK(hipStreamSynchronize(st));
+        // the read-back goes to pinned memory behind an event: whatever `while_waiting` enqueues (the next sub-batch's
+        // hot-pixel repair and pre-blur) runs on the GPU while the host waits for these four words
+        UPSP_HIP_CHECK(hipMemcpyAsync(s->h_counter, s->counter, sizeof(h), hipMemcpyDeviceToHost, st));
+        UPSP_HIP_CHECK(hipEventRecord(s->ev_counter, st));
+        if (while_waiting && !waited) {
+            waited = true;
+            const int rcw = (*while_waiting)();
+            if (rcw != UPSP_OK) return rcw;
+        }
+        UPSP_HIP_CHECK(hipEventSynchronize(s->ev_counter));
+        for (int i = 0; i < 4; ++i) h[i] = s->h_counter[i];
         if (h[1] > 0)
             return fail(UPSP_ERR_DIVERGED,
                         "ECC registration did not converge (cv::findTransformECC would throw)");
@@ -2598,7 +2617,7 @@ int run_frame_stages(FrameScratch *s, int cam, const uint16_t *d_frames, int nb,
                      int rows, int cols, const upsp_pipeline_opts &opts, const float *d_ref,
                      const PatchTables *patches, float *d_warps, int32_t *d_iters, int ncams,
                      const unsigned *d_read_list, const WarpCompact *wc, const void **img_out, int *is_f32_out,
-                     hipStream_t st, const float *preblurred, const HotFuse *hot)
+                     hipStream_t st, const float *preblurred, const HotFuse *hot, const std::function<int()> *while_waiting)
 {
     const size_t npix = (size_t)rows * cols;
     const uint16_t *cur = d_frames;
@@ -2611,7 +2630,7 @@ int run_frame_stages(FrameScratch *s, int cam, const uint16_t *d_frames, int nb,
             s->tmpl_src[cam] = d_ref;
         }
         int rc = run_ecc(s, s->tmpl[cam], s->center + cam, d_frames, nb, first_frame, rows, cols, opts.ecc_max_iters,
-                         opts.ecc_eps, st, preblurred, hot, const_cast<uint16_t *>(d_frames));
+                         opts.ecc_eps, st, preblurred, hot, const_cast<uint16_t *>(d_frames), while_waiting);
         if (rc != UPSP_OK) return rc;
         if (wc) {      // registration is the last image stage and node-major series are wanted: straight into the compact buffer
             KTimed kt("warp_u16_kernel", st);

@@ -3,6 +3,7 @@
 #ifndef UPSP_PIPELINE_H
 #define UPSP_PIPELINE_H
 
+#include <functional>
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
@@ -113,7 +114,8 @@ int run_frame_stages(FrameScratch *s, int cam, const uint16_t *d_frames, int nb,
                      int64_t first_frame, int rows, int cols, const upsp_pipeline_opts &opts,
                      const float *d_ref, const PatchTables *patches, float *d_warps, int32_t *d_iters, int ncams,
                      const unsigned *d_read_list, const WarpCompact *wc, const void **img_out, int *is_f32_out,
-                     hipStream_t st, const float *preblurred = nullptr, const HotFuse *hot = nullptr);
+                     hipStream_t st, const float *preblurred = nullptr, const HotFuse *hot = nullptr,
+                     const std::function<int()> *while_waiting = nullptr);
 // true when run_frame_stages can take the hot-pixel repair into its pre-blur for frames of this geometry (HotFuse)
 bool frame_stages_fuse_hot(const uint16_t *d_frames, int rows, int cols, const upsp_pipeline_opts &opts);
 // the ECC's 5 x 5 pre-blur of nb frames into blurred-frame buffer `slot` (0 / 1) of the scratch, on any stream

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <vector>
 
 #include "pipeline.h"
@@ -841,6 +842,22 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
             if (r == UPSP_OK) UPSP_HIP_CHECK(hipEventRecord(p->ev_blur[slot], p->pre));
             return r;
         };
+        // Default: the SAME stream, but sub-batch k + 1's repair and pre-blur are enqueued while the host waits for sub-batch k's
+        // "frames still iterating" (two blurred-frame buffers): the GPU has work during the read-back and nothing runs beside
+        // anything.  UPSP_REG_AHEAD=0: blur inside the sub-batch's own stage call.
+        const bool ahead1 = !pipelined && nframes > B && p->height > 2 && p->width > 2 && !std::getenv("UPSP_ECC_FUSED") &&
+                            !(std::getenv("UPSP_REG_AHEAD") && std::atoi(std::getenv("UPSP_REG_AHEAD")) == 0) &&
+                            !(p->opts.hot_enable && upsp::frame_stages_fuse_hot(fr, p->height, p->width, p->opts));
+        std::vector<char> blur_done(subs.size(), 0);
+        auto ahead_same_stream = [&](size_t i) -> int {            // repair + pre-blur of sub-batch i on the caller's stream
+            if (blur_done[i]) return UPSP_OK;
+            blur_done[i] = 1;
+            uint16_t *frames = fr + (size_t)subs[i].f0 * npix;
+            int r = repair(frames, subs[i].nb, st);
+            if (r == UPSP_OK) r = upsp::frame_scratch_preblur(p->scratch, (int)(i & 1), frames, subs[i].nb, p->height, p->width, st, &blurred[i & 1]);
+            return r;
+        };
+        if (ahead1) rc = ahead_same_stream(0);
         if (pipelined) {
             UPSP_HIP_CHECK(hipEventRecord(p->ev_pre_in, st));      // the frames are ready where the caller's stream is now
             UPSP_HIP_CHECK(hipStreamWaitEvent(p->pre, p->ev_pre_in, 0));
@@ -852,11 +869,21 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
             const float *pre = nullptr;
             upsp::HotFuse fuse;
             const upsp::HotFuse *hotp = nullptr;
+            std::function<int()> next_blur;
+            const std::function<int()> *while_waiting = nullptr;
             if (pipelined) {
                 if (i + 1 < subs.size()) rc = ahead(i + 1);
                 if (rc != UPSP_OK) break;
                 UPSP_HIP_CHECK(hipStreamWaitEvent(st, p->ev_blur[i & 1], 0));
                 pre = blurred[i & 1];
+            } else if (ahead1) {
+                rc = ahead_same_stream(i);                  // (already done while sub-batch i - 1 waited, normally)
+                if (rc != UPSP_OK) break;
+                pre = blurred[i & 1];
+                if (i + 1 < subs.size()) {
+                    next_blur = [&, i]() { return ahead_same_stream(i + 1); };
+                    while_waiting = &next_blur;
+                }
             } else if (p->opts.hot_enable && upsp::frame_stages_fuse_hot(frames, p->height, p->width, p->opts)) {
                 // the repair rides on the pre-blur (upsp::HotFuse): no scan launch of its own
                 rc = ensure_hot(p, nb);
@@ -876,7 +903,7 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
             int is_f32 = 0;
             rc = upsp::run_frame_stages(p->scratch, 0, frames, nb, first_frame + f0, p->height, p->width, p->opts, p->d_ref[0],
                                         nullptr, d_warps ? d_warps + (size_t)f0 * 6 : nullptr,
-                                        p->d_ecc_iters ? p->d_ecc_iters + f0 : nullptr, 1, nullptr, &wc, &img, &is_f32, st, pre, hotp);
+                                        p->d_ecc_iters ? p->d_ecc_iters + f0 : nullptr, 1, nullptr, &wc, &img, &is_f32, st, pre, hotp, while_waiting);
             if (pipelined && rc == UPSP_OK) UPSP_HIP_CHECK(hipEventRecord(p->ev_used[i & 1], st));
             const bool last_of_group = i + 1 == subs.size() || subs[i + 1].s0 != s0;
             if (rc == UPSP_OK && last_of_group) {
