@@ -63,7 +63,25 @@ def lib_comm(group=None):
             dist.broadcast(t, src=0, group=group)
         ident = (C.c_uint8 * 128)(*t.cpu().tolist())
         h = C.c_void_p()
-        _capi.check(_capi.lib().upsp_comm_create(ident, rank, world, C.byref(h)))
+        err = None
+        try:
+            _capi.check(_capi.lib().upsp_comm_create(ident, rank, world, C.byref(h)))
+        except _capi.UpspError as e:            # e.g. no librccl the library can resolve in this process
+            err = e
+        if world > 1:
+            # every rank or none: a communicator that came up on some ranks only would hang the first exchange
+            flag = torch.tensor([0 if err else 1], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            if int(flag.item()) == 0:
+                if err is None:
+                    _capi.lib().upsp_comm_destroy(h)
+                import sys
+                print("upsp: the library's RCCL communicator could not be created on every rank (%s); the exchanges of this "
+                      "group go through torch.distributed's RCCL instead" % (err or "another rank failed"), file=sys.stderr)
+                _LIB_COMM[key] = None
+                return None
+        elif err is not None:
+            raise err
         _LIB_COMM[key] = h
     return _LIB_COMM[key]
 
@@ -94,7 +112,8 @@ def shutdown():
         from . import _capi
         torch.cuda.synchronize()
         for h in _LIB_COMM.values():
-            _capi.lib().upsp_comm_destroy(h)
+            if h is not None:
+                _capi.lib().upsp_comm_destroy(h)
         _LIB_COMM.clear()
     if dist.is_initialized():
         dist.destroy_process_group()
