@@ -836,7 +836,7 @@ __device__ __forceinline__ double readlane_f64(double x)
     const int hi = __builtin_amdgcn_readlane((int)(b >> 32), L);
     return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
 }
-template <int LPR, int ROWS, bool U16>
+template <int LPR, int ROWS, bool U16, int AHEAD = 1>
 __global__ void __launch_bounds__(256)
     node_rows_kernel(const uint16_t *__restrict__ compact, unsigned cpitch, const int32_t *__restrict__ node_k,
                      const uint8_t *__restrict__ skipped, const int32_t *__restrict__ rowmap, unsigned nnodes,
@@ -865,11 +865,24 @@ __global__ void __launch_bounds__(256)
     const float qnan = __builtin_nanf("");
     const bool vec_ok = U16 ? (((ld_t & 3) == 0) && ((reinterpret_cast<size_t>(rows_t16) & 7) == 0))
                             : (((ld_t & 3) == 0) && ((reinterpret_cast<size_t>(rows_t) & 15) == 0));
+    // the series load of sweep j + 1 is issued before the rows of sweep j are converted and stored (measurement switch
+    // kRowsAhead: 0 = load at the point of use, round 2's form)
+    auto series_load = [&](int j) -> uint2 {
+        const int r = j * RPS + sub;
+        const int k = s_k[r];
+        uint2 w = make_uint2(0u, 0u);
+        // (ordinary loads: the compact buffer was written a moment ago and sits in L2 / Infinity Cache)
+        if (s_sk[r] == 0 && k >= 0 && f0 < nframes) w = *reinterpret_cast<const uint2 *>(compact + (size_t)k * cpitch + f0);
+        return w;
+    };
+    uint2 w_next = AHEAD ? series_load(0) : make_uint2(0u, 0u);
 #pragma unroll
     for (int j = 0; j < ROWS; ++j) {
         const int r = j * RPS + sub;                            // (uniform per wave)
         const int k = s_k[r], row = s_row[r];
         const bool sk = s_sk[r] != 0;
+        uint2 w = AHEAD ? w_next : series_load(j);
+        if (AHEAD && j + 1 < ROWS) w_next = series_load(j + 1);
         if (sk || k == -1) {
             // (uniform per wave) a row without data -- no camera sees the node: NaN; no pixel: 0 -- is a constant fill:
             // no load, no sums, no reductions (its partials are not read below).  These are 60 % of the rows of the bench
@@ -905,9 +918,6 @@ __global__ void __launch_bounds__(256)
             }
             continue;
         }
-        uint2 w = make_uint2(0u, 0u);
-        // (ordinary loads: the compact buffer was written a moment ago and sits in L2 / Infinity Cache)
-        if (k >= 0 && f0 < nframes) w = *reinterpret_cast<const uint2 *>(compact + (size_t)k * cpitch + f0);
         if (k == -2 && f0 < nframes) {                          // (rare) pixel outside the candidate map: from the frames
             const size_t pp = (size_t)pix[n0 + (unsigned)r];
             unsigned v[4];
@@ -1890,10 +1900,17 @@ int launch_node_rows(const PipelineGather &g, const int32_t *d_node_k, const uin
     static const int rows_env = std::getenv("UPSP_ROWS_PER_WG") ? std::atoi(std::getenv("UPSP_ROWS_PER_WG")) : 4;
     const unsigned nn = (unsigned)g.nnodes;
     KTimed kt("node_rows_kernel", st);
-#define UPSP_NR(LPR, ROWS, U16)                                                                              \
-    hipLaunchKernelGGL((node_rows_kernel<LPR, ROWS, U16>), dim3((nn + (256 / LPR) * ROWS - 1) / ((256 / LPR) * ROWS)), \
+    // UPSP_ROWS_AHEAD=1 (measurement switch): series loads one sweep ahead of the rows that use them, the arrangement that pays in
+    // the multi-camera kernel -- here 0.403-0.413 ms either way (tools/gpu_rows_ab.sh): this kernel waits for its stores
+    static const int ahead_env = std::getenv("UPSP_ROWS_AHEAD") ? std::atoi(std::getenv("UPSP_ROWS_AHEAD")) : 0;
+#define UPSP_NR1(LPR, ROWS, U16, AH)                                                                         \
+    hipLaunchKernelGGL((node_rows_kernel<LPR, ROWS, U16, AH>), dim3((nn + (256 / LPR) * ROWS - 1) / ((256 / LPR) * ROWS)), \
                        dim3(256), 0, st, d_compact, cpitch, d_node_k, g.skipped, g.rowmap, nn, g.nframes, g.rows_t,  \
                        g.rows_t16, (long long)g.ld_t, g.sum, g.sumsq, (const uint16_t *)g.img[0], g.npix, g.pix[0])
+#define UPSP_NR(LPR, ROWS, U16)                                                                              \
+    do {                                                                                                     \
+        if (ahead_env) UPSP_NR1(LPR, ROWS, U16, 1); else UPSP_NR1(LPR, ROWS, U16, 0);                        \
+    } while (0)
 #define UPSP_NR_R(LPR, U16)                                                                                  \
     do {                                                                                                     \
         if (rows_env >= 8) UPSP_NR(LPR, 8, U16); else if (rows_env >= 4) UPSP_NR(LPR, 4, U16);              \
@@ -1907,6 +1924,7 @@ int launch_node_rows(const PipelineGather &g, const int32_t *d_node_k, const uin
 #undef UPSP_NR_L
 #undef UPSP_NR_R
 #undef UPSP_NR
+#undef UPSP_NR1
     UPSP_HIP_CHECK(hipGetLastError());
     return UPSP_OK;
 }
