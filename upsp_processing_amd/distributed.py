@@ -607,9 +607,10 @@ def _pixel_rows(self):
     return c[-1], c[self.shard.rank + 1] - c[self.shard.rank]
 
 
-def _submit_pixels(self, compact, cpitch=None):
+def _submit_pixels(self, compact, cpitch=None, col0=0):
     """compact: the sender's [active pixel][>= chunk frames] u16 series of its chunk number len(submitted) -- the dict
-    FramePipeline.pixel_series returns (C-ABI exchange), or a tensor (torch.distributed path)."""
+    FramePipeline.pixel_series returns (C-ABI exchange), or a tensor (torch.distributed path).  col0: column of the chunk's
+    first frame in that buffer (a buffer that holds ALL frames of the rank: pass A ran once for the whole call)."""
     sh, k = self.shard, self.k
     if k >= self.K:
         raise RuntimeError("TimeSeriesExchange.submit_pixels: all %d chunks were already submitted (finish_pixels() first)" % self.K)
@@ -618,7 +619,7 @@ def _submit_pixels(self, compact, cpitch=None):
         import ctypes as C
         from . import _capi
         ptr, cp = (compact["ptr"], compact["cpitch"]) if isinstance(compact, dict) else (compact.data_ptr(), compact.stride(0))
-        _capi.check(_capi.lib().upsp_exchange_submit_pixels(self._x, C.c_void_p(ptr), cp, 12 if self.wire12 else 2, self._stream()))
+        _capi.check(_capi.lib().upsp_exchange_submit_pixels(self._x, C.c_void_p(ptr + 2 * int(col0)), cp, 12 if self.wire12 else 2, self._stream()))
         self.k += 1
         return
     px = self._px
@@ -627,7 +628,7 @@ def _submit_pixels(self, compact, cpitch=None):
         compact = torch.as_tensor(_DevArray(compact["ptr"], compact["rows"] * compact["cpitch"], "<i2", compact["owner"]),
                                   device="cuda").view(compact["rows"], compact["cpitch"])
     comp = compact.view(torch.int16) if compact.dtype == torch.uint16 else compact
-    send = comp.index_select(0, px["send_k"])[:, :fc].contiguous()                # [sum |L_d|][fc], by destination
+    send = comp.index_select(0, px["send_k"])[:, int(col0):int(col0) + fc].contiguous()   # [sum |L_d|][fc], by destination
     self.k += 1
     cut, r = px["cut"], sh.rank
     rows_in = cut[r + 1] - cut[r]
