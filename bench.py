@@ -9,8 +9,8 @@ ray cast + projection only):
   + frame loop        (hot-pixel repair -> nearest-pixel projection -> double
                        accumulators -> node-major time series) over every frame
   + finals            (avg / rms)
-  + for N > 1: the end-of-run exchanges (all_reduce of the accumulators and the
-    all_to_all time-series exchange over RCCL/xGMI)
+  + for N > 1: the end-of-run exchanges (all-reduce of the accumulators and the
+    time-series exchange, grouped point-to-point sends over RCCL/xGMI: upsp_exchange_* of libupsp_gpu.so)
 
 with mesh, BVH, camera and all frames already resident in HBM.  Frames shard over
 ranks (weak scaling: every GPU processes --frames frames).
@@ -27,6 +27,12 @@ pixel of the frame (1 Mpix onto the 1 M-triangle model), every ray traversed, a 
 `pixel_rays_fill` is the same on a 1 M-triangle sphere that fills the frame (every ray enters the tree), both with the
 rays that ENTER the root box counted apart and the traversal bytes per ray (nodes visited x 64 B + triangles tested x
 48 B) from the statistics counters.
+
+Schedule of the default (one GPU, plain loop): the ray casting of the projection build runs on a high-priority stream of its own,
+pass A of the frame loop (which needs only the candidate pixels of the in-frame nodes) beside it, then pass B and the repair;
+`--serial` = one stream, stage after stage.  N > 1 (`--gpus N`, or `--force-chunked` on one GPU): the rank's frames go through
+pass A in `--chunks` chunks, the active pixels' u16 series travel (`--row-wire`: packed node rows; `--wire12`: packed to 12 bits)
+through the library's exchange over RCCL while the next chunk is scanned, the owner of a node runs pass B.
 
 `configs2` (default run) / `--registration`: BASELINE configs[2], per-frame ECC registration in front of the projection,
 with its own roofline (ecc_sums_kernel), iterations per frame, CPU baseline (`register_pixel` included) and parity block
