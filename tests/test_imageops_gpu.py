@@ -404,3 +404,43 @@ def test_registration_sub_batches_pipelined(gpu_lib, oracle, monkeypatch):
         assert a[2][f, 0] == it_o and np.abs(M_g[:, :2] - M_o[:, :2]).max() <= 1e-4 and np.abs(M_g[:, 2] - M_o[:, 2]).max() <= 2e-3
         want = oracle.project_frame(oracle.warp_affine(img, M_g, 1), pix, None)
         assert np.array_equal(a[0][ok, f].view(np.int32), want[ok].view(np.int32))
+
+
+def test_ecc_shared_rows_same_bits(gpu_lib, monkeypatch):
+    """The general ECC iteration re-uses the first row's source rows for the second row of a trip wherever the second
+    footprint is the first one moved down by a row in every lane of a wave (UPSP_ECC_SHARE_ROWS, default on).  Same values,
+    fewer loads: warps, iteration counts and series bit-identical to the separate loads -- on frames with sub-pixel
+    jitter (every wave takes the shared path), with rotation and scale (waves that straddle a source-row or -column step
+    take the other), odd image sizes and a second call."""
+    import torch
+    from upsp_processing_amd import engine, synthetic as syn
+    rng = np.random.default_rng(31)
+    for (H, W, F, lin) in ((203, 301, 24, 0.0), (256, 512, 20, 4e-3), (130, 1028, 12, 1.5e-2)):
+        base = syn.synth_frames_numpy(1, H, W, seed=H, noise=0.0)[0].astype(np.float64)
+        yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+        frames = np.empty((F, H, W), np.uint16)
+        frames[0] = base
+        from scipy.ndimage import map_coordinates
+        for f in range(1, F):
+            a = rng.uniform(-lin, lin, 4)
+            sh = rng.uniform(-2.5, 2.5, 2)
+            ys = a[2] * xx + (1 + a[3]) * yy + sh[1]
+            xs = (1 + a[0]) * xx + a[1] * yy + sh[0]
+            frames[f] = np.clip(np.rint(map_coordinates(base, [ys, xs], order=1, mode="nearest") + rng.normal(0, 3, (H, W))), 0, 4095)
+        n = 2000
+        pix = (rng.integers(8, H - 8, n) * W + rng.integers(8, W - 8, n)).astype(np.int32)
+        out = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("UPSP_ECC_SHARE_ROWS", mode)
+            pipe = engine.FramePipeline(1, W, H, n, registration=1)
+            pipe.set_projection(0, pix)
+            pipe.set_reference(0, frames[0].astype(np.float32))
+            w = torch.zeros((F, 1, 6), dtype=torch.float32, device="cuda")
+            it = torch.full((F, 1), -1, dtype=torch.int32, device="cuda")
+            rows = pipe.process(torch.as_tensor(frames.copy()).cuda(), 0, warps=w, ecc_iters=it)
+            rows2 = pipe.process(torch.as_tensor(frames[: F // 2].copy()).cuda(), 0)
+            out[mode] = (w.cpu().numpy(), it.cpu().numpy(), rows.cpu().numpy(), rows2.cpu().numpy())
+        a, b = out["1"], out["0"]
+        assert int(a[1].max()) >= 2                      # general iterations did run
+        for x, y in zip(a, b):
+            assert np.array_equal(x.view(np.int32), y.view(np.int32)), (H, W)

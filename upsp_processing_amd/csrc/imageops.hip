@@ -1054,7 +1054,7 @@ __device__ __forceinline__ v2f ld_v2f(const float *base, unsigned byte_off)     
     return *reinterpret_cast<const v2f *>(reinterpret_cast<const char *>(base) + byte_off + IMM);
 }
 
-template <bool IDENT, int UR, int NEIGHBOUR = 0, int GXD = 1>
+template <bool IDENT, int UR, int NEIGHBOUR = 0, int GXD = 1, int SHARE = 0>
 __device__ __forceinline__ void ecc_cols_trip(const float *__restrict__ I, const float *__restrict__ tmpl, int cols, int x,
                                               int y, int r, int ax, int bx, const int2 *rtab, int rt0, const double *M,
                                               EccPart &P, EccTot &T)
@@ -1113,6 +1113,7 @@ __device__ __forceinline__ void ecc_cols_trip(const float *__restrict__ I, const
         // {b_1,b2} {c_1,c2} from two 4-byte loads each
         v2f A[UR], Bm[UR], Cm[UR], D[UR], Be[UR], Ce[UR];
         float tt[UR], fx[UR], fy[UR];
+        int sxk[UR], syk[UR];
         const unsigned pitch = 4u * (unsigned)cols, ot = 4u * (unsigned)(y * cols + x);
 #pragma unroll
         for (int k = 0; k < UR; ++k) {
@@ -1121,20 +1122,42 @@ __device__ __forceinline__ void ecc_cols_trip(const float *__restrict__ I, const
             const int2 rt = rtab[y + k - rt0];
             const int Xr = rt.x + ax, Yr = rt.y + bx;
             const int Xq = (Xr + 16) >> 5, Yq = (Yr + 16) >> 5;
-            const int sx = Xq >> 5, sy = Yq >> 5;        // (footprint inside the image by construction: ecc_band)
+            sxk[k] = Xq >> 5;                            // (footprint inside the image by construction: ecc_band)
+            syk[k] = Yq >> 5;
             fx[k] = (Xq & 31) * (1.f / 32);
             fy[k] = (Yq & 31) * (1.f / 32);
+        }
+        // SHARE (two rows per trip): under a warp near the identity the second pixel's footprint is the first one's moved down
+        // by exactly one row -- rows a, b, c of the second are rows b, c, d of the first.  When that holds for EVERY lane of
+        // the wave (uniform branch), the second pixel loads only what is new: the two outer pixels of its row c and its row d:
+        // 11 instead of 16 source loads per trip, the same values in the same registers' roles, so the same bits.
+        bool shared = false;
+        if (SHARE && UR == 2) shared = __all(sxk[1 % UR] == sxk[0] && syk[1 % UR] == syk[0] + 1) != 0;
+#pragma unroll
+        for (int k = 0; k < UR; ++k) {
             // (rows and columns < 2^15 here: 24-bit multiply, full rate)
-            const unsigned q0 = 4u * (unsigned)(__mul24(sy - 1, cols) + sx), q1 = q0 + pitch, q2 = q1 + pitch, q3 = q2 + pitch;
-            A[k] = ld_v2f(I, q0);
-            Be[k][0] = ld_f32<-4>(I, q1);
-            Bm[k] = ld_v2f(I, q1);
-            Be[k][1] = ld_f32<8>(I, q1);
-            Ce[k][0] = ld_f32<-4>(I, q2);
-            Cm[k] = ld_v2f(I, q2);
-            Ce[k][1] = ld_f32<8>(I, q2);
-            D[k] = ld_v2f(I, q3);
+            const unsigned q0 = 4u * (unsigned)(__mul24(syk[k] - 1, cols) + sxk[k]), q1 = q0 + pitch, q2 = q1 + pitch, q3 = q2 + pitch;
+            if (SHARE && UR == 2 && k == 1 && shared) {
+                Ce[k][0] = ld_f32<-4>(I, q2);
+                Ce[k][1] = ld_f32<8>(I, q2);
+                D[k] = ld_v2f(I, q3);
+            } else {
+                A[k] = ld_v2f(I, q0);
+                Be[k][0] = ld_f32<-4>(I, q1);
+                Bm[k] = ld_v2f(I, q1);
+                Be[k][1] = ld_f32<8>(I, q1);
+                Ce[k][0] = ld_f32<-4>(I, q2);
+                Cm[k] = ld_v2f(I, q2);
+                Ce[k][1] = ld_f32<8>(I, q2);
+                D[k] = ld_v2f(I, q3);
+            }
             tt[k] = ld_f32(tmpl, ot + (unsigned)k * pitch);
+        }
+        if (SHARE && UR == 2 && shared) {
+            A[1 % UR] = Bm[0];
+            Be[1 % UR] = Ce[0];
+            Bm[1 % UR] = Cm[0];
+            Cm[1 % UR] = D[0];
         }
 #pragma unroll
         for (int k = 0; k < UR; ++k) {
@@ -1176,7 +1199,7 @@ __device__ __forceinline__ void ecc_cols_trip(const float *__restrict__ I, const
 // Interior block `blk` of `nblk`: the inner rectangle (farther than the band from every edge) is cut into column tiles
 // of 256 and, per tile, into nblk / tiles row pieces; blocks beyond that store zeros.  Needs nblk >= tiles (the host
 // checks: cols <= 256 x interior blocks, else the round-2 kernel runs).
-template <bool IDENT, int UR, int NEIGHBOUR, int GXD>
+template <bool IDENT, int UR, int NEIGHBOUR, int GXD, int SHARE>
 __device__ __forceinline__ void ecc_cols_body(const float *__restrict__ img, const float *__restrict__ tmpl, int rows,
                                               int cols, const EccState *__restrict__ state,
                                               EccOut &out, int f, unsigned blk, unsigned nblk,
@@ -1230,7 +1253,7 @@ __device__ __forceinline__ void ecc_cols_body(const float *__restrict__ img, con
             EccPart P;
             ecc_part_zero(P);
             int r = 0;
-            for (; r + UR <= ne; r += UR) ecc_cols_trip<IDENT, UR, NEIGHBOUR, GXD>(I, tmpl, cols, x, yb + r, r, ax, bx, rt, y0, M, P, T);
+            for (; r + UR <= ne; r += UR) ecc_cols_trip<IDENT, UR, NEIGHBOUR, GXD, SHARE>(I, tmpl, cols, x, yb + r, r, ax, bx, rt, y0, M, P, T);
             for (; r < ne; ++r) ecc_cols_trip<IDENT, 1, NEIGHBOUR, GXD>(I, tmpl, cols, x, yb + r, r, ax, bx, rt, y0, M, P, T);
             ecc_part_flush(P, T, yb);
         }
@@ -1388,7 +1411,7 @@ constexpr int kEccTicketStride = 32;     // one ticket per frame on its own 128-
 // FUSE: the block that finishes a frame LAST (a ticket per frame) reduces the frame's partial sums and solves the iteration in
 // the same launch -- no ecc_solve_kernel launch between two sums launches (16 us of a dependent chain + a launch gap, 32 times
 // per 1000 frames).  The partials and the ticket move through device-scope atomics only (EccOut).
-template <bool IDENT, int UR, int WAVES, int NEIGHBOUR = 0, int GXD = 1, int FUSE = 0>
+template <bool IDENT, int UR, int WAVES, int NEIGHBOUR = 0, int GXD = 1, int FUSE = 0, int SHARE = 0>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
     ecc_cols_kernel(const float *__restrict__ img, const float *__restrict__ tmpl, int rows, int cols,
                     EccState *__restrict__ state, double *__restrict__ partial, const float *__restrict__ center,
@@ -1400,7 +1423,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
     const unsigned nint = gridDim.y - (unsigned)kEccBorderBlocks;
     EccOut out = {partial, FUSE != 0, 0ull};
     if (blockIdx.y >= (unsigned)kEccBorderBlocks)
-        ecc_cols_body<IDENT, UR, NEIGHBOUR, GXD>(img, tmpl, rows, cols, state, out, f, blockIdx.y - (unsigned)kEccBorderBlocks, nint, lds_red, *center);
+        ecc_cols_body<IDENT, UR, NEIGHBOUR, GXD, SHARE>(img, tmpl, rows, cols, state, out, f, blockIdx.y - (unsigned)kEccBorderBlocks, nint, lds_red, *center);
     else
         ecc_band_cols_body(img, tmpl, rows, cols, state, out, f, blockIdx.y, IDENT, lds_red);
     if (FUSE) {
@@ -2405,6 +2428,12 @@ static int run_ecc(FrameScratch *s, const float *tmpl_blur, const float *d_cente
                 // interior block at least.  UPSP_ECC_KERNEL=2 selects round 2's kernel (A/B, and images wider than that).
                 static const int cvariant = env_int_io("UPSP_ECC_CVARIANT", 0);
                 static const int gx_form = env_int_io("UPSP_ECC_GX", 1);
+                // UPSP_ECC_SHARE_ROWS=1 (opt-in, measured and NOT the default): the second row of a general trip re-uses the first one's
+                // source rows when its footprint is that one moved down by a row in every lane of the wave (ecc_cols_trip): 11
+                // instead of 16 source loads per trip, the same bits (tests/test_imageops_gpu.py) -- and 6.0 instead of 5.4 ms of
+                // sums per 1000 frames: the loads then wait for both rows' coordinates and a wave-wide vote.  The kernel is not
+                // bound by the number of its L1 requests.
+                const int share_rows = env_int_io("UPSP_ECC_SHARE_ROWS", 0);
                 // UPSP_ECC_FUSE_SOLVE=1 (opt-in, measured and NOT the default): the solve in the sums launch, by the block that
                 // finishes a frame last.  Same bits (tests/test_imageops_gpu.py), but the sums take 6.13 instead of 5.41 + 0.52 ms
                 // per 1000 frames: the 45 partial sums of every block leave as device-scope atomics, and the launch ends with the
@@ -2444,6 +2473,7 @@ static int run_ecc(FrameScratch *s, const float *tmpl_blur, const float *d_cente
                         else if (gv == 7) UPSP_ECC_COLS(false, 1, 5);
                         else if (gx_form == 0) UPSP_ECC_COLS(false, 2, 4, 0, 0);
                         else if (fuse_solve) { UPSP_ECC_COLS(false, 2, 3, 0, 1, 1); fused_solve = true; }
+                        else if (share_rows) UPSP_ECC_COLS(false, 2, 3, 0, 1, 0, 1);
                         else UPSP_ECC_COLS(false, 2, 3);
                     }
                 }
