@@ -430,7 +430,7 @@ def test_ecc_shared_rows_same_bits(gpu_lib, monkeypatch):
         n = 2000
         pix = (rng.integers(8, H - 8, n) * W + rng.integers(8, W - 8, n)).astype(np.int32)
         out = {}
-        for mode in ("1", "0"):
+        for mode in ("2", "1", "0"):      # 2: rows software-pipelined (the loads of two rows in flight while one is summed)
             monkeypatch.setenv("UPSP_ECC_SHARE_ROWS", mode)
             pipe = engine.FramePipeline(1, W, H, n, registration=1)
             pipe.set_projection(0, pix)
@@ -440,7 +440,8 @@ def test_ecc_shared_rows_same_bits(gpu_lib, monkeypatch):
             rows = pipe.process(torch.as_tensor(frames.copy()).cuda(), 0, warps=w, ecc_iters=it)
             rows2 = pipe.process(torch.as_tensor(frames[: F // 2].copy()).cuda(), 0)
             out[mode] = (w.cpu().numpy(), it.cpu().numpy(), rows.cpu().numpy(), rows2.cpu().numpy())
-        a, b = out["1"], out["0"]
-        assert int(a[1].max()) >= 2                      # general iterations did run
-        for x, y in zip(a, b):
-            assert np.array_equal(x.view(np.int32), y.view(np.int32)), (H, W)
+        b = out["0"]
+        assert int(b[1].max()) >= 2                      # general iterations did run
+        for other in ("1", "2"):
+            for x, y in zip(out[other], b):
+                assert np.array_equal(x.view(np.int32), y.view(np.int32)), (H, W, other)

@@ -1196,6 +1196,80 @@ __device__ __forceinline__ void ecc_cols_trip(const float *__restrict__ I, const
     }
 }
 
+// One row of the general iteration split into its loads and its sums, for the software-pipelined walk below: the 12 source pixels
+// + the template pixel of row y of this thread's column (same loads, same arithmetic as ecc_cols_trip's general path).
+struct EccRow {
+    v2f A, Bm, Cm, D, Be, Ce;
+    float tt, fx, fy;
+};
+__device__ __forceinline__ EccRow ecc_row_load(const float *__restrict__ I, const float *__restrict__ tmpl, int cols, int x, int y,
+                                               int ax, int bx, const int2 *rtab, int rt0)
+{
+    EccRow q;
+    const unsigned pitch = 4u * (unsigned)cols;
+    const int2 rt = rtab[y - rt0];
+    const int Xr = rt.x + ax, Yr = rt.y + bx;
+    const int Xq = (Xr + 16) >> 5, Yq = (Yr + 16) >> 5;
+    const int sx = Xq >> 5, sy = Yq >> 5;
+    q.fx = (Xq & 31) * (1.f / 32);
+    q.fy = (Yq & 31) * (1.f / 32);
+    const unsigned q0 = 4u * (unsigned)(__mul24(sy - 1, cols) + sx), q1 = q0 + pitch, q2 = q1 + pitch, q3 = q2 + pitch;
+    q.A = ld_v2f(I, q0);
+    q.Be[0] = ld_f32<-4>(I, q1);
+    q.Bm = ld_v2f(I, q1);
+    q.Be[1] = ld_f32<8>(I, q1);
+    q.Ce[0] = ld_f32<-4>(I, q2);
+    q.Cm = ld_v2f(I, q2);
+    q.Ce[1] = ld_f32<8>(I, q2);
+    q.D = ld_v2f(I, q3);
+    q.tt = ld_f32(tmpl, 4u * (unsigned)(y * cols + x));
+    return q;
+}
+__device__ __forceinline__ void ecc_row_sum(const EccRow &q, EccPart &P, EccTot &T, float rf)
+{
+    const v2f FY = {q.fy, q.fy};
+    const v2f Vm = __builtin_elementwise_fma(FY, q.Cm - q.Bm, q.Bm);
+    const float w = __builtin_fmaf(q.fx, Vm[1] - Vm[0], Vm[0]);
+    const v2f Dm = q.Cm - q.Bm, De = q.Ce - q.Be;
+    const float g0 = __builtin_fmaf(q.fy, Dm[1] - De[0], q.Bm[1] - q.Be[0]);
+    const float g1 = __builtin_fmaf(q.fy, De[1] - Dm[0], q.Be[1] - q.Bm[0]);
+    const float gx = 0.5f * __builtin_fmaf(q.fx, g1 - g0, g0);
+    const v2f E = q.Cm - q.A, F = q.D - q.Bm;
+    const v2f Pp = __builtin_elementwise_fma(FY, F - E, E);
+    const float gy = 0.5f * __builtin_fmaf(q.fx, Pp[1] - Pp[0], Pp[0]);
+    ecc_part_add<false>(P, T, w, gx, gy, q.tt, rf);
+}
+// rows [y0, y1) of the column, the loads of rows y + 1 and y + 2 in flight while row y is summed (three row slots rotating;
+// float segments of kEccFlush rows from y0 exactly like the trip loop: the same sums in the same order, the same bits)
+__device__ __forceinline__ void ecc_rows_pipelined(const float *__restrict__ I, const float *__restrict__ tmpl, int cols, int x,
+                                                   int y0, int y1, int ax, int bx, const int2 *rtab, EccTot &T)
+{
+    EccPart P;
+    ecc_part_zero(P);
+    EccRow s0, s1, s2;
+    s0 = ecc_row_load(I, tmpl, cols, x, y0, ax, bx, rtab, y0);
+    s1 = y0 + 1 < y1 ? ecc_row_load(I, tmpl, cols, x, y0 + 1, ax, bx, rtab, y0) : s0;
+    int yb = y0;
+    auto one = [&](EccRow &cur, EccRow &refill, int y) {
+        if (y + 2 < y1) refill = ecc_row_load(I, tmpl, cols, x, y + 2, ax, bx, rtab, y0);
+        if (y - yb == kEccFlush) {                                  // (uniform)
+            ecc_part_flush(P, T, yb);
+            ecc_part_zero(P);
+            yb = y;
+        }
+        ecc_row_sum(cur, P, T, (float)(y - yb));
+    };
+    int y = y0;
+    for (; y + 3 <= y1; y += 3) {
+        one(s0, s2, y);
+        one(s1, s0, y + 1);
+        one(s2, s1, y + 2);
+    }
+    if (y < y1) one(s0, s2, y);
+    if (y + 1 < y1) one(s1, s0, y + 1);
+    ecc_part_flush(P, T, yb);
+}
+
 // Interior block `blk` of `nblk`: the inner rectangle (farther than the band from every edge) is cut into column tiles
 // of 256 and, per tile, into nblk / tiles row pieces; blocks beyond that store zeros.  Needs nblk >= tiles (the host
 // checks: cols <= 256 x interior blocks, else the round-2 kernel runs).
@@ -1248,6 +1322,9 @@ __device__ __forceinline__ void ecc_cols_body(const float *__restrict__ img, con
     if (on || NEIGHBOUR) {
         const int ax = IDENT ? 0 : __double2int_rn(M[0] * x * 1024), bx = IDENT ? 0 : __double2int_rn(M[3] * x * 1024);
         const int2 *rt = rtab_s;
+        if (!IDENT && SHARE == 2) {
+            ecc_rows_pipelined(I, tmpl, cols, x, y0, y1, ax, bx, rt, T);
+        } else
         for (int yb = y0; yb < y1; yb += kEccFlush) {
             const int ne = min(kEccFlush, y1 - yb);
             EccPart P;
@@ -2432,7 +2509,9 @@ static int run_ecc(FrameScratch *s, const float *tmpl_blur, const float *d_cente
                 // source rows when its footprint is that one moved down by a row in every lane of the wave (ecc_cols_trip): 11
                 // instead of 16 source loads per trip, the same bits (tests/test_imageops_gpu.py) -- and 6.0 instead of 5.4 ms of
                 // sums per 1000 frames: the loads then wait for both rows' coordinates and a wave-wide vote.  The kernel is not
-                // bound by the number of its L1 requests.
+                // bound by the number of its L1 requests.  = 2: the rows software-pipelined instead (ecc_rows_pipelined: the loads of
+                // rows y + 1, y + 2 in flight while row y is summed; 160 VGPRs, no spill, same bits): 6.03 ms.  Two rows loaded, then
+                // two rows summed, three waves per SIMD taking turns, remains the fastest arrangement found.
                 const int share_rows = env_int_io("UPSP_ECC_SHARE_ROWS", 0);
                 // UPSP_ECC_FUSE_SOLVE=1 (opt-in, measured and NOT the default): the solve in the sums launch, by the block that
                 // finishes a frame last.  Same bits (tests/test_imageops_gpu.py), but the sums take 6.13 instead of 5.41 + 0.52 ms
@@ -2473,6 +2552,7 @@ static int run_ecc(FrameScratch *s, const float *tmpl_blur, const float *d_cente
                         else if (gv == 7) UPSP_ECC_COLS(false, 1, 5);
                         else if (gx_form == 0) UPSP_ECC_COLS(false, 2, 4, 0, 0);
                         else if (fuse_solve) { UPSP_ECC_COLS(false, 2, 3, 0, 1, 1); fused_solve = true; }
+                        else if (share_rows == 2) UPSP_ECC_COLS(false, 2, 3, 0, 1, 0, 2);      // rows software-pipelined, two in flight
                         else if (share_rows) UPSP_ECC_COLS(false, 2, 3, 0, 1, 0, 1);
                         else UPSP_ECC_COLS(false, 2, 3);
                     }
