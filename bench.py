@@ -795,9 +795,15 @@ def main():
             proj = engine.build_projection(bvh, cam, d_nodes, d_nrm, d_tn, 70.0, counts=False)   # no host sync
         e[1].record()
         pipe.reset()
-        pipe.set_projection(0, proj["pix"])
         if overlap:
+            # before the projection is copied into the pipeline: with the build on the side stream the copy would otherwise
+            # be ordered behind pass A only and could read entries the build is still writing
             main.wait_stream(side)
+            if swap:
+                for t in proj.values():
+                    if isinstance(t, torch.Tensor) and t.is_cuda:
+                        t.record_stream(main)       # allocated on the side stream, consumed on the main one
+        pipe.set_projection(0, proj["pix"])
         if not chunked:
             pipe.process(frames, first_frame=rank * F, rows_t=rows_t, want_rows=False)
         elif pixel_wire:

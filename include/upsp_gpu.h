@@ -566,6 +566,10 @@ int upsp_exchange_bytes(const upsp_exchange *x, uint64_t *sent, uint64_t *receiv
  *   upsp_rows_from_pixel_series pass B alone (used by the above): series and accumulators of nnodes nodes from pixel series */
 int upsp_pipeline_pixel_series(upsp_pipeline *pipe, uint16_t *d_frames, int nframes, void *stream, const uint16_t **d_compact,
                                uint32_t *cpitch, const int32_t **d_node_k, const uint32_t **d_nactive);
+/* Largest `nframes` one upsp_pipeline_pixel_series / upsp_pipeline_prescan call takes for this pipeline (a multiple of 64,
+ * 64 .. 1024: the compact buffer [min(nodes, pixels)][frames] u16 must fit opts.compact_mb) -- a caller that cuts its frames
+ * into chunks (psp_process.cpp:1519-1529 + the chunked exchange) keeps every chunk within it. */
+int upsp_pipeline_series_frames_max(const upsp_pipeline *pipe);
 int upsp_rows_from_pixel_series(const uint16_t *d_compact, uint32_t cpitch, const int32_t *d_node_k, const uint8_t *d_skipped,
                                 size_t nnodes, int64_t nframes, float *d_rows_t, int64_t ld, double *d_sum, double *d_sumsq,
                                 void *stream);

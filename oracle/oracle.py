@@ -258,6 +258,18 @@ def create_projection(bvh, cam, nodes, normals, tri_nodes, oblique_thresh, datan
                 accepted=int(acc), nrays=int(nrays.value))
 
 
+def oblique_ambiguous(cam, nodes, normals, oblique_thresh, datanode=None):
+    """In-frame nodes whose oblique verdict depends on the last bit of libm's acosf (orc_oblique_ambiguous)."""
+    nodes = _f32(nodes).reshape(-1, 3)
+    normals = _f32(normals).reshape(-1, 3)
+    dn = None if datanode is None else np.ascontiguousarray(datanode, dtype=np.uint8)
+    L = lib()
+    L.orc_oblique_ambiguous.restype = C.c_int64
+    L.orc_oblique_ambiguous.argtypes = [C.POINTER(Camera), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float]
+    return int(L.orc_oblique_ambiguous(C.byref(cam), _p(nodes), _p(normals), _p(dn), nodes.shape[0],
+                                       np.float32(oblique_thresh)))
+
+
 def adjust_weights(pix, weight, nodes, normals, centers, mode):
     pix = np.ascontiguousarray(pix, dtype=np.int32)
     ncams, n = pix.shape

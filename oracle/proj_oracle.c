@@ -158,10 +158,16 @@ int64_t orc_create_projection(const orc_bvh *bvh, const orc_camera *cam, const f
         }
         if (!visible) continue;
 
-        /* oblique test :298-306 ; acos evaluated in double then narrowed */
+        /* oblique test :298-306.  `float theta = acos(cos_theta)` with a float argument (:304-305) in a translation unit
+         * that includes <math.h> besides <cmath> (upsp.h:38 -> PSPHDF5.h:13; utils/pspError.h:5 -> pspOstr.h:13): with
+         * libstdc++ that header brings std::acos's overloads into the global namespace, so the call resolves to
+         * acos(float) = acosf -- checked with g++ 11 on a three-line TU with the same two includes.  acosf is
+         * this platform's libm (glibc 2.35: fdlibm's float kernel, < 1 ulp; glibc >= 2.41: correctly rounded), i.e. the
+         * last bit of theta is the libm's, not the reference's: orc_oblique_ambiguous() counts the nodes where that bit
+         * decides (acosf and the correctly rounded double acos on opposite sides of the threshold). */
         const float *nn = &normals3[3 * n];
         float cos_theta = nn[0] * dir[0] + nn[1] * dir[1] + nn[2] * dir[2];
-        float theta = (float)acos((double)cos_theta);
+        float theta = acosf(cos_theta);
         if (!(theta > oblique_thresh)) continue;
 
         uv[2 * n] = pt[0] / W; /* :311-314 */
@@ -182,6 +188,37 @@ int64_t orc_create_projection(const orc_bvh *bvh, const orc_camera *cam, const f
     }
     if (nrays) *nrays = rays;
     return accepted;
+}
+
+/* In-frame data nodes whose oblique verdict (psp_process.cpp:304-306) depends on the last bit of acos: libm's acosf
+ * (what the reference's call resolves to, see orc_create_projection) and the double-precision acos narrowed to float
+ * (what the GPU engine evaluates) disagree on `theta > oblique_thresh`.  Such a node is outside any bit-exact claim
+ * against "the reference" -- its entry depends on the libm the reference was linked with.  Counted regardless of
+ * what the rays say (a superset of the nodes whose matrix entry could differ). */
+int64_t orc_oblique_ambiguous(const orc_camera *cam, const float *nodes3, const float *normals3, const uint8_t *datanode,
+                              size_t nnodes, float oblique_thresh)
+{
+    const int W = cam->width, H = cam->height;
+    double cc[3];
+    orc_cam_center(cam, cc);
+    const float orig[3] = {(float)cc[0], (float)cc[1], (float)cc[2]};
+    int64_t count = 0;
+    for (size_t n = 0; n < nnodes; ++n) {
+        if (datanode && !datanode[n]) continue;
+        const float *ipos = &nodes3[3 * n];
+        float pt[2];
+        orc_project_point(cam, ipos, pt);
+        int rx = cv_round(pt[0]), ry = cv_round(pt[1]);
+        if (!(rx >= 0 && ry >= 0 && rx < W && ry < H)) continue;
+        float dir[3] = {ipos[0] - orig[0], ipos[1] - orig[1], ipos[2] - orig[2]};
+        norm3(dir);
+        const float *nn = &normals3[3 * n];
+        float cos_theta = nn[0] * dir[0] + nn[1] * dir[1] + nn[2] * dir[2];
+        const int a = acosf(cos_theta) > oblique_thresh;
+        const int b = (float)acos((double)cos_theta) > oblique_thresh;
+        count += a != b;
+    }
+    return count;
 }
 
 /* angle_between<float>, cpp/utils/cv_extras.ipp:69-73 (dot in float, norms in double) */

@@ -138,6 +138,10 @@ int64_t orc_create_projection(const orc_bvh *bvh, const orc_camera *cam,
                               float oblique_thresh, int32_t *pix, float *uv,
                               uint8_t *nodecount, uint64_t *nrays, int threads);
 
+/* Nodes whose oblique-test verdict depends on the last bit of libm's acosf (see proj_oracle.c). */
+int64_t orc_oblique_ambiguous(const orc_camera *cam, const float *nodes3, const float *normals3,
+                              const uint8_t *datanode, size_t nnodes, float oblique_thresh);
+
 /* adjust_projection_for_weights + BestView/AverageViews
  * (cpp/lib/projection.ipp:911-1078, 227-268; angle_between cv_extras.ipp:69-73).
  * pix[c*nnodes+n] <0 = not seen; weight[c*nnodes+n] in/out (1.0 where seen).

@@ -221,11 +221,13 @@ def test_cli_two_ranks(gpu_lib, tmp_path):
 
 
 @pytest.mark.gpu
-def test_cli_two_ranks_one_camera_pixel_wire(gpu_lib, tmp_path):
+@pytest.mark.parametrize("nframes,size", [(140, (96, 80)), (1410, (48, 40))])
+def test_cli_two_ranks_one_camera_pixel_wire(gpu_lib, tmp_path, nframes, size):
     """One camera, no image stage, `-ranks=2`: the time-series exchange carries the active pixels' u16 series and the owner
     of a node runs pass B (psp.Phase1.frame_loop_pixel_wire) -- every output file byte-identical to the single-rank run
     and to a two-rank run with the node rows on the wire (UPSP_ROW_WIRE=1).  140 frames: two exchange chunks per rank of
-    unequal length, hot pixels in both."""
+    unequal length, hot pixels in both.  1410 frames = 705 per rank: ceil(705 / 256) = 3 chunks cut on 64-frame boundaries
+    would end in a chunk of 257 frames, one more than a feed slot holds (distributed.chunk_count picks 4)."""
     import subprocess
     import sys
     import torch
@@ -237,7 +239,7 @@ def test_cli_two_ranks_one_camera_pixel_wire(gpu_lib, tmp_path):
     for name, ranks, extra in (("one", 0, {}), ("pixels", 2, {}), ("rows", 2, {"UPSP_ROW_WIRE": "1"})):
         tmp = str(tmp_path / name)
         os.makedirs(tmp)
-        write_case(tmp, nframes=140, size=(96, 80), ncams=1)
+        write_case(tmp, nframes=nframes, size=size, ncams=1)
         e = dict(env, **extra)
         if ranks and torch.cuda.device_count() < 2:
             e.update(UPSP_BACKEND="gloo", UPSP_ONE_GPU="1")
@@ -249,4 +251,4 @@ def test_cli_two_ranks_one_camera_pixel_wire(gpu_lib, tmp_path):
     for n, a in outs["one"].items():
         assert a == outs["pixels"][n], ("pixel wire", n)
         assert a == outs["rows"][n], ("row wire", n)
-    assert len(outs["one"]["intensity_transpose"]) > 140 * 4 * 100
+    assert len(outs["one"]["intensity_transpose"]) > nframes * 4 * 100

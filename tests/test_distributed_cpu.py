@@ -234,3 +234,24 @@ def test_two_rank_pixel_series_exchange(F, N, A):
         ok = ~skipped
         assert np.array_equal(s[ok], ws[ok]) and np.array_equal(ss[ok], wss[ok]) and np.isnan(s[~ok]).all()
         assert rows_in <= A and rows_out <= world * A
+
+
+def test_chunk_count_bounds_every_chunk():
+    """The chunked frame loop reads a chunk into buffers of `limit` frames: no chunk of any rank may be longer, although
+    the cuts sit on 64-frame boundaries (ceil(n / limit) chunks are not enough: 705 -> 3 chunks, the last of 257)."""
+    from upsp_processing_amd import distributed as D
+    assert max(D.aligned_chunks(705, 3)[1]) == 257              # what the loop used before
+    for total, world in ((705, 1), (1410, 2), (60000, 8), (20000, 4), (100000, 8), (63, 2), (1, 3)):
+        counts = D.apportion(total, world)[1]
+        for limit in (128, 256, 1024):
+            K = D.chunk_count(counts, limit)
+            for n in counts:
+                starts, ext = D.aligned_chunks(n, K)
+                assert max(ext) <= limit and sum(ext) == n
+                assert all(s % 64 == 0 for s in starts)
+            assert K == 1 or any(max(D.aligned_chunks(n, K - 1)[1]) > limit for n in counts)     # and no more chunks than needed
+    for n in range(1, 3000):
+        K = D.chunk_count([n], 256)
+        assert max(D.aligned_chunks(n, K)[1]) <= 256
+    with pytest.raises(ValueError):
+        D.chunk_count([1000], 100)

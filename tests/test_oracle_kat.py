@@ -217,3 +217,30 @@ def test_far_off_distorted_nodes_are_out_of_frame(oracle):
                                    np.float32((180.0 - 70.0) * 3.141592653589793 / 180.0))
     # every in-frame node costs one primary ray; none of them needs a retry in this scene
     assert res["nrays"] == int(in_frame.sum()) == 35
+
+
+def test_oblique_verdict_does_not_hang_on_the_last_bit_of_acos(oracle, fml):
+    """psp_process.cpp:304-305 calls acos with a float argument in a TU that has <math.h>'s global overloads: acosf, whose
+    last bit is libm's.  The oracle follows that overload; the GPU engine evaluates the double acos narrowed to float.  A
+    node's entry is outside the bit-exact claim when the two land on opposite sides of deg2rad(180 - oblique): none on the
+    reference's own grid + camera01, on the bench model (configs[1..3]) or on the config-1 sphere."""
+    from upsp_processing_amd import synthetic as syn
+    thr = np.float32((180.0 - 70.0) * 3.141592653589793 / 180.0)
+    cam = oracle.make_camera(fml["cm"], fml["dist"].reshape(-1)[:4], fml["rmat"], fml["tvec"].reshape(3), 1024, 512)
+    n_fml = oracle.oblique_ambiguous(cam, fml["nodes"], fml["norms"], thr)
+    v, t = syn.tunnel_model_quad()
+    c = syn.pinhole_camera(1024, 1024, center=(0, 0, 20), half_extent=6.0, fill=0.7)      # bench.py's camera
+    n_bench = oracle.oblique_ambiguous(oracle.make_camera(c["K"], c["dist"], c["R"], c["t"], 1024, 1024), v,
+                                       syn.node_normals(v, t), thr)
+    v, t = syn.uv_sphere(50, 100)
+    c = syn.pinhole_camera(512, 512)
+    n_sph = oracle.oblique_ambiguous(oracle.make_camera(c["K"], c["dist"], c["R"], c["t"], 512, 512), v,
+                                     syn.node_normals(v, t), thr)
+    assert (n_fml, n_bench, n_sph) == (0, 0, 0)
+    # the counter does see such nodes when they exist: normals turned so that cos(theta) sweeps every float around
+    # cos(threshold) -- libm's acosf and the rounded double acos part company on some of them (or on none, where libm's
+    # acosf is correctly rounded: then the two are the same function on these inputs)
+    cs = np.float32(np.cos(np.float64(thr)))
+    grid = cs + np.arange(-2000, 2000, dtype=np.float32) * np.float32(2.0 ** -25)
+    a = np.arccos(grid.astype(np.float64)).astype(np.float32) > thr
+    assert a.any() and (~a).any()                                # the sweep straddles the threshold

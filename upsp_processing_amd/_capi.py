@@ -139,6 +139,7 @@ SIGNATURES = {
     "upsp_exchange_verify": (_i, [_vp, _vp]),
     "upsp_exchange_bytes": (_i, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "upsp_pipeline_pixel_series": (_i, [_vp, _vp, _i, _vp, C.POINTER(_vp), C.POINTER(C.c_uint32), C.POINTER(_vp), C.POINTER(_vp)]),
+    "upsp_pipeline_series_frames_max": (_i, [_vp]),
     "upsp_rows_from_pixel_series": (_i, [_vp, C.c_uint32, _vp, _vp, _sz, C.c_int64, _vp, C.c_int64, _vp, _vp, _vp]),
     "upsp_exchange_set_pixels": (_i, [_vp, _vp, _vp, _i, _vp]),
     "upsp_exchange_pixel_rows": (_i, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

@@ -31,6 +31,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "ktimer.h"
@@ -101,6 +102,16 @@ int nccl_fail(ncclResult_t e, const char *what)
     do {                                                         \
         const ncclResult_t e_ = (call);                          \
         if (e_ != ncclSuccess) return nccl_fail(e_, what);       \
+    } while (0)
+// between ncclGroupStart and ncclGroupEnd: a failed call closes the group before it returns (an open group would swallow
+// every later RCCL call of the process), and the caller's state is left as it was before the call
+#define UPSP_NCCL_GROUP_CHECK(call, what)                        \
+    do {                                                         \
+        const ncclResult_t e_ = (call);                          \
+        if (e_ != ncclSuccess) {                                 \
+            rccl().GroupEnd();                                   \
+            return nccl_fail(e_, what);                          \
+        }                                                        \
     } while (0)
 
 // ---- the local transport: every rank of the group lives in this process ------------------------------------------
@@ -452,8 +463,8 @@ int upsp_allreduce_sums(upsp_comm *c, double *d_sum, double *d_sumsq, size_t n, 
         Rccl &r = rccl();
         KTimed kt("allreduce_sums", st);
         UPSP_NCCL_CHECK(r.GroupStart(), "ncclGroupStart");
-        UPSP_NCCL_CHECK(r.AllReduce(d_sum, d_sum, n, ncclDouble, ncclSum, c->nccl, st), "ncclAllReduce");
-        UPSP_NCCL_CHECK(r.AllReduce(d_sumsq, d_sumsq, n, ncclDouble, ncclSum, c->nccl, st), "ncclAllReduce");
+        UPSP_NCCL_GROUP_CHECK(r.AllReduce(d_sum, d_sum, n, ncclDouble, ncclSum, c->nccl, st), "ncclAllReduce");
+        UPSP_NCCL_GROUP_CHECK(r.AllReduce(d_sumsq, d_sumsq, n, ncclDouble, ncclSum, c->nccl, st), "ncclAllReduce");
         UPSP_NCCL_CHECK(r.GroupEnd(), "ncclGroupEnd");
         return UPSP_OK;
     }
@@ -649,27 +660,32 @@ static int submit_core(upsp_exchange *x, const void *d_chunk, int wire, hipStrea
         int rc = ensure_buffer(x->stage[k][s], x->stage_bytes[k][s], want);
         if (rc != UPSP_OK) return rc;
     }
-    x->k += 1;
     UPSP_HIP_CHECK(hipEventRecord(x->ev_ready, st));
     if (x->c->kind == 0) {
         Rccl &r = rccl();
         UPSP_HIP_CHECK(hipStreamWaitEvent(x->comm_stream, x->ev_ready, 0));
+        // (x->k and the byte counters move only once the whole group is in: a failed call leaves the exchange where it was)
+        uint64_t sent = 0, received = 0;
         UPSP_NCCL_CHECK(r.GroupStart(), "ncclGroupStart");
         for (int p = 0; p < W; ++p) {
             const size_t out_b = rb * (size_t)(x->cut[p + 1] - x->cut[p]);
             const size_t in_b = wire_row_bytes(wire, x->chunk_count[p][k]) * (size_t)rows_in;
             if (out_b) {
-                UPSP_NCCL_CHECK(r.Send(send + rb * (size_t)x->cut[p], out_b, ncclUint8, p, x->c->nccl, x->comm_stream), "ncclSend");
-                if (p != me) x->bytes_sent += out_b;
+                UPSP_NCCL_GROUP_CHECK(r.Send(send + rb * (size_t)x->cut[p], out_b, ncclUint8, p, x->c->nccl, x->comm_stream), "ncclSend");
+                if (p != me) sent += out_b;
             }
             if (in_b) {
-                UPSP_NCCL_CHECK(r.Recv(x->stage[k][p], in_b, ncclUint8, p, x->c->nccl, x->comm_stream), "ncclRecv");
-                if (p != me) x->bytes_received += in_b;
+                UPSP_NCCL_GROUP_CHECK(r.Recv(x->stage[k][p], in_b, ncclUint8, p, x->c->nccl, x->comm_stream), "ncclRecv");
+                if (p != me) received += in_b;
             }
         }
         UPSP_NCCL_CHECK(r.GroupEnd(), "ncclGroupEnd");
+        x->bytes_sent += sent;
+        x->bytes_received += received;
+        x->k += 1;
         return UPSP_OK;
     }
+    x->k += 1;
     // local transport: post my blocks; the receivers copy them when they finish
     LocalGroup &g = *x->c->local;
     std::lock_guard<std::mutex> lk(g.mu);
@@ -791,6 +807,11 @@ int upsp_exchange_set_pixels(upsp_exchange *x, const int32_t *d_node_k, const ui
         std::vector<uint32_t> ks;
         for (int64_t n = n0; n < n1; ++n) {
             keep[n] = sk[n] == 0;
+            // -1: the node has no pixel (series of zeros).  -2: its pixel lies outside the candidate map the table was made
+            // with (upsp_pipeline_set_active_hint) -- it HAS a series, which this exchange would silently replace by zeros
+            if (keep[n] && nk[n] < -1)
+                return fail(UPSP_ERR_INVALID, "exchange: node table made with a candidate-pixel map that misses a node's pixel "
+                                              "(take it from upsp_pipeline_pixel_series)");
             if (keep[n] && nk[n] >= 0) ks.push_back((uint32_t)nk[n]);
         }
         std::sort(ks.begin(), ks.end());

@@ -457,12 +457,25 @@ static int streamed_map(upsp_pipeline *p, const int32_t *d_pix_src, size_t npix,
 // whole frame loop with the GPU idle (measured with the projection rebuilt every step: chunked N > 1 loop
 // 0.98 -> 3.0 ms per 1000 frames).  So the buffer is sized for the bound min(nodes, pixels), within the budget
 // opts.compact_mb.  Also sizes the hot-pixel scratch of the call.
-static int streamed_buffers(upsp_pipeline *p, size_t npix, int nframes, hipStream_t st, int *S_out, unsigned *cp_out)
+// frames one pass A / pass B group holds: the compact buffer [min(nodes, pixels)][frames] u16 within opts.compact_mb
+static int streamed_group_frames(const upsp_pipeline *p, size_t npix)
 {
     const size_t budget = (size_t)(p->opts.compact_mb > 0 ? p->opts.compact_mb : 2048) << 20;
     const size_t nact = std::max<size_t>(std::min(p->nnodes, npix), 1);
-    int S = (int)std::min<size_t>((size_t)group_frames_max(), (budget / (2 * nact)) / 64 * 64);
-    S = std::max(S, 64);
+    const int S = (int)std::min<size_t>((size_t)group_frames_max(), (budget / (2 * nact)) / 64 * 64);
+    return std::max(S, 64);
+}
+
+int upsp_pipeline_series_frames_max(const upsp_pipeline *p)
+{
+    if (!p) return fail(UPSP_ERR_INVALID, "bad argument");
+    return streamed_group_frames(p, (size_t)p->width * p->height);
+}
+
+static int streamed_buffers(upsp_pipeline *p, size_t npix, int nframes, hipStream_t st, int *S_out, unsigned *cp_out)
+{
+    const size_t nact = std::max<size_t>(std::min(p->nnodes, npix), 1);
+    const int S = streamed_group_frames(p, npix);
     const unsigned cp = (unsigned)((std::min(nframes, S) + 63) / 64 * 64);
     if (nact * cp * 2 > p->compact_bytes) {
         if (p->d_compact) {
@@ -577,6 +590,14 @@ int upsp_pipeline_pixel_series(upsp_pipeline *p, uint16_t *d_frames, int nframes
     if (!p->has_proj[0]) return fail(UPSP_ERR_INVALID, "pixel series: projection not set");
     hipStream_t st = (hipStream_t)stream;
     int rc = UPSP_OK;
+    if (p->hint_active) {
+        // a candidate-pixel map (upsp_pipeline_set_active_hint) is a superset chosen by the caller: its series would carry
+        // pixels no node reads, and a node whose pixel lies outside it (node_k == -2) would have no series at all on the
+        // owner of its row.  What is exchanged follows from the projection alone.
+        p->hint_active = false;
+        invalidate_map(p);
+        p->node_k_valid = false;
+    }
     if (!p->tilemap_valid) {
         rc = streamed_map(p, p->d_pix[0], npix, st);
         if (rc != UPSP_OK) return rc;

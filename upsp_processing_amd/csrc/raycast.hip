@@ -518,6 +518,12 @@ __device__ __forceinline__ void trav_run(Trav &s, const Ray &r, const Scene &sc,
         if (cap == 0) {
             unsigned inner = 0;
             while (s.cur >= 0 && ++inner <= sc.round_cap) node_step<ANYHIT, STATS>(s, r, sc, stack);
+            if (s.cur >= 0) {                   // a descent longer than the tree: the same broken-tree verdict, at once
+                atomicOr(sc.err, 1u);           // (not round_cap re-entries of round_cap steps each)
+                s.cur = kDone;
+                s.sp = 0;
+                break;
+            }
         } else {
             for (int d = 0; d < cap && __ballot(s.cur >= 0) != 0ull; ++d) {
                 if (STATS && (threadIdx.x & 63u) == (unsigned)__ffsll((long long)__ballot(true)) - 1u) ++s.w_node_rounds;

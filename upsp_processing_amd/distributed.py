@@ -274,6 +274,21 @@ def aligned_chunks(nframes, nchunks, align=64):
     return bounds[:-1], [bounds[k + 1] - bounds[k] for k in range(nchunks)]
 
 
+def chunk_count(frame_counts, limit, align=64):
+    """Smallest K such that aligned_chunks(n, K) of every rank's frame count n holds at most `limit` frames per chunk.
+    The cuts sit on multiples of `align`, so a chunk can be up to `align` frames longer than n / K (and the last one takes
+    the remainder): ceil(n / limit) chunks are NOT enough in general (705 frames, limit 256: three chunks end in one of
+    257).  limit >= 2 * align is always reachable."""
+    limit = int(limit)
+    if limit < 2 * align:
+        raise ValueError("chunk limit %d is below two alignment units of %d frames" % (limit, align))
+    nmax = max(int(n) for n in frame_counts)
+    K = max(1, -(-nmax // limit))
+    while max(max(aligned_chunks(int(n), K, align)[1]) for n in frame_counts) > limit:
+        K += 1
+    return K
+
+
 class TimeSeriesExchange:
     """global_transpose pipelined with the frame loop: the rank's frames are produced in K
     chunks; the all-to-all of chunk k is issued asynchronously as soon as its node-major

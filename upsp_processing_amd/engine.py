@@ -353,6 +353,12 @@ class FramePipeline:
                     node_k=torch.as_tensor(_DevArray(nk.value, self.nnodes, "<i4", self), device="cuda"),
                     nactive=torch.as_tensor(_DevArray(na.value, 1, "<u4", self), device="cuda"))
 
+    def series_frames_max(self):
+        """Largest frame count one pixel_series() / prescan() call takes (upsp_pipeline_series_frames_max)."""
+        n = lib().upsp_pipeline_series_frames_max(self._h)
+        check(min(n, 0))
+        return int(n)
+
     def set_skipped(self, skipped):
         sk = None if skipped is None else _dev(skipped, torch.uint8)
         check(lib().upsp_pipeline_set_skipped(self._h, _ptr(sk)))

@@ -157,9 +157,12 @@ class Phase1:
         read_chunk(c0, n) -> list with the camera's u16 [n, H, W] device tensor of this rank's frames c0 .. c0 + n.
         Returns this rank's [nodes_r, F] f32 slice; the accumulators hold this rank's share of the sums (finalize()
         all-reduces them as always)."""
-        nf_max = max(shard.frame_count)
-        K = max(1, -(-nf_max // chunk))                                # the same on every rank
+        # K is the same on every rank and no chunk of any rank is longer than `chunk` frames -- what read_chunk's
+        # buffers hold (psp_process.py sizes its feed slots with it) -- nor than one pass A group of this pipeline
+        limit = min(int(chunk), self.pipe.series_frames_max())
+        K = D.chunk_count(shard.frame_count, limit)
         ex = D.TimeSeriesExchange(shard, K)
+        assert max(max(e) for _, e in ex.chunks) <= limit
         tab = self.pipe.pixel_series(None)                             # the active-pixel map alone
         ex.set_pixels(tab["node_k"], self.skipped)
         for k in range(K):
