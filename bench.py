@@ -369,7 +369,7 @@ def registration_block(bvh, cam, d_nodes, d_nrm, d_tn, frames, restore, N, size,
         step()
     torch.cuda.synchronize()
     _capi.timing_enable(False)
-    rep = _capi.timing_report(spread=True)
+    rep = merge_ecc_labels(_capi.timing_report(spread=True))
     ms_step = dt / steps * 1e3
     bytes_step = {
         # SURVEY.md 8(d) with registration: 8 B per pixel and ECC iteration (blurred frame + template, gradients
@@ -391,7 +391,19 @@ def registration_block(bvh, cam, d_nodes, d_nrm, d_tn, frames, restore, N, size,
         kernels[name] = k
     dom = max((n for n in kernels if "achieved_GBps" in kernels[n]), key=lambda n: kernels[n]["ms_per_step"])
     dk = kernels[dom]
+    ecc_fracs = None
+    if "ecc_sums_kernel" in kernels:
+        # SURVEY 8(d) credits 8 B per pixel and frame-iteration (blurred frame + template); one LAUNCH reads the 4-MiB template
+        # once for all of its frames (it stays in cache), so the bytes a launch must move are 4 B per pixel and frame-iteration
+        # + 4 B per pixel and launch: both fractions are reported
+        ek = kernels["ecc_sums_kernel"]
+        once = iters * F * 4 * npx + ek["calls_per_step"] * 4 * npx
+        ecc_fracs = {"survey_8B_per_px_iteration": ek["achieved_GBps"] / HBM_PEAK_GBS,
+                     "template_once_per_launch": once / (ek["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "identity_launch_ms": kernels.get("ecc_sums_identity", {}).get("avg_launch_ms"),
+                     "general_launch_ms": kernels.get("ecc_sums_general", {}).get("avg_launch_ms")}
     return {
+        "ecc_sums_fraction_of_hbm_peak": ecc_fracs,
         "workload": "configs[2]: %d frames x %dx%d u16, per-frame ECC registration + projection, projection build per step" % (F, size, size),
         "value": F * steps / dt, "unit": "frames/s", "steps": steps, "warmup": warmup, "ms_per_step": ms_step,
         "ecc_iterations_per_frame": iters,
@@ -404,9 +416,22 @@ def registration_block(bvh, cam, d_nodes, d_nrm, d_tn, frames, restore, N, size,
     }
 
 
-# "ecc_sums_kernel" is the timer label of the ECC sums launch of every round; the symbols a rocprofv3 trace shows for it
-ECC_SYMBOLS = {"ecc_sums_kernel": {"kernel_symbols": ["ecc_cols_kernel<true,4,4,1,1,0> (iterations from the identity warp)",
-                                                      "ecc_cols_kernel<false,2,3,0,1,0> (general warp)"]}}
+# "ecc_sums_kernel" = the ECC sums launches (the library times them as ecc_sums_identity / ecc_sums_general); the symbols a
+# rocprofv3 trace shows for them
+ECC_SYMBOLS = {"ecc_sums_kernel": {"kernel_symbols": ["ecc_cols_kernel<true,4,4> (iterations from the identity warp)",
+                                                      "ecc_cols_kernel<false,2,3> (general warp: source taps from an LDS tile)"]}}
+
+
+def merge_ecc_labels(rep):
+    """timing_report(spread=True) with one more entry, "ecc_sums_kernel" = the identity and the general sums launches
+    together (calls, total ms, min, median of the more frequent kind, max)."""
+    parts = [rep[k] for k in ("ecc_sums_identity", "ecc_sums_general") if k in rep]
+    if parts:
+        most = max(parts, key=lambda v: v[0])
+        rep = dict(rep)
+        rep["ecc_sums_kernel"] = (sum(v[0] for v in parts), sum(v[1] for v in parts), min(v[2] for v in parts), most[3],
+                                  max(v[4] for v in parts))
+    return rep
 
 
 def host_feed_rate(pipe, frames, N, size, pix, chunk=64, nchunks=16):
@@ -909,7 +934,7 @@ def main():
 
     # per-kernel durations: HIP events recorded by the library on the launch stream
     # during the timed steps (upsp_timing_enable / upsp_timing_report)
-    timing_full = _capi.timing_report(spread=True)
+    timing_full = merge_ecc_labels(_capi.timing_report(spread=True))
     timing = {k: v[:2] for k, v in timing_full.items()}
     kernels = {}
     n_retry_rays = 6 * retry_nodes

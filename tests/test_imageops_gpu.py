@@ -38,16 +38,13 @@ def test_blur_bitwise(gpu_lib, oracle):
                                   oracle.blur(img, k, box=True).view(np.int32)), (shape, k)
 
 
-@pytest.mark.parametrize("cols_kernel", [0, 1])
-def test_blur_u16_bitwise(gpu_lib, oracle, monkeypatch, cols_kernel):
+def test_blur_u16_bitwise(gpu_lib, oracle):
     """upsp_blur_u16 (convertTo + GaussianBlur of u16 frames in one pass, the registration's pre-blur) against the
-    oracle's GaussianBlur of the converted frame, bit for bit -- through the tile kernel and (UPSP_GAUSS5_COLS=1)
-    through the column-walking 5 x 5 kernel (one wave per 62 columns, rows rolling in registers, neighbours by DPP wave
-    shifts, reflect-101 by reflected loads): widths around the 62-column tiles and the 4-wave workgroups, heights
-    around the 64-row pieces, images smaller than the kernel's halo, several frames in one call; other kernel sizes."""
+    oracle's GaussianBlur of the converted frame, bit for bit -- widths that are not multiples of four take the fused tile
+    kernel (64 x 32 tile + halo in LDS): widths and heights around the tiles, images smaller than the kernel's halo,
+    several frames in one call; other kernel sizes."""
     import torch
     from upsp_processing_amd import engine
-    monkeypatch.setenv("UPSP_GAUSS5_COLS", str(cols_kernel))
     rng = np.random.default_rng(9)
     for shape in [(5, 5), (7, 61), (64, 62), (65, 63), (130, 124), (33, 125), (200, 249), (129, 300), (70, 1024 + 3)]:
         fr = rng.integers(0, 4096, size=(3,) + shape, dtype=np.uint16)
@@ -63,16 +60,14 @@ def test_blur_u16_bitwise(gpu_lib, oracle, monkeypatch, cols_kernel):
         assert np.array_equal(g.view(np.int32), oracle.blur(fr.astype(np.float32), k).view(np.int32)), k
 
 
-@pytest.mark.parametrize("quad", [1, 0])
-def test_blur_u16_quad_bitwise(gpu_lib, oracle, monkeypatch, quad):
+def test_blur_u16_quad_bitwise(gpu_lib, oracle):
     """The 5 x 5 blur of u16 frames with four pixels per lane (gauss5_quad_kernel: widths that are multiples of 4 --
-    every camera format; UPSP_GAUSS5_QUAD=0 = the tile kernel on the same inputs), bit for bit against the oracle:
+    every camera format), bit for bit against the oracle:
     widths around the 256-column waves and the 1024-column workgroups (partly filled waves, halo loads of lanes 0 / 63,
     reflected columns at both image edges), heights around the 64-row pieces and below the kernel's halo, extreme
     values at the borders, several frames per call."""
     import torch
     from upsp_processing_amd import engine
-    monkeypatch.setenv("UPSP_GAUSS5_QUAD", str(quad))
     rng = np.random.default_rng(19)
     for shape in [(3, 8), (5, 12), (64, 256), (65, 260), (63, 252), (130, 1024), (37, 1028), (129, 1020), (70, 2052), (200, 516)]:
         fr = rng.integers(0, 4096, size=(3,) + shape, dtype=np.uint16)
@@ -104,15 +99,13 @@ def test_register_pixel(gpu_lib, oracle, interp):
         assert np.array_equal(out_g.cpu().numpy(), oracle.warp_affine(fr[f], M_g, interp))
 
 
-@pytest.mark.parametrize("fused", [0, 1])
 @pytest.mark.parametrize("H,W,shift", [(96, 131, (7.3, -4.6)), (48, 64, (1.4, 0.7)), (200, 300, (-15.2, 11.8)), (33, 47, (0.3, -0.2))])
-def test_register_pixel_band(gpu_lib, oracle, monkeypatch, H, W, shift, fused):
+def test_register_pixel_band(gpu_lib, oracle, H, W, shift):
     """The ECC sums are taken by interior blocks (pixels farther than a band from every edge, no border handling) and
     band blocks (generic bilinear); the band follows the warp.  Odd image sizes, shifts of many pixels (wide bands, a band
     that swallows most of a small image), shear: same iteration count and warp as the oracle."""
     import torch
     from upsp_processing_amd import engine
-    monkeypatch.setenv("UPSP_ECC_FUSED", str(fused))      # 1: blur + identity iteration in one column-walking kernel
     rng = np.random.default_rng(H * W)
     yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
     def scene(y, x):
@@ -349,11 +342,12 @@ def test_registration_full_size_1024(gpu_lib, oracle):
     print("1024^2 registration: iterations %s, worst |dM| %.2e, |dt| %.2e px, |dI| %.2f" % (it_g.tolist(), *worst))
 
 
-def test_registration_sub_batches_pipelined(gpu_lib, oracle, monkeypatch):
+def test_registration_sub_batches_look_ahead(gpu_lib, oracle):
     """More frames than one sub-batch through the streamed registration path: the hot-pixel repair and the pre-blur of
-    sub-batch k + 1 run on a side stream while sub-batch k iterates (two blurred-frame buffers).  Same bits as the
-    one-stream schedule (UPSP_REG_PIPELINE=0) -- series, warps, iteration counts, accumulators, repaired frames -- over
-    several calls (buffers and events re-used), with hot pixels in frames of every sub-batch; and 3 frames against the oracle."""
+    sub-batch k + 1 are enqueued while the host waits for sub-batch k's "frames still iterating" (two blurred-frame buffers).
+    Same bits as calls of one sub-batch each (no look-ahead: nothing to look ahead to) -- series, warps, iteration counts,
+    accumulators, repaired frames -- over several calls (buffers re-used), with hot pixels in frames of every sub-batch; and
+    3 frames against the oracle."""
     import torch
     from upsp_processing_amd import engine, synthetic as syn
     H, W, F, n = 96, 160, 200, 3000
@@ -366,16 +360,7 @@ def test_registration_sub_batches_pipelined(gpu_lib, oracle, monkeypatch):
     pix[::13] = -1
     ok = pix >= 0
     out = {}
-    for mode in ("1", "0", "scan in the blur", "solve in the sums launch", "no look-ahead"):
-        # third schedule: fix_hot_pixels folded into the pre-blur (UPSP_HOT_IN_BLUR=1: the blur flags the frames that hold a hot
-        # pixel, only those are scanned, repaired and blurred again)
-        monkeypatch.setenv("UPSP_REG_PIPELINE", mode if mode in "01" else "0")
-        monkeypatch.setenv("UPSP_HOT_IN_BLUR", "1" if mode == "scan in the blur" else "0")
-        # fourth: the iteration's solve done by the last block of the sums launch (UPSP_ECC_FUSE_SOLVE=1, device-scope atomics)
-        monkeypatch.setenv("UPSP_ECC_FUSE_SOLVE", "1" if mode == "solve in the sums launch" else "0")
-        # "0" is the default schedule: one stream, the next sub-batch's repair + pre-blur enqueued while the host reads "frames
-        # still iterating" back (UPSP_REG_AHEAD=1); fifth: without that look-ahead
-        monkeypatch.setenv("UPSP_REG_AHEAD", "0" if mode == "no look-ahead" else "1")
+    for mode, calls in (("look-ahead", ((0, 150), (150, 200))), ("one sub-batch per call", ((0, 64), (64, 100), (100, 150), (150, 200)))):
         pipe = engine.FramePipeline(1, W, H, n, registration=1)
         pipe.set_projection(0, pix)
         pipe.set_reference(0, ref)
@@ -384,18 +369,16 @@ def test_registration_sub_batches_pipelined(gpu_lib, oracle, monkeypatch):
         d = torch.as_tensor(frames.copy()).cuda()
         w = torch.zeros((F, 1, 6), dtype=torch.float32, device="cuda")
         it = torch.full((F, 1), -1, dtype=torch.int32, device="cuda")
-        for f0, f1 in ((0, 150), (150, 200)):            # two calls: 3 sub-batches, then 1 (not pipelined)
+        for f0, f1 in calls:
             pipe.process(d[f0:f1], f0, rows_t=rt[:, :F], col0=f0, want_rows=False, warps=w[f0:f1], ecc_iters=it[f0:f1])
         torch.cuda.synchronize()
         out[mode] = (rt.cpu().numpy(), w.cpu().numpy(), it.cpu().numpy(), [a.cpu().numpy() for a in pipe.accumulators()], d.cpu().numpy())
-    b = out["0"]
-    for other in ("1", "scan in the blur", "solve in the sums launch", "no look-ahead"):
-        a = out[other]
-        assert np.array_equal(a[0].view(np.int32), b[0].view(np.int32)) and np.array_equal(a[1].view(np.int32), b[1].view(np.int32)), other
-        assert np.array_equal(a[2], b[2]) and np.array_equal(a[4], b[4]), other
-        for x, y in zip(a[3], b[3]):
-            assert np.array_equal(np.isnan(x), np.isnan(y)) and np.array_equal(x[~np.isnan(x)], y[~np.isnan(y)]), other
-    a = out["1"]
+        pipe.close()
+    a, b = out["look-ahead"], out["one sub-batch per call"]
+    assert np.array_equal(a[0].view(np.int32), b[0].view(np.int32)) and np.array_equal(a[1].view(np.int32), b[1].view(np.int32))
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[4], b[4])
+    for x, y in zip(a[3], b[3]):
+        assert np.array_equal(np.isnan(x), np.isnan(y)) and np.array_equal(x[~np.isnan(x)], y[~np.isnan(y)])
     for f in (64, 65, 199):
         img, _ = oracle.fix_hot_pixels(frames[f])
         assert np.array_equal(a[4][f], img)
@@ -406,32 +389,34 @@ def test_registration_sub_batches_pipelined(gpu_lib, oracle, monkeypatch):
         assert np.array_equal(a[0][ok, f].view(np.int32), want[ok].view(np.int32))
 
 
-def test_ecc_shared_rows_same_bits(gpu_lib, monkeypatch):
-    """The general ECC iteration re-uses the first row's source rows for the second row of a trip wherever the second
-    footprint is the first one moved down by a row in every lane of a wave (UPSP_ECC_SHARE_ROWS, default on).  Same values,
-    fewer loads: warps, iteration counts and series bit-identical to the separate loads -- on frames with sub-pixel
-    jitter (every wave takes the shared path), with rotation and scale (waves that straddle a source-row or -column step
-    take the other), odd image sizes and a second call."""
+def test_ecc_lds_taps_same_bits(gpu_lib, monkeypatch):
+    """The general ECC iteration takes its 12 source taps per pixel from an LDS-staged tile of the source frame (one float
+    segment of 32 rows x 256 columns at a time) instead of 8 load instructions per pixel: the same floats through the same
+    arithmetic in the same order, so warps, iteration counts and series are bit-identical to the direct loads
+    (UPSP_ECC_DIRECT=1, the path of segments whose footprint does not fit the tile) -- on frames with sub-pixel jitter, with
+    rotation and scale large enough that some segments fall back by themselves, with a width that is not a multiple of four
+    (every segment direct), widths that leave a partial column tile, shifts of several pixels (wide band), a second call."""
     import torch
     from upsp_processing_amd import engine, synthetic as syn
-    rng = np.random.default_rng(31)
-    for (H, W, F, lin) in ((203, 301, 24, 0.0), (256, 512, 20, 4e-3), (130, 1028, 12, 1.5e-2)):
+    rng = np.random.default_rng(41)
+    from scipy.ndimage import map_coordinates
+    for (H, W, F, lin, shift) in ((203, 300, 16, 0.0, 2.5), (256, 512, 12, 4e-3, 2.5), (130, 1028, 10, 1.5e-2, 2.5),
+                                  (300, 260, 10, 4e-2, 1.0), (97, 520, 8, 1e-3, 9.0), (150, 301, 8, 2e-3, 2.5)):
         base = syn.synth_frames_numpy(1, H, W, seed=H, noise=0.0)[0].astype(np.float64)
         yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
         frames = np.empty((F, H, W), np.uint16)
         frames[0] = base
-        from scipy.ndimage import map_coordinates
         for f in range(1, F):
             a = rng.uniform(-lin, lin, 4)
-            sh = rng.uniform(-2.5, 2.5, 2)
+            sh = rng.uniform(-shift, shift, 2)
             ys = a[2] * xx + (1 + a[3]) * yy + sh[1]
             xs = (1 + a[0]) * xx + a[1] * yy + sh[0]
             frames[f] = np.clip(np.rint(map_coordinates(base, [ys, xs], order=1, mode="nearest") + rng.normal(0, 3, (H, W))), 0, 4095)
         n = 2000
         pix = (rng.integers(8, H - 8, n) * W + rng.integers(8, W - 8, n)).astype(np.int32)
         out = {}
-        for mode in ("2", "1", "0"):      # 2: rows software-pipelined (the loads of two rows in flight while one is summed)
-            monkeypatch.setenv("UPSP_ECC_SHARE_ROWS", mode)
+        for mode in ("1", "0"):
+            monkeypatch.setenv("UPSP_ECC_DIRECT", mode)
             pipe = engine.FramePipeline(1, W, H, n, registration=1)
             pipe.set_projection(0, pix)
             pipe.set_reference(0, frames[0].astype(np.float32))
@@ -440,8 +425,8 @@ def test_ecc_shared_rows_same_bits(gpu_lib, monkeypatch):
             rows = pipe.process(torch.as_tensor(frames.copy()).cuda(), 0, warps=w, ecc_iters=it)
             rows2 = pipe.process(torch.as_tensor(frames[: F // 2].copy()).cuda(), 0)
             out[mode] = (w.cpu().numpy(), it.cpu().numpy(), rows.cpu().numpy(), rows2.cpu().numpy())
-        b = out["0"]
+            pipe.close()
+        b = out["1"]
         assert int(b[1].max()) >= 2                      # general iterations did run
-        for other in ("1", "2"):
-            for x, y in zip(out[other], b):
-                assert np.array_equal(x.view(np.int32), y.view(np.int32)), (H, W, other)
+        for x, y in zip(out["0"], b):
+            assert np.array_equal(x.view(np.int32), y.view(np.int32)), (H, W)

@@ -45,5 +45,6 @@ TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum
 FETCH_SIZE
 WRITE_SIZE
 GRBM_GUI_ACTIVE GRBM_TA_BUSY
+SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SMEM SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM
 GROUPS
 rm -rf $out

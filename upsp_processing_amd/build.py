@@ -19,7 +19,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libupsp_gpu.so")
 ARCH = "gfx950"
 
-HIP_SOURCES = ["raycast.hip", "frames.hip", "imageops.hip", "pipeline.hip", "ktimer.hip", "video.hip", "phase2.hip", "geom.hip", "feed.hip",
+HIP_SOURCES = ["raycast.hip", "frames.hip", "imageops.hip", "ecc.hip", "pipeline.hip", "ktimer.hip", "video.hip", "phase2.hip", "geom.hip", "feed.hip",
                "exchange.hip"]
 CXX_SOURCES = ["bvh_build.cpp"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -1,0 +1,1084 @@
+// ECC affine registration of the psp_process frame loop on MI355X (gfx950): cv::findTransformECC as called by
+// upsp::register_pixel, cpp/lib/registration.cpp:32-81 (MOTION_AFFINE, COUNT + EPS, gaussFiltSize 5).
+//
+// The arithmetic lives in OpenCV 4.5.2 in the reference (un-vendored, no reference test: PARITY UNPINNED); the kernels
+// follow the published algorithm as restated in oracle/image_oracle.c.
+//
+// All frames of a sub-batch iterate in lock step.  One iteration is ONE pass over the template-sized pixel grid per
+// frame: the warped image, the two warped gradients (central differences recomputed from the blurred frame on the fly,
+// never stored) and the nearest-neighbour mask are evaluated per pixel and folded into 45 sums; everything OpenCV
+// derives from zero-mean images (correlation, Hessian, projections, lambda, the parameter step) follows from those
+// sums algebraically, so no second pass and no Jacobian planes exist.  The sums are reduced deterministically (fixed
+// block partials, fixed order) and one workgroup per frame does the 6 x 6 float LU solve exactly like cv::Mat::inv.
+//
+// Sum slots:
+//  0 n   1 Sw   2 Sww   3 St   4 Stt   5 Stw          (masked)
+//  6..11  S_all  J_k * w        12..17 S_mask J_k      18..23 S_mask J_k * t
+//  24..44 S_all  J_a * J_b  (a <= b, row-major upper triangle),   J = [gx X, gy X, gx Y, gy Y, gx, gy]
+//
+// The pixels are split by WHERE they are (one launch, grid = frames x (band blocks + interior blocks), the frame the
+// fast index so that the band blocks of all frames are dispatched first and run beside the interior ones):
+//   * interior blocks: pixels farther than EccState::band from every edge -- the whole 12-pixel footprint of the
+//     bilinear taps and their gradient taps is inside the image and the nearest-neighbour mask is 1 by construction
+//     (ecc_band), so the loop has no test and no fallback;
+//   * band blocks: 2 x band rows + 2 x band columns (~1.5 % of a 1024^2 frame), generic bilinear with border handling.
+//
+// Interior, one COLUMN per thread.  The 45 sums are products of three things: the warped gradients {gx, gy}, the pixel
+// coordinates {X, Y, 1} and {w, 1, t} (or a second gradient).  A thread that owns ONE column x and walks down its rows
+// has a constant X, so X comes out of every sum and is multiplied in once, at the end; Y is the row offset r inside a
+// SEGMENT of kEccFlush rows (a small exact integer), shifted to the true row when the segment's partial sums are folded
+// into the thread's double totals.  What is left per pixel are 21 sums
+//     {gx, gy} x {1, w, t} x {1, r}        12        {gx^2, gy^2, gx gy} x {1, r, r^2}     9
+// accumulated as packed float pairs (v_pk_fma_f32) over at most kEccFlush rows, + the five scalar sums of w and t in
+// double (they decide rho, i.e. the iteration count).  Float partials: a segment sum of <= 32 terms carries a relative
+// error of <~1e-7, random over the 30 000 segments of a frame -- the same order as the float rounding of every Jacobian
+// element in cv::findTransformECC itself, and five orders below the 1e-4 parity bar (tests: same iteration counts,
+// |dM| ~ 1e-7).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "imageops.h"
+#include "ktimer.h"
+#include "upsp_internal.h"
+
+namespace upsp {
+namespace {
+
+// Width of the border band for the warp M: an affine displacement |M p - p| is largest at a corner of the image; the
+// fixed-point source pixel is within 1.02 of M p, the footprint reaches 1 pixel before and 2 behind it.
+__device__ __forceinline__ int ecc_band(const float *Mf, int rows, int cols)
+{
+    double D = 0.0;
+    for (int cy = 0; cy < 2; ++cy)
+        for (int cx = 0; cx < 2; ++cx) {
+            const double x = cx ? cols - 1 : 0, y = cy ? rows - 1 : 0;
+            const double dx = fabs((double)Mf[0] * x + (double)Mf[1] * y + (double)Mf[2] - x);
+            const double dy = fabs((double)Mf[3] * x + (double)Mf[4] * y + (double)Mf[5] - y);
+            D = fmax(D, fmax(dx, dy));
+        }
+    if (!(D < 1.0e6)) return 1 << 24;      // (also NaN: everything is border)
+    return (int)ceil(D) + 3;
+}
+
+struct EccMargins { int top, bottom, left, right; };
+__device__ __forceinline__ EccMargins ecc_margins(int band, int rows, int cols)
+{
+    EccMargins g;
+    g.top = min(band, rows / 2);
+    g.bottom = min(band, rows - g.top);
+    g.left = min(band, cols / 2);
+    g.right = min(band, cols - g.left);
+    return g;
+}
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+constexpr int kEccFlush = 32;        // rows per float segment
+
+struct EccPart {        // float partial sums of one segment
+    v2f G0, G1, Gw0, Gw1, Gt0, Gt1, Q0, Q1, Q2, C01;
+    float C2;
+};
+struct EccTot {         // double totals of the thread's column piece (Y = true row)
+    double G0[2], G1[2], Gw0[2], Gw1[2], Gt0[2], Gt1[2], Q0[2], Q1[2], Q2[2], C0, C1, C2;
+    double Sw, Sww, St, Stt, Stw, n;
+    float cf;           // centre: the float products are taken with (w - cf) and (t - cf), see ecc_part_add
+};
+
+__device__ __forceinline__ void ecc_part_zero(EccPart &p)
+{
+    const v2f z = {0.f, 0.f};
+    p.G0 = p.G1 = p.Gw0 = p.Gw1 = p.Gt0 = p.Gt1 = p.Q0 = p.Q1 = p.Q2 = p.C01 = z;
+    p.C2 = 0.f;
+}
+
+__device__ __forceinline__ void ecc_tot_zero(EccTot &T)
+{
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+        T.G0[k] = T.G1[k] = T.Gw0[k] = T.Gw1[k] = T.Gt0[k] = T.Gt1[k] = T.Q0[k] = T.Q1[k] = T.Q2[k] = 0.0;
+    T.C0 = T.C1 = T.C2 = T.Sw = T.Sww = T.St = T.Stt = T.Stw = T.n = 0.0;
+    T.cf = 0.f;
+}
+
+// one pixel: warped value w, warped gradients gx / gy, template t, row offset rf (= r as a float) in its segment.
+// MASKED (band pixels): m = the nearest-neighbour mask of cv::findTransformECC; masked sums (n, the scalar sums,
+// sum_mask J, sum_mask J t), the others over all pixels.
+// Interior pixels: the products with w and t are taken with (w - c), (t - c), c = T.cf = an INTEGER near the template's mean
+// (ecc_center_kernel), and c x (sum of the gradients) is added back in double at the end (ecc_tot_value).  The
+// subtraction is exact (12-bit images blurred to floats below 4096 minus an integer below 4096), the identity
+// sum g w = sum g (w - c) + c sum g too; what changes is the size of the numbers that get rounded: a product g w with
+// w ~ 1800 carries an absolute rounding error of |g| x 1e-4, the same product with |w - c| ~ 100 a tenth of that --
+// and what the solve uses is sum J w - mean(w) sum J, a difference that used to cancel the leading 1-2 digits of these
+// sums (the reference rounds every one of these sums to FLOAT before its 6 x 6 solve, so a sum that lands on another
+// float moves the result by a float ulp amplified by the solve).
+template <bool MASKED>
+__device__ __forceinline__ void ecc_part_add(EccPart &p, EccTot &T, float w, float gx, float gy, float t, float rf, bool m = true)
+{
+    const float wc = MASKED ? w : w - T.cf, tc = MASKED ? t : t - T.cf;
+    const v2f G = {gx, gy}, R = {rf, rf}, W = {wc, wc}, Tt = {tc, tc};
+    const v2f Z = {0.f, 0.f};
+    const v2f Gm = (MASKED && !m) ? Z : G;
+    const float rf2 = rf * rf;
+    const v2f R2 = {rf2, rf2};
+    p.G0 += Gm;
+    p.G1 = __builtin_elementwise_fma(Gm, R, p.G1);
+    const v2f Gw = G * W, Gt = Gm * Tt, Q = G * G;
+    p.Gw0 += Gw;
+    p.Gw1 = __builtin_elementwise_fma(Gw, R, p.Gw1);
+    p.Gt0 += Gt;
+    p.Gt1 = __builtin_elementwise_fma(Gt, R, p.Gt1);
+    p.Q0 += Q;
+    p.Q1 = __builtin_elementwise_fma(Q, R, p.Q1);
+    p.Q2 = __builtin_elementwise_fma(Q, R2, p.Q2);
+    const float c = gx * gy;
+    const v2f Cc = {c, c}, R01 = {1.f, rf};
+    p.C01 = __builtin_elementwise_fma(Cc, R01, p.C01);
+    p.C2 = __builtin_fmaf(c, rf2, p.C2);
+    const double wd = w, td = t;
+    const double wm = (MASKED && !m) ? 0.0 : wd, tm = (MASKED && !m) ? 0.0 : td;
+    if (MASKED) T.n += m ? 1.0 : 0.0;
+    T.Sw += wm;
+    T.Sww = fma(wm, wd, T.Sww);
+    T.St += tm;
+    T.Stt = fma(tm, td, T.Stt);
+    T.Stw = fma(tm, wd, T.Stw);
+}
+
+// segment -> totals: rows of the segment are yb + r
+__device__ __forceinline__ void ecc_part_flush(const EccPart &p, EccTot &T, int yb)
+{
+    const double Y = (double)yb, Y2 = Y * Y, Yd = 2.0 * Y;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const double g0 = p.G0[k], g1 = p.G1[k], gw0 = p.Gw0[k], gw1 = p.Gw1[k], gt0 = p.Gt0[k], gt1 = p.Gt1[k];
+        const double q0 = p.Q0[k], q1 = p.Q1[k], q2 = p.Q2[k];
+        T.G0[k] += g0;
+        T.G1[k] += fma(Y, g0, g1);
+        T.Gw0[k] += gw0;
+        T.Gw1[k] += fma(Y, gw0, gw1);
+        T.Gt0[k] += gt0;
+        T.Gt1[k] += fma(Y, gt0, gt1);
+        T.Q0[k] += q0;
+        T.Q1[k] += fma(Y, q0, q1);
+        T.Q2[k] += fma(Y2, q0, fma(Yd, q1, q2));
+    }
+    const double c0 = p.C01[0], c1 = p.C01[1], c2 = p.C2;
+    T.C0 += c0;
+    T.C1 += fma(Y, c0, c1);
+    T.C2 += fma(Y2, c0, fma(Yd, c1, c2));
+}
+
+// the k-th of the 45 sums from a thread's totals and its column X
+template <int K>
+__device__ __forceinline__ double ecc_tot_value(const EccTot &T, double X)
+{
+    const double X2 = X * X, c = (double)T.cf;      // (sum g w = sum g (w - c) + c sum g: exact, in double)
+    switch (K) {
+    case 0: return T.n;
+    case 1: return T.Sw;
+    case 2: return T.Sww;
+    case 3: return T.St;
+    case 4: return T.Stt;
+    case 5: return T.Stw;
+    case 6: return X * (T.Gw0[0] + c * T.G0[0]);
+    case 7: return X * (T.Gw0[1] + c * T.G0[1]);
+    case 8: return T.Gw1[0] + c * T.G1[0];
+    case 9: return T.Gw1[1] + c * T.G1[1];
+    case 10: return T.Gw0[0] + c * T.G0[0];
+    case 11: return T.Gw0[1] + c * T.G0[1];
+    case 12: return X * T.G0[0];
+    case 13: return X * T.G0[1];
+    case 14: return T.G1[0];
+    case 15: return T.G1[1];
+    case 16: return T.G0[0];
+    case 17: return T.G0[1];
+    case 18: return X * (T.Gt0[0] + c * T.G0[0]);
+    case 19: return X * (T.Gt0[1] + c * T.G0[1]);
+    case 20: return T.Gt1[0] + c * T.G1[0];
+    case 21: return T.Gt1[1] + c * T.G1[1];
+    case 22: return T.Gt0[0] + c * T.G0[0];
+    case 23: return T.Gt0[1] + c * T.G0[1];
+    case 24: return X2 * T.Q0[0];     // (0,0) gx^2 X^2
+    case 25: return X2 * T.C0;        // (0,1) gx gy X^2
+    case 26: return X * T.Q1[0];      // (0,2) gx^2 X Y
+    case 27: return X * T.C1;         // (0,3) gx gy X Y
+    case 28: return X * T.Q0[0];      // (0,4) gx^2 X
+    case 29: return X * T.C0;         // (0,5) gx gy X
+    case 30: return X2 * T.Q0[1];     // (1,1) gy^2 X^2
+    case 31: return X * T.C1;         // (1,2) gy gx X Y
+    case 32: return X * T.Q1[1];      // (1,3) gy^2 X Y
+    case 33: return X * T.C0;         // (1,4) gy gx X
+    case 34: return X * T.Q0[1];      // (1,5) gy^2 X
+    case 35: return T.Q2[0];          // (2,2) gx^2 Y^2
+    case 36: return T.C2;             // (2,3) gx gy Y^2
+    case 37: return T.Q1[0];          // (2,4) gx^2 Y
+    case 38: return T.C1;             // (2,5) gx gy Y
+    case 39: return T.Q2[1];          // (3,3) gy^2 Y^2
+    case 40: return T.C1;             // (3,4) gy gx Y
+    case 41: return T.Q1[1];          // (3,5) gy^2 Y
+    case 42: return T.Q0[0];          // (4,4) gx^2
+    case 43: return T.C0;             // (4,5) gx gy
+    default: return T.Q0[1];          // (5,5) gy^2
+    }
+}
+
+// One step of a sum over the lanes of a DPP row with moves only (no ds_bpermute round trips: 45 sums x 6 dependent
+// shuffle steps were a ~25 000-cycle latency chain at the end of every block).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add_f64(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xFFFFFFFFll), CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xF, false);
+    return v + __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);   // (rows outside the mask add 0.0)
+}
+
+// Block reduction of the 45 sums straight from the totals, through LDS in three chunks of 15 (the 45 doubles of a
+// thread never exist at once): every thread writes its 15 values, thread (v, p) = (t / 16, t % 16) adds 16 of the 256
+// entries of value v (stride 16: conflict-free), the 16 partials of a value sit in one DPP row and are added there.
+// Fixed order: deterministic.
+constexpr int kEccChunk = 15;
+static_assert(kEccSums == 3 * kEccChunk, "three chunks");
+template <int C, int J>
+__device__ __forceinline__ void ecc_tot_put(const EccTot &T, double X, bool on, double (*lds)[256])
+{
+    lds[J][threadIdx.x] = on ? ecc_tot_value<C * kEccChunk + J>(T, X) : 0.0;
+    if constexpr (J + 1 < kEccChunk) ecc_tot_put<C, J + 1>(T, X, on, lds);
+}
+template <int C>
+__device__ __forceinline__ void ecc_tot_store(const EccTot &T, double X, bool on, double (*lds)[256], double *__restrict__ partial,
+                                              int f, unsigned slot)
+{
+    ecc_tot_put<C, 0>(T, X, on, lds);
+    __syncthreads();
+    const int v = (int)threadIdx.x >> 4, p = (int)threadIdx.x & 15;
+    if (v < kEccChunk) {                       // (waves 0 .. 3, whole DPP rows)
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s += lds[v][j * 16 + p];
+        s = dpp_add_f64<0xB1, 0xF>(s);
+        s = dpp_add_f64<0x4E, 0xF>(s);
+        s = dpp_add_f64<0x141, 0xF>(s);
+        s = dpp_add_f64<0x140, 0xF>(s);        // every lane of the row holds the block's sum of value v
+        if (p == 0) partial[((size_t)f * kEccSums + (C * kEccChunk + v)) * kEccStride + slot] = s;
+    }
+    __syncthreads();
+    if constexpr (C + 1 < 3) ecc_tot_store<C + 1>(T, X, on, lds, partial, f, slot);
+}
+
+// a block without any pixel: its partial sums are zero
+__device__ __forceinline__ void ecc_store_zeros(double *__restrict__ partial, int f, unsigned slot)
+{
+    if (threadIdx.x < kEccSums) partial[((size_t)f * kEccSums + threadIdx.x) * kEccStride + slot] = 0.0;
+}
+
+// uniform base + 32-bit BYTE offset of the lane (+ a constant): the form the compiler turns into
+// `global_load_dword v, v_off, s[base] offset:imm` -- one 32-bit add per ROW of a trip instead of a 64-bit shift-and-add
+// per LOAD
+template <int IMM = 0>
+__device__ __forceinline__ float ld_f32(const float *base, unsigned byte_off)
+{
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off + IMM);
+}
+template <int IMM = 0>
+__device__ __forceinline__ v2f ld_v2f(const float *base, unsigned byte_off)      // two consecutive pixels, one 8-byte load
+{
+    return *reinterpret_cast<const v2f *>(reinterpret_cast<const char *>(base) + byte_off + IMM);
+}
+
+// ---- identity iteration (every frame starts from the identity warp, cpp/lib/registration.cpp:52-53) ---------------------
+// Source pixel = target pixel, zero fractions: the bilinear weights are (1,0,0,0) and the general arithmetic reduces
+// EXACTLY to the centre taps -- w = I, gradients = central differences of I.  UR rows of the thread's column per trip;
+// the left / right taps come from the neighbouring lanes' centre values by DPP wave shifts (lane 0 and lane 63 load
+// theirs: one load instruction per row under a two-lane exec mask), so a trip is UR + 2 column loads + UR template
+// loads.  Every lane of the wave must run the trip (lanes past the rectangle read valid columns and are left out of
+// the reduction).
+template <int UR>
+__device__ __forceinline__ void ecc_ident_trip(const float *__restrict__ I, const float *__restrict__ tmpl, int cols, int x, int y,
+                                               int r, EccPart &P, EccTot &T)
+{
+    const unsigned pitch = 4u * (unsigned)cols, o0 = 4u * (unsigned)(y * cols + x);
+    const int lane = threadIdx.x & 63;
+    float cc[UR + 2], tt[UR], hh[UR];
+    unsigned ob[UR + 2];
+#pragma unroll
+    for (int k = 0; k < UR + 2; ++k) ob[k] = o0 + (unsigned)(k - 1) * pitch;
+#pragma unroll
+    for (int k = 0; k < UR + 2; ++k) cc[k] = ld_f32(I, ob[k]);
+#pragma unroll
+    for (int k = 0; k < UR; ++k) tt[k] = ld_f32(tmpl, ob[k + 1]);
+#pragma unroll
+    for (int k = 0; k < UR; ++k) hh[k] = 0.f;
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < UR; ++k) hh[k] = ld_f32<-4>(I, ob[k + 1]);
+    } else if (lane == 63) {
+#pragma unroll
+        for (int k = 0; k < UR; ++k) hh[k] = ld_f32<4>(I, ob[k + 1]);
+    }
+#pragma unroll
+    for (int k = 0; k < UR; ++k) {
+        const float l = dpp_shr1(hh[k], cc[k + 1]), rr = dpp_shl1(hh[k], cc[k + 1]);
+        __builtin_amdgcn_sched_barrier(0);      // one row after the other: the rows' temporaries must not all be live at once
+        ecc_part_add<false>(P, T, cc[k + 1], 0.5f * (rr - l), 0.5f * (cc[k + 2] - cc[k]), tt[k], (float)(r + k));   // (= -a/2 + b/2 exactly)
+    }
+}
+
+// ---- general iteration -----------------------------------------------------------------------------------------------------
+// Footprint of a pixel (rows sy-1 .. sy+2 = a, b, c, d; columns sx-1 .. sx+2 = _1, 0, 1, 2) held as the pairs the
+// arithmetic works on: {a0,a1} {b0,b1} {c0,c1} {d0,d1} and the outer pairs {b_1,b2} {c_1,c2}.
+struct EccRow {
+    v2f A, Bm, Cm, D, Be, Ce;
+    float tt, fx, fy;
+};
+
+// Bilinear interpolation of I and of its central differences along x and y (cv::findTransformECC warps the two gradient
+// IMAGES).  All three are linear in the pixels, so with V_j = the vertical interpolation at column j
+//     w  = V_0 + fx (V_1 - V_0)
+//     gx = 1/2 [ q_0 + fx (q_1 - q_0) ],   q = (b_+ - b_-) + fy ((c_+ - c_-) - (b_+ - b_-))  at columns 0, 1
+//     gy = 1/2 [ p_0 + fx (p_1 - p_0) ],   p = (c - a) + fy ((d - b) - (c - a))  at columns 0, 1
+// With zero fractions (identity) these are exactly the taps of the identity iteration.  gx from the horizontal
+// DIFFERENCES of the pixels, interpolated -- not from differences of the interpolated V_j: those carry the rounding of
+// values ~2000, 1e-4, into a gradient of a few counts, 1e-5 relative, where the reference's warped gradient image is
+// good to 1e-7; the ECC iteration amplifies that on small or weakly textured images (tests/debug/soak_ecc.py found it,
+// 8e-3 px on a 97 x 258 frame).
+__device__ __forceinline__ void ecc_row_sum(const EccRow &q, EccPart &P, EccTot &T, float rf)
+{
+    const v2f FY = {q.fy, q.fy};
+    const v2f Vm = __builtin_elementwise_fma(FY, q.Cm - q.Bm, q.Bm);     // {V_0, V_1}
+    const float w = __builtin_fmaf(q.fx, Vm[1] - Vm[0], Vm[0]);
+    // q_j regrouped as (c_+ - b_+) - (c_- - b_-) so that the packed differences the loads deliver as pairs are used as they are
+    const v2f Dm = q.Cm - q.Bm, De = q.Ce - q.Be;                         // {c0-b0, c1-b1}, {c_1-b_1, c2-b2}
+    const float g0 = __builtin_fmaf(q.fy, Dm[1] - De[0], q.Bm[1] - q.Be[0]);
+    const float g1 = __builtin_fmaf(q.fy, De[1] - Dm[0], q.Be[1] - q.Bm[0]);
+    const float gx = 0.5f * __builtin_fmaf(q.fx, g1 - g0, g0);
+    const v2f E = q.Cm - q.A, F = q.D - q.Bm;
+    const v2f Pp = __builtin_elementwise_fma(FY, F - E, E);
+    const float gy = 0.5f * __builtin_fmaf(q.fx, Pp[1] - Pp[0], Pp[0]);
+    ecc_part_add<false>(P, T, w, gx, gy, q.tt, rf);
+}
+
+// WarpAffineInvoker's fixed-point source coordinate of (x, y): per-row term rt (table of the frame's rows, written by the
+// solve) + per-column term (ax, bx), each rounded on its own; 1/32-pixel fractions.
+__device__ __forceinline__ void ecc_coord(int2 rt, int ax, int bx, int &sx, int &sy, float &fx, float &fy)
+{
+    const int Xr = rt.x + ax, Yr = rt.y + bx;
+    const int Xq = (Xr + 16) >> 5, Yq = (Yr + 16) >> 5;
+    sx = Xq >> 5;                            // (footprint inside the image by construction: ecc_band)
+    sy = Yq >> 5;
+    fx = (Xq & 31) * (1.f / 32);
+    fy = (Yq & 31) * (1.f / 32);
+}
+
+// the 12 source pixels straight from global memory (segments whose footprint does not fit the LDS tile)
+__device__ __forceinline__ void ecc_row_load_direct(const float *__restrict__ I, int cols, int sx, int sy, EccRow &q)
+{
+    const unsigned pitch = 4u * (unsigned)cols;
+    const unsigned q0 = 4u * (unsigned)(__mul24(sy - 1, cols) + sx), q1 = q0 + pitch, q2 = q1 + pitch, q3 = q2 + pitch;   // (rows, columns < 2^15)
+    q.A = ld_v2f(I, q0);
+    q.Be[0] = ld_f32<-4>(I, q1);
+    q.Bm = ld_v2f(I, q1);
+    q.Be[1] = ld_f32<8>(I, q1);
+    q.Ce[0] = ld_f32<-4>(I, q2);
+    q.Cm = ld_v2f(I, q2);
+    q.Ce[1] = ld_f32<8>(I, q2);
+    q.D = ld_v2f(I, q3);
+}
+
+// Source taps from LDS (round 4).  Under a warp near the identity the 12 source pixels of destination pixel (x, y) are a
+// 4 x 4 patch at (x, y) + shift: the lanes of a wave read patches one column apart, consecutive rows of a column patches
+// one row apart -- every source pixel of a block's tile is wanted 12 times, and round 3's form asked the texture path for
+// each of them (8 load instructions per pixel and lane; profiles/r03_ecc_pmc.txt: L1 request floor 82 us of a 221-us
+// launch, the waves parked on those loads half of their life).  Here the block stages the source footprint of one float
+// SEGMENT (<= 32 destination rows x its 256 columns: rows sy_min - 1 .. sy_max + 2, columns from a multiple of four below
+// sx_min - 1 to sx_max + 2) with 16-byte coalesced loads, once, and every lane takes its taps from LDS.  The fixed-point
+// source coordinate is separable and monotone -- X(x, y) = a(x) + r(y), both rounded on their own -- so the corners of
+// the destination rectangle give the exact bounding box of the footprint (integer arithmetic on four table entries: all
+// scalar).  A segment whose box does not fit the tile (strong rotation / scale, a row pitch that is not a multiple of
+// four floats) walks the direct path.  The taps are the same floats and the arithmetic is ecc_row_sum either way:
+// bit-identical sums (tests/test_imageops_gpu.py::test_ecc_lds_taps_same_bits).
+constexpr int kEccTileRows = kEccFlush + 8;      // source rows of a segment: 32 + 3 of the footprint + 5 for scale / rotation
+constexpr int kEccTilePitch = 272;               // floats per tile row: 256 + 3 of the footprint + 3 alignment + 10 for scale / shear
+constexpr int kEccLdsRows = (kEccTileRows * kEccTilePitch * 4 + 256 * 8 - 1) / (256 * 8);      // the tile in rows of the reduction area
+static_assert(kEccLdsRows >= kEccChunk, "the tile area also holds the reduction chunks");
+
+struct EccSeg {          // one float segment of a block (all uniform)
+    int r0, c0;          // tile origin in the source image (row, column; c0 a multiple of 4)
+    int nr, nc4;         // tile rows, float4 per tile row
+    bool fits;
+};
+
+__device__ __forceinline__ EccSeg ecc_segment_box(int2 ra, int2 re, int ax_lo, int ax_hi, int bx_lo, int bx_hi, int rows, int cols)
+{
+    const int sx_min = ((min(ra.x, re.x) + ax_lo + 16) >> 5) >> 5, sx_max = ((max(ra.x, re.x) + ax_hi + 16) >> 5) >> 5;
+    const int sy_min = ((min(ra.y, re.y) + bx_lo + 16) >> 5) >> 5, sy_max = ((max(ra.y, re.y) + bx_hi + 16) >> 5) >> 5;
+    EccSeg g;
+    g.r0 = sy_min - 1;
+    g.c0 = (sx_min - 1) & ~3;
+    g.nr = sy_max + 2 - g.r0 + 1;
+    g.nc4 = (sx_max + 2 - g.c0 + 4) >> 2;
+    // (interior pixels have their footprint inside the image by construction -- ecc_band; the tests on the image bounds
+    //  only keep a tile load from ever leaving the frame)
+    g.fits = !(cols & 3) && g.nr <= kEccTileRows && g.nc4 * 4 <= kEccTilePitch && g.r0 >= 0 && sx_min >= 1 &&
+             sy_max + 2 < rows && sx_max + 2 < cols && g.nr > 0 && g.nc4 >= 1;
+    return g;
+}
+
+// all 256 threads: the segment's source footprint -> LDS (every load issued before the first LDS store).  Wave w takes the
+// tile rows w, w + 4, ...: lane l the float4 l of the row (256 floats: one 1-KB request per wave and row); the up to
+// four float4 beyond them (columns 256 .. 271 of the tile) are a pass of their own, thread t -> (row t / 4, float4 64 + t % 4).
+// Index arithmetic: one add per load (a division per element made the staging a quarter of the kernel's instructions).
+template <int TILE_ROWS = kEccTileRows, int PITCH = kEccTilePitch>
+__device__ __forceinline__ void ecc_stage_tile(const float *__restrict__ I, int cols, const EccSeg &g, float *tile)
+{
+    constexpr int kPerWave = (TILE_ROWS + 3) / 4;
+    const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    const int tr = (int)threadIdx.x >> 2, tc = 64 + ((int)threadIdx.x & 3);       // the tail element of this thread
+    const bool main_on = lane < g.nc4 && g.c0 + 4 * lane + 3 < cols;               // (cols % 4 == 0: a float4 is inside the row or outside it)
+    const bool tail_on = tr < g.nr && tc < g.nc4 && g.c0 + 4 * tc + 3 < cols;
+    const float *src = I + (size_t)(g.r0 + wave) * cols + (g.c0 + 4 * lane);
+    const size_t step = 4 * (size_t)cols;
+    float4 v[kPerWave], vt = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < kPerWave; ++k) {
+        v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (main_on && wave + 4 * k < g.nr) v[k] = *reinterpret_cast<const float4 *>(src + (size_t)k * step);
+    }
+    if (tail_on) vt = *reinterpret_cast<const float4 *>(I + (size_t)(g.r0 + tr) * cols + (g.c0 + 4 * tc));
+    float *dst = tile + wave * PITCH + 4 * lane;
+#pragma unroll
+    for (int k = 0; k < kPerWave; ++k)
+        if (lane < g.nc4 && wave + 4 * k < g.nr) *reinterpret_cast<float4 *>(dst + k * 4 * PITCH) = v[k];
+    if (tr < g.nr && tc < g.nc4) *reinterpret_cast<float4 *>(tile + tr * PITCH + 4 * tc) = vt;
+}
+
+// rows [yb, yb + ne) of the thread's column: taps from the staged tile (TILE) or straight from global memory; rt = the frame's
+// row table at row yb.  UR rows per trip; the template values (one coalesced 4-byte load per pixel) come one trip ahead.
+template <int UR, bool TILE>
+__device__ __forceinline__ void ecc_walk_segment(const float *tile, const EccSeg &g, const float *__restrict__ I,
+                                                 const float *__restrict__ tmpl, int cols, int x, int yb, int ne, int ax, int bx,
+                                                 const int2 *__restrict__ rt, EccPart &P, EccTot &T)
+{
+    const unsigned pitch = 4u * (unsigned)cols;
+    unsigned ot = 4u * (unsigned)(yb * cols + x);
+    auto taps = [&](int r, EccRow &q) {
+        int sx, sy;
+        ecc_coord(rt[r], ax, bx, sx, sy, q.fx, q.fy);
+        if (TILE) {
+            const float *t0 = tile + (sy - 1 - g.r0) * kEccTilePitch + (sx - 1 - g.c0);
+            const float *t1 = t0 + kEccTilePitch, *t2 = t1 + kEccTilePitch, *t3 = t2 + kEccTilePitch;
+            q.A[0] = t0[1]; q.A[1] = t0[2];
+            q.Be[0] = t1[0]; q.Bm[0] = t1[1]; q.Bm[1] = t1[2]; q.Be[1] = t1[3];
+            q.Ce[0] = t2[0]; q.Cm[0] = t2[1]; q.Cm[1] = t2[2]; q.Ce[1] = t2[3];
+            q.D[0] = t3[1]; q.D[1] = t3[2];
+        } else {
+            ecc_row_load_direct(I, cols, sx, sy, q);
+        }
+    };
+    float tn[UR];
+#pragma unroll
+    for (int k = 0; k < UR; ++k) tn[k] = k < ne ? ld_f32(tmpl, ot + (unsigned)k * pitch) : 0.f;
+    int r = 0;
+    for (; r + UR <= ne; r += UR) {
+        EccRow q[UR];
+#pragma unroll
+        for (int k = 0; k < UR; ++k) {
+            q[k].tt = tn[k];
+            tn[k] = r + UR + k < ne ? ld_f32(tmpl, ot + (unsigned)(UR + k) * pitch) : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < UR; ++k) taps(r + k, q[k]);
+#pragma unroll
+        for (int k = 0; k < UR; ++k) ecc_row_sum(q[k], P, T, (float)(r + k));
+        ot += (unsigned)UR * pitch;
+    }
+#pragma unroll
+    for (int k = 0; k < UR - 1; ++k)
+        if (r + k < ne) {
+            EccRow q;
+            q.tt = tn[k];
+            taps(r + k, q);
+            ecc_row_sum(q, P, T, (float)(r + k));
+        }
+}
+
+// Interior block `blk` of `nblk`: the inner rectangle (farther than the band from every edge) is cut into column tiles
+// of 256 and, per tile, into nblk / tiles row pieces; blocks beyond that store zeros.  Needs nblk >= tiles.  The float
+// segments follow the row pieces, i.e. the image geometry alone: the sums of a frame are the same bits in any batch.
+template <bool IDENT, int UR>
+__device__ __forceinline__ void ecc_cols_body(const float *__restrict__ img, const float *__restrict__ tmpl, int rows, int cols,
+                                              const EccState *__restrict__ state, const int2 *__restrict__ rtab,
+                                              double *__restrict__ partial, int f, unsigned slot0, unsigned blk, unsigned nblk,
+                                              double (*lds_red)[256], float center, int force_direct)
+{
+    const EccState &es = state[f];
+    const float *I = img + (size_t)f * rows * cols;
+    const EccMargins g = ecc_margins(IDENT ? 3 : es.band, rows, cols);
+    const int x_lo = g.left, x_hi = cols - g.right, y_lo = g.top, y_hi = rows - g.bottom;   // [lo, hi)
+    const int W = max(x_hi - x_lo, 0), H = max(y_hi - y_lo, 0);
+    const unsigned tiles = ((unsigned)W + 255u) / 256u;
+    const unsigned pieces = tiles ? nblk / tiles : 0u;                       // row pieces per column tile (>= 1)
+    const bool work = tiles && blk < tiles * pieces && H > 0;
+    const unsigned ct = work ? blk % tiles : 0u, piece = work ? blk / tiles : 0u;
+    const int rpp = pieces ? (int)(((unsigned)H + pieces - 1u) / pieces) : 0;  // rows per piece
+    const int y0 = work ? min(y_hi, y_lo + (int)piece * rpp) : 0, y1 = work ? min(y_hi, y0 + rpp) : 0;
+    const int x_own = x_lo + (int)ct * 256 + (int)threadIdx.x;
+    const bool on = work && x_own < x_hi && y1 > y0;
+    if (!work || y1 <= y0) {            // (uniform) more blocks than pieces: nothing to add
+        ecc_store_zeros(partial, f, slot0 + blk);
+        return;
+    }
+    EccTot T;
+    ecc_tot_zero(T);
+    T.n = on ? (double)(y1 - y0) : 0.0;          // mask = 1 on every interior pixel
+    T.cf = center;
+    int x = x_own;
+    if (IDENT) {
+        // lanes past the rectangle run along on a valid column (the DPP taps need every lane; the lane after the last one must
+        // hold column x_hi, which exists: the band is >= 3 wide) and are left out of the reduction.
+        // (Round 4: staging the segment's rows in LDS like the general iteration does was measured and is SLOWER here, 2.03-2.11
+        //  against 1.97 ms per 1000 frames: 2.5 coalesced loads per pixel are not what this kernel waits for.)
+        x = min(x_own, cols - 1);
+        for (int yb = y0; yb < y1; yb += kEccFlush) {
+            const int ne = min(kEccFlush, y1 - yb);
+            EccPart P;
+            ecc_part_zero(P);
+            int r = 0;
+            for (; r + UR <= ne; r += UR) ecc_ident_trip<UR>(I, tmpl, cols, x, yb + r, r, P, T);
+            for (; r < ne; ++r) ecc_ident_trip<1>(I, tmpl, cols, x, yb + r, r, P, T);
+            ecc_part_flush(P, T, yb);
+        }
+    } else {
+        float *tile = reinterpret_cast<float *>(&lds_red[0][0]);
+        const int2 *rt = rtab + (size_t)f * rows;
+        const double M0 = es.M[0], M3 = es.M[3];
+        // the column terms at the two ends of the block's columns (monotone in x: the extremes of the block)
+        const int xa = x_lo + (int)ct * 256, xb = min(xa + 255, x_hi - 1);
+        const int axa = __builtin_amdgcn_readfirstlane(__double2int_rn(M0 * xa * 1024)), axb = __builtin_amdgcn_readfirstlane(__double2int_rn(M0 * xb * 1024));
+        const int bxa = __builtin_amdgcn_readfirstlane(__double2int_rn(M3 * xa * 1024)), bxb = __builtin_amdgcn_readfirstlane(__double2int_rn(M3 * xb * 1024));
+        const int ax = __double2int_rn(M0 * x * 1024), bx = __double2int_rn(M3 * x * 1024);
+        bool staged = false;
+        for (int yb = y0; yb < y1; yb += kEccFlush) {
+            const int ne = min(kEccFlush, y1 - yb);
+            EccSeg s = ecc_segment_box(rt[yb], rt[yb + ne - 1], min(axa, axb), max(axa, axb), min(bxa, bxb), max(bxa, bxb), rows, cols);
+            if (force_direct) s.fits = false;
+            if (s.fits) {                              // (uniform)
+                if (staged) __syncthreads();           // every tap of the previous segment has been read
+                ecc_stage_tile<kEccTileRows, kEccTilePitch>(I, cols, s, tile);
+                __syncthreads();
+                staged = true;
+            }
+            if (on) {
+                EccPart P;
+                ecc_part_zero(P);
+                if (s.fits) ecc_walk_segment<UR, true>(tile, s, I, tmpl, cols, x, yb, ne, ax, bx, rt + yb, P, T);
+                else ecc_walk_segment<UR, false>(tile, s, I, tmpl, cols, x, yb, ne, ax, bx, rt + yb, P, T);
+                ecc_part_flush(P, T, yb);
+            }
+        }
+    }
+    __syncthreads();                              // (every read of the tile is done: the area becomes the reduction's)
+    ecc_tot_store<0>(T, (double)x, on, lds_red, partial, f, slot0 + blk);
+}
+
+// The band of the same launch, also one column per thread.  Band blocks (nband of them, >= 3 x tiles):
+//   [0, tiles)            top strip    rows [0, top),            one column tile of 256 each
+//   [tiles, 2 tiles)      bottom strip rows [rows - bottom, rows)
+//   the rest              the left + right strips between them: `side` = left + right columns; a block's 256 threads
+//                         are (column, row piece) pairs, so a 6-column band still has 42 threads per block at work
+// Generic bilinear (constant-0 border, reflect-101 gradient taps) and the nearest-neighbour mask.
+__device__ __forceinline__ void ecc_band_cols_body(const float *__restrict__ img, const float *__restrict__ tmpl, int rows,
+                                                   int cols, const EccState *__restrict__ state, const int2 *__restrict__ rtab,
+                                                   double *__restrict__ partial, int f, unsigned bidx, unsigned nband, bool ident,
+                                                   double (*lds_red)[256])
+{
+    const EccState &es = state[f];
+    const float *I = img + (size_t)f * rows * cols;
+    double M[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) M[i] = es.M[i];
+    const EccMargins g = ecc_margins(ident ? 3 : es.band, rows, cols);
+    const int tiles = (cols + 255) / 256;
+    const int tid = (int)threadIdx.x;
+    int x = -1, ya = 0, yb = 0;
+    if ((int)bidx < tiles) {
+        x = (int)bidx * 256 + tid;
+        ya = 0;
+        yb = g.top;
+    } else if ((int)bidx < 2 * tiles) {
+        x = ((int)bidx - tiles) * 256 + tid;
+        ya = rows - g.bottom;
+        yb = rows;
+    } else {
+        const int side = g.left + g.right, H = rows - g.top - g.bottom;
+        const int sb = (int)bidx - 2 * tiles, nsb = (int)nband - 2 * tiles;
+        const int tiles_s = (side + 255) / 256;
+        int pb = tiles_s ? nsb / tiles_s : 0;                    // blocks per column tile of the strips ...
+        if (side > 0 && H > 0 && pb >= 1) {
+            // ... of which only as many are used as give every thread ~8 rows (the others store zeros at once)
+            const int sp_min = 256 / min(256, side);
+            pb = min(pb, max(1, (H + 8 * sp_min - 1) / (8 * sp_min)));
+        }
+        if (side > 0 && H > 0 && pb >= 1 && sb < tiles_s * pb) {
+            const int ts = sb % tiles_s, pblk = sb / tiles_s;
+            const int cs = min(256, side - ts * 256), sp = 256 / cs;
+            const int c = tid % cs, q = tid / cs;
+            if (q < sp) {
+                const int pieces = pb * sp, rpp = (H + pieces - 1) / pieces, piece = pblk * sp + q;
+                ya = min(rows - g.bottom, g.top + piece * rpp);
+                yb = min(rows - g.bottom, ya + rpp);
+                const int k = ts * 256 + c;
+                x = k < g.left ? k : cols - side + k;
+            }
+        }
+    }
+    const bool on = x >= 0 && x < cols && yb > ya;
+    if (!__syncthreads_or(on ? 1 : 0)) {     // no thread of the block has a pixel (spare band block, empty strip)
+        ecc_store_zeros(partial, f, bidx);
+        return;
+    }
+    EccTot T;
+    ecc_tot_zero(T);
+    if (on) {
+        auto pix = [&](int yy, int xx) { return I[(size_t)yy * cols + xx]; };
+        auto gxf = [&](int yy, int xx) {
+            return -0.5f * pix(yy, reflect101(xx - 1, cols)) + 0.5f * pix(yy, reflect101(xx + 1, cols));
+        };
+        auto gyf = [&](int yy, int xx) {
+            return -0.5f * pix(reflect101(yy - 1, rows), xx) + 0.5f * pix(reflect101(yy + 1, rows), xx);
+        };
+        const int ax = __double2int_rn(M[0] * x * 1024), bx = __double2int_rn(M[3] * x * 1024);
+        for (int y0 = ya; y0 < yb; y0 += kEccFlush) {
+            const int ne = min(kEccFlush, yb - y0);
+            EccPart P;
+            ecc_part_zero(P);
+            for (int r = 0; r < ne; ++r) {
+                const int y = y0 + r;
+                if (ident) {
+                    // identity warp: source pixel = target pixel, zero fractions, mask 1 -- the generic path below evaluates to
+                    // exactly these taps (weights (1, 0, 0, 0); x * 0 terms add +-0), without its coordinate arithmetic
+                    ecc_part_add<true>(P, T, pix(y, x), gxf(y, x), gyf(y, x), tmpl[(size_t)y * cols + x], (float)r, true);
+                    continue;
+                }
+                const int2 rt = rtab[(size_t)f * rows + y];        // the per-row terms under the frame's M (written by the solve)
+                const int Xr = rt.x + ax, Yr = rt.y + bx;
+                const int Xq = (Xr + 16) >> 5, Yq = (Yr + 16) >> 5;
+                WarpCoord c;
+                c.sx = max(-32768, min(32767, Xq >> 5));
+                c.sy = max(-32768, min(32767, Yq >> 5));
+                c.ax = Xq & 31;
+                c.ay = Yq & 31;
+                const int nx = max(-32768, min(32767, (Xr + 512) >> 10)), ny = max(-32768, min(32767, (Yr + 512) >> 10));
+                const bool m = (unsigned)nx < (unsigned)cols && (unsigned)ny < (unsigned)rows;
+                float w, gx, gy;
+                if (c.sx >= 1 && c.sx + 2 < cols && c.sy >= 1 && c.sy + 2 < rows) {
+                    // footprint and gradient taps inside the image (all of the band but its outermost ring or two): the 12
+                    // pixels directly -- the generic path below evaluates to the same operations on the same values
+                    const float *r0 = I + (unsigned)((c.sy - 1) * cols + c.sx);
+                    const float *r1 = r0 + cols, *r2 = r1 + cols, *r3 = r2 + cols;
+                    const float a0 = r0[0], a1 = r0[1];
+                    const float b_1 = r1[-1], b0 = r1[0], b1 = r1[1], b2 = r1[2];
+                    const float c_1 = r2[-1], c0 = r2[0], c1 = r2[1], c2 = r2[2];
+                    const float d0 = r3[0], d1 = r3[1];
+                    const float fx = c.ax * (1.f / 32), fy = c.ay * (1.f / 32);
+                    const float w0 = (1.f - fy) * (1.f - fx), w1 = (1.f - fy) * fx, w2 = fy * (1.f - fx), w3 = fy * fx;
+                    w = b0 * w0 + b1 * w1 + c0 * w2 + c1 * w3;
+                    gx = (-0.5f * b_1 + 0.5f * b1) * w0 + (-0.5f * b0 + 0.5f * b2) * w1 +
+                         (-0.5f * c_1 + 0.5f * c1) * w2 + (-0.5f * c0 + 0.5f * c2) * w3;
+                    gy = (-0.5f * a0 + 0.5f * c0) * w0 + (-0.5f * a1 + 0.5f * c1) * w1 +
+                         (-0.5f * b0 + 0.5f * d0) * w2 + (-0.5f * b1 + 0.5f * d1) * w3;
+                } else {
+                    w = bilinear(pix, rows, cols, c);
+                    gx = bilinear(gxf, rows, cols, c);
+                    gy = bilinear(gyf, rows, cols, c);
+                }
+                ecc_part_add<true>(P, T, w, gx, gy, tmpl[(size_t)y * cols + x], (float)r, m);
+            }
+            ecc_part_flush(P, T, y0);
+        }
+    }
+    ecc_tot_store<0>(T, (double)x, on, lds_red, partial, f, bidx);
+}
+
+// centre of the float products (ecc_part_add): the mean of a 64 x 64 sample grid of the blurred template, rounded to an
+// integer and kept inside [0, 4095] (any integer there keeps w - c exact; the nearer to the image's mean, the smaller the
+// products).  Once per reference image; fixed order: deterministic.
+__global__ void __launch_bounds__(256) ecc_center_kernel(const float *__restrict__ tmpl, int rows, int cols, float *__restrict__ out)
+{
+    __shared__ double sh[256];
+    double a = 0.0;
+    for (int k = threadIdx.x; k < 4096; k += 256) {
+        const int y = (int)(((long long)(k >> 6) * rows) >> 6), x = (int)(((long long)(k & 63) * cols) >> 6);
+        a += (double)tmpl[(size_t)y * cols + x];
+    }
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double m = sh[0] / 4096.0;
+        out[0] = (m >= 0.0 && m <= 4095.0) ? (float)rint(m) : 0.f;      // (images outside the 12-bit range: no centring)
+    }
+}
+
+// grid (frames, nband + interior blocks)
+template <bool IDENT, int UR, int WAVES>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
+    ecc_cols_kernel(const float *__restrict__ img, const float *__restrict__ tmpl, int rows, int cols,
+                    const EccState *__restrict__ state, const int2 *__restrict__ rtab, double *__restrict__ partial,
+                    const float *__restrict__ center, unsigned nband, int force_direct)
+{
+    __shared__ double lds_red[IDENT ? kEccChunk : kEccLdsRows][256];     // source tile / reduction chunks of whichever body runs
+    const int f = blockIdx.x;
+    if (state[f].done) return;
+    if (blockIdx.y >= nband)
+        ecc_cols_body<IDENT, UR>(img, tmpl, rows, cols, state, rtab, partial, f, nband, blockIdx.y - nband, gridDim.y - nband, lds_red,
+                                 *center, force_direct);
+    else
+        ecc_band_cols_body(img, tmpl, rows, cols, state, rtab, partial, f, blockIdx.y, nband, IDENT, lds_red);
+}
+
+// hal::LU32f-based inverse (cv::Mat::inv, DECOMP_LU) of a 6x6 float matrix, same operations in
+// the same order.  Everything is unrolled with compile-time indices (the row exchange of the
+// partial pivoting is a select over the candidate rows), so both matrices live in registers: the
+// one lane that runs this was spending ~25 us per call on dependent scratch / LDS round trips.
+__device__ __forceinline__ bool inv6(const float *Ain, float *inv)
+{
+    float A[6][6], b[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            A[i][j] = Ain[i * 6 + j];
+            b[i][j] = i == j ? 1.f : 0.f;
+        }
+    const float eps = FLT_EPSILON * 10;
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        int k = i;
+        float best = fabsf(A[i][i]);
+#pragma unroll
+        for (int j = i + 1; j < 6; ++j) {
+            const float v = fabsf(A[j][i]);
+            if (v > best) { best = v; k = j; }
+        }
+        if (best < eps) ok = false;
+#pragma unroll
+        for (int r = i + 1; r < 6; ++r) {           // rows i <-> k, k known only at run time
+            const bool sw = k == r;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const float ta = A[i][c], tb = b[i][c];
+                A[i][c] = sw ? A[r][c] : ta;
+                A[r][c] = sw ? ta : A[r][c];
+                b[i][c] = sw ? b[r][c] : tb;
+                b[r][c] = sw ? tb : b[r][c];
+            }
+        }
+        const float d = -1 / A[i][i];
+#pragma unroll
+        for (int j = i + 1; j < 6; ++j) {
+            const float alpha = A[j][i] * d;
+#pragma unroll
+            for (int kk = i + 1; kk < 6; ++kk) A[j][kk] += alpha * A[i][kk];
+#pragma unroll
+            for (int kk = 0; kk < 6; ++kk) b[j][kk] += alpha * b[i][kk];
+        }
+    }
+    if (!ok) return false;
+#pragma unroll
+    for (int i = 5; i >= 0; --i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            float sacc = b[i][j];
+#pragma unroll
+            for (int k = i + 1; k < 6; ++k) sacc -= A[i][k] * b[k][j];
+            b[i][j] = sacc / A[i][i];
+        }
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) inv[i * 6 + j] = b[i][j];
+    return true;
+}
+
+// The body of the cv::findTransformECC iteration after the image passes (ecc.cpp): meanStdDev, rho, hessian inverse,
+// lambda, deltaP, update -- one lane, from the 45 sums in S.
+__device__ __forceinline__ void ecc_solve_scalar(EccState &es, const double *S, int max_iters, double eps, int rows, int cols)
+{
+    const double n = S[0];
+    const double mw = n ? S[1] / n : 0, mt = n ? S[3] / n : 0;
+    const double vw = n ? S[2] / n - mw * mw : 0, vt = n ? S[4] / n - mt * mt : 0;
+    const double sdw = sqrt(vw > 0 ? vw : 0), sdt = sqrt(vt > 0 ? vt : 0);
+    const double tmpNorm = sqrt(n * sdt * sdt), imgNorm = sqrt(n * sdw * sdw);
+    const double corr = S[5] - n * mt * mw;
+    float Hf[36], Hinv[36], ipf[6], tpf[6];
+    int h = 24;
+    for (int a = 0; a < 6; ++a) {
+        ipf[a] = (float)(S[6 + a] - mw * S[12 + a]);
+        tpf[a] = (float)(S[18 + a] - mt * S[12 + a]);
+        for (int b = a; b < 6; ++b) {
+            Hf[a * 6 + b] = Hf[b * 6 + a] = (float)S[h];
+            ++h;
+        }
+    }
+    if (!inv6(Hf, Hinv))
+        for (int i = 0; i < 36; ++i) Hinv[i] = 0.f;
+    es.last_rho = es.rho;
+    es.rho = corr / (imgNorm * tmpNorm);
+    es.iters += 1;
+    if (es.rho != es.rho) {  // "NaN encountered."
+        es.done = -1;
+        return;
+    }
+    float iph[6];
+    for (int i = 0; i < 6; ++i) {
+        double s = 0;
+        for (int j = 0; j < 6; ++j) s += (double)Hinv[i * 6 + j] * ipf[j];
+        iph[i] = (float)s;
+    }
+    double d_ip = 0, d_tp = 0;
+    for (int i = 0; i < 6; ++i) {
+        d_ip += (double)ipf[i] * iph[i];
+        d_tp += (double)tpf[i] * iph[i];
+    }
+    const double lambda_n = imgNorm * imgNorm - d_ip;
+    const double lambda_d = corr - d_tp;
+    if (lambda_d <= 0.0) {  // "The algorithm stopped before its convergence..."
+        es.rho = -1;
+        es.done = -2;
+        return;
+    }
+    const float lambda = (float)(lambda_n / lambda_d);
+    // errorProjection = J^T (lambda*tz - wz) = lambda*tp - ip
+    float epf[6], dp[6];
+    for (int i = 0; i < 6; ++i) epf[i] = (float)((double)lambda * tpf[i] - (double)ipf[i]);
+    for (int i = 0; i < 6; ++i) {
+        double s = 0;
+        for (int j = 0; j < 6; ++j) s += (double)Hinv[i * 6 + j] * epf[j];
+        dp[i] = (float)s;
+    }
+    es.M[0] += dp[0]; es.M[3] += dp[1]; es.M[1] += dp[2];
+    es.M[4] += dp[3]; es.M[2] += dp[4]; es.M[5] += dp[5];
+    es.band = ecc_band(es.M, rows, cols);
+    // for (i = 1; i <= N && fabs(rho - last_rho) >= eps; i++)
+    if (es.iters >= max_iters || !(fabs(es.rho - es.last_rho) >= eps)) es.done = 1;
+}
+
+// One iteration's solve, one workgroup per frame: wave w reduces sums k = w, w+4, ... over the block partials (lane l
+// takes blocks l, l+64, ...; fixed shuffle tree -> deterministic), thread 0 runs the scalar part, then -- for a frame that
+// goes on iterating -- all threads write the per-row terms of the fixed-point source coordinate under the NEW matrix
+// (WarpAffineInvoker: X0 = round((M01 y + M02) 1024), Y0 likewise; the sums kernel adds the per-column terms).
+__global__ void __launch_bounds__(256)
+    ecc_solve_kernel(EccState *__restrict__ state, const double *__restrict__ partial, int2 *__restrict__ rtab,
+                     int nframes, int nblocks, int max_iters, double eps, int rows, int cols)
+{
+    const int f = blockIdx.x;
+    if (f >= nframes) return;
+    EccState &es = state[f];
+    if (es.done) return;
+    __shared__ double Ssh[kEccSums];
+    __shared__ float Msh[8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // every load of the wave's <= 12 sums is issued before the first reduction (one sum after the
+    // other made this a chain of 12 global-load latencies)
+    constexpr int kPerWave = (kEccSums + 3) / 4;
+    double v[kPerWave];
+#pragma unroll
+    for (int i = 0; i < kPerWave; ++i) {
+        const int k = wave + 4 * i;
+        v[i] = (k < kEccSums && lane < nblocks) ? partial[((size_t)f * kEccSums + k) * kEccStride + lane] : 0.0;
+    }
+    if (nblocks > 64) {
+#pragma unroll
+        for (int i = 0; i < kPerWave; ++i) {
+            const int k = wave + 4 * i;
+            if (k < kEccSums) {
+                const double *pk = partial + ((size_t)f * kEccSums + k) * kEccStride;
+                for (int b = lane + 64; b < nblocks; b += 64) v[i] += pk[b];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < kPerWave; ++i) {
+        double x = v[i];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);   // fixed tree -> deterministic
+        const int k = wave + 4 * i;
+        if (lane == 0 && k < kEccSums) Ssh[k] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ecc_solve_scalar(es, Ssh, max_iters, eps, rows, cols);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) Msh[i] = es.M[i];
+        Msh[6] = es.done == 0 ? 1.f : 0.f;
+    }
+    __syncthreads();
+    if (Msh[6] != 0.f) {
+        const double M1 = Msh[1], M2 = Msh[2], M4 = Msh[4], M5 = Msh[5];
+        int2 *rt = rtab + (size_t)f * rows;
+        for (int y = threadIdx.x; y < rows; y += 256)
+            rt[y] = make_int2(__double2int_rn((M1 * y + M2) * 1024), __double2int_rn((M4 * y + M5) * 1024));
+    }
+}
+
+__global__ void ecc_init_kernel(EccState *state, int nframes, long long first_frame, double eps)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nframes) return;
+    EccState &es = state[f];
+    es.M[0] = 1; es.M[1] = 0; es.M[2] = 0; es.M[3] = 0; es.M[4] = 1; es.M[5] = 0;  // eye(2,3)
+    es.rho = -1;
+    es.last_rho = -eps;
+    es.iters = 0;
+    es.done = (first_frame + f == 0) ? 2 : 0;  // frame 0 is not registered (psp_process.cpp:1777)
+    es.band = 3;                               // identity
+}
+
+// one wave: out[0] frames still iterating, [1] frames in error, [2] frame-iterations so far (statistics), [3] iterations of
+// the frame that needed most (sizes the next sub-batch's first burst).  Writes all four: nothing to clear beforehand.
+__global__ void __launch_bounds__(64) ecc_count_active(const EccState *state, int nframes, int *out)
+{
+    int active = 0, err = 0, iters = 0, most = 0;
+    for (int f = threadIdx.x; f < nframes; f += 64) {
+        active += state[f].done == 0;
+        err += state[f].done < 0;
+        iters += state[f].iters;
+        most = max(most, state[f].iters);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        active += __shfl_down(active, off);
+        err += __shfl_down(err, off);
+        iters += __shfl_down(iters, off);
+        most = max(most, __shfl_down(most, off));
+    }
+    if (threadIdx.x == 0) {
+        out[0] = active;
+        out[1] = err;
+        out[2] = iters;
+        out[3] = most;
+    }
+}
+
+__global__ void ecc_export_warps(const EccState *state, int nframes, float *warps, int stride, int32_t *iters, int istride)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nframes) return;
+    if (warps)
+        for (int i = 0; i < 6; ++i) warps[(size_t)f * stride + i] = state[f].M[i];
+    if (iters) iters[(size_t)f * istride] = state[f].iters;
+}
+
+}  // namespace
+
+int launch_ecc_center(const float *tmpl_blur, int rows, int cols, float *d_center, hipStream_t st)
+{
+    hipLaunchKernelGGL(ecc_center_kernel, dim3(1), dim3(256), 0, st, tmpl_blur, rows, cols, d_center);
+    UPSP_HIP_CHECK(hipGetLastError());
+    return UPSP_OK;
+}
+
+int launch_ecc_export(const EccState *state, int nb, float *d_warps, int wstride, int32_t *d_iters, int istride, hipStream_t st)
+{
+    hipLaunchKernelGGL(ecc_export_warps, dim3((nb + 63) / 64), dim3(64), 0, st, state, nb, d_warps, wstride, d_iters, istride);
+    UPSP_HIP_CHECK(hipGetLastError());
+    return UPSP_OK;
+}
+
+int run_ecc(FrameScratch *s, const float *tmpl_blur, const float *d_center, const float *blurred, int nb, int64_t first_frame,
+            int rows, int cols, int max_iters, double eps, hipStream_t st, const std::function<int()> *while_waiting)
+{
+    // cv::warpAffine saturates source coordinates to short: images of 32768 rows or columns are outside what the reference
+    // itself registers; the kernels rely on it for 24-bit multiplies and the band-block count
+    if (rows >= 32768 || cols >= 32768) return fail(UPSP_ERR_INVALID, "registration: image dimension >= 32768");
+    if (!s || !s->state || !s->partial || !s->rtab || nb > s->batch) return fail(UPSP_ERR_INVALID, "registration: scratch not set up");
+    // Every frame starts from the identity warp (cpp/lib/registration.cpp:52-53), so the first iteration needs no warp
+    // and no interpolation (ecc_cols_kernel<true>); the later ones take their source taps from an LDS-staged tile.
+    hipLaunchKernelGGL(ecc_init_kernel, dim3((nb + 63) / 64), dim3(64), 0, st, s->state, nb, (long long)first_frame, eps);
+    // Workgroups per frame: one count per image geometry.  The float segments follow the row pieces, i.e. the block count:
+    // it must not depend on how many frames are still iterating, or the last bits of a frame's sums -- and through the
+    // reference's float 6 x 6 solve 1e-5 .. 1e-4 px of its warp -- would depend on which frames share its sub-batch.
+    // Every block ends with a reduction of the 45 sums that costs as much as ~10 rows of its 256 columns: 64 interior blocks
+    // per frame (4 column tiles x 16 row pieces of 64 rows at 1024^2; measured 16 / 32 / 64: 6.74 / 6.25 / 6.03 ms of sums
+    // per 1000 frames in round 3), at least one per column tile.
+    const int tiles = (cols + 255) / 256;
+    const int blocks = std::max(kEccInteriorBlocks, tiles);
+    const int nband = std::max(kEccBandBlocks, 3 * tiles);
+    static_assert(kEccInteriorMax >= 128 && kEccBandMax >= 3 * 128, "column tiles of an image narrower than 32768");
+    const int nblocks_total = blocks + nband;
+    // UPSP_ECC_DIRECT=1 (test switch): every segment of the general iteration takes the direct loads instead of the LDS
+    // tile -- the same bits (tests/test_imageops_gpu.py::test_ecc_lds_taps_same_bits)
+    const char *direct_env = std::getenv("UPSP_ECC_DIRECT");
+    const int force_direct = direct_env && std::atoi(direct_env) != 0;
+    bool first_burst = true, waited = false;
+    int it = 0, iters_done = 0, most_iters = 0;
+    for (;;) {
+        // a few iterations between host checks of the active-frame count; frames that have converged exit at once
+        // (a host check costs a stream round trip of ~40 us; most frames converge within 3-5 iterations, the rare
+        // oscillating ones run to max_iters, so the bursts grow).  First burst: as many iterations as the previous
+        // sub-batch's slowest frame took -- on steady footage every frame converges with its second iteration.
+        const int burst = first_burst ? std::max(1, s->ecc_first_burst - it) : (it < 7 ? 2 : (it < 15 ? 8 : 16));
+        first_burst = false;
+        for (int k = 0; k < burst && it < max_iters; ++k, ++it) {
+            {
+                KTimed kt(it == 0 ? "ecc_sums_identity" : "ecc_sums_general", st);
+                const dim3 grid((unsigned)nb, (unsigned)nblocks_total);
+                if (it == 0)
+                    hipLaunchKernelGGL((ecc_cols_kernel<true, 4, 4>), grid, dim3(256), 0, st, blurred, tmpl_blur, rows, cols,
+                                       (const EccState *)s->state, (const int2 *)s->rtab, s->partial, d_center, (unsigned)nband, 0);
+                else
+                    hipLaunchKernelGGL((ecc_cols_kernel<false, 2, 3>), grid, dim3(256), 0, st, blurred, tmpl_blur, rows, cols,
+                                       (const EccState *)s->state, (const int2 *)s->rtab, s->partial, d_center, (unsigned)nband, force_direct);
+            }
+            KTimed kt2("ecc_solve_kernel", st);
+            hipLaunchKernelGGL(ecc_solve_kernel, dim3(nb), dim3(256), 0, st, s->state, (const double *)s->partial, s->rtab, nb,
+                               nblocks_total, max_iters, eps, rows, cols);
+        }
+        hipLaunchKernelGGL(ecc_count_active, dim3(1), dim3(64), 0, st, (const EccState *)s->state, nb, s->counter);
+        // the read-back goes to pinned memory behind an event: whatever `while_waiting` enqueues (the next sub-batch's
+        // hot-pixel repair and pre-blur) runs on the GPU while the host waits for these four words
+        UPSP_HIP_CHECK(hipMemcpyAsync(s->h_counter, s->counter, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+        UPSP_HIP_CHECK(hipEventRecord(s->ev_counter, st));
+        if (while_waiting && !waited) {
+            waited = true;
+            const int rcw = (*while_waiting)();
+            if (rcw != UPSP_OK) return rcw;
+        }
+        UPSP_HIP_CHECK(hipEventSynchronize(s->ev_counter));
+        if (s->h_counter[1] > 0)
+            return fail(UPSP_ERR_DIVERGED, "ECC registration did not converge (cv::findTransformECC would throw)");
+        iters_done = s->h_counter[2];
+        most_iters = s->h_counter[3];
+        if (s->h_counter[0] == 0 || it >= max_iters) break;
+    }
+    s->ecc_first_burst = std::min(std::max(most_iters, 2), 4);
+    s->ecc_frame_iters += (unsigned long long)iters_done;
+    s->ecc_frames += (unsigned long long)nb;
+    UPSP_HIP_CHECK(hipGetLastError());
+    if (std::getenv("UPSP_TRACE_ECC")) {
+        std::vector<EccState> h(nb);
+        UPSP_HIP_CHECK(hipMemcpy(h.data(), s->state, sizeof(EccState) * nb, hipMemcpyDeviceToHost));
+        int tot = 0, mx = 0;
+        for (int i = 0; i < nb; ++i) {
+            const auto &e = h[i];
+            tot += e.iters; mx = std::max(mx, e.iters);
+            if (e.iters > 8)
+                std::fprintf(stderr, "[upsp]   frame %lld: %d iters rho=%.9f last=%.9f M=[%g %g %g; %g %g %g]\n",
+                             (long long)first_frame + i, e.iters, e.rho, e.last_rho, e.M[0], e.M[1], e.M[2], e.M[3], e.M[4], e.M[5]);
+        }
+        std::fprintf(stderr, "[upsp] ECC sub-batch of %d frames: %d frame-iterations, max %d, %d launches\n", nb, tot, mx, it);
+    }
+    return UPSP_OK;
+}
+
+}  // namespace upsp

@@ -2088,6 +2088,23 @@ int launch_hot_repair_compact(uint16_t *d_frames, size_t npix, int nframes, int 
     return UPSP_OK;
 }
 
+// Repair alone: d_count / d_pos were filled by a kernel that had the pixels in registers anyway (the registration's
+// pre-blur, imageops.hip); afterwards d_changes holds, per frame, how many pixels were replaced (words 4 .. 4 + nframes) and
+// the (frame, position, old, new) records behind them (layout of hot_changes_words()).  The counters clean themselves.
+int launch_hot_repair_list(uint16_t *d_frames, size_t npix, int nframes, int rows, int cols, int min_change, int max_hot,
+                           unsigned *d_count, const unsigned *d_pos, unsigned *d_changes, hipStream_t st)
+{
+    if (nframes <= 0) return UPSP_OK;
+    if (max_hot < 0 || max_hot >= kHotCap) return fail(UPSP_ERR_INVALID, "max_hot must be in [0,63]");
+    KTimed kt("hot_fixup_kernels", st);
+    unsigned *nch = d_changes + 4;
+    uint4 *list = reinterpret_cast<uint4 *>(d_changes + 4 + (((size_t)nframes + 3) & ~(size_t)3));
+    hipLaunchKernelGGL(hot_repair_kernel, dim3((unsigned)((nframes + 63) / 64)), dim3(64), 0, st, d_frames, npix, nframes,
+                       rows, cols, min_change, max_hot, d_count, d_pos, d_changes, nch, list);
+    UPSP_HIP_CHECK(hipGetLastError());
+    return UPSP_OK;
+}
+
 int launch_hot_fixup_multi(const PipelineGather &g, uint16_t *const *d_frames, int nframes, int rows, int cols,
                            int min_change, int max_hot, unsigned *d_count, const unsigned *d_pos,
                            unsigned *d_changes, int32_t *d_head, int32_t *d_next, hipStream_t st)

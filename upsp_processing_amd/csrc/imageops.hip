@@ -1,21 +1,12 @@
 // Image stages of the psp_process frame loop on MI355X (gfx950):
-//   register (ECC affine + inverse-map warp)   cpp/lib/registration.cpp:32-81
-//   patch    (cubic 2-D polynomial over fiducials) cpp/lib/patches.ipp:98-236
-//   filter   (GaussianBlur / blur)               cpp/exec/psp_process.cpp:1802-1807
+//   register (inverse-map warp; the ECC itself: ecc.hip)   cpp/lib/registration.cpp:32-81
+//   patch    (cubic 2-D polynomial over fiducials)          cpp/lib/patches.ipp:98-236
+//   filter   (GaussianBlur / blur)                          cpp/exec/psp_process.cpp:1802-1807
+// and the driver that runs them on a sub-batch of frames (run_frame_stages).
 //
 // The arithmetic of these stages lives in OpenCV 4.5.2 / Eigen 3.3.9 in the
-// reference (un-vendored, no reference test): the kernels follow the published
+// reference (un-vendored, no reference test: PARITY UNPINNED): the kernels follow the published
 // algorithms as restated in oracle/image_oracle.c.
-//
-// ECC on the GPU.  All frames of a sub-batch iterate in lock step.  One iteration
-// is ONE pass over the template-sized pixel grid per frame: the warped image, the
-// two warped gradients (central differences recomputed from the blurred frame on
-// the fly, never stored) and the nearest-neighbour mask are evaluated per pixel and
-// folded into 45 double sums; everything OpenCV derives from zero-mean images
-// (correlation, Hessian, projections, lambda, the parameter step) follows from
-// those sums algebraically, so no second pass and no Jacobian planes exist.  The
-// sums are reduced deterministically (fixed block partials, fixed order) and a
-// one-lane-per-frame kernel does the 6x6 float LU solve exactly like cv::Mat::inv.
 #include <hip/hip_runtime.h>
 #include <functional>
 
@@ -27,6 +18,7 @@
 #include <cstring>
 #include <vector>
 
+#include "imageops.h"
 #include "ktimer.h"
 #include "pipeline.h"
 #include "upsp_internal.h"
@@ -34,23 +26,7 @@
 namespace upsp {
 namespace {
 
-constexpr int kEccBlocks = 64;   // partial-sum blocks per frame (full sub-batch)
-constexpr int kEccBlocksMax = 512;  // ... when only a few frames are still iterating
-constexpr int kEccBorderBlocks = 48; // partial-sum blocks of the band (slots before the interior blocks'); ecc_band_cols_body needs >= 3 x ceil(cols / 256)
-constexpr int kEccStride = kEccBlocksMax + kEccBorderBlocks;   // partial sums per (frame, sum)
-constexpr int kEccSums = 45;
 constexpr int kMaxKernel = 63;   // largest odd filter size
-
-// ------------------------------------------------------------------ utils --
-__host__ __device__ inline int reflect101(int i, int n)
-{
-    if (n == 1) return 0;
-    while (i < 0 || i >= n) {
-        if (i < 0) i = -i;
-        if (i >= n) i = 2 * n - 2 - i;
-    }
-    return i;
-}
 
 __global__ void u16_to_f32_kernel(const uint16_t *__restrict__ src, float *__restrict__ dst, size_t n)
 {
@@ -219,12 +195,6 @@ __global__ void __launch_bounds__(256)
     }
 }
 
-int env_int_io(const char *name, int dflt)
-{
-    const char *v = std::getenv(name);
-    return v ? std::atoi(v) : dflt;
-}
-
 unsigned grid_for_pixels(size_t npix)
 {
     size_t g = (npix + 255) / 256;
@@ -232,11 +202,10 @@ unsigned grid_for_pixels(size_t npix)
 }
 
 // GaussianBlur(src,dst,Size(k,k),0) for nimg images; tmp: nimg*npix floats
-// the four-pixels-per-lane 5 x 5 kernel (defined with the ECC kernels below); false: not applicable, nothing launched
+// the four-pixels-per-lane 5 x 5 kernel (defined below); false: not applicable, nothing launched
 bool launch_gauss5_quad(const uint16_t *src, float *dst, int nimg, int rows, int cols, const FilterCoef &fc, hipStream_t st,
-                        unsigned thresh = 0, unsigned *flag = nullptr, int only_flagged = 0);
+                        unsigned thresh = 0, unsigned *d_count = nullptr, unsigned *d_pos = nullptr);
 inline bool launch_gauss5_quad(const float *, float *, int, int, int, const FilterCoef &, hipStream_t) { return false; }
-bool gauss5_quad_applies(const uint16_t *src, const float *dst, int nimg, int rows, int cols);
 
 template <typename SRC>
 int launch_gauss(const SRC *src, float *dst, float *tmp, int nimg, int rows, int cols, int k,
@@ -250,16 +219,6 @@ int launch_gauss(const SRC *src, float *dst, float *tmp, int nimg, int rows, int
     if (r >= 1 && r <= 3 && (const void *)src != (const void *)dst && rows > r && cols > r && nimg <= 65535) {
         const dim3 fgrid((unsigned)((cols + kGaussTW - 1) / kGaussTW), (unsigned)((rows + kGaussTH - 1) / kGaussTH),
                          (unsigned)nimg);
-        const int tv = env_int_io("UPSP_GAUSS_TILE", 0);      // (measurement switch: tile shape of the 5 x 5 kernel)
-        if (r == 2 && tv) {
-#define UPSP_GT(W_, H_)                                                                                       \
-    hipLaunchKernelGGL((gauss_fused_kernel<SRC, 2, W_, H_>), dim3((unsigned)((cols + W_ - 1) / W_), (unsigned)((rows + H_ - 1) / H_), \
-                                                                  (unsigned)nimg), block, 0, st, src, dst, rows, cols, fc)
-            if (tv == 1) UPSP_GT(128, 16); else if (tv == 2) UPSP_GT(128, 32); else if (tv == 3) UPSP_GT(256, 16); else UPSP_GT(256, 8);
-#undef UPSP_GT
-            UPSP_HIP_CHECK(hipGetLastError());
-            return UPSP_OK;
-        }
         if (r == 1) hipLaunchKernelGGL((gauss_fused_kernel<SRC, 1>), fgrid, block, 0, st, src, dst, rows, cols, fc);
         else if (r == 2 && launch_gauss5_quad(src, dst, nimg, rows, cols, fc, st)) {}        // (u16 frames, cols % 4 == 0)
         else if (r == 2) hipLaunchKernelGGL((gauss_fused_kernel<SRC, 2>), fgrid, block, 0, st, src, dst, rows, cols, fc);
@@ -275,76 +234,6 @@ int launch_gauss(const SRC *src, float *dst, float *tmp, int nimg, int rows, int
 }
 
 // -------------------------------------------------------------- warpAffine --
-struct WarpCoord {
-    int sx, sy, ax, ay;
-};
-
-// WarpAffineInvoker (OpenCV imgwarp.cpp): AB_BITS 10, INTER_BITS 5, cvRound of doubles
-__device__ __forceinline__ WarpCoord warp_coord(const double *M, int x, int y, int interp)
-{
-    const int AB_SCALE = 1024;
-    const int round_delta = interp ? 16 : 512;
-    const int adelta = __double2int_rn(M[0] * x * AB_SCALE);
-    const int bdelta = __double2int_rn(M[3] * x * AB_SCALE);
-    const int X0 = __double2int_rn((M[1] * y + M[2]) * AB_SCALE) + round_delta;
-    const int Y0 = __double2int_rn((M[4] * y + M[5]) * AB_SCALE) + round_delta;
-    WarpCoord c;
-    if (interp) {
-        const int X = (X0 + adelta) >> 5, Y = (Y0 + bdelta) >> 5;
-        c.sx = X >> 5; c.sy = Y >> 5; c.ax = X & 31; c.ay = Y & 31;
-    } else {
-        c.sx = (X0 + adelta) >> 10; c.sy = (Y0 + bdelta) >> 10; c.ax = c.ay = 0;
-    }
-    c.sx = max(-32768, min(32767, c.sx));  // saturate_cast<short>
-    c.sy = max(-32768, min(32767, c.sy));
-    return c;
-}
-
-// remapBilinear<Cast<float,T>,...>, BORDER_CONSTANT 0.  F(y,x) fetches a source pixel.
-template <typename F>
-__device__ __forceinline__ float bilinear(F fetch, int rows, int cols, WarpCoord c)
-{
-    const float fx = c.ax * (1.f / 32), fy = c.ay * (1.f / 32);
-    const float w0 = (1.f - fy) * (1.f - fx), w1 = (1.f - fy) * fx, w2 = fy * (1.f - fx), w3 = fy * fx;
-    const int sx = c.sx, sy = c.sy;
-    if ((unsigned)sx < (unsigned)(cols - 1) && (unsigned)sy < (unsigned)(rows - 1))
-        return fetch(sy, sx) * w0 + fetch(sy, sx + 1) * w1 + fetch(sy + 1, sx) * w2 + fetch(sy + 1, sx + 1) * w3;
-    if (sx >= cols || sx + 1 < 0 || sy >= rows || sy + 1 < 0) return 0.f;
-    const bool x0 = sx >= 0 && sx < cols, x1 = sx + 1 >= 0 && sx + 1 < cols;
-    const bool y0 = sy >= 0 && sy < rows, y1 = sy + 1 >= 0 && sy + 1 < rows;
-    const float v0 = (x0 && y0) ? fetch(sy, sx) : 0.f;
-    const float v1 = (x1 && y0) ? fetch(sy, sx + 1) : 0.f;
-    const float v2 = (x0 && y1) ? fetch(sy + 1, sx) : 0.f;
-    const float v3 = (x1 && y1) ? fetch(sy + 1, sx + 1) : 0.f;
-    return v0 * w0 + v1 * w1 + v2 * w2 + v3 * w3;
-}
-
-// per-frame ECC state
-struct EccState {
-    float M[6];
-    double rho, last_rho;
-    int iters;
-    int done;     // 1 converged / iteration cap, 2 identity (frame 0), <0 error
-    int band;     // pixels farther than this from every image edge have their whole bilinear footprint (and its
-                  // gradient taps) inside the image under M (ecc_band): ecc_interior_kernel takes them, ecc_border_kernel the rest
-};
-
-// Width of the border band for the warp M: an affine displacement |M p - p| is largest at a corner of the image; the
-// fixed-point source pixel is within 1.02 of M p, the footprint reaches 1 pixel before and 2 behind it.
-__device__ __forceinline__ int ecc_band(const float *Mf, int rows, int cols)
-{
-    double D = 0.0;
-    for (int cy = 0; cy < 2; ++cy)
-        for (int cx = 0; cx < 2; ++cx) {
-            const double x = cx ? cols - 1 : 0, y = cy ? rows - 1 : 0;
-            const double dx = fabs((double)Mf[0] * x + (double)Mf[1] * y + (double)Mf[2] - x);
-            const double dy = fabs((double)Mf[3] * x + (double)Mf[4] * y + (double)Mf[5] - y);
-            D = fmax(D, fmax(dx, dy));
-        }
-    if (!(D < 1.0e6)) return 1 << 24;      // (also NaN: everything is border)
-    return (int)ceil(D) + 3;
-}
-
 // cv::warpAffine(u16, M, INTER_LINEAR|NEAREST + WARP_INVERSE_MAP) for every frame.
 // list (may be null; [0] = count, then pixel indices): only the listed pixels are produced -- the warped frame of the
 // frame loop is a scratch image that nothing but the gather reads when registration is the last image stage, and the
@@ -493,1175 +382,6 @@ __global__ void __launch_bounds__(256)
     }
 }
 
-// --------------------------------------------------------------------- ECC --
-// Sum slots:
-//  0 n   1 Sw   2 Sww   3 St   4 Stt   5 Stw          (masked)
-//  6..11  S_all  J_k * w        12..17 S_mask J_k      18..23 S_mask J_k * t
-//  24..44 S_all  J_a * J_b  (a <= b, row-major upper triangle)
-// IDENT: every active frame still holds the identity warp (first iteration of register_pixel,
-// cpp/lib/registration.cpp:52-53): source pixel = target pixel, zero fractions, so the bilinear
-// weights are (1,0,0,0) and the general arithmetic reduces EXACTLY to the centre taps
-// (x*1 + y*0 + .. = x in float) -- 5 loads and no interpolation instead of 12 loads.
-//
-// One launch per iteration (ecc_sums2_kernel), the pixels split by WHERE they are:
-//   * interior blocks: pixels farther than EccState::band from every edge -- the whole 12-pixel footprint is inside
-//     the image and the nearest-neighbour mask is 1 by construction (ecc_band), so there is no test, no list and no
-//     fallback in the loop.  The inner rectangle is one index range split evenly over the blocks; a trip loads for
-//     several pixels per thread (identity iteration: 2 x 4 consecutive pixels from 16-B loads; general: 4 pixels)
-//     before it accumulates any, and lanes past the end of the range add zeros instead of branching;
-//   * band blocks: 2 x band rows + 2 x band columns (~1.5 % of a 1024^2 frame), generic bilinear with border
-//     handling; first in dispatch order so that their few long trips run beside the interior blocks.
-// Same per-pixel arithmetic everywhere, fixed order of the block partials (band slots, then interior slots).
-// (Round 2's first form was ONE sweep with a per-wave list of border pixels and an in-place fallback: 146 VGPRs, 3
-// waves per SIMD, every trip waiting a memory latency for its own loads -- 460 / 500 us per 64-frame launch for the
-// identity / a general iteration where the VALU work is 180 / 350 us; every attempt to put more loads in flight
-// INSIDE that loop made the compiler spend 220-256 registers.  Now 215 / 385 us.)
-__device__ __forceinline__ void ecc_accumulate(double (&acc)[kEccSums], float w, float gx, float gy, float t, bool m,
-                                               int x, int y)
-{
-    const float X = (float)x, Y = (float)y;
-    const float J[6] = {gx * X, gy * X, gx * Y, gy * Y, gx, gy};
-    const double mm = m ? 1.0 : 0.0, wd = w, td = t, tm = m ? td : 0.0, wm = m ? wd : 0.0;
-    acc[0] += mm;
-    acc[1] += wm;
-    acc[2] = fma(wm, wd, acc[2]);
-    acc[3] += tm;
-    acc[4] = fma(tm, td, acc[4]);
-    acc[5] = fma(tm, wd, acc[5]);
-    double Jd[6];
-#pragma unroll
-    for (int a = 0; a < 6; ++a) Jd[a] = (double)J[a];
-    int h = 24;
-#pragma unroll
-    for (int a = 0; a < 6; ++a) {
-        acc[6 + a] = fma(Jd[a], wd, acc[6 + a]);
-        acc[12 + a] = fma(Jd[a], mm, acc[12 + a]);
-        acc[18 + a] = fma(Jd[a], tm, acc[18 + a]);
-#pragma unroll
-        for (int b = a; b < 6; ++b) {
-            acc[h] = fma(Jd[a], Jd[b], acc[h]);
-            ++h;
-        }
-    }
-}
-
-// deterministic block reduction of the 45 sums: wave shuffle tree, then 4 waves through LDS
-__device__ __forceinline__ void ecc_block_store(const double (&acc)[kEccSums], double *__restrict__ partial, int f, int slot)
-{
-    __shared__ double red[4][kEccSums];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < kEccSums; ++k) {
-        double v = acc[k];
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-        if (lane == 0) red[wave][k] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < kEccSums) {
-        const double v = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
-        partial[((size_t)f * kEccSums + threadIdx.x) * kEccStride + slot] = v;
-    }
-}
-
-struct EccMargins { int top, bottom, left, right; };
-__device__ __forceinline__ EccMargins ecc_margins(int band, int rows, int cols)
-{
-    EccMargins g;
-    g.top = min(band, rows / 2);
-    g.bottom = min(band, rows - g.top);
-    g.left = min(band, cols / 2);
-    g.right = min(band, cols - g.left);
-    return g;
-}
-
-template <bool IDENT, int KP>
-__device__ __forceinline__ void ecc_interior_body(const float *__restrict__ img, const float *__restrict__ tmpl, int rows,
-                                                  int cols, const EccState *__restrict__ state,
-                                                  double *__restrict__ partial, int f, unsigned blk, unsigned nblk)
-{
-    const EccState &es = state[f];
-    const float *I = img + (size_t)f * rows * cols;
-    double acc[kEccSums];
-#pragma unroll
-    for (int k = 0; k < kEccSums; ++k) acc[k] = 0.0;
-    const EccMargins g = ecc_margins(IDENT ? 3 : es.band, rows, cols);
-    const int x_lo = g.left, x_hi = cols - g.right, y_lo = g.top, y_hi = rows - g.bottom;   // [lo, hi)
-    const int W = max(x_hi - x_lo, 0), H = max(y_hi - y_lo, 0);
-    // The inner rectangle as ONE index range split evenly over the blocks (whatever the image width: a trip always has
-    // all 256 lanes at work except at the end of the block's range); (column, row) carried along, no division per trip.
-    if (IDENT) {
-        // items = groups of four consecutive pixels of a row (the last group of a row may be short);
-        // source pixel = target pixel, zero fractions: w = I, gx / gy = central differences; mask 1
-        const unsigned G = ((unsigned)W + 3u) / 4u, total = G * (unsigned)H;
-        const unsigned per_block = (total + nblk - 1) / nblk;
-        const unsigned j_lo = min(total, blk * per_block), j_hi = min(total, j_lo + per_block);
-        unsigned j = j_lo + threadIdx.x;
-        unsigned gy = G ? j / G : 0u, gx = G ? j % G : 0u;
-        for (unsigned jb = j_lo; jb < j_hi; jb += 256u * KP) {     // (uniform trip count; lanes past the end add zeros)
-            float4 c[KP], u[KP], d[KP], t[KP];
-            float l[KP], r[KP];
-            int xs[KP], ys[KP];
-            bool in[KP];
-#pragma unroll
-            for (int k = 0; k < KP; ++k) {
-                in[k] = j < j_hi;
-                xs[k] = in[k] ? x_lo + 4 * (int)gx : x_lo;         // (lanes past the end: any address inside the image)
-                ys[k] = in[k] ? y_lo + (int)gy : y_lo;
-                const float *r1 = I + (size_t)ys[k] * cols + xs[k];
-                c[k] = *reinterpret_cast<const float4 *>(r1);      // (4-B aligned 16-B loads)
-                u[k] = *reinterpret_cast<const float4 *>(r1 - cols);
-                d[k] = *reinterpret_cast<const float4 *>(r1 + cols);
-                t[k] = *reinterpret_cast<const float4 *>(tmpl + (size_t)ys[k] * cols + xs[k]);
-                l[k] = r1[-1];
-                r[k] = r1[4];
-                j += 256u;
-                gx += 256u;
-                while (gx >= G && G) {
-                    gx -= G;
-                    ++gy;
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < KP; ++k) {
-                const int x = xs[k], y = ys[k];
-                const bool m0 = in[k], m1 = in[k] && x + 1 < x_hi, m2 = in[k] && x + 2 < x_hi, m3 = in[k] && x + 3 < x_hi;
-                __builtin_amdgcn_sched_barrier(0);
-                ecc_accumulate(acc, m0 ? c[k].x : 0.f, m0 ? -0.5f * l[k] + 0.5f * c[k].y : 0.f,
-                               m0 ? -0.5f * u[k].x + 0.5f * d[k].x : 0.f, m0 ? t[k].x : 0.f, m0, x, y);
-                __builtin_amdgcn_sched_barrier(0);
-                ecc_accumulate(acc, m1 ? c[k].y : 0.f, m1 ? -0.5f * c[k].x + 0.5f * c[k].z : 0.f,
-                               m1 ? -0.5f * u[k].y + 0.5f * d[k].y : 0.f, m1 ? t[k].y : 0.f, m1, x + 1, y);
-                __builtin_amdgcn_sched_barrier(0);
-                ecc_accumulate(acc, m2 ? c[k].z : 0.f, m2 ? -0.5f * c[k].y + 0.5f * c[k].w : 0.f,
-                               m2 ? -0.5f * u[k].z + 0.5f * d[k].z : 0.f, m2 ? t[k].z : 0.f, m2, x + 2, y);
-                __builtin_amdgcn_sched_barrier(0);
-                ecc_accumulate(acc, m3 ? c[k].w : 0.f, m3 ? -0.5f * c[k].z + 0.5f * r[k] : 0.f,
-                               m3 ? -0.5f * u[k].w + 0.5f * d[k].w : 0.f, m3 ? t[k].w : 0.f, m3, x + 3, y);
-            }
-        }
-    } else {
-        double M[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) M[i] = es.M[i];
-        const unsigned total = (unsigned)W * (unsigned)H;
-        const unsigned per_block = (total + nblk - 1) / nblk;
-        const unsigned q_lo = min(total, blk * per_block), q_hi = min(total, q_lo + per_block);
-        // the two terms of the fixed-point coordinate (WarpAffineInvoker's X0 / Y0 per row, adelta / bdelta per column),
-        // each rounded on its own, tabulated once per block: same integers as evaluating them per pixel
-        constexpr int kTabCols = 2048, kTabRows = 64;
-        __shared__ int2 ctab[kTabCols], rtab[kTabRows];
-        const unsigned ry_lo = W ? q_lo / (unsigned)W : 0u;
-        const unsigned nrows_blk = (q_hi > q_lo && W) ? (q_hi - 1u) / (unsigned)W - ry_lo + 1u : 0u;
-        const bool tab = cols <= kTabCols && nrows_blk <= (unsigned)kTabRows;
-        if (tab) {
-            for (int cx = threadIdx.x; cx < cols; cx += 256)
-                ctab[cx] = make_int2(__double2int_rn(M[0] * cx * 1024), __double2int_rn(M[3] * cx * 1024));
-            if (threadIdx.x < nrows_blk) {
-                const int yy = y_lo + (int)(ry_lo + threadIdx.x);
-                rtab[threadIdx.x] = make_int2(__double2int_rn((M[1] * yy + M[2]) * 1024), __double2int_rn((M[4] * yy + M[5]) * 1024));
-            }
-            __syncthreads();
-        }
-        unsigned q = q_lo + threadIdx.x;
-        unsigned py = W ? q / (unsigned)W : 0u, px = W ? q % (unsigned)W : 0u;     // (inside the inner rectangle)
-        for (unsigned qb = q_lo; qb < q_hi; qb += 256u * KP) {    // (uniform trip count; lanes past the end add zeros)
-            // KP pixels per thread and trip (q, q + 256, ..): KP x 13 loads in flight
-            float v[KP][12], t[KP], fx[KP], fy[KP];
-            int xs[KP], ys[KP];
-            bool on[KP];
-#pragma unroll
-            for (int k = 0; k < KP; ++k) {
-                on[k] = q < q_hi;
-                const unsigned ry = on[k] ? py : ry_lo;
-                xs[k] = on[k] ? x_lo + (int)px : x_lo;
-                ys[k] = y_lo + (int)ry;
-                int2 rt, ct;
-                if (tab) {
-                    rt = rtab[ry - ry_lo];
-                    ct = ctab[xs[k]];
-                } else {
-                    rt = make_int2(__double2int_rn((M[1] * ys[k] + M[2]) * 1024), __double2int_rn((M[4] * ys[k] + M[5]) * 1024));
-                    ct = make_int2(__double2int_rn(M[0] * xs[k] * 1024), __double2int_rn(M[3] * xs[k] * 1024));
-                }
-                const int Xr = rt.x + ct.x, Yr = rt.y + ct.y;
-                const int Xq = (Xr + 16) >> 5, Yq = (Yr + 16) >> 5;
-                const int sx = Xq >> 5, sy = Yq >> 5;     // (inside the image by construction: no saturation, no test)
-                fx[k] = (Xq & 31) * (1.f / 32);
-                fy[k] = (Yq & 31) * (1.f / 32);
-                const float *r0 = I + (unsigned)((sy - 1) * cols + sx);
-                const float *r1 = r0 + cols, *r2 = r1 + cols, *r3 = r2 + cols;
-                v[k][0] = r0[0]; v[k][1] = r0[1];
-                v[k][2] = r1[-1]; v[k][3] = r1[0]; v[k][4] = r1[1]; v[k][5] = r1[2];
-                v[k][6] = r2[-1]; v[k][7] = r2[0]; v[k][8] = r2[1]; v[k][9] = r2[2];
-                v[k][10] = r3[0]; v[k][11] = r3[1];
-                t[k] = tmpl[(size_t)ys[k] * cols + xs[k]];
-                q += 256u;
-                px += 256u;
-                while (px >= (unsigned)W && W) {
-                    px -= (unsigned)W;
-                    ++py;
-                }
-            }
-            float w[KP], gx[KP], gy[KP];
-#pragma unroll
-            for (int k = 0; k < KP; ++k) {
-                // bilinear of I, of [-0.5 0 0.5] along x and along y over the 12-pixel footprint
-                const float a0 = v[k][0], a1 = v[k][1];
-                const float b_1 = v[k][2], b0 = v[k][3], b1 = v[k][4], b2 = v[k][5];
-                const float c_1 = v[k][6], c0 = v[k][7], c1 = v[k][8], c2 = v[k][9];
-                const float d0 = v[k][10], d1 = v[k][11];
-                const float w0 = (1.f - fy[k]) * (1.f - fx[k]), w1 = (1.f - fy[k]) * fx[k], w2 = fy[k] * (1.f - fx[k]),
-                            w3 = fy[k] * fx[k];
-                w[k] = b0 * w0 + b1 * w1 + c0 * w2 + c1 * w3;
-                gx[k] = (-0.5f * b_1 + 0.5f * b1) * w0 + (-0.5f * b0 + 0.5f * b2) * w1 +
-                        (-0.5f * c_1 + 0.5f * c1) * w2 + (-0.5f * c0 + 0.5f * c2) * w3;
-                gy[k] = (-0.5f * a0 + 0.5f * c0) * w0 + (-0.5f * a1 + 0.5f * c1) * w1 +
-                        (-0.5f * b0 + 0.5f * d0) * w2 + (-0.5f * b1 + 0.5f * d1) * w3;
-            }
-#pragma unroll
-            for (int k = 0; k < KP; ++k)
-                ecc_accumulate(acc, on[k] ? w[k] : 0.f, on[k] ? gx[k] : 0.f, on[k] ? gy[k] : 0.f, on[k] ? t[k] : 0.f, on[k],
-                               xs[k], ys[k]);
-        }
-    }
-    ecc_block_store(acc, partial, f, (int)(kEccBorderBlocks + blk));
-}
-
-// The band: top and bottom strips over the full width, left and right strips between them; generic bilinear
-// (border value 0, reflect-101 gradient taps), nearest-neighbour mask evaluated.  Workgroups first_slot .. first_slot +
-// kEccBorderBlocks - 1 of the same launch as the interior ones (as a launch of its own the band cost 55 us per 64 frames
-// behind 190 / 350 us of interior: a few trips of long dependent chains that nothing overlapped).
-__device__ __forceinline__ void ecc_border_body(const float *__restrict__ img, const float *__restrict__ tmpl, int rows,
-                                                int cols, const EccState *__restrict__ state, double *__restrict__ partial,
-                                                int f, unsigned bidx, int ident)
-{
-    const EccState &es = state[f];
-    const float *I = img + (size_t)f * rows * cols;
-    double M[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) M[i] = es.M[i];
-    double acc[kEccSums];
-#pragma unroll
-    for (int k = 0; k < kEccSums; ++k) acc[k] = 0.0;
-    auto pix = [&](int yy, int xx) { return I[(size_t)yy * cols + xx]; };
-    auto gxf = [&](int yy, int xx) {
-        return -0.5f * pix(yy, reflect101(xx - 1, cols)) + 0.5f * pix(yy, reflect101(xx + 1, cols));
-    };
-    auto gyf = [&](int yy, int xx) {
-        return -0.5f * pix(reflect101(yy - 1, rows), xx) + 0.5f * pix(reflect101(yy + 1, rows), xx);
-    };
-    const EccMargins g = ecc_margins(ident ? 3 : es.band, rows, cols);
-    const int H = rows - g.top - g.bottom, side = g.left + g.right;
-    // (32-bit indices: run_ecc refuses images of 2^31 pixels)
-    const unsigned n_top = (unsigned)g.top * (unsigned)cols, n_bot = (unsigned)g.bottom * (unsigned)cols,
-                   n_side = (unsigned)H * (unsigned)side;
-    const unsigned total = n_top + n_bot + n_side;
-    for (unsigned j = bidx * 256u + threadIdx.x; j < total; j += (unsigned)kEccBorderBlocks * 256u) {
-        int x, y;
-        if (j < n_top) {
-            y = (int)(j / (unsigned)cols);
-            x = (int)(j % (unsigned)cols);
-        } else if (j < n_top + n_bot) {
-            const unsigned q = j - n_top;
-            y = rows - g.bottom + (int)(q / (unsigned)cols);
-            x = (int)(q % (unsigned)cols);
-        } else {
-            const unsigned q = j - n_top - n_bot;
-            y = g.top + (int)(q / (unsigned)side);
-            const int k = (int)(q % (unsigned)side);
-            x = k < g.left ? k : cols - side + k;
-        }
-        const int Xr = __double2int_rn((M[1] * y + M[2]) * 1024) + __double2int_rn(M[0] * x * 1024);
-        const int Yr = __double2int_rn((M[4] * y + M[5]) * 1024) + __double2int_rn(M[3] * x * 1024);
-        const int Xq = (Xr + 16) >> 5, Yq = (Yr + 16) >> 5;
-        WarpCoord c;
-        c.sx = max(-32768, min(32767, Xq >> 5));
-        c.sy = max(-32768, min(32767, Yq >> 5));
-        c.ax = Xq & 31;
-        c.ay = Yq & 31;
-        const int nx = max(-32768, min(32767, (Xr + 512) >> 10)), ny = max(-32768, min(32767, (Yr + 512) >> 10));
-        const bool m = (unsigned)nx < (unsigned)cols && (unsigned)ny < (unsigned)rows;
-        float w, gx, gy;
-        if (c.sx >= 1 && c.sx + 2 < cols && c.sy >= 1 && c.sy + 2 < rows) {
-            // footprint and gradient taps inside the image (all of the band but its outermost ring or two): the 12 pixels
-            // directly -- the generic path below evaluates to the same operations on the same values
-            const float *r0 = I + (unsigned)((c.sy - 1) * cols + c.sx);
-            const float *r1 = r0 + cols, *r2 = r1 + cols, *r3 = r2 + cols;
-            const float a0 = r0[0], a1 = r0[1];
-            const float b_1 = r1[-1], b0 = r1[0], b1 = r1[1], b2 = r1[2];
-            const float c_1 = r2[-1], c0 = r2[0], c1 = r2[1], c2 = r2[2];
-            const float d0 = r3[0], d1 = r3[1];
-            const float fx = c.ax * (1.f / 32), fy = c.ay * (1.f / 32);
-            const float w0 = (1.f - fy) * (1.f - fx), w1 = (1.f - fy) * fx, w2 = fy * (1.f - fx), w3 = fy * fx;
-            w = b0 * w0 + b1 * w1 + c0 * w2 + c1 * w3;
-            gx = (-0.5f * b_1 + 0.5f * b1) * w0 + (-0.5f * b0 + 0.5f * b2) * w1 +
-                 (-0.5f * c_1 + 0.5f * c1) * w2 + (-0.5f * c0 + 0.5f * c2) * w3;
-            gy = (-0.5f * a0 + 0.5f * c0) * w0 + (-0.5f * a1 + 0.5f * c1) * w1 +
-                 (-0.5f * b0 + 0.5f * d0) * w2 + (-0.5f * b1 + 0.5f * d1) * w3;
-        } else {
-            w = bilinear(pix, rows, cols, c);
-            gx = bilinear(gxf, rows, cols, c);
-            gy = bilinear(gyf, rows, cols, c);
-        }
-        ecc_accumulate(acc, w, gx, gy, tmpl[(size_t)y * cols + x], m, x, y);
-    }
-    ecc_block_store(acc, partial, f, (int)bidx);
-}
-
-// ---- interior of the frame, round 3: one COLUMN per thread ------------------------------------------------------
-// The 45 sums are products of three things: the warped gradients {gx, gy}, the pixel coordinates {X, Y, 1} and
-// {w, 1, t} (or a second gradient).  A thread that owns ONE column x and walks down its rows has a constant X, so X
-// comes out of every sum and is multiplied in once, at the end; Y is the row offset r inside a segment of kEccFlush
-// rows (a small exact integer), shifted to the true row when the segment's partial sums are folded into the thread's
-// double totals.  What is left per pixel are 21 sums
-//     {gx, gy} x {1, w, t} x {1, r}        12        {gx^2, gy^2, gx gy} x {1, r, r^2}     9
-// accumulated as packed float pairs (v_pk_fma_f32) over at most kEccFlush rows, + the five scalar sums of w and t
-// in double (they decide rho, i.e. the iteration count): ~22 VALU instructions per pixel where the 45 double sums of
-// round 2 took ~75, and the fixed-point source coordinate splits into a per-thread column term and a per-row term
-// from a small LDS table (~10 instead of ~45).  Float partials: a segment sum of <= 32 terms carries a relative
-// error of <~1e-7, random over the 30 000 segments of a frame -- the same order as the float rounding of every
-// Jacobian element in cv::findTransformECC itself, and five orders below the 1e-4 parity bar (tests: same iteration
-// counts, |dM| ~ 1e-7).  The identity iteration (5 loads, no interpolation) becomes memory-bound.
-typedef float v2f __attribute__((ext_vector_type(2)));
-constexpr int kEccFlush = 32;        // rows per float segment
-constexpr int kEccRowTab = 3840;     // rows of one block's piece at most: their per-row coordinate terms are tabulated in LDS
-
-struct EccPart {        // float partial sums of one segment
-    v2f G0, G1, Gw0, Gw1, Gt0, Gt1, Q0, Q1, Q2, C01;
-    float C2;
-};
-struct EccTot {         // double totals of the thread's column piece (Y = true row)
-    double G0[2], G1[2], Gw0[2], Gw1[2], Gt0[2], Gt1[2], Q0[2], Q1[2], Q2[2], C0, C1, C2;
-    double Sw, Sww, St, Stt, Stw, n;
-    float cf;           // centre: the float products are taken with (w - cf) and (t - cf), see ecc_part_add
-};
-
-__device__ __forceinline__ void ecc_part_zero(EccPart &p)
-{
-    const v2f z = {0.f, 0.f};
-    p.G0 = p.G1 = p.Gw0 = p.Gw1 = p.Gt0 = p.Gt1 = p.Q0 = p.Q1 = p.Q2 = p.C01 = z;
-    p.C2 = 0.f;
-}
-
-// one pixel: warped value w, warped gradients gx / gy, template t, row offset rf (= r as a float) in its segment.
-// MASKED (band pixels): m = the nearest-neighbour mask of cv::findTransformECC; masked sums as in ecc_accumulate
-// (n, the scalar sums, sum_mask J, sum_mask J t), the others over all pixels.
-// Interior pixels: the products with w and t are taken with (w - c), (t - c), c = T.cf = an INTEGER near the template's mean
-// (ecc_center_kernel), and c x (sum of the gradients) is added back in double at the end (ecc_tot_value).  The
-// subtraction is exact (12-bit images blurred to floats below 4096 minus an integer below 4096), the identity
-// sum g w = sum g (w - c) + c sum g too; what changes is the size of the numbers that get rounded: a product g w with
-// w ~ 1800 carries an absolute rounding error of |g| x 1e-4, the same product with |w - c| ~ 100 a tenth of that --
-// and what the solve uses is sum J w - mean(w) sum J, a difference that used to cancel the leading 1-2 digits of these
-// sums (measured on a 49 x 888 frame against sums taken in exact arithmetic: relative error of sum gy w 3.2e-8 ->
-// see DESIGN.md section 8; the reference rounds every one of these sums to FLOAT before its 6 x 6 solve, so a sum that
-// lands on another float moves the result by a float ulp amplified by the solve).
-template <bool MASKED>
-__device__ __forceinline__ void ecc_part_add(EccPart &p, EccTot &T, float w, float gx, float gy, float t, float rf, bool m = true)
-{
-    const float wc = MASKED ? w : w - T.cf, tc = MASKED ? t : t - T.cf;
-    const v2f G = {gx, gy}, R = {rf, rf}, W = {wc, wc}, Tt = {tc, tc};
-    const v2f Z = {0.f, 0.f};
-    const v2f Gm = (MASKED && !m) ? Z : G;
-    const float rf2 = rf * rf;
-    const v2f R2 = {rf2, rf2};
-    p.G0 += Gm;
-    p.G1 = __builtin_elementwise_fma(Gm, R, p.G1);
-    const v2f Gw = G * W, Gt = Gm * Tt, Q = G * G;
-    p.Gw0 += Gw;
-    p.Gw1 = __builtin_elementwise_fma(Gw, R, p.Gw1);
-    p.Gt0 += Gt;
-    p.Gt1 = __builtin_elementwise_fma(Gt, R, p.Gt1);
-    p.Q0 += Q;
-    p.Q1 = __builtin_elementwise_fma(Q, R, p.Q1);
-    p.Q2 = __builtin_elementwise_fma(Q, R2, p.Q2);
-    const float c = gx * gy;
-    const v2f Cc = {c, c}, R01 = {1.f, rf};
-    p.C01 = __builtin_elementwise_fma(Cc, R01, p.C01);
-    p.C2 = __builtin_fmaf(c, rf2, p.C2);
-    const double wd = w, td = t;
-    const double wm = (MASKED && !m) ? 0.0 : wd, tm = (MASKED && !m) ? 0.0 : td;
-    if (MASKED) T.n += m ? 1.0 : 0.0;
-    T.Sw += wm;
-    T.Sww = fma(wm, wd, T.Sww);
-    T.St += tm;
-    T.Stt = fma(tm, td, T.Stt);
-    T.Stw = fma(tm, wd, T.Stw);
-}
-
-// segment -> totals: rows of the segment are yb + r
-__device__ __forceinline__ void ecc_part_flush(const EccPart &p, EccTot &T, int yb)
-{
-    const double Y = (double)yb, Y2 = Y * Y, Yd = 2.0 * Y;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const double g0 = p.G0[k], g1 = p.G1[k], gw0 = p.Gw0[k], gw1 = p.Gw1[k], gt0 = p.Gt0[k], gt1 = p.Gt1[k];
-        const double q0 = p.Q0[k], q1 = p.Q1[k], q2 = p.Q2[k];
-        T.G0[k] += g0;
-        T.G1[k] += fma(Y, g0, g1);
-        T.Gw0[k] += gw0;
-        T.Gw1[k] += fma(Y, gw0, gw1);
-        T.Gt0[k] += gt0;
-        T.Gt1[k] += fma(Y, gt0, gt1);
-        T.Q0[k] += q0;
-        T.Q1[k] += fma(Y, q0, q1);
-        T.Q2[k] += fma(Y2, q0, fma(Yd, q1, q2));
-    }
-    const double c0 = p.C01[0], c1 = p.C01[1], c2 = p.C2;
-    T.C0 += c0;
-    T.C1 += fma(Y, c0, c1);
-    T.C2 += fma(Y2, c0, fma(Yd, c1, c2));
-}
-
-// the k-th of the 45 sums (layout of ecc_accumulate) from a thread's totals and its column X
-template <int K>
-__device__ __forceinline__ double ecc_tot_value(const EccTot &T, double X)
-{
-    const double X2 = X * X, c = (double)T.cf;      // (sum g w = sum g (w - c) + c sum g: exact, in double)
-    switch (K) {
-    case 0: return T.n;
-    case 1: return T.Sw;
-    case 2: return T.Sww;
-    case 3: return T.St;
-    case 4: return T.Stt;
-    case 5: return T.Stw;
-    case 6: return X * (T.Gw0[0] + c * T.G0[0]);
-    case 7: return X * (T.Gw0[1] + c * T.G0[1]);
-    case 8: return T.Gw1[0] + c * T.G1[0];
-    case 9: return T.Gw1[1] + c * T.G1[1];
-    case 10: return T.Gw0[0] + c * T.G0[0];
-    case 11: return T.Gw0[1] + c * T.G0[1];
-    case 12: return X * T.G0[0];
-    case 13: return X * T.G0[1];
-    case 14: return T.G1[0];
-    case 15: return T.G1[1];
-    case 16: return T.G0[0];
-    case 17: return T.G0[1];
-    case 18: return X * (T.Gt0[0] + c * T.G0[0]);
-    case 19: return X * (T.Gt0[1] + c * T.G0[1]);
-    case 20: return T.Gt1[0] + c * T.G1[0];
-    case 21: return T.Gt1[1] + c * T.G1[1];
-    case 22: return T.Gt0[0] + c * T.G0[0];
-    case 23: return T.Gt0[1] + c * T.G0[1];
-    // J J^T, upper triangle row-major, J = [gx X, gy X, gx Y, gy Y, gx, gy]
-    case 24: return X2 * T.Q0[0];     // (0,0) gx^2 X^2
-    case 25: return X2 * T.C0;        // (0,1) gx gy X^2
-    case 26: return X * T.Q1[0];      // (0,2) gx^2 X Y
-    case 27: return X * T.C1;         // (0,3) gx gy X Y
-    case 28: return X * T.Q0[0];      // (0,4) gx^2 X
-    case 29: return X * T.C0;         // (0,5) gx gy X
-    case 30: return X2 * T.Q0[1];     // (1,1) gy^2 X^2
-    case 31: return X * T.C1;         // (1,2) gy gx X Y
-    case 32: return X * T.Q1[1];      // (1,3) gy^2 X Y
-    case 33: return X * T.C0;         // (1,4) gy gx X
-    case 34: return X * T.Q0[1];      // (1,5) gy^2 X
-    case 35: return T.Q2[0];          // (2,2) gx^2 Y^2
-    case 36: return T.C2;             // (2,3) gx gy Y^2
-    case 37: return T.Q1[0];          // (2,4) gx^2 Y
-    case 38: return T.C1;             // (2,5) gx gy Y
-    case 39: return T.Q2[1];          // (3,3) gy^2 Y^2
-    case 40: return T.C1;             // (3,4) gy gx Y
-    case 41: return T.Q1[1];          // (3,5) gy^2 Y
-    case 42: return T.Q0[0];          // (4,4) gx^2
-    case 43: return T.C0;             // (4,5) gx gy
-    default: return T.Q0[1];          // (5,5) gy^2
-    }
-}
-
-// One step of a sum over the lanes of a DPP row with moves only (no ds_bpermute round trips: 45 sums x 6 dependent
-// shuffle steps were a ~25 000-cycle latency chain at the end of every block).
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_add_f64(double v)
-{
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xFFFFFFFFll), CTRL, ROW_MASK, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xF, false);
-    return v + __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);   // (rows outside the mask add 0.0)
-}
-
-// Block reduction of the 45 sums straight from the totals, through LDS in three chunks of 15 (the 45 doubles of a
-// thread never exist at once): every thread writes its 15 values, thread (v, p) = (t / 16, t % 16) adds 16 of the 256
-// entries of value v (stride 16: conflict-free), the 16 partials of a value sit in one DPP row and are added there.
-// ~80 instructions per chunk and thread where the wave-wide DPP reduction of every value took ~30 per VALUE -- 1400
-// per thread, a third of the identity kernel's VALU instructions (PMC, profiles/r03_ecc_pmc.txt).  Fixed order: deterministic.
-constexpr int kEccChunk = 15;
-static_assert(kEccSums == 3 * kEccChunk, "three chunks");
-// A block's 45 partial sums leave either as plain stores (the solve is the next launch) or, when the LAST block of the frame
-// solves in the same launch (ecc_cols_kernel<..., FUSE>), as device-scope atomic exchanges: performed at the memory side,
-// coherent across the 8 XCDs without an L2 write-back (hot_scan_kernel's hand-off).  g_ecc_sink takes the exchanges'
-// return values so that they have completed before the block's barrier and ticket.
-struct EccOut {
-    double *partial;
-    bool atomic;
-    unsigned long long sink;
-};
-__device__ __forceinline__ void ecc_out_put(EccOut &o, size_t idx, double v)
-{
-    if (o.atomic)
-        o.sink |= atomicExch(reinterpret_cast<unsigned long long *>(o.partial + idx), (unsigned long long)__double_as_longlong(v));
-    else
-        o.partial[idx] = v;
-}
-template <int C, int J>
-__device__ __forceinline__ void ecc_tot_put(const EccTot &T, double X, bool on, double (*lds)[256])
-{
-    lds[J][threadIdx.x] = on ? ecc_tot_value<C * kEccChunk + J>(T, X) : 0.0;
-    if constexpr (J + 1 < kEccChunk) ecc_tot_put<C, J + 1>(T, X, on, lds);
-}
-template <int C>
-__device__ __forceinline__ void ecc_tot_store(const EccTot &T, double X, bool on, double (*lds)[256],
-                                              EccOut &out, int f, unsigned slot)
-{
-    ecc_tot_put<C, 0>(T, X, on, lds);
-    __syncthreads();
-    const int v = (int)threadIdx.x >> 4, p = (int)threadIdx.x & 15;
-    if (v < kEccChunk) {                       // (waves 0 .. 3, whole DPP rows)
-        double s = 0.0;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) s += lds[v][j * 16 + p];
-        s = dpp_add_f64<0xB1, 0xF>(s);
-        s = dpp_add_f64<0x4E, 0xF>(s);
-        s = dpp_add_f64<0x141, 0xF>(s);
-        s = dpp_add_f64<0x140, 0xF>(s);        // every lane of the row holds the block's sum of value v
-        if (p == 0) ecc_out_put(out, ((size_t)f * kEccSums + (C * kEccChunk + v)) * kEccStride + slot, s);
-    }
-    __syncthreads();
-    if constexpr (C + 1 < 3) ecc_tot_store<C + 1>(T, X, on, lds, out, f, slot);
-}
-
-// a block without any pixel: its partial sums are zero
-__device__ __forceinline__ void ecc_store_zeros(EccOut &out, int f, unsigned slot)
-{
-    if (threadIdx.x < kEccSums) ecc_out_put(out, ((size_t)f * kEccSums + threadIdx.x) * kEccStride + slot, 0.0);
-}
-
-// Identity iteration with NEIGHBOUR = 1: the left / right taps come from the neighbouring lanes' centre values by DPP
-// wave shifts (lane 0 and lane 63 load theirs: one load instruction per row under a two-lane exec mask), so a trip is
-// UR + 2 column loads + UR template loads -- registers and load slots that go into more rows in flight: the kernel is
-// bound by the bytes it keeps in flight (measured: 8 rows per trip against 4 ...).  Every lane of the wave must run
-// the trip (lanes past the rectangle read valid columns and are left out of the reduction).
-// uniform base + 32-bit BYTE offset of the lane (+ a constant): the form the compiler turns into
-// `global_load_dword v, v_off, s[base] offset:imm` -- one 32-bit add per ROW of a trip instead of a 64-bit shift-and-add
-// per LOAD (26 of the 239 VALU instructions of a general two-row trip, 32 of 166 in the identity trip)
-template <int IMM = 0>
-__device__ __forceinline__ float ld_f32(const float *base, unsigned byte_off)
-{
-    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off + IMM);
-}
-
-template <int IMM = 0>
-__device__ __forceinline__ v2f ld_v2f(const float *base, unsigned byte_off)      // two consecutive pixels, one 8-byte load
-{
-    return *reinterpret_cast<const v2f *>(reinterpret_cast<const char *>(base) + byte_off + IMM);
-}
-
-template <bool IDENT, int UR, int NEIGHBOUR = 0, int GXD = 1, int SHARE = 0>
-__device__ __forceinline__ void ecc_cols_trip(const float *__restrict__ I, const float *__restrict__ tmpl, int cols, int x,
-                                              int y, int r, int ax, int bx, const int2 *rtab, int rt0, const double *M,
-                                              EccPart &P, EccTot &T)
-{
-    if (IDENT && NEIGHBOUR) {
-        // (uniform base + 32-bit lane offsets: one address register per load instead of a 64-bit pair)
-        const unsigned pitch = 4u * (unsigned)cols, o0 = 4u * (unsigned)(y * cols + x);
-        const int lane = threadIdx.x & 63;
-        float cc[UR + 2], tt[UR], hh[UR];
-        unsigned ob[UR + 2];
-#pragma unroll
-        for (int k = 0; k < UR + 2; ++k) ob[k] = o0 + (unsigned)(k - 1) * pitch;
-#pragma unroll
-        for (int k = 0; k < UR + 2; ++k) cc[k] = ld_f32(I, ob[k]);
-#pragma unroll
-        for (int k = 0; k < UR; ++k) tt[k] = ld_f32(tmpl, ob[k + 1]);
-#pragma unroll
-        for (int k = 0; k < UR; ++k) hh[k] = 0.f;
-        if (lane == 0) {
-#pragma unroll
-            for (int k = 0; k < UR; ++k) hh[k] = ld_f32<-4>(I, ob[k + 1]);
-        } else if (lane == 63) {
-#pragma unroll
-            for (int k = 0; k < UR; ++k) hh[k] = ld_f32<4>(I, ob[k + 1]);
-        }
-#pragma unroll
-        for (int k = 0; k < UR; ++k) {
-            // wave_shr:1 -> lane i reads lane i - 1 (lane 0 keeps `old` = its loaded halo); wave_shl:1 -> lane i + 1
-            const float l = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(hh[k]), __float_as_int(cc[k + 1]), 0x138, 0xF, 0xF, false));
-            const float rr = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(hh[k]), __float_as_int(cc[k + 1]), 0x130, 0xF, 0xF, false));
-            __builtin_amdgcn_sched_barrier(0);      // one row after the other: the rows' temporaries must not all be live at once
-            ecc_part_add<false>(P, T, cc[k + 1], 0.5f * (rr - l), 0.5f * (cc[k + 2] - cc[k]), tt[k], (float)(r + k));   // (= -a/2 + b/2 exactly)
-        }
-    } else if (IDENT) {
-        // source pixel = target pixel: w = I, gradients = central differences of I (zero fractions make the bilinear
-        // weights (1,0,0,0), so the general arithmetic reduces exactly to these taps)
-        const unsigned pitch = 4u * (unsigned)cols, o0 = 4u * (unsigned)(y * cols + x);
-        float cc[UR + 2], ll[UR], rr[UR], tt[UR];
-        unsigned ob[UR + 2];
-#pragma unroll
-        for (int k = 0; k < UR + 2; ++k) ob[k] = o0 + (unsigned)(k - 1) * pitch;
-#pragma unroll
-        for (int k = 0; k < UR + 2; ++k) cc[k] = ld_f32(I, ob[k]);
-#pragma unroll
-        for (int k = 0; k < UR; ++k) {
-            ll[k] = ld_f32<-4>(I, ob[k + 1]);
-            rr[k] = ld_f32<4>(I, ob[k + 1]);
-            tt[k] = ld_f32(tmpl, ob[k + 1]);
-        }
-#pragma unroll
-        for (int k = 0; k < UR; ++k)
-            ecc_part_add<false>(P, T, cc[k + 1], 0.5f * (rr[k] - ll[k]), 0.5f * (cc[k + 2] - cc[k]), tt[k], (float)(r + k));
-    } else {
-        // footprint of a pixel (rows sy-1 .. sy+2 = a, b, c, d; columns sx-1 .. sx+2 = _1, 0, 1, 2), loaded so that the
-        // pairs the arithmetic works on are the pairs the loads deliver: {a0,a1} {b0,b1} {c0,c1} {d0,d1} from 8-byte loads,
-        // {b_1,b2} {c_1,c2} from two 4-byte loads each
-        v2f A[UR], Bm[UR], Cm[UR], D[UR], Be[UR], Ce[UR];
-        float tt[UR], fx[UR], fy[UR];
-        int sxk[UR], syk[UR];
-        const unsigned pitch = 4u * (unsigned)cols, ot = 4u * (unsigned)(y * cols + x);
-#pragma unroll
-        for (int k = 0; k < UR; ++k) {
-            // WarpAffineInvoker's fixed-point coordinate: per-row term (LDS table of the block's rows) + per-column term,
-            // each rounded on its own
-            const int2 rt = rtab[y + k - rt0];
-            const int Xr = rt.x + ax, Yr = rt.y + bx;
-            const int Xq = (Xr + 16) >> 5, Yq = (Yr + 16) >> 5;
-            sxk[k] = Xq >> 5;                            // (footprint inside the image by construction: ecc_band)
-            syk[k] = Yq >> 5;
-            fx[k] = (Xq & 31) * (1.f / 32);
-            fy[k] = (Yq & 31) * (1.f / 32);
-        }
-        // SHARE (two rows per trip): under a warp near the identity the second pixel's footprint is the first one's moved down
-        // by exactly one row -- rows a, b, c of the second are rows b, c, d of the first.  When that holds for EVERY lane of
-        // the wave (uniform branch), the second pixel loads only what is new: the two outer pixels of its row c and its row d:
-        // 11 instead of 16 source loads per trip, the same values in the same registers' roles, so the same bits.
-        bool shared = false;
-        if (SHARE && UR == 2) shared = __all(sxk[1 % UR] == sxk[0] && syk[1 % UR] == syk[0] + 1) != 0;
-#pragma unroll
-        for (int k = 0; k < UR; ++k) {
-            // (rows and columns < 2^15 here: 24-bit multiply, full rate)
-            const unsigned q0 = 4u * (unsigned)(__mul24(syk[k] - 1, cols) + sxk[k]), q1 = q0 + pitch, q2 = q1 + pitch, q3 = q2 + pitch;
-            if (SHARE && UR == 2 && k == 1 && shared) {
-                Ce[k][0] = ld_f32<-4>(I, q2);
-                Ce[k][1] = ld_f32<8>(I, q2);
-                D[k] = ld_v2f(I, q3);
-            } else {
-                A[k] = ld_v2f(I, q0);
-                Be[k][0] = ld_f32<-4>(I, q1);
-                Bm[k] = ld_v2f(I, q1);
-                Be[k][1] = ld_f32<8>(I, q1);
-                Ce[k][0] = ld_f32<-4>(I, q2);
-                Cm[k] = ld_v2f(I, q2);
-                Ce[k][1] = ld_f32<8>(I, q2);
-                D[k] = ld_v2f(I, q3);
-            }
-            tt[k] = ld_f32(tmpl, ot + (unsigned)k * pitch);
-        }
-        if (SHARE && UR == 2 && shared) {
-            A[1 % UR] = Bm[0];
-            Be[1 % UR] = Ce[0];
-            Bm[1 % UR] = Cm[0];
-            Cm[1 % UR] = D[0];
-        }
-#pragma unroll
-        for (int k = 0; k < UR; ++k) {
-            // Bilinear interpolation of I and of its central differences along x and y (cv::findTransformECC warps the two
-            // gradient IMAGES).  All three are linear in the pixels, so with V_j = the vertical interpolation at column j
-            //     w  = V_0 + fx (V_1 - V_0)
-            //     gx = 1/2 [ q_0 + fx (q_1 - q_0) ],   q = (b_+ - b_-) + fy ((c_+ - c_-) - (b_+ - b_-))  at columns 0, 1
-            //     gy = 1/2 [ p_0 + fx (p_1 - p_0) ],   p = (c - a) + fy ((d - b) - (c - a))  at columns 0, 1
-            // -- 19 instructions where the four-weight form of round 2 took ~50.  With zero fractions (identity) these
-            // are exactly the taps of the identity iteration: V_j = b_j, w = b_0, gx = (b_1 - b_-1) / 2, gy = (c_0 - a_0) / 2.
-            // (gx from the horizontal DIFFERENCES of the pixels, interpolated -- not from differences of the interpolated
-            //  V_j: those carry the rounding of values ~2000, 1e-4, into a gradient of a few counts, 1e-5 relative, where the
-            //  reference's warped gradient image is good to 1e-7; the ECC iteration amplifies that on small or weakly
-            //  textured images -- tests/debug/soak_ecc.py found it, 8e-3 px on a 97 x 258 frame.  Two instructions more.)
-            const v2f FY = {fy[k], fy[k]};
-            const v2f Vm = __builtin_elementwise_fma(FY, Cm[k] - Bm[k], Bm[k]);     // {V_0, V_1}
-            const float w = __builtin_fmaf(fx[k], Vm[1] - Vm[0], Vm[0]);
-            float gx;
-            if (GXD) {
-                // q_j = (b_+ - b_-) + fy ((c_+ - c_-) - (b_+ - b_-)), the bracket regrouped as (c_+ - b_+) - (c_- - b_-) so that the
-                // packed differences the loads deliver as pairs (Cm - Bm, Ce - Be) are used as they are
-                const v2f Dm = Cm[k] - Bm[k], De = Ce[k] - Be[k];                     // {c0-b0, c1-b1}, {c_1-b_1, c2-b2}
-                const float q0 = __builtin_fmaf(fy[k], Dm[1] - De[0], Bm[k][1] - Be[k][0]);
-                const float q1 = __builtin_fmaf(fy[k], De[1] - Dm[0], Be[k][1] - Bm[k][0]);
-                gx = 0.5f * __builtin_fmaf(fx[k], q1 - q0, q0);
-            } else {      // (measurement switch UPSP_ECC_GX=0: the first form, differences of the interpolated columns)
-                const v2f Ve = __builtin_elementwise_fma(FY, Ce[k] - Be[k], Be[k]);     // {V_-1, V_2}
-                const float dx0 = Vm[1] - Ve[0], dx1 = Ve[1] - Vm[0];
-                gx = 0.5f * __builtin_fmaf(fx[k], dx1 - dx0, dx0);
-            }
-            const v2f E = Cm[k] - A[k], F = D[k] - Bm[k];
-            const v2f Pp = __builtin_elementwise_fma(FY, F - E, E);
-            const float gy = 0.5f * __builtin_fmaf(fx[k], Pp[1] - Pp[0], Pp[0]);
-            ecc_part_add<false>(P, T, w, gx, gy, tt[k], (float)(r + k));
-        }
-    }
-}
-
-// One row of the general iteration split into its loads and its sums, for the software-pipelined walk below: the 12 source pixels
-// + the template pixel of row y of this thread's column (same loads, same arithmetic as ecc_cols_trip's general path).
-struct EccRow {
-    v2f A, Bm, Cm, D, Be, Ce;
-    float tt, fx, fy;
-};
-__device__ __forceinline__ EccRow ecc_row_load(const float *__restrict__ I, const float *__restrict__ tmpl, int cols, int x, int y,
-                                               int ax, int bx, const int2 *rtab, int rt0)
-{
-    EccRow q;
-    const unsigned pitch = 4u * (unsigned)cols;
-    const int2 rt = rtab[y - rt0];
-    const int Xr = rt.x + ax, Yr = rt.y + bx;
-    const int Xq = (Xr + 16) >> 5, Yq = (Yr + 16) >> 5;
-    const int sx = Xq >> 5, sy = Yq >> 5;
-    q.fx = (Xq & 31) * (1.f / 32);
-    q.fy = (Yq & 31) * (1.f / 32);
-    const unsigned q0 = 4u * (unsigned)(__mul24(sy - 1, cols) + sx), q1 = q0 + pitch, q2 = q1 + pitch, q3 = q2 + pitch;
-    q.A = ld_v2f(I, q0);
-    q.Be[0] = ld_f32<-4>(I, q1);
-    q.Bm = ld_v2f(I, q1);
-    q.Be[1] = ld_f32<8>(I, q1);
-    q.Ce[0] = ld_f32<-4>(I, q2);
-    q.Cm = ld_v2f(I, q2);
-    q.Ce[1] = ld_f32<8>(I, q2);
-    q.D = ld_v2f(I, q3);
-    q.tt = ld_f32(tmpl, 4u * (unsigned)(y * cols + x));
-    return q;
-}
-__device__ __forceinline__ void ecc_row_sum(const EccRow &q, EccPart &P, EccTot &T, float rf)
-{
-    const v2f FY = {q.fy, q.fy};
-    const v2f Vm = __builtin_elementwise_fma(FY, q.Cm - q.Bm, q.Bm);
-    const float w = __builtin_fmaf(q.fx, Vm[1] - Vm[0], Vm[0]);
-    const v2f Dm = q.Cm - q.Bm, De = q.Ce - q.Be;
-    const float g0 = __builtin_fmaf(q.fy, Dm[1] - De[0], q.Bm[1] - q.Be[0]);
-    const float g1 = __builtin_fmaf(q.fy, De[1] - Dm[0], q.Be[1] - q.Bm[0]);
-    const float gx = 0.5f * __builtin_fmaf(q.fx, g1 - g0, g0);
-    const v2f E = q.Cm - q.A, F = q.D - q.Bm;
-    const v2f Pp = __builtin_elementwise_fma(FY, F - E, E);
-    const float gy = 0.5f * __builtin_fmaf(q.fx, Pp[1] - Pp[0], Pp[0]);
-    ecc_part_add<false>(P, T, w, gx, gy, q.tt, rf);
-}
-// rows [y0, y1) of the column, the loads of rows y + 1 and y + 2 in flight while row y is summed (three row slots rotating;
-// float segments of kEccFlush rows from y0 exactly like the trip loop: the same sums in the same order, the same bits)
-__device__ __forceinline__ void ecc_rows_pipelined(const float *__restrict__ I, const float *__restrict__ tmpl, int cols, int x,
-                                                   int y0, int y1, int ax, int bx, const int2 *rtab, EccTot &T)
-{
-    EccPart P;
-    ecc_part_zero(P);
-    EccRow s0, s1, s2;
-    s0 = ecc_row_load(I, tmpl, cols, x, y0, ax, bx, rtab, y0);
-    s1 = y0 + 1 < y1 ? ecc_row_load(I, tmpl, cols, x, y0 + 1, ax, bx, rtab, y0) : s0;
-    int yb = y0;
-    auto one = [&](EccRow &cur, EccRow &refill, int y) {
-        if (y + 2 < y1) refill = ecc_row_load(I, tmpl, cols, x, y + 2, ax, bx, rtab, y0);
-        if (y - yb == kEccFlush) {                                  // (uniform)
-            ecc_part_flush(P, T, yb);
-            ecc_part_zero(P);
-            yb = y;
-        }
-        ecc_row_sum(cur, P, T, (float)(y - yb));
-    };
-    int y = y0;
-    for (; y + 3 <= y1; y += 3) {
-        one(s0, s2, y);
-        one(s1, s0, y + 1);
-        one(s2, s1, y + 2);
-    }
-    if (y < y1) one(s0, s2, y);
-    if (y + 1 < y1) one(s1, s0, y + 1);
-    ecc_part_flush(P, T, yb);
-}
-
-// Interior block `blk` of `nblk`: the inner rectangle (farther than the band from every edge) is cut into column tiles
-// of 256 and, per tile, into nblk / tiles row pieces; blocks beyond that store zeros.  Needs nblk >= tiles (the host
-// checks: cols <= 256 x interior blocks, else the round-2 kernel runs).
-template <bool IDENT, int UR, int NEIGHBOUR, int GXD, int SHARE>
-__device__ __forceinline__ void ecc_cols_body(const float *__restrict__ img, const float *__restrict__ tmpl, int rows,
-                                              int cols, const EccState *__restrict__ state,
-                                              EccOut &out, int f, unsigned blk, unsigned nblk,
-                                              double (*lds_red)[256], float center)
-{
-    // one LDS area: the per-row coordinate table while the rows are walked, the reduction chunks afterwards
-    static_assert(sizeof(int2) * kEccRowTab <= sizeof(double) * kEccChunk * 256, "row table fits the reduction area");
-    int2 *rtab_s = reinterpret_cast<int2 *>(&lds_red[0][0]);
-    const EccState &es = state[f];
-    const float *I = img + (size_t)f * rows * cols;
-    const EccMargins g = ecc_margins(IDENT ? 3 : es.band, rows, cols);
-    const int x_lo = g.left, x_hi = cols - g.right, y_lo = g.top, y_hi = rows - g.bottom;   // [lo, hi)
-    const int W = max(x_hi - x_lo, 0), H = max(y_hi - y_lo, 0);
-    const unsigned tiles = ((unsigned)W + 255u) / 256u;
-    const unsigned pieces = tiles ? nblk / tiles : 0u;                       // row pieces per column tile (>= 1)
-    const bool work = tiles && blk < tiles * pieces && H > 0;
-    const unsigned ct = work ? blk % tiles : 0u, piece = work ? blk / tiles : 0u;
-    const int rpp = pieces ? (int)(((unsigned)H + pieces - 1u) / pieces) : 0;  // rows per piece
-    const int y0 = work ? min(y_hi, y_lo + (int)piece * rpp) : 0, y1 = work ? min(y_hi, y0 + rpp) : 0;
-    const int x_own = x_lo + (int)ct * 256 + (int)threadIdx.x;
-    const bool on = work && x_own < x_hi && y1 > y0;
-    // NEIGHBOUR: lanes past the rectangle run along on a valid column (the lane after the last one must hold column
-    // x_hi, which exists: the band is >= 3 wide) and are left out of the reduction
-    const int x = NEIGHBOUR ? min(x_own, cols - 1) : x_own;
-    if (!work || y1 <= y0) {            // (uniform) more blocks than pieces: nothing to add
-        ecc_store_zeros(out, f, kEccBorderBlocks + blk);
-        return;
-    }
-    double M[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) M[i] = es.M[i];
-    if (!IDENT) {      // (the host sizes the grid so that a piece has at most kEccRowTab rows)
-        for (int i = threadIdx.x; i < y1 - y0; i += 256) {
-            const int yy = y0 + i;
-            rtab_s[i] = make_int2(__double2int_rn((M[1] * yy + M[2]) * 1024), __double2int_rn((M[4] * yy + M[5]) * 1024));
-        }
-        __syncthreads();
-    }
-    EccTot T;
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-        T.G0[k] = T.G1[k] = T.Gw0[k] = T.Gw1[k] = T.Gt0[k] = T.Gt1[k] = T.Q0[k] = T.Q1[k] = T.Q2[k] = 0.0;
-    T.C0 = T.C1 = T.C2 = T.Sw = T.Sww = T.St = T.Stt = T.Stw = 0.0;
-    T.n = on ? (double)(y1 - y0) : 0.0;          // mask = 1 on every interior pixel
-    T.cf = center;
-    if (on || NEIGHBOUR) {
-        const int ax = IDENT ? 0 : __double2int_rn(M[0] * x * 1024), bx = IDENT ? 0 : __double2int_rn(M[3] * x * 1024);
-        const int2 *rt = rtab_s;
-        if (!IDENT && SHARE == 2) {
-            ecc_rows_pipelined(I, tmpl, cols, x, y0, y1, ax, bx, rt, T);
-        } else
-        for (int yb = y0; yb < y1; yb += kEccFlush) {
-            const int ne = min(kEccFlush, y1 - yb);
-            EccPart P;
-            ecc_part_zero(P);
-            int r = 0;
-            for (; r + UR <= ne; r += UR) ecc_cols_trip<IDENT, UR, NEIGHBOUR, GXD, SHARE>(I, tmpl, cols, x, yb + r, r, ax, bx, rt, y0, M, P, T);
-            for (; r < ne; ++r) ecc_cols_trip<IDENT, 1, NEIGHBOUR, GXD>(I, tmpl, cols, x, yb + r, r, ax, bx, rt, y0, M, P, T);
-            ecc_part_flush(P, T, yb);
-        }
-    }
-    __syncthreads();                              // (every read of the row table is done)
-    ecc_tot_store<0>(T, (double)x, on, lds_red, out, f, kEccBorderBlocks + blk);
-}
-
-// The band of the same launch, also one column per thread (no 45 double accumulators anywhere in this kernel: with
-// round 2's band body inside, the kernel needed 146+ VGPRs whatever the interior loop used).  Band blocks:
-//   [0, tiles)            top strip    rows [0, top),            one column tile of 256 each
-//   [tiles, 2 tiles)      bottom strip rows [rows - bottom, rows)
-//   the rest              the left + right strips between them: `side` = left + right columns; a block's 256 threads
-//                         are (column, row piece) pairs, so a 6-column band still has 42 threads per block at work
-// Generic bilinear (constant-0 border, reflect-101 gradient taps) and the nearest-neighbour mask, as in round 2.
-__device__ __forceinline__ void ecc_band_cols_body(const float *__restrict__ img, const float *__restrict__ tmpl, int rows,
-                                                   int cols, const EccState *__restrict__ state,
-                                                   EccOut &out, int f, unsigned bidx, bool ident,
-                                                   double (*lds_red)[256])
-{
-    const EccState &es = state[f];
-    const float *I = img + (size_t)f * rows * cols;
-    double M[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) M[i] = es.M[i];
-    const EccMargins g = ecc_margins(ident ? 3 : es.band, rows, cols);
-    const int tiles = (cols + 255) / 256;
-    const int tid = (int)threadIdx.x;
-    int x = -1, ya = 0, yb = 0;
-    if ((int)bidx < tiles) {
-        x = (int)bidx * 256 + tid;
-        ya = 0;
-        yb = g.top;
-    } else if ((int)bidx < 2 * tiles) {
-        x = ((int)bidx - tiles) * 256 + tid;
-        ya = rows - g.bottom;
-        yb = rows;
-    } else {
-        const int side = g.left + g.right, H = rows - g.top - g.bottom;
-        const int sb = (int)bidx - 2 * tiles, nsb = kEccBorderBlocks - 2 * tiles;
-        const int tiles_s = (side + 255) / 256;
-        int pb = tiles_s ? nsb / tiles_s : 0;                    // blocks per column tile of the strips ...
-        if (side > 0 && H > 0 && pb >= 1) {
-            // ... of which only as many are used as give every thread ~8 rows (the others store zeros at once)
-            const int sp_min = 256 / min(256, side);
-            pb = min(pb, max(1, (H + 8 * sp_min - 1) / (8 * sp_min)));
-        }
-        if (side > 0 && H > 0 && pb >= 1 && sb < tiles_s * pb) {
-            const int ts = sb % tiles_s, pblk = sb / tiles_s;
-            const int cs = min(256, side - ts * 256), sp = 256 / cs;
-            const int c = tid % cs, q = tid / cs;
-            if (q < sp) {
-                const int pieces = pb * sp, rpp = (H + pieces - 1) / pieces, piece = pblk * sp + q;
-                ya = min(rows - g.bottom, g.top + piece * rpp);
-                yb = min(rows - g.bottom, ya + rpp);
-                const int k = ts * 256 + c;
-                x = k < g.left ? k : cols - side + k;
-            }
-        }
-    }
-    const bool on = x >= 0 && x < cols && yb > ya;
-    if (!__syncthreads_or(on ? 1 : 0)) {     // no thread of the block has a pixel (spare band block, empty strip)
-        ecc_store_zeros(out, f, bidx);
-        return;
-    }
-    EccTot T;
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-        T.G0[k] = T.G1[k] = T.Gw0[k] = T.Gw1[k] = T.Gt0[k] = T.Gt1[k] = T.Q0[k] = T.Q1[k] = T.Q2[k] = 0.0;
-    T.C0 = T.C1 = T.C2 = T.Sw = T.Sww = T.St = T.Stt = T.Stw = T.n = 0.0;
-    T.cf = 0.f;
-    if (on) {
-        auto pix = [&](int yy, int xx) { return I[(size_t)yy * cols + xx]; };
-        auto gxf = [&](int yy, int xx) {
-            return -0.5f * pix(yy, reflect101(xx - 1, cols)) + 0.5f * pix(yy, reflect101(xx + 1, cols));
-        };
-        auto gyf = [&](int yy, int xx) {
-            return -0.5f * pix(reflect101(yy - 1, rows), xx) + 0.5f * pix(reflect101(yy + 1, rows), xx);
-        };
-        const int ax = __double2int_rn(M[0] * x * 1024), bx = __double2int_rn(M[3] * x * 1024);
-        for (int y0 = ya; y0 < yb; y0 += kEccFlush) {
-            const int ne = min(kEccFlush, yb - y0);
-            EccPart P;
-            ecc_part_zero(P);
-            for (int r = 0; r < ne; ++r) {
-                const int y = y0 + r;
-                const int Xr = __double2int_rn((M[1] * y + M[2]) * 1024) + ax;
-                const int Yr = __double2int_rn((M[4] * y + M[5]) * 1024) + bx;
-                const int Xq = (Xr + 16) >> 5, Yq = (Yr + 16) >> 5;
-                WarpCoord c;
-                c.sx = max(-32768, min(32767, Xq >> 5));
-                c.sy = max(-32768, min(32767, Yq >> 5));
-                c.ax = Xq & 31;
-                c.ay = Yq & 31;
-                const int nx = max(-32768, min(32767, (Xr + 512) >> 10)), ny = max(-32768, min(32767, (Yr + 512) >> 10));
-                const bool m = (unsigned)nx < (unsigned)cols && (unsigned)ny < (unsigned)rows;
-                float w, gx, gy;
-                if (c.sx >= 1 && c.sx + 2 < cols && c.sy >= 1 && c.sy + 2 < rows) {
-                    // footprint and gradient taps inside the image (all of the band but its outermost ring or two): the 12
-                    // pixels directly -- the generic path below evaluates to the same operations on the same values
-                    const float *r0 = I + (unsigned)((c.sy - 1) * cols + c.sx);
-                    const float *r1 = r0 + cols, *r2 = r1 + cols, *r3 = r2 + cols;
-                    const float a0 = r0[0], a1 = r0[1];
-                    const float b_1 = r1[-1], b0 = r1[0], b1 = r1[1], b2 = r1[2];
-                    const float c_1 = r2[-1], c0 = r2[0], c1 = r2[1], c2 = r2[2];
-                    const float d0 = r3[0], d1 = r3[1];
-                    const float fx = c.ax * (1.f / 32), fy = c.ay * (1.f / 32);
-                    const float w0 = (1.f - fy) * (1.f - fx), w1 = (1.f - fy) * fx, w2 = fy * (1.f - fx), w3 = fy * fx;
-                    w = b0 * w0 + b1 * w1 + c0 * w2 + c1 * w3;
-                    gx = (-0.5f * b_1 + 0.5f * b1) * w0 + (-0.5f * b0 + 0.5f * b2) * w1 +
-                         (-0.5f * c_1 + 0.5f * c1) * w2 + (-0.5f * c0 + 0.5f * c2) * w3;
-                    gy = (-0.5f * a0 + 0.5f * c0) * w0 + (-0.5f * a1 + 0.5f * c1) * w1 +
-                         (-0.5f * b0 + 0.5f * d0) * w2 + (-0.5f * b1 + 0.5f * d1) * w3;
-                } else {
-                    w = bilinear(pix, rows, cols, c);
-                    gx = bilinear(gxf, rows, cols, c);
-                    gy = bilinear(gyf, rows, cols, c);
-                }
-                ecc_part_add<true>(P, T, w, gx, gy, tmpl[(size_t)y * cols + x], (float)r, m);
-            }
-            ecc_part_flush(P, T, y0);
-        }
-    }
-    ecc_tot_store<0>(T, (double)x, on, lds_red, out, f, bidx);
-}
-
-// centre of the float products (ecc_part_add): the mean of a 64 x 64 sample grid of the blurred template, rounded to an
-// integer and kept inside [0, 4095] (any integer there keeps w - c exact; the nearer to the image's mean, the smaller the
-// products).  Once per reference image; fixed order: deterministic.
-__global__ void __launch_bounds__(256) ecc_center_kernel(const float *__restrict__ tmpl, int rows, int cols, float *__restrict__ out)
-{
-    __shared__ double sh[256];
-    double a = 0.0;
-    for (int k = threadIdx.x; k < 4096; k += 256) {
-        const int y = (int)(((long long)(k >> 6) * rows) >> 6), x = (int)(((long long)(k & 63) * cols) >> 6);
-        a += (double)tmpl[(size_t)y * cols + x];
-    }
-    sh[threadIdx.x] = a;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        const double m = sh[0] / 4096.0;
-        out[0] = (m >= 0.0 && m <= 4095.0) ? (float)rint(m) : 0.f;      // (images outside the 12-bit range: no centring)
-    }
-}
-
-template <bool ATOMIC>
-__device__ __forceinline__ void ecc_solve_body(EccState &es, const double *__restrict__ partial, int f, int nblocks, int max_iters, double eps,
-                               int rows, int cols, double *Ssh);
-constexpr int kEccTicketStride = 32;     // one ticket per frame on its own 128-byte line
-
-// FUSE: the block that finishes a frame LAST (a ticket per frame) reduces the frame's partial sums and solves the iteration in
-// the same launch -- no ecc_solve_kernel launch between two sums launches (16 us of a dependent chain + a launch gap, 32 times
-// per 1000 frames).  The partials and the ticket move through device-scope atomics only (EccOut).
-template <bool IDENT, int UR, int WAVES, int NEIGHBOUR = 0, int GXD = 1, int FUSE = 0, int SHARE = 0>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
-    ecc_cols_kernel(const float *__restrict__ img, const float *__restrict__ tmpl, int rows, int cols,
-                    EccState *__restrict__ state, double *__restrict__ partial, const float *__restrict__ center,
-                    unsigned *__restrict__ tickets, int max_iters, double eps)
-{
-    __shared__ double lds_red[kEccChunk][256];     // row table / reduction chunks of whichever body runs
-    const int f = blockIdx.x;
-    if (state[f].done) return;
-    const unsigned nint = gridDim.y - (unsigned)kEccBorderBlocks;
-    EccOut out = {partial, FUSE != 0, 0ull};
-    if (blockIdx.y >= (unsigned)kEccBorderBlocks)
-        ecc_cols_body<IDENT, UR, NEIGHBOUR, GXD, SHARE>(img, tmpl, rows, cols, state, out, f, blockIdx.y - (unsigned)kEccBorderBlocks, nint, lds_red, *center);
-    else
-        ecc_band_cols_body(img, tmpl, rows, cols, state, out, f, blockIdx.y, IDENT, lds_red);
-    if (FUSE) {
-        // (the exchanges' return values are in out.sink: they have completed before the barrier; the ticket follows it)
-        __shared__ int s_last;
-        const int any = __syncthreads_or((int)(out.sink == 0x7FF8DEADBEEF0001ull));      // (never true: only the dependency matters)
-        if (threadIdx.x == 0) {
-            const unsigned ticket = atomicAdd(&tickets[(size_t)f * kEccTicketStride], 1u + (unsigned)any);
-            s_last = ticket == gridDim.y - 1u;
-            if (s_last) atomicExch(&tickets[(size_t)f * kEccTicketStride], 0u);          // clean for the next launch
-        }
-        __syncthreads();
-        if (s_last) ecc_solve_body<true>(state[f], partial, f, (int)gridDim.y, max_iters, eps, rows, cols, &lds_red[0][0]);
-    }
-}
-
-// ---- Gaussian 5 x 5 pre-blur and the identity iteration of the ECC in ONE pass ----------------------------------------
-// cv::findTransformECC blurs the input (GaussianBlur 5 x 5) and its first iteration runs with the identity warp: the
-// warped image IS the blurred image and the warped gradients are its central differences.  Round 2 wrote the blurred
-// frame (tile kernel, 6 B per pixel) and read it back for the identity sums (8 B per pixel); here one column-walking
-// kernel does both: 2 B (frame) + 4 B (template) in, 4 B (blurred frame, for the later iterations) out.
-//
-// A WAVE owns 62 columns (lanes 1 .. 62; lanes 0 and 63 carry the two neighbour columns the x-gradient needs) and
-// walks down the rows of its piece with everything rolling in registers: the horizontal pass takes the four neighbour
-// pixels from the neighbouring lanes by DPP wave shifts (lanes 0 / 63 load theirs), five rows of horizontal results
-// give a blurred row, three blurred rows give the gradients -- no LDS, no barrier in the loop, waves independent.
-// Same float operations in the same order as gauss_pass_kernel / gauss_fused_kernel (the blurred frame is bit-identical:
-// tests/test_imageops_gpu.py compares upsp_blur_u16 with the oracle), reflect-101 by loading reflected rows and
-// columns: a lane on a virtual column -1 computes exactly the blurred column 1, so the gradient taps at the image border
-// are cv::Sobel's reflected ones without a special case, and the whole frame is "interior" (mask = 1 everywhere under
-// the identity warp): no band blocks in this launch.
-constexpr int kGcOwn = 62;           // columns a wave owns
-
-__device__ __forceinline__ float dpp_shr1(float old, float v)      // lane i <- lane i - 1, lane 0 <- old
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), 0x138, 0xF, 0xF, false));
-}
-__device__ __forceinline__ float dpp_shl1(float old, float v)      // lane i <- lane i + 1, lane 63 <- old
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), 0x130, 0xF, 0xF, false));
-}
-
-template <bool ECC, int U>
-__device__ __forceinline__ void gauss5_cols_body(const uint16_t *__restrict__ src, float *__restrict__ dst,
-                                                 const float *__restrict__ tmpl, int rows, int cols, int rpp, float k0,
-                                                 float k1, float k2, const EccState *__restrict__ state,
-                                                 double *__restrict__ partial, unsigned slot0, double (*lds_red)[256])
-{
-    const int f = blockIdx.x;
-    if (ECC && state[f].done) return;
-    const int lane = threadIdx.x & 63;
-    const int tile = (int)blockIdx.z * 4 + (int)(threadIdx.x >> 6);        // column tile of this wave
-    const int x = tile * kGcOwn - 1 + lane;                                // (virtual for x < 0 or x >= cols)
-    const int y0 = (int)blockIdx.y * rpp, y1 = min(rows, y0 + rpp);
-    const bool wave_on = tile * kGcOwn < cols && y1 > y0;                   // (uniform per wave)
-    const bool own = wave_on && lane >= 1 && lane <= kGcOwn && x >= 0 && x < cols;
-    const size_t npix = (size_t)rows * cols;
-    const uint16_t *S = src + (size_t)f * npix;
-    float *B = dst + (size_t)f * npix;
-    EccTot T;
-    if (ECC) {
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-            T.G0[k] = T.G1[k] = T.Gw0[k] = T.Gw1[k] = T.Gt0[k] = T.Gt1[k] = T.Q0[k] = T.Q1[k] = T.Q2[k] = 0.0;
-        T.C0 = T.C1 = T.C2 = T.Sw = T.Sww = T.St = T.Stt = T.Stw = 0.0;
-        T.n = own ? (double)(y1 - y0) : 0.0;
-        T.cf = 0.f;                               // (opt-in measurement kernel: products not centred)
-    }
-    if (wave_on) {
-        // column offsets of the lane's own pixel and of the two pixels only the edge lanes fetch (reflect-101)
-        const unsigned cx = 2u * (unsigned)reflect101(x, cols);
-        const unsigned ca = 2u * (unsigned)reflect101(lane == 0 ? x - 1 : x + 1, cols);
-        const unsigned cb = 2u * (unsigned)reflect101(lane == 0 ? x - 2 : x + 2, cols);
-        const bool edge = lane == 0 || lane == 63;
-        const unsigned pitch2 = 2u * (unsigned)cols;
-        const unsigned ox = 4u * (unsigned)max(0, min(x, cols - 1));        // f32 column offset (template, output)
-        float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f, h4 = 0.f;              // h(yi - 4 .. yi)
-        float b0 = 0.f, b1 = 0.f, b2 = 0.f;                                  // b(yb - 2 .. yb)
-        EccPart P;
-        if (ECC) ecc_part_zero(P);
-        int yseg = y0;                                                      // first row of the open float segment
-        const int niter = (y1 - y0) + 6;
-        for (int g = 0; g < niter; g += U) {
-            // the loads of U input rows first
-            float s[U], ha[U], hb[U], tt[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int yi = y0 - 3 + g + u;
-                const unsigned ro = (unsigned)reflect101(min(max(yi, -(rows - 1)), 2 * rows - 2), rows) * pitch2;
-                s[u] = (float)*reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(S) + (ro + cx));
-                ha[u] = hb[u] = 0.f;
-                if (edge) {
-                    ha[u] = (float)*reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(S) + (ro + ca));
-                    hb[u] = (float)*reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(S) + (ro + cb));
-                }
-                if (ECC) {
-                    const int ye = min(max(yi - 3, 0), rows - 1);
-                    tt[u] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(tmpl) + ((unsigned)ye * 2u * pitch2 + ox));
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int k = g + u;
-                if (k >= niter) break;                                     // (uniform)
-                const int yi = y0 - 3 + k;
-                // horizontal pass: neighbours by wave shifts; lanes 0 / 63 supply the pixels beyond the wave
-                const float m1 = dpp_shr1(ha[u], s[u]), p1 = dpp_shl1(ha[u], s[u]);
-                const float m2 = dpp_shr1(hb[u], m1), p2 = dpp_shl1(hb[u], p1);
-                float hn = k0 * s[u];
-                hn += k1 * (m1 + p1);
-                hn += k2 * (m2 + p2);
-                h0 = h1; h1 = h2; h2 = h3; h3 = h4; h4 = hn;
-                if (k < 4) continue;
-                // vertical pass: blurred row yb = yi - 2
-                float bn = k0 * h2;
-                bn += k1 * (h1 + h3);
-                bn += k2 * (h0 + h4);
-                const int yb = yi - 2;
-                if (own && yb >= y0 && yb < y1)
-                    __builtin_nontemporal_store(bn, reinterpret_cast<float *>(reinterpret_cast<char *>(B) + ((unsigned)yb * 2u * pitch2 + ox)));
-                b0 = b1; b1 = b2; b2 = bn;
-                if (!ECC || k < 6) continue;
-                // identity iteration at row ye = yi - 3: w = b, gradients = central differences of b
-                const int ye = yi - 3;
-                const float l = dpp_shr1(0.f, b1), r = dpp_shl1(0.f, b1);
-                if (ye - yseg == kEccFlush) {                               // (uniform)
-                    ecc_part_flush(P, T, yseg);
-                    ecc_part_zero(P);
-                    yseg = ye;
-                }
-                ecc_part_add<false>(P, T, b1, 0.5f * (r - l), 0.5f * (b2 - b0), tt[u], (float)(ye - yseg));
-            }
-        }
-        if (ECC) ecc_part_flush(P, T, yseg);
-    }
-    if (ECC) {
-        const unsigned slot = slot0 + blockIdx.y * gridDim.z + blockIdx.z;
-        EccOut out = {partial, false, 0ull};
-        ecc_tot_store<0>(T, (double)x, own, lds_red, out, f, slot);
-    }
-}
-
-// blur + identity iteration: the ECC totals hold the kernel at 4 (3) waves per SIMD
-template <int U, int WAVES>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
-    gauss5_ecc0_kernel(const uint16_t *__restrict__ src, float *__restrict__ dst, const float *__restrict__ tmpl, int rows,
-                       int cols, int rpp, float k0, float k1, float k2, const EccState *__restrict__ state,
-                       double *__restrict__ partial, unsigned slot0)
-{
-    __shared__ double lds_red[kEccChunk][256];
-    gauss5_cols_body<true, U>(src, dst, tmpl, rows, cols, rpp, k0, k1, k2, state, partial, slot0, lds_red);
-}
-// blur alone: ~30 registers, as many waves as the CU takes
-template <int U>
-__global__ void __launch_bounds__(256)
-    gauss5_blur_kernel(const uint16_t *__restrict__ src, float *__restrict__ dst, int rows, int cols, int rpp, float k0, float k1,
-                       float k2)
-{
-    gauss5_cols_body<false, U>(src, dst, nullptr, rows, cols, rpp, k0, k1, k2, nullptr, nullptr, 0u, nullptr);
-}
-
 // ---- Gaussian 5 x 5 of u16 frames, FOUR pixels per lane (round 3) -------------------------------------------------------
 // The tile kernel (gauss_fused_kernel) moves 6 B per pixel at 3.0 TB/s: its 2-byte loads and the LDS round trip keep
 // few bytes in flight.  Here a lane owns four consecutive pixels of a row -- one 8-byte load (a wave reads 512
@@ -1674,17 +394,14 @@ __global__ void __launch_bounds__(256)
 template <int U>
 __global__ void __launch_bounds__(256)
     gauss5_quad_kernel(const uint16_t *__restrict__ src, float *__restrict__ dst, int rows, int cols, int rpp, float k0, float k1,
-                       float k2, unsigned thresh, unsigned *__restrict__ flag, int only_flagged, int frame_slowest)
+                       float k2, unsigned thresh, unsigned *__restrict__ hot_count, unsigned *__restrict__ hot_pos)
 {
-    // flag (may be null): per-frame words.  only_flagged = 0: set flag[f] when a pixel of the frame is >= thresh (the scan of
-    // fix_hot_pixels, cv_extras.cpp:237-247, done on the pixels the blur loads anyway); 1: blur only the frames whose
-    // flag is set (their second blur, after the repair)
-    // (frame_slowest: grid (column groups, row pieces, frames) instead of (frames, row pieces, column groups) -- measurement switch)
-    const int f = frame_slowest ? blockIdx.z : blockIdx.x;
-    const int bz = frame_slowest ? blockIdx.x : blockIdx.z;
-    if (only_flagged && !flag[f]) return;
-    const bool detect = flag && !only_flagged;
-    unsigned hot = 0u;
+    // hot_count (may be null): the scan of fix_hot_pixels (cv_extras.cpp:237-247) on the pixels the blur loads anyway -- every
+    // pixel >= thresh of the rows this block OWNS is counted per frame and its position recorded (kHotPositions per frame)
+    // grid (column groups, row pieces, frames): frames slowest -- 1.27 against 1.35 ms of pre-blur per 1000 frames of 1024^2
+    // with the frame as the fast index, and the identity iteration behind it 1-2 % faster
+    const int f = blockIdx.z;
+    const int bz = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int xw = (bz * 4 + (int)(threadIdx.x >> 6)) * 256;    // first column of this wave
     if (xw >= cols) return;                                                    // (uniform per wave)
@@ -1721,9 +438,19 @@ __global__ void __launch_bounds__(256)
         for (int u = 0; u < U; ++u) {
             const int k = g + u;
             if (k >= niter) break;                                             // (uniform)
-            if (detect)
-                hot |= (unsigned)((q[u].x & 0xFFFFu) >= thresh) | (unsigned)((q[u].x >> 16) >= thresh) |
-                       (unsigned)((q[u].y & 0xFFFFu) >= thresh) | (unsigned)((q[u].y >> 16) >= thresh);
+            if (hot_count && valid) {
+                const int yi = y0 - 2 + k;
+                const unsigned v0 = q[u].x & 0xFFFFu, v1 = q[u].x >> 16, v2 = q[u].y & 0xFFFFu, v3 = q[u].y >> 16;
+                if (yi >= y0 && yi < y1 && max(max(v0, v1), max(v2, v3)) >= thresh) {       // (rare)
+                    const unsigned vv[4] = {v0, v1, v2, v3};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (vv[j] >= thresh) {
+                            const unsigned slot = atomicAdd(&hot_count[f], 1u);
+                            if (slot < (unsigned)kHotPositions) hot_pos[(size_t)f * kHotPositions + slot] = (unsigned)(yi * cols + x0 + j);
+                        }
+                }
+            }
             const float p0 = (float)(q[u].x & 0xFFFFu), p1 = (float)(q[u].x >> 16), p2 = (float)(q[u].y & 0xFFFFu), p3 = (float)(q[u].y >> 16);
             // the neighbours' pixels: lane i - 1's p2, p3 and lane i + 1's p0, p1 (lanes 0 / 63: the loaded halo)
             float a2 = dpp_shr1((float)(hl[u] & 0xFFFFu), p2), a3 = dpp_shr1((float)(hl[u] >> 16), p3);
@@ -1750,281 +477,57 @@ __global__ void __launch_bounds__(256)
             if (valid) *reinterpret_cast<float4 *>(B + ((unsigned)yb * 2u * pitch2 + 4u * (unsigned)x0)) = o;
         }
     }
-    // (every pixel of the frame is loaded by some lane -- halo rows and re-read quads only repeat pixels of the same frame)
-    if (detect && __any(hot) && lane == 0) atomicOr(&flag[f], 1u);
 }
 
-bool gauss5_quad_applies(const uint16_t *src, const float *dst, int nimg, int rows, int cols)
+// The blurred pixels a repaired hot pixel reaches: the 5 x 5 neighbourhood of every listed change, recomputed from the
+// repaired frame with gauss5_quad_kernel's own operations in its order (bit-identical to blurring the repaired frame).
+// One workgroup per frame; frames without a change (nearly all) return at once.
+__global__ void __launch_bounds__(256)
+    reblur_changes_kernel(const uint16_t *__restrict__ frames, float *__restrict__ dst, int rows, int cols,
+                          const unsigned *__restrict__ nch, const uint4 *__restrict__ changes, int max_hot, float k0, float k1, float k2)
 {
-    // UPSP_GAUSS5_QUAD=0: the tile kernel (measurement / test switch)
-    return env_int_io("UPSP_GAUSS5_QUAD", 1) && !(cols & 3) && cols >= 8 && rows >= 3 && (long long)rows * cols < (1ll << 29) &&
-           !(reinterpret_cast<uintptr_t>(src) & 7) && !(reinterpret_cast<uintptr_t>(dst) & 15) && nimg <= 65535 &&
-           !((size_t)rows * cols & 3);          // (every frame of the batch 8-byte aligned)
+    const int f = blockIdx.x;
+    const unsigned m = nch[f];
+    if (m == 0u) return;
+    const size_t npix = (size_t)rows * cols;
+    const uint16_t *S = frames + (size_t)f * npix;
+    float *B = dst + (size_t)f * npix;
+    for (unsigned t = threadIdx.x; t < m * 25u; t += 256u) {
+        const uint4 ch = changes[(size_t)f * max_hot + t / 25u];
+        const int o = (int)(t % 25u);
+        const int y = (int)(ch.y / (unsigned)cols) + o / 5 - 2, x = (int)(ch.y % (unsigned)cols) + o % 5 - 2;
+        if (y < 0 || y >= rows || x < 0 || x >= cols) continue;
+        const int xm1 = reflect101(x - 1, cols), xp1 = reflect101(x + 1, cols), xm2 = reflect101(x - 2, cols), xp2 = reflect101(x + 2, cols);
+        float h[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const uint16_t *row = S + (size_t)reflect101(y + i - 2, rows) * cols;
+            float hn = k0 * (float)row[x];
+            hn += k1 * ((float)row[xm1] + (float)row[xp1]);
+            hn += k2 * ((float)row[xm2] + (float)row[xp2]);
+            h[i] = hn;
+        }
+        float bn = k0 * h[2];
+        bn += k1 * (h[1] + h[3]);
+        bn += k2 * (h[0] + h[4]);
+        B[(size_t)y * cols + x] = bn;         // (neighbourhoods of two changes may overlap: the same value from both)
+    }
 }
 
 bool launch_gauss5_quad(const uint16_t *src, float *dst, int nimg, int rows, int cols, const FilterCoef &fc, hipStream_t st,
-                        unsigned thresh, unsigned *flag, int only_flagged)
+                        unsigned thresh, unsigned *d_count, unsigned *d_pos)
 {
-    if (!gauss5_quad_applies(src, dst, nimg, rows, cols)) return false;
-    const int rpp = std::max(8, env_int_io("UPSP_GAUSS5_QUAD_RPP", 64)), uvar = env_int_io("UPSP_GAUSS5_QUAD_U", 8);   // (measurement switches)
+    if ((cols & 3) || cols < 8 || rows < 3 || (long long)rows * cols >= (1ll << 29) || (reinterpret_cast<uintptr_t>(src) & 7) ||
+        (reinterpret_cast<uintptr_t>(dst) & 15) || nimg > 65535 || ((size_t)rows * cols & 3))      // (every frame of the batch 8-byte aligned)
+        return false;
     // (1000 frames of 1024^2, ms of pre-blur per step: 2 / 4 / 6 / 8 rows in flight 1.60 / 1.50 / 1.35 / 1.25-1.33 at 64 rows per
     //  piece; 8 rows in flight at 16 / 32 / 48 / 128 rows per piece 1.32 / 1.36 / 1.39 / 1.52; the tile kernel 2.13)
+    const int rpp = 64;
     const int pieces = (rows + rpp - 1) / rpp, zb = (cols + 1023) / 1024;
     if (pieces > 65535 || zb > 65535) return false;
-    // frames slowest in the grid: 1.27 against 1.35 ms of pre-blur per 1000 frames, and the identity iteration behind it 1-2 % faster
-    const int fs = env_int_io("UPSP_GAUSS5_QUAD_ORDER", 1);
-#define UPSP_GQ(UU)                                                                                                 \
-    hipLaunchKernelGGL((gauss5_quad_kernel<UU>), fs ? dim3((unsigned)zb, (unsigned)pieces, (unsigned)nimg) : dim3((unsigned)nimg, (unsigned)pieces, (unsigned)zb), dim3(256), 0, st, src, dst, rows, \
-                       cols, rpp, fc.k[2], fc.k[3], fc.k[4], thresh, flag, only_flagged, fs)
-    if (uvar == 2) UPSP_GQ(2); else if (uvar == 4) UPSP_GQ(4); else if (uvar == 6) UPSP_GQ(6); else UPSP_GQ(8);
-#undef UPSP_GQ
+    hipLaunchKernelGGL((gauss5_quad_kernel<8>), dim3((unsigned)zb, (unsigned)pieces, (unsigned)nimg), dim3(256), 0, st, src, dst, rows,
+                       cols, rpp, fc.k[2], fc.k[3], fc.k[4], thresh, d_count, d_pos);
     return true;
-}
-
-// grid (frames, kEccBorderBlocks + interior blocks): the frame is the FAST index, so the band blocks of all frames
-// (slots 0 .. kEccBorderBlocks-1: few trips of long dependent chains) are dispatched first and run beside the interior
-// blocks instead of after them (as the last blocks of the launch they were a 50-us tail)
-template <bool IDENT, int KP, int WAVES>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
-    ecc_sums2_kernel(const float *__restrict__ img, const float *__restrict__ tmpl, int rows, int cols,
-                     const EccState *__restrict__ state, double *__restrict__ partial)
-{
-    const int f = blockIdx.x;
-    if (state[f].done) return;
-    const unsigned nint = gridDim.y - (unsigned)kEccBorderBlocks;
-    if (blockIdx.y >= (unsigned)kEccBorderBlocks)
-        ecc_interior_body<IDENT, KP>(img, tmpl, rows, cols, state, partial, f, blockIdx.y - (unsigned)kEccBorderBlocks, nint);
-    else
-        ecc_border_body(img, tmpl, rows, cols, state, partial, f, blockIdx.y, IDENT ? 1 : 0);
-}
-
-// hal::LU32f-based inverse (cv::Mat::inv, DECOMP_LU) of a 6x6 float matrix, same operations in
-// the same order.  Everything is unrolled with compile-time indices (the row exchange of the
-// partial pivoting is a select over the candidate rows), so both matrices live in registers: the
-// one lane that runs this was spending ~25 us per call on dependent scratch / LDS round trips.
-__device__ __forceinline__ bool inv6(const float *Ain, float *inv)
-{
-    float A[6][6], b[6][6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            A[i][j] = Ain[i * 6 + j];
-            b[i][j] = i == j ? 1.f : 0.f;
-        }
-    const float eps = FLT_EPSILON * 10;
-    bool ok = true;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        int k = i;
-        float best = fabsf(A[i][i]);
-#pragma unroll
-        for (int j = i + 1; j < 6; ++j) {
-            const float v = fabsf(A[j][i]);
-            if (v > best) { best = v; k = j; }
-        }
-        if (best < eps) ok = false;
-#pragma unroll
-        for (int r = i + 1; r < 6; ++r) {           // rows i <-> k, k known only at run time
-            const bool sw = k == r;
-#pragma unroll
-            for (int c = 0; c < 6; ++c) {
-                const float ta = A[i][c], tb = b[i][c];
-                A[i][c] = sw ? A[r][c] : ta;
-                A[r][c] = sw ? ta : A[r][c];
-                b[i][c] = sw ? b[r][c] : tb;
-                b[r][c] = sw ? tb : b[r][c];
-            }
-        }
-        const float d = -1 / A[i][i];
-#pragma unroll
-        for (int j = i + 1; j < 6; ++j) {
-            const float alpha = A[j][i] * d;
-#pragma unroll
-            for (int kk = i + 1; kk < 6; ++kk) A[j][kk] += alpha * A[i][kk];
-#pragma unroll
-            for (int kk = 0; kk < 6; ++kk) b[j][kk] += alpha * b[i][kk];
-        }
-    }
-    if (!ok) return false;
-#pragma unroll
-    for (int i = 5; i >= 0; --i)
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            float sacc = b[i][j];
-#pragma unroll
-            for (int k = i + 1; k < 6; ++k) sacc -= A[i][k] * b[k][j];
-            b[i][j] = sacc / A[i][i];
-        }
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = 0; j < 6; ++j) inv[i * 6 + j] = b[i][j];
-    return true;
-}
-
-// One lane per frame: the body of the cv::findTransformECC iteration after the
-// image passes (ecc.cpp): meanStdDev, rho, hessian inverse, lambda, deltaP, update.
-// One iteration's solve for frame f: wave w reduces sums k = w, w+4, ... over the block partials (lane l takes blocks l, l+64,
-// ...; fixed shuffle tree -> deterministic), thread 0 then runs the scalar part.  All 256 threads of the workgroup call it.
-// ATOMIC: the partials were written with device-scope atomics by other workgroups of the SAME launch and are read the same way.
-template <bool ATOMIC>
-__device__ __forceinline__ void ecc_solve_body(EccState &es, const double *__restrict__ partial, int f, int nblocks, int max_iters, double eps,
-                               int rows, int cols, double *Ssh)
-{
-    auto ld = [&](const double *p) -> double {
-        if (ATOMIC)
-            return __longlong_as_double((long long)atomicAdd(reinterpret_cast<unsigned long long *>(const_cast<double *>(p)), 0ull));
-        return *p;
-    };
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // every load of the wave's <= 12 sums is issued before the first reduction (one sum after the
-    // other made this a chain of 12 global-load latencies: 33 us per launch, 15 % of the ECC path)
-    constexpr int kPerWave = (kEccSums + 3) / 4;
-    double v[kPerWave];
-#pragma unroll
-    for (int i = 0; i < kPerWave; ++i) {
-        const int k = wave + 4 * i;
-        // first block of 64 partials: one independent load per sum
-        v[i] = (k < kEccSums && lane < nblocks) ? ld(&partial[((size_t)f * kEccSums + k) * kEccStride + lane]) : 0.0;
-    }
-    if (nblocks > 64) {   // few active frames -> more, smaller blocks per frame (same order per lane as one loop)
-#pragma unroll
-        for (int i = 0; i < kPerWave; ++i) {
-            const int k = wave + 4 * i;
-            if (k < kEccSums) {
-                const double *pk = partial + ((size_t)f * kEccSums + k) * kEccStride;
-                for (int b = lane + 64; b < nblocks; b += 64) v[i] += ld(&pk[b]);
-            }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < kPerWave; ++i) {
-        double x = v[i];
-        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);   // fixed tree -> deterministic
-        const int k = wave + 4 * i;
-        if (lane == 0 && k < kEccSums) Ssh[k] = x;
-    }
-    __syncthreads();
-    if (threadIdx.x != 0) return;
-    const double *S = Ssh;          // (read from LDS where needed: 90 registers less in the kernels that carry this body)
-    const double n = S[0];
-    const double mw = n ? S[1] / n : 0, mt = n ? S[3] / n : 0;
-    const double vw = n ? S[2] / n - mw * mw : 0, vt = n ? S[4] / n - mt * mt : 0;
-    const double sdw = sqrt(vw > 0 ? vw : 0), sdt = sqrt(vt > 0 ? vt : 0);
-    const double tmpNorm = sqrt(n * sdt * sdt), imgNorm = sqrt(n * sdw * sdw);
-    const double corr = S[5] - n * mt * mw;
-    float Hf[36], Hinv[36], ipf[6], tpf[6];
-    int h = 24;
-    for (int a = 0; a < 6; ++a) {
-        ipf[a] = (float)(S[6 + a] - mw * S[12 + a]);
-        tpf[a] = (float)(S[18 + a] - mt * S[12 + a]);
-        for (int b = a; b < 6; ++b) {
-            Hf[a * 6 + b] = Hf[b * 6 + a] = (float)S[h];
-            ++h;
-        }
-    }
-    if (!inv6(Hf, Hinv))
-        for (int i = 0; i < 36; ++i) Hinv[i] = 0.f;
-    es.last_rho = es.rho;
-    es.rho = corr / (imgNorm * tmpNorm);
-    es.iters += 1;
-    if (es.rho != es.rho) {  // "NaN encountered."
-        es.done = -1;
-        return;
-    }
-    float iph[6];
-    for (int i = 0; i < 6; ++i) {
-        double s = 0;
-        for (int j = 0; j < 6; ++j) s += (double)Hinv[i * 6 + j] * ipf[j];
-        iph[i] = (float)s;
-    }
-    double d_ip = 0, d_tp = 0;
-    for (int i = 0; i < 6; ++i) {
-        d_ip += (double)ipf[i] * iph[i];
-        d_tp += (double)tpf[i] * iph[i];
-    }
-    const double lambda_n = imgNorm * imgNorm - d_ip;
-    const double lambda_d = corr - d_tp;
-    if (lambda_d <= 0.0) {  // "The algorithm stopped before its convergence..."
-        es.rho = -1;
-        es.done = -2;
-        return;
-    }
-    const float lambda = (float)(lambda_n / lambda_d);
-    // errorProjection = J^T (lambda*tz - wz) = lambda*tp - ip
-    float epf[6], dp[6];
-    for (int i = 0; i < 6; ++i) epf[i] = (float)((double)lambda * tpf[i] - (double)ipf[i]);
-    for (int i = 0; i < 6; ++i) {
-        double s = 0;
-        for (int j = 0; j < 6; ++j) s += (double)Hinv[i * 6 + j] * epf[j];
-        dp[i] = (float)s;
-    }
-    es.M[0] += dp[0]; es.M[3] += dp[1]; es.M[1] += dp[2];
-    es.M[4] += dp[3]; es.M[2] += dp[4]; es.M[5] += dp[5];
-    es.band = ecc_band(es.M, rows, cols);
-    // for (i = 1; i <= N && fabs(rho - last_rho) >= eps; i++)
-    if (es.iters >= max_iters || !(fabs(es.rho - es.last_rho) >= eps)) es.done = 1;
-}
-
-__global__ void __launch_bounds__(256)
-    ecc_solve_kernel(EccState *__restrict__ state, const double *__restrict__ partial,
-                     int nframes, int nblocks, int max_iters, double eps, int rows, int cols)
-{
-    // one workgroup per frame
-    const int f = blockIdx.x;
-    if (f >= nframes) return;
-    EccState &es = state[f];
-    if (es.done) return;
-    __shared__ double Ssh[kEccSums];
-    ecc_solve_body<false>(es, partial, f, nblocks, max_iters, eps, rows, cols, Ssh);
-}
-
-__global__ void ecc_init_kernel(EccState *state, int nframes, long long first_frame, double eps)
-{
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= nframes) return;
-    EccState &es = state[f];
-    es.M[0] = 1; es.M[1] = 0; es.M[2] = 0; es.M[3] = 0; es.M[4] = 1; es.M[5] = 0;  // eye(2,3)
-    es.rho = -1;
-    es.last_rho = -eps;
-    es.iters = 0;
-    es.done = (first_frame + f == 0) ? 2 : 0;  // frame 0 is not registered (psp_process.cpp:1777)
-    es.band = 3;                               // identity
-}
-
-// one wave: out[0] frames still iterating, [1] frames in error, [2] frame-iterations so far (statistics), [3] iterations of
-// the frame that needed most (sizes the next sub-batch's first burst).  Writes all four: nothing to clear beforehand.
-__global__ void __launch_bounds__(64) ecc_count_active(const EccState *state, int nframes, int *out)
-{
-    int active = 0, err = 0, iters = 0, most = 0;
-    for (int f = threadIdx.x; f < nframes; f += 64) {
-        active += state[f].done == 0;
-        err += state[f].done < 0;
-        iters += state[f].iters;
-        most = max(most, state[f].iters);
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        active += __shfl_down(active, off);
-        err += __shfl_down(err, off);
-        iters += __shfl_down(iters, off);
-        most = max(most, __shfl_down(most, off));
-    }
-    if (threadIdx.x == 0) {
-        out[0] = active;
-        out[1] = err;
-        out[2] = iters;
-        out[3] = most;
-    }
-}
-
-__global__ void ecc_export_warps(const EccState *state, int nframes, float *warps, int stride, int32_t *iters, int istride)
-{
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= nframes) return;
-    if (warps)
-        for (int i = 0; i < 6; ++i) warps[(size_t)f * stride + i] = state[f].M[i];
-    if (iters) iters[(size_t)f * istride] = state[f].iters;
 }
 
 // ----------------------------------------------------------------- patches --
@@ -2277,62 +780,7 @@ static int launch_patch(const PatchTables *t, float *imgs, int nimg, int rows, i
     return UPSP_OK;
 }
 
-// GaussianBlur(u16 -> f32, 5 x 5) of nimg frames by the column-walking kernel; with `state` / `partial` / `tmpl` also the
-// identity iteration of the ECC (one partial-sum slot per workgroup: *nslots of them, slots 0 .. *nslots - 1).
-static int launch_gauss5_cols(const uint16_t *src, float *dst, int nimg, int rows, int cols, const float *tmpl,
-                              const EccState *state, double *partial, int *nslots, hipStream_t st)
-{
-    FilterCoef fc;
-    if (gaussian_coef(5, fc) != 0) return fail(UPSP_ERR_INVALID, "gaussian 5");
-    const int ntiles = (cols + kGcOwn - 1) / kGcOwn, zb = (ntiles + 3) / 4;
-    int rpp = 64;
-    while ((long long)((rows + rpp - 1) / rpp) * zb > kEccStride) rpp *= 2;     // (one slot per workgroup)
-    const int pieces = (rows + rpp - 1) / rpp;
-    if (nimg > 65535 || pieces > 65535 || zb > 65535) return fail(UPSP_ERR_INVALID, "gaussian: image too large");
-    const dim3 grid((unsigned)nimg, (unsigned)pieces, (unsigned)zb);
-    const int uvar = env_int_io("UPSP_GAUSS5_VARIANT", 0);       // (measurement switch)
-    if (state) {
-        KTimed kt("gauss5_ecc0_kernel", st);
-#define UPSP_G5E(UU, WV)                                                                                        \
-    hipLaunchKernelGGL((gauss5_ecc0_kernel<UU, WV>), grid, dim3(256), 0, st, src, dst, tmpl, rows, cols, rpp, fc.k[2], fc.k[3], \
-                       fc.k[4], state, partial, 0u)
-        if (uvar == 1) UPSP_G5E(8, 3); else if (uvar == 2) UPSP_G5E(8, 4); else if (uvar == 3) UPSP_G5E(2, 4); else UPSP_G5E(4, 4);
-#undef UPSP_G5E
-        if (nslots) *nslots = pieces * zb;
-    } else {
-        KTimed kt("gauss_pass_kernels", st);
-#define UPSP_G5B(UU)                                                                                            \
-    hipLaunchKernelGGL((gauss5_blur_kernel<UU>), grid, dim3(256), 0, st, src, dst, rows, cols, rpp, fc.k[2], fc.k[3], fc.k[4])
-        if (uvar == 1) UPSP_G5B(8); else if (uvar == 2) UPSP_G5B(16); else if (uvar == 3) UPSP_G5B(2); else UPSP_G5B(4);
-#undef UPSP_G5B
-    }
-    UPSP_HIP_CHECK(hipGetLastError());
-    return UPSP_OK;
-}
-
 // ----------------------------------------------------------- FrameScratch --
-struct FrameScratch {
-    int ncams = 0, batch = 0, rows = 0, cols = 0;
-    uint16_t *warp[kMaxCams] = {nullptr};   // registered u16 frames
-    float *f32[kMaxCams] = {nullptr};       // patched / filtered frames
-    float *f32b[kMaxCams] = {nullptr};      // Gaussian-filtered frames when the filter input is f32[] itself
-    float *ecc_img = nullptr;               // blurred input frames
-    float *ecc_img2 = nullptr;              // second buffer: the pre-blur of the NEXT sub-batch runs ahead on another stream (frame_scratch_preblur)
-    float *tmp = nullptr;                   // filter intermediate (float), also box sums (double)
-    float *tmpl[kMaxCams] = {nullptr};      // blurred ECC templates
-    const float *tmpl_src[kMaxCams] = {nullptr};
-    float *center = nullptr;                // [kMaxCams] centre of the float products of the ECC sums (ecc_center_kernel)
-    unsigned *hot_flag = nullptr;           // [batch] frames in which the pre-blur saw a pixel >= the hot threshold (HotFuse)
-    int *h_counter = nullptr;               // pinned: where "frames still iterating" is read back to
-    hipEvent_t ev_counter = nullptr;        // ... and the event behind that copy
-    unsigned *tickets = nullptr;            // [batch][kEccTicketStride] blocks of a frame that have delivered their sums (fused solve); zero between launches
-    double *partial = nullptr;
-    EccState *state = nullptr;
-    int *counter = nullptr;
-    unsigned long long ecc_frame_iters = 0, ecc_frames = 0;   // statistics: ECC iterations summed over frames, frames
-    int ecc_first_burst = 3;                                  // iterations issued before the first host check
-};
-
 void frame_scratch_ecc_stats(const FrameScratch *s, unsigned long long *frame_iters, unsigned long long *frames)
 {
     *frame_iters = s ? s->ecc_frame_iters : 0;
@@ -2351,8 +799,7 @@ void frame_scratch_free(FrameScratch *s)
     if (s->ecc_img) (void)hipFree(s->ecc_img);
     if (s->ecc_img2) (void)hipFree(s->ecc_img2);
     if (s->center) (void)hipFree(s->center);
-    if (s->hot_flag) (void)hipFree(s->hot_flag);
-    if (s->tickets) (void)hipFree(s->tickets);
+    if (s->rtab) (void)hipFree(s->rtab);
     if (s->h_counter) (void)hipHostFree(s->h_counter);
     if (s->ev_counter) (void)hipEventDestroy(s->ev_counter);
     if (s->tmp) (void)hipFree(s->tmp);
@@ -2387,15 +834,11 @@ int frame_scratch_ensure(FrameScratch **ps, int ncams, int batch, int rows, int 
         if (need_warp && !s->tmpl[c]) UPSP_HIP_CHECK(hipMalloc(&s->tmpl[c], (size_t)rows * cols * sizeof(float)));
     }
     if (need_warp && !s->ecc_img) UPSP_HIP_CHECK(hipMalloc(&s->ecc_img, n * sizeof(float)));
-    if (need_warp && !s->hot_flag) UPSP_HIP_CHECK(hipMalloc(&s->hot_flag, sizeof(unsigned) * (size_t)batch));
     if (need_warp && !s->h_counter) {
         UPSP_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&s->h_counter), 4 * sizeof(int), hipHostMallocDefault));
         UPSP_HIP_CHECK(hipEventCreateWithFlags(&s->ev_counter, hipEventDisableTiming));
     }
-    if (need_warp && !s->tickets) {
-        UPSP_HIP_CHECK(hipMalloc(&s->tickets, sizeof(unsigned) * (size_t)batch * kEccTicketStride));
-        UPSP_HIP_CHECK(hipMemset(s->tickets, 0, sizeof(unsigned) * (size_t)batch * kEccTicketStride));
-    }
+    if (need_warp && !s->rtab) UPSP_HIP_CHECK(hipMalloc(&s->rtab, sizeof(int2) * (size_t)batch * rows));
     if (need_warp && !s->center) {
         UPSP_HIP_CHECK(hipMalloc(&s->center, kMaxCams * sizeof(float)));
         UPSP_HIP_CHECK(hipMemset(s->center, 0, kMaxCams * sizeof(float)));
@@ -2409,229 +852,6 @@ int frame_scratch_ensure(FrameScratch **ps, int ncams, int batch, int rows, int 
 }
 
 // ECC registration of nb frames against the blurred template; leaves the warp in state[].
-static int run_ecc(FrameScratch *s, const float *tmpl_blur, const float *d_center, const uint16_t *frames, int nb,
-                   int64_t first_frame, int rows, int cols, int max_iters, double eps, hipStream_t st,
-                   const float *preblurred = nullptr, const HotFuse *hot = nullptr, uint16_t *frames_rw = nullptr,
-                   const std::function<int()> *while_waiting = nullptr)
-{
-    if ((long long)rows * cols >= (1ll << 31)) return fail(UPSP_ERR_INVALID, "registration: image too large");
-    // Pre-blur (GaussianBlur 5 x 5) and the first iteration.  Every frame starts from the identity warp
-    // (cpp/lib/registration.cpp:52-53), so the first iteration needs no warp.  Default: the tile kernel blurs, the
-    // column kernel's identity variant takes the sums (134 + 130 us per 64 frames of 1024^2).  UPSP_ECC_FUSED=1: ONE
-    // column-walking kernel blurs and sums (gauss5_ecc0_kernel) -- built because it moves 10 instead of 14 bytes per
-    // pixel, measured at 280-290 us: a wave's 128-byte requests for its 62 u16 pixels of a row keep the L1 waiting on
-    // pending misses (PMC: 68 % of the time; 4 / 8 / 16 rows in flight, 3 / 4 / 8 waves per SIMD and streamed loads all
-    // within 280-365 us).  Kept as a switch, parity-tested; UPSP_ECC_FUSED=2: column-walking blur alone (184 us) + the
-    // identity variant.
-    const int fused_env = preblurred ? 0 : env_int_io("UPSP_ECC_FUSED", 0);
-    const bool fused = fused_env == 1 && rows >= 5 && cols >= 5;
-    const float *blurred = preblurred ? preblurred : s->ecc_img;      // (GaussianBlur 5 x 5 of the frames)
-    const dim3 g1((nb + 63) / 64), b1(64);
-    hipLaunchKernelGGL(ecc_init_kernel, g1, b1, 0, st, s->state, nb, (long long)first_frame, eps);
-    int it = 0;
-    if (fused) {
-        int nslots = 0;
-        int rc = launch_gauss5_cols(frames, s->ecc_img, nb, rows, cols, tmpl_blur, (const EccState *)s->state, s->partial, &nslots, st);
-        if (rc != UPSP_OK) return rc;
-        KTimed kt2("ecc_solve_kernel", st);
-        hipLaunchKernelGGL(ecc_solve_kernel, dim3(nb), dim3(256), 0, st, s->state, (const double *)s->partial, nb, nslots,
-                           max_iters, eps, rows, cols);
-        it = 1;
-    } else if (!preblurred && hot) {
-        // fix_hot_pixels inside the pre-blur: blur + flag, repair the flagged frames (normally none), blur those again
-        FilterCoef fc;
-        if (gaussian_coef(5, fc) != 0) return fail(UPSP_ERR_INVALID, "gaussian 5");
-        UPSP_HIP_CHECK(hipMemsetAsync(s->hot_flag, 0, sizeof(unsigned) * (size_t)nb, st));
-        {
-            KTimed kt("gauss_pass_kernels", st);
-            if (!launch_gauss5_quad(frames, s->ecc_img, nb, rows, cols, fc, st, (unsigned)hot->thresh, s->hot_flag, 0))
-                return fail(UPSP_ERR_INTERNAL, "pre-blur with the hot-pixel scan: geometry not supported (frame_stages_fuse_hot)");
-        }
-        int rc = launch_hot_fix(frames_rw, nb, rows, cols, hot->thresh, hot->min_change, hot->max_hot, hot->d_count, hot->d_pos, nullptr,
-                                st, s->hot_flag);
-        if (rc != UPSP_OK) return rc;
-        KTimed kt("gauss_pass_kernels", st);
-        (void)launch_gauss5_quad(frames, s->ecc_img, nb, rows, cols, fc, st, 0u, s->hot_flag, 1);
-    } else if (!preblurred) {
-        int rc = (fused_env == 2 && rows >= 5 && cols >= 5)
-                     ? launch_gauss5_cols(frames, s->ecc_img, nb, rows, cols, nullptr, nullptr, nullptr, nullptr, st)
-                     : launch_gauss<uint16_t>(frames, s->ecc_img, s->tmp, nb, rows, cols, 5, st);
-        if (rc != UPSP_OK) return rc;
-    }
-    bool first_burst = true, waited = false;
-    int active = nb;  // frames still iterating (known to the host after every burst)
-    int iters_done = 0, most_iters = 0;
-    for (;;) {
-        // a few iterations between host checks of the active-frame count; frames that have
-        // converged exit at once, so late bursts spread the remaining frames over more blocks
-        // (a host check costs a stream round trip of ~40 us; most frames converge within 3-5
-        // iterations, the rare oscillating ones run to max_iters, so the bursts grow)
-        // (first burst: as many iterations as the previous sub-batch's slowest frame took -- on steady footage every
-        //  frame converges with its second iteration, and a third launch pair that finds nothing to do costs 10 us)
-        const int burst = first_burst ? std::max(1, s->ecc_first_burst - it) : (it < 7 ? 2 : (it < 15 ? 8 : 16));
-        first_burst = false;
-        // Interior blocks per frame.  Round 3's kernel: every block ends with a reduction of the 45 sums that costs as
-        // much as ~10 rows of its 256 columns, so a block should walk a few hundred rows -- 16 blocks per frame (4 column
-        // tiles x 4 row pieces of 256 at 1024^2: 1024 blocks for a full sub-batch = one resident set at 4 per CU), more
-        // when few frames are still iterating; at least one per column tile of 256.
-        static const int kernel_sel = env_int_io("UPSP_ECC_KERNEL", 3);
-        const int tiles = (cols + 255) / 256;
-        const bool cols_ok = kernel_sel == 3 && 3 * tiles <= kEccBorderBlocks && tiles <= kEccBlocksMax;
-        static const int blocks0 = std::min(std::max(env_int_io("UPSP_ECC_BLOCKS", 64), 1), kEccBlocksMax);     // (measured 16 / 32 / 64: 6.74 / 6.25 / 6.03 ms of sums per 1000 frames)
-        int blocks = cols_ok ? blocks0 : kEccBlocks;
-        // The column kernel's float segments follow the row pieces, i.e. the block count: it must not depend on how many
-        // frames are still iterating, or the last bits of a frame's sums -- and through the reference's float 6 x 6 solve
-        // 1e-5 .. 1e-4 px of its warp -- would depend on which frames share its sub-batch (measured: 2.6e-4 px between a
-        // frame registered in a batch of 11 and in a batch of 7).  One count per image geometry: the warp of a frame is
-        // the same bits in any batch (tests/test_imageops_gpu.py).  UPSP_ECC_BLOCKS_GROW=1: round 2's policy for the
-        // column kernel too (more, smaller blocks when few frames are left: faster tails, batch-dependent bits).
-        static const int blocks_grow = env_int_io("UPSP_ECC_BLOCKS_GROW", 0);
-        const bool grow = !cols_ok || blocks_grow;
-        while (blocks < kEccBlocksMax && ((grow && (long long)blocks * active < (cols_ok ? 1024 : 2048)) ||
-                                          (cols_ok && (blocks < tiles || rows > (long long)kEccRowTab * (blocks / tiles)))))
-            blocks *= 2;
-        const int nblocks_total = blocks + kEccBorderBlocks;
-        for (int k = 0; k < burst && it < max_iters; ++k, ++it) {
-            bool fused_solve = false;
-            {
-                KTimed kt("ecc_sums_kernel", st);
-#define UPSP_ECC_LAUNCH(ID, KPX, WV)                                                                          \
-    hipLaunchKernelGGL((ecc_sums2_kernel<ID, KPX, WV>), dim3(nb, blocks + kEccBorderBlocks), dim3(256), 0, st,    \
-                       blurred, tmpl_blur, rows, cols, (const EccState *)s->state, s->partial)
-#define UPSP_ECC_COLS(ID, URX, WV, ...)                                                                       \
-    hipLaunchKernelGGL((ecc_cols_kernel<ID, URX, WV, ##__VA_ARGS__>), dim3(nb, blocks + kEccBorderBlocks), dim3(256), 0, st, \
-                       blurred, tmpl_blur, rows, cols, s->state, s->partial, d_center, s->tickets, max_iters, eps)
-                // Round 3: one column per thread, factored packed-float sums (ecc_cols_kernel); needs one column tile of 256 per
-                // interior block at least.  UPSP_ECC_KERNEL=2 selects round 2's kernel (A/B, and images wider than that).
-                static const int cvariant = env_int_io("UPSP_ECC_CVARIANT", 0);
-                static const int gx_form = env_int_io("UPSP_ECC_GX", 1);
-                // UPSP_ECC_SHARE_ROWS=1 (opt-in, measured and NOT the default): the second row of a general trip re-uses the first one's
-                // source rows when its footprint is that one moved down by a row in every lane of the wave (ecc_cols_trip): 11
-                // instead of 16 source loads per trip, the same bits (tests/test_imageops_gpu.py) -- and 6.0 instead of 5.4 ms of
-                // sums per 1000 frames: the loads then wait for both rows' coordinates and a wave-wide vote.  The kernel is not
-                // bound by the number of its L1 requests.  = 2: the rows software-pipelined instead (ecc_rows_pipelined: the loads of
-                // rows y + 1, y + 2 in flight while row y is summed; 160 VGPRs, no spill, same bits): 6.03 ms.  Two rows loaded, then
-                // two rows summed, three waves per SIMD taking turns, remains the fastest arrangement found.
-                const int share_rows = env_int_io("UPSP_ECC_SHARE_ROWS", 0);
-                // UPSP_ECC_FUSE_SOLVE=1 (opt-in, measured and NOT the default): the solve in the sums launch, by the block that
-                // finishes a frame last.  Same bits (tests/test_imageops_gpu.py), but the sums take 6.13 instead of 5.41 + 0.52 ms
-                // per 1000 frames: the 45 partial sums of every block leave as device-scope atomics, and the launch ends with the
-                // same one-thread chain the solve kernel is -- all 64 frames finish together, so nothing hides it.
-                const int fuse_solve = env_int_io("UPSP_ECC_FUSE_SOLVE", 0);
-                fused_solve = false;
-                const bool use_cols = cols_ok && blocks >= tiles && rows <= (long long)kEccRowTab * (blocks / tiles) &&
-                                      rows < 32768 && cols < 32768;
-                // pixels per thread and trip / waves per SIMD of round 2's kernel, measured on 1000 frames of 1024^2
-                // (tools/exp_ecc.sh; ms of the sums per step): general iteration 2 px at 3 waves per SIMD (162 VGPRs) 8.7; at 2
-                // waves: 1 px 12.2, 2 px 10.1, 3 px 10.5, 4 px 9.6; 1 px at 3 waves 9.9, 3 px at 3 waves (10 spilled registers)
-                // 10.0; identity iteration 4 px at 3 waves 9.9 (with the default general form), 8 px 9.6, 8 px at 2 waves 10.4.
-                // UPSP_ECC_VARIANT / UPSP_ECC_IVARIANT select the others.
-                static const int variant = env_int_io("UPSP_ECC_VARIANT", 4);
-                static const int ivariant = env_int_io("UPSP_ECC_IVARIANT", 1);
-                if (use_cols) {
-                    // UPSP_ECC_CVARIANT = 10 x identity variant + general variant (measurement switch)
-                    const int iv = cvariant / 10, gv = cvariant % 10;
-                    if (it == 0) {
-                        // (measured, us per 64-frame launch on one box: plain 4 rows per trip 172, DPP taps 4 rows 163, 8 rows at
-                        //  3 waves per SIMD 191, 8 rows at 4 waves -- 82 spilled registers -- 390)
-                        if (iv == 1) UPSP_ECC_COLS(true, 8, 4, 1);
-                        else if (iv == 2) UPSP_ECC_COLS(true, 4, 4);
-                        else if (iv == 3) UPSP_ECC_COLS(true, 8, 3, 1);
-                        else if (fuse_solve) { UPSP_ECC_COLS(true, 4, 4, 1, 1, 1); fused_solve = true; }
-                        else UPSP_ECC_COLS(true, 4, 4, 1);
-                    } else {
-                        // (general iteration, same box: 2 rows per trip at 4 waves per SIMD 316, 4 rows at 3 waves 306, 3 at 3: 313,
-                        //  2 at 3: 330 -- flat: neither rows in flight nor occupancy is what bounds it)
-                        // with gx taken from pixel differences (GXD, the default since the ECC soak): 2 rows at 4 waves -- 4 spilled
-                        // registers -- 6.13 ms of sums per 1000 frames, at 3 waves (146 VGPRs) 5.34, 4 rows at 3 waves 6.38;
-                        // the first gx form (UPSP_ECC_GX=0) at 4 waves 5.29
-                        if (gv == 1) UPSP_ECC_COLS(false, 4, 3);
-                        else if (gv == 3) UPSP_ECC_COLS(false, 3, 3);
-                        else if (gv == 5) UPSP_ECC_COLS(false, 2, 4);
-                        else if (gv == 6) UPSP_ECC_COLS(false, 1, 4);
-                        else if (gv == 7) UPSP_ECC_COLS(false, 1, 5);
-                        else if (gx_form == 0) UPSP_ECC_COLS(false, 2, 4, 0, 0);
-                        else if (fuse_solve) { UPSP_ECC_COLS(false, 2, 3, 0, 1, 1); fused_solve = true; }
-                        else if (share_rows == 2) UPSP_ECC_COLS(false, 2, 3, 0, 1, 0, 2);      // rows software-pipelined, two in flight
-                        else if (share_rows) UPSP_ECC_COLS(false, 2, 3, 0, 1, 0, 1);
-                        else UPSP_ECC_COLS(false, 2, 3);
-                    }
-                }
-                else if (it == 0) {
-                    if (ivariant == 1) UPSP_ECC_LAUNCH(true, 2, 3);
-                    else if (ivariant == 2) UPSP_ECC_LAUNCH(true, 2, 2);
-                    else UPSP_ECC_LAUNCH(true, 1, 3);
-                }
-                else if (variant == 1) UPSP_ECC_LAUNCH(false, 3, 2);
-                else if (variant == 2) UPSP_ECC_LAUNCH(false, 4, 2);
-                else if (variant == 3) UPSP_ECC_LAUNCH(false, 1, 2);
-                else if (variant == 4) UPSP_ECC_LAUNCH(false, 2, 3);
-                else if (variant == 5) UPSP_ECC_LAUNCH(false, 1, 3);
-                else if (variant == 6) UPSP_ECC_LAUNCH(false, 3, 3);
-                else UPSP_ECC_LAUNCH(false, 2, 2);
-#undef UPSP_ECC_COLS
-#undef UPSP_ECC_LAUNCH
-            }
-            static const int dump = env_int_io("UPSP_ECC_DUMP", -1);      // debug: the 45 sums of frame 0 at iteration `dump`
-            if (dump == it) {
-                std::vector<double> h((size_t)kEccSums * kEccStride);
-                UPSP_HIP_CHECK(hipStreamSynchronize(st));
-                UPSP_HIP_CHECK(hipMemcpy(h.data(), s->partial, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
-                for (int k = 0; k < kEccSums; ++k) {
-                    long double a = 0;
-                    for (int b = 0; b < nblocks_total; ++b) a += h[(size_t)k * kEccStride + b];
-                    std::fprintf(stderr, "[upsp] ecc sum %2d = %.17Lg\n", k, a);
-                }
-            }
-            if (!fused_solve) {
-                KTimed kt2("ecc_solve_kernel", st);
-                hipLaunchKernelGGL(ecc_solve_kernel, dim3(nb), dim3(256), 0, st, s->state,
-                                   (const double *)s->partial, nb, nblocks_total, max_iters, eps, rows, cols);
-            }
-        }
-        int h[4] = {0, 0, 0, 0};
-        hipLaunchKernelGGL(ecc_count_active, dim3(1), dim3(64), 0, st, (const EccState *)s->state, nb,
-                           s->counter);
-        // the read-back goes to pinned memory behind an event: whatever `while_waiting` enqueues (the next sub-batch's
-        // hot-pixel repair and pre-blur) runs on the GPU while the host waits for these four words
-        UPSP_HIP_CHECK(hipMemcpyAsync(s->h_counter, s->counter, sizeof(h), hipMemcpyDeviceToHost, st));
-        UPSP_HIP_CHECK(hipEventRecord(s->ev_counter, st));
-        if (while_waiting && !waited) {
-            waited = true;
-            const int rcw = (*while_waiting)();
-            if (rcw != UPSP_OK) return rcw;
-        }
-        UPSP_HIP_CHECK(hipEventSynchronize(s->ev_counter));
-        for (int i = 0; i < 4; ++i) h[i] = s->h_counter[i];
-        if (h[1] > 0)
-            return fail(UPSP_ERR_DIVERGED,
-                        "ECC registration did not converge (cv::findTransformECC would throw)");
-        iters_done = h[2];
-        most_iters = h[3];
-        if (h[0] == 0 || it >= max_iters) break;
-        active = h[0];
-    }
-    s->ecc_first_burst = std::min(std::max(most_iters, 2), 4);
-    s->ecc_frame_iters += (unsigned long long)iters_done;
-    s->ecc_frames += (unsigned long long)nb;
-    UPSP_HIP_CHECK(hipGetLastError());
-    if (std::getenv("UPSP_TRACE_ECC")) {
-        std::vector<EccState> h(nb);
-        UPSP_HIP_CHECK(hipMemcpy(h.data(), s->state, sizeof(EccState) * nb, hipMemcpyDeviceToHost));
-        int tot = 0, mx = 0;
-        for (int i = 0; i < nb; ++i) {
-            const auto &e = h[i];
-            tot += e.iters; mx = std::max(mx, e.iters);
-            if (e.iters > 8)
-                std::fprintf(stderr, "[upsp]   frame %lld: %d iters rho=%.9f last=%.9f M=[%g %g %g; %g %g %g]\n",
-                             (long long)first_frame + i, e.iters, e.rho, e.last_rho, e.M[0], e.M[1], e.M[2], e.M[3], e.M[4], e.M[5]);
-        }
-        std::fprintf(stderr, "[upsp] ECC sub-batch of %d frames: %d frame-iterations, max %d, %d launches\n",
-                     nb, tot, mx, it);
-    }
-    return UPSP_OK;
-}
-
 __global__ void __launch_bounds__(256)
     pixel_mask_kernel(const int32_t *__restrict__ pix, unsigned nnodes, unsigned npix, uint8_t *__restrict__ mask)
 {
@@ -2696,29 +916,45 @@ int launch_pixel_list(const int32_t *d_pix, size_t nnodes, uint8_t *d_mask, unsi
     return UPSP_OK;
 }
 
-// GaussianBlur 5 x 5 of nb frames (the ECC's pre-blur, cpp/lib/registration.cpp:57-60) into one of the scratch's two blurred-frame
-// buffers, on any stream: the streamed registration loop runs it for sub-batch k + 1 while sub-batch k iterates -- a
-// memory-bound kernel beside the issue-bound ECC sums, and work for the GPU while the host reads "frames still
-// iterating" back.  *out = the buffer to hand to run_frame_stages.
-bool frame_stages_fuse_hot(const uint16_t *d_frames, int rows, int cols, const upsp_pipeline_opts &opts)
-{
-    // (the scratch's blurred-frame buffer comes from hipMalloc: 256-byte aligned)
-    // Opt-in (UPSP_HOT_IN_BLUR=1), measured and NOT the default: it saves the 27-us scan per sub-batch and pays it back with
-    // what replaces it -- a memset of the flags, a scan launch whose blocks all exit and a second blur launch whose blocks
-    // all exit: 9.5-9.6 against 9.38 ms per 1000 frames.
-    return opts.registration && !std::getenv("UPSP_ECC_FUSED") && env_int_io("UPSP_HOT_IN_BLUR", 0) &&
-           gauss5_quad_applies(d_frames, nullptr, 1, rows, cols);
-}
-
-int frame_scratch_preblur(FrameScratch *s, int slot, const uint16_t *d_frames, int nb, int rows, int cols, hipStream_t st,
-                          const float **out)
+// GaussianBlur 5 x 5 of nb frames (the ECC's pre-blur, cpp/lib/registration.cpp:57-60) into one of the scratch's two
+// blurred-frame buffers: the streamed registration loop enqueues it for sub-batch k + 1 while the host waits for sub-batch
+// k's "frames still iterating".  *out = the buffer to hand to run_frame_stages.
+int frame_scratch_preblur(FrameScratch *s, int slot, uint16_t *d_frames, int nb, int rows, int cols, hipStream_t st,
+                          const float **out, const HotRepair *hot)
 {
     if (!s || !s->ecc_img || nb > s->batch) return fail(UPSP_ERR_INVALID, "pre-blur: scratch not set up");
     if (slot && !s->ecc_img2) UPSP_HIP_CHECK(hipMalloc(&s->ecc_img2, (size_t)s->batch * rows * cols * sizeof(float)));
     float *dst = slot ? s->ecc_img2 : s->ecc_img;
-    // (the 5 x 5 tile kernel: no intermediate image, nothing shared with the other stream)
-    if (rows <= 2 || cols <= 2) return fail(UPSP_ERR_INVALID, "pre-blur: image too small for the tile kernel");
-    int rc = launch_gauss<uint16_t>(d_frames, dst, nullptr, nb, rows, cols, 5, st);
+    FilterCoef fc;
+    if (gaussian_coef(5, fc) != 0) return fail(UPSP_ERR_INVALID, "gaussian 5");
+    int rc = UPSP_OK;
+    bool blurred = false;
+    if (hot && hot->max_hot < kHotPositions) {
+        // The scan of fix_hot_pixels rides on the blur's read of the frames (a pass of its own is 2 MiB per frame = 27 us per
+        // 64 frames of 1024^2): the blur counts and lists the pixels >= thresh, one lane per frame repairs the rare frames
+        // that hold 1 .. max_hot of them exactly like the reference (in place, scan order), and the blurred values such a
+        // pixel reaches -- its 5 x 5 neighbourhood -- are recomputed from the repaired frame: the same bits as repair-then-blur
+        // (tests/test_imageops_gpu.py::test_registration_sub_batches_look_ahead, test_frames_gpu.py).
+        KTimed kt("gauss_pass_kernels", st);
+        blurred = launch_gauss5_quad(d_frames, dst, nb, rows, cols, fc, st, (unsigned)hot->thresh, hot->d_count, hot->d_pos);
+    }
+    if (blurred) {
+        rc = launch_hot_repair_list(d_frames, (size_t)rows * cols, nb, rows, cols, hot->min_change, hot->max_hot, hot->d_count,
+                                    hot->d_pos, hot->d_changes, st);
+        if (rc != UPSP_OK) return rc;
+        const unsigned *nch = hot->d_changes + 4;
+        const uint4 *list = reinterpret_cast<const uint4 *>(hot->d_changes + 4 + (((size_t)nb + 3) & ~(size_t)3));
+        if (hot->max_hot > 0)
+            hipLaunchKernelGGL(reblur_changes_kernel, dim3((unsigned)nb), dim3(256), 0, st, (const uint16_t *)d_frames, dst, rows, cols,
+                               nch, list, hot->max_hot, fc.k[2], fc.k[3], fc.k[4]);
+        UPSP_HIP_CHECK(hipGetLastError());
+    } else {
+        if (hot) {
+            rc = launch_hot_fix(d_frames, nb, rows, cols, hot->thresh, hot->min_change, hot->max_hot, hot->d_count, hot->d_pos, nullptr, st);
+            if (rc != UPSP_OK) return rc;
+        }
+        rc = launch_gauss<uint16_t>(d_frames, dst, s->tmp, nb, rows, cols, 5, st);      // (tmp: images too small for the fused kernels)
+    }
     if (rc == UPSP_OK) *out = dst;
     return rc;
 }
@@ -2727,7 +963,7 @@ int run_frame_stages(FrameScratch *s, int cam, const uint16_t *d_frames, int nb,
                      int rows, int cols, const upsp_pipeline_opts &opts, const float *d_ref,
                      const PatchTables *patches, float *d_warps, int32_t *d_iters, int ncams,
                      const unsigned *d_read_list, const WarpCompact *wc, const void **img_out, int *is_f32_out,
-                     hipStream_t st, const float *preblurred, const HotFuse *hot, const std::function<int()> *while_waiting)
+                     hipStream_t st, const float *preblurred, const std::function<int()> *while_waiting)
 {
     const size_t npix = (size_t)rows * cols;
     const uint16_t *cur = d_frames;
@@ -2736,11 +972,18 @@ int run_frame_stages(FrameScratch *s, int cam, const uint16_t *d_frames, int nb,
         if (s->tmpl_src[cam] != d_ref) {  // blurred template, once per reference image
             int rc = launch_gauss<float>(d_ref, s->tmpl[cam], s->tmp, 1, rows, cols, 5, st);
             if (rc != UPSP_OK) return rc;
-            hipLaunchKernelGGL(ecc_center_kernel, dim3(1), dim3(256), 0, st, (const float *)s->tmpl[cam], rows, cols, s->center + cam);
+            rc = launch_ecc_center(s->tmpl[cam], rows, cols, s->center + cam, st);
+            if (rc != UPSP_OK) return rc;
             s->tmpl_src[cam] = d_ref;
         }
-        int rc = run_ecc(s, s->tmpl[cam], s->center + cam, d_frames, nb, first_frame, rows, cols, opts.ecc_max_iters,
-                         opts.ecc_eps, st, preblurred, hot, const_cast<uint16_t *>(d_frames), while_waiting);
+        const float *blurred = preblurred;
+        if (!blurred) {      // GaussianBlur 5 x 5 of the input frames (findTransformECC's gaussFiltSize)
+            int rc = launch_gauss<uint16_t>(d_frames, s->ecc_img, s->tmp, nb, rows, cols, 5, st);
+            if (rc != UPSP_OK) return rc;
+            blurred = s->ecc_img;
+        }
+        int rc = run_ecc(s, s->tmpl[cam], s->center + cam, blurred, nb, first_frame, rows, cols, opts.ecc_max_iters, opts.ecc_eps, st,
+                         while_waiting);
         if (rc != UPSP_OK) return rc;
         if (wc) {      // registration is the last image stage and node-major series are wanted: straight into the compact buffer
             KTimed kt("warp_u16_kernel", st);
@@ -2755,10 +998,11 @@ int run_frame_stages(FrameScratch *s, int cam, const uint16_t *d_frames, int nb,
             hipLaunchKernelGGL(warp_u16_kernel, wgrid, block, 0, st, d_frames, s->warp[cam], rows, cols,
                                (const EccState *)s->state, opts.interp, listed ? d_read_list : (const unsigned *)nullptr);
         }
-        if (d_warps || d_iters)
-            hipLaunchKernelGGL(ecc_export_warps, dim3((nb + 63) / 64), dim3(64), 0, st,
-                               (const EccState *)s->state, nb, d_warps ? d_warps + (size_t)cam * 6 : (float *)nullptr,
-                               ncams * 6, d_iters ? d_iters + cam : (int32_t *)nullptr, ncams);
+        if (d_warps || d_iters) {
+            rc = launch_ecc_export(s->state, nb, d_warps ? d_warps + (size_t)cam * 6 : (float *)nullptr, ncams * 6,
+                                   d_iters ? d_iters + cam : (int32_t *)nullptr, ncams, st);
+            if (rc != UPSP_OK) return rc;
+        }
         cur = s->warp[cam];
     }
     if (opts.filter == 1 && !opts.patch) {
@@ -2815,10 +1059,10 @@ int upsp_register_pixel_u16(const float *d_ref32f, const uint16_t *d_inp, int ro
     int rc = frame_scratch_ensure(&s, 1, 1, rows, cols, true, false);
     int iters = 0;
     if (rc == UPSP_OK) rc = launch_gauss<float>(d_ref32f, s->tmpl[0], s->tmp, 1, rows, cols, 5, st);
-    if (rc == UPSP_OK)
-        hipLaunchKernelGGL(ecc_center_kernel, dim3(1), dim3(256), 0, st, (const float *)s->tmpl[0], rows, cols, s->center);
+    if (rc == UPSP_OK) rc = launch_ecc_center(s->tmpl[0], rows, cols, s->center, st);
+    if (rc == UPSP_OK) rc = launch_gauss<uint16_t>(d_inp, s->ecc_img, s->tmp, 1, rows, cols, 5, st);
     // first_frame = 1: a stand-alone call always registers (psp_process.cpp:1662-1679)
-    if (rc == UPSP_OK) rc = run_ecc(s, s->tmpl[0], s->center, d_inp, 1, 1, rows, cols, max_iters, eps, st);
+    if (rc == UPSP_OK) rc = run_ecc(s, s->tmpl[0], s->center, s->ecc_img, 1, 1, rows, cols, max_iters, eps, st);
     if (rc == UPSP_OK) {
         hipLaunchKernelGGL(warp_u16_kernel, dim3(grid_for_pixels((size_t)rows * cols), 1), dim3(256), 0,
                            st, d_inp, d_out, rows, cols, (const EccState *)s->state, interp, (const unsigned *)nullptr);
@@ -2840,9 +1084,6 @@ int upsp_blur_u16(const uint16_t *d_src, float *d_dst, int nimg, int rows, int c
 {
     if (!d_src || !d_dst || nimg <= 0 || rows <= 0 || cols <= 0) return fail(UPSP_ERR_INVALID, "bad argument");
     hipStream_t st = (hipStream_t)stream;
-    // (UPSP_GAUSS5_COLS=1: the column-walking 5 x 5 kernel instead of the tile kernel -- measurement / test switch)
-    if (k == 5 && rows >= 5 && cols >= 5 && (long long)rows * cols < (1ll << 29) && env_int_io("UPSP_GAUSS5_COLS", 0))
-        return launch_gauss5_cols(d_src, d_dst, nimg, rows, cols, nullptr, nullptr, nullptr, nullptr, st);
     float *tmp = nullptr;
     UPSP_HIP_CHECK(hipMalloc(&tmp, sizeof(float) * (size_t)nimg * rows * cols));
     int rc = launch_gauss<uint16_t>(d_src, d_dst, tmp, nimg, rows, cols, k, st);

@@ -63,6 +63,9 @@ int launch_hot_fixup(const PipelineGather &g, uint16_t *d_frames, int nframes, i
 int launch_hot_repair_compact(uint16_t *d_frames, size_t npix, int nframes, int rows, int cols, int min_change, int max_hot,
                               unsigned *d_count, const unsigned *d_pos, unsigned *d_changes, const uint8_t *d_flag,
                               const unsigned *d_tile_off, uint16_t *d_compact, unsigned cpitch, hipStream_t st);
+int launch_hot_repair_list(uint16_t *d_frames, size_t npix, int nframes, int rows, int cols, int min_change, int max_hot,
+                           unsigned *d_count, const unsigned *d_pos, unsigned *d_changes, hipStream_t st);
+constexpr int kHotPositions = 64;   // hot-pixel positions recorded per frame (d_pos: kHotPositions words per frame)
 int launch_hot_fixup_multi(const PipelineGather &g, uint16_t *const *d_frames, int nframes, int rows, int cols,
                            int min_change, int max_hot, unsigned *d_count, const unsigned *d_pos,
                            unsigned *d_changes, int32_t *d_head, int32_t *d_next, hipStream_t st);
@@ -92,13 +95,6 @@ namespace upsp {
 // target of the warp when registration is the last image stage of the streamed schedule: the compact
 // [active pixel][frame] buffer (column col0 on, pitch cpitch); pix_of_k = pixel of every compact row,
 // *nact = rows in use (device), max_active = bound of it (grid size)
-// fix_hot_pixels folded into the registration's pre-blur (the blur reads every pixel anyway): the blur flags the frames that
-// hold a pixel >= thresh, hot_scan_kernel runs for those only (normally none), and they are blurred again.  d_count /
-// d_pos: the scratch of launch_hot_fix.
-struct HotFuse {
-    int thresh = 0, min_change = 0, max_hot = 0;
-    unsigned *d_count = nullptr, *d_pos = nullptr;
-};
 struct WarpCompact {
     const unsigned *pix_of_k = nullptr, *nact = nullptr;
     size_t max_active = 0;
@@ -114,13 +110,17 @@ int run_frame_stages(FrameScratch *s, int cam, const uint16_t *d_frames, int nb,
                      int64_t first_frame, int rows, int cols, const upsp_pipeline_opts &opts,
                      const float *d_ref, const PatchTables *patches, float *d_warps, int32_t *d_iters, int ncams,
                      const unsigned *d_read_list, const WarpCompact *wc, const void **img_out, int *is_f32_out,
-                     hipStream_t st, const float *preblurred = nullptr, const HotFuse *hot = nullptr,
-                     const std::function<int()> *while_waiting = nullptr);
-// true when run_frame_stages can take the hot-pixel repair into its pre-blur for frames of this geometry (HotFuse)
-bool frame_stages_fuse_hot(const uint16_t *d_frames, int rows, int cols, const upsp_pipeline_opts &opts);
-// the ECC's 5 x 5 pre-blur of nb frames into blurred-frame buffer `slot` (0 / 1) of the scratch, on any stream
-int frame_scratch_preblur(FrameScratch *s, int slot, const uint16_t *d_frames, int nb, int rows, int cols, hipStream_t st,
-                          const float **out);
+                     hipStream_t st, const float *preblurred = nullptr, const std::function<int()> *while_waiting = nullptr);
+// fix_hot_pixels (cpp/utils/cv_extras.cpp:230-275) scratch of a sub-batch: one counter + kHotPositions positions per frame,
+// the change list of hot_changes_words(nb, max_hot) words
+struct HotRepair {
+    int thresh = 0, min_change = 0, max_hot = 0;
+    unsigned *d_count = nullptr, *d_pos = nullptr, *d_changes = nullptr;
+};
+// fix_hot_pixels + the ECC's 5 x 5 pre-blur of nb frames into blurred-frame buffer `slot` (0 / 1) of the scratch; the frames are
+// repaired in place (hot == null: no repair)
+int frame_scratch_preblur(FrameScratch *s, int slot, uint16_t *d_frames, int nb, int rows, int cols, hipStream_t st,
+                          const float **out, const HotRepair *hot);
 // d_list[0] = number of distinct pixels with a node, d_list[1..] = those pixels (any order); d_mask: npix bytes of scratch
 int launch_pixel_list(const int32_t *d_pix, size_t nnodes, uint8_t *d_mask, unsigned *d_list, size_t npix, hipStream_t st);
 }  // namespace upsp

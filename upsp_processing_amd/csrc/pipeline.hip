@@ -78,9 +78,6 @@ struct upsp_pipeline {
     // optional second stream (UPSP_OVERLAP=1): the gather of sub-batch k overlaps the scan of k+1
     hipStream_t aux = nullptr;
     hipEvent_t ev_in = nullptr, ev_fix[2] = {nullptr, nullptr}, ev_out = nullptr;
-    // streamed registration: hot-pixel repair + pre-blur of sub-batch k + 1 run on `pre` while sub-batch k iterates
-    hipStream_t pre = nullptr;
-    hipEvent_t ev_pre_in = nullptr, ev_blur[2] = {nullptr, nullptr}, ev_used[2] = {nullptr, nullptr};
 };
 
 namespace {
@@ -206,8 +203,7 @@ void upsp_pipeline_destroy(upsp_pipeline *p)
     }
     upsp::frame_scratch_free(p->scratch);
     if (p->aux) (void)hipStreamDestroy(p->aux);
-    if (p->pre) (void)hipStreamDestroy(p->pre);
-    for (hipEvent_t e : {p->ev_in, p->ev_fix[0], p->ev_fix[1], p->ev_out, p->ev_pre_in, p->ev_blur[0], p->ev_blur[1], p->ev_used[0], p->ev_used[1]})
+    for (hipEvent_t e : {p->ev_in, p->ev_fix[0], p->ev_fix[1], p->ev_out})
         if (e) (void)hipEventDestroy(e);
     free_dev(p->d_read_mask);
     free_dev(p->d_skipped);
@@ -826,106 +822,54 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
         wc.compact = p->d_compact;
         wc.cpitch = cp;
         uint16_t *fr = d_frames[0];
-        // UPSP_REG_PIPELINE=1 (opt-in, measured and NOT the default): sub-batch k + 1's hot-pixel repair and pre-blur run on a
-        // stream of their own while sub-batch k iterates (two blurred-frame buffers) -- a memory-bound kernel beside the
-        // issue-bound ECC sums, and work for the GPU while the host reads "frames still iterating" back.  Same bits
-        // (tests/test_imageops_gpu.py::test_registration_sub_batches_pipelined), but 10.3 instead of 9.87 ms per 1000 frames:
-        // beside each other the sums take 7.9 instead of 5.3 ms and the pre-blur 3.6 instead of 2.1 -- the second 256 MB of
-        // blurred frames pushes the first out of the Infinity Cache between the identity and the general iteration, the
-        // same outcome as every other overlap of two streaming phases tried on this part (DESIGN.md sections 7 and 8).
-        const bool pipe_env = std::getenv("UPSP_REG_PIPELINE") && std::atoi(std::getenv("UPSP_REG_PIPELINE")) != 0;
-        const bool pipelined = pipe_env && nframes > B && p->height > 2 && p->width > 2 && !std::getenv("UPSP_ECC_FUSED");
-        if (pipelined && !p->pre) {
-            UPSP_HIP_CHECK(hipStreamCreateWithFlags(&p->pre, hipStreamNonBlocking));
-            for (hipEvent_t *e : {&p->ev_pre_in, &p->ev_blur[0], &p->ev_blur[1], &p->ev_used[0], &p->ev_used[1]})
-                UPSP_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
-        }
-        auto repair = [&](uint16_t *frames, int nb, hipStream_t s_) -> int {
-            if (!p->opts.hot_enable) return UPSP_OK;  // psp_process.cpp:1772
-            int r = ensure_hot(p, nb);
-            if (r == UPSP_OK)
-                r = launch_hot_fix(frames, nb, p->height, p->width, p->opts.hot_thresh, p->opts.hot_min_change, p->opts.hot_max,
-                                   p->d_hot_count, p->d_hot_pos, nullptr, s_);
-            return r;
-        };
         // sub-batches of the whole call, in order
         struct Sub { int f0, nb, s0; };
         std::vector<Sub> subs;
         for (int s0 = 0; s0 < nframes; s0 += S)
             for (int f0 = s0; f0 < std::min(s0 + S, nframes); f0 += B) subs.push_back({f0, std::min(B, std::min(s0 + S, nframes) - f0), s0});
+        // One stream; sub-batch k + 1's hot-pixel repair and pre-blur (upsp::frame_scratch_preblur: the scan of fix_hot_pixels
+        // rides on the blur, psp_process.cpp:1772) are enqueued while the host waits for sub-batch k's "frames still
+        // iterating" (two blurred-frame buffers): the GPU has work during the read-back and nothing runs beside anything.
+        // (Measured and rejected in round 3: the same kernels on a stream of their own beside the ECC sums -- same bits, 10.3
+        // instead of 9.87 ms per 1000 frames: the second 256 MB of blurred frames pushes the first out of the Infinity Cache
+        // between the identity and the general iteration.)
+        upsp::HotRepair hot;
+        if (p->opts.hot_enable) {
+            rc = ensure_hot(p, B);
+            if (rc != UPSP_OK) return rc;
+            hot.thresh = p->opts.hot_thresh;
+            hot.min_change = p->opts.hot_min_change;
+            hot.max_hot = p->opts.hot_max;
+            hot.d_count = p->d_hot_count;
+            hot.d_pos = p->d_hot_pos;
+            hot.d_changes = p->d_changes;         // (streamed_buffers: sized for the frames of the call)
+        }
         const float *blurred[2] = {nullptr, nullptr};
-        auto ahead = [&](size_t i) -> int {        // repair + pre-blur of sub-batch i on the side stream
-            const int slot = (int)(i & 1);
-            uint16_t *frames = fr + (size_t)subs[i].f0 * npix;
-            if (i >= 2) UPSP_HIP_CHECK(hipStreamWaitEvent(p->pre, p->ev_used[slot], 0));     // sub-batch i - 2 has read the buffer
-            int r = repair(frames, subs[i].nb, p->pre);
-            if (r == UPSP_OK) r = upsp::frame_scratch_preblur(p->scratch, slot, frames, subs[i].nb, p->height, p->width, p->pre, &blurred[slot]);
-            if (r == UPSP_OK) UPSP_HIP_CHECK(hipEventRecord(p->ev_blur[slot], p->pre));
-            return r;
-        };
-        // Default: the SAME stream, but sub-batch k + 1's repair and pre-blur are enqueued while the host waits for sub-batch k's
-        // "frames still iterating" (two blurred-frame buffers): the GPU has work during the read-back and nothing runs beside
-        // anything.  UPSP_REG_AHEAD=0: blur inside the sub-batch's own stage call.
-        const bool ahead1 = !pipelined && nframes > B && p->height > 2 && p->width > 2 && !std::getenv("UPSP_ECC_FUSED") &&
-                            !(std::getenv("UPSP_REG_AHEAD") && std::atoi(std::getenv("UPSP_REG_AHEAD")) == 0) &&
-                            !(p->opts.hot_enable && upsp::frame_stages_fuse_hot(fr, p->height, p->width, p->opts));
         std::vector<char> blur_done(subs.size(), 0);
-        auto ahead_same_stream = [&](size_t i) -> int {            // repair + pre-blur of sub-batch i on the caller's stream
+        auto preblur = [&](size_t i) -> int {                  // repair + pre-blur of sub-batch i on the caller's stream
             if (blur_done[i]) return UPSP_OK;
             blur_done[i] = 1;
-            uint16_t *frames = fr + (size_t)subs[i].f0 * npix;
-            int r = repair(frames, subs[i].nb, st);
-            if (r == UPSP_OK) r = upsp::frame_scratch_preblur(p->scratch, (int)(i & 1), frames, subs[i].nb, p->height, p->width, st, &blurred[i & 1]);
-            return r;
+            return upsp::frame_scratch_preblur(p->scratch, (int)(i & 1), fr + (size_t)subs[i].f0 * npix, subs[i].nb, p->height, p->width,
+                                               st, &blurred[i & 1], p->opts.hot_enable ? &hot : nullptr);
         };
-        if (ahead1) rc = ahead_same_stream(0);
-        if (pipelined) {
-            UPSP_HIP_CHECK(hipEventRecord(p->ev_pre_in, st));      // the frames are ready where the caller's stream is now
-            UPSP_HIP_CHECK(hipStreamWaitEvent(p->pre, p->ev_pre_in, 0));
-            rc = ahead(0);
-        }
         for (size_t i = 0; i < subs.size() && rc == UPSP_OK; ++i) {
             const int f0 = subs[i].f0, nb = subs[i].nb, s0 = subs[i].s0;
             uint16_t *frames = fr + (size_t)f0 * npix;
-            const float *pre = nullptr;
-            upsp::HotFuse fuse;
-            const upsp::HotFuse *hotp = nullptr;
             std::function<int()> next_blur;
             const std::function<int()> *while_waiting = nullptr;
-            if (pipelined) {
-                if (i + 1 < subs.size()) rc = ahead(i + 1);
-                if (rc != UPSP_OK) break;
-                UPSP_HIP_CHECK(hipStreamWaitEvent(st, p->ev_blur[i & 1], 0));
-                pre = blurred[i & 1];
-            } else if (ahead1) {
-                rc = ahead_same_stream(i);                  // (already done while sub-batch i - 1 waited, normally)
-                if (rc != UPSP_OK) break;
-                pre = blurred[i & 1];
-                if (i + 1 < subs.size()) {
-                    next_blur = [&, i]() { return ahead_same_stream(i + 1); };
-                    while_waiting = &next_blur;
-                }
-            } else if (p->opts.hot_enable && upsp::frame_stages_fuse_hot(frames, p->height, p->width, p->opts)) {
-                // the repair rides on the pre-blur (upsp::HotFuse): no scan launch of its own
-                rc = ensure_hot(p, nb);
-                if (rc != UPSP_OK) break;
-                fuse.thresh = p->opts.hot_thresh;
-                fuse.min_change = p->opts.hot_min_change;
-                fuse.max_hot = p->opts.hot_max;
-                fuse.d_count = p->d_hot_count;
-                fuse.d_pos = p->d_hot_pos;
-                hotp = &fuse;
-            } else {
-                rc = repair(frames, nb, st);
-                if (rc != UPSP_OK) break;
+            rc = preblur(i);                                // (already done while sub-batch i - 1 waited, normally)
+            if (rc != UPSP_OK) break;
+            const float *pre = blurred[i & 1];
+            if (i + 1 < subs.size()) {
+                next_blur = [&, i]() { return preblur(i + 1); };
+                while_waiting = &next_blur;
             }
             wc.col0 = (unsigned)(f0 - s0);
             const void *img = nullptr;
             int is_f32 = 0;
             rc = upsp::run_frame_stages(p->scratch, 0, frames, nb, first_frame + f0, p->height, p->width, p->opts, p->d_ref[0],
                                         nullptr, d_warps ? d_warps + (size_t)f0 * 6 : nullptr,
-                                        p->d_ecc_iters ? p->d_ecc_iters + f0 : nullptr, 1, nullptr, &wc, &img, &is_f32, st, pre, hotp, while_waiting);
-            if (pipelined && rc == UPSP_OK) UPSP_HIP_CHECK(hipEventRecord(p->ev_used[i & 1], st));
+                                        p->d_ecc_iters ? p->d_ecc_iters + f0 : nullptr, 1, nullptr, &wc, &img, &is_f32, st, pre, while_waiting);
             const bool last_of_group = i + 1 == subs.size() || subs[i + 1].s0 != s0;
             if (rc == UPSP_OK && last_of_group) {
                 const int ns = std::min(S, nframes - s0);
@@ -936,7 +880,6 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
                 rc = launch_node_rows(g, p->d_node_k, p->d_compact, cp, st);
             }
         }
-        if (pipelined && rc != UPSP_OK) (void)hipStreamSynchronize(p->pre);      // nothing of this call may outlive it
         return rc;
     }
     // Several cameras (weights allowed): the same two passes with one active-pixel map and one whole-call compact
