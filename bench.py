@@ -18,15 +18,15 @@ ranks (weak scaling: every GPU processes --frames frames).
 `python bench.py --gpus N` with N > 1 and no rank environment starts N rank processes itself
 (torch.distributed.run, one per GPU, RCCL) before anything touches the GPU; under an external
 launcher (RANK / WORLD_SIZE set) it is one of the ranks.  Rank 0 prints ONE JSON line.
-`value` = frames/s over the whole job; `mrays_per_s` = reference-equivalent node rays/s of the
-projection build (rays the reference would cast / build time).  The build applies the oblique test before the
-rays (nodes it rejects have no entry whatever their rays say and cast none) and decides most retry rays by
-the occluder witness instead of a traversal -- `rays_cast_per_step` counts what is really cast, and
-`mrays_cast_per_s` is that count over the build time.  `pixel_rays` is the plain ray caster: closest hit of one ray per
-pixel of the frame (1 Mpix onto the 1 M-triangle model), every ray traversed, a sample checked against the oracle;
-`pixel_rays_fill` is the same on a 1 M-triangle sphere that fills the frame (every ray enters the tree), both with the
-rays that ENTER the root box counted apart and the traversal bytes per ray (nodes visited x 64 B + triangles tested x
-48 B) from the statistics counters.
+`value` = frames/s over the whole job (`summary` says it in one sentence, with the host-feed rate beside it).
+`mrays_per_s` = closest-hit rays that ENTER the tree per second, one ray per pixel (`pixel_rays_fill`: a 1 M-triangle
+sphere that fills the frame; `pixel_rays`: the tunnel model, 8 % of the pixels), every ray traversed, a sample checked
+against the oracle, with the traversal bytes per ray (wide nodes visited x 128 B + triangles tested x 48 B)
+from the statistics counters.  The projection build applies the oblique test before the rays (nodes it rejects have no
+entry whatever their rays say and cast none) and decides most retry rays by the occluder witness instead of a traversal:
+`rays_cast_per_step` counts what is really cast (`mrays_cast_per_s` over the build time), `rays_per_step` what the
+REFERENCE casts for the same camera, and `mrays_reference_equivalent_per_s` is that count over the build time -- an
+equivalence, not a ray rate.
 
 Schedule of the default (one GPU, plain loop): the ray casting of the projection build runs on a high-priority stream of its own,
 pass A of the frame loop (which needs only the candidate pixels of the in-frame nodes) beside it, then pass B and the repair;
@@ -96,6 +96,11 @@ def parse():
                          "rays of the projection build are cast")
     ap.add_argument("--chunks", type=int, default=4,
                     help="N > 1 loop: chunks the rank's frames are exchanged in (the exchange of chunk k runs while chunk k + 1 is scanned)")
+    ap.add_argument("--config3-share", action="store_true",
+                    help="one rank's share of BASELINE configs[3] (100 000 frames on 8 GPUs) as ONE step: 12 500 resident frames through "
+                         "the N > 1 loop (implies --force-chunked on one GPU; as many exchange chunks as keep each within one pass A, "
+                         "i.e. <= 1024 frames) -- the run's chunks overlap each other, only the last one and pass B are exposed once "
+                         "per 12 500 frames, not once per 1000 as in the default N > 1 step")
     ap.add_argument("--serial", action="store_true",
                     help="one stream: projection build, then pass A, then pass B (round 2's default schedule)")
     ap.add_argument("--plain-frames", action="store_true",
@@ -173,7 +178,8 @@ def pixel_ray_rate(bvh, cam_dict, size, check_with=None):
     is traversed, nothing is culled or witnessed.  check_with: oracle BVH -> a strided sample is compared bit for bit.
     Reported: all rays / s, the rays that enter the root box / s (the others end at the first box test), the hit
     fraction, and SURVEY.md 8(d)'s traversal bytes per ray from the statistics counters of one extra, untimed call
-    (interior nodes visited x 64 B + triangles tested x 48 B; what rt::BVH::intersect touches, pspRT.cpp:376-429)."""
+    (wide nodes visited x 128 B -- one record decides two levels of rt::BVH::intersect's descent, pspRT.cpp:376-429 --
+    + triangles tested x 48 B)."""
     import torch
     org, dirs = pixel_rays(cam_dict, size)
     d_org, d_dirs = torch.as_tensor(org).cuda(), torch.as_tensor(dirs).cuda()
@@ -196,7 +202,7 @@ def pixel_ray_rate(bvh, cam_dict, size, check_with=None):
     bvh.intersect(d_org, d_dirs, want=("hit",))
     st = bvh.last_stats()
     bvh.enable_stats(False)
-    trav_bytes = st["nodes"] * 64 + st["tris"] * 48
+    trav_bytes = st["nodes"] * 128 + st["tris"] * 48
     alg = n * 40                                 # 24 B ray + 16 B hit record
     out = {"rays": int(n), "ms": ms, "mrays_per_s": n / (ms * 1e-3) / 1e6,
            "rays_entered": entered, "mrays_entered_per_s": entered / (ms * 1e-3) / 1e6,
@@ -210,7 +216,7 @@ def pixel_ray_rate(bvh, cam_dict, size, check_with=None):
            "scene_bytes": int(info["device_bytes"]),
            "what": "closest hit (t, primID) of one ray per pixel of the %d x %d frame, upsp_bvh_intersect; all rays traversed; "
                    "algorithmic bytes = 40 B per ray (the scene, %d MB, is cache-resident across the batch and not credited); "
-                   "traversal bytes = nodes visited x 64 B + triangles tested x 48 B from the statistics counters"
+                   "traversal bytes = wide nodes visited x 128 B + triangles tested x 48 B from the statistics counters"
                    % (size, size, info["device_bytes"] // 1000000)}
     if check_with is not None:
         idx = np.arange(0, dirs.shape[0], 37)
@@ -673,6 +679,11 @@ def multi_camera_main(a):
 
 def main():
     a = parse()
+    if a.config3_share:
+        a.force_chunked = True
+        if a.frames == 1000:
+            a.frames = 12500
+        a.no_reraycast = True
     if a.cameras > 1:
         if a.gpus != 1:
             raise SystemExit("bench.py --cameras: one GPU (all cameras of a frame are kept on one GPU)")
@@ -703,11 +714,25 @@ def main():
             sck.bind(("127.0.0.1", 0))
             os.environ.setdefault("MASTER_PORT", str(sck.getsockname()[1]))
     if world > 1 or force_coll:
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        import datetime
+        try:
+            # (a rank that never shows up must end the job with a message, not hang it: 5-minute rendezvous limit)
+            tmo = datetime.timedelta(seconds=int(os.environ.get("UPSP_BENCH_INIT_TIMEOUT", "300")))
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, timeout=tmo,
+                                        device_id=torch.device("cuda", local))
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
+            # first collective = the communicator really exists on every rank
+            probe = torch.ones(1, device="cuda")
+            dist.all_reduce(probe)
+            torch.cuda.synchronize()
+            if int(probe.item()) != world:
+                raise RuntimeError("all_reduce over %d ranks returned %g" % (world, float(probe.item())))
+        except Exception as e:                                   # noqa: BLE001
+            print("bench.py: rank %d of %d could not join the %s process group: %s: %s" % (rank, world, backend, type(e).__name__, e),
+                  file=sys.stderr, flush=True)
+            raise SystemExit(3)
     _capi.lib()
 
     size = a.size
@@ -751,7 +776,8 @@ def main():
     # frames that carry hot pixels (1 % of them) are therefore put back before every step -- a stand-in for new
     # frames arriving (<= 10 x 2 MiB device copy per 1000 frames, inside the timed region).
     f16 = frames.view(torch.int16)
-    hot_idx = torch.nonzero((f16.reshape(F, -1) >= 4064).any(1), as_tuple=False).reshape(-1)
+    hot_idx = torch.cat([torch.nonzero((f16[f0:f0 + 500].reshape(min(500, F - f0), -1) >= 4064).any(1), as_tuple=False).reshape(-1) + f0
+                         for f0 in range(0, F, 500)])         # (in pieces: a 12 500-frame share is 13 G pixels)
     pristine = f16[hot_idx].clone()
 
     def restore_hot():
@@ -776,6 +802,9 @@ def main():
     # N > 1: the frame loop runs in K chunks and the all-to-all of chunk k is issued
     # asynchronously while chunk k+1 is being processed (distributed.TimeSeriesExchange)
     K = max(1, a.chunks) if chunked else 1
+    if chunked and (a.config3_share or F > 1024 * K):
+        # every chunk within one pass A group (<= 1024 frames; the cuts sit on 64-frame boundaries)
+        K = D.chunk_count(shard.frame_count, 1024)
     exch = D.TimeSeriesExchange(shard, K, wire12=a.wire12) if chunked else None
     # one camera, no weights, no filter: the series values are exact 16-bit integers, so the
     # travelling rows are produced and sent as u16 (half the bytes) and widened by the receiver
@@ -907,10 +936,12 @@ def main():
         step(False)
     barrier()
     _capi.timing_enable(False)
+    dt_rank_min = dt_rank_max = dt
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt, -dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        dt_rank_max, dt_rank_min = float(tt[0].item()), -float(tt[1].item())
+        dt = dt_rank_max
 
     ms_step = dt / a.steps * 1e3
     total_frames = F * world
@@ -1052,7 +1083,10 @@ def main():
                    **({"exchange": "%d chunks, %s as %s" % (K, "active-pixel series" if pixel_wire else "visible rows",
                                                             ("u16 packed to 12 bit" if a.wire12 else "u16") if u16_wire else "f32")}
                       if chunked else {})},
-        "mrays_per_s": mrays, "mrays_per_s_kind": "reference-equivalent (rays the reference casts / build time%s)" % (
+        # rays the REFERENCE casts for this camera / the time of a build that casts a tenth of them (the oblique test first, the
+        # occluder witness): an equivalence, not a ray rate -- "mrays_per_s" below is the ray caster's own rate
+        "mrays_reference_equivalent_per_s": mrays,
+        "mrays_reference_equivalent_kind": "rays the reference casts / build time%s" % (
             " of builds timed alone after the steps: in the steps pass A runs beside the build" if overlap else ""),
         "rays_per_step": nrays, "rays_cast_per_step": primary_rays + n_retry_rays,
         "mrays_cast_per_s": (primary_rays + n_retry_rays) / (ray_alone_ms * 1e-3) / 1e6,
@@ -1069,6 +1103,10 @@ def main():
         "roofline": roof,
         "kernels": kernels,
     }
+    if world > 1 or force_coll:
+        cr = D.comm_ranks()
+        out["rccl_nranks"] = None if cr is None else cr[1]       # ncclCommCount of the communicator the exchanges ran on
+        out["ms_per_step_rank_min_max"] = [dt_rank_min / a.steps * 1e3, dt_rank_max / a.steps * 1e3]
     if chunked:
         # what a rank hands to the exchange per step, and how much of it crossed a link in THIS run (nothing in a one-rank
         # group; (N - 1) / N of it at N ranks, one block per xGMI link and chunk)
@@ -1108,7 +1146,7 @@ def main():
     if plain_default:
         # BASELINE configs[2] beside the headline: the same resident frames with per-frame ECC registration
         out["configs2"] = registration_block(bvh, cam, d_nodes, d_nrm, d_tn, frames, restore_hot, N, size, n_active,
-                                             steps=3, warmup=2)
+                                             steps=5, warmup=2)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         with_reg = a.registration or plain_default
         out["cpu_baseline"], ref = cpu_baseline(verts, tris, cd, size, F, sample, registration=with_reg)
@@ -1178,6 +1216,18 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
+        # the key named like BASELINE.json's ray metric: closest-hit rays that ENTER the tree per second, on the scene where every
+        # pixel's ray does (pixel_rays_fill) when this run measured it, on the tunnel model otherwise
+        pr = out.get("pixel_rays_fill") or out.get("pixel_rays")
+        out["mrays_per_s"] = pr.get("mrays_entered_per_s") if pr else None
+        out["mrays_per_s_kind"] = (None if not pr else "closest-hit rays entering the tree per second, one ray per pixel, %s"
+                                   % ("frame-filling 1 M-triangle sphere (pixel_rays_fill)" if "pixel_rays_fill" in out else "tunnel model (pixel_rays)"))
+        hf, c2 = out.get("host_feed"), out.get("configs2")
+        out["summary"] = "%.0f k frames/s with the frames resident in HBM (%d GPU%s)%s%s%s" % (
+            fps / 1e3, world, "" if world == 1 else "s",
+            "; %.1f k frames/s when they arrive from host memory (PCIe-bound, never `value`)" % (hf["frames_per_s"] / 1e3) if hf and hf.get("frames_per_s") else "",
+            "; configs[2] (ECC registration, parity unpinned) %.0f k frames/s" % (c2["value"] / 1e3) if c2 else "",
+            "; %.2f G rays/s entering the tree" % (out["mrays_per_s"] / 1e3) if out.get("mrays_per_s") else "")
         print(json.dumps(out), flush=True)
     if exch is not None:
         exch.verify()                   # (the timer-on steps made assume_same claims too)

@@ -296,6 +296,71 @@ static void relabel_top_breadth_first(HostBvh &out, uint32_t top)
     out.root_ref = newid[out.root_ref];
 }
 
+// Two levels of the binary tree per record (GpuWide): a wide node stands for a binary interior node the traversal enters
+// -- the root and every interior grandchild, great-great-grandchild, ... -- and lists, for each of that node's two
+// children, the child itself (a leaf) or the child's two children.  Topology, boxes, leaf order and the per-node split
+// axes are copied, nothing is recomputed: the set of leaves a ray reaches and the order it reaches them in are the
+// binary tree's.
+static void collapse_wide(HostBvh &out)
+{
+    out.wide.clear();
+    out.wide_depth = 0;
+    if (out.root_ref < 0 || out.nodes.empty()) {
+        out.wide_root = out.root_ref;
+        return;
+    }
+    out.wide.reserve(out.nodes.size() / 2 + 16);
+    struct Item { int32_t node; uint32_t self, depth; };
+    std::vector<Item> todo;
+    auto child = [&](int32_t n, int k) { int32_t r; std::memcpy(&r, &out.nodes[n].q[12 + k], 4); return r; };
+    auto meta_of = [&](int32_t n) { uint32_t m; std::memcpy(&m, &out.nodes[n].q[14], 4); return m & 7u; };
+    auto new_wide = [&](int32_t n, uint32_t depth) {
+        const uint32_t idx = (uint32_t)out.wide.size();
+        out.wide.emplace_back();
+        todo.push_back({n, idx, depth});
+        return idx;
+    };
+    out.wide_root = (int32_t)new_wide(out.root_ref, 1);
+    while (!todo.empty()) {
+        const Item it = todo.back();
+        todo.pop_back();
+        out.wide_depth = std::max(out.wide_depth, it.depth);
+        float q[32];
+        std::memset(q, 0, sizeof(q));
+        int32_t refs[4] = {kWideEmpty, kWideEmpty, kWideEmpty, kWideEmpty};
+        int32_t pending[4] = {-1, -1, -1, -1};       // binary interior node behind a slot (gets its own wide node)
+        uint32_t meta = meta_of(it.node);
+        // a slot that does not exist: an inverted box (the box test rejects it on every axis) and the empty reference
+        for (int s = 0; s < 4; ++s) {
+            float *b = q + 12 * (s / 2) + 6 * (s % 2);
+            b[0] = b[1] = b[2] = FLT_MAX;
+            b[3] = b[4] = b[5] = -FLT_MAX;
+        }
+        for (int k = 0; k < 2; ++k) {
+            const int32_t c = child(it.node, k);
+            const float *cbox = &out.nodes[it.node].q[6 * k];     // (lo.xyz, hi.xyz) of child k
+            if (c < 0) {                                           // leaf: the child itself, in the group's first slot
+                std::memcpy(q + 12 * k, cbox, 6 * sizeof(float));
+                refs[2 * k] = c;
+            } else {                                               // interior: its two children
+                meta |= meta_of(c) << (3 + 3 * k);
+                std::memcpy(q + 12 * k, &out.nodes[c].q[0], 12 * sizeof(float));
+                for (int j = 0; j < 2; ++j) {
+                    const int32_t g = child(c, j);
+                    if (g < 0) refs[2 * k + j] = g;
+                    else pending[2 * k + j] = g;
+                }
+            }
+        }
+        // (the up to four wide children of a node get consecutive indices: one 512-byte stretch of memory)
+        for (int s = 0; s < 4; ++s)
+            if (pending[s] >= 0) refs[s] = (int32_t)new_wide(pending[s], it.depth + 1);
+        std::memcpy(q + 24, refs, sizeof(refs));
+        std::memcpy(q + 28, &meta, 4);
+        std::memcpy(out.wide[it.self].q, q, sizeof(q));
+    }
+}
+
 // The tree is the one the sequential recursion produces (same splits, same leaf order); only the
 // numbering of nodes / triangle slots differs: the skeleton (upper levels, built first) comes
 // first, the deferred subtrees follow in discovery order.  Nothing depends on the numbering.
@@ -368,6 +433,7 @@ void build_bvh(const float *tris9, size_t ntris, HostBvh &out)
         out.root_max[a] = root.hi[a];
     }
     relabel_top_breadth_first(out, kTopNodesMax);
+    collapse_wide(out);
 }
 
 }  // namespace upsp

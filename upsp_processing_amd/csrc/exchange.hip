@@ -451,6 +451,19 @@ int upsp_comm_rank(const upsp_comm *c, int *rank, int *world)
     if (!c) return fail(UPSP_ERR_INVALID, "null communicator");
     if (rank) *rank = c->rank;
     if (world) *world = c->world;
+    if (c->kind == 0 && c->nccl) {
+        // what RCCL itself says about the communicator (ncclCommCount / ncclCommUserRank), not what it was created with
+        Rccl &r = rccl();
+        int n = 0, me = 0;
+        if (r.CommCount && world) {
+            UPSP_NCCL_CHECK(r.CommCount(c->nccl, &n), "ncclCommCount");
+            *world = n;
+        }
+        if (r.CommUserRank && rank) {
+            UPSP_NCCL_CHECK(r.CommUserRank(c->nccl, &me), "ncclCommUserRank");
+            *rank = me;
+        }
+    }
     return UPSP_OK;
 }
 

@@ -995,229 +995,17 @@ __global__ void __launch_bounds__(256)
     }
 }
 
-// Pass B.  16 lanes per node; the node's series over the (<= kStreamFrames) frames that pass A has
-// parked in the compact buffer goes out as one contiguous piece of its row: lane l handles frames
-// 64 c + 4 l .. + 3 of every 64-frame chunk c.  Four sub-batches per pass (1-KB row pieces, a quarter
-// of the per-node bookkeeping): 28.7 us per 64 frames of f32 rows against 32.4 with one sub-batch per
-// pass (256-byte pieces), 11.9 against 21.6 us for packed u16 rows.
-constexpr int kStreamFrames = 256;
-constexpr int kNodesPerGroup = 4;     // a wave (4 groups of 16 lanes) takes 16 consecutive nodes
-__global__ void __launch_bounds__(256)
-    node_stream_kernel(const uint16_t *__restrict__ compact, unsigned cpitch, const int32_t *__restrict__ node_k,
-                       const uint8_t *__restrict__ skipped, const int32_t *__restrict__ rowmap,
-                       unsigned nnodes, int nframes, float *__restrict__ rows_t,
-                       uint16_t *__restrict__ rows_t16, long long ld_t, double *__restrict__ sum,
-                       double *__restrict__ sumsq)
-{
-    // Per-node scalars (compact index, flags, row, accumulators) are fetched and written back by
-    // lanes 0..15 of the wave for its 16 consecutive nodes -- one coalesced transaction each -- and
-    // handed to the 16-lane groups by shuffles.  With every group fetching its own node's scalars the
-    // pass issued ~10 small memory transactions per node and took 33 us whether it wrote 128 MB of
-    // f32 rows or 24 MB of packed u16 rows: bound by the number of transactions, not by bytes.
-    const int lane = threadIdx.x & 63, grp = lane >> 4, gl = lane & 15, c4 = 4 * gl;
-    const unsigned wbase = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 16u;      // first node of the wave
-    if (wbase >= nnodes) return;                                              // (uniform per wave)
-    const float qnan = __builtin_nanf("");
-    const bool vec_ok = rows_t ? (((ld_t & 3) == 0) && ((reinterpret_cast<size_t>(rows_t) & 15) == 0))
-                               : (((ld_t & 3) == 0) && ((reinterpret_cast<size_t>(rows_t16) & 7) == 0));
-    // lanes 0..15: scalars of node wbase + lane
-    const unsigned mn = wbase + (unsigned)gl;
-    const bool mok = lane < 16 && mn < nnodes;
-    const int m_k = mok ? node_k[mn] : -1;
-    const int m_sk = (mok && skipped) ? (int)skipped[mn] : 0;
-    const int m_row = mok ? (rowmap ? rowmap[mn] : (int)mn) : -1;     // rows are < 2^31 (node count check at create)
-    double m_s = mok ? sum[mn] : 0.0, m_ss = mok ? sumsq[mn] : 0.0;
-    // group g, round i -> node j = 4 i + g of the wave
-    int k[kNodesPerGroup], row[kNodesPerGroup];
-    bool sk[kNodesPerGroup];
-#pragma unroll
-    for (int i = 0; i < kNodesPerGroup; ++i) {
-        const int j = 4 * i + grp;
-        k[i] = __shfl(m_k, j);
-        sk[i] = __shfl(m_sk, j) != 0;
-        row[i] = __shfl(m_row, j);
-    }
-    constexpr int kChunks = kStreamFrames / 64;     // 64-frame sub-batches parked in the compact buffer
-    uint2 w[kNodesPerGroup][kChunks];
-#pragma unroll
-    for (int i = 0; i < kNodesPerGroup; ++i)
-#pragma unroll
-        for (int c = 0; c < kChunks; ++c)
-            // (ordinary loads: the compact buffer was written a moment ago and sits in L2 / Infinity Cache;
-            // streaming loads here cost 20 us per launch)
-            w[i][c] = (k[i] >= 0 && 64 * c < nframes)
-                          ? *reinterpret_cast<const uint2 *>(compact + (size_t)k[i] * cpitch + 64 * c + c4)
-                          : make_uint2(0u, 0u);
-    double add_s = 0.0, add_ss = 0.0;     // lanes 0..15: what their node's accumulators gain
-#pragma unroll
-    for (int i = 0; i < kNodesPerGroup; ++i) {
-        double s = 0.0, ss = 0.0;
-#pragma unroll
-        for (int c = 0; c < kChunks; ++c) {
-            const unsigned d[4] = {w[i][c].x & 0xFFFFu, w[i][c].x >> 16, w[i][c].y & 0xFFFFu, w[i][c].y >> 16};
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (64 * c + c4 + q < nframes) {
-                    const float x = (float)d[q];
-                    s += (double)x;
-                    ss += (double)(x * x);
-                }
-        }
-        s = group16_sum(s);               // every lane of the group holds the node's total
-        ss = group16_sum(ss);
-        // node j = 4 i + g belongs to lane j of the wave: it reads the total from lane 16 g (any lane of group g)
-        const int src = 16 * (gl & 3);
-        const double ts = __shfl(s, src), tss = __shfl(ss, src);
-        if (lane < 16 && (gl >> 2) == i) {
-            add_s = ts;
-            add_ss = tss;
-        }
-        const unsigned n = wbase + (unsigned)(4 * i + grp);
-        if (n >= nnodes || row[i] < 0) continue;
-#pragma unroll
-        for (int c = 0; c < kChunks; ++c) {
-            const int f0 = 64 * c + c4;
-            if (f0 >= nframes) continue;
-            const unsigned d[4] = {w[i][c].x & 0xFFFFu, w[i][c].x >> 16, w[i][c].y & 0xFFFFu, w[i][c].y >> 16};
-            if (rows_t) {
-                float *dst = rows_t + (long long)row[i] * ld_t + f0;
-                typedef float v4f __attribute__((ext_vector_type(4)));
-                // a node without a pixel: 0 (empty row of the projection matrix); no camera sees it: NaN
-                const v4f nv = {sk[i] ? qnan : (float)d[0], sk[i] ? qnan : (float)d[1], sk[i] ? qnan : (float)d[2],
-                                sk[i] ? qnan : (float)d[3]};
-                if (vec_ok && f0 + 3 < nframes) {
-                    __builtin_nontemporal_store(nv, reinterpret_cast<v4f *>(dst));
-                } else {
-                    dst[0] = nv.x;
-                    if (f0 + 1 < nframes) dst[1] = nv.y;
-                    if (f0 + 2 < nframes) dst[2] = nv.z;
-                    if (f0 + 3 < nframes) dst[3] = nv.w;
-                }
-            } else {   // u16 series (exchange wire format): NaN rows are stored as 0
-                uint16_t *dst = rows_t16 + (long long)row[i] * ld_t + f0;
-                typedef unsigned v2u __attribute__((ext_vector_type(2)));
-                const v2u nv = {sk[i] ? 0u : (d[0] | (d[1] << 16)), sk[i] ? 0u : (d[2] | (d[3] << 16))};
-                if (vec_ok && f0 + 3 < nframes) {
-                    __builtin_nontemporal_store(nv, reinterpret_cast<v2u *>(dst));
-                } else {
-                    dst[0] = (uint16_t)(nv.x & 0xFFFFu);
-                    if (f0 + 1 < nframes) dst[1] = (uint16_t)(nv.x >> 16);
-                    if (f0 + 2 < nframes) dst[2] = (uint16_t)(nv.y & 0xFFFFu);
-                    if (f0 + 3 < nframes) dst[3] = (uint16_t)(nv.y >> 16);
-                }
-            }
-        }
-    }
-    // accumulators: node with a pixel gains its sums (NaN when no camera sees it); without a pixel it
-    // gains 0, or turns NaN when no camera sees it
-    if (mok) {
-        const bool msk = m_sk != 0;
-        if (m_k >= 0 || msk) {
-            sum[mn] = msk ? (double)qnan : m_s + add_s;
-            sumsq[mn] = msk ? (double)qnan : m_ss + add_ss;
-        }
-    }
-}
-
 // Pass B for several cameras (and weights): sol = sum over the cameras, in camera order, of
 // w_c * f32(pixel_c) exactly as gather_tile_kernel forms it (psp_process.cpp:1813-1819), from one
-// compact buffer per camera.  One node per 16-lane group; f32 rows only.  The accumulators add the
-// frames of a lane first and the lanes of the group after (DPP), a different order from the gather's:
-// same values to ~1e-16 relative (the parity bar for the accumulators is 1e-12).
+// compact buffer per camera; f32 rows only (node_rows_multi_kernel below).  The accumulators add the frames of a lane first
+// and the lanes after (DPP), a different order from the gather's: same values to ~1e-16 relative (the parity bar for the
+// accumulators is 1e-12).
 struct StreamMultiArgs {
     int ncams;
     const uint16_t *compact[kMaxCams];
     const int32_t *node_k[kMaxCams];
     const float *weight[kMaxCams];
 };
-__global__ void __launch_bounds__(256)
-    node_stream_multi_kernel(StreamMultiArgs a, unsigned cpitch, const uint8_t *__restrict__ skipped,
-                             const int32_t *__restrict__ rowmap, unsigned nnodes, int nframes,
-                             float *__restrict__ rows_t, long long ld_t, double *__restrict__ sum,
-                             double *__restrict__ sumsq)
-{
-    // like node_stream_kernel: a wave takes 16 consecutive nodes, lanes 0..15 fetch their scalars
-    // (per camera: compact index and weight) coalesced and hand them to the 16-lane groups by shuffles
-    constexpr int kChunks = kStreamFrames / 64;
-    const int lane = threadIdx.x & 63, grp = lane >> 4, gl = lane & 15, c4 = 4 * gl;
-    const unsigned wbase = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 16u;
-    if (wbase >= nnodes) return;                                              // (uniform per wave)
-    const float qnan = __builtin_nanf("");
-    const bool vec_ok = ((ld_t & 3) == 0) && ((reinterpret_cast<size_t>(rows_t) & 15) == 0);
-    const unsigned mn = wbase + (unsigned)gl;
-    const bool mok = lane < 16 && mn < nnodes;
-    const int m_sk = (mok && skipped) ? (int)skipped[mn] : 0;
-    const int m_row = mok ? (rowmap ? rowmap[mn] : (int)mn) : -1;
-    const double m_s = mok ? sum[mn] : 0.0, m_ss = mok ? sumsq[mn] : 0.0;
-    double add_s = 0.0, add_ss = 0.0;
-#pragma unroll 1
-    for (int i = 0; i < 4; ++i) {                 // group g, round i -> node j = 4 i + g of the wave
-        const int j = 4 * i + grp;
-        const bool sk = __shfl(m_sk, j) != 0;
-        const int row = __shfl(m_row, j);
-        float acc[kChunks][4];
-        for (int c = 0; c < a.ncams; ++c) {
-            const int mk = mok ? a.node_k[c][mn] : -1;                       // lanes 0..15, coalesced
-            const float mw = (mok && a.weight[c]) ? a.weight[c][mn] : 1.0f;  // (re-read per round: L1 hits)
-            const int k = __shfl(mk, j);
-            const float w = __shfl(mw, j);
-#pragma unroll
-            for (int ch = 0; ch < kChunks; ++ch) {
-                float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-                if (k >= 0 && 64 * ch < nframes) {
-                    const uint2 t = *reinterpret_cast<const uint2 *>(a.compact[c] + (size_t)k * cpitch + 64 * ch + c4);
-                    v[0] = 0.0f + w * (float)(t.x & 0xFFFFu);
-                    v[1] = 0.0f + w * (float)(t.x >> 16);
-                    v[2] = 0.0f + w * (float)(t.y & 0xFFFFu);
-                    v[3] = 0.0f + w * (float)(t.y >> 16);
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[ch][q] = (c == 0) ? v[q] : acc[ch][q] + v[q];
-            }
-        }
-        double s = 0.0, ss = 0.0;
-#pragma unroll
-        for (int ch = 0; ch < kChunks; ++ch)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (64 * ch + c4 + q < nframes) {
-                    const float sol = sk ? qnan : acc[ch][q];
-                    s += (double)sol;
-                    ss += (double)(sol * sol);
-                }
-        s = group16_sum(s);
-        ss = group16_sum(ss);
-        const int src = 16 * (gl & 3);
-        const double ts = __shfl(s, src), tss = __shfl(ss, src);
-        if (lane < 16 && (gl >> 2) == i) {
-            add_s = ts;
-            add_ss = tss;
-        }
-        const unsigned n = wbase + (unsigned)j;
-        if (n >= nnodes || row < 0) continue;
-#pragma unroll
-        for (int ch = 0; ch < kChunks; ++ch) {
-            const int f0 = 64 * ch + c4;
-            if (f0 >= nframes) continue;
-            float *dst = rows_t + (long long)row * ld_t + f0;
-            typedef float v4f __attribute__((ext_vector_type(4)));
-            const v4f nv = {sk ? qnan : acc[ch][0], sk ? qnan : acc[ch][1], sk ? qnan : acc[ch][2], sk ? qnan : acc[ch][3]};
-            if (vec_ok && f0 + 3 < nframes) {
-                __builtin_nontemporal_store(nv, reinterpret_cast<v4f *>(dst));
-            } else {
-                dst[0] = nv.x;
-                if (f0 + 1 < nframes) dst[1] = nv.y;
-                if (f0 + 2 < nframes) dst[2] = nv.z;
-                if (f0 + 3 < nframes) dst[3] = nv.w;
-            }
-        }
-    }
-    if (mok) {
-        sum[mn] = m_s + add_s;
-        sumsq[mn] = m_ss + add_ss;
-    }
-}
-
 // Pass B, whole rows, for several cameras (and weights): sol = sum over the cameras, in camera order, of
 // w_c * f32(pixel_c) exactly as gather_tile_kernel forms it (psp_process.cpp:1813-1819), from one compact
 // buffer per camera; row layout and lane mapping of node_rows_kernel.  The accumulators add the frames of
@@ -1799,8 +1587,7 @@ int launch_hot_fix(uint16_t *d_frames, int nframes, int rows, int cols, int thre
     // d_count holds hot_counter_words(nframes) counters (hot pixels per frame, then one padded
     // ticket counter per frame); zero when allocated, the kernel leaves them zero
     size_t bx = (npix / 8 + 255) / 256;
-    static const size_t bx_cap = std::getenv("UPSP_SCAN_BX") ? (size_t)std::atoi(std::getenv("UPSP_SCAN_BX")) : 128;
-    if (bx > bx_cap) bx = bx_cap;
+    if (bx > 128) bx = 128;
     if (bx < 1) bx = 1;
     KTimed kt("hot_scan_kernel", st);
     hipLaunchKernelGGL(hot_scan_kernel, dim3((unsigned)bx, (unsigned)nframes), dim3(256), 0, st,
@@ -1842,7 +1629,6 @@ int launch_amap_build(const int32_t *d_pix, size_t nnodes, size_t npix, uint8_t 
     return UPSP_OK;
 }
 
-int stream_frames_max() { return kStreamFrames; }
 int group_frames_max() { return kGroupFramesMax; }
 
 // Pass A for `nframes` frames (any number: one workgroup row per 64-frame group) into columns
@@ -1869,18 +1655,6 @@ int launch_scan_compact(uint16_t *d_frames, size_t npix, int nframes, bool hot, 
     return UPSP_OK;
 }
 
-// Pass B for the g.nframes (<= stream_frames_max()) frames parked in the compact buffer.
-int launch_node_stream(const PipelineGather &g, const int32_t *d_node_k, const uint16_t *d_compact, hipStream_t st)
-{
-    if (g.nframes <= 0 || g.nframes > kStreamFrames) return fail(UPSP_ERR_INVALID, "stream pass: too many frames");
-    KTimed kt("node_stream_kernel", st);
-    hipLaunchKernelGGL(node_stream_kernel, dim3((unsigned)((g.nnodes + 63) / 64)), dim3(256), 0, st, d_compact,
-                       (unsigned)kStreamFrames, d_node_k, g.skipped, g.rowmap, (unsigned)g.nnodes, g.nframes, g.rows_t,
-                       g.rows_t16, (long long)g.ld_t, g.sum, g.sumsq);
-    UPSP_HIP_CHECK(hipGetLastError());
-    return UPSP_OK;
-}
-
 // Pass B, whole rows, for the g.nframes (<= group_frames_max()) frames parked in the compact buffer.
 int launch_amap_nodes(const int32_t *d_pix, size_t nnodes, const uint8_t *d_flag, const unsigned *d_off,
                       int32_t *d_node_k, hipStream_t st)
@@ -1897,56 +1671,22 @@ int launch_node_rows(const PipelineGather &g, const int32_t *d_node_k, const uin
 {
     if (g.nframes <= 0 || g.nframes > kGroupFramesMax || (unsigned)g.nframes > cpitch)
         return fail(UPSP_ERR_INVALID, "row pass: too many frames");
-    static const int rows_env = std::getenv("UPSP_ROWS_PER_WG") ? std::atoi(std::getenv("UPSP_ROWS_PER_WG")) : 4;
     const unsigned nn = (unsigned)g.nnodes;
     KTimed kt("node_rows_kernel", st);
-    // UPSP_ROWS_AHEAD=1 (measurement switch): series loads one sweep ahead of the rows that use them, the arrangement that pays in
-    // the multi-camera kernel -- here 0.403-0.413 ms either way (tools/gpu_rows_ab.sh): this kernel waits for its stores
-    static const int ahead_env = std::getenv("UPSP_ROWS_AHEAD") ? std::atoi(std::getenv("UPSP_ROWS_AHEAD")) : 0;
-#define UPSP_NR1(LPR, ROWS, U16, AH)                                                                         \
-    hipLaunchKernelGGL((node_rows_kernel<LPR, ROWS, U16, AH>), dim3((nn + (256 / LPR) * ROWS - 1) / ((256 / LPR) * ROWS)), \
+    // four sweeps per workgroup (1 / 2 / 4 / 8: 486 / 412 / 370 / 422 us per 1000 frames of the bench model); the series loads
+    // of all sweeps first (one sweep ahead of the rows that use them, the arrangement that pays in the multi-camera kernel:
+    // 0.403-0.413 ms either way here -- this kernel waits for its stores)
+#define UPSP_NR(LPR, U16)                                                                                    \
+    hipLaunchKernelGGL((node_rows_kernel<LPR, 4, U16, 0>), dim3((nn + (256 / LPR) * 4 - 1) / ((256 / LPR) * 4)), \
                        dim3(256), 0, st, d_compact, cpitch, d_node_k, g.skipped, g.rowmap, nn, g.nframes, g.rows_t,  \
                        g.rows_t16, (long long)g.ld_t, g.sum, g.sumsq, (const uint16_t *)g.img[0], g.npix, g.pix[0])
-#define UPSP_NR(LPR, ROWS, U16)                                                                              \
-    do {                                                                                                     \
-        if (ahead_env) UPSP_NR1(LPR, ROWS, U16, 1); else UPSP_NR1(LPR, ROWS, U16, 0);                        \
-    } while (0)
-#define UPSP_NR_R(LPR, U16)                                                                                  \
-    do {                                                                                                     \
-        if (rows_env >= 8) UPSP_NR(LPR, 8, U16); else if (rows_env >= 4) UPSP_NR(LPR, 4, U16);              \
-        else if (rows_env >= 2) UPSP_NR(LPR, 2, U16); else UPSP_NR(LPR, 1, U16);                            \
-    } while (0)
 #define UPSP_NR_L(U16)                                                                                       \
     do {                                                                                                     \
-        if (g.nframes > 512) UPSP_NR_R(256, U16); else if (g.nframes > 256) UPSP_NR_R(128, U16); else UPSP_NR_R(64, U16); \
+        if (g.nframes > 512) UPSP_NR(256, U16); else if (g.nframes > 256) UPSP_NR(128, U16); else UPSP_NR(64, U16); \
     } while (0)
     if (g.rows_t16) UPSP_NR_L(true); else UPSP_NR_L(false);
 #undef UPSP_NR_L
-#undef UPSP_NR_R
 #undef UPSP_NR
-#undef UPSP_NR1
-    UPSP_HIP_CHECK(hipGetLastError());
-    return UPSP_OK;
-}
-
-// Pass B for g.ncams cameras: node_k[c] / compact[c] per camera, weights from g.weight.
-int launch_node_stream_multi(const PipelineGather &g, const int32_t *const *d_node_k,
-                             const uint16_t *const *d_compact, hipStream_t st)
-{
-    if (g.nframes <= 0 || g.nframes > kStreamFrames) return fail(UPSP_ERR_INVALID, "stream pass: too many frames");
-    if (g.ncams < 1 || g.ncams > kMaxCams || !g.rows_t) return fail(UPSP_ERR_INVALID, "stream pass: bad camera count / no f32 rows");
-    StreamMultiArgs a;
-    std::memset(&a, 0, sizeof(a));
-    a.ncams = g.ncams;
-    for (int c = 0; c < g.ncams; ++c) {
-        a.compact[c] = d_compact[c];
-        a.node_k[c] = d_node_k[c];
-        a.weight[c] = g.weight[c];
-    }
-    KTimed kt("node_stream_multi_kernel", st);
-    hipLaunchKernelGGL(node_stream_multi_kernel, dim3((unsigned)((g.nnodes + 63) / 64)), dim3(256), 0, st, a,
-                       (unsigned)kStreamFrames, g.skipped, g.rowmap, (unsigned)g.nnodes, g.nframes, g.rows_t,
-                       (long long)g.ld_t, g.sum, g.sumsq);
     UPSP_HIP_CHECK(hipGetLastError());
     return UPSP_OK;
 }
@@ -1979,12 +1719,6 @@ int launch_node_rows_multi(const PipelineGather &g, const int32_t *const *d_node
         else if (g.ncams == 3) UPSP_NRM(LPR, ROWS, 3, 8, 0, 1);                                               \
         else UPSP_NRM(LPR, ROWS, 4, 8, 0, 1);                                                                 \
     } while (0)
-#define UPSP_NRMA(NC, AH)                                                                                     \
-    hipLaunchKernelGGL((node_rows_multi_kernel<128, 4, NC, 8, 0, AH>), dim3((nn + 7u) / 8u), dim3(256), 0, st, a, cpitch, \
-                       g.skipped, g.rowmap, nn, g.nframes, g.rows_t, (long long)g.ld_t, g.sum, g.sumsq)
-#define UPSP_NRMP(NC)                                                                                         \
-    hipLaunchKernelGGL((node_rows_multi_kernel<128, 4, NC, 8, 1>), dim3(std::min((nn + 7u) / 8u, pipe_wgs)), dim3(256), 0, st, a, cpitch, \
-                       g.skipped, g.rowmap, nn, g.nframes, g.rows_t, (long long)g.ld_t, g.sum, g.sumsq)
 #define UPSP_NRM_NC(LPR, ROWS)                                                                                \
     do {                                                                                                      \
         if (g.ncams == 2) UPSP_NRM(LPR, ROWS, 2);                                                             \
@@ -1992,36 +1726,18 @@ int launch_node_rows_multi(const PipelineGather &g, const int32_t *const *d_node
         else if (g.ncams == 4) UPSP_NRM(LPR, ROWS, 4);                                                        \
         else UPSP_NRM(LPR, 2, 0);                                                                             \
     } while (0)
-    // sweeps per workgroup (UPSP_MULTI_ROWS, measurement switch; 4 cameras, 2.5 M nodes, 1000 frame sets: 2 sweeps 4.28 ms,
-    // 4: 3.35, 8: 3.16 -- consecutive nodes share pixels, and the per-workgroup staging is paid once per 8 rows; with the
-    // leaner sums 2.97.  Tried and dropped: row / series indices through v_readfirstlane (scalar addresses, SGPR-base
-    // loads) -- the scalar branches around the loads serialise them: 3.51 ms)
-    static const int rows_env = std::getenv("UPSP_MULTI_ROWS") ? std::atoi(std::getenv("UPSP_MULTI_ROWS")) : 8;
-    // eight frames per lane (two groups of four, 128 lanes per row of <= 1024 frames): 2.93-2.94 ms against 2.99-3.13 with four
-    // (4 cameras, 2.5 M nodes, 1000 frame sets; as 8 CONSECUTIVE frames per lane, i.e. half-empty store instructions, 4.1 ms).
-    // The kernel is not bound by its instructions (PMC: VALU busy 53 %): a workgroup lives ~12 us, most of it the two
-    // dependent memory latencies of its staging and its series loads.  UPSP_MULTI_FPL=4: the four-frame form.
-    static const int fpl_env = std::getenv("UPSP_MULTI_FPL") ? std::atoi(std::getenv("UPSP_MULTI_FPL")) : 8;
-    const bool fpl8 = fpl_env == 8 && g.ncams >= 2 && g.ncams <= 4;
-    // UPSP_MULTI_PIPE=n: n persistent workgroups per CU with the next group's staging prefetched (0: one workgroup per group)
-    static const int pipe_env = std::getenv("UPSP_MULTI_PIPE") ? std::atoi(std::getenv("UPSP_MULTI_PIPE")) : 0;
-    const unsigned pipe_wgs = 256u * (unsigned)std::max(pipe_env, 1);
-    // series loads ONE sweep in front of the rows that use them (72 VGPRs, 7 waves per SIMD) instead of all four sweeps first (96, 5
-    // waves): 2.71 against 2.86 ms on one box; two sweeps in front 2.97.  UPSP_MULTI_AHEAD=n (4 cameras): n = 2, 3, 4 for comparison
-    static const int ahead_env = std::getenv("UPSP_MULTI_AHEAD") ? std::atoi(std::getenv("UPSP_MULTI_AHEAD")) : 0;
-    if (g.nframes > 512 && fpl8 && ahead_env > 1 && rows_env == 8 && g.ncams == 4) {
-        if (ahead_env == 2) UPSP_NRMA(4, 2); else if (ahead_env == 3) UPSP_NRMA(4, 3); else UPSP_NRMA(4, 4);
-    }
-    else if (g.nframes > 512 && fpl8 && pipe_env > 0 && rows_env == 8) {
-        if (g.ncams == 2) UPSP_NRMP(2); else if (g.ncams == 3) UPSP_NRMP(3); else UPSP_NRMP(4);
-    }
-    else if (g.nframes > 512 && fpl8) { if (rows_env == 2) UPSP_NRM8_NC(128, 1); else if (rows_env == 8) UPSP_NRM8_NC(128, 4); else if (rows_env == 6) UPSP_NRM8_NC(128, 3); else if (rows_env == 10) UPSP_NRM8_NC(128, 5); else if (rows_env == 16) UPSP_NRM8_NC(128, 8); else UPSP_NRM8_NC(128, 2); }
-    else if (g.nframes > 512 && ahead_env == 1 && g.ncams == 4) UPSP_NRM(256, 8, 4, 4, 0, 1);      // (measurement: four frames per lane, one sweep ahead)
-    else if (g.nframes > 512) { if (rows_env == 8) UPSP_NRM_NC(256, 8); else if (rows_env == 2) UPSP_NRM_NC(256, 2); else UPSP_NRM_NC(256, 4); }
+    // Measured on 4 cameras, 2.5 M nodes, 1000 frame sets (rounds 2-3).  Sweeps per workgroup: 2 / 4 / 8 -> 4.28 / 3.35 / 3.16 ms
+    // (consecutive nodes share pixels, and the per-workgroup staging is paid once per 8 rows; with the leaner sums 2.97).  Eight
+    // frames per lane as two groups of four (128 lanes per row of <= 1024 frames): 2.93 against 2.99-3.13 with four (as 8
+    // CONSECUTIVE frames per lane, i.e. half-empty store instructions, 4.1).  Series loads ONE sweep in front of the rows that
+    // use them (72 VGPRs, 7 waves per SIMD) instead of all four sweeps first (96, 5 waves): 2.71 against 2.86 on one box; two
+    // sweeps in front 2.97.  Rejected: row / series indices through v_readfirstlane (3.51), persistent workgroups that prefetch
+    // the next group's staging (130 VGPRs: 3.14-3.23).  The kernel is not bound by its instructions (VALU busy 53 %): a
+    // workgroup lives ~12 us, most of it the two dependent memory latencies of its staging and its series loads.
+    if (g.nframes > 512 && g.ncams >= 2 && g.ncams <= 4) UPSP_NRM8_NC(128, 4);
+    else if (g.nframes > 512) UPSP_NRM_NC(256, 8);
     else if (g.nframes > 256) UPSP_NRM_NC(128, 4);
     else UPSP_NRM_NC(64, 4);
-#undef UPSP_NRMA
-#undef UPSP_NRMP
 #undef UPSP_NRM8_NC
 #undef UPSP_NRM_NC
 #undef UPSP_NRM
@@ -2166,21 +1882,14 @@ int launch_gather(const PipelineGather &g, hipStream_t st)
     if (g.nframes <= 64) {
         KTimed kt("gather_tile_kernel", st);
         const dim3 tgrid((unsigned)((g.nnodes + 63) / 64)), tblock(256);
-        static const bool stream_stores = std::getenv("UPSP_NO_STREAM_STORES") == nullptr;
-        static const int tile16_waves = std::getenv("UPSP_GATHER_WAVES") ? std::atoi(std::getenv("UPSP_GATHER_WAVES")) : 4;
-        if (g.ncams == 1 && !g.weight[0] && !g.is_f32[0] && tile16_waves > 0) {
+        if (g.ncams == 1 && !g.weight[0] && !g.is_f32[0]) {
             // exact 16-bit values: u16 LDS tile, more gathers in flight per CU
 #define UPSP_T16(W, SS, HS)                                                                    \
     hipLaunchKernelGGL((gather_tile16_kernel<W, SS, HS>), tgrid, dim3(W * 64), 0, st, a,       \
                        g.skipped, (unsigned)g.nnodes, g.nframes, g.rows, g.rows_t,             \
                        (long long)g.ld_t, g.sum, g.sumsq)
-#define UPSP_T16W(W)                                                                           \
-    do {                                                                                       \
-        if (g.src) { if (stream_stores) UPSP_T16(W, true, true); else UPSP_T16(W, false, true); }      \
-        else { if (stream_stores) UPSP_T16(W, true, false); else UPSP_T16(W, false, false); }          \
-    } while (0)
-            if (tile16_waves == 2) UPSP_T16W(2); else UPSP_T16W(4);   // measured: 4 waves 38 us, 2 waves 42, 8 waves 41
-#undef UPSP_T16W
+            // (non-temporal stores: the series is not read again by the loop; 4 waves 38 us, 2 waves 42, 8 waves 41 per 64 frames)
+            if (g.src) UPSP_T16(4, true, true); else UPSP_T16(4, true, false);
 #undef UPSP_T16
             UPSP_HIP_CHECK(hipGetLastError());
             return UPSP_OK;
@@ -2191,8 +1900,7 @@ int launch_gather(const PipelineGather &g, hipStream_t st)
                        g.sum, g.sumsq)
 #define UPSP_TILE(NC)                                                                          \
     do {                                                                                       \
-        if (g.src) { if (stream_stores) UPSP_TILE2(NC, true, true); else UPSP_TILE2(NC, false, true); } \
-        else { if (stream_stores) UPSP_TILE2(NC, true, false); else UPSP_TILE2(NC, false, false); }     \
+        if (g.src) UPSP_TILE2(NC, true, true); else UPSP_TILE2(NC, true, false);               \
     } while (0)
         switch (g.ncams) {  // per-camera pix / weight stay in registers for 1..4 cameras
             case 1: UPSP_TILE(1); break;

@@ -44,16 +44,12 @@ int launch_amap_build(const int32_t *d_pix, size_t nnodes, size_t npix, uint8_t 
                       unsigned *d_off, int32_t *d_node_k, unsigned *d_order, hipStream_t st);
 int launch_amap_nodes(const int32_t *d_pix, size_t nnodes, const uint8_t *d_flag, const unsigned *d_off,
                       int32_t *d_node_k, hipStream_t st);
-int stream_frames_max();   // frames per pass B of the multi-camera streamed schedule (compact row pitch there)
 int group_frames_max();    // frames per pass B (whole rows) of the one-camera streamed schedule
 int launch_scan_compact(uint16_t *d_frames, size_t npix, int nframes, bool hot, int thresh, int max_hot,
                         const uint8_t *d_flag, const unsigned *d_off, const unsigned *d_order, uint16_t *d_compact,
                         unsigned cpitch, int col, unsigned *d_count, unsigned *d_pos, hipStream_t st);
-int launch_node_stream(const PipelineGather &g, const int32_t *d_node_k, const uint16_t *d_compact, hipStream_t st);
 int launch_node_rows(const PipelineGather &g, const int32_t *d_node_k, const uint16_t *d_compact, unsigned cpitch,
                      hipStream_t st);
-int launch_node_stream_multi(const PipelineGather &g, const int32_t *const *d_node_k,
-                             const uint16_t *const *d_compact, hipStream_t st);
 int launch_node_rows_multi(const PipelineGather &g, const int32_t *const *d_node_k, const uint16_t *const *d_compact,
                            unsigned cpitch, hipStream_t st);
 size_t hot_changes_words(int nframes, int max_hot);   // size of d_changes for launch_hot_fixup

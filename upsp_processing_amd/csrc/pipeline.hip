@@ -75,9 +75,6 @@ struct upsp_pipeline {
     upsp::PatchTables *patches[kMaxCams] = {nullptr};
     upsp::FrameScratch *scratch = nullptr;
     int batch = 32;
-    // optional second stream (UPSP_OVERLAP=1): the gather of sub-batch k overlaps the scan of k+1
-    hipStream_t aux = nullptr;
-    hipEvent_t ev_in = nullptr, ev_fix[2] = {nullptr, nullptr}, ev_out = nullptr;
 };
 
 namespace {
@@ -184,8 +181,6 @@ int upsp_pipeline_create(int ncams, int width, int height, size_t nnodes,
     // patch / filter: the f32 working copies of a sub-batch should stay cache-resident between
     // the two blur passes and the gather; 32 frames measured best at 1 Mpix (21: -20 %, 64: -20 %)
     else if (!p->opts.registration) b = std::max<size_t>(b, std::min<size_t>(32, (256u << 20) / std::max<size_t>(per_frame, 1)));
-    static const int batch_env = std::getenv("UPSP_BATCH") ? std::atoi(std::getenv("UPSP_BATCH")) : 0;
-    if (batch_env > 0) b = (size_t)batch_env;
     p->batch = (int)std::min<size_t>(std::max<size_t>(b, 1), 64);
     *out = p;
     return UPSP_OK;
@@ -202,9 +197,6 @@ void upsp_pipeline_destroy(upsp_pipeline *p)
         upsp::patch_tables_free(p->patches[c]);
     }
     upsp::frame_scratch_free(p->scratch);
-    if (p->aux) (void)hipStreamDestroy(p->aux);
-    for (hipEvent_t e : {p->ev_in, p->ev_fix[0], p->ev_fix[1], p->ev_out})
-        if (e) (void)hipEventDestroy(e);
     free_dev(p->d_read_mask);
     free_dev(p->d_skipped);
     free_dev(p->d_src);
@@ -518,9 +510,8 @@ static int streamed_buffers(upsp_pipeline *p, size_t npix, int nframes, hipStrea
 static int streamed_pass_a(upsp_pipeline *p, uint16_t *fr, size_t npix, int s0, int ns, unsigned cp, hipStream_t st)
 {
     const bool hot = p->opts.hot_enable != 0;
-    static const bool dbg_noorder = std::getenv("UPSP_NO_TILE_ORDER") != nullptr;   // (measurement switch)
     return launch_scan_compact(fr + (size_t)s0 * npix, npix, ns, hot, p->opts.hot_thresh, p->opts.hot_max, p->d_aflag,
-                               p->d_tile_off, dbg_noorder ? nullptr : p->d_tile_order, p->d_compact, cp, 0,
+                               p->d_tile_off, p->d_tile_order, p->d_compact, cp, 0,
                                hot ? p->d_hot_count + s0 : nullptr, hot ? p->d_hot_pos + (size_t)s0 * 64 : nullptr, st);
 }
 
@@ -692,36 +683,18 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
         if (rc != UPSP_OK) return rc;
     }
     int rc = UPSP_OK;
-    // Two-stream schedule (plain projection path only): scan+repair on the caller's
-    // stream, gathers on an internal stream, ordered by events.  Reads of sub-batch k+1
-    // then overlap the time-series writes of sub-batch k.
-    // Opt-in (UPSP_OVERLAP=1): measured on MI355X the two kernels compete for HBM and evict each
-    // other's working set from the Infinity Cache -- 1.93 ms per 1000 frames overlapped vs
-    // 1.72 ms back to back on one stream.
-    static const bool overlap_env = std::getenv("UPSP_OVERLAP") != nullptr;
-    const bool overlap = overlap_env && !need_stage && p->opts.hot_enable && nframes > B;
-    if (overlap && !p->aux) {
-        UPSP_HIP_CHECK(hipStreamCreateWithFlags(&p->aux, hipStreamNonBlocking));
-        UPSP_HIP_CHECK(hipEventCreateWithFlags(&p->ev_in, hipEventDisableTiming));
-        UPSP_HIP_CHECK(hipEventCreateWithFlags(&p->ev_fix[0], hipEventDisableTiming));
-        UPSP_HIP_CHECK(hipEventCreateWithFlags(&p->ev_fix[1], hipEventDisableTiming));
-        UPSP_HIP_CHECK(hipEventCreateWithFlags(&p->ev_out, hipEventDisableTiming));
-    }
-    if (overlap) {  // the gather stream starts after everything already queued on `st`
-        UPSP_HIP_CHECK(hipEventRecord(p->ev_in, st));
-        UPSP_HIP_CHECK(hipStreamWaitEvent(p->aux, p->ev_in, 0));
-    }
-    // Streamed two-pass schedule (frames.hip: scan_compact_kernel + node_stream_kernel) for the plain
+    // (Round 1 also had a two-stream schedule -- scan + repair on the caller's stream, the gathers on an internal one.  Measured on
+    //  MI355X the two kernels compete for HBM and evict each other's working set from the Infinity Cache: 1.93 ms per 1000
+    //  frames overlapped against 1.72 back to back on one stream.  Removed.)
+    // Streamed two-pass schedule (frames.hip: scan_compact_kernel + node_rows_kernel) for the plain
     // path: one camera, no weights, u16 frames straight from the caller, node-major series only.
     // Measured on MI355X per 64-frame sub-batch of 1-Mpix frames: 25.8 + 32.4 us against 25.4 + 38.7 us
     // for scan kernel + gather kernel (f32 rows of all nodes), 25.5 + 21.6 against 25.4 + 32.2 us with
     // packed u16 rows (multi-GPU exchange); 4-Mpix frames (sub-batch larger than the Infinity Cache):
     // 1.3x.  It needs the active-pixel map once per projection (25 us).  Default when eligible.
-    static const char *fused_env = std::getenv("UPSP_FUSED");   // "1" / "0" override the option
-    int fused_mode = p->opts.fused_scan;
-    if (fused_env) fused_mode = std::atoi(fused_env) ? 1 : 2;
+    const int fused_mode = p->opts.fused_scan;
     const bool fused_ok = p->ncams == 1 && !p->d_weight[0] && !need_stage && !d_rows &&
-                          (d_rows_t || d_rows_t16) && !p->d_src && (npix % 2) == 0 && B == 64 && !overlap &&
+                          (d_rows_t || d_rows_t16) && !p->d_src && (npix % 2) == 0 && B == 64 &&
                           p->nnodes < ((size_t)1 << 31);
     const bool fused = fused_ok && fused_mode != 2;
     if (fused) {
@@ -775,11 +748,10 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
     }
     // Registration as the last image stage, one camera, node-major series: per 64-frame sub-batch hot-pixel repair ->
     // ECC -> warp of the active pixels straight into the compact buffer; per <= 1024 frames ONE pass B (whole rows)
-    // instead of a gather per sub-batch.  (UPSP_REG_STREAMED=0: warp the pixel list into scratch frames + gather.)
-    static const bool reg_streamed_env = !std::getenv("UPSP_REG_STREAMED") || std::atoi(std::getenv("UPSP_REG_STREAMED")) != 0;
-    const bool reg_streamed = reg_streamed_env && p->ncams == 1 && !p->d_weight[0] && p->opts.registration && !need_f32 &&
+    // instead of a gather per sub-batch.
+    const bool reg_streamed = p->ncams == 1 && !p->d_weight[0] && p->opts.registration && !need_f32 &&
                               !d_rows && (d_rows_t || d_rows_t16) && !p->d_src && (npix % 2) == 0 && npix < 0xFFFFFFFFull &&
-                              !overlap && p->nnodes < ((size_t)1 << 31) && fused_mode != 2;
+                              p->nnodes < ((size_t)1 << 31) && fused_mode != 2;
     if (reg_streamed) {
         if (!p->tilemap_valid) {
             rc = streamed_map(p, p->d_pix[0], npix, st);
@@ -885,7 +857,7 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
     // Several cameras (weights allowed): the same two passes with one active-pixel map and one whole-call compact
     // buffer per camera; pass B (node_rows_multi_kernel) sums the cameras in order with their weights.
     const bool multi_ok = p->ncams > 1 && !need_stage && !d_rows && d_rows_t && !d_rows_t16 && !p->d_src &&
-                          (npix % 2) == 0 && B == 64 && !overlap && p->nnodes < ((size_t)1 << 31);
+                          (npix % 2) == 0 && B == 64 && p->nnodes < ((size_t)1 << 31);
     // default (fused_scan = 0): streamed from 192 frames per call on -- measured on the 5 M-triangle / 4-camera
     // shape (tools/scale_5m.py): 256 frame sets 1.68 ms against 2.20 ms for scan + gather, 64 frame sets 0.84
     // against 0.57 ms (short calls write 256-B row pieces either way and pay pass A on top)
@@ -1055,18 +1027,7 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
             g.pix[c] = p->d_pix[c];
             g.weight[c] = p->d_weight[c];
         }
-        if (rc == UPSP_OK && overlap) {
-            hipEvent_t e = p->ev_fix[kbatch & 1];
-            UPSP_HIP_CHECK(hipEventRecord(e, st));
-            UPSP_HIP_CHECK(hipStreamWaitEvent(p->aux, e, 0));
-            rc = launch_gather(g, p->aux);
-        } else if (rc == UPSP_OK) {
-            rc = launch_gather(g, st);
-        }
-    }
-    if (overlap) {  // join: later work on `st` sees the gathers
-        UPSP_HIP_CHECK(hipEventRecord(p->ev_out, p->aux));
-        UPSP_HIP_CHECK(hipStreamWaitEvent(st, p->ev_out, 0));
+        if (rc == UPSP_OK) rc = launch_gather(g, st);
     }
     return rc;
 }

@@ -50,6 +50,7 @@ int fail(int status, const std::string &msg)
 namespace {
 
 constexpr int kBlock = 256;       // threads per workgroup (4 waves)
+constexpr unsigned kPackWavesPerSimd = 3;   // dense ray lists are spread over this many waves per SIMD, all resident at once
 constexpr int kChunkMax = 1024;    // largest block of work items taken from the global queue at once
 constexpr int kRefillDefault = 40;  // leave the traversal loop to re-fill below this many live lanes
 constexpr int kDone = INT32_MIN;  // "no current node"
@@ -321,16 +322,18 @@ __device__ __forceinline__ bool tri_test(const Ray &r, float ax, float ay, float
 }
 
 struct Scene {
-    const float4 *nodes;  // 4 per interior node
+    const float4 *nodes;  // 4 per interior node (binary records: cooperative walk, witness chains)
+    const float4 *wide;   // 8 per wide node (GpuWide: the one-ray-per-lane traversal)
     const float4 *tris;   // 3 per triangle slot
-    int root_ref;
+    int root_ref;         // the traversal's root: a wide node (>= 0) or a leaf
+    int root_ref2;        // the binary tree's root
     int refill;           // re-fill threshold (live lanes)
     int desc_cap;         // interior-node steps before the lanes that already hold a leaf get to test it (0 = no cap)
-    int touch;            // 1: node_step touches the records of both children before it tests their boxes
     int xcd;              // 1: XCD-aware static assignment of the work items (queue_init)
     unsigned heavy_steps; // a ray that needs more node visits + triangle tests than this is handed to heavy_kernel (0 = never)
     unsigned *heavy_items;   // list of the work items handed over (kHeavyCap entries), count in work[kWorkHeavyCount]
     unsigned heavy_stack;    // entries of heavy_kernel's stack that may be used (<= kHeavyStack; tests shrink it)
+    unsigned char *heavy_scratch;   // the cooperative walk's stacks, kHeavyScratchBytes per workgroup (global memory, see heavy_kernel)
     unsigned pack_waves;     // projection passes: waves a ray list is spread over when the grid can take it at once (0: queue)
     unsigned chunk;       // work items per queue grab (multiple of 64)
     float rlo[3], rhi[3];
@@ -358,7 +361,6 @@ struct Trav {
     float own_min;  // visibility rays: stop as soon as the closest hit is nearer than this
     unsigned n_nodes, n_tris;
     unsigned ray_nodes, ray_tris;  // STATS: steps of the current ray
-    unsigned touched;              // xor of the words read ahead (keeps those loads alive, never used)
     unsigned w_node_rounds, w_tri_rounds;   // STATS: rounds of the WAVE (counted by its first executing lane)
     unsigned steps;                // node visits + triangle tests of the current ray
 };
@@ -391,74 +393,85 @@ __device__ __forceinline__ void ray_classify(Ray &r, const Scene &sc)
     r.simple = (r.zero == 0u) & !r.exact_only & (D < lim) & (D == D) & (D < 1e30f);
 }
 
+// (the LDS stack is laid out [entry][thread]: STRIDE = threads per workgroup)
+template <int STRIDE = kBlock>
 __device__ __forceinline__ void trav_pop(Trav &s, const int *stack)
 {
     if (s.sp == 0) {
         s.cur = kDone;
     } else {
         --s.sp;
-        s.cur = stack[s.sp * kBlock];
+        s.cur = stack[s.sp * STRIDE];
     }
 }
 
-// Runs the lane's traversal until it finishes (returns) -- or, when `more` work is
-// queued, until fewer than kRefill lanes of the wave are still busy.
-// One interior-node step: fetch the 64-byte record, test both child boxes, descend to
-// the near child (push the far one) or pop.
-template <bool ANYHIT, bool STATS>
-__device__ __forceinline__ void node_step(Trav &s, const Ray &r, const Scene &sc, int *stack)
+// One step of the traversal on the wide records (GpuWide, upsp_internal.h): one 128-byte fetch decides TWO levels of the
+// reference's descent.  The record lists, for each child of a binary node the reference would be standing on, the child
+// itself (a leaf) or the child's two children, so the boxes tested here are boxes the reference tests too -- minus the
+// interior child's own box, which it enters before its children's: that test is implied (a box inside another is hit only
+// by rays that hit the outer one; Imath's slab test is monotone in the box planes: both quotients of an axis move the
+// right way when the box grows, the guards only ever turn a quotient into +-infinity on the growing side, and the
+// "origin inside" / "origin beyond the far plane" shortcuts are monotone too).  Every slot is entered iff the library
+// accepts its box (filter, exact divisions when undecided) and the depth-first near-first order is the reference's
+// applied twice: first the group of the near CHILD (sign of the ray along the node's axis, pspRT.cpp:410-419), inside a
+// group the near grandchild (the child's axis).  So the leaves reached and their order -- hence t, primID and every tie --
+// are the binary walk's.  The accepted slots are pushed in reverse visiting order and the first one popped back.
+template <bool ANYHIT, bool STATS, int STRIDE = kBlock>
+__device__ __forceinline__ void wide_step(Trav &s, const Ray &r, const Scene &sc, int *stack)
 {
-    const float4 *np = sc.nodes + 4 * (size_t)s.cur;
-    const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+    const float4 *np = sc.wide + 8 * (size_t)s.cur;
+    const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3], q4 = np[4], q5 = np[5], q6 = np[6], q7 = np[7];
     ++s.steps;
     if (STATS) { ++s.n_nodes; ++s.ray_nodes; }
-    const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
-    const unsigned meta = __float_as_uint(q3.z);
-    if (sc.touch) {
-        // Read one word of the record each child leads to (interior node or first triangle of the leaf)
-        // BEFORE the ~170 VALU instructions of the two box tests: whichever child the ray descends into,
-        // its record is on its way into L1 / L2 while the tests run, instead of a cold dependent fetch
-        // (~0.5 us from L2 / Infinity Cache under load) after them.  Traversal order and arithmetic are
-        // untouched; the extra requests are 64-B reads in kernels that use a few percent of the bandwidth.
-        const unsigned *pl = left >= 0 ? reinterpret_cast<const unsigned *>(sc.nodes + 4 * (size_t)left)
-                                       : reinterpret_cast<const unsigned *>(sc.tris + 3 * (size_t)((unsigned)(~left) >> kLeafBits));
-        const unsigned *pr = right >= 0 ? reinterpret_cast<const unsigned *>(sc.nodes + 4 * (size_t)right)
-                                        : reinterpret_cast<const unsigned *>(sc.tris + 3 * (size_t)((unsigned)(~right) >> kLeafBits));
-        s.touched ^= *pl ^ *pr;
-    }
-    float dFl, dFr;
-    BoxEval bl, br;
+    const int ref0 = __float_as_int(q6.x), ref1 = __float_as_int(q6.y), ref2 = __float_as_int(q6.z), ref3 = __float_as_int(q6.w);
+    const unsigned meta = __float_as_uint(q7.x);
+    float dF0, dF1, dF2, dF3;
+    BoxEval b0, b1, b2, b3;
     if (__ballot(!r.simple) == 0ull) {   // wave-uniform: every lane holds a simple-class ray
-        bl = box_filter_simple(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, dFl);
-        br = box_filter_simple(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, dFr);
+        b0 = box_filter_simple(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, dF0);
+        b1 = box_filter_simple(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, dF1);
+        b2 = box_filter_simple(r, q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, dF2);
+        b3 = box_filter_simple(r, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, dF3);
     } else {
-        bl = box_filter(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, dFl);
-        br = box_filter(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, dFr);
+        b0 = box_filter(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, dF0);
+        b1 = box_filter(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, dF1);
+        b2 = box_filter(r, q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, dF2);
+        b3 = box_filter(r, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, dF3);
     }
-    bool hL = bl.accept, hR = br.accept;
-    if (__ballot(bl.undecided | br.undecided) != 0ull) {  // rare: grazing contact
-        if (bl.undecided) hL = box_exact(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
-        if (br.undecided) hR = box_exact(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w);
+    bool h0 = b0.accept, h1 = b1.accept, h2 = b2.accept, h3 = b3.accept;
+    if (__ballot(b0.undecided | b1.undecided | b2.undecided | b3.undecided) != 0ull) {  // rare: grazing contact
+        if (b0.undecided) h0 = box_exact(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
+        if (b1.undecided) h1 = box_exact(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w);
+        if (b2.undecided) h2 = box_exact(r, q3.x, q3.y, q3.z, q3.w, q4.x, q4.y);
+        if (b3.undecided) h3 = box_exact(r, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w);
     }
+    // (a slot that does not exist carries an inverted box -- rejected on every axis -- and the empty reference)
+    h0 &= ref0 != kWideEmpty; h1 &= ref1 != kWideEmpty; h2 &= ref2 != kWideEmpty; h3 &= ref3 != kWideEmpty;
     if (!ANYHIT) {
-        // near plane of the child box along the ray's major axis, as a ray parameter
-        hL = hL & !(r.prune_ok & (dFl * r.absSz > s.limit));
-        hR = hR & !(r.prune_ok & (dFr * r.absSz > s.limit));
+        // near plane of the box along the ray's major axis, as a ray parameter: beyond the closest hit -> nothing in it can win
+        h0 = h0 & !(r.prune_ok & (dF0 * r.absSz > s.limit));
+        h1 = h1 & !(r.prune_ok & (dF1 * r.absSz > s.limit));
+        h2 = h2 & !(r.prune_ok & (dF2 * r.absSz > s.limit));
+        h3 = h3 & !(r.prune_ok & (dF3 * r.absSz > s.limit));
     }
-    // near child first: dirIsNeg[node->axis] (pspRT.cpp:410-419)
-    const bool swap = !(meta & kMetaOrdered) && ((r.neg >> (meta & 3u)) & 1u);
-    const int first = swap ? right : left, second = swap ? left : right;
-    const bool hF = swap ? hR : hL, hS = swap ? hL : hR;
-    if (hF) {
-        s.cur = first;
-        if (hS) {
-            stack[s.sp * kBlock] = second;
-            ++s.sp;
-        }
-    } else if (hS) {
-        s.cur = second;
+    // visiting order: near child's group first, the near grandchild first inside a group (ordered nodes: always left first)
+    auto far_first = [&](unsigned m3) { return !(m3 & kMetaOrdered) && ((r.neg >> (m3 & 3u)) & 1u); };
+    const bool swapN = far_first(meta & 7u), swapL = far_first((meta >> 3) & 7u), swapR = far_first((meta >> 6) & 7u);
+    // left group in its order, right group in its order
+    const int la = swapL ? ref1 : ref0, lb = swapL ? ref0 : ref1;
+    const bool hla = swapL ? h1 : h0, hlb = swapL ? h0 : h1;
+    const int ra = swapR ? ref3 : ref2, rb = swapR ? ref2 : ref3;
+    const bool hra = swapR ? h3 : h2, hrb = swapR ? h2 : h3;
+    const int o0 = swapN ? ra : la, o1 = swapN ? rb : lb, o2 = swapN ? la : ra, o3 = swapN ? lb : rb;
+    const bool g0 = swapN ? hra : hla, g1 = swapN ? hrb : hlb, g2 = swapN ? hla : hra, g3 = swapN ? hlb : hrb;
+    // push the accepted slots last-to-first, then take the top: the first accepted becomes the current node
+    if (g3) { stack[s.sp * STRIDE] = o3; ++s.sp; }
+    if (g2) { stack[s.sp * STRIDE] = o2; ++s.sp; }
+    if (g1) { stack[s.sp * STRIDE] = o1; ++s.sp; }
+    if (g0) {
+        s.cur = o0;
     } else {
-        trav_pop(s, stack);
+        trav_pop<STRIDE>(s, stack);
     }
 }
 
@@ -502,7 +515,7 @@ __device__ __forceinline__ bool leaf_step(Trav &s, const Ray &r, const Scene &sc
 // the interleaving of the lanes differs, so results are bit-identical.
 // (A speculative variant that parks one leaf and keeps descending was measured 15 % slower:
 // the delayed pruning limit costs more node visits than the better lane occupancy saves.)
-template <bool ANYHIT, bool STATS>
+template <bool ANYHIT, bool STATS, int STRIDE = kBlock>
 __device__ __forceinline__ void trav_run(Trav &s, const Ray &r, const Scene &sc, int *stack,
                                          bool more, int refill)
 {
@@ -517,7 +530,7 @@ __device__ __forceinline__ void trav_run(Trav &s, const Ray &r, const Scene &sc,
         }
         if (cap == 0) {
             unsigned inner = 0;
-            while (s.cur >= 0 && ++inner <= sc.round_cap) node_step<ANYHIT, STATS>(s, r, sc, stack);
+            while (s.cur >= 0 && ++inner <= sc.round_cap) wide_step<ANYHIT, STATS, STRIDE>(s, r, sc, stack);
             if (s.cur >= 0) {                   // a descent longer than the tree: the same broken-tree verdict, at once
                 atomicOr(sc.err, 1u);           // (not round_cap re-entries of round_cap steps each)
                 s.cur = kDone;
@@ -527,7 +540,7 @@ __device__ __forceinline__ void trav_run(Trav &s, const Ray &r, const Scene &sc,
         } else {
             for (int d = 0; d < cap && __ballot(s.cur >= 0) != 0ull; ++d) {
                 if (STATS && (threadIdx.x & 63u) == (unsigned)__ffsll((long long)__ballot(true)) - 1u) ++s.w_node_rounds;
-                if (s.cur >= 0) node_step<ANYHIT, STATS>(s, r, sc, stack);
+                if (s.cur >= 0) wide_step<ANYHIT, STATS, STRIDE>(s, r, sc, stack);
             }
         }
         if (s.cur != kDone && s.cur < 0) {
@@ -535,7 +548,7 @@ __device__ __forceinline__ void trav_run(Trav &s, const Ray &r, const Scene &sc,
                 s.cur = kDone;
                 s.sp = 0;
             } else {
-                trav_pop(s, stack);
+                trav_pop<STRIDE>(s, stack);
             }
         }
         if (more && __popcll(__ballot(s.cur != kDone)) < refill) break;
@@ -790,7 +803,6 @@ __global__ void __launch_bounds__(kBlock)
     Trav s;
     s.cur = kDone;
     s.n_nodes = s.n_tris = 0;
-    s.touched = 0;
     s.w_node_rounds = s.w_tri_rounds = 0;
     unsigned item = 0, my_rays = 0;
     bool busy = false;
@@ -844,7 +856,6 @@ __global__ void __launch_bounds__(kBlock)
             }
         }
     }
-    if (sc.touch > 1 && s.touched == 0xFFFFFFFFu) atomicAdd(&work[13], 1u);   // (never: keeps the read-ahead loads)
     if (STATS) {
         if (s.w_node_rounds) atomicAdd(&work[14], s.w_node_rounds);
         if (s.w_tri_rounds) atomicAdd(&work[15], s.w_tri_rounds);
@@ -1254,8 +1265,11 @@ __global__ void __launch_bounds__(256)
     }
 }
 
-template <bool STATS, int PHASE>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 8)))
+// BS = threads per workgroup.  The passes that run beside other work (the residual retries: the frame loop's pass A holds the
+// LDS of every CU in 16-KB pieces by then) use one-wave workgroups: a 10-KB stack fits a hole a 40-KB one waits for
+// (measured beside pass A: 0.21 against 0.07 ms alone for the 4-wave form).
+template <bool STATS, int PHASE, int BS>
+__global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(4, 8)))
     projection_kernel(Scene sc, Cam cam, const float *__restrict__ nodes,
                       const int32_t *__restrict__ tri_nodes, unsigned nnodes,
                       int32_t *__restrict__ pix, unsigned *__restrict__ retry_nodes,
@@ -1278,7 +1292,6 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 
     Trav s;
     s.cur = kDone;
     s.n_nodes = s.n_tris = 0;
-    s.touched = 0;
     s.w_node_rounds = s.w_tri_rounds = 0;
     unsigned item = 0, my_rays = 0;
     bool busy = false, bounded = false;
@@ -1297,9 +1310,6 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 
                     ray_setup(r, cam.ox, cam.oy, cam.oz, dx, dy, dz);
                     ray_classify(r, sc);
                     trav_begin(s, r, sc);
-                    const OwnBound ob = own_bound(r, sc, it);
-                    apply_own_bound<0>(s, ob);
-                    bounded = ob.known & ob.hit;
                     item = it;
                     busy = true;
                     ++my_rays;
@@ -1321,7 +1331,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 
         if (__ballot(busy) == 0ull) break;
 
         if (busy) {
-            trav_run<false, STATS>(s, r, sc, stack, queue_has_more(q), sc.refill);
+            trav_run<false, STATS, BS>(s, r, sc, stack, queue_has_more(q), sc.refill);
             if (sc.heavy_steps && s.cur != kDone && s.steps > sc.heavy_steps) {
                 // a ray that keeps going (e.g. through a vertex shared by ~1000 triangles: every box of the fan is
                 // pierced, every triangle hit) would hold its wave for as long as ONE lane needs for thousands of
@@ -1364,7 +1374,6 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 
             }
         }
     }
-    if (sc.touch > 1 && s.touched == 0xFFFFFFFFu) atomicAdd(&work[13], 1u);   // (never: keeps the read-ahead loads)
     if (STATS) {
         if (s.w_node_rounds) atomicAdd(&work[14], s.w_node_rounds);
         if (s.w_tri_rounds) atomicAdd(&work[15], s.w_tri_rounds);
@@ -1382,6 +1391,13 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 
 // the child visited first), the triangle's position in its leaf in the low bits -- and the winner is the
 // smallest t, then the smallest key.  Same closest hit, same verdict as the one-lane traversal.
 constexpr unsigned kHeavyStack = 4096;
+// The stack of a cooperative walk lives in GLOBAL memory (one region per workgroup: keys, refs, depths), not in LDS: with 53 KB of
+// static LDS per workgroup the kernel -- which on most models only finds an empty list and returns -- could not start beside
+// the frame loop's pass A, whose workgroups hold the LDS of every CU in 16-KB pieces (measured: 0.14 ms from launch to end
+// per empty launch, two launches on the critical path of every projection build; 0.007 ms alone).  The region stays in L2;
+// a walk's round costs two more cache round trips, rays that need the walk are rare by design.
+constexpr size_t kHeavyScratchBytes = (size_t)kHeavyStack * (8 + 4 + 1);
+constexpr unsigned kHeavyGridMax = 512;
 struct HeavyBest {
     float t;
     unsigned long long key;
@@ -1406,7 +1422,7 @@ __device__ __forceinline__ void heavy_walk(const Ray &r, const Scene &sc, int *q
     unsigned top = 0;                         // (uniform) entries on the stack
     if (box_hit(r, sc.rlo[0], sc.rlo[1], sc.rlo[2], sc.rhi[0], sc.rhi[1], sc.rhi[2])) {   // trav_begin
         if (tid == 0) {
-            q_ref[0] = sc.root_ref;
+            q_ref[0] = sc.root_ref2;
             q_key[0] = 0ull;
             q_depth[0] = 0;
         }
@@ -1513,7 +1529,7 @@ __device__ __forceinline__ void heavy_walk(const Ray &r, const Scene &sc, int *q
         any = false;
         if (tid == 0) {
             int sp = 0;
-            int cur = sc.root_ref;
+            int cur = sc.root_ref2;
             for (unsigned visits = 0;; ++visits) {
                 if (visits > sc.round_cap) {
                     atomicOr(sc.err, 4u);
@@ -1602,9 +1618,10 @@ __global__ void __launch_bounds__(kHeavyThreads)
                  int32_t *__restrict__ pix, const unsigned *__restrict__ retry_nodes,
                  unsigned *__restrict__ retry_mask, const unsigned *__restrict__ work)
 {
-    __shared__ int q_ref[kHeavyStack];
-    __shared__ unsigned long long q_key[kHeavyStack];
-    __shared__ unsigned char q_depth[kHeavyStack];
+    unsigned char *scratch = sc.heavy_scratch + (size_t)blockIdx.x * kHeavyScratchBytes;
+    unsigned long long *q_key = reinterpret_cast<unsigned long long *>(scratch);
+    int *q_ref = reinterpret_cast<int *>(scratch + (size_t)kHeavyStack * 8);
+    unsigned char *q_depth = scratch + (size_t)kHeavyStack * 12;
     const unsigned lane = threadIdx.x;
     const unsigned count = min(work[kWorkHeavyCount + (PHASE ? 1 : 0)], kHeavyCap);
     for (unsigned h = blockIdx.x; h < count; h += gridDim.x) {
@@ -1649,9 +1666,10 @@ __global__ void __launch_bounds__(kHeavyThreads)
     heavy_cast_kernel(Scene sc, const float *__restrict__ org, int org_stride, const float *__restrict__ dir,
                       upsp_hits out, const unsigned *__restrict__ work)
 {
-    __shared__ int q_ref[kHeavyStack];
-    __shared__ unsigned long long q_key[kHeavyStack];
-    __shared__ unsigned char q_depth[kHeavyStack];
+    unsigned char *scratch = sc.heavy_scratch + (size_t)blockIdx.x * kHeavyScratchBytes;
+    unsigned long long *q_key = reinterpret_cast<unsigned long long *>(scratch);
+    int *q_ref = reinterpret_cast<int *>(scratch + (size_t)kHeavyStack * 8);
+    unsigned char *q_depth = scratch + (size_t)kHeavyStack * 12;
     const unsigned count = min(work[kWorkHeavyCast], kHeavyCap);
     for (unsigned h = blockIdx.x; h < count; h += gridDim.x) {
         const unsigned item = sc.heavy_items[h];
@@ -1815,8 +1833,9 @@ int env_int(const char *name, int dflt)
 
 int stack_entries(const upsp_bvh *b)
 {
-    // LDS stack depth per thread: tree height rounded up to a multiple of 8, >= 8
-    int d = (int)b->info.depth;
+    // LDS stack depth per thread: a wide step leaves at most three entries behind and descends one wide level (two of the
+    // binary tree's), a leaf none: 3 x wide levels + 1, rounded up to a multiple of 8, >= 8
+    int d = 3 * (int)b->wide_depth + 1;
     d = ((d + 7) / 8) * 8;
     return d < 8 ? 8 : d;
 }
@@ -1834,24 +1853,19 @@ Scene make_scene(const upsp_bvh *b, size_t items, int grid)
     share = (share / 64) * 64;
     sc.chunk = (unsigned)std::min<size_t>(std::max<size_t>(share, 64), kChunkMax);
     sc.nodes = reinterpret_cast<const float4 *>(b->d_nodes);
+    sc.wide = reinterpret_cast<const float4 *>(b->d_wide);
     sc.tris = reinterpret_cast<const float4 *>(b->d_tris);
-    sc.root_ref = b->root_ref;
-    static const int refill = env_int("UPSP_REFILL", kRefillDefault);
-    sc.refill = refill;
-    static const int desc_cap = env_int("UPSP_DESC_CAP", 6);
-    sc.desc_cap = desc_cap;
-    // (measured on MI355X: off 0.573 ms per projection build, on 0.650 ms -- primary traversal 266 -> 318 us,
-    //  residual 150 -> 171 us: the traversal is not waiting for the child record, the two extra requests per
-    //  visit cost more issue slots than the warm line saves.  Kept as a switch for other models.)
-    static const int touch = env_int("UPSP_TOUCH", 0) ? 1 : 0;
-    sc.touch = touch;
+    sc.root_ref = b->wide_root;
+    sc.root_ref2 = b->root_ref;
+    sc.refill = kRefillDefault;
+    sc.desc_cap = 6;        // (measured 1 / 2 / 6 / 8 rounds: primary 0.354 / 0.295 / 0.262 / 0.269 ms in round 2)
     // (measured: primary traversal 267-271 -> 263 us, batch queries alike; residual retries +2 %: their list is not
     //  in mesh order, so they keep the plain mapping)
-    static const int xcd = env_int("UPSP_XCD_AWARE", 1) ? 1 : 0;
-    sc.xcd = xcd;
+    sc.xcd = 1;
     sc.pack_waves = 0;
     sc.heavy_steps = 0;
     sc.heavy_items = nullptr;
+    sc.heavy_scratch = nullptr;
     sc.heavy_stack = 0;
     sc.adj_off = sc.adj_slot = nullptr;
     sc.slot_path = nullptr;
@@ -1892,8 +1906,7 @@ int grid_for(size_t items, size_t lds_bytes)
 {
     const int cus = props().cus > 0 ? props().cus : 256;
     int per_cu = (int)((160u * 1024u) / (lds_bytes ? lds_bytes : 1));
-    static const int cap_per_cu = env_int("UPSP_BLOCKS_PER_CU", 8);
-    if (per_cu > cap_per_cu) per_cu = cap_per_cu;
+    if (per_cu > 8) per_cu = 8;
     if (per_cu < 1) per_cu = 1;
     size_t want = (items + kBlock - 1) / kBlock;
     size_t cap = (size_t)cus * (size_t)per_cu;
@@ -1904,9 +1917,9 @@ int grid_for(size_t items, size_t lds_bytes)
 void prefetch_bvh(upsp_bvh *b, hipStream_t st)
 {
     KTimed kt("bvh_prefetch_kernel", st);
-    const size_t na = (size_t)b->info.n_gpu_nodes * 4, nb = (size_t)b->info.ntris * 3;
+    const size_t na = (size_t)b->n_wide * 8, nb = (size_t)b->info.ntris * 3;
     hipLaunchKernelGGL(bvh_prefetch_kernel, dim3(2048), dim3(256), 0, st,
-                       reinterpret_cast<const uint4 *>(b->d_nodes), na,
+                       reinterpret_cast<const uint4 *>(b->d_wide), na,
                        reinterpret_cast<const uint4 *>(b->d_tris), nb, b->d_work);
 }
 
@@ -1973,8 +1986,10 @@ int launch_cast(const upsp_bvh *cb, const float *d_org, int org_stride, const fl
     const bool heavy_on = heavy_steps > 0 && !b->stats_on && b->info.depth <= 56;
     if (heavy_on) {
         if (!b->d_heavy) UPSP_HIP_CHECK(hipMalloc(&b->d_heavy, sizeof(unsigned) * kHeavyCap));
+    if (!b->d_heavy_scratch) UPSP_HIP_CHECK(hipMalloc(&b->d_heavy_scratch, kHeavyScratchBytes * kHeavyGridMax));
         sc.heavy_steps = (unsigned)heavy_steps;
         sc.heavy_items = b->d_heavy;
+        sc.heavy_scratch = reinterpret_cast<unsigned char *>(b->d_heavy_scratch);
         sc.heavy_stack = kHeavyStack;
     }
     auto launch_heavy = [&]() {
@@ -1984,8 +1999,7 @@ int launch_cast(const upsp_bvh *cb, const float *d_org, int org_stride, const fl
                            (const unsigned *)b->d_work);
     };
     if (n >= 65536) prefetch_bvh(b, st);
-    static const bool two_pass = env_int("UPSP_CAST_TWO_PASS", 1) != 0;
-    if (two_pass && n >= 65536 && !b->stats_on) {
+    if (n >= 65536 && !b->stats_on) {
         if (b->cast_list_capacity < n) {
             if (b->d_cast_list) (void)hipFree(b->d_cast_list);
             b->d_cast_list = nullptr;
@@ -1993,8 +2007,7 @@ int launch_cast(const upsp_bvh *cb, const float *d_org, int org_stride, const fl
             UPSP_HIP_CHECK(hipMalloc(&b->d_cast_list, sizeof(unsigned) * n));
             b->cast_list_capacity = n;
         }
-        static const int waves_per_simd = env_int("UPSP_WAVES_PER_SIMD", 3);
-        sc.pack_waves = (unsigned)std::max(waves_per_simd, 0) * 4u * (unsigned)(props().cus > 0 ? props().cus : 256);
+        sc.pack_waves = kPackWavesPerSimd * 4u * (unsigned)(props().cus > 0 ? props().cus : 256);
         {
             KTimed kte("cast_entry_kernel", st);
             const dim3 egrid((unsigned)((n + 256 * kEntryItems - 1) / (256 * kEntryItems)));
@@ -2187,6 +2200,12 @@ int upsp_bvh_create(const float *h_tris9, size_t ntris, upsp_bvh **out)
         e = hipMemcpy(b->d_nodes, hb.nodes.data(), hb.nodes.size() * sizeof(GpuNode),
                       hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(b->d_tris, hb.tris.data(), tb, hipMemcpyHostToDevice);
+    const size_t wb = std::max<size_t>(hb.wide.size(), 1) * sizeof(GpuWide);
+    if (e == hipSuccess) e = hipMalloc(&b->d_wide, wb);
+    if (e == hipSuccess && !hb.wide.empty()) e = hipMemcpy(b->d_wide, hb.wide.data(), hb.wide.size() * sizeof(GpuWide), hipMemcpyHostToDevice);
+    b->wide_root = hb.wide_root;
+    b->n_wide = (uint32_t)hb.wide.size();
+    b->wide_depth = hb.wide_depth;
     if (e == hipSuccess) e = hipMemset(b->d_work, 0, (kWorkWords + 4) * sizeof(unsigned));
     b->d_err = b->d_work + kWorkWords;      // (outlives the per-call clearing of the work words)
     if (e != hipSuccess) {
@@ -2246,7 +2265,7 @@ int upsp_bvh_create(const float *h_tris9, size_t ntris, upsp_bvh **out)
     b->info.n_gpu_nodes = (uint32_t)hb.nodes.size();
     b->info.depth = hb.depth;
     b->info.max_leaf = hb.max_leaf;
-    b->info.device_bytes = nb + tb;
+    b->info.device_bytes = nb + tb + wb;
     b->info.build_seconds =
         std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     *out = b;
@@ -2257,6 +2276,7 @@ void upsp_bvh_destroy(upsp_bvh *b)
 {
     if (!b) return;
     if (b->d_nodes) (void)hipFree(b->d_nodes);
+    if (b->d_wide) (void)hipFree(b->d_wide);
     if (b->d_tris) (void)hipFree(b->d_tris);
     if (b->d_work) (void)hipFree(b->d_work);
     if (b->d_retry_nodes) (void)hipFree(b->d_retry_nodes);
@@ -2269,6 +2289,7 @@ void upsp_bvh_destroy(upsp_bvh *b)
     if (b->d_todo_mask) (void)hipFree(b->d_todo_mask);
     if (b->d_todo_rays) (void)hipFree(b->d_todo_rays);
     if (b->d_heavy) (void)hipFree(b->d_heavy);
+    if (b->d_heavy_scratch) (void)hipFree(b->d_heavy_scratch);
     if (b->d_cast_list) (void)hipFree(b->d_cast_list);
     if (b->d_stage) (void)hipFree(b->d_stage);
     if (b->h_stage) (void)hipHostFree(b->h_stage);
@@ -2469,6 +2490,7 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
         b->retry_capacity = nnodes;
     }
     if (!b->d_heavy) UPSP_HIP_CHECK(hipMalloc(&b->d_heavy, sizeof(unsigned) * kHeavyCap));
+    if (!b->d_heavy_scratch) UPSP_HIP_CHECK(hipMalloc(&b->d_heavy_scratch, kHeavyScratchBytes * kHeavyGridMax));
     UPSP_HIP_CHECK(hipMemsetAsync(b->d_work, 0, kWorkWords * sizeof(unsigned), st));
     const int grid = grid_for(nnodes, lds);
     Scene sc = make_scene(b, nnodes, grid);
@@ -2489,47 +2511,38 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
     if (heavy_on) {
         sc.heavy_steps = sc1.heavy_steps = (unsigned)heavy_steps;
         sc.heavy_items = sc1.heavy_items = b->d_heavy;
+        sc.heavy_scratch = sc1.heavy_scratch = reinterpret_cast<unsigned char *>(b->d_heavy_scratch);
         sc.heavy_stack = sc1.heavy_stack = (unsigned)std::min<int>(std::max(heavy_stack, 128), (int)kHeavyStack);
     }
-    static const int waves_per_simd = env_int("UPSP_WAVES_PER_SIMD", 3);
-    sc.pack_waves = sc1.pack_waves = (unsigned)std::max(waves_per_simd, 0) * 4u * (unsigned)(props().cus > 0 ? props().cus : 256);
-    static const int heavy_grid = env_int("UPSP_HEAVY_GRID", 512);
+    sc.pack_waves = sc1.pack_waves = kPackWavesPerSimd * 4u * (unsigned)(props().cus > 0 ? props().cus : 256);
+    const int heavy_grid = (int)kHeavyGridMax;
 #define UPSP_LAUNCH_HEAVY(PHASE, SC)                                                                             \
     if (heavy_on) {                                                                                              \
         KTimed kth("heavy_kernel", st);                                                                          \
         hipLaunchKernelGGL((heavy_kernel<PHASE>), dim3(heavy_grid), dim3(kHeavyThreads), 0, st, SC, c, d_nodes, d_tri_nodes, \
                            d_pix, (const unsigned *)b->d_retry_nodes, b->d_retry_mask, (const unsigned *)b->d_work); \
     }
-    static const bool own_bound_on = std::getenv("UPSP_NO_OWN_BOUND") == nullptr;
     bool use_witness = false;
-    if (own_bound_on && b->d_adj_off && b->adj_src == (const void *)d_tri_nodes && b->adj_nnodes == nnodes) {
+    if (b->d_adj_off && b->adj_src == (const void *)d_tri_nodes && b->adj_nnodes == nnodes) {
         // bounded visibility rays (own_bound) for the retry pass only: measured on MI355X the
         // primary rays gain nothing (the near-first traversal finds the front surface at once
         // and prunes behind it; 0.44 -> 0.47 ms with the extra own-triangle tests), the retries
         // lose the rays that miss every own triangle and exit early: 0.70 -> 0.59 ms
-        static const bool bound_primary = std::getenv("UPSP_OWN_BOUND_PRIMARY") != nullptr;
         sc1.adj_off = b->d_adj_off;
         sc1.adj_slot = b->d_adj_slot;
         // occluder witness (witness_kernel): the primary pass records the triangle it hit, the
         // retries test that triangle and its box chain first and only the rest is traversed
-        static const bool witness_on = std::getenv("UPSP_NO_WITNESS") == nullptr;
-        if (witness_on && b->d_slot_path && b->d_path_ref && b->d_witness && b->d_todo_mask && b->d_todo_rays) {
+        if (b->d_slot_path && b->d_path_ref && b->d_witness && b->d_todo_mask && b->d_todo_rays) {
             use_witness = true;
             sc.witness = b->d_witness;
             sc1.witness = b->d_witness;
             sc1.slot_path = reinterpret_cast<const uint2 *>(b->d_slot_path);
             sc1.path_ref = b->d_path_ref;
         }
-        if (bound_primary) {
-            sc.adj_off = b->d_adj_off;
-            sc.adj_slot = b->d_adj_slot;
-        }
     }
     const dim3 egrid((unsigned)((nnodes + 255) / 256)), eblock(256);
-    // (cache-warming sweep over the BVH before the traversals: 13 us; measured neutral in round 1 and 7-12 us slower
-    //  per build in round 2 -- off unless UPSP_PREFETCH is set)
-    static const bool prefetch_on = std::getenv("UPSP_PREFETCH") != nullptr;
-    if (prefetch_on && nnodes >= 65536) prefetch_bvh(b, st);
+    // (a cache-warming sweep over the BVH before the traversals was measured neutral in round 1 and 7-12 us slower per build in
+    //  round 2: not done here; the batch queries keep theirs)
     {
         KTimed kt("project_nodes_kernel", st);
         // (UPSP_OBLIQUE_CULL=0: always cast the reference's rays; 2: never, even when they are counted -- for profiling)
@@ -2545,9 +2558,16 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
                            (unsigned)nnodes, b->d_todo_rays, (unsigned *)nullptr, b->d_work);
     }
 #define UPSP_LAUNCH_PROJ(STATS, PHASE, G, SC)                                                    \
-    hipLaunchKernelGGL((projection_kernel<STATS, PHASE>), dim3(G), dim3(kBlock), lds, st, SC, c, \
-                       d_nodes, d_tri_nodes, (unsigned)nnodes, d_pix, b->d_retry_nodes,          \
-                       b->d_retry_mask, (const unsigned *)b->d_todo_rays, b->d_work)
+    do {                                                                                         \
+        if (PHASE == 0)                                                                          \
+            hipLaunchKernelGGL((projection_kernel<STATS, PHASE, kBlock>), dim3(G), dim3(kBlock), lds, st, SC, c, \
+                               d_nodes, d_tri_nodes, (unsigned)nnodes, d_pix, b->d_retry_nodes,  \
+                               b->d_retry_mask, (const unsigned *)b->d_todo_rays, b->d_work);    \
+        else                                                                                     \
+            hipLaunchKernelGGL((projection_kernel<STATS, PHASE, 64>), dim3((G) * (kBlock / 64)), dim3(64), lds / (kBlock / 64), st, SC, c, \
+                               d_nodes, d_tri_nodes, (unsigned)nnodes, d_pix, b->d_retry_nodes,  \
+                               b->d_retry_mask, (const unsigned *)b->d_todo_rays, b->d_work);    \
+    } while (0)
     {
         KTimed kt("projection_kernel<primary>", st);
         if (b->stats_on) UPSP_LAUNCH_PROJ(true, 0, grid, sc); else UPSP_LAUNCH_PROJ(false, 0, grid, sc);
@@ -2576,8 +2596,7 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
                                (const unsigned *)b->d_todo_mask, b->d_todo_rays, b->d_work);
         }
         Scene sc2 = sc1;
-        static const int desc_cap2 = env_int("UPSP_DESC_CAP_RESIDUAL", 4);
-        sc2.desc_cap = desc_cap2;
+        sc2.desc_cap = 4;       // (residual retries: 0.179 -> 0.145 ms at 4 rounds in round 2)
         sc2.chunk = 64;   // few rays are left (~3.5 %; 16 lanes per wave and 16-ray chunks: 0.37 instead of 0.21 ms)
         {
             KTimed kt("projection_kernel<retry>", st);
@@ -2636,14 +2655,6 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
         UPSP_HIP_CHECK(hipMemcpy(cnt, b->d_work + kWorkRetryCount, sizeof(cnt), hipMemcpyDeviceToHost));
         b->last_retry_nodes = cnt[0];
         b->last_primary = cnt[1];
-        if (std::getenv("UPSP_DEBUG_COUNTS")) {
-            unsigned w[16];
-            UPSP_HIP_CHECK(hipMemcpy(w, b->d_work, sizeof(w), hipMemcpyDeviceToHost));
-            unsigned hv[2] = {0, 0};
-            UPSP_HIP_CHECK(hipMemcpy(hv, b->d_work + kWorkHeavyCount, sizeof(hv), hipMemcpyDeviceToHost));
-            std::fprintf(stderr, "upsp work: retry_nodes %u  todo_rays %u  max_nodes/ray %u  max_tris/ray %u  heavy rays: primary %u, retries %u\n",
-                         w[kWorkRetryCount], w[kWorkTodoCount], w[8], w[9], hv[0], hv[1]);
-        }
     }
     return UPSP_OK;
 }

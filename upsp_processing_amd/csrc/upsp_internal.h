@@ -35,6 +35,21 @@ struct alignas(64) GpuNode {
 };
 static_assert(sizeof(GpuNode) == 64, "GpuNode must be 64 bytes");
 
+// The same tree with every other level folded away: one 128-byte record (one cache line) per node that a traversal
+// ENTERS, holding the boxes and references of up to four descendants -- for each child of the binary node, the child
+// itself when it is a leaf, its two children when it is interior.  A traversal step decides two levels of the
+// reference's descent with one dependent fetch instead of two.
+//   q[0..11]  boxes of slots 0, 1 (the left child's group), packed like GpuNode's pair;  q[12..23] slots 2, 3 (right group)
+//   q[24..27] slot references as int bits (>= 0: wide node, < 0: leaf code as above, kWideEmpty: no such slot)
+//   q[28]     meta as int bits: bits 0-2 the binary node's (axis | ordered << 2), bits 3-5 its left child's, 6-8 its right child's
+// The reference visits the children of a node near-first by the sign of the ray direction along the node's split axis
+// (pspRT.cpp:410-419); applied twice that fixes the order of the four slots (raycast.hip: wide_step).
+struct alignas(128) GpuWide {
+    float q[32];
+};
+static_assert(sizeof(GpuWide) == 128, "GpuWide must be 128 bytes");
+constexpr int32_t kWideEmpty = (int32_t)0x7FFFFFFF;
+
 // 48-byte triangle record in leaf order: (A, primID) (B, -) (C, -)
 struct alignas(16) GpuTri {
     float a[3];
@@ -60,6 +75,9 @@ struct HostBvh {
     uint32_t depth = 0;
     uint32_t max_leaf = 0;
     uint32_t top_nodes = 0;  // nodes [0, top_nodes) are the breadth-first upper tree
+    std::vector<GpuWide> wide;   // the two-levels-per-step form of the same tree (collapse_wide)
+    int32_t wide_root = 0;       // >= 0: index into wide; < 0: the root is a leaf (its code)
+    uint32_t wide_depth = 0;     // levels of wide nodes on the longest path
 };
 
 // SAH build with the reference's topology and leaf order (pspRT.cpp:456-572).
@@ -69,6 +87,9 @@ void build_bvh(const float *tris9, size_t ntris, HostBvh &out);
 
 struct upsp_bvh {
     upsp::GpuNode *d_nodes = nullptr;
+    upsp::GpuWide *d_wide = nullptr;   // the same tree, two levels per record (the traversal kernels' layout)
+    int32_t wide_root = 0;
+    uint32_t n_wide = 0, wide_depth = 0;
     upsp::GpuTri *d_tris = nullptr;
     uint32_t *d_work = nullptr;   // [0] work-queue head, [2..7] 64-bit stats, [8..10] see raycast.hip
     uint32_t *d_err = nullptr;    // error word of the walks (round cap exceeded), behind the work words
@@ -82,6 +103,7 @@ struct upsp_bvh {
     int32_t *d_witness = nullptr;      // per node: triangle slot the primary ray hit (retry nodes)
     uint32_t *d_todo_mask = nullptr, *d_todo_rays = nullptr;   // retries the witness test left undecided
     uint32_t *d_heavy = nullptr;                               // work items handed to heavy_kernel
+    void *d_heavy_scratch = nullptr;                           // ... and the stacks of its cooperative walks (global memory)
     uint32_t *d_cast_list = nullptr;                           // batch queries: rays that enter the root box
     size_t cast_list_capacity = 0;
     const void *adj_src = nullptr;     // the d_tri_nodes buffer the adjacency was built from

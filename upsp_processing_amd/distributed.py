@@ -86,6 +86,19 @@ def lib_comm(group=None):
     return _LIB_COMM[key]
 
 
+def comm_ranks(group=None):
+    """(rank, ranks) of the library's RCCL communicator as RCCL reports them (ncclCommUserRank / ncclCommCount through
+    upsp_comm_rank); None when the exchanges of this group do not run through it."""
+    h = lib_comm(group)
+    if h is None or not dist.is_initialized():
+        return None
+    import ctypes as C
+    from . import _capi
+    r, w = C.c_int(-1), C.c_int(-1)
+    _capi.check(_capi.lib().upsp_comm_rank(h, C.byref(r), C.byref(w)))
+    return int(r.value), int(w.value)
+
+
 def init_from_env(backend=None):
     """One process per GPU: reads RANK / LOCAL_RANK / WORLD_SIZE (torchrun, or psp_process -ranks=N),
     selects this rank's device BEFORE any other GPU call and joins the process group ("nccl" = RCCL
