@@ -101,6 +101,13 @@ def parse():
                          "the N > 1 loop (implies --force-chunked on one GPU; as many exchange chunks as keep each within one pass A, "
                          "i.e. <= 1024 frames) -- the run's chunks overlap each other, only the last one and pass B are exposed once "
                          "per 12 500 frames, not once per 1000 as in the default N > 1 step")
+    ap.add_argument("--defer-exchange", action="store_true",
+                    help="--force-chunked on one GPU: the two-exchanges-in-turn schedule of the N > 1 runs (see --sync-exchange)")
+    ap.add_argument("--sync-exchange", action="store_true",
+                    help="N > 1 loop: finish every step's exchange (wait for its last chunk, run the owner's pass B) inside the step, "
+                         "as round 3 did.  Default between GPUs: two exchanges in turn -- step k's series are placed and its pass B runs "
+                         "after step k + 1's chunks are on their way, so a step waits for no link; the last step's are finished before "
+                         "the clock stops")
     ap.add_argument("--serial", action="store_true",
                     help="one stream: projection build, then pass A, then pass B (round 2's default schedule)")
     ap.add_argument("--plain-frames", action="store_true",
@@ -545,6 +552,7 @@ def multi_camera_main(a):
 
     for _ in range(a.warmup):
         step(False)
+    drain()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -814,6 +822,22 @@ def main():
                                device="cuda") for k in range(K)] if chunked else None)
     ev_log = []
     first_step = [True]
+    # Pixel-series wire: TWO exchanges used in turn.  A rank's run is many steps long (configs[3]: 12 500 frames per rank), and
+    # what a step leaves behind -- its last chunk still on the links, the owner's pass B -- does not have to be waited for
+    # before the next step's frames are scanned: step k's exchange is finished after step k + 1's chunks have been submitted.
+    # (between GPUs only, or on request: on ONE GPU nothing waits for a link, and the later pass B finds its compact series
+    #  pushed out of the Infinity Cache by the next step's frames -- 1.56 against 1.45 ms per step, measured)
+    deferred = chunked and pixel_wire and not a.sync_exchange and (world > 1 or a.defer_exchange)
+    exchs = [exch, D.TimeSeriesExchange(shard, K, wire12=a.wire12)] if deferred else [exch]
+    ex_state = {"step": 0, "pending": None, "first": [True, True], "last_done": exch}
+
+    def drain():
+        """finish the exchange the previous step left in flight (pass B of its frames: series + its slice of the sums)"""
+        if ex_state["pending"] is not None:
+            s_, ss_ = pipe.accumulators()
+            ex_state["pending"].finish_pixels(s_, ss_)
+            ex_state["last_done"] = ex_state["pending"]
+            ex_state["pending"] = None
 
     # Pass A reads the frames and needs only the CANDIDATE pixels (known after step 1 of create_projection_mat), the ray casting
     # is a latency-bound chain of dependent fetches: side by side they take 0.59-0.63 ms where one after the other they take
@@ -863,14 +887,20 @@ def main():
         elif pixel_wire:
             # the sender runs pass A (+ hot-pixel repair) per chunk and ships the active pixels' series; the owner of a node
             # runs pass B over all frames (exch.finish_pixels below)
-            exch.k = 0
+            which = ex_state["step"] % len(exchs)
+            ex = exchs[which]
+            ex_state["step"] += 1
+            ex.k = 0
             tab = pipe.pixel_series(None)           # node -> compact row of this projection
-            exch.set_pixels(tab["node_k"], engine.skipped_nodes(proj["pix"], want_count=False)[0], assume_same=not first_step[0])
-            first_step[0] = False
+            ex.set_pixels(tab["node_k"], engine.skipped_nodes(proj["pix"], want_count=False)[0], assume_same=not ex_state["first"][which])
+            ex_state["first"][which] = False
             for k in range(K):
-                c0, fc = exch.my_chunk(k)
+                c0, fc = ex.my_chunk(k)
                 ps = pipe.pixel_series(frames[c0:c0 + fc]) if fc else tab
-                exch.submit_pixels(ps)
+                ex.submit_pixels(ps)
+            if deferred:
+                drain()                             # the PREVIOUS step's series and sums, now that this step's chunks are on their way
+                ex_state["pending"] = ex
         else:
             exch.k = 0
             # rows of nodes no camera sees are NaN on every rank: they do not travel, and pass B writes
@@ -889,8 +919,8 @@ def main():
                 exch.submit(buf, packed=True)
         e[2].record()
         s, ss = pipe.accumulators()
-        if pixel_wire:
-            exch.finish_pixels(s, ss)             # pass B of this rank's nodes over all frames: series + its slice of the sums
+        if pixel_wire and not deferred:
+            exchs[0].finish_pixels(s, ss)         # pass B of this rank's nodes over all frames: series + its slice of the sums
         D.allreduce_sums(s, ss)
         if chunked and not pixel_wire:
             exch.finish()
@@ -913,10 +943,12 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step(True)
+    drain()                             # (deferred exchange: the last step's series and sums, inside the timed region)
     barrier()
     dt = time.perf_counter() - t0
     if chunked:
-        exch.verify()                   # the travelling set did not change between the steps
+        for x in exchs:
+            x.verify()                  # the travelling set did not change between the steps
     bvh.check()                         # no walk ran past its round cap (UPSP_ERR_INTERNAL otherwise)
     for e in ev_log:
         t_ray.append(e[0].elapsed_time(e[1]))
@@ -934,6 +966,7 @@ def main():
     _capi.timing_enable(True)
     for _ in range(a.steps):
         step(False)
+    drain()
     barrier()
     _capi.timing_enable(False)
     dt_rank_min = dt_rank_max = dt
@@ -1080,8 +1113,9 @@ def main():
                                      "SURVEY 8(d): model intensity x 24 fiducial discs, background 60, noise 8, "
                                      "<= 3 hot pixels in 1 % of the frames"),
                    "parallelism": "frames sharded x%d" % world, "schedule": sched,
-                   **({"exchange": "%d chunks, %s as %s" % (K, "active-pixel series" if pixel_wire else "visible rows",
-                                                            ("u16 packed to 12 bit" if a.wire12 else "u16") if u16_wire else "f32")}
+                   **({"exchange": "%d chunks, %s as %s%s" % (K, "active-pixel series" if pixel_wire else "visible rows",
+                                                              ("u16 packed to 12 bit" if a.wire12 else "u16") if u16_wire else "f32",
+                                                              "; two exchanges in turn, a step's series finished behind the next step's chunks" if deferred else "")}
                       if chunked else {})},
         # rays the REFERENCE casts for this camera / the time of a build that casts a tenth of them (the oblique test first, the
         # occluder witness): an equivalence, not a ray rate -- "mrays_per_s" below is the ray caster's own rate
@@ -1174,7 +1208,7 @@ def main():
             })
             if chunked:   # the series as it came out of the (chunked, packed, u16) exchange
                 checks["exchange_series_8_frames"] = bool(np.array_equal(
-                    exch.out[:, :8].cpu().numpy().T.view(np.int32), ref["rows8"].view(np.int32)))
+                    ex_state["last_done"].out[:, :8].cpu().numpy().T.view(np.int32), ref["rows8"].view(np.int32)))
             if not a.no_reraycast:
                 out["pixel_rays"] = pixel_ray_rate(bvh, cd, size, check_with=ref["obv"])
                 checks["pixel_rays_closest_hit_sample"] = out["pixel_rays"]["parity"]
@@ -1230,8 +1264,9 @@ def main():
             "; %.2f G rays/s entering the tree" % (out["mrays_per_s"] / 1e3) if out.get("mrays_per_s") else "")
         print(json.dumps(out), flush=True)
     if exch is not None:
-        exch.verify()                   # (the timer-on steps made assume_same claims too)
-        exch.close()
+        for x in exchs:
+            x.verify()                  # (the timer-on steps made assume_same claims too)
+            x.close()
     if world > 1 or force_coll:
         D.shutdown()
 

@@ -81,9 +81,17 @@ def test_bench_pixel_wire(gpu_lib):
     d2 = run_bench(["--force-chunked", "--row-wire", "--small", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-reraycast"],
                    env={"UPSP_FORCE_COLLECTIVES": "1"})
     assert x["travelling_rows"] < d2["exchange_bytes_per_step"]["travelling_rows"]          # fewer pixel rows than node rows
-    d = run_bench(["--gpus", "2", "--small", "--steps", "2", "--warmup", "1"],
+    # two ranks: two exchanges in turn (a step's series are finished behind the next step's chunks; the last one before the
+    # clock stops) -- and the same schedule forced on one rank through RCCL, parity checked against the oracle in the run
+    d = run_bench(["--gpus", "2", "--small", "--steps", "3", "--warmup", "1"],
                   env={"UPSP_BENCH_BACKEND": "gloo", "UPSP_BENCH_ONE_GPU": "1"})
-    assert d["n_gpus"] == 2 and d["config"]["exchange"] == "4 chunks, active-pixel series as u16"
+    assert d["n_gpus"] == 2 and d["config"]["exchange"].startswith("4 chunks, active-pixel series as u16; two exchanges in turn")
+    d = run_bench(["--force-chunked", "--defer-exchange", "--small", "--steps", "3", "--warmup", "1"], env={"UPSP_FORCE_COLLECTIVES": "1"})
+    assert d["config"]["exchange"].startswith("4 chunks, active-pixel series as u16; two exchanges in turn") and d["parity_checked"] is True
+    assert d["rccl_nranks"] == 1
+    d = run_bench(["--gpus", "2", "--small", "--steps", "2", "--warmup", "1", "--sync-exchange"],
+                  env={"UPSP_BENCH_BACKEND": "gloo", "UPSP_BENCH_ONE_GPU": "1"})
+    assert d["config"]["exchange"] == "4 chunks, active-pixel series as u16"
 
 
 def test_bench_two_ranks_rccl(gpu_lib):
@@ -91,5 +99,5 @@ def test_bench_two_ranks_rccl(gpu_lib):
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs (RCCL over xGMI)")
     d = run_bench(["--gpus", "2", "--small", "--steps", "2", "--warmup", "1"])
-    assert d["n_gpus"] == 2 and "backend" not in d
-    assert d["config"]["exchange"] == "4 chunks, active-pixel series as u16"
+    assert d["n_gpus"] == 2 and "backend" not in d and d["rccl_nranks"] == 2
+    assert d["config"]["exchange"].startswith("4 chunks, active-pixel series as u16")
