@@ -126,6 +126,40 @@ def spawn_ranks(n):
     return subprocess.call(cmd)
 
 
+class quiet_gc:
+    """No cyclic-GC pass inside a timed loop: with torch imported a full collection walks ~1 M objects and stops the issuing
+    thread for 40-65 ms -- measured as ONE 32-61-ms step in the first bench process of a fresh box (N > 1 loop, one GPU), where
+    the host is not a step ahead of the GPU.  Collected before, frozen, re-enabled after."""
+
+    def __enter__(self):
+        import gc
+        self.was = gc.isenabled()
+        if os.environ.get("UPSP_BENCH_GC"):          # diagnosis: leave the collector on and report its passes
+            t = [0.0]
+
+            def cb(phase, info):
+                if phase == "start":
+                    t[0] = time.perf_counter()
+                else:
+                    sys.stderr.write("gc: generation %d pass of %.1f ms inside a timed loop\n" % (info["generation"], (time.perf_counter() - t[0]) * 1e3))
+            self.cb = cb
+            gc.callbacks.append(cb)
+            return
+        gc.collect()
+        gc.freeze()
+        gc.disable()
+
+    def __exit__(self, *exc):
+        import gc
+        if os.environ.get("UPSP_BENCH_GC"):
+            gc.callbacks.remove(self.cb)
+            return False
+        if self.was:
+            gc.enable()
+        gc.unfreeze()
+        return False
+
+
 def usable_cpus():
     """Host cores this process may really use: the affinity mask and the cgroup CPU quota (a one-GPU box
     of the pool exposes all of the host's logical CPUs but grants a share of them)."""
@@ -370,11 +404,12 @@ def registration_block(bvh, cam, d_nodes, d_nrm, d_tn, frames, restore, N, size,
         step()
     torch.cuda.synchronize()
     st0 = pipe.ecc_stats()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    with quiet_gc():
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
     st1 = pipe.ecc_stats()
     iters = (st1["frame_iterations"] - st0["frame_iterations"]) / max(st1["frames"] - st0["frames"], 1)
     _capi.timing_enable(True)
@@ -421,7 +456,8 @@ def registration_block(bvh, cam, d_nodes, d_nrm, d_tn, frames, restore, N, size,
         "value": F * steps / dt, "unit": "frames/s", "steps": steps, "warmup": warmup, "ms_per_step": ms_step,
         "ecc_iterations_per_frame": iters,
         "roofline": dict({"kernel": dom, "bound": "hbm", "achieved": dk["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                          "frac": dk["achieved_GBps"] / HBM_PEAK_GBS, "traffic": None,
+                          "frac": dk["achieved_GBps"] / HBM_PEAK_GBS, "traffic": tracked_traffic(dom, "ecc")[0],
+                          "traffic_source": tracked_traffic(dom, "ecc")[1],
                           "algorithmic_bytes_per_launch": dk["algorithmic_bytes_per_step"] / max(dk["calls_per_step"], 1),
                           "avg_launch_ms": dk["avg_launch_ms"], "launches_per_step": dk["calls_per_step"]},
                          **ECC_SYMBOLS.get(dom, {})),
@@ -433,6 +469,34 @@ def registration_block(bvh, cam, d_nodes, d_nrm, d_tn, frames, restore, N, size,
 # rocprofv3 trace shows for them
 ECC_SYMBOLS = {"ecc_sums_kernel": {"kernel_symbols": ["ecc_cols_kernel<true,4,4> (iterations from the identity warp)",
                                                       "ecc_cols_kernel<false,2,3> (general warp: source taps from an LDS tile)"]}}
+
+
+def tracked_traffic(kernel, kind, world=1):
+    """HBM traffic of a kernel per launch: only from a rocprofv3 PMC summary of THIS configuration (tools/profile_bench.sh writes
+    it: FETCH_SIZE and WRITE_SIZE in separate passes, the gfx950 FETCH correction applied for the streaming kernels) -- the file
+    UPSP_BENCH_TRAFFIC_JSON names, else the newest tracked profiles/rNN_<kind>_summary.json, used only when its bench_args are
+    this run's arguments (kind "ecc": the summary of `bench.py --registration`, whose launches the configs2 block of the
+    default line repeats).  Returns (bytes or None, source or None)."""
+    import glob
+    prof = os.environ.get("UPSP_BENCH_TRAFFIC_JSON") if kind == "bench" else None
+    if not prof:
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_%s_summary.json" % kind)))
+        prof = cands[-1] if cands else None
+    if not (prof and os.path.exists(prof)):
+        return None, None
+    pj = json.load(open(prof))
+    mine, skip = [], False
+    for x in sys.argv[1:]:       # arguments that do not change the launches: baseline / stress switches, the step counts
+        if skip:
+            skip = False
+        elif x in ("--steps", "--warmup", "--gpus"):
+            skip = True
+        elif not (x in ("--no-cpu-baseline", "--no-reraycast") or x.startswith(("--steps=", "--warmup=", "--gpus="))):
+            mine.append(x)
+    want = mine + (["--registration"] if kind == "ecc" and "--registration" not in mine else [])
+    if pj.get("bench_args", "").split() == want and world == 1 and kernel in pj.get("traffic_bytes_per_launch", {}):
+        return pj["traffic_bytes_per_launch"][kernel], os.path.relpath(os.path.abspath(prof), ROOT)
+    return None, None
 
 
 def merge_ecc_labels(rep):
@@ -552,13 +616,13 @@ def multi_camera_main(a):
 
     for _ in range(a.warmup):
         step(False)
-    drain()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step(True)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    with quiet_gc():
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step(True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
     bvh.check()
     _capi.timing_enable(True)
     for _ in range(a.steps):
@@ -804,7 +868,7 @@ def main():
     torch.cuda.synchronize()
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
-    t_ray, t_frames, t_xchg = [], [], []
+    t_ray, t_frames, t_xchg, host_log = [], [], [], []
     last_pix = [None]
 
     # N > 1: the frame loop runs in K chunks and the all-to-all of chunk k is issued
@@ -855,6 +919,7 @@ def main():
         e = [ev() for _ in range(4)]
         restore_hot()
         e[0].record()
+        ht = [time.perf_counter()]
         main = torch.cuda.current_stream()
         if swap:
             side.wait_stream(main)
@@ -872,6 +937,7 @@ def main():
         if not swap:
             proj = engine.build_projection(bvh, cam, d_nodes, d_nrm, d_tn, 70.0, counts=False)   # no host sync
         e[1].record()
+        ht.append(time.perf_counter())
         pipe.reset()
         if overlap:
             # before the projection is copied into the pipeline: with the build on the side stream the copy would otherwise
@@ -918,16 +984,25 @@ def main():
                     pipe.process(frames[c0:c0 + fc], first_frame=rank * F + c0, rows_t=buf, want_rows=False)
                 exch.submit(buf, packed=True)
         e[2].record()
+        ht.append(time.perf_counter())
         s, ss = pipe.accumulators()
+        _h = [time.perf_counter()]
         if pixel_wire and not deferred:
             exchs[0].finish_pixels(s, ss)         # pass B of this rank's nodes over all frames: series + its slice of the sums
+        _h.append(time.perf_counter())
         D.allreduce_sums(s, ss)
+        _h.append(time.perf_counter())
         if chunked and not pixel_wire:
             exch.finish()
         avg, rms = pipe.finalize(F * world)
+        _h.append(time.perf_counter())
+        if os.environ.get("UPSP_BENCH_TRACE_HOST"):
+            sys.stderr.write("host tail: finish_pixels %.3f allreduce %.3f finalize %.3f ms\n" % tuple((b - a) * 1e3 for a, b in zip(_h[:-1], _h[1:])))
         e[3].record()
+        ht.append(time.perf_counter())
         if record:                      # events are read after the timed loop: no host sync inside it
             ev_log.append(e)
+            host_log.append([(b - a) * 1e3 for a, b in zip(ht[:-1], ht[1:])])
             last_pix[0] = proj["pix"]
         return avg
 
@@ -940,12 +1015,13 @@ def main():
         torch.cuda.synchronize()
 
     barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step(True)
-    drain()                             # (deferred exchange: the last step's series and sums, inside the timed region)
-    barrier()
-    dt = time.perf_counter() - t0
+    with quiet_gc():
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step(True)
+        drain()                         # (deferred exchange: the last step's series and sums, inside the timed region)
+        barrier()
+        dt = time.perf_counter() - t0
     if chunked:
         for x in exchs:
             x.verify()                  # the travelling set did not change between the steps
@@ -1060,27 +1136,7 @@ def main():
     # HBM traffic of that kernel: only from a rocprofv3 PMC summary of THIS configuration, handed over
     # explicitly (tools/profile_bench.sh writes it: FETCH_SIZE and WRITE_SIZE in separate passes, the
     # gfx950 FETCH correction applied for the streaming kernels); otherwise null
-    traffic, traffic_src = None, None
-    prof = os.environ.get("UPSP_BENCH_TRAFFIC_JSON")
-    if not prof:
-        # default: the newest tracked summary (tools/profile_bench.sh writes profiles/rNN_bench_summary.json from the
-        # same command); it is only used when its bench_args are this run's arguments
-        import glob
-        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_summary.json")))
-        prof = cands[-1] if cands else None
-    if prof and os.path.exists(prof):
-        pj = json.load(open(prof))
-        mine, skip = [], False
-        for x in sys.argv[1:]:       # arguments that do not change the launches: baseline / stress switches, the step counts
-            if skip:
-                skip = False
-            elif x in ("--steps", "--warmup", "--gpus"):
-                skip = True
-            elif not (x in ("--no-cpu-baseline", "--no-reraycast") or x.startswith(("--steps=", "--warmup=", "--gpus="))):
-                mine.append(x)
-        same = pj.get("bench_args", "").split() == mine and world == 1
-        if same and dom in pj.get("traffic_bytes_per_launch", {}):
-            traffic, traffic_src = pj["traffic_bytes_per_launch"][dom], os.path.relpath(os.path.abspath(prof), ROOT)
+    traffic, traffic_src = tracked_traffic(dom, "ecc" if a.registration else "bench", world)
     roof = {"kernel": dom, "bound": "hbm",
             "achieved": dk["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": dk["achieved_GBps"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
@@ -1130,6 +1186,10 @@ def main():
         #  it, pass B and the repair; "projection_build_alone" = the build timed by itself after the timed steps)
         "breakdown_ms": {"projection_build": ray_ms, "frame_loop": frm_ms, "exchange_finals": float(np.mean(t_xchg)),
                          **({"projection_build_alone": ray_alone_ms} if overlap else {})},
+        "breakdown_ms_per_step": {"projection_build": [round(x, 4) for x in t_ray], "frame_loop": [round(x, 4) for x in t_frames],
+                                  "exchange_finals": [round(x, 4) for x in t_xchg],
+                                  # time the HOST spent issuing each phase (no synchronisation inside a step: the GPU runs behind)
+                                  "host_issue": [[round(x, 4) for x in h] for h in host_log]},
         "frame_loop_frames_per_s": F / ((frm_ms_share if overlap else frm_ms) * 1e-3),
         # whole frame loop against HBM: (2 MiB + 4 B x N) per frame + 8 B x N per series launch
         "frame_loop_GBps": (F * (2 * npx + series_esz * series_rows) +

@@ -1,6 +1,6 @@
 """python tests/debug/dbg_ecc_traj.py <seed> <frame>: |M_gpu - M_oracle| of one frame of a soak_ecc.py case after 1, 2, 3, 5, 8
-iterations from the identity (stop test off), through the single-frame entry point.  Run it under UPSP_ECC_KERNEL=2 /
-UPSP_ECC_BLOCKS=n UPSP_ECC_BLOCKS_FIXED=1 to see what the sums' arithmetic does to the trajectory."""
+iterations from the identity (stop test off), through the single-frame entry point.  Run it under UPSP_ECC_DIRECT=1 to
+take the LDS tile out of the general iteration."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

@@ -50,6 +50,14 @@ def test_bench_small_registration_parity(gpu_lib):
     assert d["roofline"]["kernel"] in d["kernels"]
 
 
+def test_bench_multi_camera_line(gpu_lib):
+    """`--cameras 2` (configs[4] shape, reduced): the weighted multi-camera loop produces its line and checks itself."""
+    d = run_bench(["--small", "--cameras", "2", "--size", "512", "--steps", "1", "--warmup", "1"])
+    assert d["config"]["workload"].startswith("configs[4]") and d["n_gpus"] == 1
+    assert d["parity_checked"] is True and all(d["parity"].values()), d["parity"]
+    assert d["roofline"]["bound"] == "hbm" and d["cpu_baseline"]["kind"] == "port"
+
+
 def test_bench_two_ranks_on_one_gpu_gloo(gpu_lib):
     """`--gpus 2` launches its own two ranks; on a one-GPU box both sit on cuda:0 and talk through gloo
     (the RCCL run needs two GPUs: next test).  The exchange runs packed u16 rows in 4 chunks."""

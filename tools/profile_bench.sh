@@ -35,24 +35,28 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             a = acc[kname(r["Kernel_Name"])]; a[0] += 1; a[1] += float(r["Counter_Value"])
     for name, (n, v) in acc.items():
         res.setdefault(name, {})[c + "_KB_per_launch"] = v / n
-# kernel (as rocprof names it) -> name in bench.py's `kernels`; streaming = wide coalesced reads, for which
-# FETCH_SIZE reports half the bytes on gfx950 (MI355X_MICROARCH.md "HBM"); pointer-chasing 64-B reads are
-# taken as reported
-bench_name = {"scan_compact_kernel<true>": ("scan_compact_kernel", True), "scan_compact_kernel<false>": ("scan_compact_kernel", True),
-              "hot_scan_kernel": ("hot_scan_kernel", True), "projection_kernel<false, 0>": ("projection_kernel<primary>", False),
-              "projection_kernel<false, 2>": ("projection_kernel<retry>", False), "witness_kernel": ("witness_kernels", False),
-              "ecc_sums_kernel<false>": ("ecc_sums_kernel", True), "warp_u16_kernel": ("warp_u16_kernel", True)}
-traffic = {}
+# streaming = wide coalesced reads, for which FETCH_SIZE reports half the bytes on gfx950 (MI355X_MICROARCH.md "HBM");
+# pointer-chasing reads of the traversal kernels are taken as reported
+def bench_key(name):
+    """kernel (as rocprof names it) -> (name in bench.py's `kernels`, streaming?)"""
+    for prefix, key, stream in (("scan_compact_kernel", "scan_compact_kernel", True), ("hot_scan_kernel", "hot_scan_kernel", True),
+                                ("projection_kernel<false, 0", "projection_kernel<primary>", False),
+                                ("projection_kernel<false, 2", "projection_kernel<retry>", False), ("witness_kernel", "witness_kernels", False),
+                                ("node_rows_multi_kernel", "node_rows_multi_kernel", True), ("node_rows_kernel", "node_rows_kernel", True),
+                                ("ecc_cols_kernel", "ecc_sums_kernel", True), ("gauss5_quad_kernel", "gauss_pass_kernels", True),
+                                ("gauss_fused_kernel<unsigned short", "gauss_pass_kernels", True), ("warp_compact_kernel", "warp_u16_kernel", False),
+                                ("warp_u16_kernel", "warp_u16_kernel", True), ("gather_tile", "gather_tile_kernel", True)):
+        if name.startswith(prefix): return key, stream
+    return None, False
+traffic, weight = {}, {}
 for name, v in res.items():
-    key, stream = bench_name.get(name, (None, False))
-    if name.startswith("node_rows_kernel"): key, stream = "node_rows_kernel", True
-    if name.startswith("node_rows_multi_kernel"): key, stream = "node_rows_multi_kernel", True
-    if name.startswith("ecc_cols_kernel") or name.startswith("ecc_sums2_kernel"): key, stream = "ecc_sums_kernel", True
-    if name.startswith("gauss_fused_kernel<unsigned short"): key, stream = "gauss_pass_kernels", True
-    if name.startswith("warp_compact_kernel"): key, stream = "warp_u16_kernel", False
-    if name.startswith("gather_tile"): key, stream = "gather_tile_kernel", True
+    key, stream = bench_key(name)
     if key and "FETCH_SIZE_KB_per_launch" in v and "WRITE_SIZE_KB_per_launch" in v:
-        traffic[key] = ((2 if stream else 1) * v["FETCH_SIZE_KB_per_launch"] + v["WRITE_SIZE_KB_per_launch"]) * 1024
+        # several kernels under one bench name (the identity and the general ECC sums launches): call-weighted mean per launch
+        b = ((2 if stream else 1) * v["FETCH_SIZE_KB_per_launch"] + v["WRITE_SIZE_KB_per_launch"]) * 1024
+        n = v.get("calls", 1)
+        traffic[key] = (traffic.get(key, 0.0) * weight.get(key, 0) + b * n) / (weight.get(key, 0) + n)
+        weight[key] = weight.get(key, 0) + n
 summary = {"bench_args": " ".join(args), "kernels": res, "traffic_bytes_per_launch": traffic,
            "note": "rocprofv3 --kernel-trace --stats (durations) and two separate --pmc passes (FETCH_SIZE, WRITE_SIZE, unit KB); "
                    "traffic = FETCH x 2 for the streaming kernels (gfx950 reports half of wide coalesced reads) + WRITE"}
@@ -65,5 +69,5 @@ UPSP_BENCH_TRAFFIC_JSON=$out/summary.json timeout -k 10 ${BENCH_TIMEOUT:-500} py
 python3 - $out <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1] + "/bench_line.json").read().strip().splitlines()[-1])
-print({k: d.get(k) for k in ("value", "ms_per_step", "mrays_per_s", "breakdown_ms")}); print(d["roofline"]); print(d.get("cpu_baseline")); print(d.get("parity"))
+print({k: d.get(k) for k in ("value", "ms_per_step", "mrays_per_s", "breakdown_ms", "summary")}); print(d["roofline"]); print(d.get("cpu_baseline")); print(d.get("parity"))
 PY
