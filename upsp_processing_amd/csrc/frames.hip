@@ -1237,13 +1237,11 @@ __global__ void __launch_bounds__(256)
 // pixels), nch[f] = how many it filled -- no cap, no order that depends on the atomics.
 // *ntotal (zero on entry) counts the changes of the call: the list kernels below return at once when
 // it stays zero (nearly every call).
-__global__ void __launch_bounds__(64)
-    hot_repair_kernel(uint16_t *frames, size_t npix, int nframes, int rows, int cols, int min_change,
-                      int max_hot, unsigned *__restrict__ count, const unsigned *__restrict__ pos,
-                      unsigned *__restrict__ ntotal, unsigned *__restrict__ nch, uint4 *__restrict__ changes)
+__device__ __forceinline__ void
+    hot_repair_frame(size_t f, uint16_t *frames, size_t npix, int rows, int cols, int min_change,
+                     int max_hot, unsigned *__restrict__ count, const unsigned *__restrict__ pos,
+                     unsigned *__restrict__ ntotal, unsigned *__restrict__ nch, uint4 *__restrict__ changes)
 {
-    const size_t f = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= (size_t)nframes) return;
     const unsigned n = count[f];
     nch[f] = 0u;
     if (n == 0u) return;
@@ -1267,6 +1265,15 @@ __global__ void __launch_bounds__(64)
     }
     nch[f] = m;
     if (m) atomicAdd(ntotal, m);
+}
+__global__ void __launch_bounds__(64)
+    hot_repair_kernel(uint16_t *frames, size_t npix, int nframes, int rows, int cols, int min_change,
+                      int max_hot, unsigned *__restrict__ count, const unsigned *__restrict__ pos,
+                      unsigned *__restrict__ ntotal, unsigned *__restrict__ nch, uint4 *__restrict__ changes)
+{
+    const size_t f = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= (size_t)nframes) return;
+    hot_repair_frame(f, frames, npix, rows, cols, min_change, max_hot, count, pos, ntotal, nch, changes);
 }
 
 // Pixel -> nodes lists for the re-projection (built only in calls that replaced a pixel): head[p] =
@@ -1350,24 +1357,78 @@ __global__ void __launch_bounds__(256)
 // repaired.  Accumulators: sums of doubles in another order than the gather's (parity bar 1e-12).
 struct HotMultiArgs {
     int ncams;
-    const uint16_t *frames[kMaxCams];
+    uint16_t *frames[kMaxCams];
     const int32_t *pix[kMaxCams];
     const float *weight[kMaxCams];
 };
+// All cameras in one launch each (blockIdx.y = camera): camera c owns `words` words of d_changes (layout of
+// hot_changes_words()), counters / positions at c * nframes, lists at c * npix (head) and c * nnodes (next).
+__device__ __forceinline__ unsigned *hot_cam_changes(unsigned *d_changes, size_t words, int c) { return d_changes + (size_t)c * words; }
+__device__ __forceinline__ uint4 *hot_cam_list(unsigned *chg, int nframes)
+{
+    return reinterpret_cast<uint4 *>(chg + 4 + (((size_t)nframes + 3) & ~(size_t)3));
+}
+__global__ void hot_reset_cams_kernel(unsigned *d_changes, size_t words, int ncams)
+{
+    if ((int)threadIdx.x < ncams) d_changes[(size_t)threadIdx.x * words] = 0u;
+}
+__global__ void __launch_bounds__(64)
+    hot_repair_cams_kernel(HotMultiArgs a, size_t npix, int nframes, int rows, int cols, int min_change, int max_hot,
+                           unsigned *__restrict__ count, const unsigned *__restrict__ pos, unsigned *d_changes, size_t words)
+{
+    const size_t f = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = (int)blockIdx.y;
+    if (f >= (size_t)nframes) return;
+    unsigned *chg = hot_cam_changes(d_changes, words, c);
+    hot_repair_frame(f, a.frames[c], npix, rows, cols, min_change, max_hot, count + (size_t)c * nframes,
+                     pos + (size_t)c * nframes * kHotCap, chg, chg + 4, hot_cam_list(chg, nframes));
+}
+// Lists only for the pixels that changed: head[] is kHotUnmarked everywhere between two fix-ups; the changed pixels
+// are marked (-1 = empty list), the build threads only the nodes on marked pixels (a few hundred atomics instead of
+// one per visible node), and after the patch the marks are taken back.
+constexpr int32_t kHotUnmarked = -2;
 __global__ void __launch_bounds__(256)
-    hot_patch_multi_kernel(HotMultiArgs a, size_t npix, const unsigned *__restrict__ ntotal,
-                           const unsigned *__restrict__ nch, const uint4 *__restrict__ changes, int nframes,
+    hot_mark_cams_kernel(unsigned *d_changes, size_t words, int nframes, int max_hot, int32_t *__restrict__ head,
+                         size_t npix, int32_t value)
+{
+    const int c = (int)blockIdx.y;
+    unsigned *chg = hot_cam_changes(d_changes, words, c);
+    if (chg[0] == 0u) return;                  // (uniform per camera)
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (unsigned)nframes * (unsigned)max_hot) return;
+    const unsigned f = i / (unsigned)max_hot;
+    if (i - f * (unsigned)max_hot >= chg[4 + f]) return;
+    head[(size_t)c * npix + hot_cam_list(chg, nframes)[i].y] = value;
+}
+__global__ void __launch_bounds__(256)
+    hot_lists_build_cams_kernel(HotMultiArgs a, unsigned *d_changes, size_t words, unsigned nnodes, size_t npix,
+                                int32_t *__restrict__ head, int32_t *__restrict__ next)
+{
+    const int c = (int)blockIdx.y;
+    if (hot_cam_changes(d_changes, words, c)[0] == 0u) return;     // (uniform per camera)
+    const unsigned n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= nnodes) return;
+    const int32_t p = a.pix[c][n];
+    if (p < 0) return;
+    int32_t *h = head + (size_t)c * npix + p;
+    // (a marked entry only ever moves between values >= -1: the plain read cannot mistake it for unmarked)
+    if (*h != kHotUnmarked) next[(size_t)c * nnodes + n] = atomicExch(h, (int32_t)n);
+}
+__global__ void __launch_bounds__(256)
+    hot_patch_multi_kernel(HotMultiArgs a, size_t npix, unsigned nnodes, unsigned *d_changes, size_t words, int nframes,
                            int max_hot, const int32_t *__restrict__ head, const int32_t *__restrict__ next,
                            const uint8_t *__restrict__ skipped, float *__restrict__ rows_t, long long ld_t,
                            double *__restrict__ sum, double *__restrict__ sumsq)
 {
-    if (*ntotal == 0u) return;                 // (uniform) nearly every call
+    const int cc = (int)blockIdx.y;
+    unsigned *chg = hot_cam_changes(d_changes, words, cc);
+    if (chg[0] == 0u) return;                  // (uniform per camera) nearly every call
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (unsigned)nframes * (unsigned)max_hot) return;
     const unsigned f = i / (unsigned)max_hot;
-    if (i - f * (unsigned)max_hot >= nch[f]) return;
-    const uint4 ch = changes[i];
-    for (int32_t n = head[ch.y]; n >= 0; n = next[n]) {
+    if (i - f * (unsigned)max_hot >= chg[4 + f]) return;
+    const uint4 ch = hot_cam_list(chg, nframes)[i];
+    for (int32_t n = head[(size_t)cc * npix + ch.y]; n >= 0; n = next[(size_t)cc * nnodes + n]) {
         if (skipped && skipped[n]) continue;                  // stays NaN
         float sol = 0.0f;
         for (int c = 0; c < a.ncams; ++c) {
@@ -1384,6 +1445,11 @@ __global__ void __launch_bounds__(256)
             unsafeAtomicAdd(&sumsq[n], (double)(sol * sol) - (double)(old * old));
         }
     }
+}
+__global__ void __launch_bounds__(256) hot_fill_i32_kernel(int32_t *p, size_t n, int32_t v)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
 }
 
 __global__ void hot_patch_reset_kernel(unsigned *ntotal) { *ntotal = 0u; }
@@ -1821,14 +1887,18 @@ int launch_hot_repair_list(uint16_t *d_frames, size_t npix, int nframes, int row
     return UPSP_OK;
 }
 
+// `head_clean`: d_head (ncams * npix entries) holds kHotUnmarked everywhere (true after a previous call of this
+// function; false after an allocation or when another path used the array): refilled here when false.
 int launch_hot_fixup_multi(const PipelineGather &g, uint16_t *const *d_frames, int nframes, int rows, int cols,
                            int min_change, int max_hot, unsigned *d_count, const unsigned *d_pos,
-                           unsigned *d_changes, int32_t *d_head, int32_t *d_next, hipStream_t st)
+                           unsigned *d_changes, int32_t *d_head, int32_t *d_next, bool head_clean, hipStream_t st)
 {
     if (nframes <= 0) return UPSP_OK;
     if (g.rowmap || !g.rows_t) return fail(UPSP_ERR_INVALID, "multi-camera hot-pixel fix-up needs f32 rows without a row map");
+    if (max_hot < 0 || max_hot >= kHotCap) return fail(UPSP_ERR_INVALID, "max_hot must be in [0,63]");
     KTimed kt("hot_fixup_kernels", st);
     const size_t words = hot_changes_words(nframes, max_hot);
+    const unsigned C = (unsigned)g.ncams;
     HotMultiArgs a;
     std::memset(&a, 0, sizeof(a));
     a.ncams = g.ncams;
@@ -1837,28 +1907,26 @@ int launch_hot_fixup_multi(const PipelineGather &g, uint16_t *const *d_frames, i
         a.pix[c] = g.pix[c];
         a.weight[c] = g.weight[c];
     }
-    for (int c = 0; c < g.ncams; ++c) {       // every camera's frames are repaired before anything is re-projected
-        unsigned *chg = d_changes + (size_t)c * words;
-        uint4 *list = reinterpret_cast<uint4 *>(chg + 4 + (((size_t)nframes + 3) & ~(size_t)3));
-        hipLaunchKernelGGL(hot_patch_reset_kernel, dim3(1), dim3(1), 0, st, chg);
-        hipLaunchKernelGGL(hot_repair_kernel, dim3((unsigned)((nframes + 63) / 64)), dim3(64), 0, st, d_frames[c], g.npix,
-                           nframes, rows, cols, min_change, max_hot, d_count + (size_t)c * nframes,
-                           d_pos + (size_t)c * nframes * kHotCap, chg, chg + 4, list);
+    if (!head_clean && max_hot > 0) {
+        const size_t n = (size_t)g.npix * C;
+        hipLaunchKernelGGL(hot_fill_i32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_head, n, kHotUnmarked);
     }
-    if (max_hot > 0)
-        for (int c = 0; c < g.ncams; ++c) {
-            unsigned *chg = d_changes + (size_t)c * words;
-            uint4 *list = reinterpret_cast<uint4 *>(chg + 4 + (((size_t)nframes + 3) & ~(size_t)3));
-            int32_t *head = d_head + (size_t)c * g.npix, *next = d_next + (size_t)c * g.nnodes;
-            hipLaunchKernelGGL(hot_lists_init_kernel, dim3((unsigned)((g.npix + 255) / 256)), dim3(256), 0, st,
-                               (const unsigned *)chg, head, g.npix);
-            hipLaunchKernelGGL(hot_lists_build_kernel, dim3((unsigned)((g.nnodes + 255) / 256)), dim3(256), 0, st,
-                               (const unsigned *)chg, g.pix[c], (unsigned)g.nnodes, head, next);
-            hipLaunchKernelGGL(hot_patch_multi_kernel, dim3((unsigned)(((size_t)nframes * max_hot + 255) / 256)), dim3(256),
-                               0, st, a, g.npix, (const unsigned *)chg, (const unsigned *)(chg + 4), (const uint4 *)list,
-                               nframes, max_hot, (const int32_t *)head, (const int32_t *)next, g.skipped, g.rows_t,
-                               (long long)g.ld_t, g.sum, g.sumsq);
-        }
+    // every camera's frames are repaired (one launch) before anything is re-projected
+    hipLaunchKernelGGL(hot_reset_cams_kernel, dim3(1), dim3(64), 0, st, d_changes, words, g.ncams);
+    hipLaunchKernelGGL(hot_repair_cams_kernel, dim3((unsigned)((nframes + 63) / 64), C), dim3(64), 0, st, a, g.npix, nframes,
+                       rows, cols, min_change, max_hot, d_count, d_pos, d_changes, words);
+    if (max_hot > 0) {
+        const dim3 slots((unsigned)(((size_t)nframes * max_hot + 255) / 256), C);
+        hipLaunchKernelGGL(hot_mark_cams_kernel, slots, dim3(256), 0, st, d_changes, words, nframes, max_hot, d_head, g.npix,
+                           (int32_t)-1);
+        hipLaunchKernelGGL(hot_lists_build_cams_kernel, dim3((unsigned)((g.nnodes + 255) / 256), C), dim3(256), 0, st, a,
+                           d_changes, words, (unsigned)g.nnodes, g.npix, d_head, d_next);
+        hipLaunchKernelGGL(hot_patch_multi_kernel, slots, dim3(256), 0, st, a, g.npix, (unsigned)g.nnodes, d_changes, words,
+                           nframes, max_hot, (const int32_t *)d_head, (const int32_t *)d_next, g.skipped, g.rows_t,
+                           (long long)g.ld_t, g.sum, g.sumsq);
+        hipLaunchKernelGGL(hot_mark_cams_kernel, slots, dim3(256), 0, st, d_changes, words, nframes, max_hot, d_head, g.npix,
+                           kHotUnmarked);
+    }
     UPSP_HIP_CHECK(hipGetLastError());
     return UPSP_OK;
 }

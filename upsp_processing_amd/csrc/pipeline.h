@@ -64,7 +64,7 @@ int launch_hot_repair_list(uint16_t *d_frames, size_t npix, int nframes, int row
 constexpr int kHotPositions = 64;   // hot-pixel positions recorded per frame (d_pos: kHotPositions words per frame)
 int launch_hot_fixup_multi(const PipelineGather &g, uint16_t *const *d_frames, int nframes, int rows, int cols,
                            int min_change, int max_hot, unsigned *d_count, const unsigned *d_pos,
-                           unsigned *d_changes, int32_t *d_head, int32_t *d_next, hipStream_t st);
+                           unsigned *d_changes, int32_t *d_head, int32_t *d_next, bool head_clean, hipStream_t st);
 int launch_skipped(int ncams, size_t nnodes, const int32_t *const *d_pix, uint8_t *d_skipped,
                    hipStream_t st);
 int launch_finals(const double *sum, const double *sumsq, size_t nnodes, uint64_t nframes,

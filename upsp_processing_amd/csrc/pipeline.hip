@@ -47,6 +47,7 @@ struct upsp_pipeline {
     unsigned *d_changes = nullptr;   // hot-pixel change list of a call (frames.hip: hot_changes_words)
     size_t changes_words = 0;
     int32_t *d_head = nullptr, *d_next = nullptr;   // pixel -> nodes lists of the hot-pixel re-projection
+    bool head_clean = false;        // d_head holds 'unmarked' everywhere (multi-camera fix-up leaves it so)
     size_t head_elems = 0, next_elems = 0;
     bool tilemap_valid = false;
     // candidate map (upsp_pipeline_set_active_hint): the map outlives projection changes, only node_k is redone
@@ -493,6 +494,7 @@ static int streamed_buffers(upsp_pipeline *p, size_t npix, int nframes, hipStrea
             p->d_head = nullptr;
             UPSP_HIP_CHECK(hipMalloc(&p->d_head, sizeof(int32_t) * npix));
             p->head_elems = npix;
+            p->head_clean = false;
         }
         if (p->next_elems < p->nnodes) {
             if (p->d_next) UPSP_HIP_CHECK(hipStreamSynchronize(st));
@@ -743,6 +745,7 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
             g.rows_t16 = d_rows_t16 ? d_rows_t16 + col0 : nullptr;
             rc = launch_hot_fixup(g, fr, nframes, p->height, p->width, p->opts.hot_min_change, p->opts.hot_max,
                                   p->d_hot_count, p->d_hot_pos, p->d_changes, p->d_head, p->d_next, st);
+            p->head_clean = false;    // (this path initialises the lists for every pixel)
         }
         return rc;
     }
@@ -927,6 +930,7 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
                 p->d_head = nullptr;
                 UPSP_HIP_CHECK(hipMalloc(&p->d_head, sizeof(int32_t) * npix * p->ncams));
                 p->head_elems = npix * p->ncams;
+                p->head_clean = false;
             }
             if (p->next_elems < p->nnodes * p->ncams) {
                 if (p->d_next) UPSP_HIP_CHECK(hipStreamSynchronize(st));
@@ -969,7 +973,8 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
         if (rc == UPSP_OK && hot_fused) {
             g.rows_t = d_rows_t + col0;
             rc = launch_hot_fixup_multi(g, d_frames, nframes, p->height, p->width, p->opts.hot_min_change, p->opts.hot_max,
-                                        p->d_hot_count, p->d_hot_pos, p->d_changes, p->d_head, p->d_next, st);
+                                        p->d_hot_count, p->d_hot_pos, p->d_changes, p->d_head, p->d_next, p->head_clean, st);
+            p->head_clean = rc == UPSP_OK;
         }
         return rc;
     }
