@@ -94,13 +94,18 @@ def parse():
                     help="(the default since round 3; accepted for old command lines) pass A of the frame loop (hot-pixel count "
                          "+ compact pixel series, from the candidate pixels of the in-frame nodes) on a second stream while the "
                          "rays of the projection build are cast")
-    ap.add_argument("--chunks", type=int, default=4,
-                    help="N > 1 loop: chunks the rank's frames are exchanged in (the exchange of chunk k runs while chunk k + 1 is scanned)")
+    ap.add_argument("--chunks", type=int, default=0,
+                    help="N > 1 loop: chunks the rank's frames are exchanged in (the exchange of chunk k runs while chunk k + 1 is scanned); "
+                         "0 = 4, or 1 when pass A runs once beside the build (deferred exchange)")
     ap.add_argument("--config3-share", action="store_true",
                     help="one rank's share of BASELINE configs[3] (100 000 frames on 8 GPUs) as ONE step: 12 500 resident frames through "
                          "the N > 1 loop (implies --force-chunked on one GPU; as many exchange chunks as keep each within one pass A, "
                          "i.e. <= 1024 frames) -- the run's chunks overlap each other, only the last one and pass B are exposed once "
                          "per 12 500 frames, not once per 1000 as in the default N > 1 step")
+    ap.add_argument("--chunk-scan", action="store_true",
+                    help="N > 1 loop: pass A per chunk after the projection build (default when the exchange is finished inside the step)")
+    ap.add_argument("--scan-once", action="store_true",
+                    help="N > 1 loop: pass A once for all frames of the rank beside the projection build (default with the deferred exchange)")
     ap.add_argument("--defer-exchange", action="store_true",
                     help="--force-chunked on one GPU: the two-exchanges-in-turn schedule of the N > 1 runs (see --sync-exchange)")
     ap.add_argument("--sync-exchange", action="store_true",
@@ -873,25 +878,31 @@ def main():
 
     # N > 1: the frame loop runs in K chunks and the all-to-all of chunk k is issued
     # asynchronously while chunk k+1 is being processed (distributed.TimeSeriesExchange)
-    K = max(1, a.chunks) if chunked else 1
-    if chunked and (a.config3_share or F > 1024 * K):
-        # every chunk within one pass A group (<= 1024 frames; the cuts sit on 64-frame boundaries)
-        K = D.chunk_count(shard.frame_count, 1024)
-    exch = D.TimeSeriesExchange(shard, K, wire12=a.wire12) if chunked else None
     # one camera, no weights, no filter: the series values are exact 16-bit integers, so the
     # travelling rows are produced and sent as u16 (half the bytes) and widened by the receiver
     u16_wire = chunked and not a.f32_wire
     pixel_wire = chunked and not a.row_wire and not a.f32_wire
-    chunk_bufs = ([torch.empty((N, exch.my_chunk(k)[1]), dtype=torch.uint16 if u16_wire else torch.float32,
-                               device="cuda") for k in range(K)] if chunked else None)
-    ev_log = []
-    first_step = [True]
     # Pixel-series wire: TWO exchanges used in turn.  A rank's run is many steps long (configs[3]: 12 500 frames per rank), and
     # what a step leaves behind -- its last chunk still on the links, the owner's pass B -- does not have to be waited for
     # before the next step's frames are scanned: step k's exchange is finished after step k + 1's chunks have been submitted.
     # (between GPUs only, or on request: on ONE GPU nothing waits for a link, and the later pass B finds its compact series
     #  pushed out of the Infinity Cache by the next step's frames -- 1.56 against 1.45 ms per step, measured)
     deferred = chunked and pixel_wire and not a.sync_exchange and (world > 1 or a.defer_exchange)
+    # ... and with the exchange deferred nothing is gained by cutting a step's frames into chunks (the sends overlap the NEXT
+    # step anyway): pass A runs ONCE for all frames of the rank, on the candidate-pixel map, beside the projection build -- the
+    # arrangement of the one-GPU loop -- and one block per peer goes out (--chunk-scan: pass A per chunk after the build, the
+    # schedule of rounds 3 / early 4, still the better one when the exchange is finished inside the step: 1.52 against 1.70 ms)
+    px_once = (chunked and pixel_wire and not a.chunk_scan and (deferred or a.scan_once) and not a.config3_share and
+               F <= min(1024, pipe.series_frames_max()))
+    K = max(1, a.chunks if a.chunks > 0 else (1 if px_once else 4)) if chunked else 1
+    if chunked and (a.config3_share or F > 1024 * K):
+        # every chunk within one pass A group (<= 1024 frames; the cuts sit on 64-frame boundaries)
+        K = D.chunk_count(shard.frame_count, 1024)
+    exch = D.TimeSeriesExchange(shard, K, wire12=a.wire12) if chunked else None
+    chunk_bufs = ([torch.empty((N, exch.my_chunk(k)[1]), dtype=torch.uint16 if u16_wire else torch.float32,
+                               device="cuda") for k in range(K)] if chunked else None)
+    ev_log = []
+    first_step = [True]
     exchs = [exch, D.TimeSeriesExchange(shard, K, wire12=a.wire12)] if deferred else [exch]
     ex_state = {"step": 0, "pending": None, "first": [True, True], "last_done": exch}
 
@@ -906,14 +917,15 @@ def main():
     # Pass A reads the frames and needs only the CANDIDATE pixels (known after step 1 of create_projection_mat), the ray casting
     # is a latency-bound chain of dependent fetches: side by side they take 0.59-0.63 ms where one after the other they take
     # 0.29 + 0.35-0.39 (tools/gpu_overlap_ab.sh, three alternations in one call: step 1.10-1.13 against 1.16-1.18 ms)
-    overlap = not a.serial and not a.registration and streamed and not chunked and F <= 1024
+    overlap = not a.serial and not a.registration and streamed and F <= 1024 and (not chunked or px_once)
     # The BUILD goes to the side stream, issued first and with high priority; pass A follows on the main stream: the traversal
     # kernels are chains of dependent fetches that need few wave slots but need them early, pass A fills whatever is left
     # (tools/gpu_prio_ab.sh, step in ms: pass A on the side stream 1.151 / 1.172, the build on the side stream 1.124, the build
     # on a high-priority side stream 1.107 / 1.131, pass A on a high-priority side stream 1.208).  UPSP_BENCH_BUILD_ON_SIDE=0 /
     # UPSP_BENCH_SIDE_PRIORITY=0: the other arrangements.
     swap = overlap and os.environ.get("UPSP_BENCH_BUILD_ON_SIDE", "1") == "1"
-    side = torch.cuda.Stream(priority=int(os.environ.get("UPSP_BENCH_SIDE_PRIORITY", "-1" if swap else "0"))) if overlap else None
+    # (beside RCCL's kernels a high-priority build stream is the slower arrangement: N > 1 loop 1.85 against 1.54 ms per step)
+    side = torch.cuda.Stream(priority=int(os.environ.get("UPSP_BENCH_SIDE_PRIORITY", "-1" if swap and not chunked else "0"))) if overlap else None
 
     def step(record):
         e = [ev() for _ in range(4)]
@@ -957,13 +969,19 @@ def main():
             ex = exchs[which]
             ex_state["step"] += 1
             ex.k = 0
-            tab = pipe.pixel_series(None)           # node -> compact row of this projection
+            if px_once and overlap:
+                # pass A ran beside the build (prescan on the candidate map): rows of the nodes in that buffer + hot-pixel repair
+                tab = pipe.pixel_series(frames)
+            else:
+                tab = pipe.pixel_series(None)       # node -> compact row of this projection
             ex.set_pixels(tab["node_k"], engine.skipped_nodes(proj["pix"], want_count=False)[0], assume_same=not ex_state["first"][which])
             ex_state["first"][which] = False
             for k in range(K):
                 c0, fc = ex.my_chunk(k)
-                ps = pipe.pixel_series(frames[c0:c0 + fc]) if fc else tab
-                ex.submit_pixels(ps)
+                if px_once and overlap:
+                    ex.submit_pixels(tab, col0=c0)
+                else:
+                    ex.submit_pixels(pipe.pixel_series(frames[c0:c0 + fc]) if fc else tab)
             if deferred:
                 drain()                             # the PREVIOUS step's series and sums, now that this step's chunks are on their way
                 ex_state["pending"] = ex
@@ -1171,7 +1189,10 @@ def main():
                    "parallelism": "frames sharded x%d" % world, "schedule": sched,
                    **({"exchange": "%d chunks, %s as %s%s" % (K, "active-pixel series" if pixel_wire else "visible rows",
                                                               ("u16 packed to 12 bit" if a.wire12 else "u16") if u16_wire else "f32",
-                                                              "; two exchanges in turn, a step's series finished behind the next step's chunks" if deferred else "")}
+                                                              ("; two exchanges in turn, a step's series finished behind the next step's chunks" if deferred else "") +
+                                                              ("" if not pixel_wire else
+                                                               "; pass A once for the rank's frames beside the projection build" if px_once and overlap else
+                                                               "; pass A per chunk after the projection build"))}
                       if chunked else {})},
         # rays the REFERENCE casts for this camera / the time of a build that casts a tenth of them (the oblique test first, the
         # occluder witness): an equivalence, not a ray rate -- "mrays_per_s" below is the ray caster's own rate

@@ -126,7 +126,9 @@ static const int64_t A = 211;
 static int32_t node_pixel(int64_t n) { return n % 9 == 4 ? -1 : (int32_t)((7 * n) % A); }
 static unsigned px(int64_t k, int64_t f) { return (unsigned)((13 * k + 5 * f) % 4096); }
 
-static int run_pixels(int W)
+// F, K: frames of the run and chunks per rank.  (240, 1): every rank's share is a multiple of four frames and goes out as ONE
+// block per peer -- the owner's pass B then reads the received blocks as they lie (no placing pass); (517, 3): ragged, placed.
+static int run_pixels(int W, const int64_t F, const int K)
 {
     int bad = 0;
     std::vector<uint8_t> sk(N);
@@ -232,7 +234,10 @@ int main(int argc, char **argv)
     HIPCHECK(hipMalloc(&d_sk, N));
     HIPCHECK(hipMemcpy(d_sk, sk.data(), N, hipMemcpyHostToDevice));
     int bad = 0;
-    if (mode == "pixels") return run_pixels(argc > 2 ? std::atoi(argv[2]) : 2) ? 1 : 0;
+    if (mode == "pixels") {
+        const int W = argc > 2 ? std::atoi(argv[2]) : 2;
+        return (run_pixels(W, 517, 3) + run_pixels(W, 240, 1)) ? 1 : 0;
+    }
     if (mode == "local") {
         const int W = argc > 2 ? std::atoi(argv[2]) : 2;
         for (int wire : {4, 2, 12}) {

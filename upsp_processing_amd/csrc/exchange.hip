@@ -900,6 +900,27 @@ int upsp_exchange_finish_pixels(upsp_exchange *x, float *d_series, int64_t ld, d
     const int64_t rows_in = x->cut[me + 1] - x->cut[me];
     int rc = receive_core(x, st);
     if (rc != UPSP_OK) return rc;
+    // One chunk per rank, u16 on the wire, every block's frame count a multiple of four: what arrived from source s IS a
+    // [pixel row][frames of s] series buffer pass B can read as it lies (8-byte loads of four frames; row pitch = the block's
+    // frame count), so the owner's pass B runs once per source block into that block's columns -- no copy into one long
+    // series buffer first.  (With several chunks per rank the pieces would be short row segments: placed, below.)
+    bool direct = x->wire == 2 && x->K == 1 && rows_in > 0;
+    for (int s = 0; s < W && direct; ++s) direct = (x->chunk_count[s][0] % 4) == 0;
+    if (direct) {
+        if (x->node_count[me] > 0)
+            for (int s = 0; s < W; ++s) {
+                const int64_t fs = x->chunk_count[s][0];
+                if (!fs) continue;
+                rc = upsp_rows_from_pixel_series(static_cast<const uint16_t *>(x->stage[0][s]), (uint32_t)fs, x->d_node_local,
+                                                 x->d_skipped_me, (size_t)x->node_count[me], fs, d_series + x->frame_start[s], ld,
+                                                 d_sum_mine, d_sumsq_mine, stream);
+                if (rc != UPSP_OK) return rc;
+            }
+        x->k = 0;
+        x->last_sent = x->bytes_sent;
+        x->last_received = x->bytes_received;
+        return UPSP_OK;
+    }
     {
         KTimed kt("exchange_place_kernels", st);
         for (int k = 0; k < x->K; ++k)

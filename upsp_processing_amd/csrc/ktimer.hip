@@ -30,6 +30,12 @@ std::map<std::string, Entry> g_entries;
 std::vector<std::string> g_order;
 std::string g_current;
 hipEvent_t g_start;
+// launch order of the spans (UPSP_TRACE_TIMELINE: upsp_timing_report prints where every span sat on the device's time line)
+struct Seq {
+    std::string name;
+    Span span;
+};
+std::vector<Seq> g_seq;
 }  // namespace
 
 // roctx ranges (rocprofv3 --marker-trace shows them as a time line of phases): libroctx64 is looked up at first use,
@@ -92,6 +98,7 @@ void ktimer_end(hipStream_t st)
     (void)hipEventRecord(e, st);
     if (!g_entries.count(g_current)) g_order.push_back(g_current);
     g_entries[g_current].spans.push_back({g_start, e});
+    g_seq.push_back({g_current, {g_start, e}});
     if (roctx_wanted() && roctx().pop) roctx().pop();
 }
 }  // namespace upsp
@@ -112,6 +119,7 @@ int upsp_timing_enable(int on)
         }
     g_entries.clear();
     g_order.clear();
+    g_seq.clear();
     return UPSP_OK;
 }
 
@@ -171,6 +179,16 @@ int upsp_timing_report(char *buf, size_t cap)
         std::snprintf(line, sizeof(line), "%s %d %.6f %.6f %.6f %.6f\n", name.c_str(), n, total,
                       n ? each.front() : 0.f, n ? each[n / 2] : 0.f, n ? each.back() : 0.f);
         out += line;
+    }
+    if (std::getenv("UPSP_TRACE_TIMELINE") && !g_seq.empty()) {
+        // start and duration of every span relative to the first one: what an unprofiled run's device time line looked like
+        for (const auto &q : g_seq) {
+            float t0 = 0, dt = 0;
+            if (hipEventSynchronize(q.span.b) != hipSuccess) continue;
+            if (hipEventElapsedTime(&t0, g_seq.front().span.a, q.span.a) != hipSuccess) continue;
+            if (hipEventElapsedTime(&dt, q.span.a, q.span.b) != hipSuccess) continue;
+            std::fprintf(stderr, "timeline %10.1f us  +%8.1f us  %s\n", t0 * 1e3, dt * 1e3, q.name.c_str());
+        }
     }
     if (out.size() + 1 > cap) return fail(UPSP_ERR_INVALID, "timing report buffer too small");
     std::memcpy(buf, out.c_str(), out.size() + 1);

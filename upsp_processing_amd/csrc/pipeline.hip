@@ -579,10 +579,15 @@ int upsp_pipeline_pixel_series(upsp_pipeline *p, uint16_t *d_frames, int nframes
     if (!p->has_proj[0]) return fail(UPSP_ERR_INVALID, "pixel series: projection not set");
     hipStream_t st = (hipStream_t)stream;
     int rc = UPSP_OK;
-    if (p->hint_active) {
-        // a candidate-pixel map (upsp_pipeline_set_active_hint) is a superset chosen by the caller: its series would carry
-        // pixels no node reads, and a node whose pixel lies outside it (node_k == -2) would have no series at all on the
-        // owner of its row.  What is exchanged follows from the projection alone.
+    // Pass A of exactly these frames may already have run on a candidate-pixel map (upsp_pipeline_set_active_hint +
+    // upsp_pipeline_prescan, e.g. beside the projection build; the caller orders the streams): then the map stays, the nodes
+    // get their rows in THAT buffer, and only the hot-pixel repair is left.  The candidate set must hold every pixel a node
+    // reads: a node outside it gets node_k == -2, which upsp_exchange_set_pixels refuses (its owner would have no series).
+    const bool prescanned = p->hint_active && p->tilemap_valid && nframes > 0 && p->prescan_frames == d_frames &&
+                            p->prescan_n == nframes && p->prescan_gen == p->map_gen;
+    if (p->hint_active && !prescanned) {
+        // otherwise what is exchanged follows from the projection alone: a candidate map is a superset chosen by the caller,
+        // its series would carry pixels no node reads
         p->hint_active = false;
         invalidate_map(p);
         p->node_k_valid = false;
@@ -604,7 +609,7 @@ int upsp_pipeline_pixel_series(upsp_pipeline *p, uint16_t *d_frames, int nframes
     if (rc != UPSP_OK) return rc;
     if (nframes > S) return fail(UPSP_ERR_INVALID, "pixel series: more frames than one pass A group holds (<= 1024 per call)");
     p->prescan_frames = nullptr;
-    if (nframes > 0) rc = streamed_pass_a(p, d_frames, npix, 0, nframes, cp, st);
+    if (nframes > 0 && !prescanned) rc = streamed_pass_a(p, d_frames, npix, 0, nframes, cp, st);
     if (rc != UPSP_OK) return rc;
     if (p->opts.hot_enable && nframes > 0)
         rc = launch_hot_repair_compact(d_frames, npix, nframes, p->height, p->width, p->opts.hot_min_change, p->opts.hot_max,
