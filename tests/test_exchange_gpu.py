@@ -47,7 +47,9 @@ def test_exchange_pixel_series_local_ranks(exe, world):
     r = subprocess.run([exe, "pixels", str(world)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = r.stdout.strip().splitlines()
-    assert len(lines) == 2 and all(" ok," in l for l in lines), r.stdout
+    # (two shapes x two wires: 517 frames in 3 ragged chunks -- placed --, and 240 frames as one block per peer, which the
+    #  owner's pass B reads where it arrived)
+    assert len(lines) == 4 and all(" ok," in l for l in lines), r.stdout
     rows = int(lines[0].split(", ")[2].split()[0])
     assert rows <= 211 * world and rows < 803            # <= A pixels per destination, fewer than the travelling nodes
 
