@@ -165,6 +165,31 @@ class quiet_gc:
         return False
 
 
+def hot_pixel_restorer(frames, thresh=4064):
+    """The frame loop repairs hot pixels IN PLACE (like the reference): after the first step no frame would hold one and the
+    repair / re-projection branch would never run inside the timed region.  fix_hot_pixels writes only pixels >= thresh
+    (cv_extras.cpp:249-274), so putting THOSE pixels back before every step -- a scatter of a few dozen values, inside the timed
+    region -- makes every step see the frames as they arrived.  (Until round 4 the whole frames were copied back: 10 x 2 MiB
+    through an index_put kernel, 33 us of a 1-ms step that belonged to the bench, not to the path.)  Returns restore()."""
+    import torch
+    F = frames.shape[0]
+    f16 = frames.view(torch.int16)
+    npx = f16[0].numel()
+    pos, val = [], []
+    for f0 in range(0, F, 500):                     # (in pieces: a 12 500-frame share is 13 G pixels)
+        sub = f16[f0:f0 + 500].reshape(min(500, F - f0), -1)
+        fi, pi = torch.nonzero(sub >= thresh, as_tuple=True)
+        pos.append((fi + f0) * npx + pi)
+        val.append(sub[fi, pi])
+    pos, val = torch.cat(pos), torch.cat(val).clone()
+    flat = f16.reshape(-1)
+
+    def restore():
+        if pos.numel():
+            flat[pos] = val
+    return restore
+
+
 def usable_cpus():
     """Host cores this process may really use: the affinity mask and the cgroup CPU quota (a one-GPU box
     of the pool exposes all of the host's logical CPUs but grants a share of them)."""
@@ -592,17 +617,15 @@ def multi_camera_main(a):
     frames = [syn.synth_frames_torch(F, size, size, first=100 * c, hot=True) for c in range(C)]
     n_sample = min(F, 32)
     sample = [fr[:n_sample].cpu().view(torch.int16).numpy().view(np.uint16).copy() for fr in frames] if not a.no_cpu_baseline else None
-    hot_idx = [torch.nonzero((fr.view(torch.int16).reshape(F, -1) >= 4064).any(1), as_tuple=False).reshape(-1) for fr in frames]
-    pristine = [fr.view(torch.int16)[h].clone() for fr, h in zip(frames, hot_idx)]
+    restorers = [hot_pixel_restorer(fr) for fr in frames]
     pipe = engine.FramePipeline(C, size, size, N)
     rows_t = torch.empty((N, engine.series_ld(F, whole_rows=True)), dtype=torch.float32, device="cuda")[:, :F]
     ev = lambda: torch.cuda.Event(enable_timing=True)
     ev_log, last = [], {}
 
     def step(record):
-        for fr, h, p in zip(frames, hot_idx, pristine):       # new frames arrive: the repaired ones are put back
-            if h.numel():
-                fr.view(torch.int16)[h] = p
+        for r in restorers:                 # new frames arrive: the repaired hot pixels are put back
+            r()
         e = [ev() for _ in range(3)]
         e[0].record()
         pix = torch.stack([engine.build_projection(bvh, cam, d_nodes, d_nrm, d_tn, 70.0, counts=False)["pix"] for cam in cams])
@@ -848,18 +871,7 @@ def main():
     n_sample = min(F, 256)
     sample = (frames[:n_sample].cpu().view(torch.int16).numpy().view(np.uint16).copy()
               if (rank == 0 and world == 1 and not a.no_cpu_baseline) else None)   # before any in-place repair
-    # The frame loop repairs hot pixels IN PLACE (like the reference): after the first step no frame would hold one
-    # and the repair / re-projection branch would never run inside the timed region.  Pristine copies of the few
-    # frames that carry hot pixels (1 % of them) are therefore put back before every step -- a stand-in for new
-    # frames arriving (<= 10 x 2 MiB device copy per 1000 frames, inside the timed region).
-    f16 = frames.view(torch.int16)
-    hot_idx = torch.cat([torch.nonzero((f16[f0:f0 + 500].reshape(min(500, F - f0), -1) >= 4064).any(1), as_tuple=False).reshape(-1) + f0
-                         for f0 in range(0, F, 500)])         # (in pieces: a 12 500-frame share is 13 G pixels)
-    pristine = f16[hot_idx].clone()
-
-    def restore_hot():
-        if hot_idx.numel():
-            f16[hot_idx] = pristine
+    restore_hot = hot_pixel_restorer(frames)        # the hot pixels are put back before every step (inside the timed region)
     shard = D.Shard(F * world, N, rank, world)
     pipe = engine.FramePipeline(1, size, size, N, registration=int(a.registration),
                                 fused_scan=2 if a.two_kernel else 0)
