@@ -936,6 +936,7 @@ def main():
     # on a high-priority side stream 1.107 / 1.131, pass A on a high-priority side stream 1.208).  UPSP_BENCH_BUILD_ON_SIDE=0 /
     # UPSP_BENCH_SIDE_PRIORITY=0: the other arrangements.
     swap = overlap and os.environ.get("UPSP_BENCH_BUILD_ON_SIDE", "1") == "1"
+    side_waits = os.environ.get("UPSP_BENCH_SIDE_WAIT", "0") == "1"      # (A/B: the build of a step behind the previous step's pass B)
     # (beside RCCL's kernels a high-priority build stream is the slower arrangement: N > 1 loop 1.85 against 1.54 ms per step)
     side = torch.cuda.Stream(priority=int(os.environ.get("UPSP_BENCH_SIDE_PRIORITY", "-1" if swap and not chunked else "0"))) if overlap else None
 
@@ -946,7 +947,12 @@ def main():
         ht = [time.perf_counter()]
         main = torch.cuda.current_stream()
         if swap:
-            side.wait_stream(main)
+            # The build reads the model and the camera only and writes fresh outputs + the BVH's own scratch: it depends on
+            # nothing the main stream does, so it does NOT wait for the previous step's pass B -- the device starts it as soon as
+            # the previous build has left the side stream (the host runs a step ahead), beside whatever the main stream is at.
+            # The consumer side is ordered below (main waits for the side stream before it takes the projection).
+            if side_waits:
+                side.wait_stream(main)
             with torch.cuda.stream(side):
                 proj = engine.build_projection(bvh, cam, d_nodes, d_nrm, d_tn, 70.0, counts=False)
             pipe.set_active_hint(engine.candidate_pixels(cam, d_nodes))
