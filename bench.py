@@ -422,9 +422,16 @@ def registration_block(bvh, cam, d_nodes, d_nrm, d_tn, frames, restore, N, size,
     pipe.set_reference(0, frames[0].to(torch.float32))      # raw first frame as ECC template (psp_process.cpp:2057)
     rows_t = torch.empty((N, engine.series_ld(F)), dtype=torch.float32, device="cuda")[:, :F]
 
+    side = torch.cuda.Stream(priority=-1)       # the build of a step runs beside the previous step's registration (see main())
+    side.wait_stream(torch.cuda.current_stream())   # (once: whatever the caller still has in flight on the model's arrays)
+
     def step():
         restore()
-        proj = engine.build_projection(bvh, cam, d_nodes, d_nrm, d_tn, 70.0, counts=False)
+        main = torch.cuda.current_stream()
+        with torch.cuda.stream(side):
+            proj = engine.build_projection(bvh, cam, d_nodes, d_nrm, d_tn, 70.0, counts=False)
+        main.wait_stream(side)
+        proj["pix"].record_stream(main)
         pipe.reset()
         pipe.set_projection(0, proj["pix"])
         pipe.process(frames, first_frame=0, rows_t=rows_t, want_rows=False)
@@ -937,8 +944,10 @@ def main():
     # UPSP_BENCH_SIDE_PRIORITY=0: the other arrangements.
     swap = overlap and os.environ.get("UPSP_BENCH_BUILD_ON_SIDE", "1") == "1"
     side_waits = os.environ.get("UPSP_BENCH_SIDE_WAIT", "0") == "1"      # (A/B: the build of a step behind the previous step's pass B)
+    # configs[2]: the build of a step on a stream of its own as well -- it runs beside the previous step's registration
+    reg_side = a.registration and not a.serial and not chunked and not side_waits
     # (beside RCCL's kernels a high-priority build stream is the slower arrangement: N > 1 loop 1.85 against 1.54 ms per step)
-    side = torch.cuda.Stream(priority=int(os.environ.get("UPSP_BENCH_SIDE_PRIORITY", "-1" if swap and not chunked else "0"))) if overlap else None
+    side = torch.cuda.Stream(priority=int(os.environ.get("UPSP_BENCH_SIDE_PRIORITY", "-1" if (swap or reg_side) and not chunked else "0"))) if (overlap or reg_side) else None
 
     def step(record):
         e = [ev() for _ in range(4)]
@@ -964,11 +973,19 @@ def main():
             with torch.cuda.stream(side):
                 pipe.set_active_hint(engine.candidate_pixels(cam, d_nodes))
                 pipe.prescan(frames)
-        if not swap:
+        if reg_side:
+            with torch.cuda.stream(side):           # (as above: beside the previous step's registration)
+                proj = engine.build_projection(bvh, cam, d_nodes, d_nrm, d_tn, 70.0, counts=False)
+        elif not swap:
             proj = engine.build_projection(bvh, cam, d_nodes, d_nrm, d_tn, 70.0, counts=False)   # no host sync
         e[1].record()
         ht.append(time.perf_counter())
         pipe.reset()
+        if reg_side:
+            main.wait_stream(side)
+            for t in proj.values():
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    t.record_stream(main)
         if overlap:
             # before the projection is copied into the pipeline: with the build on the side stream the copy would otherwise
             # be ordered behind pass A only and could read entries the build is still writing
