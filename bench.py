@@ -96,16 +96,14 @@ def parse():
                          "rays of the projection build are cast")
     ap.add_argument("--chunks", type=int, default=0,
                     help="N > 1 loop: chunks the rank's frames are exchanged in (the exchange of chunk k runs while chunk k + 1 is scanned); "
-                         "0 = 4, or 1 when pass A runs once beside the build (deferred exchange)")
+                         "0 = 1 (pass A once beside the build, one block per peer), or 4 with --chunk-scan / the row wire")
     ap.add_argument("--config3-share", action="store_true",
                     help="one rank's share of BASELINE configs[3] (100 000 frames on 8 GPUs) as ONE step: 12 500 resident frames through "
                          "the N > 1 loop (implies --force-chunked on one GPU; as many exchange chunks as keep each within one pass A, "
                          "i.e. <= 1024 frames) -- the run's chunks overlap each other, only the last one and pass B are exposed once "
                          "per 12 500 frames, not once per 1000 as in the default N > 1 step")
     ap.add_argument("--chunk-scan", action="store_true",
-                    help="N > 1 loop: pass A per chunk after the projection build (default when the exchange is finished inside the step)")
-    ap.add_argument("--scan-once", action="store_true",
-                    help="N > 1 loop: pass A once for all frames of the rank beside the projection build (default with the deferred exchange)")
+                    help="N > 1 loop: pass A per chunk after the projection build (default: once for all frames of the rank, beside the build)")
     ap.add_argument("--defer-exchange", action="store_true",
                     help="--force-chunked on one GPU: the two-exchanges-in-turn schedule of the N > 1 runs (see --sync-exchange)")
     ap.add_argument("--sync-exchange", action="store_true",
@@ -907,12 +905,11 @@ def main():
     # (between GPUs only, or on request: on ONE GPU nothing waits for a link, and the later pass B finds its compact series
     #  pushed out of the Infinity Cache by the next step's frames -- 1.56 against 1.45 ms per step, measured)
     deferred = chunked and pixel_wire and not a.sync_exchange and (world > 1 or a.defer_exchange)
-    # ... and with the exchange deferred nothing is gained by cutting a step's frames into chunks (the sends overlap the NEXT
-    # step anyway): pass A runs ONCE for all frames of the rank, on the candidate-pixel map, beside the projection build -- the
-    # arrangement of the one-GPU loop -- and one block per peer goes out (--chunk-scan: pass A per chunk after the build, the
-    # schedule of rounds 3 / early 4, still the better one when the exchange is finished inside the step: 1.52 against 1.70 ms)
-    px_once = (chunked and pixel_wire and not a.chunk_scan and (deferred or a.scan_once) and not a.config3_share and
-               F <= min(1024, pipe.series_frames_max()))
+    # Pass A runs ONCE for all frames of the rank, on the candidate-pixel map, beside the projection build -- the arrangement of
+    # the one-GPU loop -- and one block per peer goes out; the owner's pass B reads the blocks where they arrive.  (--chunk-scan:
+    # pass A per chunk after the build, every chunk's sends beside the next chunk's scan -- the schedule of rounds 3 / early 4;
+    # one GPU through RCCL, same call: 1.61-1.63 / 1.74 ms per step finished in the step / deferred, against 1.46-1.48 / 1.46.)
+    px_once = (chunked and pixel_wire and not a.chunk_scan and not a.config3_share and F <= min(1024, pipe.series_frames_max()))
     K = max(1, a.chunks if a.chunks > 0 else (1 if px_once else 4)) if chunked else 1
     if chunked and (a.config3_share or F > 1024 * K):
         # every chunk within one pass A group (<= 1024 frames; the cuts sit on 64-frame boundaries)
@@ -946,8 +943,10 @@ def main():
     side_waits = os.environ.get("UPSP_BENCH_SIDE_WAIT", "0") == "1"      # (A/B: the build of a step behind the previous step's pass B)
     # configs[2]: the build of a step on a stream of its own as well -- it runs beside the previous step's registration
     reg_side = a.registration and not a.serial and not chunked and not side_waits
-    # (beside RCCL's kernels a high-priority build stream is the slower arrangement: N > 1 loop 1.85 against 1.54 ms per step)
-    side = torch.cuda.Stream(priority=int(os.environ.get("UPSP_BENCH_SIDE_PRIORITY", "-1" if (swap or reg_side) and not chunked else "0"))) if (overlap or reg_side) else None
+    # (the side stream must be a HIGH-priority one to get a hardware queue of its own: a normal-priority torch stream shares the
+    #  default stream's queue on this runtime -- kernel trace: every launch on queue 4 -- and the build then runs behind pass B
+    #  and in front of pass A instead of beside them: N > 1 loop 1.61 against 1.40 ms per step)
+    side = torch.cuda.Stream(priority=int(os.environ.get("UPSP_BENCH_SIDE_PRIORITY", "-1" if (swap or reg_side) else "0"))) if (overlap or reg_side) else None
 
     def step(record):
         e = [ev() for _ in range(4)]

@@ -83,7 +83,7 @@ def test_bench_pixel_wire(gpu_lib):
     C-ABI exchange over RCCL (one-rank group) and over gloo with two ranks on this GPU; the series that come out are
     compared with the oracle in the run (one rank) like the row exchange's."""
     d = run_bench(["--force-chunked", "--small", "--steps", "2", "--warmup", "1"], env={"UPSP_FORCE_COLLECTIVES": "1"})
-    assert d["config"]["exchange"] == "4 chunks, active-pixel series as u16; pass A per chunk after the projection build"
+    assert d["config"]["exchange"] == "1 chunks, active-pixel series as u16; pass A once for the rank's frames beside the projection build"
     assert d["parity_checked"] is True
     x = d["exchange_bytes_per_step"]
     assert x["what_travels"] == "active-pixel series" and x["transport"].startswith("C ABI")
@@ -103,12 +103,15 @@ def test_bench_pixel_wire(gpu_lib):
     # the schedules of round 3 / early round 4 stay reachable: deferred with pass A per chunk, and finished inside the step
     d = run_bench(["--force-chunked", "--defer-exchange", "--chunk-scan", "--small", "--steps", "3", "--warmup", "1"], env={"UPSP_FORCE_COLLECTIVES": "1"})
     assert d["config"]["exchange"].startswith("4 chunks, active-pixel series as u16; two exchanges in turn") and d["parity_checked"] is True
-    d = run_bench(["--force-chunked", "--sync-exchange", "--scan-once", "--chunks", "3", "--small", "--steps", "2", "--warmup", "1"], env={"UPSP_FORCE_COLLECTIVES": "1"})
+    d = run_bench(["--force-chunked", "--sync-exchange", "--chunks", "3", "--small", "--steps", "2", "--warmup", "1"], env={"UPSP_FORCE_COLLECTIVES": "1"})
     assert d["config"]["exchange"] == "3 chunks, active-pixel series as u16; pass A once for the rank's frames beside the projection build"
+    assert d["parity_checked"] is True
+    d = run_bench(["--force-chunked", "--sync-exchange", "--chunk-scan", "--small", "--steps", "2", "--warmup", "1"], env={"UPSP_FORCE_COLLECTIVES": "1"})
+    assert d["config"]["exchange"] == "4 chunks, active-pixel series as u16; pass A per chunk after the projection build"
     assert d["parity_checked"] is True
     d = run_bench(["--gpus", "2", "--small", "--steps", "2", "--warmup", "1", "--sync-exchange"],
                   env={"UPSP_BENCH_BACKEND": "gloo", "UPSP_BENCH_ONE_GPU": "1"})
-    assert d["config"]["exchange"] == "4 chunks, active-pixel series as u16; pass A per chunk after the projection build"
+    assert d["config"]["exchange"] == "1 chunks, active-pixel series as u16; pass A once for the rank's frames beside the projection build"
 
 
 def test_bench_two_ranks_rccl(gpu_lib):

@@ -13,7 +13,7 @@ PY
 }
 for rep in 1 2; do
   run sync_default_$rep "--sync-exchange"
-  run sync_once_$rep "--sync-exchange --scan-once"
+  run sync_chunkscan_$rep "--sync-exchange --chunk-scan"
   run deferred_default_$rep "--defer-exchange"
   run deferred_chunkscan_$rep "--defer-exchange --chunk-scan"
   run deferred_once_k4_$rep "--defer-exchange --chunks 4"
