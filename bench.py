@@ -28,11 +28,15 @@ entry whatever their rays say and cast none) and decides most retry rays by the 
 REFERENCE casts for the same camera, and `mrays_reference_equivalent_per_s` is that count over the build time -- an
 equivalence, not a ray rate.
 
-Schedule of the default (one GPU, plain loop): the ray casting of the projection build runs on a high-priority stream of its own,
-pass A of the frame loop (which needs only the candidate pixels of the in-frame nodes) beside it, then pass B and the repair;
-`--serial` = one stream, stage after stage.  N > 1 (`--gpus N`, or `--force-chunked` on one GPU): the rank's frames go through
-pass A in `--chunks` chunks, the active pixels' u16 series travel (`--row-wire`: packed node rows; `--wire12`: packed to 12 bits)
-through the library's exchange over RCCL while the next chunk is scanned, the owner of a node runs pass B.
+Schedule of the default (one GPU, plain loop): the ray casting of the projection build runs on a high-priority stream of its own
+(it depends on nothing the frame loop does, so it does not wait for the previous step's pass B either: the device starts it when
+the previous build has left that stream), pass A of the frame loop (which needs only the candidate pixels of the in-frame nodes)
+beside it, then pass B and the repair; `--serial` = one stream, stage after stage.  N > 1 (`--gpus N`, or `--force-chunked` on one
+GPU): the same arrangement -- pass A once for the rank's frames beside the build --, then the active pixels' u16 series travel, one
+block per peer (`--row-wire`: packed node rows; `--wire12`: packed to 12 bits; `--chunk-scan`: pass A per chunk, every chunk's sends
+beside the next chunk's scan), through the library's exchange over RCCL, and the owner of a node runs pass B; between GPUs two
+exchanges are used in turn (a step's blocks are on the links during the next step; the run's last exchange is finished before the
+clock stops).  No cyclic-GC pass runs inside a timed loop (`quiet_gc`).
 
 `configs2` (default run) / `--registration`: BASELINE configs[2], per-frame ECC registration in front of the projection,
 with its own roofline (ecc_sums_kernel), iterations per frame, CPU baseline (`register_pixel` included) and parity block
