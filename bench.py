@@ -631,14 +631,27 @@ def multi_camera_main(a):
     rows_t = torch.empty((N, engine.series_ld(F, whole_rows=True)), dtype=torch.float32, device="cuda")[:, :F]
     ev = lambda: torch.cuda.Event(enable_timing=True)
     ev_log, last = [], {}
+    torch.cuda.synchronize()
+    side = None if a.serial else torch.cuda.Stream(priority=-1)
 
     def step(record):
         for r in restorers:                 # new frames arrive: the repaired hot pixels are put back
             r()
         e = [ev() for _ in range(3)]
         e[0].record()
-        pix = torch.stack([engine.build_projection(bvh, cam, d_nodes, d_nrm, d_tn, 70.0, counts=False)["pix"] for cam in cams])
-        w = engine.projection_weights(pix, d_nodes, d_nrm, centers, "average_view")      # adjust_projection_for_weights
+        main = torch.cuda.current_stream()
+        if side is not None:
+            # the builds of a step read the model and the cameras only: on a high-priority stream of their own they run beside the
+            # PREVIOUS step's frame loop (see main(): no wait in front of them; the consumer side is ordered below)
+            with torch.cuda.stream(side):
+                pix = torch.stack([engine.build_projection(bvh, cam, d_nodes, d_nrm, d_tn, 70.0, counts=False)["pix"] for cam in cams])
+                w = engine.projection_weights(pix, d_nodes, d_nrm, centers, "average_view")  # adjust_projection_for_weights
+            main.wait_stream(side)
+            pix.record_stream(main)
+            w.record_stream(main)
+        else:
+            pix = torch.stack([engine.build_projection(bvh, cam, d_nodes, d_nrm, d_tn, 70.0, counts=False)["pix"] for cam in cams])
+            w = engine.projection_weights(pix, d_nodes, d_nrm, centers, "average_view")      # adjust_projection_for_weights
         e[1].record()
         pipe.reset()
         for c in range(C):
@@ -701,7 +714,9 @@ def multi_camera_main(a):
                                "raycast+weighted projection; a frame = one frame of every camera" % (C, F, size, size, tris.shape[0], N),
                    "cameras": C, "frames_per_camera": F, "nodes": N, "triangles": int(tris.shape[0]),
                    "nodes_seen": seen, "cameras_per_seen_node": seen_by, "active_pixels_per_camera": active,
-                   "parallelism": "one GPU", "schedule": "per camera: projection build; pass A per camera; one whole-row pass B over all cameras"},
+                   "parallelism": "one GPU", "schedule": ("per camera: projection build; pass A per camera; one whole-row pass B over all cameras" if a.serial else
+                                "the projection builds of a step on a high-priority stream of their own (beside the previous step's frame "
+                                "loop); pass A per camera; one whole-row pass B over all cameras")},
         "breakdown_ms": {"projection_builds_and_weights": float(np.mean([e[0].elapsed_time(e[1]) for e in ev_log])),
                          "frame_loop_and_finals": float(np.mean([e[1].elapsed_time(e[2]) for e in ev_log]))},
         "roofline": {"kernel": dom, "bound": "hbm", "achieved": dk["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -20,8 +20,13 @@ elif [ $part = b ]; then
   timeout -k 10 500 python3 bench.py --registration --frames 10000 --steps 2 --warmup 1 --no-cpu-baseline > $o/r04_bench_line_config2_10000_frames.json 2> $o/reg10k.err || exit 1
   bash tools/pmc_script.sh "ecc_cols|gauss5_quad|ecc_solve|reblur|hot_repair|warp_compact" tools/prof_ecc.py > $o/r04_ecc_pmc.txt 2>&1 || exit 1
 else
+  # N > 1 loop on one GPU through a one-rank RCCL communicator: finished inside the step (with the oracle check), deferred
+  # (the N > 1 default), and round 3's schedule (pass A per chunk) both ways
   UPSP_FORCE_COLLECTIVES=1 timeout -k 10 500 python3 bench.py --force-chunked > $o/r04_bench_line_chunked_rccl.json 2> $o/ck.err || exit 1
   UPSP_FORCE_COLLECTIVES=1 timeout -k 10 500 python3 bench.py --force-chunked --defer-exchange --no-cpu-baseline > $o/r04_bench_line_chunked_rccl_deferred.json 2>> $o/ck.err || exit 1
+  UPSP_FORCE_COLLECTIVES=1 timeout -k 10 500 python3 bench.py --force-chunked --chunk-scan --no-cpu-baseline > $o/r04_bench_line_chunked_rccl_chunk_scan.json 2>> $o/ck.err || exit 1
+  UPSP_FORCE_COLLECTIVES=1 timeout -k 10 500 python3 bench.py --force-chunked --chunk-scan --defer-exchange --no-cpu-baseline > $o/r04_bench_line_chunked_rccl_chunk_scan_deferred.json 2>> $o/ck.err || exit 1
+  timeout -k 10 500 python3 bench.py --no-cpu-baseline --steps 10 --warmup 3 > $o/r04_bench_line_10_steps.json 2>> $o/ck.err || exit 1
   UPSP_FORCE_COLLECTIVES=1 timeout -k 10 600 python3 bench.py --config3-share --steps 3 --warmup 2 --no-cpu-baseline > $o/r04_bench_line_config3_share.json 2>> $o/ck.err || exit 1
   timeout -k 10 600 python3 bench.py --cameras 4 --model 5m --steps 3 --warmup 1 > $o/r04_multi_bench_line.json 2> $o/multi.err || exit 1
   bash tools/pmc_script.sh "projection_kernel|witness_kernel|heavy_kernel" tools/prof_proj.py > $o/r04_proj_pmc.txt 2>&1 || exit 1
