@@ -1215,9 +1215,9 @@ def main():
             "avg_launch_ms": dk["avg_launch_ms"], "launches_per_step": calls}
     roof.update(ECC_SYMBOLS.get(dom, {}))
     if overlap:
-        roof["note"] = ("default schedule: pass A (scan_compact_kernel) runs beside the ray casting of the projection build (which has a "
-                        "high-priority stream of its own) and shares the memory system with it; alone (--serial) it takes 0.35-0.40 ms = "
-                        "0.66 of peak, and the step 5-8 % longer")
+        roof["note"] = ("default schedule: the ray casting of the projection builds has a high-priority stream of its own and runs beside "
+                        "pass A (scan_compact_kernel) and pass B (node_rows_kernel), which share the memory system with it; alone (--serial) "
+                        "pass A takes 0.40 ms = 0.66 of peak and pass B 0.41 ms = 0.61, and the step 13-20 % longer")
 
     sched = ("projection build, then hot-pixel scan + gather kernels per 64-frame sub-batch"
              if (a.two_kernel or a.registration) else
