@@ -555,10 +555,15 @@ int upsp_exchange_bytes(const upsp_exchange *x, uint64_t *sent, uint64_t *receiv
  * runs pass B (the series + accumulators of ITS nodes over ALL frames) itself:
  *   upsp_pipeline_pixel_series  pass A alone: the REPAIRED series of every active pixel over `nframes` (<= 1024) frames
  *                         in the pipeline's compact buffer [active pixel][*cpitch] u16 (frames repaired in place like
- *                         fix_hot_pixels); *d_node_k [nnodes]: compact row of every node (< 0: none)
+ *                         fix_hot_pixels); *d_node_k [nnodes]: compact row of every node (< 0: none).  If pass A of exactly
+ *                         these frames already ran on a candidate-pixel map (upsp_pipeline_set_active_hint +
+ *                         upsp_pipeline_prescan, e.g. beside the projection build) it is not repeated: the nodes get their
+ *                         rows in that buffer (the candidates must hold every pixel a node reads: a node outside them gets
+ *                         -2, which upsp_exchange_set_pixels refuses), only the hot-pixel repair is left
  *   upsp_exchange_set_pixels    which pixel rows go where, from d_node_k (identical on every rank) and the skipped nodes
  *                         (one host read per projection; assume_same as above)
- *   upsp_exchange_submit_pixels chunk k out of the sender's compact buffer (wire 2: u16, 12: packed to 12 bits)
+ *   upsp_exchange_submit_pixels chunk k out of the sender's compact buffer (wire 2: u16, 12: packed to 12 bits); d_compact
+ *                         points at the chunk's first frame (a buffer holding all frames of the rank: d_compact + c0)
  *   upsp_exchange_finish_pixels places what arrived and runs pass B: d_series [nodes of this rank][ld >= F] f32 with NaN
  *                         rows for the skipped nodes; d_sum_mine / d_sumsq_mine [nodes of this rank] gain the sums over all
  *                         frames (pass the slice of the full-length accumulators: the other ranks' slices stay zero, and
