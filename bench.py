@@ -959,6 +959,7 @@ def main():
     # on a high-priority side stream 1.107 / 1.131, pass A on a high-priority side stream 1.208).  UPSP_BENCH_BUILD_ON_SIDE=0 /
     # UPSP_BENCH_SIDE_PRIORITY=0: the other arrangements.
     swap = overlap and os.environ.get("UPSP_BENCH_BUILD_ON_SIDE", "1") == "1"
+    cand_oblique = os.environ.get("UPSP_BENCH_CAND_OBLIQUE", "1") == "1"      # (A/B: candidates = every in-frame node, round 3)
     side_waits = os.environ.get("UPSP_BENCH_SIDE_WAIT", "0") == "1"      # (A/B: the build of a step behind the previous step's pass B)
     # configs[2]: the build of a step on a stream of its own as well -- it runs beside the previous step's registration
     reg_side = a.registration and not a.serial and not chunked and not side_waits
@@ -982,14 +983,14 @@ def main():
                 side.wait_stream(main)
             with torch.cuda.stream(side):
                 proj = engine.build_projection(bvh, cam, d_nodes, d_nrm, d_tn, 70.0, counts=False)
-            pipe.set_active_hint(engine.candidate_pixels(cam, d_nodes))
+            pipe.set_active_hint(engine.candidate_pixels(cam, d_nodes, normals=d_nrm if cand_oblique else None, oblique_angle_deg=70.0))
             pipe.prescan(frames)
         elif overlap:
             # which pixels the frame loop will read is known once the nodes are projected into the image
             # (step 1 of create_projection_mat); pass A does not need the visibility verdicts
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                pipe.set_active_hint(engine.candidate_pixels(cam, d_nodes))
+                pipe.set_active_hint(engine.candidate_pixels(cam, d_nodes, normals=d_nrm if cand_oblique else None, oblique_angle_deg=70.0))
                 pipe.prescan(frames)
         if reg_side:
             with torch.cuda.stream(side):           # (as above: beside the previous step's registration)

@@ -181,6 +181,13 @@ int upsp_projection_fetch_counts(upsp_bvh *bvh, uint64_t *nrays, uint64_t *prima
  * projection of this camera is a subset: input of upsp_pipeline_set_active_hint. */
 int upsp_projection_candidate_pixels(const upsp_camera *cam, const float *d_nodes, const uint8_t *d_datanode,
                                      size_t nnodes, int32_t *d_pix, void *stream);
+/* The same restricted to the nodes that pass the oblique test of psp_process.cpp:298-306 (node normal against the camera ->
+ * node direction; `oblique_thresh` as for upsp_projection_build): a node that fails it has no entry whatever its rays say, so
+ * this is still a superset of the projection built with the same threshold -- on a closed body a third of the pixels of the
+ * plain candidate set (the back-facing nodes drop out), i.e. a pass A that stores a third of the series. */
+int upsp_projection_candidate_pixels_oblique(const upsp_camera *cam, const float *d_nodes, const float *d_normals,
+                                             const uint8_t *d_datanode, size_t nnodes, float oblique_thresh, int32_t *d_pix,
+                                             void *stream);
 
 /* adjust_projection_for_weights with BestView (mode 0) / AverageViews (mode 1)
  * (cpp/lib/projection.ipp:911-1078, 227-268).  d_pix, d_weight: [ncams*nnodes];

@@ -657,4 +657,15 @@ def test_candidate_pixels_superset(gpu_lib):
         seen = pix >= 0
         assert int(seen.sum()) > 100 and torch.equal(pix[seen], cand[seen])
         assert int((cand >= 0).sum()) > int(seen.sum())
+        # ... restricted to the nodes that pass the oblique test (upsp_projection_candidate_pixels_oblique): still a superset,
+        # exactly the nodes that cast a primary ray in the build, a subset of the plain candidates with the same pixels
+        for angle in (70.0, 40.0):
+            proj = engine.build_projection(bvh, cam, v, nrm, tn, angle, counts=False)
+            pixa = proj["pix"]
+            co = engine.candidate_pixels(cam, v, normals=nrm, oblique_angle_deg=angle)
+            seen = pixa >= 0
+            assert torch.equal(pixa[seen], co[seen])
+            sub = co >= 0
+            assert torch.equal(co[sub], cand[sub]) and int(sub.sum()) < int((cand >= 0).sum())
+            assert int(sub.sum()) == engine.projection_counts(bvh)["primary_rays"]
         bvh.close()

@@ -970,9 +970,12 @@ __global__ void __launch_bounds__(256)
 }
 
 // Step 1 + the pixel of :319 for every in-frame node, whatever the rays will say (upsp_projection_candidate_pixels)
+// normals != nullptr: ... and only for the nodes that pass the oblique test of :298-306 (a node that fails it has no entry
+// whatever its rays say): the candidates are then exactly the nodes that cast a primary ray in upsp_projection_build
 __global__ void __launch_bounds__(256)
     candidate_pixels_kernel(Cam cam, const float *__restrict__ nodes, const uint8_t *__restrict__ datanode,
-                            unsigned nnodes, int32_t *__restrict__ pix)
+                            unsigned nnodes, const float *__restrict__ normals, float oblique_thresh,
+                            int32_t *__restrict__ pix)
 {
     const unsigned n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= nnodes) return;
@@ -983,7 +986,8 @@ __global__ void __launch_bounds__(256)
                       nodes[3 * (size_t)n + 2], u, v);
         const bool finite_int = (fabsf(u) < 2147483648.0f) & (fabsf(v) < 2147483648.0f);
         const int rx = finite_int ? (int)rintf(u) : -1, ry = finite_int ? (int)rintf(v) : -1;
-        if ((rx >= 0) & (ry >= 0) & (rx < cam.W) & (ry < cam.H)) {
+        if ((rx >= 0) & (ry >= 0) & (rx < cam.W) & (ry < cam.H) &&
+            (!normals || oblique_forward(cam, nodes, normals, n, oblique_thresh))) {
             const int px_ = (int)roundf(u), py_ = (int)roundf(v);
             const long long idx = (long long)py_ * cam.W + px_;
             if (idx >= 0 && idx < (long long)cam.W * cam.H) out = (int32_t)idx;
@@ -2659,8 +2663,25 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
     return UPSP_OK;
 }
 
+static int candidate_pixels_impl(const upsp_camera *cam, const float *d_nodes, const float *d_normals, const uint8_t *d_datanode,
+                                 size_t nnodes, float oblique_thresh, int32_t *d_pix, void *stream);
+
 int upsp_projection_candidate_pixels(const upsp_camera *cam, const float *d_nodes, const uint8_t *d_datanode,
                                      size_t nnodes, int32_t *d_pix, void *stream)
+{
+    return candidate_pixels_impl(cam, d_nodes, nullptr, d_datanode, nnodes, 0.0f, d_pix, stream);
+}
+
+int upsp_projection_candidate_pixels_oblique(const upsp_camera *cam, const float *d_nodes, const float *d_normals,
+                                             const uint8_t *d_datanode, size_t nnodes, float oblique_thresh, int32_t *d_pix,
+                                             void *stream)
+{
+    if (!d_normals) return fail(UPSP_ERR_INVALID, "null normals");
+    return candidate_pixels_impl(cam, d_nodes, d_normals, d_datanode, nnodes, oblique_thresh, d_pix, stream);
+}
+
+static int candidate_pixels_impl(const upsp_camera *cam, const float *d_nodes, const float *d_normals, const uint8_t *d_datanode,
+                                 size_t nnodes, float oblique_thresh, int32_t *d_pix, void *stream)
 {
     if (!cam || !d_nodes || !d_pix) return fail(UPSP_ERR_INVALID, "null argument");
     if (cam->width <= 0 || cam->height <= 0) return fail(UPSP_ERR_INVALID, "bad image size");
@@ -2671,11 +2692,15 @@ int upsp_projection_candidate_pixels(const upsp_camera *cam, const float *d_node
     std::memcpy(c.dist, cam->dist, sizeof(c.dist));
     std::memcpy(c.R, cam->R, sizeof(c.R));
     std::memcpy(c.t, cam->t, sizeof(c.t));
-    c.ox = c.oy = c.oz = 0.0f;
+    double cc[3];
+    upsp_camera_center(cam, cc);        // (the oblique test takes the camera -> node direction, like the build)
+    c.ox = (float)cc[0];
+    c.oy = (float)cc[1];
+    c.oz = (float)cc[2];
     c.W = cam->width;
     c.H = cam->height;
     hipLaunchKernelGGL(candidate_pixels_kernel, dim3((unsigned)((nnodes + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       c, d_nodes, d_datanode, (unsigned)nnodes, d_pix);
+                       c, d_nodes, d_datanode, (unsigned)nnodes, d_normals, oblique_thresh, d_pix);
     UPSP_HIP_CHECK(hipGetLastError());
     return UPSP_OK;
 }

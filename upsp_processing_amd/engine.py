@@ -186,12 +186,20 @@ def build_projection(bvh, cam, nodes, normals, tri_nodes, oblique_angle=70.0, da
                 primary_rays=int(pr.value), retry_nodes=int(rn.value))
 
 
-def candidate_pixels(cam, nodes, datanode=None):
+def candidate_pixels(cam, nodes, datanode=None, normals=None, oblique_angle_deg=None):
     """Step 1 of create_projection_mat alone: int32 [N], the pixel every in-frame node would be stored at
-    (-1 otherwise) -- a superset of any projection of this camera (FramePipeline.set_active_hint)."""
+    (-1 otherwise) -- a superset of any projection of this camera (FramePipeline.set_active_hint).  With normals and the
+    oblique angle of the build: only the nodes that pass the oblique test (the ones that cast a primary ray) -- still a
+    superset of the projection built with that angle, a third of the pixels on a closed body."""
     nodes = _dev(nodes, torch.float32).reshape(-1, 3)
     dn = None if datanode is None else _dev(datanode, torch.uint8).reshape(-1)
     pix = torch.empty(nodes.shape[0], dtype=torch.int32, device="cuda")
+    if normals is not None:
+        nrm = _dev(normals, torch.float32).reshape(-1, 3)
+        assert nrm.shape[0] == nodes.shape[0] and oblique_angle_deg is not None
+        check(lib().upsp_projection_candidate_pixels_oblique(C.byref(cam), _ptr(nodes), _ptr(nrm), _ptr(dn), nodes.shape[0],
+                                                             C.c_float(oblique_threshold(oblique_angle_deg)), _ptr(pix), _stream()))
+        return pix
     check(lib().upsp_projection_candidate_pixels(C.byref(cam), _ptr(nodes), _ptr(dn), nodes.shape[0], _ptr(pix), _stream()))
     return pix
 
