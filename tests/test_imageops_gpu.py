@@ -342,14 +342,19 @@ def test_registration_full_size_1024(gpu_lib, oracle):
     print("1024^2 registration: iterations %s, worst |dM| %.2e, |dt| %.2e px, |dI| %.2f" % (it_g.tolist(), *worst))
 
 
-def test_registration_sub_batches_look_ahead(gpu_lib, oracle):
-    """More frames than one sub-batch through the streamed registration path: the hot-pixel repair and the pre-blur of
+@pytest.mark.parametrize("reg_batch", ["64", "128", None])
+def test_registration_sub_batches_look_ahead(gpu_lib, oracle, monkeypatch, reg_batch):
+    """(UPSP_REG_BATCH: frames per sub-batch of the streamed registration path -- 256 by default; 64 and 128 put several
+    sub-batches into the calls below.  The sums of a frame do not depend on its neighbours: the same bits whatever the size.)
+    More frames than one sub-batch through the streamed registration path: the hot-pixel repair and the pre-blur of
     sub-batch k + 1 are enqueued while the host waits for sub-batch k's "frames still iterating" (two blurred-frame buffers).
     Same bits as calls of one sub-batch each (no look-ahead: nothing to look ahead to) -- series, warps, iteration counts,
     accumulators, repaired frames -- over several calls (buffers re-used), with hot pixels in frames of every sub-batch; and
     3 frames against the oracle."""
     import torch
     from upsp_processing_amd import engine, synthetic as syn
+    if reg_batch:
+        monkeypatch.setenv("UPSP_REG_BATCH", reg_batch)
     H, W, F, n = 96, 160, 200, 3000
     frames = syn.synth_frames_numpy(F, H, W, seed=21, hot=True)
     rng = np.random.default_rng(22)

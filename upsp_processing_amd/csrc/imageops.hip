@@ -987,9 +987,10 @@ int run_frame_stages(FrameScratch *s, int cam, const uint16_t *d_frames, int nb,
         if (rc != UPSP_OK) return rc;
         if (wc) {      // registration is the last image stage and node-major series are wanted: straight into the compact buffer
             KTimed kt("warp_u16_kernel", st);
-            hipLaunchKernelGGL(warp_compact_kernel, dim3((unsigned)((wc->max_active + 63) / 64)), block, 0, st, d_frames, rows,
-                               cols, (const EccState *)s->state, nb, opts.interp, wc->pix_of_k, wc->nact, wc->compact,
-                               wc->cpitch, wc->col0);
+            for (int h = 0; h < nb; h += 64)       // (a workgroup transposes 64 pixels x <= 64 frames)
+                hipLaunchKernelGGL(warp_compact_kernel, dim3((unsigned)((wc->max_active + 63) / 64)), block, 0, st,
+                                   d_frames + (size_t)h * npix, rows, cols, (const EccState *)s->state + h, std::min(64, nb - h),
+                                   opts.interp, wc->pix_of_k, wc->nact, wc->compact, wc->cpitch, wc->col0 + (unsigned)h);
         } else {
             KTimed kt("warp_u16_kernel", st);
             const bool listed = !opts.patch && !opts.filter && d_read_list;

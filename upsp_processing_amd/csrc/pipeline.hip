@@ -783,7 +783,20 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
         unsigned cp = 0;
         rc = streamed_buffers(p, npix, nframes, st, &S, &cp);
         if (rc != UPSP_OK) return rc;
-        rc = upsp::frame_scratch_ensure(&p->scratch, 1, B, p->height, p->width, true, false);
+        // Sub-batches of this path: 256 frames where the blurred f32 copies allow it (two buffers of RB frames: 2 GiB at
+        // 1 Mpix; at most 4 GiB).  Every launch of the lock-step ECC loop -- sums, the one-lane-per-frame solve, pre-blur, repair,
+        // warp -- is paid per sub-batch, the solve (16 us of latency, nothing beside it) and the launch tails most of all;
+        // configs[2], ms per 1000 frames at 64 / 128 / 192 / 256 / 512 frames: 7.96 / 7.71 / 7.62 / 7.54 / 7.45.  The sums of a
+        // frame do not depend on its neighbours (block count per frame fixed by the image), so the bits are the ones of
+        // 64-frame sub-batches.  UPSP_REG_BATCH=n: another size (tests: 64).
+        int RB = B;
+        if (B == 64) {
+            const char *e = std::getenv("UPSP_REG_BATCH");
+            int want = e ? std::max(64, std::atoi(e) / 64 * 64) : 256;
+            while (want > 64 && npix * sizeof(float) * 2 * (size_t)want > ((size_t)4 << 30)) want -= 64;
+            RB = std::min(want, 1024);
+        }
+        rc = upsp::frame_scratch_ensure(&p->scratch, 1, RB, p->height, p->width, true, false);
         if (rc != UPSP_OK) return rc;
         PipelineGather g;
         g.ncams = 1;
@@ -806,7 +819,7 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
         struct Sub { int f0, nb, s0; };
         std::vector<Sub> subs;
         for (int s0 = 0; s0 < nframes; s0 += S)
-            for (int f0 = s0; f0 < std::min(s0 + S, nframes); f0 += B) subs.push_back({f0, std::min(B, std::min(s0 + S, nframes) - f0), s0});
+            for (int f0 = s0; f0 < std::min(s0 + S, nframes); f0 += RB) subs.push_back({f0, std::min(RB, std::min(s0 + S, nframes) - f0), s0});
         // One stream; sub-batch k + 1's hot-pixel repair and pre-blur (upsp::frame_scratch_preblur: the scan of fix_hot_pixels
         // rides on the blur, psp_process.cpp:1772) are enqueued while the host waits for sub-batch k's "frames still
         // iterating" (two blurred-frame buffers): the GPU has work during the read-back and nothing runs beside anything.
@@ -815,7 +828,7 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
         // between the identity and the general iteration.)
         upsp::HotRepair hot;
         if (p->opts.hot_enable) {
-            rc = ensure_hot(p, B);
+            rc = ensure_hot(p, RB);
             if (rc != UPSP_OK) return rc;
             hot.thresh = p->opts.hot_thresh;
             hot.min_change = p->opts.hot_min_change;
