@@ -422,7 +422,8 @@ def registration_block(bvh, cam, d_nodes, d_nrm, d_tn, frames, restore, N, size,
     pipe = engine.FramePipeline(1, size, size, N, registration=1)
     restore()
     pipe.set_reference(0, frames[0].to(torch.float32))      # raw first frame as ECC template (psp_process.cpp:2057)
-    rows_t = torch.empty((N, engine.series_ld(F)), dtype=torch.float32, device="cuda")[:, :F]
+    # (registration as the last image stage: ONE whole-row pass B per <= 1024 frames -> the plain multiple of 256 B as pitch)
+    rows_t = torch.empty((N, engine.series_ld(F, whole_rows=True)), dtype=torch.float32, device="cuda")[:, :F]
 
     side = torch.cuda.Stream(priority=-1)       # the build of a step runs beside the previous step's registration (see main())
     side.wait_stream(torch.cuda.current_stream())   # (once: whatever the caller still has in flight on the model's arrays)
@@ -903,7 +904,8 @@ def main():
         pipe.set_reference(0, frames[0].to(torch.float32))   # raw first frame as ECC template
     # node-major time series [N, F]; one process() call writes every row piece whole
     streamed = not (a.two_kernel or a.registration)
-    ld = int(os.environ.get("UPSP_BENCH_LD", "0")) or engine.series_ld(F, whole_rows=streamed)
+    # (the streamed schedule -- and registration as the last image stage -- write every row piece whole, one pass B per <= 1024 frames)
+    ld = int(os.environ.get("UPSP_BENCH_LD", "0")) or engine.series_ld(F, whole_rows=streamed or (a.registration and not a.two_kernel))
     chunked = world > 1 or a.force_chunked          # --force-chunked: exercise the N>1 loop on one GPU
     rows_t = torch.empty((N, ld), dtype=torch.float32, device="cuda")[:, :F] if not chunked else None
     torch.cuda.synchronize()
