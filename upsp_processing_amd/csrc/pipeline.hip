@@ -422,7 +422,7 @@ int upsp_pipeline_finalize(upsp_pipeline *p, uint64_t nframes_total, float *d_av
 
 // ---- streamed schedule, one camera: shared by upsp_pipeline_prescan and the frame loop ----
 // Builds the active-pixel map from `d_pix_src` (the projection, or a candidate set) if there is none.
-static int streamed_map(upsp_pipeline *p, const int32_t *d_pix_src, size_t npix, hipStream_t st)
+static int streamed_map(upsp_pipeline *p, const int32_t *d_pix_src, size_t npix, hipStream_t st, bool want_nodes = true)
 {
     if (p->tilemap_valid) return UPSP_OK;
     const size_t ntiles = tilemap_tiles(npix);
@@ -431,8 +431,8 @@ static int streamed_map(upsp_pipeline *p, const int32_t *d_pix_src, size_t npix,
     if (!p->d_tile_cnt) UPSP_HIP_CHECK(hipMalloc(&p->d_tile_cnt, sizeof(unsigned) * ntiles));
     if (!p->d_node_k) UPSP_HIP_CHECK(hipMalloc(&p->d_node_k, sizeof(int32_t) * p->nnodes));
     if (!p->d_tile_order) UPSP_HIP_CHECK(hipMalloc(&p->d_tile_order, sizeof(unsigned) * 4 * (ntiles + 1)));
-    int rc = launch_amap_build(d_pix_src, p->nnodes, npix, p->d_aflag, p->d_tile_cnt, p->d_tile_off, p->d_node_k,
-                               p->d_tile_order, st);
+    int rc = launch_amap_build(d_pix_src, p->nnodes, npix, p->d_aflag, p->d_tile_cnt, p->d_tile_off,
+                               want_nodes ? p->d_node_k : nullptr, p->d_tile_order, st);
     if (rc != UPSP_OK) return rc;
     p->tilemap_valid = true;
     p->prescan_frames = nullptr;     // a rebuilt map: whatever pass A wrote before belongs to the old one
@@ -530,7 +530,7 @@ int upsp_pipeline_set_active_hint(upsp_pipeline *p, const int32_t *d_pix_candida
     if (p->ncams != 1 || (npix % 2) != 0 || p->nnodes >= ((size_t)1 << 31))
         return fail(UPSP_ERR_INVALID, "active hint: one camera, even pixel count");
     invalidate_map(p);
-    int rc = streamed_map(p, d_pix_candidates, npix, (hipStream_t)stream);
+    int rc = streamed_map(p, d_pix_candidates, npix, (hipStream_t)stream, /*want_nodes=*/false);   // (node rows: with the projection)
     if (rc != UPSP_OK) return rc;
     p->hint_active = true;
     p->node_k_valid = false;
