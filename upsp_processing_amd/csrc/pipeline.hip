@@ -34,6 +34,7 @@ struct upsp_pipeline {
     int32_t *d_rowmap = nullptr;     // packed time-series rows (node -> row, < 0 = not stored), optional
     bool skipped_user = false, skipped_valid = false;
     double *d_sum = nullptr, *d_sumsq = nullptr;
+    size_t acc_stride = 0;          // d_sumsq = d_sum + acc_stride
     // hot-pixel scratch (per frame of a sub-batch)
     unsigned *d_hot_count = nullptr, *d_hot_pos = nullptr;
     int hot_capacity = 0;
@@ -157,11 +158,12 @@ int upsp_pipeline_create(int ncams, int width, int height, size_t nnodes,
         delete p;
         return fail(UPSP_ERR_INVALID, "filter_size must be odd");  // psp_process.cpp:1296
     }
-    hipError_t e = hipMalloc(&p->d_sum, sizeof(double) * nnodes);
-    if (e == hipSuccess) e = hipMalloc(&p->d_sumsq, sizeof(double) * nnodes);
+    // the two accumulators in ONE allocation (sumsq behind sum, 256-byte aligned): upsp_pipeline_reset is one fill
+    p->acc_stride = (nnodes + 31) & ~(size_t)31;
+    hipError_t e = hipMalloc(&p->d_sum, sizeof(double) * 2 * p->acc_stride);
+    if (e == hipSuccess) p->d_sumsq = p->d_sum + p->acc_stride;
     if (e == hipSuccess) e = hipMalloc(&p->d_skipped, nnodes);
-    if (e == hipSuccess) e = hipMemset(p->d_sum, 0, sizeof(double) * nnodes);
-    if (e == hipSuccess) e = hipMemset(p->d_sumsq, 0, sizeof(double) * nnodes);
+    if (e == hipSuccess) e = hipMemset(p->d_sum, 0, sizeof(double) * 2 * p->acc_stride);
     if (e == hipSuccess) e = hipMemset(p->d_skipped, 0, nnodes);
     if (e != hipSuccess) {
         upsp_pipeline_destroy(p);
@@ -202,8 +204,7 @@ void upsp_pipeline_destroy(upsp_pipeline *p)
     free_dev(p->d_skipped);
     free_dev(p->d_src);
     free_dev(p->d_rowmap);
-    free_dev(p->d_sum);
-    free_dev(p->d_sumsq);
+    free_dev(p->d_sum);             // (d_sumsq lives in the same allocation)
     free_dev(p->d_hot_count);
     free_dev(p->d_hot_pos);
     free_dev(p->d_pre_count);
@@ -407,8 +408,7 @@ int upsp_pipeline_set_ecc_iterations_out(upsp_pipeline *p, int32_t *d_iters)
 int upsp_pipeline_reset(upsp_pipeline *p)
 {
     if (!p) return fail(UPSP_ERR_INVALID, "null pipeline");
-    UPSP_HIP_CHECK(hipMemset(p->d_sum, 0, sizeof(double) * p->nnodes));
-    UPSP_HIP_CHECK(hipMemset(p->d_sumsq, 0, sizeof(double) * p->nnodes));
+    UPSP_HIP_CHECK(hipMemset(p->d_sum, 0, sizeof(double) * 2 * p->acc_stride));
     return UPSP_OK;
 }
 
