@@ -1096,9 +1096,30 @@ def main():
         drain()                         # (deferred exchange: the last step's series and sums, inside the timed region)
         barrier()
         dt = time.perf_counter() - t0
+    xcheck = None
     if chunked:
         for x in exchs:
             x.verify()                  # the travelling set did not change between the steps
+        # What came out of the exchange against this rank's own frames, on every rank: for a sample of the nodes this rank
+        # owns, the columns of ITS frames in the series slice must be frame[pix] (repaired frames; exact in every wire format)
+        # and the rows of nodes no ray sees NaN.  (The oracle comparison of rank 0 in a one-rank run checks values end to end;
+        # this one runs at any N and catches a block that landed in the wrong place.)
+        o = (ex_state["last_done"] if pixel_wire else exch).out
+        n0, nn = shard.my_nodes
+        ok = True
+        if nn > 0 and F > 0:
+            g = torch.Generator(device="cuda")
+            g.manual_seed(1234 + rank)
+            pick = torch.randperm(nn, generator=g, device="cuda")[:2048]
+            pp = last_pix[0][n0:n0 + nn].long()[pick]
+            vis = pp >= 0
+            want = frames.view(torch.int16).reshape(F, -1)[:, pp.clamp(min=0)].T.to(torch.float32)
+            got = o[pick][:, rank * F:(rank + 1) * F]
+            ok = bool(torch.equal(got[vis], want[vis])) and bool(torch.isnan(got[~vis]).all())
+        t = torch.tensor([1 if ok else 0], device="cuda", dtype=torch.int32)
+        if world > 1 or force_coll:
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        xcheck = bool(t.item())
     bvh.check()                         # no walk ran past its round cap (UPSP_ERR_INTERNAL otherwise)
     for e in ev_log:
         t_ray.append(e[0].elapsed_time(e[1]))
@@ -1274,6 +1295,8 @@ def main():
         "roofline": roof,
         "kernels": kernels,
     }
+    if chunked:
+        out["exchange_self_check"] = xcheck      # every rank: its own frames' columns of its series slice == frame[pix], NaN rows
     if world > 1 or force_coll:
         cr = D.comm_ranks()
         out["rccl_nranks"] = None if cr is None else cr[1]       # ncclCommCount of the communicator the exchanges ran on
@@ -1406,6 +1429,8 @@ def main():
             x.close()
     if world > 1 or force_coll:
         D.shutdown()
+    if xcheck is False:
+        raise SystemExit("bench.py: the series out of the exchange differ from this rank's frames on at least one rank")
 
 
 if __name__ == "__main__":

@@ -63,7 +63,7 @@ def test_bench_two_ranks_on_one_gpu_gloo(gpu_lib):
     (the RCCL run needs two GPUs: next test).  The exchange runs packed u16 rows in 4 chunks."""
     d = run_bench(["--gpus", "2", "--row-wire", "--small", "--steps", "2", "--warmup", "1"],
                   env={"UPSP_BENCH_BACKEND": "gloo", "UPSP_BENCH_ONE_GPU": "1"})
-    assert d["n_gpus"] == 2 and d["backend"] == "gloo"
+    assert d["n_gpus"] == 2 and d["backend"] == "gloo" and d["exchange_self_check"] is True
     assert d["config"]["exchange"] == "4 chunks, visible rows as u16"
     assert d["config"]["parallelism"] == "frames sharded x2"
 
@@ -96,7 +96,7 @@ def test_bench_pixel_wire(gpu_lib):
                   env={"UPSP_BENCH_BACKEND": "gloo", "UPSP_BENCH_ONE_GPU": "1"})
     # (deferred = the N > 1 default: one block per peer, pass A once for the rank's frames beside the projection build)
     once = "1 chunks, active-pixel series as u16; two exchanges in turn, a step's series finished behind the next step's chunks; pass A once"
-    assert d["n_gpus"] == 2 and d["config"]["exchange"].startswith(once)
+    assert d["n_gpus"] == 2 and d["config"]["exchange"].startswith(once) and d["exchange_self_check"] is True
     d = run_bench(["--force-chunked", "--defer-exchange", "--small", "--steps", "3", "--warmup", "1"], env={"UPSP_FORCE_COLLECTIVES": "1"})
     assert d["config"]["exchange"].startswith(once) and d["parity_checked"] is True
     assert d["rccl_nranks"] == 1
