@@ -669,3 +669,62 @@ def test_candidate_pixels_superset(gpu_lib):
             assert torch.equal(co[sub], cand[sub]) and int(sub.sum()) < int((cand >= 0).sum())
             assert int(sub.sum()) == engine.projection_counts(bvh)["primary_rays"]
         bvh.close()
+
+
+def test_pixel_series_on_prescanned_candidates(gpu_lib, oracle):
+    """upsp_pipeline_pixel_series after set_active_hint + prescan of the same frames (pass A beside the projection build, the
+    N > 1 loop of bench.py): pass A is not repeated, the nodes get their rows in the candidate map's buffer, the hot pixels are
+    repaired -- every node's series equals the repaired frame[pix], exactly like the series of a plain pixel_series call; a
+    prescan of OTHER frames is not consumed (the plain path runs), and a candidate set that misses a pixel shows up as -2."""
+    import torch
+    from upsp_processing_amd import _capi, engine, synthetic as syn
+    from upsp_processing_amd.engine import _DevArray
+    v, t = syn.tunnel_model_quad(40, 14)
+    s9, tn = syn.soup(v, t)
+    nrm = syn.node_normals(v, t)
+    W, H, F = 256, 192, 70
+    c = syn.pinhole_camera(W, H, center=(0.1, 0.2, 20), half_extent=5.0)
+    cam = _capi.make_camera(c["K"], c["dist"], c["R"], c["t"], W, H)
+    bvh = engine.BVH(s9)
+    pix = engine.build_projection(bvh, cam, v, nrm, tn, 70.0)["pix"]
+    vis = torch.nonzero(pix >= 0).reshape(-1)
+    frames0 = syn.synth_frames_numpy(F, H, W, seed=5, hot=False)
+    p_hot = int(pix[vis[len(vis) // 2]].item())
+    frames0[3].reshape(-1)[p_hot] = 4090                      # a hot pixel some node reads
+    frames0[40].reshape(-1)[int(pix[vis[7]].item())] = 4085
+    want = np.stack([oracle.fix_hot_pixels(f)[0] for f in frames0])
+
+    def series_of(pipe, ps, d):
+        comp = torch.as_tensor(_DevArray(ps["ptr"], ps["rows"] * ps["cpitch"], "<i2", pipe), device="cuda").view(ps["rows"], ps["cpitch"])
+        nk = ps["node_k"].long()
+        assert int((nk[vis] >= 0).all()) and int((nk[pix < 0] < 0).all())
+        got = comp[nk[vis]][:, :F].cpu().numpy().view(np.uint16)                    # [visible nodes, F]
+        assert np.array_equal(got.T, want.reshape(F, -1)[:, pix[vis].cpu().numpy()])
+        assert np.array_equal(d.cpu().view(torch.int16).numpy().view(np.uint16), want)   # frames repaired in place
+
+    for cand in (engine.candidate_pixels(cam, v), engine.candidate_pixels(cam, v, normals=nrm, oblique_angle_deg=70.0)):
+        pipe = engine.FramePipeline(1, W, H, v.shape[0])
+        d = torch.as_tensor(frames0.copy()).cuda()
+        pipe.set_active_hint(cand)
+        pipe.prescan(d)
+        pipe.set_projection(0, pix)
+        series_of(pipe, pipe.pixel_series(d), d)
+        # a prescan of other frames is not consumed: the call falls back to the projection's own map and runs pass A
+        d2 = torch.as_tensor(frames0.copy()).cuda()
+        pipe.set_active_hint(cand)
+        pipe.prescan(d)
+        series_of(pipe, pipe.pixel_series(d2), d2)
+        pipe.close()
+    # candidates that miss pixels: the nodes on them get -2 (upsp_exchange_set_pixels refuses such a table)
+    pipe = engine.FramePipeline(1, W, H, v.shape[0])
+    d = torch.as_tensor(frames0.copy()).cuda()
+    cand = engine.candidate_pixels(cam, v).clone()
+    cand[vis[::2]] = -1
+    pipe.set_active_hint(cand)
+    pipe.prescan(d)
+    pipe.set_projection(0, pix)
+    nk = pipe.pixel_series(d)["node_k"]
+    lost = ~torch.isin(pix[vis], cand[cand >= 0])
+    assert int(lost.sum()) > 0 and bool((nk[vis][lost] == -2).all()) and bool((nk[vis][~lost] >= 0).all())
+    pipe.close()
+    bvh.close()
