@@ -128,6 +128,7 @@ static unsigned px(int64_t k, int64_t f) { return (unsigned)((13 * k + 5 * f) % 
 
 // F, K: frames of the run and chunks per rank.  (240, 1): every rank's share is a multiple of four frames and goes out as ONE
 // block per peer -- the owner's pass B then reads the received blocks as they lie (no placing pass); (517, 3): ragged, placed.
+static int bad_count_global = 0;
 static int run_pixels(int W, const int64_t F, const int K)
 {
     int bad = 0;
@@ -143,6 +144,25 @@ static int run_pixels(int W, const int64_t F, const int K)
     HIPCHECK(hipMalloc(&d_nk, sizeof(int32_t) * N));
     HIPCHECK(hipMemcpy(d_sk, sk.data(), N, hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(d_nk, nk.data(), sizeof(int32_t) * N, hipMemcpyHostToDevice));
+    {
+        // a node table that points outside the series buffer (-2: a pixel the candidate map does not hold) is refused
+        std::vector<int32_t> bad(nk);
+        bad[N / 2] = -2;
+        int32_t *d_bad = nullptr;
+        HIPCHECK(hipMalloc(&d_bad, sizeof(int32_t) * N));
+        HIPCHECK(hipMemcpy(d_bad, bad.data(), sizeof(int32_t) * N, hipMemcpyHostToDevice));
+        std::vector<upsp_comm *> c1(1);
+        CHECK(upsp_comm_create_local(1, c1.data()));
+        upsp_exchange *x1 = nullptr;
+        CHECK(upsp_exchange_create(c1[0], F, N, K, &x1));
+        if (upsp_exchange_set_pixels(x1, d_bad, d_sk, 0, nullptr) == UPSP_OK) {
+            std::fprintf(stderr, "pixels: a node row of -2 was accepted\n");
+            ++bad_count_global;
+        }
+        upsp_exchange_destroy(x1);
+        upsp_comm_destroy(c1[0]);
+        HIPCHECK(hipFree(d_bad));
+    }
     for (int wire : {2, 12}) {
         std::vector<upsp_comm *> comms(W);
         CHECK(upsp_comm_create_local(W, comms.data()));
@@ -219,7 +239,7 @@ static int run_pixels(int W, const int64_t F, const int K)
             upsp_comm_destroy(comms[r]);
         }
     }
-    return bad;
+    return bad + bad_count_global;
 }
 
 int main(int argc, char **argv)
