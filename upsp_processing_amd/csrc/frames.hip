@@ -590,8 +590,8 @@ __global__ void __launch_bounds__(WAVES * 64)
 //   * hot pixels: pass A cannot know a frame's count before the whole frame has gone by, so the passes
 //     project the pixels as they are; hot_repair_kernel then repairs the (rare) frames with
 //     1..max_hot hot pixels in place exactly like fix_frame and lists the replaced pixels, and
-//     hot_patch_kernel re-projects them (through pixel -> node lists built only when a call replaced
-//     something): series entry and accumulators of every node on such a pixel.
+//     hot_patch_nodes_kernel re-projects them (every node looks its pixel up in the call's dense change list, only in
+//     calls that replaced something): series entry and accumulators of every node on such a pixel.
 //     All values are integers < 2^16 (squares rounded to float like the gather's), their double sums
 //     are exact, so "add new - old" gives the same bits as summing the repaired values.
 constexpr int kFusedPix = 128;     // pixels per tile
@@ -1249,7 +1249,7 @@ __global__ void __launch_bounds__(256)
 }
 
 // Frames with 1..max_hot hot pixels: repair in place (same code as the scan kernel's pass 2) and
-// list the replaced pixels as (frame, position, old, new) for hot_patch_kernel.  One lane per frame;
+// list the replaced pixels as (frame, position, old, new) for the patch kernels.  One lane per frame;
 // frame f owns slots [f * max_hot, (f + 1) * max_hot) of the list (a frame replaces at most max_hot
 // pixels), nch[f] = how many it filled -- no cap, no order that depends on the atomics.
 // *ntotal (zero on entry) counts the changes of the call: the list kernels below return at once when
@@ -1257,7 +1257,8 @@ __global__ void __launch_bounds__(256)
 __device__ __forceinline__ void
     hot_repair_frame(size_t f, uint16_t *frames, size_t npix, int rows, int cols, int min_change,
                      int max_hot, unsigned *__restrict__ count, const unsigned *__restrict__ pos,
-                     unsigned *__restrict__ ntotal, unsigned *__restrict__ nch, uint4 *__restrict__ changes)
+                     unsigned *__restrict__ ntotal, unsigned *__restrict__ nch, uint4 *__restrict__ changes,
+                     uint4 *__restrict__ clist = nullptr)
 {
     const unsigned n = count[f];
     nch[f] = 0u;
@@ -1281,67 +1282,73 @@ __device__ __forceinline__ void
         if (newv != oldv) changes[f * (size_t)max_hot + m++] = make_uint4((unsigned)f, p[i], oldv, newv);
     }
     nch[f] = m;
-    if (m) atomicAdd(ntotal, m);
+    if (m) {
+        // clist (optional): the same records once more, DENSE, in whatever order the frames get here (hot_patch_nodes_kernel
+        // looks every node's pixel up in them; a (pixel, frame) pair changes at most once, so the order does not matter)
+        const unsigned base = atomicAdd(ntotal, m);
+        if (clist)
+            for (unsigned j = 0; j < m; ++j) clist[base + j] = changes[f * (size_t)max_hot + j];
+    }
 }
 __global__ void __launch_bounds__(64)
     hot_repair_kernel(uint16_t *frames, size_t npix, int nframes, int rows, int cols, int min_change,
                       int max_hot, unsigned *__restrict__ count, const unsigned *__restrict__ pos,
-                      unsigned *__restrict__ ntotal, unsigned *__restrict__ nch, uint4 *__restrict__ changes)
+                      unsigned *__restrict__ ntotal, unsigned *__restrict__ nch, uint4 *__restrict__ changes,
+                      uint4 *__restrict__ clist)
 {
     const size_t f = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= (size_t)nframes) return;
-    hot_repair_frame(f, frames, npix, rows, cols, min_change, max_hot, count, pos, ntotal, nch, changes);
+    hot_repair_frame(f, frames, npix, rows, cols, min_change, max_hot, count, pos, ntotal, nch, changes, clist);
 }
 
-// Pixel -> nodes lists for the re-projection (built only in calls that replaced a pixel): head[p] =
-// a node reading pixel p (-1: none), next[n] = the next node on the same pixel.  The order inside a
-// list depends on the atomics; the patches of different nodes are independent of each other.
+// Re-projection of the replaced pixels: every node reading one gets its series entry and its accumulators corrected.
+// One lane per NODE; a workgroup loads the call's dense change list (<= 512 records at a time) into a small hash table in
+// LDS keyed by the pixel, and every node looks its own pixel up -- one launch where round 2-3 had three (lists init, lists
+// build over all nodes with an atomic each, patch per change).  A node's accumulators are touched by its own lane only;
+// every term is an integer-valued double far below 2^53, so the order of a pixel's records does not matter.
+constexpr int kHotHashSlots = 1024, kHotHashChunk = 512;
 __global__ void __launch_bounds__(256)
-    hot_lists_init_kernel(const unsigned *__restrict__ ntotal, int32_t *__restrict__ head, size_t npix)
+    hot_patch_nodes_kernel(const unsigned *__restrict__ ntotal, const uint4 *__restrict__ clist,
+                           const int32_t *__restrict__ pix, unsigned nnodes, const uint8_t *__restrict__ skipped,
+                           const int32_t *__restrict__ rowmap, float *__restrict__ rows_t, uint16_t *__restrict__ rows_t16,
+                           long long ld_t, double *__restrict__ sum, double *__restrict__ sumsq)
 {
-    if (*ntotal == 0u) return;                 // (uniform)
-    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < npix) head[p] = -1;
-}
-__global__ void __launch_bounds__(256)
-    hot_lists_build_kernel(const unsigned *__restrict__ ntotal, const int32_t *__restrict__ pix, unsigned nnodes,
-                           int32_t *__restrict__ head, int32_t *__restrict__ next)
-{
-    if (*ntotal == 0u) return;                 // (uniform)
+    const unsigned nt = *ntotal;
+    if (nt == 0u) return;                      // (uniform) nearly every call
+    __shared__ int hhead[kHotHashSlots];
+    __shared__ int hnext[kHotHashChunk];
+    __shared__ unsigned hpix[kHotHashChunk];
     const unsigned n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= nnodes) return;
-    const int32_t p = pix[n];
-    if (p >= 0) next[n] = atomicExch(&head[p], (int32_t)n);
-}
-
-// Re-projection of the replaced pixels: every node reading one gets its series entry and its
-// accumulators corrected.  One lane per change slot.  A pixel that is hot in many frames of the
-// call (a stuck pixel) has many lanes on the same node: the accumulators move by atomics -- every
-// term is an integer-valued double far below 2^53, so the result does not depend on their order.
-__global__ void __launch_bounds__(256)
-    hot_patch_kernel(const unsigned *__restrict__ ntotal, const unsigned *__restrict__ nch,
-                     const uint4 *__restrict__ changes, int nframes, int max_hot,
-                     const int32_t *__restrict__ head, const int32_t *__restrict__ next,
-                     const uint8_t *__restrict__ skipped, const int32_t *__restrict__ rowmap,
-                     float *__restrict__ rows_t, uint16_t *__restrict__ rows_t16, long long ld_t,
-                     double *__restrict__ sum, double *__restrict__ sumsq)
-{
-    if (*ntotal == 0u) return;                 // (uniform) nearly every call
-    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (unsigned)nframes * (unsigned)max_hot) return;
-    const unsigned f = i / (unsigned)max_hot;
-    if (i - f * (unsigned)max_hot >= nch[f]) return;
-    const uint4 ch = changes[i];
-    const float xo = (float)ch.z, xn = (float)ch.w;
-    const double ds = (double)xn - (double)xo, dss = (double)(xn * xn) - (double)(xo * xo);
-    for (int32_t n = head[ch.y]; n >= 0; n = next[n]) {
-        if (skipped && skipped[n]) continue;                  // stays NaN
-        unsafeAtomicAdd(&sum[n], ds);
-        unsafeAtomicAdd(&sumsq[n], dss);
-        const long long row = rowmap ? (long long)rowmap[n] : (long long)n;
-        if (row < 0) continue;
-        if (rows_t) rows_t[row * ld_t + (long long)ch.x] = xn;
-        else rows_t16[row * ld_t + (long long)ch.x] = (uint16_t)ch.w;
+    const int32_t p = n < nnodes ? pix[n] : -1;
+    const bool mine = p >= 0 && !(skipped && skipped[n]);       // skipped: stays NaN
+    const long long row = !mine ? -1 : (rowmap ? (long long)rowmap[n] : (long long)n);
+    double ds = 0.0, dss = 0.0;
+    for (unsigned base = 0; base < nt; base += kHotHashChunk) {
+        const unsigned cnt = min((unsigned)kHotHashChunk, nt - base);
+        for (int i = threadIdx.x; i < kHotHashSlots; i += 256) hhead[i] = -1;
+        __syncthreads();
+        for (unsigned i = threadIdx.x; i < cnt; i += 256) {
+            const unsigned q = clist[base + i].y;
+            hpix[i] = q;
+            hnext[i] = atomicExch(&hhead[(q * 2654435761u) >> 22], (int)i);
+        }
+        __syncthreads();
+        if (mine)
+            for (int i = hhead[((unsigned)p * 2654435761u) >> 22]; i >= 0; i = hnext[i]) {
+                if (hpix[i] != (unsigned)p) continue;
+                const uint4 ch = clist[base + i];
+                const float xo = (float)ch.z, xn = (float)ch.w;
+                ds += (double)xn - (double)xo;
+                dss += (double)(xn * xn) - (double)(xo * xo);
+                if (row < 0) continue;
+                if (rows_t) rows_t[row * ld_t + (long long)ch.x] = xn;
+                else rows_t16[row * ld_t + (long long)ch.x] = (uint16_t)ch.w;
+            }
+        __syncthreads();
+    }
+    if (mine && (ds != 0.0 || dss != 0.0)) {
+        sum[n] += ds;
+        sumsq[n] += dss;
     }
 }
 
@@ -1830,29 +1837,25 @@ int launch_node_rows_multi(const PipelineGather &g, const int32_t *const *d_node
 // up to a multiple of 4 + 4 * nframes * max_hot words (hot_changes_words()); d_head [npix], d_next [nnodes].
 size_t hot_changes_words(int nframes, int max_hot)
 {
-    return 4 + (((size_t)nframes + 3) & ~(size_t)3) + 4 * (size_t)nframes * (size_t)std::max(max_hot, 1);
+    // counters (4) + changes per frame (rounded to 4) + the per-frame record slots + the same records once more, dense
+    return 4 + (((size_t)nframes + 3) & ~(size_t)3) + 8 * (size_t)nframes * (size_t)std::max(max_hot, 1);
 }
 int launch_hot_fixup(const PipelineGather &g, uint16_t *d_frames, int nframes, int rows, int cols,
                      int min_change, int max_hot, unsigned *d_count, const unsigned *d_pos,
-                     unsigned *d_changes, int32_t *d_head, int32_t *d_next, hipStream_t st)
+                     unsigned *d_changes, hipStream_t st)
 {
     if (nframes <= 0) return UPSP_OK;
     KTimed kt("hot_fixup_kernels", st);
     unsigned *nch = d_changes + 4;
     uint4 *list = reinterpret_cast<uint4 *>(d_changes + 4 + (((size_t)nframes + 3) & ~(size_t)3));
+    uint4 *clist = list + (size_t)nframes * (size_t)std::max(max_hot, 1);
     hipLaunchKernelGGL(hot_patch_reset_kernel, dim3(1), dim3(1), 0, st, d_changes);
     hipLaunchKernelGGL(hot_repair_kernel, dim3((unsigned)((nframes + 63) / 64)), dim3(64), 0, st, d_frames, g.npix,
-                       nframes, rows, cols, min_change, max_hot, d_count, d_pos, d_changes, nch, list);
-    if (max_hot > 0) {
-        hipLaunchKernelGGL(hot_lists_init_kernel, dim3((unsigned)((g.npix + 255) / 256)), dim3(256), 0, st,
-                           (const unsigned *)d_changes, d_head, g.npix);
-        hipLaunchKernelGGL(hot_lists_build_kernel, dim3((unsigned)((g.nnodes + 255) / 256)), dim3(256), 0, st,
-                           (const unsigned *)d_changes, g.pix[0], (unsigned)g.nnodes, d_head, d_next);
-        hipLaunchKernelGGL(hot_patch_kernel, dim3((unsigned)(((size_t)nframes * max_hot + 255) / 256)), dim3(256), 0, st,
-                           (const unsigned *)d_changes, (const unsigned *)nch, (const uint4 *)list, nframes, max_hot,
-                           (const int32_t *)d_head, (const int32_t *)d_next, g.skipped, g.rowmap, g.rows_t, g.rows_t16,
-                           (long long)g.ld_t, g.sum, g.sumsq);
-    }
+                       nframes, rows, cols, min_change, max_hot, d_count, d_pos, d_changes, nch, list, clist);
+    if (max_hot > 0)
+        hipLaunchKernelGGL(hot_patch_nodes_kernel, dim3((unsigned)((g.nnodes + 255) / 256)), dim3(256), 0, st,
+                           (const unsigned *)d_changes, (const uint4 *)clist, g.pix[0], (unsigned)g.nnodes, g.skipped, g.rowmap,
+                           g.rows_t, g.rows_t16, (long long)g.ld_t, g.sum, g.sumsq);
     UPSP_HIP_CHECK(hipGetLastError());
     return UPSP_OK;
 }
@@ -1874,7 +1877,7 @@ int launch_hot_repair_compact(uint16_t *d_frames, size_t npix, int nframes, int 
     uint4 *list = reinterpret_cast<uint4 *>(d_changes + 4 + (((size_t)nframes + 3) & ~(size_t)3));
     hipLaunchKernelGGL(hot_patch_reset_kernel, dim3(1), dim3(1), 0, st, d_changes);
     hipLaunchKernelGGL(hot_repair_kernel, dim3((unsigned)((nframes + 63) / 64)), dim3(64), 0, st, d_frames, npix, nframes,
-                       rows, cols, min_change, max_hot, d_count, d_pos, d_changes, nch, list);
+                       rows, cols, min_change, max_hot, d_count, d_pos, d_changes, nch, list, (uint4 *)nullptr);
     if (max_hot > 0)
         hipLaunchKernelGGL(hot_patch_compact_kernel, dim3((unsigned)(((size_t)nframes * max_hot + 255) / 256)), dim3(256), 0, st,
                            (const unsigned *)d_changes, (const unsigned *)nch, (const uint4 *)list, nframes, max_hot, d_flag,
@@ -1895,7 +1898,7 @@ int launch_hot_repair_list(uint16_t *d_frames, size_t npix, int nframes, int row
     unsigned *nch = d_changes + 4;
     uint4 *list = reinterpret_cast<uint4 *>(d_changes + 4 + (((size_t)nframes + 3) & ~(size_t)3));
     hipLaunchKernelGGL(hot_repair_kernel, dim3((unsigned)((nframes + 63) / 64)), dim3(64), 0, st, d_frames, npix, nframes,
-                       rows, cols, min_change, max_hot, d_count, d_pos, d_changes, nch, list);
+                       rows, cols, min_change, max_hot, d_count, d_pos, d_changes, nch, list, (uint4 *)nullptr);
     UPSP_HIP_CHECK(hipGetLastError());
     return UPSP_OK;
 }

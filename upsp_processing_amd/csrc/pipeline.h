@@ -55,7 +55,7 @@ int launch_node_rows_multi(const PipelineGather &g, const int32_t *const *d_node
 size_t hot_changes_words(int nframes, int max_hot);   // size of d_changes for launch_hot_fixup
 int launch_hot_fixup(const PipelineGather &g, uint16_t *d_frames, int nframes, int rows, int cols,
                      int min_change, int max_hot, unsigned *d_count, const unsigned *d_pos,
-                     unsigned *d_changes, int32_t *d_head, int32_t *d_next, hipStream_t st);
+                     unsigned *d_changes, hipStream_t st);
 int launch_hot_repair_compact(uint16_t *d_frames, size_t npix, int nframes, int rows, int cols, int min_change, int max_hot,
                               unsigned *d_count, const unsigned *d_pos, unsigned *d_changes, const uint8_t *d_flag,
                               const unsigned *d_tile_off, uint16_t *d_compact, unsigned cpitch, hipStream_t st);

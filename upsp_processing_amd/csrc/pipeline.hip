@@ -488,21 +488,6 @@ static int streamed_buffers(upsp_pipeline *p, size_t npix, int nframes, hipStrea
             UPSP_HIP_CHECK(hipMalloc(&p->d_changes, sizeof(unsigned) * words));
             p->changes_words = words;
         }
-        if (p->head_elems < npix) {
-            if (p->d_head) UPSP_HIP_CHECK(hipStreamSynchronize(st));
-            free_dev(p->d_head);
-            p->d_head = nullptr;
-            UPSP_HIP_CHECK(hipMalloc(&p->d_head, sizeof(int32_t) * npix));
-            p->head_elems = npix;
-            p->head_clean = false;
-        }
-        if (p->next_elems < p->nnodes) {
-            if (p->d_next) UPSP_HIP_CHECK(hipStreamSynchronize(st));
-            free_dev(p->d_next);
-            p->d_next = nullptr;
-            UPSP_HIP_CHECK(hipMalloc(&p->d_next, sizeof(int32_t) * p->nnodes));
-            p->next_elems = p->nnodes;
-        }
     }
     *S_out = S;
     *cp_out = cp;
@@ -749,8 +734,7 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
             g.rows_t = d_rows_t ? d_rows_t + col0 : nullptr;
             g.rows_t16 = d_rows_t16 ? d_rows_t16 + col0 : nullptr;
             rc = launch_hot_fixup(g, fr, nframes, p->height, p->width, p->opts.hot_min_change, p->opts.hot_max,
-                                  p->d_hot_count, p->d_hot_pos, p->d_changes, p->d_head, p->d_next, st);
-            p->head_clean = false;    // (this path initialises the lists for every pixel)
+                                  p->d_hot_count, p->d_hot_pos, p->d_changes, st);
         }
         return rc;
     }
