@@ -597,7 +597,8 @@ __global__ void __launch_bounds__(WAVES * 64)
 constexpr int kFusedPix = 128;     // pixels per tile
 constexpr int kFusedPitch = 65;    // dwords per LDS row: 64 (128 px) + 1 pad
 
-// active-pixel map, step 1: flag[pixel] = 1 for pixels some node reads (flag zeroed by the caller)
+// active-pixel map, step 1: flag[pixel] = 1 for pixels some node reads.  The flags need no clearing between two maps: after
+// step 2 every flag is 0 or 0x80 | rank, never 1 (the caller zeroes the array once, when it allocates it)
 __global__ void __launch_bounds__(256)
     amap_mark_kernel(const int32_t *__restrict__ pix, unsigned nnodes, uint8_t *__restrict__ flag)
 {
@@ -615,12 +616,12 @@ __global__ void __launch_bounds__(256)
     __shared__ unsigned wave_cnt[4];
     const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool act = p < npix && flag[p] != 0;
+    const bool act = p < npix && flag[p] == 1;                      // (marked in step 1; 0x80 | rank of the previous map: not)
     const unsigned long long m = __ballot(act);
     if (lane == 0) wave_cnt[wave] = (unsigned)__popcll(m);
     __syncthreads();
     const unsigned before = (wave & 1) ? wave_cnt[wave - 1] : 0u;   // first half of the same tile
-    if (act) flag[p] = (uint8_t)(0x80u | (before + (unsigned)__popcll(m & ((1ull << lane) - 1ull))));
+    if (p < npix) flag[p] = act ? (uint8_t)(0x80u | (before + (unsigned)__popcll(m & ((1ull << lane) - 1ull)))) : (uint8_t)0;
     if (lane == 0 && !(wave & 1)) {
         const size_t tile = (size_t)blockIdx.x * 2 + (wave >> 1);
         if (tile * kFusedPix < npix) tile_cnt[tile] = wave_cnt[wave] + wave_cnt[wave + 1];
@@ -1698,7 +1699,6 @@ int launch_amap_build(const int32_t *d_pix, size_t nnodes, size_t npix, uint8_t 
 {
     const unsigned ntiles = (unsigned)tilemap_tiles(npix);
     KTimed kt("amap_build", st);
-    UPSP_HIP_CHECK(hipMemsetAsync(d_flag, 0, npix, st));
     const dim3 g((unsigned)((nnodes + 255) / 256)), b(256);
     hipLaunchKernelGGL(amap_mark_kernel, g, b, 0, st, d_pix, (unsigned)nnodes, d_flag);
     hipLaunchKernelGGL(amap_rank_kernel, dim3((unsigned)((npix + 255) / 256)), b, 0, st, d_flag, npix, d_cnt);

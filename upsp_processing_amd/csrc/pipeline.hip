@@ -426,7 +426,10 @@ static int streamed_map(upsp_pipeline *p, const int32_t *d_pix_src, size_t npix,
 {
     if (p->tilemap_valid) return UPSP_OK;
     const size_t ntiles = tilemap_tiles(npix);
-    if (!p->d_aflag) UPSP_HIP_CHECK(hipMalloc(&p->d_aflag, npix));
+    if (!p->d_aflag) {
+        UPSP_HIP_CHECK(hipMalloc(&p->d_aflag, npix));
+        UPSP_HIP_CHECK(hipMemset(p->d_aflag, 0, npix));      // (once: launch_amap_build leaves the flags in a state it can start from)
+    }
     if (!p->d_tile_off) UPSP_HIP_CHECK(hipMalloc(&p->d_tile_off, sizeof(unsigned) * (ntiles + 1)));
     if (!p->d_tile_cnt) UPSP_HIP_CHECK(hipMalloc(&p->d_tile_cnt, sizeof(unsigned) * ntiles));
     if (!p->d_node_k) UPSP_HIP_CHECK(hipMalloc(&p->d_node_k, sizeof(int32_t) * p->nnodes));
@@ -887,7 +890,10 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
                 p->m_compact_bytes[c] = nact * cp * 2;
             }
             if (p->m_valid[c]) continue;
-            if (!p->m_aflag[c]) UPSP_HIP_CHECK(hipMalloc(&p->m_aflag[c], npix));
+            if (!p->m_aflag[c]) {
+                UPSP_HIP_CHECK(hipMalloc(&p->m_aflag[c], npix));
+                UPSP_HIP_CHECK(hipMemset(p->m_aflag[c], 0, npix));
+            }
             if (!p->m_tile_off[c]) UPSP_HIP_CHECK(hipMalloc(&p->m_tile_off[c], sizeof(unsigned) * (ntiles + 1)));
             if (!p->d_tile_cnt) UPSP_HIP_CHECK(hipMalloc(&p->d_tile_cnt, sizeof(unsigned) * ntiles));
             if (!p->m_node_k[c]) UPSP_HIP_CHECK(hipMalloc(&p->m_node_k[c], sizeof(int32_t) * p->nnodes));
