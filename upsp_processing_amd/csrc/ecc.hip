@@ -1008,9 +1008,12 @@ int run_ecc(FrameScratch *s, const float *tmpl_blur, const float *d_center, cons
     // Workgroups per frame: one count per image geometry.  The float segments follow the row pieces, i.e. the block count:
     // it must not depend on how many frames are still iterating, or the last bits of a frame's sums -- and through the
     // reference's float 6 x 6 solve 1e-5 .. 1e-4 px of its warp -- would depend on which frames share its sub-batch.
-    // Every block ends with a reduction of the 45 sums that costs as much as ~10 rows of its 256 columns: 64 interior blocks
-    // per frame (4 column tiles x 16 row pieces of 64 rows at 1024^2; measured 16 / 32 / 64: 6.74 / 6.25 / 6.03 ms of sums
-    // per 1000 frames in round 3), at least one per column tile.
+    // Every block ends with a reduction of the 45 sums that costs as much as ~10 rows of its 256 columns.  32 interior blocks
+    // per frame (4 column tiles x 8 row pieces of 128 rows at 1024^2) + 16 band blocks: with 256-frame sub-batches a launch
+    // has 12 288 workgroups either way, and the fewer epilogues win -- ms per 1000 frames of configs[2] at (interior, band)
+    // = (64, 48) / (32, 24) / (32, 16) / (16, 12) / (8, 12): 7.47 / 7.29 / 7.23 / 7.26 / 7.35.  (Round 3, 64-frame launches:
+    // 16 / 32 / 64 interior blocks gave 6.74 / 6.25 / 6.03 ms of sums -- there the chip needed the blocks.)  At least one
+    // interior block per column tile.
     const int tiles = (cols + 255) / 256;
     const int blocks = std::max(kEccInteriorBlocks, tiles);
     const int nband = std::max(kEccBandBlocks, 3 * tiles);

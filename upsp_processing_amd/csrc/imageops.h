@@ -14,9 +14,9 @@ namespace upsp {
 
 // partial sums of one ECC iteration: per frame and sum one slot per workgroup -- band blocks first, then interior blocks
 constexpr int kEccSums = 45;
-constexpr int kEccInteriorBlocks = 64;    // interior workgroups per frame (one count per image geometry: see run_ecc)
+constexpr int kEccInteriorBlocks = 32;    // interior workgroups per frame (one count per image geometry: see run_ecc)
 constexpr int kEccInteriorMax = 512;      // ... at most (images wider than 64 column tiles of 256)
-constexpr int kEccBandBlocks = 48;        // band workgroups per frame, 3 x column tiles of 256 at least
+constexpr int kEccBandBlocks = 16;        // band workgroups per frame, 3 x column tiles of 256 at least
 constexpr int kEccBandMax = 3 * 128;      // ... at most (columns < 32768)
 constexpr int kEccStride = kEccInteriorMax + kEccBandMax;   // slots per (frame, sum)
 
