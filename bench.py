@@ -826,8 +826,9 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d" % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    # rehearsal of the N > 1 code path on a one-GPU box: UPSP_BENCH_BACKEND=gloo with every rank on
-    # cuda:0 (UPSP_BENCH_ONE_GPU=1).  The driver's runs use RCCL, one rank per GPU.
+    # rehearsal of the N > 1 code path on a one-GPU box (tests): UPSP_BENCH_BACKEND=gloo for torch.distributed's rendezvous with every
+    # rank on cuda:0 (UPSP_BENCH_ONE_GPU=1) and UPSP_RCCL_LIBRARY naming an RCCL that accepts that (tests/shim).  The driver's runs
+    # use RCCL, one rank per GPU.
     backend = os.environ.get("UPSP_BENCH_BACKEND", "nccl")
     if os.environ.get("UPSP_BENCH_ONE_GPU"):
         local = 0
@@ -854,6 +855,9 @@ def main():
             torch.cuda.synchronize()
             if int(probe.item()) != world:
                 raise RuntimeError("all_reduce over %d ranks returned %g" % (world, float(probe.item())))
+            # the library's own communicator (upsp_comm_create from an id broadcast over the group): the exchanges of this run have
+            # no other path -- if it does not come up on every rank the run ends here
+            D.lib_comm()
         except Exception as e:                                   # noqa: BLE001
             print("bench.py: rank %d of %d could not join the %s process group: %s: %s" % (rank, world, backend, type(e).__name__, e),
                   file=sys.stderr, flush=True)
@@ -1252,7 +1256,9 @@ def main():
         "metric": "frames/s", "value": fps, "unit": "frames/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-        "data": "synthetic", **({"backend": backend} if world > 1 and backend != "nccl" else {}),
+        "data": "synthetic", **({"rendezvous_backend": backend} if world > 1 and backend != "nccl" else {}),
+        # (set only by the tests: a stand-in RCCL that lets several rank processes share one GPU -- such a line is not a measurement)
+        **({"rccl_library": os.environ["UPSP_RCCL_LIBRARY"]} if os.environ.get("UPSP_RCCL_LIBRARY") else {}),
         **({"collectives": "issued through %s in a one-rank group" % ("RCCL" if backend == "nccl" else backend)} if force_coll else {}),
         "config": {"workload": "configs[%d]: %d frames/GPU x %dx%d u16, %d-tri tunnel model (%d nodes), "
                                "raycast+%sprojection" % (2 if a.registration else 1, F, size, size,
@@ -1312,8 +1318,7 @@ def main():
             "packed_series_bytes_per_rank": int(series_rows * F * wire_bytes),
             "leaves_the_gpu_at_8_ranks": int(series_rows * F * wire_bytes * 7 / 8),
             "sent_to_other_ranks_this_run": None if xb is None else xb[0],
-            "transport": ("C ABI upsp_exchange_* over RCCL" if (world > 1 or force_coll) else "C ABI upsp_exchange_*, one rank in process (device copies)")
-                         if xb is not None else "torch.distributed (%s)" % backend}
+            "transport": ("C ABI upsp_exchange_* over RCCL" if (world > 1 or force_coll) else "C ABI upsp_exchange_*, one rank in process (device copies)")}
     if a.registration:
         out["ecc_iterations_per_frame"] = ecc_iters_per_frame
     if world == 1 and not a.registration and not a.no_reraycast:

@@ -32,6 +32,31 @@ def gpu_lib():
     return L
 
 
+def build_rccl_shim():
+    """tests/shim/librccl_shim.so: the stand-in RCCL that lets several rank PROCESSES share one GPU (test infrastructure;
+    libupsp_gpu.so binds it only when UPSP_RCCL_LIBRARY names it)."""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "shim", "rccl_shim.cpp")
+    out = os.path.join(ROOT, "tests", "shim", "librccl_shim.so")
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O1", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, src, "-lrt"])
+    return out
+
+
+@pytest.fixture(scope="session")
+def rccl_shim():
+    return build_rccl_shim()
+
+
+def one_gpu_ranks_env(shim):
+    """Environment of a multi-rank child job on a ONE-GPU box: every rank on cuda:0, torch.distributed's rendezvous over gloo,
+    the library's exchange through the stand-in RCCL.  Two or more GPUs: nothing (real RCCL, one rank per GPU)."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        return {}
+    return {"UPSP_BACKEND": "gloo", "UPSP_ONE_GPU": "1", "UPSP_BENCH_BACKEND": "gloo", "UPSP_BENCH_ONE_GPU": "1", "UPSP_RCCL_LIBRARY": shim}
+
+
 @pytest.fixture(scope="session")
 def fml(oracle):
     """fml_tc3_volume.grid fixture of the reference's test suite, prepared like

@@ -58,12 +58,13 @@ def test_bench_multi_camera_line(gpu_lib):
     assert d["roofline"]["bound"] == "hbm" and d["cpu_baseline"]["kind"] == "port"
 
 
-def test_bench_two_ranks_on_one_gpu_gloo(gpu_lib):
-    """`--gpus 2` launches its own two ranks; on a one-GPU box both sit on cuda:0 and talk through gloo
-    (the RCCL run needs two GPUs: next test).  The exchange runs packed u16 rows in 4 chunks."""
-    d = run_bench(["--gpus", "2", "--row-wire", "--small", "--steps", "2", "--warmup", "1"],
-                  env={"UPSP_BENCH_BACKEND": "gloo", "UPSP_BENCH_ONE_GPU": "1"})
-    assert d["n_gpus"] == 2 and d["backend"] == "gloo" and d["exchange_self_check"] is True
+def test_bench_two_ranks_on_one_gpu(gpu_lib, rccl_shim):
+    """`--gpus 2` launches its own two ranks; on a one-GPU box both sit on cuda:0, torch.distributed's rendezvous runs over gloo and
+    the library's exchange (the RCCL branch of csrc/exchange.hip) through the tests' stand-in RCCL.  Packed u16 rows in 4 chunks."""
+    from conftest import one_gpu_ranks_env
+    d = run_bench(["--gpus", "2", "--row-wire", "--small", "--steps", "2", "--warmup", "1"], env=one_gpu_ranks_env(rccl_shim))
+    assert d["n_gpus"] == 2 and d["exchange_self_check"] is True and d["rccl_nranks"] == 2
+    assert d["exchange_bytes_per_step"]["transport"].startswith("C ABI") and d["exchange_bytes_per_step"]["sent_to_other_ranks_this_run"] > 0
     assert d["config"]["exchange"] == "4 chunks, visible rows as u16"
     assert d["config"]["parallelism"] == "frames sharded x2"
 
@@ -78,10 +79,12 @@ def test_bench_rccl_one_rank_group(gpu_lib):
     assert d["parity_checked"] is True
 
 
-def test_bench_pixel_wire(gpu_lib):
+def test_bench_pixel_wire(gpu_lib, rccl_shim):
     """The default of the N > 1 loop: the active pixels' series travel and the owner of a node runs pass B over all frames -- through the
-    C-ABI exchange over RCCL (one-rank group) and over gloo with two ranks on this GPU; the series that come out are
-    compared with the oracle in the run (one rank) like the row exchange's."""
+    C-ABI exchange over RCCL (one-rank group) and between two rank processes on this GPU (stand-in RCCL); the series that come
+    out are compared with the oracle in the run (one rank) like the row exchange's."""
+    from conftest import one_gpu_ranks_env
+    two = one_gpu_ranks_env(rccl_shim)
     d = run_bench(["--force-chunked", "--small", "--steps", "2", "--warmup", "1"], env={"UPSP_FORCE_COLLECTIVES": "1"})
     assert d["config"]["exchange"] == "1 chunks, active-pixel series as u16; pass A once for the rank's frames beside the projection build"
     assert d["parity_checked"] is True
@@ -92,8 +95,8 @@ def test_bench_pixel_wire(gpu_lib):
     assert x["travelling_rows"] < d2["exchange_bytes_per_step"]["travelling_rows"]          # fewer pixel rows than node rows
     # two ranks: two exchanges in turn (a step's series are finished behind the next step's chunks; the last one before the
     # clock stops) -- and the same schedule forced on one rank through RCCL, parity checked against the oracle in the run
-    d = run_bench(["--gpus", "2", "--small", "--steps", "3", "--warmup", "1"],
-                  env={"UPSP_BENCH_BACKEND": "gloo", "UPSP_BENCH_ONE_GPU": "1"})
+    d = run_bench(["--gpus", "2", "--small", "--steps", "3", "--warmup", "1"], env=two)
+    assert d["rccl_nranks"] == 2 and d["exchange_bytes_per_step"]["sent_to_other_ranks_this_run"] > 0
     # (deferred = the N > 1 default: one block per peer, pass A once for the rank's frames beside the projection build)
     once = "1 chunks, active-pixel series as u16; two exchanges in turn, a step's series finished behind the next step's chunks; pass A once"
     assert d["n_gpus"] == 2 and d["config"]["exchange"].startswith(once) and d["exchange_self_check"] is True
@@ -109,8 +112,7 @@ def test_bench_pixel_wire(gpu_lib):
     d = run_bench(["--force-chunked", "--sync-exchange", "--chunk-scan", "--small", "--steps", "2", "--warmup", "1"], env={"UPSP_FORCE_COLLECTIVES": "1"})
     assert d["config"]["exchange"] == "4 chunks, active-pixel series as u16; pass A per chunk after the projection build"
     assert d["parity_checked"] is True
-    d = run_bench(["--gpus", "2", "--small", "--steps", "2", "--warmup", "1", "--sync-exchange"],
-                  env={"UPSP_BENCH_BACKEND": "gloo", "UPSP_BENCH_ONE_GPU": "1"})
+    d = run_bench(["--gpus", "2", "--small", "--steps", "2", "--warmup", "1", "--sync-exchange"], env=two)
     assert d["config"]["exchange"] == "1 chunks, active-pixel series as u16; pass A once for the rank's frames beside the projection build"
 
 
@@ -121,3 +123,18 @@ def test_bench_two_ranks_rccl(gpu_lib):
     d = run_bench(["--gpus", "2", "--small", "--steps", "2", "--warmup", "1"])
     assert d["n_gpus"] == 2 and "backend" not in d and d["rccl_nranks"] == 2
     assert d["config"]["exchange"].startswith("1 chunks, active-pixel series as u16; two exchanges in turn")
+
+
+# (at most 4 ranks: the pool allows six processes with the GPU open -- this test process, torchrun's launcher and the ranks)
+@pytest.mark.parametrize("world,extra", [(4, []), (3, ["--sync-exchange"]), (3, ["--chunk-scan"]), (4, ["--row-wire", "--wire12"])])
+def test_bench_rank_processes_on_one_gpu(gpu_lib, rccl_shim, world, extra):
+    """`bench.py --gpus N` semantics with N rank processes on this GPU: the N > 1 loop end to end through the library's exchange
+    (upsp_comm_create from a broadcast id, grouped sends / receives per peer, owner's pass B, all-reduce of the sums) -- deferred
+    and in-step schedules, pass A once / per chunk, packed 12-bit rows -- every rank checks its series slice against its own
+    frames (exchange_self_check, all-reduced).  Needs one GPU only; on a multi-GPU box the ranks still share cuda:0 here."""
+    env = {"UPSP_BENCH_BACKEND": "gloo", "UPSP_BENCH_ONE_GPU": "1", "UPSP_RCCL_LIBRARY": rccl_shim}
+    d = run_bench(["--gpus", str(world), "--small", "--steps", "2", "--warmup", "1"] + extra, env=env)
+    assert d["n_gpus"] == world and d["rccl_nranks"] == world and d["exchange_self_check"] is True
+    x = d["exchange_bytes_per_step"]
+    assert x["transport"].startswith("C ABI") and x["sent_to_other_ranks_this_run"] > 0
+    assert d["config"]["parallelism"] == "frames sharded x%d" % world

@@ -187,9 +187,9 @@ def test_cli_target_patcher(gpu_lib, tmp_path):
 
 
 @pytest.mark.gpu
-def test_cli_two_ranks(gpu_lib, tmp_path):
+def test_cli_two_ranks(gpu_lib, rccl_shim, tmp_path):
     """`bin/psp_process -ranks=2`: the executable starts its own two ranks (one GPU here: both on
-    cuda:0 over gloo; RCCL when two GPUs are visible), frames shard, rank 0 creates the shared flat
+    cuda:0, the library's exchange through the tests' stand-in RCCL; real RCCL when two GPUs are visible), frames shard, rank 0 creates the shared flat
     files and every rank writes its node slice at its byte offset -- byte-identical to the
     single-rank run (the double accumulators are exact integer sums on this path)."""
     import subprocess
@@ -206,8 +206,8 @@ def test_cli_two_ranks(gpu_lib, tmp_path):
     r1 = subprocess.run([sys.executable, exe, "-input_file=%s/run.inp" % tmp1, "-h5_out=x"], env=env,
                         capture_output=True, text=True, timeout=600)
     assert r1.returncode == 0, r1.stderr[-2000:]
-    if torch.cuda.device_count() < 2:
-        env.update(UPSP_BACKEND="gloo", UPSP_ONE_GPU="1")
+    from conftest import one_gpu_ranks_env
+    env.update(one_gpu_ranks_env(rccl_shim))
     # a stale, longer output file must not survive
     os.makedirs(os.path.join(tmp2, "out"))
     open(os.path.join(tmp2, "out", "intensity_transpose"), "wb").write(b"\xff" * 10_000_000)
@@ -222,7 +222,7 @@ def test_cli_two_ranks(gpu_lib, tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("nframes,size", [(140, (96, 80)), (1410, (48, 40))])
-def test_cli_two_ranks_one_camera_pixel_wire(gpu_lib, tmp_path, nframes, size):
+def test_cli_two_ranks_one_camera_pixel_wire(gpu_lib, rccl_shim, tmp_path, nframes, size):
     """One camera, no image stage, `-ranks=2`: the time-series exchange carries the active pixels' u16 series and the owner
     of a node runs pass B (psp.Phase1.frame_loop_pixel_wire) -- every output file byte-identical to the single-rank run
     and to a two-rank run with the node rows on the wire (UPSP_ROW_WIRE=1).  140 frames: two exchange chunks per rank of
@@ -241,8 +241,9 @@ def test_cli_two_ranks_one_camera_pixel_wire(gpu_lib, tmp_path, nframes, size):
         os.makedirs(tmp)
         write_case(tmp, nframes=nframes, size=size, ncams=1)
         e = dict(env, **extra)
-        if ranks and torch.cuda.device_count() < 2:
-            e.update(UPSP_BACKEND="gloo", UPSP_ONE_GPU="1")
+        if ranks:
+            from conftest import one_gpu_ranks_env
+            e.update(one_gpu_ranks_env(rccl_shim))
         cmd = [sys.executable, exe, "-input_file=%s/run.inp" % tmp, "-h5_out=x"] + (["-ranks=%d" % ranks] if ranks else [])
         r = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]

@@ -6,8 +6,8 @@ size-independent properties (series == sum over the cameras, in camera order, of
 NaN rows exactly for the nodes no camera sees; accumulators == sums of the stored series), and the two
 schedules (streamed multi-camera / scan + gather) bit-identical.
 
-configs[3]: frames sharded over ranks + the end-of-run exchange: two ranks on this GPU over gloo
-(tests/test_bench_gpu.py runs the bench that way); here the sharded result is compared with the
+configs[3]: frames sharded over ranks + the end-of-run exchange: two / three rank processes on this GPU, the
+library's exchange bound to the tests' stand-in RCCL (tests/test_bench_gpu.py runs the bench that way); here the sharded result is compared with the
 unsharded one on the same frames: series slices bit-identical, avg / rms identical (integer sums)."""
 import os
 
@@ -98,6 +98,7 @@ def _rank_main(rank, world, port, tmp):
     # the chunked, packed, u16 exchange of bench.py: K chunks, all-to-all of chunk k in flight while k + 1 is processed
     K = 3
     exch = D.TimeSeriesExchange(shard, K)
+    assert exch._x is not None and D.comm_ranks() == (rank, world)        # the library's exchange, not torch.distributed's
     exch.set_skipped(engine.skipped_nodes(pix, want_count=False)[0])
     pipe.set_row_map(exch.row_map())
     for k in range(K):
@@ -136,7 +137,8 @@ def _rank_main(rank, world, port, tmp):
     dist.destroy_process_group()
 
 
-def test_config3_shape_sharded_frames_two_ranks(gpu_lib, oracle, tmp_path):
+@pytest.mark.parametrize("world", [2, 3])
+def test_config3_shape_sharded_frames_two_ranks(gpu_lib, oracle, rccl_shim, tmp_path, monkeypatch, world):
     import socket
     import torch
     import torch.multiprocessing as mp
@@ -152,7 +154,9 @@ def test_config3_shape_sharded_frames_two_ranks(gpu_lib, oracle, tmp_path):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     mp.get_context("spawn")
-    mp.spawn(_rank_main, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    # both ranks on cuda:0: the library's exchange binds the tests' stand-in RCCL (the children inherit the environment)
+    monkeypatch.setenv("UPSP_RCCL_LIBRARY", rccl_shim)
+    mp.spawn(_rank_main, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     # unsharded reference on the same frames
     pipe = engine.FramePipeline(1, W, H, N)
     pipe.set_projection(0, torch.as_tensor(pix).cuda())
@@ -160,7 +164,7 @@ def test_config3_shape_sharded_frames_two_ranks(gpu_lib, oracle, tmp_path):
     pipe.process(torch.as_tensor(frames.copy()).cuda(), 0, rows_t=rt, want_rows=False)
     avg, rms = pipe.finalize(F)
     full = rt.cpu().numpy()
-    for r in range(2):
+    for r in range(world):
         d = np.load(str(tmp_path / ("rank%d.npz" % r)))
         n0, nn = int(d["n0"]), int(d["nn"])
         assert np.array_equal(d["series"].view(np.int32), full[n0:n0 + nn].view(np.int32))
@@ -177,7 +181,7 @@ def test_config3_shape_sharded_frames_two_ranks(gpu_lib, oracle, tmp_path):
         sol[sk] = np.nan
         oracle.accumulate(sol, s_o, ss_o)
         want[f] = sol
-    got = np.concatenate([np.load(str(tmp_path / ("rank%d.npz" % r)))["series"] for r in range(2)])
+    got = np.concatenate([np.load(str(tmp_path / ("rank%d.npz" % r)))["series"] for r in range(world)])
     assert np.array_equal(got.view(np.int32), want.T.view(np.int32))
     a_o, r_o = (s_o / F).astype(np.float32), np.sqrt(ss_o / F).astype(np.float32)
     ok = ~sk

@@ -5,6 +5,10 @@ a C++ psp_process would (cpp/exec/psp_process.cpp:707-771, 1866-1872).
   (apportion, chunk boundaries, ragged blocks, packed rows, the f32 / u16 / 12-bit wire formats, NaN rows, byte
   counts) is the code a multi-GPU run executes; W = 1, 2, 3, 5 with node and frame counts that divide by none of them;
 * `rccl1`: the same through RCCL itself in a one-rank communicator (grouped ncclSend / ncclRecv to self, ncclAllReduce);
+* `ranks`: W rank PROCESSES on this GPU, the RCCL branch of csrc/exchange.hip (grouped ncclSend / ncclRecv per peer,
+  ncclAllReduce) bound to the tests' stand-in RCCL through UPSP_RCCL_LIBRARY (tests/shim/rccl_shim.cpp): every wire of the
+  node rows, the pixel-series mode placed and in place, two exchanges in turn on one communicator; W = 2, 3, 5 (the pool
+  allows six processes on a GPU, this one included);
 * two real RCCL ranks where two GPUs are visible (skipped on a one-GPU box: RCCL refuses two ranks on one device)."""
 import os
 import subprocess
@@ -65,8 +69,34 @@ def test_exchange_rccl_two_ranks(exe, tmp_path):
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs (RCCL over xGMI)")
     idf = str(tmp_path / "nccl_id")
-    ps = [subprocess.Popen([exe, "rccl", str(r), "2", idf], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    ps = [subprocess.Popen([exe, "ranks", str(r), "2", idf, str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
           for r in range(2)]
     outs = [p.communicate(timeout=300)[0] for p in ps]
     assert all(p.returncode == 0 for p in ps), outs
-    assert all(" ok," in o for o in outs), outs
+    assert all(o.count(" ok") == 8 and "FAILED" not in o for o in outs), outs
+
+
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_exchange_rank_processes_through_rccl_entry_points(exe, rccl_shim, tmp_path, world):
+    """global_transpose and the reductions (cpp/exec/psp_process.cpp:707-771, 1866-1872) between `world` rank processes: the
+    code path of an 8-GPU run -- upsp_comm_create from a shared id, one grouped send / receive per peer and chunk on the
+    communicator's transfer stream, arrival marks, the owner's pass B on the received blocks -- with ragged node and frame
+    shares (1003 nodes, 517 / 240 frames)."""
+    idf = str(tmp_path / "nccl_id")
+    env = dict(os.environ, UPSP_RCCL_LIBRARY=rccl_shim, UPSP_SHIM_TIMEOUT_S="60")
+    ps = [subprocess.Popen([exe, "ranks", str(r), str(world), idf, "0"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
+          for r in range(world)]
+    outs = [p.communicate(timeout=400)[0] for p in ps]
+    assert all(p.returncode == 0 for p in ps), outs
+    for o in outs:
+        assert o.count(" ok") == 8 and "FAILED" not in o, o          # 3 row wires + 4 pixel shapes + two exchanges in turn
+    if world > 1:
+        sent = [int(l.split(", ")[1].split()[0]) for l in outs[0].splitlines() if " rows wire=" in l]
+        assert sent[0] == 2 * sent[1] and 0 < sent[2] < sent[1]       # f32 : u16 : 12 bit really left the rank
+
+
+def test_rccl_library_that_cannot_be_loaded_is_an_error(exe, tmp_path):
+    """UPSP_RCCL_LIBRARY names the RCCL to bind; a path that does not load ends the run (no fallback to another copy)."""
+    env = dict(os.environ, UPSP_RCCL_LIBRARY=str(tmp_path / "no_such_librccl.so"))
+    r = subprocess.run([exe, "rccl1"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "UPSP_RCCL_LIBRARY" in (r.stdout + r.stderr)

@@ -126,9 +126,7 @@ def test_register_pixel_band(gpu_lib, oracle, H, W, shift):
     assert np.array_equal(out_g.cpu().numpy(), oracle.warp_affine(inp16, M_g, 1))
 
 
-def test_patch(gpu_lib, oracle):
-    import torch
-    from upsp_processing_amd import engine
+def _patch_case():
     H, W = 400, 520
     yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
     f = lambda x, y: 1500 + 0.3 * x - 0.2 * y + 1e-3 * x * y + 2e-6 * x ** 2 * y - 1e-8 * y ** 3
@@ -137,23 +135,81 @@ def test_patch(gpu_lib, oracle):
                 dict(bx=[1, 2, 3], by=[1, 1, 1], ix=[2], iy=[2])]        # last: < 10 boundary points
     for cl in clusters[:3]:
         img[cl["iy"], cl["ix"]] *= 0.3                                    # fiducial discs
+    return img, clusters
+
+
+def _f64_fit(img, cl):
+    x, y = np.asarray(cl["bx"], float), np.asarray(cl["by"], float)
+    z = img[cl["by"], cl["bx"]].astype(np.float64)
+    xm, ym = x.mean(), y.mean()
+    mono = lambda x, y: np.stack([(y - ym) ** i * (x - xm) ** j for i in range(4) for j in range(4) if i + j <= 3], 1)
+    coef = np.linalg.lstsq(mono(x, y), z, rcond=None)[0]
+    return mono(np.asarray(cl["ix"], float), np.asarray(cl["iy"], float)) @ coef
+
+
+def test_patch(gpu_lib, oracle):
+    """PatchClusters::operator() (cpp/lib/patches.ipp:98-165) in the reference's arithmetic: float column-pivoted Householder QR
+    on raw pixel coordinates (polyfit2D, :172-205) + polyval2D (:208-236).  The GPU runs the oracle's operations in the
+    oracle's order (factorisation once on the host, Q^T z / back substitution / evaluation per frame and lane): BIT FOR BIT,
+    the float-QR noise of the raw-coordinate fit included (reported below against a float64 fit)."""
+    import torch
+    from upsp_processing_amd import engine
+    img, clusters = _patch_case()
     d = torch.as_tensor(img.copy()).cuda()
     engine.patch(d, clusters)
     out = d.cpu().numpy()
     out_o = oracle.patch_clusters(img, clusters)
-    changed = np.zeros((H, W), bool)
+    assert np.array_equal(out.view(np.int32), out_o.view(np.int32))
+    changed = np.zeros(img.shape, bool)
+    noise = 0.0
     for cl in clusters[:3]:
-        x, y = np.asarray(cl["bx"], float), np.asarray(cl["by"], float)
-        z = img[cl["by"], cl["bx"]].astype(np.float64)
-        xm, ym = x.mean(), y.mean()
-        mono = lambda x, y: np.stack([(y - ym) ** i * (x - xm) ** j for i in range(4) for j in range(4) if i + j <= 3], 1)
-        coef = np.linalg.lstsq(mono(x, y), z, rcond=None)[0]
-        truth = mono(np.asarray(cl["ix"], float), np.asarray(cl["iy"], float)) @ coef
-        got = out[cl["iy"], cl["ix"]]
-        assert np.abs(got - truth).max() / 1500 <= 1e-5
-        assert np.abs(got - out_o[cl["iy"], cl["ix"]]).max() / 1500 <= 1e-2
+        noise = max(noise, float(np.abs(out[cl["iy"], cl["ix"]] - _f64_fit(img, cl)).max()) / 1500)
         changed[cl["iy"], cl["ix"]] = True
     assert np.array_equal(out[~changed], img[~changed])
+    assert noise <= 3e-2          # the reference's own deviation from a well-conditioned fit (measured: see DESIGN.md section 2)
+    print("patch: reference-arithmetic solve deviates from a float64 fit by %.2e relative" % noise)
+
+
+def test_patch_many_frames_and_long_boundaries(gpu_lib, oracle):
+    """The pipeline's shape: a wave per (cluster, 64 frames), lane = frame -- 70 frames (a full wave + a ragged one), a
+    boundary longer than the LDS holds (scratch in global memory) and clusters whose boundary crosses another's interior
+    (cluster order of the reference, patches.ipp:101): every frame bit for bit."""
+    import torch
+    from upsp_processing_amd import engine, _capi
+    H, W, F = 300, 400, 70
+    rng = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    base = 900 + 0.5 * xx + 0.25 * yy + 1e-3 * xx * yy
+    frames = np.stack([(base * (1 + 0.01 * f) + rng.normal(size=(H, W)) * 2).astype(np.float32) for f in range(F)])
+    big = disc_cluster(200, 150, 30, 34)             # ring of ~800 boundary pixels (> 240 rows: global scratch)
+    assert len(big["bx"]) > 240
+    a, b = disc_cluster(60, 60, 4, 7), disc_cluster(70, 60, 4, 7)      # b's boundary crosses a's interior
+    for clusters in ([disc_cluster(330, 80, 5, 8), big], [a, b]):
+        d = torch.as_tensor(frames.copy()).cuda()
+        engine.patch(d, clusters)
+        out = d.cpu().numpy()
+        for f in (0, 1, 63, 64, 69):
+            want = oracle.patch_clusters(frames[f], clusters)
+            assert np.array_equal(out[f].view(np.int32), want.view(np.int32)), f
+
+
+def test_patch_pseudo_inverse_opt_in(gpu_lib, oracle, monkeypatch):
+    """UPSP_PATCH_PINV=1: the centred, scaled double pseudo-inverse (a better-conditioned answer than the reference's, hence not
+    the default): within 1e-5 of a float64 fit, and away from the reference-arithmetic result by that one's own noise."""
+    import torch
+    from upsp_processing_amd import engine
+    monkeypatch.setenv("UPSP_PATCH_PINV", "1")
+    img, clusters = _patch_case()
+    d = torch.as_tensor(img.copy()).cuda()
+    engine.patch(d, clusters)
+    out = d.cpu().numpy()
+    out_o = oracle.patch_clusters(img, clusters)
+    dev = 0.0
+    for cl in clusters[:3]:
+        assert np.abs(out[cl["iy"], cl["ix"]] - _f64_fit(img, cl)).max() / 1500 <= 1e-5
+        dev = max(dev, float(np.abs(out[cl["iy"], cl["ix"]] - out_o[cl["iy"], cl["ix"]]).max()) / 1500)
+    assert dev <= 3e-2
+    print("patch: pseudo-inverse solve deviates from the oracle by %.2e relative" % dev)
 
 
 def oracle_loop(oracle, frames, ref, pix, clusters, first, registration, patch, filt, ksize):

@@ -26,6 +26,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -65,7 +66,24 @@ Rccl &rccl()
     static std::once_flag once;
     std::call_once(once, [] {
         void *h = nullptr;
+        // UPSP_RCCL_LIBRARY: the RCCL build to bind (a path for dlopen), used instead of whatever the process holds -- a site's own
+        // build of librccl, or the tests' stand-in that lets several rank PROCESSES share one GPU (tests/shim/rccl_shim.cpp).
+        // Loaded RTLD_LOCAL: its symbols serve this library only and do not interpose another RCCL in the process (PyTorch's).
+        const char *forced = getenv("UPSP_RCCL_LIBRARY");
+        if (forced && *forced) {
+            h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+            if (!h) {
+                const char *e = dlerror();
+                r.why = std::string("UPSP_RCCL_LIBRARY=") + forced + ": " + (e ? e : "dlopen failed");
+            }
+        }
+        const bool only_forced = forced && *forced;
         auto sym = [&](const char *name) -> void * {
+            if (only_forced) {
+                void *p = h ? dlsym(h, name) : nullptr;
+                if (!p && r.why.empty()) r.why = std::string("UPSP_RCCL_LIBRARY=") + forced + " has no symbol " + name;
+                return p;
+            }
             void *p = dlsym(RTLD_DEFAULT, name);          // already in the process (PyTorch's copy)?
             if (!p) {
                 if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);

@@ -531,9 +531,9 @@ bool launch_gauss5_quad(const uint16_t *src, float *dst, int nimg, int rows, int
 }
 
 // ----------------------------------------------------------------- patches --
-// Per cluster: coef = P z (P = pseudo-inverse of the cubic design matrix in centred,
-// scaled coordinates, built once on the host in double), then evaluate at the
-// interior pixels.  One workgroup per (cluster, frame).
+// Opt-in (UPSP_PATCH_PINV=1), a better-conditioned answer than the reference's: per cluster coef = P z (P = pseudo-inverse of
+// the cubic design matrix in centred, scaled coordinates, built once on the host in double), then evaluated at the
+// interior pixels.  One workgroup per (cluster, frame).  The default follows the reference's float QR (patch_qr_kernel).
 struct ClusterDesc {
     int b_off, nb, i_off, ni;
     float cx, cy, sx, sy;  // x' = (x - cx) * sx
@@ -660,15 +660,192 @@ void pinv_design(const std::vector<double> &A, int m, std::vector<float> &P)
     }
 }
 
+// ---- the reference's arithmetic (default) ------------------------------------------------------------------------------
+// polyfit2D (cpp/lib/patches.ipp:172-205) solves  min |A p - z|  with Eigen::ColPivHouseholderQR<MatrixXf> on the RAW pixel
+// coordinates: A(r, count) = (float)pow(y, i) * (float)pow(x, j), i outer / j inner, i + j <= 3 -- a float matrix whose columns
+// span 1 .. 1e10, so the answer carries the float-QR noise of that conditioning, and "the reference's result" includes it.
+// A depends on the cluster's geometry only: it is factored ONCE on the host, in float, operation for operation as Eigen 3.3.9's
+// ColPivHouseholderQR::computeInPlace does (column norms with down-dating, pivot transpositions, makeHouseholderInPlace,
+// applyHouseholderOnTheLeft, the rank rule of solve()).  Per frame the device does what solve() + polyval2D (:208-236) do: c = Q^T z
+// (each reflector: a running float sum over the rows, in row order), back substitution on R, the inverse permutation, and
+// the polynomial at the interior pixels, term by term in float.  Lane = FRAME: the 64 frames of a wave share the cluster, so
+// the control flow and every matrix element are wave-uniform (scalar loads) and each lane runs the reference's sequential
+// arithmetic on its own frame -- same operations, same order, same roundings (-ffp-contract=off, correctly rounded division).
+struct QrDesc {
+    int b_off, nb, i_off, ni;
+    int v_off;        // first float of this cluster's factored matrix in V: nb x 10, column-major (reflector k below the diagonal of
+                      // column k, R on and above it)
+    int nonzero;      // nonzeroPivots(): columns that take part in the solve
+    float tau[10];    // hCoeffs
+    int perm[10];     // colsPermutation: solution entry k is coefficient perm[k]
+};
+
+constexpr int kPatchLdsRows = 240;      // 240 rows x 64 lanes x 4 B = 60 KB of LDS; longer boundaries keep c in global scratch
+
+__global__ void __launch_bounds__(64)
+    patch_qr_kernel(float *__restrict__ imgs, size_t npix, int nimg, int cols, const QrDesc *__restrict__ cl, int cluster0,
+                    const int32_t *__restrict__ b_idx, const float *__restrict__ V, const int32_t *__restrict__ i_idx,
+                    float *__restrict__ scratch, int scratch_rows)
+{
+    extern __shared__ float patch_lds[];
+    const QrDesc &d = cl[cluster0 + blockIdx.x];
+    const int m = d.nb;
+    if (m < 10) return;  // too few boundary points (patches.ipp:103)
+    const int lane = threadIdx.x;
+    const int f = blockIdx.y * 64 + lane;
+    const bool live = f < nimg;
+    float *img = imgs + (size_t)(live ? f : 0) * npix;
+    float *c = (m <= kPatchLdsRows ? patch_lds : scratch + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (size_t)scratch_rows * 64) + lane;
+    for (int r = 0; r < m; ++r) c[r * 64] = img[b_idx[d.b_off + r]];
+    const float *A = V + d.v_off;
+    const int nz = d.nonzero;
+    // c = Q^T z : the reflectors in order (HouseholderSequence::applyThisOnTheLeft of the transposed sequence)
+    for (int k = 0; k < nz; ++k) {
+        const float tau = d.tau[k];
+        if (tau == 0.f) continue;
+        const float *col = A + (size_t)k * m;
+        float tmp = 0.f;
+        for (int r = k + 1; r < m; ++r) tmp += col[r] * c[r * 64];
+        tmp += c[k * 64];
+        c[k * 64] -= tau * tmp;
+        for (int r = k + 1; r < m; ++r) c[r * 64] -= tau * col[r] * tmp;
+    }
+    // R(0:nz, 0:nz) sol = c(0:nz): back substitution, row by row from the bottom
+    float sol[10];
+#pragma unroll
+    for (int i = 9; i >= 0; --i) {
+        float sv = 0.f;
+        if (i < nz) {
+            sv = c[i * 64];
+#pragma unroll
+            for (int j = i + 1; j < 10; ++j)
+                if (j < nz) sv -= A[(size_t)j * m + i] * sol[j];
+            sv = sv / A[(size_t)i * m + i];
+        }
+        sol[i] = sv;
+    }
+    // poly = colsPermutation * [sol; 0]
+    float poly[10];
+#pragma unroll
+    for (int t = 0; t < 10; ++t) poly[t] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        const int pk = d.perm[k];
+#pragma unroll
+        for (int t = 0; t < 10; ++t)
+            if (k < nz && pk == t) poly[t] = sol[k];
+    }
+    // polyval2D: z += poly[count] * (T)pow(y, i) * (T)pow(x, j), count running over i outer / j inner
+    for (int j = 0; j < d.ni; ++j) {
+        const int idx = i_idx[d.i_off + j];
+        const double xd = (double)(idx % cols), yd = (double)(idx / cols);      // (integer powers below 2^53: exact, like pow())
+        const float px[4] = {1.f, (float)xd, (float)(xd * xd), (float)(xd * xd * xd)};
+        const float py[4] = {1.f, (float)yd, (float)(yd * yd), (float)(yd * yd * yd)};
+        float acc = 0.f;
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i <= 3; ++i)
+#pragma unroll
+            for (int jj = 0; jj <= 3 - i; ++jj) acc += poly[cnt++] * py[i] * px[jj];
+        if (live) img[idx] = acc;
+    }
+}
+
+// Eigen 3.3.9 ColPivHouseholderQR<MatrixXf>::computeInPlace on the m x 10 column-major matrix A (overwritten with the
+// reflectors and R), every intermediate a float.
+void colpiv_householder_f32(std::vector<float> &A, int m, QrDesc &d)
+{
+    constexpr int nc = 10;
+    const int size = std::min(m, nc);
+    float norm_upd[nc], norm_dir[nc];
+    int transp[nc];
+    float biggest_norm = 0.f;
+    for (int k = 0; k < nc; ++k) {
+        float sq = 0.f;
+        for (int r = 0; r < m; ++r) sq += A[(size_t)k * m + r] * A[(size_t)k * m + r];
+        norm_dir[k] = norm_upd[k] = std::sqrt(sq);
+        biggest_norm = std::max(biggest_norm, norm_upd[k]);
+    }
+    const float th = biggest_norm * FLT_EPSILON / (float)m;
+    const float threshold_helper = th * th;
+    const float downdate_threshold = std::sqrt(FLT_EPSILON);
+    int nonzero = size;
+    for (int k = 0; k < size; ++k) {
+        int big = k;
+        for (int j = k + 1; j < nc; ++j)
+            if (norm_upd[j] > norm_upd[big]) big = j;
+        const float big_sq = norm_upd[big] * norm_upd[big];
+        if (nonzero == size && big_sq < threshold_helper * (float)(m - k)) nonzero = k;
+        transp[k] = big;
+        if (big != k) {
+            for (int r = 0; r < m; ++r) std::swap(A[(size_t)k * m + r], A[(size_t)big * m + r]);
+            std::swap(norm_upd[k], norm_upd[big]);
+            std::swap(norm_dir[k], norm_dir[big]);
+        }
+        float *col = &A[(size_t)k * m];
+        float tail_sq = 0.f;
+        for (int r = k + 1; r < m; ++r) tail_sq += col[r] * col[r];
+        const float c0 = col[k];
+        float beta, tau;
+        if (tail_sq <= FLT_MIN) {
+            tau = 0.f;
+            beta = c0;
+            for (int r = k + 1; r < m; ++r) col[r] = 0.f;
+        } else {
+            beta = std::sqrt(c0 * c0 + tail_sq);
+            if (c0 >= 0.f) beta = -beta;
+            for (int r = k + 1; r < m; ++r) col[r] = col[r] / (c0 - beta);
+            tau = (beta - c0) / beta;
+        }
+        d.tau[k] = tau;
+        col[k] = beta;
+        if (tau != 0.f)
+            for (int j = k + 1; j < nc; ++j) {
+                float *cj = &A[(size_t)j * m];
+                float tmp = 0.f;
+                for (int r = k + 1; r < m; ++r) tmp += col[r] * cj[r];
+                tmp += cj[k];
+                cj[k] -= tau * tmp;
+                for (int r = k + 1; r < m; ++r) cj[r] -= tau * col[r] * tmp;
+            }
+        for (int j = k + 1; j < nc; ++j) {
+            if (norm_upd[j] == 0.f) continue;
+            float t = std::fabs(A[(size_t)j * m + k]) / norm_upd[j];
+            t = (1.f + t) * (1.f - t);
+            t = t < 0.f ? 0.f : t;
+            const float ratio = norm_upd[j] / norm_dir[j];
+            const float t2 = t * ratio * ratio;
+            if (t2 <= downdate_threshold) {
+                float sq = 0.f;
+                for (int r = k + 1; r < m; ++r) sq += A[(size_t)j * m + r] * A[(size_t)j * m + r];
+                norm_dir[j] = std::sqrt(sq);
+                norm_upd[j] = norm_dir[j];
+            } else {
+                norm_upd[j] *= std::sqrt(t);
+            }
+        }
+    }
+    for (int k = size; k < nc; ++k) d.tau[k] = 0.f;
+    d.nonzero = nonzero;
+    for (int k = 0; k < nc; ++k) d.perm[k] = k;
+    for (int k = 0; k < size; ++k) std::swap(d.perm[k], d.perm[transp[k]]);
+}
+
 }  // namespace
 
 // ------------------------------------------------------------ PatchTables --
 struct PatchTables {
     int nclusters = 0;
     bool sequential = false;  // a boundary of one cluster overlaps another's interior
+    bool pinv = false;        // UPSP_PATCH_PINV=1: the centred double pseudo-inverse instead of the reference's float QR
     ClusterDesc *d_desc = nullptr;
     int32_t *d_bidx = nullptr, *d_iidx = nullptr;
     float *d_P = nullptr;
+    QrDesc *d_qr = nullptr;
+    float *d_V = nullptr;
+    int max_nb = 0;           // longest boundary; beyond kPatchLdsRows the right-hand sides live in d_scratch
+    mutable float *d_scratch = nullptr;
+    mutable size_t scratch_floats = 0;
 };
 
 void patch_tables_free(PatchTables *t)
@@ -678,6 +855,9 @@ void patch_tables_free(PatchTables *t)
     if (t->d_bidx) (void)hipFree(t->d_bidx);
     if (t->d_iidx) (void)hipFree(t->d_iidx);
     if (t->d_P) (void)hipFree(t->d_P);
+    if (t->d_qr) (void)hipFree(t->d_qr);
+    if (t->d_V) (void)hipFree(t->d_V);
+    if (t->d_scratch) (void)hipFree(t->d_scratch);
     delete t;
 }
 
@@ -690,9 +870,14 @@ int patch_tables_create(int rows, int cols, int nclusters, const int32_t *b_off,
     if (nclusters < 0 || !b_off || !i_off) return fail(UPSP_ERR_INVALID, "bad patch tables");
     const int nbt = b_off[nclusters], nit = i_off[nclusters];
     if ((nbt && (!bx || !by)) || (nit && (!ix || !iy))) return fail(UPSP_ERR_INVALID, "bad patch tables");
+    const char *pe = getenv("UPSP_PATCH_PINV");
+    const bool pinv = pe && *pe && *pe != '0';
     std::vector<ClusterDesc> desc(nclusters);
+    std::vector<QrDesc> qr(nclusters);
+    std::vector<float> Vall;
+    int max_nb = 0;
     std::vector<int32_t> bidx(std::max(nbt, 1)), iidx(std::max(nit, 1));
-    std::vector<float> Pall((size_t)std::max(nbt, 1) * 10, 0.f);
+    std::vector<float> Pall((size_t)std::max(pinv ? nbt : 0, 1) * 10, 0.f);
     std::vector<int> owner((size_t)rows * cols, -1);
     bool sequential = false;
     for (int c = 0; c < nclusters; ++c) {
@@ -714,7 +899,25 @@ int patch_tables_create(int rows, int cols, int nclusters, const int32_t *b_off,
             if (x < 0 || y < 0 || x >= cols || y >= rows) return fail(UPSP_ERR_INVALID, "patch pixel outside the frame");
             iidx[d.i_off + j] = y * cols + x;
         }
-        if (d.nb >= 10) {
+        QrDesc &q = qr[c];
+        std::memset(&q, 0, sizeof(q));
+        q.b_off = d.b_off; q.nb = d.nb; q.i_off = d.i_off; q.ni = d.ni;
+        if (d.nb >= 10 && !pinv) {
+            // the reference's design matrix on raw pixel coordinates (patches.ipp:185-193), factored in float
+            std::vector<float> A((size_t)d.nb * 10);
+            for (int j = 0; j < d.nb; ++j) {
+                int cnt = 0;
+                for (int i = 0; i <= 3; ++i)
+                    for (int jj = 0; jj <= 3; ++jj)
+                        if (i + jj <= 3)
+                            A[(size_t)cnt++ * d.nb + j] = (float)std::pow((double)by[d.b_off + j], i) * (float)std::pow((double)bx[d.b_off + j], jj);
+            }
+            colpiv_householder_f32(A, d.nb, q);
+            q.v_off = (int)Vall.size();
+            Vall.insert(Vall.end(), A.begin(), A.end());
+            max_nb = std::max(max_nb, d.nb);
+            d.cx = d.cy = 0; d.sx = d.sy = 1;
+        } else if (d.nb >= 10) {
             mx /= d.nb; my /= d.nb;
             const double hx = std::max(0.5 * (hix - lox), 1.0), hy = std::max(0.5 * (hiy - loy), 1.0);
             d.cx = (float)mx; d.cy = (float)my;
@@ -747,7 +950,13 @@ int patch_tables_create(int rows, int cols, int nclusters, const int32_t *b_off,
     PatchTables *t = new PatchTables();
     t->nclusters = nclusters;
     t->sequential = sequential;
+    t->pinv = pinv;
+    t->max_nb = max_nb;
     hipError_t e = hipMalloc(&t->d_desc, sizeof(ClusterDesc) * std::max(nclusters, 1));
+    if (e == hipSuccess) e = hipMalloc(&t->d_qr, sizeof(QrDesc) * std::max(nclusters, 1));
+    if (e == hipSuccess) e = hipMalloc(&t->d_V, sizeof(float) * std::max<size_t>(Vall.size(), 1));
+    if (e == hipSuccess && nclusters) e = hipMemcpy(t->d_qr, qr.data(), sizeof(QrDesc) * nclusters, hipMemcpyHostToDevice);
+    if (e == hipSuccess && !Vall.empty()) e = hipMemcpy(t->d_V, Vall.data(), sizeof(float) * Vall.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc(&t->d_bidx, sizeof(int32_t) * bidx.size());
     if (e == hipSuccess) e = hipMalloc(&t->d_iidx, sizeof(int32_t) * iidx.size());
     if (e == hipSuccess) e = hipMalloc(&t->d_P, sizeof(float) * Pall.size());
@@ -768,6 +977,32 @@ static int launch_patch(const PatchTables *t, float *imgs, int nimg, int rows, i
 {
     if (!t || t->nclusters == 0 || nimg == 0) return UPSP_OK;
     const size_t npix = (size_t)rows * cols;
+    if (!t->pinv) {
+        // lane = frame: a wave per (cluster, 64 frames)
+        const unsigned groups = (unsigned)((nimg + 63) / 64);
+        const size_t lds = sizeof(float) * 64 * (size_t)std::min(std::max(t->max_nb, 1), kPatchLdsRows);
+        if (t->max_nb > kPatchLdsRows) {
+            const size_t want = (size_t)t->nclusters * groups * (size_t)t->max_nb * 64;
+            if (want > t->scratch_floats) {
+                UPSP_HIP_CHECK(hipStreamSynchronize(st));
+                if (t->d_scratch) (void)hipFree(t->d_scratch);
+                t->d_scratch = nullptr;
+                t->scratch_floats = 0;
+                UPSP_HIP_CHECK(hipMalloc(&t->d_scratch, sizeof(float) * want));
+                t->scratch_floats = want;
+            }
+        }
+        if (!t->sequential) {
+            hipLaunchKernelGGL(patch_qr_kernel, dim3(t->nclusters, groups), dim3(64), lds, st, imgs, npix, nimg, cols, t->d_qr, 0,
+                               t->d_bidx, t->d_V, t->d_iidx, t->d_scratch, t->max_nb);
+        } else {
+            for (int c = 0; c < t->nclusters; ++c)  // cluster order of the reference (patches.ipp:101)
+                hipLaunchKernelGGL(patch_qr_kernel, dim3(1, groups), dim3(64), lds, st, imgs, npix, nimg, cols, t->d_qr, c,
+                                   t->d_bidx, t->d_V, t->d_iidx, t->d_scratch, t->max_nb);
+        }
+        UPSP_HIP_CHECK(hipGetLastError());
+        return UPSP_OK;
+    }
     if (!t->sequential) {
         hipLaunchKernelGGL(patch_kernel, dim3(t->nclusters, nimg), dim3(256), 0, st, imgs, npix, cols,
                            t->d_desc, 0, t->d_bidx, t->d_P, t->d_iidx);

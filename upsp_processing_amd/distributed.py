@@ -3,10 +3,11 @@
 One process per GPU.  torch.distributed starts the job and carries the rendezvous; the DATA of the
 end-of-run exchanges moves through the library's own C-ABI exchange (include/upsp_gpu.h section 3b:
 upsp_comm_* / upsp_allreduce_sums / upsp_exchange_*, RCCL over xGMI) whenever the ranks sit on GPUs
-with the "nccl" backend -- the same entry points a C++ psp_process binds.  With the "gloo" backend
-(CPU tests, several ranks rehearsed on one GPU) the same bookkeeping runs here on torch.distributed
-calls.  Frames shard trivially -- the reference does the same across MPI ranks
-(cpp/exec/psp_process.cpp:1519-1529) -- so the data path has no collective until the end of the run,
+-- the same entry points a C++ psp_process binds -- whatever backend the process group itself uses for the
+rendezvous ("nccl"; "gloo" when several ranks are rehearsed on one GPU with UPSP_RCCL_LIBRARY naming an RCCL that
+allows it).  There is no fallback: a communicator that does not come up ends the run.  Only under
+UPSP_ALLOW_TORCH_EXCHANGE=1 (CPU tests of the bookkeeping) the same steps run here on torch.distributed calls.
+Frames shard trivially -- the reference does the same across MPI ranks (cpp/exec/psp_process.cpp:1519-1529) -- so the data path has no collective until the end of the run,
 where three exchanges happen:
 
 * sum of the per-rank double accumulators: MPI_Reduce + MPI_Bcast in the reference
@@ -14,8 +15,8 @@ where three exchanges happen:
 * the time-series exchange: every rank holds full rows [frames_r x N] and must end
   with full time series [nodes_r x F] -- global_transpose (psp_process.cpp:707-771:
   local transpose, one block per rank pair, strided placement).  On xGMI every GPU
-  pair has its own link, so the exchange is ONE all_to_all_single in which all 7
-  links of every GPU carry exactly one block at the same time;
+  pair has its own link, so the exchange is ONE group of point-to-point sends / receives in which
+  all 7 links of every GPU carry exactly one block at the same time;
 * optional gather of everything to rank 0 (BASELINE north-star wording).
 """
 import os
@@ -31,10 +32,29 @@ FORCE_COLLECTIVES = bool(os.environ.get("UPSP_FORCE_COLLECTIVES"))
 _LIB_COMM = {}
 
 
+def torch_exchange_allowed():
+    """UPSP_ALLOW_TORCH_EXCHANGE=1: the exchanges of a multi-rank group may run on torch.distributed calls with the owner's pass B
+    in torch operators (CPU tests of the bookkeeping over gloo; no GPU needed).  NOT a product path: without the switch a
+    group whose exchanges cannot run through the library (upsp_comm_* / upsp_exchange_* of libupsp_gpu.so) is an error."""
+    return bool(os.environ.get("UPSP_ALLOW_TORCH_EXCHANGE"))
+
+
+class ExchangeUnavailable(RuntimeError):
+    pass
+
+
+def _need_library(what):
+    raise ExchangeUnavailable(
+        "upsp: %s needs the library's exchange (upsp_comm_* / upsp_exchange_* over RCCL, device tensors); there is no fallback "
+        "(UPSP_ALLOW_TORCH_EXCHANGE=1 lets the CPU tests run the bookkeeping on torch.distributed)" % what)
+
+
 def lib_comm(group=None):
     """The library's RCCL communicator of the process group (created on first use: rank 0 makes the
-    ncclUniqueId, torch.distributed broadcasts its 128 bytes, every rank calls upsp_comm_create on its
-    current device).  None when the group does not run on RCCL (gloo) or there is no group."""
+    ncclUniqueId, torch.distributed broadcasts its 128 bytes -- whatever the group's backend --, every rank calls
+    upsp_comm_create on its current device).  A communicator that does not come up on EVERY rank ends the run
+    (ExchangeUnavailable on every rank): the exchanges have one path.  None only without a GPU, or for a non-RCCL group
+    under UPSP_ALLOW_TORCH_EXCHANGE=1 (tests)."""
     if not torch.cuda.is_available():
         return None
     if not dist.is_initialized():
@@ -48,40 +68,43 @@ def lib_comm(group=None):
             _capi.check(_capi.lib().upsp_comm_create_local(1, arr))
             _LIB_COMM["local1"] = C.c_void_p(arr[0])
         return _LIB_COMM["local1"]
-    if dist.get_backend(group) != "nccl":
+    on_rccl = dist.get_backend(group) == "nccl"
+    if not on_rccl and torch_exchange_allowed():
         return None
     key = id(group)
     if key not in _LIB_COMM:
         import ctypes as C
         from . import _capi
         rank, world = dist.get_rank(group), dist.get_world_size(group)
+        dev = "cuda" if on_rccl else "cpu"          # (the rendezvous tensors live where the group's backend can reach them)
         buf = (C.c_uint8 * 128)()
+        err = None
         if rank == 0:
-            _capi.check(_capi.lib().upsp_comm_unique_id(buf))
-        t = torch.tensor(list(buf), dtype=torch.uint8, device="cuda")
+            try:
+                _capi.check(_capi.lib().upsp_comm_unique_id(buf))
+            except _capi.UpspError as e:            # e.g. no librccl the library can resolve in this process
+                err = e
+        t = torch.tensor(list(buf), dtype=torch.uint8, device=dev)
         if world > 1:
             dist.broadcast(t, src=0, group=group)
         ident = (C.c_uint8 * 128)(*t.cpu().tolist())
         h = C.c_void_p()
-        err = None
-        try:
-            _capi.check(_capi.lib().upsp_comm_create(ident, rank, world, C.byref(h)))
-        except _capi.UpspError as e:            # e.g. no librccl the library can resolve in this process
-            err = e
+        if err is None:
+            try:
+                _capi.check(_capi.lib().upsp_comm_create(ident, rank, world, C.byref(h)))
+            except _capi.UpspError as e:
+                err = e
         if world > 1:
             # every rank or none: a communicator that came up on some ranks only would hang the first exchange
-            flag = torch.tensor([0 if err else 1], dtype=torch.int32, device="cuda")
+            flag = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
             if int(flag.item()) == 0:
                 if err is None:
                     _capi.lib().upsp_comm_destroy(h)
-                import sys
-                print("upsp: the library's RCCL communicator could not be created on every rank (%s); the exchanges of this "
-                      "group go through torch.distributed's RCCL instead" % (err or "another rank failed"), file=sys.stderr)
-                _LIB_COMM[key] = None
-                return None
+                raise ExchangeUnavailable("upsp: the library's RCCL communicator could not be created on every rank of the group "
+                                          "(rank %d of %d: %s)" % (rank, world, err or "another rank failed"))
         elif err is not None:
-            raise err
+            raise ExchangeUnavailable("upsp: the library's RCCL communicator could not be created (%s)" % err)
         _LIB_COMM[key] = h
     return _LIB_COMM[key]
 
@@ -191,6 +214,8 @@ def allreduce_sums(total, sumsq, group=None):
             _capi.check(_capi.lib().upsp_allreduce_sums(comm, C.c_void_p(total.data_ptr()), C.c_void_p(sumsq.data_ptr()),
                                                         total.numel(), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
             return total, sumsq
+        if not torch_exchange_allowed():
+            _need_library("the sum of the accumulators over the ranks")
         both = torch.stack([total, sumsq])
         dist.all_reduce(both, op=dist.ReduceOp.SUM, group=group)
         total.copy_(both[0])
@@ -225,6 +250,8 @@ def exchange_time_series(rows_t, shard, group=None, out=None):
         torch.cuda.current_stream().synchronize()
         x.close()
         return res
+    if not torch_exchange_allowed():
+        _need_library("the time-series exchange")
     if out is None:
         out = torch.empty((nn, shard.nframes), dtype=rows_t.dtype, device=rows_t.device)
     rows_t = rows_t.contiguous()               # padded row pitch (engine.series_ld) -> packed blocks
@@ -352,6 +379,8 @@ class TimeSeriesExchange:
                 a, b = C.c_int64(), C.c_int64()
                 _capi.check(_capi.lib().upsp_exchange_chunk(h, k, C.byref(a), C.byref(b)))
                 assert (a.value, b.value) == self.my_chunk(k), (k, a.value, b.value, self.my_chunk(k))
+        elif shard.world > 1 and dist.is_initialized() and not torch_exchange_allowed():
+            _need_library("a time-series exchange between %d ranks (%s tensors, %s)" % (shard.world, device, dtype))
         if str(device).startswith("cuda"):
             self._prewarm(device)
 
