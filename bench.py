@@ -58,6 +58,32 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
+_PEAK = {}
+
+
+def measured_peak():
+    """the roofline's second denominator -- the rate of a streaming device copy kernel measured in THIS process
+    (upsp_copy_probe: float4 copy of 1 GiB, read + write bytes over the HIP-event time of 5 launches), and of its store half."""
+    if "v" not in _PEAK:
+        from upsp_processing_amd import _capi
+        _PEAK["v"] = _capi.copy_probe(1 << 30, 5)
+    return _PEAK["v"]
+
+
+def roofline_extras(roof, step_bytes, ms_step):
+    """peak_measured / frac_of_measured (dominant kernel against the measured copy rate) and step_frac (ALL algorithmic bytes of
+    a step over the whole step time, against the spec peak and the measured one)."""
+    pk = measured_peak()
+    roof["peak_measured"] = pk["copy_GBps"]
+    roof["peak_measured_kind"] = "device copy kernel in this process (%s, %d MiB, %d launches, HIP events); fill alone %.0f GB/s" % (
+        pk["kernel"], pk["bytes"] >> 20, pk["reps"], pk["fill_GBps"])
+    roof["frac_of_measured"] = roof["achieved"] / pk["copy_GBps"]
+    roof["step_algorithmic_bytes"] = int(step_bytes)
+    roof["step_frac"] = step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS
+    roof["step_frac_of_measured"] = step_bytes / (ms_step * 1e-3) / 1e9 / pk["copy_GBps"]
+    return roof
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -464,6 +490,10 @@ def registration_block(bvh, cam, d_nodes, d_nrm, d_tn, frames, restore, N, size,
         # recomputed on the fly); pre-blur 2 B in + 4 B out per pixel; the warp produces only the pixels a node reads:
         # per listed pixel 4 B list entry + 4 x 2 B source pixels + 2 B out
         "ecc_sums_kernel": iters * F * 8 * npx,
+        # the two kernels behind that label: every frame's FIRST iteration starts from the identity warp
+        # (ecc_cols_kernel<true,..>), the others run the general kernel (ecc_cols_kernel<false,..>)
+        "ecc_sums_identity": F * 8 * npx,
+        "ecc_sums_general": max(iters - 1.0, 0.0) * F * 8 * npx,
         "gauss_pass_kernels": F * 6 * npx,
         "warp_u16_kernel": F * n_active * 14,
         "hot_scan_kernel": F * 2 * npx,
@@ -477,7 +507,8 @@ def registration_block(bvh, cam, d_nodes, d_nrm, d_tn, frames, restore, N, size,
             k["algorithmic_bytes_per_step"] = bytes_step[name]
             k["achieved_GBps"] = bytes_step[name] / (total / steps * 1e-3) / 1e9
         kernels[name] = k
-    dom = max((n for n in kernels if "achieved_GBps" in kernels[n]), key=lambda n: kernels[n]["ms_per_step"])
+    # the dominant KERNEL (the blend "ecc_sums_kernel" of the two sums kernels is reported beside it, not as the roofline)
+    dom = max((n for n in kernels if "achieved_GBps" in kernels[n] and n != "ecc_sums_kernel"), key=lambda n: kernels[n]["ms_per_step"])
     dk = kernels[dom]
     ecc_fracs = None
     if "ecc_sums_kernel" in kernels:
@@ -493,14 +524,16 @@ def registration_block(bvh, cam, d_nodes, d_nrm, d_tn, frames, restore, N, size,
     return {
         "ecc_sums_fraction_of_hbm_peak": ecc_fracs,
         "workload": "configs[2]: %d frames x %dx%d u16, per-frame ECC registration + projection, projection build per step" % (F, size, size),
-        "value": F * steps / dt, "unit": "frames/s", "steps": steps, "warmup": warmup, "ms_per_step": ms_step,
+        "value": F * steps / dt, "unit": "frames/s", "frames": F, "steps": steps, "warmup": warmup, "ms_per_step": ms_step,
         "ecc_iterations_per_frame": iters,
-        "roofline": dict({"kernel": dom, "bound": "hbm", "achieved": dk["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": roofline_extras(dict({"kernel": dom, "bound": "hbm", "achieved": dk["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": dk["achieved_GBps"] / HBM_PEAK_GBS, "traffic": tracked_traffic(dom, "ecc")[0],
                           "traffic_source": tracked_traffic(dom, "ecc")[1],
                           "algorithmic_bytes_per_launch": dk["algorithmic_bytes_per_step"] / max(dk["calls_per_step"], 1),
                           "avg_launch_ms": dk["avg_launch_ms"], "launches_per_step": dk["calls_per_step"]},
                          **ECC_SYMBOLS.get(dom, {})),
+                         # a step's algorithmic bytes: sums 8 B / px / iteration, pre-blur 6 B / px, warp 14 B / active px, pass B rows
+                         sum(bytes_step[k] for k in ("ecc_sums_kernel", "gauss_pass_kernels", "warp_u16_kernel", "node_rows_kernel")), ms_step),
         "kernels": kernels,
     }
 
@@ -508,7 +541,9 @@ def registration_block(bvh, cam, d_nodes, d_nrm, d_tn, frames, restore, N, size,
 # "ecc_sums_kernel" = the ECC sums launches (the library times them as ecc_sums_identity / ecc_sums_general); the symbols a
 # rocprofv3 trace shows for them
 ECC_SYMBOLS = {"ecc_sums_kernel": {"kernel_symbols": ["ecc_cols_kernel<true,4,4> (iterations from the identity warp)",
-                                                      "ecc_cols_kernel<false,2,3> (general warp: source taps from an LDS tile)"]}}
+                                                      "ecc_cols_kernel<false,2,3> (general warp: source taps from an LDS tile)"]},
+               "ecc_sums_identity": {"kernel_symbols": ["ecc_cols_kernel<true,4,4> (a frame's first iteration: identity warp)"]},
+               "ecc_sums_general": {"kernel_symbols": ["ecc_cols_kernel<false,2,3> (general warp: source taps from an LDS tile)"]}}
 
 
 def tracked_traffic(kernel, kind, world=1):
@@ -727,6 +762,7 @@ def multi_camera_main(a):
         "pass_b_row_GBps": row_bytes / (kernels["node_rows_multi_kernel"]["ms_per_step"] * 1e-3) / 1e9 if "node_rows_multi_kernel" in kernels else None,
         "kernels": kernels,
     }
+    roofline_extras(out["roofline"], sum(per_step.values()), ms_step)
     if not a.no_cpu_baseline:
         # oracle (CPU port): projection of every camera on the full model, weights, and the weighted loop on a bounded
         # sample of frame sets (one frame set per thread, like the reference's OpenMP loop)
@@ -957,11 +993,11 @@ def main():
 
     # Pass A reads the frames and needs only the CANDIDATE pixels (known after step 1 of create_projection_mat), the ray casting
     # is a latency-bound chain of dependent fetches: side by side they take 0.59-0.63 ms where one after the other they take
-    # 0.29 + 0.35-0.39 (tools/gpu_overlap_ab.sh, three alternations in one call: step 1.10-1.13 against 1.16-1.18 ms)
+    # 0.29 + 0.35-0.39 (LAB_NOTES.md, three alternations in one call: step 1.10-1.13 against 1.16-1.18 ms)
     overlap = not a.serial and not a.registration and streamed and F <= 1024 and (not chunked or px_once)
     # The BUILD goes to the side stream, issued first and with high priority; pass A follows on the main stream: the traversal
     # kernels are chains of dependent fetches that need few wave slots but need them early, pass A fills whatever is left
-    # (tools/gpu_prio_ab.sh, step in ms: pass A on the side stream 1.151 / 1.172, the build on the side stream 1.124, the build
+    # (LAB_NOTES.md, step in ms: pass A on the side stream 1.151 / 1.172, the build on the side stream 1.124, the build
     # on a high-priority side stream 1.107 / 1.131, pass A on a high-priority side stream 1.208).  UPSP_BENCH_BUILD_ON_SIDE=0 /
     # UPSP_BENCH_SIDE_PRIORITY=0: the other arrangements.
     swap = overlap and os.environ.get("UPSP_BENCH_BUILD_ON_SIDE", "1") == "1"
@@ -1216,8 +1252,11 @@ def main():
         per_step_bytes["node_rows_kernel"] = f_all * 4 * nn_me + (-(-f_all // 1024)) * 8 * nn_me
     if a.registration:
         st = pipe.ecc_stats()            # average ECC iterations per frame over every step run so far
-        per_step_bytes["ecc_sums_kernel"] = st["frame_iterations"] / max(st["frames"], 1) * F * 8 * npx
         ecc_iters_per_frame = st["frame_iterations"] / max(st["frames"], 1)
+        per_step_bytes["ecc_sums_kernel"] = ecc_iters_per_frame * F * 8 * npx
+        # (the two kernels behind that label: a frame's first iteration starts from the identity warp, the others are general)
+        per_step_bytes["ecc_sums_identity"] = F * 8 * npx
+        per_step_bytes["ecc_sums_general"] = max(ecc_iters_per_frame - 1.0, 0.0) * F * 8 * npx
     for name, (calls, total_ms) in timing.items():
         ms_step_k = total_ms / a.steps
         k = {"calls_per_step": calls / a.steps, "ms_per_step": ms_step_k,
@@ -1229,7 +1268,7 @@ def main():
             lo, med, hi = timing_full[name][2:]
             k["launch_ms_min_median_max"] = [lo, med, hi]      # spread over the timed launches (device state)
         kernels[name] = k
-    dom = max((n for n in kernels if n in per_step_bytes), key=lambda n: kernels[n]["ms_per_step"])
+    dom = max((n for n in kernels if n in per_step_bytes and n != "ecc_sums_kernel"), key=lambda n: kernels[n]["ms_per_step"])
     dk = kernels[dom]
     calls = max(dk["calls_per_step"], 1)
     # HBM traffic of that kernel: only from a rocprofv3 PMC summary of THIS configuration, handed over
@@ -1242,6 +1281,10 @@ def main():
             "algorithmic_bytes_per_launch": per_step_bytes[dom] / calls,
             "avg_launch_ms": dk["avg_launch_ms"], "launches_per_step": calls}
     roof.update(ECC_SYMBOLS.get(dom, {}))
+    if rank == 0:
+        # all algorithmic bytes of a step (every kernel that has a per-step figure; the ECC blend label is not counted twice)
+        step_bytes = sum(v for k, v in per_step_bytes.items() if k in kernels and k not in ("ecc_sums_identity", "ecc_sums_general"))
+        roofline_extras(roof, step_bytes, ms_step)
     if overlap:
         roof["note"] = ("default schedule: the ray casting of the projection builds has a high-priority stream of its own and runs beside "
                         "pass A (scan_compact_kernel) and pass B (node_rows_kernel), which share the memory system with it; alone (--serial) "
@@ -1343,9 +1386,24 @@ def main():
             out["pixel_rays"] = pixel_ray_rate(bvh, cd, size)
     plain_default = world == 1 and not a.registration and not a.no_reraycast and not chunked and not a.small
     if plain_default:
-        # BASELINE configs[2] beside the headline: the same resident frames with per-frame ECC registration
-        out["configs2"] = registration_block(bvh, cam, d_nodes, d_nrm, d_tn, frames, restore_hot, N, size, n_active,
-                                             steps=5, warmup=2)
+        # BASELINE configs[2] beside the headline: per-frame ECC registration in front of the projection -- at configs[2]'s OWN
+        # size (10 000 resident frames, 2 steps) when the device has the memory for it (20 GB of frames + 20 GB of series + 2 GB
+        # of registration scratch beside what this run holds), else on the 1 000 frames of the headline (5 steps)
+        F2 = int(os.environ.get("UPSP_BENCH_CONFIGS2_FRAMES", "10000"))
+        free_b = torch.cuda.mem_get_info()[0]
+        if F2 > F and F == 1000 and free_b >= 60e9:
+            restore_hot()
+            frames2 = torch.empty((F2, size, size), dtype=torch.uint16, device="cuda")
+            frames2[:F] = frames
+            for f0 in range(F, F2, chunk):
+                syn.synth_frames_torch(min(chunk, F2 - f0), size, size, first=f0, out=frames2[f0:f0 + chunk], layout=layout, hot=True)
+            out["configs2"] = registration_block(bvh, cam, d_nodes, d_nrm, d_tn, frames2, hot_pixel_restorer(frames2), N, size, n_active,
+                                                 steps=2, warmup=1)
+            del frames2
+        else:
+            out["configs2"] = registration_block(bvh, cam, d_nodes, d_nrm, d_tn, frames, restore_hot, N, size, n_active,
+                                                 steps=5, warmup=2)
+            out["configs2"]["note"] = "%.0f GB of HBM free: configs[2] on the headline's %d frames, not its own 10 000" % (free_b / 1e9, F)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         with_reg = a.registration or plain_default
         out["cpu_baseline"], ref = cpu_baseline(verts, tris, cd, size, F, sample, registration=with_reg)
@@ -1386,11 +1444,12 @@ def main():
             if not a.registration:
                 # CPU baseline of configs[2]: the same oracle loop with register_pixel per frame
                 pf = ref["loop_per_frame"] + ref["reg"]["seconds_per_frame"] / ref["cores"]
+                Fc2 = int(out["configs2"]["frames"])
                 out["configs2"]["cpu_baseline"] = {
-                    "value": F / (ref["t_proj"] + ref["t_fixed"] + pf * F), "unit": "frames/s", "cores": ref["cores"], "kind": "port",
+                    "value": Fc2 / (ref["t_proj"] + ref["t_fixed"] + pf * Fc2), "unit": "frames/s", "cores": ref["cores"], "kind": "port",
                     "sample": "oracle/ (C, %d threads, one frame per thread): fix_hot_pixels + register_pixel + project_frame on %d frames "
                               "(%.2f s per frame and thread) + the plain loop's per-frame cost; extrapolated to %d frames"
-                              % (ref["cores"], len(ref["reg"]["fixed"]), ref["reg"]["seconds_per_frame"], F)}
+                              % (ref["cores"], len(ref["reg"]["fixed"]), ref["reg"]["seconds_per_frame"], Fc2)}
                 # the headline's CPU baseline is the PLAIN loop (configs[1]): take the registration cost out again
                 cb = out["cpu_baseline"]
                 cb["value"] = F / (ref["t_proj"] + ref["t_fixed"] + ref["loop_per_frame"] * F)

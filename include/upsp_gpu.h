@@ -415,10 +415,17 @@ int upsp_blur_f32(const float *d_src, float *d_dst, int rows, int cols, int k, i
  * cv::findTransformECC, cpp/lib/registration.cpp:57-60, and the filter stage on raw frames, psp_process.cpp:1802-1804);
  * sizes 3 / 5 / 7 in one fused tile kernel (2 B in, 4 B out per pixel). */
 int upsp_blur_u16(const uint16_t *d_src, float *d_dst, int nimg, int rows, int cols, int k, void *stream);
-/* PatchClusters<float>::operator() (cpp/lib/patches.ipp:98-165) on one f32 image */
+/* PatchClusters<float>::operator() (cpp/lib/patches.ipp:98-165) on one f32 image: per cluster polyfit2D (:172-205, float
+ * column-pivoted Householder QR on raw pixel coordinates, the reference's arithmetic operation for operation) over the
+ * boundary pixels, polyval2D (:208-236) at the interior ones; clusters of fewer than 10 boundary pixels are skipped (:103). */
 int upsp_patch_f32(float *d_img, int rows, int cols, int nclusters, const int32_t *h_b_off,
                    const int32_t *h_bx, const int32_t *h_by, const int32_t *h_i_off,
                    const int32_t *h_ix, const int32_t *h_iy, void *stream);
+/* the same on nimg f32 images [nimg][rows][cols] (the frames of a sub-batch of the loop, psp_process.cpp:1797-1800): the tables
+ * are built once, a wave takes one cluster on 64 frames */
+int upsp_patch_frames_f32(float *d_imgs, int nimg, int rows, int cols, int nclusters, const int32_t *h_b_off,
+                          const int32_t *h_bx, const int32_t *h_by, const int32_t *h_i_off,
+                          const int32_t *h_ix, const int32_t *h_iy, void *stream);
 
 /* ======================================================================== *
  *  3b. Video decode -> device   (reference:
@@ -601,6 +608,11 @@ int upsp_exchange_finish_pixels(upsp_exchange *x, float *d_series, int64_t ld, d
  * three: spread of the single timed spans); the caller must have synchronised the stream(s). */
 int upsp_timing_enable(int on);
 int upsp_timing_report(char *buf, size_t cap);
+
+/* Device copy probe: a streaming 16-byte-per-lane copy kernel d_src -> d_dst of `bytes` (d_src NULL: the store half alone),
+ * `reps` launches timed with HIP events on `stream`.  The measured HBM rate SURVEY.md 8(d) names as the roofline's
+ * denominator: GB/s = (2 x bytes, or bytes for the fill) / ms_per_rep / 1e6. */
+int upsp_copy_probe(const void *d_src, void *d_dst, size_t bytes, int reps, float *ms_per_rep, void *stream);
 
 /* Phase labels (reference: timedBarrierPoint / psp::BlockTimer, cpp/exec/psp_process.cpp:585-606): begin / end
  * nest; every phase is a roctx range (rocprofv3 --marker-trace: libroctx64 is looked up at run time, not linked) and,

@@ -51,12 +51,17 @@ def bench_key(name):
 traffic, weight = {}, {}
 for name, v in res.items():
     key, stream = bench_key(name)
-    if key and "FETCH_SIZE_KB_per_launch" in v and "WRITE_SIZE_KB_per_launch" in v:
-        # several kernels under one bench name (the identity and the general ECC sums launches): call-weighted mean per launch
-        b = ((2 if stream else 1) * v["FETCH_SIZE_KB_per_launch"] + v["WRITE_SIZE_KB_per_launch"]) * 1024
-        n = v.get("calls", 1)
-        traffic[key] = (traffic.get(key, 0.0) * weight.get(key, 0) + b * n) / (weight.get(key, 0) + n)
-        weight[key] = weight.get(key, 0) + n
+    keys = [key] if key else []
+    # the two ECC sums kernels also under their own bench names (the roofline names the dominant one, not the blend)
+    if name.startswith("ecc_cols_kernel<true"): keys.append("ecc_sums_identity")
+    if name.startswith("ecc_cols_kernel<false"): keys.append("ecc_sums_general")
+    for key in keys:
+        if "FETCH_SIZE_KB_per_launch" in v and "WRITE_SIZE_KB_per_launch" in v:
+            # several kernels under one bench name (the identity and the general ECC sums launches): call-weighted mean per launch
+            b = ((2 if stream else 1) * v["FETCH_SIZE_KB_per_launch"] + v["WRITE_SIZE_KB_per_launch"]) * 1024
+            n = v.get("calls", 1)
+            traffic[key] = (traffic.get(key, 0.0) * weight.get(key, 0) + b * n) / (weight.get(key, 0) + n)
+            weight[key] = weight.get(key, 0) + n
 summary = {"bench_args": " ".join(args), "kernels": res, "traffic_bytes_per_launch": traffic,
            "note": "rocprofv3 --kernel-trace --stats (durations) and two separate --pmc passes (FETCH_SIZE, WRITE_SIZE, unit KB); "
                    "traffic = FETCH x 2 for the streaming kernels (gfx950 reports half of wide coalesced reads) + WRITE"}

@@ -114,6 +114,7 @@ SIGNATURES = {
     "upsp_blur_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "upsp_blur_u16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "upsp_patch_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "upsp_patch_frames_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "upsp_unpack_10bit": (_i, [_vp, _i, _sz, _vp, _vp, _vp]),
     "upsp_unpack_12bit": (_i, [_vp, _i, _sz, _vp, _i, _vp, _vp]),
     "upsp_transpoly_fit": (_i, [_vp, C.c_longlong, _sz, _i, _i, _vp, C.c_longlong, _vp, _vp]),
@@ -149,6 +150,7 @@ SIGNATURES = {
     "upsp_phase_begin": (_i, [C.c_char_p]),
     "upsp_phase_end": (_i, [C.POINTER(C.c_double)]),
     "upsp_timing_enable": (_i, [_i]),
+    "upsp_copy_probe": (_i, [_vp, _vp, C.c_size_t, _i, _vp, _vp]),
     "upsp_timing_report": (_i, [C.c_char_p, _sz]),
 }
 
@@ -235,3 +237,19 @@ def timing_report(spread=False):
         name, n, ms, lo, med, hi = line.rsplit(" ", 5)
         out[name] = (int(n), float(ms), float(lo), float(med), float(hi)) if spread else (int(n), float(ms))
     return out
+
+
+def copy_probe(nbytes=1 << 30, reps=5):
+    """Measured HBM rates of this device (upsp_copy_probe: streaming float4 copy and fill of `nbytes`), GB/s."""
+    import torch
+    a = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    b = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    a.zero_()
+    ms = C.c_float()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    check(lib().upsp_copy_probe(C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), nbytes, reps, C.byref(ms), st))
+    copy = 2.0 * nbytes / (ms.value * 1e-3) / 1e9
+    check(lib().upsp_copy_probe(None, C.c_void_p(b.data_ptr()), nbytes, reps, C.byref(ms), st))
+    fill = nbytes / (ms.value * 1e-3) / 1e9
+    return {"copy_GBps": copy, "fill_GBps": fill, "bytes": int(nbytes), "reps": int(reps),
+            "kernel": "upsp::copy_probe_kernel / fill_probe_kernel (non-temporal float4, 8 workgroups per CU)"}

@@ -1355,12 +1355,19 @@ int upsp_patch_f32(float *d_img, int rows, int cols, int nclusters, const int32_
                    const int32_t *h_bx, const int32_t *h_by, const int32_t *h_i_off,
                    const int32_t *h_ix, const int32_t *h_iy, void *stream)
 {
-    if (!d_img || rows <= 0 || cols <= 0) return fail(UPSP_ERR_INVALID, "bad argument");
-    if (nclusters == 0) return UPSP_OK;
+    return upsp_patch_frames_f32(d_img, 1, rows, cols, nclusters, h_b_off, h_bx, h_by, h_i_off, h_ix, h_iy, stream);
+}
+
+int upsp_patch_frames_f32(float *d_img, int nimg, int rows, int cols, int nclusters, const int32_t *h_b_off,
+                          const int32_t *h_bx, const int32_t *h_by, const int32_t *h_i_off,
+                          const int32_t *h_ix, const int32_t *h_iy, void *stream)
+{
+    if (!d_img || nimg < 0 || rows <= 0 || cols <= 0) return fail(UPSP_ERR_INVALID, "bad argument");
+    if (nclusters == 0 || nimg == 0) return UPSP_OK;
     PatchTables *t = nullptr;
     int rc = patch_tables_create(rows, cols, nclusters, h_b_off, h_bx, h_by, h_i_off, h_ix, h_iy, &t);
     if (rc != UPSP_OK) return rc;
-    rc = launch_patch(t, d_img, 1, rows, cols, (hipStream_t)stream);
+    rc = launch_patch(t, d_img, nimg, rows, cols, (hipStream_t)stream);
     hipError_t e = hipStreamSynchronize((hipStream_t)stream);
     patch_tables_free(t);
     if (rc == UPSP_OK && e != hipSuccess) rc = fail(UPSP_ERR_HIP, hipGetErrorString(e));

@@ -195,3 +195,55 @@ int upsp_timing_report(char *buf, size_t cap)
     return UPSP_OK;
 }
 }
+
+
+// ---- device copy / fill probe: the measured HBM rate the roofline fractions are also quoted against -----------------
+// "denominator: measured peak of a rocprof'd device copy kernel on gfx950".  A streaming float4 copy
+// (non-temporal loads and stores, 16 B per lane and trip, grid of 8 workgroups per CU) and the store half alone.
+namespace upsp {
+namespace {
+typedef float v4f_probe __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) copy_probe_kernel(const v4f_probe *__restrict__ src, v4f_probe *__restrict__ dst, size_t n16)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+__global__ void __launch_bounds__(256) fill_probe_kernel(v4f_probe *__restrict__ dst, size_t n16)
+{
+    const v4f_probe v = {1.f, 2.f, 3.f, 4.f};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) __builtin_nontemporal_store(v, dst + i);
+}
+}  // namespace
+}  // namespace upsp
+
+extern "C" int upsp_copy_probe(const void *d_src, void *d_dst, size_t bytes, int reps, float *ms_per_rep, void *stream)
+{
+    using namespace upsp;
+    if (!d_dst || bytes < 16 || reps < 1 || !ms_per_rep) return fail(UPSP_ERR_INVALID, "bad argument");
+    if (((reinterpret_cast<size_t>(d_src) | reinterpret_cast<size_t>(d_dst)) & 15) != 0) return fail(UPSP_ERR_INVALID, "copy probe: 16-byte aligned buffers");
+    hipStream_t st = (hipStream_t)stream;
+    int dev = 0, cus = 256;
+    UPSP_HIP_CHECK(hipGetDevice(&dev));
+    UPSP_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const size_t n16 = bytes / 16;
+    const unsigned grid = (unsigned)std::min<size_t>((n16 + 255) / 256, (size_t)cus * 8);
+    hipEvent_t a = nullptr, b = nullptr;
+    UPSP_HIP_CHECK(hipEventCreate(&a));
+    UPSP_HIP_CHECK(hipEventCreate(&b));
+    auto launch = [&] {
+        if (d_src) hipLaunchKernelGGL(copy_probe_kernel, dim3(grid), dim3(256), 0, st, static_cast<const v4f_probe *>(d_src), static_cast<v4f_probe *>(d_dst), n16);
+        else hipLaunchKernelGGL(fill_probe_kernel, dim3(grid), dim3(256), 0, st, static_cast<v4f_probe *>(d_dst), n16);
+    };
+    launch();                                   // (untimed: first touch, code load)
+    hipError_t e = hipEventRecord(a, st);
+    for (int i = 0; i < reps && e == hipSuccess; ++i) launch();
+    if (e == hipSuccess) e = hipEventRecord(b, st);
+    if (e == hipSuccess) e = hipEventSynchronize(b);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, a, b);
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    if (e != hipSuccess) return fail(UPSP_ERR_HIP, std::string("copy probe: ") + hipGetErrorString(e));
+    *ms_per_rep = ms / (float)reps;
+    return UPSP_OK;
+}

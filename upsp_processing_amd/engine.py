@@ -522,12 +522,13 @@ def _cluster_arrays(clusters):
 
 
 def patch(img32f, clusters):
-    """PatchClusters<float>::operator() (cpp/lib/patches.ipp:98-165), in place on a f32 image."""
-    assert img32f.is_cuda and img32f.dtype == torch.float32 and img32f.is_contiguous()
-    h, w = img32f.shape
+    """PatchClusters<float>::operator() (cpp/lib/patches.ipp:98-165), in place on a f32 image [H, W] or on a stack of
+    images [F, H, W]."""
+    assert img32f.is_cuda and img32f.dtype == torch.float32 and img32f.is_contiguous() and img32f.dim() in (2, 3)
+    h, w = img32f.shape[-2:]
     arr = _cluster_arrays(clusters)
-    check(lib().upsp_patch_f32(_ptr(img32f), h, w, len(clusters),
-                               *[a.ctypes.data_as(C.c_void_p) for a in arr], _stream()))
+    check(lib().upsp_patch_frames_f32(_ptr(img32f), 1 if img32f.dim() == 2 else img32f.shape[0], h, w, len(clusters),
+                                      *[a.ctypes.data_as(C.c_void_p) for a in arr], _stream()))
     return img32f
 
 
