@@ -983,6 +983,8 @@ def main():
     exchs = [exch, D.TimeSeriesExchange(shard, K, wire12=a.wire12)] if deferred else [exch]
     ex_state = {"step": 0, "pending": None, "first": [True, True], "last_done": exch}
 
+    drain_first = os.environ.get("UPSP_BENCH_DRAIN_FIRST", "0") == "1"
+
     def drain():
         """finish the exchange the previous step left in flight (pass B of its frames: series + its slice of the sums)"""
         if ex_state["pending"] is not None:
@@ -1070,8 +1072,10 @@ def main():
                 tab = pipe.pixel_series(frames)
             else:
                 tab = pipe.pixel_series(None)       # node -> compact row of this projection
-            ex.set_pixels(tab["node_k"], engine.skipped_nodes(proj["pix"], want_count=False)[0], assume_same=not ex_state["first"][which])
+            ex.set_pixels(tab["node_k"], engine.skipped_nodes(proj["pix"], want_count=False, as_bool=False)[0], assume_same=not ex_state["first"][which])
             ex_state["first"][which] = False
+            if deferred and drain_first:
+                drain()                             # (A/B: the previous step's pass B BEFORE this step's chunks go out)
             for k in range(K):
                 c0, fc = ex.my_chunk(k)
                 if px_once and overlap:
@@ -1087,7 +1091,7 @@ def main():
             # the travelling rows packed (row map) straight into the send buffers.  The projection is
             # rebuilt every step and is the same every step: the travelling set is derived (one host
             # read of W counters) in the first step and only verified on the device afterwards.
-            exch.set_skipped(engine.skipped_nodes(proj["pix"], want_count=False)[0], assume_same=not first_step[0])
+            exch.set_skipped(engine.skipped_nodes(proj["pix"], want_count=False, as_bool=False)[0], assume_same=not first_step[0])
             first_step[0] = False
             pipe.set_row_map(exch.row_map())
             nrows = exch.packed_rows()

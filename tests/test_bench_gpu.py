@@ -73,7 +73,10 @@ def test_bench_rccl_one_rank_group(gpu_lib):
     """RCCL refuses two ranks on one GPU, so on a one-GPU box the N > 1 loop runs in a ONE-rank nccl group with the
     collectives forced (all_reduce of the accumulators, async all_to_all_single of the packed u16 chunks as bytes,
     barrier): the calls, dtypes and split sizes go through RCCL itself."""
-    d = run_bench(["--force-chunked", "--row-wire", "--small", "--steps", "2", "--warmup", "1"], env={"UPSP_FORCE_COLLECTIVES": "1"})
+    # (UPSP_EXCHANGE_SELF_RCCL=1: the rank's own block goes through ncclSend / ncclRecv to self as well -- by default a rank reads its
+    #  own block where it lies in the send buffer, and a one-rank group would then issue no point-to-point call at all)
+    d = run_bench(["--force-chunked", "--row-wire", "--small", "--steps", "2", "--warmup", "1"],
+                  env={"UPSP_FORCE_COLLECTIVES": "1", "UPSP_EXCHANGE_SELF_RCCL": "1"})
     assert d["n_gpus"] == 1 and d["collectives"].startswith("issued through RCCL")
     assert d["config"]["exchange"] == "4 chunks, visible rows as u16"
     assert d["parity_checked"] is True
@@ -100,7 +103,8 @@ def test_bench_pixel_wire(gpu_lib, rccl_shim):
     # (deferred = the N > 1 default: one block per peer, pass A once for the rank's frames beside the projection build)
     once = "1 chunks, active-pixel series as u16; two exchanges in turn, a step's series finished behind the next step's chunks; pass A once"
     assert d["n_gpus"] == 2 and d["config"]["exchange"].startswith(once) and d["exchange_self_check"] is True
-    d = run_bench(["--force-chunked", "--defer-exchange", "--small", "--steps", "3", "--warmup", "1"], env={"UPSP_FORCE_COLLECTIVES": "1"})
+    d = run_bench(["--force-chunked", "--defer-exchange", "--small", "--steps", "3", "--warmup", "1"],
+                  env={"UPSP_FORCE_COLLECTIVES": "1", "UPSP_EXCHANGE_SELF_RCCL": "1"})
     assert d["config"]["exchange"].startswith(once) and d["parity_checked"] is True
     assert d["rccl_nranks"] == 1
     # the schedules of round 3 / early round 4 stay reachable: deferred with pass A per chunk, and finished inside the step

@@ -58,8 +58,11 @@ def test_exchange_pixel_series_local_ranks(exe, world):
     assert rows <= 211 * world and rows < 803            # <= A pixels per destination, fewer than the travelling nodes
 
 
-def test_exchange_rccl_one_rank(exe):
-    r = subprocess.run([exe, "rccl1"], capture_output=True, text=True, timeout=300)
+@pytest.mark.parametrize("self_rccl", ["0", "1"])
+def test_exchange_rccl_one_rank(exe, self_rccl):
+    """One-rank RCCL communicator: the rank's own block read in place (default: no transfer, no copy) and sent through
+    ncclSend / ncclRecv to self (UPSP_EXCHANGE_SELF_RCCL=1: RCCL's own kernels carry it, as they carry every block between GPUs)."""
+    r = subprocess.run([exe, "rccl1"], capture_output=True, text=True, timeout=300, env=dict(os.environ, UPSP_EXCHANGE_SELF_RCCL=self_rccl))
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count(" ok,") == 3, r.stdout
 

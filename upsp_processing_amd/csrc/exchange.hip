@@ -345,6 +345,7 @@ struct upsp_exchange {
     int wire = 0;                              // bytes per element of the chunks submitted so far: 4, 2; 12 = packed 12 bit
     std::vector<std::vector<void *>> stage;    // [chunk][source rank] received block
     std::vector<std::vector<size_t>> stage_bytes;
+    std::vector<const void *> self_block;      // [chunk] this rank's own block where it lies in the send buffer (not copied, not sent)
     std::vector<void *> packed;                // [chunk] 12-bit send buffer
     std::vector<size_t> packed_bytes;
     std::shared_ptr<XferStream> xfer;           // the communicator's transfer stream (shared by its exchanges)
@@ -371,6 +372,23 @@ namespace {
 size_t wire_row_bytes(int wire, int64_t fc)
 {
     return wire == 12 ? (size_t)((fc + 1) / 2) * 3 : (size_t)fc * (size_t)wire;
+}
+
+// The block of chunk k that came from rank s: its staging buffer -- or, for this rank's own block over RCCL, the place in the
+// send buffer where it lies (a block for oneself needs no transfer and no copy: the send buffer stays untouched until the pass
+// is finished anyway).  UPSP_EXCHANGE_SELF_RCCL=1 sends it through ncclSend / ncclRecv to self like every other block (the
+// one-GPU rehearsals of the N > 1 loop, where RCCL's kernel is then on the device beside pass B as it is between GPUs).
+const void *block_of(const upsp_exchange *x, int k, int s)
+{
+    return (s == x->c->rank && x->self_block[k]) ? x->self_block[k] : x->stage[k][s];
+}
+bool self_through_rccl()
+{
+    static const bool v = [] {
+        const char *e = getenv("UPSP_EXCHANGE_SELF_RCCL");
+        return e && *e && *e != '0';
+    }();
+    return v;
 }
 
 void free_rows(upsp_exchange *x)
@@ -555,6 +573,7 @@ int upsp_exchange_create(upsp_comm *c, int64_t nframes_total, int64_t nnodes, in
     for (int s = 0; s < c->world; ++s) aligned_chunks(x->frame_count[s], nchunks, 64, x->chunk_start[s], x->chunk_count[s]);
     x->stage.assign(nchunks, std::vector<void *>(c->world, nullptr));
     x->stage_bytes.assign(nchunks, std::vector<size_t>(c->world, 0));
+    x->self_block.assign(nchunks, nullptr);
     x->packed.assign(nchunks, nullptr);
     x->packed_bytes.assign(nchunks, 0);
     x->gathered.assign(nchunks, nullptr);
@@ -562,7 +581,17 @@ int upsp_exchange_create(upsp_comm *c, int64_t nframes_total, int64_t nnodes, in
     hipError_t e = hipSuccess;
     if (!c->xfer) {
         c->xfer = std::make_shared<XferStream>();
-        e = hipStreamCreateWithFlags(&c->xfer->st, hipStreamNonBlocking);
+        // LOW priority: a block has until the pass is finished to arrive (with two exchanges in turn: a whole step), and RCCL's
+        // workgroups should not hold compute units the frame loop's kernels are waiting for -- one GPU through one-rank RCCL, deferred
+        // exchange, one call: 1.19 ms per step against 1.29 at normal priority (plain loop 0.95-1.00; tools/gpu_n1_ab.sh).
+        // UPSP_XFER_PRIORITY=normal|high: measurement switch.
+        const char *pe = getenv("UPSP_XFER_PRIORITY");
+        int least = 0, greatest = 0;
+        const bool have_range = hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
+        if (have_range && !(pe && pe[0] == 'n'))
+            e = hipStreamCreateWithPriority(&c->xfer->st, hipStreamNonBlocking, (pe && pe[0] == 'h') ? greatest : least);
+        else
+            e = hipStreamCreateWithFlags(&c->xfer->st, hipStreamNonBlocking);
     }
     x->xfer = c->xfer;
     x->comm_stream = c->xfer->st;
@@ -705,9 +734,12 @@ static int submit_core(upsp_exchange *x, const void *d_chunk, int wire, hipStrea
                            (long long)x->nvis, (int)fc, static_cast<uint8_t *>(x->packed[k]), x->d_flags + 1);
         send = static_cast<const uint8_t *>(x->packed[k]);
     }
-    // staging for what arrives: from rank s, my rows x its chunk k
+    // staging for what arrives: from rank s, my rows x its chunk k (my own block is read where it lies in the send buffer)
     const int64_t rows_in = x->cut[me + 1] - x->cut[me];
+    const bool self_alias = x->c->kind == 0 && !self_through_rccl();
+    x->self_block[k] = (self_alias && rows_in > 0 && fc > 0) ? send + rb * (size_t)x->cut[me] : nullptr;
     for (int s = 0; s < W; ++s) {
+        if (s == me && self_alias) continue;
         const size_t want = wire_row_bytes(wire, x->chunk_count[s][k]) * (size_t)rows_in;
         int rc = ensure_buffer(x->stage[k][s], x->stage_bytes[k][s], want);
         if (rc != UPSP_OK) return rc;
@@ -718,8 +750,10 @@ static int submit_core(upsp_exchange *x, const void *d_chunk, int wire, hipStrea
         UPSP_HIP_CHECK(hipStreamWaitEvent(x->comm_stream, x->ev_ready, 0));
         // (x->k and the byte counters move only once the whole group is in: a failed call leaves the exchange where it was)
         uint64_t sent = 0, received = 0;
-        UPSP_NCCL_CHECK(r.GroupStart(), "ncclGroupStart");
-        for (int p = 0; p < W; ++p) {
+        const bool any_peer = W > 1 || !self_alias;         // (one rank, own block in place: nothing for RCCL to do)
+        if (any_peer) UPSP_NCCL_CHECK(r.GroupStart(), "ncclGroupStart");
+        for (int p = 0; p < W && any_peer; ++p) {
+            if (p == me && self_alias) continue;
             const size_t out_b = rb * (size_t)(x->cut[p + 1] - x->cut[p]);
             const size_t in_b = wire_row_bytes(wire, x->chunk_count[p][k]) * (size_t)rows_in;
             if (out_b) {
@@ -731,7 +765,7 @@ static int submit_core(upsp_exchange *x, const void *d_chunk, int wire, hipStrea
                 if (p != me) received += in_b;
             }
         }
-        UPSP_NCCL_CHECK(r.GroupEnd(), "ncclGroupEnd");
+        if (any_peer) UPSP_NCCL_CHECK(r.GroupEnd(), "ncclGroupEnd");
         // "everything submitted so far has arrived" is marked HERE, behind this chunk: the transfer stream is shared by the
         // exchanges of the communicator, and a mark set only when the pass is finished would sit behind whatever another
         // exchange has submitted in the meantime (two exchanges in turn: the next step's blocks)
@@ -806,12 +840,12 @@ int upsp_exchange_finish(upsp_exchange *x, float *d_series, int64_t ld, void *st
                 if (!fs || !rows_in) continue;
                 float *dst = d_series + x->frame_start[s] + x->chunk_start[s][k];
                 if (x->wire == 4)
-                    rc = upsp_scatter_rows_f32(static_cast<const float *>(x->stage[k][s]), (size_t)rows_in, (int)fs, x->d_vis_mine, dst, ld, stream);
+                    rc = upsp_scatter_rows_f32(static_cast<const float *>(block_of(x, k, s)), (size_t)rows_in, (int)fs, x->d_vis_mine, dst, ld, stream);
                 else if (x->wire == 2)
-                    rc = upsp_scatter_rows_u16(static_cast<const uint16_t *>(x->stage[k][s]), (size_t)rows_in, (int)fs, x->d_vis_mine, dst, ld, stream);
+                    rc = upsp_scatter_rows_u16(static_cast<const uint16_t *>(block_of(x, k, s)), (size_t)rows_in, (int)fs, x->d_vis_mine, dst, ld, stream);
                 else
                     hipLaunchKernelGGL(place12_rows_kernel, dim3((unsigned)((rows_in + 3) / 4)), dim3(256), 0, st,
-                                       static_cast<const uint8_t *>(x->stage[k][s]), (long long)rows_in, (int)fs,
+                                       static_cast<const uint8_t *>(block_of(x, k, s)), (long long)rows_in, (int)fs,
                                        (const long long *)x->d_vis_mine, dst, (long long)ld);
                 if (rc != UPSP_OK) return rc;
             }
@@ -953,7 +987,7 @@ int upsp_exchange_finish_pixels(upsp_exchange *x, float *d_series, int64_t ld, d
             for (int s = 0; s < W; ++s) {
                 const int64_t fs = x->chunk_count[s][0];
                 if (!fs) continue;
-                rc = upsp_rows_from_pixel_series(static_cast<const uint16_t *>(x->stage[0][s]), (uint32_t)fs, x->d_node_local,
+                rc = upsp_rows_from_pixel_series(static_cast<const uint16_t *>(block_of(x, 0, s)), (uint32_t)fs, x->d_node_local,
                                                  x->d_skipped_me, (size_t)x->node_count[me], fs, d_series + x->frame_start[s], ld,
                                                  d_sum_mine, d_sumsq_mine, stream);
                 if (rc != UPSP_OK) return rc;
@@ -972,10 +1006,10 @@ int upsp_exchange_finish_pixels(upsp_exchange *x, float *d_series, int64_t ld, d
                 uint16_t *dst = x->d_compact_me + x->frame_start[s] + x->chunk_start[s][k];
                 const dim3 grid((unsigned)((rows_in + 3) / 4)), block(256);
                 if (x->wire == 2)
-                    hipLaunchKernelGGL(place_pixel_rows_kernel<2>, grid, block, 0, st, static_cast<const uint8_t *>(x->stage[k][s]),
+                    hipLaunchKernelGGL(place_pixel_rows_kernel<2>, grid, block, 0, st, static_cast<const uint8_t *>(block_of(x, k, s)),
                                        (long long)rows_in, (int)fs, dst, (long long)x->fpad);
                 else
-                    hipLaunchKernelGGL(place_pixel_rows_kernel<12>, grid, block, 0, st, static_cast<const uint8_t *>(x->stage[k][s]),
+                    hipLaunchKernelGGL(place_pixel_rows_kernel<12>, grid, block, 0, st, static_cast<const uint8_t *>(block_of(x, k, s)),
                                        (long long)rows_in, (int)fs, dst, (long long)x->fpad);
             }
         UPSP_HIP_CHECK(hipGetLastError());

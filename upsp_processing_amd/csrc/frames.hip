@@ -893,14 +893,22 @@ __global__ void __launch_bounds__(256)
         if (s_sk[r] == 0 && k >= 0 && f0 < nframes) w = *reinterpret_cast<const uint2 *>(compact + (size_t)k * cpitch + f0);
         return w;
     };
-    uint2 w_next = AHEAD ? series_load(0) : make_uint2(0u, 0u);
+    // AHEAD 2: the series of ALL sweeps are requested before the first row is stored -- one memory latency per workgroup instead
+    // of one per sweep.  Nothing for series that sit in the Infinity Cache (pass A wrote them a moment ago: 0.40-0.41 ms either
+    // way), the difference when they come from HBM (the owner's pass B over blocks that arrived a step ago: tools/passb_probe.py)
+    uint2 w_all[AHEAD == 2 ? ROWS : 1];
+    if (AHEAD == 2) {
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) w_all[j] = series_load(j);
+    }
+    uint2 w_next = AHEAD == 1 ? series_load(0) : make_uint2(0u, 0u);
 #pragma unroll
     for (int j = 0; j < ROWS; ++j) {
         const int r = j * RPS + sub;                            // (uniform per wave)
         const int k = s_k[r], row = s_row[r];
         const bool sk = s_sk[r] != 0;
-        uint2 w = AHEAD ? w_next : series_load(j);
-        if (AHEAD && j + 1 < ROWS) w_next = series_load(j + 1);
+        uint2 w = AHEAD == 2 ? w_all[AHEAD == 2 ? j : 0] : (AHEAD == 1 ? w_next : series_load(j));
+        if (AHEAD == 1 && j + 1 < ROWS) w_next = series_load(j + 1);
         if (sk || k == -1) {
             // (uniform per wave) a row without data -- no camera sees the node: NaN; no pixel: 0 -- is a constant fill:
             // no load, no sums, no reductions (its partials are not read below).  These are 60 % of the rows of the bench
@@ -1753,7 +1761,7 @@ int launch_amap_nodes(const int32_t *d_pix, size_t nnodes, const uint8_t *d_flag
 
 // g.img[0]: the group's first frame (u16) -- only read for nodes whose pixel is missing from the map (node_k == -2)
 int launch_node_rows(const PipelineGather &g, const int32_t *d_node_k, const uint16_t *d_compact, unsigned cpitch,
-                     hipStream_t st)
+                     hipStream_t st, bool cold_series)
 {
     if (g.nframes <= 0 || g.nframes > kGroupFramesMax || (unsigned)g.nframes > cpitch)
         return fail(UPSP_ERR_INVALID, "row pass: too many frames");
@@ -1762,15 +1770,30 @@ int launch_node_rows(const PipelineGather &g, const int32_t *d_node_k, const uin
     // four sweeps per workgroup (1 / 2 / 4 / 8: 486 / 412 / 370 / 422 us per 1000 frames of the bench model); the series loads
     // of all sweeps first (one sweep ahead of the rows that use them, the arrangement that pays in the multi-camera kernel:
     // 0.403-0.413 ms either way here -- this kernel waits for its stores)
-#define UPSP_NR(LPR, U16)                                                                                    \
-    hipLaunchKernelGGL((node_rows_kernel<LPR, 4, U16, 0>), dim3((nn + (256 / LPR) * 4 - 1) / ((256 / LPR) * 4)), \
+#define UPSP_NRX(LPR, ROWS, U16, AH)                                                                         \
+    hipLaunchKernelGGL((node_rows_kernel<LPR, ROWS, U16, AH>), dim3((nn + (256 / LPR) * ROWS - 1) / ((256 / LPR) * ROWS)), \
                        dim3(256), 0, st, d_compact, cpitch, d_node_k, g.skipped, g.rowmap, nn, g.nframes, g.rows_t,  \
                        g.rows_t16, (long long)g.ld_t, g.sum, g.sumsq, (const uint16_t *)g.img[0], g.npix, g.pix[0])
+#define UPSP_NR(LPR, U16) UPSP_NRX(LPR, 4, U16, 0)
 #define UPSP_NR_L(U16)                                                                                       \
     do {                                                                                                     \
         if (g.nframes > 512) UPSP_NR(256, U16); else if (g.nframes > 256) UPSP_NR(128, U16); else UPSP_NR(64, U16); \
     } while (0)
-    if (g.rows_t16) UPSP_NR_L(true); else UPSP_NR_L(false);
+    // (measurement switch UPSP_ROWS_VARIANT = <sweeps><ahead>, f32 rows of > 512 frames: 40 default, 41, 42, 80, 81, 82, 162)
+    static const int variant = [] { const char *e = getenv("UPSP_ROWS_VARIANT"); return e ? atoi(e) : 0; }();
+    const int var = (cold_series && !variant) ? 82 : variant;
+    if (var && !g.rows_t16 && g.nframes > 512) {
+        switch (var) {
+        case 41: UPSP_NRX(256, 4, false, 1); break;
+        case 42: UPSP_NRX(256, 4, false, 2); break;
+        case 80: UPSP_NRX(256, 8, false, 0); break;
+        case 81: UPSP_NRX(256, 8, false, 1); break;
+        case 82: UPSP_NRX(256, 8, false, 2); break;
+        case 162: UPSP_NRX(256, 16, false, 2); break;
+        default: UPSP_NRX(256, 4, false, 0); break;
+        }
+    } else if (g.rows_t16) UPSP_NR_L(true); else UPSP_NR_L(false);
+#undef UPSP_NRX
 #undef UPSP_NR_L
 #undef UPSP_NR
     UPSP_HIP_CHECK(hipGetLastError());

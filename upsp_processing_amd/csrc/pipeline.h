@@ -48,8 +48,10 @@ int group_frames_max();    // frames per pass B (whole rows) of the one-camera s
 int launch_scan_compact(uint16_t *d_frames, size_t npix, int nframes, bool hot, int thresh, int max_hot,
                         const uint8_t *d_flag, const unsigned *d_off, const unsigned *d_order, uint16_t *d_compact,
                         unsigned cpitch, int col, unsigned *d_count, unsigned *d_pos, hipStream_t st);
+// cold_series: the compact series were not written a moment ago (they come from HBM, not from the Infinity Cache): every
+// sweep's series are requested up front
 int launch_node_rows(const PipelineGather &g, const int32_t *d_node_k, const uint16_t *d_compact, unsigned cpitch,
-                     hipStream_t st);
+                     hipStream_t st, bool cold_series = false);
 int launch_node_rows_multi(const PipelineGather &g, const int32_t *const *d_node_k, const uint16_t *const *d_compact,
                            unsigned cpitch, hipStream_t st);
 size_t hot_changes_words(int nframes, int max_hot);   // size of d_changes for launch_hot_fixup

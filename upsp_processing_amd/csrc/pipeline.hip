@@ -630,7 +630,8 @@ int upsp_rows_from_pixel_series(const uint16_t *d_compact, uint32_t cpitch, cons
     for (int64_t f0 = 0; f0 < nframes && rc == UPSP_OK; f0 += G) {
         g.nframes = (int)std::min<int64_t>(G, nframes - f0);
         g.rows_t = d_rows_t + f0;
-        rc = launch_node_rows(g, d_node_k, d_compact + f0, cpitch, (hipStream_t)stream);
+        // (the caller's series: received from a peer, or kept from an earlier call -- not the pipeline's own pass A of a moment ago)
+        rc = launch_node_rows(g, d_node_k, d_compact + f0, cpitch, (hipStream_t)stream, true);
     }
     return rc;
 }

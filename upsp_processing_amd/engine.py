@@ -219,9 +219,10 @@ def projection_weights(pix, nodes, normals, centers, mode="average_view"):
     return w
 
 
-def skipped_nodes(pix, want_count=True):
+def skipped_nodes(pix, want_count=True, as_bool=True):
     """identify_skipped_nodes (projection.ipp:857-880).  pix: [ncams, N] or [N].
-    want_count=False skips the host read-back of the count (returns None for it)."""
+    want_count=False skips the host read-back of the count (returns None for it); as_bool=False returns the flags as the
+    uint8 array the library wrote (what set_skipped / the exchange take: no conversion kernels in a per-step call)."""
     pix = _dev(pix, torch.int32)
     if pix.dim() == 1:
         pix = pix[None]
@@ -230,7 +231,7 @@ def skipped_nodes(pix, want_count=True):
     cnt = C.c_uint64(0)
     check(lib().upsp_projection_skipped(ncams, n, _ptr(pix), _ptr(sk), C.byref(cnt) if want_count else None,
                                         _stream()))
-    return sk.bool(), (int(cnt.value) if want_count else None)
+    return (sk.bool() if as_bool else sk), (int(cnt.value) if want_count else None)
 
 
 def fix_hot_pixels(frames, thresh=4064, min_change=512, max_hot=5):
