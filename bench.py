@@ -1005,6 +1005,8 @@ def main():
     swap = overlap and os.environ.get("UPSP_BENCH_BUILD_ON_SIDE", "1") == "1"
     cand_oblique = os.environ.get("UPSP_BENCH_CAND_OBLIQUE", "1") == "1"      # (A/B: candidates = every in-frame node, round 3)
     side_waits = os.environ.get("UPSP_BENCH_SIDE_WAIT", "0") == "1"      # (A/B: the build of a step behind the previous step's pass B)
+    map_on_side = swap and os.environ.get("UPSP_BENCH_MAP_ON_SIDE", "1") == "1"     # (A/B: 0 = the map on the main stream, round 4)
+    step_end = []                                                                   # end-of-step events of the last steps (main stream)
     # configs[2]: the build of a step on a stream of its own as well -- it runs beside the previous step's registration
     reg_side = a.registration and not a.serial and not chunked and not side_waits
     # (the side stream must be a HIGH-priority one to get a hardware queue of its own: a normal-priority torch stream shares the
@@ -1025,9 +1027,24 @@ def main():
             # The consumer side is ordered below (main waits for the side stream before it takes the projection).
             if side_waits:
                 side.wait_stream(main)
-            with torch.cuda.stream(side):
-                proj = engine.build_projection(bvh, cam, d_nodes, d_nrm, d_tn, 70.0, counts=False)
-            pipe.set_active_hint(engine.candidate_pixels(cam, d_nodes, normals=d_nrm if cand_oblique else None, oblique_angle_deg=70.0))
+            if map_on_side:
+                # The candidate-pixel map of this step's pass A depends on the camera and the nodes only: it is built on the side stream
+                # too, IN FRONT of the build -- beside the previous step's pass B -- instead of between that pass B and this pass A
+                # (six small launches, 35-40 us of a 0.93-ms step).  The pipeline builds it in its second set of map arrays; that set
+                # was last read by the step before the previous one (ordered by that step's end-of-step event: the side stream
+                # waits for nothing the main stream still has to do).
+                with torch.cuda.stream(side):
+                    if len(step_end) >= 2:
+                        side.wait_event(step_end[-2])
+                    pipe.set_active_hint(engine.candidate_pixels(cam, d_nodes, normals=d_nrm if cand_oblique else None, oblique_angle_deg=70.0))
+                    ev_map = torch.cuda.Event()
+                    ev_map.record(side)
+                    proj = engine.build_projection(bvh, cam, d_nodes, d_nrm, d_tn, 70.0, counts=False)
+                main.wait_event(ev_map)
+            else:
+                with torch.cuda.stream(side):
+                    proj = engine.build_projection(bvh, cam, d_nodes, d_nrm, d_tn, 70.0, counts=False)
+                pipe.set_active_hint(engine.candidate_pixels(cam, d_nodes, normals=d_nrm if cand_oblique else None, oblique_angle_deg=70.0))
             pipe.prescan(frames)
         elif overlap:
             # which pixels the frame loop will read is known once the nodes are projected into the image
@@ -1117,6 +1134,9 @@ def main():
         if os.environ.get("UPSP_BENCH_TRACE_HOST"):
             sys.stderr.write("host tail: finish_pixels %.3f allreduce %.3f finalize %.3f ms\n" % tuple((b - a) * 1e3 for a, b in zip(_h[:-1], _h[1:])))
         e[3].record()
+        if map_on_side:
+            step_end.append(e[3])
+            del step_end[:-2]
         ht.append(time.perf_counter())
         if record:                      # events are read after the timed loop: no host sync inside it
             ev_log.append(e)

@@ -273,6 +273,10 @@ int upsp_pipeline_set_hot_enable(upsp_pipeline *p, int enable);
  *   upsp_pipeline_set_projection_async(...) ; upsp_pipeline_process(p, &d_frames, n, ...)   -- after s2's work
  *                                                         (caller's event): pass B + hot-pixel fix-up only
  * A node whose final pixel is missing from the candidate set is served from the frames directly (correct, slow).
+ * The map arrays exist twice and every call with a candidate set builds into the pair the launches already queued do not
+ * read: the call for the NEXT frame batch may be issued (on another stream) while pass B / the fix-up of the current one are
+ * still queued or running; the pair it takes was last read by the launches of the call before the previous one -- a caller
+ * whose streams can drift that far apart orders that with an event.
  * One camera, plain path. */
 int upsp_pipeline_set_active_hint(upsp_pipeline *p, const int32_t *d_pix_candidates, void *stream);
 int upsp_pipeline_prescan(upsp_pipeline *p, uint16_t *d_frames, int nframes, void *stream);
@@ -610,7 +614,8 @@ int upsp_timing_enable(int on);
 int upsp_timing_report(char *buf, size_t cap);
 
 /* Device copy probe: a streaming 16-byte-per-lane copy kernel d_src -> d_dst of `bytes` (d_src NULL: the store half alone),
- * `reps` launches timed with HIP events on `stream`.  The measured HBM rate SURVEY.md 8(d) names as the roofline's
+ * `reps` launches timed with HIP events on `stream`, the fastest of six launch shapes (non-temporal / plain accesses at 8, 16,
+ * 32 workgroups per CU).  The measured HBM rate SURVEY.md 8(d) names as the roofline's
  * denominator: GB/s = (2 x bytes, or bytes for the fill) / ms_per_rep / 1e6. */
 int upsp_copy_probe(const void *d_src, void *d_dst, size_t bytes, int reps, float *ms_per_rep, void *stream);
 

@@ -252,4 +252,4 @@ def copy_probe(nbytes=1 << 30, reps=5):
     check(lib().upsp_copy_probe(None, C.c_void_p(b.data_ptr()), nbytes, reps, C.byref(ms), st))
     fill = nbytes / (ms.value * 1e-3) / 1e9
     return {"copy_GBps": copy, "fill_GBps": fill, "bytes": int(nbytes), "reps": int(reps),
-            "kernel": "upsp::copy_probe_kernel / fill_probe_kernel (non-temporal float4, 8 workgroups per CU)"}
+            "kernel": "upsp::copy_probe_kernel / fill_probe_kernel (float4 per lane; fastest of non-temporal / plain at 8, 16, 32 workgroups per CU)"}

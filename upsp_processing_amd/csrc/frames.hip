@@ -695,7 +695,7 @@ __global__ void __launch_bounds__(1024)
 // stay neighbours, the compact rows of successive active tiles too).
 // (the j-th active / inactive tile is found by a binary search in the active-tile ranks: arank[t] = active tiles before
 //  tile t, monotone, 32 KB -- thirteen cached loads per thread instead of a kernel that writes the two lists first)
-__device__ __forceinline__ unsigned amap_kth_tile(const unsigned *__restrict__ arank, unsigned ntiles, unsigned k, bool active)
+__device__ __forceinline__ unsigned amap_kth_tile(const unsigned *arank, unsigned ntiles, unsigned k, bool active)
 {
     // smallest t with (active ? arank[t + 1] : t + 1 - arank[t + 1]) > k
     unsigned lo = 0, hi = ntiles - 1;
@@ -718,13 +718,15 @@ __global__ void __launch_bounds__(256)
 }
 
 // step 3: node -> index of its pixel's series in the compact buffer (-1: no pixel)
+// (skipped, optional: identify_skipped_nodes of a ONE-camera projection in the same sweep -- a node is skipped iff it has no pixel)
 __global__ void __launch_bounds__(256)
     amap_nodes_kernel(const int32_t *__restrict__ pix, unsigned nnodes, const uint8_t *__restrict__ flag,
-                      const unsigned *__restrict__ tile_off, int32_t *__restrict__ node_k)
+                      const unsigned *__restrict__ tile_off, int32_t *__restrict__ node_k, uint8_t *__restrict__ skipped)
 {
     const unsigned n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= nnodes) return;
     const int32_t p = pix[n];
+    if (skipped) skipped[n] = p >= 0 ? 0 : 1;
     // -2: the node reads a pixel the map does not hold (only with a map built from a candidate set,
     // upsp_pipeline_set_active_hint): pass B then fetches that node's values from the frames themselves
     int32_t k = -1;
@@ -860,8 +862,10 @@ __global__ void __launch_bounds__(256)
                      const uint8_t *__restrict__ skipped, const int32_t *__restrict__ rowmap, unsigned nnodes,
                      int nframes, float *__restrict__ rows_t, uint16_t *__restrict__ rows_t16, long long ld_t,
                      double *__restrict__ sum, double *__restrict__ sumsq, const uint16_t *__restrict__ frames,
-                     size_t npix, const int32_t *__restrict__ pix)
+                     size_t npix, const int32_t *__restrict__ pix, bool fresh)
 {
+    // fresh: the accumulators were reset and not touched since -- they are WRITTEN (0 + the sums of this launch; 0 for a node without
+    // a pixel) instead of read, added to and written, and upsp_pipeline_reset launches no fill
     constexpr int RPS = 256 / LPR;          // rows per sweep
     constexpr int WPR = LPR / 64;           // waves per row
     constexpr int NR = RPS * ROWS;          // rows (consecutive nodes) per workgroup
@@ -1014,8 +1018,11 @@ __global__ void __launch_bounds__(256)
                     as += p_s[t][q];
                     ass += p_ss[t][q];
                 }
-                sum[n] = msk ? (double)qnan : sum[n] + (double)as;
-                sumsq[n] = msk ? (double)qnan : sumsq[n] + ass;
+                sum[n] = msk ? (double)qnan : (fresh ? 0.0 : sum[n]) + (double)as;
+                sumsq[n] = msk ? (double)qnan : (fresh ? 0.0 : sumsq[n]) + ass;
+            } else if (fresh) {
+                sum[n] = 0.0;
+                sumsq[n] = 0.0;
             }
         }
     }
@@ -1299,13 +1306,16 @@ __device__ __forceinline__ void
             for (unsigned j = 0; j < m; ++j) clist[base + j] = changes[f * (size_t)max_hot + j];
     }
 }
+// ntotal_next (optional): the counter the NEXT fix-up of this buffer will use -- zeroed here, where nothing reads it (the two
+// counters of a change buffer are used in turn: no reset launch in front of every fix-up)
 __global__ void __launch_bounds__(64)
     hot_repair_kernel(uint16_t *frames, size_t npix, int nframes, int rows, int cols, int min_change,
                       int max_hot, unsigned *__restrict__ count, const unsigned *__restrict__ pos,
                       unsigned *__restrict__ ntotal, unsigned *__restrict__ nch, uint4 *__restrict__ changes,
-                      uint4 *__restrict__ clist)
+                      uint4 *__restrict__ clist, unsigned *__restrict__ ntotal_next)
 {
     const size_t f = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f == 0 && ntotal_next) *ntotal_next = 0u;
     if (f >= (size_t)nframes) return;
     hot_repair_frame(f, frames, npix, rows, cols, min_change, max_hot, count, pos, ntotal, nch, changes, clist);
 }
@@ -1484,8 +1494,6 @@ __global__ void __launch_bounds__(256) hot_fill_i32_kernel(int32_t *p, size_t n,
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
 }
-
-__global__ void hot_patch_reset_kernel(unsigned *ntotal) { *ntotal = 0u; }
 
 __global__ void finals_kernel(const double *__restrict__ sum, const double *__restrict__ sumsq,
                               unsigned nnodes, double nframes, float *__restrict__ avg,
@@ -1712,11 +1720,13 @@ int launch_amap_build(const int32_t *d_pix, size_t nnodes, size_t npix, uint8_t 
     hipLaunchKernelGGL(amap_rank_kernel, dim3((unsigned)((npix + 255) / 256)), b, 0, st, d_flag, npix, d_cnt);
     // d_order (optional): visiting order [ntiles] + active-tile ranks [ntiles + 1]
     unsigned *arank = d_order ? d_order + ntiles : nullptr;
+    // (the visiting order made by the scan's own workgroup from an LDS copy of the ranks -- one launch less -- measured: the map
+    //  build 30 -> 45 us; 8192 searches and 64-bit divisions are no work for ONE workgroup)
     hipLaunchKernelGGL(tilemap_scan_kernel, dim3(1), dim3(1024), 0, st, (const unsigned *)d_cnt, d_off, arank, ntiles);
     // (d_node_k null: a map built from a candidate set -- the nodes get their rows once the projection is there, launch_amap_nodes)
     if (d_node_k)
         hipLaunchKernelGGL(amap_nodes_kernel, g, b, 0, st, d_pix, (unsigned)nnodes, (const uint8_t *)d_flag,
-                           (const unsigned *)d_off, d_node_k);
+                           (const unsigned *)d_off, d_node_k, (uint8_t *)nullptr);
     if (d_order)
         hipLaunchKernelGGL(amap_order_kernel, dim3((ntiles + 255) / 256), b, 0, st, (const unsigned *)arank, ntiles, d_order);
     UPSP_HIP_CHECK(hipGetLastError());
@@ -1751,17 +1761,17 @@ int launch_scan_compact(uint16_t *d_frames, size_t npix, int nframes, bool hot, 
 
 // Pass B, whole rows, for the g.nframes (<= group_frames_max()) frames parked in the compact buffer.
 int launch_amap_nodes(const int32_t *d_pix, size_t nnodes, const uint8_t *d_flag, const unsigned *d_off,
-                      int32_t *d_node_k, hipStream_t st)
+                      int32_t *d_node_k, hipStream_t st, uint8_t *d_skipped_out)
 {
     hipLaunchKernelGGL(amap_nodes_kernel, dim3((unsigned)((nnodes + 255) / 256)), dim3(256), 0, st, d_pix, (unsigned)nnodes,
-                       d_flag, d_off, d_node_k);
+                       d_flag, d_off, d_node_k, d_skipped_out);
     UPSP_HIP_CHECK(hipGetLastError());
     return UPSP_OK;
 }
 
 // g.img[0]: the group's first frame (u16) -- only read for nodes whose pixel is missing from the map (node_k == -2)
 int launch_node_rows(const PipelineGather &g, const int32_t *d_node_k, const uint16_t *d_compact, unsigned cpitch,
-                     hipStream_t st, bool cold_series)
+                     hipStream_t st, bool cold_series, bool fresh_acc)
 {
     if (g.nframes <= 0 || g.nframes > kGroupFramesMax || (unsigned)g.nframes > cpitch)
         return fail(UPSP_ERR_INVALID, "row pass: too many frames");
@@ -1773,7 +1783,7 @@ int launch_node_rows(const PipelineGather &g, const int32_t *d_node_k, const uin
 #define UPSP_NRX(LPR, ROWS, U16, AH)                                                                         \
     hipLaunchKernelGGL((node_rows_kernel<LPR, ROWS, U16, AH>), dim3((nn + (256 / LPR) * ROWS - 1) / ((256 / LPR) * ROWS)), \
                        dim3(256), 0, st, d_compact, cpitch, d_node_k, g.skipped, g.rowmap, nn, g.nframes, g.rows_t,  \
-                       g.rows_t16, (long long)g.ld_t, g.sum, g.sumsq, (const uint16_t *)g.img[0], g.npix, g.pix[0])
+                       g.rows_t16, (long long)g.ld_t, g.sum, g.sumsq, (const uint16_t *)g.img[0], g.npix, g.pix[0], fresh_acc)
 #define UPSP_NR(LPR, U16) UPSP_NRX(LPR, 4, U16, 0)
 #define UPSP_NR_L(U16)                                                                                       \
     do {                                                                                                     \
@@ -1865,19 +1875,21 @@ size_t hot_changes_words(int nframes, int max_hot)
 }
 int launch_hot_fixup(const PipelineGather &g, uint16_t *d_frames, int nframes, int rows, int cols,
                      int min_change, int max_hot, unsigned *d_count, const unsigned *d_pos,
-                     unsigned *d_changes, hipStream_t st)
+                     unsigned *d_changes, int *parity, hipStream_t st)
 {
     if (nframes <= 0) return UPSP_OK;
     KTimed kt("hot_fixup_kernels", st);
     unsigned *nch = d_changes + 4;
     uint4 *list = reinterpret_cast<uint4 *>(d_changes + 4 + (((size_t)nframes + 3) & ~(size_t)3));
     uint4 *clist = list + (size_t)nframes * (size_t)std::max(max_hot, 1);
-    hipLaunchKernelGGL(hot_patch_reset_kernel, dim3(1), dim3(1), 0, st, d_changes);
+    // words 0 / 1 of the buffer: the change counter of this call / of the next one (both zero after the allocation)
+    unsigned *ntotal = d_changes + (*parity & 1), *ntotal_next = d_changes + ((*parity & 1) ^ 1);
+    *parity ^= 1;
     hipLaunchKernelGGL(hot_repair_kernel, dim3((unsigned)((nframes + 63) / 64)), dim3(64), 0, st, d_frames, g.npix,
-                       nframes, rows, cols, min_change, max_hot, d_count, d_pos, d_changes, nch, list, clist);
+                       nframes, rows, cols, min_change, max_hot, d_count, d_pos, ntotal, nch, list, clist, ntotal_next);
     if (max_hot > 0)
         hipLaunchKernelGGL(hot_patch_nodes_kernel, dim3((unsigned)((g.nnodes + 255) / 256)), dim3(256), 0, st,
-                           (const unsigned *)d_changes, (const uint4 *)clist, g.pix[0], (unsigned)g.nnodes, g.skipped, g.rowmap,
+                           (const unsigned *)ntotal, (const uint4 *)clist, g.pix[0], (unsigned)g.nnodes, g.skipped, g.rowmap,
                            g.rows_t, g.rows_t16, (long long)g.ld_t, g.sum, g.sumsq);
     UPSP_HIP_CHECK(hipGetLastError());
     return UPSP_OK;
@@ -1891,19 +1903,20 @@ int launch_hot_fixup(const PipelineGather &g, uint16_t *d_frames, int nframes, i
 // Repairs the frames with 1 .. max_hot hot pixels (fix_hot_pixels) and writes the replaced pixels into the compact
 // series pass A stored (frames of one pass A group: compact column = frame index).
 int launch_hot_repair_compact(uint16_t *d_frames, size_t npix, int nframes, int rows, int cols, int min_change, int max_hot,
-                              unsigned *d_count, const unsigned *d_pos, unsigned *d_changes, const uint8_t *d_flag,
+                              unsigned *d_count, const unsigned *d_pos, unsigned *d_changes, int *parity, const uint8_t *d_flag,
                               const unsigned *d_tile_off, uint16_t *d_compact, unsigned cpitch, hipStream_t st)
 {
     if (nframes <= 0) return UPSP_OK;
     KTimed kt("hot_fixup_kernels", st);
     unsigned *nch = d_changes + 4;
     uint4 *list = reinterpret_cast<uint4 *>(d_changes + 4 + (((size_t)nframes + 3) & ~(size_t)3));
-    hipLaunchKernelGGL(hot_patch_reset_kernel, dim3(1), dim3(1), 0, st, d_changes);
+    unsigned *ntotal = d_changes + (*parity & 1), *ntotal_next = d_changes + ((*parity & 1) ^ 1);     // (see launch_hot_fixup)
+    *parity ^= 1;
     hipLaunchKernelGGL(hot_repair_kernel, dim3((unsigned)((nframes + 63) / 64)), dim3(64), 0, st, d_frames, npix, nframes,
-                       rows, cols, min_change, max_hot, d_count, d_pos, d_changes, nch, list, (uint4 *)nullptr);
+                       rows, cols, min_change, max_hot, d_count, d_pos, ntotal, nch, list, (uint4 *)nullptr, ntotal_next);
     if (max_hot > 0)
         hipLaunchKernelGGL(hot_patch_compact_kernel, dim3((unsigned)(((size_t)nframes * max_hot + 255) / 256)), dim3(256), 0, st,
-                           (const unsigned *)d_changes, (const unsigned *)nch, (const uint4 *)list, nframes, max_hot, d_flag,
+                           (const unsigned *)ntotal, (const unsigned *)nch, (const uint4 *)list, nframes, max_hot, d_flag,
                            d_tile_off, d_compact, cpitch);
     UPSP_HIP_CHECK(hipGetLastError());
     return UPSP_OK;
@@ -1920,8 +1933,9 @@ int launch_hot_repair_list(uint16_t *d_frames, size_t npix, int nframes, int row
     KTimed kt("hot_fixup_kernels", st);
     unsigned *nch = d_changes + 4;
     uint4 *list = reinterpret_cast<uint4 *>(d_changes + 4 + (((size_t)nframes + 3) & ~(size_t)3));
+    // (this caller's consumers read the per-frame counts only: word 2 takes the unused total, the counters of the paths above stay clean)
     hipLaunchKernelGGL(hot_repair_kernel, dim3((unsigned)((nframes + 63) / 64)), dim3(64), 0, st, d_frames, npix, nframes,
-                       rows, cols, min_change, max_hot, d_count, d_pos, d_changes, nch, list, (uint4 *)nullptr);
+                       rows, cols, min_change, max_hot, d_count, d_pos, d_changes + 2, nch, list, (uint4 *)nullptr, (unsigned *)nullptr);
     UPSP_HIP_CHECK(hipGetLastError());
     return UPSP_OK;
 }

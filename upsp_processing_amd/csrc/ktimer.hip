@@ -198,20 +198,28 @@ int upsp_timing_report(char *buf, size_t cap)
 
 
 // ---- device copy / fill probe: the measured HBM rate the roofline fractions are also quoted against -----------------
-// "denominator: measured peak of a rocprof'd device copy kernel on gfx950".  A streaming float4 copy
-// (non-temporal loads and stores, 16 B per lane and trip, grid of 8 workgroups per CU) and the store half alone.
+// "denominator: measured peak of a rocprof'd device copy kernel on gfx950".  A streaming float4 copy, 16 B per
+// lane and trip, and its store half alone; the launch shape is not guessed: non-temporal and plain accesses at 8, 16 and 32
+// workgroups per CU are each timed and the FASTEST is what is reported.
 namespace upsp {
 namespace {
 typedef float v4f_probe __attribute__((ext_vector_type(4)));
+template <bool NT>
 __global__ void __launch_bounds__(256) copy_probe_kernel(const v4f_probe *__restrict__ src, v4f_probe *__restrict__ dst, size_t n16)
 {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256)
-        __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+        if (NT) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+        else dst[i] = src[i];
+    }
 }
+template <bool NT>
 __global__ void __launch_bounds__(256) fill_probe_kernel(v4f_probe *__restrict__ dst, size_t n16)
 {
     const v4f_probe v = {1.f, 2.f, 3.f, 4.f};
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) __builtin_nontemporal_store(v, dst + i);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+        if (NT) __builtin_nontemporal_store(v, dst + i);
+        else dst[i] = v;
+    }
 }
 }  // namespace
 }  // namespace upsp
@@ -226,24 +234,34 @@ extern "C" int upsp_copy_probe(const void *d_src, void *d_dst, size_t bytes, int
     UPSP_HIP_CHECK(hipGetDevice(&dev));
     UPSP_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const size_t n16 = bytes / 16;
-    const unsigned grid = (unsigned)std::min<size_t>((n16 + 255) / 256, (size_t)cus * 8);
     hipEvent_t a = nullptr, b = nullptr;
     UPSP_HIP_CHECK(hipEventCreate(&a));
     UPSP_HIP_CHECK(hipEventCreate(&b));
-    auto launch = [&] {
-        if (d_src) hipLaunchKernelGGL(copy_probe_kernel, dim3(grid), dim3(256), 0, st, static_cast<const v4f_probe *>(d_src), static_cast<v4f_probe *>(d_dst), n16);
-        else hipLaunchKernelGGL(fill_probe_kernel, dim3(grid), dim3(256), 0, st, static_cast<v4f_probe *>(d_dst), n16);
-    };
-    launch();                                   // (untimed: first touch, code load)
-    hipError_t e = hipEventRecord(a, st);
-    for (int i = 0; i < reps && e == hipSuccess; ++i) launch();
-    if (e == hipSuccess) e = hipEventRecord(b, st);
-    if (e == hipSuccess) e = hipEventSynchronize(b);
-    float ms = 0.f;
-    if (e == hipSuccess) e = hipEventElapsedTime(&ms, a, b);
+    float best = 0.f;
+    hipError_t e = hipSuccess;
+    for (int shape = 0; shape < 6 && e == hipSuccess; ++shape) {
+        const bool nt = shape < 3;
+        const unsigned grid = (unsigned)std::min<size_t>((n16 + 255) / 256, (size_t)cus * (8u << (shape % 3)));
+        auto launch = [&] {
+            const v4f_probe *s4 = static_cast<const v4f_probe *>(d_src);
+            v4f_probe *d4 = static_cast<v4f_probe *>(d_dst);
+            if (d_src && nt) hipLaunchKernelGGL(copy_probe_kernel<true>, dim3(grid), dim3(256), 0, st, s4, d4, n16);
+            else if (d_src) hipLaunchKernelGGL(copy_probe_kernel<false>, dim3(grid), dim3(256), 0, st, s4, d4, n16);
+            else if (nt) hipLaunchKernelGGL(fill_probe_kernel<true>, dim3(grid), dim3(256), 0, st, d4, n16);
+            else hipLaunchKernelGGL(fill_probe_kernel<false>, dim3(grid), dim3(256), 0, st, d4, n16);
+        };
+        launch();                               // (untimed: first touch, code load)
+        e = hipEventRecord(a, st);
+        for (int i = 0; i < reps && e == hipSuccess; ++i) launch();
+        if (e == hipSuccess) e = hipEventRecord(b, st);
+        if (e == hipSuccess) e = hipEventSynchronize(b);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, a, b);
+        if (e == hipSuccess && ms > 0.f && (best == 0.f || ms < best)) best = ms;
+    }
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b);
     if (e != hipSuccess) return fail(UPSP_ERR_HIP, std::string("copy probe: ") + hipGetErrorString(e));
-    *ms_per_rep = ms / (float)reps;
+    *ms_per_rep = best / (float)reps;
     return UPSP_OK;
 }

@@ -42,24 +42,28 @@ size_t tilemap_tiles(size_t npix);
 // d_order: optional, 4 * (tiles + 1) words; its first `tiles` words = the order pass A visits the tiles in
 int launch_amap_build(const int32_t *d_pix, size_t nnodes, size_t npix, uint8_t *d_flag, unsigned *d_cnt,
                       unsigned *d_off, int32_t *d_node_k, unsigned *d_order, hipStream_t st);
+// d_skipped_out (optional): identify_skipped_nodes of a one-camera projection in the same sweep
 int launch_amap_nodes(const int32_t *d_pix, size_t nnodes, const uint8_t *d_flag, const unsigned *d_off,
-                      int32_t *d_node_k, hipStream_t st);
+                      int32_t *d_node_k, hipStream_t st, uint8_t *d_skipped_out = nullptr);
 int group_frames_max();    // frames per pass B (whole rows) of the one-camera streamed schedule
 int launch_scan_compact(uint16_t *d_frames, size_t npix, int nframes, bool hot, int thresh, int max_hot,
                         const uint8_t *d_flag, const unsigned *d_off, const unsigned *d_order, uint16_t *d_compact,
                         unsigned cpitch, int col, unsigned *d_count, unsigned *d_pos, hipStream_t st);
 // cold_series: the compact series were not written a moment ago (they come from HBM, not from the Infinity Cache): every
 // sweep's series are requested up front
+// fresh_acc: the accumulators hold nothing yet (reset, untouched since): they are written, not added to
 int launch_node_rows(const PipelineGather &g, const int32_t *d_node_k, const uint16_t *d_compact, unsigned cpitch,
-                     hipStream_t st, bool cold_series = false);
+                     hipStream_t st, bool cold_series = false, bool fresh_acc = false);
 int launch_node_rows_multi(const PipelineGather &g, const int32_t *const *d_node_k, const uint16_t *const *d_compact,
                            unsigned cpitch, hipStream_t st);
 size_t hot_changes_words(int nframes, int max_hot);   // size of d_changes for launch_hot_fixup
+// parity: which of the buffer's two change counters this call uses (flipped by the call; the other one is zeroed for the next call;
+// both zero after the allocation)
 int launch_hot_fixup(const PipelineGather &g, uint16_t *d_frames, int nframes, int rows, int cols,
                      int min_change, int max_hot, unsigned *d_count, const unsigned *d_pos,
-                     unsigned *d_changes, hipStream_t st);
+                     unsigned *d_changes, int *parity, hipStream_t st);
 int launch_hot_repair_compact(uint16_t *d_frames, size_t npix, int nframes, int rows, int cols, int min_change, int max_hot,
-                              unsigned *d_count, const unsigned *d_pos, unsigned *d_changes, const uint8_t *d_flag,
+                              unsigned *d_count, const unsigned *d_pos, unsigned *d_changes, int *parity, const uint8_t *d_flag,
                               const unsigned *d_tile_off, uint16_t *d_compact, unsigned cpitch, hipStream_t st);
 int launch_hot_repair_list(uint16_t *d_frames, size_t npix, int nframes, int rows, int cols, int min_change, int max_hot,
                            unsigned *d_count, const unsigned *d_pos, unsigned *d_changes, hipStream_t st);

@@ -43,9 +43,16 @@ struct upsp_pipeline {
     uint8_t *d_aflag = nullptr;
     unsigned *d_tile_off = nullptr, *d_tile_cnt = nullptr, *d_tile_order = nullptr;
     int32_t *d_node_k = nullptr;
+    // a second set of the five map arrays: upsp_pipeline_set_active_hint builds the NEXT map in the set the launches already
+    // queued do not read, so the caller may issue it on another stream beside the frame loop that still uses the current one
+    uint8_t *alt_aflag = nullptr;
+    unsigned *alt_tile_off = nullptr, *alt_tile_cnt = nullptr, *alt_tile_order = nullptr;
+    int32_t *alt_node_k = nullptr;
     uint16_t *d_compact = nullptr;
     size_t compact_bytes = 0;        // allocated size of d_compact
     unsigned *d_changes = nullptr;   // hot-pixel change list of a call (frames.hip: hot_changes_words)
+    int changes_parity = 0;          // which of its two change counters the next one-camera fix-up uses
+    bool acc_unset = false;          // upsp_pipeline_reset was called and the accumulators were not zeroed yet (done by whoever touches them first)
     size_t changes_words = 0;
     int32_t *d_head = nullptr, *d_next = nullptr;   // pixel -> nodes lists of the hot-pixel re-projection
     bool head_clean = false;        // d_head holds 'unmarked' everywhere (multi-camera fix-up leaves it so)
@@ -95,6 +102,7 @@ int ensure_hot_scratch(unsigned *&count, unsigned *&pos, int &capacity, int nfra
     capacity = 0;
     UPSP_HIP_CHECK(hipMalloc(&count, sizeof(unsigned) * upsp::hot_counter_words(nframes)));   // counts + tickets
     UPSP_HIP_CHECK(hipMemset(count, 0, sizeof(unsigned) * upsp::hot_counter_words(nframes)));
+    UPSP_HIP_CHECK(hipStreamSynchronize(nullptr));      // (allocation time only: done before a launch on any other stream can see the buffer)
     UPSP_HIP_CHECK(hipDeviceSynchronize());   // rare (allocation): zeroed before any stream uses it
     UPSP_HIP_CHECK(hipMalloc(&pos, sizeof(unsigned) * (size_t)nframes * 64));
     capacity = nframes;
@@ -214,6 +222,11 @@ void upsp_pipeline_destroy(upsp_pipeline *p)
     free_dev(p->d_tile_cnt);
     free_dev(p->d_tile_order);
     free_dev(p->d_node_k);
+    free_dev(p->alt_aflag);
+    free_dev(p->alt_tile_off);
+    free_dev(p->alt_tile_cnt);
+    free_dev(p->alt_tile_order);
+    free_dev(p->alt_node_k);
     free_dev(p->d_compact);
     free_dev(p->d_pix_of_k);
     free_dev(p->d_changes);
@@ -380,9 +393,13 @@ int upsp_pipeline_set_patches(upsp_pipeline *p, int cam, int nclusters, const in
                                      h_ix, h_iy, &p->patches[cam]);
 }
 
+static int acc_zero_now(upsp_pipeline *p, hipStream_t st, bool on_stream);
+
 int upsp_pipeline_accumulators(upsp_pipeline *p, double **d_sum, double **d_sumsq)
 {
     if (!p) return fail(UPSP_ERR_INVALID, "null pipeline");
+    int rc = acc_zero_now(p, nullptr, false);      // (a reset that nothing has acted on yet: the caller is about to read or add)
+    if (rc != UPSP_OK) return rc;
     if (d_sum) *d_sum = p->d_sum;
     if (d_sumsq) *d_sumsq = p->d_sumsq;
     return UPSP_OK;
@@ -405,10 +422,21 @@ int upsp_pipeline_set_ecc_iterations_out(upsp_pipeline *p, int32_t *d_iters)
     return UPSP_OK;
 }
 
+// The accumulators are zeroed by whoever touches them first after a reset: the streamed one-camera loop WRITES them in its first
+// pass B (no fill launch, no read of 8 B x N), everything else clears them first.
+static int acc_zero_now(upsp_pipeline *p, hipStream_t st, bool on_stream)
+{
+    if (!p->acc_unset) return UPSP_OK;
+    if (on_stream) UPSP_HIP_CHECK(hipMemsetAsync(p->d_sum, 0, sizeof(double) * 2 * p->acc_stride, st));
+    else UPSP_HIP_CHECK(hipMemset(p->d_sum, 0, sizeof(double) * 2 * p->acc_stride));
+    p->acc_unset = false;
+    return UPSP_OK;
+}
+
 int upsp_pipeline_reset(upsp_pipeline *p)
 {
     if (!p) return fail(UPSP_ERR_INVALID, "null pipeline");
-    UPSP_HIP_CHECK(hipMemset(p->d_sum, 0, sizeof(double) * 2 * p->acc_stride));
+    p->acc_unset = true;
     return UPSP_OK;
 }
 
@@ -416,6 +444,8 @@ int upsp_pipeline_finalize(upsp_pipeline *p, uint64_t nframes_total, float *d_av
                            void *stream)
 {
     if (!p || nframes_total == 0) return fail(UPSP_ERR_INVALID, "bad argument");
+    int rc = acc_zero_now(p, (hipStream_t)stream, true);
+    if (rc != UPSP_OK) return rc;
     return launch_finals(p->d_sum, p->d_sumsq, p->nnodes, nframes_total, d_avg, d_rms,
                          (hipStream_t)stream);
 }
@@ -428,7 +458,9 @@ static int streamed_map(upsp_pipeline *p, const int32_t *d_pix_src, size_t npix,
     const size_t ntiles = tilemap_tiles(npix);
     if (!p->d_aflag) {
         UPSP_HIP_CHECK(hipMalloc(&p->d_aflag, npix));
-        UPSP_HIP_CHECK(hipMemset(p->d_aflag, 0, npix));      // (once: launch_amap_build leaves the flags in a state it can start from)
+        // (once: launch_amap_build leaves the flags in a state it can start from.  On `st`: a memset on the null stream is not
+        //  ordered with a non-blocking stream, and the map may be built on one)
+        UPSP_HIP_CHECK(hipMemsetAsync(p->d_aflag, 0, npix, st));
     }
     if (!p->d_tile_off) UPSP_HIP_CHECK(hipMalloc(&p->d_tile_off, sizeof(unsigned) * (ntiles + 1)));
     if (!p->d_tile_cnt) UPSP_HIP_CHECK(hipMalloc(&p->d_tile_cnt, sizeof(unsigned) * ntiles));
@@ -489,6 +521,8 @@ static int streamed_buffers(upsp_pipeline *p, size_t npix, int nframes, hipStrea
             p->d_changes = nullptr;
             p->changes_words = 0;
             UPSP_HIP_CHECK(hipMalloc(&p->d_changes, sizeof(unsigned) * words));
+                UPSP_HIP_CHECK(hipMemsetAsync(p->d_changes, 0, sizeof(unsigned) * 4, st));      // (the change counters)
+                p->changes_parity = 0;
             p->changes_words = words;
         }
     }
@@ -518,6 +552,14 @@ int upsp_pipeline_set_active_hint(upsp_pipeline *p, const int32_t *d_pix_candida
     if (p->ncams != 1 || (npix % 2) != 0 || p->nnodes >= ((size_t)1 << 31))
         return fail(UPSP_ERR_INVALID, "active hint: one camera, even pixel count");
     invalidate_map(p);
+    // the other set of map arrays: whatever is queued (pass B, the hot-pixel fix-up, an exchange's node table of the step before)
+    // keeps reading the current one; the set taken here was last used two maps ago (the caller orders THAT, if its streams can
+    // run that far apart)
+    std::swap(p->d_aflag, p->alt_aflag);
+    std::swap(p->d_tile_off, p->alt_tile_off);
+    std::swap(p->d_tile_cnt, p->alt_tile_cnt);
+    std::swap(p->d_tile_order, p->alt_tile_order);
+    std::swap(p->d_node_k, p->alt_node_k);
     int rc = streamed_map(p, d_pix_candidates, npix, (hipStream_t)stream, /*want_nodes=*/false);   // (node rows: with the projection)
     if (rc != UPSP_OK) return rc;
     p->hint_active = true;
@@ -601,7 +643,7 @@ int upsp_pipeline_pixel_series(upsp_pipeline *p, uint16_t *d_frames, int nframes
     if (rc != UPSP_OK) return rc;
     if (p->opts.hot_enable && nframes > 0)
         rc = launch_hot_repair_compact(d_frames, npix, nframes, p->height, p->width, p->opts.hot_min_change, p->opts.hot_max,
-                                       p->d_hot_count, p->d_hot_pos, p->d_changes, p->d_aflag, p->d_tile_off, p->d_compact, cp, st);
+                                       p->d_hot_count, p->d_hot_pos, p->d_changes, &p->changes_parity, p->d_aflag, p->d_tile_off, p->d_compact, cp, st);
     if (d_compact) *d_compact = p->d_compact;
     if (cpitch) *cpitch = cp;
     if (d_node_k) *d_node_k = p->d_node_k;
@@ -663,16 +705,21 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
             return fail(UPSP_ERR_INVALID, "registration enabled but no reference frame set");
     }
     if (d_rows_t && ld_t < col0 + nframes) return fail(UPSP_ERR_INVALID, "ld_t too small");
-    if (!p->skipped_valid) {
-        // identify_skipped_nodes over all cameras (projection.ipp:857-880), stream-ordered
-        int rc = upsp::launch_skipped(p->ncams, p->nnodes, p->d_pix, p->d_skipped, st);
-        if (rc != UPSP_OK) return rc;
-        p->skipped_valid = true;
-    }
     const bool need_f32 = p->opts.patch || p->opts.filter;
     const bool need_stage = need_f32 || p->opts.registration;
     const size_t npix = (size_t)p->width * p->height;
     const int B = p->batch;
+    // identify_skipped_nodes over all cameras (projection.ipp:857-880), stream-ordered.  One camera on the streamed schedule with
+    // a candidate-pixel map kept across the projection change: the sweep that gives the nodes their series rows writes the
+    // flags as well (a node of a one-camera projection is skipped iff it has no pixel) -- one launch instead of two.
+    const bool skipped_with_nodes = !p->skipped_valid && p->ncams == 1 && p->tilemap_valid && !p->node_k_valid && !p->d_weight[0] &&
+                                    !need_stage && !d_rows && (d_rows_t || d_rows_t16) && !p->d_src && (npix % 2) == 0 && B == 64 &&
+                                    p->nnodes < ((size_t)1 << 31) && p->opts.fused_scan != 2;
+    if (!p->skipped_valid && !skipped_with_nodes) {
+        int rc = upsp::launch_skipped(p->ncams, p->nnodes, p->d_pix, p->d_skipped, st);
+        if (rc != UPSP_OK) return rc;
+        p->skipped_valid = true;
+    }
     if (need_stage) {
         int rc = upsp::frame_scratch_ensure(&p->scratch, p->ncams, B, p->height, p->width,
                                             p->opts.registration != 0, need_f32);
@@ -701,14 +748,19 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
             p->hint_active = false;
         }
         if (!p->node_k_valid) {     // candidate map kept across a projection change: only node -> series index is redone
-            rc = launch_amap_nodes(p->d_pix[0], p->nnodes, p->d_aflag, p->d_tile_off, p->d_node_k, st);
+            rc = launch_amap_nodes(p->d_pix[0], p->nnodes, p->d_aflag, p->d_tile_off, p->d_node_k, st,
+                                   skipped_with_nodes ? p->d_skipped : nullptr);
             if (rc != UPSP_OK) return rc;
             p->node_k_valid = true;
+            if (skipped_with_nodes) p->skipped_valid = true;
         }
         int S = 0;
         unsigned cp = 0;
         rc = streamed_buffers(p, npix, nframes, st, &S, &cp);
         if (rc != UPSP_OK) return rc;
+        // accumulators untouched since the last reset: the first pass B writes them
+        bool fresh = p->acc_unset;
+        p->acc_unset = false;
         PipelineGather g;
         g.ncams = 1;
         g.npix = npix;
@@ -732,15 +784,20 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
             g.img[0] = fr + (size_t)s0 * npix;
             g.rows_t = d_rows_t ? d_rows_t + col0 + s0 : nullptr;
             g.rows_t16 = d_rows_t16 ? d_rows_t16 + col0 + s0 : nullptr;
-            if (rc == UPSP_OK) rc = launch_node_rows(g, p->d_node_k, p->d_compact, cp, st);
+            if (rc == UPSP_OK) rc = launch_node_rows(g, p->d_node_k, p->d_compact, cp, st, false, fresh);
+            fresh = false;
         }
         if (rc == UPSP_OK && hot) {   // repair + re-projection of the few frames that hold hot pixels
             g.rows_t = d_rows_t ? d_rows_t + col0 : nullptr;
             g.rows_t16 = d_rows_t16 ? d_rows_t16 + col0 : nullptr;
             rc = launch_hot_fixup(g, fr, nframes, p->height, p->width, p->opts.hot_min_change, p->opts.hot_max,
-                                  p->d_hot_count, p->d_hot_pos, p->d_changes, st);
+                                  p->d_hot_count, p->d_hot_pos, p->d_changes, &p->changes_parity, st);
         }
         return rc;
+    }
+    {
+        int rcz = acc_zero_now(p, st, true);     // every other schedule adds to the accumulators
+        if (rcz != UPSP_OK) return rcz;
     }
     // Registration as the last image stage, one camera, node-major series: per 64-frame sub-batch hot-pixel repair ->
     // ECC -> warp of the active pixels straight into the compact buffer; per <= 1024 frames ONE pass B (whole rows)
@@ -894,6 +951,7 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
             if (!p->m_aflag[c]) {
                 UPSP_HIP_CHECK(hipMalloc(&p->m_aflag[c], npix));
                 UPSP_HIP_CHECK(hipMemset(p->m_aflag[c], 0, npix));
+                UPSP_HIP_CHECK(hipStreamSynchronize(nullptr));      // (allocation time only)
             }
             if (!p->m_tile_off[c]) UPSP_HIP_CHECK(hipMalloc(&p->m_tile_off[c], sizeof(unsigned) * (ntiles + 1)));
             if (!p->d_tile_cnt) UPSP_HIP_CHECK(hipMalloc(&p->d_tile_cnt, sizeof(unsigned) * ntiles));
@@ -931,6 +989,8 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
                 p->d_changes = nullptr;
                 p->changes_words = 0;
                 UPSP_HIP_CHECK(hipMalloc(&p->d_changes, sizeof(unsigned) * words));
+                UPSP_HIP_CHECK(hipMemsetAsync(p->d_changes, 0, sizeof(unsigned) * 4, st));      // (the change counters)
+                p->changes_parity = 0;
                 p->changes_words = words;
             }
             if (p->head_elems < npix * p->ncams) {
