@@ -253,3 +253,96 @@ def test_cli_two_ranks_one_camera_pixel_wire(gpu_lib, rccl_shim, tmp_path, nfram
         assert a == outs["pixels"][n], ("pixel wire", n)
         assert a == outs["rows"][n], ("row wire", n)
     assert len(outs["one"]["intensity_transpose"]) > nframes * 4 * 100
+
+
+# ---- the C++ phase-1 driver (upsp_processing_amd/csrc/psp_process_main.cpp -> bin/psp_process_cpp): no Python, no torch ----
+CPP_FILES = ("intensity_transpose", "intensity_avg", "intensity_rms", "coverage", "intensity_ratio_0", "cam01-uv", "X", "Y", "Z",
+             "vv-int-rms.dat", "vv-int-avg.dat", "vv-int-coverage.dat", "vv-int-sample1.dat")
+
+
+def _cpp_exe():
+    from upsp_processing_amd import build
+    return build.build_cli()
+
+
+def _png_pixels(path):
+    import struct
+    import zlib
+    png = open(path, "rb").read()
+    w_, h_ = struct.unpack(">II", png[16:24])
+    idat = png[png.index(b"IDAT") + 4:png.index(b"IEND") - 8]
+    return np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h_, 1 + 3 * w_)
+
+
+def test_cpp_driver_deck_errors(tmp_path):
+    """Flag / deck validation of the C++ driver (cpp/exec/psp_process.cpp:1193-1218, 1284-1319): the Python driver's verdicts,
+    exit code 1 and a `psp_process:` line -- before anything touches a GPU."""
+    import subprocess
+    exe = _cpp_exe()
+    write_case(str(tmp_path))
+    deck = open(str(tmp_path / "run.inp")).read()
+    r = subprocess.run([exe, "-h5_out=x.h5"], capture_output=True, text=True)
+    assert r.returncode == 1 and "missing required flag -input_file" in r.stderr
+    for name, text, msg in (("even", deck.replace("filter_size = 3", "filter_size = 4").replace("filter = none", "filter = gaussian"), "filter_size must be odd"),
+                            ("patch", deck + "@options\n  target_patcher = polynomial\n", "Python driver"),
+                            ("sect", deck + "@nonsense\n  a = b\n", "unknown section"),
+                            ("grid", deck.replace("model.tri", "model.p3d"), "Cart3D .tri")):
+        p = str(tmp_path / (name + ".inp"))
+        open(p, "w").write(text)
+        r = subprocess.run([exe, "-input_file=" + p, "-h5_out=x.h5"], capture_output=True, text=True)
+        assert r.returncode == 1 and r.stderr.startswith("psp_process:") and msg in r.stderr, (name, r.stderr)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("filt,registration,ncams", [("none", "none", 2), ("gaussian", "none", 2), ("none", "pixel", 1)])
+def test_cpp_driver_matches_python_driver(gpu_lib, tmp_path, filt, registration, ncams):
+    """`bin/psp_process_cpp` (deck -> .tri + camera JSON + 12-bit .mraw -> BVH, projections, frame loop, finals, flat files; C++
+    over the C ABI alone) against `bin/psp_process` (Python + torch host) on the same deck: every phase-1 file byte for byte
+    (the node normals are computed on the host in both -- same float operations in the same order), the node-count PNG
+    pixel for pixel (the C++ writer stores, the Python one deflates)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for name, cmd in (("py", [sys.executable, os.path.join(root, "bin", "psp_process")]), ("cpp", [_cpp_exe()])):
+        tmp = str(tmp_path / name)
+        os.makedirs(tmp)
+        write_case(tmp, nframes=13, filt=filt, registration=registration, ncams=ncams)
+        r = subprocess.run(cmd + ["-input_file=%s/run.inp" % tmp, "-h5_out=x"], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "phase 1 complete: 13 frames" in r.stdout
+        outs[name] = tmp
+    for n in CPP_FILES + (("cam02-uv",) if ncams == 2 else ()):
+        a = open(os.path.join(outs["py"], "out", n), "rb").read()
+        b = open(os.path.join(outs["cpp"], "out", n), "rb").read()
+        assert len(a) > 0 and a == b, n
+    assert np.array_equal(_png_pixels(os.path.join(outs["py"], "out", "cam01-nodecount.png")),
+                          _png_pixels(os.path.join(outs["cpp"], "out", "cam01-nodecount.png")))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_cpp_driver_ranks(gpu_lib, rccl_shim, tmp_path, ranks):
+    """`psp_process_cpp -ranks=N`: N rank processes started by the program itself (fork + exec), frames sharded with apportion(),
+    communicator from an id file, upsp_allreduce_sums + upsp_exchange_* for the reductions and global_transpose
+    (cpp/exec/psp_process.cpp:707-771, 1866-1872), every rank writing its node slice into the shared file -- byte-identical to
+    the one-process run.  One GPU: the ranks share it and the library binds the tests' stand-in RCCL."""
+    import subprocess
+    import torch
+    exe = _cpp_exe()
+    env = dict(os.environ)
+    if torch.cuda.device_count() < ranks:
+        env.update(UPSP_ONE_GPU="1", UPSP_RCCL_LIBRARY=rccl_shim)
+    outs = {}
+    for name, extra in (("one", []), ("many", ["-ranks=%d" % ranks])):
+        tmp = str(tmp_path / name)
+        os.makedirs(tmp)
+        write_case(tmp, nframes=14)
+        if extra:        # a stale, longer output file must not survive
+            os.makedirs(os.path.join(tmp, "out"))
+            open(os.path.join(tmp, "out", "intensity_transpose"), "wb").write(b"\xff" * 10_000_000)
+        r = subprocess.run([exe, "-input_file=%s/run.inp" % tmp, "-h5_out=x"] + extra, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[name] = tmp
+    for n in CPP_FILES + ("cam02-uv",):
+        assert open(os.path.join(outs["one"], "out", n), "rb").read() == open(os.path.join(outs["many"], "out", n), "rb").read(), n

@@ -75,9 +75,21 @@ def build_pybind(force=False):
     return out
 
 
+def build_cli(force=False):
+    """bin/psp_process_cpp: the C++ phase-1 driver (csrc/psp_process_main.cpp) over the C ABI -- no Python, no torch."""
+    src = os.path.join(CSRC, "psp_process_main.cpp")
+    out = os.path.join(ROOT, "bin", "psp_process_cpp")
+    if force or _stale(out, [src, LIB, os.path.join(ROOT, "include", "upsp_gpu.h")]):
+        _run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROOT, "include"),
+              "-I/opt/rocm/include", src, "-o", out, "-L" + LIBDIR, "-lupsp_gpu", "-L/opt/rocm/lib", "-lamdhip64",
+              "-Wl,-rpath,$ORIGIN/../upsp_processing_amd/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    return out
+
+
 def build_all(force=False):
     lib = build_lib(force)
     mod = build_pybind(force)
+    build_cli(force)
     return lib, mod
 
 

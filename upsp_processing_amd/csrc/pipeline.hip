@@ -915,7 +915,9 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
                 g.img[0] = fr + (size_t)s0 * npix;
                 g.rows_t = d_rows_t ? d_rows_t + col0 + s0 : nullptr;
                 g.rows_t16 = d_rows_t16 ? d_rows_t16 + col0 + s0 : nullptr;
-                rc = launch_node_rows(g, p->d_node_k, p->d_compact, cp, st);
+                // (the group's series were written sub-batch by sub-batch over the whole registration of <= 1024 frames: most of them
+                //  have left the Infinity Cache -- pass B 0.60 ms per 1000 frames here against 0.41 in the plain loop, r04)
+                rc = launch_node_rows(g, p->d_node_k, p->d_compact, cp, st, /*cold_series=*/true);
             }
         }
         return rc;
