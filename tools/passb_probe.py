@@ -32,7 +32,7 @@ g = torch.Generator(device="cuda"); g.manual_seed(1)
 print("%d nodes, %d active pixels, %d nodes with a pixel" % (N, A, int((p >= 0).sum())))
 import subprocess
 if len(sys.argv) < 2:      # one child per kernel variant (the switch is read once per process)
-    for var in ("40", "82", "162"):
+    for var in ("40", "41", "42", "82", "162"):
         print("UPSP_ROWS_VARIANT=%s (sweeps per workgroup, series loads 0 = at use / 1 = one sweep ahead / 2 = all up front)" % var, flush=True)
         subprocess.call([sys.executable, __file__, "child"], env=dict(os.environ, UPSP_ROWS_VARIANT=var))
     sys.exit(0)
