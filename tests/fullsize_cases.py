@@ -4,7 +4,7 @@ tools/full_size.py for the footprint / timing table of DESIGN.md section 3).
 configs[3]: 100 000 frames on 8 GPUs -> 12 500 frames of 1024^2 per rank (26 GB resident), a [nodes_r, 100 000] series slice
             per rank; here one rank owns all 500 958 nodes for its 12 500 frames (W = 1, the N > 1 loop forced): the chunked
             pixel-series loop of psp.Phase1.frame_loop_pixel_wire (cpp/exec/psp_process.cpp:1519-1529, 1743-1851, 707-771).
-configs[4]: 4 cameras x 50 000 frames on 8 GPUs -> 6 250 frame sets per rank on the 5 M-triangle model; here >= 4 000 frame
+configs[4]: 4 cameras x 50 000 frames on 8 GPUs -> 6 250 frame sets per rank on the 5 M-triangle model; here all 6 250 frame
             sets of 4 x 1024^2 (33.5 GB of frames resident) through the weighted multi-camera loop.
 Everything is checked through size-independent properties: series == frame[pix] (camera-order weighted sum), NaN rows exactly
 for the nodes no camera sees, exact integer sums, the hot-pixel repair of the frames that carry hot pixels against the oracle."""
@@ -102,7 +102,7 @@ def config3_rank_share(oracle, F=12500, size=1024, sample=3000, verbose=False):
     return facts
 
 
-def config4_rank_share(F=4000, size=1024, sample=1500, verbose=False):
+def config4_rank_share(F=6250, size=1024, sample=1500, verbose=False):
     import torch
     from upsp_processing_amd import _capi, engine, synthetic as syn
     t0 = time.time()
