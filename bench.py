@@ -1373,6 +1373,7 @@ def main():
     if world > 1 or force_coll:
         cr = D.comm_ranks()
         out["rccl_nranks"] = None if cr is None else cr[1]       # ncclCommCount of the communicator the exchanges ran on
+        out["rccl_bound"] = _capi.comm_library()                 # the RCCL build behind upsp_comm_* (the process's own copy when it has one)
         out["ms_per_step_rank_min_max"] = [dt_rank_min / a.steps * 1e3, dt_rank_max / a.steps * 1e3]
     if chunked:
         # what a rank hands to the exchange per step, and how much of it crossed a link in THIS run (nothing in a one-rank

@@ -526,6 +526,8 @@ int upsp_interpolate_idw(const float *h_src_nodes3, const float *h_src_data, siz
  *                         all-reduce completes with the call of the last rank */
 typedef struct upsp_comm upsp_comm;
 int upsp_comm_unique_id(uint8_t id[128]);
+/* path of the RCCL build the library bound (the one the process had loaded, librccl.so.1, or UPSP_RCCL_LIBRARY) */
+int upsp_comm_library(char *buf, size_t cap);
 int upsp_comm_create(const uint8_t id[128], int rank, int world, upsp_comm **out);
 int upsp_comm_from_nccl(void *nccl_comm, upsp_comm **out);
 int upsp_comm_create_local(int world, upsp_comm **out_ranks);

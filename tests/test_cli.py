@@ -221,13 +221,15 @@ def test_cli_two_ranks(gpu_lib, rccl_shim, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nframes,size", [(140, (96, 80)), (1410, (48, 40))])
+@pytest.mark.parametrize("nframes,size", [(140, (96, 80)), (1410, (48, 40)), (15000, (32, 24))])
 def test_cli_two_ranks_one_camera_pixel_wire(gpu_lib, rccl_shim, tmp_path, nframes, size):
     """One camera, no image stage, `-ranks=2`: the time-series exchange carries the active pixels' u16 series and the owner
     of a node runs pass B (psp.Phase1.frame_loop_pixel_wire) -- every output file byte-identical to the single-rank run
     and to a two-rank run with the node rows on the wire (UPSP_ROW_WIRE=1).  140 frames: two exchange chunks per rank of
     unequal length, hot pixels in both.  1410 frames = 705 per rank: ceil(705 / 256) = 3 chunks cut on 64-frame boundaries
-    would end in a chunk of 257 frames, one more than a feed slot holds (distributed.chunk_count picks 4)."""
+    would end in a chunk of 257 frames, one more than a feed slot holds (distributed.chunk_count picks 4).  15 000 frames = 7 500 per
+    rank (a rank's share of 60 000 frames on 8 GPUs): the cuts on 64-frame boundaries leave a last chunk of 268 for ceil(7500 / 256) = 30
+    chunks, chunk_count picks more."""
     import subprocess
     import sys
     import torch

@@ -151,6 +151,7 @@ SIGNATURES = {
     "upsp_phase_end": (_i, [C.POINTER(C.c_double)]),
     "upsp_timing_enable": (_i, [_i]),
     "upsp_copy_probe": (_i, [_vp, _vp, C.c_size_t, _i, _vp, _vp]),
+    "upsp_comm_library": (_i, [C.c_char_p, _sz]),
     "upsp_timing_report": (_i, [C.c_char_p, _sz]),
 }
 
@@ -253,3 +254,10 @@ def copy_probe(nbytes=1 << 30, reps=5):
     fill = nbytes / (ms.value * 1e-3) / 1e9
     return {"copy_GBps": copy, "fill_GBps": fill, "bytes": int(nbytes), "reps": int(reps),
             "kernel": "upsp::copy_probe_kernel / fill_probe_kernel (float4 per lane; fastest of non-temporal / plain at 8, 16, 32 workgroups per CU)"}
+
+
+def comm_library():
+    """Path of the RCCL build the library bound (upsp_comm_library)."""
+    buf = C.create_string_buffer(4096)
+    check(lib().upsp_comm_library(buf, len(buf)))
+    return buf.value.decode()

@@ -12,8 +12,9 @@
 // fills them.  With one camera, no weights and no float image stage the travelling rows are exact 16-bit integers
 // and go as u16 -- or, for 12-bit cameras, packed to 12 bits (3 bytes per 2 frames).
 //
-// librccl is NOT a link-time dependency: its entry points are looked up in the running process first (PyTorch brings
-// its own copy, and two RCCLs in one process are one too many) and in librccl.so.1 otherwise.
+// librccl is NOT a link-time dependency: its entry points are taken from the RCCL the running process has already loaded
+// (PyTorch brings its own copy -- into a local scope, so it is found by walking the loaded objects, not by a global symbol
+// lookup -- and two RCCLs in one process are one too many), from librccl.so.1 otherwise, or from the build UPSP_RCCL_LIBRARY names.
 //
 // A second transport, "local", runs all ranks of a group inside ONE process on one GPU (device-to-device copies in
 // place of the links): the pool this was built on has one GPU per box and RCCL refuses two ranks on one device, so
@@ -21,6 +22,7 @@
 // device buffers by the tests (tests/cpp/exchange_test.cpp).
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <link.h>
 #include <rccl/rccl.h>
 
 #include <algorithm>
@@ -78,16 +80,31 @@ Rccl &rccl()
             }
         }
         const bool only_forced = forced && *forced;
+        std::string loaded;                               // path of a librccl this process holds already, if any
+        if (!only_forced)
+            dl_iterate_phdr(
+                [](struct dl_phdr_info *info, size_t, void *data) -> int {
+                    if (info->dlpi_name && std::strstr(info->dlpi_name, "librccl.so")) {
+                        *static_cast<std::string *>(data) = info->dlpi_name;
+                        return 1;
+                    }
+                    return 0;
+                },
+                &loaded);
         auto sym = [&](const char *name) -> void * {
             if (only_forced) {
                 void *p = h ? dlsym(h, name) : nullptr;
                 if (!p && r.why.empty()) r.why = std::string("UPSP_RCCL_LIBRARY=") + forced + " has no symbol " + name;
                 return p;
             }
-            void *p = dlsym(RTLD_DEFAULT, name);          // already in the process (PyTorch's copy)?
+            void *p = dlsym(RTLD_DEFAULT, name);          // in the global scope of the process?
             if (!p) {
-                if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-                if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+                // An RCCL the process has ALREADY loaded (PyTorch loads its own copy into a local scope, where the lookup above
+                // does not see it): the same instance serves both -- one set of proxy threads, one build.  Otherwise the
+                // system's; RTLD_LOCAL either way (a second copy's symbols must not interpose the first's late bindings).
+                if (!h && !loaded.empty()) h = dlopen(loaded.c_str(), RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL);
+                if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+                if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
                 if (h) p = dlsym(h, name);
             }
             if (!p && r.why.empty()) r.why = std::string("RCCL symbol not found: ") + name;
@@ -430,6 +447,17 @@ int upsp_comm_unique_id(uint8_t id[128])
     ncclUniqueId u;
     UPSP_NCCL_CHECK(r.GetUniqueId(&u), "ncclGetUniqueId");
     std::memcpy(id, &u, 128);
+    return UPSP_OK;
+}
+
+int upsp_comm_library(char *buf, size_t cap)
+{
+    if (!buf || cap == 0) return fail(UPSP_ERR_INVALID, "bad argument");
+    Rccl &r = rccl();
+    if (!r.ok) return fail(UPSP_ERR_HIP, "RCCL is not available: " + r.why);
+    Dl_info info;
+    const char *path = (dladdr(reinterpret_cast<void *>(r.GetUniqueId), &info) && info.dli_fname) ? info.dli_fname : "";
+    std::snprintf(buf, cap, "%s", path);
     return UPSP_OK;
 }
 
