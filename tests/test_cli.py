@@ -323,12 +323,14 @@ def test_cpp_driver_matches_python_driver(gpu_lib, tmp_path, filt, registration,
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ranks", [2, 3])
-def test_cpp_driver_ranks(gpu_lib, rccl_shim, tmp_path, ranks):
+@pytest.mark.parametrize("ranks,ncams,nframes,size", [(2, 2, 14, (192, 160)), (3, 2, 14, (192, 160)), (2, 1, 700, (48, 40)), (3, 1, 1410, (48, 40))])
+def test_cpp_driver_ranks(gpu_lib, rccl_shim, tmp_path, ranks, ncams, nframes, size):
     """`psp_process_cpp -ranks=N`: N rank processes started by the program itself (fork + exec), frames sharded with apportion(),
     communicator from an id file, upsp_allreduce_sums + upsp_exchange_* for the reductions and global_transpose
     (cpp/exec/psp_process.cpp:707-771, 1866-1872), every rank writing its node slice into the shared file -- byte-identical to
-    the one-process run.  One GPU: the ranks share it and the library binds the tests' stand-in RCCL."""
+    the one-process run.  One GPU: the ranks share it and the library binds the tests' stand-in RCCL.  One camera without an image
+    stage: the ACTIVE PIXELS' series travel in chunks (upsp_pipeline_pixel_series + upsp_exchange_set_pixels / submit_pixels /
+    finish_pixels; 350 and 470 frames per rank: two chunks each) and the owner of a node runs pass B; two cameras: the node rows."""
     import subprocess
     import torch
     exe = _cpp_exe()
@@ -339,12 +341,12 @@ def test_cpp_driver_ranks(gpu_lib, rccl_shim, tmp_path, ranks):
     for name, extra in (("one", []), ("many", ["-ranks=%d" % ranks])):
         tmp = str(tmp_path / name)
         os.makedirs(tmp)
-        write_case(tmp, nframes=14)
+        write_case(tmp, nframes=nframes, size=size, ncams=ncams)
         if extra:        # a stale, longer output file must not survive
             os.makedirs(os.path.join(tmp, "out"))
             open(os.path.join(tmp, "out", "intensity_transpose"), "wb").write(b"\xff" * 10_000_000)
         r = subprocess.run([exe, "-input_file=%s/run.inp" % tmp, "-h5_out=x"] + extra, env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         outs[name] = tmp
-    for n in CPP_FILES + ("cam02-uv",):
+    for n in CPP_FILES + (("cam02-uv",) if ncams == 2 else ()):
         assert open(os.path.join(outs["one"], "out", n), "rb").read() == open(os.path.join(outs["many"], "out", n), "rb").read(), n

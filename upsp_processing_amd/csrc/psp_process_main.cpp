@@ -333,6 +333,30 @@ void apportion(int64_t value, int nbins, std::vector<int64_t> &start, std::vecto
     }
 }
 
+// The cuts of a rank's frames into K exchange chunks (exchange.hip aligned_chunks: boundaries on multiples of 64 frames, round half
+// to even) and the smallest K that keeps every chunk of every rank within `limit` frames (distributed.chunk_count)
+std::vector<int64_t> aligned_chunk_extents(int64_t nframes, int K)
+{
+    std::vector<int64_t> b(K + 1);
+    for (int k = 0; k < K; ++k) b[k] = std::min<int64_t>(nframes, (int64_t)std::nearbyint((double)k * (double)nframes / (double)K / 64.0) * 64);
+    b[K] = nframes;
+    for (int k = 1; k <= K; ++k) b[k] = std::max(b[k], b[k - 1]);
+    std::vector<int64_t> e(K);
+    for (int k = 0; k < K; ++k) e[k] = b[k + 1] - b[k];
+    return e;
+}
+int chunk_count(const std::vector<int64_t> &frame_counts, int64_t limit)
+{
+    const int64_t nmax = *std::max_element(frame_counts.begin(), frame_counts.end());
+    int K = (int)std::max<int64_t>(1, (nmax + limit - 1) / limit);
+    for (;; ++K) {
+        int64_t worst = 0;
+        for (int64_t n : frame_counts)
+            for (int64_t e : aligned_chunk_extents(n, K)) worst = std::max(worst, e);
+        if (worst <= limit) return K;
+    }
+}
+
 void write_file(const std::string &path, const void *p, size_t bytes)
 {
     std::FILE *f = std::fopen(path.c_str(), "wb");
@@ -601,7 +625,41 @@ int run_rank(const std::map<std::string, std::string> &flags, int rank, int worl
         d_packed[c] = dev_alloc<uint8_t>((size_t)chunk * videos[c].frame_bytes);
         d_frames[c] = dev_alloc<uint16_t>((size_t)chunk * npix);
     }
-    for (int64_t c0 = 0; c0 < nf; c0 += chunk) {
+    // N > 1, one camera, no weights, no float image stage: the ACTIVE PIXELS' u16 series travel chunk by chunk while the next chunk
+    // is read and scanned, and the owner of a node runs pass B over all frames (psp.Phase1.frame_loop_pixel_wire; a third of the
+    // bytes of the node rows on the links).  UPSP_ROW_WIRE=1 forces the node rows.
+    const bool pixel_wire = comm && C == 1 && !po.registration && !po.filter && !std::getenv("UPSP_ROW_WIRE");
+    upsp_exchange *px = nullptr;
+    float *d_series_px = nullptr;
+    if (pixel_wire) {
+        const int64_t limit = std::min<int64_t>(chunk, upsp_pipeline_series_frames_max(pipe));
+        const int K = chunk_count(fcount, limit);
+        CHECK(upsp_exchange_create(comm, nframes, (int64_t)N, K, &px));
+        const uint16_t *d_compact = nullptr;
+        uint32_t cpitch = 0;
+        const int32_t *d_node_k = nullptr;
+        CHECK(upsp_pipeline_pixel_series(pipe, nullptr, 0, nullptr, &d_compact, &cpitch, &d_node_k, nullptr));     // the node -> row table alone
+        CHECK(upsp_exchange_set_pixels(px, d_node_k, d_skipped, 0, nullptr));
+        for (int k = 0; k < K; ++k) {
+            int64_t c0 = 0, fc = 0;
+            CHECK(upsp_exchange_chunk(px, k, &c0, &fc));
+            if (fc > 0) {
+                HIPCHECK(hipDeviceSynchronize());
+                read_packed(videos[0], f0 + c0, (int)fc, h_pinned[0]);
+                HIPCHECK(hipMemcpyAsync(d_packed[0], h_pinned[0], (size_t)fc * videos[0].frame_bytes, hipMemcpyHostToDevice, nullptr));
+                CHECK(upsp_unpack_12bit(d_packed[0], (int)fc, npix, d_frames[0], 0, nullptr, nullptr));
+                CHECK(upsp_pipeline_pixel_series(pipe, d_frames[0], (int)fc, nullptr, &d_compact, &cpitch, &d_node_k, nullptr));
+            }
+            CHECK(upsp_exchange_submit_pixels(px, d_compact, cpitch, 2, nullptr));     // (a rank with fewer chunks still takes part)
+            if (rank == 0 && k % 4 == 0) std::printf("  Rank 0:: processing frame %lld\n", (long long)(f0 + c0));
+        }
+        double *ps = nullptr, *pss = nullptr;
+        CHECK(upsp_pipeline_accumulators(pipe, &ps, &pss));
+        d_series_px = dev_alloc<float>((size_t)std::max<int64_t>(ncount[rank], 1) * (size_t)nframes);
+        CHECK(upsp_exchange_finish_pixels(px, d_series_px, nframes, ps + nstart[rank], pss + nstart[rank], nullptr));
+        HIPCHECK(hipDeviceSynchronize());
+    }
+    for (int64_t c0 = 0; c0 < (pixel_wire ? 0 : nf); c0 += chunk) {
         const int n = (int)std::min<int64_t>(chunk, nf - c0);
         HIPCHECK(hipDeviceSynchronize());                             // (the previous chunk's kernels still read the buffers)
         for (int c = 0; c < C; ++c) {
@@ -640,7 +698,11 @@ int run_rank(const std::map<std::string, std::string> &flags, int rank, int worl
     // ---- time-series exchange (global_transpose, :707-771): [N][frames of this rank] -> [nodes of this rank][all frames] ----
     const int64_t n0 = nstart[rank], nn = ncount[rank];
     std::vector<float> series((size_t)nn * (size_t)nframes);
-    if (!comm) {
+    if (pixel_wire) {
+        series = to_host(d_series_px, (size_t)nn * (size_t)nframes);
+        upsp_exchange_destroy(px);
+        (void)hipFree(d_series_px);
+    } else if (!comm) {
         std::vector<float> rows = to_host(d_rows_t, N * (size_t)ld);
         for (size_t n = 0; n < N; ++n) std::memcpy(&series[n * (size_t)nframes], &rows[n * (size_t)ld], sizeof(float) * (size_t)nframes);
     } else {
