@@ -1620,16 +1620,17 @@ template <int PHASE>
 __global__ void __launch_bounds__(kHeavyThreads)
     heavy_kernel(Scene sc, Cam cam, const float *__restrict__ nodes, const int32_t *__restrict__ tri_nodes,
                  int32_t *__restrict__ pix, const unsigned *__restrict__ retry_nodes,
-                 unsigned *__restrict__ retry_mask, const unsigned *__restrict__ work)
+                 unsigned *__restrict__ retry_mask, const unsigned *__restrict__ work, int count_word,
+                 const unsigned *__restrict__ items)
 {
     unsigned char *scratch = sc.heavy_scratch + (size_t)blockIdx.x * kHeavyScratchBytes;
     unsigned long long *q_key = reinterpret_cast<unsigned long long *>(scratch);
     int *q_ref = reinterpret_cast<int *>(scratch + (size_t)kHeavyStack * 8);
     unsigned char *q_depth = scratch + (size_t)kHeavyStack * 12;
     const unsigned lane = threadIdx.x;
-    const unsigned count = min(work[kWorkHeavyCount + (PHASE ? 1 : 0)], kHeavyCap);
+    const unsigned count = min(work[count_word], kHeavyCap);
     for (unsigned h = blockIdx.x; h < count; h += gridDim.x) {
-        const unsigned item = sc.heavy_items[h];
+        const unsigned item = items[h];
         const unsigned node = PHASE == 0 ? item : retry_nodes[item / 6u];
         Ray r;
         if (PHASE == 0) {
@@ -1668,15 +1669,15 @@ __global__ void __launch_bounds__(kHeavyThreads)
 template <bool ANYHIT>
 __global__ void __launch_bounds__(kHeavyThreads)
     heavy_cast_kernel(Scene sc, const float *__restrict__ org, int org_stride, const float *__restrict__ dir,
-                      upsp_hits out, const unsigned *__restrict__ work)
+                      upsp_hits out, const unsigned *__restrict__ work, int count_word, const unsigned *__restrict__ items)
 {
     unsigned char *scratch = sc.heavy_scratch + (size_t)blockIdx.x * kHeavyScratchBytes;
     unsigned long long *q_key = reinterpret_cast<unsigned long long *>(scratch);
     int *q_ref = reinterpret_cast<int *>(scratch + (size_t)kHeavyStack * 8);
     unsigned char *q_depth = scratch + (size_t)kHeavyStack * 12;
-    const unsigned count = min(work[kWorkHeavyCast], kHeavyCap);
+    const unsigned count = min(work[count_word], kHeavyCap);
     for (unsigned h = blockIdx.x; h < count; h += gridDim.x) {
-        const unsigned item = sc.heavy_items[h];
+        const unsigned item = items[h];
         const float *o = org + (size_t)org_stride * item;
         const float *d = dir + 3 * (size_t)item;
         Ray r;
@@ -1696,6 +1697,220 @@ __global__ void __launch_bounds__(kHeavyThreads)
             }
         }
         __syncthreads();
+    }
+}
+
+// ---- one ray per WAVE ----------------------------------------------------------------------------------------------------
+// A batch ends when its longest rays end: on the frame-filling sphere 1 % of the pixel rays need more than 64 node visits +
+// triangle tests, a few thousand more than 128, the longest ~300 -- each a chain of dependent fetches in ONE lane of a wave whose
+// other lanes have long finished.  Such a ray leaves the one-lane traversal at `heavy_steps` and a whole wave walks it here: the
+// frontier of open boxes lives on a stack in LDS (512 entries per wave), every lane pops one entry per round -- an interior node
+// of the BINARY tree: both child boxes tested, the accepted ones pushed with their depth-first keys; a leaf: its triangles tested --
+// so a ray of 300 sequential steps is ~25 rounds.  The keys make the result independent of the order of the stack (heavy_walk):
+// closest t, then the smallest key = the first triangle the reference's near-first depth-first walk would have met.  No
+// __syncthreads: the four waves of a workgroup walk four different rays.  A frontier that outgrows the stack (or a tree deeper
+// than the keys) goes on to heavy_cast_kernel's list (one workgroup per ray, 4096 entries in global memory, one-thread fallback).
+constexpr unsigned kWaveStack = 512;
+template <bool STOP_AT_ANY>
+__device__ __forceinline__ bool wave_walk(const Ray &r, const Scene &sc, int *q_ref, unsigned long long *q_key, unsigned char *q_depth,
+                                          bool &any_w, int &best_slot)
+{
+    const unsigned lane = threadIdx.x & 63u;
+    unsigned top = 0;                         // (uniform)
+    if (box_hit(r, sc.rlo[0], sc.rlo[1], sc.rlo[2], sc.rhi[0], sc.rhi[1], sc.rhi[2])) {
+        if (lane == 0) {
+            q_ref[0] = sc.root_ref2;
+            q_key[0] = 0ull;
+            q_depth[0] = 0;
+        }
+        top = 1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    HeavyBest best;
+    best.t = FLT_MAX;
+    best.key = ~0ull;
+    best.slot = -1;
+    bool any = false, overflow = false;
+    unsigned rounds = 0;
+    while (top > 0) {
+        if (++rounds > sc.round_cap) {
+            if (lane == 0) atomicOr(sc.err, 2u);
+            break;
+        }
+        const unsigned n = min(top, 64u);
+        const bool have = lane < n;
+        int ref = 0;
+        unsigned long long key = 0ull;
+        unsigned depth = 0;
+        if (have) {
+            ref = q_ref[top - n + lane];
+            key = q_key[top - n + lane];
+            depth = q_depth[top - n + lane];
+        }
+        top -= n;
+        bool pF = false, pS = false;
+        int first = 0, second = 0;
+        if (have && ref >= 0) {
+            const float4 *np = sc.nodes + 4 * (size_t)ref;
+            const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+            const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
+            const unsigned meta = __float_as_uint(q3.z);
+            const bool hL = box_hit(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
+            const bool hR = box_hit(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w);
+            const bool swap = !(meta & kMetaOrdered) && ((r.neg >> (meta & 3u)) & 1u);
+            first = swap ? right : left;
+            second = swap ? left : right;
+            pF = swap ? hR : hL;
+            pS = swap ? hL : hR;
+        } else if (have) {
+            const unsigned code = (unsigned)(~ref);
+            const unsigned f0 = code >> kLeafBits, cnt = (code & (kMaxLeaf - 1)) + 1;
+            for (unsigned i = 0; i < cnt; ++i) {
+                const float4 *tp = sc.tris + 3 * (size_t)(f0 + i);
+                const float4 a = tp[0], b = tp[1], c = tp[2];
+                TriHit th;
+                if (tri_test(r, a.x, a.y, a.z, b.x, b.y, b.z, c.x, c.y, c.z, th)) {
+                    any = true;
+                    const unsigned long long k = key | (unsigned long long)i;
+                    if (th.t < best.t || (th.t == best.t && k < best.key)) {
+                        best.t = th.t;
+                        best.key = k;
+                        best.slot = (int)(f0 + i);
+                    }
+                }
+            }
+        }
+        const unsigned long long mF = __ballot(pF), mS = __ballot(pS);
+        const unsigned add = (unsigned)__popcll(mF) + (unsigned)__popcll(mS);
+        // (sc.heavy_stack: the tests shrink it to push rays on to the workgroup walk and its one-thread fallback)
+        if (top + add > min(kWaveStack, sc.heavy_stack) || __ballot(have && ref >= 0 && depth >= 56u) != 0ull) {
+            overflow = true;
+            break;
+        }
+        if (STOP_AT_ANY && __ballot(any) != 0ull) break;
+        // (every read of this round's entries is done: the loads above were consumed by the ballots' operands)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        const unsigned pos = top + (unsigned)__popcll(mF & lt) + (unsigned)__popcll(mS & lt);
+        const unsigned long long bit = 1ull << (62u - depth);
+        if (pF) {
+            q_ref[pos] = first;
+            q_key[pos] = key;
+            q_depth[pos] = (unsigned char)(depth + 1u);
+        }
+        if (pS) {
+            const unsigned p2 = pos + (pF ? 1u : 0u);
+            q_ref[p2] = second;
+            q_key[p2] = key | bit;
+            q_depth[p2] = (unsigned char)(depth + 1u);
+        }
+        top += add;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (overflow) return false;
+    // the wave's winner: smallest t, then smallest key
+    float bt = best.t;
+    for (int off = 32; off > 0; off >>= 1) bt = fminf(bt, __shfl_xor(bt, off));
+    unsigned long long bk = best.t == bt ? best.key : ~0ull;
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(bk, off);
+        bk = o < bk ? o : bk;
+    }
+    any_w = __ballot(any) != 0ull;
+    const unsigned long long win = __ballot(any && best.t == bt && best.key == bk);
+    const int wl = win ? __ffsll((long long)win) - 1 : 0;
+    best_slot = any_w ? __shfl(best.slot, wl) : -1;
+    return true;
+}
+
+template <bool ANYHIT>
+__global__ void __launch_bounds__(256)
+    wave_cast_kernel(Scene sc, const float *__restrict__ org, int org_stride, const float *__restrict__ dir, upsp_hits out,
+                     unsigned *__restrict__ work, const unsigned *__restrict__ items, unsigned *__restrict__ items_over)
+{
+    __shared__ unsigned long long s_key[4][kWaveStack];
+    __shared__ int s_ref[4][kWaveStack];
+    __shared__ unsigned char s_depth[4][kWaveStack];
+    const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const unsigned count = min(work[kWorkHeavyCast], kHeavyCapCast);
+    for (unsigned h = blockIdx.x * 4u + wave; h < count; h += gridDim.x * 4u) {
+        const unsigned item = items[h];
+        const float *o = org + (size_t)org_stride * item;
+        const float *d = dir + 3 * (size_t)item;
+        Ray r;
+        ray_setup(r, o[0], o[1], o[2], d[0], d[1], d[2]);
+        ray_classify(r, sc);
+        bool any_w = false;
+        int best_slot = -1;
+        const bool done = wave_walk<ANYHIT>(r, sc, s_ref[wave], s_key[wave], s_depth[wave], any_w, best_slot);
+        if (lane == 0) {
+            if (!done) {
+                const unsigned slot = atomicAdd(&work[kWorkHeavyCast + 1], 1u);
+                items_over[slot] = item;               // (at most `count` <= kHeavyCapCast of them)
+            } else if (ANYHIT) {
+                if (out.hit) out.hit[item] = any_w ? 1 : 0;
+            } else {
+                Trav s;
+                s.any = any_w;
+                s.best_slot = any_w ? best_slot : -1;
+                write_hit(r, sc, s, item, out);
+            }
+        }
+    }
+}
+
+// The same for the projection build's visibility rays (work items of the primary pass, PHASE 0, or of the retry passes): the
+// verdicts heavy_kernel writes, one ray per wave; a frontier that outgrows the LDS stack goes on to heavy_kernel's list.
+constexpr int kWorkWaveOver = 19;     // [19] / [20]: rays wave_proj_kernel passed on (primary / retry phase)
+template <int PHASE>
+__global__ void __launch_bounds__(256)
+    wave_proj_kernel(Scene sc, Cam cam, const float *__restrict__ nodes, const int32_t *__restrict__ tri_nodes,
+                     int32_t *__restrict__ pix, const unsigned *__restrict__ retry_nodes, unsigned *__restrict__ retry_mask,
+                     unsigned *__restrict__ work, const unsigned *__restrict__ items, unsigned *__restrict__ items_over)
+{
+    __shared__ unsigned long long s_key[4][kWaveStack];
+    __shared__ int s_ref[4][kWaveStack];
+    __shared__ unsigned char s_depth[4][kWaveStack];
+    const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const unsigned count = min(work[kWorkHeavyCount + (PHASE ? 1 : 0)], kHeavyCap);
+    for (unsigned h = blockIdx.x * 4u + wave; h < count; h += gridDim.x * 4u) {
+        const unsigned item = items[h];
+        const unsigned node = PHASE == 0 ? item : retry_nodes[item / 6u];
+        Ray r;
+        if (PHASE == 0) {
+            float dx = nodes[3 * (size_t)item] - cam.ox, dy = nodes[3 * (size_t)item + 1] - cam.oy,
+                  dz = nodes[3 * (size_t)item + 2] - cam.oz;
+            const float len = imath_length(dx, dy, dz);
+            if (len != 0.0f) { dx /= len; dy /= len; dz /= len; }
+            ray_setup(r, cam.ox, cam.oy, cam.oz, dx, dy, dz);
+        } else {
+            retry_ray(r, cam, nodes, node, (int)(item % 6u));
+        }
+        ray_classify(r, sc);
+        bool any_w = false;
+        int best_slot = -1;
+        const bool done = wave_walk<false>(r, sc, s_ref[wave], s_key[wave], s_depth[wave], any_w, best_slot);
+        if (lane == 0) {
+            if (!done) {
+                const unsigned slot = atomicAdd(&work[kWorkWaveOver + (PHASE ? 1 : 0)], 1u);
+                items_over[slot] = item;
+            } else {
+                bool visible = false;
+                if (any_w && best_slot >= 0) {
+                    const int prim = __float_as_int(sc.tris[3 * (size_t)best_slot].w);
+                    visible = tri_has_node(tri_nodes, prim, (int)node);
+                }
+                if (PHASE == 0) {
+                    pix[node] = visible ? kPixVisible : (any_w ? kPixRetry : kPixNone);
+                    if (sc.witness && !visible && any_w) sc.witness[node] = best_slot;
+                } else if (visible) {
+                    atomicOr(&retry_mask[item / 6u], 1u << (item % 6u));
+                }
+            }
+        }
     }
 }
 
@@ -1862,7 +2077,8 @@ Scene make_scene(const upsp_bvh *b, size_t items, int grid)
     sc.root_ref = b->wide_root;
     sc.root_ref2 = b->root_ref;
     sc.refill = kRefillDefault;
-    sc.desc_cap = 6;        // (measured 1 / 2 / 6 / 8 rounds: primary 0.354 / 0.295 / 0.262 / 0.269 ms in round 2)
+    sc.desc_cap = 6;        // (measured 1 / 2 / 6 / 8 rounds: primary 0.354 / 0.295 / 0.262 / 0.269 ms in round 2; on the wide records of
+                            //  round 4: 1 / 2 / 3 / 4 / 6 / 8 -> 0.161 / 0.142 / 0.141 / 0.134 / 0.142 / 0.150 ms, within the run-to-run spread)
     // (measured: primary traversal 267-271 -> 263 us, batch queries alike; residual retries +2 %: their list is not
     //  in mesh order, so they keep the plain mapping)
     sc.xcd = 1;
@@ -1986,10 +2202,13 @@ int launch_cast(const upsp_bvh *cb, const float *d_org, int org_stride, const fl
     //   frame-filling cube sphere (42 % hits, many long grazing rays): off 564, 384: 582, 256: 583, 160: 662, 128: 679
     //   cube-sphere tunnel model: off 166, any threshold 174-180 (the empty launch)
     // -- above the projection's 160: a batch may hold any ray, and thousands that are merely long are cheaper where they are
-    const int heavy_steps = env_int("UPSP_HEAVY_STEPS_CAST", 256);   // (read per call: the tests move it)
+    // Round 5: the rays that leave go to a WAVE each first (wave_cast_kernel: LDS stack, four rays per workgroup, thousands at
+    // once) and only a frontier that outgrows that stack to the workgroup walk -- so the threshold can sit where the tail of the
+    // batch starts: frame-filling sphere, 1 Mi rays: see LAB_NOTES.md section 12.
+    const int heavy_steps = env_int("UPSP_HEAVY_STEPS_CAST", 96);   // (read per call: the tests move it)
     const bool heavy_on = heavy_steps > 0 && !b->stats_on && b->info.depth <= 56;
     if (heavy_on) {
-        if (!b->d_heavy) UPSP_HIP_CHECK(hipMalloc(&b->d_heavy, sizeof(unsigned) * kHeavyCap));
+        if (!b->d_heavy) UPSP_HIP_CHECK(hipMalloc(&b->d_heavy, sizeof(unsigned) * 2 * kHeavyCap));      // (two lists)
     if (!b->d_heavy_scratch) UPSP_HIP_CHECK(hipMalloc(&b->d_heavy_scratch, kHeavyScratchBytes * kHeavyGridMax));
         sc.heavy_steps = (unsigned)heavy_steps;
         sc.heavy_items = b->d_heavy;
@@ -1998,9 +2217,15 @@ int launch_cast(const upsp_bvh *cb, const float *d_org, int org_stride, const fl
     }
     auto launch_heavy = [&]() {
         if (!heavy_on) return;
+        {
+            KTimed ktw("wave_cast_kernel", st);
+            const int cus = props().cus > 0 ? props().cus : 256;
+            hipLaunchKernelGGL((wave_cast_kernel<ANYHIT>), dim3((unsigned)cus * 5u), dim3(256), 0, st, sc, d_org, org_stride, d_dir, out,
+                               b->d_work, (const unsigned *)b->d_heavy, b->d_heavy + kHeavyCap);
+        }
         KTimed kth("heavy_cast_kernel", st);
         hipLaunchKernelGGL((heavy_cast_kernel<ANYHIT>), dim3(512), dim3(kHeavyThreads), 0, st, sc, d_org, org_stride, d_dir, out,
-                           (const unsigned *)b->d_work);
+                           (const unsigned *)b->d_work, kWorkHeavyCast + 1, (const unsigned *)(b->d_heavy + kHeavyCap));
     };
     if (n >= 65536) prefetch_bvh(b, st);
     if (n >= 65536 && !b->stats_on) {
@@ -2025,6 +2250,12 @@ int launch_cast(const upsp_bvh *cb, const float *d_org, int org_stride, const fl
         }
         launch_heavy();
         UPSP_HIP_CHECK(hipGetLastError());
+        if (heavy_on && std::getenv("UPSP_TRACE_STATS")) {       // diagnostics: how many rays left the one-lane traversal
+            unsigned nh = 0;
+            UPSP_HIP_CHECK(hipMemcpyAsync(&nh, b->d_work + kWorkHeavyCast, sizeof(nh), hipMemcpyDeviceToHost, st));
+            UPSP_HIP_CHECK(hipStreamSynchronize(st));
+            std::fprintf(stderr, "[upsp] %u of %zu rays needed more than %d steps (cooperative walk)\n", nh, n, heavy_steps);
+        }
         return UPSP_OK;
     }
     {
@@ -2493,7 +2724,7 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
         UPSP_HIP_CHECK(hipMalloc(&b->d_todo_rays, sizeof(unsigned) * 6 * nnodes));
         b->retry_capacity = nnodes;
     }
-    if (!b->d_heavy) UPSP_HIP_CHECK(hipMalloc(&b->d_heavy, sizeof(unsigned) * kHeavyCap));
+    if (!b->d_heavy) UPSP_HIP_CHECK(hipMalloc(&b->d_heavy, sizeof(unsigned) * 2 * kHeavyCap));      // (two lists)
     if (!b->d_heavy_scratch) UPSP_HIP_CHECK(hipMalloc(&b->d_heavy_scratch, kHeavyScratchBytes * kHeavyGridMax));
     UPSP_HIP_CHECK(hipMemsetAsync(b->d_work, 0, kWorkWords * sizeof(unsigned), st));
     const int grid = grid_for(nnodes, lds);
@@ -2509,7 +2740,7 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
     // a ray costs heavy_kernel 40-100 us however few steps it had left (one round per tree level, ~1.3 us each), so the
     // threshold sits above the longest ordinary ray of the well-shaped model
     // (read per build, not once: the tests move both to drive many rays through heavy_kernel and its fallback)
-    const int heavy_steps = env_int("UPSP_HEAVY_STEPS", 160);
+    const int heavy_steps = env_int("UPSP_HEAVY_STEPS", 96);
     const int heavy_stack = env_int("UPSP_HEAVY_STACK", (int)kHeavyStack);
     const bool heavy_on = heavy_steps > 0 && b->info.depth <= 56 && b->d_heavy;
     if (heavy_on) {
@@ -2520,11 +2751,16 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
     }
     sc.pack_waves = sc1.pack_waves = kPackWavesPerSimd * 4u * (unsigned)(props().cus > 0 ? props().cus : 256);
     const int heavy_grid = (int)kHeavyGridMax;
+    const int wave_grid = 5 * (props().cus > 0 ? props().cus : 256);
 #define UPSP_LAUNCH_HEAVY(PHASE, SC)                                                                             \
     if (heavy_on) {                                                                                              \
         KTimed kth("heavy_kernel", st);                                                                          \
+        hipLaunchKernelGGL((wave_proj_kernel<PHASE>), dim3(wave_grid), dim3(256), 0, st, SC, c, d_nodes, d_tri_nodes, d_pix, \
+                           (const unsigned *)b->d_retry_nodes, b->d_retry_mask, b->d_work, (const unsigned *)b->d_heavy,  \
+                           b->d_heavy + kHeavyCap);                                                              \
         hipLaunchKernelGGL((heavy_kernel<PHASE>), dim3(heavy_grid), dim3(kHeavyThreads), 0, st, SC, c, d_nodes, d_tri_nodes, \
-                           d_pix, (const unsigned *)b->d_retry_nodes, b->d_retry_mask, (const unsigned *)b->d_work); \
+                           d_pix, (const unsigned *)b->d_retry_nodes, b->d_retry_mask, (const unsigned *)b->d_work,     \
+                           kWorkWaveOver + (PHASE ? 1 : 0), (const unsigned *)(b->d_heavy + kHeavyCap));           \
     }
     bool use_witness = false;
     if (b->d_adj_off && b->adj_src == (const void *)d_tri_nodes && b->adj_nnodes == nnodes) {
