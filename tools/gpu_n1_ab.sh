@@ -1,6 +1,6 @@
 # N > 1 loop on one GPU, one-rank RCCL group, deferred schedule: the arrangements side by side in ONE call (alternating twice)
 set -x
-python tools/passb_probe.py > gpurun_out/passb_probe.txt 2>&1
+
 B="--force-chunked --defer-exchange --steps 10 --warmup 3 --no-cpu-baseline --no-reraycast"
 for rep in 1 2; do
   python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-reraycast 2>/dev/null | tail -1 > gpurun_out/ab_plain_$rep.json

@@ -1,7 +1,6 @@
 # N > 1 loop on one GPU through one-rank RCCL under rocprofv3 --kernel-trace: one steady-state step with RCCL's own kernels in it
 # (host-bound under the profiler: durations and overlaps are what to read, not the step time); + the pass-B probe
 set -x
-python tools/passb_probe.py > gpurun_out/passb_probe.txt 2>&1
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/n1_trace
 UPSP_FORCE_COLLECTIVES=1 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/n1_trace -- python3 bench.py --force-chunked --defer-exchange --steps 6 --warmup 3 --no-cpu-baseline --no-reraycast > gpurun_out/n1_trace.log 2>&1
