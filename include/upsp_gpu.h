@@ -298,6 +298,17 @@ int upsp_pipeline_set_row_map(upsp_pipeline *pipe, const int32_t *d_rowmap);
 /* The same with the copy ordered on `stream` (no host block between the projection build and the frame loop). */
 int upsp_pipeline_set_row_map_async(upsp_pipeline *pipe, const int32_t *d_rowmap, void *stream);
 
+/* Row padding.  A node-major series buffer whose pitch ld_t is a multiple of 128 bytes usually ends every row with columns nobody
+ * reads (engine.series_ld rounds 1000 frames up to 1024).  on != 0 declares: the columns between the last frame a process call
+ * stores and the next 128-byte boundary of the row (never past ld_t) hold no data of the caller's, and the whole-row pass B may
+ * write them (0, or NaN in the row of a node no camera sees).  A 4000-byte row piece then ends with a whole 128-byte line
+ * instead of a quarter of one: 0.42 -> 0.37 ms per 1000 frames of the bench model.  Calls that fill a wider matrix chunk by
+ * chunk in ascending column order on one stream stay correct (the next chunk overwrites what the previous one padded).  Used by
+ * the one-camera whole-row passes (plain frames, registration as the last image stage, f32 or u16 series); the several-camera
+ * row pass ignores it (measured slower with it).  Off by default: intensity_transpose (cpp/exec/psp_process.cpp:2027-2032) has
+ * no padding. */
+int upsp_pipeline_set_row_padding(upsp_pipeline *p, int on);
+
 /* Receiving side of the packed exchange: block d_src [nrows][ncols] f32 (contiguous) is copied
  * to rows d_rowidx[r] (int64) of d_dst (row pitch ld floats; add the column offset to d_dst). */
 int upsp_scatter_rows_f32(const float *d_src, size_t nrows, int ncols, const int64_t *d_rowidx,
@@ -598,9 +609,20 @@ int upsp_pipeline_series_frames_max(const upsp_pipeline *pipe);
 int upsp_rows_from_pixel_series(const uint16_t *d_compact, uint32_t cpitch, const int32_t *d_node_k, const uint8_t *d_skipped,
                                 size_t nnodes, int64_t nframes, float *d_rows_t, int64_t ld, double *d_sum, double *d_sumsq,
                                 void *stream);
+/* Pass B over the series of the same pixel rows held in `nblocks` buffers that follow each other in time (block b: [row][cpitch[b]]
+ * u16 holding nframes[b] frames -- what arrived from peer b of the exchange): rows d_rows_t [nnodes][ld] over all the frames.
+ * When every block holds a multiple of 4 frames the launches are cut at 128-byte lines of the output rows (every 32 columns), not
+ * at the block boundaries: a launch reads the end of one block and the start of the next.  pad_to (frame total <= pad_to <= ld):
+ * columns the last launch may write -- the frame total, or up to the next 128-byte line where the caller has padding there. */
+int upsp_rows_from_pixel_blocks(const uint16_t *const *d_compact, const uint32_t *cpitch, const int64_t *nframes, int nblocks,
+                                const int32_t *d_node_k, const uint8_t *d_skipped, size_t nnodes, float *d_rows_t, int64_t ld,
+                                int64_t pad_to, double *d_sum, double *d_sumsq, void *stream);
 int upsp_exchange_set_pixels(upsp_exchange *x, const int32_t *d_node_k, const uint8_t *d_skipped, int assume_same, void *stream);
 int upsp_exchange_pixel_rows(const upsp_exchange *x, int64_t *rows_out, int64_t *rows_in);
 int upsp_exchange_submit_pixels(upsp_exchange *x, const uint16_t *d_compact, uint32_t cpitch, int wire, void *stream);
+/* upsp_pipeline_set_row_padding for the owner's pass B: on != 0 declares columns [F, min(ld, F rounded up to 32)) of the d_series
+ * buffer handed to upsp_exchange_finish_pixels padding that may be written. */
+int upsp_exchange_set_row_padding(upsp_exchange *x, int on);
 int upsp_exchange_finish_pixels(upsp_exchange *x, float *d_series, int64_t ld, double *d_sum_mine, double *d_sumsq_mine,
                                 void *stream);
 

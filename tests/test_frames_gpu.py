@@ -728,3 +728,136 @@ def test_pixel_series_on_prescanned_candidates(gpu_lib, oracle):
     assert int(lost.sum()) > 0 and bool((nk[vis][lost] == -2).all()) and bool((nk[vis][~lost] >= 0).all())
     pipe.close()
     bvh.close()
+
+
+@pytest.mark.parametrize("ncams", [1, 3])
+@pytest.mark.parametrize("F,chunks", [(41, None), (300, None), (1000, None), (1030, None), (200, (70, 70, 60))])
+def test_row_padding(gpu_lib, oracle, F, chunks, ncams):
+    """upsp_pipeline_set_row_padding: the row pass may write the columns between the last frame of a call and the next
+    128-byte boundary of the row (never past the pitch).  Same frames through a pipeline with the padding declared and one
+    without: the series [:, :F] and the accumulators bit-identical (and equal to the oracle loop); with the padding on, nothing
+    past the 128-byte boundary is touched; chunks that do not end on a boundary, processed in ascending order, overwrite what the
+    chunk before them padded."""
+    import torch
+    from upsp_processing_amd import engine, synthetic as syn
+    H, W, n = 64, 128, 2200
+    rng = np.random.default_rng(F + ncams)
+    frames = [np.minimum(syn.synth_frames_numpy(F, H, W, seed=70 + c, hot=False), 3000).astype(np.uint16) for c in range(ncams)]
+    pix = rng.integers(-1, H * W, size=(ncams, n)).astype(np.int32)
+    pix[:, ::13] = -1
+    weight = rng.random((ncams, n)).astype(np.float32) if ncams > 1 else np.ones((1, n), np.float32)
+    rows_o = run_loop_oracle(oracle, frames, pix, weight)[0] if F <= 300 else None
+    ld = engine.series_ld(F, whole_rows=True) + 64            # (room past the 128-byte boundary: must stay untouched)
+    got = {}
+    for pad in (False, True):
+        pipe = engine.FramePipeline(ncams, W, H, n, fused_scan=1)
+        for c in range(ncams):
+            pipe.set_projection(c, pix[c], weight[c] if ncams > 1 else None)
+        pipe.set_row_padding(pad)
+        rt = torch.full((n, ld), -7.0, dtype=torch.float32, device="cuda")
+        c0 = 0
+        for nfr in (chunks or (F,)):
+            d = [torch.as_tensor(f[c0:c0 + nfr].copy()).cuda() for f in frames]
+            pipe.process(d, c0, rows_t=rt[:, :F], col0=c0, want_rows=False)
+            c0 += nfr
+        s, ss = [a.cpu().numpy() for a in pipe.accumulators()]
+        got[pad] = (rt.cpu().numpy(), s, ss)
+    plain, padded = got[False], got[True]
+    assert np.array_equal(plain[0][:, :F].view(np.int32), padded[0][:, :F].view(np.int32))
+    assert (plain[0][:, F:] == -7.0).all()
+    stop = (F + 31) // 32 * 32
+    assert (padded[0][:, stop:] == -7.0).all()
+    tail = padded[0][:, F:stop]
+    if stop > F and ncams == 1:      # the padding was written: 0, or NaN in the row of a node no camera sees
+        assert not (tail == -7.0).any() and (np.isnan(tail) | (tail == 0)).all()
+    else:                            # (the several-camera row pass does not use the permission: measured slower there)
+        assert (tail == -7.0).all()
+    for a, b in zip(plain[1:], padded[1:]):
+        assert np.array_equal(a.view(np.int64), b.view(np.int64))
+    if rows_o is not None:
+        assert np.array_equal(padded[0][:, :F].view(np.int32), rows_o.T.view(np.int32))
+
+
+def test_row_padding_packed_u16_and_registration(gpu_lib):
+    """The padding for the other whole-row writers: packed u16 series (128-byte line = 64 values) and registration as the last image
+    stage (pass B over the warped active pixels)."""
+    import torch
+    from upsp_processing_amd import engine, synthetic as syn
+    H, W, n, F = 64, 128, 1500, 100
+    rng = np.random.default_rng(3)
+    fr = np.minimum(syn.synth_frames_numpy(F, H, W, seed=9, hot=False), 3000).astype(np.uint16)
+    pix = rng.integers(-1, H * W, size=n).astype(np.int32)
+    keep = np.nonzero(pix >= 0)[0]
+    rowmap = np.full(n, -1, np.int32); rowmap[keep] = np.arange(keep.size)
+    out = {}
+    for pad in (False, True):
+        pipe = engine.FramePipeline(1, W, H, n, fused_scan=1)
+        pipe.set_projection(0, pix)
+        pipe.set_row_map(torch.as_tensor(rowmap).cuda())
+        pipe.set_row_padding(pad)
+        buf = torch.full((keep.size, 192), 77, dtype=torch.int32, device="cuda").to(torch.uint16)
+        pipe.process(torch.as_tensor(fr.copy()).cuda(), 0, rows_t=buf[:, :F], want_rows=False)
+        out[pad] = buf.cpu().numpy()
+    assert np.array_equal(out[False][:, :F], out[True][:, :F]) and (out[False][:, F:] == 77).all()
+    assert (out[True][:, F:128] == 0).all() and (out[True][:, 128:] == 77).all()
+    assert np.array_equal(out[True][:, :F].T, fr.reshape(F, -1)[:, pix[keep]])
+    out = {}
+    for pad in (False, True):
+        pipe = engine.FramePipeline(1, W, H, n, registration=1)
+        pipe.set_projection(0, pix)
+        pipe.set_reference(0, torch.as_tensor(fr[0].astype(np.float32)).cuda())
+        pipe.set_row_padding(pad)
+        rt = torch.full((n, 192), -7.0, dtype=torch.float32, device="cuda")
+        pipe.process(torch.as_tensor(fr.copy()).cuda(), 0, rows_t=rt[:, :F], want_rows=False)
+        out[pad] = rt.cpu().numpy()
+    assert np.array_equal(out[False][:, :F].view(np.int32), out[True][:, :F].view(np.int32))
+    assert (out[False][:, F:] == -7.0).all() and (out[True][:, 128:] == -7.0).all() and not (out[True][:, F:128] == -7.0).any()
+
+
+@pytest.mark.parametrize("sizes,pad", [([1000, 1000, 1000], 0), ([100, 40, 1000, 8], 24), ([36, 1024, 4, 0, 60], 0), ([1000], 24),
+                                       ([37, 50, 3], 0), ([2048, 12], 20), ([8, 8, 8, 8], 0)])
+def test_rows_from_pixel_blocks(gpu_lib, sizes, pad):
+    """upsp_rows_from_pixel_blocks: the owner's pass B over blocks as they arrive from the peers of an exchange ([pixel row][frames of
+    the source] u16, one buffer per source).  Launches cut at 128-byte lines of the output rows read two blocks each; the rows and the
+    accumulators must be what one long series buffer gives: row n = f32 of series[node_k[n]] (0 for a node without a pixel, NaN for a
+    skipped one), sums exact.  Also blocks that are no multiple of 4 frames (one launch per block), empty blocks, blocks shorter than
+    a line, blocks longer than one launch, padding columns at the end."""
+    import ctypes as C
+    import torch
+    from upsp_processing_amd import _capi
+    rng = np.random.default_rng(sum(sizes) + pad)
+    A, n = 700, 3000
+    total = sum(sizes)
+    series = rng.integers(0, 4096, size=(A, total)).astype(np.uint16)
+    node_k = rng.integers(-1, A, size=n).astype(np.int32)
+    skipped = (rng.random(n) < 0.1).astype(np.uint8)
+    starts = np.concatenate([[0], np.cumsum(sizes)])
+    pitch = [(sz + 3) // 4 * 4 for sz in sizes]              # (series rows on 8-byte boundaries)
+    blocks = []
+    for i, sz in enumerate(sizes):
+        b = np.full((A, pitch[i]), 4444, np.uint16)
+        b[:, :sz] = series[:, starts[i]:starts[i + 1]]
+        blocks.append(torch.as_tensor(b).cuda() if sz else None)
+    ld = (total + pad + 63) // 64 * 64 + 64
+    rows = torch.full((n, ld), -9.0, dtype=torch.float32, device="cuda")
+    s = torch.zeros(n, dtype=torch.float64, device="cuda"); ss = torch.zeros_like(s)
+    ptrs = (C.c_void_p * len(sizes))(*[b.data_ptr() if b is not None else None for b in blocks])
+    pitches = (C.c_uint32 * len(sizes))(*pitch)
+    counts = (C.c_int64 * len(sizes))(*sizes)
+    d_nk, d_sk = torch.as_tensor(node_k).cuda(), torch.as_tensor(skipped).cuda()
+    for rep in range(2):       # twice: the accumulators add up
+        _capi.check(_capi.lib().upsp_rows_from_pixel_blocks(ptrs, pitches, counts, len(sizes), C.c_void_p(d_nk.data_ptr()), C.c_void_p(d_sk.data_ptr()),
+                                                            n, C.c_void_p(rows.data_ptr()), ld, total + pad, C.c_void_p(s.data_ptr()),
+                                                            C.c_void_p(ss.data_ptr()), None))
+    torch.cuda.synchronize()
+    want = np.where(node_k[:, None] >= 0, series[np.maximum(node_k, 0)].astype(np.float32), np.float32(0))
+    want[skipped != 0] = np.nan
+    got = rows.cpu().numpy()
+    assert np.array_equal(got[:, :total].view(np.int32), want.view(np.int32))
+    assert (got[:, total + pad:] == -9.0).all()
+    w64 = want.astype(np.float64)
+    ws, wss = 2 * w64.sum(axis=1), 2 * (w64 * w64).sum(axis=1)
+    gs, gss = s.cpu().numpy(), ss.cpu().numpy()
+    ok = skipped == 0
+    assert np.isnan(gs[~ok]).all() and np.isnan(gss[~ok]).all()
+    assert np.array_equal(gs[ok], ws[ok]) and np.array_equal(gss[ok], wss[ok])

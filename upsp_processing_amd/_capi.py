@@ -84,6 +84,7 @@ SIGNATURES = {
     "upsp_scatter_rows_u16": (_i, [_vp, _sz, _i, _vp, _vp, C.c_longlong, _vp]),
     "upsp_pipeline_set_row_map": (_i, [_vp, _vp]),
     "upsp_pipeline_set_row_map_async": (_i, [_vp, _vp, _vp]),
+    "upsp_pipeline_set_row_padding": (_i, [_vp, _i]),
     "upsp_pipeline_set_overlap_source": (_i, [_vp, _vp]),
     "upsp_pipeline_set_skipped": (_i, [_vp, _vp]),
     "upsp_pipeline_set_reference": (_i, [_vp, _i, _vp]),
@@ -143,10 +144,12 @@ SIGNATURES = {
     "upsp_pipeline_pixel_series": (_i, [_vp, _vp, _i, _vp, C.POINTER(_vp), C.POINTER(C.c_uint32), C.POINTER(_vp), C.POINTER(_vp)]),
     "upsp_pipeline_series_frames_max": (_i, [_vp]),
     "upsp_rows_from_pixel_series": (_i, [_vp, C.c_uint32, _vp, _vp, _sz, C.c_int64, _vp, C.c_int64, _vp, _vp, _vp]),
+    "upsp_rows_from_pixel_blocks": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _sz, _vp, C.c_int64, C.c_int64, _vp, _vp, _vp]),
     "upsp_exchange_set_pixels": (_i, [_vp, _vp, _vp, _i, _vp]),
     "upsp_exchange_pixel_rows": (_i, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "upsp_exchange_submit_pixels": (_i, [_vp, _vp, C.c_uint32, _i, _vp]),
     "upsp_exchange_finish_pixels": (_i, [_vp, _vp, C.c_int64, _vp, _vp, _vp]),
+    "upsp_exchange_set_row_padding": (_i, [_vp, _i]),
     "upsp_phase_begin": (_i, [C.c_char_p]),
     "upsp_phase_end": (_i, [C.POINTER(C.c_double)]),
     "upsp_timing_enable": (_i, [_i]),

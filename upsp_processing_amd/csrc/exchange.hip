@@ -38,6 +38,7 @@
 #include <vector>
 
 #include "ktimer.h"
+#include "pipeline.h"
 #include "upsp_gpu.h"
 #include "upsp_internal.h"
 
@@ -378,6 +379,7 @@ struct upsp_exchange {
     uint16_t *d_compact_me = nullptr;           // [rows_in][fpad]: the pixel series my nodes read, all frames of the run
     size_t compact_me_bytes = 0;
     int64_t fpad = 0;
+    bool row_padding = false;                   // upsp_exchange_set_row_padding
     std::vector<void *> gathered;               // [chunk] send buffer: the rows of d_send_k out of the sender's compact buffer
     std::vector<size_t> gathered_bytes;
     uint64_t bytes_sent = 0, bytes_received = 0;   // of the pass in flight (to other ranks: what crosses a link)
@@ -995,6 +997,13 @@ int upsp_exchange_submit_pixels(upsp_exchange *x, const uint16_t *d_compact, uin
     return submit_core(x, x->gathered[k], wire, st);
 }
 
+int upsp_exchange_set_row_padding(upsp_exchange *x, int on)
+{
+    if (!x) return fail(UPSP_ERR_INVALID, "null exchange");
+    x->row_padding = on != 0;
+    return UPSP_OK;
+}
+
 int upsp_exchange_finish_pixels(upsp_exchange *x, float *d_series, int64_t ld, double *d_sum_mine, double *d_sumsq_mine, void *stream)
 {
     if (!x || !x->have_rows || x->mode != 1 || !d_series || !d_sum_mine || !d_sumsq_mine) return fail(UPSP_ERR_INVALID, "bad argument");
@@ -1010,16 +1019,17 @@ int upsp_exchange_finish_pixels(upsp_exchange *x, float *d_series, int64_t ld, d
     // series buffer first.  (With several chunks per rank the pieces would be short row segments: placed, below.)
     bool direct = x->wire == 2 && x->K == 1 && rows_in > 0;
     for (int s = 0; s < W && direct; ++s) direct = (x->chunk_count[s][0] % 4) == 0;
+    // columns the last launch of pass B may write: up to the next 128-byte line of the rows when the caller gave up its padding
+    const int64_t pad_to = x->row_padding && (ld % 32) == 0 ? std::min<int64_t>(ld, (x->F + 31) / 32 * 32) : x->F;
     if (direct) {
-        if (x->node_count[me] > 0)
-            for (int s = 0; s < W; ++s) {
-                const int64_t fs = x->chunk_count[s][0];
-                if (!fs) continue;
-                rc = upsp_rows_from_pixel_series(static_cast<const uint16_t *>(block_of(x, 0, s)), (uint32_t)fs, x->d_node_local,
-                                                 x->d_skipped_me, (size_t)x->node_count[me], fs, d_series + x->frame_start[s], ld,
-                                                 d_sum_mine, d_sumsq_mine, stream);
-                if (rc != UPSP_OK) return rc;
-            }
+        if (x->node_count[me] > 0 && x->F > 0) {
+            std::vector<upsp::SeriesBlock> blocks;                 // (frame_start[] ascends with the rank: the blocks in time order)
+            for (int s = 0; s < W; ++s)
+                blocks.push_back({static_cast<const uint16_t *>(block_of(x, 0, s)), (unsigned)x->chunk_count[s][0], x->chunk_count[s][0]});
+            rc = upsp::rows_from_pixel_blocks(blocks.data(), W, x->d_node_local, x->d_skipped_me, (size_t)x->node_count[me], d_series, ld,
+                                              pad_to, d_sum_mine, d_sumsq_mine, st);
+            if (rc != UPSP_OK) return rc;
+        }
         x->k = 0;
         x->last_sent = x->bytes_sent;
         x->last_received = x->bytes_received;
@@ -1044,8 +1054,9 @@ int upsp_exchange_finish_pixels(upsp_exchange *x, float *d_series, int64_t ld, d
     }
     // pass B by the owner of the nodes, over every frame of the run: series, NaN rows, complete accumulators
     if (x->node_count[me] > 0 && x->F > 0) {
-        rc = upsp_rows_from_pixel_series(x->d_compact_me, (uint32_t)x->fpad, x->d_node_local, x->d_skipped_me,
-                                         (size_t)x->node_count[me], x->F, d_series, ld, d_sum_mine, d_sumsq_mine, stream);
+        const upsp::SeriesBlock all = {x->d_compact_me, (unsigned)x->fpad, x->F};
+        rc = upsp::rows_from_pixel_blocks(&all, 1, x->d_node_local, x->d_skipped_me, (size_t)x->node_count[me], d_series, ld, pad_to,
+                                          d_sum_mine, d_sumsq_mine, st);
         if (rc != UPSP_OK) return rc;
     }
     x->k = 0;

@@ -862,8 +862,17 @@ __global__ void __launch_bounds__(256)
                      const uint8_t *__restrict__ skipped, const int32_t *__restrict__ rowmap, unsigned nnodes,
                      int nframes, float *__restrict__ rows_t, uint16_t *__restrict__ rows_t16, long long ld_t,
                      double *__restrict__ sum, double *__restrict__ sumsq, const uint16_t *__restrict__ frames,
-                     size_t npix, const int32_t *__restrict__ pix, bool fresh)
+                     size_t npix, const int32_t *__restrict__ pix, bool fresh, int nstore,
+                     const uint16_t *__restrict__ compact_b, unsigned cpitch_b, int nframes_a)
 {
+    // compact_b / cpitch_b / nframes_a: the series of frames [nframes_a, nframes) of the launch come from a second buffer (same
+    // rows, its column 0 = frame nframes_a): a launch of the owner's pass B over blocks received from two peers, cut at 128-byte
+    // lines of the output rows instead of at the block boundary (launch_node_rows_blocks).  nframes_a = nframes: one buffer.
+    // nstore (>= nframes): columns [nframes, nstore) of every stored row are padding the caller gave up (upsp_pipeline_set_row_padding):
+    // they are written too (0 / the row's fill value), so that a row ends on a 128-byte line -- a 4000-byte row piece whose last line is
+    // a quarter full costs the memory system a partial write per row (tools/probe/store_shapes.hip: 5.2-5.4 TB/s against 6.1-6.2 for
+    // whole lines, same store shape)
+
     // fresh: the accumulators were reset and not touched since -- they are WRITTEN (0 + the sums of this launch; 0 for a node without
     // a pixel) instead of read, added to and written, and upsp_pipeline_reset launches no fill
     constexpr int RPS = 256 / LPR;          // rows per sweep
@@ -894,7 +903,9 @@ __global__ void __launch_bounds__(256)
         const int k = s_k[r];
         uint2 w = make_uint2(0u, 0u);
         // (ordinary loads: the compact buffer was written a moment ago and sits in L2 / Infinity Cache)
-        if (s_sk[r] == 0 && k >= 0 && f0 < nframes) w = *reinterpret_cast<const uint2 *>(compact + (size_t)k * cpitch + f0);
+        if (s_sk[r] == 0 && k >= 0 && f0 < nframes)
+            w = f0 < nframes_a ? *reinterpret_cast<const uint2 *>(compact + (size_t)k * cpitch + f0)
+                               : *reinterpret_cast<const uint2 *>(compact_b + (size_t)k * cpitch_b + (f0 - nframes_a));
         return w;
     };
     // AHEAD 2: the series of ALL sweeps are requested before the first row is stored -- one memory latency per workgroup instead
@@ -918,31 +929,31 @@ __global__ void __launch_bounds__(256)
             // no load, no sums, no reductions (its partials are not read below).  These are 60 % of the rows of the bench
             // model, and the kernel was bound by its VALU instructions (PMC: 194 M wave-instructions per launch = 0.32 of
             // its 0.40 ms at one per 4 cycles), most of them the per-row reductions.
-            if (row >= 0 && f0 < nframes) {
+            if (row >= 0 && f0 < nstore) {
                 if (!U16) {
                     float *dst = rows_t + (long long)row * ld_t + f0;
                     typedef float v4f __attribute__((ext_vector_type(4)));
                     const float c = sk ? qnan : 0.0f;
                     const v4f nv = {c, c, c, c};
-                    if (vec_ok && f0 + 3 < nframes) {
+                    if (vec_ok && f0 + 3 < nstore) {
                         __builtin_nontemporal_store(nv, reinterpret_cast<v4f *>(dst));
                     } else {
                         dst[0] = c;
-                        if (f0 + 1 < nframes) dst[1] = c;
-                        if (f0 + 2 < nframes) dst[2] = c;
-                        if (f0 + 3 < nframes) dst[3] = c;
+                        if (f0 + 1 < nstore) dst[1] = c;
+                        if (f0 + 2 < nstore) dst[2] = c;
+                        if (f0 + 3 < nstore) dst[3] = c;
                     }
                 } else {
                     uint16_t *dst = rows_t16 + (long long)row * ld_t + f0;
                     typedef unsigned v2u __attribute__((ext_vector_type(2)));
                     const v2u nv = {0u, 0u};
-                    if (vec_ok && f0 + 3 < nframes) {
+                    if (vec_ok && f0 + 3 < nstore) {
                         __builtin_nontemporal_store(nv, reinterpret_cast<v2u *>(dst));
                     } else {
                         dst[0] = 0;
-                        if (f0 + 1 < nframes) dst[1] = 0;
-                        if (f0 + 2 < nframes) dst[2] = 0;
-                        if (f0 + 3 < nframes) dst[3] = 0;
+                        if (f0 + 1 < nstore) dst[1] = 0;
+                        if (f0 + 2 < nstore) dst[2] = 0;
+                        if (f0 + 3 < nstore) dst[3] = 0;
                     }
                 }
             }
@@ -975,31 +986,33 @@ __global__ void __launch_bounds__(256)
             p_s[r][wr] = ws;
             p_ss[r][wr] = wss;
         }
-        if (row < 0 || f0 >= nframes) continue;                 // row not stored (packed series) / past the end
+        if (row < 0 || f0 >= nstore) continue;                  // row not stored (packed series) / past the end
+        // (columns past nframes: padding, written as 0)
+        const unsigned e[4] = {d[0], f0 + 1 < nframes ? d[1] : 0u, f0 + 2 < nframes ? d[2] : 0u, f0 + 3 < nframes ? d[3] : 0u};
         if (!U16) {
             float *dst = rows_t + (long long)row * ld_t + f0;
             typedef float v4f __attribute__((ext_vector_type(4)));
             // a node without a pixel: 0 (empty row of the projection matrix); no camera sees it: NaN
-            const v4f nv = {sk ? qnan : (float)d[0], sk ? qnan : (float)d[1], sk ? qnan : (float)d[2], sk ? qnan : (float)d[3]};
-            if (vec_ok && f0 + 3 < nframes) {
+            const v4f nv = {sk ? qnan : (float)e[0], sk ? qnan : (float)e[1], sk ? qnan : (float)e[2], sk ? qnan : (float)e[3]};
+            if (vec_ok && f0 + 3 < nstore) {
                 __builtin_nontemporal_store(nv, reinterpret_cast<v4f *>(dst));
             } else {
                 dst[0] = nv.x;
-                if (f0 + 1 < nframes) dst[1] = nv.y;
-                if (f0 + 2 < nframes) dst[2] = nv.z;
-                if (f0 + 3 < nframes) dst[3] = nv.w;
+                if (f0 + 1 < nstore) dst[1] = nv.y;
+                if (f0 + 2 < nstore) dst[2] = nv.z;
+                if (f0 + 3 < nstore) dst[3] = nv.w;
             }
         } else {   // u16 series (exchange wire format; callers store visible rows only)
             uint16_t *dst = rows_t16 + (long long)row * ld_t + f0;
             typedef unsigned v2u __attribute__((ext_vector_type(2)));
-            const v2u nv = {sk ? 0u : w.x, sk ? 0u : w.y};
-            if (vec_ok && f0 + 3 < nframes) {
+            const v2u nv = {sk ? 0u : (e[0] | (e[1] << 16)), sk ? 0u : (e[2] | (e[3] << 16))};
+            if (vec_ok && f0 + 3 < nstore) {
                 __builtin_nontemporal_store(nv, reinterpret_cast<v2u *>(dst));
             } else {
                 dst[0] = (uint16_t)(nv.x & 0xFFFFu);
-                if (f0 + 1 < nframes) dst[1] = (uint16_t)(nv.x >> 16);
-                if (f0 + 2 < nframes) dst[2] = (uint16_t)(nv.y & 0xFFFFu);
-                if (f0 + 3 < nframes) dst[3] = (uint16_t)(nv.y >> 16);
+                if (f0 + 1 < nstore) dst[1] = (uint16_t)(nv.x >> 16);
+                if (f0 + 2 < nstore) dst[2] = (uint16_t)(nv.y & 0xFFFFu);
+                if (f0 + 3 < nstore) dst[3] = (uint16_t)(nv.y >> 16);
             }
         }
     }
@@ -1771,27 +1784,35 @@ int launch_amap_nodes(const int32_t *d_pix, size_t nnodes, const uint8_t *d_flag
 
 // g.img[0]: the group's first frame (u16) -- only read for nodes whose pixel is missing from the map (node_k == -2)
 int launch_node_rows(const PipelineGather &g, const int32_t *d_node_k, const uint16_t *d_compact, unsigned cpitch,
-                     hipStream_t st, bool cold_series, bool fresh_acc)
+                     hipStream_t st, bool cold_series, bool fresh_acc, const uint16_t *d_compact_b, unsigned cpitch_b,
+                     int nframes_a)
 {
-    if (g.nframes <= 0 || g.nframes > kGroupFramesMax || (unsigned)g.nframes > cpitch)
+    if (g.nframes <= 0 || g.nframes > kGroupFramesMax || (unsigned)(d_compact_b ? nframes_a : g.nframes) > cpitch)
         return fail(UPSP_ERR_INVALID, "row pass: too many frames");
+    if (d_compact_b && (nframes_a <= 0 || nframes_a >= g.nframes || (nframes_a & 3) || (unsigned)(g.nframes - nframes_a) > cpitch_b))
+        return fail(UPSP_ERR_INVALID, "row pass: bad split between the two series buffers");
     const unsigned nn = (unsigned)g.nnodes;
     KTimed kt("node_rows_kernel", st);
-    // four sweeps per workgroup (1 / 2 / 4 / 8: 486 / 412 / 370 / 422 us per 1000 frames of the bench model); the series loads
-    // of all sweeps first (one sweep ahead of the rows that use them, the arrangement that pays in the multi-camera kernel:
-    // 0.403-0.413 ms either way here -- this kernel waits for its stores)
+    // four sweeps per workgroup (1 / 2 / 4 / 8: 486 / 412 / 370 / 422 us per 1000 frames of the bench model).  Series loads: with
+    // rows that end inside a 128-byte line the kernel waits for its stores and the arrangement of the loads does not matter (at
+    // use / one sweep ahead / all up front: 0.403-0.413 ms); with padded rows (nstore, 0.32-0.33 ms alone on the device) all loads
+    // up front is the default for f32 rows of > 512 frames: in the bench step, where part of the series has left the Infinity
+    // Cache behind pass A's frames, 0.370-0.373 ms against 0.381-0.385 at use (tools/passb_probe.py: warm 0.33 either way, cold
+    // 0.52 against 0.55; eight sweeps 0.41 cold but 0.375 warm -- the choice for series that are known to be cold)
 #define UPSP_NRX(LPR, ROWS, U16, AH)                                                                         \
     hipLaunchKernelGGL((node_rows_kernel<LPR, ROWS, U16, AH>), dim3((nn + (256 / LPR) * ROWS - 1) / ((256 / LPR) * ROWS)), \
                        dim3(256), 0, st, d_compact, cpitch, d_node_k, g.skipped, g.rowmap, nn, g.nframes, g.rows_t,  \
-                       g.rows_t16, (long long)g.ld_t, g.sum, g.sumsq, (const uint16_t *)g.img[0], g.npix, g.pix[0], fresh_acc)
+                       g.rows_t16, (long long)g.ld_t, g.sum, g.sumsq, (const uint16_t *)g.img[0], g.npix, g.pix[0], fresh_acc,  \
+                       std::min(std::max(g.nstore, g.nframes), 4 * (LPR)), d_compact_b, cpitch_b,                    \
+                       d_compact_b ? nframes_a : g.nframes)
 #define UPSP_NR(LPR, U16) UPSP_NRX(LPR, 4, U16, 0)
 #define UPSP_NR_L(U16)                                                                                       \
     do {                                                                                                     \
         if (g.nframes > 512) UPSP_NR(256, U16); else if (g.nframes > 256) UPSP_NR(128, U16); else UPSP_NR(64, U16); \
     } while (0)
-    // (measurement switch UPSP_ROWS_VARIANT = <sweeps><ahead>, f32 rows of > 512 frames: 40 default, 41, 42, 80, 81, 82, 162)
+    // (measurement switch UPSP_ROWS_VARIANT = <sweeps><ahead>, f32 rows of > 512 frames: 40, 41, 42 default, 80, 81, 82 for cold series, 162)
     static const int variant = [] { const char *e = getenv("UPSP_ROWS_VARIANT"); return e ? atoi(e) : 0; }();
-    const int var = (cold_series && !variant) ? 82 : variant;
+    const int var = variant ? variant : (cold_series ? 82 : 42);
     if (var && !g.rows_t16 && g.nframes > 512) {
         switch (var) {
         case 41: UPSP_NRX(256, 4, false, 1); break;

@@ -18,6 +18,7 @@ struct PipelineGather {
     size_t npix = 0;      // pixels per frame
     size_t nnodes = 0;
     int nframes = 0;
+    int nstore = 0;       // pass B (whole rows): columns [nframes, nstore) of a stored row are padding that may be written (0 = none)
     const void *img[kMaxCams] = {nullptr};  // first frame of the batch (u16 or f32)
     int is_f32[kMaxCams] = {0};
     const int32_t *pix[kMaxCams] = {nullptr};
@@ -52,8 +53,22 @@ int launch_scan_compact(uint16_t *d_frames, size_t npix, int nframes, bool hot, 
 // cold_series: the compact series were not written a moment ago (they come from HBM, not from the Infinity Cache): every
 // sweep's series are requested up front
 // fresh_acc: the accumulators hold nothing yet (reset, untouched since): they are written, not added to
+// d_compact_b / cpitch_b / nframes_a: frames [nframes_a, g.nframes) of the launch read a second series buffer (same rows; its column
+// 0 = frame nframes_a; nframes_a a multiple of 4)
 int launch_node_rows(const PipelineGather &g, const int32_t *d_node_k, const uint16_t *d_compact, unsigned cpitch,
-                     hipStream_t st, bool cold_series = false, bool fresh_acc = false);
+                     hipStream_t st, bool cold_series = false, bool fresh_acc = false, const uint16_t *d_compact_b = nullptr,
+                     unsigned cpitch_b = 0, int nframes_a = 0);
+// Pass B over the series of the same pixel rows held in `nblocks` buffers, one per run of consecutive frames (blocks received from
+// the peers of an exchange: [pixel row][frames of the source], pitch = cpitch[b] u16): node-major rows d_rows_t [nnodes][ld] over
+// all frames, accumulators.  The launches are cut at 128-byte lines of the output rows (32 columns), not at the block boundaries,
+// when every block holds a multiple of 4 frames; pad_to (>= the frame total, <= ld): columns the last launch may write (padding).
+struct SeriesBlock {
+    const uint16_t *compact;
+    unsigned cpitch;
+    int64_t nframes;
+};
+int rows_from_pixel_blocks(const SeriesBlock *blocks, int nblocks, const int32_t *d_node_k, const uint8_t *d_skipped, size_t nnodes,
+                           float *d_rows_t, int64_t ld, int64_t pad_to, double *d_sum, double *d_sumsq, hipStream_t st);
 int launch_node_rows_multi(const PipelineGather &g, const int32_t *const *d_node_k, const uint16_t *const *d_compact,
                            unsigned cpitch, hipStream_t st);
 size_t hot_changes_words(int nframes, int max_hot);   // size of d_changes for launch_hot_fixup

@@ -51,6 +51,7 @@ struct upsp_pipeline {
     uint16_t *d_compact = nullptr;
     size_t compact_bytes = 0;        // allocated size of d_compact
     unsigned *d_changes = nullptr;   // hot-pixel change list of a call (frames.hip: hot_changes_words)
+    bool row_padding = false;        // upsp_pipeline_set_row_padding
     int changes_parity = 0;          // which of its two change counters the next one-camera fix-up uses
     bool acc_unset = false;          // upsp_pipeline_reset was called and the accumulators were not zeroed yet (done by whoever touches them first)
     size_t changes_words = 0;
@@ -371,6 +372,23 @@ int upsp_pipeline_set_row_map_async(upsp_pipeline *p, const int32_t *d_rowmap, v
     return set_row_map_impl(p, d_rowmap, true, (hipStream_t)stream);
 }
 
+int upsp_pipeline_set_row_padding(upsp_pipeline *p, int on)
+{
+    if (!p) return fail(UPSP_ERR_INVALID, "null pipeline");
+    p->row_padding = on != 0;
+    return UPSP_OK;
+}
+
+// columns a whole-row pass B may store for `ns` frames that start at column `c0` of rows of pitch ld: up to the next 128-byte
+// line (32 floats / 64 u16) when the caller declared those columns padding
+static int padded_store(const upsp_pipeline *p, int64_t c0, int ns, int64_t ld, int per_line)
+{
+    if (!p->row_padding || (ld % per_line) != 0) return ns;
+    const int64_t end = c0 + ns;
+    const int64_t stop = std::min<int64_t>(ld, (end + per_line - 1) / per_line * per_line);
+    return ns + (int)(stop - end);
+}
+
 int upsp_pipeline_set_reference(upsp_pipeline *p, int cam, const float *d_ref32f)
 {
     if (!p || cam < 0 || cam >= p->ncams || !d_ref32f) return fail(UPSP_ERR_INVALID, "bad argument");
@@ -651,15 +669,33 @@ int upsp_pipeline_pixel_series(upsp_pipeline *p, uint16_t *d_frames, int nframes
     return rc;
 }
 
-// Pass B as an operator: node-major series (and accumulators) of `nnodes` nodes over `nframes` frames from the pixel
-// series they read.  d_node_k [nnodes]: row of d_compact per node (< 0: no pixel -> 0); d_skipped: NaN rows.
-int upsp_rows_from_pixel_series(const uint16_t *d_compact, uint32_t cpitch, const int32_t *d_node_k, const uint8_t *d_skipped,
-                                size_t nnodes, int64_t nframes, float *d_rows_t, int64_t ld, double *d_sum, double *d_sumsq,
-                                void *stream)
+// Pass B as an operator: node-major series (and accumulators) of `nnodes` nodes over the frames of `nblocks` series buffers that
+// follow each other in time (pipeline.h).  d_node_k [nnodes]: row of the buffers per node (< 0: no pixel -> 0); d_skipped: NaN rows.
+}  // extern "C"
+int upsp::rows_from_pixel_blocks(const SeriesBlock *blocks, int nblocks, const int32_t *d_node_k, const uint8_t *d_skipped,
+                                 size_t nnodes, float *d_rows_t, int64_t ld, int64_t pad_to, double *d_sum, double *d_sumsq,
+                                 hipStream_t st)
 {
-    if (!d_compact || !d_node_k || !d_rows_t || !d_sum || !d_sumsq || nnodes == 0 || nnodes >= ((size_t)1 << 31))
+    if (!blocks || nblocks < 1 || !d_node_k || !d_rows_t || !d_sum || !d_sumsq || nnodes == 0 || nnodes >= ((size_t)1 << 31))
         return fail(UPSP_ERR_INVALID, "bad argument");
-    if (nframes < 0 || ld < nframes || (int64_t)cpitch < nframes) return fail(UPSP_ERR_INVALID, "rows from pixel series: pitch smaller than the frame count");
+    std::vector<SeriesBlock> bl;
+    std::vector<int64_t> start;
+    int64_t total = 0;
+    bool mult4 = true;
+    for (int b = 0; b < nblocks; ++b) {
+        if (blocks[b].nframes < 0 || (int64_t)blocks[b].cpitch < blocks[b].nframes || (blocks[b].nframes && !blocks[b].compact))
+            return fail(UPSP_ERR_INVALID, "rows from pixel series: pitch smaller than the frame count");
+        if (!blocks[b].nframes) continue;
+        // (the row pass reads four frames per 8-byte load)
+        if ((blocks[b].cpitch % 4) != 0 || (reinterpret_cast<size_t>(blocks[b].compact) & 7) != 0)
+            return fail(UPSP_ERR_INVALID, "rows from pixel series: series rows must start on 8-byte boundaries (pitch a multiple of 4)");
+        bl.push_back(blocks[b]);
+        start.push_back(total);
+        total += blocks[b].nframes;
+        mult4 = mult4 && (blocks[b].nframes % 4) == 0;
+    }
+    start.push_back(total);
+    if (ld < total || pad_to < total || pad_to > ld) return fail(UPSP_ERR_INVALID, "rows from pixel series: row pitch smaller than the frame count");
     PipelineGather g;
     g.ncams = 1;
     g.nnodes = nnodes;
@@ -667,15 +703,60 @@ int upsp_rows_from_pixel_series(const uint16_t *d_compact, uint32_t cpitch, cons
     g.sum = d_sum;
     g.sumsq = d_sumsq;
     g.ld_t = ld;
-    const int G = group_frames_max();
-    int rc = UPSP_OK;
-    for (int64_t f0 = 0; f0 < nframes && rc == UPSP_OK; f0 += G) {
-        g.nframes = (int)std::min<int64_t>(G, nframes - f0);
-        g.rows_t = d_rows_t + f0;
+    const int64_t G = group_frames_max();
+    const int nb = (int)bl.size();
+    int rc = UPSP_OK, a = 0;
+    for (int64_t c = 0; c < total && rc == UPSP_OK;) {
+        while (start[a + 1] <= c) ++a;
+        const int64_t end_a = start[a + 1];
+        int64_t hi = std::min(c + G, end_a);
+        // (measurement switch UPSP_ROWS_LINE_CUT=0: one launch per block, round 4's form)
+        static const bool line_cut = [] { const char *e = getenv("UPSP_ROWS_LINE_CUT"); return !(e && *e == '0'); }();
+        if (mult4 && line_cut) {
+            // a launch ends on a 128-byte line of the output rows (32 columns) and takes the columns up to there from the next
+            // block -- a 4000-byte row piece per source otherwise starts and ends inside a line, which the memory system writes
+            // as partial lines (tools/probe/store_shapes.hip: 5.2-5.4 against 6.1-6.2 TB/s)
+            const int64_t lim = std::min(c + G, a + 1 < nb ? start[a + 2] : end_a);
+            const int64_t cut = lim == total ? total : lim / 32 * 32;
+            if (cut > c) hi = cut;
+        }
+        const int64_t n_a = std::min(hi, end_a) - c;
+        g.nframes = (int)(hi - c);
+        g.nstore = hi == total ? (int)std::min<int64_t>(pad_to - c, G) : g.nframes;
+        g.rows_t = d_rows_t + c;
+        const uint16_t *src = bl[a].compact + (c - start[a]);
         // (the caller's series: received from a peer, or kept from an earlier call -- not the pipeline's own pass A of a moment ago)
-        rc = launch_node_rows(g, d_node_k, d_compact + f0, cpitch, (hipStream_t)stream, true);
+        if (n_a < hi - c)
+            rc = launch_node_rows(g, d_node_k, src, bl[a].cpitch, st, true, false, bl[a + 1].compact, bl[a + 1].cpitch, (int)n_a);
+        else
+            rc = launch_node_rows(g, d_node_k, src, bl[a].cpitch, st, true);
+        c = hi;
     }
     return rc;
+}
+
+extern "C" {
+int upsp_rows_from_pixel_series(const uint16_t *d_compact, uint32_t cpitch, const int32_t *d_node_k, const uint8_t *d_skipped,
+                                size_t nnodes, int64_t nframes, float *d_rows_t, int64_t ld, double *d_sum, double *d_sumsq,
+                                void *stream)
+{
+    if (!d_compact || !d_node_k || !d_rows_t || !d_sum || !d_sumsq || nnodes == 0 || nnodes >= ((size_t)1 << 31) || nframes < 0)
+        return fail(UPSP_ERR_INVALID, "bad argument");
+    if (ld < nframes || (int64_t)cpitch < nframes) return fail(UPSP_ERR_INVALID, "rows from pixel series: pitch smaller than the frame count");
+    if (nframes == 0) return UPSP_OK;
+    const upsp::SeriesBlock b = {d_compact, cpitch, nframes};
+    return upsp::rows_from_pixel_blocks(&b, 1, d_node_k, d_skipped, nnodes, d_rows_t, ld, nframes, d_sum, d_sumsq, (hipStream_t)stream);
+}
+
+int upsp_rows_from_pixel_blocks(const uint16_t *const *d_compact, const uint32_t *cpitch, const int64_t *nframes, int nblocks,
+                                const int32_t *d_node_k, const uint8_t *d_skipped, size_t nnodes, float *d_rows_t, int64_t ld,
+                                int64_t pad_to, double *d_sum, double *d_sumsq, void *stream)
+{
+    if (!d_compact || !cpitch || !nframes || nblocks < 1) return fail(UPSP_ERR_INVALID, "bad argument");
+    std::vector<upsp::SeriesBlock> b((size_t)nblocks);
+    for (int i = 0; i < nblocks; ++i) b[(size_t)i] = {d_compact[i], cpitch[i], nframes[i]};
+    return upsp::rows_from_pixel_blocks(b.data(), nblocks, d_node_k, d_skipped, nnodes, d_rows_t, ld, pad_to, d_sum, d_sumsq,
+                                        (hipStream_t)stream);
 }
 
 static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes,
@@ -784,6 +865,7 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
             g.img[0] = fr + (size_t)s0 * npix;
             g.rows_t = d_rows_t ? d_rows_t + col0 + s0 : nullptr;
             g.rows_t16 = d_rows_t16 ? d_rows_t16 + col0 + s0 : nullptr;
+            g.nstore = padded_store(p, col0 + s0, ns, ld_t, d_rows_t ? 32 : 64);
             if (rc == UPSP_OK) rc = launch_node_rows(g, p->d_node_k, p->d_compact, cp, st, false, fresh);
             fresh = false;
         }
@@ -915,6 +997,7 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
                 g.img[0] = fr + (size_t)s0 * npix;
                 g.rows_t = d_rows_t ? d_rows_t + col0 + s0 : nullptr;
                 g.rows_t16 = d_rows_t16 ? d_rows_t16 + col0 + s0 : nullptr;
+                g.nstore = padded_store(p, col0 + s0, ns, ld_t, d_rows_t ? 32 : 64);
                 // (the group's series were written sub-batch by sub-batch over the whole registration of <= 1024 frames: most of them
                 //  have left the Infinity Cache -- pass B 0.60 ms per 1000 frames here against 0.41 in the plain loop, r04)
                 rc = launch_node_rows(g, p->d_node_k, p->d_compact, cp, st, /*cold_series=*/true);
@@ -1039,6 +1122,8 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
             }
             g.nframes = ns;
             g.rows_t = d_rows_t + col0 + s0;
+            // (no row padding here: measured on 4 cameras, 2.5 M nodes, 1000 frame sets the padded rows are SLOWER,
+            //  2.91-2.97 ms against 2.65-2.70, both at 72 VGPRs -- the one-camera kernel gains 10 % from them)
             if (rc == UPSP_OK) rc = launch_node_rows_multi(g, p->m_node_k, p->m_compact, cp, st);
         }
         if (rc == UPSP_OK && hot_fused) {

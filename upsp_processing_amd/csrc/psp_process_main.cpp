@@ -617,6 +617,7 @@ int run_rank(const std::map<std::string, std::string> &flags, int rank, int worl
     // ---- frame loop (psp_process.cpp:1743-1851): chunks of <= 256 frames, disk -> pinned slot -> device -> unpack -> process ----
     const int64_t ld = series_ld(std::max<int64_t>(nf, 1));
     float *d_rows_t = dev_alloc<float>(N * (size_t)ld);
+    CHECK(upsp_pipeline_set_row_padding(pipe, 1));      // (columns nf .. ld of that allocation are padding)
     const int chunk = 256;
     std::vector<uint8_t *> h_pinned(C), d_packed(C);
     std::vector<uint16_t *> d_frames(C);

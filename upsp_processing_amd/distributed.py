@@ -373,6 +373,8 @@ class TimeSeriesExchange:
             h = C.c_void_p()
             _capi.check(_capi.lib().upsp_exchange_create(comm, shard.nframes, shard.nnodes, self.K, C.byref(h)))
             self._x = h
+            # (columns nframes .. ld of self.out's allocation are padding: the owner's pass B may end its rows on a whole line)
+            _capi.check(_capi.lib().upsp_exchange_set_row_padding(h, 0 if os.environ.get("UPSP_EXCHANGE_ROW_PADDING") == "0" else 1))
             self._destroy = _capi.lib().upsp_exchange_destroy
             self._sends = []
             for k in range(self.K):            # the library cuts the chunks itself: both sides must agree

@@ -377,6 +377,12 @@ class FramePipeline:
         self._rowmap = None if rowmap is None else _dev(rowmap, torch.int32)
         check(lib().upsp_pipeline_set_row_map_async(self._h, _ptr(self._rowmap), _stream()))
 
+    def set_row_padding(self, on=True):
+        """The series buffers passed to process() were allocated as `torch.empty((N, series_ld(F)))[:, :F]`: the columns
+        between the last frame of a call and the next 128-byte boundary of the row are padding the row pass may write
+        (upsp_pipeline_set_row_padding: whole 128-byte lines at the end of every row)."""
+        check(lib().upsp_pipeline_set_row_padding(self._h, 1 if on else 0))
+
     def set_overlap_source(self, src):
         """P3D adjust_solution: src int32 [N] (grids.P3DModel.overlap_source()); None = off."""
         self._src = None if src is None else _dev(src, torch.int32)

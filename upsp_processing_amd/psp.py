@@ -293,6 +293,7 @@ def run_phase1(job, frames_per_cam, nframes_total=None, out_dir=None, chunk=256)
         return finals, series
     rows_t = torch.empty((job.nnodes, engine.series_ld(max(nf, 1))), dtype=torch.float32,
                          device="cuda")[:, :max(nf, 1)]
+    job.pipe.set_row_padding(True)          # (columns nf .. series_ld(nf) of that allocation are padding)
     for c0 in range(0, nf, chunk):
         n = min(chunk, nf - c0)
         batch = []

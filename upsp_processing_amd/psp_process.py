@@ -273,6 +273,7 @@ def run(flags):
     job.set_first_frames(first)
     rows_t = torch.empty((job.nnodes, engine.series_ld(max(nf, 1))), dtype=torch.float32,
                          device="cuda")[:, :max(nf, 1)]
+    job.pipe.set_row_padding(True)          # (columns nf .. series_ld(nf) of that allocation are padding)
     chunk = 256
     # frames go disk -> pinned ring -> device on a copy stream of their own (the reference's read-ahead
     # thread, psp_process.cpp:867-1007): the upload of chunk k + 1 overlaps the processing of chunk k
