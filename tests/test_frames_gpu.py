@@ -815,13 +815,14 @@ def test_row_padding_packed_u16_and_registration(gpu_lib):
 
 
 @pytest.mark.parametrize("sizes,pad", [([1000, 1000, 1000], 0), ([100, 40, 1000, 8], 24), ([36, 1024, 4, 0, 60], 0), ([1000], 24),
-                                       ([37, 50, 3], 0), ([2048, 12], 20), ([8, 8, 8, 8], 0)])
+                                       ([37, 50, 3], 0), ([2048, 12], 20), ([8, 8, 8, 8], 0), ([64] * 40, 0), ([1000] * 8, 0)])
 def test_rows_from_pixel_blocks(gpu_lib, sizes, pad):
     """upsp_rows_from_pixel_blocks: the owner's pass B over blocks as they arrive from the peers of an exchange ([pixel row][frames of
     the source] u16, one buffer per source).  Launches cut at 128-byte lines of the output rows read two blocks each; the rows and the
     accumulators must be what one long series buffer gives: row n = f32 of series[node_k[n]] (0 for a node without a pixel, NaN for a
     skipped one), sums exact.  Also blocks that are no multiple of 4 frames (one launch per block), empty blocks, blocks shorter than
-    a line, blocks longer than one launch, padding columns at the end."""
+    a line, blocks longer than one launch, more windows than one launch takes (16), padding columns at the end; with
+    UPSP_ROWS_WINDOWS=0 / UPSP_ROWS_LINE_CUT=0 (tools/passb_probe.py) the same through one launch per window / per block."""
     import ctypes as C
     import torch
     from upsp_processing_amd import _capi

@@ -1041,6 +1041,122 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+// The owner's pass B of an exchange in ONE launch: the frames of a run lie in several series buffers (one block per source rank),
+// the output rows are cut into windows of <= 1024 columns at 128-byte lines, each window reading the end of one block and the start
+// of the next (rows_from_pixel_blocks).  A workgroup takes ROWS consecutive nodes through ALL windows of the launch: a row piece of
+// 4 KB per store instruction like in node_rows_kernel, the sums of a lane kept in registers across the windows (values < 2^16, <= 4 per
+// lane and window, <= 16 windows: < 2^32; the squares integer-valued doubles -- exact in any order) and reduced once per row instead
+// of once per row and window.  A launch per window costs its ramp and tail 8 times per step at 8 ranks: 0.475 ms against
+// 0.41 for the same bytes in one launch (tools/passb_probe.py).  f32 rows, identity row map, every window a multiple of 4 columns.
+template <int ROWS>
+__global__ void __launch_bounds__(256)
+    node_rows_windows_kernel(RowWindows win, const int32_t *__restrict__ node_k, const uint8_t *__restrict__ skipped, unsigned nnodes,
+                             float *__restrict__ rows_t, long long ld_t, double *__restrict__ sum, double *__restrict__ sumsq)
+{
+    __shared__ int s_k[ROWS], s_sk[ROWS];
+    __shared__ unsigned p_s[ROWS][4];
+    __shared__ double p_ss[ROWS][4];
+    const unsigned n0 = blockIdx.x * (unsigned)ROWS;
+    const int t = threadIdx.x;
+    if (t < ROWS) {
+        const unsigned n = n0 + (unsigned)t;
+        const bool ok = n < nnodes;
+        s_k[t] = ok ? node_k[n] : -1;
+        s_sk[t] = (ok && skipped) ? (int)skipped[n] : 0;
+    }
+    __syncthreads();
+    const int wr = t >> 6, lane = t & 63, f0 = 4 * t;
+    const float qnan = __builtin_nanf("");
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    unsigned acc_s[ROWS];
+    double acc_ss[ROWS];
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) {
+        acc_s[j] = 0u;
+        acc_ss[j] = 0.0;
+    }
+    // the series of every row of the workgroup for a window at once, and those of window wi + 1 requested before the rows of
+    // window wi are converted and stored (they come from HBM: the latency of a window's loads lies behind the stores of the one before)
+    auto series_load = [&](int wi, uint2 *v) {
+        const RowWindow W = win.w[wi];                          // (uniform: kernel arguments)
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) {
+            const int k = s_k[j];
+            v[j] = make_uint2(0u, 0u);
+            if (s_sk[j] == 0 && k >= 0 && f0 < W.nframes)
+                v[j] = f0 < W.nframes_a ? *reinterpret_cast<const uint2 *>(W.a + (size_t)k * W.pitch_a + f0)
+                                        : *reinterpret_cast<const uint2 *>(W.b + (size_t)k * W.pitch_b + (f0 - W.nframes_a));
+        }
+    };
+    uint2 v[ROWS], v_next[ROWS];
+    series_load(0, v_next);
+    for (int wi = 0; wi < win.n; ++wi) {
+        const RowWindow W = win.w[wi];
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) v[j] = v_next[j];
+        if (wi + 1 < win.n) series_load(wi + 1, v_next);
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) {
+            if (n0 + (unsigned)j >= nnodes || f0 >= W.nstore) continue;
+            const int k = s_k[j];
+            const bool sk = s_sk[j] != 0;
+            v4f nv;
+            if (sk || k < 0) {                                  // (uniform) no camera sees the node: NaN; no pixel: 0
+                const float c = sk ? qnan : 0.0f;
+                nv = (v4f){c, c, c, c};
+            } else {
+                const unsigned d[4] = {v[j].x & 0xFFFFu, v[j].x >> 16, v[j].y & 0xFFFFu, v[j].y >> 16};
+                if (f0 < W.nframes) {                           // (nframes is a multiple of 4: the four frames of a lane are valid together)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float x = (float)d[q];
+                        acc_s[j] += d[q];
+                        acc_ss[j] += (double)(x * x);
+                    }
+                    nv = (v4f){(float)d[0], (float)d[1], (float)d[2], (float)d[3]};
+                } else {
+                    nv = (v4f){0.0f, 0.0f, 0.0f, 0.0f};          // padding
+                }
+            }
+            __builtin_nontemporal_store(nv, reinterpret_cast<v4f *>(rows_t + (long long)(n0 + (unsigned)j) * ld_t + W.col + f0));
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) {
+        if (s_sk[j] != 0 || s_k[j] < 0) continue;               // (uniform) constant rows: no sums
+        const unsigned s = group16_sum_u32(acc_s[j]);
+        const double ss = group16_sum(acc_ss[j]);
+        const unsigned ws = (unsigned)__builtin_amdgcn_readlane((int)s, 0) + (unsigned)__builtin_amdgcn_readlane((int)s, 16) +
+                            (unsigned)__builtin_amdgcn_readlane((int)s, 32) + (unsigned)__builtin_amdgcn_readlane((int)s, 48);
+        const double wss = (readlane_f64<0>(ss) + readlane_f64<16>(ss)) + (readlane_f64<32>(ss) + readlane_f64<48>(ss));
+        if (lane == 0) {
+            p_s[j][wr] = ws;
+            p_ss[j][wr] = wss;
+        }
+    }
+    __syncthreads();
+    if (t < ROWS) {
+        const unsigned n = n0 + (unsigned)t;
+        if (n < nnodes) {
+            const bool msk = s_sk[t] != 0;
+            if (msk) {
+                sum[n] = (double)qnan;
+                sumsq[n] = (double)qnan;
+            } else if (s_k[t] >= 0) {
+                unsigned as = 0u;
+                double ass = 0.0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    as += p_s[t][q];
+                    ass += p_ss[t][q];
+                }
+                sum[n] = sum[n] + (double)as;
+                sumsq[n] = sumsq[n] + ass;
+            }
+        }
+    }
+}
+
 // Pass B for several cameras (and weights): sol = sum over the cameras, in camera order, of
 // w_c * f32(pixel_c) exactly as gather_tile_kernel forms it (psp_process.cpp:1813-1819), from one
 // compact buffer per camera; f32 rows only (node_rows_multi_kernel below).  The accumulators add the frames of a lane first
@@ -1827,6 +1943,34 @@ int launch_node_rows(const PipelineGather &g, const int32_t *d_node_k, const uin
 #undef UPSP_NRX
 #undef UPSP_NR_L
 #undef UPSP_NR
+    UPSP_HIP_CHECK(hipGetLastError());
+    return UPSP_OK;
+}
+
+// The windows of rows_from_pixel_blocks in launches of <= kMaxRowWindows windows each (node_rows_windows_kernel).
+int launch_node_rows_windows(const RowWindow *w, int nwin, const int32_t *d_node_k, const uint8_t *d_skipped, size_t nnodes,
+                             float *d_rows_t, int64_t ld, double *d_sum, double *d_sumsq, hipStream_t st)
+{
+    if (nwin < 1 || nnodes == 0 || nnodes >= ((size_t)1 << 31) || (ld & 3) || (reinterpret_cast<size_t>(d_rows_t) & 15))
+        return fail(UPSP_ERR_INVALID, "row pass (windows): bad argument");
+    for (int i = 0; i < nwin; ++i)
+        if (w[i].nframes <= 0 || w[i].nframes > kGroupFramesMax || w[i].nstore < w[i].nframes || w[i].nstore > kGroupFramesMax ||
+            ((w[i].nframes | w[i].nstore | w[i].nframes_a) & 3) || (w[i].col & 3) || w[i].nframes_a < 0 || w[i].nframes_a > w[i].nframes ||
+            (w[i].nframes_a < w[i].nframes && !w[i].b) || (w[i].nframes_a > 0 && !w[i].a))
+            return fail(UPSP_ERR_INVALID, "row pass (windows): bad window");
+    // (measurement switch UPSP_WINDOW_ROWS = 4 / 8 / 16 nodes per workgroup)
+    static const int rows = [] { const char *e = getenv("UPSP_WINDOW_ROWS"); return e ? atoi(e) : 8; }();
+    KTimed kt("node_rows_kernel", st);
+    for (int i0 = 0; i0 < nwin; i0 += kMaxRowWindows) {
+        RowWindows win;
+        win.n = std::min(kMaxRowWindows, nwin - i0);
+        for (int i = 0; i < win.n; ++i) win.w[i] = w[i0 + i];
+#define UPSP_NRW(ROWS)                                                                                                              \
+        hipLaunchKernelGGL(node_rows_windows_kernel<ROWS>, dim3((unsigned)((nnodes + ROWS - 1) / ROWS)), dim3(256), 0, st, win, d_node_k, \
+                           d_skipped, (unsigned)nnodes, d_rows_t, (long long)ld, d_sum, d_sumsq)
+        if (rows == 4) UPSP_NRW(4); else if (rows == 16) UPSP_NRW(16); else UPSP_NRW(8);
+#undef UPSP_NRW
+    }
     UPSP_HIP_CHECK(hipGetLastError());
     return UPSP_OK;
 }

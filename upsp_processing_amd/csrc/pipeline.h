@@ -67,6 +67,20 @@ struct SeriesBlock {
     unsigned cpitch;
     int64_t nframes;
 };
+// one window of the output rows (columns col .. col + nframes): frames [0, nframes_a) from series buffer a, the rest from b
+struct RowWindow {
+    const uint16_t *a, *b;
+    unsigned pitch_a, pitch_b;
+    int nframes, nframes_a, nstore;
+    long long col;
+};
+constexpr int kMaxRowWindows = 16;
+struct RowWindows {
+    int n;
+    RowWindow w[kMaxRowWindows];
+};
+int launch_node_rows_windows(const RowWindow *w, int nwin, const int32_t *d_node_k, const uint8_t *d_skipped, size_t nnodes,
+                             float *d_rows_t, int64_t ld, double *d_sum, double *d_sumsq, hipStream_t st);
 int rows_from_pixel_blocks(const SeriesBlock *blocks, int nblocks, const int32_t *d_node_k, const uint8_t *d_skipped, size_t nnodes,
                            float *d_rows_t, int64_t ld, int64_t pad_to, double *d_sum, double *d_sumsq, hipStream_t st);
 int launch_node_rows_multi(const PipelineGather &g, const int32_t *const *d_node_k, const uint16_t *const *d_compact,

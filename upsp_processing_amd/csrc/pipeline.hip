@@ -705,13 +705,15 @@ int upsp::rows_from_pixel_blocks(const SeriesBlock *blocks, int nblocks, const i
     g.ld_t = ld;
     const int64_t G = group_frames_max();
     const int nb = (int)bl.size();
-    int rc = UPSP_OK, a = 0;
-    for (int64_t c = 0; c < total && rc == UPSP_OK;) {
+    // (measurement switches: UPSP_ROWS_LINE_CUT=0 one launch per block, round 4's form; UPSP_ROWS_WINDOWS=0 one launch per window)
+    static const bool line_cut = [] { const char *e = getenv("UPSP_ROWS_LINE_CUT"); return !(e && *e == '0'); }();
+    static const bool one_launch = [] { const char *e = getenv("UPSP_ROWS_WINDOWS"); return !(e && *e == '0'); }();
+    std::vector<RowWindow> wins;
+    int a = 0;
+    for (int64_t c = 0; c < total;) {
         while (start[a + 1] <= c) ++a;
         const int64_t end_a = start[a + 1];
         int64_t hi = std::min(c + G, end_a);
-        // (measurement switch UPSP_ROWS_LINE_CUT=0: one launch per block, round 4's form)
-        static const bool line_cut = [] { const char *e = getenv("UPSP_ROWS_LINE_CUT"); return !(e && *e == '0'); }();
         if (mult4 && line_cut) {
             // a launch ends on a 128-byte line of the output rows (32 columns) and takes the columns up to there from the next
             // block -- a 4000-byte row piece per source otherwise starts and ends inside a line, which the memory system writes
@@ -720,17 +722,33 @@ int upsp::rows_from_pixel_blocks(const SeriesBlock *blocks, int nblocks, const i
             const int64_t cut = lim == total ? total : lim / 32 * 32;
             if (cut > c) hi = cut;
         }
-        const int64_t n_a = std::min(hi, end_a) - c;
-        g.nframes = (int)(hi - c);
-        g.nstore = hi == total ? (int)std::min<int64_t>(pad_to - c, G) : g.nframes;
-        g.rows_t = d_rows_t + c;
-        const uint16_t *src = bl[a].compact + (c - start[a]);
-        // (the caller's series: received from a peer, or kept from an earlier call -- not the pipeline's own pass A of a moment ago)
-        if (n_a < hi - c)
-            rc = launch_node_rows(g, d_node_k, src, bl[a].cpitch, st, true, false, bl[a + 1].compact, bl[a + 1].cpitch, (int)n_a);
-        else
-            rc = launch_node_rows(g, d_node_k, src, bl[a].cpitch, st, true);
+        RowWindow w;
+        w.nframes = (int)(hi - c);
+        w.nframes_a = (int)(std::min(hi, end_a) - c);
+        w.nstore = hi == total ? (int)std::min<int64_t>(pad_to - c, G) : w.nframes;
+        w.col = c;
+        w.a = bl[a].compact + (c - start[a]);
+        w.pitch_a = bl[a].cpitch;
+        w.b = w.nframes_a < w.nframes ? bl[a + 1].compact : nullptr;
+        w.pitch_b = w.b ? bl[a + 1].cpitch : 0;
+        wins.push_back(w);
         c = hi;
+    }
+    // several windows: one launch takes a workgroup's rows through all of them (frames.hip: node_rows_windows_kernel)
+    bool together = one_launch && mult4 && wins.size() > 1 && (ld % 4) == 0 && (reinterpret_cast<size_t>(d_rows_t) & 15) == 0;
+    for (const RowWindow &w : wins) together = together && (w.nstore % 4) == 0;
+    if (together) return launch_node_rows_windows(wins.data(), (int)wins.size(), d_node_k, d_skipped, nnodes, d_rows_t, ld, d_sum, d_sumsq, st);
+    int rc = UPSP_OK;
+    for (size_t i = 0; i < wins.size() && rc == UPSP_OK; ++i) {
+        const RowWindow &w = wins[i];
+        g.nframes = w.nframes;
+        g.nstore = w.nstore;
+        g.rows_t = d_rows_t + w.col;
+        // (the caller's series: received from a peer, or kept from an earlier call -- not the pipeline's own pass A of a moment ago)
+        if (w.b)
+            rc = launch_node_rows(g, d_node_k, w.a, w.pitch_a, st, true, false, w.b, w.pitch_b, w.nframes_a);
+        else
+            rc = launch_node_rows(g, d_node_k, w.a, w.pitch_a, st, true);
     }
     return rc;
 }
