@@ -269,9 +269,10 @@ int upsp_pipeline_set_hot_enable(upsp_pipeline *p, int enable);
  * cast, :167-355, are independent in the reference too):
  *   upsp_pipeline_set_active_hint(p, d_candidates, s2)   map of the candidate pixels (kept across projection changes
  *                                                         until cleared with NULL)
- *   upsp_pipeline_prescan(p, d_frames, n, s2)             pass A of n <= 1024 frames on stream s2
+ *   upsp_pipeline_prescan(p, d_frames, n, s2)             pass A of n <= 1024 frames on stream s2 and their hot-pixel
+ *                                                         repair (in place, like the process call does it)
  *   upsp_pipeline_set_projection_async(...) ; upsp_pipeline_process(p, &d_frames, n, ...)   -- after s2's work
- *                                                         (caller's event): pass B + hot-pixel fix-up only
+ *                                                         (caller's event): pass B only
  * A node whose final pixel is missing from the candidate set is served from the frames directly (correct, slow).
  * The map arrays exist twice and every call with a candidate set builds into the pair the launches already queued do not
  * read: the call for the NEXT frame batch may be issued (on another stream) while pass B / the fix-up of the current one are

@@ -641,6 +641,32 @@ def test_stale_prescan_is_dropped(gpu_lib):
     assert torch.equal(rt.view(torch.int32), want)
 
 
+def test_dropped_prescan_with_hot_pixels(gpu_lib, oracle):
+    """A prescan repairs its frames (fix_hot_pixels, in place) and leaves the hot-pixel counters clean: when the next process call
+    takes OTHER frames -- the prescan is dropped -- those are counted, repaired and projected as if no prescan had happened."""
+    import torch
+    from upsp_processing_amd import engine, synthetic as syn
+    H, W, n, F = 64, 130, 2500, 70
+    rng = np.random.default_rng(11)
+    fr1 = syn.synth_frames_numpy(F, H, W, seed=90, hot=True)
+    fr2 = syn.synth_frames_numpy(F, H, W, seed=91, hot=True)
+    for fr in (fr1, fr2):
+        fr[::3, 7, 9] = 4095                       # a hot pixel several nodes read, in every third frame
+    pix = rng.integers(-1, H * W, size=n).astype(np.int32)
+    pix[:30] = 7 * W + 9
+    pipe = engine.FramePipeline(1, W, H, n)
+    pipe.set_projection(0, pix)
+    d1, d2 = torch.as_tensor(fr1.copy()).cuda(), torch.as_tensor(fr2.copy()).cuda()
+    pipe.prescan(d1)
+    assert np.array_equal(d1.cpu().numpy(), np.stack([oracle.fix_hot_pixels(f)[0] for f in fr1]))
+    rt = torch.empty((n, F), dtype=torch.float32, device="cuda")
+    pipe.process(d2, 0, rows_t=rt, want_rows=False)
+    want_frames = np.stack([oracle.fix_hot_pixels(f)[0] for f in fr2])
+    assert np.array_equal(d2.cpu().numpy(), want_frames)
+    want = np.where(pix[:, None] >= 0, want_frames.reshape(F, -1)[:, np.maximum(pix, 0)].T.astype(np.float32), np.float32(np.nan))
+    assert np.array_equal(rt.cpu().numpy().view(np.int32), want.view(np.int32))
+
+
 def test_candidate_pixels_superset(gpu_lib):
     """upsp_projection_candidate_pixels: every pixel of the projection equals the node's candidate pixel."""
     import torch

@@ -587,13 +587,12 @@ __global__ void __launch_bounds__(WAVES * 64)
 // single fused pass that pushes the pixels straight to the nodes' rows was built first: its node work piles
 // up on the 10 % of the tiles that cover the model, and reads and writes interleave in HBM -- level with
 // scan + gather at 1 Mpix.  DESIGN.md section 4.)
-//   * hot pixels: pass A cannot know a frame's count before the whole frame has gone by, so the passes
-//     project the pixels as they are; hot_repair_kernel then repairs the (rare) frames with
-//     1..max_hot hot pixels in place exactly like fix_frame and lists the replaced pixels, and
-//     hot_patch_nodes_kernel re-projects them (every node looks its pixel up in the call's dense change list, only in
-//     calls that replaced something): series entry and accumulators of every node on such a pixel.
-//     All values are integers < 2^16 (squares rounded to float like the gather's), their double sums
-//     are exact, so "add new - old" gives the same bits as summing the repaired values.
+//   * hot pixels: pass A cannot know a frame's count before the whole frame has gone by, so it stores
+//     the pixels as they are and counts; between the passes hot_repair_kernel repairs the (rare) frames
+//     with 1..max_hot hot pixels in place exactly like fix_frame and lists the replaced pixels, and
+//     hot_patch_compact_kernel writes them into the compact series: pass B reads repaired values.
+//     (Rounds 2-4 repaired behind pass B and corrected the rows and accumulators of the nodes on the
+//     replaced pixels; the several-camera schedule still does, launch_hot_fixup_multi.)
 constexpr int kFusedPix = 128;     // pixels per tile
 constexpr int kFusedPitch = 65;    // dwords per LDS row: 64 (128 px) + 1 pad
 
@@ -1428,8 +1427,8 @@ __device__ __forceinline__ void
     }
     nch[f] = m;
     if (m) {
-        // clist (optional): the same records once more, DENSE, in whatever order the frames get here (hot_patch_nodes_kernel
-        // looks every node's pixel up in them; a (pixel, frame) pair changes at most once, so the order does not matter)
+        // clist (optional): the same records once more, DENSE, in whatever order the frames get here (a (pixel, frame) pair
+        // changes at most once, so the order does not matter)
         const unsigned base = atomicAdd(ntotal, m);
         if (clist)
             for (unsigned j = 0; j < m; ++j) clist[base + j] = changes[f * (size_t)max_hot + j];
@@ -1447,57 +1446,6 @@ __global__ void __launch_bounds__(64)
     if (f == 0 && ntotal_next) *ntotal_next = 0u;
     if (f >= (size_t)nframes) return;
     hot_repair_frame(f, frames, npix, rows, cols, min_change, max_hot, count, pos, ntotal, nch, changes, clist);
-}
-
-// Re-projection of the replaced pixels: every node reading one gets its series entry and its accumulators corrected.
-// One lane per NODE; a workgroup loads the call's dense change list (<= 512 records at a time) into a small hash table in
-// LDS keyed by the pixel, and every node looks its own pixel up -- one launch where round 2-3 had three (lists init, lists
-// build over all nodes with an atomic each, patch per change).  A node's accumulators are touched by its own lane only;
-// every term is an integer-valued double far below 2^53, so the order of a pixel's records does not matter.
-constexpr int kHotHashSlots = 1024, kHotHashChunk = 512;
-__global__ void __launch_bounds__(256)
-    hot_patch_nodes_kernel(const unsigned *__restrict__ ntotal, const uint4 *__restrict__ clist,
-                           const int32_t *__restrict__ pix, unsigned nnodes, const uint8_t *__restrict__ skipped,
-                           const int32_t *__restrict__ rowmap, float *__restrict__ rows_t, uint16_t *__restrict__ rows_t16,
-                           long long ld_t, double *__restrict__ sum, double *__restrict__ sumsq)
-{
-    const unsigned nt = *ntotal;
-    if (nt == 0u) return;                      // (uniform) nearly every call
-    __shared__ int hhead[kHotHashSlots];
-    __shared__ int hnext[kHotHashChunk];
-    __shared__ unsigned hpix[kHotHashChunk];
-    const unsigned n = blockIdx.x * blockDim.x + threadIdx.x;
-    const int32_t p = n < nnodes ? pix[n] : -1;
-    const bool mine = p >= 0 && !(skipped && skipped[n]);       // skipped: stays NaN
-    const long long row = !mine ? -1 : (rowmap ? (long long)rowmap[n] : (long long)n);
-    double ds = 0.0, dss = 0.0;
-    for (unsigned base = 0; base < nt; base += kHotHashChunk) {
-        const unsigned cnt = min((unsigned)kHotHashChunk, nt - base);
-        for (int i = threadIdx.x; i < kHotHashSlots; i += 256) hhead[i] = -1;
-        __syncthreads();
-        for (unsigned i = threadIdx.x; i < cnt; i += 256) {
-            const unsigned q = clist[base + i].y;
-            hpix[i] = q;
-            hnext[i] = atomicExch(&hhead[(q * 2654435761u) >> 22], (int)i);
-        }
-        __syncthreads();
-        if (mine)
-            for (int i = hhead[((unsigned)p * 2654435761u) >> 22]; i >= 0; i = hnext[i]) {
-                if (hpix[i] != (unsigned)p) continue;
-                const uint4 ch = clist[base + i];
-                const float xo = (float)ch.z, xn = (float)ch.w;
-                ds += (double)xn - (double)xo;
-                dss += (double)(xn * xn) - (double)(xo * xo);
-                if (row < 0) continue;
-                if (rows_t) rows_t[row * ld_t + (long long)ch.x] = xn;
-                else rows_t16[row * ld_t + (long long)ch.x] = (uint16_t)ch.w;
-            }
-        __syncthreads();
-    }
-    if (mine && (ds != 0.0 || dss != 0.0)) {
-        sum[n] += ds;
-        sumsq[n] += dss;
-    }
 }
 
 // The replaced pixels written into the compact [active pixel][frame] series (pass A stored them as they were): what
@@ -1866,7 +1814,7 @@ int group_frames_max() { return kGroupFramesMax; }
 
 // Pass A for `nframes` frames (any number: one workgroup row per 64-frame group) into columns
 // [col, col + nframes) of the compact buffer (row pitch cpitch u16 >= col + nframes rounded up to 64).
-// d_count: one counter per frame (zero on entry; launch_hot_fixup leaves them zero), d_pos: 64
+// d_count: one counter per frame (zero on entry; the repair launches leave them zero), d_pos: 64
 // positions per frame.
 int launch_scan_compact(uint16_t *d_frames, size_t npix, int nframes, bool hot, int thresh, int max_hot,
                         const uint8_t *d_flag, const unsigned *d_off, const unsigned *d_order, uint16_t *d_compact,
@@ -2038,28 +1986,6 @@ size_t hot_changes_words(int nframes, int max_hot)
     // counters (4) + changes per frame (rounded to 4) + the per-frame record slots + the same records once more, dense
     return 4 + (((size_t)nframes + 3) & ~(size_t)3) + 8 * (size_t)nframes * (size_t)std::max(max_hot, 1);
 }
-int launch_hot_fixup(const PipelineGather &g, uint16_t *d_frames, int nframes, int rows, int cols,
-                     int min_change, int max_hot, unsigned *d_count, const unsigned *d_pos,
-                     unsigned *d_changes, int *parity, hipStream_t st)
-{
-    if (nframes <= 0) return UPSP_OK;
-    KTimed kt("hot_fixup_kernels", st);
-    unsigned *nch = d_changes + 4;
-    uint4 *list = reinterpret_cast<uint4 *>(d_changes + 4 + (((size_t)nframes + 3) & ~(size_t)3));
-    uint4 *clist = list + (size_t)nframes * (size_t)std::max(max_hot, 1);
-    // words 0 / 1 of the buffer: the change counter of this call / of the next one (both zero after the allocation)
-    unsigned *ntotal = d_changes + (*parity & 1), *ntotal_next = d_changes + ((*parity & 1) ^ 1);
-    *parity ^= 1;
-    hipLaunchKernelGGL(hot_repair_kernel, dim3((unsigned)((nframes + 63) / 64)), dim3(64), 0, st, d_frames, g.npix,
-                       nframes, rows, cols, min_change, max_hot, d_count, d_pos, ntotal, nch, list, clist, ntotal_next);
-    if (max_hot > 0)
-        hipLaunchKernelGGL(hot_patch_nodes_kernel, dim3((unsigned)((g.nnodes + 255) / 256)), dim3(256), 0, st,
-                           (const unsigned *)ntotal, (const uint4 *)clist, g.pix[0], (unsigned)g.nnodes, g.skipped, g.rowmap,
-                           g.rows_t, g.rows_t16, (long long)g.ld_t, g.sum, g.sumsq);
-    UPSP_HIP_CHECK(hipGetLastError());
-    return UPSP_OK;
-}
-
 // Hot-pixel fix-up for several cameras after a streamed pass over UNREPAIRED frames (pass A counted the hot
 // pixels per camera and frame): repair the frames of every camera, then re-project the replaced pixels.
 // d_count / d_pos: per camera c at c * nframes (counters) and c * nframes * 64 (positions); d_changes: per camera
@@ -2075,7 +2001,8 @@ int launch_hot_repair_compact(uint16_t *d_frames, size_t npix, int nframes, int 
     KTimed kt("hot_fixup_kernels", st);
     unsigned *nch = d_changes + 4;
     uint4 *list = reinterpret_cast<uint4 *>(d_changes + 4 + (((size_t)nframes + 3) & ~(size_t)3));
-    unsigned *ntotal = d_changes + (*parity & 1), *ntotal_next = d_changes + ((*parity & 1) ^ 1);     // (see launch_hot_fixup)
+    // words 0 / 1 of the buffer: the change counter of this call / of the next one (both zero after the allocation)
+    unsigned *ntotal = d_changes + (*parity & 1), *ntotal_next = d_changes + ((*parity & 1) ^ 1);
     *parity ^= 1;
     hipLaunchKernelGGL(hot_repair_kernel, dim3((unsigned)((nframes + 63) / 64)), dim3(64), 0, st, d_frames, npix, nframes,
                        rows, cols, min_change, max_hot, d_count, d_pos, ntotal, nch, list, (uint4 *)nullptr, ntotal_next);

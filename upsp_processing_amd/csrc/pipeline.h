@@ -85,12 +85,9 @@ int rows_from_pixel_blocks(const SeriesBlock *blocks, int nblocks, const int32_t
                            float *d_rows_t, int64_t ld, int64_t pad_to, double *d_sum, double *d_sumsq, hipStream_t st);
 int launch_node_rows_multi(const PipelineGather &g, const int32_t *const *d_node_k, const uint16_t *const *d_compact,
                            unsigned cpitch, hipStream_t st);
-size_t hot_changes_words(int nframes, int max_hot);   // size of d_changes for launch_hot_fixup
+size_t hot_changes_words(int nframes, int max_hot);   // size of d_changes for the repair launches
 // parity: which of the buffer's two change counters this call uses (flipped by the call; the other one is zeroed for the next call;
 // both zero after the allocation)
-int launch_hot_fixup(const PipelineGather &g, uint16_t *d_frames, int nframes, int rows, int cols,
-                     int min_change, int max_hot, unsigned *d_count, const unsigned *d_pos,
-                     unsigned *d_changes, int *parity, hipStream_t st);
 int launch_hot_repair_compact(uint16_t *d_frames, size_t npix, int nframes, int rows, int cols, int min_change, int max_hot,
                               unsigned *d_count, const unsigned *d_pos, unsigned *d_changes, int *parity, const uint8_t *d_flag,
                               const unsigned *d_tile_off, uint16_t *d_compact, unsigned cpitch, hipStream_t st);
