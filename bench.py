@@ -670,6 +670,12 @@ def multi_camera_main(a):
     ev_log, last = [], {}
     torch.cuda.synchronize()
     side = None if a.serial else torch.cuda.Stream(priority=-1)
+    # The builds of the cameras do not depend on each other (create_projection_mat per camera, psp_process.cpp:1586-1660): each on
+    # a high-priority stream and a BVH handle of its own (engine.BVH.share: same tree, own query scratch) -- four latency-bound
+    # chains side by side instead of one after the other.  UPSP_BENCH_CONCURRENT_BUILDS=0: one stream, one handle (round 4).
+    concurrent = side is not None and os.environ.get("UPSP_BENCH_CONCURRENT_BUILDS", "1") != "0"
+    bvhs = [bvh] + [bvh.share() for _ in cams[1:]] if concurrent else [bvh] * C
+    sides = [side] + [torch.cuda.Stream(priority=-1) for _ in cams[1:]] if concurrent else [side] * C
 
     def step(record):
         for r in restorers:                 # new frames arrive: the repaired hot pixels are put back
@@ -678,10 +684,18 @@ def multi_camera_main(a):
         e[0].record()
         main = torch.cuda.current_stream()
         if side is not None:
-            # the builds of a step read the model and the cameras only: on a high-priority stream of their own they run beside the
+            # the builds of a step read the model and the cameras only: on high-priority streams of their own they run beside the
             # PREVIOUS step's frame loop (see main(): no wait in front of them; the consumer side is ordered below)
+            per_cam = []
+            for c, cam in enumerate(cams):
+                with torch.cuda.stream(sides[c]):
+                    per_cam.append(engine.build_projection(bvhs[c], cam, d_nodes, d_nrm, d_tn, 70.0, counts=False)["pix"])
+            for c in range(1, C):
+                if sides[c] is not side:
+                    side.wait_stream(sides[c])
+                    per_cam[c].record_stream(side)
             with torch.cuda.stream(side):
-                pix = torch.stack([engine.build_projection(bvh, cam, d_nodes, d_nrm, d_tn, 70.0, counts=False)["pix"] for cam in cams])
+                pix = torch.stack(per_cam)
                 w = engine.projection_weights(pix, d_nodes, d_nrm, centers, "average_view")  # adjust_projection_for_weights
             main.wait_stream(side)
             pix.record_stream(main)
@@ -710,7 +724,8 @@ def multi_camera_main(a):
             step(True)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-    bvh.check()
+    for b in set(bvhs):
+        b.check()
     _capi.timing_enable(True)
     for _ in range(a.steps):
         step(False)
@@ -752,8 +767,8 @@ def multi_camera_main(a):
                    "cameras": C, "frames_per_camera": F, "nodes": N, "triangles": int(tris.shape[0]),
                    "nodes_seen": seen, "cameras_per_seen_node": seen_by, "active_pixels_per_camera": active,
                    "parallelism": "one GPU", "schedule": ("per camera: projection build; pass A per camera; one whole-row pass B over all cameras" if a.serial else
-                                "the projection builds of a step on a high-priority stream of their own (beside the previous step's frame "
-                                "loop); pass A per camera; one whole-row pass B over all cameras")},
+                                ("the projection builds of a step on high-priority streams of their own, %s (beside the previous step's frame "
+                                 "loop); pass A per camera; one whole-row pass B over all cameras") % ("the cameras side by side" if concurrent else "camera after camera"))},
         "breakdown_ms": {"projection_builds_and_weights": float(np.mean([e[0].elapsed_time(e[1]) for e in ev_log])),
                          "frame_loop_and_finals": float(np.mean([e[1].elapsed_time(e[2]) for e in ev_log]))},
         "roofline": {"kernel": dom, "bound": "hbm", "achieved": dk["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

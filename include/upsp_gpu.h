@@ -55,6 +55,10 @@ typedef struct upsp_bvh upsp_bvh;
  * uploaded to the current device. */
 int upsp_bvh_create(const float *h_tris9, size_t ntris, upsp_bvh **out);
 void upsp_bvh_destroy(upsp_bvh *bvh);
+/* A second handle on the same tree (and on the adjacency upsp_bvh_set_tri_nodes has set by then) with query scratch of its own:
+ * queries on the two handles may run at the same time on different streams -- create_projection_mat of the cameras of one model
+ * (cpp/exec/psp_process.cpp:1586-1660) does not depend on the other cameras.  The owner must outlive its shares. */
+int upsp_bvh_share(const upsp_bvh *src, upsp_bvh **out);
 
 typedef struct upsp_bvh_info {
     uint64_t ntris;

@@ -252,3 +252,52 @@ def test_projection_full_size_vs_oracle(gpu_lib, oracle, model):
         assert g["nrays"] == o["nrays"]
         assert np.array_equal(g["nodecount"].cpu().numpy(), o["nodecount"])
     bvh.close()
+
+
+def test_shared_tree_builds_side_by_side(gpu_lib):
+    """engine.BVH.share (upsp_bvh_share): handles on one tree with query scratch of their own.  The projection builds of four
+    cameras queued at the same time on four streams, one handle each, give the entries and uv of the builds run one after the
+    other on the owner; a batch query on a share gives the owner's hits; the adjacency cannot be set on a share; the shares
+    outlive nothing (closing them leaves the owner usable)."""
+    import torch
+    from upsp_processing_amd import _capi, engine, synthetic as syn
+    v, t = syn.tunnel_model(100, 240, 40, 80)
+    s9, tn = syn.soup(v, t)
+    nrm = syn.node_normals(v, t)
+    size = 512
+    cams = []
+    for c in range(4):
+        cd = syn.pinhole_camera(size, size, center=(0, 0, 20), half_extent=6.0, azimuth_deg=90.0 * c)
+        cams.append(_capi.make_camera(cd["K"], cd["dist"], cd["R"], cd["t"], size, size))
+    bvh = engine.BVH(s9)
+    d_v, d_n, d_tn = [torch.as_tensor(x).cuda() for x in (v, nrm, tn)]
+    bvh.set_tri_nodes(d_tn, v.shape[0])
+    want = [engine.build_projection(bvh, cam, d_v, d_n, d_tn, 70.0, counts=False) for cam in cams]
+    torch.cuda.synchronize()
+    handles = [bvh] + [bvh.share() for _ in cams[1:]]
+    streams = [torch.cuda.Stream() for _ in cams]
+    for rep in range(3):                       # (repeated: the scratch of every handle is reused)
+        got = []
+        for h, cam, st in zip(handles, cams, streams):
+            with torch.cuda.stream(st):
+                got.append(engine.build_projection(h, cam, d_v, d_n, d_tn, 70.0, counts=False))
+        torch.cuda.synchronize()
+        for g, w in zip(got, want):
+            assert (w["pix"] >= 0).sum() > 1000
+            assert torch.equal(g["pix"], w["pix"]) and torch.equal(g["uv"].view(torch.int32), w["uv"].view(torch.int32))
+    for h in handles:
+        h.check()
+    rng = np.random.default_rng(2)
+    org = rng.normal(size=(5000, 3)).astype(np.float32) * 8
+    dirs = -org + rng.normal(size=(5000, 3)).astype(np.float32)
+    a = bvh.intersect(org, dirs, want=("hit", "t", "prim"))
+    b = handles[2].intersect(org, dirs, want=("hit", "t", "prim"))
+    hit = a["hit"] != 0
+    assert int(hit.sum()) > 100 and torch.equal(a["hit"], b["hit"])
+    assert torch.equal(a["prim"][hit], b["prim"][hit]) and torch.equal(a["t"][hit].view(torch.int32), b["t"][hit].view(torch.int32))
+    with pytest.raises(Exception):
+        handles[1].set_tri_nodes(d_tn, v.shape[0])
+    for h in handles[1:]:
+        h.close()
+    again = engine.build_projection(bvh, cams[0], d_v, d_n, d_tn, 70.0, counts=False)
+    assert torch.equal(again["pix"], want[0]["pix"])

@@ -56,6 +56,7 @@ SIGNATURES = {
     "upsp_version": (_i, []),
     "upsp_bvh_create": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "upsp_bvh_destroy": (None, [_vp]),
+    "upsp_bvh_share": (_i, [_vp, C.POINTER(_vp)]),
     "upsp_bvh_get_info": (_i, [_vp, C.POINTER(BvhInfo)]),
     "upsp_bvh_intersect": (_i, [_vp, _vp, _i, _vp, _sz, C.POINTER(Hits), _vp]),
     "upsp_bvh_intersect_host": (_i, [_vp, _vp, _i, _vp, _sz, C.POINTER(Hits)]),

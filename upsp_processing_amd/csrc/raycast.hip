@@ -2507,19 +2507,63 @@ int upsp_bvh_create(const float *h_tris9, size_t ntris, upsp_bvh **out)
     return UPSP_OK;
 }
 
+// A second handle on the same tree: the immutable arrays (nodes, wide records, triangles, leaf paths, the node -> triangle
+// adjacency as it is now) are shared, the scratch of the queries (work words, retry / witness / hand-off lists, stacks) is its
+// own -- so queries on the two handles may run at the same time on different streams (the projection builds of several cameras
+// of one model, cpp/exec/psp_process.cpp:1586-1660, are independent of each other).
+int upsp_bvh_share(const upsp_bvh *src, upsp_bvh **out)
+{
+    if (!src || !out) return fail(UPSP_ERR_INVALID, "null argument");
+    *out = nullptr;
+    upsp_bvh *b = new upsp_bvh();
+    b->shared_from = src->shared_from ? src->shared_from : src;
+    b->device = src->device;
+    b->d_nodes = src->d_nodes;
+    b->d_wide = src->d_wide;
+    b->wide_root = src->wide_root;
+    b->n_wide = src->n_wide;
+    b->wide_depth = src->wide_depth;
+    b->d_tris = src->d_tris;
+    b->d_slot_path = src->d_slot_path;
+    b->d_path_ref = src->d_path_ref;
+    b->d_adj_off = src->d_adj_off;
+    b->d_adj_slot = src->d_adj_slot;
+    b->adj_src = src->adj_src;
+    b->adj_nnodes = src->adj_nnodes;
+    b->prim_slot = src->prim_slot;
+    b->root_ref = src->root_ref;
+    b->top_nodes = src->top_nodes;
+    for (int a = 0; a < 3; ++a) {
+        b->root_min[a] = src->root_min[a];
+        b->root_max[a] = src->root_max[a];
+    }
+    b->info = src->info;
+    hipError_t e = hipMalloc(&b->d_work, (kWorkWords + 4) * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemset(b->d_work, 0, (kWorkWords + 4) * sizeof(unsigned));
+    if (e != hipSuccess) {
+        upsp_bvh_destroy(b);
+        return fail(UPSP_ERR_HIP, std::string("BVH share: ") + hipGetErrorString(e));
+    }
+    b->d_err = b->d_work + kWorkWords;
+    *out = b;
+    return UPSP_OK;
+}
+
 void upsp_bvh_destroy(upsp_bvh *b)
 {
     if (!b) return;
-    if (b->d_nodes) (void)hipFree(b->d_nodes);
-    if (b->d_wide) (void)hipFree(b->d_wide);
-    if (b->d_tris) (void)hipFree(b->d_tris);
+    if (!b->shared_from) {
+        if (b->d_nodes) (void)hipFree(b->d_nodes);
+        if (b->d_wide) (void)hipFree(b->d_wide);
+        if (b->d_tris) (void)hipFree(b->d_tris);
+        if (b->d_adj_off) (void)hipFree(b->d_adj_off);
+        if (b->d_adj_slot) (void)hipFree(b->d_adj_slot);
+        if (b->d_slot_path) (void)hipFree(b->d_slot_path);
+        if (b->d_path_ref) (void)hipFree(b->d_path_ref);
+    }
     if (b->d_work) (void)hipFree(b->d_work);
     if (b->d_retry_nodes) (void)hipFree(b->d_retry_nodes);
     if (b->d_retry_mask) (void)hipFree(b->d_retry_mask);
-    if (b->d_adj_off) (void)hipFree(b->d_adj_off);
-    if (b->d_adj_slot) (void)hipFree(b->d_adj_slot);
-    if (b->d_slot_path) (void)hipFree(b->d_slot_path);
-    if (b->d_path_ref) (void)hipFree(b->d_path_ref);
     if (b->d_witness) (void)hipFree(b->d_witness);
     if (b->d_todo_mask) (void)hipFree(b->d_todo_mask);
     if (b->d_todo_rays) (void)hipFree(b->d_todo_rays);
@@ -2542,6 +2586,7 @@ int upsp_bvh_get_info(const upsp_bvh *b, upsp_bvh_info *info)
 int upsp_bvh_set_tri_nodes(upsp_bvh *b, const int32_t *d_tri_nodes, size_t nnodes, void *stream)
 {
     if (!b) return fail(UPSP_ERR_INVALID, "null BVH");
+    if (b->shared_from) return fail(UPSP_ERR_INVALID, "upsp_bvh_set_tri_nodes: set the adjacency on the owner of the tree, then share");
     if (b->d_adj_off) (void)hipFree(b->d_adj_off);
     if (b->d_adj_slot) (void)hipFree(b->d_adj_slot);
     b->d_adj_off = b->d_adj_slot = nullptr;

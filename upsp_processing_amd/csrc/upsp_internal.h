@@ -119,6 +119,7 @@ struct upsp_bvh {
     int stats_on = 0;
     uint64_t last_stats[3] = {0, 0, 0};
     uint64_t last_primary = 0, last_retry_nodes = 0;
+    const upsp_bvh *shared_from = nullptr;   // upsp_bvh_share: the tree / adjacency arrays belong to that handle
 };
 
 #endif

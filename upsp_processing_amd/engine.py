@@ -44,6 +44,16 @@ class BVH:
         self._destroy = lib().upsp_bvh_destroy      # bound now: module globals vanish at exit
         self.ntris = tris9.size // 9
 
+    def share(self):
+        """A second handle on the same tree (and the adjacency set so far) with query scratch of its own: builds / batches on the two
+        may run at the same time on different streams (upsp_bvh_share).  Keeps this object alive."""
+        other = BVH.__new__(BVH)
+        h = C.c_void_p()
+        check(lib().upsp_bvh_share(self._h, C.byref(h)))
+        other._h, other._destroy, other.ntris, other._owner = h, self._destroy, self.ntris, self
+        other._tri_nodes = getattr(self, "_tri_nodes", None)
+        return other
+
     def close(self):
         if getattr(self, "_h", None):
             self._destroy(self._h)
