@@ -1336,7 +1336,7 @@ def main():
     if overlap:
         roof["note"] = ("default schedule: the ray casting of the projection builds has a high-priority stream of its own and runs beside "
                         "pass A (scan_compact_kernel) and pass B (node_rows_kernel), which share the memory system with it; alone (--serial) "
-                        "pass A takes 0.40 ms = 0.66 of peak and pass B 0.41 ms = 0.61, and the step 13-20 % longer")
+                        "pass A takes 0.40 ms = 0.66 of peak and pass B 0.36 ms = 0.70, and the step 25-30 % longer")
 
     sched = ("projection build, then hot-pixel scan + gather kernels per 64-frame sub-batch"
              if (a.two_kernel or a.registration) else
