@@ -87,6 +87,13 @@ while time.time() < t_end:
         rowmap = np.full(n, -1, np.int32); rowmap[keep] = np.arange(keep.size)
         pipe.set_row_map(torch.as_tensor(rowmap).cuda())
     ld = F + int(rng.integers(0, 9))
+    # row padding (upsp_pipeline_set_row_padding): a pitch of whole 128-byte lines with room behind the frames, declared to the
+    # pipeline; the row pass may then write up to the next line boundary, nothing beyond
+    pad_on = rng.random() < 0.5
+    if pad_on:
+        pipe.set_row_padding(True)
+        if rng.random() < 0.7:
+            ld = (F + 63) // 64 * 64 + 64 * int(rng.integers(0, 2))
     if u16:
         buf = torch.full((max(keep.size, 1), ld), 7, dtype=torch.int32, device="cuda").to(torch.uint16)
     else:
@@ -99,15 +106,17 @@ while time.time() < t_end:
             if (a, b) != (0, F):               # frames are repaired in the slices: copy them back for the comparison
                 pass
     tag = "seed %d: %dx%d n=%d F=%d cams=%d fused=%d compact_mb=%d packed=%d u16=%d cuts=%s" % (
-        seed, H, W, n, F, ncams, fused, compact_mb, packed, u16, cuts)
+        seed, H, W, n, F, ncams, fused, compact_mb, packed, u16, cuts) + (" padded ld=%d" % ld if pad_on else "")
     got = buf[:keep.size, :F].cpu().numpy().astype(np.float32)
     want = rows_o.T[keep]
     ok = np.array_equal(got.view(np.int32), want.view(np.int32)) if not u16 else np.array_equal(got, want)
     if not ok:
         print("SERIES MISMATCH", tag); sys.exit(1)
-    pad = buf[:keep.size, F:].cpu().numpy()
+    per_line = 64 if u16 else 32
+    stop = min(ld, (F + per_line - 1) // per_line * per_line) if (pad_on and ld % per_line == 0) else F
+    pad = buf[:keep.size, stop:].cpu().numpy()
     if pad.size and not (pad == (7 if u16 else -7.0)).all():
-        print("WROTE PAST THE FRAMES", tag); sys.exit(1)
+        print("WROTE PAST THE FRAMES", tag, "padding", pad_on, "ld", ld); sys.exit(1)
     if cuts == [0, F]:
         for c in range(ncams):
             if not np.array_equal(d[c].cpu().numpy(), fixed_o[c]):

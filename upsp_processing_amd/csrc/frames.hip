@@ -590,7 +590,7 @@ __global__ void __launch_bounds__(WAVES * 64)
 //   * hot pixels: pass A cannot know a frame's count before the whole frame has gone by, so it stores
 //     the pixels as they are and counts; between the passes hot_repair_kernel repairs the (rare) frames
 //     with 1..max_hot hot pixels in place exactly like fix_frame and lists the replaced pixels, and
-//     hot_patch_compact_kernel writes them into the compact series: pass B reads repaired values.
+//     writes them into the compact series as well: pass B reads repaired values.
 //     (Rounds 2-4 repaired behind pass B and corrected the rows and accumulators of the nodes on the
 //     replaced pixels; the several-camera schedule still does, launch_hot_fixup_multi.)
 constexpr int kFusedPix = 128;     // pixels per tile
@@ -1440,33 +1440,25 @@ __global__ void __launch_bounds__(64)
     hot_repair_kernel(uint16_t *frames, size_t npix, int nframes, int rows, int cols, int min_change,
                       int max_hot, unsigned *__restrict__ count, const unsigned *__restrict__ pos,
                       unsigned *__restrict__ ntotal, unsigned *__restrict__ nch, uint4 *__restrict__ changes,
-                      uint4 *__restrict__ clist, unsigned *__restrict__ ntotal_next)
+                      uint4 *__restrict__ clist, unsigned *__restrict__ ntotal_next, const uint8_t *__restrict__ flag = nullptr,
+                      const unsigned *__restrict__ tile_off = nullptr, uint16_t *__restrict__ compact = nullptr, unsigned cpitch = 0)
 {
     const size_t f = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (f == 0 && ntotal_next) *ntotal_next = 0u;
     if (f >= (size_t)nframes) return;
     hot_repair_frame(f, frames, npix, rows, cols, min_change, max_hot, count, pos, ntotal, nch, changes, clist);
+    // compact (optional): the replaced pixels go into the compact [active pixel][frame] series as well (pass A stored them as they
+    // were; column = the frame's index in this launch) -- by the lane that repaired the frame, no launch of its own
+    if (compact) {
+        const unsigned m = nch[f];
+        for (unsigned j = 0; j < m; ++j) {
+            const uint4 ch = changes[f * (size_t)max_hot + j];
+            const unsigned fl = flag[ch.y];
+            if (fl) compact[(size_t)(tile_off[ch.y / kFusedPix] + (fl & 0x7Fu)) * cpitch + ch.x] = (uint16_t)ch.w;    // (0: nobody reads the pixel)
+        }
+    }
 }
 
-// The replaced pixels written into the compact [active pixel][frame] series (pass A stored them as they were): what
-// travels in the pixel-series exchange is the REPAIRED series.  One lane per change slot; col0 = column of frame 0.
-__global__ void __launch_bounds__(256)
-    hot_patch_compact_kernel(const unsigned *__restrict__ ntotal, const unsigned *__restrict__ nch,
-                             const uint4 *__restrict__ changes, int nframes, int max_hot,
-                             const uint8_t *__restrict__ flag, const unsigned *__restrict__ tile_off,
-                             uint16_t *__restrict__ compact, unsigned cpitch)
-{
-    if (*ntotal == 0u) return;                 // (uniform) nearly every call
-    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (unsigned)nframes * (unsigned)max_hot) return;
-    const unsigned f = i / (unsigned)max_hot;
-    if (i - f * (unsigned)max_hot >= nch[f]) return;
-    const uint4 ch = changes[i];
-    const unsigned fl = flag[ch.y];
-    if (!fl) return;                           // nobody reads the pixel
-    const unsigned k = tile_off[ch.y / kFusedPix] + (fl & 0x7Fu);
-    compact[(size_t)k * cpitch + ch.x] = (uint16_t)ch.w;
-}
 
 // The same for several cameras.  The value of node n in frame f is sol = sum over the cameras, in order, of
 // w_c * f32(frame_c[pix_c[n]]) in float (psp_process.cpp:1813-1819): a replaced pixel of one camera changes it
@@ -2005,11 +1997,8 @@ int launch_hot_repair_compact(uint16_t *d_frames, size_t npix, int nframes, int 
     unsigned *ntotal = d_changes + (*parity & 1), *ntotal_next = d_changes + ((*parity & 1) ^ 1);
     *parity ^= 1;
     hipLaunchKernelGGL(hot_repair_kernel, dim3((unsigned)((nframes + 63) / 64)), dim3(64), 0, st, d_frames, npix, nframes,
-                       rows, cols, min_change, max_hot, d_count, d_pos, ntotal, nch, list, (uint4 *)nullptr, ntotal_next);
-    if (max_hot > 0)
-        hipLaunchKernelGGL(hot_patch_compact_kernel, dim3((unsigned)(((size_t)nframes * max_hot + 255) / 256)), dim3(256), 0, st,
-                           (const unsigned *)ntotal, (const unsigned *)nch, (const uint4 *)list, nframes, max_hot, d_flag,
-                           d_tile_off, d_compact, cpitch);
+                       rows, cols, min_change, max_hot, d_count, d_pos, ntotal, nch, list, (uint4 *)nullptr, ntotal_next, d_flag,
+                       d_tile_off, max_hot > 0 ? d_compact : (uint16_t *)nullptr, cpitch);
     UPSP_HIP_CHECK(hipGetLastError());
     return UPSP_OK;
 }
