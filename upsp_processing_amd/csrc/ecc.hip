@@ -378,10 +378,11 @@ __device__ __forceinline__ void ecc_coord(int2 rt, int ax, int bx, int &sx, int 
 }
 
 // the 12 source pixels straight from global memory (segments whose footprint does not fit the LDS tile)
-__device__ __forceinline__ void ecc_row_load_direct(const float *__restrict__ I, int cols, int sx, int sy, EccRow &q)
+// (q0: byte offset of source pixel (sx, sy - 1) = 4 (cols (sy - 1) + sx); rows, columns < 2^15)
+__device__ __forceinline__ void ecc_row_load_direct(const float *__restrict__ I, int cols, unsigned q0, EccRow &q)
 {
     const unsigned pitch = 4u * (unsigned)cols;
-    const unsigned q0 = 4u * (unsigned)(__mul24(sy - 1, cols) + sx), q1 = q0 + pitch, q2 = q1 + pitch, q3 = q2 + pitch;   // (rows, columns < 2^15)
+    const unsigned q1 = q0 + pitch, q2 = q1 + pitch, q3 = q2 + pitch;
     q.A = ld_v2f(I, q0);
     q.Be[0] = ld_f32<-4>(I, q1);
     q.Bm = ld_v2f(I, q1);
@@ -468,18 +469,37 @@ __device__ __forceinline__ void ecc_walk_segment(const float *tile, const EccSeg
 {
     const unsigned pitch = 4u * (unsigned)cols;
     unsigned ot = 4u * (unsigned)(yb * cols + x);
+    // Source coordinate of the thread's column, row by row.  The row term rt[r] is the same for every lane, and under a warp
+    // near the identity it moves by exactly (0, +1 pixel) from most rows to the next (the x term of a row changes by one 1/1024
+    // px every 1 / |M[1]| rows, the y term leaves +1024 every 1 / |M[4] - 1| rows): then every lane's source pixel is the one
+    // below the previous row's and its fractions are the same -- the fixed-point arithmetic (a dozen vector instructions per
+    // pixel) is skipped on a scalar test, the footprint's address moves down one row.  Same coordinates, same taps, same bits.
+    float cfx = 0.f, cfy = 0.f;
+    unsigned coff = 0u;                 // TILE: float index of the footprint's corner in the tile; direct: its byte offset in the frame
+    int2 prev = make_int2(0, 0);
+    bool have = false;
     auto taps = [&](int r, EccRow &q) {
-        int sx, sy;
-        ecc_coord(rt[r], ax, bx, sx, sy, q.fx, q.fy);
+        const int2 a = rt[r];
+        if (have && a.x == prev.x && a.y == prev.y + 1024) {       // (uniform)
+            coff += TILE ? (unsigned)kEccTilePitch : pitch;
+        } else {
+            int sx, sy;
+            ecc_coord(a, ax, bx, sx, sy, cfx, cfy);
+            coff = TILE ? (unsigned)((sy - 1 - g.r0) * kEccTilePitch + (sx - 1 - g.c0)) : 4u * (unsigned)(__mul24(sy - 1, cols) + sx);
+        }
+        have = true;
+        prev = a;
+        q.fx = cfx;
+        q.fy = cfy;
         if (TILE) {
-            const float *t0 = tile + (sy - 1 - g.r0) * kEccTilePitch + (sx - 1 - g.c0);
+            const float *t0 = tile + coff;
             const float *t1 = t0 + kEccTilePitch, *t2 = t1 + kEccTilePitch, *t3 = t2 + kEccTilePitch;
             q.A[0] = t0[1]; q.A[1] = t0[2];
             q.Be[0] = t1[0]; q.Bm[0] = t1[1]; q.Bm[1] = t1[2]; q.Be[1] = t1[3];
             q.Ce[0] = t2[0]; q.Cm[0] = t2[1]; q.Cm[1] = t2[2]; q.Ce[1] = t2[3];
             q.D[0] = t3[1]; q.D[1] = t3[2];
         } else {
-            ecc_row_load_direct(I, cols, sx, sy, q);
+            ecc_row_load_direct(I, cols, coff, q);
         }
     };
     float tn[UR];
