@@ -1032,10 +1032,36 @@ def main():
     #  default stream's queue on this runtime -- kernel trace: every launch on queue 4 -- and the build then runs behind pass B
     #  and in front of pass A instead of beside them: N > 1 loop 1.61 against 1.40 ms per step)
     side = torch.cuda.Stream(priority=int(os.environ.get("UPSP_BENCH_SIDE_PRIORITY", "-1" if (swap or reg_side) else "0"))) if (overlap or reg_side) else None
+    # Nothing but pass A, the hot-pixel repair and pass B on the main stream (one GPU, default schedule).  A step's main stream used to
+    # carry seven launches -- restore, pass A, repair, the copy of the projection into the pipeline, the node -> row sweep, pass B,
+    # finals -- and every dependent launch costs ~10 us of queue turnaround on top of its run time (kernel trace: 0.11 ms of a 0.87-ms
+    # step were neither pass).  The small ones depend on other things than their neighbours, and the side stream has room:
+    #   * putting the hot pixels back for step s + 1 needs the repair of step s only (pass B reads the compact series, not the
+    #     frames -- the candidate map holds every pixel a node of this camera can read): in step s + 1's side block between the
+    #     map and the build, beside pass B of step s;
+    #   * the finals of step s need its pass B, and nothing needs them before pass B of step s + 1 overwrites the accumulators:
+    #     behind the build of step s + 1 (which waits for the end of step s there anyway); the last step's finals are issued
+    #     behind the loop, inside the timed region;
+    #   * the projection copy and the node -> row sweep (upsp_pipeline_prepare_rows) need the BUILD: they follow it on the side
+    #     stream, beside pass A.
+    # Every one of them still runs once per step, inside the timed region.  UPSP_BENCH_LEAN_MAIN=0: round 5's first arrangement (A/B).
+    lean = swap and map_on_side and not chunked and os.environ.get("UPSP_BENCH_LEAN_MAIN", "1") == "1"
+    lean_st = {"repaired": None, "finals_due": False}
 
-    def step(record):
-        e = [ev() for _ in range(4)]
-        restore_hot()
+    def lean_finals():
+        """finals of the step before (the accumulators as its pass B left them)"""
+        if lean_st["finals_due"]:
+            pipe.finalize(F * world)
+            lean_st["finals_due"] = False
+
+    class _NoEvent:                     # (lean schedule: an event record is a packet of its own on the main stream's queue, ~5 us
+        def record(self, *a):           #  between two dependent launches; the timed steps carry only the events that order work,
+            pass                        #  the per-phase breakdown comes from the instrumented repetition behind the timed loop)
+
+    def step(record, events=True):
+        e = [ev() if events else (torch.cuda.Event() if i == 3 else _NoEvent()) for i in range(4)]      # ([3]: the end of the step, orders the side stream)
+        if not lean:
+            restore_hot()
         e[0].record()
         ht = [time.perf_counter()]
         main = torch.cuda.current_stream()
@@ -1056,15 +1082,33 @@ def main():
                     if len(step_end) >= 2:
                         side.wait_event(step_end[-2])
                     pipe.set_active_hint(engine.candidate_pixels(cam, d_nodes, normals=d_nrm if cand_oblique else None, oblique_angle_deg=70.0))
+                    if lean and lean_st["repaired"] is not None:
+                        # (behind the map, which runs beside the previous step's pass A: in front of it the whole side block -- and
+                        #  with it this step's pass B -- waited for that repair: no gain, measured)
+                        side.wait_event(lean_st["repaired"])       # pass A + repair of the step before
+                        restore_hot()                              # this step's frames as they arrived
                     ev_map = torch.cuda.Event()
                     ev_map.record(side)
-                    proj = engine.build_projection(bvh, cam, d_nodes, d_nrm, d_tn, 70.0, counts=False)
+                    # (lean: built straight into the pipeline's buffer -- the 2-MB device copy of set_projection is a blit kernel
+                    #  that waited 0.2 ms for its turn beside pass A; that buffer held the projection of the step before the last,
+                    #  whose end the side stream has waited for above)
+                    proj = engine.build_projection(bvh, cam, d_nodes, d_nrm, d_tn, 70.0, counts=False,
+                                                   pix_out=pipe.projection_target(0) if lean else None)
+                    if lean:
+                        if step_end:
+                            side.wait_event(step_end[-1])          # the previous step's pass B: its sums, and it read the skipped flags
+                        lean_finals()
+                        pipe.set_projection(0, proj["pix"])
+                        pipe.prepare_rows()
                 main.wait_event(ev_map)
             else:
                 with torch.cuda.stream(side):
                     proj = engine.build_projection(bvh, cam, d_nodes, d_nrm, d_tn, 70.0, counts=False)
                 pipe.set_active_hint(engine.candidate_pixels(cam, d_nodes, normals=d_nrm if cand_oblique else None, oblique_angle_deg=70.0))
             pipe.prescan(frames)
+            if lean:
+                lean_st["repaired"] = torch.cuda.Event()
+                lean_st["repaired"].record(main)
         elif overlap:
             # which pixels the frame loop will read is known once the nodes are projected into the image
             # (step 1 of create_projection_mat); pass A does not need the visibility verdicts
@@ -1093,7 +1137,8 @@ def main():
                 for t in proj.values():
                     if isinstance(t, torch.Tensor) and t.is_cuda:
                         t.record_stream(main)       # allocated on the side stream, consumed on the main one
-        pipe.set_projection(0, proj["pix"])
+        if not lean:
+            pipe.set_projection(0, proj["pix"])
         if not chunked:
             pipe.process(frames, first_frame=rank * F, rows_t=rows_t, want_rows=False)
         elif pixel_wire:
@@ -1148,7 +1193,10 @@ def main():
         _h.append(time.perf_counter())
         if chunked and not pixel_wire:
             exch.finish()
-        avg, rms = pipe.finalize(F * world)
+        if lean:
+            avg, lean_st["finals_due"] = None, True        # (on the side stream of the next step, or behind the loop)
+        else:
+            avg, rms = pipe.finalize(F * world)
         _h.append(time.perf_counter())
         if os.environ.get("UPSP_BENCH_TRACE_HOST"):
             sys.stderr.write("host tail: finish_pixels %.3f allreduce %.3f finalize %.3f ms\n" % tuple((b - a) * 1e3 for a, b in zip(_h[:-1], _h[1:])))
@@ -1157,9 +1205,10 @@ def main():
             step_end.append(e[3])
             del step_end[:-2]
         ht.append(time.perf_counter())
-        if record:                      # events are read after the timed loop: no host sync inside it
+        if record and events:           # events are read after the timed loop: no host sync inside it
             ev_log.append(e)
             host_log.append([(b - a) * 1e3 for a, b in zip(ht[:-1], ht[1:])])
+        if record:
             last_pix[0] = proj["pix"]
         return avg
 
@@ -1175,10 +1224,13 @@ def main():
     with quiet_gc():
         t0 = time.perf_counter()
         for _ in range(a.steps):
-            step(True)
+            step(True, events=not lean)
         drain()                         # (deferred exchange: the last step's series and sums, inside the timed region)
+        lean_finals()                   # (the last step's finals, likewise)
         barrier()
         dt = time.perf_counter() - t0
+    if lean:
+        last_pix[0] = last_pix[0].clone()       # (a view of the pipeline's buffer: the repetitions below build into it again)
     xcheck = None
     if chunked:
         for x in exchs:
@@ -1204,10 +1256,6 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
         xcheck = bool(t.item())
     bvh.check()                         # no walk ran past its round cap (UPSP_ERR_INTERNAL otherwise)
-    for e in ev_log:
-        t_ray.append(e[0].elapsed_time(e[1]))
-        t_frames.append(e[1].elapsed_time(e[2]))
-        t_xchg.append(e[2].elapsed_time(e[3]))
     pc = engine.projection_counts(bvh)
     primary_rays, retry_nodes = pc["primary_rays"], pc["retry_nodes"]
     # the rays the REFERENCE casts for this camera: one build (not timed) that casts them all, in the reference's
@@ -1218,11 +1266,18 @@ def main():
     # the same K steps once more with the library's per-kernel HIP-event timers on
     # (two extra events per launch on the launch stream; kept out of the headline time)
     _capi.timing_enable(True)
+    keep_pix = last_pix[0]
     for _ in range(a.steps):
-        step(False)
+        step(lean)                      # (lean: the per-phase events of the breakdown are recorded here, not in the timed steps)
+    last_pix[0] = keep_pix
     drain()
+    lean_finals()
     barrier()
     _capi.timing_enable(False)
+    for e in ev_log:
+        t_ray.append(e[0].elapsed_time(e[1]))
+        t_frames.append(e[1].elapsed_time(e[2]))
+        t_xchg.append(e[2].elapsed_time(e[3]))
     dt_rank_min = dt_rank_max = dt
     if world > 1:
         tt = torch.tensor([dt, -dt], dtype=torch.float64, device="cuda")

@@ -258,6 +258,14 @@ int upsp_pipeline_set_projection(upsp_pipeline *p, int cam, const int32_t *d_pix
  * (upsp_projection_build) and the frame loop can then be queued back to back. */
 int upsp_pipeline_set_projection_async(upsp_pipeline *p, int cam, const int32_t *d_pix,
                                        const float *d_weight, void *stream);
+/* A projection that is rebuilt while the frame loop runs (model motion, docs/sphinx/known-issues.rst:18-30; bench.py rebuilds it
+ * every step) can be built straight into the pipeline: *d_pix = a buffer of nnodes int32 owned by the pipeline that none of its
+ * queued launches reads; pass it as upsp_projection_build's d_pix and then to upsp_pipeline_set_projection[_async], which takes
+ * it over without the device copy (a 2-MB blit that waits 0.2 ms for its turn beside pass A) and hands out the previous
+ * projection's buffer at the next call -- so the caller orders a build behind the launches of the process call BEFORE the
+ * last one (they may read that buffer).  Replaces nothing in the reference: create_projection_mat returns its matrix by value
+ * (cpp/exec/psp_process.cpp:167-355). */
+int upsp_pipeline_projection_target(upsp_pipeline *p, int cam, int32_t **d_pix);
 /* fix_hot_pixels (cpp/utils/cv_extras.cpp:230-275, called at cpp/exec/psp_process.cpp:1772) does not
  * depend on the projection: upsp_pipeline_fix_hot_pixels queues the scan + repair of `nframes`
  * resident frames (in place, pipeline's thresholds) on `stream` -- e.g. a second stream while the
@@ -285,6 +293,13 @@ int upsp_pipeline_set_hot_enable(upsp_pipeline *p, int enable);
  * One camera, plain path. */
 int upsp_pipeline_set_active_hint(upsp_pipeline *p, const int32_t *d_pix_candidates, void *stream);
 int upsp_pipeline_prescan(upsp_pipeline *p, uint16_t *d_frames, int nframes, void *stream);
+/* What the streamed frame loop derives from a NEW projection before its pass B -- every node's row in the compact pixel series
+ * (from the active-pixel map) and, unless upsp_pipeline_set_skipped gave them, the flags of identify_skipped_nodes
+ * (cpp/lib/projection.ipp:857-880) -- queued on `stream` now instead of inside the next upsp_pipeline_process call: on the
+ * stream that built the projection, behind upsp_pipeline_set_projection_async, it runs beside pass A instead of between
+ * pass A and pass B.  The caller orders `stream` behind the launches of the previous process call (they read the skipped
+ * flags) and the next process call behind `stream`.  One camera, plain path; elsewhere the call does nothing. */
+int upsp_pipeline_prepare_rows(upsp_pipeline *p, void *stream);
 /* Nodes set to NaN in every row (psp_process.cpp:1822-1825); NULL = derive from
  * the projections with identify_skipped_nodes. */
 int upsp_pipeline_set_skipped(upsp_pipeline *p, const uint8_t *d_skipped);

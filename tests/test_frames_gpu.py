@@ -530,13 +530,15 @@ def test_full_size_streamed_frame_loop_properties(gpu_lib):
     assert torch.equal(ss0.view(torch.int64), out[2][1][1].view(torch.int64))
 
 
-@pytest.mark.parametrize("F", [70, 300])
-def test_prescan_with_candidate_map(gpu_lib, oracle, F):
+@pytest.mark.parametrize("F,prepare", [(70, False), (300, False), (70, True), (300, True)])
+def test_prescan_with_candidate_map(gpu_lib, oracle, F, prepare):
     """Pass A ahead of the projection (upsp_pipeline_set_active_hint + upsp_pipeline_prescan on a second
     stream), the projection set afterwards, process() = pass B + fix-up only: series, repaired frames and
     accumulators bit-identical to the oracle loop -- with hot pixels, with a projection that is a strict
     subset of the candidates, with nodes whose pixel is NOT among the candidates (served from the frames),
-    and again after a projection change that reuses the candidate map."""
+    and again after a projection change that reuses the candidate map.
+    prepare: the projection arrives on a THIRD stream and upsp_pipeline_prepare_rows derives the nodes' series rows and the
+    skipped flags there, beside pass A (the bench's default schedule); process() then launches pass B only."""
     import torch
     from upsp_processing_amd import engine, synthetic as syn
     H, W, n = 64, 130, 2500
@@ -564,7 +566,17 @@ def test_prescan_with_candidate_map(gpu_lib, oracle, F):
                 pipe.set_active_hint(torch.as_tensor(cand).cuda())
             pipe.prescan(d)
         pipe.reset()
-        pipe.set_projection(0, pix)
+        if prepare:
+            third = torch.cuda.Stream()
+            third.wait_stream(main)
+            with torch.cuda.stream(third):
+                if trial == 0:
+                    third.wait_stream(side)              # (the map the rows are looked up in)
+                pipe.set_projection(0, pix)
+                pipe.prepare_rows()
+            main.wait_stream(third)
+        else:
+            pipe.set_projection(0, pix)
         main.wait_stream(side)
         rt = torch.full((n, engine.series_ld(F, whole_rows=True)), -3.0, dtype=torch.float32, device="cuda")
         pipe.process(d, 0, rows_t=rt[:, :F], want_rows=False)

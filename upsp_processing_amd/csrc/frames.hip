@@ -628,24 +628,30 @@ __global__ void __launch_bounds__(256)
 }
 
 // exclusive scan of the tile counts (one workgroup): off[0..ntiles], off[ntiles] = total; and of the
-// "tile has an active pixel" flags: arank[0..ntiles], arank[ntiles] = number of active tiles
-__global__ void __launch_bounds__(1024)
+// "tile has an active pixel" flags: arank[0..ntiles], arank[ntiles] = number of active tiles.
+// NT threads, PT tiles per thread.  Four waves, not sixteen: the launch runs on a side stream beside pass A / pass B, and a
+// 1024-thread workgroup waits there until ONE compute unit has sixteen wave slots free at the same moment (kernel trace: 40 us,
+// 188 us beside pass B, for a few microseconds of work).
+template <int NT, int PT>
+__global__ void __launch_bounds__(NT)
     tilemap_scan_kernel(const unsigned *__restrict__ cnt, unsigned *__restrict__ off, unsigned *__restrict__ arank,
                         unsigned ntiles)
 {
-    // 8 tiles per thread; the 1024 per-thread totals are scanned by wave shuffles, the 16 wave totals by the first wave:
-    // three barriers per 8192 tiles (the Hillis-Steele version through LDS had twenty and took 13 us of every projection)
+    // PT tiles per thread; the NT per-thread totals are scanned by wave shuffles, the wave totals by the first wave:
+    // three barriers per NT x PT tiles (the Hillis-Steele version through LDS had twenty and took 13 us of every projection)
+    constexpr int NW = NT / 64;
+    static_assert(NW >= 1 && NW <= 16 && NT % 64 == 0, "whole waves, at most sixteen");
     __shared__ unsigned long long wsum[16];     // low word: pixels, high word: active tiles
     __shared__ unsigned long long carry;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) carry = 0ull;
     __syncthreads();
-    for (unsigned base = 0; base < ntiles; base += 1024u * 8u) {
-        const unsigned i0 = base + threadIdx.x * 8u;
-        unsigned v[8];
+    for (unsigned base = 0; base < ntiles; base += (unsigned)(NT * PT)) {
+        const unsigned i0 = base + threadIdx.x * (unsigned)PT;
+        unsigned v[PT];
         unsigned long long tot = 0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < PT; ++k) {
             v[k] = i0 + k < ntiles ? cnt[i0 + k] : 0u;
             tot += (unsigned long long)v[k] + ((unsigned long long)(v[k] != 0u) << 32);
         }
@@ -658,25 +664,25 @@ __global__ void __launch_bounds__(1024)
         if (lane == 63) wsum[wave] = x;
         __syncthreads();
         if (wave == 0) {
-            unsigned long long w = lane < 16 ? wsum[lane] : 0ull;
+            unsigned long long w = lane < NW ? wsum[lane] : 0ull;
 #pragma unroll
-            for (int d = 1; d < 16; d <<= 1) {
+            for (int d = 1; d < NW; d <<= 1) {
                 const unsigned long long y = __shfl_up(w, d);
                 if (lane >= d) w += y;
             }
-            if (lane < 16) wsum[lane] = w;        // inclusive totals of the waves
+            if (lane < NW) wsum[lane] = w;        // inclusive totals of the waves
         }
         __syncthreads();
         unsigned long long run = carry + (wave ? wsum[wave - 1] : 0ull) + x - tot;
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
+        for (int k = 0; k < PT; ++k)
             if (i0 + k < ntiles) {
                 off[i0 + k] = (unsigned)(run & 0xFFFFFFFFull);
                 if (arank) arank[i0 + k] = (unsigned)(run >> 32);
                 run += (unsigned long long)v[k] + ((unsigned long long)(v[k] != 0u) << 32);
             }
         __syncthreads();
-        if (threadIdx.x == 0) carry += wsum[15];
+        if (threadIdx.x == 0) carry += wsum[NW - 1];
         __syncthreads();
     }
     if (threadIdx.x == 0) {
@@ -1791,7 +1797,11 @@ int launch_amap_build(const int32_t *d_pix, size_t nnodes, size_t npix, uint8_t 
     unsigned *arank = d_order ? d_order + ntiles : nullptr;
     // (the visiting order made by the scan's own workgroup from an LDS copy of the ranks -- one launch less -- measured: the map
     //  build 30 -> 45 us; 8192 searches and 64-bit divisions are no work for ONE workgroup)
-    hipLaunchKernelGGL(tilemap_scan_kernel, dim3(1), dim3(1024), 0, st, (const unsigned *)d_cnt, d_off, arank, ntiles);
+    static const bool big_scan = [] { const char *e = std::getenv("UPSP_EXP_BIG_WG"); return e && *e == '1'; }();     // (A/B)
+    if (big_scan)
+        hipLaunchKernelGGL((tilemap_scan_kernel<1024, 8>), dim3(1), dim3(1024), 0, st, (const unsigned *)d_cnt, d_off, arank, ntiles);
+    else
+        hipLaunchKernelGGL((tilemap_scan_kernel<256, 32>), dim3(1), dim3(256), 0, st, (const unsigned *)d_cnt, d_off, arank, ntiles);
     // (d_node_k null: a map built from a candidate set -- the nodes get their rows once the projection is there, launch_amap_nodes)
     if (d_node_k)
         hipLaunchKernelGGL(amap_nodes_kernel, g, b, 0, st, d_pix, (unsigned)nnodes, (const uint8_t *)d_flag,

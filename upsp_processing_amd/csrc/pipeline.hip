@@ -24,6 +24,7 @@ struct upsp_pipeline {
     size_t nnodes = 0;
     upsp_pipeline_opts opts;
     int32_t *d_pix[kMaxCams] = {nullptr};
+    int32_t *d_pix_next[kMaxCams] = {nullptr};      // upsp_pipeline_projection_target: where the caller builds the NEXT projection
     float *d_weight[kMaxCams] = {nullptr};
     bool has_proj[kMaxCams] = {false};
     unsigned *d_read_list[kMaxCams] = {nullptr};  // count + pixels with a node (registration as the last image stage)
@@ -203,6 +204,7 @@ void upsp_pipeline_destroy(upsp_pipeline *p)
     if (!p) return;
     for (int c = 0; c < kMaxCams; ++c) {
         free_dev(p->d_pix[c]);
+        free_dev(p->d_pix_next[c]);
         free_dev(p->d_weight[c]);
         free_dev(p->d_read_list[c]);
         free_dev(p->d_ref[c]);
@@ -246,9 +248,13 @@ int upsp_pipeline_set_projection(upsp_pipeline *p, int cam, const int32_t *d_pix
                                  const float *d_weight)
 {
     if (!p || cam < 0 || cam >= p->ncams || !d_pix) return fail(UPSP_ERR_INVALID, "bad argument");
-    if (!p->d_pix[cam]) UPSP_HIP_CHECK(hipMalloc(&p->d_pix[cam], sizeof(int32_t) * p->nnodes));
-    UPSP_HIP_CHECK(hipMemcpy(p->d_pix[cam], d_pix, sizeof(int32_t) * p->nnodes,
-                             hipMemcpyDeviceToDevice));
+    if (d_pix == p->d_pix_next[cam]) {
+        std::swap(p->d_pix[cam], p->d_pix_next[cam]);      // built in place (upsp_pipeline_projection_target): no copy
+    } else {
+        if (!p->d_pix[cam]) UPSP_HIP_CHECK(hipMalloc(&p->d_pix[cam], sizeof(int32_t) * p->nnodes));
+        UPSP_HIP_CHECK(hipMemcpy(p->d_pix[cam], d_pix, sizeof(int32_t) * p->nnodes,
+                                 hipMemcpyDeviceToDevice));
+    }
     if (d_weight) {
         if (!p->d_weight[cam]) UPSP_HIP_CHECK(hipMalloc(&p->d_weight[cam], sizeof(float) * p->nnodes));
         UPSP_HIP_CHECK(hipMemcpy(p->d_weight[cam], d_weight, sizeof(float) * p->nnodes,
@@ -271,9 +277,13 @@ int upsp_pipeline_set_projection_async(upsp_pipeline *p, int cam, const int32_t 
 {
     if (!p || cam < 0 || cam >= p->ncams || !d_pix) return fail(UPSP_ERR_INVALID, "bad argument");
     hipStream_t st = (hipStream_t)stream;
-    if (!p->d_pix[cam]) UPSP_HIP_CHECK(hipMalloc(&p->d_pix[cam], sizeof(int32_t) * p->nnodes));
-    UPSP_HIP_CHECK(hipMemcpyAsync(p->d_pix[cam], d_pix, sizeof(int32_t) * p->nnodes,
-                                  hipMemcpyDeviceToDevice, st));
+    if (d_pix == p->d_pix_next[cam]) {
+        std::swap(p->d_pix[cam], p->d_pix_next[cam]);      // built in place (upsp_pipeline_projection_target): no copy
+    } else {
+        if (!p->d_pix[cam]) UPSP_HIP_CHECK(hipMalloc(&p->d_pix[cam], sizeof(int32_t) * p->nnodes));
+        UPSP_HIP_CHECK(hipMemcpyAsync(p->d_pix[cam], d_pix, sizeof(int32_t) * p->nnodes,
+                                      hipMemcpyDeviceToDevice, st));
+    }
     if (d_weight) {
         if (!p->d_weight[cam]) UPSP_HIP_CHECK(hipMalloc(&p->d_weight[cam], sizeof(float) * p->nnodes));
         UPSP_HIP_CHECK(hipMemcpyAsync(p->d_weight[cam], d_weight, sizeof(float) * p->nnodes,
@@ -290,6 +300,14 @@ int upsp_pipeline_set_projection_async(upsp_pipeline *p, int cam, const int32_t 
     if (!p->hint_active) invalidate_map(p);
     p->node_k_valid = false;
     if (!p->skipped_user) p->skipped_valid = false;
+    return UPSP_OK;
+}
+
+int upsp_pipeline_projection_target(upsp_pipeline *p, int cam, int32_t **d_pix)
+{
+    if (!p || cam < 0 || cam >= p->ncams || !d_pix) return fail(UPSP_ERR_INVALID, "bad argument");
+    if (!p->d_pix_next[cam]) UPSP_HIP_CHECK(hipMalloc(&p->d_pix_next[cam], sizeof(int32_t) * p->nnodes));
+    *d_pix = p->d_pix_next[cam];
     return UPSP_OK;
 }
 
@@ -624,6 +642,33 @@ int upsp_pipeline_prescan(upsp_pipeline *p, uint16_t *d_frames, int nframes, voi
     p->prescan_frames = d_frames;
     p->prescan_n = nframes;
     p->prescan_gen = p->map_gen;
+    return UPSP_OK;
+}
+
+// The node -> series-row table (and the skipped flags) of the current projection, on `stream`: the block the streamed frame
+// loop would run at the head of its next call (process_impl), for callers that have a stream on which the projection is ready
+// earlier than on the frame loop's.
+int upsp_pipeline_prepare_rows(upsp_pipeline *p, void *stream)
+{
+    if (!p) return fail(UPSP_ERR_INVALID, "null pipeline");
+    const size_t npix = (size_t)p->width * p->height;
+    if (p->ncams != 1 || !p->has_proj[0] || p->d_weight[0] || p->opts.registration || p->opts.patch || p->opts.filter || p->d_src ||
+        (npix % 2) != 0 || p->batch != 64 || p->opts.fused_scan == 2 || p->nnodes >= ((size_t)1 << 31))
+        return UPSP_OK;                       // (not the streamed plain path: the process call prepares what it needs)
+    hipStream_t st = (hipStream_t)stream;
+    if (!p->tilemap_valid) {
+        int rc = streamed_map(p, p->d_pix[0], npix, st);
+        if (rc != UPSP_OK) return rc;
+        p->node_k_valid = true;
+        p->hint_active = false;
+    }
+    if (!p->node_k_valid) {
+        const bool with_flags = !p->skipped_valid;
+        int rc = launch_amap_nodes(p->d_pix[0], p->nnodes, p->d_aflag, p->d_tile_off, p->d_node_k, st, with_flags ? p->d_skipped : nullptr);
+        if (rc != UPSP_OK) return rc;
+        p->node_k_valid = true;
+        if (with_flags) p->skipped_valid = true;
+    }
     return UPSP_OK;
 }
 

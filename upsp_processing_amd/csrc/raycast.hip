@@ -1865,18 +1865,21 @@ __global__ void __launch_bounds__(256)
 // The same for the projection build's visibility rays (work items of the primary pass, PHASE 0, or of the retry passes): the
 // verdicts heavy_kernel writes, one ray per wave; a frontier that outgrows the LDS stack goes on to heavy_kernel's list.
 constexpr int kWorkWaveOver = 19;     // [19] / [20]: rays wave_proj_kernel passed on (primary / retry phase)
-template <int PHASE>
-__global__ void __launch_bounds__(256)
+// WPB waves per workgroup.  The projection build launches it with ONE (6.6 KB of LDS): the build runs on a stream of its own
+// beside pass A / pass B, its hand-off lists are empty on well-shaped models, and 1280 four-wave workgroups with 26 KB of LDS each
+// had to find their place among the passes' workgroups just to read a zero (kernel trace: 146 us beside pass A, 9 us in a gap).
+template <int PHASE, int WPB>
+__global__ void __launch_bounds__(64 * WPB)
     wave_proj_kernel(Scene sc, Cam cam, const float *__restrict__ nodes, const int32_t *__restrict__ tri_nodes,
                      int32_t *__restrict__ pix, const unsigned *__restrict__ retry_nodes, unsigned *__restrict__ retry_mask,
                      unsigned *__restrict__ work, const unsigned *__restrict__ items, unsigned *__restrict__ items_over)
 {
-    __shared__ unsigned long long s_key[4][kWaveStack];
-    __shared__ int s_ref[4][kWaveStack];
-    __shared__ unsigned char s_depth[4][kWaveStack];
+    __shared__ unsigned long long s_key[WPB][kWaveStack];
+    __shared__ int s_ref[WPB][kWaveStack];
+    __shared__ unsigned char s_depth[WPB][kWaveStack];
     const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const unsigned count = min(work[kWorkHeavyCount + (PHASE ? 1 : 0)], kHeavyCap);
-    for (unsigned h = blockIdx.x * 4u + wave; h < count; h += gridDim.x * 4u) {
+    for (unsigned h = blockIdx.x * (unsigned)WPB + wave; h < count; h += gridDim.x * (unsigned)WPB) {
         const unsigned item = items[h];
         const unsigned node = PHASE == 0 ? item : retry_nodes[item / 6u];
         Ray r;
@@ -2797,12 +2800,19 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
     sc.pack_waves = sc1.pack_waves = kPackWavesPerSimd * 4u * (unsigned)(props().cus > 0 ? props().cus : 256);
     const int heavy_grid = (int)kHeavyGridMax;
     const int wave_grid = 5 * (props().cus > 0 ? props().cus : 256);
+    static const bool big_wg = env_int("UPSP_EXP_BIG_WG", 0) == 1;            // (A/B: four-wave hand-off workgroups)
+    static const int primary_bs = env_int("UPSP_EXP_PRIMARY_BS", 256);         // (A/B: one-wave workgroups for the primary pass)
 #define UPSP_LAUNCH_HEAVY(PHASE, SC)                                                                             \
     if (heavy_on) {                                                                                              \
         KTimed kth("heavy_kernel", st);                                                                          \
-        hipLaunchKernelGGL((wave_proj_kernel<PHASE>), dim3(wave_grid), dim3(256), 0, st, SC, c, d_nodes, d_tri_nodes, d_pix, \
-                           (const unsigned *)b->d_retry_nodes, b->d_retry_mask, b->d_work, (const unsigned *)b->d_heavy,  \
-                           b->d_heavy + kHeavyCap);                                                              \
+        if (big_wg)                                                                                              \
+            hipLaunchKernelGGL((wave_proj_kernel<PHASE, 4>), dim3(wave_grid), dim3(256), 0, st, SC, c, d_nodes, d_tri_nodes, d_pix, \
+                               (const unsigned *)b->d_retry_nodes, b->d_retry_mask, b->d_work, (const unsigned *)b->d_heavy,  \
+                               b->d_heavy + kHeavyCap);                                                          \
+        else                                                                                                     \
+            hipLaunchKernelGGL((wave_proj_kernel<PHASE, 1>), dim3(4 * wave_grid), dim3(64), 0, st, SC, c, d_nodes, d_tri_nodes, d_pix, \
+                               (const unsigned *)b->d_retry_nodes, b->d_retry_mask, b->d_work, (const unsigned *)b->d_heavy,  \
+                               b->d_heavy + kHeavyCap);                                                          \
         hipLaunchKernelGGL((heavy_kernel<PHASE>), dim3(heavy_grid), dim3(kHeavyThreads), 0, st, SC, c, d_nodes, d_tri_nodes, \
                            d_pix, (const unsigned *)b->d_retry_nodes, b->d_retry_mask, (const unsigned *)b->d_work,     \
                            kWorkWaveOver + (PHASE ? 1 : 0), (const unsigned *)(b->d_heavy + kHeavyCap));           \
@@ -2844,7 +2854,7 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
     }
 #define UPSP_LAUNCH_PROJ(STATS, PHASE, G, SC)                                                    \
     do {                                                                                         \
-        if (PHASE == 0)                                                                          \
+        if (PHASE == 0 && primary_bs != 64)                                                      \
             hipLaunchKernelGGL((projection_kernel<STATS, PHASE, kBlock>), dim3(G), dim3(kBlock), lds, st, SC, c, \
                                d_nodes, d_tri_nodes, (unsigned)nnodes, d_pix, b->d_retry_nodes,  \
                                b->d_retry_mask, (const unsigned *)b->d_todo_rays, b->d_work);    \

@@ -164,7 +164,7 @@ def projection_counts(bvh):
 
 
 def build_projection(bvh, cam, nodes, normals, tri_nodes, oblique_angle=70.0, datanode=None,
-                     nodecount=False, counts=True):
+                     nodecount=False, counts=True, pix_out=None):
     """create_projection_mat (psp_process.cpp:167-355) for one camera.
 
     Returns dict(pix int32[N] (-1 = no entry), uv f32[2N], nrays, nodecount u8[H,W] | None).
@@ -172,7 +172,8 @@ def build_projection(bvh, cam, nodes, normals, tri_nodes, oblique_angle=70.0, da
     counts=False: no host synchronisation, and the oblique test runs BEFORE the rays: nodes it rejects (no entry
     whatever their rays say) cast none -- same pix / uv / nodecount, about a third of the rays on a closed body
     (include/upsp_gpu.h, upsp_projection_build).  The counters of that build stay on the device
-    (projection_counts)."""
+    (projection_counts).
+    pix_out: int32 [N] device tensor to build into (FramePipeline.projection_target(): no copy at set_projection)."""
     nodes = _dev(nodes, torch.float32).reshape(-1, 3)
     normals = _dev(normals, torch.float32).reshape(-1, 3)
     tri_nodes = _dev(tri_nodes, torch.int32).reshape(-1)
@@ -180,7 +181,9 @@ def build_projection(bvh, cam, nodes, normals, tri_nodes, oblique_angle=70.0, da
         raise ValueError("tri_nodes must hold 3 node ids per triangle of the BVH")
     n = nodes.shape[0]
     dn = None if datanode is None else _dev(datanode, torch.uint8).reshape(-1)
-    pix = torch.empty(n, dtype=torch.int32, device="cuda")
+    if pix_out is not None:
+        assert pix_out.is_cuda and pix_out.dtype == torch.int32 and pix_out.numel() == n and pix_out.is_contiguous()
+    pix = torch.empty(n, dtype=torch.int32, device="cuda") if pix_out is None else pix_out
     uv = torch.empty(2 * n, dtype=torch.float32, device="cuda")
     cnt = torch.empty((cam.height, cam.width), dtype=torch.uint8, device="cuda") if nodecount else None
     nrays = C.c_uint64(0)
@@ -354,6 +357,20 @@ class FramePipeline:
         assert frames.is_cuda and frames.dtype == torch.uint16 and frames.is_contiguous()
         assert tuple(frames.shape[1:]) == (self.height, self.width)
         check(lib().upsp_pipeline_prescan(self._h, _ptr(frames), frames.shape[0], _stream()))
+
+    def projection_target(self, cam=0):
+        """int32 [N] tensor over a pipeline-owned buffer no queued launch reads (upsp_pipeline_projection_target): build the
+        next projection into it (build_projection(pix_out=...)) and set_projection() takes it over without a copy.  Valid
+        until that set_projection() call."""
+        q = C.c_void_p()
+        check(lib().upsp_pipeline_projection_target(self._h, cam, C.byref(q)))
+        return torch.as_tensor(_DevArray(q.value, self.nnodes, "<i4", self), device="cuda")
+
+    def prepare_rows(self):
+        """What pass B needs from a new projection (every node's row in the compact series, the skipped flags), queued on the
+        current stream now instead of inside the next process() call (upsp_pipeline_prepare_rows): behind set_projection() on
+        the stream that built the projection it runs beside pass A."""
+        check(lib().upsp_pipeline_prepare_rows(self._h, _stream()))
 
     def pixel_series(self, frames):
         """Pass A alone (upsp_pipeline_pixel_series): the REPAIRED u16 series of every active pixel over these (<= 1024)
