@@ -572,7 +572,13 @@ def test_prescan_with_candidate_map(gpu_lib, oracle, F, prepare):
             with torch.cuda.stream(third):
                 if trial == 0:
                     third.wait_stream(side)              # (the map the rows are looked up in)
-                pipe.set_projection(0, pix)
+                    pipe.set_projection(0, pix)
+                else:
+                    # the projection "built" straight into the pipeline's own buffer: taken over without a copy
+                    tgt = pipe.projection_target(0)
+                    tgt.copy_(torch.as_tensor(pix).cuda())
+                    pipe.set_projection(0, tgt)
+                    assert pipe.projection_target(0).data_ptr() != tgt.data_ptr()      # (the other buffer is handed out next)
                 pipe.prepare_rows()
             main.wait_stream(third)
         else:

@@ -1797,11 +1797,7 @@ int launch_amap_build(const int32_t *d_pix, size_t nnodes, size_t npix, uint8_t 
     unsigned *arank = d_order ? d_order + ntiles : nullptr;
     // (the visiting order made by the scan's own workgroup from an LDS copy of the ranks -- one launch less -- measured: the map
     //  build 30 -> 45 us; 8192 searches and 64-bit divisions are no work for ONE workgroup)
-    static const bool big_scan = [] { const char *e = std::getenv("UPSP_EXP_BIG_WG"); return e && *e == '1'; }();     // (A/B)
-    if (big_scan)
-        hipLaunchKernelGGL((tilemap_scan_kernel<1024, 8>), dim3(1), dim3(1024), 0, st, (const unsigned *)d_cnt, d_off, arank, ntiles);
-    else
-        hipLaunchKernelGGL((tilemap_scan_kernel<256, 32>), dim3(1), dim3(256), 0, st, (const unsigned *)d_cnt, d_off, arank, ntiles);
+    hipLaunchKernelGGL((tilemap_scan_kernel<256, 32>), dim3(1), dim3(256), 0, st, (const unsigned *)d_cnt, d_off, arank, ntiles);
     // (d_node_k null: a map built from a candidate set -- the nodes get their rows once the projection is there, launch_amap_nodes)
     if (d_node_k)
         hipLaunchKernelGGL(amap_nodes_kernel, g, b, 0, st, d_pix, (unsigned)nnodes, (const uint8_t *)d_flag,

@@ -2800,19 +2800,12 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
     sc.pack_waves = sc1.pack_waves = kPackWavesPerSimd * 4u * (unsigned)(props().cus > 0 ? props().cus : 256);
     const int heavy_grid = (int)kHeavyGridMax;
     const int wave_grid = 5 * (props().cus > 0 ? props().cus : 256);
-    static const bool big_wg = env_int("UPSP_EXP_BIG_WG", 0) == 1;            // (A/B: four-wave hand-off workgroups)
-    static const int primary_bs = env_int("UPSP_EXP_PRIMARY_BS", 256);         // (A/B: one-wave workgroups for the primary pass)
 #define UPSP_LAUNCH_HEAVY(PHASE, SC)                                                                             \
     if (heavy_on) {                                                                                              \
         KTimed kth("heavy_kernel", st);                                                                          \
-        if (big_wg)                                                                                              \
-            hipLaunchKernelGGL((wave_proj_kernel<PHASE, 4>), dim3(wave_grid), dim3(256), 0, st, SC, c, d_nodes, d_tri_nodes, d_pix, \
-                               (const unsigned *)b->d_retry_nodes, b->d_retry_mask, b->d_work, (const unsigned *)b->d_heavy,  \
-                               b->d_heavy + kHeavyCap);                                                          \
-        else                                                                                                     \
-            hipLaunchKernelGGL((wave_proj_kernel<PHASE, 1>), dim3(4 * wave_grid), dim3(64), 0, st, SC, c, d_nodes, d_tri_nodes, d_pix, \
-                               (const unsigned *)b->d_retry_nodes, b->d_retry_mask, b->d_work, (const unsigned *)b->d_heavy,  \
-                               b->d_heavy + kHeavyCap);                                                          \
+        hipLaunchKernelGGL((wave_proj_kernel<PHASE, 1>), dim3(4 * wave_grid), dim3(64), 0, st, SC, c, d_nodes, d_tri_nodes, d_pix, \
+                           (const unsigned *)b->d_retry_nodes, b->d_retry_mask, b->d_work, (const unsigned *)b->d_heavy,  \
+                           b->d_heavy + kHeavyCap);                                                              \
         hipLaunchKernelGGL((heavy_kernel<PHASE>), dim3(heavy_grid), dim3(kHeavyThreads), 0, st, SC, c, d_nodes, d_tri_nodes, \
                            d_pix, (const unsigned *)b->d_retry_nodes, b->d_retry_mask, (const unsigned *)b->d_work,     \
                            kWorkWaveOver + (PHASE ? 1 : 0), (const unsigned *)(b->d_heavy + kHeavyCap));           \
@@ -2854,7 +2847,7 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
     }
 #define UPSP_LAUNCH_PROJ(STATS, PHASE, G, SC)                                                    \
     do {                                                                                         \
-        if (PHASE == 0 && primary_bs != 64)                                                      \
+        if (PHASE == 0)     /* (one-wave workgroups for the primary pass too: the pass 0.28 -> 0.21 ms beside pass A, which then takes 0.47 instead of 0.40: step 0.87 -> 0.93 ms) */ \
             hipLaunchKernelGGL((projection_kernel<STATS, PHASE, kBlock>), dim3(G), dim3(kBlock), lds, st, SC, c, \
                                d_nodes, d_tri_nodes, (unsigned)nnodes, d_pix, b->d_retry_nodes,  \
                                b->d_retry_mask, (const unsigned *)b->d_todo_rays, b->d_work);    \
