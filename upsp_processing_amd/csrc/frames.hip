@@ -700,6 +700,17 @@ __global__ void __launch_bounds__(NT)
 // stay neighbours, the compact rows of successive active tiles too).
 // (the j-th active / inactive tile is found by a binary search in the active-tile ranks: arank[t] = active tiles before
 //  tile t, monotone, 32 KB -- thirteen cached loads per thread instead of a kernel that writes the two lists first)
+// Order in which pass A visits the tiles.  Default since the second half of round 5: every frame group's tiles that nobody reads
+// first -- a pure read stream, no stores -- and the ACTIVE tiles of all groups behind them (scan_compact_kernel, one-dimensional
+// grid).  The 135 MB of compact stores cost 40-90 us wherever they sat INSIDE the read stream (spread evenly over the sweep, round 2's
+// order: pass A alone 0.36-0.40 ms; in natural order, sixteen bursts: 0.41); behind it the kernel runs at the rate of bare loads --
+// 0.313-0.317 ms alone = 6.6 TB/s, 0.373 beside the projection build -- and the series are the last thing written before pass B
+// reads them.  UPSP_SCAN_SPREAD=1: the spread order (A/B).
+static bool scan_active_last()
+{
+    static const bool v = [] { const char *e = std::getenv("UPSP_SCAN_SPREAD"); return !(e && *e == '1'); }();
+    return v;
+}
 __device__ __forceinline__ unsigned amap_kth_tile(const unsigned *arank, unsigned ntiles, unsigned k, bool active)
 {
     // smallest t with (active ? arank[t + 1] : t + 1 - arank[t + 1]) > k
@@ -712,11 +723,16 @@ __device__ __forceinline__ unsigned amap_kth_tile(const unsigned *arank, unsigne
     return lo;
 }
 __global__ void __launch_bounds__(256)
-    amap_order_kernel(const unsigned *__restrict__ arank, unsigned ntiles, unsigned *__restrict__ order)
+    amap_order_kernel(const unsigned *__restrict__ arank, unsigned ntiles, unsigned *__restrict__ order, int active_last)
 {
     const unsigned p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= ntiles) return;
     const unsigned long long A = arank[ntiles], n = ntiles;
+    if (active_last) {          // the tiles nobody reads first, the active ones behind them (scan_active_last)
+        const unsigned nI = ntiles - (unsigned)A;
+        order[p] = p < nI ? amap_kth_tile(arank, ntiles, p, false) : amap_kth_tile(arank, ntiles, p - nI, true);
+        return;
+    }
     const unsigned long long j = ((unsigned long long)p * A + n - 1) / n;    // active slots before slot p
     const bool act = j < A && (j * n) / A == p;
     order[p] = amap_kth_tile(arank, ntiles, act ? (unsigned)j : p - (unsigned)j, act);
@@ -768,13 +784,31 @@ __global__ void __launch_bounds__(256)
     scan_compact_kernel(const uint16_t *__restrict__ frames, size_t npix, int nframes_call,
                         const uint8_t *__restrict__ flag, const unsigned *__restrict__ tile_off,
                         uint16_t *__restrict__ compact, unsigned cpitch, unsigned thresh, unsigned max_hot,
-                        unsigned *__restrict__ count, unsigned *__restrict__ pos, const unsigned *__restrict__ order)
+                        unsigned *__restrict__ count, unsigned *__restrict__ pos, const unsigned *__restrict__ order,
+                        unsigned ntiles_lin)
 {
     __shared__ unsigned tile[64][kFusedPitch];   // [frame][pixel pair]
     __shared__ int act_k[kFusedPix];             // compact index of the tile's pixels, -1 = nobody reads it
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int g = blockIdx.y;
-    const unsigned tl = order ? order[blockIdx.x] : blockIdx.x;   // this workgroup's tile
+    int g = blockIdx.y;
+    unsigned tl = blockIdx.x;                                // this workgroup's tile
+    if (!ntiles_lin) {
+        if (order) tl = order[blockIdx.x];
+    } else {
+        // one-dimensional grid: every group's inactive tiles first (pure reads), then every group's active tiles
+        // (order: inactive tiles ascending, then active tiles ascending; order[2 nt] = arank[nt] = number of active tiles)
+        const unsigned nt = ntiles_lin;
+        const unsigned A = order[2u * nt], nI = nt - A, ng = gridDim.x / nt, b = blockIdx.x;
+        if (b < nI * ng) {
+            g = (int)(b / nI);
+            tl = order[b - (unsigned)g * nI];
+        } else {
+            // (group after group; a tile's groups side by side instead -- whole 2-KB rows of the series filling up -- measured the same)
+            const unsigned b2 = b - nI * ng;
+            g = (int)(b2 / A);
+            tl = order[nI + (b2 - (unsigned)g * A)];
+        }
+    }
     const int nframes = min(64, nframes_call - 64 * g);
     frames += (size_t)g * 64 * npix;
     compact += 64 * g;
@@ -1803,7 +1837,8 @@ int launch_amap_build(const int32_t *d_pix, size_t nnodes, size_t npix, uint8_t 
         hipLaunchKernelGGL(amap_nodes_kernel, g, b, 0, st, d_pix, (unsigned)nnodes, (const uint8_t *)d_flag,
                            (const unsigned *)d_off, d_node_k, (uint8_t *)nullptr);
     if (d_order)
-        hipLaunchKernelGGL(amap_order_kernel, dim3((ntiles + 255) / 256), b, 0, st, (const unsigned *)arank, ntiles, d_order);
+        hipLaunchKernelGGL(amap_order_kernel, dim3((ntiles + 255) / 256), b, 0, st, (const unsigned *)arank, ntiles, d_order,
+                           scan_active_last() ? 1 : 0);
     UPSP_HIP_CHECK(hipGetLastError());
     return UPSP_OK;
 }
@@ -1824,12 +1859,14 @@ int launch_scan_compact(uint16_t *d_frames, size_t npix, int nframes, bool hot, 
     if ((col & 63) || (unsigned)(col + 64 * ngroups) > cpitch) return fail(UPSP_ERR_INVALID, "scan pass: compact buffer too narrow");
     const unsigned ntiles = (unsigned)tilemap_tiles(npix);
     KTimed kt("scan_compact_kernel", st);
+    const bool lin = scan_active_last() && d_order;
+    const dim3 grid = lin ? dim3(ntiles * (unsigned)ngroups) : dim3(ntiles, (unsigned)ngroups);
     if (hot)
-        hipLaunchKernelGGL(scan_compact_kernel<true>, dim3(ntiles, (unsigned)ngroups), dim3(256), 0, st, d_frames, npix, nframes,
-                           d_flag, d_off, d_compact + col, cpitch, (unsigned)thresh, (unsigned)max_hot, d_count, d_pos, d_order);
+        hipLaunchKernelGGL(scan_compact_kernel<true>, grid, dim3(256), 0, st, d_frames, npix, nframes,
+                           d_flag, d_off, d_compact + col, cpitch, (unsigned)thresh, (unsigned)max_hot, d_count, d_pos, d_order, lin ? ntiles : 0u);
     else
-        hipLaunchKernelGGL(scan_compact_kernel<false>, dim3(ntiles, (unsigned)ngroups), dim3(256), 0, st, d_frames, npix, nframes,
-                           d_flag, d_off, d_compact + col, cpitch, 0u, 0u, d_count, d_pos, d_order);
+        hipLaunchKernelGGL(scan_compact_kernel<false>, grid, dim3(256), 0, st, d_frames, npix, nframes,
+                           d_flag, d_off, d_compact + col, cpitch, 0u, 0u, d_count, d_pos, d_order, lin ? ntiles : 0u);
     UPSP_HIP_CHECK(hipGetLastError());
     return UPSP_OK;
 }
