@@ -73,6 +73,7 @@ struct upsp_pipeline {
     // the same per camera for the multi-camera streamed schedule
     uint8_t *m_aflag[kMaxCams] = {nullptr};
     unsigned *m_tile_off[kMaxCams] = {nullptr};
+    unsigned *m_tile_order[kMaxCams] = {nullptr};    // pass A's visiting order per camera (launch_amap_build)
     int32_t *m_node_k[kMaxCams] = {nullptr};
     uint16_t *m_compact[kMaxCams] = {nullptr};
     size_t m_compact_bytes[kMaxCams] = {0};
@@ -238,6 +239,7 @@ void upsp_pipeline_destroy(upsp_pipeline *p)
     for (int c = 0; c < kMaxCams; ++c) {
         free_dev(p->m_aflag[c]);
         free_dev(p->m_tile_off[c]);
+        free_dev(p->m_tile_order[c]);
         free_dev(p->m_node_k[c]);
         free_dev(p->m_compact[c]);
     }
@@ -1111,10 +1113,11 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
                 UPSP_HIP_CHECK(hipStreamSynchronize(nullptr));      // (allocation time only)
             }
             if (!p->m_tile_off[c]) UPSP_HIP_CHECK(hipMalloc(&p->m_tile_off[c], sizeof(unsigned) * (ntiles + 1)));
+            if (!p->m_tile_order[c]) UPSP_HIP_CHECK(hipMalloc(&p->m_tile_order[c], sizeof(unsigned) * 4 * (ntiles + 1)));
             if (!p->d_tile_cnt) UPSP_HIP_CHECK(hipMalloc(&p->d_tile_cnt, sizeof(unsigned) * ntiles));
             if (!p->m_node_k[c]) UPSP_HIP_CHECK(hipMalloc(&p->m_node_k[c], sizeof(int32_t) * p->nnodes));
             rc = launch_amap_build(p->d_pix[c], p->nnodes, npix, p->m_aflag[c], p->d_tile_cnt, p->m_tile_off[c],
-                                   p->m_node_k[c], nullptr, st);
+                                   p->m_node_k[c], p->m_tile_order[c], st);
             if (rc != UPSP_OK) return rc;
             p->m_valid[c] = true;
         }
@@ -1172,7 +1175,7 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
                 uint16_t *fr = d_frames[c];
                 if (hot_fused) {
                     rc = launch_scan_compact(fr + (size_t)s0 * npix, npix, ns, true, p->opts.hot_thresh, p->opts.hot_max,
-                                             p->m_aflag[c], p->m_tile_off[c], nullptr, p->m_compact[c], cp, 0,
+                                             p->m_aflag[c], p->m_tile_off[c], p->m_tile_order[c], p->m_compact[c], cp, 0,
                                              p->d_hot_count + (size_t)c * nframes + s0,
                                              p->d_hot_pos + ((size_t)c * nframes + s0) * 64, st);
                     continue;
@@ -1188,7 +1191,7 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
                     }
                     if (rc == UPSP_OK)
                         rc = launch_scan_compact(fr + (size_t)f0 * npix, npix, nb, false, 0, 0, p->m_aflag[c],
-                                                 p->m_tile_off[c], nullptr, p->m_compact[c], cp, f0 - s0,
+                                                 p->m_tile_off[c], p->m_tile_order[c], p->m_compact[c], cp, f0 - s0,
                                                  nullptr, nullptr, st);
                 }
             }
