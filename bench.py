@@ -1045,9 +1045,12 @@ def main():
     #   * the projection copy and the node -> row sweep (upsp_pipeline_prepare_rows) need the BUILD: they follow it on the side
     #     stream, beside pass A.
     # Every one of them still runs once per step, inside the timed region.  UPSP_BENCH_LEAN_MAIN=0: round 5's first arrangement (A/B).
-    lean_side = swap and map_on_side and os.environ.get("UPSP_BENCH_LEAN_MAIN", "1") == "1"
-    lean = lean_side and not chunked       # (N > 1: the finals follow the all-reduce on the main stream; the rest of the arrangement holds)
-    lean_st = {"repaired": None, "finals_due": False}
+    lean = swap and map_on_side and os.environ.get("UPSP_BENCH_LEAN_MAIN", "1") == "1"
+    # (N > 1, pixel-series wire: the same arrangement -- the finals of a step follow its all-reduce, which the end-of-step event the side
+    #  stream waits for covers; the exchange's node table is checked on the side stream too, upsp_pipeline_row_tables)
+    lean_side = lean
+    lean_px = lean and chunked and pixel_wire and px_once
+    lean_st = {"repaired": None, "finals_due": False, "pixels_set": False}
 
     def lean_finals():
         """finals of the step before (the accumulators as its pass B left them)"""
@@ -1101,6 +1104,14 @@ def main():
                         lean_finals()
                         pipe.set_projection(0, proj["pix"])
                         pipe.prepare_rows()
+                        if lean_px:
+                            # which pixel rows go where: from the node -> row table and the skipped flags the sweep just wrote
+                            # (after the first step only compared with the exchange's own copy, on this stream)
+                            wh = ex_state["step"] % len(exchs)
+                            tabs = pipe.row_tables()
+                            exchs[wh].set_pixels(tabs["node_k"], tabs["skipped"], assume_same=not ex_state["first"][wh])
+                            ex_state["first"][wh] = False
+                            lean_st["pixels_set"] = True
                 main.wait_event(ev_map)
             else:
                 with torch.cuda.stream(side):
@@ -1154,8 +1165,11 @@ def main():
                 tab = pipe.pixel_series(frames)
             else:
                 tab = pipe.pixel_series(None)       # node -> compact row of this projection
-            ex.set_pixels(tab["node_k"], engine.skipped_nodes(proj["pix"], want_count=False, as_bool=False)[0], assume_same=not ex_state["first"][which])
-            ex_state["first"][which] = False
+            if lean_st["pixels_set"]:
+                lean_st["pixels_set"] = False       # (done on the side stream, behind the build)
+            else:
+                ex.set_pixels(tab["node_k"], engine.skipped_nodes(proj["pix"], want_count=False, as_bool=False)[0], assume_same=not ex_state["first"][which])
+                ex_state["first"][which] = False
             if deferred and drain_first:
                 drain()                             # (A/B: the previous step's pass B BEFORE this step's chunks go out)
             for k in range(K):

@@ -300,6 +300,11 @@ int upsp_pipeline_prescan(upsp_pipeline *p, uint16_t *d_frames, int nframes, voi
  * pass A and pass B.  The caller orders `stream` behind the launches of the previous process call (they read the skipped
  * flags) and the next process call behind `stream`.  One camera, plain path; elsewhere the call does nothing. */
 int upsp_pipeline_prepare_rows(upsp_pipeline *p, void *stream);
+/* The two tables upsp_pipeline_prepare_rows (or the last process / pixel-series call) derived, for a caller that hands them on on the
+ * same stream -- upsp_exchange_set_pixels behind the projection build instead of in the frame loop's stream: *d_node_k [nnodes] = row of
+ * the compact pixel series per node (-1: no pixel, -2: pixel outside a candidate map), *d_skipped [nnodes] = identify_skipped_nodes'
+ * flags.  Pipeline-owned, valid until the next projection / map change; UPSP_ERR_INVALID when they have not been derived. */
+int upsp_pipeline_row_tables(upsp_pipeline *p, const int32_t **d_node_k, const uint8_t **d_skipped);
 /* Nodes set to NaN in every row (psp_process.cpp:1822-1825); NULL = derive from
  * the projections with identify_skipped_nodes. */
 int upsp_pipeline_set_skipped(upsp_pipeline *p, const uint8_t *d_skipped);

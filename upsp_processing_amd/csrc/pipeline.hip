@@ -674,6 +674,16 @@ int upsp_pipeline_prepare_rows(upsp_pipeline *p, void *stream)
     return UPSP_OK;
 }
 
+int upsp_pipeline_row_tables(upsp_pipeline *p, const int32_t **d_node_k, const uint8_t **d_skipped)
+{
+    if (!p) return fail(UPSP_ERR_INVALID, "null pipeline");
+    if (!p->node_k_valid || !p->skipped_valid || !p->d_node_k || !p->d_skipped)
+        return fail(UPSP_ERR_INVALID, "row tables: not derived for the current projection (upsp_pipeline_prepare_rows)");
+    if (d_node_k) *d_node_k = p->d_node_k;
+    if (d_skipped) *d_skipped = p->d_skipped;
+    return UPSP_OK;
+}
+
 // Pass A as an operator (pixel-series exchange: the sender runs pass A only, the owner of a node runs pass B over all
 // frames of the run).  Leaves the REPAIRED series of every active pixel over these frames in the pipeline's compact
 // buffer and repairs the frames in place.

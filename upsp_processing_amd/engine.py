@@ -372,6 +372,14 @@ class FramePipeline:
         the stream that built the projection it runs beside pass A."""
         check(lib().upsp_pipeline_prepare_rows(self._h, _stream()))
 
+    def row_tables(self):
+        """dict(node_k int32 [N], skipped uint8 [N]): the tables prepare_rows() derived, as tensors over the pipeline's buffers
+        (upsp_pipeline_row_tables; valid until the next projection / map change)."""
+        nk, sk = C.c_void_p(), C.c_void_p()
+        check(lib().upsp_pipeline_row_tables(self._h, C.byref(nk), C.byref(sk)))
+        return dict(node_k=torch.as_tensor(_DevArray(nk.value, self.nnodes, "<i4", self), device="cuda"),
+                    skipped=torch.as_tensor(_DevArray(sk.value, self.nnodes, "|u1", self), device="cuda"))
+
     def pixel_series(self, frames):
         """Pass A alone (upsp_pipeline_pixel_series): the REPAIRED u16 series of every active pixel over these (<= 1024)
         frames, left in the pipeline's compact buffer; the frames are repaired in place.  Returns dict(ptr = device address
