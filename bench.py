@@ -1048,7 +1048,6 @@ def main():
     lean = swap and map_on_side and os.environ.get("UPSP_BENCH_LEAN_MAIN", "1") == "1"
     # (N > 1, pixel-series wire: the same arrangement -- the finals of a step follow its all-reduce, which the end-of-step event the side
     #  stream waits for covers; the exchange's node table is checked on the side stream too, upsp_pipeline_row_tables)
-    lean_side = lean
     lean_px = lean and chunked and pixel_wire and px_once
     lean_st = {"repaired": None, "finals_due": False, "pixels_set": False}
 
@@ -1064,7 +1063,7 @@ def main():
 
     def step(record, events=True):
         e = [ev() if events else (torch.cuda.Event() if i == 3 else _NoEvent()) for i in range(4)]      # ([3]: the end of the step, orders the side stream)
-        if not lean_side:
+        if not lean:
             restore_hot()
         e[0].record()
         ht = [time.perf_counter()]
@@ -1086,7 +1085,7 @@ def main():
                     if len(step_end) >= 2:
                         side.wait_event(step_end[-2])
                     pipe.set_active_hint(engine.candidate_pixels(cam, d_nodes, normals=d_nrm if cand_oblique else None, oblique_angle_deg=70.0))
-                    if lean_side and lean_st["repaired"] is not None:
+                    if lean and lean_st["repaired"] is not None:
                         # (behind the map, which runs beside the previous step's pass A: in front of it the whole side block -- and
                         #  with it this step's pass B -- waited for that repair: no gain, measured)
                         side.wait_event(lean_st["repaired"])       # pass A + repair of the step before
@@ -1097,8 +1096,8 @@ def main():
                     #  that waited 0.2 ms for its turn beside pass A; that buffer held the projection of the step before the last,
                     #  whose end the side stream has waited for above)
                     proj = engine.build_projection(bvh, cam, d_nodes, d_nrm, d_tn, 70.0, counts=False,
-                                                   pix_out=pipe.projection_target(0) if lean_side else None)
-                    if lean_side:
+                                                   pix_out=pipe.projection_target(0) if lean else None)
+                    if lean:
                         if step_end:
                             side.wait_event(step_end[-1])          # the previous step's pass B: its sums, and it read the skipped flags
                         lean_finals()
@@ -1118,7 +1117,7 @@ def main():
                     proj = engine.build_projection(bvh, cam, d_nodes, d_nrm, d_tn, 70.0, counts=False)
                 pipe.set_active_hint(engine.candidate_pixels(cam, d_nodes, normals=d_nrm if cand_oblique else None, oblique_angle_deg=70.0))
             pipe.prescan(frames)
-            if lean_side:
+            if lean:
                 lean_st["repaired"] = torch.cuda.Event()
                 lean_st["repaired"].record(main)
         elif overlap:
@@ -1149,7 +1148,7 @@ def main():
                 for t in proj.values():
                     if isinstance(t, torch.Tensor) and t.is_cuda:
                         t.record_stream(main)       # allocated on the side stream, consumed on the main one
-        if not lean_side:
+        if not lean:
             pipe.set_projection(0, proj["pix"])
         if not chunked:
             pipe.process(frames, first_frame=rank * F, rows_t=rows_t, want_rows=False)
@@ -1244,7 +1243,7 @@ def main():
         lean_finals()                   # (the last step's finals, likewise)
         barrier()
         dt = time.perf_counter() - t0
-    if lean_side:
+    if lean:
         last_pix[0] = last_pix[0].clone()       # (a view of the pipeline's buffer: the repetitions below build into it again)
     xcheck = None
     if chunked:
