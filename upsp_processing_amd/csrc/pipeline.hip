@@ -252,7 +252,7 @@ int upsp_pipeline_set_projection(upsp_pipeline *p, int cam, const int32_t *d_pix
     if (!p || cam < 0 || cam >= p->ncams || !d_pix) return fail(UPSP_ERR_INVALID, "bad argument");
     if (d_pix == p->d_pix_next[cam]) {
         std::swap(p->d_pix[cam], p->d_pix_next[cam]);      // built in place (upsp_pipeline_projection_target): no copy
-    } else {
+    } else if (d_pix != p->d_pix[cam]) {                   // (the current buffer itself: rewritten in place by the caller)
         if (!p->d_pix[cam]) UPSP_HIP_CHECK(hipMalloc(&p->d_pix[cam], sizeof(int32_t) * p->nnodes));
         UPSP_HIP_CHECK(hipMemcpy(p->d_pix[cam], d_pix, sizeof(int32_t) * p->nnodes,
                                  hipMemcpyDeviceToDevice));
@@ -281,7 +281,7 @@ int upsp_pipeline_set_projection_async(upsp_pipeline *p, int cam, const int32_t 
     hipStream_t st = (hipStream_t)stream;
     if (d_pix == p->d_pix_next[cam]) {
         std::swap(p->d_pix[cam], p->d_pix_next[cam]);      // built in place (upsp_pipeline_projection_target): no copy
-    } else {
+    } else if (d_pix != p->d_pix[cam]) {
         if (!p->d_pix[cam]) UPSP_HIP_CHECK(hipMalloc(&p->d_pix[cam], sizeof(int32_t) * p->nnodes));
         UPSP_HIP_CHECK(hipMemcpyAsync(p->d_pix[cam], d_pix, sizeof(int32_t) * p->nnodes,
                                       hipMemcpyDeviceToDevice, st));
