@@ -580,6 +580,11 @@ def test_prescan_with_candidate_map(gpu_lib, oracle, F, prepare):
                     pipe.set_projection(0, tgt)
                     assert pipe.projection_target(0).data_ptr() != tgt.data_ptr()      # (the other buffer is handed out next)
                 pipe.prepare_rows()
+                tabs = pipe.row_tables()                 # what an exchange would be handed on this stream
+                assert torch.equal(tabs["skipped"].bool().cpu(), torch.as_tensor(pix < 0))
+                nk = tabs["node_k"].cpu().numpy()
+                assert ((nk >= 0) | (nk == -2))[pix >= 0].all() and (nk[pix < 0] == -1).all()
+                assert set(np.flatnonzero(nk == -2)) <= set(extra.tolist())          # only pixels outside the candidate set
             main.wait_stream(third)
         else:
             pipe.set_projection(0, pix)
