@@ -301,6 +301,13 @@ __global__ void __launch_bounds__(256)
     const unsigned nact = *nact_ptr;
     const unsigned k0 = blockIdx.x * 64u;
     if (k0 >= nact) return;
+    {   // blockIdx.y: the 64-frame piece of the launch (a workgroup transposes 64 pixels x <= 64 frames)
+        const int h = 64 * (int)blockIdx.y;
+        src += (size_t)h * rows * cols;
+        state += h;
+        nframes = min(64, nframes - h);
+        col0 += (unsigned)h;
+    }
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned k = k0 + (unsigned)lane;
     const bool valid = k < nact;
@@ -1222,10 +1229,10 @@ int run_frame_stages(FrameScratch *s, int cam, const uint16_t *d_frames, int nb,
         if (rc != UPSP_OK) return rc;
         if (wc) {      // registration is the last image stage and node-major series are wanted: straight into the compact buffer
             KTimed kt("warp_u16_kernel", st);
-            for (int h = 0; h < nb; h += 64)       // (a workgroup transposes 64 pixels x <= 64 frames)
-                hipLaunchKernelGGL(warp_compact_kernel, dim3((unsigned)((wc->max_active + 63) / 64)), block, 0, st,
-                                   d_frames + (size_t)h * npix, rows, cols, (const EccState *)s->state + h, std::min(64, nb - h),
-                                   opts.interp, wc->pix_of_k, wc->nact, wc->compact, wc->cpitch, wc->col0 + (unsigned)h);
+            // one launch for the sub-batch: grid.y = its 64-frame pieces (four launches of 24 us each until round 5)
+            hipLaunchKernelGGL(warp_compact_kernel, dim3((unsigned)((wc->max_active + 63) / 64), (unsigned)((nb + 63) / 64)), block, 0, st,
+                               d_frames, rows, cols, (const EccState *)s->state, nb, opts.interp, wc->pix_of_k, wc->nact, wc->compact,
+                               wc->cpitch, wc->col0);
         } else {
             KTimed kt("warp_u16_kernel", st);
             const bool listed = !opts.patch && !opts.filter && d_read_list;
