@@ -394,7 +394,7 @@ def test_registration_full_size_1024(gpu_lib, oracle):
 
 @pytest.mark.parametrize("reg_batch", ["64", "128", None])
 def test_registration_sub_batches_look_ahead(gpu_lib, oracle, monkeypatch, reg_batch):
-    """(UPSP_REG_BATCH: frames per sub-batch of the streamed registration path -- 256 by default; 64 and 128 put several
+    """(UPSP_REG_BATCH: frames per sub-batch of the streamed registration path -- 512 by default; 64 and 128 put several
     sub-batches into the calls below.  The sums of a frame do not depend on its neighbours: the same bits whatever the size.)
     More frames than one sub-batch through the streamed registration path: the hot-pixel repair and the pre-blur of
     sub-batch k + 1 are enqueued while the host waits for sub-batch k's "frames still iterating" (two blurred-frame buffers).

@@ -994,8 +994,9 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
         unsigned cp = 0;
         rc = streamed_buffers(p, npix, nframes, st, &S, &cp);
         if (rc != UPSP_OK) return rc;
-        // Sub-batches of this path: 256 frames where the blurred f32 copies allow it (two buffers of RB frames: 2 GiB at
-        // 1 Mpix; at most 4 GiB).  Every launch of the lock-step ECC loop -- sums, the one-lane-per-frame solve, pre-blur, repair,
+        // Sub-batches of this path: 512 frames where the blurred f32 copies allow it (two buffers of RB frames: 4 GiB at
+        // 1 Mpix, the cap; 256 frames until the end of round 5: configs[2] at 10 000 frames 156.1 / 158.5 / 160.4 k frames/s
+        // at 256 / 384 / 512).  Every launch of the lock-step ECC loop -- sums, the one-lane-per-frame solve, pre-blur, repair,
         // warp -- is paid per sub-batch, the solve (16 us of latency, nothing beside it) and the launch tails most of all;
         // configs[2], ms per 1000 frames at 64 / 128 / 192 / 256 / 512 frames: 7.96 / 7.71 / 7.62 / 7.54 / 7.45.  The sums of a
         // frame do not depend on its neighbours (block count per frame fixed by the image), so the bits are the ones of
@@ -1003,7 +1004,7 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
         int RB = B;
         if (B == 64) {
             const char *e = std::getenv("UPSP_REG_BATCH");
-            int want = e ? std::max(64, std::atoi(e) / 64 * 64) : 256;
+            int want = e ? std::max(64, std::atoi(e) / 64 * 64) : 512;
             while (want > 64 && npix * sizeof(float) * 2 * (size_t)want > ((size_t)4 << 30)) want -= 64;
             RB = std::min(want, 1024);
         }
