@@ -117,6 +117,7 @@ struct upsp_bvh {
     upsp_bvh_info info;
     int device = 0;
     int stats_on = 0;
+    bool batch_warmed = false;     // the first large batch query swept the tree through the caches (prefetch_bvh)
     uint64_t last_stats[3] = {0, 0, 0};
     uint64_t last_primary = 0, last_retry_nodes = 0;
     const upsp_bvh *shared_from = nullptr;   // upsp_bvh_share: the tree / adjacency arrays belong to that handle
