@@ -1052,9 +1052,13 @@ def main():
     lean_st = {"repaired": None, "finals_due": False, "pixels_set": False}
 
     def lean_finals():
-        """finals of the step before (the accumulators as its pass B left them)"""
+        """finals of the step before (the accumulators as its pass B left them).  N > 1: the all-reduce of the two sum vectors in
+        front of them, on the stream this is called on -- the side stream, not the frame loop's: only the finals need the complete
+        sums, and a collective in the main stream is a rendezvous of all ranks in front of every pass A."""
         if lean_st["finals_due"]:
-            pipe.finalize(F * world)
+            if chunked:
+                D.allreduce_sums(*pipe.accumulators())
+            lean_st["avg"] = pipe.finalize(F * world)[0]
             lean_st["finals_due"] = False
 
     class _NoEvent:                     # (lean schedule: an event record is a packet of its own on the main stream's queue, ~5 us
@@ -1203,7 +1207,8 @@ def main():
         if pixel_wire and not deferred:
             exchs[0].finish_pixels(s, ss)         # pass B of this rank's nodes over all frames: series + its slice of the sums
         _h.append(time.perf_counter())
-        D.allreduce_sums(s, ss)
+        if not lean:
+            D.allreduce_sums(s, ss)
         _h.append(time.perf_counter())
         if chunked and not pixel_wire:
             exch.finish()
@@ -1226,6 +1231,19 @@ def main():
             last_pix[0] = proj["pix"]
         return avg
 
+    def finish_run():
+        """what the last step left to do: the deferred exchange's series and sums, and the finals that ride on the NEXT step's side
+        stream in the lean arrangement"""
+        if not lean:
+            drain()
+            return
+        lean_finals()                           # finals of the sums the last step's pass B (or its drain) left
+        if ex_state["pending"] is not None:     # deferred: the last step's own exchange -- its sums start from zero like every step's
+            pipe.reset()
+            drain()
+            lean_st["finals_due"] = True
+            lean_finals()
+
     for _ in range(a.warmup):
         step(False)
 
@@ -1239,13 +1257,12 @@ def main():
         t0 = time.perf_counter()
         for _ in range(a.steps):
             step(True, events=not lean)
-        drain()                         # (deferred exchange: the last step's series and sums, inside the timed region)
-        lean_finals()                   # (the last step's finals, likewise)
+        finish_run()                    # (deferred exchange: the last step's series and sums; the last finals: inside the timed region)
         barrier()
         dt = time.perf_counter() - t0
     if lean:
         last_pix[0] = last_pix[0].clone()       # (a view of the pipeline's buffer: the repetitions below build into it again)
-    xcheck = None
+    xcheck = fcheck = None
     if chunked:
         for x in exchs:
             x.verify()                  # the travelling set did not change between the steps
@@ -1265,10 +1282,21 @@ def main():
             want = frames.view(torch.int16).reshape(F, -1)[:, pp.clamp(min=0)].T.to(torch.float32)
             got = o[pick][:, rank * F:(rank + 1) * F]
             ok = bool(torch.equal(got[vis], want[vis])) and bool(torch.isnan(got[~vis]).all())
-        t = torch.tensor([1 if ok else 0], device="cuda", dtype=torch.int32)
+        fin_ok = True
+        if lean and lean_st.get("avg") is not None and nn > 0 and F > 0:
+            # the finals of the last exchange (sums all-reduced over the ranks) against the series this rank holds for its own nodes:
+            # avg[n] = mean of row n over ALL frames of the run, NaN for the nodes no ray sees
+            torch.cuda.synchronize()
+            rows = o[pick].double()
+            want_avg = rows.mean(1).float()
+            got_avg = lean_st["avg"][n0:n0 + nn][pick]
+            seen = ~torch.isnan(want_avg)
+            fin_ok = bool(torch.isnan(got_avg[~seen]).all()) and bool(torch.allclose(got_avg[seen], want_avg[seen], rtol=1e-6, atol=0.0))
+        t = torch.tensor([1 if ok else 0, 1 if fin_ok else 0], device="cuda", dtype=torch.int32)
         if world > 1 or force_coll:
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        xcheck = bool(t.item())
+        xcheck = bool(t[0].item())
+        fcheck = bool(t[1].item()) if lean else None
     bvh.check()                         # no walk ran past its round cap (UPSP_ERR_INTERNAL otherwise)
     pc = engine.projection_counts(bvh)
     primary_rays, retry_nodes = pc["primary_rays"], pc["retry_nodes"]
@@ -1284,8 +1312,7 @@ def main():
     for _ in range(a.steps):
         step(lean)                      # (lean: the per-phase events of the breakdown are recorded here, not in the timed steps)
     last_pix[0] = keep_pix
-    drain()
-    lean_finals()
+    finish_run()
     barrier()
     _capi.timing_enable(False)
     for e in ev_log:
@@ -1463,6 +1490,7 @@ def main():
     }
     if chunked:
         out["exchange_self_check"] = xcheck      # every rank: its own frames' columns of its series slice == frame[pix], NaN rows
+        out["exchange_finals_check"] = fcheck    # every rank: finals (all-reduced sums) of its nodes == mean of their complete series
     if world > 1 or force_coll:
         cr = D.comm_ranks()
         out["rccl_nranks"] = None if cr is None else cr[1]       # ncclCommCount of the communicator the exchanges ran on

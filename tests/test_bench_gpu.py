@@ -64,6 +64,7 @@ def test_bench_two_ranks_on_one_gpu(gpu_lib, rccl_shim):
     from conftest import one_gpu_ranks_env
     d = run_bench(["--gpus", "2", "--row-wire", "--small", "--steps", "2", "--warmup", "1"], env=one_gpu_ranks_env(rccl_shim))
     assert d["n_gpus"] == 2 and d["exchange_self_check"] is True and d["rccl_nranks"] == 2
+    assert d["exchange_finals_check"] in (True, None)       # (True with the pixel-series wire: finals of the all-reduced sums)
     assert d["exchange_bytes_per_step"]["transport"].startswith("C ABI") and d["exchange_bytes_per_step"]["sent_to_other_ranks_this_run"] > 0
     assert d["config"]["exchange"] == "4 chunks, visible rows as u16"
     assert d["config"]["parallelism"] == "frames sharded x2"
@@ -139,6 +140,7 @@ def test_bench_rank_processes_on_one_gpu(gpu_lib, rccl_shim, world, extra):
     env = {"UPSP_BENCH_BACKEND": "gloo", "UPSP_BENCH_ONE_GPU": "1", "UPSP_RCCL_LIBRARY": rccl_shim}
     d = run_bench(["--gpus", str(world), "--small", "--steps", "2", "--warmup", "1"] + extra, env=env)
     assert d["n_gpus"] == world and d["rccl_nranks"] == world and d["exchange_self_check"] is True
+    assert d["exchange_finals_check"] in (True, None)
     x = d["exchange_bytes_per_step"]
     assert x["transport"].startswith("C ABI") and x["sent_to_other_ranks_this_run"] > 0
     assert d["config"]["parallelism"] == "frames sharded x%d" % world
