@@ -2892,6 +2892,10 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
         Scene sc2 = sc1;
         sc2.desc_cap = 4;       // (residual retries: 0.179 -> 0.145 ms at 4 rounds in round 2)
         sc2.chunk = 64;   // few rays are left (~3.5 %; 16 lanes per wave and 16-ray chunks: 0.37 instead of 0.21 ms)
+        // the few thousand residual rays over ONE wave per SIMD, not three: alone the pass takes 8 % longer (4 rays to a wave instead
+        // of 1-2, each wave as long as its longest chain), but in the frame loop's schedule it runs beside pass A, which needs its
+        // eight workgroups per compute unit -- pass A 0.376 -> 0.361 ms, the step 0.810 -> 0.798 (256 or 96 waves in all: the same step)
+        sc2.pack_waves = 4u * (unsigned)(props().cus > 0 ? props().cus : 256);
         {
             KTimed kt("projection_kernel<retry>", st);
             if (b->stats_on) UPSP_LAUNCH_PROJ(true, 2, grid1, sc2); else UPSP_LAUNCH_PROJ(false, 2, grid1, sc2);
