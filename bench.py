@@ -967,6 +967,11 @@ def main():
     # (columns F .. ld of that allocation are padding: the row pass may end every row on a whole 128-byte line)
     row_padding = rows_t is not None and os.environ.get("UPSP_BENCH_ROW_PADDING", "1") != "0"
     pipe.set_row_padding(row_padding)
+    # pass A in two launches where it runs beside the projection build (the default schedule): the tiles nobody reads as one-wave
+    # workgroups without LDS -- step 0.799 -> 0.773 ms; alone on the device (--serial) the one-launch form is the faster one
+    # (the N > 1 loop keeps one launch: 1.07 against 1.10 ms per step in the one-rank rehearsal -- its pass A runs beside less of the build)
+    if not a.serial and not a.registration and not chunked and os.environ.get("UPSP_BENCH_SCAN_SPLIT", "1") != "0":
+        pipe.set_scan_split(True)
     torch.cuda.synchronize()
 
     ev = lambda: torch.cuda.Event(enable_timing=True)

@@ -333,6 +333,12 @@ int upsp_pipeline_set_row_map_async(upsp_pipeline *pipe, const int32_t *d_rowmap
  * row pass ignores it (measured slower with it).  Off by default: intensity_transpose (cpp/exec/psp_process.cpp:2027-2032) has
  * no padding. */
 int upsp_pipeline_set_row_padding(upsp_pipeline *p, int on);
+/* Pass A of the one-camera streamed loop in two launches -- the tiles nobody reads as one-wave workgroups without LDS (16-byte loads),
+ * then the active tiles -- for a frame loop that shares the device with other kernels (a projection build on a stream of its own:
+ * bench.py's step 0.799 -> 0.773 ms).  Pass A alone on the device is faster in one launch (0.314 against 0.336 ms per 1000 frames of
+ * 1 Mpix): off by default.  Same results either way.  Takes effect when the hot-pixel scan is on and the frame has a multiple of 128
+ * pixels; ignored otherwise.  (A scheduling hint of this engine; fix_hot_pixels / project_frame have no counterpart.) */
+int upsp_pipeline_set_scan_split(upsp_pipeline *p, int on);
 
 /* Receiving side of the packed exchange: block d_src [nrows][ncols] f32 (contiguous) is copied
  * to rows d_rowidx[r] (int64) of d_dst (row pitch ld floats; add the column offset to d_dst). */

@@ -39,6 +39,11 @@ def oracle_loop(frames, pix, weight, skipped):
 while time.time() < t_end:
     rng = np.random.default_rng(seed)
     H, W = int(rng.integers(1, 40)) * 2, int(rng.integers(3, 150))
+    split = rng.random() < 0.25                     # pass A in two launches (needs whole 128-pixel tiles: H x W a multiple of 128)
+    if split:
+        H, W = int(rng.choice([2, 4, 8, 16, 32, 64])), int(rng.choice([64, 128, 192]))
+        if (H * W) % 128:
+            H *= 2
     n = int(rng.integers(1, 4000))
     F = int(rng.choice([1, 2, 63, 64, 65, int(rng.integers(1, 300)), int(rng.integers(300, 1100))]))
     if H * W * F > 6_000_000:
@@ -76,6 +81,8 @@ while time.time() < t_end:
     fused = int(rng.choice([0, 1, 2]))
     compact_mb = int(rng.choice([0, 0, 1]))
     pipe = engine.FramePipeline(ncams, W, H, n, fused_scan=fused, compact_mb=compact_mb)
+    if split:
+        pipe.set_scan_split(True)
     for c in range(ncams):
         pipe.set_projection(c, pix[c], None if weight is None else weight[c])
     if user_skip:

@@ -550,6 +550,8 @@ def test_prescan_with_candidate_map(gpu_lib, oracle, F, prepare):
     cand[:40] = 7 * W + 9
     weight = np.ones((1, n), np.float32)
     pipe = engine.FramePipeline(1, W, H, n)
+    if prepare:
+        pipe.set_scan_split(True)            # (pass A in two launches, as the bench's default schedule runs it; 64 x 130 pixels = 65 tiles)
     side, main = torch.cuda.Stream(), torch.cuda.current_stream()
     for trial in range(2):
         pix = cand.copy()

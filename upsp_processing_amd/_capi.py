@@ -96,6 +96,7 @@ SIGNATURES = {
     "upsp_pipeline_set_active_hint": (_i, [_vp, _vp, _vp]),
     "upsp_pipeline_prescan": (_i, [_vp, _vp, _i, _vp]),
     "upsp_pipeline_prepare_rows": (_i, [_vp, _vp]),
+    "upsp_pipeline_set_scan_split": (_i, [_vp, _i]),
     "upsp_pipeline_row_tables": (_i, [_vp, _vp, _vp]),
     "upsp_pipeline_projection_target": (_i, [_vp, _i, _vp]),
     "upsp_projection_candidate_pixels": (_i, [C.POINTER(Camera), _vp, _vp, _sz, _vp, _vp]),

@@ -870,6 +870,125 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+// Pass A in two launches (upsp_pipeline_set_scan_split: for a frame loop that shares the device with other kernels): the tiles nobody
+// reads as ONE-WAVE workgroups without LDS and with 16-byte loads (a lane takes 8 pixels of one frame, 16 lanes a tile row, the wave
+// four frames per load instruction, 16 loads in flight: the bytes in flight of the one-launch form's four-wave workgroup in a quarter of
+// the waves and none of its 17 KB of LDS), then the active tiles on a fixed grid (the body of scan_compact_kernel in a loop).  Pass A
+// needs eight of the one-launch workgroups per compute unit (alone, with padded LDS: 8 / 4 / 3 / 2 per CU -> 0.316 / 0.348 / 0.418 /
+// 0.571 ms) and does not get them beside a projection build, whose persistent traversal workgroups take waves and LDS first at high
+// priority: beside the build 0.362 -> 0.349 ms and the bench step 0.799 -> 0.773 ms (the build gains as well); ALONE the one-launch
+// form is faster, 0.314 against 0.336 ms -- a launch boundary and the fixed grid's loop --, hence a switch, off by default.
+// Needs npix % 128 == 0 (16-byte loads of whole tiles); otherwise the one-launch form runs.
+template <bool HOT>
+__device__ __forceinline__ void scan_hot_check(unsigned v, int f, size_t p0, unsigned thresh, unsigned max_hot,
+                                               unsigned *__restrict__ count, unsigned *__restrict__ pos)
+{
+    if (HOT && (((v & 0xFFFFu) >= thresh) | ((v >> 16) >= thresh))) {
+        if (__hip_atomic_load(&count[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= max_hot) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+                if (((v >> (16 * k)) & 0xFFFFu) >= thresh) {
+                    const unsigned slot = atomicAdd(&count[f], 1u);
+                    if (slot < (unsigned)kHotCap) pos[(size_t)f * kHotCap + slot] = (unsigned)(p0 + k);
+                }
+        }
+    }
+}
+typedef unsigned scan_v4u __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(64)
+    scan_inactive_kernel(const uint16_t *__restrict__ frames, size_t npix, int nframes_call, int ngroups, unsigned thresh, unsigned max_hot,
+                         unsigned *__restrict__ count, unsigned *__restrict__ pos, const unsigned *__restrict__ order, unsigned nt)
+{
+    const unsigned A = order[2u * nt], nI = nt - A, b = blockIdx.x;
+    if (b >= nI * (unsigned)ngroups) return;
+    const int g = (int)(b / nI);
+    const unsigned tl = order[b - (unsigned)g * nI];
+    const int nframes = min(64, nframes_call - 64 * g);
+    const int lane = threadIdx.x, r4 = lane >> 4, seg = lane & 15;
+    const size_t p0 = (size_t)tl * kFusedPix + 8u * (unsigned)seg;          // this lane's eight pixels
+    const uint16_t *fr = frames + (size_t)g * 64 * npix + p0;
+    scan_v4u v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int f = 4 * i + r4;
+        const scan_v4u z = {0u, 0u, 0u, 0u};
+        v[i] = f < nframes ? __builtin_nontemporal_load(reinterpret_cast<const scan_v4u *>(fr + (size_t)f * npix)) : z;
+    }
+    unsigned *cnt = count + 64 * g;
+    unsigned *ps = pos + (size_t)64 * g * kHotCap;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int f = 4 * i + r4;
+        const unsigned m = max(max(v[i].x & 0xFFFFu, v[i].x >> 16), max(v[i].y & 0xFFFFu, v[i].y >> 16));
+        const unsigned n = max(max(v[i].z & 0xFFFFu, v[i].z >> 16), max(v[i].w & 0xFFFFu, v[i].w >> 16));
+        if (max(m, n) >= thresh) {                          // (rare)
+            scan_hot_check<true>(v[i].x, f, p0, thresh, max_hot, cnt, ps);
+            scan_hot_check<true>(v[i].y, f, p0 + 2, thresh, max_hot, cnt, ps);
+            scan_hot_check<true>(v[i].z, f, p0 + 4, thresh, max_hot, cnt, ps);
+            scan_hot_check<true>(v[i].w, f, p0 + 6, thresh, max_hot, cnt, ps);
+        }
+    }
+}
+template <bool HOT>
+__global__ void __launch_bounds__(256)
+    scan_active_kernel(const uint16_t *__restrict__ frames, size_t npix, int nframes_call, int ngroups,
+                       const uint8_t *__restrict__ flag, const unsigned *__restrict__ tile_off,
+                       uint16_t *__restrict__ compact, unsigned cpitch, unsigned thresh, unsigned max_hot,
+                       unsigned *__restrict__ count, unsigned *__restrict__ pos, const unsigned *__restrict__ order, unsigned nt)
+{
+    __shared__ unsigned tile[64][kFusedPitch];   // [frame][pixel pair]
+    __shared__ int act_k[kFusedPix];             // compact index of the tile's pixels, -1 = nobody reads it
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned A = order[2u * nt], nI = nt - A, total = A * (unsigned)ngroups;
+    for (unsigned b2 = blockIdx.x; b2 < total; b2 += gridDim.x) {          // (uniform)
+        const int g = (int)(b2 / A);
+        const unsigned tl = order[nI + (b2 - (unsigned)g * A)];
+        const int nframes = min(64, nframes_call - 64 * g);
+        const uint16_t *fr = frames + (size_t)g * 64 * npix;
+        uint16_t *cmp = compact + 64 * g;
+        unsigned *cnt = HOT ? count + 64 * g : count;
+        unsigned *ps = HOT ? pos + (size_t)64 * g * kHotCap : pos;
+        const size_t p0 = (size_t)tl * kFusedPix + 2u * (unsigned)lane;
+        const bool in = p0 + 1 < npix;
+        const unsigned k0 = tile_off[tl];
+        unsigned v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int f = wave + 4 * i;
+            v[i] = (in && f < nframes) ? __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(fr + (size_t)f * npix + p0)) : 0u;
+        }
+        if (threadIdx.x < kFusedPix) {
+            const size_t p = (size_t)tl * kFusedPix + threadIdx.x;
+            const unsigned fl = p < npix ? flag[p] : 0u;
+            act_k[threadIdx.x] = fl ? (int)(k0 + (fl & 0x7Fu)) : -1;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int f = wave + 4 * i;
+            tile[f][lane] = v[i];
+            scan_hot_check<HOT>(v[i], f, p0, thresh, max_hot, cnt, ps);
+        }
+        __syncthreads();
+        const int grp = threadIdx.x >> 3, j8 = threadIdx.x & 7;
+#pragma unroll
+        for (int r = 0; r < kFusedPix / 32; ++r) {
+            const int o = grp + 32 * r;
+            const int k = act_k[o];
+            if (k < 0) continue;
+            const unsigned col = (unsigned)o >> 1, sh = 16u * ((unsigned)o & 1u);
+            unsigned w[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned a = (tile[8 * j8 + 2 * q][col] >> sh) & 0xFFFFu;
+                const unsigned bb = (tile[8 * j8 + 2 * q + 1][col] >> sh) & 0xFFFFu;
+                w[q] = a | (bb << 16);
+            }
+            *reinterpret_cast<uint4 *>(cmp + (size_t)k * cpitch + 8 * j8) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        __syncthreads();                          // (the tile is read: the next trip may overwrite it)
+    }
+}
+
 // Pass B, whole rows.  The series of a node over all (<= kGroupFramesMax) frames of a call sits in
 // the compact buffer, so its row piece is written once, contiguously: LPR lanes per row (lane l:
 // frames 4 l .. 4 l + 3), 256 / LPR rows per sweep, ROWS sweeps per workgroup.  Rows of nodes without a
@@ -1851,7 +1970,7 @@ int group_frames_max() { return kGroupFramesMax; }
 // positions per frame.
 int launch_scan_compact(uint16_t *d_frames, size_t npix, int nframes, bool hot, int thresh, int max_hot,
                         const uint8_t *d_flag, const unsigned *d_off, const unsigned *d_order, uint16_t *d_compact,
-                        unsigned cpitch, int col, unsigned *d_count, unsigned *d_pos, hipStream_t st)
+                        unsigned cpitch, int col, unsigned *d_count, unsigned *d_pos, hipStream_t st, bool split)
 {
     if (nframes <= 0) return UPSP_OK;
     if (max_hot < 0 || max_hot >= kHotCap) return fail(UPSP_ERR_INVALID, "max_hot must be in [0,63]");
@@ -1860,6 +1979,15 @@ int launch_scan_compact(uint16_t *d_frames, size_t npix, int nframes, bool hot, 
     const unsigned ntiles = (unsigned)tilemap_tiles(npix);
     KTimed kt("scan_compact_kernel", st);
     const bool lin = scan_active_last() && d_order;
+    if (lin && split && hot && (npix % kFusedPix) == 0) {
+        const unsigned agrid = (unsigned)std::min<size_t>((size_t)ntiles * ngroups, 8u * 256u);
+        hipLaunchKernelGGL(scan_inactive_kernel, dim3(ntiles * (unsigned)ngroups), dim3(64), 0, st, d_frames, npix, nframes, ngroups,
+                           (unsigned)thresh, (unsigned)max_hot, d_count, d_pos, d_order, ntiles);
+        hipLaunchKernelGGL(scan_active_kernel<true>, dim3(agrid), dim3(256), 0, st, d_frames, npix, nframes, ngroups, d_flag, d_off,
+                           d_compact + col, cpitch, (unsigned)thresh, (unsigned)max_hot, d_count, d_pos, d_order, ntiles);
+        UPSP_HIP_CHECK(hipGetLastError());
+        return UPSP_OK;
+    }
     const dim3 grid = lin ? dim3(ntiles * (unsigned)ngroups) : dim3(ntiles, (unsigned)ngroups);
     if (hot)
         hipLaunchKernelGGL(scan_compact_kernel<true>, grid, dim3(256), 0, st, d_frames, npix, nframes,

@@ -49,7 +49,7 @@ int launch_amap_nodes(const int32_t *d_pix, size_t nnodes, const uint8_t *d_flag
 int group_frames_max();    // frames per pass B (whole rows) of the one-camera streamed schedule
 int launch_scan_compact(uint16_t *d_frames, size_t npix, int nframes, bool hot, int thresh, int max_hot,
                         const uint8_t *d_flag, const unsigned *d_off, const unsigned *d_order, uint16_t *d_compact,
-                        unsigned cpitch, int col, unsigned *d_count, unsigned *d_pos, hipStream_t st);
+                        unsigned cpitch, int col, unsigned *d_count, unsigned *d_pos, hipStream_t st, bool split = false);
 // cold_series: the compact series were not written a moment ago (they come from HBM, not from the Infinity Cache): every
 // sweep's series are requested up front
 // fresh_acc: the accumulators hold nothing yet (reset, untouched since): they are written, not added to

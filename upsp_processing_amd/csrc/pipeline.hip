@@ -62,6 +62,7 @@ struct upsp_pipeline {
     bool tilemap_valid = false;
     // candidate map (upsp_pipeline_set_active_hint): the map outlives projection changes, only node_k is redone
     bool hint_active = false, node_k_valid = false;
+    bool scan_split = false;         // pass A in two launches (upsp_pipeline_set_scan_split)
     // pass A already run by upsp_pipeline_prescan for these frames (consumed by the next matching process call)
     const uint16_t *prescan_frames = nullptr;
     int prescan_n = 0;
@@ -392,6 +393,13 @@ int upsp_pipeline_set_row_map_async(upsp_pipeline *p, const int32_t *d_rowmap, v
     return set_row_map_impl(p, d_rowmap, true, (hipStream_t)stream);
 }
 
+int upsp_pipeline_set_scan_split(upsp_pipeline *p, int on)
+{
+    if (!p) return fail(UPSP_ERR_INVALID, "null pipeline");
+    p->scan_split = on != 0;
+    return UPSP_OK;
+}
+
 int upsp_pipeline_set_row_padding(upsp_pipeline *p, int on)
 {
     if (!p) return fail(UPSP_ERR_INVALID, "null pipeline");
@@ -574,7 +582,7 @@ static int streamed_pass_a(upsp_pipeline *p, uint16_t *fr, size_t npix, int s0, 
     const bool hot = p->opts.hot_enable != 0;
     return launch_scan_compact(fr + (size_t)s0 * npix, npix, ns, hot, p->opts.hot_thresh, p->opts.hot_max, p->d_aflag,
                                p->d_tile_off, p->d_tile_order, p->d_compact, cp, 0,
-                               hot ? p->d_hot_count + s0 : nullptr, hot ? p->d_hot_pos + (size_t)s0 * 64 : nullptr, st);
+                               hot ? p->d_hot_count + s0 : nullptr, hot ? p->d_hot_pos + (size_t)s0 * 64 : nullptr, st, p->scan_split);
 }
 
 // fix_hot_pixels for the frames of a pass A group, between pass A (which counted and listed the hot pixels) and pass B: the frames

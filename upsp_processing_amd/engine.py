@@ -418,6 +418,11 @@ class FramePipeline:
         (upsp_pipeline_set_row_padding: whole 128-byte lines at the end of every row)."""
         check(lib().upsp_pipeline_set_row_padding(self._h, 1 if on else 0))
 
+    def set_scan_split(self, on=True):
+        """Pass A in two launches (upsp_pipeline_set_scan_split): for a frame loop that runs beside other kernels, e.g. a projection
+        build on a stream of its own; slower when pass A has the device to itself."""
+        check(lib().upsp_pipeline_set_scan_split(self._h, 1 if on else 0))
+
     def set_overlap_source(self, src):
         """P3D adjust_solution: src int32 [N] (grids.P3DModel.overlap_source()); None = off."""
         self._src = None if src is None else _dev(src, torch.int32)
