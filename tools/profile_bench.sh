@@ -62,6 +62,10 @@ for name, v in res.items():
             n = v.get("calls", 1)
             traffic[key] = (traffic.get(key, 0.0) * weight.get(key, 0) + b * n) / (weight.get(key, 0) + n)
             weight[key] = weight.get(key, 0) + n
+# pass A in two launches (upsp_pipeline_set_scan_split): one "launch" of bench.py's scan_compact_kernel entry = the sum of the two
+parts = [res[k] for k in res if k.startswith(("scan_inactive_kernel", "scan_active_kernel"))]
+if parts and all("FETCH_SIZE_KB_per_launch" in v and "WRITE_SIZE_KB_per_launch" in v for v in parts):
+    traffic["scan_compact_kernel"] = sum((2 * v["FETCH_SIZE_KB_per_launch"] + v["WRITE_SIZE_KB_per_launch"]) * 1024 for v in parts)
 summary = {"bench_args": " ".join(args), "kernels": res, "traffic_bytes_per_launch": traffic,
            "note": "rocprofv3 --kernel-trace --stats (durations) and two separate --pmc passes (FETCH_SIZE, WRITE_SIZE, unit KB); "
                    "traffic = FETCH x 2 for the streaming kernels (gfx950 reports half of wide coalesced reads) + WRITE"}
