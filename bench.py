@@ -1441,6 +1441,10 @@ def main():
 
     sched = ("projection build, then hot-pixel scan + gather kernels per 64-frame sub-batch"
              if (a.two_kernel or a.registration) else
+             ("the projection build of the NEXT step on a high-priority stream of its own (with the candidate-pixel map, the restore of the "
+              "hot pixels, the finals, the projection's hand-over and the node -> row sweep), the frame loop's stream carries pass A (scan + "
+              "compact pixel series of the candidate pixels%s), the hot-pixel repair and pass B (whole rows) only"
+              % (", in two launches" if (lean and not chunked) else "")) if (overlap and lean) else
              "the ray casting of the projection build on a high-priority stream of its own, pass A (scan + compact pixel series of the "
              "candidate pixels) beside it, then pass B (whole rows)" if overlap else
              "projection build, then pass A (scan + compact pixel series) and pass B (whole rows) per <= 1024 frames")
