@@ -970,7 +970,8 @@ def main():
     # pass A in two launches where it runs beside the projection build (the default schedule): the tiles nobody reads as one-wave
     # workgroups without LDS -- step 0.799 -> 0.773 ms; alone on the device (--serial) the one-launch form is the faster one
     # (the N > 1 loop keeps one launch: 1.07 against 1.10 ms per step in the one-rank rehearsal -- its pass A runs beside less of the build)
-    if not a.serial and not a.registration and not chunked and os.environ.get("UPSP_BENCH_SCAN_SPLIT", "1") != "0":
+    scan_split_on = not a.serial and not a.registration and not chunked and os.environ.get("UPSP_BENCH_SCAN_SPLIT", "1") != "0"
+    if scan_split_on:
         pipe.set_scan_split(True)
     torch.cuda.synchronize()
 
@@ -1573,8 +1574,21 @@ def main():
             # frame loop on the sample the CPU just processed (same bits in: the frames as generated)
             d_sample = torch.as_tensor(sample.view(np.int16)).view(torch.uint16).cuda()
             p2 = engine.FramePipeline(1, size, size, N, fused_scan=2 if a.two_kernel else 0)
-            p2.set_projection(0, last_pix[0])
             rt = torch.empty((N, engine.series_ld(n_sample, whole_rows=True)), dtype=torch.float32, device="cuda")[:, :n_sample]
+            if lean:
+                # through the same entry points and kernel variants as the timed steps: pass A on the candidate-pixel map (in two
+                # launches where the steps ran it so), the projection handed over in the pipeline's own buffer, the node -> row
+                # sweep as a call of its own, whole-line rows
+                p2.set_scan_split(scan_split_on)
+                p2.set_row_padding(row_padding)
+                p2.set_active_hint(engine.candidate_pixels(cam, d_nodes, normals=d_nrm if cand_oblique else None, oblique_angle_deg=70.0))
+                p2.prescan(d_sample)
+                tgt = p2.projection_target(0)
+                tgt.copy_(last_pix[0])
+                p2.set_projection(0, tgt)
+                p2.prepare_rows()
+            else:
+                p2.set_projection(0, last_pix[0])
             p2.process(d_sample, first_frame=0, rows_t=rt, want_rows=False)
             gs, gss = [x.cpu().numpy() for x in p2.accumulators()]
             ok = ~np.isnan(ref["sum"])
