@@ -462,7 +462,7 @@ def registration_block(bvh, cam, d_nodes, d_nrm, d_tn, frames, restore, N, size,
             proj = engine.build_projection(bvh, cam, d_nodes, d_nrm, d_tn, 70.0, counts=False)
         main.wait_stream(side)
         proj["pix"].record_stream(main)
-        pipe.reset()
+        pipe.reset(deferred=True)
         pipe.set_projection(0, proj["pix"])
         pipe.process(frames, first_frame=0, rows_t=rows_t, want_rows=False)
         return pipe.finalize(F)
@@ -704,7 +704,7 @@ def multi_camera_main(a):
             pix = torch.stack([engine.build_projection(bvh, cam, d_nodes, d_nrm, d_tn, 70.0, counts=False)["pix"] for cam in cams])
             w = engine.projection_weights(pix, d_nodes, d_nrm, centers, "average_view")      # adjust_projection_for_weights
         e[1].record()
-        pipe.reset()
+        pipe.reset(deferred=True)
         for c in range(C):
             pipe.set_projection(c, pix[c], w[c])
         pipe.process(frames, first_frame=0, rows_t=rows_t, want_rows=False)
@@ -1144,7 +1144,7 @@ def main():
             proj = engine.build_projection(bvh, cam, d_nodes, d_nrm, d_tn, 70.0, counts=False)   # no host sync
         e[1].record()
         ht.append(time.perf_counter())
-        pipe.reset()
+        pipe.reset(deferred=True)
         if reg_side:
             main.wait_stream(side)
             for t in proj.values():
@@ -1245,7 +1245,7 @@ def main():
             return
         lean_finals()                           # finals of the sums the last step's pass B (or its drain) left
         if ex_state["pending"] is not None:     # deferred: the last step's own exchange -- its sums start from zero like every step's
-            pipe.reset()
+            pipe.reset(deferred=True)
             drain()
             lean_st["finals_due"] = True
             lean_finals()

@@ -324,14 +324,14 @@ int upsp_pipeline_set_row_map(upsp_pipeline *pipe, const int32_t *d_rowmap);
 int upsp_pipeline_set_row_map_async(upsp_pipeline *pipe, const int32_t *d_rowmap, void *stream);
 
 /* Row padding.  A node-major series buffer whose pitch ld_t is a multiple of 128 bytes usually ends every row with columns nobody
- * reads (engine.series_ld rounds 1000 frames up to 1024).  on != 0 declares: the columns between the last frame a process call
- * stores and the next 128-byte boundary of the row (never past ld_t) hold no data of the caller's, and the whole-row pass B may
- * write them (0, or NaN in the row of a node no camera sees).  A 4000-byte row piece then ends with a whole 128-byte line
- * instead of a quarter of one: 0.42 -> 0.37 ms per 1000 frames of the bench model.  Calls that fill a wider matrix chunk by
- * chunk in ascending column order on one stream stay correct (the next chunk overwrites what the previous one padded).  Used by
- * the one-camera whole-row passes (plain frames, registration as the last image stage, f32 or u16 series); the several-camera
- * row pass ignores it (measured slower with it).  Off by default: intensity_transpose (cpp/exec/psp_process.cpp:2027-2032) has
- * no padding. */
+ * reads (engine.series_ld rounds 1000 frames up to 1024).  on != 0 declares: the columns between the LAST frame of a row and its
+ * pitch hold no data of the caller's, and a whole-row pass B whose frames end inside the row's last 128-byte line may write them
+ * (0, or NaN in the row of a node no camera sees).  A 4000-byte row piece then ends with a whole 128-byte line instead of a
+ * quarter of one: 0.42 -> 0.37 ms per 1000 frames of the bench model.  Only a row's last line is ever padded -- a call that
+ * fills a column window elsewhere in a wider matrix (chunks in any order, on any stream, live data to its right) stores its own
+ * columns only.  Used by the one-camera whole-row passes (plain frames, registration as the last image stage, f32 or u16
+ * series); the several-camera row pass ignores it (measured slower with it).  Off by default: intensity_transpose
+ * (cpp/exec/psp_process.cpp:2027-2032) has no padding. */
 int upsp_pipeline_set_row_padding(upsp_pipeline *p, int on);
 /* Pass A of the one-camera streamed loop in two launches -- the tiles nobody reads as one-wave workgroups without LDS (16-byte loads),
  * then the active tiles -- for a frame loop that shares the device with other kernels (a projection build on a stream of its own:
@@ -401,7 +401,21 @@ int upsp_pipeline_set_ecc_iterations_out(upsp_pipeline *p, int32_t *d_iters);
 /* Accumulator access (device pointers to nnodes doubles each), used for the
  * cross-GPU sum that replaces MPI_Reduce (psp_process.cpp:1866-1872). */
 int upsp_pipeline_accumulators(upsp_pipeline *p, double **d_sum, double **d_sumsq);
+/* The same for a caller that will use them on `stream`: a pending upsp_pipeline_reset_deferred is carried out there
+ * (hipMemsetAsync) instead of after a wait for the whole device. */
+int upsp_pipeline_accumulators_async(upsp_pipeline *p, double **d_sum, double **d_sumsq, void *stream);
+/* Zeroes the two accumulators; they are zero when the call returns (it waits for the device: launches queued on any stream that
+ * add to them are finished first).  Pointers from upsp_pipeline_accumulators stay valid. */
 int upsp_pipeline_reset(upsp_pipeline *p);
+/* The same without touching the device: the accumulators are zeroed by whichever call of this pipeline uses them next, on that
+ * call's stream -- the one-camera streamed frame loop WRITES them in its first pass B instead (no fill launch, no read of
+ * 8 B x N: a step that re-raycasts saves a launch on the frame loop's stream); upsp_pipeline_finalize clears them on its
+ * stream, upsp_pipeline_accumulators waits for the device and clears them.  CONTRACT: between this call and that next call
+ * the contents behind pointers obtained EARLIER from upsp_pipeline_accumulators are undefined (stale sums) and must not be read,
+ * added to, or handed to upsp_allreduce_sums / upsp_exchange_finish_pixels -- fetch the pointers again with
+ * upsp_pipeline_accumulators (which performs the pending zeroing) first.  A process call that fails before its first row pass is
+ * queued leaves the reset pending. */
+int upsp_pipeline_reset_deferred(upsp_pipeline *p);
 /* avg = sum/N, rms = sqrt(sumsq/N) narrowed to f32 (psp_process.cpp:1933-1936) */
 int upsp_pipeline_finalize(upsp_pipeline *p, uint64_t nframes_total, float *d_avg,
                            float *d_rms, void *stream);

@@ -350,3 +350,31 @@ def test_cpp_driver_ranks(gpu_lib, rccl_shim, tmp_path, ranks, ncams, nframes, s
         outs[name] = tmp
     for n in CPP_FILES + (("cam02-uv",) if ncams == 2 else ()):
         assert open(os.path.join(outs["one"], "out", n), "rb").read() == open(os.path.join(outs["many"], "out", n), "rb").read(), n
+
+
+@pytest.mark.gpu
+def test_cpp_driver_ranks_failure_tears_the_job_down(gpu_lib, rccl_shim, tmp_path):
+    """A rank that fails AFTER the communicator exists (short .mraw read on the rank that holds the last frames) must end the whole
+    `-ranks=N` job like mpiexec does: the launcher reaps with waitpid(-1), stops the surviving ranks -- which sit in
+    upsp_allreduce_sums / upsp_exchange_* waiting for the dead one -- and returns the failure's exit code; its private id directory
+    is gone afterwards (advisor finding, round 5)."""
+    import glob
+    import subprocess
+    import time
+    import torch
+    exe = _cpp_exe()
+    env = dict(os.environ)
+    if torch.cuda.device_count() < 2:
+        env.update(UPSP_ONE_GPU="1", UPSP_RCCL_LIBRARY=rccl_shim)
+    tmp = str(tmp_path / "case")
+    os.makedirs(tmp)
+    write_case(tmp, nframes=14, size=(192, 160), ncams=1)
+    mraw = os.path.join(tmp, "cam01.mraw")
+    os.truncate(mraw, int(os.path.getsize(mraw) * 0.6))
+    before = set(glob.glob("/tmp/upsp_psp_*"))
+    t0 = time.time()
+    r = subprocess.run([exe, "-input_file=%s/run.inp" % tmp, "-h5_out=x", "-ranks=2"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2, (r.returncode, r.stderr[-2000:])
+    assert "short read" in r.stderr and "stopping the other" in r.stderr, r.stderr[-2000:]
+    assert time.time() - t0 < 120
+    assert set(glob.glob("/tmp/upsp_psp_*")) == before

@@ -205,6 +205,35 @@ int main(int argc, char **argv)
         Q[kept++] = q;
     }
     printf("rays on the list %ld: wide steps %.2f + triangle tests %.2f per ray, longest %d steps\n", kept, sn / kept, st / kept, longest);
+    /* argv[5]: ray -> wave assignment.  0 = list order (default); B > 0 = stable counting sort of the list into B bins by the ray's own
+       step count (what a REPEATED build knows from the build before it: length-homogeneous waves), bin edges = equal-population
+       quantiles; -1 = full sort by step count (the floor of any binning) */
+    const int bins = argc > 5 ? atoi(argv[5]) : 0;
+    if (bins != 0 && kept > 0) {
+        int *hist = calloc((size_t)longest + 2, sizeof(int));
+        for (long i = 0; i < kept; ++i) ++hist[Q[i].n];
+        int *bin_of = calloc((size_t)longest + 2, sizeof(int));
+        const int B = bins < 0 ? longest + 1 : bins;
+        if (bins < 0) { for (int n = 0; n <= longest; ++n) bin_of[n] = n; }
+        else {
+            long acc = 0; int b = 0;
+            for (int n = 0; n <= longest; ++n) {
+                bin_of[n] = b;
+                acc += hist[n];
+                while (b + 1 < B && acc >= (long)((double)kept * (b + 1) / B)) ++b;
+            }
+            printf("bins by step count (upper edges):");
+            for (int n = 0; n < longest; ++n) if (bin_of[n] != bin_of[n + 1]) printf(" %d", n);
+            printf(" %d\n", longest);
+        }
+        long *start = calloc((size_t)B + 1, sizeof(long));
+        for (long i = 0; i < kept; ++i) ++start[bin_of[Q[i].n] + 1];
+        for (int b = 0; b < B; ++b) start[b + 1] += start[b];
+        seq_t *S = malloc(sizeof(seq_t) * (size_t)kept);
+        for (long i = 0; i < kept; ++i) S[start[bin_of[Q[i].n]]++] = Q[i];
+        memcpy(Q, S, sizeof(seq_t) * (size_t)kept);
+        free(S); free(start); free(bin_of); free(hist);
+    }
     const long nwaves = (kept + nl - 1) / nl;
     lane_t L[64];
 #define RUN(name, call)                                                                     \

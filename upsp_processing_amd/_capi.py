@@ -109,7 +109,9 @@ SIGNATURES = {
     "upsp_feed_release": (_i, [_vp, _i, _vp]),
     "upsp_pipeline_process_u16": (_i, [_vp, C.POINTER(_vp), _i, _i64, _vp, _i64, _i64, _vp, _vp]),
     "upsp_pipeline_accumulators": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
+    "upsp_pipeline_accumulators_async": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), _vp]),
     "upsp_pipeline_reset": (_i, [_vp]),
+    "upsp_pipeline_reset_deferred": (_i, [_vp]),
     "upsp_pipeline_finalize": (_i, [_vp, C.c_uint64, _vp, _vp, _vp]),
     "upsp_fix_hot_pixels": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "upsp_project_frame_u16": (_i, [_vp, _vp, _vp, _sz, _vp, _vp]),

@@ -614,12 +614,16 @@ int upsp_exchange_create(upsp_comm *c, int64_t nframes_total, int64_t nnodes, in
         // LOW priority: a block has until the pass is finished to arrive (with two exchanges in turn: a whole step), and RCCL's
         // workgroups should not hold compute units the frame loop's kernels are waiting for -- one GPU through one-rank RCCL, deferred
         // exchange, one call: 1.19 ms per step against 1.29 at normal priority (plain loop 0.95-1.00; tools/gpu_n1_ab.sh).
-        // UPSP_XFER_PRIORITY=normal|high: measurement switch.
+        // That was measured with ONE rank only (this pool has one GPU per box).  Between GPUs a starved low-priority RCCL kernel
+        // also stalls the PEER's send / receive kernels, which spin on its compute units: until that has been measured on a
+        // node with >= 2 GPUs a group of more than one rank keeps NORMAL priority.  UPSP_XFER_PRIORITY=low|normal|high overrides.
         const char *pe = getenv("UPSP_XFER_PRIORITY");
         int least = 0, greatest = 0;
         const bool have_range = hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
-        if (have_range && !(pe && pe[0] == 'n'))
-            e = hipStreamCreateWithPriority(&c->xfer->st, hipStreamNonBlocking, (pe && pe[0] == 'h') ? greatest : least);
+        const bool want_low = pe ? pe[0] == 'l' : c->world == 1;
+        const bool want_high = pe && pe[0] == 'h';
+        if (have_range && (want_low || want_high))
+            e = hipStreamCreateWithPriority(&c->xfer->st, hipStreamNonBlocking, want_high ? greatest : least);
         else
             e = hipStreamCreateWithFlags(&c->xfer->st, hipStreamNonBlocking);
     }

@@ -407,14 +407,16 @@ int upsp_pipeline_set_row_padding(upsp_pipeline *p, int on)
     return UPSP_OK;
 }
 
-// columns a whole-row pass B may store for `ns` frames that start at column `c0` of rows of pitch ld: up to the next 128-byte
-// line (32 floats / 64 u16) when the caller declared those columns padding
+// columns a whole-row pass B may store for `ns` frames that start at column `c0` of rows of pitch ld: up to the END OF THE ROW when
+// that is the next 128-byte line (32 floats / 64 u16) and the caller declared the pitch padding writable.  Only the row's last
+// line is ever padded: a call that fills a window in the middle of a wider matrix (chunks in any order, live data to the right)
+// stores its own columns and nothing else.
 static int padded_store(const upsp_pipeline *p, int64_t c0, int ns, int64_t ld, int per_line)
 {
     if (!p->row_padding || (ld % per_line) != 0) return ns;
     const int64_t end = c0 + ns;
-    const int64_t stop = std::min<int64_t>(ld, (end + per_line - 1) / per_line * per_line);
-    return ns + (int)(stop - end);
+    const int64_t stop = (end + per_line - 1) / per_line * per_line;
+    return stop == ld ? ns + (int)(stop - end) : ns;
 }
 
 int upsp_pipeline_set_reference(upsp_pipeline *p, int cam, const float *d_ref32f)
@@ -444,7 +446,17 @@ static int acc_zero_now(upsp_pipeline *p, hipStream_t st, bool on_stream);
 int upsp_pipeline_accumulators(upsp_pipeline *p, double **d_sum, double **d_sumsq)
 {
     if (!p) return fail(UPSP_ERR_INVALID, "null pipeline");
-    int rc = acc_zero_now(p, nullptr, false);      // (a reset that nothing has acted on yet: the caller is about to read or add)
+    int rc = acc_zero_now(p, nullptr, false);      // (a deferred reset that nothing has acted on yet: the caller is about to read or add)
+    if (rc != UPSP_OK) return rc;
+    if (d_sum) *d_sum = p->d_sum;
+    if (d_sumsq) *d_sumsq = p->d_sumsq;
+    return UPSP_OK;
+}
+
+int upsp_pipeline_accumulators_async(upsp_pipeline *p, double **d_sum, double **d_sumsq, void *stream)
+{
+    if (!p) return fail(UPSP_ERR_INVALID, "null pipeline");
+    int rc = acc_zero_now(p, (hipStream_t)stream, true);      // (a pending deferred reset: cleared on the stream that will use them)
     if (rc != UPSP_OK) return rc;
     if (d_sum) *d_sum = p->d_sum;
     if (d_sumsq) *d_sumsq = p->d_sumsq;
@@ -468,18 +480,32 @@ int upsp_pipeline_set_ecc_iterations_out(upsp_pipeline *p, int32_t *d_iters)
     return UPSP_OK;
 }
 
-// The accumulators are zeroed by whoever touches them first after a reset: the streamed one-camera loop WRITES them in its first
-// pass B (no fill launch, no read of 8 B x N), everything else clears them first.
+// After upsp_pipeline_reset_deferred the accumulators are zeroed by whoever touches them first: the streamed one-camera loop WRITES
+// them in its first pass B (no fill launch, no read of 8 B x N), everything else clears them first -- on the stream that is about
+// to use them, or (no stream at hand: upsp_pipeline_accumulators) after waiting for the device, because a null-stream memset is
+// not ordered against work queued on non-blocking streams.
 static int acc_zero_now(upsp_pipeline *p, hipStream_t st, bool on_stream)
 {
     if (!p->acc_unset) return UPSP_OK;
-    if (on_stream) UPSP_HIP_CHECK(hipMemsetAsync(p->d_sum, 0, sizeof(double) * 2 * p->acc_stride, st));
-    else UPSP_HIP_CHECK(hipMemset(p->d_sum, 0, sizeof(double) * 2 * p->acc_stride));
+    if (on_stream) {
+        UPSP_HIP_CHECK(hipMemsetAsync(p->d_sum, 0, sizeof(double) * 2 * p->acc_stride, st));
+    } else {
+        UPSP_HIP_CHECK(hipDeviceSynchronize());
+        UPSP_HIP_CHECK(hipMemset(p->d_sum, 0, sizeof(double) * 2 * p->acc_stride));
+        UPSP_HIP_CHECK(hipDeviceSynchronize());
+    }
     p->acc_unset = false;
     return UPSP_OK;
 }
 
 int upsp_pipeline_reset(upsp_pipeline *p)
+{
+    if (!p) return fail(UPSP_ERR_INVALID, "null pipeline");
+    p->acc_unset = true;
+    return acc_zero_now(p, nullptr, false);       // eager: zero when the call returns
+}
+
+int upsp_pipeline_reset_deferred(upsp_pipeline *p)
 {
     if (!p) return fail(UPSP_ERR_INVALID, "null pipeline");
     p->acc_unset = true;
@@ -936,8 +962,8 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
         rc = streamed_buffers(p, npix, nframes, st, &S, &cp);
         if (rc != UPSP_OK) return rc;
         // accumulators untouched since the last reset: the first pass B writes them
+        // (the flag is cleared once that pass B has been queued: a call that fails before leaves the reset pending)
         bool fresh = p->acc_unset;
-        p->acc_unset = false;
         PipelineGather g;
         g.ncams = 1;
         g.npix = npix;
@@ -965,7 +991,10 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
             g.rows_t16 = d_rows_t16 ? d_rows_t16 + col0 + s0 : nullptr;
             g.nstore = padded_store(p, col0 + s0, ns, ld_t, d_rows_t ? 32 : 64);
             if (rc == UPSP_OK) rc = launch_node_rows(g, p->d_node_k, p->d_compact, cp, st, false, fresh);
-            fresh = false;
+            if (rc == UPSP_OK && fresh) {
+                p->acc_unset = false;
+                fresh = false;
+            }
         }
         return rc;
     }

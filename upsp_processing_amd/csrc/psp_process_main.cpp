@@ -15,6 +15,8 @@
 // patcher's phase 0 and phase 2 are served by the Python driver (upsp_processing_amd/psp_process.py), which this program is
 // byte-compared with (tests/test_cli.py).  `-ranks=N` starts N rank processes (the reference's `mpiexec -n N`): frames shard
 // with apportion() (:1519-1529), the sums go through upsp_allreduce_sums and the time series through upsp_exchange_* (RCCL).
+#include <cerrno>
+#include <csignal>
 #include <fcntl.h>
 #include <hip/hip_runtime_api.h>
 #include <sys/stat.h>
@@ -517,9 +519,12 @@ int run_rank(const std::map<std::string, std::string> &flags, int rank, int worl
         uint8_t id[128];
         if (rank == 0) {
             CHECK(upsp_comm_unique_id(id));
+            // (O_EXCL in the launcher's private directory: nobody else's file or link is ever written through)
             const std::string tmp = id_file + ".tmp";
-            write_file(tmp, id, 128);
-            std::rename(tmp.c_str(), id_file.c_str());
+            const int fd = ::open(tmp.c_str(), O_CREAT | O_EXCL | O_WRONLY, 0600);
+            if (fd < 0 || ::write(fd, id, 128) != 128) throw std::runtime_error("cannot publish the communicator id in " + tmp);
+            ::close(fd);
+            if (std::rename(tmp.c_str(), id_file.c_str()) != 0) throw std::runtime_error("cannot publish the communicator id");
         } else {
             std::FILE *f = nullptr;
             for (int i = 0; i < 1200 && !(f = std::fopen(id_file.c_str(), "rb")); ++i) usleep(100000);
@@ -786,35 +791,78 @@ int run_rank(const std::map<std::string, std::string> &flags, int rank, int worl
 
 // `-ranks=N`: N rank processes (the `mpiexec -n N psp_process` of the reference's batch templates), started before this process
 // has touched a GPU; rank r runs on device r (UPSP_ONE_GPU=1: all on device 0 -- the tests, with UPSP_RCCL_LIBRARY naming an
-// RCCL that allows it).  Exit code: the first non-zero one.
+// RCCL that allows it).  Like mpiexec, the launcher tears the job down when one rank fails: the first rank that ends with a
+// non-zero status (or by a signal) gets its peers -- which would otherwise wait for it in upsp_allreduce_sums / upsp_exchange_*
+// for ever -- a SIGTERM and, after a grace period, a SIGKILL; the exit code is that first failure's.
+// NEVER under rocprofv3: the profiler's preloaded tool has initialised the GPU before main(), and fork + exec from such a process
+// is what the pool forbids.  Profile a rank by starting the N processes yourself with UPSP_RANK / UPSP_WORLD / UPSP_ID_FILE set
+// (INTEGRATION.md).  The communicator id travels through a file in a private 0700 directory (mkdtemp), written with O_EXCL.
 int spawn_ranks(int n, int argc, char **argv)
 {
-    char id_file[] = "/tmp/upsp_psp_id_XXXXXX";
-    const int tfd = mkstemp(id_file);
-    if (tfd >= 0) ::close(tfd);
-    ::unlink(id_file);
+    (void)argc;
+    char dir[] = "/tmp/upsp_psp_XXXXXX";
+    if (!mkdtemp(dir)) {
+        std::perror("mkdtemp");
+        return 2;
+    }
+    const std::string id_file = std::string(dir) + "/id";
     std::vector<pid_t> kids;
     for (int r = 0; r < n; ++r) {
         const pid_t p = fork();
         if (p == 0) {
             setenv("UPSP_RANK", std::to_string(r).c_str(), 1);
             setenv("UPSP_WORLD", std::to_string(n).c_str(), 1);
-            setenv("UPSP_ID_FILE", id_file, 1);
+            setenv("UPSP_ID_FILE", id_file.c_str(), 1);
             execv("/proc/self/exe", argv);
             std::perror("execv");
             _exit(127);
         }
+        if (p < 0) {
+            std::perror("fork");
+            break;
+        }
         kids.push_back(p);
     }
-    int rc = 0;
-    for (pid_t p : kids) {
+    int rc = (int)kids.size() == n ? 0 : 2;
+    size_t left = kids.size();
+    bool killing = rc != 0;
+    auto signal_all = [&](int sig) {
+        for (pid_t k : kids)
+            if (k > 0) ::kill(k, sig);
+    };
+    if (killing) signal_all(SIGTERM);
+    int grace = 0;                                   // tenths of a second since the SIGTERM
+    while (left > 0) {
         int st = 0;
-        waitpid(p, &st, 0);
-        const int code = WIFEXITED(st) ? WEXITSTATUS(st) : 128;
-        if (code && !rc) rc = code;
+        const pid_t p = waitpid(-1, &st, killing ? WNOHANG : 0);
+        if (p == 0) {                                // tearing down: poll, SIGKILL after 5 s
+            usleep(100000);
+            if (++grace == 50) signal_all(SIGKILL);
+            continue;
+        }
+        if (p < 0) {
+            if (errno == EINTR) continue;
+            break;
+        }
+        bool mine = false;
+        for (pid_t &k : kids)
+            if (k == p) {
+                k = -1;
+                mine = true;
+            }
+        if (!mine) continue;
+        --left;
+        const int code = WIFEXITED(st) ? WEXITSTATUS(st) : 128 + (WIFSIGNALED(st) ? WTERMSIG(st) : 0);
+        if (code && !killing) {                      // the first failure: its code, and the peers go down with it
+            rc = code;
+            killing = true;
+            std::fprintf(stderr, "psp_process: a rank ended with status %d: stopping the other %zu\n", code, left);
+            signal_all(SIGTERM);
+        }
     }
-    ::unlink(id_file);
-    (void)argc;
+    ::unlink(id_file.c_str());
+    ::unlink((id_file + ".tmp").c_str());
+    ::rmdir(dir);
     return rc;
 }
 

@@ -84,10 +84,15 @@ def lib_comm(group=None):
                 _capi.check(_capi.lib().upsp_comm_unique_id(buf))
             except _capi.UpspError as e:            # e.g. no librccl the library can resolve in this process
                 err = e
-        t = torch.tensor(list(buf), dtype=torch.uint8, device=dev)
+        # the id travels with an ok flag (byte 128): when rank 0 has no id to give, NO rank calls upsp_comm_create -- with an all-zero
+        # id the others would sit in ncclCommInitRank until the bootstrap timeout while rank 0 never joins
+        t = torch.tensor(list(buf) + [0 if err else 1], dtype=torch.uint8, device=dev)
         if world > 1:
             dist.broadcast(t, src=0, group=group)
-        ident = (C.c_uint8 * 128)(*t.cpu().tolist())
+        got = t.cpu().tolist()
+        ident = (C.c_uint8 * 128)(*got[:128])
+        if not got[128] and err is None:
+            err = ExchangeUnavailable("rank 0 could not create the communicator id")
         h = C.c_void_p()
         if err is None:
             try:

@@ -495,11 +495,14 @@ class FramePipeline:
     def accumulators(self):
         """(sum, sumsq) as float64 tensors aliasing the pipeline's device buffers."""
         a, b = C.c_void_p(), C.c_void_p()
-        check(lib().upsp_pipeline_accumulators(self._h, C.byref(a), C.byref(b)))
+        check(lib().upsp_pipeline_accumulators_async(self._h, C.byref(a), C.byref(b), _stream()))
         return _alias_f64(a.value, self.nnodes, self), _alias_f64(b.value, self.nnodes, self)
 
-    def reset(self):
-        check(lib().upsp_pipeline_reset(self._h))
+    def reset(self, deferred=False):
+        """Zero the accumulators.  deferred=True: no device work and no wait now -- the next call that uses them clears (or, in the
+        one-camera streamed loop, writes) them on its own stream; tensors from an earlier accumulators() call must not be read
+        or reduced until accumulators() has been called again (upsp_pipeline_reset_deferred, include/upsp_gpu.h)."""
+        check((lib().upsp_pipeline_reset_deferred if deferred else lib().upsp_pipeline_reset)(self._h))
 
     def finalize(self, nframes_total):
         avg = torch.empty(self.nnodes, dtype=torch.float32, device="cuda")
