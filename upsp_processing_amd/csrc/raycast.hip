@@ -349,6 +349,10 @@ struct Scene {
     // error, never a wedged device).
     unsigned round_cap;
     unsigned *err;                        // bit 0 one-lane traversal, bit 1 cooperative walk, bit 2 its one-thread fallback
+    // primary pass of a repeated projection build: rays listed in kRayBins bins by their previous step count (see RayBins)
+    unsigned short *steps_out;            // per node: steps of its primary ray (may be null)
+    unsigned nbins;                       // 0: one dense list in node order
+    unsigned bin_stride;                  // list of bin b = todo_rays + b * bin_stride
 };
 
 struct Trav {
@@ -730,6 +734,56 @@ __device__ __forceinline__ bool queue_init_spread(WaveQueue &q, unsigned *work, 
     return true;
 }
 
+// The binned dense list of a repeated projection build (kRayBins lists, see kRayBins): this wave's view of every bin and its
+// static chunk.  XCD x takes [cnt * x / 8, cnt * (x + 1) / 8) of EVERY bin -- node order inside a bin, so still one region of the
+// model per XCD -- and its waves take `pack` consecutive items of the concatenation of those pieces (short bins first).  Item j of
+// the local index space is looked up with bin_item().  Returns false (blo / blen = the whole bins, index space = their
+// concatenation, caller falls back to the queue) when the grid cannot take the list at once.
+constexpr int kWorkBinCountFwd = 22;
+__device__ __forceinline__ bool queue_init_binned(WaveQueue &q, unsigned *work, unsigned total, unsigned pack_waves, unsigned nbins)
+{
+    const unsigned pack = pack_waves ? min(max((total + pack_waves - 1u) / pack_waves, 1u), 64u) : 0u;
+    const unsigned wpb = blockDim.x >> 6;
+    const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+    unsigned lmax = 0, L = 0;
+#pragma unroll
+    for (unsigned b = 0; b < 8u; ++b) {
+        const unsigned cnt = b < nbins ? (unsigned)__builtin_amdgcn_readfirstlane((int)work[kWorkBinCountFwd + b]) : 0u;
+        lmax += cnt / 8u + 1u;
+        L += (unsigned)(((unsigned long long)cnt * (xcd + 1u)) >> 3) - (unsigned)(((unsigned long long)cnt * xcd) >> 3);
+    }
+    if (!pack || (unsigned long long)slots * wpb * pack < lmax) return false;
+    const unsigned long long first = ((unsigned long long)slot * wpb + (threadIdx.x >> 6)) * pack;
+    q.head = work;
+    q.total = L;
+    q.chunk = pack;
+    q.base = 0;
+    q.cur = (slot < slots && first < L) ? (unsigned)first : L;
+    q.end = min(q.cur + pack, L);
+    q.exhausted = true;
+    return true;
+}
+// item j of that index space -> position in the bins' lists (per_xcd: the index space queue_init_binned set up; else the
+// concatenation of the whole bins).  The bin counts are read again (six cached words per RAY, not per step): keeping the
+// sub-ranges of every bin in registers across the traversal loop cost the kernel 40 more spilled scalar registers.
+__device__ __forceinline__ unsigned bin_item(unsigned j, const unsigned *work, bool per_xcd, unsigned nbins, unsigned stride)
+{
+    const unsigned xcd = blockIdx.x & 7u;
+    unsigned idx = 0;
+    bool found = false;
+#pragma unroll
+    for (unsigned b = 0; b < 8u; ++b) {
+        const unsigned cnt = b < nbins ? work[kWorkBinCountFwd + b] : 0u;
+        const unsigned lo = per_xcd ? (unsigned)(((unsigned long long)cnt * xcd) >> 3) : 0u;
+        const unsigned hi = per_xcd ? (unsigned)(((unsigned long long)cnt * (xcd + 1u)) >> 3) : cnt;
+        const bool here = !found && j < hi - lo;
+        idx = here ? b * stride + lo + j : idx;
+        found |= here;
+        j -= found ? 0u : hi - lo;
+    }
+    return idx;
+}
+
 // First pass of a large batch: the rays that miss the root box (trav_begin's test; on the bench's pixel rays 4 of 5)
 // get their "no hit" record here, the others go on a dense list (one atomic per 2048 rays) that cast_kernel<LISTED>
 // works off with queue_init_spread.  Same records as the one-pass form.
@@ -918,6 +972,15 @@ constexpr int kWorkTodoCount = 12;   // rays witness_kernel could not decide
 constexpr int kWorkHeavyCount = 16;  // work items handed to heavy_kernel: [16] by the primary pass, [17] by the retry pass
 constexpr int kWorkWords = 32;
 constexpr unsigned kHeavyCap = 65536;
+// Length-homogeneous waves.  The 64 rays of a wave run in lock step and the wave lasts as long as its longest ray: on the bench model
+// a wave's longest ray has 36 steps for 25 of the mean (tools/probe/trav_policy_sim.c).  A build that is REPEATED on the same model
+// (model motion: bench.py rebuilds the projection every step) knows every ray's length from the build before it: the dense list of
+// the primary pass is cut into kRayBins bins by that step count (bin edges = sampled quantiles, step_edges_kernel), node order kept
+// inside a bin, and a wave takes 64 consecutive rays of ONE bin -- simulated: longest ray of a wave 36.3 -> 27 steps, rounds per
+// wave 54 -> 44.  Every XCD takes an eighth of EVERY bin (the long rays would otherwise all land on one XCD).  The first build of a
+// handle (or one with another node count) uses the plain list.  Ordering only: every ray's own sequence of steps is unchanged.
+constexpr unsigned kRayBins = 6;          // (the lists of bins 0..5 share d_todo_rays: 6 x nnodes entries)
+constexpr int kWorkBinCount = kWorkBinCountFwd;   // [22..27]: rays per bin
 
 // Step 1 (elementwise, fp64): cal.map_point_to_image + in-frame test
 // (psp_process.cpp:241-252).  The image point is parked in uv[].
@@ -1289,8 +1352,15 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(4, 8)))
     // draining a sparse item range through the queue (thousands of same-address atomics, chunks without a single ray)
     // cost more than the traversals -- the pass took 160 us with 1400 rays and 250 us with 193 k.
     WaveQueue q;
-    const bool packed = queue_init_spread(q, work, total, sc.pack_waves);
-    if (!packed) queue_init(q, work, total, sc.chunk, sc.xcd != 0 && PHASE == 0);   // (retry lists are not in mesh order)
+    const bool binned = PHASE == 0 && sc.nbins != 0u;      // a repeated build: the list in bins by the rays' previous lengths
+    bool bins_per_xcd = false;
+    if (binned) {
+        bins_per_xcd = queue_init_binned(q, work, total, sc.pack_waves, sc.nbins);
+        if (!bins_per_xcd) queue_init(q, work, total, sc.chunk, false);
+    } else {
+        const bool packed = queue_init_spread(q, work, total, sc.pack_waves);
+        if (!packed) queue_init(q, work, total, sc.chunk, sc.xcd != 0 && PHASE == 0);   // (retry lists are not in mesh order)
+    }
     Ray r;
     r.simple = true;   // idle lanes must not veto the wave-uniform fast path
     Trav s;
@@ -1305,7 +1375,7 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(4, 8)))
             unsigned it;
             const bool got = queue_take(q, !busy, it);
             if (got && PHASE == 0) {
-                it = todo_rays[it];
+                it = todo_rays[binned ? bin_item(it, work, bins_per_xcd, sc.nbins, sc.bin_stride) : it];
                 {
                     float dx = nodes[3 * (size_t)it] - cam.ox, dy = nodes[3 * (size_t)it + 1] - cam.oy,
                           dz = nodes[3 * (size_t)it + 2] - cam.oz;
@@ -1343,6 +1413,7 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(4, 8)))
                 const unsigned slot = atomicAdd(&work[kWorkHeavyCount + (PHASE ? 1 : 0)], 1u);
                 if (slot < kHeavyCap) {
                     sc.heavy_items[slot] = item;
+                    if (PHASE == 0 && sc.steps_out) sc.steps_out[item] = (unsigned short)0xFFFFu;      // (the last bin)
                     s.cur = kDone;
                     s.sp = 0;
                     busy = false;
@@ -1370,6 +1441,7 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(4, 8)))
                 if (PHASE == 0) {
                     // primary ray missed everything -> no entry (:261); hit on a foreign
                     // triangle -> jittered retries (listed by retry_list_kernel)
+                    if (sc.steps_out) sc.steps_out[node] = (unsigned short)min(max(s.steps, 1u), 0xFFFEu);
                     pix[node] = visible ? kPixVisible : (s.any ? kPixRetry : kPixNone);
                     if (sc.witness && !visible && s.any) sc.witness[node] = s.best_slot;
                 } else if (visible) {
@@ -1962,6 +2034,84 @@ __global__ void __launch_bounds__(256)
         }
 }
 
+// The dense list of the primary pass in kRayBins bins by the step count of the build before (steps_prev, 0 = unknown -> bin 0);
+// edges[j] = largest step count of bin j (j < kRayBins - 1).  One atomic per workgroup and non-empty bin.
+__global__ void __launch_bounds__(256)
+    primary_list_binned_kernel(const int32_t *__restrict__ pix, unsigned nnodes, const unsigned short *__restrict__ steps_prev,
+                               const unsigned *__restrict__ edges, unsigned *__restrict__ lists, unsigned stride, unsigned *work)
+{
+    __shared__ unsigned wave_cnt[kRayBins][kRetryListItems][4], bin_base[kRayBins];
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned base = blockIdx.x * (256u * kRetryListItems) + threadIdx.x;
+    unsigned e[kRayBins - 1];
+#pragma unroll
+    for (unsigned j = 0; j + 1 < kRayBins; ++j) e[j] = edges[j];
+    bool need[kRetryListItems];
+    unsigned bin[kRetryListItems], rank[kRetryListItems];
+#pragma unroll
+    for (int k = 0; k < kRetryListItems; ++k) {
+        const unsigned n = base + 256u * k;
+        need[k] = n < nnodes && pix[n] == kPixInFrame;
+        const unsigned st = need[k] ? (unsigned)steps_prev[n] : 0u;
+        unsigned b = 0;
+#pragma unroll
+        for (unsigned j = 0; j + 1 < kRayBins; ++j) b += st > e[j] ? 1u : 0u;
+        bin[k] = b;
+        rank[k] = 0;
+#pragma unroll
+        for (unsigned bb = 0; bb < kRayBins; ++bb) {
+            const unsigned long long m = __ballot(need[k] && b == bb);
+            if (need[k] && b == bb) rank[k] = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) wave_cnt[bb][k][wave] = (unsigned)__popcll(m);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < kRayBins) {
+        const unsigned bb = threadIdx.x;
+        unsigned tot = 0;
+        for (int k = 0; k < kRetryListItems; ++k)
+            for (int w = 0; w < 4; ++w) {   // exclusive prefix in place
+                const unsigned c = wave_cnt[bb][k][w];
+                wave_cnt[bb][k][w] = tot;
+                tot += c;
+            }
+        bin_base[bb] = tot ? atomicAdd(&work[kWorkBinCount + bb], tot) : 0u;
+        if (tot) atomicAdd(&work[kWorkPrimaryCount], tot);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kRetryListItems; ++k)
+        if (need[k]) lists[(size_t)bin[k] * stride + bin_base[bin[k]] + wave_cnt[bin[k]][k][wave] + rank[k]] = base + 256u * k;
+}
+
+// Bin edges for the NEXT build from a sample of this build's step counts (<= 16 384 nodes, every stride-th): quantiles k / kRayBins
+// of the nodes that cast a ray.  One workgroup; edges[kRayBins - 1] = 1 marks them valid.
+__global__ void __launch_bounds__(256)
+    step_edges_kernel(const unsigned short *__restrict__ steps, unsigned nnodes, unsigned *__restrict__ edges)
+{
+    constexpr unsigned kBuckets = 256;
+    __shared__ unsigned hist[kBuckets];
+    hist[threadIdx.x] = 0u;
+    __syncthreads();
+    const unsigned stride = max(1u, nnodes / 16384u);
+    for (unsigned n = threadIdx.x * stride; n < nnodes; n += 256u * stride) {
+        const unsigned st = steps[n];
+        if (st) atomicAdd(&hist[min(st, kBuckets - 1u)], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned total = 0;
+        for (unsigned i = 0; i < kBuckets; ++i) total += hist[i];
+        unsigned acc = 0, j = 0;
+        for (unsigned i = 0; i < kBuckets && j + 1 < kRayBins; ++i) {
+            acc += hist[i];
+            while (j + 1 < kRayBins && (unsigned long long)acc * kRayBins >= (unsigned long long)total * (j + 1)) edges[j++] = i;
+        }
+        while (j + 1 < kRayBins) edges[j++] = kBuckets;
+        edges[kRayBins - 1] = 1u;
+    }
+}
+
 // Step 4: retry outcome per listed node + the reference's ray count
 // (1 + index of the first successful retry, or 6).
 __global__ void projection_retry_outcome_kernel(int32_t *__restrict__ pix,
@@ -2095,6 +2245,9 @@ Scene make_scene(const upsp_bvh *b, size_t items, int grid)
     sc.path_ref = nullptr;
     sc.witness = nullptr;
     sc.hist = nullptr;
+    sc.steps_out = nullptr;
+    sc.nbins = 0;
+    sc.bin_stride = 0;
     // (UPSP_ROUND_CAP: the tests set it low to see the error come back)
     const int cap_env = env_int("UPSP_ROUND_CAP", 0);
     sc.round_cap = cap_env > 0 ? (unsigned)cap_env : 2u * (unsigned)b->info.n_gpu_nodes + 130u;
@@ -2579,6 +2732,8 @@ void upsp_bvh_destroy(upsp_bvh *b)
     if (b->d_heavy) (void)hipFree(b->d_heavy);
     if (b->d_heavy_scratch) (void)hipFree(b->d_heavy_scratch);
     if (b->d_cast_list) (void)hipFree(b->d_cast_list);
+    if (b->d_steps) (void)hipFree(b->d_steps);
+    if (b->d_step_edges) (void)hipFree(b->d_step_edges);
     if (b->d_stage) (void)hipFree(b->d_stage);
     if (b->h_stage) (void)hipHostFree(b->h_stage);
     if (b->stage_stream) (void)hipStreamDestroy(b->stage_stream);
@@ -2778,6 +2933,19 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
         UPSP_HIP_CHECK(hipMalloc(&b->d_todo_rays, sizeof(unsigned) * 6 * nnodes));
         b->retry_capacity = nnodes;
     }
+    // length-homogeneous waves (kRayBins): UPSP_RAY_BINS=0 switches them off (A/B)
+    static const int ray_bins_env = env_int("UPSP_RAY_BINS", 1);
+    const bool bins_on = ray_bins_env != 0 && nnodes < 0x7FFFFFFFull / kRayBins;
+    if (bins_on && b->steps_nnodes != nnodes) {
+        if (b->d_steps) (void)hipFree(b->d_steps);
+        b->d_steps = nullptr;
+        b->steps_valid = false;
+        b->steps_nnodes = 0;
+        UPSP_HIP_CHECK(hipMalloc(&b->d_steps, sizeof(uint16_t) * nnodes));
+        UPSP_HIP_CHECK(hipMemsetAsync(b->d_steps, 0, sizeof(uint16_t) * nnodes, st));
+        if (!b->d_step_edges) UPSP_HIP_CHECK(hipMalloc(&b->d_step_edges, sizeof(uint32_t) * kRayBins));
+        b->steps_nnodes = nnodes;
+    }
     if (!b->d_heavy) UPSP_HIP_CHECK(hipMalloc(&b->d_heavy, sizeof(unsigned) * 2 * kHeavyCap));      // (two lists)
     if (!b->d_heavy_scratch) UPSP_HIP_CHECK(hipMalloc(&b->d_heavy_scratch, kHeavyScratchBytes * kHeavyGridMax));
     UPSP_HIP_CHECK(hipMemsetAsync(b->d_work, 0, kWorkWords * sizeof(unsigned), st));
@@ -2845,11 +3013,21 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
         hipLaunchKernelGGL(project_nodes_kernel, egrid, eblock, 0, st, c, d_nodes, d_datanode,
                            (unsigned)nnodes, d_normals, oblique_thresh, cull, d_pix, d_uv);
     }
+    const bool binned = bins_on && b->steps_valid;
+    if (bins_on) sc.steps_out = b->d_steps;
     {
         KTimed kt("primary_list_kernel", st);
         const dim3 lgrid((unsigned)((nnodes + 256 * kRetryListItems - 1) / (256 * kRetryListItems)));
-        hipLaunchKernelGGL(retry_list_kernel<kPixInFrame>, lgrid, eblock, 0, st, (const int32_t *)d_pix,
-                           (unsigned)nnodes, b->d_todo_rays, (unsigned *)nullptr, b->d_work);
+        if (binned) {
+            sc.nbins = kRayBins;
+            sc.bin_stride = (unsigned)nnodes;
+            hipLaunchKernelGGL(primary_list_binned_kernel, lgrid, eblock, 0, st, (const int32_t *)d_pix, (unsigned)nnodes,
+                               (const unsigned short *)b->d_steps, (const unsigned *)b->d_step_edges, b->d_todo_rays, (unsigned)nnodes,
+                               b->d_work);
+        } else {
+            hipLaunchKernelGGL(retry_list_kernel<kPixInFrame>, lgrid, eblock, 0, st, (const int32_t *)d_pix,
+                               (unsigned)nnodes, b->d_todo_rays, (unsigned *)nullptr, b->d_work);
+        }
     }
 #define UPSP_LAUNCH_PROJ(STATS, PHASE, G, SC)                                                    \
     do {                                                                                         \
@@ -2867,6 +3045,10 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
         if (b->stats_on) UPSP_LAUNCH_PROJ(true, 0, grid, sc); else UPSP_LAUNCH_PROJ(false, 0, grid, sc);
     }
     UPSP_LAUNCH_HEAVY(0, sc)
+    if (bins_on) {      // bin edges for the next build of this handle, from the step counts the primary pass just wrote
+        hipLaunchKernelGGL(step_edges_kernel, dim3(1), dim3(256), 0, st, (const unsigned short *)b->d_steps, (unsigned)nnodes, b->d_step_edges);
+        b->steps_valid = true;
+    }
     UPSP_HIP_CHECK(hipMemsetAsync(b->d_work, 0, sizeof(unsigned), st));  // queue head
     {
         KTimed kt("retry_list_kernel", st);

@@ -121,6 +121,13 @@ struct upsp_bvh {
     uint64_t last_stats[3] = {0, 0, 0};
     uint64_t last_primary = 0, last_retry_nodes = 0;
     const upsp_bvh *shared_from = nullptr;   // upsp_bvh_share: the tree / adjacency arrays belong to that handle
+    // Length-homogeneous waves of a REPEATED projection build (round 6): the step count of every node's primary ray as the
+    // build before this one measured it (0 = no ray then), and the bin edges derived from a sample of them.  The next build's
+    // dense ray list is binned by it, so that the 64 rays of a wave end together.  Ordering only -- results do not depend on it.
+    uint16_t *d_steps = nullptr;
+    uint32_t *d_step_edges = nullptr;
+    size_t steps_nnodes = 0;
+    bool steps_valid = false;
 };
 
 #endif
