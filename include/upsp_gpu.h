@@ -325,9 +325,10 @@ int upsp_pipeline_set_row_map_async(upsp_pipeline *pipe, const int32_t *d_rowmap
 
 /* Row padding.  A node-major series buffer whose pitch ld_t is a multiple of 128 bytes usually ends every row with columns nobody
  * reads (engine.series_ld rounds 1000 frames up to 1024).  on != 0 declares: the columns between the LAST frame of a row and its
- * pitch hold no data of the caller's, and a whole-row pass B whose frames end inside the row's last 128-byte line may write them
- * (0, or NaN in the row of a node no camera sees).  A 4000-byte row piece then ends with a whole 128-byte line instead of a
- * quarter of one: 0.42 -> 0.37 ms per 1000 frames of the bench model.  Only a row's last line is ever padded -- a call that
+ * pitch hold no data of the caller's, and a whole-row pass B whose frames end within 512 bytes of the pitch (the end of the row: a
+ * pitch is a row length rounded up by less than that) may write up to the next 128-byte boundary (0, or NaN in the row of a node
+ * no camera sees).  A 4000-byte row piece then ends with a whole 128-byte line instead of a
+ * quarter of one: 0.42 -> 0.37 ms per 1000 frames of the bench model.  Only the end of a row is ever padded -- a call that
  * fills a column window elsewhere in a wider matrix (chunks in any order, on any stream, live data to its right) stores its own
  * columns only.  Used by the one-camera whole-row passes (plain frames, registration as the last image stage, f32 or u16
  * series); the several-camera row pass ignores it (measured slower with it).  Off by default: intensity_transpose
@@ -339,6 +340,51 @@ int upsp_pipeline_set_row_padding(upsp_pipeline *p, int on);
  * 1 Mpix): off by default.  Same results either way.  Takes effect when the hot-pixel scan is on and the frame has a multiple of 128
  * pixels; ignored otherwise.  (A scheduling hint of this engine; fix_hot_pixels / project_frame have no counterpart.) */
 int upsp_pipeline_set_scan_split(upsp_pipeline *p, int on);
+
+/* ---- one step of a frame loop whose projection is rebuilt per batch of frames --------------------------------------------------
+ * Model motion (docs/sphinx/known-issues.rst:18-30): the ray cast of create_projection_mat (cpp/exec/psp_process.cpp:167-355,
+ * called once per run at :1591-1640) has to be repeated while the frame loop (:1743-1851) runs.  upsp_pipeline_step queues ONE such
+ * step -- candidate pixels, active-pixel map, projection build, hand-over, pass A + hot-pixel repair, pass B, the previous step's
+ * finals -- with the build on a high-priority stream the pipeline owns and only pass A, the repair and pass B on the caller's
+ * `stream`; every ordering event between the two lives inside the library.  The host returns at once and may issue the next step
+ * (the device then works on two steps at a time: build s + 1 beside pass B of step s).  One camera, plain path (no weights, no
+ * image stage), nframes <= upsp_pipeline_series_frames_max.
+ *   d_rows_t == NULL   no pass B and no reset: the step ends with the repaired pixel series in the pipeline's compact buffer
+ *                      (upsp_pipeline_pixel_series on the same frames then returns it without another pass A): the multi-GPU
+ *                      frame loop, whose pass B runs on the owner of a node; that caller marks the end of ITS step with
+ *                      upsp_pipeline_step_mark_end (the point after which the side stream may rewrite the skipped flags).
+ *   d_avg / d_rms      finals of THIS step's sums over nframes_total frames (0: nframes), written while the NEXT step's build
+ *                      runs, or by upsp_pipeline_step_finish; NULL: none.
+ *   frames_hook        called (on the host, inside the call) with the side stream at the point where the previous step no longer
+ *                      reads or repairs d_frames and this step has not yet scanned them: the caller queues whatever refills the
+ *                      frames there (unpack of the next batch; bench.py puts the hot pixels back).
+ *   tail_hook          called with the side stream behind the node -> row sweep of the NEW projection and behind the end of the
+ *                      previous step: a caller's own per-step work that needs upsp_pipeline_row_tables or the complete sums of
+ *                      the step before (the multi-GPU loop: all-reduce + finals, the exchange's pixel table).
+ * upsp_pipeline_step_finish(p, stream): the finals the last step left, and `stream` ordered behind the side stream. */
+typedef void (*upsp_step_hook)(void *user, void *stream);
+typedef struct upsp_step_args {
+    upsp_bvh *bvh;
+    const upsp_camera *cam;
+    const float *d_nodes, *d_normals;     /* [3 nnodes] each */
+    const uint8_t *d_datanode;            /* may be NULL */
+    const int32_t *d_tri_nodes;           /* [3 ntris], the buffer given to upsp_bvh_set_tri_nodes */
+    float oblique_thresh;                 /* as for upsp_projection_build */
+    int32_t nframes;
+    uint16_t *d_frames;                   /* [nframes][H][W], repaired in place */
+    int64_t first_frame;
+    float *d_rows_t;                      /* node-major series, may be NULL (see above) */
+    int64_t ld_t, col0;
+    float *d_avg, *d_rms;                 /* may be NULL */
+    uint64_t nframes_total;
+    upsp_step_hook frames_hook;
+    void *frames_user;
+    upsp_step_hook tail_hook;
+    void *tail_user;
+} upsp_step_args;
+int upsp_pipeline_step(upsp_pipeline *p, const upsp_step_args *args, void *stream);
+int upsp_pipeline_step_mark_end(upsp_pipeline *p, void *stream);
+int upsp_pipeline_step_finish(upsp_pipeline *p, void *stream);
 
 /* Receiving side of the packed exchange: block d_src [nrows][ncols] f32 (contiguous) is copied
  * to rows d_rowidx[r] (int64) of d_dst (row pitch ld floats; add the column offset to d_dst). */

@@ -783,7 +783,7 @@ def test_pixel_series_on_prescanned_candidates(gpu_lib, oracle):
 
 @pytest.mark.parametrize("ncams", [1, 3])
 @pytest.mark.parametrize("F,chunks,extra", [(41, None, 0), (300, None, 0), (1000, None, 0), (1030, None, 0), (200, (70, 70, 60), 0),
-                                            (200, (60, 70, 70), 0), (41, None, 64), (1000, None, 32), (200, (70, 70, 60), 64)])
+                                            (200, (60, 70, 70), 0), (41, None, 128), (1000, None, 160), (200, (70, 70, 60), 128)])
 def test_row_padding(gpu_lib, oracle, F, chunks, ncams, extra):
     """upsp_pipeline_set_row_padding: the row pass may write the columns between the last frame of a ROW and its pitch when they
     share a 128-byte line -- only a row's last line is ever padded.  Same frames through a pipeline with the padding declared and
@@ -914,3 +914,81 @@ def test_rows_from_pixel_blocks(gpu_lib, sizes, pad):
     ok = skipped == 0
     assert np.isnan(gs[~ok]).all() and np.isnan(gss[~ok]).all()
     assert np.array_equal(gs[ok], ws[ok]) and np.array_equal(gss[ok], wss[ok])
+
+
+@pytest.mark.parametrize("F", [64, 200])
+def test_pipeline_step_matches_plain_sequence(gpu_lib, oracle, F):
+    """upsp_pipeline_step: one call per step of a frame loop that rebuilds its projection (model motion) -- build on the pipeline's own
+    side stream, pass A on the candidate map beside it, hand-over, pass B, the previous step's finals, all events inside the
+    library.  Four steps issued back to back without a host wait, the CAMERA moved every step (another projection, another
+    candidate map), the frames of every step uploaded into the SAME device buffer by the frames hook (the point of the schedule
+    where the previous step no longer reads them): series, repaired frames, accumulators and finals bit-identical to the plain
+    one-stream sequence projection build -> set_projection -> reset -> process -> finalize on a second pipeline, and to the
+    oracle loop for the first step."""
+    import torch
+    from upsp_processing_amd import _capi, engine, synthetic as syn
+    v, t = syn.uv_sphere(40, 80)
+    s9, tn = syn.soup(v, t)
+    nrm = syn.node_normals(v, t)
+    H = W = 128
+    N = v.shape[0]
+    bvh = engine.BVH(s9)
+    d_v, d_n, d_tn = torch.as_tensor(v).cuda(), torch.as_tensor(nrm).cuda(), torch.as_tensor(tn).cuda()
+    bvh.set_tri_nodes(d_tn, N)
+    cams = []
+    for s in range(4):
+        c = syn.pinhole_camera(W, H, center=(0.3 * s, -0.2 * s, 20), half_extent=1.3, fill=0.8)
+        cams.append(_capi.make_camera(c["K"], c["dist"], c["R"], c["t"], W, H))
+    batches = [np.minimum(syn.synth_frames_numpy(F, H, W, seed=300 + s, hot=True), 4095).astype(np.uint16) for s in range(4)]
+    staged = [torch.as_tensor(b).cuda() for b in batches]
+    ld = engine.series_ld(F, whole_rows=True)
+    # ---- the plain sequence, one stream ----
+    ref = engine.FramePipeline(1, W, H, N)
+    want = []
+    for s in range(4):
+        proj = engine.build_projection(bvh, cams[s], d_v, d_n, d_tn, 70.0, counts=False)
+        ref.set_projection(0, proj["pix"])
+        ref.reset()
+        d = staged[s].clone()
+        rt = torch.full((N, ld), -5.0, dtype=torch.float32, device="cuda")
+        ref.process(d, first_frame=s * F, rows_t=rt[:, :F], want_rows=False)
+        avg, rms = ref.finalize(F)
+        want.append((rt[:, :F].clone(), d, avg, rms, proj["pix"].clone()))
+    torch.cuda.synchronize()
+    assert len({w[4].cpu().numpy().tobytes() for w in want}) > 1          # the projections do differ
+    # ---- the same through upsp_pipeline_step ----
+    pipe = engine.FramePipeline(1, W, H, N)
+    pipe.set_row_padding(True)
+    d = torch.empty_like(staged[0])
+    rts = [torch.full((N, ld), -5.0, dtype=torch.float32, device="cuda") for _ in range(4)]
+    fin = [(torch.empty(N, dtype=torch.float32, device="cuda"), torch.empty(N, dtype=torch.float32, device="cuda")) for _ in range(4)]
+    after = []
+    tails = []
+    for s in range(4):
+        def upload(st, s=s):
+            if s:
+                after.append(d.clone())              # (the previous step's repaired frames, before they are overwritten)
+            d.copy_(staged[s])
+        pipe.step(bvh, cams[s], d_v, d_n, d_tn, d, rows_t=rts[s][:, :F], first_frame=s * F, finals=fin[s], nframes_total=F,
+                  frames_hook=upload, tail_hook=lambda st: tails.append(st.cuda_stream))
+    pipe.step_finish()
+    torch.cuda.synchronize()
+    after.append(d.clone())
+    assert len(tails) == 4 and len(set(tails)) == 1 and tails[0] != torch.cuda.current_stream().cuda_stream
+    for s in range(4):
+        rows, frames, avg, rms, _ = want[s]
+        assert torch.equal(rts[s][:, :F].view(torch.int32), rows.view(torch.int32)), s
+        assert torch.equal(after[s], frames), s
+        assert torch.equal(fin[s][0].view(torch.int32), avg.view(torch.int32)) and torch.equal(fin[s][1].view(torch.int32), rms.view(torch.int32)), s
+    # the first step against the oracle loop
+    pix0 = want[0][4].cpu().numpy()
+    rows_o, _, _ = run_loop_oracle(oracle, [batches[0]], pix0[None], np.ones((1, N), np.float32))
+    assert np.array_equal(rts[0][:, :F].cpu().numpy().view(np.int32), rows_o.T.view(np.int32))
+    # the pipeline is an ordinary pipeline afterwards
+    pipe.set_active_hint(None)
+    pipe.set_projection(0, want[3][4])
+    pipe.reset()
+    d2 = staged[3].clone()
+    rt = torch.empty((N, F), dtype=torch.float32, device="cuda")
+    pipe.process(d2, first_frame=3 * F, rows_t=rt, want_rows=False)
+    assert torch.equal(rt.view(torch.int32), want[3][0].contiguous().view(torch.int32))

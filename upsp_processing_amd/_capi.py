@@ -47,6 +47,17 @@ class PipelineOpts(C.Structure):
                 ("fused_scan", C.c_int32), ("compact_mb", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
+StepHook = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)      # upsp_step_hook(user, stream)
+
+
+class StepArgs(C.Structure):                               # upsp_step_args
+    _fields_ = [("bvh", C.c_void_p), ("cam", C.POINTER(Camera)), ("d_nodes", C.c_void_p), ("d_normals", C.c_void_p),
+                ("d_datanode", C.c_void_p), ("d_tri_nodes", C.c_void_p), ("oblique_thresh", C.c_float), ("nframes", C.c_int32),
+                ("d_frames", C.c_void_p), ("first_frame", C.c_int64), ("d_rows_t", C.c_void_p), ("ld_t", C.c_int64),
+                ("col0", C.c_int64), ("d_avg", C.c_void_p), ("d_rms", C.c_void_p), ("nframes_total", C.c_uint64),
+                ("frames_hook", StepHook), ("frames_user", C.c_void_p), ("tail_hook", StepHook), ("tail_user", C.c_void_p)]
+
+
 _vp, _sz, _i, _i64, _u64p = C.c_void_p, C.c_size_t, C.c_int, C.c_int64, C.POINTER(C.c_uint64)
 
 # name -> (restype, argtypes); every function include/upsp_gpu.h declares
@@ -111,6 +122,9 @@ SIGNATURES = {
     "upsp_pipeline_accumulators": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
     "upsp_pipeline_accumulators_async": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), _vp]),
     "upsp_pipeline_reset": (_i, [_vp]),
+    "upsp_pipeline_step": (_i, [_vp, C.POINTER(StepArgs), _vp]),
+    "upsp_pipeline_step_mark_end": (_i, [_vp, _vp]),
+    "upsp_pipeline_step_finish": (_i, [_vp, _vp]),
     "upsp_pipeline_reset_deferred": (_i, [_vp]),
     "upsp_pipeline_finalize": (_i, [_vp, C.c_uint64, _vp, _vp, _vp]),
     "upsp_fix_hot_pixels": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),

@@ -88,6 +88,20 @@ struct upsp_pipeline {
     upsp::PatchTables *patches[kMaxCams] = {nullptr};
     upsp::FrameScratch *scratch = nullptr;
     int batch = 32;
+    // upsp_pipeline_step: the side stream of the projection build (high priority: it needs few wave slots but needs them early), the
+    // events that order it against the caller's stream, the candidate pixels / uv scratch of the build, the finals the step before
+    // left to do
+    struct Step {
+        hipStream_t side = nullptr;
+        hipEvent_t ev_map[2] = {nullptr, nullptr}, ev_side[2] = {nullptr, nullptr}, ev_repaired[2] = {nullptr, nullptr};
+        hipEvent_t ev_end[3] = {nullptr, nullptr, nullptr};
+        int32_t *d_cand = nullptr;
+        float *d_uv = nullptr;
+        uint64_t count = 0;
+        bool finals_due = false;
+        float *d_avg = nullptr, *d_rms = nullptr;
+        uint64_t ntotal = 0;
+    } step;
 };
 
 namespace {
@@ -237,6 +251,15 @@ void upsp_pipeline_destroy(upsp_pipeline *p)
     free_dev(p->d_changes);
     free_dev(p->d_head);
     free_dev(p->d_next);
+    if (p->step.side) {
+        (void)hipStreamSynchronize(p->step.side);
+        (void)hipStreamDestroy(p->step.side);
+    }
+    for (hipEvent_t e : {p->step.ev_map[0], p->step.ev_map[1], p->step.ev_side[0], p->step.ev_side[1], p->step.ev_repaired[0],
+                         p->step.ev_repaired[1], p->step.ev_end[0], p->step.ev_end[1], p->step.ev_end[2]})
+        if (e) (void)hipEventDestroy(e);
+    free_dev(p->step.d_cand);
+    free_dev(p->step.d_uv);
     for (int c = 0; c < kMaxCams; ++c) {
         free_dev(p->m_aflag[c]);
         free_dev(p->m_tile_off[c]);
@@ -407,16 +430,17 @@ int upsp_pipeline_set_row_padding(upsp_pipeline *p, int on)
     return UPSP_OK;
 }
 
-// columns a whole-row pass B may store for `ns` frames that start at column `c0` of rows of pitch ld: up to the END OF THE ROW when
-// that is the next 128-byte line (32 floats / 64 u16) and the caller declared the pitch padding writable.  Only the row's last
-// line is ever padded: a call that fills a window in the middle of a wider matrix (chunks in any order, live data to the right)
-// stores its own columns and nothing else.
+// columns a whole-row pass B may store for `ns` frames that start at column `c0` of rows of pitch ld: up to the next 128-byte line
+// (32 floats / 64 u16) when the caller declared the pitch padding writable AND the call ends within 512 bytes of the pitch, i.e. at
+// the end of the row (engine.series_ld rounds a row up to 256 bytes and may add 256 more).  A call that fills a window elsewhere in a wider
+// matrix (chunks in any order, live data to the right) stores its own columns and nothing else.
 static int padded_store(const upsp_pipeline *p, int64_t c0, int ns, int64_t ld, int per_line)
 {
     if (!p->row_padding || (ld % per_line) != 0) return ns;
     const int64_t end = c0 + ns;
-    const int64_t stop = (end + per_line - 1) / per_line * per_line;
-    return stop == ld ? ns + (int)(stop - end) : ns;
+    if (ld - end >= 4 * per_line) return ns;
+    const int64_t stop = std::min<int64_t>(ld, (end + per_line - 1) / per_line * per_line);
+    return ns + (int)(stop - end);
 }
 
 int upsp_pipeline_set_reference(upsp_pipeline *p, int cam, const float *d_ref32f)
@@ -1331,6 +1355,134 @@ int upsp_pipeline_process_u16(upsp_pipeline *p, uint16_t *const *d_frames, int n
     if (!d_series_u16) return fail(UPSP_ERR_INVALID, "null series buffer");
     return process_impl(p, d_frames, nframes, first_frame, nullptr, nullptr, d_series_u16, ld_t,
                         col0, d_warps, stream);
+}
+
+
+// ---- one step of a frame loop whose projection is rebuilt per batch (model motion) --------------------------------------------
+// The whole schedule of such a step behind one call (the reference's frame loop is one function, cpp/exec/psp_process.cpp:1743-1851,
+// and create_projection_mat a call in front of it, :1591-1640).  Two streams, the caller's (`stream`) and a high-priority side stream
+// the pipeline owns:
+//
+//   side    [end of step s-2]  candidate pixels -> active-pixel map (second set of map arrays)
+//           [repair of step s-1]  frames_hook (the frames may be rewritten here)            -> ev_map
+//           projection build straight into the pipeline's buffer
+//           [end of step s-1]  finals of step s-1, projection hand-over, node -> row sweep + skipped flags, tail_hook -> ev_side
+//   stream  [ev_map]  pass A (+ hot-pixel repair) on the candidate map, beside the build     -> ev_repaired
+//           [ev_side] pass B                                                                -> end of step s
+//
+// so the caller's stream carries pass A, the repair and pass B and nothing else, and the host runs a step ahead of the device.
+// Same results as the plain sequence upsp_projection_build -> upsp_pipeline_set_projection -> upsp_pipeline_reset ->
+// upsp_pipeline_process -> upsp_pipeline_finalize on one stream (tests/test_frames_gpu.py::test_pipeline_step_*).
+static int step_setup(upsp_pipeline *p)
+{
+    upsp_pipeline::Step &s = p->step;
+    if (s.side) return UPSP_OK;
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess)
+        UPSP_HIP_CHECK(hipStreamCreateWithPriority(&s.side, hipStreamNonBlocking, greatest));
+    else
+        UPSP_HIP_CHECK(hipStreamCreateWithFlags(&s.side, hipStreamNonBlocking));
+    for (hipEvent_t *e : {&s.ev_map[0], &s.ev_map[1], &s.ev_side[0], &s.ev_side[1], &s.ev_repaired[0], &s.ev_repaired[1], &s.ev_end[0],
+                          &s.ev_end[1], &s.ev_end[2]})
+        UPSP_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    UPSP_HIP_CHECK(hipMalloc(&s.d_cand, sizeof(int32_t) * p->nnodes));
+    UPSP_HIP_CHECK(hipMalloc(&s.d_uv, sizeof(float) * 2 * p->nnodes));
+    return UPSP_OK;
+}
+
+int upsp_pipeline_step(upsp_pipeline *p, const upsp_step_args *a, void *stream)
+{
+    if (!p || !a || !a->bvh || !a->cam || !a->d_nodes || !a->d_normals || !a->d_tri_nodes || !a->d_frames || a->nframes <= 0)
+        return fail(UPSP_ERR_INVALID, "step: bad argument");
+    const size_t npix = (size_t)p->width * p->height;
+    if (p->ncams != 1 || p->d_weight[0] || p->opts.registration || p->opts.patch || p->opts.filter || p->d_src || (npix % 2) != 0 ||
+        p->batch != 64 || p->opts.fused_scan == 2 || p->nnodes >= ((size_t)1 << 31) || a->nframes > streamed_group_frames(p, npix))
+        return fail(UPSP_ERR_INVALID, "step: plain one-camera path with the streamed schedule, <= 1024 frames per step");
+    int rc = step_setup(p);
+    if (rc != UPSP_OK) return rc;
+    upsp_pipeline::Step &s = p->step;
+    hipStream_t main = (hipStream_t)stream, side = s.side;
+    const uint64_t n = s.count;
+    // ---- side stream ----
+    if (n == 0) {                                        // (the first step starts behind whatever the caller has queued)
+        UPSP_HIP_CHECK(hipEventRecord(s.ev_end[2], main));
+        UPSP_HIP_CHECK(hipStreamWaitEvent(side, s.ev_end[2], 0));
+    }
+    // the set of map arrays the new map is built in was last read by the launches of the step before the previous one
+    if (n >= 2) UPSP_HIP_CHECK(hipStreamWaitEvent(side, s.ev_end[(n - 2) % 3], 0));
+    rc = upsp_projection_candidate_pixels_oblique(a->cam, a->d_nodes, a->d_normals, a->d_datanode, p->nnodes, a->oblique_thresh, s.d_cand, side);
+    if (rc != UPSP_OK) return rc;
+    rc = upsp_pipeline_set_active_hint(p, s.d_cand, side);
+    if (rc != UPSP_OK) return rc;
+    if (a->frames_hook) {
+        // behind the map (which runs beside the previous step's pass A): in front of it the whole side block -- and with it this
+        // step's pass B -- would wait for that repair
+        if (n >= 1) UPSP_HIP_CHECK(hipStreamWaitEvent(side, s.ev_repaired[(n - 1) % 2], 0));
+        a->frames_hook(a->frames_user, side);
+    }
+    UPSP_HIP_CHECK(hipEventRecord(s.ev_map[n % 2], side));
+    int32_t *target = nullptr;
+    rc = upsp_pipeline_projection_target(p, 0, &target);
+    if (rc != UPSP_OK) return rc;
+    rc = upsp_projection_build(a->bvh, a->cam, a->d_nodes, a->d_normals, a->d_datanode, a->d_tri_nodes, p->nnodes, a->oblique_thresh,
+                               target, s.d_uv, nullptr, nullptr, side);
+    if (rc != UPSP_OK) return rc;
+    // the previous step's pass B: its sums (finals), and it read the skipped flags the sweep below rewrites
+    if (n >= 1) UPSP_HIP_CHECK(hipStreamWaitEvent(side, s.ev_end[(n - 1) % 3], 0));
+    if (s.finals_due) {
+        rc = upsp_pipeline_finalize(p, s.ntotal, s.d_avg, s.d_rms, side);
+        if (rc != UPSP_OK) return rc;
+        s.finals_due = false;
+    }
+    rc = upsp_pipeline_set_projection_async(p, 0, target, nullptr, side);
+    if (rc == UPSP_OK) rc = upsp_pipeline_prepare_rows(p, side);
+    if (rc != UPSP_OK) return rc;
+    if (a->tail_hook) a->tail_hook(a->tail_user, side);
+    UPSP_HIP_CHECK(hipEventRecord(s.ev_side[n % 2], side));
+    // ---- the caller's stream: pass A + repair, pass B ----
+    UPSP_HIP_CHECK(hipStreamWaitEvent(main, s.ev_map[n % 2], 0));
+    rc = upsp_pipeline_prescan(p, a->d_frames, a->nframes, main);      // (in two launches when upsp_pipeline_set_scan_split says so)
+    if (rc != UPSP_OK) return rc;
+    UPSP_HIP_CHECK(hipEventRecord(s.ev_repaired[n % 2], main));
+    UPSP_HIP_CHECK(hipStreamWaitEvent(main, s.ev_side[n % 2], 0));
+    if (a->d_rows_t) {
+        rc = upsp_pipeline_reset_deferred(p);            // (this step's sums start from zero: pass B writes them)
+        if (rc != UPSP_OK) return rc;
+        uint16_t *frames[1] = {a->d_frames};
+        rc = upsp_pipeline_process(p, frames, a->nframes, a->first_frame, nullptr, a->d_rows_t, a->ld_t, a->col0, nullptr, main);
+        if (rc != UPSP_OK) return rc;
+        s.finals_due = a->d_avg || a->d_rms;
+        s.d_avg = a->d_avg;
+        s.d_rms = a->d_rms;
+        s.ntotal = a->nframes_total ? a->nframes_total : (uint64_t)a->nframes;
+    }
+    UPSP_HIP_CHECK(hipEventRecord(s.ev_end[n % 3], main));
+    ++s.count;
+    return UPSP_OK;
+}
+
+int upsp_pipeline_step_mark_end(upsp_pipeline *p, void *stream)
+{
+    if (!p || !p->step.side || p->step.count == 0) return fail(UPSP_ERR_INVALID, "step: no step issued");
+    UPSP_HIP_CHECK(hipEventRecord(p->step.ev_end[(p->step.count - 1) % 3], (hipStream_t)stream));
+    return UPSP_OK;
+}
+
+int upsp_pipeline_step_finish(upsp_pipeline *p, void *stream)
+{
+    if (!p) return fail(UPSP_ERR_INVALID, "null pipeline");
+    upsp_pipeline::Step &s = p->step;
+    if (!s.side) return UPSP_OK;
+    hipStream_t main = (hipStream_t)stream;
+    if (s.finals_due) {          // the last step's finals: behind its pass B on the caller's stream
+        int rc = upsp_pipeline_finalize(p, s.ntotal, s.d_avg, s.d_rms, main);
+        if (rc != UPSP_OK) return rc;
+        s.finals_due = false;
+    }
+    // whatever the side stream still holds (nothing a finished step needs) is ordered in front of the caller's next launch
+    UPSP_HIP_CHECK(hipEventRecord(s.ev_map[0], s.side));
+    UPSP_HIP_CHECK(hipStreamWaitEvent(main, s.ev_map[0], 0));
+    return UPSP_OK;
 }
 
 }  // extern "C"

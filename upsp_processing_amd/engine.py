@@ -486,6 +486,54 @@ class FramePipeline:
                                           _ptr(rows_t), ld, col0, _ptr(warps), _stream()))
         return rows
 
+    def step(self, bvh, cam, nodes, normals, tri_nodes, frames, rows_t=None, first_frame=0, col0=0, oblique_angle=70.0,
+             datanode=None, finals=None, nframes_total=0, frames_hook=None, tail_hook=None):
+        """One step of a frame loop whose projection is rebuilt per batch (upsp_pipeline_step, include/upsp_gpu.h): candidate
+        pixels, map, projection build and hand-over on the pipeline's own high-priority stream, pass A + repair + pass B on the
+        current stream, every ordering event inside the library.  nodes / normals / tri_nodes: device tensors (f32 [N,3],
+        f32 [N,3], int32 [3T]); frames: u16 [F <= 1024, H, W] (repaired in place); rows_t: f32 [N, >= F] node-major (None: no
+        pass B, the series stay in the compact buffer for pixel_series()).  finals: (avg, rms) f32 [N] tensors written with the
+        next step or by step_finish().  frames_hook / tail_hook: callables taking a torch stream (the side stream), see the
+        header."""
+        assert frames.is_cuda and frames.dtype == torch.uint16 and frames.is_contiguous()
+        assert tuple(frames.shape[1:]) == (self.height, self.width)
+        for t_, dt in ((nodes, torch.float32), (normals, torch.float32), (tri_nodes, torch.int32)):
+            assert t_.is_cuda and t_.dtype == dt and t_.is_contiguous()
+        a = _capi.StepArgs()
+        a.bvh = bvh.handle
+        a.cam = C.pointer(cam)
+        a.d_nodes, a.d_normals, a.d_tri_nodes = nodes.data_ptr(), normals.data_ptr(), tri_nodes.data_ptr()
+        a.d_datanode = None if datanode is None else datanode.data_ptr()
+        a.oblique_thresh = oblique_threshold(oblique_angle)
+        a.nframes = frames.shape[0]
+        a.d_frames = frames.data_ptr()
+        a.first_frame = int(first_frame)
+        if rows_t is not None:
+            assert rows_t.is_cuda and rows_t.dtype == torch.float32 and (rows_t.shape[1] <= 1 or rows_t.stride(1) == 1)
+            a.d_rows_t, a.ld_t, a.col0 = rows_t.data_ptr(), rows_t.stride(0), int(col0)
+        if finals is not None:
+            a.d_avg, a.d_rms = finals[0].data_ptr(), finals[1].data_ptr()
+        a.nframes_total = int(nframes_total)
+
+        def wrap(fn):
+            def call(_user, stream_ptr):
+                st = torch.cuda.ExternalStream(stream_ptr)
+                with torch.cuda.stream(st):
+                    fn(st)
+            return _capi.StepHook(call)
+        hooks = [wrap(frames_hook) if frames_hook else _capi.StepHook(), wrap(tail_hook) if tail_hook else _capi.StepHook()]
+        a.frames_hook, a.tail_hook = hooks
+        check(lib().upsp_pipeline_step(self._h, C.byref(a), _stream()))
+        self._step_keep = (finals, rows_t, frames)      # (buffers the queued launches write)
+
+    def step_mark_end(self):
+        """The end of a step issued with rows_t=None, on the current stream (upsp_pipeline_step_mark_end)."""
+        check(lib().upsp_pipeline_step_mark_end(self._h, _stream()))
+
+    def step_finish(self):
+        """The finals the last step() left, and the current stream ordered behind the pipeline's side stream."""
+        check(lib().upsp_pipeline_step_finish(self._h, _stream()))
+
     def ecc_stats(self):
         """Registration statistics since creation: dict(frame_iterations, frames)."""
         a, b = C.c_uint64(), C.c_uint64()
