@@ -62,25 +62,45 @@ _PEAK = {}
 
 
 def measured_peak():
-    """the roofline's second denominator -- the rate of a streaming device copy kernel measured in THIS process
-    (upsp_copy_probe: float4 copy of 1 GiB, read + write bytes over the HIP-event time of 5 launches), and of its store half."""
+    """the roofline's second denominator, measured in THIS process by HIP events -- a read-only and a write-only
+    stream over 1 GiB in the access shapes of the frame loop's two passes (upsp_bandwidth_probe: non-temporal 16-byte loads,
+    several in flight per lane / a workgroup sweeping whole 4-KB row pieces with 16-byte non-temporal stores; the fastest of four
+    launch shapes each).  (Until round 5 a float4 COPY kernel was the denominator: it mixes the two streams and is slower than
+    either pass -- 5.3 TB/s against 6.0-6.6 for pass A -- so fractions came out above 1.)"""
     if "v" not in _PEAK:
         from upsp_processing_amd import _capi
-        _PEAK["v"] = _capi.copy_probe(1 << 30, 5)
+        _PEAK["v"] = _capi.bandwidth_probe(1 << 30, 5)
     return _PEAK["v"]
 
 
-def roofline_extras(roof, step_bytes, ms_step):
-    """peak_measured / frac_of_measured (dominant kernel against the measured copy rate) and step_frac (ALL algorithmic bytes of
-    a step over the whole step time, against the spec peak and the measured one)."""
+# which stream a kernel's algorithmic bytes are: fraction READ (the rest written)
+READ_SHARE = {"scan_compact_kernel": 1.0, "hot_scan_kernel": 1.0, "ecc_sums_kernel": 1.0, "ecc_sums_identity": 1.0, "ecc_sums_general": 1.0,
+              "node_rows_kernel": 0.0, "node_rows_multi_kernel": 0.0, "gather_tile_kernel": 0.0,
+              "gauss_pass_kernels": 1.0 / 3.0, "warp_u16_kernel": 12.0 / 14.0, "scan_compact_multi": 1.0}
+
+
+def floor_ms(name, nbytes, pk):
+    """time the measured read / write rates allow for `nbytes` algorithmic bytes of kernel `name`"""
+    r = READ_SHARE.get(name, 0.5)
+    return (nbytes * r / pk["read_GBps"] + nbytes * (1.0 - r) / pk["write_GBps"]) / 1e9 * 1e3
+
+
+def roofline_extras(roof, bytes_by_kernel, ms_step):
+    """peak_measured / frac_of_measured (the dominant kernel against the measured rate of ITS stream: read-only for pass A and the
+    ECC sums, write-only for pass B) and step_frac (ALL algorithmic bytes of a step over the whole step time, against the spec peak;
+    step_frac_of_measured: the time the measured rates allow for every kernel's bytes over the step time)."""
     pk = measured_peak()
-    roof["peak_measured"] = pk["copy_GBps"]
-    roof["peak_measured_kind"] = "device copy kernel in this process (%s, %d MiB, %d launches, HIP events); fill alone %.0f GB/s" % (
-        pk["kernel"], pk["bytes"] >> 20, pk["reps"], pk["fill_GBps"])
-    roof["frac_of_measured"] = roof["achieved"] / pk["copy_GBps"]
+    dom = roof["kernel"]
+    r = READ_SHARE.get(dom, 0.5)
+    kind = "read-only" if r == 1.0 else "write-only" if r == 0.0 else "read share %.2f" % r
+    roof["peak_measured"] = 1.0 / (r / pk["read_GBps"] + (1.0 - r) / pk["write_GBps"])
+    roof["peak_measured_kind"] = ("%s stream in the kernel's own access shape, in this process (upsp_bandwidth_probe, %d MiB, %d launches, HIP "
+                                  "events): read-only %.0f GB/s, write-only %.0f GB/s" % (kind, pk["bytes"] >> 20, pk["reps"], pk["read_GBps"], pk["write_GBps"]))
+    roof["frac_of_measured"] = roof["achieved"] / roof["peak_measured"]
+    step_bytes = sum(bytes_by_kernel.values())
     roof["step_algorithmic_bytes"] = int(step_bytes)
     roof["step_frac"] = step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS
-    roof["step_frac_of_measured"] = step_bytes / (ms_step * 1e-3) / 1e9 / pk["copy_GBps"]
+    roof["step_frac_of_measured"] = sum(floor_ms(k, v, pk) for k, v in bytes_by_kernel.items()) / ms_step
     return roof
 
 
@@ -167,26 +187,12 @@ class quiet_gc:
     def __enter__(self):
         import gc
         self.was = gc.isenabled()
-        if os.environ.get("UPSP_BENCH_GC"):          # diagnosis: leave the collector on and report its passes
-            t = [0.0]
-
-            def cb(phase, info):
-                if phase == "start":
-                    t[0] = time.perf_counter()
-                else:
-                    sys.stderr.write("gc: generation %d pass of %.1f ms inside a timed loop\n" % (info["generation"], (time.perf_counter() - t[0]) * 1e3))
-            self.cb = cb
-            gc.callbacks.append(cb)
-            return
         gc.collect()
         gc.freeze()
         gc.disable()
 
     def __exit__(self, *exc):
         import gc
-        if os.environ.get("UPSP_BENCH_GC"):
-            gc.callbacks.remove(self.cb)
-            return False
         if self.was:
             gc.enable()
         gc.unfreeze()
@@ -450,7 +456,7 @@ def registration_block(bvh, cam, d_nodes, d_nrm, d_tn, frames, restore, N, size,
     pipe.set_reference(0, frames[0].to(torch.float32))      # raw first frame as ECC template (psp_process.cpp:2057)
     # (registration as the last image stage: ONE whole-row pass B per <= 1024 frames -> the plain multiple of 256 B as pitch)
     rows_t = torch.empty((N, engine.series_ld(F, whole_rows=True)), dtype=torch.float32, device="cuda")[:, :F]
-    pipe.set_row_padding(os.environ.get("UPSP_BENCH_ROW_PADDING", "1") != "0")    # (columns F .. pitch of rows_t are padding)
+    pipe.set_row_padding(True)    # (columns F .. pitch of rows_t are padding)
 
     side = torch.cuda.Stream(priority=-1)       # the build of a step runs beside the previous step's registration (see main())
     side.wait_stream(torch.cuda.current_stream())   # (once: whatever the caller still has in flight on the model's arrays)
@@ -534,7 +540,7 @@ def registration_block(bvh, cam, d_nodes, d_nrm, d_tn, frames, restore, N, size,
                           "avg_launch_ms": dk["avg_launch_ms"], "launches_per_step": dk["calls_per_step"]},
                          **ECC_SYMBOLS.get(dom, {})),
                          # a step's algorithmic bytes: sums 8 B / px / iteration, pre-blur 6 B / px, warp 14 B / active px, pass B rows
-                         sum(bytes_step[k] for k in ("ecc_sums_kernel", "gauss_pass_kernels", "warp_u16_kernel", "node_rows_kernel")), ms_step),
+                         {k: bytes_step[k] for k in ("ecc_sums_kernel", "gauss_pass_kernels", "warp_u16_kernel", "node_rows_kernel")}, ms_step),
         "kernels": kernels,
     }
 
@@ -672,8 +678,8 @@ def multi_camera_main(a):
     side = None if a.serial else torch.cuda.Stream(priority=-1)
     # The builds of the cameras do not depend on each other (create_projection_mat per camera, psp_process.cpp:1586-1660): each on
     # a high-priority stream and a BVH handle of its own (engine.BVH.share: same tree, own query scratch) -- four latency-bound
-    # chains side by side instead of one after the other.  UPSP_BENCH_CONCURRENT_BUILDS=0: one stream, one handle (round 4).
-    concurrent = side is not None and os.environ.get("UPSP_BENCH_CONCURRENT_BUILDS", "1") != "0"
+    # chains side by side instead of one after the other (one stream, one handle: 8.03 against 7.26 ms per step, round 5).
+    concurrent = side is not None
     bvhs = [bvh] + [bvh.share() for _ in cams[1:]] if concurrent else [bvh] * C
     sides = [side] + [torch.cuda.Stream(priority=-1) for _ in cams[1:]] if concurrent else [side] * C
 
@@ -778,7 +784,7 @@ def multi_camera_main(a):
         "pass_b_row_GBps": row_bytes / (kernels["node_rows_multi_kernel"]["ms_per_step"] * 1e-3) / 1e9 if "node_rows_multi_kernel" in kernels else None,
         "kernels": kernels,
     }
-    roofline_extras(out["roofline"], sum(per_step.values()), ms_step)
+    roofline_extras(out["roofline"], dict(per_step), ms_step)
     if not a.no_cpu_baseline:
         # oracle (CPU port): projection of every camera on the full model, weights, and the weighted loop on a bounded
         # sample of frame sets (one frame set per thread, like the reference's OpenMP loop)
@@ -961,16 +967,16 @@ def main():
     # node-major time series [N, F]; one process() call writes every row piece whole
     streamed = not (a.two_kernel or a.registration)
     # (the streamed schedule -- and registration as the last image stage -- write every row piece whole, one pass B per <= 1024 frames)
-    ld = int(os.environ.get("UPSP_BENCH_LD", "0")) or engine.series_ld(F, whole_rows=streamed or (a.registration and not a.two_kernel))
+    ld = engine.series_ld(F, whole_rows=streamed or (a.registration and not a.two_kernel))
     chunked = world > 1 or a.force_chunked          # --force-chunked: exercise the N>1 loop on one GPU
     rows_t = torch.empty((N, ld), dtype=torch.float32, device="cuda")[:, :F] if not chunked else None
     # (columns F .. ld of that allocation are padding: the row pass may end every row on a whole 128-byte line)
-    row_padding = rows_t is not None and os.environ.get("UPSP_BENCH_ROW_PADDING", "1") != "0"
+    row_padding = rows_t is not None
     pipe.set_row_padding(row_padding)
     # pass A in two launches where it runs beside the projection build (the default schedule): the tiles nobody reads as one-wave
     # workgroups without LDS -- step 0.799 -> 0.773 ms; alone on the device (--serial) the one-launch form is the faster one
     # (the N > 1 loop keeps one launch: 1.07 against 1.10 ms per step in the one-rank rehearsal -- its pass A runs beside less of the build)
-    scan_split_on = not a.serial and not a.registration and not chunked and os.environ.get("UPSP_BENCH_SCAN_SPLIT", "1") != "0"
+    scan_split_on = not a.serial and not a.registration and not chunked
     if scan_split_on:
         pipe.set_scan_split(True)
     torch.cuda.synchronize()
@@ -1008,8 +1014,6 @@ def main():
     exchs = [exch, D.TimeSeriesExchange(shard, K, wire12=a.wire12)] if deferred else [exch]
     ex_state = {"step": 0, "pending": None, "first": [True, True], "last_done": exch}
 
-    drain_first = os.environ.get("UPSP_BENCH_DRAIN_FIRST", "0") == "1"
-
     def drain():
         """finish the exchange the previous step left in flight (pass B of its frames: series + its slice of the sums)"""
         if ex_state["pending"] is not None:
@@ -1022,125 +1026,92 @@ def main():
     # is a latency-bound chain of dependent fetches: side by side they take 0.59-0.63 ms where one after the other they take
     # 0.29 + 0.35-0.39 (LAB_NOTES.md, three alternations in one call: step 1.10-1.13 against 1.16-1.18 ms)
     overlap = not a.serial and not a.registration and streamed and F <= 1024 and (not chunked or px_once)
-    # The BUILD goes to the side stream, issued first and with high priority; pass A follows on the main stream: the traversal
-    # kernels are chains of dependent fetches that need few wave slots but need them early, pass A fills whatever is left
-    # (LAB_NOTES.md, step in ms: pass A on the side stream 1.151 / 1.172, the build on the side stream 1.124, the build
-    # on a high-priority side stream 1.107 / 1.131, pass A on a high-priority side stream 1.208).  UPSP_BENCH_BUILD_ON_SIDE=0 /
-    # UPSP_BENCH_SIDE_PRIORITY=0: the other arrangements.
-    swap = overlap and os.environ.get("UPSP_BENCH_BUILD_ON_SIDE", "1") == "1"
-    cand_oblique = os.environ.get("UPSP_BENCH_CAND_OBLIQUE", "1") == "1"      # (A/B: candidates = every in-frame node, round 3)
-    side_waits = os.environ.get("UPSP_BENCH_SIDE_WAIT", "0") == "1"      # (A/B: the build of a step behind the previous step's pass B)
-    map_on_side = swap and os.environ.get("UPSP_BENCH_MAP_ON_SIDE", "1") == "1"     # (A/B: 0 = the map on the main stream, round 4)
-    step_end = []                                                                   # end-of-step events of the last steps (main stream)
-    # configs[2]: the build of a step on a stream of its own as well -- it runs beside the previous step's registration
-    reg_side = a.registration and not a.serial and not chunked and not side_waits
-    # (the side stream must be a HIGH-priority one to get a hardware queue of its own: a normal-priority torch stream shares the
-    #  default stream's queue on this runtime -- kernel trace: every launch on queue 4 -- and the build then runs behind pass B
-    #  and in front of pass A instead of beside them: N > 1 loop 1.61 against 1.40 ms per step)
-    side = torch.cuda.Stream(priority=int(os.environ.get("UPSP_BENCH_SIDE_PRIORITY", "-1" if (swap or reg_side) else "0"))) if (overlap or reg_side) else None
-    # Nothing but pass A, the hot-pixel repair and pass B on the main stream (one GPU, default schedule).  A step's main stream used to
-    # carry seven launches -- restore, pass A, repair, the copy of the projection into the pipeline, the node -> row sweep, pass B,
-    # finals -- and every dependent launch costs ~10 us of queue turnaround on top of its run time (kernel trace: 0.11 ms of a 0.87-ms
-    # step were neither pass).  The small ones depend on other things than their neighbours, and the side stream has room:
-    #   * putting the hot pixels back for step s + 1 needs the repair of step s only (pass B reads the compact series, not the
-    #     frames -- the candidate map holds every pixel a node of this camera can read): in step s + 1's side block between the
-    #     map and the build, beside pass B of step s;
-    #   * the finals of step s need its pass B, and nothing needs them before pass B of step s + 1 overwrites the accumulators:
-    #     behind the build of step s + 1 (which waits for the end of step s there anyway); the last step's finals are issued
-    #     behind the loop, inside the timed region;
-    #   * the projection copy and the node -> row sweep (upsp_pipeline_prepare_rows) need the BUILD: they follow it on the side
-    #     stream, beside pass A.
-    # Every one of them still runs once per step, inside the timed region.  UPSP_BENCH_LEAN_MAIN=0: round 5's first arrangement (A/B).
-    lean = swap and map_on_side and os.environ.get("UPSP_BENCH_LEAN_MAIN", "1") == "1"
-    # (N > 1, pixel-series wire: the same arrangement -- the finals of a step follow its all-reduce, which the end-of-step event the side
-    #  stream waits for covers; the exchange's node table is checked on the side stream too, upsp_pipeline_row_tables)
+    # THE DEFAULT STEP IS ONE LIBRARY CALL: upsp_pipeline_step (engine.FramePipeline.step).  The build of the step -- candidate
+    # pixels, active-pixel map, ray casting, hand-over, node -> row sweep, the finals of the step before -- runs on a high-priority
+    # stream the pipeline owns, pass A + repair + pass B on this process's stream, every ordering event inside the library
+    # (include/upsp_gpu.h; LAB_NOTES.md sections 7-12 hold the measurements behind the arrangement: build on the side stream at
+    # high priority 1.107 against 1.151-1.208 ms for the alternatives in round 3, the map in front of the build 0.90-0.96 -> 0.86,
+    # three launches on the main stream 0.877 -> 0.839, pass A in two launches 0.799 -> 0.773).  What this file still does per step:
+    # put the hot pixels back (frames hook: the bench repairs the same resident frames every step) and, at N > 1, its exchange.
+    lean = overlap
+    # configs[2]: the build of a step on a stream of its own -- it runs beside the previous step's registration.  (The side stream
+    # must be a HIGH-priority one to get a hardware queue of its own: a normal-priority torch stream shares the default stream's
+    # queue on this runtime.)
+    reg_side = a.registration and not a.serial and not chunked
+    side = torch.cuda.Stream(priority=-1) if reg_side else None
+    # (N > 1, pixel-series wire: the same call without pass B -- the owner of a node runs it; the all-reduce + finals of a step and the
+    #  exchange's pixel table ride on the side stream through the tail hook)
     lean_px = lean and chunked and pixel_wire and px_once
-    lean_st = {"repaired": None, "finals_due": False, "pixels_set": False}
+    lean_st = {"finals_due": False}
+    finals_buf = (torch.empty(N, dtype=torch.float32, device="cuda"), torch.empty(N, dtype=torch.float32, device="cuda")) if lean else None
 
     def lean_finals():
-        """finals of the step before (the accumulators as its pass B left them).  N > 1: the all-reduce of the two sum vectors in
-        front of them, on the stream this is called on -- the side stream, not the frame loop's: only the finals need the complete
-        sums, and a collective in the main stream is a rendezvous of all ranks in front of every pass A."""
+        """N > 1: finals of the step before (the accumulators as its pass B left them) -- the all-reduce of the two sum vectors in
+        front of them, on the stream this is called on: the side stream, not the frame loop's (only the finals need the complete
+        sums, and a collective in the main stream is a rendezvous of all ranks in front of every pass A)."""
         if lean_st["finals_due"]:
-            if chunked:
-                D.allreduce_sums(*pipe.accumulators())
+            D.allreduce_sums(*pipe.accumulators())
             lean_st["avg"] = pipe.finalize(F * world)[0]
             lean_st["finals_due"] = False
 
-    class _NoEvent:                     # (lean schedule: an event record is a packet of its own on the main stream's queue, ~5 us
-        def record(self, *a):           #  between two dependent launches; the timed steps carry only the events that order work,
-            pass                        #  the per-phase breakdown comes from the instrumented repetition behind the timed loop)
+    def step_lean(record, events):
+        e = [ev() for _ in range(4)] if events else None
+        if events:
+            e[0].record()
+            e[1].record()
+        ht = [time.perf_counter()] * 2
+
+        def tail(_st):
+            # behind the node -> row sweep of the new projection and the end of the previous step, on the pipeline's side stream
+            lean_finals()
+            if lean_px:
+                # which pixel rows go where: from the node -> row table and the skipped flags the sweep just wrote
+                # (after the first step only compared with the exchange's own copy, on this stream)
+                wh = ex_state["step"] % len(exchs)
+                tabs = pipe.row_tables()
+                exchs[wh].set_pixels(tabs["node_k"], tabs["skipped"], assume_same=not ex_state["first"][wh])
+                ex_state["first"][wh] = False
+
+        pipe.step(bvh, cam, d_nodes, d_nrm, d_tn, frames, rows_t=None if chunked else rows_t, first_frame=rank * F,
+                  finals=None if chunked else finals_buf, nframes_total=F * world, frames_hook=lambda _st: restore_hot(),
+                  tail_hook=tail if chunked else None)
+        if chunked:
+            which = ex_state["step"] % len(exchs)
+            ex = exchs[which]
+            ex_state["step"] += 1
+            ex.k = 0
+            tab = pipe.pixel_series(frames)         # pass A ran beside the build: the rows of the nodes in that buffer
+            ex.submit_pixels(tab, col0=ex.my_chunk(0)[0])
+            if deferred:
+                drain()                             # the PREVIOUS step's series and sums, now that this step's block is on its way
+                ex_state["pending"] = ex
+            else:
+                ex.finish_pixels(*pipe.accumulators())
+            lean_st["finals_due"] = True            # (all-reduce + finals: on the side stream of the next step, or behind the loop)
+            pipe.step_mark_end()
+        ht += [time.perf_counter()] * 3
+        if events:
+            e[2].record()
+            e[3].record()
+        if record and events:
+            ev_log.append(e)
+            host_log.append([(b - a) * 1e3 for a, b in zip(ht[:-1], ht[1:])])
+        if record:
+            last_pix[0] = pipe.current_projection(0)
+        return None
 
     def step(record, events=True):
-        e = [ev() if events else (torch.cuda.Event() if i == 3 else _NoEvent()) for i in range(4)]      # ([3]: the end of the step, orders the side stream)
-        if not lean:
-            restore_hot()
+        if lean:
+            return step_lean(record, events)
+        e = [ev() for _ in range(4)]
+        restore_hot()
         e[0].record()
         ht = [time.perf_counter()]
         main = torch.cuda.current_stream()
-        if swap:
-            # The build reads the model and the camera only and writes fresh outputs + the BVH's own scratch: it depends on
-            # nothing the main stream does, so it does NOT wait for the previous step's pass B -- the device starts it as soon as
-            # the previous build has left the side stream (the host runs a step ahead), beside whatever the main stream is at.
-            # The consumer side is ordered below (main waits for the side stream before it takes the projection).
-            if side_waits:
-                side.wait_stream(main)
-            if map_on_side:
-                # The candidate-pixel map of this step's pass A depends on the camera and the nodes only: it is built on the side stream
-                # too, IN FRONT of the build -- beside the previous step's pass B -- instead of between that pass B and this pass A
-                # (six small launches, 35-40 us of a 0.93-ms step).  The pipeline builds it in its second set of map arrays; that set
-                # was last read by the step before the previous one (ordered by that step's end-of-step event: the side stream
-                # waits for nothing the main stream still has to do).
-                with torch.cuda.stream(side):
-                    if len(step_end) >= 2:
-                        side.wait_event(step_end[-2])
-                    pipe.set_active_hint(engine.candidate_pixels(cam, d_nodes, normals=d_nrm if cand_oblique else None, oblique_angle_deg=70.0))
-                    if lean and lean_st["repaired"] is not None:
-                        # (behind the map, which runs beside the previous step's pass A: in front of it the whole side block -- and
-                        #  with it this step's pass B -- waited for that repair: no gain, measured)
-                        side.wait_event(lean_st["repaired"])       # pass A + repair of the step before
-                        restore_hot()                              # this step's frames as they arrived
-                    ev_map = torch.cuda.Event()
-                    ev_map.record(side)
-                    # (lean: built straight into the pipeline's buffer -- the 2-MB device copy of set_projection is a blit kernel
-                    #  that waited 0.2 ms for its turn beside pass A; that buffer held the projection of the step before the last,
-                    #  whose end the side stream has waited for above)
-                    proj = engine.build_projection(bvh, cam, d_nodes, d_nrm, d_tn, 70.0, counts=False,
-                                                   pix_out=pipe.projection_target(0) if lean else None)
-                    if lean:
-                        if step_end:
-                            side.wait_event(step_end[-1])          # the previous step's pass B: its sums, and it read the skipped flags
-                        lean_finals()
-                        pipe.set_projection(0, proj["pix"])
-                        pipe.prepare_rows()
-                        if lean_px:
-                            # which pixel rows go where: from the node -> row table and the skipped flags the sweep just wrote
-                            # (after the first step only compared with the exchange's own copy, on this stream)
-                            wh = ex_state["step"] % len(exchs)
-                            tabs = pipe.row_tables()
-                            exchs[wh].set_pixels(tabs["node_k"], tabs["skipped"], assume_same=not ex_state["first"][wh])
-                            ex_state["first"][wh] = False
-                            lean_st["pixels_set"] = True
-                main.wait_event(ev_map)
-            else:
-                with torch.cuda.stream(side):
-                    proj = engine.build_projection(bvh, cam, d_nodes, d_nrm, d_tn, 70.0, counts=False)
-                pipe.set_active_hint(engine.candidate_pixels(cam, d_nodes, normals=d_nrm if cand_oblique else None, oblique_angle_deg=70.0))
-            pipe.prescan(frames)
-            if lean:
-                lean_st["repaired"] = torch.cuda.Event()
-                lean_st["repaired"].record(main)
-        elif overlap:
-            # which pixels the frame loop will read is known once the nodes are projected into the image
-            # (step 1 of create_projection_mat); pass A does not need the visibility verdicts
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                pipe.set_active_hint(engine.candidate_pixels(cam, d_nodes, normals=d_nrm if cand_oblique else None, oblique_angle_deg=70.0))
-                pipe.prescan(frames)
         if reg_side:
-            with torch.cuda.stream(side):           # (as above: beside the previous step's registration)
+            with torch.cuda.stream(side):           # beside the previous step's registration
                 proj = engine.build_projection(bvh, cam, d_nodes, d_nrm, d_tn, 70.0, counts=False)
-        elif not swap:
+        else:
             proj = engine.build_projection(bvh, cam, d_nodes, d_nrm, d_tn, 70.0, counts=False)   # no host sync
         e[1].record()
         ht.append(time.perf_counter())
@@ -1150,16 +1121,7 @@ def main():
             for t in proj.values():
                 if isinstance(t, torch.Tensor) and t.is_cuda:
                     t.record_stream(main)
-        if overlap:
-            # before the projection is copied into the pipeline: with the build on the side stream the copy would otherwise
-            # be ordered behind pass A only and could read entries the build is still writing
-            main.wait_stream(side)
-            if swap:
-                for t in proj.values():
-                    if isinstance(t, torch.Tensor) and t.is_cuda:
-                        t.record_stream(main)       # allocated on the side stream, consumed on the main one
-        if not lean:
-            pipe.set_projection(0, proj["pix"])
+        pipe.set_projection(0, proj["pix"])
         if not chunked:
             pipe.process(frames, first_frame=rank * F, rows_t=rows_t, want_rows=False)
         elif pixel_wire:
@@ -1169,24 +1131,12 @@ def main():
             ex = exchs[which]
             ex_state["step"] += 1
             ex.k = 0
-            if px_once and overlap:
-                # pass A ran beside the build (prescan on the candidate map): rows of the nodes in that buffer + hot-pixel repair
-                tab = pipe.pixel_series(frames)
-            else:
-                tab = pipe.pixel_series(None)       # node -> compact row of this projection
-            if lean_st["pixels_set"]:
-                lean_st["pixels_set"] = False       # (done on the side stream, behind the build)
-            else:
-                ex.set_pixels(tab["node_k"], engine.skipped_nodes(proj["pix"], want_count=False, as_bool=False)[0], assume_same=not ex_state["first"][which])
-                ex_state["first"][which] = False
-            if deferred and drain_first:
-                drain()                             # (A/B: the previous step's pass B BEFORE this step's chunks go out)
+            tab = pipe.pixel_series(None)       # node -> compact row of this projection
+            ex.set_pixels(tab["node_k"], engine.skipped_nodes(proj["pix"], want_count=False, as_bool=False)[0], assume_same=not ex_state["first"][which])
+            ex_state["first"][which] = False
             for k in range(K):
                 c0, fc = ex.my_chunk(k)
-                if px_once and overlap:
-                    ex.submit_pixels(tab, col0=c0)
-                else:
-                    ex.submit_pixels(pipe.pixel_series(frames[c0:c0 + fc]) if fc else tab)
+                ex.submit_pixels(pipe.pixel_series(frames[c0:c0 + fc]) if fc else tab)
             if deferred:
                 drain()                             # the PREVIOUS step's series and sums, now that this step's chunks are on their way
                 ex_state["pending"] = ex
@@ -1209,46 +1159,34 @@ def main():
         e[2].record()
         ht.append(time.perf_counter())
         s, ss = pipe.accumulators()
-        _h = [time.perf_counter()]
         if pixel_wire and not deferred:
             exchs[0].finish_pixels(s, ss)         # pass B of this rank's nodes over all frames: series + its slice of the sums
-        _h.append(time.perf_counter())
-        if not lean:
-            D.allreduce_sums(s, ss)
-        _h.append(time.perf_counter())
+        D.allreduce_sums(s, ss)
         if chunked and not pixel_wire:
             exch.finish()
-        if lean:
-            avg, lean_st["finals_due"] = None, True        # (on the side stream of the next step, or behind the loop)
-        else:
-            avg, rms = pipe.finalize(F * world)
-        _h.append(time.perf_counter())
-        if os.environ.get("UPSP_BENCH_TRACE_HOST"):
-            sys.stderr.write("host tail: finish_pixels %.3f allreduce %.3f finalize %.3f ms\n" % tuple((b - a) * 1e3 for a, b in zip(_h[:-1], _h[1:])))
+        avg, rms = pipe.finalize(F * world)
         e[3].record()
-        if map_on_side:
-            step_end.append(e[3])
-            del step_end[:-2]
         ht.append(time.perf_counter())
-        if record and events:           # events are read after the timed loop: no host sync inside it
+        if record:           # events are read after the timed loop: no host sync inside it
             ev_log.append(e)
             host_log.append([(b - a) * 1e3 for a, b in zip(ht[:-1], ht[1:])])
-        if record:
             last_pix[0] = proj["pix"]
         return avg
 
     def finish_run():
         """what the last step left to do: the deferred exchange's series and sums, and the finals that ride on the NEXT step's side
-        stream in the lean arrangement"""
+        stream in the one-call arrangement"""
         if not lean:
             drain()
             return
-        lean_finals()                           # finals of the sums the last step's pass B (or its drain) left
-        if ex_state["pending"] is not None:     # deferred: the last step's own exchange -- its sums start from zero like every step's
-            pipe.reset(deferred=True)
-            drain()
-            lean_st["finals_due"] = True
-            lean_finals()
+        pipe.step_finish()                      # (N = 1: the last step's finals; the main stream behind the side stream)
+        if chunked:
+            lean_finals()                       # finals of the sums the last step's pass B (or its drain) left
+            if ex_state["pending"] is not None: # deferred: the last step's own exchange -- its sums start from zero like every step's
+                pipe.reset(deferred=True)
+                drain()
+                lean_st["finals_due"] = True
+                lean_finals()
 
     for _ in range(a.warmup):
         step(False)
@@ -1433,8 +1371,7 @@ def main():
     roof.update(ECC_SYMBOLS.get(dom, {}))
     if rank == 0:
         # all algorithmic bytes of a step (every kernel that has a per-step figure; the ECC blend label is not counted twice)
-        step_bytes = sum(v for k, v in per_step_bytes.items() if k in kernels and k not in ("ecc_sums_identity", "ecc_sums_general"))
-        roofline_extras(roof, step_bytes, ms_step)
+        roofline_extras(roof, {k: v for k, v in per_step_bytes.items() if k in kernels and k not in ("ecc_sums_identity", "ecc_sums_general")}, ms_step)
     if overlap:
         roof["note"] = ("default schedule: the ray casting of the projection builds has a high-priority stream of its own and runs beside "
                         "pass A (scan_compact_kernel) and pass B (node_rows_kernel), which share the memory system with it; alone (--serial) "
@@ -1485,7 +1422,11 @@ def main():
                      "their rays say); a build in the reference's order gives the same entries: %s" % same_entries,
         # (default schedule: "projection_build" = the build WITH pass A beside it, "frame_loop" = what is left of the loop after
         #  it, pass B and the repair; "projection_build_alone" = the build timed by itself after the timed steps)
-        "breakdown_ms": {"projection_build": ray_ms, "frame_loop": frm_ms, "exchange_finals": float(np.mean(t_xchg)),
+        # (one-call step: no event of this file sits between the build and the frame loop any more -- "projection_build" = the sum of
+        #  the build's kernels as the library's timers saw them on the side stream, stretched by the passes beside them;
+        #  "frame_loop" = the whole step on this process's stream: pass A, the repair, the wait for the build, pass B)
+        "breakdown_ms": {"projection_build": (sum(v["ms_per_step"] for n, v in kernels.items() if n.startswith(side)) if lean else ray_ms),
+                         "frame_loop": frm_ms, "exchange_finals": float(np.mean(t_xchg)),
                          **({"projection_build_alone": ray_alone_ms} if overlap else {})},
         "breakdown_ms_per_step": {"projection_build": [round(x, 4) for x in t_ray], "frame_loop": [round(x, 4) for x in t_frames],
                                   "exchange_finals": [round(x, 4) for x in t_xchg],
@@ -1576,20 +1517,17 @@ def main():
             p2 = engine.FramePipeline(1, size, size, N, fused_scan=2 if a.two_kernel else 0)
             rt = torch.empty((N, engine.series_ld(n_sample, whole_rows=True)), dtype=torch.float32, device="cuda")[:, :n_sample]
             if lean:
-                # through the same entry points and kernel variants as the timed steps: pass A on the candidate-pixel map (in two
-                # launches where the steps ran it so), the projection handed over in the pipeline's own buffer, the node -> row
-                # sweep as a call of its own, whole-line rows
+                # through the same entry point as the timed steps: ONE upsp_pipeline_step call (its own projection build on the side
+                # stream, pass A on the candidate map in two launches, the projection handed over in the pipeline's buffer, the
+                # node -> row sweep, whole-line rows)
                 p2.set_scan_split(scan_split_on)
                 p2.set_row_padding(row_padding)
-                p2.set_active_hint(engine.candidate_pixels(cam, d_nodes, normals=d_nrm if cand_oblique else None, oblique_angle_deg=70.0))
-                p2.prescan(d_sample)
-                tgt = p2.projection_target(0)
-                tgt.copy_(last_pix[0])
-                p2.set_projection(0, tgt)
-                p2.prepare_rows()
+                p2.step(bvh, cam, d_nodes, d_nrm, d_tn, d_sample, rows_t=rt, first_frame=0)
+                p2.step_finish()
+                checks["step_call_same_projection"] = bool(torch.equal(p2.current_projection(0), last_pix[0]))
             else:
                 p2.set_projection(0, last_pix[0])
-            p2.process(d_sample, first_frame=0, rows_t=rt, want_rows=False)
+                p2.process(d_sample, first_frame=0, rows_t=rt, want_rows=False)
             gs, gss = [x.cpu().numpy() for x in p2.accumulators()]
             ok = ~np.isnan(ref["sum"])
             checks.update({

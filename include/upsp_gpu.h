@@ -266,6 +266,10 @@ int upsp_pipeline_set_projection_async(upsp_pipeline *p, int cam, const int32_t 
  * last one (they may read that buffer).  Replaces nothing in the reference: create_projection_mat returns its matrix by value
  * (cpp/exec/psp_process.cpp:167-355). */
 int upsp_pipeline_projection_target(upsp_pipeline *p, int cam, int32_t **d_pix);
+/* The projection of camera `cam` the pipeline currently holds (elems.projs[c]): *d_pix = its nnodes int32, pipeline-owned, valid
+ * until the next upsp_pipeline_set_projection* / upsp_pipeline_step of that camera is two calls old (the buffers are used in turn).
+ * After upsp_pipeline_step: the projection that step built (stream-ordered on the step's stream). */
+int upsp_pipeline_projection(upsp_pipeline *p, int cam, const int32_t **d_pix);
 /* fix_hot_pixels (cpp/utils/cv_extras.cpp:230-275, called at cpp/exec/psp_process.cpp:1772) does not
  * depend on the projection: upsp_pipeline_fix_hot_pixels queues the scan + repair of `nframes`
  * resident frames (in place, pipeline's thresholds) on `stream` -- e.g. a second stream while the
@@ -733,6 +737,12 @@ int upsp_timing_report(char *buf, size_t cap);
  * 32 workgroups per CU).  The measured HBM rate SURVEY.md 8(d) names as the roofline's
  * denominator: GB/s = (2 x bytes, or bytes for the fill) / ms_per_rep / 1e6. */
 int upsp_copy_probe(const void *d_src, void *d_dst, size_t bytes, int reps, float *ms_per_rep, void *stream);
+/* Read-only (kind 0) and write-only (kind 1) stream over `bytes` of d_buf in the access shapes of the frame loop's two passes --
+ * pass A: non-temporal 16-byte loads, several in flight per lane, one-wave or four-wave workgroups; pass B: a workgroup sweeping
+ * whole 4-KB row pieces with 16-byte non-temporal stores -- the fastest of four launch shapes each, *ms_per_rep by HIP events over
+ * `reps` launches: the measured denominators of bench.py's roofline (a read-bound kernel is divided by the read rate, a
+ * write-bound one by the write rate; the copy probe mixes both streams and is slower than either pass). */
+int upsp_bandwidth_probe(int kind, void *d_buf, size_t bytes, int reps, float *ms_per_rep, void *stream);
 
 /* Phase labels (reference: timedBarrierPoint / psp::BlockTimer, cpp/exec/psp_process.cpp:585-606): begin / end
  * nest; every phase is a roctx range (rocprofv3 --marker-trace: libroctx64 is looked up at run time, not linked) and,

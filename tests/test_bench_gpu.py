@@ -34,6 +34,11 @@ def test_bench_small_line_and_parity(gpu_lib):
     r = d["roofline"]
     assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert r["traffic"] is None                        # no PMC summary was handed over
+    # the measured denominators: the read-only / write-only probe of the kernel's own stream -- a fraction above 1 would mean the
+    # probe is slower than the product kernel it normalises (round-5 review: the copy probe was)
+    assert 0.0 < r["frac_of_measured"] <= 1.0 and 0.0 < r["step_frac_of_measured"] <= 1.0, r
+    assert "read-only" in r["peak_measured_kind"] and "write-only" in r["peak_measured_kind"]
+    assert d["parity"]["step_call_same_projection"] is True     # the default step = ONE upsp_pipeline_step call, checked through it
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
 
 

@@ -121,6 +121,7 @@ SIGNATURES = {
     "upsp_pipeline_process_u16": (_i, [_vp, C.POINTER(_vp), _i, _i64, _vp, _i64, _i64, _vp, _vp]),
     "upsp_pipeline_accumulators": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
     "upsp_pipeline_accumulators_async": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), _vp]),
+    "upsp_pipeline_projection": (_i, [_vp, _i, C.POINTER(_vp)]),
     "upsp_pipeline_reset": (_i, [_vp]),
     "upsp_pipeline_step": (_i, [_vp, C.POINTER(StepArgs), _vp]),
     "upsp_pipeline_step_mark_end": (_i, [_vp, _vp]),
@@ -174,6 +175,7 @@ SIGNATURES = {
     "upsp_phase_begin": (_i, [C.c_char_p]),
     "upsp_phase_end": (_i, [C.POINTER(C.c_double)]),
     "upsp_timing_enable": (_i, [_i]),
+    "upsp_bandwidth_probe": (_i, [_i, _vp, _sz, _i, C.POINTER(C.c_float), _vp]),
     "upsp_copy_probe": (_i, [_vp, _vp, C.c_size_t, _i, _vp, _vp]),
     "upsp_comm_library": (_i, [C.c_char_p, _sz]),
     "upsp_timing_report": (_i, [C.c_char_p, _sz]),
@@ -278,6 +280,20 @@ def copy_probe(nbytes=1 << 30, reps=5):
     fill = nbytes / (ms.value * 1e-3) / 1e9
     return {"copy_GBps": copy, "fill_GBps": fill, "bytes": int(nbytes), "reps": int(reps),
             "kernel": "upsp::copy_probe_kernel / fill_probe_kernel (float4 per lane; fastest of non-temporal / plain at 8, 16, 32 workgroups per CU)"}
+
+
+def bandwidth_probe(nbytes=1 << 30, reps=5):
+    """Measured read-only and write-only HBM rates in the shapes of the frame loop's two passes (upsp_bandwidth_probe), GB/s."""
+    import torch
+    a = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    a.zero_()
+    ms = C.c_float()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    out = {"bytes": int(nbytes), "reps": int(reps)}
+    for kind, name in ((0, "read_GBps"), (1, "write_GBps")):
+        check(lib().upsp_bandwidth_probe(kind, C.c_void_p(a.data_ptr()), nbytes, reps, C.byref(ms), st))
+        out[name] = nbytes / (ms.value * 1e-3) / 1e9
+    return out
 
 
 def comm_library():

@@ -265,3 +265,89 @@ extern "C" int upsp_copy_probe(const void *d_src, void *d_dst, size_t bytes, int
     *ms_per_rep = best / (float)reps;
     return UPSP_OK;
 }
+
+
+// ---- read-only / write-only probes in the product kernels' own access shapes (round 6) -----------------------------------------------
+// The copy probe above mixes a read and a write stream and is SLOWER than the frame loop's passes (5.3 TB/s against 6.0-6.6 for
+// pass A, 5.5-5.6 for pass B: a fraction above 1).  Pass A is a pure read stream (non-temporal 16-byte loads, several in flight per
+// lane before the first use, one-wave or four-wave workgroups), pass B a pure write stream (a workgroup sweeping whole 4-KB row
+// pieces with 16-byte non-temporal stores): each is divided by the probe of ITS shape.  The fastest of a few launch shapes is
+// reported, like above.
+namespace upsp {
+namespace {
+template <int UNROLL, int THREADS>
+__global__ void __launch_bounds__(THREADS) read_probe_kernel(const v4f_probe *__restrict__ src, size_t n16, unsigned *sink)
+{
+    // a workgroup takes UNROLL consecutive pieces of THREADS x 16 bytes: all loads issued before the first use
+    const size_t base = (size_t)blockIdx.x * (UNROLL * THREADS) + threadIdx.x;
+    v4f_probe v[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+        const size_t i = base + (size_t)u * THREADS;
+        v[u] = i < n16 ? __builtin_nontemporal_load(src + i) : v4f_probe{0.f, 0.f, 0.f, 0.f};
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) acc += v[u].x + v[u].y + v[u].z + v[u].w;
+    if (acc == 1.2345e38f) sink[0] = 1u;        // (keeps the loads alive; practically never taken)
+}
+template <int ROWS>
+__global__ void __launch_bounds__(256) write_probe_kernel(v4f_probe *__restrict__ dst, size_t n16)
+{
+    // pass B's shape: a workgroup writes ROWS consecutive 4-KB pieces, one 16-byte non-temporal store per lane and piece
+    const size_t base = (size_t)blockIdx.x * (ROWS * 256) + threadIdx.x;
+    const v4f_probe v = {1.f, 2.f, 3.f, (float)blockIdx.x};
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const size_t i = base + (size_t)r * 256;
+        if (i < n16) __builtin_nontemporal_store(v, dst + i);
+    }
+}
+}  // namespace
+}  // namespace upsp
+
+extern "C" int upsp_bandwidth_probe(int kind, void *d_buf, size_t bytes, int reps, float *ms_per_rep, void *stream)
+{
+    using namespace upsp;
+    if (!d_buf || bytes < 16 || reps < 1 || !ms_per_rep || (kind != 0 && kind != 1)) return fail(UPSP_ERR_INVALID, "bad argument");
+    if ((reinterpret_cast<size_t>(d_buf) & 15) != 0) return fail(UPSP_ERR_INVALID, "bandwidth probe: 16-byte aligned buffer");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n16 = bytes / 16;
+    unsigned *sink = nullptr;
+    UPSP_HIP_CHECK(hipMalloc(&sink, sizeof(unsigned)));
+    hipEvent_t a = nullptr, b = nullptr;
+    hipError_t e = hipEventCreate(&a);
+    if (e == hipSuccess) e = hipEventCreate(&b);
+    float best = 0.f;
+    v4f_probe *p4 = static_cast<v4f_probe *>(d_buf);
+    for (int shape = 0; shape < 4 && e == hipSuccess; ++shape) {
+        auto grid = [&](size_t per_block) { return dim3((unsigned)((n16 + per_block - 1) / per_block)); };
+        auto launch = [&] {
+            if (kind == 0) {
+                if (shape == 0) hipLaunchKernelGGL((read_probe_kernel<4, 64>), grid(4 * 64), dim3(64), 0, st, (const v4f_probe *)p4, n16, sink);
+                else if (shape == 1) hipLaunchKernelGGL((read_probe_kernel<8, 64>), grid(8 * 64), dim3(64), 0, st, (const v4f_probe *)p4, n16, sink);
+                else if (shape == 2) hipLaunchKernelGGL((read_probe_kernel<4, 256>), grid(4 * 256), dim3(256), 0, st, (const v4f_probe *)p4, n16, sink);
+                else hipLaunchKernelGGL((read_probe_kernel<8, 256>), grid(8 * 256), dim3(256), 0, st, (const v4f_probe *)p4, n16, sink);
+            } else {
+                if (shape == 0) hipLaunchKernelGGL((write_probe_kernel<1>), grid(256), dim3(256), 0, st, p4, n16);
+                else if (shape == 1) hipLaunchKernelGGL((write_probe_kernel<4>), grid(4 * 256), dim3(256), 0, st, p4, n16);
+                else if (shape == 2) hipLaunchKernelGGL((write_probe_kernel<8>), grid(8 * 256), dim3(256), 0, st, p4, n16);
+                else hipLaunchKernelGGL((write_probe_kernel<16>), grid(16 * 256), dim3(256), 0, st, p4, n16);
+            }
+        };
+        launch();                               // (untimed: first touch, code load)
+        e = hipEventRecord(a, st);
+        for (int i = 0; i < reps && e == hipSuccess; ++i) launch();
+        if (e == hipSuccess) e = hipEventRecord(b, st);
+        if (e == hipSuccess) e = hipEventSynchronize(b);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, a, b);
+        if (e == hipSuccess && ms > 0.f && (best == 0.f || ms < best)) best = ms;
+    }
+    if (a) (void)hipEventDestroy(a);
+    if (b) (void)hipEventDestroy(b);
+    (void)hipFree(sink);
+    if (e != hipSuccess) return fail(UPSP_ERR_HIP, std::string("bandwidth probe: ") + hipGetErrorString(e));
+    *ms_per_rep = best / (float)reps;
+    return UPSP_OK;
+}

@@ -337,6 +337,14 @@ int upsp_pipeline_projection_target(upsp_pipeline *p, int cam, int32_t **d_pix)
     return UPSP_OK;
 }
 
+int upsp_pipeline_projection(upsp_pipeline *p, int cam, const int32_t **d_pix)
+{
+    if (!p || cam < 0 || cam >= p->ncams || !d_pix) return fail(UPSP_ERR_INVALID, "bad argument");
+    if (!p->has_proj[cam]) return fail(UPSP_ERR_INVALID, "projection not set");
+    *d_pix = p->d_pix[cam];
+    return UPSP_OK;
+}
+
 int upsp_pipeline_set_hot_enable(upsp_pipeline *p, int enable)
 {
     if (!p) return fail(UPSP_ERR_INVALID, "null pipeline");

@@ -366,6 +366,13 @@ class FramePipeline:
         check(lib().upsp_pipeline_projection_target(self._h, cam, C.byref(q)))
         return torch.as_tensor(_DevArray(q.value, self.nnodes, "<i4", self), device="cuda")
 
+    def current_projection(self, cam=0):
+        """int32 [N] tensor over the projection the pipeline currently holds for camera `cam` (upsp_pipeline_projection) -- after
+        step(): the one that step built.  Clone it to keep it: the buffer is reused two projections later."""
+        q = C.c_void_p()
+        check(lib().upsp_pipeline_projection(self._h, cam, C.byref(q)))
+        return torch.as_tensor(_DevArray(q.value, self.nnodes, "<i4", self), device="cuda")
+
     def prepare_rows(self):
         """What pass B needs from a new projection (every node's row in the compact series, the skipped flags), queued on the
         current stream now instead of inside the next process() call (upsp_pipeline_prepare_rows): behind set_projection() on
