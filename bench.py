@@ -1081,7 +1081,8 @@ def main():
             ex_state["step"] += 1
             ex.k = 0
             tab = pipe.pixel_series(frames)         # pass A ran beside the build: the rows of the nodes in that buffer
-            ex.submit_pixels(tab, col0=ex.my_chunk(0)[0])
+            for k in range(K):
+                ex.submit_pixels(tab, col0=ex.my_chunk(k)[0])
             if deferred:
                 drain()                             # the PREVIOUS step's series and sums, now that this step's block is on its way
                 ex_state["pending"] = ex

@@ -51,6 +51,8 @@ struct upsp_pipeline {
     int32_t *alt_node_k = nullptr;
     uint16_t *d_compact = nullptr;
     size_t compact_bytes = 0;        // allocated size of d_compact
+    uint16_t *d_compact_alt = nullptr;   // upsp_pipeline_step: the other compact buffer (pass A of step s + 1 beside pass B of step s)
+    size_t compact_bytes_alt = 0;
     unsigned *d_changes = nullptr;   // hot-pixel change list of a call (frames.hip: hot_changes_words)
     bool row_padding = false;        // upsp_pipeline_set_row_padding
     int changes_parity = 0;          // which of its two change counters the next one-camera fix-up uses
@@ -93,6 +95,7 @@ struct upsp_pipeline {
     // left to do
     struct Step {
         hipStream_t side = nullptr;
+        hipStream_t scan = nullptr;     // pass A + repair of a step, beside the previous step's pass B (normal priority)
         hipEvent_t ev_map[2] = {nullptr, nullptr}, ev_side[2] = {nullptr, nullptr}, ev_repaired[2] = {nullptr, nullptr};
         hipEvent_t ev_end[3] = {nullptr, nullptr, nullptr};
         int32_t *d_cand = nullptr;
@@ -247,6 +250,7 @@ void upsp_pipeline_destroy(upsp_pipeline *p)
     free_dev(p->alt_tile_order);
     free_dev(p->alt_node_k);
     free_dev(p->d_compact);
+    free_dev(p->d_compact_alt);
     free_dev(p->d_pix_of_k);
     free_dev(p->d_changes);
     free_dev(p->d_head);
@@ -254,6 +258,10 @@ void upsp_pipeline_destroy(upsp_pipeline *p)
     if (p->step.side) {
         (void)hipStreamSynchronize(p->step.side);
         (void)hipStreamDestroy(p->step.side);
+    }
+    if (p->step.scan) {
+        (void)hipStreamSynchronize(p->step.scan);
+        (void)hipStreamDestroy(p->step.scan);
     }
     for (hipEvent_t e : {p->step.ev_map[0], p->step.ev_map[1], p->step.ev_side[0], p->step.ev_side[1], p->step.ev_repaired[0],
                          p->step.ev_repaired[1], p->step.ev_end[0], p->step.ev_end[1], p->step.ev_end[2]})
@@ -1375,8 +1383,8 @@ int upsp_pipeline_process_u16(upsp_pipeline *p, uint16_t *const *d_frames, int n
 //           [repair of step s-1]  frames_hook (the frames may be rewritten here)            -> ev_map
 //           projection build straight into the pipeline's buffer
 //           [end of step s-1]  finals of step s-1, projection hand-over, node -> row sweep + skipped flags, tail_hook -> ev_side
-//   stream  [ev_map]  pass A (+ hot-pixel repair) on the candidate map, beside the build     -> ev_repaired
-//           [ev_side] pass B                                                                -> end of step s
+//   scan    [ev_map]  pass A (+ hot-pixel repair) on the candidate map, beside the build and beside pass B of step s-1 -> ev_repaired
+//   stream  [ev_repaired, ev_side] pass B                                                   -> end of step s
 //
 // so the caller's stream carries pass A, the repair and pass B and nothing else, and the host runs a step ahead of the device.
 // Same results as the plain sequence upsp_projection_build -> upsp_pipeline_set_projection -> upsp_pipeline_reset ->
@@ -1393,6 +1401,7 @@ static int step_setup(upsp_pipeline *p)
     for (hipEvent_t *e : {&s.ev_map[0], &s.ev_map[1], &s.ev_side[0], &s.ev_side[1], &s.ev_repaired[0], &s.ev_repaired[1], &s.ev_end[0],
                           &s.ev_end[1], &s.ev_end[2]})
         UPSP_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    UPSP_HIP_CHECK(hipStreamCreateWithFlags(&s.scan, hipStreamNonBlocking));
     UPSP_HIP_CHECK(hipMalloc(&s.d_cand, sizeof(int32_t) * p->nnodes));
     UPSP_HIP_CHECK(hipMalloc(&s.d_uv, sizeof(float) * 2 * p->nnodes));
     return UPSP_OK;
@@ -1447,11 +1456,24 @@ int upsp_pipeline_step(upsp_pipeline *p, const upsp_step_args *a, void *stream)
     if (rc != UPSP_OK) return rc;
     if (a->tail_hook) a->tail_hook(a->tail_user, side);
     UPSP_HIP_CHECK(hipEventRecord(s.ev_side[n % 2], side));
-    // ---- the caller's stream: pass A + repair, pass B ----
-    UPSP_HIP_CHECK(hipStreamWaitEvent(main, s.ev_map[n % 2], 0));
-    rc = upsp_pipeline_prescan(p, a->d_frames, a->nframes, main);      // (in two launches when upsp_pipeline_set_scan_split says so)
+    // ---- pass A + repair ----
+    // On a stream of their own, into the OTHER of two compact buffers: pass A of this step then runs beside pass B of the step
+    // before (a read stream beside a write stream) instead of behind it -- the ~30 us between the end of one and the start of the
+    // other, and both kernels' ramps, disappear from the step.  What it reads -- the frames (the hook's, ordered by ev_map), this
+    // step's map -- nobody writes; the buffer it writes was last read by pass B two steps ago (the side stream waited for that).
+    // UPSP_STEP_SCAN_STREAM=0 (measurement switch): on the caller's stream, behind the previous pass B, one compact buffer.
+    static const bool scan_beside = [] { const char *e = std::getenv("UPSP_STEP_SCAN_STREAM"); return !(e && *e == '0'); }();
+    hipStream_t scan = scan_beside ? s.scan : main;
+    if (scan_beside) {
+        std::swap(p->d_compact, p->d_compact_alt);
+        std::swap(p->compact_bytes, p->compact_bytes_alt);
+    }
+    UPSP_HIP_CHECK(hipStreamWaitEvent(scan, s.ev_map[n % 2], 0));
+    rc = upsp_pipeline_prescan(p, a->d_frames, a->nframes, scan);      // (in two launches when upsp_pipeline_set_scan_split says so)
     if (rc != UPSP_OK) return rc;
-    UPSP_HIP_CHECK(hipEventRecord(s.ev_repaired[n % 2], main));
+    UPSP_HIP_CHECK(hipEventRecord(s.ev_repaired[n % 2], scan));
+    // ---- the caller's stream: pass B ----
+    if (scan_beside) UPSP_HIP_CHECK(hipStreamWaitEvent(main, s.ev_repaired[n % 2], 0));
     UPSP_HIP_CHECK(hipStreamWaitEvent(main, s.ev_side[n % 2], 0));
     if (a->d_rows_t) {
         rc = upsp_pipeline_reset_deferred(p);            // (this step's sums start from zero: pass B writes them)
@@ -1487,9 +1509,11 @@ int upsp_pipeline_step_finish(upsp_pipeline *p, void *stream)
         if (rc != UPSP_OK) return rc;
         s.finals_due = false;
     }
-    // whatever the side stream still holds (nothing a finished step needs) is ordered in front of the caller's next launch
+    // whatever the pipeline's own streams still hold (nothing a finished step needs) is ordered in front of the caller's next launch
     UPSP_HIP_CHECK(hipEventRecord(s.ev_map[0], s.side));
     UPSP_HIP_CHECK(hipStreamWaitEvent(main, s.ev_map[0], 0));
+    UPSP_HIP_CHECK(hipEventRecord(s.ev_map[1], s.scan));
+    UPSP_HIP_CHECK(hipStreamWaitEvent(main, s.ev_map[1], 0));
     return UPSP_OK;
 }
 
