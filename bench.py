@@ -1076,6 +1076,7 @@ def main():
                   finals=None if chunked else finals_buf, nframes_total=F * world, frames_hook=lambda _st: restore_hot(),
                   tail_hook=tail if chunked else None)
         if chunked:
+            pipe.reset(deferred=True)               # the sums of whichever exchange is finished next start from zero
             which = ex_state["step"] % len(exchs)
             ex = exchs[which]
             ex_state["step"] += 1

@@ -122,6 +122,10 @@ int upsp_bvh_enable_stats(upsp_bvh *bvh, int on);
  * device-side launches without synchronising call this at their own synchronisation point. */
 int upsp_bvh_check(upsp_bvh *bvh, void *stream);
 int upsp_bvh_last_stats(const upsp_bvh *bvh, uint64_t *nodes, uint64_t *tris, uint64_t *rays);
+/* The same launch's box tests of the one-lane traversal: boxes the first filter (a plain slab test with a per-ray error bound)
+ * saw, and how many of them it left undecided -- those go through the mirrored reciprocal filter and, inside its margin, through
+ * Imath's divisions (rt::BVH::intersect's box test, cpp/raycast/pspRT.cpp:376-383).  Statistics on. */
+int upsp_bvh_last_filter_stats(const upsp_bvh *bvh, uint64_t *boxes, uint64_t *undecided);
 
 /* ======================================================================== *
  *  2.  Projection build   (reference: create_projection_mat,

@@ -304,3 +304,39 @@ def test_random_soups_bitwise(gpu_lib, oracle, seed):
     dirs[(dirs == 0).all(1)] = [1, 0, 0]
     assert_hits_equal(bvh.intersect(org, dirs), obv.intersect(org, dirs))
     assert np.array_equal(bvh.occluded(org, dirs).cpu().numpy(), obv.intersect(org, dirs)["hit"])
+
+
+def test_slab_filter_same_bits(gpu_lib, oracle, monkeypatch):
+    """Round 6: the one-lane traversal decides most boxes with a plain slab test and a per-ray error bound (box_filter_slab) and
+    hands the rest to the mirrored reciprocal filter / Imath's divisions.  Closest hits (every field) on vertex-aimed rays, random
+    rays and a lattice of rays that graze box faces must be the oracle's with the filter on, off (UPSP_SLAB_FILTER=0) and with its
+    band widened 10^5 times (UPSP_SLAB_SCALE: nearly every box goes through the fallback); the statistics report how many boxes
+    the filter left undecided: a small share by default, most of them with the wide band."""
+    from upsp_processing_amd import engine, synthetic as syn
+    v, t = syn.tunnel_model(40, 80, 16, 32)
+    s9, _ = syn.soup(v, t)
+    obv = oracle.OracleBVH(s9)
+    cam = np.array([0.5, 3.0, 20.0], np.float32)
+    d_vertex = (v - cam).astype(np.float32)
+    org, dirs = rand_rays(20000, 5, spread=8.0, jitter=1.5)
+    # rays through box corners / along faces: origins and targets on the vertex lattice of the model
+    rng = np.random.default_rng(11)
+    a, b = v[rng.integers(0, v.shape[0], 8000)], v[rng.integers(0, v.shape[0], 8000)]
+    org_l, dir_l = (a + (a - b) * 0.5).astype(np.float32), (b - a).astype(np.float32)
+    want = [obv.intersect(cam, d_vertex), obv.intersect(org, dirs), obv.intersect(org_l, dir_l)]
+    shares = {}
+    for name, env in (("default", {}), ("off", {"UPSP_SLAB_FILTER": "0"}), ("wide", {"UPSP_SLAB_SCALE": "100000"})):
+        for k in ("UPSP_SLAB_FILTER", "UPSP_SLAB_SCALE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, val in env.items():
+            monkeypatch.setenv(k, val)
+        bvh = engine.BVH(s9)
+        bvh.enable_stats(True)
+        for (o, d), w in zip(((cam, d_vertex), (org, dirs), (org_l, dir_l)), want):
+            assert_hits_equal(bvh.intersect(o, d), w)
+        bvh.intersect(org, dirs)
+        shares[name] = bvh.last_filter_stats()
+        bvh.close()
+    assert shares["off"]["boxes"] == 0
+    assert shares["default"]["boxes"] > 0 and shares["default"]["undecided"] < 0.02 * shares["default"]["boxes"], shares
+    assert shares["wide"]["undecided"] > 0.3 * shares["wide"]["boxes"], shares

@@ -75,6 +75,7 @@ SIGNATURES = {
     "upsp_bvh_occluded_host": (_i, [_vp, _vp, _i, _vp, _sz, _vp]),
     "upsp_bvh_enable_stats": (_i, [_vp, _i]),
     "upsp_bvh_check": (_i, [_vp, _vp]),
+    "upsp_bvh_last_filter_stats": (_i, [_vp, _u64p, _u64p]),
     "upsp_bvh_last_stats": (_i, [_vp, _u64p, _u64p, _u64p]),
     "upsp_projection_build": (_i, [_vp, C.POINTER(Camera), _vp, _vp, _vp, _vp, _sz, C.c_float,
                                    _vp, _vp, _vp, _u64p, _vp]),

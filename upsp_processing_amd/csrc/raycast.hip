@@ -67,7 +67,9 @@ struct Ray {
     // branch with bit-identical differences, quotients and comparisons.
     float mox, moy, moz;  // mirrored origin
     float mlx, mly, mlz;  // |l| (0 for an axis the line does not move along)
-    float ilx, ily, ilz;  // ~1/|l| (filter only)
+    float six, siy, siz;  // ~1/l, SIGNED (filters only; the mirrored forms use |.|)
+    float cx, cy, cz;     // o * (1/l): the slab filter evaluates t = fma(plane, 1/l, -c) (ray_classify)
+    float slabE;          // absolute error bound of those t against the library's quotients, for every box inside the scene
     float limx, limy, limz;  // FLT_MAX * |l| (the library's overflow guard)
     unsigned flip;        // bit a: axis mirrored (l < 0)
     unsigned zero;        // bit a: l == 0
@@ -131,9 +133,11 @@ __device__ __forceinline__ void ray_setup(Ray &r, float ox, float oy, float oz, 
     r.moz = lz < 0.0f ? -oz : oz;
     r.mlx = fabsf(lx); r.mly = fabsf(ly); r.mlz = fabsf(lz);
     r.big = (r.mlx > 1.0f ? 1u : 0u) | (r.mly > 1.0f ? 2u : 0u) | (r.mlz > 1.0f ? 4u : 0u);
-    r.ilx = __builtin_amdgcn_rcpf(r.mlx);
-    r.ily = __builtin_amdgcn_rcpf(r.mly);
-    r.ilz = __builtin_amdgcn_rcpf(r.mlz);
+    r.six = copysignf(__builtin_amdgcn_rcpf(r.mlx), lx);
+    r.siy = copysignf(__builtin_amdgcn_rcpf(r.mly), ly);
+    r.siz = copysignf(__builtin_amdgcn_rcpf(r.mlz), lz);
+    r.cx = r.cy = r.cz = 0.0f;
+    r.slabE = __builtin_inff();
     r.limx = FLT_MAX * r.mlx; r.limy = FLT_MAX * r.mly; r.limz = FLT_MAX * r.mlz;
     const float tiny = 1e-18f;
     r.exact_only = (lx != 0.0f && r.mlx < tiny) || (ly != 0.0f && r.mly < tiny) ||
@@ -184,13 +188,14 @@ __device__ __forceinline__ BoxEval box_filter(const Ray &r, float lox, float loy
     const bool inside = ex.inside & ey.inside & ez.inside;
     const bool out = ex.out | ey.out | ez.out;
     float tBack = FLT_MAX, tFront = -1.0f;
-    const float bx = ex.dB * r.ilx, by = ey.dB * r.ily, bz = ez.dB * r.ilz;
+    const float ilx = fabsf(r.six), ily = fabsf(r.siy), ilz = fabsf(r.siz);
+    const float bx = ex.dB * ilx, by = ey.dB * ily, bz = ez.dB * ilz;
     tBack = (ex.okB & (tBack > bx)) ? bx : tBack;
     tBack = (ey.okB & (tBack > by)) ? by : tBack;
     tBack = (ez.okB & (tBack > bz)) ? bz : tBack;
-    const float fx = ex.okF ? ex.dF * r.ilx : FLT_MAX;
-    const float fy = ey.okF ? ey.dF * r.ily : FLT_MAX;
-    const float fz = ez.okF ? ez.dF * r.ilz : FLT_MAX;
+    const float fx = ex.okF ? ex.dF * ilx : FLT_MAX;
+    const float fy = ey.okF ? ey.dF * ily : FLT_MAX;
+    const float fz = ez.okF ? ez.dF * ilz : FLT_MAX;
     tFront = (ex.front & (tFront < fx)) ? fx : tFront;
     tFront = (ey.front & (tFront < fy)) ? fy : tFront;
     tFront = (ez.front & (tFront < fz)) ? fz : tFront;
@@ -217,10 +222,11 @@ __device__ __forceinline__ BoxEval box_filter_simple(const Ray &r, float lox, fl
     dFk = pick(dFx, dFy, dFz, r.kz);
     const bool out = fminf(fminf(dBx, dBy), dBz) < 0.0f;
     const bool inside = !out & !(fmaxf(fmaxf(dFx, dFy), dFz) > 0.0f);
-    const float tBack = fminf(FLT_MAX, fminf(fminf(dBx * r.ilx, dBy * r.ily), dBz * r.ilz));
-    const float fx = dFx >= 0.0f ? dFx * r.ilx : -1.0f;
-    const float fy = dFy >= 0.0f ? dFy * r.ily : -1.0f;
-    const float fz = dFz >= 0.0f ? dFz * r.ilz : -1.0f;
+    const float ilx = fabsf(r.six), ily = fabsf(r.siy), ilz = fabsf(r.siz);
+    const float tBack = fminf(FLT_MAX, fminf(fminf(dBx * ilx, dBy * ily), dBz * ilz));
+    const float fx = dFx >= 0.0f ? dFx * ilx : -1.0f;
+    const float fy = dFy >= 0.0f ? dFy * ily : -1.0f;
+    const float fz = dFz >= 0.0f ? dFz * ilz : -1.0f;
     const float tFront = fmaxf(fmaxf(fx, fy), fmaxf(fz, -1.0f));
     const float e = 6e-7f;
     const bool sure_acc = tFront + fabsf(tFront) * e <= tBack - tBack * e;
@@ -228,6 +234,35 @@ __device__ __forceinline__ BoxEval box_filter_simple(const Ray &r, float lox, fl
     BoxEval b;
     b.accept = inside | (!out & sure_acc);
     b.undecided = !inside & !out & !sure_acc & !sure_rej;
+    return b;
+}
+
+// Round 6: the first filter of the "simple" class -- a plain slab test, a third of the instructions of box_filter_simple.
+// For a simple ray (all three line components non-zero, every guard of the library's test satisfied for boxes inside the scene) the
+// library's verdict is  min_i dB_i >= 0  and  max_i qF_i <= min_i qB_i  with  q = fl(fl(plane - o) / |l|)  per axis (an axis whose
+// near quotient is negative takes no part in the library's maximum, but then it is below every far quotient of a box the origin is
+// not beyond, so including it changes nothing; "origin inside" is the case where all of them are negative).  Here every quotient is
+// replaced by  t = fma(plane, 1/l, -o/l)  with the SIGNED reciprocal (near / far = min / max of the two planes' t, no mirroring, no
+// selects): |t - q| <= 6.1 u (|plane| + |o|) / |l|  (u = 2^-24: the rounded reciprocal 2 u, the rounded product o/l one u on the
+// o/l term, the fused multiply-add one u, the library's two roundings 2 u), which for every box inside the scene bounds is below
+// the per-ray constant slabE = 6e-7 x max_i (max |bound_i| + |o_i|) / |l_i| (ray_classify).  A box is decided here when the two
+// sides are more than 2 slabE apart and the far side is more than slabE from zero; everything else -- grazing contact, the origin
+// on a face -- goes to box_filter_simple and, inside its own margin, to the library's divisions.  Same verdicts, bit for bit.
+// dFk: the mirrored near-plane difference on the ray's major axis exactly as box_filter_simple forms it (the pruning test uses it).
+__device__ __forceinline__ BoxEval box_filter_slab(const Ray &r, float lox, float loy, float loz, float hix, float hiy, float hiz,
+                                                   float &dFk)
+{
+    const float t0x = __builtin_fmaf(lox, r.six, -r.cx), t1x = __builtin_fmaf(hix, r.six, -r.cx);
+    const float t0y = __builtin_fmaf(loy, r.siy, -r.cy), t1y = __builtin_fmaf(hiy, r.siy, -r.cy);
+    const float t0z = __builtin_fmaf(loz, r.siz, -r.cz), t1z = __builtin_fmaf(hiz, r.siz, -r.cz);
+    const float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
+    const float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
+    const float lo_k = pick(lox, loy, loz, r.kz), hi_k = pick(hix, hiy, hiz, r.kz), o_k = pick(r.ox, r.oy, r.oz, r.kz);
+    dFk = ((r.flip >> r.kz) & 1u) ? o_k - hi_k : lo_k - o_k;      // = (flip ? -hi : lo) - (flip ? -o : o), the same float
+    const float gap = tn - tf, e2 = 2.0f * r.slabE;
+    BoxEval b;
+    b.accept = (gap <= -e2) & (tf >= r.slabE);
+    b.undecided = !b.accept & !((gap > e2) | (tf < -r.slabE));   // (NaN anywhere: undecided)
     return b;
 }
 
@@ -350,6 +385,8 @@ struct Scene {
     unsigned round_cap;
     unsigned *err;                        // bit 0 one-lane traversal, bit 1 cooperative walk, bit 2 its one-thread fallback
     // primary pass of a repeated projection build: rays listed in kRayBins bins by their previous step count (see RayBins)
+    int slab;                             // 1: box_filter_slab in front of the mirrored filter (UPSP_SLAB_FILTER=0: off)
+    float slab_scale;                     // >= 1: widens the slab filter's error bound (tests)
     unsigned short *steps_out;            // per node: steps of its primary ray (may be null)
     unsigned nbins;                       // 0: one dense list in node order
     unsigned bin_stride;                  // list of bin b = todo_rays + b * bin_stride
@@ -366,6 +403,7 @@ struct Trav {
     unsigned n_nodes, n_tris;
     unsigned ray_nodes, ray_tris;  // STATS: steps of the current ray
     unsigned w_node_rounds, w_tri_rounds;   // STATS: rounds of the WAVE (counted by its first executing lane)
+    unsigned n_boxes, n_band;               // STATS: boxes the slab filter saw / left undecided
     unsigned steps;                // node visits + triangle tests of the current ray
 };
 
@@ -395,6 +433,14 @@ __device__ __forceinline__ void ray_classify(Ray &r, const Scene &sc)
                           fmaxf(fabsf(sc.rlo[2] - r.oz), fabsf(sc.rhi[2] - r.oz)));
     const float lim = fminf(fminf(r.limx, r.limy), r.limz);
     r.simple = (r.zero == 0u) & !r.exact_only & (D < lim) & (D == D) & (D < 1e30f);
+    // constants of the slab filter (box_filter_slab); a ray that is not simple never reaches it
+    r.cx = r.ox * r.six;
+    r.cy = r.oy * r.siy;
+    r.cz = r.oz * r.siz;
+    const float ex = (fmaxf(fabsf(sc.rlo[0]), fabsf(sc.rhi[0])) + fabsf(r.ox)) * fabsf(r.six);
+    const float ey = (fmaxf(fabsf(sc.rlo[1]), fabsf(sc.rhi[1])) + fabsf(r.oy)) * fabsf(r.siy);
+    const float ez = (fmaxf(fabsf(sc.rlo[2]), fabsf(sc.rhi[2])) + fabsf(r.oz)) * fabsf(r.siz);
+    r.slabE = 6e-7f * sc.slab_scale * fmaxf(fmaxf(ex, ey), ez);
 }
 
 // (the LDS stack is laid out [entry][thread]: STRIDE = threads per workgroup)
@@ -432,10 +478,30 @@ __device__ __forceinline__ void wide_step(Trav &s, const Ray &r, const Scene &sc
     float dF0, dF1, dF2, dF3;
     BoxEval b0, b1, b2, b3;
     if (__ballot(!r.simple) == 0ull) {   // wave-uniform: every lane holds a simple-class ray
-        b0 = box_filter_simple(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, dF0);
-        b1 = box_filter_simple(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, dF1);
-        b2 = box_filter_simple(r, q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, dF2);
-        b3 = box_filter_simple(r, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, dF3);
+        if (sc.slab) {
+            // the slab filter decides all but the grazing boxes; those go through the mirrored filter (and, inside ITS margin,
+            // through the library's divisions below)
+            b0 = box_filter_slab(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, dF0);
+            b1 = box_filter_slab(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, dF1);
+            b2 = box_filter_slab(r, q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, dF2);
+            b3 = box_filter_slab(r, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, dF3);
+            if (STATS) {
+                s.n_boxes += 4u;
+                s.n_band += (b0.undecided ? 1u : 0u) + (b1.undecided ? 1u : 0u) + (b2.undecided ? 1u : 0u) + (b3.undecided ? 1u : 0u);
+            }
+            if (__ballot(b0.undecided | b1.undecided | b2.undecided | b3.undecided) != 0ull) {
+                float d;
+                if (b0.undecided) b0 = box_filter_simple(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, d);
+                if (b1.undecided) b1 = box_filter_simple(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, d);
+                if (b2.undecided) b2 = box_filter_simple(r, q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, d);
+                if (b3.undecided) b3 = box_filter_simple(r, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, d);
+            }
+        } else {
+            b0 = box_filter_simple(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, dF0);
+            b1 = box_filter_simple(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, dF1);
+            b2 = box_filter_simple(r, q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, dF2);
+            b3 = box_filter_simple(r, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, dF3);
+        }
     } else {
         b0 = box_filter(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, dF0);
         b1 = box_filter(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, dF1);
@@ -857,6 +923,7 @@ __global__ void __launch_bounds__(kBlock)
     Trav s;
     s.cur = kDone;
     s.n_nodes = s.n_tris = 0;
+    s.n_boxes = s.n_band = 0;
     s.w_node_rounds = s.w_tri_rounds = 0;
     unsigned item = 0, my_rays = 0;
     bool busy = false;
@@ -913,6 +980,15 @@ __global__ void __launch_bounds__(kBlock)
     if (STATS) {
         if (s.w_node_rounds) atomicAdd(&work[14], s.w_node_rounds);
         if (s.w_tri_rounds) atomicAdd(&work[15], s.w_tri_rounds);
+        unsigned nb = s.n_boxes, nu = s.n_band;       // slab filter: boxes seen / left to the mirrored filter (one atomic per wave)
+        for (int off = 32; off > 0; off >>= 1) {
+            nb += __shfl_down(nb, off);
+            nu += __shfl_down(nu, off);
+        }
+        if (lane_id() == 0 && nb) {
+            atomicAdd(&work[28], nb >> 2);            // (wide steps: 4 boxes each; a u32 holds 4 G steps)
+            atomicAdd(&work[29], nu);
+        }
     }
     if (STATS) flush_stats(work, lds_stack, s.n_nodes, s.n_tris, my_rays);
 }
@@ -1366,6 +1442,7 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(4, 8)))
     Trav s;
     s.cur = kDone;
     s.n_nodes = s.n_tris = 0;
+    s.n_boxes = s.n_band = 0;
     s.w_node_rounds = s.w_tri_rounds = 0;
     unsigned item = 0, my_rays = 0;
     bool busy = false, bounded = false;
@@ -1453,6 +1530,15 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(4, 8)))
     if (STATS) {
         if (s.w_node_rounds) atomicAdd(&work[14], s.w_node_rounds);
         if (s.w_tri_rounds) atomicAdd(&work[15], s.w_tri_rounds);
+        unsigned nb = s.n_boxes, nu = s.n_band;       // slab filter: boxes seen / left to the mirrored filter (one atomic per wave)
+        for (int off = 32; off > 0; off >>= 1) {
+            nb += __shfl_down(nb, off);
+            nu += __shfl_down(nu, off);
+        }
+        if (lane_id() == 0 && nb) {
+            atomicAdd(&work[28], nb >> 2);            // (wide steps: 4 boxes each; a u32 holds 4 G steps)
+            atomicAdd(&work[29], nu);
+        }
     }
     flush_stats(work, lds_stack, STATS ? s.n_nodes : 0u, STATS ? s.n_tris : 0u,
                 PHASE == 0 ? my_rays : 0u, PHASE == 0 ? my_rays : 0u);
@@ -2245,6 +2331,9 @@ Scene make_scene(const upsp_bvh *b, size_t items, int grid)
     sc.path_ref = nullptr;
     sc.witness = nullptr;
     sc.hist = nullptr;
+    // (read per call: the tests switch the slab filter off and widen its band in one process)
+    sc.slab = env_int("UPSP_SLAB_FILTER", 1) != 0;
+    sc.slab_scale = (float)std::max(1, env_int("UPSP_SLAB_SCALE", 1));      // test switch: a wider band = more boxes through the fallback
     sc.steps_out = nullptr;
     sc.nbins = 0;
     sc.bin_stride = 0;
@@ -2333,6 +2422,12 @@ int read_stats(upsp_bvh *b, hipStream_t st)
     b->last_stats[0] = h[0];
     b->last_stats[1] = h[1];
     b->last_stats[2] = h[2];
+    {
+        unsigned sl[2] = {0, 0};
+        UPSP_HIP_CHECK(hipMemcpy(sl, b->d_work + 28, sizeof(sl), hipMemcpyDeviceToHost));
+        b->last_slab[0] = 4ull * sl[0];
+        b->last_slab[1] = sl[1];
+    }
     return UPSP_OK;
 }
 
@@ -2804,6 +2899,14 @@ int upsp_bvh_last_stats(const upsp_bvh *b, uint64_t *nodes, uint64_t *tris, uint
     if (nodes) *nodes = b->last_stats[0];
     if (tris) *tris = b->last_stats[1];
     if (rays) *rays = b->last_stats[2];
+    return UPSP_OK;
+}
+
+int upsp_bvh_last_filter_stats(const upsp_bvh *b, uint64_t *boxes, uint64_t *undecided)
+{
+    if (!b) return fail(UPSP_ERR_INVALID, "null BVH");
+    if (boxes) *boxes = b->last_slab[0];
+    if (undecided) *undecided = b->last_slab[1];
     return UPSP_OK;
 }
 

@@ -119,6 +119,7 @@ struct upsp_bvh {
     int stats_on = 0;
     bool batch_warmed = false;     // the first large batch query swept the tree through the caches (prefetch_bvh)
     uint64_t last_stats[3] = {0, 0, 0};
+    uint64_t last_slab[2] = {0, 0};      // boxes the slab filter saw / left undecided (statistics on)
     uint64_t last_primary = 0, last_retry_nodes = 0;
     const upsp_bvh *shared_from = nullptr;   // upsp_bvh_share: the tree / adjacency arrays belong to that handle
     // Length-homogeneous waves of a REPEATED projection build (round 6): the step count of every node's primary ray as the

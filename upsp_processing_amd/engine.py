@@ -94,6 +94,12 @@ class BVH:
         check(lib().upsp_bvh_last_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return dict(nodes=a.value, tris=b.value, rays=c.value)
 
+    def last_filter_stats(self):
+        """dict(boxes, undecided): box tests of the last launch the slab filter saw / left to the mirrored filter (stats on)."""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        check(lib().upsp_bvh_last_filter_stats(self.handle, C.byref(a), C.byref(b)))
+        return dict(boxes=int(a.value), undecided=int(b.value))
+
     @staticmethod
     def _rays(org, dirs):
         dirs = _dev(dirs, torch.float32).reshape(-1, 3)
