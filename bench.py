@@ -862,17 +862,58 @@ def multi_camera_main(a):
 
 def main():
     a = parse()
-    if a.config3_share:
-        a.force_chunked = True
-        if a.frames == 1000:
-            a.frames = 12500
-        a.no_reraycast = True
     if a.cameras > 1:
         if a.gpus != 1:
             raise SystemExit("bench.py --cameras: one GPU (all cameras of a frame are kept on one GPU)")
         return multi_camera_main(a)
     if a.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(a.gpus))
+    run(a)
+
+
+def configs3_block(a, world, N, npix):
+    """BASELINE configs[3] at its OWN size inside the N > 1 line: 100 000 frames sharded over the ranks (apportion,
+    cpp/exec/psp_process.cpp:611-624, :1519-1529), every rank's share resident in HBM, ONE step through the chunked pixel-series
+    exchange with real peers (the --config3-share code path: pass A per <= 1024-frame chunk, a block per peer and chunk, the owner's
+    pass B over all frames of the run, the all-reduce of the sums; global_transpose :707-771).  The frames a rank can hold are
+    bounded by its HBM: 2 MiB of frame + 4 B x N of its series slice per frame of the rank, + the exchange's buffers -- when 70 %
+    of the free memory does not hold the share (two ranks: 50 000 frames = 230 GB), the block runs on what fits and says so.
+    UPSP_BENCH_CONFIGS3_FRAMES: another total (the tests)."""
+    import copy
+    import torch
+    import torch.distributed as dist
+    total = int(os.environ.get("UPSP_BENCH_CONFIGS3_FRAMES", "100000"))
+    share = total // world
+    per_frame = npix * 2 + N * 4 + (1 << 19)
+    free_b = torch.cuda.mem_get_info()[0]
+    fit = int(0.7 * free_b / per_frame) // 64 * 64
+    t = torch.tensor([min(share, fit)], dtype=torch.int64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    F3 = int(t.item())
+    if F3 < 64:
+        return {"skipped": "%.0f GB of HBM free on the fullest rank: no room for a share of configs[3]" % (free_b / 1e9)}
+    a3 = copy.copy(a)
+    a3.config3_share, a3.frames, a3.steps, a3.warmup = True, F3, 1, 1
+    a3.no_cpu_baseline = a3.no_reraycast = True
+    blk = run(a3, nested=True)
+    keep = ("value", "unit", "ms_per_step", "steps", "warmup", "ms_per_step_rank_min_max", "rccl_nranks", "rccl_bound", "rccl_library",
+            "exchange_self_check", "exchange_finals_check", "exchange_bytes_per_step")
+    out = {k: blk[k] for k in keep if k in blk}
+    out["workload"] = "configs[3]: %d frames x %dx%d u16 sharded over %d ranks (%d per rank), 1 M-tri model, time-series exchange at the end of the step" % (
+        F3 * world, a.size, a.size, world, F3)
+    out["frames_per_rank"] = F3
+    out["exchange"] = blk["config"].get("exchange")
+    if F3 < share:
+        out["note"] = "configs[3]'s share is %d frames per rank; %.0f GB of HBM free hold %d" % (share, free_b / 1e9, F3)
+    return out
+
+
+def run(a, nested=False):
+    if a.config3_share:
+        a.force_chunked = True
+        if a.frames == 1000:
+            a.frames = 12500
+        a.no_reraycast = True
     import torch
     import torch.distributed as dist
     from upsp_processing_amd import _capi, engine, synthetic as syn, distributed as D
@@ -897,7 +938,7 @@ def main():
         with socket.socket() as sck:
             sck.bind(("127.0.0.1", 0))
             os.environ.setdefault("MASTER_PORT", str(sck.getsockname()[1]))
-    if world > 1 or force_coll:
+    if (world > 1 or force_coll) and not nested:
         import datetime
         try:
             # (a rank that never shows up must end the job with a message, not hang it: 5-minute rendezvous limit)
@@ -926,7 +967,8 @@ def main():
     F = a.frames
     if a.small:
         verts, tris = syn.tunnel_model_quad(64, 24)
-        F = min(F, 64)
+        if not nested:
+            F = min(F, 64)
     elif a.fill_frame:
         verts, tris = syn.cube_sphere(289, 6.0)   # 1 002 252 triangles, 501 128 nodes: a sphere that fills the frame
     elif a.model == "uv":
@@ -1595,15 +1637,27 @@ def main():
             "; %.1f k frames/s when they arrive from host memory (PCIe-bound, never `value`)" % (hf["frames_per_s"] / 1e3) if hf and hf.get("frames_per_s") else "",
             "; configs[2] (ECC registration, parity unpinned) %.0f k frames/s" % (c2["value"] / 1e3) if c2 else "",
             "; %.2f G rays/s entering the tree" % (out["mrays_per_s"] / 1e3) if out.get("mrays_per_s") else "")
+    # BASELINE configs[3] at its own size, inside the N > 1 line (every rank takes part; rank 0 holds the line)
+    if (not nested and world > 1 and chunked and pixel_wire and not a.config3_share and not a.registration and not a.chunk_scan and
+            not a.sync_exchange and (not a.small or os.environ.get("UPSP_BENCH_CONFIGS3_FRAMES"))):
+        blk3 = configs3_block(a, world, N, size * size)
+        if rank == 0:
+            out["configs3"] = blk3
+    if rank == 0 and not nested:
         print(json.dumps(out), flush=True)
     if exch is not None:
         for x in exchs:
             x.verify()                  # (the timer-on steps made assume_same claims too)
             x.close()
+    if nested:
+        if xcheck is False:
+            raise SystemExit("bench.py (configs[3] block): the series out of the exchange differ from this rank's frames on at least one rank")
+        return out
     if world > 1 or force_coll:
         D.shutdown()
     if xcheck is False:
         raise SystemExit("bench.py: the series out of the exchange differ from this rank's frames on at least one rank")
+    return out
 
 
 if __name__ == "__main__":

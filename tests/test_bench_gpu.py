@@ -149,3 +149,19 @@ def test_bench_rank_processes_on_one_gpu(gpu_lib, rccl_shim, world, extra):
     x = d["exchange_bytes_per_step"]
     assert x["transport"].startswith("C ABI") and x["sent_to_other_ranks_this_run"] > 0
     assert d["config"]["parallelism"] == "frames sharded x%d" % world
+
+
+def test_bench_configs3_block_in_the_multi_rank_line(gpu_lib, rccl_shim):
+    """The N > 1 line carries BASELINE configs[3] as a block of its own: the run's total frames (here 6 600 instead of 100 000)
+    sharded over the ranks, every share resident, ONE step through the chunked pixel-series exchange with real peer processes
+    (2 200 frames per rank = three pass-A chunks), with its own value, per-rank step times, communicator size, self / finals checks
+    and exchange bytes -- the line a multi-GPU run prints must be right the first time (round-5 review)."""
+    env = {"UPSP_BENCH_BACKEND": "gloo", "UPSP_BENCH_ONE_GPU": "1", "UPSP_RCCL_LIBRARY": rccl_shim, "UPSP_BENCH_CONFIGS3_FRAMES": "6600"}
+    d = run_bench(["--gpus", "3", "--small", "--steps", "2", "--warmup", "1"], env=env, timeout=900)
+    assert d["n_gpus"] == 3 and d["exchange_self_check"] is True
+    b = d["configs3"]
+    assert b["frames_per_rank"] == 2200 and b["workload"].startswith("configs[3]: 6600 frames")
+    assert b["rccl_nranks"] == 3 and b["exchange_self_check"] is True and b["exchange_finals_check"] in (True, None)
+    assert b["value"] > 0 and b["unit"] == "frames/s" and len(b["ms_per_step_rank_min_max"]) == 2
+    assert b["exchange_bytes_per_step"]["frames_per_rank"] == 2200 and b["exchange_bytes_per_step"]["sent_to_other_ranks_this_run"] > 0
+    assert b["exchange"].startswith("3 chunks, active-pixel series")

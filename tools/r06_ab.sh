@@ -39,3 +39,16 @@ elif [ $part = stagger ]; then
     done
   done
 fi
+if [ $part = step ]; then
+  # the one-call step: pass A on its own stream (UPSP_STEP_SCAN_STREAM), slab filter, ray bins -- one switch at a time against all off
+  B="UPSP_STEP_SCAN_STREAM=0 UPSP_RAY_BINS=0 UPSP_SLAB_FILTER=0"
+  for i in 1 2 3; do
+    line base_$i $B -- --no-reraycast --steps 20 --warmup 5 || exit 1
+    line scanstream_$i UPSP_STEP_SCAN_STREAM=1 UPSP_RAY_BINS=0 UPSP_SLAB_FILTER=0 -- --no-reraycast --steps 20 --warmup 5 || exit 1
+    line slab_$i UPSP_STEP_SCAN_STREAM=0 UPSP_RAY_BINS=0 UPSP_SLAB_FILTER=1 -- --no-reraycast --steps 20 --warmup 5 || exit 1
+    line bins_$i UPSP_STEP_SCAN_STREAM=0 UPSP_RAY_BINS=1 UPSP_SLAB_FILTER=0 -- --no-reraycast --steps 20 --warmup 5 || exit 1
+  done
+elif [ $part = rays ]; then
+  UPSP_RAY_BINS=0 python3 tools/r06_rays.py || exit 1
+  UPSP_RAY_BINS=1 python3 tools/r06_rays.py || exit 1
+fi
