@@ -301,3 +301,31 @@ def test_shared_tree_builds_side_by_side(gpu_lib):
         h.close()
     again = engine.build_projection(bvh, cams[0], d_v, d_n, d_tn, 70.0, counts=False)
     assert torch.equal(again["pix"], want[0]["pix"])
+
+
+def test_length_binned_primary_lists_same_projection(gpu_lib, oracle, monkeypatch):
+    """UPSP_RAY_BINS=1 (round 6, off by default: measured slower): a REPEATED build bins the dense list of primary rays by the step
+    counts of the build before it (six lists, an eighth of every bin per XCD).  Ordering only: pix / uv of the first build (plain
+    list), the second and third (binned) and of a build with the switch off are identical, and the oracle's."""
+    import torch
+    from upsp_processing_amd import _capi, engine, synthetic as syn
+    v, t = syn.tunnel_model(60, 120, 24, 48)
+    s9, tn = syn.soup(v, t)
+    nrm = syn.node_normals(v, t)
+    c = syn.pinhole_camera(512, 512, center=(0, 0, 20), half_extent=6.0, fill=0.7)
+    cam = _capi.make_camera(c["K"], c["dist"], c["R"], c["t"], 512, 512)
+    cam_o = oracle.make_camera(c["K"], c["dist"], c["R"], c["t"], 512, 512)
+    o = oracle.create_projection(oracle.OracleBVH(s9), cam_o, v, nrm, tn, engine.oblique_threshold(70.0))
+    bvh = engine.BVH(s9)
+    d_v, d_n, d_tn = torch.as_tensor(v).cuda(), torch.as_tensor(nrm).cuda(), torch.as_tensor(tn).cuda()
+    bvh.set_tri_nodes(d_tn, v.shape[0])
+    monkeypatch.setenv("UPSP_RAY_BINS", "1")
+    outs = [engine.build_projection(bvh, cam, d_v, d_n, d_tn, 70.0, counts=False) for _ in range(3)]
+    counted = engine.build_projection(bvh, cam, d_v, d_n, d_tn, 70.0, counts=True)      # the reference's order, binned too
+    monkeypatch.setenv("UPSP_RAY_BINS", "0")
+    outs.append(engine.build_projection(bvh, cam, d_v, d_n, d_tn, 70.0, counts=False))
+    for g in outs + [counted]:
+        assert np.array_equal(g["pix"].cpu().numpy(), o["pix"])
+        assert np.array_equal(g["uv"].cpu().numpy().view(np.int32).reshape(-1), o["uv"].view(np.int32).reshape(-1))
+    assert counted["nrays"] == o["nrays"]
+    bvh.check()

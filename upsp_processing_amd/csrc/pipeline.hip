@@ -1383,8 +1383,8 @@ int upsp_pipeline_process_u16(upsp_pipeline *p, uint16_t *const *d_frames, int n
 //           [repair of step s-1]  frames_hook (the frames may be rewritten here)            -> ev_map
 //           projection build straight into the pipeline's buffer
 //           [end of step s-1]  finals of step s-1, projection hand-over, node -> row sweep + skipped flags, tail_hook -> ev_side
-//   scan    [ev_map]  pass A (+ hot-pixel repair) on the candidate map, beside the build and beside pass B of step s-1 -> ev_repaired
-//   stream  [ev_repaired, ev_side] pass B                                                   -> end of step s
+//   stream  [ev_map]  pass A (+ hot-pixel repair) on the candidate map, beside the build     -> ev_repaired
+//           [ev_side] pass B                                                                -> end of step s
 //
 // so the caller's stream carries pass A, the repair and pass B and nothing else, and the host runs a step ahead of the device.
 // Same results as the plain sequence upsp_projection_build -> upsp_pipeline_set_projection -> upsp_pipeline_reset ->
@@ -1461,8 +1461,12 @@ int upsp_pipeline_step(upsp_pipeline *p, const upsp_step_args *a, void *stream)
     // before (a read stream beside a write stream) instead of behind it -- the ~30 us between the end of one and the start of the
     // other, and both kernels' ramps, disappear from the step.  What it reads -- the frames (the hook's, ordered by ev_map), this
     // step's map -- nobody writes; the buffer it writes was last read by pass B two steps ago (the side stream waited for that).
-    // UPSP_STEP_SCAN_STREAM=0 (measurement switch): on the caller's stream, behind the previous pass B, one compact buffer.
-    static const bool scan_beside = [] { const char *e = std::getenv("UPSP_STEP_SCAN_STREAM"); return !(e && *e == '0'); }();
+    // MEASURED AND NOT THE DEFAULT (round 6, three alternations in one call): 1.09-1.10 ms per step against 0.82-0.83 with pass A
+    // behind pass B on the caller's stream -- a read stream and a write stream side by side each take twice as long (pass A 0.35 ->
+    // 0.71 ms, pass B 0.35 -> 0.81 ms, the primary pass beside them 0.36 -> 0.70 ms): the memory system moves a mix of reads and
+    // writes no faster than the copy probe does (5.3 TB/s) and the two kernels also take each other's wave slots.
+    // UPSP_STEP_SCAN_STREAM=1 (measurement switch) turns it on.
+    static const bool scan_beside = [] { const char *e = std::getenv("UPSP_STEP_SCAN_STREAM"); return e && *e == '1'; }();
     hipStream_t scan = scan_beside ? s.scan : main;
     if (scan_beside) {
         std::swap(p->d_compact, p->d_compact_alt);

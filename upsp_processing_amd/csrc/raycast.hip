@@ -1055,6 +1055,12 @@ constexpr unsigned kHeavyCap = 65536;
 // inside a bin, and a wave takes 64 consecutive rays of ONE bin -- simulated: longest ray of a wave 36.3 -> 27 steps, rounds per
 // wave 54 -> 44.  Every XCD takes an eighth of EVERY bin (the long rays would otherwise all land on one XCD).  The first build of a
 // handle (or one with another node count) uses the plain list.  Ordering only: every ray's own sequence of steps is unchanged.
+// MEASURED (round 6, bench model, three alternations): the primary pass alone 0.143 -> 0.160 ms, the build alone 0.295 -> 0.35 ms,
+// the default step 0.823-0.831 -> 0.878-0.883 ms.  The rounds do drop, but a wave's 64 rays now come from a six times wider stretch
+// of the node list: their paths through the tree share fewer records, and the pass is bound by the latency of those fetches, not by
+// the lanes that idle in a round (the instruction count is not it either: the slab filter below removes a quarter of a wide step's
+// box-test instructions for 3 % of the build).  OFF by default (UPSP_RAY_BINS=1 turns it on); kept for models whose ray lengths
+// spread more than their paths diverge.
 constexpr unsigned kRayBins = 6;          // (the lists of bins 0..5 share d_todo_rays: 6 x nnodes entries)
 constexpr int kWorkBinCount = kWorkBinCountFwd;   // [22..27]: rays per bin
 
@@ -3036,9 +3042,9 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
         UPSP_HIP_CHECK(hipMalloc(&b->d_todo_rays, sizeof(unsigned) * 6 * nnodes));
         b->retry_capacity = nnodes;
     }
-    // length-homogeneous waves (kRayBins): UPSP_RAY_BINS=0 switches them off (A/B)
-    static const int ray_bins_env = env_int("UPSP_RAY_BINS", 1);
-    const bool bins_on = ray_bins_env != 0 && nnodes < 0x7FFFFFFFull / kRayBins;
+    // length-homogeneous waves (kRayBins): OFF by default -- measured slower (see kRayBins); UPSP_RAY_BINS=1 turns them on
+    const bool bins_on = env_int("UPSP_RAY_BINS", 0) != 0 && nnodes < 0x7FFFFFFFull / kRayBins;
+    if (!bins_on) b->steps_valid = false;
     if (bins_on && b->steps_nnodes != nnodes) {
         if (b->d_steps) (void)hipFree(b->d_steps);
         b->d_steps = nullptr;
