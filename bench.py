@@ -671,6 +671,7 @@ def multi_camera_main(a):
     sample = [fr[:n_sample].cpu().view(torch.int16).numpy().view(np.uint16).copy() for fr in frames] if not a.no_cpu_baseline else None
     restorers = [hot_pixel_restorer(fr) for fr in frames]
     pipe = engine.FramePipeline(C, size, size, N)
+    pipe.set_row_padding(True)      # (columns F .. pitch of rows_t are padding; the several-camera row pass uses them when it pays)
     rows_t = torch.empty((N, engine.series_ld(F, whole_rows=True)), dtype=torch.float32, device="cuda")[:, :F]
     ev = lambda: torch.cuda.Event(enable_timing=True)
     ev_log, last = [], {}

@@ -52,3 +52,19 @@ elif [ $part = rays ]; then
   UPSP_RAY_BINS=0 python3 tools/r06_rays.py || exit 1
   UPSP_RAY_BINS=1 python3 tools/r06_rays.py || exit 1
 fi
+if [ $part = multi ]; then
+  # several-camera row pass (configs[4] shape, 4 cameras x 5 M triangles): UPSP_MULTI_VARIANT 0 = round 5, 1 = padded rows,
+  # 2 = padded + all series loads first, 3 = all loads first
+  for i in 1 2; do
+    for v in 0 1 2 3; do
+      timeout -k 10 600 env UPSP_MULTI_VARIANT=$v python3 bench.py --cameras 4 --model 5m --steps 3 --warmup 1 --no-cpu-baseline > $o/multi_${v}_$i.json 2>> $o/err.log || { tail -5 $o/err.log; exit 1; }
+      python3 - $o/multi_${v}_$i.json $v <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+k = d["kernels"]
+print("variant %s: step %.3f ms, %.0f frame sets/s, node_rows_multi %.4f ms, scan %.4f ms" % (sys.argv[2], d["ms_per_step"], d["value"],
+      k["node_rows_multi_kernel"]["avg_launch_ms"], k.get("scan_compact_kernel", {}).get("ms_per_step", 0)), flush=True)
+PY
+    done
+  done
+fi

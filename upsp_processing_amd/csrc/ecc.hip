@@ -80,7 +80,6 @@ __device__ __forceinline__ EccMargins ecc_margins(int band, int rows, int cols)
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr int kEccFlush = 32;        // rows per float segment
-constexpr int kEccStagger = 0;       // default start delay unit of the general iteration's workgroups (x 32 x 64 cycles; ecc_cols_kernel)
 
 struct EccPart {        // float partial sums of one segment
     v2f G0, G1, Gw0, Gw1, Gt0, Gt1, Q0, Q1, Q2, C01;
@@ -756,20 +755,15 @@ template <bool IDENT, int UR, int WAVES>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
     ecc_cols_kernel(const float *__restrict__ img, const float *__restrict__ tmpl, int rows, int cols,
                     const EccState *__restrict__ state, const int2 *__restrict__ rtab, double *__restrict__ partial,
-                    const float *__restrict__ center, unsigned nband, int force_direct, int stagger)
+                    const float *__restrict__ center, unsigned nband, int force_direct)
 {
     __shared__ double lds_red[IDENT ? kEccChunk : kEccLdsRows][256];     // source tile / reduction chunks of whichever body runs
     const int f = blockIdx.x;
     if (state[f].done) return;
-    if (!IDENT && stagger > 0 && blockIdx.y >= nband) {
-        // Phase offset of the workgroup (round 6).  The general iteration alternates between staging a tile (global loads, LDS
-        // stores, two barriers: latency) and walking it (VALU); the workgroups of a compute unit hide each other's staging only
-        // when they are out of phase (LAB_NOTES section 12 (5): 0.99 ms when they start together, 0.74 as the band blocks happen
-        // to stagger them).  A start delay of 0 / 1 / 2 x `stagger` sleep units by a hash of the frame index puts the three
-        // workgroups of a compute unit a third of a segment apart on average.  No effect on the sums (timing only).
-        const unsigned ph = (((unsigned)f * 2654435761u) >> 16) % 3u;
-        for (unsigned i = 0; i < ph * (unsigned)stagger; ++i) __builtin_amdgcn_s_sleep(32);
-    }
+    // (Round 6, measured and removed: a start delay of 0 / 1 / 2 units by a hash of the frame index for the interior workgroups of
+    //  the general iteration, to put the three workgroups of a compute unit out of phase so that they hide each other's tile staging.
+    //  Units of 3 / 6 / 12 x 0.85 us: 1.464 -> 1.507 / 1.551 / 1.645 ms per 512-frame launch, two alternations -- the delay is
+    //  simply added; the workgroups are not waiting for each other's phase.)
     if (blockIdx.y >= nband)
         ecc_cols_body<IDENT, UR>(img, tmpl, rows, cols, state, rtab, partial, f, nband, blockIdx.y - nband, gridDim.y - nband, lds_red,
                                  *center, force_direct);
@@ -1053,9 +1047,6 @@ int run_ecc(FrameScratch *s, const float *tmpl_blur, const float *d_center, cons
     // tile -- the same bits (tests/test_imageops_gpu.py::test_ecc_lds_taps_same_bits)
     const char *direct_env = std::getenv("UPSP_ECC_DIRECT");
     const int force_direct = direct_env && std::atoi(direct_env) != 0;
-    // UPSP_ECC_STAGGER=n (measurement switch): start delay of the general iteration's interior workgroups, see ecc_cols_kernel
-    const char *stagger_env = std::getenv("UPSP_ECC_STAGGER");
-    const int stagger = stagger_env ? std::max(0, std::atoi(stagger_env)) : kEccStagger;
     bool first_burst = true, waited = false;
     int it = 0, iters_done = 0, most_iters = 0;
     for (;;) {
@@ -1071,10 +1062,10 @@ int run_ecc(FrameScratch *s, const float *tmpl_blur, const float *d_center, cons
                 const dim3 grid((unsigned)nb, (unsigned)nblocks_total);
                 if (it == 0)
                     hipLaunchKernelGGL((ecc_cols_kernel<true, 4, 4>), grid, dim3(256), 0, st, blurred, tmpl_blur, rows, cols,
-                                       (const EccState *)s->state, (const int2 *)s->rtab, s->partial, d_center, (unsigned)nband, 0, 0);
+                                       (const EccState *)s->state, (const int2 *)s->rtab, s->partial, d_center, (unsigned)nband, 0);
                 else
                     hipLaunchKernelGGL((ecc_cols_kernel<false, 2, 3>), grid, dim3(256), 0, st, blurred, tmpl_blur, rows, cols,
-                                       (const EccState *)s->state, (const int2 *)s->rtab, s->partial, d_center, (unsigned)nband, force_direct, stagger);
+                                       (const EccState *)s->state, (const int2 *)s->rtab, s->partial, d_center, (unsigned)nband, force_direct);
             }
             KTimed kt2("ecc_solve_kernel", st);
             hipLaunchKernelGGL(ecc_solve_kernel, dim3(nb), dim3(256), 0, st, s->state, (const double *)s->partial, s->rtab, nb,

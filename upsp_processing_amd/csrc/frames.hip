@@ -1340,13 +1340,17 @@ struct StreamMultiArgs {
 // one (two staging areas in LDS): of the two dependent memory latencies per group, staging and series loads, the first is hidden.
 // Measured and NOT the default (UPSP_MULTI_PIPE=n workgroups per CU): the loop-carried staging registers take the kernel from 96 to
 // 130 VGPRs (3 instead of 5 waves per SIMD): 3.14-3.23 ms against 2.68-2.74; held to 96 registers it spills 33 of them: 4.0 ms.
-template <int LPR, int ROWS, int NC, int FPL = 4, int PIPE = 0, int AHEAD = ROWS>
-__global__ void __launch_bounds__(256)
+template <int LPR, int ROWS, int NC, int FPL = 4, int PIPE = 0, int AHEAD = ROWS, bool PAD = false>
+__global__ void __launch_bounds__(256, (PAD && AHEAD == 1) ? 7 : 1)      // (the padded form must not lose the seventh wave to two registers)
     node_rows_multi_kernel(StreamMultiArgs a, unsigned cpitch, const uint8_t *__restrict__ skipped,
                            const int32_t *__restrict__ rowmap, unsigned nnodes, int nframes,
                            float *__restrict__ rows_t, long long ld_t, double *__restrict__ sum,
                            double *__restrict__ sumsq)
 {
+    // PAD: the columns from the last frame to the next 128-byte line of a stored row are padding the caller gave up
+    // (upsp_pipeline_set_row_padding): written as 0 (NaN in the row of a node no camera sees).  (Derived from nframes, not passed:
+    // one more kernel argument took the kernel from 72 to 74 registers, i.e. from seven waves per SIMD to six.)
+    const int nstore = PAD ? ((nframes + 31) & ~31) : nframes;
     constexpr int RPS = 256 / LPR, WPR = LPR / 64, NR = RPS * ROWS;
     constexpr int MC = NC ? NC : kMaxCams;
     constexpr int NB = PIPE ? 2 : 1;
@@ -1452,7 +1456,7 @@ __global__ void __launch_bounds__(256)
         if (j + AHEAD < ROWS) series_load(j + AHEAD);
         const int r = j * RPS + sub;
         const int row = s_row[r], kind = s_kind[r];
-        const bool stored = row >= 0 && f0 < nframes && n0 + (unsigned)r < nnodes;
+        const bool stored = row >= 0 && f0 < nstore && n0 + (unsigned)r < nnodes;
         if (kind != 0) {                                        // (uniform per wave) constant fill
             if (stored) {
                 float *dst = rows_t + (long long)row * ld_t + f0;
@@ -1461,13 +1465,13 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
                 for (int h = 0; h < FPL / 4; ++h) {
                     const int fh = f0 + GS * h;
-                    if (vec_ok && fh + 3 < nframes) {
+                    if (vec_ok && fh + 3 < nstore) {
                         __builtin_nontemporal_store(nv, reinterpret_cast<v4f *>(dst + GS * h));
                     } else {
-                        if (fh < nframes) dst[GS * h] = cv;
-                        if (fh + 1 < nframes) dst[GS * h + 1] = cv;
-                        if (fh + 2 < nframes) dst[GS * h + 2] = cv;
-                        if (fh + 3 < nframes) dst[GS * h + 3] = cv;
+                        if (fh < nstore) dst[GS * h] = cv;
+                        if (fh + 1 < nstore) dst[GS * h + 1] = cv;
+                        if (fh + 2 < nstore) dst[GS * h + 2] = cv;
+                        if (fh + 3 < nstore) dst[GS * h + 3] = cv;
                     }
                 }
             }
@@ -1511,14 +1515,16 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
         for (int h = 0; h < FPL / 4; ++h) {
             const int fh = f0 + GS * h;
-            const v4f nv = {acc[4 * h], acc[4 * h + 1], acc[4 * h + 2], acc[4 * h + 3]};
-            if (vec_ok && fh + 3 < nframes) {
+            // (columns past the last frame: padding -> 0, whatever the series buffers hold there)
+            const v4f nv = {fh < nframes ? acc[4 * h] : 0.0f, fh + 1 < nframes ? acc[4 * h + 1] : 0.0f,
+                            fh + 2 < nframes ? acc[4 * h + 2] : 0.0f, fh + 3 < nframes ? acc[4 * h + 3] : 0.0f};
+            if (vec_ok && fh + 3 < nstore) {
                 __builtin_nontemporal_store(nv, reinterpret_cast<v4f *>(dst + GS * h));
             } else {
-                if (fh < nframes) dst[GS * h] = nv.x;
-                if (fh + 1 < nframes) dst[GS * h + 1] = nv.y;
-                if (fh + 2 < nframes) dst[GS * h + 2] = nv.z;
-                if (fh + 3 < nframes) dst[GS * h + 3] = nv.w;
+                if (fh < nstore) dst[GS * h] = nv.x;
+                if (fh + 1 < nstore) dst[GS * h + 1] = nv.y;
+                if (fh + 2 < nstore) dst[GS * h + 2] = nv.z;
+                if (fh + 3 < nstore) dst[GS * h + 3] = nv.w;
             }
         }
     }
@@ -2112,6 +2118,9 @@ int launch_node_rows_multi(const PipelineGather &g, const int32_t *const *d_node
     do {                                                                                                      \
         if (g.ncams == 2) UPSP_NRM(LPR, ROWS, 2, 8, 0, 1);                                                    \
         else if (g.ncams == 3) UPSP_NRM(LPR, ROWS, 3, 8, 0, 1);                                               \
+        else if (all_ahead && padded) UPSP_NRM(LPR, ROWS, 4, 8, 0, ROWS, true);                               \
+        else if (all_ahead) UPSP_NRM(LPR, ROWS, 4, 8, 0, ROWS);                                               \
+        else if (padded) UPSP_NRM(LPR, ROWS, 4, 8, 0, 1, true);                                               \
         else UPSP_NRM(LPR, ROWS, 4, 8, 0, 1);                                                                 \
     } while (0)
 #define UPSP_NRM_NC(LPR, ROWS)                                                                                \
@@ -2129,6 +2138,11 @@ int launch_node_rows_multi(const PipelineGather &g, const int32_t *const *d_node
     // sweeps in front 2.97.  Rejected: row / series indices through v_readfirstlane (3.51), persistent workgroups that prefetch
     // the next group's staging (130 VGPRs: 3.14-3.23).  The kernel is not bound by its instructions (VALU busy 53 %): a
     // workgroup lives ~12 us, most of it the two dependent memory latencies of its staging and its series loads.
+    // UPSP_MULTI_VARIANT (measurement switch, round 6): 1 = padded rows (pipeline.hip), 2 = padded rows + every series load of the
+    // workgroup's four sweeps in front of its first store, 3 = that order without the padding
+    static const int variant = [] { const char *e = std::getenv("UPSP_MULTI_VARIANT"); return e ? std::atoi(e) : 0; }();
+    const bool all_ahead = variant == 2 || variant == 3;
+    const bool padded = g.nstore == ((g.nframes + 31) & ~31) && g.nstore > g.nframes;
     if (g.nframes > 512 && g.ncams >= 2 && g.ncams <= 4) UPSP_NRM8_NC(128, 4);
     else if (g.nframes > 512) UPSP_NRM_NC(256, 8);
     else if (g.nframes > 256) UPSP_NRM_NC(128, 4);
