@@ -1340,17 +1340,19 @@ struct StreamMultiArgs {
 // one (two staging areas in LDS): of the two dependent memory latencies per group, staging and series loads, the first is hidden.
 // Measured and NOT the default (UPSP_MULTI_PIPE=n workgroups per CU): the loop-carried staging registers take the kernel from 96 to
 // 130 VGPRs (3 instead of 5 waves per SIMD): 3.14-3.23 ms against 2.68-2.74; held to 96 registers it spills 33 of them: 4.0 ms.
-template <int LPR, int ROWS, int NC, int FPL = 4, int PIPE = 0, int AHEAD = ROWS, bool PAD = false>
-__global__ void __launch_bounds__(256, (PAD && AHEAD == 1) ? 7 : 1)      // (the padded form must not lose the seventh wave to two registers)
+template <int LPR, int ROWS, int NC, int FPL = 4, int PIPE = 0, int AHEAD = ROWS>
+__global__ void __launch_bounds__(256)
     node_rows_multi_kernel(StreamMultiArgs a, unsigned cpitch, const uint8_t *__restrict__ skipped,
                            const int32_t *__restrict__ rowmap, unsigned nnodes, int nframes,
                            float *__restrict__ rows_t, long long ld_t, double *__restrict__ sum,
                            double *__restrict__ sumsq)
 {
-    // PAD: the columns from the last frame to the next 128-byte line of a stored row are padding the caller gave up
-    // (upsp_pipeline_set_row_padding): written as 0 (NaN in the row of a node no camera sees).  (Derived from nframes, not passed:
-    // one more kernel argument took the kernel from 72 to 74 registers, i.e. from seven waves per SIMD to six.)
-    const int nstore = PAD ? ((nframes + 31) & ~31) : nframes;
+    // (Rows that end on whole 128-byte lines -- the 24 padding columns behind 1000 frames written too, as node_rows_kernel does --
+    //  were measured AGAIN in round 6, with the kernel held at 72 registers / seven waves per SIMD (launch bounds; the padded form
+    //  needs two more): 3.10-3.11 ms against 2.61-2.74 for 4 cameras x 2.5 M nodes x 1000 frame sets, two alternations; with every
+    //  series load of the four sweeps in front of the first store as well: 3.19-3.22; that order without the padding: 2.78.  The
+    //  several-camera pass keeps its 4000-byte rows and its loads one sweep ahead.)
+    const int nstore = nframes;
     constexpr int RPS = 256 / LPR, WPR = LPR / 64, NR = RPS * ROWS;
     constexpr int MC = NC ? NC : kMaxCams;
     constexpr int NB = PIPE ? 2 : 1;
@@ -2118,9 +2120,6 @@ int launch_node_rows_multi(const PipelineGather &g, const int32_t *const *d_node
     do {                                                                                                      \
         if (g.ncams == 2) UPSP_NRM(LPR, ROWS, 2, 8, 0, 1);                                                    \
         else if (g.ncams == 3) UPSP_NRM(LPR, ROWS, 3, 8, 0, 1);                                               \
-        else if (all_ahead && padded) UPSP_NRM(LPR, ROWS, 4, 8, 0, ROWS, true);                               \
-        else if (all_ahead) UPSP_NRM(LPR, ROWS, 4, 8, 0, ROWS);                                               \
-        else if (padded) UPSP_NRM(LPR, ROWS, 4, 8, 0, 1, true);                                               \
         else UPSP_NRM(LPR, ROWS, 4, 8, 0, 1);                                                                 \
     } while (0)
 #define UPSP_NRM_NC(LPR, ROWS)                                                                                \
@@ -2138,11 +2137,6 @@ int launch_node_rows_multi(const PipelineGather &g, const int32_t *const *d_node
     // sweeps in front 2.97.  Rejected: row / series indices through v_readfirstlane (3.51), persistent workgroups that prefetch
     // the next group's staging (130 VGPRs: 3.14-3.23).  The kernel is not bound by its instructions (VALU busy 53 %): a
     // workgroup lives ~12 us, most of it the two dependent memory latencies of its staging and its series loads.
-    // UPSP_MULTI_VARIANT (measurement switch, round 6): 1 = padded rows (pipeline.hip), 2 = padded rows + every series load of the
-    // workgroup's four sweeps in front of its first store, 3 = that order without the padding
-    static const int variant = [] { const char *e = std::getenv("UPSP_MULTI_VARIANT"); return e ? std::atoi(e) : 0; }();
-    const bool all_ahead = variant == 2 || variant == 3;
-    const bool padded = g.nstore == ((g.nframes + 31) & ~31) && g.nstore > g.nframes;
     if (g.nframes > 512 && g.ncams >= 2 && g.ncams <= 4) UPSP_NRM8_NC(128, 4);
     else if (g.nframes > 512) UPSP_NRM_NC(256, 8);
     else if (g.nframes > 256) UPSP_NRM_NC(128, 4);

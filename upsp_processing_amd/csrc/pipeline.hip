@@ -1287,10 +1287,6 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
             g.rows_t = d_rows_t + col0 + s0;
             // (no row padding here: measured on 4 cameras, 2.5 M nodes, 1000 frame sets the padded rows are SLOWER,
             //  2.91-2.97 ms against 2.65-2.70, both at 72 VGPRs -- the one-camera kernel gains 10 % from them)
-            {
-                static const int variant = [] { const char *e = std::getenv("UPSP_MULTI_VARIANT"); return e ? std::atoi(e) : 0; }();
-                g.nstore = (variant == 1 || variant == 2) ? padded_store(p, col0 + s0, ns, ld_t, 32) : ns;
-            }
             if (rc == UPSP_OK) rc = launch_node_rows_multi(g, p->m_node_k, p->m_compact, cp, st);
         }
         if (rc == UPSP_OK && hot_fused) {
