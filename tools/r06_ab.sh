@@ -49,3 +49,10 @@ elif [ $part = rays ]; then
   UPSP_RAY_BINS=0 python3 tools/r06_rays.py || exit 1
   UPSP_RAY_BINS=1 python3 tools/r06_rays.py || exit 1
 fi
+if [ $part = sides ]; then
+  # the one-call step with one side stream (UPSP_STEP_ONE_SIDE=1) against two builds in flight (default)
+  for i in 1 2 3; do
+    line one_side_$i UPSP_STEP_ONE_SIDE=1 -- --no-reraycast --steps 20 --warmup 5 || exit 1
+    line two_sides_$i -- --no-reraycast --steps 20 --warmup 5 || exit 1
+  done
+fi

@@ -95,6 +95,11 @@ struct upsp_pipeline {
     // left to do
     struct Step {
         hipStream_t side = nullptr;
+        hipStream_t side2 = nullptr;    // the builds of odd steps (two builds in flight: see upsp_pipeline_step)
+        upsp_bvh *bvh2 = nullptr;       // ... on a handle of their own over the caller's tree (upsp_bvh_share: own query scratch)
+        const upsp_bvh *bvh2_of = nullptr;
+        int32_t *d_cand2 = nullptr;
+        float *d_uv2 = nullptr;
         hipStream_t scan = nullptr;     // pass A + repair of a step, beside the previous step's pass B (normal priority)
         hipEvent_t ev_map[2] = {nullptr, nullptr}, ev_side[2] = {nullptr, nullptr}, ev_repaired[2] = {nullptr, nullptr};
         hipEvent_t ev_end[3] = {nullptr, nullptr, nullptr};
@@ -263,6 +268,13 @@ void upsp_pipeline_destroy(upsp_pipeline *p)
         (void)hipStreamSynchronize(p->step.scan);
         (void)hipStreamDestroy(p->step.scan);
     }
+    if (p->step.side2) {
+        (void)hipStreamSynchronize(p->step.side2);
+        (void)hipStreamDestroy(p->step.side2);
+    }
+    if (p->step.bvh2) upsp_bvh_destroy(p->step.bvh2);
+    free_dev(p->step.d_cand2);
+    free_dev(p->step.d_uv2);
     for (hipEvent_t e : {p->step.ev_map[0], p->step.ev_map[1], p->step.ev_side[0], p->step.ev_side[1], p->step.ev_repaired[0],
                          p->step.ev_repaired[1], p->step.ev_end[0], p->step.ev_end[1], p->step.ev_end[2]})
         if (e) (void)hipEventDestroy(e);
@@ -1402,8 +1414,14 @@ static int step_setup(upsp_pipeline *p)
                           &s.ev_end[1], &s.ev_end[2]})
         UPSP_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
     UPSP_HIP_CHECK(hipStreamCreateWithFlags(&s.scan, hipStreamNonBlocking));
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess)
+        UPSP_HIP_CHECK(hipStreamCreateWithPriority(&s.side2, hipStreamNonBlocking, greatest));
+    else
+        UPSP_HIP_CHECK(hipStreamCreateWithFlags(&s.side2, hipStreamNonBlocking));
     UPSP_HIP_CHECK(hipMalloc(&s.d_cand, sizeof(int32_t) * p->nnodes));
     UPSP_HIP_CHECK(hipMalloc(&s.d_uv, sizeof(float) * 2 * p->nnodes));
+    UPSP_HIP_CHECK(hipMalloc(&s.d_cand2, sizeof(int32_t) * p->nnodes));
+    UPSP_HIP_CHECK(hipMalloc(&s.d_uv2, sizeof(float) * 2 * p->nnodes));
     return UPSP_OK;
 }
 
@@ -1418,18 +1436,44 @@ int upsp_pipeline_step(upsp_pipeline *p, const upsp_step_args *a, void *stream)
     int rc = step_setup(p);
     if (rc != UPSP_OK) return rc;
     upsp_pipeline::Step &s = p->step;
-    hipStream_t main = (hipStream_t)stream, side = s.side;
     const uint64_t n = s.count;
+    // TWO BUILDS IN FLIGHT (round 6).  A step's side block is one long chain -- candidate pixels, map, the primary pass (0.14 ms
+    // alone, 0.41 ms beside the passes), the retry lists, witness test, residual traversal, hand-over: 0.82 ms in the kernel trace
+    // of a 0.83-ms step, i.e. with ONE side stream the chain of step s + 1 starts when the chain of step s ends and pass B waits
+    // ~90 us for it every step.  Odd steps therefore build on a second high-priority stream and a second handle over the same
+    // tree (upsp_bvh_share: the tree is shared, the query scratch is not): the chain of step s + 1 starts as soon as the host
+    // has issued it and runs beside the chain of step s.  Every cross-step dependency is already an event wait below (map arrays
+    // of step s - 2, repair of step s - 1 in front of the frames hook, end of step s - 1 in front of the finals and the skipped
+    // flags); the two projection buffers and candidate / uv scratch exist per parity.  UPSP_STEP_ONE_SIDE=1: one stream (A/B).
+    static const bool two_sides = [] { const char *e = std::getenv("UPSP_STEP_ONE_SIDE"); return !(e && *e == '1'); }();
+    const bool odd = two_sides && (n & 1u);
+    hipStream_t main = (hipStream_t)stream, side = odd ? s.side2 : s.side;
+    upsp_bvh *bvh = a->bvh;
+    if (odd) {
+        if (s.bvh2 && s.bvh2_of != a->bvh) {
+            UPSP_HIP_CHECK(hipStreamSynchronize(s.side2));
+            upsp_bvh_destroy(s.bvh2);
+            s.bvh2 = nullptr;
+        }
+        if (!s.bvh2) {
+            rc = upsp_bvh_share(a->bvh, &s.bvh2);
+            if (rc != UPSP_OK) return rc;
+            s.bvh2_of = a->bvh;
+        }
+        bvh = s.bvh2;
+    }
+    int32_t *d_cand = odd ? s.d_cand2 : s.d_cand;
+    float *d_uv = odd ? s.d_uv2 : s.d_uv;
     // ---- side stream ----
-    if (n == 0) {                                        // (the first step starts behind whatever the caller has queued)
+    if (n < 2) {                                         // (a side stream's first block starts behind whatever the caller has queued)
         UPSP_HIP_CHECK(hipEventRecord(s.ev_end[2], main));
         UPSP_HIP_CHECK(hipStreamWaitEvent(side, s.ev_end[2], 0));
     }
     // the set of map arrays the new map is built in was last read by the launches of the step before the previous one
     if (n >= 2) UPSP_HIP_CHECK(hipStreamWaitEvent(side, s.ev_end[(n - 2) % 3], 0));
-    rc = upsp_projection_candidate_pixels_oblique(a->cam, a->d_nodes, a->d_normals, a->d_datanode, p->nnodes, a->oblique_thresh, s.d_cand, side);
+    rc = upsp_projection_candidate_pixels_oblique(a->cam, a->d_nodes, a->d_normals, a->d_datanode, p->nnodes, a->oblique_thresh, d_cand, side);
     if (rc != UPSP_OK) return rc;
-    rc = upsp_pipeline_set_active_hint(p, s.d_cand, side);
+    rc = upsp_pipeline_set_active_hint(p, d_cand, side);
     if (rc != UPSP_OK) return rc;
     if (a->frames_hook) {
         // behind the map (which runs beside the previous step's pass A): in front of it the whole side block -- and with it this
@@ -1441,8 +1485,8 @@ int upsp_pipeline_step(upsp_pipeline *p, const upsp_step_args *a, void *stream)
     int32_t *target = nullptr;
     rc = upsp_pipeline_projection_target(p, 0, &target);
     if (rc != UPSP_OK) return rc;
-    rc = upsp_projection_build(a->bvh, a->cam, a->d_nodes, a->d_normals, a->d_datanode, a->d_tri_nodes, p->nnodes, a->oblique_thresh,
-                               target, s.d_uv, nullptr, nullptr, side);
+    rc = upsp_projection_build(bvh, a->cam, a->d_nodes, a->d_normals, a->d_datanode, a->d_tri_nodes, p->nnodes, a->oblique_thresh,
+                               target, d_uv, nullptr, nullptr, side);
     if (rc != UPSP_OK) return rc;
     // the previous step's pass B: its sums (finals), and it read the skipped flags the sweep below rewrites
     if (n >= 1) UPSP_HIP_CHECK(hipStreamWaitEvent(side, s.ev_end[(n - 1) % 3], 0));
@@ -1518,6 +1562,8 @@ int upsp_pipeline_step_finish(upsp_pipeline *p, void *stream)
     UPSP_HIP_CHECK(hipStreamWaitEvent(main, s.ev_map[0], 0));
     UPSP_HIP_CHECK(hipEventRecord(s.ev_map[1], s.scan));
     UPSP_HIP_CHECK(hipStreamWaitEvent(main, s.ev_map[1], 0));
+    UPSP_HIP_CHECK(hipEventRecord(s.ev_side[0], s.side2));
+    UPSP_HIP_CHECK(hipStreamWaitEvent(main, s.ev_side[0], 0));
     return UPSP_OK;
 }
 
