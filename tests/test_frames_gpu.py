@@ -974,7 +974,8 @@ def test_pipeline_step_matches_plain_sequence(gpu_lib, oracle, F):
     pipe.step_finish()
     torch.cuda.synchronize()
     after.append(d.clone())
-    assert len(tails) == 4 and len(set(tails)) == 1 and tails[0] != torch.cuda.current_stream().cuda_stream
+    # (the hooks run on the pipeline's side streams: two of them in turn, never the caller's)
+    assert len(tails) == 4 and tails[0] == tails[2] and tails[1] == tails[3] and torch.cuda.current_stream().cuda_stream not in tails
     for s in range(4):
         rows, frames, avg, rms, _ = want[s]
         assert torch.equal(rts[s][:, :F].view(torch.int32), rows.view(torch.int32)), s
