@@ -89,4 +89,5 @@ def test_reraycast_step_from_cpp_at_full_size(gpu_lib, tmp_path):
     m = re.search(r"step perf: ([0-9.]+) ms per step of 1000 frames \((\d+) triangles, (\d+) nodes, (\d+) nodes with a series\)", r.stdout)
     assert m, r.stdout
     assert int(m.group(2)) == tris.shape[0] and int(m.group(4)) > 100000
+    print(r.stdout.strip())
     assert float(m.group(1)) <= 0.85, r.stdout

@@ -56,3 +56,10 @@ if [ $part = sides ]; then
     line two_sides_$i -- --no-reraycast --steps 20 --warmup 5 || exit 1
   done
 fi
+if [ $part = adapt ]; then
+  # hand-off launches only when the last build of the same view needed them (UPSP_HEAVY_ADAPT), and the two memsets folded into kernels
+  for i in 1 2 3; do
+    line adapt_off_$i UPSP_HEAVY_ADAPT=0 -- --no-reraycast --steps 20 --warmup 5 || exit 1
+    line adapt_on_$i -- --no-reraycast --steps 20 --warmup 5 || exit 1
+  done
+fi

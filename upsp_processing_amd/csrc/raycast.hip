@@ -806,6 +806,7 @@ __device__ __forceinline__ bool queue_init_spread(WaveQueue &q, unsigned *work, 
 // the local index space is looked up with bin_item().  Returns false (blo / blen = the whole bins, index space = their
 // concatenation, caller falls back to the queue) when the grid cannot take the list at once.
 constexpr int kWorkBinCountFwd = 22;
+constexpr int kWorkWordsFwd = 32;
 __device__ __forceinline__ bool queue_init_binned(WaveQueue &q, unsigned *work, unsigned total, unsigned pack_waves, unsigned nbins)
 {
     const unsigned pack = pack_waves ? min(max((total + pack_waves - 1u) / pack_waves, 1u), 64u) : 0u;
@@ -1046,7 +1047,7 @@ constexpr int32_t kPixRetry = -4;     // primary ray hit a foreign triangle: ret
 constexpr int kWorkRetryCount = 10;
 constexpr int kWorkTodoCount = 12;   // rays witness_kernel could not decide
 constexpr int kWorkHeavyCount = 16;  // work items handed to heavy_kernel: [16] by the primary pass, [17] by the retry pass
-constexpr int kWorkWords = 32;
+constexpr int kWorkWords = kWorkWordsFwd;
 constexpr unsigned kHeavyCap = 65536;
 // Length-homogeneous waves.  The 64 rays of a wave run in lock step and the wave lasts as long as its longest ray: on the bench model
 // a wave's longest ray has 36 steps for 25 of the mean (tools/probe/trav_policy_sim.c).  A build that is REPEATED on the same model
@@ -1091,8 +1092,11 @@ __global__ void __launch_bounds__(256)
     project_nodes_kernel(Cam cam, const float *__restrict__ nodes,
                          const uint8_t *__restrict__ datanode, unsigned nnodes,
                          const float *__restrict__ normals, float oblique_thresh, int cull,
-                         int32_t *__restrict__ pix, float *__restrict__ uv)
+                         int32_t *__restrict__ pix, float *__restrict__ uv, unsigned *__restrict__ work)
 {
+    // the build's work words start from zero: cleared here, by the first launch of the chain (a hipMemsetAsync is a launch of its
+    // own -- 6 us on the build's critical path beside the frame loop's passes)
+    if (blockIdx.x == 0 && threadIdx.x < (unsigned)kWorkWordsFwd) work[threadIdx.x] = 0u;
     const unsigned n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= nnodes) return;
     int32_t state = kPixNone;
@@ -2096,6 +2100,8 @@ __global__ void __launch_bounds__(256)
     __shared__ unsigned wave_cnt[kRetryListItems][4], block_base;
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned base = blockIdx.x * (256u * kRetryListItems) + threadIdx.x;
+    // the queue head for the retry passes (the primary pass used it; no launch of its own for one word)
+    if (STATE == kPixRetry && blockIdx.x == 0 && threadIdx.x == 0) work[0] = 0u;
     unsigned long long m[kRetryListItems];
     bool need[kRetryListItems];
 #pragma unroll
@@ -2835,6 +2841,8 @@ void upsp_bvh_destroy(upsp_bvh *b)
     if (b->d_cast_list) (void)hipFree(b->d_cast_list);
     if (b->d_steps) (void)hipFree(b->d_steps);
     if (b->d_step_edges) (void)hipFree(b->d_step_edges);
+    if (b->h_handoff) (void)hipHostFree(b->h_handoff);
+    if (b->ev_handoff) (void)hipEventDestroy(b->ev_handoff);
     if (b->d_stage) (void)hipFree(b->d_stage);
     if (b->h_stage) (void)hipHostFree(b->h_stage);
     if (b->stage_stream) (void)hipStreamDestroy(b->stage_stream);
@@ -3057,7 +3065,7 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
     }
     if (!b->d_heavy) UPSP_HIP_CHECK(hipMalloc(&b->d_heavy, sizeof(unsigned) * 2 * kHeavyCap));      // (two lists)
     if (!b->d_heavy_scratch) UPSP_HIP_CHECK(hipMalloc(&b->d_heavy_scratch, kHeavyScratchBytes * kHeavyGridMax));
-    UPSP_HIP_CHECK(hipMemsetAsync(b->d_work, 0, kWorkWords * sizeof(unsigned), st));
+    // (the work words are cleared by project_nodes_kernel, the chain's first launch)
     const int grid = grid_for(nnodes, lds);
     Scene sc = make_scene(b, nnodes, grid);
     // step 3 runs over 6 x (listed nodes), a count only the device knows: full
@@ -3073,7 +3081,24 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
     // (read per build, not once: the tests move both to drive many rays through heavy_kernel and its fallback)
     const int heavy_steps = env_int("UPSP_HEAVY_STEPS", 96);
     const int heavy_stack = env_int("UPSP_HEAVY_STACK", (int)kHeavyStack);
-    const bool heavy_on = heavy_steps > 0 && b->info.depth <= 56 && b->d_heavy;
+    bool heavy_on = heavy_steps > 0 && b->info.depth <= 56 && b->d_heavy;
+    // The hand-off machinery only when the last build of the SAME view needed it: its hand-off counts (work[16..20]) were copied to
+    // pinned memory behind an event; when that copy has arrived, belongs to this camera / node array / node count and says that no
+    // ray was handed off, this build runs without the threshold -- every ray finishes in its lane, same results -- and without the
+    // four walk launches (6 us each of finding their lists empty, on the critical path of a build that runs beside the frame loop).
+    // UPSP_HEAVY_ADAPT=0: always launch them (the tests of the walks).
+    const bool adapt = heavy_on && env_int("UPSP_HEAVY_ADAPT", 1) != 0 && !h_nrays && !b->stats_on;
+    if (adapt && b->handoff_pending && b->handoff_was_on && b->handoff_nodes == (const void *)d_nodes && b->handoff_nnodes == nnodes &&
+        std::memcmp(&b->handoff_cam, cam, sizeof(upsp_camera)) == 0 && hipEventQuery(b->ev_handoff) == hipSuccess) {
+        const uint32_t *h = b->h_handoff;
+        if (h[0] == 0u && h[1] == 0u && h[3] == 0u && h[4] == 0u) heavy_on = false;
+    } else if (adapt && b->handoff_pending && !b->handoff_was_on && b->handoff_nodes == (const void *)d_nodes && b->handoff_nnodes == nnodes &&
+               std::memcmp(&b->handoff_cam, cam, sizeof(upsp_camera)) == 0) {
+        // the view that needed no hand-off stays without it -- but every 16th build looks again (the nodes may have moved in place)
+        if (++b->handoff_skips < 16u) heavy_on = false;
+        else b->handoff_skips = 0;
+    }
+    const bool heavy_launch = heavy_on;
     if (heavy_on) {
         sc.heavy_steps = sc1.heavy_steps = (unsigned)heavy_steps;
         sc.heavy_items = sc1.heavy_items = b->d_heavy;
@@ -3084,7 +3109,7 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
     const int heavy_grid = (int)kHeavyGridMax;
     const int wave_grid = 5 * (props().cus > 0 ? props().cus : 256);
 #define UPSP_LAUNCH_HEAVY(PHASE, SC)                                                                             \
-    if (heavy_on) {                                                                                              \
+    if (heavy_launch) {                                                                                          \
         KTimed kth("heavy_kernel", st);                                                                          \
         hipLaunchKernelGGL((wave_proj_kernel<PHASE, 1>), dim3(4 * wave_grid), dim3(64), 0, st, SC, c, d_nodes, d_tri_nodes, d_pix, \
                            (const unsigned *)b->d_retry_nodes, b->d_retry_mask, b->d_work, (const unsigned *)b->d_heavy,  \
@@ -3120,7 +3145,7 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
         static const int cull_env = env_int("UPSP_OBLIQUE_CULL", 1);
         const int cull = (cull_env == 2 || (cull_env == 1 && !h_nrays && !b->stats_on)) ? 1 : 0;
         hipLaunchKernelGGL(project_nodes_kernel, egrid, eblock, 0, st, c, d_nodes, d_datanode,
-                           (unsigned)nnodes, d_normals, oblique_thresh, cull, d_pix, d_uv);
+                           (unsigned)nnodes, d_normals, oblique_thresh, cull, d_pix, d_uv, b->d_work);
     }
     const bool binned = bins_on && b->steps_valid;
     if (bins_on) sc.steps_out = b->d_steps;
@@ -3158,7 +3183,7 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
         hipLaunchKernelGGL(step_edges_kernel, dim3(1), dim3(256), 0, st, (const unsigned short *)b->d_steps, (unsigned)nnodes, b->d_step_edges);
         b->steps_valid = true;
     }
-    UPSP_HIP_CHECK(hipMemsetAsync(b->d_work, 0, sizeof(unsigned), st));  // queue head
+    // (the queue head, work[0], is reset by retry_list_kernel<kPixRetry> -- nothing else touches it in that launch)
     {
         KTimed kt("retry_list_kernel", st);
         const dim3 lgrid((unsigned)((nnodes + 256 * kRetryListItems - 1) / (256 * kRetryListItems)));
@@ -3235,6 +3260,23 @@ int upsp_projection_build(upsp_bvh *b, const upsp_camera *cam, const float *d_no
         }
         (void)hipFree(counts);
         if (e != hipSuccess) return fail(UPSP_ERR_HIP, hipGetErrorString(e));
+    }
+    if (adapt) {
+        if (!b->h_handoff) {
+            UPSP_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&b->h_handoff), 8 * sizeof(uint32_t), hipHostMallocDefault));
+            UPSP_HIP_CHECK(hipEventCreateWithFlags(&b->ev_handoff, hipEventDisableTiming));
+        }
+        if (!b->handoff_pending || hipEventQuery(b->ev_handoff) == hipSuccess) {      // (never two copies into the words at once)
+            UPSP_HIP_CHECK(hipMemcpyAsync(b->h_handoff, b->d_work + kWorkHeavyCount, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            UPSP_HIP_CHECK(hipEventRecord(b->ev_handoff, st));
+            b->handoff_pending = true;
+            b->handoff_cam = *cam;
+            b->handoff_nodes = d_nodes;
+            b->handoff_nnodes = nnodes;
+            b->handoff_was_on = heavy_launch;
+        }
+    } else {
+        b->handoff_pending = false;
     }
     if (h_nrays || b->stats_on) {
         int rc = read_stats(b, st);

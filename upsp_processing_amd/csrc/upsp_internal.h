@@ -125,6 +125,18 @@ struct upsp_bvh {
     // Length-homogeneous waves of a REPEATED projection build (round 6): the step count of every node's primary ray as the
     // build before this one measured it (0 = no ray then), and the bin edges derived from a sample of them.  The next build's
     // dense ray list is binned by it, so that the 64 rays of a wave end together.  Ordering only -- results do not depend on it.
+    // Hand-off machinery only when the last build of the SAME view needed it (round 6): the counts of rays handed to the one-ray-
+    // per-wave / per-workgroup walks are read back without a wait (pinned words behind an event); when the previous build of this
+    // handle with the same camera, nodes and node count handed off none, the next one runs without the hand-off threshold and
+    // without the four (then empty) walk launches -- every ray finishes in its lane, same results.
+    uint32_t *h_handoff = nullptr;           // pinned: work[16..20] of the last build
+    struct ihipEvent_t *ev_handoff = nullptr;
+    bool handoff_pending = false;
+    upsp_camera handoff_cam;
+    const void *handoff_nodes = nullptr;
+    size_t handoff_nnodes = 0;
+    bool handoff_was_on = false;
+    unsigned handoff_skips = 0;
     uint16_t *d_steps = nullptr;
     uint32_t *d_step_edges = nullptr;
     size_t steps_nnodes = 0;
