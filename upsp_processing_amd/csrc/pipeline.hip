@@ -1450,7 +1450,10 @@ int upsp_pipeline_step(upsp_pipeline *p, const upsp_step_args *a, void *stream)
     hipStream_t main = (hipStream_t)stream, side = odd ? s.side2 : s.side;
     upsp_bvh *bvh = a->bvh;
     if (odd) {
-        if (s.bvh2 && s.bvh2_of != a->bvh) {
+        // (a handle over another tree, or over this one before its adjacency was rebuilt -- upsp_bvh_set_tri_nodes frees and
+        //  reallocates the arrays a shared handle only points at)
+        if (s.bvh2 && (s.bvh2_of != a->bvh || s.bvh2->d_adj_off != a->bvh->d_adj_off || s.bvh2->d_slot_path != a->bvh->d_slot_path ||
+                       s.bvh2->d_wide != a->bvh->d_wide || s.bvh2->adj_src != a->bvh->adj_src)) {
             UPSP_HIP_CHECK(hipStreamSynchronize(s.side2));
             upsp_bvh_destroy(s.bvh2);
             s.bvh2 = nullptr;
