@@ -1424,9 +1424,10 @@ def run(a, nested=False):
 
     sched = ("projection build, then hot-pixel scan + gather kernels per 64-frame sub-batch"
              if (a.two_kernel or a.registration) else
-             ("the projection build of the NEXT step on a high-priority stream of its own (with the candidate-pixel map, the restore of the "
-              "hot pixels, the finals, the projection's hand-over and the node -> row sweep), the frame loop's stream carries pass A (scan + "
-              "compact pixel series of the candidate pixels%s), the hot-pixel repair and pass B (whole rows) only"
+             ("one upsp_pipeline_step call per step: the projection builds on two high-priority streams of the pipeline, used in turn (two "
+              "builds in flight; with the candidate-pixel map, the restore of the hot pixels, the finals, the projection's hand-over and the "
+              "node -> row sweep), the frame loop's stream carries pass A (scan + compact pixel series of the candidate pixels%s), the "
+              "hot-pixel repair and pass B (whole rows) only"
               % (", in two launches" if (lean and not chunked) else "")) if (overlap and lean) else
              "the ray casting of the projection build on a high-priority stream of its own, pass A (scan + compact pixel series of the "
              "candidate pixels) beside it, then pass B (whole rows)" if overlap else

@@ -63,3 +63,8 @@ if [ $part = adapt ]; then
     line adapt_on_$i -- --no-reraycast --steps 20 --warmup 5 || exit 1
   done
 fi
+if [ $part = plain ]; then
+  # default step, three runs (for before / after comparisons of a library change across two calls on the SAME box: not possible --
+  # use with a switch, or read the kernel times)
+  for i in 1 2 3; do line plain_$i -- --no-reraycast --steps 20 --warmup 5 || exit 1; done
+fi

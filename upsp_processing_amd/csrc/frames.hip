@@ -940,6 +940,9 @@ __global__ void __launch_bounds__(256)
     __shared__ int act_k[kFusedPix];             // compact index of the tile's pixels, -1 = nobody reads it
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned A = order[2u * nt], nI = nt - A, total = A * (unsigned)ngroups;
+    // (Round 6, measured and not kept: the loads of the workgroup's NEXT (tile, group) pair in flight while the current one goes
+    //  through LDS -- 26 more registers, pass A 0.349 ms in the step either way: with eight workgroups per compute unit the trips
+    //  of the others already cover a trip's wait.)
     for (unsigned b2 = blockIdx.x; b2 < total; b2 += gridDim.x) {          // (uniform)
         const int g = (int)(b2 / A);
         const unsigned tl = order[nI + (b2 - (unsigned)g * A)];
