@@ -101,6 +101,8 @@ struct upsp_pipeline {
         int32_t *d_cand2 = nullptr;
         float *d_uv2 = nullptr;
         hipStream_t scan = nullptr;     // pass A + repair of a step, beside the previous step's pass B (normal priority)
+        hipStream_t aux = nullptr;      // the frames hook: behind the previous step's repair, NOT in front of the build (see upsp_pipeline_step)
+        hipEvent_t ev_hook[2] = {nullptr, nullptr};
         hipEvent_t ev_map[2] = {nullptr, nullptr}, ev_side[2] = {nullptr, nullptr}, ev_repaired[2] = {nullptr, nullptr};
         hipEvent_t ev_end[3] = {nullptr, nullptr, nullptr};
         int32_t *d_cand = nullptr;
@@ -272,6 +274,12 @@ void upsp_pipeline_destroy(upsp_pipeline *p)
         (void)hipStreamSynchronize(p->step.side2);
         (void)hipStreamDestroy(p->step.side2);
     }
+    if (p->step.aux) {
+        (void)hipStreamSynchronize(p->step.aux);
+        (void)hipStreamDestroy(p->step.aux);
+    }
+    for (hipEvent_t e : {p->step.ev_hook[0], p->step.ev_hook[1]})
+        if (e) (void)hipEventDestroy(e);
     if (p->step.bvh2) upsp_bvh_destroy(p->step.bvh2);
     free_dev(p->step.d_cand2);
     free_dev(p->step.d_uv2);
@@ -1391,11 +1399,11 @@ int upsp_pipeline_process_u16(upsp_pipeline *p, uint16_t *const *d_frames, int n
 // and create_projection_mat a call in front of it, :1591-1640).  Two streams, the caller's (`stream`) and a high-priority side stream
 // the pipeline owns:
 //
-//   side    [end of step s-2]  candidate pixels -> active-pixel map (second set of map arrays)
-//           [repair of step s-1]  frames_hook (the frames may be rewritten here)            -> ev_map
+//   side    [end of step s-2]  candidate pixels -> active-pixel map (second set of map arrays)  -> ev_map
 //           projection build straight into the pipeline's buffer
+//   aux     [repair of step s-1]  frames_hook (the frames may be rewritten here)            -> ev_hook
 //           [end of step s-1]  finals of step s-1, projection hand-over, node -> row sweep + skipped flags, tail_hook -> ev_side
-//   stream  [ev_map]  pass A (+ hot-pixel repair) on the candidate map, beside the build     -> ev_repaired
+//   stream  [ev_map, ev_hook]  pass A (+ hot-pixel repair) on the candidate map, beside the build  -> ev_repaired
 //           [ev_side] pass B                                                                -> end of step s
 //
 // so the caller's stream carries pass A, the repair and pass B and nothing else, and the host runs a step ahead of the device.
@@ -1414,6 +1422,9 @@ static int step_setup(upsp_pipeline *p)
                           &s.ev_end[1], &s.ev_end[2]})
         UPSP_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
     UPSP_HIP_CHECK(hipStreamCreateWithFlags(&s.scan, hipStreamNonBlocking));
+    UPSP_HIP_CHECK(hipStreamCreateWithFlags(&s.aux, hipStreamNonBlocking));
+    UPSP_HIP_CHECK(hipEventCreateWithFlags(&s.ev_hook[0], hipEventDisableTiming));
+    UPSP_HIP_CHECK(hipEventCreateWithFlags(&s.ev_hook[1], hipEventDisableTiming));
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess)
         UPSP_HIP_CHECK(hipStreamCreateWithPriority(&s.side2, hipStreamNonBlocking, greatest));
     else
@@ -1478,13 +1489,16 @@ int upsp_pipeline_step(upsp_pipeline *p, const upsp_step_args *a, void *stream)
     if (rc != UPSP_OK) return rc;
     rc = upsp_pipeline_set_active_hint(p, d_cand, side);
     if (rc != UPSP_OK) return rc;
-    if (a->frames_hook) {
-        // behind the map (which runs beside the previous step's pass A): in front of it the whole side block -- and with it this
-        // step's pass B -- would wait for that repair
-        if (n >= 1) UPSP_HIP_CHECK(hipStreamWaitEvent(side, s.ev_repaired[(n - 1) % 2], 0));
-        a->frames_hook(a->frames_user, side);
-    }
     UPSP_HIP_CHECK(hipEventRecord(s.ev_map[n % 2], side));
+    if (a->frames_hook) {
+        // The frames hook needs the previous step's repair -- the BUILD does not: the hook runs on a stream of its own, so that the
+        // ray casting of this step starts as soon as its map is built instead of behind a repair that ends half a step later (kernel
+        // trace, round 6: the build chain started 0.42 ms after the event it really depends on and ended 40 us after pass B wanted it).
+        if (n == 0) UPSP_HIP_CHECK(hipStreamWaitEvent(s.aux, s.ev_end[2], 0));
+        if (n >= 1) UPSP_HIP_CHECK(hipStreamWaitEvent(s.aux, s.ev_repaired[(n - 1) % 2], 0));
+        a->frames_hook(a->frames_user, s.aux);
+        UPSP_HIP_CHECK(hipEventRecord(s.ev_hook[n % 2], s.aux));
+    }
     int32_t *target = nullptr;
     rc = upsp_pipeline_projection_target(p, 0, &target);
     if (rc != UPSP_OK) return rc;
@@ -1520,6 +1534,7 @@ int upsp_pipeline_step(upsp_pipeline *p, const upsp_step_args *a, void *stream)
         std::swap(p->compact_bytes, p->compact_bytes_alt);
     }
     UPSP_HIP_CHECK(hipStreamWaitEvent(scan, s.ev_map[n % 2], 0));
+    if (a->frames_hook) UPSP_HIP_CHECK(hipStreamWaitEvent(scan, s.ev_hook[n % 2], 0));
     rc = upsp_pipeline_prescan(p, a->d_frames, a->nframes, scan);      // (in two launches when upsp_pipeline_set_scan_split says so)
     if (rc != UPSP_OK) return rc;
     UPSP_HIP_CHECK(hipEventRecord(s.ev_repaired[n % 2], scan));
@@ -1567,6 +1582,8 @@ int upsp_pipeline_step_finish(upsp_pipeline *p, void *stream)
     UPSP_HIP_CHECK(hipStreamWaitEvent(main, s.ev_map[1], 0));
     UPSP_HIP_CHECK(hipEventRecord(s.ev_side[0], s.side2));
     UPSP_HIP_CHECK(hipStreamWaitEvent(main, s.ev_side[0], 0));
+    UPSP_HIP_CHECK(hipEventRecord(s.ev_hook[0], s.aux));
+    UPSP_HIP_CHECK(hipStreamWaitEvent(main, s.ev_hook[0], 0));
     return UPSP_OK;
 }
 
