@@ -363,10 +363,11 @@ int upsp_pipeline_set_scan_split(upsp_pipeline *p, int on);
  *                      upsp_pipeline_step_mark_end (the point after which the side stream may rewrite the skipped flags).
  *   d_avg / d_rms      finals of THIS step's sums over nframes_total frames (0: nframes), written while the NEXT step's build
  *                      runs, or by upsp_pipeline_step_finish; NULL: none.
- *   frames_hook        called (on the host, inside the call) with a stream of the pipeline that is ordered behind the previous step's
- *                      last read / repair of d_frames and in front of this step's scan of them: the caller queues whatever refills
- *                      the frames there (unpack of the next batch; bench.py puts the hot pixels back).  The projection build does
- *                      not wait for it.
+ *   frames_hook        called (on the host, inside the call) with a stream of the pipeline at the point where the previous step no
+ *                      longer reads or repairs d_frames and this step has not yet scanned them: the caller queues whatever refills
+ *                      the frames there (unpack of the next batch; bench.py puts the hot pixels back).  Keep it short: the step's
+ *                      projection build is queued behind it on the same stream (which is also what starts the ray casting with
+ *                      the previous step's pass B rather than beside its pass A).
  *   tail_hook          called with the side stream behind the node -> row sweep of the NEW projection and behind the end of the
  *                      previous step: a caller's own per-step work that needs upsp_pipeline_row_tables or the complete sums of
  *                      the step before (the multi-GPU loop: all-reduce + finals, the exchange's pixel table).

@@ -101,8 +101,6 @@ struct upsp_pipeline {
         int32_t *d_cand2 = nullptr;
         float *d_uv2 = nullptr;
         hipStream_t scan = nullptr;     // pass A + repair of a step, beside the previous step's pass B (normal priority)
-        hipStream_t aux = nullptr;      // the frames hook: behind the previous step's repair, NOT in front of the build (see upsp_pipeline_step)
-        hipEvent_t ev_hook[2] = {nullptr, nullptr};
         hipEvent_t ev_map[2] = {nullptr, nullptr}, ev_side[2] = {nullptr, nullptr}, ev_repaired[2] = {nullptr, nullptr};
         hipEvent_t ev_end[3] = {nullptr, nullptr, nullptr};
         int32_t *d_cand = nullptr;
@@ -274,12 +272,6 @@ void upsp_pipeline_destroy(upsp_pipeline *p)
         (void)hipStreamSynchronize(p->step.side2);
         (void)hipStreamDestroy(p->step.side2);
     }
-    if (p->step.aux) {
-        (void)hipStreamSynchronize(p->step.aux);
-        (void)hipStreamDestroy(p->step.aux);
-    }
-    for (hipEvent_t e : {p->step.ev_hook[0], p->step.ev_hook[1]})
-        if (e) (void)hipEventDestroy(e);
     if (p->step.bvh2) upsp_bvh_destroy(p->step.bvh2);
     free_dev(p->step.d_cand2);
     free_dev(p->step.d_uv2);
@@ -1399,11 +1391,11 @@ int upsp_pipeline_process_u16(upsp_pipeline *p, uint16_t *const *d_frames, int n
 // and create_projection_mat a call in front of it, :1591-1640).  Two streams, the caller's (`stream`) and a high-priority side stream
 // the pipeline owns:
 //
-//   side    [end of step s-2]  candidate pixels -> active-pixel map (second set of map arrays)  -> ev_map
+//   side    [end of step s-2]  candidate pixels -> active-pixel map (second set of map arrays)
+//           [repair of step s-1]  frames_hook (the frames may be rewritten here)            -> ev_map
 //           projection build straight into the pipeline's buffer
-//   aux     [repair of step s-1]  frames_hook (the frames may be rewritten here)            -> ev_hook
 //           [end of step s-1]  finals of step s-1, projection hand-over, node -> row sweep + skipped flags, tail_hook -> ev_side
-//   stream  [ev_map, ev_hook]  pass A (+ hot-pixel repair) on the candidate map, beside the build  -> ev_repaired
+//   stream  [ev_map]  pass A (+ hot-pixel repair) on the candidate map, beside the build     -> ev_repaired
 //           [ev_side] pass B                                                                -> end of step s
 //
 // so the caller's stream carries pass A, the repair and pass B and nothing else, and the host runs a step ahead of the device.
@@ -1421,10 +1413,9 @@ static int step_setup(upsp_pipeline *p)
     for (hipEvent_t *e : {&s.ev_map[0], &s.ev_map[1], &s.ev_side[0], &s.ev_side[1], &s.ev_repaired[0], &s.ev_repaired[1], &s.ev_end[0],
                           &s.ev_end[1], &s.ev_end[2]})
         UPSP_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
-    UPSP_HIP_CHECK(hipStreamCreateWithFlags(&s.scan, hipStreamNonBlocking));
-    UPSP_HIP_CHECK(hipStreamCreateWithFlags(&s.aux, hipStreamNonBlocking));
-    UPSP_HIP_CHECK(hipEventCreateWithFlags(&s.ev_hook[0], hipEventDisableTiming));
-    UPSP_HIP_CHECK(hipEventCreateWithFlags(&s.ev_hook[1], hipEventDisableTiming));
+    // (the two build streams FIRST and nothing that is not used: the runtime deals its few hardware queues out in the order streams are
+    //  created -- with two more normal-priority streams created in front of the second build stream the two builds shared a queue
+    //  and the step went from 0.77 to 1.13 ms, round 6.  The pass-A stream of the measurement switch is created when first used.)
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess)
         UPSP_HIP_CHECK(hipStreamCreateWithPriority(&s.side2, hipStreamNonBlocking, greatest));
     else
@@ -1489,16 +1480,17 @@ int upsp_pipeline_step(upsp_pipeline *p, const upsp_step_args *a, void *stream)
     if (rc != UPSP_OK) return rc;
     rc = upsp_pipeline_set_active_hint(p, d_cand, side);
     if (rc != UPSP_OK) return rc;
-    UPSP_HIP_CHECK(hipEventRecord(s.ev_map[n % 2], side));
     if (a->frames_hook) {
-        // The frames hook needs the previous step's repair -- the BUILD does not: the hook runs on a stream of its own, so that the
-        // ray casting of this step starts as soon as its map is built instead of behind a repair that ends half a step later (kernel
-        // trace, round 6: the build chain started 0.42 ms after the event it really depends on and ended 40 us after pass B wanted it).
-        if (n == 0) UPSP_HIP_CHECK(hipStreamWaitEvent(s.aux, s.ev_end[2], 0));
-        if (n >= 1) UPSP_HIP_CHECK(hipStreamWaitEvent(s.aux, s.ev_repaired[(n - 1) % 2], 0));
-        a->frames_hook(a->frames_user, s.aux);
-        UPSP_HIP_CHECK(hipEventRecord(s.ev_hook[n % 2], s.aux));
+        // behind the map (which runs beside the previous step's pass A): in front of it the whole side block -- and with it this
+        // step's pass B -- would wait for that repair.  The wait also times the build: its ray casting starts with the previous
+        // step's pass B, a write stream it disturbs little (0.343 ms with or without company), not beside the whole of pass A.
+        // (Round 6, measured and not kept: the hook on a stream of its own, so that the build starts as soon as the map is built --
+        //  the primary pass 0.35 -> 0.25 ms, but pass A beside it 0.349 -> 0.399 ms and the step 0.758 -> 0.81-0.83 ms; with the
+        //  ray casting gated on the repair again through an event: 0.79-0.83.)
+        if (n >= 1) UPSP_HIP_CHECK(hipStreamWaitEvent(side, s.ev_repaired[(n - 1) % 2], 0));
+        a->frames_hook(a->frames_user, side);
     }
+    UPSP_HIP_CHECK(hipEventRecord(s.ev_map[n % 2], side));
     int32_t *target = nullptr;
     rc = upsp_pipeline_projection_target(p, 0, &target);
     if (rc != UPSP_OK) return rc;
@@ -1528,13 +1520,13 @@ int upsp_pipeline_step(upsp_pipeline *p, const upsp_step_args *a, void *stream)
     // writes no faster than the copy probe does (5.3 TB/s) and the two kernels also take each other's wave slots.
     // UPSP_STEP_SCAN_STREAM=1 (measurement switch) turns it on.
     static const bool scan_beside = [] { const char *e = std::getenv("UPSP_STEP_SCAN_STREAM"); return e && *e == '1'; }();
+    if (scan_beside && !s.scan) UPSP_HIP_CHECK(hipStreamCreateWithFlags(&s.scan, hipStreamNonBlocking));
     hipStream_t scan = scan_beside ? s.scan : main;
     if (scan_beside) {
         std::swap(p->d_compact, p->d_compact_alt);
         std::swap(p->compact_bytes, p->compact_bytes_alt);
     }
     UPSP_HIP_CHECK(hipStreamWaitEvent(scan, s.ev_map[n % 2], 0));
-    if (a->frames_hook) UPSP_HIP_CHECK(hipStreamWaitEvent(scan, s.ev_hook[n % 2], 0));
     rc = upsp_pipeline_prescan(p, a->d_frames, a->nframes, scan);      // (in two launches when upsp_pipeline_set_scan_split says so)
     if (rc != UPSP_OK) return rc;
     UPSP_HIP_CHECK(hipEventRecord(s.ev_repaired[n % 2], scan));
@@ -1578,12 +1570,12 @@ int upsp_pipeline_step_finish(upsp_pipeline *p, void *stream)
     // whatever the pipeline's own streams still hold (nothing a finished step needs) is ordered in front of the caller's next launch
     UPSP_HIP_CHECK(hipEventRecord(s.ev_map[0], s.side));
     UPSP_HIP_CHECK(hipStreamWaitEvent(main, s.ev_map[0], 0));
-    UPSP_HIP_CHECK(hipEventRecord(s.ev_map[1], s.scan));
-    UPSP_HIP_CHECK(hipStreamWaitEvent(main, s.ev_map[1], 0));
+    if (s.scan) {
+        UPSP_HIP_CHECK(hipEventRecord(s.ev_map[1], s.scan));
+        UPSP_HIP_CHECK(hipStreamWaitEvent(main, s.ev_map[1], 0));
+    }
     UPSP_HIP_CHECK(hipEventRecord(s.ev_side[0], s.side2));
     UPSP_HIP_CHECK(hipStreamWaitEvent(main, s.ev_side[0], 0));
-    UPSP_HIP_CHECK(hipEventRecord(s.ev_hook[0], s.aux));
-    UPSP_HIP_CHECK(hipStreamWaitEvent(main, s.ev_hook[0], 0));
     return UPSP_OK;
 }
 
