@@ -68,3 +68,11 @@ if [ $part = plain ]; then
   # use with a switch, or read the kernel times)
   for i in 1 2 3; do line plain_$i -- --no-reraycast --steps 20 --warmup 5 || exit 1; done
 fi
+if [ $part = oneflush ]; then
+  # ECC interior blocks with ONE float segment per row piece (double totals behind the loop): UPSP_ECC_ONE_FLUSH
+  #   0 = round 5 (32-row segments; identity 4 waves, general 3), 1 = identity 5 waves + general 4 waves (35-row tile, 28-row staging),
+  #   2 = identity <4,6 asked> + general 4 waves, 3 = same occupancy as round 5, one flush only
+  for i in 1 2; do
+    for v in ${ONEFLUSH_VARIANTS:-0 1 2 3}; do line oneflush_${v}_$i UPSP_ECC_ONE_FLUSH=$v -- --registration --steps 3 --warmup 1 || exit 1; done
+  done
+fi

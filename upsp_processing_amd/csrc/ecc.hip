@@ -79,7 +79,9 @@ __device__ __forceinline__ EccMargins ecc_margins(int band, int rows, int cols)
 }
 
 typedef float v2f __attribute__((ext_vector_type(2)));
-constexpr int kEccFlush = 32;        // rows per float segment
+constexpr int kEccFlush = 32;        // rows per float segment (band blocks; interior blocks of images taller than 8 x kEccFlushLong)
+constexpr int kEccFlushLong = 128;   // ... of the interior blocks' ONE-FLUSH form (round 6): the whole row piece of a block is one float
+                                     // segment, so the thread's 27 double totals (54 registers) exist only behind the loop
 
 struct EccPart {        // float partial sums of one segment
     v2f G0, G1, Gw0, Gw1, Gt0, Gt1, Q0, Q1, Q2, C01;
@@ -416,7 +418,8 @@ struct EccSeg {          // one float segment of a block (all uniform)
     bool fits;
 };
 
-__device__ __forceinline__ EccSeg ecc_segment_box(int2 ra, int2 re, int ax_lo, int ax_hi, int bx_lo, int bx_hi, int rows, int cols)
+__device__ __forceinline__ EccSeg ecc_segment_box(int2 ra, int2 re, int ax_lo, int ax_hi, int bx_lo, int bx_hi, int rows, int cols,
+                                                  int tile_rows = kEccTileRows)
 {
     const int sx_min = ((min(ra.x, re.x) + ax_lo + 16) >> 5) >> 5, sx_max = ((max(ra.x, re.x) + ax_hi + 16) >> 5) >> 5;
     const int sy_min = ((min(ra.y, re.y) + bx_lo + 16) >> 5) >> 5, sy_max = ((max(ra.y, re.y) + bx_hi + 16) >> 5) >> 5;
@@ -427,7 +430,7 @@ __device__ __forceinline__ EccSeg ecc_segment_box(int2 ra, int2 re, int ax_lo, i
     g.nc4 = (sx_max + 2 - g.c0 + 4) >> 2;
     // (interior pixels have their footprint inside the image by construction -- ecc_band; the tests on the image bounds
     //  only keep a tile load from ever leaving the frame)
-    g.fits = !(cols & 3) && g.nr <= kEccTileRows && g.nc4 * 4 <= kEccTilePitch && g.r0 >= 0 && sx_min >= 1 &&
+    g.fits = !(cols & 3) && g.nr <= tile_rows && g.nc4 * 4 <= kEccTilePitch && g.r0 >= 0 && sx_min >= 1 &&
              sy_max + 2 < rows && sx_max + 2 < cols && g.nr > 0 && g.nc4 >= 1;
     return g;
 }
@@ -465,7 +468,7 @@ __device__ __forceinline__ void ecc_stage_tile(const float *__restrict__ I, int 
 template <int UR, bool TILE>
 __device__ __forceinline__ void ecc_walk_segment(const float *tile, const EccSeg &g, const float *__restrict__ I,
                                                  const float *__restrict__ tmpl, int cols, int x, int yb, int ne, int ax, int bx,
-                                                 const int2 *__restrict__ rt, EccPart &P, EccTot &T)
+                                                 const int2 *__restrict__ rt, EccPart &P, EccTot &T, int rbase = 0)
 {
     const unsigned pitch = 4u * (unsigned)cols;
     unsigned ot = 4u * (unsigned)(yb * cols + x);
@@ -516,7 +519,7 @@ __device__ __forceinline__ void ecc_walk_segment(const float *tile, const EccSeg
 #pragma unroll
         for (int k = 0; k < UR; ++k) taps(r + k, q[k]);
 #pragma unroll
-        for (int k = 0; k < UR; ++k) ecc_row_sum(q[k], P, T, (float)(r + k));
+        for (int k = 0; k < UR; ++k) ecc_row_sum(q[k], P, T, (float)(rbase + r + k));
         ot += (unsigned)UR * pitch;
     }
 #pragma unroll
@@ -525,14 +528,26 @@ __device__ __forceinline__ void ecc_walk_segment(const float *tile, const EccSeg
             EccRow q;
             q.tt = tn[k];
             taps(r + k, q);
-            ecc_row_sum(q, P, T, (float)(r + k));
+            ecc_row_sum(q, P, T, (float)(rbase + r + k));
         }
 }
 
 // Interior block `blk` of `nblk`: the inner rectangle (farther than the band from every edge) is cut into column tiles
 // of 256 and, per tile, into nblk / tiles row pieces; blocks beyond that store zeros.  Needs nblk >= tiles.  The float
 // segments follow the row pieces, i.e. the image geometry alone: the sums of a frame are the same bits in any batch.
-template <bool IDENT, int UR>
+// Round 6: the ONE-FLUSH form of the interior blocks.  A block's row piece (<= kEccFlushLong rows; the host picks the form by the image
+// height) is ONE float segment: the partial sums run over the whole piece and the double totals are formed once, behind the loop, so
+// their 54 registers are not live in it -- the general iteration fits four waves per SIMD (128 registers, 3 spilled; forcing four
+// waves on the 32-row form spilled 31, round 5), the identity iteration five.  Four workgroups per compute unit have 40 KB of LDS
+// each: the tile of that form has 35 rows -- 3 for the footprint, 4 for shear / scale -- and is staged per 28 rows (the 40-row tile:
+// per 32); a segment whose footprint is taller takes the direct loads.  A float segment of 128 rows instead of 32 doubles the
+// rounding error of a segment sum (sqrt 4) and quarters their number: the frame's sums move in the ninth digit, iteration counts and
+// the 1e-4 / 2e-3 px bars as before (tests, profiles/r06_soak_ecc.txt).  Measured, 512-frame launches: general 1.46 -> 1.375 ms,
+// identity 0.83 -> 0.80 ms (one flush at the old occupancy: 1.45 / 0.81; identity <2 rows, 5 waves> 0.91, <3, 5> 0.83; general
+// <1 row, 4 waves> 1.47).
+constexpr int ecc_tile_rows(int waves) { return waves >= 4 ? 35 : kEccTileRows; }
+constexpr int ecc_lds_rows(int waves) { return (ecc_tile_rows(waves) * kEccTilePitch * 4 + 256 * 8 - 1) / (256 * 8); }
+template <bool IDENT, int UR, bool ONE = false, int TR = kEccTileRows>
 __device__ __forceinline__ void ecc_cols_body(const float *__restrict__ img, const float *__restrict__ tmpl, int rows, int cols,
                                               const EccState *__restrict__ state, const int2 *__restrict__ rtab,
                                               double *__restrict__ partial, int f, unsigned slot0, unsigned blk, unsigned nblk,
@@ -560,20 +575,29 @@ __device__ __forceinline__ void ecc_cols_body(const float *__restrict__ img, con
     T.n = on ? (double)(y1 - y0) : 0.0;          // mask = 1 on every interior pixel
     T.cf = center;
     int x = x_own;
+    EccPart P1;                                  // ONE: the partial sums of the whole row piece
+    if (ONE) ecc_part_zero(P1);
     if (IDENT) {
         // lanes past the rectangle run along on a valid column (the DPP taps need every lane; the lane after the last one must
         // hold column x_hi, which exists: the band is >= 3 wide) and are left out of the reduction.
         // (Round 4: staging the segment's rows in LDS like the general iteration does was measured and is SLOWER here, 2.03-2.11
         //  against 1.97 ms per 1000 frames: 2.5 coalesced loads per pixel are not what this kernel waits for.)
         x = min(x_own, cols - 1);
-        for (int yb = y0; yb < y1; yb += kEccFlush) {
-            const int ne = min(kEccFlush, y1 - yb);
-            EccPart P;
-            ecc_part_zero(P);
+        if (ONE) {
+            const int ne = y1 - y0;
             int r = 0;
-            for (; r + UR <= ne; r += UR) ecc_ident_trip<UR>(I, tmpl, cols, x, yb + r, r, P, T);
-            for (; r < ne; ++r) ecc_ident_trip<1>(I, tmpl, cols, x, yb + r, r, P, T);
-            ecc_part_flush(P, T, yb);
+            for (; r + UR <= ne; r += UR) ecc_ident_trip<UR>(I, tmpl, cols, x, y0 + r, r, P1, T);
+            for (; r < ne; ++r) ecc_ident_trip<1>(I, tmpl, cols, x, y0 + r, r, P1, T);
+        } else {
+            for (int yb = y0; yb < y1; yb += kEccFlush) {
+                const int ne = min(kEccFlush, y1 - yb);
+                EccPart P;
+                ecc_part_zero(P);
+                int r = 0;
+                for (; r + UR <= ne; r += UR) ecc_ident_trip<UR>(I, tmpl, cols, x, yb + r, r, P, T);
+                for (; r < ne; ++r) ecc_ident_trip<1>(I, tmpl, cols, x, yb + r, r, P, T);
+                ecc_part_flush(P, T, yb);
+            }
         }
     } else {
         float *tile = reinterpret_cast<float *>(&lds_red[0][0]);
@@ -585,25 +609,34 @@ __device__ __forceinline__ void ecc_cols_body(const float *__restrict__ img, con
         const int bxa = __builtin_amdgcn_readfirstlane(__double2int_rn(M3 * xa * 1024)), bxb = __builtin_amdgcn_readfirstlane(__double2int_rn(M3 * xb * 1024));
         const int ax = __double2int_rn(M0 * x * 1024), bx = __double2int_rn(M3 * x * 1024);
         bool staged = false;
-        for (int yb = y0; yb < y1; yb += kEccFlush) {
-            const int ne = min(kEccFlush, y1 - yb);
-            EccSeg s = ecc_segment_box(rt[yb], rt[yb + ne - 1], min(axa, axb), max(axa, axb), min(bxa, bxb), max(bxa, bxb), rows, cols);
+        // staging segments: as many rows as leave the tile 3 rows for the footprint and >= 4 for shear / scale (40-row tile: 32;
+        // the 35-row tile of the four-wave form: 28).  In the one-flush form they are not the float segments.
+        constexpr int STG = ONE ? (TR - 7 < kEccFlush ? TR - 7 : kEccFlush) : kEccFlush;
+        for (int yb = y0; yb < y1; yb += STG) {
+            const int ne = min(STG, y1 - yb);
+            EccSeg s = ecc_segment_box(rt[yb], rt[yb + ne - 1], min(axa, axb), max(axa, axb), min(bxa, bxb), max(bxa, bxb), rows, cols, TR);
             if (force_direct) s.fits = false;
             if (s.fits) {                              // (uniform)
                 if (staged) __syncthreads();           // every tap of the previous segment has been read
-                ecc_stage_tile<kEccTileRows, kEccTilePitch>(I, cols, s, tile);
+                ecc_stage_tile<TR, kEccTilePitch>(I, cols, s, tile);
                 __syncthreads();
                 staged = true;
             }
             if (on) {
-                EccPart P;
-                ecc_part_zero(P);
-                if (s.fits) ecc_walk_segment<UR, true>(tile, s, I, tmpl, cols, x, yb, ne, ax, bx, rt + yb, P, T);
-                else ecc_walk_segment<UR, false>(tile, s, I, tmpl, cols, x, yb, ne, ax, bx, rt + yb, P, T);
-                ecc_part_flush(P, T, yb);
+                if (ONE) {
+                    if (s.fits) ecc_walk_segment<UR, true>(tile, s, I, tmpl, cols, x, yb, ne, ax, bx, rt + yb, P1, T, yb - y0);
+                    else ecc_walk_segment<UR, false>(tile, s, I, tmpl, cols, x, yb, ne, ax, bx, rt + yb, P1, T, yb - y0);
+                } else {
+                    EccPart P;
+                    ecc_part_zero(P);
+                    if (s.fits) ecc_walk_segment<UR, true>(tile, s, I, tmpl, cols, x, yb, ne, ax, bx, rt + yb, P, T);
+                    else ecc_walk_segment<UR, false>(tile, s, I, tmpl, cols, x, yb, ne, ax, bx, rt + yb, P, T);
+                    ecc_part_flush(P, T, yb);
+                }
             }
         }
     }
+    if (ONE) ecc_part_flush(P1, T, y0);
     __syncthreads();                              // (every read of the tile is done: the area becomes the reduction's)
     ecc_tot_store<0>(T, (double)x, on, lds_red, partial, f, slot0 + blk);
 }
@@ -751,13 +784,15 @@ __global__ void __launch_bounds__(256) ecc_center_kernel(const float *__restrict
 }
 
 // grid (frames, nband + interior blocks)
-template <bool IDENT, int UR, int WAVES>
+template <bool IDENT, int UR, int WAVES, bool ONE = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
     ecc_cols_kernel(const float *__restrict__ img, const float *__restrict__ tmpl, int rows, int cols,
                     const EccState *__restrict__ state, const int2 *__restrict__ rtab, double *__restrict__ partial,
                     const float *__restrict__ center, unsigned nband, int force_direct)
 {
-    __shared__ double lds_red[IDENT ? kEccChunk : kEccLdsRows][256];     // source tile / reduction chunks of whichever body runs
+    __shared__ double lds_red[IDENT ? kEccChunk : ecc_lds_rows(WAVES)][256];     // source tile / reduction chunks of whichever body runs
+    static_assert(ecc_lds_rows(WAVES) >= kEccChunk, "the tile area also holds the reduction chunks");
+    static_assert(IDENT || WAVES <= 3 || sizeof(lds_red) * WAVES <= 160 * 1024, "the tiles of the workgroups of a compute unit fit its LDS");
     const int f = blockIdx.x;
     if (state[f].done) return;
     // (Round 6, measured and removed: a start delay of 0 / 1 / 2 units by a hash of the frame index for the interior workgroups of
@@ -765,8 +800,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
     //  Units of 3 / 6 / 12 x 0.85 us: 1.464 -> 1.507 / 1.551 / 1.645 ms per 512-frame launch, two alternations -- the delay is
     //  simply added; the workgroups are not waiting for each other's phase.)
     if (blockIdx.y >= nband)
-        ecc_cols_body<IDENT, UR>(img, tmpl, rows, cols, state, rtab, partial, f, nband, blockIdx.y - nband, gridDim.y - nband, lds_red,
-                                 *center, force_direct);
+        ecc_cols_body<IDENT, UR, ONE, ecc_tile_rows(WAVES)>(img, tmpl, rows, cols, state, rtab, partial, f, nband, blockIdx.y - nband,
+                                                            gridDim.y - nband, lds_red, *center, force_direct);
     else
         ecc_band_cols_body(img, tmpl, rows, cols, state, rtab, partial, f, blockIdx.y, nband, IDENT, lds_red);
 }
@@ -1047,6 +1082,11 @@ int run_ecc(FrameScratch *s, const float *tmpl_blur, const float *d_center, cons
     // tile -- the same bits (tests/test_imageops_gpu.py::test_ecc_lds_taps_same_bits)
     const char *direct_env = std::getenv("UPSP_ECC_DIRECT");
     const int force_direct = direct_env && std::atoi(direct_env) != 0;
+    // the one-flush form of the interior blocks (ecc_cols_body): when a block's row piece has <= kEccFlushLong rows -- a property of
+    // the image geometry alone, like the block count.  UPSP_ECC_ONE_FLUSH=0: the 32-row float segments of rounds 3-5 (A/B).
+    const int pieces_min = std::max(blocks / tiles, 1);
+    static const bool one_flush_on = [] { const char *e = std::getenv("UPSP_ECC_ONE_FLUSH"); return !(e && *e == '0'); }();
+    const bool one_flush = one_flush_on && (rows - 6 + pieces_min - 1) / pieces_min <= kEccFlushLong;
     bool first_burst = true, waited = false;
     int it = 0, iters_done = 0, most_iters = 0;
     for (;;) {
@@ -1060,12 +1100,17 @@ int run_ecc(FrameScratch *s, const float *tmpl_blur, const float *d_center, cons
             {
                 KTimed kt(it == 0 ? "ecc_sums_identity" : "ecc_sums_general", st);
                 const dim3 grid((unsigned)nb, (unsigned)nblocks_total);
-                if (it == 0)
-                    hipLaunchKernelGGL((ecc_cols_kernel<true, 4, 4>), grid, dim3(256), 0, st, blurred, tmpl_blur, rows, cols,
-                                       (const EccState *)s->state, (const int2 *)s->rtab, s->partial, d_center, (unsigned)nband, 0);
-                else
-                    hipLaunchKernelGGL((ecc_cols_kernel<false, 2, 3>), grid, dim3(256), 0, st, blurred, tmpl_blur, rows, cols,
-                                       (const EccState *)s->state, (const int2 *)s->rtab, s->partial, d_center, (unsigned)nband, force_direct);
+#define UPSP_ECC_LAUNCH(IDENT, UR, WAVES, ONE, FD)                                                                             \
+    hipLaunchKernelGGL((ecc_cols_kernel<IDENT, UR, WAVES, ONE>), grid, dim3(256), 0, st, blurred, tmpl_blur, rows, cols,         \
+                       (const EccState *)s->state, (const int2 *)s->rtab, s->partial, d_center, (unsigned)nband, FD)
+                if (it == 0) {
+                    if (one_flush) UPSP_ECC_LAUNCH(true, 4, 5, true, 0);
+                    else UPSP_ECC_LAUNCH(true, 4, 4, false, 0);
+                } else {
+                    if (one_flush) UPSP_ECC_LAUNCH(false, 2, 4, true, force_direct);
+                    else UPSP_ECC_LAUNCH(false, 2, 3, false, force_direct);
+                }
+#undef UPSP_ECC_LAUNCH
             }
             KTimed kt2("ecc_solve_kernel", st);
             hipLaunchKernelGGL(ecc_solve_kernel, dim3(nb), dim3(256), 0, st, s->state, (const double *)s->partial, s->rtab, nb,
