@@ -69,10 +69,10 @@ if [ $part = plain ]; then
   for i in 1 2 3; do line plain_$i -- --no-reraycast --steps 20 --warmup 5 || exit 1; done
 fi
 if [ $part = oneflush ]; then
-  # ECC interior blocks with ONE float segment per row piece (double totals behind the loop): UPSP_ECC_ONE_FLUSH
-  #   0 = round 5 (32-row segments; identity 4 waves, general 3), 1 = identity 5 waves + general 4 waves (35-row tile, 28-row staging),
-  #   2 = identity <4,6 asked> + general 4 waves, 3 = same occupancy as round 5, one flush only
+  # ECC interior blocks with ONE float segment per row piece (double totals behind the loop; general iteration at four waves per
+  # SIMD on a 35-row tile, identity at five) -- the default -- against the 32-row segments of rounds 3-5 (UPSP_ECC_ONE_FLUSH=0)
   for i in 1 2; do
-    for v in ${ONEFLUSH_VARIANTS:-0 1 2 3}; do line oneflush_${v}_$i UPSP_ECC_ONE_FLUSH=$v -- --registration --steps 3 --warmup 1 || exit 1; done
+    line oneflush_0_$i UPSP_ECC_ONE_FLUSH=0 -- --registration --steps 3 --warmup 1 || exit 1
+    line oneflush_1_$i -- --registration --steps 3 --warmup 1 || exit 1
   done
 fi
