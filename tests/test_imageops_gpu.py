@@ -99,11 +99,25 @@ def test_register_pixel(gpu_lib, oracle, interp):
         assert np.array_equal(out_g.cpu().numpy(), oracle.warp_affine(fr[f], M_g, interp))
 
 
-@pytest.mark.parametrize("H,W,shift", [(96, 131, (7.3, -4.6)), (48, 64, (1.4, 0.7)), (200, 300, (-15.2, 11.8)), (33, 47, (0.3, -0.2))])
+@pytest.mark.parametrize("H,W,shift", [(96, 131, (7.3, -4.6)), (48, 64, (1.4, 0.7)), (200, 300, (-15.2, 11.8)), (33, 47, (0.3, -0.2)),
+                                       (1400, 1100, (3.3, -2.1))])
 def test_register_pixel_band(gpu_lib, oracle, H, W, shift):
     """The ECC sums are taken by interior blocks (pixels farther than a band from every edge, no border handling) and
     band blocks (generic bilinear); the band follows the warp.  Odd image sizes, shifts of many pixels (wide bands, a band
-    that swallows most of a small image), shear: same iteration count and warp as the oracle."""
+    that swallows most of a small image), shear: same iteration count and warp as the oracle.  1400 x 1100: an image taller
+    than 8 x 128 rows -- 5 column tiles x 11 row pieces of interior blocks instead of the 32 of a 1024^2 frame."""
+    _register_band_case(oracle, H, W, shift)
+
+
+def test_register_pixel_segments_of_32_rows(gpu_lib, oracle, monkeypatch):
+    """UPSP_ECC_ONE_FLUSH=0: the interior blocks in the 32-row float segments of rounds 3-5 (what an image beyond 512
+    interior blocks still takes) -- the same bars."""
+    monkeypatch.setenv("UPSP_ECC_ONE_FLUSH", "0")
+    _register_band_case(oracle, 200, 300, (-15.2, 11.8))
+    _register_band_case(oracle, 1400, 1100, (3.3, -2.1))
+
+
+def _register_band_case(oracle, H, W, shift):
     import torch
     from upsp_processing_amd import engine
     rng = np.random.default_rng(H * W)

@@ -79,7 +79,7 @@ __device__ __forceinline__ EccMargins ecc_margins(int band, int rows, int cols)
 }
 
 typedef float v2f __attribute__((ext_vector_type(2)));
-constexpr int kEccFlush = 32;        // rows per float segment (band blocks; interior blocks of images taller than 8 x kEccFlushLong)
+constexpr int kEccFlush = 32;        // rows per float segment (band blocks; interior blocks when UPSP_ECC_ONE_FLUSH=0 or past kEccInteriorMax)
 constexpr int kEccFlushLong = 128;   // ... of the interior blocks' ONE-FLUSH form (round 6): the whole row piece of a block is one float
                                      // segment, so the thread's 27 double totals (54 registers) exist only behind the loop
 
@@ -1073,8 +1073,11 @@ int run_ecc(FrameScratch *s, const float *tmpl_blur, const float *d_center, cons
     // = (64, 48) / (32, 24) / (32, 16) / (16, 12) / (8, 12): 7.47 / 7.29 / 7.23 / 7.26 / 7.35.  (Round 3, 64-frame launches:
     // 16 / 32 / 64 interior blocks gave 6.74 / 6.25 / 6.03 ms of sums -- there the chip needed the blocks.)  At least one
     // interior block per column tile.
+    // Images taller than 8 x kEccFlushLong rows get more row pieces, so that a piece stays within kEccFlushLong rows and the
+    // interior blocks keep their one-flush form (2048^2: 8 tiles x 16 pieces = 128 blocks; up to kEccInteriorMax).
     const int tiles = (cols + 255) / 256;
-    const int blocks = std::max(kEccInteriorBlocks, tiles);
+    const int pieces_tall = (std::max(rows - 6, 1) + kEccFlushLong - 1) / kEccFlushLong;
+    const int blocks = std::max(std::max(kEccInteriorBlocks, tiles), std::min(tiles * pieces_tall, kEccInteriorMax / tiles * tiles));
     const int nband = std::max(kEccBandBlocks, 3 * tiles);
     static_assert(kEccInteriorMax >= 128 && kEccBandMax >= 3 * 128, "column tiles of an image narrower than 32768");
     const int nblocks_total = blocks + nband;
@@ -1085,7 +1088,8 @@ int run_ecc(FrameScratch *s, const float *tmpl_blur, const float *d_center, cons
     // the one-flush form of the interior blocks (ecc_cols_body): when a block's row piece has <= kEccFlushLong rows -- a property of
     // the image geometry alone, like the block count.  UPSP_ECC_ONE_FLUSH=0: the 32-row float segments of rounds 3-5 (A/B).
     const int pieces_min = std::max(blocks / tiles, 1);
-    static const bool one_flush_on = [] { const char *e = std::getenv("UPSP_ECC_ONE_FLUSH"); return !(e && *e == '0'); }();
+    const char *one_env = std::getenv("UPSP_ECC_ONE_FLUSH");
+    const bool one_flush_on = !(one_env && *one_env == '0');
     const bool one_flush = one_flush_on && (rows - 6 + pieces_min - 1) / pieces_min <= kEccFlushLong;
     bool first_burst = true, waited = false;
     int it = 0, iters_done = 0, most_iters = 0;
