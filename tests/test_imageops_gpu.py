@@ -458,6 +458,62 @@ def test_registration_sub_batches_look_ahead(gpu_lib, oracle, monkeypatch, reg_b
         assert np.array_equal(a[0][ok, f].view(np.int32), want[ok].view(np.int32))
 
 
+@pytest.mark.parametrize("H,W,F", [(96, 160, 70), (300, 250, 20), (131, 1030, 12)])
+def test_ecc_fused_blur_same_frames_and_bars(gpu_lib, oracle, monkeypatch, H, W, F):
+    """The streamed registration loop blurs the frames and takes the sums of the ECC's identity iteration in ONE pass
+    (ecc_blur_ident_kernel: 58-column strips per wave, reflected loads at the image edges, hot-pixel scan on the way, a second
+    pass over the frames the repair changed).  Against the two-kernel path (UPSP_ECC_FUSED_BLUR=0):
+      * UPSP_ECC_FUSED_BLUR=2 keeps the pass's blurred frames and drops its sums: series, warps, iteration counts and repaired
+        frames must be the SAME BITS -- i.e. the blurred frames are bit-identical, image edges and repaired neighbourhoods included;
+      * the default (sums from the pass): same iteration counts, warps within the oracle's bars of the two-kernel path (the sums
+        are taken in another order), and the oracle's bars themselves on frames with and without hot pixels.
+    Widths that leave a partial strip, heights that leave a partial row piece, more than one row piece and sub-batch."""
+    import torch
+    from upsp_processing_amd import engine, synthetic as syn
+    monkeypatch.setenv("UPSP_REG_BATCH", "32")
+    n = 2500
+    frames = syn.synth_frames_numpy(F, H, W, seed=H + W, hot=True)
+    rng = np.random.default_rng(H)
+    hot_frames = (1, F // 2, F - 1)
+    for f in hot_frames:                                   # one in the interior, one at an image edge, one in a corner
+        frames[f, rng.integers(2, H - 2), rng.integers(2, W - 2)] = 4090
+    frames[hot_frames[1], 0, rng.integers(2, W - 2)] = 4095
+    frames[hot_frames[2], H - 1, W - 1] = 4095
+    ref = frames[0].astype(np.float32)
+    pix = (rng.integers(0, H, n) * W + rng.integers(0, W, n)).astype(np.int32)
+    out = {}
+    for mode in ("0", "2", "1"):
+        monkeypatch.setenv("UPSP_ECC_FUSED_BLUR", mode)
+        pipe = engine.FramePipeline(1, W, H, n, registration=1)
+        pipe.set_projection(0, pix)
+        pipe.set_reference(0, ref)
+        rt = torch.full((n, engine.series_ld(F)), -3.0, dtype=torch.float32, device="cuda")
+        d = torch.as_tensor(frames.copy()).cuda()
+        w = torch.zeros((F, 1, 6), dtype=torch.float32, device="cuda")
+        it = torch.full((F, 1), -1, dtype=torch.int32, device="cuda")
+        pipe.process(d, 0, rows_t=rt[:, :F], want_rows=False, warps=w, ecc_iters=it)
+        torch.cuda.synchronize()
+        out[mode] = (rt.cpu().numpy()[:, :F], w.cpu().numpy()[:, 0].reshape(F, 2, 3), it.cpu().numpy()[:, 0], d.cpu().numpy())
+        pipe.close()
+    a, b, c = out["0"], out["2"], out["1"]
+    assert np.array_equal(a[3], b[3]) and np.array_equal(a[3], c[3])                    # repaired frames
+    assert np.array_equal(a[0].view(np.int32), b[0].view(np.int32)) and np.array_equal(a[1].view(np.int32), b[1].view(np.int32))
+    assert np.array_equal(a[2], b[2])
+    assert np.array_equal(a[2], c[2]), (a[2], c[2])
+    # (the float rounding of a sum moves a warp by 1e-7 .. 1e-4 px through the reference's float 6 x 6 solve, whichever kernel took
+    #  the sums -- tools/r06_fused_dbg.py prints both paths against the oracle; frames that oscillate for tens of iterations amplify it)
+    few = a[2] <= 6
+    assert few.sum() >= F // 2
+    assert np.abs(a[1][few][:, :, :2] - c[1][few][:, :, :2]).max() <= 1e-4 and np.abs(a[1][few][:, :, 2] - c[1][few][:, :, 2]).max() <= 2e-3
+    for f in (hot_frames[0], hot_frames[2], 2):
+        img, _ = oracle.fix_hot_pixels(frames[f])
+        assert np.array_equal(c[3][f], img)
+        _, M_o, it_o = oracle.register_pixel(ref, img)
+        assert c[2][f] == it_o and np.abs(c[1][f][:, :2] - M_o[:, :2]).max() <= 1e-4 and np.abs(c[1][f][:, 2] - M_o[:, 2]).max() <= 2e-3
+        want = oracle.project_frame(oracle.warp_affine(img, c[1][f], 1), pix, None)
+        assert np.array_equal(c[0][:, f].view(np.int32), want.view(np.int32))
+
+
 def test_ecc_lds_taps_same_bits(gpu_lib, monkeypatch):
     """The general ECC iteration takes its 12 source taps per pixel from an LDS-staged tile of the source frame (one float
     segment of 32 rows x 256 columns at a time) instead of 8 load instructions per pixel: the same floats through the same

@@ -256,7 +256,7 @@ __device__ __forceinline__ void ecc_tot_put(const EccTot &T, double X, bool on, 
 }
 template <int C>
 __device__ __forceinline__ void ecc_tot_store(const EccTot &T, double X, bool on, double (*lds)[256], double *__restrict__ partial,
-                                              int f, unsigned slot)
+                                              int f, unsigned slot, unsigned stride = (unsigned)kEccStride)
 {
     ecc_tot_put<C, 0>(T, X, on, lds);
     __syncthreads();
@@ -269,10 +269,10 @@ __device__ __forceinline__ void ecc_tot_store(const EccTot &T, double X, bool on
         s = dpp_add_f64<0x4E, 0xF>(s);
         s = dpp_add_f64<0x141, 0xF>(s);
         s = dpp_add_f64<0x140, 0xF>(s);        // every lane of the row holds the block's sum of value v
-        if (p == 0) partial[((size_t)f * kEccSums + (C * kEccChunk + v)) * kEccStride + slot] = s;
+        if (p == 0) partial[((size_t)f * kEccSums + (C * kEccChunk + v)) * stride + slot] = s;
     }
     __syncthreads();
-    if constexpr (C + 1 < 3) ecc_tot_store<C + 1>(T, X, on, lds, partial, f, slot);
+    if constexpr (C + 1 < 3) ecc_tot_store<C + 1>(T, X, on, lds, partial, f, slot, stride);
 }
 
 // a block without any pixel: its partial sums are zero
@@ -760,6 +760,146 @@ __device__ __forceinline__ void ecc_band_cols_body(const float *__restrict__ img
     ecc_tot_store<0>(T, (double)x, on, lds_red, partial, f, bidx);
 }
 
+// ---- the 5 x 5 pre-blur fused into the identity iteration (round 6) ----------------------------------------------------
+// Every frame starts from the identity warp, so its first ECC iteration needs nothing but the blurred frame itself: the blur
+// (cpp/lib/registration.cpp:57-60, gaussFiltSize 5) and the identity sums are ONE pass -- the u16 frame is read (2 B / px), the
+// blurred f32 frame is written for the later iterations (4 B / px) and its values go into the sums from registers: 10 B / px with
+// the template instead of the 14 of gauss5_quad_kernel + ecc_cols_kernel<true>.
+//   * A WAVE owns a strip of 58 columns x <= 128 rows (one float segment, as in the one-flush form).  Lane l holds column
+//     58 strip - 3 + l: lanes 3 .. 60 are the strip's own columns, the three lanes on either side its neighbours' -- the horizontal
+//     blur taps come by DPP wave shifts (two chained shifts per side), so lanes 2 .. 61 hold a blurred value, and the x-gradient of
+//     an own lane is the difference of its neighbours' blurred values, which nobody else has computed yet.  The five rows of
+//     horizontal results and three blurred rows roll in registers.  Same float operations in the same order as gauss_pass_kernel:
+//     the blurred frame is bit-identical to the unfused path's (tests/test_imageops_gpu.py::test_ecc_fused_blur_*).
+//   * Image edges by reflection of the LOADS (BORDER_REFLECT_101 of the blur): the extended signal is symmetric about the edge, so the
+//     blurred value "at column -1" is the one at column 1 -- exactly filter2D's reflect-101 tap of the gradient images.  Under the
+//     identity warp every pixel is inside the mask and the bilinear weights are (1, 0, 0, 0): no band blocks, all rows x cols pixels
+//     are plain ones.
+//   * Hot pixels: the scan of fix_hot_pixels rides on the loads as in gauss5_quad_kernel.  The rare frames the repair changes
+//     afterwards run the kernel a second time (only_changed = their change counts): blurred frame and sums from the repaired pixels.
+// Block = four wave items (strip-major: neighbouring strips of one row piece), reduced like the interior blocks.
+constexpr int kFusedOwn = 58, kFusedHalo = 3;
+
+// a lane's byte offset as a value the compiler cannot hoist out of the loop as a 64-bit pair: keeps the loads in the
+// `saddr + 32-bit voffset` form (one scalar add per row instead of a 64-bit vector add per load)
+__device__ __forceinline__ unsigned opaque_u32(unsigned v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+// wave shifts that leave 0 in the lane without a source (bound_ctrl: no `old` register to initialise, and the compiler may fold the
+// shift into the instruction that uses it)
+__device__ __forceinline__ float dpp_shr1_z(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_shl1_z(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xF, 0xF, true));
+}
+
+template <bool HOT, int U>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5)))
+    ecc_blur_ident_kernel(const uint16_t *__restrict__ src, float *__restrict__ dst, const float *__restrict__ tmpl, int rows, int cols,
+                          int strips, int pieces, double *__restrict__ partial, const float *__restrict__ center, float k0, float k1,
+                          float k2, unsigned thresh, unsigned *__restrict__ hot_count, unsigned *__restrict__ hot_pos,
+                          const unsigned *__restrict__ only_changed)
+{
+    __shared__ double lds_red[kEccChunk][256];
+    const int f = blockIdx.x;
+    if (only_changed && only_changed[f] == 0u) return;                         // (uniform)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int item = (int)blockIdx.y * 4 + wave;
+    const int piece = item / strips, strip = item - piece * strips;
+    const bool work = piece < pieces;
+    const int y0 = piece * kEccFlushLong, y1 = min(rows, y0 + kEccFlushLong);
+    const int c = strip * kFusedOwn - kFusedHalo + lane;
+    const bool own = work && lane >= kFusedHalo && lane < kFusedHalo + kFusedOwn && c < cols;
+    EccTot T;
+    ecc_tot_zero(T);
+    T.cf = *center;
+    EccPart P;
+    ecc_part_zero(P);
+    if (work) {
+        const size_t npix = (size_t)rows * cols;
+        const char *S = reinterpret_cast<const char *>(src + (size_t)f * npix);
+        char *B = reinterpret_cast<char *>(dst + (size_t)f * npix);
+        const char *Tm = reinterpret_cast<const char *>(tmpl);
+        const unsigned pitch2 = 2u * (unsigned)cols, pitch4 = 4u * (unsigned)cols;
+        const unsigned cx2 = 2u * (unsigned)reflect101(min(max(c, -(cols - 1)), 2 * cols - 2), cols);
+        const unsigned cown = (unsigned)min(max(c, 0), cols - 1), cown4 = 4u * cown;
+        // rows -3 .. rows + 2 (rows >= 8): one reflection
+        auto rrow = [&](int yy) { return (unsigned)(yy < 0 ? -yy : (yy >= rows ? 2 * rows - 2 - yy : yy)); };
+        float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f, h4 = 0.f, Bm = 0.f, B0 = 0.f, Bp = 0.f;
+        auto load_row = [&](int yi, unsigned ocx2) -> unsigned {
+            const char *Sr = S + (size_t)(rrow(yi) * pitch2);                  // (uniform)
+            return *reinterpret_cast<const uint16_t *>(Sr + ocx2);
+        };
+        auto hot_scan = [&](int yi, unsigned pv) {
+            if (HOT && own && yi >= y0 && yi < y1 && pv >= thresh) {           // (rare)
+                const unsigned slot = atomicAdd(&hot_count[f], 1u);
+                if (slot < (unsigned)kHotPositions) hot_pos[(size_t)f * kHotPositions + slot] = (unsigned)yi * (unsigned)cols + cown;
+            }
+        };
+        auto hstep = [&](unsigned pv) {                                        // horizontal pass of one input row
+            const float pf = (float)pv;
+            const float a1 = dpp_shr1_z(pf), c1 = dpp_shl1_z(pf);
+            const float a2 = dpp_shr1_z(a1), c2 = dpp_shl1_z(c1);
+            float n = k0 * pf;
+            n += k1 * (a1 + c1);
+            n += k2 * (a2 + c2);
+            h0 = h1; h1 = h2; h2 = h3; h3 = h4; h4 = n;
+        };
+        auto vstep = [&](int yb, bool store, unsigned ocown4) {                // blurred row yb = the middle of the five
+            float bn = k0 * h2;
+            bn += k1 * (h1 + h3);
+            bn += k2 * (h0 + h4);
+            Bm = B0; B0 = Bp; Bp = bn;
+            if (own && store) *reinterpret_cast<float *>(B + (size_t)((unsigned)yb * pitch4) + ocown4) = bn;
+        };
+        // input rows y0 - 3 .. y0 + 2: the blurred rows y0 - 1 and y0
+        {
+            unsigned pv[6];
+            const unsigned ocx2 = opaque_u32(cx2), ocown4 = opaque_u32(cown4);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) pv[k] = load_row(y0 - 3 + k, ocx2);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                hot_scan(y0 - 3 + k, pv[k]);
+                hstep(pv[k]);
+                if (k >= 4) vstep(y0 - 5 + k, k == 5, ocown4);
+            }
+        }
+        // input row y0 + 3 + r: blurred row y0 + 1 + r, sums of row y0 + r
+        const int ne = y1 - y0;
+        for (int g = 0; g < ne; g += U) {
+            unsigned pv[U];
+            float tv[U];
+            const unsigned ocx2 = opaque_u32(cx2), ocown4 = opaque_u32(cown4);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                pv[u] = load_row(y0 + 3 + g + u, ocx2);
+                tv[u] = *reinterpret_cast<const float *>(Tm + (size_t)((unsigned)min(y0 + g + u, rows - 1) * pitch4) + ocown4);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int r = g + u;
+                if (r >= ne) break;                                            // (uniform)
+                hot_scan(y0 + 3 + r, pv[u]);
+                hstep(pv[u]);
+                vstep(y0 + 1 + r, r + 1 < ne, ocown4);
+                const float l = dpp_shr1_z(B0), rr = dpp_shl1_z(B0);
+                ecc_part_add<false>(P, T, B0, 0.5f * (rr - l), 0.5f * (Bp - Bm), tv[u], (float)r);
+            }
+        }
+    }
+    ecc_part_flush(P, T, y0);
+    T.n = own ? (double)(y1 - y0) : 0.0;          // mask = 1 on every pixel
+    ecc_tot_store<0>(T, (double)c, own, lds_red, partial, f, blockIdx.y, gridDim.y);
+}
+
 // centre of the float products (ecc_part_add): the mean of a 64 x 64 sample grid of the blurred template, rounded to an
 // integer and kept inside [0, 4095] (any integer there keeps w - c exact; the nearer to the image's mean, the smaller the
 // products).  Once per reference image; fixed order: deterministic.
@@ -940,7 +1080,7 @@ __device__ __forceinline__ void ecc_solve_scalar(EccState &es, const double *S, 
 // (WarpAffineInvoker: X0 = round((M01 y + M02) 1024), Y0 likewise; the sums kernel adds the per-column terms).
 __global__ void __launch_bounds__(256)
     ecc_solve_kernel(EccState *__restrict__ state, const double *__restrict__ partial, int2 *__restrict__ rtab,
-                     int nframes, int nblocks, int max_iters, double eps, int rows, int cols)
+                     int nframes, int nblocks, int max_iters, double eps, int rows, int cols, int stride)
 {
     const int f = blockIdx.x;
     if (f >= nframes) return;
@@ -956,14 +1096,14 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int i = 0; i < kPerWave; ++i) {
         const int k = wave + 4 * i;
-        v[i] = (k < kEccSums && lane < nblocks) ? partial[((size_t)f * kEccSums + k) * kEccStride + lane] : 0.0;
+        v[i] = (k < kEccSums && lane < nblocks) ? partial[((size_t)f * kEccSums + k) * stride + lane] : 0.0;
     }
     if (nblocks > 64) {
 #pragma unroll
         for (int i = 0; i < kPerWave; ++i) {
             const int k = wave + 4 * i;
             if (k < kEccSums) {
-                const double *pk = partial + ((size_t)f * kEccSums + k) * kEccStride;
+                const double *pk = partial + ((size_t)f * kEccSums + k) * stride;
                 for (int b = lane + 64; b < nblocks; b += 64) v[i] += pk[b];
             }
         }
@@ -1054,6 +1194,43 @@ int launch_ecc_export(const EccState *state, int nb, float *d_warps, int wstride
     return UPSP_OK;
 }
 
+bool ecc_fused_blur_eligible(int rows, int cols)
+{
+    const char *e = std::getenv("UPSP_ECC_FUSED_BLUR");       // =0: pre-blur and identity iteration as two kernels (A/B, tests)
+    return !(e && *e == '0') && rows >= 8 && cols >= 8 && rows < 32768 && cols < 32768 && (long long)rows * cols < (1ll << 29);
+}
+
+int launch_ecc_blur_ident(FrameScratch *s, int slot, const uint16_t *d_frames, float *dst, const float *tmpl_blur, const float *d_center,
+                          int nb, int rows, int cols, float k0, float k1, float k2, unsigned thresh, unsigned *hot_count,
+                          unsigned *hot_pos, const unsigned *only_changed, hipStream_t st)
+{
+    if (!s || slot < 0 || slot > 1 || nb > s->batch || !ecc_fused_blur_eligible(rows, cols))
+        return fail(UPSP_ERR_INVALID, "fused pre-blur: not set up for this geometry");
+    const int strips = (cols + kFusedOwn - 1) / kFusedOwn, pieces = (rows + kEccFlushLong - 1) / kEccFlushLong;
+    const int blocks = (strips * pieces + 3) / 4;
+    const size_t words = (size_t)s->batch * kEccSums * blocks;
+    if (s->partial_id_words < words) {
+        UPSP_HIP_CHECK(hipStreamSynchronize(st));
+        for (int k = 0; k < 2; ++k) {
+            if (s->partial_id[k]) UPSP_HIP_CHECK(hipFree(s->partial_id[k]));
+            s->partial_id[k] = nullptr;
+            UPSP_HIP_CHECK(hipMalloc(&s->partial_id[k], words * sizeof(double)));
+        }
+        s->partial_id_words = words;
+    }
+    const dim3 grid((unsigned)nb, (unsigned)blocks);
+    if (hot_count)
+        hipLaunchKernelGGL((ecc_blur_ident_kernel<true, 4>), grid, dim3(256), 0, st, d_frames, dst, tmpl_blur, rows, cols, strips, pieces,
+                           s->partial_id[slot], d_center, k0, k1, k2, thresh, hot_count, hot_pos, only_changed);
+    else
+        hipLaunchKernelGGL((ecc_blur_ident_kernel<false, 4>), grid, dim3(256), 0, st, d_frames, dst, tmpl_blur, rows, cols, strips, pieces,
+                           s->partial_id[slot], d_center, k0, k1, k2, 0u, (unsigned *)nullptr, (unsigned *)nullptr, only_changed);
+    UPSP_HIP_CHECK(hipGetLastError());
+    s->ident_for[slot] = dst;
+    s->ident_blocks = blocks;
+    return UPSP_OK;
+}
+
 int run_ecc(FrameScratch *s, const float *tmpl_blur, const float *d_center, const float *blurred, int nb, int64_t first_frame,
             int rows, int cols, int max_iters, double eps, hipStream_t st, const std::function<int()> *while_waiting)
 {
@@ -1091,6 +1268,13 @@ int run_ecc(FrameScratch *s, const float *tmpl_blur, const float *d_center, cons
     const char *one_env = std::getenv("UPSP_ECC_ONE_FLUSH");
     const bool one_flush_on = !(one_env && *one_env == '0');
     const bool one_flush = one_flush_on && (rows - 6 + pieces_min - 1) / pieces_min <= kEccFlushLong;
+    // the identity iteration's sums came with the pre-blur (launch_ecc_blur_ident): one use per blurred buffer
+    const double *ident_partial = nullptr;
+    for (int k = 0; k < 2; ++k)
+        if (s->ident_for[k] && s->ident_for[k] == blurred) {
+            ident_partial = s->partial_id[k];
+            s->ident_for[k] = nullptr;
+        }
     bool first_burst = true, waited = false;
     int it = 0, iters_done = 0, most_iters = 0;
     for (;;) {
@@ -1101,7 +1285,8 @@ int run_ecc(FrameScratch *s, const float *tmpl_blur, const float *d_center, cons
         const int burst = first_burst ? std::max(1, s->ecc_first_burst - it) : (it < 7 ? 2 : (it < 15 ? 8 : 16));
         first_burst = false;
         for (int k = 0; k < burst && it < max_iters; ++k, ++it) {
-            {
+            const bool summed = it == 0 && ident_partial;
+            if (!summed) {
                 KTimed kt(it == 0 ? "ecc_sums_identity" : "ecc_sums_general", st);
                 const dim3 grid((unsigned)nb, (unsigned)nblocks_total);
 #define UPSP_ECC_LAUNCH(IDENT, UR, WAVES, ONE, FD)                                                                             \
@@ -1117,8 +1302,9 @@ int run_ecc(FrameScratch *s, const float *tmpl_blur, const float *d_center, cons
 #undef UPSP_ECC_LAUNCH
             }
             KTimed kt2("ecc_solve_kernel", st);
-            hipLaunchKernelGGL(ecc_solve_kernel, dim3(nb), dim3(256), 0, st, s->state, (const double *)s->partial, s->rtab, nb,
-                               nblocks_total, max_iters, eps, rows, cols);
+            hipLaunchKernelGGL(ecc_solve_kernel, dim3(nb), dim3(256), 0, st, s->state, summed ? ident_partial : (const double *)s->partial,
+                               s->rtab, nb, summed ? s->ident_blocks : nblocks_total, max_iters, eps, rows, cols,
+                               summed ? s->ident_blocks : kEccStride);
         }
         hipLaunchKernelGGL(ecc_count_active, dim3(1), dim3(64), 0, st, (const EccState *)s->state, nb, s->counter);
         // the read-back goes to pinned memory behind an event: whatever `while_waiting` enqueues (the next sub-batch's

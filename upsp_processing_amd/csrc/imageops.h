@@ -111,6 +111,11 @@ struct FrameScratch {
     int *h_counter = nullptr;               // pinned: where "frames still iterating" is read back to
     hipEvent_t ev_counter = nullptr;        // ... and the event behind that copy
     double *partial = nullptr;              // [batch][kEccSums][kEccStride] block partial sums of one iteration
+    double *partial_id[2] = {nullptr, nullptr};   // [batch][kEccSums][ident_blocks]: the identity iteration's sums of the blurred-frame
+                                                  // buffer `slot`, written with the pre-blur (ecc_blur_ident_kernel)
+    size_t partial_id_words = 0;                  // ... doubles allocated per slot
+    const float *ident_for[2] = {nullptr, nullptr};   // the blurred-frame buffer whose identity sums partial_id[slot] holds (one use)
+    int ident_blocks = 0;                         // ... workgroups per frame of that launch
     int2 *rtab = nullptr;                   // [batch][rows] per-row terms of the fixed-point source coordinate under the frame's M
     EccState *state = nullptr;
     int *counter = nullptr;
@@ -125,6 +130,14 @@ struct FrameScratch {
 int run_ecc(FrameScratch *s, const float *tmpl_blur, const float *d_center, const float *blurred, int nb, int64_t first_frame,
             int rows, int cols, int max_iters, double eps, hipStream_t st, const std::function<int()> *while_waiting = nullptr);
 int launch_ecc_center(const float *tmpl_blur, int rows, int cols, float *d_center, hipStream_t st);
+// The 5 x 5 pre-blur of nb u16 frames fused with the identity iteration's sums (ecc_blur_ident_kernel): blurred frames -> dst,
+// sums -> s->partial_id[slot]; s->ident_for[slot] = dst tells run_ecc that its first iteration is already summed.  hot_count /
+// hot_pos (may be null): the scan of fix_hot_pixels on the way; only_changed (may be null): per-frame counts, frames with 0 are
+// skipped (the second pass over the frames the repair changed).  false: geometry not eligible (nothing launched).
+bool ecc_fused_blur_eligible(int rows, int cols);
+int launch_ecc_blur_ident(FrameScratch *s, int slot, const uint16_t *d_frames, float *dst, const float *tmpl_blur, const float *d_center,
+                          int nb, int rows, int cols, float k0, float k1, float k2, unsigned thresh, unsigned *hot_count,
+                          unsigned *hot_pos, const unsigned *only_changed, hipStream_t st);
 int launch_ecc_export(const EccState *state, int nb, float *d_warps, int wstride, int32_t *d_iters, int istride, hipStream_t st);
 
 }  // namespace upsp

@@ -1046,6 +1046,8 @@ void frame_scratch_free(FrameScratch *s)
     if (s->ev_counter) (void)hipEventDestroy(s->ev_counter);
     if (s->tmp) (void)hipFree(s->tmp);
     if (s->partial) (void)hipFree(s->partial);
+    for (int k = 0; k < 2; ++k)
+        if (s->partial_id[k]) (void)hipFree(s->partial_id[k]);
     if (s->state) (void)hipFree(s->state);
     if (s->counter) (void)hipFree(s->counter);
     delete s;
@@ -1161,8 +1163,20 @@ int launch_pixel_list(const int32_t *d_pix, size_t nnodes, uint8_t *d_mask, unsi
 // GaussianBlur 5 x 5 of nb frames (the ECC's pre-blur, cpp/lib/registration.cpp:57-60) into one of the scratch's two
 // blurred-frame buffers: the streamed registration loop enqueues it for sub-batch k + 1 while the host waits for sub-batch
 // k's "frames still iterating".  *out = the buffer to hand to run_frame_stages.
+int frame_scratch_template(FrameScratch *s, int cam, const float *d_ref, int rows, int cols, hipStream_t st)
+{
+    if (!s || cam < 0 || cam >= kMaxCams || !s->tmpl[cam]) return fail(UPSP_ERR_INVALID, "ECC template: scratch not set up");
+    if (s->tmpl_src[cam] == d_ref) return UPSP_OK;      // blurred template, once per reference image
+    int rc = launch_gauss<float>(d_ref, s->tmpl[cam], s->tmp, 1, rows, cols, 5, st);
+    if (rc != UPSP_OK) return rc;
+    rc = launch_ecc_center(s->tmpl[cam], rows, cols, s->center + cam, st);
+    if (rc != UPSP_OK) return rc;
+    s->tmpl_src[cam] = d_ref;
+    return UPSP_OK;
+}
+
 int frame_scratch_preblur(FrameScratch *s, int slot, uint16_t *d_frames, int nb, int rows, int cols, hipStream_t st,
-                          const float **out, const HotRepair *hot)
+                          const float **out, const HotRepair *hot, int fuse_cam)
 {
     if (!s || !s->ecc_img || nb > s->batch) return fail(UPSP_ERR_INVALID, "pre-blur: scratch not set up");
     if (slot && !s->ecc_img2) UPSP_HIP_CHECK(hipMalloc(&s->ecc_img2, (size_t)s->batch * rows * cols * sizeof(float)));
@@ -1170,6 +1184,36 @@ int frame_scratch_preblur(FrameScratch *s, int slot, uint16_t *d_frames, int nb,
     FilterCoef fc;
     if (gaussian_coef(5, fc) != 0) return fail(UPSP_ERR_INVALID, "gaussian 5");
     int rc = UPSP_OK;
+    s->ident_for[slot & 1] = nullptr;
+    // The blur and the identity iteration of the ECC in one pass (ecc_blur_ident_kernel): the template of camera `fuse_cam` is ready
+    // (frame_scratch_template).  The frames the repair changes afterwards -- rare -- take the pass again from their repaired pixels.
+    if (fuse_cam >= 0 && fuse_cam < kMaxCams && s->tmpl_src[fuse_cam] && ecc_fused_blur_eligible(rows, cols) &&
+        (!hot || hot->max_hot < kHotPositions)) {
+        {
+            KTimed kt("ecc_blur_ident_kernel", st);
+            rc = launch_ecc_blur_ident(s, slot, d_frames, dst, s->tmpl[fuse_cam], s->center + fuse_cam, nb, rows, cols, fc.k[2], fc.k[3],
+                                       fc.k[4], hot ? (unsigned)hot->thresh : 0u, hot ? hot->d_count : nullptr, hot ? hot->d_pos : nullptr,
+                                       nullptr, st);
+        }
+        if (rc != UPSP_OK) return rc;
+        if (hot) {
+            rc = launch_hot_repair_list(d_frames, (size_t)rows * cols, nb, rows, cols, hot->min_change, hot->max_hot, hot->d_count,
+                                        hot->d_pos, hot->d_changes, st);
+            if (rc != UPSP_OK) return rc;
+            if (hot->max_hot > 0) {
+                KTimed kt("hot_fixup_kernels", st);
+                rc = launch_ecc_blur_ident(s, slot, d_frames, dst, s->tmpl[fuse_cam], s->center + fuse_cam, nb, rows, cols, fc.k[2],
+                                           fc.k[3], fc.k[4], 0u, nullptr, nullptr, hot->d_changes + 4, st);
+                if (rc != UPSP_OK) return rc;
+            }
+        }
+        // UPSP_ECC_FUSED_BLUR=2 (test switch): keep the pass's blurred frames, drop its sums -- the identity iteration runs as its own
+        // kernel on them, so the results are bit-identical to the unfused path iff the blurred frames are
+        const char *e = std::getenv("UPSP_ECC_FUSED_BLUR");
+        if (e && *e == '2') s->ident_for[slot & 1] = nullptr;
+        *out = dst;
+        return UPSP_OK;
+    }
     bool blurred = false;
     if (hot && hot->max_hot < kHotPositions) {
         // The scan of fix_hot_pixels rides on the blur's read of the frames (a pass of its own is 2 MiB per frame = 27 us per
@@ -1211,20 +1255,27 @@ int run_frame_stages(FrameScratch *s, int cam, const uint16_t *d_frames, int nb,
     const uint16_t *cur = d_frames;
     const dim3 pgrid(grid_for_pixels(npix), (unsigned)nb), block(256);
     if (opts.registration) {
-        if (s->tmpl_src[cam] != d_ref) {  // blurred template, once per reference image
-            int rc = launch_gauss<float>(d_ref, s->tmpl[cam], s->tmp, 1, rows, cols, 5, st);
-            if (rc != UPSP_OK) return rc;
-            rc = launch_ecc_center(s->tmpl[cam], rows, cols, s->center + cam, st);
-            if (rc != UPSP_OK) return rc;
-            s->tmpl_src[cam] = d_ref;
-        }
+        int rc = frame_scratch_template(s, cam, d_ref, rows, cols, st);
+        if (rc != UPSP_OK) return rc;
         const float *blurred = preblurred;
         if (!blurred) {      // GaussianBlur 5 x 5 of the input frames (findTransformECC's gaussFiltSize)
-            int rc = launch_gauss<uint16_t>(d_frames, s->ecc_img, s->tmp, nb, rows, cols, 5, st);
+            s->ident_for[0] = nullptr;      // (this buffer's identity sums, if any, belong to other frames)
+            FilterCoef fc;
+            if (ecc_fused_blur_eligible(rows, cols) && gaussian_coef(5, fc) == 0) {
+                // ... with the identity iteration's sums (the frames are repaired already): the same kernel as the streamed loop's
+                // pre-blur, so a frame's warp is the same bits whichever path registers it
+                KTimed kt("ecc_blur_ident_kernel", st);
+                rc = launch_ecc_blur_ident(s, 0, d_frames, s->ecc_img, s->tmpl[cam], s->center + cam, nb, rows, cols, fc.k[2], fc.k[3], fc.k[4],
+                                           0u, nullptr, nullptr, nullptr, st);
+                const char *e = std::getenv("UPSP_ECC_FUSED_BLUR");
+                if (e && *e == '2') s->ident_for[0] = nullptr;
+            } else {
+                rc = launch_gauss<uint16_t>(d_frames, s->ecc_img, s->tmp, nb, rows, cols, 5, st);
+            }
             if (rc != UPSP_OK) return rc;
             blurred = s->ecc_img;
         }
-        int rc = run_ecc(s, s->tmpl[cam], s->center + cam, blurred, nb, first_frame, rows, cols, opts.ecc_max_iters, opts.ecc_eps, st,
+        rc = run_ecc(s, s->tmpl[cam], s->center + cam, blurred, nb, first_frame, rows, cols, opts.ecc_max_iters, opts.ecc_eps, st,
                          while_waiting);
         if (rc != UPSP_OK) return rc;
         if (wc) {      // registration is the last image stage and node-major series are wanted: straight into the compact buffer
@@ -1303,7 +1354,15 @@ int upsp_register_pixel_u16(const float *d_ref32f, const uint16_t *d_inp, int ro
     int iters = 0;
     if (rc == UPSP_OK) rc = launch_gauss<float>(d_ref32f, s->tmpl[0], s->tmp, 1, rows, cols, 5, st);
     if (rc == UPSP_OK) rc = launch_ecc_center(s->tmpl[0], rows, cols, s->center, st);
-    if (rc == UPSP_OK) rc = launch_gauss<uint16_t>(d_inp, s->ecc_img, s->tmp, 1, rows, cols, 5, st);
+    FilterCoef fc;
+    if (rc == UPSP_OK && ecc_fused_blur_eligible(rows, cols) && gaussian_coef(5, fc) == 0) {      // (the frame loop's kernel: same bits)
+        rc = launch_ecc_blur_ident(s, 0, d_inp, s->ecc_img, s->tmpl[0], s->center, 1, rows, cols, fc.k[2], fc.k[3], fc.k[4], 0u, nullptr,
+                                   nullptr, nullptr, st);
+        const char *e = std::getenv("UPSP_ECC_FUSED_BLUR");
+        if (e && *e == '2') s->ident_for[0] = nullptr;
+    } else if (rc == UPSP_OK) {
+        rc = launch_gauss<uint16_t>(d_inp, s->ecc_img, s->tmp, 1, rows, cols, 5, st);
+    }
     // first_frame = 1: a stand-alone call always registers (psp_process.cpp:1662-1679)
     if (rc == UPSP_OK) rc = run_ecc(s, s->tmpl[0], s->center, s->ecc_img, 1, 1, rows, cols, max_iters, eps, st);
     if (rc == UPSP_OK) {

@@ -147,8 +147,12 @@ struct HotRepair {
 };
 // fix_hot_pixels + the ECC's 5 x 5 pre-blur of nb frames into blurred-frame buffer `slot` (0 / 1) of the scratch; the frames are
 // repaired in place (hot == null: no repair)
+// fuse_cam >= 0: the blurred template of that camera is ready (frame_scratch_template) -- the blur also takes the sums of the ECC's
+// identity iteration (ecc.hip: ecc_blur_ident_kernel), which run_frame_stages then skips
 int frame_scratch_preblur(FrameScratch *s, int slot, uint16_t *d_frames, int nb, int rows, int cols, hipStream_t st,
-                          const float **out, const HotRepair *hot);
+                          const float **out, const HotRepair *hot, int fuse_cam = -1);
+// the blurred ECC template of camera `cam` for the reference image d_ref (once per reference image)
+int frame_scratch_template(FrameScratch *s, int cam, const float *d_ref, int rows, int cols, hipStream_t st);
 // d_list[0] = number of distinct pixels with a node, d_list[1..] = those pixels (any order); d_mask: npix bytes of scratch
 int launch_pixel_list(const int32_t *d_pix, size_t nnodes, uint8_t *d_mask, unsigned *d_list, size_t npix, hipStream_t st);
 }  // namespace upsp

@@ -1140,11 +1140,14 @@ static int process_impl(upsp_pipeline *p, uint16_t *const *d_frames, int nframes
         }
         const float *blurred[2] = {nullptr, nullptr};
         std::vector<char> blur_done(subs.size(), 0);
+        // the blurred template first: the pre-blur of the frames takes the identity iteration's sums with it
+        rc = upsp::frame_scratch_template(p->scratch, 0, p->d_ref[0], p->height, p->width, st);
+        if (rc != UPSP_OK) return rc;
         auto preblur = [&](size_t i) -> int {                  // repair + pre-blur of sub-batch i on the caller's stream
             if (blur_done[i]) return UPSP_OK;
             blur_done[i] = 1;
             return upsp::frame_scratch_preblur(p->scratch, (int)(i & 1), fr + (size_t)subs[i].f0 * npix, subs[i].nb, p->height, p->width,
-                                               st, &blurred[i & 1], p->opts.hot_enable ? &hot : nullptr);
+                                               st, &blurred[i & 1], p->opts.hot_enable ? &hot : nullptr, /*fuse_cam=*/0);
         };
         for (size_t i = 0; i < subs.size() && rc == UPSP_OK; ++i) {
             const int f0 = subs[i].f0, nb = subs[i].nb, s0 = subs[i].s0;
