@@ -3,6 +3,7 @@
 #   bash tools/r06_ab.sh bins      length-binned primary lists on / off (UPSP_RAY_BINS), hand-off threshold 96 / 48, alternating
 #   bash tools/r06_ab.sh step      the one-call step: pass A on a stream of its own / slab filter / ray bins, one switch at a time
 #   bash tools/r06_ab.sh rays      tools/r06_rays.py (1 Mi pixel rays + projection build alone, slab filter on / off) with ray bins off / on
+#   bash tools/r06_ab.sh fused     ECC pre-blur fused with the identity iteration (default) / two kernels (UPSP_ECC_FUSED_BLUR=0)
 #   (the ECC start-delay, ECC unroll / occupancy and several-camera row-pass experiments of this round were run with switches that
 #    no longer exist: their numbers are in LAB_NOTES.md section 13)
 set -o pipefail
@@ -16,7 +17,7 @@ line() { # name, env..., -- bench args
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 k = d.get("kernels", {})
-pick = {n: round(v["avg_launch_ms"], 4) for n, v in k.items() if any(s in n for s in ("primary", "retry>", "scan", "node_rows", "ecc_sums", "gauss", "primary_list"))}
+pick = {n: round(v["avg_launch_ms"], 4) for n, v in k.items() if any(s in n for s in ("primary", "retry>", "scan", "node_rows", "ecc_sums", "ecc_blur", "gauss", "primary_list"))}
 print("%-22s %9.0f %s  step %.4f ms  %s  %s" % (sys.argv[2], d["value"], d["unit"], d["ms_per_step"], {a: round(b, 3) for a, b in d.get("breakdown_ms", {}).items()}, pick), flush=True)
 pr = d.get("pixel_rays_fill")
 if pr: print("    pixel_rays_fill %.4f ms  %.0f Mrays/s" % (pr["ms"], pr["mrays_per_s"]), flush=True)
@@ -74,5 +75,13 @@ if [ $part = oneflush ]; then
   for i in 1 2; do
     line oneflush_0_$i UPSP_ECC_ONE_FLUSH=0 -- --registration --steps 3 --warmup 1 || exit 1
     line oneflush_1_$i -- --registration --steps 3 --warmup 1 || exit 1
+  done
+fi
+if [ $part = fused ]; then
+  # the ECC's pre-blur fused with the identity iteration's sums (ecc_blur_ident_kernel, the default) against the two kernels
+  # (UPSP_ECC_FUSED_BLUR=0), alternating
+  for i in 1 2; do
+    line fused_0_$i UPSP_ECC_FUSED_BLUR=0 -- --registration --steps 3 --warmup 1 || exit 1
+    line fused_1_$i -- --registration --steps 3 --warmup 1 || exit 1
   done
 fi

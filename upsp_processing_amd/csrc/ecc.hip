@@ -248,20 +248,22 @@ __device__ __forceinline__ double dpp_add_f64(double v)
 // Fixed order: deterministic.
 constexpr int kEccChunk = 15;
 static_assert(kEccSums == 3 * kEccChunk, "three chunks");
-template <int C, int J>
+// CH values per round (kEccChunk, or 5 for a kernel that wants its LDS for occupancy: 10 KB instead of 30)
+template <int CH, int C, int J>
 __device__ __forceinline__ void ecc_tot_put(const EccTot &T, double X, bool on, double (*lds)[256])
 {
-    lds[J][threadIdx.x] = on ? ecc_tot_value<C * kEccChunk + J>(T, X) : 0.0;
-    if constexpr (J + 1 < kEccChunk) ecc_tot_put<C, J + 1>(T, X, on, lds);
+    lds[J][threadIdx.x] = on ? ecc_tot_value<C * CH + J>(T, X) : 0.0;
+    if constexpr (J + 1 < CH) ecc_tot_put<CH, C, J + 1>(T, X, on, lds);
 }
-template <int C>
+template <int C, int CH = kEccChunk>
 __device__ __forceinline__ void ecc_tot_store(const EccTot &T, double X, bool on, double (*lds)[256], double *__restrict__ partial,
                                               int f, unsigned slot, unsigned stride = (unsigned)kEccStride)
 {
-    ecc_tot_put<C, 0>(T, X, on, lds);
+    static_assert(kEccSums % CH == 0 && CH <= 16, "whole rounds");
+    ecc_tot_put<CH, C, 0>(T, X, on, lds);
     __syncthreads();
     const int v = (int)threadIdx.x >> 4, p = (int)threadIdx.x & 15;
-    if (v < kEccChunk) {                       // (waves 0 .. 3, whole DPP rows)
+    if (v < CH) {                              // (whole DPP rows)
         double s = 0.0;
 #pragma unroll
         for (int j = 0; j < 16; ++j) s += lds[v][j * 16 + p];
@@ -269,10 +271,10 @@ __device__ __forceinline__ void ecc_tot_store(const EccTot &T, double X, bool on
         s = dpp_add_f64<0x4E, 0xF>(s);
         s = dpp_add_f64<0x141, 0xF>(s);
         s = dpp_add_f64<0x140, 0xF>(s);        // every lane of the row holds the block's sum of value v
-        if (p == 0) partial[((size_t)f * kEccSums + (C * kEccChunk + v)) * stride + slot] = s;
+        if (p == 0) partial[((size_t)f * kEccSums + (C * CH + v)) * stride + slot] = s;
     }
     __syncthreads();
-    if constexpr (C + 1 < 3) ecc_tot_store<C + 1>(T, X, on, lds, partial, f, slot, stride);
+    if constexpr ((C + 1) * CH < kEccSums) ecc_tot_store<C + 1, CH>(T, X, on, lds, partial, f, slot, stride);
 }
 
 // a block without any pixel: its partial sums are zero
@@ -780,14 +782,6 @@ __device__ __forceinline__ void ecc_band_cols_body(const float *__restrict__ img
 // Block = four wave items (strip-major: neighbouring strips of one row piece), reduced like the interior blocks.
 constexpr int kFusedOwn = 58, kFusedHalo = 3;
 
-// a lane's byte offset as a value the compiler cannot hoist out of the loop as a 64-bit pair: keeps the loads in the
-// `saddr + 32-bit voffset` form (one scalar add per row instead of a 64-bit vector add per load)
-__device__ __forceinline__ unsigned opaque_u32(unsigned v)
-{
-    asm volatile("" : "+v"(v));
-    return v;
-}
-
 // wave shifts that leave 0 in the lane without a source (bound_ctrl: no `old` register to initialise, and the compiler may fold the
 // shift into the instruction that uses it)
 __device__ __forceinline__ float dpp_shr1_z(float v)
@@ -800,13 +794,13 @@ __device__ __forceinline__ float dpp_shl1_z(float v)
 }
 
 template <bool HOT, int U>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 7)))
     ecc_blur_ident_kernel(const uint16_t *__restrict__ src, float *__restrict__ dst, const float *__restrict__ tmpl, int rows, int cols,
                           int strips, int pieces, double *__restrict__ partial, const float *__restrict__ center, float k0, float k1,
                           float k2, unsigned thresh, unsigned *__restrict__ hot_count, unsigned *__restrict__ hot_pos,
                           const unsigned *__restrict__ only_changed)
 {
-    __shared__ double lds_red[kEccChunk][256];
+    __shared__ double lds_red[5][256];                                          // (10 KB: the workgroups of a compute unit are bounded by registers)
     const int f = blockIdx.x;
     if (only_changed && only_changed[f] == 0u) return;                         // (uniform)
     const int lane = threadIdx.x & 63;
@@ -823,19 +817,22 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))
     EccPart P;
     ecc_part_zero(P);
     if (work) {
+        // Buffer descriptors (uniform: kernel arguments and the frame index) -- a load or store is `descriptor + the lane's constant
+        // 32-bit offset + the row's SCALAR offset`: no vector instruction per access, and a store whose lane offset lies beyond the
+        // frame is dropped by the range check (the lanes that own no pixel), so no exec mask either.
         const size_t npix = (size_t)rows * cols;
-        const char *S = reinterpret_cast<const char *>(src + (size_t)f * npix);
-        char *B = reinterpret_cast<char *>(dst + (size_t)f * npix);
-        const char *Tm = reinterpret_cast<const char *>(tmpl);
+        const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(src + (size_t)f * npix), 0, (int)(npix * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(dst + (size_t)f * npix, 0, (int)(npix * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tmpl), 0, (int)(npix * 4), 0x00020000);
         const unsigned pitch2 = 2u * (unsigned)cols, pitch4 = 4u * (unsigned)cols;
         const unsigned cx2 = 2u * (unsigned)reflect101(min(max(c, -(cols - 1)), 2 * cols - 2), cols);
         const unsigned cown = (unsigned)min(max(c, 0), cols - 1), cown4 = 4u * cown;
+        const unsigned cstore4 = own ? cown4 : 0x80000000u;
         // rows -3 .. rows + 2 (rows >= 8): one reflection
         auto rrow = [&](int yy) { return (unsigned)(yy < 0 ? -yy : (yy >= rows ? 2 * rows - 2 - yy : yy)); };
         float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f, h4 = 0.f, Bm = 0.f, B0 = 0.f, Bp = 0.f;
-        auto load_row = [&](int yi, unsigned ocx2) -> unsigned {
-            const char *Sr = S + (size_t)(rrow(yi) * pitch2);                  // (uniform)
-            return *reinterpret_cast<const uint16_t *>(Sr + ocx2);
+        auto load_row = [&](int yi) -> unsigned {
+            return (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rS, (int)cx2, (int)(rrow(yi) * pitch2), 0);
         };
         auto hot_scan = [&](int yi, unsigned pv) {
             if (HOT && own && yi >= y0 && yi < y1 && pv >= thresh) {           // (rare)
@@ -852,24 +849,23 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))
             n += k2 * (a2 + c2);
             h0 = h1; h1 = h2; h2 = h3; h3 = h4; h4 = n;
         };
-        auto vstep = [&](int yb, bool store, unsigned ocown4) {                // blurred row yb = the middle of the five
+        auto vstep = [&](int yb, bool store) {                                 // blurred row yb = the middle of the five
             float bn = k0 * h2;
             bn += k1 * (h1 + h3);
             bn += k2 * (h0 + h4);
             Bm = B0; B0 = Bp; Bp = bn;
-            if (own && store) *reinterpret_cast<float *>(B + (size_t)((unsigned)yb * pitch4) + ocown4) = bn;
+            if (store) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(bn), rB, (int)cstore4, (int)((unsigned)yb * pitch4), 0);   // (uniform)
         };
         // input rows y0 - 3 .. y0 + 2: the blurred rows y0 - 1 and y0
         {
             unsigned pv[6];
-            const unsigned ocx2 = opaque_u32(cx2), ocown4 = opaque_u32(cown4);
 #pragma unroll
-            for (int k = 0; k < 6; ++k) pv[k] = load_row(y0 - 3 + k, ocx2);
+            for (int k = 0; k < 6; ++k) pv[k] = load_row(y0 - 3 + k);
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
                 hot_scan(y0 - 3 + k, pv[k]);
                 hstep(pv[k]);
-                if (k >= 4) vstep(y0 - 5 + k, k == 5, ocown4);
+                if (k >= 4) vstep(y0 - 5 + k, k == 5);
             }
         }
         // input row y0 + 3 + r: blurred row y0 + 1 + r, sums of row y0 + r
@@ -877,11 +873,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))
         for (int g = 0; g < ne; g += U) {
             unsigned pv[U];
             float tv[U];
-            const unsigned ocx2 = opaque_u32(cx2), ocown4 = opaque_u32(cown4);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                pv[u] = load_row(y0 + 3 + g + u, ocx2);
-                tv[u] = *reinterpret_cast<const float *>(Tm + (size_t)((unsigned)min(y0 + g + u, rows - 1) * pitch4) + ocown4);
+                pv[u] = load_row(y0 + 3 + g + u);
+                tv[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rT, (int)cown4, (int)((unsigned)min(y0 + g + u, rows - 1) * pitch4), 0));
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -889,7 +884,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))
                 if (r >= ne) break;                                            // (uniform)
                 hot_scan(y0 + 3 + r, pv[u]);
                 hstep(pv[u]);
-                vstep(y0 + 1 + r, r + 1 < ne, ocown4);
+                vstep(y0 + 1 + r, r + 1 < ne);
                 const float l = dpp_shr1_z(B0), rr = dpp_shl1_z(B0);
                 ecc_part_add<false>(P, T, B0, 0.5f * (rr - l), 0.5f * (Bp - Bm), tv[u], (float)r);
             }
@@ -897,7 +892,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))
     }
     ecc_part_flush(P, T, y0);
     T.n = own ? (double)(y1 - y0) : 0.0;          // mask = 1 on every pixel
-    ecc_tot_store<0>(T, (double)c, own, lds_red, partial, f, blockIdx.y, gridDim.y);
+    ecc_tot_store<0, 5>(T, (double)c, own, lds_red, partial, f, blockIdx.y, gridDim.y);
 }
 
 // centre of the float products (ecc_part_add): the mean of a 64 x 64 sample grid of the blurred template, rounded to an
