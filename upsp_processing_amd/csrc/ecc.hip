@@ -42,6 +42,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "imageops.h"
@@ -120,7 +121,8 @@ __device__ __forceinline__ void ecc_tot_zero(EccTot &T)
 // and what the solve uses is sum J w - mean(w) sum J, a difference that used to cancel the leading 1-2 digits of these
 // sums (the reference rounds every one of these sums to FLOAT before its 6 x 6 solve, so a sum that lands on another
 // float moves the result by a float ulp amplified by the solve).
-template <bool MASKED>
+// TSUMS = false: the caller adds the template's own sums (St, Stt: constants of the template when every pixel counts) itself.
+template <bool MASKED, bool TSUMS = true>
 __device__ __forceinline__ void ecc_part_add(EccPart &p, EccTot &T, float w, float gx, float gy, float t, float rf, bool m = true)
 {
     const float wc = MASKED ? w : w - T.cf, tc = MASKED ? t : t - T.cf;
@@ -148,8 +150,10 @@ __device__ __forceinline__ void ecc_part_add(EccPart &p, EccTot &T, float w, flo
     if (MASKED) T.n += m ? 1.0 : 0.0;
     T.Sw += wm;
     T.Sww = fma(wm, wd, T.Sww);
-    T.St += tm;
-    T.Stt = fma(tm, td, T.Stt);
+    if (TSUMS) {
+        T.St += tm;
+        T.Stt = fma(tm, td, T.Stt);
+    }
     T.Stw = fma(tm, wd, T.Stw);
 }
 
@@ -794,11 +798,11 @@ __device__ __forceinline__ float dpp_shl1_z(float v)
 }
 
 template <bool HOT, int U>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 7)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7)))
     ecc_blur_ident_kernel(const uint16_t *__restrict__ src, float *__restrict__ dst, const float *__restrict__ tmpl, int rows, int cols,
                           int strips, int pieces, double *__restrict__ partial, const float *__restrict__ center, float k0, float k1,
                           float k2, unsigned thresh, unsigned *__restrict__ hot_count, unsigned *__restrict__ hot_pos,
-                          const unsigned *__restrict__ only_changed)
+                          const unsigned *__restrict__ only_changed, const double *__restrict__ tsum)
 {
     __shared__ double lds_red[5][256];                                          // (10 KB: the workgroups of a compute unit are bounded by registers)
     const int f = blockIdx.x;
@@ -868,30 +872,65 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 7))
                 if (k >= 4) vstep(y0 - 5 + k, k == 5);
             }
         }
-        // input row y0 + 3 + r: blurred row y0 + 1 + r, sums of row y0 + r
+        // input row y0 + 3 + r: blurred row y0 + 1 + r, sums of row y0 + r.  STEADY trips: every input row of the trip lies inside
+        // the piece (r + 3 < ne for its last row), so there is no reflection, every blurred row is stored, every loaded pixel is the
+        // wave's own to scan and no row is past the end -- plain scalar arithmetic per row; the last trip or two take the tests.
         const int ne = y1 - y0;
-        for (int g = 0; g < ne; g += U) {
+        auto trip = [&](int g, auto steady_tag) {
+            constexpr bool STEADY = decltype(steady_tag)::value;
             unsigned pv[U];
             float tv[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                pv[u] = load_row(y0 + 3 + g + u);
-                tv[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rT, (int)cown4, (int)((unsigned)min(y0 + g + u, rows - 1) * pitch4), 0));
+                const int yi = y0 + 3 + g + u;
+                pv[u] = STEADY ? (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rS, (int)cx2, (int)((unsigned)yi * pitch2), 0) : load_row(yi);
+                const int yt = STEADY ? y0 + g + u : min(y0 + g + u, rows - 1);
+                tv[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rT, (int)cown4, (int)((unsigned)yt * pitch4), 0));
+            }
+            // the horizontal pass of two rows at a time as packed pairs (the same operations per component)
+            static_assert(U % 2 == 0, "rows in pairs");
+            v2f N[U / 2];
+#pragma unroll
+            for (int u = 0; u < U; u += 2) {
+                const v2f Pf = {(float)pv[u], (float)pv[u + 1]};
+                const v2f A1 = {dpp_shr1_z(Pf[0]), dpp_shr1_z(Pf[1])}, C1 = {dpp_shl1_z(Pf[0]), dpp_shl1_z(Pf[1])};
+                const v2f A2 = {dpp_shr1_z(A1[0]), dpp_shr1_z(A1[1])}, C2 = {dpp_shl1_z(C1[0]), dpp_shl1_z(C1[1])};
+                const v2f K0 = {k0, k0}, K1 = {k1, k1}, K2 = {k2, k2};
+                v2f n = K0 * Pf;
+                n += K1 * (A1 + C1);
+                n += K2 * (A2 + C2);
+                N[u / 2] = n;
+            }
+            if (HOT && STEADY) {                     // one test per trip: the largest of its pixels
+                unsigned mx = pv[0];
+#pragma unroll
+                for (int u = 1; u < U; ++u) mx = max(mx, pv[u]);
+                if (own && mx >= thresh) {           // (rare)
+#pragma unroll
+                    for (int u = 0; u < U; ++u) hot_scan(y0 + 3 + g + u, pv[u]);
+                }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int r = g + u;
-                if (r >= ne) break;                                            // (uniform)
-                hot_scan(y0 + 3 + r, pv[u]);
-                hstep(pv[u]);
-                vstep(y0 + 1 + r, r + 1 < ne);
+                if (!STEADY && r >= ne) break;                                 // (uniform)
+                if (!STEADY) hot_scan(y0 + 3 + r, pv[u]);
+                h0 = h1; h1 = h2; h2 = h3; h3 = h4; h4 = N[u / 2][u & 1];
+                vstep(y0 + 1 + r, STEADY || r + 1 < ne);
                 const float l = dpp_shr1_z(B0), rr = dpp_shl1_z(B0);
-                ecc_part_add<false>(P, T, B0, 0.5f * (rr - l), 0.5f * (Bp - Bm), tv[u], (float)r);
+                ecc_part_add<false, false>(P, T, B0, 0.5f * (rr - l), 0.5f * (Bp - Bm), tv[u], (float)r);
             }
-        }
+        };
+        int g = 0;
+        for (; g + U + 3 <= ne; g += U) trip(g, std::true_type{});
+        for (; g < ne; g += U) trip(g, std::false_type{});
     }
     ecc_part_flush(P, T, y0);
     T.n = own ? (double)(y1 - y0) : 0.0;          // mask = 1 on every pixel
+    if (blockIdx.y == 0 && (int)threadIdx.x == kFusedHalo) {      // (pixel (0, 0): the thread that owns it carries the template's sums)
+        T.St = tsum[0];
+        T.Stt = tsum[1];
+    }
     ecc_tot_store<0, 5>(T, (double)c, own, lds_red, partial, f, blockIdx.y, gridDim.y);
 }
 
@@ -915,6 +954,33 @@ __global__ void __launch_bounds__(256) ecc_center_kernel(const float *__restrict
     if (threadIdx.x == 0) {
         const double m = sh[0] / 4096.0;
         out[0] = (m >= 0.0 && m <= 4095.0) ? (float)rint(m) : 0.f;      // (images outside the 12-bit range: no centring)
+    }
+}
+
+// sum t and sum t^2 over the whole blurred template, in double (one workgroup, fixed order): what every pixel's share of St and Stt
+// adds up to when the mask is 1 everywhere -- the identity iteration (ecc_blur_ident_kernel) takes them from here
+__global__ void __launch_bounds__(256) ecc_tmpl_sums_kernel(const float *__restrict__ tmpl, size_t npix, double *__restrict__ out)
+{
+    __shared__ double sh[2][256];
+    double a = 0.0, b = 0.0;
+    for (size_t i = threadIdx.x; i < npix; i += 256) {
+        const double t = (double)tmpl[i];
+        a += t;
+        b = fma(t, t, b);
+    }
+    sh[0][threadIdx.x] = a;
+    sh[1][threadIdx.x] = b;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[0] = sh[0][0];
+        out[1] = sh[1][0];
     }
 }
 
@@ -1195,9 +1261,16 @@ bool ecc_fused_blur_eligible(int rows, int cols)
     return !(e && *e == '0') && rows >= 8 && cols >= 8 && rows < 32768 && cols < 32768 && (long long)rows * cols < (1ll << 29);
 }
 
+int launch_ecc_tmpl_sums(const float *tmpl_blur, int rows, int cols, double *d_out, hipStream_t st)
+{
+    hipLaunchKernelGGL(ecc_tmpl_sums_kernel, dim3(1), dim3(256), 0, st, tmpl_blur, (size_t)rows * cols, d_out);
+    UPSP_HIP_CHECK(hipGetLastError());
+    return UPSP_OK;
+}
+
 int launch_ecc_blur_ident(FrameScratch *s, int slot, const uint16_t *d_frames, float *dst, const float *tmpl_blur, const float *d_center,
-                          int nb, int rows, int cols, float k0, float k1, float k2, unsigned thresh, unsigned *hot_count,
-                          unsigned *hot_pos, const unsigned *only_changed, hipStream_t st)
+                          const double *d_tsum, int nb, int rows, int cols, float k0, float k1, float k2, unsigned thresh,
+                          unsigned *hot_count, unsigned *hot_pos, const unsigned *only_changed, hipStream_t st)
 {
     if (!s || slot < 0 || slot > 1 || nb > s->batch || !ecc_fused_blur_eligible(rows, cols))
         return fail(UPSP_ERR_INVALID, "fused pre-blur: not set up for this geometry");
@@ -1216,10 +1289,10 @@ int launch_ecc_blur_ident(FrameScratch *s, int slot, const uint16_t *d_frames, f
     const dim3 grid((unsigned)nb, (unsigned)blocks);
     if (hot_count)
         hipLaunchKernelGGL((ecc_blur_ident_kernel<true, 4>), grid, dim3(256), 0, st, d_frames, dst, tmpl_blur, rows, cols, strips, pieces,
-                           s->partial_id[slot], d_center, k0, k1, k2, thresh, hot_count, hot_pos, only_changed);
+                           s->partial_id[slot], d_center, k0, k1, k2, thresh, hot_count, hot_pos, only_changed, d_tsum);
     else
         hipLaunchKernelGGL((ecc_blur_ident_kernel<false, 4>), grid, dim3(256), 0, st, d_frames, dst, tmpl_blur, rows, cols, strips, pieces,
-                           s->partial_id[slot], d_center, k0, k1, k2, 0u, (unsigned *)nullptr, (unsigned *)nullptr, only_changed);
+                           s->partial_id[slot], d_center, k0, k1, k2, 0u, (unsigned *)nullptr, (unsigned *)nullptr, only_changed, d_tsum);
     UPSP_HIP_CHECK(hipGetLastError());
     s->ident_for[slot] = dst;
     s->ident_blocks = blocks;

@@ -108,6 +108,7 @@ struct FrameScratch {
     float *tmpl[kMaxCams] = {nullptr};      // blurred ECC templates
     const float *tmpl_src[kMaxCams] = {nullptr};
     float *center = nullptr;                // [kMaxCams] centre of the float products of the ECC sums (ecc_center_kernel)
+    double *tsum = nullptr;                 // [kMaxCams][2] sum t, sum t^2 of the blurred templates (ecc_tmpl_sums_kernel)
     int *h_counter = nullptr;               // pinned: where "frames still iterating" is read back to
     hipEvent_t ev_counter = nullptr;        // ... and the event behind that copy
     double *partial = nullptr;              // [batch][kEccSums][kEccStride] block partial sums of one iteration
@@ -136,8 +137,10 @@ int launch_ecc_center(const float *tmpl_blur, int rows, int cols, float *d_cente
 // skipped (the second pass over the frames the repair changed).  false: geometry not eligible (nothing launched).
 bool ecc_fused_blur_eligible(int rows, int cols);
 int launch_ecc_blur_ident(FrameScratch *s, int slot, const uint16_t *d_frames, float *dst, const float *tmpl_blur, const float *d_center,
-                          int nb, int rows, int cols, float k0, float k1, float k2, unsigned thresh, unsigned *hot_count,
-                          unsigned *hot_pos, const unsigned *only_changed, hipStream_t st);
+                          const double *d_tsum, int nb, int rows, int cols, float k0, float k1, float k2, unsigned thresh,
+                          unsigned *hot_count, unsigned *hot_pos, const unsigned *only_changed, hipStream_t st);
+// d_out[0 .. 1] = sum t, sum t^2 of the blurred template (the identity iteration's St, Stt)
+int launch_ecc_tmpl_sums(const float *tmpl_blur, int rows, int cols, double *d_out, hipStream_t st);
 int launch_ecc_export(const EccState *state, int nb, float *d_warps, int wstride, int32_t *d_iters, int istride, hipStream_t st);
 
 }  // namespace upsp

@@ -1041,6 +1041,7 @@ void frame_scratch_free(FrameScratch *s)
     if (s->ecc_img) (void)hipFree(s->ecc_img);
     if (s->ecc_img2) (void)hipFree(s->ecc_img2);
     if (s->center) (void)hipFree(s->center);
+    if (s->tsum) (void)hipFree(s->tsum);
     if (s->rtab) (void)hipFree(s->rtab);
     if (s->h_counter) (void)hipHostFree(s->h_counter);
     if (s->ev_counter) (void)hipEventDestroy(s->ev_counter);
@@ -1086,6 +1087,8 @@ int frame_scratch_ensure(FrameScratch **ps, int ncams, int batch, int rows, int 
     if (need_warp && !s->center) {
         UPSP_HIP_CHECK(hipMalloc(&s->center, kMaxCams * sizeof(float)));
         UPSP_HIP_CHECK(hipMemset(s->center, 0, kMaxCams * sizeof(float)));
+        UPSP_HIP_CHECK(hipMalloc(&s->tsum, kMaxCams * 2 * sizeof(double)));
+        UPSP_HIP_CHECK(hipMemset(s->tsum, 0, kMaxCams * 2 * sizeof(double)));
     }
     if (!s->tmp) UPSP_HIP_CHECK(hipMalloc(&s->tmp, n * sizeof(double)));
     if (need_warp && !s->partial)
@@ -1171,6 +1174,8 @@ int frame_scratch_template(FrameScratch *s, int cam, const float *d_ref, int row
     if (rc != UPSP_OK) return rc;
     rc = launch_ecc_center(s->tmpl[cam], rows, cols, s->center + cam, st);
     if (rc != UPSP_OK) return rc;
+    rc = launch_ecc_tmpl_sums(s->tmpl[cam], rows, cols, s->tsum + 2 * cam, st);
+    if (rc != UPSP_OK) return rc;
     s->tmpl_src[cam] = d_ref;
     return UPSP_OK;
 }
@@ -1191,7 +1196,7 @@ int frame_scratch_preblur(FrameScratch *s, int slot, uint16_t *d_frames, int nb,
         (!hot || hot->max_hot < kHotPositions)) {
         {
             KTimed kt("ecc_blur_ident_kernel", st);
-            rc = launch_ecc_blur_ident(s, slot, d_frames, dst, s->tmpl[fuse_cam], s->center + fuse_cam, nb, rows, cols, fc.k[2], fc.k[3],
+            rc = launch_ecc_blur_ident(s, slot, d_frames, dst, s->tmpl[fuse_cam], s->center + fuse_cam, s->tsum + 2 * fuse_cam, nb, rows, cols, fc.k[2], fc.k[3],
                                        fc.k[4], hot ? (unsigned)hot->thresh : 0u, hot ? hot->d_count : nullptr, hot ? hot->d_pos : nullptr,
                                        nullptr, st);
         }
@@ -1202,7 +1207,7 @@ int frame_scratch_preblur(FrameScratch *s, int slot, uint16_t *d_frames, int nb,
             if (rc != UPSP_OK) return rc;
             if (hot->max_hot > 0) {
                 KTimed kt("hot_fixup_kernels", st);
-                rc = launch_ecc_blur_ident(s, slot, d_frames, dst, s->tmpl[fuse_cam], s->center + fuse_cam, nb, rows, cols, fc.k[2],
+                rc = launch_ecc_blur_ident(s, slot, d_frames, dst, s->tmpl[fuse_cam], s->center + fuse_cam, s->tsum + 2 * fuse_cam, nb, rows, cols, fc.k[2],
                                            fc.k[3], fc.k[4], 0u, nullptr, nullptr, hot->d_changes + 4, st);
                 if (rc != UPSP_OK) return rc;
             }
@@ -1265,7 +1270,7 @@ int run_frame_stages(FrameScratch *s, int cam, const uint16_t *d_frames, int nb,
                 // ... with the identity iteration's sums (the frames are repaired already): the same kernel as the streamed loop's
                 // pre-blur, so a frame's warp is the same bits whichever path registers it
                 KTimed kt("ecc_blur_ident_kernel", st);
-                rc = launch_ecc_blur_ident(s, 0, d_frames, s->ecc_img, s->tmpl[cam], s->center + cam, nb, rows, cols, fc.k[2], fc.k[3], fc.k[4],
+                rc = launch_ecc_blur_ident(s, 0, d_frames, s->ecc_img, s->tmpl[cam], s->center + cam, s->tsum + 2 * cam, nb, rows, cols, fc.k[2], fc.k[3], fc.k[4],
                                            0u, nullptr, nullptr, nullptr, st);
                 const char *e = std::getenv("UPSP_ECC_FUSED_BLUR");
                 if (e && *e == '2') s->ident_for[0] = nullptr;
@@ -1354,9 +1359,10 @@ int upsp_register_pixel_u16(const float *d_ref32f, const uint16_t *d_inp, int ro
     int iters = 0;
     if (rc == UPSP_OK) rc = launch_gauss<float>(d_ref32f, s->tmpl[0], s->tmp, 1, rows, cols, 5, st);
     if (rc == UPSP_OK) rc = launch_ecc_center(s->tmpl[0], rows, cols, s->center, st);
+    if (rc == UPSP_OK) rc = launch_ecc_tmpl_sums(s->tmpl[0], rows, cols, s->tsum, st);
     FilterCoef fc;
     if (rc == UPSP_OK && ecc_fused_blur_eligible(rows, cols) && gaussian_coef(5, fc) == 0) {      // (the frame loop's kernel: same bits)
-        rc = launch_ecc_blur_ident(s, 0, d_inp, s->ecc_img, s->tmpl[0], s->center, 1, rows, cols, fc.k[2], fc.k[3], fc.k[4], 0u, nullptr,
+        rc = launch_ecc_blur_ident(s, 0, d_inp, s->ecc_img, s->tmpl[0], s->center, s->tsum, 1, rows, cols, fc.k[2], fc.k[3], fc.k[4], 0u, nullptr,
                                    nullptr, nullptr, st);
         const char *e = std::getenv("UPSP_ECC_FUSED_BLUR");
         if (e && *e == '2') s->ident_for[0] = nullptr;
