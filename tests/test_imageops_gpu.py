@@ -458,7 +458,7 @@ def test_registration_sub_batches_look_ahead(gpu_lib, oracle, monkeypatch, reg_b
         assert np.array_equal(a[0][ok, f].view(np.int32), want[ok].view(np.int32))
 
 
-@pytest.mark.parametrize("H,W,F", [(96, 160, 70), (300, 250, 20), (131, 1030, 12)])
+@pytest.mark.parametrize("H,W,F", [(96, 160, 70), (300, 250, 24), (131, 1030, 22)])
 def test_ecc_fused_blur_same_frames_and_bars(gpu_lib, oracle, monkeypatch, H, W, F):
     """The streamed registration loop blurs the frames and takes the sums of the ECC's identity iteration in ONE pass
     (ecc_blur_ident_kernel: 58-column strips per wave, reflected loads at the image edges, hot-pixel scan on the way, a second
@@ -479,6 +479,11 @@ def test_ecc_fused_blur_same_frames_and_bars(gpu_lib, oracle, monkeypatch, H, W,
         frames[f, rng.integers(2, H - 2), rng.integers(2, W - 2)] = 4090
     frames[hot_frames[1], 0, rng.integers(2, W - 2)] = 4095
     frames[hot_frames[2], H - 1, W - 1] = 4095
+    # at the seams of the wave items (58-column strips, 128-row pieces): the second pass re-runs the workgroups on BOTH sides
+    for f, (y, x) in zip(range(3, 12), ((min(127, H - 1), 57), (min(128, H - 1), 58), (min(130, H - 1), 55), (5, 60), (min(125, H - 1), 115),
+                                        (min(126, H - 1), 118), (3, 0), (0, 59), (min(129, H - 1), W - 1))):
+        frames[f, y, min(x, W - 1)] = 4093
+    frames[12:20, H // 3, W // 3] = 4091                   # a stuck pixel: the same one in consecutive frames
     ref = frames[0].astype(np.float32)
     pix = (rng.integers(0, H, n) * W + rng.integers(0, W, n)).astype(np.int32)
     out = {}
@@ -505,7 +510,7 @@ def test_ecc_fused_blur_same_frames_and_bars(gpu_lib, oracle, monkeypatch, H, W,
     few = a[2] <= 6
     assert few.sum() >= F // 2
     assert np.abs(a[1][few][:, :, :2] - c[1][few][:, :, :2]).max() <= 1e-4 and np.abs(a[1][few][:, :, 2] - c[1][few][:, :, 2]).max() <= 2e-3
-    for f in (hot_frames[0], hot_frames[2], 2):
+    for f in (hot_frames[0], hot_frames[2], 2, 3, 4, 8, 11, 13):
         img, _ = oracle.fix_hot_pixels(frames[f])
         assert np.array_equal(c[3][f], img)
         _, M_o, it_o = oracle.register_pixel(ref, img)

@@ -802,11 +802,27 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))
     ecc_blur_ident_kernel(const uint16_t *__restrict__ src, float *__restrict__ dst, const float *__restrict__ tmpl, int rows, int cols,
                           int strips, int pieces, double *__restrict__ partial, const float *__restrict__ center, float k0, float k1,
                           float k2, unsigned thresh, unsigned *__restrict__ hot_count, unsigned *__restrict__ hot_pos,
-                          const unsigned *__restrict__ only_changed, const double *__restrict__ tsum)
+                          const unsigned *__restrict__ only_changed, const uint4 *__restrict__ changes, int max_hot,
+                          const double *__restrict__ tsum)
 {
     __shared__ double lds_red[5][256];                                          // (10 KB: the workgroups of a compute unit are bounded by registers)
     const int f = blockIdx.x;
-    if (only_changed && only_changed[f] == 0u) return;                         // (uniform)
+    if (only_changed) {
+        // second pass: only the workgroups a repaired pixel reaches -- it moves the blurred values within 2 pixels and, through their
+        // gradients, the sums of the pixels within 3; a workgroup whose four wave items own none of those keeps its sums
+        const unsigned m = only_changed[f];
+        bool hit = false;
+        for (unsigned i = 0; i < m; ++i) {                                     // (uniform: m <= max_hot)
+            const unsigned pos = changes[(size_t)f * max_hot + i].y;
+            const int py = (int)(pos / (unsigned)cols), px = (int)(pos % (unsigned)cols);
+            for (int w = 0; w < 4; ++w) {
+                const int it = (int)blockIdx.y * 4 + w, pc = it / strips, sp = it - pc * strips;
+                hit |= pc < pieces && px >= sp * kFusedOwn - 3 && px < (sp + 1) * kFusedOwn + 3 && py >= pc * kEccFlushLong - 3 &&
+                       py < (pc + 1) * kEccFlushLong + 3;
+            }
+        }
+        if (!hit) return;                                                      // (uniform)
+    }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int item = (int)blockIdx.y * 4 + wave;
@@ -1270,9 +1286,10 @@ int launch_ecc_tmpl_sums(const float *tmpl_blur, int rows, int cols, double *d_o
 
 int launch_ecc_blur_ident(FrameScratch *s, int slot, const uint16_t *d_frames, float *dst, const float *tmpl_blur, const float *d_center,
                           const double *d_tsum, int nb, int rows, int cols, float k0, float k1, float k2, unsigned thresh,
-                          unsigned *hot_count, unsigned *hot_pos, const unsigned *only_changed, hipStream_t st)
+                          unsigned *hot_count, unsigned *hot_pos, const unsigned *only_changed, const void *changes, int max_hot,
+                          hipStream_t st)
 {
-    if (!s || slot < 0 || slot > 1 || nb > s->batch || !ecc_fused_blur_eligible(rows, cols))
+    if (!s || slot < 0 || slot > 1 || nb > s->batch || !ecc_fused_blur_eligible(rows, cols) || (only_changed && (!changes || max_hot < 1)))
         return fail(UPSP_ERR_INVALID, "fused pre-blur: not set up for this geometry");
     const int strips = (cols + kFusedOwn - 1) / kFusedOwn, pieces = (rows + kEccFlushLong - 1) / kEccFlushLong;
     const int blocks = (strips * pieces + 3) / 4;
@@ -1289,10 +1306,11 @@ int launch_ecc_blur_ident(FrameScratch *s, int slot, const uint16_t *d_frames, f
     const dim3 grid((unsigned)nb, (unsigned)blocks);
     if (hot_count)
         hipLaunchKernelGGL((ecc_blur_ident_kernel<true, 4>), grid, dim3(256), 0, st, d_frames, dst, tmpl_blur, rows, cols, strips, pieces,
-                           s->partial_id[slot], d_center, k0, k1, k2, thresh, hot_count, hot_pos, only_changed, d_tsum);
+                           s->partial_id[slot], d_center, k0, k1, k2, thresh, hot_count, hot_pos, only_changed, (const uint4 *)changes, max_hot, d_tsum);
     else
         hipLaunchKernelGGL((ecc_blur_ident_kernel<false, 4>), grid, dim3(256), 0, st, d_frames, dst, tmpl_blur, rows, cols, strips, pieces,
-                           s->partial_id[slot], d_center, k0, k1, k2, 0u, (unsigned *)nullptr, (unsigned *)nullptr, only_changed, d_tsum);
+                           s->partial_id[slot], d_center, k0, k1, k2, 0u, (unsigned *)nullptr, (unsigned *)nullptr, only_changed,
+                           (const uint4 *)changes, max_hot, d_tsum);
     UPSP_HIP_CHECK(hipGetLastError());
     s->ident_for[slot] = dst;
     s->ident_blocks = blocks;

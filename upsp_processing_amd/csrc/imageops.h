@@ -133,12 +133,14 @@ int run_ecc(FrameScratch *s, const float *tmpl_blur, const float *d_center, cons
 int launch_ecc_center(const float *tmpl_blur, int rows, int cols, float *d_center, hipStream_t st);
 // The 5 x 5 pre-blur of nb u16 frames fused with the identity iteration's sums (ecc_blur_ident_kernel): blurred frames -> dst,
 // sums -> s->partial_id[slot]; s->ident_for[slot] = dst tells run_ecc that its first iteration is already summed.  hot_count /
-// hot_pos (may be null): the scan of fix_hot_pixels on the way; only_changed (may be null): per-frame counts, frames with 0 are
-// skipped (the second pass over the frames the repair changed).  false: geometry not eligible (nothing launched).
+// hot_pos (may be null): the scan of fix_hot_pixels on the way; only_changed (may be null): the second pass, over the frames the repair
+// changed -- per-frame change counts + their records (uint4 [frame][max_hot], .y = pixel position): only the workgroups a changed
+// pixel reaches run again.
 bool ecc_fused_blur_eligible(int rows, int cols);
 int launch_ecc_blur_ident(FrameScratch *s, int slot, const uint16_t *d_frames, float *dst, const float *tmpl_blur, const float *d_center,
                           const double *d_tsum, int nb, int rows, int cols, float k0, float k1, float k2, unsigned thresh,
-                          unsigned *hot_count, unsigned *hot_pos, const unsigned *only_changed, hipStream_t st);
+                          unsigned *hot_count, unsigned *hot_pos, const unsigned *only_changed, const void *changes, int max_hot,
+                          hipStream_t st);
 // d_out[0 .. 1] = sum t, sum t^2 of the blurred template (the identity iteration's St, Stt)
 int launch_ecc_tmpl_sums(const float *tmpl_blur, int rows, int cols, double *d_out, hipStream_t st);
 int launch_ecc_export(const EccState *state, int nb, float *d_warps, int wstride, int32_t *d_iters, int istride, hipStream_t st);

@@ -1198,7 +1198,7 @@ int frame_scratch_preblur(FrameScratch *s, int slot, uint16_t *d_frames, int nb,
             KTimed kt("ecc_blur_ident_kernel", st);
             rc = launch_ecc_blur_ident(s, slot, d_frames, dst, s->tmpl[fuse_cam], s->center + fuse_cam, s->tsum + 2 * fuse_cam, nb, rows, cols, fc.k[2], fc.k[3],
                                        fc.k[4], hot ? (unsigned)hot->thresh : 0u, hot ? hot->d_count : nullptr, hot ? hot->d_pos : nullptr,
-                                       nullptr, st);
+                                       nullptr, nullptr, 0, st);
         }
         if (rc != UPSP_OK) return rc;
         if (hot) {
@@ -1208,7 +1208,8 @@ int frame_scratch_preblur(FrameScratch *s, int slot, uint16_t *d_frames, int nb,
             if (hot->max_hot > 0) {
                 KTimed kt("hot_fixup_kernels", st);
                 rc = launch_ecc_blur_ident(s, slot, d_frames, dst, s->tmpl[fuse_cam], s->center + fuse_cam, s->tsum + 2 * fuse_cam, nb, rows, cols, fc.k[2],
-                                           fc.k[3], fc.k[4], 0u, nullptr, nullptr, hot->d_changes + 4, st);
+                                           fc.k[3], fc.k[4], 0u, nullptr, nullptr, hot->d_changes + 4,
+                                           hot->d_changes + 4 + (((size_t)nb + 3) & ~(size_t)3), hot->max_hot, st);
                 if (rc != UPSP_OK) return rc;
             }
         }
@@ -1271,7 +1272,7 @@ int run_frame_stages(FrameScratch *s, int cam, const uint16_t *d_frames, int nb,
                 // pre-blur, so a frame's warp is the same bits whichever path registers it
                 KTimed kt("ecc_blur_ident_kernel", st);
                 rc = launch_ecc_blur_ident(s, 0, d_frames, s->ecc_img, s->tmpl[cam], s->center + cam, s->tsum + 2 * cam, nb, rows, cols, fc.k[2], fc.k[3], fc.k[4],
-                                           0u, nullptr, nullptr, nullptr, st);
+                                           0u, nullptr, nullptr, nullptr, nullptr, 0, st);
                 const char *e = std::getenv("UPSP_ECC_FUSED_BLUR");
                 if (e && *e == '2') s->ident_for[0] = nullptr;
             } else {
@@ -1363,7 +1364,7 @@ int upsp_register_pixel_u16(const float *d_ref32f, const uint16_t *d_inp, int ro
     FilterCoef fc;
     if (rc == UPSP_OK && ecc_fused_blur_eligible(rows, cols) && gaussian_coef(5, fc) == 0) {      // (the frame loop's kernel: same bits)
         rc = launch_ecc_blur_ident(s, 0, d_inp, s->ecc_img, s->tmpl[0], s->center, s->tsum, 1, rows, cols, fc.k[2], fc.k[3], fc.k[4], 0u, nullptr,
-                                   nullptr, nullptr, st);
+                                   nullptr, nullptr, nullptr, 0, st);
         const char *e = std::getenv("UPSP_ECC_FUSED_BLUR");
         if (e && *e == '2') s->ident_for[0] = nullptr;
     } else if (rc == UPSP_OK) {
