@@ -76,7 +76,7 @@ def measured_peak():
 # which stream a kernel's algorithmic bytes are: fraction READ (the rest written)
 READ_SHARE = {"scan_compact_kernel": 1.0, "hot_scan_kernel": 1.0, "ecc_sums_kernel": 1.0, "ecc_sums_identity": 1.0, "ecc_sums_general": 1.0,
               "node_rows_kernel": 0.0, "node_rows_multi_kernel": 0.0, "gather_tile_kernel": 0.0,
-              "gauss_pass_kernels": 1.0 / 3.0, "warp_u16_kernel": 12.0 / 14.0, "scan_compact_multi": 1.0}
+              "gauss_pass_kernels": 1.0 / 3.0, "ecc_blur_ident_kernel": 0.6, "warp_u16_kernel": 12.0 / 14.0, "scan_compact_multi": 1.0}
 
 
 def floor_ms(name, nbytes, pk):
@@ -491,6 +491,7 @@ def registration_block(bvh, cam, d_nodes, d_nrm, d_tn, frames, restore, N, size,
     torch.cuda.synchronize()
     _capi.timing_enable(False)
     rep = merge_ecc_labels(_capi.timing_report(spread=True))
+    fused = "ecc_blur_ident_kernel" in rep and "ecc_sums_identity" not in rep
     ms_step = dt / steps * 1e3
     bytes_step = {
         # SURVEY.md 8(d) with registration: 8 B per pixel and ECC iteration (blurred frame + template, gradients
@@ -502,11 +503,16 @@ def registration_block(bvh, cam, d_nodes, d_nrm, d_tn, frames, restore, N, size,
         "ecc_sums_identity": F * 8 * npx,
         "ecc_sums_general": max(iters - 1.0, 0.0) * F * 8 * npx,
         "gauss_pass_kernels": F * 6 * npx,
+        # round 6: the pre-blur and the identity iteration in one pass (ecc_blur_ident_kernel): 2 B frame in + 4 B blurred frame out
+        # + 4 B template per pixel -- 10 B where the two kernels move 6 + 8
+        "ecc_blur_ident_kernel": F * 10 * npx,
         "warp_u16_kernel": F * n_active * 14,
         "hot_scan_kernel": F * 2 * npx,
         "gather_tile_kernel": F * 4 * N + (-(-F // 64)) * 8 * N,
         "node_rows_kernel": F * 4 * N + (-(-F // 1024)) * 8 * N,
     }
+    if fused:       # the sums launches that remain are the general iterations
+        bytes_step["ecc_sums_kernel"] = bytes_step["ecc_sums_general"]
     kernels = {}
     for name, (calls, total, lo, med, hi) in rep.items():
         k = {"calls_per_step": calls / steps, "ms_per_step": total / steps, "avg_launch_ms": total / max(calls, 1)}
@@ -523,10 +529,11 @@ def registration_block(bvh, cam, d_nodes, d_nrm, d_tn, frames, restore, N, size,
         # once for all of its frames (it stays in cache), so the bytes a launch must move are 4 B per pixel and frame-iteration
         # + 4 B per pixel and launch: both fractions are reported
         ek = kernels["ecc_sums_kernel"]
-        once = iters * F * 4 * npx + ek["calls_per_step"] * 4 * npx
+        once = (iters - 1.0 if fused else iters) * F * 4 * npx + ek["calls_per_step"] * 4 * npx
         ecc_fracs = {"survey_8B_per_px_iteration": ek["achieved_GBps"] / HBM_PEAK_GBS,
                      "template_once_per_launch": once / (ek["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "identity_launch_ms": kernels.get("ecc_sums_identity", {}).get("avg_launch_ms"),
+                     "blur_ident_launch_ms": kernels.get("ecc_blur_ident_kernel", {}).get("avg_launch_ms"),
                      "general_launch_ms": kernels.get("ecc_sums_general", {}).get("avg_launch_ms")}
     return {
         "ecc_sums_fraction_of_hbm_peak": ecc_fracs,
@@ -539,18 +546,21 @@ def registration_block(bvh, cam, d_nodes, d_nrm, d_tn, frames, restore, N, size,
                           "algorithmic_bytes_per_launch": dk["algorithmic_bytes_per_step"] / max(dk["calls_per_step"], 1),
                           "avg_launch_ms": dk["avg_launch_ms"], "launches_per_step": dk["calls_per_step"]},
                          **ECC_SYMBOLS.get(dom, {})),
-                         # a step's algorithmic bytes: sums 8 B / px / iteration, pre-blur 6 B / px, warp 14 B / active px, pass B rows
-                         {k: bytes_step[k] for k in ("ecc_sums_kernel", "gauss_pass_kernels", "warp_u16_kernel", "node_rows_kernel")}, ms_step),
+                         # a step's algorithmic bytes: sums 8 B / px / iteration, pre-blur 6 B / px (fused: 10 B / px for the pre-blur
+                         # with the first iteration), warp 14 B / active px, pass B rows
+                         {k: bytes_step[k] for k in ("ecc_sums_kernel", "ecc_blur_ident_kernel" if fused else "gauss_pass_kernels",
+                                                     "warp_u16_kernel", "node_rows_kernel")}, ms_step),
         "kernels": kernels,
     }
 
 
 # "ecc_sums_kernel" = the ECC sums launches (the library times them as ecc_sums_identity / ecc_sums_general); the symbols a
 # rocprofv3 trace shows for them
-ECC_SYMBOLS = {"ecc_sums_kernel": {"kernel_symbols": ["ecc_cols_kernel<true,4,4> (iterations from the identity warp)",
-                                                      "ecc_cols_kernel<false,2,3> (general warp: source taps from an LDS tile)"]},
-               "ecc_sums_identity": {"kernel_symbols": ["ecc_cols_kernel<true,4,4> (a frame's first iteration: identity warp)"]},
-               "ecc_sums_general": {"kernel_symbols": ["ecc_cols_kernel<false,2,3> (general warp: source taps from an LDS tile)"]}}
+ECC_SYMBOLS = {"ecc_sums_kernel": {"kernel_symbols": ["ecc_cols_kernel<true,4,5,true> (iterations from the identity warp, when not fused with the pre-blur)",
+                                                      "ecc_cols_kernel<false,2,4,true> (general warp: source taps from an LDS tile)"]},
+               "ecc_sums_identity": {"kernel_symbols": ["ecc_cols_kernel<true,4,5,true> (a frame's first iteration: identity warp)"]},
+               "ecc_sums_general": {"kernel_symbols": ["ecc_cols_kernel<false,2,4,true> (general warp: source taps from an LDS tile)"]},
+               "ecc_blur_ident_kernel": {"kernel_symbols": ["ecc_blur_ident_kernel<true,4> (5 x 5 pre-blur + the first iteration's sums in one pass)"]}}
 
 
 def tracked_traffic(kernel, kind, world=1):
@@ -1385,6 +1395,11 @@ def run(a, nested=False):
         # (the two kernels behind that label: a frame's first iteration starts from the identity warp, the others are general)
         per_step_bytes["ecc_sums_identity"] = F * 8 * npx
         per_step_bytes["ecc_sums_general"] = max(ecc_iters_per_frame - 1.0, 0.0) * F * 8 * npx
+        if "ecc_blur_ident_kernel" in timing and "ecc_sums_identity" not in timing:
+            # the pre-blur and the identity iteration in one pass: 2 B in + 4 B out + 4 B template per pixel; the sums launches
+            # that remain are the general iterations
+            per_step_bytes["ecc_blur_ident_kernel"] = F * 10 * npx
+            per_step_bytes["ecc_sums_kernel"] = per_step_bytes["ecc_sums_general"]
     for name, (calls, total_ms) in timing.items():
         ms_step_k = total_ms / a.steps
         k = {"calls_per_step": calls / a.steps, "ms_per_step": ms_step_k,

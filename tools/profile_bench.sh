@@ -43,7 +43,8 @@ def bench_key(name):
                                 ("projection_kernel<false, 0", "projection_kernel<primary>", False),
                                 ("projection_kernel<false, 2", "projection_kernel<retry>", False), ("witness_kernel", "witness_kernels", False),
                                 ("node_rows_multi_kernel", "node_rows_multi_kernel", True), ("node_rows_kernel", "node_rows_kernel", True),
-                                ("ecc_cols_kernel", "ecc_sums_kernel", True), ("gauss5_quad_kernel", "gauss_pass_kernels", True),
+                                ("ecc_cols_kernel", "ecc_sums_kernel", True), ("ecc_blur_ident_kernel", "ecc_blur_ident_kernel", True),
+                                ("gauss5_quad_kernel", "gauss_pass_kernels", True),
                                 ("gauss_fused_kernel<unsigned short", "gauss_pass_kernels", True), ("warp_compact_kernel", "warp_u16_kernel", False),
                                 ("warp_u16_kernel", "warp_u16_kernel", True), ("gather_tile", "gather_tile_kernel", True)):
         if name.startswith(prefix): return key, stream
