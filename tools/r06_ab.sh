@@ -85,3 +85,10 @@ if [ $part = fused ]; then
     line fused_1_$i -- --registration --steps 3 --warmup 1 || exit 1
   done
 fi
+if [ $part = pairs ]; then
+  # general ECC iteration: taps and footprint arithmetic of two rows as packed pairs (default) / row by row (UPSP_ECC_PAIRS=0)
+  for i in 1 2 3; do
+    line pairs_0_$i UPSP_ECC_PAIRS=0 -- --registration --steps 3 --warmup 1 || exit 1
+    line pairs_1_$i -- --registration --steps 3 --warmup 1 || exit 1
+  done
+fi

@@ -474,7 +474,7 @@ __device__ __forceinline__ void ecc_stage_tile(const float *__restrict__ I, int 
 template <int UR, bool TILE>
 __device__ __forceinline__ void ecc_walk_segment(const float *tile, const EccSeg &g, const float *__restrict__ I,
                                                  const float *__restrict__ tmpl, int cols, int x, int yb, int ne, int ax, int bx,
-                                                 const int2 *__restrict__ rt, EccPart &P, EccTot &T, int rbase = 0)
+                                                 const int2 *__restrict__ rt, EccPart &P, EccTot &T, int rbase = 0, bool pairs = true)
 {
     const unsigned pitch = 4u * (unsigned)cols;
     unsigned ot = 4u * (unsigned)(yb * cols + x);
@@ -487,8 +487,7 @@ __device__ __forceinline__ void ecc_walk_segment(const float *tile, const EccSeg
     unsigned coff = 0u;                 // TILE: float index of the footprint's corner in the tile; direct: its byte offset in the frame
     int2 prev = make_int2(0, 0);
     bool have = false;
-    auto taps = [&](int r, EccRow &q) {
-        const int2 a = rt[r];
+    auto coord = [&](int2 a) {
         if (have && a.x == prev.x && a.y == prev.y + 1024) {       // (uniform)
             coff += TILE ? (unsigned)kEccTilePitch : pitch;
         } else {
@@ -498,6 +497,9 @@ __device__ __forceinline__ void ecc_walk_segment(const float *tile, const EccSeg
         }
         have = true;
         prev = a;
+    };
+    auto taps = [&](int r, EccRow &q) {
+        coord(rt[r]);
         q.fx = cfx;
         q.fy = cfy;
         if (TILE) {
@@ -515,6 +517,53 @@ __device__ __forceinline__ void ecc_walk_segment(const float *tile, const EccSeg
 #pragma unroll
     for (int k = 0; k < UR; ++k) tn[k] = k < ne ? ld_f32(tmpl, ot + (unsigned)k * pitch) : 0.f;
     int r = 0;
+    if constexpr (TILE && UR == 2) {
+        // Two rows per trip with every value held as the PAIR {row r, row r + 1} (round 6): the footprint arithmetic of ecc_row_sum is
+        // then packed instructions throughout (24 + 8 scalar for two rows instead of 14 packed + 28 scalar), and the taps are single
+        // LDS reads with immediate offsets from ONE address per row (the tile pointer in the LDS address space and volatile, so that
+        // the compiler neither goes through flat addresses nor merges neighbouring reads into pairs of COLUMNS) -- no address
+        // arithmetic per tap.  The same operations on the same values per component: the same bits as ecc_row_sum.
+        typedef const volatile __attribute__((address_space(3))) float lds_cvf;
+        constexpr int TP = kEccTilePitch;
+        // (the row terms come by scalar loads, which share their counter with the LDS reads: fetched one trip ahead, they are
+        //  there when the wait for the taps ends instead of being a round trip of their own in front of every trip)
+        int2 rn0 = rt[0], rn1 = rt[min(1, ne - 1)];
+        for (; pairs && r + 2 <= ne; r += 2) {
+            const float t0 = tn[0], t1 = tn[1];
+            tn[0] = r + 2 < ne ? ld_f32(tmpl, ot + 2u * pitch) : 0.f;
+            tn[1] = r + 3 < ne ? ld_f32(tmpl, ot + 3u * pitch) : 0.f;
+            const int2 rc0 = rn0, rc1 = rn1;
+            rn0 = rt[min(r + 2, ne - 1)];
+            rn1 = rt[min(r + 3, ne - 1)];
+            coord(rc0);
+            lds_cvf *a = (lds_cvf *)tile + coff;
+            const float fx0 = cfx, fy0 = cfy;
+            coord(rc1);
+            lds_cvf *b = (lds_cvf *)tile + coff;
+            const v2f FX = {fx0, cfx}, FY = {fy0, cfy};
+            const v2f A0 = {a[1], b[1]}, A1 = {a[2], b[2]};
+            const v2f B_1 = {a[TP], b[TP]}, B0 = {a[TP + 1], b[TP + 1]}, B1 = {a[TP + 2], b[TP + 2]}, B2 = {a[TP + 3], b[TP + 3]};
+            const v2f C_1 = {a[2 * TP], b[2 * TP]}, C0 = {a[2 * TP + 1], b[2 * TP + 1]}, C1 = {a[2 * TP + 2], b[2 * TP + 2]},
+                      C2 = {a[2 * TP + 3], b[2 * TP + 3]};
+            const v2f D0 = {a[3 * TP + 1], b[3 * TP + 1]}, D1 = {a[3 * TP + 2], b[3 * TP + 2]};
+            const v2f Dm0 = C0 - B0, Dm1 = C1 - B1;                                   // {c0-b0}, {c1-b1}
+            const v2f V0 = __builtin_elementwise_fma(FY, Dm0, B0), V1 = __builtin_elementwise_fma(FY, Dm1, B1);
+            const v2f W = __builtin_elementwise_fma(FX, V1 - V0, V0);
+            const v2f De0 = C_1 - B_1, De1 = C2 - B2;                                 // {c_1-b_1}, {c2-b2}
+            const v2f G0 = __builtin_elementwise_fma(FY, Dm1 - De0, B1 - B_1);
+            const v2f G1 = __builtin_elementwise_fma(FY, De1 - Dm0, B2 - B0);
+            const v2f dG = G1 - G0;
+            const v2f E0 = C0 - A0, E1 = C1 - A1, F0 = D0 - B0, F1 = D1 - B1;
+            const v2f P0 = __builtin_elementwise_fma(FY, F0 - E0, E0), P1 = __builtin_elementwise_fma(FY, F1 - E1, E1);
+            const v2f dP = P1 - P0;
+            // the last step per row: {gx, gy} is the pair the sums work on
+            const float gx0 = 0.5f * __builtin_fmaf(fx0, dG[0], G0[0]), gy0 = 0.5f * __builtin_fmaf(fx0, dP[0], P0[0]);
+            const float gx1 = 0.5f * __builtin_fmaf(cfx, dG[1], G0[1]), gy1 = 0.5f * __builtin_fmaf(cfx, dP[1], P0[1]);
+            ecc_part_add<false>(P, T, W[0], gx0, gy0, t0, (float)(rbase + r));
+            ecc_part_add<false>(P, T, W[1], gx1, gy1, t1, (float)(rbase + r + 1));
+            ot += 2u * pitch;
+        }
+    }
     for (; r + UR <= ne; r += UR) {
         EccRow q[UR];
 #pragma unroll
@@ -621,7 +670,7 @@ __device__ __forceinline__ void ecc_cols_body(const float *__restrict__ img, con
         for (int yb = y0; yb < y1; yb += STG) {
             const int ne = min(STG, y1 - yb);
             EccSeg s = ecc_segment_box(rt[yb], rt[yb + ne - 1], min(axa, axb), max(axa, axb), min(bxa, bxb), max(bxa, bxb), rows, cols, TR);
-            if (force_direct) s.fits = false;
+            if (force_direct & 1) s.fits = false;
             if (s.fits) {                              // (uniform)
                 if (staged) __syncthreads();           // every tap of the previous segment has been read
                 ecc_stage_tile<TR, kEccTilePitch>(I, cols, s, tile);
@@ -630,7 +679,7 @@ __device__ __forceinline__ void ecc_cols_body(const float *__restrict__ img, con
             }
             if (on) {
                 if (ONE) {
-                    if (s.fits) ecc_walk_segment<UR, true>(tile, s, I, tmpl, cols, x, yb, ne, ax, bx, rt + yb, P1, T, yb - y0);
+                    if (s.fits) ecc_walk_segment<UR, true>(tile, s, I, tmpl, cols, x, yb, ne, ax, bx, rt + yb, P1, T, yb - y0, !(force_direct & 2));
                     else ecc_walk_segment<UR, false>(tile, s, I, tmpl, cols, x, yb, ne, ax, bx, rt + yb, P1, T, yb - y0);
                 } else {
                     EccPart P;
@@ -1381,7 +1430,8 @@ int run_ecc(FrameScratch *s, const float *tmpl_blur, const float *d_center, cons
     // UPSP_ECC_DIRECT=1 (test switch): every segment of the general iteration takes the direct loads instead of the LDS
     // tile -- the same bits (tests/test_imageops_gpu.py::test_ecc_lds_taps_same_bits)
     const char *direct_env = std::getenv("UPSP_ECC_DIRECT");
-    const int force_direct = direct_env && std::atoi(direct_env) != 0;
+    const char *pairs_env = std::getenv("UPSP_ECC_PAIRS");       // =0 (A/B): the taps of the tile path row by row, as in rounds 4-5
+    const int force_direct = ((direct_env && std::atoi(direct_env) != 0) ? 1 : 0) | ((pairs_env && *pairs_env == '0') ? 2 : 0);
     // the one-flush form of the interior blocks (ecc_cols_body): when a block's row piece has <= kEccFlushLong rows -- a property of
     // the image geometry alone, like the block count.  UPSP_ECC_ONE_FLUSH=0: the 32-row float segments of rounds 3-5 (A/B).
     const int pieces_min = std::max(blocks / tiles, 1);
