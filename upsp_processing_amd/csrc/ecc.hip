@@ -849,7 +849,7 @@ __device__ __forceinline__ float dpp_shl1_z(float v)
 // workgroup `blk` of `nblk` of frame f
 template <bool HOT, int U>
 __device__ __forceinline__ void ecc_blur_ident_block(const uint16_t *__restrict__ src, float *__restrict__ dst, const float *__restrict__ tmpl,
-                                                     int rows, int cols, int strips, int pieces, double *__restrict__ partial,
+                                                     int rows, int cols, int strips, int pieces, int prows, double *__restrict__ partial,
                                                      const float *__restrict__ center, float k0, float k1, float k2, unsigned thresh,
                                                      unsigned *__restrict__ hot_count, unsigned *__restrict__ hot_pos,
                                                      const double *__restrict__ tsum, int f, int blk, int nblk, double (*lds_red)[256])
@@ -859,7 +859,7 @@ __device__ __forceinline__ void ecc_blur_ident_block(const uint16_t *__restrict_
     const int item = blk * 4 + wave;
     const int piece = item / strips, strip = item - piece * strips;
     const bool work = piece < pieces;
-    const int y0 = piece * kEccFlushLong, y1 = min(rows, y0 + kEccFlushLong);
+    const int y0 = piece * prows, y1 = min(rows, y0 + prows);
     const int c = strip * kFusedOwn - kFusedHalo + lane;
     const bool own = work && lane >= kFusedHalo && lane < kFusedHalo + kFusedOwn && c < cols;
     EccTot T;
@@ -985,12 +985,12 @@ __device__ __forceinline__ void ecc_blur_ident_block(const uint16_t *__restrict_
 template <bool HOT, int U>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7)))
     ecc_blur_ident_kernel(const uint16_t *__restrict__ src, float *__restrict__ dst, const float *__restrict__ tmpl, int rows, int cols,
-                          int strips, int pieces, double *__restrict__ partial, const float *__restrict__ center, float k0, float k1,
-                          float k2, unsigned thresh, unsigned *__restrict__ hot_count, unsigned *__restrict__ hot_pos,
+                          int strips, int pieces, int prows, double *__restrict__ partial, const float *__restrict__ center, float k0,
+                          float k1, float k2, unsigned thresh, unsigned *__restrict__ hot_count, unsigned *__restrict__ hot_pos,
                           const double *__restrict__ tsum)
 {
     __shared__ double lds_red[5][256];                                          // (10 KB: the workgroups of a compute unit are bounded by registers)
-    ecc_blur_ident_block<HOT, U>(src, dst, tmpl, rows, cols, strips, pieces, partial, center, k0, k1, k2, thresh, hot_count, hot_pos, tsum,
+    ecc_blur_ident_block<HOT, U>(src, dst, tmpl, rows, cols, strips, pieces, prows, partial, center, k0, k1, k2, thresh, hot_count, hot_pos, tsum,
                                  (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y, lds_red);
 }
 
@@ -1004,7 +1004,7 @@ constexpr int kAgainFrames = 1;
 template <int U>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7)))
     ecc_blur_ident_again_kernel(const uint16_t *__restrict__ src, float *__restrict__ dst, const float *__restrict__ tmpl, int rows, int cols,
-                                int strips, int pieces, int nframes, double *__restrict__ partial, const float *__restrict__ center, float k0,
+                                int strips, int pieces, int prows, int nframes, double *__restrict__ partial, const float *__restrict__ center, float k0,
                                 float k1, float k2, const unsigned *__restrict__ nchanged, const uint4 *__restrict__ changes, int max_hot,
                                 const double *__restrict__ tsum)
 {
@@ -1020,12 +1020,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))
             const int py = (int)(pos / (unsigned)cols), px = (int)(pos % (unsigned)cols);
             for (int w = 0; w < 4; ++w) {
                 const int it = blk * 4 + w, pc = it / strips, sp = it - pc * strips;
-                hit |= pc < pieces && px >= sp * kFusedOwn - 3 && px < (sp + 1) * kFusedOwn + 3 && py >= pc * kEccFlushLong - 3 &&
-                       py < (pc + 1) * kEccFlushLong + 3;
+                hit |= pc < pieces && px >= sp * kFusedOwn - 3 && px < (sp + 1) * kFusedOwn + 3 && py >= pc * prows - 3 &&
+                       py < (pc + 1) * prows + 3;
             }
         }
         if (!hit) continue;                                                    // (uniform)
-        ecc_blur_ident_block<false, U>(src, dst, tmpl, rows, cols, strips, pieces, partial, center, k0, k1, k2, 0u, nullptr, nullptr, tsum, f,
+        ecc_blur_ident_block<false, U>(src, dst, tmpl, rows, cols, strips, pieces, prows, partial, center, k0, k1, k2, 0u, nullptr, nullptr, tsum, f,
                                        blk, (int)gridDim.y, lds_red);
     }
 }
@@ -1371,7 +1371,14 @@ int launch_ecc_blur_ident(FrameScratch *s, int slot, const uint16_t *d_frames, f
 {
     if (!s || slot < 0 || slot > 1 || nb > s->batch || !ecc_fused_blur_eligible(rows, cols) || (only_changed && (!changes || max_hot < 1)))
         return fail(UPSP_ERR_INVALID, "fused pre-blur: not set up for this geometry");
-    const int strips = (cols + kFusedOwn - 1) / kFusedOwn, pieces = (rows + kEccFlushLong - 1) / kEccFlushLong;
+    // Rows per piece (= per float segment): 128, fewer on small images -- about as many wave items as a 1024^2 frame has (128), but not
+    // under 16 rows (every piece blurs 6 rows more than it owns).  A property of the image geometry alone.  (The float error of a
+    // frame's sums grows with the segment length: with 128-row segments on every image the soak's statistics, mostly images of a
+    // few hundred pixels, were 1.7 x those of the two-kernel path, whose pieces on such images are 4 .. 32 rows.)
+    const int strips = (cols + kFusedOwn - 1) / kFusedOwn;
+    const int pieces_want = (128 + strips - 1) / strips;
+    const int prows = std::min(kEccFlushLong, std::max(16, (rows + pieces_want - 1) / pieces_want));
+    const int pieces = (rows + prows - 1) / prows;
     const int blocks = (strips * pieces + 3) / 4;
     const size_t words = (size_t)s->batch * kEccSums * blocks;
     if (s->partial_id_words < words) {
@@ -1386,14 +1393,14 @@ int launch_ecc_blur_ident(FrameScratch *s, int slot, const uint16_t *d_frames, f
     const dim3 grid((unsigned)nb, (unsigned)blocks);
     if (only_changed)
         hipLaunchKernelGGL((ecc_blur_ident_again_kernel<4>), dim3((unsigned)((nb + kAgainFrames - 1) / kAgainFrames), (unsigned)blocks),
-                           dim3(256), 0, st, d_frames, dst, tmpl_blur, rows, cols, strips, pieces, nb, s->partial_id[slot], d_center, k0, k1,
+                           dim3(256), 0, st, d_frames, dst, tmpl_blur, rows, cols, strips, pieces, prows, nb, s->partial_id[slot], d_center, k0, k1,
                            k2, only_changed, (const uint4 *)changes, max_hot, d_tsum);
     else if (hot_count)
         hipLaunchKernelGGL((ecc_blur_ident_kernel<true, 4>), grid, dim3(256), 0, st, d_frames, dst, tmpl_blur, rows, cols, strips, pieces,
-                           s->partial_id[slot], d_center, k0, k1, k2, thresh, hot_count, hot_pos, d_tsum);
+                           prows, s->partial_id[slot], d_center, k0, k1, k2, thresh, hot_count, hot_pos, d_tsum);
     else
         hipLaunchKernelGGL((ecc_blur_ident_kernel<false, 4>), grid, dim3(256), 0, st, d_frames, dst, tmpl_blur, rows, cols, strips, pieces,
-                           s->partial_id[slot], d_center, k0, k1, k2, 0u, (unsigned *)nullptr, (unsigned *)nullptr, d_tsum);
+                           prows, s->partial_id[slot], d_center, k0, k1, k2, 0u, (unsigned *)nullptr, (unsigned *)nullptr, d_tsum);
     UPSP_HIP_CHECK(hipGetLastError());
     s->ident_for[slot] = dst;
     s->ident_blocks = blocks;
