@@ -20,7 +20,7 @@ elif [ $part = b ]; then
   cp gpurun_out/prof_r06_reg/kernel_stats.csv $o/r06_registration_kernel_stats.csv
   cp gpurun_out/prof_r06_reg/summary.json $o/r06_ecc_summary.json
   cp gpurun_out/prof_r06_reg/bench_line.json $o/r06_bench_line_registration.json
-  bash tools/pmc_script.sh "ecc_cols|gauss5_quad|ecc_solve|reblur|hot_repair|warp_compact" tools/prof_ecc.py > $o/r06_ecc_pmc.txt 2>&1 || exit 1
+  bash tools/pmc_script.sh "ecc_cols|ecc_blur_ident|gauss5_quad|ecc_solve|reblur|hot_repair|warp_compact" tools/prof_ecc.py > $o/r06_ecc_pmc.txt 2>&1 || exit 1
 else
   # N > 1 loop on one GPU through a one-rank RCCL communicator.  "selfrccl": the rank's own block goes through ncclSend / ncclRecv to
   # self (RCCL's kernel on the device beside the frame loop, as between GPUs); without it the block is read in place.

@@ -1053,13 +1053,14 @@ __global__ void __launch_bounds__(256) ecc_center_kernel(const float *__restrict
     }
 }
 
-// sum t and sum t^2 over the whole blurred template, in double (one workgroup, fixed order): what every pixel's share of St and Stt
-// adds up to when the mask is 1 everywhere -- the identity iteration (ecc_blur_ident_kernel) takes them from here
-__global__ void __launch_bounds__(256) ecc_tmpl_sums_kernel(const float *__restrict__ tmpl, size_t npix, double *__restrict__ out)
+// sum t and sum t^2 over the whole blurred template, in double (64 workgroups + one wave, fixed order): what every pixel's share of
+// St and Stt adds up to when the mask is 1 everywhere -- the identity iteration (ecc_blur_ident_kernel) takes them from here
+constexpr int kTmplSumBlocks = 64;
+__global__ void __launch_bounds__(256) ecc_tmpl_sums_kernel(const float *__restrict__ tmpl, size_t npix, double *__restrict__ part)
 {
     __shared__ double sh[2][256];
     double a = 0.0, b = 0.0;
-    for (size_t i = threadIdx.x; i < npix; i += 256) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)kTmplSumBlocks * 256) {
         const double t = (double)tmpl[i];
         a += t;
         b = fma(t, t, b);
@@ -1075,8 +1076,21 @@ __global__ void __launch_bounds__(256) ecc_tmpl_sums_kernel(const float *__restr
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        out[0] = sh[0][0];
-        out[1] = sh[1][0];
+        part[2 * blockIdx.x] = sh[0][0];
+        part[2 * blockIdx.x + 1] = sh[1][0];
+    }
+}
+__global__ void __launch_bounds__(64) ecc_tmpl_sums_final(const double *__restrict__ part, double *__restrict__ out)
+{
+    double a = part[2 * threadIdx.x], b = part[2 * threadIdx.x + 1];
+    static_assert(kTmplSumBlocks == 64, "one wave");
+    for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_down(a, off);
+        b += __shfl_down(b, off);
+    }
+    if (threadIdx.x == 0) {
+        out[0] = a;
+        out[1] = b;
     }
 }
 
@@ -1357,9 +1371,10 @@ bool ecc_fused_blur_eligible(int rows, int cols)
     return !(e && *e == '0') && rows >= 8 && cols >= 8 && rows < 32768 && cols < 32768 && (long long)rows * cols < (1ll << 29);
 }
 
-int launch_ecc_tmpl_sums(const float *tmpl_blur, int rows, int cols, double *d_out, hipStream_t st)
+int launch_ecc_tmpl_sums(const float *tmpl_blur, int rows, int cols, double *d_part, double *d_out, hipStream_t st)
 {
-    hipLaunchKernelGGL(ecc_tmpl_sums_kernel, dim3(1), dim3(256), 0, st, tmpl_blur, (size_t)rows * cols, d_out);
+    hipLaunchKernelGGL(ecc_tmpl_sums_kernel, dim3(kTmplSumBlocks), dim3(256), 0, st, tmpl_blur, (size_t)rows * cols, d_part);
+    hipLaunchKernelGGL(ecc_tmpl_sums_final, dim3(1), dim3(64), 0, st, (const double *)d_part, d_out);
     UPSP_HIP_CHECK(hipGetLastError());
     return UPSP_OK;
 }

@@ -141,8 +141,8 @@ int launch_ecc_blur_ident(FrameScratch *s, int slot, const uint16_t *d_frames, f
                           const double *d_tsum, int nb, int rows, int cols, float k0, float k1, float k2, unsigned thresh,
                           unsigned *hot_count, unsigned *hot_pos, const unsigned *only_changed, const void *changes, int max_hot,
                           hipStream_t st);
-// d_out[0 .. 1] = sum t, sum t^2 of the blurred template (the identity iteration's St, Stt)
-int launch_ecc_tmpl_sums(const float *tmpl_blur, int rows, int cols, double *d_out, hipStream_t st);
+// d_out[0 .. 1] = sum t, sum t^2 of the blurred template (the identity iteration's St, Stt); d_part: 128 doubles of scratch
+int launch_ecc_tmpl_sums(const float *tmpl_blur, int rows, int cols, double *d_part, double *d_out, hipStream_t st);
 int launch_ecc_export(const EccState *state, int nb, float *d_warps, int wstride, int32_t *d_iters, int istride, hipStream_t st);
 
 }  // namespace upsp

@@ -1087,8 +1087,8 @@ int frame_scratch_ensure(FrameScratch **ps, int ncams, int batch, int rows, int 
     if (need_warp && !s->center) {
         UPSP_HIP_CHECK(hipMalloc(&s->center, kMaxCams * sizeof(float)));
         UPSP_HIP_CHECK(hipMemset(s->center, 0, kMaxCams * sizeof(float)));
-        UPSP_HIP_CHECK(hipMalloc(&s->tsum, kMaxCams * 2 * sizeof(double)));
-        UPSP_HIP_CHECK(hipMemset(s->tsum, 0, kMaxCams * 2 * sizeof(double)));
+        UPSP_HIP_CHECK(hipMalloc(&s->tsum, (kMaxCams * 2 + 128) * sizeof(double)));      // (+ the partial sums of ecc_tmpl_sums_kernel)
+        UPSP_HIP_CHECK(hipMemset(s->tsum, 0, (kMaxCams * 2 + 128) * sizeof(double)));
     }
     if (!s->tmp) UPSP_HIP_CHECK(hipMalloc(&s->tmp, n * sizeof(double)));
     if (need_warp && !s->partial)
@@ -1174,7 +1174,7 @@ int frame_scratch_template(FrameScratch *s, int cam, const float *d_ref, int row
     if (rc != UPSP_OK) return rc;
     rc = launch_ecc_center(s->tmpl[cam], rows, cols, s->center + cam, st);
     if (rc != UPSP_OK) return rc;
-    rc = launch_ecc_tmpl_sums(s->tmpl[cam], rows, cols, s->tsum + 2 * cam, st);
+    rc = launch_ecc_tmpl_sums(s->tmpl[cam], rows, cols, s->tsum + 2 * kMaxCams, s->tsum + 2 * cam, st);
     if (rc != UPSP_OK) return rc;
     s->tmpl_src[cam] = d_ref;
     return UPSP_OK;
@@ -1360,7 +1360,7 @@ int upsp_register_pixel_u16(const float *d_ref32f, const uint16_t *d_inp, int ro
     int iters = 0;
     if (rc == UPSP_OK) rc = launch_gauss<float>(d_ref32f, s->tmpl[0], s->tmp, 1, rows, cols, 5, st);
     if (rc == UPSP_OK) rc = launch_ecc_center(s->tmpl[0], rows, cols, s->center, st);
-    if (rc == UPSP_OK) rc = launch_ecc_tmpl_sums(s->tmpl[0], rows, cols, s->tsum, st);
+    if (rc == UPSP_OK) rc = launch_ecc_tmpl_sums(s->tmpl[0], rows, cols, s->tsum + 2 * kMaxCams, s->tsum, st);
     FilterCoef fc;
     if (rc == UPSP_OK && ecc_fused_blur_eligible(rows, cols) && gaussian_coef(5, fc) == 0) {      // (the frame loop's kernel: same bits)
         rc = launch_ecc_blur_ident(s, 0, d_inp, s->ecc_img, s->tmpl[0], s->center, s->tsum, 1, rows, cols, fc.k[2], fc.k[3], fc.k[4], 0u, nullptr,
