@@ -528,10 +528,14 @@ __device__ __forceinline__ void ecc_walk_segment(const float *tile, const EccSeg
         // (the row terms come by scalar loads, which share their counter with the LDS reads: fetched one trip ahead, they are
         //  there when the wait for the taps ends instead of being a round trip of their own in front of every trip)
         int2 rn0 = rt[0], rn1 = rt[min(1, ne - 1)];
-        for (; pairs && r + 2 <= ne; r += 2) {
-            const float t0 = tn[0], t1 = tn[1];
-            tn[0] = r + 2 < ne ? ld_f32(tmpl, ot + 2u * pitch) : 0.f;
-            tn[1] = r + 3 < ne ? ld_f32(tmpl, ot + 3u * pitch) : 0.f;
+        // Template values TWO trips ahead (a trip is ~1.4 us of the wave's life at four waves per SIMD: about one L2 / Infinity Cache
+        // round trip under load), in two register pairs used in turn -- the loop body is written out twice so that no value has to
+        // be moved from one pair to the other (a move would wait for the load it copies).
+        float tb0 = pairs && 2 < ne ? ld_f32(tmpl, ot + 2u * pitch) : 0.f, tb1 = pairs && 3 < ne ? ld_f32(tmpl, ot + 3u * pitch) : 0.f;
+        auto trip = [&](float &ta0, float &ta1) {            // rows r, r + 1: template values in (ta0, ta1), refilled for rows r + 4, r + 5
+            const float t0 = ta0, t1 = ta1;
+            ta0 = r + 4 < ne ? ld_f32(tmpl, ot + 4u * pitch) : 0.f;
+            ta1 = r + 5 < ne ? ld_f32(tmpl, ot + 5u * pitch) : 0.f;
             const int2 rc0 = rn0, rc1 = rn1;
             rn0 = rt[min(r + 2, ne - 1)];
             rn1 = rt[min(r + 3, ne - 1)];
@@ -562,6 +566,16 @@ __device__ __forceinline__ void ecc_walk_segment(const float *tile, const EccSeg
             ecc_part_add<false>(P, T, W[0], gx0, gy0, t0, (float)(rbase + r));
             ecc_part_add<false>(P, T, W[1], gx1, gy1, t1, (float)(rbase + r + 1));
             ot += 2u * pitch;
+            r += 2;
+        };
+        while (pairs && r + 4 <= ne) {
+            trip(tn[0], tn[1]);
+            trip(tb0, tb1);
+        }
+        if (pairs && r + 2 <= ne) {
+            trip(tn[0], tn[1]);
+            tn[0] = tb0;          // (what a last single row reads)
+            tn[1] = tb1;
         }
     }
     for (; r + UR <= ne; r += UR) {
