@@ -92,3 +92,10 @@ if [ $part = pairs ]; then
     line pairs_1_$i -- --registration --steps 3 --warmup 1 || exit 1
   done
 fi
+if [ $part = fusedw ]; then
+  for i in 1 2; do
+    line fusedw_2k_$i UPSP_ECC_FUSED_BLUR=0 -- --registration --steps 3 --warmup 1 || exit 1
+    line fusedw_5_$i -- --registration --steps 3 --warmup 1 || exit 1
+    line fusedw_4_$i UPSP_FUSED_W4=1 -- --registration --steps 3 --warmup 1 || exit 1
+  done
+fi

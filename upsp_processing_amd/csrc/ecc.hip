@@ -937,23 +937,28 @@ __device__ __forceinline__ void ecc_blur_ident_block(const uint16_t *__restrict_
         // the piece (r + 3 < ne for its last row), so there is no reflection, every blurred row is stored, every loaded pixel is the
         // wave's own to scan and no row is past the end -- plain scalar arithmetic per row; the last trip or two take the tests.
         const int ne = y1 - y0;
-        auto trip = [&](int g, auto steady_tag) {
+        // The pixels and template values of a trip are requested ONE TRIP AHEAD (two sets of registers used in turn, the loop written
+        // out twice so that nothing is moved behind a load): a frame's pixels come from HBM for the first time -- ~2 us -- and a trip
+        // is ~1 000 instruction cycles of the wave.
+        auto fetch = [&](int g, unsigned (&qpv)[U], float (&qtv)[U], auto steady_tag) {
             constexpr bool STEADY = decltype(steady_tag)::value;
-            unsigned pv[U];
-            float tv[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int yi = y0 + 3 + g + u;
-                pv[u] = STEADY ? (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rS, (int)cx2, (int)((unsigned)yi * pitch2), 0) : load_row(yi);
+                qpv[u] = STEADY ? (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rS, (int)cx2, (int)((unsigned)yi * pitch2), 0)
+                                 : load_row(min(yi, y1 + 2));
                 const int yt = STEADY ? y0 + g + u : min(y0 + g + u, rows - 1);
-                tv[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rT, (int)cown4, (int)((unsigned)yt * pitch4), 0));
+                qtv[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rT, (int)cown4, (int)((unsigned)yt * pitch4), 0));
             }
+        };
+        auto work = [&](int g, const unsigned (&qpv)[U], const float (&qtv)[U], auto steady_tag) {
+            constexpr bool STEADY = decltype(steady_tag)::value;
             // the horizontal pass of two rows at a time as packed pairs (the same operations per component)
             static_assert(U % 2 == 0, "rows in pairs");
             v2f N[U / 2];
 #pragma unroll
             for (int u = 0; u < U; u += 2) {
-                const v2f Pf = {(float)pv[u], (float)pv[u + 1]};
+                const v2f Pf = {(float)qpv[u], (float)qpv[u + 1]};
                 const v2f A1 = {dpp_shr1_z(Pf[0]), dpp_shr1_z(Pf[1])}, C1 = {dpp_shl1_z(Pf[0]), dpp_shl1_z(Pf[1])};
                 const v2f A2 = {dpp_shr1_z(A1[0]), dpp_shr1_z(A1[1])}, C2 = {dpp_shl1_z(C1[0]), dpp_shl1_z(C1[1])};
                 const v2f K0 = {k0, k0}, K1 = {k1, k1}, K2 = {k2, k2};
@@ -963,28 +968,50 @@ __device__ __forceinline__ void ecc_blur_ident_block(const uint16_t *__restrict_
                 N[u / 2] = n;
             }
             if (HOT && STEADY) {                     // one test per trip: the largest of its pixels
-                unsigned mx = pv[0];
+                unsigned mx = qpv[0];
 #pragma unroll
-                for (int u = 1; u < U; ++u) mx = max(mx, pv[u]);
+                for (int u = 1; u < U; ++u) mx = max(mx, qpv[u]);
                 if (own && mx >= thresh) {           // (rare)
 #pragma unroll
-                    for (int u = 0; u < U; ++u) hot_scan(y0 + 3 + g + u, pv[u]);
+                    for (int u = 0; u < U; ++u) hot_scan(y0 + 3 + g + u, qpv[u]);
                 }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int r = g + u;
                 if (!STEADY && r >= ne) break;                                 // (uniform)
-                if (!STEADY) hot_scan(y0 + 3 + r, pv[u]);
+                if (!STEADY) hot_scan(y0 + 3 + r, qpv[u]);
                 h0 = h1; h1 = h2; h2 = h3; h3 = h4; h4 = N[u / 2][u & 1];
                 vstep(y0 + 1 + r, STEADY || r + 1 < ne);
                 const float l = dpp_shr1_z(B0), rr = dpp_shl1_z(B0);
-                ecc_part_add<false, false>(P, T, B0, 0.5f * (rr - l), 0.5f * (Bp - Bm), tv[u], (float)r);
+                ecc_part_add<false, false>(P, T, B0, 0.5f * (rr - l), 0.5f * (Bp - Bm), qtv[u], (float)r);
             }
         };
+        unsigned pa[U], pb[U];
+        float ta[U], tb[U];
         int g = 0;
-        for (; g + U + 3 <= ne; g += U) trip(g, std::true_type{});
-        for (; g < ne; g += U) trip(g, std::false_type{});
+        fetch(0, pa, ta, std::false_type{});
+        while (g + 3 * U + 3 <= ne) {            // trips g, g + U and g + 2 U are steady ones
+            fetch(g + U, pb, tb, std::true_type{});
+            __builtin_amdgcn_sched_barrier(0);        // (one trip's arithmetic after the other: interleaved they need 122 registers)
+            work(g, pa, ta, std::true_type{});
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(g + 2 * U, pa, ta, std::true_type{});
+            __builtin_amdgcn_sched_barrier(0);
+            work(g + U, pb, tb, std::true_type{});
+            __builtin_amdgcn_sched_barrier(0);
+            g += 2 * U;
+        }
+        while (g < ne) {                          // the last trips (pa / ta hold trip g)
+            if (g + U < ne) fetch(g + U, pb, tb, std::false_type{});
+            work(g, pa, ta, std::false_type{});
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                pa[u] = pb[u];
+                ta[u] = tb[u];
+            }
+            g += U;
+        }
     }
     ecc_part_flush(P, T, y0);
     T.n = own ? (double)(y1 - y0) : 0.0;          // mask = 1 on every pixel
@@ -996,8 +1023,8 @@ __device__ __forceinline__ void ecc_blur_ident_block(const uint16_t *__restrict_
 }
 
 // first pass: grid (frames, workgroups per frame)
-template <bool HOT, int U>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7)))
+template <bool HOT, int U, int W>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W)))
     ecc_blur_ident_kernel(const uint16_t *__restrict__ src, float *__restrict__ dst, const float *__restrict__ tmpl, int rows, int cols,
                           int strips, int pieces, int prows, double *__restrict__ partial, const float *__restrict__ center, float k0,
                           float k1, float k2, unsigned thresh, unsigned *__restrict__ hot_count, unsigned *__restrict__ hot_pos,
@@ -1016,7 +1043,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))
 // per frame, running what is reached one after the other: 55 / 140 us.
 constexpr int kAgainFrames = 1;
 template <int U>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
     ecc_blur_ident_again_kernel(const uint16_t *__restrict__ src, float *__restrict__ dst, const float *__restrict__ tmpl, int rows, int cols,
                                 int strips, int pieces, int prows, int nframes, double *__restrict__ partial, const float *__restrict__ center, float k0,
                                 float k1, float k2, const unsigned *__restrict__ nchanged, const uint4 *__restrict__ changes, int max_hot,
@@ -1425,10 +1452,10 @@ int launch_ecc_blur_ident(FrameScratch *s, int slot, const uint16_t *d_frames, f
                            dim3(256), 0, st, d_frames, dst, tmpl_blur, rows, cols, strips, pieces, prows, nb, s->partial_id[slot], d_center, k0, k1,
                            k2, only_changed, (const uint4 *)changes, max_hot, d_tsum);
     else if (hot_count)
-        hipLaunchKernelGGL((ecc_blur_ident_kernel<true, 4>), grid, dim3(256), 0, st, d_frames, dst, tmpl_blur, rows, cols, strips, pieces,
+        hipLaunchKernelGGL((ecc_blur_ident_kernel<true, 4, 4>), grid, dim3(256), 0, st, d_frames, dst, tmpl_blur, rows, cols, strips, pieces,
                            prows, s->partial_id[slot], d_center, k0, k1, k2, thresh, hot_count, hot_pos, d_tsum);
     else
-        hipLaunchKernelGGL((ecc_blur_ident_kernel<false, 4>), grid, dim3(256), 0, st, d_frames, dst, tmpl_blur, rows, cols, strips, pieces,
+        hipLaunchKernelGGL((ecc_blur_ident_kernel<false, 4, 4>), grid, dim3(256), 0, st, d_frames, dst, tmpl_blur, rows, cols, strips, pieces,
                            prows, s->partial_id[slot], d_center, k0, k1, k2, 0u, (unsigned *)nullptr, (unsigned *)nullptr, d_tsum);
     UPSP_HIP_CHECK(hipGetLastError());
     s->ident_for[slot] = dst;
