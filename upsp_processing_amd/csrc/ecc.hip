@@ -834,7 +834,8 @@ __device__ __forceinline__ void ecc_band_cols_body(const float *__restrict__ img
 // (cpp/lib/registration.cpp:57-60, gaussFiltSize 5) and the identity sums are ONE pass -- the u16 frame is read (2 B / px), the
 // blurred f32 frame is written for the later iterations (4 B / px) and its values go into the sums from registers: 10 B / px with
 // the template instead of the 14 of gauss5_quad_kernel + ecc_cols_kernel<true>.
-//   * A WAVE owns a strip of 58 columns x <= 128 rows (one float segment, as in the one-flush form).  Lane l holds column
+//   * A WAVE owns a strip of 58 columns x 16 .. 128 rows (one float segment; the host picks the row count by the image size:
+//     launch_ecc_blur_ident).  Lane l holds column
 //     58 strip - 3 + l: lanes 3 .. 60 are the strip's own columns, the three lanes on either side its neighbours' -- the horizontal
 //     blur taps come by DPP wave shifts (two chained shifts per side), so lanes 2 .. 61 hold a blurred value, and the x-gradient of
 //     an own lane is the difference of its neighbours' blurred values, which nobody else has computed yet.  The five rows of
@@ -844,8 +845,10 @@ __device__ __forceinline__ void ecc_band_cols_body(const float *__restrict__ img
 //     blurred value "at column -1" is the one at column 1 -- exactly filter2D's reflect-101 tap of the gradient images.  Under the
 //     identity warp every pixel is inside the mask and the bilinear weights are (1, 0, 0, 0): no band blocks, all rows x cols pixels
 //     are plain ones.
-//   * Hot pixels: the scan of fix_hot_pixels rides on the loads as in gauss5_quad_kernel.  The rare frames the repair changes
-//     afterwards run the kernel a second time (only_changed = their change counts): blurred frame and sums from the repaired pixels.
+//   * Hot pixels: the scan of fix_hot_pixels rides on the loads as in gauss5_quad_kernel.  In the frames the repair changes
+//     afterwards, the workgroups a repaired pixel reaches run again (ecc_blur_ident_again_kernel): blurred pixels and sums from the
+//     repaired frame.
+//   * Four waves per SIMD (108 registers), the loads of a trip requested one trip ahead: see the loop.
 // Block = four wave items (strip-major: neighbouring strips of one row piece), reduced like the interior blocks.
 constexpr int kFusedOwn = 58, kFusedHalo = 3;
 
