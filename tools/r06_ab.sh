@@ -99,3 +99,10 @@ if [ $part = fusedw ]; then
     line fusedw_4_$i UPSP_FUSED_W4=1 -- --registration --steps 3 --warmup 1 || exit 1
   done
 fi
+if [ $part = again ]; then
+  # the second pass of the fused pre-blur on its own stream (default) / in line (UPSP_ECC_AGAIN_STREAM=0), configs[2]-sized runs
+  for i in 1 2 3; do
+    line again_0_$i UPSP_ECC_AGAIN_STREAM=0 -- --registration --frames 4096 --steps 3 --warmup 1 || exit 1
+    line again_1_$i -- --registration --frames 4096 --steps 3 --warmup 1 || exit 1
+  done
+fi

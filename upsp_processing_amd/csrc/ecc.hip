@@ -1504,6 +1504,12 @@ int run_ecc(FrameScratch *s, const float *tmpl_blur, const float *d_center, cons
     const char *one_env = std::getenv("UPSP_ECC_ONE_FLUSH");
     const bool one_flush_on = !(one_env && *one_env == '0');
     const bool one_flush = one_flush_on && (rows - 6 + pieces_min - 1) / pieces_min <= kEccFlushLong;
+    // the second pass of the fused pre-blur over this buffer may still be running on its own stream (frame_scratch_preblur)
+    for (int k = 0; k < 2; ++k)
+        if (s->again_pending[k] && blurred == (k ? s->ecc_img2 : s->ecc_img)) {
+            UPSP_HIP_CHECK(hipStreamWaitEvent(st, s->ev_again[k], 0));
+            s->again_pending[k] = false;
+        }
     // the identity iteration's sums came with the pre-blur (launch_ecc_blur_ident): one use per blurred buffer
     const double *ident_partial = nullptr;
     for (int k = 0; k < 2; ++k)

@@ -117,6 +117,12 @@ struct FrameScratch {
     size_t partial_id_words = 0;                  // ... doubles allocated per slot
     const float *ident_for[2] = {nullptr, nullptr};   // the blurred-frame buffer whose identity sums partial_id[slot] holds (one use)
     int ident_blocks = 0;                         // ... workgroups per frame of that launch
+    // The second pass of the fused pre-blur (the workgroups a repaired hot pixel reaches: a handful, ~40 us of one workgroup's
+    // latency) runs on a stream of its own beside whatever the frame loop's stream does between the pre-blur and the first solve of
+    // that sub-batch; run_ecc waits for ev_again[slot] when again_pending[slot].
+    hipStream_t again_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_again[2] = {nullptr, nullptr};
+    bool again_pending[2] = {false, false};
     int2 *rtab = nullptr;                   // [batch][rows] per-row terms of the fixed-point source coordinate under the frame's M
     EccState *state = nullptr;
     int *counter = nullptr;
