@@ -1209,35 +1209,35 @@ int frame_scratch_preblur(FrameScratch *s, int slot, uint16_t *d_frames, int nb,
         }
         if (rc != UPSP_OK) return rc;
         if (hot) {
+            // The repair (one lane per frame) and the second pass behind it (a handful of workgroups) are ~60 us of latency with the
+            // device nearly empty: they run on a stream of their own (FrameScratch::again_stream), forked here and joined in front
+            // of this sub-batch's first solve (run_ecc) -- beside whatever the loop's stream does in between (the previous
+            // sub-batch's warp and row pass).  UPSP_ECC_AGAIN_STREAM=0: in line (A/B).
+            static const bool side = [] { const char *e = std::getenv("UPSP_ECC_AGAIN_STREAM"); return !(e && *e == '0'); }();
+            hipStream_t as = st;
+            if (side) {
+                if (!s->again_stream) {
+                    UPSP_HIP_CHECK(hipStreamCreateWithFlags(&s->again_stream, hipStreamNonBlocking));
+                    UPSP_HIP_CHECK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+                    for (int k = 0; k < 2; ++k) UPSP_HIP_CHECK(hipEventCreateWithFlags(&s->ev_again[k], hipEventDisableTiming));
+                }
+                as = s->again_stream;
+                UPSP_HIP_CHECK(hipEventRecord(s->ev_fork, st));
+                UPSP_HIP_CHECK(hipStreamWaitEvent(as, s->ev_fork, 0));
+            }
             rc = launch_hot_repair_list(d_frames, (size_t)rows * cols, nb, rows, cols, hot->min_change, hot->max_hot, hot->d_count,
-                                        hot->d_pos, hot->d_changes, st);
+                                        hot->d_pos, hot->d_changes, as);
             if (rc != UPSP_OK) return rc;
             if (hot->max_hot > 0) {
-                // on a stream of its own (see FrameScratch::again_stream); UPSP_ECC_AGAIN_STREAM=0: in line (A/B)
-                static const bool side_on = [] { const char *e = std::getenv("UPSP_ECC_AGAIN_STREAM"); return !(e && *e == '0'); }();
-                const bool side = side_on;
-                hipStream_t as = st;
-                if (side) {
-                    if (!s->again_stream) {
-                        UPSP_HIP_CHECK(hipStreamCreateWithFlags(&s->again_stream, hipStreamNonBlocking));
-                        UPSP_HIP_CHECK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
-                        for (int k = 0; k < 2; ++k) UPSP_HIP_CHECK(hipEventCreateWithFlags(&s->ev_again[k], hipEventDisableTiming));
-                    }
-                    as = s->again_stream;
-                    UPSP_HIP_CHECK(hipEventRecord(s->ev_fork, st));
-                    UPSP_HIP_CHECK(hipStreamWaitEvent(as, s->ev_fork, 0));
-                }
-                {
-                    KTimed kt("hot_fixup_kernels", as);
-                    rc = launch_ecc_blur_ident(s, slot, d_frames, dst, s->tmpl[fuse_cam], s->center + fuse_cam, s->tsum + 2 * fuse_cam, nb, rows, cols,
-                                               fc.k[2], fc.k[3], fc.k[4], 0u, nullptr, nullptr, hot->d_changes + 4,
-                                               hot->d_changes + 4 + (((size_t)nb + 3) & ~(size_t)3), hot->max_hot, as);
-                }
+                KTimed kt("hot_fixup_kernels", as);
+                rc = launch_ecc_blur_ident(s, slot, d_frames, dst, s->tmpl[fuse_cam], s->center + fuse_cam, s->tsum + 2 * fuse_cam, nb, rows, cols,
+                                           fc.k[2], fc.k[3], fc.k[4], 0u, nullptr, nullptr, hot->d_changes + 4,
+                                           hot->d_changes + 4 + (((size_t)nb + 3) & ~(size_t)3), hot->max_hot, as);
                 if (rc != UPSP_OK) return rc;
-                if (side) {
-                    UPSP_HIP_CHECK(hipEventRecord(s->ev_again[slot & 1], as));
-                    s->again_pending[slot & 1] = true;
-                }
+            }
+            if (side) {
+                UPSP_HIP_CHECK(hipEventRecord(s->ev_again[slot & 1], as));
+                s->again_pending[slot & 1] = true;
             }
         }
         // UPSP_ECC_FUSED_BLUR=2 (test switch): keep the pass's blurred frames, drop its sums -- the identity iteration runs as its own
